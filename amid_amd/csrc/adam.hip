@@ -1,0 +1,198 @@
+// K4: optimizer.  The reference runs torch.optim.Adam(model.parameters(), lr) DENSE over every
+// parameter including the whole item table (train_sr.py:480, :213-215): 7 passes over 458 MB per
+// step.  Here the table is updated lazily but dense-EQUIVALENTLY: a row keeps (m, v, last_step);
+// a zero-gradient Adam step still moves a row through its momentum, so before a row is read by
+// the forward gather of step t its pending zero-gradient steps last+1 .. t-1 are replayed
+// (amid_lazy_adam_catchup), and after backward the real step t is applied (amid_lazy_adam_apply).
+// Rows never touched have m = v = 0 => every update is exactly 0 => nothing to replay.
+// Arithmetic follows torch's single-tensor CPU Adam op by op (lerp as fma, addcmul / addcdiv
+// unfused), with bias corrections evaluated in double like the Python side does.
+#include "common.h"
+#include "rng.h"
+
+namespace amid {
+
+struct AdamCoef {              // per-step scalars, as torch computes them (double -> float at the op)
+    float w1;                  // 1 - beta1                     (lerp weight)
+    float beta2, w2;           // beta2, 1 - beta2
+    float neg_step_size;       // -(lr / (1 - beta1^t))
+    float bc2_sqrt;            // sqrt(1 - beta2^t)
+    float eps;
+};
+
+__device__ __forceinline__ AdamCoef adam_coef(const StepState& st, double b1pow, double b2pow) {
+    AdamCoef c;
+    c.w1 = (float)(1.0 - st.beta1);
+    c.beta2 = (float)st.beta2;
+    c.w2 = (float)(1.0 - st.beta2);
+    c.neg_step_size = (float)(-(st.lr / (1.0 - b1pow)));
+    c.bc2_sqrt = (float)sqrt(1.0 - b2pow);
+    c.eps = (float)st.eps;
+    return c;
+}
+
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, const AdamCoef& c) {
+    m = __fmaf_rn(c.w1, __fsub_rn(g, m), m);                                   // exp_avg.lerp_(grad, 1 - beta1)
+    v = __fadd_rn(__fmul_rn(v, c.beta2), __fmul_rn(__fmul_rn(c.w2, g), g));    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), c.bc2_sqrt), c.eps); // (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps)
+    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(c.neg_step_size, m), denom));          // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__device__ __forceinline__ void adam_quad(float4& p, float4& m, float4& v, float4 g, const AdamCoef& c) {
+    adam_elem(p.x, m.x, v.x, g.x, c);
+    adam_elem(p.y, m.y, v.y, g.y, c);
+    adam_elem(p.z, m.z, v.z, g.z, c);
+    adam_elem(p.w, m.w, v.w, g.w, c);
+}
+
+// replay zero-gradient steps s = from .. to (inclusive) on one float4 of a row
+__device__ __forceinline__ void replay_quad(float4& p, float4& m, float4& v, long long from, long long to, const StepState& st) {
+    double b1pow = pow(st.beta1, (double)(from - 1)), b2pow = pow(st.beta2, (double)(from - 1));
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long s = from; s <= to; ++s) {
+        b1pow *= st.beta1;
+        b2pow *= st.beta2;
+        adam_quad(p, m, v, zero, adam_coef(st, b1pow, b2pow));
+    }
+}
+
+// mode 0: catch-up (steps last+1 .. t-1, g = 0)   mode 1: apply (catch-up if needed, then step t with g)
+template <int MODE>
+__global__ __launch_bounds__(256) void lazy_adam_rows_kernel(float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
+                                                             int* __restrict__ last, const int* __restrict__ uniq_ids,
+                                                             const int* __restrict__ n_uniq_p, const float* __restrict__ uniq_grad, int D,
+                                                             const StepState* __restrict__ stp, float grad_scale) {
+    const StepState st = *stp;
+    const long long t = st.step;
+    const int U = *n_uniq_p;
+    const int sub = threadIdx.x & 31;
+    const int q = D >> 2;
+    const int hw0 = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), n_hw = gridDim.x * (blockDim.x >> 5);
+    for (int u = hw0; u < U; u += n_hw) {
+        const long long r = uniq_ids[u];
+        const long long l = last[r];
+        const bool lag = (l > 0 && l < t - 1);
+        if (MODE == 0 && !lag) continue;
+        for (int c = sub; c < q; c += 32) {
+            const long long off = r * D + 4 * c;
+            float4 p = ld4(table + off), m = ld4(m_tab + off), v = ld4(v_tab + off);
+            if (lag) replay_quad(p, m, v, l + 1, t - 1, st);
+            if (MODE == 1) {
+                const float4 g = f4scale(ld4(uniq_grad + (long long)u * D + 4 * c), grad_scale);
+                adam_quad(p, m, v, g, adam_coef(st, pow(st.beta1, (double)t), pow(st.beta2, (double)t)));
+            }
+            st4(table + off, p); st4(m_tab + off, m); st4(v_tab + off, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (sub == 0) last[r] = (MODE == 1) ? (int)t : (int)(t - 1);
+    }
+}
+
+// bring every row with pending zero-gradient steps up to date (before eval / checkpoint / parity dumps)
+__global__ __launch_bounds__(256) void lazy_adam_flush_kernel(float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
+                                                              int* __restrict__ last, long long n_rows, int D, const StepState* __restrict__ stp) {
+    const StepState st = *stp;
+    const long long t = st.step;
+    const int sub = threadIdx.x & 31;
+    const int q = D >> 2;
+    const long long hw0 = (long long)blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), n_hw = (long long)gridDim.x * (blockDim.x >> 5);
+    for (long long r = hw0; r < n_rows; r += n_hw) {
+        const long long l = last[r];
+        if (!(l > 0 && l < t)) continue;
+        for (int c = sub; c < q; c += 32) {
+            const long long off = r * D + 4 * c;
+            float4 p = ld4(table + off), m = ld4(m_tab + off), v = ld4(v_tab + off);
+            replay_quad(p, m, v, l + 1, t, st);
+            st4(table + off, p); st4(m_tab + off, m); st4(v_tab + off, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (sub == 0) last[r] = (int)t;
+    }
+}
+
+// dense Adam over the flat (non-table) parameter buffer
+__global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                         const float* __restrict__ g, long long n, const StepState* __restrict__ stp,
+                                                         float grad_scale) {
+    const StepState st = *stp;
+    const AdamCoef c = adam_coef(st, pow(st.beta1, (double)st.step), pow(st.beta2, (double)st.step));
+    const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = i0; i < n; i += stride) {
+        if (i + 4 <= n) {
+            float4 pp = ld4(p + i), mm = ld4(m + i), vv = ld4(v + i);
+            adam_quad(pp, mm, vv, f4scale(ld4(g + i), grad_scale), c);
+            st4(p + i, pp); st4(m + i, mm); st4(v + i, vv);
+        } else {
+            for (long long k = i; k < n; ++k) adam_elem(p[k], m[k], v[k], g[k] * grad_scale, c);
+        }
+    }
+}
+
+__global__ void step_begin_kernel(StepState* st) { st->step += 1; }
+
+}  // namespace amid
+
+using namespace amid;
+
+extern "C" int amid_step_state_bytes(void) { return (int)sizeof(StepState); }
+
+// host-side fill helper: writes a StepState image into `host_buf` (caller copies it to the device)
+extern "C" int amid_step_state_pack(void* host_buf, unsigned long long seed, long long step, double lr, double beta1, double beta2, double eps) {
+    AMID_CHECK_ARG(host_buf);
+    StepState s;
+    s.seed = seed; s.step = step; s.lr = lr; s.beta1 = beta1; s.beta2 = beta2; s.eps = eps;
+    *(StepState*)host_buf = s;
+    return AMID_OK;
+}
+
+extern "C" int amid_step_begin(void* step_state, void* stream) {
+    AMID_CHECK_ARG(step_state);
+    step_begin_kernel<<<1, 1, 0, (hipStream_t)stream>>>((StepState*)step_state);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+static inline int rows_grid(long long n_rows_hint) {
+    long long b = (n_rows_hint + 7) / 8;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+extern "C" int amid_lazy_adam_catchup_f32(float* table, float* m, float* v, int* last, const int* uniq_ids, const int* n_uniq,
+                                          int n_uniq_max, int D, const void* step_state, void* stream) {
+    AMID_CHECK_ARG(table && m && v && last && uniq_ids && n_uniq && step_state && D > 0 && (D % 4) == 0 && n_uniq_max > 0);
+    lazy_adam_rows_kernel<0><<<rows_grid(n_uniq_max), 256, 0, (hipStream_t)stream>>>(table, m, v, last, uniq_ids, n_uniq, nullptr, D,
+                                                                                      (const StepState*)step_state, 1.0f);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_lazy_adam_apply_f32(float* table, float* m, float* v, int* last, const int* uniq_ids, const int* n_uniq,
+                                        int n_uniq_max, const float* uniq_grad, float grad_scale, int D, const void* step_state, void* stream) {
+    AMID_CHECK_ARG(table && m && v && last && uniq_ids && n_uniq && uniq_grad && step_state && D > 0 && (D % 4) == 0 && n_uniq_max > 0);
+    lazy_adam_rows_kernel<1><<<rows_grid(n_uniq_max), 256, 0, (hipStream_t)stream>>>(table, m, v, last, uniq_ids, n_uniq, uniq_grad, D,
+                                                                                      (const StepState*)step_state, grad_scale);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_lazy_adam_flush_f32(float* table, float* m, float* v, int* last, long long n_rows, int D, const void* step_state,
+                                        void* stream) {
+    AMID_CHECK_ARG(table && m && v && last && step_state && n_rows > 0 && D > 0 && (D % 4) == 0);
+    lazy_adam_flush_kernel<<<rows_grid(n_rows), 256, 0, (hipStream_t)stream>>>(table, m, v, last, n_rows, D, (const StepState*)step_state);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_adam_dense_f32(float* p, float* m, float* v, const float* g, long long n, float grad_scale, const void* step_state,
+                                   void* stream) {
+    AMID_CHECK_ARG(p && m && v && g && step_state && n > 0);
+    long long b = (n / 4 + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    adam_dense_kernel<<<(int)b, 256, 0, (hipStream_t)stream>>>(p, m, v, g, n, (const StepState*)step_state, grad_scale);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}

@@ -1,0 +1,339 @@
+// K2: multi-head attention core for short sequences (T <= ~150, head dim 8/16/32), forward and backward.
+// Reference: torch.nn.MultiheadAttention as called at model_seq.py:374 (explicit softmax path: q scaled
+// by sqrt(1/hd) BEFORE q.k^T, additive -inf causal mask, dropout p=.5 on the probabilities) and the
+// hand-written Attention of BERT4Rec (model_seq.py:149-162: scores / sqrt(d_k), masked_fill(mask == 0, -1e9)
+// with ONE key mask taken from seq_d2 > 0 for both domains, dropout p=.1).
+//
+// One workgroup per (domain, batch row); one wave per head.  A lane owns one query row, so the
+// softmax reduction is lane-local (no cross-lane traffic at all); K/V rows are LDS broadcasts
+// (every lane reads the same address).  Backward recomputes the probabilities from the saved
+// row max / 1/sum and runs twice: lanes = queries for dQ, then lanes = keys for dK/dV, so that no
+// gradient needs a cross-lane or cross-wave reduction; the dropout keep bits found in the first
+// phase are handed to the second through a 64-bit-per-row LDS mask instead of re-running Philox.
+// VALU-bound (hd 16: 4*T^2*hd FLOP per (b, h) forward); no HBM pressure: q/k/v/o tiles are read once.
+#include "common.h"
+#include "rng.h"
+
+namespace amid {
+
+struct AttnArgs {
+    const float* q; const float* k; const float* v;       // [2M, D]
+    float* o;                                             // [2M, D]
+    float* stats;                                         // [2M, H, 2] row max, 1 / row sum
+    const float* d_o; float* dq; float* dk; float* dv;    // backward only
+    const unsigned char* key_keep;                        // [B, T] 1 = key visible (BERT4Rec), null = no key mask
+    int B, T, D, H;
+    int causal;                                           // 1: SASRec causal mask, q pre-scaled; 0: BERT4Rec
+    float scale;                                          // sqrt(1/hd) (causal) or sqrt(d_k) divisor (BERT)
+    const StepState* st; int train; unsigned thr16; float dscale; int layer;
+};
+
+template <int HD>
+__device__ __forceinline__ float dot_lds(const float (&a)[HD], const float* __restrict__ b) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+        const float4 t = ld4(b + d);
+        s = fmaf(a[d], t.x, s); s = fmaf(a[d + 1], t.y, s); s = fmaf(a[d + 2], t.z, s); s = fmaf(a[d + 3], t.w, s);
+    }
+    return s;
+}
+
+template <int HD>
+__device__ __forceinline__ void load_vec(float (&a)[HD], const float* __restrict__ p) {
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) { const float4 t = ld4(p + d); a[d] = t.x; a[d + 1] = t.y; a[d + 2] = t.z; a[d + 3] = t.w; }
+}
+template <int HD>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&a)[HD]) {
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) st4(p + d, make_float4(a[d], a[d + 1], a[d + 2], a[d + 3]));
+}
+
+__device__ __forceinline__ void copy_tile(float* __restrict__ dst, const float* __restrict__ src, int nfloat) {
+    for (int i = threadIdx.x * 4; i < nfloat; i += blockDim.x * 4) st4(dst + i, ld4(src + i));
+}
+
+// score of (query i, key j) exactly as the forward computes it
+template <int HD>
+__device__ __forceinline__ float score(const AttnArgs& a, const float (&qs)[HD], const float* __restrict__ krow, int i, int j, bool key_ok) {
+    float s = dot_lds<HD>(qs, krow);
+    if (a.causal) { if (j > i) s = -INFINITY; }
+    else { s = s / a.scale; if (!key_ok) s = -1e9f; }
+    return s;
+}
+
+template <int HD>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = a.T, D = a.D;
+    float* Ks = smem;
+    float* Vs = smem + T * D;
+    const int seq = blockIdx.x, g = seq / a.B, b = seq - g * a.B;
+    const long long rowbase = (long long)seq * T;
+    copy_tile(Ks, a.k + rowbase * D, T * D);
+    copy_tile(Vs, a.v + rowbase * D, T * D);
+    __syncthreads();
+    const int h = wave_id(), lane = lane_id();
+    const int TP8 = (T + 7) >> 3;
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+    const unsigned site = site_id(g, a.layer, SITE_ATTN);
+    const unsigned char* kk = a.key_keep ? a.key_keep + (long long)b * T : nullptr;
+    for (int qb = 0; qb * 64 < T; ++qb) {
+        const int i = qb * 64 + lane;
+        const bool valid = i < T;
+        const int ic = valid ? i : T - 1;
+        float qs[HD];
+        load_vec<HD>(qs, a.q + (rowbase + ic) * D + h * HD);
+        if (a.causal) {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) qs[d] *= a.scale;
+        }
+        const int jmax = a.causal ? min(T, qb * 64 + 64) : T;
+        float m = -INFINITY;
+        for (int j = 0; j < jmax; ++j) m = fmaxf(m, score<HD>(a, qs, Ks + j * D + h * HD, ic, j, kk ? kk[j] != 0 : true));
+        float l = 0.f;
+        float acc[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+        const unsigned long long rowcall = ((unsigned long long)(b * a.H + h) * T + ic) * TP8;
+        for (int j0 = 0; j0 < jmax; j0 += 8) {
+            uint4 r = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (a.train) r = rng_call(seed, rowcall + (j0 >> 3), site, step);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j0 + jj;
+                if (j < jmax) {
+                    const float s = score<HD>(a, qs, Ks + j * D + h * HD, ic, j, kk ? kk[j] != 0 : true);
+                    const float p = expf(s - m);
+                    l += p;
+                    const float pd = (!a.train || rng_half(r, jj) >= a.thr16) ? p * a.dscale : 0.f;
+                    const float* vr = Vs + j * D + h * HD;
+#pragma unroll
+                    for (int d = 0; d < HD; d += 4) {
+                        const float4 t = ld4(vr + d);
+                        acc[d] = fmaf(pd, t.x, acc[d]); acc[d + 1] = fmaf(pd, t.y, acc[d + 1]);
+                        acc[d + 2] = fmaf(pd, t.z, acc[d + 2]); acc[d + 3] = fmaf(pd, t.w, acc[d + 3]);
+                    }
+                }
+            }
+        }
+        const float rl = 1.0f / l;
+        if (valid) {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] *= rl;
+            store_vec<HD>(a.o + (rowbase + i) * D + h * HD, acc);
+            if (a.stats) {
+                float* sp = a.stats + ((rowbase + i) * a.H + h) * 2;
+                sp[0] = m; sp[1] = rl;
+            }
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = a.T, D = a.D, H = a.H;
+    const int TW = (T + 63) >> 6;                              // 64-bit keep words per query row
+    float* S0 = smem;                                          // K, then Q
+    float* S1 = smem + T * D;                                  // V, then dO
+    float* rstat = smem + 2 * T * D;                           // [H][T][3]  m, 1/l, delta
+    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(rstat + H * T * 3 + ((H * T * 3) & 1));   // [H][T][TW]
+    const int seq = blockIdx.x, g = seq / a.B, b = seq - g * a.B;
+    const long long rowbase = (long long)seq * T;
+    const int h = wave_id(), lane = lane_id();
+    const int TP8 = (T + 7) >> 3;
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+    const unsigned site = site_id(g, a.layer, SITE_ATTN);
+    const unsigned char* kk = a.key_keep ? a.key_keep + (long long)b * T : nullptr;
+
+    // ---- phase 1: lanes = queries -> dQ; leaves row stats and dropout keep words in LDS --------
+    copy_tile(S0, a.k + rowbase * D, T * D);
+    copy_tile(S1, a.v + rowbase * D, T * D);
+    __syncthreads();
+    for (int qb = 0; qb * 64 < T; ++qb) {
+        const int i = qb * 64 + lane;
+        const bool valid = i < T;
+        const int ic = valid ? i : T - 1;
+        float qs[HD], dO[HD], acc[HD];
+        load_vec<HD>(qs, a.q + (rowbase + ic) * D + h * HD);
+        load_vec<HD>(dO, a.d_o + (rowbase + ic) * D + h * HD);
+        float delta = 0.f;
+        {
+            float ov[HD];
+            load_vec<HD>(ov, a.o + (rowbase + ic) * D + h * HD);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) delta = fmaf(dO[d], ov[d], delta);
+        }
+        if (a.causal) {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) qs[d] *= a.scale;
+        }
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+        const float* sp = a.stats + ((rowbase + ic) * H + h) * 2;
+        const float m = sp[0], rl = sp[1];
+        if (valid) { float* rs = rstat + (h * T + i) * 3; rs[0] = m; rs[1] = rl; rs[2] = delta; }
+        const int jmax = a.causal ? min(T, qb * 64 + 64) : T;
+        const unsigned long long rowcall = ((unsigned long long)(b * H + h) * T + ic) * TP8;
+        unsigned long long kw = 0;
+        for (int j0 = 0; j0 < jmax; j0 += 8) {                 // phase 2 only needs the bits of pairs (i, j < jmax)
+            if ((j0 & 63) == 0) kw = 0;
+            uint4 r = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (a.train) r = rng_call(seed, rowcall + (j0 >> 3), site, step);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j0 + jj;
+                const bool keep = !a.train || rng_half(r, jj) >= a.thr16;
+                if (keep) kw |= 1ull << (j & 63);
+                if (j < jmax) {
+                    const float s = score<HD>(a, qs, S0 + j * D + h * HD, ic, j, kk ? kk[j] != 0 : true);
+                    const float p = expf(s - m) * rl;
+                    const float dpd = dot_lds<HD>(dO, S1 + j * D + h * HD);
+                    const float dp = keep ? dpd * a.dscale : 0.f;
+                    const float ds = p * (dp - delta);
+                    const float* kr = S0 + j * D + h * HD;
+#pragma unroll
+                    for (int d = 0; d < HD; d += 4) {
+                        const float4 t = ld4(kr + d);
+                        acc[d] = fmaf(ds, t.x, acc[d]); acc[d + 1] = fmaf(ds, t.y, acc[d + 1]);
+                        acc[d + 2] = fmaf(ds, t.z, acc[d + 2]); acc[d + 3] = fmaf(ds, t.w, acc[d + 3]);
+                    }
+                }
+            }
+            if (valid && ((j0 & 63) == 56 || j0 + 8 >= jmax)) keepw[(h * T + i) * TW + (j0 >> 6)] = kw;
+        }
+        if (valid) {
+            const float sc = a.causal ? a.scale : 1.0f / a.scale;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] *= sc;
+            store_vec<HD>(a.dq + (rowbase + i) * D + h * HD, acc);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: lanes = keys -> dK, dV -------------------------------------------------------
+    copy_tile(S0, a.q + rowbase * D, T * D);
+    copy_tile(S1, a.d_o + rowbase * D, T * D);
+    __syncthreads();
+    for (int kb = 0; kb * 64 < T; ++kb) {
+        const int j = kb * 64 + lane;
+        const bool valid = j < T;
+        const int jc = valid ? j : T - 1;
+        float kv[HD], vv[HD], dk[HD], dv[HD];
+        load_vec<HD>(kv, a.k + (rowbase + jc) * D + h * HD);
+        load_vec<HD>(vv, a.v + (rowbase + jc) * D + h * HD);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+        const bool key_ok = kk ? kk[jc] != 0 : true;
+        const int i0 = a.causal ? kb * 64 : 0;
+        for (int i = i0; i < T; ++i) {
+            const float* qr = S0 + i * D + h * HD;
+            const float* dor = S1 + i * D + h * HD;
+            const float* rs = rstat + (h * T + i) * 3;
+            float qs[HD];
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) { const float4 t = ld4(qr + d); qs[d] = t.x; qs[d + 1] = t.y; qs[d + 2] = t.z; qs[d + 3] = t.w; }
+            if (a.causal) {
+#pragma unroll
+                for (int d = 0; d < HD; ++d) qs[d] *= a.scale;
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s = fmaf(qs[d], kv[d], s);
+            if (a.causal) { if (jc > i) s = -INFINITY; }
+            else { s = s / a.scale; if (!key_ok) s = -1e9f; }
+            const float p = expf(s - rs[0]) * rs[1];
+            const float dpd = dot_lds<HD>(vv, dor);
+            const bool keep = (keepw[(h * T + i) * TW + (jc >> 6)] >> (jc & 63)) & 1ull;
+            const float pd = keep ? p * a.dscale : 0.f;
+            const float dp = keep ? dpd * a.dscale : 0.f;
+            const float ds = p * (dp - rs[2]);
+            const float dsq = a.causal ? ds : ds / a.scale;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const float4 t = ld4(dor + d);
+                dv[d] = fmaf(pd, t.x, dv[d]); dv[d + 1] = fmaf(pd, t.y, dv[d + 1]);
+                dv[d + 2] = fmaf(pd, t.z, dv[d + 2]); dv[d + 3] = fmaf(pd, t.w, dv[d + 3]);
+                dk[d] = fmaf(dsq, qs[d], dk[d]); dk[d + 1] = fmaf(dsq, qs[d + 1], dk[d + 1]);
+                dk[d + 2] = fmaf(dsq, qs[d + 2], dk[d + 2]); dk[d + 3] = fmaf(dsq, qs[d + 3], dk[d + 3]);
+            }
+        }
+        if (valid) {
+            store_vec<HD>(a.dk + (rowbase + j) * D + h * HD, dk);
+            store_vec<HD>(a.dv + (rowbase + j) * D + h * HD, dv);
+        }
+    }
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+static size_t attn_fwd_lds(int T, int D) { return (size_t)2 * T * D * sizeof(float); }
+static size_t attn_bwd_lds(int T, int D, int H) {
+    size_t f = (size_t)2 * T * D + (size_t)H * T * 3;
+    f += f & 1;
+    return f * sizeof(float) + (size_t)H * T * ((T + 63) / 64) * 8;
+}
+
+template <typename KernelT>
+static int attn_launch(KernelT kern, const AttnArgs& a, size_t lds, void* stream) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    kern<<<2 * a.B, a.H * 64, lds, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+static int attn_fill(AttnArgs& a, const float* q, const float* k, const float* v, const unsigned char* key_keep, int B, int T, int D,
+                     int H, int causal, int layer, const void* step_state, int train, float p_drop) {
+    if (!(q && k && v) || B <= 0 || T <= 0 || H <= 0 || H > 8 || D % H != 0 || (train && !step_state)) return AMID_ERR_ARG;
+    a.q = q; a.k = k; a.v = v; a.key_keep = key_keep;
+    a.B = B; a.T = T; a.D = D; a.H = H; a.causal = causal; a.layer = layer;
+    const int hd = D / H;
+    a.scale = causal ? sqrtf(1.0f / (float)hd) : sqrtf((float)hd);
+    a.st = (const StepState*)step_state;
+    a.train = (train && p_drop > 0.f) ? 1 : 0;
+    a.thr16 = keep_thr16(p_drop);
+    a.dscale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+    return AMID_OK;
+}
+
+extern "C" int amid_attn_fwd_f32(const float* q, const float* k, const float* v, const unsigned char* key_keep, int B, int T, int D, int H,
+                                 int causal, int layer, const void* step_state, int train, float p_drop, float* o, float* stats,
+                                 void* stream) {
+    AttnArgs a = {};
+    if (int e = attn_fill(a, q, k, v, key_keep, B, T, D, H, causal, layer, step_state, train, p_drop)) return e;
+    AMID_CHECK_ARG(o);
+    a.o = o; a.stats = stats;
+    const size_t lds = attn_fwd_lds(T, D);
+    if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
+    switch (D / H) {
+        case 8: return attn_launch(attn_fwd_kernel<8>, a, lds, stream);
+        case 16: return attn_launch(attn_fwd_kernel<16>, a, lds, stream);
+        case 32: return attn_launch(attn_fwd_kernel<32>, a, lds, stream);
+        default: return AMID_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int amid_attn_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o,
+                                 const unsigned char* key_keep, int B, int T, int D, int H, int causal, int layer, const void* step_state,
+                                 int train, float p_drop, float* dq, float* dk, float* dv, void* stream) {
+    AttnArgs a = {};
+    if (int e = attn_fill(a, q, k, v, key_keep, B, T, D, H, causal, layer, step_state, train, p_drop)) return e;
+    AMID_CHECK_ARG(o && stats && d_o && dq && dk && dv);
+    a.o = const_cast<float*>(o); a.stats = const_cast<float*>(stats); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
+    const size_t lds = attn_bwd_lds(T, D, H);
+    if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
+    switch (D / H) {
+        case 8: return attn_launch(attn_bwd_kernel<8>, a, lds, stream);
+        case 16: return attn_launch(attn_bwd_kernel<16>, a, lds, stream);
+        case 32: return attn_launch(attn_bwd_kernel<32>, a, lds, stream);
+        default: return AMID_ERR_UNSUPPORTED;
+    }
+}

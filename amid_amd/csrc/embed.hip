@@ -1,0 +1,243 @@
+// K1: item-embedding gathers (reference: embItemLayerEnhance.forward, model_seq.py:27-29, called
+// four times per forward at model_seq.py:418-421) fused with Log2feats' positional add, embedding
+// dropout and the feature-level (==0) timeline mask (model_seq.py:361-366), plus the matching backward
+// (dropout/mask on the incoming gradient and the pos_emb gradient).
+//
+// Layout: one concatenated index array idx_all[N_idx] = [seq_d1 (B*T) | seq_d2 (B*T) | items (B*NI)]
+// with items[b] = (i_node[b], neg_samples[b,:]); the gathered rows land in one [N_idx, D] buffer in
+// the same order, so the embedding backward can segment-reduce one contiguous gradient buffer.
+//
+// HBM-bound: per index 8 B (idx as delivered, int64 at the boundary) + D*4 read + D*4 written.
+// A row (512 B at D=128) is moved by one half-wave as float4 per lane; each half-wave keeps ROWS_IN_FLIGHT
+// independent rows in flight so that random 512-B reads of a table far larger than the 256 MiB
+// Infinity Cache still cover the HBM latency.
+#include "common.h"
+#include "rng.h"
+
+namespace amid {
+
+constexpr int ROWS_IN_FLIGHT = 4;
+
+// ---------------------------------------------------------------------------------------------
+// plain gather: out[i,:] = table[idx[i],:]           (bit-exact; G1)
+// ---------------------------------------------------------------------------------------------
+template <typename IdxT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, long long n_rows, int D,
+                                                          const IdxT* __restrict__ idx, long long n_idx,
+                                                          float* __restrict__ out, int* __restrict__ err) {
+    const int sub = threadIdx.x & 31;                              // lane within the half-wave
+    const long long hw = (long long)blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    const long long n_hw = (long long)gridDim.x * (blockDim.x >> 5);
+    const int q = D >> 2;                                          // float4 per row
+    for (long long r0 = hw * ROWS_IN_FLIGHT; r0 < n_idx; r0 += n_hw * ROWS_IN_FLIGHT) {
+        long long src[ROWS_IN_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+            long long r = r0 + u;
+            long long id = (r < n_idx) ? (long long)idx[r] : 0;
+            if (id < 0 || id >= n_rows) { if (err && sub == 0 && r < n_idx) atomicOr(err, 1); id = 0; }
+            src[u] = id;
+        }
+        for (int c = sub; c < q; c += 32) {
+            float4 v[ROWS_IN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) v[u] = ld4(table + src[u] * D + 4 * c);
+#pragma unroll
+            for (int u = 0; u < ROWS_IN_FLIGHT; ++u)
+                if (r0 + u < n_idx) st4(out + (r0 + u) * D + 4 * c, v[u]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// int64 -> int32 index packing at the module boundary (train_sr.py:191-199 hands LongTensors)
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_indices_kernel(const long long* __restrict__ i_node, const long long* __restrict__ neg,
+                                    const long long* __restrict__ seq_d1, const long long* __restrict__ seq_d2,
+                                    int B, int T, int n_neg, long long n_rows, int* __restrict__ idx_all, int* __restrict__ err) {
+    const int M = B * T, NI = 1 + n_neg;
+    const int n = 2 * M + B * NI;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        long long v;
+        if (i < M) v = seq_d1[i];
+        else if (i < 2 * M) v = seq_d2[i - M];
+        else {
+            int j = i - 2 * M, b = j / NI, k = j % NI;
+            v = (k == 0) ? i_node[b] : neg[(long long)b * n_neg + (k - 1)];
+        }
+        if (v < 0 || v >= n_rows) { atomicOr(err, 1); v = 0; }
+        idx_all[i] = (int)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused SASRec embedding forward.
+//   seq rows  r <  2M : x = E[idx] + P_g[t]; tm = (x == 0); x *= dropout; x = tm ? 0 : x
+//   item rows r >= 2M : x = E[idx]
+// tmq[r][c] (uint8, one per float4 column quad) keeps the 4 "== 0" bits for the later per-layer
+// re-masking (model_seq.py:383) and for backward.  pos == nullptr (BERT4Rec: no positional table,
+// no embedding dropout, no mask) degrades to the plain gather for every row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ table, const int* __restrict__ idx_all,
+                                                        const float* __restrict__ pos0, const float* __restrict__ pos1,
+                                                        int B, int T, int D, int n_item_rows,
+                                                        float* __restrict__ xg, unsigned char* __restrict__ tmq,
+                                                        const RngState* __restrict__ rng, int train, unsigned thr16, float scale) {
+    const int sub = threadIdx.x & 31;
+    const int hw = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    const int n_hw = gridDim.x * (blockDim.x >> 5);
+    const int q = D >> 2;
+    const int M = B * T;
+    const int n_idx = 2 * M + n_item_rows;
+    unsigned long long seed = 0;
+    unsigned step = 0;
+    if (train) { seed = rng->seed; step = (unsigned)rng->step; }
+    for (int r0 = hw * ROWS_IN_FLIGHT; r0 < n_idx; r0 += n_hw * ROWS_IN_FLIGHT) {
+        long long src[ROWS_IN_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+            int r = r0 + u;
+            src[u] = (r < n_idx) ? (long long)idx_all[r] : 0;
+        }
+        for (int c = sub; c < q; c += 32) {
+            float4 v[ROWS_IN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) v[u] = ld4(table + src[u] * D + 4 * c);
+#pragma unroll
+            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+                const int r = r0 + u;
+                if (r >= n_idx) continue;
+                float4 x = v[u];
+                if (r < 2 * M && pos0 != nullptr) {
+                    const int g = r >= M;
+                    const int local = r - g * M;
+                    const int t = local % T;
+                    const float4 p = ld4((g ? pos1 : pos0) + (long long)t * D + 4 * c);
+                    x = f4add(x, p);
+                    const unsigned bits = (x.x == 0.f ? 1u : 0u) | (x.y == 0.f ? 2u : 0u) | (x.z == 0.f ? 4u : 0u) | (x.w == 0.f ? 8u : 0u);
+                    if (train) {
+                        const float4 m = dropout_mult4(seed, site_id(g, 0, SITE_EMB), step, (unsigned long long)local * D + 4 * c, thr16, scale);
+                        x = f4mul(x, m);
+                    }
+                    if (bits) {
+                        if (bits & 1u) x.x = 0.f;
+                        if (bits & 2u) x.y = 0.f;
+                        if (bits & 4u) x.z = 0.f;
+                        if (bits & 8u) x.w = 0.f;
+                    }
+                    tmq[(long long)r * q + c] = (unsigned char)bits;
+                }
+                st4(xg + (long long)r * D + 4 * c, x);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding backward, seq rows only: block (t, g) walks b = 0..B-1
+//   dxe[r] = dx0[r] * ~tm * dropout          (in place: the buffer then feeds the segment reduce)
+//   dP_g[t] = sum_b dxe[g,b,t]               (fixed-order tree => bitwise reproducible)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_bwd_kernel(float* __restrict__ dxg, const unsigned char* __restrict__ tmq,
+                                                        int B, int T, int D, float* __restrict__ dpos0, float* __restrict__ dpos1,
+                                                        const RngState* __restrict__ rng, int train, unsigned thr16, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [8][D]
+    const int t = blockIdx.x, g = blockIdx.y;
+    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;        // 8 row groups
+    const int q = D >> 2;
+    const int M = B * T;
+    unsigned long long seed = 0;
+    unsigned step = 0;
+    if (train) { seed = rng->seed; step = (unsigned)rng->step; }
+    for (int c = sub; c < q; c += 32) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = rg; b < B; b += 8) {
+            const int local = b * T + t;
+            const long long r = (long long)g * M + local;
+            float4 v = ld4(dxg + r * D + 4 * c);
+            if (train) v = f4mul(v, dropout_mult4(seed, site_id(g, 0, SITE_EMB), step, (unsigned long long)local * D + 4 * c, thr16, scale));
+            const unsigned bits = tmq[r * q + c];
+            if (bits) {
+                if (bits & 1u) v.x = 0.f;
+                if (bits & 2u) v.y = 0.f;
+                if (bits & 4u) v.z = 0.f;
+                if (bits & 8u) v.w = 0.f;
+            }
+            st4(dxg + r * D + 4 * c, v);
+            acc = f4add(acc, v);
+        }
+        st4(red + rg * D + 4 * c, acc);
+    }
+    __syncthreads();
+    float* dp = (g ? dpos1 : dpos0) + (long long)t * D;
+    for (int e = threadIdx.x; e < D; e += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k * D + e];
+        dp[e] = s;
+    }
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+static inline int gather_grid(long long n_rows_to_move) {
+    long long hw_needed = (n_rows_to_move + ROWS_IN_FLIGHT - 1) / ROWS_IN_FLIGHT;
+    long long blocks = (hw_needed + 7) / 8;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;     // 16 blocks per CU, grid-stride beyond
+    return (int)blocks;
+}
+
+extern "C" int amid_gather_rows_f32(const float* table, long long n_rows, int D, const void* idx, int idx_is_i64,
+                                    long long n_idx, float* out, int* err_flag, void* stream) {
+    AMID_CHECK_ARG(table && idx && out && D > 0 && (D % 4) == 0 && n_idx >= 0);
+    if (n_idx == 0) return AMID_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (idx_is_i64)
+        gather_rows_kernel<long long><<<gather_grid(n_idx), 256, 0, s>>>(table, n_rows, D, (const long long*)idx, n_idx, out, err_flag);
+    else
+        gather_rows_kernel<int><<<gather_grid(n_idx), 256, 0, s>>>(table, n_rows, D, (const int*)idx, n_idx, out, err_flag);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_pack_indices(const long long* i_node, const long long* neg, const long long* seq_d1, const long long* seq_d2,
+                                 int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* stream) {
+    AMID_CHECK_ARG(i_node && neg && seq_d1 && seq_d2 && idx_all && err_flag && B > 0 && T > 0 && n_neg >= 0);
+    int n = 2 * B * T + B * (1 + n_neg);
+    int blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    pack_indices_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(i_node, neg, seq_d1, seq_d2, B, T, n_neg, n_rows, idx_all, err_flag);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_embed_fwd_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
+                                  int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
+                                  void* stream) {
+    AMID_CHECK_ARG(table && idx_all && xg && B > 0 && T > 0 && D > 0 && (D % 4) == 0 && n_item_rows >= 0);
+    AMID_CHECK_ARG((pos0 == nullptr) == (pos1 == nullptr));
+    AMID_CHECK_ARG(pos0 == nullptr || tmq != nullptr);
+    AMID_CHECK_ARG(!train || rng_state != nullptr);
+    const long long n_idx = 2LL * B * T + n_item_rows;
+    const int tr = (train && pos0 != nullptr && p_drop > 0.f) ? 1 : 0;
+    embed_fwd_kernel<<<gather_grid(n_idx), 256, 0, (hipStream_t)stream>>>(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq,
+                                                                           (const RngState*)rng_state, tr, keep_thr16(p_drop),
+                                                                           tr ? 1.0f / (1.0f - p_drop) : 1.0f);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, float* dpos0, float* dpos1,
+                                  const void* rng_state, int train, float p_drop, void* stream) {
+    AMID_CHECK_ARG(dxg && tmq && dpos0 && dpos1 && B > 0 && T > 0 && D > 0 && (D % 4) == 0);
+    AMID_CHECK_ARG(!train || rng_state != nullptr);
+    const int tr = (train && p_drop > 0.f) ? 1 : 0;
+    embed_bwd_kernel<<<dim3(T, 2), 256, 8 * D * sizeof(float), (hipStream_t)stream>>>(dxg, tmq, B, T, D, dpos0, dpos1,
+                                                                                      (const RngState*)rng_state, tr, keep_thr16(p_drop),
+                                                                                      tr ? 1.0f / (1.0f - p_drop) : 1.0f);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}

@@ -1,0 +1,347 @@
+// Everything after the encoder stack:
+//   lnmean  : u[g,b,:] = mean_t LN_last(x[g,b,t,:])          (model_seq.py:385, :432-434: mean over ALL T, pads included)
+//   scorer  : p_d[b,n] = sigmoid(W2 relu(W1 [u_d[b] ; item[b,n]] + b1) + b2), d = 1,2   (predictModule.forward, model_seq.py:40-54)
+//   loss    : mean over B*(1+neg) of BCE(p_1)*(1-domain) + BCE(p_2)*domain, log clamped at -100
+//             (nn.BCELoss(reduce=False), train_sr.py:184, :203-212) and its gradient wrt p.
+// and the matching backward kernels.  All of it is tiny next to the encoder (B*(1+neg) rows).
+#include "common.h"
+
+namespace amid {
+
+// ---- final LayerNorm + mean over time ---------------------------------------------------------
+// block = (g, b); 256 threads = 8 row groups of 32 lanes
+__global__ __launch_bounds__(256) void lnmean_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ b0,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1, int B, int T, int D,
+                                                         float eps, int use_ln, float* __restrict__ u) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [8][D]
+    const int seq = blockIdx.x, g = seq / B;
+    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int q = D >> 2;
+    const float* w = g ? w1 : w0;
+    const float* bb = g ? b1 : b0;
+    for (int c = sub; c < q; c += 32) st4(red + rg * D + 4 * c, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int t = rg; t < T; t += 8) {
+        const float* row = x + ((long long)seq * T + t) * D;
+        float s = 0.f;
+        for (int c = sub; c < q; c += 32) s += f4hsum(ld4(row + 4 * c));
+        const float mean = use_ln ? group_sum<32>(s) / D : 0.f;
+        float vs = 0.f;
+        if (use_ln) for (int c = sub; c < q; c += 32) { float4 v = ld4(row + 4 * c); v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean; vs += f4hsum(f4mul(v, v)); }
+        const float rstd = use_ln ? 1.0f / sqrtf(group_sum<32>(vs) / D + eps) : 1.f;
+        for (int c = sub; c < q; c += 32) {
+            float4 v = ld4(row + 4 * c);
+            if (use_ln) {
+                const float4 ww = ld4(w + 4 * c), b4 = ld4(bb + 4 * c);
+                v.x = (v.x - mean) * rstd * ww.x + b4.x; v.y = (v.y - mean) * rstd * ww.y + b4.y;
+                v.z = (v.z - mean) * rstd * ww.z + b4.z; v.w = (v.w - mean) * rstd * ww.w + b4.w;
+            }
+            float* rp = red + rg * D + 4 * c;
+            st4(rp, f4add(ld4(rp), v));
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < D; e += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k * D + e];
+        u[(long long)seq * D + e] = s / T;
+    }
+}
+
+// dx[g,b,t,:] = LN_last'(du[g,b,:] / T ; x[g,b,t,:]) ; per-block partials of d gamma / d beta -> part[seq][2][D]
+__global__ __launch_bounds__(256) void lnmean_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du, const float* __restrict__ w0,
+                                                         const float* __restrict__ w1, int B, int T, int D, float eps, int use_ln,
+                                                         float* __restrict__ dx, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [8][2][D]
+    const int seq = blockIdx.x, g = seq / B;
+    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int q = D >> 2;
+    const float* w = g ? w1 : w0;
+    const float invT = 1.0f / T;
+    for (int c = sub; c < 2 * q; c += 32) st4(red + rg * 2 * D + 4 * c, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int t = rg; t < T; t += 8) {
+        const long long ro = ((long long)seq * T + t) * D;
+        if (!use_ln) {
+            for (int c = sub; c < q; c += 32) st4(dx + ro + 4 * c, f4scale(ld4(du + (long long)seq * D + 4 * c), invT));
+            continue;
+        }
+        float s = 0.f;
+        for (int c = sub; c < q; c += 32) s += f4hsum(ld4(x + ro + 4 * c));
+        const float mean = group_sum<32>(s) / D;
+        float vs = 0.f;
+        for (int c = sub; c < q; c += 32) { float4 v = ld4(x + ro + 4 * c); v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean; vs += f4hsum(f4mul(v, v)); }
+        const float rstd = 1.0f / sqrtf(group_sum<32>(vs) / D + eps);
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = sub; c < q; c += 32) {
+            const float4 v = ld4(x + ro + 4 * c), dy = f4scale(ld4(du + (long long)seq * D + 4 * c), invT), gy = f4mul(dy, ld4(w + 4 * c));
+            const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+            a1 += f4hsum(gy);
+            a2 += f4hsum(f4mul(gy, xh));
+        }
+        const float c1 = group_sum<32>(a1) / D, c2 = group_sum<32>(a2) / D;
+        for (int c = sub; c < q; c += 32) {
+            const float4 v = ld4(x + ro + 4 * c), dy = f4scale(ld4(du + (long long)seq * D + 4 * c), invT), gy = f4mul(dy, ld4(w + 4 * c));
+            const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+            st4(dx + ro + 4 * c, make_float4(rstd * (gy.x - c1 - xh.x * c2), rstd * (gy.y - c1 - xh.y * c2), rstd * (gy.z - c1 - xh.z * c2),
+                                             rstd * (gy.w - c1 - xh.w * c2)));
+            float* rp = red + rg * 2 * D + 4 * c;
+            st4(rp, f4add(ld4(rp), f4mul(dy, xh)));
+            st4(rp + D, f4add(ld4(rp + D), dy));
+        }
+    }
+    __syncthreads();
+    if (part) {
+        for (int e = threadIdx.x; e < 2 * D; e += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += red[k * 2 * D + e];
+            part[(long long)seq * 2 * D + e] = s;
+        }
+    }
+}
+
+// ---- scorer ------------------------------------------------------------------------------------
+// block = batch row b; thread layout: hid units x lanes.  W1 = [hid, 2D] (user half | item half).
+struct ScorerArgs {
+    const float* u;            // [2, B, D]   u_d1 | u_d2
+    const float* items;        // [B, NI, D]
+    const float* w1; const float* b1; const float* w2; const float* b2;
+    const float* labels;       // [B, NI] or null
+    const long long* domain;   // [B]     or null
+    float* p1; float* p2;      // [B, NI]
+    float* dp1; float* dp2;    // dLoss/dp (written when labels given)
+    float* loss_part;          // [B]
+    int B, NI, D, hid;
+};
+
+__global__ __launch_bounds__(256) void scorer_fwd_kernel(const ScorerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, D = a.D, hid = a.hid, NI = a.NI;
+    float* au = sm;                    // [2][hid]  W1u . u_d + b1
+    float* ci = sm + 2 * hid;          // [NI][hid] W1i . item_n      (processed in chunks of <= 64 items)
+    const int lane = lane_id(), w = wave_id();          // 4 waves
+    // user halves: one (d, j) dot product per wave iteration
+    for (int dj = w; dj < 2 * hid; dj += 4) {
+        const int d = dj / hid, j = dj - d * hid;
+        const float* ur = a.u + ((long long)d * a.B + b) * D;
+        const float* wr = a.w1 + (long long)j * 2 * D;
+        float s = 0.f;
+        for (int e = lane; e < D; e += 64) s = fmaf(wr[e], ur[e], s);
+        s = group_sum<64>(s);
+        if (lane == 0) au[d * hid + j] = s + a.b1[j];
+    }
+    float lsum = 0.f;
+    for (int n0 = 0; n0 < NI; n0 += 64) {
+        const int nn = min(64, NI - n0);
+        __syncthreads();
+        for (int nj = w; nj < nn * hid; nj += 4) {
+            const int n = nj / hid, j = nj - n * hid;
+            const float* ir = a.items + ((long long)b * NI + n0 + n) * D;
+            const float* wr = a.w1 + (long long)j * 2 * D + D;
+            float s = 0.f;
+            for (int e = lane; e < D; e += 64) s = fmaf(wr[e], ir[e], s);
+            s = group_sum<64>(s);
+            if (lane == 0) ci[n * hid + j] = s;
+        }
+        __syncthreads();
+        // one thread per (n, d)
+        for (int nd = threadIdx.x; nd < nn * 2; nd += 256) {
+            const int n = nd >> 1, d = nd & 1;
+            float z = a.b2[0];
+            for (int j = 0; j < hid; ++j) z = fmaf(a.w2[j], fmaxf(au[d * hid + j] + ci[n * hid + j], 0.f), z);
+            const float p = 1.0f / (1.0f + expf(-z));
+            const long long o = (long long)b * NI + n0 + n;
+            (d ? a.p2 : a.p1)[o] = p;
+            if (a.labels) {
+                const float y = a.labels[o];
+                const float md = a.domain[b] ? (d ? 1.f : 0.f) : (d ? 0.f : 1.f);
+                const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.0f - p), -100.f);
+                const float inv = 1.0f / ((float)a.B * (float)NI);
+                lsum += -(y * lp + (1.f - y) * l1p) * md;
+                (d ? a.dp2 : a.dp1)[o] = md * inv * (p - y) / fmaxf((1.f - p) * p, 1e-12f);   // torch binary_cross_entropy_backward
+            }
+        }
+    }
+    if (a.labels) {
+        __syncthreads();
+        float* red = sm;               // au/ci are dead
+        lsum = group_sum<64>(lsum);
+        if (lane == 0) red[w] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) a.loss_part[b] = ((red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+struct ScorerBwdArgs {
+    const float* u; const float* items; const float* w1; const float* b1; const float* w2; const float* b2;
+    const float* p1; const float* p2; const float* dp1; const float* dp2;
+    float* du;                 // [2, B, D]
+    float* ditems;             // [B, NI, D]
+    float* part;               // [B][hid*2D + hid + hid + 1]  (dW1 | db1 | dW2 | db2) per-row partials
+    int B, NI, D, hid;
+};
+
+// block = batch row b.  Recomputes the hidden activations, then back-propagates.
+__global__ __launch_bounds__(256) void scorer_bwd_kernel(const ScorerBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, D = a.D, hid = a.hid, NI = a.NI;
+    float* au = sm;                         // [2][hid]
+    float* da = au + 2 * hid;               // [2][hid]   sum_n dpre[d][n][:]
+    float* dw2 = da + 2 * hid;              // [hid] + [1]
+    float* ci = dw2 + hid + 4;              // [64][hid]
+    float* dc = ci + 64 * hid;              // [64][hid]  dpre[0][n] + dpre[1][n]
+    const int lane = lane_id(), w = wave_id();
+    const int P = hid * 2 * D + 2 * hid + 1;
+    float* part = a.part + (long long)b * P;
+    for (int dj = w; dj < 2 * hid; dj += 4) {
+        const int d = dj / hid, j = dj - d * hid;
+        const float* ur = a.u + ((long long)d * a.B + b) * D;
+        const float* wr = a.w1 + (long long)j * 2 * D;
+        float s = 0.f;
+        for (int e = lane; e < D; e += 64) s = fmaf(wr[e], ur[e], s);
+        s = group_sum<64>(s);
+        if (lane == 0) au[d * hid + j] = s + a.b1[j];
+    }
+    for (int e = threadIdx.x; e < 2 * hid; e += 256) da[e] = 0.f;
+    for (int e = threadIdx.x; e < hid + 1; e += 256) dw2[e] = 0.f;
+    for (int e = threadIdx.x; e < hid * D; e += 256) part[(e / D) * 2 * D + D + (e % D)] = 0.f;      // item half of dW1 accumulates over chunks
+    for (int n0 = 0; n0 < NI; n0 += 64) {
+        const int nn = min(64, NI - n0);
+        __syncthreads();
+        for (int nj = w; nj < nn * hid; nj += 4) {
+            const int n = nj / hid, j = nj - n * hid;
+            const float* ir = a.items + ((long long)b * NI + n0 + n) * D;
+            const float* wr = a.w1 + (long long)j * 2 * D + D;
+            float s = 0.f;
+            for (int e = lane; e < D; e += 64) s = fmaf(wr[e], ir[e], s);
+            s = group_sum<64>(s);
+            if (lane == 0) ci[n * hid + j] = s;
+        }
+        __syncthreads();
+        // thread j < hid: walks the chunk's items in order (fixed summation order)
+        if (threadIdx.x < hid) {
+            const int j = threadIdx.x;
+            float s_da0 = 0.f, s_da1 = 0.f, s_w2 = 0.f;
+            for (int n = 0; n < nn; ++n) {
+                const long long o = (long long)b * NI + n0 + n;
+                const float p1 = a.p1[o], p2 = a.p2[o];
+                const float dz1 = a.dp1[o] * p1 * (1.f - p1), dz2 = a.dp2[o] * p2 * (1.f - p2);
+                const float h1 = fmaxf(au[j] + ci[n * hid + j], 0.f), h2 = fmaxf(au[hid + j] + ci[n * hid + j], 0.f);
+                const float g1 = h1 > 0.f ? dz1 * a.w2[j] : 0.f, g2 = h2 > 0.f ? dz2 * a.w2[j] : 0.f;
+                s_w2 += dz1 * h1 + dz2 * h2;
+                s_da0 += g1; s_da1 += g2;
+                dc[n * hid + j] = g1 + g2;
+            }
+            da[j] += s_da0; da[hid + j] += s_da1; dw2[j] += s_w2;
+        }
+        if (threadIdx.x == 64) {
+            float s = 0.f;
+            for (int n = 0; n < nn; ++n) {
+                const long long o = (long long)b * NI + n0 + n;
+                const float p1 = a.p1[o], p2 = a.p2[o];
+                s += a.dp1[o] * p1 * (1.f - p1) + a.dp2[o] * p2 * (1.f - p2);
+            }
+            dw2[hid] += s;
+        }
+        __syncthreads();
+        // d item[n][e] = sum_j dc[n][j] W1[j][D+e] ; dW1[j][D+e] += sum_n dc[n][j] item[n][e]
+        for (int ne = threadIdx.x; ne < nn * D; ne += 256) {
+            const int n = ne / D, e = ne - n * D;
+            float s = 0.f;
+            for (int j = 0; j < hid; ++j) s = fmaf(dc[n * hid + j], a.w1[(long long)j * 2 * D + D + e], s);
+            a.ditems[((long long)b * NI + n0 + n) * D + e] = s;
+        }
+        for (int je = threadIdx.x; je < hid * D; je += 256) {
+            const int j = je / D, e = je - j * D;
+            float s = 0.f;
+            for (int n = 0; n < nn; ++n) s = fmaf(dc[n * hid + j], a.items[((long long)b * NI + n0 + n) * D + e], s);
+            part[j * 2 * D + D + e] += s;
+        }
+    }
+    __syncthreads();
+    // user halves
+    for (int de = threadIdx.x; de < 2 * D; de += 256) {
+        const int d = de / D, e = de - d * D;
+        float s = 0.f;
+        for (int j = 0; j < hid; ++j) s = fmaf(da[d * hid + j], a.w1[(long long)j * 2 * D + e], s);
+        a.du[((long long)d * a.B + b) * D + e] = s;
+    }
+    for (int je = threadIdx.x; je < hid * D; je += 256) {
+        const int j = je / D, e = je - j * D;
+        part[j * 2 * D + e] = da[j] * a.u[(long long)b * D + e] + da[hid + j] * a.u[((long long)a.B + b) * D + e];
+    }
+    for (int j = threadIdx.x; j < hid; j += 256) {
+        part[hid * 2 * D + j] = da[j] + da[hid + j];            // db1
+        part[hid * 2 * D + hid + j] = dw2[j];                   // dW2
+    }
+    if (threadIdx.x == 0) part[hid * 2 * D + 2 * hid] = dw2[hid];   // db2
+}
+
+__global__ void sum_vector_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    // single wave, fixed order
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += v[i];
+    s = group_sum<64>(s);
+    if (threadIdx.x == 0) *out = s;
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+extern "C" int amid_lnmean_fwd_f32(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, int B, int T, int D,
+                                   float eps, float* u, void* stream) {
+    AMID_CHECK_ARG(x && u && B > 0 && T > 0 && D > 0 && (D % 4) == 0);
+    const int use_ln = (w0 != nullptr);
+    AMID_CHECK_ARG(!use_ln || (b0 && w1 && b1));
+    lnmean_fwd_kernel<<<2 * B, 256, 8 * D * sizeof(float), (hipStream_t)stream>>>(x, w0, b0, w1, b1, B, T, D, eps, use_ln, u);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_lnmean_bwd_f32(const float* x, const float* du, const float* w0, const float* w1, int B, int T, int D, float eps,
+                                   float* dx, float* part, void* stream) {
+    AMID_CHECK_ARG(x && du && dx && B > 0 && T > 0 && D > 0 && (D % 4) == 0);
+    const int use_ln = (w0 != nullptr);
+    AMID_CHECK_ARG(!use_ln || (w1 && part));
+    lnmean_bwd_kernel<<<2 * B, 256, 16 * D * sizeof(float), (hipStream_t)stream>>>(x, du, w0, w1, B, T, D, eps, use_ln, dx, part);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_scorer_fwd_f32(const float* u, const float* items, const float* w1, const float* b1, const float* w2, const float* b2,
+                                   const float* labels, const long long* domain_id, int B, int NI, int D, int hid, float* p1, float* p2,
+                                   float* dp1, float* dp2, float* loss_part, void* stream) {
+    AMID_CHECK_ARG(u && items && w1 && b1 && w2 && b2 && p1 && p2 && B > 0 && NI > 0 && D > 0 && hid > 0 && hid <= 256);
+    AMID_CHECK_ARG(!labels || (domain_id && dp1 && dp2 && loss_part));
+    ScorerArgs a;
+    a.u = u; a.items = items; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.labels = labels; a.domain = domain_id;
+    a.p1 = p1; a.p2 = p2; a.dp1 = dp1; a.dp2 = dp2; a.loss_part = loss_part; a.B = B; a.NI = NI; a.D = D; a.hid = hid;
+    const size_t lds = (size_t)(2 * hid + 64 * hid) * sizeof(float);
+    scorer_fwd_kernel<<<B, 256, lds, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" long long amid_scorer_part_floats(int D, int hid) { return (long long)hid * 2 * D + 2 * hid + 1; }
+
+extern "C" int amid_scorer_bwd_f32(const float* u, const float* items, const float* w1, const float* b1, const float* w2, const float* b2,
+                                   const float* p1, const float* p2, const float* dp1, const float* dp2, int B, int NI, int D, int hid,
+                                   float* du, float* ditems, float* part, void* stream) {
+    AMID_CHECK_ARG(u && items && w1 && b1 && w2 && b2 && p1 && p2 && dp1 && dp2 && du && ditems && part && B > 0 && NI > 0 && hid > 0 &&
+                   hid <= 64);
+    ScorerBwdArgs a;
+    a.u = u; a.items = items; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.p1 = p1; a.p2 = p2; a.dp1 = dp1; a.dp2 = dp2;
+    a.du = du; a.ditems = ditems; a.part = part; a.B = B; a.NI = NI; a.D = D; a.hid = hid;
+    const size_t lds = (size_t)(4 * hid + hid + 4 + 128 * hid) * sizeof(float);
+    scorer_bwd_kernel<<<B, 256, lds, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_sum_vector_f32(const float* v, int n, float* out, void* stream) {
+    AMID_CHECK_ARG(v && out && n > 0);
+    sum_vector_kernel<<<1, 64, 0, (hipStream_t)stream>>>(v, n, out);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}

@@ -1,0 +1,437 @@
+// Fused backward kernels of one SASRec encoder layer (autograd of Log2feats.forward model_seq.py:371-383;
+// reference: loss.backward(), train_sr.py:214).  Mirrors sasrec_fwd.hip; weights arrive TRANSPOSED
+// (wT[in][out], refreshed once per step by amid_transpose_weights) so that every data gradient is again
+// C[rows, N] = A[rows, K] * W'[N, K]^T on the same row-tile machinery.
+//
+//   ffn_bwd : dz = dx' * ~tm ; dpre2 = dz * drop2 ; dpre1 = (dpre2 C2) * relu'(h) ; dy = dpre1 C1 + dz ;
+//             dr = LN2'(dy ; r) ; d_o = dr Wo           (+ per-tile partial sums for d gamma2 / d beta2)
+//   qkv_bwd : dx = LN1'(dq Wq + dr ; x) + dk Wk + dv Wv  (+ per-tile partials for d gamma1 / d beta1)
+//   wgrad   : dW = dY^T X and db = colsum(dY) for the six projections of a layer, split over row
+//             ranges; partials are summed in fixed order by amid_reduce_partials (no atomics).
+#include "common.h"
+#include "rng.h"
+#include "tile_gemm.h"
+
+namespace amid {
+
+struct TileGeomB { int M; int rows_per_tile; int tiles_per_group; };
+
+__device__ __forceinline__ void tile_rows_b(const TileGeomB& tg, int tile, int& g, long long& row0, int& nrows, int& local0) {
+    g = tile / tg.tiles_per_group;
+    const int tl = tile - g * tg.tiles_per_group;
+    local0 = tl * tg.rows_per_tile;
+    nrows = min(tg.rows_per_tile, tg.M - local0);
+    row0 = (long long)g * tg.M + local0;
+}
+
+__device__ __forceinline__ float4 apply_tm(float4 v, unsigned bits) {
+    if (bits) {
+        if (bits & 1u) v.x = 0.f;
+        if (bits & 2u) v.y = 0.f;
+        if (bits & 4u) v.z = 0.f;
+        if (bits & 8u) v.w = 0.f;
+    }
+    return v;
+}
+
+// LayerNorm backward for one row held as a float4 per lane (QPR lanes): given dy, the LN input x and gamma,
+// returns dx; accumulates the per-column d gamma / d beta contributions.
+template <int QPR>
+__device__ __forceinline__ float4 ln_bwd_row(float4 dy, float4 x, float4 gam, int n, float eps, float4& dgam, float4& dbet) {
+    float mean, rstd;
+    row_stats<QPR>(x, n, eps, mean, rstd);
+    const float4 xh = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
+    const float4 gy = f4mul(gam, dy);
+    const float c1 = group_sum<QPR>(f4hsum(gy)) * (1.0f / n);
+    const float c2 = group_sum<QPR>(f4hsum(f4mul(gy, xh))) * (1.0f / n);
+    dgam = f4add(dgam, f4mul(dy, xh));
+    dbet = f4add(dbet, dy);
+    return make_float4(rstd * (gy.x - c1 - xh.x * c2), rstd * (gy.y - c1 - xh.y * c2), rstd * (gy.z - c1 - xh.z * c2),
+                       rstd * (gy.w - c1 - xh.w * c2));
+}
+
+// block-level reduction of the per-thread (d gamma, d beta) column sums -> part[2][D]
+template <int D>
+__device__ __forceinline__ void ln_partials_out(float* __restrict__ scratch, float4 dgam, float4 dbet, float* __restrict__ part) {
+    using RP = RowPass<D>;
+    const int sub = RP::sub(), slot = RP::first_row();            // slot in [0, RPP)
+    st4(scratch + (slot * 2 + 0) * D + 4 * sub, dgam);
+    st4(scratch + (slot * 2 + 1) * D + 4 * sub, dbet);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * D; e += GEMM_THREADS) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < RP::RPP; ++k) s += scratch[k * 2 * D + e];
+        part[e] = s;
+    }
+}
+
+struct FfnBwdArgs {
+    const float* dxo;                  // [2M, D] grad of the layer output
+    const unsigned char* tmq;
+    const float* h; const float* r;    // saved relu output, saved pre-LN2 sum
+    const float* ln_w[2];              // LN2 gamma
+    const float* w1T[2]; const float* w2T[2]; const float* woT[2];   // [D][D] transposed conv1 / conv2 / out_proj weights
+    float* dpre2; float* dpre1; float* dr; float* d_o;               // [2M, D]
+    float* ln_part;                    // [ntiles][2][D]
+    float ln_eps;
+    const StepState* st; int train; unsigned thr16; float scale; int layer;
+    TileGeomB tg;
+};
+
+template <int D>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_bwd_kernel(const FfnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using RP = RowPass<D>;
+    constexpr int LDK = TileCfg<D>::LDK, LDC = D + 4;
+    float* As = smem;
+    float* Ws = smem + TileCfg<D>::A_FLOATS;
+    float* Cs = Ws;
+    int g, nrows, local0; long long row0;
+    tile_rows_b(a.tg, blockIdx.x, g, row0, nrows, local0);
+    const int nrt = (nrows + 15) >> 4;
+    const int sub = RP::sub();
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+    // 1. dpre2 = (dxo * ~tm) * drop2  -> A image + global
+    for (int r = RP::first_row(); r < nrt * 16; r += RP::RPP) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nrows) {
+            const long long off = (row0 + r) * D + 4 * sub;
+            v = ld4(a.dxo + off);
+            if (a.tmq) v = apply_tm(v, a.tmq[(row0 + r) * (D / 4) + sub]);
+            if (a.train) v = f4mul(v, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN2), step, (unsigned long long)(local0 + r) * D + 4 * sub,
+                                                    a.thr16, a.scale));
+            st4(a.dpre2 + off, v);
+        }
+        st4(As + r * LDK + 4 * sub, v);
+    }
+    stage_weights<D, D>(Ws, a.w2T[g], D, 0);
+    __syncthreads();
+    f32x4 acc[WaveMap<D>::ACC];
+    zero_acc<D>(acc);
+    mma_tile<D, D>(As, Ws, acc, nrt);
+    __syncthreads();
+    acc_to_lds<D>(Cs, LDC, acc, nrt);
+    __syncthreads();
+    // 2. dpre1 = dh * relu'(h) * drop1   (h > 0 implies the unit was kept by drop1)
+    for (int r = RP::first_row(); r < nrt * 16; r += RP::RPP) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nrows) {
+            const long long off = (row0 + r) * D + 4 * sub;
+            const float4 dh = ld4(Cs + r * LDC + 4 * sub), hv = ld4(a.h + off);
+            v.x = hv.x > 0.f ? dh.x * a.scale : 0.f; v.y = hv.y > 0.f ? dh.y * a.scale : 0.f;
+            v.z = hv.z > 0.f ? dh.z * a.scale : 0.f; v.w = hv.w > 0.f ? dh.w * a.scale : 0.f;
+            st4(a.dpre1 + off, v);
+        }
+        st4(As + r * LDK + 4 * sub, v);
+    }
+    __syncthreads();
+    stage_weights<D, D>(Ws, a.w1T[g], D, 0);
+    __syncthreads();
+    zero_acc<D>(acc);
+    mma_tile<D, D>(As, Ws, acc, nrt);
+    __syncthreads();
+    acc_to_lds<D>(Cs, LDC, acc, nrt);
+    __syncthreads();
+    // 3. dy = C + dz ; dr = LN2'(dy ; r) -> global + A image of the out-proj data gradient
+    float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
+    {
+        const float4 gam = ld4(a.ln_w[g] + 4 * sub);
+        for (int r = RP::first_row(); r < nrt * 16; r += RP::RPP) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nrows) {                                   // nrows is uniform over the QPR lanes of a row
+                const long long off = (row0 + r) * D + 4 * sub;
+                float4 dz = ld4(a.dxo + off);
+                if (a.tmq) dz = apply_tm(dz, a.tmq[(row0 + r) * (D / 4) + sub]);
+                const float4 dy = f4add(ld4(Cs + r * LDC + 4 * sub), dz);
+                v = ln_bwd_row<RP::QPR>(dy, ld4(a.r + off), gam, D, a.ln_eps, dgam, dbet);
+                st4(a.dr + off, v);
+            }
+            st4(As + r * LDK + 4 * sub, v);
+        }
+    }
+    __syncthreads();
+    stage_weights<D, D>(Ws, a.woT[g], D, 0);
+    __syncthreads();
+    zero_acc<D>(acc);
+    mma_tile<D, D>(As, Ws, acc, nrt);
+    __syncthreads();
+    acc_to_lds<D>(Cs, LDC, acc, nrt);
+    __syncthreads();
+    for (int r = RP::first_row(); r < nrows; r += RP::RPP) st4(a.d_o + (row0 + r) * D + 4 * sub, ld4(Cs + r * LDC + 4 * sub));
+    // As is free now: use it as the reduction scratch for the LN partials
+    ln_partials_out<D>(As, dgam, dbet, a.ln_part + (long long)blockIdx.x * 2 * D);
+}
+
+struct QkvBwdArgs {
+    const float* dq; const float* dk; const float* dv;    // [2M, D]
+    const float* dr;                                      // residual-path grad of the normed query
+    const float* x;                                       // layer input (LN1 input)
+    const float* ln_w[2];
+    const float* wqT[2]; const float* wkT[2]; const float* wvT[2];
+    float* dx;                                            // [2M, D] grad of the layer input
+    float* ln_part;                                       // [ntiles][2][D]
+    float ln_eps;
+    TileGeomB tg;
+};
+
+template <int D>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_bwd_kernel(const QkvBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using RP = RowPass<D>;
+    constexpr int LDC = D + 4;
+    float* As = smem;
+    float* Ws = smem + TileCfg<D>::A_FLOATS;
+    int g, nrows, local0; long long row0;
+    tile_rows_b(a.tg, blockIdx.x, g, row0, nrows, local0);
+    const int nrt = (nrows + 15) >> 4;
+    const int sub = RP::sub();
+    f32x4 acc_kv[WaveMap<D>::ACC], acc_q[WaveMap<D>::ACC];
+    zero_acc<D>(acc_kv);
+    zero_acc<D>(acc_q);
+    stage_rows<D>(As, a.dk, row0, nrows, D, 0, nrt * 16);
+    stage_weights<D, D>(Ws, a.wkT[g], D, 0);
+    __syncthreads();
+    mma_tile<D, D>(As, Ws, acc_kv, nrt);
+    __syncthreads();
+    stage_rows<D>(As, a.dv, row0, nrows, D, 0, nrt * 16);
+    stage_weights<D, D>(Ws, a.wvT[g], D, 0);
+    __syncthreads();
+    mma_tile<D, D>(As, Ws, acc_kv, nrt);
+    __syncthreads();
+    stage_rows<D>(As, a.dq, row0, nrows, D, 0, nrt * 16);
+    stage_weights<D, D>(Ws, a.wqT[g], D, 0);
+    __syncthreads();
+    mma_tile<D, D>(As, Ws, acc_q, nrt);
+    __syncthreads();
+    float* Ckv = As;                    // both operand images are dead: reuse them as the two C images
+    float* Cq = Ws;
+    acc_to_lds<D>(Ckv, LDC, acc_kv, nrt);
+    acc_to_lds<D>(Cq, LDC, acc_q, nrt);
+    __syncthreads();
+    float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
+    const float4 gam = ld4(a.ln_w[g] + 4 * sub);
+    for (int r = RP::first_row(); r < nrows; r += RP::RPP) {
+        const long long off = (row0 + r) * D + 4 * sub;
+        const float4 dqn = f4add(ld4(Cq + r * LDC + 4 * sub), ld4(a.dr + off));
+        const float4 dxl = ln_bwd_row<RP::QPR>(dqn, ld4(a.x + off), gam, D, a.ln_eps, dgam, dbet);
+        st4(a.dx + off, f4add(dxl, ld4(Ckv + r * LDC + 4 * sub)));
+    }
+    __syncthreads();
+    ln_partials_out<D>(Ws, dgam, dbet, a.ln_part + (long long)blockIdx.x * 2 * D);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients of one layer: blockIdx = (split, weight 0..5, domain)
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* dy[6];        // dq, dk, dv, dr, dpre1, dpre2        [2M, D]
+    const float* xin[6];       // qn, x,  x,  o,  y,     h            [2M, D]
+    float* w_part;             // [2][6][splits][D*D]
+    float* b_part;             // [2][6][splits][D]
+    int M, splits, rows_per_split;
+};
+
+constexpr int WG_ROWS = 64;    // rows staged per step
+
+template <int D>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LD = D + 16;                         // (4*LD) % 32 words == 16: the four m-rows of an MFMA hit disjoint banks
+    constexpr int NTn = D / 16;
+    constexpr int WPN = 8 / NTn > 0 ? 8 / NTn : 1;     // waves per n tile (1 at D=128, 2 at D=64)
+    constexpr int KTW = NTn / WPN;                     // k tiles per wave (8 at D=128, 2 at D=64)
+    float* Ys = smem;
+    float* Xs = smem + WG_ROWS * LD;
+    const int split = blockIdx.x, wsel = blockIdx.y, g = blockIdx.z;
+    const float* __restrict__ dy = a.dy[wsel];
+    const float* __restrict__ xin = a.xin[wsel];
+    const int local_beg = split * a.rows_per_split;
+    const int local_end = min(a.M, local_beg + a.rows_per_split);
+    const int w = wave_id(), lane = lane_id();
+    const int nt = w / WPN, kt0 = (w % WPN) * KTW;
+    const int i = lane & 15, gq = lane >> 4;
+    constexpr int QPR = D / 4, RPP = GEMM_THREADS / QPR;
+    const int sub = threadIdx.x % QPR, rl = threadIdx.x / QPR;
+    f32x4 acc[KTW];
+#pragma unroll
+    for (int t = 0; t < KTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = local_beg; c0 < local_end; c0 += WG_ROWS) {
+        const int nr = min(WG_ROWS, local_end - c0);
+        const long long grow = (long long)g * a.M + c0;
+        __syncthreads();                               // previous chunk fully consumed
+        for (int r = rl; r < WG_ROWS; r += RPP) {
+            float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vx = vy;
+            if (r < nr) { vy = ld4(dy + (grow + r) * D + 4 * sub); vx = ld4(xin + (grow + r) * D + 4 * sub); }
+            bsum = f4add(bsum, vy);
+            st4(Ys + r * LD + 4 * sub, vy);
+            st4(Xs + r * LD + 4 * sub, vx);
+        }
+        __syncthreads();
+        const int msteps = (nr + 3) >> 2;
+        for (int ms = 0; ms < msteps; ++ms) {
+            const int m = ms * 4 + gq;
+            const float av = Ys[m * LD + nt * 16 + i];
+#pragma unroll
+            for (int t = 0; t < KTW; ++t) acc[t] = mfma16(av, Xs[m * LD + (kt0 + t) * 16 + i], acc[t]);
+        }
+    }
+    float* wp = a.w_part + (((long long)g * 6 + wsel) * a.splits + split) * D * D;
+#pragma unroll
+    for (int t = 0; t < KTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wp[(long long)(nt * 16 + gq * 4 + r) * D + (kt0 + t) * 16 + i] = acc[t][r];
+    __syncthreads();
+    st4(Ys + rl * D + 4 * sub, bsum);                  // [RPP][D] scratch
+    __syncthreads();
+    float* bp = a.b_part + (((long long)g * 6 + wsel) * a.splits + split) * D;
+    for (int e = threadIdx.x; e < D; e += GEMM_THREADS) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < RPP; ++k) s += Ys[k * D + e];
+        bp[e] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[j][i] = in[i][j] for a batch of square D x D matrices (per-step refresh of the transposed weights)
+// ---------------------------------------------------------------------------------------------
+struct TransposeArgs { const float* src[32]; float* dst[32]; int n; };
+
+__global__ __launch_bounds__(256) void transpose_sq_kernel(const TransposeArgs a, int D) {
+    __shared__ float tile[32][33];
+    const float* __restrict__ s = a.src[blockIdx.z];
+    float* __restrict__ d = a.dst[blockIdx.z];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = s[(long long)(by + r) * D + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) d[(long long)(bx + r) * D + by + tx] = tile[tx][r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// fixed-order sum of partial buffers: dst[e] = sum_k src[k * stride + e]
+// ---------------------------------------------------------------------------------------------
+struct ReduceEntry { const float* src; float* dst; long long stride; int n_part; int count; };
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceEntry* __restrict__ entries) {
+    const ReduceEntry en = entries[blockIdx.y];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < en.count; e += gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < en.n_part; ++k) s += en.src[k * en.stride + e];
+        en.dst[e] = s;
+    }
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+template <int D> static constexpr size_t fused_lds_bytes_b() { return (size_t)(TileCfg<D>::A_FLOATS + D * TileCfg<D>::LDK) * sizeof(float); }
+
+static int make_geom_b(int M, int rows_per_tile, TileGeomB* tg) {
+    if (M <= 0 || rows_per_tile <= 0 || rows_per_tile > TILE_ROWS) return AMID_ERR_ARG;
+    tg->M = M;
+    tg->rows_per_tile = rows_per_tile;
+    tg->tiles_per_group = (M + rows_per_tile - 1) / rows_per_tile;
+    return AMID_OK;
+}
+
+#define AMID_LAUNCH_FUSED_B(KERNEL, ARGS, DVAL)                                                                            \
+    do {                                                                                                                   \
+        static bool attr_set_##DVAL = false;                                                                               \
+        if (!attr_set_##DVAL) {                                                                                            \
+            hipError_t e = hipFuncSetAttribute((const void*)KERNEL<DVAL>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                               (int)fused_lds_bytes_b<DVAL>());                                            \
+            if (e != hipSuccess) return (int)e;                                                                            \
+            attr_set_##DVAL = true;                                                                                        \
+        }                                                                                                                  \
+        KERNEL<DVAL><<<2 * ARGS.tg.tiles_per_group, GEMM_THREADS, fused_lds_bytes_b<DVAL>(), (hipStream_t)stream>>>(ARGS); \
+    } while (0)
+
+extern "C" int amid_sas_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                                    const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
+                                    int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2,
+                                    float* dpre1, float* dr, float* d_o, float* ln_part, void* stream) {
+    AMID_CHECK_ARG(dxo && h && r && ln_w && w1T && w2T && woT && dpre2 && dpre1 && dr && d_o && ln_part && (!train || step_state));
+    FfnBwdArgs a;
+    a.dxo = dxo; a.tmq = tmq; a.h = h; a.r = r; a.dpre2 = dpre2; a.dpre1 = dpre1; a.dr = dr; a.d_o = d_o; a.ln_part = ln_part;
+    a.ln_eps = ln_eps; a.st = (const StepState*)step_state; a.layer = layer;
+    a.train = (train && p_drop > 0.f) ? 1 : 0;
+    a.thr16 = keep_thr16(p_drop);
+    a.scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+    for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.w1T[g] = w1T[g]; a.w2T[g] = w2T[g]; a.woT[g] = woT[g]; }
+    if (int e = make_geom_b(M, rows_per_tile, &a.tg)) return e;
+    if (D == 128) AMID_LAUNCH_FUSED_B(sas_ffn_bwd_kernel, a, 128);
+    else if (D == 64) AMID_LAUNCH_FUSED_B(sas_ffn_bwd_kernel, a, 64);
+    else return AMID_ERR_UNSUPPORTED;
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_sas_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                    const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
+                                    float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, void* stream) {
+    AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && dx && ln_part);
+    QkvBwdArgs a;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.dr = dr; a.x = x; a.dx = dx; a.ln_part = ln_part; a.ln_eps = ln_eps;
+    for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.wqT[g] = wqT[g]; a.wkT[g] = wkT[g]; a.wvT[g] = wvT[g]; }
+    if (int e = make_geom_b(M, rows_per_tile, &a.tg)) return e;
+    if (D == 128) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 128);
+    else if (D == 64) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 64);
+    else return AMID_ERR_UNSUPPORTED;
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_sas_wgrad_f32(const float* const* dy6, const float* const* x6, int M, int D, int splits, float* w_part, float* b_part,
+                                  void* stream) {
+    AMID_CHECK_ARG(dy6 && x6 && w_part && b_part && M > 0 && splits > 0);
+    WgradArgs a;
+    for (int i = 0; i < 6; ++i) { a.dy[i] = dy6[i]; a.xin[i] = x6[i]; AMID_CHECK_ARG(dy6[i] && x6[i]); }
+    a.w_part = w_part; a.b_part = b_part; a.M = M; a.splits = splits;
+    a.rows_per_split = (M + splits - 1) / splits;
+    const dim3 grid(splits, 6, 2);
+    if (D == 128) {
+        const size_t lds = (size_t)2 * WG_ROWS * (128 + 16) * sizeof(float);
+        static bool set128 = false;
+        if (!set128) { hipError_t e = hipFuncSetAttribute((const void*)sas_wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; set128 = true; }
+        sas_wgrad_kernel<128><<<grid, GEMM_THREADS, lds, (hipStream_t)stream>>>(a);
+    } else if (D == 64) {
+        const size_t lds = (size_t)2 * WG_ROWS * (64 + 16) * sizeof(float);
+        sas_wgrad_kernel<64><<<grid, GEMM_THREADS, lds, (hipStream_t)stream>>>(a);
+    } else return AMID_ERR_UNSUPPORTED;
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_transpose_weights_f32(const float* const* src, float* const* dst, int n, int D, void* stream) {
+    AMID_CHECK_ARG(src && dst && n > 0 && n <= 32 && D > 0 && (D % 32) == 0);
+    TransposeArgs a;
+    a.n = n;
+    for (int i = 0; i < n; ++i) { AMID_CHECK_ARG(src[i] && dst[i]); a.src[i] = src[i]; a.dst[i] = dst[i]; }
+    transpose_sq_kernel<<<dim3(D / 32, D / 32, n), 256, 0, (hipStream_t)stream>>>(a, D);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_reduce_entry_bytes(void) { return (int)sizeof(ReduceEntry); }
+
+extern "C" int amid_reduce_entry_pack(void* host_buf, int index, const float* src, float* dst, long long stride, int n_part, int count) {
+    AMID_CHECK_ARG(host_buf && src && dst && n_part > 0 && count > 0 && index >= 0);
+    ReduceEntry e;
+    e.src = src; e.dst = dst; e.stride = stride; e.n_part = n_part; e.count = count;
+    ((ReduceEntry*)host_buf)[index] = e;
+    return AMID_OK;
+}
+
+extern "C" int amid_reduce_partials_f32(const void* entries_dev, int n_entries, int max_count, void* stream) {
+    AMID_CHECK_ARG(entries_dev && n_entries > 0 && max_count > 0);
+    int bx = (max_count + 255) / 256;
+    if (bx > 64) bx = 64;
+    reduce_partials_kernel<<<dim3(bx, n_entries), 256, 0, (hipStream_t)stream>>>((const ReduceEntry*)entries_dev);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}

@@ -1,0 +1,294 @@
+// Fused forward kernels of one SASRec encoder layer (reference: Log2feats.forward model_seq.py:371-383,
+// nn.MultiheadAttention projections as called at :374, PointWiseFeedForward model_seq.py:322-326).
+// Both domains (sac1 / sac2) run in the same launch: rows [0, M) belong to domain 0, [M, 2M) to
+// domain 1, each with its own weights; a row tile never straddles the two.
+//
+//   qkv_fwd   : Qn = LN1(x) ; q = Qn Wq^T + bq ; k = x Wk^T + bk ; v = x Wv^T + bv      (k, v from the UN-normed x)
+//   oproj_fwd : r = Qn + (o Wo^T + bo)  (residual on the NORMED query, :378) ; y = LN2(r)
+//   ffn_fwd   : h = relu(drop1(y C1^T + c1)) ; x' = (drop2(h C2^T + c2) + y) * ~tm        (:323-325, :383)
+// MFMA-bound (exact fp32 MFMA, 64 FLOP/clk/SIMD); algorithmic FLOPs per row: 2*D*D per projection.
+#include "common.h"
+#include "rng.h"
+#include "tile_gemm.h"
+
+namespace amid {
+
+struct TileGeom {           // how the 2*M activation rows are cut into row tiles
+    int M;                  // rows per domain (B*T)
+    int rows_per_tile;      // <= TILE_ROWS
+    int tiles_per_group;
+};
+
+__device__ __forceinline__ void tile_rows(const TileGeom& tg, int tile, int& g, long long& row0, int& nrows, int& local0) {
+    g = tile / tg.tiles_per_group;
+    const int tl = tile - g * tg.tiles_per_group;
+    local0 = tl * tg.rows_per_tile;
+    nrows = min(tg.rows_per_tile, tg.M - local0);
+    row0 = (long long)g * tg.M + local0;
+}
+
+struct QkvFwdArgs {
+    const float* x;                 // [2M, D] layer input
+    const float* ln_w[2]; const float* ln_b[2];
+    const float* w_in[2];           // [3D, D] in_proj_weight
+    const float* b_in[2];           // [3D]
+    float* qn; float* q; float* k; float* v;   // [2M, D] each
+    float ln_eps;
+    TileGeom tg;
+};
+
+template <int D>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_fwd_kernel(const QkvFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using RP = RowPass<D>;
+    constexpr int LDK = TileCfg<D>::LDK, LDC = D + 4;
+    float* As = smem;
+    float* Ws = smem + TileCfg<D>::A_FLOATS;
+    float* Cs = Ws;
+    int g, nrows, local0; long long row0;
+    tile_rows(a.tg, blockIdx.x, g, row0, nrows, local0);
+    const int nrt = (nrows + 15) >> 4;
+    const int sub = RP::sub();
+    stage_rows<D>(As, a.x, row0, nrows, D, 0, nrt * 16);
+    f32x4 acc[WaveMap<D>::ACC];
+#pragma unroll 1
+    for (int s = 0; s < 3; ++s) {
+        // order k, v, q: the tile is normalised in place before the q slab
+        const int which = (s == 0) ? 1 : (s == 1) ? 2 : 0;
+        if (which == 0) {
+            __syncthreads();
+            const float4 w = ld4(a.ln_w[g] + 4 * sub), b = ld4(a.ln_b[g] + 4 * sub);
+            for (int r = RP::first_row(); r < nrt * 16; r += RP::RPP) {
+                float4 x = ld4(As + r * LDK + 4 * sub);
+                float mean, rstd;
+                row_stats<RP::QPR>(x, D, a.ln_eps, mean, rstd);
+                float4 y;
+                y.x = (x.x - mean) * rstd * w.x + b.x; y.y = (x.y - mean) * rstd * w.y + b.y;
+                y.z = (x.z - mean) * rstd * w.z + b.z; y.w = (x.w - mean) * rstd * w.w + b.w;
+                st4(As + r * LDK + 4 * sub, y);
+                if (r < nrows) st4(a.qn + (row0 + r) * D + 4 * sub, y);
+            }
+        }
+        stage_weights<D, D>(Ws, a.w_in[g] + (long long)which * D * D, D, 0);
+        __syncthreads();
+        zero_acc<D>(acc);
+        mma_tile<D, D>(As, Ws, acc, nrt);
+        __syncthreads();
+        acc_to_lds<D>(Cs, LDC, acc, nrt);
+        __syncthreads();
+        float* out = (which == 0) ? a.q : (which == 1) ? a.k : a.v;
+        const float4 bias = ld4(a.b_in[g] + which * D + 4 * sub);
+        for (int r = RP::first_row(); r < nrows; r += RP::RPP)
+            st4(out + (row0 + r) * D + 4 * sub, f4add(ld4(Cs + r * LDC + 4 * sub), bias));
+        __syncthreads();
+    }
+}
+
+struct OprojFwdArgs {
+    const float* o;                  // [2M, D] attention output (heads merged)
+    const float* w_o[2]; const float* b_o[2];
+    const float* qn;                 // residual source
+    const float* ln_w[2]; const float* ln_b[2];
+    float* r; float* y;              // pre-LN2 sum, LN2 output
+    float ln_eps;
+    TileGeom tg;
+};
+
+template <int D>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_fwd_kernel(const OprojFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using RP = RowPass<D>;
+    constexpr int LDC = D + 4;
+    float* As = smem;
+    float* Ws = smem + TileCfg<D>::A_FLOATS;
+    float* Cs = Ws;
+    int g, nrows, local0; long long row0;
+    tile_rows(a.tg, blockIdx.x, g, row0, nrows, local0);
+    const int nrt = (nrows + 15) >> 4;
+    const int sub = RP::sub();
+    stage_rows<D>(As, a.o, row0, nrows, D, 0, nrt * 16);
+    stage_weights<D, D>(Ws, a.w_o[g], D, 0);
+    __syncthreads();
+    f32x4 acc[WaveMap<D>::ACC];
+    zero_acc<D>(acc);
+    mma_tile<D, D>(As, Ws, acc, nrt);
+    __syncthreads();
+    acc_to_lds<D>(Cs, LDC, acc, nrt);
+    __syncthreads();
+    const float4 bias = ld4(a.b_o[g] + 4 * sub), w = ld4(a.ln_w[g] + 4 * sub), b = ld4(a.ln_b[g] + 4 * sub);
+    for (int r = RP::first_row(); r < nrows; r += RP::RPP) {
+        const long long off = (row0 + r) * D + 4 * sub;
+        const float4 x = f4add(ld4(a.qn + off), f4add(ld4(Cs + r * LDC + 4 * sub), bias));
+        st4(a.r + off, x);
+        float mean, rstd;
+        row_stats<RP::QPR>(x, D, a.ln_eps, mean, rstd);
+        float4 y;
+        y.x = (x.x - mean) * rstd * w.x + b.x; y.y = (x.y - mean) * rstd * w.y + b.y;
+        y.z = (x.z - mean) * rstd * w.z + b.z; y.w = (x.w - mean) * rstd * w.w + b.w;
+        st4(a.y + off, y);
+    }
+}
+
+struct FfnFwdArgs {
+    const float* y;                  // [2M, D] LN2 output
+    const float* w1[2]; const float* b1[2]; const float* w2[2]; const float* b2[2];   // conv{1,2}.weight[:, :, 0], bias
+    const unsigned char* tmq;        // [2M, D/4] feature-level "== 0" bits (may be null: no mask)
+    float* h; float* xo;             // relu output, layer output
+    const StepState* st; int train; unsigned thr16; float scale; int layer;
+    TileGeom tg;
+};
+
+template <int D>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_fwd_kernel(const FfnFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using RP = RowPass<D>;
+    constexpr int LDK = TileCfg<D>::LDK, LDC = D + 4;
+    float* As = smem;
+    float* Ws = smem + TileCfg<D>::A_FLOATS;
+    float* Cs = Ws;
+    int g, nrows, local0; long long row0;
+    tile_rows(a.tg, blockIdx.x, g, row0, nrows, local0);
+    const int nrt = (nrows + 15) >> 4;
+    const int sub = RP::sub();
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+    stage_rows<D>(As, a.y, row0, nrows, D, 0, nrt * 16);
+    stage_weights<D, D>(Ws, a.w1[g], D, 0);
+    __syncthreads();
+    f32x4 acc[WaveMap<D>::ACC];
+    zero_acc<D>(acc);
+    mma_tile<D, D>(As, Ws, acc, nrt);
+    __syncthreads();
+    acc_to_lds<D>(Cs, LDC, acc, nrt);
+    __syncthreads();
+    {   // h = relu(drop1(C + c1)) -> global and the A image of the second GEMM
+        const float4 bias = ld4(a.b1[g] + 4 * sub);
+        for (int r = RP::first_row(); r < nrt * 16; r += RP::RPP) {
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nrows) {
+                hv = f4add(ld4(Cs + r * LDC + 4 * sub), bias);
+                if (a.train) hv = f4mul(hv, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN1), step,
+                                                          (unsigned long long)(local0 + r) * D + 4 * sub, a.thr16, a.scale));
+                hv.x = fmaxf(hv.x, 0.f); hv.y = fmaxf(hv.y, 0.f); hv.z = fmaxf(hv.z, 0.f); hv.w = fmaxf(hv.w, 0.f);
+                st4(a.h + (row0 + r) * D + 4 * sub, hv);
+            }
+            st4(As + r * LDK + 4 * sub, hv);
+        }
+    }
+    __syncthreads();
+    stage_weights<D, D>(Ws, a.w2[g], D, 0);
+    __syncthreads();
+    zero_acc<D>(acc);
+    mma_tile<D, D>(As, Ws, acc, nrt);
+    __syncthreads();
+    acc_to_lds<D>(Cs, LDC, acc, nrt);
+    __syncthreads();
+    {
+        const float4 bias = ld4(a.b2[g] + 4 * sub);
+        for (int r = RP::first_row(); r < nrows; r += RP::RPP) {
+            const long long off = (row0 + r) * D + 4 * sub;
+            float4 z = f4add(ld4(Cs + r * LDC + 4 * sub), bias);
+            if (a.train) z = f4mul(z, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN2), step,
+                                                    (unsigned long long)(local0 + r) * D + 4 * sub, a.thr16, a.scale));
+            z = f4add(z, ld4(a.y + off));
+            if (a.tmq) {
+                const unsigned bits = a.tmq[(row0 + r) * (D / 4) + sub];
+                if (bits) {
+                    if (bits & 1u) z.x = 0.f;
+                    if (bits & 2u) z.y = 0.f;
+                    if (bits & 4u) z.z = 0.f;
+                    if (bits & 8u) z.w = 0.f;
+                }
+            }
+            st4(a.xo + off, z);
+        }
+    }
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+template <int D> static constexpr size_t fused_lds_bytes() { return (size_t)(TileCfg<D>::A_FLOATS + D * TileCfg<D>::LDK) * sizeof(float); }
+
+static int make_geom(int M, int rows_per_tile, TileGeom* tg) {
+    if (M <= 0 || rows_per_tile <= 0 || rows_per_tile > TILE_ROWS) return AMID_ERR_ARG;
+    tg->M = M;
+    tg->rows_per_tile = rows_per_tile;
+    tg->tiles_per_group = (M + rows_per_tile - 1) / rows_per_tile;
+    return AMID_OK;
+}
+
+// Rows per tile for a launch over 2*M rows: spread the rows evenly over a whole number of rounds of the
+// 256 CUs (one 512-thread workgroup per CU), at most TILE_ROWS rows per tile.
+extern "C" int amid_rows_per_tile(int M) {
+    const long long total = 2LL * M;
+    for (int rounds = 1;; ++rounds) {
+        const long long tiles = 256LL * rounds;
+        long long rpt = (total + tiles - 1) / tiles;
+        if (rpt <= TILE_ROWS) {
+            if (rpt < 16) rpt = 16;
+            return (int)rpt;
+        }
+    }
+}
+
+#define AMID_LAUNCH_FUSED(KERNEL, ARGS, DVAL)                                                                              \
+    do {                                                                                                                   \
+        static bool attr_set_##DVAL = false;                                                                               \
+        if (!attr_set_##DVAL) {                                                                                            \
+            hipError_t e = hipFuncSetAttribute((const void*)KERNEL<DVAL>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                               (int)fused_lds_bytes<DVAL>());                                              \
+            if (e != hipSuccess) return (int)e;                                                                            \
+            attr_set_##DVAL = true;                                                                                        \
+        }                                                                                                                  \
+        KERNEL<DVAL><<<2 * ARGS.tg.tiles_per_group, GEMM_THREADS, fused_lds_bytes<DVAL>(), (hipStream_t)stream>>>(ARGS);   \
+    } while (0)
+
+extern "C" int amid_sas_qkv_fwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
+                                    const float* const* b_in, float ln_eps, int M, int D, int rows_per_tile, float* qn, float* q, float* k,
+                                    float* v, void* stream) {
+    AMID_CHECK_ARG(x && ln_w && ln_b && w_in && b_in && qn && q && k && v);
+    QkvFwdArgs a;
+    a.x = x; a.qn = qn; a.q = q; a.k = k; a.v = v; a.ln_eps = ln_eps;
+    for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.ln_b[g] = ln_b[g]; a.w_in[g] = w_in[g]; a.b_in[g] = b_in[g]; }
+    if (int e = make_geom(M, rows_per_tile, &a.tg)) return e;
+    if (D == 128) AMID_LAUNCH_FUSED(sas_qkv_fwd_kernel, a, 128);
+    else if (D == 64) AMID_LAUNCH_FUSED(sas_qkv_fwd_kernel, a, 64);
+    else return AMID_ERR_UNSUPPORTED;
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_sas_oproj_fwd_f32(const float* o, const float* const* w_o, const float* const* b_o, const float* qn,
+                                      const float* const* ln_w, const float* const* ln_b, float ln_eps, int M, int D, int rows_per_tile,
+                                      float* r, float* y, void* stream) {
+    AMID_CHECK_ARG(o && w_o && b_o && qn && ln_w && ln_b && r && y);
+    OprojFwdArgs a;
+    a.o = o; a.qn = qn; a.r = r; a.y = y; a.ln_eps = ln_eps;
+    for (int g = 0; g < 2; ++g) { a.w_o[g] = w_o[g]; a.b_o[g] = b_o[g]; a.ln_w[g] = ln_w[g]; a.ln_b[g] = ln_b[g]; }
+    if (int e = make_geom(M, rows_per_tile, &a.tg)) return e;
+    if (D == 128) AMID_LAUNCH_FUSED(sas_oproj_fwd_kernel, a, 128);
+    else if (D == 64) AMID_LAUNCH_FUSED(sas_oproj_fwd_kernel, a, 64);
+    else return AMID_ERR_UNSUPPORTED;
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_sas_ffn_fwd_f32(const float* y, const float* const* w1, const float* const* b1, const float* const* w2,
+                                    const float* const* b2, const unsigned char* tmq, int M, int D, int rows_per_tile, int layer,
+                                    const void* step_state, int train, float p_drop, float* h, float* xo, void* stream) {
+    AMID_CHECK_ARG(y && w1 && b1 && w2 && b2 && h && xo && (!train || step_state));
+    FfnFwdArgs a;
+    a.y = y; a.tmq = tmq; a.h = h; a.xo = xo; a.st = (const StepState*)step_state; a.layer = layer;
+    a.train = (train && p_drop > 0.f) ? 1 : 0;
+    a.thr16 = keep_thr16(p_drop);
+    a.scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+    for (int g = 0; g < 2; ++g) { a.w1[g] = w1[g]; a.b1[g] = b1[g]; a.w2[g] = w2[g]; a.b2[g] = b2[g]; }
+    if (int e = make_geom(M, rows_per_tile, &a.tg)) return e;
+    if (D == 128) AMID_LAUNCH_FUSED(sas_ffn_fwd_kernel, a, 128);
+    else if (D == 64) AMID_LAUNCH_FUSED(sas_ffn_fwd_kernel, a, 64);
+    else return AMID_ERR_UNSUPPORTED;
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}

@@ -1,0 +1,159 @@
+// K3: embedding gradient as a segment reduce over the sorted inverted index (sortuniq.hip):
+//   uniq_grad[u,:] = sum over e in [seg_off[u], seg_off[u+1]) of grad_rows[pos_sorted[e], :]
+// Replaces the reference's four dense EmbeddingBackward index_adds into zero-filled [n_rows, D]
+// gradients (autograd of model_seq.py:418-421; 24 % of the reference step is the zero fill alone,
+// SURVEY.md section 3).  No atomics: a row's addends are summed in sorted (position) order, so the
+// result is bitwise reproducible.
+//
+// HBM-bound: reads N*(D*4 + 4) B, writes U*D*4 B.  Skew (one pad row owns 80-90 % of the
+// positions) is handled by cutting the sorted list into fixed 64-entry chunks, one wave each:
+// a run that lies inside one chunk is finished there; a run that crosses chunk borders leaves one
+// partial per chunk, and the chunk in which the run starts adds the partials up in chunk order.
+#include "common.h"
+
+namespace amid {
+
+constexpr int SEG_CHUNK = 64;
+
+__device__ __forceinline__ int seg_of_entry(const int* __restrict__ seg_off, int U, int e) {
+    // largest u in [0,U) with seg_off[u] <= e
+    int lo = 0, hi = U - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg_off[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <int VEC> struct RowVec { float v[VEC]; };
+
+template <int VEC>
+__device__ __forceinline__ RowVec<VEC> load_row(const float* __restrict__ base, long long row, int D, int lane) {
+    RowVec<VEC> r;
+    const float* p = base + row * D + lane * VEC;
+    if constexpr (VEC == 4) { float4 t = ld4(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+    else if constexpr (VEC == 2) { float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+    else { r.v[0] = *p; }
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void store_row(float* __restrict__ base, long long row, int D, int lane, const RowVec<VEC>& r) {
+    float* p = base + row * D + lane * VEC;
+    if constexpr (VEC == 4) st4(p, make_float4(r.v[0], r.v[1], r.v[2], r.v[3]));
+    else if constexpr (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1]);
+    else *p = r.v[0];
+}
+
+// phase A: one wave per 64-entry chunk of the sorted list
+template <int VEC>
+__global__ __launch_bounds__(256) void segreduce_chunks_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
+                                                               const int* __restrict__ seg_off, const int* __restrict__ n_uniq_p, int n,
+                                                               float* __restrict__ uniq_grad, float* __restrict__ partial) {
+    const int D = VEC * 64;
+    const int lane = lane_id();
+    const int c = blockIdx.x * 4 + wave_id();
+    const int e0 = c * SEG_CHUNK;
+    if (e0 >= n) return;
+    const int U = *n_uniq_p;
+    const int e_end = min(e0 + SEG_CHUNK, n);
+    const int mypos = (e0 + lane < n) ? pos_sorted[e0 + lane] : 0;
+    int u = seg_of_entry(seg_off, U, e0);
+    int e = e0;
+    while (e < e_end) {
+        const int s_beg = seg_off[u], s_end = seg_off[u + 1];
+        const int stop = min(s_end, e_end);
+        RowVec<VEC> acc;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
+        int i = e;
+        for (; i + 8 <= stop; i += 8) {              // 8 independent row loads in flight
+            RowVec<VEC> r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = load_row<VEC>(grad_rows, __shfl(mypos, i + j - e0, 64), D, lane);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc.v[k] += r[j].v[k];
+        }
+        for (; i < stop; ++i) {
+            const RowVec<VEC> r = load_row<VEC>(grad_rows, __shfl(mypos, i - e0, 64), D, lane);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc.v[k] += r.v[k];
+        }
+        if (s_beg >= e0 && s_end <= e_end) store_row<VEC>(uniq_grad, u, D, lane, acc);
+        else store_row<VEC>(partial, (long long)c * 2 + (s_beg < e0 ? 0 : 1), D, lane, acc);
+        e = stop;
+        ++u;
+    }
+}
+
+// phase B: the chunk in which a border-crossing run STARTS owns its final sum
+template <int VEC>
+__global__ __launch_bounds__(1024) void segreduce_spans_kernel(const int* __restrict__ seg_off, const int* __restrict__ n_uniq_p, int n,
+                                                               const float* __restrict__ partial, float* __restrict__ uniq_grad) {
+    const int D = VEC * 64;
+    __shared__ float red[16][VEC * 64];
+    const int c = blockIdx.x;
+    const int e0 = c * SEG_CHUNK;
+    if (e0 >= n) return;
+    const int e_end = min(e0 + SEG_CHUNK, n);
+    const int U = *n_uniq_p;
+    const int u = seg_of_entry(seg_off, U, e_end - 1);
+    const int s_beg = seg_off[u], s_end = seg_off[u + 1];
+    if (!(s_beg >= e0 && s_end > e_end)) return;     // block-uniform
+    const int c_last = (s_end - 1) / SEG_CHUNK;
+    const int lane = lane_id(), w = wave_id();
+    RowVec<VEC> acc;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
+    // wave w sums chunks c + w, c + w + 16, ... (first chunk: tail slot 1, later chunks: head slot 0)
+    int cc = c + w;
+    for (; cc + 48 <= c_last; cc += 64) {
+        RowVec<VEC> r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int ci = cc + 16 * j; r[j] = load_row<VEC>(partial, (long long)ci * 2 + (ci == c ? 1 : 0), D, lane); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc.v[k] += r[j].v[k];
+    }
+    for (; cc <= c_last; cc += 16) {
+        const RowVec<VEC> r = load_row<VEC>(partial, (long long)cc * 2 + (cc == c ? 1 : 0), D, lane);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc.v[k] += r.v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[w][lane * VEC + k] = acc.v[k];
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 1024) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][d];
+        uniq_grad[(long long)u * D + d] = s;
+    }
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+extern "C" long long amid_segreduce_workspace_bytes(int n_idx, int D) {
+    const long long nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK;
+    return nch * 2 * D * 4 + 256;
+}
+
+extern "C" int amid_embgrad_segreduce_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* n_uniq,
+                                          int n_idx, int D, void* workspace, float* uniq_grad, void* stream) {
+    AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && n_uniq && workspace && uniq_grad && n_idx > 0);
+    if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK;
+    float* partial = (float*)workspace;
+#define AMID_SEG_LAUNCH(VEC)                                                                                                  \
+    segreduce_chunks_kernel<VEC><<<(nch + 3) / 4, 256, 0, s>>>(grad_rows, pos_sorted, seg_off, n_uniq, n_idx, uniq_grad, partial); \
+    segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, n_uniq, n_idx, partial, uniq_grad);
+    if (D == 64) { AMID_SEG_LAUNCH(1) } else if (D == 128) { AMID_SEG_LAUNCH(2) } else { AMID_SEG_LAUNCH(4) }
+#undef AMID_SEG_LAUNCH
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}

@@ -1,0 +1,244 @@
+// Index preparation for the sparse side of the step: a stable LSD radix sort of (item id, position)
+// pairs followed by run detection.  Produces, for the N_idx gathered indices of one step,
+//   pos_sorted[N]  positions ordered by (id, position)         -> inverted index for the segment reduce
+//   uniq_ids[U]    distinct ids, ascending                     -> rows the lazy Adam has to touch
+//   seg_off[U+1]   run starts in pos_sorted (seg_off[U] = N)
+//   n_uniq         U (device scalar; everything downstream reads it from memory => graph-replay safe)
+// There is no reference counterpart: the reference lets autograd build four dense 458 MB
+// gradients (nn.Embedding(sparse=False), model_seq.py:25) and runs dense Adam over them
+// (train_sr.py:480).  Sorting fixes the summation order of every row gradient => reproducible.
+//
+// 8-bit digits, ceil(bits(n_rows-1)/8) passes; per pass: per-block digit counts -> one-block scan ->
+// stable scatter.  Ranking inside a wave uses ballot-based match-any, so a wave full of the pad id
+// (83-91 % of all indices) costs one LDS add per wave, not 64 serialized atomics.
+#include "common.h"
+
+namespace amid {
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 8;                       // rounds of 64 keys per wave
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 2048 keys per block
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+
+__device__ __forceinline__ unsigned long long match_digit(unsigned d, bool valid) {
+    // lanes of this wave holding the same 8-bit digit (invalid lanes match nobody)
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const unsigned long long m = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    return peers;
+}
+
+// counts[digit * nblk + blk]
+__global__ __launch_bounds__(SORT_THREADS) void radix_count_kernel(const int* __restrict__ keys, int n, int shift, int nblk,
+                                                                   int* __restrict__ counts) {
+    __shared__ int hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const int base = blockIdx.x * SORT_TILE + w * (64 * SORT_ITEMS);
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int k = base + i * 64 + lane;
+        const bool valid = k < n;
+        const unsigned d = valid ? (((unsigned)keys[k] >> shift) & 0xFFu) : 0u;
+        const unsigned long long peers = match_digit(d, valid);
+        if (valid && (__ffsll((long long)peers) - 1) == lane) atomicAdd(&hist[d], __popcll(peers));
+    }
+    __syncthreads();
+    counts[threadIdx.x * nblk + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan of counts[0 .. 256*nblk) in place (digit-major order = final output order)
+__global__ __launch_bounds__(1024) void radix_scan_kernel(int* __restrict__ counts, int total) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int lane = lane_id(), w = wave_id();
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < total) ? counts[i] : 0;
+        int x = v;                                   // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        const int carry = carry_s;
+        if (i < total) counts[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const int* __restrict__ keys_in, const int* __restrict__ vals_in,
+                                                                     int* __restrict__ keys_out, int* __restrict__ vals_out, int n,
+                                                                     int shift, int nblk, const int* __restrict__ offsets, int first_pass) {
+    __shared__ int whist[SORT_WAVES][256];          // per-wave digit totals, then running output cursors
+    const int w = wave_id(), lane = lane_id();
+    for (int i = threadIdx.x; i < SORT_WAVES * 256; i += SORT_THREADS) (&whist[0][0])[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * SORT_TILE + w * (64 * SORT_ITEMS);
+    int key[SORT_ITEMS];
+    unsigned long long peers[SORT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int k = base + i * 64 + lane;
+        const bool valid = k < n;
+        key[i] = valid ? keys_in[k] : 0;
+        const unsigned d = ((unsigned)key[i] >> shift) & 0xFFu;
+        peers[i] = match_digit(d, valid);
+        if (valid && (__ffsll((long long)peers[i]) - 1) == lane) atomicAdd(&whist[w][d], __popcll(peers[i]));
+    }
+    __syncthreads();
+    {   // cursor[w][d] = global offset of (d, this block) + totals of earlier waves
+        const int d = threadIdx.x;
+        int run = offsets[d * nblk + blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < SORT_WAVES; ++k) {
+            const int c = whist[k][d];
+            whist[k][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int k = base + i * 64 + lane;
+        const bool valid = k < n;
+        const unsigned d = ((unsigned)key[i] >> shift) & 0xFFu;
+        int dst = 0;
+        if (valid) dst = whist[w][d] + __popcll(peers[i] & lt);
+        __builtin_amdgcn_wave_barrier();            // every lane has read the cursor before the leader bumps it
+        if (valid && (__ffsll((long long)peers[i]) - 1) == lane) whist[w][d] += __popcll(peers[i]);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            keys_out[dst] = key[i];
+            vals_out[dst] = first_pass ? k : vals_in[k];
+        }
+    }
+}
+
+// run heads of the sorted keys: per-block head counts
+__global__ __launch_bounds__(256) void heads_count_kernel(const int* __restrict__ keys, int n, int* __restrict__ blk_heads) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool head = (i < n) && (i == 0 || keys[i] != keys[i - 1]);
+    const unsigned long long m = __ballot(head);
+    if (lane_id() == 0 && m) atomicAdd(&cnt, __popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) blk_heads[blockIdx.x] = cnt;
+}
+
+// one block: exclusive scan of blk_heads (in place), total -> n_uniq, seg_off[total] = n
+__global__ __launch_bounds__(1024) void heads_scan_kernel(int* __restrict__ blk_heads, int nblk, int* __restrict__ n_uniq,
+                                                          int* __restrict__ seg_off, int n) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int lane = lane_id(), w = wave_id();
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < nblk) ? blk_heads[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        const int carry = carry_s;
+        if (i < nblk) blk_heads[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *n_uniq = carry_s;
+        seg_off[carry_s] = n;
+    }
+}
+
+__global__ __launch_bounds__(256) void heads_write_kernel(const int* __restrict__ keys, int n, const int* __restrict__ blk_base,
+                                                          int* __restrict__ uniq_ids, int* __restrict__ seg_off) {
+    __shared__ int wcnt[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = lane_id(), w = wave_id();
+    const bool head = (i < n) && (i == 0 || keys[i] != keys[i - 1]);
+    const unsigned long long m = __ballot(head);
+    if (lane == 0) wcnt[w] = __popcll(m);
+    __syncthreads();
+    int off = blk_base[blockIdx.x];
+    for (int k = 0; k < w; ++k) off += wcnt[k];
+    if (head) {
+        const int u = off + __popcll(m & ((1ull << lane) - 1ull));
+        uniq_ids[u] = keys[i];
+        seg_off[u] = i;
+    }
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+static inline int sort_nblk(int n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" long long amid_sort_unique_workspace_bytes(int n_idx) {
+    if (n_idx <= 0) return 256;
+    const size_t nblk = sort_nblk(n_idx);
+    size_t b = 0;
+    b += 4 * align256((size_t)n_idx * 4);            // keys a/b, vals a/b
+    b += align256(256 * nblk * 4);                   // digit counts / offsets
+    b += align256(((size_t)n_idx + 255) / 256 * 4);  // per-block head counts
+    return (long long)b;
+}
+
+extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
+                                    int* seg_off, int* n_uniq, void* stream) {
+    AMID_CHECK_ARG(idx && workspace && pos_sorted && uniq_ids && seg_off && n_uniq && n_idx > 0 && n_rows > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = sort_nblk(n_idx);
+    char* ws = (char*)workspace;
+    const size_t kb = align256((size_t)n_idx * 4);
+    int* keys[2] = {(int*)ws, (int*)(ws + kb)};
+    int* vals[2] = {(int*)(ws + 2 * kb), (int*)(ws + 3 * kb)};
+    int* counts = (int*)(ws + 4 * kb);
+    int* blk_heads = (int*)(ws + 4 * kb + align256((size_t)256 * nblk * 4));
+    int bits = 1;
+    while (bits < 31 && (1LL << bits) < n_rows) ++bits;
+    const int passes = (bits + 7) / 8;
+    const int* kin = idx;
+    const int* vin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        int* kout = keys[p & 1];
+        int* vout = (p == passes - 1) ? pos_sorted : vals[p & 1];
+        radix_count_kernel<<<nblk, SORT_THREADS, 0, s>>>(kin, n_idx, shift, nblk, counts);
+        radix_scan_kernel<<<1, 1024, 0, s>>>(counts, 256 * nblk);
+        radix_scatter_kernel<<<nblk, SORT_THREADS, 0, s>>>(kin, vin, kout, vout, n_idx, shift, nblk, counts, p == 0);
+        kin = kout;
+        vin = vout;
+    }
+    const int hblk = (n_idx + 255) / 256;
+    heads_count_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads);
+    heads_scan_kernel<<<1, 1024, 0, s>>>(blk_heads, hblk, n_uniq, seg_off, n_idx);
+    heads_write_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads, uniq_ids, seg_off);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}

@@ -1,0 +1,511 @@
+"""Host-side driver of the SASRec training hot path on one MI355X.
+
+Mirrors the loop body of the reference's ``train()`` (train_sr.py:190-217) for
+``SASRec`` (model_seq.py:390-443): forward, masked BCE, backward, optimizer --
+as one sequence of launches of the hand-written HIP kernels in
+``libamid_hip.so`` on a single HIP stream, capturable into a hipGraph.
+PyTorch only provides device memory and the stream.
+
+Memory layout (all fp32, resident in HBM for the life of the engine):
+  table / m / v      [n_rows, D]   item embedding + lazy-Adam moments; ``last`` [n_rows] int32
+  dense              flat buffer holding every other parameter in state_dict order (16-B aligned
+                     slots); grad / Adam m / Adam v mirror it, so dense Adam and the data-parallel
+                     all-reduce are one call each
+  plan workspace     activations saved for backward, gradient scratch, sort / segment-reduce
+                     workspaces -- allocated once per (B, T, n_items) shape
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from ._lib import lib, ptr_array
+
+SASREC_HEADS = 8          # model_seq.py:348-350
+SASREC_P_DROP = 0.5       # model_seq.py:335,350,356
+SASREC_LN_EPS = 1e-8      # model_seq.py:342-353
+
+
+def sasrec_dense_names(T: int, D: int, hid: int) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Non-table parameters in the reference's state_dict order."""
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    for d in (1, 2):
+        pre = f"sac{d}"
+        out.append((f"{pre}.pos_emb.weight", (T, D)))
+        out.append((f"{pre}.attention_layernorms.0.weight", (D,)))
+        out.append((f"{pre}.attention_layernorms.0.bias", (D,)))
+        out.append((f"{pre}.attention_layernorms.1.weight", (D,)))
+        out.append((f"{pre}.attention_layernorms.1.bias", (D,)))
+        for l in (0, 1):
+            out.append((f"{pre}.attention_layers.{l}.in_proj_weight", (3 * D, D)))
+            out.append((f"{pre}.attention_layers.{l}.in_proj_bias", (3 * D,)))
+            out.append((f"{pre}.attention_layers.{l}.out_proj.weight", (D, D)))
+            out.append((f"{pre}.attention_layers.{l}.out_proj.bias", (D,)))
+        out.append((f"{pre}.forward_layernorms.0.weight", (D,)))
+        out.append((f"{pre}.forward_layernorms.0.bias", (D,)))
+        out.append((f"{pre}.forward_layernorms.1.weight", (D,)))
+        out.append((f"{pre}.forward_layernorms.1.bias", (D,)))
+        for l in (0, 1):
+            out.append((f"{pre}.forward_layers.{l}.conv1.weight", (D, D, 1)))
+            out.append((f"{pre}.forward_layers.{l}.conv1.bias", (D,)))
+            out.append((f"{pre}.forward_layers.{l}.conv2.weight", (D, D, 1)))
+            out.append((f"{pre}.forward_layers.{l}.conv2.bias", (D,)))
+        out.append((f"{pre}.last_layernorm.weight", (D,)))
+        out.append((f"{pre}.last_layernorm.bias", (D,)))
+    out.append(("predictModule.fc.0.weight", (hid, 2 * D)))
+    out.append(("predictModule.fc.0.bias", (hid,)))
+    out.append(("predictModule.fc.2.weight", (1, hid)))
+    out.append(("predictModule.fc.2.bias", (1,)))
+    return out
+
+
+class FlatParams:
+    """One flat fp32 buffer with named views (each slot padded to 4 floats = 16 B)."""
+
+    def __init__(self, names: List[Tuple[str, Tuple[int, ...]]], device):
+        self.slots: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for n, shp in names:
+            numel = 1
+            for s in shp:
+                numel *= s
+            self.slots[n] = (off, shp)
+            off += (numel + 3) & ~3
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.data)
+        self.m = torch.zeros_like(self.data)
+        self.v = torch.zeros_like(self.data)
+
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        off, shp = self.slots[name]
+        numel = 1
+        for s in shp:
+            numel *= s
+        return (self.data if buf is None else buf)[off: off + numel].view(*shp)
+
+    def ptr(self, name: str, buf: Optional[torch.Tensor] = None, extra: int = 0) -> int:
+        off, _ = self.slots[name]
+        return (self.data if buf is None else buf).data_ptr() + 4 * (off + extra)
+
+
+@dataclass
+class Shape:
+    B: int
+    T: int
+    NI: int          # items scored per row: 1 positive + negatives
+
+    @property
+    def M(self) -> int:
+        return self.B * self.T
+
+    @property
+    def n_idx(self) -> int:
+        return 2 * self.B * self.T + self.B * self.NI
+
+
+class SasrecPlan:
+    """Workspace for one batch shape: saved activations, gradient scratch, index workspaces."""
+
+    def __init__(self, eng: "SasrecEngine", shp: Shape, need_grad: bool):
+        L = lib()
+        self.shape = shp
+        self.need_grad = need_grad
+        dev, D, H, hid = eng.device, eng.D, eng.H, eng.hid
+        B, T, NI, M, N = shp.B, shp.T, shp.NI, shp.M, shp.n_idx
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
+        self.rpt = L.value("amid_rows_per_tile", M)
+        self.tpg = (M + self.rpt - 1) // self.rpt
+        # static inputs (graph-replay safe)
+        self.idx_all = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.in_i_node = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.in_neg = torch.zeros(B, NI - 1, dtype=torch.int64, device=dev)
+        self.in_seq_d1 = torch.zeros(B, T, dtype=torch.int64, device=dev)
+        self.in_seq_d2 = torch.zeros(B, T, dtype=torch.int64, device=dev)
+        self.labels = torch.zeros(B, NI, dtype=torch.float32, device=dev)
+        self.domain = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        # forward
+        self.xg = f(N, D)
+        self.tmq = torch.zeros(2 * M, D // 4, dtype=torch.uint8, device=dev)
+        self.x = [self.xg[: 2 * M], f(2 * M, D), f(2 * M, D)]
+        self.qn = [f(2 * M, D) for _ in range(2)]
+        self.q = [f(2 * M, D) for _ in range(2)]
+        self.k = [f(2 * M, D) for _ in range(2)]
+        self.v = [f(2 * M, D) for _ in range(2)]
+        self.o = [f(2 * M, D) for _ in range(2)]
+        self.stats = [f(2 * M, H, 2) for _ in range(2)]
+        self.r = [f(2 * M, D) for _ in range(2)]
+        self.y = [f(2 * M, D) for _ in range(2)]
+        self.h = [f(2 * M, D) for _ in range(2)]
+        self.u = f(2, B, D)
+        self.p1 = f(B, NI)
+        self.p2 = f(B, NI)
+        self.dp1 = torch.zeros(B, NI, dtype=torch.float32, device=dev)
+        self.dp2 = torch.zeros(B, NI, dtype=torch.float32, device=dev)
+        self.loss_part = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        if not need_grad:
+            return
+        # backward
+        self.dxg = f(N, D)
+        self.dxbuf = f(2 * M, D)
+        self.du = f(2, B, D)
+        self.dpre1, self.dpre2, self.dr, self.d_o = f(2 * M, D), f(2 * M, D), f(2 * M, D), f(2 * M, D)
+        self.dq, self.dk, self.dv = f(2 * M, D), f(2 * M, D), f(2 * M, D)
+        self.splits = max(1, min(32, (M + 511) // 512))
+        self.w_part = [f(2, 6, self.splits, D * D) for _ in range(2)]
+        self.b_part = [f(2, 6, self.splits, D) for _ in range(2)]
+        self.ln1_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
+        self.ln2_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
+        self.last_part = f(2 * B, 2, D)
+        self.sc_P = L.value("amid_scorer_part_floats", D, hid)
+        self.sc_part = f(B, self.sc_P)
+        # sparse side
+        self.sort_ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", N), dtype=torch.uint8, device=dev)
+        self.pos_sorted = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.uniq_ids = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.seg_off = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+        self.n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", N, D), dtype=torch.uint8, device=dev)
+        self.uniq_grad = f(N, D)
+        self._build_reduce_table(eng)
+        self.graph = None
+
+    def _build_reduce_table(self, eng: "SasrecEngine") -> None:
+        L = lib()
+        D, hid, B = eng.D, eng.hid, self.shape.B
+        fp, G = eng.dense, eng.dense.grad
+        ent: List[Tuple[int, int, int, int, int]] = []      # src_ptr, dst_ptr, stride, n_part, count
+
+        def add(src_t: torch.Tensor, src_off: int, dst_ptr: int, stride: int, n_part: int, count: int):
+            ent.append((src_t.data_ptr() + 4 * src_off, dst_ptr, stride, n_part, count))
+
+        S = self.splits
+        for l in (0, 1):
+            for g in (0, 1):
+                pre = f"sac{g + 1}"
+                wbase = lambda w: ((g * 6 + w) * S) * D * D      # noqa: E731
+                bbase = lambda w: ((g * 6 + w) * S) * D          # noqa: E731
+                for j in range(3):
+                    add(self.w_part[l], wbase(j), fp.ptr(f"{pre}.attention_layers.{l}.in_proj_weight", G, j * D * D), D * D, S, D * D)
+                    add(self.b_part[l], bbase(j), fp.ptr(f"{pre}.attention_layers.{l}.in_proj_bias", G, j * D), D, S, D)
+                add(self.w_part[l], wbase(3), fp.ptr(f"{pre}.attention_layers.{l}.out_proj.weight", G), D * D, S, D * D)
+                add(self.b_part[l], bbase(3), fp.ptr(f"{pre}.attention_layers.{l}.out_proj.bias", G), D, S, D)
+                add(self.w_part[l], wbase(4), fp.ptr(f"{pre}.forward_layers.{l}.conv1.weight", G), D * D, S, D * D)
+                add(self.b_part[l], bbase(4), fp.ptr(f"{pre}.forward_layers.{l}.conv1.bias", G), D, S, D)
+                add(self.w_part[l], wbase(5), fp.ptr(f"{pre}.forward_layers.{l}.conv2.weight", G), D * D, S, D * D)
+                add(self.b_part[l], bbase(5), fp.ptr(f"{pre}.forward_layers.{l}.conv2.bias", G), D, S, D)
+                tb = g * self.tpg * 2 * D
+                add(self.ln1_part[l], tb, fp.ptr(f"{pre}.attention_layernorms.{l}.weight", G), 2 * D, self.tpg, D)
+                add(self.ln1_part[l], tb + D, fp.ptr(f"{pre}.attention_layernorms.{l}.bias", G), 2 * D, self.tpg, D)
+                add(self.ln2_part[l], tb, fp.ptr(f"{pre}.forward_layernorms.{l}.weight", G), 2 * D, self.tpg, D)
+                add(self.ln2_part[l], tb + D, fp.ptr(f"{pre}.forward_layernorms.{l}.bias", G), 2 * D, self.tpg, D)
+        for g in (0, 1):
+            pre = f"sac{g + 1}"
+            add(self.last_part, g * B * 2 * D, fp.ptr(f"{pre}.last_layernorm.weight", G), 2 * D, B, D)
+            add(self.last_part, g * B * 2 * D + D, fp.ptr(f"{pre}.last_layernorm.bias", G), 2 * D, B, D)
+        P = self.sc_P
+        add(self.sc_part, 0, fp.ptr("predictModule.fc.0.weight", G), P, B, hid * 2 * D)
+        add(self.sc_part, hid * 2 * D, fp.ptr("predictModule.fc.0.bias", G), P, B, hid)
+        add(self.sc_part, hid * 2 * D + hid, fp.ptr("predictModule.fc.2.weight", G), P, B, hid)
+        add(self.sc_part, hid * 2 * D + 2 * hid, fp.ptr("predictModule.fc.2.bias", G), P, B, 1)
+        esz = L.value("amid_reduce_entry_bytes")
+        host = (ctypes.c_ubyte * (esz * len(ent)))()
+        for i, (s, d, st, n, c) in enumerate(ent):
+            L.call("amid_reduce_entry_pack", ctypes.addressof(host), i, s, d, st, n, c)
+        self.red_entries = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(eng.device)
+        self.red_n = len(ent)
+        self.red_max = max(c for *_, c in ent)
+
+
+class SasrecEngine:
+    """Parameters, optimizer state and launch sequences for SASRec (isInC = isItC = isDR = False)."""
+
+    def __init__(self, item_length: int, emb_dim: int, seq_len: int, hid_dim: int, device="cuda:0", lr: float = 5e-4,
+                 betas=(0.9, 0.999), eps: float = 1e-8, seed: int = 0):
+        L = lib()        # raises AmidLibraryError when the HIP library is missing: no fallback
+        if emb_dim not in (64, 128):
+            raise ValueError(f"amid_amd SASRec kernels are built for emb_dim in (64, 128), got {emb_dim}")
+        self.device = torch.device(device)
+        self.n_rows, self.D, self.T, self.hid, self.H = int(item_length), int(emb_dim), int(seq_len), int(hid_dim), SASREC_HEADS
+        D = self.D
+        self.dense = FlatParams(sasrec_dense_names(self.T, D, self.hid), self.device)
+        self.table = torch.zeros(self.n_rows, D, dtype=torch.float32, device=self.device)
+        self.table_m: Optional[torch.Tensor] = None        # allocated on the first optimizer use
+        self.table_v: Optional[torch.Tensor] = None
+        self.table_last: Optional[torch.Tensor] = None
+        # transposed copies of the 24 square projection weights
+        self.wT = torch.zeros(2, 2, 6, D * D, dtype=torch.float32, device=self.device)     # [layer][domain][q,k,v,o,c1,c2]
+        self.hyper = dict(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps)
+        self.seed = int(seed)
+        self.step = 0
+        self._st_bytes = L.value("amid_step_state_bytes")
+        self.step_state = torch.zeros(self._st_bytes, dtype=torch.uint8, device=self.device)
+        self._push_step_state()
+        self.plans: Dict[Tuple[int, int, int, bool], SasrecPlan] = {}
+        self.grad_scale = 1.0
+        # every kernel of the engine runs on this (non-default, hence capturable) HIP stream
+        self.stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.synchronize(self.device)
+        self._ptr_cache: Dict[str, object] = {}
+
+    @property
+    def s(self) -> int:
+        return self.stream.cuda_stream
+
+    def sync(self) -> None:
+        self.stream.synchronize()
+
+    # ------------------------------------------------------------------ state
+    def _push_step_state(self) -> None:
+        L = lib()
+        host = (ctypes.c_ubyte * self._st_bytes)()
+        L.call("amid_step_state_pack", ctypes.addressof(host), self.seed, self.step, self.hyper["lr"], self.hyper["beta1"],
+               self.hyper["beta2"], self.hyper["eps"])
+        with torch.cuda.stream(self.stream):
+            self.step_state.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8), non_blocking=False)
+
+    def set_step(self, step: int, seed: Optional[int] = None) -> None:
+        self.step = int(step)
+        if seed is not None:
+            self.seed = int(seed)
+        self._push_step_state()
+
+    def set_lr(self, lr: float) -> None:
+        self.hyper["lr"] = float(lr)
+        self._push_step_state()
+
+    def _ensure_opt_state(self) -> None:
+        if self.table_m is None:
+            self.table_m = torch.zeros_like(self.table)
+            self.table_v = torch.zeros_like(self.table)
+            self.table_last = torch.zeros(self.n_rows, dtype=torch.int32, device=self.device)
+
+    def plan(self, B: int, T: int, NI: int, need_grad: bool) -> SasrecPlan:
+        key = (B, T, NI, need_grad)
+        if key not in self.plans:
+            if T > self.T:
+                raise ValueError(f"sequence length {T} exceeds pos_emb size {self.T}")
+            self.plans[key] = SasrecPlan(self, Shape(B, T, NI), need_grad)
+            torch.cuda.synchronize(self.device)      # buffers were zero-filled on torch's stream
+        return self.plans[key]
+
+    # ------------------------------------------------------------------ pointer helpers
+    def _pp(self, fmt: str, buf: Optional[torch.Tensor] = None, extra: int = 0):
+        """Host array (domain 0, domain 1) of device pointers of a per-domain parameter."""
+        key = (fmt, 0 if buf is None else buf.data_ptr(), extra)
+        c = self._ptr_cache.get(key)
+        if c is None:
+            c = ptr_array([self.dense.ptr(fmt.format(d=d), buf, extra) for d in (1, 2)])
+            self._ptr_cache[key] = c
+        return c
+
+    def _wT(self, layer: int, which: int):
+        key = ("wT", layer, which)
+        c = self._ptr_cache.get(key)
+        if c is None:
+            c = ptr_array([self.wT[layer, g, which].data_ptr() for g in (0, 1)])
+            self._ptr_cache[key] = c
+        return c
+
+    # ------------------------------------------------------------------ launch sequences
+    def load_batch(self, pl: SasrecPlan, i_node, neg_samples, seq_d1, seq_d2, labels=None, domain_id=None) -> None:
+        """Copy a batch into the plan's static input buffers (async on the engine stream)."""
+        with torch.cuda.stream(self.stream):
+            pl.in_i_node.copy_(i_node.reshape(-1), non_blocking=True)
+            pl.in_neg.copy_(neg_samples.reshape(pl.shape.B, -1), non_blocking=True)
+            pl.in_seq_d1.copy_(seq_d1, non_blocking=True)
+            pl.in_seq_d2.copy_(seq_d2, non_blocking=True)
+            if labels is not None:
+                pl.labels.copy_(labels.reshape(pl.shape.B, -1), non_blocking=True)
+                pl.domain.copy_(domain_id.reshape(-1), non_blocking=True)
+
+    def enqueue_prepare(self, pl: SasrecPlan, sparse: bool) -> None:
+        L, s, shp = lib(), self.s, pl.shape
+        L.call("amid_pack_indices", pl.in_i_node.data_ptr(), pl.in_neg.data_ptr(), pl.in_seq_d1.data_ptr(), pl.in_seq_d2.data_ptr(),
+               shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(), s)
+        if sparse:
+            L.call("amid_sort_unique_i32", pl.idx_all.data_ptr(), shp.n_idx, self.n_rows, pl.sort_ws.data_ptr(), pl.pos_sorted.data_ptr(),
+                   pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.n_uniq.data_ptr(), s)
+
+    def enqueue_catchup(self, pl: SasrecPlan) -> None:
+        self._ensure_opt_state()
+        lib().call("amid_lazy_adam_catchup_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
+                   self.table_last.data_ptr(), pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), pl.shape.n_idx, self.D,
+                   self.step_state.data_ptr(), self.s)
+
+    def enqueue_forward(self, pl: SasrecPlan, train: bool, with_loss: bool) -> None:
+        L, s, shp, D = lib(), self.s, pl.shape, self.D
+        B, T, NI, M = shp.B, shp.T, shp.NI, shp.M
+        st = self.step_state.data_ptr()
+        tr = 1 if train else 0
+        fp = self.dense
+        L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"),
+               B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, s)
+        for l in (0, 1):
+            L.call("amid_sas_qkv_fwd_f32", pl.x[l].data_ptr(), self._pp(f"sac{{d}}.attention_layernorms.{l}.weight"),
+                   self._pp(f"sac{{d}}.attention_layernorms.{l}.bias"), self._pp(f"sac{{d}}.attention_layers.{l}.in_proj_weight"),
+                   self._pp(f"sac{{d}}.attention_layers.{l}.in_proj_bias"), SASREC_LN_EPS, M, D, pl.rpt, pl.qn[l].data_ptr(),
+                   pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), s)
+            L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), None, B, T, D, self.H, 1, l, st, tr,
+                   SASREC_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
+            L.call("amid_sas_oproj_fwd_f32", pl.o[l].data_ptr(), self._pp(f"sac{{d}}.attention_layers.{l}.out_proj.weight"),
+                   self._pp(f"sac{{d}}.attention_layers.{l}.out_proj.bias"), pl.qn[l].data_ptr(),
+                   self._pp(f"sac{{d}}.forward_layernorms.{l}.weight"), self._pp(f"sac{{d}}.forward_layernorms.{l}.bias"), SASREC_LN_EPS,
+                   M, D, pl.rpt, pl.r[l].data_ptr(), pl.y[l].data_ptr(), s)
+            L.call("amid_sas_ffn_fwd_f32", pl.y[l].data_ptr(), self._pp(f"sac{{d}}.forward_layers.{l}.conv1.weight"),
+                   self._pp(f"sac{{d}}.forward_layers.{l}.conv1.bias"), self._pp(f"sac{{d}}.forward_layers.{l}.conv2.weight"),
+                   self._pp(f"sac{{d}}.forward_layers.{l}.conv2.bias"), pl.tmq.data_ptr(), M, D, pl.rpt, l, st, tr, SASREC_P_DROP,
+                   pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(), s)
+        L.call("amid_lnmean_fwd_f32", pl.x[2].data_ptr(), fp.ptr("sac1.last_layernorm.weight"), fp.ptr("sac1.last_layernorm.bias"),
+               fp.ptr("sac2.last_layernorm.weight"), fp.ptr("sac2.last_layernorm.bias"), B, T, D, SASREC_LN_EPS, pl.u.data_ptr(), s)
+        items = pl.xg.data_ptr() + 4 * 2 * M * D
+        L.call("amid_scorer_fwd_f32", pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
+               fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"),
+               pl.labels.data_ptr() if with_loss else None, pl.domain.data_ptr() if with_loss else None, B, NI, D, self.hid,
+               pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr() if with_loss else None, pl.dp2.data_ptr() if with_loss else None,
+               pl.loss_part.data_ptr() if with_loss else None, s)
+        if with_loss:
+            L.call("amid_sum_vector_f32", pl.loss_part.data_ptr(), B, pl.loss.data_ptr(), s)
+
+    def enqueue_backward(self, pl: SasrecPlan, train: bool) -> None:
+        """Backward from pl.dp1 / pl.dp2 (dLoss/dp) to pl.uniq_grad (table rows) and dense.grad."""
+        L, s, shp, D = lib(), self.s, pl.shape, self.D
+        B, T, NI, M = shp.B, shp.T, shp.NI, shp.M
+        st = self.step_state.data_ptr()
+        tr = 1 if train else 0
+        fp = self.dense
+        # transposed weights: in_proj q/k/v blocks, out_proj, conv1, conv2 for both layers and domains
+        src, dst = [], []
+        for l in (0, 1):
+            for g in (0, 1):
+                pre = f"sac{g + 1}"
+                for j in range(3):
+                    src.append(fp.ptr(f"{pre}.attention_layers.{l}.in_proj_weight", None, j * D * D))
+                src.append(fp.ptr(f"{pre}.attention_layers.{l}.out_proj.weight"))
+                src.append(fp.ptr(f"{pre}.forward_layers.{l}.conv1.weight"))
+                src.append(fp.ptr(f"{pre}.forward_layers.{l}.conv2.weight"))
+                dst += [self.wT[l, g, w].data_ptr() for w in range(6)]
+        L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
+        items = pl.xg.data_ptr() + 4 * 2 * M * D
+        ditems = pl.dxg.data_ptr() + 4 * 2 * M * D
+        L.call("amid_scorer_bwd_f32", pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
+               fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(), pl.p2.data_ptr(),
+               pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, NI, D, self.hid, pl.du.data_ptr(), ditems, pl.sc_part.data_ptr(), s)
+        L.call("amid_lnmean_bwd_f32", pl.x[2].data_ptr(), pl.du.data_ptr(), fp.ptr("sac1.last_layernorm.weight"),
+               fp.ptr("sac2.last_layernorm.weight"), B, T, D, SASREC_LN_EPS, pl.dxbuf.data_ptr(), pl.last_part.data_ptr(), s)
+        for l in (1, 0):
+            L.call("amid_sas_ffn_bwd_f32", pl.dxbuf.data_ptr(), pl.tmq.data_ptr(), pl.h[l].data_ptr(), pl.r[l].data_ptr(),
+                   self._pp(f"sac{{d}}.forward_layernorms.{l}.weight"), self._wT(l, 4), self._wT(l, 5), self._wT(l, 3), SASREC_LN_EPS,
+                   M, D, pl.rpt, l, st, tr, SASREC_P_DROP, pl.dpre2.data_ptr(), pl.dpre1.data_ptr(), pl.dr.data_ptr(), pl.d_o.data_ptr(),
+                   pl.ln2_part[l].data_ptr(), s)
+            L.call("amid_attn_bwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(),
+                   pl.stats[l].data_ptr(), pl.d_o.data_ptr(), None, B, T, D, self.H, 1, l, st, tr, SASREC_P_DROP, pl.dq.data_ptr(),
+                   pl.dk.data_ptr(), pl.dv.data_ptr(), s)
+            dx_out = pl.dxg if l == 0 else pl.dxbuf
+            L.call("amid_sas_qkv_bwd_f32", pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dr.data_ptr(), pl.x[l].data_ptr(),
+                   self._pp(f"sac{{d}}.attention_layernorms.{l}.weight"), self._wT(l, 0), self._wT(l, 1), self._wT(l, 2), SASREC_LN_EPS,
+                   M, D, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), s)
+            dy6 = ptr_array([pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dr.data_ptr(), pl.dpre1.data_ptr(), pl.dpre2.data_ptr()])
+            x6 = ptr_array([pl.qn[l].data_ptr(), pl.x[l].data_ptr(), pl.x[l].data_ptr(), pl.o[l].data_ptr(), pl.y[l].data_ptr(),
+                            pl.h[l].data_ptr()])
+            L.call("amid_sas_wgrad_f32", dy6, x6, M, D, pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), s)
+        L.call("amid_embed_bwd_f32", pl.dxg.data_ptr(), pl.tmq.data_ptr(), B, T, D, fp.ptr("sac1.pos_emb.weight", fp.grad),
+               fp.ptr("sac2.pos_emb.weight", fp.grad), st, tr, SASREC_P_DROP, s)
+        L.call("amid_reduce_partials_f32", pl.red_entries.data_ptr(), pl.red_n, pl.red_max, s)
+        L.call("amid_embgrad_segreduce_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.n_uniq.data_ptr(),
+               shp.n_idx, D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), s)
+
+    def enqueue_optimizer(self, pl: SasrecPlan) -> None:
+        L, s = lib(), self.s
+        self._ensure_opt_state()
+        fp = self.dense
+        L.call("amid_adam_dense_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel, self.grad_scale,
+               self.step_state.data_ptr(), s)
+        L.call("amid_lazy_adam_apply_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
+               pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), pl.shape.n_idx, pl.uniq_grad.data_ptr(), self.grad_scale, self.D,
+               self.step_state.data_ptr(), s)
+
+    def enqueue_step_begin(self) -> None:
+        lib().call("amid_step_begin", self.step_state.data_ptr(), self.s)
+        self.step += 1
+
+    def enqueue_train_step(self, pl: SasrecPlan) -> None:
+        """Whole step t on the current stream: t += 1; unique; catch-up; forward; loss; backward; Adam."""
+        self.enqueue_step_begin()
+        self.enqueue_prepare(pl, sparse=True)
+        self.enqueue_catchup(pl)
+        self.enqueue_forward(pl, train=True, with_loss=True)
+        self.enqueue_backward(pl, train=True)
+        self.enqueue_optimizer(pl)
+
+    # ------------------------------------------------------------------ graph replay
+    def capture_train_step(self, pl: SasrecPlan) -> None:
+        """Capture one train step into a hipGraph (inputs = the plan's static buffers)."""
+        L = lib()
+        self._ensure_opt_state()
+        # warm-up outside capture: sets the dynamic-LDS attributes, pages code objects in
+        saved = self.snapshot()
+        self.enqueue_train_step(pl)
+        self.sync()
+        self.restore(saved)
+        self.sync()
+        s = self.s
+        step0 = self.step
+        L.call("amid_graph_capture_begin", s)
+        try:
+            self.enqueue_train_step(pl)
+        finally:
+            out = ctypes.c_void_p()
+            L.call("amid_graph_capture_end", s, ctypes.byref(out))
+        self.step = step0          # capture does not execute; the device counter did not move
+        pl.graph = out.value
+
+    def replay_train_step(self, pl: SasrecPlan) -> None:
+        lib().call("amid_graph_launch", pl.graph, self.s)
+        self.step += 1
+
+    def flush_table(self) -> None:
+        """Apply every pending zero-gradient Adam step (before eval / checkpoint / parity dumps)."""
+        if self.table_m is None:
+            return
+        lib().call("amid_lazy_adam_flush_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
+                   self.table_last.data_ptr(), self.n_rows, self.D, self.step_state.data_ptr(), self.s)
+
+    # ------------------------------------------------------------------ snapshots (tests / warm-up)
+    def snapshot(self):
+        self._ensure_opt_state()
+        self.sync()
+        fp = self.dense
+        return dict(step=self.step, seed=self.seed, data=fp.data.clone(), m=fp.m.clone(), v=fp.v.clone(), table=self.table.clone(),
+                    tm=self.table_m.clone(), tv=self.table_v.clone(), tl=self.table_last.clone())
+
+    def restore(self, snap) -> None:
+        fp = self.dense
+        with torch.cuda.stream(self.stream):
+            fp.data.copy_(snap["data"]); fp.m.copy_(snap["m"]); fp.v.copy_(snap["v"])
+            self.table.copy_(snap["table"]); self.table_m.copy_(snap["tm"]); self.table_v.copy_(snap["tv"]); self.table_last.copy_(snap["tl"])
+        self.set_step(snap["step"], snap["seed"])
+
+    # ------------------------------------------------------------------ parameter interchange
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        with torch.no_grad(), torch.cuda.stream(self.stream):
+            self.table.copy_(sd["item_emb_layer.emb_item.weight"].to(self.device, torch.float32))
+            for name in self.dense.slots:
+                self.dense.view(name).copy_(sd[name].to(self.device, torch.float32))
+        self.sync()
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = {"item_emb_layer.emb_item.weight": self.table}
+        for name in self.dense.slots:
+            out[name] = self.dense.view(name)
+        return out
+
+    def check_index_error(self, pl: SasrecPlan) -> None:
+        if int(pl.err.item()) != 0:
+            pl.err.zero_()
+            raise IndexError("amid_amd: item index out of range in the batch (nn.Embedding would raise here, model_seq.py:27-29)")

@@ -1,0 +1,159 @@
+/* libamid_hip.so -- C ABI of the MI355X (gfx950) kernels behind the AMID training hot path.
+ *
+ * The reference (WujiangXu/AMID) has no native layer: its "FFI" for this path is PyTorch's
+ * ATen operators called from model_seq.py / train_sr.py.  Each entry point below names the
+ * reference call site (file:line into the reference checkout) whose arithmetic it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; every pointer is DEVICE memory unless named host_*;
+ *  - the caller owns every buffer including workspaces; the library keeps no state (the only
+ *    handles it hands out are hipGraphExec / hipEvent wrappers the caller destroys);
+ *  - all work is enqueued on the caller's hipStream_t (passed as void*), no internal sync, safe
+ *    to capture into a hipGraph; scalars that change per step (step counter, lr, dropout seed,
+ *    number of unique rows) live in device memory for that reason;
+ *  - return 0 on success, AMID_ERR_* (< 0) for argument errors, a hipError_t (> 0) otherwise;
+ *    nothing throws or aborts across the ABI;
+ *  - fp32 everywhere; activations are row-major [rows, D]; "2M rows" = domain 0 rows [0, M)
+ *    followed by domain 1 rows [M, 2M), M = B*T;
+ *  - D in {64, 128} for the fused encoder kernels, D in {64, 128, 256} for the segment reduce,
+ *    D % 4 == 0 elsewhere.
+ */
+#ifndef AMID_HIP_H
+#define AMID_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMID_OK 0
+#define AMID_ERR_ARG (-1)
+#define AMID_ERR_UNSUPPORTED (-2)
+
+int amid_version(void);
+const char* amid_error_string(int code);
+int amid_device_sync(void);
+
+/* ---- per-step device state: dropout seed, global step t, Adam hyper-parameters -------------
+ * replaces: python-side step counters of torch.optim.Adam (train_sr.py:480) and torch's global
+ * RNG feeding nn.Dropout (model_seq.py:335,350,356). */
+int amid_step_state_bytes(void);
+int amid_step_state_pack(void* host_buf, unsigned long long seed, long long step, double lr, double beta1, double beta2, double eps);
+int amid_step_begin(void* step_state, void* stream);                       /* step += 1 */
+
+/* ---- K1 embedding gather ---------------------------------------------------------------------
+ * replaces: embItemLayerEnhance.forward = nn.Embedding lookup, model_seq.py:27-29, called at
+ * :418-421 (SASRec) / :279-282 (BERT4Rec).  idx may be int64 (LongTensor, train_sr.py:191-199) or int32.
+ * err_flag (optional int): bit 0 set when an index is outside [0, n_rows) (the row is read as 0). */
+int amid_gather_rows_f32(const float* table, long long n_rows, int D, const void* idx, int idx_is_i64, long long n_idx,
+                         float* out, int* err_flag, void* stream);
+/* concatenate + narrow the four index tensors of a batch: idx_all = [seq_d1 | seq_d2 | (i_node, neg)[b]] */
+int amid_pack_indices(const long long* i_node, const long long* neg, const long long* seq_d1, const long long* seq_d2,
+                      int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* stream);
+/* fused gather + positional add + embedding dropout + feature-level (==0) mask.
+ * replaces: model_seq.py:418-421 + Log2feats.forward :361-366.  pos0/pos1 = sac{1,2}.pos_emb.weight
+ * (both NULL: plain gather for all rows, BERT4Rec).  xg: [2M + n_item_rows, D]; tmq: [2M, D/4] bytes. */
+int amid_embed_fwd_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
+                       int n_item_rows, float* xg, unsigned char* tmq, const void* step_state, int train, float p_drop, void* stream);
+/* backward of the above on the seq rows, in place on dxg [2M(+items), D]; writes d pos_emb.weight [T, D] x2.
+ * replaces: autograd of model_seq.py:361-366 (EmbeddingBackward of pos_emb). */
+int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, float* dpos0, float* dpos1,
+                       const void* step_state, int train, float p_drop, void* stream);
+
+/* ---- index sort / unique (no reference counterpart: enables the sparse gradient path) ------ */
+long long amid_sort_unique_workspace_bytes(int n_idx);
+int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
+                         int* seg_off /* [n_idx + 1] */, int* n_uniq /* device scalar */, void* stream);
+
+/* ---- K3 embedding gradient as segment reduce -------------------------------------------------
+ * replaces: autograd EmbeddingBackward (dense index_add into zero-filled [n_rows, D]) of the four
+ * lookups at model_seq.py:418-421, run by loss.backward() train_sr.py:214. */
+long long amid_segreduce_workspace_bytes(int n_idx, int D);
+int amid_embgrad_segreduce_f32(const float* grad_rows /* [n_idx, D] */, const int* pos_sorted, const int* seg_off, const int* n_uniq,
+                               int n_idx, int D, void* workspace, float* uniq_grad /* [n_idx, D] */, void* stream);
+
+/* ---- K4 optimizer ----------------------------------------------------------------------------
+ * replaces: torch.optim.Adam(model.parameters(), lr).step(), train_sr.py:480, :215 (dense over the table).
+ * lazy rows: m, v [n_rows, D], last [n_rows] int32 (0 = never touched). */
+int amid_lazy_adam_catchup_f32(float* table, float* m, float* v, int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max,
+                               int D, const void* step_state, void* stream);
+int amid_lazy_adam_apply_f32(float* table, float* m, float* v, int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max,
+                             const float* uniq_grad, float grad_scale, int D, const void* step_state, void* stream);
+int amid_lazy_adam_flush_f32(float* table, float* m, float* v, int* last, long long n_rows, int D, const void* step_state, void* stream);
+int amid_adam_dense_f32(float* p, float* m, float* v, const float* g, long long n, float grad_scale, const void* step_state, void* stream);
+
+/* ---- SASRec encoder layer, forward ------------------------------------------------------------
+ * Pointer-array arguments are HOST arrays of 2 device pointers (domain 0, domain 1). */
+int amid_rows_per_tile(int M);
+/* replaces: attention_layernorms[i] + the packed in-projection of nn.MultiheadAttention, model_seq.py:373-374 */
+int amid_sas_qkv_fwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
+                         const float* const* b_in, float ln_eps, int M, int D, int rows_per_tile, float* qn, float* q, float* k, float* v,
+                         void* stream);
+/* replaces: out_proj of nn.MultiheadAttention + "seqs = Q + mha_outputs" + forward_layernorms[i], model_seq.py:374-381 */
+int amid_sas_oproj_fwd_f32(const float* o, const float* const* w_o, const float* const* b_o, const float* qn, const float* const* ln_w,
+                           const float* const* ln_b, float ln_eps, int M, int D, int rows_per_tile, float* r, float* y, void* stream);
+/* replaces: PointWiseFeedForward.forward model_seq.py:322-326 + "seqs *= ~timeline_mask" :383 */
+int amid_sas_ffn_fwd_f32(const float* y, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
+                         const unsigned char* tmq, int M, int D, int rows_per_tile, int layer, const void* step_state, int train,
+                         float p_drop, float* h, float* xo, void* stream);
+
+/* ---- K2 attention core ------------------------------------------------------------------------
+ * replaces: softmax(q k^T + mask) dropout v inside nn.MultiheadAttention (model_seq.py:374, causal=1) and
+ * Attention.forward of BERT4Rec (model_seq.py:149-162, causal=0 with key_keep [B,T] from seq_d2 > 0, :288).
+ * stats: [2M, H, 2] (row max, 1/row sum) saved for backward. */
+int amid_attn_fwd_f32(const float* q, const float* k, const float* v, const unsigned char* key_keep, int B, int T, int D, int H, int causal,
+                      int layer, const void* step_state, int train, float p_drop, float* o, float* stats, void* stream);
+int amid_attn_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o,
+                      const unsigned char* key_keep, int B, int T, int D, int H, int causal, int layer, const void* step_state, int train,
+                      float p_drop, float* dq, float* dk, float* dv, void* stream);
+
+/* ---- SASRec encoder layer, backward (autograd of model_seq.py:371-383 under loss.backward(), train_sr.py:214) */
+int amid_transpose_weights_f32(const float* const* src, float* const* dst, int n /* <= 32 */, int D, void* stream);
+int amid_sas_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                         const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
+                         int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
+                         float* dr, float* d_o, float* ln_part /* [tiles][2][D] */, void* stream);
+int amid_sas_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
+                         const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
+                         int rows_per_tile, float* dx, float* ln_part, void* stream);
+/* six weight + bias gradients of a layer as split partials: w_part [2][6][splits][D*D], b_part [2][6][splits][D];
+ * order: in_proj q, k, v, out_proj, conv1, conv2 */
+int amid_sas_wgrad_f32(const float* const* dy6, const float* const* x6, int M, int D, int splits, float* w_part, float* b_part,
+                       void* stream);
+/* fixed-order reduction of partial buffers; entries are packed on the host then copied to the device by the caller */
+int amid_reduce_entry_bytes(void);
+int amid_reduce_entry_pack(void* host_buf, int index, const float* src, float* dst, long long stride, int n_part, int count);
+int amid_reduce_partials_f32(const void* entries_dev, int n_entries, int max_count, void* stream);
+
+/* ---- head: last LayerNorm + mean over time, scorer, masked BCE ------------------------------------
+ * replaces: last_layernorm model_seq.py:385 + torch.mean(seq, 1) :432-434 (w0 == NULL: mean only, BERT4Rec :299-300) */
+int amid_lnmean_fwd_f32(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, int B, int T, int D, float eps,
+                        float* u /* [2, B, D] */, void* stream);
+int amid_lnmean_bwd_f32(const float* x, const float* du, const float* w0, const float* w1, int B, int T, int D, float eps, float* dx,
+                        float* part /* [2B][2][D] */, void* stream);
+/* replaces: predictModule.forward model_seq.py:40-54; with labels != NULL also the masked BCE mean of
+ * train_sr.py:203-212 (per-row loss partials + dLoss/dp). */
+int amid_scorer_fwd_f32(const float* u, const float* items, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* labels, const long long* domain_id, int B, int NI, int D, int hid, float* p1, float* p2, float* dp1,
+                        float* dp2, float* loss_part, void* stream);
+long long amid_scorer_part_floats(int D, int hid);
+int amid_scorer_bwd_f32(const float* u, const float* items, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* p1, const float* p2, const float* dp1, const float* dp2, int B, int NI, int D, int hid, float* du,
+                        float* ditems, float* part /* [B][amid_scorer_part_floats] */, void* stream);
+int amid_sum_vector_f32(const float* v, int n, float* out, void* stream);
+
+/* ---- hipGraph capture / replay of a whole step; HIP events on the caller's stream ---------------- */
+int amid_graph_capture_begin(void* stream);
+int amid_graph_capture_end(void* stream, void** graph_exec_out);
+int amid_graph_launch(void* graph_exec, void* stream);
+int amid_graph_destroy(void* graph_exec);
+int amid_event_create(void** ev_out);
+int amid_event_record(void* ev, void* stream);
+int amid_event_sync(void* ev);
+int amid_event_elapsed_ms(void* start, void* stop, float* ms_out);
+int amid_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMID_HIP_H */

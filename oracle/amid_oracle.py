@@ -51,7 +51,7 @@ BERT_LN_EPS = 1e-6        # model_seq.py:118
 # counter-based RNG shared with the HIP kernels (our spec, not the reference's:
 # GPU dropout cannot reproduce CPU bernoulli_, SURVEY.md section 7 "Dropout
 # parity").  Philox4x32-10; key = seed, counter = (idx_lo, idx_hi, site, step).
-# Element e of a site uses word (e & 3) of call (e >> 2).
+# One call serves 8 elements (16-bit halves), see philox_keep_flat.
 # --------------------------------------------------------------------------
 _PHILOX_M0 = np.uint64(0xD2511F53)
 _PHILOX_M1 = np.uint64(0xCD9E8D57)
@@ -83,13 +83,15 @@ def philox4x32(ctr: np.ndarray, key: Tuple[int, int]) -> np.ndarray:
 
 
 def keep_threshold(p: float) -> int:
-    """keep <=> u32 >= thr ; P(keep) = 1 - p."""
-    return min(int(round(p * 4294967296.0)), 0xFFFFFFFF)
+    """16-bit threshold: keep <=> u16 >= thr ; P(keep) = 1 - thr/65536."""
+    return min(int(round(p * 65536.0)), 0xFFFF)
 
 
 def philox_keep_flat(n_elem: int, seed: int, site: int, step: int, p: float) -> np.ndarray:
-    """Keep mask (float32 0/1) for linear element indices [0, n_elem)."""
-    n_call = (n_elem + 3) // 4
+    """Keep mask (float32 0/1) for linear element indices [0, n_elem).
+    One Philox call serves 8 elements: element e uses 16-bit half (e & 1)
+    (0 = low) of word ((e >> 1) & 3) of call (e >> 3)."""
+    n_call = (n_elem + 7) // 8
     idx = np.arange(n_call, dtype=np.uint64)
     ctr = np.stack([
         (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32),
@@ -97,8 +99,9 @@ def philox_keep_flat(n_elem: int, seed: int, site: int, step: int, p: float) -> 
         np.full(n_call, site, dtype=np.uint32),
         np.full(n_call, step & 0xFFFFFFFF, dtype=np.uint32),
     ], axis=1)
-    r = philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).reshape(-1)[:n_elem]
-    return (r >= np.uint32(keep_threshold(p))).astype(np.float32)
+    r = philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))          # [n_call,4]
+    halves = np.stack([r & np.uint32(0xFFFF), r >> np.uint32(16)], axis=2).reshape(-1)[:n_elem]
+    return (halves >= np.uint32(keep_threshold(p))).astype(np.float32)
 
 
 # mask-site numbering shared with amid_amd/csrc/rng.h
@@ -117,7 +120,7 @@ def site_id(domain: int, layer: int, kind: int) -> int:
 
 
 def attn_row_stride(T: int) -> int:
-    return (T + 3) & ~3
+    return (T + 7) & ~7
 
 
 def philox_masks_sasrec(B: int, T: int, D: int, seed: int, step: int,

@@ -164,7 +164,7 @@ def main():
                             **{"P/sac1." + k: v.detach().numpy() for k, v in enc.state_dict().items()})
 
     # ---- G3/G4/G5 SASRec -------------------------------------------------
-    n_items, D, T, hid, B, neg = 600, 32, 50, 16, 6, 1
+    n_items, D, T, hid, B, neg = 600, 64, 50, 16, 6, 1
     torch.manual_seed(3)
     m = model_seq.SASRec(10, D, n_items, D, T, hid, B, False, False, 0.5, 0.5)
     with torch.no_grad():

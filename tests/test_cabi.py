@@ -1,0 +1,44 @@
+"""CPU-side checks of the C-ABI boundary: the built library loads and exports every entry point
+declared in include/amid_hip.h (no compute calls: there is no GPU here)."""
+import os
+import subprocess
+
+import pytest
+
+from amid_amd import _lib
+
+
+def test_header_parses_and_lists_entry_points():
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    for must in ("amid_gather_rows_f32", "amid_embed_fwd_f32", "amid_attn_fwd_f32", "amid_attn_bwd_f32", "amid_embgrad_segreduce_f32",
+                 "amid_lazy_adam_apply_f32", "amid_sas_qkv_fwd_f32", "amid_sas_wgrad_f32", "amid_graph_launch"):
+        assert must in protos
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    missing = [s for s in _lib.declared_symbols() if s not in exported]
+    assert not missing, missing
+    extra = [s for s in exported if s.startswith("amid_") and s not in _lib.declared_symbols()]
+    assert not extra, f"exported but not declared in include/amid_hip.h: {extra}"
+
+
+def test_library_loads_and_answers_host_only_queries():
+    L = _lib.lib()
+    assert L.value("amid_version") >= 100
+    assert L.value("amid_rows_per_tile", 12800) == 100          # 25 600 rows over 256 CUs
+    assert L.value("amid_rows_per_tile", 400) == 16
+    assert L.value("amid_step_state_bytes") == 48
+    assert L.value("amid_sort_unique_workspace_bytes", 26112) > 4 * 26112 * 4
+    assert L.raw("amid_error_string")(-2).decode().startswith("amid: shape not supported")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libamid_hip.so")
+    with pytest.raises(_lib.AmidLibraryError):
+        _lib._Lib()
