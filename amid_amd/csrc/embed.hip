@@ -192,8 +192,9 @@ static inline int gather_grid(long long n_rows_to_move) {
 
 extern "C" int amid_gather_rows_f32(const float* table, long long n_rows, int D, const void* idx, int idx_is_i64,
                                     long long n_idx, float* out, int* err_flag, void* stream) {
-    AMID_CHECK_ARG(table && idx && out && D > 0 && (D % 4) == 0 && n_idx >= 0);
-    if (n_idx == 0) return AMID_OK;
+    AMID_CHECK_ARG(D > 0 && (D % 4) == 0 && n_idx >= 0);
+    if (n_idx == 0) return AMID_OK;                 // empty lookup: nothing to move, pointers may be null
+    AMID_CHECK_ARG(table && idx && out);
     hipStream_t s = (hipStream_t)stream;
     if (idx_is_i64)
         gather_rows_kernel<long long><<<gather_grid(n_idx), 256, 0, s>>>(table, n_rows, D, (const long long*)idx, n_idx, out, err_flag);

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void scorer_fwd_kernel(const ScorerArgs a) {
                 const float md = a.domain[b] ? (d ? 1.f : 0.f) : (d ? 0.f : 1.f);
                 const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.0f - p), -100.f);
                 const float inv = 1.0f / ((float)a.B * (float)NI);
-                lsum += -(y * lp + (1.f - y) * l1p) * md;
+                lsum += -(y * lp + (1.f - y) * l1p) * md * inv;
                 (d ? a.dp2 : a.dp1)[o] = md * inv * (p - y) / fmaxf((1.f - p) * p, 1e-12f);   // torch binary_cross_entropy_backward
             }
         }

@@ -231,6 +231,8 @@ class SasrecEngine:
         if emb_dim not in (64, 128):
             raise ValueError(f"amid_amd SASRec kernels are built for emb_dim in (64, 128), got {emb_dim}")
         self.device = torch.device(device)
+        # every kernel of the engine runs on this (non-default, hence capturable) HIP stream
+        self.stream = torch.cuda.Stream(device=self.device)
         self.n_rows, self.D, self.T, self.hid, self.H = int(item_length), int(emb_dim), int(seq_len), int(hid_dim), SASREC_HEADS
         D = self.D
         self.dense = FlatParams(sasrec_dense_names(self.T, D, self.hid), self.device)
@@ -248,8 +250,6 @@ class SasrecEngine:
         self._push_step_state()
         self.plans: Dict[Tuple[int, int, int, bool], SasrecPlan] = {}
         self.grad_scale = 1.0
-        # every kernel of the engine runs on this (non-default, hence capturable) HIP stream
-        self.stream = torch.cuda.Stream(device=self.device)
         torch.cuda.synchronize(self.device)
         self._ptr_cache: Dict[str, object] = {}
 

@@ -184,7 +184,7 @@ def test_lazy_adam_equals_dense_adam_with_idle_rows(L):
         L.call("amid_lazy_adam_apply_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), ud.data_ptr(), nu.data_ptr(),
                n_rows, gd.data_ptr(), 1.0, D, st.data_ptr(), stream())
         torch.cuda.synchronize()
-    st = step_state(L, 0, steps)
+    st = step_state(L, 0, steps, lr=5e-3)
     L.call("amid_lazy_adam_flush_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), n_rows, D, st.data_ptr(), stream())
     torch.cuda.synchronize()
     assert float((tab.cpu() - P["t"]).abs().max()) < 2e-6
