@@ -83,6 +83,7 @@ class _Lib:
         except OSError as e:  # pragma: no cover
             raise AmidLibraryError(f"cannot load {LIB_PATH}: {e}") from e
         self._fn = {}
+        self.timer = None          # optional KernelTimer (bench.py): HIP events around every launch
         for name, (restype, argtypes) in parse_header().items():
             try:
                 f = getattr(self._dll, name)
@@ -97,6 +98,8 @@ class _Lib:
 
     def call(self, name: str, *args) -> None:
         """Call an int-returning entry point; raise AmidError on a non-zero code."""
+        if self.timer is not None and name not in _UNTIMED:
+            return self.timer.timed_call(self, name, args)
         code = self._fn[name](*args)
         if code != 0:
             text = self._fn["amid_error_string"](code)
@@ -105,6 +108,45 @@ class _Lib:
     def value(self, name: str, *args):
         """Call an entry point that returns a plain value (sizes, counts)."""
         return self._fn[name](*args)
+
+
+_UNTIMED = {"amid_event_create", "amid_event_record", "amid_event_sync", "amid_event_elapsed_ms", "amid_event_destroy",
+            "amid_graph_capture_begin", "amid_graph_capture_end", "amid_graph_launch", "amid_graph_destroy", "amid_step_state_pack",
+            "amid_reduce_entry_pack"}
+
+
+class KernelTimer:
+    """Brackets every kernel-launching C-ABI call with HIP events recorded on the stream the kernels
+    run on (the last argument of every launching entry point); durations are read after a sync."""
+
+    def __init__(self):
+        self.records = []      # (name, start_event, stop_event)
+
+    def timed_call(self, L: "_Lib", name: str, args) -> None:
+        stream = args[-1]
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        L._fn["amid_event_create"](ctypes.byref(e0))
+        L._fn["amid_event_create"](ctypes.byref(e1))
+        L._fn["amid_event_record"](e0, stream)
+        code = L._fn[name](*args)
+        L._fn["amid_event_record"](e1, stream)
+        self.records.append((name, e0, e1))
+        if code != 0:
+            text = L._fn["amid_error_string"](code)
+            raise AmidError(name, code, text.decode() if text else "?")
+
+    def collect(self, L: "_Lib") -> Dict[str, List[float]]:
+        """name -> list of durations in ms (call order preserved); destroys the events."""
+        out: Dict[str, List[float]] = {}
+        for name, e0, e1 in self.records:
+            L._fn["amid_event_sync"](e1)
+            ms = ctypes.c_float()
+            L._fn["amid_event_elapsed_ms"](e0, e1, ctypes.byref(ms))
+            out.setdefault(name, []).append(float(ms.value))
+            L._fn["amid_event_destroy"](e0)
+            L._fn["amid_event_destroy"](e1)
+        self.records = []
+        return out
 
 
 _LIB = None

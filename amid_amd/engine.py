@@ -420,15 +420,21 @@ class SasrecEngine:
         L.call("amid_embgrad_segreduce_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.n_uniq.data_ptr(),
                shp.n_idx, D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), s)
 
-    def enqueue_optimizer(self, pl: SasrecPlan) -> None:
+    def enqueue_optimizer(self, pl: SasrecPlan, sparse=None) -> None:
+        """Dense Adam on the flat buffer + lazy row Adam on (uniq_ids, uniq_grad, n_uniq); `sparse`
+        overrides the plan's local lists with the world-merged ones under data parallelism."""
         L, s = lib(), self.s
         self._ensure_opt_state()
         fp = self.dense
+        if sparse is None:
+            ids, rows, nu, cap = pl.uniq_ids, pl.uniq_grad, pl.n_uniq, pl.shape.n_idx
+        else:
+            ids, rows, nu = sparse
+            cap = ids.numel()
         L.call("amid_adam_dense_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel, self.grad_scale,
                self.step_state.data_ptr(), s)
         L.call("amid_lazy_adam_apply_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
-               pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), pl.shape.n_idx, pl.uniq_grad.data_ptr(), self.grad_scale, self.D,
-               self.step_state.data_ptr(), s)
+               ids.data_ptr(), nu.data_ptr(), cap, rows.data_ptr(), self.grad_scale, self.D, self.step_state.data_ptr(), s)
 
     def enqueue_step_begin(self) -> None:
         lib().call("amid_step_begin", self.step_state.data_ptr(), self.s)
@@ -442,6 +448,46 @@ class SasrecEngine:
         self.enqueue_forward(pl, train=True, with_loss=True)
         self.enqueue_backward(pl, train=True)
         self.enqueue_optimizer(pl)
+
+    # ------------------------------------------------------------------ data parallel (one process per GPU)
+    def enqueue_local_grads(self, pl: SasrecPlan) -> None:
+        """Everything of step t that needs no communication: t += 1 .. local segment-reduced gradients."""
+        self.enqueue_step_begin()
+        self.enqueue_prepare(pl, sparse=True)
+        self.enqueue_catchup(pl)
+        self.enqueue_forward(pl, train=True, with_loss=True)
+        self.enqueue_backward(pl, train=True)
+
+    def capture_local_grads(self, pl: SasrecPlan) -> None:
+        L = lib()
+        self._ensure_opt_state()
+        saved = self.snapshot()
+        self.enqueue_local_grads(pl)
+        self.sync()
+        self.restore(saved)
+        self.sync()
+        step0 = self.step
+        L.call("amid_graph_capture_begin", self.s)
+        try:
+            self.enqueue_local_grads(pl)
+        finally:
+            out = ctypes.c_void_p()
+            L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
+        self.step = step0
+        pl.graph_local = out.value
+
+    def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False) -> None:
+        """One data-parallel step: local grads -> dense all-reduce + sparse all-gather/merge -> Adam."""
+        with torch.cuda.stream(self.stream):
+            if use_graph:
+                lib().call("amid_graph_launch", pl.graph_local, self.s)
+                self.step += 1
+            else:
+                self.enqueue_local_grads(pl)
+            self.grad_scale = exchange.grad_scale
+            exchange.all_reduce_dense(self.dense.grad)
+            merged = exchange.exchange_sparse(pl.uniq_ids, pl.uniq_grad, pl.n_uniq)
+            self.enqueue_optimizer(pl, sparse=merged if exchange.world > 1 else None)
 
     # ------------------------------------------------------------------ graph replay
     def capture_train_step(self, pl: SasrecPlan) -> None:
@@ -505,7 +551,39 @@ class SasrecEngine:
             out[name] = self.dense.view(name)
         return out
 
+    def merge_backend(self, capacity: int) -> "HipMergeBackend":
+        return HipMergeBackend(self, capacity)
+
     def check_index_error(self, pl: SasrecPlan) -> None:
         if int(pl.err.item()) != 0:
             pl.err.zero_()
             raise IndexError("amid_amd: item index out of range in the batch (nn.Embedding would raise here, model_seq.py:27-29)")
+
+
+class HipMergeBackend:
+    """Merges the world's (ids, rows) lists with the same sort-unique + segment-reduce kernels the
+    local backward uses (amid_amd.dist.MergeBackend on the GPU)."""
+
+    def __init__(self, eng: SasrecEngine, capacity: int):
+        L = lib()
+        self.eng, self.cap = eng, int(capacity)
+        dev, D = eng.device, eng.D
+        self.sort_ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", self.cap), dtype=torch.uint8, device=dev)
+        self.pos_sorted = torch.zeros(self.cap, dtype=torch.int32, device=dev)
+        self.uniq_ids = torch.zeros(self.cap, dtype=torch.int32, device=dev)
+        self.seg_off = torch.zeros(self.cap + 1, dtype=torch.int32, device=dev)
+        self.n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", self.cap, D), dtype=torch.uint8, device=dev)
+        self.uniq_rows = torch.empty(self.cap, D, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+
+    def merge(self, ids: torch.Tensor, rows: torch.Tensor):
+        L, eng = lib(), self.eng
+        n = ids.numel()
+        if n > self.cap:
+            raise ValueError(f"merge of {n} entries exceeds the backend capacity {self.cap}")
+        L.call("amid_sort_unique_i32", ids.data_ptr(), n, eng.n_rows, self.sort_ws.data_ptr(), self.pos_sorted.data_ptr(),
+               self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.n_uniq.data_ptr(), eng.s)
+        L.call("amid_embgrad_segreduce_f32", rows.data_ptr(), self.pos_sorted.data_ptr(), self.seg_off.data_ptr(), self.n_uniq.data_ptr(),
+               n, eng.D, self.seg_ws.data_ptr(), self.uniq_rows.data_ptr(), eng.s)
+        return self.uniq_ids[:n], self.uniq_rows[:n], self.n_uniq

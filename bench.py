@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SASRec training throughput (train samples/s) on the reference's
+cloth_sport_train75 configuration (BASELINE.json configs[1]): batch 256 per GPU, seq_len 50,
+emb_dim 128, hid 32, 1 negative, fp32, item table 2 x 447 410 rows (train_sr.py:450,456), dropout on.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is the loop body of the reference's train() (train_sr.py:190-217): forward, masked BCE,
+backward, Adam.  Synthetic batches with the measured statistics of cloth_sport_train75
+(89 % pad positions, mean length ~5.5, ids <= 42 441, pad id 447 411) are
+resident in HBM before the timed region; random-init weights.  Prints ONE JSON line (rank 0).
+
+N = 1   the whole step is one hipGraph replay.
+N > 1   weak scaling (256 samples per GPU): per step one RCCL all-reduce of the flat dense gradient
+        and one all-gather of the segment-reduced sparse rows (amid_amd/dist.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+B, T, D, HID, NEG = 256, 50, 128, 32, 1
+ITEM_LENGTH = 447410              # train_sr.py:450
+N_ROWS = 2 * ITEM_LENGTH          # train_sr.py:456
+PAD_ID = ITEM_LENGTH + 1          # train_sr.py:451
+MAX_REAL_ID = 42441               # largest id in cloth_sport_train75
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def synth_batch(gen, device):
+    """One batch shaped like collate_fn_enhance's output after train_sr.py:191-200."""
+    lens1 = torch.clamp(torch.poisson(torch.full((B,), 4.5), generator=gen).long() + 1, max=T)
+    lens2 = torch.clamp(torch.poisson(torch.full((B,), 4.5), generator=gen).long(), max=T)      # other domain may be empty
+    col = torch.arange(T).unsqueeze(0)
+    seqs = []
+    for lens in (lens1, lens2):
+        s = torch.full((B, T), PAD_ID, dtype=torch.long)
+        ids = torch.randint(1, MAX_REAL_ID + 1, (B, T), generator=gen)
+        real = col >= (T - lens).unsqueeze(1)
+        s[real] = ids[real]
+        seqs.append(s)
+    label = torch.zeros(B, 1 + NEG)
+    label[:, 0] = 1.0
+    b = dict(i_node=torch.randint(1, MAX_REAL_ID + 1, (B,), generator=gen),
+             neg_samples=torch.randint(1, MAX_REAL_ID + 1, (B, NEG), generator=gen),
+             seq_d1=seqs[0], seq_d2=seqs[1], label=label, domain_id=(torch.rand(B, generator=gen) < 0.5).long())
+    return {k: v.to(device) for k, v in b.items()}
+
+
+def init_params(eng, seed):
+    """Random-init weights of the reference architecture (nn.Embedding N(0,1); small dense weights)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    with torch.no_grad():
+        eng.table.copy_(torch.randn(eng.n_rows, eng.D, generator=g))
+        flat = torch.randn(eng.dense.numel, generator=g) * 0.05
+        eng.dense.data.copy_(flat)
+        for name in eng.dense.slots:
+            v = eng.dense.view(name)
+            if "layernorm" in name and name.endswith("weight"):
+                v.fill_(1.0)
+            elif name.endswith("bias"):
+                v.zero_()
+            elif name.endswith("pos_emb.weight"):
+                v.copy_(torch.randn(v.shape, generator=g))
+    torch.cuda.synchronize()
+
+
+def algorithmic_work():
+    """Per launch, at this workload (formulas: DESIGN.md section 5 / SURVEY.md section 8(d))."""
+    M2 = 2 * B * T
+    n_idx = M2 + B * (1 + NEG)
+    gemm = 2.0 * M2 * D * D                     # FLOP of one [M2, D] x [D, D] projection
+    H, hd = 8, D // 8
+    return {
+        "amid_sas_qkv_fwd_f32": ("mfma", 3 * gemm),
+        "amid_sas_oproj_fwd_f32": ("mfma", gemm),
+        "amid_sas_ffn_fwd_f32": ("mfma", 2 * gemm),
+        "amid_sas_ffn_bwd_f32": ("mfma", 3 * gemm),
+        "amid_sas_qkv_bwd_f32": ("mfma", 3 * gemm),
+        "amid_sas_wgrad_f32": ("mfma", 6 * gemm),
+        "amid_attn_fwd_f32": ("valu", 4.0 * T * T * hd * 2 * B * H),
+        "amid_attn_bwd_f32": ("valu", 10.0 * T * T * hd * 2 * B * H),
+        "amid_embed_fwd_f32": ("hbm", n_idx * (4 + 2 * D * 4) + M2 * (D // 4)),
+        "amid_embgrad_segreduce_f32": ("hbm", n_idx * (D * 4 + 4)),
+    }
+
+
+def cpu_baseline(steps_warm=2, steps_timed=6):
+    """The oracle (CPU restatement of the reference path: dense embedding grads + dense Adam over the
+    894 820-row table) timed on this host's cores on the same workload."""
+    from oracle import amid_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    P = orc.random_params(orc.sasrec_param_shapes(N_ROWS, D, T, HID), seed=0)
+    opt = orc.DenseAdam(P, lr=5e-4)
+    gen = torch.Generator().manual_seed(99)
+    batches = [synth_batch(gen, "cpu") for _ in range(steps_warm + steps_timed)]
+    masks = {k: (torch.rand(v.shape) >= 0.5).float() for k, v in orc.philox_masks_sasrec(1, T, D, 0, 1).items()}
+    masks = {k: (torch.rand((B,) + tuple(v.shape[1:])) >= 0.5).float() for k, v in masks.items()}
+    ts = []
+    for i, b in enumerate(batches):
+        t0 = time.perf_counter()
+        orc.train_step("sasrec", P, opt, b, masks)
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[steps_warm:])
+    med = ts[len(ts) // 2]
+    return {"value": round(B / med, 2), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "ms_per_step": round(med * 1e3, 1),
+            "sample": f"{steps_timed} timed steps (+{steps_warm} warm-up) of oracle/amid_oracle.py train_step at the same "
+                      f"batch {B} x seq {T} x dim {D}, dense Adam over the {N_ROWS}-row table, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from amid_amd._lib import KernelTimer, lib
+    from amid_amd.dist import SparseDenseExchange
+    from amid_amd.engine import SasrecEngine
+
+    eng = SasrecEngine(N_ROWS, D, T, HID, device=device, lr=5e-4, seed=1234)
+    init_params(eng, seed=0)                  # identical replicas on every rank
+    pl = eng.plan(B, T, 1 + NEG, need_grad=True)
+    gen = torch.Generator().manual_seed(1000 + rank)          # each rank draws its own shard of the global batch
+    n_pool = 60                               # one epoch of cloth_sport_train75 at batch 256
+    pool = [synth_batch(gen, device) for _ in range(n_pool)]
+    torch.cuda.synchronize()
+
+    def load(i):
+        b = pool[i % n_pool]
+        eng.load_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"])
+
+    use_graph = not args.no_graph
+    exchange = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx)) if world > 1 else None
+    load(0)
+    if use_graph:
+        if world == 1:
+            eng.capture_train_step(pl)
+        else:
+            eng.capture_local_grads(pl)
+
+    def step(i):
+        load(i)
+        if world == 1:
+            if use_graph:
+                eng.replay_train_step(pl)
+            else:
+                eng.enqueue_train_step(pl)
+        else:
+            eng.train_step_dp(pl, exchange, use_graph=use_graph)
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_last = float(pl.loss.item())
+
+    # ---- per-kernel durations, measured live with HIP events on the engine's stream (eager launches) ----
+    roof, kernels = None, {}
+    if rank == 0:
+        L = lib()
+        n_prof = 20
+        L.timer = KernelTimer()
+        for i in range(n_prof):
+            load(i)
+            if world == 1:
+                eng.enqueue_train_step(pl)
+            else:
+                eng.enqueue_local_grads(pl)
+                eng.enqueue_optimizer(pl)
+            eng.sync()
+        durs = L.timer.collect(L)
+        L.timer = None
+        work = algorithmic_work()
+        total_ms = 0.0
+        for name, v in durs.items():
+            per_step = sum(v) / n_prof
+            total_ms += per_step
+            calls = len(v) // n_prof
+            ent = {"ms_per_step": round(per_step, 4), "launches_per_step": calls, "avg_launch_us": round(1e3 * per_step / max(calls, 1), 2)}
+            if name in work:
+                kind, amount = work[name]
+                avg_s = per_step / max(calls, 1) * 1e-3
+                if kind == "hbm":
+                    ent.update(bound="hbm", achieved=round(amount / avg_s / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s")
+                else:
+                    ent.update(bound="mfma" if kind == "mfma" else "valu", achieved=round(amount / avg_s / 1e12, 2),
+                               peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
+                ent["frac"] = round(ent["achieved"] / ent["peak"], 4)
+            kernels[name] = ent
+        dom = max((k for k in kernels if k in work and work[k][0] in ("mfma", "hbm")), key=lambda k: kernels[k]["ms_per_step"])
+        roof = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"], "peak": kernels[dom]["peak"],
+                "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"], "traffic": None,
+                "avg_launch_us": kernels[dom]["avg_launch_us"], "sum_kernel_ms_per_step": round(total_ms, 4)}
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        out = {
+            "metric": "train samples/sec", "value": round(B * world * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cloth_sport_train75-shaped SASRec train step (BASELINE.json configs[1])", "batch_per_gpu": B,
+                       "global_batch": B * world, "seq_len": T, "emb_dim": D, "hid_dim": HID, "neg": NEG, "table_rows": N_ROWS,
+                       "dropout": "on (p=0.5)", "optimizer": "Adam (dense-equivalent lazy rows)", "graph": use_graph,
+                       "parallelism": f"dp{world}"},
+            "loss_last": round(loss_last, 6),
+            "roofline": roof,
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
