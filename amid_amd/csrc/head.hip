@@ -277,6 +277,27 @@ __global__ __launch_bounds__(256) void scorer_bwd_kernel(const ScorerBwdArgs a) 
     if (threadIdx.x == 0) part[hid * 2 * D + 2 * hid] = dw2[hid];   // db2
 }
 
+// plain row LayerNorm (biased variance, eps inside the sqrt): one half-wave per row
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                             long long rows, int D, float eps, float* __restrict__ y) {
+    const int sub = threadIdx.x & 31;
+    const int q = D >> 2;
+    for (long long r = (long long)blockIdx.x * 8 + (threadIdx.x >> 5); r < rows; r += (long long)gridDim.x * 8) {
+        const float* row = x + r * D;
+        float s = 0.f;
+        for (int c = sub; c < q; c += 32) s += f4hsum(ld4(row + 4 * c));
+        const float mean = group_sum<32>(s) / D;
+        float vs = 0.f;
+        for (int c = sub; c < q; c += 32) { float4 v = ld4(row + 4 * c); v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean; vs += f4hsum(f4mul(v, v)); }
+        const float rstd = 1.0f / sqrtf(group_sum<32>(vs) / D + eps);
+        for (int c = sub; c < q; c += 32) {
+            const float4 v = ld4(row + 4 * c), ww = ld4(w + 4 * c), bb = ld4(b + 4 * c);
+            st4(y + r * D + 4 * c, make_float4((v.x - mean) * rstd * ww.x + bb.x, (v.y - mean) * rstd * ww.y + bb.y,
+                                               (v.z - mean) * rstd * ww.z + bb.z, (v.w - mean) * rstd * ww.w + bb.w));
+        }
+    }
+}
+
 __global__ void sum_vector_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
     // single wave, fixed order
     float s = 0.f;
@@ -335,6 +356,16 @@ extern "C" int amid_scorer_bwd_f32(const float* u, const float* items, const flo
     a.du = du; a.ditems = ditems; a.part = part; a.B = B; a.NI = NI; a.D = D; a.hid = hid;
     const size_t lds = (size_t)(4 * hid + hid + 4 + 128 * hid) * sizeof(float);
     scorer_bwd_kernel<<<B, 256, lds, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_layernorm_rows_f32(const float* x, const float* w, const float* b, long long rows, int D, float eps, float* y,
+                                       void* stream) {
+    AMID_CHECK_ARG(x && w && b && y && rows > 0 && D > 0 && (D % 4) == 0);
+    long long blocks = (rows + 7) / 8;
+    if (blocks > 4096) blocks = 4096;
+    layernorm_rows_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, w, b, rows, D, eps, y);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -1,0 +1,114 @@
+"""Data side of the hot path (reference: dataset_seq.py:12-22, :131-274), pre-tokenised.
+
+The reference parses two JSON lists per sample inside ``__getitem__``, builds a Python set difference
+per sample for the negatives and collates to float32 tensors (2.5 k samples/s per worker,
+SURVEY.md section 3(D)).  Here the CSV is tokenised ONCE into left-padded int64 ``[N, T]`` arrays
+(same ``seq_padding`` rule, same positive / duplicate-removal rule), negatives are drawn per epoch
+on the host with the same constraint (uniform over the domain's item pool minus the row's own
+sequence, without replacement) and batches are index_select-ed on the device.  Ids stay integers
+end to end (the reference's float32 wire format is exact only below 2**24).
+"""
+from __future__ import annotations
+
+import json
+from typing import Dict, Iterator, List
+
+import numpy as np
+import torch
+
+
+def seq_padding(seq: List[int], length_enc: int, long_length: int, pad_id: int):
+    """dataset_seq.py:12-22 (called with length_enc = seq_len + 1): left-pad / keep the tail."""
+    long_mask = 1 if len(seq) >= long_length else 0
+    if len(seq) >= length_enc:
+        enc = list(seq[-length_enc + 1:])
+    else:
+        enc = [pad_id] * (length_enc - len(seq) - 1) + list(seq)
+    return enc, long_mask
+
+
+class DualDomainSeqDataset:
+    """Same constructor as the reference (dataset_seq.py:131-132)."""
+
+    def __init__(self, seq_len, isTrain, neg_nums, long_length, pad_id, csv_path="", seed: int = 0):
+        import pandas as pd
+        df = pd.read_csv(csv_path)
+        self.seq_len, self.isTrain, self.neg_nums, self.long_length, self.pad_id = seq_len, isTrain, neg_nums, long_length, pad_id
+        raw1 = [json.loads(s) for s in df["seq_d1"].tolist()]
+        raw2 = [json.loads(s) for s in df["seq_d2"].tolist()]
+        self.domain_id = np.asarray(df["domain_id"].tolist(), dtype=np.int64)
+        self.user_nodes = np.asarray(df["user_id"].tolist(), dtype=np.int64)
+        self.pool = [np.array(sorted({i for s in raw1 for i in s}), dtype=np.int64),
+                     np.array(sorted({i for s in raw2 for i in s}), dtype=np.int64)]      # dataset_seq.py:141-142
+        N, T = len(raw1), seq_len
+        self.seq_d1 = np.empty((N, T), dtype=np.int64)
+        self.seq_d2 = np.empty((N, T), dtype=np.int64)
+        self.i_node = np.empty(N, dtype=np.int64)
+        self.overlap_label = np.zeros(N, dtype=np.int64)
+        self.long_tail_mask_d1 = np.zeros(N, dtype=np.int64)
+        self.long_tail_mask_d2 = np.zeros(N, dtype=np.int64)
+        self.own_items: List[np.ndarray] = []
+        for r in range(N):
+            s1, s2 = list(raw1[r]), list(raw2[r])
+            self.overlap_label[r] = 1 if (len(s1) and len(s2)) else 0                  # :181-184
+            own = s1 if self.domain_id[r] == 0 else s2
+            self.own_items.append(np.unique(np.asarray(own, dtype=np.int64)))           # excluded from the negatives (:188/:206)
+            item = own[-1]                                                              # positive = last item (:189/:207)
+            own = [x for x in own[:-1] if x != item]                                    # :190-195
+            if self.domain_id[r] == 0:
+                s1 = own
+            else:
+                s2 = own
+            self.i_node[r] = item
+            e1, m1 = seq_padding(s1, T + 1, long_length, pad_id)
+            e2, m2 = seq_padding(s2, T + 1, long_length, pad_id)
+            self.seq_d1[r], self.seq_d2[r] = e1, e2
+            self.long_tail_mask_d1[r], self.long_tail_mask_d2[r] = m1, m2
+        self.rng = np.random.default_rng(seed)
+
+    def __len__(self) -> int:
+        return len(self.i_node)
+
+    def sample_negatives(self) -> np.ndarray:
+        """[N, k] negatives: uniform without replacement from the row's domain pool minus its own sequence."""
+        k = 1 if self.isTrain else self.neg_nums
+        out = np.empty((len(self), k), dtype=np.int64)
+        for r in range(len(self)):
+            pool = self.pool[int(self.domain_id[r] != 0)]
+            need = k + len(self.own_items[r])
+            if need > len(pool):
+                raise ValueError("negative pool smaller than neg_nums")
+            cand = pool[self.rng.choice(len(pool), size=need, replace=False)]
+            cand = cand[~np.isin(cand, self.own_items[r])]
+            out[r] = cand[:k]
+        return out
+
+
+class DeviceBatches:
+    """DataLoader(batch_size, shuffle, drop_last=True) over a tokenised dataset resident on the device."""
+
+    def __init__(self, ds: DualDomainSeqDataset, batch_size: int, shuffle: bool, device, seed: int = 0):
+        self.ds, self.bs, self.shuffle, self.device = ds, batch_size, shuffle, torch.device(device)
+        to = lambda a: torch.from_numpy(a).to(self.device)       # noqa: E731
+        self.t = dict(user_node=to(ds.user_nodes), i_node=to(ds.i_node), seq_d1=to(ds.seq_d1), seq_d2=to(ds.seq_d2),
+                      domain_id=to(ds.domain_id), overlap_label=to(ds.overlap_label), long_tail_mask_d1=to(ds.long_tail_mask_d1),
+                      long_tail_mask_d2=to(ds.long_tail_mask_d2))
+        self.gen = torch.Generator().manual_seed(seed)
+        k = 1 if ds.isTrain else ds.neg_nums
+        self.label = torch.zeros(batch_size, 1 + k, device=self.device)
+        self.label[:, 0] = 1.0                                                            # dataset_seq.py:191,199
+
+    def __len__(self) -> int:
+        return len(self.ds) // self.bs                                                    # drop_last=True (train_sr.py:452,455)
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        neg = torch.from_numpy(self.ds.sample_negatives()).to(self.device)
+        n = len(self.ds)
+        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        order = order.to(self.device)
+        for b in range(len(self)):
+            sel = order[b * self.bs:(b + 1) * self.bs]
+            batch = {k: v.index_select(0, sel) for k, v in self.t.items()}
+            batch["neg_samples"] = neg.index_select(0, sel)
+            batch["label"] = self.label
+            yield batch

@@ -1,0 +1,373 @@
+"""Drop-in ``nn.Module`` surface of the reference's ``model_seq.py`` for the MI355X hot path.
+
+Same class names, constructor signatures, ``forward`` signatures and ``state_dict`` keys as the
+reference; the arithmetic runs in the hand-written HIP kernels of
+``libamid_hip.so`` (there is no PyTorch fallback: without the library, construction raises).
+
+  SASRec(user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim, bs,
+         isInC, isItC, threshold1, threshold2, isDR=False)          model_seq.py:391
+      forward(u_node, i_node, neg_samples, seq_d1, seq_d2, long_tail_mask_d1, long_tail_mask_d2,
+              isTrain=True) -> (logits_d1, logits_d2)                 model_seq.py:416
+  embItemLayerEnhance(item_length, emb_dim)                           model_seq.py:23
+  predictModule(emb_dim, hid_dim)                                     model_seq.py:33
+  Log2feats(user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim)   model_seq.py:332
+
+As in the reference, ``u_node``, both ``long_tail_mask_*``, ``isTrain``, ``user_length`` and ``bs``
+are accepted and ignored; dropout follows ``module.training``.  Two ways to train:
+
+  reference loop   ``opt = torch.optim.Adam(model.parameters(), lr)``; ``loss.backward(); opt.step()``
+                   (train_sr.py:213-215) works unchanged: backward runs the HIP kernels and hands autograd
+                   the gradients (the table gradient is materialised densely for torch's optimizer);
+  fused step       ``model.train_step(batch)`` = forward + masked BCE + backward + dense-equivalent lazy
+                   Adam as one hipGraph replay -- what ``train_sr.py`` of this repo and ``bench.py`` use.
+
+Out of scope this round (constructors kept for import / state_dict parity, ``forward`` raises):
+GRU4Rec (recurrent), BERT4Rec, InnerComp / InterComp (isInC / isItC), embUserLayerEnhance (dead code in
+the reference), the isDR heads.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from ._lib import lib
+from .engine import SASREC_LN_EPS, SasrecEngine
+
+
+def _register_tree(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
+    """Register ``param`` under a dotted state_dict name, creating plain container modules on the way."""
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], param)
+
+
+def _not_built(what: str, cite: str):
+    raise NotImplementedError(
+        f"{what} ({cite}) is outside the MI355X hot path built so far (SURVEY.md section 8(f)); the constructor exists for "
+        f"signature / state_dict parity only.  There is deliberately no PyTorch fallback.")
+
+
+# ------------------------------------------------------------------------------------------------
+class _SasrecFunction(torch.autograd.Function):
+    """Autograd bridge: forward / backward are the HIP launch sequences of SasrecEngine."""
+
+    @staticmethod
+    def forward(ctx, model, need_grad, i_node, neg_samples, seq_d1, seq_d2, *params):
+        eng: SasrecEngine = model.engine
+        B, T = seq_d1.shape
+        neg = neg_samples.reshape(B, -1)
+        pl = eng.plan(B, T, 1 + neg.shape[1], need_grad=bool(need_grad))
+        eng.stream.wait_stream(torch.cuda.current_stream())
+        eng.load_batch(pl, i_node, neg, seq_d1, seq_d2)
+        if model.training:
+            eng.enqueue_step_begin()                   # fresh dropout counter per training forward
+        eng.enqueue_prepare(pl, sparse=need_grad)
+        if need_grad and eng.table_m is not None:
+            eng.enqueue_catchup(pl)                    # lazy-Adam rows must be current before they are gathered
+        eng.enqueue_forward(pl, train=model.training, with_loss=False)
+        torch.cuda.current_stream().wait_stream(eng.stream)
+        ctx.model, ctx.pl, ctx.train = model, pl, model.training
+        eng.check_index_error(pl)
+        return pl.p1.clone(), pl.p2.clone()
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        model, pl = ctx.model, ctx.pl
+        eng: SasrecEngine = model.engine
+        eng.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(eng.stream):
+            pl.dp1.copy_(g1.reshape(pl.dp1.shape))
+            pl.dp2.copy_(g2.reshape(pl.dp2.shape))
+        eng.enqueue_backward(pl, train=ctx.train)
+        grads = []
+        with torch.cuda.stream(eng.stream):
+            for name in model._param_names:
+                if name == "item_emb_layer.emb_item.weight":
+                    if model.fused_optimizer:
+                        grads.append(None)             # rows stay in pl.uniq_ids / pl.uniq_grad for the lazy Adam
+                    else:
+                        U = int(pl.n_uniq.item())
+                        dense = torch.zeros_like(eng.table)
+                        dense.index_copy_(0, pl.uniq_ids[:U].long(), pl.uniq_grad[:U])
+                        grads.append(dense)
+                else:
+                    grads.append(eng.dense.view(name, eng.dense.grad).clone())
+        torch.cuda.current_stream().wait_stream(eng.stream)
+        model._last_plan = pl
+        return (None, None, None, None, None, None, *grads)
+
+
+class SASRec(nn.Module):
+    """model_seq.py:390-443 on the HIP engine (isInC = isItC = isDR = False)."""
+
+    def __init__(self, user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim, bs, isInC, isItC, threshold1,
+                 threshold2, isDR=False, device: Optional[str] = None, lr: float = 5e-4, seed: int = 0):
+        super().__init__()
+        if isInC or isItC:
+            _not_built("InnerComp / InterComp (isInC / isItC)", "model_seq.py:422-431")
+        if isDR:
+            _not_built("the doubly-robust heads (isDR)", "model_seq.py:411-414")
+        if user_emb_dim != item_emb_dim:
+            raise ValueError("the reference feeds item rows into encoders built with user_emb_dim: the two must be equal")
+        lib()                                                   # fail loudly without libamid_hip.so
+        self.user_emb_dim = user_emb_dim
+        self.isInC, self.isItC, self.isDR = isInC, isItC, isDR
+        dev = device or ("cuda:%d" % torch.cuda.current_device())
+        self.engine = SasrecEngine(item_length, item_emb_dim, seq_len, hid_dim, device=dev, lr=lr, seed=seed)
+        eng = self.engine
+        self._param_names = ["item_emb_layer.emb_item.weight"] + list(eng.dense.slots)
+        self._init_reference_defaults(seed)
+        _register_tree(self, "item_emb_layer.emb_item.weight", nn.Parameter(eng.table))
+        for name in eng.dense.slots:
+            _register_tree(self, name, nn.Parameter(eng.dense.view(name)))
+        self.fused_optimizer = False            # set by train_step(): table gradient stays sparse, Adam runs in HIP
+        self._last_plan = None
+
+    def _init_reference_defaults(self, seed: int) -> None:
+        """Same initial distributions as the reference's modules (nn.Embedding N(0,1); nn.Linear / Conv1d /
+        MultiheadAttention defaults; LayerNorm 1/0), drawn from a private generator."""
+        eng = self.engine
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        D, hid = eng.D, eng.hid
+        with torch.no_grad():
+            eng.table.copy_(torch.randn(eng.n_rows, D, generator=g))
+            for name in eng.dense.slots:
+                v = eng.dense.view(name)
+                if name.endswith("pos_emb.weight"):
+                    v.copy_(torch.randn(v.shape, generator=g))
+                elif "layernorm" in name:
+                    v.fill_(1.0 if name.endswith("weight") else 0.0)
+                elif name.endswith("in_proj_weight"):          # xavier_uniform_ (nn.MultiheadAttention._reset_parameters)
+                    a = (6.0 / (3 * D + D)) ** 0.5
+                    v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * a)
+                elif name.endswith("in_proj_bias") or name.endswith("out_proj.bias"):
+                    v.zero_()
+                else:                                          # kaiming_uniform_(a=sqrt(5)) => U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                    fan_in = {"predictModule.fc.0.weight": 2 * D, "predictModule.fc.0.bias": 2 * D, "predictModule.fc.2.weight": hid,
+                              "predictModule.fc.2.bias": hid}.get(name, D)
+                    a = 1.0 / fan_in ** 0.5
+                    v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * a)
+        torch.cuda.synchronize(eng.device)
+
+    # -- reference forward ---------------------------------------------------------------------
+    def forward(self, u_node, i_node, neg_samples, seq_d1, seq_d2, long_tail_mask_d1, long_tail_mask_d2, isTrain=True):
+        if not self.training and self.engine.table_m is not None:
+            self.engine.flush_table()               # rows with pending zero-gradient Adam steps must be current for eval
+        params = [self.get_parameter(n) for n in self._param_names]
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        p1, p2 = _SasrecFunction.apply(self, need_grad, i_node, neg_samples, seq_d1, seq_d2, *params)
+        return p1.squeeze(), p2.squeeze()              # model_seq.py:54
+
+    # -- fused fast path -------------------------------------------------------------------------
+    def train_step(self, i_node, neg_samples, seq_d1, seq_d2, labels, domain_id, use_graph: bool = True) -> torch.Tensor:
+        """train_sr.py:190-217 as one launch sequence (one hipGraph replay once captured).  Returns the loss (device scalar)."""
+        eng = self.engine
+        self.fused_optimizer = True
+        B, T = seq_d1.shape
+        neg = neg_samples.reshape(B, -1)
+        pl = eng.plan(B, T, 1 + neg.shape[1], need_grad=True)
+        eng.stream.wait_stream(torch.cuda.current_stream())
+        eng.load_batch(pl, i_node, neg, seq_d1, seq_d2, labels, domain_id)
+        if use_graph:
+            if getattr(pl, "graph", None) is None:
+                eng.capture_train_step(pl)
+            eng.replay_train_step(pl)
+        else:
+            eng.enqueue_train_step(pl)
+        torch.cuda.current_stream().wait_stream(eng.stream)
+        self._last_plan = pl
+        return pl.loss
+
+    def flush(self) -> None:
+        """Bring lazily-updated table rows up to date (call before eval / state_dict() / checkpoints)."""
+        self.engine.flush_table()
+        self.engine.sync()
+
+    def state_dict(self, *args, **kwargs):
+        self.flush()
+        return super().state_dict(*args, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------------
+class _GatherFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, idx):
+        L = lib()
+        flat = idx.reshape(-1).contiguous()
+        out = torch.empty(flat.numel(), weight.shape[1], dtype=weight.dtype, device=weight.device)
+        err = torch.zeros(1, dtype=torch.int32, device=weight.device)
+        is64 = 1 if flat.dtype == torch.int64 else 0
+        if not is64 and flat.dtype != torch.int32:
+            raise TypeError("item ids must be int64 or int32")
+        L.call("amid_gather_rows_f32", weight.data_ptr(), weight.shape[0], weight.shape[1], flat.data_ptr(), is64, flat.numel(),
+               out.data_ptr(), err.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if int(err.item()):
+            raise IndexError("index out of range in embItemLayerEnhance")
+        ctx.save_for_backward(flat)
+        ctx.shape = weight.shape
+        return out.reshape(*idx.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (flat,) = ctx.saved_tensors
+        L, s = lib(), torch.cuda.current_stream().cuda_stream
+        n, D = flat.numel(), ctx.shape[1]
+        if D not in (64, 128, 256):
+            raise NotImplementedError(f"embItemLayerEnhance backward: the segment-reduce kernel is built for emb_dim in (64, 128, 256), got {D}")
+        dev = g.device
+        idx32 = flat.to(torch.int32)
+        rows = g.reshape(n, D).contiguous()
+        ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device=dev)
+        pos, uniq = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+        seg, nu = torch.empty(n + 1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        L.call("amid_sort_unique_i32", idx32.data_ptr(), n, ctx.shape[0], ws.data_ptr(), pos.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
+               nu.data_ptr(), s)
+        ws2 = torch.empty(L.value("amid_segreduce_workspace_bytes", n, D), dtype=torch.uint8, device=dev)
+        ug = torch.empty(n, D, dtype=torch.float32, device=dev)
+        L.call("amid_embgrad_segreduce_f32", rows.data_ptr(), pos.data_ptr(), seg.data_ptr(), nu.data_ptr(), n, D, ws2.data_ptr(),
+               ug.data_ptr(), s)
+        U = int(nu.item())
+        dense = torch.zeros(ctx.shape, dtype=torch.float32, device=dev)
+        dense.index_copy_(0, uniq[:U].long(), ug[:U])
+        return dense, None
+
+
+class embItemLayerEnhance(nn.Module):
+    """model_seq.py:22-29: plain lookup, no padding_idx (the pad id is an ordinary trainable row)."""
+
+    def __init__(self, item_length, emb_dim):
+        super().__init__()
+        lib()
+        self.emb_item = nn.Module()
+        self.emb_item.register_parameter("weight", nn.Parameter(torch.randn(item_length, emb_dim, device="cuda")))
+
+    def forward(self, item_id):
+        return _GatherFunction.apply(self.emb_item.weight, item_id)
+
+
+class predictModule(nn.Module):
+    """model_seq.py:32-54 (forward only through the HIP scorer; training goes through SASRec)."""
+
+    def __init__(self, emb_dim, hid_dim):
+        super().__init__()
+        lib()
+        self.fc = nn.Sequential(nn.Linear(emb_dim * 2, hid_dim), nn.ReLU(), nn.Linear(hid_dim, 1)).cuda()
+        self.emb_dim, self.hid_dim = emb_dim, hid_dim
+
+    @torch.no_grad()
+    def forward(self, user_spf1, user_spf2, i_feat):
+        L = lib()
+        B, NI, D = i_feat.shape
+        u = torch.stack((user_spf1, user_spf2)).contiguous().float()
+        items = i_feat.contiguous().float()
+        p1 = torch.empty(B, NI, device=u.device)
+        p2 = torch.empty(B, NI, device=u.device)
+        L.call("amid_scorer_fwd_f32", u.data_ptr(), items.data_ptr(), self.fc[0].weight.data_ptr(), self.fc[0].bias.data_ptr(),
+               self.fc[2].weight.data_ptr(), self.fc[2].bias.data_ptr(), None, None, B, NI, D, self.hid_dim, p1.data_ptr(), p2.data_ptr(),
+               None, None, None, torch.cuda.current_stream().cuda_stream)
+        return p1.squeeze(), p2.squeeze()
+
+
+class Log2feats(nn.Module):
+    """model_seq.py:331-387 as a standalone module (eval / inference): LN -> causal MHA -> FFN, two blocks."""
+
+    def __init__(self, user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim):
+        super().__init__()
+        lib()
+        self.D, self.T = user_emb_dim, seq_len
+        # a private two-domain engine whose table is the identity of the rows handed to forward()
+        self._eng: Optional[SasrecEngine] = None
+        names = [(n[len("sac1."):], s) for n, s in __import__("amid_amd.engine", fromlist=["x"]).sasrec_dense_names(seq_len, user_emb_dim, hid_dim)
+                 if n.startswith("sac1.")]
+        for n, shp in names:
+            init = torch.ones(shp) if ("layernorm" in n and n.endswith("weight")) else torch.randn(shp) * 0.05
+            if "layernorm" in n and n.endswith("bias"):
+                init = torch.zeros(shp)
+            _register_tree(self, n, nn.Parameter(init.cuda()))
+
+    @torch.no_grad()
+    def forward(self, log_seqs):
+        B, T, D = log_seqs.shape
+        eng = SasrecEngine(B * T + 2, D, self.T, 8, device=str(log_seqs.device))
+        sd: Dict[str, torch.Tensor] = {"item_emb_layer.emb_item.weight": torch.cat((log_seqs.reshape(B * T, D).float(),
+                                                                                     torch.zeros(2, D, device=log_seqs.device)))}
+        own = dict(self.named_parameters())
+        for name in eng.dense.slots:
+            if name.startswith("sac"):
+                sd[name] = own[name.split(".", 1)[1]]
+            else:
+                sd[name] = torch.zeros(eng.dense.slots[name][1], device=log_seqs.device)
+        eng.load_state_dict(sd)
+        pl = eng.plan(B, T, 2, need_grad=False)
+        seq = torch.arange(B * T, device=log_seqs.device).reshape(B, T)
+        z = torch.zeros(B, dtype=torch.long, device=log_seqs.device)
+        eng.stream.wait_stream(torch.cuda.current_stream())
+        eng.load_batch(pl, z, z.reshape(B, 1), seq, seq)
+        eng.enqueue_prepare(pl, sparse=False)
+        eng.enqueue_forward(pl, train=False, with_loss=False)
+        # last LayerNorm (model_seq.py:385) of the first domain's rows, row by row on the host side of the ABI
+        x = pl.x[2][: B * T]
+        out = torch.empty_like(x)
+        lib().call("amid_layernorm_rows_f32", x.data_ptr(), own["last_layernorm.weight"].data_ptr(), own["last_layernorm.bias"].data_ptr(),
+                   B * T, D, SASREC_LN_EPS, out.data_ptr(), eng.s)          # model_seq.py:385
+        torch.cuda.current_stream().wait_stream(eng.stream)
+        return out.reshape(B, T, D)
+
+
+# ------------------------------------------------------------------------------------------------
+# signature-parity shells (constructors build the reference's parameters; forward is not built yet)
+class embUserLayerEnhance(nn.Module):
+    def __init__(self, user_length, emb_dim):          # model_seq.py:9-20 (never instantiated by the reference's models)
+        super().__init__()
+        self.emb_user_share = nn.Embedding(user_length, emb_dim)
+        self.transd1 = nn.Linear(emb_dim, emb_dim)
+        self.transd2 = nn.Linear(emb_dim, emb_dim)
+
+    def forward(self, user_id):
+        _not_built("embUserLayerEnhance", "model_seq.py:9-20")
+
+
+def getBinaryTensor(imgTensor, boundary):              # model_seq.py:445-448
+    return torch.where(imgTensor > boundary, torch.ones_like(imgTensor), torch.zeros_like(imgTensor))
+
+
+class InnerComp(nn.Module):
+    def __init__(self, user_emb_dim, bs, threshold):   # model_seq.py:450-457
+        super().__init__()
+        self.bs, self.threshold = bs, threshold
+        self.trans_nn = nn.Linear(user_emb_dim, user_emb_dim)
+        self.trans_bs = nn.Linear(bs, 1)
+
+    def forward(self, seq):
+        _not_built("InnerComp", "model_seq.py:459-472")
+
+
+class InterComp(nn.Module):
+    def __init__(self, user_emb_dim, bs, threshold):   # model_seq.py:474-481
+        super().__init__()
+        self.bs, self.threshold = bs, threshold
+        self.trans_nn = nn.Linear(user_emb_dim, user_emb_dim)
+        self.trans_bs = nn.Linear(bs, 1)
+
+    def forward(self, seq_d1, seq_d2):
+        _not_built("InterComp", "model_seq.py:483-497")
+
+
+class GRU4Rec(nn.Module):
+    def __init__(self, user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim, bs, isInC, isItC, threshold1, threshold2,
+                 isDR=False):                          # model_seq.py:58
+        super().__init__()
+        _not_built("GRU4Rec (recurrent encoder, not the attention path)", "model_seq.py:56-113")
+
+
+class BERT4Rec(nn.Module):
+    def __init__(self, user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim, bs, isInC, isItC, threshold1, threshold2,
+                 isDR=False):                          # model_seq.py:250
+        super().__init__()
+        _not_built("BERT4Rec", "model_seq.py:248-309")

@@ -1,0 +1,176 @@
+"""Training driver with the reference's ``train_sr.py`` command line (train_sr.py:357-625), running the hot
+loop on the MI355X engine.
+
+Same flags as the reference (train_sr.py:360-389; the ones the reference never reads are accepted and
+ignored; ``type=bool`` flags keep the reference's "any non-empty string is True" behaviour), same
+constants (item_length 447 410, pad id item_length + 1, table of 2 x item_length rows, drop_last on both
+loaders, five seeds 0..4, loss logged every 20 iterations, best-so-far HR/NDCG/MRR per epoch).
+Additions: ``--data_root`` (the reference hard-codes /ossfs/workspace/CDSR), ``--seeds``, ``--device``,
+``--no_graph``, ``--max_steps``.
+
+    python train_sr.py --data_root /path/to/AMID -ds amazon -dm cloth_sport --overlap_ratio 0.75 \
+        --model sasrec --bs 256 --seq_len 50 --emb_dim 128 --epoch 2 --seeds 1
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from .dataset_seq import DeviceBatches, DualDomainSeqDataset
+from .model_seq import BERT4Rec, GRU4Rec, SASRec
+from .utils import AverageMeter, choose_predict, choose_predict_overlap, get_sample_scores, init_logger
+
+logger = logging.getLogger()
+FIX_VALUE = 1e-7          # train_sr.py:42: ties between the positive and a negative count against the positive
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Multi-edge multi-domain training")
+    p.add_argument("--epoch", type=int, default=50, help="# of epoch")
+    p.add_argument("--bs", type=int, default=256, help="# images in batch")
+    p.add_argument("--use_gpu", type=bool, default=True)
+    p.add_argument("--lr", type=float, default=5e-4, help="initial learning rate for adam")
+    p.add_argument("--emb_dim", type=int, default=128, help="embedding size")
+    p.add_argument("--hid_dim", type=int, default=32, help="hidden layer dim")
+    p.add_argument("--seq_len", type=int, default=20, help="the length of the sequence")
+    p.add_argument("--graph_nums", type=int, default=2)
+    p.add_argument("--head_nums", type=int, default=32)
+    p.add_argument("--long_length", type=int, default=7, help="the length for setting long-tail node")
+    p.add_argument("--m1_layers", type=int, default=3)
+    p.add_argument("--m2_layers", type=int, default=3)
+    p.add_argument("--m3_layers", type=int, default=4)
+    p.add_argument("--m4_layers", type=int, default=2)
+    p.add_argument("--alpha_l", type=int, default=3)
+    p.add_argument("--neg_nums", type=int, default=199, help="sample negative numbers")
+    p.add_argument("--mask_rate_enc", type=float, default=0.9)
+    p.add_argument("--mask_rate_dec", type=float, default=0.9)
+    p.add_argument("--overlap_ratio", type=float, default=0.5, help="overlap ratio for choose dataset")
+    p.add_argument("--bs_ratio", type=float, default=0.5)
+    p.add_argument("-md", "--model-dir", type=str, default="model/")
+    p.add_argument("--log-file", type=str, default="log")
+    p.add_argument("--model", type=str, default="model select")
+    p.add_argument("-ds", "--dataset_type", type=str, default="amazon")
+    p.add_argument("-dm", "--domain_type", type=str, default="movie_book")
+    p.add_argument("--isInC", type=bool, default=False, help="add inc")
+    p.add_argument("--isItC", type=bool, default=False, help="add itc")
+    p.add_argument("--ts1", type=float, default=0.5)
+    p.add_argument("--ts2", type=float, default=0.5)
+    p.add_argument("--overlap", type=bool, default=False, help="split the metrics by overlapped / non-overlapped users")
+    # additions
+    p.add_argument("--data_root", type=str, default=".", help="directory holding {amazon,mybank}_dataset/ (reference: /ossfs/workspace/CDSR)")
+    p.add_argument("--seeds", type=int, default=5, help="number of seeds 0..n-1 (reference: 5)")
+    p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--no_graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
+    p.add_argument("--max_steps", type=int, default=0, help="stop each epoch after this many steps (0 = full epoch)")
+    return p
+
+
+@torch.no_grad()
+def test(model, args, val_batches):
+    """train_sr.py:31-128: forward with neg_nums negatives, masked BCE, HR/NDCG/MRR of the positive's rank."""
+    model.eval()
+    stats = AverageMeter("loss", "loss_cls")
+    p1s, p2s, doms, ovs = [], [], [], []
+    for b in val_batches:
+        p1, p2 = model(b["user_node"], b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["long_tail_mask_d1"],
+                       b["long_tail_mask_d2"], False)
+        p1, p2 = p1.reshape(len(b["i_node"]), -1), p2.reshape(len(b["i_node"]), -1)
+        y = b["label"]
+        m2 = b["domain_id"].float().unsqueeze(1)
+        bce = torch.nn.functional.binary_cross_entropy
+        loss = (bce(p1, y, reduction="none") * (1 - m2) + bce(p2, y, reduction="none") * m2).mean()     # train_sr.py:63-64
+        stats.update(loss=loss.item(), loss_cls=loss.item())
+        p1s.append(p1.cpu().numpy()); p2s.append(p2.cpu().numpy())
+        doms.append(b["domain_id"].cpu().numpy()); ovs.append(b["overlap_label"].cpu().numpy())
+    p1, p2, dom, ov = np.concatenate(p1s), np.concatenate(p2s), np.concatenate(doms), np.concatenate(ovs)
+
+    def scores(pred):
+        pred = pred.copy()
+        pred[:, 0] -= FIX_VALUE                                                           # train_sr.py:114-115
+        return get_sample_scores(pred)
+
+    d1, d2 = choose_predict(p1, p2, dom)
+    out = {"loss": stats.loss, "d1": scores(d1), "d2": scores(d2)}
+    if args.overlap:
+        a, b_, c, d = choose_predict_overlap(p1, p2, dom, ov)
+        out.update(d1_ov=get_sample_scores(a), d1_no=get_sample_scores(b_), d2_ov=get_sample_scores(c), d2_no=get_sample_scores(d))
+    return out
+
+
+def train(model, train_batches, args, val_batches):
+    """train_sr.py:130-355 with the loop body (:190-217) fused into model.train_step."""
+    best = {}
+    for epoch in range(args.epoch):
+        stats = AverageMeter("loss", "loss_cls")
+        model.train()
+        t0, n_samples = time.perf_counter(), 0
+        for i, b in enumerate(train_batches):
+            loss = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
+                                    use_graph=not args.no_graph)
+            n_samples += len(b["i_node"])
+            if i % 20 == 0:                                                               # train_sr.py:217-219 (the only host sync)
+                stats.update(loss=loss.item(), loss_cls=loss.item())
+                logger.info(f"train total loss:{stats.loss}, cls loss:{stats.loss_cls} \t")
+            if args.max_steps and i + 1 >= args.max_steps:
+                break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        logger.info(f"epoch {epoch}: {n_samples} samples in {dt:.2f} s = {n_samples / dt:.0f} samples/s (loader included)")
+        res = test(model, args, val_batches)
+        names = ("HR@1", "NDCG@1", "HR@5", "NDCG@5", "HR@10", "NDCG@10", "MRR")
+        msg = [f"Epoch: {epoch}/{args.epoch} \tTrain Loss: {stats.loss:.4f} \tVal loss: {res['loss']:.4f}"]
+        for key, sc in res.items():
+            if key == "loss":
+                continue
+            for n, v in zip(names, sc):
+                best[(key, n)] = max(best.get((key, n), 0.0), v)
+            msg.append(f"val {key} cur/max " + ", ".join(f"{n}: {v:.4f}/{best[(key, n)]:.4f}" for n, v in zip(names, sc)))
+        logger.info("\n".join(msg))
+    return best
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    summary = []
+    for i in range(args.seeds):
+        torch.manual_seed(i); np.random.seed(i); random.seed(i)                           # train_sr.py:439-443
+        args.log_file = "log" + str(i) + ".txt"
+        user_length = 895510                                                              # train_sr.py:447
+        item_length = 447410                                                              # train_sr.py:450
+        root = os.path.join(args.data_root, f"{args.dataset_type}_dataset")
+        ds_train = DualDomainSeqDataset(seq_len=args.seq_len, isTrain=True, neg_nums=args.neg_nums, long_length=args.long_length,
+                                        pad_id=item_length + 1, seed=i,
+                                        csv_path=os.path.join(root, f"{args.domain_type}_train{int(args.overlap_ratio * 100)}.csv"))
+        ds_val = DualDomainSeqDataset(seq_len=args.seq_len, isTrain=False, neg_nums=args.neg_nums, long_length=args.long_length,
+                                      pad_id=item_length + 1, seed=1000 + i, csv_path=os.path.join(root, f"{args.domain_type}_test.csv"))
+        train_batches = DeviceBatches(ds_train, args.bs, shuffle=True, device=args.device, seed=i)
+        val_batches = DeviceBatches(ds_val, args.bs, shuffle=False, device=args.device, seed=i)
+        item_length *= 2                                                                  # train_sr.py:456 ("for pad id")
+        user_length *= 2
+        cls = {"gru4rec": GRU4Rec, "sasrec": SASRec, "bert4rec": BERT4Rec}.get(args.model.lower())
+        if cls is None:
+            raise SystemExit(f"unknown --model {args.model!r} (gru4rec | sasrec | bert4rec)")
+        torch.cuda.set_device(torch.device(args.device))
+        model = cls(user_length=user_length, user_emb_dim=args.emb_dim, item_length=item_length, item_emb_dim=args.emb_dim,
+                    seq_len=args.seq_len, hid_dim=args.hid_dim, bs=args.bs, isInC=args.isInC, isItC=args.isItC, threshold1=args.ts1,
+                    threshold2=args.ts2, lr=args.lr, seed=i)
+        init_logger(args.model_dir, args.log_file)
+        logger.info(vars(args))
+        best = train(model, train_batches, args, val_batches)
+        summary.append(best)
+    keys = sorted(summary[0]) if summary else []
+    init_logger(args.model_dir, "log_all.txt")
+    for k in keys:                                                                        # train_sr.py:549-569: mean / std over the seeds
+        v = np.array([s[k] for s in summary])
+        logger.info(f"{k[0]} {k[1]}: mean {v.mean():.4f} std {v.std():.4f}")
+    return summary
+
+
+if __name__ == "__main__":
+    main()

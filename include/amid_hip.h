@@ -141,6 +141,8 @@ int amid_scorer_bwd_f32(const float* u, const float* items, const float* w1, con
                         const float* p1, const float* p2, const float* dp1, const float* dp2, int B, int NI, int D, int hid, float* du,
                         float* ditems, float* part /* [B][amid_scorer_part_floats] */, void* stream);
 int amid_sum_vector_f32(const float* v, int n, float* out, void* stream);
+/* replaces: torch.nn.LayerNorm(D, eps) applied row-wise (last_layernorm of a standalone Log2feats, model_seq.py:385) */
+int amid_layernorm_rows_f32(const float* x, const float* w, const float* b, long long rows, int D, float eps, float* y, void* stream);
 
 /* ---- hipGraph capture / replay of a whole step; HIP events on the caller's stream ---------------- */
 int amid_graph_capture_begin(void* stream);

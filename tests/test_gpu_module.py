@@ -1,0 +1,207 @@
+"""GPU tests of the drop-in boundary: reference class names / constructor signatures / state_dict keys,
+the reference training loop with torch.optim.Adam, the fused train_step, and the train_sr.py CLI."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import amid_oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    P = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P/")}
+    B = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("B/")}
+    return z, P, B
+
+
+def relmax(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def make_model(P, T, lr=5e-4, seed=0):
+    from amid_amd.model_seq import SASRec
+    n_rows, D = P["item_emb_layer.emb_item.weight"].shape
+    hid = P["predictModule.fc.0.weight"].shape[0]
+    m = SASRec(10, D, n_rows, D, T, hid, 4, False, False, 0.5, 0.5, lr=lr, seed=seed).cuda()     # reference ctor order, .cuda() as train_sr.py:461
+    m.load_state_dict(P)
+    return m
+
+
+def test_state_dict_keys_and_shapes_match_reference():
+    z, P, B = load_golden("g3_sasrec_eval.npz")
+    m = make_model(P, 50)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(P.keys())            # same names, same order as the reference's state_dict
+    for k in P:
+        assert tuple(sd[k].shape) == tuple(P[k].shape), k
+        assert torch.equal(sd[k].cpu(), P[k]), k
+    assert sum(p.numel() for p in m.parameters()) == sum(v.numel() for v in P.values())
+
+
+def test_forward_matches_reference_golden_and_squeezes():
+    z, P, B = load_golden("g3_sasrec_eval_neg9.npz")
+    m = make_model(P, 50).eval()
+    cu = {k: v.cuda() for k, v in B.items()}
+    with torch.no_grad():
+        p1, p2 = m(None, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], None, None, False)
+    assert tuple(p1.shape) == z["p1"].shape
+    assert relmax(p1, z["p1"]) < 1e-4 and relmax(p2, z["p2"]) < 1e-4
+
+
+def test_reference_training_loop_with_torch_adam():
+    """optimizer.zero_grad(); loss.backward(); optimizer.step() exactly as train_sr.py:203-215."""
+    T, Bn, D, hid, n_items, seed = 20, 8, 64, 16, 150, 21
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=2)
+    m = make_model(P, T, seed=seed)
+    m.train()
+    optimizer = torch.optim.Adam(m.parameters(), lr=1e-3)
+    criterion_cls = torch.nn.BCELoss(reduction="none")
+    Po = {k: v.clone() for k, v in P.items()}
+    opt_o = orc.DenseAdam(Po, lr=1e-3)
+    for t in range(1, 4):
+        batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=300 + t)
+        cu = {k: v.cuda() for k, v in batch.items()}
+        predict_d1, predict_d2 = m(None, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], None, None)
+        mask_d1 = (1 - cu["domain_id"]).unsqueeze(1)
+        mask_d2 = cu["domain_id"].unsqueeze(1)
+        loss = torch.mean(criterion_cls(predict_d1, cu["label"]) * mask_d1 + criterion_cls(predict_d2, cu["label"]) * mask_d2)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        loss_o = orc.train_step("sasrec", Po, opt_o, batch, orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=t))
+        assert abs(loss.item() - loss_o) < 5e-5, t
+    sd = m.state_dict()
+    for k, v in Po.items():
+        d = (sd[k].cpu() - v).abs()
+        if k.endswith("in_proj_bias"):
+            n = v.numel() // 3
+            d = torch.cat((d[:n], d[2 * n:]))
+        assert float(d.max()) < 1e-4, k
+
+
+def test_fused_train_step_matches_oracle_and_graph_is_reused():
+    T, Bn, D, hid, n_items, seed = 20, 8, 64, 16, 150, 5
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=3)
+    m = make_model(P, T, lr=1e-3, seed=seed)
+    m.train()
+    Po = {k: v.clone() for k, v in P.items()}
+    opt_o = orc.DenseAdam(Po, lr=1e-3)
+    for t in range(1, 5):
+        batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=400 + t)
+        cu = {k: v.cuda() for k, v in batch.items()}
+        loss = m.train_step(cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"])
+        loss_o = orc.train_step("sasrec", Po, opt_o, batch, orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=t))
+        assert abs(loss.item() - loss_o) < 5e-5, t
+    assert m._last_plan.graph is not None
+    sd = m.state_dict()                  # flushes lazily-updated rows
+    assert relmax(sd["item_emb_layer.emb_item.weight"], Po["item_emb_layer.emb_item.weight"]) < 1e-5
+    assert relmax(sd["predictModule.fc.0.weight"], Po["predictModule.fc.0.weight"]) < 1e-4
+    # eval forward after fused training sees the flushed table
+    m.eval()
+    batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=3, seed=9)
+    cu = {k: v.cuda() for k, v in batch.items()}
+    with torch.no_grad():
+        p1, _ = m(None, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], None, None, False)
+    q1, _ = orc.sasrec_forward(Po, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"])
+    assert relmax(p1, q1) < 1e-4
+
+
+def test_out_of_range_item_raises_like_nn_embedding():
+    P = orc.random_params(orc.sasrec_param_shapes(50, 64, 10, 8), seed=1)
+    m = make_model(P, 10).eval()
+    batch = orc.synthetic_batch(4, 10, 49, pad_id=49, neg=1, seed=1)
+    batch["seq_d1"][0, 3] = 50
+    cu = {k: v.cuda() for k, v in batch.items()}
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            m(None, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], None, None, False)
+
+
+def test_embitemlayer_forward_backward():
+    from amid_amd.model_seq import embItemLayerEnhance
+    z = np.load(os.path.join(GOLDEN, "g1_gather.npz"))
+    emb = embItemLayerEnhance(z["table"].shape[0], z["table"].shape[1])
+    with torch.no_grad():
+        emb.emb_item.weight.copy_(torch.from_numpy(z["table"]))
+    idx = torch.from_numpy(z["idx"]).cuda()
+    out = emb(idx)
+    assert np.array_equal(out.detach().cpu().numpy(), z["rows"])
+    # backward (HIP sort-unique + segment reduce) on a width the kernels are built for
+    emb = embItemLayerEnhance(500, 64)
+    idx = torch.randint(0, 500, (6, 9)).cuda()
+    idx[:, :5] = 499
+    out = emb(idx)
+    g = torch.randn_like(out)
+    out.backward(g)
+    want = torch.zeros(500, 64, dtype=torch.float64)
+    want.index_add_(0, idx.reshape(-1).cpu(), g.reshape(-1, 64).double().cpu())
+    assert float((emb.emb_item.weight.grad.cpu().double() - want).abs().max()) < 1e-5
+
+
+def test_log2feats_standalone_matches_golden():
+    from amid_amd.model_seq import Log2feats
+    z = np.load(os.path.join(GOLDEN, "g2_log2feats_d128.npz"))
+    enc = Log2feats(10, 128, 100, 128, 50, 16)
+    sd = {k[len("P/sac1."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P/sac1.")}
+    assert set(sd) == set(enc.state_dict())
+    enc.load_state_dict(sd)
+    y = enc(torch.from_numpy(z["x"]).cuda())
+    assert float((y.cpu() - torch.from_numpy(z["y"])).abs().max()) < 2e-5
+
+
+def test_predict_module_standalone():
+    from amid_amd.model_seq import predictModule
+    pm = predictModule(64, 16)
+    g = torch.Generator().manual_seed(0)
+    u1, u2, it = torch.randn(5, 64, generator=g), torch.randn(5, 64, generator=g), torch.randn(5, 70, 64, generator=g)
+    p1, p2 = pm(u1.cuda(), u2.cuda(), it.cuda())
+    P = {"predictModule." + k: v.detach().cpu() for k, v in pm.state_dict().items()}
+    q1, q2 = orc.predict_module(u1, u2, it, P)
+    assert relmax(p1, q1) < 1e-5 and relmax(p2, q2) < 1e-5
+
+
+def test_unbuilt_models_fail_loudly():
+    from amid_amd import model_seq
+    for cls in (model_seq.GRU4Rec, model_seq.BERT4Rec):
+        with pytest.raises(NotImplementedError):
+            cls(10, 128, 100, 128, 20, 32, 4, False, False, 0.5, 0.5)
+    with pytest.raises(NotImplementedError):
+        model_seq.SASRec(10, 128, 100, 128, 20, 32, 4, False, True, 0.5, 0.5)
+
+
+def _write_csv(path, n, rng, lo1, hi1, lo2, hi2):
+    rows = ["user_id,seq_d1,seq_d2,domain_id"]
+    for u in range(n):
+        dom = int(rng.random() < 0.5)
+        l1 = int(rng.integers(1 if dom == 0 else 0, 9))
+        l2 = int(rng.integers(1 if dom == 1 else 0, 9))
+        s1 = [int(x) for x in rng.integers(lo1, hi1, l1)]
+        s2 = [int(x) for x in rng.integers(lo2, hi2, l2)]
+        rows.append(f'{u},"{json.dumps(s1)}","{json.dumps(s2)}",{dom}')
+    with open(path, "w") as f:
+        f.write("\n".join(rows) + "\n")
+
+
+def test_train_sr_cli_end_to_end(tmp_path):
+    """The reference's command line on a synthetic CSV pair with the reference's column layout."""
+    from amid_amd.train_sr import main
+    rng = np.random.default_rng(0)
+    root = tmp_path / "amazon_dataset"
+    root.mkdir()
+    _write_csv(root / "toy_train75.csv", 300, rng, 1, 400, 400, 900)
+    _write_csv(root / "toy_test.csv", 80, rng, 1, 400, 400, 900)
+    summary = main(["--data_root", str(tmp_path), "-ds", "amazon", "-dm", "toy", "--overlap_ratio", "0.75", "--model", "sasrec",
+                    "--bs", "32", "--seq_len", "20", "--emb_dim", "64", "--hid_dim", "16", "--epoch", "2", "--neg_nums", "19",
+                    "--seeds", "1", "-md", str(tmp_path / "model")])
+    assert len(summary) == 1
+    best = summary[0]
+    assert ("d1", "HR@10") in best and ("d2", "MRR") in best
+    assert all(0.0 <= v <= 1.0 for v in best.values())
+    assert (tmp_path / "model" / "log0.txt").exists()
