@@ -17,6 +17,7 @@ struct AdamCoef {              // per-step scalars, as torch computes them (doub
     float beta2, w2;           // beta2, 1 - beta2
     float neg_step_size;       // -(lr / (1 - beta1^t))
     float bc2_sqrt;            // sqrt(1 - beta2^t)
+    float inv_bc2_sqrt;        // 1 / bc2_sqrt (replay fast path)
     float eps;
 };
 
@@ -27,6 +28,7 @@ __device__ __forceinline__ AdamCoef adam_coef(const StepState& st, double b1pow,
     c.w2 = (float)(1.0 - st.beta2);
     c.neg_step_size = (float)(-(st.lr / (1.0 - b1pow)));
     c.bc2_sqrt = (float)sqrt(1.0 - b2pow);
+    c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2pow));
     c.eps = (float)st.eps;
     return c;
 }
@@ -38,6 +40,23 @@ __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g,
     p = __fadd_rn(p, __fdiv_rn(__fmul_rn(c.neg_step_size, m), denom));          // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+// Zero-gradient step used by the lazy replay: same recurrences for m and v (exact: one fma / one multiply), the
+// parameter increment through the hardware sqrt / reciprocal (<= 1 ulp each) instead of the IEEE divide sequences --
+// a row idle for g steps replays g of these, and the precise divides made the catch-up kernel throughput-bound
+// (31 us per step at a 60-step gap).  The real-gradient step of every touched row stays on the exact path.
+__device__ __forceinline__ void adam_elem_idle(float& p, float& m, float& v, const AdamCoef& c) {
+    m = __fmaf_rn(c.w1, -m, m);
+    v = __fmul_rn(v, c.beta2);
+    const float denom = __fmaf_rn(__builtin_amdgcn_sqrtf(v), c.inv_bc2_sqrt, c.eps);
+    p = __fmaf_rn(__fmul_rn(c.neg_step_size, m), __builtin_amdgcn_rcpf(denom), p);
+}
+__device__ __forceinline__ void adam_quad_idle(float4& p, float4& m, float4& v, const AdamCoef& c) {
+    adam_elem_idle(p.x, m.x, v.x, c);
+    adam_elem_idle(p.y, m.y, v.y, c);
+    adam_elem_idle(p.z, m.z, v.z, c);
+    adam_elem_idle(p.w, m.w, v.w, c);
+}
+
 __device__ __forceinline__ void adam_quad(float4& p, float4& m, float4& v, float4 g, const AdamCoef& c) {
     adam_elem(p.x, m.x, v.x, g.x, c);
     adam_elem(p.y, m.y, v.y, g.y, c);
@@ -45,15 +64,29 @@ __device__ __forceinline__ void adam_quad(float4& p, float4& m, float4& v, float
     adam_elem(p.w, m.w, v.w, g.w, c);
 }
 
-// replay zero-gradient steps s = from .. to (inclusive) on one float4 of a row
-__device__ __forceinline__ void replay_quad(float4& p, float4& m, float4& v, long long from, long long to, const StepState& st) {
-    double b1pow = pow(st.beta1, (double)(from - 1)), b2pow = pow(st.beta2, (double)(from - 1));
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long s = from; s <= to; ++s) {
-        b1pow *= st.beta1;
-        b2pow *= st.beta2;
-        adam_quad(p, m, v, zero, adam_coef(st, b1pow, b2pow));
+// Per-step coefficients of the last COEF_TAB steps (t - COEF_TAB + 1 .. t), computed once per block:
+// a row that was idle for g steps replays g zero-gradient steps, and evaluating pow / sqrt / divide in double
+// for every replayed step in every lane dominated the catch-up kernel (31 us -> a few us at a 60-step gap).
+constexpr int COEF_TAB = 256;
+
+__device__ __forceinline__ void fill_coef_table(AdamCoef* tab, const StepState& st) {
+    for (int i = threadIdx.x; i < COEF_TAB; i += blockDim.x) {
+        const long long s = st.step - (COEF_TAB - 1) + i;
+        if (s >= 1) tab[i] = adam_coef(st, pow(st.beta1, (double)s), pow(st.beta2, (double)s));
     }
+    __syncthreads();
+}
+
+__device__ __forceinline__ AdamCoef coef_at(const AdamCoef* tab, const StepState& st, long long s) {
+    const long long i = s - (st.step - (COEF_TAB - 1));
+    if (i >= 0) return tab[i];
+    return adam_coef(st, pow(st.beta1, (double)s), pow(st.beta2, (double)s));     // gaps longer than the table: slow path
+}
+
+// replay zero-gradient steps s = from .. to (inclusive) on one float4 of a row
+__device__ __forceinline__ void replay_quad(float4& p, float4& m, float4& v, long long from, long long to, const StepState& st,
+                                            const AdamCoef* tab) {
+    for (long long s = from; s <= to; ++s) adam_quad_idle(p, m, v, coef_at(tab, st, s));
 }
 
 // mode 0: catch-up (steps last+1 .. t-1, g = 0)   mode 1: apply (catch-up if needed, then step t with g)
@@ -62,12 +95,15 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(float* __restrict__
                                                              int* __restrict__ last, const int* __restrict__ uniq_ids,
                                                              const int* __restrict__ n_uniq_p, const float* __restrict__ uniq_grad, int D,
                                                              const StepState* __restrict__ stp, float grad_scale) {
+    __shared__ AdamCoef tab[COEF_TAB];
     const StepState st = *stp;
     const long long t = st.step;
     const int U = *n_uniq_p;
     const int sub = threadIdx.x & 31;
     const int q = D >> 2;
     const int hw0 = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), n_hw = gridDim.x * (blockDim.x >> 5);
+    if (blockIdx.x * (blockDim.x >> 5) >= U) return;              // block-uniform: nothing to do for this block
+    fill_coef_table(tab, st);
     for (int u = hw0; u < U; u += n_hw) {
         const long long r = uniq_ids[u];
         const long long l = last[r];
@@ -76,10 +112,10 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(float* __restrict__
         for (int c = sub; c < q; c += 32) {
             const long long off = r * D + 4 * c;
             float4 p = ld4(table + off), m = ld4(m_tab + off), v = ld4(v_tab + off);
-            if (lag) replay_quad(p, m, v, l + 1, t - 1, st);
+            if (lag) replay_quad(p, m, v, l + 1, t - 1, st, tab);
             if (MODE == 1) {
                 const float4 g = f4scale(ld4(uniq_grad + (long long)u * D + 4 * c), grad_scale);
-                adam_quad(p, m, v, g, adam_coef(st, pow(st.beta1, (double)t), pow(st.beta2, (double)t)));
+                adam_quad(p, m, v, g, tab[COEF_TAB - 1]);
             }
             st4(table + off, p); st4(m_tab + off, m); st4(v_tab + off, v);
         }
@@ -91,18 +127,20 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(float* __restrict__
 // bring every row with pending zero-gradient steps up to date (before eval / checkpoint / parity dumps)
 __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
                                                               int* __restrict__ last, long long n_rows, int D, const StepState* __restrict__ stp) {
+    __shared__ AdamCoef tab[COEF_TAB];
     const StepState st = *stp;
     const long long t = st.step;
     const int sub = threadIdx.x & 31;
     const int q = D >> 2;
     const long long hw0 = (long long)blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), n_hw = (long long)gridDim.x * (blockDim.x >> 5);
+    fill_coef_table(tab, st);
     for (long long r = hw0; r < n_rows; r += n_hw) {
         const long long l = last[r];
         if (!(l > 0 && l < t)) continue;
         for (int c = sub; c < q; c += 32) {
             const long long off = r * D + 4 * c;
             float4 p = ld4(table + off), m = ld4(m_tab + off), v = ld4(v_tab + off);
-            replay_quad(p, m, v, l + 1, t, st);
+            replay_quad(p, m, v, l + 1, t, st, tab);
             st4(table + off, p); st4(m_tab + off, m); st4(v_tab + off, v);
         }
         __builtin_amdgcn_wave_barrier();
@@ -130,6 +168,53 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, 
 }
 
 __global__ void step_begin_kernel(StepState* st) { st->step += 1; }
+
+// One launch for the whole optimizer: blocks [0, dense_blocks) run dense Adam over the flat buffer, the rest apply the
+// lazy row Adam to the touched table rows (independent memory, so the two roles need no ordering).
+__global__ __launch_bounds__(256) void optimizer_step_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                             const float* __restrict__ g, long long n, int dense_blocks,
+                                                             float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
+                                                             int* __restrict__ last, const int* __restrict__ uniq_ids,
+                                                             const int* __restrict__ n_uniq_p, const float* __restrict__ uniq_grad, int D,
+                                                             const StepState* __restrict__ stp, float grad_scale) {
+    __shared__ AdamCoef tab[COEF_TAB];
+    const StepState st = *stp;
+    if ((int)blockIdx.x < dense_blocks) {
+        const AdamCoef c = adam_coef(st, pow(st.beta1, (double)st.step), pow(st.beta2, (double)st.step));
+        const long long stride = (long long)dense_blocks * blockDim.x * 4;
+        for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+            if (i + 4 <= n) {
+                float4 pp = ld4(p + i), mm = ld4(m + i), vv = ld4(v + i);
+                adam_quad(pp, mm, vv, f4scale(ld4(g + i), grad_scale), c);
+                st4(p + i, pp); st4(m + i, mm); st4(v + i, vv);
+            } else {
+                for (long long k = i; k < n; ++k) adam_elem(p[k], m[k], v[k], g[k] * grad_scale, c);
+            }
+        }
+        return;
+    }
+    const long long t = st.step;
+    const int U = *n_uniq_p;
+    const int rb = blockIdx.x - dense_blocks, n_rb = gridDim.x - dense_blocks;
+    if (rb * 8 >= U) return;
+    fill_coef_table(tab, st);
+    const int sub = threadIdx.x & 31;
+    const int q = D >> 2;
+    for (int u = rb * 8 + (threadIdx.x >> 5); u < U; u += n_rb * 8) {
+        const long long r = uniq_ids[u];
+        const long long l = last[r];
+        const bool lag = (l > 0 && l < t - 1);
+        for (int c = sub; c < q; c += 32) {
+            const long long off = r * D + 4 * c;
+            float4 pp = ld4(table + off), mm = ld4(m_tab + off), vv = ld4(v_tab + off);
+            if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
+            adam_quad(pp, mm, vv, f4scale(ld4(uniq_grad + (long long)u * D + 4 * c), grad_scale), tab[COEF_TAB - 1]);
+            st4(table + off, pp); st4(m_tab + off, mm); st4(v_tab + off, vv);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (sub == 0) last[r] = (int)t;
+    }
+}
 
 }  // namespace amid
 
@@ -193,6 +278,21 @@ extern "C" int amid_adam_dense_f32(float* p, float* m, float* v, const float* g,
     if (b < 1) b = 1;
     if (b > 2048) b = 2048;
     adam_dense_kernel<<<(int)b, 256, 0, (hipStream_t)stream>>>(p, m, v, g, n, (const StepState*)step_state, grad_scale);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_optimizer_step_f32(float* p, float* m, float* v, const float* g, long long n, float* table, float* m_tab, float* v_tab,
+                                       int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max, const float* uniq_grad, int D,
+                                       float grad_scale, const void* step_state, void* stream) {
+    AMID_CHECK_ARG(p && m && v && g && n > 0 && table && m_tab && v_tab && last && uniq_ids && n_uniq && uniq_grad && step_state && D > 0 &&
+                   (D % 4) == 0 && n_uniq_max > 0);
+    long long db = (n / 4 + 255) / 256;
+    if (db < 1) db = 1;
+    if (db > 1024) db = 1024;
+    const int rb = rows_grid(n_uniq_max);
+    optimizer_step_kernel<<<(int)db + rb, 256, 0, (hipStream_t)stream>>>(p, m, v, g, n, (int)db, table, m_tab, v_tab, last, uniq_ids, n_uniq,
+                                                                          uniq_grad, D, (const StepState*)step_state, grad_scale);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_indices_kernel(const long long* __restrict__ i_node, const long long* __restrict__ neg,
                                     const long long* __restrict__ seq_d1, const long long* __restrict__ seq_d2,
-                                    int B, int T, int n_neg, long long n_rows, int* __restrict__ idx_all, int* __restrict__ err) {
+                                    int B, int T, int n_neg, long long n_rows, int* __restrict__ idx_all, int* __restrict__ err,
+                                    StepState* __restrict__ bump) {
+    if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) bump->step += 1;      // folded amid_step_begin (nobody in this launch reads it)
     const int M = B * T, NI = 1 + n_neg;
     const int n = 2 * M + B * NI;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -139,19 +141,21 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
 //   dP_g[t] = sum_b dxe[g,b,t]               (fixed-order tree => bitwise reproducible)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_bwd_kernel(float* __restrict__ dxg, const unsigned char* __restrict__ tmq,
-                                                        int B, int T, int D, float* __restrict__ dpos0, float* __restrict__ dpos1,
+                                                        int B, int T, int D, int nsplit, float* __restrict__ dpos_part,
                                                         const RngState* __restrict__ rng, int train, unsigned thr16, float scale) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [8][D]
-    const int t = blockIdx.x, g = blockIdx.y;
+    const int t = blockIdx.x, g = blockIdx.y, z = blockIdx.z;
     const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;        // 8 row groups
     const int q = D >> 2;
     const int M = B * T;
+    const int per = (B + nsplit - 1) / nsplit;
+    const int b_beg = z * per, b_end = min(B, b_beg + per);
     unsigned long long seed = 0;
     unsigned step = 0;
     if (train) { seed = rng->seed; step = (unsigned)rng->step; }
     for (int c = sub; c < q; c += 32) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int b = rg; b < B; b += 8) {
+        for (int b = b_beg + rg; b < b_end; b += 8) {
             const int local = b * T + t;
             const long long r = (long long)g * M + local;
             float4 v = ld4(dxg + r * D + 4 * c);
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(float* __restrict__ dxg,
         st4(red + rg * D + 4 * c, acc);
     }
     __syncthreads();
-    float* dp = (g ? dpos1 : dpos0) + (long long)t * D;
+    float* dp = dpos_part + (((long long)z * 2 + g) * T + t) * D;     // [nsplit][2][T][D]
     for (int e = threadIdx.x; e < D; e += blockDim.x) {
         float s = 0.f;
 #pragma unroll
@@ -205,12 +209,14 @@ extern "C" int amid_gather_rows_f32(const float* table, long long n_rows, int D,
 }
 
 extern "C" int amid_pack_indices(const long long* i_node, const long long* neg, const long long* seq_d1, const long long* seq_d2,
-                                 int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* stream) {
+                                 int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* step_state_to_bump,
+                                 void* stream) {
     AMID_CHECK_ARG(i_node && neg && seq_d1 && seq_d2 && idx_all && err_flag && B > 0 && T > 0 && n_neg >= 0);
     int n = 2 * B * T + B * (1 + n_neg);
     int blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    pack_indices_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(i_node, neg, seq_d1, seq_d2, B, T, n_neg, n_rows, idx_all, err_flag);
+    pack_indices_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(i_node, neg, seq_d1, seq_d2, B, T, n_neg, n_rows, idx_all, err_flag,
+                                                                  (StepState*)step_state_to_bump);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
@@ -231,14 +237,15 @@ extern "C" int amid_embed_fwd_f32(const float* table, const int* idx_all, const 
     return AMID_OK;
 }
 
-extern "C" int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, float* dpos0, float* dpos1,
+extern "C" int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part,
                                   const void* rng_state, int train, float p_drop, void* stream) {
-    AMID_CHECK_ARG(dxg && tmq && dpos0 && dpos1 && B > 0 && T > 0 && D > 0 && (D % 4) == 0);
+    AMID_CHECK_ARG(dxg && tmq && dpos_part && B > 0 && T > 0 && D > 0 && (D % 4) == 0 && nsplit > 0 && nsplit <= B);
     AMID_CHECK_ARG(!train || rng_state != nullptr);
     const int tr = (train && p_drop > 0.f) ? 1 : 0;
-    embed_bwd_kernel<<<dim3(T, 2), 256, 8 * D * sizeof(float), (hipStream_t)stream>>>(dxg, tmq, B, T, D, dpos0, dpos1,
-                                                                                      (const RngState*)rng_state, tr, keep_thr16(p_drop),
-                                                                                      tr ? 1.0f / (1.0f - p_drop) : 1.0f);
+    embed_bwd_kernel<<<dim3(T, 2, nsplit), 256, 8 * D * sizeof(float), (hipStream_t)stream>>>(dxg, tmq, B, T, D, nsplit, dpos_part,
+                                                                                               (const RngState*)rng_state, tr,
+                                                                                               keep_thr16(p_drop),
+                                                                                               tr ? 1.0f / (1.0f - p_drop) : 1.0f);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -1,0 +1,381 @@
+// Fused head of the SASRec step, one workgroup per batch row b (both domains):
+//   head_fwd : u_g[b] = mean_t LN_last(x[g,b,t,:])  (model_seq.py:385, :432-434)  ->  scorer (predictModule.forward,
+//              model_seq.py:40-54)  ->  masked BCE partial + dLoss/dp (train_sr.py:203-212)
+//   head_bwd : scorer backward  ->  d u_g[b]  ->  LN_last' + mean' for the T rows of (g, b)
+// One launch each instead of lnmean + scorer (+ sum) launches; every short kernel of the step costs ~5 us of
+// timeline whatever it does.  The first scorer weight W1 [hid, 2D] is staged TRANSPOSED in LDS (row stride hid+1:
+// conflict-free both for "lane = hidden unit" and for "lane = feature" accesses), so no dot product waits on a
+// global load.  Extra workgroups (blockIdx >= B) of head_bwd refresh the transposed copies of the encoder's
+// projection weights for the backward GEMMs.
+#include "common.h"
+
+namespace amid {
+
+struct HeadArgs {
+    const float* x;            // [2, B, T, D] output of the last encoder layer
+    const float* lnw[2]; const float* lnb[2];   // last_layernorm (null: no LN, BERT4Rec)
+    const float* items;        // [B, NI, D] gathered item rows
+    const float* w1; const float* b1; const float* w2; const float* b2;
+    const float* labels;       // [B, NI] or null
+    const long long* domain;   // [B] or null
+    float* u;                  // [2, B, D]
+    float* p1; float* p2; float* dp1; float* dp2;   // [B, NI]
+    float* loss_part;          // [B]
+    // backward
+    float* dx;                 // [2, B, T, D]
+    float* ditems;             // [B, NI, D]
+    float* ln_part;            // [2B][2][D]
+    float* sc_part;            // [B][hid*2D + 2 hid + 1]
+    const float* tr_src[32]; float* tr_dst[32]; int n_tr;   // square D x D transposes done by the extra blocks
+    int B, T, NI, D, hid;
+    float eps;
+};
+
+__device__ __forceinline__ void stage_w1t(float* __restrict__ w1t, const float* __restrict__ w1, int D2, int hid) {
+    // w1t[e][j] = w1[j][e], row stride hid + 1
+    const int q = D2 >> 2;
+    for (int i = threadIdx.x; i < hid * q; i += blockDim.x) {
+        const int j = i / q, c = i - j * q;
+        const float4 v = ld4(w1 + (long long)j * D2 + 4 * c);
+        float* o = w1t + (4 * c) * (hid + 1) + j;
+        o[0] = v.x; o[hid + 1] = v.y; o[2 * (hid + 1)] = v.z; o[3 * (hid + 1)] = v.w;
+    }
+}
+
+// LN_last + mean over T for (g, b): 8 row groups of 32 lanes; result u_s[D] (LDS) and u (global)
+__device__ __forceinline__ void lnmean_rows(const HeadArgs& a, int g, int b, float* __restrict__ red /* [8][D] */, float* __restrict__ u_s) {
+    const int D = a.D, T = a.T, q = D >> 2;
+    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const bool use_ln = a.lnw[0] != nullptr;
+    const float* w = a.lnw[g];
+    const float* bb = a.lnb[g];
+    for (int c = sub; c < q; c += 32) st4(red + rg * D + 4 * c, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int t = rg; t < T; t += 8) {
+        const float* row = a.x + (((long long)g * a.B + b) * T + t) * D;
+        float mean = 0.f, rstd = 1.f;
+        if (use_ln) {
+            float s = 0.f;
+            for (int c = sub; c < q; c += 32) s += f4hsum(ld4(row + 4 * c));
+            mean = group_sum<32>(s) / D;
+            float vs = 0.f;
+            for (int c = sub; c < q; c += 32) { float4 v = ld4(row + 4 * c); v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean; vs += f4hsum(f4mul(v, v)); }
+            rstd = 1.0f / sqrtf(group_sum<32>(vs) / D + a.eps);
+        }
+        for (int c = sub; c < q; c += 32) {
+            float4 v = ld4(row + 4 * c);
+            if (use_ln) {
+                const float4 ww = ld4(w + 4 * c), b4 = ld4(bb + 4 * c);
+                v.x = (v.x - mean) * rstd * ww.x + b4.x; v.y = (v.y - mean) * rstd * ww.y + b4.y;
+                v.z = (v.z - mean) * rstd * ww.z + b4.z; v.w = (v.w - mean) * rstd * ww.w + b4.w;
+            }
+            float* rp = red + rg * D + 4 * c;
+            st4(rp, f4add(ld4(rp), v));
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < D; e += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k * D + e];
+        s /= T;
+        u_s[e] = s;
+        a.u[((long long)g * a.B + b) * D + e] = s;
+    }
+    __syncthreads();
+}
+
+// LDS carve (floats): w1t [2D][hid+1] | u_s [2][D] | au [2][hid] | da [2][hid] | dw2 [hid+4] | ci [64][hid+1] | dc [64][hid+1] | scratch [16][D]
+struct HeadLds {
+    float *w1t, *u_s, *au, *da, *dw2, *ci, *dc, *scr;
+    __device__ HeadLds(float* base, int D, int hid) {
+        w1t = base; u_s = w1t + 2 * D * (hid + 1); au = u_s + 2 * D; da = au + 2 * hid; dw2 = da + 2 * hid;
+        ci = dw2 + hid + 4; dc = ci + 64 * (hid + 1); scr = dc + 64 * (hid + 1);
+        scr = base + ((scr - base + 3) & ~3);
+    }
+};
+__host__ __device__ inline size_t head_lds_floats(int D, int hid) {
+    size_t f = (size_t)2 * D * (hid + 1) + 2 * D + 4 * hid + hid + 4 + 128 * (hid + 1);
+    f = (f + 3) & ~(size_t)3;
+    return f + 16 * D;
+}
+
+// au[d][j] = b1[j] + sum_e w1t[e][j] u_d[e]
+__device__ __forceinline__ void user_half(const HeadArgs& a, const HeadLds& s) {
+    const int D = a.D, hid = a.hid;
+    for (int dj = threadIdx.x; dj < 2 * hid; dj += blockDim.x) {
+        const int d = dj / hid, j = dj - d * hid;
+        float acc = a.b1[j];
+        const float* ur = s.u_s + d * D;
+        for (int e = 0; e < D; ++e) acc = fmaf(s.w1t[e * (hid + 1) + j], ur[e], acc);
+        s.au[dj] = acc;
+    }
+}
+// ci[n][j] = sum_e w1t[D+e][j] item[n][e] for the chunk's items (items read from global: each lane group of `hid` lanes shares a row)
+__device__ __forceinline__ void item_half(const HeadArgs& a, const HeadLds& s, int b, int n0, int nn) {
+    const int D = a.D, hid = a.hid;
+    for (int nj = threadIdx.x; nj < nn * hid; nj += blockDim.x) {
+        const int n = nj / hid, j = nj - n * hid;
+        const float* ir = a.items + ((long long)b * a.NI + n0 + n) * D;
+        float acc = 0.f;
+        for (int e = 0; e < D; e += 4) {
+            const float4 it = ld4(ir + e);
+            const float* wp = s.w1t + (D + e) * (hid + 1) + j;
+            acc = fmaf(wp[0], it.x, acc); acc = fmaf(wp[hid + 1], it.y, acc);
+            acc = fmaf(wp[2 * (hid + 1)], it.z, acc); acc = fmaf(wp[3 * (hid + 1)], it.w, acc);
+        }
+        s.ci[n * (hid + 1) + j] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const HeadLds s(sm, a.D, a.hid);
+    const int b = blockIdx.x, D = a.D, hid = a.hid, NI = a.NI;
+    stage_w1t(s.w1t, a.w1, 2 * D, hid);
+    lnmean_rows(a, 0, b, s.scr, s.u_s);
+    lnmean_rows(a, 1, b, s.scr, s.u_s + D);
+    user_half(a, s);
+    float lsum = 0.f;
+    for (int n0 = 0; n0 < NI; n0 += 64) {
+        const int nn = min(64, NI - n0);
+        __syncthreads();
+        item_half(a, s, b, n0, nn);
+        __syncthreads();
+        for (int nd = threadIdx.x; nd < nn * 2; nd += blockDim.x) {
+            const int n = nd >> 1, d = nd & 1;
+            float z = a.b2[0];
+            for (int j = 0; j < hid; ++j) z = fmaf(a.w2[j], fmaxf(s.au[d * hid + j] + s.ci[n * (hid + 1) + j], 0.f), z);
+            const float p = 1.0f / (1.0f + expf(-z));
+            const long long o = (long long)b * NI + n0 + n;
+            (d ? a.p2 : a.p1)[o] = p;
+            if (a.labels) {
+                const float y = a.labels[o];
+                const float md = a.domain[b] ? (d ? 1.f : 0.f) : (d ? 0.f : 1.f);
+                const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.0f - p), -100.f);
+                const float inv = 1.0f / ((float)a.B * (float)NI);
+                lsum += -(y * lp + (1.f - y) * l1p) * md * inv;
+                (d ? a.dp2 : a.dp1)[o] = md * inv * (p - y) / fmaxf((1.f - p) * p, 1e-12f);   // torch binary_cross_entropy_backward
+            }
+        }
+    }
+    if (a.labels) {
+        __syncthreads();
+        lsum = group_sum<64>(lsum);
+        if (lane_id() == 0) s.scr[wave_id()] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) a.loss_part[b] = ((s.scr[0] + s.scr[1]) + (s.scr[2] + s.scr[3]));
+    }
+}
+
+// dx rows of (g, b) from du_s[D] (LDS): dx = LN_last'(du / T ; x) ; partial d gamma / d beta -> ln_part[(g*B+b)][2][D]
+__device__ __forceinline__ void lnmean_rows_bwd(const HeadArgs& a, int g, int b, const float* __restrict__ du_s, float* __restrict__ red /* [8][2][D] */) {
+    const int D = a.D, T = a.T, q = D >> 2;
+    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const bool use_ln = a.lnw[0] != nullptr;
+    const float* w = a.lnw[g];
+    const float invT = 1.0f / T;
+    for (int c = sub; c < 2 * q; c += 32) st4(red + rg * 2 * D + 4 * c, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int t = rg; t < T; t += 8) {
+        const long long ro = (((long long)g * a.B + b) * T + t) * D;
+        if (!use_ln) {
+            for (int c = sub; c < q; c += 32) st4(a.dx + ro + 4 * c, f4scale(ld4(du_s + 4 * c), invT));
+            continue;
+        }
+        float sx = 0.f;
+        for (int c = sub; c < q; c += 32) sx += f4hsum(ld4(a.x + ro + 4 * c));
+        const float mean = group_sum<32>(sx) / D;
+        float vs = 0.f;
+        for (int c = sub; c < q; c += 32) { float4 v = ld4(a.x + ro + 4 * c); v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean; vs += f4hsum(f4mul(v, v)); }
+        const float rstd = 1.0f / sqrtf(group_sum<32>(vs) / D + a.eps);
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = sub; c < q; c += 32) {
+            const float4 v = ld4(a.x + ro + 4 * c), dy = f4scale(ld4(du_s + 4 * c), invT), gy = f4mul(dy, ld4(w + 4 * c));
+            const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+            a1 += f4hsum(gy);
+            a2 += f4hsum(f4mul(gy, xh));
+        }
+        const float c1 = group_sum<32>(a1) / D, c2 = group_sum<32>(a2) / D;
+        for (int c = sub; c < q; c += 32) {
+            const float4 v = ld4(a.x + ro + 4 * c), dy = f4scale(ld4(du_s + 4 * c), invT), gy = f4mul(dy, ld4(w + 4 * c));
+            const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+            st4(a.dx + ro + 4 * c, make_float4(rstd * (gy.x - c1 - xh.x * c2), rstd * (gy.y - c1 - xh.y * c2), rstd * (gy.z - c1 - xh.z * c2),
+                                               rstd * (gy.w - c1 - xh.w * c2)));
+            float* rp = red + rg * 2 * D + 4 * c;
+            st4(rp, f4add(ld4(rp), f4mul(dy, xh)));
+            st4(rp + D, f4add(ld4(rp + D), dy));
+        }
+    }
+    __syncthreads();
+    if (use_ln) {
+        for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sacc += red[k * 2 * D + e];
+            a.ln_part[((long long)g * a.B + b) * 2 * D + e] = sacc;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = a.D, hid = a.hid, NI = a.NI;
+    if ((int)blockIdx.x >= a.B) {
+        // ---- extra workgroups: out[j][i] = in[i][j] for the projection weights, 32x32 tiles ----
+        const int tiles = D / 32, per = tiles * tiles;
+        float (*tile)[33] = reinterpret_cast<float (*)[33]>(sm);
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int w = (int)blockIdx.x - a.B; w < a.n_tr * per; w += (int)gridDim.x - a.B) {
+            const int m = w / per, tt = w - m * per, bx = (tt % tiles) * 32, by = (tt / tiles) * 32;
+            const float* __restrict__ src = a.tr_src[m];
+            float* __restrict__ dst = a.tr_dst[m];
+            __syncthreads();
+            for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(long long)(by + r) * D + bx + tx];
+            __syncthreads();
+            for (int r = ty; r < 32; r += 8) dst[(long long)(bx + r) * D + by + tx] = tile[tx][r];
+        }
+        return;
+    }
+    const HeadLds s(sm, D, hid);
+    const int b = blockIdx.x;
+    const int P = hid * 2 * D + 2 * hid + 1;
+    float* part = a.sc_part + (long long)b * P;
+    stage_w1t(s.w1t, a.w1, 2 * D, hid);
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) s.u_s[e] = a.u[((long long)(e / D) * a.B + b) * D + (e % D)];
+    for (int e = threadIdx.x; e < 2 * hid; e += blockDim.x) s.da[e] = 0.f;
+    for (int e = threadIdx.x; e < hid + 1; e += blockDim.x) s.dw2[e] = 0.f;
+    __syncthreads();
+    user_half(a, s);
+    // item half of dW1 accumulates over item chunks in registers: thread owns (j, e) pairs je = tid + 256 k
+    for (int n0 = 0; n0 < NI; n0 += 64) {
+        const int nn = min(64, NI - n0);
+        __syncthreads();
+        item_half(a, s, b, n0, nn);
+        __syncthreads();
+        if (threadIdx.x < hid) {                       // hidden unit j walks the chunk's items in order
+            const int j = threadIdx.x;
+            float s_da0 = 0.f, s_da1 = 0.f, s_w2 = 0.f;
+            const float w2j = a.w2[j];
+            for (int n = 0; n < nn; ++n) {
+                const long long o = (long long)b * NI + n0 + n;
+                const float p1 = a.p1[o], p2 = a.p2[o];
+                const float dz1 = a.dp1[o] * p1 * (1.f - p1), dz2 = a.dp2[o] * p2 * (1.f - p2);
+                const float c = s.ci[n * (hid + 1) + j];
+                const float h1 = fmaxf(s.au[j] + c, 0.f), h2 = fmaxf(s.au[hid + j] + c, 0.f);
+                const float g1 = h1 > 0.f ? dz1 * w2j : 0.f, g2 = h2 > 0.f ? dz2 * w2j : 0.f;
+                s_w2 += dz1 * h1 + dz2 * h2;
+                s_da0 += g1; s_da1 += g2;
+                s.dc[n * (hid + 1) + j] = g1 + g2;
+            }
+            s.da[j] += s_da0; s.da[hid + j] += s_da1; s.dw2[j] += s_w2;
+        }
+        if (threadIdx.x == 64) {
+            float acc = 0.f;
+            for (int n = 0; n < nn; ++n) {
+                const long long o = (long long)b * NI + n0 + n;
+                const float p1 = a.p1[o], p2 = a.p2[o];
+                acc += a.dp1[o] * p1 * (1.f - p1) + a.dp2[o] * p2 * (1.f - p2);
+            }
+            s.dw2[hid] += acc;
+        }
+        __syncthreads();
+        // d item[n][e] = sum_j dc[n][j] w1t[D+e][j]
+        for (int ne = threadIdx.x; ne < nn * D; ne += blockDim.x) {
+            const int n = ne / D, e = ne - n * D;
+            float acc = 0.f;
+            const float* wp = s.w1t + (D + e) * (hid + 1);
+            for (int j = 0; j < hid; ++j) acc = fmaf(s.dc[n * (hid + 1) + j], wp[j], acc);
+            a.ditems[((long long)b * NI + n0 + n) * D + e] = acc;
+        }
+        // dW1[j][D+e] (+)= sum_n dc[n][j] item[n][e]
+        for (int je = threadIdx.x; je < hid * D; je += blockDim.x) {
+            const int j = je / D, e = je - j * D;
+            float acc = 0.f;
+            for (int n = 0; n < nn; ++n) acc = fmaf(s.dc[n * (hid + 1) + j], a.items[((long long)b * NI + n0 + n) * D + e], acc);
+            float* dst = part + j * 2 * D + D + e;
+            *dst = (n0 == 0) ? acc : *dst + acc;
+        }
+    }
+    __syncthreads();
+    // user halves: du_d[e] = sum_j da[d][j] w1t[e][j]  -> scratch region [2][D] reused from ci (dead now)
+    float* du_s = s.ci;
+    for (int de = threadIdx.x; de < 2 * D; de += blockDim.x) {
+        const int d = de / D, e = de - d * D;
+        float acc = 0.f;
+        const float* wp = s.w1t + e * (hid + 1);
+        for (int j = 0; j < hid; ++j) acc = fmaf(s.da[d * hid + j], wp[j], acc);
+        du_s[de] = acc;
+    }
+    for (int je = threadIdx.x; je < hid * D; je += blockDim.x) {
+        const int j = je / D, e = je - j * D;
+        part[j * 2 * D + e] = s.da[j] * s.u_s[e] + s.da[hid + j] * s.u_s[D + e];
+    }
+    for (int j = threadIdx.x; j < hid; j += blockDim.x) {
+        part[hid * 2 * D + j] = s.da[j] + s.da[hid + j];            // db1
+        part[hid * 2 * D + hid + j] = s.dw2[j];                     // dW2
+    }
+    if (threadIdx.x == 0) part[hid * 2 * D + 2 * hid] = s.dw2[hid];   // db2
+    __syncthreads();
+    lnmean_rows_bwd(a, 0, b, du_s, s.scr);
+    lnmean_rows_bwd(a, 1, b, du_s + D, s.scr);
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+static int head_fill(HeadArgs& a, const float* x, const float* const* lnw, const float* const* lnb, const float* items, const float* w1,
+                     const float* b1, const float* w2, const float* b2, int B, int T, int NI, int D, int hid, float eps) {
+    if (!(x && items && w1 && b1 && w2 && b2) || B <= 0 || T <= 0 || NI <= 0 || D <= 0 || (D % 32) != 0 || hid <= 0 || hid > 64 || (hid % 4) != 0)
+        return AMID_ERR_ARG;
+    a.x = x; a.items = items; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    for (int g = 0; g < 2; ++g) { a.lnw[g] = lnw ? lnw[g] : nullptr; a.lnb[g] = lnb ? lnb[g] : nullptr; }
+    a.B = B; a.T = T; a.NI = NI; a.D = D; a.hid = hid; a.eps = eps; a.n_tr = 0;
+    return AMID_OK;
+}
+
+static int head_lds_attr(const void* fn, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return AMID_OK;
+}
+
+// ln_w / ln_b: host arrays of 2 device pointers (both null arrays: no LayerNorm, plain mean over T)
+extern "C" int amid_head_fwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
+                                 const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id, int B,
+                                 int T, int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1, float* dp2,
+                                 float* loss_part, void* stream) {
+    HeadArgs a = {};
+    if (int e = head_fill(a, x, ln_w, ln_b, items, w1, b1, w2, b2, B, T, NI, D, hid, eps)) return e;
+    AMID_CHECK_ARG(u && p1 && p2 && (!labels || (domain_id && dp1 && dp2 && loss_part)));
+    a.labels = labels; a.domain = domain_id; a.u = u; a.p1 = p1; a.p2 = p2; a.dp1 = dp1; a.dp2 = dp2; a.loss_part = loss_part;
+    const size_t lds = head_lds_floats(D, hid) * sizeof(float);
+    if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
+    if (int e = head_lds_attr((const void*)head_fwd_kernel, lds)) return e;
+    head_fwd_kernel<<<B, 256, lds, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// tr_src / tr_dst: optional host arrays of n_tr (<= 32) device pointers of square D x D matrices transposed by extra workgroups
+extern "C" int amid_head_bwd_f32(const float* x, const float* const* ln_w, const float* u, const float* items, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, const float* p1, const float* p2, const float* dp1, const float* dp2, int B,
+                                 int T, int NI, int D, int hid, float eps, float* dx, float* ditems, float* ln_part, float* sc_part,
+                                 const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream) {
+    HeadArgs a = {};
+    if (int e = head_fill(a, x, ln_w, nullptr, items, w1, b1, w2, b2, B, T, NI, D, hid, eps)) return e;
+    AMID_CHECK_ARG(u && p1 && p2 && dp1 && dp2 && dx && ditems && sc_part && (!ln_w || ln_part) && n_tr >= 0 && n_tr <= 32);
+    a.u = const_cast<float*>(u); a.p1 = const_cast<float*>(p1); a.p2 = const_cast<float*>(p2);
+    a.dp1 = const_cast<float*>(dp1); a.dp2 = const_cast<float*>(dp2);
+    a.dx = dx; a.ditems = ditems; a.ln_part = ln_part; a.sc_part = sc_part; a.n_tr = n_tr;
+    for (int i = 0; i < n_tr; ++i) { AMID_CHECK_ARG(tr_src && tr_dst && tr_src[i] && tr_dst[i]); a.tr_src[i] = tr_src[i]; a.tr_dst[i] = tr_dst[i]; }
+    const size_t lds = head_lds_floats(D, hid) * sizeof(float);
+    if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
+    if (int e = head_lds_attr((const void*)head_bwd_kernel, lds)) return e;
+    const int extra = n_tr > 0 ? min(n_tr * (D / 32) * (D / 32), 96) : 0;
+    head_bwd_kernel<<<B + extra, 256, lds, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}

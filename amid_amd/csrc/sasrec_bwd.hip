@@ -93,74 +93,86 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_bwd_kernel(const FfnBwdA
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+    TileRegs<D> dz, aux;                                  // dz = dxo * ~tm is needed again for the residual path
+    WRegs<D, D> wr;
+    load_tile<D>(dz, a.dxo, row0, nrows, D);
+    load_w<D, D>(wr, a.w2T[g], D);
+    load_tile<D>(aux, a.h, row0, nrows, D);               // relu output: consumed by the first epilogue
     // 1. dpre2 = (dxo * ~tm) * drop2  -> A image + global
-    for (int r = RP::first_row(); r < nrt * 16; r += RP::RPP) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nrows) {
-            const long long off = (row0 + r) * D + 4 * sub;
-            v = ld4(a.dxo + off);
-            if (a.tmq) v = apply_tm(v, a.tmq[(row0 + r) * (D / 4) + sub]);
-            if (a.train) v = f4mul(v, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN2), step, (unsigned long long)(local0 + r) * D + 4 * sub,
-                                                    a.thr16, a.scale));
-            st4(a.dpre2 + off, v);
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = RP::first_row() + i * RP::RPP;
+        if (r < TileCfg<D>::ROWS) {
+            float4 v = dz.v[i];
+            if (r < nrows) {
+                if (a.tmq) v = apply_tm(v, a.tmq[(row0 + r) * (D / 4) + sub]);
+                dz.v[i] = v;
+                if (a.train) v = f4mul(v, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN2), step, (unsigned long long)(local0 + r) * D + 4 * sub,
+                                                        a.thr16, a.scale));
+                st4(a.dpre2 + (row0 + r) * D + 4 * sub, v);
+            }
+            st4(As + r * LDK + 4 * sub, v);
         }
-        st4(As + r * LDK + 4 * sub, v);
     }
-    stage_weights<D, D>(Ws, a.w2T[g], D, 0);
+    w_to_lds<D, D>(Ws, wr);
     __syncthreads();
+    load_w<D, D>(wr, a.w1T[g], D);
     f32x4 acc[WaveMap<D>::ACC];
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc, nrt);
+    mma_tile<D, D>(As, Ws, acc);
     __syncthreads();
-    acc_to_lds<D>(Cs, LDC, acc, nrt);
+    acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();
     // 2. dpre1 = dh * relu'(h) * drop1   (h > 0 implies the unit was kept by drop1)
-    for (int r = RP::first_row(); r < nrt * 16; r += RP::RPP) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nrows) {
-            const long long off = (row0 + r) * D + 4 * sub;
-            const float4 dh = ld4(Cs + r * LDC + 4 * sub), hv = ld4(a.h + off);
-            v.x = hv.x > 0.f ? dh.x * a.scale : 0.f; v.y = hv.y > 0.f ? dh.y * a.scale : 0.f;
-            v.z = hv.z > 0.f ? dh.z * a.scale : 0.f; v.w = hv.w > 0.f ? dh.w * a.scale : 0.f;
-            st4(a.dpre1 + off, v);
-        }
-        st4(As + r * LDK + 4 * sub, v);
-    }
-    __syncthreads();
-    stage_weights<D, D>(Ws, a.w1T[g], D, 0);
-    __syncthreads();
-    zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc, nrt);
-    __syncthreads();
-    acc_to_lds<D>(Cs, LDC, acc, nrt);
-    __syncthreads();
-    // 3. dy = C + dz ; dr = LN2'(dy ; r) -> global + A image of the out-proj data gradient
-    float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
-    {
-        const float4 gam = ld4(a.ln_w[g] + 4 * sub);
-        for (int r = RP::first_row(); r < nrt * 16; r += RP::RPP) {
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = RP::first_row() + i * RP::RPP;
+        if (r < TileCfg<D>::ROWS) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < nrows) {                                   // nrows is uniform over the QPR lanes of a row
-                const long long off = (row0 + r) * D + 4 * sub;
-                float4 dz = ld4(a.dxo + off);
-                if (a.tmq) dz = apply_tm(dz, a.tmq[(row0 + r) * (D / 4) + sub]);
-                const float4 dy = f4add(ld4(Cs + r * LDC + 4 * sub), dz);
-                v = ln_bwd_row<RP::QPR>(dy, ld4(a.r + off), gam, D, a.ln_eps, dgam, dbet);
-                st4(a.dr + off, v);
+            if (r < nrows) {
+                const float4 dh = ld4(Cs + r * LDC + 4 * sub), hv = aux.v[i];
+                v.x = hv.x > 0.f ? dh.x * a.scale : 0.f; v.y = hv.y > 0.f ? dh.y * a.scale : 0.f;
+                v.z = hv.z > 0.f ? dh.z * a.scale : 0.f; v.w = hv.w > 0.f ? dh.w * a.scale : 0.f;
+                st4(a.dpre1 + (row0 + r) * D + 4 * sub, v);
             }
             st4(As + r * LDK + 4 * sub, v);
         }
     }
     __syncthreads();
-    stage_weights<D, D>(Ws, a.woT[g], D, 0);
+    w_to_lds<D, D>(Ws, wr);
+    __syncthreads();
+    load_w<D, D>(wr, a.woT[g], D);
+    load_tile<D>(aux, a.r, row0, nrows, D);               // LN2 input rows for the next epilogue
+    zero_acc<D>(acc);
+    mma_tile<D, D>(As, Ws, acc);
+    __syncthreads();
+    acc_to_lds<D>(Cs, LDC, acc);
+    __syncthreads();
+    // 3. dy = C + dz ; dr = LN2'(dy ; r) -> global + A image of the out-proj data gradient
+    float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
+    {
+        const float4 gam = ld4(a.ln_w[g] + 4 * sub);
+#pragma unroll
+        for (int i = 0; i < RP::NR; ++i) {
+            const int r = RP::first_row() + i * RP::RPP;
+            if (r < TileCfg<D>::ROWS) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < nrows) {                               // nrows is uniform over the QPR lanes of a row
+                    const float4 dy = f4add(ld4(Cs + r * LDC + 4 * sub), dz.v[i]);
+                    v = ln_bwd_row<RP::QPR>(dy, aux.v[i], gam, D, a.ln_eps, dgam, dbet);
+                    st4(a.dr + (row0 + r) * D + 4 * sub, v);
+                }
+                st4(As + r * LDK + 4 * sub, v);
+            }
+        }
+    }
+    __syncthreads();
+    w_to_lds<D, D>(Ws, wr);
     __syncthreads();
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc, nrt);
-    __syncthreads();
-    acc_to_lds<D>(Cs, LDC, acc, nrt);
-    __syncthreads();
-    for (int r = RP::first_row(); r < nrows; r += RP::RPP) st4(a.d_o + (row0 + r) * D + 4 * sub, ld4(Cs + r * LDC + 4 * sub));
-    // As is free now: use it as the reduction scratch for the LN partials
+    mma_tile<D, D>(As, Ws, acc);
+    acc_to_global<D>(a.d_o, row0, nrows, D, nullptr, acc);
+    __syncthreads();                                      // As is free now: reduction scratch for the LN partials
     ln_partials_out<D>(As, dgam, dbet, a.ln_part + (long long)blockIdx.x * 2 * D);
 }
 
@@ -190,33 +202,46 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_bwd_kernel(const QkvBwdA
     f32x4 acc_kv[WaveMap<D>::ACC], acc_q[WaveMap<D>::ACC];
     zero_acc<D>(acc_kv);
     zero_acc<D>(acc_q);
-    stage_rows<D>(As, a.dk, row0, nrows, D, 0, nrt * 16);
-    stage_weights<D, D>(Ws, a.wkT[g], D, 0);
+    TileRegs<D> ar, xr;
+    WRegs<D, D> wr;
+    load_tile<D>(ar, a.dk, row0, nrows, D);
+    load_w<D, D>(wr, a.wkT[g], D);
+    tile_to_lds<D>(As, ar);
+    w_to_lds<D, D>(Ws, wr);
     __syncthreads();
-    mma_tile<D, D>(As, Ws, acc_kv, nrt);
+    load_tile<D>(ar, a.dv, row0, nrows, D);               // next operand pair flies under the MFMAs
+    load_w<D, D>(wr, a.wvT[g], D);
+    mma_tile<D, D>(As, Ws, acc_kv);
     __syncthreads();
-    stage_rows<D>(As, a.dv, row0, nrows, D, 0, nrt * 16);
-    stage_weights<D, D>(Ws, a.wvT[g], D, 0);
+    tile_to_lds<D>(As, ar);
+    w_to_lds<D, D>(Ws, wr);
     __syncthreads();
-    mma_tile<D, D>(As, Ws, acc_kv, nrt);
+    load_tile<D>(ar, a.dq, row0, nrows, D);
+    load_w<D, D>(wr, a.wqT[g], D);
+    mma_tile<D, D>(As, Ws, acc_kv);
     __syncthreads();
-    stage_rows<D>(As, a.dq, row0, nrows, D, 0, nrt * 16);
-    stage_weights<D, D>(Ws, a.wqT[g], D, 0);
+    tile_to_lds<D>(As, ar);
+    w_to_lds<D, D>(Ws, wr);
     __syncthreads();
-    mma_tile<D, D>(As, Ws, acc_q, nrt);
+    load_tile<D>(ar, a.dr, row0, nrows, D);               // epilogue inputs: residual-path grad and the LN1 input rows
+    load_tile<D>(xr, a.x, row0, nrows, D);
+    mma_tile<D, D>(As, Ws, acc_q);
     __syncthreads();
     float* Ckv = As;                    // both operand images are dead: reuse them as the two C images
     float* Cq = Ws;
-    acc_to_lds<D>(Ckv, LDC, acc_kv, nrt);
-    acc_to_lds<D>(Cq, LDC, acc_q, nrt);
+    acc_to_lds<D>(Ckv, LDC, acc_kv);
+    acc_to_lds<D>(Cq, LDC, acc_q);
     __syncthreads();
     float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
     const float4 gam = ld4(a.ln_w[g] + 4 * sub);
-    for (int r = RP::first_row(); r < nrows; r += RP::RPP) {
-        const long long off = (row0 + r) * D + 4 * sub;
-        const float4 dqn = f4add(ld4(Cq + r * LDC + 4 * sub), ld4(a.dr + off));
-        const float4 dxl = ln_bwd_row<RP::QPR>(dqn, ld4(a.x + off), gam, D, a.ln_eps, dgam, dbet);
-        st4(a.dx + off, f4add(dxl, ld4(Ckv + r * LDC + 4 * sub)));
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = RP::first_row() + i * RP::RPP;
+        if (r < nrows) {
+            const float4 dqn = f4add(ld4(Cq + r * LDC + 4 * sub), ar.v[i]);
+            const float4 dxl = ln_bwd_row<RP::QPR>(dqn, xr.v[i], gam, D, a.ln_eps, dgam, dbet);
+            st4(a.dx + (row0 + r) * D + 4 * sub, f4add(dxl, ld4(Ckv + r * LDC + 4 * sub)));
+        }
     }
     __syncthreads();
     ln_partials_out<D>(Ws, dgam, dbet, a.ln_part + (long long)blockIdx.x * 2 * D);
@@ -258,18 +283,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_wgrad_kernel(const WgradArgs
 #pragma unroll
     for (int t = 0; t < KTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c0 = local_beg; c0 < local_end; c0 += WG_ROWS) {
+    constexpr int NRW = WG_ROWS / RPP;                 // rows of a chunk per thread (4 at D=128, 2 at D=64)
+    float4 py[NRW], px[NRW];
+    auto fetch = [&](int c0) {                         // issue every load of chunk c0 (zeros beyond the split's range)
         const int nr = min(WG_ROWS, local_end - c0);
         const long long grow = (long long)g * a.M + c0;
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) {
+            const int r = rl + i * RPP;
+            const bool ok = r < nr;
+            py[i] = ok ? ld4(dy + (grow + r) * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            px[i] = ok ? ld4(xin + (grow + r) * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (local_beg < local_end) fetch(local_beg);
+    for (int c0 = local_beg; c0 < local_end; c0 += WG_ROWS) {
+        const int nr = min(WG_ROWS, local_end - c0);
         __syncthreads();                               // previous chunk fully consumed
-        for (int r = rl; r < WG_ROWS; r += RPP) {
-            float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vx = vy;
-            if (r < nr) { vy = ld4(dy + (grow + r) * D + 4 * sub); vx = ld4(xin + (grow + r) * D + 4 * sub); }
-            bsum = f4add(bsum, vy);
-            st4(Ys + r * LD + 4 * sub, vy);
-            st4(Xs + r * LD + 4 * sub, vx);
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) {
+            const int r = rl + i * RPP;
+            bsum = f4add(bsum, py[i]);
+            st4(Ys + r * LD + 4 * sub, py[i]);
+            st4(Xs + r * LD + 4 * sub, px[i]);
         }
         __syncthreads();
+        if (c0 + WG_ROWS < local_end) fetch(c0 + WG_ROWS);     // next chunk flies under this chunk's MFMAs
         const int msteps = (nr + 3) >> 2;
         for (int ms = 0; ms < msteps; ++ms) {
             const int m = ms * 4 + gq;
@@ -316,12 +355,34 @@ __global__ __launch_bounds__(256) void transpose_sq_kernel(const TransposeArgs a
 // ---------------------------------------------------------------------------------------------
 struct ReduceEntry { const float* src; float* dst; long long stride; int n_part; int count; };
 
+// 256 threads = 32 consecutive elements x 8 partial groups; group pg sums partials pg, pg+8, ... with four
+// independent loads in flight, then the eight group sums are added in group order (fixed order => reproducible).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceEntry* __restrict__ entries) {
+    __shared__ float red[8][33];
     const ReduceEntry en = entries[blockIdx.y];
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < en.count; e += gridDim.x * 256) {
+    const int el = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    for (int e0 = blockIdx.x * 32; e0 < en.count; e0 += gridDim.x * 32) {       // block-uniform
+        const int e = e0 + el;
         float s = 0.f;
-        for (int k = 0; k < en.n_part; ++k) s += en.src[k * en.stride + e];
-        en.dst[e] = s;
+        if (e < en.count) {
+            const float* __restrict__ p = en.src + e;
+            int k = pg;
+            for (; k + 24 < en.n_part; k += 32) {
+                const float a = p[(long long)k * en.stride], b = p[(long long)(k + 8) * en.stride];
+                const float c = p[(long long)(k + 16) * en.stride], d = p[(long long)(k + 24) * en.stride];
+                s += a; s += b; s += c; s += d;
+            }
+            for (; k < en.n_part; k += 8) s += p[(long long)k * en.stride];
+        }
+        red[pg][el] = s;
+        __syncthreads();
+        if (pg == 0 && e < en.count) {
+            float t = red[0][el];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) t += red[g][el];
+            en.dst[e] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -329,7 +390,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceEntry*
 
 using namespace amid;
 
-template <int D> static constexpr size_t fused_lds_bytes_b() { return (size_t)(TileCfg<D>::A_FLOATS + D * TileCfg<D>::LDK) * sizeof(float); }
+template <int D> static constexpr size_t fused_lds_bytes_b() { return (size_t)(TileCfg<D>::A_FLOATS + TileCfg<D>::W_FLOATS) * sizeof(float); }
 
 static int make_geom_b(int M, int rows_per_tile, TileGeomB* tg) {
     if (M <= 0 || rows_per_tile <= 0 || rows_per_tile > TILE_ROWS) return AMID_ERR_ARG;
@@ -429,8 +490,8 @@ extern "C" int amid_reduce_entry_pack(void* host_buf, int index, const float* sr
 
 extern "C" int amid_reduce_partials_f32(const void* entries_dev, int n_entries, int max_count, void* stream) {
     AMID_CHECK_ARG(entries_dev && n_entries > 0 && max_count > 0);
-    int bx = (max_count + 255) / 256;
-    if (bx > 64) bx = 64;
+    int bx = (max_count + 31) / 32;
+    if (bx > 512) bx = 512;
     reduce_partials_kernel<<<dim3(bx, n_entries), 256, 0, (hipStream_t)stream>>>((const ReduceEntry*)entries_dev);
     AMID_LAUNCH_CHECK();
     return AMID_OK;

@@ -41,45 +41,47 @@ template <int D>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_fwd_kernel(const QkvFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using RP = RowPass<D>;
-    constexpr int LDK = TileCfg<D>::LDK, LDC = D + 4;
+    constexpr int LDK = TileCfg<D>::LDK;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
-    float* Cs = Ws;
     int g, nrows, local0; long long row0;
     tile_rows(a.tg, blockIdx.x, g, row0, nrows, local0);
     const int nrt = (nrows + 15) >> 4;
     const int sub = RP::sub();
-    stage_rows<D>(As, a.x, row0, nrows, D, 0, nrt * 16);
+    TileRegs<D> xr;
+    WRegs<D, D> wr;
+    load_tile<D>(xr, a.x, row0, nrows, D);
+    load_w<D, D>(wr, a.w_in[g] + (long long)1 * D * D, D);           // slab order k, v, q
+    const float4 lw = ld4(a.ln_w[g] + 4 * sub), lb = ld4(a.ln_b[g] + 4 * sub);
+    tile_to_lds<D>(As, xr);
+    w_to_lds<D, D>(Ws, wr);
+    __syncthreads();
     f32x4 acc[WaveMap<D>::ACC];
 #pragma unroll 1
     for (int s = 0; s < 3; ++s) {
-        // order k, v, q: the tile is normalised in place before the q slab
         const int which = (s == 0) ? 1 : (s == 1) ? 2 : 0;
-        if (which == 0) {
-            __syncthreads();
-            const float4 w = ld4(a.ln_w[g] + 4 * sub), b = ld4(a.ln_b[g] + 4 * sub);
-            for (int r = RP::first_row(); r < nrt * 16; r += RP::RPP) {
-                float4 x = ld4(As + r * LDK + 4 * sub);
-                float mean, rstd;
-                row_stats<RP::QPR>(x, D, a.ln_eps, mean, rstd);
-                float4 y;
-                y.x = (x.x - mean) * rstd * w.x + b.x; y.y = (x.y - mean) * rstd * w.y + b.y;
-                y.z = (x.z - mean) * rstd * w.z + b.z; y.w = (x.w - mean) * rstd * w.w + b.w;
-                st4(As + r * LDK + 4 * sub, y);
-                if (r < nrows) st4(a.qn + (row0 + r) * D + 4 * sub, y);
+        const int next = (s == 0) ? 2 : 0;
+        if (s < 2) load_w<D, D>(wr, a.w_in[g] + (long long)next * D * D, D);   // next slab's weights fly under the MFMAs
+        zero_acc<D>(acc);
+        mma_tile<D, D>(As, Ws, acc);
+        float* out = (which == 0) ? a.q : (which == 1) ? a.k : a.v;
+        acc_to_global<D>(out, row0, nrows, D, a.b_in[g] + which * D, acc);
+        if (s == 2) break;
+        __syncthreads();                                  // all waves are done with As / Ws of this slab
+        if (s == 1) {                                     // normalise the tile in place before the q slab; Qn also goes to global
+#pragma unroll
+            for (int i = 0; i < RP::NR; ++i) {
+                const int r = RP::first_row() + i * RP::RPP;
+                if (r < TileCfg<D>::ROWS) {                       // uniform over the QPR lanes of a row
+                    float mean, rstd;
+                    row_stats<RP::QPR>(xr.v[i], D, a.ln_eps, mean, rstd);
+                    const float4 y = ln_apply(xr.v[i], mean, rstd, lw, lb);
+                    st4(As + r * LDK + 4 * sub, y);
+                    if (r < nrows) st4(a.qn + (row0 + r) * D + 4 * sub, y);
+                }
             }
         }
-        stage_weights<D, D>(Ws, a.w_in[g] + (long long)which * D * D, D, 0);
-        __syncthreads();
-        zero_acc<D>(acc);
-        mma_tile<D, D>(As, Ws, acc, nrt);
-        __syncthreads();
-        acc_to_lds<D>(Cs, LDC, acc, nrt);
-        __syncthreads();
-        float* out = (which == 0) ? a.q : (which == 1) ? a.k : a.v;
-        const float4 bias = ld4(a.b_in[g] + which * D + 4 * sub);
-        for (int r = RP::first_row(); r < nrows; r += RP::RPP)
-            st4(out + (row0 + r) * D + 4 * sub, f4add(ld4(Cs + r * LDC + 4 * sub), bias));
+        w_to_lds<D, D>(Ws, wr);
         __syncthreads();
     }
 }
@@ -106,26 +108,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_fwd_kernel(const Oproj
     tile_rows(a.tg, blockIdx.x, g, row0, nrows, local0);
     const int nrt = (nrows + 15) >> 4;
     const int sub = RP::sub();
-    stage_rows<D>(As, a.o, row0, nrows, D, 0, nrt * 16);
-    stage_weights<D, D>(Ws, a.w_o[g], D, 0);
+    TileRegs<D> orr, res;
+    WRegs<D, D> wr;
+    load_tile<D>(orr, a.o, row0, nrows, D);
+    load_w<D, D>(wr, a.w_o[g], D);
+    load_tile<D>(res, a.qn, row0, nrows, D);              // residual rows: in flight during the MFMAs
+    const float4 bias = ld4(a.b_o[g] + 4 * sub), w = ld4(a.ln_w[g] + 4 * sub), b = ld4(a.ln_b[g] + 4 * sub);
+    tile_to_lds<D>(As, orr);
+    w_to_lds<D, D>(Ws, wr);
     __syncthreads();
     f32x4 acc[WaveMap<D>::ACC];
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc, nrt);
+    mma_tile<D, D>(As, Ws, acc);
     __syncthreads();
-    acc_to_lds<D>(Cs, LDC, acc, nrt);
+    acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();
-    const float4 bias = ld4(a.b_o[g] + 4 * sub), w = ld4(a.ln_w[g] + 4 * sub), b = ld4(a.ln_b[g] + 4 * sub);
-    for (int r = RP::first_row(); r < nrows; r += RP::RPP) {
-        const long long off = (row0 + r) * D + 4 * sub;
-        const float4 x = f4add(ld4(a.qn + off), f4add(ld4(Cs + r * LDC + 4 * sub), bias));
-        st4(a.r + off, x);
-        float mean, rstd;
-        row_stats<RP::QPR>(x, D, a.ln_eps, mean, rstd);
-        float4 y;
-        y.x = (x.x - mean) * rstd * w.x + b.x; y.y = (x.y - mean) * rstd * w.y + b.y;
-        y.z = (x.z - mean) * rstd * w.z + b.z; y.w = (x.w - mean) * rstd * w.w + b.w;
-        st4(a.y + off, y);
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = RP::first_row() + i * RP::RPP;
+        if (r < nrows) {
+            const long long off = (row0 + r) * D + 4 * sub;
+            const float4 x = f4add(res.v[i], f4add(ld4(Cs + r * LDC + 4 * sub), bias));
+            st4(a.r + off, x);
+            float mean, rstd;
+            row_stats<RP::QPR>(x, D, a.ln_eps, mean, rstd);
+            st4(a.y + off, ln_apply(x, mean, rstd, w, b));
+        }
     }
 }
 
@@ -152,21 +160,35 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_fwd_kernel(const FfnFwdA
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
-    stage_rows<D>(As, a.y, row0, nrows, D, 0, nrt * 16);
-    stage_weights<D, D>(Ws, a.w1[g], D, 0);
+    TileRegs<D> yr;                                       // kept: the residual of the second epilogue
+    WRegs<D, D> wr;
+    load_tile<D>(yr, a.y, row0, nrows, D);
+    load_w<D, D>(wr, a.w1[g], D);
+    unsigned tm[RP::NR];
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = RP::first_row() + i * RP::RPP;
+        tm[i] = (a.tmq && r < nrows) ? a.tmq[(row0 + r) * (D / 4) + sub] : 0u;
+    }
+    const float4 bias1 = ld4(a.b1[g] + 4 * sub), bias2 = ld4(a.b2[g] + 4 * sub);
+    tile_to_lds<D>(As, yr);
+    w_to_lds<D, D>(Ws, wr);
     __syncthreads();
+    load_w<D, D>(wr, a.w2[g], D);                         // second weight matrix flies under the first GEMM
     f32x4 acc[WaveMap<D>::ACC];
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc, nrt);
+    mma_tile<D, D>(As, Ws, acc);
     __syncthreads();
-    acc_to_lds<D>(Cs, LDC, acc, nrt);
+    acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();
-    {   // h = relu(drop1(C + c1)) -> global and the A image of the second GEMM
-        const float4 bias = ld4(a.b1[g] + 4 * sub);
-        for (int r = RP::first_row(); r < nrt * 16; r += RP::RPP) {
+    // h = relu(drop1(C + c1)) -> global and the A image of the second GEMM
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = RP::first_row() + i * RP::RPP;
+        if (r < TileCfg<D>::ROWS) {
             float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < nrows) {
-                hv = f4add(ld4(Cs + r * LDC + 4 * sub), bias);
+                hv = f4add(ld4(Cs + r * LDC + 4 * sub), bias1);
                 if (a.train) hv = f4mul(hv, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN1), step,
                                                           (unsigned long long)(local0 + r) * D + 4 * sub, a.thr16, a.scale));
                 hv.x = fmaxf(hv.x, 0.f); hv.y = fmaxf(hv.y, 0.f); hv.z = fmaxf(hv.z, 0.f); hv.w = fmaxf(hv.w, 0.f);
@@ -175,32 +197,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_fwd_kernel(const FfnFwdA
             st4(As + r * LDK + 4 * sub, hv);
         }
     }
-    __syncthreads();
-    stage_weights<D, D>(Ws, a.w2[g], D, 0);
+    __syncthreads();                                      // Cs (= Ws) fully read, As rewritten
+    w_to_lds<D, D>(Ws, wr);
     __syncthreads();
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc, nrt);
+    mma_tile<D, D>(As, Ws, acc);
     __syncthreads();
-    acc_to_lds<D>(Cs, LDC, acc, nrt);
+    acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();
-    {
-        const float4 bias = ld4(a.b2[g] + 4 * sub);
-        for (int r = RP::first_row(); r < nrows; r += RP::RPP) {
-            const long long off = (row0 + r) * D + 4 * sub;
-            float4 z = f4add(ld4(Cs + r * LDC + 4 * sub), bias);
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = RP::first_row() + i * RP::RPP;
+        if (r < nrows) {
+            float4 z = f4add(ld4(Cs + r * LDC + 4 * sub), bias2);
             if (a.train) z = f4mul(z, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN2), step,
                                                     (unsigned long long)(local0 + r) * D + 4 * sub, a.thr16, a.scale));
-            z = f4add(z, ld4(a.y + off));
-            if (a.tmq) {
-                const unsigned bits = a.tmq[(row0 + r) * (D / 4) + sub];
-                if (bits) {
-                    if (bits & 1u) z.x = 0.f;
-                    if (bits & 2u) z.y = 0.f;
-                    if (bits & 4u) z.z = 0.f;
-                    if (bits & 8u) z.w = 0.f;
-                }
+            z = f4add(z, yr.v[i]);
+            const unsigned bits = tm[i];
+            if (bits) {
+                if (bits & 1u) z.x = 0.f;
+                if (bits & 2u) z.y = 0.f;
+                if (bits & 4u) z.z = 0.f;
+                if (bits & 8u) z.w = 0.f;
             }
-            st4(a.xo + off, z);
+            st4(a.xo + (row0 + r) * D + 4 * sub, z);
         }
     }
 }
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_fwd_kernel(const FfnFwdA
 
 using namespace amid;
 
-template <int D> static constexpr size_t fused_lds_bytes() { return (size_t)(TileCfg<D>::A_FLOATS + D * TileCfg<D>::LDK) * sizeof(float); }
+template <int D> static constexpr size_t fused_lds_bytes() { return (size_t)(TileCfg<D>::A_FLOATS + TileCfg<D>::W_FLOATS) * sizeof(float); }
 
 static int make_geom(int M, int rows_per_tile, TileGeom* tg) {
     if (M <= 0 || rows_per_tile <= 0 || rows_per_tile > TILE_ROWS) return AMID_ERR_ARG;

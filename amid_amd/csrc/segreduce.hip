@@ -44,52 +44,64 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, long long ro
     else *p = r.v[0];
 }
 
-// phase A: one wave per 64-entry chunk of the sorted list
+// phase A: one wave per 64-entry chunk of the sorted list.  Lane l keeps (position, run index) of entry e0 + l; rows
+// are fetched eight at a time whatever runs they belong to (independent loads), then folded in order, flushing at
+// every run change: control flow is wave-uniform (run indices come from readlane-style shuffles), no global load
+// sits on the per-run critical path.
 template <int VEC>
 __global__ __launch_bounds__(256) void segreduce_chunks_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
-                                                               const int* __restrict__ seg_off, const int* __restrict__ n_uniq_p, int n,
-                                                               float* __restrict__ uniq_grad, float* __restrict__ partial) {
+                                                               const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
+                                                               float* __restrict__ partial) {
     const int D = VEC * 64;
     const int lane = lane_id();
     const int c = blockIdx.x * 4 + wave_id();
     const int e0 = c * SEG_CHUNK;
     if (e0 >= n) return;
-    const int U = *n_uniq_p;
-    const int e_end = min(e0 + SEG_CHUNK, n);
-    const int mypos = (e0 + lane < n) ? pos_sorted[e0 + lane] : 0;
-    int u = seg_of_entry(seg_off, U, e0);
-    int e = e0;
-    while (e < e_end) {
-        const int s_beg = seg_off[u], s_end = seg_off[u + 1];
-        const int stop = min(s_end, e_end);
-        RowVec<VEC> acc;
+    const int cnt = min(SEG_CHUNK, n - e0);
+    const bool valid = lane < cnt;
+    const int mypos = valid ? pos_sorted[e0 + lane] : 0;
+    const int mysg = valid ? seg_of[e0 + lane] : -1;
+    const int first_sg = __shfl(mysg, 0, 64), last_sg = __shfl(mysg, cnt - 1, 64);
+    const bool starts_before = (e0 > 0) && (seg_of[e0 - 1] == first_sg);
+    const bool continues_after = (e0 + cnt < n) && (seg_of[e0 + cnt] == last_sg);
+    RowVec<VEC> acc;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
-        int i = e;
-        for (; i + 8 <= stop; i += 8) {              // 8 independent row loads in flight
-            RowVec<VEC> r[8];
+    for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
+    int cur = first_sg;
+    auto flush = [&](int sg) {
+        const bool head_cut = (sg == first_sg) && starts_before;
+        const bool tail_cut = (sg == last_sg) && continues_after;
+        if (!head_cut && !tail_cut) store_row<VEC>(uniq_grad, sg, D, lane, acc);
+        else store_row<VEC>(partial, (long long)c * 2 + (head_cut ? 0 : 1), D, lane, acc);
+    };
+    for (int i = 0; i < cnt; i += 8) {
+        RowVec<VEC> r[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = load_row<VEC>(grad_rows, __shfl(mypos, i + j - e0, 64), D, lane);
+        for (int j = 0; j < 8; ++j) {
+            const int src = min(i + j, cnt - 1);
+            r[j] = load_row<VEC>(grad_rows, __shfl(mypos, src, 64), D, lane);
+        }
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8; ++j) {
+            if (i + j < cnt) {
+                const int sg = __shfl(mysg, i + j, 64);
+                if (sg != cur) {
+                    flush(cur);
+                    cur = sg;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
+                }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc.v[k] += r[j].v[k];
+            }
         }
-        for (; i < stop; ++i) {
-            const RowVec<VEC> r = load_row<VEC>(grad_rows, __shfl(mypos, i - e0, 64), D, lane);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc.v[k] += r.v[k];
-        }
-        if (s_beg >= e0 && s_end <= e_end) store_row<VEC>(uniq_grad, u, D, lane, acc);
-        else store_row<VEC>(partial, (long long)c * 2 + (s_beg < e0 ? 0 : 1), D, lane, acc);
-        e = stop;
-        ++u;
     }
+    flush(cur);
 }
 
 // phase B: the chunk in which a border-crossing run STARTS owns its final sum
 template <int VEC>
-__global__ __launch_bounds__(1024) void segreduce_spans_kernel(const int* __restrict__ seg_off, const int* __restrict__ n_uniq_p, int n,
+__global__ __launch_bounds__(1024) void segreduce_spans_kernel(const int* __restrict__ seg_off, const int* __restrict__ seg_of, int n,
                                                                const float* __restrict__ partial, float* __restrict__ uniq_grad) {
     const int D = VEC * 64;
     __shared__ float red[16][VEC * 64];
@@ -97,10 +109,11 @@ __global__ __launch_bounds__(1024) void segreduce_spans_kernel(const int* __rest
     const int e0 = c * SEG_CHUNK;
     if (e0 >= n) return;
     const int e_end = min(e0 + SEG_CHUNK, n);
-    const int U = *n_uniq_p;
-    const int u = seg_of_entry(seg_off, U, e_end - 1);
+    if (e_end >= n) return;                           // the last chunk's tail run cannot continue
+    const int u = seg_of[e_end - 1];
+    if (seg_of[e_end] != u) return;                   // block-uniform: the tail run ends inside this chunk
     const int s_beg = seg_off[u], s_end = seg_off[u + 1];
-    if (!(s_beg >= e0 && s_end > e_end)) return;     // block-uniform
+    if (s_beg < e0) return;                           // started in an earlier chunk: that chunk owns the sum
     const int c_last = (s_end - 1) / SEG_CHUNK;
     const int lane = lane_id(), w = wave_id();
     RowVec<VEC> acc;
@@ -142,16 +155,16 @@ extern "C" long long amid_segreduce_workspace_bytes(int n_idx, int D) {
     return nch * 2 * D * 4 + 256;
 }
 
-extern "C" int amid_embgrad_segreduce_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* n_uniq,
+extern "C" int amid_embgrad_segreduce_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of,
                                           int n_idx, int D, void* workspace, float* uniq_grad, void* stream) {
-    AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && n_uniq && workspace && uniq_grad && n_idx > 0);
+    AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0);
     if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK;
     float* partial = (float*)workspace;
 #define AMID_SEG_LAUNCH(VEC)                                                                                                  \
-    segreduce_chunks_kernel<VEC><<<(nch + 3) / 4, 256, 0, s>>>(grad_rows, pos_sorted, seg_off, n_uniq, n_idx, uniq_grad, partial); \
-    segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, n_uniq, n_idx, partial, uniq_grad);
+    segreduce_chunks_kernel<VEC><<<(nch + 3) / 4, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial); \
+    segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad);
     if (D == 64) { AMID_SEG_LAUNCH(1) } else if (D == 128) { AMID_SEG_LAUNCH(2) } else { AMID_SEG_LAUNCH(4) }
 #undef AMID_SEG_LAUNCH
     AMID_LAUNCH_CHECK();

@@ -3,6 +3,7 @@
 //   pos_sorted[N]  positions ordered by (id, position)         -> inverted index for the segment reduce
 //   uniq_ids[U]    distinct ids, ascending                     -> rows the lazy Adam has to touch
 //   seg_off[U+1]   run starts in pos_sorted (seg_off[U] = N)
+//   seg_of[N]      run index of every sorted entry (saves the segment reduce a binary search per chunk)
 //   n_uniq         U (device scalar; everything downstream reads it from memory => graph-replay safe)
 // There is no reference counterpart: the reference lets autograd build four dense 458 MB
 // gradients (nn.Embedding(sparse=False), model_seq.py:25) and runs dense Adam over them
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(1024) void heads_scan_kernel(int* __restrict__ blk_
 }
 
 __global__ __launch_bounds__(256) void heads_write_kernel(const int* __restrict__ keys, int n, const int* __restrict__ blk_base,
-                                                          int* __restrict__ uniq_ids, int* __restrict__ seg_off) {
+                                                          int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of) {
     __shared__ int wcnt[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = lane_id(), w = wave_id();
@@ -185,8 +186,9 @@ __global__ __launch_bounds__(256) void heads_write_kernel(const int* __restrict_
     __syncthreads();
     int off = blk_base[blockIdx.x];
     for (int k = 0; k < w; ++k) off += wcnt[k];
+    const int u = off + __popcll(m & ((2ull << lane) - 1ull)) - 1;      // run index of sorted entry i (heads up to and including lane)
+    if (i < n) seg_of[i] = u;
     if (head) {
-        const int u = off + __popcll(m & ((1ull << lane) - 1ull));
         uniq_ids[u] = keys[i];
         seg_off[u] = i;
     }
@@ -210,8 +212,8 @@ extern "C" long long amid_sort_unique_workspace_bytes(int n_idx) {
 }
 
 extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
-                                    int* seg_off, int* n_uniq, void* stream) {
-    AMID_CHECK_ARG(idx && workspace && pos_sorted && uniq_ids && seg_off && n_uniq && n_idx > 0 && n_rows > 0);
+                                    int* seg_off, int* seg_of, int* n_uniq, void* stream) {
+    AMID_CHECK_ARG(idx && workspace && pos_sorted && uniq_ids && seg_off && seg_of && n_uniq && n_idx > 0 && n_rows > 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = sort_nblk(n_idx);
     char* ws = (char*)workspace;
@@ -238,7 +240,7 @@ extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows,
     const int hblk = (n_idx + 255) / 256;
     heads_count_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads);
     heads_scan_kernel<<<1, 1024, 0, s>>>(blk_heads, hblk, n_uniq, seg_off, n_idx);
-    heads_write_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads, uniq_ids, seg_off);
+    heads_write_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads, uniq_ids, seg_off, seg_of);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

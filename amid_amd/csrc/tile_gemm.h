@@ -1,4 +1,4 @@
-// fp32 MFMA row-tile GEMM primitives shared by the fused encoder kernels (linear.hip).
+// fp32 MFMA row-tile GEMM primitives shared by the fused encoder kernels (sasrec_fwd.hip / sasrec_bwd.hip).
 //
 // Every dense op of the encoder is C[rows, N] = A[rows, K] * W[N, K]^T with K, N in {64, 128} per
 // slab and rows = B*T*2 (tens of thousands): weights are tiny (<= 64 KB), activations stream.  A
@@ -8,15 +8,22 @@
 // 128: at the headline shape (B 256, T 50, two domains) 25 600 rows / 256 CUs = exactly 100 rows per
 // CU; 16-row MFMA tiles waste 11 % there, 32-row tiles would waste 22 %.
 //
-// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).  Operand maps (cdna_hip_programming.md §3):
-//   A: lane l holds A[i = l & 15][k = l >> 4]   B: lane l holds B[k = l >> 4][j = l & 15]
-//   C: reg r of lane l is C[row = (l >> 4) * 4 + r][col = l & 15]
+// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain), issued as C^T = W * A^T:
+//   first operand : lane l holds W[n = l & 15][k = l >> 4]      second: lane l holds A[m = l & 15][k = l >> 4]
+//   result        : reg r of lane l is C[m = l & 15][n = (l >> 4) * 4 + r]
+// so a lane ends up with FOUR CONSECUTIVE COLUMNS of one row: accumulators leave as 16-byte stores
+// (to LDS or straight to global), a quarter of the instructions of the C = A W^T orientation.
 // Both operands come from K-contiguous LDS images ([row][K] for A, [n][K] for W) with one
 // ds_read_b128 per 4 MFMAs: lane (i, g) reads k = 16*kk + 4*g .. +3 and issue j of the group uses
-// element j, i.e. the four lane groups of issue j cover k = 16*kk + {0,4,8,12} + j.  A and B use the
-// same assignment, and a sum over k does not care about the order.
+// element j, i.e. the four lane groups of issue j cover k = 16*kk + {0,4,8,12} + j (same assignment
+// on both operands; a sum over k does not care about the order).
 // LDS row stride K + 8 floats: (K + 8) * 4 B = 2 * 256 + 32 (K = 128) or 256 + 32 (K = 64) puts the
 // 16 lanes of every ds_read_b128 lane group on 16 distinct 16-B slots (slot = 2 i + g mod 16).
+//
+// Latency: every global -> LDS staging and every row-wise epilogue input goes through REGISTER
+// prefetch (TileRegs / WRegs): all loads of a phase are issued back to back, before the MFMA loop
+// that precedes their use, instead of one dependent load per row-loop iteration (the first version of
+// these kernels spent ~2/3 of its time in such load->use chains: profiles/r01).
 #pragma once
 #include "common.h"
 
@@ -28,7 +35,12 @@ constexpr int GEMM_THREADS = 512;
 
 template <int K> struct TileCfg {
     static constexpr int LDK = K + 8;                 // A / W image row stride (floats)
-    static constexpr int A_FLOATS = TILE_ROWS * LDK;
+    // rows of the A image: every accumulator tile of every wave is computed unconditionally (no per-tile branch in
+    // the MFMA loop), so the image covers 16 * ACC * WR rows: 112 at D = 128, 128 at D = 64 (rows past the tile are zero)
+    static constexpr int ROWS = (K >= 128) ? TILE_ROWS : 128;
+    static constexpr int A_FLOATS = ROWS * LDK;
+    // second region: the W slab [K rows][LDK], reused as the C image [ROWS][K + 4]
+    static constexpr int W_FLOATS = (K * LDK > ROWS * (K + 4)) ? K * LDK : ROWS * (K + 4);
 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -40,54 +52,98 @@ template <int N> struct WaveMap {
     static constexpr int ACC = (TILE_RT + WR - 1) / WR;     // accumulator tiles per wave: 7 (N=128) or 4 (N=64)
 };
 
-// Copy `nrows` rows x K columns (global row stride ldg floats, first column k0) into an LDS image
-// [TILE_ROWS][K+8]; rows >= nrows are zero-filled so the MFMAs may run on whole 16-row tiles.
-template <int K>
-__device__ __forceinline__ void stage_rows(float* __restrict__ As, const float* __restrict__ g, long long row0, int nrows, int ldg, int k0,
-                                           int rows_to_fill) {
-    constexpr int QPR = K / 4;
-    constexpr int RPP = GEMM_THREADS / QPR;
-    const int sub = threadIdx.x % QPR, rl = threadIdx.x / QPR;
-    for (int r = rl; r < rows_to_fill; r += RPP) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nrows) v = ld4(g + (row0 + r) * ldg + k0 + 4 * sub);
-        st4(As + r * TileCfg<K>::LDK + 4 * sub, v);
+// Row-pass geometry over an N-column tile: QPR lanes own one row (a float4 each); the block covers
+// RPP rows per pass; a thread visits rows first_row() + i * RPP, i < NR, always with the same column quad.
+template <int N> struct RowPass {
+    static constexpr int QPR = N / 4;
+    static constexpr int RPP = GEMM_THREADS / QPR;
+    static constexpr int NR = (TILE_ROWS + RPP - 1) / RPP;  // 7 (N=128) or 4 (N=64)
+    __device__ static __forceinline__ int sub() { return threadIdx.x % QPR; }
+    __device__ static __forceinline__ int first_row() { return threadIdx.x / QPR; }
+};
+
+// a thread's share of a [rows, N] tile held in registers (row i of the thread = first_row() + i * RPP)
+template <int N> struct TileRegs { float4 v[RowPass<N>::NR]; };
+
+// issue every load of the thread's share; rows >= nrows read as zero
+template <int N>
+__device__ __forceinline__ void load_tile(TileRegs<N>& t, const float* __restrict__ g, long long row0, int nrows, int ldg) {
+    using RP = RowPass<N>;
+    const int sub = RP::sub(), r0 = RP::first_row();
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = r0 + i * RP::RPP;
+        t.v[i] = (r < nrows) ? ld4(g + (row0 + r) * ldg + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
-
-// W slab: N rows (output features) x K columns, global row stride ldw
-template <int K, int N>
-__device__ __forceinline__ void stage_weights(float* __restrict__ Ws, const float* __restrict__ w, int ldw, int k0) {
-    constexpr int QPR = K / 4;
-    constexpr int RPP = GEMM_THREADS / QPR;
-    const int sub = threadIdx.x % QPR, rl = threadIdx.x / QPR;
-#pragma unroll 4
-    for (int r = rl; r < N; r += RPP) st4(Ws + r * TileCfg<K>::LDK + 4 * sub, ld4(w + (long long)r * ldw + k0 + 4 * sub));
+// registers -> LDS image [TileCfg::ROWS][N + 8]; every image row is written (NR * RPP == ROWS), rows past the tile as zeros
+template <int N>
+__device__ __forceinline__ void tile_to_lds(float* __restrict__ As, const TileRegs<N>& t) {
+    using RP = RowPass<N>;
+    static_assert(RP::NR * RP::RPP == TileCfg<N>::ROWS, "row pass must cover the A image exactly");
+    const int sub = RP::sub(), r0 = RP::first_row();
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) st4(As + (r0 + i * RP::RPP) * TileCfg<N>::LDK + 4 * sub, t.v[i]);
 }
 
+// W slab [N rows (output features)][K] in registers / LDS
+template <int K, int N> struct WRegs {
+    static constexpr int QPR = K / 4, RPP = GEMM_THREADS / QPR, NR = N / RPP;
+    float4 v[NR];
+};
 template <int K, int N>
-__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Ws, f32x4 (&acc)[WaveMap<N>::ACC], int nrt) {
+__device__ __forceinline__ void load_w(WRegs<K, N>& t, const float* __restrict__ w, int ldw) {
+    using W = WRegs<K, N>;
+    const int sub = threadIdx.x % W::QPR, r0 = threadIdx.x / W::QPR;
+#pragma unroll
+    for (int i = 0; i < W::NR; ++i) t.v[i] = ld4(w + (long long)(r0 + i * W::RPP) * ldw + 4 * sub);
+}
+template <int K, int N>
+__device__ __forceinline__ void w_to_lds(float* __restrict__ Ws, const WRegs<K, N>& t) {
+    using W = WRegs<K, N>;
+    const int sub = threadIdx.x % W::QPR, r0 = threadIdx.x / W::QPR;
+#pragma unroll
+    for (int i = 0; i < W::NR; ++i) st4(Ws + (r0 + i * W::RPP) * TileCfg<K>::LDK + 4 * sub, t.v[i]);
+}
+
+// MFMA loop over the whole K of the slab.  Software-pipelined by hand: the operand fragments of k-step kk+1 are read
+// from LDS while the MFMAs of step kk issue, and inside a step the issue order is element-major / tile-minor, so
+// back-to-back MFMAs hit DIFFERENT accumulators (a 16x16x4 f32 MFMA issues every 32 cycles but needs 40 before a
+// dependent one).  No per-tile branch: all ACC tiles are always computed (rows past the tile are zeros in the image).
+// The first version (read -> wait -> 4 dependent MFMAs per tile, a branch per tile) ran the matrix pipe at ~37 %.
+template <int K, int N>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Ws, f32x4 (&acc)[WaveMap<N>::ACC]) {
     using WM = WaveMap<N>;
-    constexpr int LDK = TileCfg<K>::LDK;
+    constexpr int LDK = TileCfg<K>::LDK, ACC = WM::ACC, KK = K / 16;
     const int w = wave_id(), lane = lane_id();
     const int ct = w % WM::NT, rg = w / WM::NT;
     const int i = lane & 15, g = lane >> 4;
     const float* wp = Ws + (ct * 16 + i) * LDK + 4 * g;
-    const float* ap = As + i * LDK + 4 * g;
-#pragma unroll 2
-    for (int kk = 0; kk < K / 16; ++kk) {
-        const float4 b = ld4(wp + 16 * kk);
+    const float* ap = As + (rg * 16 + i) * LDK + 4 * g;
+    float4 b_cur = ld4(wp), a_cur[ACC];
 #pragma unroll
-        for (int t = 0; t < WM::ACC; ++t) {
-            const int rt = rg + t * WM::WR;
-            if (rt < nrt) {
-                const float4 a = ld4(ap + rt * 16 * LDK + 16 * kk);
-                acc[t] = mfma16(a.x, b.x, acc[t]);
-                acc[t] = mfma16(a.y, b.y, acc[t]);
-                acc[t] = mfma16(a.z, b.z, acc[t]);
-                acc[t] = mfma16(a.w, b.w, acc[t]);
-            }
+    for (int t = 0; t < ACC; ++t) a_cur[t] = ld4(ap + t * WM::WR * 16 * LDK);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        float4 b_nxt = b_cur, a_nxt[ACC];
+#pragma unroll
+        for (int t = 0; t < ACC; ++t) a_nxt[t] = a_cur[t];
+        if (kk + 1 < KK) {
+            b_nxt = ld4(wp + 16 * (kk + 1));
+#pragma unroll
+            for (int t = 0; t < ACC; ++t) a_nxt[t] = ld4(ap + t * WM::WR * 16 * LDK + 16 * (kk + 1));
         }
+#pragma unroll
+        for (int t = 0; t < ACC; ++t) acc[t] = mfma16(b_cur.x, a_cur[t].x, acc[t]);
+#pragma unroll
+        for (int t = 0; t < ACC; ++t) acc[t] = mfma16(b_cur.y, a_cur[t].y, acc[t]);
+#pragma unroll
+        for (int t = 0; t < ACC; ++t) acc[t] = mfma16(b_cur.z, a_cur[t].z, acc[t]);
+#pragma unroll
+        for (int t = 0; t < ACC; ++t) acc[t] = mfma16(b_cur.w, a_cur[t].w, acc[t]);
+        b_cur = b_nxt;
+#pragma unroll
+        for (int t = 0; t < ACC; ++t) a_cur[t] = a_nxt[t];
     }
 }
 
@@ -97,31 +153,38 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[WaveMap<N>::ACC]) {
     for (int t = 0; t < WaveMap<N>::ACC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// accumulators -> LDS C image [TILE_ROWS][ldc]
+// accumulators -> LDS C image [TILE_ROWS][ldc]: one 16-byte store per tile per lane
 template <int N>
-__device__ __forceinline__ void acc_to_lds(float* __restrict__ Cs, int ldc, const f32x4 (&acc)[WaveMap<N>::ACC], int nrt) {
+__device__ __forceinline__ void acc_to_lds(float* __restrict__ Cs, int ldc, const f32x4 (&acc)[WaveMap<N>::ACC]) {
     using WM = WaveMap<N>;
     const int w = wave_id(), lane = lane_id();
     const int ct = w % WM::NT, rg = w / WM::NT;
-    const int col = ct * 16 + (lane & 15), rbase = (lane >> 4) * 4;
+    const int m = lane & 15, n = ct * 16 + (lane >> 4) * 4;
 #pragma unroll
     for (int t = 0; t < WM::ACC; ++t) {
         const int rt = rg + t * WM::WR;
-        if (rt < nrt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cs[(rt * 16 + rbase + r) * ldc + col] = acc[t][r];
-        }
+        st4(Cs + (rt * 16 + m) * ldc + n, make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]));
     }
 }
 
-// Row-pass geometry over an N-column tile: QPR lanes own one row (a float4 each); the block covers
-// RPP rows per pass.  A thread keeps the same column quad for every row it visits.
-template <int N> struct RowPass {
-    static constexpr int QPR = N / 4;
-    static constexpr int RPP = GEMM_THREADS / QPR;
-    __device__ static __forceinline__ int sub() { return threadIdx.x % QPR; }
-    __device__ static __forceinline__ int first_row() { return threadIdx.x / QPR; }
-};
+// accumulators (+ bias) -> global [rows, ldo] directly: 16-byte stores, 64 contiguous bytes per row per wave instruction
+template <int N>
+__device__ __forceinline__ void acc_to_global(float* __restrict__ out, long long row0, int nrows, int ldo, const float* __restrict__ bias,
+                                              const f32x4 (&acc)[WaveMap<N>::ACC]) {
+    using WM = WaveMap<N>;
+    const int w = wave_id(), lane = lane_id();
+    const int ct = w % WM::NT, rg = w / WM::NT;
+    const int m = lane & 15, n = ct * 16 + (lane >> 4) * 4;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = ld4(bias + n);
+#pragma unroll
+    for (int t = 0; t < WM::ACC; ++t) {
+        const int rt = rg + t * WM::WR;
+        const int r = rt * 16 + m;
+        if (r < nrows)
+            st4(out + (row0 + r) * ldo + n, make_float4(acc[t][0] + b.x, acc[t][1] + b.y, acc[t][2] + b.z, acc[t][3] + b.w));
+    }
+}
 
 // LayerNorm statistics of one row spread over QPR lanes (biased variance, eps inside the sqrt)
 template <int QPR>
@@ -130,6 +193,11 @@ __device__ __forceinline__ void row_stats(float4 x, int n, float eps, float& mea
     const float4 d = make_float4(x.x - mean, x.y - mean, x.z - mean, x.w - mean);
     const float var = group_sum<QPR>(f4hsum(f4mul(d, d))) * (1.0f / n);
     rstd = 1.0f / sqrtf(var + eps);
+}
+
+__device__ __forceinline__ float4 ln_apply(float4 x, float mean, float rstd, float4 w, float4 b) {
+    return make_float4((x.x - mean) * rstd * w.x + b.x, (x.y - mean) * rstd * w.y + b.y, (x.z - mean) * rstd * w.z + b.z,
+                       (x.w - mean) * rstd * w.w + b.w);
 }
 
 }  // namespace amid

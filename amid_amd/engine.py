@@ -119,14 +119,19 @@ class SasrecPlan:
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
         self.rpt = L.value("amid_rows_per_tile", M)
         self.tpg = (M + self.rpt - 1) // self.rpt
-        # static inputs (graph-replay safe)
+        # static inputs (graph-replay safe): ONE int64 buffer so a batch arrives with a single copy
+        #   [i_node B | neg B*(NI-1) | seq_d1 B*T | seq_d2 B*T | domain B | labels B*NI fp32 (packed two per word)]
+        n_lab_words = (B * NI + 1) // 2
+        self.in_words = B + B * (NI - 1) + 2 * B * T + B + n_lab_words
+        self.in_pack = torch.zeros(self.in_words, dtype=torch.int64, device=dev)
+        o = 0
+        self.in_i_node = self.in_pack[o:o + B]; o += B
+        self.in_neg = self.in_pack[o:o + B * (NI - 1)].view(B, NI - 1); o += B * (NI - 1)
+        self.in_seq_d1 = self.in_pack[o:o + B * T].view(B, T); o += B * T
+        self.in_seq_d2 = self.in_pack[o:o + B * T].view(B, T); o += B * T
+        self.domain = self.in_pack[o:o + B]; o += B
+        self.labels = self.in_pack[o:o + n_lab_words].view(torch.float32)[: B * NI].view(B, NI)
         self.idx_all = torch.zeros(N, dtype=torch.int32, device=dev)
-        self.in_i_node = torch.zeros(B, dtype=torch.int64, device=dev)
-        self.in_neg = torch.zeros(B, NI - 1, dtype=torch.int64, device=dev)
-        self.in_seq_d1 = torch.zeros(B, T, dtype=torch.int64, device=dev)
-        self.in_seq_d2 = torch.zeros(B, T, dtype=torch.int64, device=dev)
-        self.labels = torch.zeros(B, NI, dtype=torch.float32, device=dev)
-        self.domain = torch.zeros(B, dtype=torch.int64, device=dev)
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         # forward
         self.xg = f(N, D)
@@ -162,6 +167,8 @@ class SasrecPlan:
         self.ln1_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
         self.ln2_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
         self.last_part = f(2 * B, 2, D)
+        self.pos_splits = max(1, min(8, B // 16))
+        self.dpos_part = f(self.pos_splits, 2, T, D)
         self.sc_P = L.value("amid_scorer_part_floats", D, hid)
         self.sc_part = f(B, self.sc_P)
         # sparse side
@@ -169,6 +176,7 @@ class SasrecPlan:
         self.pos_sorted = torch.zeros(N, dtype=torch.int32, device=dev)
         self.uniq_ids = torch.zeros(N, dtype=torch.int32, device=dev)
         self.seg_off = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+        self.seg_of = torch.zeros(N, dtype=torch.int32, device=dev)
         self.n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
         self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", N, D), dtype=torch.uint8, device=dev)
         self.uniq_grad = f(N, D)
@@ -208,6 +216,10 @@ class SasrecPlan:
             pre = f"sac{g + 1}"
             add(self.last_part, g * B * 2 * D, fp.ptr(f"{pre}.last_layernorm.weight", G), 2 * D, B, D)
             add(self.last_part, g * B * 2 * D + D, fp.ptr(f"{pre}.last_layernorm.bias", G), 2 * D, B, D)
+        T = self.shape.T
+        for g in (0, 1):
+            add(self.dpos_part, g * T * D, fp.ptr(f"sac{g + 1}.pos_emb.weight", G), 2 * T * D, self.pos_splits, T * D)
+        ent.append((self.loss_part.data_ptr(), self.loss.data_ptr(), 1, B, 1))          # loss = sum of the per-row partials
         P = self.sc_P
         add(self.sc_part, 0, fp.ptr("predictModule.fc.0.weight", G), P, B, hid * 2 * D)
         add(self.sc_part, hid * 2 * D, fp.ptr("predictModule.fc.0.bias", G), P, B, hid)
@@ -324,13 +336,28 @@ class SasrecEngine:
                 pl.labels.copy_(labels.reshape(pl.shape.B, -1), non_blocking=True)
                 pl.domain.copy_(domain_id.reshape(-1), non_blocking=True)
 
-    def enqueue_prepare(self, pl: SasrecPlan, sparse: bool) -> None:
+    def pack_batch(self, pl: SasrecPlan, i_node, neg_samples, seq_d1, seq_d2, labels, domain_id) -> torch.Tensor:
+        """Pre-pack a batch into the plan's input layout (one contiguous int64 tensor) for load_packed()."""
+        B, NI = pl.shape.B, pl.shape.NI
+        lab = torch.zeros(2 * ((B * NI + 1) // 2), dtype=torch.float32, device=labels.device)
+        lab[: B * NI] = labels.reshape(-1).float()
+        return torch.cat((i_node.reshape(-1).long(), neg_samples.reshape(-1).long(), seq_d1.reshape(-1).long(), seq_d2.reshape(-1).long(),
+                          domain_id.reshape(-1).long(), lab.view(torch.int64))).contiguous()
+
+    def load_packed(self, pl: SasrecPlan, packed: torch.Tensor) -> None:
+        with torch.cuda.stream(self.stream):
+            pl.in_pack.copy_(packed, non_blocking=True)
+
+    def enqueue_prepare(self, pl: SasrecPlan, sparse: bool, bump_step: bool = False) -> None:
         L, s, shp = lib(), self.s, pl.shape
         L.call("amid_pack_indices", pl.in_i_node.data_ptr(), pl.in_neg.data_ptr(), pl.in_seq_d1.data_ptr(), pl.in_seq_d2.data_ptr(),
-               shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(), s)
+               shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
+               self.step_state.data_ptr() if bump_step else None, s)
+        if bump_step:
+            self.step += 1
         if sparse:
             L.call("amid_sort_unique_i32", pl.idx_all.data_ptr(), shp.n_idx, self.n_rows, pl.sort_ws.data_ptr(), pl.pos_sorted.data_ptr(),
-                   pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.n_uniq.data_ptr(), s)
+                   pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_uniq.data_ptr(), s)
 
     def enqueue_catchup(self, pl: SasrecPlan) -> None:
         self._ensure_opt_state()
@@ -338,7 +365,7 @@ class SasrecEngine:
                    self.table_last.data_ptr(), pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), pl.shape.n_idx, self.D,
                    self.step_state.data_ptr(), self.s)
 
-    def enqueue_forward(self, pl: SasrecPlan, train: bool, with_loss: bool) -> None:
+    def enqueue_forward(self, pl: SasrecPlan, train: bool, with_loss: bool, sum_loss: bool = True) -> None:
         L, s, shp, D = lib(), self.s, pl.shape, self.D
         B, T, NI, M = shp.B, shp.T, shp.NI, shp.M
         st = self.step_state.data_ptr()
@@ -361,15 +388,14 @@ class SasrecEngine:
                    self._pp(f"sac{{d}}.forward_layers.{l}.conv1.bias"), self._pp(f"sac{{d}}.forward_layers.{l}.conv2.weight"),
                    self._pp(f"sac{{d}}.forward_layers.{l}.conv2.bias"), pl.tmq.data_ptr(), M, D, pl.rpt, l, st, tr, SASREC_P_DROP,
                    pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(), s)
-        L.call("amid_lnmean_fwd_f32", pl.x[2].data_ptr(), fp.ptr("sac1.last_layernorm.weight"), fp.ptr("sac1.last_layernorm.bias"),
-               fp.ptr("sac2.last_layernorm.weight"), fp.ptr("sac2.last_layernorm.bias"), B, T, D, SASREC_LN_EPS, pl.u.data_ptr(), s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
-        L.call("amid_scorer_fwd_f32", pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
-               fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"),
-               pl.labels.data_ptr() if with_loss else None, pl.domain.data_ptr() if with_loss else None, B, NI, D, self.hid,
-               pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr() if with_loss else None, pl.dp2.data_ptr() if with_loss else None,
+        L.call("amid_head_fwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"), items,
+               fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
+               fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr() if with_loss else None, pl.domain.data_ptr() if with_loss else None,
+               B, T, NI, D, self.hid, SASREC_LN_EPS, pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(),
+               pl.dp1.data_ptr() if with_loss else None, pl.dp2.data_ptr() if with_loss else None,
                pl.loss_part.data_ptr() if with_loss else None, s)
-        if with_loss:
+        if with_loss and sum_loss:
             L.call("amid_sum_vector_f32", pl.loss_part.data_ptr(), B, pl.loss.data_ptr(), s)
 
     def enqueue_backward(self, pl: SasrecPlan, train: bool) -> None:
@@ -390,14 +416,13 @@ class SasrecEngine:
                 src.append(fp.ptr(f"{pre}.forward_layers.{l}.conv1.weight"))
                 src.append(fp.ptr(f"{pre}.forward_layers.{l}.conv2.weight"))
                 dst += [self.wT[l, g, w].data_ptr() for w in range(6)]
-        L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
         ditems = pl.dxg.data_ptr() + 4 * 2 * M * D
-        L.call("amid_scorer_bwd_f32", pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
-               fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(), pl.p2.data_ptr(),
-               pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, NI, D, self.hid, pl.du.data_ptr(), ditems, pl.sc_part.data_ptr(), s)
-        L.call("amid_lnmean_bwd_f32", pl.x[2].data_ptr(), pl.du.data_ptr(), fp.ptr("sac1.last_layernorm.weight"),
-               fp.ptr("sac2.last_layernorm.weight"), B, T, D, SASREC_LN_EPS, pl.dxbuf.data_ptr(), pl.last_part.data_ptr(), s)
+        L.call("amid_head_bwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), pl.u.data_ptr(), items,
+               fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
+               fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, T, NI, D,
+               self.hid, SASREC_LN_EPS, pl.dxbuf.data_ptr(), ditems, pl.last_part.data_ptr(), pl.sc_part.data_ptr(),
+               ptr_array(src), ptr_array(dst), len(src), s)
         for l in (1, 0):
             L.call("amid_sas_ffn_bwd_f32", pl.dxbuf.data_ptr(), pl.tmq.data_ptr(), pl.h[l].data_ptr(), pl.r[l].data_ptr(),
                    self._pp(f"sac{{d}}.forward_layernorms.{l}.weight"), self._wT(l, 4), self._wT(l, 5), self._wT(l, 3), SASREC_LN_EPS,
@@ -414,10 +439,10 @@ class SasrecEngine:
             x6 = ptr_array([pl.qn[l].data_ptr(), pl.x[l].data_ptr(), pl.x[l].data_ptr(), pl.o[l].data_ptr(), pl.y[l].data_ptr(),
                             pl.h[l].data_ptr()])
             L.call("amid_sas_wgrad_f32", dy6, x6, M, D, pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), s)
-        L.call("amid_embed_bwd_f32", pl.dxg.data_ptr(), pl.tmq.data_ptr(), B, T, D, fp.ptr("sac1.pos_emb.weight", fp.grad),
-               fp.ptr("sac2.pos_emb.weight", fp.grad), st, tr, SASREC_P_DROP, s)
+        L.call("amid_embed_bwd_f32", pl.dxg.data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits, pl.dpos_part.data_ptr(), st, tr,
+               SASREC_P_DROP, s)
         L.call("amid_reduce_partials_f32", pl.red_entries.data_ptr(), pl.red_n, pl.red_max, s)
-        L.call("amid_embgrad_segreduce_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.n_uniq.data_ptr(),
+        L.call("amid_embgrad_segreduce_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(),
                shp.n_idx, D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), s)
 
     def enqueue_optimizer(self, pl: SasrecPlan, sparse=None) -> None:
@@ -431,10 +456,9 @@ class SasrecEngine:
         else:
             ids, rows, nu = sparse
             cap = ids.numel()
-        L.call("amid_adam_dense_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel, self.grad_scale,
-               self.step_state.data_ptr(), s)
-        L.call("amid_lazy_adam_apply_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
-               ids.data_ptr(), nu.data_ptr(), cap, rows.data_ptr(), self.grad_scale, self.D, self.step_state.data_ptr(), s)
+        L.call("amid_optimizer_step_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel,
+               self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), ids.data_ptr(),
+               nu.data_ptr(), cap, rows.data_ptr(), self.D, self.grad_scale, self.step_state.data_ptr(), s)
 
     def enqueue_step_begin(self) -> None:
         lib().call("amid_step_begin", self.step_state.data_ptr(), self.s)
@@ -442,20 +466,18 @@ class SasrecEngine:
 
     def enqueue_train_step(self, pl: SasrecPlan) -> None:
         """Whole step t on the current stream: t += 1; unique; catch-up; forward; loss; backward; Adam."""
-        self.enqueue_step_begin()
-        self.enqueue_prepare(pl, sparse=True)
+        self.enqueue_prepare(pl, sparse=True, bump_step=True)
         self.enqueue_catchup(pl)
-        self.enqueue_forward(pl, train=True, with_loss=True)
+        self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)      # the loss sum rides in reduce_partials
         self.enqueue_backward(pl, train=True)
         self.enqueue_optimizer(pl)
 
     # ------------------------------------------------------------------ data parallel (one process per GPU)
     def enqueue_local_grads(self, pl: SasrecPlan) -> None:
         """Everything of step t that needs no communication: t += 1 .. local segment-reduced gradients."""
-        self.enqueue_step_begin()
-        self.enqueue_prepare(pl, sparse=True)
+        self.enqueue_prepare(pl, sparse=True, bump_step=True)
         self.enqueue_catchup(pl)
-        self.enqueue_forward(pl, train=True, with_loss=True)
+        self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)
         self.enqueue_backward(pl, train=True)
 
     def capture_local_grads(self, pl: SasrecPlan) -> None:
@@ -572,6 +594,7 @@ class HipMergeBackend:
         self.pos_sorted = torch.zeros(self.cap, dtype=torch.int32, device=dev)
         self.uniq_ids = torch.zeros(self.cap, dtype=torch.int32, device=dev)
         self.seg_off = torch.zeros(self.cap + 1, dtype=torch.int32, device=dev)
+        self.seg_of = torch.zeros(self.cap, dtype=torch.int32, device=dev)
         self.n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
         self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", self.cap, D), dtype=torch.uint8, device=dev)
         self.uniq_rows = torch.empty(self.cap, D, dtype=torch.float32, device=dev)
@@ -583,7 +606,7 @@ class HipMergeBackend:
         if n > self.cap:
             raise ValueError(f"merge of {n} entries exceeds the backend capacity {self.cap}")
         L.call("amid_sort_unique_i32", ids.data_ptr(), n, eng.n_rows, self.sort_ws.data_ptr(), self.pos_sorted.data_ptr(),
-               self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.n_uniq.data_ptr(), eng.s)
-        L.call("amid_embgrad_segreduce_f32", rows.data_ptr(), self.pos_sorted.data_ptr(), self.seg_off.data_ptr(), self.n_uniq.data_ptr(),
+               self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(), self.n_uniq.data_ptr(), eng.s)
+        L.call("amid_embgrad_segreduce_f32", rows.data_ptr(), self.pos_sorted.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
                n, eng.D, self.seg_ws.data_ptr(), self.uniq_rows.data_ptr(), eng.s)
         return self.uniq_ids[:n], self.uniq_rows[:n], self.n_uniq

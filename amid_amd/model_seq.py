@@ -226,11 +226,12 @@ class _GatherFunction(torch.autograd.Function):
         ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device=dev)
         pos, uniq = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
         seg, nu = torch.empty(n + 1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        sof = torch.empty(n, dtype=torch.int32, device=dev)
         L.call("amid_sort_unique_i32", idx32.data_ptr(), n, ctx.shape[0], ws.data_ptr(), pos.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
-               nu.data_ptr(), s)
+               sof.data_ptr(), nu.data_ptr(), s)
         ws2 = torch.empty(L.value("amid_segreduce_workspace_bytes", n, D), dtype=torch.uint8, device=dev)
         ug = torch.empty(n, D, dtype=torch.float32, device=dev)
-        L.call("amid_embgrad_segreduce_f32", rows.data_ptr(), pos.data_ptr(), seg.data_ptr(), nu.data_ptr(), n, D, ws2.data_ptr(),
+        L.call("amid_embgrad_segreduce_f32", rows.data_ptr(), pos.data_ptr(), seg.data_ptr(), sof.data_ptr(), n, D, ws2.data_ptr(),
                ug.data_ptr(), s)
         U = int(nu.item())
         dense = torch.zeros(ctx.shape, dtype=torch.float32, device=dev)

@@ -162,12 +162,14 @@ def main():
     pl = eng.plan(B, T, 1 + NEG, need_grad=True)
     gen = torch.Generator().manual_seed(1000 + rank)          # each rank draws its own shard of the global batch
     n_pool = 60                               # one epoch of cloth_sport_train75 at batch 256
-    pool = [synth_batch(gen, device) for _ in range(n_pool)]
+    pool = []
+    for _ in range(n_pool):                   # batches are packed in the engine's input layout: one device copy per step
+        b = synth_batch(gen, device)
+        pool.append(eng.pack_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"]))
     torch.cuda.synchronize()
 
     def load(i):
-        b = pool[i % n_pool]
-        eng.load_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"])
+        eng.load_packed(pl, pool[i % n_pool])
 
     use_graph = not args.no_graph
     exchange = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx)) if world > 1 else None

@@ -48,28 +48,31 @@ int amid_step_begin(void* step_state, void* stream);                       /* st
 int amid_gather_rows_f32(const float* table, long long n_rows, int D, const void* idx, int idx_is_i64, long long n_idx,
                          float* out, int* err_flag, void* stream);
 /* concatenate + narrow the four index tensors of a batch: idx_all = [seq_d1 | seq_d2 | (i_node, neg)[b]] */
+/* step_state_to_bump (optional): the same launch performs amid_step_begin (one launch fewer per step) */
 int amid_pack_indices(const long long* i_node, const long long* neg, const long long* seq_d1, const long long* seq_d2,
-                      int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* stream);
+                      int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* step_state_to_bump, void* stream);
 /* fused gather + positional add + embedding dropout + feature-level (==0) mask.
  * replaces: model_seq.py:418-421 + Log2feats.forward :361-366.  pos0/pos1 = sac{1,2}.pos_emb.weight
  * (both NULL: plain gather for all rows, BERT4Rec).  xg: [2M + n_item_rows, D]; tmq: [2M, D/4] bytes. */
 int amid_embed_fwd_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
                        int n_item_rows, float* xg, unsigned char* tmq, const void* step_state, int train, float p_drop, void* stream);
-/* backward of the above on the seq rows, in place on dxg [2M(+items), D]; writes d pos_emb.weight [T, D] x2.
+/* backward of the above on the seq rows, in place on dxg [2M(+items), D]; the batch is cut into nsplit row ranges, each
+ * writing its partial d pos_emb.weight: dpos_part [nsplit][2][T][D] (summed by amid_reduce_partials_f32).
  * replaces: autograd of model_seq.py:361-366 (EmbeddingBackward of pos_emb). */
-int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, float* dpos0, float* dpos1,
+int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part,
                        const void* step_state, int train, float p_drop, void* stream);
 
 /* ---- index sort / unique (no reference counterpart: enables the sparse gradient path) ------ */
 long long amid_sort_unique_workspace_bytes(int n_idx);
 int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
-                         int* seg_off /* [n_idx + 1] */, int* n_uniq /* device scalar */, void* stream);
+                         int* seg_off /* [n_idx + 1] */, int* seg_of /* [n_idx] run index of each sorted entry */,
+                         int* n_uniq /* device scalar */, void* stream);
 
 /* ---- K3 embedding gradient as segment reduce -------------------------------------------------
  * replaces: autograd EmbeddingBackward (dense index_add into zero-filled [n_rows, D]) of the four
  * lookups at model_seq.py:418-421, run by loss.backward() train_sr.py:214. */
 long long amid_segreduce_workspace_bytes(int n_idx, int D);
-int amid_embgrad_segreduce_f32(const float* grad_rows /* [n_idx, D] */, const int* pos_sorted, const int* seg_off, const int* n_uniq,
+int amid_embgrad_segreduce_f32(const float* grad_rows /* [n_idx, D] */, const int* pos_sorted, const int* seg_off, const int* seg_of,
                                int n_idx, int D, void* workspace, float* uniq_grad /* [n_idx, D] */, void* stream);
 
 /* ---- K4 optimizer ----------------------------------------------------------------------------
@@ -81,6 +84,10 @@ int amid_lazy_adam_apply_f32(float* table, float* m, float* v, int* last, const 
                              const float* uniq_grad, float grad_scale, int D, const void* step_state, void* stream);
 int amid_lazy_adam_flush_f32(float* table, float* m, float* v, int* last, long long n_rows, int D, const void* step_state, void* stream);
 int amid_adam_dense_f32(float* p, float* m, float* v, const float* g, long long n, float grad_scale, const void* step_state, void* stream);
+/* amid_adam_dense_f32 + amid_lazy_adam_apply_f32 as ONE launch */
+int amid_optimizer_step_f32(float* p, float* m, float* v, const float* g, long long n, float* table, float* m_tab, float* v_tab,
+                            int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max, const float* uniq_grad, int D,
+                            float grad_scale, const void* step_state, void* stream);
 
 /* ---- SASRec encoder layer, forward ------------------------------------------------------------
  * Pointer-array arguments are HOST arrays of 2 device pointers (domain 0, domain 1). */
@@ -141,6 +148,19 @@ int amid_scorer_bwd_f32(const float* u, const float* items, const float* w1, con
                         const float* p1, const float* p2, const float* dp1, const float* dp2, int B, int NI, int D, int hid, float* du,
                         float* ditems, float* part /* [B][amid_scorer_part_floats] */, void* stream);
 int amid_sum_vector_f32(const float* v, int n, float* out, void* stream);
+/* fused head, one workgroup per batch row: last LayerNorm + mean over T (model_seq.py:385, :432-434) -> predictModule
+ * (model_seq.py:40-54) -> masked BCE partials + dLoss/dp (train_sr.py:203-212); ln_w / ln_b: host arrays of 2 device pointers
+ * (NULL arrays: plain mean, BERT4Rec model_seq.py:299-300) */
+int amid_head_fwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
+                      const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id, int B, int T,
+                      int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1, float* dp2, float* loss_part,
+                      void* stream);
+/* backward of the head (scorer -> mean -> last LayerNorm); extra workgroups transpose n_tr (<= 32) square D x D weight
+ * matrices (tr_src / tr_dst: host arrays of device pointers) for the backward GEMMs of the encoder */
+int amid_head_bwd_f32(const float* x, const float* const* ln_w, const float* u, const float* items, const float* w1, const float* b1,
+                      const float* w2, const float* b2, const float* p1, const float* p2, const float* dp1, const float* dp2, int B, int T,
+                      int NI, int D, int hid, float eps, float* dx, float* ditems, float* ln_part, float* sc_part,
+                      const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream);
 /* replaces: torch.nn.LayerNorm(D, eps) applied row-wise (last_layernorm of a standalone Log2feats, model_seq.py:385) */
 int amid_layernorm_rows_f32(const float* x, const float* w, const float* b, long long rows, int D, float eps, float* y, void* stream);
 

@@ -79,11 +79,12 @@ def run_sort_unique(L, idx, n_rows):
     uniq = torch.zeros(n, dtype=torch.int32, device="cuda")
     seg = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
     nu = torch.zeros(1, dtype=torch.int32, device="cuda")
-    L.call("amid_sort_unique_i32", idd.data_ptr(), n, n_rows, ws.data_ptr(), pos.data_ptr(), uniq.data_ptr(), seg.data_ptr(), nu.data_ptr(),
-           stream())
+    sof = torch.zeros(n, dtype=torch.int32, device="cuda")
+    L.call("amid_sort_unique_i32", idd.data_ptr(), n, n_rows, ws.data_ptr(), pos.data_ptr(), uniq.data_ptr(), seg.data_ptr(), sof.data_ptr(),
+           nu.data_ptr(), stream())
     torch.cuda.synchronize()
     U = int(nu.item())
-    return pos.cpu().long(), uniq[:U].cpu().long(), seg[: U + 1].cpu().long(), U, (pos, uniq, seg, nu)
+    return pos.cpu().long(), uniq[:U].cpu().long(), seg[: U + 1].cpu().long(), U, (pos, uniq, seg, sof)
 
 
 @pytest.mark.parametrize("n,n_rows,pad_frac", [(26112, 894820, 0.89), (6528, 894820, 0.85), (300, 50, 0.0), (1, 10, 0.0),
@@ -98,6 +99,7 @@ def test_sort_unique_matches_stable_sort(L, n, n_rows, pad_frac):
     wu, wc = torch.unique(idx, return_counts=True)
     assert U == wu.numel() and torch.equal(uniq, wu)
     assert torch.equal(seg, torch.cat((torch.zeros(1, dtype=torch.long), wc.cumsum(0))))
+    assert torch.equal(_[3].cpu().long(), torch.repeat_interleave(torch.arange(U), wc))      # run index of every sorted entry
 
 
 @pytest.mark.parametrize("D,n,n_rows,pad_frac", [(128, 26112, 894820, 0.89), (64, 6528, 5000, 0.85), (128, 70, 1000, 0.0),
@@ -107,11 +109,11 @@ def test_segreduce_matches_index_add(L, D, n, n_rows, pad_frac):
     idx = torch.randint(0, n_rows, (n,), generator=g)
     idx[torch.rand(n, generator=g) < pad_frac] = n_rows - 1
     rows = torch.randn(n, D, generator=g)
-    pos, uniq, seg, U, (pos_d, uniq_d, seg_d, nu_d) = run_sort_unique(L, idx, n_rows)
+    pos, uniq, seg, U, (pos_d, uniq_d, seg_d, sof_d) = run_sort_unique(L, idx, n_rows)
     rd = dev(rows)
     ws = torch.empty(L.value("amid_segreduce_workspace_bytes", n, D), dtype=torch.uint8, device="cuda")
     out = torch.full((n, D), float("nan"), device="cuda")
-    L.call("amid_embgrad_segreduce_f32", rd.data_ptr(), pos_d.data_ptr(), seg_d.data_ptr(), nu_d.data_ptr(), n, D, ws.data_ptr(),
+    L.call("amid_embgrad_segreduce_f32", rd.data_ptr(), pos_d.data_ptr(), seg_d.data_ptr(), sof_d.data_ptr(), n, D, ws.data_ptr(),
            out.data_ptr(), stream())
     torch.cuda.synchronize()
     # reference semantics: dense index_add (EmbeddingBackward) restricted to the touched rows, in fp64
@@ -123,7 +125,7 @@ def test_segreduce_matches_index_add(L, D, n, n_rows, pad_frac):
     assert float((got - want).abs().max() / scale) < 2e-6
     # reproducible: a second run is bitwise identical
     out2 = torch.empty_like(out)
-    L.call("amid_embgrad_segreduce_f32", rd.data_ptr(), pos_d.data_ptr(), seg_d.data_ptr(), nu_d.data_ptr(), n, D, ws.data_ptr(),
+    L.call("amid_embgrad_segreduce_f32", rd.data_ptr(), pos_d.data_ptr(), seg_d.data_ptr(), sof_d.data_ptr(), n, D, ws.data_ptr(),
            out2.data_ptr(), stream())
     torch.cuda.synchronize()
     assert torch.equal(out[:U], out2[:U])
@@ -233,10 +235,12 @@ def test_embed_fwd_bwd_vs_oracle(L, D):
     # backward (train mode): dxe = dx * ~tm * keep*2 ; dpos = sum_b
     dxg = torch.randn(N, D, generator=g)
     dd = dev(dxg.clone())
-    dp0, dp1 = torch.zeros(T, D, device="cuda"), torch.zeros(T, D, device="cuda")
-    L.call("amid_embed_bwd_f32", dd.data_ptr(), tmq.data_ptr(), B, T, D, dp0.data_ptr(), dp1.data_ptr(), st.data_ptr(), 1, 0.5, stream())
+    nsplit = 3
+    dpart = torch.zeros(nsplit, 2, T, D, device="cuda")
+    L.call("amid_embed_bwd_f32", dd.data_ptr(), tmq.data_ptr(), B, T, D, nsplit, dpart.data_ptr(), st.data_ptr(), 1, 0.5, stream())
     torch.cuda.synchronize()
-    for gi, dp in ((0, dp0), (1, dp1)):
+    dsum = dpart.sum(0)
+    for gi, dp in ((0, dsum[0]), (1, dsum[1])):
         rows = table[idx[gi * B * T:(gi + 1) * B * T]].reshape(B, T, D) + pos[gi]
         tm = rows == 0
         keep = torch.from_numpy(orc.philox_keep_flat(B * T * D, seed, orc.site_id(gi, 0, orc.SITE_EMB), step, 0.5)).reshape(B, T, D)
