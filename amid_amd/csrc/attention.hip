@@ -75,7 +75,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs a) {
     copy_tile(Vs, a.v + rowbase * D, T * D);
     __syncthreads();
     const int h = wave_id(), lane = lane_id();
-    const int TP8 = (T + 7) >> 3;
+    const int dbits = spec_bits(a.thr16), per = 128 / dbits;       // decisions per Philox call
+    const unsigned dthr = spec_thr(a.thr16);
+    const int calls_per_row = (T + per - 1) / per;
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
     const unsigned site = site_id(g, a.layer, SITE_ATTN);
@@ -97,10 +99,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs a) {
         float acc[HD];
 #pragma unroll
         for (int d = 0; d < HD; ++d) acc[d] = 0.f;
-        const unsigned long long rowcall = ((unsigned long long)(b * a.H + h) * T + ic) * TP8;
+        const unsigned long long rowcall = ((unsigned long long)(b * a.H + h) * T + ic) * calls_per_row;
+        uint4 r = make_uint4(~0u, ~0u, ~0u, ~0u);
         for (int j0 = 0; j0 < jmax; j0 += 8) {
-            uint4 r = make_uint4(~0u, ~0u, ~0u, ~0u);
-            if (a.train) r = rng_call(seed, rowcall + (j0 >> 3), site, step);
+            if (a.train && (j0 % per) == 0) r = rng_call(seed, rowcall + j0 / per, site, step);
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const int j = j0 + jj;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs a) {
                     const float s = score<HD>(a, qs, Ks + j * D + h * HD, ic, j, kk ? kk[j] != 0 : true);
                     const float p = expf(s - m);
                     l += p;
-                    const float pd = (!a.train || rng_half(r, jj) >= a.thr16) ? p * a.dscale : 0.f;
+                    const float pd = (!a.train || rng_field(r, j % per, dbits) >= dthr) ? p * a.dscale : 0.f;
                     const float* vr = Vs + j * D + h * HD;
 #pragma unroll
                     for (int d = 0; d < HD; d += 4) {
@@ -144,7 +146,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
     const int seq = blockIdx.x, g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
     const int h = wave_id(), lane = lane_id();
-    const int TP8 = (T + 7) >> 3;
+    const int dbits = spec_bits(a.thr16), per = 128 / dbits;
+    const unsigned dthr = spec_thr(a.thr16);
+    const int calls_per_row = (T + per - 1) / per;
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
     const unsigned site = site_id(g, a.layer, SITE_ATTN);
@@ -178,16 +182,16 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
         const float m = sp[0], rl = sp[1];
         if (valid) { float* rs = rstat + (h * T + i) * 3; rs[0] = m; rs[1] = rl; rs[2] = delta; }
         const int jmax = a.causal ? min(T, qb * 64 + 64) : T;
-        const unsigned long long rowcall = ((unsigned long long)(b * H + h) * T + ic) * TP8;
+        const unsigned long long rowcall = ((unsigned long long)(b * H + h) * T + ic) * calls_per_row;
         unsigned long long kw = 0;
+        uint4 r = make_uint4(~0u, ~0u, ~0u, ~0u);
         for (int j0 = 0; j0 < jmax; j0 += 8) {                 // phase 2 only needs the bits of pairs (i, j < jmax)
             if ((j0 & 63) == 0) kw = 0;
-            uint4 r = make_uint4(~0u, ~0u, ~0u, ~0u);
-            if (a.train) r = rng_call(seed, rowcall + (j0 >> 3), site, step);
+            if (a.train && (j0 % per) == 0) r = rng_call(seed, rowcall + j0 / per, site, step);
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const int j = j0 + jj;
-                const bool keep = !a.train || rng_half(r, jj) >= a.thr16;
+                const bool keep = !a.train || rng_field(r, j % per, dbits) >= dthr;
                 if (keep) kw |= 1ull << (j & 63);
                 if (j < jmax) {
                     const float s = score<HD>(a, qs, S0 + j * D + h * HD, ic, j, kk ? kk[j] != 0 : true);
@@ -272,6 +276,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
 
 using namespace amid;
 
+// attention_mfma.hip: matrix-core kernels for the causal head-dim-16 T <= 64 case
+int amid_attn_mfma_fwd_launch(const void* args, void* stream);
+int amid_attn_mfma_bwd_launch(const void* args, void* stream);
+static bool mfma_shape(const AttnArgs& a) { return a.causal && a.key_keep == nullptr && a.D / a.H == 16 && a.T <= 64 && a.H <= 8; }
+
 static size_t attn_fwd_lds(int T, int D) { return (size_t)2 * T * D * sizeof(float); }
 static size_t attn_bwd_lds(int T, int D, int H) {
     size_t f = (size_t)2 * T * D + (size_t)H * T * 3;
@@ -311,6 +320,7 @@ extern "C" int amid_attn_fwd_f32(const float* q, const float* k, const float* v,
     if (int e = attn_fill(a, q, k, v, key_keep, B, T, D, H, causal, layer, step_state, train, p_drop)) return e;
     AMID_CHECK_ARG(o);
     a.o = o; a.stats = stats;
+    if (mfma_shape(a)) return amid_attn_mfma_fwd_launch(&a, stream);
     const size_t lds = attn_fwd_lds(T, D);
     if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
     switch (D / H) {
@@ -328,6 +338,7 @@ extern "C" int amid_attn_bwd_f32(const float* q, const float* k, const float* v,
     if (int e = attn_fill(a, q, k, v, key_keep, B, T, D, H, causal, layer, step_state, train, p_drop)) return e;
     AMID_CHECK_ARG(o && stats && d_o && dq && dk && dv);
     a.o = const_cast<float*>(o); a.stats = const_cast<float*>(stats); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
+    if (mfma_shape(a)) return amid_attn_mfma_bwd_launch(&a, stream);
     const size_t lds = attn_bwd_lds(T, D, H);
     if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
     switch (D / H) {

@@ -1,8 +1,7 @@
 // Counter-based dropout RNG shared by every kernel (and restated in
 // oracle/amid_oracle.py: philox_keep_flat).  Philox4x32-10, key = 64-bit seed,
-// counter = (call_lo, call_hi, site, step).  One call serves 8 consecutive
-// elements: element e uses 16-bit half (e & 1) of word ((e >> 1) & 3) of call
-// (e >> 3); keep <=> half >= thr16, thr16 = round(p * 65536).
+// counter = (call_lo, call_hi, site, step).  How the 128 bits of a call are cut
+// into keep/drop decisions: "decision format" below.
 #pragma once
 #include "common.h"
 
@@ -30,30 +29,62 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, unsigned k0, unsigned k1
     return c;
 }
 
-// random words for elements [8*call, 8*call+8)
+// 128 random bits of one call
 __device__ __forceinline__ uint4 rng_call(unsigned long long seed, unsigned long long call, unsigned site, unsigned step) {
     return philox4x32_10(make_uint4((unsigned)call, (unsigned)(call >> 32), site, step), (unsigned)seed, (unsigned)(seed >> 32));
 }
-__device__ __forceinline__ unsigned rng_half(uint4 r, int e_in_call) {   // e_in_call in [0,8)
-    unsigned w = (e_in_call >> 1) == 0 ? r.x : (e_in_call >> 1) == 1 ? r.y : (e_in_call >> 1) == 2 ? r.z : r.w;
-    return (e_in_call & 1) ? (w >> 16) : (w & 0xFFFFu);
-}
-__host__ __device__ __forceinline__ unsigned keep_thr16(float p) {
+
+// ---- decision format ("drop spec") ---------------------------------------------------------------------------------
+// A keep/drop decision consumes b bits: the smallest b in {1, 2, 4, 8, 16} for which p * 2^b is an integer (p = 0.5 -> 1
+// bit, so ONE Philox call decides 128 elements: a whole D = 128 activation row, or a whole attention row of <= 128 keys);
+// otherwise b = 16 with the threshold rounded (p = 0.1 -> 6554 / 65536).  keep <=> field >= thr, thr = p * 2^b.
+// Element e uses call e / (128 / b), field e % (128 / b); fields are packed LSB-first in the words x, y, z, w.
+// spec = (b << 16) | thr travels as one int.  Restated in oracle/amid_oracle.py (drop_bits / philox_keep_flat).
+__host__ __device__ __forceinline__ unsigned drop_spec(float p) {
+    for (int b = 1; b <= 8; b <<= 1) {
+        const float t = p * (float)(1 << b);
+        if (t == (float)(int)t) return ((unsigned)b << 16) | (unsigned)(int)t;
+    }
     float t = p * 65536.0f + 0.5f;
     unsigned u = (unsigned)t;
-    return u > 0xFFFFu ? 0xFFFFu : u;
+    if (u > 0xFFFFu) u = 0xFFFFu;
+    return (16u << 16) | u;
+}
+__host__ __device__ __forceinline__ unsigned keep_thr16(float p) { return drop_spec(p); }      // historical name at the call sites
+__host__ __device__ __forceinline__ int spec_bits(unsigned spec) { return (int)(spec >> 16); }
+__host__ __device__ __forceinline__ unsigned spec_thr(unsigned spec) { return spec & 0xFFFFu; }
+__host__ __device__ __forceinline__ int spec_per_call(unsigned spec) { return 128 / spec_bits(spec); }
+
+__device__ __forceinline__ unsigned rng_word(uint4 r, int w) { return w == 0 ? r.x : w == 1 ? r.y : w == 2 ? r.z : r.w; }
+// field f (0 .. 128/b - 1) of a call
+__device__ __forceinline__ unsigned rng_field(uint4 r, int f, int b) {
+    const int off = f * b;
+    return (rng_word(r, off >> 5) >> (off & 31)) & ((1u << b) - 1u);
 }
 
-// keep flags (as 0/scale multipliers) for 4 consecutive elements starting at e0 (e0 % 4 == 0)
+// keep multipliers (scale or 0) for 4 consecutive elements starting at e0 (e0 % 4 == 0)
 __device__ __forceinline__ float4 dropout_mult4(unsigned long long seed, unsigned site, unsigned step, unsigned long long e0,
-                                                unsigned thr16, float scale) {
-    uint4 r = rng_call(seed, e0 >> 3, site, step);
-    unsigned w0 = (e0 & 4) ? r.z : r.x, w1 = (e0 & 4) ? r.w : r.y;
+                                                unsigned spec, float scale) {
+    const int b = spec_bits(spec);
+    const unsigned thr = spec_thr(spec);
+    const int lg_per = 7 - (__ffs(b) - 1);                       // b is a power of two: shifts, not 64-bit divisions
+    const uint4 r = rng_call(seed, e0 >> lg_per, site, step);
+    const int off = ((int)e0 & ((1 << lg_per) - 1)) * b;         // 4 fields never straddle a word (4 b <= 32 needs b <= 8; b = 16: two words)
     float4 m;
-    m.x = ((w0 & 0xFFFFu) >= thr16) ? scale : 0.f;
-    m.y = ((w0 >> 16) >= thr16) ? scale : 0.f;
-    m.z = ((w1 & 0xFFFFu) >= thr16) ? scale : 0.f;
-    m.w = ((w1 >> 16) >= thr16) ? scale : 0.f;
+    if (b == 16) {
+        const unsigned w0 = rng_word(r, off >> 5), w1 = rng_word(r, (off >> 5) + 1);
+        m.x = ((w0 & 0xFFFFu) >= thr) ? scale : 0.f;
+        m.y = ((w0 >> 16) >= thr) ? scale : 0.f;
+        m.z = ((w1 & 0xFFFFu) >= thr) ? scale : 0.f;
+        m.w = ((w1 >> 16) >= thr) ? scale : 0.f;
+    } else {
+        const unsigned w = rng_word(r, off >> 5) >> (off & 31);
+        const unsigned mask = (1u << b) - 1u;
+        m.x = ((w & mask) >= thr) ? scale : 0.f;
+        m.y = (((w >> b) & mask) >= thr) ? scale : 0.f;
+        m.z = (((w >> (2 * b)) & mask) >= thr) ? scale : 0.f;
+        m.w = (((w >> (3 * b)) & mask) >= thr) ? scale : 0.f;
+    }
     return m;
 }
 

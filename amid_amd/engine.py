@@ -161,7 +161,8 @@ class SasrecPlan:
         self.du = f(2, B, D)
         self.dpre1, self.dpre2, self.dr, self.d_o = f(2 * M, D), f(2 * M, D), f(2 * M, D), f(2 * M, D)
         self.dq, self.dk, self.dv = f(2 * M, D), f(2 * M, D), f(2 * M, D)
-        self.splits = max(1, min(32, (M + 511) // 512))
+        # 2 domains x 6 weights x splits workgroups: 21 splits = 252 workgroups, one round on the 256 CUs
+        self.splits = max(1, min(21, M // 128))
         self.w_part = [f(2, 6, self.splits, D * D) for _ in range(2)]
         self.b_part = [f(2, 6, self.splits, D) for _ in range(2)]
         self.ln1_part = [f(2 * self.tpg, 2, D) for _ in range(2)]

@@ -82,16 +82,27 @@ def philox4x32(ctr: np.ndarray, key: Tuple[int, int]) -> np.ndarray:
     return c
 
 
-def keep_threshold(p: float) -> int:
-    """16-bit threshold: keep <=> u16 >= thr ; P(keep) = 1 - thr/65536."""
-    return min(int(round(p * 65536.0)), 0xFFFF)
+def drop_bits(p: float) -> Tuple[int, int]:
+    """(bits per decision b, threshold): smallest b in {1,2,4,8} with p * 2**b an integer, else 16 bits with the
+    threshold rounded.  keep <=> field >= thr ; P(keep) = 1 - thr / 2**b.  (amid_amd/csrc/rng.h: drop_spec)"""
+    for b in (1, 2, 4, 8):
+        t = np.float32(p) * np.float32(1 << b)
+        if float(t) == float(int(t)):
+            return b, int(t)
+    return 16, min(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)), 0xFFFF)
+
+
+def drop_per_call(p: float) -> int:
+    return 128 // drop_bits(p)[0]
 
 
 def philox_keep_flat(n_elem: int, seed: int, site: int, step: int, p: float) -> np.ndarray:
-    """Keep mask (float32 0/1) for linear element indices [0, n_elem).
-    One Philox call serves 8 elements: element e uses 16-bit half (e & 1)
-    (0 = low) of word ((e >> 1) & 3) of call (e >> 3)."""
-    n_call = (n_elem + 7) // 8
+    """Keep mask (float32 0/1) for linear element indices [0, n_elem).  One Philox call decides 128 / b
+    elements: element e uses field (e % (128 / b)) of call (e // (128 / b)), fields packed LSB-first in the
+    four 32-bit words of the call."""
+    b, thr = drop_bits(p)
+    per = 128 // b
+    n_call = (n_elem + per - 1) // per
     idx = np.arange(n_call, dtype=np.uint64)
     ctr = np.stack([
         (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32),
@@ -99,9 +110,10 @@ def philox_keep_flat(n_elem: int, seed: int, site: int, step: int, p: float) -> 
         np.full(n_call, site, dtype=np.uint32),
         np.full(n_call, step & 0xFFFFFFFF, dtype=np.uint32),
     ], axis=1)
-    r = philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))          # [n_call,4]
-    halves = np.stack([r & np.uint32(0xFFFF), r >> np.uint32(16)], axis=2).reshape(-1)[:n_elem]
-    return (halves >= np.uint32(keep_threshold(p))).astype(np.float32)
+    r = philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))          # [n_call, 4]
+    shifts = (np.arange(32 // b, dtype=np.uint32) * np.uint32(b))
+    fields = (r[:, :, None] >> shifts[None, None, :]) & np.uint32((1 << b) - 1)   # [n_call, 4, 32/b]
+    return (fields.reshape(-1)[:n_elem] >= np.uint32(thr)).astype(np.float32)
 
 
 # mask-site numbering shared with amid_amd/csrc/rng.h
@@ -119,15 +131,17 @@ def site_id(domain: int, layer: int, kind: int) -> int:
     return (domain * 2 + layer) * 8 + kind
 
 
-def attn_row_stride(T: int) -> int:
-    return (T + 7) & ~7
+def attn_row_stride(T: int, p: float) -> int:
+    """Attention keep masks are indexed [b, h, i, j] with the row padded to a whole number of Philox calls."""
+    per = drop_per_call(p)
+    return (T + per - 1) // per * per
 
 
 def philox_masks_sasrec(B: int, T: int, D: int, seed: int, step: int,
                         H: int = SASREC_HEADS, p: float = SASREC_DROPOUT) -> Dict[str, torch.Tensor]:
     """All SASRec train-mode keep masks exactly as the HIP kernels derive them."""
     out: Dict[str, torch.Tensor] = {}
-    TP = attn_row_stride(T)
+    TP = attn_row_stride(T, p)
     for d in (0, 1):
         pre = f"sac{d + 1}"
         out[f"{pre}.emb"] = torch.from_numpy(
@@ -145,7 +159,7 @@ def philox_masks_sasrec(B: int, T: int, D: int, seed: int, step: int,
 def philox_masks_bert4rec(B: int, T: int, seed: int, step: int, p: float = BERT_DROPOUT) -> Dict[str, torch.Tensor]:
     out: Dict[str, torch.Tensor] = {}
     D, H, F = BERT_HIDDEN, BERT_HEADS, BERT_FF
-    TP = attn_row_stride(T)
+    TP = attn_row_stride(T, p)
     for d in (0, 1):
         pre = f"transform{d + 1}"
         for l in (0, 1):

@@ -248,3 +248,50 @@ def test_embed_fwd_bwd_vs_oracle(L, D):
         assert torch.equal(dd.cpu()[gi * B * T:(gi + 1) * B * T].reshape(B, T, D), want)
         assert relmax(dp, want.sum(0)) < 1e-6
     assert torch.equal(dd.cpu()[2 * B * T:], dxg[2 * B * T:])
+
+
+# ---------------------------------------------------------------------------------------------
+def oracle_attention(q, k, v, H, p_keep_mask=None, p=0.5):
+    """softmax((q*scale) k^T + causal) [dropout] v on [B,T,D] tensors, fp64."""
+    import math
+    B, T, D = q.shape
+    hd = D // H
+    qh = q.double().reshape(B, T, H, hd).permute(0, 2, 1, 3) * math.sqrt(1.0 / hd)
+    kh = k.double().reshape(B, T, H, hd).permute(0, 2, 1, 3)
+    vh = v.double().reshape(B, T, H, hd).permute(0, 2, 1, 3)
+    S = qh @ kh.transpose(-1, -2)
+    S = S.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool), 1), float("-inf"))
+    A = torch.softmax(S, -1)
+    if p_keep_mask is not None:
+        A = A * p_keep_mask.double() / (1.0 - p)
+    return (A @ vh).permute(0, 2, 1, 3).reshape(B, T, D)
+
+
+@pytest.mark.parametrize("T", [64, 50, 17, 70])          # <= 64: matrix-core kernels; 70: general VALU kernels
+@pytest.mark.parametrize("train", [0, 1])
+def test_attention_fwd_bwd_vs_autograd(L, T, train):
+    B, D, H = 3, 128, 8
+    g = torch.Generator().manual_seed(T + train)
+    q, k, v, do = (torch.randn(2 * B, T, D, generator=g) for _ in range(4))
+    seed, step, layer = 77, 4, 1
+    st = step_state(L, seed, step)
+    qd, kd, vd, dod = dev(q), dev(k), dev(v), dev(do)
+    o = torch.empty_like(qd); stats = torch.empty(2 * B * T, H, 2, device="cuda")
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(qd), torch.empty_like(qd)
+    L.call("amid_attn_fwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), None, B, T, D, H, 1, layer, st.data_ptr(), train, 0.5,
+           o.data_ptr(), stats.data_ptr(), stream())
+    L.call("amid_attn_bwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), stats.data_ptr(), dod.data_ptr(), None, B, T, D, H,
+           1, layer, st.data_ptr(), train, 0.5, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), stream())
+    torch.cuda.synchronize()
+    for dom in range(2):
+        sl = slice(dom * B, (dom + 1) * B)
+        mask = None
+        if train:
+            TP = orc.attn_row_stride(T, 0.5)
+            m = orc.philox_keep_flat(B * H * T * TP, seed, orc.site_id(dom, layer, orc.SITE_ATTN), step, 0.5)
+            mask = torch.from_numpy(m.reshape(B, H, T, TP)[..., :T].copy())
+        qq, kk, vv = (t[sl].clone().double().requires_grad_(True) for t in (q, k, v))
+        want = oracle_attention(qq, kk, vv, H, mask)
+        want.backward(do[sl].double())
+        assert relmax(o[sl], want.detach()) < 2e-6, (dom, "o")
+        assert relmax(dq[sl], qq.grad) < 5e-6 and relmax(dk[sl], kk.grad) < 5e-6 and relmax(dv[sl], vv.grad) < 5e-6, dom
