@@ -124,6 +124,50 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(float* __restrict__
     }
 }
 
+// Catch-up driven by the raw index list instead of the unique list: one half-wave per gathered POSITION checks its
+// row and replays if it lags.  Positions sharing a row are serialised by an atomic claim on `last[row]` (the winner
+// moves it to t - 1 and replays from the value it saw; the others find the row current), and the pad row (80-90 %
+// of the positions) is touched every step, so it never lags.  This takes the sort/unique off the critical path:
+// it is only needed after backward.
+__global__ __launch_bounds__(256) void lazy_adam_catchup_pos_kernel(float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
+                                                                    int* __restrict__ last, const int* __restrict__ idx, int n_idx, int D,
+                                                                    const StepState* __restrict__ stp) {
+    __shared__ AdamCoef tab[COEF_TAB];
+    __shared__ int any_lag;
+    const StepState st = *stp;
+    const long long t = st.step;
+    const int sub = threadIdx.x & 31;
+    const int q = D >> 2;
+    const int hw0 = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), n_hw = gridDim.x * (blockDim.x >> 5);
+    // first sweep: does this block have any lagging row at all? (usually not: skip the coefficient table)
+    if (threadIdx.x == 0) any_lag = 0;
+    __syncthreads();
+    bool mine = false;
+    for (int i = hw0; i < n_idx; i += n_hw) {
+        const long long l = last[idx[i]];
+        if (l > 0 && l < t - 1) mine = true;
+    }
+    if (mine && sub == 0) any_lag = 1;
+    __syncthreads();
+    if (!any_lag) return;
+    fill_coef_table(tab, st);
+    for (int i = hw0; i < n_idx; i += n_hw) {
+        const long long r = idx[i];
+        const int l = last[r];
+        if (!(l > 0 && l < t - 1)) continue;
+        int won = 0;
+        if (sub == 0) won = (atomicCAS(&last[r], l, (int)(t - 1)) == l) ? 1 : 0;      // claim the row for this half-wave
+        won = __shfl(won, threadIdx.x & 32, 64);
+        if (!won) continue;
+        for (int c = sub; c < q; c += 32) {
+            const long long off = r * D + 4 * c;
+            float4 p = ld4(table + off), m = ld4(m_tab + off), v = ld4(v_tab + off);
+            replay_quad(p, m, v, (long long)l + 1, t - 1, st, tab);
+            st4(table + off, p); st4(m_tab + off, m); st4(v_tab + off, v);
+        }
+    }
+}
+
 // bring every row with pending zero-gradient steps up to date (before eval / checkpoint / parity dumps)
 __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
                                                               int* __restrict__ last, long long n_rows, int D, const StepState* __restrict__ stp) {
@@ -293,6 +337,15 @@ extern "C" int amid_optimizer_step_f32(float* p, float* m, float* v, const float
     const int rb = rows_grid(n_uniq_max);
     optimizer_step_kernel<<<(int)db + rb, 256, 0, (hipStream_t)stream>>>(p, m, v, g, n, (int)db, table, m_tab, v_tab, last, uniq_ids, n_uniq,
                                                                           uniq_grad, D, (const StepState*)step_state, grad_scale);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_lazy_adam_catchup_positions_f32(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D,
+                                                    const void* step_state, void* stream) {
+    AMID_CHECK_ARG(table && m && v && last && idx && step_state && D > 0 && (D % 4) == 0 && n_idx > 0);
+    lazy_adam_catchup_pos_kernel<<<rows_grid(n_idx), 256, 0, (hipStream_t)stream>>>(table, m, v, last, idx, n_idx, D,
+                                                                                     (const StepState*)step_state);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -42,35 +42,50 @@ __device__ __forceinline__ void stage_w1t(float* __restrict__ w1t, const float* 
     }
 }
 
-// LN_last + mean over T for (g, b): 8 row groups of 32 lanes; result u_s[D] (LDS) and u (global)
+// LN_last + mean over T for (g, b): 8 row groups of 32 lanes; result u_s[D] (LDS) and u (global).
+// Rows are fetched in chunks of 64 (8 per row group), every load of a chunk issued before the first use:
+// the first version walked the rows one by one through three dependent global passes (mean, variance,
+// normalise) and was pure load latency (33 us for a kernel that moves 13 MB).
+constexpr int HEAD_CHUNK = 8;      // rows per row group per chunk
+
 __device__ __forceinline__ void lnmean_rows(const HeadArgs& a, int g, int b, float* __restrict__ red /* [8][D] */, float* __restrict__ u_s) {
     const int D = a.D, T = a.T, q = D >> 2;
     const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const bool use_ln = a.lnw[0] != nullptr;
     const float* w = a.lnw[g];
     const float* bb = a.lnb[g];
-    for (int c = sub; c < q; c += 32) st4(red + rg * D + 4 * c, make_float4(0.f, 0.f, 0.f, 0.f));
-    for (int t = rg; t < T; t += 8) {
-        const float* row = a.x + (((long long)g * a.B + b) * T + t) * D;
-        float mean = 0.f, rstd = 1.f;
-        if (use_ln) {
-            float s = 0.f;
-            for (int c = sub; c < q; c += 32) s += f4hsum(ld4(row + 4 * c));
-            mean = group_sum<32>(s) / D;
-            float vs = 0.f;
-            for (int c = sub; c < q; c += 32) { float4 v = ld4(row + 4 * c); v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean; vs += f4hsum(f4mul(v, v)); }
-            rstd = 1.0f / sqrtf(group_sum<32>(vs) / D + a.eps);
-        }
-        for (int c = sub; c < q; c += 32) {
-            float4 v = ld4(row + 4 * c);
-            if (use_ln) {
-                const float4 ww = ld4(w + 4 * c), b4 = ld4(bb + 4 * c);
-                v.x = (v.x - mean) * rstd * ww.x + b4.x; v.y = (v.y - mean) * rstd * ww.y + b4.y;
-                v.z = (v.z - mean) * rstd * ww.z + b4.z; v.w = (v.w - mean) * rstd * ww.w + b4.w;
+    const float* xb = a.x + ((long long)g * a.B + b) * T * D;
+    {   // D <= 128: one float4 per lane covers the row; lanes past the row (D = 64) take part in the shuffles with zeros
+        const int c = sub;
+        const bool on = c < q;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 ww = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (use_ln && on) { ww = ld4(w + 4 * c); b4 = ld4(bb + 4 * c); }
+        for (int t0 = 0; t0 < T; t0 += 8 * HEAD_CHUNK) {
+            float4 v[HEAD_CHUNK];
+#pragma unroll
+            for (int i = 0; i < HEAD_CHUNK; ++i) {
+                const int t = t0 + rg + 8 * i;
+                v[i] = (t < T && on) ? ld4(xb + (long long)t * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            float* rp = red + rg * D + 4 * c;
-            st4(rp, f4add(ld4(rp), v));
+#pragma unroll
+            for (int i = 0; i < HEAD_CHUNK; ++i) {
+                const int t = t0 + rg + 8 * i;
+                if (t < T) {                              // uniform over the 32 lanes of the row group
+                    float4 y = v[i];
+                    if (use_ln) {
+                        float mean, rstd;
+                        mean = group_sum<32>(f4hsum(y)) / D;
+                        float4 d4 = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
+                        if (!on) d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        rstd = 1.0f / sqrtf(group_sum<32>(f4hsum(f4mul(d4, d4))) / D + a.eps);
+                        y = make_float4(d4.x * rstd * ww.x + b4.x, d4.y * rstd * ww.y + b4.y, d4.z * rstd * ww.z + b4.z, d4.w * rstd * ww.w + b4.w);
+                    }
+                    acc = f4add(acc, y);
+                }
+            }
         }
+        if (on) st4(red + rg * D + 4 * c, acc);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < D; e += blockDim.x) {
@@ -174,35 +189,48 @@ __device__ __forceinline__ void lnmean_rows_bwd(const HeadArgs& a, int g, int b,
     const bool use_ln = a.lnw[0] != nullptr;
     const float* w = a.lnw[g];
     const float invT = 1.0f / T;
-    for (int c = sub; c < 2 * q; c += 32) st4(red + rg * 2 * D + 4 * c, make_float4(0.f, 0.f, 0.f, 0.f));
-    for (int t = rg; t < T; t += 8) {
-        const long long ro = (((long long)g * a.B + b) * T + t) * D;
-        if (!use_ln) {
-            for (int c = sub; c < q; c += 32) st4(a.dx + ro + 4 * c, f4scale(ld4(du_s + 4 * c), invT));
-            continue;
+    const long long base = ((long long)g * a.B + b) * T * D;
+    {
+        const int c = sub;
+        const bool on = c < q;
+        float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
+        const float4 dy = on ? f4scale(ld4(du_s + 4 * c), invT) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 gy = dy;
+        if (use_ln && on) gy = f4mul(dy, ld4(w + 4 * c));
+        const float c1 = use_ln ? group_sum<32>(f4hsum(gy)) / D : 0.f;      // same for every row: dy does not depend on t
+        for (int t0 = 0; t0 < T; t0 += 8 * HEAD_CHUNK) {
+            float4 v[HEAD_CHUNK];
+            if (use_ln) {
+#pragma unroll
+                for (int i = 0; i < HEAD_CHUNK; ++i) {
+                    const int t = t0 + rg + 8 * i;
+                    v[i] = (t < T && on) ? ld4(a.x + base + (long long)t * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < HEAD_CHUNK; ++i) {
+                const int t = t0 + rg + 8 * i;
+                if (t < T) {
+                    float4 out = dy;
+                    if (use_ln) {
+                        const float mean = group_sum<32>(f4hsum(v[i])) / D;
+                        float4 d4 = make_float4(v[i].x - mean, v[i].y - mean, v[i].z - mean, v[i].w - mean);
+                        if (!on) d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float rstd = 1.0f / sqrtf(group_sum<32>(f4hsum(f4mul(d4, d4))) / D + a.eps);
+                        const float4 xh = f4scale(d4, rstd);
+                        const float c2 = group_sum<32>(f4hsum(f4mul(gy, xh))) / D;
+                        out = make_float4(rstd * (gy.x - c1 - xh.x * c2), rstd * (gy.y - c1 - xh.y * c2), rstd * (gy.z - c1 - xh.z * c2),
+                                          rstd * (gy.w - c1 - xh.w * c2));
+                        dgam = f4add(dgam, f4mul(dy, xh));
+                        dbet = f4add(dbet, dy);
+                    }
+                    if (on) st4(a.dx + base + (long long)t * D + 4 * c, out);
+                }
+            }
         }
-        float sx = 0.f;
-        for (int c = sub; c < q; c += 32) sx += f4hsum(ld4(a.x + ro + 4 * c));
-        const float mean = group_sum<32>(sx) / D;
-        float vs = 0.f;
-        for (int c = sub; c < q; c += 32) { float4 v = ld4(a.x + ro + 4 * c); v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean; vs += f4hsum(f4mul(v, v)); }
-        const float rstd = 1.0f / sqrtf(group_sum<32>(vs) / D + a.eps);
-        float a1 = 0.f, a2 = 0.f;
-        for (int c = sub; c < q; c += 32) {
-            const float4 v = ld4(a.x + ro + 4 * c), dy = f4scale(ld4(du_s + 4 * c), invT), gy = f4mul(dy, ld4(w + 4 * c));
-            const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
-            a1 += f4hsum(gy);
-            a2 += f4hsum(f4mul(gy, xh));
-        }
-        const float c1 = group_sum<32>(a1) / D, c2 = group_sum<32>(a2) / D;
-        for (int c = sub; c < q; c += 32) {
-            const float4 v = ld4(a.x + ro + 4 * c), dy = f4scale(ld4(du_s + 4 * c), invT), gy = f4mul(dy, ld4(w + 4 * c));
-            const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
-            st4(a.dx + ro + 4 * c, make_float4(rstd * (gy.x - c1 - xh.x * c2), rstd * (gy.y - c1 - xh.y * c2), rstd * (gy.z - c1 - xh.z * c2),
-                                               rstd * (gy.w - c1 - xh.w * c2)));
-            float* rp = red + rg * 2 * D + 4 * c;
-            st4(rp, f4add(ld4(rp), f4mul(dy, xh)));
-            st4(rp + D, f4add(ld4(rp + D), dy));
+        if (on) {
+            st4(red + rg * 2 * D + 4 * c, dgam);
+            st4(red + rg * 2 * D + D + 4 * c, dbet);
         }
     }
     __syncthreads();
@@ -326,7 +354,7 @@ using namespace amid;
 
 static int head_fill(HeadArgs& a, const float* x, const float* const* lnw, const float* const* lnb, const float* items, const float* w1,
                      const float* b1, const float* w2, const float* b2, int B, int T, int NI, int D, int hid, float eps) {
-    if (!(x && items && w1 && b1 && w2 && b2) || B <= 0 || T <= 0 || NI <= 0 || D <= 0 || (D % 32) != 0 || hid <= 0 || hid > 64 || (hid % 4) != 0)
+    if (!(x && items && w1 && b1 && w2 && b2) || B <= 0 || T <= 0 || NI <= 0 || D <= 0 || (D % 32) != 0 || D > 128 || hid <= 0 || hid > 64 || (hid % 4) != 0)
         return AMID_ERR_ARG;
     a.x = x; a.items = items; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     for (int g = 0; g < 2; ++g) { a.lnw[g] = lnw ? lnw[g] : nullptr; a.lnb[g] = lnb ? lnb[g] : nullptr; }

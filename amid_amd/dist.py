@@ -32,9 +32,12 @@ class MergeBackend(Protocol):
 
 
 class SparseDenseExchange:
-    def __init__(self, backend: MergeBackend, group=None):
+    def __init__(self, backend: MergeBackend, group=None, host_staging: bool = False):
         self.backend = backend
         self.group = group
+        # host_staging: move collective payloads through pinned host memory (for process groups without device
+        # collectives, e.g. gloo with GPU tensors in the single-GPU two-process test); never used with RCCL
+        self.host_staging = host_staging
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -45,7 +48,12 @@ class SparseDenseExchange:
 
     def all_reduce_dense(self, flat_grad: torch.Tensor) -> None:
         if self.world > 1:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            if self.host_staging and flat_grad.is_cuda:
+                h = flat_grad.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                flat_grad.copy_(h)
+            else:
+                dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
     def exchange_sparse(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor
                         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -53,7 +61,7 @@ class SparseDenseExchange:
         if self.world == 1:
             return uniq_ids, uniq_rows, n_uniq
         # one small host sync per step: the padded length is the world's largest unique count
-        nmax = n_uniq.clone()
+        nmax = n_uniq.cpu() if self.host_staging else n_uniq.clone()
         dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=self.group)
         umax = int(nmax.item())
         ids = uniq_ids[:umax].clone()
@@ -63,8 +71,15 @@ class SparseDenseExchange:
         rows = rows * (~pad).unsqueeze(1).to(rows.dtype)
         all_ids = torch.empty(self.world * umax, dtype=ids.dtype, device=ids.device)
         all_rows = torch.empty(self.world * umax, rows.shape[1], dtype=rows.dtype, device=rows.device)
-        dist.all_gather_into_tensor(all_ids, ids, group=self.group)
-        dist.all_gather_into_tensor(all_rows, rows, group=self.group)
+        if self.host_staging and ids.is_cuda:
+            h_ids, h_rows = torch.empty(all_ids.shape, dtype=ids.dtype), torch.empty(all_rows.shape, dtype=rows.dtype)
+            dist.all_gather_into_tensor(h_ids, ids.cpu(), group=self.group)
+            dist.all_gather_into_tensor(h_rows, rows.cpu(), group=self.group)
+            all_ids.copy_(h_ids)
+            all_rows.copy_(h_rows)
+        else:
+            dist.all_gather_into_tensor(all_ids, ids, group=self.group)
+            dist.all_gather_into_tensor(all_rows, rows, group=self.group)
         return self.backend.merge(all_ids, all_rows)
 
 

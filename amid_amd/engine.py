@@ -246,6 +246,10 @@ class SasrecEngine:
         self.device = torch.device(device)
         # every kernel of the engine runs on this (non-default, hence capturable) HIP stream
         self.stream = torch.cuda.Stream(device=self.device)
+        # the index sort only feeds the segment reduce after backward: it runs on this side stream, beside the forward pass
+        self.side = torch.cuda.Stream(device=self.device)
+        self.ev_idx = torch.cuda.Event()
+        self.ev_sorted = torch.cuda.Event()
         self.n_rows, self.D, self.T, self.hid, self.H = int(item_length), int(emb_dim), int(seq_len), int(hid_dim), SASREC_HEADS
         D = self.D
         self.dense = FlatParams(sasrec_dense_names(self.T, D, self.hid), self.device)
@@ -271,6 +275,7 @@ class SasrecEngine:
         return self.stream.cuda_stream
 
     def sync(self) -> None:
+        self.join_sort()
         self.stream.synchronize()
 
     # ------------------------------------------------------------------ state
@@ -357,14 +362,25 @@ class SasrecEngine:
         if bump_step:
             self.step += 1
         if sparse:
+            # fork: sort / unique on the side stream (joined by enqueue_backward just before the segment reduce)
+            self.ev_idx.record(self.stream)
+            self.side.wait_event(self.ev_idx)
             L.call("amid_sort_unique_i32", pl.idx_all.data_ptr(), shp.n_idx, self.n_rows, pl.sort_ws.data_ptr(), pl.pos_sorted.data_ptr(),
-                   pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_uniq.data_ptr(), s)
+                   pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_uniq.data_ptr(), self.side.cuda_stream)
+            self.ev_sorted.record(self.side)
+            self._sort_pending = True
+
+    def join_sort(self) -> None:
+        """Make the main stream wait for the side-stream sort (no-op if nothing is pending)."""
+        if getattr(self, "_sort_pending", False):
+            self.stream.wait_event(self.ev_sorted)
+            self._sort_pending = False
 
     def enqueue_catchup(self, pl: SasrecPlan) -> None:
+        """Replay pending zero-gradient Adam steps of the rows this batch is about to gather (by position: no sort needed)."""
         self._ensure_opt_state()
-        lib().call("amid_lazy_adam_catchup_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
-                   self.table_last.data_ptr(), pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), pl.shape.n_idx, self.D,
-                   self.step_state.data_ptr(), self.s)
+        lib().call("amid_lazy_adam_catchup_positions_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
+                   self.table_last.data_ptr(), pl.idx_all.data_ptr(), pl.shape.n_idx, self.D, self.step_state.data_ptr(), self.s)
 
     def enqueue_forward(self, pl: SasrecPlan, train: bool, with_loss: bool, sum_loss: bool = True) -> None:
         L, s, shp, D = lib(), self.s, pl.shape, self.D
@@ -443,6 +459,7 @@ class SasrecEngine:
         L.call("amid_embed_bwd_f32", pl.dxg.data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits, pl.dpos_part.data_ptr(), st, tr,
                SASREC_P_DROP, s)
         L.call("amid_reduce_partials_f32", pl.red_entries.data_ptr(), pl.red_n, pl.red_max, s)
+        self.join_sort()
         L.call("amid_embgrad_segreduce_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(),
                shp.n_idx, D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), s)
 

@@ -147,11 +147,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # AMID_BENCH_BACKEND=gloo (+ host-staged payloads, ranks folded onto the visible GPUs) only exists to smoke-test the
+    # N > 1 control flow on a single-GPU box; real runs use RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("AMID_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from amid_amd._lib import KernelTimer, lib
     from amid_amd.dist import SparseDenseExchange
@@ -172,7 +179,7 @@ def main():
         eng.load_packed(pl, pool[i % n_pool])
 
     use_graph = not args.no_graph
-    exchange = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx)) if world > 1 else None
+    exchange = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=(backend != "nccl")) if world > 1 else None
     load(0)
     if use_graph:
         if world == 1:
@@ -206,7 +213,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     loss_last = float(pl.loss.item())

@@ -80,6 +80,9 @@ int amid_embgrad_segreduce_f32(const float* grad_rows /* [n_idx, D] */, const in
  * lazy rows: m, v [n_rows, D], last [n_rows] int32 (0 = never touched). */
 int amid_lazy_adam_catchup_f32(float* table, float* m, float* v, int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max,
                                int D, const void* step_state, void* stream);
+/* catch-up driven by the raw (non-unique) index list: needs no sort, so the sort can overlap the forward pass */
+int amid_lazy_adam_catchup_positions_f32(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D,
+                                         const void* step_state, void* stream);
 int amid_lazy_adam_apply_f32(float* table, float* m, float* v, int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max,
                              const float* uniq_grad, float grad_scale, int D, const void* step_state, void* stream);
 int amid_lazy_adam_flush_f32(float* table, float* m, float* v, int* last, long long n_rows, int D, const void* step_state, void* stream);

@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
         U = int(mnu.item())
         table_grad = torch.zeros(n_items, D)
         table_grad[mid[:U].long()] = mrows[:U]
-        q.put((rank, flat * ex.grad_scale, table_grad * ex.grad_scale, int(nu.item()), U))
+        q.put((rank, (flat * ex.grad_scale).numpy(), (table_grad * ex.grad_scale).numpy(), int(nu.item()), U))
     finally:
         dist.destroy_process_group()
 
@@ -86,6 +86,7 @@ def test_exchange_world2_matches_single_process_global_batch():
     names = [k for k in g if k != "item_emb_layer.emb_item.weight"]
     want_flat = torch.cat([g[k].reshape(-1) for k in names])
     want_tab = g["item_emb_layer.emb_item.weight"]
+    outs = [(r, torch.from_numpy(f), torch.from_numpy(t), nu, U) for r, f, t, nu, U in outs]
     for rank, flat, tab, nu, U in outs:
         assert float((flat - want_flat).abs().max()) < 1e-6
         assert float((tab - want_tab).abs().max()) < 1e-6

@@ -157,8 +157,10 @@ def test_dense_adam_matches_torch_op_order(L):
         assert float((pd.cpu() - P["w"]).abs().max()) < 1e-6, t
 
 
-def test_lazy_adam_equals_dense_adam_with_idle_rows(L):
-    """Rows touched at some steps and idle at others must follow the dense trajectory."""
+@pytest.mark.parametrize("by_position", [False, True])
+def test_lazy_adam_equals_dense_adam_with_idle_rows(L, by_position):
+    """Rows touched at some steps and idle at others must follow the dense trajectory.
+    by_position: catch-up driven by the raw index list (duplicates included) instead of the unique list."""
     g = torch.Generator().manual_seed(11)
     n_rows, D, steps = 40, 64, 30
     tab0 = torch.randn(n_rows, D, generator=g)
@@ -177,8 +179,14 @@ def test_lazy_adam_equals_dense_adam_with_idle_rows(L):
         st = step_state(L, 0, t, lr=5e-3)
         ud, gd = dev(touched.int()), dev(grows)
         nu = torch.tensor([touched.numel()], dtype=torch.int32, device="cuda")
-        L.call("amid_lazy_adam_catchup_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), ud.data_ptr(), nu.data_ptr(),
-               n_rows, D, st.data_ptr(), stream())
+        if by_position:
+            pos = touched[torch.randint(0, touched.numel(), (3 * touched.numel() + 5,), generator=g)]       # duplicates, any order
+            pos = torch.cat((pos, touched)).int().cuda()
+            L.call("amid_lazy_adam_catchup_positions_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), pos.data_ptr(),
+                   pos.numel(), D, st.data_ptr(), stream())
+        else:
+            L.call("amid_lazy_adam_catchup_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), ud.data_ptr(), nu.data_ptr(),
+                   n_rows, D, st.data_ptr(), stream())
         torch.cuda.synchronize()
         # the rows about to be gathered must already equal the dense trajectory after step t-1
         assert float((tab.cpu()[touched] - P["t"][touched]).abs().max()) < 2e-6, ("pre-gather", t)
