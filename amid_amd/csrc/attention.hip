@@ -194,11 +194,13 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
                 const bool keep = !a.train || rng_field(r, j % per, dbits) >= dthr;
                 if (keep) kw |= 1ull << (j & 63);
                 if (j < jmax) {
-                    const float s = score<HD>(a, qs, S0 + j * D + h * HD, ic, j, kk ? kk[j] != 0 : true);
+                    const bool key_ok = kk ? kk[j] != 0 : true;
+                    const float s = score<HD>(a, qs, S0 + j * D + h * HD, ic, j, key_ok);
                     const float p = expf(s - m) * rl;
                     const float dpd = dot_lds<HD>(dO, S1 + j * D + h * HD);
                     const float dp = keep ? dpd * a.dscale : 0.f;
-                    const float ds = p * (dp - delta);
+                    // masked_fill cuts the gradient of a masked score (it matters when EVERY key of a row is masked: p = 1/T there)
+                    const float ds = key_ok ? p * (dp - delta) : 0.f;
                     const float* kr = S0 + j * D + h * HD;
 #pragma unroll
                     for (int d = 0; d < HD; d += 4) {
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
             const bool keep = (keepw[(h * T + i) * TW + (jc >> 6)] >> (jc & 63)) & 1ull;
             const float pd = keep ? p * a.dscale : 0.f;
             const float dp = keep ? dpd * a.dscale : 0.f;
-            const float ds = p * (dp - rs[2]);
+            const float ds = key_ok ? p * (dp - rs[2]) : 0.f;
             const float dsq = a.causal ? ds : ds / a.scale;
 #pragma unroll
             for (int d = 0; d < HD; d += 4) {

@@ -182,6 +182,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(float* __restrict__ dxg,
     }
 }
 
+// key mask of BERT4Rec: keep[b][t] = seq[b][t] > 0 (reference model_seq.py:288)
+__global__ __launch_bounds__(256) void key_keep_kernel(const long long* __restrict__ seq, long long n, unsigned char* __restrict__ keep) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keep[i] = seq[i] > 0 ? 1 : 0;
+}
+
 }  // namespace amid
 
 using namespace amid;
@@ -246,6 +252,13 @@ extern "C" int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, i
                                                                                                (const RngState*)rng_state, tr,
                                                                                                keep_thr16(p_drop),
                                                                                                tr ? 1.0f / (1.0f - p_drop) : 1.0f);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_key_keep_u8(const long long* seq, long long n, unsigned char* keep, void* stream) {
+    AMID_CHECK_ARG(seq && keep && n > 0);
+    key_keep_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(seq, n, keep);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -135,17 +135,13 @@ class SasrecPlan:
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         # forward
         self.xg = f(N, D)
-        self.tmq = torch.zeros(2 * M, D // 4, dtype=torch.uint8, device=dev)
         self.x = [self.xg[: 2 * M], f(2 * M, D), f(2 * M, D)]
-        self.qn = [f(2 * M, D) for _ in range(2)]
         self.q = [f(2 * M, D) for _ in range(2)]
         self.k = [f(2 * M, D) for _ in range(2)]
         self.v = [f(2 * M, D) for _ in range(2)]
         self.o = [f(2 * M, D) for _ in range(2)]
         self.stats = [f(2 * M, H, 2) for _ in range(2)]
-        self.r = [f(2 * M, D) for _ in range(2)]
-        self.y = [f(2 * M, D) for _ in range(2)]
-        self.h = [f(2 * M, D) for _ in range(2)]
+        self._alloc_model_fwd(eng, f)
         self.u = f(2, B, D)
         self.p1 = f(B, NI)
         self.p2 = f(B, NI)
@@ -159,17 +155,12 @@ class SasrecPlan:
         self.dxg = f(N, D)
         self.dxbuf = f(2 * M, D)
         self.du = f(2, B, D)
-        self.dpre1, self.dpre2, self.dr, self.d_o = f(2 * M, D), f(2 * M, D), f(2 * M, D), f(2 * M, D)
+        self.d_o = f(2 * M, D)
         self.dq, self.dk, self.dv = f(2 * M, D), f(2 * M, D), f(2 * M, D)
-        # 2 domains x 6 weights x splits workgroups: 21 splits = 252 workgroups, one round on the 256 CUs
-        self.splits = max(1, min(21, M // 128))
-        self.w_part = [f(2, 6, self.splits, D * D) for _ in range(2)]
-        self.b_part = [f(2, 6, self.splits, D) for _ in range(2)]
         self.ln1_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
         self.ln2_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
         self.last_part = f(2 * B, 2, D)
-        self.pos_splits = max(1, min(8, B // 16))
-        self.dpos_part = f(self.pos_splits, 2, T, D)
+        self._alloc_model_bwd(eng, f)
         self.sc_P = L.value("amid_scorer_part_floats", D, hid)
         self.sc_part = f(B, self.sc_P)
         # sparse side
@@ -184,6 +175,25 @@ class SasrecPlan:
         self._build_reduce_table(eng)
         self.graph = None
 
+    # ---- model-specific pieces (BertPlan overrides these three) -------------------------------------
+    def _alloc_model_fwd(self, eng: "SasrecEngine", f) -> None:
+        M, D = self.shape.M, eng.D
+        self.tmq = torch.zeros(2 * M, D // 4, dtype=torch.uint8, device=eng.device)
+        self.qn = [f(2 * M, D) for _ in range(2)]
+        self.r = [f(2 * M, D) for _ in range(2)]
+        self.y = [f(2 * M, D) for _ in range(2)]
+        self.h = [f(2 * M, D) for _ in range(2)]
+
+    def _alloc_model_bwd(self, eng: "SasrecEngine", f) -> None:
+        M, D, B, T = self.shape.M, eng.D, self.shape.B, self.shape.T
+        self.dpre1, self.dpre2, self.dr = f(2 * M, D), f(2 * M, D), f(2 * M, D)
+        # 2 domains x 6 weights x splits workgroups: 21 splits = 252 workgroups, one round on the 256 CUs
+        self.splits = max(1, min(21, M // 128))
+        self.w_part = [f(2, 6, self.splits, D * D) for _ in range(2)]
+        self.b_part = [f(2, 6, self.splits, D) for _ in range(2)]
+        self.pos_splits = max(1, min(8, B // 16))
+        self.dpos_part = f(self.pos_splits, 2, T, D)
+
     def _build_reduce_table(self, eng: "SasrecEngine") -> None:
         L = lib()
         D, hid, B = eng.D, eng.hid, self.shape.B
@@ -193,6 +203,24 @@ class SasrecPlan:
         def add(src_t: torch.Tensor, src_off: int, dst_ptr: int, stride: int, n_part: int, count: int):
             ent.append((src_t.data_ptr() + 4 * src_off, dst_ptr, stride, n_part, count))
 
+        self._model_reduce_entries(eng, add)
+        ent.append((self.loss_part.data_ptr(), self.loss.data_ptr(), 1, B, 1))          # loss = sum of the per-row partials
+        P = self.sc_P
+        add(self.sc_part, 0, fp.ptr("predictModule.fc.0.weight", G), P, B, hid * 2 * D)
+        add(self.sc_part, hid * 2 * D, fp.ptr("predictModule.fc.0.bias", G), P, B, hid)
+        add(self.sc_part, hid * 2 * D + hid, fp.ptr("predictModule.fc.2.weight", G), P, B, hid)
+        add(self.sc_part, hid * 2 * D + 2 * hid, fp.ptr("predictModule.fc.2.bias", G), P, B, 1)
+        esz = L.value("amid_reduce_entry_bytes")
+        host = (ctypes.c_ubyte * (esz * len(ent)))()
+        for i, (s, d, st, n, c) in enumerate(ent):
+            L.call("amid_reduce_entry_pack", ctypes.addressof(host), i, s, d, st, n, c)
+        self.red_entries = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(eng.device)
+        self.red_n = len(ent)
+        self.red_max = max(c for *_, c in ent)
+
+    def _model_reduce_entries(self, eng: "SasrecEngine", add) -> None:
+        D, B = eng.D, self.shape.B
+        fp, G = eng.dense, eng.dense.grad
         S = self.splits
         for l in (0, 1):
             for g in (0, 1):
@@ -220,29 +248,28 @@ class SasrecPlan:
         T = self.shape.T
         for g in (0, 1):
             add(self.dpos_part, g * T * D, fp.ptr(f"sac{g + 1}.pos_emb.weight", G), 2 * T * D, self.pos_splits, T * D)
-        ent.append((self.loss_part.data_ptr(), self.loss.data_ptr(), 1, B, 1))          # loss = sum of the per-row partials
-        P = self.sc_P
-        add(self.sc_part, 0, fp.ptr("predictModule.fc.0.weight", G), P, B, hid * 2 * D)
-        add(self.sc_part, hid * 2 * D, fp.ptr("predictModule.fc.0.bias", G), P, B, hid)
-        add(self.sc_part, hid * 2 * D + hid, fp.ptr("predictModule.fc.2.weight", G), P, B, hid)
-        add(self.sc_part, hid * 2 * D + 2 * hid, fp.ptr("predictModule.fc.2.bias", G), P, B, 1)
-        esz = L.value("amid_reduce_entry_bytes")
-        host = (ctypes.c_ubyte * (esz * len(ent)))()
-        for i, (s, d, st, n, c) in enumerate(ent):
-            L.call("amid_reduce_entry_pack", ctypes.addressof(host), i, s, d, st, n, c)
-        self.red_entries = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(eng.device)
-        self.red_n = len(ent)
-        self.red_max = max(c for *_, c in ent)
 
 
 class SasrecEngine:
     """Parameters, optimizer state and launch sequences for SASRec (isInC = isItC = isDR = False)."""
 
+    HEADS = SASREC_HEADS
+    PLAN_CLS = SasrecPlan
+    EMB_DIMS = (64, 128)
+
+    def _dense_names(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        return sasrec_dense_names(self.T, self.D, self.hid)
+
+    def _alloc_model_buffers(self) -> None:
+        D = self.D
+        # transposed copies of the 24 square projection weights
+        self.wT = torch.zeros(2, 2, 6, D * D, dtype=torch.float32, device=self.device)     # [layer][domain][q,k,v,o,c1,c2]
+
     def __init__(self, item_length: int, emb_dim: int, seq_len: int, hid_dim: int, device="cuda:0", lr: float = 5e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, seed: int = 0):
         L = lib()        # raises AmidLibraryError when the HIP library is missing: no fallback
-        if emb_dim not in (64, 128):
-            raise ValueError(f"amid_amd SASRec kernels are built for emb_dim in (64, 128), got {emb_dim}")
+        if emb_dim not in self.EMB_DIMS:
+            raise ValueError(f"amid_amd {type(self).__name__} kernels are built for emb_dim in {self.EMB_DIMS}, got {emb_dim}")
         self.device = torch.device(device)
         # every kernel of the engine runs on this (non-default, hence capturable) HIP stream
         self.stream = torch.cuda.Stream(device=self.device)
@@ -250,15 +277,14 @@ class SasrecEngine:
         self.side = torch.cuda.Stream(device=self.device)
         self.ev_idx = torch.cuda.Event()
         self.ev_sorted = torch.cuda.Event()
-        self.n_rows, self.D, self.T, self.hid, self.H = int(item_length), int(emb_dim), int(seq_len), int(hid_dim), SASREC_HEADS
+        self.n_rows, self.D, self.T, self.hid, self.H = int(item_length), int(emb_dim), int(seq_len), int(hid_dim), self.HEADS
         D = self.D
-        self.dense = FlatParams(sasrec_dense_names(self.T, D, self.hid), self.device)
+        self.dense = FlatParams(self._dense_names(), self.device)
         self.table = torch.zeros(self.n_rows, D, dtype=torch.float32, device=self.device)
         self.table_m: Optional[torch.Tensor] = None        # allocated on the first optimizer use
         self.table_v: Optional[torch.Tensor] = None
         self.table_last: Optional[torch.Tensor] = None
-        # transposed copies of the 24 square projection weights
-        self.wT = torch.zeros(2, 2, 6, D * D, dtype=torch.float32, device=self.device)     # [layer][domain][q,k,v,o,c1,c2]
+        self._alloc_model_buffers()
         self.hyper = dict(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps)
         self.seed = int(seed)
         self.step = 0
@@ -308,7 +334,7 @@ class SasrecEngine:
         if key not in self.plans:
             if T > self.T:
                 raise ValueError(f"sequence length {T} exceeds pos_emb size {self.T}")
-            self.plans[key] = SasrecPlan(self, Shape(B, T, NI), need_grad)
+            self.plans[key] = self.PLAN_CLS(self, Shape(B, T, NI), need_grad)
             torch.cuda.synchronize(self.device)      # buffers were zero-filled on torch's stream
         return self.plans[key]
 

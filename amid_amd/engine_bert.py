@@ -1,0 +1,200 @@
+"""Host-side driver of the BERT4Rec variant of the hot path (reference: BERT4Rec model_seq.py:248-309; training loop
+train_sr.py:190-217).  Same engine as SASRec (table, lazy Adam, index sort, segment reduce, fused head, hipGraph);
+only the encoder launches, the saved activations and the dense parameter list differ.
+
+Reference quirks kept: hidden size 128 / 4 heads / FFN 512 / dropout 0.1 are hard-coded whatever ``--emb_dim`` says
+(model_seq.py:264-267), so emb_dim must be 128; there is NO positional embedding and no final LayerNorm; ONE key mask,
+taken from ``seq_d2 > 0``, is applied to BOTH encoders (model_seq.py:288, :295-298)."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+from ._lib import lib, ptr_array
+from .engine import SasrecEngine, SasrecPlan
+
+BERT_HEADS, BERT_FF, BERT_P_DROP, BERT_HIDDEN = 4, 512, 0.1, 128
+
+
+def bert4rec_dense_names(hid: int) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Non-table parameters in the reference's state_dict order."""
+    D, F = BERT_HIDDEN, BERT_FF
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    for d in (1, 2):
+        for l in (0, 1):
+            pre = f"transform{d}.{l}"
+            for j in range(3):
+                out.append((f"{pre}.attention.linear_layers.{j}.weight", (D, D)))
+                out.append((f"{pre}.attention.linear_layers.{j}.bias", (D,)))
+            out.append((f"{pre}.attention.output_linear.weight", (D, D)))
+            out.append((f"{pre}.attention.output_linear.bias", (D,)))
+            out.append((f"{pre}.feed_forward.w_1.weight", (F, D)))
+            out.append((f"{pre}.feed_forward.w_1.bias", (F,)))
+            out.append((f"{pre}.feed_forward.w_2.weight", (D, F)))
+            out.append((f"{pre}.feed_forward.w_2.bias", (D,)))
+            out.append((f"{pre}.input_sublayer.norm.a_2", (D,)))
+            out.append((f"{pre}.input_sublayer.norm.b_2", (D,)))
+            out.append((f"{pre}.output_sublayer.norm.a_2", (D,)))
+            out.append((f"{pre}.output_sublayer.norm.b_2", (D,)))
+    out.append(("predictModule.fc.0.weight", (hid, 2 * D)))
+    out.append(("predictModule.fc.0.bias", (hid,)))
+    out.append(("predictModule.fc.2.weight", (1, hid)))
+    out.append(("predictModule.fc.2.bias", (1,)))
+    return out
+
+
+N_ENT = 12      # weight-gradient tiles of 128 x 128 per block: q, k, v, o, 4 x w_1, 4 x w_2
+
+
+class BertPlan(SasrecPlan):
+    def _alloc_model_fwd(self, eng, f) -> None:
+        M, D, F = self.shape.M, eng.D, BERT_FF
+        self.key_keep = torch.zeros(self.shape.B, self.shape.T, dtype=torch.uint8, device=eng.device)
+        self.y = [f(2 * M, D) for _ in range(2)]        # LNb_in(x)
+        self.x1 = [f(2 * M, D) for _ in range(2)]
+        self.y2 = [f(2 * M, D) for _ in range(2)]       # LNb_out(x1)
+        self.pre = [f(2 * M, F) for _ in range(2)]
+        self.h = [f(2 * M, F) for _ in range(2)]
+
+    def _alloc_model_bwd(self, eng, f) -> None:
+        M, D, F = self.shape.M, eng.D, BERT_FF
+        self.dz, self.dt, self.dx1 = f(2 * M, D), f(2 * M, D), f(2 * M, D)
+        self.dpre = f(2 * M, F)
+        self.splits = max(1, min(10, M // 128))          # 2 domains x 12 tiles x 10 splits = 240 workgroups
+        self.w_part = [f(2, N_ENT, self.splits, D * D) for _ in range(2)]
+        self.b_part = [f(2, N_ENT, self.splits, D) for _ in range(2)]
+
+    def _model_reduce_entries(self, eng, add) -> None:
+        D, F = eng.D, BERT_FF
+        fp, G = eng.dense, eng.dense.grad
+        S = self.splits
+        for l in (0, 1):
+            for g in (0, 1):
+                pre = f"transform{g + 1}.{l}"
+                wbase = lambda e: ((g * N_ENT + e) * S) * D * D      # noqa: E731
+                bbase = lambda e: ((g * N_ENT + e) * S) * D          # noqa: E731
+                for j in range(3):
+                    add(self.w_part[l], wbase(j), fp.ptr(f"{pre}.attention.linear_layers.{j}.weight", G), D * D, S, D * D)
+                    add(self.b_part[l], bbase(j), fp.ptr(f"{pre}.attention.linear_layers.{j}.bias", G), D, S, D)
+                add(self.w_part[l], wbase(3), fp.ptr(f"{pre}.attention.output_linear.weight", G), D * D, S, D * D)
+                add(self.b_part[l], bbase(3), fp.ptr(f"{pre}.attention.output_linear.bias", G), D, S, D)
+                for c in range(4):
+                    # w_1 [512,128]: rows c*128 .. are one contiguous 128 x 128 tile
+                    add(self.w_part[l], wbase(4 + c), fp.ptr(f"{pre}.feed_forward.w_1.weight", G, c * D * D), D * D, S, D * D)
+                    add(self.b_part[l], bbase(4 + c), fp.ptr(f"{pre}.feed_forward.w_1.bias", G, c * D), D, S, D)
+                # w_2 [128,512]: its four column tiles share output group 8 -> partials are [S][128*512] from entry 8 on
+                add(self.w_part[l], wbase(8), fp.ptr(f"{pre}.feed_forward.w_2.weight", G), D * F, S, D * F)
+                add(self.b_part[l], bbase(8), fp.ptr(f"{pre}.feed_forward.w_2.bias", G), D, S, D)
+                tb = g * self.tpg * 2 * D
+                add(self.ln1_part[l], tb, fp.ptr(f"{pre}.input_sublayer.norm.a_2", G), 2 * D, self.tpg, D)
+                add(self.ln1_part[l], tb + D, fp.ptr(f"{pre}.input_sublayer.norm.b_2", G), 2 * D, self.tpg, D)
+                add(self.ln2_part[l], tb, fp.ptr(f"{pre}.output_sublayer.norm.a_2", G), 2 * D, self.tpg, D)
+                add(self.ln2_part[l], tb + D, fp.ptr(f"{pre}.output_sublayer.norm.b_2", G), 2 * D, self.tpg, D)
+
+
+class Bert4recEngine(SasrecEngine):
+    HEADS = BERT_HEADS
+    PLAN_CLS = BertPlan
+    EMB_DIMS = (BERT_HIDDEN,)
+
+    def _dense_names(self):
+        return bert4rec_dense_names(self.hid)
+
+    def _alloc_model_buffers(self) -> None:
+        D, F = self.D, BERT_FF
+        # transposed weights per [layer][domain]: q, k, v, o (128x128), w_1^T [128,512], w_2^T [512,128]
+        self.wT_sq = torch.zeros(2, 2, 4, D * D, dtype=torch.float32, device=self.device)
+        self.w1T = torch.zeros(2, 2, D * F, dtype=torch.float32, device=self.device)
+        self.w2T = torch.zeros(2, 2, F * D, dtype=torch.float32, device=self.device)
+
+    def enqueue_forward(self, pl: BertPlan, train: bool, with_loss: bool, sum_loss: bool = True) -> None:
+        L, s, shp, D = lib(), self.s, pl.shape, self.D
+        B, T, NI, M = shp.B, shp.T, shp.NI, shp.M
+        st = self.step_state.data_ptr()
+        tr = 1 if train else 0
+        fp = self.dense
+        # model_seq.py:288: ONE mask, from domain 2, for both encoders
+        L.call("amid_key_keep_u8", pl.in_seq_d2.data_ptr(), B * T, pl.key_keep.data_ptr(), s)
+        L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI, pl.xg.data_ptr(), None, st, 0,
+               0.0, s)
+        for l in (0, 1):
+            pre = f"transform{{d}}.{l}"
+            w3 = ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.weight") for j in range(3) for d in (1, 2)])
+            b3 = ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.bias") for j in range(3) for d in (1, 2)])
+            L.call("amid_bert_qkv_fwd_f32", pl.x[l].data_ptr(), self._pp(pre + ".input_sublayer.norm.a_2"), self._pp(pre + ".input_sublayer.norm.b_2"),
+                   w3, b3, M, pl.rpt, pl.y[l].data_ptr(), pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), s)
+            L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l,
+                   st, tr, BERT_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
+            L.call("amid_bert_oproj_fwd_f32", pl.o[l].data_ptr(), pl.x[l].data_ptr(), self._pp(pre + ".attention.output_linear.weight"),
+                   self._pp(pre + ".attention.output_linear.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x1[l].data_ptr(), s)
+            L.call("amid_bert_ffn1_fwd_f32", pl.x1[l].data_ptr(), self._pp(pre + ".output_sublayer.norm.a_2"), self._pp(pre + ".output_sublayer.norm.b_2"),
+                   self._pp(pre + ".feed_forward.w_1.weight"), self._pp(pre + ".feed_forward.w_1.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP,
+                   pl.y2[l].data_ptr(), pl.pre[l].data_ptr(), pl.h[l].data_ptr(), s)
+            L.call("amid_bert_ffn2_fwd_f32", pl.h[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".feed_forward.w_2.weight"),
+                   self._pp(pre + ".feed_forward.w_2.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x[l + 1].data_ptr(), s)
+        items = pl.xg.data_ptr() + 4 * 2 * M * D
+        L.call("amid_head_fwd_f32", pl.x[2].data_ptr(), None, None, items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
+               fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr() if with_loss else None,
+               pl.domain.data_ptr() if with_loss else None, B, T, NI, D, self.hid, 0.0, pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(),
+               pl.dp1.data_ptr() if with_loss else None, pl.dp2.data_ptr() if with_loss else None,
+               pl.loss_part.data_ptr() if with_loss else None, s)
+        if with_loss and sum_loss:
+            L.call("amid_sum_vector_f32", pl.loss_part.data_ptr(), B, pl.loss.data_ptr(), s)
+
+    def enqueue_backward(self, pl: BertPlan, train: bool) -> None:
+        L, s, shp, D, F = lib(), self.s, pl.shape, self.D, BERT_FF
+        B, T, NI, M = shp.B, shp.T, shp.NI, shp.M
+        st = self.step_state.data_ptr()
+        tr = 1 if train else 0
+        fp = self.dense
+        # transposed weights (rectangular ones included)
+        src, dst, rows, cols = [], [], [], []
+        for l in (0, 1):
+            for g in (0, 1):
+                pre = f"transform{g + 1}.{l}"
+                for j in range(3):
+                    src.append(fp.ptr(f"{pre}.attention.linear_layers.{j}.weight")); dst.append(self.wT_sq[l, g, j].data_ptr()); rows.append(D); cols.append(D)
+                src.append(fp.ptr(f"{pre}.attention.output_linear.weight")); dst.append(self.wT_sq[l, g, 3].data_ptr()); rows.append(D); cols.append(D)
+                src.append(fp.ptr(f"{pre}.feed_forward.w_1.weight")); dst.append(self.w1T[l, g].data_ptr()); rows.append(F); cols.append(D)
+                src.append(fp.ptr(f"{pre}.feed_forward.w_2.weight")); dst.append(self.w2T[l, g].data_ptr()); rows.append(D); cols.append(F)
+        import ctypes
+        L.call("amid_transpose_rect_f32", ptr_array(src), ptr_array(dst), (ctypes.c_int * len(rows))(*rows), (ctypes.c_int * len(cols))(*cols),
+               len(src), s)
+        items = pl.xg.data_ptr() + 4 * 2 * M * D
+        ditems = pl.dxg.data_ptr() + 4 * 2 * M * D
+        L.call("amid_head_bwd_f32", pl.x[2].data_ptr(), None, pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"),
+               fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(),
+               pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, T, NI, D, self.hid, 0.0, pl.dxbuf.data_ptr(), ditems, None,
+               pl.sc_part.data_ptr(), None, None, 0, s)
+        for l in (1, 0):
+            pre = f"transform{{d}}.{l}"
+            wsq = lambda j: ptr_array([self.wT_sq[l, g, j].data_ptr() for g in (0, 1)])      # noqa: E731
+            L.call("amid_bert_ffn2_bwd_f32", pl.dxbuf.data_ptr(), pl.pre[l].data_ptr(), ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]),
+                   M, pl.rpt, l, st, tr, BERT_P_DROP, pl.dz.data_ptr(), pl.dpre.data_ptr(), s)
+            L.call("amid_bert_ffn1_bwd_f32", pl.dpre.data_ptr(), pl.dxbuf.data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".output_sublayer.norm.a_2"),
+                   ptr_array([self.w1T[l, g].data_ptr() for g in (0, 1)]), wsq(3), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.dx1.data_ptr(),
+                   pl.dt.data_ptr(), pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), s)
+            L.call("amid_attn_bwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(), pl.stats[l].data_ptr(),
+                   pl.d_o.data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l, st, tr, BERT_P_DROP, pl.dq.data_ptr(), pl.dk.data_ptr(),
+                   pl.dv.data_ptr(), s)
+            dx_out = pl.dxg if l == 0 else pl.dxbuf
+            wT3 = ptr_array([self.wT_sq[l, g, j].data_ptr() for j in range(3) for g in (0, 1)])
+            # weight-gradient tiles need dx-independent operands only: launch before qkv_bwd overwrites dxbuf
+            dy = [pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dt.data_ptr()]
+            xx = [pl.y[l].data_ptr()] * 3 + [pl.o[l].data_ptr()]
+            ldy, ldx = [D] * 4, [D] * 4
+            old, ogr, oco = [D] * 8 + [F] * 4, list(range(8)) + [8] * 4, [0] * 8 + [c * D for c in range(4)]
+            for c in range(4):                                   # w_1 tile c: dY = dpre[:, c*128:], X = y2
+                dy.append(pl.dpre.data_ptr() + 4 * c * D); xx.append(pl.y2[l].data_ptr()); ldy.append(F); ldx.append(D)
+            for c in range(4):                                   # w_2 tile c: dY = dz, X = h[:, c*128:]
+                dy.append(pl.dz.data_ptr()); xx.append(pl.h[l].data_ptr() + 4 * c * D); ldy.append(D); ldx.append(F)
+            L.call("amid_bert_wgrad_f32", ptr_array(dy), ptr_array(xx), (ctypes.c_int * N_ENT)(*ldy), (ctypes.c_int * N_ENT)(*ldx),
+                   (ctypes.c_int * N_ENT)(*old), (ctypes.c_int * N_ENT)(*ogr), (ctypes.c_int * N_ENT)(*oco), N_ENT, M,
+                   pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), s)
+            L.call("amid_bert_qkv_bwd_f32", pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[l].data_ptr(),
+                   self._pp(pre + ".input_sublayer.norm.a_2"), wT3, M, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), s)
+        L.call("amid_reduce_partials_f32", pl.red_entries.data_ptr(), pl.red_n, pl.red_max, s)
+        self.join_sort()
+        L.call("amid_embgrad_segreduce_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(),
+               shp.n_idx, D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), s)

@@ -8,6 +8,8 @@ reference; the arithmetic runs in the hand-written HIP 
          isInC, isItC, threshold1, threshold2, isDR=False)          model_seq.py:391
       forward(u_node, i_node, neg_samples, seq_d1, seq_d2, long_tail_mask_d1, long_tail_mask_d2,
               isTrain=True) -> (logits_d1, logits_d2)                 model_seq.py:416
+  BERT4Rec(same arguments)                                            model_seq.py:250
+      forward(same arguments) -> (logits_d1, logits_d2)               model_seq.py:277
   embItemLayerEnhance(item_length, emb_dim)                           model_seq.py:23
   predictModule(emb_dim, hid_dim)                                     model_seq.py:33
   Log2feats(user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim)   model_seq.py:332
@@ -22,7 +24,7 @@ are accepted and ignored; dropout follows ``module.training``.  Two ways to trai
                    Adam as one hipGraph replay -- what ``train_sr.py`` of this repo and ``bench.py`` use.
 
 Out of scope this round (constructors kept for import / state_dict parity, ``forward`` raises):
-GRU4Rec (recurrent), BERT4Rec, InnerComp / InterComp (isInC / isItC), embUserLayerEnhance (dead code in
+GRU4Rec (recurrent), InnerComp / InterComp (isInC / isItC), embUserLayerEnhance (dead code in
 the reference), the isDR heads.
 """
 from __future__ import annotations
@@ -34,6 +36,7 @@ import torch.nn as nn
 
 from ._lib import lib
 from .engine import SASREC_LN_EPS, SasrecEngine
+from .engine_bert import Bert4recEngine
 
 
 def _register_tree(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
@@ -106,6 +109,8 @@ class _SasrecFunction(torch.autograd.Function):
 class SASRec(nn.Module):
     """model_seq.py:390-443 on the HIP engine (isInC = isItC = isDR = False)."""
 
+    ENGINE_CLS = SasrecEngine
+
     def __init__(self, user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim, bs, isInC, isItC, threshold1,
                  threshold2, isDR=False, device: Optional[str] = None, lr: float = 5e-4, seed: int = 0):
         super().__init__()
@@ -119,7 +124,7 @@ class SASRec(nn.Module):
         self.user_emb_dim = user_emb_dim
         self.isInC, self.isItC, self.isDR = isInC, isItC, isDR
         dev = device or ("cuda:%d" % torch.cuda.current_device())
-        self.engine = SasrecEngine(item_length, item_emb_dim, seq_len, hid_dim, device=dev, lr=lr, seed=seed)
+        self.engine = self.ENGINE_CLS(item_length, item_emb_dim, seq_len, hid_dim, device=dev, lr=lr, seed=seed)
         eng = self.engine
         self._param_names = ["item_emb_layer.emb_item.weight"] + list(eng.dense.slots)
         self._init_reference_defaults(seed)
@@ -143,6 +148,8 @@ class SASRec(nn.Module):
                     v.copy_(torch.randn(v.shape, generator=g))
                 elif "layernorm" in name:
                     v.fill_(1.0 if name.endswith("weight") else 0.0)
+                elif name.endswith("norm.a_2") or name.endswith("norm.b_2"):      # BERT4Rec LayerNorm, model_seq.py:119-120
+                    v.fill_(1.0 if name.endswith("a_2") else 0.0)
                 elif name.endswith("in_proj_weight"):          # xavier_uniform_ (nn.MultiheadAttention._reset_parameters)
                     a = (6.0 / (3 * D + D)) ** 0.5
                     v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * a)
@@ -150,7 +157,7 @@ class SASRec(nn.Module):
                     v.zero_()
                 else:                                          # kaiming_uniform_(a=sqrt(5)) => U(-1/sqrt(fan_in), 1/sqrt(fan_in))
                     fan_in = {"predictModule.fc.0.weight": 2 * D, "predictModule.fc.0.bias": 2 * D, "predictModule.fc.2.weight": hid,
-                              "predictModule.fc.2.bias": hid}.get(name, D)
+                              "predictModule.fc.2.bias": hid}.get(name, 4 * D if ".feed_forward.w_2." in name else D)
                     a = 1.0 / fan_in ** 0.5
                     v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * a)
         torch.cuda.synchronize(eng.device)
@@ -367,8 +374,10 @@ class GRU4Rec(nn.Module):
         _not_built("GRU4Rec (recurrent encoder, not the attention path)", "model_seq.py:56-113")
 
 
-class BERT4Rec(nn.Module):
-    def __init__(self, user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim, bs, isInC, isItC, threshold1, threshold2,
-                 isDR=False):                          # model_seq.py:250
-        super().__init__()
-        _not_built("BERT4Rec", "model_seq.py:248-309")
+class BERT4Rec(SASRec):
+    """model_seq.py:248-309 on the HIP engine (isInC = isItC = isDR = False): two stacks of two TransformerBlocks whose
+    hidden size 128 / 4 heads / FFN 512 / dropout 0.1 the reference hard-codes (:264-267), so emb dims must be 128; no
+    positional embedding; ONE key mask from seq_d2 > 0 for both stacks (:288); plain mean over time, then predictModule.
+    Same constructor, forward signature, state_dict keys (transform{1,2}.{0,1}.*) and train_step() as SASRec above."""
+
+    ENGINE_CLS = Bert4recEngine

@@ -167,6 +167,36 @@ int amid_head_bwd_f32(const float* x, const float* const* ln_w, const float* u, 
 /* replaces: torch.nn.LayerNorm(D, eps) applied row-wise (last_layernorm of a standalone Log2feats, model_seq.py:385) */
 int amid_layernorm_rows_f32(const float* x, const float* w, const float* b, long long rows, int D, float eps, float* y, void* stream);
 
+/* ---- BERT4Rec encoder block (hidden 128, 4 heads, FFN 512, dropout 0.1: hard-coded by the reference, model_seq.py:264-267)
+ * replaces: TransformerBlock.forward model_seq.py:242-245 (SublayerConnection :140-142, LayerNorm :124-127 with unbiased std and
+ * eps added to the std, MultiHeadedAttention :183-196, PositionwiseFeedForward :216-217, GELU :204) and its autograd.
+ * Pointer-array parameters are HOST arrays of device pointers: [domain] or, for the three q/k/v projections, [which * 2 + domain].
+ * The attention core in between is amid_attn_{fwd,bwd}_f32 with causal = 0 and key_keep from seq_d2 > 0 (model_seq.py:288). */
+int amid_bert_qkv_fwd_f32(const float* x, const float* const* ln_a, const float* const* ln_b, const float* const* w3x2,
+                          const float* const* b3x2, int M, int rows_per_tile, float* y, float* q, float* k, float* v, void* stream);
+int amid_bert_oproj_fwd_f32(const float* o, const float* x, const float* const* w, const float* const* b, int M, int rows_per_tile, int layer,
+                            const void* step_state, int train, float p_drop, float* x1, void* stream);
+int amid_bert_ffn1_fwd_f32(const float* x1, const float* const* ln_a, const float* const* ln_b, const float* const* w1, const float* const* b1,
+                           int M, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* y2, float* pre,
+                           float* h, void* stream);
+int amid_bert_ffn2_fwd_f32(const float* h, const float* x1, const float* const* w2, const float* const* b2, int M, int rows_per_tile, int layer,
+                           const void* step_state, int train, float p_drop, float* x2, void* stream);
+int amid_bert_ffn2_bwd_f32(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                           const void* step_state, int train, float p_drop, float* dz, float* dpre, void* stream);
+int amid_bert_ffn1_bwd_f32(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                           const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train, float p_drop,
+                           float* dx1, float* dt, float* d_o, float* ln_part, void* stream);
+int amid_bert_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                          const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream);
+/* n_ent (<= 12) weight-gradient tiles of 128 x 128 as split partials: w_part [2][n_ent][splits][128*128], b_part [2][n_ent][splits][128];
+ * tile e lands in w_part[domain][out_group[e]][split] at column out_col[e] with row stride out_ld[e] (standalone tile: 128, e, 0; the
+ * out_ld/128 tiles of one [128, out_ld] matrix share out_group so its partials are one contiguous [splits][128*out_ld] block) */
+int amid_bert_wgrad_f32(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
+                        const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part, float* b_part, void* stream);
+/* key mask keep[b][t] = seq[b][t] > 0, replaces: mask = (seq_d2 > 0)... model_seq.py:288 */
+int amid_key_keep_u8(const long long* seq, long long n, unsigned char* keep, void* stream);
+int amid_transpose_rect_f32(const float* const* src, float* const* dst, const int* rows, const int* cols, int n, void* stream);
+
 /* ---- hipGraph capture / replay of a whole step; HIP events on the caller's stream ---------------- */
 int amid_graph_capture_begin(void* stream);
 int amid_graph_capture_end(void* stream, void** graph_exec_out);

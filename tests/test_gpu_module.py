@@ -169,11 +169,13 @@ def test_predict_module_standalone():
 
 def test_unbuilt_models_fail_loudly():
     from amid_amd import model_seq
-    for cls in (model_seq.GRU4Rec, model_seq.BERT4Rec):
-        with pytest.raises(NotImplementedError):
-            cls(10, 128, 100, 128, 20, 32, 4, False, False, 0.5, 0.5)
     with pytest.raises(NotImplementedError):
-        model_seq.SASRec(10, 128, 100, 128, 20, 32, 4, False, True, 0.5, 0.5)
+        model_seq.GRU4Rec(10, 128, 100, 128, 20, 32, 4, False, False, 0.5, 0.5)
+    for cls in (model_seq.SASRec, model_seq.BERT4Rec):
+        with pytest.raises(NotImplementedError):
+            cls(10, 128, 100, 128, 20, 32, 4, False, True, 0.5, 0.5)
+    with pytest.raises(ValueError):                      # the reference hard-codes hidden size 128 (model_seq.py:264-267)
+        model_seq.BERT4Rec(10, 64, 100, 64, 20, 32, 4, False, False, 0.5, 0.5)
 
 
 def _write_csv(path, n, rng, lo1, hi1, lo2, hi2):
@@ -189,7 +191,8 @@ def _write_csv(path, n, rng, lo1, hi1, lo2, hi2):
         f.write("\n".join(rows) + "\n")
 
 
-def test_train_sr_cli_end_to_end(tmp_path):
+@pytest.mark.parametrize("model,emb", [("sasrec", "64"), ("bert4rec", "128")])
+def test_train_sr_cli_end_to_end(tmp_path, model, emb):
     """The reference's command line on a synthetic CSV pair with the reference's column layout."""
     from amid_amd.train_sr import main
     rng = np.random.default_rng(0)
@@ -197,8 +200,8 @@ def test_train_sr_cli_end_to_end(tmp_path):
     root.mkdir()
     _write_csv(root / "toy_train75.csv", 300, rng, 1, 400, 400, 900)
     _write_csv(root / "toy_test.csv", 80, rng, 1, 400, 400, 900)
-    summary = main(["--data_root", str(tmp_path), "-ds", "amazon", "-dm", "toy", "--overlap_ratio", "0.75", "--model", "sasrec",
-                    "--bs", "32", "--seq_len", "20", "--emb_dim", "64", "--hid_dim", "16", "--epoch", "2", "--neg_nums", "19",
+    summary = main(["--data_root", str(tmp_path), "-ds", "amazon", "-dm", "toy", "--overlap_ratio", "0.75", "--model", model,
+                    "--bs", "32", "--seq_len", "20", "--emb_dim", emb, "--hid_dim", "16", "--epoch", "2", "--neg_nums", "19",
                     "--seeds", "1", "-md", str(tmp_path / "model")])
     assert len(summary) == 1
     best = summary[0]
