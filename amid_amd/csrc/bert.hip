@@ -488,7 +488,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_wgrad_kernel(const BWgradAr
     };
     if (local_beg < local_end) fetch(local_beg);
     for (int c0 = local_beg; c0 < local_end; c0 += BWG_ROWS) {
-        const int nr = min(BWG_ROWS, local_end - c0);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NRW; ++j) {
@@ -499,12 +498,33 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_wgrad_kernel(const BWgradAr
         }
         __syncthreads();
         if (c0 + BWG_ROWS < local_end) fetch(c0 + BWG_ROWS);
-        const int msteps = (nr + 3) >> 2;
-        for (int ms = 0; ms < msteps; ++ms) {
-            const int m = ms * 4 + gq;
-            const float av = Ys[m * LD + nt * 16 + i];
+        // branch-free, operands of step ms + 1 read under the MFMAs of step ms (same loop as sas_wgrad_kernel)
+        const float* yp = Ys + gq * LD + nt * 16 + i;
+        const float* xp = Xs + gq * LD + i;
+        float a_cur = yp[0], x_cur[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] = mfma16(av, Xs[m * LD + t * 16 + i], acc[t]);
+        for (int t = 0; t < 8; ++t) x_cur[t] = xp[t * 16];
+#pragma unroll
+        for (int ms = 0; ms < BWG_ROWS / 4; ++ms) {
+            float a_nxt = a_cur, x_nxt[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x_nxt[t] = x_cur[t];
+            if (ms + 1 < BWG_ROWS / 4) {
+                a_nxt = yp[(ms + 1) * 4 * LD];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) x_nxt[t] = xp[(ms + 1) * 4 * LD + t * 16];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = mfma16(a_cur, x_cur[t], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x_cur[t] = x_nxt[t];
         }
     }
     const int ldw = a.ldw[e];

@@ -267,8 +267,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_wgrad_kernel(const WgradArgs
     constexpr int NTn = D / 16;
     constexpr int WPN = 8 / NTn > 0 ? 8 / NTn : 1;     // waves per n tile (1 at D=128, 2 at D=64)
     constexpr int KTW = NTn / WPN;                     // k tiles per wave (8 at D=128, 2 at D=64)
-    float* Ys = smem;
-    float* Xs = smem + WG_ROWS * LD;
+    constexpr int BUF = 2 * WG_ROWS * LD;              // one LDS buffer: dY image then X image (two buffers: 147 KB at D=128)
     const int split = blockIdx.x, wsel = blockIdx.y, g = blockIdx.z;
     const float* __restrict__ dy = a.dy[wsel];
     const float* __restrict__ xin = a.xin[wsel];
@@ -284,8 +283,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_wgrad_kernel(const WgradArgs
     for (int t = 0; t < KTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int NRW = WG_ROWS / RPP;                 // rows of a chunk per thread (4 at D=128, 2 at D=64)
-    float4 py[NRW], px[NRW];
-    auto fetch = [&](int c0) {                         // issue every load of chunk c0 (zeros beyond the split's range)
+    // Pipeline per chunk c (one barrier per chunk):  request chunk c + 2 (registers)  ->  MFMAs on LDS buffer c & 1  ->
+    // store chunk c + 1 (requested a whole chunk earlier) into buffer (c + 1) & 1  ->  barrier.
+    // Two waves share a SIMD and the older one gets the matrix pipe first, so a wave's LDS stores run while its SIMD
+    // partner still issues MFMAs.  The first version (single buffer: barrier, store, barrier, MFMAs) measured, per
+    // 8192 MFMA cycles of a chunk, ~1000 cycles of store + barrier and ~2400 of other waiting (s_memtime instrumentation).
+    float4 py0[NRW], px0[NRW], py1[NRW], px1[NRW];
+    auto fetch = [&](float4 (&py)[NRW], float4 (&px)[NRW], int c0) {   // issue every load of chunk c0 (zeros beyond the split's range)
         const int nr = min(WG_ROWS, local_end - c0);
         const long long grow = (long long)g * a.M + c0;
 #pragma unroll
@@ -296,25 +300,66 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_wgrad_kernel(const WgradArgs
             px[i] = ok ? ld4(xin + (grow + r) * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    if (local_beg < local_end) fetch(local_beg);
-    for (int c0 = local_beg; c0 < local_end; c0 += WG_ROWS) {
-        const int nr = min(WG_ROWS, local_end - c0);
-        __syncthreads();                               // previous chunk fully consumed
+    auto stage = [&](const float4 (&py)[NRW], const float4 (&px)[NRW], float* buf) {
 #pragma unroll
         for (int i = 0; i < NRW; ++i) {
             const int r = rl + i * RPP;
             bsum = f4add(bsum, py[i]);
-            st4(Ys + r * LD + 4 * sub, py[i]);
-            st4(Xs + r * LD + 4 * sub, px[i]);
+            st4(buf + r * LD + 4 * sub, py[i]);
+            st4(buf + WG_ROWS * LD + r * LD + 4 * sub, px[i]);
         }
-        __syncthreads();
-        if (c0 + WG_ROWS < local_end) fetch(c0 + WG_ROWS);     // next chunk flies under this chunk's MFMAs
-        const int msteps = (nr + 3) >> 2;
-        for (int ms = 0; ms < msteps; ++ms) {
-            const int m = ms * 4 + gq;
-            const float av = Ys[m * LD + nt * 16 + i];
+    };
+    auto mma = [&](const float* buf) {
+        // all 16 m-steps, always (rows past the split's range are zeros in LDS): branch-free, with the operands of step
+        // ms + 1 read while the MFMAs of step ms issue
+        const float* yp = buf + gq * LD + nt * 16 + i;
+        const float* xp = buf + WG_ROWS * LD + gq * LD + kt0 * 16 + i;
+        float a_cur = yp[0], x_cur[KTW];
 #pragma unroll
-            for (int t = 0; t < KTW; ++t) acc[t] = mfma16(av, Xs[m * LD + (kt0 + t) * 16 + i], acc[t]);
+        for (int t = 0; t < KTW; ++t) x_cur[t] = xp[t * 16];
+#pragma unroll
+        for (int ms = 0; ms < WG_ROWS / 4; ++ms) {
+            float a_nxt = a_cur, x_nxt[KTW];
+#pragma unroll
+            for (int t = 0; t < KTW; ++t) x_nxt[t] = x_cur[t];
+            if (ms + 1 < WG_ROWS / 4) {
+                a_nxt = yp[(ms + 1) * 4 * LD];
+#pragma unroll
+                for (int t = 0; t < KTW; ++t) x_nxt[t] = xp[(ms + 1) * 4 * LD + t * 16];
+            }
+#pragma unroll
+            for (int t = 0; t < KTW; ++t) acc[t] = mfma16(a_cur, x_cur[t], acc[t]);
+            // pin the issue order: one LDS read of the next step behind every MFMA of this one (left alone, the scheduler
+            // sinks each read to just before its first use and waits on it)
+#pragma unroll
+            for (int t = 0; t < KTW; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t = 0; t < KTW; ++t) x_cur[t] = x_nxt[t];
+        }
+    };
+    if (local_beg < local_end) {
+        fetch(py0, px0, local_beg);
+        if (local_beg + WG_ROWS < local_end) fetch(py1, px1, local_beg + WG_ROWS);
+        stage(py0, px0, smem);
+        __syncthreads();
+        for (int c0 = local_beg; c0 < local_end; c0 += 2 * WG_ROWS) {
+            // even chunk: lives in buffer 0; chunk c0 + 1 is in (py1, px1), chunk c0 + 2 is requested into (py0, px0)
+            const bool has1 = c0 + WG_ROWS < local_end, has2 = c0 + 2 * WG_ROWS < local_end;
+            if (has2) fetch(py0, px0, c0 + 2 * WG_ROWS);
+            mma(smem);
+            if (has1) stage(py1, px1, smem + BUF);
+            __syncthreads();
+            if (!has1) break;
+            // odd chunk: buffer 1; chunk c0 + 2 is in (py0, px0), chunk c0 + 3 is requested into (py1, px1)
+            if (c0 + 3 * WG_ROWS < local_end) fetch(py1, px1, c0 + 3 * WG_ROWS);
+            mma(smem + BUF);
+            if (has2) stage(py0, px0, smem);
+            __syncthreads();
         }
     }
     float* wp = a.w_part + (((long long)g * 6 + wsel) * a.splits + split) * D * D;
@@ -322,8 +367,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_wgrad_kernel(const WgradArgs
     for (int t = 0; t < KTW; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) wp[(long long)(nt * 16 + gq * 4 + r) * D + (kt0 + t) * 16 + i] = acc[t][r];
-    __syncthreads();
-    st4(Ys + rl * D + 4 * sub, bsum);                  // [RPP][D] scratch
+    float* Ys = smem;
+    st4(Ys + rl * D + 4 * sub, bsum);                  // [RPP][D] scratch (the loop ended on a barrier)
     __syncthreads();
     float* bp = a.b_part + (((long long)g * 6 + wsel) * a.splits + split) * D;
     for (int e = threadIdx.x; e < D; e += GEMM_THREADS) {
@@ -456,12 +501,14 @@ extern "C" int amid_sas_wgrad_f32(const float* const* dy6, const float* const* x
     a.rows_per_split = (M + splits - 1) / splits;
     const dim3 grid(splits, 6, 2);
     if (D == 128) {
-        const size_t lds = (size_t)2 * WG_ROWS * (128 + 16) * sizeof(float);
+        const size_t lds = (size_t)4 * WG_ROWS * (128 + 16) * sizeof(float);
         static bool set128 = false;
         if (!set128) { hipError_t e = hipFuncSetAttribute((const void*)sas_wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; set128 = true; }
         sas_wgrad_kernel<128><<<grid, GEMM_THREADS, lds, (hipStream_t)stream>>>(a);
     } else if (D == 64) {
-        const size_t lds = (size_t)2 * WG_ROWS * (64 + 16) * sizeof(float);
+        const size_t lds = (size_t)4 * WG_ROWS * (64 + 16) * sizeof(float);
+        static bool set64 = false;
+        if (!set64) { hipError_t e = hipFuncSetAttribute((const void*)sas_wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; set64 = true; }
         sas_wgrad_kernel<64><<<grid, GEMM_THREADS, lds, (hipStream_t)stream>>>(a);
     } else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();

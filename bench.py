@@ -93,6 +93,29 @@ def algorithmic_work():
     }
 
 
+KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's name in rocprofv3 output
+    "amid_sas_qkv_fwd_f32": "sas_qkv_fwd_kernel", "amid_sas_oproj_fwd_f32": "sas_oproj_fwd_kernel", "amid_sas_ffn_fwd_f32": "sas_ffn_fwd_kernel",
+    "amid_sas_ffn_bwd_f32": "sas_ffn_bwd_kernel", "amid_sas_qkv_bwd_f32": "sas_qkv_bwd_kernel", "amid_sas_wgrad_f32": "sas_wgrad_kernel",
+    "amid_attn_fwd_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_f32": "embed_fwd_kernel",
+    "amid_embgrad_segreduce_f32": "segreduce_chunks_kernel",
+}
+
+
+def pmc_traffic(entry: str):
+    """HBM bytes per launch of one kernel from the committed PMC summary (profiles/*_hbm_traffic.json, produced by
+    profiles/summarize.py from two separate rocprofv3 --pmc passes of this same command); None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    sym = KERNEL_SYMBOL.get(entry)
+    if not files or sym is None:
+        return None, None
+    ks = json.load(open(files[-1]))["kernels"]
+    for name, v in ks.items():
+        if sym in name:
+            return v["hbm_bytes_per_launch"], os.path.basename(files[-1])
+    return None, None
+
+
 def usable_cpus() -> int:
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -255,6 +278,9 @@ def main():
         roof = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"], "peak": kernels[dom]["peak"],
                 "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"], "traffic": None,
                 "avg_launch_us": kernels[dom]["avg_launch_us"], "sum_kernel_ms_per_step": round(total_ms, 4)}
+        roof["traffic"], src = pmc_traffic(dom)
+        if src:
+            roof["traffic_unit"], roof["traffic_source"] = "bytes/launch", "profiles/" + src
 
     if world > 1:
         dist.barrier()
