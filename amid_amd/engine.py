@@ -277,6 +277,8 @@ class SasrecEngine:
         self.side = torch.cuda.Stream(device=self.device)
         self.ev_idx = torch.cuda.Event()
         self.ev_sorted = torch.cuda.Event()
+        self.ev_tail = torch.cuda.Event()
+        self.ev_reduced = torch.cuda.Event()
         self.n_rows, self.D, self.T, self.hid, self.H = int(item_length), int(emb_dim), int(seq_len), int(hid_dim), self.HEADS
         D = self.D
         self.dense = FlatParams(self._dense_names(), self.device)
@@ -484,10 +486,20 @@ class SasrecEngine:
             L.call("amid_sas_wgrad_f32", dy6, x6, M, D, pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), s)
         L.call("amid_embed_bwd_f32", pl.dxg.data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits, pl.dpos_part.data_ptr(), st, tr,
                SASREC_P_DROP, s)
-        L.call("amid_reduce_partials_f32", pl.red_entries.data_ptr(), pl.red_n, pl.red_max, s)
-        self.join_sort()
+        self._enqueue_grad_tail(pl)
+
+    def _enqueue_grad_tail(self, pl: SasrecPlan) -> None:
+        """Two independent, bandwidth-bound ends of backward side by side: the fixed-order sum of every partial buffer (dense
+        gradients + loss) on the side stream, the segment reduce of the table-row gradients on the main one."""
+        L, s, shp = lib(), self.s, pl.shape
+        self.join_sort()                          # the side stream is free again (and pos_sorted / seg_off are ready)
+        self.ev_tail.record(self.stream)
+        self.side.wait_event(self.ev_tail)
+        L.call("amid_reduce_partials_f32", pl.red_entries.data_ptr(), pl.red_n, pl.red_max, self.side.cuda_stream)
+        self.ev_reduced.record(self.side)
         L.call("amid_embgrad_segreduce_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(),
-               shp.n_idx, D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), s)
+               shp.n_idx, self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), s)
+        self.stream.wait_event(self.ev_reduced)
 
     def enqueue_optimizer(self, pl: SasrecPlan, sparse=None) -> None:
         """Dense Adam on the flat buffer + lazy row Adam on (uniq_ids, uniq_grad, n_uniq); `sparse`

@@ -194,7 +194,4 @@ class Bert4recEngine(SasrecEngine):
                    pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), s)
             L.call("amid_bert_qkv_bwd_f32", pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[l].data_ptr(),
                    self._pp(pre + ".input_sublayer.norm.a_2"), wT3, M, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), s)
-        L.call("amid_reduce_partials_f32", pl.red_entries.data_ptr(), pl.red_n, pl.red_max, s)
-        self.join_sort()
-        L.call("amid_embgrad_segreduce_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(),
-               shp.n_idx, D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), s)
+        self._enqueue_grad_tail(pl)
