@@ -34,24 +34,52 @@ MAX_REAL_ID = 42441               # largest id in cloth_sport_train75 (SURVEY 8(
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBPS = 8000.0
 
+# --workload: the default is the configuration BASELINE.json's metric is quoted on (configs[1]); the two cfg5 entries are the
+# synthetic gather / scatter stress of SURVEY.md section 8(d) (table 10 M x 128 fp32 = 5.12 GB >> the 256 MiB Infinity Cache,
+# batch 4096 per GPU): reported in DESIGN.md / profiles/, never the headline line.
+CFG5_ROWS = 10_000_000
+WORKLOADS = {
+    "cfg2": dict(B=256, n_rows=N_ROWS, pad_id=PAD_ID, max_id=MAX_REAL_ID, kind="real",
+                 label="cloth_sport_train75-shaped SASRec train step (BASELINE.json configs[1])"),
+    "cfg5-uniform": dict(B=4096, n_rows=CFG5_ROWS + 2, pad_id=CFG5_ROWS + 1, max_id=CFG5_ROWS - 1, kind="uniform",
+                         label="synthetic S-uniform (BASELINE.json configs[4]): every position a uniform id in [0, 10M), no pads"),
+    "cfg5-real": dict(B=4096, n_rows=CFG5_ROWS + 2, pad_id=CFG5_ROWS + 1, max_id=CFG5_ROWS - 1, kind="zipf",
+                      label="synthetic S-real (BASELINE.json configs[4]): cloth_sport length histogram (89 % pads), ids Zipf(1.05)"),
+}
 
-def synth_batch(gen, device):
+
+def synth_batch(gen, device, wl=None):
     """One batch shaped like collate_fn_enhance's output after train_sr.py:191-200."""
-    lens1 = torch.clamp(torch.poisson(torch.full((B,), 4.5), generator=gen).long() + 1, max=T)
-    lens2 = torch.clamp(torch.poisson(torch.full((B,), 4.5), generator=gen).long(), max=T)      # other domain may be empty
-    col = torch.arange(T).unsqueeze(0)
-    seqs = []
-    for lens in (lens1, lens2):
-        s = torch.full((B, T), PAD_ID, dtype=torch.long)
-        ids = torch.randint(1, MAX_REAL_ID + 1, (B, T), generator=gen)
-        real = col >= (T - lens).unsqueeze(1)
-        s[real] = ids[real]
-        seqs.append(s)
-    label = torch.zeros(B, 1 + NEG)
+    wl = wl or WORKLOADS["cfg2"]
+    Bw, pad, hi, kind = wl["B"], wl["pad_id"], wl["max_id"], wl["kind"]
+
+    def ids(shape):
+        if kind == "zipf":            # Zipf(1.05) ranks folded into [1, hi]: a few hot rows, a long cold tail
+            import numpy as np
+            rng = np.random.default_rng(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=gen)))
+            n = 1
+            for d in shape:
+                n *= d
+            return torch.from_numpy(((rng.zipf(1.05, n) - 1) % hi + 1).astype("int64")).reshape(shape)
+        return torch.randint(0 if kind == "uniform" else 1, hi + 1, shape, generator=gen)
+
+    if kind == "uniform":
+        seqs = [ids((Bw, T)), ids((Bw, T))]
+    else:
+        lens1 = torch.clamp(torch.poisson(torch.full((Bw,), 4.5), generator=gen).long() + 1, max=T)
+        lens2 = torch.clamp(torch.poisson(torch.full((Bw,), 4.5), generator=gen).long(), max=T)      # other domain may be empty
+        col = torch.arange(T).unsqueeze(0)
+        seqs = []
+        for lens in (lens1, lens2):
+            s = torch.full((Bw, T), pad, dtype=torch.long)
+            v = ids((Bw, T))
+            real = col >= (T - lens).unsqueeze(1)
+            s[real] = v[real]
+            seqs.append(s)
+    label = torch.zeros(Bw, 1 + NEG)
     label[:, 0] = 1.0
-    b = dict(i_node=torch.randint(1, MAX_REAL_ID + 1, (B,), generator=gen),
-             neg_samples=torch.randint(1, MAX_REAL_ID + 1, (B, NEG), generator=gen),
-             seq_d1=seqs[0], seq_d2=seqs[1], label=label, domain_id=(torch.rand(B, generator=gen) < 0.5).long())
+    b = dict(i_node=ids((Bw,)), neg_samples=ids((Bw, NEG)), seq_d1=seqs[0], seq_d2=seqs[1], label=label,
+             domain_id=(torch.rand(Bw, generator=gen) < 0.5).long())
     return {k: v.to(device) for k, v in b.items()}
 
 
@@ -59,7 +87,11 @@ def init_params(eng, seed):
     """Random-init weights of the reference architecture (nn.Embedding N(0,1); small dense weights)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     with torch.no_grad():
-        eng.table.copy_(torch.randn(eng.n_rows, eng.D, generator=g))
+        if eng.n_rows > 2_000_000:            # cfg5: 5 GB of N(0,1) drawn on the device (seeded), not on the host
+            dg = torch.Generator(device=eng.device).manual_seed(seed)
+            eng.table.normal_(generator=dg)
+        else:
+            eng.table.copy_(torch.randn(eng.n_rows, eng.D, generator=g))
         flat = torch.randn(eng.dense.numel, generator=g) * 0.05
         eng.dense.data.copy_(flat)
         for name in eng.dense.slots:
@@ -73,10 +105,11 @@ def init_params(eng, seed):
     torch.cuda.synchronize()
 
 
-def algorithmic_work():
+def algorithmic_work(Bw=B, n_uniq=None):
     """Per launch, at this workload (formulas: DESIGN.md section 5 / SURVEY.md section 8(d))."""
-    M2 = 2 * B * T
-    n_idx = M2 + B * (1 + NEG)
+    M2 = 2 * Bw * T
+    n_idx = M2 + Bw * (1 + NEG)
+    U = n_uniq if n_uniq is not None else n_idx
     gemm = 2.0 * M2 * D * D                     # FLOP of one [M2, D] x [D, D] projection
     H, hd = 8, D // 8
     return {
@@ -86,10 +119,14 @@ def algorithmic_work():
         "amid_sas_ffn_bwd_f32": ("mfma", 3 * gemm),
         "amid_sas_qkv_bwd_f32": ("mfma", 3 * gemm),
         "amid_sas_wgrad_f32": ("mfma", 6 * gemm),
-        "amid_attn_fwd_f32": ("valu", 4.0 * T * T * hd * 2 * B * H),
-        "amid_attn_bwd_f32": ("valu", 10.0 * T * T * hd * 2 * B * H),
+        "amid_attn_fwd_f32": ("valu", 4.0 * T * T * hd * 2 * Bw * H),
+        "amid_attn_bwd_f32": ("valu", 10.0 * T * T * hd * 2 * Bw * H),
+        # K1: index + row read + row write (+ the feature-mask bytes); K3: rows + positions read, unique rows + ids written;
+        # K4: table row, m, v read and written for every unique row (+ its `last` stamp), grad row read
         "amid_embed_fwd_f32": ("hbm", n_idx * (4 + 2 * D * 4) + M2 * (D // 4)),
-        "amid_embgrad_segreduce_f32": ("hbm", n_idx * (D * 4 + 4)),
+        "amid_embgrad_segreduce_f32": ("hbm", n_idx * (D * 4 + 8) + U * (D * 4 + 8)),
+        "amid_lazy_adam_catchup_positions_f32": ("hbm", n_idx * 4 + U * (D * 4 * 6 + 8)),
+        "amid_optimizer_step_f32": ("hbm", U * (D * 4 * 7 + 8)),
     }
 
 
@@ -162,6 +199,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
+                    help="cfg2 = the headline configuration (default); cfg5-* = synthetic gather / scatter stress (SURVEY.md 8(d))")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -187,14 +226,16 @@ def main():
     from amid_amd.dist import SparseDenseExchange
     from amid_amd.engine import SasrecEngine
 
-    eng = SasrecEngine(N_ROWS, D, T, HID, device=device, lr=5e-4, seed=1234)
+    wl = WORKLOADS[args.workload]
+    Bw = wl["B"]
+    eng = SasrecEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234)
     init_params(eng, seed=0)                  # identical replicas on every rank
-    pl = eng.plan(B, T, 1 + NEG, need_grad=True)
+    pl = eng.plan(Bw, T, 1 + NEG, need_grad=True)
     gen = torch.Generator().manual_seed(1000 + rank)          # each rank draws its own shard of the global batch
-    n_pool = 60                               # one epoch of cloth_sport_train75 at batch 256
+    n_pool = 60 if args.workload == "cfg2" else 16     # cfg2: one epoch of cloth_sport_train75 at batch 256
     pool = []
     for _ in range(n_pool):                   # batches are packed in the engine's input layout: one device copy per step
-        b = synth_batch(gen, device)
+        b = synth_batch(gen, device, wl)
         pool.append(eng.pack_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"]))
     torch.cuda.synchronize()
 
@@ -257,7 +298,7 @@ def main():
             eng.sync()
         durs = L.timer.collect(L)
         L.timer = None
-        work = algorithmic_work()
+        work = algorithmic_work(Bw, int(pl.n_uniq.item()))
         total_ms = 0.0
         for name, v in durs.items():
             per_step = sum(v) / n_prof
@@ -278,7 +319,9 @@ def main():
         roof = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"], "peak": kernels[dom]["peak"],
                 "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"], "traffic": None,
                 "avg_launch_us": kernels[dom]["avg_launch_us"], "sum_kernel_ms_per_step": round(total_ms, 4)}
-        roof["traffic"], src = pmc_traffic(dom)
+        src = None
+        if args.workload == "cfg2":
+            roof["traffic"], src = pmc_traffic(dom)
         if src:
             roof["traffic_unit"], roof["traffic_source"] = "bytes/launch", "profiles/" + src
 
@@ -286,18 +329,19 @@ def main():
         dist.barrier()
     if rank == 0:
         out = {
-            "metric": "train samples/sec", "value": round(B * world * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world,
+            "metric": "train samples/sec", "value": round(Bw * world * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cloth_sport_train75-shaped SASRec train step (BASELINE.json configs[1])", "batch_per_gpu": B,
-                       "global_batch": B * world, "seq_len": T, "emb_dim": D, "hid_dim": HID, "neg": NEG, "table_rows": N_ROWS,
+            "config": {"workload": wl["label"], "batch_per_gpu": Bw,
+                       "global_batch": Bw * world, "seq_len": T, "emb_dim": D, "hid_dim": HID, "neg": NEG, "table_rows": wl["n_rows"],
+                       "unique_rows_last_step": int(pl.n_uniq.item()),
                        "dropout": "on (p=0.5)", "optimizer": "Adam (dense-equivalent lazy rows)", "graph": use_graph,
                        "parallelism": f"dp{world}"},
             "loss_last": round(loss_last, 6),
             "roofline": roof,
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
