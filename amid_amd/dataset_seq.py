@@ -87,8 +87,11 @@ class DualDomainSeqDataset:
 class DeviceBatches:
     """DataLoader(batch_size, shuffle, drop_last=True) over a tokenised dataset resident on the device."""
 
-    def __init__(self, ds: DualDomainSeqDataset, batch_size: int, shuffle: bool, device, seed: int = 0):
+    def __init__(self, ds: DualDomainSeqDataset, batch_size: int, shuffle: bool, device, seed: int = 0, rank: int = 0, world: int = 1):
+        """rank / world: data parallel -- every rank walks the same shuffled order (same seed) in global batches of
+        world x batch_size rows and keeps its own contiguous slice (DistributedSampler-style, drop_last)."""
         self.ds, self.bs, self.shuffle, self.device = ds, batch_size, shuffle, torch.device(device)
+        self.rank, self.world = rank, world
         to = lambda a: torch.from_numpy(a).to(self.device)       # noqa: E731
         self.t = dict(user_node=to(ds.user_nodes), i_node=to(ds.i_node), seq_d1=to(ds.seq_d1), seq_d2=to(ds.seq_d2),
                       domain_id=to(ds.domain_id), overlap_label=to(ds.overlap_label), long_tail_mask_d1=to(ds.long_tail_mask_d1),
@@ -99,7 +102,7 @@ class DeviceBatches:
         self.label[:, 0] = 1.0                                                            # dataset_seq.py:191,199
 
     def __len__(self) -> int:
-        return len(self.ds) // self.bs                                                    # drop_last=True (train_sr.py:452,455)
+        return len(self.ds) // (self.bs * self.world)                                     # drop_last=True (train_sr.py:452,455)
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         neg = torch.from_numpy(self.ds.sample_negatives()).to(self.device)
@@ -107,7 +110,8 @@ class DeviceBatches:
         order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
         order = order.to(self.device)
         for b in range(len(self)):
-            sel = order[b * self.bs:(b + 1) * self.bs]
+            lo = (b * self.world + self.rank) * self.bs
+            sel = order[lo:lo + self.bs]
             batch = {k: v.index_select(0, sel) for k, v in self.t.items()}
             batch["neg_samples"] = neg.index_select(0, sel)
             batch["label"] = self.label

@@ -18,13 +18,21 @@ by world_size-2 gloo tests on CPU, with a test double in place of the HIP kernel
 """
 from __future__ import annotations
 
-from typing import Protocol, Tuple
+from typing import Optional, Protocol, Tuple
 
 import torch
 import torch.distributed as dist
 
 
 class MergeBackend(Protocol):
+    def pad(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, umax: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """First umax entries of a rank's lists; entries at and beyond n_uniq (device scalar) become (uniq_ids[0], zero row)."""
+        ...
+
+    def gather_buffers(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Receive buffers (ids [n] int32, rows [n, D]) for the all-gather."""
+        ...
+
     def merge(self, ids: torch.Tensor, rows: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """ids [n] int32 (duplicates allowed), rows [n, D] -> (uniq_ids [n], uniq_rows [n, D], n_uniq [1] int32);
         only the first n_uniq entries of the outputs are meaningful."""
@@ -55,22 +63,22 @@ class SparseDenseExchange:
             else:
                 dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
-    def exchange_sparse(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor
+    def exchange_sparse(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, umax: Optional[int] = None
                         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """uniq_ids [cap] int32, uniq_rows [cap, D], n_uniq [1] int32 (device) -> merged world lists."""
+        """uniq_ids [cap] int32, uniq_rows [cap, D], n_uniq [1] int32 (device) -> merged world lists.
+
+        umax = the world's largest per-rank unique count for THIS step when the host already knows it (the data pipeline can
+        count a batch's unique ids while packing it and max-reduce the counts ahead of time, as bench.py does): the exchange
+        then needs no device -> host synchronisation.  With umax=None it costs one small host sync per step."""
         if self.world == 1:
             return uniq_ids, uniq_rows, n_uniq
-        # one small host sync per step: the padded length is the world's largest unique count
-        nmax = n_uniq.cpu() if self.host_staging else n_uniq.clone()
-        dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=self.group)
-        umax = int(nmax.item())
-        ids = uniq_ids[:umax].clone()
-        rows = uniq_rows[:umax].clone()
-        pad = torch.arange(umax, device=ids.device, dtype=torch.int32) >= n_uniq.to(torch.int32)
-        ids = torch.where(pad, ids[0:1].expand(umax), ids)          # (first id, zero row): adds an exact 0.0
-        rows = rows * (~pad).unsqueeze(1).to(rows.dtype)
-        all_ids = torch.empty(self.world * umax, dtype=ids.dtype, device=ids.device)
-        all_rows = torch.empty(self.world * umax, rows.shape[1], dtype=rows.dtype, device=rows.device)
+        if umax is None:
+            nmax = n_uniq.cpu() if self.host_staging else n_uniq.clone()
+            dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=self.group)
+            umax = int(nmax.item())
+        umax = max(1, min(int(umax), uniq_ids.numel()))
+        ids, rows = self.backend.pad(uniq_ids, uniq_rows, n_uniq, umax)      # (first id, zero row) padding: adds an exact 0.0
+        all_ids, all_rows = self.backend.gather_buffers(self.world * umax)
         if self.host_staging and ids.is_cuda:
             h_ids, h_rows = torch.empty(all_ids.shape, dtype=ids.dtype), torch.empty(all_rows.shape, dtype=rows.dtype)
             dist.all_gather_into_tensor(h_ids, ids.cpu(), group=self.group)
@@ -81,6 +89,34 @@ class SparseDenseExchange:
             dist.all_gather_into_tensor(all_ids, ids, group=self.group)
             dist.all_gather_into_tensor(all_rows, rows, group=self.group)
         return self.backend.merge(all_ids, all_rows)
+
+
+class TorchMergeBackend:
+    """Reference implementation of the backend protocol in plain torch (the test double of the gloo tests; also documents
+    what the HIP backend must compute)."""
+
+    def __init__(self, D: int, device="cpu"):
+        self.D, self.device = D, device
+
+    def pad(self, uniq_ids, uniq_rows, n_uniq, umax):
+        ids = uniq_ids[:umax].clone()
+        rows = uniq_rows[:umax].clone()
+        pad = torch.arange(umax, device=ids.device, dtype=torch.int32) >= n_uniq.to(torch.int32)
+        ids = torch.where(pad, uniq_ids[0:1].expand(umax), ids)
+        rows = rows * (~pad).unsqueeze(1).to(rows.dtype)
+        return ids, rows
+
+    def gather_buffers(self, n):
+        return torch.empty(n, dtype=torch.int32, device=self.device), torch.empty(n, self.D, dtype=torch.float32, device=self.device)
+
+    def merge(self, ids, rows):
+        n = ids.numel()
+        u, inv = torch.unique(ids.long(), return_inverse=True)        # sorted ascending, like the radix sort
+        out = torch.zeros(n, rows.shape[1], dtype=rows.dtype, device=rows.device)
+        out.index_add_(0, inv, rows)
+        uid = torch.zeros(n, dtype=torch.int32, device=ids.device)
+        uid[: u.numel()] = u.to(torch.int32)
+        return uid, out, torch.tensor([u.numel()], dtype=torch.int32, device=ids.device)
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:

@@ -554,8 +554,9 @@ class SasrecEngine:
         self.step = step0
         pl.graph_local = out.value
 
-    def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False) -> None:
-        """One data-parallel step: local grads -> dense all-reduce + sparse all-gather/merge -> Adam."""
+    def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False, umax: Optional[int] = None) -> None:
+        """One data-parallel step: local grads -> dense all-reduce + sparse all-gather/merge -> Adam.
+        umax: the world's largest unique-row count of this step if the host knows it (no host sync then, see dist.py)."""
         with torch.cuda.stream(self.stream):
             if use_graph:
                 lib().call("amid_graph_launch", pl.graph_local, self.s)
@@ -564,7 +565,7 @@ class SasrecEngine:
                 self.enqueue_local_grads(pl)
             self.grad_scale = exchange.grad_scale
             exchange.all_reduce_dense(self.dense.grad)
-            merged = exchange.exchange_sparse(pl.uniq_ids, pl.uniq_grad, pl.n_uniq)
+            merged = exchange.exchange_sparse(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax=umax)
             self.enqueue_optimizer(pl, sparse=merged if exchange.world > 1 else None)
 
     # ------------------------------------------------------------------ graph replay
@@ -654,7 +655,22 @@ class HipMergeBackend:
         self.n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
         self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", self.cap, D), dtype=torch.uint8, device=dev)
         self.uniq_rows = torch.empty(self.cap, D, dtype=torch.float32, device=dev)
+        # exchange buffers: this rank's padded lists and the world's gathered lists (sliced per step, never reallocated)
+        self.send_ids = torch.zeros(self.cap, dtype=torch.int32, device=dev)
+        self.send_rows = torch.zeros(self.cap, D, dtype=torch.float32, device=dev)
+        self.all_ids = torch.zeros(self.cap, dtype=torch.int32, device=dev)
+        self.all_rows = torch.zeros(self.cap, D, dtype=torch.float32, device=dev)
         torch.cuda.synchronize(dev)
+
+    def pad(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, umax: int):
+        lib().call("amid_sparse_pad_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), umax, self.eng.D,
+                   self.send_ids.data_ptr(), self.send_rows.data_ptr(), self.eng.s)
+        return self.send_ids[:umax], self.send_rows[:umax]
+
+    def gather_buffers(self, n: int):
+        if n > self.cap:
+            raise ValueError(f"gather of {n} entries exceeds the backend capacity {self.cap}")
+        return self.all_ids[:n], self.all_rows[:n]
 
     def merge(self, ids: torch.Tensor, rows: torch.Tensor):
         L, eng = lib(), self.eng

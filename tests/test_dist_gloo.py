@@ -12,19 +12,6 @@ import torch.multiprocessing as mp
 from oracle import amid_oracle as orc
 
 
-class TorchMerge:
-    """CPU stand-in for HipMergeBackend: unique + index_add (fp64 accumulate, fixed order)."""
-
-    def merge(self, ids, rows):
-        n = ids.numel()
-        u, inv = torch.unique(ids, return_inverse=True)
-        out = torch.zeros(n, rows.shape[1], dtype=torch.float64)
-        out.index_add_(0, inv, rows.double())
-        uid = torch.zeros(n, dtype=torch.int32)
-        uid[: u.numel()] = u.to(torch.int32)
-        return uid, out.to(rows.dtype), torch.tensor([u.numel()], dtype=torch.int32)
-
-
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -33,16 +20,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, host_knows_umax):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from amid_amd.dist import SparseDenseExchange, shard_batch
+        from amid_amd.dist import SparseDenseExchange, TorchMergeBackend, shard_batch
         torch.manual_seed(0)
         n_items, D, T, hid, B = 120, 16, 10, 8, 8
         P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=3)
         batch = orc.synthetic_batch(B, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=5)
-        ex = SparseDenseExchange(TorchMerge())
+        ex = SparseDenseExchange(TorchMergeBackend(D))
         assert ex.world == world and ex.rank == rank and ex.grad_scale == 1.0 / world
         local = shard_batch(batch, rank, world)
         _, _, g = orc.loss_and_grads("sasrec", P, local, None)
@@ -58,7 +45,12 @@ def _worker(rank, world, port, q):
         rows[touched.numel():] = 777.0          # garbage beyond n_uniq must never leak into the merge
         nu = torch.tensor([touched.numel()], dtype=torch.int32)
         ex.all_reduce_dense(flat)
-        mid, mrows, mnu = ex.exchange_sparse(ids, rows, nu)
+        umax = None
+        if host_knows_umax:                      # the data pipeline counted the uniques and max-reduced them ahead of time
+            cnt = torch.tensor([touched.numel()])
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+            umax = int(cnt)
+        mid, mrows, mnu = ex.exchange_sparse(ids, rows, nu, umax=umax)
         U = int(mnu.item())
         table_grad = torch.zeros(n_items, D)
         table_grad[mid[:U].long()] = mrows[:U]
@@ -67,12 +59,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("host_knows_umax", [False, True])
 @pytest.mark.timeout(300)
-def test_exchange_world2_matches_single_process_global_batch():
+def test_exchange_world2_matches_single_process_global_batch(host_knows_umax):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, host_knows_umax)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
@@ -96,8 +89,8 @@ def test_exchange_world2_matches_single_process_global_batch():
 
 
 def test_exchange_world1_is_passthrough():
-    from amid_amd.dist import SparseDenseExchange
-    ex = SparseDenseExchange(TorchMerge())
+    from amid_amd.dist import SparseDenseExchange, TorchMergeBackend
+    ex = SparseDenseExchange(TorchMergeBackend(8))
     assert ex.world == 1 and ex.grad_scale == 1.0
     ids, rows, nu = torch.arange(4, dtype=torch.int32), torch.randn(4, 8), torch.tensor([3], dtype=torch.int32)
     a, b, c = ex.exchange_sparse(ids, rows, nu)

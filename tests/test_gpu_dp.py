@@ -28,7 +28,7 @@ def _batches():
     return [orc.synthetic_batch(c["B"], c["T"], c["n_items"] - 1, pad_id=c["n_items"] - 1, neg=1, seed=500 + t) for t in range(c["K"])]
 
 
-def _worker(rank, world, port, use_graph, q):
+def _worker(rank, world, port, use_graph, q, host_knows_umax=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -49,7 +49,12 @@ def _worker(rank, world, port, use_graph, q):
             if use_graph and first:
                 eng.capture_local_grads(pl)
                 first = False
-            eng.train_step_dp(pl, ex, use_graph=use_graph)
+            umax = None
+            if host_knows_umax:       # what a data pipeline does while packing: count the uniques, max-reduce ahead of the step
+                cnt = torch.tensor([int(torch.unique(torch.cat([local[k].reshape(-1) for k in ("i_node", "neg_samples", "seq_d1", "seq_d2")])).numel())])
+                dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+                umax = int(cnt)
+            eng.train_step_dp(pl, ex, use_graph=use_graph, umax=umax)
             eng.sync()
         eng.flush_table()
         eng.sync()
@@ -58,13 +63,13 @@ def _worker(rank, world, port, use_graph, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("use_graph,host_knows_umax", [(False, False), (True, False), (True, True)])
 @pytest.mark.timeout(600)
-def test_two_rank_dp_matches_global_batch_oracle(use_graph):
+def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, use_graph, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_graph, q, host_knows_umax)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
@@ -87,3 +92,49 @@ def test_two_rank_dp_matches_global_batch_oracle(use_graph):
             n = v.numel() // 3
             d = torch.cat((d[:n], d[2 * n:]))
         assert float(d.max()) < 1e-4, k
+
+
+def _cli_worker(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD_SIZE=str(world),
+                      RANK=str(rank), LOCAL_RANK=str(rank), AMID_DIST_BACKEND="gloo")
+    import amid_amd.train_sr as tsr
+    captured = {}
+    real_train = tsr.train
+
+    def spy(model, *a, **k):               # keep the trained module to compare the replicas afterwards
+        out = real_train(model, *a, **k)
+        captured["sd"] = {n: v.detach().cpu().numpy().copy() for n, v in model.state_dict().items()}
+        return out
+
+    tsr.train = spy
+    summary = tsr.main(["--data_root", root, "-ds", "amazon", "-dm", "toy", "--overlap_ratio", "0.75", "--model", "sasrec", "--bs", "16",
+                        "--seq_len", "20", "--emb_dim", "64", "--hid_dim", "16", "--epoch", "1", "--neg_nums", "19", "--seeds", "1",
+                        "--device", "cuda:0", "-md", os.path.join(root, "model")])
+    q.put((rank, captured["sd"], {f"{k[0]}/{k[1]}": float(v) for k, v in summary[0].items()}))
+
+
+@pytest.mark.timeout(600)
+def test_train_sr_cli_data_parallel_two_ranks(tmp_path):
+    """The CLI under a two-process launch (what torch.distributed.run sets up): ranks shard every global batch, exchange
+    gradients each step and must end with bit-identical parameters and identical metrics."""
+    import numpy as np
+    from tests.test_gpu_module import _write_csv
+    rng = np.random.default_rng(1)
+    root = tmp_path / "amazon_dataset"
+    root.mkdir()
+    _write_csv(root / "toy_train75.csv", 200, rng, 1, 400, 400, 900)
+    _write_csv(root / "toy_test.csv", 64, rng, 1, 400, 400, 900)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cli_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, sd0, m0), (_, sd1, m1) = outs
+    for k in sd0:
+        assert np.array_equal(sd0[k], sd1[k]), k
+    assert m0 == m1 and all(0.0 <= v <= 1.0 for v in m0.values())
