@@ -146,17 +146,17 @@ __global__ __launch_bounds__(1024) void segreduce_spans_kernel(const int* __rest
     }
 }
 
-// Data-parallel exchange: a rank's (unique ids, gradient rows) padded to the world's largest count with (first id, zero row)
-// pairs, which add exact zeros in the merge (amid_amd/dist.py).  One half-wave per row.
+// Data-parallel exchange: a rank's (unique ids, gradient rows) padded to the world's largest count with (pad_id, zero row)
+// pairs (amid_amd/dist.py); pad_id < 0 = repeat the first id (adds exact zeros to a real row).  One half-wave per row.
 __global__ __launch_bounds__(256) void sparse_pad_kernel(const int* __restrict__ ids, const float* __restrict__ rows,
-                                                         const int* __restrict__ n_uniq, int n_out, int D,
+                                                         const int* __restrict__ n_uniq, int n_out, int D, int pad_id,
                                                          int* __restrict__ out_ids, float* __restrict__ out_rows) {
     const int sub = threadIdx.x & 31;
     const int r = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (r >= n_out) return;
     const int n = *n_uniq;
     const bool live = r < n;
-    if (sub == 0) out_ids[r] = live ? ids[r] : ids[0];
+    if (sub == 0) out_ids[r] = live ? ids[r] : (pad_id < 0 ? ids[0] : pad_id);
     for (int c = sub; c < (D >> 2); c += 32)
         st4(out_rows + (long long)r * D + 4 * c, live ? ld4(rows + (long long)r * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f));
 }
@@ -186,10 +186,10 @@ extern "C" int amid_embgrad_segreduce_f32(const float* grad_rows, const int* pos
     return AMID_OK;
 }
 
-extern "C" int amid_sparse_pad_f32(const int* uniq_ids, const float* uniq_rows, const int* n_uniq, int n_out, int D, int* out_ids,
-                                   float* out_rows, void* stream) {
+extern "C" int amid_sparse_pad_f32(const int* uniq_ids, const float* uniq_rows, const int* n_uniq, int n_out, int D, int pad_id,
+                                   int* out_ids, float* out_rows, void* stream) {
     AMID_CHECK_ARG(uniq_ids && uniq_rows && n_uniq && out_ids && out_rows && n_out > 0 && D > 0 && (D % 4) == 0);
-    sparse_pad_kernel<<<(n_out + 7) / 8, 256, 0, (hipStream_t)stream>>>(uniq_ids, uniq_rows, n_uniq, n_out, D, out_ids, out_rows);
+    sparse_pad_kernel<<<(n_out + 7) / 8, 256, 0, (hipStream_t)stream>>>(uniq_ids, uniq_rows, n_uniq, n_out, D, pad_id, out_ids, out_rows);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

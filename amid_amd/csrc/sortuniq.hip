@@ -143,8 +143,10 @@ __global__ __launch_bounds__(256) void heads_count_kernel(const int* __restrict_
 }
 
 // one block: exclusive scan of blk_heads (in place), total -> n_uniq, seg_off[total] = n
+// keys / sentinel (optional): when the largest key equals `sentinel` (padding of the data-parallel merge) its run is not counted
 __global__ __launch_bounds__(1024) void heads_scan_kernel(int* __restrict__ blk_heads, int nblk, int* __restrict__ n_uniq,
-                                                          int* __restrict__ seg_off, int n) {
+                                                          int* __restrict__ seg_off, int n, const int* __restrict__ keys = nullptr,
+                                                          int sentinel = -1) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int lane = lane_id(), w = wave_id();
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(1024) void heads_scan_kernel(int* __restrict__ blk_
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        *n_uniq = carry_s;
+        *n_uniq = (keys != nullptr && keys[n - 1] == sentinel) ? carry_s - 1 : carry_s;
         seg_off[carry_s] = n;
     }
 }
@@ -192,6 +194,46 @@ __global__ __launch_bounds__(256) void heads_write_kernel(const int* __restrict_
         uniq_ids[u] = keys[i];
         seg_off[u] = i;
     }
+}
+
+// Stable merge of `world` sorted lists of `len` keys each (list r = keys[r * len ..]): the merged position of entry (r, i) with
+// key x is i + sum over the other lists of (# keys < x), or (# keys <= x) for lists of lower rank -- ties go in rank order, so the
+// result equals a stable sort of the concatenation.  All binary searches of a thread advance in lock-step (independent loads).
+constexpr int MERGE_MAX_WORLD = 16;
+__global__ __launch_bounds__(256) void merge_rank_kernel(const int* __restrict__ keys, int world, int len, int* __restrict__ keys_sorted,
+                                                         int* __restrict__ pos_sorted) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= world * len) return;
+    const int r = e / len, i = e - r * len;
+    const int x = keys[e];
+    int lo[MERGE_MAX_WORLD], hi[MERGE_MAX_WORLD];
+#pragma unroll
+    for (int q = 0; q < MERGE_MAX_WORLD; ++q) { lo[q] = 0; hi[q] = len; }
+    for (int span = len; span > 0; span >>= 1) {               // ceil(log2(len)) + 1 rounds close every interval
+#pragma unroll
+        for (int q = 0; q < MERGE_MAX_WORLD; ++q) {
+            if (q < world && q != r && lo[q] < hi[q]) {
+                const int mid = (lo[q] + hi[q]) >> 1;
+                const int v = keys[q * len + mid];
+                const bool left = (q < r) ? (v <= x) : (v < x);      // lower ranks: upper bound; higher ranks: lower bound
+                if (left) lo[q] = mid + 1; else hi[q] = mid;
+            }
+        }
+    }
+    int p = i;
+#pragma unroll
+    for (int q = 0; q < MERGE_MAX_WORLD; ++q)
+        if (q < world && q != r) {
+            while (lo[q] < hi[q]) {                                  // (defensive: the loop above already closed it)
+                const int mid = (lo[q] + hi[q]) >> 1;
+                const int v = keys[q * len + mid];
+                const bool left = (q < r) ? (v <= x) : (v < x);
+                if (left) lo[q] = mid + 1; else hi[q] = mid;
+            }
+            p += lo[q];
+        }
+    keys_sorted[p] = x;
+    pos_sorted[p] = e;
 }
 
 }  // namespace amid
@@ -241,6 +283,28 @@ extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows,
     heads_count_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads);
     heads_scan_kernel<<<1, 1024, 0, s>>>(blk_heads, hblk, n_uniq, seg_off, n_idx);
     heads_write_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads, uniq_ids, seg_off, seg_of);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// Data-parallel merge (amid_amd/dist.py): `world` lists of `len` keys, each non-decreasing (a rank's unique ids in ascending order,
+// then `sentinel` padding with sentinel > every id) -> the same outputs as amid_sort_unique_i32 on the concatenation, in 4 launches
+// instead of a full radix sort; the sentinel run, if any, is left out of n_uniq.  Workspace: amid_sort_unique_workspace_bytes(world*len).
+extern "C" int amid_merge_sorted_lists_i32(const int* keys, int world, int len, int sentinel, void* workspace, int* pos_sorted,
+                                           int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq, void* stream) {
+    AMID_CHECK_ARG(keys && workspace && pos_sorted && uniq_ids && seg_off && seg_of && n_uniq && world > 0 && world <= MERGE_MAX_WORLD &&
+                   len > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int n = world * len;
+    char* ws = (char*)workspace;
+    const size_t kb = align256((size_t)n * 4);
+    int* keys_sorted = (int*)ws;
+    int* blk_heads = (int*)(ws + 4 * kb + align256((size_t)256 * sort_nblk(n) * 4));
+    merge_rank_kernel<<<(n + 255) / 256, 256, 0, s>>>(keys, world, len, keys_sorted, pos_sorted);
+    const int hblk = (n + 255) / 256;
+    heads_count_kernel<<<hblk, 256, 0, s>>>(keys_sorted, n, blk_heads);
+    heads_scan_kernel<<<1, 1024, 0, s>>>(blk_heads, hblk, n_uniq, seg_off, n, keys_sorted, sentinel);
+    heads_write_kernel<<<hblk, 256, 0, s>>>(keys_sorted, n, blk_heads, uniq_ids, seg_off, seg_of);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

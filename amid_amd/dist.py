@@ -9,9 +9,11 @@ exactly one exchange, made of
   dense   one flat-buffer all-reduce(sum) of every non-table gradient (1.7 MB: latency-bound, so ONE
           call, never per-parameter buckets); averaging is folded into Adam's ``grad_scale``;
   sparse  all-gather of each rank's segment-reduced (unique ids, gradient rows): ids and rows are
-          padded to the largest per-rank count with (first id, zero row) pairs, which add exact
-          zeros, then every rank merges the world's lists with the same sort + segment-reduce kernels
-          it used locally.  Same inputs, same fixed summation order => replicas stay bit-identical.
+          padded to the largest per-rank count with zero rows under a neutral id (the HIP backend uses a
+          sentinel one past the table so that every list stays sorted; the torch backend repeats the first
+          id, which adds exact zeros), then every rank merges the world's lists -- a stable rank-ordered
+          merge of sorted lists (4 launches) + the segment-reduce kernel it used locally.  Same inputs,
+          same fixed summation order => replicas stay bit-identical.
 
 Device-specific work (merging) is delegated to a backend object so the protocol itself is covered
 by world_size-2 gloo tests on CPU, with a test double in place of the HIP kernels.
@@ -33,7 +35,7 @@ class MergeBackend(Protocol):
         """Receive buffers (ids [n] int32, rows [n, D]) for the all-gather."""
         ...
 
-    def merge(self, ids: torch.Tensor, rows: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def merge(self, ids: torch.Tensor, rows: torch.Tensor, world: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """ids [n] int32 (duplicates allowed), rows [n, D] -> (uniq_ids [n], uniq_rows [n, D], n_uniq [1] int32);
         only the first n_uniq entries of the outputs are meaningful."""
         ...
@@ -77,7 +79,7 @@ class SparseDenseExchange:
             dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=self.group)
             umax = int(nmax.item())
         umax = max(1, min(int(umax), uniq_ids.numel()))
-        ids, rows = self.backend.pad(uniq_ids, uniq_rows, n_uniq, umax)      # (first id, zero row) padding: adds an exact 0.0
+        ids, rows = self.backend.pad(uniq_ids, uniq_rows, n_uniq, umax)      # neutral padding: zero rows under a repeated / sentinel id
         all_ids, all_rows = self.backend.gather_buffers(self.world * umax)
         if self.host_staging and ids.is_cuda:
             h_ids, h_rows = torch.empty(all_ids.shape, dtype=ids.dtype), torch.empty(all_rows.shape, dtype=rows.dtype)
@@ -88,7 +90,7 @@ class SparseDenseExchange:
         else:
             dist.all_gather_into_tensor(all_ids, ids, group=self.group)
             dist.all_gather_into_tensor(all_rows, rows, group=self.group)
-        return self.backend.merge(all_ids, all_rows)
+        return self.backend.merge(all_ids, all_rows, self.world)
 
 
 class TorchMergeBackend:
@@ -109,7 +111,7 @@ class TorchMergeBackend:
     def gather_buffers(self, n):
         return torch.empty(n, dtype=torch.int32, device=self.device), torch.empty(n, self.D, dtype=torch.float32, device=self.device)
 
-    def merge(self, ids, rows):
+    def merge(self, ids, rows, world=0):
         n = ids.numel()
         u, inv = torch.unique(ids.long(), return_inverse=True)        # sorted ascending, like the radix sort
         out = torch.zeros(n, rows.shape[1], dtype=rows.dtype, device=rows.device)

@@ -663,8 +663,9 @@ class HipMergeBackend:
         torch.cuda.synchronize(dev)
 
     def pad(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, umax: int):
+        # sentinel padding (one past the last table row) keeps every rank's list sorted, so merge() is a merge, not a sort
         lib().call("amid_sparse_pad_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), umax, self.eng.D,
-                   self.send_ids.data_ptr(), self.send_rows.data_ptr(), self.eng.s)
+                   self.eng.n_rows, self.send_ids.data_ptr(), self.send_rows.data_ptr(), self.eng.s)
         return self.send_ids[:umax], self.send_rows[:umax]
 
     def gather_buffers(self, n: int):
@@ -672,13 +673,20 @@ class HipMergeBackend:
             raise ValueError(f"gather of {n} entries exceeds the backend capacity {self.cap}")
         return self.all_ids[:n], self.all_rows[:n]
 
-    def merge(self, ids: torch.Tensor, rows: torch.Tensor):
+    def merge(self, ids: torch.Tensor, rows: torch.Tensor, world: int = 0):
+        """world > 0: `ids` is `world` equal-length lists produced by pad() (sorted, sentinel-padded) -> 4-launch stable merge;
+        world == 0: arbitrary ids -> full radix sort."""
         L, eng = lib(), self.eng
         n = ids.numel()
         if n > self.cap:
             raise ValueError(f"merge of {n} entries exceeds the backend capacity {self.cap}")
-        L.call("amid_sort_unique_i32", ids.data_ptr(), n, eng.n_rows, self.sort_ws.data_ptr(), self.pos_sorted.data_ptr(),
-               self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(), self.n_uniq.data_ptr(), eng.s)
+        if world > 0:
+            L.call("amid_merge_sorted_lists_i32", ids.data_ptr(), world, n // world, eng.n_rows, self.sort_ws.data_ptr(),
+                   self.pos_sorted.data_ptr(), self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
+                   self.n_uniq.data_ptr(), eng.s)
+        else:
+            L.call("amid_sort_unique_i32", ids.data_ptr(), n, eng.n_rows, self.sort_ws.data_ptr(), self.pos_sorted.data_ptr(),
+                   self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(), self.n_uniq.data_ptr(), eng.s)
         L.call("amid_embgrad_segreduce_f32", rows.data_ptr(), self.pos_sorted.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
                n, eng.D, self.seg_ws.data_ptr(), self.uniq_rows.data_ptr(), eng.s)
         return self.uniq_ids[:n], self.uniq_rows[:n], self.n_uniq

@@ -102,6 +102,39 @@ def test_sort_unique_matches_stable_sort(L, n, n_rows, pad_frac):
     assert torch.equal(_[3].cpu().long(), torch.repeat_interleave(torch.arange(U), wc))      # run index of every sorted entry
 
 
+@pytest.mark.parametrize("world,length,n_rows", [(2, 37, 100), (8, 2600, 894820), (3, 1, 10), (16, 500, 4000), (4, 4096, 3000)])
+def test_merge_sorted_lists_matches_stable_sort(L, world, length, n_rows):
+    """Data-parallel merge: `world` ascending unique lists, sentinel-padded to a common length (what HipMergeBackend.pad
+    produces) -> same outputs as a stable sort of the concatenation, with the sentinel run left out of n_uniq."""
+    g = torch.Generator().manual_seed(world * 1000 + length)
+    lists, counts = [], []
+    for r in range(world):
+        k = int(torch.randint(0, min(length, n_rows) + 1, (1,), generator=g)) if r else min(length, n_rows)     # rank 0 full, others ragged
+        ids = torch.randperm(n_rows, generator=g)[:k].sort().values
+        lists.append(torch.cat((ids, torch.full((length - k,), n_rows, dtype=torch.long))))
+        counts.append(k)
+    keys = torch.cat(lists)
+    n = world * length
+    kd = keys.to(torch.int32).cuda()
+    ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device="cuda")
+    pos = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    uniq = torch.zeros(n, dtype=torch.int32, device="cuda")
+    seg = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+    sof = torch.zeros(n, dtype=torch.int32, device="cuda")
+    nu = torch.zeros(1, dtype=torch.int32, device="cuda")
+    L.call("amid_merge_sorted_lists_i32", kd.data_ptr(), world, length, n_rows, ws.data_ptr(), pos.data_ptr(), uniq.data_ptr(),
+           seg.data_ptr(), sof.data_ptr(), nu.data_ptr(), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(pos.cpu().long(), torch.sort(keys, stable=True).indices)         # ties in rank order
+    wu, wc = torch.unique(keys, return_counts=True)
+    has_pad = bool((keys == n_rows).any())
+    U = int(nu.item())
+    assert U == wu.numel() - (1 if has_pad else 0)
+    assert torch.equal(uniq[:wu.numel()].cpu().long(), wu)
+    assert torch.equal(seg[: wu.numel() + 1].cpu().long(), torch.cat((torch.zeros(1, dtype=torch.long), wc.cumsum(0))))
+    assert torch.equal(sof.cpu().long(), torch.repeat_interleave(torch.arange(wu.numel()), wc))
+
+
 @pytest.mark.parametrize("D,n,n_rows,pad_frac", [(128, 26112, 894820, 0.89), (64, 6528, 5000, 0.85), (128, 70, 1000, 0.0),
                                                  (256, 1000, 20, 0.3), (128, 417792, 10_000_002, 0.89), (128, 4096, 7, 0.0)])
 def test_segreduce_matches_index_add(L, D, n, n_rows, pad_frac):
