@@ -282,15 +282,36 @@ def predict_module(u1: torch.Tensor, u2: torch.Tensor, items: torch.Tensor, P: P
 # --------------------------------------------------------------------------
 # a5  SASRec.forward                          model_seq.py:416-443
 # --------------------------------------------------------------------------
+def inter_comp(seq_self: torch.Tensor, seq_other: torch.Tensor, P: Params, pre: str, threshold: float,
+               taps: Optional[dict] = None) -> torch.Tensor:
+    """InterComp.forward model_seq.py:483-497 (next-1), compute-once form: the reference repeats seq_other
+    `bs` times along a new leading axis (:487) and every slice of that axis computes the same thing, so the appended block
+    is ONE [T, D] token group shared by every row.  InnerComp.forward (:459-472) is inter_comp(seq, seq)."""
+    s = torch.matmul(seq_self, seq_other.transpose(1, 2)).amax(dim=(1, 2))          # [B]  :488-489 max over both time axes
+    sm = torch.softmax(s, dim=0)                                                    # :490 softmax over the BATCH
+    gate = (sm > threshold).to(seq_self.dtype)                                      # :491 getBinaryTensor (no gradient)
+    h = (seq_other * gate[:, None, None]) @ P[f"{pre}.trans_nn.weight"].t() + P[f"{pre}.trans_nn.bias"]      # :492-493
+    grp = (h * P[f"{pre}.trans_bs.weight"][0][:, None, None]).sum(0) + P[f"{pre}.trans_bs.bias"]             # :494 Linear(bs, 1) over the batch
+    if taps is not None:
+        taps[pre] = dict(s=s.detach(), softmax=sm.detach(), gate=gate.detach(), margin=float((sm.detach() - threshold).abs().min()))
+    return torch.cat((seq_self, grp.unsqueeze(0).expand(seq_self.shape[0], -1, -1)), 1)                     # :495
+
+
+def inner_comp(seq: torch.Tensor, P: Params, pre: str, threshold: float) -> torch.Tensor:
+    return inter_comp(seq, seq, P, pre, threshold)
+
+
 def sasrec_forward(P: Params, i_node: torch.Tensor, neg_samples: torch.Tensor, seq_d1: torch.Tensor,
-                   seq_d2: torch.Tensor, masks: Masks = None, taps: Optional[dict] = None
-                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+                   seq_d2: torch.Tensor, masks: Masks = None, taps: Optional[dict] = None, isItC: bool = False,
+                   threshold2: float = 0.5) -> Tuple[torch.Tensor, torch.Tensor]:
     E = P["item_emb_layer.emb_item.weight"]
     i_feat = gather_rows(E, i_node).unsqueeze(1)                         # :418
     neg_feat = gather_rows(E, neg_samples)                               # :419
     f1 = sasrec_encoder(gather_rows(E, seq_d1), P, "sac1", masks, taps=None if taps is None else taps.setdefault("sac1", {}))
     f2 = sasrec_encoder(gather_rows(E, seq_d2), P, "sac2", masks, taps=None if taps is None else taps.setdefault("sac2", {}))
-    u1 = f1.mean(1)                                                      # :432 mean over ALL T (pads included)
+    if isItC:                                                            # :426-431 (after the encoders, both from the un-mixed features)
+        f1, f2 = inter_comp(f1, f2, P, "itc_d1", threshold2, taps), inter_comp(f2, f1, P, "itc_d2", threshold2, taps)
+    u1 = f1.mean(1)                                                      # :432 mean over ALL T (pads included; 2T with isItC)
     u2 = f2.mean(1)                                                      # :434
     items = torch.cat((i_feat, neg_feat), 1)                             # :435
     if taps is not None:
@@ -409,13 +430,13 @@ class DenseAdam:
 # --------------------------------------------------------------------------
 # a7+a8+a9+a10  one training step (train_sr.py:190-217)
 # --------------------------------------------------------------------------
-def loss_and_grads(model: str, P: Params, batch: Dict[str, torch.Tensor], masks: Masks = None
+def loss_and_grads(model: str, P: Params, batch: Dict[str, torch.Tensor], masks: Masks = None, **fwd_kw
                    ) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor], Dict[str, torch.Tensor]]:
     """Forward + masked BCE + autograd backward.  Embedding grads are DENSE
     (nn.Embedding(sparse=False), model_seq.py:25) exactly as in the reference."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     fwd = sasrec_forward if model == "sasrec" else bert4rec_forward
-    p1, p2 = fwd(leaves, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], masks)
+    p1, p2 = fwd(leaves, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], masks, **fwd_kw)
     loss = masked_bce_loss(p1, p2, batch["label"], batch["domain_id"])
     names = list(leaves)
     gs = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
@@ -423,8 +444,8 @@ def loss_and_grads(model: str, P: Params, batch: Dict[str, torch.Tensor], masks:
     return loss.detach(), (p1.detach(), p2.detach()), grads
 
 
-def train_step(model: str, P: Params, opt: DenseAdam, batch: Dict[str, torch.Tensor], masks: Masks = None) -> float:
-    loss, _, grads = loss_and_grads(model, P, batch, masks)
+def train_step(model: str, P: Params, opt: DenseAdam, batch: Dict[str, torch.Tensor], masks: Masks = None, **fwd_kw) -> float:
+    loss, _, grads = loss_and_grads(model, P, batch, masks, **fwd_kw)
     opt.step(P, grads)
     return float(loss)
 
@@ -469,8 +490,15 @@ def get_sample_scores(pred: np.ndarray):
 # --------------------------------------------------------------------------
 # parameter construction helpers for tests / bench (shapes as SURVEY 8(b))
 # --------------------------------------------------------------------------
-def sasrec_param_shapes(item_length: int, D: int, T: int, hid: int) -> Dict[str, Tuple[int, ...]]:
+def sasrec_param_shapes(item_length: int, D: int, T: int, hid: int, itc_bs: int = 0) -> Dict[str, Tuple[int, ...]]:
+    """itc_bs > 0: also the InterComp parameters of SASRec(isItC=True, bs=itc_bs) (model_seq.py:403-405, :478-480)."""
     s: Dict[str, Tuple[int, ...]] = {"item_emb_layer.emb_item.weight": (item_length, D)}
+    if itc_bs:
+        for d in (1, 2):
+            s[f"itc_d{d}.trans_nn.weight"] = (D, D)
+            s[f"itc_d{d}.trans_nn.bias"] = (D,)
+            s[f"itc_d{d}.trans_bs.weight"] = (1, itc_bs)
+            s[f"itc_d{d}.trans_bs.bias"] = (1,)
     for d in (1, 2):
         pre = f"sac{d}"
         s[f"{pre}.pos_emb.weight"] = (T, D)

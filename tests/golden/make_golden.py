@@ -22,6 +22,7 @@ Fixture inventory:
   g7_marshal.npz         seq_padding / __getitem__ / collate_fn_enhance layout
   g8_metrics.npz         get_sample_scores on a fixed prediction matrix
   g9_comp.npz            InterComp / InnerComp forward (next-1)
+  g10_sasrec_itc.npz     SASRec(isItC=True) logits, loss, all grads -- written by make_golden_itc.py
 """
 import os
 import random

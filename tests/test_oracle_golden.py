@@ -60,10 +60,10 @@ def test_g3_bert4rec_eval():
     assert rel_err(p1, z["p1"]) < 1e-6 and rel_err(p2, z["p2"]) < 1e-6
 
 
-def check_grads(model, z, P, B, G, masks, tol=2e-5):
+def check_grads(model, z, P, B, G, masks, tol=2e-5, **fwd_kw):
     batch = dict(B)
     batch["label"] = torch.from_numpy(z["labels"])
-    loss, (p1, p2), grads = orc.loss_and_grads(model, P, batch, masks)
+    loss, (p1, p2), grads = orc.loss_and_grads(model, P, batch, masks, **fwd_kw)
     assert rel_err(p1, z["p1"]) < 1e-6 and rel_err(p2, z["p2"]) < 1e-6
     assert abs(float(loss) - float(z["loss"])) < 1e-6 * max(1.0, abs(float(z["loss"])))
     assert G, "fixture holds no grads"
@@ -160,3 +160,22 @@ def test_philox_known_answer():
     assert [hex(int(x)) for x in out[0]] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
     keep = orc.philox_keep_flat(100000, seed=7, site=3, step=1, p=0.5)
     assert 0.49 < keep.mean() < 0.51
+
+
+def test_g9_inter_inner_comp_forward():
+    """InterComp / InnerComp (next-1): the compute-once restatement against the reference's [bs, b, n, d] formulation."""
+    z, P, *_ = load("g9_comp.npz")
+    a, b = torch.from_numpy(z["a"]), torch.from_numpy(z["b"])
+    assert float((orc.inter_comp(a, b, P, "itc", 0.15) - torch.from_numpy(z["inter"])).abs().max()) < 1e-6
+    assert float((orc.inner_comp(a, P, "inc", 0.15) - torch.from_numpy(z["inner"])).abs().max()) < 1e-6
+
+
+def test_g10_sasrec_itc_grads():
+    """SASRec(isItC=True) -- the configuration run.sh trains: logits, loss and every gradient (trans_nn / trans_bs included)."""
+    z, P, B, G, _ = load("g10_sasrec_itc.npz")
+    taps = {}
+    orc.sasrec_forward(P, B["i_node"], B["neg_samples"], B["seq_d1"], B["seq_d2"], None, taps, isItC=True, threshold2=float(z["threshold2"]))
+    assert np.array_equal(taps["itc_d1"]["gate"].numpy().astype(bool), z["gate"])
+    assert np.array_equal(taps["itc_d2"]["gate"].numpy().astype(bool), z["gate"])          # max over all (a, c) pairs is symmetric
+    assert set(G) == set(orc.sasrec_param_shapes(P["item_emb_layer.emb_item.weight"].shape[0], 64, 20, 16, itc_bs=6))
+    check_grads("sasrec", z, P, B, G, None, isItC=True, threshold2=float(z["threshold2"]))
