@@ -1,0 +1,275 @@
+// InterComp on the SASRec path (reference: InterComp.forward model_seq.py:483-497, used at model_seq.py:426-431 when
+// isItC -- the configuration run.sh trains).  SURVEY.md A.4: the reference repeats the other domain's features `bs` times
+// along a new axis and every slice computes the same thing, so the block it appends to each row is ONE [T, D] token group
+// shared by the whole batch; and since SASRec only takes the mean over the (now 2T) time axis afterwards (:432-434), the
+// whole module collapses onto the per-row means:
+//     s_j     = max_{a,c} f_self[j,a] . f_other[j,c]                        (pair-max; symmetric in the two domains)
+//     gate_j  = [ softmax_j(s)_j > threshold ]                              (softmax over the BATCH; no gradient)
+//     z_g     = sum_j w_bs_g[j] gate_j mean_t f_other[j,t]                  [D]
+//     c_g     = W_nn_g z_g + b_nn_g sum_j w_bs_g[j] + b_bs_g                = mean_t of the appended token group
+//     u_g[b]  = 0.5 mean_t f_g[b,t] + 0.5 c_g
+// Three small kernels: the pair-max per batch row (the only part that needs the full features), and a single-workgroup
+// mix forward / backward over [B, D] means.  Batch-coupled by construction (trans_bs is Linear(bs, 1) over the batch).
+#include "common.h"
+
+namespace amid {
+
+// ---- s_j: one workgroup per batch row; LN_last of both domains' rows staged in LDS, then all T x T dot products ----
+struct PairMaxArgs {
+    const float* x;                       // [2, B, T, D] output of the last encoder layer
+    const float* lnw[2]; const float* lnb[2];
+    float* s;                             // [B]
+    int B, T, D; float eps;
+};
+
+__global__ __launch_bounds__(256) void itc_pairmax_kernel(const PairMaxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = a.T, D = a.D, LD = D + 4, q = D >> 2;
+    float* F[2] = {smem, smem + T * LD};
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;          // 8 rows at a time, 32 lanes per row (D <= 128)
+    for (int g = 0; g < 2; ++g) {
+        const float* xb = a.x + ((long long)g * a.B + b) * T * D;
+        const bool on = sub < q;
+        float4 ww = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) { ww = ld4(a.lnw[g] + 4 * sub); bb = ld4(a.lnb[g] + 4 * sub); }
+        for (int t = rg; t < T; t += 8) {
+            float4 y = on ? ld4(xb + (long long)t * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float mean = group_sum<32>(f4hsum(y)) / D;
+            float4 d4 = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
+            if (!on) d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float rstd = 1.0f / sqrtf(group_sum<32>(f4hsum(f4mul(d4, d4))) / D + a.eps);
+            if (on) st4(F[g] + t * LD + 4 * sub, make_float4(d4.x * rstd * ww.x + bb.x, d4.y * rstd * ww.y + bb.y,
+                                                             d4.z * rstd * ww.z + bb.z, d4.w * rstd * ww.w + bb.w));
+        }
+    }
+    __syncthreads();
+    float best = -INFINITY;
+    for (int p = threadIdx.x; p < T * T; p += 256) {
+        const int i = p / T, j = p - i * T;
+        const float* fa = F[0] + i * LD;
+        const float* fc = F[1] + j * LD;
+        float acc = 0.f;
+        for (int c = 0; c < q; ++c) {
+            const float4 u = ld4(fa + 4 * c), v = ld4(fc + 4 * c);
+            acc = fmaf(u.x, v.x, acc); acc = fmaf(u.y, v.y, acc); acc = fmaf(u.z, v.z, acc); acc = fmaf(u.w, v.w, acc);
+        }
+        best = fmaxf(best, acc);
+    }
+    best = group_max<64>(best);
+    if (lane_id() == 0) red[wave_id()] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) a.s[b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ---- mix, forward: one workgroup -------------------------------------------------------------------------------------
+struct MixArgs {
+    const float* u_raw;                   // [2, B, D] mean_t LN_last(x)
+    const float* s;                       // [B]
+    const float* wnn[2]; const float* bnn[2]; const float* wbs[2]; const float* bbs[2];   // itc_d{1,2}: [D,D], [D], [B], [1]
+    float threshold;
+    float* gate;                          // [B]
+    float* z;                             // [2, D]
+    float* sw;                            // [2]
+    float* u_mix;                         // [2, B, D]
+    // backward
+    const float* du_mix;                  // [2, B, D]
+    float* du_raw;                        // [2, B, D]
+    float* dwnn[2]; float* dbnn[2]; float* dwbs[2]; float* dbbs[2];
+    int B, D;
+};
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {      // 1024 threads max; all threads get the result
+    v = group_sum<64>(v);
+    __syncthreads();
+    if (lane_id() == 0) red[wave_id()] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+    return s;
+}
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {
+    v = group_max<64>(v);
+    __syncthreads();
+    if (lane_id() == 0) red[wave_id()] = v;
+    __syncthreads();
+    float s = -INFINITY;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s = fmaxf(s, red[k]);
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void itc_mix_fwd_kernel(const MixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // gate [B] | z [2][D] | c [2][D]
+    __shared__ float red[16];
+    const int B = a.B, D = a.D;
+    float* gate_s = smem;
+    float* z_s = smem + B;
+    float* c_s = z_s + 2 * D;
+    // softmax over the batch, thresholded (model_seq.py:490-491)
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < B; j += blockDim.x) m = fmaxf(m, a.s[j]);
+    m = block_reduce_max(m, red);
+    float l = 0.f;
+    for (int j = threadIdx.x; j < B; j += blockDim.x) l += expf(a.s[j] - m);
+    l = block_reduce_sum(l, red);
+    for (int j = threadIdx.x; j < B; j += blockDim.x) {
+        const float gt = (expf(a.s[j] - m) / l > a.threshold) ? 1.f : 0.f;
+        gate_s[j] = gt;
+        a.gate[j] = gt;
+    }
+    float sw[2];
+    for (int g = 0; g < 2; ++g) {
+        float t = 0.f;
+        for (int j = threadIdx.x; j < B; j += blockDim.x) t += a.wbs[g][j];
+        sw[g] = block_reduce_sum(t, red);
+    }
+    if (threadIdx.x < 2) a.sw[threadIdx.x] = sw[threadIdx.x];
+    __syncthreads();
+    // z_g[d] = sum_j w_g[j] gate_j u_raw[other(g)][j][d]   (fixed order over j)
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
+        const int g = e / D, d = e - g * D;
+        const float* uo = a.u_raw + (long long)(1 - g) * B * D;
+        float t = 0.f;
+        for (int j = 0; j < B; ++j) t = fmaf(a.wbs[g][j] * gate_s[j], uo[(long long)j * D + d], t);
+        z_s[e] = t;
+        a.z[e] = t;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
+        const int g = e / D, o = e - g * D;
+        const float* w = a.wnn[g] + (long long)o * D;
+        float t = 0.f;
+        for (int d = 0; d < D; ++d) t = fmaf(w[d], z_s[g * D + d], t);
+        c_s[e] = t + a.bnn[g][o] * sw[g] + a.bbs[g][0];
+    }
+    __syncthreads();
+    const long long n = 2LL * B * D;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const int g = (int)(i / ((long long)B * D)), d = (int)(i % D);
+        a.u_mix[i] = 0.5f * a.u_raw[i] + 0.5f * c_s[g * D + d];      // mean over the 2T rows of cat(f, group)  (:432-434, :495)
+    }
+}
+
+__global__ __launch_bounds__(1024) void itc_mix_bwd_kernel(const MixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // dc [2][D] | dz [2][D]
+    __shared__ float red[16];
+    const int B = a.B, D = a.D;
+    float* dc_s = smem;
+    float* dz_s = smem + 2 * D;
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {          // dc_g = 0.5 sum_b du_mix[g][b]   (fixed order over b)
+        const int g = e / D, d = e - g * D;
+        const float* p = a.du_mix + (long long)g * B * D + d;
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t += p[(long long)b * D];
+        dc_s[e] = 0.5f * t;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {          // dz_g = W_nn_g^T dc_g ; d b_nn_g = dc_g * sum_j w_g[j]
+        const int g = e / D, d = e - g * D;
+        float t = 0.f;
+        for (int o = 0; o < D; ++o) t = fmaf(a.wnn[g][(long long)o * D + d], dc_s[g * D + o], t);
+        dz_s[e] = t;
+        a.dbnn[g][d] = dc_s[e] * a.sw[g];
+    }
+    for (int g = 0; g < 2; ++g) {                                     // d b_bs_g = sum_e dc_g[e] ; bdc_g = b_nn_g . dc_g
+        float t = 0.f;
+        for (int e = threadIdx.x; e < D; e += blockDim.x) t += dc_s[g * D + e];
+        t = block_reduce_sum(t, red);
+        if (threadIdx.x == 0) a.dbbs[g][0] = t;
+    }
+    __syncthreads();
+    for (long long i = threadIdx.x; i < 2LL * D * D; i += blockDim.x) {          // d W_nn_g = dc_g (x) z_g
+        const int g = (int)(i / ((long long)D * D));
+        const int r = (int)(i - (long long)g * D * D);
+        a.dwnn[g][r] = dc_s[g * D + r / D] * a.z[g * D + r % D];
+    }
+    float bdc[2];
+    for (int g = 0; g < 2; ++g) {
+        float t = 0.f;
+        for (int e = threadIdx.x; e < D; e += blockDim.x) t += a.bnn[g][e] * dc_s[g * D + e];
+        bdc[g] = block_reduce_sum(t, red);
+    }
+    // d w_bs_g[j] = gate_j (u_raw[other(g)][j] . dz_g) + b_nn_g . dc_g : one wave per (g, j)
+    const int nw = blockDim.x >> 6, w = wave_id(), lane = lane_id();
+    for (int p = w; p < 2 * B; p += nw) {
+        const int g = p / B, j = p - g * B;
+        const float* uo = a.u_raw + ((long long)(1 - g) * B + j) * D;
+        float t = 0.f;
+        for (int d = lane; d < D; d += 64) t = fmaf(uo[d], dz_s[g * D + d], t);
+        t = group_sum<64>(t);
+        if (lane == 0) a.dwbs[g][j] = a.gate[j] * t + bdc[g];
+    }
+    // d u_raw[g][b] = 0.5 d u_mix[g][b] + gate_b w_bs_{g'}[b] dz_{g'},  g' = the domain whose group is built from g
+    const long long n = 2LL * B * D;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const int g = (int)(i / ((long long)B * D));
+        const long long r = i - (long long)g * B * D;
+        const int b = (int)(r / D), d = (int)(r - (long long)b * D);
+        a.du_raw[i] = 0.5f * a.du_mix[i] + a.gate[b] * a.wbs[1 - g][b] * dz_s[(1 - g) * D + d];
+    }
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+// Pointer-array parameters are HOST arrays of 2 device pointers (itc_d1, itc_d2 / sac1, sac2).
+extern "C" int amid_itc_pairmax_f32(const float* x, const float* const* ln_w, const float* const* ln_b, int B, int T, int D, float eps,
+                                    float* s, void* stream) {
+    AMID_CHECK_ARG(x && ln_w && ln_b && ln_w[0] && ln_w[1] && ln_b[0] && ln_b[1] && s && B > 0 && T > 0 && D > 0 && (D % 4) == 0);
+    if (D > 128) return AMID_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)2 * T * (D + 4) * sizeof(float);
+    if (lds > 150 * 1024) return AMID_ERR_UNSUPPORTED;
+    PairMaxArgs a;
+    a.x = x; a.s = s; a.B = B; a.T = T; a.D = D; a.eps = eps;
+    for (int g = 0; g < 2; ++g) { a.lnw[g] = ln_w[g]; a.lnb[g] = ln_b[g]; }
+    hipError_t e = hipFuncSetAttribute((const void*)itc_pairmax_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    itc_pairmax_kernel<<<B, 256, lds, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+static int mix_fill(MixArgs& a, const float* u_raw, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs,
+                    const float* const* b_bs, int B, int D) {
+    AMID_CHECK_ARG(u_raw && w_nn && b_nn && w_bs && b_bs && B > 0 && D > 0 && (D % 4) == 0);
+    a.u_raw = u_raw; a.B = B; a.D = D;
+    for (int g = 0; g < 2; ++g) {
+        AMID_CHECK_ARG(w_nn[g] && b_nn[g] && w_bs[g] && b_bs[g]);
+        a.wnn[g] = w_nn[g]; a.bnn[g] = b_nn[g]; a.wbs[g] = w_bs[g]; a.bbs[g] = b_bs[g];
+    }
+    return AMID_OK;
+}
+
+extern "C" int amid_itc_mix_fwd_f32(const float* u_raw, const float* s, const float* const* w_nn, const float* const* b_nn,
+                                    const float* const* w_bs, const float* const* b_bs, float threshold, int B, int D, float* gate,
+                                    float* z, float* sw, float* u_mix, void* stream) {
+    MixArgs a = {};
+    if (int e = mix_fill(a, u_raw, w_nn, b_nn, w_bs, b_bs, B, D)) return e;
+    AMID_CHECK_ARG(s && gate && z && sw && u_mix);
+    a.s = s; a.threshold = threshold; a.gate = gate; a.z = z; a.sw = sw; a.u_mix = u_mix;
+    const size_t lds = (size_t)(B + 4 * D) * sizeof(float);
+    if (lds > 60 * 1024) return AMID_ERR_UNSUPPORTED;
+    itc_mix_fwd_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_itc_mix_bwd_f32(const float* du_mix, const float* u_raw, const float* gate, const float* z, const float* sw,
+                                    const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int D,
+                                    float* du_raw, float* const* dw_nn, float* const* db_nn, float* const* dw_bs, float* const* db_bs,
+                                    void* stream) {
+    MixArgs a = {};
+    const float* dummy[2] = {sw, sw};
+    if (int e = mix_fill(a, u_raw, w_nn, b_nn, w_bs, dummy, B, D)) return e;
+    AMID_CHECK_ARG(du_mix && gate && z && sw && du_raw && dw_nn && db_nn && dw_bs && db_bs);
+    a.du_mix = du_mix; a.gate = const_cast<float*>(gate); a.z = const_cast<float*>(z); a.sw = const_cast<float*>(sw); a.du_raw = du_raw;
+    for (int g = 0; g < 2; ++g) {
+        AMID_CHECK_ARG(dw_nn[g] && db_nn[g] && dw_bs[g] && db_bs[g]);
+        a.dwnn[g] = dw_nn[g]; a.dbnn[g] = db_nn[g]; a.dwbs[g] = dw_bs[g]; a.dbbs[g] = db_bs[g];
+    }
+    itc_mix_bwd_kernel<<<1, 1024, (size_t)4 * D * sizeof(float), (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}

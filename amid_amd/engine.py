@@ -29,9 +29,16 @@ SASREC_P_DROP = 0.5       # model_seq.py:335,350,356
 SASREC_LN_EPS = 1e-8      # model_seq.py:342-353
 
 
-def sasrec_dense_names(T: int, D: int, hid: int) -> List[Tuple[str, Tuple[int, ...]]]:
-    """Non-table parameters in the reference's state_dict order."""
+def sasrec_dense_names(T: int, D: int, hid: int, itc_bs: int = 0) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Non-table parameters in the reference's state_dict order; itc_bs > 0: with the InterComp
+    modules of SASRec(isItC=True, bs=itc_bs) (model_seq.py:403-405, :478-480)."""
     out: List[Tuple[str, Tuple[int, ...]]] = []
+    if itc_bs:
+        for d in (1, 2):
+            out.append((f"itc_d{d}.trans_nn.weight", (D, D)))
+            out.append((f"itc_d{d}.trans_nn.bias", (D,)))
+            out.append((f"itc_d{d}.trans_bs.weight", (1, itc_bs)))
+            out.append((f"itc_d{d}.trans_bs.bias", (1,)))
     for d in (1, 2):
         pre = f"sac{d}"
         out.append((f"{pre}.pos_emb.weight", (T, D)))
@@ -143,6 +150,12 @@ class SasrecPlan:
         self.stats = [f(2 * M, H, 2) for _ in range(2)]
         self._alloc_model_fwd(eng, f)
         self.u = f(2, B, D)
+        if getattr(eng, "itc_bs", 0):
+            if B != eng.itc_bs:
+                raise ValueError(f"isItC: the batch must hold exactly bs = {eng.itc_bs} rows (trans_bs is Linear(bs, 1) over the batch, "
+                                 f"model_seq.py:480), got {B}")
+            self.u_raw, self.du_raw = f(2, B, D), f(2, B, D)
+            self.itc_s, self.itc_gate, self.itc_z, self.itc_sw = f(B), f(B), f(2, D), f(2)
         self.p1 = f(B, NI)
         self.p2 = f(B, NI)
         self.dp1 = torch.zeros(B, NI, dtype=torch.float32, device=dev)
@@ -258,7 +271,7 @@ class SasrecEngine:
     EMB_DIMS = (64, 128)
 
     def _dense_names(self) -> List[Tuple[str, Tuple[int, ...]]]:
-        return sasrec_dense_names(self.T, self.D, self.hid)
+        return sasrec_dense_names(self.T, self.D, self.hid, self.itc_bs)
 
     def _alloc_model_buffers(self) -> None:
         D = self.D
@@ -266,8 +279,11 @@ class SasrecEngine:
         self.wT = torch.zeros(2, 2, 6, D * D, dtype=torch.float32, device=self.device)     # [layer][domain][q,k,v,o,c1,c2]
 
     def __init__(self, item_length: int, emb_dim: int, seq_len: int, hid_dim: int, device="cuda:0", lr: float = 5e-4,
-                 betas=(0.9, 0.999), eps: float = 1e-8, seed: int = 0):
+                 betas=(0.9, 0.999), eps: float = 1e-8, seed: int = 0, itc_bs: int = 0, itc_threshold: float = 0.5):
+        """itc_bs > 0: SASRec(isItC=True, bs=itc_bs, threshold2=itc_threshold) -- InterComp after the encoders
+        (model_seq.py:426-431); every batch must then hold exactly itc_bs rows (trans_bs is Linear(bs, 1) over the batch)."""
         L = lib()        # raises AmidLibraryError when the HIP library is missing: no fallback
+        self.itc_bs, self.itc_threshold = int(itc_bs), float(itc_threshold)
         if emb_dim not in self.EMB_DIMS:
             raise ValueError(f"amid_amd {type(self).__name__} kernels are built for emb_dim in {self.EMB_DIMS}, got {emb_dim}")
         self.device = torch.device(device)
@@ -434,6 +450,11 @@ class SasrecEngine:
                    self._pp(f"sac{{d}}.forward_layers.{l}.conv2.bias"), pl.tmq.data_ptr(), M, D, pl.rpt, l, st, tr, SASREC_P_DROP,
                    pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(), s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
+        if self.itc_bs:
+            self._enqueue_head_itc_fwd(pl, items, with_loss)
+            if with_loss and sum_loss:
+                L.call("amid_sum_vector_f32", pl.loss_part.data_ptr(), B, pl.loss.data_ptr(), s)
+            return
         L.call("amid_head_fwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"), items,
                fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
                fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr() if with_loss else None, pl.domain.data_ptr() if with_loss else None,
@@ -442,6 +463,38 @@ class SasrecEngine:
                pl.loss_part.data_ptr() if with_loss else None, s)
         if with_loss and sum_loss:
             L.call("amid_sum_vector_f32", pl.loss_part.data_ptr(), B, pl.loss.data_ptr(), s)
+
+    # ---- isItC head: last LayerNorm + mean -> pair-max -> batch-softmax gate + mix -> scorer (csrc/intercomp.hip) ----
+    def _enqueue_head_itc_fwd(self, pl: SasrecPlan, items: int, with_loss: bool) -> None:
+        L, s, shp, D = lib(), self.s, pl.shape, self.D
+        B, T, NI = shp.B, shp.T, shp.NI
+        fp = self.dense
+        lw, lb = self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias")
+        L.call("amid_lnmean_fwd_f32", pl.x[2].data_ptr(), fp.ptr("sac1.last_layernorm.weight"), fp.ptr("sac1.last_layernorm.bias"),
+               fp.ptr("sac2.last_layernorm.weight"), fp.ptr("sac2.last_layernorm.bias"), B, T, D, SASREC_LN_EPS, pl.u_raw.data_ptr(), s)
+        L.call("amid_itc_pairmax_f32", pl.x[2].data_ptr(), lw, lb, B, T, D, SASREC_LN_EPS, pl.itc_s.data_ptr(), s)
+        L.call("amid_itc_mix_fwd_f32", pl.u_raw.data_ptr(), pl.itc_s.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"),
+               self._pp("itc_d{d}.trans_nn.bias"), self._pp("itc_d{d}.trans_bs.weight"), self._pp("itc_d{d}.trans_bs.bias"),
+               self.itc_threshold, B, D, pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(), pl.itc_sw.data_ptr(), pl.u.data_ptr(), s)
+        L.call("amid_scorer_fwd_f32", pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
+               fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr() if with_loss else None,
+               pl.domain.data_ptr() if with_loss else None, B, NI, D, self.hid, pl.p1.data_ptr(), pl.p2.data_ptr(),
+               pl.dp1.data_ptr() if with_loss else None, pl.dp2.data_ptr() if with_loss else None,
+               pl.loss_part.data_ptr() if with_loss else None, s)
+
+    def _enqueue_head_itc_bwd(self, pl: SasrecPlan, items: int, ditems: int) -> None:
+        L, s, shp, D = lib(), self.s, pl.shape, self.D
+        B, T, NI = shp.B, shp.T, shp.NI
+        fp, G = self.dense, self.dense.grad
+        L.call("amid_scorer_bwd_f32", pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
+               fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(), pl.p2.data_ptr(),
+               pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, NI, D, self.hid, pl.du.data_ptr(), ditems, pl.sc_part.data_ptr(), s)
+        L.call("amid_itc_mix_bwd_f32", pl.du.data_ptr(), pl.u_raw.data_ptr(), pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(),
+               pl.itc_sw.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"), self._pp("itc_d{d}.trans_nn.bias"),
+               self._pp("itc_d{d}.trans_bs.weight"), B, D, pl.du_raw.data_ptr(), self._pp("itc_d{d}.trans_nn.weight", G),
+               self._pp("itc_d{d}.trans_nn.bias", G), self._pp("itc_d{d}.trans_bs.weight", G), self._pp("itc_d{d}.trans_bs.bias", G), s)
+        L.call("amid_lnmean_bwd_f32", pl.x[2].data_ptr(), pl.du_raw.data_ptr(), fp.ptr("sac1.last_layernorm.weight"),
+               fp.ptr("sac2.last_layernorm.weight"), B, T, D, SASREC_LN_EPS, pl.dxbuf.data_ptr(), pl.last_part.data_ptr(), s)
 
     def enqueue_backward(self, pl: SasrecPlan, train: bool) -> None:
         """Backward from pl.dp1 / pl.dp2 (dLoss/dp) to pl.uniq_grad (table rows) and dense.grad."""
@@ -463,11 +516,15 @@ class SasrecEngine:
                 dst += [self.wT[l, g, w].data_ptr() for w in range(6)]
         items = pl.xg.data_ptr() + 4 * 2 * M * D
         ditems = pl.dxg.data_ptr() + 4 * 2 * M * D
-        L.call("amid_head_bwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), pl.u.data_ptr(), items,
-               fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
-               fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, T, NI, D,
-               self.hid, SASREC_LN_EPS, pl.dxbuf.data_ptr(), ditems, pl.last_part.data_ptr(), pl.sc_part.data_ptr(),
-               ptr_array(src), ptr_array(dst), len(src), s)
+        if self.itc_bs:
+            L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
+            self._enqueue_head_itc_bwd(pl, items, ditems)
+        else:
+            L.call("amid_head_bwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), pl.u.data_ptr(), items,
+                   fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
+                   fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, T, NI, D,
+                   self.hid, SASREC_LN_EPS, pl.dxbuf.data_ptr(), ditems, pl.last_part.data_ptr(), pl.sc_part.data_ptr(),
+                   ptr_array(src), ptr_array(dst), len(src), s)
         for l in (1, 0):
             L.call("amid_sas_ffn_bwd_f32", pl.dxbuf.data_ptr(), pl.tmq.data_ptr(), pl.h[l].data_ptr(), pl.r[l].data_ptr(),
                    self._pp(f"sac{{d}}.forward_layernorms.{l}.weight"), self._wT(l, 4), self._wT(l, 5), self._wT(l, 3), SASREC_LN_EPS,
@@ -557,6 +614,9 @@ class SasrecEngine:
     def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False, umax: Optional[int] = None) -> None:
         """One data-parallel step: local grads -> dense all-reduce + sparse all-gather/merge -> Adam.
         umax: the world's largest unique-row count of this step if the host knows it (no host sync then, see dist.py)."""
+        if self.itc_bs and exchange.world > 1:
+            raise NotImplementedError("isItC couples the rows of a batch (softmax and Linear(bs, 1) over the batch, model_seq.py:490-494): "
+                                      "data-parallel sharding would change the model; train isItC on one GPU")
         with torch.cuda.stream(self.stream):
             if use_graph:
                 lib().call("amid_graph_launch", pl.graph_local, self.s)

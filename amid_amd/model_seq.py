@@ -24,8 +24,9 @@ are accepted and ignored; dropout follows ``module.training``.  Two ways to trai
                    Adam as one hipGraph replay -- what ``train_sr.py`` of this repo and ``bench.py`` use.
 
 Out of scope this round (constructors kept for import / state_dict parity, ``forward`` raises):
-GRU4Rec (recurrent), InnerComp / InterComp (isInC / isItC), embUserLayerEnhance (dead code in
-the reference), the isDR heads.
+GRU4Rec (recurrent), the standalone InnerComp / InterComp modules, isInC, BERT4Rec with isItC (both put the
+appended token group in FRONT of the encoders), embUserLayerEnhance (dead code in the reference), the isDR heads.
+SASRec(isItC=True) -- InterComp after the encoders, what run.sh trains -- IS built (csrc/intercomp.hip).
 """
 from __future__ import annotations
 
@@ -107,15 +108,19 @@ class _SasrecFunction(torch.autograd.Function):
 
 
 class SASRec(nn.Module):
-    """model_seq.py:390-443 on the HIP engine (isInC = isItC = isDR = False)."""
+    """model_seq.py:390-443 on the HIP engine (isInC = isDR = False; isItC either way: with it every batch must hold exactly
+    `bs` rows, as in the reference where trans_bs is Linear(bs, 1) over the batch, and state_dict gains itc_d{1,2}.*)."""
 
     ENGINE_CLS = SasrecEngine
+    SUPPORTS_ITC = True          # InterComp after the encoders (model_seq.py:426-431), the configuration run.sh trains
 
     def __init__(self, user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim, bs, isInC, isItC, threshold1,
                  threshold2, isDR=False, device: Optional[str] = None, lr: float = 5e-4, seed: int = 0):
         super().__init__()
-        if isInC or isItC:
-            _not_built("InnerComp / InterComp (isInC / isItC)", "model_seq.py:422-431")
+        if isInC:
+            _not_built("InnerComp (isInC)", "model_seq.py:422-424")
+        if isItC and not self.SUPPORTS_ITC:
+            _not_built("InterComp (isItC) for this model", "model_seq.py:289-294")
         if isDR:
             _not_built("the doubly-robust heads (isDR)", "model_seq.py:411-414")
         if user_emb_dim != item_emb_dim:
@@ -124,7 +129,8 @@ class SASRec(nn.Module):
         self.user_emb_dim = user_emb_dim
         self.isInC, self.isItC, self.isDR = isInC, isItC, isDR
         dev = device or ("cuda:%d" % torch.cuda.current_device())
-        self.engine = self.ENGINE_CLS(item_length, item_emb_dim, seq_len, hid_dim, device=dev, lr=lr, seed=seed)
+        kw = dict(itc_bs=bs, itc_threshold=threshold2) if isItC else {}
+        self.engine = self.ENGINE_CLS(item_length, item_emb_dim, seq_len, hid_dim, device=dev, lr=lr, seed=seed, **kw)
         eng = self.engine
         self._param_names = ["item_emb_layer.emb_item.weight"] + list(eng.dense.slots)
         self._init_reference_defaults(seed)
@@ -158,6 +164,8 @@ class SASRec(nn.Module):
                 else:                                          # kaiming_uniform_(a=sqrt(5)) => U(-1/sqrt(fan_in), 1/sqrt(fan_in))
                     fan_in = {"predictModule.fc.0.weight": 2 * D, "predictModule.fc.0.bias": 2 * D, "predictModule.fc.2.weight": hid,
                               "predictModule.fc.2.bias": hid}.get(name, 4 * D if ".feed_forward.w_2." in name else D)
+                    if ".trans_bs." in name:                   # InterComp's Linear(bs, 1) over the batch (model_seq.py:480)
+                        fan_in = eng.itc_bs
                     a = 1.0 / fan_in ** 0.5
                     v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * a)
         torch.cuda.synchronize(eng.device)
@@ -387,3 +395,4 @@ class BERT4Rec(SASRec):
     Same constructor, forward signature, state_dict keys (transform{1,2}.{0,1}.*) and train_step() as SASRec above."""
 
     ENGINE_CLS = Bert4recEngine
+    SUPPORTS_ITC = False         # BERT4Rec applies InterComp BEFORE the encoders (2T tokens, :289-294): not built

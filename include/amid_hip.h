@@ -208,6 +208,23 @@ int amid_bert_wgrad_f32(const float* const* dy, const float* const* x, const int
 int amid_key_keep_u8(const long long* seq, long long n, unsigned char* keep, void* stream);
 int amid_transpose_rect_f32(const float* const* src, float* const* dst, const int* rows, const int* cols, int n, void* stream);
 
+/* ---- InterComp on the SASRec path (isItC; next-1 of SURVEY.md 8(f)) -------------------------------------------------------
+ * replaces: InterComp.forward model_seq.py:483-497 as used at model_seq.py:426-434 (both directions) and its autograd.  Since
+ * SASRec only means over the time axis afterwards, the module collapses onto per-row means (derivation: csrc/intercomp.hip):
+ *   pairmax : s[j] = max_{a,c} LN_last(x[0,j,a]) . LN_last(x[1,j,c])                                   (:488-489)
+ *   mix_fwd : gate = softmax_batch(s) > threshold (:490-491); z_g = sum_j w_bs_g[j] gate_j u_raw[1-g][j];
+ *             u_mix[g][b] = 0.5 u_raw[g][b] + 0.5 (W_nn_g z_g + b_nn_g sum_j w_bs_g[j] + b_bs_g)        (:492-495, :432-434)
+ *   mix_bwd : gradients of the above into du_raw and the eight InterComp parameters (written whole, no partials).
+ * Host pointer arrays hold 2 device pointers: index 0 = itc_d1 / sac1, 1 = itc_d2 / sac2.  u_raw: amid_lnmean_fwd_f32. */
+int amid_itc_pairmax_f32(const float* x, const float* const* ln_w, const float* const* ln_b, int B, int T, int D, float eps, float* s,
+                         void* stream);
+int amid_itc_mix_fwd_f32(const float* u_raw, const float* s, const float* const* w_nn, const float* const* b_nn,
+                         const float* const* w_bs, const float* const* b_bs, float threshold, int B, int D, float* gate, float* z,
+                         float* sw, float* u_mix, void* stream);
+int amid_itc_mix_bwd_f32(const float* du_mix, const float* u_raw, const float* gate, const float* z, const float* sw,
+                         const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int D, float* du_raw,
+                         float* const* dw_nn, float* const* db_nn, float* const* dw_bs, float* const* db_bs, void* stream);
+
 /* ---- hipGraph capture / replay of a whole step; HIP events on the caller's stream ---------------- */
 int amid_graph_capture_begin(void* stream);
 int amid_graph_capture_end(void* stream, void** graph_exec_out);

@@ -171,9 +171,10 @@ def test_unbuilt_models_fail_loudly():
     from amid_amd import model_seq
     with pytest.raises(NotImplementedError):
         model_seq.GRU4Rec(10, 128, 100, 128, 20, 32, 4, False, False, 0.5, 0.5)
-    for cls in (model_seq.SASRec, model_seq.BERT4Rec):
-        with pytest.raises(NotImplementedError):
-            cls(10, 128, 100, 128, 20, 32, 4, False, True, 0.5, 0.5)
+    with pytest.raises(NotImplementedError):                 # InnerComp puts its token group in front of the encoder: not built
+        model_seq.SASRec(10, 128, 100, 128, 20, 32, 4, True, False, 0.5, 0.5)
+    with pytest.raises(NotImplementedError):                 # so does BERT4Rec's InterComp (model_seq.py:289-294)
+        model_seq.BERT4Rec(10, 128, 100, 128, 20, 32, 4, False, True, 0.5, 0.5)
     with pytest.raises(ValueError):                      # the reference hard-codes hidden size 128 (model_seq.py:264-267)
         model_seq.BERT4Rec(10, 64, 100, 64, 20, 32, 4, False, False, 0.5, 0.5)
 
@@ -191,8 +192,31 @@ def _write_csv(path, n, rng, lo1, hi1, lo2, hi2):
         f.write("\n".join(rows) + "\n")
 
 
-@pytest.mark.parametrize("model,emb", [("sasrec", "64"), ("bert4rec", "128")])
-def test_train_sr_cli_end_to_end(tmp_path, model, emb):
+def test_sasrec_itc_module_surface():
+    """SASRec(isItC=True): the reference's extra state_dict keys, eval forward vs the oracle, a batch of the wrong size refused."""
+    from amid_amd.model_seq import SASRec
+    D, T, hid, n_items, bs = 64, 20, 16, 200, 8
+    m = SASRec(10, D, n_items, D, T, hid, bs, False, True, 0.5, 0.15).cuda()
+    want = set(orc.sasrec_param_shapes(n_items, D, T, hid, itc_bs=bs))
+    assert set(m.state_dict().keys()) == want
+    assert tuple(m.itc_d2.trans_bs.weight.shape) == (1, bs)
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    batch = orc.synthetic_batch(bs, T, n_items - 1, pad_id=n_items - 1, neg=3, seed=2)
+    batch["seq_d1"] = torch.randint(1, n_items - 1, (bs, T), generator=g)
+    batch["seq_d2"] = torch.randint(1, n_items - 1, (bs, T), generator=g)
+    cu = {k: v.cuda() for k, v in batch.items()}
+    m.eval()
+    with torch.no_grad():
+        p1, p2 = m(None, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], None, None, False)
+    o1, o2 = orc.sasrec_forward(P, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], isItC=True, threshold2=0.15)
+    assert relmax(p1, o1.squeeze()) < 3e-5 and relmax(p2, o2.squeeze()) < 3e-5
+    with pytest.raises(ValueError):
+        m(None, cu["i_node"][:4], cu["neg_samples"][:4], cu["seq_d1"][:4], cu["seq_d2"][:4], None, None, False)
+
+
+@pytest.mark.parametrize("model,emb,extra", [("sasrec", "64", []), ("bert4rec", "128", []), ("sasrec", "64", ["--isItC", "True", "--ts2", "0.4"])])
+def test_train_sr_cli_end_to_end(tmp_path, model, emb, extra):
     """The reference's command line on a synthetic CSV pair with the reference's column layout."""
     from amid_amd.train_sr import main
     rng = np.random.default_rng(0)
@@ -202,7 +226,7 @@ def test_train_sr_cli_end_to_end(tmp_path, model, emb):
     _write_csv(root / "toy_test.csv", 80, rng, 1, 400, 400, 900)
     summary = main(["--data_root", str(tmp_path), "-ds", "amazon", "-dm", "toy", "--overlap_ratio", "0.75", "--model", model,
                     "--bs", "32", "--seq_len", "20", "--emb_dim", emb, "--hid_dim", "16", "--epoch", "2", "--neg_nums", "19",
-                    "--seeds", "1", "-md", str(tmp_path / "model")])
+                    "--seeds", "1", "-md", str(tmp_path / "model")] + extra)
     assert len(summary) == 1
     best = summary[0]
     assert ("d1", "HR@10") in best and ("d2", "MRR") in best

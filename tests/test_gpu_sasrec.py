@@ -250,3 +250,78 @@ def test_graph_replay_equals_eager():
     assert l0 == l1
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+# ---------------------------------------------------------------------------- isItC (next-1 of SURVEY.md section 8(f))
+def make_itc_engine(P, T, bs, ts2, lr=5e-4, seed=0):
+    from amid_amd.engine import SasrecEngine
+    n_rows, D = P["item_emb_layer.emb_item.weight"].shape
+    hid = P["predictModule.fc.0.weight"].shape[0]
+    eng = SasrecEngine(n_rows, D, T, hid, lr=lr, seed=seed, itc_bs=bs, itc_threshold=ts2)
+    eng.load_state_dict(P)
+    return eng
+
+
+def test_itc_golden_logits_loss_grads():
+    """SASRec(isItC=True) against the reference's own logits, loss and gradients (g10; trans_nn / trans_bs included)."""
+    z, P, B, G = load_golden("g10_sasrec_itc.npz")
+    B = dict(B)
+    B["label"] = torch.from_numpy(z["labels"])
+    eng = make_itc_engine(P, B["seq_d1"].shape[1], B["seq_d1"].shape[0], float(z["threshold2"]))
+    pl = run_forward(eng, B, train=False, with_loss=True)
+    assert np.array_equal(pl.itc_gate.cpu().numpy() > 0.5, z["gate"])
+    assert relmax(pl.p1, z["p1"]) < 1e-4 and relmax(pl.p2, z["p2"]) < 1e-4
+    eng.enqueue_backward(pl, train=False)
+    eng.sync()
+    assert abs(float(pl.loss.item()) - float(z["loss"])) < 1e-5
+    grads_check("golden g10 itc", eng, pl, G, 5e-4, 5e-4)
+
+
+@pytest.mark.parametrize("D,train", [(64, False), (128, True)])
+def test_itc_vs_oracle_and_train_steps(D, train):
+    """isItC forward / backward against the oracle on unpadded rows (a non-trivial gate), then full train steps with graph replay."""
+    T, Bn, hid, n_items, ts2 = 20, 8, 16, 300, 0.15
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid, itc_bs=Bn), seed=40 + D)
+    for d in (1, 2):
+        P[f"sac{d}.last_layernorm.weight"] *= 0.3          # keeps the batch softmax of the pair-max scores away from one-hot
+    g = torch.Generator().manual_seed(7)
+    batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=9)
+    batch["seq_d1"] = torch.randint(1, n_items - 1, (Bn, T), generator=g)      # no shared pad positions: distinct pair-max scores
+    batch["seq_d2"] = torch.randint(1, n_items - 1, (Bn, T), generator=g)
+    seed, step = 31, 3
+    masks = orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=step) if train else None
+    taps = {}
+    orc.sasrec_forward(P, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], masks, taps, isItC=True, threshold2=ts2)
+    gate = taps["itc_d1"]["gate"]
+    log(f"itc D={D} train={train}: gate {gate.int().tolist()} softmax margin {taps['itc_d1']['margin']:.3e}")
+    assert 0 < int(gate.sum()) < Bn and taps["itc_d1"]["margin"] > 1e-3
+    loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, masks, isItC=True, threshold2=ts2)
+    eng = make_itc_engine(P, T, Bn, ts2, lr=1e-3, seed=seed)
+    pl = run_forward(eng, batch, train=train, with_loss=True, step=step, seed=seed)
+    assert torch.equal(pl.itc_gate.cpu(), gate)
+    assert relmax(pl.p1, p1) < 3e-5 and relmax(pl.p2, p2) < 3e-5
+    eng.enqueue_backward(pl, train=train)
+    eng.sync()
+    assert abs(float(pl.loss.item()) - float(loss)) < 1e-5
+    grads_check(f"itc D={D} train={train}", eng, pl, grads, 5e-4 if train else 2e-4, 5e-3 if train else 2e-4)
+    # train steps: eager vs hipGraph replay, bit-identical, and a wrong batch size is refused
+    def run(use_graph):
+        e = make_itc_engine(P, T, Bn, ts2, lr=1e-3, seed=seed)
+        q = e.plan(Bn, T, 2, need_grad=True)
+        cu = {k: v.cuda() for k, v in batch.items()}
+        e.load_batch(q, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"])
+        if use_graph:
+            e.capture_train_step(q)
+        losses = []
+        for _ in range(3):
+            e.replay_train_step(q) if use_graph else e.enqueue_train_step(q)
+            e.sync()
+            losses.append(float(q.loss.item()))
+        e.flush_table(); e.sync()
+        return losses, {k: v.cpu().clone() for k, v in e.state_dict().items()}
+    l0, s0 = run(False)
+    l1, s1 = run(True)
+    assert l0 == l1 and all(torch.equal(s0[k], s1[k]) for k in s0)
+    assert l0[2] < l0[0]
+    with pytest.raises(ValueError):
+        eng.plan(Bn + 1, T, 2, need_grad=True)
