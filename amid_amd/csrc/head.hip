@@ -306,6 +306,23 @@ __global__ void sum_vector_kernel(const float* __restrict__ v, int n, float* __r
     if (threadIdx.x == 0) *out = s;
 }
 
+// rank (0 = best) of the positive (column 0) among a row's NI scores, judged by the head of the row's own domain -- the device
+// form of choose_predict + the double argsort of get_sample_scores (reference utils.py:21-40, :296-297; train_sr.py:114-115
+// subtracts fix_value from the positive first, so a tie counts against it).  One wave per row.
+__global__ __launch_bounds__(256) void positive_rank_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                            const long long* __restrict__ domain, int B, int NI, float fix_value,
+                                                            int* __restrict__ rank) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    if (b >= B) return;
+    const float* row = (domain[b] ? p2 : p1) + (long long)b * NI;
+    const float pos = row[0] - fix_value;
+    int c = 0;
+    for (int k = 1 + lane; k < NI; k += 64) c += (row[k] > pos) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) rank[b] = c;
+}
+
 }  // namespace amid
 
 using namespace amid;
@@ -373,6 +390,14 @@ extern "C" int amid_layernorm_rows_f32(const float* x, const float* w, const flo
 extern "C" int amid_sum_vector_f32(const float* v, int n, float* out, void* stream) {
     AMID_CHECK_ARG(v && out && n > 0);
     sum_vector_kernel<<<1, 64, 0, (hipStream_t)stream>>>(v, n, out);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_positive_rank_f32(const float* p1, const float* p2, const long long* domain_id, int B, int NI, float fix_value,
+                                      int* rank, void* stream) {
+    AMID_CHECK_ARG(p1 && p2 && domain_id && rank && B > 0 && NI > 0);
+    positive_rank_kernel<<<(B + 3) / 4, 256, 0, (hipStream_t)stream>>>(p1, p2, domain_id, B, NI, fix_value, rank);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

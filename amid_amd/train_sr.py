@@ -25,7 +25,7 @@ import torch
 
 from .dataset_seq import DeviceBatches, DualDomainSeqDataset
 from .model_seq import BERT4Rec, GRU4Rec, SASRec
-from .utils import AverageMeter, choose_predict, choose_predict_overlap, get_sample_scores, init_logger
+from .utils import AverageMeter, device_positive_ranks, init_logger, scores_from_ranks
 
 logger = logging.getLogger()
 FIX_VALUE = 1e-7          # train_sr.py:42: ties between the positive and a negative count against the positive
@@ -74,10 +74,11 @@ def build_parser() -> argparse.ArgumentParser:
 
 @torch.no_grad()
 def test(model, args, val_batches):
-    """train_sr.py:31-128: forward with neg_nums negatives, masked BCE, HR/NDCG/MRR of the positive's rank."""
+    """train_sr.py:31-128: forward with neg_nums negatives, masked BCE, HR/NDCG/MRR of the positive's rank.  The rank of the
+    positive is computed on the device per batch (amid_positive_rank_f32); only B ints per batch ever reach the host."""
     model.eval()
     stats = AverageMeter("loss", "loss_cls")
-    p1s, p2s, doms, ovs = [], [], [], []
+    ranks, ranks_raw, doms, ovs, losses = [], [], [], [], []
     for b in val_batches:
         p1, p2 = model(b["user_node"], b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["long_tail_mask_d1"],
                        b["long_tail_mask_d2"], False)
@@ -85,22 +86,20 @@ def test(model, args, val_batches):
         y = b["label"]
         m2 = b["domain_id"].float().unsqueeze(1)
         bce = torch.nn.functional.binary_cross_entropy
-        loss = (bce(p1, y, reduction="none") * (1 - m2) + bce(p2, y, reduction="none") * m2).mean()     # train_sr.py:63-64
-        stats.update(loss=loss.item(), loss_cls=loss.item())
-        p1s.append(p1.cpu().numpy()); p2s.append(p2.cpu().numpy())
-        doms.append(b["domain_id"].cpu().numpy()); ovs.append(b["overlap_label"].cpu().numpy())
-    p1, p2, dom, ov = np.concatenate(p1s), np.concatenate(p2s), np.concatenate(doms), np.concatenate(ovs)
-
-    def scores(pred):
-        pred = pred.copy()
-        pred[:, 0] -= FIX_VALUE                                                           # train_sr.py:114-115
-        return get_sample_scores(pred)
-
-    d1, d2 = choose_predict(p1, p2, dom)
-    out = {"loss": stats.loss, "d1": scores(d1), "d2": scores(d2)}
+        losses.append((bce(p1, y, reduction="none") * (1 - m2) + bce(p2, y, reduction="none") * m2).mean())   # train_sr.py:63-64
+        ranks.append(device_positive_ranks(p1, p2, b["domain_id"], FIX_VALUE))            # train_sr.py:114-115
+        if args.overlap:
+            ranks_raw.append(device_positive_ranks(p1, p2, b["domain_id"], 0.0))          # the overlap splits skip fix_value
+            ovs.append(b["overlap_label"])
+        doms.append(b["domain_id"])
+    for v in torch.stack(losses).tolist():                                                # one host transfer for the epoch
+        stats.update(loss=v, loss_cls=v)
+    rank, dom = torch.cat(ranks), torch.cat(doms)
+    out = {"loss": stats.loss, "d1": scores_from_ranks(rank[dom == 0]), "d2": scores_from_ranks(rank[dom == 1])}
     if args.overlap:
-        a, b_, c, d = choose_predict_overlap(p1, p2, dom, ov)
-        out.update(d1_ov=get_sample_scores(a), d1_no=get_sample_scores(b_), d2_ov=get_sample_scores(c), d2_no=get_sample_scores(d))
+        raw, ov = torch.cat(ranks_raw), torch.cat(ovs)
+        out.update(d1_ov=scores_from_ranks(raw[(dom == 0) & (ov == 1)]), d1_no=scores_from_ranks(raw[(dom == 0) & (ov == 0)]),
+                   d2_ov=scores_from_ranks(raw[(dom == 1) & (ov == 1)]), d2_no=scores_from_ranks(raw[(dom == 1) & (ov == 0)]))
     return out
 
 

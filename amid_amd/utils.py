@@ -54,6 +54,34 @@ def get_sample_scores(pred: np.ndarray):
     return tuple(out) + ((1.0 / (rank + 1.0)).sum() / n,)
 
 
+FIX_VALUE_DOC = "train_sr.py:42,114-115: pred[:, 0] -= 1e-7 before ranking, so a tie between the positive and a negative counts against the positive"
+
+
+def scores_from_ranks(rank) -> tuple:
+    """The seven numbers of get_sample_scores from positive ranks (numpy array or torch tensor, any device)."""
+    import torch
+    r = torch.as_tensor(rank).to(torch.float64)
+    n = float(r.numel())
+    if n == 0:
+        return (float("nan"),) * 7
+    out = []
+    for k in (1, 5, 10):
+        hit = (r < k).to(torch.float64)
+        out += [float(hit.sum() / n), float((hit / torch.log2(r + 2.0)).sum() / n)]
+    return tuple(out) + (float((1.0 / (r + 1.0)).sum() / n),)
+
+
+def device_positive_ranks(p1, p2, domain_id, fix_value: float):
+    """Positive ranks on the GPU (libamid_hip: amid_positive_rank_f32), one int per row, judged by the row's own domain head."""
+    import torch
+    from ._lib import lib
+    B, NI = p1.shape
+    rank = torch.empty(B, dtype=torch.int32, device=p1.device)
+    lib().call("amid_positive_rank_f32", p1.contiguous().data_ptr(), p2.contiguous().data_ptr(), domain_id.contiguous().data_ptr(), B, NI,
+               float(fix_value), rank.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return rank
+
+
 def choose_predict(pred_d1: np.ndarray, pred_d2: np.ndarray, domain_id: np.ndarray):
     """utils.py:21-40: rows of domain 0 are judged by the d1 head, rows of domain 1 by the d2 head."""
     d = domain_id.reshape(len(pred_d1), -1)[:, 0]

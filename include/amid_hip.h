@@ -175,6 +175,12 @@ int amid_head_bwd_f32(const float* x, const float* const* ln_w, const float* u, 
                       const float* w2, const float* b2, const float* p1, const float* p2, const float* dp1, const float* dp2, int B, int T,
                       int NI, int D, int hid, float eps, float* dx, float* ditems, float* ln_part, float* sc_part,
                       const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream);
+/* evaluation (next-2 of SURVEY.md 8(f)): rank (0 = best) of the positive, column 0, among the NI scores of a row, read from the
+ * head of the row's own domain.  replaces: choose_predict utils.py:21-40 + the double argsort of get_sample_scores utils.py:296-297
+ * after "pred[:, 0] -= fix_value" (train_sr.py:114-115: a tie counts against the positive; fix_value = 0: a tie favours it, as a
+ * stable sort would) */
+int amid_positive_rank_f32(const float* p1, const float* p2, const long long* domain_id, int B, int NI, float fix_value, int* rank,
+                           void* stream);
 /* replaces: torch.nn.LayerNorm(D, eps) applied row-wise (last_layernorm of a standalone Log2feats, model_seq.py:385) */
 int amid_layernorm_rows_f32(const float* x, const float* w, const float* b, long long rows, int D, float eps, float* y, void* stream);
 

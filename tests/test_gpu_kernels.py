@@ -336,3 +336,30 @@ def test_attention_fwd_bwd_vs_autograd(L, T, train):
         want.backward(do[sl].double())
         assert relmax(o[sl], want.detach()) < 2e-6, (dom, "o")
         assert relmax(dq[sl], qq.grad) < 5e-6 and relmax(dk[sl], kk.grad) < 5e-6 and relmax(dv[sl], vv.grad) < 5e-6, dom
+
+
+def test_positive_rank_matches_reference_metrics(L):
+    """Device ranks -> the seven metrics of the reference's get_sample_scores (g8 golden: HR/NDCG@1,5,10 + MRR, with a tie)."""
+    import os
+    import numpy as np
+    from amid_amd.utils import FIX_VALUE_DOC, device_positive_ranks, get_sample_scores, scores_from_ranks
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_metrics.npz"))
+    pred = torch.from_numpy(z["pred"]).cuda()
+    dom = torch.zeros(pred.shape[0], dtype=torch.long, device="cuda")
+    rank = device_positive_ranks(pred, pred, dom, 0.0)          # g8 was generated without the fix_value shift
+    got = scores_from_ranks(rank)
+    assert np.allclose(np.array(got), z["scores"], rtol=0, atol=1e-12)
+    # domain selection + fix_value: ties count against the positive
+    g = torch.Generator().manual_seed(0)
+    p1, p2 = torch.rand(300, 200, generator=g), torch.rand(300, 200, generator=g)
+    p1[5, 7] = p1[5, 0]; p2[6, 3] = p2[6, 0]
+    d = (torch.rand(300, generator=g) < 0.5).long()
+    d[5], d[6] = 0, 1
+    fix = 1e-7
+    r = device_positive_ranks(p1.cuda(), p2.cuda(), d.cuda(), fix).cpu()
+    sel = torch.where(d[:, None] == 0, p1, p2).numpy().copy()
+    sel[:, 0] -= np.float32(fix)
+    want = (-sel).argsort(kind="stable").argsort(kind="stable")[:, 0]
+    assert np.array_equal(r.numpy(), want)
+    assert np.allclose(np.array(scores_from_ranks(r)), np.array(get_sample_scores(sel)), atol=1e-12)
+    assert FIX_VALUE_DOC
