@@ -26,6 +26,7 @@ struct AttnArgs {
     int causal;                                           // 1: SASRec causal mask, q pre-scaled; 0: BERT4Rec
     float scale;                                          // sqrt(1/hd) (causal) or sqrt(d_k) divisor (BERT)
     const StepState* st; int train; unsigned thr16; float dscale; int layer;
+    int stagger_from, stagger_sleeps;      // set by the MFMA backward launcher only
 };
 
 template <int HD>
@@ -312,6 +313,7 @@ static int attn_fill(AttnArgs& a, const float* q, const float* k, const float* v
     a.train = (train && p_drop > 0.f) ? 1 : 0;
     a.thr16 = keep_thr16(p_drop);
     a.dscale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+    a.stagger_from = -1; a.stagger_sleeps = 0;
     return AMID_OK;
 }
 

@@ -32,6 +32,7 @@ struct AttnArgs {          // must stay identical to the struct in attention.hip
     int causal;
     float scale;
     const StepState* st; int train; unsigned thr16; float dscale; int layer;
+    int stagger_from, stagger_sleeps;      // set by the MFMA backward launcher only
 };
 
 constexpr int AHD = 16;
@@ -80,12 +81,18 @@ __device__ __forceinline__ unsigned long long row_keep_word(unsigned long long s
 
 __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const AttnArgs a) {
     const int T = a.T, D = a.D, H = a.H;
-    const int seq = blockIdx.x, g = seq / a.B, b = seq - g * a.B;
+    const int hw = blockDim.x >> 6, parts = H / hw;
+    const int seq = blockIdx.x / parts, part = blockIdx.x - seq * parts, g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
-    const int h = wave_id(), lane = lane_id();
+    const int h = part * hw + wave_id(), lane = lane_id();
     const int m = lane & 15, gq = lane >> 4;
     const int NT = (T + 15) >> 4;
     const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
+    if (a.stagger_from > 0) {                                  // k-th resident of a CU starts k units late (see the backward kernel)
+        const int late = min((int)blockIdx.x / a.stagger_from, 7) * a.stagger_sleeps;
+#pragma unroll 1
+        for (int i = 0; i < late; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // operands that every query tile reuses
     float4 kf[4];
     float vt[4][4];
@@ -156,26 +163,51 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const AttnArgs a) {
 __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, D = a.D, H = a.H;
-    const int seq = blockIdx.x, g = seq / a.B, b = seq - g * a.B;
+    // a workgroup = `hw` heads of one sequence (hw = blockDim / 64): with 4 heads per workgroup two workgroups fit a CU at
+    // this kernel's ~190 VGPRs, and the second residents of the first wave of workgroups start late (below), so that from then
+    // on one workgroup's loads run under the other's MFMAs (one 8-head workgroup per CU ran load -> compute -> load -> compute)
+    const int hw = blockDim.x >> 6, parts = H / hw;
+    const int seq = blockIdx.x / parts, part = blockIdx.x - seq * parts, g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
-    const int h = wave_id(), lane = lane_id();
+    const int wv = wave_id(), h = part * hw + wv, lane = lane_id();
     const int m = lane & 15, gq = lane >> 4;
     const int NT = (T + 15) >> 4;
     const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
-    float4* rstat = reinterpret_cast<float4*>(smem) + h * 64;                          // [H][64] (max, 1/sum, delta, -)
-    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(smem + H * 64 * 4) + h * 64;   // [H][64]
+    float4* rstat = reinterpret_cast<float4*>(smem) + wv * 64;                          // [hw][64] (max, 1/sum, delta, -)
+    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(smem + hw * 64 * 4) + wv * 64;   // [hw][64]
+    if (a.stagger_from >= 0 && (int)blockIdx.x >= a.stagger_from && (int)blockIdx.x < 2 * a.stagger_from) {
+#pragma unroll 1
+        for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);       // 127 x 64 clocks each
+    }
 
-    // ---------------- phase 1: lanes = queries -> dQ; row stats + keep words to LDS ----------------
+    // Every operand of BOTH phases is requested here, up front (one exposure of the memory latency per workgroup instead of
+    // two): row fragments of Q, K, V, dO, O (float4 along the head dim) and the transposed dword fragments K^T (phase 1), Q^T,
+    // dO^T (phase 2).  The first version reloaded Q, dO, K, V after the barrier between the phases.
+    float4 kfr[4], vfr[4], qfr[4], dofr[4];
+    float qts[4][4], dots[4][4];
     {
-        float4 kf[4], vf[4];
         float kt[4][4];
+        float4 ofr[4];
+        float2 str[4];
 #pragma unroll
-        for (int kj = 0; kj < 4; ++kj) {
-            kf[kj] = ld4_row(a.k, rowbase, kj * 16 + m, T, D, col4);
-            vf[kj] = ld4_row(a.v, rowbase, kj * 16 + m, T, D, col4);
+        for (int t = 0; t < 4; ++t) {
+            kfr[t] = ld4_row(a.k, rowbase, t * 16 + m, T, D, col4);
+            vfr[t] = ld4_row(a.v, rowbase, t * 16 + m, T, D, col4);
+            qfr[t] = f4scale(ld4_row(a.q, rowbase, t * 16 + m, T, D, col4), a.scale);
+            dofr[t] = ld4_row(a.d_o, rowbase, t * 16 + m, T, D, col4);
+            ofr[t] = ld4_row(a.o, rowbase, t * 16 + m, T, D, col4);
+            str[t] = *reinterpret_cast<const float2*>(a.stats + ((rowbase + min(t * 16 + m, T - 1)) * H + h) * 2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) kt[kj][r] = ld1_row(a.k, rowbase, kj * 16 + 4 * gq + r, T, D, colm);
+            for (int r = 0; r < 4; ++r) kt[t][r] = ld1_row(a.k, rowbase, t * 16 + 4 * gq + r, T, D, colm);
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                qts[t][r] = ld1_row(a.q, rowbase, t * 16 + 4 * gq + r, T, D, colm) * a.scale;
+                dots[t][r] = ld1_row(a.d_o, rowbase, t * 16 + 4 * gq + r, T, D, colm);
+            }
+        // ---------------- phase 1: lanes = queries -> dQ; row stats + keep words to LDS ----------------
         unsigned long long kw_own = ~0ull;
         if (a.train) {
             const int qrow = min(gq * 16 + m, T - 1);
@@ -183,16 +215,6 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
                                    (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
         }
         keepw[lane] = kw_own;                                                            // row index = 16 gq + m = lane
-        float4 qfr[4], dofr[4], ofr[4];
-        float2 str[4];
-#pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {                   // every query tile's operands are requested up front
-            const int q = qi * 16 + m;
-            qfr[qi] = f4scale(ld4_row(a.q, rowbase, q, T, D, col4), a.scale);
-            dofr[qi] = ld4_row(a.d_o, rowbase, q, T, D, col4);
-            ofr[qi] = ld4_row(a.o, rowbase, q, T, D, col4);
-            str[qi] = *reinterpret_cast<const float2*>(a.stats + ((rowbase + min(q, T - 1)) * H + h) * 2);
-        }
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi) {
             if (qi >= NT) break;
@@ -207,8 +229,8 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
             for (int kj = 0; kj < 4; ++kj) {
                 if (kj <= qi) {
                     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
-                    s = mfma_frag(kf[kj], qf, s);
-                    dp = mfma_frag(vf[kj], dof, dp);
+                    s = mfma_frag(kfr[kj], qf, s);
+                    dp = mfma_frag(vfr[kj], dof, dp);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = kj * 16 + 4 * gq + r;
@@ -222,22 +244,9 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
             if (q < T) st4(a.dq + (rowbase + q) * D + col4, make_float4(dq[0] * a.scale, dq[1] * a.scale, dq[2] * a.scale, dq[3] * a.scale));
         }
     }
-    __syncthreads();      // rstat / keepw of this wave are only read by this wave, but keep the phases cleanly separated
-    // ---------------- phase 2: lanes = keys -> dK, dV ----------------------------------------------
-    float4 qfr[4], dofr[4], kfr[4], vfr[4];
-    float qts[4][4], dots[4][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {                          // all query- and key-side operands of the head, requested up front
-        qfr[t] = f4scale(ld4_row(a.q, rowbase, t * 16 + m, T, D, col4), a.scale);
-        dofr[t] = ld4_row(a.d_o, rowbase, t * 16 + m, T, D, col4);
-        kfr[t] = ld4_row(a.k, rowbase, t * 16 + m, T, D, col4);
-        vfr[t] = ld4_row(a.v, rowbase, t * 16 + m, T, D, col4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            qts[t][r] = ld1_row(a.q, rowbase, t * 16 + 4 * gq + r, T, D, colm) * a.scale;
-            dots[t][r] = ld1_row(a.d_o, rowbase, t * 16 + 4 * gq + r, T, D, colm);
-        }
-    }
+    // no workgroup barrier here: rstat / keepw of a wave are written and read by that wave only (LDS operations of one wave
+    // complete in order), and without it the waves of a workgroup drift apart -- the late ones' loads overlap the early ones' MFMAs
+    // ---------------- phase 2: lanes = keys -> dK, dV (operands already in registers) ----------------
 #pragma unroll
     for (int kj = 0; kj < 4; ++kj) {
         if (kj >= NT) break;
@@ -278,17 +287,34 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
 using namespace amid;
 
 // called by the entry points in attention.hip when the shape fits (causal, head dim 16, T <= 64, no key mask)
+static int cu_count() {
+    static int n_cu = 0;
+    if (n_cu == 0) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n_cu = p.multiProcessorCount; else n_cu = 256; }
+    return n_cu;
+}
+
 int amid_attn_mfma_fwd_launch(const void* args, void* stream) {
-    const AttnArgs& a = *(const AttnArgs*)args;
-    attn_fwd_mfma_kernel<<<2 * a.B, a.H * 64, 0, (hipStream_t)stream>>>(a);
+    AttnArgs a = *(const AttnArgs*)args;
+    const int hw = (a.H % 4 == 0) ? 4 : a.H;                   // heads per workgroup
+    const int parts = a.H / hw, grid = 2 * a.B * parts;
+    a.stagger_from = -1;                                       // measured: any stagger only delays the forward kernel (20.6 -> 22.5+ us)
+    a.stagger_sleeps = 0;
+    attn_fwd_mfma_kernel<<<grid, hw * 64, 0, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
 
 int amid_attn_mfma_bwd_launch(const void* args, void* stream) {
-    const AttnArgs& a = *(const AttnArgs*)args;
-    const size_t lds = (size_t)a.H * 64 * (16 + 8);
-    attn_bwd_mfma_kernel<<<2 * a.B, a.H * 64, lds, (hipStream_t)stream>>>(a);
+    AttnArgs a = *(const AttnArgs*)args;
+    const int hw = (a.H % 4 == 0) ? 4 : a.H;                   // heads per workgroup
+    const int parts = a.H / hw, grid = 2 * a.B * parts;
+    // workgroups are handed out one per CU first, so with more than 256 of them [256, 512) are the second residents of the CUs:
+    // they wait ~8 us (their neighbour's load phase) before requesting their own operands
+    const int n_cu = cu_count();
+    a.stagger_from = (grid >= 2 * n_cu) ? n_cu : -1;
+    a.stagger_sleeps = 2;                                      // measured at B 256: 0: 52.2 us, 1: 50.4, 2: 48.2, 3: 53.5, 4: 55.6
+    const size_t lds = (size_t)hw * 64 * (16 + 8);
+    attn_bwd_mfma_kernel<<<grid, hw * 64, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -248,27 +248,37 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_bwd_kernel(const QkvBwdA
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight gradients of one layer: blockIdx = (split, weight 0..5, domain)
+// weight gradients of up to two layers in one launch: blockIdx = (split, layer * 6 + weight 0..5, domain)
 // ---------------------------------------------------------------------------------------------
+constexpr int WG_MAX = 12;
 struct WgradArgs {
-    const float* dy[6];        // dq, dk, dv, dr, dpre1, dpre2        [2M, D]
-    const float* xin[6];       // qn, x,  x,  o,  y,     h            [2M, D]
-    float* w_part;             // [2][6][splits][D*D]
-    float* b_part;             // [2][6][splits][D]
+    const float* dy[WG_MAX];   // per layer: dq, dk, dv, dr, dpre1, dpre2   [2M, D]
+    const float* xin[WG_MAX];  // per layer: qn, x,  x,  o,  y,     h       [2M, D]
+    float* w_part[2];          // per layer: [2][6][splits][D*D]
+    float* b_part[2];          // per layer: [2][6][splits][D]
     int M, splits, rows_per_split;
 };
 
 constexpr int WG_ROWS = 64;    // rows staged per step
 
+// One workgroup = one (domain, weight, row split): it streams its rows of (dY, X) in 64-row chunks through LDS and
+// accumulates dW = dY^T X on the matrix cores (one wave per 16 output rows at D = 128).  Single LDS buffer (74 KB at
+// D = 128) and <= 128 VGPRs, so that TWO workgroups share a CU: while one stores its next chunk and waits at its barriers
+// the other issues MFMAs.  (History: one workgroup per CU with a double-buffered 147 KB image and two chunks of register
+// prefetch measured, by s_memtime, 10 % in the prologue -- all workgroups requesting their first chunks at once --, 8 % in
+// stores + barriers and 40 cycles per MFMA against the 32-cycle issue rate; with both layers' 504 workgroups in one launch,
+// two per CU, those phases of one workgroup hide behind the other's.)
 template <int D>
-__global__ __launch_bounds__(GEMM_THREADS) void sas_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LD = D + 16;                         // (4*LD) % 32 words == 16: the four m-rows of an MFMA hit disjoint banks
     constexpr int NTn = D / 16;
     constexpr int WPN = 8 / NTn > 0 ? 8 / NTn : 1;     // waves per n tile (1 at D=128, 2 at D=64)
     constexpr int KTW = NTn / WPN;                     // k tiles per wave (8 at D=128, 2 at D=64)
-    constexpr int BUF = 2 * WG_ROWS * LD;              // one LDS buffer: dY image then X image (two buffers: 147 KB at D=128)
+    float* Ys = smem;
+    float* Xs = smem + WG_ROWS * LD;
     const int split = blockIdx.x, wsel = blockIdx.y, g = blockIdx.z;
+    const int layer = wsel / 6, wi = wsel - layer * 6;
     const float* __restrict__ dy = a.dy[wsel];
     const float* __restrict__ xin = a.xin[wsel];
     const int local_beg = split * a.rows_per_split;
@@ -283,13 +293,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_wgrad_kernel(const WgradArgs
     for (int t = 0; t < KTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int NRW = WG_ROWS / RPP;                 // rows of a chunk per thread (4 at D=128, 2 at D=64)
-    // Pipeline per chunk c (one barrier per chunk):  request chunk c + 2 (registers)  ->  MFMAs on LDS buffer c & 1  ->
-    // store chunk c + 1 (requested a whole chunk earlier) into buffer (c + 1) & 1  ->  barrier.
-    // Two waves share a SIMD and the older one gets the matrix pipe first, so a wave's LDS stores run while its SIMD
-    // partner still issues MFMAs.  The first version (single buffer: barrier, store, barrier, MFMAs) measured, per
-    // 8192 MFMA cycles of a chunk, ~1000 cycles of store + barrier and ~2400 of other waiting (s_memtime instrumentation).
-    float4 py0[NRW], px0[NRW], py1[NRW], px1[NRW];
-    auto fetch = [&](float4 (&py)[NRW], float4 (&px)[NRW], int c0) {   // issue every load of chunk c0 (zeros beyond the split's range)
+    float4 py[NRW], px[NRW];
+    auto fetch = [&](int c0) {                         // issue every load of chunk c0 (zeros beyond the split's range)
         const int nr = min(WG_ROWS, local_end - c0);
         const long long grow = (long long)g * a.M + c0;
 #pragma unroll
@@ -300,20 +305,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_wgrad_kernel(const WgradArgs
             px[i] = ok ? ld4(xin + (grow + r) * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto stage = [&](const float4 (&py)[NRW], const float4 (&px)[NRW], float* buf) {
+    if (local_beg < local_end) fetch(local_beg);
+    for (int c0 = local_beg; c0 < local_end; c0 += WG_ROWS) {
+        __syncthreads();                               // previous chunk fully consumed
 #pragma unroll
         for (int i = 0; i < NRW; ++i) {
             const int r = rl + i * RPP;
             bsum = f4add(bsum, py[i]);
-            st4(buf + r * LD + 4 * sub, py[i]);
-            st4(buf + WG_ROWS * LD + r * LD + 4 * sub, px[i]);
+            st4(Ys + r * LD + 4 * sub, py[i]);
+            st4(Xs + r * LD + 4 * sub, px[i]);
         }
-    };
-    auto mma = [&](const float* buf) {
+        __syncthreads();
+        if (c0 + WG_ROWS < local_end) fetch(c0 + WG_ROWS);     // next chunk flies under this chunk's MFMAs
         // all 16 m-steps, always (rows past the split's range are zeros in LDS): branch-free, with the operands of step
         // ms + 1 read while the MFMAs of step ms issue
-        const float* yp = buf + gq * LD + nt * 16 + i;
-        const float* xp = buf + WG_ROWS * LD + gq * LD + kt0 * 16 + i;
+        const float* yp = Ys + gq * LD + nt * 16 + i;
+        const float* xp = Xs + gq * LD + kt0 * 16 + i;
         float a_cur = yp[0], x_cur[KTW];
 #pragma unroll
         for (int t = 0; t < KTW; ++t) x_cur[t] = xp[t * 16];
@@ -341,36 +348,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_wgrad_kernel(const WgradArgs
 #pragma unroll
             for (int t = 0; t < KTW; ++t) x_cur[t] = x_nxt[t];
         }
-    };
-    if (local_beg < local_end) {
-        fetch(py0, px0, local_beg);
-        if (local_beg + WG_ROWS < local_end) fetch(py1, px1, local_beg + WG_ROWS);
-        stage(py0, px0, smem);
-        __syncthreads();
-        for (int c0 = local_beg; c0 < local_end; c0 += 2 * WG_ROWS) {
-            // even chunk: lives in buffer 0; chunk c0 + 1 is in (py1, px1), chunk c0 + 2 is requested into (py0, px0)
-            const bool has1 = c0 + WG_ROWS < local_end, has2 = c0 + 2 * WG_ROWS < local_end;
-            if (has2) fetch(py0, px0, c0 + 2 * WG_ROWS);
-            mma(smem);
-            if (has1) stage(py1, px1, smem + BUF);
-            __syncthreads();
-            if (!has1) break;
-            // odd chunk: buffer 1; chunk c0 + 2 is in (py0, px0), chunk c0 + 3 is requested into (py1, px1)
-            if (c0 + 3 * WG_ROWS < local_end) fetch(py1, px1, c0 + 3 * WG_ROWS);
-            mma(smem + BUF);
-            if (has2) stage(py0, px0, smem);
-            __syncthreads();
-        }
     }
-    float* wp = a.w_part + (((long long)g * 6 + wsel) * a.splits + split) * D * D;
+    float* wp = a.w_part[layer] + (((long long)g * 6 + wi) * a.splits + split) * D * D;
 #pragma unroll
     for (int t = 0; t < KTW; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) wp[(long long)(nt * 16 + gq * 4 + r) * D + (kt0 + t) * 16 + i] = acc[t][r];
-    float* Ys = smem;
-    st4(Ys + rl * D + 4 * sub, bsum);                  // [RPP][D] scratch (the loop ended on a barrier)
     __syncthreads();
-    float* bp = a.b_part + (((long long)g * 6 + wsel) * a.splits + split) * D;
+    st4(Ys + rl * D + 4 * sub, bsum);                  // [RPP][D] scratch
+    __syncthreads();
+    float* bp = a.b_part[layer] + (((long long)g * 6 + wi) * a.splits + split) * D;
     for (int e = threadIdx.x; e < D; e += GEMM_THREADS) {
         float s = 0.f;
 #pragma unroll 4
@@ -492,23 +479,22 @@ extern "C" int amid_sas_qkv_bwd_f32(const float* dq, const float* dk, const floa
     return AMID_OK;
 }
 
-extern "C" int amid_sas_wgrad_f32(const float* const* dy6, const float* const* x6, int M, int D, int splits, float* w_part, float* b_part,
-                                  void* stream) {
-    AMID_CHECK_ARG(dy6 && x6 && w_part && b_part && M > 0 && splits > 0);
+extern "C" int amid_sas_wgrad_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits,
+                                  float* const* w_part, float* const* b_part, void* stream) {
+    AMID_CHECK_ARG(dy && x && w_part && b_part && (n_layers == 1 || n_layers == 2) && M > 0 && splits > 0);
     WgradArgs a;
-    for (int i = 0; i < 6; ++i) { a.dy[i] = dy6[i]; a.xin[i] = x6[i]; AMID_CHECK_ARG(dy6[i] && x6[i]); }
-    a.w_part = w_part; a.b_part = b_part; a.M = M; a.splits = splits;
+    for (int i = 0; i < 6 * n_layers; ++i) { AMID_CHECK_ARG(dy[i] && x[i]); a.dy[i] = dy[i]; a.xin[i] = x[i]; }
+    for (int l = 0; l < n_layers; ++l) { AMID_CHECK_ARG(w_part[l] && b_part[l]); a.w_part[l] = w_part[l]; a.b_part[l] = b_part[l]; }
+    a.M = M; a.splits = splits;
     a.rows_per_split = (M + splits - 1) / splits;
-    const dim3 grid(splits, 6, 2);
+    const dim3 grid(splits, 6 * n_layers, 2);
     if (D == 128) {
-        const size_t lds = (size_t)4 * WG_ROWS * (128 + 16) * sizeof(float);
+        const size_t lds = (size_t)2 * WG_ROWS * (128 + 16) * sizeof(float);
         static bool set128 = false;
         if (!set128) { hipError_t e = hipFuncSetAttribute((const void*)sas_wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; set128 = true; }
         sas_wgrad_kernel<128><<<grid, GEMM_THREADS, lds, (hipStream_t)stream>>>(a);
     } else if (D == 64) {
-        const size_t lds = (size_t)4 * WG_ROWS * (64 + 16) * sizeof(float);
-        static bool set64 = false;
-        if (!set64) { hipError_t e = hipFuncSetAttribute((const void*)sas_wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; set64 = true; }
+        const size_t lds = (size_t)2 * WG_ROWS * (64 + 16) * sizeof(float);
         sas_wgrad_kernel<64><<<grid, GEMM_THREADS, lds, (hipStream_t)stream>>>(a);
     } else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();

@@ -141,6 +141,15 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
         for (int t = 0; t < ACC; ++t) acc[t] = mfma16(b_cur.z, a_cur[t].z, acc[t]);
 #pragma unroll
         for (int t = 0; t < ACC; ++t) acc[t] = mfma16(b_cur.w, a_cur[t].w, acc[t]);
+        // pin the issue order: the ACC + 1 fragment reads of step kk + 1 are spread behind the 4 * ACC MFMAs of step kk
+        // (left alone, the scheduler sinks each read to just before its first use and waits on it)
+        if (kk + 1 < KK) {
+#pragma unroll
+            for (int t = 0; t < ACC + 1; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
         b_cur = b_nxt;
 #pragma unroll
         for (int t = 0; t < ACC; ++t) a_cur[t] = a_nxt[t];

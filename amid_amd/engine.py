@@ -199,8 +199,10 @@ class SasrecPlan:
 
     def _alloc_model_bwd(self, eng: "SasrecEngine", f) -> None:
         M, D, B, T = self.shape.M, eng.D, self.shape.B, self.shape.T
-        self.dpre1, self.dpre2, self.dr = f(2 * M, D), f(2 * M, D), f(2 * M, D)
-        # 2 domains x 6 weights x splits workgroups: 21 splits = 252 workgroups, one round on the 256 CUs
+        # per LAYER copies of the six dY tensors of the weight gradients: both layers' weight gradients run as one launch at the
+        # end of backward (2 layers x 2 domains x 6 weights x 21 splits = 504 workgroups, two per CU)
+        self.dpre1, self.dpre2, self.dr = ([f(2 * M, D), f(2 * M, D)] for _ in range(3))
+        self.dq_l, self.dk_l, self.dv_l = [self.dq, f(2 * M, D)], [self.dk, f(2 * M, D)], [self.dv, f(2 * M, D)]
         self.splits = max(1, min(21, M // 128))
         self.w_part = [f(2, 6, self.splits, D * D) for _ in range(2)]
         self.b_part = [f(2, 6, self.splits, D) for _ in range(2)]
@@ -528,19 +530,23 @@ class SasrecEngine:
         for l in (1, 0):
             L.call("amid_sas_ffn_bwd_f32", pl.dxbuf.data_ptr(), pl.tmq.data_ptr(), pl.h[l].data_ptr(), pl.r[l].data_ptr(),
                    self._pp(f"sac{{d}}.forward_layernorms.{l}.weight"), self._wT(l, 4), self._wT(l, 5), self._wT(l, 3), SASREC_LN_EPS,
-                   M, D, pl.rpt, l, st, tr, SASREC_P_DROP, pl.dpre2.data_ptr(), pl.dpre1.data_ptr(), pl.dr.data_ptr(), pl.d_o.data_ptr(),
-                   pl.ln2_part[l].data_ptr(), s)
+                   M, D, pl.rpt, l, st, tr, SASREC_P_DROP, pl.dpre2[l].data_ptr(), pl.dpre1[l].data_ptr(), pl.dr[l].data_ptr(),
+                   pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), s)
             L.call("amid_attn_bwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(),
-                   pl.stats[l].data_ptr(), pl.d_o.data_ptr(), None, B, T, D, self.H, 1, l, st, tr, SASREC_P_DROP, pl.dq.data_ptr(),
-                   pl.dk.data_ptr(), pl.dv.data_ptr(), s)
+                   pl.stats[l].data_ptr(), pl.d_o.data_ptr(), None, B, T, D, self.H, 1, l, st, tr, SASREC_P_DROP, pl.dq_l[l].data_ptr(),
+                   pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), s)
             dx_out = pl.dxg if l == 0 else pl.dxbuf
-            L.call("amid_sas_qkv_bwd_f32", pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dr.data_ptr(), pl.x[l].data_ptr(),
-                   self._pp(f"sac{{d}}.attention_layernorms.{l}.weight"), self._wT(l, 0), self._wT(l, 1), self._wT(l, 2), SASREC_LN_EPS,
-                   M, D, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), s)
-            dy6 = ptr_array([pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dr.data_ptr(), pl.dpre1.data_ptr(), pl.dpre2.data_ptr()])
-            x6 = ptr_array([pl.qn[l].data_ptr(), pl.x[l].data_ptr(), pl.x[l].data_ptr(), pl.o[l].data_ptr(), pl.y[l].data_ptr(),
-                            pl.h[l].data_ptr()])
-            L.call("amid_sas_wgrad_f32", dy6, x6, M, D, pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), s)
+            L.call("amid_sas_qkv_bwd_f32", pl.dq_l[l].data_ptr(), pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), pl.dr[l].data_ptr(),
+                   pl.x[l].data_ptr(), self._pp(f"sac{{d}}.attention_layernorms.{l}.weight"), self._wT(l, 0), self._wT(l, 1),
+                   self._wT(l, 2), SASREC_LN_EPS, M, D, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), s)
+        dy, xx = [], []
+        for l in (0, 1):
+            dy += [pl.dq_l[l].data_ptr(), pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), pl.dr[l].data_ptr(), pl.dpre1[l].data_ptr(),
+                   pl.dpre2[l].data_ptr()]
+            xx += [pl.qn[l].data_ptr(), pl.x[l].data_ptr(), pl.x[l].data_ptr(), pl.o[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr()]
+        # NOTE: pl.x[0] is the gathered-row buffer xg, still intact here (its gradient lives in dxg)
+        L.call("amid_sas_wgrad_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
+               ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), s)
         L.call("amid_embed_bwd_f32", pl.dxg.data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits, pl.dpos_part.data_ptr(), st, tr,
                SASREC_P_DROP, s)
         self._enqueue_grad_tail(pl)

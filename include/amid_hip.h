@@ -137,10 +137,11 @@ int amid_sas_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float
 int amid_sas_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
                          const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
                          int rows_per_tile, float* dx, float* ln_part, void* stream);
-/* six weight + bias gradients of a layer as split partials: w_part [2][6][splits][D*D], b_part [2][6][splits][D];
- * order: in_proj q, k, v, out_proj, conv1, conv2 */
-int amid_sas_wgrad_f32(const float* const* dy6, const float* const* x6, int M, int D, int splits, float* w_part, float* b_part,
-                       void* stream);
+/* the six weight + bias gradients of n_layers (1 or 2) layers as split partials, ONE launch (two workgroups per CU): dy / x are host
+ * arrays of 6 * n_layers device pointers, per layer in the order in_proj q, k, v, out_proj, conv1, conv2; w_part / b_part are host
+ * arrays of n_layers device pointers to [2][6][splits][D*D] and [2][6][splits][D] */
+int amid_sas_wgrad_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
+                       float* const* b_part, void* stream);
 /* fixed-order reduction of partial buffers; entries are packed on the host then copied to the device by the caller */
 int amid_reduce_entry_bytes(void);
 int amid_reduce_entry_pack(void* host_buf, int index, const float* src, float* dst, long long stride, int n_part, int count);
