@@ -35,6 +35,8 @@ _SCALARS = {
     "double": ctypes.c_double,
     "long long": ctypes.c_longlong,
     "unsigned long long": ctypes.c_ulonglong,
+    "unsigned": ctypes.c_uint,
+    "unsigned int": ctypes.c_uint,
 }
 
 

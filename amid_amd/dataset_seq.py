@@ -4,8 +4,8 @@ The reference parses two JSON lists per sample inside ``__getitem__``, builds a 
 per sample for the negatives and collates to float32 tensors (2.5 k samples/s per worker,
 SURVEY.md section 3(D)).  Here the CSV is tokenised ONCE into left-padded int64 ``[N, T]`` arrays
 (same ``seq_padding`` rule, same positive / duplicate-removal rule), negatives are drawn per epoch
-on the host with the same constraint (uniform over the domain's item pool minus the row's own
-sequence, without replacement) and batches are index_select-ed on the device.  Ids stay integers
+ON THE DEVICE with the same constraint (uniform over the domain's item pool minus the row's own
+sequence, without replacement: ``amid_sample_negatives_i64``) and batches are index_select-ed on the device.  Ids stay integers
 end to end (the reference's float32 wire format is exact only below 2**24).
 """
 from __future__ import annotations
@@ -69,19 +69,6 @@ class DualDomainSeqDataset:
     def __len__(self) -> int:
         return len(self.i_node)
 
-    def sample_negatives(self) -> np.ndarray:
-        """[N, k] negatives: uniform without replacement from the row's domain pool minus its own sequence."""
-        k = 1 if self.isTrain else self.neg_nums
-        out = np.empty((len(self), k), dtype=np.int64)
-        for r in range(len(self)):
-            pool = self.pool[int(self.domain_id[r] != 0)]
-            need = k + len(self.own_items[r])
-            if need > len(pool):
-                raise ValueError("negative pool smaller than neg_nums")
-            cand = pool[self.rng.choice(len(pool), size=need, replace=False)]
-            cand = cand[~np.isin(cand, self.own_items[r])]
-            out[r] = cand[:k]
-        return out
 
 
 class DeviceBatches:
@@ -97,15 +84,39 @@ class DeviceBatches:
                       domain_id=to(ds.domain_id), overlap_label=to(ds.overlap_label), long_tail_mask_d1=to(ds.long_tail_mask_d1),
                       long_tail_mask_d2=to(ds.long_tail_mask_d2))
         self.gen = torch.Generator().manual_seed(seed)
+        # negative sampling state on the device: the two item pools and every row's own items (dataset_seq.py:141-142, :188/:206)
+        self.pool = [to(p) for p in ds.pool]
+        off = np.zeros(len(ds) + 1, dtype=np.int32)
+        np.cumsum([len(o) for o in ds.own_items], out=off[1:])
+        self.own_off = torch.from_numpy(off).to(self.device)
+        self.own = to(np.concatenate(ds.own_items) if len(ds) else np.zeros(0, np.int64))
+        self.seed, self.epoch = int(seed), 0
         k = 1 if ds.isTrain else ds.neg_nums
+        self.k = k
+        for r, o in enumerate(ds.own_items):
+            if k + len(o) > len(ds.pool[int(ds.domain_id[r] != 0)]):
+                raise ValueError("negative pool smaller than neg_nums")
         self.label = torch.zeros(batch_size, 1 + k, device=self.device)
         self.label[:, 0] = 1.0                                                            # dataset_seq.py:191,199
+
+    def sample_negatives(self) -> torch.Tensor:
+        """[N, k] negatives for one epoch, drawn ON THE DEVICE (amid_sample_negatives_i64): uniform without replacement from the
+        row's domain pool minus its own sequence -- the reference's random.sample(pool - set(seq), k) (dataset_seq.py:198, :215).
+        Every rank of a data-parallel run draws the same table (same seed, same epoch counter)."""
+        from ._lib import lib
+        N = len(self.ds)
+        out = torch.empty(N, self.k, dtype=torch.int64, device=self.device)
+        self.epoch += 1
+        lib().call("amid_sample_negatives_i64", self.pool[0].data_ptr(), self.pool[0].numel(), self.pool[1].data_ptr(),
+                   self.pool[1].numel(), self.own.data_ptr(), self.own_off.data_ptr(), self.t["domain_id"].data_ptr(), N, self.k,
+                   self.seed, self.epoch, out.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+        return out
 
     def __len__(self) -> int:
         return len(self.ds) // (self.bs * self.world)                                     # drop_last=True (train_sr.py:452,455)
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
-        neg = torch.from_numpy(self.ds.sample_negatives()).to(self.device)
+        neg = self.sample_negatives()
         n = len(self.ds)
         order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
         order = order.to(self.device)

@@ -215,6 +215,14 @@ int amid_bert_wgrad_f32(const float* const* dy, const float* const* x, const int
 int amid_key_keep_u8(const long long* seq, long long n, unsigned char* keep, void* stream);
 int amid_transpose_rect_f32(const float* const* src, float* const* dst, const int* rows, const int* cols, int n, void* stream);
 
+/* ---- data pipeline on the device (next-3 of SURVEY.md 8(f)) ------------------------------------------------------------------
+ * replaces: random.sample(item_pool_d - set(own sequence), k) per sample in DualDomainSeqDataset.__getitem__ (dataset_seq.py:188,
+ * :198, :206, :215): k distinct negatives per row, uniform over the row's domain pool minus its own items.  pool_d*: sorted unique
+ * ids; own_items / own_off [N + 1]: the rows' own item ids, concatenated; out [N, k] (out[r][0] = -1: pool exhausted for row r). */
+int amid_sample_negatives_i64(const long long* pool_d1, int n_pool_d1, const long long* pool_d2, int n_pool_d2,
+                              const long long* own_items, const int* own_off, const long long* domain_id, int N, int k,
+                              unsigned long long seed, unsigned epoch, long long* out, void* stream);
+
 /* ---- InterComp on the SASRec path (isItC; next-1 of SURVEY.md 8(f)) -------------------------------------------------------
  * replaces: InterComp.forward model_seq.py:483-497 as used at model_seq.py:426-434 (both directions) and its autograd.  Since
  * SASRec only means over the time axis afterwards, the module collapses onto per-row means (derivation: csrc/intercomp.hip):

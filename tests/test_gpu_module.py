@@ -232,3 +232,34 @@ def test_train_sr_cli_end_to_end(tmp_path, model, emb, extra):
     assert ("d1", "HR@10") in best and ("d2", "MRR") in best
     assert all(0.0 <= v <= 1.0 for v in best.values())
     assert (tmp_path / "model" / "log0.txt").exists()
+
+
+def test_device_negative_sampling(tmp_path):
+    """next-3: negatives drawn on the device obey the reference's rule (dataset_seq.py:188/:198): k distinct items of the row's
+    own domain pool, none of them in the row's own sequence; fresh draws every epoch; roughly uniform."""
+    from amid_amd.dataset_seq import DeviceBatches, DualDomainSeqDataset
+    rng = np.random.default_rng(5)
+    root = tmp_path / "amazon_dataset"
+    root.mkdir()
+    _write_csv(root / "toy_test.csv", 120, rng, 1, 300, 300, 700)
+    for is_train, k in ((True, 1), (False, 99)):
+        ds = DualDomainSeqDataset(seq_len=20, isTrain=is_train, neg_nums=99, long_length=7, pad_id=1001, seed=3, csv_path=str(root / "toy_test.csv"))
+        db = DeviceBatches(ds, 16, shuffle=False, device="cuda:0", seed=3)
+        a, b = db.sample_negatives().cpu().numpy(), db.sample_negatives().cpu().numpy()
+        assert a.shape == (len(ds), k) and not np.array_equal(a, b)
+        for r in range(len(ds)):
+            pool = ds.pool[int(ds.domain_id[r] != 0)]
+            assert np.isin(a[r], pool).all() and not np.isin(a[r], ds.own_items[r]).any() and len(set(a[r].tolist())) == k
+    # uniformity: over many epochs every eligible item of row 0 shows up about equally often
+    ds = DualDomainSeqDataset(seq_len=20, isTrain=False, neg_nums=50, long_length=7, pad_id=1001, seed=3, csv_path=str(root / "toy_test.csv"))
+    db = DeviceBatches(ds, 16, shuffle=False, device="cuda:0", seed=9)
+    cnt = {}
+    for _ in range(200):
+        for v in db.sample_negatives()[0].tolist():
+            cnt[v] = cnt.get(v, 0) + 1
+    pool = ds.pool[int(ds.domain_id[0] != 0)]
+    elig = len(pool) - len(ds.own_items[0])
+    freq = np.array([cnt.get(int(v), 0) for v in pool if v not in set(ds.own_items[0].tolist())], dtype=np.float64)
+    assert len(freq) == elig and abs(freq.sum() - 200 * 50) < 1e-9
+    expect = 200 * 50 / elig
+    assert freq.min() > 0.3 * expect and freq.max() < 2.0 * expect
