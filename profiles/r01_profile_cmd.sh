@@ -1,12 +1,12 @@
 set -x
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r1b
-python3 $R/bench.py --steps 200 --warmup 20 > $R/gpurun_out/r1b/bench.json 2> $R/gpurun_out/r1b/bench.err
+mkdir -p $R/gpurun_out/r1c
+python3 $R/bench.py --steps 200 --warmup 20 > $R/gpurun_out/r1c/bench.json 2> $R/gpurun_out/r1c/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r1b/prof -o r1b -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $R/gpurun_out/r1b/bench_under_prof.json 2> $R/gpurun_out/r1b/prof_err.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r1b/pmc_fetch -o f -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/r1b/pmc_fetch.json 2> $R/gpurun_out/r1b/pmc_fetch_err.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r1b/pmc_write -o w -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/r1b/pmc_write.json 2> $R/gpurun_out/r1b/pmc_write_err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r1c/prof -o r1c -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $R/gpurun_out/r1c/bench_under_prof.json 2> $R/gpurun_out/r1c/prof_err.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r1c/pmc_fetch -o f -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/r1c/pmc_fetch.json 2> $R/gpurun_out/r1c/pmc_fetch_err.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r1c/pmc_write -o w -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/r1c/pmc_write.json 2> $R/gpurun_out/r1c/pmc_write_err.log
 cd $R
-rm -f gpurun_out/r1b/prof/*kernel_trace.csv gpurun_out/r1b/pmc_*/*kernel_trace.csv
-ls -la gpurun_out/r1b gpurun_out/r1b/*
-tail -c 600 gpurun_out/r1b/bench.json
+rm -f gpurun_out/r1c/prof/*kernel_trace.csv gpurun_out/r1c/pmc_*/*kernel_trace.csv
+ls -la gpurun_out/r1c gpurun_out/r1c/*
+tail -c 600 gpurun_out/r1c/bench.json
