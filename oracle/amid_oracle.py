@@ -303,7 +303,7 @@ def inner_comp(seq: torch.Tensor, P: Params, pre: str, threshold: float) -> torc
 
 def sasrec_forward(P: Params, i_node: torch.Tensor, neg_samples: torch.Tensor, seq_d1: torch.Tensor,
                    seq_d2: torch.Tensor, masks: Masks = None, taps: Optional[dict] = None, isItC: bool = False,
-                   threshold2: float = 0.5) -> Tuple[torch.Tensor, torch.Tensor]:
+                   threshold2: float = 0.5, isDR: bool = False) -> Tuple[torch.Tensor, ...]:
     E = P["item_emb_layer.emb_item.weight"]
     i_feat = gather_rows(E, i_node).unsqueeze(1)                         # :418
     neg_feat = gather_rows(E, neg_samples)                               # :419
@@ -316,6 +316,9 @@ def sasrec_forward(P: Params, i_node: torch.Tensor, neg_samples: torch.Tensor, s
     items = torch.cat((i_feat, neg_feat), 1)                             # :435
     if taps is not None:
         taps.update(u1=u1, u2=u2, items=items, f1=f1, f2=f2)
+    if isDR:                                                             # :436-440 (next-4): three heads on the same (u, items)
+        return (predict_module(u1, u2, items, P) + predict_module(u1, u2, items, P, "predict_ips")
+                + predict_module(u1, u2, items, P, "predict_gfunc"))
     return predict_module(u1, u2, items, P)                              # :442
 
 
@@ -396,6 +399,35 @@ def masked_bce_loss(p1: torch.Tensor, p2: torch.Tensor, labels: torch.Tensor, do
     m2 = domain_id.to(p1.dtype).unsqueeze(1)
     m1 = 1.0 - m2
     return (bce_elementwise(p1, labels) * m1 + bce_elementwise(p2, labels) * m2).mean()
+
+
+def dr_losses(outs, labels: torch.Tensor, domain_id: torch.Tensor, ob_label: Optional[torch.Tensor] = None, dr_e_w: float = 0.1):
+    """The doubly-robust trainer's losses (next-4; train_sr_dr.py:216-221 and :392-394) on the six outputs of
+    sasrec_forward(isDR=True).  Returns (loss_cls, loss_dr_e, loss_cls + dr_e_w * loss_dr_e, loss_dr_r); loss_dr_r is None
+    without ob_label.  The first total drives optimizer (lr), loss_dr_r drives optimizer2 (lr * lr2)."""
+    p1, p2, i1, i2, g1, g2 = outs
+    m2 = domain_id.to(p1.dtype).unsqueeze(1)
+    m1 = 1.0 - m2
+    b1, b2 = bce_elementwise(p1, labels), bce_elementwise(p2, labels)
+    loss_cls = (b1 * m1 + b2 * m2).mean()
+    loss_dr_e = ((b1 - g1) ** 2 / i1 * m1 + (b2 - g2) ** 2 / i2 * m2).mean()
+    loss_dr_r = None
+    if ob_label is not None:
+        ob = ob_label.to(p1.dtype).unsqueeze(1).expand_as(p1)
+        loss_dr_r = ((g1 ** 2 + ob * (b1 ** 2 - g1 ** 2) ** 2 / i1) * m1 + (g2 ** 2 + ob * (b2 ** 2 - g2 ** 2) ** 2 / i2) * m2).mean()
+    return loss_cls, loss_dr_e, loss_cls + dr_e_w * loss_dr_e, loss_dr_r
+
+
+def dr_loss_and_grads(P: Params, batch: Dict[str, torch.Tensor], which: str, masks: Masks = None, dr_e_w: float = 0.1, **fwd_kw):
+    """which = "e": gradient of loss_cls + dr_e_w * loss_dr_e (first loop); "r": gradient of loss_dr_r (second loop)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    outs = sasrec_forward(leaves, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], masks, isDR=True, **fwd_kw)
+    lc, le, tot, lr_ = dr_losses(outs, batch["label"], batch["domain_id"], batch.get("ob_label"), dr_e_w)
+    loss = tot if which == "e" else lr_
+    names = list(leaves)
+    gs = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    grads = {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(names, gs)}
+    return dict(loss_cls=lc.detach(), loss_dr_e=le.detach(), loss=loss.detach()), tuple(o.detach() for o in outs), grads
 
 
 # --------------------------------------------------------------------------
@@ -490,8 +522,9 @@ def get_sample_scores(pred: np.ndarray):
 # --------------------------------------------------------------------------
 # parameter construction helpers for tests / bench (shapes as SURVEY 8(b))
 # --------------------------------------------------------------------------
-def sasrec_param_shapes(item_length: int, D: int, T: int, hid: int, itc_bs: int = 0) -> Dict[str, Tuple[int, ...]]:
-    """itc_bs > 0: also the InterComp parameters of SASRec(isItC=True, bs=itc_bs) (model_seq.py:403-405, :478-480)."""
+def sasrec_param_shapes(item_length: int, D: int, T: int, hid: int, itc_bs: int = 0, dr: bool = False) -> Dict[str, Tuple[int, ...]]:
+    """itc_bs > 0: also the InterComp parameters of SASRec(isItC=True, bs=itc_bs) (model_seq.py:403-405, :478-480);
+    dr: also the predict_ips / predict_gfunc heads of isDR=True (:411-414)."""
     s: Dict[str, Tuple[int, ...]] = {"item_emb_layer.emb_item.weight": (item_length, D)}
     if itc_bs:
         for d in (1, 2):
@@ -517,10 +550,11 @@ def sasrec_param_shapes(item_length: int, D: int, T: int, hid: int, itc_bs: int 
             s[f"{pre}.forward_layers.{l}.conv1.bias"] = (D,)
             s[f"{pre}.forward_layers.{l}.conv2.weight"] = (D, D, 1)
             s[f"{pre}.forward_layers.{l}.conv2.bias"] = (D,)
-    s["predictModule.fc.0.weight"] = (hid, 2 * D)
-    s["predictModule.fc.0.bias"] = (hid,)
-    s["predictModule.fc.2.weight"] = (1, hid)
-    s["predictModule.fc.2.bias"] = (1,)
+    for head in ("predictModule",) + (("predict_ips", "predict_gfunc") if dr else ()):
+        s[f"{head}.fc.0.weight"] = (hid, 2 * D)
+        s[f"{head}.fc.0.bias"] = (hid,)
+        s[f"{head}.fc.2.weight"] = (1, hid)
+        s[f"{head}.fc.2.bias"] = (1,)
     return s
 
 

@@ -179,3 +179,25 @@ def test_g10_sasrec_itc_grads():
     assert np.array_equal(taps["itc_d2"]["gate"].numpy().astype(bool), z["gate"])          # max over all (a, c) pairs is symmetric
     assert set(G) == set(orc.sasrec_param_shapes(P["item_emb_layer.emb_item.weight"].shape[0], 64, 20, 16, itc_bs=6))
     check_grads("sasrec", z, P, B, G, None, isItC=True, threshold2=float(z["threshold2"]))
+
+
+def test_g11_sasrec_dr_outputs_losses_grads():
+    """SASRec(isDR=True, isItC=True) -- what run.sh launches through train_sr_dr.py: six outputs, the three losses and the
+    gradients of both objectives (loss_cls + dr_e_w * loss_dr_e for optimizer, loss_dr_r for optimizer2)."""
+    z, P, B, *_ = load("g11_sasrec_dr.npz")
+    batch = dict(B)
+    batch["label"] = torch.from_numpy(z["labels"])
+    batch["ob_label"] = torch.from_numpy(z["ob_label"])
+    kw = dict(isItC=True, threshold2=float(z["threshold2"]))
+    assert set(P) == set(orc.sasrec_param_shapes(P["item_emb_layer.emb_item.weight"].shape[0], 64, 20, 16, itc_bs=6, dr=True))
+    for which, pre in (("e", "GE/"), ("r", "GR/")):
+        info, outs, grads = orc.dr_loss_and_grads(P, batch, which, dr_e_w=float(z["dr_e_w"]), **kw)
+        for o, name in zip(outs, ("p1", "p2", "ips1", "ips2", "g1", "g2")):
+            assert rel_err(o, z[name]) < 1e-6, name
+        assert abs(float(info["loss_cls"]) - float(z["loss_cls"])) < 1e-6 and abs(float(info["loss_dr_e"]) - float(z["loss_dr_e"])) < 1e-6
+        if which == "r":
+            assert abs(float(info["loss"]) - float(z["loss_dr_r"])) < 1e-6
+        G = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+        assert set(G) == set(P)
+        for k, g in G.items():
+            assert rel_err(grads[k], g) < 2e-5 or float((grads[k] - g).abs().max()) < 1e-8, (which, k)
