@@ -179,6 +179,7 @@ struct ScorerBwdArgs {
     float* ditems;             // [B, NI, D]
     float* part;               // [B][hid*2D + hid + hid + 1]  (dW1 | db1 | dW2 | db2) per-row partials
     int B, NI, D, hid;
+    int accumulate;            // 1: du and ditems are added to (several heads share u and items: the doubly-robust trainer)
 };
 
 // block = batch row b.  Recomputes the hidden activations, then back-propagates.
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(256) void scorer_bwd_kernel(const ScorerBwdArgs a) 
             const int n = ne / D, e = ne - n * D;
             float s = 0.f;
             for (int j = 0; j < hid; ++j) s = fmaf(dc[n * hid + j], a.w1[(long long)j * 2 * D + D + e], s);
-            a.ditems[((long long)b * NI + n0 + n) * D + e] = s;
+            float* dip = a.ditems + ((long long)b * NI + n0 + n) * D + e;
+            *dip = a.accumulate ? *dip + s : s;
         }
         for (int je = threadIdx.x; je < hid * D; je += 256) {
             const int j = je / D, e = je - j * D;
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(256) void scorer_bwd_kernel(const ScorerBwdArgs a) 
         const int d = de / D, e = de - d * D;
         float s = 0.f;
         for (int j = 0; j < hid; ++j) s = fmaf(da[d * hid + j], a.w1[(long long)j * 2 * D + e], s);
-        a.du[((long long)d * a.B + b) * D + e] = s;
+        float* dup = a.du + ((long long)d * a.B + b) * D + e;
+        *dup = a.accumulate ? *dup + s : s;
     }
     for (int je = threadIdx.x; je < hid * D; je += 256) {
         const int j = je / D, e = je - j * D;
@@ -304,6 +307,51 @@ __global__ void sum_vector_kernel(const float* __restrict__ v, int n, float* __r
     for (int i = threadIdx.x; i < n; i += 64) s += v[i];
     s = group_sum<64>(s);
     if (threadIdx.x == 0) *out = s;
+}
+
+// Doubly-robust objectives (next-4; reference train_sr_dr.py:216-221 and :392-394), elementwise over [B, NI] on the three heads'
+// sigmoid outputs (p: predictModule, ips: predict_ips, g: predict_gfunc), each read from the head of the row's own domain:
+//   mode 0:  L = mean( BCE(p, y) + w (BCE(p, y) - g)^2 / ips )           (loss_cls + dr_e_w * loss_dr_e; optimizer)
+//   mode 1:  L = mean( g^2 + ob ((BCE(p, y))^2 - g^2)^2 / ips )          (loss_dr_r; optimizer2)
+// Writes dL/dp, dL/dips, dL/dg for both domains (zero on the head a row does not use) and per-row partials of
+// (loss_cls, loss_dr_e, loss_dr_r).  BCE and its derivative follow torch's BCELoss (log clamped at -100, denominator at 1e-12).
+struct DrLossArgs {
+    const float* p[2]; const float* ips[2]; const float* g[2];
+    const float* labels; const long long* domain; const long long* ob;
+    float* dp[2]; float* dips[2]; float* dg[2];
+    float* loss_part;          // [B][3]
+    int B, NI, mode; float w;
+};
+__global__ __launch_bounds__(64) void dr_loss_kernel(const DrLossArgs a) {
+    const int b = blockIdx.x, lane = lane_id();
+    const int d = a.domain[b] != 0;
+    const float ob = (a.ob != nullptr) ? (float)a.ob[b] : 0.f;
+    const float inv = 1.0f / (float)((long long)a.B * a.NI);
+    float lc = 0.f, le = 0.f, lr = 0.f;
+    for (int n = lane; n < a.NI; n += 64) {
+        const long long o = (long long)b * a.NI + n;
+        const float p = a.p[d][o], ips = a.ips[d][o], g = a.g[d][o], y = a.labels[o];
+        const float bce = -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+        const float dbce = (p - y) / fmaxf(p * (1.f - p), 1e-12f);
+        float dp, dg, dips;
+        lc += bce;
+        le += (bce - g) * (bce - g) / ips;
+        const float q = bce * bce - g * g;
+        lr += g * g + ob * q * q / ips;
+        if (a.mode == 0) {
+            dp = (1.f + 2.f * a.w * (bce - g) / ips) * dbce;
+            dg = -2.f * a.w * (bce - g) / ips;
+            dips = -a.w * (bce - g) * (bce - g) / (ips * ips);
+        } else {
+            dp = ob * 4.f * q * bce / ips * dbce;
+            dg = 2.f * g - ob * 4.f * q * g / ips;
+            dips = -ob * q * q / (ips * ips);
+        }
+        a.dp[d][o] = dp * inv; a.dg[d][o] = dg * inv; a.dips[d][o] = dips * inv;
+        a.dp[1 - d][o] = 0.f; a.dg[1 - d][o] = 0.f; a.dips[1 - d][o] = 0.f;
+    }
+    lc = group_sum<64>(lc); le = group_sum<64>(le); lr = group_sum<64>(lr);
+    if (lane == 0) { a.loss_part[b * 3 + 0] = lc * inv; a.loss_part[b * 3 + 1] = le * inv; a.loss_part[b * 3 + 2] = lr * inv; }
 }
 
 // rank (0 = best) of the positive (column 0) among a row's NI scores, judged by the head of the row's own domain -- the device
@@ -365,12 +413,12 @@ extern "C" long long amid_scorer_part_floats(int D, int hid) { return (long long
 
 extern "C" int amid_scorer_bwd_f32(const float* u, const float* items, const float* w1, const float* b1, const float* w2, const float* b2,
                                    const float* p1, const float* p2, const float* dp1, const float* dp2, int B, int NI, int D, int hid,
-                                   float* du, float* ditems, float* part, void* stream) {
+                                   float* du, float* ditems, float* part, int accumulate, void* stream) {
     AMID_CHECK_ARG(u && items && w1 && b1 && w2 && b2 && p1 && p2 && dp1 && dp2 && du && ditems && part && B > 0 && NI > 0 && hid > 0 &&
                    hid <= 64);
     ScorerBwdArgs a;
     a.u = u; a.items = items; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.p1 = p1; a.p2 = p2; a.dp1 = dp1; a.dp2 = dp2;
-    a.du = du; a.ditems = ditems; a.part = part; a.B = B; a.NI = NI; a.D = D; a.hid = hid;
+    a.du = du; a.ditems = ditems; a.part = part; a.B = B; a.NI = NI; a.D = D; a.hid = hid; a.accumulate = accumulate ? 1 : 0;
     const size_t lds = (size_t)(4 * hid + hid + 4 + 128 * hid) * sizeof(float);
     scorer_bwd_kernel<<<B, 256, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
@@ -398,6 +446,23 @@ extern "C" int amid_positive_rank_f32(const float* p1, const float* p2, const lo
                                       int* rank, void* stream) {
     AMID_CHECK_ARG(p1 && p2 && domain_id && rank && B > 0 && NI > 0);
     positive_rank_kernel<<<(B + 3) / 4, 256, 0, (hipStream_t)stream>>>(p1, p2, domain_id, B, NI, fix_value, rank);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// pointer arrays: HOST arrays of 2 device pointers (domain-1 head output, domain-2 head output)
+extern "C" int amid_dr_loss_f32(const float* const* p, const float* const* ips, const float* const* g, const float* labels,
+                                const long long* domain_id, const long long* ob_label, int mode, float dr_e_w, int B, int NI,
+                                float* const* dp, float* const* dips, float* const* dg, float* loss_part, void* stream) {
+    AMID_CHECK_ARG(p && ips && g && labels && domain_id && dp && dips && dg && loss_part && B > 0 && NI > 0 && (mode == 0 || mode == 1));
+    AMID_CHECK_ARG(mode == 0 || ob_label != nullptr);
+    DrLossArgs a;
+    for (int d = 0; d < 2; ++d) {
+        AMID_CHECK_ARG(p[d] && ips[d] && g[d] && dp[d] && dips[d] && dg[d]);
+        a.p[d] = p[d]; a.ips[d] = ips[d]; a.g[d] = g[d]; a.dp[d] = dp[d]; a.dips[d] = dips[d]; a.dg[d] = dg[d];
+    }
+    a.labels = labels; a.domain = domain_id; a.ob = ob_label; a.loss_part = loss_part; a.B = B; a.NI = NI; a.mode = mode; a.w = dr_e_w;
+    dr_loss_kernel<<<B, 64, 0, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -29,7 +29,7 @@ SASREC_P_DROP = 0.5       # model_seq.py:335,350,356
 SASREC_LN_EPS = 1e-8      # model_seq.py:342-353
 
 
-def sasrec_dense_names(T: int, D: int, hid: int, itc_bs: int = 0) -> List[Tuple[str, Tuple[int, ...]]]:
+def sasrec_dense_names(T: int, D: int, hid: int, itc_bs: int = 0, dr: bool = False) -> List[Tuple[str, Tuple[int, ...]]]:
     """Non-table parameters in the reference's state_dict order; itc_bs > 0: with the InterComp
     modules of SASRec(isItC=True, bs=itc_bs) (model_seq.py:403-405, :478-480)."""
     out: List[Tuple[str, Tuple[int, ...]]] = []
@@ -62,11 +62,15 @@ def sasrec_dense_names(T: int, D: int, hid: int, itc_bs: int = 0) -> List[Tuple[
             out.append((f"{pre}.forward_layers.{l}.conv2.bias", (D,)))
         out.append((f"{pre}.last_layernorm.weight", (D,)))
         out.append((f"{pre}.last_layernorm.bias", (D,)))
-    out.append(("predictModule.fc.0.weight", (hid, 2 * D)))
-    out.append(("predictModule.fc.0.bias", (hid,)))
-    out.append(("predictModule.fc.2.weight", (1, hid)))
-    out.append(("predictModule.fc.2.bias", (1,)))
+    for head in ("predictModule",) + (("predict_ips", "predict_gfunc") if dr else ()):      # isDR heads: model_seq.py:411-414
+        out.append((f"{head}.fc.0.weight", (hid, 2 * D)))
+        out.append((f"{head}.fc.0.bias", (hid,)))
+        out.append((f"{head}.fc.2.weight", (1, hid)))
+        out.append((f"{head}.fc.2.bias", (1,)))
     return out
+
+
+DR_HEADS = ("predictModule", "predict_ips", "predict_gfunc")
 
 
 class FlatParams:
@@ -129,7 +133,8 @@ class SasrecPlan:
         # static inputs (graph-replay safe): ONE int64 buffer so a batch arrives with a single copy
         #   [i_node B | neg B*(NI-1) | seq_d1 B*T | seq_d2 B*T | domain B | labels B*NI fp32 (packed two per word)]
         n_lab_words = (B * NI + 1) // 2
-        self.in_words = B + B * (NI - 1) + 2 * B * T + B + n_lab_words
+        dr = bool(getattr(eng, "dr", False))
+        self.in_words = B + B * (NI - 1) + 2 * B * T + B + n_lab_words + (B if dr else 0)       # DR: + ob_label [B] at the end
         self.in_pack = torch.zeros(self.in_words, dtype=torch.int64, device=dev)
         o = 0
         self.in_i_node = self.in_pack[o:o + B]; o += B
@@ -137,7 +142,8 @@ class SasrecPlan:
         self.in_seq_d1 = self.in_pack[o:o + B * T].view(B, T); o += B * T
         self.in_seq_d2 = self.in_pack[o:o + B * T].view(B, T); o += B * T
         self.domain = self.in_pack[o:o + B]; o += B
-        self.labels = self.in_pack[o:o + n_lab_words].view(torch.float32)[: B * NI].view(B, NI)
+        self.labels = self.in_pack[o:o + n_lab_words].view(torch.float32)[: B * NI].view(B, NI); o += n_lab_words
+        self.in_ob = self.in_pack[o:o + B] if dr else None
         self.idx_all = torch.zeros(N, dtype=torch.int32, device=dev)
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         # forward
@@ -162,6 +168,11 @@ class SasrecPlan:
         self.dp2 = torch.zeros(B, NI, dtype=torch.float32, device=dev)
         self.loss_part = torch.zeros(B, dtype=torch.float32, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        if dr:            # the two extra heads' outputs / output gradients, and per-row partials of (loss_cls, loss_dr_e, loss_dr_r)
+            self.ips1, self.ips2, self.g1, self.g2 = (f(B, NI) for _ in range(4))
+            self.dips1, self.dips2, self.dg1, self.dg2 = (torch.zeros(B, NI, dtype=torch.float32, device=dev) for _ in range(4))
+            self.dr_loss_part = torch.zeros(B, 3, dtype=torch.float32, device=dev)
+            self.dr_losses = torch.zeros(3, dtype=torch.float32, device=dev)
         if not need_grad:
             return
         # backward
@@ -176,6 +187,8 @@ class SasrecPlan:
         self._alloc_model_bwd(eng, f)
         self.sc_P = L.value("amid_scorer_part_floats", D, hid)
         self.sc_part = f(B, self.sc_P)
+        if dr:
+            self.sc_part_ips, self.sc_part_g = f(B, self.sc_P), f(B, self.sc_P)
         # sparse side
         self.sort_ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", N), dtype=torch.uint8, device=dev)
         self.pos_sorted = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -187,6 +200,7 @@ class SasrecPlan:
         self.uniq_grad = f(N, D)
         self._build_reduce_table(eng)
         self.graph = None
+        self.graphs = {}
 
     # ---- model-specific pieces (BertPlan overrides these three) -------------------------------------
     def _alloc_model_fwd(self, eng: "SasrecEngine", f) -> None:
@@ -219,12 +233,19 @@ class SasrecPlan:
             ent.append((src_t.data_ptr() + 4 * src_off, dst_ptr, stride, n_part, count))
 
         self._model_reduce_entries(eng, add)
-        ent.append((self.loss_part.data_ptr(), self.loss.data_ptr(), 1, B, 1))          # loss = sum of the per-row partials
         P = self.sc_P
-        add(self.sc_part, 0, fp.ptr("predictModule.fc.0.weight", G), P, B, hid * 2 * D)
-        add(self.sc_part, hid * 2 * D, fp.ptr("predictModule.fc.0.bias", G), P, B, hid)
-        add(self.sc_part, hid * 2 * D + hid, fp.ptr("predictModule.fc.2.weight", G), P, B, hid)
-        add(self.sc_part, hid * 2 * D + 2 * hid, fp.ptr("predictModule.fc.2.bias", G), P, B, 1)
+        heads = [("predictModule", self.sc_part)]
+        if getattr(eng, "dr", False):
+            heads += [("predict_ips", self.sc_part_ips), ("predict_gfunc", self.sc_part_g)]
+            for c in range(3):                                                           # loss_cls, loss_dr_e, loss_dr_r
+                ent.append((self.dr_loss_part.data_ptr() + 4 * c, self.dr_losses.data_ptr() + 4 * c, 3, B, 1))
+        else:
+            ent.append((self.loss_part.data_ptr(), self.loss.data_ptr(), 1, B, 1))      # loss = sum of the per-row partials
+        for head, part in heads:
+            add(part, 0, fp.ptr(f"{head}.fc.0.weight", G), P, B, hid * 2 * D)
+            add(part, hid * 2 * D, fp.ptr(f"{head}.fc.0.bias", G), P, B, hid)
+            add(part, hid * 2 * D + hid, fp.ptr(f"{head}.fc.2.weight", G), P, B, hid)
+            add(part, hid * 2 * D + 2 * hid, fp.ptr(f"{head}.fc.2.bias", G), P, B, 1)
         esz = L.value("amid_reduce_entry_bytes")
         host = (ctypes.c_ubyte * (esz * len(ent)))()
         for i, (s, d, st, n, c) in enumerate(ent):
@@ -273,7 +294,7 @@ class SasrecEngine:
     EMB_DIMS = (64, 128)
 
     def _dense_names(self) -> List[Tuple[str, Tuple[int, ...]]]:
-        return sasrec_dense_names(self.T, self.D, self.hid, self.itc_bs)
+        return sasrec_dense_names(self.T, self.D, self.hid, self.itc_bs, self.dr)
 
     def _alloc_model_buffers(self) -> None:
         D = self.D
@@ -281,11 +302,15 @@ class SasrecEngine:
         self.wT = torch.zeros(2, 2, 6, D * D, dtype=torch.float32, device=self.device)     # [layer][domain][q,k,v,o,c1,c2]
 
     def __init__(self, item_length: int, emb_dim: int, seq_len: int, hid_dim: int, device="cuda:0", lr: float = 5e-4,
-                 betas=(0.9, 0.999), eps: float = 1e-8, seed: int = 0, itc_bs: int = 0, itc_threshold: float = 0.5):
+                 betas=(0.9, 0.999), eps: float = 1e-8, seed: int = 0, itc_bs: int = 0, itc_threshold: float = 0.5, dr: bool = False,
+                 dr_e_w: float = 0.1):
         """itc_bs > 0: SASRec(isItC=True, bs=itc_bs, threshold2=itc_threshold) -- InterComp after the encoders
         (model_seq.py:426-431); every batch must then hold exactly itc_bs rows (trans_bs is Linear(bs, 1) over the batch)."""
         L = lib()        # raises AmidLibraryError when the HIP library is missing: no fallback
         self.itc_bs, self.itc_threshold = int(itc_bs), float(itc_threshold)
+        # dr: SASRec(isDR=True) -- predict_ips / predict_gfunc heads and the two objectives of train_sr_dr.py; dr_mode selects
+        # the objective of the next train step (0: loss_cls + dr_e_w * loss_dr_e, 1: loss_dr_r), see select_optimizer()
+        self.dr, self.dr_e_w, self.dr_mode = bool(dr), float(dr_e_w), 0
         if emb_dim not in self.EMB_DIMS:
             raise ValueError(f"amid_amd {type(self).__name__} kernels are built for emb_dim in {self.EMB_DIMS}, got {emb_dim}")
         self.device = torch.device(device)
@@ -313,6 +338,7 @@ class SasrecEngine:
         self._push_step_state()
         self.plans: Dict[Tuple[int, int, int, bool], SasrecPlan] = {}
         self.grad_scale = 1.0
+        self.opt_bank, self._banks = 0, {}          # several Adam states over the same parameters (train_sr_dr.py:668-669)
         torch.cuda.synchronize(self.device)
         self._ptr_cache: Dict[str, object] = {}
 
@@ -349,6 +375,34 @@ class SasrecEngine:
             self.table_v = torch.zeros_like(self.table)
             self.table_last = torch.zeros(self.n_rows, dtype=torch.int32, device=self.device)
 
+    def select_optimizer(self, k: int, lr: Optional[float] = None) -> None:
+        """Switch to Adam state `k` (its own moments, step counter and learning rate over the SAME parameters): the reference's
+        doubly-robust trainer alternates two torch.optim.Adam instances (train_sr_dr.py:668-669, :222-224, :396-398).  Pending
+        lazy updates of the state being left are applied first (one pass over the table), so rows never owe moves to an idle state."""
+        if k == self.opt_bank:
+            if lr is not None and lr != self.hyper["lr"]:
+                self.set_lr(lr)
+            return
+        self.flush_table()
+        self.sync()
+        fp = self.dense
+        self._banks[self.opt_bank] = dict(m=fp.m, v=fp.v, tm=self.table_m, tv=self.table_v, tl=self.table_last, st=self.step_state,
+                                          step=self.step, lr=self.hyper["lr"], seed=self.seed)
+        b = self._banks.get(k)
+        if b is None:
+            b = dict(m=torch.zeros_like(fp.m), v=torch.zeros_like(fp.v), tm=None, tv=None, tl=None,
+                     st=torch.zeros(self._st_bytes, dtype=torch.uint8, device=self.device), step=0,
+                     lr=self.hyper["lr"] if lr is None else float(lr), seed=self.seed + 0x9E3779B9 * k)
+        fp.m, fp.v, self.table_m, self.table_v, self.table_last = b["m"], b["v"], b["tm"], b["tv"], b["tl"]
+        self.step_state, self.step, self.seed = b["st"], b["step"], b["seed"]
+        self.hyper["lr"] = b["lr"] if lr is None else float(lr)
+        self.opt_bank = k
+        self._push_step_state()
+        torch.cuda.synchronize(self.device)
+
+    def _graph_key(self) -> Tuple[int, int]:
+        return (self.opt_bank, self.dr_mode if self.dr else 0)
+
     def plan(self, B: int, T: int, NI: int, need_grad: bool) -> SasrecPlan:
         key = (B, T, NI, need_grad)
         if key not in self.plans:
@@ -377,7 +431,7 @@ class SasrecEngine:
         return c
 
     # ------------------------------------------------------------------ launch sequences
-    def load_batch(self, pl: SasrecPlan, i_node, neg_samples, seq_d1, seq_d2, labels=None, domain_id=None) -> None:
+    def load_batch(self, pl: SasrecPlan, i_node, neg_samples, seq_d1, seq_d2, labels=None, domain_id=None, ob_label=None) -> None:
         """Copy a batch into the plan's static input buffers (async on the engine stream)."""
         with torch.cuda.stream(self.stream):
             pl.in_i_node.copy_(i_node.reshape(-1), non_blocking=True)
@@ -387,6 +441,8 @@ class SasrecEngine:
             if labels is not None:
                 pl.labels.copy_(labels.reshape(pl.shape.B, -1), non_blocking=True)
                 pl.domain.copy_(domain_id.reshape(-1), non_blocking=True)
+            if ob_label is not None:
+                pl.in_ob.copy_(ob_label.reshape(-1), non_blocking=True)
 
     def pack_batch(self, pl: SasrecPlan, i_node, neg_samples, seq_d1, seq_d2, labels, domain_id) -> torch.Tensor:
         """Pre-pack a batch into the plan's input layout (one contiguous int64 tensor) for load_packed()."""
@@ -452,6 +508,9 @@ class SasrecEngine:
                    self._pp(f"sac{{d}}.forward_layers.{l}.conv2.bias"), pl.tmq.data_ptr(), M, D, pl.rpt, l, st, tr, SASREC_P_DROP,
                    pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(), s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
+        if self.dr:
+            self._enqueue_head_dr_fwd(pl, items, with_loss)
+            return
         if self.itc_bs:
             self._enqueue_head_itc_fwd(pl, items, with_loss)
             if with_loss and sum_loss:
@@ -467,36 +526,77 @@ class SasrecEngine:
             L.call("amid_sum_vector_f32", pl.loss_part.data_ptr(), B, pl.loss.data_ptr(), s)
 
     # ---- isItC head: last LayerNorm + mean -> pair-max -> batch-softmax gate + mix -> scorer (csrc/intercomp.hip) ----
-    def _enqueue_head_itc_fwd(self, pl: SasrecPlan, items: int, with_loss: bool) -> None:
+    def _enqueue_user_vectors(self, pl: SasrecPlan) -> None:
+        """pl.u [2, B, D]: mean over time of the last LayerNorm (:385, :432-434), mixed with the InterComp group when isItC."""
         L, s, shp, D = lib(), self.s, pl.shape, self.D
-        B, T, NI = shp.B, shp.T, shp.NI
+        B, T = shp.B, shp.T
         fp = self.dense
-        lw, lb = self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias")
+        dst = pl.u_raw if self.itc_bs else pl.u
         L.call("amid_lnmean_fwd_f32", pl.x[2].data_ptr(), fp.ptr("sac1.last_layernorm.weight"), fp.ptr("sac1.last_layernorm.bias"),
-               fp.ptr("sac2.last_layernorm.weight"), fp.ptr("sac2.last_layernorm.bias"), B, T, D, SASREC_LN_EPS, pl.u_raw.data_ptr(), s)
-        L.call("amid_itc_pairmax_f32", pl.x[2].data_ptr(), lw, lb, B, T, D, SASREC_LN_EPS, pl.itc_s.data_ptr(), s)
-        L.call("amid_itc_mix_fwd_f32", pl.u_raw.data_ptr(), pl.itc_s.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"),
-               self._pp("itc_d{d}.trans_nn.bias"), self._pp("itc_d{d}.trans_bs.weight"), self._pp("itc_d{d}.trans_bs.bias"),
-               self.itc_threshold, B, D, pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(), pl.itc_sw.data_ptr(), pl.u.data_ptr(), s)
-        L.call("amid_scorer_fwd_f32", pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
-               fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr() if with_loss else None,
-               pl.domain.data_ptr() if with_loss else None, B, NI, D, self.hid, pl.p1.data_ptr(), pl.p2.data_ptr(),
-               pl.dp1.data_ptr() if with_loss else None, pl.dp2.data_ptr() if with_loss else None,
-               pl.loss_part.data_ptr() if with_loss else None, s)
+               fp.ptr("sac2.last_layernorm.weight"), fp.ptr("sac2.last_layernorm.bias"), B, T, D, SASREC_LN_EPS, dst.data_ptr(), s)
+        if self.itc_bs:
+            L.call("amid_itc_pairmax_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
+                   B, T, D, SASREC_LN_EPS, pl.itc_s.data_ptr(), s)
+            L.call("amid_itc_mix_fwd_f32", pl.u_raw.data_ptr(), pl.itc_s.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"),
+                   self._pp("itc_d{d}.trans_nn.bias"), self._pp("itc_d{d}.trans_bs.weight"), self._pp("itc_d{d}.trans_bs.bias"),
+                   self.itc_threshold, B, D, pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(), pl.itc_sw.data_ptr(), pl.u.data_ptr(), s)
+
+    def _enqueue_user_vectors_bwd(self, pl: SasrecPlan) -> None:
+        """pl.du (gradient of pl.u) -> InterComp parameter gradients (isItC) -> dx of the last layer's output + LayerNorm partials."""
+        L, s, shp, D = lib(), self.s, pl.shape, self.D
+        B, T = shp.B, shp.T
+        fp, G = self.dense, self.dense.grad
+        du = pl.du
+        if self.itc_bs:
+            L.call("amid_itc_mix_bwd_f32", pl.du.data_ptr(), pl.u_raw.data_ptr(), pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(),
+                   pl.itc_sw.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"), self._pp("itc_d{d}.trans_nn.bias"),
+                   self._pp("itc_d{d}.trans_bs.weight"), B, D, pl.du_raw.data_ptr(), self._pp("itc_d{d}.trans_nn.weight", G),
+                   self._pp("itc_d{d}.trans_nn.bias", G), self._pp("itc_d{d}.trans_bs.weight", G), self._pp("itc_d{d}.trans_bs.bias", G), s)
+            du = pl.du_raw
+        L.call("amid_lnmean_bwd_f32", pl.x[2].data_ptr(), du.data_ptr(), fp.ptr("sac1.last_layernorm.weight"),
+               fp.ptr("sac2.last_layernorm.weight"), B, T, D, SASREC_LN_EPS, pl.dxbuf.data_ptr(), pl.last_part.data_ptr(), s)
+
+    def _scorer_fwd(self, pl: SasrecPlan, head: str, items: int, p1, p2, with_loss: bool) -> None:
+        shp, fp = pl.shape, self.dense
+        lib().call("amid_scorer_fwd_f32", pl.u.data_ptr(), items, fp.ptr(f"{head}.fc.0.weight"), fp.ptr(f"{head}.fc.0.bias"),
+                   fp.ptr(f"{head}.fc.2.weight"), fp.ptr(f"{head}.fc.2.bias"), pl.labels.data_ptr() if with_loss else None,
+                   pl.domain.data_ptr() if with_loss else None, shp.B, shp.NI, self.D, self.hid, p1.data_ptr(), p2.data_ptr(),
+                   pl.dp1.data_ptr() if with_loss else None, pl.dp2.data_ptr() if with_loss else None,
+                   pl.loss_part.data_ptr() if with_loss else None, self.s)
+
+    def _scorer_bwd(self, pl: SasrecPlan, head: str, items: int, ditems: int, p1, p2, dp1, dp2, part, accumulate: int) -> None:
+        shp, fp = pl.shape, self.dense
+        lib().call("amid_scorer_bwd_f32", pl.u.data_ptr(), items, fp.ptr(f"{head}.fc.0.weight"), fp.ptr(f"{head}.fc.0.bias"),
+                   fp.ptr(f"{head}.fc.2.weight"), fp.ptr(f"{head}.fc.2.bias"), p1.data_ptr(), p2.data_ptr(), dp1.data_ptr(), dp2.data_ptr(),
+                   shp.B, shp.NI, self.D, self.hid, pl.du.data_ptr(), ditems, part.data_ptr(), accumulate, self.s)
+
+    # ---- isItC head: last LayerNorm + mean -> pair-max -> batch-softmax gate + mix -> scorer (csrc/intercomp.hip) ----
+    def _enqueue_head_itc_fwd(self, pl: SasrecPlan, items: int, with_loss: bool) -> None:
+        self._enqueue_user_vectors(pl)
+        self._scorer_fwd(pl, "predictModule", items, pl.p1, pl.p2, with_loss)
 
     def _enqueue_head_itc_bwd(self, pl: SasrecPlan, items: int, ditems: int) -> None:
-        L, s, shp, D = lib(), self.s, pl.shape, self.D
-        B, T, NI = shp.B, shp.T, shp.NI
-        fp, G = self.dense, self.dense.grad
-        L.call("amid_scorer_bwd_f32", pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
-               fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(), pl.p2.data_ptr(),
-               pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, NI, D, self.hid, pl.du.data_ptr(), ditems, pl.sc_part.data_ptr(), s)
-        L.call("amid_itc_mix_bwd_f32", pl.du.data_ptr(), pl.u_raw.data_ptr(), pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(),
-               pl.itc_sw.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"), self._pp("itc_d{d}.trans_nn.bias"),
-               self._pp("itc_d{d}.trans_bs.weight"), B, D, pl.du_raw.data_ptr(), self._pp("itc_d{d}.trans_nn.weight", G),
-               self._pp("itc_d{d}.trans_nn.bias", G), self._pp("itc_d{d}.trans_bs.weight", G), self._pp("itc_d{d}.trans_bs.bias", G), s)
-        L.call("amid_lnmean_bwd_f32", pl.x[2].data_ptr(), pl.du_raw.data_ptr(), fp.ptr("sac1.last_layernorm.weight"),
-               fp.ptr("sac2.last_layernorm.weight"), B, T, D, SASREC_LN_EPS, pl.dxbuf.data_ptr(), pl.last_part.data_ptr(), s)
+        self._scorer_bwd(pl, "predictModule", items, ditems, pl.p1, pl.p2, pl.dp1, pl.dp2, pl.sc_part, 0)
+        self._enqueue_user_vectors_bwd(pl)
+
+    # ---- isDR head (next-4): three scorers on the same (u, items) + the doubly-robust objective of the current mode ----
+    def _enqueue_head_dr_fwd(self, pl: SasrecPlan, items: int, with_loss: bool) -> None:
+        L, shp = lib(), pl.shape
+        self._enqueue_user_vectors(pl)
+        self._scorer_fwd(pl, "predictModule", items, pl.p1, pl.p2, False)
+        self._scorer_fwd(pl, "predict_ips", items, pl.ips1, pl.ips2, False)
+        self._scorer_fwd(pl, "predict_gfunc", items, pl.g1, pl.g2, False)
+        if with_loss:
+            pa = lambda a, b: ptr_array([a.data_ptr(), b.data_ptr()])       # noqa: E731
+            L.call("amid_dr_loss_f32", pa(pl.p1, pl.p2), pa(pl.ips1, pl.ips2), pa(pl.g1, pl.g2), pl.labels.data_ptr(), pl.domain.data_ptr(),
+                   pl.in_ob.data_ptr(), self.dr_mode, self.dr_e_w, shp.B, shp.NI, pa(pl.dp1, pl.dp2), pa(pl.dips1, pl.dips2),
+                   pa(pl.dg1, pl.dg2), pl.dr_loss_part.data_ptr(), self.s)
+
+    def _enqueue_head_dr_bwd(self, pl: SasrecPlan, items: int, ditems: int) -> None:
+        self._scorer_bwd(pl, "predictModule", items, ditems, pl.p1, pl.p2, pl.dp1, pl.dp2, pl.sc_part, 0)
+        self._scorer_bwd(pl, "predict_ips", items, ditems, pl.ips1, pl.ips2, pl.dips1, pl.dips2, pl.sc_part_ips, 1)
+        self._scorer_bwd(pl, "predict_gfunc", items, ditems, pl.g1, pl.g2, pl.dg1, pl.dg2, pl.sc_part_g, 1)
+        self._enqueue_user_vectors_bwd(pl)
 
     def enqueue_backward(self, pl: SasrecPlan, train: bool) -> None:
         """Backward from pl.dp1 / pl.dp2 (dLoss/dp) to pl.uniq_grad (table rows) and dense.grad."""
@@ -518,7 +618,10 @@ class SasrecEngine:
                 dst += [self.wT[l, g, w].data_ptr() for w in range(6)]
         items = pl.xg.data_ptr() + 4 * 2 * M * D
         ditems = pl.dxg.data_ptr() + 4 * 2 * M * D
-        if self.itc_bs:
+        if self.dr:
+            L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
+            self._enqueue_head_dr_bwd(pl, items, ditems)
+        elif self.itc_bs:
             L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
             self._enqueue_head_itc_bwd(pl, items, ditems)
         else:
@@ -654,10 +757,16 @@ class SasrecEngine:
             out = ctypes.c_void_p()
             L.call("amid_graph_capture_end", s, ctypes.byref(out))
         self.step = step0          # capture does not execute; the device counter did not move
-        pl.graph = out.value
+        if not hasattr(pl, "graphs"):
+            pl.graphs = {}
+        pl.graphs[self._graph_key()] = out.value       # the Adam state's buffers and the DR objective are baked into a graph
+        pl.graph = pl.graphs.get((0, 0), out.value)
+
+    def has_graph(self, pl: SasrecPlan) -> bool:
+        return self._graph_key() in getattr(pl, "graphs", {})
 
     def replay_train_step(self, pl: SasrecPlan) -> None:
-        lib().call("amid_graph_launch", pl.graph, self.s)
+        lib().call("amid_graph_launch", pl.graphs[self._graph_key()], self.s)
         self.step += 1
 
     def flush_table(self) -> None:

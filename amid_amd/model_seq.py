@@ -24,9 +24,10 @@ are accepted and ignored; dropout follows ``module.training``.  Two ways to trai
                    Adam as one hipGraph replay -- what ``train_sr.py`` of this repo and ``bench.py`` use.
 
 Out of scope this round (constructors kept for import / state_dict parity, ``forward`` raises):
-GRU4Rec (recurrent), the standalone InnerComp / InterComp modules, isInC, BERT4Rec with isItC (both put the
-appended token group in FRONT of the encoders), embUserLayerEnhance (dead code in the reference), the isDR heads.
-SASRec(isItC=True) -- InterComp after the encoders, what run.sh trains -- IS built (csrc/intercomp.hip).
+GRU4Rec (recurrent), the standalone InnerComp / InterComp modules, isInC, BERT4Rec with isItC / isDR (isItC there puts the
+appended token group in FRONT of the encoders), embUserLayerEnhance (dead code in the reference).
+SASRec(isItC=True, isDR=True) -- InterComp after the encoders + the doubly-robust heads, what run.sh trains through
+train_sr_dr.py -- IS built (csrc/intercomp.hip, amid_dr_loss_f32).
 """
 from __future__ import annotations
 
@@ -78,16 +79,21 @@ class _SasrecFunction(torch.autograd.Function):
         torch.cuda.current_stream().wait_stream(eng.stream)
         ctx.model, ctx.pl, ctx.train = model, pl, model.training
         eng.check_index_error(pl)
-        return pl.p1.clone(), pl.p2.clone()
+        outs = (pl.p1, pl.p2) + ((pl.ips1, pl.ips2, pl.g1, pl.g2) if eng.dr else ())      # isDR: model_seq.py:436-440
+        return tuple(o.clone() for o in outs)
 
     @staticmethod
-    def backward(ctx, g1, g2):
+    def backward(ctx, *gouts):
         model, pl = ctx.model, ctx.pl
         eng: SasrecEngine = model.engine
         eng.stream.wait_stream(torch.cuda.current_stream())
+        dsts = (pl.dp1, pl.dp2) + ((pl.dips1, pl.dips2, pl.dg1, pl.dg2) if eng.dr else ())
         with torch.cuda.stream(eng.stream):
-            pl.dp1.copy_(g1.reshape(pl.dp1.shape))
-            pl.dp2.copy_(g2.reshape(pl.dp2.shape))
+            for d, g in zip(dsts, gouts):
+                if g is None:
+                    d.zero_()
+                else:
+                    d.copy_(g.reshape(d.shape))
         eng.enqueue_backward(pl, train=ctx.train)
         grads = []
         with torch.cuda.stream(eng.stream):
@@ -108,8 +114,10 @@ class _SasrecFunction(torch.autograd.Function):
 
 
 class SASRec(nn.Module):
-    """model_seq.py:390-443 on the HIP engine (isInC = isDR = False; isItC either way: with it every batch must hold exactly
-    `bs` rows, as in the reference where trans_bs is Linear(bs, 1) over the batch, and state_dict gains itc_d{1,2}.*)."""
+    """model_seq.py:390-443 on the HIP engine (isInC = False; isItC either way: with it every batch must hold exactly `bs` rows,
+    as in the reference where trans_bs is Linear(bs, 1) over the batch, and state_dict gains itc_d{1,2}.*; isDR either way:
+    with it forward returns six outputs -- logits, ips, gfunc per domain, :436-440 -- and state_dict gains predict_ips.*,
+    predict_gfunc.*)."""
 
     ENGINE_CLS = SasrecEngine
     SUPPORTS_ITC = True          # InterComp after the encoders (model_seq.py:426-431), the configuration run.sh trains
@@ -121,8 +129,8 @@ class SASRec(nn.Module):
             _not_built("InnerComp (isInC)", "model_seq.py:422-424")
         if isItC and not self.SUPPORTS_ITC:
             _not_built("InterComp (isItC) for this model", "model_seq.py:289-294")
-        if isDR:
-            _not_built("the doubly-robust heads (isDR)", "model_seq.py:411-414")
+        if isDR and not self.SUPPORTS_ITC:
+            _not_built("the doubly-robust heads (isDR) for this model", "model_seq.py:268-271")
         if user_emb_dim != item_emb_dim:
             raise ValueError("the reference feeds item rows into encoders built with user_emb_dim: the two must be equal")
         lib()                                                   # fail loudly without libamid_hip.so
@@ -130,6 +138,8 @@ class SASRec(nn.Module):
         self.isInC, self.isItC, self.isDR = isInC, isItC, isDR
         dev = device or ("cuda:%d" % torch.cuda.current_device())
         kw = dict(itc_bs=bs, itc_threshold=threshold2) if isItC else {}
+        if isDR:
+            kw["dr"] = True
         self.engine = self.ENGINE_CLS(item_length, item_emb_dim, seq_len, hid_dim, device=dev, lr=lr, seed=seed, **kw)
         eng = self.engine
         self._param_names = ["item_emb_layer.emb_item.weight"] + list(eng.dense.slots)
@@ -166,6 +176,10 @@ class SASRec(nn.Module):
                               "predictModule.fc.2.bias": hid}.get(name, 4 * D if ".feed_forward.w_2." in name else D)
                     if ".trans_bs." in name:                   # InterComp's Linear(bs, 1) over the batch (model_seq.py:480)
                         fan_in = eng.itc_bs
+                    elif name.startswith(("predict_ips.fc.0", "predict_gfunc.fc.0")):
+                        fan_in = 2 * D
+                    elif name.startswith(("predict_ips.fc.2", "predict_gfunc.fc.2")):
+                        fan_in = hid
                     a = 1.0 / fan_in ** 0.5
                     v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * a)
         torch.cuda.synchronize(eng.device)
@@ -176,34 +190,44 @@ class SASRec(nn.Module):
             self.engine.flush_table()               # rows with pending zero-gradient Adam steps must be current for eval
         params = [self.get_parameter(n) for n in self._param_names]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        p1, p2 = _SasrecFunction.apply(self, need_grad, i_node, neg_samples, seq_d1, seq_d2, *params)
-        return p1.squeeze(), p2.squeeze()              # model_seq.py:54
+        outs = _SasrecFunction.apply(self, need_grad, i_node, neg_samples, seq_d1, seq_d2, *params)
+        return tuple(o.squeeze() for o in outs)        # model_seq.py:54 ; isDR: six outputs (:436-440)
 
     # -- fused fast path -------------------------------------------------------------------------
-    def train_step(self, i_node, neg_samples, seq_d1, seq_d2, labels, domain_id, use_graph: bool = True, exchange=None) -> torch.Tensor:
+    def train_step(self, i_node, neg_samples, seq_d1, seq_d2, labels, domain_id, use_graph: bool = True, exchange=None,
+                   ob_label=None, dr_objective: int = 0) -> torch.Tensor:
         """train_sr.py:190-217 as one launch sequence (one hipGraph replay once captured).  Returns the loss (device scalar;
         under data parallelism the mean over THIS rank's shard).  exchange: an amid_amd.dist.SparseDenseExchange for
-        data-parallel training (one process per GPU): local gradients, one dense all-reduce + sparse all-gather, Adam."""
+        data-parallel training (one process per GPU): local gradients, one dense all-reduce + sparse all-gather, Adam.
+        isDR models: dr_objective 0 = loss_cls + dr_e_w * loss_dr_e (train_sr_dr.py:216-224), 1 = loss_dr_r with ob_label
+        (:392-398); returns the three-element tensor (loss_cls, loss_dr_e, loss_dr_r) of this batch.  Pick the Adam state with
+        engine.select_optimizer() (the reference alternates two optimizers)."""
         eng = self.engine
         self.fused_optimizer = True
         B, T = seq_d1.shape
         neg = neg_samples.reshape(B, -1)
         pl = eng.plan(B, T, 1 + neg.shape[1], need_grad=True)
         eng.stream.wait_stream(torch.cuda.current_stream())
-        eng.load_batch(pl, i_node, neg, seq_d1, seq_d2, labels, domain_id)
+        if eng.dr:
+            eng.dr_mode = int(dr_objective)
+            if ob_label is None:
+                if eng.dr_mode == 1:
+                    raise ValueError("dr_objective 1 (loss_dr_r) needs ob_label (train_sr_dr.py:372)")
+                ob_label = torch.zeros(B, dtype=torch.int64, device=seq_d1.device)
+        eng.load_batch(pl, i_node, neg, seq_d1, seq_d2, labels, domain_id, ob_label if eng.dr else None)
         if exchange is not None and exchange.world > 1:
             if use_graph and getattr(pl, "graph_local", None) is None:
                 eng.capture_local_grads(pl)
             eng.train_step_dp(pl, exchange, use_graph=use_graph)
         elif use_graph:
-            if getattr(pl, "graph", None) is None:
+            if not eng.has_graph(pl):
                 eng.capture_train_step(pl)
             eng.replay_train_step(pl)
         else:
             eng.enqueue_train_step(pl)
         torch.cuda.current_stream().wait_stream(eng.stream)
         self._last_plan = pl
-        return pl.loss
+        return pl.dr_losses if eng.dr else pl.loss
 
     def flush(self) -> None:
         """Bring lazily-updated table rows up to date (call before eval / state_dict() / checkpoints)."""

@@ -161,7 +161,14 @@ int amid_scorer_fwd_f32(const float* u, const float* items, const float* w1, con
 long long amid_scorer_part_floats(int D, int hid);
 int amid_scorer_bwd_f32(const float* u, const float* items, const float* w1, const float* b1, const float* w2, const float* b2,
                         const float* p1, const float* p2, const float* dp1, const float* dp2, int B, int NI, int D, int hid, float* du,
-                        float* ditems, float* part /* [B][amid_scorer_part_floats] */, void* stream);
+                        float* ditems, float* part /* [B][amid_scorer_part_floats] */, int accumulate /* 1: du, ditems += */, void* stream);
+/* doubly-robust objectives (next-4 of SURVEY.md 8(f)); replaces: train_sr_dr.py:216-221 (mode 0: loss_cls + dr_e_w * loss_dr_e) and
+ * :392-394 (mode 1: loss_dr_r, needs ob_label [B]) and their autograd down to the three heads' outputs.  p / ips / g and the gradient
+ * outputs are HOST arrays of 2 device pointers ([B, NI] each: domain-1 head, domain-2 head); loss_part [B][3] = per-row partials of
+ * (loss_cls, loss_dr_e, loss_dr_r), already divided by B * NI */
+int amid_dr_loss_f32(const float* const* p, const float* const* ips, const float* const* g, const float* labels,
+                     const long long* domain_id, const long long* ob_label, int mode, float dr_e_w, int B, int NI, float* const* dp,
+                     float* const* dips, float* const* dg, float* loss_part, void* stream);
 int amid_sum_vector_f32(const float* v, int n, float* out, void* stream);
 /* fused head, one workgroup per batch row: last LayerNorm + mean over T (model_seq.py:385, :432-434) -> predictModule
  * (model_seq.py:40-54) -> masked BCE partials + dLoss/dp (train_sr.py:203-212); ln_w / ln_b: host arrays of 2 device pointers

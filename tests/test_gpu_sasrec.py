@@ -325,3 +325,106 @@ def test_itc_vs_oracle_and_train_steps(D, train):
     assert l0[2] < l0[0]
     with pytest.raises(ValueError):
         eng.plan(Bn + 1, T, 2, need_grad=True)
+
+
+# ---------------------------------------------------------------------------- isDR (next-4 of SURVEY.md section 8(f))
+def dr_grads_check(tag, eng, pl, grads, tol):
+    bad = []
+    for name in eng.dense.slots:
+        got = eng.dense.view(name, eng.dense.grad)
+        want = grads[name]
+        if name.endswith("in_proj_bias"):
+            Dd = got.numel() // 3
+            got, want = got.cpu().clone(), want.clone()
+            got[Dd:2 * Dd] = 0; want[Dd:2 * Dd] = 0
+        e = relmax(got, want) if float(want.abs().max()) > 1e-12 else float(torch.as_tensor(got).abs().max().cpu())
+        log(f"{tag} grad {name:50s} relmax {e:.3e}")
+        if not e < tol:
+            bad.append((name, e))
+    assert not bad, bad
+    tg = dense_table_grad(eng, pl)
+    assert relmax(tg, grads["item_emb_layer.emb_item.weight"]) < tol
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_dr_golden_outputs_losses_grads(mode):
+    """SASRec(isDR=True, isItC=True) against the reference: six outputs, the three losses, gradients of objective `mode` (g11)."""
+    from amid_amd.engine import SasrecEngine
+    z, P, B, _ = load_golden("g11_sasrec_dr.npz")
+    B = dict(B)
+    Bn, T = B["seq_d1"].shape
+    eng = SasrecEngine(P["item_emb_layer.emb_item.weight"].shape[0], 64, T, 16, itc_bs=Bn, itc_threshold=float(z["threshold2"]), dr=True,
+                       dr_e_w=float(z["dr_e_w"]))
+    eng.load_state_dict(P)
+    eng.dr_mode = mode
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    cu = {k: v.cuda() for k, v in B.items()}
+    eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], torch.from_numpy(z["labels"]).cuda(), cu["domain_id"],
+                   torch.from_numpy(z["ob_label"]).cuda())
+    eng.enqueue_prepare(pl, sparse=True)
+    eng.enqueue_forward(pl, train=False, with_loss=True)
+    eng.enqueue_backward(pl, train=False)
+    eng.sync()
+    for got, name in ((pl.p1, "p1"), (pl.p2, "p2"), (pl.ips1, "ips1"), (pl.ips2, "ips2"), (pl.g1, "g1"), (pl.g2, "g2")):
+        assert relmax(got, z[name]) < 1e-4, name
+    lc, le, lr_ = (float(v) for v in pl.dr_losses.cpu())
+    assert abs(lc - float(z["loss_cls"])) < 1e-5 and abs(le - float(z["loss_dr_e"])) < 1e-5 and abs(lr_ - float(z["loss_dr_r"])) < 1e-5
+    pre = "GE/" if mode == 0 else "GR/"
+    G = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+    dr_grads_check(f"golden g11 dr mode {mode}", eng, pl, G, 1e-3)
+
+
+def test_dr_two_optimizers_track_oracle():
+    """The doubly-robust epoch: steps of objective 0 under Adam(lr), then steps of objective 1 under a second Adam(lr * lr2) with its
+    own moments (train_sr_dr.py:668-669), dropout on, lazy table rows, graph replay -- against two DenseAdam instances in the oracle."""
+    from amid_amd.engine import SasrecEngine
+    D, T, Bn, hid, n_items, ts2, w, lr, lr2 = 64, 20, 8, 16, 300, 0.15, 0.1, 1e-3, 0.5
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid, itc_bs=Bn, dr=True), seed=77)
+    for d in (1, 2):
+        P[f"sac{d}.last_layernorm.weight"] *= 0.3
+    seed = 5
+    eng = SasrecEngine(n_items, D, T, hid, lr=lr, seed=seed, itc_bs=Bn, itc_threshold=ts2, dr=True, dr_e_w=w)
+    eng.load_state_dict(P)
+    Po = {k: v.clone() for k, v in P.items()}
+    opts = [orc.DenseAdam(Po, lr=lr), orc.DenseAdam(Po, lr=lr * lr2)]
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    g = torch.Generator().manual_seed(1)
+
+    def batch(t):
+        b = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=600 + t)
+        b["seq_d1"] = torch.randint(1, 120, (Bn, T), generator=g)
+        b["seq_d2"] = torch.randint(120, n_items - 1, (Bn, T), generator=g)
+        b["ob_label"] = (torch.rand(Bn, generator=g) < 0.6).long()
+        return b
+
+    steps = {0: 0, 1: 0}
+    for epoch in range(2):
+        for mode in (0, 1):
+            eng.select_optimizer(mode, lr=lr if mode == 0 else lr * lr2)
+            eng.dr_mode = mode
+            for _ in range(3):
+                steps[mode] += 1
+                b = batch(10 * epoch + 5 * mode + steps[mode])
+                bank_seed = seed + 0x9E3779B9 * mode
+                masks = orc.philox_masks_sasrec(Bn, T, D, seed=bank_seed, step=steps[mode])
+                info, _, grads = orc.dr_loss_and_grads(Po, b, "e" if mode == 0 else "r", masks, dr_e_w=w, isItC=True, threshold2=ts2)
+                opts[mode].step(Po, grads)
+                cu = {k: v.cuda() for k, v in b.items()}
+                eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"], cu["ob_label"])
+                if not eng.has_graph(pl):
+                    eng.capture_train_step(pl)
+                eng.replay_train_step(pl)
+                eng.sync()
+                got = [float(v) for v in pl.dr_losses.cpu()]
+                log(f"dr traj epoch {epoch} mode {mode} step {steps[mode]}: gpu {got} oracle cls {float(info['loss_cls']):.6f} e {float(info['loss_dr_e']):.6f}")
+                assert abs(got[0] - float(info["loss_cls"])) < 5e-5 and abs(got[1] - float(info["loss_dr_e"])) < 5e-5
+                if mode == 1:
+                    assert abs(got[2] - float(info["loss"])) < 5e-5
+    eng.flush_table(); eng.sync()
+    sd = eng.state_dict()
+    for k, v in Po.items():
+        d = (sd[k].cpu() - v).abs()
+        if k.endswith("in_proj_bias"):
+            Dd = v.numel() // 3
+            d = torch.cat((d[:Dd], d[2 * Dd:]))
+        assert float(d.max()) < 3e-4, (k, float(d.max()))
