@@ -38,6 +38,9 @@ class DualDomainSeqDataset:
         raw2 = [json.loads(s) for s in df["seq_d2"].tolist()]
         self.domain_id = np.asarray(df["domain_id"].tolist(), dtype=np.int64)
         self.user_nodes = np.asarray(df["user_id"].tolist(), dtype=np.int64)
+        # observation label of the doubly-robust trainer's second loader (DualDomainSeqDatasetDR, dataset_seq.py:453); zeros if absent
+        self.ob_label = (np.asarray(df["ob_label"].tolist(), dtype=np.int64) if "ob_label" in df.columns
+                         else np.zeros(len(df), dtype=np.int64))
         self.pool = [np.array(sorted({i for s in raw1 for i in s}), dtype=np.int64),
                      np.array(sorted({i for s in raw2 for i in s}), dtype=np.int64)]      # dataset_seq.py:141-142
         N, T = len(raw1), seq_len
@@ -81,7 +84,8 @@ class DeviceBatches:
         self.rank, self.world = rank, world
         to = lambda a: torch.from_numpy(a).to(self.device)       # noqa: E731
         self.t = dict(user_node=to(ds.user_nodes), i_node=to(ds.i_node), seq_d1=to(ds.seq_d1), seq_d2=to(ds.seq_d2),
-                      domain_id=to(ds.domain_id), overlap_label=to(ds.overlap_label), long_tail_mask_d1=to(ds.long_tail_mask_d1),
+                      domain_id=to(ds.domain_id), overlap_label=to(ds.overlap_label), ob_label=to(ds.ob_label),
+                      long_tail_mask_d1=to(ds.long_tail_mask_d1),
                       long_tail_mask_d2=to(ds.long_tail_mask_d2))
         self.gen = torch.Generator().manual_seed(seed)
         # negative sampling state on the device: the two item pools and every row's own items (dataset_seq.py:141-142, :188/:206)

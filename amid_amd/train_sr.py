@@ -80,8 +80,9 @@ def test(model, args, val_batches):
     stats = AverageMeter("loss", "loss_cls")
     ranks, ranks_raw, doms, ovs, losses = [], [], [], [], []
     for b in val_batches:
-        p1, p2 = model(b["user_node"], b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["long_tail_mask_d1"],
-                       b["long_tail_mask_d2"], False)
+        outs = model(b["user_node"], b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["long_tail_mask_d1"],
+                     b["long_tail_mask_d2"], False)
+        p1, p2 = outs[0], outs[1]                                                         # isDR models return six outputs
         p1, p2 = p1.reshape(len(b["i_node"]), -1), p2.reshape(len(b["i_node"]), -1)
         y = b["label"]
         m2 = b["domain_id"].float().unsqueeze(1)

@@ -31,6 +31,7 @@ def init_logger(log_dir: str, log_file: str) -> None:
     """utils.py:282-294: root logger to stdout + <log_dir>/<log_file>."""
     fmt = r"[%(asctime)s] %(message)s"
     logging.basicConfig(level=logging.INFO, datefmt=r"%Y/%m/%d %H:%M:%S", format=fmt)
+    logging.getLogger().setLevel(logging.INFO)          # basicConfig is a no-op when a host application already installed handlers
     d = Path(log_dir)
     d.mkdir(parents=True, exist_ok=True)
     fh = logging.FileHandler(str(d / log_file))

@@ -179,15 +179,15 @@ def test_unbuilt_models_fail_loudly():
         model_seq.BERT4Rec(10, 64, 100, 64, 20, 32, 4, False, False, 0.5, 0.5)
 
 
-def _write_csv(path, n, rng, lo1, hi1, lo2, hi2):
-    rows = ["user_id,seq_d1,seq_d2,domain_id"]
+def _write_csv(path, n, rng, lo1, hi1, lo2, hi2, ob_label=False):
+    rows = ["user_id,seq_d1,seq_d2,domain_id" + (",ob_label" if ob_label else "")]
     for u in range(n):
         dom = int(rng.random() < 0.5)
         l1 = int(rng.integers(1 if dom == 0 else 0, 9))
         l2 = int(rng.integers(1 if dom == 1 else 0, 9))
         s1 = [int(x) for x in rng.integers(lo1, hi1, l1)]
         s2 = [int(x) for x in rng.integers(lo2, hi2, l2)]
-        rows.append(f'{u},"{json.dumps(s1)}","{json.dumps(s2)}",{dom}')
+        rows.append(f'{u},"{json.dumps(s1)}","{json.dumps(s2)}",{dom}' + (f",{int(rng.random() < 0.6)}" if ob_label else ""))
     with open(path, "w") as f:
         f.write("\n".join(rows) + "\n")
 
@@ -263,3 +263,57 @@ def test_device_negative_sampling(tmp_path):
     assert len(freq) == elig and abs(freq.sum() - 200 * 50) < 1e-9
     expect = 200 * 50 / elig
     assert freq.min() > 0.3 * expect and freq.max() < 2.0 * expect
+
+
+def test_train_sr_dr_cli_end_to_end(tmp_path):
+    """run.sh's command line (train_sr_dr.py, --isItC True, doubly-robust heads, two optimizers) on synthetic CSVs with the
+    reference's column layout (the second loader's CSV carries ob_label)."""
+    from amid_amd.train_sr_dr import main
+    rng = np.random.default_rng(2)
+    root = tmp_path / "mybank_dataset"
+    root.mkdir()
+    _write_csv(root / "toy_train25.csv", 200, rng, 1, 400, 400, 900)
+    _write_csv(root / "toy_train25_DR.csv", 160, rng, 1, 400, 400, 900, ob_label=True)
+    _write_csv(root / "toy_test.csv", 64, rng, 1, 400, 400, 900)
+    summary = main(["--data_root", str(tmp_path), "-ds", "mybank", "-dm", "toy", "--overlap_ratio", "0.25", "--model", "sasrec", "--overlap", "True",
+                    "--isItC", "True", "--ts2", "0.4", "--neg_nums", "19", "--lr2", "0.01", "--dr_e_w", "0.01", "--bs", "32", "--seq_len", "20",
+                    "--emb_dim", "64", "--hid_dim", "16", "--epoch", "2", "--seeds", "1", "-md", str(tmp_path / "model")])
+    best = summary[0]
+    assert ("d1", "HR@10") in best and ("d2_ov", "MRR") in best
+    assert all((0.0 <= v <= 1.0) or np.isnan(v) for v in best.values())
+    log = (tmp_path / "model" / "log0.txt").read_text()
+    assert "train loss_dr_r" in log and "dr_e loss" in log
+
+
+def test_sasrec_dr_module_reference_loop():
+    """SASRec(isDR=True) through the reference's own loop shape: six outputs, loss from train_sr_dr.py:216-221 written with torch
+    ops, loss.backward(), torch.optim.Adam -- one step must match the oracle's dense Adam."""
+    from amid_amd.model_seq import SASRec
+    D, T, hid, n_items, bs, w = 64, 20, 16, 200, 8, 0.1
+    m = SASRec(10, D, n_items, D, T, hid, bs, False, False, 0.5, 0.5, isDR=True).cuda()
+    assert set(m.state_dict().keys()) == set(orc.sasrec_param_shapes(n_items, D, T, hid, dr=True))
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    batch = orc.synthetic_batch(bs, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=4)
+    cu = {k: v.cuda() for k, v in batch.items()}
+    m.eval()                                   # dropout off on both sides
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    p1, p2, i1, i2, g1, g2 = m(None, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], None, None)
+    crit = torch.nn.BCELoss(reduction="none")
+    y = cu["label"]
+    m1 = (1 - cu["domain_id"]).unsqueeze(1).float()
+    m2 = cu["domain_id"].unsqueeze(1).float()
+    loss_cls = torch.mean(crit(p1, y) * m1 + crit(p2, y) * m2)
+    loss_dr_e = torch.mean((crit(p1, y) - g1) ** 2 / i1 * m1 + (crit(p2, y) - g2) ** 2 / i2 * m2)
+    (loss_cls + w * loss_dr_e).backward()
+    opt.step()
+    Po = {k: v.clone() for k, v in P.items()}
+    info, outs, grads = orc.dr_loss_and_grads(Po, batch, "e", None, dr_e_w=w)
+    orc.DenseAdam(Po, lr=1e-3).step(Po, grads)
+    assert abs(float(loss_cls.detach()) - float(info["loss_cls"])) < 5e-5 and abs(float(loss_dr_e.detach()) - float(info["loss_dr_e"])) < 5e-5
+    sd = m.state_dict()
+    for k, v in Po.items():
+        dlt = (sd[k].cpu() - v).abs()
+        if k.endswith("in_proj_bias"):
+            Dd = v.numel() // 3
+            dlt = torch.cat((dlt[:Dd], dlt[2 * Dd:]))
+        assert float(dlt.max()) < 2e-4, k
