@@ -428,3 +428,36 @@ def test_dr_two_optimizers_track_oracle():
             Dd = v.numel() // 3
             d = torch.cat((d[:Dd], d[2 * Dd:]))
         assert float(d.max()) < 3e-4, (k, float(d.max()))
+
+
+# ---------------------------------------------------------------------------- edge shapes (ragged / empty / maximum inputs)
+@pytest.mark.parametrize("Bn,T,D,neg", [(1, 50, 128, 1), (3, 7, 64, 4), (5, 64, 128, 1), (4, 70, 64, 2), (2, 1, 64, 1), (512, 50, 128, 1),
+                                         (16, 20, 128, 999)])
+def test_edge_shapes_forward_backward_vs_oracle(Bn, T, D, neg):
+    """One row, odd small shapes, T at the matrix-core attention limit (64) and beyond it (70: general kernel), a single time
+    step, the cfg 3 batch (512 x 50) and the evaluation fan-out of run.sh (999 negatives); some rows entirely padding (an empty
+    history in one or both domains) and some with no padding at all."""
+    hid, n_items = 16, 700
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=Bn + T)
+    batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=neg, seed=Bn * 7 + T, mean_len=min(5.0, T))
+    batch["seq_d1"][0] = n_items - 1                          # empty history in domain 1
+    if Bn > 1:
+        batch["seq_d2"][1] = n_items - 1                      # empty history in domain 2
+        batch["seq_d1"][1] = torch.arange(1, T + 1)           # full-length history
+    if Bn > 2:
+        batch["seq_d1"][2] = n_items - 1
+        batch["seq_d2"][2] = n_items - 1                      # nothing at all
+    eng = make_engine(P, T, seed=3)
+    pl = run_forward(eng, batch, train=False, with_loss=True)
+    p1, p2 = orc.sasrec_forward(P, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"])
+    assert relmax(pl.p1, p1) < 3e-5 and relmax(pl.p2, p2) < 3e-5
+    if Bn <= 16 and neg <= 4:
+        loss, _, grads = orc.loss_and_grads("sasrec", P, batch, None)
+        eng.enqueue_backward(pl, train=False)
+        eng.sync()
+        assert abs(float(pl.loss.item()) - float(loss)) < 1e-5
+        taps = {}
+        orc.sasrec_forward({k: v.double() for k, v in P.items()}, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], None, taps)
+        margin = min(taps[s][f"relu_margin{l}"] for s in ("sac1", "sac2") for l in (0, 1))
+        tol = 3e-4 if margin > 2e-5 else 5e-2
+        grads_check(f"edge B={Bn} T={T} D={D}", eng, pl, grads, tol, 3e-4 if margin > 2e-5 else 1e-2)
