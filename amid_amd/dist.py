@@ -42,7 +42,9 @@ class MergeBackend(Protocol):
 
 
 class SparseDenseExchange:
-    def __init__(self, backend: MergeBackend, group=None, host_staging: bool = False):
+    def __init__(self, backend: MergeBackend, group=None, host_staging: bool = False, always: bool = False):
+        """always: run the collectives and the merge even in a world of one (profiling the exchange path on a single GPU)."""
+        self.always = always
         self.backend = backend
         self.group = group
         # host_staging: move collective payloads through pinned host memory (for process groups without device
@@ -57,7 +59,7 @@ class SparseDenseExchange:
         return 1.0 / self.world
 
     def all_reduce_dense(self, flat_grad: torch.Tensor) -> None:
-        if self.world > 1:
+        if self.world > 1 or self.always:
             if self.host_staging and flat_grad.is_cuda:
                 h = flat_grad.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -72,7 +74,7 @@ class SparseDenseExchange:
         umax = the world's largest per-rank unique count for THIS step when the host already knows it (the data pipeline can
         count a batch's unique ids while packing it and max-reduce the counts ahead of time, as bench.py does): the exchange
         then needs no device -> host synchronisation.  With umax=None it costs one small host sync per step."""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return uniq_ids, uniq_rows, n_uniq
         if umax is None:
             nmax = n_uniq.cpu() if self.host_staging else n_uniq.clone()

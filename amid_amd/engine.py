@@ -735,7 +735,7 @@ class SasrecEngine:
             self.grad_scale = exchange.grad_scale
             exchange.all_reduce_dense(self.dense.grad)
             merged = exchange.exchange_sparse(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax=umax)
-            self.enqueue_optimizer(pl, sparse=merged if exchange.world > 1 else None)
+            self.enqueue_optimizer(pl, sparse=merged if (exchange.world > 1 or getattr(exchange, "always", False)) else None)
 
     # ------------------------------------------------------------------ graph replay
     def capture_train_step(self, pl: SasrecPlan) -> None:

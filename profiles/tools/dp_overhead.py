@@ -1,0 +1,36 @@
+"""Cost of the data-parallel code path on ONE GPU: a world of one RCCL rank runs the full per-step exchange (dense all-reduce,
+sparse pad + all-gather, sorted-list merge, Adam on the merged lists) after the local-gradients graph, against the single-GPU
+whole-step graph.  The collectives of a 1-rank world cost their launch latency only, so the difference is the host + merge
+overhead a multi-GPU step pays on top of the wire time.   python profiles/tools/dp_overhead.py"""
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+import torch, torch.distributed as dist
+import bench
+from amid_amd.dist import SparseDenseExchange
+from amid_amd.engine import SasrecEngine
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+eng = SasrecEngine(bench.N_ROWS, bench.D, bench.T, bench.HID, lr=5e-4, seed=1)
+bench.init_params(eng, 0)
+pl = eng.plan(bench.B, bench.T, 2, True)
+gen = torch.Generator().manual_seed(1)
+pool, cnt = [], []
+for _ in range(30):
+    b = bench.synth_batch(gen, "cuda")
+    pool.append(eng.pack_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"]))
+    cnt.append(int(torch.unique(torch.cat([b[k].reshape(-1) for k in ("i_node", "neg_samples", "seq_d1", "seq_d2")])).numel()))
+ex = SparseDenseExchange(eng.merge_backend(pl.shape.n_idx), always=True)
+eng.load_packed(pl, pool[0]); eng.capture_local_grads(pl)
+def run(n, umax_known):
+    eng.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(n):
+        eng.load_packed(pl, pool[i % 30])
+        eng.train_step_dp(pl, ex, use_graph=True, umax=cnt[i % 30] if umax_known else None)
+    eng.sync(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+run(20, True)
+print("dp path, host knows umax : %.4f ms/step" % run(200, True))
+print("dp path, host sync / step: %.4f ms/step" % run(200, False))
+dist.destroy_process_group()
