@@ -200,12 +200,15 @@ __global__ __launch_bounds__(256) void heads_write_kernel(const int* __restrict_
 // key x is i + sum over the other lists of (# keys < x), or (# keys <= x) for lists of lower rank -- ties go in rank order, so the
 // result equals a stable sort of the concatenation.  All binary searches of a thread advance in lock-step (independent loads).
 constexpr int MERGE_MAX_WORLD = 16;
-__global__ __launch_bounds__(256) void merge_rank_kernel(const int* __restrict__ keys, int world, int len, int* __restrict__ keys_sorted,
+// key_stride: distance (in ints) between two ranks' lists; the merged position table holds row_base + r * row_stride + i for
+// entry (r, i), i.e. the row of that entry's gradient in whatever layout the gathered buffer has (packed exchange, dist.py).
+__global__ __launch_bounds__(256) void merge_rank_kernel(const int* __restrict__ keys, int world, int len, long long key_stride,
+                                                         int row_base, int row_stride, int* __restrict__ keys_sorted,
                                                          int* __restrict__ pos_sorted) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= world * len) return;
     const int r = e / len, i = e - r * len;
-    const int x = keys[e];
+    const int x = keys[r * key_stride + i];
     int lo[MERGE_MAX_WORLD], hi[MERGE_MAX_WORLD];
 #pragma unroll
     for (int q = 0; q < MERGE_MAX_WORLD; ++q) { lo[q] = 0; hi[q] = len; }
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void merge_rank_kernel(const int* __restrict__
         for (int q = 0; q < MERGE_MAX_WORLD; ++q) {
             if (q < world && q != r && lo[q] < hi[q]) {
                 const int mid = (lo[q] + hi[q]) >> 1;
-                const int v = keys[q * len + mid];
+                const int v = keys[q * key_stride + mid];
                 const bool left = (q < r) ? (v <= x) : (v < x);      // lower ranks: upper bound; higher ranks: lower bound
                 if (left) lo[q] = mid + 1; else hi[q] = mid;
             }
@@ -226,14 +229,14 @@ __global__ __launch_bounds__(256) void merge_rank_kernel(const int* __restrict__
         if (q < world && q != r) {
             while (lo[q] < hi[q]) {                                  // (defensive: the loop above already closed it)
                 const int mid = (lo[q] + hi[q]) >> 1;
-                const int v = keys[q * len + mid];
+                const int v = keys[q * key_stride + mid];
                 const bool left = (q < r) ? (v <= x) : (v < x);
                 if (left) lo[q] = mid + 1; else hi[q] = mid;
             }
             p += lo[q];
         }
     keys_sorted[p] = x;
-    pos_sorted[p] = e;
+    pos_sorted[p] = row_base + r * row_stride + i;
 }
 
 }  // namespace amid
@@ -290,17 +293,18 @@ extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows,
 // Data-parallel merge (amid_amd/dist.py): `world` lists of `len` keys, each non-decreasing (a rank's unique ids in ascending order,
 // then `sentinel` padding with sentinel > every id) -> the same outputs as amid_sort_unique_i32 on the concatenation, in 4 launches
 // instead of a full radix sort; the sentinel run, if any, is left out of n_uniq.  Workspace: amid_sort_unique_workspace_bytes(world*len).
-extern "C" int amid_merge_sorted_lists_i32(const int* keys, int world, int len, int sentinel, void* workspace, int* pos_sorted,
-                                           int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq, void* stream) {
+extern "C" int amid_merge_sorted_lists_i32(const int* keys, int world, int len, long long key_stride, int row_base, int row_stride,
+                                           int sentinel, void* workspace, int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of,
+                                           int* n_uniq, void* stream) {
     AMID_CHECK_ARG(keys && workspace && pos_sorted && uniq_ids && seg_off && seg_of && n_uniq && world > 0 && world <= MERGE_MAX_WORLD &&
-                   len > 0);
+                   len > 0 && key_stride >= len && row_base >= 0 && row_stride >= len);
     hipStream_t s = (hipStream_t)stream;
     const int n = world * len;
     char* ws = (char*)workspace;
     const size_t kb = align256((size_t)n * 4);
     int* keys_sorted = (int*)ws;
     int* blk_heads = (int*)(ws + 4 * kb + align256((size_t)256 * sort_nblk(n) * 4));
-    merge_rank_kernel<<<(n + 255) / 256, 256, 0, s>>>(keys, world, len, keys_sorted, pos_sorted);
+    merge_rank_kernel<<<(n + 255) / 256, 256, 0, s>>>(keys, world, len, key_stride, row_base, row_stride, keys_sorted, pos_sorted);
     const int hblk = (n + 255) / 256;
     heads_count_kernel<<<hblk, 256, 0, s>>>(keys_sorted, n, blk_heads);
     heads_scan_kernel<<<1, 1024, 0, s>>>(blk_heads, hblk, n_uniq, seg_off, n, keys_sorted, sentinel);

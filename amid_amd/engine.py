@@ -721,21 +721,60 @@ class SasrecEngine:
         pl.graph_local = out.value
 
     def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False, umax: Optional[int] = None) -> None:
-        """One data-parallel step: local grads -> dense all-reduce + sparse all-gather/merge -> Adam.
-        umax: the world's largest unique-row count of this step if the host knows it (no host sync then, see dist.py)."""
-        if self.itc_bs and exchange.world > 1:
+        """One data-parallel step: local grads -> dense all-reduce + ONE sparse all-gather -> merge -> Adam.
+        umax: a bound on the world's largest unique-row count of this step if the host knows one (no host sync then, see
+        dist.py).  With use_graph and a known umax the step is graph A (local gradients + packing of this rank's chunk), the
+        two collectives, graph B (merge + Adam): four host calls; the pair of graphs is captured per distinct umax, so callers
+        should pass a bucketed bound (bench.py: the pool's maximum)."""
+        if self.itc_bs and exchange.active:
             raise NotImplementedError("isItC couples the rows of a batch (softmax and Linear(bs, 1) over the batch, model_seq.py:490-494): "
                                       "data-parallel sharding would change the model; train isItC on one GPU")
+        L = lib()
         with torch.cuda.stream(self.stream):
+            self.grad_scale = exchange.grad_scale
+            fast = use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")
+            pair = getattr(pl, "dp_graphs", {}).get(umax) if fast else None
+            if pair is not None:
+                be = exchange.backend
+                L.call("amid_graph_launch", pair[0], self.s)
+                self.step += 1
+                exchange.all_reduce_dense(self.dense.grad)
+                exchange.all_gather_packed(pair[2], pair[3])
+                L.call("amid_graph_launch", pair[1], self.s)
+                return
             if use_graph:
-                lib().call("amid_graph_launch", pl.graph_local, self.s)
+                L.call("amid_graph_launch", pl.graph_local, self.s)
                 self.step += 1
             else:
                 self.enqueue_local_grads(pl)
-            self.grad_scale = exchange.grad_scale
             exchange.all_reduce_dense(self.dense.grad)
             merged = exchange.exchange_sparse(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax=umax)
-            self.enqueue_optimizer(pl, sparse=merged if (exchange.world > 1 or getattr(exchange, "always", False)) else None)
+            self.enqueue_optimizer(pl, sparse=merged if exchange.active else None)
+        if fast:                               # this step ran eagerly (it also warmed every kernel up); capture the pair for the next ones
+            self._capture_dp_pair(pl, exchange, int(umax))
+
+    def _capture_dp_pair(self, pl: SasrecPlan, exchange, umax: int) -> None:
+        L, be = lib(), exchange.backend
+        self.sync()
+        step0 = self.step
+        graphs = []
+        for part in (0, 1):
+            L.call("amid_graph_capture_begin", self.s)
+            try:
+                if part == 0:
+                    self.enqueue_local_grads(pl)
+                    send = be.pad_packed(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax)
+                else:
+                    recv = be.gather_buffer(exchange.world, umax)
+                    self.enqueue_optimizer(pl, sparse=be.merge_packed(recv, exchange.world, umax))
+            finally:
+                out = ctypes.c_void_p()
+                L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
+            graphs.append(out.value)
+        self.step = step0                      # capture does not execute
+        if not hasattr(pl, "dp_graphs"):
+            pl.dp_graphs = {}
+        pl.dp_graphs[umax] = (graphs[0], graphs[1], send, recv)
 
     # ------------------------------------------------------------------ graph replay
     def capture_train_step(self, pl: SasrecPlan) -> None:
@@ -830,38 +869,51 @@ class HipMergeBackend:
         self.n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
         self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", self.cap, D), dtype=torch.uint8, device=dev)
         self.uniq_rows = torch.empty(self.cap, D, dtype=torch.float32, device=dev)
-        # exchange buffers: this rank's padded lists and the world's gathered lists (sliced per step, never reallocated)
-        self.send_ids = torch.zeros(self.cap, dtype=torch.int32, device=dev)
-        self.send_rows = torch.zeros(self.cap, D, dtype=torch.float32, device=dev)
-        self.all_ids = torch.zeros(self.cap, dtype=torch.int32, device=dev)
-        self.all_rows = torch.zeros(self.cap, D, dtype=torch.float32, device=dev)
+        # exchange buffers: this rank's packed chunk and the world's gathered chunks (sliced per step, never reallocated);
+        # capacity counts entries, so the id rows of the packed layout come on top (dist.packed_rows)
+        self.send = torch.zeros((self.cap + (self.cap + D - 1) // D + 16) * D, dtype=torch.float32, device=dev)
+        self.all = torch.zeros((self.cap + (self.cap + D - 1) // D + 16 * 16) * D, dtype=torch.float32, device=dev)
         torch.cuda.synchronize(dev)
 
-    def pad(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, umax: int):
-        # sentinel padding (one past the last table row) keeps every rank's list sorted, so merge() is a merge, not a sort
-        lib().call("amid_sparse_pad_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), umax, self.eng.D,
-                   self.eng.n_rows, self.send_ids.data_ptr(), self.send_rows.data_ptr(), self.eng.s)
-        return self.send_ids[:umax], self.send_rows[:umax]
+    def pad_packed(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, umax: int) -> torch.Tensor:
+        from .dist import packed_rows
+        D = self.eng.D
+        id_rows, rows = packed_rows(umax, D)
+        send = self.send[: rows * D]
+        # sentinel padding (one past the last table row) keeps every rank's list sorted, so merge_packed() is a merge, not a sort
+        lib().call("amid_sparse_pad_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), umax, D, self.eng.n_rows,
+                   send.data_ptr(), send.data_ptr() + 4 * id_rows * D, self.eng.s)
+        return send
 
-    def gather_buffers(self, n: int):
-        if n > self.cap:
-            raise ValueError(f"gather of {n} entries exceeds the backend capacity {self.cap}")
-        return self.all_ids[:n], self.all_rows[:n]
+    def gather_buffer(self, world: int, umax: int) -> torch.Tensor:
+        from .dist import packed_rows
+        n = world * packed_rows(umax, self.eng.D)[1] * self.eng.D
+        if n > self.all.numel() or world * umax > self.cap:
+            raise ValueError(f"gather of {world} x {umax} entries exceeds the backend capacity {self.cap}")
+        return self.all[:n]
 
-    def merge(self, ids: torch.Tensor, rows: torch.Tensor, world: int = 0):
-        """world > 0: `ids` is `world` equal-length lists produced by pad() (sorted, sentinel-padded) -> 4-launch stable merge;
-        world == 0: arbitrary ids -> full radix sort."""
+    def merge_packed(self, gathered: torch.Tensor, world: int, umax: int):
+        """`world` packed chunks (sorted, sentinel-padded ids + rows) -> 4-launch stable merge + segment reduce."""
+        from .dist import packed_rows
+        L, eng = lib(), self.eng
+        D = eng.D
+        id_rows, rows = packed_rows(umax, D)
+        n = world * umax
+        L.call("amid_merge_sorted_lists_i32", gathered.data_ptr(), world, umax, rows * D, id_rows, rows, eng.n_rows, self.sort_ws.data_ptr(),
+               self.pos_sorted.data_ptr(), self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
+               self.n_uniq.data_ptr(), eng.s)
+        L.call("amid_embgrad_segreduce_f32", gathered.data_ptr(), self.pos_sorted.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
+               n, D, self.seg_ws.data_ptr(), self.uniq_rows.data_ptr(), eng.s)
+        return self.uniq_ids[:n], self.uniq_rows[:n], self.n_uniq
+
+    def merge(self, ids: torch.Tensor, rows: torch.Tensor):
+        """Arbitrary (unsorted) ids -> full radix sort + segment reduce."""
         L, eng = lib(), self.eng
         n = ids.numel()
         if n > self.cap:
             raise ValueError(f"merge of {n} entries exceeds the backend capacity {self.cap}")
-        if world > 0:
-            L.call("amid_merge_sorted_lists_i32", ids.data_ptr(), world, n // world, eng.n_rows, self.sort_ws.data_ptr(),
-                   self.pos_sorted.data_ptr(), self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
-                   self.n_uniq.data_ptr(), eng.s)
-        else:
-            L.call("amid_sort_unique_i32", ids.data_ptr(), n, eng.n_rows, self.sort_ws.data_ptr(), self.pos_sorted.data_ptr(),
-                   self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(), self.n_uniq.data_ptr(), eng.s)
+        L.call("amid_sort_unique_i32", ids.data_ptr(), n, eng.n_rows, self.sort_ws.data_ptr(), self.pos_sorted.data_ptr(),
+               self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(), self.n_uniq.data_ptr(), eng.s)
         L.call("amid_embgrad_segreduce_f32", rows.data_ptr(), self.pos_sorted.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
                n, eng.D, self.seg_ws.data_ptr(), self.uniq_rows.data_ptr(), eng.s)
         return self.uniq_ids[:n], self.uniq_rows[:n], self.n_uniq

@@ -246,6 +246,8 @@ def main():
         cnt = torch.tensor(uniq_counts, dtype=torch.int64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
         umax_pool = [int(v) for v in cnt.tolist()]
+        # one padded length for the whole run (the pool's largest count, rounded up): the graph pair of the exchange is captured once
+        umax_pool = [(max(umax_pool) + 255) // 256 * 256] * len(umax_pool)
 
     def load(i):
         eng.load_packed(pl, pool[i % n_pool])

@@ -78,13 +78,15 @@ int amid_embgrad_segreduce_f32(const float* grad_rows /* [n_idx, D] */, const in
 /* data-parallel exchange helpers (no reference counterpart: the reference is single-GPU, train_sr.py:473).
  * pad: a rank's segment-reduced (ids, rows) padded to n_out entries with (pad_id, zero row) pairs (pad_id < 0: repeat the first id);
  * n_uniq is a device scalar.
- * merge: `world` (<= 16) lists of `len` non-decreasing keys (ascending unique ids, then `sentinel` > every id as padding) merged
- * stably in rank order -> the outputs of amid_sort_unique_i32 on the concatenation; the sentinel run is left out of n_uniq.
+ * merge: `world` (<= 16) lists of `len` non-decreasing keys (ascending unique ids, then `sentinel` > every id as padding), rank r's
+ * list at keys + r * key_stride, merged stably in rank order -> the outputs of amid_sort_unique_i32 on the concatenation, except that
+ * pos_sorted holds row_base + r * row_stride + i for entry (r, i): the row of its gradient in the caller's gathered buffer (packed
+ * exchange: ids and rows of a rank travel in one buffer); the sentinel run is left out of n_uniq.
  * workspace: amid_sort_unique_workspace_bytes(world * len). */
 int amid_sparse_pad_f32(const int* uniq_ids, const float* uniq_rows, const int* n_uniq, int n_out, int D, int pad_id, int* out_ids,
                         float* out_rows, void* stream);
-int amid_merge_sorted_lists_i32(const int* keys, int world, int len, int sentinel, void* workspace, int* pos_sorted, int* uniq_ids,
-                                int* seg_off, int* seg_of, int* n_uniq, void* stream);
+int amid_merge_sorted_lists_i32(const int* keys, int world, int len, long long key_stride, int row_base, int row_stride, int sentinel,
+                                void* workspace, int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq, void* stream);
 
 /* ---- K4 optimizer ----------------------------------------------------------------------------
  * replaces: torch.optim.Adam(model.parameters(), lr).step(), train_sr.py:480, :215 (dense over the table).

@@ -32,5 +32,11 @@ def run(n, umax_known):
     return (time.perf_counter() - t0) / n * 1e3
 run(20, True)
 print("dp path, host knows umax : %.4f ms/step" % run(200, True))
+cap = (max(cnt) + 255) // 256 * 256
+cnt_b = cnt
+cnt = [cap] * len(cnt)
+run(5, True)
+print("dp path, fixed bound %d, graph pair : %.4f ms/step" % (cap, run(200, True)))
+cnt = cnt_b
 print("dp path, host sync / step: %.4f ms/step" % run(200, False))
 dist.destroy_process_group()

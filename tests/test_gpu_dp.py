@@ -53,7 +53,7 @@ def _worker(rank, world, port, use_graph, q, host_knows_umax=False):
             if host_knows_umax:       # what a data pipeline does while packing: count the uniques, max-reduce ahead of the step
                 cnt = torch.tensor([int(torch.unique(torch.cat([local[k].reshape(-1) for k in ("i_node", "neg_samples", "seq_d1", "seq_d2")])).numel())])
                 dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-                umax = int(cnt)
+                umax = (int(cnt) + 63) // 64 * 64             # a bucketed bound: the graph pair of the exchange is reused across steps
             eng.train_step_dp(pl, ex, use_graph=use_graph, umax=umax)
             eng.sync()
         eng.flush_table()

@@ -122,7 +122,7 @@ def test_merge_sorted_lists_matches_stable_sort(L, world, length, n_rows):
     seg = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
     sof = torch.zeros(n, dtype=torch.int32, device="cuda")
     nu = torch.zeros(1, dtype=torch.int32, device="cuda")
-    L.call("amid_merge_sorted_lists_i32", kd.data_ptr(), world, length, n_rows, ws.data_ptr(), pos.data_ptr(), uniq.data_ptr(),
+    L.call("amid_merge_sorted_lists_i32", kd.data_ptr(), world, length, length, 0, length, n_rows, ws.data_ptr(), pos.data_ptr(), uniq.data_ptr(),
            seg.data_ptr(), sof.data_ptr(), nu.data_ptr(), stream())
     torch.cuda.synchronize()
     assert torch.equal(pos.cpu().long(), torch.sort(keys, stable=True).indices)         # ties in rank order
