@@ -79,7 +79,7 @@ struct FfnBwdArgs {
     TileGeomB tg;
 };
 
-template <int D>
+template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_bwd_kernel(const FfnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using RP = RowPass<D>;
@@ -111,15 +111,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_bwd_kernel(const FfnBwdA
                                                         a.thr16, a.scale));
                 st4(a.dpre2 + (row0 + r) * D + 4 * sub, v);
             }
-            st4(As + r * LDK + 4 * sub, v);
+            store_a4<D, BF>(As, r, sub, v);
         }
     }
-    w_to_lds<D, D>(Ws, wr);
+    w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     load_w<D, D>(wr, a.w1T[g], D);
     f32x4 acc[WaveMap<D>::ACC];
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc);
+    mma_tile<D, D, BF>(As, Ws, acc);
     __syncthreads();
     acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();
@@ -135,16 +135,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_bwd_kernel(const FfnBwdA
                 v.z = hv.z > 0.f ? dh.z * a.scale : 0.f; v.w = hv.w > 0.f ? dh.w * a.scale : 0.f;
                 st4(a.dpre1 + (row0 + r) * D + 4 * sub, v);
             }
-            st4(As + r * LDK + 4 * sub, v);
+            store_a4<D, BF>(As, r, sub, v);
         }
     }
     __syncthreads();
-    w_to_lds<D, D>(Ws, wr);
+    w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     load_w<D, D>(wr, a.woT[g], D);
     load_tile<D>(aux, a.r, row0, nrows, D);               // LN2 input rows for the next epilogue
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc);
+    mma_tile<D, D, BF>(As, Ws, acc);
     __syncthreads();
     acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();
@@ -162,15 +162,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_bwd_kernel(const FfnBwdA
                     v = ln_bwd_row<RP::QPR>(dy, aux.v[i], gam, D, a.ln_eps, dgam, dbet);
                     st4(a.dr + (row0 + r) * D + 4 * sub, v);
                 }
-                st4(As + r * LDK + 4 * sub, v);
+                store_a4<D, BF>(As, r, sub, v);
             }
         }
     }
     __syncthreads();
-    w_to_lds<D, D>(Ws, wr);
+    w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc);
+    mma_tile<D, D, BF>(As, Ws, acc);
     acc_to_global<D>(a.d_o, row0, nrows, D, nullptr, acc);
     __syncthreads();                                      // As is free now: reduction scratch for the LN partials
     ln_partials_out<D>(As, dgam, dbet, a.ln_part + (long long)blockIdx.x * 2 * D);
@@ -188,7 +188,7 @@ struct QkvBwdArgs {
     TileGeomB tg;
 };
 
-template <int D>
+template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_bwd_kernel(const QkvBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using RP = RowPass<D>;
@@ -206,26 +206,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_bwd_kernel(const QkvBwdA
     WRegs<D, D> wr;
     load_tile<D>(ar, a.dk, row0, nrows, D);
     load_w<D, D>(wr, a.wkT[g], D);
-    tile_to_lds<D>(As, ar);
-    w_to_lds<D, D>(Ws, wr);
+    tile_to_lds<D, BF>(As, ar);
+    w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     load_tile<D>(ar, a.dv, row0, nrows, D);               // next operand pair flies under the MFMAs
     load_w<D, D>(wr, a.wvT[g], D);
-    mma_tile<D, D>(As, Ws, acc_kv);
+    mma_tile<D, D, BF>(As, Ws, acc_kv);
     __syncthreads();
-    tile_to_lds<D>(As, ar);
-    w_to_lds<D, D>(Ws, wr);
+    tile_to_lds<D, BF>(As, ar);
+    w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     load_tile<D>(ar, a.dq, row0, nrows, D);
     load_w<D, D>(wr, a.wqT[g], D);
-    mma_tile<D, D>(As, Ws, acc_kv);
+    mma_tile<D, D, BF>(As, Ws, acc_kv);
     __syncthreads();
-    tile_to_lds<D>(As, ar);
-    w_to_lds<D, D>(Ws, wr);
+    tile_to_lds<D, BF>(As, ar);
+    w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     load_tile<D>(ar, a.dr, row0, nrows, D);               // epilogue inputs: residual-path grad and the LN1 input rows
     load_tile<D>(xr, a.x, row0, nrows, D);
-    mma_tile<D, D>(As, Ws, acc_q);
+    mma_tile<D, D, BF>(As, Ws, acc_q);
     __syncthreads();
     float* Ckv = As;                    // both operand images are dead: reuse them as the two C images
     float* Cq = Ws;
@@ -432,22 +432,22 @@ static int make_geom_b(int M, int rows_per_tile, TileGeomB* tg) {
     return AMID_OK;
 }
 
-#define AMID_LAUNCH_FUSED_B(KERNEL, ARGS, DVAL)                                                                            \
+#define AMID_LAUNCH_FUSED_B(KERNEL, ARGS, DVAL, BFVAL)                                                                        \
     do {                                                                                                                   \
-        static bool attr_set_##DVAL = false;                                                                               \
-        if (!attr_set_##DVAL) {                                                                                            \
-            hipError_t e = hipFuncSetAttribute((const void*)KERNEL<DVAL>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                               (int)fused_lds_bytes_b<DVAL>());                                            \
+        static bool attr_set = false;                                                                                      \
+        if (!attr_set) {                                                                                                   \
+            hipError_t e = hipFuncSetAttribute((const void*)KERNEL<DVAL, BFVAL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)fused_lds_bytes_b<DVAL>());                                              \
             if (e != hipSuccess) return (int)e;                                                                            \
-            attr_set_##DVAL = true;                                                                                        \
+            attr_set = true;                                                                                               \
         }                                                                                                                  \
-        KERNEL<DVAL><<<2 * ARGS.tg.tiles_per_group, GEMM_THREADS, fused_lds_bytes_b<DVAL>(), (hipStream_t)stream>>>(ARGS); \
+        KERNEL<DVAL, BFVAL><<<2 * ARGS.tg.tiles_per_group, GEMM_THREADS, fused_lds_bytes_b<DVAL>(), (hipStream_t)stream>>>(ARGS); \
     } while (0)
 
 extern "C" int amid_sas_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
                                     const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
                                     int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2,
-                                    float* dpre1, float* dr, float* d_o, float* ln_part, void* stream) {
+                                    float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(dxo && h && r && ln_w && w1T && w2T && woT && dpre2 && dpre1 && dr && d_o && ln_part && (!train || step_state));
     FfnBwdArgs a;
     a.dxo = dxo; a.tmq = tmq; a.h = h; a.r = r; a.dpre2 = dpre2; a.dpre1 = dpre1; a.dr = dr; a.d_o = d_o; a.ln_part = ln_part;
@@ -457,8 +457,9 @@ extern "C" int amid_sas_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, 
     a.scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
     for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.w1T[g] = w1T[g]; a.w2T[g] = w2T[g]; a.woT[g] = woT[g]; }
     if (int e = make_geom_b(M, rows_per_tile, &a.tg)) return e;
-    if (D == 128) AMID_LAUNCH_FUSED_B(sas_ffn_bwd_kernel, a, 128);
-    else if (D == 64) AMID_LAUNCH_FUSED_B(sas_ffn_bwd_kernel, a, 64);
+    if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED_B(sas_ffn_bwd_kernel, a, 128, true);
+    else if (D == 128) AMID_LAUNCH_FUSED_B(sas_ffn_bwd_kernel, a, 128, false);
+    else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED_B(sas_ffn_bwd_kernel, a, 64, false);
     else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();
     return AMID_OK;
@@ -466,14 +467,15 @@ extern "C" int amid_sas_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, 
 
 extern "C" int amid_sas_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
                                     const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
-                                    float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, void* stream) {
+                                    float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && dx && ln_part);
     QkvBwdArgs a;
     a.dq = dq; a.dk = dk; a.dv = dv; a.dr = dr; a.x = x; a.dx = dx; a.ln_part = ln_part; a.ln_eps = ln_eps;
     for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.wqT[g] = wqT[g]; a.wkT[g] = wkT[g]; a.wvT[g] = wvT[g]; }
     if (int e = make_geom_b(M, rows_per_tile, &a.tg)) return e;
-    if (D == 128) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 128);
-    else if (D == 64) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 64);
+    if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 128, true);
+    else if (D == 128) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 128, false);
+    else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 64, false);
     else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();
     return AMID_OK;

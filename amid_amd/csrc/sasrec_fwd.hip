@@ -37,7 +37,7 @@ struct QkvFwdArgs {
     TileGeom tg;
 };
 
-template <int D>
+template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_fwd_kernel(const QkvFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using RP = RowPass<D>;
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_fwd_kernel(const QkvFwdA
     load_tile<D>(xr, a.x, row0, nrows, D);
     load_w<D, D>(wr, a.w_in[g] + (long long)1 * D * D, D);           // slab order k, v, q
     const float4 lw = ld4(a.ln_w[g] + 4 * sub), lb = ld4(a.ln_b[g] + 4 * sub);
-    tile_to_lds<D>(As, xr);
-    w_to_lds<D, D>(Ws, wr);
+    tile_to_lds<D, BF>(As, xr);
+    w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     f32x4 acc[WaveMap<D>::ACC];
 #pragma unroll 1
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_fwd_kernel(const QkvFwdA
         const int next = (s == 0) ? 2 : 0;
         if (s < 2) load_w<D, D>(wr, a.w_in[g] + (long long)next * D * D, D);   // next slab's weights fly under the MFMAs
         zero_acc<D>(acc);
-        mma_tile<D, D>(As, Ws, acc);
+        mma_tile<D, D, BF>(As, Ws, acc);
         float* out = (which == 0) ? a.q : (which == 1) ? a.k : a.v;
         acc_to_global<D>(out, row0, nrows, D, a.b_in[g] + which * D, acc);
         if (s == 2) break;
@@ -76,12 +76,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_fwd_kernel(const QkvFwdA
                     float mean, rstd;
                     row_stats<RP::QPR>(xr.v[i], D, a.ln_eps, mean, rstd);
                     const float4 y = ln_apply(xr.v[i], mean, rstd, lw, lb);
-                    st4(As + r * LDK + 4 * sub, y);
+                    store_a4<D, BF>(As, r, sub, y);
                     if (r < nrows) st4(a.qn + (row0 + r) * D + 4 * sub, y);
                 }
             }
         }
-        w_to_lds<D, D>(Ws, wr);
+        w_to_lds<D, D, BF>(Ws, wr);
         __syncthreads();
     }
 }
@@ -96,7 +96,7 @@ struct OprojFwdArgs {
     TileGeom tg;
 };
 
-template <int D>
+template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_fwd_kernel(const OprojFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using RP = RowPass<D>;
@@ -114,12 +114,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_fwd_kernel(const Oproj
     load_w<D, D>(wr, a.w_o[g], D);
     load_tile<D>(res, a.qn, row0, nrows, D);              // residual rows: in flight during the MFMAs
     const float4 bias = ld4(a.b_o[g] + 4 * sub), w = ld4(a.ln_w[g] + 4 * sub), b = ld4(a.ln_b[g] + 4 * sub);
-    tile_to_lds<D>(As, orr);
-    w_to_lds<D, D>(Ws, wr);
+    tile_to_lds<D, BF>(As, orr);
+    w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     f32x4 acc[WaveMap<D>::ACC];
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc);
+    mma_tile<D, D, BF>(As, Ws, acc);
     __syncthreads();
     acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();
@@ -146,7 +146,7 @@ struct FfnFwdArgs {
     TileGeom tg;
 };
 
-template <int D>
+template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_fwd_kernel(const FfnFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using RP = RowPass<D>;
@@ -171,13 +171,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_fwd_kernel(const FfnFwdA
         tm[i] = (a.tmq && r < nrows) ? a.tmq[(row0 + r) * (D / 4) + sub] : 0u;
     }
     const float4 bias1 = ld4(a.b1[g] + 4 * sub), bias2 = ld4(a.b2[g] + 4 * sub);
-    tile_to_lds<D>(As, yr);
-    w_to_lds<D, D>(Ws, wr);
+    tile_to_lds<D, BF>(As, yr);
+    w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     load_w<D, D>(wr, a.w2[g], D);                         // second weight matrix flies under the first GEMM
     f32x4 acc[WaveMap<D>::ACC];
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc);
+    mma_tile<D, D, BF>(As, Ws, acc);
     __syncthreads();
     acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();
@@ -194,14 +194,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_fwd_kernel(const FfnFwdA
                 hv.x = fmaxf(hv.x, 0.f); hv.y = fmaxf(hv.y, 0.f); hv.z = fmaxf(hv.z, 0.f); hv.w = fmaxf(hv.w, 0.f);
                 st4(a.h + (row0 + r) * D + 4 * sub, hv);
             }
-            st4(As + r * LDK + 4 * sub, hv);
+            store_a4<D, BF>(As, r, sub, hv);
         }
     }
     __syncthreads();                                      // Cs (= Ws) fully read, As rewritten
-    w_to_lds<D, D>(Ws, wr);
+    w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     zero_acc<D>(acc);
-    mma_tile<D, D>(As, Ws, acc);
+    mma_tile<D, D, BF>(As, Ws, acc);
     __syncthreads();
     acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();
@@ -253,28 +253,29 @@ extern "C" int amid_rows_per_tile(int M) {
     }
 }
 
-#define AMID_LAUNCH_FUSED(KERNEL, ARGS, DVAL)                                                                              \
+#define AMID_LAUNCH_FUSED(KERNEL, ARGS, DVAL, BFVAL)                                                                        \
     do {                                                                                                                   \
-        static bool attr_set_##DVAL = false;                                                                               \
-        if (!attr_set_##DVAL) {                                                                                            \
-            hipError_t e = hipFuncSetAttribute((const void*)KERNEL<DVAL>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+        static bool attr_set = false;                                                                                      \
+        if (!attr_set) {                                                                                                   \
+            hipError_t e = hipFuncSetAttribute((const void*)KERNEL<DVAL, BFVAL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                (int)fused_lds_bytes<DVAL>());                                              \
             if (e != hipSuccess) return (int)e;                                                                            \
-            attr_set_##DVAL = true;                                                                                        \
+            attr_set = true;                                                                                               \
         }                                                                                                                  \
-        KERNEL<DVAL><<<2 * ARGS.tg.tiles_per_group, GEMM_THREADS, fused_lds_bytes<DVAL>(), (hipStream_t)stream>>>(ARGS);   \
+        KERNEL<DVAL, BFVAL><<<2 * ARGS.tg.tiles_per_group, GEMM_THREADS, fused_lds_bytes<DVAL>(), (hipStream_t)stream>>>(ARGS); \
     } while (0)
 
 extern "C" int amid_sas_qkv_fwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
                                     const float* const* b_in, float ln_eps, int M, int D, int rows_per_tile, float* qn, float* q, float* k,
-                                    float* v, void* stream) {
+                                    float* v, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(x && ln_w && ln_b && w_in && b_in && qn && q && k && v);
     QkvFwdArgs a;
     a.x = x; a.qn = qn; a.q = q; a.k = k; a.v = v; a.ln_eps = ln_eps;
     for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.ln_b[g] = ln_b[g]; a.w_in[g] = w_in[g]; a.b_in[g] = b_in[g]; }
     if (int e = make_geom(M, rows_per_tile, &a.tg)) return e;
-    if (D == 128) AMID_LAUNCH_FUSED(sas_qkv_fwd_kernel, a, 128);
-    else if (D == 64) AMID_LAUNCH_FUSED(sas_qkv_fwd_kernel, a, 64);
+    if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED(sas_qkv_fwd_kernel, a, 128, true);
+    else if (D == 128) AMID_LAUNCH_FUSED(sas_qkv_fwd_kernel, a, 128, false);
+    else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED(sas_qkv_fwd_kernel, a, 64, false);
     else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();
     return AMID_OK;
@@ -282,14 +283,15 @@ extern "C" int amid_sas_qkv_fwd_f32(const float* x, const float* const* ln_w, co
 
 extern "C" int amid_sas_oproj_fwd_f32(const float* o, const float* const* w_o, const float* const* b_o, const float* qn,
                                       const float* const* ln_w, const float* const* ln_b, float ln_eps, int M, int D, int rows_per_tile,
-                                      float* r, float* y, void* stream) {
+                                      float* r, float* y, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(o && w_o && b_o && qn && ln_w && ln_b && r && y);
     OprojFwdArgs a;
     a.o = o; a.qn = qn; a.r = r; a.y = y; a.ln_eps = ln_eps;
     for (int g = 0; g < 2; ++g) { a.w_o[g] = w_o[g]; a.b_o[g] = b_o[g]; a.ln_w[g] = ln_w[g]; a.ln_b[g] = ln_b[g]; }
     if (int e = make_geom(M, rows_per_tile, &a.tg)) return e;
-    if (D == 128) AMID_LAUNCH_FUSED(sas_oproj_fwd_kernel, a, 128);
-    else if (D == 64) AMID_LAUNCH_FUSED(sas_oproj_fwd_kernel, a, 64);
+    if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED(sas_oproj_fwd_kernel, a, 128, true);
+    else if (D == 128) AMID_LAUNCH_FUSED(sas_oproj_fwd_kernel, a, 128, false);
+    else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED(sas_oproj_fwd_kernel, a, 64, false);
     else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();
     return AMID_OK;
@@ -297,7 +299,7 @@ extern "C" int amid_sas_oproj_fwd_f32(const float* o, const float* const* w_o, c
 
 extern "C" int amid_sas_ffn_fwd_f32(const float* y, const float* const* w1, const float* const* b1, const float* const* w2,
                                     const float* const* b2, const unsigned char* tmq, int M, int D, int rows_per_tile, int layer,
-                                    const void* step_state, int train, float p_drop, float* h, float* xo, void* stream) {
+                                    const void* step_state, int train, float p_drop, float* h, float* xo, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(y && w1 && b1 && w2 && b2 && h && xo && (!train || step_state));
     FfnFwdArgs a;
     a.y = y; a.tmq = tmq; a.h = h; a.xo = xo; a.st = (const StepState*)step_state; a.layer = layer;
@@ -306,8 +308,9 @@ extern "C" int amid_sas_ffn_fwd_f32(const float* y, const float* const* w1, cons
     a.scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
     for (int g = 0; g < 2; ++g) { a.w1[g] = w1[g]; a.b1[g] = b1[g]; a.w2[g] = w2[g]; a.b2[g] = b2[g]; }
     if (int e = make_geom(M, rows_per_tile, &a.tg)) return e;
-    if (D == 128) AMID_LAUNCH_FUSED(sas_ffn_fwd_kernel, a, 128);
-    else if (D == 64) AMID_LAUNCH_FUSED(sas_ffn_fwd_kernel, a, 64);
+    if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED(sas_ffn_fwd_kernel, a, 128, true);
+    else if (D == 128) AMID_LAUNCH_FUSED(sas_ffn_fwd_kernel, a, 128, false);
+    else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED(sas_ffn_fwd_kernel, a, 64, false);
     else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();
     return AMID_OK;

@@ -45,6 +45,27 @@ template <int K> struct TileCfg {
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// ---- bf16 matrix-core mode (BASELINE.json configs[2]: "bf16 with fp32 ref tolerance check") -------------------------------------
+// BF = true: the MFMA operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) when they are staged into LDS and the
+// products run on v_mfma_f32_16x16x32_bf16 (16x the fp32 matrix rate), accumulating in fp32; everything outside the matrix products
+// (LayerNorm, softmax, residuals, epilogues, what is stored in HBM, Adam) stays fp32.  LDS images become [row][K + 8] bf16: the
+// 16-byte fragment of lane (i, g) is k = 32 kk + 8 g .. + 7, and the 272-byte row stride puts the 16 lanes of a lane group on 16
+// distinct 16-byte slots ((17 i + g) mod 16).  The C image stays fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    const bf16x2 v = __builtin_convertvector(f32x2v{a, b}, bf16x2);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ uint2 pack_bf16x4(float4 v) { return make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+// four consecutive k of image row r (A or W image, K + 8 elements per row)
+template <int K, bool BF>
+__device__ __forceinline__ void store_a4(float* __restrict__ img, int r, int sub, float4 v) {
+    if constexpr (BF) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(img) + r * (K + 8) + 4 * sub) = pack_bf16x4(v);
+    else st4(img + r * (K + 8) + 4 * sub, v);
+}
+
 // wave -> (column tile, row-tile group) for an N-column slab: NT = N/16 column tiles, WR = 8/NT row groups
 template <int N> struct WaveMap {
     static constexpr int NT = N / 16;
@@ -77,13 +98,13 @@ __device__ __forceinline__ void load_tile(TileRegs<N>& t, const float* __restric
     }
 }
 // registers -> LDS image [TileCfg::ROWS][N + 8]; every image row is written (NR * RPP == ROWS), rows past the tile as zeros
-template <int N>
+template <int N, bool BF = false>
 __device__ __forceinline__ void tile_to_lds(float* __restrict__ As, const TileRegs<N>& t) {
     using RP = RowPass<N>;
     static_assert(RP::NR * RP::RPP == TileCfg<N>::ROWS, "row pass must cover the A image exactly");
     const int sub = RP::sub(), r0 = RP::first_row();
 #pragma unroll
-    for (int i = 0; i < RP::NR; ++i) st4(As + (r0 + i * RP::RPP) * TileCfg<N>::LDK + 4 * sub, t.v[i]);
+    for (int i = 0; i < RP::NR; ++i) store_a4<N, BF>(As, r0 + i * RP::RPP, sub, t.v[i]);
 }
 
 // W slab [N rows (output features)][K] in registers / LDS
@@ -98,12 +119,12 @@ __device__ __forceinline__ void load_w(WRegs<K, N>& t, const float* __restrict__
 #pragma unroll
     for (int i = 0; i < W::NR; ++i) t.v[i] = ld4(w + (long long)(r0 + i * W::RPP) * ldw + 4 * sub);
 }
-template <int K, int N>
+template <int K, int N, bool BF = false>
 __device__ __forceinline__ void w_to_lds(float* __restrict__ Ws, const WRegs<K, N>& t) {
     using W = WRegs<K, N>;
     const int sub = threadIdx.x % W::QPR, r0 = threadIdx.x / W::QPR;
 #pragma unroll
-    for (int i = 0; i < W::NR; ++i) st4(Ws + (r0 + i * W::RPP) * TileCfg<K>::LDK + 4 * sub, t.v[i]);
+    for (int i = 0; i < W::NR; ++i) store_a4<K, BF>(Ws, r0 + i * W::RPP, sub, t.v[i]);
 }
 
 // MFMA loop over the whole K of the slab.  Software-pipelined by hand: the operand fragments of k-step kk+1 are read
@@ -112,7 +133,37 @@ __device__ __forceinline__ void w_to_lds(float* __restrict__ Ws, const WRegs<K, 
 // dependent one).  No per-tile branch: all ACC tiles are always computed (rows past the tile are zeros in the image).
 // The first version (read -> wait -> 4 dependent MFMAs per tile, a branch per tile) ran the matrix pipe at ~37 %.
 template <int K, int N>
-__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Ws, f32x4 (&acc)[WaveMap<N>::ACC]) {
+__device__ __forceinline__ void mma_tile_bf16(const float* __restrict__ As, const float* __restrict__ Ws, f32x4 (&acc)[WaveMap<N>::ACC]) {
+    using WM = WaveMap<N>;
+    constexpr int LDB = K + 8, ACC = WM::ACC, KK = K / 32;
+    const int w = wave_id(), lane = lane_id();
+    const int ct = w % WM::NT, rg = w / WM::NT;
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned short* wp = reinterpret_cast<const unsigned short*>(Ws) + (ct * 16 + i) * LDB + 8 * g;
+    const unsigned short* ap = reinterpret_cast<const unsigned short*>(As) + (rg * 16 + i) * LDB + 8 * g;
+    bf16x8 b_cur = *reinterpret_cast<const bf16x8*>(wp), a_cur[ACC];
+#pragma unroll
+    for (int t = 0; t < ACC; ++t) a_cur[t] = *reinterpret_cast<const bf16x8*>(ap + t * WM::WR * 16 * LDB);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        bf16x8 b_nxt = b_cur, a_nxt[ACC];
+#pragma unroll
+        for (int t = 0; t < ACC; ++t) a_nxt[t] = a_cur[t];
+        if (kk + 1 < KK) {
+            b_nxt = *reinterpret_cast<const bf16x8*>(wp + 32 * (kk + 1));
+#pragma unroll
+            for (int t = 0; t < ACC; ++t) a_nxt[t] = *reinterpret_cast<const bf16x8*>(ap + t * WM::WR * 16 * LDB + 32 * (kk + 1));
+        }
+#pragma unroll
+        for (int t = 0; t < ACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur, a_cur[t], acc[t], 0, 0, 0);
+        b_cur = b_nxt;
+#pragma unroll
+        for (int t = 0; t < ACC; ++t) a_cur[t] = a_nxt[t];
+    }
+}
+
+template <int K, int N>
+__device__ __forceinline__ void mma_tile_f32(const float* __restrict__ As, const float* __restrict__ Ws, f32x4 (&acc)[WaveMap<N>::ACC]) {
     using WM = WaveMap<N>;
     constexpr int LDK = TileCfg<K>::LDK, ACC = WM::ACC, KK = K / 16;
     const int w = wave_id(), lane = lane_id();
@@ -154,6 +205,12 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
 #pragma unroll
         for (int t = 0; t < ACC; ++t) a_cur[t] = a_nxt[t];
     }
+}
+
+template <int K, int N, bool BF = false>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Ws, f32x4 (&acc)[WaveMap<N>::ACC]) {
+    if constexpr (BF) mma_tile_bf16<K, N>(As, Ws, acc);
+    else mma_tile_f32<K, N>(As, Ws, acc);
 }
 
 template <int N>

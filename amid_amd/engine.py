@@ -303,7 +303,7 @@ class SasrecEngine:
 
     def __init__(self, item_length: int, emb_dim: int, seq_len: int, hid_dim: int, device="cuda:0", lr: float = 5e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, seed: int = 0, itc_bs: int = 0, itc_threshold: float = 0.5, dr: bool = False,
-                 dr_e_w: float = 0.1):
+                 dr_e_w: float = 0.1, compute: str = "f32"):
         """itc_bs > 0: SASRec(isItC=True, bs=itc_bs, threshold2=itc_threshold) -- InterComp after the encoders
         (model_seq.py:426-431); every batch must then hold exactly itc_bs rows (trans_bs is Linear(bs, 1) over the batch)."""
         L = lib()        # raises AmidLibraryError when the HIP library is missing: no fallback
@@ -311,6 +311,13 @@ class SasrecEngine:
         # dr: SASRec(isDR=True) -- predict_ips / predict_gfunc heads and the two objectives of train_sr_dr.py; dr_mode selects
         # the objective of the next train step (0: loss_cls + dr_e_w * loss_dr_e, 1: loss_dr_r), see select_optimizer()
         self.dr, self.dr_e_w, self.dr_mode = bool(dr), float(dr_e_w), 0
+        # compute = "bf16": the dense projections' matrix products take bf16 operands (fp32 accumulate, fp32 everything else);
+        # BASELINE.json configs[2].  "f32" (default): exact fp32 products.
+        if compute not in ("f32", "bf16"):
+            raise ValueError(f"compute must be 'f32' or 'bf16', got {compute!r}")
+        if compute == "bf16" and emb_dim != 128:
+            raise ValueError("the bf16 matrix-core kernels are built for emb_dim 128")
+        self.compute, self.mma_bf16 = compute, 1 if compute == "bf16" else 0
         if emb_dim not in self.EMB_DIMS:
             raise ValueError(f"amid_amd {type(self).__name__} kernels are built for emb_dim in {self.EMB_DIMS}, got {emb_dim}")
         self.device = torch.device(device)
@@ -496,17 +503,17 @@ class SasrecEngine:
             L.call("amid_sas_qkv_fwd_f32", pl.x[l].data_ptr(), self._pp(f"sac{{d}}.attention_layernorms.{l}.weight"),
                    self._pp(f"sac{{d}}.attention_layernorms.{l}.bias"), self._pp(f"sac{{d}}.attention_layers.{l}.in_proj_weight"),
                    self._pp(f"sac{{d}}.attention_layers.{l}.in_proj_bias"), SASREC_LN_EPS, M, D, pl.rpt, pl.qn[l].data_ptr(),
-                   pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), s)
+                   pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), self.mma_bf16, s)
             L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), None, B, T, D, self.H, 1, l, st, tr,
                    SASREC_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
             L.call("amid_sas_oproj_fwd_f32", pl.o[l].data_ptr(), self._pp(f"sac{{d}}.attention_layers.{l}.out_proj.weight"),
                    self._pp(f"sac{{d}}.attention_layers.{l}.out_proj.bias"), pl.qn[l].data_ptr(),
                    self._pp(f"sac{{d}}.forward_layernorms.{l}.weight"), self._pp(f"sac{{d}}.forward_layernorms.{l}.bias"), SASREC_LN_EPS,
-                   M, D, pl.rpt, pl.r[l].data_ptr(), pl.y[l].data_ptr(), s)
+                   M, D, pl.rpt, pl.r[l].data_ptr(), pl.y[l].data_ptr(), self.mma_bf16, s)
             L.call("amid_sas_ffn_fwd_f32", pl.y[l].data_ptr(), self._pp(f"sac{{d}}.forward_layers.{l}.conv1.weight"),
                    self._pp(f"sac{{d}}.forward_layers.{l}.conv1.bias"), self._pp(f"sac{{d}}.forward_layers.{l}.conv2.weight"),
                    self._pp(f"sac{{d}}.forward_layers.{l}.conv2.bias"), pl.tmq.data_ptr(), M, D, pl.rpt, l, st, tr, SASREC_P_DROP,
-                   pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(), s)
+                   pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(), self.mma_bf16, s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
         if self.dr:
             self._enqueue_head_dr_fwd(pl, items, with_loss)
@@ -634,14 +641,14 @@ class SasrecEngine:
             L.call("amid_sas_ffn_bwd_f32", pl.dxbuf.data_ptr(), pl.tmq.data_ptr(), pl.h[l].data_ptr(), pl.r[l].data_ptr(),
                    self._pp(f"sac{{d}}.forward_layernorms.{l}.weight"), self._wT(l, 4), self._wT(l, 5), self._wT(l, 3), SASREC_LN_EPS,
                    M, D, pl.rpt, l, st, tr, SASREC_P_DROP, pl.dpre2[l].data_ptr(), pl.dpre1[l].data_ptr(), pl.dr[l].data_ptr(),
-                   pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), s)
+                   pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), self.mma_bf16, s)
             L.call("amid_attn_bwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(),
                    pl.stats[l].data_ptr(), pl.d_o.data_ptr(), None, B, T, D, self.H, 1, l, st, tr, SASREC_P_DROP, pl.dq_l[l].data_ptr(),
                    pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), s)
             dx_out = pl.dxg if l == 0 else pl.dxbuf
             L.call("amid_sas_qkv_bwd_f32", pl.dq_l[l].data_ptr(), pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), pl.dr[l].data_ptr(),
                    pl.x[l].data_ptr(), self._pp(f"sac{{d}}.attention_layernorms.{l}.weight"), self._wT(l, 0), self._wT(l, 1),
-                   self._wT(l, 2), SASREC_LN_EPS, M, D, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), s)
+                   self._wT(l, 2), SASREC_LN_EPS, M, D, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), self.mma_bf16, s)
         dy, xx = [], []
         for l in (0, 1):
             dy += [pl.dq_l[l].data_ptr(), pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), pl.dr[l].data_ptr(), pl.dpre1[l].data_ptr(),

@@ -123,7 +123,10 @@ class SASRec(nn.Module):
     SUPPORTS_ITC = True          # InterComp after the encoders (model_seq.py:426-431), the configuration run.sh trains
 
     def __init__(self, user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim, bs, isInC, isItC, threshold1,
-                 threshold2, isDR=False, device: Optional[str] = None, lr: float = 5e-4, seed: int = 0):
+                 threshold2, isDR=False, device: Optional[str] = None, lr: float = 5e-4, seed: int = 0, compute: str = "f32"):
+        """Beyond the reference's arguments: device, lr / seed (the fused train_step owns Adam and the dropout counter) and
+        compute ("f32": exact fp32 matrix products, the default; "bf16": bf16 MFMA operands with fp32 accumulation, SASRec with
+        emb_dim 128 only -- BASELINE.json configs[2])."""
         super().__init__()
         if isInC:
             _not_built("InnerComp (isInC)", "model_seq.py:422-424")
@@ -140,6 +143,8 @@ class SASRec(nn.Module):
         kw = dict(itc_bs=bs, itc_threshold=threshold2) if isItC else {}
         if isDR:
             kw["dr"] = True
+        if compute != "f32":
+            kw["compute"] = compute
         self.engine = self.ENGINE_CLS(item_length, item_emb_dim, seq_len, hid_dim, device=dev, lr=lr, seed=seed, **kw)
         eng = self.engine
         self._param_names = ["item_emb_layer.emb_item.weight"] + list(eng.dense.slots)

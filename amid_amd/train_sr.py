@@ -6,7 +6,7 @@ ignored; ``type=bool`` flags keep the reference's "any non-empty string is True"
 constants (item_length 447 410, pad id item_length + 1, table of 2 x item_length rows, drop_last on both
 loaders, five seeds 0..4, loss logged every 20 iterations, best-so-far HR/NDCG/MRR per epoch).
 Additions: ``--data_root`` (the reference hard-codes /ossfs/workspace/CDSR), ``--seeds``, ``--device``,
-``--no_graph``, ``--max_steps``; data parallel when launched by ``python -m torch.distributed.run --nproc-per-node N``
+``--no_graph``, ``--max_steps``, ``--dtype {fp32,bf16}``; data parallel when launched by ``python -m torch.distributed.run --nproc-per-node N``
 (one process per GPU, RCCL, ``--bs`` per GPU; BASELINE.json configs[3]).
 
     python train_sr.py --data_root /path/to/AMID -ds amazon -dm cloth_sport --overlap_ratio 0.75 \
@@ -69,6 +69,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--device", type=str, default="cuda:0")
     p.add_argument("--no_graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     p.add_argument("--max_steps", type=int, default=0, help="stop each epoch after this many steps (0 = full epoch)")
+    p.add_argument("--dtype", type=str, default="fp32", choices=("fp32", "bf16"),
+                   help="fp32: exact fp32 matrix products; bf16: bf16 MFMA operands, fp32 accumulation and storage (sasrec, emb_dim 128)")
     return p
 
 
@@ -179,7 +181,7 @@ def main(argv=None):
         torch.cuda.set_device(torch.device(args.device))
         model = cls(user_length=user_length, user_emb_dim=args.emb_dim, item_length=item_length, item_emb_dim=args.emb_dim,
                     seq_len=args.seq_len, hid_dim=args.hid_dim, bs=args.bs, isInC=args.isInC, isItC=args.isItC, threshold1=args.ts1,
-                    threshold2=args.ts2, lr=args.lr, seed=i)
+                    threshold2=args.ts2, lr=args.lr, seed=i, **({"compute": "bf16"} if args.dtype == "bf16" else {}))
         exchange = None
         if world > 1:
             from .dist import SparseDenseExchange

@@ -110,7 +110,7 @@ def main(argv=None):
         torch.cuda.set_device(torch.device(args.device))
         model = SASRec(user_length=2 * user_length, user_emb_dim=args.emb_dim, item_length=2 * item_length, item_emb_dim=args.emb_dim,
                        seq_len=args.seq_len, hid_dim=args.hid_dim, bs=args.bs, isInC=args.isInC, isItC=args.isItC, threshold1=args.ts1,
-                       threshold2=args.ts2, isDR=True, lr=args.lr, seed=i)
+                       threshold2=args.ts2, isDR=True, lr=args.lr, seed=i, **({"compute": "bf16"} if args.dtype == "bf16" else {}))
         model.engine.dr_e_w = float(args.dr_e_w)
         init_logger(args.model_dir, args.log_file)
         logger.info(vars(args))

@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
+                    help="f32 (default, the headline): exact fp32 matrix products; bf16: bf16 MFMA operands with fp32 accumulation "
+                         "(BASELINE.json configs[2]) -- reported with dtype bf16, never the headline line")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
                     help="cfg2 = the headline configuration (default); cfg5-* = synthetic gather / scatter stress (SURVEY.md 8(d))")
     args = ap.parse_args()
@@ -228,7 +231,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     Bw = wl["B"]
-    eng = SasrecEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234)
+    eng = SasrecEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234, compute=args.dtype)
     init_params(eng, seed=0)                  # identical replicas on every rank
     pl = eng.plan(Bw, T, 1 + NEG, need_grad=True)
     gen = torch.Generator().manual_seed(1000 + rank)          # each rank draws its own shard of the global batch
@@ -341,7 +344,7 @@ def main():
         out = {
             "metric": "train samples/sec", "value": round(Bw * world * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["label"], "batch_per_gpu": Bw,
                        "global_batch": Bw * world, "seq_len": T, "emb_dim": D, "hid_dim": HID, "neg": NEG, "table_rows": wl["n_rows"],
                        "unique_rows_last_step": int(pl.n_uniq.item()),

@@ -106,19 +106,22 @@ int amid_optimizer_step_f32(float* p, float* m, float* v, const float* g, long l
                             float grad_scale, const void* step_state, void* stream);
 
 /* ---- SASRec encoder layer, forward ------------------------------------------------------------
- * Pointer-array arguments are HOST arrays of 2 device pointers (domain 0, domain 1). */
+ * Pointer-array arguments are HOST arrays of 2 device pointers (domain 0, domain 1).
+ * mma_bf16 (D = 128 only): 0 = exact fp32 matrix products (v_mfma_f32_16x16x4_f32); 1 = the products' operands rounded to bf16 with
+ * fp32 accumulation (v_mfma_f32_16x16x32_bf16), everything else fp32 -- BASELINE.json configs[2], checked against the fp32 oracle
+ * at 2e-2 relative. */
 int amid_rows_per_tile(int M);
 /* replaces: attention_layernorms[i] + the packed in-projection of nn.MultiheadAttention, model_seq.py:373-374 */
 int amid_sas_qkv_fwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
                          const float* const* b_in, float ln_eps, int M, int D, int rows_per_tile, float* qn, float* q, float* k, float* v,
-                         void* stream);
+                         int mma_bf16, void* stream);
 /* replaces: out_proj of nn.MultiheadAttention + "seqs = Q + mha_outputs" + forward_layernorms[i], model_seq.py:374-381 */
 int amid_sas_oproj_fwd_f32(const float* o, const float* const* w_o, const float* const* b_o, const float* qn, const float* const* ln_w,
-                           const float* const* ln_b, float ln_eps, int M, int D, int rows_per_tile, float* r, float* y, void* stream);
+                           const float* const* ln_b, float ln_eps, int M, int D, int rows_per_tile, float* r, float* y, int mma_bf16, void* stream);
 /* replaces: PointWiseFeedForward.forward model_seq.py:322-326 + "seqs *= ~timeline_mask" :383 */
 int amid_sas_ffn_fwd_f32(const float* y, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
                          const unsigned char* tmq, int M, int D, int rows_per_tile, int layer, const void* step_state, int train,
-                         float p_drop, float* h, float* xo, void* stream);
+                         float p_drop, float* h, float* xo, int mma_bf16, void* stream);
 
 /* ---- K2 attention core ------------------------------------------------------------------------
  * replaces: softmax(q k^T + mask) dropout v inside nn.MultiheadAttention (model_seq.py:374, causal=1) and
@@ -135,10 +138,10 @@ int amid_transpose_weights_f32(const float* const* src, float* const* dst, int n
 int amid_sas_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
                          const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
                          int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
-                         float* dr, float* d_o, float* ln_part /* [tiles][2][D] */, void* stream);
+                         float* dr, float* d_o, float* ln_part /* [tiles][2][D] */, int mma_bf16, void* stream);
 int amid_sas_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
                          const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
-                         int rows_per_tile, float* dx, float* ln_part, void* stream);
+                         int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream);
 /* the six weight + bias gradients of n_layers (1 or 2) layers as split partials, ONE launch (two workgroups per CU): dy / x are host
  * arrays of 6 * n_layers device pointers, per layer in the order in_proj q, k, v, out_proj, conv1, conv2; w_part / b_part are host
  * arrays of n_layers device pointers to [2][6][splits][D*D] and [2][6][splits][D] */

@@ -215,7 +215,8 @@ def test_sasrec_itc_module_surface():
         m(None, cu["i_node"][:4], cu["neg_samples"][:4], cu["seq_d1"][:4], cu["seq_d2"][:4], None, None, False)
 
 
-@pytest.mark.parametrize("model,emb,extra", [("sasrec", "64", []), ("bert4rec", "128", []), ("sasrec", "64", ["--isItC", "True", "--ts2", "0.4"])])
+@pytest.mark.parametrize("model,emb,extra", [("sasrec", "64", []), ("bert4rec", "128", []), ("sasrec", "64", ["--isItC", "True", "--ts2", "0.4"]),
+                                             ("sasrec", "128", ["--dtype", "bf16"])])
 def test_train_sr_cli_end_to_end(tmp_path, model, emb, extra):
     """The reference's command line on a synthetic CSV pair with the reference's column layout."""
     from amid_amd.train_sr import main

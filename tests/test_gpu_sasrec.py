@@ -461,3 +461,55 @@ def test_edge_shapes_forward_backward_vs_oracle(Bn, T, D, neg):
         margin = min(taps[s][f"relu_margin{l}"] for s in ("sac1", "sac2") for l in (0, 1))
         tol = 3e-4 if margin > 2e-5 else 5e-2
         grads_check(f"edge B={Bn} T={T} D={D}", eng, pl, grads, tol, 3e-4 if margin > 2e-5 else 1e-2)
+
+
+# ---------------------------------------------------------------------------- bf16 matrix products (BASELINE.json configs[2])
+def test_bf16_compute_within_tolerance_of_fp32_oracle():
+    """compute="bf16": bf16 MFMA operands, fp32 accumulation / storage / everything else, at the cfg-3 batch (512 x 50 x 128):
+    logits within 2e-2 relative of the fp32 oracle, gradients close in the L2 sense, training moves the loss."""
+    from amid_amd.engine import SasrecEngine
+    D, T, Bn, hid, n_items = 128, 50, 512, 32, 3000
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=91)
+    batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=17)
+    eng = SasrecEngine(n_items, D, T, hid, lr=1e-3, seed=4, compute="bf16")
+    eng.load_state_dict(P)
+    pl = run_forward(eng, batch, train=False, with_loss=True)
+    p1, p2 = orc.sasrec_forward(P, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"])
+    e1, e2 = relmax(pl.p1, p1), relmax(pl.p2, p2)
+    log(f"bf16 cfg3 logits relmax {e1:.3e} {e2:.3e}")
+    assert e1 < 2e-2 and e2 < 2e-2
+    assert e1 > 1e-5                                   # the mode is really on (fp32 products land at ~1e-6)
+    sub = {k: v[:32] for k, v in batch.items()}        # gradients on a slice the oracle differentiates quickly
+    eng2 = SasrecEngine(n_items, D, T, hid, lr=1e-3, seed=4, compute="bf16")
+    eng2.load_state_dict(P)
+    pl2 = run_forward(eng2, sub, train=False, with_loss=True)
+    eng2.enqueue_backward(pl2, train=False)
+    eng2.sync()
+    loss, _, grads = orc.loss_and_grads("sasrec", P, sub, None)
+    assert abs(float(pl2.loss.item()) - float(loss)) < 2e-3
+    worst = 0.0
+    for name in eng2.dense.slots:
+        if name.endswith("in_proj_bias"):
+            continue
+        e = rel_l2(eng2.dense.view(name, eng2.dense.grad), grads[name])
+        worst = max(worst, e)
+        assert e < 6e-2, (name, e)
+    log(f"bf16 grads worst rel L2 {worst:.3e}")
+    assert rel_l2(dense_table_grad(eng2, pl2), grads["item_emb_layer.emb_item.weight"]) < 6e-2
+    # a few train steps (dropout on, graph replay): the loss goes down and stays close to the fp32 engine's
+    ref = make_engine(P, T, lr=1e-3, seed=4)
+    losses = {}
+    for key, e in (("bf16", eng), ("f32", ref)):
+        q = e.plan(Bn, T, 2, need_grad=True)
+        cu = {k: v.cuda() for k, v in batch.items()}
+        e.load_batch(q, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"])
+        e.capture_train_step(q)
+        ls = []
+        for _ in range(5):
+            e.replay_train_step(q)
+            e.sync()
+            ls.append(float(q.loss.item()))
+        losses[key] = ls
+    log(f"bf16 train losses {losses}")
+    assert losses["bf16"][-1] < losses["bf16"][0]
+    assert all(abs(a - b) < 5e-3 for a, b in zip(losses["bf16"], losses["f32"]))
