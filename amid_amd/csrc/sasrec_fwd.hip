@@ -225,6 +225,130 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_fwd_kernel(const FfnFwdA
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// out-projection + residual + LayerNorm2 + point-wise feed-forward in ONE kernel (sas_oproj_fwd_kernel followed by
+// sas_ffn_fwd_kernel on the same row tile): the LN2 output y never leaves the chip between the two, one prologue and one
+// launch instead of two.  Three chained GEMMs on one A image: o Wo^T -> (r, y) ; y C1^T -> h ; h C2^T -> xo.
+// ---------------------------------------------------------------------------------------------------------------------
+struct OprojFfnFwdArgs {
+    const float* o; const float* qn;
+    const float* w_o[2]; const float* b_o[2]; const float* ln_w[2]; const float* ln_b[2];
+    const float* w1[2]; const float* b1[2]; const float* w2[2]; const float* b2[2];
+    const unsigned char* tmq;
+    float* r; float* y; float* h; float* xo;
+    float ln_eps;
+    const StepState* st; int train; unsigned thr16; float scale; int layer;
+    TileGeom tg;
+};
+
+template <int D, bool BF>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_ffn_fwd_kernel(const OprojFfnFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using RP = RowPass<D>;
+    constexpr int LDC = D + 4;
+    float* As = smem;
+    float* Ws = smem + TileCfg<D>::A_FLOATS;
+    float* Cs = Ws;
+    int g, nrows, local0; long long row0;
+    tile_rows(a.tg, blockIdx.x, g, row0, nrows, local0);
+    const int sub = RP::sub();
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+    TileRegs<D> tr;                                       // o rows, then the residual (qn), then y (the FFN residual)
+    WRegs<D, D> wr;
+    load_tile<D>(tr, a.o, row0, nrows, D);
+    load_w<D, D>(wr, a.w_o[g], D);
+    tile_to_lds<D, BF>(As, tr);
+    w_to_lds<D, D, BF>(Ws, wr);
+    load_tile<D>(tr, a.qn, row0, nrows, D);               // residual rows and the next weights fly under the first GEMM
+    load_w<D, D>(wr, a.w1[g], D);
+    unsigned tm[RP::NR];
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = RP::first_row() + i * RP::RPP;
+        tm[i] = (a.tmq && r < nrows) ? a.tmq[(row0 + r) * (D / 4) + sub] : 0u;
+    }
+    __syncthreads();
+    f32x4 acc[WaveMap<D>::ACC];
+    zero_acc<D>(acc);
+    mma_tile<D, D, BF>(As, Ws, acc);
+    __syncthreads();
+    acc_to_lds<D>(Cs, LDC, acc);
+    __syncthreads();
+    {   // r = qn + (o Wo^T + bo) ; y = LN2(r) -> global, registers (FFN residual) and the A image of the second GEMM
+        const float4 bias = ld4(a.b_o[g] + 4 * sub), w = ld4(a.ln_w[g] + 4 * sub), b = ld4(a.ln_b[g] + 4 * sub);
+#pragma unroll
+        for (int i = 0; i < RP::NR; ++i) {
+            const int r = RP::first_row() + i * RP::RPP;
+            if (r < TileCfg<D>::ROWS) {
+                float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < nrows) {
+                    const long long off = (row0 + r) * D + 4 * sub;
+                    const float4 x = f4add(tr.v[i], f4add(ld4(Cs + r * LDC + 4 * sub), bias));
+                    st4(a.r + off, x);
+                    float mean, rstd;
+                    row_stats<RP::QPR>(x, D, a.ln_eps, mean, rstd);
+                    yv = ln_apply(x, mean, rstd, w, b);
+                    st4(a.y + off, yv);
+                }
+                tr.v[i] = yv;
+                store_a4<D, BF>(As, r, sub, yv);
+            }
+        }
+    }
+    __syncthreads();                                      // Cs (= Ws) fully read, As rewritten
+    w_to_lds<D, D, BF>(Ws, wr);
+    __syncthreads();
+    load_w<D, D>(wr, a.w2[g], D);
+    zero_acc<D>(acc);
+    mma_tile<D, D, BF>(As, Ws, acc);
+    __syncthreads();
+    acc_to_lds<D>(Cs, LDC, acc);
+    __syncthreads();
+    const float4 bias1 = ld4(a.b1[g] + 4 * sub), bias2 = ld4(a.b2[g] + 4 * sub);
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {                    // h = relu(drop1(C + c1)) -> global and the A image of the third GEMM
+        const int r = RP::first_row() + i * RP::RPP;
+        if (r < TileCfg<D>::ROWS) {
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nrows) {
+                hv = f4add(ld4(Cs + r * LDC + 4 * sub), bias1);
+                if (a.train) hv = f4mul(hv, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN1), step,
+                                                          (unsigned long long)(local0 + r) * D + 4 * sub, a.thr16, a.scale));
+                hv.x = fmaxf(hv.x, 0.f); hv.y = fmaxf(hv.y, 0.f); hv.z = fmaxf(hv.z, 0.f); hv.w = fmaxf(hv.w, 0.f);
+                st4(a.h + (row0 + r) * D + 4 * sub, hv);
+            }
+            store_a4<D, BF>(As, r, sub, hv);
+        }
+    }
+    __syncthreads();
+    w_to_lds<D, D, BF>(Ws, wr);
+    __syncthreads();
+    zero_acc<D>(acc);
+    mma_tile<D, D, BF>(As, Ws, acc);
+    __syncthreads();
+    acc_to_lds<D>(Cs, LDC, acc);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = RP::first_row() + i * RP::RPP;
+        if (r < nrows) {
+            float4 z = f4add(ld4(Cs + r * LDC + 4 * sub), bias2);
+            if (a.train) z = f4mul(z, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN2), step,
+                                                    (unsigned long long)(local0 + r) * D + 4 * sub, a.thr16, a.scale));
+            z = f4add(z, tr.v[i]);
+            const unsigned bits = tm[i];
+            if (bits) {
+                if (bits & 1u) z.x = 0.f;
+                if (bits & 2u) z.y = 0.f;
+                if (bits & 4u) z.z = 0.f;
+                if (bits & 8u) z.w = 0.f;
+            }
+            st4(a.xo + (row0 + r) * D + 4 * sub, z);
+        }
+    }
+}
+
 }  // namespace amid
 
 using namespace amid;
@@ -311,6 +435,31 @@ extern "C" int amid_sas_ffn_fwd_f32(const float* y, const float* const* w1, cons
     if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED(sas_ffn_fwd_kernel, a, 128, true);
     else if (D == 128) AMID_LAUNCH_FUSED(sas_ffn_fwd_kernel, a, 128, false);
     else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED(sas_ffn_fwd_kernel, a, 64, false);
+    else return AMID_ERR_UNSUPPORTED;
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_sas_oproj_ffn_fwd_f32(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
+                                          const float* const* ln_w, const float* const* ln_b, const float* const* w1, const float* const* b1,
+                                          const float* const* w2, const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D,
+                                          int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* r, float* y,
+                                          float* h, float* xo, int mma_bf16, void* stream) {
+    AMID_CHECK_ARG(o && qn && w_o && b_o && ln_w && ln_b && w1 && b1 && w2 && b2 && r && y && h && xo && (!train || step_state));
+    OprojFfnFwdArgs a;
+    a.o = o; a.qn = qn; a.tmq = tmq; a.r = r; a.y = y; a.h = h; a.xo = xo; a.ln_eps = ln_eps;
+    a.st = (const StepState*)step_state; a.layer = layer;
+    a.train = (train && p_drop > 0.f) ? 1 : 0;
+    a.thr16 = keep_thr16(p_drop);
+    a.scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+    for (int g = 0; g < 2; ++g) {
+        a.w_o[g] = w_o[g]; a.b_o[g] = b_o[g]; a.ln_w[g] = ln_w[g]; a.ln_b[g] = ln_b[g];
+        a.w1[g] = w1[g]; a.b1[g] = b1[g]; a.w2[g] = w2[g]; a.b2[g] = b2[g];
+    }
+    if (int e = make_geom(M, rows_per_tile, &a.tg)) return e;
+    if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED(sas_oproj_ffn_fwd_kernel, a, 128, true);
+    else if (D == 128) AMID_LAUNCH_FUSED(sas_oproj_ffn_fwd_kernel, a, 128, false);
+    else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED(sas_oproj_ffn_fwd_kernel, a, 64, false);
     else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();
     return AMID_OK;

@@ -115,6 +115,7 @@ def algorithmic_work(Bw=B, n_uniq=None):
     return {
         "amid_sas_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_sas_oproj_fwd_f32": ("mfma", gemm),
+        "amid_sas_oproj_ffn_fwd_f32": ("mfma", 3 * gemm),
         "amid_sas_ffn_fwd_f32": ("mfma", 2 * gemm),
         "amid_sas_ffn_bwd_f32": ("mfma", 3 * gemm),
         "amid_sas_qkv_bwd_f32": ("mfma", 3 * gemm),

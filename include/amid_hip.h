@@ -123,6 +123,14 @@ int amid_sas_ffn_fwd_f32(const float* y, const float* const* w1, const float* co
                          const unsigned char* tmq, int M, int D, int rows_per_tile, int layer, const void* step_state, int train,
                          float p_drop, float* h, float* xo, int mma_bf16, void* stream);
 
+/* amid_sas_oproj_fwd_f32 + amid_sas_ffn_fwd_f32 as ONE launch (the LN2 output stays on chip between the out-projection and the
+ * feed-forward): replaces model_seq.py:374-383 after the attention core */
+int amid_sas_oproj_ffn_fwd_f32(const float* o, const float* qn, const float* const* w_o, const float* const* b_o, const float* const* ln_w,
+                               const float* const* ln_b, const float* const* w1, const float* const* b1, const float* const* w2,
+                               const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D, int rows_per_tile, int layer,
+                               const void* step_state, int train, float p_drop, float* r, float* y, float* h, float* xo, int mma_bf16,
+                               void* stream);
+
 /* ---- K2 attention core ------------------------------------------------------------------------
  * replaces: softmax(q k^T + mask) dropout v inside nn.MultiheadAttention (model_seq.py:374, causal=1) and
  * Attention.forward of BERT4Rec (model_seq.py:149-162, causal=0 with key_keep [B,T] from seq_d2 > 0, :288).
