@@ -17,147 +17,14 @@
 // Causality skips the tiles above the diagonal (10 of 16 tiles at T = 50..64).
 // Dropout: p = 0.5 needs ONE Philox call per query row (1 bit per key, rng.h); lane (m, g) computes the row 16 g + m,
 // i.e. a single call sequence per wave covers all 64 rows; a row's word reaches its query tile with two shuffles.
-#include "common.h"
-#include "rng.h"
+#include "attention_mfma.h"
 
 namespace amid {
 
-struct AttnArgs {          // must stay identical to the struct in attention.hip
-    const float* q; const float* k; const float* v;
-    float* o;
-    float* stats;
-    const float* d_o; float* dq; float* dk; float* dv;
-    const unsigned char* key_keep;
-    int B, T, D, H;
-    int causal;
-    float scale;
-    const StepState* st; int train; unsigned thr16; float dscale; int layer;
-    int stagger_from, stagger_sleeps;      // set by the MFMA backward launcher only
-};
-
-constexpr int AHD = 16;
-constexpr float LOG2E = 1.4426950408889634f;
-// exp(x) as one v_exp_f32 (2^y, ~1 ulp): the softmax here evaluates ~2 500 exponentials per head, and the library expf
-// (range reduction + polynomial, ~12 instructions) was the largest VALU item of the kernel.
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x4 mfma_frag(float4 a, float4 b, f32x4 c) {
-    c = mfma4(a.x, b.x, c); c = mfma4(a.y, b.y, c); c = mfma4(a.z, b.z, c); c = mfma4(a.w, b.w, c);
-    return c;
-}
-__device__ __forceinline__ float4 ld4_row(const float* __restrict__ base, long long rowbase, int row, int T, int D, int col) {
-    return (row < T) ? ld4(base + (rowbase + row) * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-__device__ __forceinline__ float ld1_row(const float* __restrict__ base, long long rowbase, int row, int T, int D, int col) {
-    return (row < T) ? base[(rowbase + row) * D + col] : 0.f;
-}
-__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
-    const unsigned lo = __shfl((unsigned)v, src, 64), hi = __shfl((unsigned)(v >> 32), src, 64);
-    return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ float quad_group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float quad_group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
-
-// keep bits (1 = keep) of keys 0..63 of attention row `row` (row-major [b, h, i]); same indexing as attention.hip / the oracle
-__device__ __forceinline__ unsigned long long row_keep_word(unsigned long long seed, unsigned site, unsigned step, unsigned long long row, int T,
-                                                            unsigned spec) {
-    const int b = spec_bits(spec), per = 128 / b;
-    const unsigned thr = spec_thr(spec);
-    const int calls = (T + per - 1) / per;
-    if (b == 1) {                                        // the SASRec case: one call, keep <=> bit >= thr (thr = 1)
-        const uint4 r = rng_call(seed, row * calls, site, step);
-        const unsigned long long w = ((unsigned long long)r.y << 32) | r.x;
-        return thr ? w : ~0ull;
-    }
-    unsigned long long w = 0;
-    for (int c = 0; c * per < 64 && c < calls; ++c) {
-        const uint4 r = rng_call(seed, row * calls + c, site, step);
-        for (int f = 0; f < per; ++f)
-            if (rng_field(r, f, b) >= thr) w |= 1ull << (c * per + f);
-    }
-    return w;
-}
-
 __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const AttnArgs a) {
-    const int T = a.T, D = a.D, H = a.H;
-    const int hw = blockDim.x >> 6, parts = H / hw;
+    const int hw = blockDim.x >> 6, parts = a.H / hw;
     const int seq = blockIdx.x / parts, part = blockIdx.x - seq * parts, g = seq / a.B, b = seq - g * a.B;
-    const long long rowbase = (long long)seq * T;
-    const int h = part * hw + wave_id(), lane = lane_id();
-    const int m = lane & 15, gq = lane >> 4;
-    const int NT = (T + 15) >> 4;
-    const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
-    if (a.stagger_from > 0) {                                  // k-th resident of a CU starts k units late (see the backward kernel)
-        const int late = min((int)blockIdx.x / a.stagger_from, 7) * a.stagger_sleeps;
-#pragma unroll 1
-        for (int i = 0; i < late; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    // operands that every query tile reuses
-    float4 kf[4];
-    float vt[4][4];
-#pragma unroll
-    for (int kj = 0; kj < 4; ++kj) {
-        kf[kj] = ld4_row(a.k, rowbase, kj * 16 + m, T, D, col4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vt[kj][r] = ld1_row(a.v, rowbase, kj * 16 + 4 * gq + r, T, D, colm);
-    }
-    unsigned long long kw_own = ~0ull;
-    if (a.train) {
-        const int qrow = min(gq * 16 + m, T - 1);
-        kw_own = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step,
-                               (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
-    }
-    float4 qfr[4];
-#pragma unroll
-    for (int qi = 0; qi < 4; ++qi) qfr[qi] = f4scale(ld4_row(a.q, rowbase, qi * 16 + m, T, D, col4), a.scale);
-#pragma unroll
-    for (int qi = 0; qi < 4; ++qi) {
-        if (qi >= NT) break;
-        const int q = qi * 16 + m;
-        const float4 qf = qfr[qi];
-        const unsigned long long kw = shfl64(kw_own, qi * 16 + m);
-        f32x4 s[4];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kj = 0; kj < 4; ++kj) {
-            s[kj] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kj <= qi) {
-                s[kj] = mfma_frag(kf[kj], qf, s[kj]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = kj * 16 + 4 * gq + r;
-                    s[kj][r] = (n > q) ? -INFINITY : s[kj][r];
-                    mx = fmaxf(mx, s[kj][r]);
-                }
-            }
-        }
-        mx = quad_group_max(mx);
-        float l = 0.f;
-        f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kj = 0; kj < 4; ++kj) {
-            if (kj <= qi) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = kj * 16 + 4 * gq + r;
-                    const float p = fast_exp(s[kj][r] - mx);
-                    l += p;
-                    const float pd = ((kw >> n) & 1ull) ? p * a.dscale : 0.f;
-                    oacc = mfma4(vt[kj][r], pd, oacc);
-                }
-            }
-        }
-        l = quad_group_sum(l);
-        const float rl = 1.0f / l;
-        if (q < T) {
-            st4(a.o + (rowbase + q) * D + col4, make_float4(oacc[0] * rl, oacc[1] * rl, oacc[2] * rl, oacc[3] * rl));
-            if (gq == 0 && a.stats) {
-                float* sp = a.stats + ((rowbase + q) * H + h) * 2;
-                sp[0] = mx; sp[1] = rl;
-            }
-        }
-    }
+    attn_fwd_head(a, g, b, (long long)seq * a.T, part * hw + wave_id());
 }
 
 __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {

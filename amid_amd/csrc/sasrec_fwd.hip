@@ -38,14 +38,13 @@ struct QkvFwdArgs {
 };
 
 template <int D, bool BF>
-__global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_fwd_kernel(const QkvFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void qkv_fwd_body(const QkvFwdArgs& a, float* __restrict__ smem, int tile) {
     using RP = RowPass<D>;
     constexpr int LDK = TileCfg<D>::LDK;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
     int g, nrows, local0; long long row0;
-    tile_rows(a.tg, blockIdx.x, g, row0, nrows, local0);
+    tile_rows(a.tg, tile, g, row0, nrows, local0);
     const int nrt = (nrows + 15) >> 4;
     const int sub = RP::sub();
     TileRegs<D> xr;
@@ -85,6 +84,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_fwd_kernel(const QkvFwdA
         __syncthreads();
     }
 }
+
+template <int D, bool BF>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_fwd_kernel(const QkvFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    qkv_fwd_body<D, BF>(a, smem, blockIdx.x);
+}
+
 
 struct OprojFwdArgs {
     const float* o;                  // [2M, D] attention output (heads merged)
@@ -242,15 +248,14 @@ struct OprojFfnFwdArgs {
 };
 
 template <int D, bool BF>
-__global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_ffn_fwd_kernel(const OprojFfnFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void oproj_ffn_fwd_body(const OprojFfnFwdArgs& a, float* __restrict__ smem, int tile) {
     using RP = RowPass<D>;
     constexpr int LDC = D + 4;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
     float* Cs = Ws;
     int g, nrows, local0; long long row0;
-    tile_rows(a.tg, blockIdx.x, g, row0, nrows, local0);
+    tile_rows(a.tg, tile, g, row0, nrows, local0);
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
@@ -347,6 +352,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_ffn_fwd_kernel(const O
             st4(a.xo + (row0 + r) * D + 4 * sub, z);
         }
     }
+}
+
+template <int D, bool BF>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_ffn_fwd_kernel(const OprojFfnFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    oproj_ffn_fwd_body<D, BF>(a, smem, blockIdx.x);
 }
 
 }  // namespace amid

@@ -500,19 +500,20 @@ class SasrecEngine:
         L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"),
                B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, s)
         for l in (0, 1):
-            L.call("amid_sas_qkv_fwd_f32", pl.x[l].data_ptr(), self._pp(f"sac{{d}}.attention_layernorms.{l}.weight"),
-                   self._pp(f"sac{{d}}.attention_layernorms.{l}.bias"), self._pp(f"sac{{d}}.attention_layers.{l}.in_proj_weight"),
-                   self._pp(f"sac{{d}}.attention_layers.{l}.in_proj_bias"), SASREC_LN_EPS, M, D, pl.rpt, pl.qn[l].data_ptr(),
+            pre = f"sac{{d}}"
+            ln1w, ln1b = self._pp(f"{pre}.attention_layernorms.{l}.weight"), self._pp(f"{pre}.attention_layernorms.{l}.bias")
+            w_in, b_in = self._pp(f"{pre}.attention_layers.{l}.in_proj_weight"), self._pp(f"{pre}.attention_layers.{l}.in_proj_bias")
+            rest = (self._pp(f"{pre}.attention_layers.{l}.out_proj.weight"), self._pp(f"{pre}.attention_layers.{l}.out_proj.bias"),
+                    self._pp(f"{pre}.forward_layernorms.{l}.weight"), self._pp(f"{pre}.forward_layernorms.{l}.bias"),
+                    self._pp(f"{pre}.forward_layers.{l}.conv1.weight"), self._pp(f"{pre}.forward_layers.{l}.conv1.bias"),
+                    self._pp(f"{pre}.forward_layers.{l}.conv2.weight"), self._pp(f"{pre}.forward_layers.{l}.conv2.bias"))
+            L.call("amid_sas_qkv_fwd_f32", pl.x[l].data_ptr(), ln1w, ln1b, w_in, b_in, SASREC_LN_EPS, M, D, pl.rpt, pl.qn[l].data_ptr(),
                    pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), self.mma_bf16, s)
             L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), None, B, T, D, self.H, 1, l, st, tr,
                    SASREC_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
-            pre = f"sac{{d}}"
-            L.call("amid_sas_oproj_ffn_fwd_f32", pl.o[l].data_ptr(), pl.qn[l].data_ptr(), self._pp(f"{pre}.attention_layers.{l}.out_proj.weight"),
-                   self._pp(f"{pre}.attention_layers.{l}.out_proj.bias"), self._pp(f"{pre}.forward_layernorms.{l}.weight"),
-                   self._pp(f"{pre}.forward_layernorms.{l}.bias"), self._pp(f"{pre}.forward_layers.{l}.conv1.weight"),
-                   self._pp(f"{pre}.forward_layers.{l}.conv1.bias"), self._pp(f"{pre}.forward_layers.{l}.conv2.weight"),
-                   self._pp(f"{pre}.forward_layers.{l}.conv2.bias"), pl.tmq.data_ptr(), SASREC_LN_EPS, M, D, pl.rpt, l, st, tr, SASREC_P_DROP,
-                   pl.r[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(), self.mma_bf16, s)
+            L.call("amid_sas_oproj_ffn_fwd_f32", pl.o[l].data_ptr(), pl.qn[l].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
+                   pl.rpt, l, st, tr, SASREC_P_DROP, pl.r[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(),
+                   self.mma_bf16, s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
         if self.dr:
             self._enqueue_head_dr_fwd(pl, items, with_loss)
