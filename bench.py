@@ -96,8 +96,10 @@ def init_params(eng, seed):
         eng.dense.data.copy_(flat)
         for name in eng.dense.slots:
             v = eng.dense.view(name)
-            if "layernorm" in name and name.endswith("weight"):
+            if ("layernorm" in name and name.endswith("weight")) or name.endswith("norm.a_2"):
                 v.fill_(1.0)
+            elif name.endswith("norm.b_2"):
+                v.zero_()
             elif name.endswith("bias"):
                 v.zero_()
             elif name.endswith("pos_emb.weight"):
@@ -200,6 +202,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--model", default="sasrec", choices=("sasrec", "bert4rec"),
+                    help="sasrec (default, the headline); bert4rec: the same workload through the BERT4Rec encoder (reference a7), "
+                         "reported with config.model, never the headline line")
     ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
                     help="f32 (default, the headline): exact fp32 matrix products; bf16: bf16 MFMA operands with fp32 accumulation "
                          "(BASELINE.json configs[2]) -- reported with dtype bf16, never the headline line")
@@ -232,7 +237,11 @@ def main():
 
     wl = WORKLOADS[args.workload]
     Bw = wl["B"]
-    eng = SasrecEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234, compute=args.dtype)
+    if args.model == "bert4rec":
+        from amid_amd.engine_bert import Bert4recEngine
+        eng = Bert4recEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234)
+    else:
+        eng = SasrecEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234, compute=args.dtype)
     init_params(eng, seed=0)                  # identical replicas on every rank
     pl = eng.plan(Bw, T, 1 + NEG, need_grad=True)
     gen = torch.Generator().manual_seed(1000 + rank)          # each rank draws its own shard of the global batch
@@ -346,7 +355,8 @@ def main():
             "metric": "train samples/sec", "value": round(Bw * world * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": wl["label"], "batch_per_gpu": Bw,
+            "config": {"workload": wl["label"] if args.model == "sasrec" else wl["label"].replace("SASRec", "BERT4Rec"), "model": args.model,
+                       "batch_per_gpu": Bw,
                        "global_batch": Bw * world, "seq_len": T, "emb_dim": D, "hid_dim": HID, "neg": NEG, "table_rows": wl["n_rows"],
                        "unique_rows_last_step": int(pl.n_uniq.item()),
                        "dropout": "on (p=0.5)", "optimizer": "Adam (dense-equivalent lazy rows)", "graph": use_graph,
