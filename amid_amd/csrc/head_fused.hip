@@ -48,9 +48,13 @@ __device__ __forceinline__ void stage_w1t(float* __restrict__ w1t, const float* 
 // normalise) and was pure load latency (33 us for a kernel that moves 13 MB).
 constexpr int HEAD_CHUNK = 8;      // rows per row group per chunk
 
-__device__ __forceinline__ void lnmean_rows(const HeadArgs& a, int g, int b, float* __restrict__ red /* [8][D] */, float* __restrict__ u_s) {
+// 512 threads: threads 0..255 take domain 0, 256..511 domain 1 (both LayerNorm passes in flight at once: the kernel is one
+// latency chain per workgroup, and there is one workgroup per CU); red [2][8][D], u_s [2][D]
+__device__ __forceinline__ void lnmean_rows(const HeadArgs& a, int b, float* __restrict__ red_all, float* __restrict__ u_all) {
     const int D = a.D, T = a.T, q = D >> 2;
-    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int g = threadIdx.x >> 8;
+    const int sub = threadIdx.x & 31, rg = (threadIdx.x >> 5) & 7;
+    float* red = red_all + g * 8 * D;
     const bool use_ln = a.lnw[0] != nullptr;
     const float* w = a.lnw[g];
     const float* bb = a.lnb[g];
@@ -88,13 +92,14 @@ __device__ __forceinline__ void lnmean_rows(const HeadArgs& a, int g, int b, flo
         if (on) st4(red + rg * D + 4 * c, acc);
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < D; e += blockDim.x) {
+    for (int ge = threadIdx.x; ge < 2 * D; ge += blockDim.x) {
+        const int g2 = ge / D, e = ge - g2 * D;
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k * D + e];
+        for (int k = 0; k < 8; ++k) s += red_all[(g2 * 8 + k) * D + e];
         s /= T;
-        u_s[e] = s;
-        a.u[((long long)g * a.B + b) * D + e] = s;
+        u_all[ge] = s;
+        a.u[((long long)g2 * a.B + b) * D + e] = s;
     }
     __syncthreads();
 }
@@ -111,7 +116,7 @@ struct HeadLds {
 __host__ __device__ inline size_t head_lds_floats(int D, int hid) {
     size_t f = (size_t)2 * D * (hid + 1) + 2 * D + 4 * hid + hid + 4 + 128 * (hid + 1);
     f = (f + 3) & ~(size_t)3;
-    return f + 16 * D;
+    return f + 32 * D;          // scratch: [2][8][2][D] partials of the LayerNorm backward (forward uses half)
 }
 
 // au[d][j] = b1[j] + sum_e w1t[e][j] u_d[e]
@@ -142,13 +147,12 @@ __device__ __forceinline__ void item_half(const HeadArgs& a, const HeadLds& s, i
     }
 }
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
+__global__ __launch_bounds__(512) void head_fwd_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const HeadLds s(sm, a.D, a.hid);
     const int b = blockIdx.x, D = a.D, hid = a.hid, NI = a.NI;
     stage_w1t(s.w1t, a.w1, 2 * D, hid);
-    lnmean_rows(a, 0, b, s.scr, s.u_s);
-    lnmean_rows(a, 1, b, s.scr, s.u_s + D);
+    lnmean_rows(a, b, s.scr, s.u_s);
     user_half(a, s);
     float lsum = 0.f;
     for (int n0 = 0; n0 < NI; n0 += 64) {
@@ -178,14 +182,18 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
         lsum = group_sum<64>(lsum);
         if (lane_id() == 0) s.scr[wave_id()] = lsum;
         __syncthreads();
-        if (threadIdx.x == 0) a.loss_part[b] = ((s.scr[0] + s.scr[1]) + (s.scr[2] + s.scr[3]));
+        if (threadIdx.x == 0) a.loss_part[b] = ((s.scr[0] + s.scr[1]) + (s.scr[2] + s.scr[3])) + ((s.scr[4] + s.scr[5]) + (s.scr[6] + s.scr[7]));
     }
 }
 
 // dx rows of (g, b) from du_s[D] (LDS): dx = LN_last'(du / T ; x) ; partial d gamma / d beta -> ln_part[(g*B+b)][2][D]
-__device__ __forceinline__ void lnmean_rows_bwd(const HeadArgs& a, int g, int b, const float* __restrict__ du_s, float* __restrict__ red /* [8][2][D] */) {
+__device__ __forceinline__ void lnmean_rows_bwd(const HeadArgs& a, int b, const float* __restrict__ du_all /* [2][D] */,
+                                                float* __restrict__ red_all /* [2][8][2][D] */) {
     const int D = a.D, T = a.T, q = D >> 2;
-    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int g = threadIdx.x >> 8;
+    const int sub = threadIdx.x & 31, rg = (threadIdx.x >> 5) & 7;
+    const float* du_s = du_all + g * D;
+    float* red = red_all + g * 16 * D;
     const bool use_ln = a.lnw[0] != nullptr;
     const float* w = a.lnw[g];
     const float invT = 1.0f / T;
@@ -235,17 +243,18 @@ __device__ __forceinline__ void lnmean_rows_bwd(const HeadArgs& a, int g, int b,
     }
     __syncthreads();
     if (use_ln) {
-        for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
+        for (int ge = threadIdx.x; ge < 4 * D; ge += blockDim.x) {
+            const int g2 = ge / (2 * D), e = ge - g2 * 2 * D;
             float sacc = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) sacc += red[k * 2 * D + e];
-            a.ln_part[((long long)g * a.B + b) * 2 * D + e] = sacc;
+            for (int k = 0; k < 8; ++k) sacc += red_all[g2 * 16 * D + k * 2 * D + e];
+            a.ln_part[((long long)g2 * a.B + b) * 2 * D + e] = sacc;
         }
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void head_bwd_kernel(const HeadArgs a) {
+__global__ __launch_bounds__(512) void head_bwd_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = a.D, hid = a.hid, NI = a.NI;
     if ((int)blockIdx.x >= a.B) {
@@ -258,9 +267,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadArgs a) {
             const float* __restrict__ src = a.tr_src[m];
             float* __restrict__ dst = a.tr_dst[m];
             __syncthreads();
-            for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(long long)(by + r) * D + bx + tx];
+            for (int r = ty; r < 32; r += 16) tile[r][tx] = src[(long long)(by + r) * D + bx + tx];
             __syncthreads();
-            for (int r = ty; r < 32; r += 8) dst[(long long)(bx + r) * D + by + tx] = tile[tx][r];
+            for (int r = ty; r < 32; r += 16) dst[(long long)(bx + r) * D + by + tx] = tile[tx][r];
         }
         return;
     }
@@ -344,8 +353,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadArgs a) {
     }
     if (threadIdx.x == 0) part[hid * 2 * D + 2 * hid] = s.dw2[hid];   // db2
     __syncthreads();
-    lnmean_rows_bwd(a, 0, b, du_s, s.scr);
-    lnmean_rows_bwd(a, 1, b, du_s + D, s.scr);
+    lnmean_rows_bwd(a, b, du_s, s.scr);
 }
 
 }  // namespace amid
@@ -382,7 +390,7 @@ extern "C" int amid_head_fwd_f32(const float* x, const float* const* ln_w, const
     const size_t lds = head_lds_floats(D, hid) * sizeof(float);
     if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
     if (int e = head_lds_attr((const void*)head_fwd_kernel, lds)) return e;
-    head_fwd_kernel<<<B, 256, lds, (hipStream_t)stream>>>(a);
+    head_fwd_kernel<<<B, 512, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
@@ -403,7 +411,7 @@ extern "C" int amid_head_bwd_f32(const float* x, const float* const* ln_w, const
     if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
     if (int e = head_lds_attr((const void*)head_bwd_kernel, lds)) return e;
     const int extra = n_tr > 0 ? min(n_tr * (D / 32) * (D / 32), 96) : 0;
-    head_bwd_kernel<<<B + extra, 256, lds, (hipStream_t)stream>>>(a);
+    head_bwd_kernel<<<B + extra, 512, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
