@@ -80,15 +80,14 @@ struct FfnBwdArgs {
 };
 
 template <int D, bool BF>
-__global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_bwd_kernel(const FfnBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restrict__ smem, int tile) {
     using RP = RowPass<D>;
     constexpr int LDK = TileCfg<D>::LDK, LDC = D + 4;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
     float* Cs = Ws;
     int g, nrows, local0; long long row0;
-    tile_rows_b(a.tg, blockIdx.x, g, row0, nrows, local0);
+    tile_rows_b(a.tg, tile, g, row0, nrows, local0);
     const int nrt = (nrows + 15) >> 4;
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_bwd_kernel(const FfnBwdA
     mma_tile<D, D, BF>(As, Ws, acc);
     acc_to_global<D>(a.d_o, row0, nrows, D, nullptr, acc);
     __syncthreads();                                      // As is free now: reduction scratch for the LN partials
-    ln_partials_out<D>(As, dgam, dbet, a.ln_part + (long long)blockIdx.x * 2 * D);
+    ln_partials_out<D>(As, dgam, dbet, a.ln_part + (long long)tile * 2 * D);
 }
 
 struct QkvBwdArgs {
@@ -189,14 +188,13 @@ struct QkvBwdArgs {
 };
 
 template <int D, bool BF>
-__global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_bwd_kernel(const QkvBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void qkv_bwd_body(const QkvBwdArgs& a, float* __restrict__ smem, int tile) {
     using RP = RowPass<D>;
     constexpr int LDC = D + 4;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
     int g, nrows, local0; long long row0;
-    tile_rows_b(a.tg, blockIdx.x, g, row0, nrows, local0);
+    tile_rows_b(a.tg, tile, g, row0, nrows, local0);
     const int nrt = (nrows + 15) >> 4;
     const int sub = RP::sub();
     f32x4 acc_kv[WaveMap<D>::ACC], acc_q[WaveMap<D>::ACC];
@@ -244,7 +242,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_bwd_kernel(const QkvBwdA
         }
     }
     __syncthreads();
-    ln_partials_out<D>(Ws, dgam, dbet, a.ln_part + (long long)blockIdx.x * 2 * D);
+    ln_partials_out<D>(Ws, dgam, dbet, a.ln_part + (long long)tile * 2 * D);
+}
+
+template <int D, bool BF>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_bwd_kernel(const FfnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ffn_bwd_body<D, BF>(a, smem, blockIdx.x);
+}
+
+template <int D, bool BF>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_bwd_kernel(const QkvBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    qkv_bwd_body<D, BF>(a, smem, blockIdx.x);
+}
+
+// layer l + 1's q / k / v + LayerNorm1 backward followed by layer l's feed-forward / out-projection backward on the same row
+// tile, one launch: the tile's rows of d x[l + 1] are read back by the workgroup that has just written them
+struct QkvFfnBwdArgs { QkvBwdArgs qkv; FfnBwdArgs ffn; TileGeomB tg; };
+
+template <int D, bool BF>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_ffn_bwd_kernel(const QkvFfnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    qkv_bwd_body<D, BF>(a.qkv, smem, blockIdx.x);
+    __threadfence_block();
+    __syncthreads();
+    ffn_bwd_body<D, BF>(a.ffn, smem, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -476,6 +499,37 @@ extern "C" int amid_sas_qkv_bwd_f32(const float* dq, const float* dk, const floa
     if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 128, true);
     else if (D == 128) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 128, false);
     else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 64, false);
+    else return AMID_ERR_UNSUPPORTED;
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// amid_sas_qkv_bwd_f32 of layer l + 1 followed by amid_sas_ffn_bwd_f32 of layer l (f* arguments; its dxo is the dx just produced)
+extern "C" int amid_sas_qkv_ffn_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                        const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
+                                        float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part,
+                                        const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
+                                        const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
+                                        const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o,
+                                        float* fln_part, int mma_bf16, void* stream) {
+    AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && dx && ln_part);
+    AMID_CHECK_ARG(fh && fr && fln_w && fw1T && fw2T && fwoT && fdpre2 && fdpre1 && fdr && fd_o && fln_part && (!train || step_state));
+    QkvFfnBwdArgs a;
+    a.qkv.dq = dq; a.qkv.dk = dk; a.qkv.dv = dv; a.qkv.dr = dr; a.qkv.x = x; a.qkv.dx = dx; a.qkv.ln_part = ln_part; a.qkv.ln_eps = ln_eps;
+    a.ffn.dxo = dx; a.ffn.tmq = tmq; a.ffn.h = fh; a.ffn.r = fr; a.ffn.dpre2 = fdpre2; a.ffn.dpre1 = fdpre1; a.ffn.dr = fdr; a.ffn.d_o = fd_o;
+    a.ffn.ln_part = fln_part; a.ffn.ln_eps = ln_eps; a.ffn.st = (const StepState*)step_state; a.ffn.layer = flayer;
+    a.ffn.train = (train && p_drop > 0.f) ? 1 : 0;
+    a.ffn.thr16 = keep_thr16(p_drop);
+    a.ffn.scale = a.ffn.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+    for (int g = 0; g < 2; ++g) {
+        a.qkv.ln_w[g] = ln_w[g]; a.qkv.wqT[g] = wqT[g]; a.qkv.wkT[g] = wkT[g]; a.qkv.wvT[g] = wvT[g];
+        a.ffn.ln_w[g] = fln_w[g]; a.ffn.w1T[g] = fw1T[g]; a.ffn.w2T[g] = fw2T[g]; a.ffn.woT[g] = fwoT[g];
+    }
+    if (int e = make_geom_b(M, rows_per_tile, &a.tg)) return e;
+    a.qkv.tg = a.tg; a.ffn.tg = a.tg;
+    if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED_B(sas_qkv_ffn_bwd_kernel, a, 128, true);
+    else if (D == 128) AMID_LAUNCH_FUSED_B(sas_qkv_ffn_bwd_kernel, a, 128, false);
+    else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED_B(sas_qkv_ffn_bwd_kernel, a, 64, false);
     else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();
     return AMID_OK;

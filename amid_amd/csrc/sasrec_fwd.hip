@@ -360,6 +360,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_ffn_fwd_kernel(const O
     oproj_ffn_fwd_body<D, BF>(a, smem, blockIdx.x);
 }
 
+// layer l's out-projection + feed-forward followed by layer l + 1's LayerNorm + q / k / v projections on the same row tile, one
+// launch: the tile's rows of x[l + 1] are read back by the workgroup that has just written them (L2), and one launch + prologue
+// of the forward pass disappears
+struct OprojFfnQkvArgs { OprojFfnFwdArgs of; QkvFwdArgs qkv; TileGeom tg; };
+
+template <int D, bool BF>
+__global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_ffn_qkv_fwd_kernel(const OprojFfnQkvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    oproj_ffn_fwd_body<D, BF>(a.of, smem, blockIdx.x);
+    __threadfence_block();
+    __syncthreads();
+    qkv_fwd_body<D, BF>(a.qkv, smem, blockIdx.x);
+}
+
 }  // namespace amid
 
 using namespace amid;
@@ -471,6 +485,37 @@ extern "C" int amid_sas_oproj_ffn_fwd_f32(const float* o, const float* qn, const
     if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED(sas_oproj_ffn_fwd_kernel, a, 128, true);
     else if (D == 128) AMID_LAUNCH_FUSED(sas_oproj_ffn_fwd_kernel, a, 128, false);
     else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED(sas_oproj_ffn_fwd_kernel, a, 64, false);
+    else return AMID_ERR_UNSUPPORTED;
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_sas_oproj_ffn_qkv_fwd_f32(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
+                                              const float* const* ln_w, const float* const* ln_b, const float* const* w1, const float* const* b1,
+                                              const float* const* w2, const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D,
+                                              int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* r, float* y,
+                                              float* h, float* xo, const float* const* nln_w, const float* const* nln_b,
+                                              const float* const* nw_in, const float* const* nb_in, float* nqn, float* nq, float* nk, float* nv,
+                                              int mma_bf16, void* stream) {
+    AMID_CHECK_ARG(o && qn && w_o && b_o && ln_w && ln_b && w1 && b1 && w2 && b2 && r && y && h && xo && (!train || step_state));
+    AMID_CHECK_ARG(nln_w && nln_b && nw_in && nb_in && nqn && nq && nk && nv);
+    OprojFfnQkvArgs a;
+    a.of.o = o; a.of.qn = qn; a.of.tmq = tmq; a.of.r = r; a.of.y = y; a.of.h = h; a.of.xo = xo; a.of.ln_eps = ln_eps;
+    a.of.st = (const StepState*)step_state; a.of.layer = layer;
+    a.of.train = (train && p_drop > 0.f) ? 1 : 0;
+    a.of.thr16 = keep_thr16(p_drop);
+    a.of.scale = a.of.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+    for (int g = 0; g < 2; ++g) {
+        a.of.w_o[g] = w_o[g]; a.of.b_o[g] = b_o[g]; a.of.ln_w[g] = ln_w[g]; a.of.ln_b[g] = ln_b[g];
+        a.of.w1[g] = w1[g]; a.of.b1[g] = b1[g]; a.of.w2[g] = w2[g]; a.of.b2[g] = b2[g];
+        a.qkv.ln_w[g] = nln_w[g]; a.qkv.ln_b[g] = nln_b[g]; a.qkv.w_in[g] = nw_in[g]; a.qkv.b_in[g] = nb_in[g];
+    }
+    a.qkv.x = xo; a.qkv.qn = nqn; a.qkv.q = nq; a.qkv.k = nk; a.qkv.v = nv; a.qkv.ln_eps = ln_eps;
+    if (int e = make_geom(M, rows_per_tile, &a.of.tg)) return e;
+    a.qkv.tg = a.of.tg; a.tg = a.of.tg;
+    if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED(sas_oproj_ffn_qkv_fwd_kernel, a, 128, true);
+    else if (D == 128) AMID_LAUNCH_FUSED(sas_oproj_ffn_qkv_fwd_kernel, a, 128, false);
+    else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED(sas_oproj_ffn_qkv_fwd_kernel, a, 64, false);
     else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();
     return AMID_OK;

@@ -499,21 +499,31 @@ class SasrecEngine:
         fp = self.dense
         L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"),
                B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, s)
-        for l in (0, 1):
+        def layer_ptrs(l):
             pre = f"sac{{d}}"
-            ln1w, ln1b = self._pp(f"{pre}.attention_layernorms.{l}.weight"), self._pp(f"{pre}.attention_layernorms.{l}.bias")
-            w_in, b_in = self._pp(f"{pre}.attention_layers.{l}.in_proj_weight"), self._pp(f"{pre}.attention_layers.{l}.in_proj_bias")
-            rest = (self._pp(f"{pre}.attention_layers.{l}.out_proj.weight"), self._pp(f"{pre}.attention_layers.{l}.out_proj.bias"),
-                    self._pp(f"{pre}.forward_layernorms.{l}.weight"), self._pp(f"{pre}.forward_layernorms.{l}.bias"),
-                    self._pp(f"{pre}.forward_layers.{l}.conv1.weight"), self._pp(f"{pre}.forward_layers.{l}.conv1.bias"),
-                    self._pp(f"{pre}.forward_layers.{l}.conv2.weight"), self._pp(f"{pre}.forward_layers.{l}.conv2.bias"))
-            L.call("amid_sas_qkv_fwd_f32", pl.x[l].data_ptr(), ln1w, ln1b, w_in, b_in, SASREC_LN_EPS, M, D, pl.rpt, pl.qn[l].data_ptr(),
-                   pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), self.mma_bf16, s)
+            return ((self._pp(f"{pre}.attention_layernorms.{l}.weight"), self._pp(f"{pre}.attention_layernorms.{l}.bias"),
+                     self._pp(f"{pre}.attention_layers.{l}.in_proj_weight"), self._pp(f"{pre}.attention_layers.{l}.in_proj_bias")),
+                    (self._pp(f"{pre}.attention_layers.{l}.out_proj.weight"), self._pp(f"{pre}.attention_layers.{l}.out_proj.bias"),
+                     self._pp(f"{pre}.forward_layernorms.{l}.weight"), self._pp(f"{pre}.forward_layernorms.{l}.bias"),
+                     self._pp(f"{pre}.forward_layers.{l}.conv1.weight"), self._pp(f"{pre}.forward_layers.{l}.conv1.bias"),
+                     self._pp(f"{pre}.forward_layers.{l}.conv2.weight"), self._pp(f"{pre}.forward_layers.{l}.conv2.bias")))
+
+        qkv0, rest0 = layer_ptrs(0)
+        qkv1, rest1 = layer_ptrs(1)
+        L.call("amid_sas_qkv_fwd_f32", pl.x[0].data_ptr(), *qkv0, SASREC_LN_EPS, M, D, pl.rpt, pl.qn[0].data_ptr(), pl.q[0].data_ptr(),
+               pl.k[0].data_ptr(), pl.v[0].data_ptr(), self.mma_bf16, s)
+        for l in (0, 1):
             L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), None, B, T, D, self.H, 1, l, st, tr,
                    SASREC_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
-            L.call("amid_sas_oproj_ffn_fwd_f32", pl.o[l].data_ptr(), pl.qn[l].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
-                   pl.rpt, l, st, tr, SASREC_P_DROP, pl.r[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(),
-                   self.mma_bf16, s)
+            rest = rest0 if l == 0 else rest1
+            if l == 0:      # layer 0's out-projection + feed-forward and layer 1's LayerNorm + q / k / v: one launch
+                L.call("amid_sas_oproj_ffn_qkv_fwd_f32", pl.o[0].data_ptr(), pl.qn[0].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
+                       pl.rpt, 0, st, tr, SASREC_P_DROP, pl.r[0].data_ptr(), pl.y[0].data_ptr(), pl.h[0].data_ptr(), pl.x[1].data_ptr(),
+                       *qkv1, pl.qn[1].data_ptr(), pl.q[1].data_ptr(), pl.k[1].data_ptr(), pl.v[1].data_ptr(), self.mma_bf16, s)
+            else:
+                L.call("amid_sas_oproj_ffn_fwd_f32", pl.o[l].data_ptr(), pl.qn[l].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
+                       pl.rpt, l, st, tr, SASREC_P_DROP, pl.r[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(),
+                       self.mma_bf16, s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
         if self.dr:
             self._enqueue_head_dr_fwd(pl, items, with_loss)
@@ -637,18 +647,31 @@ class SasrecEngine:
                    fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, T, NI, D,
                    self.hid, SASREC_LN_EPS, pl.dxbuf.data_ptr(), ditems, pl.last_part.data_ptr(), pl.sc_part.data_ptr(),
                    ptr_array(src), ptr_array(dst), len(src), s)
-        for l in (1, 0):
-            L.call("amid_sas_ffn_bwd_f32", pl.dxbuf.data_ptr(), pl.tmq.data_ptr(), pl.h[l].data_ptr(), pl.r[l].data_ptr(),
-                   self._pp(f"sac{{d}}.forward_layernorms.{l}.weight"), self._wT(l, 4), self._wT(l, 5), self._wT(l, 3), SASREC_LN_EPS,
-                   M, D, pl.rpt, l, st, tr, SASREC_P_DROP, pl.dpre2[l].data_ptr(), pl.dpre1[l].data_ptr(), pl.dr[l].data_ptr(),
-                   pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), self.mma_bf16, s)
+        def ffn_bwd_args(l):
+            return (pl.tmq.data_ptr(), pl.h[l].data_ptr(), pl.r[l].data_ptr(), self._pp(f"sac{{d}}.forward_layernorms.{l}.weight"),
+                    self._wT(l, 4), self._wT(l, 5), self._wT(l, 3))
+
+        def attn_bwd(l):
             L.call("amid_attn_bwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(),
                    pl.stats[l].data_ptr(), pl.d_o.data_ptr(), None, B, T, D, self.H, 1, l, st, tr, SASREC_P_DROP, pl.dq_l[l].data_ptr(),
                    pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), s)
-            dx_out = pl.dxg if l == 0 else pl.dxbuf
-            L.call("amid_sas_qkv_bwd_f32", pl.dq_l[l].data_ptr(), pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), pl.dr[l].data_ptr(),
-                   pl.x[l].data_ptr(), self._pp(f"sac{{d}}.attention_layernorms.{l}.weight"), self._wT(l, 0), self._wT(l, 1),
-                   self._wT(l, 2), SASREC_LN_EPS, M, D, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), self.mma_bf16, s)
+
+        tm, h1, r1, lnw1, w1T1, w2T1, woT1 = ffn_bwd_args(1)
+        L.call("amid_sas_ffn_bwd_f32", pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, M, D, pl.rpt, 1, st, tr,
+               SASREC_P_DROP, pl.dpre2[1].data_ptr(), pl.dpre1[1].data_ptr(), pl.dr[1].data_ptr(), pl.d_o.data_ptr(),
+               pl.ln2_part[1].data_ptr(), self.mma_bf16, s)
+        attn_bwd(1)
+        # layer 1's q / k / v + LayerNorm1 backward and layer 0's feed-forward / out-projection backward: one launch
+        tm, h0, r0, lnw0, w1T0, w2T0, woT0 = ffn_bwd_args(0)
+        L.call("amid_sas_qkv_ffn_bwd_f32", pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
+               pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
+               SASREC_LN_EPS, M, D, pl.rpt, pl.dxbuf.data_ptr(), pl.ln1_part[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr,
+               SASREC_P_DROP, pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(),
+               pl.ln2_part[0].data_ptr(), self.mma_bf16, s)
+        attn_bwd(0)
+        L.call("amid_sas_qkv_bwd_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
+               pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
+               SASREC_LN_EPS, M, D, pl.rpt, pl.dxg.data_ptr(), pl.ln1_part[0].data_ptr(), self.mma_bf16, s)
         dy, xx = [], []
         for l in (0, 1):
             dy += [pl.dq_l[l].data_ptr(), pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), pl.dr[l].data_ptr(), pl.dpre1[l].data_ptr(),

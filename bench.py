@@ -118,9 +118,11 @@ def algorithmic_work(Bw=B, n_uniq=None):
         "amid_sas_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_sas_oproj_fwd_f32": ("mfma", gemm),
         "amid_sas_oproj_ffn_fwd_f32": ("mfma", 3 * gemm),
+        "amid_sas_oproj_ffn_qkv_fwd_f32": ("mfma", 6 * gemm),
         "amid_sas_ffn_fwd_f32": ("mfma", 2 * gemm),
         "amid_sas_ffn_bwd_f32": ("mfma", 3 * gemm),
         "amid_sas_qkv_bwd_f32": ("mfma", 3 * gemm),
+        "amid_sas_qkv_ffn_bwd_f32": ("mfma", 6 * gemm),
         "amid_sas_wgrad_f32": ("mfma", 12 * gemm),          # both layers in one launch
         "amid_attn_fwd_f32": ("valu", 4.0 * T * T * hd * 2 * Bw * H),
         "amid_attn_bwd_f32": ("valu", 10.0 * T * T * hd * 2 * Bw * H),

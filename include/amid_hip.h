@@ -131,6 +131,14 @@ int amid_sas_oproj_ffn_fwd_f32(const float* o, const float* qn, const float* con
                                const void* step_state, int train, float p_drop, float* r, float* y, float* h, float* xo, int mma_bf16,
                                void* stream);
 
+/* amid_sas_oproj_ffn_fwd_f32 of layer l followed by amid_sas_qkv_fwd_f32 of layer l + 1 (n* arguments) on the same row tile, ONE launch */
+int amid_sas_oproj_ffn_qkv_fwd_f32(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
+                                   const float* const* ln_w, const float* const* ln_b, const float* const* w1, const float* const* b1,
+                                   const float* const* w2, const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D,
+                                   int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* r, float* y, float* h,
+                                   float* xo, const float* const* nln_w, const float* const* nln_b, const float* const* nw_in,
+                                   const float* const* nb_in, float* nqn, float* nq, float* nk, float* nv, int mma_bf16, void* stream);
+
 /* ---- K2 attention core ------------------------------------------------------------------------
  * replaces: softmax(q k^T + mask) dropout v inside nn.MultiheadAttention (model_seq.py:374, causal=1) and
  * Attention.forward of BERT4Rec (model_seq.py:149-162, causal=0 with key_keep [B,T] from seq_d2 > 0, :288).
@@ -150,6 +158,14 @@ int amid_sas_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float
 int amid_sas_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
                          const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
                          int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream);
+/* amid_sas_qkv_bwd_f32 of layer l + 1 followed by amid_sas_ffn_bwd_f32 of layer l (f* arguments; its dxo is the dx just produced) on the
+ * same row tile, ONE launch */
+int amid_sas_qkv_ffn_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
+                             const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
+                             int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
+                             const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
+                             int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
+                             float* fd_o, float* fln_part, int mma_bf16, void* stream);
 /* the six weight + bias gradients of n_layers (1 or 2) layers as split partials, ONE launch (two workgroups per CU): dy / x are host
  * arrays of 6 * n_layers device pointers, per layer in the order in_proj q, k, v, out_proj, conv1, conv2; w_part / b_part are host
  * arrays of n_layers device pointers to [2][6][splits][D*D] and [2][6][splits][D] */
