@@ -283,6 +283,10 @@ using namespace amid;
 int amid_attn_mfma_fwd_launch(const void* args, void* stream);
 int amid_attn_mfma_bwd_launch(const void* args, void* stream);
 static bool mfma_shape(const AttnArgs& a) { return a.causal && a.key_keep == nullptr && a.D / a.H == 16 && a.T <= 64 && a.H <= 8; }
+// attention_mfma_bert.hip: matrix-core kernels for the bidirectional head-dim-32 T <= 64 case (key mask optional)
+int amid_attn_bert_fwd_launch(const void* args, void* stream);
+int amid_attn_bert_bwd_launch(const void* args, void* stream);
+static bool bert_shape(const AttnArgs& a) { return !a.causal && a.D / a.H == 32 && a.T <= 64 && a.H <= 8; }
 
 static size_t attn_fwd_lds(int T, int D) { return (size_t)2 * T * D * sizeof(float); }
 static size_t attn_bwd_lds(int T, int D, int H) {
@@ -325,6 +329,7 @@ extern "C" int amid_attn_fwd_f32(const float* q, const float* k, const float* v,
     AMID_CHECK_ARG(o);
     a.o = o; a.stats = stats;
     if (mfma_shape(a)) return amid_attn_mfma_fwd_launch(&a, stream);
+    if (bert_shape(a)) return amid_attn_bert_fwd_launch(&a, stream);
     const size_t lds = attn_fwd_lds(T, D);
     if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
     switch (D / H) {
@@ -343,6 +348,7 @@ extern "C" int amid_attn_bwd_f32(const float* q, const float* k, const float* v,
     AMID_CHECK_ARG(o && stats && d_o && dq && dk && dv);
     a.o = const_cast<float*>(o); a.stats = const_cast<float*>(stats); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
     if (mfma_shape(a)) return amid_attn_mfma_bwd_launch(&a, stream);
+    if (bert_shape(a)) return amid_attn_bert_bwd_launch(&a, stream);
     const size_t lds = attn_bwd_lds(T, D, H);
     if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
     switch (D / H) {

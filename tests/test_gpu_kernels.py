@@ -338,6 +338,49 @@ def test_attention_fwd_bwd_vs_autograd(L, T, train):
         assert relmax(dq[sl], qq.grad) < 5e-6 and relmax(dk[sl], kk.grad) < 5e-6 and relmax(dv[sl], vv.grad) < 5e-6, dom
 
 
+@pytest.mark.parametrize("T", [64, 50, 17, 70])          # <= 64: matrix-core kernels (attention_mfma_bert.hip); 70: general VALU kernels
+@pytest.mark.parametrize("train", [0, 1])
+def test_attention_bert_shape_fwd_bwd_vs_autograd(L, T, train):
+    """Bidirectional attention of BERT4Rec (model_seq.py:149-162): 4 heads of 32, scores / sqrt(d_k), masked keys at -1e9 (one row
+    with EVERY key masked: uniform softmax, no score gradient), dropout 0.1 from the counter RNG."""
+    B, D, H, p = 3, 128, 4, 0.1
+    g = torch.Generator().manual_seed(100 + T + train)
+    q, k, v, do = (torch.randn(2 * B, T, D, generator=g) for _ in range(4))
+    keep = torch.rand(B, T, generator=g) > 0.3
+    keep[0] = False                                        # every key of batch row 0 masked
+    keep[1] = True
+    seed, step, layer = 78, 6, 0
+    st = step_state(L, seed, step)
+    qd, kd, vd, dod = dev(q), dev(k), dev(v), dev(do)
+    kk = keep.to(torch.uint8).cuda()
+    o = torch.empty_like(qd); stats = torch.empty(2 * B * T, H, 2, device="cuda")
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(qd), torch.empty_like(qd)
+    L.call("amid_attn_fwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), kk.data_ptr(), B, T, D, H, 0, layer, st.data_ptr(), train, p,
+           o.data_ptr(), stats.data_ptr(), stream())
+    L.call("amid_attn_bwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), stats.data_ptr(), dod.data_ptr(), kk.data_ptr(), B, T,
+           D, H, 0, layer, st.data_ptr(), train, p, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), stream())
+    torch.cuda.synchronize()
+    dkk = D // H
+    for dom in range(2):
+        sl = slice(dom * B, (dom + 1) * B)
+        mask = None
+        if train:
+            TP = orc.attn_row_stride(T, p)
+            mm = orc.philox_keep_flat(B * H * T * TP, seed, orc.site_id(dom, layer, orc.SITE_ATTN), step, p)
+            mask = torch.from_numpy(mm.reshape(B, H, T, TP)[..., :T].copy())
+        qq, kx, vv = (t[sl].clone().double().requires_grad_(True) for t in (q, k, v))
+        qh, kh, vh = (t.reshape(B, T, H, dkk).permute(0, 2, 1, 3) for t in (qq, kx, vv))
+        S = (qh @ kh.transpose(-2, -1)) / (dkk ** 0.5)
+        S = S.masked_fill(~keep[:, None, None, :], -1e9)
+        A = torch.softmax(S, -1)
+        if mask is not None:
+            A = A * mask.double() / (1.0 - p)
+        want = (A @ vh).permute(0, 2, 1, 3).reshape(B, T, D)
+        want.backward(do[sl].double())
+        assert relmax(o[sl], want.detach()) < 3e-6, (dom, "o")
+        assert relmax(dq[sl], qq.grad) < 1e-5 and relmax(dk[sl], kx.grad) < 1e-5 and relmax(dv[sl], vv.grad) < 1e-5, dom
+
+
 def test_positive_rank_matches_reference_metrics(L):
     """Device ranks -> the seven metrics of the reference's get_sample_scores (g8 golden: HR/NDCG@1,5,10 + MRR, with a tie)."""
     import os
