@@ -265,9 +265,8 @@ template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_ffn_bwd_kernel(const QkvFfnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     qkv_bwd_body<D, BF>(a.qkv, smem, blockIdx.x);
-    __threadfence();                                        // this tile's rows are complete in L2 ...
-    __syncthreads();
-    __threadfence();                                        // ... and no wave of the workgroup reads them from a stale L1 line
+    __threadfence_block();      // workgroup scope is enough (rows written and read by the same workgroup, never read before);
+    __syncthreads();            // an agent-scope fence here costs 0.12 ms per step (L2 write-back + invalidate in 229 workgroups x 2)
     ffn_bwd_body<D, BF>(a.ffn, smem, blockIdx.x);
 }
 

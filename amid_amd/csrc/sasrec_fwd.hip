@@ -369,9 +369,8 @@ template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_ffn_qkv_fwd_kernel(const OprojFfnQkvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     oproj_ffn_fwd_body<D, BF>(a.of, smem, blockIdx.x);
-    __threadfence();                                        // this tile's rows are complete in L2 ...
-    __syncthreads();
-    __threadfence();                                        // ... and no wave of the workgroup reads them from a stale L1 line
+    __threadfence_block();      // workgroup scope is enough (rows written and read by the same workgroup, never read before);
+    __syncthreads();            // an agent-scope fence here costs 0.12 ms per step (L2 write-back + invalidate in 229 workgroups x 2)
     qkv_fwd_body<D, BF>(a.qkv, smem, blockIdx.x);
 }
 
