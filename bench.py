@@ -357,7 +357,7 @@ def main():
             "metric": "train samples/sec", "value": round(Bw * world * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": wl["label"] if args.model == "sasrec" else wl["label"].replace("SASRec", "BERT4Rec"), "model": args.model,
+            "config": {"workload": wl["label"] if args.model == "sasrec" else wl["label"].replace("SASRec", "BERT4Rec") + " [encoder: bert4rec]",
                        "batch_per_gpu": Bw,
                        "global_batch": Bw * world, "seq_len": T, "emb_dim": D, "hid_dim": HID, "neg": NEG, "table_rows": wl["n_rows"],
                        "unique_rows_last_step": int(pl.n_uniq.item()),
