@@ -10,6 +10,7 @@
 // a run that lies inside one chunk is finished there; a run that crosses chunk borders leaves one
 // partial per chunk, and the chunk in which the run starts adds the partials up in chunk order.
 #include "common.h"
+#include "reduce_partials.h"
 
 namespace amid {
 
@@ -49,12 +50,12 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, long long ro
 // every run change: control flow is wave-uniform (run indices come from readlane-style shuffles), no global load
 // sits on the per-run critical path.
 template <int VEC>
-__global__ __launch_bounds__(256) void segreduce_chunks_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
-                                                               const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
-                                                               float* __restrict__ partial) {
+__device__ __forceinline__ void segreduce_chunks_block(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
+                                                       const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
+                                                       float* __restrict__ partial, int block) {
     const int D = VEC * 64;
     const int lane = lane_id();
-    const int c = blockIdx.x * 4 + wave_id();
+    const int c = block * 4 + wave_id();
     const int e0 = c * SEG_CHUNK;
     if (e0 >= n) return;
     const int cnt = min(SEG_CHUNK, n - e0);
@@ -97,6 +98,27 @@ __global__ __launch_bounds__(256) void segreduce_chunks_kernel(const float* __re
         }
     }
     flush(cur);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void segreduce_chunks_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
+                                                               const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
+                                                               float* __restrict__ partial) {
+    segreduce_chunks_block<VEC>(grad_rows, pos_sorted, seg_of, n, uniq_grad, partial, blockIdx.x);
+}
+
+// The two independent, bandwidth-bound ends of backward in ONE launch: blocks [0, n_seg) run phase A of the segment reduce, blocks
+// [n_seg, n_seg + red_bx * n_entries) run the fixed-order reduction of the partial buffers (dense gradients + loss).  (As two
+// kernels on two streams inside the step's graph they did run side by side, but the fork and the join each cost ~10 us of idle
+// timeline -- rocprofv3 trace of a replayed step -- which ate the whole gain.)
+template <int VEC>
+__global__ __launch_bounds__(256) void grad_tail_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
+                                                        const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
+                                                        float* __restrict__ partial, int n_seg, const ReduceEntry* __restrict__ entries,
+                                                        int red_bx) {
+    if ((int)blockIdx.x < n_seg) { segreduce_chunks_block<VEC>(grad_rows, pos_sorted, seg_of, n, uniq_grad, partial, blockIdx.x); return; }
+    const int rb = blockIdx.x - n_seg;
+    reduce_partials_block(entries[rb / red_bx], rb % red_bx, red_bx);
 }
 
 // phase B: the chunk in which a border-crossing run STARTS owns its final sum
@@ -182,6 +204,27 @@ extern "C" int amid_embgrad_segreduce_f32(const float* grad_rows, const int* pos
     segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad);
     if (D == 64) { AMID_SEG_LAUNCH(1) } else if (D == 128) { AMID_SEG_LAUNCH(2) } else { AMID_SEG_LAUNCH(4) }
 #undef AMID_SEG_LAUNCH
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// amid_embgrad_segreduce_f32 and amid_reduce_partials_f32 (sasrec_bwd.hip) with their first phases in ONE launch
+extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                                  void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count, void* stream) {
+    AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
+                   max_count > 0);
+    if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK, n_seg = (nch + 3) / 4;
+    int bx = (max_count + 31) / 32;
+    if (bx > 512) bx = 512;
+    float* partial = (float*)workspace;
+    const ReduceEntry* en = (const ReduceEntry*)entries_dev;
+#define AMID_TAIL_LAUNCH(VEC)                                                                                                       \
+    grad_tail_kernel<VEC><<<n_seg + bx * n_entries, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial, n_seg, en, bx); \
+    segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad);
+    if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }
+#undef AMID_TAIL_LAUNCH
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

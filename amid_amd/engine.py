@@ -327,8 +327,6 @@ class SasrecEngine:
         self.side = torch.cuda.Stream(device=self.device)
         self.ev_idx = torch.cuda.Event()
         self.ev_sorted = torch.cuda.Event()
-        self.ev_tail = torch.cuda.Event()
-        self.ev_reduced = torch.cuda.Event()
         self.n_rows, self.D, self.T, self.hid, self.H = int(item_length), int(emb_dim), int(seq_len), int(hid_dim), self.HEADS
         D = self.D
         self.dense = FlatParams(self._dense_names(), self.device)
@@ -463,7 +461,10 @@ class SasrecEngine:
         with torch.cuda.stream(self.stream):
             pl.in_pack.copy_(packed, non_blocking=True)
 
-    def enqueue_prepare(self, pl: SasrecPlan, sparse: bool, bump_step: bool = False) -> None:
+    def enqueue_prepare(self, pl: SasrecPlan, sparse: bool, bump_step: bool = False, defer_sort: bool = False) -> None:
+        """defer_sort: only mark the fork point; the caller launches the sort with enqueue_sort() AFTER the main stream's next
+        kernel.  (In the captured graph the branch that is enqueued first is dispatched first: with the sort ahead of the catch-up
+        kernel the latter started ~20 us late in every replay.)"""
         L, s, shp = lib(), self.s, pl.shape
         L.call("amid_pack_indices", pl.in_i_node.data_ptr(), pl.in_neg.data_ptr(), pl.in_seq_d1.data_ptr(), pl.in_seq_d2.data_ptr(),
                shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
@@ -471,13 +472,18 @@ class SasrecEngine:
         if bump_step:
             self.step += 1
         if sparse:
-            # fork: sort / unique on the side stream (joined by enqueue_backward just before the segment reduce)
-            self.ev_idx.record(self.stream)
-            self.side.wait_event(self.ev_idx)
-            L.call("amid_sort_unique_i32", pl.idx_all.data_ptr(), shp.n_idx, self.n_rows, pl.sort_ws.data_ptr(), pl.pos_sorted.data_ptr(),
-                   pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_uniq.data_ptr(), self.side.cuda_stream)
-            self.ev_sorted.record(self.side)
-            self._sort_pending = True
+            self.ev_idx.record(self.stream)       # fork point: the index list is complete
+            if not defer_sort:
+                self.enqueue_sort(pl)
+
+    def enqueue_sort(self, pl: SasrecPlan) -> None:
+        """Sort / unique on the side stream (joined by the gradient tail just before the segment reduce)."""
+        L, shp = lib(), pl.shape
+        self.side.wait_event(self.ev_idx)
+        L.call("amid_sort_unique_i32", pl.idx_all.data_ptr(), shp.n_idx, self.n_rows, pl.sort_ws.data_ptr(), pl.pos_sorted.data_ptr(),
+               pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_uniq.data_ptr(), self.side.cuda_stream)
+        self.ev_sorted.record(self.side)
+        self._sort_pending = True
 
     def join_sort(self) -> None:
         """Make the main stream wait for the side-stream sort (no-op if nothing is pending)."""
@@ -685,17 +691,12 @@ class SasrecEngine:
         self._enqueue_grad_tail(pl)
 
     def _enqueue_grad_tail(self, pl: SasrecPlan) -> None:
-        """Two independent, bandwidth-bound ends of backward side by side: the fixed-order sum of every partial buffer (dense
-        gradients + loss) on the side stream, the segment reduce of the table-row gradients on the main one."""
+        """The two independent, bandwidth-bound ends of backward side by side in one launch: the fixed-order sum of every partial
+        buffer (dense gradients + loss) and the segment reduce of the table-row gradients."""
         L, s, shp = lib(), self.s, pl.shape
-        self.join_sort()                          # the side stream is free again (and pos_sorted / seg_off are ready)
-        self.ev_tail.record(self.stream)
-        self.side.wait_event(self.ev_tail)
-        L.call("amid_reduce_partials_f32", pl.red_entries.data_ptr(), pl.red_n, pl.red_max, self.side.cuda_stream)
-        self.ev_reduced.record(self.side)
-        L.call("amid_embgrad_segreduce_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(),
-               shp.n_idx, self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), s)
-        self.stream.wait_event(self.ev_reduced)
+        self.join_sort()                          # pos_sorted / seg_off come from the side-stream sort
+        L.call("amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), shp.n_idx,
+               self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), pl.red_entries.data_ptr(), pl.red_n, pl.red_max, s)
 
     def enqueue_optimizer(self, pl: SasrecPlan, sparse=None) -> None:
         """Dense Adam on the flat buffer + lazy row Adam on (uniq_ids, uniq_grad, n_uniq); `sparse`
@@ -718,17 +719,19 @@ class SasrecEngine:
 
     def enqueue_train_step(self, pl: SasrecPlan) -> None:
         """Whole step t on the current stream: t += 1; unique; catch-up; forward; loss; backward; Adam."""
-        self.enqueue_prepare(pl, sparse=True, bump_step=True)
+        self.enqueue_prepare(pl, sparse=True, bump_step=True, defer_sort=True)
         self.enqueue_catchup(pl)
-        self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)      # the loss sum rides in reduce_partials
+        self.enqueue_sort(pl)
+        self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)      # the loss sum rides in the gradient tail
         self.enqueue_backward(pl, train=True)
         self.enqueue_optimizer(pl)
 
     # ------------------------------------------------------------------ data parallel (one process per GPU)
     def enqueue_local_grads(self, pl: SasrecPlan) -> None:
         """Everything of step t that needs no communication: t += 1 .. local segment-reduced gradients."""
-        self.enqueue_prepare(pl, sparse=True, bump_step=True)
+        self.enqueue_prepare(pl, sparse=True, bump_step=True, defer_sort=True)
         self.enqueue_catchup(pl)
+        self.enqueue_sort(pl)
         self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)
         self.enqueue_backward(pl, train=True)
 

@@ -88,6 +88,11 @@ int amid_sparse_pad_f32(const int* uniq_ids, const float* uniq_rows, const int* 
 int amid_merge_sorted_lists_i32(const int* keys, int world, int len, long long key_stride, int row_base, int row_stride, int sentinel,
                                 void* workspace, int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq, void* stream);
 
+/* amid_embgrad_segreduce_f32 + amid_reduce_partials_f32 with their first phases in ONE launch (the two independent ends of backward
+ * side by side without a second stream) */
+int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                       void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count, void* stream);
+
 /* ---- K4 optimizer ----------------------------------------------------------------------------
  * replaces: torch.optim.Adam(model.parameters(), lr).step(), train_sr.py:480, :215 (dense over the table).
  * lazy rows: m, v [n_rows, D], last [n_rows] int32 (0 = never touched). */
