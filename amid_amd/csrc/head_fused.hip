@@ -147,10 +147,9 @@ __device__ __forceinline__ void item_half(const HeadArgs& a, const HeadLds& s, i
     }
 }
 
-__global__ __launch_bounds__(512) void head_fwd_kernel(const HeadArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void head_fwd_body(const HeadArgs& a, float* __restrict__ sm, int b) {
     const HeadLds s(sm, a.D, a.hid);
-    const int b = blockIdx.x, D = a.D, hid = a.hid, NI = a.NI;
+    const int D = a.D, hid = a.hid, NI = a.NI;
     stage_w1t(s.w1t, a.w1, 2 * D, hid);
     lnmean_rows(a, b, s.scr, s.u_s);
     user_half(a, s);
@@ -254,8 +253,10 @@ __device__ __forceinline__ void lnmean_rows_bwd(const HeadArgs& a, int b, const 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(512) void head_bwd_kernel(const HeadArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// FUSED = true: called right after head_fwd_body in the same workgroup -- W1^T, the user vectors and their hidden pre-activations
+// (s.w1t, s.u_s, s.au) are still in LDS, and with NI <= 64 so are the item pre-activations (s.ci)
+template <bool FUSED>
+__device__ __forceinline__ void head_bwd_body(const HeadArgs& a, float* __restrict__ sm) {
     const int D = a.D, hid = a.hid, NI = a.NI;
     if ((int)blockIdx.x >= a.B) {
         // ---- extra workgroups: out[j][i] = in[i][j] for the projection weights, 32x32 tiles ----
@@ -277,17 +278,19 @@ __global__ __launch_bounds__(512) void head_bwd_kernel(const HeadArgs a) {
     const int b = blockIdx.x;
     const int P = hid * 2 * D + 2 * hid + 1;
     float* part = a.sc_part + (long long)b * P;
-    stage_w1t(s.w1t, a.w1, 2 * D, hid);
-    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) s.u_s[e] = a.u[((long long)(e / D) * a.B + b) * D + (e % D)];
+    if (!FUSED) {
+        stage_w1t(s.w1t, a.w1, 2 * D, hid);
+        for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) s.u_s[e] = a.u[((long long)(e / D) * a.B + b) * D + (e % D)];
+    }
     for (int e = threadIdx.x; e < 2 * hid; e += blockDim.x) s.da[e] = 0.f;
     for (int e = threadIdx.x; e < hid + 1; e += blockDim.x) s.dw2[e] = 0.f;
     __syncthreads();
-    user_half(a, s);
+    if (!FUSED) user_half(a, s);
     // item half of dW1 accumulates over item chunks in registers: thread owns (j, e) pairs je = tid + 256 k
     for (int n0 = 0; n0 < NI; n0 += 64) {
         const int nn = min(64, NI - n0);
         __syncthreads();
-        item_half(a, s, b, n0, nn);
+        if (!(FUSED && NI <= 64)) item_half(a, s, b, n0, nn);
         __syncthreads();
         if (threadIdx.x < hid) {                       // hidden unit j walks the chunk's items in order
             const int j = threadIdx.x;
@@ -356,6 +359,28 @@ __global__ __launch_bounds__(512) void head_bwd_kernel(const HeadArgs a) {
     lnmean_rows_bwd(a, b, du_s, s.scr);
 }
 
+__global__ __launch_bounds__(512) void head_fwd_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    head_fwd_body(a, sm, blockIdx.x);
+}
+
+__global__ __launch_bounds__(512) void head_bwd_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    head_bwd_body<false>(a, sm);
+}
+
+// the training step's head in ONE launch: forward (loss partials, dLoss/dp) then, in the same workgroup with its LDS state
+// intact, backward; the extra workgroups (blockIdx >= B) only transpose the projection weights
+__global__ __launch_bounds__(512) void head_fwd_bwd_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    if ((int)blockIdx.x < a.B) {
+        head_fwd_body(a, sm, blockIdx.x);
+        __threadfence_block();                            // dLoss/dp written above is read by other threads of this workgroup below
+        __syncthreads();
+    }
+    head_bwd_body<true>(a, sm);
+}
+
 }  // namespace amid
 
 using namespace amid;
@@ -412,6 +437,28 @@ extern "C" int amid_head_bwd_f32(const float* x, const float* const* ln_w, const
     if (int e = head_lds_attr((const void*)head_bwd_kernel, lds)) return e;
     const int extra = n_tr > 0 ? min(n_tr * (D / 32) * (D / 32), 96) : 0;
     head_bwd_kernel<<<B + extra, 512, lds, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// amid_head_fwd_f32 (with labels) immediately followed by amid_head_bwd_f32, ONE launch -- the training step's head
+extern "C" int amid_head_fwd_bwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
+                                     const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id,
+                                     int B, int T, int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1, float* dp2,
+                                     float* loss_part, float* dx, float* ditems, float* ln_part, float* sc_part,
+                                     const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream) {
+    HeadArgs a = {};
+    if (int e = head_fill(a, x, ln_w, ln_b, items, w1, b1, w2, b2, B, T, NI, D, hid, eps)) return e;
+    AMID_CHECK_ARG(labels && domain_id && u && p1 && p2 && dp1 && dp2 && loss_part && dx && ditems && sc_part && (!ln_w || ln_part) &&
+                   n_tr >= 0 && n_tr <= 32);
+    a.labels = labels; a.domain = domain_id; a.u = u; a.p1 = p1; a.p2 = p2; a.dp1 = dp1; a.dp2 = dp2; a.loss_part = loss_part;
+    a.dx = dx; a.ditems = ditems; a.ln_part = ln_part; a.sc_part = sc_part; a.n_tr = n_tr;
+    for (int i = 0; i < n_tr; ++i) { AMID_CHECK_ARG(tr_src && tr_dst && tr_src[i] && tr_dst[i]); a.tr_src[i] = tr_src[i]; a.tr_dst[i] = tr_dst[i]; }
+    const size_t lds = head_lds_floats(D, hid) * sizeof(float);
+    if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
+    if (int e = head_lds_attr((const void*)head_fwd_bwd_kernel, lds)) return e;
+    const int extra = n_tr > 0 ? min(n_tr * (D / 32) * (D / 32), 96) : 0;
+    head_fwd_bwd_kernel<<<B + extra, 512, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -539,6 +539,8 @@ class SasrecEngine:
             if with_loss and sum_loss:
                 L.call("amid_sum_vector_f32", pl.loss_part.data_ptr(), B, pl.loss.data_ptr(), s)
             return
+        if getattr(self, "_fuse_head", False) and with_loss and not sum_loss:
+            return                                   # train step: the head runs as ONE forward + backward launch in enqueue_backward
         L.call("amid_head_fwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"), items,
                fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
                fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr() if with_loss else None, pl.domain.data_ptr() if with_loss else None,
@@ -647,6 +649,12 @@ class SasrecEngine:
         elif self.itc_bs:
             L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
             self._enqueue_head_itc_bwd(pl, items, ditems)
+        elif getattr(self, "_fuse_head", False):
+            L.call("amid_head_fwd_bwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
+                   items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
+                   fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr(), pl.domain.data_ptr(), B, T, NI, D, self.hid, SASREC_LN_EPS,
+                   pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), pl.loss_part.data_ptr(),
+                   pl.dxbuf.data_ptr(), ditems, pl.last_part.data_ptr(), pl.sc_part.data_ptr(), ptr_array(src), ptr_array(dst), len(src), s)
         else:
             L.call("amid_head_bwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), pl.u.data_ptr(), items,
                    fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
@@ -722,8 +730,7 @@ class SasrecEngine:
         self.enqueue_prepare(pl, sparse=True, bump_step=True, defer_sort=True)
         self.enqueue_catchup(pl)
         self.enqueue_sort(pl)
-        self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)      # the loss sum rides in the gradient tail
-        self.enqueue_backward(pl, train=True)
+        self._enqueue_fwd_bwd(pl)
         self.enqueue_optimizer(pl)
 
     # ------------------------------------------------------------------ data parallel (one process per GPU)
@@ -732,8 +739,18 @@ class SasrecEngine:
         self.enqueue_prepare(pl, sparse=True, bump_step=True, defer_sort=True)
         self.enqueue_catchup(pl)
         self.enqueue_sort(pl)
-        self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)
-        self.enqueue_backward(pl, train=True)
+        self._enqueue_fwd_bwd(pl)
+
+    FUSED_HEAD = True          # the plain SASRec head (no isItC / isDR) can run forward + backward as one launch
+
+    def _enqueue_fwd_bwd(self, pl: SasrecPlan) -> None:
+        """Forward (loss included; its sum rides in the gradient tail) + backward of a training step."""
+        self._fuse_head = self.FUSED_HEAD and not self.dr and not self.itc_bs
+        try:
+            self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)
+            self.enqueue_backward(pl, train=True)
+        finally:
+            self._fuse_head = False
 
     def capture_local_grads(self, pl: SasrecPlan) -> None:
         L = lib()

@@ -95,6 +95,7 @@ class BertPlan(SasrecPlan):
 
 class Bert4recEngine(SasrecEngine):
     HEADS = BERT_HEADS
+    FUSED_HEAD = False         # this engine launches its head kernels itself (enqueue_forward / enqueue_backward below)
     PLAN_CLS = BertPlan
     EMB_DIMS = (BERT_HIDDEN,)
 

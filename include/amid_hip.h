@@ -217,6 +217,13 @@ int amid_head_bwd_f32(const float* x, const float* const* ln_w, const float* u, 
                       const float* w2, const float* b2, const float* p1, const float* p2, const float* dp1, const float* dp2, int B, int T,
                       int NI, int D, int hid, float eps, float* dx, float* ditems, float* ln_part, float* sc_part,
                       const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream);
+/* amid_head_fwd_f32 (with labels) immediately followed by amid_head_bwd_f32 in ONE launch: the head of a training step (the backward half
+ * reuses the forward half's LDS state) */
+int amid_head_fwd_bwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
+                          const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id, int B, int T,
+                          int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1, float* dp2, float* loss_part,
+                          float* dx, float* ditems, float* ln_part, float* sc_part, const float* const* tr_src, float* const* tr_dst,
+                          int n_tr, void* stream);
 /* evaluation (next-2 of SURVEY.md 8(f)): rank (0 = best) of the positive, column 0, among the NI scores of a row, read from the
  * head of the row's own domain.  replaces: choose_predict utils.py:21-40 + the double argsort of get_sample_scores utils.py:296-297
  * after "pred[:, 0] -= fix_value" (train_sr.py:114-115: a tie counts against the positive; fix_value = 0: a tie favours it, as a
