@@ -95,7 +95,6 @@ class BertPlan(SasrecPlan):
 
 class Bert4recEngine(SasrecEngine):
     HEADS = BERT_HEADS
-    FUSED_HEAD = False         # this engine launches its head kernels itself (enqueue_forward / enqueue_backward below)
     PLAN_CLS = BertPlan
     EMB_DIMS = (BERT_HIDDEN,)
 
@@ -135,6 +134,8 @@ class Bert4recEngine(SasrecEngine):
             L.call("amid_bert_ffn2_fwd_f32", pl.h[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".feed_forward.w_2.weight"),
                    self._pp(pre + ".feed_forward.w_2.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x[l + 1].data_ptr(), s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
+        if getattr(self, "_fuse_head", False) and with_loss and not sum_loss:
+            return                                   # train step: the head runs as ONE forward + backward launch in enqueue_backward
         L.call("amid_head_fwd_f32", pl.x[2].data_ptr(), None, None, items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
                fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr() if with_loss else None,
                pl.domain.data_ptr() if with_loss else None, B, T, NI, D, self.hid, 0.0, pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(),
@@ -164,7 +165,14 @@ class Bert4recEngine(SasrecEngine):
                len(src), s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
         ditems = pl.dxg.data_ptr() + 4 * 2 * M * D
-        L.call("amid_head_bwd_f32", pl.x[2].data_ptr(), None, pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"),
+        if getattr(self, "_fuse_head", False):
+            L.call("amid_head_fwd_bwd_f32", pl.x[2].data_ptr(), None, None, items, fp.ptr("predictModule.fc.0.weight"),
+                   fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"),
+                   pl.labels.data_ptr(), pl.domain.data_ptr(), B, T, NI, D, self.hid, 0.0, pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(),
+                   pl.dp1.data_ptr(), pl.dp2.data_ptr(), pl.loss_part.data_ptr(), pl.dxbuf.data_ptr(), ditems, None, pl.sc_part.data_ptr(),
+                   None, None, 0, s)
+        else:
+            L.call("amid_head_bwd_f32", pl.x[2].data_ptr(), None, pl.u.data_ptr(), items, fp.ptr("predictModule.fc.0.weight"),
                fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(),
                pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, T, NI, D, self.hid, 0.0, pl.dxbuf.data_ptr(), ditems, None,
                pl.sc_part.data_ptr(), None, None, 0, s)
