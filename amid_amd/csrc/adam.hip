@@ -285,7 +285,7 @@ extern "C" int amid_step_state_bytes(void) { return (int)sizeof(StepState); }
 extern "C" int amid_step_state_pack(void* host_buf, unsigned long long seed, long long step, double lr, double beta1, double beta2, double eps) {
     AMID_CHECK_ARG(host_buf);
     StepState s;
-    s.seed = seed; s.step = step; s.lr = lr; s.beta1 = beta1; s.beta2 = beta2; s.eps = eps;
+    s.seed = seed; s.step = step; s.lr = lr; s.beta1 = beta1; s.beta2 = beta2; s.eps = eps; s.ticket = 0; s.pad_ = 0;
     *(StepState*)host_buf = s;
     return AMID_OK;
 }

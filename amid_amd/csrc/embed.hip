@@ -73,6 +73,39 @@ __global__ void pack_indices_kernel(const long long* __restrict__ i_node, const 
     }
 }
 
+// Pool-input variant: the batches of an epoch are resident in HBM as `n_pool` packed images ([i_node B][neg B n_neg][seq_d1 M]
+// [seq_d2 M][domain, labels, ...]: the plan's input layout).  The kernel picks image (step + phase) % n_pool by the DEVICE step
+// counter, so a replayed hipGraph walks the pool with no per-step host copy; it also mirrors the image into the plan's static
+// input words (the head kernels read domain / labels there).  Every block reads the step before it takes a ticket and the
+// block that takes the last ticket bumps it: no block can see the bumped value.
+__global__ void pack_indices_pool_kernel(const long long* __restrict__ pool, long long stride, int n_pool, long long phase,
+                                         long long* __restrict__ in_pack, int in_words, int B, int T, int n_neg, long long n_rows,
+                                         int* __restrict__ idx_all, int* __restrict__ err, StepState* __restrict__ st) {
+    const long long t_pre = __atomic_load_n(&st->step, __ATOMIC_RELAXED);
+    long long which = (t_pre + phase) % n_pool;
+    if (which < 0) which += n_pool;
+    const long long* __restrict__ src = pool + which * stride;
+    const int M = B * T, NI = 1 + n_neg;
+    const int n_items = B * n_neg, n_index_words = B + n_items + 2 * M;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < in_words; i += gridDim.x * blockDim.x) {
+        long long v = src[i];
+        in_pack[i] = v;
+        if (i < n_index_words) {
+            int dst;
+            if (i < B) dst = 2 * M + i * NI;
+            else if (i < B + n_items) { const int j = i - B; dst = 2 * M + (j / n_neg) * NI + 1 + (j % n_neg); }
+            else dst = i - B - n_items;
+            if (v < 0 || v >= n_rows) { atomicOr(err, 1); v = 0; }
+            idx_all[dst] = (int)v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicInc(&st->ticket, gridDim.x - 1) == gridDim.x - 1) st->step = t_pre + 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fused SASRec embedding forward.
 //   seq rows  r <  2M : x = E[idx] + P_g[t]; tm = (x == 0); x *= dropout; x = tm ? 0 : x
@@ -225,6 +258,19 @@ extern "C" int amid_pack_indices(const long long* i_node, const long long* neg, 
     if (blocks > 1024) blocks = 1024;
     pack_indices_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(i_node, neg, seq_d1, seq_d2, B, T, n_neg, n_rows, idx_all, err_flag,
                                                                   (StepState*)step_state_to_bump);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_pack_indices_pool(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack,
+                                      int in_words, int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag,
+                                      void* step_state, void* stream) {
+    AMID_CHECK_ARG(pool && in_pack && idx_all && err_flag && step_state && n_pool > 0 && B > 0 && T > 0 && n_neg >= 0);
+    AMID_CHECK_ARG(in_words >= B + B * n_neg + 2 * B * T && pool_stride >= in_words);
+    int blocks = (in_words + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    pack_indices_pool_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(pool, pool_stride, n_pool, phase, in_pack, in_words, B, T, n_neg,
+                                                                       n_rows, idx_all, err_flag, (StepState*)step_state);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -11,6 +11,7 @@ struct StepState {         // lives in device memory so that hipGraph replays se
     unsigned long long seed;   // dropout seed
     long long step;            // 1-based global step t: dropout counter and Adam bias correction; bumped by amid_step_begin
     double lr, beta1, beta2, eps;   // torch.optim.Adam hyper-parameters (train_sr.py:480: lr only, rest defaults)
+    unsigned ticket, pad_;     // "last block out" counter of the pool-input pack kernel (embed.hip); wraps to 0 by itself
 };
 using RngState = StepState;
 

@@ -144,6 +144,7 @@ class SasrecPlan:
         self.domain = self.in_pack[o:o + B]; o += B
         self.labels = self.in_pack[o:o + n_lab_words].view(torch.float32)[: B * NI].view(B, NI); o += n_lab_words
         self.in_ob = self.in_pack[o:o + B] if dr else None
+        self.pool, self.pool_phase = None, 0          # SasrecEngine.set_input_pool
         self.idx_all = torch.zeros(N, dtype=torch.int32, device=dev)
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         # forward
@@ -457,6 +458,22 @@ class SasrecEngine:
         return torch.cat((i_node.reshape(-1).long(), neg_samples.reshape(-1).long(), seq_d1.reshape(-1).long(), seq_d2.reshape(-1).long(),
                           domain_id.reshape(-1).long(), lab.view(torch.int64))).contiguous()
 
+    def set_input_pool(self, pl: SasrecPlan, pool: Optional[torch.Tensor]) -> None:
+        """Make `pool` ([n_pool, in_words] int64, rows = pack_batch() images, resident in HBM) the plan's input: every following
+        train step consumes the next row, chosen ON THE DEVICE by the step counter, so the replayed graph needs no per-step input
+        copy (train_sr.py:185-199 moves each batch inside the loop).  None returns to load_batch()/load_packed().  Graphs of the
+        plan are re-captured."""
+        if pool is not None:
+            if pool.dtype != torch.int64 or pool.dim() != 2 or pool.shape[1] != pl.in_words or pool.stride(1) != 1 \
+                    or pool.device != pl.in_pack.device:
+                raise ValueError(f"input pool must be a device int64 [n, {pl.in_words}] tensor with contiguous rows")
+            pl.pool_phase = (-self.step) % pool.shape[0]
+        pl.pool = pool
+        torch.cuda.synchronize(self.device)
+        for cache in ("graphs", "dp_graphs"):         # the pool pointer is baked into captured launches
+            if getattr(pl, cache, None):
+                getattr(pl, cache).clear()
+
     def load_packed(self, pl: SasrecPlan, packed: torch.Tensor) -> None:
         with torch.cuda.stream(self.stream):
             pl.in_pack.copy_(packed, non_blocking=True)
@@ -466,6 +483,19 @@ class SasrecEngine:
         kernel.  (In the captured graph the branch that is enqueued first is dispatched first: with the sort ahead of the catch-up
         kernel the latter started ~20 us late in every replay.)"""
         L, s, shp = lib(), self.s, pl.shape
+        pool = getattr(pl, "pool", None)
+        if pool is not None:
+            if not bump_step:
+                raise ValueError("an input pool advances with the step counter: enqueue_prepare(bump_step=True) only")
+            L.call("amid_pack_indices_pool", pool.data_ptr(), pool.stride(0), pool.shape[0], pl.pool_phase, pl.in_pack.data_ptr(),
+                   pl.in_words, shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
+                   self.step_state.data_ptr(), s)
+            self.step += 1
+            if sparse:
+                self.ev_idx.record(self.stream)
+                if not defer_sort:
+                    self.enqueue_sort(pl)
+            return
         L.call("amid_pack_indices", pl.in_i_node.data_ptr(), pl.in_neg.data_ptr(), pl.in_seq_d1.data_ptr(), pl.in_seq_d2.data_ptr(),
                shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
                self.step_state.data_ptr() if bump_step else None, s)

@@ -51,6 +51,13 @@ int amid_gather_rows_f32(const float* table, long long n_rows, int D, const void
 /* step_state_to_bump (optional): the same launch performs amid_step_begin (one launch fewer per step) */
 int amid_pack_indices(const long long* i_node, const long long* neg, const long long* seq_d1, const long long* seq_d2,
                       int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* step_state_to_bump, void* stream);
+/* the same with the epoch's batches resident in HBM (train_sr.py:185-199: the reference moves each batch with .cuda() inside the
+ * loop): `pool` holds n_pool packed batch images of `pool_stride` int64 words ([i_node B][neg B n_neg][seq_d1 B T][seq_d2 B T]
+ * [tail words]); the launch consumes image (step + phase) mod n_pool by the DEVICE step counter, mirrors its in_words words into
+ * `in_pack` and bumps the step (amid_step_begin folded in): a replayed graph walks the pool without a per-step copy. */
+int amid_pack_indices_pool(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack,
+                           int in_words, int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag,
+                           void* step_state, void* stream);
 /* fused gather + positional add + embedding dropout + feature-level (==0) mask.
  * replaces: model_seq.py:418-421 + Log2feats.forward :361-366.  pos0/pos1 = sac{1,2}.pos_emb.weight
  * (both NULL: plain gather for all rows, BERT4Rec).  xg: [2M + n_item_rows, D]; tmq: [2M, D/4] bytes. */

@@ -252,6 +252,72 @@ def test_graph_replay_equals_eager():
         assert torch.equal(s0[k], s1[k]), k
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_input_pool_equals_per_step_load(use_graph):
+    """set_input_pool(): the step's first kernel picks its batch from the HBM-resident pool by the device step counter (wrapping
+    around the pool, and starting from the step the pool was installed at); results are bit-identical to copying each batch in."""
+    D, T, Bn, hid, n_items = 64, 20, 8, 16, 200
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=5)
+    batches = [orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=300 + t) for t in range(3)]
+    n_steps, pre_steps = 7, 2
+
+    def run(pool_mode):
+        eng = make_engine(P, T, lr=1e-3, seed=9)
+        pl = eng.plan(Bn, T, 2, need_grad=True)
+        packed = []
+        for b in batches:
+            cu = {k: v.cuda() for k, v in b.items()}
+            packed.append(eng.pack_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"]))
+        for t in range(pre_steps):                       # the pool is installed at a non-zero step
+            eng.load_packed(pl, packed[2 - t])
+            eng.enqueue_train_step(pl)
+        if pool_mode:
+            eng.set_input_pool(pl, torch.stack(packed))
+        else:
+            eng.load_packed(pl, packed[0])
+        if use_graph:
+            eng.capture_train_step(pl)
+        losses = []
+        for t in range(n_steps):
+            if not pool_mode:
+                eng.load_packed(pl, packed[t % 3])
+            if use_graph:
+                eng.replay_train_step(pl)
+            else:
+                eng.enqueue_train_step(pl)
+            eng.sync()
+            losses.append(float(pl.loss.item()))
+            if pool_mode:
+                assert torch.equal(pl.in_pack, packed[t % 3])      # the image is mirrored into the static input words
+        eng.check_index_error(pl)
+        eng.flush_table()
+        eng.sync()
+        return losses, {k: v.cpu().clone() for k, v in eng.state_dict().items()}
+
+    l0, s0 = run(False)
+    l1, s1 = run(True)
+    assert l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
+def test_input_pool_rejects_wrong_layout():
+    D, T, Bn, hid, n_items = 64, 20, 8, 16, 200
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=5)
+    eng = make_engine(P, T)
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    with pytest.raises(ValueError):
+        eng.set_input_pool(pl, torch.zeros(4, pl.in_words + 1, dtype=torch.int64, device="cuda"))
+    with pytest.raises(ValueError):
+        eng.set_input_pool(pl, torch.zeros(4, pl.in_words, dtype=torch.int32, device="cuda"))
+    eng.set_input_pool(pl, torch.zeros(4, pl.in_words, dtype=torch.int64, device="cuda"))
+    with pytest.raises(ValueError):
+        eng.enqueue_prepare(pl, sparse=True)             # a pool only advances with the step
+    eng.set_input_pool(pl, None)
+    eng.enqueue_prepare(pl, sparse=True)
+    eng.sync()
+
+
 # ---------------------------------------------------------------------------- isItC (next-1 of SURVEY.md section 8(f))
 def make_itc_engine(P, T, bs, ts2, lr=5e-4, seed=0):
     from amid_amd.engine import SasrecEngine
