@@ -297,18 +297,21 @@ def inter_comp(seq_self: torch.Tensor, seq_other: torch.Tensor, P: Params, pre: 
     return torch.cat((seq_self, grp.unsqueeze(0).expand(seq_self.shape[0], -1, -1)), 1)                     # :495
 
 
-def inner_comp(seq: torch.Tensor, P: Params, pre: str, threshold: float) -> torch.Tensor:
-    return inter_comp(seq, seq, P, pre, threshold)
+def inner_comp(seq: torch.Tensor, P: Params, pre: str, threshold: float, taps: Optional[dict] = None) -> torch.Tensor:
+    return inter_comp(seq, seq, P, pre, threshold, taps)
 
 
 def sasrec_forward(P: Params, i_node: torch.Tensor, neg_samples: torch.Tensor, seq_d1: torch.Tensor,
                    seq_d2: torch.Tensor, masks: Masks = None, taps: Optional[dict] = None, isItC: bool = False,
-                   threshold2: float = 0.5, isDR: bool = False) -> Tuple[torch.Tensor, ...]:
+                   threshold2: float = 0.5, isDR: bool = False, isInC: bool = False, threshold1: float = 0.5) -> Tuple[torch.Tensor, ...]:
     E = P["item_emb_layer.emb_item.weight"]
     i_feat = gather_rows(E, i_node).unsqueeze(1)                         # :418
     neg_feat = gather_rows(E, neg_samples)                               # :419
-    f1 = sasrec_encoder(gather_rows(E, seq_d1), P, "sac1", masks, taps=None if taps is None else taps.setdefault("sac1", {}))
-    f2 = sasrec_encoder(gather_rows(E, seq_d2), P, "sac2", masks, taps=None if taps is None else taps.setdefault("sac2", {}))
+    e1, e2 = gather_rows(E, seq_d1), gather_rows(E, seq_d2)              # :420-421
+    if isInC:                                                            # :422-424 on the raw gathered rows; the encoders then see 2T tokens
+        e1, e2 = inner_comp(e1, P, "inc_d1", threshold1, taps), inner_comp(e2, P, "inc_d2", threshold1, taps)
+    f1 = sasrec_encoder(e1, P, "sac1", masks, taps=None if taps is None else taps.setdefault("sac1", {}))
+    f2 = sasrec_encoder(e2, P, "sac2", masks, taps=None if taps is None else taps.setdefault("sac2", {}))
     if isItC:                                                            # :426-431 (after the encoders, both from the un-mixed features)
         f1, f2 = inter_comp(f1, f2, P, "itc_d1", threshold2, taps), inter_comp(f2, f1, P, "itc_d2", threshold2, taps)
     u1 = f1.mean(1)                                                      # :432 mean over ALL T (pads included; 2T with isItC)
@@ -522,10 +525,19 @@ def get_sample_scores(pred: np.ndarray):
 # --------------------------------------------------------------------------
 # parameter construction helpers for tests / bench (shapes as SURVEY 8(b))
 # --------------------------------------------------------------------------
-def sasrec_param_shapes(item_length: int, D: int, T: int, hid: int, itc_bs: int = 0, dr: bool = False) -> Dict[str, Tuple[int, ...]]:
+def sasrec_param_shapes(item_length: int, D: int, T: int, hid: int, itc_bs: int = 0, dr: bool = False,
+                        inc_bs: int = 0) -> Dict[str, Tuple[int, ...]]:
     """itc_bs > 0: also the InterComp parameters of SASRec(isItC=True, bs=itc_bs) (model_seq.py:403-405, :478-480);
-    dr: also the predict_ips / predict_gfunc heads of isDR=True (:411-414)."""
+    dr: also the predict_ips / predict_gfunc heads of isDR=True (:411-414); inc_bs > 0: the InnerComp parameters of
+    SASRec(isInC=True, bs=inc_bs) and pos_emb tables of 2T rows (:398-401: seq_len *= 2)."""
     s: Dict[str, Tuple[int, ...]] = {"item_emb_layer.emb_item.weight": (item_length, D)}
+    if inc_bs:
+        T = 2 * T
+        for d in (1, 2):
+            s[f"inc_d{d}.trans_nn.weight"] = (D, D)
+            s[f"inc_d{d}.trans_nn.bias"] = (D,)
+            s[f"inc_d{d}.trans_bs.weight"] = (1, inc_bs)
+            s[f"inc_d{d}.trans_bs.bias"] = (1,)
     if itc_bs:
         for d in (1, 2):
             s[f"itc_d{d}.trans_nn.weight"] = (D, D)

@@ -181,6 +181,19 @@ def test_g10_sasrec_itc_grads():
     check_grads("sasrec", z, P, B, G, None, isItC=True, threshold2=float(z["threshold2"]))
 
 
+def test_g12_sasrec_inc_grads():
+    """SASRec(isInC=True): InnerComp on the gathered rows, encoders over 2T tokens (2T-row pos_emb): logits, loss, every gradient."""
+    z, P, B, G, _ = load("g12_sasrec_inc.npz")
+    taps = {}
+    ts1 = float(z["threshold1"])
+    orc.sasrec_forward(P, B["i_node"], B["neg_samples"], B["seq_d1"], B["seq_d2"], None, taps, isInC=True, threshold1=ts1)
+    assert np.array_equal(taps["inc_d1"]["gate"].numpy().astype(bool), z["gate_d1"])
+    assert np.array_equal(taps["inc_d2"]["gate"].numpy().astype(bool), z["gate_d2"])
+    assert set(G) == set(orc.sasrec_param_shapes(P["item_emb_layer.emb_item.weight"].shape[0], 64, 20, 16, inc_bs=6))
+    assert P["sac1.pos_emb.weight"].shape == (40, 64)
+    check_grads("sasrec", z, P, B, G, None, isInC=True, threshold1=ts1)
+
+
 def test_g11_sasrec_dr_outputs_losses_grads():
     """SASRec(isDR=True, isItC=True) -- what run.sh launches through train_sr_dr.py: six outputs, the three losses and the
     gradients of both objectives (loss_cls + dr_e_w * loss_dr_e for optimizer, loss_dr_r for optimizer2)."""
