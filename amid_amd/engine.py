@@ -29,10 +29,17 @@ SASREC_P_DROP = 0.5       # model_seq.py:335,350,356
 SASREC_LN_EPS = 1e-8      # model_seq.py:342-353
 
 
-def sasrec_dense_names(T: int, D: int, hid: int, itc_bs: int = 0, dr: bool = False) -> List[Tuple[str, Tuple[int, ...]]]:
+def sasrec_dense_names(T: int, D: int, hid: int, itc_bs: int = 0, dr: bool = False, inc_bs: int = 0) -> List[Tuple[str, Tuple[int, ...]]]:
     """Non-table parameters in the reference's state_dict order; itc_bs > 0: with the InterComp
-    modules of SASRec(isItC=True, bs=itc_bs) (model_seq.py:403-405, :478-480)."""
+    modules of SASRec(isItC=True, bs=itc_bs) (model_seq.py:403-405, :478-480); inc_bs > 0: with the InnerComp modules of
+    isInC=True (:398-401; T is then the doubled pos_emb length)."""
     out: List[Tuple[str, Tuple[int, ...]]] = []
+    if inc_bs:
+        for d in (1, 2):
+            out.append((f"inc_d{d}.trans_nn.weight", (D, D)))
+            out.append((f"inc_d{d}.trans_nn.bias", (D,)))
+            out.append((f"inc_d{d}.trans_bs.weight", (1, inc_bs)))
+            out.append((f"inc_d{d}.trans_bs.bias", (1,)))
     if itc_bs:
         for d in (1, 2):
             out.append((f"itc_d{d}.trans_nn.weight", (D, D)))
@@ -108,9 +115,20 @@ class Shape:
     B: int
     T: int
     NI: int          # items scored per row: 1 positive + negatives
+    Te: int = 0      # tokens per sequence inside the encoder when it differs from T (isInC appends T tokens: 2T); 0 = T
+
+    @property
+    def Tenc(self) -> int:
+        return self.Te or self.T
 
     @property
     def M(self) -> int:
+        """Encoder rows per domain."""
+        return self.B * self.Tenc
+
+    @property
+    def Mi(self) -> int:
+        """Gathered sequence rows per domain (index layout)."""
         return self.B * self.T
 
     @property
@@ -149,7 +167,15 @@ class SasrecPlan:
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         # forward
         self.xg = f(N, D)
-        self.x = [self.xg[: 2 * M], f(2 * M, D), f(2 * M, D)]
+        inc = int(getattr(eng, "inc_bs", 0))
+        # the gathered seq rows ARE the encoder input, except with isInC (the encoder input has 2T tokens per row)
+        self.x = [self.xg[: 2 * M] if not inc else f(2 * M, D), f(2 * M, D), f(2 * M, D)]
+        if inc:
+            if B != inc:
+                raise ValueError(f"isInC: the batch must hold exactly bs = {inc} rows (trans_bs is Linear(bs, 1) over the batch, "
+                                 f"model_seq.py:457), got {B}")
+            self.inc_s, self.inc_gate, self.inc_sw = f(2, B), f(2, B), f(2)
+            self.inc_S, self.inc_Z = f(2, T, D), f(2, T, D)
         self.q = [f(2 * M, D) for _ in range(2)]
         self.k = [f(2 * M, D) for _ in range(2)]
         self.v = [f(2 * M, D) for _ in range(2)]
@@ -178,6 +204,9 @@ class SasrecPlan:
             return
         # backward
         self.dxg = f(N, D)
+        if inc:
+            self.dx0 = f(2 * M, D)                      # encoder-input gradient; its first halves + InnerComp's share -> dxg
+            self.inc_dZ, self.inc_dS, self.inc_rows = f(2, T, D), f(2, T, D), f(2, T, 2)
         self.dxbuf = f(2 * M, D)
         self.du = f(2, B, D)
         self.d_o = f(2 * M, D)
@@ -213,7 +242,7 @@ class SasrecPlan:
         self.h = [f(2 * M, D) for _ in range(2)]
 
     def _alloc_model_bwd(self, eng: "SasrecEngine", f) -> None:
-        M, D, B, T = self.shape.M, eng.D, self.shape.B, self.shape.T
+        M, D, B, T = self.shape.M, eng.D, self.shape.B, self.shape.Tenc
         # per LAYER copies of the six dY tensors of the weight gradients: both layers' weight gradients run as one launch at the
         # end of backward (2 layers x 2 domains x 6 weights x 21 splits = 504 workgroups, two per CU)
         self.dpre1, self.dpre2, self.dr = ([f(2 * M, D), f(2 * M, D)] for _ in range(3))
@@ -282,7 +311,7 @@ class SasrecPlan:
             pre = f"sac{g + 1}"
             add(self.last_part, g * B * 2 * D, fp.ptr(f"{pre}.last_layernorm.weight", G), 2 * D, B, D)
             add(self.last_part, g * B * 2 * D + D, fp.ptr(f"{pre}.last_layernorm.bias", G), 2 * D, B, D)
-        T = self.shape.T
+        T = self.shape.Tenc
         for g in (0, 1):
             add(self.dpos_part, g * T * D, fp.ptr(f"sac{g + 1}.pos_emb.weight", G), 2 * T * D, self.pos_splits, T * D)
 
@@ -295,7 +324,7 @@ class SasrecEngine:
     EMB_DIMS = (64, 128)
 
     def _dense_names(self) -> List[Tuple[str, Tuple[int, ...]]]:
-        return sasrec_dense_names(self.T, self.D, self.hid, self.itc_bs, self.dr)
+        return sasrec_dense_names(self.Tpos, self.D, self.hid, self.itc_bs, self.dr, self.inc_bs)
 
     def _alloc_model_buffers(self) -> None:
         D = self.D
@@ -304,11 +333,14 @@ class SasrecEngine:
 
     def __init__(self, item_length: int, emb_dim: int, seq_len: int, hid_dim: int, device="cuda:0", lr: float = 5e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, seed: int = 0, itc_bs: int = 0, itc_threshold: float = 0.5, dr: bool = False,
-                 dr_e_w: float = 0.1, compute: str = "f32"):
+                 dr_e_w: float = 0.1, compute: str = "f32", inc_bs: int = 0, inc_threshold: float = 0.5):
         """itc_bs > 0: SASRec(isItC=True, bs=itc_bs, threshold2=itc_threshold) -- InterComp after the encoders
         (model_seq.py:426-431); every batch must then hold exactly itc_bs rows (trans_bs is Linear(bs, 1) over the batch)."""
         L = lib()        # raises AmidLibraryError when the HIP library is missing: no fallback
         self.itc_bs, self.itc_threshold = int(itc_bs), float(itc_threshold)
+        # inc_bs > 0: SASRec(isInC=True, bs=inc_bs, threshold1=inc_threshold) -- InnerComp on the gathered rows before the encoders,
+        # which then see 2 * seq_len tokens per row (model_seq.py:398-401, :422-424; csrc/innercomp.hip); batches of exactly inc_bs rows
+        self.inc_bs, self.inc_threshold = int(inc_bs), float(inc_threshold)
         # dr: SASRec(isDR=True) -- predict_ips / predict_gfunc heads and the two objectives of train_sr_dr.py; dr_mode selects
         # the objective of the next train step (0: loss_cls + dr_e_w * loss_dr_e, 1: loss_dr_r), see select_optimizer()
         self.dr, self.dr_e_w, self.dr_mode = bool(dr), float(dr_e_w), 0
@@ -329,6 +361,7 @@ class SasrecEngine:
         self.ev_idx = torch.cuda.Event()
         self.ev_sorted = torch.cuda.Event()
         self.n_rows, self.D, self.T, self.hid, self.H = int(item_length), int(emb_dim), int(seq_len), int(hid_dim), self.HEADS
+        self.Tpos = 2 * self.T if getattr(self, "inc_bs", 0) else self.T          # rows of the pos_emb tables
         D = self.D
         self.dense = FlatParams(self._dense_names(), self.device)
         self.table = torch.zeros(self.n_rows, D, dtype=torch.float32, device=self.device)
@@ -412,9 +445,10 @@ class SasrecEngine:
     def plan(self, B: int, T: int, NI: int, need_grad: bool) -> SasrecPlan:
         key = (B, T, NI, need_grad)
         if key not in self.plans:
-            if T > self.T:
-                raise ValueError(f"sequence length {T} exceeds pos_emb size {self.T}")
-            self.plans[key] = self.PLAN_CLS(self, Shape(B, T, NI), need_grad)
+            inc = getattr(self, "inc_bs", 0)
+            if (2 * T if inc else T) > self.Tpos:
+                raise ValueError(f"sequence length {T} exceeds pos_emb size {self.Tpos}" + (" / 2 (isInC)" if inc else ""))
+            self.plans[key] = self.PLAN_CLS(self, Shape(B, T, NI, 2 * T if inc else 0), need_grad)
             torch.cuda.synchronize(self.device)      # buffers were zero-filled on torch's stream
         return self.plans[key]
 
@@ -529,12 +563,21 @@ class SasrecEngine:
 
     def enqueue_forward(self, pl: SasrecPlan, train: bool, with_loss: bool, sum_loss: bool = True) -> None:
         L, s, shp, D = lib(), self.s, pl.shape, self.D
-        B, T, NI, M = shp.B, shp.T, shp.NI, shp.M
+        B, T, NI, M = shp.B, shp.Tenc, shp.NI, shp.M
         st = self.step_state.data_ptr()
         tr = 1 if train else 0
         fp = self.dense
-        L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"),
-               B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, s)
+        if self.inc_bs:      # plain gather, InnerComp's token group, then the 2T-token encoder input (csrc/innercomp.hip)
+            L.call("amid_gather_rows_f32", self.table.data_ptr(), self.n_rows, D, pl.idx_all.data_ptr(), 0, shp.n_idx, pl.xg.data_ptr(), None, s)
+            L.call("amid_inc_score_f32", pl.xg.data_ptr(), B, shp.T, D, pl.inc_s.data_ptr(), s)
+            L.call("amid_inc_embed_fwd_f32", pl.xg.data_ptr(), pl.inc_s.data_ptr(), self._pp("inc_d{d}.trans_nn.weight"),
+                   self._pp("inc_d{d}.trans_nn.bias"), self._pp("inc_d{d}.trans_bs.weight"), self._pp("inc_d{d}.trans_bs.bias"),
+                   self.inc_threshold, fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), B, shp.T, D, pl.inc_gate.data_ptr(),
+                   pl.inc_S.data_ptr(), pl.inc_Z.data_ptr(), pl.inc_sw.data_ptr(), pl.x[0].data_ptr(), pl.tmq.data_ptr(), st, tr,
+                   SASREC_P_DROP, s)
+        else:
+            L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"),
+                   fp.ptr("sac2.pos_emb.weight"), B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, s)
         def layer_ptrs(l):
             pre = f"sac{{d}}"
             return ((self._pp(f"{pre}.attention_layernorms.{l}.weight"), self._pp(f"{pre}.attention_layernorms.{l}.bias"),
@@ -560,7 +603,7 @@ class SasrecEngine:
                 L.call("amid_sas_oproj_ffn_fwd_f32", pl.o[l].data_ptr(), pl.qn[l].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
                        pl.rpt, l, st, tr, SASREC_P_DROP, pl.r[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(),
                        self.mma_bf16, s)
-        items = pl.xg.data_ptr() + 4 * 2 * M * D
+        items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
         if self.dr:
             self._enqueue_head_dr_fwd(pl, items, with_loss)
             return
@@ -584,7 +627,7 @@ class SasrecEngine:
     def _enqueue_user_vectors(self, pl: SasrecPlan) -> None:
         """pl.u [2, B, D]: mean over time of the last LayerNorm (:385, :432-434), mixed with the InterComp group when isItC."""
         L, s, shp, D = lib(), self.s, pl.shape, self.D
-        B, T = shp.B, shp.T
+        B, T = shp.B, shp.Tenc
         fp = self.dense
         dst = pl.u_raw if self.itc_bs else pl.u
         L.call("amid_lnmean_fwd_f32", pl.x[2].data_ptr(), fp.ptr("sac1.last_layernorm.weight"), fp.ptr("sac1.last_layernorm.bias"),
@@ -599,7 +642,7 @@ class SasrecEngine:
     def _enqueue_user_vectors_bwd(self, pl: SasrecPlan) -> None:
         """pl.du (gradient of pl.u) -> InterComp parameter gradients (isItC) -> dx of the last layer's output + LayerNorm partials."""
         L, s, shp, D = lib(), self.s, pl.shape, self.D
-        B, T = shp.B, shp.T
+        B, T = shp.B, shp.Tenc
         fp, G = self.dense, self.dense.grad
         du = pl.du
         if self.itc_bs:
@@ -656,7 +699,7 @@ class SasrecEngine:
     def enqueue_backward(self, pl: SasrecPlan, train: bool) -> None:
         """Backward from pl.dp1 / pl.dp2 (dLoss/dp) to pl.uniq_grad (table rows) and dense.grad."""
         L, s, shp, D = lib(), self.s, pl.shape, self.D
-        B, T, NI, M = shp.B, shp.T, shp.NI, shp.M
+        B, T, NI, M = shp.B, shp.Tenc, shp.NI, shp.M
         st = self.step_state.data_ptr()
         tr = 1 if train else 0
         fp = self.dense
@@ -671,8 +714,8 @@ class SasrecEngine:
                 src.append(fp.ptr(f"{pre}.forward_layers.{l}.conv1.weight"))
                 src.append(fp.ptr(f"{pre}.forward_layers.{l}.conv2.weight"))
                 dst += [self.wT[l, g, w].data_ptr() for w in range(6)]
-        items = pl.xg.data_ptr() + 4 * 2 * M * D
-        ditems = pl.dxg.data_ptr() + 4 * 2 * M * D
+        items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
+        ditems = pl.dxg.data_ptr() + 4 * 2 * shp.Mi * D
         if self.dr:
             L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
             self._enqueue_head_dr_bwd(pl, items, ditems)
@@ -715,7 +758,7 @@ class SasrecEngine:
         attn_bwd(0)
         L.call("amid_sas_qkv_bwd_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
                pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
-               SASREC_LN_EPS, M, D, pl.rpt, pl.dxg.data_ptr(), pl.ln1_part[0].data_ptr(), self.mma_bf16, s)
+               SASREC_LN_EPS, M, D, pl.rpt, (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.ln1_part[0].data_ptr(), self.mma_bf16, s)
         dy, xx = [], []
         for l in (0, 1):
             dy += [pl.dq_l[l].data_ptr(), pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), pl.dr[l].data_ptr(), pl.dpre1[l].data_ptr(),
@@ -724,8 +767,15 @@ class SasrecEngine:
         # NOTE: pl.x[0] is the gathered-row buffer xg, still intact here (its gradient lives in dxg)
         L.call("amid_sas_wgrad_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
                ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), s)
-        L.call("amid_embed_bwd_f32", pl.dxg.data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits, pl.dpos_part.data_ptr(), st, tr,
-               SASREC_P_DROP, s)
+        L.call("amid_embed_bwd_f32", (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits,
+               pl.dpos_part.data_ptr(), st, tr, SASREC_P_DROP, s)
+        if self.inc_bs:      # InnerComp's parameter gradients; the rows' own halves + its share -> the table-row gradient buffer
+            G = self.dense.grad
+            L.call("amid_inc_bwd_f32", pl.dpos_part.data_ptr(), pl.pos_splits, pl.xg.data_ptr(), pl.dx0.data_ptr(), pl.inc_gate.data_ptr(),
+                   pl.inc_S.data_ptr(), pl.inc_sw.data_ptr(), self._pp("inc_d{d}.trans_nn.weight"), self._pp("inc_d{d}.trans_nn.bias"),
+                   self._pp("inc_d{d}.trans_bs.weight"), B, shp.T, D, pl.inc_dZ.data_ptr(), pl.inc_dS.data_ptr(), pl.inc_rows.data_ptr(),
+                   self._pp("inc_d{d}.trans_nn.weight", G), self._pp("inc_d{d}.trans_nn.bias", G), self._pp("inc_d{d}.trans_bs.weight", G),
+                   self._pp("inc_d{d}.trans_bs.bias", G), pl.dxg.data_ptr(), s)
         self._enqueue_grad_tail(pl)
 
     def _enqueue_grad_tail(self, pl: SasrecPlan) -> None:
@@ -806,9 +856,9 @@ class SasrecEngine:
         dist.py).  With use_graph and a known umax the step is graph A (local gradients + packing of this rank's chunk), the
         two collectives, graph B (merge + Adam): four host calls; the pair of graphs is captured per distinct umax, so callers
         should pass a bucketed bound (bench.py: the pool's maximum)."""
-        if self.itc_bs and exchange.active:
-            raise NotImplementedError("isItC couples the rows of a batch (softmax and Linear(bs, 1) over the batch, model_seq.py:490-494): "
-                                      "data-parallel sharding would change the model; train isItC on one GPU")
+        if (self.itc_bs or self.inc_bs) and exchange.active:
+            raise NotImplementedError("isItC / isInC couple the rows of a batch (softmax and Linear(bs, 1) over the batch, "
+                                      "model_seq.py:465-469, :490-494): data-parallel sharding would change the model; train them on one GPU")
         L = lib()
         with torch.cuda.stream(self.stream):
             self.grad_scale = exchange.grad_scale

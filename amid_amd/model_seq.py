@@ -24,10 +24,11 @@ are accepted and ignored; dropout follows ``module.training``.  Two ways to trai
                    Adam as one hipGraph replay -- what ``train_sr.py`` of this repo and ``bench.py`` use.
 
 Out of scope this round (constructors kept for import / state_dict parity, ``forward`` raises):
-GRU4Rec (recurrent), the standalone InnerComp / InterComp modules, isInC, BERT4Rec with isItC / isDR (isItC there puts the
+GRU4Rec (recurrent), the standalone InnerComp / InterComp modules, BERT4Rec with isInC / isItC / isDR (isItC there puts the
 appended token group in FRONT of the encoders), embUserLayerEnhance (dead code in the reference).
 SASRec(isItC=True, isDR=True) -- InterComp after the encoders + the doubly-robust heads, what run.sh trains through
-train_sr_dr.py -- IS built (csrc/intercomp.hip, amid_dr_loss_f32).
+train_sr_dr.py -- IS built (csrc/intercomp.hip, amid_dr_loss_f32), and so is SASRec(isInC=True) -- InnerComp on the gathered rows
+before the encoders, which then run over 2 * seq_len tokens (csrc/innercomp.hip).
 """
 from __future__ import annotations
 
@@ -114,8 +115,9 @@ class _SasrecFunction(torch.autograd.Function):
 
 
 class SASRec(nn.Module):
-    """model_seq.py:390-443 on the HIP engine (isInC = False; isItC either way: with it every batch must hold exactly `bs` rows,
-    as in the reference where trans_bs is Linear(bs, 1) over the batch, and state_dict gains itc_d{1,2}.*; isDR either way:
+    """model_seq.py:390-443 on the HIP engine (isInC / isItC either way: with either every batch must hold exactly `bs` rows,
+    as in the reference where trans_bs is Linear(bs, 1) over the batch, and state_dict gains inc_d{1,2}.* / itc_d{1,2}.*; with
+    isInC the encoders run over 2 * seq_len tokens and pos_emb has 2 * seq_len rows, :398-401; isDR either way:
     with it forward returns six outputs -- logits, ips, gfunc per domain, :436-440 -- and state_dict gains predict_ips.*,
     predict_gfunc.*)."""
 
@@ -128,8 +130,8 @@ class SASRec(nn.Module):
         compute ("f32": exact fp32 matrix products, the default; "bf16": bf16 MFMA operands with fp32 accumulation, SASRec with
         emb_dim 128 only -- BASELINE.json configs[2])."""
         super().__init__()
-        if isInC:
-            _not_built("InnerComp (isInC)", "model_seq.py:422-424")
+        if isInC and not self.SUPPORTS_ITC:
+            _not_built("InnerComp (isInC) for this model", "model_seq.py:283-285")
         if isItC and not self.SUPPORTS_ITC:
             _not_built("InterComp (isItC) for this model", "model_seq.py:289-294")
         if isDR and not self.SUPPORTS_ITC:
@@ -141,6 +143,8 @@ class SASRec(nn.Module):
         self.isInC, self.isItC, self.isDR = isInC, isItC, isDR
         dev = device or ("cuda:%d" % torch.cuda.current_device())
         kw = dict(itc_bs=bs, itc_threshold=threshold2) if isItC else {}
+        if isInC:
+            kw.update(inc_bs=bs, inc_threshold=threshold1)
         if isDR:
             kw["dr"] = True
         if compute != "f32":
@@ -179,8 +183,8 @@ class SASRec(nn.Module):
                 else:                                          # kaiming_uniform_(a=sqrt(5)) => U(-1/sqrt(fan_in), 1/sqrt(fan_in))
                     fan_in = {"predictModule.fc.0.weight": 2 * D, "predictModule.fc.0.bias": 2 * D, "predictModule.fc.2.weight": hid,
                               "predictModule.fc.2.bias": hid}.get(name, 4 * D if ".feed_forward.w_2." in name else D)
-                    if ".trans_bs." in name:                   # InterComp's Linear(bs, 1) over the batch (model_seq.py:480)
-                        fan_in = eng.itc_bs
+                    if ".trans_bs." in name:                   # Inter/InnerComp's Linear(bs, 1) over the batch (model_seq.py:480, :457)
+                        fan_in = eng.itc_bs or eng.inc_bs
                     elif name.startswith(("predict_ips.fc.0", "predict_gfunc.fc.0")):
                         fan_in = 2 * D
                     elif name.startswith(("predict_ips.fc.2", "predict_gfunc.fc.2")):

@@ -295,6 +295,26 @@ int amid_itc_mix_bwd_f32(const float* du_mix, const float* u_raw, const float* g
                          const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int D, float* du_raw,
                          float* const* dw_nn, float* const* db_nn, float* const* dw_bs, float* const* db_bs, void* stream);
 
+/* ---- InnerComp on the SASRec path (isInC; next-1 of SURVEY.md 8(f)) -------------------------------------------------------
+ * replaces: InnerComp.forward model_seq.py:459-472 as used at model_seq.py:422-424 (on the gathered rows, before the encoders,
+ * which then run over 2T tokens with 2T-row pos_emb tables, :398-401) and its autograd.  Compute-once form (csrc/innercomp.hip):
+ *   score     : s[g][j] = max_{a,c} e[g,j,a] . e[g,j,c]                                              (:463-464)
+ *   embed_fwd : gate = softmax_batch(s[g]) > threshold (:465-466); S[g][t] = sum_j w_bs_g[j] gate_j e[g,j,t];
+ *               Z[g][t] = W_nn_g S[g][t] + b_nn_g sum_j w_bs_g[j] + b_bs_g (:467-469); then the encoder input
+ *               x0[g,b,0..2T) = [e[g,b,:] | Z[g]] + P_g[0..2T), dropout, (==0) mask (:470, :361-366); tmq as amid_embed_fwd_f32
+ *   bwd       : after amid_embed_bwd_f32(dx0, tmq, B, 2T, ...) -- whose pos_emb partials of rows T..2T-1 are dZ's partials --:
+ *               InnerComp parameter gradients (written whole) and dxg[g,j,t] = dx0[g,j,t] + w_bs_g[j] gate_j (dZ[g][t] W_nn_g).
+ * xg: [2, B, T, D] plain gathered rows (amid_gather_rows_f32); host pointer arrays hold 2 device pointers (inc_d1, inc_d2). */
+int amid_inc_score_f32(const float* xg, int B, int T, int D, float* s, void* stream);
+int amid_inc_embed_fwd_f32(const float* xg, const float* s, const float* const* w_nn, const float* const* b_nn,
+                           const float* const* w_bs, const float* const* b_bs, float threshold, const float* pos0,
+                           const float* pos1, int B, int T, int D, float* gate, float* S, float* Z, float* sw, float* x0,
+                           unsigned char* tmq, const void* step_state, int train, float p_drop, void* stream);
+int amid_inc_bwd_f32(const float* dpos_part, int nsplit, const float* xg, const float* dx0, const float* gate, const float* S,
+                     const float* sw, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int T,
+                     int D, float* dZ, float* dS, float* rows, float* const* dw_nn, float* const* db_nn, float* const* dw_bs,
+                     float* const* db_bs, float* dxg, void* stream);
+
 /* ---- hipGraph capture / replay of a whole step; HIP events on the caller's stream ---------------- */
 int amid_graph_capture_begin(void* stream);
 int amid_graph_capture_end(void* stream, void** graph_exec_out);

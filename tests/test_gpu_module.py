@@ -171,9 +171,9 @@ def test_unbuilt_models_fail_loudly():
     from amid_amd import model_seq
     with pytest.raises(NotImplementedError):
         model_seq.GRU4Rec(10, 128, 100, 128, 20, 32, 4, False, False, 0.5, 0.5)
-    with pytest.raises(NotImplementedError):                 # InnerComp puts its token group in front of the encoder: not built
-        model_seq.SASRec(10, 128, 100, 128, 20, 32, 4, True, False, 0.5, 0.5)
-    with pytest.raises(NotImplementedError):                 # so does BERT4Rec's InterComp (model_seq.py:289-294)
+    with pytest.raises(NotImplementedError):                 # BERT4Rec with InnerComp (model_seq.py:283-285): not built
+        model_seq.BERT4Rec(10, 128, 100, 128, 20, 32, 4, True, False, 0.5, 0.5)
+    with pytest.raises(NotImplementedError):                 # nor its InterComp, which goes in FRONT of the encoders (:289-294)
         model_seq.BERT4Rec(10, 128, 100, 128, 20, 32, 4, False, True, 0.5, 0.5)
     with pytest.raises(ValueError):                      # the reference hard-codes hidden size 128 (model_seq.py:264-267)
         model_seq.BERT4Rec(10, 64, 100, 64, 20, 32, 4, False, False, 0.5, 0.5)
@@ -215,8 +215,55 @@ def test_sasrec_itc_module_surface():
         m(None, cu["i_node"][:4], cu["neg_samples"][:4], cu["seq_d1"][:4], cu["seq_d2"][:4], None, None, False)
 
 
+def test_sasrec_inc_module_surface_and_reference_loop():
+    """SASRec(isInC=True): the reference's extra state_dict keys (inc_d*, 2T-row pos_emb), eval forward vs the oracle, then the
+    reference's own loop shape (loss.backward(), torch.optim.Adam) for one step against the oracle's dense Adam."""
+    from amid_amd.model_seq import SASRec
+    D, T, hid, n_items, bs, ts1 = 64, 20, 16, 200, 8, 0.13
+    m = SASRec(10, D, n_items, D, T, hid, bs, True, False, ts1, 0.5).cuda()
+    assert set(m.state_dict().keys()) == set(orc.sasrec_param_shapes(n_items, D, T, hid, inc_bs=bs))
+    assert tuple(m.inc_d1.trans_bs.weight.shape) == (1, bs) and tuple(m.sac2.pos_emb.weight.shape) == (2 * T, D)
+    with torch.no_grad():
+        m.item_emb_layer.emb_item.weight.mul_(0.3)            # self pair-max scores close enough for a non-trivial gate
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    batch = orc.synthetic_batch(bs, T, n_items - 1, pad_id=n_items - 1, neg=3, seed=2)
+    batch["seq_d1"] = torch.randint(1, n_items - 1, (bs, T), generator=g)
+    batch["seq_d2"] = torch.randint(1, n_items - 1, (bs, T), generator=g)
+    cu = {k: v.cuda() for k, v in batch.items()}
+    m.eval()
+    with torch.no_grad():
+        p1, p2 = m(None, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], None, None, False)
+    taps = {}
+    o1, o2 = orc.sasrec_forward(P, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], None, taps, isInC=True, threshold1=ts1)
+    assert 0 < int(taps["inc_d1"]["gate"].sum()) < bs and taps["inc_d1"]["margin"] > 1e-3 and taps["inc_d2"]["margin"] > 1e-3
+    assert relmax(p1, o1.squeeze()) < 3e-5 and relmax(p2, o2.squeeze()) < 3e-5
+    with pytest.raises(ValueError):
+        m(None, cu["i_node"][:4], cu["neg_samples"][:4], cu["seq_d1"][:4], cu["seq_d2"][:4], None, None, False)
+    # reference loop, dropout off on both sides
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    p1, p2 = m(None, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], None, None)
+    crit = torch.nn.BCELoss(reduction="none")
+    y = cu["label"]
+    loss = torch.mean(crit(p1, y) * (1 - cu["domain_id"]).unsqueeze(1).float() + crit(p2, y) * cu["domain_id"].unsqueeze(1).float())
+    loss.backward()
+    opt.step()
+    Po = {k: v.clone() for k, v in P.items()}
+    oo = orc.DenseAdam(Po, lr=1e-3)
+    lo = orc.train_step("sasrec", Po, oo, batch, None, isInC=True, threshold1=ts1)
+    assert abs(float(loss.detach()) - lo) < 1e-5
+    sd = m.state_dict()
+    for k, v in Po.items():
+        d = (sd[k].cpu() - v).abs()
+        if k.endswith("in_proj_bias"):
+            Dd = v.numel() // 3
+            d = torch.cat((d[:Dd], d[2 * Dd:]))
+        assert float(d.max()) < 2e-4, (k, float(d.max()))
+
+
 @pytest.mark.parametrize("model,emb,extra", [("sasrec", "64", []), ("bert4rec", "128", []), ("sasrec", "64", ["--isItC", "True", "--ts2", "0.4"]),
-                                             ("sasrec", "128", ["--dtype", "bf16"])])
+                                             ("sasrec", "128", ["--dtype", "bf16"]), ("sasrec", "64", ["--isInC", "True", "--ts1", "0.02"]),
+                                             ("sasrec", "64", ["--isInC", "True", "--ts1", "0.02", "--isItC", "True", "--ts2", "0.02"])])
 def test_train_sr_cli_end_to_end(tmp_path, model, emb, extra):
     """The reference's command line on a synthetic CSV pair with the reference's column layout."""
     from amid_amd.train_sr import main

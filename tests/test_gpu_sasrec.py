@@ -393,6 +393,174 @@ def test_itc_vs_oracle_and_train_steps(D, train):
         eng.plan(Bn + 1, T, 2, need_grad=True)
 
 
+# ---------------------------------------------------------------------------- isInC (next-1 of SURVEY.md section 8(f))
+def make_inc_engine(P, T, bs, ts1, lr=5e-4, seed=0, **kw):
+    from amid_amd.engine import SasrecEngine
+    n_rows, D = P["item_emb_layer.emb_item.weight"].shape
+    hid = P["predictModule.fc.0.weight"].shape[0]
+    eng = SasrecEngine(n_rows, D, T, hid, lr=lr, seed=seed, inc_bs=bs, inc_threshold=ts1, **kw)
+    eng.load_state_dict(P)
+    return eng
+
+
+def test_inc_golden_logits_loss_grads():
+    """SASRec(isInC=True) against the reference's own logits, loss and gradients (g12; inc_d*.trans_nn / trans_bs and the 2T-row
+    pos_emb included)."""
+    z, P, B, G = load_golden("g12_sasrec_inc.npz")
+    B = dict(B)
+    B["label"] = torch.from_numpy(z["labels"])
+    T = B["seq_d1"].shape[1]
+    assert P["sac1.pos_emb.weight"].shape[0] == 2 * T
+    eng = make_inc_engine(P, T, B["seq_d1"].shape[0], float(z["threshold1"]))
+    pl = run_forward(eng, B, train=False, with_loss=True)
+    assert np.array_equal(pl.inc_gate[0].cpu().numpy() > 0.5, z["gate_d1"])
+    assert np.array_equal(pl.inc_gate[1].cpu().numpy() > 0.5, z["gate_d2"])
+    assert relmax(pl.p1, z["p1"]) < 1e-4 and relmax(pl.p2, z["p2"]) < 1e-4
+    eng.enqueue_backward(pl, train=False)
+    eng.sync()
+    assert abs(float(pl.loss.item()) - float(z["loss"])) < 1e-5
+    grads_check("golden g12 inc", eng, pl, G, 5e-4, 5e-4)
+
+
+@pytest.mark.parametrize("D,T,train", [(64, 20, False), (128, 50, True), (128, 30, True)])
+def test_inc_vs_oracle_and_train_steps(D, T, train):
+    """isInC forward / backward against the oracle (2T = 40 / 60: matrix-core attention; 2T = 100: the general kernels), train-mode
+    dropout over the 2T-token rows from the same counters, then full train steps with graph replay."""
+    Bn, hid, n_items, ts1 = 8, 16, 300, 0.13
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid, inc_bs=Bn), seed=50 + D + T)
+    P["item_emb_layer.emb_item.weight"] *= 3.0 if D == 64 else 2.2        # self pair-max scores a few units apart, softmax not flat
+    g = torch.Generator().manual_seed(11)
+    batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=9)
+    batch["seq_d1"] = torch.randint(1, n_items - 1, (Bn, T), generator=g)
+    batch["seq_d2"] = torch.randint(1, n_items - 1, (Bn, T), generator=g)
+    seed, step = 33, 3
+    masks = orc.philox_masks_sasrec(Bn, 2 * T, D, seed=seed, step=step) if train else None
+    taps = {}
+    orc.sasrec_forward(P, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], masks, taps, isInC=True, threshold1=ts1)
+    for d in (1, 2):
+        gate = taps[f"inc_d{d}"]["gate"]
+        log(f"inc D={D} T={T} train={train} d{d}: gate {gate.int().tolist()} softmax margin {taps[f'inc_d{d}']['margin']:.3e}")
+        assert 0 < int(gate.sum()) < Bn and taps[f"inc_d{d}"]["margin"] > 1e-3
+    loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, masks, isInC=True, threshold1=ts1)
+    eng = make_inc_engine(P, T, Bn, ts1, lr=1e-3, seed=seed)
+    pl = run_forward(eng, batch, train=train, with_loss=True, step=step, seed=seed)
+    for d in (1, 2):
+        assert torch.equal(pl.inc_gate[d - 1].cpu(), taps[f"inc_d{d}"]["gate"])
+    assert relmax(pl.p1, p1) < 3e-5 and relmax(pl.p2, p2) < 3e-5
+    eng.enqueue_backward(pl, train=train)
+    eng.sync()
+    assert abs(float(pl.loss.item()) - float(loss)) < 1e-5
+    grads_check(f"inc D={D} T={T} train={train}", eng, pl, grads, 5e-4 if train else 2e-4, 5e-3 if train else 2e-4)
+
+    def run(use_graph):
+        e = make_inc_engine(P, T, Bn, ts1, lr=1e-3, seed=seed)
+        q = e.plan(Bn, T, 2, need_grad=True)
+        cu = {k: v.cuda() for k, v in batch.items()}
+        e.load_batch(q, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"])
+        if use_graph:
+            e.capture_train_step(q)
+        losses = []
+        for _ in range(3):
+            e.replay_train_step(q) if use_graph else e.enqueue_train_step(q)
+            e.sync()
+            losses.append(float(q.loss.item()))
+        e.flush_table(); e.sync()
+        return losses, {k: v.cpu().clone() for k, v in e.state_dict().items()}
+    l0, s0 = run(False)
+    l1, s1 = run(True)
+    assert l0 == l1 and all(torch.equal(s0[k], s1[k]) for k in s0)
+    assert l0[2] < l0[0]
+    with pytest.raises(ValueError):
+        eng.plan(Bn + 1, T, 2, need_grad=True)
+
+
+@pytest.mark.parametrize("dr", [False, True])
+def test_inc_plus_itc_vs_oracle(dr):
+    """isInC and isItC together (InnerComp before the encoders, InterComp after them over the 2T-token features), optionally with the
+    doubly-robust heads: outputs, loss and every gradient against the oracle."""
+    from amid_amd.engine import SasrecEngine
+    D, T, Bn, hid, n_items, ts1, ts2 = 64, 20, 8, 16, 300, 0.13, 0.15
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid, itc_bs=Bn, inc_bs=Bn, dr=dr), seed=61)
+    P["item_emb_layer.emb_item.weight"] *= 3.0
+    for d in (1, 2):
+        P[f"sac{d}.last_layernorm.weight"] *= 0.3
+    g = torch.Generator().manual_seed(13)
+    batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=9)
+    batch["seq_d1"] = torch.randint(1, n_items - 1, (Bn, T), generator=g)
+    batch["seq_d2"] = torch.randint(1, n_items - 1, (Bn, T), generator=g)
+    kw = dict(isInC=True, threshold1=ts1, isItC=True, threshold2=ts2)
+    taps = {}
+    orc.sasrec_forward(P, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], None, taps, isDR=dr, **kw)
+    for pre in ("inc_d1", "inc_d2", "itc_d1"):
+        log(f"inc+itc dr={dr} {pre}: gate {taps[pre]['gate'].int().tolist()} margin {taps[pre]['margin']:.3e}")
+        assert taps[pre]["margin"] > 1e-3
+    assert 0 < int(taps["itc_d1"]["gate"].sum()) < Bn
+    eng = SasrecEngine(n_items, D, T, hid, lr=1e-3, seed=1, itc_bs=Bn, itc_threshold=ts2, inc_bs=Bn, inc_threshold=ts1, dr=dr)
+    eng.load_state_dict(P)
+    if dr:
+        batch["ob_label"] = torch.tensor([1, 0, 1, 1, 0, 1, 0, 1])
+        info, outs, grads = orc.dr_loss_and_grads(P, batch, "e", dr_e_w=0.1, **kw)
+        pl = eng.plan(Bn, T, 2, need_grad=True)
+        cu = {k: v.cuda() for k, v in batch.items()}
+        eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"], cu["ob_label"])
+        eng.dr_mode = 0
+        eng.enqueue_prepare(pl, sparse=True)
+        eng.enqueue_forward(pl, train=False, with_loss=True)
+        eng.enqueue_backward(pl, train=False)
+        eng.sync()
+        for got, want in zip((pl.p1, pl.p2, pl.ips1, pl.ips2, pl.g1, pl.g2), outs):
+            assert relmax(got, want) < 3e-5
+        dr_grads_check("inc+itc+dr", eng, pl, grads, 5e-4)
+        tg = dense_table_grad(eng, pl)
+        assert relmax(tg, grads["item_emb_layer.emb_item.weight"]) < 5e-4
+        return
+    loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, None, **kw)
+    pl = run_forward(eng, batch, train=False, with_loss=True)
+    assert torch.equal(pl.itc_gate.cpu(), taps["itc_d1"]["gate"])
+    assert relmax(pl.p1, p1) < 3e-5 and relmax(pl.p2, p2) < 3e-5
+    eng.enqueue_backward(pl, train=False)
+    eng.sync()
+    assert abs(float(pl.loss.item()) - float(loss)) < 1e-5
+    grads_check("inc+itc", eng, pl, grads, 2e-4, 2e-4)
+
+
+def test_inc_train_step_vs_oracle_dense_adam():
+    """Three isInC train steps (dropout on) against the oracle's dense Adam: parameters after the steps, InnerComp's included."""
+    D, T, Bn, hid, n_items, ts1 = 64, 20, 8, 16, 300, 0.13
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid, inc_bs=Bn), seed=77)
+    P["item_emb_layer.emb_item.weight"] *= 3.0
+    g = torch.Generator().manual_seed(12)
+    batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=19)
+    batch["seq_d1"] = torch.randint(1, n_items - 1, (Bn, T), generator=g)
+    batch["seq_d2"] = torch.randint(1, n_items - 1, (Bn, T), generator=g)
+    seed, lr = 5, 1e-3
+    Pref = {k: v.clone() for k, v in P.items()}
+    opt = orc.DenseAdam(Pref, lr=lr)
+    ref_losses = []
+    for t in range(1, 4):
+        masks = orc.philox_masks_sasrec(Bn, 2 * T, D, seed=seed, step=t)
+        ref_losses.append(orc.train_step("sasrec", Pref, opt, batch, masks, isInC=True, threshold1=ts1))
+    eng = make_inc_engine(P, T, Bn, ts1, lr=lr, seed=seed)
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    cu = {k: v.cuda() for k, v in batch.items()}
+    eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"])
+    losses = []
+    for _ in range(3):
+        eng.enqueue_train_step(pl)
+        eng.sync()
+        losses.append(float(pl.loss.item()))
+    eng.flush_table(); eng.sync()
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - float(b)) < 2e-5
+    sd = eng.state_dict()
+    for k, v in Pref.items():
+        d = (sd[k].cpu() - v).abs()
+        if k.endswith("in_proj_bias"):
+            Dd = v.numel() // 3
+            d = torch.cat((d[:Dd], d[2 * Dd:]))      # chaotic key-bias slice, see test_oracle_golden
+        assert float(d.max()) < 2e-4, (k, float(d.max()))
+
+
 # ---------------------------------------------------------------------------- isDR (next-4 of SURVEY.md section 8(f))
 def dr_grads_check(tag, eng, pl, grads, tol):
     bad = []
