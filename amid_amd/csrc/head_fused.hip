@@ -31,10 +31,15 @@ struct HeadArgs {
     float eps;
 };
 
-__device__ __forceinline__ void stage_w1t(float* __restrict__ w1t, const float* __restrict__ w1, int D2, int hid) {
+// a group of `n` consecutive threads of the workgroup working on one head (tid = index inside the group); the whole workgroup for
+// the one-head kernels, 256-thread thirds in the three-head kernel (all groups run the same control flow: barriers stay aligned)
+struct Tg { int tid, n; };
+__device__ __forceinline__ Tg whole_block() { return Tg{(int)threadIdx.x, (int)blockDim.x}; }
+
+__device__ __forceinline__ void stage_w1t(float* __restrict__ w1t, const float* __restrict__ w1, int D2, int hid, const Tg tg) {
     // w1t[e][j] = w1[j][e], row stride hid + 1
     const int q = D2 >> 2;
-    for (int i = threadIdx.x; i < hid * q; i += blockDim.x) {
+    for (int i = tg.tid; i < hid * q; i += tg.n) {
         const int j = i / q, c = i - j * q;
         const float4 v = ld4(w1 + (long long)j * D2 + 4 * c);
         float* o = w1t + (4 * c) * (hid + 1) + j;
@@ -105,24 +110,30 @@ __device__ __forceinline__ void lnmean_rows(const HeadArgs& a, int b, float* __r
 }
 
 // LDS carve (floats): w1t [2D][hid+1] | u_s [2][D] | au [2][hid] | da [2][hid] | dw2 [hid+4] | ci [64][hid+1] | dc [64][hid+1] | scratch [16][D]
+// `chunk` = items whose pre-activations are resident at once (64 for the one-head kernels; the three-head kernel keeps three
+// carves in LDS and uses 16)
 struct HeadLds {
     float *w1t, *u_s, *au, *da, *dw2, *ci, *dc, *scr;
-    __device__ HeadLds(float* base, int D, int hid) {
+    int chunk;
+    __device__ HeadLds(float* base, int D, int hid, int chunk_ = 64) {
+        chunk = chunk_;
         w1t = base; u_s = w1t + 2 * D * (hid + 1); au = u_s + 2 * D; da = au + 2 * hid; dw2 = da + 2 * hid;
-        ci = dw2 + hid + 4; dc = ci + 64 * (hid + 1); scr = dc + 64 * (hid + 1);
+        ci = dw2 + hid + 4; dc = ci + chunk * (hid + 1); scr = dc + chunk * (hid + 1);
         scr = base + ((scr - base + 3) & ~3);
     }
 };
+__host__ __device__ inline size_t head_carve_floats(int D, int hid, int chunk) {
+    size_t f = (size_t)2 * D * (hid + 1) + 2 * D + 4 * hid + hid + 4 + 2 * chunk * (hid + 1);
+    return (f + 3) & ~(size_t)3;
+}
 __host__ __device__ inline size_t head_lds_floats(int D, int hid) {
-    size_t f = (size_t)2 * D * (hid + 1) + 2 * D + 4 * hid + hid + 4 + 128 * (hid + 1);
-    f = (f + 3) & ~(size_t)3;
-    return f + 32 * D;          // scratch: [2][8][2][D] partials of the LayerNorm backward (forward uses half)
+    return head_carve_floats(D, hid, 64) + 32 * D;          // scratch: [2][8][2][D] partials of the LayerNorm backward (forward uses half)
 }
 
 // au[d][j] = b1[j] + sum_e w1t[e][j] u_d[e]
-__device__ __forceinline__ void user_half(const HeadArgs& a, const HeadLds& s) {
+__device__ __forceinline__ void user_half(const HeadArgs& a, const HeadLds& s, const Tg tg) {
     const int D = a.D, hid = a.hid;
-    for (int dj = threadIdx.x; dj < 2 * hid; dj += blockDim.x) {
+    for (int dj = tg.tid; dj < 2 * hid; dj += tg.n) {
         const int d = dj / hid, j = dj - d * hid;
         float acc = a.b1[j];
         const float* ur = s.u_s + d * D;
@@ -131,9 +142,9 @@ __device__ __forceinline__ void user_half(const HeadArgs& a, const HeadLds& s) {
     }
 }
 // ci[n][j] = sum_e w1t[D+e][j] item[n][e] for the chunk's items (items read from global: each lane group of `hid` lanes shares a row)
-__device__ __forceinline__ void item_half(const HeadArgs& a, const HeadLds& s, int b, int n0, int nn) {
+__device__ __forceinline__ void item_half(const HeadArgs& a, const HeadLds& s, int b, int n0, int nn, const Tg tg) {
     const int D = a.D, hid = a.hid;
-    for (int nj = threadIdx.x; nj < nn * hid; nj += blockDim.x) {
+    for (int nj = tg.tid; nj < nn * hid; nj += tg.n) {
         const int n = nj / hid, j = nj - n * hid;
         const float* ir = a.items + ((long long)b * a.NI + n0 + n) * D;
         float acc = 0.f;
@@ -147,19 +158,19 @@ __device__ __forceinline__ void item_half(const HeadArgs& a, const HeadLds& s, i
     }
 }
 
-__device__ __forceinline__ void head_fwd_body(const HeadArgs& a, float* __restrict__ sm, int b) {
-    const HeadLds s(sm, a.D, a.hid);
-    const int D = a.D, hid = a.hid, NI = a.NI;
-    stage_w1t(s.w1t, a.w1, 2 * D, hid);
-    lnmean_rows(a, b, s.scr, s.u_s);
-    user_half(a, s);
+// scorer forward for row b from the user vectors in s.u_s (W1^T staged in s.w1t): p1 / p2, and with labels the masked BCE
+// partial + dLoss/dp
+__device__ __forceinline__ void scorer_fwd_part(const HeadArgs& a, const HeadLds& s, int b, const Tg tg) {
+    const int hid = a.hid, NI = a.NI;
+    user_half(a, s, tg);
     float lsum = 0.f;
-    for (int n0 = 0; n0 < NI; n0 += 64) {
-        const int nn = min(64, NI - n0);
+    const int CH = s.chunk;
+    for (int n0 = 0; n0 < NI; n0 += CH) {
+        const int nn = min(CH, NI - n0);
         __syncthreads();
-        item_half(a, s, b, n0, nn);
+        item_half(a, s, b, n0, nn, tg);
         __syncthreads();
-        for (int nd = threadIdx.x; nd < nn * 2; nd += blockDim.x) {
+        for (int nd = tg.tid; nd < nn * 2; nd += tg.n) {
             const int n = nd >> 1, d = nd & 1;
             float z = a.b2[0];
             for (int j = 0; j < hid; ++j) z = fmaf(a.w2[j], fmaxf(s.au[d * hid + j] + s.ci[n * (hid + 1) + j], 0.f), z);
@@ -181,8 +192,15 @@ __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, float* __restri
         lsum = group_sum<64>(lsum);
         if (lane_id() == 0) s.scr[wave_id()] = lsum;
         __syncthreads();
-        if (threadIdx.x == 0) a.loss_part[b] = ((s.scr[0] + s.scr[1]) + (s.scr[2] + s.scr[3])) + ((s.scr[4] + s.scr[5]) + (s.scr[6] + s.scr[7]));
+        if (tg.tid == 0) a.loss_part[b] = ((s.scr[0] + s.scr[1]) + (s.scr[2] + s.scr[3])) + ((s.scr[4] + s.scr[5]) + (s.scr[6] + s.scr[7]));
     }
+}
+
+__device__ __forceinline__ void head_fwd_body(const HeadArgs& a, float* __restrict__ sm, int b) {
+    const HeadLds s(sm, a.D, a.hid);
+    stage_w1t(s.w1t, a.w1, 2 * a.D, a.hid, whole_block());
+    lnmean_rows(a, b, s.scr, s.u_s);
+    scorer_fwd_part(a, s, b, whole_block());
 }
 
 // dx rows of (g, b) from du_s[D] (LDS): dx = LN_last'(du / T ; x) ; partial d gamma / d beta -> ln_part[(g*B+b)][2][D]
@@ -255,45 +273,49 @@ __device__ __forceinline__ void lnmean_rows_bwd(const HeadArgs& a, int b, const 
 
 // FUSED = true: called right after head_fwd_body in the same workgroup -- W1^T, the user vectors and their hidden pre-activations
 // (s.w1t, s.u_s, s.au) are still in LDS, and with NI <= 64 so are the item pre-activations (s.ci)
-template <bool FUSED>
-__device__ __forceinline__ void head_bwd_body(const HeadArgs& a, float* __restrict__ sm) {
-    const int D = a.D, hid = a.hid, NI = a.NI;
-    if ((int)blockIdx.x >= a.B) {
-        // ---- extra workgroups: out[j][i] = in[i][j] for the projection weights, 32x32 tiles ----
-        const int tiles = D / 32, per = tiles * tiles;
-        float (*tile)[33] = reinterpret_cast<float (*)[33]>(sm);
-        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-        for (int w = (int)blockIdx.x - a.B; w < a.n_tr * per; w += (int)gridDim.x - a.B) {
-            const int m = w / per, tt = w - m * per, bx = (tt % tiles) * 32, by = (tt / tiles) * 32;
-            const float* __restrict__ src = a.tr_src[m];
-            float* __restrict__ dst = a.tr_dst[m];
-            __syncthreads();
-            for (int r = ty; r < 32; r += 16) tile[r][tx] = src[(long long)(by + r) * D + bx + tx];
-            __syncthreads();
-            for (int r = ty; r < 32; r += 16) dst[(long long)(bx + r) * D + by + tx] = tile[tx][r];
-        }
-        return;
+// extra workgroups (blockIdx >= B): out[j][i] = in[i][j] for the projection weights, 32x32 tiles
+__device__ __forceinline__ void transpose_extra(const HeadArgs& a, float* __restrict__ sm) {
+    const int D = a.D;
+    const int tiles = D / 32, per = tiles * tiles;
+    float (*tile)[33] = reinterpret_cast<float (*)[33]>(sm);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int w = (int)blockIdx.x - a.B; w < a.n_tr * per; w += (int)gridDim.x - a.B) {
+        const int m = w / per, tt = w - m * per, bx = (tt % tiles) * 32, by = (tt / tiles) * 32;
+        const float* __restrict__ src = a.tr_src[m];
+        float* __restrict__ dst = a.tr_dst[m];
+        __syncthreads();
+        for (int r = ty; r < 32; r += 16) tile[r][tx] = src[(long long)(by + r) * D + bx + tx];
+        __syncthreads();
+        for (int r = ty; r < 32; r += 16) dst[(long long)(bx + r) * D + by + tx] = tile[tx][r];
     }
-    const HeadLds s(sm, D, hid);
-    const int b = blockIdx.x;
+}
+
+// scorer backward for row b: d items (ACC: added to what another head wrote), the head's weight-gradient partials, and d u[2][D]
+// left in LDS (returned pointer; a region of s.ci).
+// FUSED = true: called right after scorer_fwd_part in the same workgroup -- W1^T, the user vectors and their hidden pre-activations
+// (s.w1t, s.u_s, s.au) are still in LDS, and with NI <= 64 so are the item pre-activations (s.ci)
+template <bool FUSED, bool ACC>
+__device__ __forceinline__ float* scorer_bwd_part(const HeadArgs& a, const HeadLds& s, int b, const Tg tg, float* __restrict__ dit_lds = nullptr) {
+    const int D = a.D, hid = a.hid, NI = a.NI;
     const int P = hid * 2 * D + 2 * hid + 1;
     float* part = a.sc_part + (long long)b * P;
     if (!FUSED) {
-        stage_w1t(s.w1t, a.w1, 2 * D, hid);
-        for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) s.u_s[e] = a.u[((long long)(e / D) * a.B + b) * D + (e % D)];
+        stage_w1t(s.w1t, a.w1, 2 * D, hid, tg);
+        for (int e = tg.tid; e < 2 * D; e += tg.n) s.u_s[e] = a.u[((long long)(e / D) * a.B + b) * D + (e % D)];
     }
-    for (int e = threadIdx.x; e < 2 * hid; e += blockDim.x) s.da[e] = 0.f;
-    for (int e = threadIdx.x; e < hid + 1; e += blockDim.x) s.dw2[e] = 0.f;
+    for (int e = tg.tid; e < 2 * hid; e += tg.n) s.da[e] = 0.f;
+    for (int e = tg.tid; e < hid + 1; e += tg.n) s.dw2[e] = 0.f;
     __syncthreads();
-    if (!FUSED) user_half(a, s);
+    if (!FUSED) user_half(a, s, tg);
     // item half of dW1 accumulates over item chunks in registers: thread owns (j, e) pairs je = tid + 256 k
-    for (int n0 = 0; n0 < NI; n0 += 64) {
-        const int nn = min(64, NI - n0);
+    const int CH = s.chunk;
+    for (int n0 = 0; n0 < NI; n0 += CH) {
+        const int nn = min(CH, NI - n0);
         __syncthreads();
-        if (!(FUSED && NI <= 64)) item_half(a, s, b, n0, nn);
+        if (!(FUSED && NI <= CH)) item_half(a, s, b, n0, nn, tg);
         __syncthreads();
-        if (threadIdx.x < hid) {                       // hidden unit j walks the chunk's items in order
-            const int j = threadIdx.x;
+        if (tg.tid < hid) {                       // hidden unit j walks the chunk's items in order
+            const int j = tg.tid;
             float s_da0 = 0.f, s_da1 = 0.f, s_w2 = 0.f;
             const float w2j = a.w2[j];
             for (int n = 0; n < nn; ++n) {
@@ -309,7 +331,7 @@ __device__ __forceinline__ void head_bwd_body(const HeadArgs& a, float* __restri
             }
             s.da[j] += s_da0; s.da[hid + j] += s_da1; s.dw2[j] += s_w2;
         }
-        if (threadIdx.x == 64) {
+        if (tg.tid == 64) {
             float acc = 0.f;
             for (int n = 0; n < nn; ++n) {
                 const long long o = (long long)b * NI + n0 + n;
@@ -320,15 +342,17 @@ __device__ __forceinline__ void head_bwd_body(const HeadArgs& a, float* __restri
         }
         __syncthreads();
         // d item[n][e] = sum_j dc[n][j] w1t[D+e][j]
-        for (int ne = threadIdx.x; ne < nn * D; ne += blockDim.x) {
+        for (int ne = tg.tid; ne < nn * D; ne += tg.n) {
             const int n = ne / D, e = ne - n * D;
             float acc = 0.f;
             const float* wp = s.w1t + (D + e) * (hid + 1);
             for (int j = 0; j < hid; ++j) acc = fmaf(s.dc[n * (hid + 1) + j], wp[j], acc);
-            a.ditems[((long long)b * NI + n0 + n) * D + e] = acc;
+            if (dit_lds != nullptr) { dit_lds[ne] = acc; continue; }        // single chunk: the caller sums the heads' shares
+            float* dst = a.ditems + ((long long)b * NI + n0 + n) * D + e;
+            *dst = ACC ? *dst + acc : acc;
         }
         // dW1[j][D+e] (+)= sum_n dc[n][j] item[n][e]
-        for (int je = threadIdx.x; je < hid * D; je += blockDim.x) {
+        for (int je = tg.tid; je < hid * D; je += tg.n) {
             const int j = je / D, e = je - j * D;
             float acc = 0.f;
             for (int n = 0; n < nn; ++n) acc = fmaf(s.dc[n * (hid + 1) + j], a.items[((long long)b * NI + n0 + n) * D + e], acc);
@@ -339,23 +363,32 @@ __device__ __forceinline__ void head_bwd_body(const HeadArgs& a, float* __restri
     __syncthreads();
     // user halves: du_d[e] = sum_j da[d][j] w1t[e][j]  -> scratch region [2][D] reused from ci (dead now)
     float* du_s = s.ci;
-    for (int de = threadIdx.x; de < 2 * D; de += blockDim.x) {
+    for (int de = tg.tid; de < 2 * D; de += tg.n) {
         const int d = de / D, e = de - d * D;
         float acc = 0.f;
         const float* wp = s.w1t + e * (hid + 1);
         for (int j = 0; j < hid; ++j) acc = fmaf(s.da[d * hid + j], wp[j], acc);
         du_s[de] = acc;
     }
-    for (int je = threadIdx.x; je < hid * D; je += blockDim.x) {
+    for (int je = tg.tid; je < hid * D; je += tg.n) {
         const int j = je / D, e = je - j * D;
         part[j * 2 * D + e] = s.da[j] * s.u_s[e] + s.da[hid + j] * s.u_s[D + e];
     }
-    for (int j = threadIdx.x; j < hid; j += blockDim.x) {
+    for (int j = tg.tid; j < hid; j += tg.n) {
         part[hid * 2 * D + j] = s.da[j] + s.da[hid + j];            // db1
         part[hid * 2 * D + hid + j] = s.dw2[j];                     // dW2
     }
-    if (threadIdx.x == 0) part[hid * 2 * D + 2 * hid] = s.dw2[hid];   // db2
+    if (tg.tid == 0) part[hid * 2 * D + 2 * hid] = s.dw2[hid];   // db2
     __syncthreads();
+    return du_s;
+}
+
+template <bool FUSED>
+__device__ __forceinline__ void head_bwd_body(const HeadArgs& a, float* __restrict__ sm) {
+    if ((int)blockIdx.x >= a.B) { transpose_extra(a, sm); return; }
+    const HeadLds s(sm, a.D, a.hid);
+    const int b = blockIdx.x;
+    float* du_s = scorer_bwd_part<FUSED, false>(a, s, b, whole_block());
     lnmean_rows_bwd(a, b, du_s, s.scr);
 }
 
@@ -379,6 +412,100 @@ __global__ __launch_bounds__(512) void head_fwd_bwd_kernel(const HeadArgs a) {
         __syncthreads();
     }
     head_bwd_body<true>(a, sm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The head of the isItC / isDR train step after the user vectors are mixed (csrc/intercomp.hip): up to three scorers
+// (predictModule, predict_ips, predict_gfunc; model_seq.py:436-440) forward on the same (u, items) of row b, the row's loss
+// terms -- masked BCE (one head) or the doubly-robust objective of the current mode (three heads; train_sr_dr.py:216-221,
+// :392-394, same arithmetic as dr_loss_kernel in head.hip) --, then every scorer's backward: d items and d u summed over the
+// heads, weight-gradient partials per head.  One launch instead of 3 + 1 + 3 (each 20-40 us of mostly latency).
+// Every head keeps its own LDS carve (W1^T, hidden pre-activations of the user vectors and of the items) from forward to backward,
+// and the three heads run SIDE BY SIDE on three 256-thread groups of the workgroup (run one after the other they cost 89 us).
+// ---------------------------------------------------------------------------------------------
+struct MultiHeadArgs {
+    HeadArgs h[3];             // per head: w1..b2, p1/p2 (outputs), dp1/dp2 (their gradients), sc_part; shared x-less fields
+    int n_heads;               // 1: masked BCE on head 0 (h[0].labels set) ; 3: doubly-robust objective
+    const float* labels; const long long* domain; const long long* ob;
+    int mode; float w;
+    float* dr_loss_part;       // [B][3]
+    float* du;                 // [2, B, D]
+};
+
+__global__ __launch_bounds__(768) void scorer_multi_fwd_bwd_kernel(const MultiHeadArgs m) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const HeadArgs& a0 = m.h[0];
+    if ((int)blockIdx.x >= a0.B) { transpose_extra(a0, sm); return; }
+    const int b = blockIdx.x, D = a0.D, NI = a0.NI, nh = m.n_heads;
+    // three heads: the workgroup's 768 threads are three groups of 256, one head each, side by side (same control flow, so the
+    // barriers inside the scorer parts line up); one head: the whole workgroup
+    const int gsz = nh == 1 ? (int)blockDim.x : 256;
+    const int h = __builtin_amdgcn_readfirstlane((int)threadIdx.x / gsz);
+    const Tg tg{(int)threadIdx.x - h * gsz, gsz};
+    const int CH = nh == 1 ? 64 : 16;
+    const size_t carve = head_carve_floats(D, a0.hid, CH);
+    HeadLds s(sm + h * carve, D, a0.hid, CH);
+    float* dit_all = sm + nh * carve;                         // three heads: [3][NI <= 16][D] shares of d items
+    float* scratch = dit_all + (nh == 1 ? 0 : nh * CH * D);   // [8 D]
+    s.scr = scratch;
+    const HeadArgs& a = m.h[h];
+    stage_w1t(s.w1t, a.w1, 2 * D, a0.hid, tg);
+    for (int e = tg.tid; e < 2 * D; e += tg.n) s.u_s[e] = a0.u[((long long)(e / D) * a0.B + b) * D + (e % D)];
+    __syncthreads();
+    scorer_fwd_part(a, s, b, tg);
+    if (nh == 3) {
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x < 64) {                               // wave 0: the row's doubly-robust terms (dr_loss_kernel, head.hip)
+            const int lane = threadIdx.x;
+            const int d = m.domain[b] != 0;
+            const float ob = (m.ob != nullptr) ? (float)m.ob[b] : 0.f;
+            const float inv = 1.0f / (float)((long long)a0.B * NI);
+            float lc = 0.f, le = 0.f, lr = 0.f;
+            for (int n = lane; n < NI; n += 64) {
+                const long long o = (long long)b * NI + n;
+                const float p = (d ? m.h[0].p2 : m.h[0].p1)[o], ips = (d ? m.h[1].p2 : m.h[1].p1)[o], g = (d ? m.h[2].p2 : m.h[2].p1)[o];
+                const float y = m.labels[o];
+                const float bce = -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+                const float dbce = (p - y) / fmaxf(p * (1.f - p), 1e-12f);
+                float dp, dg, dips;
+                lc += bce;
+                le += (bce - g) * (bce - g) / ips;
+                const float q = bce * bce - g * g;
+                lr += g * g + ob * q * q / ips;
+                if (m.mode == 0) {
+                    dp = (1.f + 2.f * m.w * (bce - g) / ips) * dbce;
+                    dg = -2.f * m.w * (bce - g) / ips;
+                    dips = -m.w * (bce - g) * (bce - g) / (ips * ips);
+                } else {
+                    dp = ob * 4.f * q * bce / ips * dbce;
+                    dg = 2.f * g - ob * 4.f * q * g / ips;
+                    dips = -ob * q * q / (ips * ips);
+                }
+                (d ? m.h[0].dp2 : m.h[0].dp1)[o] = dp * inv; (d ? m.h[0].dp1 : m.h[0].dp2)[o] = 0.f;
+                (d ? m.h[1].dp2 : m.h[1].dp1)[o] = dips * inv; (d ? m.h[1].dp1 : m.h[1].dp2)[o] = 0.f;
+                (d ? m.h[2].dp2 : m.h[2].dp1)[o] = dg * inv; (d ? m.h[2].dp1 : m.h[2].dp2)[o] = 0.f;
+            }
+            lc = group_sum<64>(lc); le = group_sum<64>(le); lr = group_sum<64>(lr);
+            if (lane == 0) { m.dr_loss_part[b * 3 + 0] = lc * inv; m.dr_loss_part[b * 3 + 1] = le * inv; m.dr_loss_part[b * 3 + 2] = lr * inv; }
+        }
+    }
+    __threadfence_block();                                    // dLoss/dp written above is read by other threads of this workgroup below
+    __syncthreads();
+    scorer_bwd_part<true, false>(a, s, b, tg, nh == 1 ? nullptr : dit_all + h * CH * D);      // ends with a barrier
+    // d u (left by every head at the start of its ci region) and, with three heads, d items: fixed-order sums over the heads
+    const size_t ci_off = (size_t)(s.ci - (sm + h * carve));
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
+        float t = sm[ci_off + e];
+        for (int k = 1; k < nh; ++k) t += sm[k * carve + ci_off + e];
+        m.du[((long long)(e / D) * a0.B + b) * D + (e % D)] = t;
+    }
+    if (nh > 1)
+        for (int i = threadIdx.x; i < NI * D; i += blockDim.x) {
+            float t = dit_all[i];
+            for (int k = 1; k < nh; ++k) t += dit_all[k * CH * D + i];
+            a0.ditems[(long long)b * NI * D + i] = t;
+        }
 }
 
 }  // namespace amid
@@ -459,6 +586,43 @@ extern "C" int amid_head_fwd_bwd_f32(const float* x, const float* const* ln_w, c
     if (int e = head_lds_attr((const void*)head_fwd_bwd_kernel, lds)) return e;
     const int extra = n_tr > 0 ? min(n_tr * (D / 32) * (D / 32), 96) : 0;
     head_fwd_bwd_kernel<<<B + extra, 512, lds, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// Up to three scorers forward + loss + backward in ONE launch on given user vectors u [2, B, D] (the isItC / isDR train step, see
+// scorer_multi_fwd_bwd_kernel).  Host arrays of n_heads device pointers: w1, b1, w2, b2, p1, p2 (outputs), dp1, dp2 (gradients of
+// the outputs, written here), sc_part (weight-gradient partials).  n_heads == 1: masked BCE of train_sr.py:203-212 (loss_part [B]);
+// n_heads == 3 (predictModule, predict_ips, predict_gfunc): the doubly-robust objective `mode` of amid_dr_loss_f32
+// (dr_loss_part [B][3]; ob_label needed for mode 1).  du [2, B, D] and ditems [B, NI, D] are sums over the heads.
+extern "C" int amid_scorer_multi_fwd_bwd_f32(const float* u, const float* items, const float* const* w1, const float* const* b1,
+                                             const float* const* w2, const float* const* b2, int n_heads, const float* labels,
+                                             const long long* domain_id, const long long* ob_label, int mode, float dr_e_w, int B, int NI,
+                                             int D, int hid, float* const* p1, float* const* p2, float* const* dp1, float* const* dp2,
+                                             float* loss_part, float* dr_loss_part, float* du, float* ditems, float* const* sc_part,
+                                             const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream) {
+    AMID_CHECK_ARG(u && items && w1 && b1 && w2 && b2 && labels && domain_id && p1 && p2 && dp1 && dp2 && du && ditems && sc_part);
+    AMID_CHECK_ARG((n_heads == 1 && loss_part) || (n_heads == 3 && dr_loss_part && (mode == 0 || (mode == 1 && ob_label))));
+    AMID_CHECK_ARG(n_tr >= 0 && n_tr <= 32);
+    MultiHeadArgs m = {};
+    for (int h = 0; h < n_heads; ++h) {
+        HeadArgs& a = m.h[h];
+        AMID_CHECK_ARG(p1[h] && p2[h] && dp1[h] && dp2[h] && sc_part[h]);
+        if (int e = head_fill(a, u, nullptr, nullptr, items, w1[h], b1[h], w2[h], b2[h], B, 1, NI, D, hid, 0.f)) return e;
+        a.u = const_cast<float*>(u); a.p1 = p1[h]; a.p2 = p2[h]; a.dp1 = dp1[h]; a.dp2 = dp2[h]; a.sc_part = sc_part[h]; a.ditems = ditems;
+        if (n_heads == 1) { a.labels = labels; a.domain = domain_id; a.loss_part = loss_part; }
+    }
+    m.h[0].n_tr = n_tr;
+    for (int i = 0; i < n_tr; ++i) { AMID_CHECK_ARG(tr_src && tr_dst && tr_src[i] && tr_dst[i]); m.h[0].tr_src[i] = tr_src[i]; m.h[0].tr_dst[i] = tr_dst[i]; }
+    m.n_heads = n_heads; m.labels = labels; m.domain = domain_id; m.ob = ob_label; m.mode = mode; m.w = dr_e_w;
+    m.dr_loss_part = dr_loss_part; m.du = du;
+    if (n_heads == 3 && NI > 16) return AMID_ERR_UNSUPPORTED;          // the three heads' d item shares are summed through LDS
+    const size_t lds = ((size_t)n_heads * head_carve_floats(D, hid, n_heads == 1 ? 64 : 16) + (n_heads == 1 ? 0 : (size_t)n_heads * 16 * D) +
+                        8 * (size_t)D) * sizeof(float);
+    if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
+    if (int e = head_lds_attr((const void*)scorer_multi_fwd_bwd_kernel, lds)) return e;
+    const int extra = n_tr > 0 ? min(n_tr * (D / 32) * (D / 32), 96) : 0;
+    scorer_multi_fwd_bwd_kernel<<<B + extra, n_heads == 1 ? 512 : 768, lds, (hipStream_t)stream>>>(m);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

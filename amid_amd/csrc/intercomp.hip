@@ -19,6 +19,7 @@ struct PairMaxArgs {
     const float* x;                       // [2, B, T, D] output of the last encoder layer
     const float* lnw[2]; const float* lnb[2];
     float* s;                             // [B]
+    float* u_raw;                         // optional [2, B, D]: mean_t LN_last(x[g, b]) (what amid_lnmean_fwd_f32 computes)
     int B, T, D; float eps;
 };
 
@@ -45,6 +46,13 @@ __global__ __launch_bounds__(256) void itc_pairmax_kernel(const PairMaxArgs a) {
         }
     }
     __syncthreads();
+    if (a.u_raw != nullptr)
+        for (int e = threadIdx.x; e < 2 * D; e += 256) {
+            const int g = e / D, d = e - g * D;
+            float acc = 0.f;
+            for (int t = 0; t < T; ++t) acc += F[g][t * LD + d];
+            a.u_raw[((long long)g * a.B + b) * D + d] = acc / T;
+        }
     float best = -INFINITY;
     for (int p = threadIdx.x; p < T * T; p += 256) {
         const int i = p / T, j = p - i * T;
@@ -99,56 +107,78 @@ __device__ __forceinline__ float block_reduce_max(float v, float* red) {
     return s;
 }
 
+// Both mix kernels run on a grid of `nb` workgroups: the small shared quantities (gate, z, c / dc, dz: a few hundred values that
+// need the whole batch) are recomputed by every workgroup from L2-resident inputs, then each workgroup handles its slice of the
+// [2, B, D] elementwise part and of the parameter gradients.  (As single workgroups they were 58 us forward / 139 us backward of
+// serial latency on the configuration run.sh trains.)
 __global__ __launch_bounds__(1024) void itc_mix_fwd_kernel(const MixArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // gate [B] | z [2][D] | c [2][D]
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // gate [B rounded to 4] | z [2][D] | c [2][D] | part [8][2 D]
     __shared__ float red[16];
     const int B = a.B, D = a.D;
     float* gate_s = smem;
-    float* z_s = smem + B;
+    float* z_s = smem + ((B + 3) & ~3);
     float* c_s = z_s + 2 * D;
+    const bool first = blockIdx.x == 0;
     // softmax over the batch, thresholded (model_seq.py:490-491)
     float m = -INFINITY;
     for (int j = threadIdx.x; j < B; j += blockDim.x) m = fmaxf(m, a.s[j]);
     m = block_reduce_max(m, red);
-    float l = 0.f;
-    for (int j = threadIdx.x; j < B; j += blockDim.x) l += expf(a.s[j] - m);
+    float l = 0.f, sw[2] = {0.f, 0.f};
+    for (int j = threadIdx.x; j < B; j += blockDim.x) { l += expf(a.s[j] - m); sw[0] += a.wbs[0][j]; sw[1] += a.wbs[1][j]; }
     l = block_reduce_sum(l, red);
+    sw[0] = block_reduce_sum(sw[0], red);
+    sw[1] = block_reduce_sum(sw[1], red);
     for (int j = threadIdx.x; j < B; j += blockDim.x) {
         const float gt = (expf(a.s[j] - m) / l > a.threshold) ? 1.f : 0.f;
         gate_s[j] = gt;
-        a.gate[j] = gt;
+        if (first) a.gate[j] = gt;
     }
-    float sw[2];
+    if (first && threadIdx.x < 2) a.sw[threadIdx.x] = sw[threadIdx.x];
+    __syncthreads();
+    // z_g[d] = sum_j w_g[j] gate_j u_raw[other(g)][j][d]: 8 row groups of 32 lanes (float4 per lane) stride over j with every load
+    // independent, then a fixed-order sum of the 8 partials
+    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5, q = D >> 2, nrg = blockDim.x >> 5;
+    const bool on = sub < q;
+    float* part = c_s + 2 * D;                                        // [row groups][2 D]
     for (int g = 0; g < 2; ++g) {
-        float t = 0.f;
-        for (int j = threadIdx.x; j < B; j += blockDim.x) t += a.wbs[g][j];
-        sw[g] = block_reduce_sum(t, red);
-    }
-    if (threadIdx.x < 2) a.sw[threadIdx.x] = sw[threadIdx.x];
-    __syncthreads();
-    // z_g[d] = sum_j w_g[j] gate_j u_raw[other(g)][j][d]   (fixed order over j)
-    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
-        const int g = e / D, d = e - g * D;
         const float* uo = a.u_raw + (long long)(1 - g) * B * D;
-        float t = 0.f;
-        for (int j = 0; j < B; ++j) t = fmaf(a.wbs[g][j] * gate_s[j], uo[(long long)j * D + d], t);
-        z_s[e] = t;
-        a.z[e] = t;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int j = rg; j < B; j += nrg) {
+            const float w = a.wbs[g][j] * gate_s[j];
+            const float4 v = on ? ld4(uo + (long long)j * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+        }
+        if (on) st4(part + rg * 2 * D + g * D + 4 * sub, acc);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
-        const int g = e / D, o = e - g * D;
-        const float* w = a.wnn[g] + (long long)o * D;
         float t = 0.f;
-        for (int d = 0; d < D; ++d) t = fmaf(w[d], z_s[g * D + d], t);
-        c_s[e] = t + a.bnn[g][o] * sw[g] + a.bbs[g][0];
+        for (int k = 0; k < nrg; ++k) t += part[k * 2 * D + e];
+        z_s[e] = t;
+        if (first) a.z[e] = t;
     }
     __syncthreads();
-    const long long n = 2LL * B * D;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-        const int g = (int)(i / ((long long)B * D)), d = (int)(i % D);
-        a.u_mix[i] = 0.5f * a.u_raw[i] + 0.5f * c_s[g * D + d];      // mean over the 2T rows of cat(f, group)  (:432-434, :495)
+    // c_g[o] = W_nn_g[o, :] . z_g + b_nn_g[o] sum_j w_g[j] + b_bs_g : one row per row group and pass
+#pragma unroll 8
+    for (int r = rg; r < 2 * D; r += nrg) {
+        const int g = r / D, o = r - g * D;
+        float t = 0.f;
+        if (on) {
+            const float4 w4 = ld4(a.wnn[g] + (long long)o * D + 4 * sub), z4 = ld4(z_s + g * D + 4 * sub);
+            t = fmaf(w4.x, z4.x, fmaf(w4.y, z4.y, fmaf(w4.z, z4.z, w4.w * z4.w)));
+        }
+        t = group_sum<32>(t);
+        if (sub == 0) c_s[r] = t + a.bnn[g][o] * sw[g] + a.bbs[g][0];
     }
+    __syncthreads();
+    const int per = (B + gridDim.x - 1) / gridDim.x;
+    const int b0 = blockIdx.x * per, b1 = min(B, b0 + per);
+    for (int g = 0; g < 2; ++g)
+        for (int i = b0 * D + threadIdx.x; i < b1 * D; i += blockDim.x) {
+            const long long o = (long long)g * B * D + i;
+            a.u_mix[o] = 0.5f * a.u_raw[o] + 0.5f * c_s[g * D + i % D];      // mean over the 2T rows of cat(f, group)  (:432-434, :495)
+        }
 }
 
 __global__ __launch_bounds__(1024) void itc_mix_bwd_kernel(const MixArgs a) {
@@ -157,43 +187,65 @@ __global__ __launch_bounds__(1024) void itc_mix_bwd_kernel(const MixArgs a) {
     const int B = a.B, D = a.D;
     float* dc_s = smem;
     float* dz_s = smem + 2 * D;
-    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {          // dc_g = 0.5 sum_b du_mix[g][b]   (fixed order over b)
-        const int g = e / D, d = e - g * D;
-        const float* p = a.du_mix + (long long)g * B * D + d;
+    const bool first = blockIdx.x == 0;
+    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5, q = D >> 2, nrg = blockDim.x >> 5;
+    const bool on = sub < q;
+    float* part = dz_s + 2 * D;                                       // [row groups][2 D]
+    for (int g = 0; g < 2; ++g) {                                     // dc_g = 0.5 sum_b du_mix[g][b]: 8 row groups over b, then a fixed-order sum
+        const float* p = a.du_mix + (long long)g * B * D;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int b = rg; b < B; b += nrg)
+            if (on) acc = f4add(acc, ld4(p + (long long)b * D + 4 * sub));
+        if (on) st4(part + rg * 2 * D + g * D + 4 * sub, acc);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
         float t = 0.f;
-        for (int b = 0; b < B; ++b) t += p[(long long)b * D];
+        for (int k = 0; k < nrg; ++k) t += part[k * 2 * D + e];
         dc_s[e] = 0.5f * t;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {          // dz_g = W_nn_g^T dc_g ; d b_nn_g = dc_g * sum_j w_g[j]
-        const int g = e / D, d = e - g * D;
-        float t = 0.f;
-        for (int o = 0; o < D; ++o) t = fmaf(a.wnn[g][(long long)o * D + d], dc_s[g * D + o], t);
-        dz_s[e] = t;
-        a.dbnn[g][d] = dc_s[e] * a.sw[g];
-    }
-    for (int g = 0; g < 2; ++g) {                                     // d b_bs_g = sum_e dc_g[e] ; bdc_g = b_nn_g . dc_g
-        float t = 0.f;
-        for (int e = threadIdx.x; e < D; e += blockDim.x) t += dc_s[g * D + e];
-        t = block_reduce_sum(t, red);
-        if (threadIdx.x == 0) a.dbbs[g][0] = t;
+    for (int g = 0; g < 2; ++g) {                                     // dz_g = W_nn_g^T dc_g : row groups over the rows o of W_nn
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int o = rg; o < D; o += nrg) {
+            const float c = dc_s[g * D + o];
+            const float4 w4 = on ? ld4(a.wnn[g] + (long long)o * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc.x = fmaf(c, w4.x, acc.x); acc.y = fmaf(c, w4.y, acc.y); acc.z = fmaf(c, w4.z, acc.z); acc.w = fmaf(c, w4.w, acc.w);
+        }
+        __syncthreads();                                              // part is reused
+        if (on) st4(part + rg * 2 * D + g * D + 4 * sub, acc);
     }
     __syncthreads();
-    for (long long i = threadIdx.x; i < 2LL * D * D; i += blockDim.x) {          // d W_nn_g = dc_g (x) z_g
-        const int g = (int)(i / ((long long)D * D));
-        const int r = (int)(i - (long long)g * D * D);
-        a.dwnn[g][r] = dc_s[g * D + r / D] * a.z[g * D + r % D];
-    }
-    float bdc[2];
-    for (int g = 0; g < 2; ++g) {
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {          // d b_nn_g = dc_g * sum_j w_g[j]
         float t = 0.f;
-        for (int e = threadIdx.x; e < D; e += blockDim.x) t += a.bnn[g][e] * dc_s[g * D + e];
-        bdc[g] = block_reduce_sum(t, red);
+        for (int k = 0; k < nrg; ++k) t += part[k * 2 * D + e];
+        dz_s[e] = t;
+        if (first) a.dbnn[e / D][e % D] = dc_s[e] * a.sw[e / D];
     }
+    __syncthreads();
+    float bdc[2];
+    for (int g = 0; g < 2; ++g) {                                     // d b_bs_g = sum_e dc_g[e] ; bdc_g = b_nn_g . dc_g
+        float t = 0.f, u = 0.f;
+        for (int e = threadIdx.x; e < D; e += blockDim.x) { t += dc_s[g * D + e]; u += a.bnn[g][e] * dc_s[g * D + e]; }
+        t = block_reduce_sum(t, red);
+        bdc[g] = block_reduce_sum(u, red);
+        if (first && threadIdx.x == 0) a.dbbs[g][0] = t;
+    }
+    __syncthreads();
+    {   // d W_nn_g = dc_g (x) z_g : this workgroup's rows
+        const int per = (D + gridDim.x - 1) / gridDim.x;
+        const int o0 = blockIdx.x * per, o1 = min(D, o0 + per);
+        for (int g = 0; g < 2; ++g)
+            for (int i = o0 * D + threadIdx.x; i < o1 * D; i += blockDim.x) a.dwnn[g][i] = dc_s[g * D + i / D] * a.z[g * D + i % D];
+    }
+    const int per = (B + gridDim.x - 1) / gridDim.x;
+    const int b0 = blockIdx.x * per, b1 = min(B, b0 + per);
     // d w_bs_g[j] = gate_j (u_raw[other(g)][j] . dz_g) + b_nn_g . dc_g : one wave per (g, j)
     const int nw = blockDim.x >> 6, w = wave_id(), lane = lane_id();
-    for (int p = w; p < 2 * B; p += nw) {
-        const int g = p / B, j = p - g * B;
+    for (int p = w; p < 2 * (b1 - b0); p += nw) {
+        const int g = p / (b1 - b0), j = b0 + p - g * (b1 - b0);
         const float* uo = a.u_raw + ((long long)(1 - g) * B + j) * D;
         float t = 0.f;
         for (int d = lane; d < D; d += 64) t = fmaf(uo[d], dz_s[g * D + d], t);
@@ -201,13 +253,12 @@ __global__ __launch_bounds__(1024) void itc_mix_bwd_kernel(const MixArgs a) {
         if (lane == 0) a.dwbs[g][j] = a.gate[j] * t + bdc[g];
     }
     // d u_raw[g][b] = 0.5 d u_mix[g][b] + gate_b w_bs_{g'}[b] dz_{g'},  g' = the domain whose group is built from g
-    const long long n = 2LL * B * D;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-        const int g = (int)(i / ((long long)B * D));
-        const long long r = i - (long long)g * B * D;
-        const int b = (int)(r / D), d = (int)(r - (long long)b * D);
-        a.du_raw[i] = 0.5f * a.du_mix[i] + a.gate[b] * a.wbs[1 - g][b] * dz_s[(1 - g) * D + d];
-    }
+    for (int g = 0; g < 2; ++g)
+        for (int i = b0 * D + threadIdx.x; i < b1 * D; i += blockDim.x) {
+            const int b = i / D, d = i - b * D;
+            const long long o = (long long)g * B * D + i;
+            a.du_raw[o] = 0.5f * a.du_mix[o] + a.gate[b] * a.wbs[1 - g][b] * dz_s[(1 - g) * D + d];
+        }
 }
 
 }  // namespace amid
@@ -216,13 +267,13 @@ using namespace amid;
 
 // Pointer-array parameters are HOST arrays of 2 device pointers (itc_d1, itc_d2 / sac1, sac2).
 extern "C" int amid_itc_pairmax_f32(const float* x, const float* const* ln_w, const float* const* ln_b, int B, int T, int D, float eps,
-                                    float* s, void* stream) {
+                                    float* s, float* u_raw, void* stream) {
     AMID_CHECK_ARG(x && ln_w && ln_b && ln_w[0] && ln_w[1] && ln_b[0] && ln_b[1] && s && B > 0 && T > 0 && D > 0 && (D % 4) == 0);
     if (D > 128) return AMID_ERR_UNSUPPORTED;
     const size_t lds = (size_t)2 * T * (D + 4) * sizeof(float);
     if (lds > 150 * 1024) return AMID_ERR_UNSUPPORTED;
     PairMaxArgs a;
-    a.x = x; a.s = s; a.B = B; a.T = T; a.D = D; a.eps = eps;
+    a.x = x; a.s = s; a.u_raw = u_raw; a.B = B; a.T = T; a.D = D; a.eps = eps;
     for (int g = 0; g < 2; ++g) { a.lnw[g] = ln_w[g]; a.lnb[g] = ln_b[g]; }
     hipError_t e = hipFuncSetAttribute((const void*)itc_pairmax_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -249,9 +300,9 @@ extern "C" int amid_itc_mix_fwd_f32(const float* u_raw, const float* s, const fl
     if (int e = mix_fill(a, u_raw, w_nn, b_nn, w_bs, b_bs, B, D)) return e;
     AMID_CHECK_ARG(s && gate && z && sw && u_mix);
     a.s = s; a.threshold = threshold; a.gate = gate; a.z = z; a.sw = sw; a.u_mix = u_mix;
-    const size_t lds = (size_t)(B + 4 * D) * sizeof(float);
+    const size_t lds = (size_t)(((B + 3) & ~3) + 4 * D + 32 * 2 * D) * sizeof(float);
     if (lds > 60 * 1024) return AMID_ERR_UNSUPPORTED;
-    itc_mix_fwd_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(a);
+    itc_mix_fwd_kernel<<<B < 32 ? B : 32, 1024, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
@@ -269,7 +320,7 @@ extern "C" int amid_itc_mix_bwd_f32(const float* du_mix, const float* u_raw, con
         AMID_CHECK_ARG(dw_nn[g] && db_nn[g] && dw_bs[g] && db_bs[g]);
         a.dwnn[g] = dw_nn[g]; a.dbnn[g] = db_nn[g]; a.dwbs[g] = dw_bs[g]; a.dbbs[g] = db_bs[g];
     }
-    itc_mix_bwd_kernel<<<1, 1024, (size_t)4 * D * sizeof(float), (hipStream_t)stream>>>(a);
+    itc_mix_bwd_kernel<<<B < 32 ? B : 32, 1024, (size_t)(4 * D + 32 * 2 * D) * sizeof(float), (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -604,6 +604,9 @@ class SasrecEngine:
                        pl.rpt, l, st, tr, SASREC_P_DROP, pl.r[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(),
                        self.mma_bf16, s)
         items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
+        if (self.dr or self.itc_bs) and getattr(self, "_fuse_scorers", False) and with_loss and not sum_loss:
+            self._enqueue_user_vectors(pl)           # train step: the scorers run as ONE forward + loss + backward launch in enqueue_backward
+            return
         if self.dr:
             self._enqueue_head_dr_fwd(pl, items, with_loss)
             return
@@ -629,12 +632,12 @@ class SasrecEngine:
         L, s, shp, D = lib(), self.s, pl.shape, self.D
         B, T = shp.B, shp.Tenc
         fp = self.dense
-        dst = pl.u_raw if self.itc_bs else pl.u
-        L.call("amid_lnmean_fwd_f32", pl.x[2].data_ptr(), fp.ptr("sac1.last_layernorm.weight"), fp.ptr("sac1.last_layernorm.bias"),
-               fp.ptr("sac2.last_layernorm.weight"), fp.ptr("sac2.last_layernorm.bias"), B, T, D, SASREC_LN_EPS, dst.data_ptr(), s)
-        if self.itc_bs:
+        if not self.itc_bs:
+            L.call("amid_lnmean_fwd_f32", pl.x[2].data_ptr(), fp.ptr("sac1.last_layernorm.weight"), fp.ptr("sac1.last_layernorm.bias"),
+                   fp.ptr("sac2.last_layernorm.weight"), fp.ptr("sac2.last_layernorm.bias"), B, T, D, SASREC_LN_EPS, pl.u.data_ptr(), s)
+        else:            # the pair-max kernel has every LayerNorm'd row of (b) in LDS: it emits the means too
             L.call("amid_itc_pairmax_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
-                   B, T, D, SASREC_LN_EPS, pl.itc_s.data_ptr(), s)
+                   B, T, D, SASREC_LN_EPS, pl.itc_s.data_ptr(), pl.u_raw.data_ptr(), s)
             L.call("amid_itc_mix_fwd_f32", pl.u_raw.data_ptr(), pl.itc_s.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"),
                    self._pp("itc_d{d}.trans_nn.bias"), self._pp("itc_d{d}.trans_bs.weight"), self._pp("itc_d{d}.trans_bs.bias"),
                    self.itc_threshold, B, D, pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(), pl.itc_sw.data_ptr(), pl.u.data_ptr(), s)
@@ -716,7 +719,21 @@ class SasrecEngine:
                 dst += [self.wT[l, g, w].data_ptr() for w in range(6)]
         items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
         ditems = pl.dxg.data_ptr() + 4 * 2 * shp.Mi * D
-        if self.dr:
+        if (self.dr or self.itc_bs) and getattr(self, "_fuse_scorers", False):
+            heads = DR_HEADS if self.dr else DR_HEADS[:1]
+            outs = [(pl.p1, pl.p2, pl.dp1, pl.dp2, pl.sc_part)]
+            if self.dr:
+                outs += [(pl.ips1, pl.ips2, pl.dips1, pl.dips2, pl.sc_part_ips), (pl.g1, pl.g2, pl.dg1, pl.dg2, pl.sc_part_g)]
+            pa = lambda seq: ptr_array(list(seq))          # noqa: E731
+            L.call("amid_scorer_multi_fwd_bwd_f32", pl.u.data_ptr(), items, pa(fp.ptr(f"{h}.fc.0.weight") for h in heads),
+                   pa(fp.ptr(f"{h}.fc.0.bias") for h in heads), pa(fp.ptr(f"{h}.fc.2.weight") for h in heads),
+                   pa(fp.ptr(f"{h}.fc.2.bias") for h in heads), len(heads), pl.labels.data_ptr(), pl.domain.data_ptr(),
+                   pl.in_ob.data_ptr() if self.dr else None, self.dr_mode if self.dr else 0, self.dr_e_w, B, NI, D, self.hid,
+                   pa(o[0].data_ptr() for o in outs), pa(o[1].data_ptr() for o in outs), pa(o[2].data_ptr() for o in outs),
+                   pa(o[3].data_ptr() for o in outs), pl.loss_part.data_ptr(), pl.dr_loss_part.data_ptr() if self.dr else None,
+                   pl.du.data_ptr(), ditems, pa(o[4].data_ptr() for o in outs), ptr_array(src), ptr_array(dst), len(src), s)
+            self._enqueue_user_vectors_bwd(pl)
+        elif self.dr:
             L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
             self._enqueue_head_dr_bwd(pl, items, ditems)
         elif self.itc_bs:
@@ -826,11 +843,12 @@ class SasrecEngine:
     def _enqueue_fwd_bwd(self, pl: SasrecPlan) -> None:
         """Forward (loss included; its sum rides in the gradient tail) + backward of a training step."""
         self._fuse_head = self.FUSED_HEAD and not self.dr and not self.itc_bs
+        self._fuse_scorers = self.FUSED_HEAD and bool(self.dr or self.itc_bs) and (not self.dr or pl.shape.NI <= 16)
         try:
             self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)
             self.enqueue_backward(pl, train=True)
         finally:
-            self._fuse_head = False
+            self._fuse_head = self._fuse_scorers = False
 
     def capture_local_grads(self, pl: SasrecPlan) -> None:
         L = lib()

@@ -287,6 +287,7 @@ int amid_sample_negatives_i64(const long long* pool_d1, int n_pool_d1, const lon
  *   mix_bwd : gradients of the above into du_raw and the eight InterComp parameters (written whole, no partials).
  * Host pointer arrays hold 2 device pointers: index 0 = itc_d1 / sac1, 1 = itc_d2 / sac2.  u_raw: amid_lnmean_fwd_f32. */
 int amid_itc_pairmax_f32(const float* x, const float* const* ln_w, const float* const* ln_b, int B, int T, int D, float eps, float* s,
+                         float* u_raw /* optional [2, B, D]: also emit mean_t LN_last(x), saving the amid_lnmean_fwd_f32 launch */,
                          void* stream);
 int amid_itc_mix_fwd_f32(const float* u_raw, const float* s, const float* const* w_nn, const float* const* b_nn,
                          const float* const* w_bs, const float* const* b_bs, float threshold, int B, int D, float* gate, float* z,
@@ -294,6 +295,19 @@ int amid_itc_mix_fwd_f32(const float* u_raw, const float* s, const float* const*
 int amid_itc_mix_bwd_f32(const float* du_mix, const float* u_raw, const float* gate, const float* z, const float* sw,
                          const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int D, float* du_raw,
                          float* const* dw_nn, float* const* db_nn, float* const* dw_bs, float* const* db_bs, void* stream);
+
+/* Up to three scorers forward + the row's loss terms + backward in ONE launch on given user vectors u [2, B, D]: the head of the
+ * isItC / isDR train step (replaces predictModule / predict_ips / predict_gfunc forward model_seq.py:436-440, the objectives of
+ * train_sr.py:203-212 or train_sr_dr.py:216-221 / :392-394, and their autograd).  Host arrays of n_heads device pointers: w1, b1,
+ * w2, b2, p1, p2 (outputs), dp1, dp2 (gradients of the outputs, written here), sc_part (weight-gradient partials as
+ * amid_scorer_bwd_f32).  n_heads 1: masked BCE (loss_part [B]); n_heads 3: objective `mode` of amid_dr_loss_f32 (dr_loss_part
+ * [B][3]).  du [2, B, D] and ditems [B, NI, D] are sums over the heads.  tr_*: as amid_head_bwd_f32. */
+int amid_scorer_multi_fwd_bwd_f32(const float* u, const float* items, const float* const* w1, const float* const* b1,
+                                  const float* const* w2, const float* const* b2, int n_heads, const float* labels,
+                                  const long long* domain_id, const long long* ob_label, int mode, float dr_e_w, int B, int NI,
+                                  int D, int hid, float* const* p1, float* const* p2, float* const* dp1, float* const* dp2,
+                                  float* loss_part, float* dr_loss_part, float* du, float* ditems, float* const* sc_part,
+                                  const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream);
 
 /* ---- InnerComp on the SASRec path (isInC; next-1 of SURVEY.md 8(f)) -------------------------------------------------------
  * replaces: InnerComp.forward model_seq.py:459-472 as used at model_seq.py:422-424 (on the gathered rows, before the encoders,
