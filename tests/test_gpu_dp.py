@@ -28,7 +28,7 @@ def _batches():
     return [orc.synthetic_batch(c["B"], c["T"], c["n_items"] - 1, pad_id=c["n_items"] - 1, neg=1, seed=500 + t) for t in range(c["K"])]
 
 
-def _worker(rank, world, port, use_graph, q, host_knows_umax=False):
+def _worker(rank, world, port, use_graph, q, host_knows_umax=False, pool=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -43,9 +43,17 @@ def _worker(rank, world, port, use_graph, q, host_knows_umax=False):
         pl = eng.plan(Bl, c["T"], 2, need_grad=True)
         ex = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=True)
         first = True
+        if pool:                 # the rank's shards of all K batches resident in HBM; the step picks its batch by the device step counter
+            packed = []
+            for batch in _batches():
+                local = {k: v.cuda() for k, v in shard_batch(batch, rank, world).items()}
+                packed.append(eng.pack_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"],
+                                             local["domain_id"]))
+            eng.set_input_pool(pl, torch.stack(packed))
         for batch in _batches():
             local = {k: v.cuda() for k, v in shard_batch(batch, rank, world).items()}
-            eng.load_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"], local["domain_id"])
+            if not pool:
+                eng.load_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"], local["domain_id"])
             if use_graph and first:
                 eng.capture_local_grads(pl)
                 first = False
@@ -63,13 +71,13 @@ def _worker(rank, world, port, use_graph, q, host_knows_umax=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph,host_knows_umax", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("use_graph,host_knows_umax,pool", [(False, False, False), (True, False, False), (True, True, False), (True, True, True)])
 @pytest.mark.timeout(600)
-def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax):
+def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax, pool):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, use_graph, q, host_knows_umax)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_graph, q, host_knows_umax, pool)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
