@@ -83,13 +83,12 @@ struct FfnBwdArgs {
 template <int D, bool BF>
 __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restrict__ smem, int tile) {
     using RP = RowPass<D>;
-    constexpr int LDK = TileCfg<D>::LDK, LDC = D + 4;
+    constexpr int LDC = D + 4;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
     float* Cs = Ws;
     int g, nrows, local0; long long row0;
     tile_rows_b(a.tg, tile, g, row0, nrows, local0);
-    const int nrt = (nrows + 15) >> 4;
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
@@ -196,7 +195,6 @@ __device__ __forceinline__ void qkv_bwd_body(const QkvBwdArgs& a, float* __restr
     float* Ws = smem + TileCfg<D>::A_FLOATS;
     int g, nrows, local0; long long row0;
     tile_rows_b(a.tg, tile, g, row0, nrows, local0);
-    const int nrt = (nrows + 15) >> 4;
     const int sub = RP::sub();
     f32x4 acc_kv[WaveMap<D>::ACC], acc_q[WaveMap<D>::ACC];
     zero_acc<D>(acc_kv);

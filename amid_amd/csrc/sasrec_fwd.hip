@@ -40,12 +40,10 @@ struct QkvFwdArgs {
 template <int D, bool BF>
 __device__ __forceinline__ void qkv_fwd_body(const QkvFwdArgs& a, float* __restrict__ smem, int tile) {
     using RP = RowPass<D>;
-    constexpr int LDK = TileCfg<D>::LDK;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
     int g, nrows, local0; long long row0;
     tile_rows(a.tg, tile, g, row0, nrows, local0);
-    const int nrt = (nrows + 15) >> 4;
     const int sub = RP::sub();
     TileRegs<D> xr;
     WRegs<D, D> wr;
@@ -112,7 +110,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_fwd_kernel(const Oproj
     float* Cs = Ws;
     int g, nrows, local0; long long row0;
     tile_rows(a.tg, blockIdx.x, g, row0, nrows, local0);
-    const int nrt = (nrows + 15) >> 4;
     const int sub = RP::sub();
     TileRegs<D> orr, res;
     WRegs<D, D> wr;
@@ -156,13 +153,12 @@ template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_fwd_kernel(const FfnFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using RP = RowPass<D>;
-    constexpr int LDK = TileCfg<D>::LDK, LDC = D + 4;
+    constexpr int LDC = D + 4;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
     float* Cs = Ws;
     int g, nrows, local0; long long row0;
     tile_rows(a.tg, blockIdx.x, g, row0, nrows, local0);
-    const int nrt = (nrows + 15) >> 4;
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }

@@ -119,11 +119,15 @@ class DeviceBatches:
     def __len__(self) -> int:
         return len(self.ds) // (self.bs * self.world)                                     # drop_last=True (train_sr.py:452,455)
 
-    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+    def _new_epoch(self):
+        """Negatives and row order of the next epoch (advances the sampler's epoch counter and the shuffle generator)."""
         neg = self.sample_negatives()
         n = len(self.ds)
         order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
-        order = order.to(self.device)
+        return neg, order.to(self.device)
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        neg, order = self._new_epoch()
         for b in range(len(self)):
             lo = (b * self.world + self.rank) * self.bs
             sel = order[lo:lo + self.bs]
@@ -131,3 +135,16 @@ class DeviceBatches:
             batch["neg_samples"] = neg.index_select(0, sel)
             batch["label"] = self.label
             yield batch
+
+    def epoch_tensors(self) -> Dict[str, torch.Tensor]:
+        """The batches __iter__ would yield for the next epoch, stacked: every value gains a leading [n_batches] axis (label stays
+        [bs, 1 + k]).  Feeds SasrecEngine.pack_epoch / set_input_pool: the whole epoch becomes resident in HBM with a handful of
+        device ops, and the train loop replays one graph per step with no per-step tensor work on the host."""
+        neg, order = self._new_epoch()
+        nb = len(self)
+        rows = (torch.arange(nb, device=self.device).unsqueeze(1) * self.world + self.rank) * self.bs + torch.arange(self.bs, device=self.device)
+        sel = order[rows.reshape(-1)]
+        out = {k: v.index_select(0, sel).reshape(nb, self.bs, *v.shape[1:]) for k, v in self.t.items()}
+        out["neg_samples"] = neg.index_select(0, sel).reshape(nb, self.bs, -1)
+        out["label"] = self.label
+        return out

@@ -79,6 +79,16 @@ class SparseDenseExchange:
             else:
                 dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
+    def all_reduce_max(self, t: torch.Tensor) -> None:
+        """In-place MAX over the world (data-pipeline bookkeeping, e.g. the epoch's largest unique-row count)."""
+        if self.active:
+            if self.host_staging and t.is_cuda:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
     def all_gather_packed(self, send: torch.Tensor, recv: torch.Tensor) -> None:
         if self.host_staging and send.is_cuda:
             h = torch.empty(recv.shape, dtype=recv.dtype)

@@ -238,6 +238,64 @@ class SASRec(nn.Module):
         self._last_plan = pl
         return pl.dr_losses if eng.dr else pl.loss
 
+    def begin_epoch_pool(self, ep: Dict[str, torch.Tensor], exchange=None, dr_objective: int = 0) -> int:
+        """Make a whole epoch resident in HBM (ep = DeviceBatches.epoch_tensors()): the batches are packed into one
+        [n_batches, words] tensor and every following pool_step() consumes the next one, picked on the device by the step counter
+        -- no per-step input copies or host tensor work (train_sr.py:185-199 builds and moves each batch inside the loop).
+        Returns the number of batches.  Under data parallelism the world's largest per-step unique-row count of the epoch is reduced
+        here, once, so the sparse exchange of every step runs without a device -> host sync."""
+        eng = self.engine
+        if eng.dr:
+            eng.dr_mode = int(dr_objective)          # isDR: a pool belongs to the (Adam state, objective) selected now
+        nb, B, T = ep["seq_d1"].shape
+        neg = ep["neg_samples"].reshape(nb, B, -1)
+        pl = eng.plan(B, T, 1 + neg.shape[2], need_grad=True)
+        eng.stream.wait_stream(torch.cuda.current_stream())
+        pool = eng.pack_epoch(pl, ep["i_node"], neg, ep["seq_d1"], ep["seq_d2"], ep["label"], ep["domain_id"], ep.get("ob_label") if eng.dr else None)
+        self._pool_umax = None
+        if exchange is not None and exchange.world > 1:
+            idx = torch.cat((ep["i_node"].reshape(nb, -1), neg.reshape(nb, -1), ep["seq_d1"].reshape(nb, -1), ep["seq_d2"].reshape(nb, -1)), 1)
+            srt = torch.sort(idx, dim=1).values
+            cnt = ((srt[:, 1:] != srt[:, :-1]).sum(1) + 1).max().reshape(1)
+            exchange.all_reduce_max(cnt)
+            self._pool_umax = (int(cnt.item()) + 255) // 256 * 256          # one bucketed bound per epoch: the exchange's graph pair is reused
+        torch.cuda.current_stream().synchronize()
+        if not eng.refill_input_pool(pl, pool):            # same shape, step on a pool boundary: the captured graphs stay valid
+            eng.set_input_pool(pl, pool)
+        self._pool_plan = pl
+        self.fused_optimizer = True
+        return nb
+
+    def pool_step(self, use_graph: bool = True, exchange=None, dr_objective: int = 0) -> torch.Tensor:
+        """One train step on the next batch of the pool installed by begin_epoch_pool(); returns what train_step() returns."""
+        eng, pl = self.engine, self._pool_plan
+        if eng.dr:
+            eng.dr_mode = int(dr_objective)
+        if exchange is not None and exchange.world > 1:
+            if use_graph and getattr(pl, "graph_local", None) is None:
+                eng.capture_local_grads(pl)
+            eng.train_step_dp(pl, exchange, use_graph=use_graph, umax=self._pool_umax)
+        elif use_graph:
+            if not eng.has_graph(pl):
+                eng.capture_train_step(pl)
+            eng.replay_train_step(pl)
+        else:
+            eng.enqueue_train_step(pl)
+        self._last_plan = pl
+        return pl.dr_losses if eng.dr else pl.loss
+
+    def end_epoch_pool(self) -> None:
+        """Hand the device back to torch's stream after an epoch of pool_step()s (the pool stays installed for the next epoch's
+        refill; train_step() on the same plan is refused while it is -- use drop_epoch_pool())."""
+        torch.cuda.current_stream().wait_stream(self.engine.stream)
+
+    def drop_epoch_pool(self) -> None:
+        """Remove the pool of the current (Adam state, objective)."""
+        eng = self.engine
+        eng.sync()
+        if getattr(self, "_pool_plan", None) is not None:
+            eng.set_input_pool(self._pool_plan, None)
+
     def flush(self) -> None:
         """Bring lazily-updated table rows up to date (call before eval / state_dict() / checkpoints)."""
         self.engine.flush_table()

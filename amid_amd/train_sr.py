@@ -6,7 +6,7 @@ ignored; ``type=bool`` flags keep the reference's "any non-empty string is True"
 constants (item_length 447 410, pad id item_length + 1, table of 2 x item_length rows, drop_last on both
 loaders, five seeds 0..4, loss logged every 20 iterations, best-so-far HR/NDCG/MRR per epoch).
 Additions: ``--data_root`` (the reference hard-codes /ossfs/workspace/CDSR), ``--seeds``, ``--device``,
-``--no_graph``, ``--max_steps``, ``--dtype {fp32,bf16}``; data parallel when launched by ``python -m torch.distributed.run --nproc-per-node N``
+``--no_graph``, ``--no_pool``, ``--max_steps``, ``--dtype {fp32,bf16}``; data parallel when launched by ``python -m torch.distributed.run --nproc-per-node N``
 (one process per GPU, RCCL, ``--bs`` per GPU; BASELINE.json configs[3]).
 
     python train_sr.py --data_root /path/to/AMID -ds amazon -dm cloth_sport --overlap_ratio 0.75 \
@@ -68,6 +68,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--seeds", type=int, default=5, help="number of seeds 0..n-1 (reference: 5)")
     p.add_argument("--device", type=str, default="cuda:0")
     p.add_argument("--no_graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
+    p.add_argument("--no_pool", action="store_true", help="build and copy every batch inside the loop (the reference's way) instead of "
+                                                          "keeping the epoch's packed batches resident in HBM")
     p.add_argument("--max_steps", type=int, default=0, help="stop each epoch after this many steps (0 = full epoch)")
     p.add_argument("--dtype", type=str, default="fp32", choices=("fp32", "bf16"),
                    help="fp32: exact fp32 matrix products; bf16: bf16 MFMA operands, fp32 accumulation and storage (sasrec, emb_dim 128)")
@@ -113,15 +115,28 @@ def train(model, train_batches, args, val_batches, exchange=None):
         stats = AverageMeter("loss", "loss_cls")
         model.train()
         t0, n_samples = time.perf_counter(), 0
-        for i, b in enumerate(train_batches):
-            loss = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
-                                    use_graph=not args.no_graph, exchange=exchange)
-            n_samples += len(b["i_node"]) * (exchange.world if exchange is not None else 1)
+        pooled = not args.no_pool and hasattr(model, "begin_epoch_pool")
+        if pooled:            # the epoch's batches resident in HBM, one graph replay per step, no per-step tensor work on the host
+            n_batches = model.begin_epoch_pool(train_batches.epoch_tensors(), exchange=exchange)
+            steps = ((None, None) for _ in range(n_batches))
+        else:
+            steps = enumerate(train_batches)
+        for i, (_, b) in enumerate(steps):
+            if pooled:
+                loss = model.pool_step(use_graph=not args.no_graph, exchange=exchange)
+            else:
+                loss = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
+                                        use_graph=not args.no_graph, exchange=exchange)
+            n_samples += args.bs * (exchange.world if exchange is not None else 1)
             if i % 20 == 0:                                                               # train_sr.py:217-219 (the only host sync)
+                if pooled:
+                    model.engine.sync()
                 stats.update(loss=loss.item(), loss_cls=loss.item())
                 logger.info(f"train total loss:{stats.loss}, cls loss:{stats.loss_cls} \t")
             if args.max_steps and i + 1 >= args.max_steps:
                 break
+        if pooled:
+            model.end_epoch_pool()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         logger.info(f"epoch {epoch}: {n_samples} samples in {dt:.2f} s = {n_samples / dt:.0f} samples/s (loader included)")

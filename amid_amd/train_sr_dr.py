@@ -48,28 +48,45 @@ def train(model, train_batches, train_batches_dr, args, val_batches):
         model.train()
         t0, n_samples = time.perf_counter(), 0
         eng.select_optimizer(0, lr=args.lr)                                              # optimizer   (train_sr_dr.py:668)
-        for i, b in enumerate(train_batches):
-            losses = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
-                                      use_graph=not args.no_graph, dr_objective=0)
-            n_samples += len(b["i_node"])
+        pooled = not args.no_pool        # each loop's epoch resident in HBM, one graph replay per step (see train_sr.py of this repo)
+        steps = ((None, None) for _ in range(model.begin_epoch_pool(train_batches.epoch_tensors(), dr_objective=0))) if pooled \
+            else enumerate(train_batches)
+        for i, (_, b) in enumerate(steps):
+            if pooled:
+                losses = model.pool_step(use_graph=not args.no_graph, dr_objective=0)
+            else:
+                losses = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
+                                          use_graph=not args.no_graph, dr_objective=0)
+            n_samples += args.bs
             if i % 20 == 0:                                                               # train_sr_dr.py:226-227
+                eng.sync()
                 lc, le, _ = losses.tolist()
                 stats.update(loss_cls=lc, loss_dr_e=le)
                 logger.info(f"train cls loss:{stats.loss_cls}, dr_e loss:{stats.loss_dr_e} \t")
             if args.max_steps and i + 1 >= args.max_steps:
                 break
+        if pooled:
+            model.end_epoch_pool()
         res = base.test(model, args, val_batches)
         model.train()
         eng.select_optimizer(1, lr=args.lr * args.lr2)                                   # optimizer2  (train_sr_dr.py:669)
-        for i, b in enumerate(train_batches_dr):
-            losses = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
-                                      use_graph=not args.no_graph, ob_label=b["ob_label"], dr_objective=1)
-            n_samples += len(b["i_node"])
+        steps = ((None, None) for _ in range(model.begin_epoch_pool(train_batches_dr.epoch_tensors(), dr_objective=1))) if pooled \
+            else enumerate(train_batches_dr)
+        for i, (_, b) in enumerate(steps):
+            if pooled:
+                losses = model.pool_step(use_graph=not args.no_graph, dr_objective=1)
+            else:
+                losses = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
+                                          use_graph=not args.no_graph, ob_label=b["ob_label"], dr_objective=1)
+            n_samples += args.bs
             if i % 20 == 0:                                                               # train_sr_dr.py:400-402
+                eng.sync()
                 stats.update(loss_dr_r=losses.tolist()[2])
                 logger.info(f"train loss_dr_r:{stats.loss_dr_r} \t")
             if args.max_steps and i + 1 >= args.max_steps:
                 break
+        if pooled:
+            model.end_epoch_pool()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         logger.info(f"epoch {epoch}: {n_samples} samples in {dt:.2f} s = {n_samples / dt:.0f} samples/s (loaders and evaluation included)")

@@ -282,6 +282,52 @@ def test_train_sr_cli_end_to_end(tmp_path, model, emb, extra):
     assert (tmp_path / "model" / "log0.txt").exists()
 
 
+@pytest.mark.parametrize("variant", ["sasrec", "dr"])
+def test_epoch_pool_equals_per_step_batches(tmp_path, variant):
+    """Two epochs fed from the HBM-resident epoch pool (DeviceBatches.epoch_tensors -> begin_epoch_pool / pool_step; the second
+    epoch refills the pool under the captured graph) leave exactly the parameters that per-step batches leave; isDR: both loops,
+    each with its own pool, Adam state and objective."""
+    from amid_amd.dataset_seq import DeviceBatches, DualDomainSeqDataset
+    from amid_amd.model_seq import SASRec
+    rng = np.random.default_rng(7)
+    root = tmp_path / "amazon_dataset"
+    root.mkdir()
+    dr = variant == "dr"
+    _write_csv(root / "toy_train75.csv", 150, rng, 1, 300, 300, 700, ob_label=dr)
+    _write_csv(root / "toy_b.csv", 110, rng, 1, 300, 300, 700, ob_label=dr)
+
+    def run(pooled):
+        dss = [DualDomainSeqDataset(seq_len=20, isTrain=True, neg_nums=9, long_length=7, pad_id=1001, seed=3, csv_path=str(root / f))
+               for f in (("toy_train75.csv", "toy_b.csv") if dr else ("toy_train75.csv",))]
+        loaders = [DeviceBatches(d, 16, shuffle=True, device="cuda:0", seed=3 + k) for k, d in enumerate(dss)]
+        m = SASRec(10, 64, 2000, 64, 20, 16, 16, False, False, 0.5, 0.5, isDR=dr, lr=1e-3, seed=1).cuda()
+        losses = []
+        for _ in range(2):
+            for k, ld in enumerate(loaders):
+                if dr:
+                    m.engine.select_optimizer(k, lr=1e-3 * (1.0 if k == 0 else 0.5))
+                if pooled:
+                    n = m.begin_epoch_pool(ld.epoch_tensors(), dr_objective=k)
+                    assert n == len(ld)
+                    for _i in range(n):
+                        out = m.pool_step(dr_objective=k)
+                    m.end_epoch_pool()
+                else:
+                    for b in ld:
+                        out = m.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
+                                           ob_label=b["ob_label"] if dr else None, dr_objective=k)
+                m.engine.sync()
+                losses.append(out.detach().cpu().clone())
+        return losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+    l0, s0 = run(False)
+    l1, s1 = run(True)
+    for a, b in zip(l0, l1):
+        assert torch.equal(a, b)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
 def test_device_negative_sampling(tmp_path):
     """next-3: negatives drawn on the device obey the reference's rule (dataset_seq.py:188/:198): k distinct items of the row's
     own domain pool, none of them in the row's own sequence; fresh draws every epoch; roughly uniform."""
