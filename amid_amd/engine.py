@@ -912,9 +912,10 @@ class SasrecEngine:
     def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False, umax: Optional[int] = None) -> None:
         """One data-parallel step: local grads -> dense all-reduce + ONE sparse all-gather -> merge -> Adam.
         umax: a bound on the world's largest unique-row count of this step if the host knows one (no host sync then, see
-        dist.py).  With use_graph and a known umax the step is graph A (local gradients + packing of this rank's chunk), the
-        two collectives, graph B (merge + Adam): four host calls; the pair of graphs is captured per distinct umax, so callers
-        should pass a bucketed bound (bench.py: the pool's maximum)."""
+        dist.py).  With use_graph and a known umax the step is graph A (local gradients + packing of this rank's chunk: ids, rows
+        and, behind them, the flat dense gradient), ONE all-gather, graph B (rank-ordered sum of the dense parts, merge of the
+        sparse parts, Adam): three host calls, and replicas that are bit-identical by construction; the pair of graphs is captured
+        per distinct umax, so callers should pass a bucketed bound (bench.py: the pool's maximum)."""
         if (self.itc_bs or self.inc_bs) and exchange.active:
             raise NotImplementedError("isItC / isInC couple the rows of a batch (softmax and Linear(bs, 1) over the batch, "
                                       "model_seq.py:465-469, :490-494): data-parallel sharding would change the model; train them on one GPU")
@@ -923,11 +924,9 @@ class SasrecEngine:
             self.grad_scale = exchange.grad_scale
             fast = use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")
             pair = getattr(pl, "dp_graphs", {}).get(umax) if fast else None
-            if pair is not None:
-                be = exchange.backend
+            if pair is not None:       # graph A, ONE collective (the dense gradient rides behind the sparse rows), graph B
                 L.call("amid_graph_launch", pair[0], self.s)
                 self.step += 1
-                exchange.all_reduce_dense(self.dense.grad)
                 exchange.all_gather_packed(pair[2], pair[3])
                 L.call("amid_graph_launch", pair[1], self.s)
                 return
@@ -946,16 +945,18 @@ class SasrecEngine:
         L, be = lib(), exchange.backend
         self.sync()
         step0 = self.step
+        be.prepare_dense(exchange.world, umax, self.dense.grad)      # device tables are built here, not under capture
         graphs = []
         for part in (0, 1):
             L.call("amid_graph_capture_begin", self.s)
             try:
                 if part == 0:
                     self.enqueue_local_grads(pl)
-                    send = be.pad_packed(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax)
+                    send = be.pad_packed(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax, dense=self.dense.grad)
                 else:
-                    recv = be.gather_buffer(exchange.world, umax)
-                    self.enqueue_optimizer(pl, sparse=be.merge_packed(recv, exchange.world, umax))
+                    recv = be.gather_buffer(exchange.world, umax, dense=self.dense.grad)
+                    be.sum_dense(recv, exchange.world, umax, self.dense.grad)
+                    self.enqueue_optimizer(pl, sparse=be.merge_packed(recv, exchange.world, umax, dense=self.dense.grad))
             finally:
                 out = ctypes.c_void_p()
                 L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
@@ -1060,33 +1061,80 @@ class HipMergeBackend:
         self.uniq_rows = torch.empty(self.cap, D, dtype=torch.float32, device=dev)
         # exchange buffers: this rank's packed chunk and the world's gathered chunks (sliced per step, never reallocated);
         # capacity counts entries, so the id rows of the packed layout come on top (dist.packed_rows)
-        self.send = torch.zeros((self.cap + (self.cap + D - 1) // D + 16) * D, dtype=torch.float32, device=dev)
-        self.all = torch.zeros((self.cap + (self.cap + D - 1) // D + 16 * 16) * D, dtype=torch.float32, device=dev)
+        # (+ the flat dense gradient, which rides behind the rows in the one-collective step: up to MAX_WORLD chunks of it)
+        self.dense_rows = (eng.dense.numel + D - 1) // D
+        self.send = torch.zeros((self.cap + (self.cap + D - 1) // D + 16 + self.dense_rows) * D, dtype=torch.float32, device=dev)
+        self.all = torch.zeros((self.cap + (self.cap + D - 1) // D + 16 * 16 + self.MAX_WORLD * self.dense_rows) * D, dtype=torch.float32,
+                               device=dev)
+        self._entries = {}
         torch.cuda.synchronize(dev)
 
-    def pad_packed(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, umax: int) -> torch.Tensor:
+    MAX_WORLD = 16
+
+    def _entry(self, key, src: int, dst: int, stride: int, n_part: int, count: int) -> torch.Tensor:
+        """A one-entry table for amid_reduce_partials_f32 (device resident, cached: captured graphs keep pointing at it)."""
+        ent = self._entries.get(key)
+        if ent is None:
+            L = lib()
+            host = (ctypes.c_ubyte * L.value("amid_reduce_entry_bytes"))()
+            L.call("amid_reduce_entry_pack", ctypes.addressof(host), 0, src, dst, stride, n_part, count)
+            ent = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(self.eng.device)
+            torch.cuda.synchronize(self.eng.device)
+            self._entries[key] = ent
+        return ent
+
+    def prepare_dense(self, world: int, umax: int, dense: torch.Tensor) -> None:
+        """Build the reduce tables pad_packed(dense=...) / sum_dense() will use for this (world, umax): they copy to the device and
+        synchronise, which is not allowed while a stream is being captured."""
+        from .dist import packed_rows
+        D = self.eng.D
+        rows = packed_rows(umax, D)[1]
+        self._entry(("copy", umax), dense.data_ptr(), self.send.data_ptr() + 4 * rows * D, 0, 1, dense.numel())
+        self._entry(("sum", self.all.data_ptr(), world, umax), self.all.data_ptr() + 4 * rows * D, dense.data_ptr(),
+                    self.chunk_rows(umax, dense) * D, world, dense.numel())
+
+    def chunk_rows(self, umax: int, dense: Optional[torch.Tensor]) -> int:
+        from .dist import packed_rows
+        return packed_rows(umax, self.eng.D)[1] + (self.dense_rows if dense is not None else 0)
+
+    def sum_dense(self, gathered: torch.Tensor, world: int, umax: int, dense: torch.Tensor) -> None:
+        """dense <- sum over the ranks, in rank order, of the dense parts that travelled behind the sparse rows."""
+        from .dist import packed_rows
+        D = self.eng.D
+        off = packed_rows(umax, D)[1] * D
+        stride = self.chunk_rows(umax, dense) * D
+        ent = self._entry(("sum", gathered.data_ptr(), world, umax), gathered.data_ptr() + 4 * off, dense.data_ptr(), stride, world, dense.numel())
+        lib().call("amid_reduce_partials_f32", ent.data_ptr(), 1, dense.numel(), self.eng.s)
+
+    def pad_packed(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, umax: int,
+                   dense: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dense: also append this flat fp32 buffer (the dense gradient) behind the rows, so that ONE all-gather moves everything."""
         from .dist import packed_rows
         D = self.eng.D
         id_rows, rows = packed_rows(umax, D)
-        send = self.send[: rows * D]
+        send = self.send[: self.chunk_rows(umax, dense) * D]
+        if dense is not None:
+            ent = self._entry(("copy", umax), dense.data_ptr(), send.data_ptr() + 4 * rows * D, 0, 1, dense.numel())
+            lib().call("amid_reduce_partials_f32", ent.data_ptr(), 1, dense.numel(), self.eng.s)
         # sentinel padding (one past the last table row) keeps every rank's list sorted, so merge_packed() is a merge, not a sort
         lib().call("amid_sparse_pad_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), umax, D, self.eng.n_rows,
                    send.data_ptr(), send.data_ptr() + 4 * id_rows * D, self.eng.s)
         return send
 
-    def gather_buffer(self, world: int, umax: int) -> torch.Tensor:
-        from .dist import packed_rows
-        n = world * packed_rows(umax, self.eng.D)[1] * self.eng.D
-        if n > self.all.numel() or world * umax > self.cap:
+    def gather_buffer(self, world: int, umax: int, dense: Optional[torch.Tensor] = None) -> torch.Tensor:
+        n = world * self.chunk_rows(umax, dense) * self.eng.D
+        if n > self.all.numel() or world * umax > self.cap or (dense is not None and world > self.MAX_WORLD):
             raise ValueError(f"gather of {world} x {umax} entries exceeds the backend capacity {self.cap}")
         return self.all[:n]
 
-    def merge_packed(self, gathered: torch.Tensor, world: int, umax: int):
-        """`world` packed chunks (sorted, sentinel-padded ids + rows) -> 4-launch stable merge + segment reduce."""
+    def merge_packed(self, gathered: torch.Tensor, world: int, umax: int, dense: Optional[torch.Tensor] = None):
+        """`world` packed chunks (sorted, sentinel-padded ids + rows [+ a dense tail the merge skips]) -> 4-launch stable merge +
+        segment reduce."""
         from .dist import packed_rows
         L, eng = lib(), self.eng
         D = eng.D
-        id_rows, rows = packed_rows(umax, D)
+        id_rows, _ = packed_rows(umax, D)
+        rows = self.chunk_rows(umax, dense)
         n = world * umax
         L.call("amid_merge_sorted_lists_i32", gathered.data_ptr(), world, umax, rows * D, id_rows, rows, eng.n_rows, self.sort_ws.data_ptr(),
                self.pos_sorted.data_ptr(), self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
