@@ -740,6 +740,23 @@ class SasrecEngine:
         self._scorer_bwd(pl, "predict_gfunc", items, ditems, pl.g1, pl.g2, pl.dg1, pl.dg2, pl.sc_part_g, 1)
         self._enqueue_user_vectors_bwd(pl)
 
+    def _enqueue_scorers_fused(self, pl: SasrecPlan, items: int, ditems: int, tr_src, tr_dst, n_tr: int) -> None:
+        """Every scorer of the model (one, or the three of isDR) forward + the row's loss terms + backward on pl.u in ONE launch
+        (amid_scorer_multi_fwd_bwd_f32): pl.du, d items, per-head weight-gradient partials, loss partials."""
+        shp, fp = pl.shape, self.dense
+        heads = DR_HEADS if self.dr else DR_HEADS[:1]
+        outs = [(pl.p1, pl.p2, pl.dp1, pl.dp2, pl.sc_part)]
+        if self.dr:
+            outs += [(pl.ips1, pl.ips2, pl.dips1, pl.dips2, pl.sc_part_ips), (pl.g1, pl.g2, pl.dg1, pl.dg2, pl.sc_part_g)]
+        pa = lambda seq: ptr_array(list(seq))          # noqa: E731
+        lib().call("amid_scorer_multi_fwd_bwd_f32", pl.u.data_ptr(), items, pa(fp.ptr(f"{h}.fc.0.weight") for h in heads),
+                   pa(fp.ptr(f"{h}.fc.0.bias") for h in heads), pa(fp.ptr(f"{h}.fc.2.weight") for h in heads),
+                   pa(fp.ptr(f"{h}.fc.2.bias") for h in heads), len(heads), pl.labels.data_ptr(), pl.domain.data_ptr(),
+                   pl.in_ob.data_ptr() if self.dr else None, self.dr_mode if self.dr else 0, self.dr_e_w, shp.B, shp.NI, self.D, self.hid,
+                   pa(o[0].data_ptr() for o in outs), pa(o[1].data_ptr() for o in outs), pa(o[2].data_ptr() for o in outs),
+                   pa(o[3].data_ptr() for o in outs), pl.loss_part.data_ptr(), pl.dr_loss_part.data_ptr() if self.dr else None,
+                   pl.du.data_ptr(), ditems, pa(o[4].data_ptr() for o in outs), tr_src, tr_dst, n_tr, self.s)
+
     def enqueue_backward(self, pl: SasrecPlan, train: bool) -> None:
         """Backward from pl.dp1 / pl.dp2 (dLoss/dp) to pl.uniq_grad (table rows) and dense.grad."""
         L, s, shp, D = lib(), self.s, pl.shape, self.D
@@ -761,18 +778,7 @@ class SasrecEngine:
         items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
         ditems = pl.dxg.data_ptr() + 4 * 2 * shp.Mi * D
         if (self.dr or self.itc_bs) and getattr(self, "_fuse_scorers", False):
-            heads = DR_HEADS if self.dr else DR_HEADS[:1]
-            outs = [(pl.p1, pl.p2, pl.dp1, pl.dp2, pl.sc_part)]
-            if self.dr:
-                outs += [(pl.ips1, pl.ips2, pl.dips1, pl.dips2, pl.sc_part_ips), (pl.g1, pl.g2, pl.dg1, pl.dg2, pl.sc_part_g)]
-            pa = lambda seq: ptr_array(list(seq))          # noqa: E731
-            L.call("amid_scorer_multi_fwd_bwd_f32", pl.u.data_ptr(), items, pa(fp.ptr(f"{h}.fc.0.weight") for h in heads),
-                   pa(fp.ptr(f"{h}.fc.0.bias") for h in heads), pa(fp.ptr(f"{h}.fc.2.weight") for h in heads),
-                   pa(fp.ptr(f"{h}.fc.2.bias") for h in heads), len(heads), pl.labels.data_ptr(), pl.domain.data_ptr(),
-                   pl.in_ob.data_ptr() if self.dr else None, self.dr_mode if self.dr else 0, self.dr_e_w, B, NI, D, self.hid,
-                   pa(o[0].data_ptr() for o in outs), pa(o[1].data_ptr() for o in outs), pa(o[2].data_ptr() for o in outs),
-                   pa(o[3].data_ptr() for o in outs), pl.loss_part.data_ptr(), pl.dr_loss_part.data_ptr() if self.dr else None,
-                   pl.du.data_ptr(), ditems, pa(o[4].data_ptr() for o in outs), ptr_array(src), ptr_array(dst), len(src), s)
+            self._enqueue_scorers_fused(pl, items, ditems, ptr_array(src), ptr_array(dst), len(src))
             self._enqueue_user_vectors_bwd(pl)
         elif self.dr:
             L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)

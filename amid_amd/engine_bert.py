@@ -17,8 +17,9 @@ from .engine import SasrecEngine, SasrecPlan
 BERT_HEADS, BERT_FF, BERT_P_DROP, BERT_HIDDEN = 4, 512, 0.1, 128
 
 
-def bert4rec_dense_names(hid: int) -> List[Tuple[str, Tuple[int, ...]]]:
-    """Non-table parameters in the reference's state_dict order."""
+def bert4rec_dense_names(hid: int, dr: bool = False) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Non-table parameters in the reference's state_dict order; dr: with the predict_ips / predict_gfunc heads of isDR=True
+    (model_seq.py:268-271)."""
     D, F = BERT_HIDDEN, BERT_FF
     out: List[Tuple[str, Tuple[int, ...]]] = []
     for d in (1, 2):
@@ -37,10 +38,11 @@ def bert4rec_dense_names(hid: int) -> List[Tuple[str, Tuple[int, ...]]]:
             out.append((f"{pre}.input_sublayer.norm.b_2", (D,)))
             out.append((f"{pre}.output_sublayer.norm.a_2", (D,)))
             out.append((f"{pre}.output_sublayer.norm.b_2", (D,)))
-    out.append(("predictModule.fc.0.weight", (hid, 2 * D)))
-    out.append(("predictModule.fc.0.bias", (hid,)))
-    out.append(("predictModule.fc.2.weight", (1, hid)))
-    out.append(("predictModule.fc.2.bias", (1,)))
+    for head in ("predictModule",) + (("predict_ips", "predict_gfunc") if dr else ()):
+        out.append((f"{head}.fc.0.weight", (hid, 2 * D)))
+        out.append((f"{head}.fc.0.bias", (hid,)))
+        out.append((f"{head}.fc.2.weight", (1, hid)))
+        out.append((f"{head}.fc.2.bias", (1,)))
     return out
 
 
@@ -99,7 +101,17 @@ class Bert4recEngine(SasrecEngine):
     EMB_DIMS = (BERT_HIDDEN,)
 
     def _dense_names(self):
-        return bert4rec_dense_names(self.hid)
+        return bert4rec_dense_names(self.hid, self.dr)
+
+    # BERT4Rec has no last LayerNorm: the user vectors are the plain means over time (model_seq.py:299-300)
+    def _enqueue_user_vectors(self, pl) -> None:
+        shp = pl.shape
+        lib().call("amid_lnmean_fwd_f32", pl.x[2].data_ptr(), None, None, None, None, shp.B, shp.T, self.D, 0.0, pl.u.data_ptr(), self.s)
+
+    def _enqueue_user_vectors_bwd(self, pl) -> None:
+        shp = pl.shape
+        lib().call("amid_lnmean_bwd_f32", pl.x[2].data_ptr(), pl.du.data_ptr(), None, None, shp.B, shp.T, self.D, 0.0, pl.dxbuf.data_ptr(), None,
+                   self.s)
 
     def _alloc_model_buffers(self) -> None:
         D, F = self.D, BERT_FF
@@ -134,6 +146,12 @@ class Bert4recEngine(SasrecEngine):
             L.call("amid_bert_ffn2_fwd_f32", pl.h[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".feed_forward.w_2.weight"),
                    self._pp(pre + ".feed_forward.w_2.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x[l + 1].data_ptr(), s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
+        if self.dr:                                  # three heads (model_seq.py:301-305) on the plain means
+            if getattr(self, "_fuse_scorers", False) and with_loss and not sum_loss:
+                self._enqueue_user_vectors(pl)       # the scorers run as ONE forward + loss + backward launch in enqueue_backward
+            else:
+                self._enqueue_head_dr_fwd(pl, items, with_loss)
+            return
         if getattr(self, "_fuse_head", False) and with_loss and not sum_loss:
             return                                   # train step: the head runs as ONE forward + backward launch in enqueue_backward
         L.call("amid_head_fwd_f32", pl.x[2].data_ptr(), None, None, items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
@@ -165,7 +183,12 @@ class Bert4recEngine(SasrecEngine):
                len(src), s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
         ditems = pl.dxg.data_ptr() + 4 * 2 * M * D
-        if getattr(self, "_fuse_head", False):
+        if self.dr and getattr(self, "_fuse_scorers", False):
+            self._enqueue_scorers_fused(pl, items, ditems, None, None, 0)
+            self._enqueue_user_vectors_bwd(pl)
+        elif self.dr:
+            self._enqueue_head_dr_bwd(pl, items, ditems)
+        elif getattr(self, "_fuse_head", False):
             L.call("amid_head_fwd_bwd_f32", pl.x[2].data_ptr(), None, None, items, fp.ptr("predictModule.fc.0.weight"),
                    fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"),
                    pl.labels.data_ptr(), pl.domain.data_ptr(), B, T, NI, D, self.hid, 0.0, pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(),

@@ -24,7 +24,7 @@ are accepted and ignored; dropout follows ``module.training``.  Two ways to trai
                    Adam as one hipGraph replay -- what ``train_sr.py`` of this repo and ``bench.py`` use.
 
 Out of scope this round (constructors kept for import / state_dict parity, ``forward`` raises):
-GRU4Rec (recurrent), the standalone InnerComp / InterComp modules, BERT4Rec with isInC / isItC / isDR (isItC there puts the
+GRU4Rec (recurrent), the standalone InnerComp / InterComp modules, BERT4Rec with isInC / isItC (isItC there puts the
 appended token group in FRONT of the encoders), embUserLayerEnhance (dead code in the reference).
 SASRec(isItC=True, isDR=True) -- InterComp after the encoders + the doubly-robust heads, what run.sh trains through
 train_sr_dr.py -- IS built (csrc/intercomp.hip, amid_dr_loss_f32), and so is SASRec(isInC=True) -- InnerComp on the gathered rows
@@ -134,8 +134,6 @@ class SASRec(nn.Module):
             _not_built("InnerComp (isInC) for this model", "model_seq.py:283-285")
         if isItC and not self.SUPPORTS_ITC:
             _not_built("InterComp (isItC) for this model", "model_seq.py:289-294")
-        if isDR and not self.SUPPORTS_ITC:
-            _not_built("the doubly-robust heads (isDR) for this model", "model_seq.py:268-271")
         if user_emb_dim != item_emb_dim:
             raise ValueError("the reference feeds item rows into encoders built with user_emb_dim: the two must be equal")
         lib()                                                   # fail loudly without libamid_hip.so
@@ -480,7 +478,7 @@ class GRU4Rec(nn.Module):
 
 
 class BERT4Rec(SASRec):
-    """model_seq.py:248-309 on the HIP engine (isInC = isItC = isDR = False): two stacks of two TransformerBlocks whose
+    """model_seq.py:248-309 on the HIP engine (isInC = isItC = False; isDR either way): two stacks of two TransformerBlocks whose
     hidden size 128 / 4 heads / FFN 512 / dropout 0.1 the reference hard-codes (:264-267), so emb dims must be 128; no
     positional embedding; ONE key mask from seq_d2 > 0 for both stacks (:288); plain mean over time, then predictModule.
     Same constructor, forward signature, state_dict keys (transform{1,2}.{0,1}.*) and train_step() as SASRec above."""

@@ -26,7 +26,7 @@ import torch
 
 from . import train_sr as base
 from .dataset_seq import DeviceBatches, DualDomainSeqDataset
-from .model_seq import SASRec
+from .model_seq import BERT4Rec, SASRec
 from .utils import AverageMeter, init_logger
 
 logger = logging.getLogger()
@@ -108,8 +108,8 @@ def main(argv=None):
     if not args.isDR:
         raise SystemExit("train_sr_dr.py trains the doubly-robust heads (the reference's loop unpacks six outputs, train_sr_dr.py:204); "
                          "use train_sr.py without them")
-    if args.model.lower() != "sasrec":
-        raise SystemExit("the doubly-robust heads are built for --model sasrec (what run.sh trains)")
+    if args.model.lower() not in ("sasrec", "bert4rec"):
+        raise SystemExit("the doubly-robust heads are built for --model sasrec (what run.sh trains) and bert4rec")
     summary = []
     for i in range(args.seeds):
         torch.manual_seed(i); np.random.seed(i); random.seed(i)                           # train_sr_dr.py:624-627
@@ -125,7 +125,7 @@ def main(argv=None):
         train_batches_dr = DeviceBatches(ds_dr, args.bs, shuffle=True, device=args.device, seed=500 + i)
         val_batches = DeviceBatches(ds_val, args.bs, shuffle=False, device=args.device, seed=i)
         torch.cuda.set_device(torch.device(args.device))
-        model = SASRec(user_length=2 * user_length, user_emb_dim=args.emb_dim, item_length=2 * item_length, item_emb_dim=args.emb_dim,
+        model = (SASRec if args.model.lower() == "sasrec" else BERT4Rec)(user_length=2 * user_length, user_emb_dim=args.emb_dim, item_length=2 * item_length, item_emb_dim=args.emb_dim,
                        seq_len=args.seq_len, hid_dim=args.hid_dim, bs=args.bs, isInC=args.isInC, isItC=args.isItC, threshold1=args.ts1,
                        threshold2=args.ts2, isDR=True, lr=args.lr, seed=i, **({"compute": "bf16"} if args.dtype == "bf16" else {}))
         model.engine.dr_e_w = float(args.dr_e_w)

@@ -370,8 +370,8 @@ def bert_block(x: torch.Tensor, key_keep: torch.Tensor, P: Params, pre: str, mas
 
 
 def bert4rec_forward(P: Params, i_node: torch.Tensor, neg_samples: torch.Tensor, seq_d1: torch.Tensor,
-                     seq_d2: torch.Tensor, masks: Masks = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """BERT4Rec.forward model_seq.py:277-309 (isInC = isItC = False)."""
+                     seq_d2: torch.Tensor, masks: Masks = None, isDR: bool = False) -> Tuple[torch.Tensor, ...]:
+    """BERT4Rec.forward model_seq.py:277-309 (isInC = isItC = False); isDR: the three heads of :301-305."""
     E = P["item_emb_layer.emb_item.weight"]
     i_feat = gather_rows(E, i_node).unsqueeze(1)
     neg_feat = gather_rows(E, neg_samples)
@@ -384,6 +384,9 @@ def bert4rec_forward(P: Params, i_node: torch.Tensor, neg_samples: torch.Tensor,
         x2 = bert_block(x2, key_keep, P, f"transform2.{l}", masks)       # :297-298
     u1, u2 = x1.mean(1), x2.mean(1)                                      # :299-300
     items = torch.cat((i_feat, neg_feat), 1)
+    if isDR:
+        return (predict_module(u1, u2, items, P) + predict_module(u1, u2, items, P, "predict_ips")
+                + predict_module(u1, u2, items, P, "predict_gfunc"))
     return predict_module(u1, u2, items, P)
 
 
@@ -421,10 +424,12 @@ def dr_losses(outs, labels: torch.Tensor, domain_id: torch.Tensor, ob_label: Opt
     return loss_cls, loss_dr_e, loss_cls + dr_e_w * loss_dr_e, loss_dr_r
 
 
-def dr_loss_and_grads(P: Params, batch: Dict[str, torch.Tensor], which: str, masks: Masks = None, dr_e_w: float = 0.1, **fwd_kw):
+def dr_loss_and_grads(P: Params, batch: Dict[str, torch.Tensor], which: str, masks: Masks = None, dr_e_w: float = 0.1,
+                      model: str = "sasrec", **fwd_kw):
     """which = "e": gradient of loss_cls + dr_e_w * loss_dr_e (first loop); "r": gradient of loss_dr_r (second loop)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
-    outs = sasrec_forward(leaves, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], masks, isDR=True, **fwd_kw)
+    fwd = sasrec_forward if model == "sasrec" else bert4rec_forward
+    outs = fwd(leaves, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], masks, isDR=True, **fwd_kw)
     lc, le, tot, lr_ = dr_losses(outs, batch["label"], batch["domain_id"], batch.get("ob_label"), dr_e_w)
     loss = tot if which == "e" else lr_
     names = list(leaves)
@@ -570,7 +575,8 @@ def sasrec_param_shapes(item_length: int, D: int, T: int, hid: int, itc_bs: int 
     return s
 
 
-def bert4rec_param_shapes(item_length: int, hid: int) -> Dict[str, Tuple[int, ...]]:
+def bert4rec_param_shapes(item_length: int, hid: int, dr: bool = False) -> Dict[str, Tuple[int, ...]]:
+    """dr: also the predict_ips / predict_gfunc heads of isDR=True (model_seq.py:268-271)."""
     D, F = BERT_HIDDEN, BERT_FF
     s: Dict[str, Tuple[int, ...]] = {"item_emb_layer.emb_item.weight": (item_length, D)}
     for d in (1, 2):
@@ -589,10 +595,11 @@ def bert4rec_param_shapes(item_length: int, hid: int) -> Dict[str, Tuple[int, ..
             s[f"{pre}.input_sublayer.norm.b_2"] = (D,)
             s[f"{pre}.output_sublayer.norm.a_2"] = (D,)
             s[f"{pre}.output_sublayer.norm.b_2"] = (D,)
-    s["predictModule.fc.0.weight"] = (hid, 2 * D)
-    s["predictModule.fc.0.bias"] = (hid,)
-    s["predictModule.fc.2.weight"] = (1, hid)
-    s["predictModule.fc.2.bias"] = (1,)
+    for head in ("predictModule",) + (("predict_ips", "predict_gfunc") if dr else ()):
+        s[f"{head}.fc.0.weight"] = (hid, 2 * D)
+        s[f"{head}.fc.0.bias"] = (hid,)
+        s[f"{head}.fc.2.weight"] = (1, hid)
+        s[f"{head}.fc.2.bias"] = (1,)
     return s
 
 

@@ -233,3 +233,102 @@ def test_module_surface_matches_reference():
     for k, v in Po.items():
         if not k.endswith("linear_layers.1.bias"):          # zero-gradient key bias, see above
             assert float((sd[k].cpu() - v).abs().max()) < 2e-4, k
+
+
+# ---------------------------------------------------------------------------- isDR (model_seq.py:268-271, :301-305)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_dr_golden_outputs_losses_grads(mode):
+    """BERT4Rec(isDR=True) against the reference's own six outputs, losses and gradients of both objectives (g13)."""
+    from amid_amd.engine_bert import Bert4recEngine
+    z = np.load(os.path.join(GOLDEN, "g13_bert4rec_dr.npz"))
+    P = orc.random_params(orc.bert4rec_param_shapes(int(z["n_items"]), int(z["hid"]), dr=True), seed=int(z["param_seed"]))
+    B = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("B/")}
+    Bn, T = B["seq_d1"].shape
+    eng = Bert4recEngine(int(z["n_items"]), 128, T, int(z["hid"]), lr=1e-3, seed=0, dr=True, dr_e_w=float(z["dr_e_w"]))
+    eng.load_state_dict(P)
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    cu = {k: v.cuda() for k, v in B.items()}
+    eng.dr_mode = mode
+    eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], torch.from_numpy(z["labels"]).cuda(), cu["domain_id"],
+                   torch.from_numpy(z["ob_label"]).cuda())
+    eng.enqueue_prepare(pl, sparse=True)
+    eng.enqueue_forward(pl, train=False, with_loss=True)
+    eng.enqueue_backward(pl, train=False)
+    eng.sync()
+    for got, name in zip((pl.p1, pl.p2, pl.ips1, pl.ips2, pl.g1, pl.g2), ("p1", "p2", "ips1", "ips2", "g1", "g2")):
+        assert relmax(got, z[name]) < 1e-4, name
+    losses = pl.dr_losses.cpu()
+    for c, name in enumerate(("loss_cls", "loss_dr_e", "loss_dr_r")):
+        assert abs(float(losses[c]) - float(z[name])) < 2e-5 * max(1.0, abs(float(z[name]))), name
+    pre = "GE/" if mode == 0 else "GR/"
+    G = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+    bad = []
+    for name, want in G.items():
+        if name == "item_emb_layer.emb_item.weight" or name.endswith("linear_layers.1.bias"):
+            continue
+        got = eng.dense.view(name, eng.dense.grad)
+        e = relmax(got, want) if float(want.abs().max()) > 1e-12 else float(got.abs().max().cpu())
+        if not e < 1e-3:
+            bad.append((name, e))
+    assert not bad, bad
+    tg = dense_table_grad(eng, pl)
+    assert relmax(tg, G["item_emb_layer.emb_item.weight"]) < 1e-3
+
+
+def test_dr_train_steps_fused_vs_oracle_two_optimizers():
+    """BERT4Rec(isDR=True) train steps (fused three-head scorer launch, dropout on) alternating the two objectives / Adam states
+    against the oracle's two dense Adams; graph replay bit-identical to eager."""
+    from amid_amd.engine_bert import Bert4recEngine
+    T, Bn, hid, n_items, w, lr = 12, 6, 16, 200, 0.1, 1e-3
+    P = orc.random_params(orc.bert4rec_param_shapes(n_items, hid, dr=True), seed=21)
+    batches = []
+    for t in range(4):
+        b = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=0, neg=1, seed=700 + t)
+        b["ob_label"] = (torch.rand(Bn, generator=torch.Generator().manual_seed(t)) < 0.6).long()
+        batches.append(b)
+    seed = 17
+    Po = {k: v.clone() for k, v in P.items()}
+    opts = [orc.DenseAdam(Po, lr=lr), orc.DenseAdam(Po, lr=lr * 0.5)]
+    want = []
+    for t, b in enumerate(batches):
+        k = t % 2
+        masks = orc.philox_masks_bert4rec(Bn, T, seed=seed + (0 if k == 0 else 0x9E3779B9), step=opts[k].t + 1)
+        info, _, grads = orc.dr_loss_and_grads(Po, b, "e" if k == 0 else "r", masks, dr_e_w=w, model="bert4rec")
+        opts[k].step(Po, grads)
+        want.append(float(info["loss"]))
+
+    def run(use_graph):
+        eng = Bert4recEngine(n_items, 128, T, hid, lr=lr, seed=seed, dr=True, dr_e_w=w)
+        eng.load_state_dict(P)
+        pl = eng.plan(Bn, T, 2, need_grad=True)
+        got = []
+        for t, b in enumerate(batches):
+            k = t % 2
+            eng.select_optimizer(k, lr=lr * (1.0 if k == 0 else 0.5))
+            eng.dr_mode = k
+            cu = {kk: v.cuda() for kk, v in b.items()}
+            eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"], cu["ob_label"])
+            if use_graph:
+                if not eng.has_graph(pl):
+                    eng.capture_train_step(pl)
+                eng.replay_train_step(pl)
+            else:
+                eng.enqueue_train_step(pl)
+            eng.sync()
+            ls = pl.dr_losses.cpu()
+            got.append(float(ls[0] + w * ls[1]) if k == 0 else float(ls[2]))
+        eng.flush_table(); eng.sync()
+        return got, {kk: v.cpu().clone() for kk, v in eng.state_dict().items()}
+
+    g0, s0 = run(False)
+    g1, s1 = run(True)
+    assert g0 == g1 and all(torch.equal(s0[k], s1[k]) for k in s0)
+    for a, b_ in zip(g0, want):
+        assert abs(a - b_) < 5e-5 * max(1.0, abs(b_)), (g0, want)
+    for k, v in Po.items():
+        d = (s0[k] - v).abs()
+        if k.endswith("linear_layers.1.bias"):
+            continue
+        # Adam's first steps move every weight by ~lr * sign(g): where the true gradient is ~0 (rows with ob_label 0 give the
+        # encoders no gradient under loss_dr_r) rounding noise picks the sign, so a few elements may sit one step apart
+        assert float((d > 3e-4).float().mean()) < 2e-3 and float(d.max()) < 2.5e-3, (k, float(d.max()), float((d > 3e-4).float().mean()))

@@ -379,6 +379,24 @@ def test_train_sr_dr_cli_end_to_end(tmp_path):
     assert "train loss_dr_r" in log and "dr_e loss" in log
 
 
+def test_train_sr_dr_cli_bert4rec(tmp_path):
+    """train_sr_dr.py with --model bert4rec: the doubly-robust heads on the BERT4Rec encoders (model_seq.py:268-271)."""
+    from amid_amd.train_sr_dr import main
+    rng = np.random.default_rng(3)
+    root = tmp_path / "mybank_dataset"
+    root.mkdir()
+    _write_csv(root / "toy_train25.csv", 160, rng, 1, 400, 400, 900)
+    _write_csv(root / "toy_train25_DR.csv", 128, rng, 1, 400, 400, 900, ob_label=True)
+    _write_csv(root / "toy_test.csv", 64, rng, 1, 400, 400, 900)
+    summary = main(["--data_root", str(tmp_path), "-ds", "mybank", "-dm", "toy", "--overlap_ratio", "0.25", "--model", "bert4rec", "--overlap", "True",
+                    "--neg_nums", "19", "--lr2", "0.01", "--dr_e_w", "0.01", "--bs", "32", "--seq_len", "20", "--emb_dim", "128",
+                    "--hid_dim", "16", "--epoch", "2", "--seeds", "1", "-md", str(tmp_path / "model")])
+    best = summary[0]
+    assert ("d1", "HR@10") in best and all((0.0 <= v <= 1.0) or np.isnan(v) for v in best.values())
+    log = (tmp_path / "model" / "log0.txt").read_text()
+    assert "train loss_dr_r" in log and "dr_e loss" in log
+
+
 def test_sasrec_dr_module_reference_loop():
     """SASRec(isDR=True) through the reference's own loop shape: six outputs, loss from train_sr_dr.py:216-221 written with torch
     ops, loss.backward(), torch.optim.Adam -- one step must match the oracle's dense Adam."""

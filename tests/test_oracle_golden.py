@@ -46,8 +46,8 @@ def test_g3_sasrec_eval(name):
     assert rel_err(p1, z["p1"]) < 1e-6 and rel_err(p2, z["p2"]) < 1e-6
 
 
-def bert_params(z):
-    P = orc.random_params(orc.bert4rec_param_shapes(int(z["n_items"]), int(z["hid"])), seed=int(z["param_seed"]))
+def bert_params(z, dr=False):
+    P = orc.random_params(orc.bert4rec_param_shapes(int(z["n_items"]), int(z["hid"]), dr=dr), seed=int(z["param_seed"]))
     s = sum(float(v.double().sum()) for v in P.values())
     assert abs(s - float(z["param_sum"])) < 1e-9 * max(1.0, abs(s)), "random_params drifted from the fixture generator"
     return P
@@ -179,6 +179,29 @@ def test_g10_sasrec_itc_grads():
     assert np.array_equal(taps["itc_d2"]["gate"].numpy().astype(bool), z["gate"])          # max over all (a, c) pairs is symmetric
     assert set(G) == set(orc.sasrec_param_shapes(P["item_emb_layer.emb_item.weight"].shape[0], 64, 20, 16, itc_bs=6))
     check_grads("sasrec", z, P, B, G, None, isItC=True, threshold2=float(z["threshold2"]))
+
+
+def test_g13_bert4rec_dr_outputs_losses_grads():
+    """BERT4Rec(isDR=True): six outputs, the three losses and the gradients of both objectives against the reference."""
+    z, _, B, *_ = load("g13_bert4rec_dr.npz")
+    P = bert_params(z, dr=True)
+    batch = dict(B)
+    batch["label"] = torch.from_numpy(z["labels"])
+    batch["ob_label"] = torch.from_numpy(z["ob_label"])
+    for which, pre in (("e", "GE/"), ("r", "GR/")):
+        info, outs, grads = orc.dr_loss_and_grads(P, batch, which, dr_e_w=float(z["dr_e_w"]), model="bert4rec")
+        for o, name in zip(outs, ("p1", "p2", "ips1", "ips2", "g1", "g2")):
+            assert rel_err(o, z[name]) < 1e-6, name
+        close = lambda a, b: abs(float(a) - float(b)) < 2e-6 * max(1.0, abs(float(b)))      # noqa: E731
+        assert close(info["loss_cls"], z["loss_cls"]) and close(info["loss_dr_e"], z["loss_dr_e"])
+        if which == "r":
+            assert close(info["loss"], z["loss_dr_r"])
+        G = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+        assert len(G) > 20 and set(G) <= set(P)
+        for k, g in G.items():
+            if k.endswith("linear_layers.1.bias"):      # the key bias: analytically zero (softmax shift invariance), rounding noise only
+                continue
+            assert rel_err(grads[k], g) < 5e-5 or float((grads[k] - g).abs().max()) < 1e-8, (which, k)
 
 
 def test_g12_sasrec_inc_grads():
