@@ -41,6 +41,11 @@ CFG5_ROWS = 10_000_000
 WORKLOADS = {
     "cfg2": dict(B=256, n_rows=N_ROWS, pad_id=PAD_ID, max_id=MAX_REAL_ID, kind="real",
                  label="cloth_sport_train75-shaped SASRec train step (BASELINE.json configs[1])"),
+    # BASELINE.json configs[2] / [3], shaped after the data statistics of SURVEY.md section 8(d); side measurements like cfg5
+    "cfg3": dict(B=512, n_rows=N_ROWS, pad_id=PAD_ID, max_id=89987, kind="real", mean_len=8.0,
+                 label="phone_elec_train25-shaped SASRec train step, batch 512 (BASELINE.json configs[2]; quoted with --dtype bf16)"),
+    "cfg4": dict(B=256, T=20, n_rows=N_ROWS, pad_id=PAD_ID, max_id=123132, kind="real", mean_len=2.2,
+                 label="mybank loan_fund + loan_account shaped SASRec train step, seq_len 20, batch 256 per GPU (BASELINE.json configs[3])"),
     "cfg5-uniform": dict(B=4096, n_rows=CFG5_ROWS + 2, pad_id=CFG5_ROWS + 1, max_id=CFG5_ROWS - 1, kind="uniform",
                          label="synthetic S-uniform (BASELINE.json configs[4]): every position a uniform id in [0, 10M), no pads"),
     "cfg5-real": dict(B=4096, n_rows=CFG5_ROWS + 2, pad_id=CFG5_ROWS + 1, max_id=CFG5_ROWS - 1, kind="zipf",
@@ -52,6 +57,7 @@ def synth_batch(gen, device, wl=None):
     """One batch shaped like collate_fn_enhance's output after train_sr.py:191-200."""
     wl = wl or WORKLOADS["cfg2"]
     Bw, pad, hi, kind = wl["B"], wl["pad_id"], wl["max_id"], wl["kind"]
+    T, mean_len = wl.get("T", globals()["T"]), wl.get("mean_len", 4.5)
 
     def ids(shape):
         if kind == "zipf":            # Zipf(1.05) ranks folded into [1, hi]: a few hot rows, a long cold tail
@@ -66,8 +72,8 @@ def synth_batch(gen, device, wl=None):
     if kind == "uniform":
         seqs = [ids((Bw, T)), ids((Bw, T))]
     else:
-        lens1 = torch.clamp(torch.poisson(torch.full((Bw,), 4.5), generator=gen).long() + 1, max=T)
-        lens2 = torch.clamp(torch.poisson(torch.full((Bw,), 4.5), generator=gen).long(), max=T)      # other domain may be empty
+        lens1 = torch.clamp(torch.poisson(torch.full((Bw,), mean_len), generator=gen).long() + 1, max=T)
+        lens2 = torch.clamp(torch.poisson(torch.full((Bw,), mean_len), generator=gen).long(), max=T)      # other domain may be empty
         col = torch.arange(T).unsqueeze(0)
         seqs = []
         for lens in (lens1, lens2):
@@ -107,7 +113,7 @@ def init_params(eng, seed):
     torch.cuda.synchronize()
 
 
-def algorithmic_work(Bw=B, n_uniq=None):
+def algorithmic_work(Bw=B, n_uniq=None, T=T):
     """Per launch, at this workload (formulas: DESIGN.md section 5 / SURVEY.md section 8(d))."""
     M2 = 2 * Bw * T
     n_idx = M2 + Bw * (1 + NEG)
@@ -242,6 +248,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     Bw = wl["B"]
+    T = wl.get("T", globals()["T"])
     if args.model == "bert4rec":
         from amid_amd.engine_bert import Bert4recEngine
         eng = Bert4recEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234)
@@ -250,7 +257,7 @@ def main():
     init_params(eng, seed=0)                  # identical replicas on every rank
     pl = eng.plan(Bw, T, 1 + NEG, need_grad=True)
     gen = torch.Generator().manual_seed(1000 + rank)          # each rank draws its own shard of the global batch
-    n_pool = 60 if args.workload == "cfg2" else 16     # cfg2: one epoch of cloth_sport_train75 at batch 256
+    n_pool = 60 if args.workload in ("cfg2", "cfg3", "cfg4") else 16     # cfg2: one epoch of cloth_sport_train75 at batch 256
     pool, uniq_counts = [], []
     for _ in range(n_pool):                   # batches are packed in the engine's input layout: one device copy per step
         b = synth_batch(gen, device, wl)
@@ -333,7 +340,7 @@ def main():
             eng.sync()
         durs = L.timer.collect(L)
         L.timer = None
-        work = algorithmic_work(Bw, int(pl.n_uniq.item()))
+        work = algorithmic_work(Bw, int(pl.n_uniq.item()), T)
         total_ms = 0.0
         for name, v in durs.items():
             per_step = sum(v) / n_prof
