@@ -437,7 +437,7 @@ static int make_geom_b(int M, int rows_per_tile, TileGeomB* tg) {
         KERNEL<DVAL, BFVAL><<<2 * ARGS.tg.tiles_per_group, GEMM_THREADS, fused_lds_bytes_b<DVAL>(), (hipStream_t)stream>>>(ARGS); \
     } while (0)
 
-extern "C" int amid_sas_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+extern "C" int AMID_ENTRY(amid_sas_ffn_bwd_f32)(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
                                     const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
                                     int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2,
                                     float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, void* stream) {
@@ -458,7 +458,7 @@ extern "C" int amid_sas_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, 
     return AMID_OK;
 }
 
-extern "C" int amid_sas_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+extern "C" int AMID_ENTRY(amid_sas_qkv_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
                                     const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
                                     float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && dx && ln_part);
@@ -475,7 +475,7 @@ extern "C" int amid_sas_qkv_bwd_f32(const float* dq, const float* dk, const floa
 }
 
 // amid_sas_qkv_bwd_f32 of layer l + 1 followed by amid_sas_ffn_bwd_f32 of layer l (f* arguments; its dxo is the dx just produced)
-extern "C" int amid_sas_qkv_ffn_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+extern "C" int AMID_ENTRY(amid_sas_qkv_ffn_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
                                         const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
                                         float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part,
                                         const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
@@ -505,6 +505,7 @@ extern "C" int amid_sas_qkv_ffn_bwd_f32(const float* dq, const float* dk, const 
     return AMID_OK;
 }
 
+#if AMID_TILE_RT == 7      // everything below is independent of the row-tile height: one copy only
 extern "C" int amid_sas_wgrad_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits,
                                   float* const* w_part, float* const* b_part, void* stream) {
     AMID_CHECK_ARG(dy && x && w_part && b_part && (n_layers == 1 || n_layers == 2) && M > 0 && splits > 0);
@@ -555,3 +556,4 @@ extern "C" int amid_reduce_partials_f32(const void* entries_dev, int n_entries, 
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
+#endif

@@ -384,6 +384,7 @@ static int make_geom(int M, int rows_per_tile, TileGeom* tg) {
     return AMID_OK;
 }
 
+#if AMID_TILE_RT == 7
 // Rows per tile for a launch over 2*M rows: spread the rows evenly over a whole number of rounds of the
 // 256 CUs (one 512-thread workgroup per CU), at most TILE_ROWS rows per tile.
 extern "C" int amid_rows_per_tile(int M) {
@@ -398,6 +399,8 @@ extern "C" int amid_rows_per_tile(int M) {
     }
 }
 
+#endif
+
 #define AMID_LAUNCH_FUSED(KERNEL, ARGS, DVAL, BFVAL)                                                                        \
     do {                                                                                                                   \
         static bool attr_set = false;                                                                                      \
@@ -410,7 +413,7 @@ extern "C" int amid_rows_per_tile(int M) {
         KERNEL<DVAL, BFVAL><<<2 * ARGS.tg.tiles_per_group, GEMM_THREADS, fused_lds_bytes<DVAL>(), (hipStream_t)stream>>>(ARGS); \
     } while (0)
 
-extern "C" int amid_sas_qkv_fwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
+extern "C" int AMID_ENTRY(amid_sas_qkv_fwd_f32)(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
                                     const float* const* b_in, float ln_eps, int M, int D, int rows_per_tile, float* qn, float* q, float* k,
                                     float* v, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(x && ln_w && ln_b && w_in && b_in && qn && q && k && v);
@@ -426,7 +429,7 @@ extern "C" int amid_sas_qkv_fwd_f32(const float* x, const float* const* ln_w, co
     return AMID_OK;
 }
 
-extern "C" int amid_sas_oproj_fwd_f32(const float* o, const float* const* w_o, const float* const* b_o, const float* qn,
+extern "C" int AMID_ENTRY(amid_sas_oproj_fwd_f32)(const float* o, const float* const* w_o, const float* const* b_o, const float* qn,
                                       const float* const* ln_w, const float* const* ln_b, float ln_eps, int M, int D, int rows_per_tile,
                                       float* r, float* y, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(o && w_o && b_o && qn && ln_w && ln_b && r && y);
@@ -442,7 +445,7 @@ extern "C" int amid_sas_oproj_fwd_f32(const float* o, const float* const* w_o, c
     return AMID_OK;
 }
 
-extern "C" int amid_sas_ffn_fwd_f32(const float* y, const float* const* w1, const float* const* b1, const float* const* w2,
+extern "C" int AMID_ENTRY(amid_sas_ffn_fwd_f32)(const float* y, const float* const* w1, const float* const* b1, const float* const* w2,
                                     const float* const* b2, const unsigned char* tmq, int M, int D, int rows_per_tile, int layer,
                                     const void* step_state, int train, float p_drop, float* h, float* xo, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(y && w1 && b1 && w2 && b2 && h && xo && (!train || step_state));
@@ -461,7 +464,7 @@ extern "C" int amid_sas_ffn_fwd_f32(const float* y, const float* const* w1, cons
     return AMID_OK;
 }
 
-extern "C" int amid_sas_oproj_ffn_fwd_f32(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
+extern "C" int AMID_ENTRY(amid_sas_oproj_ffn_fwd_f32)(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
                                           const float* const* ln_w, const float* const* ln_b, const float* const* w1, const float* const* b1,
                                           const float* const* w2, const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D,
                                           int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* r, float* y,
@@ -486,7 +489,7 @@ extern "C" int amid_sas_oproj_ffn_fwd_f32(const float* o, const float* qn, const
     return AMID_OK;
 }
 
-extern "C" int amid_sas_oproj_ffn_qkv_fwd_f32(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
+extern "C" int AMID_ENTRY(amid_sas_oproj_ffn_qkv_fwd_f32)(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
                                               const float* const* ln_w, const float* const* ln_b, const float* const* w1, const float* const* b1,
                                               const float* const* w2, const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D,
                                               int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* r, float* y,

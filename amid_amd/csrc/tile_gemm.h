@@ -29,15 +29,28 @@
 
 namespace amid {
 
-constexpr int TILE_ROWS = 112;
-constexpr int TILE_RT = TILE_ROWS / 16;   // 7
+// The row-tile height is a build parameter: sasrec_fwd.hip / sasrec_bwd.hip are compiled twice, with 7 MFMA row tiles (112 rows,
+// the headline shape's 100 rows per CU) and with 3 (48 rows: every accumulator tile is always computed, so at seq_len 20 -- the
+// mybank shape, 40 rows per CU -- the 112-row build spends 64 % of its matrix work on zero rows).  The second build lives in
+// namespace amid_rt3 and exports the same entry points with the suffix _rt3 (csrc/Makefile); the host picks by rows_per_tile.
+#ifndef AMID_TILE_RT
+#define AMID_TILE_RT 7
+#endif
+#ifndef AMID_ENTRY_SUFFIX
+#define AMID_ENTRY_SUFFIX
+#endif
+#define AMID_CAT2(a, b) a##b
+#define AMID_CAT(a, b) AMID_CAT2(a, b)
+#define AMID_ENTRY(name) AMID_CAT(name, AMID_ENTRY_SUFFIX)
+constexpr int TILE_RT = AMID_TILE_RT;
+constexpr int TILE_ROWS = 16 * TILE_RT;   // 112 (or 48)
 constexpr int GEMM_THREADS = 512;
 
 template <int K> struct TileCfg {
     static constexpr int LDK = K + 8;                 // A / W image row stride (floats)
     // rows of the A image: every accumulator tile of every wave is computed unconditionally (no per-tile branch in
-    // the MFMA loop), so the image covers 16 * ACC * WR rows: 112 at D = 128, 128 at D = 64 (rows past the tile are zero)
-    static constexpr int ROWS = (K >= 128) ? TILE_ROWS : 128;
+    // the MFMA loop), so the image covers 16 * ACC * WR rows: 112 at D = 128, 128 at D = 64 (48 / 64 in the _rt3 build; rows past the tile are zero)
+    static constexpr int ROWS = (K >= 128) ? TILE_ROWS : 32 * ((TILE_RT + 1) / 2);
     static constexpr int A_FLOATS = ROWS * LDK;
     // second region: the W slab [K rows][LDK], reused as the C image [ROWS][K + 4]
     static constexpr int W_FLOATS = (K * LDK > ROWS * (K + 4)) ? K * LDK : ROWS * (K + 4);

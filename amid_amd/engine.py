@@ -148,6 +148,8 @@ class SasrecPlan:
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
         self.rpt = L.value("amid_rows_per_tile", M)
         self.tpg = (M + self.rpt - 1) // self.rpt
+        # short tiles (seq_len 20 at batch 256: 40 rows per CU) run the 48-row build of the row-tile kernels (csrc/tile_gemm.h)
+        self.rt_suffix = "_rt3" if (self.rpt <= 48 and D == 128 and type(eng).__name__ == "SasrecEngine") else ""
         # static inputs (graph-replay safe): ONE int64 buffer so a batch arrives with a single copy
         #   [i_node B | neg B*(NI-1) | seq_d1 B*T | seq_d2 B*T | domain B | labels B*NI fp32 (packed two per word)]
         n_lab_words = (B * NI + 1) // 2
@@ -630,18 +632,18 @@ class SasrecEngine:
 
         qkv0, rest0 = layer_ptrs(0)
         qkv1, rest1 = layer_ptrs(1)
-        L.call("amid_sas_qkv_fwd_f32", pl.x[0].data_ptr(), *qkv0, SASREC_LN_EPS, M, D, pl.rpt, pl.qn[0].data_ptr(), pl.q[0].data_ptr(),
+        L.call("amid_sas_qkv_fwd_f32" + pl.rt_suffix, pl.x[0].data_ptr(), *qkv0, SASREC_LN_EPS, M, D, pl.rpt, pl.qn[0].data_ptr(), pl.q[0].data_ptr(),
                pl.k[0].data_ptr(), pl.v[0].data_ptr(), self.mma_bf16, s)
         for l in (0, 1):
             L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), None, B, T, D, self.H, 1, l, st, tr,
                    SASREC_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
             rest = rest0 if l == 0 else rest1
             if l == 0:      # layer 0's out-projection + feed-forward and layer 1's LayerNorm + q / k / v: one launch
-                L.call("amid_sas_oproj_ffn_qkv_fwd_f32", pl.o[0].data_ptr(), pl.qn[0].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
+                L.call("amid_sas_oproj_ffn_qkv_fwd_f32" + pl.rt_suffix, pl.o[0].data_ptr(), pl.qn[0].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
                        pl.rpt, 0, st, tr, SASREC_P_DROP, pl.r[0].data_ptr(), pl.y[0].data_ptr(), pl.h[0].data_ptr(), pl.x[1].data_ptr(),
                        *qkv1, pl.qn[1].data_ptr(), pl.q[1].data_ptr(), pl.k[1].data_ptr(), pl.v[1].data_ptr(), self.mma_bf16, s)
             else:
-                L.call("amid_sas_oproj_ffn_fwd_f32", pl.o[l].data_ptr(), pl.qn[l].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
+                L.call("amid_sas_oproj_ffn_fwd_f32" + pl.rt_suffix, pl.o[l].data_ptr(), pl.qn[l].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
                        pl.rpt, l, st, tr, SASREC_P_DROP, pl.r[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(),
                        self.mma_bf16, s)
         items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
@@ -808,19 +810,19 @@ class SasrecEngine:
                    pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), s)
 
         tm, h1, r1, lnw1, w1T1, w2T1, woT1 = ffn_bwd_args(1)
-        L.call("amid_sas_ffn_bwd_f32", pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, M, D, pl.rpt, 1, st, tr,
+        L.call("amid_sas_ffn_bwd_f32" + pl.rt_suffix, pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, M, D, pl.rpt, 1, st, tr,
                SASREC_P_DROP, pl.dpre2[1].data_ptr(), pl.dpre1[1].data_ptr(), pl.dr[1].data_ptr(), pl.d_o.data_ptr(),
                pl.ln2_part[1].data_ptr(), self.mma_bf16, s)
         attn_bwd(1)
         # layer 1's q / k / v + LayerNorm1 backward and layer 0's feed-forward / out-projection backward: one launch
         tm, h0, r0, lnw0, w1T0, w2T0, woT0 = ffn_bwd_args(0)
-        L.call("amid_sas_qkv_ffn_bwd_f32", pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
+        L.call("amid_sas_qkv_ffn_bwd_f32" + pl.rt_suffix, pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
                pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
                SASREC_LN_EPS, M, D, pl.rpt, pl.dxbuf.data_ptr(), pl.ln1_part[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr,
                SASREC_P_DROP, pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(),
                pl.ln2_part[0].data_ptr(), self.mma_bf16, s)
         attn_bwd(0)
-        L.call("amid_sas_qkv_bwd_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
+        L.call("amid_sas_qkv_bwd_f32" + pl.rt_suffix, pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
                pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
                SASREC_LN_EPS, M, D, pl.rpt, (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.ln1_part[0].data_ptr(), self.mma_bf16, s)
         dy, xx = [], []

@@ -1,7 +1,7 @@
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/tr
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tr -o t -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline > $R/gpurun_out/tr/out.json 2> $R/gpurun_out/tr/err.log
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tr -o t -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline $BENCH_ARGS > $R/gpurun_out/tr/out.json 2> $R/gpurun_out/tr/err.log
 cd $R
 python3 - <<'PY'
 import csv, os
