@@ -6,7 +6,7 @@ cd $R
 python3 - <<'PY'
 import csv, os
 rows = list(csv.DictReader(open("gpurun_out/tr/t_kernel_trace.csv")))
-rows = [r for r in rows if "amid::" in r["Kernel_Name"] or "copyBuffer" in r["Kernel_Name"]]
+rows = [r for r in rows if "amid" in r["Kernel_Name"] or "copyBuffer" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # find graph-replay steps: sequences starting with pack_indices; take step #30 (well inside the timed region)
 starts = [i for i, r in enumerate(rows) if "pack_indices" in r["Kernel_Name"]]

@@ -8,7 +8,7 @@ cd $R
 python3 - <<'PY'
 import csv
 rows = list(csv.DictReader(open("gpurun_out/tv/t_kernel_trace.csv")))
-rows = [r for r in rows if "amid::" in r["Kernel_Name"] or "copyBuffer" in r["Kernel_Name"]]
+rows = [r for r in rows if "amid" in r["Kernel_Name"] or "copyBuffer" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "pack_indices" in r["Kernel_Name"]]
 i0, i1 = starts[100], starts[101]
