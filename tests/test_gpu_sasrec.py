@@ -697,6 +697,34 @@ def test_edge_shapes_forward_backward_vs_oracle(Bn, T, D, neg):
         grads_check(f"edge B={Bn} T={T} D={D}", eng, pl, grads, tol, 3e-4 if margin > 2e-5 else 1e-2)
 
 
+@pytest.mark.parametrize("D,train", [(128, True), (64, False)])
+def test_headline_shape_forward_backward_vs_oracle(D, train):
+    """BASELINE.json configs[1] itself (B 256, T 50; 100 rows per workgroup: the 112-row build of the row-tile kernels, which the
+    small shapes above no longer reach) forward + backward against the oracle, dropout on; relative L2 on the gradients (at this
+    size some relu pre-activation always sits within rounding of the kink)."""
+    Bn, T, hid, n_items = 256, 50, 32, 3000
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=90 + D)
+    batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=77)
+    seed, step = 21, 4
+    masks = orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=step) if train else None
+    loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, masks)
+    eng = make_engine(P, T, seed=seed)
+    pl = run_forward(eng, batch, train=train, with_loss=True, step=step, seed=seed)
+    assert pl.rt_suffix == "" and pl.rpt == 100
+    eng.enqueue_backward(pl, train=train)
+    eng.sync()
+    assert relmax(pl.p1, p1) < 1e-4 and relmax(pl.p2, p2) < 1e-4
+    assert abs(float(pl.loss.item()) - float(loss)) < 1e-5
+    for name in eng.dense.slots:
+        got, want = eng.dense.view(name, eng.dense.grad), grads[name]
+        if name.endswith("in_proj_bias"):
+            n3 = got.numel() // 3
+            got, want = got.cpu().clone(), want.clone()
+            got[n3:2 * n3] = 0; want[n3:2 * n3] = 0
+        assert rel_l2(got, want) < 2e-3, (name, rel_l2(got, want))
+    assert rel_l2(dense_table_grad(eng, pl), grads["item_emb_layer.emb_item.weight"]) < 2e-3
+
+
 # ---------------------------------------------------------------------------- bf16 matrix products (BASELINE.json configs[2])
 def test_bf16_compute_within_tolerance_of_fp32_oracle():
     """compute="bf16": bf16 MFMA operands, fp32 accumulation / storage / everything else, at the cfg-3 batch (512 x 50 x 128):
