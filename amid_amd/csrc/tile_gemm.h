@@ -29,10 +29,11 @@
 
 namespace amid {
 
-// The row-tile height is a build parameter: sasrec_fwd.hip / sasrec_bwd.hip are compiled twice, with 7 MFMA row tiles (112 rows,
-// the headline shape's 100 rows per CU) and with 3 (48 rows: every accumulator tile is always computed, so at seq_len 20 -- the
-// mybank shape, 40 rows per CU -- the 112-row build spends 64 % of its matrix work on zero rows).  The second build lives in
-// namespace amid_rt3 and exports the same entry points with the suffix _rt3 (csrc/Makefile); the host picks by rows_per_tile.
+// The row-tile height is a build parameter: sasrec_fwd.hip / sasrec_bwd.hip are compiled three times, with 7 MFMA row tiles (112
+// rows, the headline shape's 100 rows per CU), with 5 (80 rows) and with 3 (48 rows: every accumulator tile is always computed, so
+// at seq_len 20 -- the mybank shape, 40 rows per CU -- the 112-row build spends 64 % of its matrix work on zero rows).  The extra
+// builds live in namespaces amid_rt5 / amid_rt3 and export the same entry points with the suffix _rt5 / _rt3 (csrc/Makefile); the
+// host picks by rows_per_tile.
 #ifndef AMID_TILE_RT
 #define AMID_TILE_RT 7
 #endif

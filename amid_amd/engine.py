@@ -148,8 +148,8 @@ class SasrecPlan:
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
         self.rpt = L.value("amid_rows_per_tile", M)
         self.tpg = (M + self.rpt - 1) // self.rpt
-        # short tiles (seq_len 20 at batch 256: 40 rows per CU) run the 48-row build of the row-tile kernels (csrc/tile_gemm.h)
-        self.rt_suffix = "_rt3" if (self.rpt <= 48 and type(eng).__name__ == "SasrecEngine") else ""
+        # short tiles (seq_len 20 at batch 256: 40 rows per CU) run the 48- / 80-row builds of the row-tile kernels (csrc/tile_gemm.h)
+        self.rt_suffix = ("_rt3" if self.rpt <= 48 else "_rt5" if self.rpt <= 80 else "") if type(eng).__name__ == "SasrecEngine" else ""
         # static inputs (graph-replay safe): ONE int64 buffer so a batch arrives with a single copy
         #   [i_node B | neg B*(NI-1) | seq_d1 B*T | seq_d2 B*T | domain B | labels B*NI fp32 (packed two per word)]
         n_lab_words = (B * NI + 1) // 2

@@ -343,7 +343,7 @@ def main():
         work = algorithmic_work(Bw, int(pl.n_uniq.item()), T)
         total_ms = 0.0
         for name, v in durs.items():
-            name = name[:-4] if name.endswith("_rt3") else name        # the 48-row build of the row-tile kernels (short sequences)
+            name = name[:-4] if name.endswith(("_rt3", "_rt5")) else name        # the 48- / 80-row builds of the row-tile kernels
             per_step = sum(v) / n_prof
             total_ms += per_step
             calls = len(v) // n_prof

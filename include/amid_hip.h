@@ -329,9 +329,10 @@ int amid_inc_bwd_f32(const float* dpos_part, int nsplit, const float* xg, const 
                      int D, float* dZ, float* dS, float* rows, float* const* dw_nn, float* const* db_nn, float* const* dw_bs,
                      float* const* db_bs, float* dxg, void* stream);
 
-/* ---- the same row-tile entry points built with 48-row tiles (3 MFMA row tiles per workgroup instead of 7) -----------------
- * Identical signatures and semantics; callers use them when rows_per_tile <= 48 (seq_len 20 at batch 256: the mybank shape of
- * BASELINE.json configs[3]), where the 112-row build would spend most of its matrix work on zero rows (csrc/tile_gemm.h). */
+/* ---- the same row-tile entry points built with shorter tiles (3 or 5 MFMA row tiles per workgroup instead of 7) --------------
+ * Identical signatures and semantics; callers use *_rt3 when rows_per_tile <= 48 (seq_len 20 at batch 256: the mybank shape of
+ * BASELINE.json configs[3]) and *_rt5 when rows_per_tile <= 80, where the 112-row build would spend much of its matrix work on zero
+ * rows (csrc/tile_gemm.h). */
 int amid_sas_qkv_fwd_f32_rt3(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
                          const float* const* b_in, float ln_eps, int M, int D, int rows_per_tile, float* qn, float* q, float* k, float* v,
                          int mma_bf16, void* stream);
@@ -359,6 +360,38 @@ int amid_sas_qkv_bwd_f32_rt3(const float* dq, const float* dk, const float* dv, 
                          const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
                          int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream);
 int amid_sas_qkv_ffn_bwd_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
+                             const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
+                             int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
+                             const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
+                             int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
+                             float* fd_o, float* fln_part, int mma_bf16, void* stream);
+int amid_sas_qkv_fwd_f32_rt5(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
+                         const float* const* b_in, float ln_eps, int M, int D, int rows_per_tile, float* qn, float* q, float* k, float* v,
+                         int mma_bf16, void* stream);
+int amid_sas_oproj_fwd_f32_rt5(const float* o, const float* const* w_o, const float* const* b_o, const float* qn, const float* const* ln_w,
+                           const float* const* ln_b, float ln_eps, int M, int D, int rows_per_tile, float* r, float* y, int mma_bf16, void* stream);
+int amid_sas_ffn_fwd_f32_rt5(const float* y, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
+                         const unsigned char* tmq, int M, int D, int rows_per_tile, int layer, const void* step_state, int train,
+                         float p_drop, float* h, float* xo, int mma_bf16, void* stream);
+int amid_sas_oproj_ffn_fwd_f32_rt5(const float* o, const float* qn, const float* const* w_o, const float* const* b_o, const float* const* ln_w,
+                               const float* const* ln_b, const float* const* w1, const float* const* b1, const float* const* w2,
+                               const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D, int rows_per_tile, int layer,
+                               const void* step_state, int train, float p_drop, float* r, float* y, float* h, float* xo, int mma_bf16,
+                               void* stream);
+int amid_sas_oproj_ffn_qkv_fwd_f32_rt5(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
+                                   const float* const* ln_w, const float* const* ln_b, const float* const* w1, const float* const* b1,
+                                   const float* const* w2, const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D,
+                                   int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* r, float* y, float* h,
+                                   float* xo, const float* const* nln_w, const float* const* nln_b, const float* const* nw_in,
+                                   const float* const* nb_in, float* nqn, float* nq, float* nk, float* nv, int mma_bf16, void* stream);
+int amid_sas_ffn_bwd_f32_rt5(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                         const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
+                         int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
+                         float* dr, float* d_o, float* ln_part /* [tiles][2][D] */, int mma_bf16, void* stream);
+int amid_sas_qkv_bwd_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
+                         const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
+                         int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream);
+int amid_sas_qkv_ffn_bwd_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
                              const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
                              int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
                              const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
