@@ -25,8 +25,9 @@ extern "C" int amid_graph_capture_end(void* stream, void** graph_exec_out) {
     if (e != hipSuccess) return (int)e;
     hipGraphExec_t ex = nullptr;
     e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    const hipError_t e2 = hipGraphDestroy(g);
     if (e != hipSuccess) return (int)e;
+    if (e2 != hipSuccess) return (int)e2;
     *graph_exec_out = (void*)ex;
     return AMID_OK;
 }

@@ -160,7 +160,6 @@ __global__ __launch_bounds__(1024) void itc_mix_fwd_kernel(const MixArgs a) {
     }
     __syncthreads();
     // c_g[o] = W_nn_g[o, :] . z_g + b_nn_g[o] sum_j w_g[j] + b_bs_g : one row per row group and pass
-#pragma unroll 8
     for (int r = rg; r < 2 * D; r += nrg) {
         const int g = r / D, o = r - g * D;
         float t = 0.f;
