@@ -1,4 +1,5 @@
-// K2: multi-head attention core for short sequences (T <= ~150, head dim 8/16/32), forward and backward.
+// K2: multi-head attention core, general form (any T whose per-head K / V fit in LDS: ~900 at head dim 16; head dim 8/16/32),
+// forward and backward.
 // Reference: torch.nn.MultiheadAttention as called at model_seq.py:374 (explicit softmax path: q scaled
 // by sqrt(1/hd) BEFORE q.k^T, additive -inf causal mask, dropout p=.5 on the probabilities) and the
 // hand-written Attention of BERT4Rec (model_seq.py:149-162: scores / sqrt(d_k), masked_fill(mask == 0, -1e9)
@@ -51,8 +52,13 @@ __device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&a
     for (int d = 0; d < HD; d += 4) st4(p + d, make_float4(a[d], a[d + 1], a[d + 2], a[d + 3]));
 }
 
-__device__ __forceinline__ void copy_tile(float* __restrict__ dst, const float* __restrict__ src, int nfloat) {
-    for (int i = threadIdx.x * 4; i < nfloat; i += blockDim.x * 4) st4(dst + i, ld4(src + i));
+// rows x `cols` window of a [rows, ld] global tile -> dense [rows][cols] LDS image (cols = the columns of the workgroup's heads)
+__device__ __forceinline__ void copy_cols(float* __restrict__ dst, const float* __restrict__ src, int rows, int cols, int ld) {
+    const int q = cols >> 2;
+    for (int i = threadIdx.x; i < rows * q; i += blockDim.x) {
+        const int r = i / q, c = i - r * q;
+        st4(dst + r * cols + 4 * c, ld4(src + (long long)r * ld + 4 * c));
+    }
 }
 
 // score of (query i, key j) exactly as the forward computes it
@@ -68,14 +74,17 @@ template <int HD>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, D = a.D;
+    // blockIdx.y = head group: the workgroup's waves take heads hg * HL .. + HL - 1 and only their columns of K / V live in LDS
+    // (long sequences: all eight heads' K and V no longer fit at T > ~150, see attn_head_groups)
+    const int HL = blockDim.x >> 6, DL = HL * HD, hl = wave_id(), lane = lane_id();
+    const int h = blockIdx.y * HL + hl;
     float* Ks = smem;
-    float* Vs = smem + T * D;
+    float* Vs = smem + T * DL;
     const int seq = blockIdx.x, g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
-    copy_tile(Ks, a.k + rowbase * D, T * D);
-    copy_tile(Vs, a.v + rowbase * D, T * D);
+    copy_cols(Ks, a.k + rowbase * D + blockIdx.y * DL, T, DL, D);
+    copy_cols(Vs, a.v + rowbase * D + blockIdx.y * DL, T, DL, D);
     __syncthreads();
-    const int h = wave_id(), lane = lane_id();
     const int dbits = spec_bits(a.thr16), per = 128 / dbits;       // decisions per Philox call
     const unsigned dthr = spec_thr(a.thr16);
     const int calls_per_row = (T + per - 1) / per;
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs a) {
         }
         const int jmax = a.causal ? min(T, qb * 64 + 64) : T;
         float m = -INFINITY;
-        for (int j = 0; j < jmax; ++j) m = fmaxf(m, score<HD>(a, qs, Ks + j * D + h * HD, ic, j, kk ? kk[j] != 0 : true));
+        for (int j = 0; j < jmax; ++j) m = fmaxf(m, score<HD>(a, qs, Ks + j * DL + hl * HD, ic, j, kk ? kk[j] != 0 : true));
         float l = 0.f;
         float acc[HD];
 #pragma unroll
@@ -108,11 +117,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs a) {
             for (int jj = 0; jj < 8; ++jj) {
                 const int j = j0 + jj;
                 if (j < jmax) {
-                    const float s = score<HD>(a, qs, Ks + j * D + h * HD, ic, j, kk ? kk[j] != 0 : true);
+                    const float s = score<HD>(a, qs, Ks + j * DL + hl * HD, ic, j, kk ? kk[j] != 0 : true);
                     const float p = expf(s - m);
                     l += p;
                     const float pd = (!a.train || rng_field(r, j % per, dbits) >= dthr) ? p * a.dscale : 0.f;
-                    const float* vr = Vs + j * D + h * HD;
+                    const float* vr = Vs + j * DL + hl * HD;
 #pragma unroll
                     for (int d = 0; d < HD; d += 4) {
                         const float4 t = ld4(vr + d);
@@ -140,13 +149,15 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, D = a.D, H = a.H;
     const int TW = (T + 63) >> 6;                              // 64-bit keep words per query row
-    float* S0 = smem;                                          // K, then Q
-    float* S1 = smem + T * D;                                  // V, then dO
-    float* rstat = smem + 2 * T * D;                           // [H][T][3]  m, 1/l, delta
-    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(rstat + H * T * 3 + ((H * T * 3) & 1));   // [H][T][TW]
+    const int HL = blockDim.x >> 6, DL = HL * HD, hl = wave_id(), lane = lane_id();      // head group blockIdx.y, as in the forward
+    const int h = blockIdx.y * HL + hl;
+    const int col0 = blockIdx.y * DL;
+    float* S0 = smem;                                          // K, then Q        [T][DL]
+    float* S1 = smem + T * DL;                                 // V, then dO
+    float* rstat = smem + 2 * T * DL;                          // [HL][T][3]  m, 1/l, delta
+    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(rstat + HL * T * 3 + ((2 * T * DL + HL * T * 3) & 1));   // [HL][T][TW]
     const int seq = blockIdx.x, g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
-    const int h = wave_id(), lane = lane_id();
     const int dbits = spec_bits(a.thr16), per = 128 / dbits;
     const unsigned dthr = spec_thr(a.thr16);
     const int calls_per_row = (T + per - 1) / per;
@@ -156,8 +167,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
     const unsigned char* kk = a.key_keep ? a.key_keep + (long long)b * T : nullptr;
 
     // ---- phase 1: lanes = queries -> dQ; leaves row stats and dropout keep words in LDS --------
-    copy_tile(S0, a.k + rowbase * D, T * D);
-    copy_tile(S1, a.v + rowbase * D, T * D);
+    copy_cols(S0, a.k + rowbase * D + col0, T, DL, D);
+    copy_cols(S1, a.v + rowbase * D + col0, T, DL, D);
     __syncthreads();
     for (int qb = 0; qb * 64 < T; ++qb) {
         const int i = qb * 64 + lane;
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
         for (int d = 0; d < HD; ++d) acc[d] = 0.f;
         const float* sp = a.stats + ((rowbase + ic) * H + h) * 2;
         const float m = sp[0], rl = sp[1];
-        if (valid) { float* rs = rstat + (h * T + i) * 3; rs[0] = m; rs[1] = rl; rs[2] = delta; }
+        if (valid) { float* rs = rstat + (hl * T + i) * 3; rs[0] = m; rs[1] = rl; rs[2] = delta; }
         const int jmax = a.causal ? min(T, qb * 64 + 64) : T;
         const unsigned long long rowcall = ((unsigned long long)(b * H + h) * T + ic) * calls_per_row;
         unsigned long long kw = 0;
@@ -196,13 +207,13 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
                 if (keep) kw |= 1ull << (j & 63);
                 if (j < jmax) {
                     const bool key_ok = kk ? kk[j] != 0 : true;
-                    const float s = score<HD>(a, qs, S0 + j * D + h * HD, ic, j, key_ok);
+                    const float s = score<HD>(a, qs, S0 + j * DL + hl * HD, ic, j, key_ok);
                     const float p = expf(s - m) * rl;
-                    const float dpd = dot_lds<HD>(dO, S1 + j * D + h * HD);
+                    const float dpd = dot_lds<HD>(dO, S1 + j * DL + hl * HD);
                     const float dp = keep ? dpd * a.dscale : 0.f;
                     // masked_fill cuts the gradient of a masked score (it matters when EVERY key of a row is masked: p = 1/T there)
                     const float ds = key_ok ? p * (dp - delta) : 0.f;
-                    const float* kr = S0 + j * D + h * HD;
+                    const float* kr = S0 + j * DL + hl * HD;
 #pragma unroll
                     for (int d = 0; d < HD; d += 4) {
                         const float4 t = ld4(kr + d);
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
                     }
                 }
             }
-            if (valid && ((j0 & 63) == 56 || j0 + 8 >= jmax)) keepw[(h * T + i) * TW + (j0 >> 6)] = kw;
+            if (valid && ((j0 & 63) == 56 || j0 + 8 >= jmax)) keepw[(hl * T + i) * TW + (j0 >> 6)] = kw;
         }
         if (valid) {
             const float sc = a.causal ? a.scale : 1.0f / a.scale;
@@ -222,8 +233,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
     }
     __syncthreads();
     // ---- phase 2: lanes = keys -> dK, dV -------------------------------------------------------
-    copy_tile(S0, a.q + rowbase * D, T * D);
-    copy_tile(S1, a.d_o + rowbase * D, T * D);
+    copy_cols(S0, a.q + rowbase * D + col0, T, DL, D);
+    copy_cols(S1, a.d_o + rowbase * D + col0, T, DL, D);
     __syncthreads();
     for (int kb = 0; kb * 64 < T; ++kb) {
         const int j = kb * 64 + lane;
@@ -237,9 +248,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
         const bool key_ok = kk ? kk[jc] != 0 : true;
         const int i0 = a.causal ? kb * 64 : 0;
         for (int i = i0; i < T; ++i) {
-            const float* qr = S0 + i * D + h * HD;
-            const float* dor = S1 + i * D + h * HD;
-            const float* rs = rstat + (h * T + i) * 3;
+            const float* qr = S0 + i * DL + hl * HD;
+            const float* dor = S1 + i * DL + hl * HD;
+            const float* rs = rstat + (hl * T + i) * 3;
             float qs[HD];
 #pragma unroll
             for (int d = 0; d < HD; d += 4) { const float4 t = ld4(qr + d); qs[d] = t.x; qs[d + 1] = t.y; qs[d + 2] = t.z; qs[d + 3] = t.w; }
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnArgs a) {
             else { s = s / a.scale; if (!key_ok) s = -1e9f; }
             const float p = expf(s - rs[0]) * rs[1];
             const float dpd = dot_lds<HD>(vv, dor);
-            const bool keep = (keepw[(h * T + i) * TW + (jc >> 6)] >> (jc & 63)) & 1ull;
+            const bool keep = (keepw[(hl * T + i) * TW + (jc >> 6)] >> (jc & 63)) & 1ull;
             const float pd = keep ? p * a.dscale : 0.f;
             const float dp = keep ? dpd * a.dscale : 0.f;
             const float ds = key_ok ? p * (dp - rs[2]) : 0.f;
@@ -288,20 +299,29 @@ int amid_attn_bert_fwd_launch(const void* args, void* stream);
 int amid_attn_bert_bwd_launch(const void* args, void* stream);
 static bool bert_shape(const AttnArgs& a) { return !a.causal && a.D / a.H == 32 && a.T <= 64 && a.H <= 8; }
 
-static size_t attn_fwd_lds(int T, int D) { return (size_t)2 * T * D * sizeof(float); }
-static size_t attn_bwd_lds(int T, int D, int H) {
-    size_t f = (size_t)2 * T * D + (size_t)H * T * 3;
+// LDS of one workgroup that serves H / hg heads (their D / hg columns of K / V, then of Q / dO)
+static size_t attn_fwd_lds(int T, int D, int hg) { return (size_t)2 * T * (D / hg) * sizeof(float); }
+static size_t attn_bwd_lds(int T, int D, int H, int hg) {
+    size_t f = (size_t)2 * T * (D / hg) + (size_t)(H / hg) * T * 3;
     f += f & 1;
-    return f * sizeof(float) + (size_t)H * T * ((T + 63) / 64) * 8;
+    return f * sizeof(float) + (size_t)(H / hg) * T * ((T + 63) / 64) * 8;
+}
+// smallest number of head groups (workgroups per sequence) whose LDS image fits: 1 up to T ~ 118 (backward) at D = 128, 2 up to
+// ~240, ...; 0 = does not fit even with one head per workgroup
+template <typename F>
+static int attn_head_groups(int H, F lds_of) {
+    for (int hg = 1; hg <= H; hg <<= 1)
+        if (H % hg == 0 && lds_of(hg) <= (size_t)160 * 1024) return hg;
+    return 0;
 }
 
 template <typename KernelT>
-static int attn_launch(KernelT kern, const AttnArgs& a, size_t lds, void* stream) {
+static int attn_launch(KernelT kern, const AttnArgs& a, size_t lds, int hg, void* stream) {
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    kern<<<2 * a.B, a.H * 64, lds, (hipStream_t)stream>>>(a);
+    kern<<<dim3(2 * a.B, hg), (a.H / hg) * 64, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
@@ -330,12 +350,13 @@ extern "C" int amid_attn_fwd_f32(const float* q, const float* k, const float* v,
     a.o = o; a.stats = stats;
     if (mfma_shape(a)) return amid_attn_mfma_fwd_launch(&a, stream);
     if (bert_shape(a)) return amid_attn_bert_fwd_launch(&a, stream);
-    const size_t lds = attn_fwd_lds(T, D);
-    if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
+    const int hg = attn_head_groups(H, [&](int g_) { return attn_fwd_lds(T, D, g_); });
+    if (hg == 0) return AMID_ERR_UNSUPPORTED;
+    const size_t lds = attn_fwd_lds(T, D, hg);
     switch (D / H) {
-        case 8: return attn_launch(attn_fwd_kernel<8>, a, lds, stream);
-        case 16: return attn_launch(attn_fwd_kernel<16>, a, lds, stream);
-        case 32: return attn_launch(attn_fwd_kernel<32>, a, lds, stream);
+        case 8: return attn_launch(attn_fwd_kernel<8>, a, lds, hg, stream);
+        case 16: return attn_launch(attn_fwd_kernel<16>, a, lds, hg, stream);
+        case 32: return attn_launch(attn_fwd_kernel<32>, a, lds, hg, stream);
         default: return AMID_ERR_UNSUPPORTED;
     }
 }
@@ -349,12 +370,13 @@ extern "C" int amid_attn_bwd_f32(const float* q, const float* k, const float* v,
     a.o = const_cast<float*>(o); a.stats = const_cast<float*>(stats); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
     if (mfma_shape(a)) return amid_attn_mfma_bwd_launch(&a, stream);
     if (bert_shape(a)) return amid_attn_bert_bwd_launch(&a, stream);
-    const size_t lds = attn_bwd_lds(T, D, H);
-    if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
+    const int hg = attn_head_groups(H, [&](int g_) { return attn_bwd_lds(T, D, H, g_); });
+    if (hg == 0) return AMID_ERR_UNSUPPORTED;
+    const size_t lds = attn_bwd_lds(T, D, H, hg);
     switch (D / H) {
-        case 8: return attn_launch(attn_bwd_kernel<8>, a, lds, stream);
-        case 16: return attn_launch(attn_bwd_kernel<16>, a, lds, stream);
-        case 32: return attn_launch(attn_bwd_kernel<32>, a, lds, stream);
+        case 8: return attn_launch(attn_bwd_kernel<8>, a, lds, hg, stream);
+        case 16: return attn_launch(attn_bwd_kernel<16>, a, lds, hg, stream);
+        case 32: return attn_launch(attn_bwd_kernel<32>, a, lds, hg, stream);
         default: return AMID_ERR_UNSUPPORTED;
     }
 }

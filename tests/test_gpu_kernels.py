@@ -308,8 +308,8 @@ def oracle_attention(q, k, v, H, p_keep_mask=None, p=0.5):
     return (A @ vh).permute(0, 2, 1, 3).reshape(B, T, D)
 
 
-@pytest.mark.parametrize("T", [64, 50, 17, 70])          # <= 64: matrix-core kernels; 70: general VALU kernels
-@pytest.mark.parametrize("train", [0, 1])
+@pytest.mark.parametrize("T", [64, 50, 17, 70, 150, 260])          # <= 64: matrix-core kernels; beyond: general VALU kernels (150: the
+@pytest.mark.parametrize("train", [0, 1])                           # reference's amazon seq_len, two head groups; 260: four)
 def test_attention_fwd_bwd_vs_autograd(L, T, train):
     B, D, H = 3, 128, 8
     g = torch.Generator().manual_seed(T + train)
@@ -338,7 +338,7 @@ def test_attention_fwd_bwd_vs_autograd(L, T, train):
         assert relmax(dq[sl], qq.grad) < 5e-6 and relmax(dk[sl], kk.grad) < 5e-6 and relmax(dv[sl], vv.grad) < 5e-6, dom
 
 
-@pytest.mark.parametrize("T", [64, 50, 17, 70])          # <= 64: matrix-core kernels (attention_mfma_bert.hip); 70: general VALU kernels
+@pytest.mark.parametrize("T", [64, 50, 17, 70, 150])          # <= 64: matrix-core kernels (attention_mfma_bert.hip); beyond: general VALU kernels
 @pytest.mark.parametrize("train", [0, 1])
 def test_attention_bert_shape_fwd_bwd_vs_autograd(L, T, train):
     """Bidirectional attention of BERT4Rec (model_seq.py:149-162): 4 heads of 32, scores / sqrt(d_k), masked keys at -1e9 (one row

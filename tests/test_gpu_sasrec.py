@@ -666,10 +666,11 @@ def test_dr_two_optimizers_track_oracle():
 
 # ---------------------------------------------------------------------------- edge shapes (ragged / empty / maximum inputs)
 @pytest.mark.parametrize("Bn,T,D,neg", [(1, 50, 128, 1), (3, 7, 64, 4), (5, 64, 128, 1), (4, 70, 64, 2), (2, 1, 64, 1), (512, 50, 128, 1),
-                                         (16, 20, 128, 999)])
+                                         (16, 20, 128, 999), (3, 150, 128, 1)])
 def test_edge_shapes_forward_backward_vs_oracle(Bn, T, D, neg):
     """One row, odd small shapes, T at the matrix-core attention limit (64) and beyond it (70: general kernel), a single time
-    step, the cfg 3 batch (512 x 50) and the evaluation fan-out of run.sh (999 negatives); some rows entirely padding (an empty
+    step, the cfg 3 batch (512 x 50), the evaluation fan-out of run.sh (999 negatives) and the reference's amazon sequence length
+    (train_sr_dr.py:550: 150; attention in two head groups per sequence); some rows entirely padding (an empty
     history in one or both domains) and some with no padding at all."""
     hid, n_items = 16, 700
     P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=Bn + T)
