@@ -259,7 +259,11 @@ using namespace amid;
 extern "C" int amid_inc_score_f32(const float* xg, int B, int T, int D, float* s, void* stream) {
     AMID_CHECK_ARG(xg && s && B > 0 && T > 0 && D > 0 && (D % 4) == 0);
     const size_t lds = (size_t)T * (D + 4) * sizeof(float);
-    if (lds > 64 * 1024) return AMID_ERR_UNSUPPORTED;
+    if (lds > 160 * 1024 - 256) return AMID_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)inc_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
     inc_score_kernel<<<dim3(B, 2), 256, lds, (hipStream_t)stream>>>(xg, B, T, D, s);
     AMID_LAUNCH_CHECK();
     return AMID_OK;

@@ -270,7 +270,7 @@ extern "C" int amid_itc_pairmax_f32(const float* x, const float* const* ln_w, co
     AMID_CHECK_ARG(x && ln_w && ln_b && ln_w[0] && ln_w[1] && ln_b[0] && ln_b[1] && s && B > 0 && T > 0 && D > 0 && (D % 4) == 0);
     if (D > 128) return AMID_ERR_UNSUPPORTED;
     const size_t lds = (size_t)2 * T * (D + 4) * sizeof(float);
-    if (lds > 150 * 1024) return AMID_ERR_UNSUPPORTED;
+    if (lds > 160 * 1024 - 256) return AMID_ERR_UNSUPPORTED;       // T <= 151 at D = 128 (both domains' LayerNorm'd rows of a batch row)
     PairMaxArgs a;
     a.x = x; a.s = s; a.u_raw = u_raw; a.B = B; a.T = T; a.D = D; a.eps = eps;
     for (int g = 0; g < 2; ++g) { a.lnw[g] = ln_w[g]; a.lnb[g] = ln_b[g]; }

@@ -524,6 +524,41 @@ def test_inc_plus_itc_vs_oracle(dr):
     grads_check("inc+itc", eng, pl, grads, 2e-4, 2e-4)
 
 
+@pytest.mark.parametrize("variant", ["itc", "inc"])
+def test_comp_modules_at_seq_len_150(variant):
+    """The reference's amazon sequence length (train_sr_dr.py:550: 150) with InterComp (pair-max over 150 x 150 pairs, both domains'
+    rows of a batch row in LDS) and with InnerComp (encoders over 300 tokens): logits, loss and gradients against the oracle."""
+    from amid_amd.engine import SasrecEngine
+    D, T, Bn, hid, n_items = 128, 150, 4, 16, 400
+    kw_shapes = dict(itc_bs=Bn) if variant == "itc" else dict(inc_bs=Bn)
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid, **kw_shapes), seed=150)
+    if variant == "itc":
+        for d in (1, 2):
+            P[f"sac{d}.last_layernorm.weight"] *= 0.3
+    else:
+        P["item_emb_layer.emb_item.weight"] *= 2.2
+    g = torch.Generator().manual_seed(15)
+    batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=5)
+    batch["seq_d1"] = torch.randint(1, n_items - 1, (Bn, T), generator=g)
+    batch["seq_d2"] = torch.randint(1, n_items - 1, (Bn, T), generator=g)
+    kw = dict(isItC=True, threshold2=0.2) if variant == "itc" else dict(isInC=True, threshold1=0.2)
+    taps = {}
+    orc.sasrec_forward(P, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], None, taps, **kw)
+    pre = "itc_d1" if variant == "itc" else "inc_d1"
+    log(f"T=150 {variant}: gate {taps[pre]['gate'].int().tolist()} margin {taps[pre]['margin']:.3e}")
+    assert taps[pre]["margin"] > 1e-3
+    loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, None, **kw)
+    ekw = dict(itc_bs=Bn, itc_threshold=0.2) if variant == "itc" else dict(inc_bs=Bn, inc_threshold=0.2)
+    eng = SasrecEngine(n_items, D, T, hid, lr=1e-3, seed=1, **ekw)
+    eng.load_state_dict(P)
+    pl = run_forward(eng, batch, train=False, with_loss=True)
+    assert relmax(pl.p1, p1) < 3e-5 and relmax(pl.p2, p2) < 3e-5
+    eng.enqueue_backward(pl, train=False)
+    eng.sync()
+    assert abs(float(pl.loss.item()) - float(loss)) < 1e-5
+    grads_check(f"T=150 {variant}", eng, pl, grads, 5e-4, 5e-4)
+
+
 def test_inc_train_step_vs_oracle_dense_adam():
     """Three isInC train steps (dropout on) against the oracle's dense Adam: parameters after the steps, InnerComp's included."""
     D, T, Bn, hid, n_items, ts1 = 64, 20, 8, 16, 300, 0.13
