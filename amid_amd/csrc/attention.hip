@@ -294,6 +294,12 @@ using namespace amid;
 int amid_attn_mfma_fwd_launch(const void* args, void* stream);
 int amid_attn_mfma_bwd_launch(const void* args, void* stream);
 static bool mfma_shape(const AttnArgs& a) { return a.causal && a.key_keep == nullptr && a.D / a.H == 16 && a.T <= 64 && a.H <= 8; }
+// attention_mfma_long.hip: the same shape at 64 < T <= 256, queries and keys walked in blocks of 64
+int amid_attn_long_fwd_launch(const void* args, void* stream);
+int amid_attn_long_bwd_launch(const void* args, void* stream);
+static bool long_shape(const AttnArgs& a) {
+    return a.causal && a.key_keep == nullptr && a.D / a.H == 16 && a.T > 64 && a.T <= 256 && a.H <= 8 && a.H % 4 == 0;
+}
 // attention_mfma_bert.hip: matrix-core kernels for the bidirectional head-dim-32 T <= 64 case (key mask optional)
 int amid_attn_bert_fwd_launch(const void* args, void* stream);
 int amid_attn_bert_bwd_launch(const void* args, void* stream);
@@ -349,6 +355,7 @@ extern "C" int amid_attn_fwd_f32(const float* q, const float* k, const float* v,
     AMID_CHECK_ARG(o);
     a.o = o; a.stats = stats;
     if (mfma_shape(a)) return amid_attn_mfma_fwd_launch(&a, stream);
+    if (long_shape(a)) return amid_attn_long_fwd_launch(&a, stream);
     if (bert_shape(a)) return amid_attn_bert_fwd_launch(&a, stream);
     const int hg = attn_head_groups(H, [&](int g_) { return attn_fwd_lds(T, D, g_); });
     if (hg == 0) return AMID_ERR_UNSUPPORTED;
@@ -369,6 +376,7 @@ extern "C" int amid_attn_bwd_f32(const float* q, const float* k, const float* v,
     AMID_CHECK_ARG(o && stats && d_o && dq && dk && dv);
     a.o = const_cast<float*>(o); a.stats = const_cast<float*>(stats); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
     if (mfma_shape(a)) return amid_attn_mfma_bwd_launch(&a, stream);
+    if (long_shape(a)) return amid_attn_long_bwd_launch(&a, stream);
     if (bert_shape(a)) return amid_attn_bert_bwd_launch(&a, stream);
     const int hg = attn_head_groups(H, [&](int g_) { return attn_bwd_lds(T, D, H, g_); });
     if (hg == 0) return AMID_ERR_UNSUPPORTED;

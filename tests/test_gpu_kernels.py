@@ -308,8 +308,8 @@ def oracle_attention(q, k, v, H, p_keep_mask=None, p=0.5):
     return (A @ vh).permute(0, 2, 1, 3).reshape(B, T, D)
 
 
-@pytest.mark.parametrize("T", [64, 50, 17, 70, 150, 260])          # <= 64: matrix-core kernels; beyond: general VALU kernels (150: the
-@pytest.mark.parametrize("train", [0, 1])                           # reference's amazon seq_len, two head groups; 260: four)
+@pytest.mark.parametrize("T", [64, 50, 17, 70, 100, 128, 129, 150, 256, 260])      # <= 64: matrix-core kernels; 65..256: their blocked form
+@pytest.mark.parametrize("train", [0, 1])                           # (100: isInC at seq_len 50; 150: the reference's amazon seq_len); 260: general VALU kernels
 def test_attention_fwd_bwd_vs_autograd(L, T, train):
     B, D, H = 3, 128, 8
     g = torch.Generator().manual_seed(T + train)
