@@ -102,75 +102,6 @@ __global__ __launch_bounds__(256) void lnmean_bwd_kernel(const float* __restrict
 
 // ---- scorer ------------------------------------------------------------------------------------
 // block = batch row b; thread layout: hid units x lanes.  W1 = [hid, 2D] (user half | item half).
-struct ScorerArgs {
-    const float* u;            // [2, B, D]   u_d1 | u_d2
-    const float* items;        // [B, NI, D]
-    const float* w1; const float* b1; const float* w2; const float* b2;
-    const float* labels;       // [B, NI] or null
-    const long long* domain;   // [B]     or null
-    float* p1; float* p2;      // [B, NI]
-    float* dp1; float* dp2;    // dLoss/dp (written when labels given)
-    float* loss_part;          // [B]
-    int B, NI, D, hid;
-};
-
-__global__ __launch_bounds__(256) void scorer_fwd_kernel(const ScorerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, D = a.D, hid = a.hid, NI = a.NI;
-    float* au = sm;                    // [2][hid]  W1u . u_d + b1
-    float* ci = sm + 2 * hid;          // [NI][hid] W1i . item_n      (processed in chunks of <= 64 items)
-    const int lane = lane_id(), w = wave_id();          // 4 waves
-    // user halves: one (d, j) dot product per wave iteration
-    for (int dj = w; dj < 2 * hid; dj += 4) {
-        const int d = dj / hid, j = dj - d * hid;
-        const float* ur = a.u + ((long long)d * a.B + b) * D;
-        const float* wr = a.w1 + (long long)j * 2 * D;
-        float s = 0.f;
-        for (int e = lane; e < D; e += 64) s = fmaf(wr[e], ur[e], s);
-        s = group_sum<64>(s);
-        if (lane == 0) au[d * hid + j] = s + a.b1[j];
-    }
-    float lsum = 0.f;
-    for (int n0 = 0; n0 < NI; n0 += 64) {
-        const int nn = min(64, NI - n0);
-        __syncthreads();
-        for (int nj = w; nj < nn * hid; nj += 4) {
-            const int n = nj / hid, j = nj - n * hid;
-            const float* ir = a.items + ((long long)b * NI + n0 + n) * D;
-            const float* wr = a.w1 + (long long)j * 2 * D + D;
-            float s = 0.f;
-            for (int e = lane; e < D; e += 64) s = fmaf(wr[e], ir[e], s);
-            s = group_sum<64>(s);
-            if (lane == 0) ci[n * hid + j] = s;
-        }
-        __syncthreads();
-        // one thread per (n, d)
-        for (int nd = threadIdx.x; nd < nn * 2; nd += 256) {
-            const int n = nd >> 1, d = nd & 1;
-            float z = a.b2[0];
-            for (int j = 0; j < hid; ++j) z = fmaf(a.w2[j], fmaxf(au[d * hid + j] + ci[n * hid + j], 0.f), z);
-            const float p = 1.0f / (1.0f + expf(-z));
-            const long long o = (long long)b * NI + n0 + n;
-            (d ? a.p2 : a.p1)[o] = p;
-            if (a.labels) {
-                const float y = a.labels[o];
-                const float md = a.domain[b] ? (d ? 1.f : 0.f) : (d ? 0.f : 1.f);
-                const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.0f - p), -100.f);
-                const float inv = 1.0f / ((float)a.B * (float)NI);
-                lsum += -(y * lp + (1.f - y) * l1p) * md * inv;
-                (d ? a.dp2 : a.dp1)[o] = md * inv * (p - y) / fmaxf((1.f - p) * p, 1e-12f);   // torch binary_cross_entropy_backward
-            }
-        }
-    }
-    if (a.labels) {
-        __syncthreads();
-        float* red = sm;               // au/ci are dead
-        lsum = group_sum<64>(lsum);
-        if (lane == 0) red[w] = lsum;
-        __syncthreads();
-        if (threadIdx.x == 0) a.loss_part[b] = ((red[0] + red[1]) + (red[2] + red[3]));
-    }
-}
 
 struct ScorerBwdArgs {
     const float* u; const float* items; const float* w1; const float* b1; const float* w2; const float* b2;
@@ -391,20 +322,6 @@ extern "C" int amid_lnmean_bwd_f32(const float* x, const float* du, const float*
     const int use_ln = (w0 != nullptr);
     AMID_CHECK_ARG(!use_ln || (w1 && part));
     lnmean_bwd_kernel<<<2 * B, 256, 16 * D * sizeof(float), (hipStream_t)stream>>>(x, du, w0, w1, B, T, D, eps, use_ln, dx, part);
-    AMID_LAUNCH_CHECK();
-    return AMID_OK;
-}
-
-extern "C" int amid_scorer_fwd_f32(const float* u, const float* items, const float* w1, const float* b1, const float* w2, const float* b2,
-                                   const float* labels, const long long* domain_id, int B, int NI, int D, int hid, float* p1, float* p2,
-                                   float* dp1, float* dp2, float* loss_part, void* stream) {
-    AMID_CHECK_ARG(u && items && w1 && b1 && w2 && b2 && p1 && p2 && B > 0 && NI > 0 && D > 0 && hid > 0 && hid <= 256);
-    AMID_CHECK_ARG(!labels || (domain_id && dp1 && dp2 && loss_part));
-    ScorerArgs a;
-    a.u = u; a.items = items; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.labels = labels; a.domain = domain_id;
-    a.p1 = p1; a.p2 = p2; a.dp1 = dp1; a.dp2 = dp2; a.loss_part = loss_part; a.B = B; a.NI = NI; a.D = D; a.hid = hid;
-    const size_t lds = (size_t)(2 * hid + 64 * hid) * sizeof(float);
-    scorer_fwd_kernel<<<B, 256, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

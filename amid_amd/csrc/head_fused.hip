@@ -414,6 +414,18 @@ __global__ __launch_bounds__(512) void head_fwd_bwd_kernel(const HeadArgs a) {
     head_bwd_body<true>(a, sm);
 }
 
+// scorer forward alone on given user vectors u [2, B, D] (evaluation of the isItC / isDR models, up to 1 000 candidates per row):
+// W1^T staged in LDS, items in chunks of 64 -- the same code path as the fused head's forward half
+__global__ __launch_bounds__(512) void scorer_fwd_only_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const HeadLds s(sm, a.D, a.hid);
+    const int b = blockIdx.x, D = a.D;
+    stage_w1t(s.w1t, a.w1, 2 * D, a.hid, whole_block());
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) s.u_s[e] = a.u[((long long)(e / D) * a.B + b) * D + (e % D)];
+    __syncthreads();
+    scorer_fwd_part(a, s, b, whole_block());
+}
+
 // ---------------------------------------------------------------------------------------------
 // The head of the isItC / isDR train step after the user vectors are mixed (csrc/intercomp.hip): up to three scorers
 // (predictModule, predict_ips, predict_gfunc; model_seq.py:436-440) forward on the same (u, items) of row b, the row's loss
@@ -623,6 +635,23 @@ extern "C" int amid_scorer_multi_fwd_bwd_f32(const float* u, const float* items,
     if (int e = head_lds_attr((const void*)scorer_multi_fwd_bwd_kernel, lds)) return e;
     const int extra = n_tr > 0 ? min(n_tr * (D / 32) * (D / 32), 96) : 0;
     scorer_multi_fwd_bwd_kernel<<<B + extra, n_heads == 1 ? 512 : 768, lds, (hipStream_t)stream>>>(m);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// replaces: predictModule.forward model_seq.py:40-54 on given user vectors; with labels != NULL also the masked BCE mean of
+// train_sr.py:203-212 (per-row loss partials + dLoss/dp)
+extern "C" int amid_scorer_fwd_f32(const float* u, const float* items, const float* w1, const float* b1, const float* w2, const float* b2,
+                                   const float* labels, const long long* domain_id, int B, int NI, int D, int hid, float* p1, float* p2,
+                                   float* dp1, float* dp2, float* loss_part, void* stream) {
+    AMID_CHECK_ARG(u && p1 && p2 && (!labels || (domain_id && dp1 && dp2 && loss_part)));
+    HeadArgs a = {};
+    if (int e = head_fill(a, u, nullptr, nullptr, items, w1, b1, w2, b2, B, 1, NI, D, hid, 0.f)) return e;
+    a.u = const_cast<float*>(u); a.labels = labels; a.domain = domain_id; a.p1 = p1; a.p2 = p2; a.dp1 = dp1; a.dp2 = dp2; a.loss_part = loss_part;
+    const size_t lds = head_lds_floats(D, hid) * sizeof(float);
+    if (lds > 160 * 1024) return AMID_ERR_UNSUPPORTED;
+    if (int e = head_lds_attr((const void*)scorer_fwd_only_kernel, lds)) return e;
+    scorer_fwd_only_kernel<<<B, 512, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

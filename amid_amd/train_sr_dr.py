@@ -49,8 +49,10 @@ def train(model, train_batches, train_batches_dr, args, val_batches):
         t0, n_samples = time.perf_counter(), 0
         eng.select_optimizer(0, lr=args.lr)                                              # optimizer   (train_sr_dr.py:668)
         pooled = not args.no_pool        # each loop's epoch resident in HBM, one graph replay per step (see train_sr.py of this repo)
+        t_pool = time.perf_counter()
         steps = ((None, None) for _ in range(model.begin_epoch_pool(train_batches.epoch_tensors(), dr_objective=0))) if pooled \
             else enumerate(train_batches)
+        t_pool = time.perf_counter() - t_pool
         for i, (_, b) in enumerate(steps):
             if pooled:
                 losses = model.pool_step(use_graph=not args.no_graph, dr_objective=0)
@@ -67,11 +69,19 @@ def train(model, train_batches, train_batches_dr, args, val_batches):
                 break
         if pooled:
             model.end_epoch_pool()
+        torch.cuda.synchronize()
+        t_eval = time.perf_counter()
         res = base.test(model, args, val_batches)
+        torch.cuda.synchronize()
+        t_eval = time.perf_counter() - t_eval
         model.train()
+        t_sw = time.perf_counter()
         eng.select_optimizer(1, lr=args.lr * args.lr2)                                   # optimizer2  (train_sr_dr.py:669)
+        t_sw = time.perf_counter() - t_sw
+        t0p = time.perf_counter()
         steps = ((None, None) for _ in range(model.begin_epoch_pool(train_batches_dr.epoch_tensors(), dr_objective=1))) if pooled \
             else enumerate(train_batches_dr)
+        t_pool += time.perf_counter() - t0p
         for i, (_, b) in enumerate(steps):
             if pooled:
                 losses = model.pool_step(use_graph=not args.no_graph, dr_objective=1)
@@ -89,7 +99,8 @@ def train(model, train_batches, train_batches_dr, args, val_batches):
             model.end_epoch_pool()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        logger.info(f"epoch {epoch}: {n_samples} samples in {dt:.2f} s = {n_samples / dt:.0f} samples/s (loaders and evaluation included)")
+        logger.info(f"epoch {epoch}: {n_samples} samples in {dt:.2f} s = {n_samples / dt:.0f} samples/s (loaders and evaluation included; "
+                    f"epoch pools {t_pool:.3f} s, evaluation {t_eval:.3f} s, optimizer switch {t_sw:.3f} s)")
         names = ("HR@1", "NDCG@1", "HR@5", "NDCG@5", "HR@10", "NDCG@10", "MRR")
         msg = [f"Epoch: {epoch}/{args.epoch} \tTrain cls Loss: {stats.loss_cls:.4f} \tTrain dr_e Loss: {stats.loss_dr_e:.4f} \t"
                f"Train dr_r Loss: {stats.loss_dr_r:.4f} \tVal loss: {res['loss']:.4f}"]
