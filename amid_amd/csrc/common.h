@@ -37,6 +37,13 @@ __device__ __forceinline__ float group_max(float v) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// store through an explicitly GLOBAL pointer (a pointer that went through a struct can lose its address space: flat_store counts on
+// lgkmcnt too and forces full waits in front of LDS reads)
+typedef float amid_gv4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_global(float* p, float4 v) {
+    amid_gv4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *(__attribute__((address_space(1))) amid_gv4*)(p) = t;
+}
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }

@@ -60,7 +60,12 @@ __device__ __forceinline__ void qkv_fwd_body(const QkvFwdArgs& a, float* __restr
         const int next = (s == 0) ? 2 : 0;
         if (s < 2) load_w<D, D>(wr, a.w_in[g] + (long long)next * D * D, D);   // next slab's weights fly under the MFMAs
         zero_acc<D>(acc);
-        mma_tile<D, D, BF>(As, Ws, acc);
+        if (s == 2) {                                     // the q slab: Qn sits in the A image, its global copy leaves under these MFMAs
+            const ImageRowsPending<D> pq{As, a.qn + row0 * D, D, nrows};
+            mma_tile<D, D, BF>(As, Ws, acc, pq);
+        } else {
+            mma_tile<D, D, BF>(As, Ws, acc);
+        }
         float* out = (which == 0) ? a.q : (which == 1) ? a.k : a.v;
         acc_to_global<D>(out, row0, nrows, D, a.b_in[g] + which * D, acc);
         if (s == 2) break;
@@ -74,7 +79,7 @@ __device__ __forceinline__ void qkv_fwd_body(const QkvFwdArgs& a, float* __restr
                     row_stats<RP::QPR>(xr.v[i], D, a.ln_eps, mean, rstd);
                     const float4 y = ln_apply(xr.v[i], mean, rstd, lw, lb);
                     store_a4<D, BF>(As, r, sub, y);
-                    if (r < nrows) st4(a.qn + (row0 + r) * D + 4 * sub, y);
+                    if constexpr (BF) { if (r < nrows) st4(a.qn + (row0 + r) * D + 4 * sub, y); }     // fp32: from the A image, below
                 }
             }
         }
@@ -290,7 +295,7 @@ __device__ __forceinline__ void oproj_ffn_fwd_body(const OprojFfnFwdArgs& a, flo
                     float mean, rstd;
                     row_stats<RP::QPR>(x, D, a.ln_eps, mean, rstd);
                     yv = ln_apply(x, mean, rstd, w, b);
-                    st4(a.y + off, yv);
+                    if constexpr (BF) st4(a.y + off, yv);            // fp32: stored from the A image inside the next MFMA loop
                 }
                 tr.v[i] = yv;
                 store_a4<D, BF>(As, r, sub, yv);
@@ -301,12 +306,15 @@ __device__ __forceinline__ void oproj_ffn_fwd_body(const OprojFfnFwdArgs& a, flo
     w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     load_w<D, D>(wr, a.w2[g], D);
+    const float4 bias1 = ld4(a.b1[g] + 4 * sub), bias2 = ld4(a.b2[g] + 4 * sub);
     zero_acc<D>(acc);
-    mma_tile<D, D, BF>(As, Ws, acc);
+    {
+        const ImageRowsPending<D> py{As, a.y + row0 * D, D, nrows};
+        mma_tile<D, D, BF>(As, Ws, acc, py);
+    }
     __syncthreads();
     acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();
-    const float4 bias1 = ld4(a.b1[g] + 4 * sub), bias2 = ld4(a.b2[g] + 4 * sub);
 #pragma unroll
     for (int i = 0; i < RP::NR; ++i) {                    // h = relu(drop1(C + c1)) -> global and the A image of the third GEMM
         const int r = RP::first_row() + i * RP::RPP;
@@ -317,7 +325,7 @@ __device__ __forceinline__ void oproj_ffn_fwd_body(const OprojFfnFwdArgs& a, flo
                 if (a.train) hv = f4mul(hv, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN1), step,
                                                           (unsigned long long)(local0 + r) * D + 4 * sub, a.thr16, a.scale));
                 hv.x = fmaxf(hv.x, 0.f); hv.y = fmaxf(hv.y, 0.f); hv.z = fmaxf(hv.z, 0.f); hv.w = fmaxf(hv.w, 0.f);
-                st4(a.h + (row0 + r) * D + 4 * sub, hv);
+                if constexpr (BF) st4(a.h + (row0 + r) * D + 4 * sub, hv);
             }
             store_a4<D, BF>(As, r, sub, hv);
         }
@@ -326,7 +334,10 @@ __device__ __forceinline__ void oproj_ffn_fwd_body(const OprojFfnFwdArgs& a, flo
     w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     zero_acc<D>(acc);
-    mma_tile<D, D, BF>(As, Ws, acc);
+    {
+        const ImageRowsPending<D> ph{As, a.h + row0 * D, D, nrows};
+        mma_tile<D, D, BF>(As, Ws, acc, ph);
+    }
     __syncthreads();
     acc_to_lds<D>(Cs, LDC, acc);
     __syncthreads();

@@ -141,6 +141,33 @@ __device__ __forceinline__ void w_to_lds(float* __restrict__ Ws, const WRegs<K, 
     for (int i = 0; i < W::NR; ++i) store_a4<K, BF>(Ws, r0 + i * W::RPP, sub, t.v[i]);
 }
 
+// ---- deferred epilogue stores -------------------------------------------------------------------------------------------
+// A CU drains global stores at only ~8 B per clock: in a row pass that writes a [rows, N] tensor every wave sits at a full store
+// queue with the matrix pipe idle (s_memtime: 7 500 cycles to ISSUE seven st4).  Many of those tensors (LN
+// outputs, relu outputs, dgrad inputs) are ALSO written to the A image for the next GEMM -- so the row pass skips the global store
+// and the next mma_tile issues it, one row slot per k-step between its MFMAs, re-reading the values from the A image: the stores
+// drain under the matrix work at no register cost.  fp32 images only (the bf16 images hold rounded values).
+// Every store is UNCONDITIONAL so that the compiler can count the stores in flight and wait for older loads with
+// s_waitcnt vmcnt(k > 0): a dead slot (row >= nrows) re-stores a live element -- the thread's first row, or row 0 of the tile for
+// a thread without live rows: same address, same value as its owner writes.
+template <int N> struct ImageRowsPending {
+    const float* img;          // A image [ROWS][N + 8]
+    float* out;                // global [.., ld], already offset to the tile's first row
+    int ld, nrows;
+    static constexpr int COUNT = RowPass<N>::NR;
+    __device__ __forceinline__ void issue(int i) const {
+        using RP = RowPass<N>;
+        const int r0 = RP::first_row(), sub = RP::sub();
+        const int r = r0 + i * RP::RPP;
+        const int row = (r < nrows) ? r : ((r0 < nrows) ? r0 : 0);
+        st4_global(out + (long long)row * ld + 4 * sub, ld4(img + row * (N + 8) + 4 * sub));
+    }
+};
+struct NoPending {
+    static constexpr int COUNT = 0;
+    __device__ __forceinline__ void issue(int) const {}
+};
+
 // MFMA loop over the whole K of the slab.  Software-pipelined by hand: the operand fragments of k-step kk+1 are read
 // from LDS while the MFMAs of step kk issue, and inside a step the issue order is element-major / tile-minor, so
 // back-to-back MFMAs hit DIFFERENT accumulators (a 16x16x4 f32 MFMA issues every 32 cycles but needs 40 before a
@@ -176,8 +203,9 @@ __device__ __forceinline__ void mma_tile_bf16(const float* __restrict__ As, cons
     }
 }
 
-template <int K, int N>
-__device__ __forceinline__ void mma_tile_f32(const float* __restrict__ As, const float* __restrict__ Ws, f32x4 (&acc)[WaveMap<N>::ACC]) {
+template <int K, int N, class P0, class P1>
+__device__ __forceinline__ void mma_tile_f32(const float* __restrict__ As, const float* __restrict__ Ws, f32x4 (&acc)[WaveMap<N>::ACC],
+                                             const P0& p0, const P1& p1) {
     using WM = WaveMap<N>;
     constexpr int LDK = TileCfg<K>::LDK, ACC = WM::ACC, KK = K / 16;
     const int w = wave_id(), lane = lane_id();
@@ -215,16 +243,27 @@ __device__ __forceinline__ void mma_tile_f32(const float* __restrict__ As, const
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
+        {   // deferred stores of the previous epilogue(s): one row slot (a few at K = 64) per k-step, behind this step's MFMAs
+            constexpr int C0 = (P0::COUNT + KK - 1) / KK, C1 = (P1::COUNT + KK - 1) / KK, PER = C0 > C1 ? C0 : C1;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                if (kk * PER + u < P0::COUNT) p0.issue(kk * PER + u);
+                if (kk * PER + u < P1::COUNT) p1.issue(kk * PER + u);
+            }
+        }
         b_cur = b_nxt;
 #pragma unroll
         for (int t = 0; t < ACC; ++t) a_cur[t] = a_nxt[t];
     }
 }
 
-template <int K, int N, bool BF = false>
-__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Ws, f32x4 (&acc)[WaveMap<N>::ACC]) {
+// p0 / p1: stores a previous row pass left to this loop (ImageRowsPending; fp32 images only -- ignored in the bf16 mode, whose
+// callers keep storing directly)
+template <int K, int N, bool BF = false, class P0 = NoPending, class P1 = NoPending>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Ws, f32x4 (&acc)[WaveMap<N>::ACC],
+                                         const P0& p0 = NoPending(), const P1& p1 = NoPending()) {
     if constexpr (BF) mma_tile_bf16<K, N>(As, Ws, acc);
-    else mma_tile_f32<K, N>(As, Ws, acc);
+    else mma_tile_f32<K, N>(As, Ws, acc, p0, p1);
 }
 
 template <int N>
