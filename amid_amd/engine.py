@@ -149,7 +149,7 @@ class SasrecPlan:
         self.rpt = L.value("amid_rows_per_tile", M)
         self.tpg = (M + self.rpt - 1) // self.rpt
         # short tiles (seq_len 20 at batch 256: 40 rows per CU) run the 48- / 80-row builds of the row-tile kernels (csrc/tile_gemm.h)
-        self.rt_suffix = ("_rt3" if self.rpt <= 48 else "_rt5" if self.rpt <= 80 else "") if type(eng).__name__ == "SasrecEngine" else ""
+        self.rt_suffix = ("_rt3" if self.rpt <= 48 else "_rt5" if self.rpt <= 80 else "") if eng.SHORT_TILE_BUILDS else ""
         # static inputs (graph-replay safe): ONE int64 buffer so a batch arrives with a single copy
         #   [i_node B | neg B*(NI-1) | seq_d1 B*T | seq_d2 B*T | domain B | labels B*NI fp32 (packed two per word)]
         n_lab_words = (B * NI + 1) // 2
@@ -324,6 +324,7 @@ class SasrecEngine:
     HEADS = SASREC_HEADS
     PLAN_CLS = SasrecPlan
     EMB_DIMS = (64, 128)
+    SHORT_TILE_BUILDS = True     # the row-tile kernels of this encoder also exist as *_rt3 / *_rt5 (48- / 80-row tiles, csrc/Makefile)
 
     def _dense_names(self) -> List[Tuple[str, Tuple[int, ...]]]:
         return sasrec_dense_names(self.Tpos, self.D, self.hid, self.itc_bs, self.dr, self.inc_bs)

@@ -99,6 +99,7 @@ class Bert4recEngine(SasrecEngine):
     HEADS = BERT_HEADS
     PLAN_CLS = BertPlan
     EMB_DIMS = (BERT_HIDDEN,)
+    SHORT_TILE_BUILDS = False
 
     def _dense_names(self):
         return bert4rec_dense_names(self.hid, self.dr)
