@@ -276,7 +276,7 @@ def main():
 
     # inputs resident in HBM (the bench contract): the epoch's packed batches form one [n_pool, in_words] tensor and the step's
     # first kernel picks its batch by the device step counter -- no per-step input copy (--input copy restores the D2D copy)
-    use_pool = args.input == "pool" and args.model == "sasrec"
+    use_pool = args.input == "pool"
     if use_pool:
         eng.set_input_pool(pl, torch.stack(pool))
 
