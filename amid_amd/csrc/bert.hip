@@ -594,7 +594,7 @@ static DropCfg bdropcfg(const void* st, int train, float p, int layer) {
     } while (0)
 
 // Pointer-array parameters are HOST arrays of device pointers indexed [which * 2 + domain] or [domain].
-extern "C" int amid_bert_qkv_fwd_f32(const float* x, const float* const* ln_a, const float* const* ln_b, const float* const* w3x2,
+extern "C" int AMID_ENTRY(amid_bert_qkv_fwd_f32)(const float* x, const float* const* ln_a, const float* const* ln_b, const float* const* w3x2,
                                      const float* const* b3x2, int M, int rows_per_tile, float* y, float* q, float* k, float* v, void* stream) {
     AMID_CHECK_ARG(x && ln_a && ln_b && w3x2 && b3x2 && y && q && k && v);
     BQkvArgs a;
@@ -605,7 +605,7 @@ extern "C" int amid_bert_qkv_fwd_f32(const float* x, const float* const* ln_a, c
     return AMID_OK;
 }
 
-extern "C" int amid_bert_oproj_fwd_f32(const float* o, const float* x, const float* const* w, const float* const* b, int M, int rows_per_tile,
+extern "C" int AMID_ENTRY(amid_bert_oproj_fwd_f32)(const float* o, const float* x, const float* const* w, const float* const* b, int M, int rows_per_tile,
                                        int layer, const void* step_state, int train, float p_drop, float* x1, void* stream) {
     AMID_CHECK_ARG(o && x && w && b && x1 && (!train || step_state));
     BOprojArgs a;
@@ -616,7 +616,7 @@ extern "C" int amid_bert_oproj_fwd_f32(const float* o, const float* x, const flo
     return AMID_OK;
 }
 
-extern "C" int amid_bert_ffn1_fwd_f32(const float* x1, const float* const* ln_a, const float* const* ln_b, const float* const* w1,
+extern "C" int AMID_ENTRY(amid_bert_ffn1_fwd_f32)(const float* x1, const float* const* ln_a, const float* const* ln_b, const float* const* w1,
                                       const float* const* b1, int M, int rows_per_tile, int layer, const void* step_state, int train,
                                       float p_drop, float* y2, float* pre, float* h, void* stream) {
     AMID_CHECK_ARG(x1 && ln_a && ln_b && w1 && b1 && y2 && pre && h && (!train || step_state));
@@ -628,7 +628,7 @@ extern "C" int amid_bert_ffn1_fwd_f32(const float* x1, const float* const* ln_a,
     return AMID_OK;
 }
 
-extern "C" int amid_bert_ffn2_fwd_f32(const float* h, const float* x1, const float* const* w2, const float* const* b2, int M, int rows_per_tile,
+extern "C" int AMID_ENTRY(amid_bert_ffn2_fwd_f32)(const float* h, const float* x1, const float* const* w2, const float* const* b2, int M, int rows_per_tile,
                                       int layer, const void* step_state, int train, float p_drop, float* x2, void* stream) {
     AMID_CHECK_ARG(h && x1 && w2 && b2 && x2 && (!train || step_state));
     BFfn2Args a;
@@ -639,7 +639,7 @@ extern "C" int amid_bert_ffn2_fwd_f32(const float* h, const float* x1, const flo
     return AMID_OK;
 }
 
-extern "C" int amid_bert_ffn2_bwd_f32(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+extern "C" int AMID_ENTRY(amid_bert_ffn2_bwd_f32)(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
                                       const void* step_state, int train, float p_drop, float* dz, float* dpre, void* stream) {
     AMID_CHECK_ARG(dx2 && pre && w2T && dz && dpre && (!train || step_state));
     BFfn2BwdArgs a;
@@ -650,7 +650,7 @@ extern "C" int amid_bert_ffn2_bwd_f32(const float* dx2, const float* pre, const 
     return AMID_OK;
 }
 
-extern "C" int amid_bert_ffn1_bwd_f32(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+extern "C" int AMID_ENTRY(amid_bert_ffn1_bwd_f32)(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
                                       const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
                                       float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, void* stream) {
     AMID_CHECK_ARG(dpre && dx2 && x1 && ln_a && w1T && woT && dx1 && dt && d_o && ln_part && (!train || step_state));
@@ -663,7 +663,7 @@ extern "C" int amid_bert_ffn1_bwd_f32(const float* dpre, const float* dx2, const
     return AMID_OK;
 }
 
-extern "C" int amid_bert_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
                                      const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream) {
     AMID_CHECK_ARG(dq && dk && dv && dx1 && x && ln_a && wT3x2 && dx && ln_part);
     BQkvBwdArgs a;
@@ -678,6 +678,7 @@ extern "C" int amid_bert_qkv_bwd_f32(const float* dq, const float* dk, const flo
 // Output placement: tile e of domain g, split s goes to w_part[g][out_group[e]][s] at column out_col[e] with row stride out_ld[e]; a
 // standalone tile has (out_ld, out_group, out_col) = (128, e, 0); the out_ld/128 tiles forming one [128, out_ld] matrix (w_2) share
 // out_group = their first entry, so that matrix's partials are contiguous: [splits][128 * out_ld] starting at entry out_group.
+#if AMID_TILE_RT == 7      // independent of the row-tile height: one copy only
 extern "C" int amid_bert_wgrad_f32(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
                                    const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part, float* b_part,
                                    void* stream) {
@@ -715,3 +716,4 @@ extern "C" int amid_transpose_rect_f32(const float* const* src, float* const* ds
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
+#endif

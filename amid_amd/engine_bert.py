@@ -99,7 +99,7 @@ class Bert4recEngine(SasrecEngine):
     HEADS = BERT_HEADS
     PLAN_CLS = BertPlan
     EMB_DIMS = (BERT_HIDDEN,)
-    SHORT_TILE_BUILDS = False
+    SHORT_TILE_BUILDS = True
 
     def _dense_names(self):
         return bert4rec_dense_names(self.hid, self.dr)
@@ -135,16 +135,16 @@ class Bert4recEngine(SasrecEngine):
             pre = f"transform{{d}}.{l}"
             w3 = ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.weight") for j in range(3) for d in (1, 2)])
             b3 = ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.bias") for j in range(3) for d in (1, 2)])
-            L.call("amid_bert_qkv_fwd_f32", pl.x[l].data_ptr(), self._pp(pre + ".input_sublayer.norm.a_2"), self._pp(pre + ".input_sublayer.norm.b_2"),
+            L.call("amid_bert_qkv_fwd_f32" + pl.rt_suffix, pl.x[l].data_ptr(), self._pp(pre + ".input_sublayer.norm.a_2"), self._pp(pre + ".input_sublayer.norm.b_2"),
                    w3, b3, M, pl.rpt, pl.y[l].data_ptr(), pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), s)
             L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l,
                    st, tr, BERT_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
-            L.call("amid_bert_oproj_fwd_f32", pl.o[l].data_ptr(), pl.x[l].data_ptr(), self._pp(pre + ".attention.output_linear.weight"),
+            L.call("amid_bert_oproj_fwd_f32" + pl.rt_suffix, pl.o[l].data_ptr(), pl.x[l].data_ptr(), self._pp(pre + ".attention.output_linear.weight"),
                    self._pp(pre + ".attention.output_linear.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x1[l].data_ptr(), s)
-            L.call("amid_bert_ffn1_fwd_f32", pl.x1[l].data_ptr(), self._pp(pre + ".output_sublayer.norm.a_2"), self._pp(pre + ".output_sublayer.norm.b_2"),
+            L.call("amid_bert_ffn1_fwd_f32" + pl.rt_suffix, pl.x1[l].data_ptr(), self._pp(pre + ".output_sublayer.norm.a_2"), self._pp(pre + ".output_sublayer.norm.b_2"),
                    self._pp(pre + ".feed_forward.w_1.weight"), self._pp(pre + ".feed_forward.w_1.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP,
                    pl.y2[l].data_ptr(), pl.pre[l].data_ptr(), pl.h[l].data_ptr(), s)
-            L.call("amid_bert_ffn2_fwd_f32", pl.h[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".feed_forward.w_2.weight"),
+            L.call("amid_bert_ffn2_fwd_f32" + pl.rt_suffix, pl.h[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".feed_forward.w_2.weight"),
                    self._pp(pre + ".feed_forward.w_2.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x[l + 1].data_ptr(), s)
         items = pl.xg.data_ptr() + 4 * 2 * M * D
         if self.dr:                                  # three heads (model_seq.py:301-305) on the plain means
@@ -203,9 +203,9 @@ class Bert4recEngine(SasrecEngine):
         for l in (1, 0):
             pre = f"transform{{d}}.{l}"
             wsq = lambda j: ptr_array([self.wT_sq[l, g, j].data_ptr() for g in (0, 1)])      # noqa: E731
-            L.call("amid_bert_ffn2_bwd_f32", pl.dxbuf.data_ptr(), pl.pre[l].data_ptr(), ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]),
+            L.call("amid_bert_ffn2_bwd_f32" + pl.rt_suffix, pl.dxbuf.data_ptr(), pl.pre[l].data_ptr(), ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]),
                    M, pl.rpt, l, st, tr, BERT_P_DROP, pl.dz.data_ptr(), pl.dpre.data_ptr(), s)
-            L.call("amid_bert_ffn1_bwd_f32", pl.dpre.data_ptr(), pl.dxbuf.data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".output_sublayer.norm.a_2"),
+            L.call("amid_bert_ffn1_bwd_f32" + pl.rt_suffix, pl.dpre.data_ptr(), pl.dxbuf.data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".output_sublayer.norm.a_2"),
                    ptr_array([self.w1T[l, g].data_ptr() for g in (0, 1)]), wsq(3), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.dx1.data_ptr(),
                    pl.dt.data_ptr(), pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), s)
             L.call("amid_attn_bwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(), pl.stats[l].data_ptr(),
@@ -225,6 +225,6 @@ class Bert4recEngine(SasrecEngine):
             L.call("amid_bert_wgrad_f32", ptr_array(dy), ptr_array(xx), (ctypes.c_int * N_ENT)(*ldy), (ctypes.c_int * N_ENT)(*ldx),
                    (ctypes.c_int * N_ENT)(*old), (ctypes.c_int * N_ENT)(*ogr), (ctypes.c_int * N_ENT)(*oco), N_ENT, M,
                    pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), s)
-            L.call("amid_bert_qkv_bwd_f32", pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[l].data_ptr(),
+            L.call("amid_bert_qkv_bwd_f32" + pl.rt_suffix, pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[l].data_ptr(),
                    self._pp(pre + ".input_sublayer.norm.a_2"), wT3, M, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), s)
         self._enqueue_grad_tail(pl)

@@ -398,6 +398,40 @@ int amid_sas_qkv_ffn_bwd_f32_rt5(const float* dq, const float* dk, const float* 
                              int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
                              float* fd_o, float* fln_part, int mma_bf16, void* stream);
 
+/* ... and of the BERT4Rec row-tile entry points */
+int amid_bert_qkv_fwd_f32_rt3(const float* x, const float* const* ln_a, const float* const* ln_b, const float* const* w3x2,
+                          const float* const* b3x2, int M, int rows_per_tile, float* y, float* q, float* k, float* v, void* stream);
+int amid_bert_qkv_fwd_f32_rt5(const float* x, const float* const* ln_a, const float* const* ln_b, const float* const* w3x2,
+                          const float* const* b3x2, int M, int rows_per_tile, float* y, float* q, float* k, float* v, void* stream);
+int amid_bert_oproj_fwd_f32_rt3(const float* o, const float* x, const float* const* w, const float* const* b, int M, int rows_per_tile, int layer,
+                            const void* step_state, int train, float p_drop, float* x1, void* stream);
+int amid_bert_oproj_fwd_f32_rt5(const float* o, const float* x, const float* const* w, const float* const* b, int M, int rows_per_tile, int layer,
+                            const void* step_state, int train, float p_drop, float* x1, void* stream);
+int amid_bert_ffn1_fwd_f32_rt3(const float* x1, const float* const* ln_a, const float* const* ln_b, const float* const* w1, const float* const* b1,
+                           int M, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* y2, float* pre,
+                           float* h, void* stream);
+int amid_bert_ffn1_fwd_f32_rt5(const float* x1, const float* const* ln_a, const float* const* ln_b, const float* const* w1, const float* const* b1,
+                           int M, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* y2, float* pre,
+                           float* h, void* stream);
+int amid_bert_ffn2_fwd_f32_rt3(const float* h, const float* x1, const float* const* w2, const float* const* b2, int M, int rows_per_tile, int layer,
+                           const void* step_state, int train, float p_drop, float* x2, void* stream);
+int amid_bert_ffn2_fwd_f32_rt5(const float* h, const float* x1, const float* const* w2, const float* const* b2, int M, int rows_per_tile, int layer,
+                           const void* step_state, int train, float p_drop, float* x2, void* stream);
+int amid_bert_ffn2_bwd_f32_rt3(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                           const void* step_state, int train, float p_drop, float* dz, float* dpre, void* stream);
+int amid_bert_ffn2_bwd_f32_rt5(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                           const void* step_state, int train, float p_drop, float* dz, float* dpre, void* stream);
+int amid_bert_ffn1_bwd_f32_rt3(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                           const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train, float p_drop,
+                           float* dx1, float* dt, float* d_o, float* ln_part, void* stream);
+int amid_bert_ffn1_bwd_f32_rt5(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                           const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train, float p_drop,
+                           float* dx1, float* dt, float* d_o, float* ln_part, void* stream);
+int amid_bert_qkv_bwd_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                          const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream);
+int amid_bert_qkv_bwd_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                          const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream);
+
 /* ---- hipGraph capture / replay of a whole step; HIP events on the caller's stream ---------------- */
 int amid_graph_capture_begin(void* stream);
 int amid_graph_capture_end(void* stream, void** graph_exec_out);

@@ -124,6 +124,30 @@ def test_backward_grads_vs_oracle(train):
     grads_check(f"bert bwd train={train}", eng, pl, grads, 2e-4, 2e-4)          # GELU is smooth: no knife edge here
 
 
+@pytest.mark.parametrize("Bn,T,build", [(256, 50, ""), (128, 50, "_rt5"), (256, 20, "_rt3")])
+def test_tile_builds_forward_backward_vs_oracle(Bn, T, build):
+    """The three builds of the row-tile kernels (112 / 80 / 48 rows per workgroup: the headline batch, half of it, the mybank
+    sequence length) forward + backward against the oracle, dropout on."""
+    hid, n_items = 32, 2000
+    P = orc.random_params(orc.bert4rec_param_shapes(n_items, hid), seed=60 + T)
+    batch = batch_with_masked_keys(Bn, T, n_items, seed=8)
+    seed, step = 5, 3
+    masks = orc.philox_masks_bert4rec(Bn, T, seed=seed, step=step)
+    loss, (p1, p2), grads = orc.loss_and_grads("bert4rec", P, batch, masks)
+    eng = make_engine(P, T, seed=seed)
+    pl = run_forward(eng, batch, train=True, with_loss=True, step=step, seed=seed)
+    assert pl.rt_suffix == build
+    eng.enqueue_backward(pl, train=True)
+    eng.sync()
+    assert abs(float(pl.loss.item()) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    assert relmax(pl.p1, p1) < 1e-4
+    for name in eng.dense.slots:
+        if name.endswith("linear_layers.1.bias"):
+            continue
+        assert rel_l2(eng.dense.view(name, eng.dense.grad), grads[name]) < 1e-3, name
+    assert rel_l2(dense_table_grad(eng, pl), grads["item_emb_layer.emb_item.weight"]) < 1e-3
+
+
 def test_backward_golden_bert4rec_grads():
     z, _, B, G = load_golden("g4_bert4rec_grads.npz")
     P = golden_params(z)
