@@ -37,8 +37,10 @@ struct QkvFwdArgs {
     TileGeom tg;
 };
 
+// xin != nullptr (fused after the previous layer's feed-forward, fp32): the tile's rows of x arrive in registers from that body --
+// no global round trip -- and their global copy (the saved layer input) is stored from the A image inside the k slab's MFMA loop
 template <int D, bool BF>
-__device__ __forceinline__ void qkv_fwd_body(const QkvFwdArgs& a, float* __restrict__ smem, int tile) {
+__device__ __forceinline__ void qkv_fwd_body(const QkvFwdArgs& a, float* __restrict__ smem, int tile, const TileRegs<D>* xin = nullptr) {
     using RP = RowPass<D>;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
@@ -47,7 +49,7 @@ __device__ __forceinline__ void qkv_fwd_body(const QkvFwdArgs& a, float* __restr
     const int sub = RP::sub();
     TileRegs<D> xr;
     WRegs<D, D> wr;
-    load_tile<D>(xr, a.x, row0, nrows, D);
+    if (xin != nullptr) xr = *xin; else load_tile<D>(xr, a.x, row0, nrows, D);
     load_w<D, D>(wr, a.w_in[g] + (long long)1 * D * D, D);           // slab order k, v, q
     const float4 lw = ld4(a.ln_w[g] + 4 * sub), lb = ld4(a.ln_b[g] + 4 * sub);
     tile_to_lds<D, BF>(As, xr);
@@ -63,6 +65,9 @@ __device__ __forceinline__ void qkv_fwd_body(const QkvFwdArgs& a, float* __restr
         if (s == 2) {                                     // the q slab: Qn sits in the A image, its global copy leaves under these MFMAs
             const ImageRowsPending<D> pq{As, a.qn + row0 * D, D, nrows};
             mma_tile<D, D, BF>(As, Ws, acc, pq);
+        } else if (s == 0 && xin != nullptr && !BF) {     // handed-over x: its global copy leaves under the k slab
+            const ImageRowsPending<D> px{As, const_cast<float*>(a.x) + row0 * D, D, nrows};
+            mma_tile<D, D, BF>(As, Ws, acc, px);
         } else {
             mma_tile<D, D, BF>(As, Ws, acc);
         }
@@ -248,8 +253,10 @@ struct OprojFfnFwdArgs {
     TileGeom tg;
 };
 
+// keep != nullptr: the layer output rows are ALSO left in registers for a fused successor (and in fp32 not stored here: the
+// successor stores them from its A image)
 template <int D, bool BF>
-__device__ __forceinline__ void oproj_ffn_fwd_body(const OprojFfnFwdArgs& a, float* __restrict__ smem, int tile) {
+__device__ __forceinline__ void oproj_ffn_fwd_body(const OprojFfnFwdArgs& a, float* __restrict__ smem, int tile, TileRegs<D>* keep = nullptr) {
     using RP = RowPass<D>;
     constexpr int LDC = D + 4;
     float* As = smem;
@@ -344,8 +351,9 @@ __device__ __forceinline__ void oproj_ffn_fwd_body(const OprojFfnFwdArgs& a, flo
 #pragma unroll
     for (int i = 0; i < RP::NR; ++i) {
         const int r = RP::first_row() + i * RP::RPP;
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < nrows) {
-            float4 z = f4add(ld4(Cs + r * LDC + 4 * sub), bias2);
+            z = f4add(ld4(Cs + r * LDC + 4 * sub), bias2);
             if (a.train) z = f4mul(z, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN2), step,
                                                     (unsigned long long)(local0 + r) * D + 4 * sub, a.thr16, a.scale));
             z = f4add(z, tr.v[i]);
@@ -356,8 +364,9 @@ __device__ __forceinline__ void oproj_ffn_fwd_body(const OprojFfnFwdArgs& a, flo
                 if (bits & 4u) z.z = 0.f;
                 if (bits & 8u) z.w = 0.f;
             }
-            st4(a.xo + (row0 + r) * D + 4 * sub, z);
+            if (keep == nullptr || BF) st4(a.xo + (row0 + r) * D + 4 * sub, z);
         }
+        if (keep != nullptr) keep->v[i] = z;
     }
 }
 
@@ -368,17 +377,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_ffn_fwd_kernel(const O
 }
 
 // layer l's out-projection + feed-forward followed by layer l + 1's LayerNorm + q / k / v projections on the same row tile, one
-// launch: the tile's rows of x[l + 1] are read back by the workgroup that has just written them (L2), and one launch + prologue
-// of the forward pass disappears
+// launch: the tile's rows of x[l + 1] stay in registers between the two bodies (their global copy, the saved layer input, is
+// written from the A image under the k slab's MFMAs), and one launch + prologue of the forward pass disappears
 struct OprojFfnQkvArgs { OprojFfnFwdArgs of; QkvFwdArgs qkv; TileGeom tg; };
 
 template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_oproj_ffn_qkv_fwd_kernel(const OprojFfnQkvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    oproj_ffn_fwd_body<D, BF>(a.of, smem, blockIdx.x);
-    __threadfence_block();      // workgroup scope is enough (rows written and read by the same workgroup, never read before);
-    __syncthreads();            // an agent-scope fence here costs 0.12 ms per step (L2 write-back + invalidate in 229 workgroups x 2)
-    qkv_fwd_body<D, BF>(a.qkv, smem, blockIdx.x);
+    TileRegs<D> xnext;          // layer l + 1's input rows go from the feed-forward epilogue to the q / k / v body in registers
+    oproj_ffn_fwd_body<D, BF>(a.of, smem, blockIdx.x, &xnext);
+    __syncthreads();            // the C image (= W region) of the last epilogue is read; the second body restages both LDS regions
+    qkv_fwd_body<D, BF>(a.qkv, smem, blockIdx.x, &xnext);
 }
 
 }  // namespace amid
