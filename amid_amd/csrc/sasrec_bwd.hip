@@ -80,8 +80,9 @@ struct FfnBwdArgs {
     TileGeomB tg;
 };
 
+// dzin != nullptr (fused behind the next layer's q / k / v backward): the incoming gradient rows arrive in registers
 template <int D, bool BF>
-__device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restrict__ smem, int tile) {
+__device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restrict__ smem, int tile, const TileRegs<D>* dzin = nullptr) {
     using RP = RowPass<D>;
     constexpr int LDC = D + 4;
     float* As = smem;
@@ -94,7 +95,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restr
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
     TileRegs<D> dz, aux;                                  // dz = dxo * ~tm is needed again for the residual path
     WRegs<D, D> wr;
-    load_tile<D>(dz, a.dxo, row0, nrows, D);
+    if (dzin != nullptr) dz = *dzin; else load_tile<D>(dz, a.dxo, row0, nrows, D);
     load_w<D, D>(wr, a.w2T[g], D);
     load_tile<D>(aux, a.h, row0, nrows, D);               // relu output: consumed by the first epilogue
     // 1. dpre2 = (dxo * ~tm) * drop2  -> A image + global
@@ -187,8 +188,9 @@ struct QkvBwdArgs {
     TileGeomB tg;
 };
 
+// keep != nullptr: the input-gradient rows are left in registers for a fused successor and NOT stored (nothing else reads them)
 template <int D, bool BF>
-__device__ __forceinline__ void qkv_bwd_body(const QkvBwdArgs& a, float* __restrict__ smem, int tile) {
+__device__ __forceinline__ void qkv_bwd_body(const QkvBwdArgs& a, float* __restrict__ smem, int tile, TileRegs<D>* keep = nullptr) {
     using RP = RowPass<D>;
     constexpr int LDC = D + 4;
     float* As = smem;
@@ -234,11 +236,14 @@ __device__ __forceinline__ void qkv_bwd_body(const QkvBwdArgs& a, float* __restr
 #pragma unroll
     for (int i = 0; i < RP::NR; ++i) {
         const int r = RP::first_row() + i * RP::RPP;
+        float4 dxv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < nrows) {
             const float4 dqn = f4add(ld4(Cq + r * LDC + 4 * sub), ar.v[i]);
             const float4 dxl = ln_bwd_row<RP::QPR>(dqn, xr.v[i], gam, D, a.ln_eps, dgam, dbet);
-            st4(a.dx + (row0 + r) * D + 4 * sub, f4add(dxl, ld4(Ckv + r * LDC + 4 * sub)));
+            dxv = f4add(dxl, ld4(Ckv + r * LDC + 4 * sub));
+            if (keep == nullptr) st4(a.dx + (row0 + r) * D + 4 * sub, dxv);
         }
+        if (keep != nullptr) keep->v[i] = dxv;
     }
     __syncthreads();
     ln_partials_out<D>(Ws, dgam, dbet, a.ln_part + (long long)tile * 2 * D);
@@ -257,16 +262,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_bwd_kernel(const QkvBwdA
 }
 
 // layer l + 1's q / k / v + LayerNorm1 backward followed by layer l's feed-forward / out-projection backward on the same row
-// tile, one launch: the tile's rows of d x[l + 1] are read back by the workgroup that has just written them
+// tile, one launch: the tile's rows of d x[l + 1] pass between the two bodies in registers (no HBM copy at all)
 struct QkvFfnBwdArgs { QkvBwdArgs qkv; FfnBwdArgs ffn; TileGeomB tg; };
 
 template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_ffn_bwd_kernel(const QkvFfnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    qkv_bwd_body<D, BF>(a.qkv, smem, blockIdx.x);
-    __threadfence_block();      // workgroup scope is enough (rows written and read by the same workgroup, never read before);
-    __syncthreads();            // an agent-scope fence here costs 0.12 ms per step (L2 write-back + invalidate in 229 workgroups x 2)
-    ffn_bwd_body<D, BF>(a.ffn, smem, blockIdx.x);
+    TileRegs<D> dxr;            // d x[l + 1] of the tile goes from one body to the other in registers and never to HBM
+    qkv_bwd_body<D, BF>(a.qkv, smem, blockIdx.x, &dxr);
+    __syncthreads();            // the first body's LDS scratch (LayerNorm partials) is read; the second restages both regions
+    ffn_bwd_body<D, BF>(a.ffn, smem, blockIdx.x, &dxr);
 }
 
 // ---------------------------------------------------------------------------------------------
