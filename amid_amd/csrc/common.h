@@ -21,19 +21,40 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // wave index made provably wave-uniform for the compiler (scalar addressing, no waterfall loops)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
-// butterfly reductions over `width` consecutive lanes (width = power of two <= 64)
-template <int WIDTH>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// All-reduce over `WIDTH` consecutive lanes (WIDTH = power of two <= 64).  Inside a row of 16 lanes the exchange is done by DPP
+// (quad_perm, row_half_mirror, row_mirror: plain VALU operands, a few cycles each); rows are combined through v_readlane.  The
+// __shfl_xor form (ds_bpermute_b32 through the LDS crossbar) cost ~200 cycles per dependent level -- 1 000 cycles for one
+// 32-lane LayerNorm statistic, seven of them back to back in every row pass.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+struct SumOp { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct MaxOp { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+
+template <int WIDTH, class OP>
+__device__ __forceinline__ float group_allreduce(float v, OP op) {
+    if constexpr (WIDTH >= 2) v = op(v, dpp_move<0xB1>(v));           // quad_perm [1,0,3,2]  : lane ^ 1
+    if constexpr (WIDTH >= 4) v = op(v, dpp_move<0x4E>(v));           // quad_perm [2,3,0,1]  : lane ^ 2
+    if constexpr (WIDTH >= 8) v = op(v, dpp_move<0x141>(v));          // row_half_mirror      : i <-> 7 - i  (the other quad)
+    if constexpr (WIDTH >= 16) v = op(v, dpp_move<0x140>(v));         // row_mirror           : i <-> 15 - i (the other half row)
+    if constexpr (WIDTH == 32) {
+        const float r0 = lane_value(v, 0), r1 = lane_value(v, 16), r2 = lane_value(v, 32), r3 = lane_value(v, 48);
+        v = (threadIdx.x & 32) ? op(r2, r3) : op(r0, r1);
+    }
+    if constexpr (WIDTH == 64) {
+        const float r0 = lane_value(v, 0), r1 = lane_value(v, 16), r2 = lane_value(v, 32), r3 = lane_value(v, 48);
+        v = op(op(r0, r1), op(r2, r3));
+    }
     return v;
 }
 template <int WIDTH>
-__device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return group_allreduce<WIDTH>(v, SumOp()); }
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) { return group_allreduce<WIDTH>(v, MaxOp()); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
