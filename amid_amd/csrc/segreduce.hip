@@ -62,7 +62,8 @@ __device__ __forceinline__ void segreduce_chunks_block(const float* __restrict__
     const bool valid = lane < cnt;
     const int mypos = valid ? pos_sorted[e0 + lane] : 0;
     const int mysg = valid ? seg_of[e0 + lane] : -1;
-    const int first_sg = __shfl(mysg, 0, 64), last_sg = __shfl(mysg, cnt - 1, 64);
+    // lane indices below are wave-uniform: v_readlane (a few cycles) instead of a ds_bpermute round trip per row
+    const int first_sg = __builtin_amdgcn_readlane(mysg, 0), last_sg = __builtin_amdgcn_readlane(mysg, __builtin_amdgcn_readfirstlane(cnt - 1));
     const bool starts_before = (e0 > 0) && (seg_of[e0 - 1] == first_sg);
     const bool continues_after = (e0 + cnt < n) && (seg_of[e0 + cnt] == last_sg);
     RowVec<VEC> acc;
@@ -80,12 +81,12 @@ __device__ __forceinline__ void segreduce_chunks_block(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int src = min(i + j, cnt - 1);
-            r[j] = load_row<VEC>(grad_rows, __shfl(mypos, src, 64), D, lane);
+            r[j] = load_row<VEC>(grad_rows, __builtin_amdgcn_readlane(mypos, __builtin_amdgcn_readfirstlane(src)), D, lane);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (i + j < cnt) {
-                const int sg = __shfl(mysg, i + j, 64);
+                const int sg = __builtin_amdgcn_readlane(mysg, __builtin_amdgcn_readfirstlane(i + j));
                 if (sg != cur) {
                     flush(cur);
                     cur = sg;
