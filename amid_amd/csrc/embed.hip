@@ -223,6 +223,17 @@ __global__ __launch_bounds__(256) void key_keep_kernel(const long long* __restri
     if (i < n) keep[i] = seq[i] > 0 ? 1 : 0;
 }
 
+// the same mask tiled `reps` times along the key axis: keep[b][r * T + t] = seq[b][t] > 0 (model_seq.py:286, :294 `.repeat(1, n, 2)`)
+__global__ __launch_bounds__(256) void key_keep_tiled_kernel(const long long* __restrict__ seq, int B, int T, int reps,
+                                                             unsigned char* __restrict__ keep) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)B * T * reps;
+    if (i >= n) return;
+    const int b = (int)(i / ((long long)T * reps));
+    const int t = (int)(i % T);
+    keep[i] = seq[(long long)b * T + t] > 0 ? 1 : 0;
+}
+
 }  // namespace amid
 
 using namespace amid;
@@ -300,6 +311,14 @@ extern "C" int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, i
                                                                                                (const RngState*)rng_state, tr,
                                                                                                keep_thr16(p_drop),
                                                                                                tr ? 1.0f / (1.0f - p_drop) : 1.0f);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_key_keep_tiled_u8(const long long* seq, int B, int T, int reps, unsigned char* keep, void* stream) {
+    AMID_CHECK_ARG(seq && keep && B > 0 && T > 0 && reps > 0);
+    const long long n = (long long)B * T * reps;
+    key_keep_tiled_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(seq, B, T, reps, keep);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

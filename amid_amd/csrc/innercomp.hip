@@ -19,8 +19,9 @@
 
 namespace amid {
 
-// ---- s[g][j]: one workgroup per (row j, domain g); the row's T gathered rows in LDS, all pairs a <= c ----
-__global__ __launch_bounds__(256) void inc_score_kernel(const float* __restrict__ xg, int B, int T, int D, float* __restrict__ s) {
+// ---- s[g][j]: one workgroup per (row j, domain g); the row's T gathered rows in LDS, all pairs a <= c.  cross (InterComp in front
+// of BERT4Rec's encoders, model_seq.py:289-293): a runs over domain g's rows and c over the OTHER domain's, all T x T pairs ----
+__global__ __launch_bounds__(256) void inc_score_kernel(const float* __restrict__ xg, int B, int T, int D, int cross, float* __restrict__ s) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[4];
     const int LD = D + 4, q = D >> 2;
@@ -30,13 +31,23 @@ __global__ __launch_bounds__(256) void inc_score_kernel(const float* __restrict_
         const int t = i / q, c = i - t * q;
         st4(smem + t * LD + 4 * c, ld4(e + (long long)t * D + 4 * c));
     }
+    const float* other = smem;
+    if (cross) {
+        const float* e2 = xg + ((long long)(1 - g) * B + j) * T * D;
+        float* o2 = smem + T * LD;
+        for (int i = threadIdx.x; i < T * q; i += 256) {
+            const int t = i / q, c = i - t * q;
+            st4(o2 + t * LD + 4 * c, ld4(e2 + (long long)t * D + 4 * c));
+        }
+        other = o2;
+    }
     __syncthreads();
     float best = -INFINITY;
     for (int p = threadIdx.x; p < T * T; p += 256) {
         const int a = p / T, c = p - a * T;
-        if (c < a) continue;
+        if (!cross && c < a) continue;
         const float* fa = smem + a * LD;
-        const float* fc = smem + c * LD;
+        const float* fc = other + c * LD;
         float acc = 0.f;
         for (int k = 0; k < q; ++k) {
             const float4 u = ld4(fa + 4 * k), v = ld4(fc + 4 * k);
@@ -56,6 +67,7 @@ struct IncFwdArgs {
     const float* w_nn[2]; const float* b_nn[2]; const float* w_bs[2]; const float* b_bs[2];
     float threshold;
     int B, T, D;
+    int cross;                           // 1: module g mixes the OTHER domain's rows (InterComp), 0: its own (InnerComp)
     float* gate;                         // [2, B]
     float* S;                            // [2, T, D]
     float* Z;                            // [2, T, D]
@@ -83,6 +95,7 @@ __global__ __launch_bounds__(256) void inc_mix_fwd_kernel(const IncFwdArgs a) {
     __shared__ float red[4];
     const int B = a.B, T = a.T, D = a.D, q = D >> 2;
     const int t = blockIdx.x, g = blockIdx.y;
+    const int sd = a.cross ? 1 - g : g;
     float* cj = smem;
     float* part = smem + ((B + 3) & ~3);
     float* Srow = part + 8 * D;
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(256) void inc_mix_fwd_kernel(const IncFwdArgs a) {
         for (int j = rg; j < B; j += 8) {
             const float w = cj[j];
             if (w != 0.f) {
-                const float4 v = ld4(a.xg + (((long long)g * B + j) * T + t) * D + 4 * c);
+                const float4 v = ld4(a.xg + (((long long)sd * B + j) * T + t) * D + 4 * c);
                 acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
             }
         }
@@ -148,9 +161,10 @@ __global__ __launch_bounds__(256) void inc_embed_fwd_kernel(const float* __restr
         const int local = r - g * Me;
         const int b = local / Te, t = local - b * Te;
         const float* src = (t < T) ? xg + (((long long)g * B + b) * T + t) * D : Z + ((long long)g * T + (t - T)) * D;
-        const float* pp = (g ? pos1 : pos0) + (long long)t * D;
+        const float* pp = pos0 ? (g ? pos1 : pos0) + (long long)t * D : nullptr;        // BERT4Rec: no positional rows
         for (int c = sub; c < q; c += 32) {
-            float4 x = f4add(ld4(src + 4 * c), ld4(pp + 4 * c));
+            float4 x = ld4(src + 4 * c);
+            if (pp) x = f4add(x, ld4(pp + 4 * c));
             const unsigned bits = (x.x == 0.f ? 1u : 0u) | (x.y == 0.f ? 2u : 0u) | (x.z == 0.f ? 4u : 0u) | (x.w == 0.f ? 8u : 0u);
             if (train) x = f4mul(x, dropout_mult4(seed, site_id(g, 0, SITE_EMB), step, (unsigned long long)local * D + 4 * c, thr16, scale));
             if (bits) {
@@ -159,15 +173,16 @@ __global__ __launch_bounds__(256) void inc_embed_fwd_kernel(const float* __restr
                 if (bits & 4u) x.z = 0.f;
                 if (bits & 8u) x.w = 0.f;
             }
-            tmq[(long long)r * q + c] = (unsigned char)bits;
+            if (tmq) tmq[(long long)r * q + c] = (unsigned char)bits;
             st4(x0 + (long long)r * D + 4 * c, x);
         }
     }
 }
 
 struct IncBwdArgs {
-    const float* dpos_part;              // [nsplit][2][2T][D] partials of the embedding backward (rows T.. are dZ's partials)
-    int nsplit;
+    const float* dpos_part;              // [nsplit][2][2T][D] partials of the embedding backward (rows T.. are dZ's partials);
+    int nsplit;                          // nullptr: no embedding backward ran (BERT4Rec) -- dZ[t] = sum_b dx0[b, T + t] is formed here
+    int cross;                           // as IncFwdArgs
     const float* xg;                     // [2, B, T, D]
     const float* dx0;                    // [2, B, 2T, D] encoder-input gradient after the dropout / mask backward
     const float* gate; const float* S; const float* sw;
@@ -182,14 +197,30 @@ struct IncBwdArgs {
 
 // ---- grid (T, 2): dZ[t] (fixed-order sum of the partials), dS[t] = dZ[t] W_nn, the two row sums ----
 __global__ __launch_bounds__(256) void inc_dz_kernel(const IncBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // dZ row [D]
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // dZ row [D] | column partials [256 / D][D]
     __shared__ float red[4];
-    const int T = a.T, D = a.D;
+    const int B = a.B, T = a.T, D = a.D;
     const int t = blockIdx.x, g = blockIdx.y;
+    if (!a.dpos_part) {                  // fixed-order column sum over the batch, 256 / D interleaved partial sums per column
+        const int nh = 256 / D > 0 ? 256 / D : 1;
+        float* cp = smem + D;
+        for (int i = threadIdx.x; i < nh * D; i += 256) {
+            const int d = i % D, h = i / D;
+            float v = 0.f;
+            for (int j = h; j < B; j += nh) v += a.dx0[(((long long)g * B + j) * 2 * T + T + t) * D + d];
+            cp[h * D + d] = v;
+        }
+        __syncthreads();
+    }
     float rs = 0.f, rb = 0.f;
     for (int d = threadIdx.x; d < D; d += 256) {
         float v = 0.f;
-        for (int z = 0; z < a.nsplit; ++z) v += a.dpos_part[(((long long)z * 2 + g) * 2 * T + T + t) * D + d];
+        if (a.dpos_part) {
+            for (int z = 0; z < a.nsplit; ++z) v += a.dpos_part[(((long long)z * 2 + g) * 2 * T + T + t) * D + d];
+        } else {
+            const int nh = 256 / D > 0 ? 256 / D : 1;
+            for (int h = 0; h < nh; ++h) v += smem[D + h * D + d];
+        }
         smem[d] = v;
         a.dZ[((long long)g * T + t) * D + d] = v;
         rs += v;
@@ -228,16 +259,18 @@ __global__ __launch_bounds__(256) void inc_wgrad_kernel(const IncBwdArgs a) {
     }
 }
 
-// ---- grid (B, 2): dw_bs[j] and the row's table-row gradients ----
+// ---- grid (B, 2): dw_bs[j] of module g and the table-row gradients of the rows it mixed (its own domain's, or with cross the
+// other domain's: every (j, domain) is the source of exactly one module either way, so the output is covered once) ----
 __global__ __launch_bounds__(256) void inc_scatter_bwd_kernel(const IncBwdArgs a) {
     __shared__ float red[4];
     const int B = a.B, T = a.T, D = a.D, q = D >> 2;
     const int j = blockIdx.x, g = blockIdx.y;
+    const int sd = a.cross ? 1 - g : g;
     const float gt = a.gate[g * B + j];
     const float cj = a.w_bs[g][j] * gt;
-    const float* e = a.xg + ((long long)g * B + j) * T * D;
-    const float* dx = a.dx0 + ((long long)g * B + j) * 2 * T * D;      // the row's own half: tokens 0..T-1 of its 2T
-    float* out = a.dxg + ((long long)g * B + j) * T * D;
+    const float* e = a.xg + ((long long)sd * B + j) * T * D;
+    const float* dx = a.dx0 + ((long long)sd * B + j) * 2 * T * D;     // the row's own half: tokens 0..T-1 of its 2T
+    float* out = a.dxg + ((long long)sd * B + j) * T * D;
     const float* dS = a.dS + (long long)g * T * D;
     float dot = 0.f;
     for (int i = threadIdx.x; i < T * q; i += 256) {
@@ -256,27 +289,27 @@ __global__ __launch_bounds__(256) void inc_scatter_bwd_kernel(const IncBwdArgs a
 
 using namespace amid;
 
-extern "C" int amid_inc_score_f32(const float* xg, int B, int T, int D, float* s, void* stream) {
+static int comp_score(const float* xg, int B, int T, int D, int cross, float* s, void* stream) {
     AMID_CHECK_ARG(xg && s && B > 0 && T > 0 && D > 0 && (D % 4) == 0);
-    const size_t lds = (size_t)T * (D + 4) * sizeof(float);
+    const size_t lds = (size_t)(cross ? 2 : 1) * T * (D + 4) * sizeof(float);
     if (lds > 160 * 1024 - 256) return AMID_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)inc_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    inc_score_kernel<<<dim3(B, 2), 256, lds, (hipStream_t)stream>>>(xg, B, T, D, s);
+    inc_score_kernel<<<dim3(B, 2), 256, lds, (hipStream_t)stream>>>(xg, B, T, D, cross, s);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
 
-extern "C" int amid_inc_embed_fwd_f32(const float* xg, const float* s, const float* const* w_nn, const float* const* b_nn,
-                                      const float* const* w_bs, const float* const* b_bs, float threshold, const float* pos0,
-                                      const float* pos1, int B, int T, int D, float* gate, float* S, float* Z, float* sw, float* x0,
-                                      unsigned char* tmq, const void* step_state, int train, float p_drop, void* stream) {
-    AMID_CHECK_ARG(xg && s && w_nn && b_nn && w_bs && b_bs && pos0 && pos1 && gate && S && Z && sw && x0 && tmq);
+static int comp_tokens_fwd(const float* xg, const float* s, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs,
+                           const float* const* b_bs, float threshold, int cross, const float* pos0, const float* pos1, int B, int T, int D,
+                           float* gate, float* S, float* Z, float* sw, float* x0, unsigned char* tmq, const void* step_state, int train,
+                           float p_drop, void* stream) {
+    AMID_CHECK_ARG(xg && s && w_nn && b_nn && w_bs && b_bs && gate && S && Z && sw && x0 && (!pos0 == !pos1));
     AMID_CHECK_ARG(B > 0 && T > 0 && D > 0 && (D % 4) == 0 && D <= 256 && (!train || step_state));
     IncFwdArgs a;
-    a.xg = xg; a.s = s; a.threshold = threshold; a.B = B; a.T = T; a.D = D; a.gate = gate; a.S = S; a.Z = Z; a.sw = sw;
+    a.xg = xg; a.s = s; a.threshold = threshold; a.B = B; a.T = T; a.D = D; a.cross = cross ? 1 : 0; a.gate = gate; a.S = S; a.Z = Z; a.sw = sw;
     for (int g = 0; g < 2; ++g) {
         AMID_CHECK_ARG(w_nn[g] && b_nn[g] && w_bs[g] && b_bs[g]);
         a.w_nn[g] = w_nn[g]; a.b_nn[g] = b_nn[g]; a.w_bs[g] = w_bs[g]; a.b_bs[g] = b_bs[g];
@@ -295,26 +328,69 @@ extern "C" int amid_inc_embed_fwd_f32(const float* xg, const float* s, const flo
     return AMID_OK;
 }
 
-extern "C" int amid_inc_bwd_f32(const float* dpos_part, int nsplit, const float* xg, const float* dx0, const float* gate, const float* S,
-                                const float* sw, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int T,
-                                int D, float* dZ, float* dS, float* rows, float* const* dw_nn, float* const* db_nn, float* const* dw_bs,
-                                float* const* db_bs, float* dxg, void* stream) {
-    AMID_CHECK_ARG(dpos_part && nsplit > 0 && xg && dx0 && gate && S && sw && w_nn && b_nn && w_bs && dZ && dS && rows && dw_nn && db_nn &&
-                   dw_bs && db_bs && dxg && B > 0 && T > 0 && D > 0 && (D % 4) == 0);
+static int comp_tokens_bwd(const float* dpos_part, int nsplit, int cross, const float* xg, const float* dx0, const float* gate, const float* S,
+                           const float* sw, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int T,
+                           int D, float* dZ, float* dS, float* rows, float* const* dw_nn, float* const* db_nn, float* const* dw_bs,
+                           float* const* db_bs, float* dxg, void* stream) {
+    AMID_CHECK_ARG((!dpos_part || nsplit > 0) && xg && dx0 && gate && S && sw && w_nn && b_nn && w_bs && dZ && dS && rows && dw_nn && db_nn &&
+                   dw_bs && db_bs && dxg && B > 0 && T > 0 && D > 0 && (D % 4) == 0 && D <= 256);
     IncBwdArgs a;
-    a.dpos_part = dpos_part; a.nsplit = nsplit; a.xg = xg; a.dx0 = dx0; a.gate = gate; a.S = S; a.sw = sw; a.B = B; a.T = T; a.D = D;
-    a.dZ = dZ; a.dS = dS; a.rows = rows; a.dxg = dxg;
+    a.dpos_part = dpos_part; a.nsplit = nsplit; a.cross = cross ? 1 : 0; a.xg = xg; a.dx0 = dx0; a.gate = gate; a.S = S; a.sw = sw;
+    a.B = B; a.T = T; a.D = D; a.dZ = dZ; a.dS = dS; a.rows = rows; a.dxg = dxg;
     for (int g = 0; g < 2; ++g) {
         AMID_CHECK_ARG(w_nn[g] && b_nn[g] && w_bs[g] && dw_nn[g] && db_nn[g] && dw_bs[g] && db_bs[g]);
         a.w_nn[g] = w_nn[g]; a.b_nn[g] = b_nn[g]; a.w_bs[g] = w_bs[g];
         a.dw_nn[g] = dw_nn[g]; a.db_nn[g] = db_nn[g]; a.dw_bs[g] = dw_bs[g]; a.db_bs[g] = db_bs[g];
     }
     hipStream_t st = (hipStream_t)stream;
-    inc_dz_kernel<<<dim3(T, 2), 256, (size_t)D * sizeof(float), st>>>(a);
+    const int nh = 256 / D > 0 ? 256 / D : 1;
+    inc_dz_kernel<<<dim3(T, 2), 256, (size_t)(1 + nh) * D * sizeof(float), st>>>(a);
     AMID_LAUNCH_CHECK();
     inc_wgrad_kernel<<<dim3(D, 2), 256, 0, st>>>(a);
     AMID_LAUNCH_CHECK();
     inc_scatter_bwd_kernel<<<dim3(B, 2), 256, 0, st>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+
+extern "C" int amid_inc_score_f32(const float* xg, int B, int T, int D, float* s, void* stream) {
+    return comp_score(xg, B, T, D, 0, s, stream);
+}
+
+extern "C" int amid_inc_embed_fwd_f32(const float* xg, const float* s, const float* const* w_nn, const float* const* b_nn,
+                                      const float* const* w_bs, const float* const* b_bs, float threshold, const float* pos0,
+                                      const float* pos1, int B, int T, int D, float* gate, float* S, float* Z, float* sw, float* x0,
+                                      unsigned char* tmq, const void* step_state, int train, float p_drop, void* stream) {
+    AMID_CHECK_ARG(pos0 && pos1 && tmq);
+    return comp_tokens_fwd(xg, s, w_nn, b_nn, w_bs, b_bs, threshold, 0, pos0, pos1, B, T, D, gate, S, Z, sw, x0, tmq, step_state, train, p_drop,
+                           stream);
+}
+
+extern "C" int amid_inc_bwd_f32(const float* dpos_part, int nsplit, const float* xg, const float* dx0, const float* gate, const float* S,
+                                const float* sw, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int T,
+                                int D, float* dZ, float* dS, float* rows, float* const* dw_nn, float* const* db_nn, float* const* dw_bs,
+                                float* const* db_bs, float* dxg, void* stream) {
+    AMID_CHECK_ARG(dpos_part);
+    return comp_tokens_bwd(dpos_part, nsplit, 0, xg, dx0, gate, S, sw, w_nn, b_nn, w_bs, B, T, D, dZ, dS, rows, dw_nn, db_nn, dw_bs, db_bs, dxg,
+                           stream);
+}
+
+// ---- the same token group in front of BERT4Rec's encoders (model_seq.py:283-294): no positional rows, no input dropout ----
+extern "C" int amid_bert_comp_score_f32(const float* xg, int B, int T, int D, int cross, float* s, void* stream) {
+    return comp_score(xg, B, T, D, cross ? 1 : 0, s, stream);
+}
+
+extern "C" int amid_bert_comp_fwd_f32(const float* xg, const float* s, const float* const* w_nn, const float* const* b_nn,
+                                      const float* const* w_bs, const float* const* b_bs, float threshold, int cross, int B, int T, int D,
+                                      float* gate, float* S, float* Z, float* sw, float* x0, void* stream) {
+    return comp_tokens_fwd(xg, s, w_nn, b_nn, w_bs, b_bs, threshold, cross, nullptr, nullptr, B, T, D, gate, S, Z, sw, x0, nullptr, nullptr, 0, 0.f,
+                           stream);
+}
+
+extern "C" int amid_bert_comp_bwd_f32(const float* xg, const float* dx0, const float* gate, const float* S, const float* sw,
+                                      const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int cross, int B, int T,
+                                      int D, float* dZ, float* dS, float* rows, float* const* dw_nn, float* const* db_nn, float* const* dw_bs,
+                                      float* const* db_bs, float* dxg, void* stream) {
+    return comp_tokens_bwd(nullptr, 0, cross, xg, dx0, gate, S, sw, w_nn, b_nn, w_bs, B, T, D, dZ, dS, rows, dw_nn, db_nn, dw_bs, db_bs, dxg,
+                           stream);
 }

@@ -17,11 +17,18 @@ from .engine import SasrecEngine, SasrecPlan
 BERT_HEADS, BERT_FF, BERT_P_DROP, BERT_HIDDEN = 4, 512, 0.1, 128
 
 
-def bert4rec_dense_names(hid: int, dr: bool = False) -> List[Tuple[str, Tuple[int, ...]]]:
+def bert4rec_dense_names(hid: int, dr: bool = False, comp: str = "", comp_bs: int = 0) -> List[Tuple[str, Tuple[int, ...]]]:
     """Non-table parameters in the reference's state_dict order; dr: with the predict_ips / predict_gfunc heads of isDR=True
-    (model_seq.py:268-271)."""
+    (model_seq.py:268-271); comp = "inc" / "itc": with the InnerComp / InterComp modules of isInC / isItC at bs = comp_bs
+    (:257-263)."""
     D, F = BERT_HIDDEN, BERT_FF
     out: List[Tuple[str, Tuple[int, ...]]] = []
+    if comp:
+        for d in (1, 2):
+            out.append((f"{comp}_d{d}.trans_nn.weight", (D, D)))
+            out.append((f"{comp}_d{d}.trans_nn.bias", (D,)))
+            out.append((f"{comp}_d{d}.trans_bs.weight", (1, comp_bs)))
+            out.append((f"{comp}_d{d}.trans_bs.bias", (1,)))
     for d in (1, 2):
         for l in (0, 1):
             pre = f"transform{d}.{l}"
@@ -52,7 +59,7 @@ N_ENT = 12      # weight-gradient tiles of 128 x 128 per block: q, k, v, o, 4 x 
 class BertPlan(SasrecPlan):
     def _alloc_model_fwd(self, eng, f) -> None:
         M, D, F = self.shape.M, eng.D, BERT_FF
-        self.key_keep = torch.zeros(self.shape.B, self.shape.T, dtype=torch.uint8, device=eng.device)
+        self.key_keep = torch.zeros(self.shape.B, self.shape.Tenc, dtype=torch.uint8, device=eng.device)
         self.y = [f(2 * M, D) for _ in range(2)]        # LNb_in(x)
         self.x1 = [f(2 * M, D) for _ in range(2)]
         self.y2 = [f(2 * M, D) for _ in range(2)]       # LNb_out(x1)
@@ -101,17 +108,30 @@ class Bert4recEngine(SasrecEngine):
     EMB_DIMS = (BERT_HIDDEN,)
     SHORT_TILE_BUILDS = True
 
+    def __init__(self, *args, comp: str = "", comp_bs: int = 0, comp_threshold: float = 0.5, **kw):
+        """comp = "inc" / "itc": BERT4Rec(isInC=True) / (isItC=True) with bs = comp_bs and threshold1 / threshold2 = comp_threshold:
+        the comp module runs on the gathered rows in FRONT of the encoders (model_seq.py:283-294; csrc/innercomp.hip), which then
+        see 2T tokens per row under the T-token key mask tiled twice; every batch must hold exactly comp_bs rows.  The reference
+        itself fails with both flags (2T mask keys for 4T tokens, :294), so there is no combined mode."""
+        if comp not in ("", "inc", "itc"):
+            raise ValueError(f"comp must be '', 'inc' or 'itc', got {comp!r}")
+        if comp and comp_bs <= 0:
+            raise ValueError("comp needs comp_bs = the reference's bs argument")
+        self.comp, self.comp_cross = comp, 1 if comp == "itc" else 0
+        # the base plan's isInC workspace (separate 2T-token encoder input, token-group buffers) is exactly what both modes need
+        super().__init__(*args, inc_bs=comp_bs if comp else 0, inc_threshold=comp_threshold, **kw)
+
     def _dense_names(self):
-        return bert4rec_dense_names(self.hid, self.dr)
+        return bert4rec_dense_names(self.hid, self.dr, self.comp, self.inc_bs)
 
     # BERT4Rec has no last LayerNorm: the user vectors are the plain means over time (model_seq.py:299-300)
     def _enqueue_user_vectors(self, pl) -> None:
         shp = pl.shape
-        lib().call("amid_lnmean_fwd_f32", pl.x[2].data_ptr(), None, None, None, None, shp.B, shp.T, self.D, 0.0, pl.u.data_ptr(), self.s)
+        lib().call("amid_lnmean_fwd_f32", pl.x[2].data_ptr(), None, None, None, None, shp.B, shp.Tenc, self.D, 0.0, pl.u.data_ptr(), self.s)
 
     def _enqueue_user_vectors_bwd(self, pl) -> None:
         shp = pl.shape
-        lib().call("amid_lnmean_bwd_f32", pl.x[2].data_ptr(), pl.du.data_ptr(), None, None, shp.B, shp.T, self.D, 0.0, pl.dxbuf.data_ptr(), None,
+        lib().call("amid_lnmean_bwd_f32", pl.x[2].data_ptr(), pl.du.data_ptr(), None, None, shp.B, shp.Tenc, self.D, 0.0, pl.dxbuf.data_ptr(), None,
                    self.s)
 
     def _alloc_model_buffers(self) -> None:
@@ -123,14 +143,24 @@ class Bert4recEngine(SasrecEngine):
 
     def enqueue_forward(self, pl: BertPlan, train: bool, with_loss: bool, sum_loss: bool = True) -> None:
         L, s, shp, D = lib(), self.s, pl.shape, self.D
-        B, T, NI, M = shp.B, shp.T, shp.NI, shp.M
+        B, T, NI, M = shp.B, shp.Tenc, shp.NI, shp.M
         st = self.step_state.data_ptr()
         tr = 1 if train else 0
         fp = self.dense
         # model_seq.py:288: ONE mask, from domain 2, for both encoders
-        L.call("amid_key_keep_u8", pl.in_seq_d2.data_ptr(), B * T, pl.key_keep.data_ptr(), s)
-        L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI, pl.xg.data_ptr(), None, st, 0,
-               0.0, s)
+        if self.comp:      # :286 / :294 the T-token mask tiled twice over the 2T keys; the comp module's token group behind each row
+            c = self.comp
+            L.call("amid_key_keep_tiled_u8", pl.in_seq_d2.data_ptr(), B, shp.T, 2, pl.key_keep.data_ptr(), s)
+            L.call("amid_gather_rows_f32", self.table.data_ptr(), self.n_rows, D, pl.idx_all.data_ptr(), 0, shp.n_idx, pl.xg.data_ptr(), None, s)
+            L.call("amid_bert_comp_score_f32", pl.xg.data_ptr(), B, shp.T, D, self.comp_cross, pl.inc_s.data_ptr(), s)
+            L.call("amid_bert_comp_fwd_f32", pl.xg.data_ptr(), pl.inc_s.data_ptr(), self._pp(c + "_d{d}.trans_nn.weight"),
+                   self._pp(c + "_d{d}.trans_nn.bias"), self._pp(c + "_d{d}.trans_bs.weight"), self._pp(c + "_d{d}.trans_bs.bias"),
+                   self.inc_threshold, self.comp_cross, B, shp.T, D, pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(), pl.inc_Z.data_ptr(),
+                   pl.inc_sw.data_ptr(), pl.x[0].data_ptr(), s)
+        else:
+            L.call("amid_key_keep_u8", pl.in_seq_d2.data_ptr(), B * T, pl.key_keep.data_ptr(), s)
+            L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI, pl.xg.data_ptr(), None, st, 0,
+                   0.0, s)
         for l in (0, 1):
             pre = f"transform{{d}}.{l}"
             w3 = ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.weight") for j in range(3) for d in (1, 2)])
@@ -146,7 +176,7 @@ class Bert4recEngine(SasrecEngine):
                    pl.y2[l].data_ptr(), pl.pre[l].data_ptr(), pl.h[l].data_ptr(), s)
             L.call("amid_bert_ffn2_fwd_f32" + pl.rt_suffix, pl.h[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".feed_forward.w_2.weight"),
                    self._pp(pre + ".feed_forward.w_2.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x[l + 1].data_ptr(), s)
-        items = pl.xg.data_ptr() + 4 * 2 * M * D
+        items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
         if self.dr:                                  # three heads (model_seq.py:301-305) on the plain means
             if getattr(self, "_fuse_scorers", False) and with_loss and not sum_loss:
                 self._enqueue_user_vectors(pl)       # the scorers run as ONE forward + loss + backward launch in enqueue_backward
@@ -165,7 +195,7 @@ class Bert4recEngine(SasrecEngine):
 
     def enqueue_backward(self, pl: BertPlan, train: bool) -> None:
         L, s, shp, D, F = lib(), self.s, pl.shape, self.D, BERT_FF
-        B, T, NI, M = shp.B, shp.T, shp.NI, shp.M
+        B, T, NI, M = shp.B, shp.Tenc, shp.NI, shp.M
         st = self.step_state.data_ptr()
         tr = 1 if train else 0
         fp = self.dense
@@ -182,8 +212,8 @@ class Bert4recEngine(SasrecEngine):
         import ctypes
         L.call("amid_transpose_rect_f32", ptr_array(src), ptr_array(dst), (ctypes.c_int * len(rows))(*rows), (ctypes.c_int * len(cols))(*cols),
                len(src), s)
-        items = pl.xg.data_ptr() + 4 * 2 * M * D
-        ditems = pl.dxg.data_ptr() + 4 * 2 * M * D
+        items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
+        ditems = pl.dxg.data_ptr() + 4 * 2 * shp.Mi * D
         if self.dr and getattr(self, "_fuse_scorers", False):
             self._enqueue_scorers_fused(pl, items, ditems, None, None, 0)
             self._enqueue_user_vectors_bwd(pl)
@@ -211,7 +241,7 @@ class Bert4recEngine(SasrecEngine):
             L.call("amid_attn_bwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(), pl.stats[l].data_ptr(),
                    pl.d_o.data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l, st, tr, BERT_P_DROP, pl.dq.data_ptr(), pl.dk.data_ptr(),
                    pl.dv.data_ptr(), s)
-            dx_out = pl.dxg if l == 0 else pl.dxbuf
+            dx_out = (pl.dx0 if self.comp else pl.dxg) if l == 0 else pl.dxbuf
             wT3 = ptr_array([self.wT_sq[l, g, j].data_ptr() for j in range(3) for g in (0, 1)])
             # weight-gradient tiles need dx-independent operands only: launch before qkv_bwd overwrites dxbuf
             dy = [pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dt.data_ptr()]
@@ -227,4 +257,11 @@ class Bert4recEngine(SasrecEngine):
                    pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), s)
             L.call("amid_bert_qkv_bwd_f32" + pl.rt_suffix, pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[l].data_ptr(),
                    self._pp(pre + ".input_sublayer.norm.a_2"), wT3, M, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), s)
+        if self.comp:      # the comp modules' parameter gradients; the rows' own halves + their share of the token group -> dxg
+            c, G = self.comp, self.dense.grad
+            L.call("amid_bert_comp_bwd_f32", pl.xg.data_ptr(), pl.dx0.data_ptr(), pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(),
+                   pl.inc_sw.data_ptr(), self._pp(c + "_d{d}.trans_nn.weight"), self._pp(c + "_d{d}.trans_nn.bias"),
+                   self._pp(c + "_d{d}.trans_bs.weight"), self.comp_cross, B, shp.T, D, pl.inc_dZ.data_ptr(), pl.inc_dS.data_ptr(),
+                   pl.inc_rows.data_ptr(), self._pp(c + "_d{d}.trans_nn.weight", G), self._pp(c + "_d{d}.trans_nn.bias", G),
+                   self._pp(c + "_d{d}.trans_bs.weight", G), self._pp(c + "_d{d}.trans_bs.bias", G), pl.dxg.data_ptr(), s)
         self._enqueue_grad_tail(pl)

@@ -24,8 +24,8 @@ are accepted and ignored; dropout follows ``module.training``.  Two ways to trai
                    Adam as one hipGraph replay -- what ``train_sr.py`` of this repo and ``bench.py`` use.
 
 Out of scope this round (constructors kept for import / state_dict parity, ``forward`` raises):
-GRU4Rec (recurrent), the standalone InnerComp / InterComp modules, BERT4Rec with isInC / isItC (isItC there puts the
-appended token group in FRONT of the encoders), embUserLayerEnhance (dead code in the reference).
+GRU4Rec (recurrent), embUserLayerEnhance (dead code in the reference).  BERT4Rec(isInC=True) / (isItC=True) -- the comp module in
+FRONT of the encoders, model_seq.py:283-294 -- are built (the reference itself fails with both flags).
 SASRec(isItC=True, isDR=True) -- InterComp after the encoders + the doubly-robust heads, what run.sh trains through
 train_sr_dr.py -- IS built (csrc/intercomp.hip, amid_dr_loss_f32), and so is SASRec(isInC=True) -- InnerComp on the gathered rows
 before the encoders, which then run over 2 * seq_len tokens (csrc/innercomp.hip).
@@ -37,7 +37,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
-from ._lib import lib
+from ._lib import lib, ptr_array
 from .engine import SASREC_LN_EPS, SasrecEngine
 from .engine_bert import Bert4recEngine
 
@@ -122,7 +122,7 @@ class SASRec(nn.Module):
     predict_gfunc.*)."""
 
     ENGINE_CLS = SasrecEngine
-    SUPPORTS_ITC = True          # InterComp after the encoders (model_seq.py:426-431), the configuration run.sh trains
+    COMP_IN_FRONT = False        # InterComp after the encoders (model_seq.py:426-431), the configuration run.sh trains
 
     def __init__(self, user_length, user_emb_dim, item_length, item_emb_dim, seq_len, hid_dim, bs, isInC, isItC, threshold1,
                  threshold2, isDR=False, device: Optional[str] = None, lr: float = 5e-4, seed: int = 0, compute: str = "f32"):
@@ -130,19 +130,24 @@ class SASRec(nn.Module):
         compute ("f32": exact fp32 matrix products, the default; "bf16": bf16 MFMA operands with fp32 accumulation, SASRec with
         emb_dim 128 only -- BASELINE.json configs[2])."""
         super().__init__()
-        if isInC and not self.SUPPORTS_ITC:
-            _not_built("InnerComp (isInC) for this model", "model_seq.py:283-285")
-        if isItC and not self.SUPPORTS_ITC:
-            _not_built("InterComp (isItC) for this model", "model_seq.py:289-294")
+        if isInC and isItC and self.COMP_IN_FRONT:
+            raise ValueError("BERT4Rec(isInC=True, isItC=True): the reference itself fails on this combination (its key mask keeps 2T "
+                             "keys for 4T tokens, model_seq.py:294); pick one")
         if user_emb_dim != item_emb_dim:
             raise ValueError("the reference feeds item rows into encoders built with user_emb_dim: the two must be equal")
         lib()                                                   # fail loudly without libamid_hip.so
         self.user_emb_dim = user_emb_dim
         self.isInC, self.isItC, self.isDR = isInC, isItC, isDR
         dev = device or ("cuda:%d" % torch.cuda.current_device())
-        kw = dict(itc_bs=bs, itc_threshold=threshold2) if isItC else {}
-        if isInC:
-            kw.update(inc_bs=bs, inc_threshold=threshold1)
+        kw = {}
+        if self.COMP_IN_FRONT:          # BERT4Rec: either module runs on the gathered rows, before the encoders (:283-294)
+            if isInC or isItC:
+                kw.update(comp="inc" if isInC else "itc", comp_bs=bs, comp_threshold=threshold1 if isInC else threshold2)
+        else:
+            if isItC:
+                kw.update(itc_bs=bs, itc_threshold=threshold2)
+            if isInC:
+                kw.update(inc_bs=bs, inc_threshold=threshold1)
         if isDR:
             kw["dr"] = True
         if compute != "f32":
@@ -448,6 +453,58 @@ def getBinaryTensor(imgTensor, boundary):              # model_seq.py:445-448
     return torch.where(imgTensor > boundary, torch.ones_like(imgTensor), torch.zeros_like(imgTensor))
 
 
+class _CompFunction(torch.autograd.Function):
+    """The standalone comp modules on the kernels BERT4Rec's front-of-encoder form uses (csrc/innercomp.hip): the rows are packed
+    as the [2, B, T, D] pair those kernels take (slot 0 = the rows that keep their place, slot 1 = the rows mixed into the token
+    group; InnerComp: the same rows twice) and slot 0's half of every result is what the module returns."""
+
+    @staticmethod
+    def forward(ctx, cross, threshold, seq_a, seq_b, w_nn, b_nn, w_bs, b_bs):
+        L, st = lib(), torch.cuda.current_stream().cuda_stream
+        B, T, D = seq_a.shape
+        dev = seq_a.device
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)      # noqa: E731
+        xg = torch.stack((seq_a.float(), seq_b.float())).contiguous()
+        par = [t.detach().float().contiguous() for t in (w_nn, b_nn, w_bs, b_bs)]
+        two = lambda t: ptr_array([t.data_ptr(), t.data_ptr()])                # noqa: E731
+        s, gate, S, Z, sw, x0 = f(2, B), f(2, B), f(2, T, D), f(2, T, D), f(2), f(2, B, 2 * T, D)
+        L.call("amid_bert_comp_score_f32", xg.data_ptr(), B, T, D, cross, s.data_ptr(), st)
+        L.call("amid_bert_comp_fwd_f32", xg.data_ptr(), s.data_ptr(), two(par[0]), two(par[1]), two(par[2]), two(par[3]), float(threshold),
+               cross, B, T, D, gate.data_ptr(), S.data_ptr(), Z.data_ptr(), sw.data_ptr(), x0.data_ptr(), st)
+        ctx.save_for_backward(xg, gate, S, sw, *par[:3])
+        ctx.cross = cross
+        return x0[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        xg, gate, S, sw, w_nn, b_nn, w_bs = ctx.saved_tensors
+        L, st = lib(), torch.cuda.current_stream().cuda_stream
+        _, B, T, D = xg.shape
+        dev = xg.device
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)      # noqa: E731
+        two = lambda t: ptr_array([t.data_ptr(), t.data_ptr()])                # noqa: E731
+        dx0 = torch.zeros(2, B, 2 * T, D, dtype=torch.float32, device=dev)
+        dx0[0] = dout
+        dZ, dS, rows, dxg = f(2, T, D), f(2, T, D), f(2, T, 2), f(2, B, T, D)
+        dw_nn, db_nn, dw_bs, db_bs = f(2, D, D), f(2, D), f(2, 1, B), f(2, 1)
+        per = lambda t: ptr_array([t[0].data_ptr(), t[1].data_ptr()])          # noqa: E731
+        L.call("amid_bert_comp_bwd_f32", xg.data_ptr(), dx0.data_ptr(), gate.data_ptr(), S.data_ptr(), sw.data_ptr(), two(w_nn), two(b_nn),
+               two(w_bs), ctx.cross, B, T, D, dZ.data_ptr(), dS.data_ptr(), rows.data_ptr(), per(dw_nn), per(db_nn), per(dw_bs), per(db_bs),
+               dxg.data_ptr(), st)
+        # slot 1 received no gradient, so module 1's shares are exact zeros: slot 0 / module 0 carry everything
+        d_a = dxg[0]
+        d_b = dxg[1] if ctx.cross else None
+        return None, None, d_a, d_b, dw_nn[0], db_nn[0], dw_bs[0], db_bs[0]
+
+
+def _comp_check(mod, seq):
+    lib()
+    if seq.dim() != 3 or not seq.is_cuda:
+        raise ValueError("expected a [b, n, d] tensor on the GPU")
+    if seq.shape[0] != mod.bs:
+        raise ValueError(f"the batch must hold exactly bs = {mod.bs} rows (trans_bs is Linear(bs, 1) over the batch), got {seq.shape[0]}")
+
+
 class InnerComp(nn.Module):
     def __init__(self, user_emb_dim, bs, threshold):   # model_seq.py:450-457
         super().__init__()
@@ -455,8 +512,10 @@ class InnerComp(nn.Module):
         self.trans_nn = nn.Linear(user_emb_dim, user_emb_dim)
         self.trans_bs = nn.Linear(bs, 1)
 
-    def forward(self, seq):
-        _not_built("InnerComp", "model_seq.py:459-472")
+    def forward(self, seq):                            # model_seq.py:459-472: [b, n, d] -> [b, 2n, d]
+        _comp_check(self, seq)
+        return _CompFunction.apply(0, self.threshold, seq, seq.detach(), self.trans_nn.weight, self.trans_nn.bias, self.trans_bs.weight,
+                                   self.trans_bs.bias)
 
 
 class InterComp(nn.Module):
@@ -466,8 +525,13 @@ class InterComp(nn.Module):
         self.trans_nn = nn.Linear(user_emb_dim, user_emb_dim)
         self.trans_bs = nn.Linear(bs, 1)
 
-    def forward(self, seq_d1, seq_d2):
-        _not_built("InterComp", "model_seq.py:483-497")
+    def forward(self, seq_d1, seq_d2):                 # model_seq.py:483-497: information seq_d2 --> seq_d1, [b, 2n, d]
+        _comp_check(self, seq_d1)
+        _comp_check(self, seq_d2)
+        if seq_d1.shape != seq_d2.shape:
+            raise ValueError("seq_d1 and seq_d2 must have the same shape")
+        return _CompFunction.apply(1, self.threshold, seq_d1, seq_d2, self.trans_nn.weight, self.trans_nn.bias, self.trans_bs.weight,
+                                   self.trans_bs.bias)
 
 
 class GRU4Rec(nn.Module):
@@ -478,10 +542,11 @@ class GRU4Rec(nn.Module):
 
 
 class BERT4Rec(SASRec):
-    """model_seq.py:248-309 on the HIP engine (isInC = isItC = False; isDR either way): two stacks of two TransformerBlocks whose
+    """model_seq.py:248-309 on the HIP engine (isDR either way; isInC or isItC -- the reference fails with both -- put the comp
+    module in front of the encoders, which then see 2 * seq_len tokens, :283-294): two stacks of two TransformerBlocks whose
     hidden size 128 / 4 heads / FFN 512 / dropout 0.1 the reference hard-codes (:264-267), so emb dims must be 128; no
     positional embedding; ONE key mask from seq_d2 > 0 for both stacks (:288); plain mean over time, then predictModule.
     Same constructor, forward signature, state_dict keys (transform{1,2}.{0,1}.*) and train_step() as SASRec above."""
 
     ENGINE_CLS = Bert4recEngine
-    SUPPORTS_ITC = False         # BERT4Rec applies InterComp BEFORE the encoders (2T tokens, :289-294): not built
+    COMP_IN_FRONT = True         # BERT4Rec applies InnerComp / InterComp BEFORE the encoders (2T tokens, :283-294)

@@ -329,6 +329,25 @@ int amid_inc_bwd_f32(const float* dpos_part, int nsplit, const float* xg, const 
                      int D, float* dZ, float* dS, float* rows, float* const* dw_nn, float* const* db_nn, float* const* dw_bs,
                      float* const* db_bs, float* dxg, void* stream);
 
+/* ---- the comp modules in front of BERT4Rec's encoders (isInC model_seq.py:283-286, isItC :289-294) -------------------------
+ * replaces: InnerComp.forward (:459-472) / InterComp.forward (:483-497) as BERT4Rec calls them -- on the gathered rows, before
+ * the transformer blocks, which then see 2T tokens -- and their autograd.  Same compute-once token group as above without
+ * positional rows or input dropout; cross = 1 (InterComp): module g scores row j by max_{a,c} e[g,j,a] . e[1-g,j,c] and mixes
+ * the OTHER domain's rows, S[g][t] = sum_j w_bs_g[j] gate_g[j] e[1-g,j,t]; cross = 0 (InnerComp): its own.
+ *   score : s [2, B];   fwd : gate, S, Z, sw as amid_inc_embed_fwd_f32 and x0[g,b,0..2T) = [e[g,b,:] | Z[g]]
+ *   bwd   : dZ[g][t] = sum_b dx0[g,b,T+t] (fixed order), the modules' parameter gradients (written whole) and
+ *           dxg[sd,j,t] = dx0[sd,j,t] + w_bs_g[j] gate_g[j] (dZ[g][t] W_nn_g),  sd = cross ? 1-g : g
+ * amid_key_keep_tiled_u8: the key mask of :286 / :294, keep[b][r*T + t] = seq[b][t] > 0 for r < reps. */
+int amid_bert_comp_score_f32(const float* xg, int B, int T, int D, int cross, float* s, void* stream);
+int amid_bert_comp_fwd_f32(const float* xg, const float* s, const float* const* w_nn, const float* const* b_nn,
+                           const float* const* w_bs, const float* const* b_bs, float threshold, int cross, int B, int T, int D,
+                           float* gate, float* S, float* Z, float* sw, float* x0, void* stream);
+int amid_bert_comp_bwd_f32(const float* xg, const float* dx0, const float* gate, const float* S, const float* sw,
+                           const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int cross, int B, int T,
+                           int D, float* dZ, float* dS, float* rows, float* const* dw_nn, float* const* db_nn, float* const* dw_bs,
+                           float* const* db_bs, float* dxg, void* stream);
+int amid_key_keep_tiled_u8(const long long* seq, int B, int T, int reps, unsigned char* keep, void* stream);
+
 /* ---- the same row-tile entry points built with shorter tiles (3 or 5 MFMA row tiles per workgroup instead of 7) --------------
  * Identical signatures and semantics; callers use *_rt3 when rows_per_tile <= 48 (seq_len 20 at batch 256: the mybank shape of
  * BASELINE.json configs[3]) and *_rt5 when rows_per_tile <= 80, where the 112-row build would spend much of its matrix work on zero

@@ -370,14 +370,29 @@ def bert_block(x: torch.Tensor, key_keep: torch.Tensor, P: Params, pre: str, mas
 
 
 def bert4rec_forward(P: Params, i_node: torch.Tensor, neg_samples: torch.Tensor, seq_d1: torch.Tensor,
-                     seq_d2: torch.Tensor, masks: Masks = None, isDR: bool = False) -> Tuple[torch.Tensor, ...]:
-    """BERT4Rec.forward model_seq.py:277-309 (isInC = isItC = False); isDR: the three heads of :301-305."""
+                     seq_d2: torch.Tensor, masks: Masks = None, isDR: bool = False, isInC: bool = False, isItC: bool = False,
+                     threshold1: float = 0.5, threshold2: float = 0.5, taps: Optional[dict] = None) -> Tuple[torch.Tensor, ...]:
+    """BERT4Rec.forward model_seq.py:277-309; isDR: the three heads of :301-305.  isInC (:283-286) / isItC (:289-294): the comp
+    module runs on the gathered rows BEFORE the encoders (unlike SASRec's InterComp), which then see 2T tokens; the key mask is the
+    T-token mask tiled twice along the key axis (`.repeat(1, 2T, 2)`).  Both flags together make the reference fail (the mask
+    keeps 2T keys while the sequences have 4T tokens, :291-294), so that combination is refused here as well."""
+    if isInC and isItC:
+        raise ValueError("BERT4Rec(isInC=True, isItC=True): the reference's own mask has 2T keys for 4T tokens (model_seq.py:294)")
     E = P["item_emb_layer.emb_item.weight"]
     i_feat = gather_rows(E, i_node).unsqueeze(1)
     neg_feat = gather_rows(E, neg_samples)
     x1 = gather_rows(E, seq_d1)
     x2 = gather_rows(E, seq_d2)
     key_keep = seq_d2 > 0                                                # :288 ONE mask, from domain 2, for BOTH encoders
+    if isInC:
+        x1 = inner_comp(x1, P, "inc_d1", threshold1, taps)               # :284
+        x2 = inner_comp(x2, P, "inc_d2", threshold1, taps)               # :285
+        key_keep = torch.cat((key_keep, key_keep), 1)                    # :286
+    if isItC:
+        e1, e2 = x1, x2
+        x1 = inter_comp(e1, e2, P, "itc_d1", threshold2, taps)           # :292
+        x2 = inter_comp(e2, e1, P, "itc_d2", threshold2, taps)           # :293
+        key_keep = torch.cat((key_keep, key_keep), 1)                    # :294
     for l in range(2):
         x1 = bert_block(x1, key_keep, P, f"transform1.{l}", masks)       # :295-296
     for l in range(2):
@@ -575,10 +590,18 @@ def sasrec_param_shapes(item_length: int, D: int, T: int, hid: int, itc_bs: int 
     return s
 
 
-def bert4rec_param_shapes(item_length: int, hid: int, dr: bool = False) -> Dict[str, Tuple[int, ...]]:
-    """dr: also the predict_ips / predict_gfunc heads of isDR=True (model_seq.py:268-271)."""
+def bert4rec_param_shapes(item_length: int, hid: int, dr: bool = False, inc_bs: int = 0, itc_bs: int = 0) -> Dict[str, Tuple[int, ...]]:
+    """dr: also the predict_ips / predict_gfunc heads of isDR=True (model_seq.py:268-271); inc_bs / itc_bs > 0: the InnerComp /
+    InterComp modules of isInC / isItC with bs rows (:257-263)."""
     D, F = BERT_HIDDEN, BERT_FF
     s: Dict[str, Tuple[int, ...]] = {"item_emb_layer.emb_item.weight": (item_length, D)}
+    for kind, bs in (("inc", inc_bs), ("itc", itc_bs)):
+        if bs:
+            for d in (1, 2):
+                s[f"{kind}_d{d}.trans_nn.weight"] = (D, D)
+                s[f"{kind}_d{d}.trans_nn.bias"] = (D,)
+                s[f"{kind}_d{d}.trans_bs.weight"] = (1, bs)
+                s[f"{kind}_d{d}.trans_bs.bias"] = (1,)
     for d in (1, 2):
         for l in (0, 1):
             pre = f"transform{d}.{l}"

@@ -356,3 +356,141 @@ def test_dr_train_steps_fused_vs_oracle_two_optimizers():
         # Adam's first steps move every weight by ~lr * sign(g): where the true gradient is ~0 (rows with ob_label 0 give the
         # encoders no gradient under loss_dr_r) rounding noise picks the sign, so a few elements may sit one step apart
         assert float((d > 3e-4).float().mean()) < 2e-3 and float(d.max()) < 2.5e-3, (k, float(d.max()), float((d > 3e-4).float().mean()))
+
+
+# ---------------------------------------------------------------------------- isInC / isItC (model_seq.py:283-294)
+def comp_kw(kind, bs, thr):
+    return dict(comp=kind, comp_bs=bs, comp_threshold=thr)
+
+
+def comp_fwd_kw(kind, thr):
+    return dict(isInC=True, threshold1=thr) if kind == "inc" else dict(isItC=True, threshold2=thr)
+
+
+@pytest.mark.parametrize("kind", ["inc", "itc"])
+def test_comp_golden_outputs_loss_grads(kind):
+    """BERT4Rec(isInC=True) / (isItC=True) against the reference's own logits, loss and gradients (g14 / g15): the comp module
+    in front of the encoders, 2T tokens under the T-token key mask tiled twice."""
+    from amid_amd.engine_bert import Bert4recEngine
+    z = np.load(os.path.join(GOLDEN, "g14_bert4rec_inc.npz" if kind == "inc" else "g15_bert4rec_itc.npz"))
+    B = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("B/")}
+    Bn, T = B["seq_d1"].shape
+    P = orc.random_params(orc.bert4rec_param_shapes(int(z["n_items"]), int(z["hid"]), inc_bs=Bn if kind == "inc" else 0,
+                                                    itc_bs=Bn if kind == "itc" else 0), seed=int(z["param_seed"]))
+    P["item_emb_layer.emb_item.weight"] = P["item_emb_layer.emb_item.weight"] * float(z["table_scale"])
+    thr = float(z["threshold"])
+    eng = Bert4recEngine(int(z["n_items"]), 128, T, int(z["hid"]), lr=1e-3, seed=0, **comp_kw(kind, Bn, thr))
+    eng.load_state_dict(P)
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    assert pl.shape.Tenc == 2 * T
+    cu = {k: v.cuda() for k, v in B.items()}
+    eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], torch.from_numpy(z["labels"]).cuda(), cu["domain_id"])
+    eng.enqueue_prepare(pl, sparse=True)
+    eng.enqueue_forward(pl, train=False, with_loss=True)
+    eng.enqueue_backward(pl, train=False)
+    eng.sync()
+    assert np.array_equal(pl.inc_gate[0].cpu().numpy().astype(bool), z["gate_d1"])
+    assert np.array_equal(pl.inc_gate[1].cpu().numpy().astype(bool), z["gate_d2"])
+    assert relmax(pl.p1, z["p1"]) < 1e-4 and relmax(pl.p2, z["p2"]) < 1e-4
+    assert abs(float(pl.loss.cpu()) - float(z["loss"])) < 2e-5
+    G = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("G/")}
+    bad = []
+    for name, want in G.items():
+        if name == "item_emb_layer.emb_item.weight" or name.endswith("linear_layers.1.bias"):
+            continue
+        got = eng.dense.view(name, eng.dense.grad)
+        e = relmax(got, want) if float(want.abs().max()) > 1e-12 else float(got.abs().max().cpu())
+        if not e < 1e-3:
+            bad.append((name, e))
+    assert not bad, bad
+    assert any(n.startswith(kind + "_d") for n in G)
+    tg = dense_table_grad(eng, pl)
+    assert relmax(tg, G["item_emb_layer.emb_item.weight"]) < 1e-3
+
+
+@pytest.mark.parametrize("kind,Bn,T", [("inc", 6, 12), ("itc", 6, 12), ("itc", 32, 50), ("inc", 24, 20)])
+def test_comp_train_steps_vs_oracle_and_graph(kind, Bn, T):
+    """Train steps with dropout on (the encoders' Philox sites indexed over 2T tokens) against the oracle's dense Adam; graph
+    replay bit-identical to eager.  The table is scaled so that the batch softmax gates are mixed, and the threshold sits in
+    the widest gap of the first batch's softmax so that rounding cannot flip a gate."""
+    from amid_amd.engine_bert import Bert4recEngine
+    hid, n_items, lr, seed = 16, 400, 1e-3, 23
+    P = orc.random_params(orc.bert4rec_param_shapes(n_items, hid, inc_bs=Bn if kind == "inc" else 0, itc_bs=Bn if kind == "itc" else 0),
+                          seed=31)
+    P["item_emb_layer.emb_item.weight"] = P["item_emb_layer.emb_item.weight"] * 0.1
+    batches = [batch_with_masked_keys(Bn, T, n_items, 900 + t) for t in range(3)]
+    taps = {}
+    orc.bert4rec_forward(P, batches[0]["i_node"], batches[0]["neg_samples"], batches[0]["seq_d1"], batches[0]["seq_d2"], None, taps=taps,
+                         **comp_fwd_kw(kind, 0.5))
+    sm = torch.sort(torch.cat([taps[f"{kind}_d{d}"]["softmax"] for d in (1, 2)])).values
+    gaps = sm[1:] - sm[:-1]
+    i = int(torch.argmax(gaps))
+    thr = float((sm[i] + sm[i + 1]) / 2)
+    Po = {k: v.clone() for k, v in P.items()}
+    opt = orc.DenseAdam(Po, lr=lr)
+    want, margins = [], []
+    for b in batches:
+        masks = orc.philox_masks_bert4rec(Bn, 2 * T, seed=seed, step=opt.t + 1)
+        tp = {}
+        loss, _, grads = orc.loss_and_grads("bert4rec", Po, b, masks, taps=tp, **comp_fwd_kw(kind, thr))
+        margins.append(min(tp[f"{kind}_d{d}"]["margin"] for d in (1, 2)))
+        opt.step(Po, grads)
+        want.append(float(loss))
+    log(f"bert comp {kind} B {Bn} T {T}: threshold {thr:.5f} gate margins {margins}")
+    if min(margins) < 1e-5:
+        pytest.skip(f"a batch-softmax value sits within {min(margins):.2e} of the threshold: the gate is rounding-dependent")
+
+    def run(use_graph):
+        eng = Bert4recEngine(n_items, 128, T, hid, lr=lr, seed=seed, **comp_kw(kind, Bn, thr))
+        eng.load_state_dict(P)
+        pl = eng.plan(Bn, T, 2, need_grad=True)
+        got = []
+        for b in batches:
+            cu = {kk: v.cuda() for kk, v in b.items()}
+            eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"])
+            if use_graph:
+                if not eng.has_graph(pl):
+                    eng.capture_train_step(pl)
+                eng.replay_train_step(pl)
+            else:
+                eng.enqueue_train_step(pl)
+            eng.sync()
+            got.append(float(pl.loss.cpu()))
+        eng.flush_table(); eng.sync()
+        return got, {kk: v.cpu().clone() for kk, v in eng.state_dict().items()}
+
+    g0, s0 = run(False)
+    g1, s1 = run(True)
+    assert g0 == g1 and all(torch.equal(s0[k], s1[k]) for k in s0)
+    for a, b_ in zip(g0, want):
+        assert abs(a - b_) < 5e-5 * max(1.0, abs(b_)), (g0, want)
+    for k, v in Po.items():
+        if k.endswith("linear_layers.1.bias"):
+            continue
+        d = (s0[k] - v).abs()
+        assert float((d > 3e-4).float().mean()) < 2e-3 and float(d.max()) < 3.5e-3, (k, float(d.max()), float((d > 3e-4).float().mean()))
+
+
+def test_comp_module_surface():
+    """model_seq.BERT4Rec(isItC=True): state_dict keys, forward against the oracle, the batch-size contract, and the refusal of the
+    combination the reference itself cannot run."""
+    from amid_amd import model_seq as ms
+    Bn, T, hid, n_items = 8, 10, 16, 300
+    with pytest.raises(ValueError):
+        ms.BERT4Rec(10, 128, n_items, 128, T, hid, Bn, True, True, 0.5, 0.5)
+    m = ms.BERT4Rec(10, 128, n_items, 128, T, hid, Bn, False, True, 0.5, 0.13)
+    sd = m.state_dict()
+    assert sd["itc_d2.trans_bs.weight"].shape == (1, Bn) and sd["itc_d1.trans_nn.weight"].shape == (128, 128)
+    P = {k: v.detach().cpu().clone() for k, v in sd.items()}
+    P["item_emb_layer.emb_item.weight"] *= 0.1
+    m.load_state_dict(P)
+    b = batch_with_masked_keys(Bn, T, n_items, 77)
+    m.eval()
+    with torch.no_grad():
+        p1, p2 = m(None, b["i_node"].cuda(), b["neg_samples"].cuda(), b["seq_d1"].cuda(), b["seq_d2"].cuda(), None, None)
+    taps = {}
+    w1, w2 = orc.bert4rec_forward(P, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], None, isItC=True, threshold2=0.13, taps=taps)
+    if min(taps[f"itc_d{d}"]["margin"] for d in (1, 2)) > 1e-5:
+        assert relmax(p1, w1) < 1e-4 and relmax(p2, w2) < 1e-4
+    with pytest.raises(ValueError):      # trans_bs is Linear(bs, 1) over the batch: other batch sizes cannot run (as in the reference)
+        m(None, b["i_node"][:4].cuda(), b["neg_samples"][:4].cuda(), b["seq_d1"][:4].cuda(), b["seq_d2"][:4].cuda(), None, None)

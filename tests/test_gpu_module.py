@@ -171,10 +171,8 @@ def test_unbuilt_models_fail_loudly():
     from amid_amd import model_seq
     with pytest.raises(NotImplementedError):
         model_seq.GRU4Rec(10, 128, 100, 128, 20, 32, 4, False, False, 0.5, 0.5)
-    with pytest.raises(NotImplementedError):                 # BERT4Rec with InnerComp (model_seq.py:283-285): not built
-        model_seq.BERT4Rec(10, 128, 100, 128, 20, 32, 4, True, False, 0.5, 0.5)
-    with pytest.raises(NotImplementedError):                 # nor its InterComp, which goes in FRONT of the encoders (:289-294)
-        model_seq.BERT4Rec(10, 128, 100, 128, 20, 32, 4, False, True, 0.5, 0.5)
+    with pytest.raises(ValueError):                      # both comp modules on BERT4Rec: the reference itself fails (model_seq.py:294)
+        model_seq.BERT4Rec(10, 128, 100, 128, 20, 32, 4, True, True, 0.5, 0.5)
     with pytest.raises(ValueError):                      # the reference hard-codes hidden size 128 (model_seq.py:264-267)
         model_seq.BERT4Rec(10, 64, 100, 64, 20, 32, 4, False, False, 0.5, 0.5)
 
@@ -263,7 +261,9 @@ def test_sasrec_inc_module_surface_and_reference_loop():
 
 @pytest.mark.parametrize("model,emb,extra", [("sasrec", "64", []), ("bert4rec", "128", []), ("sasrec", "64", ["--isItC", "True", "--ts2", "0.4"]),
                                              ("sasrec", "128", ["--dtype", "bf16"]), ("sasrec", "64", ["--isInC", "True", "--ts1", "0.02"]),
-                                             ("sasrec", "64", ["--isInC", "True", "--ts1", "0.02", "--isItC", "True", "--ts2", "0.02"])])
+                                             ("sasrec", "64", ["--isInC", "True", "--ts1", "0.02", "--isItC", "True", "--ts2", "0.02"]),
+                                             ("bert4rec", "128", ["--isItC", "True", "--ts2", "0.02"]),
+                                             ("bert4rec", "128", ["--isInC", "True", "--ts1", "0.02"])])
 def test_train_sr_cli_end_to_end(tmp_path, model, emb, extra):
     """The reference's command line on a synthetic CSV pair with the reference's column layout."""
     from amid_amd.train_sr import main
@@ -429,3 +429,35 @@ def test_sasrec_dr_module_reference_loop():
             Dd = v.numel() // 3
             dlt = torch.cat((dlt[:Dd], dlt[2 * Dd:]))
         assert float(dlt.max()) < 2e-4, k
+
+
+def test_standalone_comp_modules_golden_and_autograd():
+    """model_seq.InnerComp / InterComp as modules of their own (model_seq.py:450-497): forward against the reference's outputs
+    (g9, its [bs, b, n, d] formulation), backward against the oracle's autograd, the batch-size contract."""
+    from amid_amd import model_seq as ms
+    from oracle import amid_oracle as orc
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_comp.npz"))
+    P = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("P/")}
+    a, b = torch.from_numpy(z["a"]), torch.from_numpy(z["b"])
+    bs, T, D = a.shape
+    for kind, cls, want in (("itc", ms.InterComp, z["inter"]), ("inc", ms.InnerComp, z["inner"])):
+        m = cls(D, bs, 0.15).cuda()
+        m.load_state_dict({k[len(kind) + 1:]: v for k, v in P.items() if k.startswith(kind + ".")})
+        xa, xb = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        out = m(xa, xb) if kind == "itc" else m(xa)
+        assert out.shape == (bs, 2 * T, D)
+        assert float((out.detach().cpu() - torch.from_numpy(want)).abs().max()) < 1e-5
+        w = torch.randn(bs, 2 * T, D, generator=torch.Generator().manual_seed(5))
+        (out * w.cuda()).sum().backward()
+        leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        ca, cb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = orc.inter_comp(ca, cb, leaves, "itc", 0.15) if kind == "itc" else orc.inner_comp(ca, leaves, "inc", 0.15)
+        (ref * w).sum().backward()
+        rel = lambda g, r: float((g.cpu() - r).abs().max() / (r.abs().max() + 1e-30))      # noqa: E731
+        assert rel(xa.grad, ca.grad) < 1e-4
+        if kind == "itc":
+            assert rel(xb.grad, cb.grad) < 1e-4
+        for n in ("trans_nn.weight", "trans_nn.bias", "trans_bs.weight", "trans_bs.bias"):
+            assert rel(m.get_parameter(n).grad, leaves[f"{kind}.{n}"].grad) < 1e-4, (kind, n)
+        with pytest.raises(ValueError):
+            m(xa[:2], xb[:2]) if kind == "itc" else m(xa[:2])

@@ -46,8 +46,11 @@ def test_g3_sasrec_eval(name):
     assert rel_err(p1, z["p1"]) < 1e-6 and rel_err(p2, z["p2"]) < 1e-6
 
 
-def bert_params(z, dr=False):
-    P = orc.random_params(orc.bert4rec_param_shapes(int(z["n_items"]), int(z["hid"]), dr=dr), seed=int(z["param_seed"]))
+def bert_params(z, dr=False, inc_bs=0, itc_bs=0):
+    P = orc.random_params(orc.bert4rec_param_shapes(int(z["n_items"]), int(z["hid"]), dr=dr, inc_bs=inc_bs, itc_bs=itc_bs),
+                          seed=int(z["param_seed"]))
+    if "table_scale" in z.files:
+        P["item_emb_layer.emb_item.weight"] = P["item_emb_layer.emb_item.weight"] * float(z["table_scale"])
     s = sum(float(v.double().sum()) for v in P.values())
     assert abs(s - float(z["param_sum"])) < 1e-9 * max(1.0, abs(s)), "random_params drifted from the fixture generator"
     return P
@@ -202,6 +205,32 @@ def test_g13_bert4rec_dr_outputs_losses_grads():
             if k.endswith("linear_layers.1.bias"):      # the key bias: analytically zero (softmax shift invariance), rounding noise only
                 continue
             assert rel_err(grads[k], g) < 5e-5 or float((grads[k] - g).abs().max()) < 1e-8, (which, k)
+
+
+@pytest.mark.parametrize("kind", ["inc", "itc"])
+def test_g14_g15_bert4rec_comp_grads(kind):
+    """BERT4Rec(isInC=True) / (isItC=True): the comp module in FRONT of the encoders (model_seq.py:283-294), 2T tokens, the key
+    mask tiled twice: gates, logits, loss and the stored gradients against the reference."""
+    z, _, B, G, _ = load("g14_bert4rec_inc.npz" if kind == "inc" else "g15_bert4rec_itc.npz")
+    bs = B["seq_d1"].shape[0]
+    P = bert_params(z, inc_bs=bs if kind == "inc" else 0, itc_bs=bs if kind == "itc" else 0)
+    kw = dict(isInC=True, threshold1=float(z["threshold"])) if kind == "inc" else dict(isItC=True, threshold2=float(z["threshold"]))
+    taps = {}
+    orc.bert4rec_forward(P, B["i_node"], B["neg_samples"], B["seq_d1"], B["seq_d2"], None, taps=taps, **kw)
+    assert np.array_equal(taps[f"{kind}_d1"]["gate"].numpy().astype(bool), z["gate_d1"])
+    assert np.array_equal(taps[f"{kind}_d2"]["gate"].numpy().astype(bool), z["gate_d2"])
+    batch = dict(B)
+    batch["label"] = torch.from_numpy(z["labels"])
+    loss, (p1, p2), grads = orc.loss_and_grads("bert4rec", P, batch, None, **kw)
+    assert rel_err(p1, z["p1"]) < 1e-6 and rel_err(p2, z["p2"]) < 1e-6
+    assert abs(float(loss) - float(z["loss"])) < 2e-6
+    assert len(G) > 20 and set(G) <= set(P) and any(k.startswith(kind + "_d") for k in G)
+    for k, g in G.items():
+        if k.endswith("linear_layers.1.bias"):      # the key bias: analytically zero (softmax shift invariance), rounding noise only
+            continue
+        assert rel_err(grads[k], g) < 5e-5 or float((grads[k] - g).abs().max()) < 1e-8, k
+    with pytest.raises(ValueError):
+        orc.bert4rec_forward(P, B["i_node"], B["neg_samples"], B["seq_d1"], B["seq_d2"], None, isInC=True, isItC=True)
 
 
 def test_g12_sasrec_inc_grads():
