@@ -21,6 +21,20 @@ struct AdamCoef {              // per-step scalars, as torch computes them (doub
     float eps;
 };
 
+// beta^s for an integer step count by repeated squaring: <= 2 log2(s) double multiplies (relative error < 1e-14, invisible after
+// the coefficients are rounded to float) instead of libm's pow(double, double), several hundred fp64 instructions per call --
+// every workgroup of the catch-up / row kernels fills a 256-entry coefficient table with two of these per entry, and that fill,
+// not the row traffic, was most of those kernels' time.
+__device__ __forceinline__ double pow_step(double b, long long s) {
+    double r = 1.0;
+    while (s > 0) {
+        if (s & 1) r *= b;
+        b *= b;
+        s >>= 1;
+    }
+    return r;
+}
+
 __device__ __forceinline__ AdamCoef adam_coef(const StepState& st, double b1pow, double b2pow) {
     AdamCoef c;
     c.w1 = (float)(1.0 - st.beta1);
@@ -72,7 +86,7 @@ constexpr int COEF_TAB = 256;
 __device__ __forceinline__ void fill_coef_table(AdamCoef* tab, const StepState& st) {
     for (int i = threadIdx.x; i < COEF_TAB; i += blockDim.x) {
         const long long s = st.step - (COEF_TAB - 1) + i;
-        if (s >= 1) tab[i] = adam_coef(st, pow(st.beta1, (double)s), pow(st.beta2, (double)s));
+        if (s >= 1) tab[i] = adam_coef(st, pow_step(st.beta1, s), pow_step(st.beta2, s));
     }
     __syncthreads();
 }
@@ -80,7 +94,7 @@ __device__ __forceinline__ void fill_coef_table(AdamCoef* tab, const StepState& 
 __device__ __forceinline__ AdamCoef coef_at(const AdamCoef* tab, const StepState& st, long long s) {
     const long long i = s - (st.step - (COEF_TAB - 1));
     if (i >= 0) return tab[i];
-    return adam_coef(st, pow(st.beta1, (double)s), pow(st.beta2, (double)s));     // gaps longer than the table: slow path
+    return adam_coef(st, pow_step(st.beta1, s), pow_step(st.beta2, s));     // gaps longer than the table: slow path
 }
 
 // replay zero-gradient steps s = from .. to (inclusive) on one float4 of a row.  Steps older than the table (a row idle for
@@ -93,7 +107,7 @@ __device__ __forceinline__ void replay_quad(float4& p, float4& m, float4& v, lon
     long long s = from;
     const long long tab_first = st.step - (COEF_TAB - 1);
     if (s < tab_first) {
-        double b1p = pow(st.beta1, (double)s), b2p = pow(st.beta2, (double)s);
+        double b1p = pow_step(st.beta1, s), b2p = pow_step(st.beta2, s);
         const long long stop = (to + 1 < tab_first) ? to + 1 : tab_first;
         for (; s < stop; ++s) {
             adam_quad_idle(p, m, v, adam_coef(st, b1p, b2p));
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, 
                                                          const float* __restrict__ g, long long n, const StepState* __restrict__ stp,
                                                          float grad_scale) {
     const StepState st = *stp;
-    const AdamCoef c = adam_coef(st, pow(st.beta1, (double)st.step), pow(st.beta2, (double)st.step));
+    const AdamCoef c = adam_coef(st, pow_step(st.beta1, st.step), pow_step(st.beta2, st.step));
     const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const long long stride = (long long)gridDim.x * blockDim.x * 4;
     for (long long i = i0; i < n; i += stride) {
@@ -239,7 +253,7 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(float* __restrict__
     __shared__ AdamCoef tab[COEF_TAB];
     const StepState st = *stp;
     if ((int)blockIdx.x < dense_blocks) {
-        const AdamCoef c = adam_coef(st, pow(st.beta1, (double)st.step), pow(st.beta2, (double)st.step));
+        const AdamCoef c = adam_coef(st, pow_step(st.beta1, st.step), pow_step(st.beta2, st.step));
         const long long stride = (long long)dense_blocks * blockDim.x * 4;
         for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
             if (i + 4 <= n) {

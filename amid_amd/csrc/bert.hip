@@ -56,14 +56,17 @@ __device__ __forceinline__ float4 lnb_bwd(float4 dy, float4 x, float4 a, float4&
     return make_float4(r * (gg.x - gm) - c * xc.x, r * (gg.y - gm) - c * xc.y, r * (gg.z - gm) - c * xc.z, r * (gg.w - gm) - c * xc.w);
 }
 
-__device__ __forceinline__ float gelu_f(float x) {       // model_seq.py:204
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+// tanh GELU (model_seq.py:204) through the identity 0.5 (1 + tanh u) = sigmoid(2u): one v_exp_f32 and one v_rcp_f32 per element,
+// no cancellation anywhere (libm's tanhf is ~40 instructions over two divergent branches; the feed-forward kernels evaluate
+// 13 M of these per launch).  gelu'(x) = s + 2 x s (1 - s) u'(x) with s = sigmoid(2u), since 1 - tanh^2 u = 4 s (1 - s).
+__device__ __forceinline__ float gelu_sig(float x) {
+    const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);         // 2 u
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
 }
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_sig(x); }
 __device__ __forceinline__ float gelu_df(float x) {
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float t = tanhf(u);
-    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+    const float sg = gelu_sig(x);
+    return sg + 2.0f * x * sg * (1.0f - sg) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
 }
 
 // visit the accumulator tiles of a wave: f(row r in tile, first column n, float4 value)

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void scorer_bwd_kernel(const ScorerBwdArgs a) 
     float* ci = dw2 + hid + 4;              // [64][hid]
     float* dc = ci + 64 * hid;              // [64][hid]  dpre[0][n] + dpre[1][n]
     const int lane = lane_id(), w = wave_id();
-    const int P = hid * 2 * D + 2 * hid + 1;
+    const int P = (hid * 2 * D + 2 * hid + 1 + 3) & ~3;      // amid_scorer_part_floats: rows padded to whole float4s
     float* part = a.part + (long long)b * P;
     for (int dj = w; dj < 2 * hid; dj += 4) {
         const int d = dj / hid, j = dj - d * hid;
@@ -326,7 +326,9 @@ extern "C" int amid_lnmean_bwd_f32(const float* x, const float* du, const float*
     return AMID_OK;
 }
 
-extern "C" long long amid_scorer_part_floats(int D, int hid) { return (long long)hid * 2 * D + 2 * hid + 1; }
+// per-row partials of the scorer gradients: [w1 (hid x 2D) | b1 (hid) | w2 (hid) | b2 (1)], padded to whole float4s so that the
+// fixed-order reduction (reduce_partials.h) takes its 16-byte path
+extern "C" long long amid_scorer_part_floats(int D, int hid) { return ((long long)hid * 2 * D + 2 * hid + 1 + 3) & ~3LL; }
 
 extern "C" int amid_scorer_bwd_f32(const float* u, const float* items, const float* w1, const float* b1, const float* w2, const float* b2,
                                    const float* p1, const float* p2, const float* dp1, const float* dp2, int B, int NI, int D, int hid,

@@ -297,7 +297,7 @@ __device__ __forceinline__ void transpose_extra(const HeadArgs& a, float* __rest
 template <bool FUSED, bool ACC>
 __device__ __forceinline__ float* scorer_bwd_part(const HeadArgs& a, const HeadLds& s, int b, const Tg tg, float* __restrict__ dit_lds = nullptr) {
     const int D = a.D, hid = a.hid, NI = a.NI;
-    const int P = hid * 2 * D + 2 * hid + 1;
+    const int P = (hid * 2 * D + 2 * hid + 1 + 3) & ~3;      // amid_scorer_part_floats: rows padded to whole float4s
     float* part = a.sc_part + (long long)b * P;
     if (!FUSED) {
         stage_w1t(s.w1t, a.w1, 2 * D, hid, tg);

@@ -6,18 +6,62 @@ namespace amid {
 
 struct ReduceEntry { const float* src; float* dst; long long stride; int n_part; int count; };
 
-// 256 threads = 32 consecutive elements x 8 partial groups; group pg sums partials pg, pg+8, ... with four
-// independent loads in flight, then the eight group sums are added in group order (fixed order => reproducible).
+// 256 threads = 32 consecutive elements (or float4s) x 8 partial groups; group pg sums partials pg, pg+8, ... with four (eight when
+// there are many partials) independent loads in flight, then the eight group sums are added in group order (fixed order => reproducible).
 // (bx, nbx): this block's index / the number of blocks along the element axis of entry `en`.
 __device__ __forceinline__ void reduce_partials_block(const ReduceEntry en, int bx, int nbx) {
-    __shared__ float red[8][33];
+    __shared__ float4 red[8][33];
     const int el = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    // entries whose rows are whole, aligned float4s (every weight / bias matrix) move 16 bytes per lane: a wave covers two
+    // 512-byte runs instead of two 128-byte ones.  Same partial order per element as the scalar path => the same bits.
+    const bool vec = ((en.count | (int)(en.stride & 3)) & 3) == 0 && ((((unsigned long long)en.src) | ((unsigned long long)en.dst)) & 15) == 0;
+    if (vec) {
+        for (int e0 = bx * 128; e0 < en.count; e0 += nbx * 128) {     // block-uniform
+            const int e = e0 + 4 * el;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < en.count) {
+                const float* __restrict__ p = en.src + e;
+                int k = pg;
+                for (; k + 56 < en.n_part; k += 64) {      // many partials (per-row partials of the head: one per batch row): 8 in flight
+                    float4 r[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[j] = ld4(p + (long long)(k + 8 * j) * en.stride);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s = f4add(s, r[j]);
+                }
+                for (; k + 24 < en.n_part; k += 32) {
+                    const float4 a = ld4(p + (long long)k * en.stride), b = ld4(p + (long long)(k + 8) * en.stride);
+                    const float4 c = ld4(p + (long long)(k + 16) * en.stride), d = ld4(p + (long long)(k + 24) * en.stride);
+                    s = f4add(s, a); s = f4add(s, b); s = f4add(s, c); s = f4add(s, d);
+                }
+                for (; k < en.n_part; k += 8) s = f4add(s, ld4(p + (long long)k * en.stride));
+            }
+            red[pg][el] = s;
+            __syncthreads();
+            if (pg == 0 && e < en.count) {
+                float4 t = red[0][el];
+#pragma unroll
+                for (int g = 1; g < 8; ++g) t = f4add(t, red[g][el]);
+                st4(en.dst + e, t);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    float* reds = reinterpret_cast<float*>(&red[0][0]);               // scalar path: [8][33] floats of the same buffer
     for (int e0 = bx * 32; e0 < en.count; e0 += nbx * 32) {       // block-uniform
         const int e = e0 + el;
         float s = 0.f;
         if (e < en.count) {
             const float* __restrict__ p = en.src + e;
             int k = pg;
+            for (; k + 56 < en.n_part; k += 64) {
+                float r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = p[(long long)(k + 8 * j) * en.stride];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += r[j];
+            }
             for (; k + 24 < en.n_part; k += 32) {
                 const float a = p[(long long)k * en.stride], b = p[(long long)(k + 8) * en.stride];
                 const float c = p[(long long)(k + 16) * en.stride], d = p[(long long)(k + 24) * en.stride];
@@ -25,12 +69,12 @@ __device__ __forceinline__ void reduce_partials_block(const ReduceEntry en, int 
             }
             for (; k < en.n_part; k += 8) s += p[(long long)k * en.stride];
         }
-        red[pg][el] = s;
+        reds[pg * 33 + el] = s;
         __syncthreads();
         if (pg == 0 && e < en.count) {
-            float t = red[0][el];
+            float t = reds[el];
 #pragma unroll
-            for (int g = 1; g < 8; ++g) t += red[g][el];
+            for (int g = 1; g < 8; ++g) t += reds[g * 33 + el];
             en.dst[e] = t;
         }
         __syncthreads();

@@ -555,7 +555,7 @@ extern "C" int amid_reduce_entry_pack(void* host_buf, int index, const float* sr
 
 extern "C" int amid_reduce_partials_f32(const void* entries_dev, int n_entries, int max_count, void* stream) {
     AMID_CHECK_ARG(entries_dev && n_entries > 0 && max_count > 0);
-    int bx = (max_count + 31) / 32;
+    int bx = (max_count + 127) / 128;      // aligned entries move 128 elements per block pass; the (small) others loop
     if (bx > 512) bx = 512;
     reduce_partials_kernel<<<dim3(bx, n_entries), 256, 0, (hipStream_t)stream>>>((const ReduceEntry*)entries_dev);
     AMID_LAUNCH_CHECK();

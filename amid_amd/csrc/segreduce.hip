@@ -15,6 +15,7 @@
 namespace amid {
 
 constexpr int SEG_CHUNK = 64;
+constexpr int SEG_BATCH = 16;      // rows a wave requests before folding them (8: 8 dependent round trips per chunk, 16: 4)
 
 __device__ __forceinline__ int seg_of_entry(const int* __restrict__ seg_off, int U, int e) {
     // largest u in [0,U) with seg_off[u] <= e
@@ -46,7 +47,7 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, long long ro
 }
 
 // phase A: one wave per 64-entry chunk of the sorted list.  Lane l keeps (position, run index) of entry e0 + l; rows
-// are fetched eight at a time whatever runs they belong to (independent loads), then folded in order, flushing at
+// are fetched SEG_BATCH at a time whatever runs they belong to (independent loads), then folded in order, flushing at
 // every run change: control flow is wave-uniform (run indices come from readlane-style shuffles), no global load
 // sits on the per-run critical path.
 template <int VEC>
@@ -76,15 +77,15 @@ __device__ __forceinline__ void segreduce_chunks_block(const float* __restrict__
         if (!head_cut && !tail_cut) store_row<VEC>(uniq_grad, sg, D, lane, acc);
         else store_row<VEC>(partial, (long long)c * 2 + (head_cut ? 0 : 1), D, lane, acc);
     };
-    for (int i = 0; i < cnt; i += 8) {
-        RowVec<VEC> r[8];
+    for (int i = 0; i < cnt; i += SEG_BATCH) {
+        RowVec<VEC> r[SEG_BATCH];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < SEG_BATCH; ++j) {
             const int src = min(i + j, cnt - 1);
             r[j] = load_row<VEC>(grad_rows, __builtin_amdgcn_readlane(mypos, __builtin_amdgcn_readfirstlane(src)), D, lane);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < SEG_BATCH; ++j) {
             if (i + j < cnt) {
                 const int sg = __builtin_amdgcn_readlane(mysg, __builtin_amdgcn_readfirstlane(i + j));
                 if (sg != cur) {
@@ -217,7 +218,7 @@ extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted,
     if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK, n_seg = (nch + 3) / 4;
-    int bx = (max_count + 31) / 32;
+    int bx = (max_count + 127) / 128;      // aligned entries move 128 elements per block pass; the (small) others loop
     if (bx > 512) bx = 512;
     float* partial = (float*)workspace;
     const ReduceEntry* en = (const ReduceEntry*)entries_dev;

@@ -278,6 +278,9 @@ class SasrecPlan:
             add(part, hid * 2 * D, fp.ptr(f"{head}.fc.0.bias", G), P, B, hid)
             add(part, hid * 2 * D + hid, fp.ptr(f"{head}.fc.2.weight", G), P, B, hid)
             add(part, hid * 2 * D + 2 * hid, fp.ptr(f"{head}.fc.2.bias", G), P, B, 1)
+        # the blocks of an entry with many partials (the head's per-row partials: one per batch row) run the longest chains of
+        # dependent loads: dispatch them first, so that they do not form the tail of the launch
+        ent.sort(key=lambda e: -e[3])
         esz = L.value("amid_reduce_entry_bytes")
         host = (ctypes.c_ubyte * (esz * len(ent)))()
         for i, (s, d, st, n, c) in enumerate(ent):
