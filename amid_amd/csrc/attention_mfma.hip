@@ -179,7 +179,10 @@ int amid_attn_mfma_bwd_launch(const void* args, void* stream) {
     // they wait ~8 us (their neighbour's load phase) before requesting their own operands
     const int n_cu = cu_count();
     a.stagger_from = (grid >= 2 * n_cu) ? n_cu : -1;
-    a.stagger_sleeps = 2;                                      // measured at B 256: 0: 52.2 us, 1: 50.4, 2: 48.2, 3: 53.5, 4: 55.6
+    // measured at B 256, T 50 (4 key tiles): 0 sleeps: 52.2 us, 1: 50.4, 2: 48.2, 3: 53.5, 4: 55.6; at T 20 (2 tiles) the neighbour's load
+    // phase is too short to be worth waiting for: 0: 22.2 us, 1: 23.8, 2: 25.7
+    const int nt = (a.T + 15) >> 4;
+    a.stagger_sleeps = nt >= 4 ? 2 : nt == 3 ? 1 : 0;
     const size_t lds = (size_t)hw * 64 * (16 + 8);
     attn_bwd_mfma_kernel<<<grid, hw * 64, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();

@@ -13,6 +13,9 @@ tail -c 600 gpurun_out/r1h/bench.json
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r1h/smoke.log 2>&1
 for w in cfg5-uniform cfg5-real cfg4; do python3 bench.py --workload $w --no-cpu-baseline > gpurun_out/r1h/bench_$w.json 2> gpurun_out/r1h/bench_$w.err; done
 python3 bench.py --model bert4rec --no-cpu-baseline > gpurun_out/r1h/bench_bert4rec.json 2> gpurun_out/r1h/bench_bert4rec.err
+python3 bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/r1h/bench_cfg2_bf16.json 2> gpurun_out/r1h/bench_cfg2_bf16.err
+python3 bench.py --workload cfg3 --no-cpu-baseline > gpurun_out/r1h/bench_cfg3_f32.json 2> gpurun_out/r1h/bench_cfg3_f32.err
+python3 bench.py --workload cfg3 --dtype bf16 --no-cpu-baseline > gpurun_out/r1h/bench_cfg3_bf16.json 2> gpurun_out/r1h/bench_cfg3_bf16.err
 python3 profiles/tools/dp_overhead.py 2>&1 | grep "dp path" > gpurun_out/r1h/dp_overhead.txt
 bash profiles/tools/trace_gaps.sh > gpurun_out/r1h/step_timeline.txt 2>&1
 tail -3 gpurun_out/r1h/smoke.log
