@@ -14,7 +14,8 @@
 
 namespace amid {
 
-constexpr int SEG_CHUNK = 64;
+constexpr int SEG_CHUNK = 64;        // entries per wave in phase A (the step's own lists: the pad run spans ~360 of these chunks)
+constexpr int SEG_CHUNK_SHORT = 16;  // ... for short lists without long runs (the data-parallel merge: <= world duplicates per id): 4x the waves
 constexpr int SEG_BATCH = 16;      // rows a wave requests before folding them (8: 8 dependent round trips per chunk, 16: 4)
 
 __device__ __forceinline__ int seg_of_entry(const int* __restrict__ seg_off, int U, int e) {
@@ -53,13 +54,13 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, long long ro
 template <int VEC>
 __device__ __forceinline__ void segreduce_chunks_block(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
                                                        const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
-                                                       float* __restrict__ partial, int block) {
+                                                       float* __restrict__ partial, int block, int chunk = SEG_CHUNK) {
     const int D = VEC * 64;
     const int lane = lane_id();
     const int c = block * 4 + wave_id();
-    const int e0 = c * SEG_CHUNK;
+    const int e0 = c * chunk;
     if (e0 >= n) return;
-    const int cnt = min(SEG_CHUNK, n - e0);
+    const int cnt = min(chunk, n - e0);
     const bool valid = lane < cnt;
     const int mypos = valid ? pos_sorted[e0 + lane] : 0;
     const int mysg = valid ? seg_of[e0 + lane] : -1;
@@ -105,8 +106,8 @@ __device__ __forceinline__ void segreduce_chunks_block(const float* __restrict__
 template <int VEC>
 __global__ __launch_bounds__(256) void segreduce_chunks_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
                                                                const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
-                                                               float* __restrict__ partial) {
-    segreduce_chunks_block<VEC>(grad_rows, pos_sorted, seg_of, n, uniq_grad, partial, blockIdx.x);
+                                                               float* __restrict__ partial, int chunk) {
+    segreduce_chunks_block<VEC>(grad_rows, pos_sorted, seg_of, n, uniq_grad, partial, blockIdx.x, chunk);
 }
 
 // The two independent, bandwidth-bound ends of backward in ONE launch: blocks [0, n_seg) run phase A of the segment reduce, blocks
@@ -126,19 +127,20 @@ __global__ __launch_bounds__(256) void grad_tail_kernel(const float* __restrict_
 // phase B: the chunk in which a border-crossing run STARTS owns its final sum
 template <int VEC>
 __global__ __launch_bounds__(1024) void segreduce_spans_kernel(const int* __restrict__ seg_off, const int* __restrict__ seg_of, int n,
-                                                               const float* __restrict__ partial, float* __restrict__ uniq_grad) {
+                                                               const float* __restrict__ partial, float* __restrict__ uniq_grad,
+                                                               int chunk = SEG_CHUNK) {
     const int D = VEC * 64;
     __shared__ float red[16][VEC * 64];
     const int c = blockIdx.x;
-    const int e0 = c * SEG_CHUNK;
+    const int e0 = c * chunk;
     if (e0 >= n) return;
-    const int e_end = min(e0 + SEG_CHUNK, n);
+    const int e_end = min(e0 + chunk, n);
     if (e_end >= n) return;                           // the last chunk's tail run cannot continue
     const int u = seg_of[e_end - 1];
     if (seg_of[e_end] != u) return;                   // block-uniform: the tail run ends inside this chunk
     const int s_beg = seg_off[u], s_end = seg_off[u + 1];
     if (s_beg < e0) return;                           // started in an earlier chunk: that chunk owns the sum
-    const int c_last = (s_end - 1) / SEG_CHUNK;
+    const int c_last = (s_end - 1) / chunk;
     const int lane = lane_id(), w = wave_id();
     RowVec<VEC> acc;
 #pragma unroll
@@ -172,9 +174,16 @@ __global__ __launch_bounds__(1024) void segreduce_spans_kernel(const int* __rest
 
 // Data-parallel exchange: a rank's (unique ids, gradient rows) padded to the world's largest count with (pad_id, zero row)
 // pairs (amid_amd/dist.py); pad_id < 0 = repeat the first id (adds exact zeros to a real row).  One half-wave per row.
+// Blocks past n_pad (optional) run fixed-order sums of reduce_partials.h: the copy of the flat dense gradient behind the rows.
 __global__ __launch_bounds__(256) void sparse_pad_kernel(const int* __restrict__ ids, const float* __restrict__ rows,
                                                          const int* __restrict__ n_uniq, int n_out, int D, int pad_id,
-                                                         int* __restrict__ out_ids, float* __restrict__ out_rows) {
+                                                         int* __restrict__ out_ids, float* __restrict__ out_rows, int n_pad,
+                                                         const ReduceEntry* __restrict__ entries, int red_bx) {
+    if ((int)blockIdx.x >= n_pad) {
+        const int rb = blockIdx.x - n_pad;
+        reduce_partials_block(entries[rb / red_bx], rb % red_bx, red_bx);
+        return;
+    }
     const int sub = threadIdx.x & 31;
     const int r = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (r >= n_out) return;
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256) void sparse_pad_kernel(const int* __restrict__
 using namespace amid;
 
 extern "C" long long amid_segreduce_workspace_bytes(int n_idx, int D) {
-    const long long nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK;
+    const long long nch = (n_idx + SEG_CHUNK_SHORT - 1) / SEG_CHUNK_SHORT;       // the finer of the two chunkings
     return nch * 2 * D * 4 + 256;
 }
 
@@ -199,11 +208,14 @@ extern "C" int amid_embgrad_segreduce_f32(const float* grad_rows, const int* pos
     AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0);
     if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK;
+    // standalone use = the data-parallel merge (ids repeat at most `world` times) and the module-level gather backward: short lists
+    // take the fine chunking, 4x the waves for the same rows (3 072 rows: 11.9 -> see DESIGN.md)
+    const int chunk = n_idx <= 65536 ? SEG_CHUNK_SHORT : SEG_CHUNK;
+    const int nch = (n_idx + chunk - 1) / chunk;
     float* partial = (float*)workspace;
 #define AMID_SEG_LAUNCH(VEC)                                                                                                  \
-    segreduce_chunks_kernel<VEC><<<(nch + 3) / 4, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial); \
-    segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad);
+    segreduce_chunks_kernel<VEC><<<(nch + 3) / 4, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial, chunk); \
+    segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad, chunk);
     if (D == 64) { AMID_SEG_LAUNCH(1) } else if (D == 128) { AMID_SEG_LAUNCH(2) } else { AMID_SEG_LAUNCH(4) }
 #undef AMID_SEG_LAUNCH
     AMID_LAUNCH_CHECK();
@@ -231,10 +243,28 @@ extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted,
     return AMID_OK;
 }
 
-extern "C" int amid_sparse_pad_f32(const int* uniq_ids, const float* uniq_rows, const int* n_uniq, int n_out, int D, int pad_id,
-                                   int* out_ids, float* out_rows, void* stream) {
+static int sparse_pad(const int* uniq_ids, const float* uniq_rows, const int* n_uniq, int n_out, int D, int pad_id, int* out_ids,
+                      float* out_rows, const void* entries_dev, int n_entries, int max_count, void* stream) {
     AMID_CHECK_ARG(uniq_ids && uniq_rows && n_uniq && out_ids && out_rows && n_out > 0 && D > 0 && (D % 4) == 0);
-    sparse_pad_kernel<<<(n_out + 7) / 8, 256, 0, (hipStream_t)stream>>>(uniq_ids, uniq_rows, n_uniq, n_out, D, pad_id, out_ids, out_rows);
+    AMID_CHECK_ARG(n_entries == 0 || (entries_dev && n_entries > 0 && max_count > 0));
+    const int n_pad = (n_out + 7) / 8;
+    int bx = n_entries ? (max_count + 127) / 128 : 0;
+    if (bx > 512) bx = 512;
+    sparse_pad_kernel<<<n_pad + bx * n_entries, 256, 0, (hipStream_t)stream>>>(uniq_ids, uniq_rows, n_uniq, n_out, D, pad_id, out_ids, out_rows,
+                                                                              n_pad, (const ReduceEntry*)entries_dev, bx > 0 ? bx : 1);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+
+extern "C" int amid_sparse_pad_f32(const int* uniq_ids, const float* uniq_rows, const int* n_uniq, int n_out, int D, int pad_id,
+                                   int* out_ids, float* out_rows, void* stream) {
+    return sparse_pad(uniq_ids, uniq_rows, n_uniq, n_out, D, pad_id, out_ids, out_rows, nullptr, 0, 0, stream);
+}
+
+// the same padding with `n_entries` fixed-order sums (amid_reduce_entry_pack tables) in the same launch
+extern "C" int amid_sparse_pad_sum_f32(const int* uniq_ids, const float* uniq_rows, const int* n_uniq, int n_out, int D, int pad_id,
+                                       int* out_ids, float* out_rows, const void* entries_dev, int n_entries, int max_count,
+                                       void* stream) {
+    AMID_CHECK_ARG(entries_dev && n_entries > 0);
+    return sparse_pad(uniq_ids, uniq_rows, n_uniq, n_out, D, pad_id, out_ids, out_rows, entries_dev, n_entries, max_count, stream);
 }

@@ -13,6 +13,7 @@
 // stable scatter.  Ranking inside a wave uses ballot-based match-any, so a wave full of the pad id
 // (83-91 % of all indices) costs one LDS add per wave, not 64 serialized atomics.
 #include "common.h"
+#include "reduce_partials.h"
 
 namespace amid {
 
@@ -196,16 +197,63 @@ __global__ __launch_bounds__(256) void heads_write_kernel(const int* __restrict_
     }
 }
 
+// the three kernels above as ONE workgroup for short lists (n <= HEADS_FUSED_MAX: every per-step index list of the cfg 1-4 shapes
+// and the data-parallel merge up to 16 ranks x 4096 rows): thread t owns the contiguous span [t * per, (t + 1) * per), counts its run
+// heads, the 1024 counts are scanned through LDS, and a second pass over the same span writes uniq_ids / seg_off / seg_of.  Three
+// dependent ~5 us launches become one of about that length (they sit on the critical path of the data-parallel step's merge).
+constexpr int HEADS_FUSED_MAX = 65536;
+__global__ __launch_bounds__(1024) void heads_fused_kernel(const int* __restrict__ keys, int n, int* __restrict__ n_uniq,
+                                                           int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of,
+                                                           int use_sentinel, int sentinel) {
+    __shared__ int wsum[16];
+    const int lane = lane_id(), w = wave_id();
+    const int per = (n + 1023) >> 10;
+    const int i0 = min((int)threadIdx.x * per, n), i1 = min(i0 + per, n);
+    int cnt = 0;
+    {
+        int prev = (i0 > 0 && i0 < n) ? keys[i0 - 1] : 0;
+        for (int i = i0; i < i1; ++i) {
+            const int k = keys[i];
+            cnt += (i == 0 || k != prev) ? 1 : 0;
+            prev = k;
+        }
+    }
+    int x = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int k = 0; k < 16; ++k) { if (k < w) woff += wsum[k]; total += wsum[k]; }
+    int u = woff + x - cnt - 1;                          // run index of the entry before this span
+    {
+        int prev = (i0 > 0 && i0 < n) ? keys[i0 - 1] : 0;
+        for (int i = i0; i < i1; ++i) {
+            const int k = keys[i];
+            if (i == 0 || k != prev) { ++u; uniq_ids[u] = k; seg_off[u] = i; }
+            seg_of[i] = u;
+            prev = k;
+        }
+    }
+    if (threadIdx.x == 0) {
+        *n_uniq = (use_sentinel && keys[n - 1] == sentinel) ? total - 1 : total;
+        seg_off[total] = n;
+    }
+}
+
 // Stable merge of `world` sorted lists of `len` keys each (list r = keys[r * len ..]): the merged position of entry (r, i) with
 // key x is i + sum over the other lists of (# keys < x), or (# keys <= x) for lists of lower rank -- ties go in rank order, so the
 // result equals a stable sort of the concatenation.  All binary searches of a thread advance in lock-step (independent loads).
 constexpr int MERGE_MAX_WORLD = 16;
 // key_stride: distance (in ints) between two ranks' lists; the merged position table holds row_base + r * row_stride + i for
 // entry (r, i), i.e. the row of that entry's gradient in whatever layout the gathered buffer has (packed exchange, dist.py).
-__global__ __launch_bounds__(256) void merge_rank_kernel(const int* __restrict__ keys, int world, int len, long long key_stride,
-                                                         int row_base, int row_stride, int* __restrict__ keys_sorted,
-                                                         int* __restrict__ pos_sorted) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void merge_rank_block(const int* __restrict__ keys, int world, int len, long long key_stride,
+                                                 int row_base, int row_stride, int* __restrict__ keys_sorted,
+                                                 int* __restrict__ pos_sorted, int block) {
+    const int e = block * 256 + threadIdx.x;
     if (e >= world * len) return;
     const int r = e / len, i = e - r * len;
     const int x = keys[r * key_stride + i];
@@ -237,6 +285,17 @@ __global__ __launch_bounds__(256) void merge_rank_kernel(const int* __restrict__
         }
     keys_sorted[p] = x;
     pos_sorted[p] = row_base + r * row_stride + i;
+}
+
+// blocks [0, n_merge): the merge; the rest (optional): fixed-order sums of reduce_partials.h -- the rank-ordered sum of the dense
+// gradients that travelled behind the sparse rows is independent of the merge and rides in the same launch
+__global__ __launch_bounds__(256) void merge_rank_kernel(const int* __restrict__ keys, int world, int len, long long key_stride,
+                                                         int row_base, int row_stride, int* __restrict__ keys_sorted,
+                                                         int* __restrict__ pos_sorted, int n_merge, const ReduceEntry* __restrict__ entries,
+                                                         int red_bx) {
+    if ((int)blockIdx.x < n_merge) { merge_rank_block(keys, world, len, key_stride, row_base, row_stride, keys_sorted, pos_sorted, blockIdx.x); return; }
+    const int rb = blockIdx.x - n_merge;
+    reduce_partials_block(entries[rb / red_bx], rb % red_bx, red_bx);
 }
 
 }  // namespace amid
@@ -283,9 +342,13 @@ extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows,
         vin = vout;
     }
     const int hblk = (n_idx + 255) / 256;
-    heads_count_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads);
-    heads_scan_kernel<<<1, 1024, 0, s>>>(blk_heads, hblk, n_uniq, seg_off, n_idx);
-    heads_write_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads, uniq_ids, seg_off, seg_of);
+    if (n_idx <= HEADS_FUSED_MAX) {
+        heads_fused_kernel<<<1, 1024, 0, s>>>(kin, n_idx, n_uniq, uniq_ids, seg_off, seg_of, 0, 0);
+    } else {
+        heads_count_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads);
+        heads_scan_kernel<<<1, 1024, 0, s>>>(blk_heads, hblk, n_uniq, seg_off, n_idx);
+        heads_write_kernel<<<hblk, 256, 0, s>>>(kin, n_idx, blk_heads, uniq_ids, seg_off, seg_of);
+    }
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
@@ -293,22 +356,47 @@ extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows,
 // Data-parallel merge (amid_amd/dist.py): `world` lists of `len` keys, each non-decreasing (a rank's unique ids in ascending order,
 // then `sentinel` padding with sentinel > every id) -> the same outputs as amid_sort_unique_i32 on the concatenation, in 4 launches
 // instead of a full radix sort; the sentinel run, if any, is left out of n_uniq.  Workspace: amid_sort_unique_workspace_bytes(world*len).
-extern "C" int amid_merge_sorted_lists_i32(const int* keys, int world, int len, long long key_stride, int row_base, int row_stride,
-                                           int sentinel, void* workspace, int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of,
-                                           int* n_uniq, void* stream) {
+static int merge_sorted_lists(const int* keys, int world, int len, long long key_stride, int row_base, int row_stride, int sentinel,
+                              void* workspace, int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq,
+                              const void* entries_dev, int n_entries, int max_count, void* stream) {
     AMID_CHECK_ARG(keys && workspace && pos_sorted && uniq_ids && seg_off && seg_of && n_uniq && world > 0 && world <= MERGE_MAX_WORLD &&
                    len > 0 && key_stride >= len && row_base >= 0 && row_stride >= len);
+    AMID_CHECK_ARG(n_entries == 0 || (entries_dev && n_entries > 0 && max_count > 0));
     hipStream_t s = (hipStream_t)stream;
     const int n = world * len;
     char* ws = (char*)workspace;
     const size_t kb = align256((size_t)n * 4);
     int* keys_sorted = (int*)ws;
     int* blk_heads = (int*)(ws + 4 * kb + align256((size_t)256 * sort_nblk(n) * 4));
-    merge_rank_kernel<<<(n + 255) / 256, 256, 0, s>>>(keys, world, len, key_stride, row_base, row_stride, keys_sorted, pos_sorted);
+    const int n_merge = (n + 255) / 256;
+    int bx = n_entries ? (max_count + 127) / 128 : 0;
+    if (bx > 512) bx = 512;
+    merge_rank_kernel<<<n_merge + bx * n_entries, 256, 0, s>>>(keys, world, len, key_stride, row_base, row_stride, keys_sorted, pos_sorted, n_merge,
+                                                             (const ReduceEntry*)entries_dev, bx > 0 ? bx : 1);
     const int hblk = (n + 255) / 256;
-    heads_count_kernel<<<hblk, 256, 0, s>>>(keys_sorted, n, blk_heads);
-    heads_scan_kernel<<<1, 1024, 0, s>>>(blk_heads, hblk, n_uniq, seg_off, n, keys_sorted, sentinel);
-    heads_write_kernel<<<hblk, 256, 0, s>>>(keys_sorted, n, blk_heads, uniq_ids, seg_off, seg_of);
+    if (n <= HEADS_FUSED_MAX) {
+        heads_fused_kernel<<<1, 1024, 0, s>>>(keys_sorted, n, n_uniq, uniq_ids, seg_off, seg_of, 1, sentinel);
+    } else {
+        heads_count_kernel<<<hblk, 256, 0, s>>>(keys_sorted, n, blk_heads);
+        heads_scan_kernel<<<1, 1024, 0, s>>>(blk_heads, hblk, n_uniq, seg_off, n, keys_sorted, sentinel);
+        heads_write_kernel<<<hblk, 256, 0, s>>>(keys_sorted, n, blk_heads, uniq_ids, seg_off, seg_of);
+    }
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+
+extern "C" int amid_merge_sorted_lists_i32(const int* keys, int world, int len, long long key_stride, int row_base, int row_stride,
+                                           int sentinel, void* workspace, int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of,
+                                           int* n_uniq, void* stream) {
+    return merge_sorted_lists(keys, world, len, key_stride, row_base, row_stride, sentinel, workspace, pos_sorted, uniq_ids, seg_off, seg_of,
+                              n_uniq, nullptr, 0, 0, stream);
+}
+
+// the same merge with `n_entries` fixed-order sums (amid_reduce_entry_pack tables, as amid_reduce_partials_f32) in its first launch
+extern "C" int amid_merge_sorted_lists_sum_i32(const int* keys, int world, int len, long long key_stride, int row_base, int row_stride,
+                                               int sentinel, void* workspace, int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of,
+                                               int* n_uniq, const void* entries_dev, int n_entries, int max_count, void* stream) {
+    AMID_CHECK_ARG(entries_dev && n_entries > 0);
+    return merge_sorted_lists(keys, world, len, key_stride, row_base, row_stride, sentinel, workspace, pos_sorted, uniq_ids, seg_off, seg_of,
+                              n_uniq, entries_dev, n_entries, max_count, stream);
 }

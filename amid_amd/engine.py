@@ -967,8 +967,7 @@ class SasrecEngine:
                     send = be.pad_packed(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax, dense=self.dense.grad)
                 else:
                     recv = be.gather_buffer(exchange.world, umax, dense=self.dense.grad)
-                    be.sum_dense(recv, exchange.world, umax, self.dense.grad)
-                    self.enqueue_optimizer(pl, sparse=be.merge_packed(recv, exchange.world, umax, dense=self.dense.grad))
+                    self.enqueue_optimizer(pl, sparse=be.merge_packed(recv, exchange.world, umax, dense=self.dense.grad, sum_dense=True))
             finally:
                 out = ctypes.c_void_p()
                 L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
@@ -1125,12 +1124,14 @@ class HipMergeBackend:
         D = self.eng.D
         id_rows, rows = packed_rows(umax, D)
         send = self.send[: self.chunk_rows(umax, dense) * D]
-        if dense is not None:
-            ent = self._entry(("copy", umax), dense.data_ptr(), send.data_ptr() + 4 * rows * D, 0, 1, dense.numel())
-            lib().call("amid_reduce_partials_f32", ent.data_ptr(), 1, dense.numel(), self.eng.s)
         # sentinel padding (one past the last table row) keeps every rank's list sorted, so merge_packed() is a merge, not a sort
-        lib().call("amid_sparse_pad_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), umax, D, self.eng.n_rows,
-                   send.data_ptr(), send.data_ptr() + 4 * id_rows * D, self.eng.s)
+        if dense is not None:          # the copy of the flat dense gradient behind the rows rides in the padding launch
+            ent = self._entry(("copy", umax), dense.data_ptr(), send.data_ptr() + 4 * rows * D, 0, 1, dense.numel())
+            lib().call("amid_sparse_pad_sum_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), umax, D, self.eng.n_rows,
+                       send.data_ptr(), send.data_ptr() + 4 * id_rows * D, ent.data_ptr(), 1, dense.numel(), self.eng.s)
+        else:
+            lib().call("amid_sparse_pad_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), umax, D, self.eng.n_rows,
+                       send.data_ptr(), send.data_ptr() + 4 * id_rows * D, self.eng.s)
         return send
 
     def gather_buffer(self, world: int, umax: int, dense: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -1139,18 +1140,27 @@ class HipMergeBackend:
             raise ValueError(f"gather of {world} x {umax} entries exceeds the backend capacity {self.cap}")
         return self.all[:n]
 
-    def merge_packed(self, gathered: torch.Tensor, world: int, umax: int, dense: Optional[torch.Tensor] = None):
-        """`world` packed chunks (sorted, sentinel-padded ids + rows [+ a dense tail the merge skips]) -> 4-launch stable merge +
-        segment reduce."""
+    def merge_packed(self, gathered: torch.Tensor, world: int, umax: int, dense: Optional[torch.Tensor] = None, sum_dense: bool = False):
+        """`world` packed chunks (sorted, sentinel-padded ids + rows [+ a dense tail the merge skips]) -> 2-launch stable merge +
+        segment reduce.  sum_dense: the rank-ordered sum of the dense tails into `dense` (what sum_dense() does) rides in the
+        merge's first launch."""
         from .dist import packed_rows
         L, eng = lib(), self.eng
         D = eng.D
         id_rows, _ = packed_rows(umax, D)
         rows = self.chunk_rows(umax, dense)
         n = world * umax
-        L.call("amid_merge_sorted_lists_i32", gathered.data_ptr(), world, umax, rows * D, id_rows, rows, eng.n_rows, self.sort_ws.data_ptr(),
-               self.pos_sorted.data_ptr(), self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
-               self.n_uniq.data_ptr(), eng.s)
+        if sum_dense and dense is not None:
+            off = packed_rows(umax, D)[1] * D
+            ent = self._entry(("sum", gathered.data_ptr(), world, umax), gathered.data_ptr() + 4 * off, dense.data_ptr(), rows * D, world,
+                              dense.numel())
+            L.call("amid_merge_sorted_lists_sum_i32", gathered.data_ptr(), world, umax, rows * D, id_rows, rows, eng.n_rows,
+                   self.sort_ws.data_ptr(), self.pos_sorted.data_ptr(), self.uniq_ids.data_ptr(), self.seg_off.data_ptr(),
+                   self.seg_of.data_ptr(), self.n_uniq.data_ptr(), ent.data_ptr(), 1, dense.numel(), eng.s)
+        else:
+            L.call("amid_merge_sorted_lists_i32", gathered.data_ptr(), world, umax, rows * D, id_rows, rows, eng.n_rows, self.sort_ws.data_ptr(),
+                   self.pos_sorted.data_ptr(), self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
+                   self.n_uniq.data_ptr(), eng.s)
         L.call("amid_embgrad_segreduce_f32", gathered.data_ptr(), self.pos_sorted.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
                n, D, self.seg_ws.data_ptr(), self.uniq_rows.data_ptr(), eng.s)
         return self.uniq_ids[:n], self.uniq_rows[:n], self.n_uniq

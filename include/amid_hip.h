@@ -94,6 +94,14 @@ int amid_sparse_pad_f32(const int* uniq_ids, const float* uniq_rows, const int* 
                         float* out_rows, void* stream);
 int amid_merge_sorted_lists_i32(const int* keys, int world, int len, long long key_stride, int row_base, int row_stride, int sentinel,
                                 void* workspace, int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq, void* stream);
+/* the two helpers with `n_entries` fixed-order sums (tables of amid_reduce_entry_pack, semantics of amid_reduce_partials_f32) riding in
+ * their first launch: the data-parallel step copies its flat dense gradient behind the padded rows (pad) and sums the ranks' dense
+ * parts in rank order (merge) without a launch of their own -- both are independent of the sparse work they ride with. */
+int amid_sparse_pad_sum_f32(const int* uniq_ids, const float* uniq_rows, const int* n_uniq, int n_out, int D, int pad_id, int* out_ids,
+                            float* out_rows, const void* entries_dev, int n_entries, int max_count, void* stream);
+int amid_merge_sorted_lists_sum_i32(const int* keys, int world, int len, long long key_stride, int row_base, int row_stride, int sentinel,
+                                    void* workspace, int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq,
+                                    const void* entries_dev, int n_entries, int max_count, void* stream);
 
 /* amid_embgrad_segreduce_f32 + amid_reduce_partials_f32 with their first phases in ONE launch (the two independent ends of backward
  * side by side without a second stream) */
