@@ -28,6 +28,7 @@ struct AttnArgs {
     float scale;                                          // sqrt(1/hd) (causal) or sqrt(d_k) divisor (BERT)
     const StepState* st; int train; unsigned thr16; float dscale; int layer;
     int stagger_from, stagger_sleeps;      // set by the MFMA backward launcher only
+    const long long* row_domain;           // backward only, optional [B]: sequence (g, b) has a gradient only if (row_domain[b] != 0) == g
 };
 
 template <int HD>
@@ -368,13 +369,35 @@ extern "C" int amid_attn_fwd_f32(const float* q, const float* k, const float* v,
     }
 }
 
+static int attn_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o,
+                         const unsigned char* key_keep, int B, int T, int D, int H, int causal, int layer, const void* step_state,
+                         int train, float p_drop, float* dq, float* dk, float* dv, const long long* row_domain, void* stream);
+
 extern "C" int amid_attn_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o,
                                  const unsigned char* key_keep, int B, int T, int D, int H, int causal, int layer, const void* step_state,
                                  int train, float p_drop, float* dq, float* dk, float* dv, void* stream) {
+    return attn_bwd_impl(q, k, v, o, stats, d_o, key_keep, B, T, D, H, causal, layer, step_state, train, p_drop, dq, dk, dv, nullptr, stream);
+}
+
+// the same with the training loss's structure handed in: train_sr.py:205-211 masks row b's BCE of domain 1 - domain_id[b] with
+// zero, so the sequence (g, b) with g != domain_id[b] receives an all-zero d_o and its dq / dk / dv are exact zeros -- the
+// matrix-core kernels write those zeros without loading or computing anything (half of all sequences); the other kernels ignore
+// the hint and compute the same zeros the long way.  Only valid when d_o really is zero there (the caller's loss is that BCE).
+extern "C" int amid_attn_bwd_rows_f32(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o,
+                                      const unsigned char* key_keep, int B, int T, int D, int H, int causal, int layer,
+                                      const void* step_state, int train, float p_drop, float* dq, float* dk, float* dv,
+                                      const long long* row_domain, void* stream) {
+    return attn_bwd_impl(q, k, v, o, stats, d_o, key_keep, B, T, D, H, causal, layer, step_state, train, p_drop, dq, dk, dv, row_domain, stream);
+}
+
+static int attn_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o,
+                         const unsigned char* key_keep, int B, int T, int D, int H, int causal, int layer, const void* step_state,
+                         int train, float p_drop, float* dq, float* dk, float* dv, const long long* row_domain, void* stream) {
     AttnArgs a = {};
     if (int e = attn_fill(a, q, k, v, key_keep, B, T, D, H, causal, layer, step_state, train, p_drop)) return e;
     AMID_CHECK_ARG(o && stats && d_o && dq && dk && dv);
     a.o = const_cast<float*>(o); a.stats = const_cast<float*>(stats); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.row_domain = row_domain;
     if (mfma_shape(a)) return amid_attn_mfma_bwd_launch(&a, stream);
     if (long_shape(a)) return amid_attn_long_bwd_launch(&a, stream);
     if (bert_shape(a)) return amid_attn_bert_bwd_launch(&a, stream);

@@ -34,7 +34,49 @@ struct AttnArgs {          // must stay identical to the struct in attention.hip
     float scale;
     const StepState* st; int train; unsigned thr16; float dscale; int layer;
     int stagger_from, stagger_sleeps;      // set by the MFMA backward launcher only
+    const long long* row_domain;           // backward only, optional [B]: sequence (g, b) has a gradient only if (row_domain[b] != 0) == g
 };
+
+
+// ---- backward with a row_domain hint (AttnArgs::row_domain): which sequence does workgroup slot j work on? ----
+// Sequence (g, b) carries a gradient only if (row_domain[b] != 0) == g.  Handing slot j the sequence j would leave the CUs
+// unevenly loaded (the hardware spreads consecutive workgroups over the CUs in a fixed pattern: with a random half of them exiting at
+// once some CUs keep twice the work of others -- measured at B 256: 36.5 us against 26.8 us for an all-active launch of half the size), so
+// the slots are renumbered: [0, B) = the B live sequences (domain 0's, then domain 1's, each in batch order), [B, 2B) = the dead
+// ones, which only store zeros.  Every workgroup derives the mapping itself from the B domain flags (ballots + popcounts, wave-uniform,
+// under a microsecond for B <= 1024); larger batches keep the identity mapping.
+__device__ __forceinline__ int nth_row_with(const long long* __restrict__ dom, int B, int val, int k) {
+    const int lane = lane_id();
+    for (int c = 0; c < B; c += 64) {
+        const int b = c + lane;
+        const bool f = b < B && ((dom[b] != 0 ? 1 : 0) == val);
+        unsigned long long m = __ballot(f);
+        const int n = __popcll(m);
+        if (k < n) {
+            for (int i = 0; i < k; ++i) m &= m - 1;          // drop the k lowest set bits
+            return c + __ffsll((long long)m) - 1;
+        }
+        k -= n;
+    }
+    return 0;
+}
+__device__ __forceinline__ int live_rows_remap(const long long* __restrict__ dom, int B, int j, bool& live) {
+    if (B > 1024) {                                           // identity: the sequence's own flag decides
+        const int g = j / B, b = j - g * B;
+        live = (dom[b] != 0 ? 1 : 0) == g;
+        return j;
+    }
+    const int lane = lane_id();
+    int n0 = 0;                                               // rows whose own domain is 0
+    for (int c = 0; c < B; c += 64) n0 += __popcll(__ballot(c + lane < B && dom[c + lane] == 0));
+    live = j < B;
+    int g, val, k;
+    if (j < n0)          { g = 0; val = 0; k = j; }                     // live sequences of domain 0
+    else if (j < B)      { g = 1; val = 1; k = j - n0; }                // live sequences of domain 1
+    else if (j - B < B - n0) { g = 0; val = 1; k = j - B; }             // dead ones: domain-0 encoder rows of domain-1 samples
+    else                 { g = 1; val = 0; k = j - B - (B - n0); }      //            domain-1 encoder rows of domain-0 samples
+    return g * B + nth_row_with(dom, B, val, k);
+}
 
 constexpr int AHD = 16;
 constexpr float LOG2E = 1.4426950408889634f;

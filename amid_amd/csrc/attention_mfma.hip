@@ -34,7 +34,10 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
     // this kernel's ~190 VGPRs, and the second residents of the first wave of workgroups start late (below), so that from then
     // on one workgroup's loads run under the other's MFMAs (one 8-head workgroup per CU ran load -> compute -> load -> compute)
     const int hw = blockDim.x >> 6, parts = H / hw;
-    const int seq = blockIdx.x / parts, part = blockIdx.x - seq * parts, g = seq / a.B, b = seq - g * a.B;
+    const int slot = blockIdx.x / parts, part = blockIdx.x - slot * parts;
+    bool live = true;
+    const int seq = a.row_domain != nullptr ? live_rows_remap(a.row_domain, a.B, slot, live) : slot;
+    const int g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
     const int wv = wave_id(), h = part * hw + wv, lane = lane_id();
     const int m = lane & 15, gq = lane >> 4;
@@ -42,6 +45,14 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
     const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
     float4* rstat = reinterpret_cast<float4*>(smem) + wv * 64;                          // [hw][64] (max, 1/sum, delta, -)
     unsigned long long* keepw = reinterpret_cast<unsigned long long*>(smem + hw * 64 * 4) + wv * 64;   // [hw][64]
+    if (!live) {                                                                       // no gradient reaches this sequence: exact zeros
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < T * (AHD / 4); i += 64) {
+            const long long off = (rowbase + i / (AHD / 4)) * D + h * AHD + 4 * (i % (AHD / 4));
+            st4(a.dq + off, z); st4(a.dk + off, z); st4(a.dv + off, z);
+        }
+        return;
+    }
     if (a.stagger_from >= 0 && (int)blockIdx.x >= a.stagger_from && (int)blockIdx.x < 2 * a.stagger_from) {
 #pragma unroll 1
         for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);       // 127 x 64 clocks each

@@ -116,13 +116,24 @@ __global__ __launch_bounds__(512) void attn_fwd_bert_kernel(const AttnArgs a) {
 __global__ __launch_bounds__(512) void attn_bwd_bert_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, D = a.D, H = a.H;
-    const int seq = blockIdx.x, g = seq / a.B, b = seq - g * a.B;
+    bool live = true;
+    const int seq = a.row_domain != nullptr ? live_rows_remap(a.row_domain, a.B, blockIdx.x, live) : (int)blockIdx.x;
+    const int g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
     const int h = wave_id(), lane = lane_id();
     const int m = lane & 15, gq = lane >> 4;
     const int NT = (T + 15) >> 4;
     const float inv = 1.0f / a.scale;
     const unsigned char* kk = a.key_keep ? a.key_keep + (long long)b * T : nullptr;
+    if (!live) {                                                                       // no gradient reaches this sequence: exact zeros
+        const int hd = D / H, q4 = hd >> 2;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < T * q4; i += 64) {
+            const long long off = (rowbase + i / q4) * D + h * hd + 4 * (i % q4);
+            st4(a.dq + off, z); st4(a.dk + off, z); st4(a.dv + off, z);
+        }
+        return;
+    }
     float4* rstat = reinterpret_cast<float4*>(smem) + h * 64;                                       // [H][64] (max, 1/sum, delta, -)
     unsigned long long* keepw = reinterpret_cast<unsigned long long*>(smem + H * 64 * 4) + h * 64;   // [H][64]
     // ---------------- phase 1: lanes = queries -> dQ; row stats + keep words to LDS ----------------

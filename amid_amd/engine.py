@@ -809,9 +809,9 @@ class SasrecEngine:
                     self._wT(l, 4), self._wT(l, 5), self._wT(l, 3))
 
         def attn_bwd(l):
-            L.call("amid_attn_bwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(),
+            L.call("amid_attn_bwd_rows_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(),
                    pl.stats[l].data_ptr(), pl.d_o.data_ptr(), None, B, T, D, self.H, 1, l, st, tr, SASREC_P_DROP, pl.dq_l[l].data_ptr(),
-                   pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), s)
+                   pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), self._own_rows(pl), s)
 
         tm, h1, r1, lnw1, w1T1, w2T1, woT1 = ffn_bwd_args(1)
         L.call("amid_sas_ffn_bwd_f32" + pl.rt_suffix, pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, M, D, pl.rpt, 1, st, tr,
@@ -897,11 +897,20 @@ class SasrecEngine:
         """Forward (loss included; its sum rides in the gradient tail) + backward of a training step."""
         self._fuse_head = self.FUSED_HEAD and not self.dr and not self.itc_bs
         self._fuse_scorers = self.FUSED_HEAD and bool(self.dr or self.itc_bs) and (not self.dr or pl.shape.NI <= 16)
+        # the step's own loss masks row b's terms of domain 1 - domain_id[b] with zero (train_sr.py:205-211; the doubly-robust
+        # objectives likewise, train_sr_dr.py:216-221, :392-394): the encoder of that domain gets an all-zero gradient for row b.
+        # InterComp AFTER the encoders mixes the rows' user vectors, so every sequence has a gradient there.
+        self._own_domain_only = not self.itc_bs
         try:
             self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)
             self.enqueue_backward(pl, train=True)
         finally:
-            self._fuse_head = self._fuse_scorers = False
+            self._fuse_head = self._fuse_scorers = self._own_domain_only = False
+
+    def _own_rows(self, pl: SasrecPlan):
+        """Device pointer of the batch's domain ids when backward may treat the other domain's sequences as gradient-free (see
+        _enqueue_fwd_bwd), else None: a backward driven by someone else's loss (the autograd path) makes no such promise."""
+        return pl.domain.data_ptr() if getattr(self, "_own_domain_only", False) else None
 
     def capture_local_grads(self, pl: SasrecPlan) -> None:
         L = lib()

@@ -238,9 +238,9 @@ class Bert4recEngine(SasrecEngine):
             L.call("amid_bert_ffn1_bwd_f32" + pl.rt_suffix, pl.dpre.data_ptr(), pl.dxbuf.data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".output_sublayer.norm.a_2"),
                    ptr_array([self.w1T[l, g].data_ptr() for g in (0, 1)]), wsq(3), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.dx1.data_ptr(),
                    pl.dt.data_ptr(), pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), s)
-            L.call("amid_attn_bwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(), pl.stats[l].data_ptr(),
+            L.call("amid_attn_bwd_rows_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(), pl.stats[l].data_ptr(),
                    pl.d_o.data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l, st, tr, BERT_P_DROP, pl.dq.data_ptr(), pl.dk.data_ptr(),
-                   pl.dv.data_ptr(), s)
+                   pl.dv.data_ptr(), self._own_rows(pl), s)
             dx_out = (pl.dx0 if self.comp else pl.dxg) if l == 0 else pl.dxbuf
             wT3 = ptr_array([self.wT_sq[l, g, j].data_ptr() for j in range(3) for g in (0, 1)])
             # weight-gradient tiles need dx-independent operands only: launch before qkv_bwd overwrites dxbuf

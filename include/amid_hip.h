@@ -168,6 +168,12 @@ int amid_attn_fwd_f32(const float* q, const float* k, const float* v, const unsi
 int amid_attn_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o,
                       const unsigned char* key_keep, int B, int T, int D, int H, int causal, int layer, const void* step_state, int train,
                       float p_drop, float* dq, float* dk, float* dv, void* stream);
+/* backward with the loss's structure as a hint: row_domain [B] (= the batch's domain_id, train_sr.py:184) says that sequence (g, b)
+ * has a non-zero d_o only if (row_domain[b] != 0) == g -- the other domain's BCE is multiplied by zero (train_sr.py:205-211) -- so
+ * the matrix-core kernels store exact zeros for the other half without loading anything.  Same results as amid_attn_bwd_f32. */
+int amid_attn_bwd_rows_f32(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o,
+                           const unsigned char* key_keep, int B, int T, int D, int H, int causal, int layer, const void* step_state,
+                           int train, float p_drop, float* dq, float* dk, float* dv, const long long* row_domain, void* stream);
 
 /* ---- SASRec encoder layer, backward (autograd of model_seq.py:371-383 under loss.backward(), train_sr.py:214) */
 int amid_transpose_weights_f32(const float* const* src, float* const* dst, int n /* <= 32 */, int D, void* stream);

@@ -441,3 +441,39 @@ def test_lazy_adam_long_idle_gap_beyond_coefficient_table(L):
     L.call("amid_lazy_adam_flush_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), n_rows, D, st.data_ptr(), stream())
     torch.cuda.synchronize()
     assert float((tab.cpu() - P["t"]).abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize("shape", ["sasrec", "bert"])
+@pytest.mark.parametrize("B", [5, 130, 1030])          # 1030 > 1024: the kernels keep the identity slot -> sequence mapping
+def test_attention_bwd_rows_hint_equals_plain_backward(L, shape, B):
+    """amid_attn_bwd_rows_f32 (the loss structure as a hint: the sequence (g, b) with g != row_domain[b] has an all-zero d_o) against
+    amid_attn_bwd_f32 on the same inputs: bit-identical on the live sequences, exact zeros on the others."""
+    T, D = 50, 128
+    H, causal, p = (8, 1, 0.5) if shape == "sasrec" else (4, 0, 0.1)
+    g = torch.Generator().manual_seed(B)
+    q, k, v, do = (dev(torch.randn(2 * B, T, D, generator=g)) for _ in range(4))
+    dom = (torch.rand(B, generator=g) < 0.5).long()
+    live = torch.cat((dom == 0, dom == 1))                      # [2B]: sequence g * B + b carries a gradient iff dom[b] == g
+    do = do * dev(live.float())[:, None, None]
+    keep = None
+    if shape == "bert":
+        keep = dev((torch.rand(B, T, generator=g) < 0.8).to(torch.uint8))
+    kp = keep.data_ptr() if keep is not None else None
+    st = step_state(L, 5, 9)
+    o = torch.empty_like(q); stats = torch.empty(2 * B * T, H, 2, device="cuda")
+    L.call("amid_attn_fwd_f32", q.data_ptr(), k.data_ptr(), v.data_ptr(), kp, B, T, D, H, causal, 0, st.data_ptr(), 1, p, o.data_ptr(),
+           stats.data_ptr(), stream())
+    outs = []
+    for hint in (None, dev(dom)):
+        dq, dk, dv = (torch.full_like(q, float("nan")) for _ in range(3))
+        args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), stats.data_ptr(), do.data_ptr(), kp, B, T, D, H, causal, 0, st.data_ptr(), 1, p,
+                dq.data_ptr(), dk.data_ptr(), dv.data_ptr())
+        if hint is None:
+            L.call("amid_attn_bwd_f32", *args, stream())
+        else:
+            L.call("amid_attn_bwd_rows_f32", *args, hint.data_ptr(), stream())
+        torch.cuda.synchronize()
+        outs.append((dq.cpu(), dk.cpu(), dv.cpu()))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a[live], b_[live])
+        assert float(b_[~live].abs().max()) == 0.0 and float(a[~live].abs().max()) == 0.0
