@@ -284,9 +284,14 @@ struct WgradArgs {
     float* w_part[2];          // per layer: [2][6][splits][D*D]
     float* b_part[2];          // per layer: [2][6][splits][D]
     int M, splits, rows_per_split;
+    // optional hint (amid_sas_wgrad_rows_f32): only the sequences b of domain g with (row_domain[b] != 0) == g have non-zero dY rows
+    // (the loss masks the other domain of every sample, train_sr.py:205-211); the M = B * T rows of a domain are then walked as
+    // n_live * T "virtual" rows -- the live sequences back to back -- and the dead half is never read
+    const long long* row_domain; int B, T;
 };
 
 constexpr int WG_ROWS = 64;    // rows staged per step
+[[maybe_unused]] constexpr int WG_LIVE_MAX = 1024;      // sequences per domain the live list (LDS, one int each) is built for
 
 // One workgroup = one (domain, weight, row split): it streams its rows of (dY, X) in 64-row chunks through LDS and
 // accumulates dW = dY^T X on the matrix cores (one wave per 16 output rows at D = 128).  Single LDS buffer (74 KB at
@@ -304,13 +309,34 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradA
     constexpr int KTW = NTn / WPN;                     // k tiles per wave (8 at D=128, 2 at D=64)
     float* Ys = smem;
     float* Xs = smem + WG_ROWS * LD;
+    int* live = reinterpret_cast<int*>(smem + 2 * WG_ROWS * LD);       // [B] batch rows of this domain's live sequences (hint only)
     const int split = blockIdx.x, wsel = blockIdx.y, g = blockIdx.z;
     const int layer = wsel / 6, wi = wsel - layer * 6;
     const float* __restrict__ dy = a.dy[wsel];
     const float* __restrict__ xin = a.xin[wsel];
-    const int local_beg = split * a.rows_per_split;
-    const int local_end = min(a.M, local_beg + a.rows_per_split);
     const int w = wave_id(), lane = lane_id();
+    const bool hint = a.row_domain != nullptr;
+    int local_beg = split * a.rows_per_split;
+    int local_end = min(a.M, local_beg + a.rows_per_split);
+    if (hint) {                                        // wave 0 lists the live sequences in batch order; everyone learns the count
+        __shared__ int n_live_s;
+        if (w == 0) {
+            int n = 0;
+            for (int c = 0; c < a.B; c += 64) {
+                const int b = c + lane;
+                const bool f = b < a.B && ((a.row_domain[b] != 0 ? 1 : 0) == g);
+                const unsigned long long m = __ballot(f);
+                if (f) live[n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+                n += __popcll(m);
+            }
+            if (lane == 0) n_live_s = n;
+        }
+        __syncthreads();
+        const int mv = n_live_s * a.T;                 // virtual rows of this domain
+        const int rps = (mv + a.splits - 1) / a.splits;
+        local_beg = min(mv, split * rps);
+        local_end = min(mv, local_beg + rps);
+    }
     const int nt = w / WPN, kt0 = (w % WPN) * KTW;
     const int i = lane & 15, gq = lane >> 4;
     constexpr int QPR = D / 4, RPP = GEMM_THREADS / QPR;
@@ -328,8 +354,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradA
         for (int i = 0; i < NRW; ++i) {
             const int r = rl + i * RPP;
             const bool ok = r < nr;
-            py[i] = ok ? ld4(dy + (grow + r) * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-            px[i] = ok ? ld4(xin + (grow + r) * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            long long row = grow + r;
+            if (hint && ok) {                          // virtual row -> (live sequence, position) -> row of the domain
+                const int v = c0 + r, sq = v / a.T;
+                row = (long long)g * a.M + (long long)live[sq] * a.T + (v - sq * a.T);
+            }
+            py[i] = ok ? ld4(dy + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            px[i] = ok ? ld4(xin + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if (local_beg < local_end) fetch(local_beg);
@@ -511,26 +542,44 @@ extern "C" int AMID_ENTRY(amid_sas_qkv_ffn_bwd_f32)(const float* dq, const float
 }
 
 #if AMID_TILE_RT == 7      // everything below is independent of the row-tile height: one copy only
-extern "C" int amid_sas_wgrad_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits,
-                                  float* const* w_part, float* const* b_part, void* stream) {
+static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
+                     float* const* b_part, const long long* row_domain, int B, int T, void* stream) {
     AMID_CHECK_ARG(dy && x && w_part && b_part && (n_layers == 1 || n_layers == 2) && M > 0 && splits > 0);
+    AMID_CHECK_ARG(!row_domain || (B > 0 && T > 0 && (long long)B * T == M));
     WgradArgs a;
     for (int i = 0; i < 6 * n_layers; ++i) { AMID_CHECK_ARG(dy[i] && x[i]); a.dy[i] = dy[i]; a.xin[i] = x[i]; }
     for (int l = 0; l < n_layers; ++l) { AMID_CHECK_ARG(w_part[l] && b_part[l]); a.w_part[l] = w_part[l]; a.b_part[l] = b_part[l]; }
     a.M = M; a.splits = splits;
     a.rows_per_split = (M + splits - 1) / splits;
+    // the live list lives in LDS: beyond WG_LIVE_MAX sequences the hint is dropped (every row is walked; same result)
+    a.row_domain = (row_domain && B <= WG_LIVE_MAX) ? row_domain : nullptr; a.B = B; a.T = T;
+    const size_t live_bytes = a.row_domain ? (size_t)((B + 3) & ~3) * sizeof(int) : 0;
     const dim3 grid(splits, 6 * n_layers, 2);
     if (D == 128) {
-        const size_t lds = (size_t)2 * WG_ROWS * (128 + 16) * sizeof(float);
-        static bool set128 = false;
-        if (!set128) { hipError_t e = hipFuncSetAttribute((const void*)sas_wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; set128 = true; }
+        const size_t lds = (size_t)2 * WG_ROWS * (128 + 16) * sizeof(float) + live_bytes;
+        static size_t set128 = 0;
+        const size_t want = (size_t)2 * WG_ROWS * (128 + 16) * sizeof(float) + WG_LIVE_MAX * sizeof(int);
+        if (set128 < want) { hipError_t e = hipFuncSetAttribute((const void*)sas_wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want); if (e != hipSuccess) return (int)e; set128 = want; }
         sas_wgrad_kernel<128><<<grid, GEMM_THREADS, lds, (hipStream_t)stream>>>(a);
     } else if (D == 64) {
-        const size_t lds = (size_t)2 * WG_ROWS * (64 + 16) * sizeof(float);
+        const size_t lds = (size_t)2 * WG_ROWS * (64 + 16) * sizeof(float) + live_bytes;
         sas_wgrad_kernel<64><<<grid, GEMM_THREADS, lds, (hipStream_t)stream>>>(a);
     } else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+
+extern "C" int amid_sas_wgrad_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits,
+                                  float* const* w_part, float* const* b_part, void* stream) {
+    return sas_wgrad(dy, x, n_layers, M, D, splits, w_part, b_part, nullptr, 0, 0, stream);
+}
+
+// the same with the loss structure as a hint (see WgradArgs::row_domain): M = B * T rows per domain, row_domain [B] = the batch's
+// domain ids; the rows of the sequences whose dY is zero by construction are skipped -- same partial sums up to the zeros left out
+extern "C" int amid_sas_wgrad_rows_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits,
+                                       float* const* w_part, float* const* b_part, const long long* row_domain, int B, int T,
+                                       void* stream) {
+    return sas_wgrad(dy, x, n_layers, M, D, splits, w_part, b_part, row_domain, B, T, stream);
 }
 
 extern "C" int amid_transpose_weights_f32(const float* const* src, float* const* dst, int n, int D, void* stream) {

@@ -835,8 +835,8 @@ class SasrecEngine:
                    pl.dpre2[l].data_ptr()]
             xx += [pl.qn[l].data_ptr(), pl.x[l].data_ptr(), pl.x[l].data_ptr(), pl.o[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr()]
         # NOTE: pl.x[0] is the gathered-row buffer xg, still intact here (its gradient lives in dxg)
-        L.call("amid_sas_wgrad_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
-               ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), s)
+        L.call("amid_sas_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
+               ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), self._own_rows(pl), B, T, s)
         L.call("amid_embed_bwd_f32", (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits,
                pl.dpos_part.data_ptr(), st, tr, SASREC_P_DROP, s)
         if self.inc_bs:      # InnerComp's parameter gradients; the rows' own halves + its share -> the table-row gradient buffer

@@ -131,6 +131,10 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_sas_qkv_bwd_f32": ("mfma", 3 * gemm),
         "amid_sas_qkv_ffn_bwd_f32": ("mfma", 6 * gemm),
         "amid_sas_wgrad_f32": ("mfma", 12 * gemm),          # both layers in one launch
+        # the train step's own backward: of each domain only the samples of that domain carry a gradient (the loss multiplies the
+        # other domain's BCE by zero, train_sr.py:205-211), the kernels walk those sequences only -- half the rows, priced as such
+        "amid_sas_wgrad_rows_f32": ("mfma", 6 * gemm),
+        "amid_attn_bwd_rows_f32": ("mfma", 10.0 * T * T * hd * Bw * H),
         "amid_bert_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_bert_oproj_fwd_f32": ("mfma", gemm),
         "amid_bert_ffn1_fwd_f32": ("mfma", 4 * gemm),       # [M, 128] x [128, 512]
@@ -154,6 +158,9 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
 KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's name in rocprofv3 output
     "amid_sas_qkv_fwd_f32": "sas_qkv_fwd_kernel", "amid_sas_oproj_fwd_f32": "sas_oproj_fwd_kernel", "amid_sas_ffn_fwd_f32": "sas_ffn_fwd_kernel",
     "amid_sas_ffn_bwd_f32": "sas_ffn_bwd_kernel", "amid_sas_qkv_bwd_f32": "sas_qkv_bwd_kernel", "amid_sas_wgrad_f32": "sas_wgrad_kernel",
+    "amid_sas_wgrad_rows_f32": "sas_wgrad_kernel", "amid_attn_bwd_rows_f32": "attn_bwd_mfma_kernel",
+    "amid_sas_qkv_ffn_bwd_f32": "sas_qkv_ffn_bwd_kernel", "amid_sas_oproj_ffn_qkv_fwd_f32": "sas_oproj_ffn_qkv_fwd_kernel",
+    "amid_sas_oproj_ffn_fwd_f32": "sas_oproj_ffn_fwd_kernel",
     "amid_attn_fwd_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_f32": "embed_fwd_kernel",
     "amid_embgrad_segreduce_f32": "segreduce_chunks_kernel",
 }

@@ -197,6 +197,11 @@ int amid_sas_qkv_ffn_bwd_f32(const float* dq, const float* dk, const float* dv, 
  * arrays of n_layers device pointers to [2][6][splits][D*D] and [2][6][splits][D] */
 int amid_sas_wgrad_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
                        float* const* b_part, void* stream);
+/* with the loss structure as a hint (row_domain [B] = the batch's domain_id, M = B * T): of domain g only the sequences b with
+ * (row_domain[b] != 0) == g have non-zero dY rows (train_sr.py:205-211 multiplies the other domain's BCE by zero), and only those
+ * rows are read -- the K dimension of every weight-gradient product halves.  Same results as amid_sas_wgrad_f32 (zeros left out). */
+int amid_sas_wgrad_rows_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
+                            float* const* b_part, const long long* row_domain, int B, int T, void* stream);
 /* fixed-order reduction of partial buffers; entries are packed on the host then copied to the device by the caller */
 int amid_reduce_entry_bytes(void);
 int amid_reduce_entry_pack(void* host_buf, int index, const float* src, float* dst, long long stride, int n_part, int count);

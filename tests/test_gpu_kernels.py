@@ -477,3 +477,33 @@ def test_attention_bwd_rows_hint_equals_plain_backward(L, shape, B):
     for a, b_ in zip(*outs):
         assert torch.equal(a[live], b_[live])
         assert float(b_[~live].abs().max()) == 0.0 and float(a[~live].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,T", [(6, 50), (37, 20), (256, 50)])
+def test_wgrad_rows_hint_equals_plain(L, B, T):
+    """amid_sas_wgrad_rows_f32 (only the live sequences' rows are read) against amid_sas_wgrad_f32 on dY whose dead rows are zero:
+    the sums over the splits agree to rounding (the rows are grouped into the splits differently)."""
+    D, M, splits = 128, B * T, 5
+    g = torch.Generator().manual_seed(B + T)
+    dom = (torch.rand(B, generator=g) < 0.5).long()
+    live = torch.cat((dom == 0, dom == 1)).float().repeat_interleave(T)          # [2M]
+    dy = [dev(torch.randn(2 * M, D, generator=g) * live[:, None]) for _ in range(6)]
+    xx = [dev(torch.randn(2 * M, D, generator=g)) for _ in range(6)]
+    from amid_amd._lib import ptr_array
+    outs = []
+    for hint in (False, True):
+        wp = torch.full((2, 6, splits, D * D), float("nan"), device="cuda"); bp = torch.full((2, 6, splits, D), float("nan"), device="cuda")
+        args = (ptr_array([t.data_ptr() for t in dy]), ptr_array([t.data_ptr() for t in xx]), 1, M, D, splits, ptr_array([wp.data_ptr()]),
+                ptr_array([bp.data_ptr()]))
+        if hint:
+            L.call("amid_sas_wgrad_rows_f32", *args, dev(dom).data_ptr(), B, T, stream())
+        else:
+            L.call("amid_sas_wgrad_f32", *args, stream())
+        torch.cuda.synchronize()
+        outs.append((wp.sum(2).cpu(), bp.sum(2).cpu()))
+    for a, b_ in zip(*outs):
+        assert torch.isfinite(b_).all()
+        assert float((a - b_).abs().max()) < 2e-5 * float(a.abs().max())
+    for gdom in range(2):          # against the plain definition dW = dY^T X
+        want = dy[0][gdom * M:(gdom + 1) * M].double().t() @ xx[0][gdom * M:(gdom + 1) * M].double()
+        assert relmax(outs[1][0][gdom, 0].view(D, D), want) < 1e-5
