@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_bwd_kernel(float* __restrict__ dxg, const unsigned char* __restrict__ tmq,
                                                         int B, int T, int D, int nsplit, float* __restrict__ dpos_part,
-                                                        const RngState* __restrict__ rng, int train, unsigned thr16, float scale) {
+                                                        const RngState* __restrict__ rng, int train, unsigned thr16, float scale,
+                                                        const long long* __restrict__ row_domain) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [8][D]
     const int t = blockIdx.x, g = blockIdx.y, z = blockIdx.z;
     const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;        // 8 row groups
@@ -193,6 +194,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(float* __restrict__ dxg,
         for (int b = b_beg + rg; b < b_end; b += 8) {
             const int local = b * T + t;
             const long long r = (long long)g * M + local;
+            if (row_domain != nullptr && (row_domain[b] != 0 ? 1 : 0) != g) {      // no gradient reached this sequence: the buffer holds
+                st4(dxg + r * D + 4 * c, make_float4(0.f, 0.f, 0.f, 0.f));          // nothing for it (the row-tile kernels skipped it)
+                continue;
+            }
             float4 v = ld4(dxg + r * D + 4 * c);
             if (train) v = f4mul(v, dropout_mult4(seed, site_id(g, 0, SITE_EMB), step, (unsigned long long)local * D + 4 * c, thr16, scale));
             const unsigned bits = tmq[r * q + c];
@@ -302,17 +307,30 @@ extern "C" int amid_embed_fwd_f32(const float* table, const int* idx_all, const 
     return AMID_OK;
 }
 
-extern "C" int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part,
-                                  const void* rng_state, int train, float p_drop, void* stream) {
+static int embed_bwd(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part, const void* rng_state,
+                     int train, float p_drop, const long long* row_domain, void* stream) {
     AMID_CHECK_ARG(dxg && tmq && dpos_part && B > 0 && T > 0 && D > 0 && (D % 4) == 0 && nsplit > 0 && nsplit <= B);
     AMID_CHECK_ARG(!train || rng_state != nullptr);
     const int tr = (train && p_drop > 0.f) ? 1 : 0;
     embed_bwd_kernel<<<dim3(T, 2, nsplit), 256, 8 * D * sizeof(float), (hipStream_t)stream>>>(dxg, tmq, B, T, D, nsplit, dpos_part,
                                                                                                (const RngState*)rng_state, tr,
                                                                                                keep_thr16(p_drop),
-                                                                                               tr ? 1.0f / (1.0f - p_drop) : 1.0f);
+                                                                                               tr ? 1.0f / (1.0f - p_drop) : 1.0f, row_domain);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+
+extern "C" int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part,
+                                  const void* rng_state, int train, float p_drop, void* stream) {
+    return embed_bwd(dxg, tmq, B, T, D, nsplit, dpos_part, rng_state, train, p_drop, nullptr, stream);
+}
+
+// behind the *_rows backward kernels (sasrec_bwd.hip): the rows of the sequences (g, b) with (row_domain[b] != 0) != g were never
+// written -- they are set to the zeros they stand for here, without being read
+extern "C" int amid_embed_bwd_rows_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part,
+                                       const void* rng_state, int train, float p_drop, const long long* row_domain, void* stream) {
+    AMID_CHECK_ARG(row_domain != nullptr);
+    return embed_bwd(dxg, tmq, B, T, D, nsplit, dpos_part, rng_state, train, p_drop, row_domain, stream);
 }
 
 extern "C" int amid_key_keep_tiled_u8(const long long* seq, int B, int T, int reps, unsigned char* keep, void* stream) {

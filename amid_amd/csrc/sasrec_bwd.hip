@@ -15,14 +15,98 @@
 
 namespace amid {
 
-struct TileGeomB { int M; int rows_per_tile; int tiles_per_group; };
+struct TileGeomB {
+    int M; int rows_per_tile; int tiles_per_group;
+    // optional hint (the *_rows entry points): of domain g only the sequences b with (row_domain[b] != 0) == g carry a gradient (the
+    // step's own loss masks the other domain of every sample, train_sr.py:205-211).  The tiles then walk those sequences' rows only --
+    // "virtual" rows v = 0 .. n_live * T - 1 of a domain, live sequences back to back, rows_per_tile of them per tile -- and the
+    // launch still has 2 * tiles_per_group workgroups (the worst case: every sample in one domain): the first tiles0 + tiles1 are
+    // the live tiles, the rest only zero the LayerNorm partial slot they would have filled.
+    const long long* row_domain; int B, T;
+};
 
-__device__ __forceinline__ void tile_rows_b(const TileGeomB& tg, int tile, int& g, long long& row0, int& nrows, int& local0) {
-    g = tile / tg.tiles_per_group;
-    const int tl = tile - g * tg.tiles_per_group;
-    local0 = tl * tg.rows_per_tile;
-    nrows = min(tg.rows_per_tile, tg.M - local0);
-    row0 = (long long)g * tg.M + local0;
+constexpr int MAP_LIVE_MAX = 1024;                         // sequences per domain the live list is built for (LDS ints)
+constexpr int MAP_INTS = MAP_LIVE_MAX + 128;               // live list + the tile's row map
+
+struct TileRowsB {
+    int g, nrows, slot, local0;        // slot: the tile's LayerNorm-partial slot (g * tiles_per_group + index within the domain)
+    long long base;                    // g * M
+    const int* rmap;                   // hint: LDS table tile row -> row of the domain; nullptr: local0 + r
+    bool live;
+    __device__ __forceinline__ int lrow(int r) const { return rmap ? rmap[r] : local0 + r; }
+    __device__ __forceinline__ long long grow(int r) const { return base + lrow(r); }
+};
+
+__device__ __forceinline__ TileRowsB tile_rows_b(const TileGeomB& tg, int tile, int* __restrict__ ints) {
+    TileRowsB tr;
+    tr.rmap = nullptr; tr.live = true;
+    if (tg.row_domain == nullptr) {
+        tr.g = tile / tg.tiles_per_group;
+        const int tl = tile - tr.g * tg.tiles_per_group;
+        tr.local0 = tl * tg.rows_per_tile;
+        tr.nrows = min(tg.rows_per_tile, tg.M - tr.local0);
+        tr.base = (long long)tr.g * tg.M;
+        tr.slot = tile;
+        return tr;
+    }
+    __shared__ int hdr[4];
+    int* live = ints;                  // [B] batch rows of the tile's domain that carry a gradient, in batch order
+    int* rmap = ints + MAP_LIVE_MAX;
+    const int lane = lane_id();
+    const int B = tg.B, T = tg.T, rpt = tg.rows_per_tile, tpg = tg.tiles_per_group;
+    if (wave_id() == 0) {
+        int n0 = 0;
+        for (int c = 0; c < B; c += 64) n0 += __popcll(__ballot(c + lane < B && tg.row_domain[c + lane] == 0));
+        const int tiles0 = (n0 * T + rpt - 1) / rpt, tiles1 = ((B - n0) * T + rpt - 1) / rpt;
+        int g, tl, lv = 1;
+        if (tile < tiles0) { g = 0; tl = tile; }
+        else if (tile < tiles0 + tiles1) { g = 1; tl = tile - tiles0; }
+        else {                                                       // a slot no live tile fills
+            lv = 0;
+            const int d = tile - tiles0 - tiles1;
+            if (d < tpg - tiles0) { g = 0; tl = tiles0 + d; } else { g = 1; tl = tiles1 + d - (tpg - tiles0); }
+        }
+        if (lv) {
+            int n = 0;
+            for (int c = 0; c < B; c += 64) {
+                const int b = c + lane;
+                const bool f = b < B && ((tg.row_domain[b] != 0 ? 1 : 0) == g);
+                const unsigned long long m = __ballot(f);
+                if (f) live[n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+                n += __popcll(m);
+            }
+        }
+        if (lane == 0) { hdr[0] = g; hdr[1] = tl; hdr[2] = lv; hdr[3] = (g == 0 ? n0 : B - n0) * T; }
+    }
+    __syncthreads();
+    tr.g = hdr[0];
+    const int tl = hdr[1];
+    tr.live = hdr[2] != 0;
+    tr.slot = tr.g * tpg + tl;
+    tr.base = (long long)tr.g * tg.M;
+    tr.local0 = 0;
+    tr.nrows = 0;
+    if (!tr.live) return tr;
+    const int v0 = tl * rpt;
+    tr.nrows = min(rpt, hdr[3] - v0);
+    for (int r = threadIdx.x; r < tr.nrows; r += blockDim.x) {
+        const int v = v0 + r, sq = v / T;
+        rmap[r] = live[sq] * T + (v - sq * T);
+    }
+    __syncthreads();
+    tr.rmap = rmap;
+    return tr;
+}
+
+// the live list / row map sit behind the two operand regions of the row-tile kernels' LDS
+template <int D>
+__device__ __forceinline__ int* map_ints(float* __restrict__ smem) {
+    return reinterpret_cast<int*>(smem + TileCfg<D>::A_FLOATS + TileCfg<D>::W_FLOATS);
+}
+
+template <int D>
+__device__ __forceinline__ void zero_ln_slot(float* __restrict__ part, int slot) {
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) part[(long long)slot * 2 * D + e] = 0.f;
 }
 
 __device__ __forceinline__ float4 apply_tm(float4 v, unsigned bits) {
@@ -82,22 +166,22 @@ struct FfnBwdArgs {
 
 // dzin != nullptr (fused behind the next layer's q / k / v backward): the incoming gradient rows arrive in registers
 template <int D, bool BF>
-__device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restrict__ smem, int tile, const TileRegs<D>* dzin = nullptr) {
+__device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restrict__ smem, const TileRowsB& tr, const TileRegs<D>* dzin = nullptr) {
     using RP = RowPass<D>;
     constexpr int LDC = D + 4;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
     float* Cs = Ws;
-    int g, nrows, local0; long long row0;
-    tile_rows_b(a.tg, tile, g, row0, nrows, local0);
+    const int g = tr.g, nrows = tr.nrows;
+    auto rowf = [&](int r) { return tr.grow(r); };
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
     TileRegs<D> dz, aux;                                  // dz = dxo * ~tm is needed again for the residual path
     WRegs<D, D> wr;
-    if (dzin != nullptr) dz = *dzin; else load_tile<D>(dz, a.dxo, row0, nrows, D);
+    if (dzin != nullptr) dz = *dzin; else load_tile_rows<D>(dz, a.dxo, rowf, nrows, D);
     load_w<D, D>(wr, a.w2T[g], D);
-    load_tile<D>(aux, a.h, row0, nrows, D);               // relu output: consumed by the first epilogue
+    load_tile_rows<D>(aux, a.h, rowf, nrows, D);               // relu output: consumed by the first epilogue
     // 1. dpre2 = (dxo * ~tm) * drop2  -> A image + global
 #pragma unroll
     for (int i = 0; i < RP::NR; ++i) {
@@ -105,11 +189,11 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restr
         if (r < TileCfg<D>::ROWS) {
             float4 v = dz.v[i];
             if (r < nrows) {
-                if (a.tmq) v = apply_tm(v, a.tmq[(row0 + r) * (D / 4) + sub]);
+                if (a.tmq) v = apply_tm(v, a.tmq[tr.grow(r) * (D / 4) + sub]);
                 dz.v[i] = v;
-                if (a.train) v = f4mul(v, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN2), step, (unsigned long long)(local0 + r) * D + 4 * sub,
+                if (a.train) v = f4mul(v, dropout_mult4(seed, site_id(g, a.layer, SITE_FFN2), step, (unsigned long long)tr.lrow(r) * D + 4 * sub,
                                                         a.thr16, a.scale));
-                st4(a.dpre2 + (row0 + r) * D + 4 * sub, v);
+                st4(a.dpre2 + tr.grow(r) * D + 4 * sub, v);
             }
             store_a4<D, BF>(As, r, sub, v);
         }
@@ -133,7 +217,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restr
                 const float4 dh = ld4(Cs + r * LDC + 4 * sub), hv = aux.v[i];
                 v.x = hv.x > 0.f ? dh.x * a.scale : 0.f; v.y = hv.y > 0.f ? dh.y * a.scale : 0.f;
                 v.z = hv.z > 0.f ? dh.z * a.scale : 0.f; v.w = hv.w > 0.f ? dh.w * a.scale : 0.f;
-                st4(a.dpre1 + (row0 + r) * D + 4 * sub, v);
+                st4(a.dpre1 + tr.grow(r) * D + 4 * sub, v);
             }
             store_a4<D, BF>(As, r, sub, v);
         }
@@ -142,7 +226,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restr
     w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
     load_w<D, D>(wr, a.woT[g], D);
-    load_tile<D>(aux, a.r, row0, nrows, D);               // LN2 input rows for the next epilogue
+    load_tile_rows<D>(aux, a.r, rowf, nrows, D);               // LN2 input rows for the next epilogue
     zero_acc<D>(acc);
     mma_tile<D, D, BF>(As, Ws, acc);
     __syncthreads();
@@ -160,7 +244,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restr
                 if (r < nrows) {                               // nrows is uniform over the QPR lanes of a row
                     const float4 dy = f4add(ld4(Cs + r * LDC + 4 * sub), dz.v[i]);
                     v = ln_bwd_row<RP::QPR>(dy, aux.v[i], gam, D, a.ln_eps, dgam, dbet);
-                    st4(a.dr + (row0 + r) * D + 4 * sub, v);
+                    st4(a.dr + tr.grow(r) * D + 4 * sub, v);
                 }
                 store_a4<D, BF>(As, r, sub, v);
             }
@@ -171,9 +255,9 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, float* __restr
     __syncthreads();
     zero_acc<D>(acc);
     mma_tile<D, D, BF>(As, Ws, acc);
-    acc_to_global<D>(a.d_o, row0, nrows, D, nullptr, acc);
+    acc_to_global_rows<D>(a.d_o, rowf, nrows, D, nullptr, acc);
     __syncthreads();                                      // As is free now: reduction scratch for the LN partials
-    ln_partials_out<D>(As, dgam, dbet, a.ln_part + (long long)tile * 2 * D);
+    ln_partials_out<D>(As, dgam, dbet, a.ln_part + (long long)tr.slot * 2 * D);
 }
 
 struct QkvBwdArgs {
@@ -190,40 +274,40 @@ struct QkvBwdArgs {
 
 // keep != nullptr: the input-gradient rows are left in registers for a fused successor and NOT stored (nothing else reads them)
 template <int D, bool BF>
-__device__ __forceinline__ void qkv_bwd_body(const QkvBwdArgs& a, float* __restrict__ smem, int tile, TileRegs<D>* keep = nullptr) {
+__device__ __forceinline__ void qkv_bwd_body(const QkvBwdArgs& a, float* __restrict__ smem, const TileRowsB& tr, TileRegs<D>* keep = nullptr) {
     using RP = RowPass<D>;
     constexpr int LDC = D + 4;
     float* As = smem;
     float* Ws = smem + TileCfg<D>::A_FLOATS;
-    int g, nrows, local0; long long row0;
-    tile_rows_b(a.tg, tile, g, row0, nrows, local0);
+    const int g = tr.g, nrows = tr.nrows;
+    auto rowf = [&](int r) { return tr.grow(r); };
     const int sub = RP::sub();
     f32x4 acc_kv[WaveMap<D>::ACC], acc_q[WaveMap<D>::ACC];
     zero_acc<D>(acc_kv);
     zero_acc<D>(acc_q);
     TileRegs<D> ar, xr;
     WRegs<D, D> wr;
-    load_tile<D>(ar, a.dk, row0, nrows, D);
+    load_tile_rows<D>(ar, a.dk, rowf, nrows, D);
     load_w<D, D>(wr, a.wkT[g], D);
     tile_to_lds<D, BF>(As, ar);
     w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
-    load_tile<D>(ar, a.dv, row0, nrows, D);               // next operand pair flies under the MFMAs
+    load_tile_rows<D>(ar, a.dv, rowf, nrows, D);               // next operand pair flies under the MFMAs
     load_w<D, D>(wr, a.wvT[g], D);
     mma_tile<D, D, BF>(As, Ws, acc_kv);
     __syncthreads();
     tile_to_lds<D, BF>(As, ar);
     w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
-    load_tile<D>(ar, a.dq, row0, nrows, D);
+    load_tile_rows<D>(ar, a.dq, rowf, nrows, D);
     load_w<D, D>(wr, a.wqT[g], D);
     mma_tile<D, D, BF>(As, Ws, acc_kv);
     __syncthreads();
     tile_to_lds<D, BF>(As, ar);
     w_to_lds<D, D, BF>(Ws, wr);
     __syncthreads();
-    load_tile<D>(ar, a.dr, row0, nrows, D);               // epilogue inputs: residual-path grad and the LN1 input rows
-    load_tile<D>(xr, a.x, row0, nrows, D);
+    load_tile_rows<D>(ar, a.dr, rowf, nrows, D);               // epilogue inputs: residual-path grad and the LN1 input rows
+    load_tile_rows<D>(xr, a.x, rowf, nrows, D);
     mma_tile<D, D, BF>(As, Ws, acc_q);
     __syncthreads();
     float* Ckv = As;                    // both operand images are dead: reuse them as the two C images
@@ -241,24 +325,28 @@ __device__ __forceinline__ void qkv_bwd_body(const QkvBwdArgs& a, float* __restr
             const float4 dqn = f4add(ld4(Cq + r * LDC + 4 * sub), ar.v[i]);
             const float4 dxl = ln_bwd_row<RP::QPR>(dqn, xr.v[i], gam, D, a.ln_eps, dgam, dbet);
             dxv = f4add(dxl, ld4(Ckv + r * LDC + 4 * sub));
-            if (keep == nullptr) st4(a.dx + (row0 + r) * D + 4 * sub, dxv);
+            if (keep == nullptr) st4(a.dx + tr.grow(r) * D + 4 * sub, dxv);
         }
         if (keep != nullptr) keep->v[i] = dxv;
     }
     __syncthreads();
-    ln_partials_out<D>(Ws, dgam, dbet, a.ln_part + (long long)tile * 2 * D);
+    ln_partials_out<D>(Ws, dgam, dbet, a.ln_part + (long long)tr.slot * 2 * D);
 }
 
 template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_ffn_bwd_kernel(const FfnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    ffn_bwd_body<D, BF>(a, smem, blockIdx.x);
+    const TileRowsB tr = tile_rows_b(a.tg, blockIdx.x, map_ints<D>(smem));
+    if (!tr.live) { zero_ln_slot<D>(a.ln_part, tr.slot); return; }
+    ffn_bwd_body<D, BF>(a, smem, tr);
 }
 
 template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_bwd_kernel(const QkvBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    qkv_bwd_body<D, BF>(a, smem, blockIdx.x);
+    const TileRowsB tr = tile_rows_b(a.tg, blockIdx.x, map_ints<D>(smem));
+    if (!tr.live) { zero_ln_slot<D>(a.ln_part, tr.slot); return; }
+    qkv_bwd_body<D, BF>(a, smem, tr);
 }
 
 // layer l + 1's q / k / v + LayerNorm1 backward followed by layer l's feed-forward / out-projection backward on the same row
@@ -268,10 +356,12 @@ struct QkvFfnBwdArgs { QkvBwdArgs qkv; FfnBwdArgs ffn; TileGeomB tg; };
 template <int D, bool BF>
 __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_ffn_bwd_kernel(const QkvFfnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const TileRowsB tr = tile_rows_b(a.tg, blockIdx.x, map_ints<D>(smem));
+    if (!tr.live) { zero_ln_slot<D>(a.qkv.ln_part, tr.slot); zero_ln_slot<D>(a.ffn.ln_part, tr.slot); return; }
     TileRegs<D> dxr;            // d x[l + 1] of the tile goes from one body to the other in registers and never to HBM
-    qkv_bwd_body<D, BF>(a.qkv, smem, blockIdx.x, &dxr);
+    qkv_bwd_body<D, BF>(a.qkv, smem, tr, &dxr);
     __syncthreads();            // the first body's LDS scratch (LayerNorm partials) is read; the second restages both regions
-    ffn_bwd_body<D, BF>(a.ffn, smem, blockIdx.x, &dxr);
+    ffn_bwd_body<D, BF>(a.ffn, smem, tr, &dxr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -451,13 +541,20 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceEntry*
 
 using namespace amid;
 
-template <int D> static constexpr size_t fused_lds_bytes_b() { return (size_t)(TileCfg<D>::A_FLOATS + TileCfg<D>::W_FLOATS) * sizeof(float); }
+template <int D> static constexpr size_t fused_lds_bytes_b() {
+    return (size_t)(TileCfg<D>::A_FLOATS + TileCfg<D>::W_FLOATS) * sizeof(float) + (size_t)MAP_INTS * sizeof(int);
+}
 
-static int make_geom_b(int M, int rows_per_tile, TileGeomB* tg) {
+static int make_geom_b(int M, int rows_per_tile, TileGeomB* tg, const long long* row_domain = nullptr, int B = 0, int T = 0) {
     if (M <= 0 || rows_per_tile <= 0 || rows_per_tile > TILE_ROWS) return AMID_ERR_ARG;
     tg->M = M;
     tg->rows_per_tile = rows_per_tile;
     tg->tiles_per_group = (M + rows_per_tile - 1) / rows_per_tile;
+    tg->row_domain = nullptr; tg->B = B; tg->T = T;
+    if (row_domain) {
+        if (B <= 0 || T <= 0 || (long long)B * T != M || B > MAP_LIVE_MAX) return AMID_ERR_ARG;
+        tg->row_domain = row_domain;
+    }
     return AMID_OK;
 }
 
@@ -473,10 +570,10 @@ static int make_geom_b(int M, int rows_per_tile, TileGeomB* tg) {
         KERNEL<DVAL, BFVAL><<<2 * ARGS.tg.tiles_per_group, GEMM_THREADS, fused_lds_bytes_b<DVAL>(), (hipStream_t)stream>>>(ARGS); \
     } while (0)
 
-extern "C" int AMID_ENTRY(amid_sas_ffn_bwd_f32)(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+static int amid_sas_ffn_bwd_impl(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
                                     const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
                                     int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2,
-                                    float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, void* stream) {
+                                    float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream) {
     AMID_CHECK_ARG(dxo && h && r && ln_w && w1T && w2T && woT && dpre2 && dpre1 && dr && d_o && ln_part && (!train || step_state));
     FfnBwdArgs a;
     a.dxo = dxo; a.tmq = tmq; a.h = h; a.r = r; a.dpre2 = dpre2; a.dpre1 = dpre1; a.dr = dr; a.d_o = d_o; a.ln_part = ln_part;
@@ -485,7 +582,7 @@ extern "C" int AMID_ENTRY(amid_sas_ffn_bwd_f32)(const float* dxo, const unsigned
     a.thr16 = keep_thr16(p_drop);
     a.scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
     for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.w1T[g] = w1T[g]; a.w2T[g] = w2T[g]; a.woT[g] = woT[g]; }
-    if (int e = make_geom_b(M, rows_per_tile, &a.tg)) return e;
+    if (int e = make_geom_b(M, rows_per_tile, &a.tg, row_domain, B, T)) return e;
     if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED_B(sas_ffn_bwd_kernel, a, 128, true);
     else if (D == 128) AMID_LAUNCH_FUSED_B(sas_ffn_bwd_kernel, a, 128, false);
     else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED_B(sas_ffn_bwd_kernel, a, 64, false);
@@ -494,14 +591,31 @@ extern "C" int AMID_ENTRY(amid_sas_ffn_bwd_f32)(const float* dxo, const unsigned
     return AMID_OK;
 }
 
-extern "C" int AMID_ENTRY(amid_sas_qkv_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+extern "C" int AMID_ENTRY(amid_sas_ffn_bwd_f32)(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                                    const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
+                                    int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2,
+                                    float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, void* stream) {
+    return amid_sas_ffn_bwd_impl(dxo, tmq, h, r, ln_w, w1T, w2T, woT, ln_eps, M, D, rows_per_tile, layer, step_state, train, p_drop, dpre2, dpre1, dr, d_o, ln_part, mma_bf16, nullptr, 0, 0, stream);
+}
+
+// amid_sas_ffn_bwd_f32 over the live sequences only (TileGeomB::row_domain): M = B * T, row_domain [B] = the batch's domain ids; rows_per_tile
+// counts live rows, ln_part holds 2 * ceil(M / rows_per_tile) slots
+extern "C" int AMID_ENTRY(amid_sas_ffn_bwd_rows_f32)(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                                    const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
+                                    int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2,
+                                    float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream) {
+    AMID_CHECK_ARG(row_domain != nullptr);
+    return amid_sas_ffn_bwd_impl(dxo, tmq, h, r, ln_w, w1T, w2T, woT, ln_eps, M, D, rows_per_tile, layer, step_state, train, p_drop, dpre2, dpre1, dr, d_o, ln_part, mma_bf16, row_domain, B, T, stream);
+}
+
+static int amid_sas_qkv_bwd_impl(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
                                     const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
-                                    float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream) {
+                                    float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream) {
     AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && dx && ln_part);
     QkvBwdArgs a;
     a.dq = dq; a.dk = dk; a.dv = dv; a.dr = dr; a.x = x; a.dx = dx; a.ln_part = ln_part; a.ln_eps = ln_eps;
     for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.wqT[g] = wqT[g]; a.wkT[g] = wkT[g]; a.wvT[g] = wvT[g]; }
-    if (int e = make_geom_b(M, rows_per_tile, &a.tg)) return e;
+    if (int e = make_geom_b(M, rows_per_tile, &a.tg, row_domain, B, T)) return e;
     if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 128, true);
     else if (D == 128) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 128, false);
     else if (D == 64 && !mma_bf16) AMID_LAUNCH_FUSED_B(sas_qkv_bwd_kernel, a, 64, false);
@@ -510,14 +624,29 @@ extern "C" int AMID_ENTRY(amid_sas_qkv_bwd_f32)(const float* dq, const float* dk
     return AMID_OK;
 }
 
+extern "C" int AMID_ENTRY(amid_sas_qkv_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                    const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
+                                    float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream) {
+    return amid_sas_qkv_bwd_impl(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, M, D, rows_per_tile, dx, ln_part, mma_bf16, nullptr, 0, 0, stream);
+}
+
+// amid_sas_qkv_bwd_f32 over the live sequences only (TileGeomB::row_domain): M = B * T, row_domain [B] = the batch's domain ids; rows_per_tile
+// counts live rows, ln_part holds 2 * ceil(M / rows_per_tile) slots
+extern "C" int AMID_ENTRY(amid_sas_qkv_bwd_rows_f32)(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                    const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
+                                    float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream) {
+    AMID_CHECK_ARG(row_domain != nullptr);
+    return amid_sas_qkv_bwd_impl(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, M, D, rows_per_tile, dx, ln_part, mma_bf16, row_domain, B, T, stream);
+}
+
 // amid_sas_qkv_bwd_f32 of layer l + 1 followed by amid_sas_ffn_bwd_f32 of layer l (f* arguments; its dxo is the dx just produced)
-extern "C" int AMID_ENTRY(amid_sas_qkv_ffn_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+static int amid_sas_qkv_ffn_bwd_impl(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
                                         const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
                                         float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part,
                                         const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
                                         const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
                                         const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o,
-                                        float* fln_part, int mma_bf16, void* stream) {
+                                        float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream) {
     AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && dx && ln_part);
     AMID_CHECK_ARG(fh && fr && fln_w && fw1T && fw2T && fwoT && fdpre2 && fdpre1 && fdr && fd_o && fln_part && (!train || step_state));
     QkvFfnBwdArgs a;
@@ -531,7 +660,7 @@ extern "C" int AMID_ENTRY(amid_sas_qkv_ffn_bwd_f32)(const float* dq, const float
         a.qkv.ln_w[g] = ln_w[g]; a.qkv.wqT[g] = wqT[g]; a.qkv.wkT[g] = wkT[g]; a.qkv.wvT[g] = wvT[g];
         a.ffn.ln_w[g] = fln_w[g]; a.ffn.w1T[g] = fw1T[g]; a.ffn.w2T[g] = fw2T[g]; a.ffn.woT[g] = fwoT[g];
     }
-    if (int e = make_geom_b(M, rows_per_tile, &a.tg)) return e;
+    if (int e = make_geom_b(M, rows_per_tile, &a.tg, row_domain, B, T)) return e;
     a.qkv.tg = a.tg; a.ffn.tg = a.tg;
     if (D == 128 && mma_bf16) AMID_LAUNCH_FUSED_B(sas_qkv_ffn_bwd_kernel, a, 128, true);
     else if (D == 128) AMID_LAUNCH_FUSED_B(sas_qkv_ffn_bwd_kernel, a, 128, false);
@@ -539,6 +668,29 @@ extern "C" int AMID_ENTRY(amid_sas_qkv_ffn_bwd_f32)(const float* dq, const float
     else return AMID_ERR_UNSUPPORTED;
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+
+extern "C" int AMID_ENTRY(amid_sas_qkv_ffn_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                        const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
+                                        float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part,
+                                        const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
+                                        const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
+                                        const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o,
+                                        float* fln_part, int mma_bf16, void* stream) {
+    return amid_sas_qkv_ffn_bwd_impl(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, M, D, rows_per_tile, dx, ln_part, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, flayer, step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, mma_bf16, nullptr, 0, 0, stream);
+}
+
+// amid_sas_qkv_ffn_bwd_f32 over the live sequences only (TileGeomB::row_domain): M = B * T, row_domain [B] = the batch's domain ids; rows_per_tile
+// counts live rows, ln_part holds 2 * ceil(M / rows_per_tile) slots
+extern "C" int AMID_ENTRY(amid_sas_qkv_ffn_bwd_rows_f32)(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                        const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
+                                        float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part,
+                                        const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
+                                        const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
+                                        const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o,
+                                        float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream) {
+    AMID_CHECK_ARG(row_domain != nullptr);
+    return amid_sas_qkv_ffn_bwd_impl(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, M, D, rows_per_tile, dx, ln_part, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, flayer, step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, mma_bf16, row_domain, B, T, stream);
 }
 
 #if AMID_TILE_RT == 7      // everything below is independent of the row-tile height: one copy only

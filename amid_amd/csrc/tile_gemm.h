@@ -111,6 +111,17 @@ __device__ __forceinline__ void load_tile(TileRegs<N>& t, const float* __restric
         t.v[i] = (r < nrows) ? ld4(g + (row0 + r) * ldg + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
+// the same through a tile-row -> global-row map (tiles over scattered rows: the backward of the live sequences only)
+template <int N, class RowFn>
+__device__ __forceinline__ void load_tile_rows(TileRegs<N>& t, const float* __restrict__ g, RowFn rowf, int nrows, int ldg) {
+    using RP = RowPass<N>;
+    const int sub = RP::sub(), r0 = RP::first_row();
+#pragma unroll
+    for (int i = 0; i < RP::NR; ++i) {
+        const int r = r0 + i * RP::RPP;
+        t.v[i] = (r < nrows) ? ld4(g + rowf(r) * ldg + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 // registers -> LDS image [TileCfg::ROWS][N + 8]; every image row is written (NR * RPP == ROWS), rows past the tile as zeros
 template <int N, bool BF = false>
 __device__ __forceinline__ void tile_to_lds(float* __restrict__ As, const TileRegs<N>& t) {
@@ -302,6 +313,23 @@ __device__ __forceinline__ void acc_to_global(float* __restrict__ out, long long
         const int r = rt * 16 + m;
         if (r < nrows)
             st4(out + (row0 + r) * ldo + n, make_float4(acc[t][0] + b.x, acc[t][1] + b.y, acc[t][2] + b.z, acc[t][3] + b.w));
+    }
+}
+template <int N, class RowFn>
+__device__ __forceinline__ void acc_to_global_rows(float* __restrict__ out, RowFn rowf, int nrows, int ldo, const float* __restrict__ bias,
+                                              const f32x4 (&acc)[WaveMap<N>::ACC]) {
+    using WM = WaveMap<N>;
+    const int w = wave_id(), lane = lane_id();
+    const int ct = w % WM::NT, rg = w / WM::NT;
+    const int m = lane & 15, n = ct * 16 + (lane >> 4) * 4;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = ld4(bias + n);
+#pragma unroll
+    for (int t = 0; t < WM::ACC; ++t) {
+        const int rt = rg + t * WM::WR;
+        const int r = rt * 16 + m;
+        if (r < nrows)
+            st4(out + rowf(r) * ldo + n, make_float4(acc[t][0] + b.x, acc[t][1] + b.y, acc[t][2] + b.z, acc[t][3] + b.w));
     }
 }
 

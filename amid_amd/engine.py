@@ -215,6 +215,16 @@ class SasrecPlan:
         self.dq, self.dk, self.dv = f(2 * M, D), f(2 * M, D), f(2 * M, D)
         self.ln1_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
         self.ln2_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
+        # the train step's own backward walks the LIVE sequences only (engine._own_rows): half the rows, re-tiled over the CUs
+        # (csrc/sasrec_bwd.hip TileGeomB::row_domain); its LayerNorm partials have their own slots and reduce table
+        self.live_rows = bool(self.LIVE_ROWS_BWD and B <= 1024)
+        if self.live_rows:
+            self.rpt_v = L.value("amid_rows_per_tile", (M + 1) // 2)
+            self.tpg_v = (M + self.rpt_v - 1) // self.rpt_v
+            self.rt_suffix_v = (("_rt3" if self.rpt_v <= 48 else "_rt4" if self.rpt_v <= 64 else "_rt5" if self.rpt_v <= 80 else "")
+                                if eng.SHORT_TILE_BUILDS else "")
+            self.ln1_part_v = [f(2 * self.tpg_v, 2, D) for _ in range(2)]
+            self.ln2_part_v = [f(2 * self.tpg_v, 2, D) for _ in range(2)]
         self.last_part = f(2 * B, 2, D)
         self._alloc_model_bwd(eng, f)
         self.sc_P = L.value("amid_scorer_part_floats", D, hid)
@@ -230,7 +240,9 @@ class SasrecPlan:
         self.n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
         self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", N, D), dtype=torch.uint8, device=dev)
         self.uniq_grad = f(N, D)
-        self._build_reduce_table(eng)
+        self.red_entries, self.red_n, self.red_max = self._build_reduce_table(eng)
+        if self.live_rows:
+            self.red_entries_v, self.red_n_v, self.red_max_v = self._build_reduce_table(eng, live=True)
         self.graph = None
         self.graphs = {}
 
@@ -255,7 +267,9 @@ class SasrecPlan:
         self.pos_splits = max(1, min(8, B // 16))
         self.dpos_part = f(self.pos_splits, 2, T, D)
 
-    def _build_reduce_table(self, eng: "SasrecEngine") -> None:
+    LIVE_ROWS_BWD = True       # BertPlan: False (its backward kernels take no row_domain hint)
+
+    def _build_reduce_table(self, eng: "SasrecEngine", live: bool = False):
         L = lib()
         D, hid, B = eng.D, eng.hid, self.shape.B
         fp, G = eng.dense, eng.dense.grad
@@ -264,7 +278,10 @@ class SasrecPlan:
         def add(src_t: torch.Tensor, src_off: int, dst_ptr: int, stride: int, n_part: int, count: int):
             ent.append((src_t.data_ptr() + 4 * src_off, dst_ptr, stride, n_part, count))
 
-        self._model_reduce_entries(eng, add)
+        if live:
+            self._model_reduce_entries(eng, add, live=True)
+        else:
+            self._model_reduce_entries(eng, add)
         P = self.sc_P
         heads = [("predictModule", self.sc_part)]
         if getattr(eng, "dr", False):
@@ -285,14 +302,13 @@ class SasrecPlan:
         host = (ctypes.c_ubyte * (esz * len(ent)))()
         for i, (s, d, st, n, c) in enumerate(ent):
             L.call("amid_reduce_entry_pack", ctypes.addressof(host), i, s, d, st, n, c)
-        self.red_entries = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(eng.device)
-        self.red_n = len(ent)
-        self.red_max = max(c for *_, c in ent)
+        return torch.frombuffer(bytearray(host), dtype=torch.uint8).to(eng.device), len(ent), max(c for *_, c in ent)
 
-    def _model_reduce_entries(self, eng: "SasrecEngine", add) -> None:
+    def _model_reduce_entries(self, eng: "SasrecEngine", add, live: bool = False) -> None:
         D, B = eng.D, self.shape.B
         fp, G = eng.dense, eng.dense.grad
         S = self.splits
+        ln1, ln2, tpg = (self.ln1_part_v, self.ln2_part_v, self.tpg_v) if live else (self.ln1_part, self.ln2_part, self.tpg)
         for l in (0, 1):
             for g in (0, 1):
                 pre = f"sac{g + 1}"
@@ -307,11 +323,11 @@ class SasrecPlan:
                 add(self.b_part[l], bbase(4), fp.ptr(f"{pre}.forward_layers.{l}.conv1.bias", G), D, S, D)
                 add(self.w_part[l], wbase(5), fp.ptr(f"{pre}.forward_layers.{l}.conv2.weight", G), D * D, S, D * D)
                 add(self.b_part[l], bbase(5), fp.ptr(f"{pre}.forward_layers.{l}.conv2.bias", G), D, S, D)
-                tb = g * self.tpg * 2 * D
-                add(self.ln1_part[l], tb, fp.ptr(f"{pre}.attention_layernorms.{l}.weight", G), 2 * D, self.tpg, D)
-                add(self.ln1_part[l], tb + D, fp.ptr(f"{pre}.attention_layernorms.{l}.bias", G), 2 * D, self.tpg, D)
-                add(self.ln2_part[l], tb, fp.ptr(f"{pre}.forward_layernorms.{l}.weight", G), 2 * D, self.tpg, D)
-                add(self.ln2_part[l], tb + D, fp.ptr(f"{pre}.forward_layernorms.{l}.bias", G), 2 * D, self.tpg, D)
+                tb = g * tpg * 2 * D
+                add(ln1[l], tb, fp.ptr(f"{pre}.attention_layernorms.{l}.weight", G), 2 * D, tpg, D)
+                add(ln1[l], tb + D, fp.ptr(f"{pre}.attention_layernorms.{l}.bias", G), 2 * D, tpg, D)
+                add(ln2[l], tb, fp.ptr(f"{pre}.forward_layernorms.{l}.weight", G), 2 * D, tpg, D)
+                add(ln2[l], tb + D, fp.ptr(f"{pre}.forward_layernorms.{l}.bias", G), 2 * D, tpg, D)
         for g in (0, 1):
             pre = f"sac{g + 1}"
             add(self.last_part, g * B * 2 * D, fp.ptr(f"{pre}.last_layernorm.weight", G), 2 * D, B, D)
@@ -813,22 +829,28 @@ class SasrecEngine:
                    pl.stats[l].data_ptr(), pl.d_o.data_ptr(), None, B, T, D, self.H, 1, l, st, tr, SASREC_P_DROP, pl.dq_l[l].data_ptr(),
                    pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), self._own_rows(pl), s)
 
+        # live: the three row-tile kernels walk the sequences that carry a gradient only (see _own_rows), re-tiled over the CUs
+        dom = self._own_rows(pl)
+        live = dom is not None and pl.live_rows
+        rows, suf, rpt = ("_rows", pl.rt_suffix_v, pl.rpt_v) if live else ("", pl.rt_suffix, pl.rpt)
+        ln1p, ln2p = (pl.ln1_part_v, pl.ln2_part_v) if live else (pl.ln1_part, pl.ln2_part)
+        hint = (dom, B, T) if live else ()
         tm, h1, r1, lnw1, w1T1, w2T1, woT1 = ffn_bwd_args(1)
-        L.call("amid_sas_ffn_bwd_f32" + pl.rt_suffix, pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, M, D, pl.rpt, 1, st, tr,
+        L.call(f"amid_sas_ffn_bwd{rows}_f32" + suf, pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, M, D, rpt, 1, st, tr,
                SASREC_P_DROP, pl.dpre2[1].data_ptr(), pl.dpre1[1].data_ptr(), pl.dr[1].data_ptr(), pl.d_o.data_ptr(),
-               pl.ln2_part[1].data_ptr(), self.mma_bf16, s)
+               ln2p[1].data_ptr(), self.mma_bf16, *hint, s)
         attn_bwd(1)
         # layer 1's q / k / v + LayerNorm1 backward and layer 0's feed-forward / out-projection backward: one launch
         tm, h0, r0, lnw0, w1T0, w2T0, woT0 = ffn_bwd_args(0)
-        L.call("amid_sas_qkv_ffn_bwd_f32" + pl.rt_suffix, pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
+        L.call(f"amid_sas_qkv_ffn_bwd{rows}_f32" + suf, pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
                pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
-               SASREC_LN_EPS, M, D, pl.rpt, pl.dxbuf.data_ptr(), pl.ln1_part[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr,
+               SASREC_LN_EPS, M, D, rpt, pl.dxbuf.data_ptr(), ln1p[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr,
                SASREC_P_DROP, pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(),
-               pl.ln2_part[0].data_ptr(), self.mma_bf16, s)
+               ln2p[0].data_ptr(), self.mma_bf16, *hint, s)
         attn_bwd(0)
-        L.call("amid_sas_qkv_bwd_f32" + pl.rt_suffix, pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
+        L.call(f"amid_sas_qkv_bwd{rows}_f32" + suf, pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
                pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
-               SASREC_LN_EPS, M, D, pl.rpt, (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.ln1_part[0].data_ptr(), self.mma_bf16, s)
+               SASREC_LN_EPS, M, D, rpt, (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), ln1p[0].data_ptr(), self.mma_bf16, *hint, s)
         dy, xx = [], []
         for l in (0, 1):
             dy += [pl.dq_l[l].data_ptr(), pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), pl.dr[l].data_ptr(), pl.dpre1[l].data_ptr(),
@@ -837,8 +859,12 @@ class SasrecEngine:
         # NOTE: pl.x[0] is the gathered-row buffer xg, still intact here (its gradient lives in dxg)
         L.call("amid_sas_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
                ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), self._own_rows(pl), B, T, s)
-        L.call("amid_embed_bwd_f32", (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits,
-               pl.dpos_part.data_ptr(), st, tr, SASREC_P_DROP, s)
+        if live:     # the dead sequences' rows of the encoder-input gradient were never written: zero-filled here, not read
+            L.call("amid_embed_bwd_rows_f32", (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits,
+                   pl.dpos_part.data_ptr(), st, tr, SASREC_P_DROP, dom, s)
+        else:
+            L.call("amid_embed_bwd_f32", (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits,
+                   pl.dpos_part.data_ptr(), st, tr, SASREC_P_DROP, s)
         if self.inc_bs:      # InnerComp's parameter gradients; the rows' own halves + its share -> the table-row gradient buffer
             G = self.dense.grad
             L.call("amid_inc_bwd_f32", pl.dpos_part.data_ptr(), pl.pos_splits, pl.xg.data_ptr(), pl.dx0.data_ptr(), pl.inc_gate.data_ptr(),
@@ -846,15 +872,16 @@ class SasrecEngine:
                    self._pp("inc_d{d}.trans_bs.weight"), B, shp.T, D, pl.inc_dZ.data_ptr(), pl.inc_dS.data_ptr(), pl.inc_rows.data_ptr(),
                    self._pp("inc_d{d}.trans_nn.weight", G), self._pp("inc_d{d}.trans_nn.bias", G), self._pp("inc_d{d}.trans_bs.weight", G),
                    self._pp("inc_d{d}.trans_bs.bias", G), pl.dxg.data_ptr(), s)
-        self._enqueue_grad_tail(pl)
+        self._enqueue_grad_tail(pl, live)
 
-    def _enqueue_grad_tail(self, pl: SasrecPlan) -> None:
+    def _enqueue_grad_tail(self, pl: SasrecPlan, live: bool = False) -> None:
         """The two independent, bandwidth-bound ends of backward side by side in one launch: the fixed-order sum of every partial
         buffer (dense gradients + loss) and the segment reduce of the table-row gradients."""
         L, s, shp = lib(), self.s, pl.shape
         self.join_sort()                          # pos_sorted / seg_off come from the side-stream sort
         L.call("amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), shp.n_idx,
-               self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), pl.red_entries.data_ptr(), pl.red_n, pl.red_max, s)
+               self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), (pl.red_entries_v if live else pl.red_entries).data_ptr(),
+               pl.red_n_v if live else pl.red_n, pl.red_max_v if live else pl.red_max, s)
 
     def enqueue_optimizer(self, pl: SasrecPlan, sparse=None) -> None:
         """Dense Adam on the flat buffer + lazy row Adam on (uniq_ids, uniq_grad, n_uniq); `sparse`

@@ -57,6 +57,8 @@ N_ENT = 12      # weight-gradient tiles of 128 x 128 per block: q, k, v, o, 4 x 
 
 
 class BertPlan(SasrecPlan):
+    LIVE_ROWS_BWD = False
+
     def _alloc_model_fwd(self, eng, f) -> None:
         M, D, F = self.shape.M, eng.D, BERT_FF
         self.key_keep = torch.zeros(self.shape.B, self.shape.Tenc, dtype=torch.uint8, device=eng.device)

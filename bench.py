@@ -134,6 +134,9 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         # the train step's own backward: of each domain only the samples of that domain carry a gradient (the loss multiplies the
         # other domain's BCE by zero, train_sr.py:205-211), the kernels walk those sequences only -- half the rows, priced as such
         "amid_sas_wgrad_rows_f32": ("mfma", 6 * gemm),
+        "amid_sas_ffn_bwd_rows_f32": ("mfma", 1.5 * gemm),
+        "amid_sas_qkv_bwd_rows_f32": ("mfma", 1.5 * gemm),
+        "amid_sas_qkv_ffn_bwd_rows_f32": ("mfma", 3 * gemm),
         "amid_attn_bwd_rows_f32": ("mfma", 10.0 * T * T * hd * Bw * H),
         "amid_bert_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_bert_oproj_fwd_f32": ("mfma", gemm),
@@ -159,6 +162,8 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_qkv_fwd_f32": "sas_qkv_fwd_kernel", "amid_sas_oproj_fwd_f32": "sas_oproj_fwd_kernel", "amid_sas_ffn_fwd_f32": "sas_ffn_fwd_kernel",
     "amid_sas_ffn_bwd_f32": "sas_ffn_bwd_kernel", "amid_sas_qkv_bwd_f32": "sas_qkv_bwd_kernel", "amid_sas_wgrad_f32": "sas_wgrad_kernel",
     "amid_sas_wgrad_rows_f32": "sas_wgrad_kernel", "amid_attn_bwd_rows_f32": "attn_bwd_mfma_kernel",
+    "amid_sas_ffn_bwd_rows_f32": "sas_ffn_bwd_kernel", "amid_sas_qkv_bwd_rows_f32": "sas_qkv_bwd_kernel",
+    "amid_sas_qkv_ffn_bwd_rows_f32": "sas_qkv_ffn_bwd_kernel",
     "amid_sas_qkv_ffn_bwd_f32": "sas_qkv_ffn_bwd_kernel", "amid_sas_oproj_ffn_qkv_fwd_f32": "sas_oproj_ffn_qkv_fwd_kernel",
     "amid_sas_oproj_ffn_fwd_f32": "sas_oproj_ffn_fwd_kernel",
     "amid_attn_fwd_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_f32": "embed_fwd_kernel",
@@ -360,7 +365,7 @@ def main():
         work = algorithmic_work(Bw, int(pl.n_uniq.item()), T)
         total_ms = 0.0
         for name, v in durs.items():
-            name = name[:-4] if name.endswith(("_rt3", "_rt5")) else name        # the 48- / 80-row builds of the row-tile kernels
+            name = name[:-4] if name.endswith(("_rt3", "_rt4", "_rt5")) else name        # the 48- / 64- / 80-row builds of the row-tile kernels
             per_step = sum(v) / n_prof
             total_ms += per_step
             calls = len(v) // n_prof

@@ -481,6 +481,44 @@ int amid_event_sync(void* ev);
 int amid_event_elapsed_ms(void* start, void* stop, float* ms_out);
 int amid_event_destroy(void* ev);
 
+
+/* ---- the three SASRec backward row-tile kernels over the LIVE sequences only ------------------------------------------------
+ * The train step's own loss multiplies the other domain's BCE of every sample by zero (train_sr.py:205-211): of encoder g only the
+ * sequences b with (row_domain[b] != 0) == g receive a gradient, everything else in its backward is exact zeros.  These entry points
+ * take the batch's domain ids and tile those sequences' rows only (M = B * T; rows_per_tile counts live rows; ln_part needs
+ * 2 * ceil(M / rows_per_tile) slots, the unused ones are zeroed); rows of the dead sequences are neither read nor written.
+ * Same arguments as the plain entry points otherwise; *_rt5 / *_rt4 / *_rt3: the 80- / 64- / 48-row builds. */
+int amid_sas_ffn_bwd_rows_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w, const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_ffn_bwd_rows_f32_rt5(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w, const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_ffn_bwd_rows_f32_rt4(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w, const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_ffn_bwd_rows_f32_rt3(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w, const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_qkv_bwd_rows_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_qkv_bwd_rows_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_qkv_bwd_rows_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_qkv_bwd_rows_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_qkv_ffn_bwd_rows_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_qkv_ffn_bwd_rows_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_qkv_ffn_bwd_rows_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+int amid_sas_qkv_ffn_bwd_rows_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
+
+int amid_embed_bwd_rows_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part, const void* rng_state,
+                            int train, float p_drop, const long long* row_domain, void* stream);   /* amid_embed_bwd_f32 behind the *_rows kernels: the dead sequences' rows are zero-filled, not read */
+
+/* the 64-row (_rt4) build exists for the backward row-tile kernels only (the live-row backward of the headline shape: 50 rows per tile) */
+int amid_sas_ffn_bwd_f32_rt4(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                         const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
+                         int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
+                         float* dr, float* d_o, float* ln_part /* [tiles][2][D] */, int mma_bf16, void* stream);
+int amid_sas_qkv_bwd_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
+                         const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
+                         int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream);
+int amid_sas_qkv_ffn_bwd_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
+                             const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
+                             int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
+                             const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
+                             int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
+                             float* fd_o, float* fln_part, int mma_bf16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
