@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void heads_write_kernel(const int* __restrict_
 // and the data-parallel merge up to 16 ranks x 4096 rows): thread t owns the contiguous span [t * per, (t + 1) * per), counts its run
 // heads, the 1024 counts are scanned through LDS, and a second pass over the same span writes uniq_ids / seg_off / seg_of.  Three
 // dependent ~5 us launches become one of about that length (they sit on the critical path of the data-parallel step's merge).
-constexpr int HEADS_FUSED_MAX = 65536;
+constexpr int HEADS_FUSED_MAX = 8192;       // beyond: the three short kernels (one 1024-thread workgroup walking 26 k entries ran 58 us and
+                                            // held a CU against the one-round kernels of the main stream)
 __global__ __launch_bounds__(1024) void heads_fused_kernel(const int* __restrict__ keys, int n, int* __restrict__ n_uniq,
                                                            int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of,
                                                            int use_sentinel, int sentinel) {

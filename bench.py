@@ -133,7 +133,8 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_sas_wgrad_f32": ("mfma", 12 * gemm),          # both layers in one launch
         # the train step's own backward: of each domain only the samples of that domain carry a gradient (the loss multiplies the
         # other domain's BCE by zero, train_sr.py:205-211), the kernels walk those sequences only -- half the rows, priced as such
-        "amid_sas_wgrad_rows_f32": ("mfma", 6 * gemm),
+        # (beyond 1024 samples per batch the live list no longer fits the kernels' LDS budget and they walk every row: full price)
+        "amid_sas_wgrad_rows_f32": ("mfma", (6 if Bw <= 1024 else 12) * gemm),
         "amid_sas_ffn_bwd_rows_f32": ("mfma", 1.5 * gemm),
         "amid_sas_qkv_bwd_rows_f32": ("mfma", 1.5 * gemm),
         "amid_sas_qkv_ffn_bwd_rows_f32": ("mfma", 3 * gemm),
