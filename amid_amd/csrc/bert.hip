@@ -457,8 +457,10 @@ struct BWgradArgs {
     float* w_part;                                          // [2][n_ent][splits][128*128]
     float* b_part;                                          // [2][n_ent][splits][128]
     int n_ent, M, splits, rows_per_split;
+    const long long* row_domain; int B, T;                  // optional hint, as WgradArgs::row_domain (sasrec_bwd.hip): walk the live sequences only
 };
 constexpr int BWG_ROWS = 64;
+[[maybe_unused]] constexpr int BWG_LIVE_MAX = 1024;
 __global__ __launch_bounds__(GEMM_THREADS) void bert_wgrad_kernel(const BWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int D = BD, LD = D + 16;
@@ -468,9 +470,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_wgrad_kernel(const BWgradAr
     const float* __restrict__ dy = a.dy[e];
     const float* __restrict__ xin = a.x[e];
     const int ldy = a.ldy[e], ldx = a.ldx[e];
-    const int local_beg = split * a.rows_per_split, local_end = min(a.M, local_beg + a.rows_per_split);
+    int local_beg = split * a.rows_per_split, local_end = min(a.M, local_beg + a.rows_per_split);
     const int w = wave_id(), lane = lane_id();
     const int nt = w, i = lane & 15, gq = lane >> 4;
+    int* live = reinterpret_cast<int*>(smem + 2 * BWG_ROWS * LD);        // [B] (hint only)
+    const bool hint = a.row_domain != nullptr;
+    if (hint) {                                        // wave 0 lists the domain's live sequences in batch order
+        __shared__ int n_live_s;
+        if (w == 0) {
+            int n = 0;
+            for (int c = 0; c < a.B; c += 64) {
+                const int b = c + lane;
+                const bool f = b < a.B && ((a.row_domain[b] != 0 ? 1 : 0) == g);
+                const unsigned long long m = __ballot(f);
+                if (f) live[n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+                n += __popcll(m);
+            }
+            if (lane == 0) n_live_s = n;
+        }
+        __syncthreads();
+        const int mv = n_live_s * a.T, rps = (mv + a.splits - 1) / a.splits;
+        local_beg = min(mv, split * rps);
+        local_end = min(mv, local_beg + rps);
+    }
     constexpr int QPR = D / 4, RPP = GEMM_THREADS / QPR, NRW = BWG_ROWS / RPP;
     const int sub = threadIdx.x % QPR, rl = threadIdx.x / QPR;
     f32x4 acc[8];
@@ -485,8 +507,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_wgrad_kernel(const BWgradAr
         for (int j = 0; j < NRW; ++j) {
             const int r = rl + j * RPP;
             const bool ok = r < nr;
-            py[j] = ok ? ld4(dy + (grow + r) * ldy + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-            px[j] = ok ? ld4(xin + (grow + r) * ldx + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            long long row = grow + r;
+            if (hint && ok) {
+                const int v = c0 + r, sq = v / a.T;
+                row = (long long)g * a.M + (long long)live[sq] * a.T + (v - sq * a.T);
+            }
+            py[j] = ok ? ld4(dy + row * ldy + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            px[j] = ok ? ld4(xin + row * ldx + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if (local_beg < local_end) fetch(local_beg);
@@ -682,9 +709,9 @@ extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_f32)(const float* dq, const float* d
 // standalone tile has (out_ld, out_group, out_col) = (128, e, 0); the out_ld/128 tiles forming one [128, out_ld] matrix (w_2) share
 // out_group = their first entry, so that matrix's partials are contiguous: [splits][128 * out_ld] starting at entry out_group.
 #if AMID_TILE_RT == 7      // independent of the row-tile height: one copy only
-extern "C" int amid_bert_wgrad_f32(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
-                                   const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part, float* b_part,
-                                   void* stream) {
+static int bert_wgrad(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
+                      const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part, float* b_part,
+                      const long long* row_domain, int B, int T, void* stream) {
     AMID_CHECK_ARG(dy && x && ldy && ldx && out_ld && out_group && out_col && w_part && b_part && n_ent > 0 && n_ent <= BW_MAX && M > 0 &&
                    splits > 0);
     BWgradArgs a;
@@ -695,7 +722,9 @@ extern "C" int amid_bert_wgrad_f32(const float* const* dy, const float* const* x
         a.ldw[i] = out_ld[i]; a.wgrp[i] = out_group[i]; a.wcol[i] = out_col[i];
     }
     a.w_part = w_part; a.b_part = b_part; a.n_ent = n_ent; a.M = M; a.splits = splits; a.rows_per_split = (M + splits - 1) / splits;
-    const size_t lds = (size_t)2 * BWG_ROWS * (BD + 16) * sizeof(float);
+    AMID_CHECK_ARG(!row_domain || (B > 0 && T > 0 && (long long)B * T == M));
+    a.row_domain = (row_domain && B <= BWG_LIVE_MAX) ? row_domain : nullptr; a.B = B; a.T = T;
+    const size_t lds = (size_t)2 * BWG_ROWS * (BD + 16) * sizeof(float) + BWG_LIVE_MAX * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)bert_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -705,6 +734,19 @@ extern "C" int amid_bert_wgrad_f32(const float* const* dy, const float* const* x
     bert_wgrad_kernel<<<dim3(splits, n_ent, 2), GEMM_THREADS, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+
+extern "C" int amid_bert_wgrad_f32(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
+                                   const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part, float* b_part,
+                                   void* stream) {
+    return bert_wgrad(dy, x, ldy, ldx, out_ld, out_group, out_col, n_ent, M, splits, w_part, b_part, nullptr, 0, 0, stream);
+}
+
+// the live sequences only, as amid_sas_wgrad_rows_f32 (M = B * T, row_domain [B] = the batch's domain ids)
+extern "C" int amid_bert_wgrad_rows_f32(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
+                                        const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part,
+                                        float* b_part, const long long* row_domain, int B, int T, void* stream) {
+    return bert_wgrad(dy, x, ldy, ldx, out_ld, out_group, out_col, n_ent, M, splits, w_part, b_part, row_domain, B, T, stream);
 }
 
 extern "C" int amid_transpose_rect_f32(const float* const* src, float* const* dst, const int* rows, const int* cols, int n, void* stream) {

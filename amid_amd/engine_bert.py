@@ -254,9 +254,9 @@ class Bert4recEngine(SasrecEngine):
                 dy.append(pl.dpre.data_ptr() + 4 * c * D); xx.append(pl.y2[l].data_ptr()); ldy.append(F); ldx.append(D)
             for c in range(4):                                   # w_2 tile c: dY = dz, X = h[:, c*128:]
                 dy.append(pl.dz.data_ptr()); xx.append(pl.h[l].data_ptr() + 4 * c * D); ldy.append(D); ldx.append(F)
-            L.call("amid_bert_wgrad_f32", ptr_array(dy), ptr_array(xx), (ctypes.c_int * N_ENT)(*ldy), (ctypes.c_int * N_ENT)(*ldx),
+            L.call("amid_bert_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), (ctypes.c_int * N_ENT)(*ldy), (ctypes.c_int * N_ENT)(*ldx),
                    (ctypes.c_int * N_ENT)(*old), (ctypes.c_int * N_ENT)(*ogr), (ctypes.c_int * N_ENT)(*oco), N_ENT, M,
-                   pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), s)
+                   pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), self._own_rows(pl), B, T, s)
             L.call("amid_bert_qkv_bwd_f32" + pl.rt_suffix, pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[l].data_ptr(),
                    self._pp(pre + ".input_sublayer.norm.a_2"), wT3, M, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), s)
         if self.comp:      # the comp modules' parameter gradients; the rows' own halves + their share of the token group -> dxg

@@ -147,6 +147,7 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_bert_ffn1_bwd_f32": ("mfma", 5 * gemm),       # d pre W_1 -> d y2, and dt W_o -> d o
         "amid_bert_qkv_bwd_f32": ("mfma", 3 * gemm),
         "amid_bert_wgrad_f32": ("mfma", 12 * gemm),         # one layer per launch: q, k, v, o and the 4 + 4 tiles of w_1, w_2
+        "amid_bert_wgrad_rows_f32": ("mfma", (6 if Bw <= 1024 else 12) * gemm),      # the live sequences only (see amid_sas_wgrad_rows_f32)
         # matrix-core kernels (H hd = D either way: SASRec 8 x 16, BERT4Rec 4 x 32); unpadded T x T products
         "amid_attn_fwd_f32": ("mfma", 4.0 * T * T * hd * 2 * Bw * H),
         "amid_attn_bwd_f32": ("mfma", 10.0 * T * T * hd * 2 * Bw * H),

@@ -519,6 +519,11 @@ int amid_sas_qkv_ffn_bwd_f32_rt4(const float* dq, const float* dk, const float* 
                              int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
                              float* fd_o, float* fln_part, int mma_bf16, void* stream);
 
+/* amid_bert_wgrad_f32 over the live sequences only (see amid_sas_wgrad_rows_f32) */
+int amid_bert_wgrad_rows_f32(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
+                             const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part, float* b_part,
+                             const long long* row_domain, int B, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
