@@ -475,23 +475,28 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_wgrad_kernel(const BWgradAr
     const int nt = w, i = lane & 15, gq = lane >> 4;
     int* live = reinterpret_cast<int*>(smem + 2 * BWG_ROWS * LD);        // [B] (hint only)
     const bool hint = a.row_domain != nullptr;
-    if (hint) {                                        // wave 0 lists the domain's live sequences in batch order
-        __shared__ int n_live_s;
+    int sq0 = 0;
+    if (hint) {                // wave 0 counts the domain's live sequences, then lists the window of them this split walks
+        __shared__ int hd[3];
         if (w == 0) {
+            int nl = 0;
+            for (int c = 0; c < a.B; c += 64) nl += __popcll(__ballot(c + lane < a.B && ((a.row_domain[c + lane] != 0 ? 1 : 0) == g)));
+            const int mv = nl * a.T, rps = (mv + a.splits - 1) / a.splits;
+            const int lb = min(mv, split * rps), le = min(mv, lb + rps);
+            const int s0 = lb / a.T, s1 = le > lb ? (le - 1) / a.T : s0 - 1;
             int n = 0;
-            for (int c = 0; c < a.B; c += 64) {
+            for (int c = 0; c < a.B && n <= s1; c += 64) {
                 const int b = c + lane;
                 const bool f = b < a.B && ((a.row_domain[b] != 0 ? 1 : 0) == g);
                 const unsigned long long m = __ballot(f);
-                if (f) live[n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+                const int k = n + __popcll(m & ((1ull << lane) - 1ull));
+                if (f && k >= s0 && k <= s1) live[k - s0] = b;
                 n += __popcll(m);
             }
-            if (lane == 0) n_live_s = n;
+            if (lane == 0) { hd[0] = lb; hd[1] = le; hd[2] = s0; }
         }
         __syncthreads();
-        const int mv = n_live_s * a.T, rps = (mv + a.splits - 1) / a.splits;
-        local_beg = min(mv, split * rps);
-        local_end = min(mv, local_beg + rps);
+        local_beg = hd[0]; local_end = hd[1]; sq0 = hd[2];
     }
     constexpr int QPR = D / 4, RPP = GEMM_THREADS / QPR, NRW = BWG_ROWS / RPP;
     const int sub = threadIdx.x % QPR, rl = threadIdx.x / QPR;
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_wgrad_kernel(const BWgradAr
             long long row = grow + r;
             if (hint && ok) {
                 const int v = c0 + r, sq = v / a.T;
-                row = (long long)g * a.M + (long long)live[sq] * a.T + (v - sq * a.T);
+                row = (long long)g * a.M + (long long)live[sq - sq0] * a.T + (v - sq * a.T);
             }
             py[j] = ok ? ld4(dy + row * ldy + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
             px[j] = ok ? ld4(xin + row * ldx + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -723,7 +728,7 @@ static int bert_wgrad(const float* const* dy, const float* const* x, const int* 
     }
     a.w_part = w_part; a.b_part = b_part; a.n_ent = n_ent; a.M = M; a.splits = splits; a.rows_per_split = (M + splits - 1) / splits;
     AMID_CHECK_ARG(!row_domain || (B > 0 && T > 0 && (long long)B * T == M));
-    a.row_domain = (row_domain && B <= BWG_LIVE_MAX) ? row_domain : nullptr; a.B = B; a.T = T;
+    a.row_domain = (row_domain && a.rows_per_split / T + 2 <= BWG_LIVE_MAX) ? row_domain : nullptr; a.B = B; a.T = T;
     const size_t lds = (size_t)2 * BWG_ROWS * (BD + 16) * sizeof(float) + BWG_LIVE_MAX * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {

@@ -25,7 +25,7 @@ struct TileGeomB {
     const long long* row_domain; int B, T;
 };
 
-constexpr int MAP_LIVE_MAX = 1024;                         // sequences per domain the live list is built for (LDS ints)
+constexpr int MAP_LIVE_MAX = 1024;                         // live sequences a tile's window may hold (LDS ints); any batch size
 constexpr int MAP_INTS = MAP_LIVE_MAX + 128;               // live list + the tile's row map
 
 struct TileRowsB {
@@ -49,8 +49,8 @@ __device__ __forceinline__ TileRowsB tile_rows_b(const TileGeomB& tg, int tile, 
         tr.slot = tile;
         return tr;
     }
-    __shared__ int hdr[4];
-    int* live = ints;                  // [B] batch rows of the tile's domain that carry a gradient, in batch order
+    __shared__ int hdr[5];
+    int* live = ints;                  // the tile's window of its domain's live batch rows, in batch order
     int* rmap = ints + MAP_LIVE_MAX;
     const int lane = lane_id();
     const int B = tg.B, T = tg.T, rpt = tg.rows_per_tile, tpg = tg.tiles_per_group;
@@ -66,17 +66,23 @@ __device__ __forceinline__ TileRowsB tile_rows_b(const TileGeomB& tg, int tile, 
             const int d = tile - tiles0 - tiles1;
             if (d < tpg - tiles0) { g = 0; tl = tiles0 + d; } else { g = 1; tl = tiles1 + d - (tpg - tiles0); }
         }
-        if (lv) {
+        const int ng = g == 0 ? n0 : B - n0;
+        int sq0 = 0;
+        if (lv) {                                                    // the tile's window of the domain's live sequences (<= rpt / T + 2 of them)
+            const int v0 = tl * rpt, nr = min(rpt, ng * T - v0);
+            sq0 = v0 / T;
+            const int sq1 = (v0 + nr - 1) / T;
             int n = 0;
-            for (int c = 0; c < B; c += 64) {
+            for (int c = 0; c < B && n <= sq1; c += 64) {
                 const int b = c + lane;
                 const bool f = b < B && ((tg.row_domain[b] != 0 ? 1 : 0) == g);
                 const unsigned long long m = __ballot(f);
-                if (f) live[n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+                const int k = n + __popcll(m & ((1ull << lane) - 1ull));
+                if (f && k >= sq0 && k <= sq1) live[k - sq0] = b;
                 n += __popcll(m);
             }
         }
-        if (lane == 0) { hdr[0] = g; hdr[1] = tl; hdr[2] = lv; hdr[3] = (g == 0 ? n0 : B - n0) * T; }
+        if (lane == 0) { hdr[0] = g; hdr[1] = tl; hdr[2] = lv; hdr[3] = ng * T; hdr[4] = sq0; }
     }
     __syncthreads();
     tr.g = hdr[0];
@@ -87,11 +93,11 @@ __device__ __forceinline__ TileRowsB tile_rows_b(const TileGeomB& tg, int tile, 
     tr.local0 = 0;
     tr.nrows = 0;
     if (!tr.live) return tr;
-    const int v0 = tl * rpt;
+    const int v0 = tl * rpt, sq0 = hdr[4];
     tr.nrows = min(rpt, hdr[3] - v0);
     for (int r = threadIdx.x; r < tr.nrows; r += blockDim.x) {
         const int v = v0 + r, sq = v / T;
-        rmap[r] = live[sq] * T + (v - sq * T);
+        rmap[r] = live[sq - sq0] * T + (v - sq * T);
     }
     __syncthreads();
     tr.rmap = rmap;
@@ -381,7 +387,7 @@ struct WgradArgs {
 };
 
 constexpr int WG_ROWS = 64;    // rows staged per step
-[[maybe_unused]] constexpr int WG_LIVE_MAX = 1024;      // sequences per domain the live list (LDS, one int each) is built for
+[[maybe_unused]] constexpr int WG_LIVE_MAX = 1024;      // live sequences a split's window may hold (LDS, one int each)
 
 // One workgroup = one (domain, weight, row split): it streams its rows of (dY, X) in 64-row chunks through LDS and
 // accumulates dW = dY^T X on the matrix cores (one wave per 16 output rows at D = 128).  Single LDS buffer (74 KB at
@@ -408,24 +414,28 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradA
     const bool hint = a.row_domain != nullptr;
     int local_beg = split * a.rows_per_split;
     int local_end = min(a.M, local_beg + a.rows_per_split);
-    if (hint) {                                        // wave 0 lists the live sequences in batch order; everyone learns the count
-        __shared__ int n_live_s;
+    int sq0 = 0;
+    if (hint) {                // wave 0 counts the domain's live sequences, then lists the window of them this split walks
+        __shared__ int hd[3];
         if (w == 0) {
+            int nl = 0;
+            for (int c = 0; c < a.B; c += 64) nl += __popcll(__ballot(c + lane < a.B && ((a.row_domain[c + lane] != 0 ? 1 : 0) == g)));
+            const int mv = nl * a.T, rps = (mv + a.splits - 1) / a.splits;
+            const int lb = min(mv, split * rps), le = min(mv, lb + rps);
+            const int s0 = lb / a.T, s1 = le > lb ? (le - 1) / a.T : s0 - 1;
             int n = 0;
-            for (int c = 0; c < a.B; c += 64) {
+            for (int c = 0; c < a.B && n <= s1; c += 64) {
                 const int b = c + lane;
                 const bool f = b < a.B && ((a.row_domain[b] != 0 ? 1 : 0) == g);
                 const unsigned long long m = __ballot(f);
-                if (f) live[n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+                const int k = n + __popcll(m & ((1ull << lane) - 1ull));
+                if (f && k >= s0 && k <= s1) live[k - s0] = b;
                 n += __popcll(m);
             }
-            if (lane == 0) n_live_s = n;
+            if (lane == 0) { hd[0] = lb; hd[1] = le; hd[2] = s0; }
         }
         __syncthreads();
-        const int mv = n_live_s * a.T;                 // virtual rows of this domain
-        const int rps = (mv + a.splits - 1) / a.splits;
-        local_beg = min(mv, split * rps);
-        local_end = min(mv, local_beg + rps);
+        local_beg = hd[0]; local_end = hd[1]; sq0 = hd[2];
     }
     const int nt = w / WPN, kt0 = (w % WPN) * KTW;
     const int i = lane & 15, gq = lane >> 4;
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradA
             long long row = grow + r;
             if (hint && ok) {                          // virtual row -> (live sequence, position) -> row of the domain
                 const int v = c0 + r, sq = v / a.T;
-                row = (long long)g * a.M + (long long)live[sq] * a.T + (v - sq * a.T);
+                row = (long long)g * a.M + (long long)live[sq - sq0] * a.T + (v - sq * a.T);
             }
             py[i] = ok ? ld4(dy + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
             px[i] = ok ? ld4(xin + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -552,7 +562,7 @@ static int make_geom_b(int M, int rows_per_tile, TileGeomB* tg, const long long*
     tg->tiles_per_group = (M + rows_per_tile - 1) / rows_per_tile;
     tg->row_domain = nullptr; tg->B = B; tg->T = T;
     if (row_domain) {
-        if (B <= 0 || T <= 0 || (long long)B * T != M || B > MAP_LIVE_MAX) return AMID_ERR_ARG;
+        if (B <= 0 || T <= 0 || (long long)B * T != M || rows_per_tile / T + 2 > MAP_LIVE_MAX) return AMID_ERR_ARG;
         tg->row_domain = row_domain;
     }
     return AMID_OK;
@@ -704,8 +714,10 @@ static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers
     a.M = M; a.splits = splits;
     a.rows_per_split = (M + splits - 1) / splits;
     // the live list lives in LDS: beyond WG_LIVE_MAX sequences the hint is dropped (every row is walked; same result)
-    a.row_domain = (row_domain && B <= WG_LIVE_MAX) ? row_domain : nullptr; a.B = B; a.T = T;
-    const size_t live_bytes = a.row_domain ? (size_t)((B + 3) & ~3) * sizeof(int) : 0;
+    // a split's window of live sequences lives in LDS: rows_per_split / T + 2 entries at most (any batch size)
+    const int win = row_domain ? a.rows_per_split / T + 2 : 0;
+    a.row_domain = (row_domain && win <= WG_LIVE_MAX) ? row_domain : nullptr; a.B = B; a.T = T;
+    const size_t live_bytes = a.row_domain ? (size_t)((win + 3) & ~3) * sizeof(int) : 0;
     const dim3 grid(splits, 6 * n_layers, 2);
     if (D == 128) {
         const size_t lds = (size_t)2 * WG_ROWS * (128 + 16) * sizeof(float) + live_bytes;

@@ -217,7 +217,7 @@ class SasrecPlan:
         self.ln2_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
         # the train step's own backward walks the LIVE sequences only (engine._own_rows): half the rows, re-tiled over the CUs
         # (csrc/sasrec_bwd.hip TileGeomB::row_domain); its LayerNorm partials have their own slots and reduce table
-        self.live_rows = bool(self.LIVE_ROWS_BWD and B <= 1024)
+        self.live_rows = bool(self.LIVE_ROWS_BWD)
         if self.live_rows:
             self.rpt_v = L.value("amid_rows_per_tile", (M + 1) // 2)
             self.tpg_v = (M + self.rpt_v - 1) // self.rpt_v

@@ -133,8 +133,7 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_sas_wgrad_f32": ("mfma", 12 * gemm),          # both layers in one launch
         # the train step's own backward: of each domain only the samples of that domain carry a gradient (the loss multiplies the
         # other domain's BCE by zero, train_sr.py:205-211), the kernels walk those sequences only -- half the rows, priced as such
-        # (beyond 1024 samples per batch the live list no longer fits the kernels' LDS budget and they walk every row: full price)
-        "amid_sas_wgrad_rows_f32": ("mfma", (6 if Bw <= 1024 else 12) * gemm),
+        "amid_sas_wgrad_rows_f32": ("mfma", 6 * gemm),
         "amid_sas_ffn_bwd_rows_f32": ("mfma", 1.5 * gemm),
         "amid_sas_qkv_bwd_rows_f32": ("mfma", 1.5 * gemm),
         "amid_sas_qkv_ffn_bwd_rows_f32": ("mfma", 3 * gemm),
@@ -147,7 +146,7 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_bert_ffn1_bwd_f32": ("mfma", 5 * gemm),       # d pre W_1 -> d y2, and dt W_o -> d o
         "amid_bert_qkv_bwd_f32": ("mfma", 3 * gemm),
         "amid_bert_wgrad_f32": ("mfma", 12 * gemm),         # one layer per launch: q, k, v, o and the 4 + 4 tiles of w_1, w_2
-        "amid_bert_wgrad_rows_f32": ("mfma", (6 if Bw <= 1024 else 12) * gemm),      # the live sequences only (see amid_sas_wgrad_rows_f32)
+        "amid_bert_wgrad_rows_f32": ("mfma", 6 * gemm),      # the live sequences only (see amid_sas_wgrad_rows_f32)
         # matrix-core kernels (H hd = D either way: SASRec 8 x 16, BERT4Rec 4 x 32); unpadded T x T products
         "amid_attn_fwd_f32": ("mfma", 4.0 * T * T * hd * 2 * Bw * H),
         "amid_attn_bwd_f32": ("mfma", 10.0 * T * T * hd * 2 * Bw * H),

@@ -479,7 +479,7 @@ def test_attention_bwd_rows_hint_equals_plain_backward(L, shape, B):
         assert float(b_[~live].abs().max()) == 0.0 and float(a[~live].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,T", [(6, 50), (37, 20), (256, 50)])
+@pytest.mark.parametrize("B,T", [(6, 50), (37, 20), (256, 50), (1500, 8)])     # 1500: more sequences than one LDS window holds at once
 def test_wgrad_rows_hint_equals_plain(L, B, T):
     """amid_sas_wgrad_rows_f32 (only the live sequences' rows are read) against amid_sas_wgrad_f32 on dY whose dead rows are zero:
     the sums over the splits agree to rounding (the rows are grouped into the splits differently)."""
