@@ -50,7 +50,7 @@ def traffic(fetch_csv, write_csv, dst):
     fe, wr = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     out = {}
     for k in sorted(set(fe) | set(wr)):
-        if "amid::" not in k and "amid_rt3::" not in k:
+        if "amid::" not in k and "amid_rt" not in k:
             continue
         f = fe.get(k, [0.0])
         w = wr.get(k, [0.0])
