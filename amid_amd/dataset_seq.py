@@ -72,16 +72,56 @@ class DualDomainSeqDataset:
     def __len__(self) -> int:
         return len(self.i_node)
 
+    @classmethod
+    def from_tokenised(cls, path: str, isTrain: bool = True, neg_nums: int = 1, seed: int = 0) -> "DualDomainSeqDataset":
+        """A dataset from a tokenised fixture (tests/golden/make_tokenised.py: the arrays the REFERENCE's DualDomainSeqDataset
+        produced for a CSV -- dataset_seq.py:177-248 --, its two item pools and every row's own item set) instead of a CSV: the
+        same object the constructor builds, without pandas / JSON.  `ref_neg` keeps the negative the reference drew for every row
+        (a valid draw: DeviceBatches(negatives="fixture") trains on exactly those)."""
+        z = np.load(path)
+        ds = cls.__new__(cls)
+        ds.seq_len, ds.isTrain, ds.neg_nums = int(z["seq_len"]), isTrain, neg_nums
+        ds.long_length, ds.pad_id = int(z["long_length"]), int(z["pad_id"])
+        i64 = lambda k: z[k].astype(np.int64)       # noqa: E731
+        ds.seq_d1, ds.seq_d2, ds.i_node = i64("seq_d1"), i64("seq_d2"), i64("i_node")
+        ds.domain_id, ds.user_nodes, ds.overlap_label = i64("domain_id"), i64("user_node"), i64("overlap_label")
+        ds.long_tail_mask_d1, ds.long_tail_mask_d2 = i64("long_tail_mask_d1"), i64("long_tail_mask_d2")
+        ds.ob_label = np.zeros(len(ds.i_node), dtype=np.int64)
+        ds.pool = [i64("pool_d1"), i64("pool_d2")]
+        own, off = i64("own"), z["own_off"].astype(np.int64)
+        ds.own_items = [own[off[r]:off[r + 1]] for r in range(len(ds.i_node))]
+        ds.ref_neg = i64("neg_samples")
+        ds.rng = np.random.default_rng(seed)
+        return ds
+
+    def shift_items(self, offset: int) -> "DualDomainSeqDataset":
+        """Move every item id except the pad id by `offset` (in place; returns self): the joint mode puts a second dataset's items
+        behind the first one's in the shared table (cfg 4)."""
+        sh = lambda a: np.where(a == self.pad_id, a, a + offset)     # noqa: E731
+        self.seq_d1, self.seq_d2, self.i_node = sh(self.seq_d1), sh(self.seq_d2), self.i_node + offset
+        self.pool = [p + offset for p in self.pool]
+        self.own_items = [o + offset for o in self.own_items]
+        if hasattr(self, "ref_neg"):
+            self.ref_neg = self.ref_neg + offset
+        return self
 
 
 class DeviceBatches:
     """DataLoader(batch_size, shuffle, drop_last=True) over a tokenised dataset resident on the device."""
 
-    def __init__(self, ds: DualDomainSeqDataset, batch_size: int, shuffle: bool, device, seed: int = 0, rank: int = 0, world: int = 1):
+    def __init__(self, ds: DualDomainSeqDataset, batch_size: int, shuffle: bool, device, seed: int = 0, rank: int = 0, world: int = 1,
+                 negatives: str = "device"):
         """rank / world: data parallel -- every rank walks the same shuffled order (same seed) in global batches of
-        world x batch_size rows and keeps its own contiguous slice (DistributedSampler-style, drop_last)."""
+        world x batch_size rows and keeps its own contiguous slice (DistributedSampler-style, drop_last).
+        negatives: "device" = drawn per epoch by amid_sample_negatives_i64; "fixture" = the draw stored with a tokenised fixture
+        (DualDomainSeqDataset.from_tokenised: what the reference's random.sample produced under random.seed(0); needs no GPU)."""
         self.ds, self.bs, self.shuffle, self.device = ds, batch_size, shuffle, torch.device(device)
         self.rank, self.world = rank, world
+        if negatives not in ("device", "fixture"):
+            raise ValueError(f"negatives must be 'device' or 'fixture', got {negatives!r}")
+        if negatives == "fixture" and (not hasattr(ds, "ref_neg") or ds.ref_neg.shape[1] < (1 if ds.isTrain else ds.neg_nums)):
+            raise ValueError("negatives='fixture' needs a tokenised dataset carrying enough stored negatives")
+        self.negatives = negatives
         to = lambda a: torch.from_numpy(a).to(self.device)       # noqa: E731
         self.t = dict(user_node=to(ds.user_nodes), i_node=to(ds.i_node), seq_d1=to(ds.seq_d1), seq_d2=to(ds.seq_d2),
                       domain_id=to(ds.domain_id), overlap_label=to(ds.overlap_label), ob_label=to(ds.ob_label),
@@ -107,6 +147,9 @@ class DeviceBatches:
         """[N, k] negatives for one epoch, drawn ON THE DEVICE (amid_sample_negatives_i64): uniform without replacement from the
         row's domain pool minus its own sequence -- the reference's random.sample(pool - set(seq), k) (dataset_seq.py:198, :215).
         Every rank of a data-parallel run draws the same table (same seed, same epoch counter)."""
+        if self.negatives == "fixture":
+            self.epoch += 1
+            return torch.from_numpy(np.ascontiguousarray(self.ds.ref_neg[:, : self.k])).to(self.device)
         from ._lib import lib
         N = len(self.ds)
         out = torch.empty(N, self.k, dtype=torch.int64, device=self.device)
@@ -146,5 +189,47 @@ class DeviceBatches:
         sel = order[rows.reshape(-1)]
         out = {k: v.index_select(0, sel).reshape(nb, self.bs, *v.shape[1:]) for k, v in self.t.items()}
         out["neg_samples"] = neg.index_select(0, sel).reshape(nb, self.bs, -1)
+        out["label"] = self.label
+        return out
+
+
+class JointBatches:
+    """Two datasets trained as ONE job on a shared table (BASELINE.json configs[3]: "mybank loan_fund + loan_account joint train";
+    not a reference mode -- the reference trains one -dm per run, train_sr.py:447-457 -- but defined by SURVEY.md section 8(d)):
+    the second dataset's item ids sit `offset` rows behind the first's (DualDomainSeqDataset.shift_items; the pad row is shared),
+    and the batches of the two loaders ALTERNATE (a0, b0, a1, b1, ...; the longer loader's surplus at the end), each batch
+    holding rows of one dataset only so that negatives come from that dataset's own pools.  Same iteration / epoch_tensors
+    interface as DeviceBatches; under data parallelism each loader shards its global batches by rank as before."""
+
+    def __init__(self, a: DeviceBatches, b: DeviceBatches):
+        if a.bs != b.bs or a.k != b.k or a.ds.seq_len != b.ds.seq_len or a.ds.pad_id != b.ds.pad_id:
+            raise ValueError("joint loaders must agree on batch size, negatives per row, seq_len and pad id")
+        self.a, self.b, self.bs, self.k = a, b, a.bs, a.k
+        self.device, self.rank, self.world, self.label = a.device, a.rank, a.world, a.label
+
+    def __len__(self) -> int:
+        return len(self.a) + len(self.b)
+
+    def order(self):
+        """[(loader index, batch index)] of one epoch."""
+        na, nb = len(self.a), len(self.b)
+        out = []
+        for i in range(max(na, nb)):
+            if i < na:
+                out.append((0, i))
+            if i < nb:
+                out.append((1, i))
+        return out
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        ia, ib = iter(self.a), iter(self.b)
+        for which, _ in self.order():
+            yield next(ia if which == 0 else ib)
+
+    def epoch_tensors(self) -> Dict[str, torch.Tensor]:
+        ea, eb = self.a.epoch_tensors(), self.b.epoch_tensors()
+        na = len(self.a)
+        pos = torch.tensor([i if w == 0 else na + i for w, i in self.order()], device=self.device)
+        out = {k: torch.cat((ea[k], eb[k]), 0).index_select(0, pos) for k in ea if k != "label"}
         out["label"] = self.label
         return out

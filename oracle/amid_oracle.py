@@ -208,8 +208,12 @@ def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) ->
 #           PointWiseFeedForward.forward      model_seq.py:322-326
 # --------------------------------------------------------------------------
 def sasrec_encoder(x: torch.Tensor, P: Params, pre: str, masks: Masks = None,
-                   heads: int = SASREC_HEADS, taps: Optional[dict] = None) -> torch.Tensor:
-    """x: gathered item rows [B,T,D] (not modified).  Returns log_feats [B,T,D]."""
+                   heads: int = SASREC_HEADS, taps: Optional[dict] = None, relu_keep: Optional[dict] = None) -> torch.Tensor:
+    """x: gathered item rows [B,T,D] (not modified).  Returns log_feats [B,T,D].
+    relu_keep (tests only): {f"{pre}.relu{l}": [B,T,D] of 1 / 0 / -1} replaces relu(h) by h * keep -- the decisions of the
+    implementation under test; -1 = the oracle's own decision -- so that gradients can be compared to rounding even when some
+    pre-activation sits within rounding of the kink (a flipped decision changes a gradient by O(1), not O(eps)).  taps[f"relu_flip{l}"] then records the largest |h| among the
+    elements whose forced decision differs from the oracle's own: the caller asserts it is rounding-sized."""
     B, T, D = x.shape
     hd = D // heads
     p = SASREC_DROPOUT
@@ -253,7 +257,17 @@ def sasrec_encoder(x: torch.Tensor, P: Params, pre: str, masks: Masks = None,
         if taps is not None:     # distance of the closest live pre-activation from the relu kink (test robustness)
             live = h[h != 0]
             taps[f"relu_margin{l}"] = float(live.abs().min()) if live.numel() else float("inf")
-        h = torch.relu(h)
+        rk = None if relu_keep is None else relu_keep.get(f"{pre}.relu{l}")
+        if rk is None:
+            h = torch.relu(h)
+        else:
+            own = h.detach() > 0
+            dec = torch.where(rk < 0, own, rk > 0)
+            if taps is not None:
+                flipped = dec != own
+                taps[f"relu_flip{l}"] = float(h.detach()[flipped].abs().max()) if bool(flipped.any()) else 0.0
+                taps[f"relu_nflip{l}"] = int(flipped.sum())
+            h = h * dec.to(h.dtype)
         z = _drop(h @ C2.t() + c2, masks, f"{pre}.ffn2_{l}", p)          # conv2 -> dropout2
         x = (z + y) * keep                                               # :325 (+= inputs, the LN output), :383
         if taps is not None:
@@ -303,15 +317,16 @@ def inner_comp(seq: torch.Tensor, P: Params, pre: str, threshold: float, taps: O
 
 def sasrec_forward(P: Params, i_node: torch.Tensor, neg_samples: torch.Tensor, seq_d1: torch.Tensor,
                    seq_d2: torch.Tensor, masks: Masks = None, taps: Optional[dict] = None, isItC: bool = False,
-                   threshold2: float = 0.5, isDR: bool = False, isInC: bool = False, threshold1: float = 0.5) -> Tuple[torch.Tensor, ...]:
+                   threshold2: float = 0.5, isDR: bool = False, isInC: bool = False, threshold1: float = 0.5,
+                   relu_keep: Optional[dict] = None) -> Tuple[torch.Tensor, ...]:
     E = P["item_emb_layer.emb_item.weight"]
     i_feat = gather_rows(E, i_node).unsqueeze(1)                         # :418
     neg_feat = gather_rows(E, neg_samples)                               # :419
     e1, e2 = gather_rows(E, seq_d1), gather_rows(E, seq_d2)              # :420-421
     if isInC:                                                            # :422-424 on the raw gathered rows; the encoders then see 2T tokens
         e1, e2 = inner_comp(e1, P, "inc_d1", threshold1, taps), inner_comp(e2, P, "inc_d2", threshold1, taps)
-    f1 = sasrec_encoder(e1, P, "sac1", masks, taps=None if taps is None else taps.setdefault("sac1", {}))
-    f2 = sasrec_encoder(e2, P, "sac2", masks, taps=None if taps is None else taps.setdefault("sac2", {}))
+    f1 = sasrec_encoder(e1, P, "sac1", masks, taps=None if taps is None else taps.setdefault("sac1", {}), relu_keep=relu_keep)
+    f2 = sasrec_encoder(e2, P, "sac2", masks, taps=None if taps is None else taps.setdefault("sac2", {}), relu_keep=relu_keep)
     if isItC:                                                            # :426-431 (after the encoders, both from the un-mixed features)
         f1, f2 = inter_comp(f1, f2, P, "itc_d1", threshold2, taps), inter_comp(f2, f1, P, "itc_d2", threshold2, taps)
     u1 = f1.mean(1)                                                      # :432 mean over ALL T (pads included; 2T with isItC)

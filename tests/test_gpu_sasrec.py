@@ -736,19 +736,25 @@ def test_edge_shapes_forward_backward_vs_oracle(Bn, T, D, neg):
 @pytest.mark.parametrize("Bn,D,train,build", [(256, 128, True, ""), (256, 64, False, ""), (128, 128, True, "_rt5"), (160, 64, False, "_rt5")])
 def test_headline_shape_forward_backward_vs_oracle(Bn, D, train, build):
     """BASELINE.json configs[1] itself (B 256, T 50; 100 rows per workgroup: the 112-row build of the row-tile kernels, which the
-    small shapes above no longer reach; batches of 128 / 160: the 80-row build) forward + backward against the oracle, dropout on;
-    relative L2 on the gradients (at this size some relu pre-activation always sits within rounding of the kink)."""
+    small shapes above no longer reach; batches of 128 / 160: the 80-row build) forward + backward through the PLAIN kernels against
+    the oracle, dropout on.  At this size some relu pre-activation always sits within rounding of the kink, so the oracle is given
+    the kernels' own relu decisions (relu_keep; every decision that differs from the oracle's own must be rounding-sized) and the
+    gradients are held to max-abs 2e-4."""
     T, hid, n_items = 50, 32, 3000
     P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=90 + D)
     batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=77)
     seed, step = 21, 4
     masks = orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=step) if train else None
-    loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, masks)
     eng = make_engine(P, T, seed=seed)
     pl = run_forward(eng, batch, train=train, with_loss=True, step=step, seed=seed)
     assert pl.rt_suffix == build and pl.rpt == -(-2 * Bn * T // 256)        # 100 rows: the 112-row build; 50 / 63: the 80-row build
     eng.enqueue_backward(pl, train=train)
     eng.sync()
+    M = Bn * T
+    keep = {f"sac{g + 1}.relu{l}": (pl.h[l][g * M:(g + 1) * M].reshape(Bn, T, D).cpu() > 0).float() for g in (0, 1) for l in (0, 1)}
+    taps = {}
+    loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, masks, relu_keep=keep, taps=taps)
+    assert max(taps[s_].get(f"relu_flip{l}", 0.0) for s_ in ("sac1", "sac2") for l in (0, 1)) < 2e-5
     assert relmax(pl.p1, p1) < 1e-4 and relmax(pl.p2, p2) < 1e-4
     assert abs(float(pl.loss.item()) - float(loss)) < 1e-5
     for name in eng.dense.slots:
@@ -757,8 +763,9 @@ def test_headline_shape_forward_backward_vs_oracle(Bn, D, train, build):
             n3 = got.numel() // 3
             got, want = got.cpu().clone(), want.clone()
             got[n3:2 * n3] = 0; want[n3:2 * n3] = 0
-        assert rel_l2(got, want) < 2e-3, (name, rel_l2(got, want))
-    assert rel_l2(dense_table_grad(eng, pl), grads["item_emb_layer.emb_item.weight"]) < 2e-3
+        assert relmax(got, want) < 2e-4 and rel_l2(got, want) < 5e-5, (name, relmax(got, want), rel_l2(got, want))
+    tg = dense_table_grad(eng, pl)
+    assert relmax(tg, grads["item_emb_layer.emb_item.weight"]) < 2e-4 and rel_l2(tg, grads["item_emb_layer.emb_item.weight"]) < 5e-5
 
 
 # ---------------------------------------------------------------------------- bf16 matrix products (BASELINE.json configs[2])

@@ -1,0 +1,351 @@
+"""Parity of the path that train_step / graph replay / bench.py actually TIME: the fused step whose encoder work covers the live
+sequences only (the step's own loss multiplies the other domain's terms of every sample by zero, train_sr.py:205-211), entered the
+way the product enters it -- enqueue_local_grads / enqueue_train_step / capture + replay -- and compared with the CPU oracle.
+
+The gradient comparisons are made kink-free instead of loose: the oracle is told the implementation's own relu decisions
+(relu_keep), the test asserts that every decision that differs from the oracle's own sits within rounding of the kink, and the
+gradients are then held to max-abs tolerances."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import amid_oracle as orc
+
+pytestmark = pytest.mark.gpu
+LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def log(msg):
+    os.makedirs(LOG, exist_ok=True)
+    with open(os.path.join(LOG, "parity.log"), "a") as f:
+        f.write(msg + "\n")
+
+
+def relmax(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def make_engine(P, T, lr=5e-4, seed=0):
+    from amid_amd.engine import SasrecEngine
+    n_rows, D = P["item_emb_layer.emb_item.weight"].shape
+    hid = P["predictModule.fc.0.weight"].shape[0]
+    eng = SasrecEngine(n_rows, D, T, hid, lr=lr, seed=seed)
+    eng.load_state_dict(P)
+    return eng
+
+
+def load(eng, pl, batch):
+    cu = {k: v.cuda() for k, v in batch.items()}
+    eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"])
+
+
+def timed_local_grads(eng, pl, batch, step, seed):
+    """Step `step` up to the local gradients exactly as train_step / capture_train_step enqueue it (t += 1, lazy-Adam catch-up,
+    side-stream sort, forward + loss + backward over the live sequences, gradient tail)."""
+    eng.set_step(step - 1, seed)
+    load(eng, pl, batch)
+    eng.enqueue_local_grads(pl)
+    eng.sync()
+    eng.check_index_error(pl)
+    assert eng.step == step
+
+
+def gpu_relu_keep(eng, pl, batch):
+    """The implementation's relu decisions, from the saved relu outputs, as the oracle's relu_keep; -1 (the oracle's own
+    decision) for the sequences the timed path does not encode or differentiate: domain g of the samples with domain_id != g."""
+    Bn, T = batch["seq_d1"].shape
+    M, D = Bn * T, eng.D
+    dom = batch["domain_id"]
+    out = {}
+    for g in (0, 1):
+        live = (dom == g)
+        for l in (0, 1):
+            h = pl.h[l][g * M:(g + 1) * M].reshape(Bn, T, D).cpu()
+            keep = (h > 0).float()
+            keep[~live] = -1.0
+            out[f"sac{g + 1}.relu{l}"] = keep
+    return out
+
+
+def dense_table_grad(eng, pl):
+    U = int(pl.n_uniq.item())
+    g = torch.zeros(eng.n_rows, eng.D)
+    g[pl.uniq_ids[:U].cpu().long()] = pl.uniq_grad[:U].cpu()
+    return g
+
+
+def check_grads(tag, eng, pl, grads, tol, l2tol):
+    worst = worst2 = 0.0
+    for name in eng.dense.slots:
+        got, want = eng.dense.view(name, eng.dense.grad).cpu().clone(), grads[name].clone()
+        if name.endswith("in_proj_bias"):            # the key-bias third is analytically zero (softmax shift invariance)
+            n3 = got.numel() // 3
+            got[n3:2 * n3] = 0; want[n3:2 * n3] = 0
+        e, e2 = relmax(got, want), rel_l2(got, want)
+        worst, worst2 = max(worst, e), max(worst2, e2)
+        assert e < tol and e2 < l2tol, (tag, name, e, e2)
+    tg = dense_table_grad(eng, pl)
+    e, e2 = relmax(tg, grads["item_emb_layer.emb_item.weight"]), rel_l2(tg, grads["item_emb_layer.emb_item.weight"])
+    log(f"{tag}: worst dense grad relmax {worst:.3e} l2 {worst2:.3e}; table relmax {e:.3e} l2 {e2:.3e}")
+    assert e < tol and e2 < l2tol, (tag, "table", e, e2)
+
+
+def split_batch(Bn, T, n_items, seed, split):
+    batch = orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=seed)
+    if split == "all0":
+        batch["domain_id"] = torch.zeros(Bn, dtype=torch.long)
+    elif split == "all1":
+        batch["domain_id"] = torch.ones(Bn, dtype=torch.long)
+    elif split == "one0":                 # a single live sequence in domain 0, the rest in domain 1
+        batch["domain_id"] = torch.ones(Bn, dtype=torch.long)
+        batch["domain_id"][Bn // 3] = 0
+    return batch
+
+
+# B, T, D, expected live-row build of the row-tile kernels, domain split
+TIMED_CASES = [
+    (256, 50, 128, "_rt4", "mixed"),      # BASELINE.json configs[1]: the headline shape, 50 live rows per workgroup
+    (256, 20, 128, "_rt3", "mixed"),      # configs[3] (mybank, seq_len 20)
+    (384, 50, 128, "_rt5", "mixed"),      # 75 live rows per workgroup: the 80-row build
+    (512, 50, 128, "", "mixed"),          # configs[2]'s batch: 100 live rows, the 112-row build
+    (256, 50, 64, "_rt4", "mixed"),
+    (256, 50, 128, "_rt4", "all0"),       # every sample in domain 0: domain 1's encoder has no live sequence at all
+    (256, 50, 128, "_rt4", "all1"),
+    (200, 50, 128, "_rt3", "one0"),       # one live sequence in domain 0 (a one-row-tile domain), ragged last tiles
+    (37, 13, 64, "_rt3", "mixed"),        # odd everything
+    (1100, 50, 128, "", "mixed"),         # B > 1024: the live-sequence windows of the tiles / splits / attention slots
+]
+
+
+@pytest.mark.parametrize("Bn,T,D,build,split", TIMED_CASES)
+def test_timed_path_loss_and_grads_vs_oracle(Bn, T, D, build, split):
+    hid, n_items = 32, 3000
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=300 + D + Bn)
+    batch = split_batch(Bn, T, n_items, seed=Bn + T, split=split)
+    seed, step = 21, 4
+    masks = orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=step)
+    eng = make_engine(P, T, seed=seed)
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    timed_local_grads(eng, pl, batch, step, seed)
+    if hasattr(pl, "rt_suffix_v") and not getattr(pl, "fused_seq", False):
+        assert pl.rt_suffix_v == build, (pl.rt_suffix_v, pl.rpt_v)
+    keep = gpu_relu_keep(eng, pl, batch)
+    taps = {}
+    loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, masks, relu_keep=keep, taps=taps)
+    flips = [(taps[s].get(f"relu_flip{l}", 0.0), taps[s].get(f"relu_nflip{l}", 0)) for s in ("sac1", "sac2") for l in (0, 1)]
+    log(f"timed B={Bn} T={T} D={D} {split}: relu decisions that differ from the oracle's own (|h|, count): {flips}")
+    assert max(f[0] for f in flips) < 2e-5            # only pre-activations within rounding of the kink may be decided differently
+    assert abs(float(pl.loss.item()) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    dom = batch["domain_id"]
+    own = torch.where(dom[:, None] == 0, pl.p1.cpu(), pl.p2.cpu())          # the logits the loss reads
+    want = torch.where(dom[:, None] == 0, p1, p2)
+    assert relmax(own, want) < 1e-4
+    check_grads(f"timed B={Bn} T={T} D={D} {split}", eng, pl, grads, 2e-4, 5e-5)
+
+
+@pytest.mark.parametrize("Bn,T,D", [(256, 50, 128), (256, 20, 128)])
+@pytest.mark.parametrize("pool", [False, True])
+def test_timed_path_trajectory_graph_replay_vs_oracle(Bn, T, D, pool):
+    """Three whole steps at the headline shape (and the mybank shape) through capture_train_step + replay_train_step -- the thing
+    bench.py times -- against the oracle's dense-Adam trajectory: loss per step and every parameter after the flush."""
+    hid, n_items, K, lr, seed = 32, 3000, 3, 1e-3, 4242
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=20 + T)
+    eng = make_engine(P, T, lr=lr, seed=seed)
+    Po = {k: v.clone() for k, v in P.items()}
+    opt = orc.DenseAdam(Po, lr=lr)
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    batches = [orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=500 + t) for t in range(K)]
+    if pool:
+        packed = []
+        for b in batches:
+            cu = {k: v.cuda() for k, v in b.items()}
+            packed.append(eng.pack_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"]))
+        eng.set_input_pool(pl, torch.stack(packed))
+    else:
+        load(eng, pl, batches[0])
+    eng.capture_train_step(pl)
+    for t in range(1, K + 1):
+        if not pool:
+            load(eng, pl, batches[t - 1])
+        eng.replay_train_step(pl)
+        eng.sync()
+        loss_o = orc.train_step("sasrec", Po, opt, batches[t - 1], orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=t))
+        log(f"timed traj B={Bn} T={T} pool={pool} step {t}: loss gpu {float(pl.loss.item()):.7f} oracle {loss_o:.7f}")
+        assert abs(float(pl.loss.item()) - loss_o) < 5e-5
+    eng.check_index_error(pl)
+    eng.flush_table()
+    eng.sync()
+    sd = eng.state_dict()
+    worst = 0.0
+    for k, v in Po.items():
+        d = (sd[k].cpu() - v).abs()
+        if k.endswith("in_proj_bias"):
+            n3 = v.numel() // 3
+            d = torch.cat((d[:n3], d[2 * n3:]))      # chaotic key-bias slice, see test_oracle_golden
+        worst = max(worst, float(d.max()))
+        assert float(d.max()) < 2e-4, k
+    log(f"timed traj B={Bn} T={T} pool={pool}: worst |param diff| after {K} steps {worst:.3e}")
+
+
+def plain_local_grads(eng, pl, batch, step, seed):
+    """The same step through the PLAIN kernels (every sequence of both domains encoded and differentiated)."""
+    eng.set_step(step, seed)
+    load(eng, pl, batch)
+    eng.enqueue_prepare(pl, sparse=True)
+    eng.enqueue_forward(pl, train=True, with_loss=True)
+    eng.enqueue_backward(pl, train=True)
+    eng.sync()
+
+
+@pytest.mark.parametrize("Bn,T,n_items", [(4096, 50, 10_000_000), (256, 50, 3000), (300, 20, 3000)])
+def test_timed_path_equals_plain_path(Bn, T, n_items):
+    """BASELINE.json configs[4]'s per-GPU step (B 4096 on a 10 M-row table) and two small shapes: the timed path against the plain
+    path of the same engine -- the encoder-input gradient rows of the live sequences bit for bit, exact zeros (or rows left out
+    of the reduction) for the others, the reduced table-row and dense gradients to rounding --, and its loss-side logits against
+    the oracle on a 64-sample slice (a sample's logits depend on that sample only)."""
+    D, hid = 128, 32
+    seed, step = 5, 3
+    shapes = orc.sasrec_param_shapes(8, D, T, hid)
+    P = orc.random_params(shapes, seed=77)
+    from amid_amd.engine import SasrecEngine
+    eng = SasrecEngine(n_items, D, T, hid, seed=seed)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    eng.table.copy_(torch.randn(n_items, D, generator=g, device="cuda"))
+    with torch.no_grad():
+        for name in eng.dense.slots:
+            eng.dense.view(name).copy_(P[name].cuda())
+    torch.cuda.synchronize()
+    gb = torch.Generator().manual_seed(Bn)
+    batch = orc.synthetic_batch(Bn, T, n_items - 2, pad_id=n_items - 1, neg=1, seed=9)
+    if n_items > 100000:                  # S-uniform: every position a uniform id, no pads
+        batch["seq_d1"] = torch.randint(0, n_items, (Bn, T), generator=gb)
+        batch["seq_d2"] = torch.randint(0, n_items, (Bn, T), generator=gb)
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    timed_local_grads(eng, pl, batch, step, seed)
+    M = Bn * T
+    dom = batch["domain_id"]
+    live = torch.cat((dom == 0, dom == 1)).repeat_interleave(T)              # [2M]
+    t_dx = pl.dxg[: 2 * M].cpu().clone()
+    t_loss, t_ids_n = float(pl.loss.item()), int(pl.n_uniq.item())
+    t_tab = (pl.uniq_ids[:t_ids_n].cpu().clone(), pl.uniq_grad[:t_ids_n].cpu().clone())
+    t_dense = eng.dense.grad.cpu().clone()
+    t_own = torch.where(dom[:, None] == 0, pl.p1.cpu(), pl.p2.cpu())
+    plain_local_grads(eng, pl, batch, step, seed)
+    p_dx = pl.dxg[: 2 * M].cpu()
+    assert torch.equal(t_dx[live], p_dx[live])
+    assert float(p_dx[~live].abs().max()) == 0.0
+    p_n = int(pl.n_uniq.item())
+    p_ids, p_rows = pl.uniq_ids[:p_n].cpu(), pl.uniq_grad[:p_n].cpu()
+    nz = p_rows.abs().amax(1) > 0                                            # rows only dead positions touch reduce to exact zeros
+    tz = t_tab[1].abs().amax(1) > 0
+    assert torch.equal(p_ids[nz], t_tab[0][tz])
+    assert relmax(t_tab[1][tz], p_rows[nz]) < 2e-6
+    assert abs(t_loss - float(pl.loss.item())) < 1e-6
+    assert relmax(t_dense, eng.dense.grad) < 2e-5
+    assert torch.equal(t_own, torch.where(dom[:, None] == 0, pl.p1.cpu(), pl.p2.cpu()))
+    # oracle on the first 64 samples (ids remapped onto the rows they touch; dropout counters are indexed b-major, so the slice's
+    # masks are the first entries of the whole batch's)
+    S = 64
+    sub = {k: v[:S].clone() for k, v in batch.items()}
+    ids = torch.cat([sub[k].reshape(-1) for k in ("i_node", "neg_samples", "seq_d1", "seq_d2")])
+    uniq, inv = torch.unique(ids, return_inverse=True)
+    Ps = dict(P)
+    Ps["item_emb_layer.emb_item.weight"] = eng.table[uniq.cuda()].cpu()
+    o = 0
+    for k in ("i_node", "neg_samples", "seq_d1", "seq_d2"):
+        n = sub[k].numel()
+        sub[k] = inv[o:o + n].reshape(sub[k].shape); o += n
+    p1, p2 = orc.sasrec_forward(Ps, sub["i_node"], sub["neg_samples"], sub["seq_d1"], sub["seq_d2"],
+                                orc.philox_masks_sasrec(S, T, D, seed=seed, step=step))
+    want = torch.where(dom[:S, None] == 0, p1, p2)
+    assert relmax(t_own[:S], want) < 1e-4
+
+
+# ---------------------------------------------------------------------------- kernel level: every build of the three row-tile kernels
+def _rand(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("suf,rpt", [("", 100), ("_rt3", 40), ("_rt4", 50), ("_rt5", 75)])
+@pytest.mark.parametrize("Bn,T", [(64, 50), (37, 20), (1100, 8)])
+def test_rows_row_tile_kernels_equal_plain_in_every_build(suf, rpt, Bn, T):
+    """amid_sas_{ffn_bwd,qkv_bwd,qkv_ffn_bwd}_rows_f32<suf> (tiles over the live sequences through the LDS row map) against the plain
+    entry points of the same build on inputs whose dead rows carry zero gradients: every per-row output bit-identical on the live
+    rows, the LayerNorm partial sums equal to rounding (the rows are grouped into tiles differently)."""
+    from amid_amd._lib import lib, ptr_array
+    L = lib()
+    D, M = 128, Bn * T
+    g = torch.Generator().manual_seed(Bn * 31 + T)
+    dom = (torch.rand(Bn, generator=g) < 0.5).long()
+    livef = torch.cat((dom == 0, dom == 1)).float().repeat_interleave(T).cuda()          # [2M]
+    live = livef.bool().cpu()
+    s = torch.cuda.current_stream().cuda_stream
+    host = (ctypes.c_ubyte * L.value("amid_step_state_bytes"))()
+    L.call("amid_step_state_pack", ctypes.addressof(host), 11, 6, 5e-4, 0.9, 0.999, 1e-8)
+    st = torch.frombuffer(bytearray(host), dtype=torch.uint8).cuda()
+    pa = lambda a, b: ptr_array([a.data_ptr(), b.data_ptr()])          # noqa: E731
+    W = lambda: (_rand(g, D, D, scale=0.1), _rand(g, D, D, scale=0.1))  # noqa: E731  per-domain [D, D]
+    lnw = (1 + _rand(g, D, scale=0.1), 1 + _rand(g, D, scale=0.1))
+    tmq = (torch.rand(2 * M, D // 4, generator=g) < 0.02).to(torch.uint8).cuda() * 5
+    tpg = -(-M // rpt)
+    dom_d = dom.cuda()
+
+    def inputs(kind):
+        mk = lambda: _rand(g, 2 * M, D)                                # noqa: E731
+        if kind == "ffn":
+            return dict(dxo=mk() * livef[:, None], h=mk().relu(), r=mk(), w1T=W(), w2T=W(), woT=W())
+        d = dict(dq=mk() * livef[:, None], dk=mk() * livef[:, None], dv=mk() * livef[:, None], dr=mk() * livef[:, None], x=mk(),
+                 wq=W(), wk=W(), wv=W())
+        if kind == "qkv_ffn":
+            d.update(h=mk().relu(), r=mk(), w1T=W(), w2T=W(), woT=W())
+        return d
+
+    def run(kind, i, rows):
+        nanbuf = lambda: torch.full((2 * M, D), float("nan"), device="cuda")   # noqa: E731
+        part = lambda: torch.full((2 * tpg, 2, D), float("nan"), device="cuda")  # noqa: E731
+        hint = (dom_d.data_ptr(), Bn, T) if rows else ()
+        sufx = ("_rows" if rows else "") + "_f32" + suf
+        if kind == "ffn":
+            dpre2, dpre1, dr, d_o, lp = nanbuf(), nanbuf(), nanbuf(), nanbuf(), part()
+            L.call("amid_sas_ffn_bwd" + sufx, i["dxo"].data_ptr(), tmq.data_ptr(), i["h"].data_ptr(), i["r"].data_ptr(), pa(*lnw),
+                   pa(*i["w1T"]), pa(*i["w2T"]), pa(*i["woT"]), 1e-8, M, D, rpt, 1, st.data_ptr(), 1, 0.5, dpre2.data_ptr(),
+                   dpre1.data_ptr(), dr.data_ptr(), d_o.data_ptr(), lp.data_ptr(), 0, *hint, s)
+            torch.cuda.synchronize()
+            return [dpre2.cpu(), dpre1.cpu(), dr.cpu(), d_o.cpu()], [lp.cpu()]
+        if kind == "qkv":
+            dx, lp = nanbuf(), part()
+            L.call("amid_sas_qkv_bwd" + sufx, i["dq"].data_ptr(), i["dk"].data_ptr(), i["dv"].data_ptr(), i["dr"].data_ptr(),
+                   i["x"].data_ptr(), pa(*lnw), pa(*i["wq"]), pa(*i["wk"]), pa(*i["wv"]), 1e-8, M, D, rpt, dx.data_ptr(), lp.data_ptr(),
+                   0, *hint, s)
+            torch.cuda.synchronize()
+            return [dx.cpu()], [lp.cpu()]
+        dx, lp, dpre2, dpre1, fdr, d_o, flp = nanbuf(), part(), nanbuf(), nanbuf(), nanbuf(), nanbuf(), part()
+        L.call("amid_sas_qkv_ffn_bwd" + sufx, i["dq"].data_ptr(), i["dk"].data_ptr(), i["dv"].data_ptr(), i["dr"].data_ptr(),
+               i["x"].data_ptr(), pa(*lnw), pa(*i["wq"]), pa(*i["wk"]), pa(*i["wv"]), 1e-8, M, D, rpt, dx.data_ptr(), lp.data_ptr(),
+               tmq.data_ptr(), i["h"].data_ptr(), i["r"].data_ptr(), pa(*lnw), pa(*i["w1T"]), pa(*i["w2T"]), pa(*i["woT"]), 0,
+               st.data_ptr(), 1, 0.5, dpre2.data_ptr(), dpre1.data_ptr(), fdr.data_ptr(), d_o.data_ptr(), flp.data_ptr(), 0, *hint, s)
+        torch.cuda.synchronize()
+        return [dpre2.cpu(), dpre1.cpu(), fdr.cpu(), d_o.cpu()], [lp.cpu(), flp.cpu()]      # d x[l+1] stays in registers: not an output
+
+    for kind in ("ffn", "qkv", "qkv_ffn"):
+        inp = inputs(kind)
+        rows_plain, parts_plain = run(kind, inp, False)
+        rows_hint, parts_hint = run(kind, inp, True)
+        for a, b in zip(rows_plain, rows_hint):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a[live], b[live]), (kind, suf)
+        for a, b in zip(parts_plain, parts_hint):
+            # [2 * tpg, 2, D]: domain g's slots are [g * tpg, (g + 1) * tpg); unused live-tile slots are zero-filled
+            sa = a.reshape(2, tpg, 2, D).double().sum(1)
+            sb = b.reshape(2, tpg, 2, D).double().sum(1)
+            assert torch.isfinite(sb).all()
+            assert float((sa - sb).abs().max()) < 2e-5 * float(sa.abs().max() + 1e-30), (kind, suf)
