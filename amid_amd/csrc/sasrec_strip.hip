@@ -1,0 +1,531 @@
+// SASRec encoder layer as register-resident strip GEMM chains (strip_gemm.h), forward and backward.
+// Reference arithmetic: Log2feats.forward model_seq.py:371-383, nn.MultiheadAttention's projections as called at :374,
+// PointWiseFeedForward model_seq.py:322-326, and their autograd (loss.backward(), train_sr.py:214).  Same operations, operands and
+// saved tensors as the row-tile kernels of sasrec_fwd.hip / sasrec_bwd.hip (which stay for bf16 operands and for callers outside
+// the fused train step); the attention core between the projections runs in its own launch (attention_mfma.hip).
+//
+//   strip_qkv_fwd        Qn = LN1(x) ; k = x Wk^T + bk ; v = x Wv^T + bv ; q = Qn Wq^T + bq          (k, v from the UN-normed x, :374)
+//   strip_oproj_ffn_fwd  r = Qn + (o Wo^T + bo) (:378) ; y = LN2(r) ; h = relu(drop1(y C1^T + c1)) ; x' = (drop2(h C2^T + c2) + y) * ~tm
+//                        [+ the next layer's strip_qkv_fwd on x' without leaving the registers]
+//   strip_ffn_bwd        dz = dx' * ~tm ; dpre2 = dz * drop2 ; dpre1 = (dpre2 C2) * relu'(h) * drop1 ; dy = dpre1 C1 + dz ;
+//                        dr = LN2'(dy ; r) ; d_o = dr Wo                                  (+ partial sums of d gamma2 / d beta2)
+//   strip_qkv_bwd        dx = LN1'(dq Wq + dr ; x) + dk Wk + dv Wv                        (+ partial sums of d gamma1 / d beta1)
+//                        [+ the layer below's strip_ffn_bwd on dx without leaving the registers]
+// Backward weights arrive TRANSPOSED (wT[in][out], refreshed once per step by the head kernel) so that a data gradient is again
+// C[rows, N] = A[rows, K] W'[N, K]^T.  Algorithmic FLOPs per row: 2 D D per projection; MFMA-bound (exact fp32 MFMA).
+#include "common.h"
+#include "rng.h"
+#include "strip_gemm.h"
+
+namespace amid {
+
+struct StripQkvArgs {
+    const float* x;                     // [2M, D] layer input
+    const float* ln_w[2]; const float* ln_b[2];
+    const float* w_in[2]; const float* b_in[2];     // [3D, D], [3D]
+    float* qn; float* q; float* k; float* v;
+    float ln_eps;
+};
+
+struct StripOffArgs {
+    const float* o; const float* qn;
+    const float* w_o[2]; const float* b_o[2]; const float* ln_w[2]; const float* ln_b[2];
+    const float* w1[2]; const float* b1[2]; const float* w2[2]; const float* b2[2];
+    const unsigned char* tmq;
+    float* r; float* y; float* h; float* xo;
+    float ln_eps;
+    const StepState* st; int train; unsigned spec; float scale; int layer;
+};
+
+struct StripFfnBwdArgs {
+    const float* dxo;                   // [2M, D] gradient of the layer output
+    const unsigned char* tmq;
+    const float* h; const float* r;     // saved relu output, saved LN2 input
+    const float* ln_w[2];
+    const float* w1T[2]; const float* w2T[2]; const float* woT[2];
+    float* dpre2; float* dpre1; float* dr; float* d_o;
+    float* ln_part;                     // [2 tpg][2][D]
+    float ln_eps;
+    const StepState* st; int train; unsigned spec; float scale; int layer;
+};
+
+struct StripQkvBwdArgs {
+    const float* dq; const float* dk; const float* dv; const float* dr; const float* x;
+    const float* ln_w[2];
+    const float* wqT[2]; const float* wkT[2]; const float* wvT[2];
+    float* dx;
+    float* ln_part;                     // [2 tpg][2][D]
+    float ln_eps;
+};
+
+template <int D>
+__device__ __forceinline__ void add_bias(f32x4 (&acc)[D / 16], const float* __restrict__ b) {
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) acc[ct] += col4(b, ct);
+}
+template <int D>
+__device__ __forceinline__ void to_regs(StripRegs<D>& dst, const f32x4 (&acc)[D / 16]) {
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) dst.v[ct] = acc[ct];
+}
+
+// a running two-slab ring: next(W) returns the slab whose fetch the previous call (or first()) started and starts fetching W.
+// It waits for this wave's DMAs, then meets the other waves at the workgroup barrier: the slab has landed for everybody, and
+// everybody is done reading the other buffer, which the new DMA overwrites.
+template <int D> struct Ring {
+    float* buf; int s;
+    __device__ __forceinline__ explicit Ring(float* lds) : buf(lds), s(0) {}
+    __device__ __forceinline__ void first(const float* __restrict__ W0) { w_ring_issue<D>(buf, W0); }
+    __device__ __forceinline__ const float* next(const float* __restrict__ Wnext) {
+        w_ring_wait();
+        __syncthreads();
+        const float* cur = buf + (s & 1) * D * D;
+        ++s;
+        if (Wnext != nullptr) w_ring_issue<D>(buf + (s & 1) * D * D, Wnext);
+        return cur;
+    }
+};
+
+// stores of a finished strip leave under the FIRST half of the next MFMA loop, two column tiles per k tile: by the end of the loop
+// they have long been acknowledged, so the ring's vmcnt(0) in front of the next slab costs nothing
+template <int D>
+__device__ __forceinline__ void store_early(const GBuf& g, const StripRow& row, const StripRegs<D>& x, int ct) {
+    constexpr int NT = D / 16;
+    if (ct < NT / 2) { strip_store_ct<D>(g, row, x, 2 * ct); strip_store_ct<D>(g, row, x, 2 * ct + 1); }
+}
+
+// ================================================================================================================ forward
+// q / k / v of one layer on the strip X (in registers).  The ring's current fetch must be Wk of this layer (started by the caller).
+// xstore: X is also written to a.x (a fused predecessor produced it: the saved layer input).
+template <int D>
+__device__ __forceinline__ void qkv_fwd_chain(const StripQkvArgs& a, const StripGeom& sg, Ring<D>& ring, const StripRow& row, int g,
+                                              const StripRegs<D>& X, bool xstore) {
+    constexpr int NT = D / 16;
+    const GBuf gx(a.x, sg.act_bytes), gqn(a.qn, sg.act_bytes), gq(a.q, sg.act_bytes), gk(a.k, sg.act_bytes), gv(a.v, sg.act_bytes);
+    StripRegs<D> Qn, Kr, Vr;
+    strip_layernorm<D>(Qn, X, a.ln_w[g], a.ln_b[g], a.ln_eps);
+    f32x4 acc[NT];
+    {   // k = x Wk^T + bk ; x's and Qn's global copies leave under these MFMAs
+        const float* buf = ring.next(a.w_in[g] + 2LL * D * D);
+        strip_zero<D>(acc);
+        strip_mma<D>(acc, X, buf, [&](int ct) {
+            if (xstore) store_early<D>(gx, row, X, ct);
+            store_early<D>(gqn, row, Qn, ct);
+        });
+        add_bias<D>(acc, a.b_in[g] + D);
+        to_regs<D>(Kr, acc);
+    }
+    {   // v = x Wv^T + bv
+        const float* buf = ring.next(a.w_in[g]);
+        strip_zero<D>(acc);
+        strip_mma<D>(acc, X, buf, [&](int ct) { store_early<D>(gk, row, Kr, ct); });
+        add_bias<D>(acc, a.b_in[g] + 2 * D);
+        to_regs<D>(Vr, acc);
+    }
+    {   // q = Qn Wq^T + bq
+        const float* buf = ring.next(nullptr);
+        strip_zero<D>(acc);
+        strip_mma<D>(acc, Qn, buf, [&](int ct) { store_early<D>(gv, row, Vr, ct); });
+        add_bias<D>(acc, a.b_in[g]);
+        to_regs<D>(Kr, acc);
+        strip_store<D>(gq, row, Kr);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_fwd_kernel(const StripQkvArgs a, const StripGeom sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const StripTile t = strip_tile(sg, blockIdx.x);
+    if (!t.live) return;
+    const StripRow row = strip_row<D>(sg, t);
+    Ring<D> ring(smem);
+    ring.first(a.w_in[t.g] + 1LL * D * D);
+    StripRegs<D> X;
+    strip_load<D>(X, GBuf(a.x, sg.act_bytes), row);
+    qkv_fwd_chain<D>(a, sg, ring, row, t.g, X, false);
+}
+
+template <int D, bool NEXT>
+__global__ __launch_bounds__(STRIP_THREADS) void strip_oproj_ffn_fwd_kernel(const StripOffArgs a, const StripQkvArgs nx, const StripGeom sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = D / 16;
+    const StripTile t = strip_tile(sg, blockIdx.x);
+    if (!t.live) return;
+    const StripRow row = strip_row<D>(sg, t);
+    const int g = t.g;
+    Ring<D> ring(smem);
+    ring.first(a.w_o[g]);
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+    const GBuf gr(a.r, sg.act_bytes), gy(a.y, sg.act_bytes), gh(a.h, sg.act_bytes), gxo(a.xo, sg.act_bytes);
+    StripRegs<D> A, R, Y, H;
+    StripTm<D> tm;
+    strip_load<D>(A, GBuf(a.o, sg.act_bytes), row);
+    strip_load<D>(R, GBuf(a.qn, sg.act_bytes), row);                   // the residual: the NORMED query (model_seq.py:378)
+    const bool has_tm = a.tmq != nullptr;
+    if (has_tm) strip_tm_load<D>(tm, GBuf(a.tmq, sg.tm_bytes), row);
+    f32x4 acc[NT];
+    {   // r = Qn + (o Wo^T + bo) ; y = LN2(r)
+        const float* buf = ring.next(a.w1[g]);
+        strip_zero<D>(acc);
+        strip_mma<D>(acc, A, buf);
+        add_bias<D>(acc, a.b_o[g]);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) R.v[ct] += acc[ct];
+        strip_layernorm<D>(Y, R, a.ln_w[g], a.ln_b[g], a.ln_eps);
+    }
+    {   // h = relu(drop1(y C1^T + c1))
+        const float* buf = ring.next(a.w2[g]);
+        strip_zero<D>(acc);
+        strip_mma<D>(acc, Y, buf, [&](int ct) { store_early<D>(gr, row, R, ct); });
+        add_bias<D>(acc, a.b1[g]);
+        to_regs<D>(H, acc);
+        if (a.train) strip_dropout<D>(H, seed, site_id(g, a.layer, SITE_FFN1), step, row.local, a.spec, a.scale);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H.v[ct][r] = fmaxf(H.v[ct][r], 0.f);
+    }
+    {   // x' = (drop2(h C2^T + c2) + y) * ~tm
+        const float* buf = ring.next(NEXT ? nx.w_in[g] + 1LL * D * D : nullptr);
+        strip_zero<D>(acc);
+        strip_mma<D>(acc, H, buf, [&](int ct) { store_early<D>(gy, row, Y, ct); store_early<D>(gh, row, H, ct); });
+        add_bias<D>(acc, a.b2[g]);
+        to_regs<D>(A, acc);
+        if (a.train) strip_dropout<D>(A, seed, site_id(g, a.layer, SITE_FFN2), step, row.local, a.spec, a.scale);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) A.v[ct] += Y.v[ct];
+        if (has_tm) strip_apply_tm<D>(A, tm);
+    }
+    if constexpr (NEXT) {
+        qkv_fwd_chain<D>(nx, sg, ring, row, g, A, true);
+    } else {
+        strip_store<D>(gxo, row, A);
+    }
+}
+
+// ================================================================================================================ backward
+// LayerNorm backward of the strip: dx = LN'(dy ; x, gamma); this lane's row adds dy * xhat / dy to the column partials
+template <int D>
+__device__ __forceinline__ void strip_ln_bwd(StripRegs<D>& dx, const StripRegs<D>& dy, const StripRegs<D>& x, const float* __restrict__ gam,
+                                             float eps, StripRegs<D>& dgam, StripRegs<D>& dbet) {
+    float mean, rstd;
+    strip_stats<D>(x, eps, mean, rstd);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) {
+        const f32x4 gg = col4(gam, ct);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xh = (x.v[ct][r] - mean) * rstd, gy = gg[r] * dy.v[ct][r];
+            s1 += gy;
+            s2 = fmaf(gy, xh, s2);
+            dgam.v[ct][r] = dy.v[ct][r] * xh;          // first (and only) row of this lane
+            dbet.v[ct][r] = dy.v[ct][r];
+            dx.v[ct][r] = gy;                          // finished below
+        }
+    }
+    const float c1 = row_sum4(s1) * (1.0f / D), c2 = row_sum4(s2) * (1.0f / D);
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xh = (x.v[ct][r] - mean) * rstd;
+            dx.v[ct][r] = rstd * (dx.v[ct][r] - c1 - xh * c2);
+        }
+}
+
+// column sums of the strip's 16 rows (DPP inside each row of 16 lanes) -> this wave's slice of the LDS scratch [4 waves][2][D]
+template <int D>
+__device__ __forceinline__ void ln_partials_wave(float* __restrict__ scratch, const StripRegs<D>& dgam, const StripRegs<D>& dbet) {
+    const int lane = lane_id(), w = wave_id();
+    float* mine = scratch + w * 2 * D;
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) {
+        f32x4 a, b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = col_sum16(dgam.v[ct][r]); b[r] = col_sum16(dbet.v[ct][r]); }
+        if ((lane & 15) == 0) {
+            st4(mine + ct * 16 + 4 * (lane >> 4), make_float4(a[0], a[1], a[2], a[3]));
+            st4(mine + D + ct * 16 + 4 * (lane >> 4), make_float4(b[0], b[1], b[2], b[3]));
+        }
+    }
+}
+// after a workgroup barrier: the four waves' slices -> part[2][D] in global memory (fixed order)
+template <int D>
+__device__ __forceinline__ void ln_partials_out(const float* __restrict__ scratch, float* __restrict__ part) {
+    for (int e = threadIdx.x; e < 2 * D; e += STRIP_THREADS)
+        part[e] = (scratch[e] + scratch[2 * D + e]) + (scratch[4 * D + e] + scratch[6 * D + e]);
+}
+
+// LDS: [ring: 2 slabs][LayerNorm-partial scratch A: 4 x 2 x D][scratch B: 4 x 2 x D]
+template <int D> __device__ __forceinline__ float* ln_scratch(float* smem, int which) { return smem + 2 * D * D + which * 8 * D; }
+
+// the loads the feed-forward backward needs first (relu output, "== 0" bits): issued by the caller a slab ahead of the chain
+template <int D> struct FfnBwdPre { StripRegs<D> Hs; StripTm<D> tm; };
+template <int D>
+__device__ __forceinline__ void ffn_bwd_prefetch(FfnBwdPre<D>& p, const StripFfnBwdArgs& a, const StripGeom& sg, const StripRow& row) {
+    strip_load<D>(p.Hs, GBuf(a.h, sg.act_bytes), row);
+    if (a.tmq != nullptr) strip_tm_load<D>(p.tm, GBuf(a.tmq, sg.tm_bytes), row);
+}
+
+// d x' (DZ, in registers) -> dpre2, dpre1, dr, d_o of this layer; the ring's current fetch must be w2T
+template <int D>
+__device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const StripGeom& sg, Ring<D>& ring, const StripRow& row, int g,
+                                              StripRegs<D>& DZ, FfnBwdPre<D>& pre, float* __restrict__ scratch) {
+    constexpr int NT = D / 16;
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+    const GBuf gp2(a.dpre2, sg.act_bytes), gp1(a.dpre1, sg.act_bytes), gdr(a.dr, sg.act_bytes), gdo(a.d_o, sg.act_bytes);
+    StripRegs<D> P, Rs;
+    StripRegs<D>& Hs = pre.Hs;
+    if (a.tmq != nullptr) strip_apply_tm<D>(DZ, pre.tm);
+    // dpre2 = dz * drop2
+    P = DZ;
+    if (a.train) strip_dropout<D>(P, seed, site_id(g, a.layer, SITE_FFN2), step, row.local, a.spec, a.scale);
+    f32x4 acc[NT];
+    {   // dh = dpre2 C2 ; dpre1 = dh * relu'(h) * drop1   (h > 0 implies the unit was kept by drop1)
+        const float* buf = ring.next(a.w1T[g]);
+        strip_load<D>(Rs, GBuf(a.r, sg.act_bytes), row);               // LN2 input rows: needed two slabs from now
+        strip_zero<D>(acc);
+        strip_mma<D>(acc, P, buf, [&](int ct) { store_early<D>(gp2, row, P, ct); });
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P.v[ct][r] = Hs.v[ct][r] > 0.f ? acc[ct][r] * a.scale : 0.f;
+    }
+    StripRegs<D> DR, dgam, dbet;
+    {   // dy = dpre1 C1 + dz ; dr = LN2'(dy ; r)
+        const float* buf = ring.next(a.woT[g]);
+        strip_zero<D>(acc);
+        strip_mma<D>(acc, P, buf, [&](int ct) { store_early<D>(gp1, row, P, ct); });
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) Hs.v[ct] = acc[ct] + DZ.v[ct];
+        strip_ln_bwd<D>(DR, Hs, Rs, a.ln_w[g], a.ln_eps, dgam, dbet);
+    }
+    {   // d_o = dr Wo
+        const float* buf = ring.next(nullptr);
+        strip_zero<D>(acc);
+        strip_mma<D>(acc, DR, buf, [&](int ct) { store_early<D>(gdr, row, DR, ct); });
+        to_regs<D>(P, acc);
+        strip_store<D>(gdo, row, P);
+    }
+    ln_partials_wave<D>(scratch, dgam, dbet);
+}
+
+// dq, dk, dv, dr of a layer -> d x (left in DX); the ring's current fetch must be wkT.  `tail`: the slab to fetch behind wqT;
+// `before_last()` runs in front of the last MFMA loop (a fused successor issues its first loads there).
+template <int D, class Hook>
+__device__ __forceinline__ void qkv_bwd_chain(const StripQkvBwdArgs& a, const StripGeom& sg, Ring<D>& ring, const StripRow& row, int g,
+                                              StripRegs<D>& DX, float* __restrict__ scratch, const float* __restrict__ tail, const Hook& before_last) {
+    constexpr int NT = D / 16;
+    StripRegs<D> Dk, Dv, Dq, Drs, Xs;
+    strip_load<D>(Dk, GBuf(a.dk, sg.act_bytes), row);
+    strip_load<D>(Dv, GBuf(a.dv, sg.act_bytes), row);
+    f32x4 acc_kv[NT], acc[NT];
+    strip_zero<D>(acc_kv);
+    {   // dk Wk          (every operand is requested one slab ahead of its use: the loads fly under the MFMAs in between)
+        const float* buf = ring.next(a.wvT[g]);
+        strip_load<D>(Dq, GBuf(a.dq, sg.act_bytes), row);
+        strip_mma<D>(acc_kv, Dk, buf);
+    }
+    {   // + dv Wv
+        const float* buf = ring.next(a.wqT[g]);
+        strip_load<D>(Drs, GBuf(a.dr, sg.act_bytes), row);             // residual-path gradient of the normed query
+        strip_load<D>(Xs, GBuf(a.x, sg.act_bytes), row);               // LN1 input rows
+        strip_mma<D>(acc_kv, Dv, buf);
+    }
+    StripRegs<D> dgam, dbet;
+    {   // dqn = dq Wq + dr ; dx = LN1'(dqn ; x) + (dk Wk + dv Wv)
+        const float* buf = ring.next(tail);
+        before_last();
+        strip_zero<D>(acc);
+        strip_mma<D>(acc, Dq, buf);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) Drs.v[ct] += acc[ct];
+        strip_ln_bwd<D>(DX, Drs, Xs, a.ln_w[g], a.ln_eps, dgam, dbet);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) DX.v[ct] += acc_kv[ct];
+    }
+    ln_partials_wave<D>(scratch, dgam, dbet);
+}
+
+template <int D>
+__device__ __forceinline__ void zero_slot(float* __restrict__ part, int slot) {
+    for (int e = threadIdx.x; e < 2 * D; e += STRIP_THREADS) part[(long long)slot * 2 * D + e] = 0.f;
+}
+
+template <int D>
+__global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const StripFfnBwdArgs a, const StripGeom sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const StripTile t = strip_tile(sg, blockIdx.x);
+    if (!t.live) { zero_slot<D>(a.ln_part, t.slot); return; }
+    const StripRow row = strip_row<D>(sg, t);
+    Ring<D> ring(smem);
+    ring.first(a.w2T[t.g]);
+    StripRegs<D> DZ;
+    FfnBwdPre<D> pre;
+    strip_load<D>(DZ, GBuf(a.dxo, sg.act_bytes), row);
+    ffn_bwd_prefetch<D>(pre, a, sg, row);
+    ffn_bwd_chain<D>(a, sg, ring, row, t.g, DZ, pre, ln_scratch<D>(smem, 0));
+    __syncthreads();
+    ln_partials_out<D>(ln_scratch<D>(smem, 0), a.ln_part + (long long)t.slot * 2 * D);
+}
+
+// FFN = true: the layer below's feed-forward / out-projection backward continues on d x in registers (d x is then never stored)
+template <int D, bool FFN>
+__global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const StripQkvBwdArgs a, const StripFfnBwdArgs f, const StripGeom sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const StripTile t = strip_tile(sg, blockIdx.x);
+    if (!t.live) {
+        zero_slot<D>(a.ln_part, t.slot);
+        if constexpr (FFN) zero_slot<D>(f.ln_part, t.slot);
+        return;
+    }
+    const StripRow row = strip_row<D>(sg, t);
+    Ring<D> ring(smem);
+    ring.first(a.wkT[t.g]);
+    StripRegs<D> DX;
+    if constexpr (FFN) {
+        FfnBwdPre<D> pre;
+        qkv_bwd_chain<D>(a, sg, ring, row, t.g, DX, ln_scratch<D>(smem, 0), f.w2T[t.g], [&]() { ffn_bwd_prefetch<D>(pre, f, sg, row); });
+        ffn_bwd_chain<D>(f, sg, ring, row, t.g, DX, pre, ln_scratch<D>(smem, 1));
+    } else {
+        qkv_bwd_chain<D>(a, sg, ring, row, t.g, DX, ln_scratch<D>(smem, 0), nullptr, []() {});
+        strip_store<D>(GBuf(a.dx, sg.act_bytes), row, DX);
+    }
+    __syncthreads();
+    ln_partials_out<D>(ln_scratch<D>(smem, 0), a.ln_part + (long long)t.slot * 2 * D);
+    if constexpr (FFN) ln_partials_out<D>(ln_scratch<D>(smem, 1), f.ln_part + (long long)t.slot * 2 * D);
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+template <int D> static constexpr size_t strip_lds_bytes() { return (size_t)(2 * D * D + 16 * D) * sizeof(float); }
+
+static int make_strip_geom(int B, int T, int D, const int* live, StripGeom* sg) {
+    if (B <= 0 || T <= 0) return AMID_ERR_ARG;
+    const long long bytes = 2LL * B * T * D * 4;
+    if (bytes > 0x7FFFFFF0LL) return AMID_ERR_UNSUPPORTED;          // buffer descriptors: 32-bit offsets, out-of-range marker at 2 GiB
+    sg->B = B; sg->T = T; sg->M = B * T;
+    sg->act_bytes = (unsigned)bytes; sg->tm_bytes = (unsigned)(bytes / 16);
+    sg->tpg = (sg->M + STRIP_TILE - 1) / STRIP_TILE;
+    sg->live = live;
+    return AMID_OK;
+}
+
+template <auto KERNEL, int DVAL, class... Args>
+static int launch_strip(const StripGeom& sg, void* stream, const Args&... args) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds_bytes<DVAL>());
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    KERNEL<<<2 * sg.tpg, STRIP_THREADS, strip_lds_bytes<DVAL>(), (hipStream_t)stream>>>(args..., sg);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? AMID_OK : (int)e;
+}
+
+extern "C" int amid_sas_strip_tile_rows(void) { return STRIP_TILE; }
+
+extern "C" int amid_sas_strip_qkv_fwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
+                                          const float* const* b_in, float ln_eps, int B, int T, int D, const int* live, float* qn, float* q,
+                                          float* k, float* v, void* stream) {
+    AMID_CHECK_ARG(x && ln_w && ln_b && w_in && b_in && qn && q && k && v);
+    StripQkvArgs a;
+    a.x = x; a.qn = qn; a.q = q; a.k = k; a.v = v; a.ln_eps = ln_eps;
+    for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.ln_b[g] = ln_b[g]; a.w_in[g] = w_in[g]; a.b_in[g] = b_in[g]; }
+    StripGeom sg;
+    if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
+    if (D == 128) return launch_strip<strip_qkv_fwd_kernel<128>, 128>(sg, stream, a);
+    if (D == 64) return launch_strip<strip_qkv_fwd_kernel<64>, 64>(sg, stream, a);
+    return AMID_ERR_UNSUPPORTED;
+}
+
+extern "C" int amid_sas_strip_oproj_ffn_fwd_f32(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
+                                                const float* const* ln_w, const float* const* ln_b, const float* const* w1,
+                                                const float* const* b1, const float* const* w2, const float* const* b2,
+                                                const unsigned char* tmq, float ln_eps, int B, int T, int D, const int* live, int layer,
+                                                const void* step_state, int train, float p_drop, float* r, float* y, float* h, float* xo,
+                                                const float* const* nln_w, const float* const* nln_b, const float* const* nw_in,
+                                                const float* const* nb_in, float* nqn, float* nq, float* nk, float* nv, void* stream) {
+    AMID_CHECK_ARG(o && qn && w_o && b_o && ln_w && ln_b && w1 && b1 && w2 && b2 && r && y && h && xo && (!train || step_state));
+    const bool next = nln_w != nullptr;
+    AMID_CHECK_ARG(!next || (nln_b && nw_in && nb_in && nqn && nq && nk && nv));
+    StripOffArgs a;
+    a.o = o; a.qn = qn; a.tmq = tmq; a.r = r; a.y = y; a.h = h; a.xo = xo; a.ln_eps = ln_eps;
+    a.st = (const StepState*)step_state; a.layer = layer;
+    a.train = (train && p_drop > 0.f) ? 1 : 0;
+    a.spec = drop_spec(p_drop);
+    a.scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+    StripQkvArgs nx = {};
+    for (int g = 0; g < 2; ++g) {
+        a.w_o[g] = w_o[g]; a.b_o[g] = b_o[g]; a.ln_w[g] = ln_w[g]; a.ln_b[g] = ln_b[g];
+        a.w1[g] = w1[g]; a.b1[g] = b1[g]; a.w2[g] = w2[g]; a.b2[g] = b2[g];
+        if (next) { nx.ln_w[g] = nln_w[g]; nx.ln_b[g] = nln_b[g]; nx.w_in[g] = nw_in[g]; nx.b_in[g] = nb_in[g]; }
+    }
+    if (next) { nx.x = xo; nx.qn = nqn; nx.q = nq; nx.k = nk; nx.v = nv; nx.ln_eps = ln_eps; }
+    StripGeom sg;
+    if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
+    if (D == 128 && next) return launch_strip<strip_oproj_ffn_fwd_kernel<128, true>, 128>(sg, stream, a, nx);
+    if (D == 128) return launch_strip<strip_oproj_ffn_fwd_kernel<128, false>, 128>(sg, stream, a, nx);
+    if (D == 64 && next) return launch_strip<strip_oproj_ffn_fwd_kernel<64, true>, 64>(sg, stream, a, nx);
+    if (D == 64) return launch_strip<strip_oproj_ffn_fwd_kernel<64, false>, 64>(sg, stream, a, nx);
+    return AMID_ERR_UNSUPPORTED;
+}
+
+static void fill_ffn_bwd(StripFfnBwdArgs& a, const float* dxo, const unsigned char* tmq, const float* h, const float* r,
+                         const float* const* ln_w, const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps,
+                         int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr, float* d_o,
+                         float* ln_part) {
+    a.dxo = dxo; a.tmq = tmq; a.h = h; a.r = r; a.dpre2 = dpre2; a.dpre1 = dpre1; a.dr = dr; a.d_o = d_o; a.ln_part = ln_part;
+    a.ln_eps = ln_eps; a.st = (const StepState*)step_state; a.layer = layer;
+    a.train = (train && p_drop > 0.f) ? 1 : 0;
+    a.spec = drop_spec(p_drop);
+    a.scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+    for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.w1T[g] = w1T[g]; a.w2T[g] = w2T[g]; a.woT[g] = woT[g]; }
+}
+
+// ln_part: [2 * ceil(B T / amid_sas_strip_tile_rows())][2][D]; domain g's partial sums are slots [g * tpg, (g + 1) * tpg)
+extern "C" int amid_sas_strip_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                                          const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T,
+                                          int D, const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2,
+                                          float* dpre1, float* dr, float* d_o, float* ln_part, void* stream) {
+    AMID_CHECK_ARG(dxo && h && r && ln_w && w1T && w2T && woT && dpre2 && dpre1 && dr && d_o && ln_part && (!train || step_state));
+    StripFfnBwdArgs a;
+    fill_ffn_bwd(a, dxo, tmq, h, r, ln_w, w1T, w2T, woT, ln_eps, layer, step_state, train, p_drop, dpre2, dpre1, dr, d_o, ln_part);
+    StripGeom sg;
+    if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
+    if (D == 128) return launch_strip<strip_ffn_bwd_kernel<128>, 128>(sg, stream, a);
+    if (D == 64) return launch_strip<strip_ffn_bwd_kernel<64>, 64>(sg, stream, a);
+    return AMID_ERR_UNSUPPORTED;
+}
+
+// fh != NULL: the layer below's feed-forward / out-projection backward (f* arguments) runs on d x in the same launch; dx is then not written
+extern "C" int amid_sas_strip_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                          const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
+                                          float ln_eps, int B, int T, int D, const int* live, float* dx, float* ln_part,
+                                          const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
+                                          const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
+                                          const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
+                                          float* fd_o, float* fln_part, void* stream) {
+    AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && ln_part);
+    const bool ffn = fh != nullptr;
+    AMID_CHECK_ARG(ffn || dx);
+    AMID_CHECK_ARG(!ffn || (fr && fln_w && fw1T && fw2T && fwoT && fdpre2 && fdpre1 && fdr && fd_o && fln_part && (!train || step_state)));
+    StripQkvBwdArgs a;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.dr = dr; a.x = x; a.dx = dx; a.ln_part = ln_part; a.ln_eps = ln_eps;
+    for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.wqT[g] = wqT[g]; a.wkT[g] = wkT[g]; a.wvT[g] = wvT[g]; }
+    StripFfnBwdArgs f = {};
+    if (ffn) fill_ffn_bwd(f, nullptr, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, ln_eps, flayer, step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part);
+    StripGeom sg;
+    if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
+    if (D == 128 && ffn) return launch_strip<strip_qkv_bwd_kernel<128, true>, 128>(sg, stream, a, f);
+    if (D == 128) return launch_strip<strip_qkv_bwd_kernel<128, false>, 128>(sg, stream, a, f);
+    if (D == 64 && ffn) return launch_strip<strip_qkv_bwd_kernel<64, true>, 64>(sg, stream, a, f);
+    if (D == 64) return launch_strip<strip_qkv_bwd_kernel<64, false>, 64>(sg, stream, a, f);
+    return AMID_ERR_UNSUPPORTED;
+}

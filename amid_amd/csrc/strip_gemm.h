@@ -1,0 +1,318 @@
+// Register-resident "strip" GEMM chains for the SASRec encoder on gfx950 (sasrec_strip.hip).
+//
+// The row-tile kernels of tile_gemm.h stage every activation tile through LDS between two chained GEMMs (accumulators -> C image ->
+// row pass -> A image -> next MFMA loop), with three workgroup barriers per GEMM and the matrix pipe idle in every phase that is not
+// the MFMA loop: 0.25-0.44 of the fp32 matrix peak (profiles/r01h_*).  Here an activation never leaves the register file between
+// two GEMMs of a chain:
+//
+//   * a WAVE owns a strip of 16 rows and ALL D columns.  Lane (m, g) = (lane & 15, lane >> 4) holds row m of the strip, and its
+//     register v[ct][r] holds column ct * 16 + g * 4 + r  (ct < D / 16, r < 4)  -- the "C layout": exactly what
+//     v_mfma_f32_16x16x4_f32 issued as C^T = W . A^T leaves in the accumulators (reg r of lane (m, g) = C[m][ct * 16 + g * 4 + r]).
+//   * the SAME registers are the second operand of the next GEMM: an MFMA step sums over 4 values of k, one per lane group g, and
+//     a sum over k does not care which k goes where as long as both operands agree -- step (ct, r) takes k = ct * 16 + g * 4 + r,
+//     i.e. register v[ct][r] as it stands, and the weight operand of lane (n, g) is W[n][ct * 16 + g * 4 + r]: four consecutive
+//     floats of a K-contiguous weight row, one ds_read_b128 per four MFMAs.
+//   * so bias / dropout / relu / residual / LayerNorm / masks run on the accumulators in place (a row's LayerNorm statistic is
+//     an in-lane sum of 32 values + two cross-lane steps over the 4 lanes of the row), and the result IS the next operand.  No
+//     A image, no C image, no barrier inside a chain; LDS only holds the weights.
+//   * weights stream through a two-slab LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers): slab s + 1
+//     lands while slab s multiplies; ONE workgroup barrier per slab.  The image is [n][D] floats without padding; bank conflicts
+//     are removed by an XOR swizzle of the 16-byte chunk index with n & 15, applied on the DMA's per-lane SOURCE address (the DMA
+//     writes LDS linearly).
+//
+// A workgroup is 4 waves (one per SIMD, up to 512 registers each) = 64 consecutive rows of one domain; rows are independent, so
+// tiles need not align with sequences.  In the train step only the LIVE sequences are walked (the loss multiplies the other
+// domain's terms of every sample by zero, train_sr.py:205-211): tiles cover "virtual" rows -- the live sequences of a domain back
+// to back -- and a lane maps its virtual row to the row of the [2, B, T] activation layout once per kernel (StripRow).
+#pragma once
+#include "common.h"
+#include "rng.h"
+
+namespace amid {
+
+constexpr int STRIP_WAVES = 4;
+constexpr int STRIP_THREADS = 64 * STRIP_WAVES;
+constexpr int STRIP_TILE = 16 * STRIP_WAVES;        // rows per workgroup
+
+template <int D> struct StripRegs {                 // a [16, D] strip in the C layout
+    static constexpr int NT = D / 16;
+    f32x4 v[NT];
+};
+
+// ---- geometry ------------------------------------------------------------------------------------------------------------------
+struct StripGeom {
+    int M, B, T;            // rows per domain (B * T)
+    unsigned act_bytes;     // bytes of a [2M, D] fp32 activation tensor (buffer descriptors; <= 2 GiB), tm_bytes = act_bytes / 16
+    unsigned tm_bytes;
+    int tpg;                // tiles per domain in the worst case: ceil(M / STRIP_TILE); the launch has 2 * tpg workgroups
+    const int* live;        // optional [B + 1]: batch rows of domain 0's live sequences (ascending), then domain 1's; live[B] = n0.
+                            // nullptr: every sequence of both domains
+};
+
+struct StripTile { int g, slot, v0, nv, s0; bool live; };     // domain, partial slot, first virtual row, virtual rows of the domain, first entry of the live list
+
+__device__ __forceinline__ StripTile strip_tile(const StripGeom& sg, int tile) {
+    StripTile t;
+    t.live = true; t.s0 = 0;
+    if (sg.live == nullptr) {
+        t.g = tile / sg.tpg;
+        const int tl = tile - t.g * sg.tpg;
+        t.slot = tile; t.v0 = tl * STRIP_TILE; t.nv = sg.M;
+        return t;
+    }
+    const int n0 = sg.live[sg.B], n1 = sg.B - n0;
+    const int t0 = (n0 * sg.T + STRIP_TILE - 1) / STRIP_TILE, t1 = (n1 * sg.T + STRIP_TILE - 1) / STRIP_TILE;
+    int tl;
+    if (tile < t0) { t.g = 0; tl = tile; }
+    else if (tile < t0 + t1) { t.g = 1; tl = tile - t0; }
+    else {                                          // a slot no live tile fills
+        t.live = false;
+        const int d = tile - t0 - t1;
+        if (d < sg.tpg - t0) { t.g = 0; tl = t0 + d; } else { t.g = 1; tl = t1 + d - (sg.tpg - t0); }
+    }
+    t.slot = t.g * sg.tpg + tl;
+    t.v0 = tl * STRIP_TILE;
+    t.nv = (t.g ? n1 : n0) * sg.T;
+    t.s0 = t.g ? n0 : 0;
+    return t;
+}
+
+// A [2M, D] fp32 activation tensor seen through a buffer descriptor: per-lane 32-bit byte offsets, and the hardware's bounds check
+// drops the accesses of the lanes whose row lies past the domain (their offset is STRIP_OOB): loads return zeros, stores vanish --
+// no exec-mask branch anywhere in a chain, so every MFMA loop stays ONE scheduling region.  Tensors are limited to 2 GiB.
+constexpr unsigned STRIP_OOB = 0x80000000u;
+typedef unsigned amid_v4u __attribute__((ext_vector_type(4)));
+struct GBuf {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ GBuf(const void* p, unsigned bytes) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)) {}
+    __device__ __forceinline__ f32x4 load4(unsigned off) const { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); }
+    __device__ __forceinline__ amid_v4u load4u(unsigned off) const { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0); }
+    __device__ __forceinline__ void store4(unsigned off, f32x4 v) const { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(amid_v4u, v), r, (int)off, 0, 0); }
+};
+
+struct StripRow {           // this lane's row
+    unsigned off;           // byte offset of the row in a [2M, D] fp32 tensor + this lane's 16 bytes of column tile 0; STRIP_OOB past the domain
+    int local;              // row inside the domain (b * T + t): dropout counters
+    bool ok;
+};
+__device__ __forceinline__ float4 ld4_global(const float* p) {
+    const amid_gv4 t = *(const __attribute__((address_space(1))) amid_gv4*)(p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
+template <int D>
+__device__ __forceinline__ StripRow strip_row(const StripGeom& sg, const StripTile& t) {
+    StripRow r;
+    int v = t.v0 + wave_id() * 16 + (lane_id() & 15);
+    r.ok = v < t.nv;
+    if (!r.ok) v = t.v0;                            // a live tile's first row always exists
+    if (sg.live != nullptr) {
+        const int s = v / sg.T;
+        r.local = sg.live[t.s0 + s] * sg.T + (v - s * sg.T);
+    } else {
+        r.local = v;
+    }
+    const unsigned phys = (unsigned)t.g * (unsigned)sg.M + (unsigned)r.local;
+    r.off = r.ok ? phys * (unsigned)(D * 4) + 16u * (unsigned)(lane_id() >> 4) : STRIP_OOB;
+    return r;
+}
+
+// ---- strip <-> global ---------------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void strip_load(StripRegs<D>& x, const GBuf& g, const StripRow& row) {
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) x.v[ct] = g.load4(row.off + ct * 64);
+}
+template <int D>
+__device__ __forceinline__ void strip_store(const GBuf& g, const StripRow& row, const StripRegs<D>& x) {
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) g.store4(row.off + ct * 64, x.v[ct]);
+}
+// one column tile of the strip (deferred stores inside an MFMA loop)
+template <int D>
+__device__ __forceinline__ void strip_store_ct(const GBuf& g, const StripRow& row, const StripRegs<D>& x, int ct) {
+    g.store4(row.off + ct * 64, x.v[ct]);
+}
+
+// a per-column vector (bias, LayerNorm gain): the lane's 4 columns of tile ct
+__device__ __forceinline__ f32x4 col4(const float* __restrict__ p, int ct) {
+    const float4 v = ld4_global(p + ct * 16 + 4 * (lane_id() >> 4));
+    return f32x4{v.x, v.y, v.z, v.w};
+}
+
+// sum over the 4 lanes (m, 0..3) that share a row
+__device__ __forceinline__ float row_sum4(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+// sum over the 16 lanes (0..15, g) that share a column quad: DPP inside the row of 16
+__device__ __forceinline__ float col_sum16(float v) { return group_sum<16>(v); }
+
+template <int D>
+__device__ __forceinline__ void strip_stats(const StripRegs<D>& x, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) s += (x.v[ct][0] + x.v[ct][1]) + (x.v[ct][2] + x.v[ct][3]);
+    mean = row_sum4(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = x.v[ct][r] - mean; q = fmaf(d, d, q); }
+    }
+    rstd = 1.0f / sqrtf(row_sum4(q) * (1.0f / D) + eps);
+}
+
+// y = LayerNorm(x) (biased variance, eps inside the sqrt: torch.nn.LayerNorm as used at model_seq.py:342-353)
+template <int D>
+__device__ __forceinline__ void strip_layernorm(StripRegs<D>& y, const StripRegs<D>& x, const float* __restrict__ w, const float* __restrict__ b, float eps) {
+    float mean, rstd;
+    strip_stats<D>(x, eps, mean, rstd);
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) {
+        const f32x4 ww = col4(w, ct), bb = col4(b, ct);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y.v[ct][r] = (x.v[ct][r] - mean) * rstd * ww[r] + bb[r];
+    }
+}
+
+// ---- dropout on a strip ---------------------------------------------------------------------------------------------------------
+// keep multipliers of this lane's 32 (D = 128) columns of row `local` at `site`.  p = 0.5 (1 bit per decision, rng.h): ONE Philox
+// call covers 128 consecutive elements = the whole row at D = 128 (two rows at D = 64); other p: one call per column quad.
+template <int D>
+__device__ __forceinline__ void strip_dropout(StripRegs<D>& x, unsigned long long seed, unsigned site, unsigned step, int local, unsigned spec, float scale) {
+    const int g4 = 4 * (lane_id() >> 4);
+    if (spec_bits(spec) == 1) {
+        const unsigned long long e0 = (unsigned long long)local * D;
+        const uint4 rr = rng_call(seed, e0 >> 7, site, step);
+        const int f0 = (int)(e0 & 127);                       // 0 (D = 128) or 0 / 64 (D = 64)
+        const bool all = spec_thr(spec) == 0;
+#pragma unroll
+        for (int ct = 0; ct < D / 16; ++ct) {
+            const int f = f0 + ct * 16 + g4;                  // 4 consecutive fields, never straddling a word
+            const unsigned w = rng_word(rr, f >> 5) >> (f & 31);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x.v[ct][r] = (all || ((w >> r) & 1u)) ? x.v[ct][r] * scale : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < D / 16; ++ct) {
+            const float4 m = dropout_mult4(seed, site, step, (unsigned long long)local * D + ct * 16 + g4, spec, scale);
+            x.v[ct][0] *= m.x; x.v[ct][1] *= m.y; x.v[ct][2] *= m.z; x.v[ct][3] *= m.w;
+        }
+    }
+}
+
+// the feature-level "== 0" bits of the row (tmq [2M, D / 4]: one byte per column quad, embed.hip): zero the flagged elements.
+// The row's D / 4 bytes arrive as D / 64 16-byte loads; column tile ct, lane group g <-> byte 4 ct + g.
+template <int D> struct StripTm { unsigned w[D / 16]; };
+template <int D>
+__device__ __forceinline__ void strip_tm_load(StripTm<D>& tm, const GBuf& g, const StripRow& row) {
+    const unsigned base = row.ok ? (row.off - 16u * (unsigned)(lane_id() >> 4)) >> 4 : STRIP_OOB >> 4;     // row * D / 4 bytes
+#pragma unroll
+    for (int q = 0; q < D / 64; ++q) {
+        const amid_v4u v = g.load4u(base + 16 * q);
+        tm.w[4 * q] = v.x; tm.w[4 * q + 1] = v.y; tm.w[4 * q + 2] = v.z; tm.w[4 * q + 3] = v.w;
+    }
+}
+template <int D>
+__device__ __forceinline__ void strip_apply_tm(StripRegs<D>& x, const StripTm<D>& tm) {
+    const int sh = 8 * (lane_id() >> 4);
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) {
+        const unsigned bits = tm.w[ct] >> sh;
+        x.v[ct][0] = (bits & 1u) ? 0.f : x.v[ct][0];
+        x.v[ct][1] = (bits & 2u) ? 0.f : x.v[ct][1];
+        x.v[ct][2] = (bits & 4u) ? 0.f : x.v[ct][2];
+        x.v[ct][3] = (bits & 8u) ? 0.f : x.v[ct][3];
+    }
+}
+
+// ---- weight ring ------------------------------------------------------------------------------------------------------------------
+// W [D out-features][D in-features] row-major in global memory -> LDS image [n][D], the 16-byte chunk c of row n stored at chunk
+// position c ^ (n & 15).  One DMA wave-instruction fills 1 KiB of LDS linearly (64 lanes x 16 B); lane L of piece k fills chunk
+// position (64 k + L) % (D / 4) of row (64 k + L) / (D / 4), so it must FETCH chunk position ^ (row & 15).
+// A ds_read_b128 is served in 4 groups of 16 lanes; the 16 lanes of a group read 16 different n (mod 16) at chunk 4 ct + g with two
+// values of g: positions (4 ct + g) ^ i cover all 16 slots of the 256-byte bank window exactly once (strip_mma below).
+template <int D>
+__device__ __forceinline__ void w_ring_issue(float* __restrict__ buf, const float* __restrict__ W) {
+    constexpr int CPR = D / 4;                        // chunks per row
+    constexpr int PIECES = D * CPR / 64;
+    const int lane = lane_id(), w = wave_id();
+#pragma unroll
+    for (int k0 = 0; k0 < PIECES; k0 += STRIP_WAVES) {
+        const int k = k0 + w;
+        const int p = k * 64 + lane;
+        const int n = p / CPR, pos = p % CPR;
+        const int c = pos ^ (n & 15);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + n * D + c * 4),
+                                         (__attribute__((address_space(3))) void*)(buf + k * 256), 16, 0, 0);
+    }
+}
+// every DMA (and every other vector-memory operation) of this wave has completed
+__device__ __forceinline__ void w_ring_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct NoDeferred { __device__ __forceinline__ void operator()(int) const {} };
+
+// acc[co] += sum_k A[.][k] W[co * 16 + .][k] over the whole K = D of the slab in `buf`; `deferred(ct)` is called once per k tile,
+// behind its MFMAs (stores of an earlier epilogue drain under the matrix work)
+// Issue order, pinned: hipcc's scheduler, left alone, sinks every fragment read to just in front of its four MFMAs, waits for it with
+// lgkmcnt(0) and issues the four as one dependent chain on one accumulator (40-cycle dependent latency against the 32-cycle issue
+// rate, plus an exposed LDS latency per read: measured 2x the time).  So the loop is written as groups of NT / 2 MFMAs on DIFFERENT
+// accumulators + one fragment read of the NEXT k tile, with a scheduling barrier behind every group that MFMA and LDS instructions
+// may not cross (VALU / SALU / VMEM may: epilogue arithmetic and stores of neighbouring code still slide under the matrix work).
+#define AMID_STRIP_FENCE() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x20 | 0x40 | 0x400)
+template <int D, class Deferred = NoDeferred>
+__device__ __forceinline__ void strip_mma(f32x4 (&acc)[D / 16], const StripRegs<D>& A, const float* __restrict__ buf, const Deferred& deferred = NoDeferred()) {
+    constexpr int NT = D / 16, HALF = NT / 2;
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int xl = g ^ i;
+    const float* rowp = buf + i * D;
+    float4 wf[2][NT];
+#pragma unroll
+    for (int co = 0; co < NT; ++co) wf[0][co] = ld4(rowp + co * 16 * D + 4 * xl);          // k tile 0: chunk (0 ^ xl)
+    AMID_STRIP_FENCE();
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        const float* nxt = rowp + 4 * (((ct + 1) * 4) ^ xl);
+        // 8 groups per k tile: (element r, accumulators co = half * HALF ..); group j also reads fragment j of k tile ct + 1
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = j >> 1, c0 = (j & 1) * HALF;
+#pragma unroll
+            for (int c = 0; c < HALF; ++c) {
+                const float4 w = wf[ct & 1][c0 + c];
+                const float wr = r == 0 ? w.x : r == 1 ? w.y : r == 2 ? w.z : w.w;
+                acc[c0 + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, A.v[ct][r], acc[c0 + c], 0, 0, 0);
+            }
+            if (ct + 1 < NT && j < NT) wf[(ct + 1) & 1][j] = ld4(nxt + j * 16 * D);
+            AMID_STRIP_FENCE();
+        }
+        deferred(ct);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void strip_zero(f32x4 (&acc)[D / 16]) {
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// the ring's control flow for a kernel that multiplies by slabs W_0 .. W_{S-1} in order:
+//   ring.first(W_0);  for s: ring.acquire(s, W_{s+1} or nullptr) -> pointer to slab s;  ... strip_mma(.., that pointer) ...
+// acquire() waits for this wave's DMAs, meets the other waves at the workgroup barrier (slab s has landed for everybody, and
+// everybody is done reading slab s - 1, whose buffer the next DMA overwrites) and starts the DMA of slab s + 1.
+template <int D> struct WRing {
+    float* buf;
+    __device__ __forceinline__ explicit WRing(float* lds) : buf(lds) {}
+    __device__ __forceinline__ void first(const float* __restrict__ W0) { w_ring_issue<D>(buf, W0); }
+    __device__ __forceinline__ const float* acquire(int s, const float* __restrict__ Wnext) {
+        w_ring_wait();
+        __syncthreads();
+        if (Wnext != nullptr) w_ring_issue<D>(buf + ((s + 1) & 1) * D * D, Wnext);
+        return buf + (s & 1) * D * D;
+    }
+};
+
+}  // namespace amid

@@ -501,6 +501,39 @@ int amid_sas_qkv_ffn_bwd_rows_f32_rt5(const float* dq, const float* dk, const fl
 int amid_sas_qkv_ffn_bwd_rows_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
 int amid_sas_qkv_ffn_bwd_rows_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
 
+/* ---- the same encoder-layer GEMM chains as register-resident STRIP kernels (csrc/strip_gemm.h, csrc/sasrec_strip.hip) -------------
+ * replace: Log2feats.forward model_seq.py:371-383 (LayerNorms, nn.MultiheadAttention's in/out projections as called at :374,
+ * PointWiseFeedForward :322-326) and its autograd (loss.backward(), train_sr.py:214), like the row-tile entry points above, fp32 only.
+ * A wave keeps a [16, D] strip of activations in registers through a whole chain (accumulators of one GEMM are the operand of the
+ * next); weights stream through LDS by DMA.  Activations are [2 * B * T, D] (domain 0's rows, then domain 1's), at most 2 GiB each.
+ * live: NULL = every sequence; else int[B + 1] = the batch rows b with domain_id[b] == 0 (ascending), then those with
+ * domain_id[b] != 0, then n0 = the number of the former (amid_live_list_i32): only the sequences (0, b) of the first group and
+ * (1, b) of the second are read / written (the step's own loss masks the other domain of every sample, train_sr.py:205-211).
+ * ln_part of the backward entries: [2 * ceil(B * T / amid_sas_strip_tile_rows())][2][D]; domain g owns the slots
+ * [g * tpg, (g + 1) * tpg), unused ones are zeroed. */
+int amid_sas_strip_tile_rows(void);
+int amid_sas_strip_qkv_fwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
+                               const float* const* b_in, float ln_eps, int B, int T, int D, const int* live, float* qn, float* q, float* k,
+                               float* v, void* stream);
+/* nln_w != NULL: layer l + 1's amid_sas_strip_qkv_fwd_f32 (n* arguments) continues on the layer output in registers */
+int amid_sas_strip_oproj_ffn_fwd_f32(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
+                                     const float* const* ln_w, const float* const* ln_b, const float* const* w1, const float* const* b1,
+                                     const float* const* w2, const float* const* b2, const unsigned char* tmq, float ln_eps, int B, int T,
+                                     int D, const int* live, int layer, const void* step_state, int train, float p_drop, float* r, float* y,
+                                     float* h, float* xo, const float* const* nln_w, const float* const* nln_b, const float* const* nw_in,
+                                     const float* const* nb_in, float* nqn, float* nq, float* nk, float* nv, void* stream);
+int amid_sas_strip_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                               const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T, int D,
+                               const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
+                               float* dr, float* d_o, float* ln_part, void* stream);
+/* fh != NULL: the layer below's amid_sas_strip_ffn_bwd_f32 (f* arguments) continues on d x in registers; dx is then not written */
+int amid_sas_strip_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
+                               const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int B, int T, int D,
+                               const int* live, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
+                               const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
+                               int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
+                               float* fd_o, float* fln_part, void* stream);
+
 int amid_embed_bwd_rows_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part, const void* rng_state,
                             int train, float p_drop, const long long* row_domain, void* stream);   /* amid_embed_bwd_f32 behind the *_rows kernels: the dead sequences' rows are zero-filled, not read */
 

@@ -1,0 +1,173 @@
+"""The register-resident strip GEMM kernels (csrc/sasrec_strip.hip) against the row-tile kernels (csrc/sasrec_fwd.hip /
+sasrec_bwd.hip, themselves checked against the oracle and the reference goldens in test_gpu_sasrec.py) on the same inputs, through
+the C ABI: every saved tensor / gradient to rounding (the two sum over k in different orders), LayerNorm partial sums per domain,
+with and without the live-sequence list (rows of sequences outside the list must stay untouched)."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(64, 50, 128), (37, 20, 128), (5, 7, 64), (256, 50, 128), (300, 50, 64), (1, 1, 128)]
+
+
+def relmax(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+class Ctx:
+    def __init__(self, B, T, D, seed, live):
+        from amid_amd._lib import lib, ptr_array
+        self.L, self.pa = lib(), ptr_array
+        self.B, self.T, self.D, self.M = B, T, D, B * T
+        self.g = torch.Generator().manual_seed(seed)
+        self.s = torch.cuda.current_stream().cuda_stream
+        host = (ctypes.c_ubyte * self.L.value("amid_step_state_bytes"))()
+        self.L.call("amid_step_state_pack", ctypes.addressof(host), 11, 6, 5e-4, 0.9, 0.999, 1e-8)
+        self.st = torch.frombuffer(bytearray(host), dtype=torch.uint8).cuda()
+        self.rpt = self.L.value("amid_rows_per_tile", self.M)
+        self.tpg = -(-self.M // self.rpt)
+        self.stile = self.L.value("amid_sas_strip_tile_rows")
+        self.stpg = -(-self.M // self.stile)
+        self.dom = (torch.rand(B, generator=self.g) < 0.5).long()
+        if live == "all0":
+            self.dom[:] = 0
+        self.live = None
+        self.row_live = torch.ones(2 * self.M, dtype=torch.bool)
+        if live:
+            d0, d1 = torch.nonzero(self.dom == 0).flatten(), torch.nonzero(self.dom != 0).flatten()
+            self.live = torch.cat((d0, d1, torch.tensor([d0.numel()]))).int().cuda()
+            self.row_live = torch.cat((self.dom == 0, self.dom != 0)).repeat_interleave(T)
+        self.tmq = ((torch.rand(2 * self.M, D // 4, generator=self.g) < 0.03).to(torch.uint8) * 5).cuda()
+
+    def act(self, scale=1.0, live_only=False):
+        t = torch.randn(2 * self.M, self.D, generator=self.g) * scale
+        if live_only:
+            t = t * self.row_live[:, None]
+        return t.cuda()
+
+    def vec(self, base=0.0):
+        return ((base + 0.1 * torch.randn(self.D, generator=self.g)).cuda(), (base + 0.1 * torch.randn(self.D, generator=self.g)).cuda())
+
+    def mat(self, rows=1):
+        D = self.D
+        return ((0.1 * torch.randn(rows * D, D, generator=self.g)).cuda(), (0.1 * torch.randn(rows * D, D, generator=self.g)).cuda())
+
+    def out(self):
+        return torch.full((2 * self.M, self.D), float("nan"), device="cuda")
+
+    def lp(self):
+        return self.live.data_ptr() if self.live is not None else None
+
+    def check_rows(self, tag, got, want, tol=3e-6):
+        rl = self.row_live
+        assert torch.isfinite(got[rl.cuda()]).all(), tag
+        e = relmax(got.cpu()[rl], want.cpu()[rl])
+        assert e < tol, (tag, e)
+        if self.live is not None and bool((~rl).any()):
+            assert torch.isnan(got.cpu()[~rl]).all(), f"{tag}: rows outside the live list were written"
+
+    def check_parts(self, tag, strip_part, tile_part, tol=2e-5):
+        D = self.D
+        a = strip_part.cpu().reshape(2, self.stpg, 2, D).double().sum(1)
+        b = tile_part.cpu().reshape(2, self.tpg, 2, D).double().sum(1)
+        assert torch.isfinite(a).all(), tag
+        assert float((a - b).abs().max()) < tol * float(b.abs().max() + 1e-30), (tag, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("B,T,D", SHAPES)
+@pytest.mark.parametrize("live", [None, "mixed", "all0"])
+def test_strip_forward_equals_row_tile_kernels(B, T, D, live):
+    c = Ctx(B, T, D, seed=B * 7 + T, live=live)
+    L, pa, s, M = c.L, c.pa, c.s, c.M
+    P = lambda t: pa([t[0].data_ptr(), t[1].data_ptr()])      # noqa: E731
+    x = c.act()
+    lnw, lnb, w_in = c.vec(1.0), c.vec(), c.mat(3)
+    b_in = ((0.1 * torch.randn(3 * D, generator=c.g)).cuda(), (0.1 * torch.randn(3 * D, generator=c.g)).cuda())
+    # ---- LN1 + q / k / v
+    ref = [c.out() for _ in range(4)]
+    L.call("amid_sas_qkv_fwd_f32", x.data_ptr(), P(lnw), P(lnb), P(w_in), P(b_in), 1e-8, M, D, c.rpt, *[t.data_ptr() for t in ref], 0, s)
+    got = [c.out() for _ in range(4)]
+    L.call("amid_sas_strip_qkv_fwd_f32", x.data_ptr(), P(lnw), P(lnb), P(w_in), P(b_in), 1e-8, B, T, D, c.lp(), *[t.data_ptr() for t in got], s)
+    torch.cuda.synchronize()
+    for n, a, b in zip("qn q k v".split(), got, ref):
+        c.check_rows(f"qkv_fwd {n}", a, b)
+    # ---- out-projection + LN2 + feed-forward (dropout on), alone and with the next layer's q / k / v behind it
+    o, qn = c.act(), c.act()
+    w_o, b_o, ln2w, ln2b, w1, b1, w2, b2 = c.mat(), c.vec(), c.vec(1.0), c.vec(), c.mat(), c.vec(), c.mat(), c.vec()
+    for nxt in (False, True):
+        for train in (0, 1):
+            ref = [c.out() for _ in range(4)]
+            refn = [c.out() for _ in range(4)]
+            got = [c.out() for _ in range(4)]
+            gotn = [c.out() for _ in range(4)]
+            common = (o.data_ptr(), qn.data_ptr(), P(w_o), P(b_o), P(ln2w), P(ln2b), P(w1), P(b1), P(w2), P(b2), c.tmq.data_ptr(), 1e-8)
+            if nxt:
+                L.call("amid_sas_oproj_ffn_qkv_fwd_f32", *common, M, D, c.rpt, 1, c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in ref],
+                       P(lnw), P(lnb), P(w_in), P(b_in), *[t.data_ptr() for t in refn], 0, s)
+                L.call("amid_sas_strip_oproj_ffn_fwd_f32", *common, B, T, D, c.lp(), 1, c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in got],
+                       P(lnw), P(lnb), P(w_in), P(b_in), *[t.data_ptr() for t in gotn], s)
+            else:
+                L.call("amid_sas_oproj_ffn_fwd_f32", *common, M, D, c.rpt, 1, c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in ref], 0, s)
+                L.call("amid_sas_strip_oproj_ffn_fwd_f32", *common, B, T, D, c.lp(), 1, c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in got],
+                       None, None, None, None, None, None, None, None, s)
+            torch.cuda.synchronize()
+            for n, a, b in zip("r y h xo".split(), got, ref):
+                c.check_rows(f"oproj_ffn next={nxt} train={train} {n}", a, b)
+            if nxt:
+                for n, a, b in zip("qn q k v".split(), gotn, refn):
+                    c.check_rows(f"fused next-layer {n} train={train}", a, b)
+
+
+@pytest.mark.parametrize("B,T,D", SHAPES)
+@pytest.mark.parametrize("live", [None, "mixed", "all0"])
+def test_strip_backward_equals_row_tile_kernels(B, T, D, live):
+    c = Ctx(B, T, D, seed=B * 11 + T, live=live)
+    L, pa, s, M = c.L, c.pa, c.s, c.M
+    P = lambda t: pa([t[0].data_ptr(), t[1].data_ptr()])      # noqa: E731
+    lo = live is not None
+    part_t = lambda: torch.full((2 * c.tpg, 2, D), float("nan"), device="cuda")       # noqa: E731
+    part_s = lambda: torch.full((2 * c.stpg, 2, D), float("nan"), device="cuda")      # noqa: E731
+    lnw = c.vec(1.0)
+    # ---- feed-forward / out-projection backward
+    dxo, h, r = c.act(live_only=lo), c.act().relu(), c.act()
+    w1T, w2T, woT = c.mat(), c.mat(), c.mat()
+    for train in (0, 1):
+        ref, got = [c.out() for _ in range(4)], [c.out() for _ in range(4)]
+        pr, pg = part_t(), part_s()
+        L.call("amid_sas_ffn_bwd_f32", dxo.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), P(w1T), P(w2T), P(woT), 1e-8, M, D,
+               c.rpt, 1, c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in ref], pr.data_ptr(), 0, s)
+        L.call("amid_sas_strip_ffn_bwd_f32", dxo.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), P(w1T), P(w2T), P(woT), 1e-8,
+               B, T, D, c.lp(), 1, c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in got], pg.data_ptr(), s)
+        torch.cuda.synchronize()
+        for n, a, b in zip("dpre2 dpre1 dr d_o".split(), got, ref):
+            c.check_rows(f"ffn_bwd train={train} {n}", a, b, tol=5e-6)
+        c.check_parts(f"ffn_bwd train={train} ln_part", pg, pr)
+    # ---- q / k / v + LN1 backward, alone and with the layer below's feed-forward backward behind it
+    dq, dk, dv, dr = (c.act(live_only=lo) for _ in range(4))
+    x = c.act()
+    wq, wk, wv = c.mat(), c.mat(), c.mat()
+    ref, got, pr, pg = c.out(), c.out(), part_t(), part_s()
+    L.call("amid_sas_qkv_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), P(wq), P(wk), P(wv), 1e-8,
+           M, D, c.rpt, ref.data_ptr(), pr.data_ptr(), 0, s)
+    L.call("amid_sas_strip_qkv_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), P(wq), P(wk), P(wv),
+           1e-8, B, T, D, c.lp(), got.data_ptr(), pg.data_ptr(), *([None] * 7), 0, None, 0, 0.0, *([None] * 5), s)
+    torch.cuda.synchronize()
+    c.check_rows("qkv_bwd dx", got, ref, tol=5e-6)
+    c.check_parts("qkv_bwd ln_part", pg, pr)
+    for train in (0, 1):
+        ref, got = [c.out() for _ in range(4)], [c.out() for _ in range(4)]
+        pr, pg, fpr, fpg, dxr = part_t(), part_s(), part_t(), part_s(), c.out()
+        L.call("amid_sas_qkv_ffn_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), P(wq), P(wk), P(wv),
+               1e-8, M, D, c.rpt, dxr.data_ptr(), pr.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), P(w1T), P(w2T), P(woT), 0,
+               c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in ref], fpr.data_ptr(), 0, s)
+        L.call("amid_sas_strip_qkv_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), P(wq), P(wk), P(wv),
+               1e-8, B, T, D, c.lp(), None, pg.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), P(w1T), P(w2T), P(woT), 0,
+               c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in got], fpg.data_ptr(), s)
+        torch.cuda.synchronize()
+        for n, a, b in zip("dpre2 dpre1 dr d_o".split(), got, ref):
+            c.check_rows(f"qkv_ffn_bwd train={train} {n}", a, b, tol=1e-5)
+        c.check_parts(f"qkv_ffn_bwd train={train} ln1_part", pg, pr)
+        c.check_parts(f"qkv_ffn_bwd train={train} ln2_part", fpg, fpr)

@@ -173,27 +173,41 @@ def test_timed_path_trajectory_graph_replay_vs_oracle(Bn, T, D, pool):
     else:
         load(eng, pl, batches[0])
     eng.capture_train_step(pl)
+    # Adam divides by sqrt(v): an element whose gradient is within ~1e-7 of zero turns rounding noise (1e-10 absolute) into a visible
+    # fraction of lr -- in the reference itself (cf. the key-bias slice, test_oracle_golden).  Those elements are listed from the
+    # ORACLE's gradients and left out of the max-abs comparison; there must be very few of them.
+    unstable = {k: torch.zeros_like(v, dtype=torch.bool) for k, v in Po.items()}
+    touched = 0
     for t in range(1, K + 1):
         if not pool:
             load(eng, pl, batches[t - 1])
         eng.replay_train_step(pl)
         eng.sync()
-        loss_o = orc.train_step("sasrec", Po, opt, batches[t - 1], orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=t))
+        loss_o, _, grads = orc.loss_and_grads("sasrec", Po, batches[t - 1], orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=t))
+        for k, g in grads.items():
+            unstable[k] |= (g != 0) & (g.abs() < 1e-7)
+            touched += int((g != 0).sum())
+        opt.step(Po, grads)
+        loss_o = float(loss_o)
         log(f"timed traj B={Bn} T={T} pool={pool} step {t}: loss gpu {float(pl.loss.item()):.7f} oracle {loss_o:.7f}")
         assert abs(float(pl.loss.item()) - loss_o) < 5e-5
     eng.check_index_error(pl)
     eng.flush_table()
     eng.sync()
     sd = eng.state_dict()
-    worst = 0.0
+    worst, n_unstable = 0.0, 0
     for k, v in Po.items():
         d = (sd[k].cpu() - v).abs()
         if k.endswith("in_proj_bias"):
             n3 = v.numel() // 3
-            d = torch.cat((d[:n3], d[2 * n3:]))      # chaotic key-bias slice, see test_oracle_golden
+            d[n3:2 * n3] = 0                         # chaotic key-bias slice, see test_oracle_golden
+        n_unstable += int(unstable[k].sum())
+        d = d.masked_fill(unstable[k], 0.0)
         worst = max(worst, float(d.max()))
         assert float(d.max()) < 2e-4, k
-    log(f"timed traj B={Bn} T={T} pool={pool}: worst |param diff| after {K} steps {worst:.3e}")
+    log(f"timed traj B={Bn} T={T} pool={pool}: worst |param diff| after {K} steps {worst:.3e}; {n_unstable} near-zero-gradient "
+        f"elements of {touched} left out")
+    assert n_unstable < 2e-3 * touched
 
 
 def plain_local_grads(eng, pl, batch, step, seed):
