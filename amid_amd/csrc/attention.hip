@@ -29,6 +29,8 @@ struct AttnArgs {
     const StepState* st; int train; unsigned thr16; float dscale; int layer;
     int stagger_from, stagger_sleeps;      // set by the MFMA backward launcher only
     const long long* row_domain;           // backward only, optional [B]: sequence (g, b) has a gradient only if (row_domain[b] != 0) == g
+    const int* live;                       // matrix-core kernels only, optional [B + 1] (amid_live_list_i32): the launch covers the B
+                                           // listed sequences only -- slot j < live[B]: (0, live[j]), else (1, live[j]); nothing else is touched
 };
 
 template <int HD>
@@ -377,6 +379,32 @@ extern "C" int amid_attn_bwd_f32(const float* q, const float* k, const float* v,
                                  const unsigned char* key_keep, int B, int T, int D, int H, int causal, int layer, const void* step_state,
                                  int train, float p_drop, float* dq, float* dk, float* dv, void* stream) {
     return attn_bwd_impl(q, k, v, o, stats, d_o, key_keep, B, T, D, H, causal, layer, step_state, train, p_drop, dq, dk, dv, nullptr, stream);
+}
+
+// the matrix-core kernels over the sequences of a live list only (amid_live_list_i32; see AttnArgs::live): forward and backward of
+// the fused train step, whose loss never reads the other domain's logits of a sample (train_sr.py:205-211).  Shapes outside the
+// matrix-core kernels' range (causal, head dim 16, T <= 64) are refused: the caller then encodes every sequence.
+extern "C" int amid_attn_live_supported(int T, int D, int H, int causal) {
+    return (causal && H > 0 && H <= 8 && D % H == 0 && D / H == 16 && T > 0 && T <= 64) ? 1 : 0;
+}
+extern "C" int amid_attn_fwd_live_f32(const float* q, const float* k, const float* v, int B, int T, int D, int H, int causal, int layer,
+                                      const void* step_state, int train, float p_drop, float* o, float* stats, const int* live, void* stream) {
+    AttnArgs a = {};
+    if (int e = attn_fill(a, q, k, v, nullptr, B, T, D, H, causal, layer, step_state, train, p_drop)) return e;
+    AMID_CHECK_ARG(o && live);
+    a.o = o; a.stats = stats; a.live = live;
+    if (!mfma_shape(a)) return AMID_ERR_UNSUPPORTED;
+    return amid_attn_mfma_fwd_launch(&a, stream);
+}
+extern "C" int amid_attn_bwd_live_f32(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o,
+                                      int B, int T, int D, int H, int causal, int layer, const void* step_state, int train, float p_drop,
+                                      float* dq, float* dk, float* dv, const int* live, void* stream) {
+    AttnArgs a = {};
+    if (int e = attn_fill(a, q, k, v, nullptr, B, T, D, H, causal, layer, step_state, train, p_drop)) return e;
+    AMID_CHECK_ARG(o && stats && d_o && dq && dk && dv && live);
+    a.o = const_cast<float*>(o); a.stats = const_cast<float*>(stats); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv; a.live = live;
+    if (!mfma_shape(a)) return AMID_ERR_UNSUPPORTED;
+    return amid_attn_mfma_bwd_launch(&a, stream);
 }
 
 // the same with the training loss's structure handed in: train_sr.py:205-211 masks row b's BCE of domain 1 - domain_id[b] with

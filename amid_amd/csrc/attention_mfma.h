@@ -35,6 +35,8 @@ struct AttnArgs {          // must stay identical to the struct in attention.hip
     const StepState* st; int train; unsigned thr16; float dscale; int layer;
     int stagger_from, stagger_sleeps;      // set by the MFMA backward launcher only
     const long long* row_domain;           // backward only, optional [B]: sequence (g, b) has a gradient only if (row_domain[b] != 0) == g
+    const int* live;                       // matrix-core kernels only, optional [B + 1] (amid_live_list_i32): the launch covers the B
+                                           // listed sequences only -- slot j < live[B]: (0, live[j]), else (1, live[j]); nothing else is touched
 };
 
 

@@ -23,7 +23,10 @@ namespace amid {
 
 __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const AttnArgs a) {
     const int hw = blockDim.x >> 6, parts = a.H / hw;
-    const int seq = blockIdx.x / parts, part = blockIdx.x - seq * parts, g = seq / a.B, b = seq - g * a.B;
+    int seq = blockIdx.x / parts;
+    const int part = blockIdx.x - seq * parts;
+    if (a.live != nullptr) seq = (seq >= a.live[a.B] ? a.B : 0) + a.live[seq];      // slot -> (g, b) of the live list
+    const int g = seq / a.B, b = seq - g * a.B;
     attn_fwd_head(a, g, b, (long long)seq * a.T, part * hw + wave_id());
 }
 
@@ -36,7 +39,8 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
     const int hw = blockDim.x >> 6, parts = H / hw;
     const int slot = blockIdx.x / parts, part = blockIdx.x - slot * parts;
     bool live = true;
-    const int seq = a.row_domain != nullptr ? live_rows_remap(a.row_domain, a.B, slot, live) : slot;
+    const int seq = a.live != nullptr ? (slot >= a.live[a.B] ? a.B : 0) + a.live[slot]
+                  : a.row_domain != nullptr ? live_rows_remap(a.row_domain, a.B, slot, live) : slot;
     const int g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
     const int wv = wave_id(), h = part * hw + wv, lane = lane_id();
@@ -174,7 +178,7 @@ static int cu_count() {
 int amid_attn_mfma_fwd_launch(const void* args, void* stream) {
     AttnArgs a = *(const AttnArgs*)args;
     const int hw = (a.H % 4 == 0) ? 4 : a.H;                   // heads per workgroup
-    const int parts = a.H / hw, grid = 2 * a.B * parts;
+    const int parts = a.H / hw, grid = (a.live != nullptr ? 1 : 2) * a.B * parts;
     a.stagger_from = -1;                                       // measured: any stagger only delays the forward kernel (20.6 -> 22.5+ us)
     a.stagger_sleeps = 0;
     attn_fwd_mfma_kernel<<<grid, hw * 64, 0, (hipStream_t)stream>>>(a);
@@ -185,7 +189,7 @@ int amid_attn_mfma_fwd_launch(const void* args, void* stream) {
 int amid_attn_mfma_bwd_launch(const void* args, void* stream) {
     AttnArgs a = *(const AttnArgs*)args;
     const int hw = (a.H % 4 == 0) ? 4 : a.H;                   // heads per workgroup
-    const int parts = a.H / hw, grid = 2 * a.B * parts;
+    const int parts = a.H / hw, grid = (a.live != nullptr ? 1 : 2) * a.B * parts;
     // workgroups are handed out one per CU first, so with more than 256 of them [256, 512) are the second residents of the CUs:
     // they wait ~8 us (their neighbour's load phase) before requesting their own operands
     const int n_cu = cu_count();

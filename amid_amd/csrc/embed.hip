@@ -107,6 +107,44 @@ __global__ void pack_indices_pool_kernel(const long long* __restrict__ pool, lon
 }
 
 // ---------------------------------------------------------------------------------------------
+// live list of a batch: live[0 .. n0) = the batch rows b with domain[b] == 0 (ascending), live[n0 .. B) = those with
+// domain[b] != 0, live[B] = n0.  In the fused train step only the sequence (domain_id[b], b) of sample b is ever read by the loss
+// (train_sr.py:205-211: the other domain's BCE terms are multiplied by zero), so encoder work is enumerated through this list.
+// One workgroup; ballots + popcounts (a few microseconds even at B = 4096).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void live_list_kernel(const long long* __restrict__ domain, int B, int* __restrict__ live) {
+    __shared__ int tot[2][4];
+    const int lane = lane_id(), w = wave_id();
+    const int chunks = (B + 63) / 64, per = (chunks + 3) / 4;          // chunks of 64 batch rows, `per` consecutive chunks per wave
+    const int c_beg = w * per, c_end = min(chunks, c_beg + per);
+    int n0w = 0, n1w = 0;
+    for (int c = c_beg; c < c_end; ++c) {
+        const int b = c * 64 + lane;
+        const bool in = b < B;
+        const bool d = in && domain[b] != 0;
+        n0w += __popcll(__ballot(in && !d));
+        n1w += __popcll(__ballot(d));
+    }
+    if (lane == 0) { tot[0][w] = n0w; tot[1][w] = n1w; }
+    __syncthreads();
+    const int n0 = tot[0][0] + tot[0][1] + tot[0][2] + tot[0][3];
+    int off0 = 0, off1 = n0;
+    for (int ww = 0; ww < w; ++ww) { off0 += tot[0][ww]; off1 += tot[1][ww]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int c = c_beg; c < c_end; ++c) {
+        const int b = c * 64 + lane;
+        const bool in = b < B;
+        const bool d = in && domain[b] != 0;
+        const unsigned long long m0 = __ballot(in && !d), m1 = __ballot(d);
+        if (in && !d) live[off0 + __popcll(m0 & below)] = b;
+        if (d) live[off1 + __popcll(m1 & below)] = b;
+        off0 += __popcll(m0);
+        off1 += __popcll(m1);
+    }
+    if (threadIdx.x == 0) live[B] = n0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused SASRec embedding forward.
 //   seq rows  r <  2M : x = E[idx] + P_g[t]; tm = (x == 0); x *= dropout; x = tm ? 0 : x
 //   item rows r >= 2M : x = E[idx]
@@ -119,22 +157,33 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ pos0, const float* __restrict__ pos1,
                                                         int B, int T, int D, int n_item_rows,
                                                         float* __restrict__ xg, unsigned char* __restrict__ tmq,
-                                                        const RngState* __restrict__ rng, int train, unsigned thr16, float scale) {
+                                                        const RngState* __restrict__ rng, int train, unsigned thr16, float scale,
+                                                        const int* __restrict__ live) {
     const int sub = threadIdx.x & 31;
     const int hw = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     const int n_hw = gridDim.x * (blockDim.x >> 5);
     const int q = D >> 2;
     const int M = B * T;
     const int n_idx = 2 * M + n_item_rows;
+    // live != nullptr: only the sequences of the live list are gathered (B of the 2 B): the walk covers B * T "virtual" sequence
+    // rows + the item rows; everything else (index layout, dropout counters, output rows) is unchanged
+    const int n_walk = live != nullptr ? M + n_item_rows : n_idx;
+    const int n0 = live != nullptr ? live[B] : 0;
     unsigned long long seed = 0;
     unsigned step = 0;
     if (train) { seed = rng->seed; step = (unsigned)rng->step; }
-    for (int r0 = hw * RIF; r0 < n_idx; r0 += n_hw * RIF) {
+    for (int r0 = hw * RIF; r0 < n_walk; r0 += n_hw * RIF) {
         long long src[RIF];
+        int row[RIF];
 #pragma unroll
         for (int u = 0; u < RIF; ++u) {
             int r = r0 + u;
-            src[u] = (r < n_idx) ? (long long)idx_all[r] : 0;
+            if (live != nullptr && r < n_walk) {
+                if (r < M) { const int sq = r / T; r = (sq >= n0 ? M : 0) + live[sq] * T + (r - sq * T); }
+                else r += M;
+            }
+            row[u] = r;
+            src[u] = (r0 + u < n_walk) ? (long long)idx_all[r] : 0;
         }
         for (int c = sub; c < q; c += 32) {
             float4 v[RIF];
@@ -142,8 +191,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
             for (int u = 0; u < RIF; ++u) v[u] = ld4(table + src[u] * D + 4 * c);
 #pragma unroll
             for (int u = 0; u < RIF; ++u) {
-                const int r = r0 + u;
-                if (r >= n_idx) continue;
+                const int r = row[u];
+                if (r0 + u >= n_walk) continue;
                 float4 x = v[u];
                 if (r < 2 * M && pos0 != nullptr) {
                     const int g = r >= M;
@@ -291,18 +340,39 @@ extern "C" int amid_pack_indices_pool(const long long* pool, long long pool_stri
     return AMID_OK;
 }
 
-extern "C" int amid_embed_fwd_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
-                                  int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
-                                  void* stream) {
+static int embed_fwd(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
+                     int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop, const int* live,
+                     void* stream) {
     AMID_CHECK_ARG(table && idx_all && xg && B > 0 && T > 0 && D > 0 && (D % 4) == 0 && n_item_rows >= 0);
     AMID_CHECK_ARG((pos0 == nullptr) == (pos1 == nullptr));
     AMID_CHECK_ARG(pos0 == nullptr || tmq != nullptr);
     AMID_CHECK_ARG(!train || rng_state != nullptr);
-    const long long n_idx = 2LL * B * T + n_item_rows;
+    const long long n_walk = (live != nullptr ? 1LL : 2LL) * B * T + n_item_rows;
     const int tr = (train && pos0 != nullptr && p_drop > 0.f) ? 1 : 0;
-    embed_fwd_kernel<ROWS_IN_FLIGHT><<<gather_grid(n_idx), 256, 0, (hipStream_t)stream>>>(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq,
-                                                                                           (const RngState*)rng_state, tr, keep_thr16(p_drop),
-                                                                                           tr ? 1.0f / (1.0f - p_drop) : 1.0f);
+    embed_fwd_kernel<ROWS_IN_FLIGHT><<<gather_grid(n_walk), 256, 0, (hipStream_t)stream>>>(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq,
+                                                                                            (const RngState*)rng_state, tr, keep_thr16(p_drop),
+                                                                                            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_embed_fwd_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
+                                  int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
+                                  void* stream) {
+    return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, nullptr, stream);
+}
+
+// K1 over the live sequences only (live: amid_live_list_i32): the rows of the other B sequences of xg / tmq are left untouched
+extern "C" int amid_embed_fwd_live_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
+                                       int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
+                                       const int* live, void* stream) {
+    AMID_CHECK_ARG(live != nullptr);
+    return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, live, stream);
+}
+
+extern "C" int amid_live_list_i32(const long long* domain, int B, int* live, void* stream) {
+    AMID_CHECK_ARG(domain && live && B > 0);
+    live_list_kernel<<<1, 256, 0, (hipStream_t)stream>>>(domain, B, live);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

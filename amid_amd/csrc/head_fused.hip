@@ -29,6 +29,8 @@ struct HeadArgs {
     const float* tr_src[32]; float* tr_dst[32]; int n_tr;   // square D x D transposes done by the extra blocks
     int B, T, NI, D, hid;
     float eps;
+    int own_only;              // fused train step over the live sequences: of row b only the sequence of its OWN domain (domain[b]) was
+                               // encoded; the other domain's user vector reads as 0, gets no gradient and its rows are not touched
 };
 
 // a group of `n` consecutive threads of the workgroup working on one head (tid = index inside the group); the whole workgroup for
@@ -103,6 +105,60 @@ __device__ __forceinline__ void lnmean_rows(const HeadArgs& a, int b, float* __r
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += red_all[(g2 * 8 + k) * D + e];
         s /= T;
+        u_all[ge] = s;
+        a.u[((long long)g2 * a.B + b) * D + e] = s;
+    }
+    __syncthreads();
+}
+
+// own_only: the T rows of (domain[b], b) over all 16 row groups of the workgroup; red [16][D]
+__device__ __forceinline__ void lnmean_rows_own(const HeadArgs& a, int b, float* __restrict__ red, float* __restrict__ u_all) {
+    const int D = a.D, T = a.T, q = D >> 2;
+    const int own = a.domain[b] != 0 ? 1 : 0;
+    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;          // 16 row groups
+    const bool use_ln = a.lnw[0] != nullptr;
+    const float* xb = a.x + ((long long)own * a.B + b) * T * D;
+    constexpr int CH = HEAD_CHUNK / 2;
+    {
+        const int c = sub;
+        const bool on = c < q;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 ww = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (use_ln && on) { ww = ld4(a.lnw[own] + 4 * c); b4 = ld4(a.lnb[own] + 4 * c); }
+        for (int t0 = 0; t0 < T; t0 += 16 * CH) {
+            float4 v[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int t = t0 + rg + 16 * i;
+                v[i] = (t < T && on) ? ld4(xb + (long long)t * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int t = t0 + rg + 16 * i;
+                if (t < T) {
+                    float4 y = v[i];
+                    if (use_ln) {
+                        const float mean = group_sum<32>(f4hsum(y)) / D;
+                        float4 d4 = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
+                        if (!on) d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float rstd = 1.0f / sqrtf(group_sum<32>(f4hsum(f4mul(d4, d4))) / D + a.eps);
+                        y = make_float4(d4.x * rstd * ww.x + b4.x, d4.y * rstd * ww.y + b4.y, d4.z * rstd * ww.z + b4.z, d4.w * rstd * ww.w + b4.w);
+                    }
+                    acc = f4add(acc, y);
+                }
+            }
+        }
+        if (on) st4(red + rg * D + 4 * c, acc);
+    }
+    __syncthreads();
+    for (int ge = threadIdx.x; ge < 2 * D; ge += blockDim.x) {
+        const int g2 = ge / D, e = ge - g2 * D;
+        float s = 0.f;
+        if (g2 == own) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += red[k * D + e];
+            s /= T;
+        }
         u_all[ge] = s;
         a.u[((long long)g2 * a.B + b) * D + e] = s;
     }
@@ -199,7 +255,7 @@ __device__ __forceinline__ void scorer_fwd_part(const HeadArgs& a, const HeadLds
 __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, float* __restrict__ sm, int b) {
     const HeadLds s(sm, a.D, a.hid);
     stage_w1t(s.w1t, a.w1, 2 * a.D, a.hid, whole_block());
-    lnmean_rows(a, b, s.scr, s.u_s);
+    if (a.own_only) lnmean_rows_own(a, b, s.scr, s.u_s); else lnmean_rows(a, b, s.scr, s.u_s);
     scorer_fwd_part(a, s, b, whole_block());
 }
 
@@ -265,6 +321,74 @@ __device__ __forceinline__ void lnmean_rows_bwd(const HeadArgs& a, int b, const 
             float sacc = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) sacc += red_all[g2 * 16 * D + k * 2 * D + e];
+            a.ln_part[((long long)g2 * a.B + b) * 2 * D + e] = sacc;
+        }
+    }
+    __syncthreads();
+}
+
+// own_only: dx rows of (domain[b], b) only, over all 16 row groups; the other domain's LayerNorm-partial slot is zeroed; red [16][2][D]
+__device__ __forceinline__ void lnmean_rows_bwd_own(const HeadArgs& a, int b, const float* __restrict__ du_all, float* __restrict__ red) {
+    const int D = a.D, T = a.T, q = D >> 2;
+    const int own = a.domain[b] != 0 ? 1 : 0;
+    const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const float* du_s = du_all + own * D;
+    const bool use_ln = a.lnw[0] != nullptr;
+    const float invT = 1.0f / T;
+    const long long base = ((long long)own * a.B + b) * T * D;
+    constexpr int CH = HEAD_CHUNK / 2;
+    {
+        const int c = sub;
+        const bool on = c < q;
+        float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
+        const float4 dy = on ? f4scale(ld4(du_s + 4 * c), invT) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 gy = dy;
+        if (use_ln && on) gy = f4mul(dy, ld4(a.lnw[own] + 4 * c));
+        const float c1 = use_ln ? group_sum<32>(f4hsum(gy)) / D : 0.f;
+        for (int t0 = 0; t0 < T; t0 += 16 * CH) {
+            float4 v[CH];
+            if (use_ln) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int t = t0 + rg + 16 * i;
+                    v[i] = (t < T && on) ? ld4(a.x + base + (long long)t * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int t = t0 + rg + 16 * i;
+                if (t < T) {
+                    float4 out = dy;
+                    if (use_ln) {
+                        const float mean = group_sum<32>(f4hsum(v[i])) / D;
+                        float4 d4 = make_float4(v[i].x - mean, v[i].y - mean, v[i].z - mean, v[i].w - mean);
+                        if (!on) d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float rstd = 1.0f / sqrtf(group_sum<32>(f4hsum(f4mul(d4, d4))) / D + a.eps);
+                        const float4 xh = f4scale(d4, rstd);
+                        const float c2 = group_sum<32>(f4hsum(f4mul(gy, xh))) / D;
+                        out = make_float4(rstd * (gy.x - c1 - xh.x * c2), rstd * (gy.y - c1 - xh.y * c2), rstd * (gy.z - c1 - xh.z * c2),
+                                          rstd * (gy.w - c1 - xh.w * c2));
+                        dgam = f4add(dgam, f4mul(dy, xh));
+                        dbet = f4add(dbet, dy);
+                    }
+                    if (on) st4(a.dx + base + (long long)t * D + 4 * c, out);
+                }
+            }
+        }
+        if (on) {
+            st4(red + rg * 2 * D + 4 * c, dgam);
+            st4(red + rg * 2 * D + D + 4 * c, dbet);
+        }
+    }
+    __syncthreads();
+    if (use_ln) {
+        for (int ge = threadIdx.x; ge < 4 * D; ge += blockDim.x) {
+            const int g2 = ge / (2 * D), e = ge - g2 * 2 * D;
+            float sacc = 0.f;
+            if (g2 == own) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sacc += red[k * 2 * D + e];
+            }
             a.ln_part[((long long)g2 * a.B + b) * 2 * D + e] = sacc;
         }
     }
@@ -389,7 +513,7 @@ __device__ __forceinline__ void head_bwd_body(const HeadArgs& a, float* __restri
     const HeadLds s(sm, a.D, a.hid);
     const int b = blockIdx.x;
     float* du_s = scorer_bwd_part<FUSED, false>(a, s, b, whole_block());
-    lnmean_rows_bwd(a, b, du_s, s.scr);
+    if (a.own_only) lnmean_rows_bwd_own(a, b, du_s, s.scr); else lnmean_rows_bwd(a, b, du_s, s.scr);
 }
 
 __global__ __launch_bounds__(512) void head_fwd_kernel(const HeadArgs a) {
@@ -581,13 +705,14 @@ extern "C" int amid_head_bwd_f32(const float* x, const float* const* ln_w, const
 }
 
 // amid_head_fwd_f32 (with labels) immediately followed by amid_head_bwd_f32, ONE launch -- the training step's head
-extern "C" int amid_head_fwd_bwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
+static int head_fwd_bwd(int own_only, const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
                                      const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id,
                                      int B, int T, int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1, float* dp2,
                                      float* loss_part, float* dx, float* ditems, float* ln_part, float* sc_part,
                                      const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream) {
     HeadArgs a = {};
     if (int e = head_fill(a, x, ln_w, ln_b, items, w1, b1, w2, b2, B, T, NI, D, hid, eps)) return e;
+    a.own_only = own_only;
     AMID_CHECK_ARG(labels && domain_id && u && p1 && p2 && dp1 && dp2 && loss_part && dx && ditems && sc_part && (!ln_w || ln_part) &&
                    n_tr >= 0 && n_tr <= 32);
     a.labels = labels; a.domain = domain_id; a.u = u; a.p1 = p1; a.p2 = p2; a.dp1 = dp1; a.dp2 = dp2; a.loss_part = loss_part;
@@ -600,6 +725,27 @@ extern "C" int amid_head_fwd_bwd_f32(const float* x, const float* const* ln_w, c
     head_fwd_bwd_kernel<<<B + extra, 512, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+
+extern "C" int amid_head_fwd_bwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
+                                     const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id,
+                                     int B, int T, int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1, float* dp2,
+                                     float* loss_part, float* dx, float* ditems, float* ln_part, float* sc_part,
+                                     const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream) {
+    return head_fwd_bwd(0, x, ln_w, ln_b, items, w1, b1, w2, b2, labels, domain_id, B, T, NI, D, hid, eps, u, p1, p2, dp1, dp2, loss_part, dx,
+                        ditems, ln_part, sc_part, tr_src, tr_dst, n_tr, stream);
+}
+
+// the same when only the sequence (domain_id[b], b) of every sample was encoded (the train step over the live sequences): the other
+// domain's user vector reads as zero (its logits are NOT the model's: the masked loss never reads them, train_sr.py:205-211), it
+// receives no gradient, and of x / dx only the own sequences' rows are read / written
+extern "C" int amid_head_fwd_bwd_own_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
+                                         const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id,
+                                         int B, int T, int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1,
+                                         float* dp2, float* loss_part, float* dx, float* ditems, float* ln_part, float* sc_part,
+                                         const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream) {
+    return head_fwd_bwd(1, x, ln_w, ln_b, items, w1, b1, w2, b2, labels, domain_id, B, T, NI, D, hid, eps, u, p1, p2, dp1, dp2, loss_part, dx,
+                        ditems, ln_part, sc_part, tr_src, tr_dst, n_tr, stream);
 }
 
 // Up to three scorers forward + loss + backward in ONE launch on given user vectors u [2, B, D] (the isItC / isDR train step, see

@@ -148,6 +148,12 @@ class SasrecPlan:
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
         self.rpt = L.value("amid_rows_per_tile", M)
         self.tpg = (M + self.rpt - 1) // self.rpt
+        # the encoder's GEMM chains as register-resident strip kernels (csrc/sasrec_strip.hip): fp32, activations up to 2 GiB each;
+        # one tile geometry (64-row tiles) for every sequence and for the live sequences of a train step alike
+        self.strip = bool(eng.STRIP_KERNELS and eng.compute == "f32" and 2 * M * D * 4 <= 0x7FFFFFF0)
+        if self.strip:
+            self.stpg = -(-M // L.value("amid_sas_strip_tile_rows"))
+        self.live = torch.zeros(B + 1, dtype=torch.int32, device=dev)       # amid_live_list_i32: the step's live sequences
         # short tiles (seq_len 20 at batch 256: 40 rows per CU) run the 48- / 80-row builds of the row-tile kernels (csrc/tile_gemm.h)
         self.rt_suffix = ("_rt3" if self.rpt <= 48 else "_rt5" if self.rpt <= 80 else "") if eng.SHORT_TILE_BUILDS else ""
         # static inputs (graph-replay safe): ONE int64 buffer so a batch arrives with a single copy
@@ -213,12 +219,15 @@ class SasrecPlan:
         self.du = f(2, B, D)
         self.d_o = f(2 * M, D)
         self.dq, self.dk, self.dv = f(2 * M, D), f(2 * M, D), f(2 * M, D)
-        self.ln1_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
-        self.ln2_part = [f(2 * self.tpg, 2, D) for _ in range(2)]
+        tpg_ln = self.stpg if self.strip else self.tpg
+        self.ln1_part = [f(2 * tpg_ln, 2, D) for _ in range(2)]
+        self.ln2_part = [f(2 * tpg_ln, 2, D) for _ in range(2)]
         # the train step's own backward walks the LIVE sequences only (engine._own_rows): half the rows, re-tiled over the CUs
         # (csrc/sasrec_bwd.hip TileGeomB::row_domain); its LayerNorm partials have their own slots and reduce table
         self.live_rows = bool(self.LIVE_ROWS_BWD)
-        if self.live_rows:
+        if self.live_rows and self.strip:          # the strip kernels tile live and all rows alike: same partial slots, same reduce table
+            self.ln1_part_v, self.ln2_part_v = self.ln1_part, self.ln2_part
+        elif self.live_rows:
             self.rpt_v = L.value("amid_rows_per_tile", (M + 1) // 2)
             self.tpg_v = (M + self.rpt_v - 1) // self.rpt_v
             self.rt_suffix_v = (("_rt3" if self.rpt_v <= 48 else "_rt4" if self.rpt_v <= 64 else "_rt5" if self.rpt_v <= 80 else "")
@@ -241,7 +250,9 @@ class SasrecPlan:
         self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", N, D), dtype=torch.uint8, device=dev)
         self.uniq_grad = f(N, D)
         self.red_entries, self.red_n, self.red_max = self._build_reduce_table(eng)
-        if self.live_rows:
+        if self.live_rows and self.strip:
+            self.red_entries_v, self.red_n_v, self.red_max_v = self.red_entries, self.red_n, self.red_max
+        elif self.live_rows:
             self.red_entries_v, self.red_n_v, self.red_max_v = self._build_reduce_table(eng, live=True)
         self.graph = None
         self.graphs = {}
@@ -309,6 +320,8 @@ class SasrecPlan:
         fp, G = eng.dense, eng.dense.grad
         S = self.splits
         ln1, ln2, tpg = (self.ln1_part_v, self.ln2_part_v, self.tpg_v) if live else (self.ln1_part, self.ln2_part, self.tpg)
+        if getattr(self, "strip", False):
+            tpg = self.stpg
         for l in (0, 1):
             for g in (0, 1):
                 pre = f"sac{g + 1}"
@@ -344,6 +357,7 @@ class SasrecEngine:
     PLAN_CLS = SasrecPlan
     EMB_DIMS = (64, 128)
     SHORT_TILE_BUILDS = True     # the row-tile kernels of this encoder also exist as *_rt3 / *_rt5 (48- / 80-row tiles, csrc/Makefile)
+    STRIP_KERNELS = True         # fp32: the layer's GEMM chains run as register-resident strip kernels (csrc/sasrec_strip.hip)
 
     def _dense_names(self) -> List[Tuple[str, Tuple[int, ...]]]:
         return sasrec_dense_names(self.Tpos, self.D, self.hid, self.itc_bs, self.dr, self.inc_bs)
@@ -630,6 +644,13 @@ class SasrecEngine:
         st = self.step_state.data_ptr()
         tr = 1 if train else 0
         fp = self.dense
+        # the train step's own loss reads only the sequence (domain_id[b], b) of every sample (see _enqueue_fwd_bwd): those B "live"
+        # sequences are listed on the device; with live_fwd the forward encodes nothing else
+        lv = self._live_list(pl)
+        live_fwd = lv is not None and getattr(self, "_live_fwd", False)
+        lf = lv if live_fwd else None
+        if lv is not None:
+            L.call("amid_live_list_i32", pl.domain.data_ptr(), B, pl.live.data_ptr(), s)
         if self.inc_bs:      # plain gather, InnerComp's token group, then the 2T-token encoder input (csrc/innercomp.hip)
             L.call("amid_gather_rows_f32", self.table.data_ptr(), self.n_rows, D, pl.idx_all.data_ptr(), 0, shp.n_idx, pl.xg.data_ptr(), None, s)
             L.call("amid_inc_score_f32", pl.xg.data_ptr(), B, shp.T, D, pl.inc_s.data_ptr(), s)
@@ -638,6 +659,9 @@ class SasrecEngine:
                    self.inc_threshold, fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), B, shp.T, D, pl.inc_gate.data_ptr(),
                    pl.inc_S.data_ptr(), pl.inc_Z.data_ptr(), pl.inc_sw.data_ptr(), pl.x[0].data_ptr(), pl.tmq.data_ptr(), st, tr,
                    SASREC_P_DROP, s)
+        elif live_fwd:
+            L.call("amid_embed_fwd_live_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"),
+                   fp.ptr("sac2.pos_emb.weight"), B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, lf, s)
         else:
             L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"),
                    fp.ptr("sac2.pos_emb.weight"), B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, s)
@@ -652,20 +676,40 @@ class SasrecEngine:
 
         qkv0, rest0 = layer_ptrs(0)
         qkv1, rest1 = layer_ptrs(1)
-        L.call("amid_sas_qkv_fwd_f32" + pl.rt_suffix, pl.x[0].data_ptr(), *qkv0, SASREC_LN_EPS, M, D, pl.rpt, pl.qn[0].data_ptr(), pl.q[0].data_ptr(),
-               pl.k[0].data_ptr(), pl.v[0].data_ptr(), self.mma_bf16, s)
-        for l in (0, 1):
-            L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), None, B, T, D, self.H, 1, l, st, tr,
-                   SASREC_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
-            rest = rest0 if l == 0 else rest1
-            if l == 0:      # layer 0's out-projection + feed-forward and layer 1's LayerNorm + q / k / v: one launch
-                L.call("amid_sas_oproj_ffn_qkv_fwd_f32" + pl.rt_suffix, pl.o[0].data_ptr(), pl.qn[0].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
-                       pl.rpt, 0, st, tr, SASREC_P_DROP, pl.r[0].data_ptr(), pl.y[0].data_ptr(), pl.h[0].data_ptr(), pl.x[1].data_ptr(),
-                       *qkv1, pl.qn[1].data_ptr(), pl.q[1].data_ptr(), pl.k[1].data_ptr(), pl.v[1].data_ptr(), self.mma_bf16, s)
+
+        def attn_fwd(l):
+            if live_fwd:
+                L.call("amid_attn_fwd_live_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), B, T, D, self.H, 1, l, st, tr,
+                       SASREC_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), lf, s)
             else:
-                L.call("amid_sas_oproj_ffn_fwd_f32" + pl.rt_suffix, pl.o[l].data_ptr(), pl.qn[l].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
-                       pl.rpt, l, st, tr, SASREC_P_DROP, pl.r[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(),
-                       self.mma_bf16, s)
+                L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), None, B, T, D, self.H, 1, l, st, tr,
+                       SASREC_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
+
+        if pl.strip:         # register-resident strip chains (csrc/sasrec_strip.hip): same operations, operands and saved tensors
+            L.call("amid_sas_strip_qkv_fwd_f32", pl.x[0].data_ptr(), *qkv0, SASREC_LN_EPS, B, T, D, lf, pl.qn[0].data_ptr(), pl.q[0].data_ptr(),
+                   pl.k[0].data_ptr(), pl.v[0].data_ptr(), s)
+            attn_fwd(0)
+            L.call("amid_sas_strip_oproj_ffn_fwd_f32", pl.o[0].data_ptr(), pl.qn[0].data_ptr(), *rest0, pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, lf,
+                   0, st, tr, SASREC_P_DROP, pl.r[0].data_ptr(), pl.y[0].data_ptr(), pl.h[0].data_ptr(), pl.x[1].data_ptr(), *qkv1,
+                   pl.qn[1].data_ptr(), pl.q[1].data_ptr(), pl.k[1].data_ptr(), pl.v[1].data_ptr(), s)
+            attn_fwd(1)
+            L.call("amid_sas_strip_oproj_ffn_fwd_f32", pl.o[1].data_ptr(), pl.qn[1].data_ptr(), *rest1, pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, lf,
+                   1, st, tr, SASREC_P_DROP, pl.r[1].data_ptr(), pl.y[1].data_ptr(), pl.h[1].data_ptr(), pl.x[2].data_ptr(), None, None, None,
+                   None, None, None, None, None, s)
+        else:
+            L.call("amid_sas_qkv_fwd_f32" + pl.rt_suffix, pl.x[0].data_ptr(), *qkv0, SASREC_LN_EPS, M, D, pl.rpt, pl.qn[0].data_ptr(), pl.q[0].data_ptr(),
+                   pl.k[0].data_ptr(), pl.v[0].data_ptr(), self.mma_bf16, s)
+            for l in (0, 1):
+                attn_fwd(l)
+                rest = rest0 if l == 0 else rest1
+                if l == 0:      # layer 0's out-projection + feed-forward and layer 1's LayerNorm + q / k / v: one launch
+                    L.call("amid_sas_oproj_ffn_qkv_fwd_f32" + pl.rt_suffix, pl.o[0].data_ptr(), pl.qn[0].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
+                           pl.rpt, 0, st, tr, SASREC_P_DROP, pl.r[0].data_ptr(), pl.y[0].data_ptr(), pl.h[0].data_ptr(), pl.x[1].data_ptr(),
+                           *qkv1, pl.qn[1].data_ptr(), pl.q[1].data_ptr(), pl.k[1].data_ptr(), pl.v[1].data_ptr(), self.mma_bf16, s)
+                else:
+                    L.call("amid_sas_oproj_ffn_fwd_f32" + pl.rt_suffix, pl.o[l].data_ptr(), pl.qn[l].data_ptr(), *rest, pl.tmq.data_ptr(), SASREC_LN_EPS, M, D,
+                           pl.rpt, l, st, tr, SASREC_P_DROP, pl.r[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(),
+                           self.mma_bf16, s)
         items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
         if (self.dr or self.itc_bs) and getattr(self, "_fuse_scorers", False) and with_loss and not sum_loss:
             self._enqueue_user_vectors(pl)           # train step: the scorers run as ONE forward + loss + backward launch in enqueue_backward
@@ -809,7 +853,7 @@ class SasrecEngine:
             L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
             self._enqueue_head_itc_bwd(pl, items, ditems)
         elif getattr(self, "_fuse_head", False):
-            L.call("amid_head_fwd_bwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
+            L.call("amid_head_fwd_bwd_own_f32" if getattr(self, "_live_fwd", False) and self._live_list(pl) is not None else "amid_head_fwd_bwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
                    items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
                    fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr(), pl.domain.data_ptr(), B, T, NI, D, self.hid, SASREC_LN_EPS,
                    pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), pl.loss_part.data_ptr(),
@@ -824,7 +868,15 @@ class SasrecEngine:
             return (pl.tmq.data_ptr(), pl.h[l].data_ptr(), pl.r[l].data_ptr(), self._pp(f"sac{{d}}.forward_layernorms.{l}.weight"),
                     self._wT(l, 4), self._wT(l, 5), self._wT(l, 3))
 
+        lv = self._live_list(pl)
+        live_attn = lv is not None and bool(lib().value("amid_attn_live_supported", T, D, self.H, 1))
+
         def attn_bwd(l):
+            if live_attn:        # the live sequences only; the others' rows of dq / dk / dv are never read (strip kernels, wgrad hint)
+                L.call("amid_attn_bwd_live_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(),
+                       pl.stats[l].data_ptr(), pl.d_o.data_ptr(), B, T, D, self.H, 1, l, st, tr, SASREC_P_DROP, pl.dq_l[l].data_ptr(),
+                       pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), lv, s)
+                return
             L.call("amid_attn_bwd_rows_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(),
                    pl.stats[l].data_ptr(), pl.d_o.data_ptr(), None, B, T, D, self.H, 1, l, st, tr, SASREC_P_DROP, pl.dq_l[l].data_ptr(),
                    pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), self._own_rows(pl), s)
@@ -832,25 +884,42 @@ class SasrecEngine:
         # live: the three row-tile kernels walk the sequences that carry a gradient only (see _own_rows), re-tiled over the CUs
         dom = self._own_rows(pl)
         live = dom is not None and pl.live_rows
-        rows, suf, rpt = ("_rows", pl.rt_suffix_v, pl.rpt_v) if live else ("", pl.rt_suffix, pl.rpt)
-        ln1p, ln2p = (pl.ln1_part_v, pl.ln2_part_v) if live else (pl.ln1_part, pl.ln2_part)
-        hint = (dom, B, T) if live else ()
         tm, h1, r1, lnw1, w1T1, w2T1, woT1 = ffn_bwd_args(1)
-        L.call(f"amid_sas_ffn_bwd{rows}_f32" + suf, pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, M, D, rpt, 1, st, tr,
-               SASREC_P_DROP, pl.dpre2[1].data_ptr(), pl.dpre1[1].data_ptr(), pl.dr[1].data_ptr(), pl.d_o.data_ptr(),
-               ln2p[1].data_ptr(), self.mma_bf16, *hint, s)
-        attn_bwd(1)
-        # layer 1's q / k / v + LayerNorm1 backward and layer 0's feed-forward / out-projection backward: one launch
         tm, h0, r0, lnw0, w1T0, w2T0, woT0 = ffn_bwd_args(0)
-        L.call(f"amid_sas_qkv_ffn_bwd{rows}_f32" + suf, pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
-               pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
-               SASREC_LN_EPS, M, D, rpt, pl.dxbuf.data_ptr(), ln1p[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr,
-               SASREC_P_DROP, pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(),
-               ln2p[0].data_ptr(), self.mma_bf16, *hint, s)
-        attn_bwd(0)
-        L.call(f"amid_sas_qkv_bwd{rows}_f32" + suf, pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
-               pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
-               SASREC_LN_EPS, M, D, rpt, (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), ln1p[0].data_ptr(), self.mma_bf16, *hint, s)
+        dx_in = (pl.dx0 if self.inc_bs else pl.dxg).data_ptr()
+        if pl.strip:
+            ln1p, ln2p = pl.ln1_part, pl.ln2_part
+            L.call("amid_sas_strip_ffn_bwd_f32", pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, B, T, D, lv, 1, st, tr,
+                   SASREC_P_DROP, pl.dpre2[1].data_ptr(), pl.dpre1[1].data_ptr(), pl.dr[1].data_ptr(), pl.d_o.data_ptr(), ln2p[1].data_ptr(), s)
+            attn_bwd(1)
+            # layer 1's q / k / v + LayerNorm1 backward and layer 0's feed-forward / out-projection backward: one launch
+            L.call("amid_sas_strip_qkv_bwd_f32", pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
+                   pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
+                   SASREC_LN_EPS, B, T, D, lv, None, ln1p[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr, SASREC_P_DROP,
+                   pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(), ln2p[0].data_ptr(), s)
+            attn_bwd(0)
+            L.call("amid_sas_strip_qkv_bwd_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
+                   pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
+                   SASREC_LN_EPS, B, T, D, lv, dx_in, ln1p[0].data_ptr(), None, None, None, None, None, None, None, 0, None, 0, 0.0, None,
+                   None, None, None, None, s)
+        else:
+            rows, suf, rpt = ("_rows", pl.rt_suffix_v, pl.rpt_v) if live else ("", pl.rt_suffix, pl.rpt)
+            ln1p, ln2p = (pl.ln1_part_v, pl.ln2_part_v) if live else (pl.ln1_part, pl.ln2_part)
+            hint = (dom, B, T) if live else ()
+            L.call(f"amid_sas_ffn_bwd{rows}_f32" + suf, pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, M, D, rpt, 1, st, tr,
+                   SASREC_P_DROP, pl.dpre2[1].data_ptr(), pl.dpre1[1].data_ptr(), pl.dr[1].data_ptr(), pl.d_o.data_ptr(),
+                   ln2p[1].data_ptr(), self.mma_bf16, *hint, s)
+            attn_bwd(1)
+            # layer 1's q / k / v + LayerNorm1 backward and layer 0's feed-forward / out-projection backward: one launch
+            L.call(f"amid_sas_qkv_ffn_bwd{rows}_f32" + suf, pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
+                   pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
+                   SASREC_LN_EPS, M, D, rpt, pl.dxbuf.data_ptr(), ln1p[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr,
+                   SASREC_P_DROP, pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(),
+                   ln2p[0].data_ptr(), self.mma_bf16, *hint, s)
+            attn_bwd(0)
+            L.call(f"amid_sas_qkv_bwd{rows}_f32" + suf, pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
+                   pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
+                   SASREC_LN_EPS, M, D, rpt, dx_in, ln1p[0].data_ptr(), self.mma_bf16, *hint, s)
         dy, xx = [], []
         for l in (0, 1):
             dy += [pl.dq_l[l].data_ptr(), pl.dk_l[l].data_ptr(), pl.dv_l[l].data_ptr(), pl.dr[l].data_ptr(), pl.dpre1[l].data_ptr(),
@@ -928,11 +997,23 @@ class SasrecEngine:
         # objectives likewise, train_sr_dr.py:216-221, :392-394): the encoder of that domain gets an all-zero gradient for row b.
         # InterComp AFTER the encoders mixes the rows' user vectors, so every sequence has a gradient there.
         self._own_domain_only = not self.itc_bs
+        # ... and neither do the other domain's logits of a sample: with the plain head (no isDR heads, no InterComp / InnerComp) and
+        # the matrix-core attention kernels the forward encodes the B live sequences only.  model.forward, which RETURNS both
+        # domains' logits (model_seq.py:442), keeps encoding everything.
+        self._live_fwd = (self._own_domain_only and self._fuse_head and pl.strip and not self.inc_bs and self.LIVE_FORWARD
+                          and bool(lib().value("amid_attn_live_supported", pl.shape.Tenc, self.D, self.H, 1)))
         try:
             self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)
             self.enqueue_backward(pl, train=True)
         finally:
-            self._fuse_head = self._fuse_scorers = self._own_domain_only = False
+            self._fuse_head = self._fuse_scorers = self._own_domain_only = self._live_fwd = False
+
+    LIVE_FORWARD = True        # the fused train step may skip the forward of the sequences its loss never reads
+
+    def _live_list(self, pl: SasrecPlan):
+        """Device pointer of the plan's live-sequence list (filled by amid_live_list_i32 at the head of enqueue_forward) when the
+        step's loss masks the other domain of every sample and the encoder runs on the strip kernels, else None."""
+        return pl.live.data_ptr() if getattr(self, "_own_domain_only", False) and pl.strip else None
 
     def _own_rows(self, pl: SasrecPlan):
         """Device pointer of the batch's domain ids when backward may treat the other domain's sequences as gradient-free (see

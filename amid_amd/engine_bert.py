@@ -109,6 +109,7 @@ class Bert4recEngine(SasrecEngine):
     PLAN_CLS = BertPlan
     EMB_DIMS = (BERT_HIDDEN,)
     SHORT_TILE_BUILDS = True
+    STRIP_KERNELS = False        # its encoder launches are bert.hip's row-tile kernels
 
     def __init__(self, *args, comp: str = "", comp_bs: int = 0, comp_threshold: float = 0.5, **kw):
         """comp = "inc" / "itc": BERT4Rec(isInC=True) / (isItC=True) with bs = comp_bs and threshold1 / threshold2 = comp_threshold:

@@ -115,13 +115,26 @@ def init_params(eng, seed):
 
 def algorithmic_work(Bw=B, n_uniq=None, T=T):
     """Per launch, at this workload (formulas: DESIGN.md section 5 / SURVEY.md section 8(d)).  BERT4Rec: 24 B T D^2 per
-    domain-layer forward (4 D^2 projections + the 128 -> 512 -> 128 feed-forward), the same again twice for backward."""
+    domain-layer forward (4 D^2 projections + the 128 -> 512 -> 128 feed-forward), the same again twice for backward.
+    The fused SASRec train step encodes and differentiates the LIVE sequences only -- of each sample the sequence of its own domain,
+    B of the 2 B (the loss multiplies the other domain's BCE by zero, train_sr.py:205-211): its kernels are priced on B T rows."""
     M2 = 2 * Bw * T
     n_idx = M2 + Bw * (1 + NEG)
     U = n_uniq if n_uniq is not None else n_idx
     gemm = 2.0 * M2 * D * D                     # FLOP of one [M2, D] x [D, D] projection
+    gl = gemm / 2                               # the same over the live rows
     H, hd = 8, D // 8
     return {
+        # strip kernels of the fused step ("#k": k-th launch of that entry in a step -- the fused cross-layer launch comes first)
+        "amid_sas_strip_qkv_fwd_f32": ("mfma", 3 * gl),
+        "amid_sas_strip_oproj_ffn_fwd_f32#0": ("mfma", 6 * gl),       # layer 0's out-proj + FFN, layer 1's q / k / v
+        "amid_sas_strip_oproj_ffn_fwd_f32#1": ("mfma", 3 * gl),
+        "amid_sas_strip_ffn_bwd_f32": ("mfma", 3 * gl),
+        "amid_sas_strip_qkv_bwd_f32#0": ("mfma", 6 * gl),             # layer 1's q / k / v backward, layer 0's FFN / out-proj backward
+        "amid_sas_strip_qkv_bwd_f32#1": ("mfma", 3 * gl),
+        "amid_attn_fwd_live_f32": ("mfma", 4.0 * T * T * hd * Bw * H),
+        "amid_attn_bwd_live_f32": ("mfma", 10.0 * T * T * hd * Bw * H),
+        "amid_embed_fwd_live_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (4 + 2 * D * 4) + Bw * T * (D // 4)),
         "amid_sas_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_sas_oproj_fwd_f32": ("mfma", gemm),
         "amid_sas_oproj_ffn_fwd_f32": ("mfma", 3 * gemm),
@@ -168,6 +181,10 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_qkv_ffn_bwd_f32": "sas_qkv_ffn_bwd_kernel", "amid_sas_oproj_ffn_qkv_fwd_f32": "sas_oproj_ffn_qkv_fwd_kernel",
     "amid_sas_oproj_ffn_fwd_f32": "sas_oproj_ffn_fwd_kernel",
     "amid_attn_fwd_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_f32": "embed_fwd_kernel",
+    "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
+    "amid_sas_strip_oproj_ffn_fwd_f32#1": "strip_oproj_ffn_fwd_kernelILi128ELb0", "amid_sas_strip_ffn_bwd_f32": "strip_ffn_bwd_kernel",
+    "amid_sas_strip_qkv_bwd_f32#0": "strip_qkv_bwd_kernelILi128ELb1", "amid_sas_strip_qkv_bwd_f32#1": "strip_qkv_bwd_kernelILi128ELb0",
+    "amid_attn_fwd_live_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_live_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_live_f32": "embed_fwd_kernel",
     "amid_embgrad_segreduce_f32": "segreduce_chunks_kernel",
 }
 
@@ -363,6 +380,12 @@ def main():
             eng.sync()
         durs = L.timer.collect(L)
         L.timer = None
+        for name in ("amid_sas_strip_oproj_ffn_fwd_f32", "amid_sas_strip_qkv_bwd_f32"):      # two different launches per step under one entry
+            v = durs.pop(name, None)
+            if v is not None and len(v) == 2 * n_prof:
+                durs[name + "#0"], durs[name + "#1"] = v[0::2], v[1::2]
+            elif v is not None:
+                durs[name] = v
         work = algorithmic_work(Bw, int(pl.n_uniq.item()), T)
         total_ms = 0.0
         for name, v in durs.items():

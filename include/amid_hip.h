@@ -501,6 +501,27 @@ int amid_sas_qkv_ffn_bwd_rows_f32_rt5(const float* dq, const float* dk, const fl
 int amid_sas_qkv_ffn_bwd_rows_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
 int amid_sas_qkv_ffn_bwd_rows_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
 
+/* ---- the fused train step over the LIVE sequences -------------------------------------------------------------------------------
+ * train_sr.py:205-211 multiplies the BCE terms of domain 1 - domain_id[b] of every sample b by zero: of the 2 B sequences a step
+ * encodes only the B "live" ones (domain_id[b], b) reach the loss.  amid_live_list_i32 lists them ([B + 1] ints: batch rows of
+ * domain 0's live sequences ascending, then domain 1's, then n0); the *_live / *_own entry points walk that list only and leave
+ * every row of the other sequences untouched.  model.forward (which returns both domains' logits) never uses them. */
+int amid_live_list_i32(const long long* domain, int B, int* live, void* stream);
+int amid_embed_fwd_live_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
+                            int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
+                            const int* live, void* stream);
+int amid_attn_live_supported(int T, int D, int H, int causal);
+int amid_attn_fwd_live_f32(const float* q, const float* k, const float* v, int B, int T, int D, int H, int causal, int layer,
+                           const void* step_state, int train, float p_drop, float* o, float* stats, const int* live, void* stream);
+int amid_attn_bwd_live_f32(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o, int B,
+                           int T, int D, int H, int causal, int layer, const void* step_state, int train, float p_drop, float* dq,
+                           float* dk, float* dv, const int* live, void* stream);
+int amid_head_fwd_bwd_own_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
+                              const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id, int B,
+                              int T, int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1, float* dp2,
+                              float* loss_part, float* dx, float* ditems, float* ln_part, float* sc_part, const float* const* tr_src,
+                              float* const* tr_dst, int n_tr, void* stream);
+
 /* ---- the same encoder-layer GEMM chains as register-resident STRIP kernels (csrc/strip_gemm.h, csrc/sasrec_strip.hip) -------------
  * replace: Log2feats.forward model_seq.py:371-383 (LayerNorms, nn.MultiheadAttention's in/out projections as called at :374,
  * PointWiseFeedForward :322-326) and its autograd (loss.backward(), train_sr.py:214), like the row-tile entry points above, fp32 only.

@@ -136,8 +136,9 @@ def test_timed_path_loss_and_grads_vs_oracle(Bn, T, D, build, split):
     eng = make_engine(P, T, seed=seed)
     pl = eng.plan(Bn, T, 2, need_grad=True)
     timed_local_grads(eng, pl, batch, step, seed)
-    if hasattr(pl, "rt_suffix_v") and not getattr(pl, "fused_seq", False):
-        assert pl.rt_suffix_v == build, (pl.rt_suffix_v, pl.rpt_v)
+    # the encoder's GEMM chains of the fused step run as strip kernels over the live sequences (csrc/sasrec_strip.hip); engines
+    # built without them fall back to the live-row builds of the row-tile kernels named in the case
+    assert pl.strip or pl.rt_suffix_v == build
     keep = gpu_relu_keep(eng, pl, batch)
     taps = {}
     loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, masks, relu_keep=keep, taps=taps)
@@ -156,7 +157,15 @@ def test_timed_path_loss_and_grads_vs_oracle(Bn, T, D, build, split):
 @pytest.mark.parametrize("pool", [False, True])
 def test_timed_path_trajectory_graph_replay_vs_oracle(Bn, T, D, pool):
     """Three whole steps at the headline shape (and the mybank shape) through capture_train_step + replay_train_step -- the thing
-    bench.py times -- against the oracle's dense-Adam trajectory: loss per step and every parameter after the flush."""
+    bench.py times -- against the oracle, step by step: the loss and every gradient of the step against the oracle's at the same
+    parameters, and the optimizer against the oracle's dense Adam.
+
+    Adam divides by sqrt(v), so an element whose gradient is within ~1e-7 of zero (1 % of the touched table elements at this size)
+    turns rounding noise into a visible fraction of lr -- in the reference itself --, and the perturbation then feeds the next
+    step: a free-running max-abs comparison of parameters is ill-posed here (the key-bias slice of test_oracle_golden is the same
+    effect).  So the oracle's Adam is driven by the gradients the GPU produced: parameters must then agree to rounding after every
+    step -- which checks the lazy row updates, their catch-up and the flush exactly --, while the gradients themselves are checked
+    against the oracle's own at those parameters."""
     hid, n_items, K, lr, seed = 32, 3000, 3, 1e-3, 4242
     P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=20 + T)
     eng = make_engine(P, T, lr=lr, seed=seed)
@@ -164,6 +173,8 @@ def test_timed_path_trajectory_graph_replay_vs_oracle(Bn, T, D, pool):
     opt = orc.DenseAdam(Po, lr=lr)
     pl = eng.plan(Bn, T, 2, need_grad=True)
     batches = [orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=500 + t) for t in range(K)]
+    for t in (1, 2):                  # rows 1..40 are only touched at step 1: idle rows must keep moving through their momentum
+        batches[t]["seq_d1"] = torch.where(batches[t]["seq_d1"] == n_items - 1, batches[t]["seq_d1"], batches[t]["seq_d1"].clamp(min=41))
     if pool:
         packed = []
         for b in batches:
@@ -173,41 +184,31 @@ def test_timed_path_trajectory_graph_replay_vs_oracle(Bn, T, D, pool):
     else:
         load(eng, pl, batches[0])
     eng.capture_train_step(pl)
-    # Adam divides by sqrt(v): an element whose gradient is within ~1e-7 of zero turns rounding noise (1e-10 absolute) into a visible
-    # fraction of lr -- in the reference itself (cf. the key-bias slice, test_oracle_golden).  Those elements are listed from the
-    # ORACLE's gradients and left out of the max-abs comparison; there must be very few of them.
-    unstable = {k: torch.zeros_like(v, dtype=torch.bool) for k, v in Po.items()}
-    touched = 0
     for t in range(1, K + 1):
         if not pool:
             load(eng, pl, batches[t - 1])
         eng.replay_train_step(pl)
         eng.sync()
-        loss_o, _, grads = orc.loss_and_grads("sasrec", Po, batches[t - 1], orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=t))
-        for k, g in grads.items():
-            unstable[k] |= (g != 0) & (g.abs() < 1e-7)
-            touched += int((g != 0).sum())
-        opt.step(Po, grads)
-        loss_o = float(loss_o)
-        log(f"timed traj B={Bn} T={T} pool={pool} step {t}: loss gpu {float(pl.loss.item()):.7f} oracle {loss_o:.7f}")
-        assert abs(float(pl.loss.item()) - loss_o) < 5e-5
+        masks = orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=t)
+        taps = {}
+        loss_o, _, grads = orc.loss_and_grads("sasrec", Po, batches[t - 1], masks, relu_keep=gpu_relu_keep(eng, pl, batches[t - 1]), taps=taps)
+        assert max(taps[s_].get(f"relu_flip{l}", 0.0) for s_ in ("sac1", "sac2") for l in (0, 1)) < 2e-5
+        log(f"timed traj B={Bn} T={T} pool={pool} step {t}: loss gpu {float(pl.loss.item()):.7f} oracle {float(loss_o):.7f}")
+        assert abs(float(pl.loss.item()) - float(loss_o)) < 5e-5
+        check_grads(f"timed traj B={Bn} T={T} pool={pool} step {t}", eng, pl, grads, 2e-4, 5e-5)
+        g_gpu = {name: eng.dense.view(name, eng.dense.grad).cpu().clone() for name in eng.dense.slots}
+        g_gpu["item_emb_layer.emb_item.weight"] = dense_table_grad(eng, pl)
+        opt.step(Po, g_gpu)
     eng.check_index_error(pl)
     eng.flush_table()
     eng.sync()
     sd = eng.state_dict()
-    worst, n_unstable = 0.0, 0
+    worst = 0.0
     for k, v in Po.items():
-        d = (sd[k].cpu() - v).abs()
-        if k.endswith("in_proj_bias"):
-            n3 = v.numel() // 3
-            d[n3:2 * n3] = 0                         # chaotic key-bias slice, see test_oracle_golden
-        n_unstable += int(unstable[k].sum())
-        d = d.masked_fill(unstable[k], 0.0)
-        worst = max(worst, float(d.max()))
-        assert float(d.max()) < 2e-4, k
-    log(f"timed traj B={Bn} T={T} pool={pool}: worst |param diff| after {K} steps {worst:.3e}; {n_unstable} near-zero-gradient "
-        f"elements of {touched} left out")
-    assert n_unstable < 2e-3 * touched
+        d = float((sd[k].cpu() - v).abs().max())
+        worst = max(worst, d)
+        assert d < 5e-6, (k, d)
+    log(f"timed traj B={Bn} T={T} pool={pool}: worst |param diff| after {K} steps {worst:.3e}")
 
 
 def plain_local_grads(eng, pl, batch, step, seed):
