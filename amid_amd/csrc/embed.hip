@@ -51,68 +51,13 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// int64 -> int32 index packing at the module boundary (train_sr.py:191-199 hands LongTensors)
-// ---------------------------------------------------------------------------------------------
-__global__ void pack_indices_kernel(const long long* __restrict__ i_node, const long long* __restrict__ neg,
-                                    const long long* __restrict__ seq_d1, const long long* __restrict__ seq_d2,
-                                    int B, int T, int n_neg, long long n_rows, int* __restrict__ idx_all, int* __restrict__ err,
-                                    StepState* __restrict__ bump) {
-    if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) bump->step += 1;      // folded amid_step_begin (nobody in this launch reads it)
-    const int M = B * T, NI = 1 + n_neg;
-    const int n = 2 * M + B * NI;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        long long v;
-        if (i < M) v = seq_d1[i];
-        else if (i < 2 * M) v = seq_d2[i - M];
-        else {
-            int j = i - 2 * M, b = j / NI, k = j % NI;
-            v = (k == 0) ? i_node[b] : neg[(long long)b * n_neg + (k - 1)];
-        }
-        if (v < 0 || v >= n_rows) { atomicOr(err, 1); v = 0; }
-        idx_all[i] = (int)v;
-    }
-}
-
-// Pool-input variant: the batches of an epoch are resident in HBM as `n_pool` packed images ([i_node B][neg B n_neg][seq_d1 M]
-// [seq_d2 M][domain, labels, ...]: the plan's input layout).  The kernel picks image (step + phase) % n_pool by the DEVICE step
-// counter, so a replayed hipGraph walks the pool with no per-step host copy; it also mirrors the image into the plan's static
-// input words (the head kernels read domain / labels there).  Every block reads the step before it takes a ticket and the
-// block that takes the last ticket bumps it: no block can see the bumped value.
-__global__ void pack_indices_pool_kernel(const long long* __restrict__ pool, long long stride, int n_pool, long long phase,
-                                         long long* __restrict__ in_pack, int in_words, int B, int T, int n_neg, long long n_rows,
-                                         int* __restrict__ idx_all, int* __restrict__ err, StepState* __restrict__ st) {
-    const long long t_pre = __atomic_load_n(&st->step, __ATOMIC_RELAXED);
-    long long which = (t_pre + phase) % n_pool;
-    if (which < 0) which += n_pool;
-    const long long* __restrict__ src = pool + which * stride;
-    const int M = B * T, NI = 1 + n_neg;
-    const int n_items = B * n_neg, n_index_words = B + n_items + 2 * M;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < in_words; i += gridDim.x * blockDim.x) {
-        long long v = src[i];
-        in_pack[i] = v;
-        if (i < n_index_words) {
-            int dst;
-            if (i < B) dst = 2 * M + i * NI;
-            else if (i < B + n_items) { const int j = i - B; dst = 2 * M + (j / n_neg) * NI + 1 + (j % n_neg); }
-            else dst = i - B - n_items;
-            if (v < 0 || v >= n_rows) { atomicOr(err, 1); v = 0; }
-            idx_all[dst] = (int)v;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicInc(&st->ticket, gridDim.x - 1) == gridDim.x - 1) st->step = t_pre + 1;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // live list of a batch: live[0 .. n0) = the batch rows b with domain[b] == 0 (ascending), live[n0 .. B) = those with
 // domain[b] != 0, live[B] = n0.  In the fused train step only the sequence (domain_id[b], b) of sample b is ever read by the loss
 // (train_sr.py:205-211: the other domain's BCE terms are multiplied by zero), so encoder work is enumerated through this list.
 // One workgroup; ballots + popcounts (a few microseconds even at B = 4096).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void live_list_kernel(const long long* __restrict__ domain, int B, int* __restrict__ live) {
+// body for one 256-thread workgroup
+__device__ __forceinline__ void live_list_block(const long long* __restrict__ domain, int B, int* __restrict__ live) {
     __shared__ int tot[2][4];
     const int lane = lane_id(), w = wave_id();
     const int chunks = (B + 63) / 64, per = (chunks + 3) / 4;          // chunks of 64 batch rows, `per` consecutive chunks per wave
@@ -142,6 +87,69 @@ __global__ __launch_bounds__(256) void live_list_kernel(const long long* __restr
         off1 += __popcll(m1);
     }
     if (threadIdx.x == 0) live[B] = n0;
+}
+
+__global__ __launch_bounds__(256) void live_list_kernel(const long long* __restrict__ domain, int B, int* __restrict__ live) {
+    live_list_block(domain, B, live);
+}
+
+// ---------------------------------------------------------------------------------------------
+// int64 -> int32 index packing at the module boundary (train_sr.py:191-199 hands LongTensors)
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_indices_kernel(const long long* __restrict__ i_node, const long long* __restrict__ neg,
+                                    const long long* __restrict__ seq_d1, const long long* __restrict__ seq_d2,
+                                    int B, int T, int n_neg, long long n_rows, int* __restrict__ idx_all, int* __restrict__ err,
+                                    StepState* __restrict__ bump, const long long* __restrict__ domain, int* __restrict__ live) {
+    if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) bump->step += 1;      // folded amid_step_begin (nobody in this launch reads it)
+    if (live != nullptr && blockIdx.x == gridDim.x - 1) live_list_block(domain, B, live);        // folded amid_live_list_i32
+    const int M = B * T, NI = 1 + n_neg;
+    const int n = 2 * M + B * NI;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        long long v;
+        if (i < M) v = seq_d1[i];
+        else if (i < 2 * M) v = seq_d2[i - M];
+        else {
+            int j = i - 2 * M, b = j / NI, k = j % NI;
+            v = (k == 0) ? i_node[b] : neg[(long long)b * n_neg + (k - 1)];
+        }
+        if (v < 0 || v >= n_rows) { atomicOr(err, 1); v = 0; }
+        idx_all[i] = (int)v;
+    }
+}
+
+// Pool-input variant: the batches of an epoch are resident in HBM as `n_pool` packed images ([i_node B][neg B n_neg][seq_d1 M]
+// [seq_d2 M][domain, labels, ...]: the plan's input layout).  The kernel picks image (step + phase) % n_pool by the DEVICE step
+// counter, so a replayed hipGraph walks the pool with no per-step host copy; it also mirrors the image into the plan's static
+// input words (the head kernels read domain / labels there).  Every block reads the step before it takes a ticket and the
+// block that takes the last ticket bumps it: no block can see the bumped value.
+__global__ void pack_indices_pool_kernel(const long long* __restrict__ pool, long long stride, int n_pool, long long phase,
+                                         long long* __restrict__ in_pack, int in_words, int B, int T, int n_neg, long long n_rows,
+                                         int* __restrict__ idx_all, int* __restrict__ err, StepState* __restrict__ st, int* __restrict__ live) {
+    const long long t_pre = __atomic_load_n(&st->step, __ATOMIC_RELAXED);
+    long long which = (t_pre + phase) % n_pool;
+    if (which < 0) which += n_pool;
+    const long long* __restrict__ src = pool + which * stride;
+    const int M = B * T, NI = 1 + n_neg;
+    const int n_items = B * n_neg, n_index_words = B + n_items + 2 * M;
+    // folded amid_live_list_i32: straight from the image's domain words (read-only input: no ordering against the mirroring below)
+    if (live != nullptr && blockIdx.x == gridDim.x - 1) live_list_block(src + n_index_words, B, live);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < in_words; i += gridDim.x * blockDim.x) {
+        long long v = src[i];
+        in_pack[i] = v;
+        if (i < n_index_words) {
+            int dst;
+            if (i < B) dst = 2 * M + i * NI;
+            else if (i < B + n_items) { const int j = i - B; dst = 2 * M + (j / n_neg) * NI + 1 + (j % n_neg); }
+            else dst = i - B - n_items;
+            if (v < 0 || v >= n_rows) { atomicOr(err, 1); v = 0; }
+            idx_all[dst] = (int)v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicInc(&st->ticket, gridDim.x - 1) == gridDim.x - 1) st->step = t_pre + 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -314,15 +322,42 @@ extern "C" int amid_gather_rows_f32(const float* table, long long n_rows, int D,
     return AMID_OK;
 }
 
-extern "C" int amid_pack_indices(const long long* i_node, const long long* neg, const long long* seq_d1, const long long* seq_d2,
-                                 int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* step_state_to_bump,
-                                 void* stream) {
+static int pack_indices(const long long* i_node, const long long* neg, const long long* seq_d1, const long long* seq_d2,
+                        int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* step_state_to_bump,
+                        const long long* domain, int* live, void* stream) {
     AMID_CHECK_ARG(i_node && neg && seq_d1 && seq_d2 && idx_all && err_flag && B > 0 && T > 0 && n_neg >= 0);
     int n = 2 * B * T + B * (1 + n_neg);
     int blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     pack_indices_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(i_node, neg, seq_d1, seq_d2, B, T, n_neg, n_rows, idx_all, err_flag,
-                                                                  (StepState*)step_state_to_bump);
+                                                                  (StepState*)step_state_to_bump, domain, live);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_pack_indices(const long long* i_node, const long long* neg, const long long* seq_d1, const long long* seq_d2,
+                                 int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* step_state_to_bump,
+                                 void* stream) {
+    return pack_indices(i_node, neg, seq_d1, seq_d2, B, T, n_neg, n_rows, idx_all, err_flag, step_state_to_bump, nullptr, nullptr, stream);
+}
+
+// the same + amid_live_list_i32(domain, B, live) in the same launch
+extern "C" int amid_pack_indices_live(const long long* i_node, const long long* neg, const long long* seq_d1, const long long* seq_d2,
+                                      int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* step_state_to_bump,
+                                      const long long* domain, int* live, void* stream) {
+    AMID_CHECK_ARG(domain && live);
+    return pack_indices(i_node, neg, seq_d1, seq_d2, B, T, n_neg, n_rows, idx_all, err_flag, step_state_to_bump, domain, live, stream);
+}
+
+static int pack_indices_pool(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack,
+                             int in_words, int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag,
+                             void* step_state, int* live, void* stream) {
+    AMID_CHECK_ARG(pool && in_pack && idx_all && err_flag && step_state && n_pool > 0 && B > 0 && T > 0 && n_neg >= 0);
+    AMID_CHECK_ARG(in_words >= B + B * n_neg + 2 * B * T + (live ? B : 0) && pool_stride >= in_words);
+    int blocks = (in_words + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    pack_indices_pool_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(pool, pool_stride, n_pool, phase, in_pack, in_words, B, T, n_neg,
+                                                                       n_rows, idx_all, err_flag, (StepState*)step_state, live);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
@@ -330,14 +365,15 @@ extern "C" int amid_pack_indices(const long long* i_node, const long long* neg, 
 extern "C" int amid_pack_indices_pool(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack,
                                       int in_words, int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag,
                                       void* step_state, void* stream) {
-    AMID_CHECK_ARG(pool && in_pack && idx_all && err_flag && step_state && n_pool > 0 && B > 0 && T > 0 && n_neg >= 0);
-    AMID_CHECK_ARG(in_words >= B + B * n_neg + 2 * B * T && pool_stride >= in_words);
-    int blocks = (in_words + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    pack_indices_pool_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(pool, pool_stride, n_pool, phase, in_pack, in_words, B, T, n_neg,
-                                                                       n_rows, idx_all, err_flag, (StepState*)step_state);
-    AMID_LAUNCH_CHECK();
-    return AMID_OK;
+    return pack_indices_pool(pool, pool_stride, n_pool, phase, in_pack, in_words, B, T, n_neg, n_rows, idx_all, err_flag, step_state, nullptr, stream);
+}
+
+// the same + amid_live_list_i32 on the image's domain words (the B words behind the index words) in the same launch
+extern "C" int amid_pack_indices_pool_live(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack,
+                                           int in_words, int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag,
+                                           void* step_state, int* live, void* stream) {
+    AMID_CHECK_ARG(live != nullptr);
+    return pack_indices_pool(pool, pool_stride, n_pool, phase, in_pack, in_words, B, T, n_neg, n_rows, idx_all, err_flag, step_state, live, stream);
 }
 
 static int embed_fwd(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,

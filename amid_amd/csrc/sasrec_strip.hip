@@ -59,9 +59,9 @@ struct StripQkvBwdArgs {
 };
 
 template <int D>
-__device__ __forceinline__ void add_bias(f32x4 (&acc)[D / 16], const float* __restrict__ b) {
+__device__ __forceinline__ void add_bias(f32x4 (&acc)[D / 16], const ColVec<D>& b) {
 #pragma unroll
-    for (int ct = 0; ct < D / 16; ++ct) acc[ct] += col4(b, ct);
+    for (int ct = 0; ct < D / 16; ++ct) acc[ct] += b.v[ct];
 }
 template <int D>
 __device__ __forceinline__ void to_regs(StripRegs<D>& dst, const f32x4 (&acc)[D / 16]) {
@@ -69,116 +69,146 @@ __device__ __forceinline__ void to_regs(StripRegs<D>& dst, const f32x4 (&acc)[D 
     for (int ct = 0; ct < D / 16; ++ct) dst.v[ct] = acc[ct];
 }
 
-// a running two-slab ring: next(W) returns the slab whose fetch the previous call (or first()) started and starts fetching W.
-// It waits for this wave's DMAs, then meets the other waves at the workgroup barrier: the slab has landed for everybody, and
-// everybody is done reading the other buffer, which the new DMA overwrites.
+// a running two-slab ring.  next() returns the slab whose fetch was started one slab ago: it waits for this wave's DMAs, then meets
+// the other waves at the workgroup barrier -- the slab has landed for everybody, and everybody is done reading the OTHER buffer,
+// which the pieces issued from inside the coming MFMA loop (fetch()) overwrite.
 template <int D> struct Ring {
-    float* buf; int s;
+    float* buf; int s; WDma<D> dma;
     __device__ __forceinline__ explicit Ring(float* lds) : buf(lds), s(0) {}
-    __device__ __forceinline__ void first(const float* __restrict__ W0) { w_ring_issue<D>(buf, W0); }
-    __device__ __forceinline__ const float* next(const float* __restrict__ Wnext) {
+    __device__ __forceinline__ void first(const float* __restrict__ W0) { dma.all(buf, W0); }
+    __device__ __forceinline__ const float* next() {
         w_ring_wait();
         __syncthreads();
         const float* cur = buf + (s & 1) * D * D;
         ++s;
-        if (Wnext != nullptr) w_ring_issue<D>(buf + (s & 1) * D * D, Wnext);
         return cur;
+    }
+    // group (ct, j) of the current MFMA loop: this wave's share of slab W's DMA, one piece every few groups (address arithmetic and
+    // issue slide under the matrix work instead of standing in front of the loop)
+    __device__ __forceinline__ void fetch(const float* __restrict__ W, int ct, int j) const {
+        // all of them in the FIRST half of the loop: a piece takes a couple of thousand cycles to land, and the next slab starts
+        // with a wait for every one of them
+        constexpr int SLOTS = 8 * (D / 16), EVERY = (SLOTS / 2) / WDma<D>::PER_WAVE;
+        const int slot = ct * 8 + j;
+        if (slot % EVERY == 0 && slot / EVERY < WDma<D>::PER_WAVE) dma.piece(buf + (s & 1) * D * D, W, slot / EVERY);
     }
 };
 
-// stores of a finished strip leave under the FIRST half of the next MFMA loop, two column tiles per k tile: by the end of the loop
-// they have long been acknowledged, so the ring's vmcnt(0) in front of the next slab costs nothing
+// stores of a finished strip leave under the FIRST half of the next MFMA loop, one column tile every fourth group: by the end of the
+// loop they have long been acknowledged, so the ring's vmcnt(0) in front of the next slab costs nothing
 template <int D>
-__device__ __forceinline__ void store_early(const GBuf& g, const StripRow& row, const StripRegs<D>& x, int ct) {
+__device__ __forceinline__ void store_spread(const GBuf& g, const StripRow& row, const StripRegs<D>& x, int ct, int j) {
     constexpr int NT = D / 16;
-    if (ct < NT / 2) { strip_store_ct<D>(g, row, x, 2 * ct); strip_store_ct<D>(g, row, x, 2 * ct + 1); }
+    if (ct < NT / 2 && (j & 3) == 1) strip_store_ct<D>(g, row, x, 2 * ct + (j >> 2));
 }
 
 // ================================================================================================================ forward
 // q / k / v of one layer on the strip X (in registers).  The ring's current fetch must be Wk of this layer (started by the caller).
-// xstore: X is also written to a.x (a fused predecessor produced it: the saved layer input).
-template <int D>
+// XSTORE: X is also written to a.x (a fused predecessor produced it: the saved layer input).
+template <int D, bool XSTORE>
 __device__ __forceinline__ void qkv_fwd_chain(const StripQkvArgs& a, const StripGeom& sg, Ring<D>& ring, const StripRow& row, int g,
-                                              const StripRegs<D>& X, bool xstore) {
+                                              const StripRegs<D>& X, const ColVec<D>& lw, const ColVec<D>& lb) {
     constexpr int NT = D / 16;
     const GBuf gx(a.x, sg.act_bytes), gqn(a.qn, sg.act_bytes), gq(a.q, sg.act_bytes), gk(a.k, sg.act_bytes), gv(a.v, sg.act_bytes);
     StripRegs<D> Qn, Kr, Vr;
-    strip_layernorm<D>(Qn, X, a.ln_w[g], a.ln_b[g], a.ln_eps);
+    ColVec<D> bias;
+    strip_layernorm<D>(Qn, X, lw, lb, a.ln_eps);
+    STRIP_STAMP(3);
     f32x4 acc[NT];
     {   // k = x Wk^T + bk ; x's and Qn's global copies leave under these MFMAs
-        const float* buf = ring.next(a.w_in[g] + 2LL * D * D);
+        const float* buf = ring.next();
+        STRIP_STAMP(4);
+        bias.load(a.b_in[g] + D);
         strip_zero<D>(acc);
-        strip_mma<D>(acc, X, buf, [&](int ct) {
-            if (xstore) store_early<D>(gx, row, X, ct);
-            store_early<D>(gqn, row, Qn, ct);
+        strip_mma<D>(acc, X, buf, [&](int ct, int j) {
+            ring.fetch(a.w_in[g] + 2LL * D * D, ct, j);
+            if constexpr (XSTORE) store_spread<D>(gx, row, X, ct, j);
+            store_spread<D>(gqn, row, Qn, ct, j);
         });
-        add_bias<D>(acc, a.b_in[g] + D);
+        STRIP_STAMP(5);
+        add_bias<D>(acc, bias);
         to_regs<D>(Kr, acc);
+        STRIP_STAMP(6);
     }
     {   // v = x Wv^T + bv
-        const float* buf = ring.next(a.w_in[g]);
+        const float* buf = ring.next();
+        STRIP_STAMP(7);
+        bias.load(a.b_in[g] + 2 * D);
         strip_zero<D>(acc);
-        strip_mma<D>(acc, X, buf, [&](int ct) { store_early<D>(gk, row, Kr, ct); });
-        add_bias<D>(acc, a.b_in[g] + 2 * D);
+        strip_mma<D>(acc, X, buf, [&](int ct, int j) { ring.fetch(a.w_in[g], ct, j); store_spread<D>(gk, row, Kr, ct, j); });
+        STRIP_STAMP(8);
+        add_bias<D>(acc, bias);
         to_regs<D>(Vr, acc);
     }
     {   // q = Qn Wq^T + bq
-        const float* buf = ring.next(nullptr);
+        const float* buf = ring.next();
+        STRIP_STAMP(9);
+        bias.load(a.b_in[g]);
         strip_zero<D>(acc);
-        strip_mma<D>(acc, Qn, buf, [&](int ct) { store_early<D>(gv, row, Vr, ct); });
-        add_bias<D>(acc, a.b_in[g]);
+        strip_mma<D>(acc, Qn, buf, [&](int ct, int j) { store_spread<D>(gv, row, Vr, ct, j); });
+        STRIP_STAMP(10);
+        add_bias<D>(acc, bias);
         to_regs<D>(Kr, acc);
         strip_store<D>(gq, row, Kr);
+        STRIP_STAMP(11);
     }
 }
 
 template <int D>
 __global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_fwd_kernel(const StripQkvArgs a, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const StripTile t = strip_tile(sg, blockIdx.x);
-    if (!t.live) return;
-    const StripRow row = strip_row<D>(sg, t);
+    STRIP_STAMP(0);
     Ring<D> ring(smem);
-    ring.first(a.w_in[t.g] + 1LL * D * D);
+    ring.first(a.w_in[strip_domain(blockIdx.x)] + 1LL * D * D);
+    const StripTile t = strip_tile(sg, blockIdx.x);
+    if (!t.live) { w_ring_wait(); return; }
+    const StripRow row = strip_row<D>(sg, t);
+    STRIP_STAMP(1);
     StripRegs<D> X;
+    ColVec<D> lw, lb;
     strip_load<D>(X, GBuf(a.x, sg.act_bytes), row);
-    qkv_fwd_chain<D>(a, sg, ring, row, t.g, X, false);
+    lw.load(a.ln_w[t.g]); lb.load(a.ln_b[t.g]);
+    STRIP_STAMP(2);
+    qkv_fwd_chain<D, false>(a, sg, ring, row, t.g, X, lw, lb);
 }
 
 template <int D, bool NEXT>
 __global__ __launch_bounds__(STRIP_THREADS) void strip_oproj_ffn_fwd_kernel(const StripOffArgs a, const StripQkvArgs nx, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = D / 16;
+    Ring<D> ring(smem);
+    ring.first(a.w_o[strip_domain(blockIdx.x)]);
     const StripTile t = strip_tile(sg, blockIdx.x);
-    if (!t.live) return;
+    if (!t.live) { w_ring_wait(); return; }
     const StripRow row = strip_row<D>(sg, t);
     const int g = t.g;
-    Ring<D> ring(smem);
-    ring.first(a.w_o[g]);
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
     const GBuf gr(a.r, sg.act_bytes), gy(a.y, sg.act_bytes), gh(a.h, sg.act_bytes), gxo(a.xo, sg.act_bytes);
     StripRegs<D> A, R, Y, H;
     StripTm<D> tm;
+    ColVec<D> bias, lw, lb;
     strip_load<D>(A, GBuf(a.o, sg.act_bytes), row);
     strip_load<D>(R, GBuf(a.qn, sg.act_bytes), row);                   // the residual: the NORMED query (model_seq.py:378)
     const bool has_tm = a.tmq != nullptr;
     if (has_tm) strip_tm_load<D>(tm, GBuf(a.tmq, sg.tm_bytes), row);
+    bias.load(a.b_o[g]); lw.load(a.ln_w[g]); lb.load(a.ln_b[g]);
     f32x4 acc[NT];
     {   // r = Qn + (o Wo^T + bo) ; y = LN2(r)
-        const float* buf = ring.next(a.w1[g]);
+        const float* buf = ring.next();
         strip_zero<D>(acc);
-        strip_mma<D>(acc, A, buf);
-        add_bias<D>(acc, a.b_o[g]);
+        strip_mma<D>(acc, A, buf, [&](int ct, int j) { ring.fetch(a.w1[g], ct, j); });
+        add_bias<D>(acc, bias);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) R.v[ct] += acc[ct];
-        strip_layernorm<D>(Y, R, a.ln_w[g], a.ln_b[g], a.ln_eps);
+        strip_layernorm<D>(Y, R, lw, lb, a.ln_eps);
     }
     {   // h = relu(drop1(y C1^T + c1))
-        const float* buf = ring.next(a.w2[g]);
+        const float* buf = ring.next();
+        bias.load(a.b1[g]);
         strip_zero<D>(acc);
-        strip_mma<D>(acc, Y, buf, [&](int ct) { store_early<D>(gr, row, R, ct); });
-        add_bias<D>(acc, a.b1[g]);
+        strip_mma<D>(acc, Y, buf, [&](int ct, int j) { ring.fetch(a.w2[g], ct, j); store_spread<D>(gr, row, R, ct, j); });
+        add_bias<D>(acc, bias);
         to_regs<D>(H, acc);
         if (a.train) strip_dropout<D>(H, seed, site_id(g, a.layer, SITE_FFN1), step, row.local, a.spec, a.scale);
 #pragma unroll
@@ -187,10 +217,16 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_oproj_ffn_fwd_kernel(cons
             for (int r = 0; r < 4; ++r) H.v[ct][r] = fmaxf(H.v[ct][r], 0.f);
     }
     {   // x' = (drop2(h C2^T + c2) + y) * ~tm
-        const float* buf = ring.next(NEXT ? nx.w_in[g] + 1LL * D * D : nullptr);
+        const float* buf = ring.next();
+        bias.load(a.b2[g]);
+        if constexpr (NEXT) { lw.load(nx.ln_w[g]); lb.load(nx.ln_b[g]); }
         strip_zero<D>(acc);
-        strip_mma<D>(acc, H, buf, [&](int ct) { store_early<D>(gy, row, Y, ct); store_early<D>(gh, row, H, ct); });
-        add_bias<D>(acc, a.b2[g]);
+        strip_mma<D>(acc, H, buf, [&](int ct, int j) {
+            if constexpr (NEXT) ring.fetch(nx.w_in[g] + 1LL * D * D, ct, j);
+            store_spread<D>(gy, row, Y, ct, j);
+            if (ct < NT / 2 && (j & 3) == 3) strip_store_ct<D>(gh, row, H, 2 * ct + (j >> 2));
+        });
+        add_bias<D>(acc, bias);
         to_regs<D>(A, acc);
         if (a.train) strip_dropout<D>(A, seed, site_id(g, a.layer, SITE_FFN2), step, row.local, a.spec, a.scale);
 #pragma unroll
@@ -198,7 +234,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_oproj_ffn_fwd_kernel(cons
         if (has_tm) strip_apply_tm<D>(A, tm);
     }
     if constexpr (NEXT) {
-        qkv_fwd_chain<D>(nx, sg, ring, row, g, A, true);
+        qkv_fwd_chain<D, true>(nx, sg, ring, row, g, A, lw, lb);
     } else {
         strip_store<D>(gxo, row, A);
     }
@@ -207,17 +243,16 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_oproj_ffn_fwd_kernel(cons
 // ================================================================================================================ backward
 // LayerNorm backward of the strip: dx = LN'(dy ; x, gamma); this lane's row adds dy * xhat / dy to the column partials
 template <int D>
-__device__ __forceinline__ void strip_ln_bwd(StripRegs<D>& dx, const StripRegs<D>& dy, const StripRegs<D>& x, const float* __restrict__ gam,
+__device__ __forceinline__ void strip_ln_bwd(StripRegs<D>& dx, const StripRegs<D>& dy, const StripRegs<D>& x, const ColVec<D>& gam,
                                              float eps, StripRegs<D>& dgam, StripRegs<D>& dbet) {
     float mean, rstd;
     strip_stats<D>(x, eps, mean, rstd);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int ct = 0; ct < D / 16; ++ct) {
-        const f32x4 gg = col4(gam, ct);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float xh = (x.v[ct][r] - mean) * rstd, gy = gg[r] * dy.v[ct][r];
+            const float xh = (x.v[ct][r] - mean) * rstd, gy = gam.v[ct][r] * dy.v[ct][r];
             s1 += gy;
             s2 = fmaf(gy, xh, s2);
             dgam.v[ct][r] = dy.v[ct][r] * xh;          // first (and only) row of this lane
@@ -261,12 +296,13 @@ __device__ __forceinline__ void ln_partials_out(const float* __restrict__ scratc
 // LDS: [ring: 2 slabs][LayerNorm-partial scratch A: 4 x 2 x D][scratch B: 4 x 2 x D]
 template <int D> __device__ __forceinline__ float* ln_scratch(float* smem, int which) { return smem + 2 * D * D + which * 8 * D; }
 
-// the loads the feed-forward backward needs first (relu output, "== 0" bits): issued by the caller a slab ahead of the chain
-template <int D> struct FfnBwdPre { StripRegs<D> Hs; StripTm<D> tm; };
+// the loads the feed-forward backward needs first (relu output, "== 0" bits, LayerNorm gain): issued by the caller a slab ahead
+template <int D> struct FfnBwdPre { StripRegs<D> Hs; StripTm<D> tm; ColVec<D> gam; };
 template <int D>
-__device__ __forceinline__ void ffn_bwd_prefetch(FfnBwdPre<D>& p, const StripFfnBwdArgs& a, const StripGeom& sg, const StripRow& row) {
+__device__ __forceinline__ void ffn_bwd_prefetch(FfnBwdPre<D>& p, const StripFfnBwdArgs& a, const StripGeom& sg, const StripRow& row, int g) {
     strip_load<D>(p.Hs, GBuf(a.h, sg.act_bytes), row);
     if (a.tmq != nullptr) strip_tm_load<D>(p.tm, GBuf(a.tmq, sg.tm_bytes), row);
+    p.gam.load(a.ln_w[g]);
 }
 
 // d x' (DZ, in registers) -> dpre2, dpre1, dr, d_o of this layer; the ring's current fetch must be w2T
@@ -285,10 +321,10 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
     if (a.train) strip_dropout<D>(P, seed, site_id(g, a.layer, SITE_FFN2), step, row.local, a.spec, a.scale);
     f32x4 acc[NT];
     {   // dh = dpre2 C2 ; dpre1 = dh * relu'(h) * drop1   (h > 0 implies the unit was kept by drop1)
-        const float* buf = ring.next(a.w1T[g]);
+        const float* buf = ring.next();
         strip_load<D>(Rs, GBuf(a.r, sg.act_bytes), row);               // LN2 input rows: needed two slabs from now
         strip_zero<D>(acc);
-        strip_mma<D>(acc, P, buf, [&](int ct) { store_early<D>(gp2, row, P, ct); });
+        strip_mma<D>(acc, P, buf, [&](int ct, int j) { ring.fetch(a.w1T[g], ct, j); store_spread<D>(gp2, row, P, ct, j); });
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -296,54 +332,56 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
     }
     StripRegs<D> DR, dgam, dbet;
     {   // dy = dpre1 C1 + dz ; dr = LN2'(dy ; r)
-        const float* buf = ring.next(a.woT[g]);
+        const float* buf = ring.next();
         strip_zero<D>(acc);
-        strip_mma<D>(acc, P, buf, [&](int ct) { store_early<D>(gp1, row, P, ct); });
+        strip_mma<D>(acc, P, buf, [&](int ct, int j) { ring.fetch(a.woT[g], ct, j); store_spread<D>(gp1, row, P, ct, j); });
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) Hs.v[ct] = acc[ct] + DZ.v[ct];
-        strip_ln_bwd<D>(DR, Hs, Rs, a.ln_w[g], a.ln_eps, dgam, dbet);
+        strip_ln_bwd<D>(DR, Hs, Rs, pre.gam, a.ln_eps, dgam, dbet);
     }
     {   // d_o = dr Wo
-        const float* buf = ring.next(nullptr);
+        const float* buf = ring.next();
         strip_zero<D>(acc);
-        strip_mma<D>(acc, DR, buf, [&](int ct) { store_early<D>(gdr, row, DR, ct); });
+        strip_mma<D>(acc, DR, buf, [&](int ct, int j) { store_spread<D>(gdr, row, DR, ct, j); });
         to_regs<D>(P, acc);
         strip_store<D>(gdo, row, P);
     }
     ln_partials_wave<D>(scratch, dgam, dbet);
 }
 
-// dq, dk, dv, dr of a layer -> d x (left in DX); the ring's current fetch must be wkT.  `tail`: the slab to fetch behind wqT;
+// dq, dk, dv, dr of a layer -> d x (left in DX); the ring's current fetch must be wkT.  TAIL: a slab (`tail`) is fetched behind wqT;
 // `before_last()` runs in front of the last MFMA loop (a fused successor issues its first loads there).
-template <int D, class Hook>
+template <int D, bool TAIL, class Hook>
 __device__ __forceinline__ void qkv_bwd_chain(const StripQkvBwdArgs& a, const StripGeom& sg, Ring<D>& ring, const StripRow& row, int g,
                                               StripRegs<D>& DX, float* __restrict__ scratch, const float* __restrict__ tail, const Hook& before_last) {
     constexpr int NT = D / 16;
     StripRegs<D> Dk, Dv, Dq, Drs, Xs;
+    ColVec<D> gam;
     strip_load<D>(Dk, GBuf(a.dk, sg.act_bytes), row);
     strip_load<D>(Dv, GBuf(a.dv, sg.act_bytes), row);
     f32x4 acc_kv[NT], acc[NT];
     strip_zero<D>(acc_kv);
     {   // dk Wk          (every operand is requested one slab ahead of its use: the loads fly under the MFMAs in between)
-        const float* buf = ring.next(a.wvT[g]);
+        const float* buf = ring.next();
         strip_load<D>(Dq, GBuf(a.dq, sg.act_bytes), row);
-        strip_mma<D>(acc_kv, Dk, buf);
+        strip_mma<D>(acc_kv, Dk, buf, [&](int ct, int j) { ring.fetch(a.wvT[g], ct, j); });
     }
     {   // + dv Wv
-        const float* buf = ring.next(a.wqT[g]);
+        const float* buf = ring.next();
         strip_load<D>(Drs, GBuf(a.dr, sg.act_bytes), row);             // residual-path gradient of the normed query
         strip_load<D>(Xs, GBuf(a.x, sg.act_bytes), row);               // LN1 input rows
-        strip_mma<D>(acc_kv, Dv, buf);
+        gam.load(a.ln_w[g]);
+        strip_mma<D>(acc_kv, Dv, buf, [&](int ct, int j) { ring.fetch(a.wqT[g], ct, j); });
     }
     StripRegs<D> dgam, dbet;
     {   // dqn = dq Wq + dr ; dx = LN1'(dqn ; x) + (dk Wk + dv Wv)
-        const float* buf = ring.next(tail);
+        const float* buf = ring.next();
         before_last();
         strip_zero<D>(acc);
-        strip_mma<D>(acc, Dq, buf);
+        strip_mma<D>(acc, Dq, buf, [&](int ct, int j) { if constexpr (TAIL) ring.fetch(tail, ct, j); });
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) Drs.v[ct] += acc[ct];
-        strip_ln_bwd<D>(DX, Drs, Xs, a.ln_w[g], a.ln_eps, dgam, dbet);
+        strip_ln_bwd<D>(DX, Drs, Xs, gam, a.ln_eps, dgam, dbet);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) DX.v[ct] += acc_kv[ct];
     }
@@ -358,15 +396,15 @@ __device__ __forceinline__ void zero_slot(float* __restrict__ part, int slot) {
 template <int D>
 __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const StripFfnBwdArgs a, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const StripTile t = strip_tile(sg, blockIdx.x);
-    if (!t.live) { zero_slot<D>(a.ln_part, t.slot); return; }
-    const StripRow row = strip_row<D>(sg, t);
     Ring<D> ring(smem);
-    ring.first(a.w2T[t.g]);
+    ring.first(a.w2T[strip_domain(blockIdx.x)]);
+    const StripTile t = strip_tile(sg, blockIdx.x);
+    if (!t.live) { zero_slot<D>(a.ln_part, t.slot); w_ring_wait(); return; }
+    const StripRow row = strip_row<D>(sg, t);
     StripRegs<D> DZ;
     FfnBwdPre<D> pre;
     strip_load<D>(DZ, GBuf(a.dxo, sg.act_bytes), row);
-    ffn_bwd_prefetch<D>(pre, a, sg, row);
+    ffn_bwd_prefetch<D>(pre, a, sg, row, t.g);
     ffn_bwd_chain<D>(a, sg, ring, row, t.g, DZ, pre, ln_scratch<D>(smem, 0));
     __syncthreads();
     ln_partials_out<D>(ln_scratch<D>(smem, 0), a.ln_part + (long long)t.slot * 2 * D);
@@ -376,22 +414,23 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const Stri
 template <int D, bool FFN>
 __global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const StripQkvBwdArgs a, const StripFfnBwdArgs f, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    Ring<D> ring(smem);
+    ring.first(a.wkT[strip_domain(blockIdx.x)]);
     const StripTile t = strip_tile(sg, blockIdx.x);
     if (!t.live) {
         zero_slot<D>(a.ln_part, t.slot);
         if constexpr (FFN) zero_slot<D>(f.ln_part, t.slot);
+        w_ring_wait();
         return;
     }
     const StripRow row = strip_row<D>(sg, t);
-    Ring<D> ring(smem);
-    ring.first(a.wkT[t.g]);
     StripRegs<D> DX;
     if constexpr (FFN) {
         FfnBwdPre<D> pre;
-        qkv_bwd_chain<D>(a, sg, ring, row, t.g, DX, ln_scratch<D>(smem, 0), f.w2T[t.g], [&]() { ffn_bwd_prefetch<D>(pre, f, sg, row); });
+        qkv_bwd_chain<D, true>(a, sg, ring, row, t.g, DX, ln_scratch<D>(smem, 0), f.w2T[t.g], [&]() { ffn_bwd_prefetch<D>(pre, f, sg, row, t.g); });
         ffn_bwd_chain<D>(f, sg, ring, row, t.g, DX, pre, ln_scratch<D>(smem, 1));
     } else {
-        qkv_bwd_chain<D>(a, sg, ring, row, t.g, DX, ln_scratch<D>(smem, 0), nullptr, []() {});
+        qkv_bwd_chain<D, false>(a, sg, ring, row, t.g, DX, ln_scratch<D>(smem, 0), nullptr, []() {});
         strip_store<D>(GBuf(a.dx, sg.act_bytes), row, DX);
     }
     __syncthreads();
@@ -430,6 +469,12 @@ static int launch_strip(const StripGeom& sg, void* stream, const Args&... args) 
 }
 
 extern "C" int amid_sas_strip_tile_rows(void) { return STRIP_TILE; }
+
+#ifdef AMID_STRIP_STAMPS
+extern "C" int amid_strip_stamps_read(unsigned long long* host) {       // diagnostic library only
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_strip_stamp_buf), sizeof(unsigned long long) * STRIP_STAMP_WAVES * 32);
+}
+#endif
 
 extern "C" int amid_sas_strip_qkv_fwd_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
                                           const float* const* b_in, float ln_eps, int B, int T, int D, const int* live, float* qn, float* q,

@@ -28,7 +28,18 @@
 #include "common.h"
 #include "rng.h"
 
+#define STRIP_STAMP_WAVES 4
+
 namespace amid {
+
+// diagnostic builds only (profiles/tools/strip_stamps.py compiles sasrec_strip.hip with -DAMID_STRIP_STAMPS into its own library):
+// s_memtime stamps of workgroup 0, one row of 32 per wave, in a buffer no kernel reads
+#ifdef AMID_STRIP_STAMPS
+__device__ unsigned long long amid_strip_stamp_buf[STRIP_STAMP_WAVES * 32];
+#define STRIP_STAMP(i) do { if (blockIdx.x == 0 && lane_id() == 0) amid_strip_stamp_buf[wave_id() * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STRIP_STAMP(i) do { } while (0)
+#endif
 
 constexpr int STRIP_WAVES = 4;
 constexpr int STRIP_THREADS = 64 * STRIP_WAVES;
@@ -51,29 +62,26 @@ struct StripGeom {
 
 struct StripTile { int g, slot, v0, nv, s0; bool live; };     // domain, partial slot, first virtual row, virtual rows of the domain, first entry of the live list
 
+// Workgroup -> (domain, tile) straight from the workgroup index: even workgroups walk domain 0, odd ones domain 1, so the weight
+// pointers and the first slab's DMA need no load of the live list (two dependent global loads that used to stand in front of
+// everything else); a workgroup whose tile lies past its domain's live rows finds out AFTER it has started the DMA -- it waits for
+// the DMA (the LDS it targets dies with the workgroup) and leaves.  With the domains interleaved the live tiles of an even split
+// are the first workgroups dispatched.
+__device__ __forceinline__ int strip_domain(int tile) { return tile & 1; }
 __device__ __forceinline__ StripTile strip_tile(const StripGeom& sg, int tile) {
     StripTile t;
-    t.live = true; t.s0 = 0;
-    if (sg.live == nullptr) {
-        t.g = tile / sg.tpg;
-        const int tl = tile - t.g * sg.tpg;
-        t.slot = tile; t.v0 = tl * STRIP_TILE; t.nv = sg.M;
-        return t;
-    }
-    const int n0 = sg.live[sg.B], n1 = sg.B - n0;
-    const int t0 = (n0 * sg.T + STRIP_TILE - 1) / STRIP_TILE, t1 = (n1 * sg.T + STRIP_TILE - 1) / STRIP_TILE;
-    int tl;
-    if (tile < t0) { t.g = 0; tl = tile; }
-    else if (tile < t0 + t1) { t.g = 1; tl = tile - t0; }
-    else {                                          // a slot no live tile fills
-        t.live = false;
-        const int d = tile - t0 - t1;
-        if (d < sg.tpg - t0) { t.g = 0; tl = t0 + d; } else { t.g = 1; tl = t1 + d - (sg.tpg - t0); }
-    }
+    t.g = tile & 1;
+    const int tl = tile >> 1;
     t.slot = t.g * sg.tpg + tl;
     t.v0 = tl * STRIP_TILE;
-    t.nv = (t.g ? n1 : n0) * sg.T;
-    t.s0 = t.g ? n0 : 0;
+    t.s0 = 0;
+    t.nv = sg.M;
+    if (sg.live != nullptr) {
+        const int n0 = sg.live[sg.B];
+        t.nv = (t.g ? sg.B - n0 : n0) * sg.T;
+        t.s0 = t.g ? n0 : 0;
+    }
+    t.live = t.v0 < t.nv;
     return t;
 }
 
@@ -140,6 +148,15 @@ __device__ __forceinline__ f32x4 col4(const float* __restrict__ p, int ct) {
     return f32x4{v.x, v.y, v.z, v.w};
 }
 
+// a whole per-column vector in the strip's column layout, requested ahead of its use
+template <int D> struct ColVec {
+    f32x4 v[D / 16];
+    __device__ __forceinline__ void load(const float* __restrict__ p) {
+#pragma unroll
+        for (int ct = 0; ct < D / 16; ++ct) v[ct] = col4(p, ct);
+    }
+};
+
 // sum over the 4 lanes (m, 0..3) that share a row
 __device__ __forceinline__ float row_sum4(float v) {
     v += __shfl_xor(v, 16, 64);
@@ -174,6 +191,16 @@ __device__ __forceinline__ void strip_layernorm(StripRegs<D>& y, const StripRegs
 #pragma unroll
         for (int r = 0; r < 4; ++r) y.v[ct][r] = (x.v[ct][r] - mean) * rstd * ww[r] + bb[r];
     }
+}
+
+template <int D>
+__device__ __forceinline__ void strip_layernorm(StripRegs<D>& y, const StripRegs<D>& x, const ColVec<D>& w, const ColVec<D>& b, float eps) {
+    float mean, rstd;
+    strip_stats<D>(x, eps, mean, rstd);
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y.v[ct][r] = (x.v[ct][r] - mean) * rstd * w.v[ct][r] + b.v[ct][r];
 }
 
 // ---- dropout on a strip ---------------------------------------------------------------------------------------------------------
@@ -234,25 +261,46 @@ __device__ __forceinline__ void strip_apply_tm(StripRegs<D>& x, const StripTm<D>
 // position (64 k + L) % (D / 4) of row (64 k + L) / (D / 4), so it must FETCH chunk position ^ (row & 15).
 // A ds_read_b128 is served in 4 groups of 16 lanes; the 16 lanes of a group read 16 different n (mod 16) at chunk 4 ct + g with two
 // values of g: positions (4 ct + g) ^ i cover all 16 slots of the 256-byte bank window exactly once (strip_mma below).
-template <int D>
-__device__ __forceinline__ void w_ring_issue(float* __restrict__ buf, const float* __restrict__ W) {
-    constexpr int CPR = D / 4;                        // chunks per row
-    constexpr int PIECES = D * CPR / 64;
-    const int lane = lane_id(), w = wave_id();
+// this wave's pieces are k = 4 k0 + wave, k0 < WDma::PER_WAVE; the per-lane source offsets repeat with period 2 in k0 (the row advances
+// by 256 / CPR per k0 step: n & 15 flips bit 3 at D = 128 and does not change at D = 64), so two offsets + a stride describe them all
+template <int D> struct WDma {
+    static constexpr int CPR = D / 4;                 // 16-byte chunks per row
+    static constexpr int PER_WAVE = D * CPR / 64 / STRIP_WAVES;
+    static constexpr unsigned STRIDE2 = 2u * (256 / CPR) * D * 4;      // bytes between pieces k0 and k0 + 2
+    unsigned off[2];
+    int w;
+    __device__ __forceinline__ WDma() {
+        const int lane = lane_id();
+        w = wave_id();
 #pragma unroll
-    for (int k0 = 0; k0 < PIECES; k0 += STRIP_WAVES) {
-        const int k = k0 + w;
-        const int p = k * 64 + lane;
-        const int n = p / CPR, pos = p % CPR;
-        const int c = pos ^ (n & 15);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + n * D + c * 4),
-                                         (__attribute__((address_space(3))) void*)(buf + k * 256), 16, 0, 0);
+        for (int k0 = 0; k0 < 2; ++k0) {
+            const int p = (k0 * STRIP_WAVES + w) * 64 + lane;
+            const int n = p / CPR, pos = p % CPR;
+            off[k0] = (unsigned)((n * D + ((pos ^ (n & 15)) * 4)) * 4);
+        }
     }
-}
+    // One piece as INLINE ASM: beside a compiler-visible LDS-DMA hipcc waits lgkmcnt(0) in front of every MFMA group that follows a
+    // fragment read (it cannot order the DMA's LDS write against ds_reads by a count), i.e. right behind the read it has just issued:
+    // a full LDS latency per k tile.  The asm is invisible to its counters -- completion is waited for by w_ring_wait() (vmcnt(0))
+    // + the workgroup barrier in front of the slab's first read; a compiler wait vmcnt(N) for an older ordinary load only becomes
+    // stricter by the uncounted pieces.  M0 (the DMA's LDS base) is saved and restored inside the statement.
+    __device__ __forceinline__ void piece(float* __restrict__ buf, const float* __restrict__ W, int k0) const {
+        const unsigned voff = off[k0 & 1] + (unsigned)(k0 >> 1) * STRIDE2;
+        const unsigned lds = __builtin_amdgcn_readfirstlane(
+            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(buf + (k0 * STRIP_WAVES + w) * 256));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
+    }
+    __device__ __forceinline__ void all(float* __restrict__ buf, const float* __restrict__ W) const {
+#pragma unroll
+        for (int k0 = 0; k0 < PER_WAVE; ++k0) piece(buf, W, k0);
+    }
+};
 // every DMA (and every other vector-memory operation) of this wave has completed
 __device__ __forceinline__ void w_ring_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-struct NoDeferred { __device__ __forceinline__ void operator()(int) const {} };
+struct NoDeferred { __device__ __forceinline__ void operator()(int, int) const {} };
 
 // acc[co] += sum_k A[.][k] W[co * 16 + .][k] over the whole K = D of the slab in `buf`; `deferred(ct)` is called once per k tile,
 // behind its MFMAs (stores of an earlier epilogue drain under the matrix work)
@@ -261,9 +309,12 @@ struct NoDeferred { __device__ __forceinline__ void operator()(int) const {} };
 // rate, plus an exposed LDS latency per read: measured 2x the time).  So the loop is written as groups of NT / 2 MFMAs on DIFFERENT
 // accumulators + one fragment read of the NEXT k tile, with a scheduling barrier behind every group that MFMA and LDS instructions
 // may not cross (VALU / SALU / VMEM may: epilogue arithmetic and stores of neighbouring code still slide under the matrix work).
-#define AMID_STRIP_FENCE() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x20 | 0x40 | 0x400)
-template <int D, class Deferred = NoDeferred>
-__device__ __forceinline__ void strip_mma(f32x4 (&acc)[D / 16], const StripRegs<D>& A, const float* __restrict__ buf, const Deferred& deferred = NoDeferred()) {
+#define AMID_STRIP_FENCE() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400)
+// `hook(ct, j)` runs behind group j of k tile ct (8 groups per k tile): deferred stores of an earlier epilogue, the DMA pieces of the
+// next weight slab -- vector-memory instructions stay where they are written (they may not cross the fences either: a load placed
+// in front of the loop is in flight during the loop, a store placed in group j is issued there)
+template <int D, class Hook = NoDeferred>
+__device__ __forceinline__ void strip_mma(f32x4 (&acc)[D / 16], const StripRegs<D>& A, const float* __restrict__ buf, const Hook& hook = NoDeferred()) {
     constexpr int NT = D / 16, HALF = NT / 2;
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;
@@ -287,9 +338,9 @@ __device__ __forceinline__ void strip_mma(f32x4 (&acc)[D / 16], const StripRegs<
                 acc[c0 + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, A.v[ct][r], acc[c0 + c], 0, 0, 0);
             }
             if (ct + 1 < NT && j < NT) wf[(ct + 1) & 1][j] = ld4(nxt + j * 16 * D);
+            hook(ct, j);
             AMID_STRIP_FENCE();
         }
-        deferred(ct);
     }
 }
 
@@ -298,21 +349,5 @@ __device__ __forceinline__ void strip_zero(f32x4 (&acc)[D / 16]) {
 #pragma unroll
     for (int ct = 0; ct < D / 16; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-
-// the ring's control flow for a kernel that multiplies by slabs W_0 .. W_{S-1} in order:
-//   ring.first(W_0);  for s: ring.acquire(s, W_{s+1} or nullptr) -> pointer to slab s;  ... strip_mma(.., that pointer) ...
-// acquire() waits for this wave's DMAs, meets the other waves at the workgroup barrier (slab s has landed for everybody, and
-// everybody is done reading slab s - 1, whose buffer the next DMA overwrites) and starts the DMA of slab s + 1.
-template <int D> struct WRing {
-    float* buf;
-    __device__ __forceinline__ explicit WRing(float* lds) : buf(lds) {}
-    __device__ __forceinline__ void first(const float* __restrict__ W0) { w_ring_issue<D>(buf, W0); }
-    __device__ __forceinline__ const float* acquire(int s, const float* __restrict__ Wnext) {
-        w_ring_wait();
-        __syncthreads();
-        if (Wnext != nullptr) w_ring_issue<D>(buf + ((s + 1) & 1) * D * D, Wnext);
-        return buf + (s & 1) * D * D;
-    }
-};
 
 }  // namespace amid

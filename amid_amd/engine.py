@@ -593,23 +593,37 @@ class SasrecEngine:
         kernel.  (In the captured graph the branch that is enqueued first is dispatched first: with the sort ahead of the catch-up
         kernel the latter started ~20 us late in every replay.)"""
         L, s, shp = lib(), self.s, pl.shape
+        # a train step (bump_step) of a loss that masks the other domain of every sample: the batch's live-sequence list
+        # (amid_live_list_i32) rides in the packing launch; enqueue_forward then finds it in place (pl.live_packed)
+        with_live = bool(bump_step and getattr(pl, "strip", False) and not self.itc_bs)
+        pl.live_packed = with_live
         ent = self.input_pool(pl)
         if ent is not None:
             pool, phase = ent
             if not bump_step:
                 raise ValueError("an input pool advances with the step counter: enqueue_prepare(bump_step=True) only")
-            L.call("amid_pack_indices_pool", pool.data_ptr(), pool.stride(0), pool.shape[0], phase, pl.in_pack.data_ptr(),
-                   pl.in_words, shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
-                   self.step_state.data_ptr(), s)
+            if with_live:
+                L.call("amid_pack_indices_pool_live", pool.data_ptr(), pool.stride(0), pool.shape[0], phase, pl.in_pack.data_ptr(),
+                       pl.in_words, shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
+                       self.step_state.data_ptr(), pl.live.data_ptr(), s)
+            else:
+                L.call("amid_pack_indices_pool", pool.data_ptr(), pool.stride(0), pool.shape[0], phase, pl.in_pack.data_ptr(),
+                       pl.in_words, shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
+                       self.step_state.data_ptr(), s)
             self.step += 1
             if sparse:
                 self.ev_idx.record(self.stream)
                 if not defer_sort:
                     self.enqueue_sort(pl)
             return
-        L.call("amid_pack_indices", pl.in_i_node.data_ptr(), pl.in_neg.data_ptr(), pl.in_seq_d1.data_ptr(), pl.in_seq_d2.data_ptr(),
-               shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
-               self.step_state.data_ptr() if bump_step else None, s)
+        if with_live:
+            L.call("amid_pack_indices_live", pl.in_i_node.data_ptr(), pl.in_neg.data_ptr(), pl.in_seq_d1.data_ptr(), pl.in_seq_d2.data_ptr(),
+                   shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
+                   self.step_state.data_ptr() if bump_step else None, pl.domain.data_ptr(), pl.live.data_ptr(), s)
+        else:
+            L.call("amid_pack_indices", pl.in_i_node.data_ptr(), pl.in_neg.data_ptr(), pl.in_seq_d1.data_ptr(), pl.in_seq_d2.data_ptr(),
+                   shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
+                   self.step_state.data_ptr() if bump_step else None, s)
         if bump_step:
             self.step += 1
         if sparse:
@@ -649,7 +663,7 @@ class SasrecEngine:
         lv = self._live_list(pl)
         live_fwd = lv is not None and getattr(self, "_live_fwd", False)
         lf = lv if live_fwd else None
-        if lv is not None:
+        if lv is not None and not getattr(pl, "live_packed", False):
             L.call("amid_live_list_i32", pl.domain.data_ptr(), B, pl.live.data_ptr(), s)
         if self.inc_bs:      # plain gather, InnerComp's token group, then the 2T-token encoder input (csrc/innercomp.hip)
             L.call("amid_gather_rows_f32", self.table.data_ptr(), self.n_rows, D, pl.idx_all.data_ptr(), 0, shp.n_idx, pl.xg.data_ptr(), None, s)

@@ -507,6 +507,14 @@ int amid_sas_qkv_ffn_bwd_rows_f32_rt3(const float* dq, const float* dk, const fl
  * domain 0's live sequences ascending, then domain 1's, then n0); the *_live / *_own entry points walk that list only and leave
  * every row of the other sequences untouched.  model.forward (which returns both domains' logits) never uses them. */
 int amid_live_list_i32(const long long* domain, int B, int* live, void* stream);
+/* amid_pack_indices / amid_pack_indices_pool with the live list written by the same launch (the pool images carry the batch's
+ * domain ids in the B words behind the index words: SasrecEngine.pack_batch) */
+int amid_pack_indices_live(const long long* i_node, const long long* neg, const long long* seq_d1, const long long* seq_d2, int B, int T,
+                           int n_neg, long long n_rows, int* idx_all, int* err_flag, void* step_state_to_bump, const long long* domain,
+                           int* live, void* stream);
+int amid_pack_indices_pool_live(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack,
+                                int in_words, int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* step_state,
+                                int* live, void* stream);
 int amid_embed_fwd_live_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
                             int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
                             const int* live, void* stream);
