@@ -1,0 +1,460 @@
+// The whole SASRec encoder forward of a sequence in ONE launch: for every layer LayerNorm1 + q / k / v projections, the causal
+// multi-head attention core, out-projection + residual + LayerNorm2 + point-wise feed-forward -- the register-resident strip chains
+// of sasrec_strip.hip with the attention core of attention_mfma.hip between them, nothing but the saved activations leaving the chip.
+// Reference: Log2feats.forward model_seq.py:371-383 with nn.MultiheadAttention as called at :374 (softmax((q sqrt(1/hd)) k^T +
+// causal(-inf)) -> dropout(p) -> . v) and PointWiseFeedForward :322-326.
+//
+// Why it fits: in the strip layout a wave's accumulators are the next product's operand, and that holds for the attention core as well.
+//   * the tile is sequence-aligned: a workgroup (4 waves) owns 4 / WPS sequences, WPS = 1, 2 or 4 waves (16-row strips) per sequence
+//     (T <= 16 / 32 / 64); wave (sq, si) holds query rows 16 si .. 16 si + 15 of its sequence.
+//   * S = Qs K^T for the wave's 16 queries and key tile kt <= si: second operand = the q accumulators of head h as they stand
+//     (C layout: lane (m, g) register r = q[m][16 h + 4 g + r]), first operand = 16 K rows read from an LDS image with one
+//     ds_read_b128 per 4 MFMAs -> lane (m, g) holds S[m][16 kt + 4 g + r]: the softmax is in-lane + two shuffles.
+//   * O = P~ V: the P~ registers are the second operand (lane group g supplies key 4 g + r), V^T comes from the LDS image as dwords;
+//     the result lands as lane (m, g) register r = O[m][16 h + 4 g + r] -- column tile h of the C layout, i.e. the out-projection's
+//     operand.  No transposes, no staging of Q or O.
+//   * only K and V cross waves.  LDS holds the two-slab weight ring (128 KB at D = 128), so the images carry TWO heads at a time
+//     (2 x 64 rows x 32 columns x 4 B = 16 KB): four rounds per layer, each: barrier, every wave writes its rows of the two heads'
+//     K / V columns (from its accumulators), barrier, attention of the two heads.  Image rows are 128 B; the 16-byte chunk c of row R
+//     sits at chunk position c ^ ((R >> 1) & 7): conflict-free for the ds_read_b128 K fragments and the ds_read_b32 V^T fragments.
+// Saved for backward exactly what the separate kernels save: x, qn, q (unscaled), k, v, o, stats (row max, 1 / row sum), r, y, h.
+#include "common.h"
+#include "rng.h"
+#include "strip_gemm.h"
+#include "attention_mfma.h"
+
+namespace amid {
+
+struct SeqLayer {
+    const float* ln1_w[2]; const float* ln1_b[2]; const float* w_in[2]; const float* b_in[2];
+    const float* w_o[2]; const float* b_o[2]; const float* ln2_w[2]; const float* ln2_b[2];
+    const float* w1[2]; const float* b1[2]; const float* w2[2]; const float* b2[2];
+    float* x;                           // this layer's INPUT rows (written for layers >= 1: the previous layer's output)
+    float* qn; float* q; float* k; float* v; float* o; float* stats; float* r; float* y; float* h;
+};
+
+struct SeqFwdArgs {
+    SeqLayer L[2];
+    int n_layers;
+    const float* x0;                    // layer 0's input (the gathered rows)
+    float* xout;                        // the last layer's output
+    const unsigned char* tmq;
+    float ln_eps, att_scale, dscale, ffn_scale;
+    const StepState* st; int train; unsigned spec;
+};
+
+struct SeqGeom {
+    int B, T, M;
+    unsigned act_bytes, tm_bytes, stats_bytes;
+    const int* live;                    // as StripGeom::live
+};
+
+template <int D>
+__device__ __forceinline__ void add_bias_s(f32x4 (&acc)[D / 16], const ColVec<D>& b) {
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) acc[ct] += b.v[ct];
+}
+template <int D>
+__device__ __forceinline__ void to_regs_s(StripRegs<D>& dst, const f32x4 (&acc)[D / 16]) {
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) dst.v[ct] = acc[ct];
+}
+
+template <int D> struct SeqRing {       // the two-slab weight ring of sasrec_strip.hip
+    float* buf; int s; WDma<D> dma;
+    __device__ __forceinline__ explicit SeqRing(float* lds) : buf(lds), s(0) {}
+    __device__ __forceinline__ void first(const float* __restrict__ W0) { dma.all(buf, W0); }
+    __device__ __forceinline__ const float* next() {
+        w_ring_wait();
+        __syncthreads();
+        const float* cur = buf + (s & 1) * D * D;
+        ++s;
+        return cur;
+    }
+    __device__ __forceinline__ void fetch(const float* __restrict__ W, int ct, int j) const {
+        constexpr int SLOTS = 8 * (D / 16), EVERY = (SLOTS / 2) / WDma<D>::PER_WAVE;
+        const int slot = ct * 8 + j;
+        if (slot % EVERY == 0 && slot / EVERY < WDma<D>::PER_WAVE) dma.piece(buf + (s & 1) * D * D, W, slot / EVERY);
+    }
+};
+
+template <int D>
+__device__ __forceinline__ void spread(const GBuf& g, const StripRow& row, const StripRegs<D>& x, int ct, int j, int phase) {
+    constexpr int NT = D / 16;
+    if (ct < NT / 2 && (j & 3) == phase) strip_store_ct<D>(g, row, x, 2 * ct + (j >> 2));
+}
+
+// workgroup barrier between LDS phases WITHOUT draining the vector-memory queue (__syncthreads() waits for every store in flight)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+constexpr int IMG_COLS = 32;            // two heads of 16
+constexpr int IMG_ROWS = 64;
+// K image [64 key rows][32]: 128-byte rows, chunk c of row R at chunk position c ^ ((R >> 1) & 7).
+// V image TRANSPOSED [32 = 2 heads x 16 dims][64 keys]: 256-byte rows, the chunk of keys 4 c .. 4 c + 3 of row d at position
+// c ^ (d & 15): the V^T fragment of lane (d, g) -- keys 16 kt + 4 g .. + 3 -- is ONE ds_read_b128 (a row-major image costs four
+// ds_read_b32 per fragment: 32 reads per round instead of 8), conflict-free like the weight image; the writes (4 dwords per lane and
+// column tile: keys are lanes, dims are registers) are conflict-free too.
+
+// 32-bit value of lane group `src` (lanes m + 16 src) to all four groups of the same m: two half-exchanges
+__device__ __forceinline__ unsigned bcast_group(unsigned v, int SRC) {
+    float a = __builtin_bit_cast(float, v), b = a;
+    swap16(a, b);                                          // a: rows (0, 0, 2, 2), b: rows (1, 1, 3, 3)
+    float x = (SRC & 1) ? b : a, y = x;
+    swap32(x, y);                                          // x: (lo half, lo half), y: (hi half, hi half)
+    return __builtin_bit_cast(unsigned, (SRC >> 1) ? y : x);
+}
+
+// attention of the wave's 16 query rows (strip si of its sequence) over all heads; Q, K, V in the C layout
+template <int D, int WPS>
+__device__ __forceinline__ void seq_attention_fwd(StripRegs<D>& O, f32x4 (&stat)[D / 32], const StripRegs<D>& Q, const StripRegs<D>& K,
+                                                  const StripRegs<D>& V, float* __restrict__ kimg, float* __restrict__ vimg, int si, int t,
+                                                  int T, unsigned long long rowbase_bh, float scale, int train, unsigned long long seed,
+                                                  unsigned site, unsigned step, unsigned spec, float dscale) {
+    constexpr int H = D / 16;
+    const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    const int R = wave_id() * 16 + m;                      // this lane's row of the K image / key column of the V^T image
+    const int img0 = (wave_id() - si) * 16;                // first image row of the wave's sequence
+    const int qrow = min(t, T - 1);
+    // causal mask as the accumulators' initial value (-inf + anything finite stays -inf): tiles above the diagonal and the diagonal
+    // tile's upper triangle; the same for every head
+    f32x4 minit[WPS];
+#pragma unroll
+    for (int kt = 0; kt < WPS; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) minit[kt][r] = (kt * 16 + 4 * gq + r > t) ? -INFINITY : 0.f;
+    // dropout keep words (64 keys each) of this lane's query row: lane group g draws the words of heads 2 g and 2 g + 1 -- one
+    // Philox call each instead of eight per lane -- and round rd fetches its two from group rd
+    unsigned kwl[2], kwh[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        unsigned long long kw = ~0ull;
+        if (train) kw = row_keep_word(seed, site, step, (rowbase_bh + 2 * gq + e) * T + qrow, T, spec);
+        kwl[e] = (unsigned)kw; kwh[e] = (unsigned)(kw >> 32);
+    }
+    const float qscale = scale * LOG2E;                    // softmax in base 2: p = 2^(s' - max s'), s' = s log2(e)
+#pragma unroll
+    for (int rd = 0; rd < H / 2; ++rd) {
+        if (rd == 1) STRIP_STAMP(22);
+        lds_barrier();                                     // everybody is done reading the previous round's images
+        if (rd == 1) STRIP_STAMP(23);
+        {
+            const int sw = (R >> 1) & 7;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x4 kk = K.v[2 * rd + hh], vv = V.v[2 * rd + hh];
+                st4(kimg + R * IMG_COLS + ((hh * 4 + gq) ^ sw) * 4, make_float4(kk[0], kk[1], kk[2], kk[3]));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = hh * 16 + 4 * gq + r;    // this register's dim: row of the transposed image; this lane's key R: column
+                    vimg[d * IMG_ROWS + (((R >> 2) ^ (d & 15)) * 4) + (R & 3)] = vv[r];
+                }
+            }
+        }
+        if (rd == 1) STRIP_STAMP(24);
+        lds_barrier();                                     // the two heads' K / V of every sequence are in place
+        if (rd == 1) STRIP_STAMP(25);
+        // Both heads of the round and ALL key tiles of the sequence in one branch-free block (tiles above the diagonal are masked
+        // like the diagonal's upper triangle: with one wave per SIMD the scheduler needs every independent chain it can get, and the
+        // waves below the last strip would wait for it at the next barrier anyway).
+        float4 kf[2][WPS], vf[2][WPS];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int d = hh * 16 + m;                     // V^T fragment: lane (d, g) reads keys 16 kt + 4 g .. + 3 of row d
+#pragma unroll
+            for (int kt = 0; kt < WPS; ++kt) {
+                const int Rk = img0 + kt * 16 + m;
+                kf[hh][kt] = ld4(kimg + Rk * IMG_COLS + (((hh * 4 + gq) ^ ((Rk >> 1) & 7)) * 4));
+                vf[hh][kt] = ld4(vimg + d * IMG_ROWS + ((((img0 >> 2) + kt * 4 + gq) ^ (d & 15)) * 4));
+            }
+        }
+        unsigned kl[2], kh[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { kl[e] = bcast_group(kwl[e], rd); kh[e] = bcast_group(kwh[e], rd); }
+        if (rd == 1) STRIP_STAMP(26);
+        f32x4 s[2][WPS];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int kt = 0; kt < WPS; ++kt) s[hh][kt] = minit[kt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const float qs = Q.v[2 * rd + hh][r] * qscale;
+#pragma unroll
+                for (int kt = 0; kt < WPS; ++kt) {
+                    const float4 k4 = kf[hh][kt];
+                    s[hh][kt] = mfma4(r == 0 ? k4.x : r == 1 ? k4.y : r == 2 ? k4.z : k4.w, qs, s[hh][kt]);
+                }
+            }
+        if (rd == 1) STRIP_STAMP(27);
+        float mx[2], l[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float v = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < WPS; ++kt) v = fmaxf(fmaxf(v, fmaxf(s[hh][kt][0], s[hh][kt][1])), fmaxf(s[hh][kt][2], s[hh][kt][3]));
+            mx[hh] = row_max4(v);
+        }
+        if (rd == 1) STRIP_STAMP(28);
+        f32x4 oacc[2][WPS];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float lsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < WPS; ++kt) {
+                oacc[hh][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const unsigned kwd = (kt < 2 ? kl[hh] : kh[hh]) >> ((kt & 1) * 16 + 4 * gq);      // this lane's keys 16 kt + 4 g + r: bits 0..3
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[hh][kt][r] - mx[hh]);
+                    lsum += p;
+                    s[hh][kt][r] = ((kwd >> r) & 1u) ? p : 0.f;
+                }
+            }
+            l[hh] = lsum;
+        }
+        if (rd == 1) STRIP_STAMP(29);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int kt = 0; kt < WPS; ++kt) {
+                    const float4 v4 = vf[hh][kt];
+                    oacc[hh][kt] = mfma4(r == 0 ? v4.x : r == 1 ? v4.y : r == 2 ? v4.z : v4.w, s[hh][kt][r], oacc[hh][kt]);
+                }
+        if (rd == 1) STRIP_STAMP(30);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = 2 * rd + hh;
+            const float rl = 1.0f / row_sum4(l[hh]);
+            const float ro = rl * dscale;                  // dropout's 1 / (1 - p) rides on the normalisation
+            f32x4 o = oacc[hh][0];
+#pragma unroll
+            for (int kt = 1; kt < WPS; ++kt) o += oacc[hh][kt];
+            O.v[h] = f32x4{o[0] * ro, o[1] * ro, o[2] * ro, o[3] * ro};
+            const float mxn = mx[hh] * (1.0f / LOG2E);     // saved in natural units, as the separate kernels save it
+            if (hh == 0) { stat[rd][0] = mxn; stat[rd][1] = rl; } else { stat[rd][2] = mxn; stat[rd][3] = rl; }
+        }
+    }
+}
+
+template <int D, int WPS>
+__global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs a, const SeqGeom sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = D / 16, H = D / 16, SPW = STRIP_WAVES / WPS;
+    const int g = blockIdx.x & 1, tl = blockIdx.x >> 1;
+    STRIP_STAMP(0);
+    const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    const int sq = w / WPS, si = w - sq * WPS;
+    const int sidx = tl * SPW + sq;
+    // the live-list entry this wave may need is requested before the split point n0 is known (both candidates: it sits at
+    // sidx in domain 0's part, at n0 + sidx in domain 1's): one memory latency instead of two dependent ones; then the DMA
+    // of the first weight slab is issued (its address arithmetic runs while those loads fly), then the rows are requested
+    int n0 = sg.B, cand0 = sidx;
+    if (sg.live != nullptr) { n0 = sg.live[sg.B]; cand0 = sg.live[min(sidx, sg.B - 1)]; }
+    SeqRing<D> ring(smem);
+    ring.first(a.L[0].w_in[g] + 1LL * D * D);
+    float* kimg = smem + 2 * D * D;
+    float* vimg = kimg + IMG_ROWS * IMG_COLS;
+    int n_g = sg.B, s0 = 0;
+    if (sg.live != nullptr) {
+        n_g = g ? sg.B - n0 : n0;
+        s0 = g ? n0 : 0;
+    }
+    if (tl * SPW >= n_g) { w_ring_wait(); return; }
+    const bool seq_ok = sidx < n_g;
+    int b = sidx;
+    if (sg.live != nullptr) b = g ? sg.live[min(s0 + sidx, sg.B - 1)] : cand0;
+    if (!seq_ok) b = 0;
+    const int t = si * 16 + m;
+    StripRow row;
+    row.ok = seq_ok && t < sg.T;
+    row.local = b * sg.T + min(t, sg.T - 1);
+    const unsigned phys = (unsigned)g * (unsigned)sg.M + (unsigned)(b * sg.T + t);
+    row.off = row.ok ? phys * (unsigned)(D * 4) + 16u * (unsigned)gq : STRIP_OOB;
+    const unsigned stat_off = row.ok ? phys * (unsigned)(H * 8) + 16u * (unsigned)gq : STRIP_OOB;
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+
+    StripRegs<D> X, Qn, Kr, Vr, Qr, O, R, Y;
+    StripTm<D> tm;
+    ColVec<D> bias, lw, lb;
+    strip_load<D>(X, GBuf(a.x0, sg.act_bytes), row);
+    const bool has_tm = a.tmq != nullptr;
+    if (has_tm) strip_tm_load<D>(tm, GBuf(a.tmq, sg.tm_bytes), row);
+    lw.load(a.L[0].ln1_w[g]); lb.load(a.L[0].ln1_b[g]);
+    f32x4 acc[NT];
+    f32x4 stat[H / 2];
+    STRIP_STAMP(1);
+#pragma unroll 1
+    for (int l = 0; l < a.n_layers; ++l) {
+        const SeqLayer& P = a.L[l];
+        const bool last = l + 1 == a.n_layers;
+        const GBuf gx(P.x, sg.act_bytes), gqn(P.qn, sg.act_bytes), gq_(P.q, sg.act_bytes), gk(P.k, sg.act_bytes), gv(P.v, sg.act_bytes),
+                   go(P.o, sg.act_bytes), gst(P.stats, sg.stats_bytes), gr(P.r, sg.act_bytes), gy(P.y, sg.act_bytes), gh(P.h, sg.act_bytes);
+        strip_layernorm<D>(Qn, X, lw, lb, a.ln_eps);
+        STRIP_STAMP(2 + 10 * l);
+        StripRow rowx = row;                                     // layer 0's input is the caller's buffer: nothing to write back
+        rowx.off = l > 0 ? row.off : STRIP_OOB;
+        {   // k = x Wk^T + bk  (the layer input's and Qn's global copies leave under these MFMAs)
+            const float* buf = ring.next();
+            bias.load(P.b_in[g] + D);
+            strip_zero<D>(acc);
+            strip_mma<D>(acc, X, buf, [&](int ct, int j) {
+                ring.fetch(P.w_in[g] + 2LL * D * D, ct, j);
+                spread<D>(gx, rowx, X, ct, j, 1);
+                spread<D>(gqn, row, Qn, ct, j, 3);
+            });
+            add_bias_s<D>(acc, bias);
+            to_regs_s<D>(Kr, acc);
+            STRIP_STAMP(3 + 10 * l);
+        }
+        {   // v = x Wv^T + bv
+            const float* buf = ring.next();
+            bias.load(P.b_in[g] + 2 * D);
+            strip_zero<D>(acc);
+            strip_mma<D>(acc, X, buf, [&](int ct, int j) { ring.fetch(P.w_in[g], ct, j); spread<D>(gk, row, Kr, ct, j, 1); });
+            add_bias_s<D>(acc, bias);
+            to_regs_s<D>(Vr, acc);
+            STRIP_STAMP(4 + 10 * l);
+        }
+        {   // q = Qn Wq^T + bq
+            const float* buf = ring.next();
+            bias.load(P.b_in[g]);
+            strip_zero<D>(acc);
+            strip_mma<D>(acc, Qn, buf, [&](int ct, int j) { ring.fetch(P.w_o[g], ct, j); spread<D>(gv, row, Vr, ct, j, 1); });
+            add_bias_s<D>(acc, bias);
+            to_regs_s<D>(Qr, acc);
+            STRIP_STAMP(5 + 10 * l);
+        }
+        strip_store<D>(gq_, row, Qr);
+        seq_attention_fwd<D, WPS>(O, stat, Qr, Kr, Vr, kimg, vimg, si, t, sg.T, (unsigned long long)b * H, a.att_scale, a.train, seed,
+                                  site_id(g, l, SITE_ATTN), step, a.spec, a.dscale);
+        STRIP_STAMP(6 + 10 * l);
+        bias.load(P.b_o[g]); lw.load(P.ln2_w[g]); lb.load(P.ln2_b[g]);      // (not across the attention rounds: 96 registers)
+        {   // the statistics of heads 2 gq, 2 gq + 1 of this lane's row: 16 contiguous bytes
+            f32x4 sv = stat[0];
+#pragma unroll
+            for (int k = 1; k < H / 2; ++k) sv = (gq == k) ? stat[k] : sv;
+            gst.store4(stat_off, sv);
+        }
+        {   // r = Qn + (o Wo^T + bo) ; y = LN2(r)
+            const float* buf = ring.next();
+            strip_zero<D>(acc);
+            strip_mma<D>(acc, O, buf, [&](int ct, int j) { ring.fetch(P.w1[g], ct, j); spread<D>(go, row, O, ct, j, 1); });
+            add_bias_s<D>(acc, bias);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) R.v[ct] = Qn.v[ct] + acc[ct];
+            strip_layernorm<D>(Y, R, lw, lb, a.ln_eps);
+            STRIP_STAMP(7 + 10 * l);
+        }
+        {   // h = relu(drop1(y C1^T + c1))
+            const float* buf = ring.next();
+            bias.load(P.b1[g]);
+            strip_zero<D>(acc);
+            strip_mma<D>(acc, Y, buf, [&](int ct, int j) { ring.fetch(P.w2[g], ct, j); spread<D>(gr, row, R, ct, j, 1); });
+            add_bias_s<D>(acc, bias);
+            to_regs_s<D>(Kr, acc);                               // Kr: the relu output from here on
+            if (a.train) strip_dropout<D>(Kr, seed, site_id(g, l, SITE_FFN1), step, row.local, a.spec, a.ffn_scale);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Kr.v[ct][r] = fmaxf(Kr.v[ct][r], 0.f);
+            STRIP_STAMP(8 + 10 * l);
+        }
+        {   // x' = (drop2(h C2^T + c2) + y) * ~tm
+            const float* buf = ring.next();
+            bias.load(P.b2[g]);
+            const SeqLayer& Pn = a.L[last ? l : l + 1];          // (the last layer refetches its own Wk into the free buffer: harmless)
+            lw.load(Pn.ln1_w[g]); lb.load(Pn.ln1_b[g]);
+            strip_zero<D>(acc);
+            strip_mma<D>(acc, Kr, buf, [&](int ct, int j) {
+                ring.fetch(Pn.w_in[g] + 1LL * D * D, ct, j);
+                spread<D>(gy, row, Y, ct, j, 1);
+                spread<D>(gh, row, Kr, ct, j, 3);
+            });
+            add_bias_s<D>(acc, bias);
+            to_regs_s<D>(X, acc);
+            if (a.train) strip_dropout<D>(X, seed, site_id(g, l, SITE_FFN2), step, row.local, a.spec, a.ffn_scale);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) X.v[ct] += Y.v[ct];
+            if (has_tm) strip_apply_tm<D>(X, tm);
+            STRIP_STAMP(9 + 10 * l);
+        }
+    }
+    strip_store<D>(GBuf(a.xout, sg.act_bytes), row, X);
+    w_ring_wait();                                               // the last (redundant) weight fetch targets this workgroup's LDS
+}
+
+}  // namespace amid
+
+using namespace amid;
+
+#ifdef AMID_STRIP_STAMPS
+extern "C" int amid_seq_stamps_read(unsigned long long* host) {       // diagnostic library only
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_strip_stamp_buf), sizeof(unsigned long long) * STRIP_STAMP_WAVES * 32);
+}
+#endif
+
+template <int D> static constexpr size_t seq_lds_bytes() { return (size_t)(2 * D * D + 2 * IMG_ROWS * IMG_COLS) * sizeof(float); }
+
+// 1 when the fused per-sequence forward covers this shape: head dim 16 with D = 128, T <= 64, activations within 2 GiB
+extern "C" int amid_sas_seq_supported(int B, int T, int D, int H) {
+    return (D == 128 && H == 8 && T > 0 && T <= 64 && B > 0 && 2LL * B * T * D * 4 <= 0x7FFFFFF0LL) ? 1 : 0;
+}
+
+// Per-layer pointer arrays: the per-domain parameter families hold 2 * n_layers entries ordered [layer][domain], the saved-tensor
+// families n_layers entries; x_in[l] = layer l's input rows (x_in[0] is read, x_in[l >= 1] written), xout = the last layer's output.
+extern "C" int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                    const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                    const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                    const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
+                                    float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
+                                    const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                                    const void* step_state, int train, float p_drop, void* stream) {
+    AMID_CHECK_ARG(n_layers >= 1 && n_layers <= 2 && x_in && xout && ln1_w && ln1_b && w_in && b_in && w_o && b_o && ln2_w && ln2_b && w1 && b1 &&
+                   w2 && b2 && qn && q && k && v && o && stats && r && y && h && (!train || step_state));
+    if (!amid_sas_seq_supported(B, T, D, H)) return AMID_ERR_UNSUPPORTED;
+    SeqFwdArgs a = {};
+    a.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        SeqLayer& P = a.L[l];
+        for (int g = 0; g < 2; ++g) {
+            const int i = 2 * l + g;
+            AMID_CHECK_ARG(ln1_w[i] && ln1_b[i] && w_in[i] && b_in[i] && w_o[i] && b_o[i] && ln2_w[i] && ln2_b[i] && w1[i] && b1[i] && w2[i] && b2[i]);
+            P.ln1_w[g] = ln1_w[i]; P.ln1_b[g] = ln1_b[i]; P.w_in[g] = w_in[i]; P.b_in[g] = b_in[i]; P.w_o[g] = w_o[i]; P.b_o[g] = b_o[i];
+            P.ln2_w[g] = ln2_w[i]; P.ln2_b[g] = ln2_b[i]; P.w1[g] = w1[i]; P.b1[g] = b1[i]; P.w2[g] = w2[i]; P.b2[g] = b2[i];
+        }
+        AMID_CHECK_ARG(x_in[l] && qn[l] && q[l] && k[l] && v[l] && o[l] && stats[l] && r[l] && y[l] && h[l]);
+        P.x = const_cast<float*>(x_in[l]); P.qn = qn[l]; P.q = q[l]; P.k = k[l]; P.v = v[l]; P.o = o[l]; P.stats = stats[l];
+        P.r = r[l]; P.y = y[l]; P.h = h[l];
+    }
+    a.x0 = x_in[0]; a.xout = xout; a.tmq = tmq; a.ln_eps = ln_eps;
+    a.att_scale = sqrtf(1.0f / (float)(D / H));
+    a.st = (const StepState*)step_state;
+    a.train = (train && p_drop > 0.f) ? 1 : 0;
+    a.spec = drop_spec(p_drop);
+    a.dscale = a.ffn_scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+    SeqGeom sg;
+    sg.B = B; sg.T = T; sg.M = B * T; sg.live = live;
+    const long long bytes = 2LL * B * T * D * 4;
+    sg.act_bytes = (unsigned)bytes; sg.tm_bytes = (unsigned)(bytes / 16); sg.stats_bytes = (unsigned)(2LL * B * T * H * 8);
+    const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4, spw = STRIP_WAVES / wps;
+    const int grid = 2 * ((B + spw - 1) / spw);
+    const size_t lds = seq_lds_bytes<128>();
+    auto launch = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        kern<<<grid, STRIP_THREADS, lds, (hipStream_t)stream>>>(a, sg);
+        e = hipGetLastError();
+        return e == hipSuccess ? AMID_OK : (int)e;
+    };
+    if (wps == 1) return launch(seq_fwd_kernel<128, 1>);
+    if (wps == 2) return launch(seq_fwd_kernel<128, 2>);
+    return launch(seq_fwd_kernel<128, 4>);
+}

@@ -35,7 +35,7 @@ namespace amid {
 // diagnostic builds only (profiles/tools/strip_stamps.py compiles sasrec_strip.hip with -DAMID_STRIP_STAMPS into its own library):
 // s_memtime stamps of workgroup 0, one row of 32 per wave, in a buffer no kernel reads
 #ifdef AMID_STRIP_STAMPS
-__device__ unsigned long long amid_strip_stamp_buf[STRIP_STAMP_WAVES * 32];
+static __device__ unsigned long long amid_strip_stamp_buf[STRIP_STAMP_WAVES * 32];      // one per translation unit
 #define STRIP_STAMP(i) do { if (blockIdx.x == 0 && lane_id() == 0) amid_strip_stamp_buf[wave_id() * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STRIP_STAMP(i) do { } while (0)
@@ -157,10 +157,26 @@ template <int D> struct ColVec {
     }
 };
 
-// sum over the 4 lanes (m, 0..3) that share a row
+// all-reduce over the 4 lanes (m, 0..3) that share a row, i.e. over lane ^ 16 and lane ^ 32: two half-exchanges on the VALU
+// (v_permlane16_swap: odd rows of 16 lanes of the first operand <-> even rows of the second; v_permlane32_swap: upper half <-> lower
+// half) instead of two ds_bpermute round trips through the LDS crossbar -- with one wave per SIMD nothing hides those
+// (written as inline asm: with the builtins hipcc 7.2 treats the two results of a swap as equal when both inputs carry the same
+// value and emits v_add v1, v1, v1 behind it; the two wait states a VALU write needs in front of a v_permlane read sit in the string)
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ float row_sum4(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+    float a = v, b = v;
+    swap16(a, b);
+    a += b; b = a;
+    swap32(a, b);
+    return a + b;
+}
+__device__ __forceinline__ float row_max4(float v) {
+    float a = v, b = v;
+    swap16(a, b);
+    a = fmaxf(a, b); b = a;
+    swap32(a, b);
+    return fmaxf(a, b);
 }
 // sum over the 16 lanes (0..15, g) that share a column quad: DPP inside the row of 16
 __device__ __forceinline__ float col_sum16(float v) { return group_sum<16>(v); }

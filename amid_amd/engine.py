@@ -699,7 +699,24 @@ class SasrecEngine:
                 L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), None, B, T, D, self.H, 1, l, st, tr,
                        SASREC_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
 
-        if pl.strip:         # register-resident strip chains (csrc/sasrec_strip.hip): same operations, operands and saved tensors
+        if pl.strip and self.SEQ_FORWARD and not self.inc_bs and L.value("amid_sas_seq_supported", B, T, D, self.H):
+            # the whole encoder -- both layers, attention cores included -- as ONE launch, a workgroup per sequence (csrc/sasrec_seq.hip)
+            fam = lambda fmt: ptr_array([fp.ptr(fmt.format(d=d, l=l)) for l in (0, 1) for d in (1, 2)])      # noqa: E731  [layer][domain]
+            key = ("seq_fwd", pl.x[0].data_ptr())
+            c = self._ptr_cache.get(key)
+            if c is None:
+                tl = lambda ts: ptr_array([t.data_ptr() for t in ts])      # noqa: E731
+                c = (tl(pl.x[:2]), fam("sac{d}.attention_layernorms.{l}.weight"), fam("sac{d}.attention_layernorms.{l}.bias"),
+                     fam("sac{d}.attention_layers.{l}.in_proj_weight"), fam("sac{d}.attention_layers.{l}.in_proj_bias"),
+                     fam("sac{d}.attention_layers.{l}.out_proj.weight"), fam("sac{d}.attention_layers.{l}.out_proj.bias"),
+                     fam("sac{d}.forward_layernorms.{l}.weight"), fam("sac{d}.forward_layernorms.{l}.bias"),
+                     fam("sac{d}.forward_layers.{l}.conv1.weight"), fam("sac{d}.forward_layers.{l}.conv1.bias"),
+                     fam("sac{d}.forward_layers.{l}.conv2.weight"), fam("sac{d}.forward_layers.{l}.conv2.bias"),
+                     tl(pl.qn), tl(pl.q), tl(pl.k), tl(pl.v), tl(pl.o), tl(pl.stats), tl(pl.r), tl(pl.y), tl(pl.h))
+                self._ptr_cache[key] = c
+            L.call("amid_sas_seq_fwd_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:], pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr,
+                   SASREC_P_DROP, s)
+        elif pl.strip:       # register-resident strip chains (csrc/sasrec_strip.hip): same operations, operands and saved tensors
             L.call("amid_sas_strip_qkv_fwd_f32", pl.x[0].data_ptr(), *qkv0, SASREC_LN_EPS, B, T, D, lf, pl.qn[0].data_ptr(), pl.q[0].data_ptr(),
                    pl.k[0].data_ptr(), pl.v[0].data_ptr(), s)
             attn_fwd(0)
@@ -1023,6 +1040,7 @@ class SasrecEngine:
             self._fuse_head = self._fuse_scorers = self._own_domain_only = self._live_fwd = False
 
     LIVE_FORWARD = True        # the fused train step may skip the forward of the sequences its loss never reads
+    SEQ_FORWARD = True         # the encoder forward as one launch per step where csrc/sasrec_seq.hip covers the shape
 
     def _live_list(self, pl: SasrecPlan):
         """Device pointer of the plan's live-sequence list (filled by amid_live_list_i32 at the head of enqueue_forward) when the

@@ -501,6 +501,21 @@ int amid_sas_qkv_ffn_bwd_rows_f32_rt5(const float* dq, const float* dk, const fl
 int amid_sas_qkv_ffn_bwd_rows_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
 int amid_sas_qkv_ffn_bwd_rows_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
 
+/* ---- the whole encoder forward of a sequence in ONE launch (csrc/sasrec_seq.hip) ------------------------------------------------------
+ * replaces: Log2feats.forward model_seq.py:371-383 for n_layers layers, the attention core of nn.MultiheadAttention (:374) included --
+ * amid_sas_strip_qkv_fwd_f32 + amid_attn_fwd_f32 + amid_sas_strip_oproj_ffn_fwd_f32 per layer, with q / k / v / o never re-read.
+ * Shapes: amid_sas_seq_supported (D 128, 8 heads of 16, T <= 64).  Per-domain parameter families: 2 * n_layers pointers ordered
+ * [layer][domain]; saved-tensor families: n_layers pointers; x_in[l] = layer l's input rows (x_in[0] read, the others written),
+ * xout = the last layer's output; stats [2 B T, H, 2]; live as for the strip kernels. */
+int amid_sas_seq_supported(int B, int T, int D, int H);
+int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                         const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                         const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                         const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
+                         float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
+                         const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live, const void* step_state,
+                         int train, float p_drop, void* stream);
+
 /* ---- the fused train step over the LIVE sequences -------------------------------------------------------------------------------
  * train_sr.py:205-211 multiplies the BCE terms of domain 1 - domain_id[b] of every sample b by zero: of the 2 B sequences a step
  * encodes only the B "live" ones (domain_id[b], b) reach the loss.  amid_live_list_i32 lists them ([B + 1] ints: batch rows of

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Where the fused encoder-forward kernel's cycles go (csrc/sasrec_seq.hip): runs a train step of the headline shape on the DIAGNOSTIC
+library built by profiles/tools/build_diag.sh (s_memtime stamps of workgroup 0) and prints the deltas per wave."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import amid_amd._lib as _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.join(ROOT, "profiles", "tools", "_diag", "libamid_hip_diag.so")
+import torch  # noqa: E402
+from amid_amd.engine import SasrecEngine  # noqa: E402
+from oracle import amid_oracle as orc  # noqa: E402
+
+B, T, D, hid, n_items = 256, 50, 128, 32, 3000
+P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=1)
+eng = SasrecEngine(n_items, D, T, hid, seed=3)
+eng.load_state_dict(P)
+pl = eng.plan(B, T, 2, need_grad=True)
+batch = orc.synthetic_batch(B, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=2)
+cu = {k: v.cuda() for k, v in batch.items()}
+for _ in range(4):
+    eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"])
+    eng.enqueue_train_step(pl)
+    eng.sync()
+L = _lib.lib()._dll
+host = (ctypes.c_ulonglong * (4 * 32))()
+assert L.amid_seq_stamps_read(host) == 0
+names = {0: "entry", 1: "prologue"}
+for l in (0, 1):
+    for i, n in enumerate(("LN1", "k", "v", "q", "attention", "o+LN2", "c1", "c2")):
+        names[2 + 10 * l + i] = f"L{l}.{n}"
+for i, n in zip(range(22, 31), ("rd1 begin", "barrier A", "K/V written", "barrier B", "reads + keep words issued", "S MFMAs", "mask + max", "exp", "PV MFMAs")):
+    names[i] = n
+order = sorted(k for k in names if k < 20)
+fine = list(range(22, 31))
+for w in range(4):
+    t = {i: host[w * 32 + i] for i in order}
+    tf = [host[w * 32 + i] for i in fine]
+    print(f"wave {w} attention round 1 (last layer): " + ", ".join(f"{names[fine[k]]} +{tf[k] - tf[k - 1]}" for k in range(1, len(fine))))
+    print(f"wave {w}: total {t[order[-1]] - t[0]}: " + ", ".join(f"{names[i]} +{t[i] - t[order[k - 1]]}" for k, i in enumerate(order) if k))
