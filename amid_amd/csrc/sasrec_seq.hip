@@ -25,6 +25,15 @@
 
 namespace amid {
 
+#ifdef AMID_STRIP_STAMPS
+static __device__ unsigned long long amid_seq_sched_buf[1024 * 4];     // per workgroup: start, end (100 MHz real-time counter), HW_ID
+#define SEQ_SCHED(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) amid_seq_sched_buf[blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SEQ_SCHED_ID() do { if (threadIdx.x == 0 && blockIdx.x < 1024) amid_seq_sched_buf[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } while (0)
+#else
+#define SEQ_SCHED(slot) do { } while (0)
+#define SEQ_SCHED_ID() do { } while (0)
+#endif
+
 struct SeqLayer {
     const float* ln1_w[2]; const float* ln1_b[2]; const float* w_in[2]; const float* b_in[2];
     const float* w_o[2]; const float* b_o[2]; const float* ln2_w[2]; const float* ln2_b[2];
@@ -247,30 +256,34 @@ template <int D, int WPS>
 __global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs a, const SeqGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = D / 16, H = D / 16, SPW = STRIP_WAVES / WPS;
-    const int g = blockIdx.x & 1, tl = blockIdx.x >> 1;
+    // Workgroup -> (domain, tile): the live tiles are the FIRST workgroups, domain 0's then domain 1's.  The hardware deals workgroups
+    // round-robin over the 8 XCDs and, inside an XCD, over its 4 shader engines of 8 CUs (index mod 32 picks the engine); a workgroup
+    // here needs a whole CU (147 KB of LDS, 512 registers per lane), so at 256 live sequences on 256 CUs every engine must get
+    // EXACTLY 8 of them: only a contiguous range of live indices guarantees that.  (Mappings that derive the domain from the index
+    // -- by parity, or in chunks of 8 -- put 9 or more on some engines whenever the batch's domain split is uneven: two rounds,
+    // 176 us instead of 91.)  The price is one scalar load (n0) in front of the first weight DMA.
     STRIP_STAMP(0);
+    STRIP_RSTAMP(20);
+    SEQ_SCHED(0);
     const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
     const int sq = w / WPS, si = w - sq * WPS;
+    int n0 = sg.B;
+    if (sg.live != nullptr) n0 = sg.live[sg.B];
+    const int n1 = sg.live != nullptr ? sg.B - n0 : sg.B;
+    const int t0 = (n0 + SPW - 1) / SPW, t1 = (n1 + SPW - 1) / SPW;
+    if ((int)blockIdx.x >= t0 + t1) { SEQ_SCHED(1); return; }
+    const int g = (int)blockIdx.x >= t0 ? 1 : 0;
+    const int tl = (int)blockIdx.x - (g ? t0 : 0);
+    const int n_g = g ? n1 : n0, s0 = (g && sg.live != nullptr) ? n0 : 0;
     const int sidx = tl * SPW + sq;
-    // the live-list entry this wave may need is requested before the split point n0 is known (both candidates: it sits at
-    // sidx in domain 0's part, at n0 + sidx in domain 1's): one memory latency instead of two dependent ones; then the DMA
-    // of the first weight slab is issued (its address arithmetic runs while those loads fly), then the rows are requested
-    int n0 = sg.B, cand0 = sidx;
-    if (sg.live != nullptr) { n0 = sg.live[sg.B]; cand0 = sg.live[min(sidx, sg.B - 1)]; }
     SeqRing<D> ring(smem);
     ring.first(a.L[0].w_in[g] + 1LL * D * D);
     float* kimg = smem + 2 * D * D;
     float* vimg = kimg + IMG_ROWS * IMG_COLS;
-    int n_g = sg.B, s0 = 0;
-    if (sg.live != nullptr) {
-        n_g = g ? sg.B - n0 : n0;
-        s0 = g ? n0 : 0;
-    }
-    if (tl * SPW >= n_g) { w_ring_wait(); return; }
-    const bool seq_ok = sidx < n_g;
     int b = sidx;
-    if (sg.live != nullptr) b = g ? sg.live[min(s0 + sidx, sg.B - 1)] : cand0;
-    if (!seq_ok) b = 0;
+    if (sg.live != nullptr) b = sg.live[min(s0 + sidx, sg.B - 1)];
+    if (sidx >= n_g) b = 0;
+    const bool seq_ok = sidx < n_g;
     const int t = si * 16 + m;
     StripRow row;
     row.ok = seq_ok && t < sg.T;
@@ -388,7 +401,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs
         }
     }
     strip_store<D>(GBuf(a.xout, sg.act_bytes), row, X);
-    w_ring_wait();                                               // the last (redundant) weight fetch targets this workgroup's LDS
+    STRIP_STAMP(21);
+    STRIP_RSTAMP(31);
+    w_ring_wait();
+    SEQ_SCHED(1);                                               // the last (redundant) weight fetch targets this workgroup's LDS
 }
 
 }  // namespace amid
@@ -396,6 +412,9 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs
 using namespace amid;
 
 #ifdef AMID_STRIP_STAMPS
+extern "C" int amid_seq_sched_read(unsigned long long* host) {          // diagnostic library only
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_seq_sched_buf), sizeof(unsigned long long) * 1024 * 4);
+}
 extern "C" int amid_seq_stamps_read(unsigned long long* host) {       // diagnostic library only
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_strip_stamp_buf), sizeof(unsigned long long) * STRIP_STAMP_WAVES * 32);
 }
@@ -445,7 +464,8 @@ extern "C" int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, floa
     const long long bytes = 2LL * B * T * D * 4;
     sg.act_bytes = (unsigned)bytes; sg.tm_bytes = (unsigned)(bytes / 16); sg.stats_bytes = (unsigned)(2LL * B * T * H * 8);
     const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4, spw = STRIP_WAVES / wps;
-    const int grid = 2 * ((B + spw - 1) / spw);
+    const int tiles = (B + spw - 1) / spw;
+    const int grid = live != nullptr ? tiles + 1 : 2 * tiles;      // the live tiles of both domains (one more when both are ragged) / every tile
     const size_t lds = seq_lds_bytes<128>();
     auto launch = [&](auto kern) -> int {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -37,8 +37,10 @@ namespace amid {
 #ifdef AMID_STRIP_STAMPS
 static __device__ unsigned long long amid_strip_stamp_buf[STRIP_STAMP_WAVES * 32];      // one per translation unit
 #define STRIP_STAMP(i) do { if (blockIdx.x == 0 && lane_id() == 0) amid_strip_stamp_buf[wave_id() * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STRIP_RSTAMP(i) do { if (blockIdx.x == 0 && lane_id() == 0) amid_strip_stamp_buf[wave_id() * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define STRIP_STAMP(i) do { } while (0)
+#define STRIP_RSTAMP(i) do { } while (0)
 #endif
 
 constexpr int STRIP_WAVES = 4;

@@ -1006,7 +1006,7 @@ class SasrecEngine:
         """Whole step t on the current stream: t += 1; unique; catch-up; forward; loss; backward; Adam."""
         self.enqueue_prepare(pl, sparse=True, bump_step=True, defer_sort=True)
         self.enqueue_catchup(pl)
-        self.enqueue_sort(pl)
+        self._fork_sort(pl)
         self._enqueue_fwd_bwd(pl)
         self.enqueue_optimizer(pl)
 
@@ -1015,8 +1015,12 @@ class SasrecEngine:
         """Everything of step t that needs no communication: t += 1 .. local segment-reduced gradients."""
         self.enqueue_prepare(pl, sparse=True, bump_step=True, defer_sort=True)
         self.enqueue_catchup(pl)
-        self.enqueue_sort(pl)
+        self._fork_sort(pl)
         self._enqueue_fwd_bwd(pl)
+
+    def _fork_sort(self, pl: SasrecPlan) -> None:
+        """Start the side-stream sort beside the forward pass (joined by the gradient tail)."""
+        self.enqueue_sort(pl)
 
     FUSED_HEAD = True          # the plain SASRec head (no isItC / isDR) can run forward + backward as one launch
 

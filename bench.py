@@ -126,6 +126,8 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
     H, hd = 8, D // 8
     return {
         # strip kernels of the fused step ("#k": k-th launch of that entry in a step -- the fused cross-layer launch comes first)
+        # the whole encoder forward, both layers: 12 projections over the live rows + the two attention cores (4 T^2 hd per head)
+        "amid_sas_seq_fwd_f32": ("mfma", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
         "amid_sas_strip_qkv_fwd_f32": ("mfma", 3 * gl),
         "amid_sas_strip_oproj_ffn_fwd_f32#0": ("mfma", 6 * gl),       # layer 0's out-proj + FFN, layer 1's q / k / v
         "amid_sas_strip_oproj_ffn_fwd_f32#1": ("mfma", 3 * gl),
@@ -181,7 +183,7 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_qkv_ffn_bwd_f32": "sas_qkv_ffn_bwd_kernel", "amid_sas_oproj_ffn_qkv_fwd_f32": "sas_oproj_ffn_qkv_fwd_kernel",
     "amid_sas_oproj_ffn_fwd_f32": "sas_oproj_ffn_fwd_kernel",
     "amid_attn_fwd_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_f32": "embed_fwd_kernel",
-    "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
+    "amid_sas_seq_fwd_f32": "seq_fwd_kernel", "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
     "amid_sas_strip_oproj_ffn_fwd_f32#1": "strip_oproj_ffn_fwd_kernelILi128ELb0", "amid_sas_strip_ffn_bwd_f32": "strip_ffn_bwd_kernel",
     "amid_sas_strip_qkv_bwd_f32#0": "strip_qkv_bwd_kernelILi128ELb1", "amid_sas_strip_qkv_bwd_f32#1": "strip_qkv_bwd_kernelILi128ELb0",
     "amid_attn_fwd_live_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_live_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_live_f32": "embed_fwd_kernel",

@@ -21,7 +21,7 @@ eng.load_state_dict(P)
 pl = eng.plan(B, T, 2, need_grad=True)
 batch = orc.synthetic_batch(B, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=2)
 cu = {k: v.cuda() for k, v in batch.items()}
-for _ in range(4):
+for _ in range(int(os.environ.get("STAMP_STEPS", "4"))):
     eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"])
     eng.enqueue_train_step(pl)
     eng.sync()
@@ -36,8 +36,22 @@ for i, n in zip(range(22, 31), ("rd1 begin", "barrier A", "K/V written", "barrie
     names[i] = n
 order = sorted(k for k in names if k < 20)
 fine = list(range(22, 31))
+for w in range(1):
+    dc, dr = host[w * 32 + 21] - host[w * 32 + 0], host[w * 32 + 31] - host[w * 32 + 20]
+    print(f"in-kernel clock: {dc} shader cycles in {dr} ticks of the 100 MHz real-time counter = {dc / dr * 0.1:.3f} GHz")
 for w in range(4):
     t = {i: host[w * 32 + i] for i in order}
     tf = [host[w * 32 + i] for i in fine]
     print(f"wave {w} attention round 1 (last layer): " + ", ".join(f"{names[fine[k]]} +{tf[k] - tf[k - 1]}" for k in range(1, len(fine))))
     print(f"wave {w}: total {t[order[-1]] - t[0]}: " + ", ".join(f"{names[i]} +{t[i] - t[order[k - 1]]}" for k, i in enumerate(order) if k))
+
+sched = (ctypes.c_ulonglong * (1024 * 4))()
+assert L.amid_seq_sched_read(sched) == 0
+rows = [(i, sched[i * 4], sched[i * 4 + 1], sched[i * 4 + 2]) for i in range(512) if sched[i * 4]]
+t0 = min(r[1] for r in rows)
+live = [r for r in rows if r[2] - r[1] > 2000]
+print(f"{len(rows)} workgroups stamped, {len(live)} long ones; kernel span {(max(r[2] for r in rows) - t0) / 100:.1f} us")
+starts = sorted((r[1] - t0) / 100 for r in live)
+print("start times of the long workgroups (us), deciles:", [round(starts[int(k * (len(starts) - 1) / 10)], 1) for k in range(11)])
+durs = sorted((r[2] - r[1]) / 100 for r in live)
+print("durations (us), deciles:", [round(durs[int(k * (len(durs) - 1) / 10)], 1) for k in range(11)])
