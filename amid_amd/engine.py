@@ -309,6 +309,8 @@ class SasrecPlan:
         # the blocks of an entry with many partials (the head's per-row partials: one per batch row) run the longest chains of
         # dependent loads: dispatch them first, so that they do not form the tail of the launch
         ent.sort(key=lambda e: -e[3])
+        # algorithmic HBM bytes of the partial-sum reduce (every partial read once, every sum written once): bench.py prices the launch
+        setattr(self, "red_bytes_v" if live else "red_bytes", sum(4 * (n + 1) * c for *_, n, c in ent))
         esz = L.value("amid_reduce_entry_bytes")
         host = (ctypes.c_ubyte * (esz * len(ent)))()
         for i, (s, d, st, n, c) in enumerate(ent):
@@ -433,6 +435,13 @@ class SasrecEngine:
                self.hyper["beta2"], self.hyper["eps"])
         with torch.cuda.stream(self.stream):
             self.step_state.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8), non_blocking=False)
+
+    @staticmethod
+    def rank_seed(seed: int, rank: int) -> int:
+        """Dropout seed of data-parallel rank `rank`: the counters are indexed by the LOCAL row, so ranks sharing one seed would apply
+        the same masks to their different shards -- correlated noise a single-GPU run at the global batch does not have.  Weights
+        are initialised from `seed` itself on every rank (identical replicas)."""
+        return (int(seed) + 0x9E3779B97F4A7C15 * int(rank)) & 0x7FFFFFFFFFFFFFFF
 
     def set_step(self, step: int, seed: Optional[int] = None) -> None:
         self.step = int(step)
@@ -1085,6 +1094,8 @@ class SasrecEngine:
             raise NotImplementedError("isItC / isInC couple the rows of a batch (softmax and Linear(bs, 1) over the batch, "
                                       "model_seq.py:465-469, :490-494): data-parallel sharding would change the model; train them on one GPU")
         L = lib()
+        if umax is not None:                   # a caller's bound may be rounded up past the plan's index count (e.g. to a multiple of 256):
+            umax = max(1, min(int(umax), pl.shape.n_idx))      # clamp BEFORE it keys the captured graph pair (as dist.exchange_sparse does)
         with torch.cuda.stream(self.stream):
             self.grad_scale = exchange.grad_scale
             fast = use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")

@@ -287,10 +287,19 @@ class SASRec(nn.Module):
         self._last_plan = pl
         return pl.dr_losses if eng.dr else pl.loss
 
+    def check_indices(self) -> None:
+        """Raise IndexError if any batch since the last check carried an item id outside the table (nn.Embedding raises on the spot,
+        model_seq.py:27-29; the fused step flags it on the device and keeps going with row 0).  One device -> host read: call it
+        where the loop synchronises anyway (the loss log every 20 iterations, the end of an epoch)."""
+        pl = getattr(self, "_last_plan", None) or getattr(self, "_pool_plan", None)
+        if pl is not None:
+            self.engine.check_index_error(pl)
+
     def end_epoch_pool(self) -> None:
         """Hand the device back to torch's stream after an epoch of pool_step()s (the pool stays installed for the next epoch's
         refill; train_step() on the same plan is refused while it is -- use drop_epoch_pool())."""
         torch.cuda.current_stream().wait_stream(self.engine.stream)
+        self.check_indices()
 
     def drop_epoch_pool(self) -> None:
         """Remove the pool of the current (Adam state, objective)."""

@@ -132,6 +132,8 @@ def train(model, train_batches, args, val_batches, exchange=None):
                 if pooled:
                     model.engine.sync()
                 stats.update(loss=loss.item(), loss_cls=loss.item())
+                if hasattr(model, "check_indices"):
+                    model.check_indices()                                                 # nn.Embedding would have raised (model_seq.py:27-29)
                 logger.info(f"train total loss:{stats.loss}, cls loss:{stats.loss_cls} \t")
             if args.max_steps and i + 1 >= args.max_steps:
                 break
@@ -204,6 +206,8 @@ def main(argv=None):
                     threshold2=args.ts2, lr=args.lr, seed=i, **({"compute": "bf16"} if args.dtype == "bf16" else {}))
         exchange = None
         if world > 1:
+            # identical replicas (weights from seed i on every rank), but each rank's own dropout stream
+            model.engine.set_step(model.engine.step, seed=model.engine.rank_seed(i, rank))
             from .dist import SparseDenseExchange
             n_idx = args.bs * (2 * args.seq_len + 2)                                      # per-rank index count of a train batch (1 negative)
             exchange = SparseDenseExchange(model.engine.merge_backend(world * n_idx),

@@ -63,6 +63,7 @@ def train(model, train_batches, train_batches_dr, args, val_batches):
             if i % 20 == 0:                                                               # train_sr_dr.py:226-227
                 eng.sync()
                 lc, le, _ = losses.tolist()
+                model.check_indices()
                 stats.update(loss_cls=lc, loss_dr_e=le)
                 logger.info(f"train cls loss:{stats.loss_cls}, dr_e loss:{stats.loss_dr_e} \t")
             if args.max_steps and i + 1 >= args.max_steps:
@@ -92,6 +93,7 @@ def train(model, train_batches, train_batches_dr, args, val_batches):
             if i % 20 == 0:                                                               # train_sr_dr.py:400-402
                 eng.sync()
                 stats.update(loss_dr_r=losses.tolist()[2])
+                model.check_indices()
                 logger.info(f"train loss_dr_r:{stats.loss_dr_r} \t")
             if args.max_steps and i + 1 >= args.max_steps:
                 break

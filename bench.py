@@ -89,6 +89,29 @@ def synth_batch(gen, device, wl=None):
     return {k: v.to(device) for k, v in b.items()}
 
 
+FIXTURES = os.path.join(ROOT, "tests", "golden")
+REAL = {   # --workload -> tokenised fixtures (tests/golden/make_tokenised.py: the arrays the reference's own DualDomainSeqDataset produced)
+    "cfg2": ("cloth_sport_train75",),
+    "cfg3": ("phone_elec_train25",),          # phone_elec_train75 is not in the reference checkout (.MISSING_LARGE_BLOBS): BASELINE.md section 4
+    "cfg4": ("loan_fund_train75", "loan_account_train75"),      # joint mode: SURVEY.md section 8(d)
+}
+JOINT_OFFSET = ITEM_LENGTH + 2    # loan_account's items sit behind loan_fund's in the shared table (the pad row is shared)
+
+
+def real_batches(workload, Bw, device, rank, world, seed=0):
+    """The workload's real training batches: the reference's tokenisation (fixtures), its negative draw, a seeded shuffle; one epoch,
+    resident on the device.  Returns (epoch tensors with a leading [n_batches] axis, description)."""
+    from amid_amd.dataset_seq import DeviceBatches, DualDomainSeqDataset, JointBatches
+    names = REAL[workload]
+    dss = [DualDomainSeqDataset.from_tokenised(os.path.join(FIXTURES, f"tok_{n}.npz")) for n in names]
+    if len(dss) == 2:
+        dss[1].shift_items(JOINT_OFFSET)
+    loaders = [DeviceBatches(d, Bw, shuffle=True, device=device, seed=seed, rank=rank, world=world, negatives="fixture") for d in dss]
+    ld = loaders[0] if len(loaders) == 1 else JointBatches(*loaders)
+    desc = " + ".join(names) + f" ({sum(len(d) for d in dss)} rows, tokenised by the reference's DualDomainSeqDataset; negatives: its draw)"
+    return ld, desc
+
+
 def init_params(eng, seed):
     """Random-init weights of the reference architecture (nn.Embedding N(0,1); small dense weights)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -191,11 +214,12 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
 }
 
 
-def pmc_traffic(entry: str):
-    """HBM bytes per launch of one kernel from the committed PMC summary (profiles/*_hbm_traffic.json, produced by
-    profiles/summarize.py from two separate rocprofv3 --pmc passes of this same command); None when no summary is committed."""
+def pmc_traffic(entry: str, tag: str):
+    """HBM bytes per launch of one kernel REPLAYED from the committed PMC summary of THIS configuration
+    (profiles/r*_<tag>_hbm_traffic.json, produced by profiles/summarize.py from two separate rocprofv3 --pmc passes of the same
+    command; tag = workload_model_dtype); None when no summary of this configuration is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_hbm_traffic.json")))
     sym = KERNEL_SYMBOL.get(entry)
     if not files or sym is None:
         return None, None
@@ -204,6 +228,49 @@ def pmc_traffic(entry: str):
         if sym in name:
             return v["hbm_bytes_per_launch"], os.path.basename(files[-1])
     return None, None
+
+
+def gather_stress(device, n_steps=6):
+    """BASELINE.json configs[4], S-uniform, one GPU: a few eager steps at batch 4096 over a 10 M x 128 fp32 table (5.12 GB, far beyond
+    the 256 MiB Infinity Cache); returns {kernel: avg launch us, algorithmic GB/s, fraction of the 8 TB/s HBM peak} for the step's
+    HBM-bound kernels (K1 gather, K3 segment reduce + partial sums, K4a lazy catch-up, K4b Adam), timed with HIP events."""
+    from amid_amd._lib import KernelTimer, lib
+    from amid_amd.engine import SasrecEngine
+    wl = WORKLOADS["cfg5-uniform"]
+    eng = SasrecEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234)
+    init_params(eng, seed=0)
+    pl = eng.plan(wl["B"], T, 1 + NEG, need_grad=True)
+    gen = torch.Generator().manual_seed(7)
+    packs = []
+    for _ in range(3):
+        b = synth_batch(gen, device, wl)
+        packs.append(eng.pack_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"]))
+    L = lib()
+    for i in range(2 + n_steps):
+        if i == 2:
+            eng.sync()
+            L.timer = KernelTimer()
+        eng.load_packed(pl, packs[i % 3])
+        eng.enqueue_train_step(pl)
+        eng.sync()
+    durs = L.timer.collect(L)
+    L.timer = None
+    work = algorithmic_work(wl["B"], int(pl.n_uniq.item()), T)
+    if getattr(pl, "red_bytes", None):
+        work["amid_grad_tail_f32"] = ("hbm", work["amid_embgrad_segreduce_f32"][1] + pl.red_bytes)
+    role = {"amid_embed_fwd_live_f32": "K1 gather (live sequences)", "amid_embed_fwd_f32": "K1 gather",
+            "amid_grad_tail_f32": "K3 segment reduce + dense partial sums", "amid_embgrad_segreduce_f32": "K3 segment reduce",
+            "amid_lazy_adam_catchup_positions_f32": "K4a lazy-Adam catch-up", "amid_optimizer_step_f32": "K4b Adam (dense + unique rows)"}
+    out = {"workload": wl["label"], "batch": wl["B"], "unique_rows": int(pl.n_uniq.item()), "kernels": {}}
+    for name, v in durs.items():
+        if name in role and name in work:
+            us = 1e3 * sum(v) / len(v)
+            gbps = work[name][1] / (us * 1e-6) / 1e9
+            out["kernels"][name] = {"role": role[name], "avg_launch_us": round(us, 1), "achieved": round(gbps, 1), "unit": "GB/s",
+                                    "peak": PEAK_HBM_GBPS, "frac": round(gbps / PEAK_HBM_GBPS, 4)}
+    del eng, pl
+    torch.cuda.empty_cache()
+    return out
 
 
 def usable_cpus() -> int:
@@ -261,6 +328,10 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
                     help="f32 (default, the headline): exact fp32 matrix products; bf16: bf16 MFMA operands with fp32 accumulation "
                          "(BASELINE.json configs[2]) -- reported with dtype bf16, never the headline line")
+    ap.add_argument("--data", default="real", choices=("real", "synthetic"),
+                    help="real (default where the workload has a fixture: cfg2, cfg3, cfg4): the reference's training CSV as tokenised by "
+                         "its own dataset class (tests/golden/tok_*.npz); synthetic: batches drawn to the file's statistics")
+    ap.add_argument("--no-stress", action="store_true", help="skip the cfg5 gather / scatter stress appended to the headline line")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
                     help="cfg2 = the headline configuration (default); cfg5-* = synthetic gather / scatter stress (SURVEY.md 8(d))")
     args = ap.parse_args()
@@ -299,9 +370,20 @@ def main():
     init_params(eng, seed=0)                  # identical replicas on every rank
     pl = eng.plan(Bw, T, 1 + NEG, need_grad=True)
     gen = torch.Generator().manual_seed(1000 + rank)          # each rank draws its own shard of the global batch
-    n_pool = 60 if args.workload in ("cfg2", "cfg3", "cfg4") else 16     # cfg2: one epoch of cloth_sport_train75 at batch 256
+    use_real = args.data == "real" and args.workload in REAL
+    loader, data_desc = None, "synthetic (batches drawn to the statistics of the file, SURVEY.md section 8(d))"
     pool, uniq_counts = [], []
-    for _ in range(n_pool):                   # batches are packed in the engine's input layout: one device copy per step
+    if use_real:                              # one epoch of the REAL file, sharded by rank, packed once: [n_batches, words] in HBM
+        loader, data_desc = real_batches(args.workload, Bw, device, rank, world)
+        ep = loader.epoch_tensors()
+        packed = eng.pack_epoch(pl, ep["i_node"], ep["neg_samples"], ep["seq_d1"], ep["seq_d2"], ep["label"], ep["domain_id"])
+        pool = list(packed)
+        idx = torch.cat([ep[k].reshape(len(pool), -1) for k in ("i_node", "neg_samples", "seq_d1", "seq_d2")], 1)
+        srt = torch.sort(idx, dim=1).values
+        uniq_counts = ((srt[:, 1:] != srt[:, :-1]).sum(1) + 1).tolist()
+        data_desc = "real: " + data_desc
+    n_pool = len(pool) if use_real else (60 if args.workload in ("cfg2", "cfg3", "cfg4") else 16)
+    for _ in range(0 if use_real else n_pool):          # batches are packed in the engine's input layout: one device copy per step
         b = synth_batch(gen, device, wl)
         pool.append(eng.pack_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"]))
         uniq_counts.append(int(torch.unique(torch.cat([b[k].reshape(-1) for k in ("i_node", "neg_samples", "seq_d1", "seq_d2")])).numel()))
@@ -389,6 +471,9 @@ def main():
             elif v is not None:
                 durs[name] = v
         work = algorithmic_work(Bw, int(pl.n_uniq.item()), T)
+        red_bytes = (getattr(pl, "red_bytes_v", None) if getattr(eng, "_own_domain_only", False) else None) or getattr(pl, "red_bytes", None)
+        if red_bytes:         # K3 (the segment reduce of the row gradients) + the reduce of every dense partial sum, one launch
+            work["amid_grad_tail_f32"] = ("hbm", work["amid_embgrad_segreduce_f32"][1] + red_bytes)
         total_ms = 0.0
         for name, v in durs.items():
             name = name[:-4] if name.endswith(("_rt3", "_rt4", "_rt5")) else name        # the 48- / 64- / 80-row builds of the row-tile kernels
@@ -409,11 +494,45 @@ def main():
         roof = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"], "peak": kernels[dom]["peak"],
                 "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"], "traffic": None,
                 "avg_launch_us": kernels[dom]["avg_launch_us"], "sum_kernel_ms_per_step": round(total_ms, 4)}
-        src = None
-        if args.workload == "cfg2":
-            roof["traffic"], src = pmc_traffic(dom)
+        roof["traffic"], src = pmc_traffic(dom, f"{args.workload}_{args.model}_{args.dtype}")
         if src:
-            roof["traffic_unit"], roof["traffic_source"] = "bytes/launch", "profiles/" + src
+            roof["traffic_unit"] = "bytes/launch"
+            roof["traffic_source"] = "replayed from profiles/" + src + " (PMC passes of this configuration; not collected in this run)"
+
+    # ---- the same job with the epoch's data pipeline inside the clock: every epoch the loader shuffles, draws fresh negatives
+    # (device sampler), packs the epoch and refills the resident pool; then one graph replay per batch (train_sr.py's epoch loop)
+    loader_incl = None
+    if use_real and use_pool and use_graph and world == 1 and args.model == "sasrec":
+        from amid_amd.dataset_seq import DeviceBatches, DualDomainSeqDataset, JointBatches
+        dss = [DualDomainSeqDataset.from_tokenised(os.path.join(FIXTURES, f"tok_{n}.npz")) for n in REAL[args.workload]]
+        if len(dss) == 2:
+            dss[1].shift_items(JOINT_OFFSET)
+        lds = [DeviceBatches(d, Bw, shuffle=True, device=device, seed=1, negatives="device") for d in dss]
+        ld2 = lds[0] if len(lds) == 1 else JointBatches(*lds)
+        while (-eng.step) % n_pool != eng.input_pool(pl)[1]:       # finish the running epoch: the pool is refilled on its boundary
+            step(0)
+        n_ep = max(2, min(20, args.steps // n_pool))
+
+        def epoch():
+            e = ld2.epoch_tensors()
+            pk = eng.pack_epoch(pl, e["i_node"], e["neg_samples"], e["seq_d1"], e["seq_d2"], e["label"], e["domain_id"])
+            eng.stream.wait_stream(torch.cuda.current_stream())
+            if not eng.refill_input_pool(pl, pk):
+                raise RuntimeError("pool refill off an epoch boundary")
+            pk.record_stream(eng.stream)
+            for _ in range(n_pool):
+                eng.replay_train_step(pl)
+
+        epoch()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_ep):
+            epoch()
+        barrier()
+        dt_l = time.perf_counter() - t1
+        loader_incl = {"value": round(Bw * n_pool * n_ep / dt_l, 1), "unit": "samples/s", "epochs": n_ep, "batches_per_epoch": n_pool,
+                       "ms_per_step": round(1e3 * dt_l / (n_pool * n_ep), 4),
+                       "what": "per epoch: device shuffle + negative sampling + pack + pool refill, then one graph replay per batch"}
 
     if world > 1:
         dist.barrier()
@@ -421,7 +540,7 @@ def main():
         out = {
             "metric": "train samples/sec", "value": round(Bw * world * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": data_desc,
             "config": {"workload": wl["label"] if args.model == "sasrec" else wl["label"].replace("SASRec", "BERT4Rec") + " [encoder: bert4rec]",
                        "batch_per_gpu": Bw,
                        "global_batch": Bw * world, "seq_len": T, "emb_dim": D, "hid_dim": HID, "neg": NEG, "table_rows": wl["n_rows"],
@@ -433,6 +552,13 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
+        if loader_incl:
+            out["samples_per_s_loader_included"] = loader_incl
+        if world > 1:
+            ex_bytes = exchange.bytes_per_step() if hasattr(exchange, "bytes_per_step") else None
+            out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "exchange_bytes_per_step_per_rank": ex_bytes}
+        if world == 1 and args.workload == "cfg2" and args.model == "sasrec" and args.dtype == "f32" and not args.no_stress:
+            out["gather_stress"] = gather_stress(device)
         if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

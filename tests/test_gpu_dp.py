@@ -37,7 +37,7 @@ def _worker(rank, world, port, use_graph, q, host_knows_umax=False, pool=False):
         c = CFG
         torch.cuda.set_device(0)
         P = orc.random_params(orc.sasrec_param_shapes(c["n_items"], c["D"], c["T"], c["hid"]), seed=7)
-        eng = SasrecEngine(c["n_items"], c["D"], c["T"], c["hid"], device="cuda:0", lr=c["lr"], seed=c["seed"])
+        eng = SasrecEngine(c["n_items"], c["D"], c["T"], c["hid"], device="cuda:0", lr=c["lr"], seed=SasrecEngine.rank_seed(c["seed"], rank))
         eng.load_state_dict(P)
         Bl = c["B"] // world
         pl = eng.plan(Bl, c["T"], 2, need_grad=True)
@@ -89,8 +89,10 @@ def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax, poo
     opt = orc.DenseAdam(P, lr=c["lr"])
     Bl = c["B"] // world
     for t, batch in enumerate(_batches(), start=1):
-        local_masks = orc.philox_masks_sasrec(Bl, c["T"], c["D"], seed=c["seed"], step=t)       # every rank: same seed, local row indices
-        masks = {k: torch.cat([v] * world, 0) for k, v in local_masks.items()}
+        # every rank draws its own dropout stream (SasrecEngine.rank_seed) over its local row indices
+        from amid_amd.engine import SasrecEngine
+        per_rank = [orc.philox_masks_sasrec(Bl, c["T"], c["D"], seed=SasrecEngine.rank_seed(c["seed"], r), step=t) for r in range(world)]
+        masks = {k: torch.cat([m[k] for m in per_rank], 0) for k in per_rank[0]}
         orc.train_step("sasrec", P, opt, batch, masks)
     sd0, sd1 = ({k: torch.from_numpy(v) for k, v in o[1].items()} for o in outs)
     for k, v in P.items():
