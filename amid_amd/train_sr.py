@@ -23,7 +23,7 @@ import time
 import numpy as np
 import torch
 
-from .dataset_seq import DeviceBatches, DualDomainSeqDataset
+from .dataset_seq import DeviceBatches, DualDomainSeqDataset, JointBatches
 from .model_seq import BERT4Rec, GRU4Rec, SASRec
 from .utils import AverageMeter, device_positive_ranks, init_logger, scores_from_ranks
 
@@ -188,13 +188,25 @@ def main(argv=None):
         user_length = 895510                                                              # train_sr.py:447
         item_length = 447410                                                              # train_sr.py:450
         root = os.path.join(args.data_root, f"{args.dataset_type}_dataset")
-        ds_train = DualDomainSeqDataset(seq_len=args.seq_len, isTrain=True, neg_nums=args.neg_nums, long_length=args.long_length,
-                                        pad_id=item_length + 1, seed=i,
-                                        csv_path=os.path.join(root, f"{args.domain_type}_train{int(args.overlap_ratio * 100)}.csv"))
-        ds_val = DualDomainSeqDataset(seq_len=args.seq_len, isTrain=False, neg_nums=args.neg_nums, long_length=args.long_length,
-                                      pad_id=item_length + 1, seed=1000 + i, csv_path=os.path.join(root, f"{args.domain_type}_test.csv"))
-        train_batches = DeviceBatches(ds_train, args.bs, shuffle=True, device=args.device, seed=i, rank=rank, world=world)
-        val_batches = DeviceBatches(ds_val, args.bs, shuffle=False, device=args.device, seed=i)
+        # "-dm a+b": two datasets trained as ONE job on the shared table (BASELINE.json configs[3]): b's item
+        # ids sit item_length + 2 rows behind a's (a's ids and the pad id are all <= item_length + 1), batches alternate a0 b0 a1 b1 ...
+        parts = args.domain_type.split("+")
+        if len(parts) > 2:
+            raise SystemExit("-dm takes one dataset or two joined with '+'")
+        trains, vals = [], []
+        for j, dm in enumerate(parts):
+            ds_train = DualDomainSeqDataset(seq_len=args.seq_len, isTrain=True, neg_nums=args.neg_nums, long_length=args.long_length,
+                                            pad_id=item_length + 1, seed=i,
+                                            csv_path=os.path.join(root, f"{dm}_train{int(args.overlap_ratio * 100)}.csv"))
+            ds_val = DualDomainSeqDataset(seq_len=args.seq_len, isTrain=False, neg_nums=args.neg_nums, long_length=args.long_length,
+                                          pad_id=item_length + 1, seed=1000 + i, csv_path=os.path.join(root, f"{dm}_test.csv"))
+            if j:
+                ds_train.shift_items(item_length + 2)
+                ds_val.shift_items(item_length + 2)
+            trains.append(DeviceBatches(ds_train, args.bs, shuffle=True, device=args.device, seed=i, rank=rank, world=world))
+            vals.append(DeviceBatches(ds_val, args.bs, shuffle=False, device=args.device, seed=i))
+        train_batches = trains[0] if len(parts) == 1 else JointBatches(*trains)
+        val_batches = vals[0] if len(parts) == 1 else JointBatches(*vals)
         item_length *= 2                                                                  # train_sr.py:456 ("for pad id")
         user_length *= 2
         cls = {"gru4rec": GRU4Rec, "sasrec": SASRec, "bert4rec": BERT4Rec}.get(args.model.lower())

@@ -104,7 +104,7 @@ def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax, poo
         assert float(d.max()) < 1e-4, k
 
 
-def _cli_worker(rank, world, port, root, q):
+def _cli_worker(rank, world, port, root, q, dm="toy", extra=()):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD_SIZE=str(world),
                       RANK=str(rank), LOCAL_RANK=str(rank), AMID_DIST_BACKEND="gloo")
     import amid_amd.train_sr as tsr
@@ -117,9 +117,9 @@ def _cli_worker(rank, world, port, root, q):
         return out
 
     tsr.train = spy
-    summary = tsr.main(["--data_root", root, "-ds", "amazon", "-dm", "toy", "--overlap_ratio", "0.75", "--model", "sasrec", "--bs", "16",
+    summary = tsr.main(["--data_root", root, "-ds", "amazon", "-dm", dm, "--overlap_ratio", "0.75", "--model", "sasrec", "--bs", "16",
                         "--seq_len", "20", "--emb_dim", "64", "--hid_dim", "16", "--epoch", "1", "--neg_nums", "19", "--seeds", "1",
-                        "--device", "cuda:0", "-md", os.path.join(root, "model")])
+                        "--device", "cuda:0", "-md", os.path.join(root, "model")] + list(extra))
     q.put((rank, captured["sd"], {f"{k[0]}/{k[1]}": float(v) for k, v in summary[0].items()}))
 
 
@@ -148,3 +148,69 @@ def test_train_sr_cli_data_parallel_two_ranks(tmp_path):
     for k in sd0:
         assert np.array_equal(sd0[k], sd1[k]), k
     assert m0 == m1 and all(0.0 <= v <= 1.0 for v in m0.values())
+
+
+JOINT_STEPS = 6
+
+
+@pytest.mark.timeout(900)
+def test_train_sr_cli_joint_mode_two_ranks_equals_single_process_oracle(tmp_path):
+    """BASELINE.json configs[3]'s joint mode through the CLI (-dm toy+toyb: shared table, the second dataset's items item_length + 2
+    rows behind the first's, alternating batches) under a two-process launch: both replicas end bit-identical, and equal to ONE
+    process stepping the oracle (dense Adam, the reference's arithmetic) over the same global batches -- each global batch being
+    rank 0's rows followed by rank 1's, with each rank's own dropout stream."""
+    import numpy as np
+    from tests.test_gpu_module import _write_csv
+    from amid_amd.dataset_seq import DeviceBatches, DualDomainSeqDataset, JointBatches
+    from amid_amd.engine import SasrecEngine
+    from amid_amd.model_seq import SASRec
+    rng = np.random.default_rng(2)
+    root = tmp_path / "amazon_dataset"
+    root.mkdir()
+    _write_csv(root / "toy_train75.csv", 140, rng, 1, 400, 400, 900)
+    _write_csv(root / "toy_test.csv", 40, rng, 1, 400, 400, 900)
+    _write_csv(root / "toyb_train75.csv", 100, rng, 1, 300, 300, 800)
+    _write_csv(root / "toyb_test.csv", 40, rng, 1, 300, 300, 800)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cli_worker, args=(r, world, port, str(tmp_path), q, "toy+toyb", ("--max_steps", str(JOINT_STEPS))))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=800) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, sd0, m0), (_, sd1, m1) = outs
+    for k in sd0:
+        assert np.array_equal(sd0[k], sd1[k]), k
+    assert m0 == m1
+
+    # one process, the oracle, the same global batches (world x bs rows each)
+    item_length, T, D, hid, bs = 447410, 20, 64, 16, 16
+    dss = []
+    for j, dm in enumerate(("toy", "toyb")):
+        ds = DualDomainSeqDataset(seq_len=T, isTrain=True, neg_nums=19, long_length=7, pad_id=item_length + 1, seed=0,
+                                  csv_path=str(root / f"{dm}_train75.csv"))
+        if j:
+            ds.shift_items(item_length + 2)
+            assert int(ds.i_node.min()) > item_length + 1
+        dss.append(ds)
+    loader = JointBatches(*[DeviceBatches(d, world * bs, shuffle=True, device="cuda:0", seed=0) for d in dss])
+    assert [w for w, _ in loader.order()][:4] == [0, 1, 0, 1]
+    model = SASRec(user_length=2 * 895510, user_emb_dim=D, item_length=2 * item_length, item_emb_dim=D, seq_len=T, hid_dim=hid, bs=bs,
+                   isInC=False, isItC=False, threshold1=0.5, threshold2=0.5, lr=5e-4, seed=0)
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    del model
+    opt = orc.DenseAdam(P, lr=5e-4)
+    for t, b in zip(range(1, JOINT_STEPS + 1), loader):
+        batch = {k: b[k].cpu() for k in ("i_node", "neg_samples", "seq_d1", "seq_d2", "label", "domain_id")}
+        per_rank = [orc.philox_masks_sasrec(bs, T, D, seed=SasrecEngine.rank_seed(0, r), step=t) for r in range(world)]
+        orc.train_step("sasrec", P, opt, batch, {k: torch.cat([m[k] for m in per_rank], 0) for k in per_rank[0]})
+    for k, v in P.items():
+        d = (torch.from_numpy(sd0[k]) - v).abs()
+        if k.endswith("in_proj_bias"):
+            n = v.numel() // 3
+            d = torch.cat((d[:n], d[2 * n:]))          # the key bias has a zero gradient (softmax shift invariance): Adam noise only
+        assert float(d.max()) < 2e-4, (k, float(d.max()))
