@@ -15,8 +15,16 @@ exactly one exchange, made of
           merge of sorted lists (4 launches) + the segment-reduce kernel it used locally.  Same inputs,
           same fixed summation order => replicas stay bit-identical.
 
-Device-specific work (merging) is delegated to a backend object so the protocol itself is covered
-by world_size-2 gloo tests on CPU, with a test double in place of the HIP kernels.
+  sparse, owner-bucketed (SURVEY.md section 8(e)'s alternative, chosen when the all-gather would move more than
+          `owner_threshold` bytes per rank, i.e. world * umax * D * 4 -- the cfg 5 regime of ~400 k unique rows per rank):
+          every rank splits its list by owner = id % world into `world` buckets, ONE all-to-all hands each owner its buckets, the
+          owner merges them (same merge + segment-reduce kernels, rank order), and ONE all-gather of the reduced lists gives every
+          rank the world's gradient rows -- each id once, however many ranks touched it.  Bucket and reduced-list capacities are
+          sized from the actual counts (two scalar max-reductions per step), so this path runs eagerly, not from a captured graph:
+          at the sizes that select it a step is milliseconds long.
+
+Device-specific work (merging, bucketing) is delegated to a backend object so the protocol itself is covered
+by world_size-2 / -4 gloo tests on CPU, with a test double in place of the HIP kernels.
 """
 from __future__ import annotations
 
@@ -49,10 +57,29 @@ class MergeBackend(Protocol):
         ...
 
 
+    # optional, for the owner-bucketed exchange:
+    #   bucket_counts(uniq_ids, n_uniq, world) -> [world] int tensor: entries per owner (id % world)
+    #   fill_buckets(uniq_ids, uniq_rows, n_uniq, world, bmax) -> [world * chunk(bmax)] float32: the stable split, one packed chunk
+    #       per owner (same layout as pad_packed's), unused slots neutral
+    #   capacity -> int: the largest world * len the merge accepts
+
+
+OWNER_THRESHOLD_BYTES = 64 << 20
+
+
+def round_up(n: int, m: int) -> int:
+    return (int(n) + m - 1) // m * m
+
+
 class SparseDenseExchange:
-    def __init__(self, backend: MergeBackend, group=None, host_staging: bool = False, always: bool = False):
-        """always: run the collectives and the merge even in a world of one (profiling the exchange path on a single GPU)."""
+    def __init__(self, backend: MergeBackend, group=None, host_staging: bool = False, always: bool = False,
+                 owner_threshold: Optional[int] = OWNER_THRESHOLD_BYTES):
+        """always: run the collectives and the merge even in a world of one (profiling the exchange path on a single GPU).
+        owner_threshold: bytes per rank an all-gather of the sparse lists may move (world * umax * D * 4) before the owner-bucketed
+        exchange takes over; None = never, 0 = always (tests)."""
         self.always = always
+        self.owner_threshold = owner_threshold
+        self.stats = {"collectives": 0, "bytes_out": 0, "bytes_in": 0, "owner_steps": 0, "gather_steps": 0}
         self.backend = backend
         self.group = group
         # host_staging: move collective payloads through host memory (for process groups without device
@@ -70,8 +97,14 @@ class SparseDenseExchange:
     def active(self) -> bool:
         return self.world > 1 or self.always
 
+    def _count(self, out_bytes: int, in_bytes: int) -> None:
+        self.stats["collectives"] += 1
+        self.stats["bytes_out"] += int(out_bytes)
+        self.stats["bytes_in"] += int(in_bytes)
+
     def all_reduce_dense(self, flat_grad: torch.Tensor) -> None:
         if self.active:
+            self._count(flat_grad.numel() * 4, flat_grad.numel() * 4)
             if self.host_staging and flat_grad.is_cuda:
                 h = flat_grad.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -89,7 +122,30 @@ class SparseDenseExchange:
             else:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
 
+    def all_to_all_packed(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        """send = world equal chunks, chunk r for rank r; recv = world chunks, chunk r from rank r."""
+        self._count(send.numel() * 4, recv.numel() * 4)
+        if self.host_staging and send.is_cuda:
+            h = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(h, send.cpu(), group=self.group)
+            recv.copy_(h)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
+
+    def _max_over_world(self, t: torch.Tensor) -> int:
+        """max over the ranks of a device scalar; one small host synchronisation."""
+        h = t.detach().reshape(1).to("cpu" if self.host_staging else t.device, torch.int64)
+        if self.world > 1:
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+        return int(h.item())
+
+    def use_owner(self, umax: Optional[int], D: int) -> bool:
+        """Whether a step whose largest per-rank unique count is `umax` takes the owner-bucketed exchange."""
+        return (self.active and self.owner_threshold is not None and umax is not None and hasattr(self.backend, "fill_buckets")
+                and self.world * int(umax) * D * 4 > self.owner_threshold)
+
     def all_gather_packed(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        self._count(send.numel() * 4, recv.numel() * 4)
         if self.host_staging and send.is_cuda:
             h = torch.empty(recv.shape, dtype=recv.dtype)
             dist.all_gather_into_tensor(h, send.cpu(), group=self.group)
@@ -111,10 +167,35 @@ class SparseDenseExchange:
             dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=self.group)
             umax = int(nmax.item())
         umax = max(1, min(int(umax), uniq_ids.numel()))
+        if self.use_owner(umax, uniq_rows.shape[1]):
+            out = self._exchange_owner(uniq_ids, uniq_rows, n_uniq)
+            if out is not None:
+                self.stats["owner_steps"] += 1
+                return out
+        self.stats["gather_steps"] += 1
         send = self.backend.pad_packed(uniq_ids, uniq_rows, n_uniq, umax)
         recv = self.backend.gather_buffer(self.world, umax)
         self.all_gather_packed(send, recv)                       # ids and rows of a rank travel together: ONE collective
         return self.backend.merge_packed(recv, self.world, umax)
+
+    def _exchange_owner(self, uniq_ids, uniq_rows, n_uniq):
+        """Owner-bucketed exchange: split by id % world -> all-to-all -> owner merge -> all-gather of the reduced lists -> merge
+        (the reduced lists are disjoint, so the last merge only interleaves them).  None when a reduced list is too long for the
+        backend (ids crowding on one owner): the caller falls back to the plain all-gather; the decision is taken on world-reduced
+        counts, so every rank takes it alike."""
+        be, W = self.backend, self.world
+        bmax = round_up(max(1, self._max_over_world(be.bucket_counts(uniq_ids, n_uniq, W).max())), 64)
+        send = be.fill_buckets(uniq_ids, uniq_rows, n_uniq, W, bmax)
+        recv = be.gather_buffer(W, bmax)
+        self.all_to_all_packed(send, recv)
+        ids_o, rows_o, n_o = be.merge_packed(recv, W, bmax)                     # this owner's ids, each once, rows summed in rank order
+        rmax = min(round_up(max(1, self._max_over_world(n_o)), 64), ids_o.numel())
+        if W * rmax > be.capacity:
+            return None
+        send2 = be.pad_packed(ids_o, rows_o, n_o, rmax)
+        recv2 = be.gather_buffer(W, rmax)
+        self.all_gather_packed(send2, recv2)
+        return be.merge_packed(recv2, W, rmax)
 
 
 class TorchMergeBackend:
@@ -133,6 +214,25 @@ class TorchMergeBackend:
         out[:umax] = ids.to(torch.int32).view(torch.float32)
         out[id_rows * D:] = (uniq_rows[:umax] * (~pad).unsqueeze(1).to(uniq_rows.dtype)).reshape(-1)
         return out
+
+    capacity = 1 << 30
+
+    def bucket_counts(self, uniq_ids, n_uniq, world):
+        n = int(n_uniq)
+        return torch.bincount(uniq_ids[:n].long() % world, minlength=world)
+
+    def fill_buckets(self, uniq_ids, uniq_rows, n_uniq, world, bmax):
+        """One pad_packed() chunk per owner; the boolean selection keeps the ascending order (stable split)."""
+        n = int(n_uniq)
+        ids, rws = uniq_ids[:n], uniq_rows[:n]
+        chunks = []
+        for o in range(world):
+            sel = (ids.long() % world) == o
+            k = int(sel.sum())
+            bi = torch.cat((ids[sel], uniq_ids[0:1].expand(max(bmax - k, 0))))            # neutral padding as in pad_packed
+            br = torch.cat((rws[sel], torch.zeros(max(bmax - k, 0), self.D, dtype=rws.dtype, device=rws.device)))
+            chunks.append(self.pad_packed(bi, br, torch.tensor([k], dtype=torch.int32), bmax))
+        return torch.cat(chunks)
 
     def gather_buffer(self, world, umax):
         return torch.empty(world * packed_rows(umax, self.D)[1] * self.D, dtype=torch.float32, device=self.device)

@@ -1098,7 +1098,8 @@ class SasrecEngine:
             umax = max(1, min(int(umax), pl.shape.n_idx))      # clamp BEFORE it keys the captured graph pair (as dist.exchange_sparse does)
         with torch.cuda.stream(self.stream):
             self.grad_scale = exchange.grad_scale
-            fast = use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")
+            fast = (use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")
+                    and not exchange.use_owner(umax, self.D))      # the owner-bucketed exchange sizes its buffers per step: eager
             pair = getattr(pl, "dp_graphs", {}).get(umax) if fast else None
             if pair is not None:       # graph A, ONE collective (the dense gradient rides behind the sparse rows), graph B
                 L.call("amid_graph_launch", pair[0], self.s)
@@ -1242,9 +1243,34 @@ class HipMergeBackend:
         self.all = torch.zeros((self.cap + (self.cap + D - 1) // D + 16 * 16 + self.MAX_WORLD * self.dense_rows) * D, dtype=torch.float32,
                                device=dev)
         self._entries = {}
+        # owner-bucketed exchange (dist.SparseDenseExchange._exchange_owner): per-owner counts (+ the fill's overflow flag)
+        self.owner_ws = torch.empty(L.value("amid_owner_workspace_bytes", self.cap), dtype=torch.uint8, device=dev)
+        self.owner_counts = torch.zeros(self.MAX_WORLD + 1, dtype=torch.int32, device=dev)
         torch.cuda.synchronize(dev)
 
     MAX_WORLD = 16
+
+    @property
+    def capacity(self) -> int:
+        return self.cap
+
+    def bucket_counts(self, uniq_ids: torch.Tensor, n_uniq: torch.Tensor, world: int) -> torch.Tensor:
+        """[world] int32: how many of this rank's unique ids each owner (id % world) gets; also prepares fill_buckets()."""
+        lib().call("amid_owner_count_i32", uniq_ids.data_ptr(), n_uniq.data_ptr(), uniq_ids.numel(), world, self.owner_ws.data_ptr(),
+                   self.owner_counts.data_ptr(), self.eng.s)
+        return self.owner_counts[:world]
+
+    def fill_buckets(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, world: int, bmax: int) -> torch.Tensor:
+        """The stable split of (ids, rows) by owner into `world` packed chunks of bmax entries (after bucket_counts() on the same list)."""
+        from .dist import packed_rows
+        D = self.eng.D
+        id_rows, rows = packed_rows(bmax, D)
+        if world * rows * D > self.send.numel():
+            raise ValueError(f"{world} buckets of {bmax} entries exceed the backend capacity {self.cap}")
+        send = self.send[: world * rows * D]
+        lib().call("amid_owner_buckets_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), uniq_ids.numel(), D, world, bmax,
+                   self.eng.n_rows, self.owner_ws.data_ptr(), send.data_ptr(), rows * D, id_rows, self.owner_counts.data_ptr(), self.eng.s)
+        return send
 
     def _entry(self, key, src: int, dst: int, stride: int, n_part: int, count: int) -> torch.Tensor:
         """A one-entry table for amid_reduce_partials_f32 (device resident, cached: captured graphs keep pointing at it)."""

@@ -437,11 +437,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    ex0 = dict(exchange.stats) if exchange is not None else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    ex1 = dict(exchange.stats) if exchange is not None else None
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -555,8 +557,13 @@ def main():
         if loader_incl:
             out["samples_per_s_loader_included"] = loader_incl
         if world > 1:
-            ex_bytes = exchange.bytes_per_step() if hasattr(exchange, "bytes_per_step") else None
-            out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "exchange_bytes_per_step_per_rank": ex_bytes}
+            per = lambda k: round((ex1[k] - ex0[k]) / args.steps, 1)       # noqa: E731
+            out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                           "collectives_per_step": per("collectives"), "bytes_sent_per_step_per_rank": per("bytes_out"),
+                           "bytes_received_per_step_per_rank": per("bytes_in"),
+                           "sparse_exchange": "owner-bucketed (all-to-all + all-gather)" if ex1["owner_steps"] > ex0["owner_steps"]
+                           else "all-gather of per-rank unique rows, dense gradient riding behind",
+                           "padded_unique_rows_per_rank": umax_pool[0]}
         if world == 1 and args.workload == "cfg2" and args.model == "sasrec" and args.dtype == "f32" and not args.no_stress:
             out["gather_stress"] = gather_stress(device)
         if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":

@@ -103,6 +103,18 @@ int amid_merge_sorted_lists_sum_i32(const int* keys, int world, int len, long lo
                                     void* workspace, int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq,
                                     const void* entries_dev, int n_entries, int max_count, void* stream);
 
+/* Owner-bucketed sparse exchange (the alternative for large unique-row counts; the reference has no multi-GPU
+ * path to mirror: train_sr.py:473).  count: counts[o] = how many of the first n_uniq (device scalar, <= cap) ascending unique ids
+ * have id % world == o (o < world <= 16); counts[world] = 0 (the fill's overflow flag).  workspace: amid_owner_workspace_bytes(cap),
+ * shared by the two calls.  buckets: the stable split of (ids, rows) into `world` packed chunks at out + o * chunk_floats, each
+ * [id_rows rows of D floats holding bmax int32 ids | bmax gradient rows] -- the layout amid_merge_sorted_lists_i32 reads; slots past
+ * an owner's count carry `sentinel` and a zero row; an owner with more than bmax entries sets counts[world] = 1 (nothing is written
+ * out of range). */
+long long amid_owner_workspace_bytes(int cap);
+int amid_owner_count_i32(const int* uniq_ids, const int* n_uniq, int cap, int world, void* workspace, int* counts, void* stream);
+int amid_owner_buckets_f32(const int* uniq_ids, const float* uniq_rows, const int* n_uniq, int cap, int D, int world, int bmax, int sentinel,
+                           const void* workspace, float* out, long long chunk_floats, int id_rows, int* counts, void* stream);
+
 /* amid_embgrad_segreduce_f32 + amid_reduce_partials_f32 with their first phases in ONE launch (the two independent ends of backward
  * side by side without a second stream) */
 int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,

@@ -1,6 +1,6 @@
-"""world_size-2 gloo tests (CPU) of the data-parallel exchange protocol in amid_amd/dist.py.
+"""world_size-2 / -4 gloo tests (CPU) of the data-parallel exchange protocol in amid_amd/dist.py.
 The HIP merge kernels are replaced by a torch test double; the protocol (flat dense all-reduce,
-padded sparse all-gather, merge, 1/world scaling) is the code under test."""
+padded sparse all-gather or the owner-bucketed all-to-all + all-gather, merge, 1/world scaling) is the code under test."""
 import os
 import socket
 
@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, host_knows_umax):
+def _worker(rank, world, port, q, host_knows_umax, owner=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -29,7 +29,8 @@ def _worker(rank, world, port, q, host_knows_umax):
         n_items, D, T, hid, B = 120, 16, 10, 8, 8
         P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=3)
         batch = orc.synthetic_batch(B, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=5)
-        ex = SparseDenseExchange(TorchMergeBackend(D))
+        # owner: the owner-bucketed exchange (split by id % world, all-to-all, owner merge, all-gather) whatever the size
+        ex = SparseDenseExchange(TorchMergeBackend(D), owner_threshold=0 if owner else None)
         assert ex.world == world and ex.rank == rank and ex.grad_scale == 1.0 / world
         local = shard_batch(batch, rank, world)
         _, _, g = orc.loss_and_grads("sasrec", P, local, None)
@@ -54,18 +55,21 @@ def _worker(rank, world, port, q, host_knows_umax):
         U = int(mnu.item())
         table_grad = torch.zeros(n_items, D)
         table_grad[mid[:U].long()] = mrows[:U]
+        assert ex.stats["owner_steps" if owner else "gather_steps"] == 1 and ex.stats["gather_steps" if owner else "owner_steps"] == 0
+        assert ex.stats["collectives"] == (3 if owner else 2)          # dense all-reduce + (all-to-all, all-gather | all-gather)
         q.put((rank, (flat * ex.grad_scale).numpy(), (table_grad * ex.grad_scale).numpy(), int(nu.item()), U))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("host_knows_umax", [False, True])
+@pytest.mark.parametrize("world,host_knows_umax,owner", [(2, False, False), (2, True, False), (2, False, True), (2, True, True),
+                                                         (4, False, True), (4, True, False)])
 @pytest.mark.timeout(300)
-def test_exchange_world2_matches_single_process_global_batch(host_knows_umax):
-    world, port = 2, _free_port()
+def test_exchange_matches_single_process_global_batch(world, host_knows_umax, owner):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, host_knows_umax)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, host_knows_umax, owner)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
@@ -84,8 +88,8 @@ def test_exchange_world2_matches_single_process_global_batch(host_knows_umax):
         assert float((flat - want_flat).abs().max()) < 1e-6
         assert float((tab - want_tab).abs().max()) < 1e-6
         assert U >= nu
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])    # replicas identical
-    assert outs[0][3] != outs[1][3] or True
+    for o in outs[1:]:
+        assert torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])    # replicas identical
 
 
 def test_exchange_world1_is_passthrough():
@@ -99,3 +103,21 @@ def test_exchange_world1_is_passthrough():
     g = f.clone()
     ex.all_reduce_dense(g)
     assert torch.equal(f, g)
+
+
+def test_torch_backend_buckets_are_a_stable_split():
+    from amid_amd.dist import TorchMergeBackend, packed_rows
+    D, W = 8, 4
+    be = TorchMergeBackend(D)
+    ids = torch.tensor([1, 2, 4, 5, 8, 9, 13, 21, 0, 0], dtype=torch.int32)
+    rows = torch.arange(10 * D, dtype=torch.float32).reshape(10, D)
+    nu = torch.tensor([8], dtype=torch.int32)
+    cnt = be.bucket_counts(ids, nu, W)
+    assert cnt.tolist() == [2, 5, 1, 0]
+    bmax = 6
+    out = be.fill_buckets(ids, rows, nu, W, bmax).view(W, -1)
+    id_rows, tot = packed_rows(bmax, D)
+    got = out[:, :bmax].contiguous().view(torch.int32)
+    assert got[0, :2].tolist() == [4, 8] and got[1, :5].tolist() == [1, 5, 9, 13, 21] and got[2, :1].tolist() == [2]
+    r = out[:, id_rows * D:].reshape(W, bmax, D)
+    assert torch.equal(r[1, :5], rows[[0, 3, 5, 6, 7]]) and float(r[1, 5:].abs().sum()) == 0.0 and float(r[3].abs().sum()) == 0.0

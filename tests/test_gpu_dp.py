@@ -23,25 +23,45 @@ def _free_port():
     return p
 
 
+def _get(q, procs, timeout=500):
+    """q.get() that gives up as soon as a worker has died instead of waiting out the whole timeout."""
+    import queue
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            return q.get(timeout=2)
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                raise AssertionError("a worker process failed: " + str([p.exitcode for p in procs]))
+            if time.time() - t0 > timeout:
+                raise
+
+
 def _batches():
     c = CFG
     return [orc.synthetic_batch(c["B"], c["T"], c["n_items"] - 1, pad_id=c["n_items"] - 1, neg=1, seed=500 + t) for t in range(c["K"])]
 
 
-def _worker(rank, world, port, use_graph, q, host_knows_umax=False, pool=False):
+def _worker(rank, world, port, use_graph, q, host_knows_umax=False, pool=False, owner=False, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    devi = rank if backend == "nccl" else 0               # RCCL refuses two ranks on one device ("Duplicate GPU detected")
+    if backend == "nccl":
+        torch.cuda.set_device(devi)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", devi))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from amid_amd.dist import SparseDenseExchange, shard_batch
         from amid_amd.engine import SasrecEngine
         c = CFG
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(devi)
         P = orc.random_params(orc.sasrec_param_shapes(c["n_items"], c["D"], c["T"], c["hid"]), seed=7)
-        eng = SasrecEngine(c["n_items"], c["D"], c["T"], c["hid"], device="cuda:0", lr=c["lr"], seed=SasrecEngine.rank_seed(c["seed"], rank))
+        eng = SasrecEngine(c["n_items"], c["D"], c["T"], c["hid"], device=f"cuda:{devi}", lr=c["lr"], seed=SasrecEngine.rank_seed(c["seed"], rank))
         eng.load_state_dict(P)
         Bl = c["B"] // world
         pl = eng.plan(Bl, c["T"], 2, need_grad=True)
-        ex = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=True)
+        ex = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=backend != "nccl", owner_threshold=0 if owner else None)
         first = True
         if pool:                 # the rank's shards of all K batches resident in HBM; the step picks its batch by the device step counter
             packed = []
@@ -60,27 +80,33 @@ def _worker(rank, world, port, use_graph, q, host_knows_umax=False, pool=False):
             umax = None
             if host_knows_umax:       # what a data pipeline does while packing: count the uniques, max-reduce ahead of the step
                 cnt = torch.tensor([int(torch.unique(torch.cat([local[k].reshape(-1) for k in ("i_node", "neg_samples", "seq_d1", "seq_d2")])).numel())])
+                cnt = cnt.cuda() if backend == "nccl" else cnt
                 dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
                 umax = (int(cnt) + 63) // 64 * 64             # a bucketed bound: the graph pair of the exchange is reused across steps
             eng.train_step_dp(pl, ex, use_graph=use_graph, umax=umax)
             eng.sync()
         eng.flush_table()
         eng.sync()
+        assert ex.stats["owner_steps"] == (c["K"] if owner else 0) and (not owner or ex.stats["gather_steps"] == 0)
+        assert int(ex.backend.owner_counts[world].item()) == 0          # no bucket overflowed
         q.put((rank, {k: v.cpu().numpy().copy() for k, v in eng.state_dict().items()}, float(pl.loss.item())))   # by value
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph,host_knows_umax,pool", [(False, False, False), (True, False, False), (True, True, False), (True, True, True)])
+@pytest.mark.parametrize("use_graph,host_knows_umax,pool,owner", [(False, False, False, False), (True, False, False, False),
+                                                                   (True, True, False, False), (True, True, True, False),
+                                                                   (False, False, False, True), (True, True, True, True)])
 @pytest.mark.timeout(600)
-def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax, pool):
+def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax, pool, owner):
+    """owner: the owner-bucketed sparse exchange (amid_owner_count_i32 / amid_owner_buckets_f32 + all-to-all + all-gather)."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, use_graph, q, host_knows_umax, pool)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_graph, q, host_knows_umax, pool, owner)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -102,6 +128,26 @@ def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax, poo
             n = v.numel() // 3
             d = torch.cat((d[:n], d[2 * n:]))
         assert float(d.max()) < 1e-4, k
+
+
+@pytest.mark.parametrize("owner", [False, True])
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL refuses two ranks on one device (ncclInvalidUsage: Duplicate GPU detected; "
+                    "profiles/tools/probe/nccl_two_ranks_one_gpu.py), so the nccl leg needs two GPUs; the single-GPU box runs the gloo legs")
+@pytest.mark.timeout(600)
+def test_two_rank_dp_over_rccl_two_gpus(owner):
+    """The same two-rank step with the production backend: RCCL ("nccl"), one GPU per rank, device collectives, no host staging."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, True, q, True, True, owner, "nccl")) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in outs[0][1]:
+        assert (outs[0][1][k] == outs[1][1][k]).all(), f"replicas diverged on {k}"
 
 
 def _cli_worker(rank, world, port, root, q, dm="toy", extra=()):
@@ -140,7 +186,7 @@ def test_train_sr_cli_data_parallel_two_ranks(tmp_path):
     procs = [ctx.Process(target=_cli_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -178,7 +224,7 @@ def test_train_sr_cli_joint_mode_two_ranks_equals_single_process_oracle(tmp_path
              for r in range(world)]
     for p in procs:
         p.start()
-    outs = sorted([q.get(timeout=800) for _ in range(world)], key=lambda t: t[0])
+    outs = sorted([_get(q, procs, 800) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

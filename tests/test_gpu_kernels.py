@@ -507,3 +507,48 @@ def test_wgrad_rows_hint_equals_plain(L, B, T):
     for gdom in range(2):          # against the plain definition dW = dY^T X
         want = dy[0][gdom * M:(gdom + 1) * M].double().t() @ xx[0][gdom * M:(gdom + 1) * M].double()
         assert relmax(outs[1][0][gdom, 0].view(D, D), want) < 1e-5
+
+
+@pytest.mark.parametrize("n,world,D", [(1, 2, 64), (300, 2, 128), (5000, 4, 128), (70000, 8, 128), (2049, 16, 64), (777, 3, 128)])
+def test_owner_buckets_equal_torch_split(L, n, world, D):
+    """amid_owner_count_i32 / amid_owner_buckets_f32 (the split of the owner-bucketed exchange) against the
+    protocol's torch double (amid_amd.dist.TorchMergeBackend): counts, ids and rows bit-exact, sentinel + zero rows in the unused
+    slots, the overflow flag when the bound is too small."""
+    from amid_amd.dist import TorchMergeBackend, packed_rows
+    g = torch.Generator().manual_seed(n)
+    n_rows = 1_000_003
+    cap = n + 37
+    ids = torch.sort(torch.randperm(n_rows, generator=g)[:n]).values.to(torch.int32)
+    ids_full = torch.cat((ids, torch.full((cap - n,), 12345, dtype=torch.int32)))          # garbage beyond n_uniq
+    rows = torch.randn(cap, D, generator=g)
+    want_cnt = torch.bincount(ids.long() % world, minlength=world)
+    bmax = (int(want_cnt.max()) + 63) // 64 * 64
+    d_ids, d_rows, d_n = ids_full.cuda(), rows.cuda(), torch.tensor([n], dtype=torch.int32).cuda()
+    ws = torch.empty(L.value("amid_owner_workspace_bytes", cap), dtype=torch.uint8, device="cuda")
+    cnt = torch.full((17,), -1, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    L.call("amid_owner_count_i32", d_ids.data_ptr(), d_n.data_ptr(), cap, world, ws.data_ptr(), cnt.data_ptr(), s)
+    assert cnt[:world].cpu().tolist() == want_cnt.tolist() and int(cnt[world]) == 0
+    id_rows, tot = packed_rows(bmax, D)
+    out = torch.full((world, tot * D), 7.0, device="cuda")
+    L.call("amid_owner_buckets_f32", d_ids.data_ptr(), d_rows.data_ptr(), d_n.data_ptr(), cap, D, world, bmax, n_rows, ws.data_ptr(),
+           out.data_ptr(), tot * D, id_rows, cnt.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert int(cnt[world]) == 0
+    out = out.cpu()
+    got_ids = out[:, :bmax].contiguous().view(torch.int32)
+    got_rows = out[:, id_rows * D:].reshape(world, bmax, D)
+    for o in range(world):
+        sel = (ids.long() % world) == o
+        k = int(sel.sum())
+        assert torch.equal(got_ids[o, :k], ids[sel]) and bool((got_ids[o, k:] == n_rows).all())
+        assert torch.equal(got_rows[o, :k], rows[:n][sel]) and float(got_rows[o, k:].abs().sum()) == 0.0
+    if int(want_cnt.max()) > 1:                                     # a bound that is too small: flagged, nothing out of range
+        small = int(want_cnt.max()) - 1
+        id_rows2, tot2 = packed_rows(small, D)
+        out2 = torch.full((world, tot2 * D + 64), 7.0, device="cuda")
+        L.call("amid_owner_count_i32", d_ids.data_ptr(), d_n.data_ptr(), cap, world, ws.data_ptr(), cnt.data_ptr(), s)
+        L.call("amid_owner_buckets_f32", d_ids.data_ptr(), d_rows.data_ptr(), d_n.data_ptr(), cap, D, world, small, n_rows, ws.data_ptr(),
+               out2.data_ptr(), tot2 * D + 64, id_rows2, cnt.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert int(cnt[world]) == 1 and bool((out2[:, tot2 * D:] == 7.0).all())
