@@ -289,6 +289,94 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(float* __restrict__
     }
 }
 
+// The data-parallel optimizer: the whole of "graph B" as ONE launch, reading the world's gathered chunks directly.  Chunk r (at
+// gathered + r * chunk_floats) = [id rows: umax ascending unique ids, sentinel-padded | umax gradient rows | the rank's flat dense
+// gradient].  Dense role: g = the ranks' dense parts summed in rank order, then Adam.  Row role: entry (r, i) is applied by the
+// FIRST rank whose list holds its id (a binary search of every earlier list), with the rows of the later lists that hold the same
+// id added in rank order -- the same sums on every rank, hence bit-identical replicas, without the merge / segment-reduce launches.
+__device__ __forceinline__ int find_id(const int* __restrict__ ids, int n, int x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ids[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && ids[lo] == x) ? lo : -1;
+}
+
+__global__ __launch_bounds__(256) void optimizer_gathered_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                                 float* __restrict__ g, long long n, int dense_blocks,
+                                                                 float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
+                                                                 int* __restrict__ last, const float* __restrict__ gathered, int world, int umax,
+                                                                 long long chunk_floats, int id_rows, long long dense_off, int D, int sentinel,
+                                                                 const StepState* __restrict__ stp, float grad_scale) {
+    __shared__ AdamCoef tab[COEF_TAB];
+    const StepState st = *stp;
+    if ((int)blockIdx.x < dense_blocks) {
+        const AdamCoef c = adam_coef(st, pow_step(st.beta1, st.step), pow_step(st.beta2, st.step));
+        const long long stride = (long long)dense_blocks * blockDim.x * 4;
+        const float* d0 = gathered + dense_off;
+        for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+            if (i + 4 <= n) {
+                float4 gg = ld4(d0 + i);
+                for (int r = 1; r < world; ++r) {
+                    const float4 t = ld4(d0 + r * chunk_floats + i);
+                    gg.x += t.x; gg.y += t.y; gg.z += t.z; gg.w += t.w;
+                }
+                st4(g + i, gg);
+                float4 pp = ld4(p + i), mm = ld4(m + i), vv = ld4(v + i);
+                adam_quad(pp, mm, vv, f4scale(gg, grad_scale), c);
+                st4(p + i, pp); st4(m + i, mm); st4(v + i, vv);
+            } else {
+                for (long long k = i; k < n; ++k) {
+                    float gs = d0[k];
+                    for (int r = 1; r < world; ++r) gs += d0[r * chunk_floats + k];
+                    g[k] = gs;
+                    adam_elem(p[k], m[k], v[k], gs * grad_scale, c);
+                }
+            }
+        }
+        return;
+    }
+    const long long t = st.step;
+    const int rb = blockIdx.x - dense_blocks, n_rb = gridDim.x - dense_blocks;
+    const int total = world * umax;
+    if (rb * 8 >= total) return;
+    fill_coef_table(tab, st);
+    const int sub = threadIdx.x & 31;
+    const int q = D >> 2;
+    for (int u = rb * 8 + (threadIdx.x >> 5); u < total; u += n_rb * 8) {
+        const int r0 = u / umax, i0 = u - r0 * umax;
+        const int x = ((const int*)(gathered + r0 * chunk_floats))[i0];
+        if (x >= sentinel) continue;                                   // padding
+        // lane `sub` of the half-wave searches rank sub's list; the half-wave then shares what was found
+        const int half = (threadIdx.x >> 5) & 1;
+        int j = -1;
+        if (sub < world && sub != r0) j = find_id((const int*)(gathered + sub * chunk_floats), umax, x);
+        const unsigned int fm = (unsigned int)(__ballot(j >= 0) >> (32 * half));
+        if (fm & ((1u << r0) - 1u)) continue;                          // an earlier rank's entry applies this id
+        const long long row = x;
+        const long long l = last[row];
+        const bool lag = (l > 0 && l < t - 1);
+        for (int c = sub; c < q; c += 32) {
+            float4 gg = ld4(gathered + r0 * chunk_floats + (long long)(id_rows + i0) * D + 4 * c);
+            for (int r = r0 + 1; r < world; ++r) {                     // the later ranks' rows of the same id, in rank order
+                const int jr = __shfl(j, 32 * half + r);
+                if ((fm >> r) & 1u) {
+                    const float4 tt = ld4(gathered + r * chunk_floats + (long long)(id_rows + jr) * D + 4 * c);
+                    gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w;
+                }
+            }
+            const long long off = row * D + 4 * c;
+            float4 pp = ld4(table + off), mm = ld4(m_tab + off), vv = ld4(v_tab + off);
+            if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
+            adam_quad(pp, mm, vv, f4scale(gg, grad_scale), tab[COEF_TAB - 1]);
+            st4(table + off, pp); st4(m_tab + off, mm); st4(v_tab + off, vv);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (sub == 0) last[row] = (int)t;
+    }
+}
+
 }  // namespace amid
 
 using namespace amid;
@@ -366,6 +454,24 @@ extern "C" int amid_optimizer_step_f32(float* p, float* m, float* v, const float
     const int rb = rows_grid(n_uniq_max);
     optimizer_step_kernel<<<(int)db + rb, 256, 0, (hipStream_t)stream>>>(p, m, v, g, n, (int)db, table, m_tab, v_tab, last, uniq_ids, n_uniq,
                                                                           uniq_grad, D, (const StepState*)step_state, grad_scale);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_optimizer_step_gathered_f32(float* p, float* m, float* v, float* g, long long n, float* table, float* m_tab, float* v_tab,
+                                                int* last, const float* gathered, int world, int umax, long long chunk_floats, int id_rows,
+                                                long long dense_off, int D, int sentinel, float grad_scale, const void* step_state,
+                                                void* stream) {
+    AMID_CHECK_ARG(p && m && v && g && n > 0 && table && m_tab && v_tab && last && gathered && step_state && D > 0 && (D % 4) == 0);
+    AMID_CHECK_ARG(world > 0 && world <= 16 && umax > 0 && id_rows * (long long)D >= umax && dense_off >= (long long)(id_rows + umax) * D &&
+                   (dense_off % 4) == 0 && (chunk_floats % 4) == 0 && chunk_floats >= dense_off + n);
+    long long db = (n / 4 + 255) / 256;
+    if (db < 1) db = 1;
+    if (db > 1024) db = 1024;
+    const int rb = rows_grid((long long)world * umax);
+    optimizer_gathered_kernel<<<(int)db + rb, 256, 0, (hipStream_t)stream>>>(p, m, v, g, n, (int)db, table, m_tab, v_tab, last, gathered, world,
+                                                                              umax, chunk_floats, id_rows, dense_off, D, sentinel,
+                                                                              (const StepState*)step_state, grad_scale);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -126,12 +126,10 @@ __global__ __launch_bounds__(256) void grad_tail_kernel(const float* __restrict_
 
 // phase B: the chunk in which a border-crossing run STARTS owns its final sum
 template <int VEC>
-__global__ __launch_bounds__(1024) void segreduce_spans_kernel(const int* __restrict__ seg_off, const int* __restrict__ seg_of, int n,
-                                                               const float* __restrict__ partial, float* __restrict__ uniq_grad,
-                                                               int chunk = SEG_CHUNK) {
+__device__ __forceinline__ void segreduce_spans_block(int c, const int* __restrict__ seg_off, const int* __restrict__ seg_of, int n,
+                                                      const float* __restrict__ partial, float* __restrict__ uniq_grad, int chunk) {
     const int D = VEC * 64;
     __shared__ float red[16][VEC * 64];
-    const int c = blockIdx.x;
     const int e0 = c * chunk;
     if (e0 >= n) return;
     const int e_end = min(e0 + chunk, n);
@@ -169,6 +167,41 @@ __global__ __launch_bounds__(1024) void segreduce_spans_kernel(const int* __rest
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[k][d];
         uniq_grad[(long long)u * D + d] = s;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(1024) void segreduce_spans_kernel(const int* __restrict__ seg_off, const int* __restrict__ seg_of, int n,
+                                                               const float* __restrict__ partial, float* __restrict__ uniq_grad,
+                                                               int chunk = SEG_CHUNK) {
+    segreduce_spans_block<VEC>(blockIdx.x, seg_off, seg_of, n, partial, uniq_grad, chunk);
+}
+
+// The data-parallel step's grad tail: phase B of the segment reduce, and behind it the packing of this rank's exchange chunk -- the
+// unique ids padded to n_out with pad_id (blocks [nch, nch + id_blocks)) and a copy of the flat dense gradient, which the first
+// launch of the tail has just summed (the remaining blocks).  The gradient rows need no copy: the segment reduce writes them into
+// the chunk.  Rows past n_uniq stay stale; their ids say "padding".
+template <int VEC>
+__global__ __launch_bounds__(1024) void segreduce_spans_pack_kernel(const int* __restrict__ seg_off, const int* __restrict__ seg_of, int n,
+                                                                    const float* __restrict__ partial, float* __restrict__ uniq_grad, int nch,
+                                                                    const int* __restrict__ ids, const int* __restrict__ n_uniq, int n_out,
+                                                                    int pad_id, int* __restrict__ out_ids, int id_blocks,
+                                                                    const float* __restrict__ dense_src, float* __restrict__ dense_dst,
+                                                                    long long dense_n) {
+    const int b = blockIdx.x;
+    if (b < nch) {
+        segreduce_spans_block<VEC>(b, seg_off, seg_of, n, partial, uniq_grad, SEG_CHUNK);
+        return;
+    }
+    if (b < nch + id_blocks) {
+        const int r = (b - nch) * 1024 + threadIdx.x;
+        if (r < n_out) out_ids[r] = r < *n_uniq ? ids[r] : pad_id;
+        return;
+    }
+    const long long nb = gridDim.x - nch - id_blocks;
+    for (long long i = ((long long)(b - nch - id_blocks) * 1024 + threadIdx.x) * 4; i < dense_n; i += nb * 4096) {
+        if (i + 4 <= dense_n) st4(dense_dst + i, ld4(dense_src + i));
+        else for (long long k = i; k < dense_n; ++k) dense_dst[k] = dense_src[k];
     }
 }
 
@@ -237,6 +270,35 @@ extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted,
 #define AMID_TAIL_LAUNCH(VEC)                                                                                                       \
     grad_tail_kernel<VEC><<<n_seg + bx * n_entries, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial, n_seg, en, bx); \
     segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad);
+    if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }
+#undef AMID_TAIL_LAUNCH
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+extern "C" int amid_grad_tail_pack_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                                       void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count,
+                                       const int* uniq_ids, const int* n_uniq, int n_out, int pad_id, int* out_ids, const float* dense_src,
+                                       float* dense_dst, long long dense_n, void* stream) {
+    AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
+                   max_count > 0);
+    AMID_CHECK_ARG(uniq_ids && n_uniq && out_ids && n_out > 0 && n_out <= n_idx && dense_src && dense_dst && dense_n > 0 &&
+                   ((((unsigned long long)dense_src) | ((unsigned long long)dense_dst)) & 15) == 0);
+    if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK, n_seg = (nch + 3) / 4;
+    int bx = (max_count + 127) / 128;
+    if (bx > 512) bx = 512;
+    float* partial = (float*)workspace;
+    const ReduceEntry* en = (const ReduceEntry*)entries_dev;
+    const int id_blocks = (n_out + 1023) / 1024;
+    long long cb = (dense_n / 4 + 1023) / 1024;
+    if (cb < 1) cb = 1;
+    if (cb > 256) cb = 256;
+#define AMID_TAIL_LAUNCH(VEC)                                                                                                       \
+    grad_tail_kernel<VEC><<<n_seg + bx * n_entries, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial, n_seg, en, bx); \
+    segreduce_spans_pack_kernel<VEC><<<nch + id_blocks + (int)cb, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad, nch, uniq_ids, n_uniq, \
+                                                                              n_out, pad_id, out_ids, id_blocks, dense_src, dense_dst, dense_n);
     if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }
 #undef AMID_TAIL_LAUNCH
     AMID_LAUNCH_CHECK();

@@ -988,6 +988,16 @@ class SasrecEngine:
         buffer (dense gradients + loss) and the segment reduce of the table-row gradients."""
         L, s, shp = lib(), self.s, pl.shape
         self.join_sort()                          # pos_sorted / seg_off come from the side-stream sort
+        pk = getattr(self, "_tail_pack", None)
+        if pk is not None:       # graph A of the data-parallel step: the tail also packs this rank's exchange chunk (ids | rows | dense)
+            from .dist import packed_rows
+            send, umax = pk
+            id_rows, rows = packed_rows(umax, self.D)
+            L.call("amid_grad_tail_pack_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), shp.n_idx,
+                   self.D, pl.seg_ws.data_ptr(), send.data_ptr() + 4 * id_rows * self.D, (pl.red_entries_v if live else pl.red_entries).data_ptr(),
+                   pl.red_n_v if live else pl.red_n, pl.red_max_v if live else pl.red_max, pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), umax,
+                   self.n_rows, send.data_ptr(), self.dense.grad.data_ptr(), send.data_ptr() + 4 * rows * self.D, self.dense.numel, s)
+            return
         L.call("amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), shp.n_idx,
                self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), (pl.red_entries_v if live else pl.red_entries).data_ptr(),
                pl.red_n_v if live else pl.red_n, pl.red_max_v if live else pl.red_max, s)
@@ -1006,6 +1016,19 @@ class SasrecEngine:
         L.call("amid_optimizer_step_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel,
                self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), ids.data_ptr(),
                nu.data_ptr(), cap, rows.data_ptr(), self.D, self.grad_scale, self.step_state.data_ptr(), s)
+
+    def enqueue_optimizer_gathered(self, be: "HipMergeBackend", recv: torch.Tensor, world: int, umax: int) -> None:
+        """The data-parallel optimizer: ONE launch over the world's gathered chunks (ids | rows | dense gradient per rank) -- the
+        rank-ordered sums of the dense parts and of the rows of equal ids happen inside it (amid_optimizer_step_gathered_f32), so
+        the step needs no merge / segment-reduce launches after the all-gather."""
+        from .dist import packed_rows
+        self._ensure_opt_state()
+        fp, D = self.dense, self.D
+        id_rows, rows = packed_rows(umax, D)
+        lib().call("amid_optimizer_step_gathered_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel,
+                   self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), recv.data_ptr(),
+                   world, umax, be.chunk_rows(umax, fp.grad) * D, id_rows, rows * D, D, self.n_rows, self.grad_scale,
+                   self.step_state.data_ptr(), self.s)
 
     def enqueue_step_begin(self) -> None:
         lib().call("amid_step_begin", self.step_state.data_ptr(), self.s)
@@ -1127,12 +1150,16 @@ class SasrecEngine:
         for part in (0, 1):
             L.call("amid_graph_capture_begin", self.s)
             try:
-                if part == 0:
-                    self.enqueue_local_grads(pl)
-                    send = be.pad_packed(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax, dense=self.dense.grad)
+                if part == 0:          # the tail of backward packs the chunk itself: no padding launch (amid_grad_tail_pack_f32)
+                    send = be.send[: be.chunk_rows(umax, self.dense.grad) * self.D]
+                    self._tail_pack = (send, umax)
+                    try:
+                        self.enqueue_local_grads(pl)
+                    finally:
+                        self._tail_pack = None
                 else:
                     recv = be.gather_buffer(exchange.world, umax, dense=self.dense.grad)
-                    self.enqueue_optimizer(pl, sparse=be.merge_packed(recv, exchange.world, umax, dense=self.dense.grad, sum_dense=True))
+                    self.enqueue_optimizer_gathered(be, recv, exchange.world, umax)
             finally:
                 out = ctypes.c_void_p()
                 L.call("amid_graph_capture_end", self.s, ctypes.byref(out))

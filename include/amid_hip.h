@@ -119,6 +119,13 @@ int amid_owner_buckets_f32(const int* uniq_ids, const float* uniq_rows, const in
  * side by side without a second stream) */
 int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
                        void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count, void* stream);
+/* amid_grad_tail_f32 that also packs this rank's chunk of the data-parallel exchange in its second launch: uniq_grad points INTO the
+ * chunk (the segment reduce writes the rows in place), out_ids[0, n_out) <- the first n_uniq unique ids then pad_id, and
+ * dense_dst[0, dense_n) <- dense_src (the flat dense gradient the first launch has just reduced); 16-byte aligned dense pointers. */
+int amid_grad_tail_pack_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                            void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count, const int* uniq_ids,
+                            const int* n_uniq, int n_out, int pad_id, int* out_ids, const float* dense_src, float* dense_dst,
+                            long long dense_n, void* stream);
 
 /* ---- K4 optimizer ----------------------------------------------------------------------------
  * replaces: torch.optim.Adam(model.parameters(), lr).step(), train_sr.py:480, :215 (dense over the table).
@@ -136,6 +143,14 @@ int amid_adam_dense_f32(float* p, float* m, float* v, const float* g, long long 
 int amid_optimizer_step_f32(float* p, float* m, float* v, const float* g, long long n, float* table, float* m_tab, float* v_tab,
                             int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max, const float* uniq_grad, int D,
                             float grad_scale, const void* step_state, void* stream);
+/* The data-parallel optimizer as ONE launch over the world's gathered chunks (the reference has no multi-GPU path: train_sr.py:473).
+ * Chunk r at gathered + r * chunk_floats = [id_rows rows of D floats holding umax ascending unique int32 ids, padded with `sentinel`
+ * (> every id) | umax gradient rows | at dense_off: the rank's flat dense gradient, n floats].  g <- the ranks' dense parts summed in
+ * rank order, then dense Adam; every table row whose id occurs in some chunk gets the lazy row Adam with the rows of equal ids
+ * summed in rank order.  world <= 16; dense_off and chunk_floats multiples of 4. */
+int amid_optimizer_step_gathered_f32(float* p, float* m, float* v, float* g, long long n, float* table, float* m_tab, float* v_tab,
+                                     int* last, const float* gathered, int world, int umax, long long chunk_floats, int id_rows,
+                                     long long dense_off, int D, int sentinel, float grad_scale, const void* step_state, void* stream);
 
 /* ---- SASRec encoder layer, forward ------------------------------------------------------------
  * Pointer-array arguments are HOST arrays of 2 device pointers (domain 0, domain 1).

@@ -22,14 +22,23 @@ for _ in range(30):
     pool.append(eng.pack_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"]))
     cnt.append(int(torch.unique(torch.cat([b[k].reshape(-1) for k in ("i_node", "neg_samples", "seq_d1", "seq_d2")])).numel()))
 ex = SparseDenseExchange(eng.merge_backend(pl.shape.n_idx), always=True)
-eng.load_packed(pl, pool[0]); eng.capture_local_grads(pl)
+eng.set_input_pool(pl, torch.stack(pool))          # as bench.py: the batches stay in HBM, the step picks its batch on the device
+eng.capture_local_grads(pl)
+def single(n):
+    eng.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(n):
+        eng.replay_train_step(pl)
+    eng.sync(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
 def run(n, umax_known):
     eng.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(n):
-        eng.load_packed(pl, pool[i % 30])
         eng.train_step_dp(pl, ex, use_graph=True, umax=cnt[i % 30] if umax_known else None)
     eng.sync(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
+eng.capture_train_step(pl)
+single(30)
+print("single-GPU whole-step graph : %.4f ms/step" % single(300))
 run(20, True)
 print("dp path, host knows umax : %.4f ms/step" % run(200, True))
 cap = (max(cnt) + 255) // 256 * 256
@@ -39,4 +48,4 @@ run(5, True)
 print("dp path, fixed bound %d, graph pair : %.4f ms/step" % (cap, run(200, True)))
 cnt = cnt_b
 print("dp path, host sync / step: %.4f ms/step" % run(200, False))
-dist.destroy_process_group()
+eng.sync(); torch.cuda.synchronize(); dist.barrier(); dist.destroy_process_group()
