@@ -245,6 +245,322 @@ __global__ __launch_bounds__(1024) void heads_fused_kernel(const int* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Two-pass sort in FOUR launches (keys below 2^24: every table up to 16.7 M rows).  Digits of ceil(bits / 2) and floor(bits / 2) bits
+// (cfg 2: 10 + 10, cfg 5: 12 + 12 -- up to 4096 bins); tiles of 2048 keys, supertiles of 16 tiles.  For each pass p three tables
+// say where a tile's keys of a bin go:  gtot_p[bin] (all keys), stot_p[supertile][bin], counts_p[tile][bin]; a scatter block adds up
+// base(bin) = exclusive scan of gtot_p, the earlier supertiles' stot_p and the earlier tiles' counts_p of its own supertile
+// (at most n_super + 15 coalesced, cached rows) -- nothing waits for another block, nothing is scanned by a single block.
+//   launch 1  os_count     counts_0 (plain stores), stot_0 / gtot_0 / gtot_1 (atomics; digit totals do not depend on the order);
+//                          zeroes counts_1 / stot_1 and launch 4's status words
+//   launch 2  os_scatter   stable scatter by digit 0; every key also bumps counts_1 / stot_1 of the tile its DESTINATION lies in
+//                          (pass 1's tiles are contiguous slices of this pass's output)
+//   launch 3  os_scatter   stable scatter by digit 1 -> sorted keys + positions; zeroes stot_0 / gtot_0 for the next call
+//   launch 4  os_heads     run heads: per-tile count, a wave-parallel look-back over the earlier tiles' status words gives the tile's
+//                          first run index (tile ids are handed out by an atomic counter: a tile only waits for tiles that already
+//                          run); writes uniq_ids / seg_off / seg_of / n_uniq; zeroes gtot_1 for the next call
+// The workspace must be zero-filled once before its first use; every call leaves it ready for the next.
+constexpr int OS_BINS_MAX = 4096;
+constexpr int OS_STATE_INTS = 64;                 // [2] tile counter of launch 4
+constexpr int OS_SUPER = 16;                      // tiles per supertile
+
+struct OsGeom {
+    int n, ntiles;
+    int shift, bits;                              // this pass's digit
+    int next_shift, next_bits;                    // the other pass's digit
+};
+
+__device__ __forceinline__ unsigned long long match_bits(unsigned d, bool valid, int bits) {
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+        const unsigned long long m = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    return peers;
+}
+
+// BINS: LDS is sized for 1024 bins when both digits have at most 10 bits (every table below 2^20 rows: 12 KB in the scatter) -- small
+// enough to share a CU with a one-workgroup-per-CU kernel of the main stream (the fused forward holds 144 of the 160 KB).
+template <int BINS>
+__global__ __launch_bounds__(SORT_THREADS) void os_count_kernel(const int* __restrict__ keys, OsGeom g, int* __restrict__ state,
+                                                                int* __restrict__ counts0, int* __restrict__ stot0, int* __restrict__ gtot0,
+                                                                int* __restrict__ gtot1, int* __restrict__ counts1, long long n_counts1,
+                                                                int* __restrict__ stot1, int n_stot1, int* __restrict__ hstatus) {
+    __shared__ int hist0[BINS], hist1[BINS];
+    const int bins0 = 1 << g.bits, bins1 = 1 << g.next_bits;
+    for (int d = threadIdx.x; d < bins0; d += SORT_THREADS) hist0[d] = 0;
+    for (int d = threadIdx.x; d < bins1; d += SORT_THREADS) hist1[d] = 0;
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const int base = blockIdx.x * SORT_TILE + w * (64 * SORT_ITEMS);
+    const unsigned mask0 = (unsigned)bins0 - 1u, mask1 = (unsigned)bins1 - 1u;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int k = base + i * 64 + lane;
+        const bool valid = k < g.n;
+        const unsigned key = valid ? (unsigned)keys[k] : 0u;
+        const unsigned d0 = (key >> g.shift) & mask0, d1 = (key >> g.next_shift) & mask1;
+        const unsigned long long peers = match_bits(d0, valid, g.bits);
+        if (valid && (__ffsll((long long)peers) - 1) == lane) atomicAdd(&hist0[d0], __popcll(peers));
+        // digit 1: the lanes that share the first lane's value (a wave full of the pad id) add once, the others one by one
+        const unsigned lead = __builtin_amdgcn_readfirstlane(d1);
+        const unsigned long long same = __ballot(valid && d1 == lead);
+        if (valid) {
+            if (d1 == lead) { if ((__ffsll((long long)same) - 1) == lane) atomicAdd(&hist1[d1], __popcll(same)); }
+            else atomicAdd(&hist1[d1], 1);
+        }
+    }
+    __syncthreads();
+    const int sup = blockIdx.x / OS_SUPER;
+    for (int d = threadIdx.x; d < bins0; d += SORT_THREADS) {
+        const int c = hist0[d];
+        counts0[(long long)blockIdx.x * bins0 + d] = c;
+        if (c) { atomicAdd(&stot0[(long long)sup * bins0 + d], c); atomicAdd(&gtot0[d], c); }
+    }
+    for (int d = threadIdx.x; d < bins1; d += SORT_THREADS) {
+        const int c = hist1[d];
+        if (c) atomicAdd(&gtot1[d], c);
+    }
+    // housekeeping for the later launches of this call
+    for (long long i = (long long)blockIdx.x * SORT_THREADS + threadIdx.x; i < n_counts1; i += (long long)gridDim.x * SORT_THREADS) counts1[i] = 0;
+    for (int i = blockIdx.x * SORT_THREADS + threadIdx.x; i < n_stot1; i += gridDim.x * SORT_THREADS) stot1[i] = 0;
+    for (int i = blockIdx.x * SORT_THREADS + threadIdx.x; i < g.ntiles; i += gridDim.x * SORT_THREADS) hstatus[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[2] = 0;
+}
+
+// stable scatter of one pass.  COUNT_NEXT (pass 0): also the next pass's counts / stot (global atomics).  !COUNT_NEXT (pass 1):
+// zeroes the atomically accumulated tables of pass 0 for the next call (zero_a = stot_0, zero_b = gtot_0; launch 4 zeroes gtot_1,
+// which the blocks of this launch are still reading).
+template <bool COUNT_NEXT, int BINS>
+__global__ __launch_bounds__(SORT_THREADS) void os_scatter_kernel(const int* __restrict__ keys_in, const int* __restrict__ vals_in,
+                                                                  int* __restrict__ keys_out, int* __restrict__ vals_out, OsGeom g,
+                                                                  const int* __restrict__ counts, const int* __restrict__ stot,
+                                                                  const int* __restrict__ gtot, int* __restrict__ counts_next,
+                                                                  int* __restrict__ stot_next, int* __restrict__ zero_a, int n_zero_a,
+                                                                  int* __restrict__ zero_b) {
+    __shared__ unsigned short woff[SORT_WAVES][BINS];           // per-wave digit counts, then running offsets inside the tile's bin
+    __shared__ int tile_base[BINS];                             // output position of the tile's first key of every bin
+    __shared__ int wsum[SORT_WAVES];
+    const int bins = 1 << g.bits;
+    const unsigned mask = (unsigned)bins - 1u;
+    const int w = wave_id(), lane = lane_id();
+    for (int i = threadIdx.x; i < SORT_WAVES * BINS / 2; i += SORT_THREADS) ((unsigned*)&woff[0][0])[i] = 0u;
+    __syncthreads();
+    const int kb = blockIdx.x * SORT_TILE + w * (64 * SORT_ITEMS);
+    int key[SORT_ITEMS];
+    unsigned long long peers[SORT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int k = kb + i * 64 + lane;
+        const bool valid = k < g.n;
+        key[i] = valid ? keys_in[k] : 0;
+        const unsigned d = ((unsigned)key[i] >> g.shift) & mask;
+        peers[i] = match_bits(d, valid, g.bits);
+        // one leader per digit group and round, rounds in program order: no two lanes ever update the same counter at once
+        if (valid && (__ffsll((long long)peers[i]) - 1) == lane) woff[w][d] = (unsigned short)(woff[w][d] + __popcll(peers[i]));
+        __builtin_amdgcn_wave_barrier();
+    }
+    // where the tile's keys of every bin start: thread t owns the bins [t * per, (t + 1) * per) -- bin totals first (for the scan)
+    const int per = bins / SORT_THREADS > 0 ? bins / SORT_THREADS : 1;
+    const int d0 = threadIdx.x * per;
+    const int sup = blockIdx.x / OS_SUPER;
+    int mine = 0;
+    if (d0 < bins) for (int k = 0; k < per; ++k) mine += gtot[d0 + k];
+    int x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();                                             // (also: every wave's woff counts are complete)
+    // earlier supertiles' stot rows + the earlier tiles' counts rows of this supertile, summed per bin into tile_base: every thread
+    // reads its `per` consecutive bins of a row as int4s (a wave covers a contiguous KB), four rows in flight
+    const int nrows = sup + ((int)blockIdx.x - sup * OS_SUPER);
+    auto rowp = [&](int r) -> const int* {
+        return r < sup ? stot + (long long)r * bins : counts + (long long)(sup * OS_SUPER + (r - sup)) * bins;
+    };
+    if (d0 < bins) {
+        if ((per & 3) == 0) {
+            for (int k = 0; k < per; k += 4) {
+                int4 acc = make_int4(0, 0, 0, 0);
+                int r = 0;
+                for (; r + 4 <= nrows; r += 4) {
+                    const int4 a = *(const int4*)(rowp(r) + d0 + k), b = *(const int4*)(rowp(r + 1) + d0 + k);
+                    const int4 c = *(const int4*)(rowp(r + 2) + d0 + k), e = *(const int4*)(rowp(r + 3) + d0 + k);
+                    acc.x += a.x + b.x + c.x + e.x; acc.y += a.y + b.y + c.y + e.y;
+                    acc.z += a.z + b.z + c.z + e.z; acc.w += a.w + b.w + c.w + e.w;
+                }
+                for (; r < nrows; ++r) {
+                    const int4 a = *(const int4*)(rowp(r) + d0 + k);
+                    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+                }
+                *(int4*)&tile_base[d0 + k] = acc;
+            }
+        } else {
+            for (int k = 0; k < per; ++k) {
+                int acc = 0;
+                for (int r = 0; r < nrows; ++r) acc += rowp(r)[d0 + k];
+                tile_base[d0 + k] = acc;
+            }
+        }
+        int run = x - mine;
+        for (int k = 0; k < w; ++k) run += wsum[k];
+        for (int k = 0; k < per; ++k) {
+            const int d = d0 + k;
+            tile_base[d] += run;                                 // + base(d)
+            run += gtot[d];
+            unsigned wrun = 0;
+#pragma unroll
+            for (int q = 0; q < SORT_WAVES; ++q) {
+                const unsigned c = woff[q][d];
+                woff[q][d] = (unsigned short)wrun;
+                wrun += c;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned nmask = (1u << g.next_bits) - 1u;
+    const int nbins = 1 << g.next_bits;
+    int pend_cell = -1, pend_n = 0;                 // wave-uniform: the leading cell of the last rounds and its carried count
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int k = kb + i * 64 + lane;
+        const bool valid = k < g.n;
+        const unsigned d = ((unsigned)key[i] >> g.shift) & mask;
+        int dst = 0;
+        if (valid) dst = tile_base[d] + woff[w][d] + __popcll(peers[i] & lt);
+        __builtin_amdgcn_wave_barrier();            // every lane has read the offset before the leader bumps it
+        if (valid && (__ffsll((long long)peers[i]) - 1) == lane) woff[w][d] = (unsigned short)(woff[w][d] + __popcll(peers[i]));
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            keys_out[dst] = key[i];
+            vals_out[dst] = vals_in ? vals_in[k] : k;
+        }
+        if (COUNT_NEXT) {
+            // counts_next[dst / tile][digit 1] (+ the supertile's stot_next).  Equal keys share digit 1 and land next to each other, and
+            // the pad id is 80-90 % of a real batch: the lanes that share the first lane's cell are counted together and the count is
+            // CARRIED across the rounds while the leading cell stays the same (same-address atomics serialise in L2: one per wave
+            // and cell instead of one per round); the other lanes add one each.
+            const int tile1 = dst / SORT_TILE;
+            const int d1 = (int)(((unsigned)key[i] >> g.next_shift) & nmask);
+            const int cell = valid ? tile1 * nbins + d1 : -1;
+            const int lead_cell = __builtin_amdgcn_readfirstlane(cell);
+            const unsigned long long same = __ballot(valid && cell == lead_cell);
+            if (lead_cell >= 0) {
+                if (lead_cell == pend_cell) pend_n += __popcll(same);
+                else {
+                    if (pend_n && lane == 0) {
+                        atomicAdd(&counts_next[pend_cell], pend_n);
+                        atomicAdd(&stot_next[(long long)(pend_cell / nbins / OS_SUPER) * nbins + (pend_cell % nbins)], pend_n);
+                    }
+                    pend_cell = lead_cell;
+                    pend_n = __popcll(same);
+                }
+            }
+            if (valid && cell != lead_cell) {
+                atomicAdd(&counts_next[cell], 1);
+                atomicAdd(&stot_next[(long long)(tile1 / OS_SUPER) * nbins + d1], 1);
+            }
+        }
+    }
+    if (COUNT_NEXT) {           // the waves' carried counts: equal cells of the four waves merged, then one atomic each
+        __shared__ int pc[SORT_WAVES], pn[SORT_WAVES];
+        if (lane == 0) { pc[w] = pend_cell; pn[w] = pend_n; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int a = 0; a < SORT_WAVES; ++a) {
+                int n_a = pn[a];
+                if (!n_a) continue;
+#pragma unroll
+                for (int b = a + 1; b < SORT_WAVES; ++b)
+                    if (pn[b] && pc[b] == pc[a]) { n_a += pn[b]; pn[b] = 0; }
+                atomicAdd(&counts_next[pc[a]], n_a);
+                atomicAdd(&stot_next[(long long)(pc[a] / nbins / OS_SUPER) * nbins + (pc[a] % nbins)], n_a);
+            }
+        }
+    }
+    if (!COUNT_NEXT) {
+        for (int i2 = blockIdx.x * SORT_THREADS + threadIdx.x; i2 < n_zero_a; i2 += gridDim.x * SORT_THREADS) zero_a[i2] = 0;
+        for (int i2 = blockIdx.x * SORT_THREADS + threadIdx.x; i2 < OS_BINS_MAX; i2 += gridDim.x * SORT_THREADS) zero_b[i2] = 0;
+    }
+}
+
+// run heads of the sorted keys in one launch: thread t of a tile owns 8 consecutive entries
+constexpr unsigned OS_ST_AGG = 1u << 30, OS_ST_PRE = 2u << 30, OS_ST_VAL = (1u << 30) - 1u;
+__global__ __launch_bounds__(SORT_THREADS) void os_heads_kernel(const int* __restrict__ keys, int n, int ntiles, int* __restrict__ state,
+                                                                unsigned* __restrict__ hstatus, int* __restrict__ n_uniq,
+                                                                int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of,
+                                                                int* __restrict__ zero_g) {
+    __shared__ int tile_s, excl_s;
+    for (int i2 = blockIdx.x * SORT_THREADS + threadIdx.x; i2 < OS_BINS_MAX; i2 += gridDim.x * SORT_THREADS) zero_g[i2] = 0;
+    __shared__ int wsum[SORT_WAVES];
+    if (threadIdx.x == 0) tile_s = atomicAdd(&state[2], 1);
+    __syncthreads();
+    const int tile = tile_s;
+    const int lane = lane_id(), w = wave_id();
+    const int i0 = tile * SORT_TILE + threadIdx.x * SORT_ITEMS;
+    int k[SORT_ITEMS];
+    int prev = (i0 > 0 && i0 < n) ? keys[i0 - 1] : 0;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        const int i = i0 + j;
+        k[j] = i < n ? keys[i] : 0;
+        cnt += (i < n && (i == 0 || k[j] != (j ? k[j - 1] : prev))) ? 1 : 0;
+    }
+    int x = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < SORT_WAVES; ++q) { if (q < w) woff += wsum[q]; total += wsum[q]; }
+    if (w == 0) {                                       // wave 0: publish the tile's count, look back, publish the inclusive prefix
+        int excl = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(&hstatus[tile], OS_ST_AGG | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int t = tile - 1;
+            while (true) {
+                const int idx = t - lane;
+                const unsigned s = idx >= 0 ? __hip_atomic_load(&hstatus[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_ST_PRE;
+                const unsigned long long nr = __ballot((s >> 30) == 0u), pre = __ballot((s >> 30) == 2u);
+                const int first_pre = pre ? __ffsll((long long)pre) - 1 : 64;
+                const int first_nr = nr ? __ffsll((long long)nr) - 1 : 64;
+                if (first_nr < first_pre) { __builtin_amdgcn_s_sleep(2); continue; }     // a tile before the nearest prefix is not ready
+                const int upto = first_pre < 64 ? first_pre : 63;
+                int v = lane <= upto ? (int)(s & OS_ST_VAL) : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                excl += v;
+                if (first_pre < 64) break;
+                t -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&hstatus[tile], OS_ST_PRE | (unsigned)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            excl_s = excl;
+            if (tile == ntiles - 1) { *n_uniq = excl + total; seg_off[excl + total] = n; }
+        }
+    }
+    __syncthreads();
+    int u = excl_s + woff + x - cnt - 1;                // run index of the entry before this thread's span
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        const int i = i0 + j;
+        if (i < n) {
+            if (i == 0 || k[j] != (j ? k[j - 1] : prev)) { ++u; uniq_ids[u] = k[j]; seg_off[u] = i; }
+            seg_of[i] = u;
+        }
+    }
+}
+
 // Stable merge of `world` sorted lists of `len` keys each (list r = keys[r * len ..]): the merged position of entry (r, i) with
 // key x is i + sum over the other lists of (# keys < x), or (# keys <= x) for lists of lower rank -- ties go in rank order, so the
 // result equals a stable sort of the concatenation.  All binary searches of a thread advance in lock-step (independent loads).
@@ -306,6 +622,13 @@ using namespace amid;
 static inline int sort_nblk(int n) { return (n + SORT_TILE - 1) / SORT_TILE; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// four-launch sort: [state | gtot0 | gtot1 | stot0 | stot1 | counts0 | counts1 | hstatus]
+static inline size_t os_nsuper(size_t ntiles) { return (ntiles + OS_SUPER - 1) / OS_SUPER; }
+static inline size_t os_bytes(size_t ntiles) {
+    return align256(OS_STATE_INTS * 4) + 2 * align256(OS_BINS_MAX * 4) + 2 * align256(os_nsuper(ntiles) * OS_BINS_MAX * 4) +
+           2 * align256(ntiles * OS_BINS_MAX * 4) + align256(ntiles * 4);
+}
+
 extern "C" long long amid_sort_unique_workspace_bytes(int n_idx) {
     if (n_idx <= 0) return 256;
     const size_t nblk = sort_nblk(n_idx);
@@ -313,7 +636,20 @@ extern "C" long long amid_sort_unique_workspace_bytes(int n_idx) {
     b += 4 * align256((size_t)n_idx * 4);            // keys a/b, vals a/b
     b += align256(256 * nblk * 4);                   // digit counts / offsets
     b += align256(((size_t)n_idx + 255) / 256 * 4);  // per-block head counts
+    b += os_bytes(nblk);                             // state of the four-launch sort
     return (long long)b;
+}
+
+// Lists of at least this many indices take the four-launch sort.  Shorter ones (every per-step list of the cfg 1-4 shapes) keep the
+// 8-bit passes: that sort runs on a side stream beside the encoder, where its many 5-9 us launches of 13 small blocks cost nothing,
+// while the four ~15 us launches of the two-pass sort hold their CUs long enough to delay the one-round kernels of the main stream
+// (measured at cfg 2: 0.408 -> 0.432 ms per step).  At cfg 5 (418 k indices) the sort is exposed: 574 -> 125 us.
+static int g_four_launch_min = 65536;
+
+extern "C" int amid_sort_set_four_launch_min(int n_idx) {
+    const int prev = g_four_launch_min;
+    if (n_idx >= 0) g_four_launch_min = n_idx;
+    return prev;
 }
 
 extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
@@ -329,6 +665,33 @@ extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows,
     int* blk_heads = (int*)(ws + 4 * kb + align256((size_t)256 * nblk * 4));
     int bits = 1;
     while (bits < 31 && (1LL << bits) < n_rows) ++bits;
+    if (bits <= 24 && n_idx >= g_four_launch_min) {            // four launches (see os_count_kernel)
+        char* os = ws + 4 * kb + align256((size_t)256 * nblk * 4) + align256(((size_t)n_idx + 255) / 256 * 4);
+        const size_t nsup = os_nsuper(nblk);
+        int* state = (int*)os;
+        int* gtot0 = (int*)(os + align256(OS_STATE_INTS * 4));
+        int* gtot1 = (int*)((char*)gtot0 + align256(OS_BINS_MAX * 4));
+        int* stot0 = (int*)((char*)gtot1 + align256(OS_BINS_MAX * 4));
+        int* stot1 = (int*)((char*)stot0 + align256(nsup * OS_BINS_MAX * 4));
+        int* counts0 = (int*)((char*)stot1 + align256(nsup * OS_BINS_MAX * 4));
+        int* counts1 = (int*)((char*)counts0 + align256((size_t)nblk * OS_BINS_MAX * 4));
+        unsigned* hstatus = (unsigned*)((char*)counts1 + align256((size_t)nblk * OS_BINS_MAX * 4));
+        if (bits < 2) bits = 2;
+        const int b0 = (bits + 1) / 2, b1 = bits - b0;
+        OsGeom g0{n_idx, nblk, 0, b0, b0, b1}, g1{n_idx, nblk, b0, b1, 0, b0};
+#define AMID_OS_LAUNCH(BINS)                                                                                                              \
+        os_count_kernel<BINS><<<nblk, SORT_THREADS, 0, s>>>(idx, g0, state, counts0, stot0, gtot0, gtot1, counts1, (long long)nblk << b1, stot1, \
+                                                            (int)(nsup << b1), (int*)hstatus);                                            \
+        os_scatter_kernel<true, BINS><<<nblk, SORT_THREADS, 0, s>>>(idx, nullptr, keys[0], vals[0], g0, counts0, stot0, gtot0, counts1, stot1,  \
+                                                                    nullptr, 0, nullptr);                                                 \
+        os_scatter_kernel<false, BINS><<<nblk, SORT_THREADS, 0, s>>>(keys[0], vals[0], keys[1], pos_sorted, g1, counts1, stot1, gtot1, nullptr, \
+                                                                     nullptr, stot0, (int)(nsup << b0), gtot0);
+        if (b0 <= 10) { AMID_OS_LAUNCH(1024) } else { AMID_OS_LAUNCH(4096) }
+#undef AMID_OS_LAUNCH
+        os_heads_kernel<<<nblk, SORT_THREADS, 0, s>>>(keys[1], n_idx, nblk, state, hstatus, n_uniq, uniq_ids, seg_off, seg_of, gtot1);
+        AMID_LAUNCH_CHECK();
+        return AMID_OK;
+    }
     const int passes = (bits + 7) / 8;
     const int* kin = idx;
     const int* vin = nullptr;

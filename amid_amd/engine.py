@@ -17,6 +17,7 @@ Memory layout (all fp32, resident in HBM for the life of the engine):
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -241,7 +242,7 @@ class SasrecPlan:
         if dr:
             self.sc_part_ips, self.sc_part_g = f(B, self.sc_P), f(B, self.sc_P)
         # sparse side
-        self.sort_ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", N), dtype=torch.uint8, device=dev)
+        self.sort_ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", N), dtype=torch.uint8, device=dev)
         self.pos_sorted = torch.zeros(N, dtype=torch.int32, device=dev)
         self.uniq_ids = torch.zeros(N, dtype=torch.int32, device=dev)
         self.seg_off = torch.zeros(N + 1, dtype=torch.int32, device=dev)
@@ -395,7 +396,7 @@ class SasrecEngine:
         # every kernel of the engine runs on this (non-default, hence capturable) HIP stream
         self.stream = torch.cuda.Stream(device=self.device)
         # the index sort only feeds the segment reduce after backward: it runs on this side stream, beside the forward pass
-        self.side = torch.cuda.Stream(device=self.device)
+        self.side = self.stream if os.environ.get("AMID_SORT_SERIAL") else torch.cuda.Stream(device=self.device)
         self.ev_idx = torch.cuda.Event()
         self.ev_sorted = torch.cuda.Event()
         self.n_rows, self.D, self.T, self.hid, self.H = int(item_length), int(emb_dim), int(seq_len), int(hid_dim), self.HEADS
@@ -622,6 +623,7 @@ class SasrecEngine:
             self.step += 1
             if sparse:
                 self.ev_idx.record(self.stream)
+                self._sort_owed = bool(defer_sort)
                 if not defer_sort:
                     self.enqueue_sort(pl)
             return
@@ -637,6 +639,7 @@ class SasrecEngine:
             self.step += 1
         if sparse:
             self.ev_idx.record(self.stream)       # fork point: the index list is complete
+            self._sort_owed = bool(defer_sort)
             if not defer_sort:
                 self.enqueue_sort(pl)
 
@@ -648,6 +651,7 @@ class SasrecEngine:
                pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_uniq.data_ptr(), self.side.cuda_stream)
         self.ev_sorted.record(self.side)
         self._sort_pending = True
+        self._sort_owed = False
 
     def join_sort(self) -> None:
         """Make the main stream wait for the side-stream sort (no-op if nothing is pending)."""
@@ -966,6 +970,7 @@ class SasrecEngine:
                    pl.dpre2[l].data_ptr()]
             xx += [pl.qn[l].data_ptr(), pl.x[l].data_ptr(), pl.x[l].data_ptr(), pl.o[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr()]
         # NOTE: pl.x[0] is the gathered-row buffer xg, still intact here (its gradient lives in dxg)
+        self._fork_sort(pl, "wgrad")
         L.call("amid_sas_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
                ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), self._own_rows(pl), B, T, s)
         if live:     # the dead sequences' rows of the encoder-input gradient were never written: zero-filled here, not read
@@ -987,6 +992,9 @@ class SasrecEngine:
         """The two independent, bandwidth-bound ends of backward side by side in one launch: the fixed-order sum of every partial
         buffer (dense gradients + loss) and the segment reduce of the table-row gradients."""
         L, s, shp = lib(), self.s, pl.shape
+        if getattr(self, "_sort_owed", False):    # no fork point of this engine's backward launched the deferred sort: do it now
+            self.ev_idx.record(self.stream)
+            self.enqueue_sort(pl)
         self.join_sort()                          # pos_sorted / seg_off come from the side-stream sort
         pk = getattr(self, "_tail_pack", None)
         if pk is not None:       # graph A of the data-parallel step: the tail also packs this rank's exchange chunk (ids | rows | dense)
@@ -1050,9 +1058,16 @@ class SasrecEngine:
         self._fork_sort(pl)
         self._enqueue_fwd_bwd(pl)
 
-    def _fork_sort(self, pl: SasrecPlan) -> None:
-        """Start the side-stream sort beside the forward pass (joined by the gradient tail)."""
-        self.enqueue_sort(pl)
+    # where the side-stream sort of a train step starts (the gradient tail joins it): "catchup" = beside the forward, "forward" =
+    # when the forward has finished, "wgrad" = beside the weight-gradient launch
+    SORT_FORK = os.environ.get("AMID_SORT_FORK", "catchup")
+
+    def _fork_sort(self, pl: SasrecPlan, at: str = "catchup") -> None:
+        """Start the side-stream sort if `at` is this engine's fork point."""
+        if self.SORT_FORK == at and getattr(self, "_sort_owed", False):
+            if at != "catchup":
+                self.ev_idx.record(self.stream)       # the side stream starts when the main stream's work so far has finished
+            self.enqueue_sort(pl)
 
     FUSED_HEAD = True          # the plain SASRec head (no isItC / isDR) can run forward + backward as one launch
 
@@ -1071,6 +1086,7 @@ class SasrecEngine:
                           and bool(lib().value("amid_attn_live_supported", pl.shape.Tenc, self.D, self.H, 1)))
         try:
             self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)
+            self._fork_sort(pl, "forward")
             self.enqueue_backward(pl, train=True)
         finally:
             self._fuse_head = self._fuse_scorers = self._own_domain_only = self._live_fwd = False
@@ -1254,7 +1270,7 @@ class HipMergeBackend:
         L = lib()
         self.eng, self.cap = eng, int(capacity)
         dev, D = eng.device, eng.D
-        self.sort_ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", self.cap), dtype=torch.uint8, device=dev)
+        self.sort_ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", self.cap), dtype=torch.uint8, device=dev)
         self.pos_sorted = torch.zeros(self.cap, dtype=torch.int32, device=dev)
         self.uniq_ids = torch.zeros(self.cap, dtype=torch.int32, device=dev)
         self.seg_off = torch.zeros(self.cap + 1, dtype=torch.int32, device=dev)

@@ -347,7 +347,7 @@ class _GatherFunction(torch.autograd.Function):
         dev = g.device
         idx32 = flat.to(torch.int32)
         rows = g.reshape(n, D).contiguous()
-        ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device=dev)
+        ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device=dev)
         pos, uniq = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
         seg, nu = torch.empty(n + 1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
         sof = torch.empty(n, dtype=torch.int32, device=dev)

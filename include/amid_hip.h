@@ -70,7 +70,12 @@ int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, int T, int D
                        const void* step_state, int train, float p_drop, void* stream);
 
 /* ---- index sort / unique (no reference counterpart: enables the sparse gradient path) ------ */
+/* workspace: amid_sort_unique_workspace_bytes(n_idx) bytes, ZERO-FILLED once before its first use (the four-launch sort keeps two
+ * tickets there and leaves them zero), used by one call at a time. */
 long long amid_sort_unique_workspace_bytes(int n_idx);
+/* lists of at least n_idx indices (default 65536) and keys below 2^24 are sorted in four launches, shorter ones by 8-bit passes
+ * (3 launches per pass + run detection): same outputs.  Returns the previous threshold; a negative argument only queries. */
+int amid_sort_set_four_launch_min(int n_idx);
 int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
                          int* seg_off /* [n_idx + 1] */, int* seg_of /* [n_idx] run index of each sorted entry */,
                          int* n_uniq /* device scalar */, void* stream);

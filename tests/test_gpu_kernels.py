@@ -71,10 +71,11 @@ def test_gather_out_of_range_sets_flag(L):
 
 
 # ---------------------------------------------------------------------------------------------
-def run_sort_unique(L, idx, n_rows):
+def run_sort_unique(L, idx, n_rows, ws=None):
     n = idx.numel()
     idd = dev(idx.int())
-    ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device="cuda")
+    if ws is None:           # zero-filled once; every call leaves it ready for the next
+        ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device="cuda")
     pos = torch.zeros(n, dtype=torch.int32, device="cuda")
     uniq = torch.zeros(n, dtype=torch.int32, device="cuda")
     seg = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
@@ -102,6 +103,38 @@ def test_sort_unique_matches_stable_sort(L, n, n_rows, pad_frac):
     assert torch.equal(_[3].cpu().long(), torch.repeat_interleave(torch.arange(U), wc))      # run index of every sorted entry
 
 
+def check_sort(idx, out):
+    pos, uniq, seg, U, raw = out
+    assert torch.equal(pos, torch.sort(idx, stable=True).indices)
+    wu, wc = torch.unique(idx, return_counts=True)
+    assert U == wu.numel() and torch.equal(uniq, wu)
+    assert torch.equal(seg, torch.cat((torch.zeros(1, dtype=torch.long), wc.cumsum(0))))
+    assert torch.equal(raw[3].cpu().long(), torch.repeat_interleave(torch.arange(U), wc))
+
+
+@pytest.mark.parametrize("n,n_rows", [(26112, 894820), (10752, 894820), (417792, 10_000_002), (4097, 1 << 24), (30000, (1 << 24) + 5),
+                                      (5000, 2), (2048, 3)])
+def test_sort_unique_workspace_reuse_and_key_shapes(L, n, n_rows):
+    """The four-launch sort (forced for every length here) keeps its tables in the workspace and leaves them zero: five different
+    inputs through ONE workspace (uniform, all keys equal, already sorted, a few hot keys, reversed), key ranges of 1 .. 24 bits, and
+    the multi-pass path above 2^24."""
+    prev = L.value("amid_sort_set_four_launch_min", 0)
+    try:
+        _sort_reuse_cases(L, n, n_rows)
+    finally:
+        L.value("amid_sort_set_four_launch_min", prev)
+
+
+def _sort_reuse_cases(L, n, n_rows):
+    ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device="cuda")
+    g = torch.Generator().manual_seed(n + 1)
+    hot = torch.randint(0, n_rows, (7,), generator=g)
+    cases = [torch.randint(0, n_rows, (n,), generator=g), torch.full((n,), n_rows - 1), torch.sort(torch.randint(0, n_rows, (n,), generator=g)).values,
+             hot[torch.randint(0, 7, (n,), generator=g)], torch.randint(0, n_rows, (n,), generator=g).flip(0)]
+    for idx in cases:
+        check_sort(idx, run_sort_unique(L, idx, n_rows, ws))
+
+
 @pytest.mark.parametrize("world,length,n_rows", [(2, 37, 100), (8, 2600, 894820), (3, 1, 10), (16, 500, 4000), (4, 4096, 3000)])
 def test_merge_sorted_lists_matches_stable_sort(L, world, length, n_rows):
     """Data-parallel merge: `world` ascending unique lists, sentinel-padded to a common length (what HipMergeBackend.pad
@@ -116,7 +149,7 @@ def test_merge_sorted_lists_matches_stable_sort(L, world, length, n_rows):
     keys = torch.cat(lists)
     n = world * length
     kd = keys.to(torch.int32).cuda()
-    ws = torch.empty(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device="cuda")
     pos = torch.full((n,), -1, dtype=torch.int32, device="cuda")
     uniq = torch.zeros(n, dtype=torch.int32, device="cuda")
     seg = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
