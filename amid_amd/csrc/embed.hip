@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
                                                         int B, int T, int D, int n_item_rows,
                                                         float* __restrict__ xg, unsigned char* __restrict__ tmq,
                                                         const RngState* __restrict__ rng, int train, unsigned thr16, float scale,
-                                                        const int* __restrict__ live) {
+                                                        const int* __restrict__ live, int* __restrict__ idx_c, int* __restrict__ row_c) {
     const int sub = threadIdx.x & 31;
     const int hw = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     const int n_hw = gridDim.x * (blockDim.x >> 5);
@@ -192,6 +192,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
             }
             row[u] = r;
             src[u] = (r0 + u < n_walk) ? (long long)idx_all[r] : 0;
+            // the walk over the live sequences is the step's compact index list: the id at every walk position and the row of the
+            // full layout its gradient will stand in (what the sort, the segment reduce and the row Adam of the step then run on)
+            if (idx_c != nullptr && sub == 0 && r0 + u < n_walk) { idx_c[r0 + u] = (int)src[u]; row_c[r0 + u] = r; }
         }
         for (int c = sub; c < q; c += 32) {
             float4 v[RIF];
@@ -378,7 +381,8 @@ extern "C" int amid_pack_indices_pool_live(const long long* pool, long long pool
 
 static int embed_fwd(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
                      int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop, const int* live,
-                     void* stream) {
+                     int* idx_c, int* row_c, void* stream) {
+    AMID_CHECK_ARG((idx_c == nullptr) == (row_c == nullptr) && (idx_c == nullptr || live != nullptr));
     AMID_CHECK_ARG(table && idx_all && xg && B > 0 && T > 0 && D > 0 && (D % 4) == 0 && n_item_rows >= 0);
     AMID_CHECK_ARG((pos0 == nullptr) == (pos1 == nullptr));
     AMID_CHECK_ARG(pos0 == nullptr || tmq != nullptr);
@@ -387,7 +391,7 @@ static int embed_fwd(const float* table, const int* idx_all, const float* pos0, 
     const int tr = (train && pos0 != nullptr && p_drop > 0.f) ? 1 : 0;
     embed_fwd_kernel<ROWS_IN_FLIGHT><<<gather_grid(n_walk), 256, 0, (hipStream_t)stream>>>(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq,
                                                                                             (const RngState*)rng_state, tr, keep_thr16(p_drop),
-                                                                                            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live);
+                                                                                            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
@@ -395,7 +399,7 @@ static int embed_fwd(const float* table, const int* idx_all, const float* pos0, 
 extern "C" int amid_embed_fwd_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
                                   int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
                                   void* stream) {
-    return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, nullptr, stream);
+    return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, nullptr, nullptr, nullptr, stream);
 }
 
 // K1 over the live sequences only (live: amid_live_list_i32): the rows of the other B sequences of xg / tmq are left untouched
@@ -403,7 +407,16 @@ extern "C" int amid_embed_fwd_live_f32(const float* table, const int* idx_all, c
                                        int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
                                        const int* live, void* stream) {
     AMID_CHECK_ARG(live != nullptr);
-    return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, live, stream);
+    return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, live, nullptr, nullptr, stream);
+}
+
+// the same, also writing the step's compact index list (B T + n_item_rows entries): idx_c[i] = the id at position i of the walk over
+// the live sequences and the items, row_c[i] = that position's row in the full [2 B T + items] layout
+extern "C" int amid_embed_fwd_live_compact_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T,
+                                               int D, int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train,
+                                               float p_drop, const int* live, int* idx_c, int* row_c, void* stream) {
+    AMID_CHECK_ARG(live != nullptr && idx_c != nullptr && row_c != nullptr);
+    return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, live, idx_c, row_c, stream);
 }
 
 extern "C" int amid_live_list_i32(const long long* domain, int B, int* live, void* stream) {

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const int* 
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             keys_out[dst] = key[i];
-            vals_out[dst] = first_pass ? k : vals_in[k];
+            vals_out[dst] = (first_pass && vals_in == nullptr) ? k : vals_in[k];
         }
     }
 }
@@ -247,22 +247,24 @@ __global__ __launch_bounds__(1024) void heads_fused_kernel(const int* __restrict
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Two-pass sort in FOUR launches (keys below 2^24: every table up to 16.7 M rows).  Digits of ceil(bits / 2) and floor(bits / 2) bits
-// (cfg 2: 10 + 10, cfg 5: 12 + 12 -- up to 4096 bins); tiles of 2048 keys, supertiles of 16 tiles.  For each pass p three tables
-// say where a tile's keys of a bin go:  gtot_p[bin] (all keys), stot_p[supertile][bin], counts_p[tile][bin]; a scatter block adds up
-// base(bin) = exclusive scan of gtot_p, the earlier supertiles' stot_p and the earlier tiles' counts_p of its own supertile
-// (at most n_super + 15 coalesced, cached rows) -- nothing waits for another block, nothing is scanned by a single block.
-//   launch 1  os_count     counts_0 (plain stores), stot_0 / gtot_0 / gtot_1 (atomics; digit totals do not depend on the order);
-//                          zeroes counts_1 / stot_1 and launch 4's status words
+// (cfg 2: 10 + 10, cfg 5: 12 + 12 -- up to 4096 bins); tiles of 2048 keys, supertiles of 16 tiles.  For each pass p two tables say
+// where a tile's keys of a bin go: stot_p[supertile][bin] and counts_p[tile][bin]; a scatter block sweeps the stot_p rows (all of
+// them: the bin totals, whose exclusive scan is the bin's base; the earlier supertiles': its share) and the counts_p rows of the
+// earlier tiles of its own supertile -- at most n_super + 15 coalesced, cached rows; nothing waits for another block, nothing is
+// scanned by a single block.
+//   launch 1  os_count     counts_0 (plain stores), stot_0 (atomics); zeroes counts_1 / stot_1 and launch 4's status words
 //   launch 2  os_scatter   stable scatter by digit 0; every key also bumps counts_1 / stot_1 of the tile its DESTINATION lies in
 //                          (pass 1's tiles are contiguous slices of this pass's output)
-//   launch 3  os_scatter   stable scatter by digit 1 -> sorted keys + positions; zeroes stot_0 / gtot_0 for the next call
+//   launch 3  os_scatter   stable scatter by digit 1 -> sorted keys + positions; zeroes stot_0 for the next call
 //   launch 4  os_heads     run heads: per-tile count, a wave-parallel look-back over the earlier tiles' status words gives the tile's
 //                          first run index (tile ids are handed out by an atomic counter: a tile only waits for tiles that already
-//                          run); writes uniq_ids / seg_off / seg_of / n_uniq; zeroes gtot_1 for the next call
-// The workspace must be zero-filled once before its first use; every call leaves it ready for the next.
+//                          run); writes uniq_ids / seg_off / seg_of / n_uniq
+// stot_0 is the one table that must be zero when a call starts: it sits at a FIXED place at the head of the workspace (whatever
+// n_idx the workspace is used with), is zero-filled once with the workspace and re-zeroed by launch 3 of every call.
 constexpr int OS_BINS_MAX = 4096;
 constexpr int OS_STATE_INTS = 64;                 // [2] tile counter of launch 4
 constexpr int OS_SUPER = 16;                      // tiles per supertile
+constexpr int OS_SUPER_MAX = 256;                 // supertiles the fixed stot_0 area holds (4096 tiles = 8.4 M indices; beyond: 8-bit passes)
 
 struct OsGeom {
     int n, ntiles;
@@ -283,43 +285,30 @@ __device__ __forceinline__ unsigned long long match_bits(unsigned d, bool valid,
 // enough to share a CU with a one-workgroup-per-CU kernel of the main stream (the fused forward holds 144 of the 160 KB).
 template <int BINS>
 __global__ __launch_bounds__(SORT_THREADS) void os_count_kernel(const int* __restrict__ keys, OsGeom g, int* __restrict__ state,
-                                                                int* __restrict__ counts0, int* __restrict__ stot0, int* __restrict__ gtot0,
-                                                                int* __restrict__ gtot1, int* __restrict__ counts1, long long n_counts1,
-                                                                int* __restrict__ stot1, int n_stot1, int* __restrict__ hstatus) {
-    __shared__ int hist0[BINS], hist1[BINS];
-    const int bins0 = 1 << g.bits, bins1 = 1 << g.next_bits;
+                                                                int* __restrict__ counts0, int* __restrict__ stot0, int* __restrict__ counts1,
+                                                                long long n_counts1, int* __restrict__ stot1, int n_stot1,
+                                                                int* __restrict__ hstatus) {
+    __shared__ int hist0[BINS];
+    const int bins0 = 1 << g.bits;
     for (int d = threadIdx.x; d < bins0; d += SORT_THREADS) hist0[d] = 0;
-    for (int d = threadIdx.x; d < bins1; d += SORT_THREADS) hist1[d] = 0;
     __syncthreads();
     const int w = wave_id(), lane = lane_id();
     const int base = blockIdx.x * SORT_TILE + w * (64 * SORT_ITEMS);
-    const unsigned mask0 = (unsigned)bins0 - 1u, mask1 = (unsigned)bins1 - 1u;
+    const unsigned mask0 = (unsigned)bins0 - 1u;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const int k = base + i * 64 + lane;
         const bool valid = k < g.n;
-        const unsigned key = valid ? (unsigned)keys[k] : 0u;
-        const unsigned d0 = (key >> g.shift) & mask0, d1 = (key >> g.next_shift) & mask1;
+        const unsigned d0 = valid ? (((unsigned)keys[k] >> g.shift) & mask0) : 0u;
         const unsigned long long peers = match_bits(d0, valid, g.bits);
         if (valid && (__ffsll((long long)peers) - 1) == lane) atomicAdd(&hist0[d0], __popcll(peers));
-        // digit 1: the lanes that share the first lane's value (a wave full of the pad id) add once, the others one by one
-        const unsigned lead = __builtin_amdgcn_readfirstlane(d1);
-        const unsigned long long same = __ballot(valid && d1 == lead);
-        if (valid) {
-            if (d1 == lead) { if ((__ffsll((long long)same) - 1) == lane) atomicAdd(&hist1[d1], __popcll(same)); }
-            else atomicAdd(&hist1[d1], 1);
-        }
     }
     __syncthreads();
     const int sup = blockIdx.x / OS_SUPER;
     for (int d = threadIdx.x; d < bins0; d += SORT_THREADS) {
         const int c = hist0[d];
         counts0[(long long)blockIdx.x * bins0 + d] = c;
-        if (c) { atomicAdd(&stot0[(long long)sup * bins0 + d], c); atomicAdd(&gtot0[d], c); }
-    }
-    for (int d = threadIdx.x; d < bins1; d += SORT_THREADS) {
-        const int c = hist1[d];
-        if (c) atomicAdd(&gtot1[d], c);
+        if (c) atomicAdd(&stot0[(long long)sup * bins0 + d], c);
     }
     // housekeeping for the later launches of this call
     for (long long i = (long long)blockIdx.x * SORT_THREADS + threadIdx.x; i < n_counts1; i += (long long)gridDim.x * SORT_THREADS) counts1[i] = 0;
@@ -329,15 +318,13 @@ __global__ __launch_bounds__(SORT_THREADS) void os_count_kernel(const int* __res
 }
 
 // stable scatter of one pass.  COUNT_NEXT (pass 0): also the next pass's counts / stot (global atomics).  !COUNT_NEXT (pass 1):
-// zeroes the atomically accumulated tables of pass 0 for the next call (zero_a = stot_0, zero_b = gtot_0; launch 4 zeroes gtot_1,
-// which the blocks of this launch are still reading).
+// zeroes stot_0 (zero_a), the one table that must be zero when the next call starts.
 template <bool COUNT_NEXT, int BINS>
 __global__ __launch_bounds__(SORT_THREADS) void os_scatter_kernel(const int* __restrict__ keys_in, const int* __restrict__ vals_in,
                                                                   int* __restrict__ keys_out, int* __restrict__ vals_out, OsGeom g,
-                                                                  const int* __restrict__ counts, const int* __restrict__ stot,
-                                                                  const int* __restrict__ gtot, int* __restrict__ counts_next,
-                                                                  int* __restrict__ stot_next, int* __restrict__ zero_a, int n_zero_a,
-                                                                  int* __restrict__ zero_b) {
+                                                                  const int* __restrict__ counts, const int* __restrict__ stot, int nsup,
+                                                                  int* __restrict__ counts_next, int* __restrict__ stot_next,
+                                                                  int* __restrict__ zero_a, int n_zero_a) {
     __shared__ unsigned short woff[SORT_WAVES][BINS];           // per-wave digit counts, then running offsets inside the tile's bin
     __shared__ int tile_base[BINS];                             // output position of the tile's first key of every bin
     __shared__ int wsum[SORT_WAVES];
@@ -360,12 +347,44 @@ __global__ __launch_bounds__(SORT_THREADS) void os_scatter_kernel(const int* __r
         if (valid && (__ffsll((long long)peers[i]) - 1) == lane) woff[w][d] = (unsigned short)(woff[w][d] + __popcll(peers[i]));
         __builtin_amdgcn_wave_barrier();
     }
-    // where the tile's keys of every bin start: thread t owns the bins [t * per, (t + 1) * per) -- bin totals first (for the scan)
+    // where the tile's keys of every bin start: thread t owns the bins [t * per, (t + 1) * per).  One sweep over the supertile rows
+    // gives both the bin totals (all rows: for the scan over the bins) and the earlier supertiles' share (rows below this tile's
+    // supertile); the earlier tiles of the own supertile follow.  A thread reads its bins of a row as int4s (a wave covers a
+    // contiguous KB), two rows in flight.
+    constexpr int PERMAX = BINS / SORT_THREADS;
     const int per = bins / SORT_THREADS > 0 ? bins / SORT_THREADS : 1;
     const int d0 = threadIdx.x * per;
     const int sup = blockIdx.x / OS_SUPER;
+    int tot[PERMAX], pre[PERMAX];
+#pragma unroll
+    for (int k = 0; k < PERMAX; ++k) { tot[k] = 0; pre[k] = 0; }
+    if (d0 < bins) {
+        if ((per & 3) == 0) {
+            auto add_row = [&](const int* __restrict__ rowp, bool early, bool total) {
+#pragma unroll
+                for (int k = 0; k < PERMAX; k += 4) {
+                    if (k < per) {
+                        const int4 a = *(const int4*)(rowp + d0 + k);
+                        if (total) { tot[k] += a.x; tot[k + 1] += a.y; tot[k + 2] += a.z; tot[k + 3] += a.w; }
+                        if (early) { pre[k] += a.x; pre[k + 1] += a.y; pre[k + 2] += a.z; pre[k + 3] += a.w; }
+                    }
+                }
+            };
+            for (int s2 = 0; s2 < nsup; ++s2) add_row(stot + (long long)s2 * bins, s2 < sup, true);
+            for (int t = sup * OS_SUPER; t < (int)blockIdx.x; ++t) add_row(counts + (long long)t * bins, true, false);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PERMAX; ++k) {
+                if (k < per) {
+                    for (int s2 = 0; s2 < nsup; ++s2) { const int a = stot[(long long)s2 * bins + d0 + k]; tot[k] += a; if (s2 < sup) pre[k] += a; }
+                    for (int t = sup * OS_SUPER; t < (int)blockIdx.x; ++t) pre[k] += counts[(long long)t * bins + d0 + k];
+                }
+            }
+        }
+    }
     int mine = 0;
-    if (d0 < bins) for (int k = 0; k < per; ++k) mine += gtot[d0 + k];
+#pragma unroll
+    for (int k = 0; k < PERMAX; ++k) mine += tot[k];
     int x = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -374,48 +393,22 @@ __global__ __launch_bounds__(SORT_THREADS) void os_scatter_kernel(const int* __r
     }
     if (lane == 63) wsum[w] = x;
     __syncthreads();                                             // (also: every wave's woff counts are complete)
-    // earlier supertiles' stot rows + the earlier tiles' counts rows of this supertile, summed per bin into tile_base: every thread
-    // reads its `per` consecutive bins of a row as int4s (a wave covers a contiguous KB), four rows in flight
-    const int nrows = sup + ((int)blockIdx.x - sup * OS_SUPER);
-    auto rowp = [&](int r) -> const int* {
-        return r < sup ? stot + (long long)r * bins : counts + (long long)(sup * OS_SUPER + (r - sup)) * bins;
-    };
     if (d0 < bins) {
-        if ((per & 3) == 0) {
-            for (int k = 0; k < per; k += 4) {
-                int4 acc = make_int4(0, 0, 0, 0);
-                int r = 0;
-                for (; r + 4 <= nrows; r += 4) {
-                    const int4 a = *(const int4*)(rowp(r) + d0 + k), b = *(const int4*)(rowp(r + 1) + d0 + k);
-                    const int4 c = *(const int4*)(rowp(r + 2) + d0 + k), e = *(const int4*)(rowp(r + 3) + d0 + k);
-                    acc.x += a.x + b.x + c.x + e.x; acc.y += a.y + b.y + c.y + e.y;
-                    acc.z += a.z + b.z + c.z + e.z; acc.w += a.w + b.w + c.w + e.w;
-                }
-                for (; r < nrows; ++r) {
-                    const int4 a = *(const int4*)(rowp(r) + d0 + k);
-                    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
-                }
-                *(int4*)&tile_base[d0 + k] = acc;
-            }
-        } else {
-            for (int k = 0; k < per; ++k) {
-                int acc = 0;
-                for (int r = 0; r < nrows; ++r) acc += rowp(r)[d0 + k];
-                tile_base[d0 + k] = acc;
-            }
-        }
         int run = x - mine;
         for (int k = 0; k < w; ++k) run += wsum[k];
-        for (int k = 0; k < per; ++k) {
-            const int d = d0 + k;
-            tile_base[d] += run;                                 // + base(d)
-            run += gtot[d];
-            unsigned wrun = 0;
 #pragma unroll
-            for (int q = 0; q < SORT_WAVES; ++q) {
-                const unsigned c = woff[q][d];
-                woff[q][d] = (unsigned short)wrun;
-                wrun += c;
+        for (int k = 0; k < PERMAX; ++k) {
+            if (k < per) {
+                const int d = d0 + k;
+                tile_base[d] = run + pre[k];                     // base(d) + the earlier tiles' keys of the bin
+                run += tot[k];
+                unsigned wrun = 0;
+#pragma unroll
+                for (int q = 0; q < SORT_WAVES; ++q) {
+                    const unsigned c = woff[q][d];
+                    woff[q][d] = (unsigned short)wrun;
+                    wrun += c;
+                }
             }
         }
     }
@@ -484,7 +477,6 @@ __global__ __launch_bounds__(SORT_THREADS) void os_scatter_kernel(const int* __r
     }
     if (!COUNT_NEXT) {
         for (int i2 = blockIdx.x * SORT_THREADS + threadIdx.x; i2 < n_zero_a; i2 += gridDim.x * SORT_THREADS) zero_a[i2] = 0;
-        for (int i2 = blockIdx.x * SORT_THREADS + threadIdx.x; i2 < OS_BINS_MAX; i2 += gridDim.x * SORT_THREADS) zero_b[i2] = 0;
     }
 }
 
@@ -492,10 +484,8 @@ __global__ __launch_bounds__(SORT_THREADS) void os_scatter_kernel(const int* __r
 constexpr unsigned OS_ST_AGG = 1u << 30, OS_ST_PRE = 2u << 30, OS_ST_VAL = (1u << 30) - 1u;
 __global__ __launch_bounds__(SORT_THREADS) void os_heads_kernel(const int* __restrict__ keys, int n, int ntiles, int* __restrict__ state,
                                                                 unsigned* __restrict__ hstatus, int* __restrict__ n_uniq,
-                                                                int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of,
-                                                                int* __restrict__ zero_g) {
+                                                                int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of) {
     __shared__ int tile_s, excl_s;
-    for (int i2 = blockIdx.x * SORT_THREADS + threadIdx.x; i2 < OS_BINS_MAX; i2 += gridDim.x * SORT_THREADS) zero_g[i2] = 0;
     __shared__ int wsum[SORT_WAVES];
     if (threadIdx.x == 0) tile_s = atomicAdd(&state[2], 1);
     __syncthreads();
@@ -622,17 +612,18 @@ using namespace amid;
 static inline int sort_nblk(int n) { return (n + SORT_TILE - 1) / SORT_TILE; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// four-launch sort: [state | gtot0 | gtot1 | stot0 | stot1 | counts0 | counts1 | hstatus]
+// four-launch sort.  Head of the workspace, independent of n_idx: [state | stot0 (OS_SUPER_MAX rows)]; behind the 8-bit sort's
+// arrays: [stot1 | counts0 | counts1 | hstatus]
 static inline size_t os_nsuper(size_t ntiles) { return (ntiles + OS_SUPER - 1) / OS_SUPER; }
+static inline size_t os_head_bytes() { return align256(OS_STATE_INTS * 4) + align256((size_t)OS_SUPER_MAX * OS_BINS_MAX * 4); }
 static inline size_t os_bytes(size_t ntiles) {
-    return align256(OS_STATE_INTS * 4) + 2 * align256(OS_BINS_MAX * 4) + 2 * align256(os_nsuper(ntiles) * OS_BINS_MAX * 4) +
-           2 * align256(ntiles * OS_BINS_MAX * 4) + align256(ntiles * 4);
+    return align256(os_nsuper(ntiles) * OS_BINS_MAX * 4) + 2 * align256(ntiles * OS_BINS_MAX * 4) + align256(ntiles * 4);
 }
 
 extern "C" long long amid_sort_unique_workspace_bytes(int n_idx) {
     if (n_idx <= 0) return 256;
     const size_t nblk = sort_nblk(n_idx);
-    size_t b = 0;
+    size_t b = os_head_bytes();
     b += 4 * align256((size_t)n_idx * 4);            // keys a/b, vals a/b
     b += align256(256 * nblk * 4);                   // digit counts / offsets
     b += align256(((size_t)n_idx + 255) / 256 * 4);  // per-block head counts
@@ -652,12 +643,13 @@ extern "C" int amid_sort_set_four_launch_min(int n_idx) {
     return prev;
 }
 
-extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
-                                    int* seg_off, int* seg_of, int* n_uniq, void* stream) {
+static int sort_unique(const int* idx, const int* rows, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
+                       int* seg_off, int* seg_of, int* n_uniq, void* stream) {
     AMID_CHECK_ARG(idx && workspace && pos_sorted && uniq_ids && seg_off && seg_of && n_uniq && n_idx > 0 && n_rows > 0);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = sort_nblk(n_idx);
-    char* ws = (char*)workspace;
+    char* const ws_head = (char*)workspace;                    // [state | stot0]: fixed, whatever n_idx
+    char* ws = ws_head + os_head_bytes();
     const size_t kb = align256((size_t)n_idx * 4);
     int* keys[2] = {(int*)ws, (int*)(ws + kb)};
     int* vals[2] = {(int*)(ws + 2 * kb), (int*)(ws + 3 * kb)};
@@ -665,14 +657,12 @@ extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows,
     int* blk_heads = (int*)(ws + 4 * kb + align256((size_t)256 * nblk * 4));
     int bits = 1;
     while (bits < 31 && (1LL << bits) < n_rows) ++bits;
-    if (bits <= 24 && n_idx >= g_four_launch_min) {            // four launches (see os_count_kernel)
+    if (bits <= 24 && n_idx >= g_four_launch_min && os_nsuper(nblk) <= (size_t)OS_SUPER_MAX) {      // four launches (see os_count_kernel)
         char* os = ws + 4 * kb + align256((size_t)256 * nblk * 4) + align256(((size_t)n_idx + 255) / 256 * 4);
         const size_t nsup = os_nsuper(nblk);
-        int* state = (int*)os;
-        int* gtot0 = (int*)(os + align256(OS_STATE_INTS * 4));
-        int* gtot1 = (int*)((char*)gtot0 + align256(OS_BINS_MAX * 4));
-        int* stot0 = (int*)((char*)gtot1 + align256(OS_BINS_MAX * 4));
-        int* stot1 = (int*)((char*)stot0 + align256(nsup * OS_BINS_MAX * 4));
+        int* state = (int*)ws_head;
+        int* stot0 = (int*)(ws_head + align256(OS_STATE_INTS * 4));
+        int* stot1 = (int*)os;
         int* counts0 = (int*)((char*)stot1 + align256(nsup * OS_BINS_MAX * 4));
         int* counts1 = (int*)((char*)counts0 + align256((size_t)nblk * OS_BINS_MAX * 4));
         unsigned* hstatus = (unsigned*)((char*)counts1 + align256((size_t)nblk * OS_BINS_MAX * 4));
@@ -680,21 +670,21 @@ extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows,
         const int b0 = (bits + 1) / 2, b1 = bits - b0;
         OsGeom g0{n_idx, nblk, 0, b0, b0, b1}, g1{n_idx, nblk, b0, b1, 0, b0};
 #define AMID_OS_LAUNCH(BINS)                                                                                                              \
-        os_count_kernel<BINS><<<nblk, SORT_THREADS, 0, s>>>(idx, g0, state, counts0, stot0, gtot0, gtot1, counts1, (long long)nblk << b1, stot1, \
+        os_count_kernel<BINS><<<nblk, SORT_THREADS, 0, s>>>(idx, g0, state, counts0, stot0, counts1, (long long)nblk << b1, stot1,               \
                                                             (int)(nsup << b1), (int*)hstatus);                                            \
-        os_scatter_kernel<true, BINS><<<nblk, SORT_THREADS, 0, s>>>(idx, nullptr, keys[0], vals[0], g0, counts0, stot0, gtot0, counts1, stot1,  \
-                                                                    nullptr, 0, nullptr);                                                 \
-        os_scatter_kernel<false, BINS><<<nblk, SORT_THREADS, 0, s>>>(keys[0], vals[0], keys[1], pos_sorted, g1, counts1, stot1, gtot1, nullptr, \
-                                                                     nullptr, stot0, (int)(nsup << b0), gtot0);
+        os_scatter_kernel<true, BINS><<<nblk, SORT_THREADS, 0, s>>>(idx, rows, keys[0], vals[0], g0, counts0, stot0, (int)nsup, counts1, stot1, \
+                                                                    nullptr, 0);                                                          \
+        os_scatter_kernel<false, BINS><<<nblk, SORT_THREADS, 0, s>>>(keys[0], vals[0], keys[1], pos_sorted, g1, counts1, stot1, (int)nsup,      \
+                                                                     nullptr, nullptr, stot0, (int)(nsup << b0));
         if (b0 <= 10) { AMID_OS_LAUNCH(1024) } else { AMID_OS_LAUNCH(4096) }
 #undef AMID_OS_LAUNCH
-        os_heads_kernel<<<nblk, SORT_THREADS, 0, s>>>(keys[1], n_idx, nblk, state, hstatus, n_uniq, uniq_ids, seg_off, seg_of, gtot1);
+        os_heads_kernel<<<nblk, SORT_THREADS, 0, s>>>(keys[1], n_idx, nblk, state, hstatus, n_uniq, uniq_ids, seg_off, seg_of);
         AMID_LAUNCH_CHECK();
         return AMID_OK;
     }
     const int passes = (bits + 7) / 8;
     const int* kin = idx;
-    const int* vin = nullptr;
+    const int* vin = rows;
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
         int* kout = keys[p & 1];
@@ -717,6 +707,19 @@ extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows,
     return AMID_OK;
 }
 
+extern "C" int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
+                                    int* seg_off, int* seg_of, int* n_uniq, void* stream) {
+    return sort_unique(idx, nullptr, n_idx, n_rows, workspace, pos_sorted, uniq_ids, seg_off, seg_of, n_uniq, stream);
+}
+
+// the same with a payload: pos_sorted holds rows[i] instead of i (the sort of a compact index list whose entries' gradient rows
+// stand elsewhere: amid_lazy_adam_catchup_live_f32); ties keep the order of the list
+extern "C" int amid_sort_unique_rows_i32(const int* idx, const int* rows, int n_idx, long long n_rows, void* workspace, int* pos_sorted,
+                                         int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq, void* stream) {
+    AMID_CHECK_ARG(rows != nullptr);
+    return sort_unique(idx, rows, n_idx, n_rows, workspace, pos_sorted, uniq_ids, seg_off, seg_of, n_uniq, stream);
+}
+
 // Data-parallel merge (amid_amd/dist.py): `world` lists of `len` keys, each non-decreasing (a rank's unique ids in ascending order,
 // then `sentinel` padding with sentinel > every id) -> the same outputs as amid_sort_unique_i32 on the concatenation, in 4 launches
 // instead of a full radix sort; the sentinel run, if any, is left out of n_uniq.  Workspace: amid_sort_unique_workspace_bytes(world*len).
@@ -728,7 +731,7 @@ static int merge_sorted_lists(const int* keys, int world, int len, long long key
     AMID_CHECK_ARG(n_entries == 0 || (entries_dev && n_entries > 0 && max_count > 0));
     hipStream_t s = (hipStream_t)stream;
     const int n = world * len;
-    char* ws = (char*)workspace;
+    char* ws = (char*)workspace + os_head_bytes();             // (the head belongs to the four-launch sort)
     const size_t kb = align256((size_t)n * 4);
     int* keys_sorted = (int*)ws;
     int* blk_heads = (int*)(ws + 4 * kb + align256((size_t)256 * sort_nblk(n) * 4));

@@ -155,6 +155,12 @@ class SasrecPlan:
         if self.strip:
             self.stpg = -(-M // L.value("amid_sas_strip_tile_rows"))
         self.live = torch.zeros(B + 1, dtype=torch.int32, device=dev)       # amid_live_list_i32: the step's live sequences
+        # the train step's compact index list over the live sequences + items (amid_lazy_adam_catchup_live_f32): ids and, for every
+        # entry, the row of its gradient in the full [2 B T + items] layout
+        self.n_compact = B * self.shape.T + B * self.shape.NI
+        self.idx_c = torch.zeros(self.n_compact, dtype=torch.int32, device=dev)
+        self.row_c = torch.zeros(self.n_compact, dtype=torch.int32, device=dev)
+        self.compact = False             # set per step by enqueue_prepare
         # short tiles (seq_len 20 at batch 256: 40 rows per CU) run the 48- / 80-row builds of the row-tile kernels (csrc/tile_gemm.h)
         self.rt_suffix = ("_rt3" if self.rpt <= 48 else "_rt5" if self.rpt <= 80 else "") if eng.SHORT_TILE_BUILDS else ""
         # static inputs (graph-replay safe): ONE int64 buffer so a batch arrives with a single copy
@@ -607,6 +613,10 @@ class SasrecEngine:
         # (amid_live_list_i32) rides in the packing launch; enqueue_forward then finds it in place (pl.live_packed)
         with_live = bool(bump_step and getattr(pl, "strip", False) and not self.itc_bs)
         pl.live_packed = with_live
+        # ... and then sort, segment reduce and row Adam run on the live sequences' positions only (the dead sequences' gradient rows
+        # are exact zeros; a row only they hold is not touched this step -- the lazy Adam replays it when it is next read).  InnerComp
+        # couples the rows of a batch in front of the encoders: every position keeps its gradient there.
+        pl.compact = bool(with_live and sparse and self.compact_ok(pl))
         ent = self.input_pool(pl)
         if ent is not None:
             pool, phase = ent
@@ -647,8 +657,13 @@ class SasrecEngine:
         """Sort / unique on the side stream (joined by the gradient tail just before the segment reduce)."""
         L, shp = lib(), pl.shape
         self.side.wait_event(self.ev_idx)
-        L.call("amid_sort_unique_i32", pl.idx_all.data_ptr(), shp.n_idx, self.n_rows, pl.sort_ws.data_ptr(), pl.pos_sorted.data_ptr(),
-               pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_uniq.data_ptr(), self.side.cuda_stream)
+        if getattr(pl, "compact", False):
+            L.call("amid_sort_unique_rows_i32", pl.idx_c.data_ptr(), pl.row_c.data_ptr(), pl.n_compact, self.n_rows, pl.sort_ws.data_ptr(),
+                   pl.pos_sorted.data_ptr(), pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_uniq.data_ptr(),
+                   self.side.cuda_stream)
+        else:
+            L.call("amid_sort_unique_i32", pl.idx_all.data_ptr(), shp.n_idx, self.n_rows, pl.sort_ws.data_ptr(), pl.pos_sorted.data_ptr(),
+                   pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_uniq.data_ptr(), self.side.cuda_stream)
         self.ev_sorted.record(self.side)
         self._sort_pending = True
         self._sort_owed = False
@@ -658,6 +673,26 @@ class SasrecEngine:
         if getattr(self, "_sort_pending", False):
             self.stream.wait_event(self.ev_sorted)
             self._sort_pending = False
+
+    COMPACT_LIVE = True
+    COMPACT_MIN_IDX = 65536    # shorter index lists gain nothing from the compact list (the tail is bound by the dense partial sums,
+                               # the row Adam by its dense half) and lose the early fork of the side-stream sort: cfg 2 keeps the full list
+
+    def live_forward_ok(self, pl: SasrecPlan) -> bool:
+        """Whether this engine's train step on `pl` encodes the live sequences only (see _enqueue_fwd_bwd)."""
+        return bool(getattr(pl, "strip", False) and not self.itc_bs and not self.dr and not self.inc_bs and self.FUSED_HEAD and self.LIVE_FORWARD
+                    and lib().value("amid_attn_live_supported", pl.shape.Tenc, self.D, self.H, 1))
+
+    def n_sparse_train(self, pl: SasrecPlan) -> int:
+        """n_sparse() of this engine's train steps on `pl` (known before the step is enqueued)."""
+        return pl.n_compact if self.compact_ok(pl) else pl.shape.n_idx
+
+    def compact_ok(self, pl: SasrecPlan) -> bool:
+        return bool(self.COMPACT_LIVE and pl.shape.n_idx >= self.COMPACT_MIN_IDX and self.live_forward_ok(pl))
+
+    def n_sparse(self, pl: SasrecPlan) -> int:
+        """Entries of the step's index list as the sparse side (sort, segment reduce, row Adam) sees it."""
+        return pl.n_compact if getattr(pl, "compact", False) else pl.shape.n_idx
 
     def enqueue_catchup(self, pl: SasrecPlan) -> None:
         """Replay pending zero-gradient Adam steps of the rows this batch is about to gather (by position: no sort needed)."""
@@ -686,6 +721,15 @@ class SasrecEngine:
                    self.inc_threshold, fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), B, shp.T, D, pl.inc_gate.data_ptr(),
                    pl.inc_S.data_ptr(), pl.inc_Z.data_ptr(), pl.inc_sw.data_ptr(), pl.x[0].data_ptr(), pl.tmq.data_ptr(), st, tr,
                    SASREC_P_DROP, s)
+        elif live_fwd and getattr(pl, "compact", False):
+            # K1 also writes the step's compact index list (ids + gradient rows of the live sequences' positions and the items): the
+            # deferred sort can start behind it
+            L.call("amid_embed_fwd_live_compact_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"),
+                   fp.ptr("sac2.pos_emb.weight"), B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, lf,
+                   pl.idx_c.data_ptr(), pl.row_c.data_ptr(), s)
+            if self.SORT_FORK == "catchup" and getattr(self, "_sort_owed", False):
+                self.ev_idx.record(self.stream)
+                self.enqueue_sort(pl)
         elif live_fwd:
             L.call("amid_embed_fwd_live_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"),
                    fp.ptr("sac2.pos_emb.weight"), B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, lf, s)
@@ -1001,12 +1045,12 @@ class SasrecEngine:
             from .dist import packed_rows
             send, umax = pk
             id_rows, rows = packed_rows(umax, self.D)
-            L.call("amid_grad_tail_pack_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), shp.n_idx,
+            L.call("amid_grad_tail_pack_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), self.n_sparse(pl),
                    self.D, pl.seg_ws.data_ptr(), send.data_ptr() + 4 * id_rows * self.D, (pl.red_entries_v if live else pl.red_entries).data_ptr(),
                    pl.red_n_v if live else pl.red_n, pl.red_max_v if live else pl.red_max, pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), umax,
                    self.n_rows, send.data_ptr(), self.dense.grad.data_ptr(), send.data_ptr() + 4 * rows * self.D, self.dense.numel, s)
             return
-        L.call("amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), shp.n_idx,
+        L.call("amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), self.n_sparse(pl),
                self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), (pl.red_entries_v if live else pl.red_entries).data_ptr(),
                pl.red_n_v if live else pl.red_n, pl.red_max_v if live else pl.red_max, s)
 
@@ -1017,7 +1061,7 @@ class SasrecEngine:
         self._ensure_opt_state()
         fp = self.dense
         if sparse is None:
-            ids, rows, nu, cap = pl.uniq_ids, pl.uniq_grad, pl.n_uniq, pl.shape.n_idx
+            ids, rows, nu, cap = pl.uniq_ids, pl.uniq_grad, pl.n_uniq, self.n_sparse(pl)
         else:
             ids, rows, nu = sparse
             cap = ids.numel()
@@ -1064,6 +1108,8 @@ class SasrecEngine:
 
     def _fork_sort(self, pl: SasrecPlan, at: str = "catchup") -> None:
         """Start the side-stream sort if `at` is this engine's fork point."""
+        if at == "catchup" and getattr(pl, "compact", False):
+            return                                    # the compact index list is K1's by-product: enqueue_forward forks behind K1
         if self.SORT_FORK == at and getattr(self, "_sort_owed", False):
             if at != "catchup":
                 self.ev_idx.record(self.stream)       # the side stream starts when the main stream's work so far has finished
@@ -1082,8 +1128,7 @@ class SasrecEngine:
         # ... and neither do the other domain's logits of a sample: with the plain head (no isDR heads, no InterComp / InnerComp) and
         # the matrix-core attention kernels the forward encodes the B live sequences only.  model.forward, which RETURNS both
         # domains' logits (model_seq.py:442), keeps encoding everything.
-        self._live_fwd = (self._own_domain_only and self._fuse_head and pl.strip and not self.inc_bs and self.LIVE_FORWARD
-                          and bool(lib().value("amid_attn_live_supported", pl.shape.Tenc, self.D, self.H, 1)))
+        self._live_fwd = self._own_domain_only and self._fuse_head and self.live_forward_ok(pl)
         try:
             self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)
             self._fork_sort(pl, "forward")
@@ -1134,7 +1179,7 @@ class SasrecEngine:
                                       "model_seq.py:465-469, :490-494): data-parallel sharding would change the model; train them on one GPU")
         L = lib()
         if umax is not None:                   # a caller's bound may be rounded up past the plan's index count (e.g. to a multiple of 256):
-            umax = max(1, min(int(umax), pl.shape.n_idx))      # clamp BEFORE it keys the captured graph pair (as dist.exchange_sparse does)
+            umax = max(1, min(int(umax), self.n_sparse_train(pl)))      # clamp BEFORE it keys the captured graph pair (as dist.exchange_sparse does)
         with torch.cuda.stream(self.stream):
             self.grad_scale = exchange.grad_scale
             fast = (use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")

@@ -192,6 +192,9 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         # K4: table row, m, v read and written for every unique row (+ its `last` stamp), grad row read
         "amid_embed_fwd_f32": ("hbm", n_idx * (4 + 2 * D * 4) + M2 * (D // 4)),
         "amid_embgrad_segreduce_f32": ("hbm", n_idx * (D * 4 + 8) + U * (D * 4 + 8)),
+        # the fused train step's sparse side runs on the live sequences' positions + the items (half the index list)
+        "amid_embgrad_segreduce_live": ("hbm", (Bw * T + Bw * (1 + NEG)) * (D * 4 + 8) + U * (D * 4 + 8)),
+        "amid_lazy_adam_catchup_live_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * 12 + U * (D * 4 * 6 + 8)),
         "amid_lazy_adam_catchup_positions_f32": ("hbm", n_idx * 4 + U * (D * 4 * 6 + 8)),
         "amid_optimizer_step_f32": ("hbm", U * (D * 4 * 7 + 8)),
     }
@@ -257,8 +260,10 @@ def gather_stress(device, n_steps=6):
     L.timer = None
     work = algorithmic_work(wl["B"], int(pl.n_uniq.item()), T)
     if getattr(pl, "red_bytes", None):
-        work["amid_grad_tail_f32"] = ("hbm", work["amid_embgrad_segreduce_f32"][1] + pl.red_bytes)
+        k3 = "amid_embgrad_segreduce_live" if getattr(pl, "compact", False) else "amid_embgrad_segreduce_f32"
+        work["amid_grad_tail_f32"] = ("hbm", work[k3][1] + pl.red_bytes)
     role = {"amid_embed_fwd_live_f32": "K1 gather (live sequences)", "amid_embed_fwd_f32": "K1 gather",
+            "amid_lazy_adam_catchup_live_f32": "K4a lazy-Adam catch-up (live sequences)",
             "amid_grad_tail_f32": "K3 segment reduce + dense partial sums", "amid_embgrad_segreduce_f32": "K3 segment reduce",
             "amid_lazy_adam_catchup_positions_f32": "K4a lazy-Adam catch-up", "amid_optimizer_step_f32": "K4b Adam (dense + unique rows)"}
     out = {"workload": wl["label"], "batch": wl["B"], "unique_rows": int(pl.n_uniq.item()), "kernels": {}}
@@ -475,7 +480,8 @@ def main():
         work = algorithmic_work(Bw, int(pl.n_uniq.item()), T)
         red_bytes = (getattr(pl, "red_bytes_v", None) if getattr(eng, "_own_domain_only", False) else None) or getattr(pl, "red_bytes", None)
         if red_bytes:         # K3 (the segment reduce of the row gradients) + the reduce of every dense partial sum, one launch
-            work["amid_grad_tail_f32"] = ("hbm", work["amid_embgrad_segreduce_f32"][1] + red_bytes)
+            k3 = "amid_embgrad_segreduce_live" if getattr(pl, "compact", False) else "amid_embgrad_segreduce_f32"
+            work["amid_grad_tail_f32"] = ("hbm", work[k3][1] + red_bytes)
         total_ms = 0.0
         for name, v in durs.items():
             name = name[:-4] if name.endswith(("_rt3", "_rt4", "_rt5")) else name        # the 48- / 64- / 80-row builds of the row-tile kernels

@@ -79,6 +79,9 @@ int amid_sort_set_four_launch_min(int n_idx);
 int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
                          int* seg_off /* [n_idx + 1] */, int* seg_of /* [n_idx] run index of each sorted entry */,
                          int* n_uniq /* device scalar */, void* stream);
+/* amid_sort_unique_i32 with a payload: pos_sorted holds rows[i] instead of i (ties keep the order of the list). */
+int amid_sort_unique_rows_i32(const int* idx, const int* rows, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
+                              int* seg_off, int* seg_of, int* n_uniq, void* stream);
 
 /* ---- K3 embedding gradient as segment reduce -------------------------------------------------
  * replaces: autograd EmbeddingBackward (dense index_add into zero-filled [n_rows, D]) of the four
@@ -565,6 +568,13 @@ int amid_pack_indices_pool_live(const long long* pool, long long pool_stride, in
 int amid_embed_fwd_live_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
                             int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
                             const int* live, void* stream);
+/* amid_embed_fwd_live_f32 that also writes the step's compact index list over the live sequences + the items (B T + n_item_rows
+ * entries): idx_c[i] = the id at walk position i, row_c[i] = that position's row in the full [2 B T + items] layout (where its
+ * gradient will stand).  Sort (amid_sort_unique_rows_i32), segment reduce and row Adam of the step then run on half the entries:
+ * the dead sequences' gradient rows are exact zeros (train_sr.py:205-211). */
+int amid_embed_fwd_live_compact_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
+                                    int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
+                                    const int* live, int* idx_c, int* row_c, void* stream);
 int amid_attn_live_supported(int T, int D, int H, int causal);
 int amid_attn_fwd_live_f32(const float* q, const float* k, const float* v, int B, int T, int D, int H, int causal, int layer,
                            const void* step_state, int train, float p_drop, float* o, float* stats, const int* live, void* stream);

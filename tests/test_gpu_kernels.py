@@ -103,6 +103,37 @@ def test_sort_unique_matches_stable_sort(L, n, n_rows, pad_frac):
     assert torch.equal(_[3].cpu().long(), torch.repeat_interleave(torch.arange(U), wc))      # run index of every sorted entry
 
 
+@pytest.mark.parametrize("four_min", [65536, 0])
+def test_sort_unique_rows_payload_and_one_workspace_for_many_lengths(L, four_min):
+    """amid_sort_unique_rows_i32: pos_sorted carries the caller's row of every entry (the compact index list of the live train step);
+    and ONE workspace, sized for the longest list, serves lists of different lengths in turn -- what a plan's timed (compact) and
+    plain (full) steps do -- through both sorts."""
+    prev = L.value("amid_sort_set_four_launch_min", four_min)
+    try:
+        n_max, n_rows = 417792, 10_000_002
+        ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", n_max), dtype=torch.uint8, device="cuda")
+        g = torch.Generator().manual_seed(3)
+        for n in (212992, 417792, 13312, 212992, 70000, 417792):
+            idx = torch.randint(0, n_rows, (n,), generator=g)
+            idx[torch.rand(n, generator=g) < 0.5] = n_rows - 1
+            rows = torch.randperm(2 * n, generator=g)[:n].to(torch.int32)
+            out = [torch.zeros(n + 1, dtype=torch.int32, device="cuda") for _ in range(4)]
+            nu = torch.zeros(1, dtype=torch.int32, device="cuda")
+            d_idx, d_rows = idx.int().cuda(), rows.cuda()
+            L.call("amid_sort_unique_rows_i32", d_idx.data_ptr(), d_rows.data_ptr(), n, n_rows, ws.data_ptr(), out[0].data_ptr(),
+                   out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), nu.data_ptr(), stream())
+            torch.cuda.synchronize()
+            order = torch.sort(idx, stable=True).indices
+            assert torch.equal(out[0][:n].cpu().long(), rows.long()[order])
+            wu, wc = torch.unique(idx, return_counts=True)
+            U = int(nu.item())
+            assert U == wu.numel() and torch.equal(out[1][:U].cpu().long(), wu)
+            assert torch.equal(out[2][: U + 1].cpu().long(), torch.cat((torch.zeros(1, dtype=torch.long), wc.cumsum(0))))
+            check_sort(idx, run_sort_unique(L, idx, n_rows, ws))              # and the same workspace without a payload
+    finally:
+        L.value("amid_sort_set_four_launch_min", prev)
+
+
 def check_sort(idx, out):
     pos, uniq, seg, U, raw = out
     assert torch.equal(pos, torch.sort(idx, stable=True).indices)

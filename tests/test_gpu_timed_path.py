@@ -128,14 +128,28 @@ TIMED_CASES = [
 
 @pytest.mark.parametrize("Bn,T,D,build,split", TIMED_CASES)
 def test_timed_path_loss_and_grads_vs_oracle(Bn, T, D, build, split):
+    _timed_vs_oracle(Bn, T, D, build, split, compact_min=None)
+
+
+@pytest.mark.parametrize("Bn,T,D,build,split", [TIMED_CASES[0], TIMED_CASES[1], TIMED_CASES[5], TIMED_CASES[7], TIMED_CASES[8]])
+def test_timed_path_with_compact_index_list_vs_oracle(Bn, T, D, build, split):
+    """The same with the step's sparse side (sort, segment reduce, row Adam inputs) on the compact index list of the live sequences,
+    which the engine only takes for long lists (SasrecEngine.COMPACT_MIN_IDX): forced here for the small shapes."""
+    _timed_vs_oracle(Bn, T, D, build, split, compact_min=0)
+
+
+def _timed_vs_oracle(Bn, T, D, build, split, compact_min):
     hid, n_items = 32, 3000
     P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=300 + D + Bn)
     batch = split_batch(Bn, T, n_items, seed=Bn + T, split=split)
     seed, step = 21, 4
     masks = orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=step)
     eng = make_engine(P, T, seed=seed)
+    if compact_min is not None:
+        eng.COMPACT_MIN_IDX = compact_min
     pl = eng.plan(Bn, T, 2, need_grad=True)
     timed_local_grads(eng, pl, batch, step, seed)
+    assert pl.compact == eng.compact_ok(pl) and (compact_min != 0 or D != 128 or pl.compact)
     # the encoder's GEMM chains of the fused step run as strip kernels over the live sequences (csrc/sasrec_strip.hip); engines
     # built without them fall back to the live-row builds of the row-tile kernels named in the case
     assert pl.strip or pl.rt_suffix_v == build
