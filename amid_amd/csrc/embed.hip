@@ -18,6 +18,7 @@
 namespace amid {
 
 constexpr int ROWS_IN_FLIGHT = 2;
+constexpr int EMBED_RIF = 4;        // rows a half-wave of the fused embedding forward keeps in flight (its indices come 32 at a time)
 
 // ---------------------------------------------------------------------------------------------
 // plain gather: out[i,:] = table[idx[i],:]           (bit-exact; G1)
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
                                                         int B, int T, int D, int n_item_rows,
                                                         float* __restrict__ xg, unsigned char* __restrict__ tmq,
                                                         const RngState* __restrict__ rng, int train, unsigned thr16, float scale,
-                                                        const int* __restrict__ live, int* __restrict__ idx_c, int* __restrict__ row_c) {
+                                                        const int* __restrict__ live, int* __restrict__ idx_c, int* __restrict__ row_c, int chunk) {
     const int sub = threadIdx.x & 31;
     const int hw = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     const int n_hw = gridDim.x * (blockDim.x >> 5);
@@ -180,51 +181,88 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
     unsigned long long seed = 0;
     unsigned step = 0;
     if (train) { seed = rng->seed; step = (unsigned)rng->step; }
-    for (int r0 = hw * RIF; r0 < n_walk; r0 += n_hw * RIF) {
-        long long src[RIF];
-        int row[RIF];
-#pragma unroll
-        for (int u = 0; u < RIF; ++u) {
-            int r = r0 + u;
-            if (live != nullptr && r < n_walk) {
+    // A half-wave owns a chunk of `chunk` (4 .. 32) walk positions: lane j < chunk resolves position j's (row, id) -- the dependent
+    // chain live -> index -> table row is paid once per chunk, in parallel across the lanes, not once per row --, then the rows are
+    // moved RIF at a time with every lane on its float4 column.  Long lists take chunks of 32, short ones small chunks (more waves).
+    const int half = threadIdx.x & 32;
+    for (int c0 = hw * chunk; c0 < n_walk; c0 += n_hw * chunk) {
+        const int mine = c0 + sub;
+        int my_row = 0, my_src = 0;
+        if (sub < chunk && mine < n_walk) {
+            int r = mine;
+            if (live != nullptr) {
                 if (r < M) { const int sq = r / T; r = (sq >= n0 ? M : 0) + live[sq] * T + (r - sq * T); }
                 else r += M;
             }
-            row[u] = r;
-            src[u] = (r0 + u < n_walk) ? (long long)idx_all[r] : 0;
+            my_row = r;
+            my_src = idx_all[r];
             // the walk over the live sequences is the step's compact index list: the id at every walk position and the row of the
             // full layout its gradient will stand in (what the sort, the segment reduce and the row Adam of the step then run on)
-            if (idx_c != nullptr && sub == 0 && r0 + u < n_walk) { idx_c[r0 + u] = (int)src[u]; row_c[r0 + u] = r; }
+            if (idx_c != nullptr) { idx_c[mine] = my_src; row_c[mine] = r; }
         }
-        for (int c = sub; c < q; c += 32) {
-            float4 v[RIF];
-#pragma unroll
-            for (int u = 0; u < RIF; ++u) v[u] = ld4(table + src[u] * D + 4 * c);
+        // p = 0.5 at D = 128: ONE Philox call decides a whole row (rng.h).  Lane j draws the call of ITS row; the row loop below
+        // fetches the word a lane's column quad needs from the row's lane -- one call per row instead of one per lane and row.
+        const bool row_calls = train && D == 128 && spec_bits(thr16) == 1 && pos0 != nullptr;
+        uint4 my_bits = make_uint4(0u, 0u, 0u, 0u);
+        if (row_calls && sub < chunk && mine < n_walk && my_row < 2 * M) {
+            const int g = my_row >= M;
+            my_bits = rng_call(seed, (unsigned long long)(my_row - g * M), site_id(g, 0, SITE_EMB), step);
+        }
+        const int n_here = min(chunk, n_walk - c0);
+        for (int u0 = 0; u0 < n_here; u0 += RIF) {
+            long long src[RIF];
+            int row[RIF];
 #pragma unroll
             for (int u = 0; u < RIF; ++u) {
-                const int r = row[u];
-                if (r0 + u >= n_walk) continue;
-                float4 x = v[u];
-                if (r < 2 * M && pos0 != nullptr) {
-                    const int g = r >= M;
-                    const int local = r - g * M;
-                    const int t = local % T;
-                    const float4 p = ld4((g ? pos1 : pos0) + (long long)t * D + 4 * c);
-                    x = f4add(x, p);
-                    const unsigned bits = (x.x == 0.f ? 1u : 0u) | (x.y == 0.f ? 2u : 0u) | (x.z == 0.f ? 4u : 0u) | (x.w == 0.f ? 8u : 0u);
-                    if (train) {
-                        const float4 m = dropout_mult4(seed, site_id(g, 0, SITE_EMB), step, (unsigned long long)local * D + 4 * c, thr16, scale);
-                        x = f4mul(x, m);
-                    }
-                    if (bits) {
-                        if (bits & 1u) x.x = 0.f;
-                        if (bits & 2u) x.y = 0.f;
-                        if (bits & 4u) x.z = 0.f;
-                        if (bits & 8u) x.w = 0.f;
-                    }
-                    tmq[(long long)r * q + c] = (unsigned char)bits;
+                src[u] = __shfl(my_src, half + ((u0 + u) & 31), 64);
+                row[u] = __shfl(my_row, half + ((u0 + u) & 31), 64);
+            }
+            unsigned kbits[RIF];                       // the 32-bit word of row u's call that holds this lane's column quad (c = sub)
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
+                kbits[u] = 0u;
+                if (row_calls) {
+                    const int from = half + ((u0 + u) & 31);
+                    const unsigned wx = __shfl(my_bits.x, from, 64), wy = __shfl(my_bits.y, from, 64);
+                    const unsigned wz = __shfl(my_bits.z, from, 64), ww = __shfl(my_bits.w, from, 64);
+                    const int wsel = sub >> 3;
+                    kbits[u] = wsel == 0 ? wx : wsel == 1 ? wy : wsel == 2 ? wz : ww;
                 }
-                st4(xg + (long long)r * D + 4 * c, x);
+            }
+            for (int c = sub; c < q; c += 32) {
+                float4 v[RIF];
+#pragma unroll
+                for (int u = 0; u < RIF; ++u) v[u] = ld4(table + src[u] * D + 4 * c);
+#pragma unroll
+                for (int u = 0; u < RIF; ++u) {
+                    const int r = row[u];
+                    if (u0 + u >= n_here) continue;
+                    float4 x = v[u];
+                    if (r < 2 * M && pos0 != nullptr) {
+                        const int g = r >= M;
+                        const int local = r - g * M;
+                        const int t = local % T;
+                        const float4 p = ld4((g ? pos1 : pos0) + (long long)t * D + 4 * c);
+                        x = f4add(x, p);
+                        const unsigned bits = (x.x == 0.f ? 1u : 0u) | (x.y == 0.f ? 2u : 0u) | (x.z == 0.f ? 4u : 0u) | (x.w == 0.f ? 8u : 0u);
+                        if (row_calls) {
+                            const unsigned kw = (kbits[u] >> ((c & 7) * 4)) | (spec_thr(thr16) == 0 ? 0xFu : 0u);      // keep bits of this quad
+                            x = make_float4((kw & 1u) ? x.x * scale : 0.f, (kw & 2u) ? x.y * scale : 0.f, (kw & 4u) ? x.z * scale : 0.f,
+                                            (kw & 8u) ? x.w * scale : 0.f);
+                        } else if (train) {
+                            const float4 m = dropout_mult4(seed, site_id(g, 0, SITE_EMB), step, (unsigned long long)local * D + 4 * c, thr16, scale);
+                            x = f4mul(x, m);
+                        }
+                        if (bits) {
+                            if (bits & 1u) x.x = 0.f;
+                            if (bits & 2u) x.y = 0.f;
+                            if (bits & 4u) x.z = 0.f;
+                            if (bits & 8u) x.w = 0.f;
+                        }
+                        tmq[(long long)r * q + c] = (unsigned char)bits;
+                    }
+                    st4(xg + (long long)r * D + 4 * c, x);
+                }
             }
         }
     }
@@ -302,6 +340,20 @@ __global__ __launch_bounds__(256) void key_keep_tiled_kernel(const long long* __
 }  // namespace amid
 
 using namespace amid;
+
+// embed_fwd_kernel: a half-wave per chunk of rows; the largest chunk that still fills every wave slot of the chip (8 blocks per CU:
+// the gather wants as many rows in flight as the chip can hold -- measured at cfg 5, 221 k rows: chunks of 32 / 864 blocks 78.8 us)
+static inline int embed_chunk(long long n_rows_to_move) {
+    int chunk = 32;
+    while (chunk > EMBED_RIF && (n_rows_to_move / chunk + 7) / 8 < 2048) chunk >>= 1;
+    return chunk;
+}
+static inline int embed_grid(long long n_rows_to_move, int chunk) {
+    long long blocks = ((n_rows_to_move + chunk - 1) / chunk + 7) / 8;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 16384) blocks = 16384;
+    return (int)blocks;
+}
 
 static inline int gather_grid(long long n_rows_to_move) {
     long long hw_needed = (n_rows_to_move + ROWS_IN_FLIGHT - 1) / ROWS_IN_FLIGHT;
@@ -389,9 +441,10 @@ static int embed_fwd(const float* table, const int* idx_all, const float* pos0, 
     AMID_CHECK_ARG(!train || rng_state != nullptr);
     const long long n_walk = (live != nullptr ? 1LL : 2LL) * B * T + n_item_rows;
     const int tr = (train && pos0 != nullptr && p_drop > 0.f) ? 1 : 0;
-    embed_fwd_kernel<ROWS_IN_FLIGHT><<<gather_grid(n_walk), 256, 0, (hipStream_t)stream>>>(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq,
+    const int chunk = embed_chunk(n_walk);
+    embed_fwd_kernel<EMBED_RIF><<<embed_grid(n_walk, chunk), 256, 0, (hipStream_t)stream>>>(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq,
                                                                                             (const RngState*)rng_state, tr, keep_thr16(p_drop),
-                                                                                            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c);
+                                                                                            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -160,6 +160,7 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_attn_fwd_live_f32": ("mfma", 4.0 * T * T * hd * Bw * H),
         "amid_attn_bwd_live_f32": ("mfma", 10.0 * T * T * hd * Bw * H),
         "amid_embed_fwd_live_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (4 + 2 * D * 4) + Bw * T * (D // 4)),
+        "amid_embed_fwd_live_compact_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (12 + 2 * D * 4) + Bw * T * (D // 4)),
         "amid_sas_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_sas_oproj_fwd_f32": ("mfma", gemm),
         "amid_sas_oproj_ffn_fwd_f32": ("mfma", 3 * gemm),
@@ -212,7 +213,7 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_seq_fwd_f32": "seq_fwd_kernel", "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
     "amid_sas_strip_oproj_ffn_fwd_f32#1": "strip_oproj_ffn_fwd_kernelILi128ELb0", "amid_sas_strip_ffn_bwd_f32": "strip_ffn_bwd_kernel",
     "amid_sas_strip_qkv_bwd_f32#0": "strip_qkv_bwd_kernelILi128ELb1", "amid_sas_strip_qkv_bwd_f32#1": "strip_qkv_bwd_kernelILi128ELb0",
-    "amid_attn_fwd_live_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_live_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_live_f32": "embed_fwd_kernel",
+    "amid_attn_fwd_live_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_live_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_live_f32": "embed_fwd_kernel", "amid_embed_fwd_live_compact_f32": "embed_fwd_kernel",
     "amid_embgrad_segreduce_f32": "segreduce_chunks_kernel",
 }
 
@@ -263,6 +264,7 @@ def gather_stress(device, n_steps=6):
         k3 = "amid_embgrad_segreduce_live" if getattr(pl, "compact", False) else "amid_embgrad_segreduce_f32"
         work["amid_grad_tail_f32"] = ("hbm", work[k3][1] + pl.red_bytes)
     role = {"amid_embed_fwd_live_f32": "K1 gather (live sequences)", "amid_embed_fwd_f32": "K1 gather",
+            "amid_embed_fwd_live_compact_f32": "K1 gather (live sequences; writes the compact index list)",
             "amid_lazy_adam_catchup_live_f32": "K4a lazy-Adam catch-up (live sequences)",
             "amid_grad_tail_f32": "K3 segment reduce + dense partial sums", "amid_embgrad_segreduce_f32": "K3 segment reduce",
             "amid_lazy_adam_catchup_positions_f32": "K4a lazy-Adam catch-up", "amid_optimizer_step_f32": "K4b Adam (dense + unique rows)"}
