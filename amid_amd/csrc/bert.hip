@@ -19,7 +19,19 @@ constexpr int BD = 128;      // hidden
 constexpr int BF = 512;      // feed-forward
 constexpr float BERT_EPS = 1e-6f;
 
-struct BGeom { int M; int rows_per_tile; int tiles_per_group; };
+struct BGeom {
+    int M; int rows_per_tile; int tiles_per_group;
+    // optional hint of the backward kernels (the *_rows entry points): rows_per_tile is a multiple of T, so a tile holds whole
+    // sequences; of domain g only the sequences b with (row_domain[b] != 0) == g carry a gradient (the step's own loss masks the
+    // other domain of every sample, train_sr.py:205-211) -- a tile without such a sequence does no work (bdead)
+    const long long* row_domain; int T;
+};
+__device__ __forceinline__ bool bdead(const BGeom& tg, int g, int local0, int nrows) {
+    if (tg.row_domain == nullptr) return false;
+    for (int b = local0 / tg.T, b1 = (local0 + nrows - 1) / tg.T; b <= b1; ++b)
+        if ((tg.row_domain[b] != 0 ? 1 : 0) == g) return false;
+    return true;
+}
 __device__ __forceinline__ void btile(const BGeom& tg, int tile, int& g, long long& row0, int& nrows, int& local0) {
     g = tile / tg.tiles_per_group;
     const int tl = tile - g * tg.tiles_per_group;
@@ -283,6 +295,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_ffn2_bwd_kernel(const BFfn2
     float* Ws = smem + TileCfg<BD>::A_FLOATS;
     int g, nrows, local0; long long row0;
     btile(a.tg, blockIdx.x, g, row0, nrows, local0);
+    if (bdead(a.tg, g, local0, nrows)) return;              // dz / dpre of dead sequences are read by nobody (the consumers take the same hint)
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
     if (a.dc.train) { seed = a.dc.st->seed; step = (unsigned)a.dc.st->step; }
@@ -339,6 +352,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_ffn1_bwd_kernel(const BFfn1
     float* Cs = Ws;
     int g, nrows, local0; long long row0;
     btile(a.tg, blockIdx.x, g, row0, nrows, local0);
+    if (bdead(a.tg, g, local0, nrows)) {                    // only the tile's LayerNorm-partial slot is read (by the fixed-order reduce)
+        for (int i = threadIdx.x; i < 2 * BD; i += GEMM_THREADS) a.ln_part[(long long)blockIdx.x * 2 * BD + i] = 0.f;
+        return;
+    }
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
     if (a.dc.train) { seed = a.dc.st->seed; step = (unsigned)a.dc.st->step; }
@@ -408,6 +425,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_qkv_bwd_kernel(const BQkvBw
     float* Cs = Ws;
     int g, nrows, local0; long long row0;
     btile(a.tg, blockIdx.x, g, row0, nrows, local0);
+    if (bdead(a.tg, g, local0, nrows)) {                    // dx feeds the embedding gradient of every position (layer 0): exact zeros
+        for (int i = threadIdx.x; i < 2 * BD; i += GEMM_THREADS) a.ln_part[(long long)blockIdx.x * 2 * BD + i] = 0.f;
+        for (int i = threadIdx.x; i < nrows * (BD / 4); i += GEMM_THREADS) st4(a.dx + row0 * BD + 4 * (long long)i, make_float4(0.f, 0.f, 0.f, 0.f));
+        return;
+    }
     const int sub = RP::sub();
     const float* src[3] = {a.dq, a.dk, a.dv};
     TileRegs<BD> ar, xr, rr;
@@ -602,9 +624,14 @@ __global__ __launch_bounds__(256) void transpose_rect_kernel(const BTransArgs a)
 using namespace amid;
 
 static constexpr size_t bert_lds() { return (size_t)(TileCfg<BD>::A_FLOATS + TileCfg<BD>::W_FLOATS) * sizeof(float); }
-static int bgeom(int M, int rpt, BGeom* tg) {
+static int bgeom(int M, int rpt, BGeom* tg, const long long* row_domain = nullptr, int B = 0, int T = 0) {
     if (M <= 0 || rpt <= 0 || rpt > TILE_ROWS) return AMID_ERR_ARG;
     tg->M = M; tg->rows_per_tile = rpt; tg->tiles_per_group = (M + rpt - 1) / rpt;
+    tg->row_domain = nullptr; tg->T = 0;
+    if (row_domain) {                          // whole sequences per tile
+        if (B <= 0 || T <= 0 || (long long)B * T != M || rpt % T != 0) return AMID_ERR_ARG;
+        tg->row_domain = row_domain; tg->T = T;
+    }
     return AMID_OK;
 }
 static DropCfg bdropcfg(const void* st, int train, float p, int layer) {
@@ -674,39 +701,76 @@ extern "C" int AMID_ENTRY(amid_bert_ffn2_fwd_f32)(const float* h, const float* x
     return AMID_OK;
 }
 
-extern "C" int AMID_ENTRY(amid_bert_ffn2_bwd_f32)(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                      const void* step_state, int train, float p_drop, float* dz, float* dpre, void* stream) {
+static int bert_ffn2_bwd(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                         const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain, int B, int T,
+                         void* stream) {
     AMID_CHECK_ARG(dx2 && pre && w2T && dz && dpre && (!train || step_state));
     BFfn2BwdArgs a;
     a.dx2 = dx2; a.pre = pre; a.dz = dz; a.dpre = dpre; a.dc = bdropcfg(step_state, train, p_drop, layer);
     for (int g = 0; g < 2; ++g) a.w2T[g] = w2T[g];
-    if (int e = bgeom(M, rows_per_tile, &a.tg)) return e;
+    if (int e = bgeom(M, rows_per_tile, &a.tg, row_domain, B, T)) return e;
     BERT_LAUNCH(bert_ffn2_bwd_kernel, a);
     return AMID_OK;
 }
+extern "C" int AMID_ENTRY(amid_bert_ffn2_bwd_f32)(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                                      const void* step_state, int train, float p_drop, float* dz, float* dpre, void* stream) {
+    return bert_ffn2_bwd(dx2, pre, w2T, M, rows_per_tile, layer, step_state, train, p_drop, dz, dpre, nullptr, 0, 0, stream);
+}
+// the three backward kernels over the live sequences only: row_domain [B] = the batch's domain ids, M = B * T, rows_per_tile a
+// multiple of T (tiles hold whole sequences); tiles without a live sequence do no work (see BGeom)
+extern "C" int AMID_ENTRY(amid_bert_ffn2_bwd_rows_f32)(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                                      const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain,
+                                      int B, int T, void* stream) {
+    AMID_CHECK_ARG(row_domain != nullptr);
+    return bert_ffn2_bwd(dx2, pre, w2T, M, rows_per_tile, layer, step_state, train, p_drop, dz, dpre, row_domain, B, T, stream);
+}
 
-extern "C" int AMID_ENTRY(amid_bert_ffn1_bwd_f32)(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
-                                      const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                                      float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, void* stream) {
+static int bert_ffn1_bwd(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                         const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
+                         float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const long long* row_domain, int B, int T,
+                         void* stream) {
     AMID_CHECK_ARG(dpre && dx2 && x1 && ln_a && w1T && woT && dx1 && dt && d_o && ln_part && (!train || step_state));
     BFfn1BwdArgs a;
     a.dpre = dpre; a.dx2 = dx2; a.x1 = x1; a.dx1 = dx1; a.dt = dt; a.d_o = d_o; a.ln_part = ln_part;
     a.dc = bdropcfg(step_state, train, p_drop, layer);
     for (int g = 0; g < 2; ++g) { a.la[g] = ln_a[g]; a.w1T[g] = w1T[g]; a.woT[g] = woT[g]; }
-    if (int e = bgeom(M, rows_per_tile, &a.tg)) return e;
+    if (int e = bgeom(M, rows_per_tile, &a.tg, row_domain, B, T)) return e;
     BERT_LAUNCH(bert_ffn1_bwd_kernel, a);
     return AMID_OK;
 }
+extern "C" int AMID_ENTRY(amid_bert_ffn1_bwd_f32)(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                                      const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
+                                      float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, void* stream) {
+    return bert_ffn1_bwd(dpre, dx2, x1, ln_a, w1T, woT, M, rows_per_tile, layer, step_state, train, p_drop, dx1, dt, d_o, ln_part, nullptr, 0, 0, stream);
+}
+extern "C" int AMID_ENTRY(amid_bert_ffn1_bwd_rows_f32)(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a,
+                                      const float* const* w1T, const float* const* woT, int M, int rows_per_tile, int layer,
+                                      const void* step_state, int train, float p_drop, float* dx1, float* dt, float* d_o, float* ln_part,
+                                      const long long* row_domain, int B, int T, void* stream) {
+    AMID_CHECK_ARG(row_domain != nullptr);
+    return bert_ffn1_bwd(dpre, dx2, x1, ln_a, w1T, woT, M, rows_per_tile, layer, step_state, train, p_drop, dx1, dt, d_o, ln_part, row_domain, B, T, stream);
+}
 
-extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                                     const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream) {
+static int bert_qkv_bwd(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                        const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const long long* row_domain, int B,
+                        int T, void* stream) {
     AMID_CHECK_ARG(dq && dk && dv && dx1 && x && ln_a && wT3x2 && dx && ln_part);
     BQkvBwdArgs a;
     a.dq = dq; a.dk = dk; a.dv = dv; a.dx1 = dx1; a.x = x; a.dx = dx; a.ln_part = ln_part;
     for (int g = 0; g < 2; ++g) { a.la[g] = ln_a[g]; for (int j = 0; j < 3; ++j) a.wT[j][g] = wT3x2[j * 2 + g]; }
-    if (int e = bgeom(M, rows_per_tile, &a.tg)) return e;
+    if (int e = bgeom(M, rows_per_tile, &a.tg, row_domain, B, T)) return e;
     BERT_LAUNCH(bert_qkv_bwd_kernel, a);
     return AMID_OK;
+}
+extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                                     const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream) {
+    return bert_qkv_bwd(dq, dk, dv, dx1, x, ln_a, wT3x2, M, rows_per_tile, dx, ln_part, nullptr, 0, 0, stream);
+}
+extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_rows_f32)(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x,
+                                     const float* const* ln_a, const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part,
+                                     const long long* row_domain, int B, int T, void* stream) {
+    AMID_CHECK_ARG(row_domain != nullptr);
+    return bert_qkv_bwd(dq, dk, dv, dx1, x, ln_a, wT3x2, M, rows_per_tile, dx, ln_part, row_domain, B, T, stream);
 }
 
 // n_ent (<= 12) output tiles of 128 x 128; dy / x: host arrays of n_ent device pointers (column offsets folded in), ld*: row strides.

@@ -70,6 +70,26 @@ class BertPlan(SasrecPlan):
 
     def _alloc_model_bwd(self, eng, f) -> None:
         M, D, F = self.shape.M, eng.D, BERT_FF
+        # The three backward row-tile kernels tile WHOLE sequences (rows_per_tile = k * T) so that, in a train step, tiles without a
+        # live sequence do no work (bert.hip BGeom::row_domain: the loss sends no gradient into the other domain's encoder of a
+        # sample).  (k, build) minimise the MFMA rows spent per live sequence: a tile of k sequences is live with probability
+        # 1 - 2^-k and serves k / 2 live sequences on average.  T = 50: one sequence on the 64-row build; T = 20: two on the 48-row one.
+        T = self.shape.Tenc
+        best = None
+        for cap, suf in ((48, "_rt3"), (64, "_rt4"), (80, "_rt5"), (112, "")):
+            k = cap // T
+            if k >= 1 and eng.SHORT_TILE_BUILDS and eng.LIVE_TILES_BWD:
+                cost = cap * (1.0 - 0.5 ** k) / (0.5 * k)
+                if best is None or cost < best[0]:
+                    best = (cost, k * T, suf)
+        if best is not None:
+            self.rpt_b, self.rt_suffix_b = best[1], best[2]
+        else:
+            self.rpt_b, self.rt_suffix_b = self.rpt, self.rt_suffix
+        self.live_tiles = best is not None
+        self.tpg_b = (M + self.rpt_b - 1) // self.rpt_b
+        self.ln1_part = [f(2 * self.tpg_b, 2, D) for _ in range(2)]       # one slot per backward tile
+        self.ln2_part = [f(2 * self.tpg_b, 2, D) for _ in range(2)]
         self.dz, self.dt, self.dx1 = f(2 * M, D), f(2 * M, D), f(2 * M, D)
         self.dpre = f(2 * M, F)
         self.splits = max(1, min(10, M // 128))          # 2 domains x 12 tiles x 10 splits = 240 workgroups
@@ -97,11 +117,11 @@ class BertPlan(SasrecPlan):
                 # w_2 [128,512]: its four column tiles share output group 8 -> partials are [S][128*512] from entry 8 on
                 add(self.w_part[l], wbase(8), fp.ptr(f"{pre}.feed_forward.w_2.weight", G), D * F, S, D * F)
                 add(self.b_part[l], bbase(8), fp.ptr(f"{pre}.feed_forward.w_2.bias", G), D, S, D)
-                tb = g * self.tpg * 2 * D
-                add(self.ln1_part[l], tb, fp.ptr(f"{pre}.input_sublayer.norm.a_2", G), 2 * D, self.tpg, D)
-                add(self.ln1_part[l], tb + D, fp.ptr(f"{pre}.input_sublayer.norm.b_2", G), 2 * D, self.tpg, D)
-                add(self.ln2_part[l], tb, fp.ptr(f"{pre}.output_sublayer.norm.a_2", G), 2 * D, self.tpg, D)
-                add(self.ln2_part[l], tb + D, fp.ptr(f"{pre}.output_sublayer.norm.b_2", G), 2 * D, self.tpg, D)
+                tb = g * self.tpg_b * 2 * D
+                add(self.ln1_part[l], tb, fp.ptr(f"{pre}.input_sublayer.norm.a_2", G), 2 * D, self.tpg_b, D)
+                add(self.ln1_part[l], tb + D, fp.ptr(f"{pre}.input_sublayer.norm.b_2", G), 2 * D, self.tpg_b, D)
+                add(self.ln2_part[l], tb, fp.ptr(f"{pre}.output_sublayer.norm.a_2", G), 2 * D, self.tpg_b, D)
+                add(self.ln2_part[l], tb + D, fp.ptr(f"{pre}.output_sublayer.norm.b_2", G), 2 * D, self.tpg_b, D)
 
 
 class Bert4recEngine(SasrecEngine):
@@ -111,6 +131,11 @@ class Bert4recEngine(SasrecEngine):
     SHORT_TILE_BUILDS = True
     STRIP_KERNELS = False        # its encoder launches are bert.hip's row-tile kernels
     SORT_FORK = "catchup"        # the side-stream sort runs beside the forward (no launch of this encoder fills every CU)
+    # the backward row-tile kernels can tile whole sequences and skip the tiles without a live one (BertPlan).  Off: these kernels
+    # are bound by the 256 KB of weights every tile streams through LDS, not by its rows -- at cfg 2 the 256 live 50-row tiles of
+    # the 64-row build take as long as the 256 tiles of 100 rows they replace (ffn2_bwd 75 vs 71 us).  Gathering two live
+    # sequences into one 112-row tile (a row map as in sasrec_bwd.hip) is what would halve them.
+    LIVE_TILES_BWD = False
 
     def __init__(self, *args, comp: str = "", comp_bs: int = 0, comp_threshold: float = 0.5, **kw):
         """comp = "inc" / "itc": BERT4Rec(isInC=True) / (isItC=True) with bs = comp_bs and threshold1 / threshold2 = comp_threshold:
@@ -237,11 +262,14 @@ class Bert4recEngine(SasrecEngine):
         for l in (1, 0):
             pre = f"transform{{d}}.{l}"
             wsq = lambda j: ptr_array([self.wT_sq[l, g, j].data_ptr() for g in (0, 1)])      # noqa: E731
-            L.call("amid_bert_ffn2_bwd_f32" + pl.rt_suffix, pl.dxbuf.data_ptr(), pl.pre[l].data_ptr(), ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]),
-                   M, pl.rpt, l, st, tr, BERT_P_DROP, pl.dz.data_ptr(), pl.dpre.data_ptr(), s)
-            L.call("amid_bert_ffn1_bwd_f32" + pl.rt_suffix, pl.dpre.data_ptr(), pl.dxbuf.data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".output_sublayer.norm.a_2"),
-                   ptr_array([self.w1T[l, g].data_ptr() for g in (0, 1)]), wsq(3), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.dx1.data_ptr(),
-                   pl.dt.data_ptr(), pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), s)
+            own = self._own_rows(pl) if pl.live_tiles else None          # the batch's domain ids: tiles without a live sequence do no work
+            rows, hint = ("_rows", (own, B, T)) if own is not None else ("", ())
+            L.call("amid_bert_ffn2_bwd" + rows + "_f32" + pl.rt_suffix_b, pl.dxbuf.data_ptr(), pl.pre[l].data_ptr(),
+                   ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]), M, pl.rpt_b, l, st, tr, BERT_P_DROP, pl.dz.data_ptr(), pl.dpre.data_ptr(),
+                   *hint, s)
+            L.call("amid_bert_ffn1_bwd" + rows + "_f32" + pl.rt_suffix_b, pl.dpre.data_ptr(), pl.dxbuf.data_ptr(), pl.x1[l].data_ptr(),
+                   self._pp(pre + ".output_sublayer.norm.a_2"), ptr_array([self.w1T[l, g].data_ptr() for g in (0, 1)]), wsq(3), M, pl.rpt_b, l, st, tr,
+                   BERT_P_DROP, pl.dx1.data_ptr(), pl.dt.data_ptr(), pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), *hint, s)
             L.call("amid_attn_bwd_rows_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(), pl.stats[l].data_ptr(),
                    pl.d_o.data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l, st, tr, BERT_P_DROP, pl.dq.data_ptr(), pl.dk.data_ptr(),
                    pl.dv.data_ptr(), self._own_rows(pl), s)
@@ -259,8 +287,9 @@ class Bert4recEngine(SasrecEngine):
             L.call("amid_bert_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), (ctypes.c_int * N_ENT)(*ldy), (ctypes.c_int * N_ENT)(*ldx),
                    (ctypes.c_int * N_ENT)(*old), (ctypes.c_int * N_ENT)(*ogr), (ctypes.c_int * N_ENT)(*oco), N_ENT, M,
                    pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), self._own_rows(pl), B, T, s)
-            L.call("amid_bert_qkv_bwd_f32" + pl.rt_suffix, pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[l].data_ptr(),
-                   self._pp(pre + ".input_sublayer.norm.a_2"), wT3, M, pl.rpt, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(), s)
+            L.call("amid_bert_qkv_bwd" + rows + "_f32" + pl.rt_suffix_b, pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(),
+                   pl.x[l].data_ptr(), self._pp(pre + ".input_sublayer.norm.a_2"), wT3, M, pl.rpt_b, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(),
+                   *hint, s)
         if self.comp:      # the comp modules' parameter gradients; the rows' own halves + their share of the token group -> dxg
             c, G = self.comp, self.dense.grad
             L.call("amid_bert_comp_bwd_f32", pl.xg.data_ptr(), pl.dx0.data_ptr(), pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(),

@@ -315,6 +315,19 @@ int amid_bert_ffn1_bwd_f32(const float* dpre, const float* dx2, const float* x1,
                            float* dx1, float* dt, float* d_o, float* ln_part, void* stream);
 int amid_bert_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
                           const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream);
+/* the three backward kernels over the live sequences only (the step's own loss sends no gradient into the other domain's encoder
+ * of a sample, train_sr.py:205-211): row_domain [B] = the batch's domain ids, M = B * T, rows_per_tile a multiple of T (tiles hold
+ * whole sequences); a tile without a live sequence does no work (qkv: writes zero dx rows; the LayerNorm-partial slots read 0) */
+int amid_bert_ffn2_bwd_rows_f32(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain, int B,
+                                int T, void* stream);
+int amid_bert_ffn1_bwd_rows_f32(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                                const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
+                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const long long* row_domain, int B, int T,
+                                void* stream);
+int amid_bert_qkv_bwd_rows_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const long long* row_domain,
+                               int B, int T, void* stream);
 /* n_ent (<= 12) weight-gradient tiles of 128 x 128 as split partials: w_part [2][n_ent][splits][128*128], b_part [2][n_ent][splits][128];
  * tile e lands in w_part[domain][out_group[e]][split] at column out_col[e] with row stride out_ld[e] (standalone tile: 128, e, 0; the
  * out_ld/128 tiles of one [128, out_ld] matrix share out_group so its partials are one contiguous [splits][128*out_ld] block) */
@@ -642,6 +655,55 @@ int amid_sas_qkv_ffn_bwd_f32_rt4(const float* dq, const float* dk, const float* 
 int amid_bert_wgrad_rows_f32(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
                              const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part, float* b_part,
                              const long long* row_domain, int B, int T, void* stream);
+
+
+/* the 64-row build of the BERT4Rec row-tile entry points (_rt4) and the *_rows entry points in every build */
+int amid_bert_qkv_fwd_f32_rt4(const float* x, const float* const* ln_a, const float* const* ln_b, const float* const* w3x2,
+                          const float* const* b3x2, int M, int rows_per_tile, float* y, float* q, float* k, float* v, void* stream);
+int amid_bert_oproj_fwd_f32_rt4(const float* o, const float* x, const float* const* w, const float* const* b, int M, int rows_per_tile, int layer,
+                            const void* step_state, int train, float p_drop, float* x1, void* stream);
+int amid_bert_ffn1_fwd_f32_rt4(const float* x1, const float* const* ln_a, const float* const* ln_b, const float* const* w1, const float* const* b1,
+                           int M, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* y2, float* pre,
+                           float* h, void* stream);
+int amid_bert_ffn2_fwd_f32_rt4(const float* h, const float* x1, const float* const* w2, const float* const* b2, int M, int rows_per_tile, int layer,
+                           const void* step_state, int train, float p_drop, float* x2, void* stream);
+int amid_bert_ffn2_bwd_f32_rt4(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                           const void* step_state, int train, float p_drop, float* dz, float* dpre, void* stream);
+int amid_bert_ffn1_bwd_f32_rt4(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                           const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train, float p_drop,
+                           float* dx1, float* dt, float* d_o, float* ln_part, void* stream);
+int amid_bert_qkv_bwd_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                          const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream);
+int amid_bert_ffn2_bwd_rows_f32_rt4(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain, int B,
+                                int T, void* stream);
+int amid_bert_ffn1_bwd_rows_f32_rt4(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                                const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
+                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const long long* row_domain, int B, int T,
+                                void* stream);
+int amid_bert_qkv_bwd_rows_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const long long* row_domain,
+                               int B, int T, void* stream);
+int amid_bert_ffn2_bwd_rows_f32_rt3(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain, int B,
+                                int T, void* stream);
+int amid_bert_ffn1_bwd_rows_f32_rt3(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                                const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
+                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const long long* row_domain, int B, int T,
+                                void* stream);
+int amid_bert_qkv_bwd_rows_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const long long* row_domain,
+                               int B, int T, void* stream);
+int amid_bert_ffn2_bwd_rows_f32_rt5(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain, int B,
+                                int T, void* stream);
+int amid_bert_ffn1_bwd_rows_f32_rt5(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                                const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
+                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const long long* row_domain, int B, int T,
+                                void* stream);
+int amid_bert_qkv_bwd_rows_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const long long* row_domain,
+                               int B, int T, void* stream);
 
 #ifdef __cplusplus
 }
