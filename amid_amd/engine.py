@@ -1206,6 +1206,7 @@ class SasrecEngine:
         L, be = lib(), exchange.backend
         self.sync()
         step0 = self.step
+        be.gather_buffer(exchange.world, umax, dense=self.dense.grad)   # capacity errors are raised here, not in the middle of a stream capture
         be.prepare_dense(exchange.world, umax, self.dense.grad)      # device tables are built here, not under capture
         graphs = []
         for part in (0, 1):
