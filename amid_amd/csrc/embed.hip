@@ -147,10 +147,9 @@ __global__ void pack_indices_pool_kernel(const long long* __restrict__ pool, lon
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicInc(&st->ticket, gridDim.x - 1) == gridDim.x - 1) st->step = t_pre + 1;
-    }
+    // (no __threadfence: the only access that must precede the ticket is this block's READ of the step, and its value has been
+    // consumed -- it addresses every load above; a fence per block writes the L2 back and was most of this launch's time)
+    if (threadIdx.x == 0 && atomicInc(&st->ticket, gridDim.x - 1) == gridDim.x - 1) st->step = t_pre + 1;
 }
 
 // ---------------------------------------------------------------------------------------------
