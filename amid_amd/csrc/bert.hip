@@ -21,23 +21,64 @@ constexpr float BERT_EPS = 1e-6f;
 
 struct BGeom {
     int M; int rows_per_tile; int tiles_per_group;
-    // optional hint of the backward kernels (the *_rows entry points): rows_per_tile is a multiple of T, so a tile holds whole
-    // sequences; of domain g only the sequences b with (row_domain[b] != 0) == g carry a gradient (the step's own loss masks the
-    // other domain of every sample, train_sr.py:205-211) -- a tile without such a sequence does no work (bdead)
-    const long long* row_domain; int T;
+    // optional hint of the backward kernels (the *_rows entry points): live = the batch's live-sequence list (amid_live_list_i32:
+    // domain 0's batch rows, then domain 1's, then n0).  Of domain g only its live sequences carry a gradient (the step's own loss
+    // masks the other domain of every sample, train_sr.py:205-211): tiles then hold rows_per_tile / T WHOLE live sequences, back
+    // to back, wherever they sit in the batch -- half the tiles, and these kernels are bound by the weights every tile streams.
+    // The launch keeps 2 * tiles_per_group workgroups (tiles_per_group = the worst case, every sample in one domain): the first
+    // tiles0 + tiles1 are live, the rest only zero the LayerNorm-partial slot they would have filled.
+    const int* live; int B, T;
 };
-__device__ __forceinline__ bool bdead(const BGeom& tg, int g, int local0, int nrows) {
-    if (tg.row_domain == nullptr) return false;
-    for (int b = local0 / tg.T, b1 = (local0 + nrows - 1) / tg.T; b <= b1; ++b)
-        if ((tg.row_domain[b] != 0 ? 1 : 0) == g) return false;
-    return true;
-}
 __device__ __forceinline__ void btile(const BGeom& tg, int tile, int& g, long long& row0, int& nrows, int& local0) {
     g = tile / tg.tiles_per_group;
     const int tl = tile - g * tg.tiles_per_group;
     local0 = tl * tg.rows_per_tile;
     nrows = min(tg.rows_per_tile, tg.M - local0);
     row0 = (long long)g * tg.M + local0;
+}
+
+// the backward kernels' view of a tile: row r of the tile <-> row lrow(r) of domain g (dropout counters) / grow(r) of the buffers
+struct BTile {
+    int g, nrows, slot, local0;
+    long long base;                    // g * M
+    const int* rmap;                   // live list: LDS table tile row -> row of the domain; nullptr: local0 + r
+    bool is_live;
+    __device__ __forceinline__ int lrow(int r) const { return rmap ? rmap[r] : local0 + r; }
+    __device__ __forceinline__ long long grow(int r) const { return base + lrow(r); }
+};
+__device__ __forceinline__ BTile btile_bwd(const BGeom& tg, int tile, int* __restrict__ rmap) {
+    BTile t;
+    t.rmap = nullptr; t.is_live = true;
+    if (tg.live == nullptr) {
+        long long row0;
+        btile(tg, tile, t.g, row0, t.nrows, t.local0);
+        t.base = (long long)t.g * tg.M;
+        t.slot = tile;
+        return t;
+    }
+    const int B = tg.B, T = tg.T, k = tg.rows_per_tile / T, tpg = tg.tiles_per_group;
+    const int n0 = tg.live[B];
+    const int tiles0 = (n0 + k - 1) / k, tiles1 = (B - n0 + k - 1) / k;
+    int g, tl;
+    if (tile < tiles0) { g = 0; tl = tile; }
+    else if (tile < tiles0 + tiles1) { g = 1; tl = tile - tiles0; }
+    else {                                                           // a slot no live tile fills
+        t.is_live = false;
+        const int d = tile - tiles0 - tiles1;
+        if (d < tpg - tiles0) { g = 0; tl = tiles0 + d; } else { g = 1; tl = tiles1 + d - (tpg - tiles0); }
+    }
+    t.g = g; t.slot = g * tpg + tl; t.base = (long long)g * tg.M; t.local0 = 0; t.nrows = 0;
+    if (!t.is_live) return t;
+    const int ng = g == 0 ? n0 : B - n0, s0 = g == 0 ? 0 : n0;
+    const int nseq = min(k, ng - tl * k);
+    t.nrows = nseq * T;
+    for (int r = threadIdx.x; r < t.nrows; r += blockDim.x) {
+        const int sq = r / T;
+        rmap[r] = tg.live[s0 + tl * k + sq] * T + (r - sq * T);
+    }
+    __syncthreads();
+    t.rmap = rmap;
+    return t;
 }
 
 struct DropCfg { const StepState* st; int train; unsigned spec; float scale; int layer; };
@@ -290,28 +331,30 @@ struct BFfn2BwdArgs {
 };
 __global__ __launch_bounds__(GEMM_THREADS) void bert_ffn2_bwd_kernel(const BFfn2BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int rmap_s[TILE_ROWS];
     using RP = RowPass<BD>;
     float* As = smem;
     float* Ws = smem + TileCfg<BD>::A_FLOATS;
-    int g, nrows, local0; long long row0;
-    btile(a.tg, blockIdx.x, g, row0, nrows, local0);
-    if (bdead(a.tg, g, local0, nrows)) return;              // dz / dpre of dead sequences are read by nobody (the consumers take the same hint)
+    const BTile tr = btile_bwd(a.tg, blockIdx.x, rmap_s);
+    if (!tr.is_live) return;                                // dz / dpre of dead sequences are read by nobody (the consumers take the same hint)
+    const int g = tr.g, nrows = tr.nrows;
+    auto rowf = [&](int r) { return tr.grow(r); };
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
     if (a.dc.train) { seed = a.dc.st->seed; step = (unsigned)a.dc.st->step; }
     TileRegs<BD> dr;
     WRegs<BD, BD> wr;
-    load_tile<BD>(dr, a.dx2, row0, nrows, BD);
+    load_tile_rows<BD>(dr, a.dx2, rowf, nrows, BD);
     load_w<BD, BD>(wr, a.w2T[g], BD);
 #pragma unroll
     for (int i = 0; i < RP::NR; ++i) {
         const int r = RP::first_row() + i * RP::RPP;
         if (r < nrows) {
-            const unsigned long long e0 = (unsigned long long)(local0 + r) * BD + 4 * sub;
+            const unsigned long long e0 = (unsigned long long)tr.lrow(r) * BD + 4 * sub;
             float4 v = bdrop(a.dc, seed, step, g, SITE_BLOCK, e0, dr.v[i]);
             v = bdrop(a.dc, seed, step, g, SITE_SUB_OUT, e0, v);
             dr.v[i] = v;
-            st4(a.dz + (row0 + r) * BD + 4 * sub, v);
+            st4(a.dz + tr.grow(r) * BD + 4 * sub, v);
         }
     }
     tile_to_lds<BD>(As, dr);
@@ -324,9 +367,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_ffn2_bwd_kernel(const BFfn2
         zero_acc<BD>(acc);
         mma_tile<BD, BD>(As, Ws, acc);
         acc_visit(acc, nrows, [&](int r, int n, float4 c) {
-            const long long off = (row0 + r) * BF + s * BD + n;
+            const long long off = tr.grow(r) * BF + s * BD + n;
             const float4 p = ld4(a.pre + off);
-            float4 d = bdrop(a.dc, seed, step, g, SITE_FFN1, (unsigned long long)(local0 + r) * BF + s * BD + n, c);
+            float4 d = bdrop(a.dc, seed, step, g, SITE_FFN1, (unsigned long long)tr.lrow(r) * BF + s * BD + n, c);
             d = make_float4(d.x * gelu_df(p.x), d.y * gelu_df(p.y), d.z * gelu_df(p.z), d.w * gelu_df(p.w));
             st4(a.dpre + off, d);
         });
@@ -350,18 +393,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_ffn1_bwd_kernel(const BFfn1
     float* As = smem;
     float* Ws = smem + TileCfg<BD>::A_FLOATS;
     float* Cs = Ws;
-    int g, nrows, local0; long long row0;
-    btile(a.tg, blockIdx.x, g, row0, nrows, local0);
-    if (bdead(a.tg, g, local0, nrows)) {                    // only the tile's LayerNorm-partial slot is read (by the fixed-order reduce)
-        for (int i = threadIdx.x; i < 2 * BD; i += GEMM_THREADS) a.ln_part[(long long)blockIdx.x * 2 * BD + i] = 0.f;
+    __shared__ int rmap_s[TILE_ROWS];
+    const BTile tr = btile_bwd(a.tg, blockIdx.x, rmap_s);
+    if (!tr.is_live) {                                      // only the LayerNorm-partial slot it would have filled is read (fixed-order reduce)
+        for (int i = threadIdx.x; i < 2 * BD; i += GEMM_THREADS) a.ln_part[(long long)tr.slot * 2 * BD + i] = 0.f;
         return;
     }
+    const int g = tr.g, nrows = tr.nrows;
+    auto rowf = [&](int r) { return tr.grow(r); };
     const int sub = RP::sub();
     unsigned long long seed = 0; unsigned step = 0;
     if (a.dc.train) { seed = a.dc.st->seed; step = (unsigned)a.dc.st->step; }
     TileRegs<BD> ar, xr, dxr;
     WRegs<BD, BD> wr;
-    load_tile<BD>(ar, a.dpre, row0, nrows, BF);
+    load_tile_rows<BD>(ar, a.dpre, rowf, nrows, BF);
     load_w<BD, BD>(wr, a.w1T[g], BF);
     f32x4 acc[WaveMap<BD>::ACC];
     zero_acc<BD>(acc);
@@ -372,15 +417,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_ffn1_bwd_kernel(const BFfn1
         w_to_lds<BD, BD>(Ws, wr);
         __syncthreads();
         if (kc + 1 < BF / BD) {
-            load_tile<BD>(ar, a.dpre + (kc + 1) * BD, row0, nrows, BF);
+            load_tile_rows<BD>(ar, a.dpre + (kc + 1) * BD, rowf, nrows, BF);
             load_w<BD, BD>(wr, a.w1T[g] + (kc + 1) * BD, BF);
         } else {
             load_w<BD, BD>(wr, a.woT[g], BD);              // next weights fly under the last chunk
         }
         mma_tile<BD, BD>(As, Ws, acc);
     }
-    load_tile<BD>(xr, a.x1, row0, nrows, BD);              // epilogue inputs (kept out of the MFMA loop: register budget)
-    load_tile<BD>(dxr, a.dx2, row0, nrows, BD);
+    load_tile_rows<BD>(xr, a.x1, rowf, nrows, BD);              // epilogue inputs (kept out of the MFMA loop: register budget)
+    load_tile_rows<BD>(dxr, a.dx2, rowf, nrows, BD);
     __syncthreads();
     acc_to_lds<BD>(Cs, LDC, acc);
     __syncthreads();
@@ -391,13 +436,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_ffn1_bwd_kernel(const BFfn1
         const int r = RP::first_row() + i * RP::RPP;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < nrows) {
-            const unsigned long long e0 = (unsigned long long)(local0 + r) * BD + 4 * sub;
+            const unsigned long long e0 = (unsigned long long)tr.lrow(r) * BD + 4 * sub;
             const float4 dy2 = ld4(Cs + r * LDC + 4 * sub);
             const float4 dxb = bdrop(a.dc, seed, step, g, SITE_BLOCK, e0, dxr.v[i]);      // residual path of x1 -> x2
             const float4 dx1 = f4add(lnb_bwd(dy2, xr.v[i], gam, dgam, dbet), dxb);
-            st4(a.dx1 + (row0 + r) * BD + 4 * sub, dx1);
+            st4(a.dx1 + tr.grow(r) * BD + 4 * sub, dx1);
             t = bdrop(a.dc, seed, step, g, SITE_SUB_IN, e0, dx1);
-            st4(a.dt + (row0 + r) * BD + 4 * sub, t);
+            st4(a.dt + tr.grow(r) * BD + 4 * sub, t);
         }
         st4(As + r * LDK + 4 * sub, t);
     }
@@ -406,9 +451,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_ffn1_bwd_kernel(const BFfn1
     __syncthreads();
     zero_acc<BD>(acc);
     mma_tile<BD, BD>(As, Ws, acc);
-    acc_to_global<BD>(a.d_o, row0, nrows, BD, nullptr, acc);
+    acc_to_global_rows<BD>(a.d_o, rowf, nrows, BD, nullptr, acc);
     __syncthreads();
-    ln_part_out<BD>(As, dgam, dbet, a.ln_part + (long long)blockIdx.x * 2 * BD);
+    ln_part_out<BD>(As, dgam, dbet, a.ln_part + (long long)tr.slot * 2 * BD);
 }
 
 struct BQkvBwdArgs {
@@ -423,18 +468,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_qkv_bwd_kernel(const BQkvBw
     float* As = smem;
     float* Ws = smem + TileCfg<BD>::A_FLOATS;
     float* Cs = Ws;
-    int g, nrows, local0; long long row0;
-    btile(a.tg, blockIdx.x, g, row0, nrows, local0);
-    if (bdead(a.tg, g, local0, nrows)) {                    // dx feeds the embedding gradient of every position (layer 0): exact zeros
-        for (int i = threadIdx.x; i < 2 * BD; i += GEMM_THREADS) a.ln_part[(long long)blockIdx.x * 2 * BD + i] = 0.f;
-        for (int i = threadIdx.x; i < nrows * (BD / 4); i += GEMM_THREADS) st4(a.dx + row0 * BD + 4 * (long long)i, make_float4(0.f, 0.f, 0.f, 0.f));
+    __shared__ int rmap_s[TILE_ROWS];
+    const BTile tr = btile_bwd(a.tg, blockIdx.x, rmap_s);
+    if (!tr.is_live) {
+        for (int i = threadIdx.x; i < 2 * BD; i += GEMM_THREADS) a.ln_part[(long long)tr.slot * 2 * BD + i] = 0.f;
         return;
+    }
+    const int g = tr.g, nrows = tr.nrows;
+    auto rowf = [&](int r) { return tr.grow(r); };
+    if (tr.rmap != nullptr) {
+        // dx feeds the embedding gradient of EVERY position (layer 0): sample b is live in domain g and dead in the other one --
+        // this tile writes the exact zeros of its sequences' counterparts (same local rows, the other domain's half)
+        const long long other = (long long)(1 - g) * a.tg.M;
+        for (int i = threadIdx.x; i < nrows * (BD / 4); i += GEMM_THREADS)
+            st4(a.dx + (other + tr.lrow(i / (BD / 4))) * BD + 4 * (i % (BD / 4)), make_float4(0.f, 0.f, 0.f, 0.f));
     }
     const int sub = RP::sub();
     const float* src[3] = {a.dq, a.dk, a.dv};
     TileRegs<BD> ar, xr, rr;
     WRegs<BD, BD> wr;
-    load_tile<BD>(ar, src[0], row0, nrows, BD);
+    load_tile_rows<BD>(ar, src[0], rowf, nrows, BD);
     load_w<BD, BD>(wr, a.wT[0][g], BD);
     f32x4 acc[WaveMap<BD>::ACC];
     zero_acc<BD>(acc);
@@ -445,13 +498,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_qkv_bwd_kernel(const BQkvBw
         w_to_lds<BD, BD>(Ws, wr);
         __syncthreads();
         if (s < 2) {
-            load_tile<BD>(ar, src[s + 1], row0, nrows, BD);
+            load_tile_rows<BD>(ar, src[s + 1], rowf, nrows, BD);
             load_w<BD, BD>(wr, a.wT[s + 1][g], BD);
         }
         mma_tile<BD, BD>(As, Ws, acc);
     }
-    load_tile<BD>(xr, a.x, row0, nrows, BD);
-    load_tile<BD>(rr, a.dx1, row0, nrows, BD);
+    load_tile_rows<BD>(xr, a.x, rowf, nrows, BD);
+    load_tile_rows<BD>(rr, a.dx1, rowf, nrows, BD);
     __syncthreads();
     acc_to_lds<BD>(Cs, LDC, acc);
     __syncthreads();
@@ -462,11 +515,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_qkv_bwd_kernel(const BQkvBw
         const int r = RP::first_row() + i * RP::RPP;
         if (r < nrows) {
             const float4 dy = ld4(Cs + r * LDC + 4 * sub);
-            st4(a.dx + (row0 + r) * BD + 4 * sub, f4add(lnb_bwd(dy, xr.v[i], gam, dgam, dbet), rr.v[i]));
+            st4(a.dx + tr.grow(r) * BD + 4 * sub, f4add(lnb_bwd(dy, xr.v[i], gam, dgam, dbet), rr.v[i]));
         }
     }
     __syncthreads();
-    ln_part_out<BD>(As, dgam, dbet, a.ln_part + (long long)blockIdx.x * 2 * BD);
+    ln_part_out<BD>(As, dgam, dbet, a.ln_part + (long long)tr.slot * 2 * BD);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients
@@ -624,13 +677,14 @@ __global__ __launch_bounds__(256) void transpose_rect_kernel(const BTransArgs a)
 using namespace amid;
 
 static constexpr size_t bert_lds() { return (size_t)(TileCfg<BD>::A_FLOATS + TileCfg<BD>::W_FLOATS) * sizeof(float); }
-static int bgeom(int M, int rpt, BGeom* tg, const long long* row_domain = nullptr, int B = 0, int T = 0) {
+static int bgeom(int M, int rpt, BGeom* tg, const int* live = nullptr, int B = 0, int T = 0) {
     if (M <= 0 || rpt <= 0 || rpt > TILE_ROWS) return AMID_ERR_ARG;
     tg->M = M; tg->rows_per_tile = rpt; tg->tiles_per_group = (M + rpt - 1) / rpt;
-    tg->row_domain = nullptr; tg->T = 0;
-    if (row_domain) {                          // whole sequences per tile
+    tg->live = nullptr; tg->B = 0; tg->T = 0;
+    if (live) {                                // whole live sequences per tile; worst case: every sample in one domain
         if (B <= 0 || T <= 0 || (long long)B * T != M || rpt % T != 0) return AMID_ERR_ARG;
-        tg->row_domain = row_domain; tg->T = T;
+        tg->live = live; tg->B = B; tg->T = T;
+        tg->tiles_per_group = (B + rpt / T - 1) / (rpt / T);
     }
     return AMID_OK;
 }
@@ -702,13 +756,13 @@ extern "C" int AMID_ENTRY(amid_bert_ffn2_fwd_f32)(const float* h, const float* x
 }
 
 static int bert_ffn2_bwd(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                         const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain, int B, int T,
+                         const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live, int B, int T,
                          void* stream) {
     AMID_CHECK_ARG(dx2 && pre && w2T && dz && dpre && (!train || step_state));
     BFfn2BwdArgs a;
     a.dx2 = dx2; a.pre = pre; a.dz = dz; a.dpre = dpre; a.dc = bdropcfg(step_state, train, p_drop, layer);
     for (int g = 0; g < 2; ++g) a.w2T[g] = w2T[g];
-    if (int e = bgeom(M, rows_per_tile, &a.tg, row_domain, B, T)) return e;
+    if (int e = bgeom(M, rows_per_tile, &a.tg, live, B, T)) return e;
     BERT_LAUNCH(bert_ffn2_bwd_kernel, a);
     return AMID_OK;
 }
@@ -716,25 +770,25 @@ extern "C" int AMID_ENTRY(amid_bert_ffn2_bwd_f32)(const float* dx2, const float*
                                       const void* step_state, int train, float p_drop, float* dz, float* dpre, void* stream) {
     return bert_ffn2_bwd(dx2, pre, w2T, M, rows_per_tile, layer, step_state, train, p_drop, dz, dpre, nullptr, 0, 0, stream);
 }
-// the three backward kernels over the live sequences only: row_domain [B] = the batch's domain ids, M = B * T, rows_per_tile a
-// multiple of T (tiles hold whole sequences); tiles without a live sequence do no work (see BGeom)
+// the three backward kernels over the live sequences only: live = amid_live_list_i32's list of the batch, M = B * T, rows_per_tile a
+// multiple of T (a tile holds rows_per_tile / T whole live sequences, gathered from wherever they sit; see BGeom)
 extern "C" int AMID_ENTRY(amid_bert_ffn2_bwd_rows_f32)(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                      const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain,
+                                      const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live,
                                       int B, int T, void* stream) {
-    AMID_CHECK_ARG(row_domain != nullptr);
-    return bert_ffn2_bwd(dx2, pre, w2T, M, rows_per_tile, layer, step_state, train, p_drop, dz, dpre, row_domain, B, T, stream);
+    AMID_CHECK_ARG(live != nullptr);
+    return bert_ffn2_bwd(dx2, pre, w2T, M, rows_per_tile, layer, step_state, train, p_drop, dz, dpre, live, B, T, stream);
 }
 
 static int bert_ffn1_bwd(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
                          const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                         float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const long long* row_domain, int B, int T,
+                         float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const int* live, int B, int T,
                          void* stream) {
     AMID_CHECK_ARG(dpre && dx2 && x1 && ln_a && w1T && woT && dx1 && dt && d_o && ln_part && (!train || step_state));
     BFfn1BwdArgs a;
     a.dpre = dpre; a.dx2 = dx2; a.x1 = x1; a.dx1 = dx1; a.dt = dt; a.d_o = d_o; a.ln_part = ln_part;
     a.dc = bdropcfg(step_state, train, p_drop, layer);
     for (int g = 0; g < 2; ++g) { a.la[g] = ln_a[g]; a.w1T[g] = w1T[g]; a.woT[g] = woT[g]; }
-    if (int e = bgeom(M, rows_per_tile, &a.tg, row_domain, B, T)) return e;
+    if (int e = bgeom(M, rows_per_tile, &a.tg, live, B, T)) return e;
     BERT_LAUNCH(bert_ffn1_bwd_kernel, a);
     return AMID_OK;
 }
@@ -746,19 +800,19 @@ extern "C" int AMID_ENTRY(amid_bert_ffn1_bwd_f32)(const float* dpre, const float
 extern "C" int AMID_ENTRY(amid_bert_ffn1_bwd_rows_f32)(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a,
                                       const float* const* w1T, const float* const* woT, int M, int rows_per_tile, int layer,
                                       const void* step_state, int train, float p_drop, float* dx1, float* dt, float* d_o, float* ln_part,
-                                      const long long* row_domain, int B, int T, void* stream) {
-    AMID_CHECK_ARG(row_domain != nullptr);
-    return bert_ffn1_bwd(dpre, dx2, x1, ln_a, w1T, woT, M, rows_per_tile, layer, step_state, train, p_drop, dx1, dt, d_o, ln_part, row_domain, B, T, stream);
+                                      const int* live, int B, int T, void* stream) {
+    AMID_CHECK_ARG(live != nullptr);
+    return bert_ffn1_bwd(dpre, dx2, x1, ln_a, w1T, woT, M, rows_per_tile, layer, step_state, train, p_drop, dx1, dt, d_o, ln_part, live, B, T, stream);
 }
 
 static int bert_qkv_bwd(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                        const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const long long* row_domain, int B,
+                        const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const int* live, int B,
                         int T, void* stream) {
     AMID_CHECK_ARG(dq && dk && dv && dx1 && x && ln_a && wT3x2 && dx && ln_part);
     BQkvBwdArgs a;
     a.dq = dq; a.dk = dk; a.dv = dv; a.dx1 = dx1; a.x = x; a.dx = dx; a.ln_part = ln_part;
     for (int g = 0; g < 2; ++g) { a.la[g] = ln_a[g]; for (int j = 0; j < 3; ++j) a.wT[j][g] = wT3x2[j * 2 + g]; }
-    if (int e = bgeom(M, rows_per_tile, &a.tg, row_domain, B, T)) return e;
+    if (int e = bgeom(M, rows_per_tile, &a.tg, live, B, T)) return e;
     BERT_LAUNCH(bert_qkv_bwd_kernel, a);
     return AMID_OK;
 }
@@ -768,9 +822,9 @@ extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_f32)(const float* dq, const float* d
 }
 extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_rows_f32)(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x,
                                      const float* const* ln_a, const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part,
-                                     const long long* row_domain, int B, int T, void* stream) {
-    AMID_CHECK_ARG(row_domain != nullptr);
-    return bert_qkv_bwd(dq, dk, dv, dx1, x, ln_a, wT3x2, M, rows_per_tile, dx, ln_part, row_domain, B, T, stream);
+                                     const int* live, int B, int T, void* stream) {
+    AMID_CHECK_ARG(live != nullptr);
+    return bert_qkv_bwd(dq, dk, dv, dx1, x, ln_a, wT3x2, M, rows_per_tile, dx, ln_part, live, B, T, stream);
 }
 
 // n_ent (<= 12) output tiles of 128 x 128; dy / x: host arrays of n_ent device pointers (column offsets folded in), ld*: row strides.

@@ -70,24 +70,19 @@ class BertPlan(SasrecPlan):
 
     def _alloc_model_bwd(self, eng, f) -> None:
         M, D, F = self.shape.M, eng.D, BERT_FF
-        # The three backward row-tile kernels tile WHOLE sequences (rows_per_tile = k * T) so that, in a train step, tiles without a
-        # live sequence do no work (bert.hip BGeom::row_domain: the loss sends no gradient into the other domain's encoder of a
-        # sample).  (k, build) minimise the MFMA rows spent per live sequence: a tile of k sequences is live with probability
-        # 1 - 2^-k and serves k / 2 live sequences on average.  T = 50: one sequence on the 64-row build; T = 20: two on the 48-row one.
+        # In a train step the three backward row-tile kernels walk the LIVE sequences only (bert.hip BGeom::live: the loss sends no
+        # gradient into the other domain's encoder of a sample): a tile gathers rows_per_tile / T whole live sequences of one domain.
+        # These kernels are bound by the 256 KB of weights every tile streams, so the fullest tile wins: the 112-row build with
+        # 112 // T sequences (T = 50: 2, T = 20: 5) -- half as many tiles as over all rows.
         T = self.shape.Tenc
-        best = None
-        for cap, suf in ((48, "_rt3"), (64, "_rt4"), (80, "_rt5"), (112, "")):
-            k = cap // T
-            if k >= 1 and eng.SHORT_TILE_BUILDS and eng.LIVE_TILES_BWD:
-                cost = cap * (1.0 - 0.5 ** k) / (0.5 * k)
-                if best is None or cost < best[0]:
-                    best = (cost, k * T, suf)
-        if best is not None:
-            self.rpt_b, self.rt_suffix_b = best[1], best[2]
+        k = 112 // T
+        self.live_tiles = bool(eng.LIVE_TILES_BWD and k >= 1)
+        if self.live_tiles:
+            self.rpt_b, self.rt_suffix_b = k * T, ""
+            self.tpg_b = (self.shape.B + k - 1) // k               # worst case: every sample in one domain
         else:
             self.rpt_b, self.rt_suffix_b = self.rpt, self.rt_suffix
-        self.live_tiles = best is not None
-        self.tpg_b = (M + self.rpt_b - 1) // self.rpt_b
+            self.tpg_b = (M + self.rpt_b - 1) // self.rpt_b
         self.ln1_part = [f(2 * self.tpg_b, 2, D) for _ in range(2)]       # one slot per backward tile
         self.ln2_part = [f(2 * self.tpg_b, 2, D) for _ in range(2)]
         self.dz, self.dt, self.dx1 = f(2 * M, D), f(2 * M, D), f(2 * M, D)
@@ -131,10 +126,12 @@ class Bert4recEngine(SasrecEngine):
     SHORT_TILE_BUILDS = True
     STRIP_KERNELS = False        # its encoder launches are bert.hip's row-tile kernels
     SORT_FORK = "catchup"        # the side-stream sort runs beside the forward (no launch of this encoder fills every CU)
-    # the backward row-tile kernels can tile whole sequences and skip the tiles without a live one (BertPlan).  Off: these kernels
-    # are bound by the 256 KB of weights every tile streams through LDS, not by its rows -- at cfg 2 the 256 live 50-row tiles of
-    # the 64-row build take as long as the 256 tiles of 100 rows they replace (ffn2_bwd 75 vs 71 us).  Gathering two live
-    # sequences into one 112-row tile (a row map as in sasrec_bwd.hip) is what would halve them.
+    # The train step's backward row-tile kernels can walk tiles of LIVE sequences only (BertPlan._alloc_model_bwd, bert.hip
+    # BGeom::live: half the tiles).  Off: measured at cfg 2, 128 gathered 100-row tiles take as long as the 256 tiles over every
+    # row (ffn2_bwd 67.8 vs 71.5 us, ffn1_bwd 57.6 vs 60.9, qkv_bwd 40.3 vs 41.4) -- either way the launch is ONE round of
+    # workgroups and lasts as long as a single tile's chain of weight slabs (global -> registers -> LDS -> barrier per 128 x 128
+    # slab); at cfg 4 the 100-row tiles lose to the 48-row build's shorter chains (0.74 vs 0.60 ms per step).  What would speed
+    # these kernels up is the strip kernels' LDS-DMA weight ring (csrc/strip_gemm.h), not fewer rows.
     LIVE_TILES_BWD = False
 
     def __init__(self, *args, comp: str = "", comp_bs: int = 0, comp_threshold: float = 0.5, **kw):
@@ -259,11 +256,15 @@ class Bert4recEngine(SasrecEngine):
                fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(),
                pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, T, NI, D, self.hid, 0.0, pl.dxbuf.data_ptr(), ditems, None,
                pl.sc_part.data_ptr(), None, None, 0, s)
+        # the train step's own backward: tiles of live sequences (BertPlan._alloc_model_bwd); a backward driven by someone else's
+        # loss (the autograd path) walks every row, in tiles of the same height
+        live_tiles = pl.live_tiles and self._own_rows(pl) is not None
+        if live_tiles:
+            L.call("amid_live_list_i32", pl.domain.data_ptr(), B, pl.live.data_ptr(), s)
         for l in (1, 0):
             pre = f"transform{{d}}.{l}"
             wsq = lambda j: ptr_array([self.wT_sq[l, g, j].data_ptr() for g in (0, 1)])      # noqa: E731
-            own = self._own_rows(pl) if pl.live_tiles else None          # the batch's domain ids: tiles without a live sequence do no work
-            rows, hint = ("_rows", (own, B, T)) if own is not None else ("", ())
+            rows, hint = ("_rows", (pl.live.data_ptr(), B, T)) if live_tiles else ("", ())
             L.call("amid_bert_ffn2_bwd" + rows + "_f32" + pl.rt_suffix_b, pl.dxbuf.data_ptr(), pl.pre[l].data_ptr(),
                    ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]), M, pl.rpt_b, l, st, tr, BERT_P_DROP, pl.dz.data_ptr(), pl.dpre.data_ptr(),
                    *hint, s)

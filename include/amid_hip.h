@@ -316,17 +316,19 @@ int amid_bert_ffn1_bwd_f32(const float* dpre, const float* dx2, const float* x1,
 int amid_bert_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
                           const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream);
 /* the three backward kernels over the live sequences only (the step's own loss sends no gradient into the other domain's encoder
- * of a sample, train_sr.py:205-211): row_domain [B] = the batch's domain ids, M = B * T, rows_per_tile a multiple of T (tiles hold
- * whole sequences); a tile without a live sequence does no work (qkv: writes zero dx rows; the LayerNorm-partial slots read 0) */
+ * of a sample, train_sr.py:205-211): live = amid_live_list_i32's list of the batch, M = B * T, rows_per_tile a multiple of T -- a
+ * tile holds rows_per_tile / T whole live sequences of one domain, gathered from wherever they sit in the batch (half the tiles;
+ * these kernels are bound by the weights every tile streams).  qkv also writes the exact-zero dx rows of its sequences'
+ * counterparts in the other domain; LayerNorm partials: 2 * ceil(B / (rows_per_tile / T)) slots. */
 int amid_bert_ffn2_bwd_rows_f32(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain, int B,
+                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live, int B,
                                 int T, void* stream);
 int amid_bert_ffn1_bwd_rows_f32(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
                                 const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const long long* row_domain, int B, int T,
+                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const int* live, int B, int T,
                                 void* stream);
 int amid_bert_qkv_bwd_rows_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const long long* row_domain,
+                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const int* live,
                                int B, int T, void* stream);
 /* n_ent (<= 12) weight-gradient tiles of 128 x 128 as split partials: w_part [2][n_ent][splits][128*128], b_part [2][n_ent][splits][128];
  * tile e lands in w_part[domain][out_group[e]][split] at column out_col[e] with row stride out_ld[e] (standalone tile: 128, e, 0; the
@@ -675,34 +677,34 @@ int amid_bert_ffn1_bwd_f32_rt4(const float* dpre, const float* dx2, const float*
 int amid_bert_qkv_bwd_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
                           const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream);
 int amid_bert_ffn2_bwd_rows_f32_rt4(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain, int B,
+                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live, int B,
                                 int T, void* stream);
 int amid_bert_ffn1_bwd_rows_f32_rt4(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
                                 const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const long long* row_domain, int B, int T,
+                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const int* live, int B, int T,
                                 void* stream);
 int amid_bert_qkv_bwd_rows_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const long long* row_domain,
+                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const int* live,
                                int B, int T, void* stream);
 int amid_bert_ffn2_bwd_rows_f32_rt3(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain, int B,
+                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live, int B,
                                 int T, void* stream);
 int amid_bert_ffn1_bwd_rows_f32_rt3(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
                                 const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const long long* row_domain, int B, int T,
+                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const int* live, int B, int T,
                                 void* stream);
 int amid_bert_qkv_bwd_rows_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const long long* row_domain,
+                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const int* live,
                                int B, int T, void* stream);
 int amid_bert_ffn2_bwd_rows_f32_rt5(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const long long* row_domain, int B,
+                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live, int B,
                                 int T, void* stream);
 int amid_bert_ffn1_bwd_rows_f32_rt5(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
                                 const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const long long* row_domain, int B, int T,
+                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const int* live, int B, int T,
                                 void* stream);
 int amid_bert_qkv_bwd_rows_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const long long* row_domain,
+                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const int* live,
                                int B, int T, void* stream);
 
 #ifdef __cplusplus
