@@ -15,6 +15,23 @@ __device__ __forceinline__ void reduce_partials_block(const ReduceEntry en, int 
     // entries whose rows are whole, aligned float4s (every weight / bias matrix) move 16 bytes per lane: a wave covers two
     // 512-byte runs instead of two 128-byte ones.  Same partial order per element as the scalar path => the same bits.
     const bool vec = ((en.count | (int)(en.stride & 3)) & 3) == 0 && ((((unsigned long long)en.src) | ((unsigned long long)en.dst)) & 15) == 0;
+    if (vec && en.n_part <= 32) {
+        // few partials (weight-gradient splits, tile partials of a short batch): a thread owns one float4 and adds the partials in
+        // order, every load in flight at once -- 1024 elements per block pass, no LDS, no barrier
+        for (int e = (bx * 256 + (int)threadIdx.x) * 4; e < en.count; e += nbx * 1024) {
+            const float* __restrict__ p = en.src + e;
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k0 = 0; k0 < en.n_part; k0 += 8) {      // eight loads in flight, added in partial order
+                float4 r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (k0 + j < en.n_part) ? ld4(p + (long long)(k0 + j) * en.stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s4 = f4add(s4, r[j]);
+            }
+            st4(en.dst + e, s4);
+        }
+        return;
+    }
     if (vec) {
         for (int e0 = bx * 128; e0 < en.count; e0 += nbx * 128) {     // block-uniform
             const int e = e0 + 4 * el;

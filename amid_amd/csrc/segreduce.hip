@@ -118,10 +118,18 @@ template <int VEC>
 __global__ __launch_bounds__(256) void grad_tail_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
                                                         const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
                                                         float* __restrict__ partial, int n_seg, const ReduceEntry* __restrict__ entries,
-                                                        int red_bx) {
+                                                        int red_bx, const int* __restrict__ blk_off, int n_entries) {
     if ((int)blockIdx.x < n_seg) { segreduce_chunks_block<VEC>(grad_rows, pos_sorted, seg_of, n, uniq_grad, partial, blockIdx.x); return; }
     const int rb = blockIdx.x - n_seg;
-    reduce_partials_block(entries[rb / red_bx], rb % red_bx, red_bx);
+    if (blk_off == nullptr) { reduce_partials_block(entries[rb / red_bx], rb % red_bx, red_bx); return; }
+    // blk_off [n_entries + 1]: entry e owns the blocks [blk_off[e], blk_off[e + 1]) -- as many as its size needs (with one grid
+    // row of red_bx blocks per entry, most blocks of the many short entries -- biases, LayerNorm vectors -- found nothing to do)
+    int lo = 0, hi = n_entries;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blk_off[mid] <= rb) lo = mid; else hi = mid;
+    }
+    reduce_partials_block(entries[lo], rb - blk_off[lo], blk_off[lo + 1] - blk_off[lo]);
 }
 
 // phase B: the chunk in which a border-crossing run STARTS owns its final sum
@@ -257,7 +265,9 @@ extern "C" int amid_embgrad_segreduce_f32(const float* grad_rows, const int* pos
 
 // amid_embgrad_segreduce_f32 and amid_reduce_partials_f32 (sasrec_bwd.hip) with their first phases in ONE launch
 extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
-                                  void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count, void* stream) {
+                                  void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count,
+                                  const int* blk_off, int total_blocks, void* stream) {
+    AMID_CHECK_ARG(blk_off == nullptr || total_blocks > 0);
     AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
                    max_count > 0);
     if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
@@ -268,7 +278,8 @@ extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted,
     float* partial = (float*)workspace;
     const ReduceEntry* en = (const ReduceEntry*)entries_dev;
 #define AMID_TAIL_LAUNCH(VEC)                                                                                                       \
-    grad_tail_kernel<VEC><<<n_seg + bx * n_entries, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial, n_seg, en, bx); \
+    grad_tail_kernel<VEC><<<n_seg + (blk_off ? total_blocks : bx * n_entries), 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, \
+                                                                                           partial, n_seg, en, bx, blk_off, n_entries);     \
     segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad);
     if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }
 #undef AMID_TAIL_LAUNCH
@@ -279,7 +290,8 @@ extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted,
 extern "C" int amid_grad_tail_pack_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
                                        void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count,
                                        const int* uniq_ids, const int* n_uniq, int n_out, int pad_id, int* out_ids, const float* dense_src,
-                                       float* dense_dst, long long dense_n, void* stream) {
+                                       float* dense_dst, long long dense_n, const int* blk_off, int total_blocks, void* stream) {
+    AMID_CHECK_ARG(blk_off == nullptr || total_blocks > 0);
     AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
                    max_count > 0);
     AMID_CHECK_ARG(uniq_ids && n_uniq && out_ids && n_out > 0 && n_out <= n_idx && dense_src && dense_dst && dense_n > 0 &&
@@ -296,7 +308,8 @@ extern "C" int amid_grad_tail_pack_f32(const float* grad_rows, const int* pos_so
     if (cb < 1) cb = 1;
     if (cb > 256) cb = 256;
 #define AMID_TAIL_LAUNCH(VEC)                                                                                                       \
-    grad_tail_kernel<VEC><<<n_seg + bx * n_entries, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial, n_seg, en, bx); \
+    grad_tail_kernel<VEC><<<n_seg + (blk_off ? total_blocks : bx * n_entries), 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, \
+                                                                                           partial, n_seg, en, bx, blk_off, n_entries);     \
     segreduce_spans_pack_kernel<VEC><<<nch + id_blocks + (int)cb, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad, nch, uniq_ids, n_uniq, \
                                                                               n_out, pad_id, out_ids, id_blocks, dense_src, dense_dst, dense_n);
     if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }

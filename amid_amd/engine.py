@@ -322,6 +322,14 @@ class SasrecPlan:
         host = (ctypes.c_ubyte * (esz * len(ent)))()
         for i, (s, d, st, n, c) in enumerate(ent):
             L.call("amid_reduce_entry_pack", ctypes.addressof(host), i, s, d, st, n, c)
+        # blocks per entry for the gradient tail (amid_grad_tail_f32 blk_off): what the entry's size needs -- 1024 elements per block
+        # when it has at most 32 aligned partials (csrc/reduce_partials.h), 128 otherwise
+        off = [0]
+        for s, d, st, n, c in ent:
+            per = 1024 if (n <= 32 and c % 4 == 0 and st % 4 == 0 and s % 16 == 0 and d % 16 == 0) else 128
+            off.append(off[-1] + min(512, (c + per - 1) // per))
+        blk = torch.tensor(off, dtype=torch.int32).to(eng.device)
+        setattr(self, "red_blk_v" if live else "red_blk", (blk, off[-1]))
         return torch.frombuffer(bytearray(host), dtype=torch.uint8).to(eng.device), len(ent), max(c for *_, c in ent)
 
     def _model_reduce_entries(self, eng: "SasrecEngine", add, live: bool = False) -> None:
@@ -1040,6 +1048,7 @@ class SasrecEngine:
             self.ev_idx.record(self.stream)
             self.enqueue_sort(pl)
         self.join_sort()                          # pos_sorted / seg_off come from the side-stream sort
+        blk = (getattr(pl, "red_blk_v", None) if live else None) or pl.red_blk       # per-entry block ranges of the partial sums
         pk = getattr(self, "_tail_pack", None)
         if pk is not None:       # graph A of the data-parallel step: the tail also packs this rank's exchange chunk (ids | rows | dense)
             from .dist import packed_rows
@@ -1048,11 +1057,12 @@ class SasrecEngine:
             L.call("amid_grad_tail_pack_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), self.n_sparse(pl),
                    self.D, pl.seg_ws.data_ptr(), send.data_ptr() + 4 * id_rows * self.D, (pl.red_entries_v if live else pl.red_entries).data_ptr(),
                    pl.red_n_v if live else pl.red_n, pl.red_max_v if live else pl.red_max, pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), umax,
-                   self.n_rows, send.data_ptr(), self.dense.grad.data_ptr(), send.data_ptr() + 4 * rows * self.D, self.dense.numel, s)
+                   self.n_rows, send.data_ptr(), self.dense.grad.data_ptr(), send.data_ptr() + 4 * rows * self.D, self.dense.numel,
+                   blk[0].data_ptr(), blk[1], s)
             return
         L.call("amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), self.n_sparse(pl),
                self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), (pl.red_entries_v if live else pl.red_entries).data_ptr(),
-               pl.red_n_v if live else pl.red_n, pl.red_max_v if live else pl.red_max, s)
+               pl.red_n_v if live else pl.red_n, pl.red_max_v if live else pl.red_max, blk[0].data_ptr(), blk[1], s)
 
     def enqueue_optimizer(self, pl: SasrecPlan, sparse=None) -> None:
         """Dense Adam on the flat buffer + lazy row Adam on (uniq_ids, uniq_grad, n_uniq); `sparse`

@@ -126,14 +126,18 @@ int amid_owner_buckets_f32(const int* uniq_ids, const float* uniq_rows, const in
 /* amid_embgrad_segreduce_f32 + amid_reduce_partials_f32 with their first phases in ONE launch (the two independent ends of backward
  * side by side without a second stream) */
 int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
-                       void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count, void* stream);
+                       void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count, const int* blk_off,
+                       int total_blocks, void* stream);
+/* blk_off (optional, device, [n_entries + 1] ascending from 0; total_blocks = its last value): entry e's sums run on the blocks
+ * [blk_off[e], blk_off[e + 1]) -- sized by the caller to the entry (1024 elements per block when it has at most 32 aligned
+ * partials, 128 otherwise) -- instead of max_count / 128 blocks for every entry. */
 /* amid_grad_tail_f32 that also packs this rank's chunk of the data-parallel exchange in its second launch: uniq_grad points INTO the
  * chunk (the segment reduce writes the rows in place), out_ids[0, n_out) <- the first n_uniq unique ids then pad_id, and
  * dense_dst[0, dense_n) <- dense_src (the flat dense gradient the first launch has just reduced); 16-byte aligned dense pointers. */
 int amid_grad_tail_pack_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
                             void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count, const int* uniq_ids,
                             const int* n_uniq, int n_out, int pad_id, int* out_ids, const float* dense_src, float* dense_dst,
-                            long long dense_n, void* stream);
+                            long long dense_n, const int* blk_off, int total_blocks, void* stream);
 
 /* ---- K4 optimizer ----------------------------------------------------------------------------
  * replaces: torch.optim.Adam(model.parameters(), lr).step(), train_sr.py:480, :215 (dense over the table).
