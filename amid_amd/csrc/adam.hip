@@ -9,6 +9,7 @@
 // unfused), with bias corrections evaluated in double like the Python side does.
 #include "common.h"
 #include "rng.h"
+#include "sort_phases.h"
 
 namespace amid {
 
@@ -160,14 +161,18 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(float* __restrict__
 // it is only needed after backward.
 __global__ __launch_bounds__(256) void lazy_adam_catchup_pos_kernel(float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
                                                                     int* __restrict__ last, const int* __restrict__ idx, int n_idx, int D,
-                                                                    const StepState* __restrict__ stp) {
+                                                                    const StepState* __restrict__ stp, const SortRider rd) {
+    // rider: the first workgroups run a phase of the step's index sort (sort_phases.h) beside the catch-up
+    const int nrb = rider_blocks(rd);
+    if ((int)blockIdx.x < nrb) { sort_phase_ct<1024, 1>(rd.plan, blockIdx.x); return; }
+    const int bid = blockIdx.x - nrb, nbk = gridDim.x - nrb;
     __shared__ AdamCoef tab[COEF_TAB];
     __shared__ int any_lag;
     const StepState st = *stp;
     const long long t = st.step;
     const int sub = threadIdx.x & 31;
     const int q = D >> 2;
-    const int hw0 = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), n_hw = gridDim.x * (blockDim.x >> 5);
+    const int hw0 = bid * (blockDim.x >> 5) + (threadIdx.x >> 5), n_hw = nbk * (blockDim.x >> 5);
     // first sweep: does this block have any lagging row at all? (usually not: skip the coefficient table)
     if (threadIdx.x == 0) any_lag = 0;
     __syncthreads();
@@ -476,15 +481,34 @@ extern "C" int amid_optimizer_step_gathered_f32(float* p, float* m, float* v, fl
     return AMID_OK;
 }
 
-extern "C" int amid_lazy_adam_catchup_positions_f32(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D,
-                                                    const void* step_state, void* stream) {
+static int catchup_positions(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D, const void* step_state,
+                             const void* sort_plan, int sort_phase, void* stream) {
     AMID_CHECK_ARG(table && m && v && last && idx && step_state && D > 0 && (D % 4) == 0 && n_idx > 0);
     // one position per half-wave up to 64 blocks per CU: the kernel is a chain of dependent loads (idx -> stamp -> row), more
     // waves in flight beat fewer, fatter ones (measured: 2048-block cap 24.8 us at cfg 2 / 388 us at cfg 5, 16384: 22.4 / 341)
     long long blocks = ((long long)n_idx + 7) / 8;
     if (blocks > 16384) blocks = 16384;
-    lazy_adam_catchup_pos_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(table, m, v, last, idx, n_idx, D,
-                                                                                     (const StepState*)step_state);
+    SortRider rd;
+    rd.phase = 0;
+    if (sort_plan != nullptr) {
+        if (sort_phase != 1) return AMID_ERR_UNSUPPORTED;          // this launch carries phase 1
+        rd.plan = *(const SortPlan*)sort_plan;
+        rd.phase = sort_phase;
+    }
+    lazy_adam_catchup_pos_kernel<<<(int)blocks + rider_blocks_host(rd), 256, 0, (hipStream_t)stream>>>(table, m, v, last, idx, n_idx, D,
+                                                                                     (const StepState*)step_state, rd);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+
+extern "C" int amid_lazy_adam_catchup_positions_f32(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D,
+                                                    const void* step_state, void* stream) {
+    return catchup_positions(table, m, v, last, idx, n_idx, D, step_state, nullptr, 0, stream);
+}
+
+// the same launch carrying phase `sort_phase` of a sort plan (amid_sort_plan_pack) as extra workgroups
+extern "C" int amid_lazy_adam_catchup_positions_sort_f32(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D,
+                                                         const void* step_state, const void* sort_plan, int sort_phase, void* stream) {
+    AMID_CHECK_ARG(sort_plan != nullptr);
+    return catchup_positions(table, m, v, last, idx, n_idx, D, step_state, sort_plan, sort_phase, stream);
 }

@@ -14,6 +14,7 @@
 // algorithmic read + write) -- many light waves beat few heavy ones here.
 #include "common.h"
 #include "rng.h"
+#include "sort_phases.h"
 
 namespace amid {
 
@@ -275,8 +276,15 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void embed_bwd_kernel(float* __restrict__ dxg, const unsigned char* __restrict__ tmq,
                                                         int B, int T, int D, int nsplit, float* __restrict__ dpos_part,
                                                         const RngState* __restrict__ rng, int train, unsigned thr16, float scale,
-                                                        const long long* __restrict__ row_domain) {
+                                                        const long long* __restrict__ row_domain, const SortRider rd) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [8][D]
+    // rider: with rd.phase set the launch has one more z-slice, whose first rd.plan.nblk workgroups run the last phase of the step's
+    // index sort (sort_phases.h: run heads)
+    if (rd.phase != 0 && (int)blockIdx.z == nsplit) {
+        const int rb = blockIdx.y * gridDim.x + blockIdx.x;
+        if (rb < rd.plan.nblk) sort_phase_ct<1024, 5>(rd.plan, rb);
+        return;
+    }
     const int t = blockIdx.x, g = blockIdx.y, z = blockIdx.z;
     const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;        // 8 row groups
     const int q = D >> 2;
@@ -479,21 +487,29 @@ extern "C" int amid_live_list_i32(const long long* domain, int B, int* live, voi
 }
 
 static int embed_bwd(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part, const void* rng_state,
-                     int train, float p_drop, const long long* row_domain, void* stream) {
+                     int train, float p_drop, const long long* row_domain, const void* sort_plan, int sort_phase, void* stream) {
     AMID_CHECK_ARG(dxg && tmq && dpos_part && B > 0 && T > 0 && D > 0 && (D % 4) == 0 && nsplit > 0 && nsplit <= B);
     AMID_CHECK_ARG(!train || rng_state != nullptr);
     const int tr = (train && p_drop > 0.f) ? 1 : 0;
-    embed_bwd_kernel<<<dim3(T, 2, nsplit), 256, 8 * D * sizeof(float), (hipStream_t)stream>>>(dxg, tmq, B, T, D, nsplit, dpos_part,
+    SortRider rd;
+    rd.phase = 0;
+    if (sort_plan != nullptr) {
+        if (sort_phase != 5) return AMID_ERR_UNSUPPORTED;                  // this launch carries phase 5 (run heads)
+        rd.plan = *(const SortPlan*)sort_plan;
+        rd.phase = 5;
+        if (rd.plan.nblk > 2 * T) return AMID_ERR_UNSUPPORTED;             // the riders sit in one extra z-slice of T x 2 workgroups
+    }
+    embed_bwd_kernel<<<dim3(T, 2, nsplit + (rd.phase ? 1 : 0)), 256, 8 * D * sizeof(float), (hipStream_t)stream>>>(dxg, tmq, B, T, D, nsplit, dpos_part,
                                                                                                (const RngState*)rng_state, tr,
                                                                                                keep_thr16(p_drop),
-                                                                                               tr ? 1.0f / (1.0f - p_drop) : 1.0f, row_domain);
+                                                                                               tr ? 1.0f / (1.0f - p_drop) : 1.0f, row_domain, rd);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
 
 extern "C" int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part,
                                   const void* rng_state, int train, float p_drop, void* stream) {
-    return embed_bwd(dxg, tmq, B, T, D, nsplit, dpos_part, rng_state, train, p_drop, nullptr, stream);
+    return embed_bwd(dxg, tmq, B, T, D, nsplit, dpos_part, rng_state, train, p_drop, nullptr, nullptr, 0, stream);
 }
 
 // behind the *_rows backward kernels (sasrec_bwd.hip): the rows of the sequences (g, b) with (row_domain[b] != 0) != g were never
@@ -501,7 +517,15 @@ extern "C" int amid_embed_bwd_f32(float* dxg, const unsigned char* tmq, int B, i
 extern "C" int amid_embed_bwd_rows_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part,
                                        const void* rng_state, int train, float p_drop, const long long* row_domain, void* stream) {
     AMID_CHECK_ARG(row_domain != nullptr);
-    return embed_bwd(dxg, tmq, B, T, D, nsplit, dpos_part, rng_state, train, p_drop, row_domain, stream);
+    return embed_bwd(dxg, tmq, B, T, D, nsplit, dpos_part, rng_state, train, p_drop, row_domain, nullptr, 0, stream);
+}
+
+// either of the two (row_domain optional) carrying phase 5 of a sort plan (amid_sort_plan_pack: the run heads) as extra workgroups
+extern "C" int amid_embed_bwd_sort_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part,
+                                       const void* rng_state, int train, float p_drop, const long long* row_domain, const void* sort_plan,
+                                       int sort_phase, void* stream) {
+    AMID_CHECK_ARG(sort_plan != nullptr);
+    return embed_bwd(dxg, tmq, B, T, D, nsplit, dpos_part, rng_state, train, p_drop, row_domain, sort_plan, sort_phase, stream);
 }
 
 extern "C" int amid_key_keep_tiled_u8(const long long* seq, int B, int T, int reps, unsigned char* keep, void* stream) {

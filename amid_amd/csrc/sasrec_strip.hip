@@ -16,6 +16,7 @@
 #include "common.h"
 #include "rng.h"
 #include "strip_gemm.h"
+#include "sort_phases.h"
 
 namespace amid {
 
@@ -393,12 +394,19 @@ __device__ __forceinline__ void zero_slot(float* __restrict__ part, int slot) {
     for (int e = threadIdx.x; e < 2 * D; e += STRIP_THREADS) part[(long long)slot * 2 * D + e] = 0.f;
 }
 
-template <int D>
-__global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const StripFfnBwdArgs a, const StripGeom sg) {
+// RIDER: 0, or the phase of the step's index sort (sort_phases.h) that the first rd.plan.nblk workgroups run, on CUs the live tiles
+// leave free (this launch: phase 2, the scatter of pass 0)
+template <int D, int RIDER>
+__global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const StripFfnBwdArgs a, const StripGeom sg, const SortRider rd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bid = blockIdx.x;
+    if constexpr (RIDER != 0) {
+        if (bid < rd.plan.nblk) { sort_phase_ct<1024, RIDER>(rd.plan, bid); return; }
+        bid -= rd.plan.nblk;
+    }
     Ring<D> ring(smem);
-    ring.first(a.w2T[strip_domain(blockIdx.x)]);
-    const StripTile t = strip_tile(sg, blockIdx.x);
+    ring.first(a.w2T[strip_domain(bid)]);
+    const StripTile t = strip_tile(sg, bid);
     if (!t.live) { zero_slot<D>(a.ln_part, t.slot); w_ring_wait(); return; }
     const StripRow row = strip_row<D>(sg, t);
     StripRegs<D> DZ;
@@ -411,12 +419,19 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const Stri
 }
 
 // FFN = true: the layer below's feed-forward / out-projection backward continues on d x in registers (d x is then never stored)
-template <int D, bool FFN>
-__global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const StripQkvBwdArgs a, const StripFfnBwdArgs f, const StripGeom sg) {
+// RIDER: as strip_ffn_bwd_kernel (with FFN: phase 3, pass 1's counts; without: phase 4, the scatter of pass 1)
+template <int D, bool FFN, int RIDER>
+__global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const StripQkvBwdArgs a, const StripFfnBwdArgs f, const StripGeom sg,
+                                                                      const SortRider rd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bid = blockIdx.x;
+    if constexpr (RIDER != 0) {
+        if (bid < rd.plan.nblk) { sort_phase_ct<1024, RIDER>(rd.plan, bid); return; }
+        bid -= rd.plan.nblk;
+    }
     Ring<D> ring(smem);
-    ring.first(a.wkT[strip_domain(blockIdx.x)]);
-    const StripTile t = strip_tile(sg, blockIdx.x);
+    ring.first(a.wkT[strip_domain(bid)]);
+    const StripTile t = strip_tile(sg, bid);
     if (!t.live) {
         zero_slot<D>(a.ln_part, t.slot);
         if constexpr (FFN) zero_slot<D>(f.ln_part, t.slot);
@@ -453,6 +468,29 @@ static int make_strip_geom(int B, int T, int D, const int* live, StripGeom* sg) 
     sg->tpg = (sg->M + STRIP_TILE - 1) / STRIP_TILE;
     sg->live = live;
     return AMID_OK;
+}
+
+static int make_rider(SortRider& rd, const void* sort_plan, int sort_phase) {
+    rd.phase = 0;
+    if (sort_plan == nullptr) return AMID_OK;
+    if (sort_phase < 1 || sort_phase > 4) return AMID_ERR_ARG;
+    rd.plan = *(const SortPlan*)sort_plan;
+    rd.phase = sort_phase;
+    return AMID_OK;
+}
+
+// a strip launch with a sort rider: rd.plan.nblk extra workgroups in front of the tiles'
+template <auto KERNEL, int DVAL, class... Args>
+static int launch_strip_rider(const StripGeom& sg, const SortRider& rd, void* stream, const Args&... args) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds_bytes<DVAL>());
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    KERNEL<<<2 * sg.tpg + rider_blocks_host(rd), STRIP_THREADS, strip_lds_bytes<DVAL>(), (hipStream_t)stream>>>(args..., sg, rd);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? AMID_OK : (int)e;
 }
 
 template <auto KERNEL, int DVAL, class... Args>
@@ -535,28 +573,52 @@ static void fill_ffn_bwd(StripFfnBwdArgs& a, const float* dxo, const unsigned ch
 }
 
 // ln_part: [2 * ceil(B T / amid_sas_strip_tile_rows())][2][D]; domain g's partial sums are slots [g * tpg, (g + 1) * tpg)
-extern "C" int amid_sas_strip_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
-                                          const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T,
-                                          int D, const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2,
-                                          float* dpre1, float* dr, float* d_o, float* ln_part, void* stream) {
+static int strip_ffn_bwd(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                         const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T,
+                         int D, const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2,
+                         float* dpre1, float* dr, float* d_o, float* ln_part, const void* sort_plan, int sort_phase, void* stream) {
     AMID_CHECK_ARG(dxo && h && r && ln_w && w1T && w2T && woT && dpre2 && dpre1 && dr && d_o && ln_part && (!train || step_state));
     StripFfnBwdArgs a;
     fill_ffn_bwd(a, dxo, tmq, h, r, ln_w, w1T, w2T, woT, ln_eps, layer, step_state, train, p_drop, dpre2, dpre1, dr, d_o, ln_part);
     StripGeom sg;
     if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
-    if (D == 128) return launch_strip<strip_ffn_bwd_kernel<128>, 128>(sg, stream, a);
-    if (D == 64) return launch_strip<strip_ffn_bwd_kernel<64>, 64>(sg, stream, a);
+    SortRider rd;
+    if (int e = make_rider(rd, sort_plan, sort_phase)) return e;
+    if (rd.phase != 0 && rd.phase != 2) return AMID_ERR_UNSUPPORTED;           // this launch carries phase 2
+    if (D == 128 && rd.phase) return launch_strip_rider<strip_ffn_bwd_kernel<128, 2>, 128>(sg, rd, stream, a);
+    if (D == 128) return launch_strip_rider<strip_ffn_bwd_kernel<128, 0>, 128>(sg, rd, stream, a);
+    if (D == 64 && rd.phase) return launch_strip_rider<strip_ffn_bwd_kernel<64, 2>, 64>(sg, rd, stream, a);
+    if (D == 64) return launch_strip_rider<strip_ffn_bwd_kernel<64, 0>, 64>(sg, rd, stream, a);
     return AMID_ERR_UNSUPPORTED;
 }
 
+extern "C" int amid_sas_strip_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                                          const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T,
+                                          int D, const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2,
+                                          float* dpre1, float* dr, float* d_o, float* ln_part, void* stream) {
+    return strip_ffn_bwd(dxo, tmq, h, r, ln_w, w1T, w2T, woT, ln_eps, B, T, D, live, layer, step_state, train, p_drop, dpre2, dpre1, dr, d_o,
+                         ln_part, nullptr, 0, stream);
+}
+
+// ... carrying phase `sort_phase` (1 .. 4) of a sort plan (amid_sort_plan_pack) as extra workgroups in front of the tiles'
+extern "C" int amid_sas_strip_ffn_bwd_sort_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r,
+                                               const float* const* ln_w, const float* const* w1T, const float* const* w2T,
+                                               const float* const* woT, float ln_eps, int B, int T, int D, const int* live, int layer,
+                                               const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr,
+                                               float* d_o, float* ln_part, const void* sort_plan, int sort_phase, void* stream) {
+    AMID_CHECK_ARG(sort_plan != nullptr);
+    return strip_ffn_bwd(dxo, tmq, h, r, ln_w, w1T, w2T, woT, ln_eps, B, T, D, live, layer, step_state, train, p_drop, dpre2, dpre1, dr, d_o,
+                         ln_part, sort_plan, sort_phase, stream);
+}
+
 // fh != NULL: the layer below's feed-forward / out-projection backward (f* arguments) runs on d x in the same launch; dx is then not written
-extern "C" int amid_sas_strip_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
-                                          const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
-                                          float ln_eps, int B, int T, int D, const int* live, float* dx, float* ln_part,
-                                          const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
-                                          const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
-                                          const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
-                                          float* fd_o, float* fln_part, void* stream) {
+static int strip_qkv_bwd(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                         const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
+                         float ln_eps, int B, int T, int D, const int* live, float* dx, float* ln_part,
+                         const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
+                         const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
+                         const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
+                         float* fd_o, float* fln_part, const void* sort_plan, int sort_phase, void* stream) {
     AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && ln_part);
     const bool ffn = fh != nullptr;
     AMID_CHECK_ARG(ffn || dx);
@@ -568,9 +630,42 @@ extern "C" int amid_sas_strip_qkv_bwd_f32(const float* dq, const float* dk, cons
     if (ffn) fill_ffn_bwd(f, nullptr, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, ln_eps, flayer, step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part);
     StripGeom sg;
     if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
-    if (D == 128 && ffn) return launch_strip<strip_qkv_bwd_kernel<128, true>, 128>(sg, stream, a, f);
-    if (D == 128) return launch_strip<strip_qkv_bwd_kernel<128, false>, 128>(sg, stream, a, f);
-    if (D == 64 && ffn) return launch_strip<strip_qkv_bwd_kernel<64, true>, 64>(sg, stream, a, f);
-    if (D == 64) return launch_strip<strip_qkv_bwd_kernel<64, false>, 64>(sg, stream, a, f);
+    SortRider rd;
+    if (int e = make_rider(rd, sort_plan, sort_phase)) return e;
+    if (rd.phase != 0 && rd.phase != (ffn ? 3 : 4)) return AMID_ERR_UNSUPPORTED;      // phase 3 with the fused feed-forward backward, 4 without
+    const bool ride = rd.phase != 0;
+    if (D == 128 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3>, 128>(sg, rd, stream, a, f)
+                                     : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0>, 128>(sg, rd, stream, a, f);
+    if (D == 128) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4>, 128>(sg, rd, stream, a, f)
+                              : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0>, 128>(sg, rd, stream, a, f);
+    if (D == 64 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<64, true, 3>, 64>(sg, rd, stream, a, f)
+                                    : launch_strip_rider<strip_qkv_bwd_kernel<64, true, 0>, 64>(sg, rd, stream, a, f);
+    if (D == 64) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<64, false, 4>, 64>(sg, rd, stream, a, f)
+                             : launch_strip_rider<strip_qkv_bwd_kernel<64, false, 0>, 64>(sg, rd, stream, a, f);
     return AMID_ERR_UNSUPPORTED;
+}
+
+extern "C" int amid_sas_strip_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                          const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
+                                          float ln_eps, int B, int T, int D, const int* live, float* dx, float* ln_part,
+                                          const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
+                                          const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
+                                          const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
+                                          float* fd_o, float* fln_part, void* stream) {
+    return strip_qkv_bwd(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, B, T, D, live, dx, ln_part, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, flayer,
+                         step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, nullptr, 0, stream);
+}
+
+// ... carrying phase `sort_phase` (1 .. 4) of a sort plan (amid_sort_plan_pack) as extra workgroups in front of the tiles'
+extern "C" int amid_sas_strip_qkv_bwd_sort_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                               const float* const* ln_w, const float* const* wqT, const float* const* wkT,
+                                               const float* const* wvT, float ln_eps, int B, int T, int D, const int* live, float* dx,
+                                               float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
+                                               const float* const* fln_w, const float* const* fw1T, const float* const* fw2T,
+                                               const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop,
+                                               float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, const void* sort_plan,
+                                               int sort_phase, void* stream) {
+    AMID_CHECK_ARG(sort_plan != nullptr);
+    return strip_qkv_bwd(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, B, T, D, live, dx, ln_part, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, flayer,
+                         step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, sort_plan, sort_phase, stream);
 }

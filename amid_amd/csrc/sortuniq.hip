@@ -14,13 +14,10 @@
 // (83-91 % of all indices) costs one LDS add per wave, not 64 serialized atomics.
 #include "common.h"
 #include "reduce_partials.h"
+#include "sort_phases.h"
 
 namespace amid {
 
-constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 8;                       // rounds of 64 keys per wave
-constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS; // 2048 keys per block
-constexpr int SORT_WAVES = SORT_THREADS / 64;
 
 __device__ __forceinline__ unsigned long long match_digit(unsigned d, bool valid) {
     // lanes of this wave holding the same 8-bit digit (invalid lanes match nobody)
@@ -245,310 +242,28 @@ __global__ __launch_bounds__(1024) void heads_fused_kernel(const int* __restrict
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Two-pass sort in FOUR launches (keys below 2^24: every table up to 16.7 M rows).  Digits of ceil(bits / 2) and floor(bits / 2) bits
-// (cfg 2: 10 + 10, cfg 5: 12 + 12 -- up to 4096 bins); tiles of 2048 keys, supertiles of 16 tiles.  For each pass p two tables say
-// where a tile's keys of a bin go: stot_p[supertile][bin] and counts_p[tile][bin]; a scatter block sweeps the stot_p rows (all of
-// them: the bin totals, whose exclusive scan is the bin's base; the earlier supertiles': its share) and the counts_p rows of the
-// earlier tiles of its own supertile -- at most n_super + 15 coalesced, cached rows; nothing waits for another block, nothing is
-// scanned by a single block.
-//   launch 1  os_count     counts_0 (plain stores), stot_0 (atomics); zeroes counts_1 / stot_1 and launch 4's status words
-//   launch 2  os_scatter   stable scatter by digit 0; every key also bumps counts_1 / stot_1 of the tile its DESTINATION lies in
-//                          (pass 1's tiles are contiguous slices of this pass's output)
-//   launch 3  os_scatter   stable scatter by digit 1 -> sorted keys + positions; zeroes stot_0 for the next call
-//   launch 4  os_heads     run heads: per-tile count, a wave-parallel look-back over the earlier tiles' status words gives the tile's
-//                          first run index (tile ids are handed out by an atomic counter: a tile only waits for tiles that already
-//                          run); writes uniq_ids / seg_off / seg_of / n_uniq
-// stot_0 is the one table that must be zero when a call starts: it sits at a FIXED place at the head of the workspace (whatever
-// n_idx the workspace is used with), is zero-filled once with the workspace and re-zeroed by launch 3 of every call.
-constexpr int OS_BINS_MAX = 4096;
-constexpr int OS_STATE_INTS = 64;                 // [2] tile counter of launch 4
-constexpr int OS_SUPER = 16;                      // tiles per supertile
-constexpr int OS_SUPER_MAX = 256;                 // supertiles the fixed stot_0 area holds (4096 tiles = 8.4 M indices; beyond: 8-bit passes)
-
-struct OsGeom {
-    int n, ntiles;
-    int shift, bits;                              // this pass's digit
-    int next_shift, next_bits;                    // the other pass's digit
-};
-
-__device__ __forceinline__ unsigned long long match_bits(unsigned d, bool valid, int bits) {
-    unsigned long long peers = __ballot(valid);
-    for (int b = 0; b < bits; ++b) {
-        const unsigned long long m = __ballot((d >> b) & 1u);
-        peers &= ((d >> b) & 1u) ? m : ~m;
-    }
-    return peers;
-}
-
-// BINS: LDS is sized for 1024 bins when both digits have at most 10 bits (every table below 2^20 rows: 12 KB in the scatter) -- small
-// enough to share a CU with a one-workgroup-per-CU kernel of the main stream (the fused forward holds 144 of the 160 KB).
+// the four phases as launches of their own (bodies: sort_phases.h)
 template <int BINS>
 __global__ __launch_bounds__(SORT_THREADS) void os_count_kernel(const int* __restrict__ keys, OsGeom g, int* __restrict__ state,
-                                                                int* __restrict__ counts0, int* __restrict__ stot0, int* __restrict__ counts1,
-                                                                long long n_counts1, int* __restrict__ stot1, int n_stot1,
-                                                                int* __restrict__ hstatus) {
-    __shared__ int hist0[BINS];
-    const int bins0 = 1 << g.bits;
-    for (int d = threadIdx.x; d < bins0; d += SORT_THREADS) hist0[d] = 0;
-    __syncthreads();
-    const int w = wave_id(), lane = lane_id();
-    const int base = blockIdx.x * SORT_TILE + w * (64 * SORT_ITEMS);
-    const unsigned mask0 = (unsigned)bins0 - 1u;
-#pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        const int k = base + i * 64 + lane;
-        const bool valid = k < g.n;
-        const unsigned d0 = valid ? (((unsigned)keys[k] >> g.shift) & mask0) : 0u;
-        const unsigned long long peers = match_bits(d0, valid, g.bits);
-        if (valid && (__ffsll((long long)peers) - 1) == lane) atomicAdd(&hist0[d0], __popcll(peers));
-    }
-    __syncthreads();
-    const int sup = blockIdx.x / OS_SUPER;
-    for (int d = threadIdx.x; d < bins0; d += SORT_THREADS) {
-        const int c = hist0[d];
-        counts0[(long long)blockIdx.x * bins0 + d] = c;
-        if (c) atomicAdd(&stot0[(long long)sup * bins0 + d], c);
-    }
-    // housekeeping for the later launches of this call
-    for (long long i = (long long)blockIdx.x * SORT_THREADS + threadIdx.x; i < n_counts1; i += (long long)gridDim.x * SORT_THREADS) counts1[i] = 0;
-    for (int i = blockIdx.x * SORT_THREADS + threadIdx.x; i < n_stot1; i += gridDim.x * SORT_THREADS) stot1[i] = 0;
-    for (int i = blockIdx.x * SORT_THREADS + threadIdx.x; i < g.ntiles; i += gridDim.x * SORT_THREADS) hstatus[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) state[2] = 0;
+                                                                int* __restrict__ counts0, int* __restrict__ stot0, int stot0_copy, int n_stot0,
+                                                                int* __restrict__ counts1, long long n_counts1, int* __restrict__ stot1,
+                                                                int n_stot1, int* __restrict__ hstatus) {
+    os_count_block<BINS>(blockIdx.x, gridDim.x, keys, g, state, counts0, stot0, stot0_copy, n_stot0, counts1, n_counts1, stot1, n_stot1, hstatus);
 }
-
-// stable scatter of one pass.  COUNT_NEXT (pass 0): also the next pass's counts / stot (global atomics).  !COUNT_NEXT (pass 1):
-// zeroes stot_0 (zero_a), the one table that must be zero when the next call starts.
 template <bool COUNT_NEXT, int BINS>
 __global__ __launch_bounds__(SORT_THREADS) void os_scatter_kernel(const int* __restrict__ keys_in, const int* __restrict__ vals_in,
                                                                   int* __restrict__ keys_out, int* __restrict__ vals_out, OsGeom g,
                                                                   const int* __restrict__ counts, const int* __restrict__ stot, int nsup,
                                                                   int* __restrict__ counts_next, int* __restrict__ stot_next,
-                                                                  int* __restrict__ zero_a, int n_zero_a) {
-    __shared__ unsigned short woff[SORT_WAVES][BINS];           // per-wave digit counts, then running offsets inside the tile's bin
-    __shared__ int tile_base[BINS];                             // output position of the tile's first key of every bin
-    __shared__ int wsum[SORT_WAVES];
-    const int bins = 1 << g.bits;
-    const unsigned mask = (unsigned)bins - 1u;
-    const int w = wave_id(), lane = lane_id();
-    for (int i = threadIdx.x; i < SORT_WAVES * BINS / 2; i += SORT_THREADS) ((unsigned*)&woff[0][0])[i] = 0u;
-    __syncthreads();
-    const int kb = blockIdx.x * SORT_TILE + w * (64 * SORT_ITEMS);
-    int key[SORT_ITEMS];
-    unsigned long long peers[SORT_ITEMS];
-#pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        const int k = kb + i * 64 + lane;
-        const bool valid = k < g.n;
-        key[i] = valid ? keys_in[k] : 0;
-        const unsigned d = ((unsigned)key[i] >> g.shift) & mask;
-        peers[i] = match_bits(d, valid, g.bits);
-        // one leader per digit group and round, rounds in program order: no two lanes ever update the same counter at once
-        if (valid && (__ffsll((long long)peers[i]) - 1) == lane) woff[w][d] = (unsigned short)(woff[w][d] + __popcll(peers[i]));
-        __builtin_amdgcn_wave_barrier();
-    }
-    // where the tile's keys of every bin start: thread t owns the bins [t * per, (t + 1) * per).  One sweep over the supertile rows
-    // gives both the bin totals (all rows: for the scan over the bins) and the earlier supertiles' share (rows below this tile's
-    // supertile); the earlier tiles of the own supertile follow.  A thread reads its bins of a row as int4s (a wave covers a
-    // contiguous KB), two rows in flight.
-    constexpr int PERMAX = BINS / SORT_THREADS;
-    const int per = bins / SORT_THREADS > 0 ? bins / SORT_THREADS : 1;
-    const int d0 = threadIdx.x * per;
-    const int sup = blockIdx.x / OS_SUPER;
-    int tot[PERMAX], pre[PERMAX];
-#pragma unroll
-    for (int k = 0; k < PERMAX; ++k) { tot[k] = 0; pre[k] = 0; }
-    if (d0 < bins) {
-        if ((per & 3) == 0) {
-            auto add_row = [&](const int* __restrict__ rowp, bool early, bool total) {
-#pragma unroll
-                for (int k = 0; k < PERMAX; k += 4) {
-                    if (k < per) {
-                        const int4 a = *(const int4*)(rowp + d0 + k);
-                        if (total) { tot[k] += a.x; tot[k + 1] += a.y; tot[k + 2] += a.z; tot[k + 3] += a.w; }
-                        if (early) { pre[k] += a.x; pre[k + 1] += a.y; pre[k + 2] += a.z; pre[k + 3] += a.w; }
-                    }
-                }
-            };
-            for (int s2 = 0; s2 < nsup; ++s2) add_row(stot + (long long)s2 * bins, s2 < sup, true);
-            for (int t = sup * OS_SUPER; t < (int)blockIdx.x; ++t) add_row(counts + (long long)t * bins, true, false);
-        } else {
-#pragma unroll
-            for (int k = 0; k < PERMAX; ++k) {
-                if (k < per) {
-                    for (int s2 = 0; s2 < nsup; ++s2) { const int a = stot[(long long)s2 * bins + d0 + k]; tot[k] += a; if (s2 < sup) pre[k] += a; }
-                    for (int t = sup * OS_SUPER; t < (int)blockIdx.x; ++t) pre[k] += counts[(long long)t * bins + d0 + k];
-                }
-            }
-        }
-    }
-    int mine = 0;
-#pragma unroll
-    for (int k = 0; k < PERMAX; ++k) mine += tot[k];
-    int x = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) wsum[w] = x;
-    __syncthreads();                                             // (also: every wave's woff counts are complete)
-    if (d0 < bins) {
-        int run = x - mine;
-        for (int k = 0; k < w; ++k) run += wsum[k];
-#pragma unroll
-        for (int k = 0; k < PERMAX; ++k) {
-            if (k < per) {
-                const int d = d0 + k;
-                tile_base[d] = run + pre[k];                     // base(d) + the earlier tiles' keys of the bin
-                run += tot[k];
-                unsigned wrun = 0;
-#pragma unroll
-                for (int q = 0; q < SORT_WAVES; ++q) {
-                    const unsigned c = woff[q][d];
-                    woff[q][d] = (unsigned short)wrun;
-                    wrun += c;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned nmask = (1u << g.next_bits) - 1u;
-    const int nbins = 1 << g.next_bits;
-    int pend_cell = -1, pend_n = 0;                 // wave-uniform: the leading cell of the last rounds and its carried count
-#pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        const int k = kb + i * 64 + lane;
-        const bool valid = k < g.n;
-        const unsigned d = ((unsigned)key[i] >> g.shift) & mask;
-        int dst = 0;
-        if (valid) dst = tile_base[d] + woff[w][d] + __popcll(peers[i] & lt);
-        __builtin_amdgcn_wave_barrier();            // every lane has read the offset before the leader bumps it
-        if (valid && (__ffsll((long long)peers[i]) - 1) == lane) woff[w][d] = (unsigned short)(woff[w][d] + __popcll(peers[i]));
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            keys_out[dst] = key[i];
-            vals_out[dst] = vals_in ? vals_in[k] : k;
-        }
-        if (COUNT_NEXT) {
-            // counts_next[dst / tile][digit 1] (+ the supertile's stot_next).  Equal keys share digit 1 and land next to each other, and
-            // the pad id is 80-90 % of a real batch: the lanes that share the first lane's cell are counted together and the count is
-            // CARRIED across the rounds while the leading cell stays the same (same-address atomics serialise in L2: one per wave
-            // and cell instead of one per round); the other lanes add one each.
-            const int tile1 = dst / SORT_TILE;
-            const int d1 = (int)(((unsigned)key[i] >> g.next_shift) & nmask);
-            const int cell = valid ? tile1 * nbins + d1 : -1;
-            const int lead_cell = __builtin_amdgcn_readfirstlane(cell);
-            const unsigned long long same = __ballot(valid && cell == lead_cell);
-            if (lead_cell >= 0) {
-                if (lead_cell == pend_cell) pend_n += __popcll(same);
-                else {
-                    if (pend_n && lane == 0) {
-                        atomicAdd(&counts_next[pend_cell], pend_n);
-                        atomicAdd(&stot_next[(long long)(pend_cell / nbins / OS_SUPER) * nbins + (pend_cell % nbins)], pend_n);
-                    }
-                    pend_cell = lead_cell;
-                    pend_n = __popcll(same);
-                }
-            }
-            if (valid && cell != lead_cell) {
-                atomicAdd(&counts_next[cell], 1);
-                atomicAdd(&stot_next[(long long)(tile1 / OS_SUPER) * nbins + d1], 1);
-            }
-        }
-    }
-    if (COUNT_NEXT) {           // the waves' carried counts: equal cells of the four waves merged, then one atomic each
-        __shared__ int pc[SORT_WAVES], pn[SORT_WAVES];
-        if (lane == 0) { pc[w] = pend_cell; pn[w] = pend_n; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int a = 0; a < SORT_WAVES; ++a) {
-                int n_a = pn[a];
-                if (!n_a) continue;
-#pragma unroll
-                for (int b = a + 1; b < SORT_WAVES; ++b)
-                    if (pn[b] && pc[b] == pc[a]) { n_a += pn[b]; pn[b] = 0; }
-                atomicAdd(&counts_next[pc[a]], n_a);
-                atomicAdd(&stot_next[(long long)(pc[a] / nbins / OS_SUPER) * nbins + (pc[a] % nbins)], n_a);
-            }
-        }
-    }
-    if (!COUNT_NEXT) {
-        for (int i2 = blockIdx.x * SORT_THREADS + threadIdx.x; i2 < n_zero_a; i2 += gridDim.x * SORT_THREADS) zero_a[i2] = 0;
-    }
+                                                                  const int* __restrict__ state, int stot_copy) {
+    // pass 0 reads the stot_0 copy this call fills (os_count_block)
+    const int* st = COUNT_NEXT ? stot + (long long)(state[3] & 1) * stot_copy : stot;
+    os_scatter_block<COUNT_NEXT, BINS>(blockIdx.x, gridDim.x, keys_in, vals_in, keys_out, vals_out, g, counts, st, nsup, counts_next, stot_next);
 }
-
-// run heads of the sorted keys in one launch: thread t of a tile owns 8 consecutive entries
-constexpr unsigned OS_ST_AGG = 1u << 30, OS_ST_PRE = 2u << 30, OS_ST_VAL = (1u << 30) - 1u;
 __global__ __launch_bounds__(SORT_THREADS) void os_heads_kernel(const int* __restrict__ keys, int n, int ntiles, int* __restrict__ state,
                                                                 unsigned* __restrict__ hstatus, int* __restrict__ n_uniq,
                                                                 int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of) {
-    __shared__ int tile_s, excl_s;
-    __shared__ int wsum[SORT_WAVES];
-    if (threadIdx.x == 0) tile_s = atomicAdd(&state[2], 1);
-    __syncthreads();
-    const int tile = tile_s;
-    const int lane = lane_id(), w = wave_id();
-    const int i0 = tile * SORT_TILE + threadIdx.x * SORT_ITEMS;
-    int k[SORT_ITEMS];
-    int prev = (i0 > 0 && i0 < n) ? keys[i0 - 1] : 0;
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const int i = i0 + j;
-        k[j] = i < n ? keys[i] : 0;
-        cnt += (i < n && (i == 0 || k[j] != (j ? k[j - 1] : prev))) ? 1 : 0;
-    }
-    int x = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) wsum[w] = x;
-    __syncthreads();
-    int woff = 0, total = 0;
-#pragma unroll
-    for (int q = 0; q < SORT_WAVES; ++q) { if (q < w) woff += wsum[q]; total += wsum[q]; }
-    if (w == 0) {                                       // wave 0: publish the tile's count, look back, publish the inclusive prefix
-        int excl = 0;
-        if (tile > 0) {
-            if (lane == 0) __hip_atomic_store(&hstatus[tile], OS_ST_AGG | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int t = tile - 1;
-            while (true) {
-                const int idx = t - lane;
-                const unsigned s = idx >= 0 ? __hip_atomic_load(&hstatus[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_ST_PRE;
-                const unsigned long long nr = __ballot((s >> 30) == 0u), pre = __ballot((s >> 30) == 2u);
-                const int first_pre = pre ? __ffsll((long long)pre) - 1 : 64;
-                const int first_nr = nr ? __ffsll((long long)nr) - 1 : 64;
-                if (first_nr < first_pre) { __builtin_amdgcn_s_sleep(2); continue; }     // a tile before the nearest prefix is not ready
-                const int upto = first_pre < 64 ? first_pre : 63;
-                int v = lane <= upto ? (int)(s & OS_ST_VAL) : 0;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                excl += v;
-                if (first_pre < 64) break;
-                t -= 64;
-            }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(&hstatus[tile], OS_ST_PRE | (unsigned)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            excl_s = excl;
-            if (tile == ntiles - 1) { *n_uniq = excl + total; seg_off[excl + total] = n; }
-        }
-    }
-    __syncthreads();
-    int u = excl_s + woff + x - cnt - 1;                // run index of the entry before this thread's span
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const int i = i0 + j;
-        if (i < n) {
-            if (i == 0 || k[j] != (j ? k[j - 1] : prev)) { ++u; uniq_ids[u] = k[j]; seg_off[u] = i; }
-            seg_of[i] = u;
-        }
-    }
+    os_heads_block(keys, n, ntiles, state, hstatus, n_uniq, uniq_ids, seg_off, seg_of);
 }
 
 // Stable merge of `world` sorted lists of `len` keys each (list r = keys[r * len ..]): the merged position of entry (r, i) with
@@ -615,7 +330,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // four-launch sort.  Head of the workspace, independent of n_idx: [state | stot0 (OS_SUPER_MAX rows)]; behind the 8-bit sort's
 // arrays: [stot1 | counts0 | counts1 | hstatus]
 static inline size_t os_nsuper(size_t ntiles) { return (ntiles + OS_SUPER - 1) / OS_SUPER; }
-static inline size_t os_head_bytes() { return align256(OS_STATE_INTS * 4) + align256((size_t)OS_SUPER_MAX * OS_BINS_MAX * 4); }
+static inline size_t os_head_bytes() { return align256(OS_STATE_INTS * 4) + 2 * align256((size_t)OS_SUPER_MAX * OS_BINS_MAX * 4); }      // two stot_0 copies
 static inline size_t os_bytes(size_t ntiles) {
     return align256(os_nsuper(ntiles) * OS_BINS_MAX * 4) + 2 * align256(ntiles * OS_BINS_MAX * 4) + align256(ntiles * 4);
 }
@@ -643,6 +358,51 @@ extern "C" int amid_sort_set_four_launch_min(int n_idx) {
     return prev;
 }
 
+// the four-phase sort's pointers into the caller's workspace (layout: amid_sort_unique_workspace_bytes)
+static int make_plan(SortPlan& sp, const int* idx, const int* rows, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
+                     int* seg_off, int* seg_of, int* n_uniq) {
+    const int nblk = sort_nblk(n_idx);
+    const size_t nsup = os_nsuper(nblk);
+    int bits = 1;
+    while (bits < 31 && (1LL << bits) < n_rows) ++bits;
+    if (bits > 24 || nsup > (size_t)OS_SUPER_MAX) return AMID_ERR_UNSUPPORTED;
+    if (bits < 2) bits = 2;
+    const int b0 = (bits + 1) / 2, b1 = bits - b0;
+    char* const ws_head = (char*)workspace;
+    char* ws = ws_head + os_head_bytes();
+    const size_t kb = align256((size_t)n_idx * 4);
+    char* os = ws + 4 * kb + align256((size_t)256 * nblk * 4) + align256(((size_t)n_idx + 255) / 256 * 4);
+    sp.idx = idx; sp.rows = rows; sp.n = n_idx; sp.nblk = nblk; sp.nsup = (int)nsup;
+    sp.g0 = OsGeom{n_idx, nblk, 0, b0, b0, b1};
+    sp.g1 = OsGeom{n_idx, nblk, b0, b1, 0, b0};
+    sp.state = (int*)ws_head;
+    sp.stot0 = (int*)(ws_head + align256(OS_STATE_INTS * 4));
+    sp.stot1 = (int*)os;
+    sp.counts0 = (int*)((char*)sp.stot1 + align256(nsup * OS_BINS_MAX * 4));
+    sp.counts1 = (int*)((char*)sp.counts0 + align256((size_t)nblk * OS_BINS_MAX * 4));
+    sp.hstatus = (unsigned*)((char*)sp.counts1 + align256((size_t)nblk * OS_BINS_MAX * 4));
+    sp.keys0 = (int*)ws; sp.keys1 = (int*)(ws + kb); sp.vals0 = (int*)(ws + 2 * kb);
+    sp.pos_sorted = pos_sorted; sp.uniq_ids = uniq_ids; sp.seg_off = seg_off; sp.seg_of = seg_of; sp.n_uniq = n_uniq;
+    sp.n_counts1 = (long long)nblk << b1; sp.n_stot1 = (int)(nsup << b1); sp.n_zero_a = (int)(nsup << b0);
+    sp.stot0_copy = (int)(align256((size_t)OS_SUPER_MAX * OS_BINS_MAX * 4) / 4);
+    return AMID_OK;
+}
+
+extern "C" int amid_sort_plan_bytes(void) { return (int)sizeof(SortPlan); }
+
+// The sort of amid_sort_unique_i32 / amid_sort_unique_rows_i32 (rows optional) as a PLAN: nothing is launched; launches of the train
+// step that take a plan + a phase (1 .. 4, in this order, each in a later launch of the same stream than the one before) run the
+// sort as extra workgroups of their own (keys below 2^20; AMID_ERR_UNSUPPORTED otherwise).  host_buf: amid_sort_plan_bytes().
+extern "C" int amid_sort_plan_pack(void* host_buf, const int* idx, const int* rows, int n_idx, long long n_rows, void* workspace,
+                                   int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq) {
+    AMID_CHECK_ARG(host_buf && idx && workspace && pos_sorted && uniq_ids && seg_off && seg_of && n_uniq && n_idx > 0 && n_rows > 0);
+    SortPlan sp;
+    if (int e = make_plan(sp, idx, rows, n_idx, n_rows, workspace, pos_sorted, uniq_ids, seg_off, seg_of, n_uniq)) return e;
+    if (sp.g0.bits > 10) return AMID_ERR_UNSUPPORTED;           // riders carry the 1024-bin instantiation only (12 KB of LDS)
+    *(SortPlan*)host_buf = sp;
+    return AMID_OK;
+}
+
 static int sort_unique(const int* idx, const int* rows, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
                        int* seg_off, int* seg_of, int* n_uniq, void* stream) {
     AMID_CHECK_ARG(idx && workspace && pos_sorted && uniq_ids && seg_off && seg_of && n_uniq && n_idx > 0 && n_rows > 0);
@@ -657,28 +417,19 @@ static int sort_unique(const int* idx, const int* rows, int n_idx, long long n_r
     int* blk_heads = (int*)(ws + 4 * kb + align256((size_t)256 * nblk * 4));
     int bits = 1;
     while (bits < 31 && (1LL << bits) < n_rows) ++bits;
-    if (bits <= 24 && n_idx >= g_four_launch_min && os_nsuper(nblk) <= (size_t)OS_SUPER_MAX) {      // four launches (see os_count_kernel)
-        char* os = ws + 4 * kb + align256((size_t)256 * nblk * 4) + align256(((size_t)n_idx + 255) / 256 * 4);
-        const size_t nsup = os_nsuper(nblk);
-        int* state = (int*)ws_head;
-        int* stot0 = (int*)(ws_head + align256(OS_STATE_INTS * 4));
-        int* stot1 = (int*)os;
-        int* counts0 = (int*)((char*)stot1 + align256(nsup * OS_BINS_MAX * 4));
-        int* counts1 = (int*)((char*)counts0 + align256((size_t)nblk * OS_BINS_MAX * 4));
-        unsigned* hstatus = (unsigned*)((char*)counts1 + align256((size_t)nblk * OS_BINS_MAX * 4));
-        if (bits < 2) bits = 2;
-        const int b0 = (bits + 1) / 2, b1 = bits - b0;
-        OsGeom g0{n_idx, nblk, 0, b0, b0, b1}, g1{n_idx, nblk, b0, b1, 0, b0};
-#define AMID_OS_LAUNCH(BINS)                                                                                                              \
-        os_count_kernel<BINS><<<nblk, SORT_THREADS, 0, s>>>(idx, g0, state, counts0, stot0, counts1, (long long)nblk << b1, stot1,               \
-                                                            (int)(nsup << b1), (int*)hstatus);                                            \
-        os_scatter_kernel<true, BINS><<<nblk, SORT_THREADS, 0, s>>>(idx, rows, keys[0], vals[0], g0, counts0, stot0, (int)nsup, counts1, stot1, \
-                                                                    nullptr, 0);                                                          \
-        os_scatter_kernel<false, BINS><<<nblk, SORT_THREADS, 0, s>>>(keys[0], vals[0], keys[1], pos_sorted, g1, counts1, stot1, (int)nsup,      \
-                                                                     nullptr, nullptr, stot0, (int)(nsup << b0));
-        if (b0 <= 10) { AMID_OS_LAUNCH(1024) } else { AMID_OS_LAUNCH(4096) }
+    if (bits <= 24 && n_idx >= g_four_launch_min && os_nsuper(nblk) <= (size_t)OS_SUPER_MAX) {      // four launches (sort_phases.h)
+        SortPlan sp;
+        if (make_plan(sp, idx, rows, n_idx, n_rows, workspace, pos_sorted, uniq_ids, seg_off, seg_of, n_uniq) != AMID_OK) return AMID_ERR_ARG;
+#define AMID_OS_LAUNCH(BINS)                                                                                                            \
+        os_count_kernel<BINS><<<nblk, SORT_THREADS, 0, s>>>(sp.idx, sp.g0, sp.state, sp.counts0, sp.stot0, sp.stot0_copy, sp.n_zero_a, sp.counts1,   \
+                                                            sp.n_counts1, sp.stot1, sp.n_stot1, (int*)sp.hstatus);                       \
+        os_scatter_kernel<true, BINS><<<nblk, SORT_THREADS, 0, s>>>(sp.idx, sp.rows, sp.keys0, sp.vals0, sp.g0, sp.counts0, sp.stot0, sp.nsup,   \
+                                                                    sp.counts1, sp.stot1, sp.state, sp.stot0_copy);                        \
+        os_scatter_kernel<false, BINS><<<nblk, SORT_THREADS, 0, s>>>(sp.keys0, sp.vals0, sp.keys1, sp.pos_sorted, sp.g1, sp.counts1, sp.stot1,  \
+                                                                     sp.nsup, nullptr, nullptr, sp.state, 0);
+        if (sp.g0.bits <= 10) { AMID_OS_LAUNCH(1024) } else { AMID_OS_LAUNCH(4096) }
 #undef AMID_OS_LAUNCH
-        os_heads_kernel<<<nblk, SORT_THREADS, 0, s>>>(keys[1], n_idx, nblk, state, hstatus, n_uniq, uniq_ids, seg_off, seg_of);
+        os_heads_kernel<<<nblk, SORT_THREADS, 0, s>>>(sp.keys1, sp.n, sp.nblk, sp.state, sp.hstatus, sp.n_uniq, sp.uniq_ids, sp.seg_off, sp.seg_of);
         AMID_LAUNCH_CHECK();
         return AMID_OK;
     }

@@ -625,6 +625,10 @@ class SasrecEngine:
         # are exact zeros; a row only they hold is not touched this step -- the lazy Adam replays it when it is next read).  InnerComp
         # couples the rows of a batch in front of the encoders: every position keeps its gradient there.
         pl.compact = bool(with_live and sparse and self.compact_ok(pl))
+        # ... and the step's index sort rides in main-stream launches (catch-up + the three strip backward launches carry one phase
+        # each as extra workgroups: no side stream, no fork, no join) when the keys fit the riders' 1024-bin build
+        pl.riding = bool(bump_step and sparse and defer_sort and self.SORT_RIDERS and getattr(pl, "strip", False) and not pl.compact
+                         and (shp.n_idx + 2047) // 2048 <= 2 * shp.Tenc and self._sort_plan(pl) is not None)
         ent = self.input_pool(pl)
         if ent is not None:
             pool, phase = ent
@@ -639,7 +643,9 @@ class SasrecEngine:
                        pl.in_words, shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
                        self.step_state.data_ptr(), s)
             self.step += 1
-            if sparse:
+            if sparse and pl.riding:
+                self._sort_owed = False
+            elif sparse:
                 self.ev_idx.record(self.stream)
                 self._sort_owed = bool(defer_sort)
                 if not defer_sort:
@@ -655,7 +661,9 @@ class SasrecEngine:
                    self.step_state.data_ptr() if bump_step else None, s)
         if bump_step:
             self.step += 1
-        if sparse:
+        if sparse and pl.riding:
+            self._sort_owed = False
+        elif sparse:
             self.ev_idx.record(self.stream)       # fork point: the index list is complete
             self._sort_owed = bool(defer_sort)
             if not defer_sort:
@@ -682,6 +690,19 @@ class SasrecEngine:
             self.stream.wait_event(self.ev_sorted)
             self._sort_pending = False
 
+    SORT_RIDERS = os.environ.get("AMID_SORT_RIDERS", "1") != "0"
+
+    def _sort_plan(self, pl: SasrecPlan):
+        """Host address of the plan of the step's index sort (amid_sort_plan_pack), or None when the riders do not cover it."""
+        if not hasattr(pl, "_sort_plan_buf"):
+            L = lib()
+            buf = (ctypes.c_ubyte * L.value("amid_sort_plan_bytes"))()
+            rc = L._fn["amid_sort_plan_pack"](ctypes.addressof(buf), pl.idx_all.data_ptr(), None, pl.shape.n_idx, self.n_rows,
+                                              pl.sort_ws.data_ptr(), pl.pos_sorted.data_ptr(), pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(),
+                                              pl.seg_of.data_ptr(), pl.n_uniq.data_ptr())
+            pl._sort_plan_buf = buf if rc == 0 else None
+        return ctypes.addressof(pl._sort_plan_buf) if pl._sort_plan_buf is not None else None
+
     COMPACT_LIVE = True
     COMPACT_MIN_IDX = 65536    # shorter index lists gain nothing from the compact list (the tail is bound by the dense partial sums,
                                # the row Adam by its dense half) and lose the early fork of the side-stream sort: cfg 2 keeps the full list
@@ -705,6 +726,11 @@ class SasrecEngine:
     def enqueue_catchup(self, pl: SasrecPlan) -> None:
         """Replay pending zero-gradient Adam steps of the rows this batch is about to gather (by position: no sort needed)."""
         self._ensure_opt_state()
+        if getattr(pl, "riding", False):          # phase 1 of the step's sort rides here
+            lib().call("amid_lazy_adam_catchup_positions_sort_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
+                       self.table_last.data_ptr(), pl.idx_all.data_ptr(), pl.shape.n_idx, self.D, self.step_state.data_ptr(),
+                       self._sort_plan(pl), 1, self.s)
+            return
         lib().call("amid_lazy_adam_catchup_positions_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
                    self.table_last.data_ptr(), pl.idx_all.data_ptr(), pl.shape.n_idx, self.D, self.step_state.data_ptr(), self.s)
 
@@ -985,19 +1011,24 @@ class SasrecEngine:
         dx_in = (pl.dx0 if self.inc_bs else pl.dxg).data_ptr()
         if pl.strip:
             ln1p, ln2p = pl.ln1_part, pl.ln2_part
-            L.call("amid_sas_strip_ffn_bwd_f32", pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, B, T, D, lv, 1, st, tr,
-                   SASREC_P_DROP, pl.dpre2[1].data_ptr(), pl.dpre1[1].data_ptr(), pl.dr[1].data_ptr(), pl.d_o.data_ptr(), ln2p[1].data_ptr(), s)
+            # a train step's index sort rides in these three launches (phases 2, 3, 4; phase 1 rode in the catch-up launch)
+            riding = getattr(pl, "riding", False)
+            sfx = "_sort" if riding else ""
+            ride = lambda ph: (self._sort_plan(pl), ph) if riding else ()      # noqa: E731
+            L.call(f"amid_sas_strip_ffn_bwd{sfx}_f32", pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, B, T, D, lv, 1, st, tr,
+                   SASREC_P_DROP, pl.dpre2[1].data_ptr(), pl.dpre1[1].data_ptr(), pl.dr[1].data_ptr(), pl.d_o.data_ptr(), ln2p[1].data_ptr(),
+                   *ride(2), s)
             attn_bwd(1)
             # layer 1's q / k / v + LayerNorm1 backward and layer 0's feed-forward / out-projection backward: one launch
-            L.call("amid_sas_strip_qkv_bwd_f32", pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
+            L.call(f"amid_sas_strip_qkv_bwd{sfx}_f32", pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
                    pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
                    SASREC_LN_EPS, B, T, D, lv, None, ln1p[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr, SASREC_P_DROP,
-                   pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(), ln2p[0].data_ptr(), s)
+                   pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(), ln2p[0].data_ptr(), *ride(3), s)
             attn_bwd(0)
-            L.call("amid_sas_strip_qkv_bwd_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
+            L.call(f"amid_sas_strip_qkv_bwd{sfx}_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
                    pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
                    SASREC_LN_EPS, B, T, D, lv, dx_in, ln1p[0].data_ptr(), None, None, None, None, None, None, None, 0, None, 0, 0.0, None,
-                   None, None, None, None, s)
+                   None, None, None, None, *ride(4), s)
         else:
             rows, suf, rpt = ("_rows", pl.rt_suffix_v, pl.rpt_v) if live else ("", pl.rt_suffix, pl.rpt)
             ln1p, ln2p = (pl.ln1_part_v, pl.ln2_part_v) if live else (pl.ln1_part, pl.ln2_part)
@@ -1025,7 +1056,10 @@ class SasrecEngine:
         self._fork_sort(pl, "wgrad")
         L.call("amid_sas_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
                ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), self._own_rows(pl), B, T, s)
-        if live:     # the dead sequences' rows of the encoder-input gradient were never written: zero-filled here, not read
+        if getattr(pl, "riding", False):     # the last phase of the step's index sort (run heads) rides here
+            L.call("amid_embed_bwd_sort_f32", (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits,
+                   pl.dpos_part.data_ptr(), st, tr, SASREC_P_DROP, dom if live else None, self._sort_plan(pl), 5, s)
+        elif live:     # the dead sequences' rows of the encoder-input gradient were never written: zero-filled here, not read
             L.call("amid_embed_bwd_rows_f32", (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits,
                    pl.dpos_part.data_ptr(), st, tr, SASREC_P_DROP, dom, s)
         else:

@@ -79,6 +79,16 @@ int amid_sort_set_four_launch_min(int n_idx);
 int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
                          int* seg_off /* [n_idx + 1] */, int* seg_of /* [n_idx] run index of each sorted entry */,
                          int* n_uniq /* device scalar */, void* stream);
+/* The same sort as a PLAN for riders: nothing is launched; the train-step launches that take (plan, phase) run it as extra workgroups
+ * in front of their own, so the step's sort costs no launch, no side stream, no fork and no join.  Five phases, each in a later
+ * launch of the same stream than the one before, each launch carrying the phase it is built for: 1 (digit-0 counts)
+ * amid_lazy_adam_catchup_positions_sort_f32, 2 (scatter 0) amid_sas_strip_ffn_bwd_sort_f32, 3 (digit-1 counts) / 4 (scatter 1)
+ * amid_sas_strip_qkv_bwd_sort_f32 with / without the fused feed-forward backward, 5 (run heads) amid_embed_bwd_sort_f32; any other
+ * phase number: AMID_ERR_UNSUPPORTED.  host_buf: amid_sort_plan_bytes() bytes; rows optional (as amid_sort_unique_rows_i32);
+ * workspace as above.  AMID_ERR_UNSUPPORTED for keys of 2^20 and more. */
+int amid_sort_plan_bytes(void);
+int amid_sort_plan_pack(void* host_buf, const int* idx, const int* rows, int n_idx, long long n_rows, void* workspace, int* pos_sorted,
+                        int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq);
 /* amid_sort_unique_i32 with a payload: pos_sorted holds rows[i] instead of i (ties keep the order of the list). */
 int amid_sort_unique_rows_i32(const int* idx, const int* rows, int n_idx, long long n_rows, void* workspace, int* pos_sorted, int* uniq_ids,
                               int* seg_off, int* seg_of, int* n_uniq, void* stream);
@@ -147,6 +157,9 @@ int amid_lazy_adam_catchup_f32(float* table, float* m, float* v, int* last, cons
 /* catch-up driven by the raw (non-unique) index list: needs no sort, so the sort can overlap the forward pass */
 int amid_lazy_adam_catchup_positions_f32(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D,
                                          const void* step_state, void* stream);
+/* ... carrying phase 1 of a sort plan (amid_sort_plan_pack) as extra workgroups in front of its own */
+int amid_lazy_adam_catchup_positions_sort_f32(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D,
+                                              const void* step_state, const void* sort_plan, int sort_phase, void* stream);
 int amid_lazy_adam_apply_f32(float* table, float* m, float* v, int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max,
                              const float* uniq_grad, float grad_scale, int D, const void* step_state, void* stream);
 int amid_lazy_adam_flush_f32(float* table, float* m, float* v, int* last, long long n_rows, int D, const void* step_state, void* stream);
@@ -584,6 +597,9 @@ int amid_pack_indices_live(const long long* i_node, const long long* neg, const 
 int amid_pack_indices_pool_live(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack,
                                 int in_words, int B, int T, int n_neg, long long n_rows, int* idx_all, int* err_flag, void* step_state,
                                 int* live, void* stream);
+/* amid_embed_bwd_f32 / amid_embed_bwd_rows_f32 (row_domain optional) carrying phase 5 of a sort plan as extra workgroups */
+int amid_embed_bwd_sort_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part, const void* rng_state,
+                            int train, float p_drop, const long long* row_domain, const void* sort_plan, int sort_phase, void* stream);
 int amid_embed_fwd_live_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
                             int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
                             const int* live, void* stream);
@@ -638,6 +654,18 @@ int amid_sas_strip_qkv_bwd_f32(const float* dq, const float* dk, const float* dv
                                const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
                                int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
                                float* fd_o, float* fln_part, void* stream);
+/* the backward strip launches carrying a phase of a sort plan (amid_sort_plan_pack; ffn: 2, qkv with / without the fused
+ * feed-forward backward: 3 / 4) as extra workgroups in front of the tiles' (the live tiles leave CUs free) */
+int amid_sas_strip_ffn_bwd_sort_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                               const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T, int D,
+                               const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
+                               float* dr, float* d_o, float* ln_part, const void* sort_plan, int sort_phase, void* stream);
+int amid_sas_strip_qkv_bwd_sort_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
+                               const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int B, int T, int D,
+                               const int* live, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
+                               const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
+                               int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
+                               float* fd_o, float* fln_part, const void* sort_plan, int sort_phase, void* stream);
 
 int amid_embed_bwd_rows_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part, const void* rng_state,
                             int train, float p_drop, const long long* row_domain, void* stream);   /* amid_embed_bwd_f32 behind the *_rows kernels: the dead sequences' rows are zero-filled, not read */
