@@ -587,6 +587,9 @@ class SasrecEngine:
         torch.cuda.synchronize(self.device)
         if getattr(pl, "graphs", None):               # the pool pointer is baked into captured launches
             pl.graphs.pop(key, None)
+        if getattr(pl, "graphs_n", None):
+            for k in [k for k in pl.graphs_n if k[0] == key]:
+                pl.graphs_n.pop(k)
         if getattr(pl, "dp_graphs", None):
             pl.dp_graphs.clear()
         pl.graph_local = None
@@ -1299,6 +1302,32 @@ class SasrecEngine:
             pl.graphs = {}
         pl.graphs[self._graph_key()] = out.value       # the Adam state's buffers and the DR objective are baked into a graph
         pl.graph = pl.graphs.get((0, 0), out.value)
+
+    def capture_train_steps(self, pl: SasrecPlan, n_steps: int) -> None:
+        """n_steps consecutive train steps as ONE hipGraph (replay_train_steps).  Only with an input pool: every step's first kernel
+        picks its batch by the device step counter, so the steps of a graph see consecutive batches; a replayed graph costs ~8 us of
+        idle device time between two launches, which a graph of several steps pays once."""
+        if self.input_pool(pl) is None:
+            raise ValueError("a graph of several train steps needs an input pool (set_input_pool)")
+        L = lib()
+        if not self.has_graph(pl):
+            self.capture_train_step(pl)              # (also the warm-up outside capture)
+        s, step0 = self.s, self.step
+        L.call("amid_graph_capture_begin", s)
+        try:
+            for _ in range(n_steps):
+                self.enqueue_train_step(pl)
+        finally:
+            out = ctypes.c_void_p()
+            L.call("amid_graph_capture_end", s, ctypes.byref(out))
+        self.step = step0
+        if not hasattr(pl, "graphs_n"):
+            pl.graphs_n = {}
+        pl.graphs_n[(self._graph_key(), n_steps)] = out.value
+
+    def replay_train_steps(self, pl: SasrecPlan, n_steps: int) -> None:
+        lib().call("amid_graph_launch", pl.graphs_n[(self._graph_key(), n_steps)], self.s)
+        self.step += n_steps
 
     def has_graph(self, pl: SasrecPlan) -> bool:
         return self._graph_key() in getattr(pl, "graphs", {})

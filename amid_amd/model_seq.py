@@ -269,12 +269,19 @@ class SASRec(nn.Module):
         self.fused_optimizer = True
         return nb
 
-    def pool_step(self, use_graph: bool = True, exchange=None, dr_objective: int = 0) -> torch.Tensor:
-        """One train step on the next batch of the pool installed by begin_epoch_pool(); returns what train_step() returns."""
+    def pool_step(self, use_graph: bool = True, exchange=None, dr_objective: int = 0, n_steps: int = 1) -> torch.Tensor:
+        """One train step on the next batch of the pool installed by begin_epoch_pool(); returns what train_step() returns.
+        n_steps > 1 (single GPU, graphs): that many consecutive steps as ONE replayed graph (the caller sees the last step's loss)."""
         eng, pl = self.engine, self._pool_plan
         if eng.dr:
             eng.dr_mode = int(dr_objective)
-        if exchange is not None and exchange.world > 1:
+        if n_steps > 1:
+            if not use_graph or (exchange is not None and exchange.world > 1):
+                raise ValueError("several steps per call need graph replay on a single GPU")
+            if (eng._graph_key(), n_steps) not in getattr(pl, "graphs_n", {}):
+                eng.capture_train_steps(pl, n_steps)
+            eng.replay_train_steps(pl, n_steps)
+        elif exchange is not None and exchange.world > 1:
             if use_graph and getattr(pl, "graph_local", None) is None:
                 eng.capture_local_grads(pl)
             eng.train_step_dp(pl, exchange, use_graph=use_graph, umax=self._pool_umax)

@@ -31,6 +31,9 @@ logger = logging.getLogger()
 FIX_VALUE = 1e-7          # train_sr.py:42: ties between the positive and a negative count against the positive
 
 
+STEPS_PER_GRAPH = 4          # train(): consecutive pooled steps per replayed hipGraph (single GPU)
+
+
 def build_parser() -> argparse.ArgumentParser:
     p = argparse.ArgumentParser(description="Multi-edge multi-domain training")
     p.add_argument("--epoch", type=int, default=50, help="# of epoch")
@@ -116,19 +119,33 @@ def train(model, train_batches, args, val_batches, exchange=None):
         model.train()
         t0, n_samples = time.perf_counter(), 0
         pooled = not args.no_pool and hasattr(model, "begin_epoch_pool")
-        if pooled:            # the epoch's batches resident in HBM, one graph replay per step, no per-step tensor work on the host
+        # the epoch's batches resident in HBM, one graph replay per STEPS_PER_GRAPH steps (a replayed graph costs ~8 us of idle device
+        # time between launches), no per-step tensor work on the host; the loss is looked at every 20 iterations as in the reference
+        chunk = STEPS_PER_GRAPH if (pooled and not args.no_graph and exchange is None and not args.max_steps) else 1
+        if pooled:
             n_batches = model.begin_epoch_pool(train_batches.epoch_tensors(), exchange=exchange)
             steps = ((None, None) for _ in range(n_batches))
         else:
             steps = enumerate(train_batches)
+        pending = 0
         for i, (_, b) in enumerate(steps):
             if pooled:
-                loss = model.pool_step(use_graph=not args.no_graph, exchange=exchange)
+                pending += 1
+                last = i + 1 == n_batches
+                if chunk > 1 and pending < chunk and not last:
+                    continue                                   # the graph of `chunk` steps is replayed when its last step comes up
+                if pending == chunk and chunk > 1:
+                    loss = model.pool_step(use_graph=True, exchange=exchange, n_steps=chunk)
+                else:
+                    for _ in range(pending):                   # the epoch's tail (or chunk == 1): single-step graphs
+                        loss = model.pool_step(use_graph=not args.no_graph, exchange=exchange)
+                n_done, pending = pending, 0
             else:
                 loss = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
                                         use_graph=not args.no_graph, exchange=exchange)
-            n_samples += args.bs * (exchange.world if exchange is not None else 1)
-            if i % 20 == 0:                                                               # train_sr.py:217-219 (the only host sync)
+                n_done = 1
+            n_samples += n_done * args.bs * (exchange.world if exchange is not None else 1)
+            if (i + 1) % 20 == 0 or i == 0:                                               # train_sr.py:217-219 (the only host sync)
                 if pooled:
                     model.engine.sync()
                 stats.update(loss=loss.item(), loss_cls=loss.item())

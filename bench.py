@@ -338,6 +338,9 @@ def main():
     ap.add_argument("--data", default="real", choices=("real", "synthetic"),
                     help="real (default where the workload has a fixture: cfg2, cfg3, cfg4): the reference's training CSV as tokenised by "
                          "its own dataset class (tests/golden/tok_*.npz); synthetic: batches drawn to the file's statistics")
+    ap.add_argument("--steps-per-graph", type=int, default=int(os.environ.get("AMID_STEPS_PER_GRAPH", "4")),
+                    help="consecutive train steps captured into one replayed hipGraph (single GPU, pool input; default 4 = what the "
+                         "CLI's train loop replays, amid_amd/train_sr.py STEPS_PER_GRAPH)")
     ap.add_argument("--no-stress", action="store_true", help="skip the cfg5 gather / scatter stress appended to the headline line")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
                     help="cfg2 = the headline configuration (default); cfg5-* = synthetic gather / scatter stress (SURVEY.md 8(d))")
@@ -417,18 +420,28 @@ def main():
             eng.load_packed(pl, pool[i % n_pool])
 
     use_graph = not args.no_graph
+    # steps per replayed graph: a graph of several consecutive steps (each picks its batch by the device step counter) pays the idle
+    # time between two graph launches once; K timed steps are still K steps
+    spg = args.steps_per_graph if (use_graph and use_pool and world == 1) else 1
+    while spg > 1 and (args.steps % spg or args.warmup % spg):
+        spg -= 1
     exchange = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=(backend != "nccl")) if world > 1 else None
     load(0)
     if use_graph:
         if world == 1:
             eng.capture_train_step(pl)
+            if spg > 1:
+                eng.capture_train_steps(pl, spg)
         else:
             eng.capture_local_grads(pl)
 
     def step(i):
         load(i)
         if world == 1:
-            if use_graph:
+            if use_graph and spg > 1:
+                if i % spg == 0:
+                    eng.replay_train_steps(pl, spg)
+            elif use_graph:
                 eng.replay_train_step(pl)
             else:
                 eng.enqueue_train_step(pl)
@@ -521,7 +534,7 @@ def main():
         lds = [DeviceBatches(d, Bw, shuffle=True, device=device, seed=1, negatives="device") for d in dss]
         ld2 = lds[0] if len(lds) == 1 else JointBatches(*lds)
         while (-eng.step) % n_pool != eng.input_pool(pl)[1]:       # finish the running epoch: the pool is refilled on its boundary
-            step(0)
+            eng.replay_train_step(pl)
         n_ep = max(2, min(20, args.steps // n_pool))
 
         def epoch():
@@ -531,7 +544,12 @@ def main():
             if not eng.refill_input_pool(pl, pk):
                 raise RuntimeError("pool refill off an epoch boundary")
             pk.record_stream(eng.stream)
-            for _ in range(n_pool):
+            for k in range(0, n_pool - n_pool % spg, spg):        # as the CLI's train loop: graphs of spg steps, single steps for the tail
+                if spg > 1:
+                    eng.replay_train_steps(pl, spg)
+                else:
+                    eng.replay_train_step(pl)
+            for _ in range(n_pool % spg if spg > 1 else 0):
                 eng.replay_train_step(pl)
 
         epoch()
@@ -557,7 +575,7 @@ def main():
                        "global_batch": Bw * world, "seq_len": T, "emb_dim": D, "hid_dim": HID, "neg": NEG, "table_rows": wl["n_rows"],
                        "unique_rows_last_step": int(pl.n_uniq.item()),
                        "input": "HBM-resident batch pool" if use_pool else "device copy per step",
-                       "dropout": "on (p=0.5)" if args.model == "sasrec" else "on (p=0.1)", "optimizer": "Adam (dense-equivalent lazy rows)", "graph": use_graph,
+                       "dropout": "on (p=0.5)" if args.model == "sasrec" else "on (p=0.1)", "optimizer": "Adam (dense-equivalent lazy rows)", "graph": use_graph, "steps_per_graph": spg,
                        "parallelism": f"dp{world}"},
             "loss_last": round(loss_last, 6),
             "roofline": roof,
