@@ -378,3 +378,36 @@ def test_rows_row_tile_kernels_equal_plain_in_every_build(suf, rpt, Bn, T):
             sb = b.reshape(2, tpg, 2, D).double().sum(1)
             assert torch.isfinite(sb).all()
             assert float((sa - sb).abs().max()) < 2e-5 * float(sa.abs().max() + 1e-30), (kind, suf)
+
+
+def test_graphs_of_four_steps_equal_single_step_replays():
+    """capture_train_steps: eight pooled steps as two replays of a four-step graph leave bit-identical parameters to eight replays of
+    the single-step graph (every step picks its batch by the device step counter either way)."""
+    Bn, T, D, hid, n_items, K = 64, 20, 128, 32, 900, 8
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=5)
+    batches = [orc.synthetic_batch(Bn, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=700 + t) for t in range(K)]
+    out = []
+    for chunk in (1, 4):
+        eng = make_engine(P, T, seed=9)
+        pl = eng.plan(Bn, T, 2, need_grad=True)
+        packed = []
+        for b in batches:
+            cu = {k: v.cuda() for k, v in b.items()}
+            packed.append(eng.pack_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"]))
+        eng.set_input_pool(pl, torch.stack(packed))
+        eng.capture_train_step(pl)
+        if chunk > 1:
+            eng.capture_train_steps(pl, chunk)
+        for i in range(0, K, chunk):
+            if chunk > 1:
+                eng.replay_train_steps(pl, chunk)
+            else:
+                eng.replay_train_step(pl)
+        eng.sync()
+        assert eng.step == K
+        eng.check_index_error(pl)
+        eng.flush_table()
+        eng.sync()
+        out.append({k: v.cpu().clone() for k, v in eng.state_dict().items()})
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
