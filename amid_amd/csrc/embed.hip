@@ -294,6 +294,50 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(float* __restrict__ dxg,
     unsigned long long seed = 0;
     unsigned step = 0;
     if (train) { seed = rng->seed; step = (unsigned)rng->step; }
+    if (D == 128 && (!train || spec_bits(thr16) == 1)) {
+        // one float4 column per lane, the row group's rows four at a time: every load of a batch is issued before the first use, and
+        // the batch's dropout words come from ONE Philox call per row (p = 0.5: a call decides a whole row, rng.h), drawn by lane i
+        // for row i and handed round -- not one call per lane and row
+        const int c = sub, half = threadIdx.x & 32;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b0 = b_beg + rg; b0 < b_end; b0 += 32) {
+            float4 v[4];
+            unsigned bits[4], kw[4];
+            bool in[4], livef[4];
+            uint4 mine = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (train && sub < 4 && b0 + 8 * sub < b_end)
+                mine = rng_call(seed, (unsigned long long)((b0 + 8 * sub) * T + t), site_id(g, 0, SITE_EMB), step);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = b0 + 8 * i;
+                in[i] = b < b_end;
+                livef[i] = in[i] && !(row_domain != nullptr && (row_domain[b] != 0 ? 1 : 0) != g);
+                const long long r = (long long)g * M + (long long)(in[i] ? b : b_beg) * T + t;
+                v[i] = livef[i] ? ld4(dxg + r * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bits[i] = livef[i] ? tmq[r * q + c] : 0u;
+                const unsigned wx = __shfl(mine.x, half + i, 64), wy = __shfl(mine.y, half + i, 64);
+                const unsigned wz = __shfl(mine.z, half + i, 64), ww = __shfl(mine.w, half + i, 64);
+                const int wsel = c >> 3;
+                kw[i] = ((wsel == 0 ? wx : wsel == 1 ? wy : wsel == 2 ? wz : ww) >> ((c & 7) * 4)) | (spec_thr(thr16) == 0 ? 0xFu : 0u);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!in[i]) continue;
+                const long long r = (long long)g * M + (long long)(b0 + 8 * i) * T + t;
+                float4 x = v[i];
+                if (train) x = make_float4((kw[i] & 1u) ? x.x * scale : 0.f, (kw[i] & 2u) ? x.y * scale : 0.f, (kw[i] & 4u) ? x.z * scale : 0.f,
+                                           (kw[i] & 8u) ? x.w * scale : 0.f);
+                if (bits[i] & 1u) x.x = 0.f;
+                if (bits[i] & 2u) x.y = 0.f;
+                if (bits[i] & 4u) x.z = 0.f;
+                if (bits[i] & 8u) x.w = 0.f;
+                if (!livef[i]) x = make_float4(0.f, 0.f, 0.f, 0.f);    // no gradient reached this sequence: the zeros it stands for
+                st4(dxg + r * D + 4 * c, x);
+                acc = f4add(acc, x);
+            }
+        }
+        st4(red + rg * D + 4 * c, acc);
+    } else
     for (int c = sub; c < q; c += 32) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int b = b_beg + rg; b < b_end; b += 8) {
