@@ -21,6 +21,10 @@
 #include "common.h"
 #include "rng.h"
 
+#ifndef STRIP_RSTAMP
+#define STRIP_RSTAMP(i) do { } while (0)
+#endif
+
 namespace amid {
 
 struct AttnArgs {          // must stay identical to the struct in attention.hip
@@ -199,5 +203,202 @@ __device__ __forceinline__ void attn_fwd_head(const AttnArgs& a, int g, int b, l
     }
 }
 
+
+// ---- backward of ONE head of ONE sequence by the calling wave ---------------------------------------------------------------------
+// a sequence's [T, D] slice of an activation tensor behind a buffer descriptor: rows past T read as zeros and stores to them vanish
+// (the hardware's bounds check), so no load or store of the backward needs a branch or a select
+typedef unsigned attn_v4u __attribute__((ext_vector_type(4)));
+struct SeqBuf {
+    __amdgpu_buffer_rsrc_t r;
+    int ld;                                             // floats per row
+    __device__ __forceinline__ SeqBuf(const float* base, long long rowbase, int T, int row_floats) : ld(row_floats) {
+        const unsigned long long p = (unsigned long long)(base + rowbase * row_floats);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        r = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, T * row_floats * 4, 0x00020000);
+    }
+    __device__ __forceinline__ float4 ld4(int row, int col) const {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (row * ld + col) * 4, 0, 0));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __device__ __forceinline__ float2 ld2(int row, int col) const {
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (row * ld + col) * 4, 0, 0);
+        return make_float2(__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]));
+    }
+    __device__ __forceinline__ float ld1(int row, int col) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (row * ld + col) * 4, 0, 0));
+    }
+    __device__ __forceinline__ void st4(int row, int col, float4 v) const {
+        const f32x4 t = {v.x, v.y, v.z, v.w};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(attn_v4u, t), r, (row * ld + col) * 4, 0, 0);
+    }
+};
+
+__device__ __forceinline__ float f4comp(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// one head's operands in their matrix-core lane layouts: row fragments of Q, K, V, dO, O (float4 along the head dim: lane (m, g) holds
+// row 16 t + m, dims 4 g .. 4 g + 3) and the transposed dword fragments K^T (phase 1), Q^T, dO^T (phase 2): lane (m, g) holds
+// row 16 t + 4 g + r, dim m.  Rows past T are zeros.
+struct AttnBwdOps {
+    float4 kfr[4], vfr[4], qfr[4], dofr[4], ofr[4];
+    float2 str[4];
+    float kt[4][4], qts[4][4], dots[4][4];
+    unsigned long long kw_own;                          // dropout keep word (64 keys) of query row `lane`
+};
+
+// every operand of BOTH phases is requested here, up front, without a wait (one exposure of the memory latency; a caller with
+// registers to spare requests its next head's operands before it computes this one)
+template <int NT>
+__device__ __forceinline__ void attn_bwd_load(AttnBwdOps& o, const AttnArgs& a, int g, int b, long long rowbase, int h) {
+    const int T = a.T, D = a.D, H = a.H;
+    const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
+    const SeqBuf bq(a.q, rowbase, T, D), bk(a.k, rowbase, T, D), bv(a.v, rowbase, T, D), bo(a.o, rowbase, T, D), bdo(a.d_o, rowbase, T, D),
+                 bst(a.stats, rowbase, T, 2 * H);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        o.kfr[t] = bk.ld4(t * 16 + m, col4);
+        o.vfr[t] = bv.ld4(t * 16 + m, col4);
+        o.qfr[t] = bq.ld4(t * 16 + m, col4);
+        o.dofr[t] = bdo.ld4(t * 16 + m, col4);
+        o.ofr[t] = bo.ld4(t * 16 + m, col4);
+        o.str[t] = make_float2(bst.ld1(t * 16 + m, 2 * h), bst.ld1(t * 16 + m, 2 * h + 1));
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o.kt[t][r] = bk.ld1(t * 16 + 4 * gq + r, colm);
+            o.qts[t][r] = bq.ld1(t * 16 + 4 * gq + r, colm);
+            o.dots[t][r] = bdo.ld1(t * 16 + 4 * gq + r, colm);
+        }
+    o.kw_own = ~0ull;
+    if (a.train) {
+        const int qrow = min(lane, T - 1);
+        o.kw_own = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step,
+                                 (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
+    }
+}
+
+// dq, dk, dv of the head's 16 columns.  stat_lds: this wave's [3][64] floats (row max, 1 / row sum, delta of the query rows), keepw: its
+// [64] dropout keep words.  NT = ceil(T / 16) key / query tiles, all of them computed without a branch (rows past T are zeros and
+// their results are not stored).  Every group of matrix instructions runs over independent accumulators (a dependent
+// v_mfma_f32_16x16x4_f32 chain issues at 40 cycles per instruction against 32).
+template <int NT>
+__device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& a, long long rowbase, int h, float* __restrict__ stat_lds,
+                                                 unsigned long long* __restrict__ keepw) {
+    const int T = a.T, D = a.D;
+    const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    const int col4 = h * AHD + 4 * gq;
+    const SeqBuf bdq(a.dq, rowbase, T, D), bdk(a.dk, rowbase, T, D), bdv(a.dv, rowbase, T, D);
+    float* smax = stat_lds; float* srl = stat_lds + 64; float* sdl = stat_lds + 128;
+    keepw[lane] = o.kw_own;                                                               // row index = 16 gq + m = lane
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        o.qfr[t] = f4scale(o.qfr[t], a.scale);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.qts[t][r] *= a.scale;
+    }
+    // ---------------- phase 1: lanes = queries -> dQ; row stats + keep words to LDS ----------------
+#pragma unroll
+    for (int qi = 0; qi < NT; ++qi) {
+        const int q = qi * 16 + m;
+        const float4 qf = o.qfr[qi], dof = o.dofr[qi];
+        const float delta = quad_group_sum(f4hsum(f4mul(dof, o.ofr[qi])));
+        const float mrow = o.str[qi].x, rl = o.str[qi].y;
+        smax[q] = mrow; srl[q] = rl; sdl[q] = delta;          // (all four lane groups of a row hold the same values: no branch)
+        const unsigned long long kw = shfl64(o.kw_own, q);
+        const unsigned kwh[2] = {(unsigned)kw, (unsigned)(kw >> 32)};
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int kj = 0; kj <= qi; ++kj) { s[kj] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kj] = s[kj]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int kj = 0; kj <= qi; ++kj) {
+                s[kj] = mfma4(f4comp(o.kfr[kj], c), f4comp(qf, c), s[kj]);
+                dp[kj] = mfma4(f4comp(o.vfr[kj], c), f4comp(dof, c), dp[kj]);
+            }
+        f32x4 dqa = f32x4{0.f, 0.f, 0.f, 0.f}, dqb = dqa;
+#pragma unroll
+        for (int kj = 0; kj <= qi; ++kj) {
+            const unsigned bits = kwh[kj >> 1] >> ((kj & 1) * 16 + 4 * gq);              // this lane's keys 16 kj + 4 gq + r: bits 0..3
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = kj * 16 + 4 * gq + r;
+                float p = fast_exp(s[kj][r] - mrow) * rl;
+                if (kj == qi) p = (n > q) ? 0.f : p;                                    // the diagonal tile's upper triangle
+                const float dpk = ((bits >> r) & 1u) ? dp[kj][r] * a.dscale : 0.f;
+                const float ds = p * (dpk - delta);
+                if (r & 1) dqb = mfma4(o.kt[kj][r], ds, dqb); else dqa = mfma4(o.kt[kj][r], ds, dqa);
+            }
+        }
+        dqa += dqb;
+        bdq.st4(q, col4, make_float4(dqa[0] * a.scale, dqa[1] * a.scale, dqa[2] * a.scale, dqa[3] * a.scale));
+    }
+    // no workgroup barrier here: the LDS scratch of a wave is written and read by that wave only (LDS operations of one wave
+    // complete in order), and without it the waves of a workgroup drift apart -- the late ones' loads overlap the early ones' MFMAs
+    // ---------------- phase 2: lanes = keys -> dK, dV (operands already in registers) ----------------
+    // the statistics and keep words of this lane's 16 query columns (16 qi + 4 gq + r), read once for all key tiles
+    STRIP_RSTAMP(18);
+    float4 mx4[4], rl4[4], dl4[4];
+    unsigned kq[4][4][2];
+#pragma unroll
+    for (int qi = 0; qi < NT; ++qi) {
+        mx4[qi] = ld4(smax + qi * 16 + 4 * gq); rl4[qi] = ld4(srl + qi * 16 + 4 * gq); dl4[qi] = ld4(sdl + qi * 16 + 4 * gq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long w = keepw[qi * 16 + 4 * gq + r];
+            kq[qi][r][0] = (unsigned)w; kq[qi][r][1] = (unsigned)(w >> 32);
+        }
+    }
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj) {
+        const int key = kj * 16 + m;
+        const float4 kf = o.kfr[kj], vf = o.vfr[kj];
+        f32x4 st[4], dpt[4];
+#pragma unroll
+        for (int qi = kj; qi < NT; ++qi) { st[qi] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[qi] = st[qi]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int qi = kj; qi < NT; ++qi) {
+                st[qi] = mfma4(f4comp(o.qfr[qi], c), f4comp(kf, c), st[qi]);             // S^T: lane (key m, gq), reg r <-> query 16 qi + 4 gq + r
+                dpt[qi] = mfma4(f4comp(o.dofr[qi], c), f4comp(vf, c), dpt[qi]);
+            }
+        f32x4 dka = f32x4{0.f, 0.f, 0.f, 0.f}, dkb = dka, dva = dka, dvb = dka;
+#pragma unroll
+        for (int qi = kj; qi < NT; ++qi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = qi * 16 + 4 * gq + r;
+                const bool keep = (kq[qi][r][kj >> 1] >> ((kj & 1) * 16 + m)) & 1u;
+                // (a query row past T has 1 / row sum = 0: p = 0 without a test)
+                float p = fast_exp(st[qi][r] - f4comp(mx4[qi], r)) * f4comp(rl4[qi], r);
+                if (qi == kj) p = (key <= qq) ? p : 0.f;
+                const float pd = keep ? p * a.dscale : 0.f;
+                const float dpk = keep ? dpt[qi][r] * a.dscale : 0.f;
+                const float ds = p * (dpk - f4comp(dl4[qi], r));
+                if (r & 1) { dvb = mfma4(o.dots[qi][r], pd, dvb); dkb = mfma4(o.qts[qi][r], ds, dkb); }
+                else       { dva = mfma4(o.dots[qi][r], pd, dva); dka = mfma4(o.qts[qi][r], ds, dka); }
+            }
+        dka += dkb; dva += dvb;
+        bdk.st4(key, col4, make_float4(dka[0], dka[1], dka[2], dka[3]));
+        bdv.st4(key, col4, make_float4(dva[0], dva[1], dva[2], dva[3]));
+    }
+}
+
+// the LDS scratch of a wave: [3][64] floats of row statistics + [64] keep words
+constexpr int ATTN_BWD_LDS_PER_WAVE = 3 * 64 * 4 + 64 * 8;
+
+template <int NT>
+__device__ __forceinline__ void attn_bwd_head(const AttnArgs& a, int g, int b, long long rowbase, int h, float* __restrict__ stat_lds,
+                                              unsigned long long* __restrict__ keepw) {
+    AttnBwdOps o;
+    STRIP_RSTAMP(16);                                   // (diagnostic builds of sasrec_strip.hip only)
+    attn_bwd_load<NT>(o, a, g, b, rowbase, h);
+    STRIP_RSTAMP(17);
+    attn_bwd_compute<NT>(o, a, rowbase, h, stat_lds, keepw);
+}
 
 }  // namespace amid

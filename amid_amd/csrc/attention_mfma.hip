@@ -44,11 +44,8 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
     const int g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
     const int wv = wave_id(), h = part * hw + wv, lane = lane_id();
-    const int m = lane & 15, gq = lane >> 4;
-    const int NT = (T + 15) >> 4;
-    const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
-    float4* rstat = reinterpret_cast<float4*>(smem) + wv * 64;                          // [hw][64] (max, 1/sum, delta, -)
-    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(smem + hw * 64 * 4) + wv * 64;   // [hw][64]
+    float* stat_lds = smem + wv * 3 * 64;                                                 // [hw][3][64] (max, 1 / sum, delta)
+    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(smem + hw * 3 * 64) + wv * 64;   // [hw][64]
     if (!live) {                                                                       // no gradient reaches this sequence: exact zeros
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = lane; i < T * (AHD / 4); i += 64) {
@@ -62,105 +59,11 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
         for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);       // 127 x 64 clocks each
     }
 
-    // Every operand of BOTH phases is requested here, up front (one exposure of the memory latency per workgroup instead of
-    // two): row fragments of Q, K, V, dO, O (float4 along the head dim) and the transposed dword fragments K^T (phase 1), Q^T,
-    // dO^T (phase 2).  The first version reloaded Q, dO, K, V after the barrier between the phases.
-    float4 kfr[4], vfr[4], qfr[4], dofr[4];
-    float qts[4][4], dots[4][4];
-    {
-        float kt[4][4];
-        float4 ofr[4];
-        float2 str[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            kfr[t] = ld4_row(a.k, rowbase, t * 16 + m, T, D, col4);
-            vfr[t] = ld4_row(a.v, rowbase, t * 16 + m, T, D, col4);
-            qfr[t] = f4scale(ld4_row(a.q, rowbase, t * 16 + m, T, D, col4), a.scale);
-            dofr[t] = ld4_row(a.d_o, rowbase, t * 16 + m, T, D, col4);
-            ofr[t] = ld4_row(a.o, rowbase, t * 16 + m, T, D, col4);
-            str[t] = *reinterpret_cast<const float2*>(a.stats + ((rowbase + min(t * 16 + m, T - 1)) * H + h) * 2);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) kt[t][r] = ld1_row(a.k, rowbase, t * 16 + 4 * gq + r, T, D, colm);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                qts[t][r] = ld1_row(a.q, rowbase, t * 16 + 4 * gq + r, T, D, colm) * a.scale;
-                dots[t][r] = ld1_row(a.d_o, rowbase, t * 16 + 4 * gq + r, T, D, colm);
-            }
-        // ---------------- phase 1: lanes = queries -> dQ; row stats + keep words to LDS ----------------
-        unsigned long long kw_own = ~0ull;
-        if (a.train) {
-            const int qrow = min(gq * 16 + m, T - 1);
-            kw_own = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step,
-                                   (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
-        }
-        keepw[lane] = kw_own;                                                            // row index = 16 gq + m = lane
-#pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-            if (qi >= NT) break;
-            const int q = qi * 16 + m;
-            const float4 qf = qfr[qi], dof = dofr[qi], of = ofr[qi];
-            const float delta = quad_group_sum(f4hsum(f4mul(dof, of)));
-            const float mrow = str[qi].x, rl = str[qi].y;
-            if (gq == 0) rstat[q] = make_float4(mrow, rl, delta, 0.f);
-            const unsigned long long kw = shfl64(kw_own, qi * 16 + m);
-            f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kj = 0; kj < 4; ++kj) {
-                if (kj <= qi) {
-                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
-                    s = mfma_frag(kfr[kj], qf, s);
-                    dp = mfma_frag(vfr[kj], dof, dp);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = kj * 16 + 4 * gq + r;
-                        const float p = (n > q) ? 0.f : fast_exp(s[r] - mrow) * rl;
-                        const float dpk = ((kw >> n) & 1ull) ? dp[r] * a.dscale : 0.f;
-                        const float ds = p * (dpk - delta);
-                        dq = mfma4(kt[kj][r], ds, dq);
-                    }
-                }
-            }
-            if (q < T) st4(a.dq + (rowbase + q) * D + col4, make_float4(dq[0] * a.scale, dq[1] * a.scale, dq[2] * a.scale, dq[3] * a.scale));
-        }
-    }
-    // no workgroup barrier here: rstat / keepw of a wave are written and read by that wave only (LDS operations of one wave
-    // complete in order), and without it the waves of a workgroup drift apart -- the late ones' loads overlap the early ones' MFMAs
-    // ---------------- phase 2: lanes = keys -> dK, dV (operands already in registers) ----------------
-#pragma unroll
-    for (int kj = 0; kj < 4; ++kj) {
-        if (kj >= NT) break;
-        const int key = kj * 16 + m;
-        const float4 kf = kfr[kj], vf = vfr[kj];
-        f32x4 dk = f32x4{0.f, 0.f, 0.f, 0.f}, dv = dk;
-#pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-            if (qi < kj || qi >= NT) continue;
-            const float4 qf = qfr[qi], dof = dofr[qi];
-            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = st;
-            st = mfma_frag(qf, kf, st);                  // S^T: lane (key m, gq), reg r <-> query qi*16 + 4 gq + r
-            dpt = mfma_frag(dof, vf, dpt);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qq = qi * 16 + 4 * gq + r;
-                const float qt = qts[qi][r], dot = dots[qi][r];
-                const float4 rs = rstat[min(qq, 63)];
-                const bool live = (qq < T) && (key <= qq);
-                const bool keep = (keepw[min(qq, 63)] >> key) & 1ull;
-                const float p = live ? fast_exp(st[r] - rs.x) * rs.y : 0.f;
-                const float pd = keep ? p * a.dscale : 0.f;
-                const float dpk = keep ? dpt[r] * a.dscale : 0.f;
-                const float ds = p * (dpk - rs.z);
-                dv = mfma4(dot, pd, dv);
-                dk = mfma4(qt, ds, dk);
-            }
-        }
-        if (key < T) {
-            st4(a.dk + (rowbase + key) * D + col4, make_float4(dk[0], dk[1], dk[2], dk[3]));
-            st4(a.dv + (rowbase + key) * D + col4, make_float4(dv[0], dv[1], dv[2], dv[3]));
-        }
+    switch ((T + 15) >> 4) {
+        case 1: attn_bwd_head<1>(a, g, b, rowbase, h, stat_lds, keepw); break;
+        case 2: attn_bwd_head<2>(a, g, b, rowbase, h, stat_lds, keepw); break;
+        case 3: attn_bwd_head<3>(a, g, b, rowbase, h, stat_lds, keepw); break;
+        default: attn_bwd_head<4>(a, g, b, rowbase, h, stat_lds, keepw); break;
     }
 }
 
@@ -198,7 +101,7 @@ int amid_attn_mfma_bwd_launch(const void* args, void* stream) {
     // phase is too short to be worth waiting for: 0: 22.2 us, 1: 23.8, 2: 25.7
     const int nt = (a.T + 15) >> 4;
     a.stagger_sleeps = nt >= 4 ? 2 : nt == 3 ? 1 : 0;
-    const size_t lds = (size_t)hw * 64 * (16 + 8);
+    const size_t lds = (size_t)hw * ATTN_BWD_LDS_PER_WAVE;
     attn_bwd_mfma_kernel<<<grid, hw * 64, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;

@@ -17,6 +17,7 @@
 #include "rng.h"
 #include "strip_gemm.h"
 #include "sort_phases.h"
+#include "attention_mfma.h"
 
 namespace amid {
 
@@ -306,10 +307,12 @@ __device__ __forceinline__ void ffn_bwd_prefetch(FfnBwdPre<D>& p, const StripFfn
     p.gam.load(a.ln_w[g]);
 }
 
-// d x' (DZ, in registers) -> dpre2, dpre1, dr, d_o of this layer; the ring's current fetch must be w2T
-template <int D>
+// d x' (DZ, in registers) -> dpre2, dpre1, dr, d_o of this layer; the ring's current fetch must be w2T.  TAIL: a slab (`tail`) is
+// fetched under the last MFMA loop (a fused successor's first weight)
+template <int D, bool TAIL = false>
 __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const StripGeom& sg, Ring<D>& ring, const StripRow& row, int g,
-                                              StripRegs<D>& DZ, FfnBwdPre<D>& pre, float* __restrict__ scratch) {
+                                              StripRegs<D>& DZ, FfnBwdPre<D>& pre, float* __restrict__ scratch,
+                                              const float* __restrict__ tail = nullptr) {
     constexpr int NT = D / 16;
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
@@ -343,7 +346,10 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
     {   // d_o = dr Wo
         const float* buf = ring.next();
         strip_zero<D>(acc);
-        strip_mma<D>(acc, DR, buf, [&](int ct, int j) { store_spread<D>(gdr, row, DR, ct, j); });
+        strip_mma<D>(acc, DR, buf, [&](int ct, int j) {
+            if constexpr (TAIL) ring.fetch(tail, ct, j);
+            store_spread<D>(gdr, row, DR, ct, j);
+        });
         to_regs<D>(P, acc);
         strip_store<D>(gdo, row, P);
     }
@@ -451,6 +457,99 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const Stri
     __syncthreads();
     ln_partials_out<D>(ln_scratch<D>(smem, 0), a.ln_part + (long long)t.slot * 2 * D);
     if constexpr (FFN) ln_partials_out<D>(ln_scratch<D>(smem, 1), f.ln_part + (long long)t.slot * 2 * D);
+}
+
+
+// ================================================================================================ the whole backward of a sequence
+// ONE launch for the encoder's data gradients of a train step: per layer, top down, the feed-forward / out-projection chain, the
+// attention core's backward (attention_mfma.h) and the q / k / v + LayerNorm-1 chain, for the LIVE sequences only -- the launches of
+// strip_ffn_bwd, attn_bwd, strip_qkv_bwd [+ strip_ffn_bwd], attn_bwd, strip_qkv_bwd as one workgroup-long chain per sequence.
+// A workgroup owns one sequence (T <= 64: four strips, as the fused forward's WPS = 4 tiling), so the attention core sees all of
+// its rows: wave w computes heads w and w + 4.  The chains keep d x in registers from layer to layer; the attention core exchanges
+// through global memory (d_o written by the chain, dq / dk / dv read by the next one -- the weight-gradient launch needs those
+// copies anyway): a workgroup barrier behind a vmcnt(0) makes a workgroup's stores visible to its own loads (same CU, same L1).
+// What it saves is every launch boundary's tail and head -- the last stores, the launch, the first weight slab, the first
+// operand loads: the next chain's first slab lands under the attention core and its operands are L2 hits.
+struct SeqBwdLayer {
+    StripFfnBwdArgs f;                  // f.dxo: the top layer's only; f.ln_part / a.ln_part: [2 B][2][D], slot g * B + (index in the domain's live list)
+    StripQkvBwdArgs a;                  // a.dx: layer 0's only
+    AttnArgs at;
+};
+struct SeqBwdArgs { SeqBwdLayer L[2]; int n_layers; };
+
+template <int D>
+__global__ __launch_bounds__(STRIP_THREADS) void seq_bwd_kernel(const SeqBwdArgs a, const StripGeom sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    const int B = sg.B, T = sg.T;
+    // workgroup -> live sequence: the live list holds domain 0's batch rows, then domain 1's (contiguous ranges: see seq_fwd_kernel)
+    const int n0 = sg.live[B], n1 = B - n0;
+    const int g = bid >= n0 ? 1 : 0;
+    const int tl = bid - (g ? n0 : 0);
+    const int top = a.n_layers - 1;
+    Ring<D> ring(smem);
+    ring.first(a.L[top].f.w2T[g]);
+    const int b = sg.live[bid];
+    const int slot = g * B + tl;
+    {   // the B slots without a live sequence (domain 0: [n0, B), domain 1: [n1, B)) hold zeros: workgroup j writes dead slot j
+        const int dslot = bid < n1 ? n0 + bid : B + n1 + (bid - n1);
+        for (int l = 0; l <= top; ++l) { zero_slot<D>(a.L[l].f.ln_part, dslot); zero_slot<D>(a.L[l].a.ln_part, dslot); }
+    }
+    const int t = w * 16 + m;
+    StripRow row;
+    row.ok = t < T;
+    row.local = b * T + min(t, T - 1);
+    const unsigned phys = (unsigned)g * (unsigned)sg.M + (unsigned)(b * T + t);
+    row.off = row.ok ? phys * (unsigned)(D * 4) + 16u * (unsigned)gq : STRIP_OOB;
+    const long long rowbase = (long long)g * sg.M + (long long)b * T;
+    float* att = smem + 2 * D * D + 16 * D;                                       // behind the ring and the two LayerNorm scratch blocks
+    float* stat_lds = att + w * 3 * 64;
+    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(att + STRIP_WAVES * 3 * 64) + w * 64;
+
+    STRIP_RSTAMP(0);
+    STRIP_STAMP(14);
+    StripRegs<D> DZ;
+    FfnBwdPre<D> pre;
+    strip_load<D>(DZ, GBuf(a.L[top].f.dxo, sg.act_bytes), row);
+    ffn_bwd_prefetch<D>(pre, a.L[top].f, sg, row, g);
+#pragma unroll 1
+    for (int l = top; l >= 0; --l) {
+        const SeqBwdLayer& P = a.L[l];
+        const SeqBwdLayer& Pn = a.L[l > 0 ? l - 1 : 0];
+        [[maybe_unused]] const int sb = 1 + 6 * (top - l);                // (diagnostic builds: real-time stamps of workgroup 0)
+        ffn_bwd_chain<D, true>(P.f, sg, ring, row, g, DZ, pre, ln_scratch<D>(smem, 0), P.a.wkT[g]);
+        STRIP_RSTAMP(sb);
+        w_ring_wait();                  // d_o has reached L2 (the Wk slab has landed as well: it was requested half a GEMM ago)
+        __syncthreads();
+        ln_partials_out<D>(ln_scratch<D>(smem, 0), P.f.ln_part + (long long)slot * 2 * D);
+        STRIP_RSTAMP(sb + 1);
+        if (T > 48) {
+            attn_bwd_head<4>(P.at, g, b, rowbase, w, stat_lds, keepw);
+            STRIP_RSTAMP(sb + 2);
+            attn_bwd_head<4>(P.at, g, b, rowbase, w + STRIP_WAVES, stat_lds, keepw);
+        } else {
+            attn_bwd_head<3>(P.at, g, b, rowbase, w, stat_lds, keepw);
+            STRIP_RSTAMP(sb + 2);
+            attn_bwd_head<3>(P.at, g, b, rowbase, w + STRIP_WAVES, stat_lds, keepw);
+        }
+        STRIP_RSTAMP(sb + 3);
+        w_ring_wait();                  // dq / dk / dv have reached L2
+        __syncthreads();
+        STRIP_RSTAMP(sb + 4);
+        StripRegs<D> DX;
+        // (layer 0 "prefetches" its own w2T into the free buffer: harmless, waited for at the end)
+        qkv_bwd_chain<D, true>(P.a, sg, ring, row, g, DX, ln_scratch<D>(smem, 1), Pn.f.w2T[g],
+                               [&]() { if (l > 0) ffn_bwd_prefetch<D>(pre, Pn.f, sg, row, g); });
+        STRIP_RSTAMP(sb + 5);
+        __syncthreads();
+        ln_partials_out<D>(ln_scratch<D>(smem, 1), P.a.ln_part + (long long)slot * 2 * D);
+        if (l == 0) strip_store<D>(GBuf(P.a.dx, sg.act_bytes), row, DX);
+        DZ = DX;
+    }
+    STRIP_RSTAMP(13);
+    STRIP_STAMP(15);
+    w_ring_wait();
 }
 
 }  // namespace amid
@@ -668,4 +767,71 @@ extern "C" int amid_sas_strip_qkv_bwd_sort_f32(const float* dq, const float* dk,
     AMID_CHECK_ARG(sort_plan != nullptr);
     return strip_qkv_bwd(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, B, T, D, live, dx, ln_part, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, flayer,
                          step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, sort_plan, sort_phase, stream);
+}
+
+// ---- the fused per-sequence backward ------------------------------------------------------------------------------------------------
+template <int D> static constexpr size_t seq_bwd_lds_bytes() { return strip_lds_bytes<D>() + (size_t)STRIP_WAVES * ATTN_BWD_LDS_PER_WAVE; }
+
+// 1 when amid_sas_seq_bwd_f32 covers the shape: D = 128 with 8 heads of 16, 32 < T <= 64 (one sequence per workgroup), activations
+// within 2 GiB
+extern "C" int amid_sas_seq_bwd_supported(int B, int T, int D, int H) {
+    return (D == 128 && H == 8 && T > 32 && T <= 64 && B > 0 && 2LL * B * T * D * 4 <= 0x7FFFFFF0LL) ? 1 : 0;
+}
+
+// The data gradients of the encoder for the live sequences of a train step in one launch (seq_bwd_kernel).  Per-layer arrays hold
+// n_layers entries (saved tensors, gradient outputs, LayerNorm partials) or 2 * n_layers ordered [layer][domain] (parameters and
+// transposed weights).  dxo: gradient of the last layer's output; dx: gradient of layer 0's input (rows of live sequences only; the
+// others are not touched).  ln1_part / ln2_part: per layer [2 B][2][D], domain g's slots are [g B, (g + 1) B), the first n_g of them
+// the live sequences' partial sums, the rest zeros.  live: amid_live_list_i32 (required).
+extern "C" int amid_sas_seq_bwd_f32(int n_layers, const float* dxo, const unsigned char* tmq, const float* const* h, const float* const* r,
+                                    const float* const* x, const float* const* q, const float* const* k, const float* const* v,
+                                    const float* const* o, const float* const* stats, const float* const* ln1_w,
+                                    const float* const* ln2_w, const float* const* wqT, const float* const* wkT, const float* const* wvT,
+                                    const float* const* woT, const float* const* w1T, const float* const* w2T, float ln_eps, int B, int T,
+                                    int D, int H, const int* live, const void* step_state, int train, float p_drop, float* const* dpre2,
+                                    float* const* dpre1, float* const* dr, float* d_o, float* const* dq, float* const* dk, float* const* dv,
+                                    float* dx, float* const* ln1_part, float* const* ln2_part, void* stream) {
+    AMID_CHECK_ARG(n_layers >= 1 && n_layers <= 2 && dxo && h && r && x && q && k && v && o && stats && ln1_w && ln2_w && wqT && wkT && wvT &&
+                   woT && w1T && w2T && live && dpre2 && dpre1 && dr && d_o && dq && dk && dv && dx && ln1_part && ln2_part &&
+                   (!train || step_state));
+    if (!amid_sas_seq_bwd_supported(B, T, D, H)) return AMID_ERR_UNSUPPORTED;
+    SeqBwdArgs a = {};
+    a.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        SeqBwdLayer& P = a.L[l];
+        AMID_CHECK_ARG(h[l] && r[l] && x[l] && q[l] && k[l] && v[l] && o[l] && stats[l] && dpre2[l] && dpre1[l] && dr[l] && dq[l] && dk[l] &&
+                       dv[l] && ln1_part[l] && ln2_part[l]);
+        for (int g = 0; g < 2; ++g) {
+            const int i = 2 * l + g;
+            AMID_CHECK_ARG(ln1_w[i] && ln2_w[i] && wqT[i] && wkT[i] && wvT[i] && woT[i] && w1T[i] && w2T[i]);
+        }
+        fill_ffn_bwd(P.f, l + 1 == n_layers ? dxo : nullptr, tmq, h[l], r[l], ln2_w + 2 * l, w1T + 2 * l, w2T + 2 * l, woT + 2 * l, ln_eps, l,
+                     step_state, train, p_drop, dpre2[l], dpre1[l], dr[l], d_o, ln2_part[l]);
+        P.a.dq = dq[l]; P.a.dk = dk[l]; P.a.dv = dv[l]; P.a.dr = dr[l]; P.a.x = x[l]; P.a.dx = l == 0 ? dx : nullptr;
+        P.a.ln_part = ln1_part[l]; P.a.ln_eps = ln_eps;
+        for (int g = 0; g < 2; ++g) {
+            P.a.ln_w[g] = ln1_w[2 * l + g]; P.a.wqT[g] = wqT[2 * l + g]; P.a.wkT[g] = wkT[2 * l + g]; P.a.wvT[g] = wvT[2 * l + g];
+        }
+        AttnArgs& at = P.at;
+        at.q = q[l]; at.k = k[l]; at.v = v[l]; at.o = const_cast<float*>(o[l]); at.stats = const_cast<float*>(stats[l]);
+        at.d_o = d_o; at.dq = dq[l]; at.dk = dk[l]; at.dv = dv[l];
+        at.B = B; at.T = T; at.D = D; at.H = H; at.causal = 1; at.layer = l;
+        at.scale = sqrtf(1.0f / (float)(D / H));
+        at.st = (const StepState*)step_state;
+        at.train = (train && p_drop > 0.f) ? 1 : 0;
+        at.thr16 = drop_spec(p_drop);
+        at.dscale = at.train ? 1.0f / (1.0f - p_drop) : 1.0f;
+        at.stagger_from = -1;
+    }
+    StripGeom sg;
+    if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)seq_bwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_bwd_lds_bytes<128>());
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    seq_bwd_kernel<128><<<B, STRIP_THREADS, seq_bwd_lds_bytes<128>(), (hipStream_t)stream>>>(a, sg);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? AMID_OK : (int)e;
 }

@@ -241,6 +241,13 @@ class SasrecPlan:
                                 if eng.SHORT_TILE_BUILDS else "")
             self.ln1_part_v = [f(2 * self.tpg_v, 2, D) for _ in range(2)]
             self.ln2_part_v = [f(2 * self.tpg_v, 2, D) for _ in range(2)]
+        # the fused per-sequence backward (csrc/sasrec_strip.hip seq_bwd_kernel) tiles one live sequence per workgroup: its LayerNorm
+        # partials have a slot per sequence and their own reduce table
+        self.seq_bwd = bool(self.strip and self.live_rows and getattr(eng, "SEQ_BACKWARD", False) and not inc
+                            and L.value("amid_sas_seq_bwd_supported", B, shp.Tenc, D, H))
+        if self.seq_bwd:
+            self.ln1_part_s = [f(2 * B, 2, D) for _ in range(2)]
+            self.ln2_part_s = [f(2 * B, 2, D) for _ in range(2)]
         self.last_part = f(2 * B, 2, D)
         self._alloc_model_bwd(eng, f)
         self.sc_P = L.value("amid_scorer_part_floats", D, hid)
@@ -261,6 +268,8 @@ class SasrecPlan:
             self.red_entries_v, self.red_n_v, self.red_max_v = self.red_entries, self.red_n, self.red_max
         elif self.live_rows:
             self.red_entries_v, self.red_n_v, self.red_max_v = self._build_reduce_table(eng, live=True)
+        if self.seq_bwd:
+            self.red_entries_s, self.red_n_s, self.red_max_s = self._build_reduce_table(eng, live=True, seq=True)
         self.graph = None
         self.graphs = {}
 
@@ -287,7 +296,7 @@ class SasrecPlan:
 
     LIVE_ROWS_BWD = True       # BertPlan: False (its backward kernels take no row_domain hint)
 
-    def _build_reduce_table(self, eng: "SasrecEngine", live: bool = False):
+    def _build_reduce_table(self, eng: "SasrecEngine", live: bool = False, seq: bool = False):
         L = lib()
         D, hid, B = eng.D, eng.hid, self.shape.B
         fp, G = eng.dense, eng.dense.grad
@@ -296,7 +305,9 @@ class SasrecPlan:
         def add(src_t: torch.Tensor, src_off: int, dst_ptr: int, stride: int, n_part: int, count: int):
             ent.append((src_t.data_ptr() + 4 * src_off, dst_ptr, stride, n_part, count))
 
-        if live:
+        if seq:
+            self._model_reduce_entries(eng, add, seq=True)
+        elif live:
             self._model_reduce_entries(eng, add, live=True)
         else:
             self._model_reduce_entries(eng, add)
@@ -317,7 +328,8 @@ class SasrecPlan:
         # dependent loads: dispatch them first, so that they do not form the tail of the launch
         ent.sort(key=lambda e: -e[3])
         # algorithmic HBM bytes of the partial-sum reduce (every partial read once, every sum written once): bench.py prices the launch
-        setattr(self, "red_bytes_v" if live else "red_bytes", sum(4 * (n + 1) * c for *_, n, c in ent))
+        sfx = "_s" if seq else "_v" if live else ""
+        setattr(self, "red_bytes" + sfx, sum(4 * (n + 1) * c for *_, n, c in ent))
         esz = L.value("amid_reduce_entry_bytes")
         host = (ctypes.c_ubyte * (esz * len(ent)))()
         for i, (s, d, st, n, c) in enumerate(ent):
@@ -329,16 +341,18 @@ class SasrecPlan:
             per = 1024 if (n <= 32 and c % 4 == 0 and st % 4 == 0 and s % 16 == 0 and d % 16 == 0) else 128
             off.append(off[-1] + min(512, (c + per - 1) // per))
         blk = torch.tensor(off, dtype=torch.int32).to(eng.device)
-        setattr(self, "red_blk_v" if live else "red_blk", (blk, off[-1]))
+        setattr(self, "red_blk" + sfx, (blk, off[-1]))
         return torch.frombuffer(bytearray(host), dtype=torch.uint8).to(eng.device), len(ent), max(c for *_, c in ent)
 
-    def _model_reduce_entries(self, eng: "SasrecEngine", add, live: bool = False) -> None:
+    def _model_reduce_entries(self, eng: "SasrecEngine", add, live: bool = False, seq: bool = False) -> None:
         D, B = eng.D, self.shape.B
         fp, G = eng.dense, eng.dense.grad
         S = self.splits
         ln1, ln2, tpg = (self.ln1_part_v, self.ln2_part_v, self.tpg_v) if live else (self.ln1_part, self.ln2_part, self.tpg)
         if getattr(self, "strip", False):
             tpg = self.stpg
+        if seq:             # one slot per sequence and domain (amid_sas_seq_bwd_f32)
+            ln1, ln2, tpg = self.ln1_part_s, self.ln2_part_s, B
         for l in (0, 1):
             for g in (0, 1):
                 pre = f"sac{g + 1}"
@@ -631,6 +645,7 @@ class SasrecEngine:
         # ... and the step's index sort rides in main-stream launches (catch-up + the three strip backward launches carry one phase
         # each as extra workgroups: no side stream, no fork, no join) when the keys fit the riders' 1024-bin build
         pl.riding = bool(bump_step and sparse and defer_sort and self.SORT_RIDERS and getattr(pl, "strip", False) and not pl.compact
+                         and not self._seq_backward(pl)             # (the fused backward is one launch: three of the riders' hosts are gone)
                          and (shp.n_idx + 2047) // 2048 <= 2 * shp.Tenc and self._sort_plan(pl) is not None)
         ent = self.input_pool(pl)
         if ent is not None:
@@ -694,6 +709,11 @@ class SasrecEngine:
             self._sort_pending = False
 
     SORT_RIDERS = os.environ.get("AMID_SORT_RIDERS", "1") != "0"
+    # the train step's encoder backward (data gradients) as ONE launch over the live sequences where csrc/sasrec_strip.hip covers the shape
+    SEQ_BACKWARD = os.environ.get("AMID_SEQ_BACKWARD", "1") != "0"
+
+    def _seq_backward(self, pl: SasrecPlan) -> bool:
+        return bool(self.SEQ_BACKWARD and getattr(pl, "seq_bwd", False) and not self.itc_bs)
 
     def _sort_plan(self, pl: SasrecPlan):
         """Host address of the plan of the step's index sort (amid_sort_plan_pack), or None when the riders do not cover it."""
@@ -1012,7 +1032,26 @@ class SasrecEngine:
         tm, h1, r1, lnw1, w1T1, w2T1, woT1 = ffn_bwd_args(1)
         tm, h0, r0, lnw0, w1T0, w2T0, woT0 = ffn_bwd_args(0)
         dx_in = (pl.dx0 if self.inc_bs else pl.dxg).data_ptr()
-        if pl.strip:
+        seq = bool(pl.strip and lv is not None and live and live_attn and self._seq_backward(pl))
+        if seq:
+            # the five launches below as one workgroup-long chain per live sequence
+            pa = lambda ts: ptr_array([t.data_ptr() for t in ts])          # noqa: E731
+            key = ("seq_bwd", id(pl))
+            c = self._ptr_cache.get(key)
+            if c is None:
+                def wts(which):
+                    return ptr_array([self.wT[l, g, which].data_ptr() for l in (0, 1) for g in (0, 1)])
+                def lnw(fmt):
+                    return ptr_array([fp.ptr(fmt.format(d=g + 1, l=l)) for l in (0, 1) for g in (0, 1)])
+                c = dict(h=pa(pl.h), r=pa(pl.r), x=pa(pl.x[:2]), q=pa(pl.q), k=pa(pl.k), v=pa(pl.v), o=pa(pl.o), stats=pa(pl.stats),
+                         ln1=lnw("sac{d}.attention_layernorms.{l}.weight"), ln2=lnw("sac{d}.forward_layernorms.{l}.weight"),
+                         wq=wts(0), wk=wts(1), wv=wts(2), wo=wts(3), w1=wts(4), w2=wts(5), dpre2=pa(pl.dpre2), dpre1=pa(pl.dpre1),
+                         dr=pa(pl.dr), dq=pa(pl.dq_l), dk=pa(pl.dk_l), dv=pa(pl.dv_l), ln1p=pa(pl.ln1_part_s), ln2p=pa(pl.ln2_part_s))
+                self._ptr_cache[key] = c
+            L.call("amid_sas_seq_bwd_f32", 2, pl.dxbuf.data_ptr(), tm, c["h"], c["r"], c["x"], c["q"], c["k"], c["v"], c["o"], c["stats"],
+                   c["ln1"], c["ln2"], c["wq"], c["wk"], c["wv"], c["wo"], c["w1"], c["w2"], SASREC_LN_EPS, B, T, D, self.H, lv, st, tr,
+                   SASREC_P_DROP, c["dpre2"], c["dpre1"], c["dr"], pl.d_o.data_ptr(), c["dq"], c["dk"], c["dv"], dx_in, c["ln1p"], c["ln2p"], s)
+        elif pl.strip:
             ln1p, ln2p = pl.ln1_part, pl.ln2_part
             # a train step's index sort rides in these three launches (phases 2, 3, 4; phase 1 rode in the catch-up launch)
             riding = getattr(pl, "riding", False)
@@ -1075,9 +1114,9 @@ class SasrecEngine:
                    self._pp("inc_d{d}.trans_bs.weight"), B, shp.T, D, pl.inc_dZ.data_ptr(), pl.inc_dS.data_ptr(), pl.inc_rows.data_ptr(),
                    self._pp("inc_d{d}.trans_nn.weight", G), self._pp("inc_d{d}.trans_nn.bias", G), self._pp("inc_d{d}.trans_bs.weight", G),
                    self._pp("inc_d{d}.trans_bs.bias", G), pl.dxg.data_ptr(), s)
-        self._enqueue_grad_tail(pl, live)
+        self._enqueue_grad_tail(pl, live, seq)
 
-    def _enqueue_grad_tail(self, pl: SasrecPlan, live: bool = False) -> None:
+    def _enqueue_grad_tail(self, pl: SasrecPlan, live: bool = False, seq: bool = False) -> None:
         """The two independent, bandwidth-bound ends of backward side by side in one launch: the fixed-order sum of every partial
         buffer (dense gradients + loss) and the segment reduce of the table-row gradients."""
         L, s, shp = lib(), self.s, pl.shape
@@ -1085,21 +1124,22 @@ class SasrecEngine:
             self.ev_idx.record(self.stream)
             self.enqueue_sort(pl)
         self.join_sort()                          # pos_sorted / seg_off come from the side-stream sort
-        blk = (getattr(pl, "red_blk_v", None) if live else None) or pl.red_blk       # per-entry block ranges of the partial sums
+        blk = (pl.red_blk_s if seq else getattr(pl, "red_blk_v", None) if live else None) or pl.red_blk   # per-entry block ranges of the partial sums
+        ent, n_ent, ent_max = ((pl.red_entries_s, pl.red_n_s, pl.red_max_s) if seq else (pl.red_entries_v, pl.red_n_v, pl.red_max_v) if live
+                               else (pl.red_entries, pl.red_n, pl.red_max))
         pk = getattr(self, "_tail_pack", None)
         if pk is not None:       # graph A of the data-parallel step: the tail also packs this rank's exchange chunk (ids | rows | dense)
             from .dist import packed_rows
             send, umax = pk
             id_rows, rows = packed_rows(umax, self.D)
             L.call("amid_grad_tail_pack_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), self.n_sparse(pl),
-                   self.D, pl.seg_ws.data_ptr(), send.data_ptr() + 4 * id_rows * self.D, (pl.red_entries_v if live else pl.red_entries).data_ptr(),
-                   pl.red_n_v if live else pl.red_n, pl.red_max_v if live else pl.red_max, pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), umax,
+                   self.D, pl.seg_ws.data_ptr(), send.data_ptr() + 4 * id_rows * self.D, ent.data_ptr(),
+                   n_ent, ent_max, pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), umax,
                    self.n_rows, send.data_ptr(), self.dense.grad.data_ptr(), send.data_ptr() + 4 * rows * self.D, self.dense.numel,
                    blk[0].data_ptr(), blk[1], s)
             return
         L.call("amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), self.n_sparse(pl),
-               self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), (pl.red_entries_v if live else pl.red_entries).data_ptr(),
-               pl.red_n_v if live else pl.red_n, pl.red_max_v if live else pl.red_max, blk[0].data_ptr(), blk[1], s)
+               self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), ent.data_ptr(), n_ent, ent_max, blk[0].data_ptr(), blk[1], s)
 
     def enqueue_optimizer(self, pl: SasrecPlan, sparse=None) -> None:
         """Dense Adam on the flat buffer + lazy row Adam on (uniq_ids, uniq_grad, n_uniq); `sparse`

@@ -154,6 +154,7 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_sas_strip_qkv_fwd_f32": ("mfma", 3 * gl),
         "amid_sas_strip_oproj_ffn_fwd_f32#0": ("mfma", 6 * gl),       # layer 0's out-proj + FFN, layer 1's q / k / v
         "amid_sas_strip_oproj_ffn_fwd_f32#1": ("mfma", 3 * gl),
+        "amid_sas_seq_bwd_f32": ("mfma", 12 * gl + 2 * 10.0 * T * T * hd * Bw * H),    # the five launches below as one
         "amid_sas_strip_ffn_bwd_f32": ("mfma", 3 * gl),
         "amid_sas_strip_qkv_bwd_f32#0": ("mfma", 6 * gl),             # layer 1's q / k / v backward, layer 0's FFN / out-proj backward
         "amid_sas_strip_qkv_bwd_f32#1": ("mfma", 3 * gl),
@@ -494,7 +495,7 @@ def main():
             elif v is not None:
                 durs[name] = v
         work = algorithmic_work(Bw, int(pl.n_uniq.item()), T)
-        red_bytes = (getattr(pl, "red_bytes_v", None) if getattr(eng, "_own_domain_only", False) else None) or getattr(pl, "red_bytes", None)
+        red_bytes = (getattr(pl, "red_bytes_s", None) if eng._seq_backward(pl) else None) or getattr(pl, "red_bytes_v", None) or getattr(pl, "red_bytes", None)
         if red_bytes:         # K3 (the segment reduce of the row gradients) + the reduce of every dense partial sum, one launch
             k3 = "amid_embgrad_segreduce_live" if getattr(pl, "compact", False) else "amid_embgrad_segreduce_f32"
             work["amid_grad_tail_f32"] = ("hbm", work[k3][1] + red_bytes)

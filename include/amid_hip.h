@@ -583,6 +583,24 @@ int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, float* xout, co
                          const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live, const void* step_state,
                          int train, float p_drop, void* stream);
 
+/* ---- the encoder's data gradients of the live sequences in ONE launch (csrc/sasrec_strip.hip: seq_bwd_kernel) -------------------------
+ * replaces: autograd of Log2feats.forward model_seq.py:371-383 under loss.backward() (train_sr.py:214) -- per layer, top down,
+ * amid_sas_strip_ffn_bwd_f32 + amid_attn_bwd_live_f32 + amid_sas_strip_qkv_bwd_f32 as one workgroup-long chain per live sequence.
+ * Shapes: amid_sas_seq_bwd_supported (D 128, 8 heads of 16, 32 < T <= 64).  Saved tensors / gradient outputs / LayerNorm partials:
+ * n_layers pointers each; parameters and transposed weights: 2 * n_layers pointers ordered [layer][domain].  dxo: gradient of the last
+ * layer's output; dx: gradient of layer 0's input (rows of the live sequences; the others are not touched); d_o: scratch [2 B T, D].
+ * ln1_part / ln2_part[l]: [2 B][2][D] -- domain g's slots are [g B, (g + 1) B): its live sequences' partial sums first, then zeros.
+ * live: amid_live_list_i32 (required).  The weight gradients (amid_sas_wgrad_rows_f32) read dq / dk / dv / dr / dpre1 / dpre2 as before. */
+int amid_sas_seq_bwd_supported(int B, int T, int D, int H);
+int amid_sas_seq_bwd_f32(int n_layers, const float* dxo, const unsigned char* tmq, const float* const* h, const float* const* r,
+                         const float* const* x, const float* const* q, const float* const* k, const float* const* v,
+                         const float* const* o, const float* const* stats, const float* const* ln1_w, const float* const* ln2_w,
+                         const float* const* wqT, const float* const* wkT, const float* const* wvT, const float* const* woT,
+                         const float* const* w1T, const float* const* w2T, float ln_eps, int B, int T, int D, int H, const int* live,
+                         const void* step_state, int train, float p_drop, float* const* dpre2, float* const* dpre1, float* const* dr,
+                         float* d_o, float* const* dq, float* const* dk, float* const* dv, float* dx, float* const* ln1_part,
+                         float* const* ln2_part, void* stream);
+
 /* ---- the fused train step over the LIVE sequences -------------------------------------------------------------------------------
  * train_sr.py:205-211 multiplies the BCE terms of domain 1 - domain_id[b] of every sample b by zero: of the 2 B sequences a step
  * encodes only the B "live" ones (domain_id[b], b) reach the loss.  amid_live_list_i32 lists them ([B + 1] ints: batch rows of

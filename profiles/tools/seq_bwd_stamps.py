@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Where the fused per-sequence backward's time goes: builds csrc/sasrec_strip.hip with -DAMID_STRIP_STAMPS into a DIAGNOSTIC library
+(gpurun_out/libstrip_diag.so; the product library carries no stamps), runs amid_sas_seq_bwd_f32 at the headline shape (B 256, T 50,
+D 128, eval-mode dropout) and prints the real-time-counter (100 MHz) deltas between the phase boundaries of workgroup 0's four waves."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "gpurun_out")
+os.makedirs(out, exist_ok=True)
+so = os.path.join(out, "libstrip_diag.so")
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-DAMID_STRIP_STAMPS",
+                "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "amid_amd/csrc/sasrec_strip.hip"), "-o", so], check=True)
+L = ctypes.CDLL(so)
+B, T, D, H = 256, 50, 128, 8
+M = B * T
+g = torch.Generator().manual_seed(0)
+dev = "cuda"
+act = lambda: (torch.randn(2 * M, D, generator=g) * 0.5).to(dev)      # noqa: E731
+wt = lambda: (torch.randn(D, D, generator=g) * 0.05).to(dev)           # noqa: E731
+vec = lambda: (1.0 + 0.1 * torch.randn(D, generator=g)).to(dev)        # noqa: E731
+keep = []
+
+
+def arr(ts):
+    keep.append(ts)
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+dxo = act()
+tmq = torch.zeros(2 * M, D // 4, dtype=torch.uint8, device=dev)
+per_layer = {n: [act(), act()] for n in ("h", "r", "x", "q", "k", "v", "o", "dpre2", "dpre1", "dr", "dq", "dk", "dv")}
+stats = [torch.stack((torch.full((2 * M, H), 4.0), torch.full((2 * M, H), 0.05)), -1).contiguous().to(dev) for _ in range(2)]
+per_dom = {n: [wt() for _ in range(4)] for n in ("wq", "wk", "wv", "wo", "w1", "w2")}
+lnw = {n: [vec() for _ in range(4)] for n in ("ln1", "ln2")}
+ln1p = [torch.empty(2 * B, 2, D, device=dev) for _ in range(2)]
+ln2p = [torch.empty(2 * B, 2, D, device=dev) for _ in range(2)]
+d_o, dx = act(), act()
+dom = (torch.rand(B, generator=g) < 0.5).long()
+d0, d1 = torch.nonzero(dom == 0).flatten(), torch.nonzero(dom != 0).flatten()
+live = torch.cat((d0, d1, torch.tensor([d0.numel()]))).int().to(dev)
+f = L.amid_sas_seq_bwd_f32
+vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+f.argtypes = [ci] + [vp] * 18 + [cf, ci, ci, ci, ci, vp, vp, ci, cf] + [vp] * 11
+P = per_layer
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for it in range(6):
+    if it == 5:
+        ev0.record()
+    rc = f(2, dxo.data_ptr(), tmq.data_ptr(), arr(P["h"]), arr(P["r"]), arr(P["x"]), arr(P["q"]), arr(P["k"]), arr(P["v"]), arr(P["o"]),
+           arr(stats), arr(lnw["ln1"]), arr(lnw["ln2"]), arr(per_dom["wq"]), arr(per_dom["wk"]), arr(per_dom["wv"]), arr(per_dom["wo"]),
+           arr(per_dom["w1"]), arr(per_dom["w2"]), 1e-8, B, T, D, H, live.data_ptr(), None, 0, 0.5, arr(P["dpre2"]), arr(P["dpre1"]),
+           arr(P["dr"]), d_o.data_ptr(), arr(P["dq"]), arr(P["dk"]), arr(P["dv"]), dx.data_ptr(), arr(ln1p), arr(ln2p), None)
+    assert rc == 0, rc
+    if it == 5:
+        ev1.record()
+    torch.cuda.synchronize()
+print(f"launch (events, null stream): {ev0.elapsed_time(ev1) * 1e3:.1f} us")
+host = (ctypes.c_ulonglong * (4 * 32))()
+assert L.amid_strip_stamps_read(host) == 0
+names = ["entry"]
+for l in (1, 0):
+    names += [f"L{l} ffn chain", f"L{l} barrier", f"L{l} attn head a", f"L{l} attn head b", f"L{l} barrier", f"L{l} qkv chain"]
+names += ["end"]
+print(f"s_memtime ticks per microsecond over the kernel (wave 0): {(host[15] - host[14]) / ((host[13] - host[0]) / 100):.1f}")
+for w in range(4):
+    t = [host[w * 32 + i] for i in range(14)]
+    print(f"wave {w}: total {(t[13] - t[0]) / 100:.2f} us; " + ", ".join(f"{names[i]} +{(t[i] - t[i - 1]) / 100:.2f}" for i in range(1, 14)))
+for w in range(4):        # stamps 16..18 inside the last attention call (layer 0, second head), which ends at stamp 10
+    t = [host[w * 32 + i] for i in (16, 17, 18, 10)]
+    print(f"wave {w}, last attention call: loads issued + Philox +{(t[1] - t[0]) / 100:.2f}, scale + phase 1 (waits for the loads) "
+          f"+{(t[2] - t[1]) / 100:.2f}, phase 2 +{(t[3] - t[2]) / 100:.2f}")
