@@ -246,22 +246,24 @@ struct AttnBwdOps {
     unsigned long long kw_own;                          // dropout keep word (64 keys) of query row `lane`
 };
 
-// every operand of BOTH phases is requested here, up front, without a wait (one exposure of the memory latency; a caller with
-// registers to spare requests its next head's operands before it computes this one)
+// Every operand of BOTH phases is requested up front, without a wait, in two parts: what the forward saved (q, k, v, o, row statistics;
+// the dropout keep word is drawn here too) and what the backward's predecessor produces (d_o).  A caller with registers to spare requests
+// the saved part long before d_o exists (the fused per-sequence backward: under the last product of the chain that computes d_o).
+// (A wave has at most 63 vector-memory operations in flight: the two parts together are 80, so issuing them back to back stalls for
+// one memory round trip -- the saved part of a cold tensor comes from HBM.)
 template <int NT>
-__device__ __forceinline__ void attn_bwd_load(AttnBwdOps& o, const AttnArgs& a, int g, int b, long long rowbase, int h) {
+__device__ __forceinline__ void attn_bwd_load_saved(AttnBwdOps& o, const AttnArgs& a, int g, int b, long long rowbase, int h) {
     const int T = a.T, D = a.D, H = a.H;
     const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
     const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
-    const SeqBuf bq(a.q, rowbase, T, D), bk(a.k, rowbase, T, D), bv(a.v, rowbase, T, D), bo(a.o, rowbase, T, D), bdo(a.d_o, rowbase, T, D),
-                 bst(a.stats, rowbase, T, 2 * H);
+    const SeqBuf bq(a.q, rowbase, T, D), bk(a.k, rowbase, T, D), bv(a.v, rowbase, T, D), bo(a.o, rowbase, T, D), bst(a.stats, rowbase, T, 2 * H);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         o.kfr[t] = bk.ld4(t * 16 + m, col4);
         o.vfr[t] = bv.ld4(t * 16 + m, col4);
         o.qfr[t] = bq.ld4(t * 16 + m, col4);
-        o.dofr[t] = bdo.ld4(t * 16 + m, col4);
         o.ofr[t] = bo.ld4(t * 16 + m, col4);
+        // (two dword loads: hipcc 7.2 drops the second half of a raw_buffer_load_b64 here)
         o.str[t] = make_float2(bst.ld1(t * 16 + m, 2 * h), bst.ld1(t * 16 + m, 2 * h + 1));
     }
 #pragma unroll
@@ -270,7 +272,6 @@ __device__ __forceinline__ void attn_bwd_load(AttnBwdOps& o, const AttnArgs& a, 
         for (int r = 0; r < 4; ++r) {
             o.kt[t][r] = bk.ld1(t * 16 + 4 * gq + r, colm);
             o.qts[t][r] = bq.ld1(t * 16 + 4 * gq + r, colm);
-            o.dots[t][r] = bdo.ld1(t * 16 + 4 * gq + r, colm);
         }
     o.kw_own = ~0ull;
     if (a.train) {
@@ -279,11 +280,25 @@ __device__ __forceinline__ void attn_bwd_load(AttnBwdOps& o, const AttnArgs& a, 
                                  (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
     }
 }
+template <int NT>
+__device__ __forceinline__ void attn_bwd_load_dout(AttnBwdOps& o, const AttnArgs& a, long long rowbase, int h) {
+    const int T = a.T, D = a.D;
+    const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
+    const SeqBuf bdo(a.d_o, rowbase, T, D);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o.dofr[t] = bdo.ld4(t * 16 + m, col4);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.dots[t][r] = bdo.ld1(t * 16 + 4 * gq + r, colm);
+}
 
-// dq, dk, dv of the head's 16 columns.  stat_lds: this wave's [3][64] floats (row max, 1 / row sum, delta of the query rows), keepw: its
-// [64] dropout keep words.  NT = ceil(T / 16) key / query tiles, all of them computed without a branch (rows past T are zeros and
-// their results are not stored).  Every group of matrix instructions runs over independent accumulators (a dependent
-// v_mfma_f32_16x16x4_f32 chain issues at 40 cycles per instruction against 32).
+// dq, dk, dv of the head's 16 columns.  stat_lds: this wave's [3][64] floats (per query row: row max * log2(e), dropout scale / row sum,
+// delta / row sum), keepw: its [64] dropout keep words.  NT = ceil(T / 16) key / query tiles, all of them computed without a branch
+// (rows past T are zeros and their results are not stored).  Every group of matrix instructions runs over independent accumulators
+// (a dependent v_mfma_f32_16x16x4_f32 chain issues at 40 cycles per instruction against 32).
+// With e = 2^(s log2(e) - m log2(e)), c = keep ? dscale / l : 0:  P~ = e c,  dS = P (dP~ - delta) = e (dP c - delta / l).
 template <int NT>
 __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& a, long long rowbase, int h, float* __restrict__ stat_lds,
                                                  unsigned long long* __restrict__ keepw) {
@@ -291,7 +306,7 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
     const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
     const int col4 = h * AHD + 4 * gq;
     const SeqBuf bdq(a.dq, rowbase, T, D), bdk(a.dk, rowbase, T, D), bdv(a.dv, rowbase, T, D);
-    float* smax = stat_lds; float* srl = stat_lds + 64; float* sdl = stat_lds + 128;
+    float* sml = stat_lds; float* sc1 = stat_lds + 64; float* sdr = stat_lds + 128;
     keepw[lane] = o.kw_own;                                                               // row index = 16 gq + m = lane
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -299,14 +314,14 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
 #pragma unroll
         for (int r = 0; r < 4; ++r) o.qts[t][r] *= a.scale;
     }
-    // ---------------- phase 1: lanes = queries -> dQ; row stats + keep words to LDS ----------------
+    // ---------------- phase 1: lanes = queries -> dQ; row constants + keep words to LDS ----------------
 #pragma unroll
     for (int qi = 0; qi < NT; ++qi) {
         const int q = qi * 16 + m;
         const float4 qf = o.qfr[qi], dof = o.dofr[qi];
         const float delta = quad_group_sum(f4hsum(f4mul(dof, o.ofr[qi])));
-        const float mrow = o.str[qi].x, rl = o.str[qi].y;
-        smax[q] = mrow; srl[q] = rl; sdl[q] = delta;          // (all four lane groups of a row hold the same values: no branch)
+        const float ml = o.str[qi].x * LOG2E, c1 = o.str[qi].y * a.dscale, dr = delta * o.str[qi].y;
+        sml[q] = ml; sc1[q] = c1; sdr[q] = dr;             // (all four lane groups of a row hold the same values: no branch)
         const unsigned long long kw = shfl64(o.kw_own, q);
         const unsigned kwh[2] = {(unsigned)kw, (unsigned)(kw >> 32)};
         f32x4 s[4], dp[4];
@@ -326,10 +341,10 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = kj * 16 + 4 * gq + r;
-                float p = fast_exp(s[kj][r] - mrow) * rl;
-                if (kj == qi) p = (n > q) ? 0.f : p;                                    // the diagonal tile's upper triangle
-                const float dpk = ((bits >> r) & 1u) ? dp[kj][r] * a.dscale : 0.f;
-                const float ds = p * (dpk - delta);
+                float e = __builtin_amdgcn_exp2f(fmaf(s[kj][r], LOG2E, -ml));
+                if (kj == qi) e = (n > q) ? 0.f : e;                                    // the diagonal tile's upper triangle
+                const float c = ((bits >> r) & 1u) ? c1 : 0.f;
+                const float ds = e * fmaf(dp[kj][r], c, -dr);
                 if (r & 1) dqb = mfma4(o.kt[kj][r], ds, dqb); else dqa = mfma4(o.kt[kj][r], ds, dqa);
             }
         }
@@ -339,17 +354,18 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
     // no workgroup barrier here: the LDS scratch of a wave is written and read by that wave only (LDS operations of one wave
     // complete in order), and without it the waves of a workgroup drift apart -- the late ones' loads overlap the early ones' MFMAs
     // ---------------- phase 2: lanes = keys -> dK, dV (operands already in registers) ----------------
-    // the statistics and keep words of this lane's 16 query columns (16 qi + 4 gq + r), read once for all key tiles
+    // the constants and keep words of this lane's 16 query columns (16 qi + 4 gq + r), read once for all key tiles; the keep words
+    // arrive shifted by this lane's key offset m: key tile kj then tests bit 16 (kj & 1) of half kj >> 1
     STRIP_RSTAMP(18);
-    float4 mx4[4], rl4[4], dl4[4];
+    float4 ml4[4], c14[4], dr4[4];
     unsigned kq[4][4][2];
 #pragma unroll
     for (int qi = 0; qi < NT; ++qi) {
-        mx4[qi] = ld4(smax + qi * 16 + 4 * gq); rl4[qi] = ld4(srl + qi * 16 + 4 * gq); dl4[qi] = ld4(sdl + qi * 16 + 4 * gq);
+        ml4[qi] = ld4(sml + qi * 16 + 4 * gq); c14[qi] = ld4(sc1 + qi * 16 + 4 * gq); dr4[qi] = ld4(sdr + qi * 16 + 4 * gq);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const unsigned long long w = keepw[qi * 16 + 4 * gq + r];
-            kq[qi][r][0] = (unsigned)w; kq[qi][r][1] = (unsigned)(w >> 32);
+            kq[qi][r][0] = (unsigned)w >> m; kq[qi][r][1] = (unsigned)(w >> 32) >> m;
         }
     }
 #pragma unroll
@@ -372,13 +388,12 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qq = qi * 16 + 4 * gq + r;
-                const bool keep = (kq[qi][r][kj >> 1] >> ((kj & 1) * 16 + m)) & 1u;
-                // (a query row past T has 1 / row sum = 0: p = 0 without a test)
-                float p = fast_exp(st[qi][r] - f4comp(mx4[qi], r)) * f4comp(rl4[qi], r);
-                if (qi == kj) p = (key <= qq) ? p : 0.f;
-                const float pd = keep ? p * a.dscale : 0.f;
-                const float dpk = keep ? dpt[qi][r] * a.dscale : 0.f;
-                const float ds = p * (dpk - f4comp(dl4[qi], r));
+                // (a query row past T has 1 / row sum = 0, i.e. c = 0 and delta / l = 0: P~ = dS = 0 without a test)
+                float e = __builtin_amdgcn_exp2f(fmaf(st[qi][r], LOG2E, -f4comp(ml4[qi], r)));
+                if (qi == kj) e = (key <= qq) ? e : 0.f;
+                const float c = ((kq[qi][r][kj >> 1] >> ((kj & 1) * 16)) & 1u) ? f4comp(c14[qi], r) : 0.f;
+                const float pd = e * c;
+                const float ds = e * fmaf(dpt[qi][r], c, -f4comp(dr4[qi], r));
                 if (r & 1) { dvb = mfma4(o.dots[qi][r], pd, dvb); dkb = mfma4(o.qts[qi][r], ds, dkb); }
                 else       { dva = mfma4(o.dots[qi][r], pd, dva); dka = mfma4(o.qts[qi][r], ds, dka); }
             }
@@ -396,7 +411,8 @@ __device__ __forceinline__ void attn_bwd_head(const AttnArgs& a, int g, int b, l
                                               unsigned long long* __restrict__ keepw) {
     AttnBwdOps o;
     STRIP_RSTAMP(16);                                   // (diagnostic builds of sasrec_strip.hip only)
-    attn_bwd_load<NT>(o, a, g, b, rowbase, h);
+    attn_bwd_load_saved<NT>(o, a, g, b, rowbase, h);
+    attn_bwd_load_dout<NT>(o, a, rowbase, h);
     STRIP_RSTAMP(17);
     attn_bwd_compute<NT>(o, a, rowbase, h, stat_lds, keepw);
 }

@@ -309,10 +309,11 @@ __device__ __forceinline__ void ffn_bwd_prefetch(FfnBwdPre<D>& p, const StripFfn
 
 // d x' (DZ, in registers) -> dpre2, dpre1, dr, d_o of this layer; the ring's current fetch must be w2T.  TAIL: a slab (`tail`) is
 // fetched under the last MFMA loop (a fused successor's first weight)
-template <int D, bool TAIL = false>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int D, bool TAIL = false, class Hook = NoHook>
 __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const StripGeom& sg, Ring<D>& ring, const StripRow& row, int g,
                                               StripRegs<D>& DZ, FfnBwdPre<D>& pre, float* __restrict__ scratch,
-                                              const float* __restrict__ tail = nullptr) {
+                                              const float* __restrict__ tail = nullptr, const Hook& before_last = NoHook()) {
     constexpr int NT = D / 16;
     unsigned long long seed = 0; unsigned step = 0;
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
@@ -345,6 +346,7 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
     }
     {   // d_o = dr Wo
         const float* buf = ring.next();
+        before_last();                  // (a fused successor requests operands here: they fly under this product)
         strip_zero<D>(acc);
         strip_mma<D>(acc, DR, buf, [&](int ct, int j) {
             if constexpr (TAIL) ring.fetch(tail, ct, j);
@@ -518,20 +520,30 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_bwd_kernel(const SeqBwdArgs
         const SeqBwdLayer& P = a.L[l];
         const SeqBwdLayer& Pn = a.L[l > 0 ? l - 1 : 0];
         [[maybe_unused]] const int sb = 1 + 6 * (top - l);                // (diagnostic builds: real-time stamps of workgroup 0)
-        ffn_bwd_chain<D, true>(P.f, sg, ring, row, g, DZ, pre, ln_scratch<D>(smem, 0), P.a.wkT[g]);
+        // the first head's operands that the forward saved are requested under the chain's last product (they come from HBM: a wave that
+        // asked for them behind the barrier would sit out the round trip), the second head's fly under the first head's arithmetic
+        AttnBwdOps oa, ob;
+        const bool nt4 = T > 48;
+        ffn_bwd_chain<D, true>(P.f, sg, ring, row, g, DZ, pre, ln_scratch<D>(smem, 0), P.a.wkT[g], [&]() {
+            if (nt4) attn_bwd_load_saved<4>(oa, P.at, g, b, rowbase, w); else attn_bwd_load_saved<3>(oa, P.at, g, b, rowbase, w);
+        });
         STRIP_RSTAMP(sb);
         w_ring_wait();                  // d_o has reached L2 (the Wk slab has landed as well: it was requested half a GEMM ago)
         __syncthreads();
         ln_partials_out<D>(ln_scratch<D>(smem, 0), P.f.ln_part + (long long)slot * 2 * D);
         STRIP_RSTAMP(sb + 1);
-        if (T > 48) {
-            attn_bwd_head<4>(P.at, g, b, rowbase, w, stat_lds, keepw);
+        if (nt4) {
+            attn_bwd_load_dout<4>(oa, P.at, rowbase, w);
+            attn_bwd_load_saved<4>(ob, P.at, g, b, rowbase, w + STRIP_WAVES); attn_bwd_load_dout<4>(ob, P.at, rowbase, w + STRIP_WAVES);
+            attn_bwd_compute<4>(oa, P.at, rowbase, w, stat_lds, keepw);
             STRIP_RSTAMP(sb + 2);
-            attn_bwd_head<4>(P.at, g, b, rowbase, w + STRIP_WAVES, stat_lds, keepw);
+            attn_bwd_compute<4>(ob, P.at, rowbase, w + STRIP_WAVES, stat_lds, keepw);
         } else {
-            attn_bwd_head<3>(P.at, g, b, rowbase, w, stat_lds, keepw);
+            attn_bwd_load_dout<3>(oa, P.at, rowbase, w);
+            attn_bwd_load_saved<3>(ob, P.at, g, b, rowbase, w + STRIP_WAVES); attn_bwd_load_dout<3>(ob, P.at, rowbase, w + STRIP_WAVES);
+            attn_bwd_compute<3>(oa, P.at, rowbase, w, stat_lds, keepw);
             STRIP_RSTAMP(sb + 2);
-            attn_bwd_head<3>(P.at, g, b, rowbase, w + STRIP_WAVES, stat_lds, keepw);
+            attn_bwd_compute<3>(ob, P.at, rowbase, w + STRIP_WAVES, stat_lds, keepw);
         }
         STRIP_RSTAMP(sb + 3);
         w_ring_wait();                  // dq / dk / dv have reached L2
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_bwd_kernel(const SeqBwdArgs
         StripRegs<D> DX;
         // (layer 0 "prefetches" its own w2T into the free buffer: harmless, waited for at the end)
         qkv_bwd_chain<D, true>(P.a, sg, ring, row, g, DX, ln_scratch<D>(smem, 1), Pn.f.w2T[g],
-                               [&]() { if (l > 0) ffn_bwd_prefetch<D>(pre, Pn.f, sg, row, g); });
+                               [&]() { ffn_bwd_prefetch<D>(pre, Pn.f, sg, row, g); });      // (unconditional: `pre` is then dead across the attention core)
         STRIP_RSTAMP(sb + 5);
         __syncthreads();
         ln_partials_out<D>(ln_scratch<D>(smem, 1), P.a.ln_part + (long long)slot * 2 * D);

@@ -243,7 +243,7 @@ class SasrecPlan:
             self.ln2_part_v = [f(2 * self.tpg_v, 2, D) for _ in range(2)]
         # the fused per-sequence backward (csrc/sasrec_strip.hip seq_bwd_kernel) tiles one live sequence per workgroup: its LayerNorm
         # partials have a slot per sequence and their own reduce table
-        self.seq_bwd = bool(self.strip and self.live_rows and getattr(eng, "SEQ_BACKWARD", False) and not inc
+        self.seq_bwd = bool(self.strip and self.live_rows and getattr(eng, "SEQ_BACKWARD", "0") not in ("0", False) and not inc
                             and L.value("amid_sas_seq_bwd_supported", B, shp.Tenc, D, H))
         if self.seq_bwd:
             self.ln1_part_s = [f(2 * B, 2, D) for _ in range(2)]
@@ -709,11 +709,21 @@ class SasrecEngine:
             self._sort_pending = False
 
     SORT_RIDERS = os.environ.get("AMID_SORT_RIDERS", "1") != "0"
-    # the train step's encoder backward (data gradients) as ONE launch over the live sequences where csrc/sasrec_strip.hip covers the shape
-    SEQ_BACKWARD = os.environ.get("AMID_SEQ_BACKWARD", "1") != "0"
+    # The train step's encoder backward (data gradients) as ONE launch over the live sequences where csrc/sasrec_strip.hip covers the
+    # shape (amid_sas_seq_bwd_f32): "auto" = where it wins.  It tiles one sequence per workgroup, a whole CU each, so the step's sort
+    # riders find no free CU in it and the sort goes back to the side stream (a fork and a join, ~10 us of a replayed graph).  Measured
+    # (MI355X, T 50): B 256 = one round of workgroups either way, a tie (0.391 against 0.389 ms with the riders); B 512 = two full
+    # rounds against 400 row tiles in two uneven ones, 0.690 against 0.740 ms; B 4096 = 16 rounds against 12.5 rounds of denser row
+    # tiles, 4.75 against 4.48 ms.  So: more live sequences than CUs, at most two rounds.  AMID_SEQ_BACKWARD = 1 / 0 forces it on / off.
+    SEQ_BACKWARD = os.environ.get("AMID_SEQ_BACKWARD", "auto")
 
     def _seq_backward(self, pl: SasrecPlan) -> bool:
-        return bool(self.SEQ_BACKWARD and getattr(pl, "seq_bwd", False) and not self.itc_bs)
+        if not getattr(pl, "seq_bwd", False) or self.itc_bs or self.SEQ_BACKWARD in ("0", False):
+            return False
+        if self.SEQ_BACKWARD in ("1", True):
+            return True
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        return n_cu < pl.shape.B <= 2 * n_cu
 
     def _sort_plan(self, pl: SasrecPlan):
         """Host address of the plan of the step's index sort (amid_sort_plan_pack), or None when the riders do not cover it."""

@@ -138,7 +138,17 @@ def test_timed_path_with_compact_index_list_vs_oracle(Bn, T, D, build, split):
     _timed_vs_oracle(Bn, T, D, build, split, compact_min=0)
 
 
-def _timed_vs_oracle(Bn, T, D, build, split, compact_min):
+# The encoder's backward as ONE launch per step (amid_sas_seq_bwd_f32; SasrecEngine.SEQ_BACKWARD "auto" takes it for batches of more
+# live sequences than CUs and at most two rounds, i.e. cases 2 and 3 above): forced on for the headline shape, degenerate domain
+# splits, three key tiles (T 40) and many rounds, and forced off for a shape "auto" would take.
+@pytest.mark.parametrize("Bn,T,D,split,force", [(256, 50, 128, "mixed", "1"), (256, 50, 128, "all0", "1"), (256, 50, 128, "all1", "1"),
+                                                (200, 50, 128, "one0", "1"), (300, 40, 128, "mixed", "1"), (64, 33, 128, "mixed", "1"),
+                                                (1100, 50, 128, "mixed", "1"), (512, 50, 128, "mixed", "0")])
+def test_timed_path_fused_backward_vs_oracle(Bn, T, D, split, force):
+    _timed_vs_oracle(Bn, T, D, None, split, compact_min=None, seq_backward=force)
+
+
+def _timed_vs_oracle(Bn, T, D, build, split, compact_min, seq_backward=None):
     hid, n_items = 32, 3000
     P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=300 + D + Bn)
     batch = split_batch(Bn, T, n_items, seed=Bn + T, split=split)
@@ -147,12 +157,16 @@ def _timed_vs_oracle(Bn, T, D, build, split, compact_min):
     eng = make_engine(P, T, seed=seed)
     if compact_min is not None:
         eng.COMPACT_MIN_IDX = compact_min
+    if seq_backward is not None:
+        eng.SEQ_BACKWARD = seq_backward
     pl = eng.plan(Bn, T, 2, need_grad=True)
     timed_local_grads(eng, pl, batch, step, seed)
+    if seq_backward is not None:
+        assert eng._seq_backward(pl) == (seq_backward == "1")
     assert pl.compact == eng.compact_ok(pl) and (compact_min != 0 or D != 128 or pl.compact)
     # the encoder's GEMM chains of the fused step run as strip kernels over the live sequences (csrc/sasrec_strip.hip); engines
     # built without them fall back to the live-row builds of the row-tile kernels named in the case
-    assert pl.strip or pl.rt_suffix_v == build
+    assert pl.strip or build is None or pl.rt_suffix_v == build
     keep = gpu_relu_keep(eng, pl, batch)
     taps = {}
     loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, masks, relu_keep=keep, taps=taps)
@@ -167,7 +181,7 @@ def _timed_vs_oracle(Bn, T, D, build, split, compact_min):
     check_grads(f"timed B={Bn} T={T} D={D} {split}", eng, pl, grads, 2e-4, 5e-5)
 
 
-@pytest.mark.parametrize("Bn,T,D", [(256, 50, 128), (256, 20, 128)])
+@pytest.mark.parametrize("Bn,T,D", [(256, 50, 128), (256, 20, 128), (320, 50, 128)])     # (320: the fused per-sequence backward, side-stream sort)
 @pytest.mark.parametrize("pool", [False, True])
 def test_timed_path_trajectory_graph_replay_vs_oracle(Bn, T, D, pool):
     """Three whole steps at the headline shape (and the mybank shape) through capture_train_step + replay_train_step -- the thing
