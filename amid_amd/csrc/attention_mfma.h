@@ -95,11 +95,16 @@ __device__ __forceinline__ f32x4 mfma_frag(float4 a, float4 b, f32x4 c) {
     c = mfma4(a.x, b.x, c); c = mfma4(a.y, b.y, c); c = mfma4(a.z, b.z, c); c = mfma4(a.w, b.w, c);
     return c;
 }
+// rows past T read as zeros WITHOUT a branch: the address is clamped to the last row and the value selected afterwards -- a load inside
+// a conditional block is waited for at the block's end when anything (a scale factor) is applied to it there, i.e. a kernel's operand
+// loads complete one memory round trip after the other instead of all being in flight at once
 __device__ __forceinline__ float4 ld4_row(const float* __restrict__ base, long long rowbase, int row, int T, int D, int col) {
-    return (row < T) ? ld4(base + (rowbase + row) * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = ld4(base + (rowbase + min(row, T - 1)) * D + col);
+    return (row < T) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __device__ __forceinline__ float ld1_row(const float* __restrict__ base, long long rowbase, int row, int T, int D, int col) {
-    return (row < T) ? base[(rowbase + row) * D + col] : 0.f;
+    const float v = base[(rowbase + min(row, T - 1)) * D + col];
+    return (row < T) ? v : 0.f;
 }
 __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
     const unsigned lo = __shfl((unsigned)v, src, 64), hi = __shfl((unsigned)(v >> 32), src, 64);
