@@ -242,8 +242,9 @@ struct SeqBuf {
 __device__ __forceinline__ float f4comp(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
 // one head's operands in their matrix-core lane layouts: row fragments of Q, K, V, dO, O (float4 along the head dim: lane (m, g) holds
-// row 16 t + m, dims 4 g .. 4 g + 3) and the transposed dword fragments K^T (phase 1), Q^T, dO^T (phase 2): lane (m, g) holds
-// row 16 t + 4 g + r, dim m.  Rows past T are zeros.
+// row 16 t + m, dims 4 g .. 4 g + 3), loaded from memory, and the transposed fragments K^T (phase 1), Q^T, dO^T (phase 2): lane (m, g)
+// holds row 16 t + 4 g + r, dim m -- made from the row fragments by a 16 x 16 transpose through the wave's LDS scratch (as loads they
+// were 48 of a head's 80 vector-memory operations: more than the 63 a wave can have in flight).  Rows past T are zeros.
 struct AttnBwdOps {
     float4 kfr[4], vfr[4], qfr[4], dofr[4], ofr[4];
     float2 str[4];
@@ -254,13 +255,12 @@ struct AttnBwdOps {
 // Every operand of BOTH phases is requested up front, without a wait, in two parts: what the forward saved (q, k, v, o, row statistics;
 // the dropout keep word is drawn here too) and what the backward's predecessor produces (d_o).  A caller with registers to spare requests
 // the saved part long before d_o exists (the fused per-sequence backward: under the last product of the chain that computes d_o).
-// (A wave has at most 63 vector-memory operations in flight: the two parts together are 80, so issuing them back to back stalls for
-// one memory round trip -- the saved part of a cold tensor comes from HBM.)
+// (A wave has at most 63 vector-memory operations in flight; a head's two parts are 28.)
 template <int NT>
 __device__ __forceinline__ void attn_bwd_load_saved(AttnBwdOps& o, const AttnArgs& a, int g, int b, long long rowbase, int h) {
     const int T = a.T, D = a.D, H = a.H;
     const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
-    const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
+    const int col4 = h * AHD + 4 * gq;
     const SeqBuf bq(a.q, rowbase, T, D), bk(a.k, rowbase, T, D), bv(a.v, rowbase, T, D), bo(a.o, rowbase, T, D), bst(a.stats, rowbase, T, 2 * H);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -271,13 +271,6 @@ __device__ __forceinline__ void attn_bwd_load_saved(AttnBwdOps& o, const AttnArg
         // (two dword loads: hipcc 7.2 drops the second half of a raw_buffer_load_b64 here)
         o.str[t] = make_float2(bst.ld1(t * 16 + m, 2 * h), bst.ld1(t * 16 + m, 2 * h + 1));
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            o.kt[t][r] = bk.ld1(t * 16 + 4 * gq + r, colm);
-            o.qts[t][r] = bq.ld1(t * 16 + 4 * gq + r, colm);
-        }
     o.kw_own = ~0ull;
     if (a.train) {
         const int qrow = min(lane, T - 1);
@@ -289,18 +282,18 @@ template <int NT>
 __device__ __forceinline__ void attn_bwd_load_dout(AttnBwdOps& o, const AttnArgs& a, long long rowbase, int h) {
     const int T = a.T, D = a.D;
     const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
-    const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
+    const int col4 = h * AHD + 4 * gq;
     const SeqBuf bdo(a.d_o, rowbase, T, D);
 #pragma unroll
     for (int t = 0; t < NT; ++t) o.dofr[t] = bdo.ld4(t * 16 + m, col4);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o.dots[t][r] = bdo.ld1(t * 16 + 4 * gq + r, colm);
 }
 
-// dq, dk, dv of the head's 16 columns.  stat_lds: this wave's [3][64] floats (per query row: row max * log2(e), dropout scale / row sum,
-// delta / row sum), keepw: its [64] dropout keep words.  NT = ceil(T / 16) key / query tiles, all of them computed without a branch
+// the LDS scratch of a wave: [3][64] floats of row statistics, [64] keep words, a [16][20] transpose tile -- ONE contiguous block per wave
+constexpr int ATTN_BWD_STAT_FLOATS = 3 * 64;
+constexpr int ATTN_BWD_LDS_PER_WAVE = (ATTN_BWD_STAT_FLOATS + 2 * 64 + 16 * 20) * 4;
+
+// dq, dk, dv of the head's 16 columns.  stat_lds: this wave's scratch block ([3][64] floats (per query row: row max * log2(e), dropout scale / row sum,
+// delta / row sum, then the keep words and the transpose tile), keepw: the [64] dropout keep words inside it.  NT = ceil(T / 16) key / query tiles, all of them computed without a branch
 // (rows past T are zeros and their results are not stored).  Every group of matrix instructions runs over independent accumulators
 // (a dependent v_mfma_f32_16x16x4_f32 chain issues at 40 cycles per instruction against 32).
 // With e = 2^(s log2(e) - m log2(e)), c = keep ? dscale / l : 0:  P~ = e c,  dS = P (dP~ - delta) = e (dP c - delta / l).
@@ -313,11 +306,22 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
     const SeqBuf bdq(a.dq, rowbase, T, D), bdk(a.dk, rowbase, T, D), bdv(a.dv, rowbase, T, D);
     float* sml = stat_lds; float* sc1 = stat_lds + 64; float* sdr = stat_lds + 128;
     keepw[lane] = o.kw_own;                                                               // row index = 16 gq + m = lane
+    // the transposed fragments: tile[m][4 gq ..] = row fragment, then [4 gq + r][m] back (rows of 20 floats: the 16-byte writes stay
+    // aligned, the dword reads of the four lane groups fall on two bank sets).  LDS operations of a wave execute in order: the next
+    // tile's write needs no wait for this tile's reads.
+    float* tile = stat_lds + ATTN_BWD_STAT_FLOATS + 2 * 64;          // behind the statistics and the keep words
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         o.qfr[t] = f4scale(o.qfr[t], a.scale);
+        st4(tile + m * 20 + 4 * gq, o.kfr[t]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o.qts[t][r] *= a.scale;
+        for (int r = 0; r < 4; ++r) o.kt[t][r] = tile[(4 * gq + r) * 20 + m];
+        st4(tile + m * 20 + 4 * gq, o.qfr[t]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.qts[t][r] = tile[(4 * gq + r) * 20 + m];
+        st4(tile + m * 20 + 4 * gq, o.dofr[t]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.dots[t][r] = tile[(4 * gq + r) * 20 + m];
     }
     // ---------------- phase 1: lanes = queries -> dQ; row constants + keep words to LDS ----------------
 #pragma unroll
@@ -408,8 +412,7 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
     }
 }
 
-// the LDS scratch of a wave: [3][64] floats of row statistics + [64] keep words
-constexpr int ATTN_BWD_LDS_PER_WAVE = 3 * 64 * 4 + 64 * 8;
+
 
 template <int NT>
 __device__ __forceinline__ void attn_bwd_head(const AttnArgs& a, int g, int b, long long rowbase, int h, float* __restrict__ stat_lds,

@@ -44,8 +44,8 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
     const int g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
     const int wv = wave_id(), h = part * hw + wv, lane = lane_id();
-    float* stat_lds = smem + wv * 3 * 64;                                                 // [hw][3][64] (max, 1 / sum, delta)
-    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(smem + hw * 3 * 64) + wv * 64;   // [hw][64]
+    float* stat_lds = smem + wv * (ATTN_BWD_LDS_PER_WAVE / 4);                            // this wave's scratch block (attention_mfma.h)
+    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(stat_lds + ATTN_BWD_STAT_FLOATS);
     if (!live) {                                                                       // no gradient reaches this sequence: exact zeros
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = lane; i < T * (AHD / 4); i += 64) {

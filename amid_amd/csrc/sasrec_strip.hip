@@ -506,8 +506,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_bwd_kernel(const SeqBwdArgs
     row.off = row.ok ? phys * (unsigned)(D * 4) + 16u * (unsigned)gq : STRIP_OOB;
     const long long rowbase = (long long)g * sg.M + (long long)b * T;
     float* att = smem + 2 * D * D + 16 * D;                                       // behind the ring and the two LayerNorm scratch blocks
-    float* stat_lds = att + w * 3 * 64;
-    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(att + STRIP_WAVES * 3 * 64) + w * 64;
+    float* stat_lds = att + w * (ATTN_BWD_LDS_PER_WAVE / 4);                      // this wave's scratch block (attention_mfma.h)
+    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(stat_lds + ATTN_BWD_STAT_FLOATS);
 
     STRIP_RSTAMP(0);
     STRIP_STAMP(14);
