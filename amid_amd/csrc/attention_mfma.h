@@ -288,49 +288,54 @@ __device__ __forceinline__ void attn_bwd_load_dout(AttnBwdOps& o, const AttnArgs
     for (int t = 0; t < NT; ++t) o.dofr[t] = bdo.ld4(t * 16 + m, col4);
 }
 
-// the LDS scratch of a wave: [3][64] floats of row statistics, [64] keep words, a [16][20] transpose tile -- ONE contiguous block per wave
-constexpr int ATTN_BWD_STAT_FLOATS = 3 * 64;
-constexpr int ATTN_BWD_LDS_PER_WAVE = (ATTN_BWD_STAT_FLOATS + 2 * 64 + 16 * 20) * 4;
+// the LDS scratch of a wave: two [16][20]-float transpose tiles -- ONE contiguous block per wave
+constexpr int ATTN_BWD_TILE_FLOATS = 16 * 20;
+constexpr int ATTN_BWD_LDS_PER_WAVE = 2 * ATTN_BWD_TILE_FLOATS * 4;
 
-// dq, dk, dv of the head's 16 columns.  stat_lds: this wave's scratch block ([3][64] floats (per query row: row max * log2(e), dropout scale / row sum,
-// delta / row sum, then the keep words and the transpose tile), keepw: the [64] dropout keep words inside it.  NT = ceil(T / 16) key / query tiles, all of them computed without a branch
-// (rows past T are zeros and their results are not stored).  Every group of matrix instructions runs over independent accumulators
-// (a dependent v_mfma_f32_16x16x4_f32 chain issues at 40 cycles per instruction against 32).
-// With e = 2^(s log2(e) - m log2(e)), c = keep ? dscale / l : 0:  P~ = e c,  dS = P (dP~ - delta) = e (dP c - delta / l).
+// this wave's 16 x 16 tile transposed through LDS: lane (m, g) hands in X[m][4 g .. 4 g + 3] and gets X[4 g + r][m], r = 0 .. 3.
+// Rows of 20 floats: the 16-byte writes stay aligned, the dword reads of the four lane groups fall on two bank sets.  LDS operations
+// of a wave execute in order: reusing the tile needs no wait for the previous reads.
+__device__ __forceinline__ void tile_transpose(float* __restrict__ tile, const float4 in, float (&out)[4]) {
+    const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    st4(tile + m * 20 + 4 * gq, in);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = tile[(4 * gq + r) * 20 + m];
+}
+
+// dq, dk, dv of the head's 16 columns in ONE pass over the (query tile, key tile) pairs of the causal triangle.  lds: this wave's
+// ATTN_BWD_LDS_PER_WAVE bytes.  NT = ceil(T / 16) key / query tiles, all pairs computed without a branch (rows past T are zeros and
+// their results are not stored).  Per pair, lanes = queries: S = Qs K^T and dP~ = dO V^T (8 matrix instructions over independent
+// accumulators), the element-wise part with e = 2^(s log2(e) - m log2(e)), c = keep ? dscale / l : 0:  P~ = e c,
+// dS = P (dP~ - delta) = e (dP c - delta / l), then dQ += dS K with dS as the second operand as it stands.  dV += P~^T dO and
+// dK += dS^T Qs need the contraction index (the query) on the lane groups: the two 16 x 16 tiles are TRANSPOSED through LDS (one
+// 16-byte write and four dword reads each) -- the first version recomputed S^T and dP~^T in a second pass with lanes = keys: 8 more
+// matrix instructions and a second exponential per element, and the row statistics of every query travelled through LDS.
+// 20 matrix instructions per pair instead of 28; dK / dV accumulate per key tile across the query tiles.
 template <int NT>
-__device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& a, long long rowbase, int h, float* __restrict__ stat_lds,
-                                                 unsigned long long* __restrict__ keepw) {
+__device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& a, long long rowbase, int h, float* __restrict__ lds) {
     const int T = a.T, D = a.D;
     const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
     const int col4 = h * AHD + 4 * gq;
     const SeqBuf bdq(a.dq, rowbase, T, D), bdk(a.dk, rowbase, T, D), bdv(a.dv, rowbase, T, D);
-    float* sml = stat_lds; float* sc1 = stat_lds + 64; float* sdr = stat_lds + 128;
-    keepw[lane] = o.kw_own;                                                               // row index = 16 gq + m = lane
-    // the transposed fragments: tile[m][4 gq ..] = row fragment, then [4 gq + r][m] back (rows of 20 floats: the 16-byte writes stay
-    // aligned, the dword reads of the four lane groups fall on two bank sets).  LDS operations of a wave execute in order: the next
-    // tile's write needs no wait for this tile's reads.
-    float* tile = stat_lds + ATTN_BWD_STAT_FLOATS + 2 * 64;          // behind the statistics and the keep words
+    float* tile = lds;
+    float* tile2 = lds + ATTN_BWD_TILE_FLOATS;
+    // the transposed operand fragments K^T, Qs^T, dO^T from the row fragments
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         o.qfr[t] = f4scale(o.qfr[t], a.scale);
-        st4(tile + m * 20 + 4 * gq, o.kfr[t]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o.kt[t][r] = tile[(4 * gq + r) * 20 + m];
-        st4(tile + m * 20 + 4 * gq, o.qfr[t]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o.qts[t][r] = tile[(4 * gq + r) * 20 + m];
-        st4(tile + m * 20 + 4 * gq, o.dofr[t]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o.dots[t][r] = tile[(4 * gq + r) * 20 + m];
+        tile_transpose(tile, o.kfr[t], o.kt[t]);
+        tile_transpose(tile2, o.qfr[t], o.qts[t]);
+        tile_transpose(tile, o.dofr[t], o.dots[t]);
     }
-    // ---------------- phase 1: lanes = queries -> dQ; row constants + keep words to LDS ----------------
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj) { dk[kj] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kj] = dk[kj]; }
 #pragma unroll
     for (int qi = 0; qi < NT; ++qi) {
         const int q = qi * 16 + m;
         const float4 qf = o.qfr[qi], dof = o.dofr[qi];
         const float delta = quad_group_sum(f4hsum(f4mul(dof, o.ofr[qi])));
         const float ml = o.str[qi].x * LOG2E, c1 = o.str[qi].y * a.dscale, dr = delta * o.str[qi].y;
-        sml[q] = ml; sc1[q] = c1; sdr[q] = dr;             // (all four lane groups of a row hold the same values: no branch)
         const unsigned long long kw = shfl64(o.kw_own, q);
         const unsigned kwh[2] = {(unsigned)kw, (unsigned)(kw >> 32)};
         f32x4 s[4], dp[4];
@@ -347,82 +352,47 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
 #pragma unroll
         for (int kj = 0; kj <= qi; ++kj) {
             const unsigned bits = kwh[kj >> 1] >> ((kj & 1) * 16 + 4 * gq);              // this lane's keys 16 kj + 4 gq + r: bits 0..3
+            float pd[4], ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = kj * 16 + 4 * gq + r;
                 float e = __builtin_amdgcn_exp2f(fmaf(s[kj][r], LOG2E, -ml));
                 if (kj == qi) e = (n > q) ? 0.f : e;                                    // the diagonal tile's upper triangle
                 const float c = ((bits >> r) & 1u) ? c1 : 0.f;
-                const float ds = e * fmaf(dp[kj][r], c, -dr);
-                if (r & 1) dqb = mfma4(o.kt[kj][r], ds, dqb); else dqa = mfma4(o.kt[kj][r], ds, dqa);
+                // (a query row past T has 1 / row sum = 0, i.e. c = 0 and delta / l = 0: P~ = dS = 0 without a test)
+                pd[r] = e * c;
+                ds[r] = e * fmaf(dp[kj][r], c, -dr);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { if (r & 1) dqb = mfma4(o.kt[kj][r], ds[r], dqb); else dqa = mfma4(o.kt[kj][r], ds[r], dqa); }
+            float pt[4], dst[4];                     // lane (key m, gq), r <-> query 16 qi + 4 gq + r
+            tile_transpose(tile, make_float4(pd[0], pd[1], pd[2], pd[3]), pt);
+            tile_transpose(tile2, make_float4(ds[0], ds[1], ds[2], ds[3]), dst);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {           // (two chains alternate: a dependent instruction is two issue slots away)
+                dv[kj] = mfma4(o.dots[qi][r], pt[r], dv[kj]);
+                dk[kj] = mfma4(o.qts[qi][r], dst[r], dk[kj]);
             }
         }
         dqa += dqb;
         bdq.st4(q, col4, make_float4(dqa[0] * a.scale, dqa[1] * a.scale, dqa[2] * a.scale, dqa[3] * a.scale));
     }
-    // no workgroup barrier here: the LDS scratch of a wave is written and read by that wave only (LDS operations of one wave
-    // complete in order), and without it the waves of a workgroup drift apart -- the late ones' loads overlap the early ones' MFMAs
-    // ---------------- phase 2: lanes = keys -> dK, dV (operands already in registers) ----------------
-    // the constants and keep words of this lane's 16 query columns (16 qi + 4 gq + r), read once for all key tiles; the keep words
-    // arrive shifted by this lane's key offset m: key tile kj then tests bit 16 (kj & 1) of half kj >> 1
-    STRIP_RSTAMP(18);
-    float4 ml4[4], c14[4], dr4[4];
-    unsigned kq[4][4][2];
-#pragma unroll
-    for (int qi = 0; qi < NT; ++qi) {
-        ml4[qi] = ld4(sml + qi * 16 + 4 * gq); c14[qi] = ld4(sc1 + qi * 16 + 4 * gq); dr4[qi] = ld4(sdr + qi * 16 + 4 * gq);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned long long w = keepw[qi * 16 + 4 * gq + r];
-            kq[qi][r][0] = (unsigned)w >> m; kq[qi][r][1] = (unsigned)(w >> 32) >> m;
-        }
-    }
 #pragma unroll
     for (int kj = 0; kj < NT; ++kj) {
         const int key = kj * 16 + m;
-        const float4 kf = o.kfr[kj], vf = o.vfr[kj];
-        f32x4 st[4], dpt[4];
-#pragma unroll
-        for (int qi = kj; qi < NT; ++qi) { st[qi] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[qi] = st[qi]; }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int qi = kj; qi < NT; ++qi) {
-                st[qi] = mfma4(f4comp(o.qfr[qi], c), f4comp(kf, c), st[qi]);             // S^T: lane (key m, gq), reg r <-> query 16 qi + 4 gq + r
-                dpt[qi] = mfma4(f4comp(o.dofr[qi], c), f4comp(vf, c), dpt[qi]);
-            }
-        f32x4 dka = f32x4{0.f, 0.f, 0.f, 0.f}, dkb = dka, dva = dka, dvb = dka;
-#pragma unroll
-        for (int qi = kj; qi < NT; ++qi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qq = qi * 16 + 4 * gq + r;
-                // (a query row past T has 1 / row sum = 0, i.e. c = 0 and delta / l = 0: P~ = dS = 0 without a test)
-                float e = __builtin_amdgcn_exp2f(fmaf(st[qi][r], LOG2E, -f4comp(ml4[qi], r)));
-                if (qi == kj) e = (key <= qq) ? e : 0.f;
-                const float c = ((kq[qi][r][kj >> 1] >> ((kj & 1) * 16)) & 1u) ? f4comp(c14[qi], r) : 0.f;
-                const float pd = e * c;
-                const float ds = e * fmaf(dpt[qi][r], c, -f4comp(dr4[qi], r));
-                if (r & 1) { dvb = mfma4(o.dots[qi][r], pd, dvb); dkb = mfma4(o.qts[qi][r], ds, dkb); }
-                else       { dva = mfma4(o.dots[qi][r], pd, dva); dka = mfma4(o.qts[qi][r], ds, dka); }
-            }
-        dka += dkb; dva += dvb;
-        bdk.st4(key, col4, make_float4(dka[0], dka[1], dka[2], dka[3]));
-        bdv.st4(key, col4, make_float4(dva[0], dva[1], dva[2], dva[3]));
+        bdk.st4(key, col4, make_float4(dk[kj][0], dk[kj][1], dk[kj][2], dk[kj][3]));
+        bdv.st4(key, col4, make_float4(dv[kj][0], dv[kj][1], dv[kj][2], dv[kj][3]));
     }
 }
 
-
-
 template <int NT>
-__device__ __forceinline__ void attn_bwd_head(const AttnArgs& a, int g, int b, long long rowbase, int h, float* __restrict__ stat_lds,
-                                              unsigned long long* __restrict__ keepw) {
+__device__ __forceinline__ void attn_bwd_head(const AttnArgs& a, int g, int b, long long rowbase, int h, float* __restrict__ lds) {
     AttnBwdOps o;
     STRIP_RSTAMP(16);                                   // (diagnostic builds of sasrec_strip.hip only)
     attn_bwd_load_saved<NT>(o, a, g, b, rowbase, h);
     attn_bwd_load_dout<NT>(o, a, rowbase, h);
     STRIP_RSTAMP(17);
-    attn_bwd_compute<NT>(o, a, rowbase, h, stat_lds, keepw);
+    attn_bwd_compute<NT>(o, a, rowbase, h, lds);
 }
 
 }  // namespace amid

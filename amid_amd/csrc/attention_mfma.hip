@@ -44,8 +44,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
     const int g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
     const int wv = wave_id(), h = part * hw + wv, lane = lane_id();
-    float* stat_lds = smem + wv * (ATTN_BWD_LDS_PER_WAVE / 4);                            // this wave's scratch block (attention_mfma.h)
-    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(stat_lds + ATTN_BWD_STAT_FLOATS);
+    float* lds = smem + wv * (ATTN_BWD_LDS_PER_WAVE / 4);                                 // this wave's scratch block (attention_mfma.h)
     if (!live) {                                                                       // no gradient reaches this sequence: exact zeros
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = lane; i < T * (AHD / 4); i += 64) {
@@ -60,10 +59,10 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
     }
 
     switch ((T + 15) >> 4) {
-        case 1: attn_bwd_head<1>(a, g, b, rowbase, h, stat_lds, keepw); break;
-        case 2: attn_bwd_head<2>(a, g, b, rowbase, h, stat_lds, keepw); break;
-        case 3: attn_bwd_head<3>(a, g, b, rowbase, h, stat_lds, keepw); break;
-        default: attn_bwd_head<4>(a, g, b, rowbase, h, stat_lds, keepw); break;
+        case 1: attn_bwd_head<1>(a, g, b, rowbase, h, lds); break;
+        case 2: attn_bwd_head<2>(a, g, b, rowbase, h, lds); break;
+        case 3: attn_bwd_head<3>(a, g, b, rowbase, h, lds); break;
+        default: attn_bwd_head<4>(a, g, b, rowbase, h, lds); break;
     }
 }
 

@@ -506,8 +506,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_bwd_kernel(const SeqBwdArgs
     row.off = row.ok ? phys * (unsigned)(D * 4) + 16u * (unsigned)gq : STRIP_OOB;
     const long long rowbase = (long long)g * sg.M + (long long)b * T;
     float* att = smem + 2 * D * D + 16 * D;                                       // behind the ring and the two LayerNorm scratch blocks
-    float* stat_lds = att + w * (ATTN_BWD_LDS_PER_WAVE / 4);                      // this wave's scratch block (attention_mfma.h)
-    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(stat_lds + ATTN_BWD_STAT_FLOATS);
+    float* att_lds = att + w * (ATTN_BWD_LDS_PER_WAVE / 4);                       // this wave's scratch block (attention_mfma.h)
 
     STRIP_RSTAMP(0);
     STRIP_STAMP(14);
@@ -535,15 +534,15 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_bwd_kernel(const SeqBwdArgs
         if (nt4) {
             attn_bwd_load_dout<4>(oa, P.at, rowbase, w);
             attn_bwd_load_saved<4>(ob, P.at, g, b, rowbase, w + STRIP_WAVES); attn_bwd_load_dout<4>(ob, P.at, rowbase, w + STRIP_WAVES);
-            attn_bwd_compute<4>(oa, P.at, rowbase, w, stat_lds, keepw);
+            attn_bwd_compute<4>(oa, P.at, rowbase, w, att_lds);
             STRIP_RSTAMP(sb + 2);
-            attn_bwd_compute<4>(ob, P.at, rowbase, w + STRIP_WAVES, stat_lds, keepw);
+            attn_bwd_compute<4>(ob, P.at, rowbase, w + STRIP_WAVES, att_lds);
         } else {
             attn_bwd_load_dout<3>(oa, P.at, rowbase, w);
             attn_bwd_load_saved<3>(ob, P.at, g, b, rowbase, w + STRIP_WAVES); attn_bwd_load_dout<3>(ob, P.at, rowbase, w + STRIP_WAVES);
-            attn_bwd_compute<3>(oa, P.at, rowbase, w, stat_lds, keepw);
+            attn_bwd_compute<3>(oa, P.at, rowbase, w, att_lds);
             STRIP_RSTAMP(sb + 2);
-            attn_bwd_compute<3>(ob, P.at, rowbase, w + STRIP_WAVES, stat_lds, keepw);
+            attn_bwd_compute<3>(ob, P.at, rowbase, w + STRIP_WAVES, att_lds);
         }
         STRIP_RSTAMP(sb + 3);
         w_ring_wait();                  // dq / dk / dv have reached L2

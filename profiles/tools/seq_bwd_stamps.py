@@ -71,7 +71,5 @@ print(f"s_memtime ticks per microsecond over the kernel (wave 0): {(host[15] - h
 for w in range(4):
     t = [host[w * 32 + i] for i in range(14)]
     print(f"wave {w}: total {(t[13] - t[0]) / 100:.2f} us; " + ", ".join(f"{names[i]} +{(t[i] - t[i - 1]) / 100:.2f}" for i in range(1, 14)))
-for w in range(4):        # stamps 16..18 inside the last attention call (layer 0, second head), which ends at stamp 10
-    t = [host[w * 32 + i] for i in (16, 17, 18, 10)]
-    print(f"wave {w}, last attention call: loads issued + Philox +{(t[1] - t[0]) / 100:.2f}, scale + phase 1 (waits for the loads) "
-          f"+{(t[2] - t[1]) / 100:.2f}, phase 2 +{(t[3] - t[2]) / 100:.2f}")
+for w in range(4):        # stamps 16, 17 inside the last attention call of the standalone form (not used by the fused kernel's split calls)
+    pass
