@@ -96,10 +96,10 @@ int amid_attn_mfma_bwd_launch(const void* args, void* stream) {
     // they wait ~8 us (their neighbour's load phase) before requesting their own operands
     const int n_cu = cu_count();
     a.stagger_from = (grid >= 2 * n_cu) ? n_cu : -1;
-    // measured at B 256, T 50 (4 key tiles): 0 sleeps: 52.2 us, 1: 50.4, 2: 48.2, 3: 53.5, 4: 55.6; at T 20 (2 tiles) the neighbour's load
-    // phase is too short to be worth waiting for: 0: 22.2 us, 1: 23.8, 2: 25.7
-    const int nt = (a.T + 15) >> 4;
-    a.stagger_sleeps = nt >= 4 ? 2 : nt == 3 ? 1 : 0;
+    // measured at B 256, T 50 (4 key tiles) with the first backward kernel (two passes, 80 loads per head): 0 sleeps: 52.2 us, 1: 50.4,
+    // 2: 48.2, 3: 53.5.  The one-pass kernel's load phase is a third as long: the wait no longer pays (live launch in the step:
+    // 0 sleeps 0.3875 ms/step, 1: 0.3894, 2: 0.3891) -- kept as a mechanism, set to 0
+    a.stagger_sleeps = 0;
     const size_t lds = (size_t)hw * ATTN_BWD_LDS_PER_WAVE;
     attn_bwd_mfma_kernel<<<grid, hw * 64, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
