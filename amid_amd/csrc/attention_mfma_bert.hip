@@ -10,6 +10,8 @@
 namespace amid {
 
 constexpr int BHD = 32;
+constexpr int BERT_KT_LD = 68;                                  // row stride of the backward's K^T image
+constexpr int BERT_BWD_LDS_PER_WAVE = ATTN_BWD_LDS_PER_WAVE + BHD * BERT_KT_LD * 4;
 
 __device__ __forceinline__ f32x4 frag2(const float4 (&a)[2], const float4 (&b)[2], f32x4 c) {
     c = mfma_frag(a[0], b[0], c);
@@ -113,6 +115,121 @@ __global__ __launch_bounds__(512) void attn_fwd_bert_kernel(const AttnArgs a) {
     }
 }
 
+// Backward in ONE pass over the (query tile, key tile) pairs, as attention_mfma.h's attn_bwd_compute: per pair, lanes = queries,
+// S and dP~ (16 matrix instructions over the two halves of the head dim), the element-wise part, dQ += dS K; then the P~ and dS tiles
+// are TRANSPOSED through the wave's LDS scratch and dV += P~^T dO, dK += dS^T Qs accumulate per key tile across the query tiles
+// (the first version recomputed S^T and dP~^T with lanes = keys in a second pass: 56 matrix instructions per pair, now 40, and one
+// exponential per element).  K, V and K^T stay in registers for all query tiles; Q, dO, O of a query tile are loaded when it is
+// reached (two waves per SIMD cover the latency), their transposed fragments made through LDS.
+template <int NT>
+__device__ __forceinline__ void attn_bwd_bert_body(const AttnArgs& a, int g, int b, long long rowbase, int h, float* __restrict__ lds) {
+    const int T = a.T, D = a.D, H = a.H;
+    const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    const float inv = 1.0f / a.scale;
+    const unsigned char* kk = a.key_keep ? a.key_keep + (long long)b * T : nullptr;
+    float* tile = lds;
+    float* tile2 = lds + ATTN_BWD_TILE_FLOATS;
+    const SeqBuf bq(a.q, rowbase, T, D), bk(a.k, rowbase, T, D), bv(a.v, rowbase, T, D), bo(a.o, rowbase, T, D), bdo(a.d_o, rowbase, T, D),
+                 bst(a.stats, rowbase, T, 2 * H), bdq(a.dq, rowbase, T, D), bdk(a.dk, rowbase, T, D), bdv(a.dv, rowbase, T, D);
+    const int colb = h * BHD + 4 * gq;
+    float4 kf[4][2], vf[4][2];
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { kf[kj][c] = bk.ld4(kj * 16 + m, colb + 16 * c); vf[kj][c] = bv.ld4(kj * 16 + m, colb + 16 * c); }
+    unsigned valid, okb;
+    key_bits(kk, T, gq, valid, okb);
+    unsigned long long kw_own = ~0ull;
+    if (a.train) {
+        const int qrow = min(lane, T - 1);
+        kw_own = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step, (unsigned long long)(b * H + h) * T + qrow, T,
+                               a.thr16);
+    }
+    // K^T of the head as an LDS image [32 dims][68] (keys along the row; 68: the 16 dims of a read fall on 8 bank sets): the dQ product's
+    // first operand -- K[key 16 kj + 4 gq + r][dim 16 c + m], r = 0 .. 3 -- is one 16-byte read instead of 32 registers held for all pairs
+    float* ktimg = lds + 2 * ATTN_BWD_TILE_FLOATS;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ktimg[(16 * c + 4 * gq + e) * BERT_KT_LD + kj * 16 + m] = f4comp(kf[kj][c], e);
+    f32x4 dk[4][2], dv[4][2];
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { dk[kj][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kj][c] = dk[kj][c]; }
+#pragma unroll 1                          // (a real loop: unrolled, the scheduler hoists every query tile's operand loads to the top and spills)
+    for (int qi = 0; qi < NT; ++qi) {
+        const int q = qi * 16 + m;
+        float4 qf[2], dof[2];
+        float dsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            qf[c] = f4scale(bq.ld4(q, colb + 16 * c), inv);
+            dof[c] = bdo.ld4(q, colb + 16 * c);
+            dsum += f4hsum(f4mul(dof[c], bo.ld4(q, colb + 16 * c)));
+        }
+        const float mrow = bst.ld1(q, 2 * h), rl = bst.ld1(q, 2 * h + 1);       // (a query row past T: both zero -> P = 0)
+        const float delta = quad_group_sum(dsum);
+        float qts[2][4], dots[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { tile_transpose(tile, qf[c], qts[c]); tile_transpose(tile2, dof[c], dots[c]); }
+        const unsigned long long kw = shfl64(kw_own, q);
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int kj = 0; kj < NT; ++kj) { s[kj] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kj] = s[kj]; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int kj = 0; kj < NT; ++kj) {
+                    s[kj] = mfma4(f4comp(kf[kj][c], e), f4comp(qf[c], e), s[kj]);
+                    dp[kj] = mfma4(f4comp(vf[kj][c], e), f4comp(dof[c], e), dp[kj]);
+                }
+        f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kj = 0; kj < NT; ++kj) {
+            float pd[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = kj * 16 + 4 * gq + r;
+                const unsigned bit = 1u << (kj * 4 + r);
+                const bool vld = valid & bit, ok = okb & bit;
+                const float p = vld ? fast_exp((ok ? s[kj][r] : -1e9f) - mrow) * rl : 0.f;
+                const bool keep = (kw >> n) & 1ull;
+                pd[r] = keep ? p * a.dscale : 0.f;
+                const float dpk = keep ? dp[kj][r] * a.dscale : 0.f;
+                ds[r] = ok ? p * (dpk - delta) : 0.f;                            // masked_fill: no gradient through a masked score
+            }
+            const float4 k0 = ld4(ktimg + m * BERT_KT_LD + kj * 16 + 4 * gq), k1 = ld4(ktimg + (16 + m) * BERT_KT_LD + kj * 16 + 4 * gq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dq[0] = mfma4(f4comp(k0, r), ds[r], dq[0]); dq[1] = mfma4(f4comp(k1, r), ds[r], dq[1]); }
+            float pt[4], dst[4];                          // lane (key m, gq), r <-> query 16 qi + 4 gq + r
+            tile_transpose(tile, make_float4(pd[0], pd[1], pd[2], pd[3]), pt);
+            tile_transpose(tile2, make_float4(ds[0], ds[1], ds[2], ds[3]), dst);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    dv[kj][c] = mfma4(dots[c][r], pt[r], dv[kj][c]);
+                    dk[kj][c] = mfma4(qts[c][r], dst[r], dk[kj][c]);
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            bdq.st4(q, colb + 16 * c, make_float4(dq[c][0] * inv, dq[c][1] * inv, dq[c][2] * inv, dq[c][3] * inv));
+    }
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bdk.st4(kj * 16 + m, colb + 16 * c, make_float4(dk[kj][c][0], dk[kj][c][1], dk[kj][c][2], dk[kj][c][3]));
+            bdv.st4(kj * 16 + m, colb + 16 * c, make_float4(dv[kj][c][0], dv[kj][c][1], dv[kj][c][2], dv[kj][c][3]));
+        }
+}
+
 __global__ __launch_bounds__(512) void attn_bwd_bert_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, D = a.D, H = a.H;
@@ -121,10 +238,6 @@ __global__ __launch_bounds__(512) void attn_bwd_bert_kernel(const AttnArgs a) {
     const int g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
     const int h = wave_id(), lane = lane_id();
-    const int m = lane & 15, gq = lane >> 4;
-    const int NT = (T + 15) >> 4;
-    const float inv = 1.0f / a.scale;
-    const unsigned char* kk = a.key_keep ? a.key_keep + (long long)b * T : nullptr;
     if (!live) {                                                                       // no gradient reaches this sequence: exact zeros
         const int hd = D / H, q4 = hd >> 2;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -134,136 +247,12 @@ __global__ __launch_bounds__(512) void attn_bwd_bert_kernel(const AttnArgs a) {
         }
         return;
     }
-    float4* rstat = reinterpret_cast<float4*>(smem) + h * 64;                                       // [H][64] (max, 1/sum, delta, -)
-    unsigned long long* keepw = reinterpret_cast<unsigned long long*>(smem + H * 64 * 4) + h * 64;   // [H][64]
-    // ---------------- phase 1: lanes = queries -> dQ; row stats + keep words to LDS ----------------
-    {
-        float4 kf[4][2], vf[4][2];
-        float kt[4][4][2];
-#pragma unroll
-        for (int kj = 0; kj < 4; ++kj)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                kf[kj][c] = ld4_row(a.k, rowbase, kj * 16 + m, T, D, h * BHD + 16 * c + 4 * gq);
-                vf[kj][c] = ld4_row(a.v, rowbase, kj * 16 + m, T, D, h * BHD + 16 * c + 4 * gq);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) kt[kj][r][c] = ld1_row(a.k, rowbase, kj * 16 + 4 * gq + r, T, D, h * BHD + 16 * c + m);
-            }
-        unsigned valid, okb;
-        key_bits(kk, T, gq, valid, okb);
-        unsigned long long kw_own = ~0ull;
-        if (a.train) {
-            const int qrow = min(gq * 16 + m, T - 1);
-            kw_own = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step,
-                                   (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
-        }
-        keepw[lane] = kw_own;                                                            // row index = 16 gq + m = lane
-#pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-            if (qi >= NT) break;
-            const int q = qi * 16 + m;
-            float4 qf[2], dof[2];
-            float dsum = 0.f;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int col = h * BHD + 16 * c + 4 * gq;
-                qf[c] = f4scale(ld4_row(a.q, rowbase, q, T, D, col), inv);
-                dof[c] = ld4_row(a.d_o, rowbase, q, T, D, col);
-                dsum += f4hsum(f4mul(dof[c], ld4_row(a.o, rowbase, q, T, D, col)));
-            }
-            const float delta = quad_group_sum(dsum);
-            const float2 st2 = *reinterpret_cast<const float2*>(a.stats + ((rowbase + min(q, T - 1)) * H + h) * 2);
-            const float mrow = st2.x, rl = st2.y;
-            if (gq == 0) rstat[q] = make_float4(mrow, rl, delta, 0.f);
-            const unsigned long long kw = shfl64(kw_own, qi * 16 + m);
-            f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int kj = 0; kj < 4; ++kj) {
-                if (kj < NT) {
-                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
-                    s = frag2(kf[kj], qf, s);
-                    dp = frag2(vf[kj], dof, dp);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = kj * 16 + 4 * gq + r;
-                        const unsigned bit = 1u << (kj * 4 + r);
-                        const bool vld = valid & bit, ok = okb & bit;
-                        const float p = vld ? fast_exp((ok ? s[r] : -1e9f) - mrow) * rl : 0.f;
-                        const float dpk = ((kw >> n) & 1ull) ? dp[r] * a.dscale : 0.f;
-                        const float ds = ok ? p * (dpk - delta) : 0.f;               // masked_fill: no gradient through a masked score
-                        dq[0] = mfma4(kt[kj][r][0], ds, dq[0]);
-                        dq[1] = mfma4(kt[kj][r][1], ds, dq[1]);
-                    }
-                }
-            }
-            if (q < T) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    st4(a.dq + (rowbase + q) * D + h * BHD + 16 * c + 4 * gq,
-                        make_float4(dq[c][0] * inv, dq[c][1] * inv, dq[c][2] * inv, dq[c][3] * inv));
-            }
-        }
-    }
-    // rstat / keepw of a wave are written and read by that wave only (LDS operations of one wave complete in order)
-    // ---------------- phase 2: lanes = keys -> dK, dV ----------------------------------------------
-    float4 qfr[4][2], dofr[4][2];
-    float qts[4][4][2], dots[4][4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            qfr[t][c] = f4scale(ld4_row(a.q, rowbase, t * 16 + m, T, D, h * BHD + 16 * c + 4 * gq), inv);
-            dofr[t][c] = ld4_row(a.d_o, rowbase, t * 16 + m, T, D, h * BHD + 16 * c + 4 * gq);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                qts[t][r][c] = ld1_row(a.q, rowbase, t * 16 + 4 * gq + r, T, D, h * BHD + 16 * c + m) * inv;
-                dots[t][r][c] = ld1_row(a.d_o, rowbase, t * 16 + 4 * gq + r, T, D, h * BHD + 16 * c + m);
-            }
-        }
-#pragma unroll
-    for (int kj = 0; kj < 4; ++kj) {
-        if (kj >= NT) break;
-        const int key = kj * 16 + m;
-        float4 kf[2], vf[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            kf[c] = ld4_row(a.k, rowbase, key, T, D, h * BHD + 16 * c + 4 * gq);
-            vf[c] = ld4_row(a.v, rowbase, key, T, D, h * BHD + 16 * c + 4 * gq);
-        }
-        const bool key_in = key < T;
-        const bool key_ok = key_in && (kk == nullptr || kk[min(key, T - 1)] != 0);
-        f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dv[2] = {dk[0], dk[0]};
-#pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-            if (qi >= NT) continue;
-            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = st;
-            st = frag2(qfr[qi], kf, st);                 // S^T: lane (key m, gq), reg r <-> query qi*16 + 4 gq + r
-            dpt = frag2(dofr[qi], vf, dpt);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qq = qi * 16 + 4 * gq + r;
-                const float4 rs = rstat[min(qq, 63)];
-                const bool live = (qq < T) && key_in;
-                const bool keep = (keepw[min(qq, 63)] >> key) & 1ull;
-                const float p = live ? fast_exp((key_ok ? st[r] : -1e9f) - rs.x) * rs.y : 0.f;
-                const float pd = keep ? p * a.dscale : 0.f;
-                const float dpk = keep ? dpt[r] * a.dscale : 0.f;
-                const float ds = (live && key_ok) ? p * (dpk - rs.z) : 0.f;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    dv[c] = mfma4(dots[qi][r][c], pd, dv[c]);
-                    dk[c] = mfma4(qts[qi][r][c], ds, dk[c]);
-                }
-            }
-        }
-        if (key_in) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const long long off = (rowbase + key) * D + h * BHD + 16 * c + 4 * gq;
-                st4(a.dk + off, make_float4(dk[c][0], dk[c][1], dk[c][2], dk[c][3]));
-                st4(a.dv + off, make_float4(dv[c][0], dv[c][1], dv[c][2], dv[c][3]));
-            }
-        }
+    float* lds = smem + h * (BERT_BWD_LDS_PER_WAVE / 4);
+    switch ((T + 15) >> 4) {
+        case 1: attn_bwd_bert_body<1>(a, g, b, rowbase, h, lds); break;
+        case 2: attn_bwd_bert_body<2>(a, g, b, rowbase, h, lds); break;
+        case 3: attn_bwd_bert_body<3>(a, g, b, rowbase, h, lds); break;
+        default: attn_bwd_bert_body<4>(a, g, b, rowbase, h, lds); break;
     }
 }
 
@@ -281,7 +270,7 @@ int amid_attn_bert_fwd_launch(const void* args, void* stream) {
 
 int amid_attn_bert_bwd_launch(const void* args, void* stream) {
     const AttnArgs& a = *(const AttnArgs*)args;
-    const size_t lds = (size_t)a.H * 64 * (16 + 8);
+    const size_t lds = (size_t)a.H * BERT_BWD_LDS_PER_WAVE;
     attn_bwd_bert_kernel<<<2 * a.B, a.H * 64, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
