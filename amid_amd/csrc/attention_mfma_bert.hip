@@ -60,13 +60,18 @@ __global__ __launch_bounds__(512) void attn_fwd_bert_kernel(const AttnArgs a) {
         kw_own = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step,
                                (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
     }
+    float4 qall[4][2];                   // every query tile's rows requested up front (inside the loop each tile waited out its own round trip)
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) qall[qi][c] = ld4_row(a.q, rowbase, qi * 16 + m, T, D, h * BHD + 16 * c + 4 * gq);
 #pragma unroll
     for (int qi = 0; qi < 4; ++qi) {
         if (qi >= NT) break;
         const int q = qi * 16 + m;
         float4 qf[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) qf[c] = f4scale(ld4_row(a.q, rowbase, q, T, D, h * BHD + 16 * c + 4 * gq), inv);
+        for (int c = 0; c < 2; ++c) qf[c] = f4scale(qall[qi][c], inv);
         const unsigned long long kw = shfl64(kw_own, qi * 16 + m);
         f32x4 s[4];
         float mx = -INFINITY;
