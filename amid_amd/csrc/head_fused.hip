@@ -11,6 +11,15 @@
 
 namespace amid {
 
+// diagnostic builds only (profiles/tools/head_stamps.py compiles this file with -DAMID_HEAD_STAMPS into its own library): real-time
+// (100 MHz) stamps of workgroup 0's thread 0, in a buffer no kernel reads
+#ifdef AMID_HEAD_STAMPS
+static __device__ unsigned long long amid_head_stamp_buf[32];
+#define HEAD_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) amid_head_stamp_buf[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HEAD_STAMP(i) do { } while (0)
+#endif
+
 struct HeadArgs {
     const float* x;            // [2, B, T, D] output of the last encoder layer
     const float* lnw[2]; const float* lnb[2];   // last_layernorm (null: no LN, BERT4Rec)
@@ -186,31 +195,45 @@ __host__ __device__ inline size_t head_lds_floats(int D, int hid) {
     return head_carve_floats(D, hid, 64) + 32 * D;          // scratch: [2][8][2][D] partials of the LayerNorm backward (forward uses half)
 }
 
-// au[d][j] = b1[j] + sum_e w1t[e][j] u_d[e]
+// au[d][j] = b1[j] + sum_e w1t[e][j] u_d[e].  Eight lanes per output, each summing every eighth e (a thread per output walked D
+// dependent fmas: 2.2 us of the 22 this kernel's workgroup lives -- profiles/tools/head_stamps.py).
 __device__ __forceinline__ void user_half(const HeadArgs& a, const HeadLds& s, const Tg tg) {
     const int D = a.D, hid = a.hid;
-    for (int dj = tg.tid; dj < 2 * hid; dj += tg.n) {
-        const int d = dj / hid, j = dj - d * hid;
-        float acc = a.b1[j];
-        const float* ur = s.u_s + d * D;
-        for (int e = 0; e < D; ++e) acc = fmaf(s.w1t[e * (hid + 1) + j], ur[e], acc);
-        s.au[dj] = acc;
+    const int part = tg.tid & 7;
+    for (int o0 = 0; o0 < 2 * hid; o0 += tg.n >> 3) {             // (uniform trip count: the shuffles below need every lane)
+        const int dj = o0 + (tg.tid >> 3);
+        const bool on = dj < 2 * hid;
+        const int d = on ? dj / hid : 0, j = on ? dj - d * hid : 0;
+        float acc = 0.f;
+        if (on) {
+            const float* ur = s.u_s + d * D;
+            for (int e = part; e < D; e += 8) acc = fmaf(s.w1t[e * (hid + 1) + j], ur[e], acc);
+        }
+        acc = group_sum<8>(acc);
+        if (on && part == 0) s.au[dj] = acc + a.b1[j];
     }
 }
-// ci[n][j] = sum_e w1t[D+e][j] item[n][e] for the chunk's items (items read from global: each lane group of `hid` lanes shares a row)
+// ci[n][j] = sum_e w1t[D+e][j] item[n][e] for the chunk's items (items read from global).  Eight lanes per output, each taking every
+// eighth column quad of the item row: the eight lanes of an output read 128 consecutive bytes.
 __device__ __forceinline__ void item_half(const HeadArgs& a, const HeadLds& s, int b, int n0, int nn, const Tg tg) {
     const int D = a.D, hid = a.hid;
-    for (int nj = tg.tid; nj < nn * hid; nj += tg.n) {
-        const int n = nj / hid, j = nj - n * hid;
-        const float* ir = a.items + ((long long)b * a.NI + n0 + n) * D;
+    const int part = tg.tid & 7;
+    for (int o0 = 0; o0 < nn * hid; o0 += tg.n >> 3) {
+        const int nj = o0 + (tg.tid >> 3);
+        const bool on = nj < nn * hid;
+        const int n = on ? nj / hid : 0, j = on ? nj - n * hid : 0;
         float acc = 0.f;
-        for (int e = 0; e < D; e += 4) {
-            const float4 it = ld4(ir + e);
-            const float* wp = s.w1t + (D + e) * (hid + 1) + j;
-            acc = fmaf(wp[0], it.x, acc); acc = fmaf(wp[hid + 1], it.y, acc);
-            acc = fmaf(wp[2 * (hid + 1)], it.z, acc); acc = fmaf(wp[3 * (hid + 1)], it.w, acc);
+        if (on) {
+            const float* ir = a.items + ((long long)b * a.NI + n0 + n) * D;
+            for (int e = 4 * part; e < D; e += 32) {
+                const float4 it = ld4(ir + e);
+                const float* wp = s.w1t + (D + e) * (hid + 1) + j;
+                acc = fmaf(wp[0], it.x, acc); acc = fmaf(wp[hid + 1], it.y, acc);
+                acc = fmaf(wp[2 * (hid + 1)], it.z, acc); acc = fmaf(wp[3 * (hid + 1)], it.w, acc);
+            }
         }
-        s.ci[n * (hid + 1) + j] = acc;
+        acc = group_sum<8>(acc);
+        if (on && part == 0) s.ci[n * (hid + 1) + j] = acc;
     }
 }
 
@@ -219,6 +242,7 @@ __device__ __forceinline__ void item_half(const HeadArgs& a, const HeadLds& s, i
 __device__ __forceinline__ void scorer_fwd_part(const HeadArgs& a, const HeadLds& s, int b, const Tg tg) {
     const int hid = a.hid, NI = a.NI;
     user_half(a, s, tg);
+    HEAD_STAMP(3);
     float lsum = 0.f;
     const int CH = s.chunk;
     for (int n0 = 0; n0 < NI; n0 += CH) {
@@ -226,10 +250,16 @@ __device__ __forceinline__ void scorer_fwd_part(const HeadArgs& a, const HeadLds
         __syncthreads();
         item_half(a, s, b, n0, nn, tg);
         __syncthreads();
-        for (int nd = tg.tid; nd < nn * 2; nd += tg.n) {
-            const int n = nd >> 1, d = nd & 1;
-            float z = a.b2[0];
-            for (int j = 0; j < hid; ++j) z = fmaf(a.w2[j], fmaxf(s.au[d * hid + j] + s.ci[n * (hid + 1) + j], 0.f), z);
+        HEAD_STAMP(4);
+        // 32 lanes per logit, one hidden unit each (a thread per logit walked `hid` dependent loads and fmas)
+        for (int nd0 = 0; nd0 < nn * 2; nd0 += tg.n >> 5) {
+            const int nd = nd0 + (tg.tid >> 5), j0 = tg.tid & 31;
+            const bool on = nd < nn * 2;
+            const int n = on ? nd >> 1 : 0, d = nd & 1;
+            float zp = 0.f;
+            if (on) for (int j = j0; j < hid; j += 32) zp = fmaf(a.w2[j], fmaxf(s.au[d * hid + j] + s.ci[n * (hid + 1) + j], 0.f), zp);
+            const float z = group_sum<32>(zp) + a.b2[0];
+            if (!on || j0 != 0) continue;
             const float p = 1.0f / (1.0f + expf(-z));
             const long long o = (long long)b * NI + n0 + n;
             (d ? a.p2 : a.p1)[o] = p;
@@ -243,6 +273,7 @@ __device__ __forceinline__ void scorer_fwd_part(const HeadArgs& a, const HeadLds
             }
         }
     }
+    HEAD_STAMP(5);
     if (a.labels) {
         __syncthreads();
         lsum = group_sum<64>(lsum);
@@ -254,9 +285,13 @@ __device__ __forceinline__ void scorer_fwd_part(const HeadArgs& a, const HeadLds
 
 __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, float* __restrict__ sm, int b) {
     const HeadLds s(sm, a.D, a.hid);
+    HEAD_STAMP(0);
     stage_w1t(s.w1t, a.w1, 2 * a.D, a.hid, whole_block());
+    HEAD_STAMP(1);
     if (a.own_only) lnmean_rows_own(a, b, s.scr, s.u_s); else lnmean_rows(a, b, s.scr, s.u_s);
+    HEAD_STAMP(2);
     scorer_fwd_part(a, s, b, whole_block());
+    HEAD_STAMP(6);
 }
 
 // dx rows of (g, b) from du_s[D] (LDS): dx = LN_last'(du / T ; x) ; partial d gamma / d beta -> ln_part[(g*B+b)][2][D]
@@ -465,6 +500,7 @@ __device__ __forceinline__ float* scorer_bwd_part(const HeadArgs& a, const HeadL
             s.dw2[hid] += acc;
         }
         __syncthreads();
+        HEAD_STAMP(8);
         // d item[n][e] = sum_j dc[n][j] w1t[D+e][j]
         for (int ne = tg.tid; ne < nn * D; ne += tg.n) {
             const int n = ne / D, e = ne - n * D;
@@ -485,6 +521,7 @@ __device__ __forceinline__ float* scorer_bwd_part(const HeadArgs& a, const HeadL
         }
     }
     __syncthreads();
+    HEAD_STAMP(9);
     // user halves: du_d[e] = sum_j da[d][j] w1t[e][j]  -> scratch region [2][D] reused from ci (dead now)
     float* du_s = s.ci;
     for (int de = tg.tid; de < 2 * D; de += tg.n) {
@@ -512,8 +549,11 @@ __device__ __forceinline__ void head_bwd_body(const HeadArgs& a, float* __restri
     if ((int)blockIdx.x >= a.B) { transpose_extra(a, sm); return; }
     const HeadLds s(sm, a.D, a.hid);
     const int b = blockIdx.x;
+    HEAD_STAMP(7);
     float* du_s = scorer_bwd_part<FUSED, false>(a, s, b, whole_block());
+    HEAD_STAMP(10);
     if (a.own_only) lnmean_rows_bwd_own(a, b, du_s, s.scr); else lnmean_rows_bwd(a, b, du_s, s.scr);
+    HEAD_STAMP(11);
 }
 
 __global__ __launch_bounds__(512) void head_fwd_kernel(const HeadArgs a) {
@@ -647,6 +687,12 @@ __global__ __launch_bounds__(768) void scorer_multi_fwd_bwd_kernel(const MultiHe
 }  // namespace amid
 
 using namespace amid;
+
+#ifdef AMID_HEAD_STAMPS
+extern "C" int amid_head_stamps_read(unsigned long long* host) {       // diagnostic library only
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_head_stamp_buf), sizeof(unsigned long long) * 32);
+}
+#endif
 
 static int head_fill(HeadArgs& a, const float* x, const float* const* lnw, const float* const* lnb, const float* items, const float* w1,
                      const float* b1, const float* w2, const float* b2, int B, int T, int NI, int D, int hid, float eps) {
