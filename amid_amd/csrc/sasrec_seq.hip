@@ -269,6 +269,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs
     const int sq = w / WPS, si = w - sq * WPS;
     int n0 = sg.B;
     if (sg.live != nullptr) n0 = sg.live[sg.B];
+    // one sequence per workgroup: the live list holds domain 0's batch rows, then domain 1's, and tile i of the launch is its entry i --
+    // requested together with n0 instead of behind it (one scalar round trip less in front of the first loads)
+    int b_direct = 0;
+    if (SPW == 1 && sg.live != nullptr) b_direct = sg.live[min((int)blockIdx.x, sg.B - 1)];
     const int n1 = sg.live != nullptr ? sg.B - n0 : sg.B;
     const int t0 = (n0 + SPW - 1) / SPW, t1 = (n1 + SPW - 1) / SPW;
     if ((int)blockIdx.x >= t0 + t1) { SEQ_SCHED(1); return; }
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs
     float* kimg = smem + 2 * D * D;
     float* vimg = kimg + IMG_ROWS * IMG_COLS;
     int b = sidx;
-    if (sg.live != nullptr) b = sg.live[min(s0 + sidx, sg.B - 1)];
+    if (sg.live != nullptr) b = SPW == 1 ? b_direct : sg.live[min(s0 + sidx, sg.B - 1)];
     if (sidx >= n_g) b = 0;
     const bool seq_ok = sidx < n_g;
     const int t = si * 16 + m;
