@@ -387,6 +387,17 @@ struct WgradArgs {
 };
 
 constexpr int WG_ROWS = 64;    // rows staged per step
+// diagnostic builds only (profiles/tools/wgrad_stamps.py compiles this file with -DAMID_WGRAD_STAMPS into its own library): real-time
+// (100 MHz) stamps of workgroup 0's phases and every workgroup's start / end, in buffers no kernel reads
+#if defined(AMID_WGRAD_STAMPS) && AMID_TILE_RT == 7
+static __device__ unsigned long long amid_wgrad_stamp_buf[64];
+static __device__ unsigned long long amid_wgrad_sched_buf[1024 * 2];     // per workgroup: start, end
+#define WG_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (i) < 64) amid_wgrad_stamp_buf[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define WG_SCHED(slot) do { const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && wg_ < 1024) amid_wgrad_sched_buf[wg_ * 2 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WG_STAMP(i) do { } while (0)
+#define WG_SCHED(slot) do { } while (0)
+#endif
 [[maybe_unused]] constexpr int WG_LIVE_MAX = 1024;      // live sequences a split's window may hold (LDS, one int each)
 
 // One workgroup = one (domain, weight, row split): it streams its rows of (dY, X) in 64-row chunks through LDS and
@@ -406,6 +417,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradA
     float* Ys = smem;
     float* Xs = smem + WG_ROWS * LD;
     int* live = reinterpret_cast<int*>(smem + 2 * WG_ROWS * LD);       // [B] batch rows of this domain's live sequences (hint only)
+    WG_STAMP(0);
+    WG_SCHED(0);
     const int split = blockIdx.x, wsel = blockIdx.y, g = blockIdx.z;
     const int layer = wsel / 6, wi = wsel - layer * 6;
     const float* __restrict__ dy = a.dy[wsel];
@@ -437,6 +450,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradA
         __syncthreads();
         local_beg = hd[0]; local_end = hd[1]; sq0 = hd[2];
     }
+    WG_STAMP(1);
     const int nt = w / WPN, kt0 = (w % WPN) * KTW;
     const int i = lane & 15, gq = lane >> 4;
     constexpr int QPR = D / 4, RPP = GEMM_THREADS / QPR;
@@ -464,6 +478,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradA
         }
     };
     if (local_beg < local_end) fetch(local_beg);
+    WG_STAMP(2);
     for (int c0 = local_beg; c0 < local_end; c0 += WG_ROWS) {
         __syncthreads();                               // previous chunk fully consumed
 #pragma unroll
@@ -507,6 +522,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradA
             for (int t = 0; t < KTW; ++t) x_cur[t] = x_nxt[t];
         }
     }
+    WG_STAMP(40);
     float* wp = a.w_part[layer] + (((long long)g * 6 + wi) * a.splits + split) * D * D;
 #pragma unroll
     for (int t = 0; t < KTW; ++t)
@@ -522,6 +538,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradA
         for (int k = 0; k < RPP; ++k) s += Ys[k * D + e];
         bp[e] = s;
     }
+    WG_STAMP(41);
+    WG_SCHED(1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -732,6 +750,15 @@ static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
+
+#ifdef AMID_WGRAD_STAMPS
+extern "C" int amid_wgrad_sched_read(unsigned long long* host) {        // diagnostic library only
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_wgrad_sched_buf), sizeof(unsigned long long) * 2048);
+}
+extern "C" int amid_wgrad_stamps_read(unsigned long long* host) {       // diagnostic library only
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_wgrad_stamp_buf), sizeof(unsigned long long) * 64);
+}
+#endif
 
 extern "C" int amid_sas_wgrad_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits,
                                   float* const* w_part, float* const* b_part, void* stream) {
