@@ -41,8 +41,8 @@ print(f"launch (events, null stream): {ev0.elapsed_time(ev1) * 1e3:.1f} us")
 host = (ctypes.c_ulonglong * 64)()
 assert L.amid_wgrad_stamps_read(host) == 0
 t = list(host)
-print(f"workgroup (0,0,0): hint prologue +{(t[1] - t[0]) / 100:.2f}, first two chunks requested +{(t[2] - t[1]) / 100:.2f}, "
-      f"pipeline +{(t[40] - t[2]) / 100:.2f}, accumulators stored + bias sums +{(t[41] - t[40]) / 100:.2f}; total {(t[41] - t[0]) / 100:.2f} us")
+print(f"workgroup (0,0,0): hint prologue +{(t[1] - t[0]) / 100:.2f}, first chunk requested +{(t[2] - t[1]) / 100:.2f}, "
+      f"chunk loop +{(t[40] - t[2]) / 100:.2f}, accumulators stored + bias sums +{(t[41] - t[40]) / 100:.2f}; total {(t[41] - t[0]) / 100:.2f} us")
 sched = (ctypes.c_ulonglong * 2048)()
 assert L.amid_wgrad_sched_read(sched) == 0
 n = S * 12 * 2
