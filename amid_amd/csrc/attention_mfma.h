@@ -225,11 +225,7 @@ struct SeqBuf {
         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (row * ld + col) * 4, 0, 0));
         return make_float4(v[0], v[1], v[2], v[3]);
     }
-    __device__ __forceinline__ float2 ld2(int row, int col) const {
-        typedef unsigned v2u __attribute__((ext_vector_type(2)));
-        const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (row * ld + col) * 4, 0, 0);
-        return make_float2(__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]));
-    }
+    // (no 8-byte load: hipcc 7.2 dropped the second dword of __builtin_amdgcn_raw_buffer_load_b64 in this kernel -- two ld1 instead)
     __device__ __forceinline__ float ld1(int row, int col) const {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (row * ld + col) * 4, 0, 0));
     }
