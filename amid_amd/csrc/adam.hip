@@ -322,19 +322,24 @@ __global__ __launch_bounds__(256) void optimizer_gathered_kernel(float* __restri
         const float* d0 = gathered + dense_off;
         for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
             if (i + 4 <= n) {
-                float4 gg = ld4(d0 + i);
-                for (int r = 1; r < world; ++r) {
-                    const float4 t = ld4(d0 + r * chunk_floats + i);
-                    gg.x += t.x; gg.y += t.y; gg.z += t.z; gg.w += t.w;
+                float4 gg;
+                if (dense_off < 0) {                                   // the dense gradient was all-reduced into g by the caller
+                    gg = ld4(g + i);
+                } else {
+                    gg = ld4(d0 + i);
+                    for (int r = 1; r < world; ++r) {
+                        const float4 t = ld4(d0 + r * chunk_floats + i);
+                        gg.x += t.x; gg.y += t.y; gg.z += t.z; gg.w += t.w;
+                    }
+                    st4(g + i, gg);
                 }
-                st4(g + i, gg);
                 float4 pp = ld4(p + i), mm = ld4(m + i), vv = ld4(v + i);
                 adam_quad(pp, mm, vv, f4scale(gg, grad_scale), c);
                 st4(p + i, pp); st4(m + i, mm); st4(v + i, vv);
             } else {
                 for (long long k = i; k < n; ++k) {
-                    float gs = d0[k];
-                    for (int r = 1; r < world; ++r) gs += d0[r * chunk_floats + k];
+                    float gs = dense_off < 0 ? g[k] : d0[k];
+                    for (int r = 1; dense_off >= 0 && r < world; ++r) gs += d0[r * chunk_floats + k];
                     g[k] = gs;
                     adam_elem(p[k], m[k], v[k], gs * grad_scale, c);
                 }
@@ -468,8 +473,10 @@ extern "C" int amid_optimizer_step_gathered_f32(float* p, float* m, float* v, fl
                                                 long long dense_off, int D, int sentinel, float grad_scale, const void* step_state,
                                                 void* stream) {
     AMID_CHECK_ARG(p && m && v && g && n > 0 && table && m_tab && v_tab && last && gathered && step_state && D > 0 && (D % 4) == 0);
-    AMID_CHECK_ARG(world > 0 && world <= 16 && umax > 0 && id_rows * (long long)D >= umax && dense_off >= (long long)(id_rows + umax) * D &&
-                   (dense_off % 4) == 0 && (chunk_floats % 4) == 0 && chunk_floats >= dense_off + n);
+    // dense_off < 0: the chunks carry no dense part -- g already holds the world's summed dense gradient (the caller's all-reduce)
+    AMID_CHECK_ARG(world > 0 && world <= 16 && umax > 0 && id_rows * (long long)D >= umax && (chunk_floats % 4) == 0 &&
+                   (dense_off < 0 ? chunk_floats >= (long long)(id_rows + umax) * D
+                                  : (dense_off >= (long long)(id_rows + umax) * D && (dense_off % 4) == 0 && chunk_floats >= dense_off + n)));
     long long db = (n / 4 + 255) / 256;
     if (db < 1) db = 1;
     if (db > 1024) db = 1024;

@@ -6,6 +6,8 @@
 #define AMID_OK 0
 #define AMID_ERR_ARG (-1)        // bad argument (null pointer, unsupported size)
 #define AMID_ERR_UNSUPPORTED (-2)  // shape outside what the kernels are built for
+#define AMID_FLAG_INDEX_RANGE (1)
+#define AMID_FLAG_UMAX_EXCEEDED (2)
 
 #define AMID_CHECK_ARG(cond) do { if (!(cond)) return AMID_ERR_ARG; } while (0)
 #define AMID_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

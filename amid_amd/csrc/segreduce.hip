@@ -195,7 +195,7 @@ __global__ __launch_bounds__(1024) void segreduce_spans_pack_kernel(const int* _
                                                                     const int* __restrict__ ids, const int* __restrict__ n_uniq, int n_out,
                                                                     int pad_id, int* __restrict__ out_ids, int id_blocks,
                                                                     const float* __restrict__ dense_src, float* __restrict__ dense_dst,
-                                                                    long long dense_n) {
+                                                                    long long dense_n, int* __restrict__ err) {
     const int b = blockIdx.x;
     if (b < nch) {
         segreduce_spans_block<VEC>(b, seg_off, seg_of, n, partial, uniq_grad, SEG_CHUNK);
@@ -204,6 +204,9 @@ __global__ __launch_bounds__(1024) void segreduce_spans_pack_kernel(const int* _
     if (b < nch + id_blocks) {
         const int r = (b - nch) * 1024 + threadIdx.x;
         if (r < n_out) out_ids[r] = r < *n_uniq ? ids[r] : pad_id;
+        // more unique rows than the caller's bound: the segment reduce has written rows past the chunk's row part (into its dense
+        // tail) -- the step is corrupt; say so (the host checks the flag at its next synchronisation point)
+        if (r == 0 && err != nullptr && *n_uniq > n_out) atomicOr(err, AMID_FLAG_UMAX_EXCEEDED);
         return;
     }
     const long long nb = gridDim.x - nch - id_blocks;
@@ -290,12 +293,13 @@ extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted,
 extern "C" int amid_grad_tail_pack_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
                                        void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count,
                                        const int* uniq_ids, const int* n_uniq, int n_out, int pad_id, int* out_ids, const float* dense_src,
-                                       float* dense_dst, long long dense_n, const int* blk_off, int total_blocks, void* stream) {
+                                       float* dense_dst, long long dense_n, int* err_flag, const int* blk_off, int total_blocks, void* stream) {
     AMID_CHECK_ARG(blk_off == nullptr || total_blocks > 0);
     AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
                    max_count > 0);
-    AMID_CHECK_ARG(uniq_ids && n_uniq && out_ids && n_out > 0 && n_out <= n_idx && dense_src && dense_dst && dense_n > 0 &&
-                   ((((unsigned long long)dense_src) | ((unsigned long long)dense_dst)) & 15) == 0);
+    // dense_n == 0: the chunk carries no dense part (the caller all-reduces the dense gradient itself)
+    AMID_CHECK_ARG(uniq_ids && n_uniq && out_ids && n_out > 0 && n_out <= n_idx && dense_n >= 0 &&
+                   (dense_n == 0 || (dense_src && dense_dst && ((((unsigned long long)dense_src) | ((unsigned long long)dense_dst)) & 15) == 0)));
     if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK, n_seg = (nch + 3) / 4;
@@ -307,11 +311,12 @@ extern "C" int amid_grad_tail_pack_f32(const float* grad_rows, const int* pos_so
     long long cb = (dense_n / 4 + 1023) / 1024;
     if (cb < 1) cb = 1;
     if (cb > 256) cb = 256;
+    if (dense_n == 0) cb = 0;
 #define AMID_TAIL_LAUNCH(VEC)                                                                                                       \
     grad_tail_kernel<VEC><<<n_seg + (blk_off ? total_blocks : bx * n_entries), 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, \
                                                                                            partial, n_seg, en, bx, blk_off, n_entries);     \
     segreduce_spans_pack_kernel<VEC><<<nch + id_blocks + (int)cb, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad, nch, uniq_ids, n_uniq, \
-                                                                              n_out, pad_id, out_ids, id_blocks, dense_src, dense_dst, dense_n);
+                                                                              n_out, pad_id, out_ids, id_blocks, dense_src, dense_dst, dense_n, err_flag);
     if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }
 #undef AMID_TAIL_LAUNCH
     AMID_LAUNCH_CHECK();

@@ -28,9 +28,9 @@ constexpr int SORT_WAVES = SORT_THREADS / 64;
 //                          run); writes uniq_ids / seg_off / seg_of / n_uniq; flips the stot_0 copy
 // stot_0 is the one table that must be zero when a call starts: its two copies sit at a FIXED place at the head of the workspace
 // (whatever n_idx the workspace is used with), zero-filled once with the workspace; calls alternate between them and launch 1
-// re-zeroes the copy the next call will use.
+// re-zeroes the copy the next call will use, over the extent the previous call recorded for it (state[4 + copy]).
 constexpr int OS_BINS_MAX = 4096;
-constexpr int OS_STATE_INTS = 64;                 // [2] tile counter of launch 4
+constexpr int OS_STATE_INTS = 64;                 // [2] tile counter of launch 4, [3] stot_0 copy of this call, [4 + c] dirty extent of copy c
 constexpr int OS_SUPER = 16;                      // tiles per supertile
 constexpr int OS_SUPER_MAX = 256;                 // supertiles the fixed stot_0 area holds (4096 tiles = 8.4 M indices; beyond: 8-bit passes)
 
@@ -83,7 +83,12 @@ __device__ __forceinline__ void os_count_block(const int blk, const int nblk, co
         counts0[(long long)blk * bins0 + d] = c;
         if (c) atomicAdd(&st_use[(long long)sup * bins0 + d], c);
     }
-    for (int i = blk * SORT_THREADS + threadIdx.x; i < n_stot0; i += nblk * SORT_THREADS) st_zero[i] = 0;
+    // The other copy is dirty over what the PREVIOUS call (calls alternate between the copies) accumulated into it -- that call's
+    // n_stot0, which is not this call's when one workspace serves lists of different lengths (a plan's compact list and its full
+    // autograd list): every call records its extent in state[4 + copy], and the next one zeroes exactly that.
+    const int ext_other = state[4 + (1 - par)];
+    for (int i = blk * SORT_THREADS + threadIdx.x; i < ext_other; i += nblk * SORT_THREADS) st_zero[i] = 0;
+    if (blk == 0 && threadIdx.x == 0) state[4 + par] = n_stot0;       // (no block of this launch reads this word)
     // housekeeping for the later launches of this call
     for (long long i = (long long)blk * SORT_THREADS + threadIdx.x; i < n_counts1; i += (long long)nblk * SORT_THREADS) counts1[i] = 0;
     for (int i = blk * SORT_THREADS + threadIdx.x; i < n_stot1; i += nblk * SORT_THREADS) stot1[i] = 0;

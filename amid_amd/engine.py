@@ -1140,13 +1140,14 @@ class SasrecEngine:
         pk = getattr(self, "_tail_pack", None)
         if pk is not None:       # graph A of the data-parallel step: the tail also packs this rank's exchange chunk (ids | rows | dense)
             from .dist import packed_rows
-            send, umax = pk
+            send, umax, with_dense = pk
             id_rows, rows = packed_rows(umax, self.D)
             L.call("amid_grad_tail_pack_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), self.n_sparse(pl),
                    self.D, pl.seg_ws.data_ptr(), send.data_ptr() + 4 * id_rows * self.D, ent.data_ptr(),
                    n_ent, ent_max, pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), umax,
-                   self.n_rows, send.data_ptr(), self.dense.grad.data_ptr(), send.data_ptr() + 4 * rows * self.D, self.dense.numel,
-                   blk[0].data_ptr(), blk[1], s)
+                   self.n_rows, send.data_ptr(), self.dense.grad.data_ptr() if with_dense else None,
+                   send.data_ptr() + 4 * rows * self.D if with_dense else None, self.dense.numel if with_dense else 0,
+                   pl.err.data_ptr(), blk[0].data_ptr(), blk[1], s)
             return
         L.call("amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), self.n_sparse(pl),
                self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), ent.data_ptr(), n_ent, ent_max, blk[0].data_ptr(), blk[1], s)
@@ -1166,18 +1167,19 @@ class SasrecEngine:
                self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), ids.data_ptr(),
                nu.data_ptr(), cap, rows.data_ptr(), self.D, self.grad_scale, self.step_state.data_ptr(), s)
 
-    def enqueue_optimizer_gathered(self, be: "HipMergeBackend", recv: torch.Tensor, world: int, umax: int) -> None:
+    def enqueue_optimizer_gathered(self, be: "HipMergeBackend", recv: torch.Tensor, world: int, umax: int, dense_in_chunk: bool = True) -> None:
         """The data-parallel optimizer: ONE launch over the world's gathered chunks (ids | rows | dense gradient per rank) -- the
         rank-ordered sums of the dense parts and of the rows of equal ids happen inside it (amid_optimizer_step_gathered_f32), so
-        the step needs no merge / segment-reduce launches after the all-gather."""
+        the step needs no merge / segment-reduce launches after the all-gather.  dense_in_chunk=False: the chunks hold ids | rows
+        only and dense.grad already is the world's sum (the caller's all-reduce)."""
         from .dist import packed_rows
         self._ensure_opt_state()
         fp, D = self.dense, self.D
         id_rows, rows = packed_rows(umax, D)
         lib().call("amid_optimizer_step_gathered_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel,
                    self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), recv.data_ptr(),
-                   world, umax, be.chunk_rows(umax, fp.grad) * D, id_rows, rows * D, D, self.n_rows, self.grad_scale,
-                   self.step_state.data_ptr(), self.s)
+                   world, umax, be.chunk_rows(umax, fp.grad if dense_in_chunk else None) * D, id_rows, rows * D if dense_in_chunk else -1, D,
+                   self.n_rows, self.grad_scale, self.step_state.data_ptr(), self.s)
 
     def enqueue_step_begin(self) -> None:
         lib().call("amid_step_begin", self.step_state.data_ptr(), self.s)
@@ -1264,16 +1266,28 @@ class SasrecEngine:
         self.step = step0
         pl.graph_local = out.value
 
-    def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False, umax: Optional[int] = None) -> None:
+    # How the 1.7 MB flat dense gradient crosses the ranks in the graph-pair step: "gather" = behind the sparse rows inside the step's ONE
+    # all-gather (every rank sums the world's copies in rank order: one collective's latency, world x 1.7 MB received per rank);
+    # "allreduce" = its own RCCL all-reduce next to the all-gather of the sparse rows (two collectives, ~2 x 1.7 MB on the wire per
+    # rank whatever the world size) -- what BASELINE.json's north_star words ("RCCL all-reduce of dense parameter grads").  Both are
+    # bit-identical across replicas; bench.py --dense-exchange measures either.
+    DENSE_EXCHANGE = os.environ.get("AMID_DENSE_EXCHANGE", "gather")
+
+    def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False, umax: Optional[int] = None, dense: Optional[str] = None) -> None:
         """One data-parallel step: local grads -> dense all-reduce + ONE sparse all-gather -> merge -> Adam.
         umax: a bound on the world's largest unique-row count of this step if the host knows one (no host sync then, see
-        dist.py).  With use_graph and a known umax the step is graph A (local gradients + packing of this rank's chunk: ids, rows
-        and, behind them, the flat dense gradient), ONE all-gather, graph B (rank-ordered sum of the dense parts, merge of the
-        sparse parts, Adam): three host calls, and replicas that are bit-identical by construction; the pair of graphs is captured
-        per distinct umax, so callers should pass a bucketed bound (bench.py: the pool's maximum)."""
+        dist.py) -- it MUST cover every rank's count: a step that finds more raises AMID_FLAG_UMAX_EXCEEDED in the plan's error word
+        (check_index_error).  With use_graph and a known umax the step is graph A (local gradients + packing of this rank's chunk: ids,
+        rows and, with dense="gather", the flat dense gradient behind them), the collective(s), graph B (rank-ordered sum of the dense
+        parts, merge of the sparse parts, Adam): three or four host calls, and replicas that are bit-identical by construction; the
+        pair of graphs is captured per distinct (umax, dense), so callers should pass a bucketed bound (bench.py: the pool's maximum).
+        dense: "gather" | "allreduce" (default: DENSE_EXCHANGE)."""
         if (self.itc_bs or self.inc_bs) and exchange.active:
             raise NotImplementedError("isItC / isInC couple the rows of a batch (softmax and Linear(bs, 1) over the batch, "
                                       "model_seq.py:465-469, :490-494): data-parallel sharding would change the model; train them on one GPU")
+        dense = dense or self.DENSE_EXCHANGE
+        if dense not in ("gather", "allreduce"):
+            raise ValueError(f"dense exchange must be 'gather' or 'allreduce', got {dense!r}")
         L = lib()
         if umax is not None:                   # a caller's bound may be rounded up past the plan's index count (e.g. to a multiple of 256):
             umax = max(1, min(int(umax), self.n_sparse_train(pl)))      # clamp BEFORE it keys the captured graph pair (as dist.exchange_sparse does)
@@ -1281,11 +1295,13 @@ class SasrecEngine:
             self.grad_scale = exchange.grad_scale
             fast = (use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")
                     and not exchange.use_owner(umax, self.D))      # the owner-bucketed exchange sizes its buffers per step: eager
-            pair = getattr(pl, "dp_graphs", {}).get(umax) if fast else None
-            if pair is not None:       # graph A, ONE collective (the dense gradient rides behind the sparse rows), graph B
+            pair = getattr(pl, "dp_graphs", {}).get((umax, dense)) if fast else None
+            if pair is not None:       # graph A, the collective(s), graph B
                 L.call("amid_graph_launch", pair[0], self.s)
                 self.step += 1
                 exchange.all_gather_packed(pair[2], pair[3])
+                if dense == "allreduce":
+                    exchange.all_reduce_dense(self.dense.grad)
                 L.call("amid_graph_launch", pair[1], self.s)
                 return
             if use_graph:
@@ -1297,28 +1313,33 @@ class SasrecEngine:
             merged = exchange.exchange_sparse(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax=umax)
             self.enqueue_optimizer(pl, sparse=merged if exchange.active else None)
         if fast:                               # this step ran eagerly (it also warmed every kernel up); capture the pair for the next ones
-            self._capture_dp_pair(pl, exchange, int(umax))
+            self._capture_dp_pair(pl, exchange, int(umax), dense)
 
-    def _capture_dp_pair(self, pl: SasrecPlan, exchange, umax: int) -> None:
+    def _capture_dp_pair(self, pl: SasrecPlan, exchange, umax: int, dense: str = "gather") -> None:
         L, be = lib(), exchange.backend
         self.sync()
+        if int(pl.n_uniq.item()) > umax:       # the eager step just ran with this bound: a bound that is already too small never gets captured
+            raise ValueError(f"train_step_dp: umax = {umax} is smaller than this step's {int(pl.n_uniq.item())} unique rows")
         step0 = self.step
-        be.gather_buffer(exchange.world, umax, dense=self.dense.grad)   # capacity errors are raised here, not in the middle of a stream capture
-        be.prepare_dense(exchange.world, umax, self.dense.grad)      # device tables are built here, not under capture
+        in_chunk = dense == "gather"
+        dgrad = self.dense.grad if in_chunk else None
+        be.gather_buffer(exchange.world, umax, dense=dgrad)   # capacity errors are raised here, not in the middle of a stream capture
+        if in_chunk:
+            be.prepare_dense(exchange.world, umax, self.dense.grad)      # device tables are built here, not under capture
         graphs = []
         for part in (0, 1):
             L.call("amid_graph_capture_begin", self.s)
             try:
                 if part == 0:          # the tail of backward packs the chunk itself: no padding launch (amid_grad_tail_pack_f32)
-                    send = be.send[: be.chunk_rows(umax, self.dense.grad) * self.D]
-                    self._tail_pack = (send, umax)
+                    send = be.send[: be.chunk_rows(umax, dgrad) * self.D]
+                    self._tail_pack = (send, umax, in_chunk)
                     try:
                         self.enqueue_local_grads(pl)
                     finally:
                         self._tail_pack = None
                 else:
-                    recv = be.gather_buffer(exchange.world, umax, dense=self.dense.grad)
-                    self.enqueue_optimizer_gathered(be, recv, exchange.world, umax)
+                    recv = be.gather_buffer(exchange.world, umax, dense=dgrad)
+                    self.enqueue_optimizer_gathered(be, recv, exchange.world, umax, dense_in_chunk=in_chunk)
             finally:
                 out = ctypes.c_void_p()
                 L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
@@ -1326,7 +1347,7 @@ class SasrecEngine:
         self.step = step0                      # capture does not execute
         if not hasattr(pl, "dp_graphs"):
             pl.dp_graphs = {}
-        pl.dp_graphs[umax] = (graphs[0], graphs[1], send, recv)
+        pl.dp_graphs[(umax, dense)] = (graphs[0], graphs[1], send, recv)
 
     # ------------------------------------------------------------------ graph replay
     def capture_train_step(self, pl: SasrecPlan) -> None:
@@ -1426,8 +1447,12 @@ class SasrecEngine:
         return HipMergeBackend(self, capacity)
 
     def check_index_error(self, pl: SasrecPlan) -> None:
-        if int(pl.err.item()) != 0:
+        flags = int(pl.err.item())
+        if flags != 0:
             pl.err.zero_()
+            if flags & 2:      # AMID_FLAG_UMAX_EXCEEDED
+                raise RuntimeError("amid_amd: a data-parallel step found more unique rows than the bound umax it was given "
+                                   "(train_step_dp): its exchange chunk is corrupt")
             raise IndexError("amid_amd: item index out of range in the batch (nn.Embedding would raise here, model_seq.py:27-29)")
 
 

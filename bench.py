@@ -3,20 +3,33 @@
 cloth_sport_train75 configuration (BASELINE.json configs[1]): batch 256 per GPU, seq_len 50,
 emb_dim 128, hid 32, 1 negative, fp32, item table 2 x 447 410 rows (train_sr.py:450,456), dropout on.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 either way: under a launcher that has set WORLD_SIZE / RANK / LOCAL_RANK (python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...) this process is one rank; started plainly (python bench.py --gpus N) it
+starts that launcher itself as a CHILD process -- before anything here has touched the GPU, never by exec -- relays
+rank 0's JSON line and exits with the launcher's code.
 
 A "step" is the loop body of the reference's train() (train_sr.py:190-217): forward, masked BCE,
-backward, Adam.  Synthetic batches with the measured statistics of cloth_sport_train75
-(89 % pad positions, mean length ~5.5, ids <= 42 441, pad id 447 411) are
-resident in HBM before the timed region; random-init weights.  Prints ONE JSON line (rank 0).
+backward, Adam.  Default data: the REAL cloth_sport_train75 epoch -- what the reference's own
+DualDomainSeqDataset.__getitem__ returned for every row of the CSV, with its negative draw
+(tests/golden/tok_cloth_sport_train75.npz, written by tests/golden/make_tokenised.py) -- packed once and
+resident in HBM before the timed region; --data synthetic draws batches to the file's statistics instead
+(89 % pad positions, ids <= 42 441, pad id 447 411).  Random-init weights.
+Prints ONE JSON line (rank 0).
 
-N = 1   the whole step is one hipGraph replay.
-N > 1   weak scaling (256 samples per GPU): per step one RCCL all-reduce of the flat dense gradient
-        and one all-gather of the segment-reduced sparse rows (amid_amd/dist.py).
+N = 1   the whole step is one hipGraph replay (graphs of four consecutive steps).
+N > 1   weak scaling (256 samples per GPU), one exchange per step (amid_amd/dist.py): graph A (local gradients +
+        this rank's packed chunk), the collective(s), graph B (Adam over the world's chunks).  --dense-exchange
+        gather: the 1.7 MB dense gradient rides behind the sparse rows in ONE RCCL all-gather; allreduce: its own
+        RCCL all-reduce beside the all-gather of the sparse rows.  The line's "dist" object carries the
+        collectives and bytes per step of the run.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -320,6 +333,21 @@ def cpu_baseline(budget_s=25.0):
                       f"{os.cpu_count()} logical CPUs, {usable_cpus()} usable"}
 
 
+def self_launch(n: int) -> int:
+    """python bench.py --gpus N without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a
+    child of this process (which has not touched the GPU: importing torch does not initialise HIP) and relay its output."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -345,13 +373,17 @@ def main():
     ap.add_argument("--no-stress", action="store_true", help="skip the cfg5 gather / scatter stress appended to the headline line")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
                     help="cfg2 = the headline configuration (default); cfg5-* = synthetic gather / scatter stress (SURVEY.md 8(d))")
+    ap.add_argument("--dense-exchange", default=os.environ.get("AMID_DENSE_EXCHANGE", "gather"), choices=("gather", "allreduce"),
+                    help="N > 1: how the flat dense gradient crosses the ranks -- gather: behind the sparse rows in the step's one "
+                         "all-gather; allreduce: its own RCCL all-reduce next to it (amid_amd/engine.py DENSE_EXCHANGE)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))          # rank processes are children; this one never initialises the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE {world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # AMID_BENCH_BACKEND=gloo (+ host-staged payloads, ranks folded onto the visible GPUs) only exists to smoke-test the
     # N > 1 control flow on a single-GPU box; real runs use RCCL ("nccl") with one GPU per rank.
@@ -447,7 +479,7 @@ def main():
             else:
                 eng.enqueue_train_step(pl)
         else:
-            eng.train_step_dp(pl, exchange, use_graph=use_graph, umax=umax_pool[i % n_pool])
+            eng.train_step_dp(pl, exchange, use_graph=use_graph, umax=umax_pool[i % n_pool], dense=args.dense_exchange)
 
     def barrier():
         eng.sync()
@@ -586,11 +618,19 @@ def main():
             out["samples_per_s_loader_included"] = loader_incl
         if world > 1:
             per = lambda k: round((ex1[k] - ex0[k]) / args.steps, 1)       # noqa: E731
+            owner = ex1["owner_steps"] > ex0["owner_steps"]
+            dense_bytes = eng.dense.numel * 4
+            from amid_amd.dist import packed_rows
+            sparse_bytes = packed_rows(min(umax_pool[0], eng.n_sparse_train(pl)), D)[1] * D * 4
             out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                            "collectives_per_step": per("collectives"), "bytes_sent_per_step_per_rank": per("bytes_out"),
                            "bytes_received_per_step_per_rank": per("bytes_in"),
-                           "sparse_exchange": "owner-bucketed (all-to-all + all-gather)" if ex1["owner_steps"] > ex0["owner_steps"]
-                           else "all-gather of per-rank unique rows, dense gradient riding behind",
+                           "sparse_exchange": "owner-bucketed (all-to-all + all-gather)" if owner
+                           else "all-gather of per-rank unique rows",
+                           "dense_exchange": "all-reduce (eager owner-bucketed step)" if owner else args.dense_exchange,
+                           "dense_gradient_bytes": dense_bytes, "sparse_chunk_bytes_per_rank": sparse_bytes,
+                           # what either dense exchange puts on this rank's receive side per step at this world size
+                           "dense_bytes_received_per_step": {"gather": world * dense_bytes, "allreduce": dense_bytes},
                            "padded_unique_rows_per_rank": umax_pool[0]}
         if world == 1 and args.workload == "cfg2" and args.model == "sasrec" and args.dtype == "f32" and not args.no_stress:
             try:

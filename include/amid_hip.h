@@ -29,6 +29,10 @@ extern "C" {
 #define AMID_OK 0
 #define AMID_ERR_ARG (-1)
 #define AMID_ERR_UNSUPPORTED (-2)
+/* bits of a plan's device error word (err_flag arguments): 1 = an item index outside the table (nn.Embedding would raise,
+ * model_seq.py:27-29); 2 = a data-parallel step found more unique rows than the caller's bound umax (amid_grad_tail_pack_f32) */
+#define AMID_FLAG_INDEX_RANGE (1)
+#define AMID_FLAG_UMAX_EXCEEDED (2)
 
 int amid_version(void);
 const char* amid_error_string(int code);
@@ -143,11 +147,13 @@ int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted, const int*
  * partials, 128 otherwise) -- instead of max_count / 128 blocks for every entry. */
 /* amid_grad_tail_f32 that also packs this rank's chunk of the data-parallel exchange in its second launch: uniq_grad points INTO the
  * chunk (the segment reduce writes the rows in place), out_ids[0, n_out) <- the first n_uniq unique ids then pad_id, and
- * dense_dst[0, dense_n) <- dense_src (the flat dense gradient the first launch has just reduced); 16-byte aligned dense pointers. */
+ * dense_dst[0, dense_n) <- dense_src (the flat dense gradient the first launch has just reduced); 16-byte aligned dense pointers;
+ * dense_n = 0: no dense part (the caller all-reduces the dense gradient itself).  The caller's bound n_out must cover the step's
+ * unique rows: when *n_uniq > n_out the rows have overrun the chunk's row part and err_flag (optional) gets AMID_FLAG_UMAX_EXCEEDED. */
 int amid_grad_tail_pack_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
                             void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count, const int* uniq_ids,
                             const int* n_uniq, int n_out, int pad_id, int* out_ids, const float* dense_src, float* dense_dst,
-                            long long dense_n, const int* blk_off, int total_blocks, void* stream);
+                            long long dense_n, int* err_flag, const int* blk_off, int total_blocks, void* stream);
 
 /* ---- K4 optimizer ----------------------------------------------------------------------------
  * replaces: torch.optim.Adam(model.parameters(), lr).step(), train_sr.py:480, :215 (dense over the table).
@@ -172,7 +178,8 @@ int amid_optimizer_step_f32(float* p, float* m, float* v, const float* g, long l
  * Chunk r at gathered + r * chunk_floats = [id_rows rows of D floats holding umax ascending unique int32 ids, padded with `sentinel`
  * (> every id) | umax gradient rows | at dense_off: the rank's flat dense gradient, n floats].  g <- the ranks' dense parts summed in
  * rank order, then dense Adam; every table row whose id occurs in some chunk gets the lazy row Adam with the rows of equal ids
- * summed in rank order.  world <= 16; dense_off and chunk_floats multiples of 4. */
+ * summed in rank order.  world <= 16; dense_off and chunk_floats multiples of 4.  dense_off < 0: the chunks carry no dense part and
+ * g already holds the world's summed dense gradient (the caller's RCCL all-reduce). */
 int amid_optimizer_step_gathered_f32(float* p, float* m, float* v, float* g, long long n, float* table, float* m_tab, float* v_tab,
                                      int* last, const float* gathered, int world, int umax, long long chunk_floats, int id_rows,
                                      long long dense_off, int D, int sentinel, float grad_scale, const void* step_state, void* stream);

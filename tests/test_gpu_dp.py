@@ -43,7 +43,7 @@ def _batches():
     return [orc.synthetic_batch(c["B"], c["T"], c["n_items"] - 1, pad_id=c["n_items"] - 1, neg=1, seed=500 + t) for t in range(c["K"])]
 
 
-def _worker(rank, world, port, use_graph, q, host_knows_umax=False, pool=False, owner=False, backend="gloo"):
+def _worker(rank, world, port, use_graph, q, host_knows_umax=False, pool=False, owner=False, backend="gloo", dense="gather"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     devi = rank if backend == "nccl" else 0               # RCCL refuses two ranks on one device ("Duplicate GPU detected")
     if backend == "nccl":
@@ -83,7 +83,7 @@ def _worker(rank, world, port, use_graph, q, host_knows_umax=False, pool=False, 
                 cnt = cnt.cuda() if backend == "nccl" else cnt
                 dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
                 umax = (int(cnt) + 63) // 64 * 64             # a bucketed bound: the graph pair of the exchange is reused across steps
-            eng.train_step_dp(pl, ex, use_graph=use_graph, umax=umax)
+            eng.train_step_dp(pl, ex, use_graph=use_graph, umax=umax, dense=dense)
             eng.sync()
         eng.flush_table()
         eng.sync()
@@ -94,16 +94,19 @@ def _worker(rank, world, port, use_graph, q, host_knows_umax=False, pool=False, 
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph,host_knows_umax,pool,owner", [(False, False, False, False), (True, False, False, False),
-                                                                   (True, True, False, False), (True, True, True, False),
-                                                                   (False, False, False, True), (True, True, True, True)])
+@pytest.mark.parametrize("use_graph,host_knows_umax,pool,owner,dense", [(False, False, False, False, "gather"), (True, False, False, False, "gather"),
+                                                                         (True, True, False, False, "gather"), (True, True, True, False, "gather"),
+                                                                         (False, False, False, True, "gather"), (True, True, True, True, "gather"),
+                                                                         (True, True, True, False, "allreduce"), (True, True, False, False, "allreduce")])
 @pytest.mark.timeout(600)
-def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax, pool, owner):
-    """owner: the owner-bucketed sparse exchange (amid_owner_count_i32 / amid_owner_buckets_f32 + all-to-all + all-gather)."""
+def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax, pool, owner, dense):
+    """owner: the owner-bucketed sparse exchange (amid_owner_count_i32 / amid_owner_buckets_f32 + all-to-all + all-gather).
+    dense: how the flat dense gradient crosses the ranks in the graph-pair step (SasrecEngine.DENSE_EXCHANGE): behind the sparse rows
+    in the one all-gather, or as its own all-reduce."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, use_graph, q, host_knows_umax, pool, owner)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_graph, q, host_knows_umax, pool, owner, "gloo", dense)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])
@@ -130,16 +133,16 @@ def test_two_rank_dp_matches_global_batch_oracle(use_graph, host_knows_umax, poo
         assert float(d.max()) < 1e-4, k
 
 
-@pytest.mark.parametrize("owner", [False, True])
+@pytest.mark.parametrize("owner,dense", [(False, "gather"), (True, "gather"), (False, "allreduce")])
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL refuses two ranks on one device (ncclInvalidUsage: Duplicate GPU detected; "
                     "profiles/tools/probe/nccl_two_ranks_one_gpu.py), so the nccl leg needs two GPUs; the single-GPU box runs the gloo legs")
 @pytest.mark.timeout(600)
-def test_two_rank_dp_over_rccl_two_gpus(owner):
+def test_two_rank_dp_over_rccl_two_gpus(owner, dense):
     """The same two-rank step with the production backend: RCCL ("nccl"), one GPU per rank, device collectives, no host staging."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, True, q, True, True, owner, "nccl")) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, True, q, True, True, owner, "nccl", dense)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])

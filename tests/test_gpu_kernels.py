@@ -134,6 +134,25 @@ def test_sort_unique_rows_payload_and_one_workspace_for_many_lengths(L, four_min
         L.value("amid_sort_set_four_launch_min", prev)
 
 
+@pytest.mark.parametrize("four_min", [65536, 0])
+def test_sort_one_workspace_odd_number_of_calls_per_length(L, four_min):
+    """big, small, big (and small, big, small) with ONE call each on one workspace: the two copies of the four-launch sort's stot_0 table
+    alternate between calls, and a call must zero the OTHER copy over what the previous call accumulated there -- not over its own,
+    shorter extent (csrc/sort_phases.h os_count_block).  The lengths are those of a cfg 5 plan's full autograd list (13 supertiles)
+    and compact train list (7)."""
+    prev = L.value("amid_sort_set_four_launch_min", four_min)
+    try:
+        n_rows = 10_000_002
+        ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", 417792), dtype=torch.uint8, device="cuda")
+        g = torch.Generator().manual_seed(5)
+        for n in (417792, 212992, 417792, 70000, 417792, 212992, 70000, 212992):
+            idx = torch.randint(0, n_rows, (n,), generator=g)
+            idx[torch.rand(n, generator=g) < 0.3] = n_rows - 1
+            check_sort(idx, run_sort_unique(L, idx, n_rows, ws))
+    finally:
+        L.value("amid_sort_set_four_launch_min", prev)
+
+
 def check_sort(idx, out):
     pos, uniq, seg, U, raw = out
     assert torch.equal(pos, torch.sort(idx, stable=True).indices)
