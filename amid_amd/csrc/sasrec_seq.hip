@@ -22,6 +22,7 @@
 #include "rng.h"
 #include "strip_gemm.h"
 #include "attention_mfma.h"
+#include "seq_fwd.h"
 
 namespace amid {
 
@@ -29,34 +30,13 @@ namespace amid {
 static __device__ unsigned long long amid_seq_sched_buf[1024 * 4];     // per workgroup: start, end (100 MHz real-time counter), HW_ID
 #define SEQ_SCHED(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) amid_seq_sched_buf[blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define SEQ_SCHED_ID() do { if (threadIdx.x == 0 && blockIdx.x < 1024) amid_seq_sched_buf[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } while (0)
+static __device__ unsigned long long amid_seq_fine_buf[8 * 64];        // workgroup 0, last layer: per slab after the ring wait / the MFMA loop / the epilogue
+#define SEQ_FINE(i) do { if (blockIdx.x == 0 && lane_id() == 0 && l == 1) amid_seq_fine_buf[wave_id() * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define SEQ_FINE(i) do { } while (0)
 #define SEQ_SCHED(slot) do { } while (0)
 #define SEQ_SCHED_ID() do { } while (0)
 #endif
-
-struct SeqLayer {
-    const float* ln1_w[2]; const float* ln1_b[2]; const float* w_in[2]; const float* b_in[2];
-    const float* w_o[2]; const float* b_o[2]; const float* ln2_w[2]; const float* ln2_b[2];
-    const float* w1[2]; const float* b1[2]; const float* w2[2]; const float* b2[2];
-    float* x;                           // this layer's INPUT rows (written for layers >= 1: the previous layer's output)
-    float* qn; float* q; float* k; float* v; float* o; float* stats; float* r; float* y; float* h;
-};
-
-struct SeqFwdArgs {
-    SeqLayer L[2];
-    int n_layers;
-    const float* x0;                    // layer 0's input (the gathered rows)
-    float* xout;                        // the last layer's output
-    const unsigned char* tmq;
-    float ln_eps, att_scale, dscale, ffn_scale;
-    const StepState* st; int train; unsigned spec;
-};
-
-struct SeqGeom {
-    int B, T, M;
-    unsigned act_bytes, tm_bytes, stats_bytes;
-    const int* live;                    // as StripGeom::live
-};
 
 template <int D>
 __device__ __forceinline__ void add_bias_s(f32x4 (&acc)[D / 16], const ColVec<D>& b) {
@@ -93,12 +73,6 @@ __device__ __forceinline__ void spread(const GBuf& g, const StripRow& row, const
     if (ct < NT / 2 && (j & 3) == phase) strip_store_ct<D>(g, row, x, 2 * ct + (j >> 2));
 }
 
-// workgroup barrier between LDS phases WITHOUT draining the vector-memory queue (__syncthreads() waits for every store in flight)
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
 constexpr int IMG_COLS = 32;            // two heads of 16
 constexpr int IMG_ROWS = 64;
 // K image [64 key rows][32]: 128-byte rows, chunk c of row R at chunk position c ^ ((R >> 1) & 7).
@@ -106,15 +80,6 @@ constexpr int IMG_ROWS = 64;
 // c ^ (d & 15): the V^T fragment of lane (d, g) -- keys 16 kt + 4 g .. + 3 -- is ONE ds_read_b128 (a row-major image costs four
 // ds_read_b32 per fragment: 32 reads per round instead of 8), conflict-free like the weight image; the writes (4 dwords per lane and
 // column tile: keys are lanes, dims are registers) are conflict-free too.
-
-// 32-bit value of lane group `src` (lanes m + 16 src) to all four groups of the same m: two half-exchanges
-__device__ __forceinline__ unsigned bcast_group(unsigned v, int SRC) {
-    float a = __builtin_bit_cast(float, v), b = a;
-    swap16(a, b);                                          // a: rows (0, 0, 2, 2), b: rows (1, 1, 3, 3)
-    float x = (SRC & 1) ? b : a, y = x;
-    swap32(x, y);                                          // x: (lo half, lo half), y: (hi half, hi half)
-    return __builtin_bit_cast(unsigned, (SRC >> 1) ? y : x);
-}
 
 // attention of the wave's 16 query rows (strip si of its sequence) over all heads; Q, K, V in the C layout
 template <int D, int WPS>
@@ -319,7 +284,9 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs
         StripRow rowx = row;                                     // layer 0's input is the caller's buffer: nothing to write back
         rowx.off = l > 0 ? row.off : STRIP_OOB;
         {   // k = x Wk^T + bk  (the layer input's and Qn's global copies leave under these MFMAs)
+            SEQ_FINE(0);
             const float* buf = ring.next();
+            SEQ_FINE(1);
             bias.load(P.b_in[g] + D);
             strip_zero<D>(acc);
             strip_mma<D>(acc, X, buf, [&](int ct, int j) {
@@ -327,32 +294,42 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs
                 spread<D>(gx, rowx, X, ct, j, 1);
                 spread<D>(gqn, row, Qn, ct, j, 3);
             });
+            SEQ_FINE(2);
             add_bias_s<D>(acc, bias);
             to_regs_s<D>(Kr, acc);
+            SEQ_FINE(3);
             STRIP_STAMP(3 + 10 * l);
         }
         {   // v = x Wv^T + bv
             const float* buf = ring.next();
+            SEQ_FINE(4);
             bias.load(P.b_in[g] + 2 * D);
             strip_zero<D>(acc);
             strip_mma<D>(acc, X, buf, [&](int ct, int j) { ring.fetch(P.w_in[g], ct, j); spread<D>(gk, row, Kr, ct, j, 1); });
+            SEQ_FINE(5);
             add_bias_s<D>(acc, bias);
             to_regs_s<D>(Vr, acc);
+            SEQ_FINE(6);
             STRIP_STAMP(4 + 10 * l);
         }
         {   // q = Qn Wq^T + bq
             const float* buf = ring.next();
+            SEQ_FINE(7);
             bias.load(P.b_in[g]);
             strip_zero<D>(acc);
             strip_mma<D>(acc, Qn, buf, [&](int ct, int j) { ring.fetch(P.w_o[g], ct, j); spread<D>(gv, row, Vr, ct, j, 1); });
+            SEQ_FINE(8);
             add_bias_s<D>(acc, bias);
             to_regs_s<D>(Qr, acc);
+            SEQ_FINE(9);
             STRIP_STAMP(5 + 10 * l);
         }
         strip_store<D>(gq_, row, Qr);
+        SEQ_FINE(10);
         seq_attention_fwd<D, WPS>(O, stat, Qr, Kr, Vr, kimg, vimg, si, t, sg.T, (unsigned long long)b * H, a.att_scale, a.train, seed,
                                   site_id(g, l, SITE_ATTN), step, a.spec, a.dscale);
         STRIP_STAMP(6 + 10 * l);
+        SEQ_FINE(11);
         bias.load(P.b_o[g]); lw.load(P.ln2_w[g]); lb.load(P.ln2_b[g]);      // (not across the attention rounds: 96 registers)
         {   // the statistics of heads 2 gq, 2 gq + 1 of this lane's row: 16 contiguous bytes
             f32x4 sv = stat[0];
@@ -361,20 +338,26 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs
             gst.store4(stat_off, sv);
         }
         {   // r = Qn + (o Wo^T + bo) ; y = LN2(r)
+            SEQ_FINE(12);
             const float* buf = ring.next();
+            SEQ_FINE(13);
             strip_zero<D>(acc);
             strip_mma<D>(acc, O, buf, [&](int ct, int j) { ring.fetch(P.w1[g], ct, j); spread<D>(go, row, O, ct, j, 1); });
+            SEQ_FINE(14);
             add_bias_s<D>(acc, bias);
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) R.v[ct] = Qn.v[ct] + acc[ct];
             strip_layernorm<D>(Y, R, lw, lb, a.ln_eps);
+            SEQ_FINE(15);
             STRIP_STAMP(7 + 10 * l);
         }
         {   // h = relu(drop1(y C1^T + c1))
             const float* buf = ring.next();
+            SEQ_FINE(16);
             bias.load(P.b1[g]);
             strip_zero<D>(acc);
             strip_mma<D>(acc, Y, buf, [&](int ct, int j) { ring.fetch(P.w2[g], ct, j); spread<D>(gr, row, R, ct, j, 1); });
+            SEQ_FINE(17);
             add_bias_s<D>(acc, bias);
             to_regs_s<D>(Kr, acc);                               // Kr: the relu output from here on
             if (a.train) strip_dropout<D>(Kr, seed, site_id(g, l, SITE_FFN1), step, row.local, a.spec, a.ffn_scale);
@@ -382,10 +365,12 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs
             for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Kr.v[ct][r] = fmaxf(Kr.v[ct][r], 0.f);
+            SEQ_FINE(18);
             STRIP_STAMP(8 + 10 * l);
         }
         {   // x' = (drop2(h C2^T + c2) + y) * ~tm
             const float* buf = ring.next();
+            SEQ_FINE(19);
             bias.load(P.b2[g]);
             const SeqLayer& Pn = a.L[last ? l : l + 1];          // (the last layer refetches its own Wk into the free buffer: harmless)
             lw.load(Pn.ln1_w[g]); lb.load(Pn.ln1_b[g]);
@@ -395,12 +380,14 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_fwd_kernel(const SeqFwdArgs
                 spread<D>(gy, row, Y, ct, j, 1);
                 spread<D>(gh, row, Kr, ct, j, 3);
             });
+            SEQ_FINE(20);
             add_bias_s<D>(acc, bias);
             to_regs_s<D>(X, acc);
             if (a.train) strip_dropout<D>(X, seed, site_id(g, l, SITE_FFN2), step, row.local, a.spec, a.ffn_scale);
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) X.v[ct] += Y.v[ct];
             if (has_tm) strip_apply_tm<D>(X, tm);
+            SEQ_FINE(21);
             STRIP_STAMP(9 + 10 * l);
         }
     }
@@ -419,12 +406,24 @@ using namespace amid;
 extern "C" int amid_seq_sched_read(unsigned long long* host) {          // diagnostic library only
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_seq_sched_buf), sizeof(unsigned long long) * 1024 * 4);
 }
+extern "C" int amid_seq_fine_read(unsigned long long* host) {         // diagnostic library only
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_seq_fine_buf), sizeof(unsigned long long) * 8 * 64);
+}
 extern "C" int amid_seq_stamps_read(unsigned long long* host) {       // diagnostic library only
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_strip_stamp_buf), sizeof(unsigned long long) * STRIP_STAMP_WAVES * 32);
 }
 #endif
 
 template <int D> static constexpr size_t seq_lds_bytes() { return (size_t)(2 * D * D + 2 * IMG_ROWS * IMG_COLS) * sizeof(float); }
+
+// Which build runs: 0 = auto (the measured choice per shape), 1 = sasrec_seq.hip's whole-row waves, 2 = the N-split build's default
+// split, 42 / 22 / 24 / 14 / 18 = an explicit (strips per sequence, column parts) pair of sasrec_seqn.hip.  Returns the previous value.
+static int g_seq_fwd_variant = 0;
+extern "C" int amid_sas_seq_fwd_variant(int v) {
+    const int prev = g_seq_fwd_variant;
+    if (v >= 0) g_seq_fwd_variant = v;
+    return prev;
+}
 
 // 1 when the fused per-sequence forward covers this shape: head dim 16 with D = 128, T <= 64, activations within 2 GiB
 extern "C" int amid_sas_seq_supported(int B, int T, int D, int H) {
@@ -467,6 +466,14 @@ extern "C" int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, floa
     sg.B = B; sg.T = T; sg.M = B * T; sg.live = live;
     const long long bytes = 2LL * B * T * D * 4;
     sg.act_bytes = (unsigned)bytes; sg.tm_bytes = (unsigned)(bytes / 16); sg.stats_bytes = (unsigned)(2LL * B * T * H * 8);
+    {
+        int v = g_seq_fwd_variant;
+        if (v == 0) v = 1;                                 // auto
+        if (v != 1) {
+            const int rc = launch_seqn_fwd(a, sg, v == 2 ? 0 : v, stream);
+            if (rc != AMID_ERR_UNSUPPORTED) return rc;
+        }
+    }
     const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4, spw = STRIP_WAVES / wps;
     const int tiles = (B + spw - 1) / spw;
     const int grid = live != nullptr ? tiles + 1 : 2 * tiles;      // the live tiles of both domains (one more when both are ragged) / every tile

@@ -1,0 +1,558 @@
+// The one-launch SASRec encoder forward, N-split build: NS waves share a 16-row strip of a sequence, each owning D / NS output columns
+// (= 8 / NS heads) of every product.  Same operations, operands, dropout counters and saved tensors as sasrec_seq.hip (reference:
+// Log2feats.forward model_seq.py:371-383, nn.MultiheadAttention as called at :374, PointWiseFeedForward :322-326).
+//
+// Why a second build.  In sasrec_seq.hip a wave owns a strip and ALL columns, so a launch lasts as long as one wave's serial chain:
+// 12 weight slabs x 256 MFMAs + the attention core, with nothing to cover its epilogues, barriers and LDS round trips (one wave per
+// SIMD), and at T <= 32 only 2 * T / 32 of the chip's SIMDs have a strip at all (batch 256, T 20: 128 workgroups on 256 CUs).  Here
+//   * a workgroup is ONE sequence: WPS strips (T <= 16 * WPS) x NS column parts = WPS * NS waves.  WPS = 4, NS = 2: eight waves, two per
+//     SIMD, the partner's matrix work under a wave's epilogue / softmax / waits.  WPS = 2, NS = 2 (T <= 32): four waves, one per SIMD, and
+//     every sequence has a workgroup of its own -- a wave's chain is 128 MFMAs per slab instead of 256.
+//   * a product needs the whole row of its operand (K = D), a wave produces D / NS columns of the result: after every product the
+//     strip's waves exchange their parts through LDS ([strip][column tile][lane] float4: lane (m, g) writes and reads the SAME slot, so
+//     the exchange is conflict-free and needs no layout thought).  Per-row work on whole rows (LayerNorm) is done redundantly by the NS
+//     waves of the strip; element-wise work (bias, relu, dropout, masks, residuals, stores) on the own columns only.
+//   * attention: a wave handles its own heads (its columns of q / k / v ARE whole heads).  The K and V^T images of ALL heads sit in the
+//     weight ring's idle slab (the one that held Wq; Wo is landing in the other one, W1 is fetched into it only after the core): one
+//     barrier pair per layer instead of one per two heads.  K image = a weight image [key][D] with the ring's swizzle, so S = Qs K^T
+//     is one k-tile of strip_mma per head; V^T image [dim][64 keys] as in sasrec_seq.hip.
+// LDS: ring 2 x 64 KB + exchange WPS x 8 KB = 160 KB at WPS = 4 (the whole CU).
+#include "common.h"
+#include "rng.h"
+#include "strip_gemm.h"
+#include "attention_mfma.h"
+#include "seq_fwd.h"
+
+namespace amid {
+
+typedef __attribute__((address_space(3))) float lds_f;
+typedef float lds_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_ld4(const float* p) {
+    const lds_v4 t = *(const __attribute__((address_space(3))) lds_v4*)(p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void lds_st4(float* p, f32x4 v) { *(__attribute__((address_space(3))) lds_v4*)(p) = lds_v4{v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ void lds_st1(float* p, float v) { *(__attribute__((address_space(3))) float*)(p) = v; }
+
+#ifdef AMID_STRIP_STAMPS
+static __device__ unsigned long long amid_seqn_stamp_buf[8 * 64];
+#define SEQN_STAMP(i) do { if (blockIdx.x == 0 && lane_id() == 0 && l == 1) amid_seqn_stamp_buf[wave_id() * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SEQN_STAMP0(i) do { if (blockIdx.x == 0 && lane_id() == 0) amid_seqn_stamp_buf[wave_id() * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEQN_STAMP(i) do { } while (0)
+#define SEQN_STAMP0(i) do { } while (0)
+#endif
+
+// ---- weight ring for NW waves (strip_gemm.h's WDma with the wave count as a parameter) ----------------------------------------------
+template <int D, int NW> struct WDmaN {
+    static constexpr int CPR = D / 4;
+    static constexpr int PER_WAVE = D * CPR / 64 / NW;
+    static constexpr unsigned STRIDE2 = 2u * (NW * 64 / CPR) * D * 4;      // bytes between pieces k0 and k0 + 2
+    unsigned off[2];
+    int w;
+    __device__ __forceinline__ WDmaN() {
+        const int lane = lane_id();
+        w = wave_id();
+#pragma unroll
+        for (int k0 = 0; k0 < 2; ++k0) {
+            const int p = (k0 * NW + w) * 64 + lane;
+            const int n = p / CPR, pos = p % CPR;
+            off[k0] = (unsigned)((n * D + ((pos ^ (n & 15)) * 4)) * 4);
+        }
+    }
+    __device__ __forceinline__ void piece(float* __restrict__ buf, const float* __restrict__ W, int k0) const {
+        const unsigned voff = off[k0 & 1] + (unsigned)(k0 >> 1) * STRIDE2;
+        const unsigned lds = __builtin_amdgcn_readfirstlane(
+            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(buf + (k0 * NW + w) * 256));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
+    }
+};
+
+template <int D, int NW> struct SeqRingN {
+    float* buf; int s; WDmaN<D, NW> dma;
+    static constexpr int SLOTS = 4 * (D / 16);
+    __device__ __forceinline__ explicit SeqRingN(float* lds) : buf(lds), s(0) {}
+    __device__ __forceinline__ void first(const float* __restrict__ W0) {
+#pragma unroll
+        for (int k0 = 0; k0 < WDmaN<D, NW>::PER_WAVE; ++k0) dma.piece(buf, W0, k0);
+    }
+    __device__ __forceinline__ float* next() {
+        w_ring_wait();
+        __syncthreads();
+        float* cur = buf + (s & 1) * D * D;
+        ++s;
+        return cur;
+    }
+    // slot = ct * 4 + j of the product that reads slab s - 1; pieces go into the other buffer over the first half of the loop
+    __device__ __forceinline__ void fetch(const float* __restrict__ W, int ct, int j) const {
+        constexpr int PW = WDmaN<D, NW>::PER_WAVE, EVERY = (SLOTS / 2) / PW > 0 ? (SLOTS / 2) / PW : 1;
+        const int slot = ct * 4 + j;
+        if (slot % EVERY == 0 && slot / EVERY < PW) dma.piece(buf + (s & 1) * D * D, W, slot / EVERY);
+    }
+};
+
+// ---- the own columns of a strip ---------------------------------------------------------------------------------------------------
+template <int NCT> struct PartRegs { f32x4 v[NCT]; };
+
+template <int NCT>
+__device__ __forceinline__ void part_load(PartRegs<NCT>& x, const GBuf& g, unsigned off_own) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) x.v[c] = g.load4(off_own + c * 64);
+}
+template <int NCT>
+__device__ __forceinline__ void part_store(const GBuf& g, unsigned off_own, const PartRegs<NCT>& x) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) g.store4(off_own + c * 64, x.v[c]);
+}
+// one column tile per call, from inside an MFMA loop: tensor `x` leaves in groups j == phase of the first NCT k tiles
+template <int NCT>
+__device__ __forceinline__ void part_spread(const GBuf& g, unsigned off_own, const PartRegs<NCT>& x, int ct, int j, int phase) {
+    if (ct < NCT && j == phase) g.store4(off_own + ct * 64, x.v[ct]);
+}
+template <int NCT>
+__device__ __forceinline__ void part_cols(PartRegs<NCT>& v, const float* __restrict__ p, int c0) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) v.v[c] = col4(p, c0 + c);
+}
+
+// exchange: own parts -> xb[column tile][lane]; after a barrier every wave of the strip reads all D / 16 tiles
+template <int NCT>
+__device__ __forceinline__ void xchg_write(float* __restrict__ xb, int c0, const PartRegs<NCT>& x) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) lds_st4(xb + ((c0 + c) * 64 + lane) * 4, x.v[c]);
+}
+template <int D>
+__device__ __forceinline__ void xchg_read(StripRegs<D>& full, const float* __restrict__ xb) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) {
+        const float4 t = lds_ld4(xb + (ct * 64 + lane) * 4);
+        full.v[ct] = f32x4{t.x, t.y, t.z, t.w};
+    }
+}
+
+// acc[c] += sum_k A[.][k] W[(c0 + c) * 16 + .][k]: strip_mma for the own column tiles.  4 groups per k tile (one per element r of the
+// operand quad): NCT MFMAs on different accumulators + one fragment read of the next k tile; hook(ct, j) behind group j.
+template <int D, int NCT, class Hook>
+__device__ __forceinline__ void part_mma(f32x4 (&acc)[NCT], const StripRegs<D>& A, const float* __restrict__ buf, int c0, const Hook& hook) {
+    constexpr int NT = D / 16;
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int xl = g ^ i;
+    const float* rowp = buf + (c0 * 16 + i) * D;
+    float4 wf[2][NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) wf[0][c] = lds_ld4(rowp + c * 16 * D + 4 * xl);
+    AMID_STRIP_FENCE();
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        const float* nxt = rowp + 4 * (((ct + 1) * 4) ^ xl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float4 w = wf[ct & 1][c];
+                const float wr = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, A.v[ct][j], acc[c], 0, 0, 0);
+            }
+            if (ct + 1 < NT && j < NCT) wf[(ct + 1) & 1][j] = lds_ld4(nxt + j * 16 * D);
+            hook(ct, j);
+            AMID_STRIP_FENCE();
+        }
+    }
+}
+
+// keep multipliers of the own columns of row `local` at `site` (p = 0.5: the row's ONE Philox call, requested ahead: `rr`)
+template <int NCT>
+__device__ __forceinline__ void part_dropout(PartRegs<NCT>& x, const uint4 rr, int c0, unsigned spec, float scale) {
+    const int g4 = 4 * (lane_id() >> 4);
+    const bool all = spec_thr(spec) == 0;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const int f = (c0 + c) * 16 + g4;
+        const unsigned wlo = (f & 64) ? rr.z : rr.x, whi = (f & 64) ? rr.w : rr.y;
+        const unsigned w = ((f & 32) ? whi : wlo) >> (f & 31);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x.v[c][r] = (all || ((w >> r) & 1u)) ? x.v[c][r] * scale : 0.f;
+    }
+}
+
+// attention of the wave's 16 query rows over its own heads h = c0 .. c0 + NCT - 1; K / V^T images of the whole sequence in LDS
+constexpr int NIMG_KEYS = 64;
+template <int D, int WPS, int NCT>
+__device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)[NCT], float (&st_rl)[NCT], const PartRegs<NCT>& Q,
+                                               const float* __restrict__ kimg, const float* __restrict__ vimg, int c0, int m, int gq, int t, int T,
+                                               unsigned long long rowbase_bh, float scale, int train, unsigned long long seed, unsigned site,
+                                               unsigned step, unsigned spec, float dscale) {
+    const int qrow = min(t, T - 1);
+    f32x4 minit[WPS];
+#pragma unroll
+    for (int kt = 0; kt < WPS; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) minit[kt][r] = (kt * 16 + 4 * gq + r > t) ? -INFINITY : 0.f;
+    // dropout keep word (64 keys) of this lane's query row for head c0 + gq (lane groups past the own heads idle); head hl's word is
+    // then fetched from group hl
+    unsigned kwl = ~0u, kwh = ~0u;
+    if (train && gq < NCT) {
+        const unsigned long long kw = row_keep_word(seed, site, step, (rowbase_bh + c0 + gq) * T + qrow, T, spec);
+        kwl = (unsigned)kw; kwh = (unsigned)(kw >> 32);
+    }
+    const float qscale = scale * LOG2E;
+#pragma unroll
+    for (int hl = 0; hl < NCT; ++hl) {
+        const int h = c0 + hl;
+        float4 kf[WPS], vf[WPS];
+#pragma unroll
+        for (int kt = 0; kt < WPS; ++kt) {
+            kf[kt] = lds_ld4(kimg + (kt * 16 + m) * D + 4 * ((4 * h + gq) ^ m));
+            vf[kt] = lds_ld4(vimg + (h * 16 + m) * NIMG_KEYS + 4 * ((kt * 4 + gq) ^ m));
+        }
+        const unsigned kl = train ? bcast_group(kwl, hl) : ~0u, kh = train ? bcast_group(kwh, hl) : ~0u;
+        f32x4 s[WPS];
+#pragma unroll
+        for (int kt = 0; kt < WPS; ++kt) s[kt] = minit[kt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float qs = Q.v[hl][r] * qscale;
+#pragma unroll
+            for (int kt = 0; kt < WPS; ++kt) {
+                const float4 k4 = kf[kt];
+                s[kt] = mfma4(r == 0 ? k4.x : r == 1 ? k4.y : r == 2 ? k4.z : k4.w, qs, s[kt]);
+            }
+        }
+        float v = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < WPS; ++kt) v = fmaxf(fmaxf(v, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+        const float mx = row_max4(v);
+        float lsum = 0.f;
+        f32x4 oacc[WPS];
+#pragma unroll
+        for (int kt = 0; kt < WPS; ++kt) {
+            oacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned kwd = (kt < 2 ? kl : kh) >> ((kt & 1) * 16 + 4 * gq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+                lsum += p;
+                s[kt][r] = ((kwd >> r) & 1u) ? p : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int kt = 0; kt < WPS; ++kt) {
+                const float4 v4 = vf[kt];
+                oacc[kt] = mfma4(r == 0 ? v4.x : r == 1 ? v4.y : r == 2 ? v4.z : v4.w, s[kt][r], oacc[kt]);
+            }
+        const float rl = 1.0f / row_sum4(lsum);
+        const float ro = rl * dscale;
+        f32x4 o = oacc[0];
+#pragma unroll
+        for (int kt = 1; kt < WPS; ++kt) o += oacc[kt];
+        O.v[hl] = f32x4{o[0] * ro, o[1] * ro, o[2] * ro, o[3] * ro};
+        st_max[hl] = mx * (1.0f / LOG2E);
+        st_rl[hl] = rl;
+    }
+}
+
+template <int D, int WPS, int NS>
+__global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArgs a, const SeqGeom sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = D / 16, H = D / 16, NW = WPS * NS, NCT = NT / NS;
+    static_assert(D == 128 && NT % NS == 0 && NCT >= 1, "");
+    const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    const int si = w % WPS, part = w / WPS;
+    const int c0 = part * NCT;                              // first own column tile = first own head
+    // workgroup -> sequence: the live sequences are the first workgroups, domain 0's then domain 1's (sasrec_seq.hip: a contiguous
+    // range keeps the deal over XCDs and shader engines even)
+    int n0 = sg.B, b = 0, g = 0;
+    if (sg.live != nullptr) {
+        n0 = sg.live[sg.B];
+        b = sg.live[min((int)blockIdx.x, sg.B - 1)];
+        if ((int)blockIdx.x >= sg.B) return;
+        g = (int)blockIdx.x >= n0 ? 1 : 0;
+    } else {
+        g = (int)blockIdx.x >= sg.B ? 1 : 0;
+        b = (int)blockIdx.x - g * sg.B;
+    }
+    SeqRingN<D, NW> ring(smem);
+    ring.first(a.L[0].w_in[g] + 1LL * D * D);
+    float* xb = smem + 2 * D * D + si * (NT * 64 * 4);      // this strip's exchange slots
+    const int t = si * 16 + m;
+    const bool row_ok = t < sg.T;
+    const int local = b * sg.T + min(t, sg.T - 1);
+    const unsigned phys = (unsigned)g * (unsigned)sg.M + (unsigned)(b * sg.T + t);
+    const unsigned off_full = row_ok ? phys * (unsigned)(D * 4) + 16u * (unsigned)gq : STRIP_OOB;
+    const unsigned off_own = row_ok ? off_full + (unsigned)c0 * 64u : STRIP_OOB;
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+
+    StripRegs<D> F;                                         // the whole-row operand of the next product
+    StripRegs<D> Qn;
+    PartRegs<NCT> Xo, Qno, Ko, Vo, Qo, Oo, Ro, Yo, Ho, bias;
+    ColVec<D> lw, lb;
+    {
+        StripRow row; row.ok = row_ok; row.local = local; row.off = off_full;
+        strip_load<D>(F, GBuf(a.x0, sg.act_bytes), row);
+    }
+    part_load<NCT>(Xo, GBuf(a.x0, sg.act_bytes), off_own);
+    unsigned tmw[NCT];                                      // the "== 0" bits of the own column tiles (one byte per column quad)
+    const bool has_tm = a.tmq != nullptr;
+    if (has_tm) {
+        const GBuf gtm(a.tmq, sg.tm_bytes);
+        const unsigned tbase = row_ok ? phys * (unsigned)(D / 4) + (unsigned)c0 * 4u : STRIP_OOB;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) tmw[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(gtm.r, (int)(tbase + 4 * c), 0, 0);
+    }
+    f32x4 acc[NCT];
+    SEQN_STAMP0(62);
+#pragma unroll 1
+    for (int l = 0; l < a.n_layers; ++l) {
+        const SeqLayer& P = a.L[l];
+        const bool last = l + 1 == a.n_layers;
+        const GBuf gx(P.x, sg.act_bytes), gqn(P.qn, sg.act_bytes), gq_(P.q, sg.act_bytes), gk(P.k, sg.act_bytes), gv(P.v, sg.act_bytes),
+                   go(P.o, sg.act_bytes), gst(P.stats, sg.stats_bytes), gr(P.r, sg.act_bytes), gy(P.y, sg.act_bytes), gh(P.h, sg.act_bytes);
+        SEQN_STAMP(0);
+        float* bufk = ring.next();                         // Wk has landed; the previous layer's output parts are visible
+        SEQN_STAMP(1);
+        if (l > 0) {
+            xchg_read<D>(F, xb);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {                 // the own tiles again (runtime slot address, static registers)
+                const float4 t4 = lds_ld4(xb + ((c0 + c) * 64 + lane) * 4);
+                Xo.v[c] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            }
+        }
+        {   // Qn = LN1(x): whole row for the q product, own columns for the residual and the saved copy
+            // (the gains are requested HERE, not ahead of the previous product: 64 registers across an MFMA loop do not fit two waves per SIMD)
+            lw.load(P.ln1_w[g]); lb.load(P.ln1_b[g]);
+            float mean, rstd;
+            strip_stats<D>(F, a.ln_eps, mean, rstd);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Qn.v[ct][r] = (F.v[ct][r] - mean) * rstd * lw.v[ct][r] + lb.v[ct][r];
+            PartRegs<NCT> lwo, lbo;
+            part_cols<NCT>(lwo, P.ln1_w[g], c0); part_cols<NCT>(lbo, P.ln1_b[g], c0);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Qno.v[c][r] = (Xo.v[c][r] - mean) * rstd * lwo.v[c][r] + lbo.v[c][r];
+        }
+        SEQN_STAMP(2);
+        {   // k = x Wk^T + bk
+            part_cols<NCT>(bias, P.b_in[g] + D, c0);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            part_mma<D, NCT>(acc, F, bufk, c0, [&](int ct, int j) {
+                ring.fetch(P.w_in[g] + 2LL * D * D, ct, j);
+                part_spread<NCT>(gqn, off_own, Qno, ct, j, 1);
+            });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Ko.v[c] = acc[c] + bias.v[c];
+        }
+        SEQN_STAMP(3);
+        {   // v = x Wv^T + bv
+            const float* buf = ring.next();
+            SEQN_STAMP(4);
+            part_cols<NCT>(bias, P.b_in[g] + 2 * D, c0);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            part_mma<D, NCT>(acc, F, buf, c0, [&](int ct, int j) { ring.fetch(P.w_in[g], ct, j); part_spread<NCT>(gk, off_own, Ko, ct, j, 1); });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Vo.v[c] = acc[c] + bias.v[c];
+        }
+        SEQN_STAMP(5);
+        float* img;
+        {   // q = Qn Wq^T + bq
+            float* buf = ring.next();
+            SEQN_STAMP(6);
+            img = buf;
+            part_cols<NCT>(bias, P.b_in[g], c0);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            part_mma<D, NCT>(acc, Qn, buf, c0, [&](int ct, int j) { ring.fetch(P.w_o[g], ct, j); part_spread<NCT>(gv, off_own, Vo, ct, j, 1); });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Qo.v[c] = acc[c] + bias.v[c];
+        }
+        SEQN_STAMP(7);
+        part_store<NCT>(gq_, off_own, Qo);
+        // ---- attention core: images of all heads in the slab that held Wq
+        float* kimg = img;
+        float* vimg = img + NIMG_KEYS * D;
+        // (lane-derived LDS addresses and masks of the core are recomputed per layer: hoisted out of the layer loop they cost ~80
+        // registers that two waves per SIMD do not have)
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const int m_ = lane_l & 15, gl_ = lane_l >> 4;
+        lds_barrier();                                     // every wave has read its last Wq fragment
+        {
+            const int m = m_, gq = gl_;
+            const int R = si * 16 + m;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int h = c0 + c;
+                lds_st4(kimg + R * D + 4 * ((4 * h + gq) ^ m), Ko.v[c]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = h * 16 + 4 * gq + r;     // row of the transposed image (d & 15 = 4 gq + r); this lane's key R: column
+                    lds_st1(vimg + d * NIMG_KEYS + (((R >> 2) ^ (d & 15)) * 4) + (R & 3), Vo.v[c][r]);
+                }
+            }
+        }
+        lds_barrier();
+        SEQN_STAMP(8);
+        float st_max[NCT], st_rl[NCT];
+        seqn_attention<D, WPS, NCT>(Oo, st_max, st_rl, Qo, kimg, vimg, c0, m_, gl_, si * 16 + m_, sg.T, (unsigned long long)b * H, a.att_scale, a.train, seed,
+                                    site_id(g, l, SITE_ATTN), step, a.spec, a.dscale);
+        SEQN_STAMP(9);
+        {   // row statistics of the own heads: [2M][H][2] floats
+            const unsigned so = row_ok ? phys * (unsigned)(H * 8) + (unsigned)c0 * 8u : STRIP_OOB;
+            if constexpr (NCT >= 2) {
+                f32x4 sv = f32x4{st_max[0], st_rl[0], st_max[1], st_rl[1]};
+#pragma unroll
+                for (int k = 1; k < NCT / 2; ++k) sv = (gq == k) ? f32x4{st_max[2 * k], st_rl[2 * k], st_max[2 * k + 1], st_rl[2 * k + 1]} : sv;
+                gst.store4(gq < NCT / 2 ? so + 16u * (unsigned)gq : STRIP_OOB, sv);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gq == 0 ? st_max[0] : st_rl[0]), gst.r,
+                                                      (int)(gq < 2 ? so + 4u * (unsigned)gq : STRIP_OOB), 0, 0);
+            }
+        }
+        // ---- r = Qn + (o Wo^T + bo) ; y = LN2(r)
+        xchg_write<NCT>(xb, c0, Oo);                       // (the previous exchange's reads lie behind several barriers)
+        part_cols<NCT>(bias, P.b_o[g], c0);
+        {
+            const float* buf = ring.next();
+            SEQN_STAMP(10);
+            xchg_read<D>(F, xb);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            part_mma<D, NCT>(acc, F, buf, c0, [&](int ct, int j) { ring.fetch(P.w1[g], ct, j); part_spread<NCT>(go, off_own, Oo, ct, j, 1); });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Ro.v[c] = Qno.v[c] + (acc[c] + bias.v[c]);
+        }
+        SEQN_STAMP(11);
+        lds_barrier();                                     // every wave of the strip has read the o parts
+        xchg_write<NCT>(xb, c0, Ro);
+        uint4 rr1 = make_uint4(0, 0, 0, 0), rr2 = rr1;
+        if (a.train) {                                     // the row's dropout words of both feed-forward sites, ahead of their use
+            rr1 = rng_call(seed, (unsigned long long)local * D >> 7, site_id(g, l, SITE_FFN1), step);
+            rr2 = rng_call(seed, (unsigned long long)local * D >> 7, site_id(g, l, SITE_FFN2), step);
+        }
+        {   // h = relu(drop1(y C1^T + c1))
+            const float* buf = ring.next();
+            SEQN_STAMP(12);
+            xchg_read<D>(F, xb);                           // the whole row of r
+            {
+                lw.load(P.ln2_w[g]); lb.load(P.ln2_b[g]);
+                float mean, rstd;
+                strip_stats<D>(F, a.ln_eps, mean, rstd);
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) F.v[ct][r] = (F.v[ct][r] - mean) * rstd * lw.v[ct][r] + lb.v[ct][r];
+                PartRegs<NCT> lwo, lbo;
+                part_cols<NCT>(lwo, P.ln2_w[g], c0); part_cols<NCT>(lbo, P.ln2_b[g], c0);
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Yo.v[c][r] = (Ro.v[c][r] - mean) * rstd * lwo.v[c][r] + lbo.v[c][r];
+            }
+            SEQN_STAMP(13);
+            part_cols<NCT>(bias, P.b1[g], c0);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            part_mma<D, NCT>(acc, F, buf, c0, [&](int ct, int j) { ring.fetch(P.w2[g], ct, j); part_spread<NCT>(gr, off_own, Ro, ct, j, 1); });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Ho.v[c] = acc[c] + bias.v[c];
+            if (a.train) part_dropout<NCT>(Ho, rr1, c0, a.spec, a.ffn_scale);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ho.v[c][r] = fmaxf(Ho.v[c][r], 0.f);
+        }
+        SEQN_STAMP(14);
+        lds_barrier();
+        xchg_write<NCT>(xb, c0, Ho);
+        {   // x' = (drop2(h C2^T + c2) + y) * ~tm
+            const float* buf = ring.next();
+            SEQN_STAMP(15);
+            xchg_read<D>(F, xb);
+            part_cols<NCT>(bias, P.b2[g], c0);
+            const SeqLayer& Pn = a.L[last ? l : l + 1];          // (the last layer refetches its own Wk into the free buffer: harmless)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            part_mma<D, NCT>(acc, F, buf, c0, [&](int ct, int j) {
+                ring.fetch(Pn.w_in[g] + 1LL * D * D, ct, j);
+                part_spread<NCT>(gy, off_own, Yo, ct, j, 1);
+                part_spread<NCT>(gh, off_own, Ho, ct, j, 3);
+            });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Xo.v[c] = acc[c] + bias.v[c];
+            if (a.train) part_dropout<NCT>(Xo, rr2, c0, a.spec, a.ffn_scale);
+            const int sh = 8 * gq;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                Xo.v[c] += Yo.v[c];
+                if (has_tm) {
+                    const unsigned bits = tmw[c] >> sh;
+                    Xo.v[c][0] = (bits & 1u) ? 0.f : Xo.v[c][0];
+                    Xo.v[c][1] = (bits & 2u) ? 0.f : Xo.v[c][1];
+                    Xo.v[c][2] = (bits & 4u) ? 0.f : Xo.v[c][2];
+                    Xo.v[c][3] = (bits & 8u) ? 0.f : Xo.v[c][3];
+                }
+            }
+        }
+        SEQN_STAMP(16);
+        if (!last) {
+            lds_barrier();
+            xchg_write<NCT>(xb, c0, Xo);                   // read at the top of the next layer, behind its ring barrier
+            part_store<NCT>(GBuf(a.L[l + 1].x, sg.act_bytes), off_own, Xo);     // the next layer's saved input
+        } else {
+            part_store<NCT>(GBuf(a.xout, sg.act_bytes), off_own, Xo);
+        }
+    }
+    SEQN_STAMP0(63);
+    w_ring_wait();                                          // the last (redundant) weight fetch targets this workgroup's LDS
+}
+
+template <int D, int WPS> static constexpr size_t seqn_lds_bytes() { return (size_t)(2 * D * D + WPS * (D / 16) * 64 * 4) * sizeof(float); }
+
+template <int WPS, int NS>
+static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
+    constexpr size_t lds = seqn_lds_bytes<128, WPS>();
+    auto kern = seqn_fwd_kernel<128, WPS, NS>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const int grid = sg.live != nullptr ? sg.B : 2 * sg.B;
+    kern<<<grid, 64 * WPS * NS, lds, (hipStream_t)stream>>>(a, sg);
+    e = hipGetLastError();
+    return e == hipSuccess ? AMID_OK : (int)e;
+}
+
+// variant: 0 = the default split for the shape; 42 / 22 / 24 / 14 / 18 = WPS, NS spelled out (diagnostics and tests)
+int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int variant, void* stream) {
+    const int T = sg.T;
+    const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4;
+    if (variant == 0) variant = wps == 4 ? 42 : wps == 2 ? 22 : 14;
+    if (variant / 10 != wps) return AMID_ERR_UNSUPPORTED;
+    switch (variant) {
+        case 42: return seqn_launch<4, 2>(a, sg, stream);
+        case 22: return seqn_launch<2, 2>(a, sg, stream);
+        case 24: return seqn_launch<2, 4>(a, sg, stream);
+        case 14: return seqn_launch<1, 4>(a, sg, stream);
+        case 18: return seqn_launch<1, 8>(a, sg, stream);
+        default: return AMID_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace amid
+
+#ifdef AMID_STRIP_STAMPS
+extern "C" int amid_seqn_stamps_read(unsigned long long* host) {       // diagnostic library only
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_seqn_stamp_buf), sizeof(unsigned long long) * 8 * 64);
+}
+#endif

@@ -1,0 +1,53 @@
+// Shared by the two builds of the one-launch SASRec encoder forward: sasrec_seq.hip (a wave owns a 16-row strip and all D columns) and
+// sasrec_seqn.hip (NS waves share a strip, each owning D / NS columns).  Reference: Log2feats.forward, model_seq.py:371-383.
+#pragma once
+#include "common.h"
+#include "rng.h"
+#include "strip_gemm.h"
+
+namespace amid {
+
+struct SeqLayer {
+    const float* ln1_w[2]; const float* ln1_b[2]; const float* w_in[2]; const float* b_in[2];
+    const float* w_o[2]; const float* b_o[2]; const float* ln2_w[2]; const float* ln2_b[2];
+    const float* w1[2]; const float* b1[2]; const float* w2[2]; const float* b2[2];
+    float* x;                           // this layer's INPUT rows (written for layers >= 1: the previous layer's output)
+    float* qn; float* q; float* k; float* v; float* o; float* stats; float* r; float* y; float* h;
+};
+
+struct SeqFwdArgs {
+    SeqLayer L[2];
+    int n_layers;
+    const float* x0;                    // layer 0's input (the gathered rows)
+    float* xout;                        // the last layer's output
+    const unsigned char* tmq;
+    float ln_eps, att_scale, dscale, ffn_scale;
+    const StepState* st; int train; unsigned spec;
+};
+
+struct SeqGeom {
+    int B, T, M;
+    unsigned act_bytes, tm_bytes, stats_bytes;
+    const int* live;                    // as StripGeom::live
+};
+
+// workgroup barrier between LDS phases WITHOUT draining the vector-memory queue (__syncthreads() waits for every store in flight)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// 32-bit value of lane group `src` (lanes m + 16 src) to all four groups of the same m: two half-exchanges
+__device__ __forceinline__ unsigned bcast_group(unsigned v, int SRC) {
+    float a = __builtin_bit_cast(float, v), b = a;
+    swap16(a, b);                                          // a: rows (0, 0, 2, 2), b: rows (1, 1, 3, 3)
+    float x = (SRC & 1) ? b : a, y = x;
+    swap32(x, y);                                          // x: (lo half, lo half), y: (hi half, hi half)
+    return __builtin_bit_cast(unsigned, (SRC >> 1) ? y : x);
+}
+
+
+// sasrec_seqn.hip: the N-split kernels.  variant: 0 = auto.  Returns AMID_ERR_UNSUPPORTED when no N-split build covers the shape.
+int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int variant, void* stream);
+
+}  // namespace amid

@@ -589,6 +589,11 @@ int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, float* xout, co
                          float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
                          const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live, const void* step_state,
                          int train, float p_drop, void* stream);
+/* Which build of the fused forward runs (diagnostics, tests, A/B measurements): 0 = auto (per shape), 1 = whole-row waves
+ * (csrc/sasrec_seq.hip), 2 = the N-split build's default split (csrc/sasrec_seqn.hip: NS waves share a 16-row strip, each owning
+ * D / NS columns), 42 / 22 / 24 / 14 / 18 = (strips per sequence, column parts) spelled out.  v < 0 only queries.  Returns the previous
+ * value.  Process-wide host state, not a kernel launch. */
+int amid_sas_seq_fwd_variant(int v);
 
 /* ---- the encoder's data gradients of the live sequences in ONE launch (csrc/sasrec_strip.hip: seq_bwd_kernel) -------------------------
  * replaces: autograd of Log2feats.forward model_seq.py:371-383 under loss.backward() (train_sr.py:214) -- per layer, top down,

@@ -45,6 +45,14 @@ for w in range(4):
     print(f"wave {w} attention round 1 (last layer): " + ", ".join(f"{names[fine[k]]} +{tf[k] - tf[k - 1]}" for k in range(1, len(fine))))
     print(f"wave {w}: total {t[order[-1]] - t[0]}: " + ", ".join(f"{names[i]} +{t[i] - t[order[k - 1]]}" for k, i in enumerate(order) if k))
 
+fine = (ctypes.c_ulonglong * (8 * 64))()
+if hasattr(L, "amid_seq_fine_read") and L.amid_seq_fine_read(fine) == 0:
+    fn = ["k:wait", "k:mma", "k:epi", "v:wait", "v:mma", "v:epi", "q:wait", "q:mma", "q:epi", "q store", "attention", "(bias loads)", "o:wait", "o:mma",
+          "o:epi+LN2", "c1:wait", "c1:mma", "c1:epi", "c2:wait", "c2:mma", "c2:epi"]
+    for w in range(4):
+        t = [fine[w * 64 + i] for i in range(22)]
+        print(f"wave {w} last layer, fine: " + ", ".join(f"{fn[i]} +{t[i + 1] - t[i]}" for i in range(21)))
+
 sched = (ctypes.c_ulonglong * (1024 * 4))()
 assert L.amid_seq_sched_read(sched) == 0
 rows = [(i, sched[i * 4], sched[i * 4 + 1], sched[i * 4 + 2]) for i in range(512) if sched[i * 4]]

@@ -1,0 +1,92 @@
+"""The N-split build of the one-launch encoder forward (csrc/sasrec_seqn.hip: NS waves share a 16-row strip, each owning D / NS
+columns) against the whole-row build (csrc/sasrec_seq.hip, itself held to the oracle and the reference goldens by
+test_gpu_sasrec.py / test_gpu_timed_path.py) through the C ABI, on the same inputs: both sum every product over k in the same order,
+draw the same dropout counters and save the same tensors, so everything a layer saves -- x, qn, q, k, v, o, row statistics, r, y, h --
+and the encoder output must agree BIT FOR BIT, train and eval, with and without the live-sequence list (rows outside the list must
+stay untouched).  Reference arithmetic: Log2feats.forward, model_seq.py:371-383."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+D, H = 128, 8
+# (B, T, variants): every (strips per sequence, column parts) build that covers T
+CASES = [(256, 50, (42,)), (37, 64, (42,)), (9, 33, (42,)), (64, 20, (22, 24)), (300, 32, (22, 24)), (5, 17, (22, 24)),
+         (64, 16, (14, 18)), (300, 9, (14, 18)), (3, 1, (14, 18))]
+
+
+def _setup(B, T, seed, live):
+    from amid_amd._lib import lib, ptr_array
+    L = lib()
+    g = torch.Generator().manual_seed(seed)
+    M = B * T
+    host = (ctypes.c_ubyte * L.value("amid_step_state_bytes"))()
+    L.call("amid_step_state_pack", ctypes.addressof(host), 77, 3, 5e-4, 0.9, 0.999, 1e-8)
+    st = torch.frombuffer(bytearray(host), dtype=torch.uint8).cuda()
+    dom = (torch.rand(B, generator=g) < 0.5).long()
+    if live == "all1":
+        dom[:] = 1
+    lv, row_live = None, torch.ones(2 * M, dtype=torch.bool)
+    if live:
+        d0, d1 = torch.nonzero(dom == 0).flatten(), torch.nonzero(dom != 0).flatten()
+        lv = torch.cat((d0, d1, torch.tensor([d0.numel()]))).int().cuda()
+        row_live = torch.cat((dom == 0, dom != 0)).repeat_interleave(T)
+    rnd = lambda *s, sc=0.1, base=0.0: (base + sc * torch.randn(*s, generator=g)).cuda()      # noqa: E731
+    fam = lambda *s, **k: [rnd(*s, **k) for _ in range(4)]                                      # noqa: E731  [layer][domain]
+    P = dict(ln1_w=fam(D, base=1.0), ln1_b=fam(D), w_in=fam(3 * D, D), b_in=fam(3 * D), w_o=fam(D, D), b_o=fam(D), ln2_w=fam(D, base=1.0),
+             ln2_b=fam(D), w1=fam(D, D), b1=fam(D), w2=fam(D, D), b2=fam(D))
+    x0 = rnd(2 * M, D, sc=1.0)
+    tmq = ((torch.rand(2 * M, D // 4, generator=g) < 0.04).to(torch.uint8) * 9).cuda()
+    return L, ptr_array, st, lv, row_live, P, x0, tmq
+
+
+def _run(L, pa, variant, B, T, st, lv, P, x0, tmq, train):
+    M = B * T
+    nan = lambda *s: torch.full(s, float("nan"), device="cuda")      # noqa: E731
+    saved = {k: [nan(2 * M, D) for _ in range(2)] for k in "qn q k v o r y h".split()}
+    saved["stats"] = [nan(2 * M, H, 2) for _ in range(2)]
+    x1, xout = nan(2 * M, D), nan(2 * M, D)
+    tl = lambda ts: pa([t.data_ptr() for t in ts])      # noqa: E731
+    prev = L.value("amid_sas_seq_fwd_variant", variant)
+    try:
+        L.call("amid_sas_seq_fwd_f32", 2, tl([x0, x1]), xout.data_ptr(), *[tl(P[k]) for k in
+               "ln1_w ln1_b w_in b_in w_o b_o ln2_w ln2_b w1 b1 w2 b2".split()], *[tl(saved[k]) for k in "qn q k v o stats r y h".split()],
+               tmq.data_ptr(), 1e-8, B, T, D, H, lv.data_ptr() if lv is not None else None, st.data_ptr(), train, 0.5,
+               torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        L.value("amid_sas_seq_fwd_variant", prev)
+    out = {f"{k}{l}": v[l] for k, v in saved.items() for l in (0, 1)}
+    out["x1"], out["xout"] = x1, xout
+    return out
+
+
+@pytest.mark.parametrize("B,T,variants", CASES)
+@pytest.mark.parametrize("live", [None, "mixed", "all1"])
+@pytest.mark.parametrize("train", [0, 1])
+def test_n_split_forward_is_bit_identical_to_whole_row_forward(B, T, variants, live, train):
+    L, pa, st, lv, row_live, P, x0, tmq = _setup(B, T, seed=B * 13 + T, live=live)
+    ref = _run(L, pa, 1, B, T, st, lv, P, x0, tmq, train)
+    rl = row_live.cuda()
+    for v in variants:
+        got = _run(L, pa, v, B, T, st, lv, P, x0, tmq, train)
+        for name, want in ref.items():
+            a, b = got[name], want
+            assert torch.isfinite(b[rl]).all(), (name, "reference build")
+            assert torch.equal(a[rl], b[rl]), (v, name, float((a[rl] - b[rl]).abs().max()))
+            if bool((~rl).any()):
+                assert torch.isnan(a[~rl]).all(), f"variant {v} {name}: rows outside the live list were written"
+
+
+def test_variant_switch_round_trips_and_refuses_a_split_that_does_not_cover_t():
+    from amid_amd._lib import AmidError
+    L, pa, st, lv, row_live, P, x0, tmq = _setup(4, 50, seed=1, live=None)
+    prev = L.value("amid_sas_seq_fwd_variant", -1)
+    assert L.value("amid_sas_seq_fwd_variant", 24) == prev and L.value("amid_sas_seq_fwd_variant", prev) == 24
+    # an explicit (2 strips, ...) build cannot hold 50 rows: the entry falls back to the whole-row build instead of failing
+    out = _run(L, pa, 24, 4, 50, st, lv, P, x0, tmq, 0)
+    ref = _run(L, pa, 1, 4, 50, st, lv, P, x0, tmq, 0)
+    assert torch.equal(out["xout"], ref["xout"])
+    assert AmidError is not None
