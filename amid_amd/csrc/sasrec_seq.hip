@@ -468,7 +468,7 @@ extern "C" int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, floa
     sg.act_bytes = (unsigned)bytes; sg.tm_bytes = (unsigned)(bytes / 16); sg.stats_bytes = (unsigned)(2LL * B * T * H * 8);
     {
         int v = g_seq_fwd_variant;
-        if (v == 0) v = 1;                                 // auto
+        if (v == 0) v = 2;                                 // auto: the N-split build wins at every measured shape (profiles/r03_*)
         if (v != 1) {
             const int rc = launch_seqn_fwd(a, sg, v == 2 ? 0 : v, stream);
             if (rc != AMID_ERR_UNSUPPORTED) return rc;

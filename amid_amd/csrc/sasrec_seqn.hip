@@ -158,7 +158,16 @@ __device__ __forceinline__ void part_mma(f32x4 (&acc)[NCT], const StripRegs<D>& 
                 const float wr = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, A.v[ct][j], acc[c], 0, 0, 0);
             }
-            if (ct + 1 < NT && j < NCT) wf[(ct + 1) & 1][j] = lds_ld4(nxt + j * 16 * D);
+            // the next k tile's fragments: two behind group 0, one behind groups 1 and 2 -- the last one has a whole group (128 cycles)
+            // + three MFMAs in front of its use instead of three MFMAs
+            if (ct + 1 < NT) {
+                if (j == 0) {
+                    wf[(ct + 1) & 1][0] = lds_ld4(nxt);
+                    if (NCT > 1) wf[(ct + 1) & 1][1] = lds_ld4(nxt + 16 * D);
+                } else if (j + 1 < NCT) {
+                    wf[(ct + 1) & 1][j + 1] = lds_ld4(nxt + (j + 1) * 16 * D);
+                }
+            }
             hook(ct, j);
             AMID_STRIP_FENCE();
         }
@@ -184,15 +193,13 @@ __device__ __forceinline__ void part_dropout(PartRegs<NCT>& x, const uint4 rr, i
 constexpr int NIMG_KEYS = 64;
 template <int D, int WPS, int NCT>
 __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)[NCT], float (&st_rl)[NCT], const PartRegs<NCT>& Q,
-                                               const float* __restrict__ kimg, const float* __restrict__ vimg, int c0, int m, int gq, int t, int T,
+                                               const float* __restrict__ kimg, const float* __restrict__ vimg, int c0, int si, int m, int gq, int t, int T,
                                                unsigned long long rowbase_bh, float scale, int train, unsigned long long seed, unsigned site,
                                                unsigned step, unsigned spec, float dscale) {
     const int qrow = min(t, T - 1);
-    f32x4 minit[WPS];
+    f32x4 mdiag;                                           // causal mask of the diagonal tile (kt = si) as the accumulators' initial value
 #pragma unroll
-    for (int kt = 0; kt < WPS; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) minit[kt][r] = (kt * 16 + 4 * gq + r > t) ? -INFINITY : 0.f;
+    for (int r = 0; r < 4; ++r) mdiag[r] = (4 * gq + r > m) ? -INFINITY : 0.f;
     // dropout keep word (64 keys) of this lane's query row for head c0 + gq (lane groups past the own heads idle); head hl's word is
     // then fetched from group hl
     unsigned kwl = ~0u, kwh = ~0u;
@@ -201,55 +208,69 @@ __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)
         kwl = (unsigned)kw; kwh = (unsigned)(kw >> 32);
     }
     const float qscale = scale * LOG2E;
+    // key tiles above the wave's own strip are all in the future (causal): only tiles kt <= si are computed.  (Workgroups of eight waves
+    // pair strip si with strip WPS - 1 - si on a SIMD, so every SIMD carries WPS + 1 tiles per head pair instead of 2 .. 2 WPS.)
 #pragma unroll
     for (int hl = 0; hl < NCT; ++hl) {
         const int h = c0 + hl;
         float4 kf[WPS], vf[WPS];
 #pragma unroll
         for (int kt = 0; kt < WPS; ++kt) {
-            kf[kt] = lds_ld4(kimg + (kt * 16 + m) * D + 4 * ((4 * h + gq) ^ m));
-            vf[kt] = lds_ld4(vimg + (h * 16 + m) * NIMG_KEYS + 4 * ((kt * 4 + gq) ^ m));
+            if (kt <= si) {
+                kf[kt] = lds_ld4(kimg + (kt * 16 + m) * D + 4 * ((4 * h + gq) ^ m));
+                vf[kt] = lds_ld4(vimg + (h * 16 + m) * NIMG_KEYS + 4 * ((kt * 4 + gq) ^ m));
+            }
         }
         const unsigned kl = train ? bcast_group(kwl, hl) : ~0u, kh = train ? bcast_group(kwh, hl) : ~0u;
         f32x4 s[WPS];
 #pragma unroll
-        for (int kt = 0; kt < WPS; ++kt) s[kt] = minit[kt];
+        for (int kt = 0; kt < WPS; ++kt) s[kt] = (kt == si) ? mdiag : (kt < si) ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float qs = Q.v[hl][r] * qscale;
 #pragma unroll
             for (int kt = 0; kt < WPS; ++kt) {
-                const float4 k4 = kf[kt];
-                s[kt] = mfma4(r == 0 ? k4.x : r == 1 ? k4.y : r == 2 ? k4.z : k4.w, qs, s[kt]);
+                if (kt <= si) {
+                    const float4 k4 = kf[kt];
+                    s[kt] = mfma4(r == 0 ? k4.x : r == 1 ? k4.y : r == 2 ? k4.z : k4.w, qs, s[kt]);
+                }
             }
         }
         float v = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < WPS; ++kt) v = fmaxf(fmaxf(v, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+        for (int kt = 0; kt < WPS; ++kt)
+            if (kt <= si) v = fmaxf(fmaxf(v, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
         const float mx = row_max4(v);
         float lsum = 0.f;
-        f32x4 oacc[WPS];
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < WPS; ++kt) {
-            oacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const unsigned kwd = (kt < 2 ? kl : kh) >> ((kt & 1) * 16 + 4 * gq);
+            if (kt <= si) {
+                const unsigned kwd = (kt < 2 ? kl : kh) >> ((kt & 1) * 16 + 4 * gq);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kt][r] - mx);
-                lsum += p;
-                s[kt][r] = ((kwd >> r) & 1u) ? p : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+                    lsum += p;
+                    s[kt][r] = ((kwd >> r) & 1u) ? p : 0.f;
+                }
             }
         }
+        // P~ V: the key tiles in ascending order, one accumulator per tile summed at the end -- the order sasrec_seq.hip adds them in
+        f32x4 oacc[WPS];
+#pragma unroll
+        for (int kt = 0; kt < WPS; ++kt) oacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int kt = 0; kt < WPS; ++kt) {
-                const float4 v4 = vf[kt];
-                oacc[kt] = mfma4(r == 0 ? v4.x : r == 1 ? v4.y : r == 2 ? v4.z : v4.w, s[kt][r], oacc[kt]);
+                if (kt <= si) {
+                    const float4 v4 = vf[kt];
+                    oacc[kt] = mfma4(r == 0 ? v4.x : r == 1 ? v4.y : r == 2 ? v4.z : v4.w, s[kt][r], oacc[kt]);
+                }
             }
         const float rl = 1.0f / row_sum4(lsum);
         const float ro = rl * dscale;
-        f32x4 o = oacc[0];
+        o = oacc[0];
 #pragma unroll
         for (int kt = 1; kt < WPS; ++kt) o += oacc[kt];
         O.v[hl] = f32x4{o[0] * ro, o[1] * ro, o[2] * ro, o[3] * ro};
@@ -264,7 +285,9 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
     constexpr int NT = D / 16, H = D / 16, NW = WPS * NS, NCT = NT / NS;
     static_assert(D == 128 && NT % NS == 0 && NCT >= 1, "");
     const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
-    const int si = w % WPS, part = w / WPS;
+    // waves w and w + 4 share a SIMD: strip si beside strip WPS - 1 - si (the causal attention core costs si + 1 key tiles per head)
+    const int part = w / WPS;
+    const int si = (NW == 8 && w >= 4) ? WPS - 1 - (w % WPS) : w % WPS;
     const int c0 = part * NCT;                              // first own column tile = first own head
     // workgroup -> sequence: the live sequences are the first workgroups, domain 0's then domain 1's (sasrec_seq.hip: a contiguous
     // range keeps the deal over XCDs and shader engines even)
@@ -406,7 +429,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
         lds_barrier();
         SEQN_STAMP(8);
         float st_max[NCT], st_rl[NCT];
-        seqn_attention<D, WPS, NCT>(Oo, st_max, st_rl, Qo, kimg, vimg, c0, m_, gl_, si * 16 + m_, sg.T, (unsigned long long)b * H, a.att_scale, a.train, seed,
+        seqn_attention<D, WPS, NCT>(Oo, st_max, st_rl, Qo, kimg, vimg, c0, si, m_, gl_, si * 16 + m_, sg.T, (unsigned long long)b * H, a.att_scale, a.train, seed,
                                     site_id(g, l, SITE_ATTN), step, a.spec, a.dscale);
         SEQN_STAMP(9);
         {   // row statistics of the own heads: [2M][H][2] floats
@@ -537,7 +560,7 @@ static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
 int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int variant, void* stream) {
     const int T = sg.T;
     const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4;
-    if (variant == 0) variant = wps == 4 ? 42 : wps == 2 ? 22 : 14;
+    if (variant == 0) variant = wps == 4 ? 42 : wps == 2 ? 24 : 14;
     if (variant / 10 != wps) return AMID_ERR_UNSUPPORTED;
     switch (variant) {
         case 42: return seqn_launch<4, 2>(a, sg, stream);

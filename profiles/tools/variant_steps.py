@@ -20,6 +20,16 @@ def run(tag, steps=200, objective=0, **kw):
     ob = torch.randint(0, 2, (bench.B,), device="cuda") if kw.get("dr") else None
     eng.load_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"], ob)
     eng.dr_mode = objective
+    if os.environ.get("VARIANT_KERNELS"):        # one eager step under the C-ABI timer: which entry points this variant's step is made of
+        from amid_amd._lib import KernelTimer, lib
+        L = lib()
+        eng.enqueue_train_step(pl); eng.sync()
+        L.timer = KernelTimer()
+        for _ in range(5):
+            eng.enqueue_train_step(pl); eng.sync()
+        durs = L.timer.collect(L)
+        L.timer = None
+        print(f"  {tag}: " + ", ".join(f"{k} {1e3 * sum(v) / 5:.1f}us/{len(v) // 5}" for k, v in durs.items()), flush=True)
     eng.capture_train_step(pl)
     for _ in range(20):
         eng.replay_train_step(pl)

@@ -123,6 +123,9 @@ TIMED_CASES = [
     (200, 50, 128, "_rt3", "one0"),       # one live sequence in domain 0 (a one-row-tile domain), ragged last tiles
     (37, 13, 64, "_rt3", "mixed"),        # odd everything
     (1100, 50, 128, "", "mixed"),         # B > 1024: the live-sequence windows of the tiles / splits / attention slots
+    (64, 16, 128, "_rt3", "mixed"),       # T <= 16 at D 128: the one-strip builds of the fused forward (seq_fwd_kernel<128, 1>, seqn <1, 4>)
+    (300, 9, 128, "_rt3", "mixed"),       # ... with a ragged strip
+    (256, 32, 128, "_rt3", "mixed"),      # T = 32: two full strips
 ]
 
 
