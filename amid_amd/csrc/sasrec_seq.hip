@@ -432,13 +432,13 @@ extern "C" int amid_sas_seq_supported(int B, int T, int D, int H) {
 
 // Per-layer pointer arrays: the per-domain parameter families hold 2 * n_layers entries ordered [layer][domain], the saved-tensor
 // families n_layers entries; x_in[l] = layer l's input rows (x_in[0] is read, x_in[l >= 1] written), xout = the last layer's output.
-extern "C" int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
-                                    const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
-                                    const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
-                                    const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
-                                    float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
-                                    const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
-                                    const void* step_state, int train, float p_drop, void* stream) {
+static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                        const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                        const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                        const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
+                        float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
+                        const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                        const void* step_state, int train, float p_drop, const void* w16, void* stream) {
     AMID_CHECK_ARG(n_layers >= 1 && n_layers <= 2 && x_in && xout && ln1_w && ln1_b && w_in && b_in && w_o && b_o && ln2_w && ln2_b && w1 && b1 &&
                    w2 && b2 && qn && q && k && v && o && stats && r && y && h && (!train || step_state));
     if (!amid_sas_seq_supported(B, T, D, H)) return AMID_ERR_UNSUPPORTED;
@@ -457,6 +457,7 @@ extern "C" int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, floa
         P.r = r[l]; P.y = y[l]; P.h = h[l];
     }
     a.x0 = x_in[0]; a.xout = xout; a.tmq = tmq; a.ln_eps = ln_eps;
+    a.w16 = (const unsigned short*)w16;
     a.att_scale = sqrtf(1.0f / (float)(D / H));
     a.st = (const StepState*)step_state;
     a.train = (train && p_drop > 0.f) ? 1 : 0;
@@ -469,9 +470,11 @@ extern "C" int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, floa
     {
         int v = g_seq_fwd_variant;
         if (v == 0) v = 2;                                 // auto: the N-split build wins at every measured shape (profiles/r03_*)
+        if (w16 != nullptr && v == 1) return AMID_ERR_UNSUPPORTED;      // the whole-row build has no bf16 products
         if (v != 1) {
-            const int rc = launch_seqn_fwd(a, sg, v == 2 ? 0 : v, stream);
-            if (rc != AMID_ERR_UNSUPPORTED) return rc;
+            int rc = launch_seqn_fwd(a, sg, v == 2 ? 0 : v, stream);
+            if (rc == AMID_ERR_UNSUPPORTED && w16 != nullptr) rc = launch_seqn_fwd(a, sg, 0, stream);
+            if (rc != AMID_ERR_UNSUPPORTED || w16 != nullptr) return rc;
         }
     }
     const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4, spw = STRIP_WAVES / wps;
@@ -488,4 +491,70 @@ extern "C" int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, floa
     if (wps == 1) return launch(seq_fwd_kernel<128, 1>);
     if (wps == 2) return launch(seq_fwd_kernel<128, 2>);
     return launch(seq_fwd_kernel<128, 4>);
+}
+
+extern "C" int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                    const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                    const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                    const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
+                                    float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
+                                    const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                                    const void* step_state, int train, float p_drop, void* stream) {
+    return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, qn, q, k, v, o, stats, r, y, h, tmq,
+                        ln_eps, B, T, D, H, live, step_state, train, p_drop, nullptr, stream);
+}
+
+// The same forward with the twelve projections' matrix products on v_mfma_f32_16x16x32_bf16 (operands rounded to bf16, fp32
+// accumulation; LayerNorm, the attention core, residuals, dropout, everything stored stays fp32): w16 = the weights' bf16 fragment images
+// written by amid_sas_weights_bf16 for this step's weights.  BASELINE.json configs[2]; arithmetic: model_seq.py:371-383.
+extern "C" int amid_sas_seq_fwd_bf16w_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                          const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                          const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                          const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
+                                          float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
+                                          const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                                          const void* step_state, int train, float p_drop, const void* w16, void* stream) {
+    AMID_CHECK_ARG(w16 != nullptr);
+    return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, qn, q, k, v, o, stats, r, y, h, tmq,
+                        ln_eps, B, T, D, H, live, step_state, train, p_drop, w16, stream);
+}
+
+// bf16 fragment images of n square [D][D] fp32 matrices (row-major [out n][in k]; transposed != 0: of their transposes):
+// dst16 [n][D][D / 8 chunks][8] bf16, chunk 4 s + g of row n = W[n][32 s + 4 g + 0..3], W[n][32 s + 16 + 4 g + 0..3] -- the eight k a lane
+// group supplies in k-step s of v_mfma_f32_16x16x32_bf16 when the other operand sits in the strip kernels' C layout (csrc/sasrec_seqn.hip).
+namespace amid {
+struct W16Args { const float* src[48]; int n; };
+__global__ __launch_bounds__(256) void weights_bf16_kernel(const W16Args a, unsigned short* __restrict__ dst, int D, int transposed) {
+    const float* __restrict__ W = a.src[blockIdx.y];
+    unsigned short* __restrict__ out = dst + (size_t)blockIdx.y * D * D;
+    const int cpr = D / 8;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < D * cpr; q += gridDim.x * 256) {
+        const int n = q / cpr, c = q % cpr;
+        const int s = c >> 2, g = c & 3;
+        unsigned pk[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = 32 * s + 16 * h + 4 * g + 2 * e;
+                const float v0 = transposed ? W[(size_t)k * D + n] : W[(size_t)n * D + k];
+                const float v1 = transposed ? W[(size_t)(k + 1) * D + n] : W[(size_t)n * D + k + 1];
+                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                pk[2 * h + e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{v0, v1}, bf2));
+            }
+        *reinterpret_cast<uint4*>(out + (size_t)q * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+}
+}  // namespace amid
+
+extern "C" int amid_sas_weights_bf16(const float* const* src, int n, int D, int transposed, void* dst16, void* stream) {
+    AMID_CHECK_ARG(src && dst16 && n > 0 && n <= 48 && D > 0 && (D % 32) == 0);
+    amid::W16Args a;
+    a.n = n;
+    for (int i = 0; i < n; ++i) { AMID_CHECK_ARG(src[i]); a.src[i] = src[i]; }
+    const int per = (D * (D / 8) + 255) / 256;
+    amid::weights_bf16_kernel<<<dim3(per, n), 256, 0, (hipStream_t)stream>>>(a, (unsigned short*)dst16, D, transposed);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
 }

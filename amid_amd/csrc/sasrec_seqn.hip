@@ -22,6 +22,7 @@
 #include "strip_gemm.h"
 #include "attention_mfma.h"
 #include "seq_fwd.h"
+#include <type_traits>
 
 namespace amid {
 
@@ -92,6 +93,77 @@ template <int D, int NW> struct SeqRingN {
         if (slot % EVERY == 0 && slot / EVERY < PW) dma.piece(buf + (s & 1) * D * D, W, slot / EVERY);
     }
 };
+
+// ---- bf16 weight images (amid_sas_weights_bf16): row n = D bf16 = D / 8 chunks of 16 bytes; chunk 4 s + g of a row holds the eight k
+// values lane group g supplies in k-step s of v_mfma_f32_16x16x32_bf16 when the operand sits in the C layout: k = 32 s + 4 g + r
+// (column tile 2 s, elements 0..3) and k = 32 s + 16 + 4 g + r (column tile 2 s + 1, elements 4..7).  In LDS chunk c of row n sits at
+// chunk position c ^ (n & 15), applied on the DMA's source address as for the fp32 images: conflict-free ds_read_b128 fragments.
+template <int D, int NW> struct SeqRing16 {
+    static constexpr int CPR = D / 8;                                   // 16-byte chunks per row
+    static constexpr int PIECES = D * CPR / 64, PER_WAVE = PIECES / NW;
+    static constexpr int SLAB = D * D / 2;                              // floats per slab (32 KB at D = 128)
+    float* buf; int s; unsigned off0; int w;
+    __device__ __forceinline__ explicit SeqRing16(float* lds) : buf(lds), s(0) {
+        w = wave_id();
+        const int p = w * 64 + lane_id();
+        const int n = p / CPR, pos = p % CPR;
+        off0 = (unsigned)(n * D * 2 + ((pos ^ (n & 15)) * 16));
+    }
+    __device__ __forceinline__ void piece(float* __restrict__ dst, const unsigned short* __restrict__ W, int k0) const {
+        const unsigned voff = off0 + (unsigned)k0 * (unsigned)(NW * 64 / CPR) * (unsigned)(D * 2);      // NW * 4 rows further: n & 15 unchanged
+        const unsigned lds = __builtin_amdgcn_readfirstlane(
+            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(dst + (k0 * NW + w) * 256));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
+    }
+    __device__ __forceinline__ void first(const unsigned short* __restrict__ W0) {
+#pragma unroll
+        for (int k0 = 0; k0 < PER_WAVE; ++k0) piece(buf, W0, k0);
+    }
+    __device__ __forceinline__ float* next() {
+        w_ring_wait();
+        __syncthreads();
+        float* cur = buf + (s & 1) * SLAB;
+        ++s;
+        return cur;
+    }
+    __device__ __forceinline__ void fetch_all(const unsigned short* __restrict__ W) const {
+#pragma unroll
+        for (int k0 = 0; k0 < PER_WAVE; ++k0) piece(buf + (s & 1) * SLAB, W, k0);
+    }
+};
+
+typedef __bf16 seqn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 seqn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float seqn_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned seqn_pack2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(seqn_f32x2{a, b}, seqn_bf16x2));       // v_cvt_pk_bf16_f32: round to nearest even
+}
+// acc[c] += A W^T over the own column tiles with bf16 operands: 4 k-steps of 32; the operand's eight values of step s are the lane's
+// elements of column tiles 2 s and 2 s + 1
+template <int D, int NCT>
+__device__ __forceinline__ void part_mma16(f32x4 (&acc)[NCT], const StripRegs<D>& A, const float* __restrict__ buf, int c0) {
+    constexpr int KS = D / 32;
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const float* rowp = buf + (c0 * 16 + i) * (D / 2);                  // a row = D bf16 = D / 2 floats
+    amid_v4u a16[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        a16[s] = amid_v4u{seqn_pack2(A.v[2 * s][0], A.v[2 * s][1]), seqn_pack2(A.v[2 * s][2], A.v[2 * s][3]),
+                          seqn_pack2(A.v[2 * s + 1][0], A.v[2 * s + 1][1]), seqn_pack2(A.v[2 * s + 1][2], A.v[2 * s + 1][3])};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float4 wf[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) wf[c] = lds_ld4(rowp + c * 16 * (D / 2) + 4 * ((4 * s + g) ^ i));
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(seqn_bf16x8, wf[c]), __builtin_bit_cast(seqn_bf16x8, a16[s]),
+                                                             acc[c], 0, 0, 0);
+    }
+}
 
 // ---- the own columns of a strip ---------------------------------------------------------------------------------------------------
 template <int NCT> struct PartRegs { f32x4 v[NCT]; };
@@ -279,7 +351,24 @@ __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)
     }
 }
 
-template <int D, int WPS, int NS>
+// one product of the chain on the own column tiles: fp32 -- strip MFMA loop with the next slab's DMA pieces and the deferred stores
+// (`stores(ct, j)`) in its groups; bf16 -- the next slab requested up front, 16 MFMAs, the deferred stores behind them
+template <int D, int NCT, bool BF, class Ring, class Stores>
+__device__ __forceinline__ void seqn_product(f32x4 (&acc)[NCT], const StripRegs<D>& A, const float* __restrict__ buf, const Ring& ring,
+                                             const float* __restrict__ wn32, const unsigned short* __restrict__ wn16, int c0, const Stores& stores) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+        ring.fetch_all(wn16);
+        part_mma16<D, NCT>(acc, A, buf, c0);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) { stores(ct, 1); stores(ct, 3); }
+    } else {
+        part_mma<D, NCT>(acc, A, buf, c0, [&](int ct, int j) { ring.fetch(wn32, ct, j); stores(ct, j); });
+    }
+}
+
+template <int D, int WPS, int NS, bool BF>
 __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArgs a, const SeqGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = D / 16, H = D / 16, NW = WPS * NS, NCT = NT / NS;
@@ -301,9 +390,14 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
         g = (int)blockIdx.x >= sg.B ? 1 : 0;
         b = (int)blockIdx.x - g * sg.B;
     }
-    SeqRingN<D, NW> ring(smem);
-    ring.first(a.L[0].w_in[g] + 1LL * D * D);
-    float* xb = smem + 2 * D * D + si * (NT * 64 * 4);      // this strip's exchange slots
+    // LDS: fp32 -- [ring 2 x D D floats][exchange]; the attention images alias the ring's idle slab.  bf16 -- [ring 2 x D D / 2][images
+    // 2 x 64 D floats][exchange]: a 32 KB slab cannot hold them
+    using Ring = typename std::conditional<BF, SeqRing16<D, NW>, SeqRingN<D, NW>>::type;
+    Ring ring(smem);
+    auto w16 = [&](int layer, int which) { return a.w16 + ((size_t)((layer * 2 + g) * 6 + which)) * D * D; };     // q, k, v, o, c1, c2
+    if constexpr (BF) ring.first(w16(0, 1)); else ring.first(a.L[0].w_in[g] + 1LL * D * D);
+    float* const img16 = smem + D * D;
+    float* xb = smem + (BF ? D * D + 2 * NIMG_KEYS * D : 2 * D * D) + si * (NT * 64 * 4);      // this strip's exchange slots
     const int t = si * 16 + m;
     const bool row_ok = t < sg.T;
     const int local = b * sg.T + min(t, sg.T - 1);
@@ -368,12 +462,8 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
         SEQN_STAMP(2);
         {   // k = x Wk^T + bk
             part_cols<NCT>(bias, P.b_in[g] + D, c0);
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            part_mma<D, NCT>(acc, F, bufk, c0, [&](int ct, int j) {
-                ring.fetch(P.w_in[g] + 2LL * D * D, ct, j);
-                part_spread<NCT>(gqn, off_own, Qno, ct, j, 1);
-            });
+            seqn_product<D, NCT, BF>(acc, F, bufk, ring, P.w_in[g] + 2LL * D * D, BF ? w16(l, 2) : nullptr, c0,
+                                     [&](int ct, int j) { part_spread<NCT>(gqn, off_own, Qno, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ko.v[c] = acc[c] + bias.v[c];
         }
@@ -382,9 +472,8 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
             const float* buf = ring.next();
             SEQN_STAMP(4);
             part_cols<NCT>(bias, P.b_in[g] + 2 * D, c0);
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            part_mma<D, NCT>(acc, F, buf, c0, [&](int ct, int j) { ring.fetch(P.w_in[g], ct, j); part_spread<NCT>(gk, off_own, Ko, ct, j, 1); });
+            seqn_product<D, NCT, BF>(acc, F, buf, ring, P.w_in[g], BF ? w16(l, 0) : nullptr, c0,
+                                     [&](int ct, int j) { part_spread<NCT>(gk, off_own, Ko, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Vo.v[c] = acc[c] + bias.v[c];
         }
@@ -393,11 +482,10 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
         {   // q = Qn Wq^T + bq
             float* buf = ring.next();
             SEQN_STAMP(6);
-            img = buf;
+            img = BF ? img16 : buf;
             part_cols<NCT>(bias, P.b_in[g], c0);
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            part_mma<D, NCT>(acc, Qn, buf, c0, [&](int ct, int j) { ring.fetch(P.w_o[g], ct, j); part_spread<NCT>(gv, off_own, Vo, ct, j, 1); });
+            seqn_product<D, NCT, BF>(acc, Qn, buf, ring, P.w_o[g], BF ? w16(l, 3) : nullptr, c0,
+                                     [&](int ct, int j) { part_spread<NCT>(gv, off_own, Vo, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Qo.v[c] = acc[c] + bias.v[c];
         }
@@ -451,9 +539,8 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
             const float* buf = ring.next();
             SEQN_STAMP(10);
             xchg_read<D>(F, xb);
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            part_mma<D, NCT>(acc, F, buf, c0, [&](int ct, int j) { ring.fetch(P.w1[g], ct, j); part_spread<NCT>(go, off_own, Oo, ct, j, 1); });
+            seqn_product<D, NCT, BF>(acc, F, buf, ring, P.w1[g], BF ? w16(l, 4) : nullptr, c0,
+                                     [&](int ct, int j) { part_spread<NCT>(go, off_own, Oo, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ro.v[c] = Qno.v[c] + (acc[c] + bias.v[c]);
         }
@@ -486,9 +573,8 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
             }
             SEQN_STAMP(13);
             part_cols<NCT>(bias, P.b1[g], c0);
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            part_mma<D, NCT>(acc, F, buf, c0, [&](int ct, int j) { ring.fetch(P.w2[g], ct, j); part_spread<NCT>(gr, off_own, Ro, ct, j, 1); });
+            seqn_product<D, NCT, BF>(acc, F, buf, ring, P.w2[g], BF ? w16(l, 5) : nullptr, c0,
+                                     [&](int ct, int j) { part_spread<NCT>(gr, off_own, Ro, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ho.v[c] = acc[c] + bias.v[c];
             if (a.train) part_dropout<NCT>(Ho, rr1, c0, a.spec, a.ffn_scale);
@@ -506,10 +592,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
             xchg_read<D>(F, xb);
             part_cols<NCT>(bias, P.b2[g], c0);
             const SeqLayer& Pn = a.L[last ? l : l + 1];          // (the last layer refetches its own Wk into the free buffer: harmless)
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            part_mma<D, NCT>(acc, F, buf, c0, [&](int ct, int j) {
-                ring.fetch(Pn.w_in[g] + 1LL * D * D, ct, j);
+            seqn_product<D, NCT, BF>(acc, F, buf, ring, Pn.w_in[g] + 1LL * D * D, BF ? w16(last ? l : l + 1, 1) : nullptr, c0, [&](int ct, int j) {
                 part_spread<NCT>(gy, off_own, Yo, ct, j, 1);
                 part_spread<NCT>(gh, off_own, Ho, ct, j, 3);
             });
@@ -542,18 +625,25 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
     w_ring_wait();                                          // the last (redundant) weight fetch targets this workgroup's LDS
 }
 
-template <int D, int WPS> static constexpr size_t seqn_lds_bytes() { return (size_t)(2 * D * D + WPS * (D / 16) * 64 * 4) * sizeof(float); }
+template <int D, int WPS, bool BF> static constexpr size_t seqn_lds_bytes() {
+    return (size_t)((BF ? D * D + 2 * NIMG_KEYS * D : 2 * D * D) + WPS * (D / 16) * 64 * 4) * sizeof(float);
+}
 
-template <int WPS, int NS>
-static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
-    constexpr size_t lds = seqn_lds_bytes<128, WPS>();
-    auto kern = seqn_fwd_kernel<128, WPS, NS>;
+template <int WPS, int NS, bool BF>
+static int seqn_launch_t(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
+    constexpr size_t lds = seqn_lds_bytes<128, WPS, BF>();
+    auto kern = seqn_fwd_kernel<128, WPS, NS, BF>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int grid = sg.live != nullptr ? sg.B : 2 * sg.B;
     kern<<<grid, 64 * WPS * NS, lds, (hipStream_t)stream>>>(a, sg);
     e = hipGetLastError();
     return e == hipSuccess ? AMID_OK : (int)e;
+}
+
+template <int WPS, int NS>
+static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
+    return a.w16 != nullptr ? seqn_launch_t<WPS, NS, true>(a, sg, stream) : seqn_launch_t<WPS, NS, false>(a, sg, stream);
 }
 
 // variant: 0 = the default split for the shape; 42 / 22 / 24 / 14 / 18 = WPS, NS spelled out (diagnostics and tests)

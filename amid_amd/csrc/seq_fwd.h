@@ -23,6 +23,9 @@ struct SeqFwdArgs {
     const unsigned char* tmq;
     float ln_eps, att_scale, dscale, ffn_scale;
     const StepState* st; int train; unsigned spec;
+    // bf16 matrix products (sasrec_seqn.hip only): the projection weights as bf16 fragment images [layer][domain][q, k, v, o, c1, c2]
+    // [D][D] written by amid_sas_weights_bf16 for THIS step's weights; nullptr = exact fp32 products
+    const unsigned short* w16;
 };
 
 struct SeqGeom {

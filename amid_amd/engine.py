@@ -151,7 +151,11 @@ class SasrecPlan:
         self.tpg = (M + self.rpt - 1) // self.rpt
         # the encoder's GEMM chains as register-resident strip kernels (csrc/sasrec_strip.hip): fp32, activations up to 2 GiB each;
         # one tile geometry (64-row tiles) for every sequence and for the live sequences of a train step alike
-        self.strip = bool(eng.STRIP_KERNELS and eng.compute == "f32" and 2 * M * D * 4 <= 0x7FFFFFF0)
+        # compute = "bf16": the strip path when the one-launch forward covers the shape -- its twelve projection products then run on the
+        # bf16 matrix cores (amid_sas_seq_fwd_bf16w_f32); other shapes keep the row-tile kernels' bf16 mode
+        self.strip = bool(eng.STRIP_KERNELS and 2 * M * D * 4 <= 0x7FFFFFF0 and
+                          (eng.compute == "f32" or (eng.BF16_STRIP and not getattr(eng, "inc_bs", 0)
+                                                    and L.value("amid_sas_seq_supported", B, shp.Tenc, D, H))))
         if self.strip:
             self.stpg = -(-M // L.value("amid_sas_strip_tile_rows"))
         self.live = torch.zeros(B + 1, dtype=torch.int32, device=dev)       # amid_live_list_i32: the step's live sequences
@@ -389,6 +393,7 @@ class SasrecEngine:
     EMB_DIMS = (64, 128)
     SHORT_TILE_BUILDS = True     # the row-tile kernels of this encoder also exist as *_rt3 / *_rt5 (48- / 80-row tiles, csrc/Makefile)
     STRIP_KERNELS = True         # fp32: the layer's GEMM chains run as register-resident strip kernels (csrc/sasrec_strip.hip)
+    BF16_STRIP = os.environ.get("AMID_BF16_STRIP", "1") != "0"      # compute = "bf16" on the strip path (the forward's products in bf16)
 
     def _dense_names(self) -> List[Tuple[str, Tuple[int, ...]]]:
         return sasrec_dense_names(self.Tpos, self.D, self.hid, self.itc_bs, self.dr, self.inc_bs)
@@ -840,8 +845,22 @@ class SasrecEngine:
                      fam("sac{d}.forward_layers.{l}.conv2.weight"), fam("sac{d}.forward_layers.{l}.conv2.bias"),
                      tl(pl.qn), tl(pl.q), tl(pl.k), tl(pl.v), tl(pl.o), tl(pl.stats), tl(pl.r), tl(pl.y), tl(pl.h))
                 self._ptr_cache[key] = c
-            L.call("amid_sas_seq_fwd_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:], pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr,
-                   SASREC_P_DROP, s)
+            if self.compute == "bf16":       # this step's weights as bf16 fragment images, then the forward with bf16 products
+                if not hasattr(self, "w16"):
+                    self.w16 = torch.empty(2, 2, 6, D * D, dtype=torch.bfloat16, device=self.device)
+                    srcs = []
+                    for l in (0, 1):
+                        for g in (1, 2):
+                            srcs += [fp.ptr(f"sac{g}.attention_layers.{l}.in_proj_weight", None, j * D * D) for j in range(3)]
+                            srcs += [fp.ptr(f"sac{g}.attention_layers.{l}.out_proj.weight"), fp.ptr(f"sac{g}.forward_layers.{l}.conv1.weight"),
+                                     fp.ptr(f"sac{g}.forward_layers.{l}.conv2.weight")]
+                    self._w16_src = ptr_array(srcs)
+                L.call("amid_sas_weights_bf16", self._w16_src, 24, D, 0, self.w16.data_ptr(), s)
+                L.call("amid_sas_seq_fwd_bf16w_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:], pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr,
+                       SASREC_P_DROP, self.w16.data_ptr(), s)
+            else:
+                L.call("amid_sas_seq_fwd_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:], pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr,
+                       SASREC_P_DROP, s)
         elif pl.strip:       # register-resident strip chains (csrc/sasrec_strip.hip): same operations, operands and saved tensors
             L.call("amid_sas_strip_qkv_fwd_f32", pl.x[0].data_ptr(), *qkv0, SASREC_LN_EPS, B, T, D, lf, pl.qn[0].data_ptr(), pl.q[0].data_ptr(),
                    pl.k[0].data_ptr(), pl.v[0].data_ptr(), s)

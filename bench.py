@@ -224,7 +224,7 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_qkv_ffn_bwd_f32": "sas_qkv_ffn_bwd_kernel", "amid_sas_oproj_ffn_qkv_fwd_f32": "sas_oproj_ffn_qkv_fwd_kernel",
     "amid_sas_oproj_ffn_fwd_f32": "sas_oproj_ffn_fwd_kernel",
     "amid_attn_fwd_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_f32": "embed_fwd_kernel",
-    "amid_sas_seq_fwd_f32": "seq_fwd_kernel", "amid_sas_seq_bwd_f32": "seq_bwd_kernel", "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
+    "amid_sas_seq_fwd_f32": ("seqn_fwd_kernel", "seq_fwd_kernel"), "amid_sas_seq_bwd_f32": "seq_bwd_kernel", "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
     "amid_sas_strip_oproj_ffn_fwd_f32#1": "strip_oproj_ffn_fwd_kernelILi128ELb0", "amid_sas_strip_ffn_bwd_f32": "strip_ffn_bwd_kernel",
     "amid_sas_strip_qkv_bwd_f32#0": "strip_qkv_bwd_kernelILi128ELb1", "amid_sas_strip_qkv_bwd_f32#1": "strip_qkv_bwd_kernelILi128ELb0",
     "amid_attn_fwd_live_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_live_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_live_f32": "embed_fwd_kernel", "amid_embed_fwd_live_compact_f32": "embed_fwd_kernel",
@@ -242,9 +242,10 @@ def pmc_traffic(entry: str, tag: str):
     if not files or sym is None:
         return None, None
     ks = json.load(open(files[-1]))["kernels"]
-    for name, v in ks.items():
-        if sym in name:
-            return v["hbm_bytes_per_launch"], os.path.basename(files[-1])
+    for one in (sym if isinstance(sym, tuple) else (sym,)):          # (several builds of one entry point: the first that was profiled)
+        for name, v in ks.items():
+            if one in name:
+                return v["hbm_bytes_per_launch"], os.path.basename(files[-1])
     return None, None
 
 

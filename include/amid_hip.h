@@ -594,6 +594,21 @@ int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, float* xout, co
  * D / NS columns), 42 / 22 / 24 / 14 / 18 = (strips per sequence, column parts) spelled out.  v < 0 only queries.  Returns the previous
  * value.  Process-wide host state, not a kernel launch. */
 int amid_sas_seq_fwd_variant(int v);
+/* The same forward with the twelve projections' matrix products on v_mfma_f32_16x16x32_bf16 (operands rounded to bf16, fp32 accumulation;
+ * LayerNorm, the attention core, residuals, dropout and everything stored stay fp32) -- BASELINE.json configs[2], arithmetic
+ * model_seq.py:371-383.  w16 = amid_sas_weights_bf16 images of THIS step's weights, [layer][domain][q, k, v, o, conv1, conv2][D][D] bf16.
+ * The fp32 weight arguments are still required (biases, and the fp32 builds' operands). */
+int amid_sas_seq_fwd_bf16w_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                               const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                               const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                               const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
+                               float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
+                               const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                               const void* step_state, int train, float p_drop, const void* w16, void* stream);
+/* bf16 fragment images of n (<= 48) square [D][D] fp32 matrices, row-major [out][in] (transposed != 0: of their transposes -- the
+ * backward data-gradient products): dst16 [n][D][D] bf16 with the in-features of a row permuted into the order the bf16 MFMA's lanes
+ * consume them (csrc/sasrec_seq.hip weights_bf16_kernel).  Once per step, before the forward. */
+int amid_sas_weights_bf16(const float* const* src, int n, int D, int transposed, void* dst16, void* stream);
 
 /* ---- the encoder's data gradients of the live sequences in ONE launch (csrc/sasrec_strip.hip: seq_bwd_kernel) -------------------------
  * replaces: autograd of Log2feats.forward model_seq.py:371-383 under loss.backward() (train_sr.py:214) -- per layer, top down,

@@ -42,7 +42,7 @@ def _setup(B, T, seed, live):
     return L, ptr_array, st, lv, row_live, P, x0, tmq
 
 
-def _run(L, pa, variant, B, T, st, lv, P, x0, tmq, train):
+def _run(L, pa, variant, B, T, st, lv, P, x0, tmq, train, bf16=False):
     M = B * T
     nan = lambda *s: torch.full(s, float("nan"), device="cuda")      # noqa: E731
     saved = {k: [nan(2 * M, D) for _ in range(2)] for k in "qn q k v o r y h".split()}
@@ -51,10 +51,19 @@ def _run(L, pa, variant, B, T, st, lv, P, x0, tmq, train):
     tl = lambda ts: pa([t.data_ptr() for t in ts])      # noqa: E731
     prev = L.value("amid_sas_seq_fwd_variant", variant)
     try:
-        L.call("amid_sas_seq_fwd_f32", 2, tl([x0, x1]), xout.data_ptr(), *[tl(P[k]) for k in
-               "ln1_w ln1_b w_in b_in w_o b_o ln2_w ln2_b w1 b1 w2 b2".split()], *[tl(saved[k]) for k in "qn q k v o stats r y h".split()],
-               tmq.data_ptr(), 1e-8, B, T, D, H, lv.data_ptr() if lv is not None else None, st.data_ptr(), train, 0.5,
-               torch.cuda.current_stream().cuda_stream)
+        args = (2, tl([x0, x1]), xout.data_ptr(), *[tl(P[k]) for k in "ln1_w ln1_b w_in b_in w_o b_o ln2_w ln2_b w1 b1 w2 b2".split()],
+                *[tl(saved[k]) for k in "qn q k v o stats r y h".split()], tmq.data_ptr(), 1e-8, B, T, D, H,
+                lv.data_ptr() if lv is not None else None, st.data_ptr(), train, 0.5)
+        s = torch.cuda.current_stream().cuda_stream
+        if bf16:        # the weights' bf16 fragment images, [layer][domain][q, k, v, o, c1, c2]
+            w16 = torch.empty(2, 2, 6, D * D, dtype=torch.bfloat16, device="cuda")
+            srcs = []
+            for i in range(4):
+                srcs += [P["w_in"][i].data_ptr() + 4 * j * D * D for j in range(3)] + [P["w_o"][i].data_ptr(), P["w1"][i].data_ptr(), P["w2"][i].data_ptr()]
+            L.call("amid_sas_weights_bf16", pa(srcs), 24, D, 0, w16.data_ptr(), s)
+            L.call("amid_sas_seq_fwd_bf16w_f32", *args, w16.data_ptr(), s)
+        else:
+            L.call("amid_sas_seq_fwd_f32", *args, s)
         torch.cuda.synchronize()
     finally:
         L.value("amid_sas_seq_fwd_variant", prev)
@@ -90,3 +99,48 @@ def test_variant_switch_round_trips_and_refuses_a_split_that_does_not_cover_t():
     ref = _run(L, pa, 1, 4, 50, st, lv, P, x0, tmq, 0)
     assert torch.equal(out["xout"], ref["xout"])
     assert AmidError is not None
+
+
+def test_weight_images_hold_the_rounded_weights_in_fragment_order():
+    """amid_sas_weights_bf16: chunk 4 s + g of row n = bf16(W[n][32 s + 4 g + 0..3]), bf16(W[n][32 s + 16 + 4 g + 0..3]); transposed: of W^T."""
+    from amid_amd._lib import lib, ptr_array
+    L = lib()
+    g = torch.Generator().manual_seed(5)
+    W = [torch.randn(D, D, generator=g).cuda() for _ in range(3)]
+    k = torch.arange(D)
+    s_, h_, g_, r_ = k >> 5, (k >> 4) & 1, (k >> 2) & 3, k & 3
+    pos = (4 * s_ + g_) * 8 + 4 * h_ + r_                    # where in-feature k of a row sits in the image
+    for tr in (0, 1):
+        out = torch.zeros(3, D, D, dtype=torch.bfloat16, device="cuda")
+        L.call("amid_sas_weights_bf16", ptr_array([w.data_ptr() for w in W]), 3, D, tr, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(3):
+            want = torch.empty(D, D, dtype=torch.bfloat16)
+            src = (W[i].t() if tr else W[i]).cpu()
+            want[:, pos] = src.to(torch.bfloat16)                # round to nearest even, as v_cvt_pk_bf16_f32
+            assert torch.equal(out[i].cpu().view(torch.int16), want.view(torch.int16)), (tr, i)
+
+
+@pytest.mark.parametrize("B,T,variants", [CASES[0], CASES[3], CASES[6]])
+@pytest.mark.parametrize("live", [None, "mixed"])
+@pytest.mark.parametrize("train", [0, 1])
+def test_bf16_products_stay_within_bf16_rounding_of_the_fp32_forward(B, T, variants, live, train):
+    """amid_sas_seq_fwd_bf16w_f32 (BASELINE.json configs[2]: the projections' operands rounded to bf16, fp32 accumulation and everything
+    else) against the fp32 forward on the same inputs: every saved tensor within 2e-2 of its largest magnitude (the bar SURVEY.md
+    section 8(c) sets for bf16 against the fp32 reference), and visibly different (the mode is on).  The relu / dropout decisions are
+    the fp32 run's except where a pre-activation sits within rounding of zero, hence the L2 view for h and behind."""
+    L, pa, st, lv, row_live, P, x0, tmq = _setup(B, T, seed=B * 17 + T, live=live)
+    ref = _run(L, pa, 1, B, T, st, lv, P, x0, tmq, train)
+    rl = row_live.cuda()
+    for v in variants:
+        got = _run(L, pa, v, B, T, st, lv, P, x0, tmq, train, bf16=True)
+        worst = 0.0
+        for name, want in ref.items():
+            a, b = got[name][rl].double(), want[rl].double()
+            assert torch.isfinite(a).all(), (v, name)
+            e = float((a - b).norm() / (b.norm() + 1e-30))
+            worst = max(worst, e)
+            assert e < 2e-2, (v, name, e)
+            if bool((~rl).any()):
+                assert torch.isnan(got[name][~rl]).all(), f"variant {v} {name}: rows outside the live list were written"
+        assert worst > 1e-4, "bf16 products left no trace: the fp32 kernel ran"
