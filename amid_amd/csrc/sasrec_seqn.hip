@@ -353,18 +353,40 @@ __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)
 
 // one product of the chain on the own column tiles: fp32 -- strip MFMA loop with the next slab's DMA pieces and the deferred stores
 // (`stores(ct, j)`) in its groups; bf16 -- the next slab requested up front, 16 MFMAs, the deferred stores behind them
-template <int D, int NCT, bool BF, class Ring, class Stores>
+struct NoLate { __device__ __forceinline__ void operator()() const {} };
+// `late()` runs half way through the loop: loads the epilogue needs (LayerNorm gains: 64 registers) are requested there --
+// early enough to land under the remaining MFMAs, late enough not to be carried through the whole loop (vector-memory instructions do
+// not cross the loop's scheduling fences)
+template <int D, int NCT, bool BF, class Ring, class Stores, class Late = NoLate>
 __device__ __forceinline__ void seqn_product(f32x4 (&acc)[NCT], const StripRegs<D>& A, const float* __restrict__ buf, const Ring& ring,
-                                             const float* __restrict__ wn32, const unsigned short* __restrict__ wn16, int c0, const Stores& stores) {
+                                             const float* __restrict__ wn32, const unsigned short* __restrict__ wn16, int c0, const Stores& stores,
+                                             const Late& late = NoLate()) {
 #pragma unroll
     for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (BF) {
         ring.fetch_all(wn16);
+        late();
         part_mma16<D, NCT>(acc, A, buf, c0);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) { stores(ct, 1); stores(ct, 3); }
     } else {
-        part_mma<D, NCT>(acc, A, buf, c0, [&](int ct, int j) { ring.fetch(wn32, ct, j); stores(ct, j); });
+        part_mma<D, NCT>(acc, A, buf, c0, [&](int ct, int j) {
+            ring.fetch(wn32, ct, j);
+            stores(ct, j);
+            if (ct == D / 16 / 2 && j == 0) late();
+        });
+    }
+}
+
+// the own column tiles of a per-column vector held whole: two parts -- selects on the wave-uniform part index; more parts -- loaded
+// (select chains over four or eight candidates end up as scratch arrays)
+template <int D, int NCT>
+__device__ __forceinline__ void own_cols(PartRegs<NCT>& o, const ColVec<D>& full, const float* __restrict__ p, int part, int c0) {
+    if constexpr ((D / 16) / NCT == 2) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) o.v[c] = part ? full.v[NCT + c] : full.v[c];
+    } else {
+        part_cols<NCT>(o, p, c0);
     }
 }
 
@@ -424,6 +446,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
 #pragma unroll
         for (int c = 0; c < NCT; ++c) tmw[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(gtm.r, (int)(tbase + 4 * c), 0, 0);
     }
+    lw.load(a.L[0].ln1_w[g]); lb.load(a.L[0].ln1_b[g]);
     f32x4 acc[NCT];
     SEQN_STAMP0(62);
 #pragma unroll 1
@@ -444,8 +467,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
             }
         }
         {   // Qn = LN1(x): whole row for the q product, own columns for the residual and the saved copy
-            // (the gains are requested HERE, not ahead of the previous product: 64 registers across an MFMA loop do not fit two waves per SIMD)
-            lw.load(P.ln1_w[g]); lb.load(P.ln1_b[g]);
+            // (the gains were requested late in the previous product -- the prologue for layer 0)
             float mean, rstd;
             strip_stats<D>(F, a.ln_eps, mean, rstd);
 #pragma unroll
@@ -453,7 +475,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Qn.v[ct][r] = (F.v[ct][r] - mean) * rstd * lw.v[ct][r] + lb.v[ct][r];
             PartRegs<NCT> lwo, lbo;
-            part_cols<NCT>(lwo, P.ln1_w[g], c0); part_cols<NCT>(lbo, P.ln1_b[g], c0);
+            own_cols<D, NCT>(lwo, lw, P.ln1_w[g], part, c0); own_cols<D, NCT>(lbo, lb, P.ln1_b[g], part, c0);
 #pragma unroll
             for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -540,7 +562,8 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
             SEQN_STAMP(10);
             xchg_read<D>(F, xb);
             seqn_product<D, NCT, BF>(acc, F, buf, ring, P.w1[g], BF ? w16(l, 4) : nullptr, c0,
-                                     [&](int ct, int j) { part_spread<NCT>(go, off_own, Oo, ct, j, 1); });
+                                     [&](int ct, int j) { part_spread<NCT>(go, off_own, Oo, ct, j, 1); },
+                                     [&]() { lw.load(P.ln2_w[g]); lb.load(P.ln2_b[g]); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ro.v[c] = Qno.v[c] + (acc[c] + bias.v[c]);
         }
@@ -557,7 +580,6 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
             SEQN_STAMP(12);
             xchg_read<D>(F, xb);                           // the whole row of r
             {
-                lw.load(P.ln2_w[g]); lb.load(P.ln2_b[g]);
                 float mean, rstd;
                 strip_stats<D>(F, a.ln_eps, mean, rstd);
 #pragma unroll
@@ -565,7 +587,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
 #pragma unroll
                     for (int r = 0; r < 4; ++r) F.v[ct][r] = (F.v[ct][r] - mean) * rstd * lw.v[ct][r] + lb.v[ct][r];
                 PartRegs<NCT> lwo, lbo;
-                part_cols<NCT>(lwo, P.ln2_w[g], c0); part_cols<NCT>(lbo, P.ln2_b[g], c0);
+                own_cols<D, NCT>(lwo, lw, P.ln2_w[g], part, c0); own_cols<D, NCT>(lbo, lb, P.ln2_b[g], part, c0);
 #pragma unroll
                 for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -595,7 +617,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
             seqn_product<D, NCT, BF>(acc, F, buf, ring, Pn.w_in[g] + 1LL * D * D, BF ? w16(last ? l : l + 1, 1) : nullptr, c0, [&](int ct, int j) {
                 part_spread<NCT>(gy, off_own, Yo, ct, j, 1);
                 part_spread<NCT>(gh, off_own, Ho, ct, j, 3);
-            });
+            }, [&]() { if (!last) { lw.load(Pn.ln1_w[g]); lb.load(Pn.ln1_b[g]); } });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Xo.v[c] = acc[c] + bias.v[c];
             if (a.train) part_dropout<NCT>(Xo, rr2, c0, a.spec, a.ffn_scale);

@@ -18,7 +18,7 @@ from oracle import amid_oracle as orc  # noqa: E402
 
 B, T, D, hid, n_items = int(os.environ.get("STAMP_B", "256")), int(os.environ.get("STAMP_T", "50")), 128, 32, 3000
 P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=1)
-eng = SasrecEngine(n_items, D, T, hid, seed=3)
+eng = SasrecEngine(n_items, D, T, hid, seed=3, compute=os.environ.get("STAMP_DTYPE", "f32"))
 eng.load_state_dict(P)
 pl = eng.plan(B, T, 2, need_grad=True)
 batch = orc.synthetic_batch(B, T, n_items - 1, pad_id=n_items - 1, neg=1, seed=2)
