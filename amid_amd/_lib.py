@@ -15,7 +15,7 @@ import re
 from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libamid_hip.so")
+LIB_PATH = os.environ.get("AMID_LIB_PATH") or os.path.join(_HERE, "libamid_hip.so")      # (AMID_LIB_PATH: diagnostic builds)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "amid_hip.h")
 
 

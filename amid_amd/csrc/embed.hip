@@ -232,7 +232,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
             for (int c = sub; c < q; c += 32) {
                 float4 v[RIF];
 #pragma unroll
-                for (int u = 0; u < RIF; ++u) v[u] = ld4(table + src[u] * D + 4 * c);
+                for (int u = 0; u < RIF; ++u) {
+                    // non-temporal: a table row is read once per step and the table is far larger than the caches -- inside the cfg 5 step,
+                    // behind the catch-up's footprint, 59.1 -> 55.2 us (profiles/tools/probe/k1_instep.py)
+                    const f32x4 t = __builtin_nontemporal_load((const f32x4*)(table + src[u] * D + 4 * c));
+                    v[u] = make_float4(t[0], t[1], t[2], t[3]);
+                }
 #pragma unroll
                 for (int u = 0; u < RIF; ++u) {
                     const int r = row[u];
@@ -402,7 +407,7 @@ static inline int embed_chunk(long long n_rows_to_move) {
 static inline int embed_grid(long long n_rows_to_move, int chunk) {
     long long blocks = ((n_rows_to_move + chunk - 1) / chunk + 7) / 8;
     if (blocks < 1) blocks = 1;
-    if (blocks > 16384) blocks = 16384;
+    if (blocks > 16384) blocks = 16384;      // (caps of 1024 / 2048 / 4096 blocks with chunks of 4 or 8 measured the same: profiles/tools/probe/k1_ab.py)
     return (int)blocks;
 }
 
