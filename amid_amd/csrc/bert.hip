@@ -19,16 +19,7 @@ constexpr int BD = 128;      // hidden
 constexpr int BF = 512;      // feed-forward
 constexpr float BERT_EPS = 1e-6f;
 
-struct BGeom {
-    int M; int rows_per_tile; int tiles_per_group;
-    // optional hint of the backward kernels (the *_rows entry points): live = the batch's live-sequence list (amid_live_list_i32:
-    // domain 0's batch rows, then domain 1's, then n0).  Of domain g only its live sequences carry a gradient (the step's own loss
-    // masks the other domain of every sample, train_sr.py:205-211): tiles then hold rows_per_tile / T WHOLE live sequences, back
-    // to back, wherever they sit in the batch -- half the tiles, and these kernels are bound by the weights every tile streams.
-    // The launch keeps 2 * tiles_per_group workgroups (tiles_per_group = the worst case, every sample in one domain): the first
-    // tiles0 + tiles1 are live, the rest only zero the LayerNorm-partial slot they would have filled.
-    const int* live; int B, T;
-};
+struct BGeom { int M; int rows_per_tile; int tiles_per_group; };
 __device__ __forceinline__ void btile(const BGeom& tg, int tile, int& g, long long& row0, int& nrows, int& local0) {
     g = tile / tg.tiles_per_group;
     const int tl = tile - g * tg.tiles_per_group;
@@ -37,47 +28,20 @@ __device__ __forceinline__ void btile(const BGeom& tg, int tile, int& g, long lo
     row0 = (long long)g * tg.M + local0;
 }
 
-// the backward kernels' view of a tile: row r of the tile <-> row lrow(r) of domain g (dropout counters) / grow(r) of the buffers
+// the backward kernels' view of a tile.  (A variant that gathered tiles of LIVE sequences only -- half the tiles -- was built and measured:
+// no gain, each launch is one round of workgroups either way and lasts as long as one tile's chain of weight slabs; removed.)
 struct BTile {
     int g, nrows, slot, local0;
     long long base;                    // g * M
-    const int* rmap;                   // live list: LDS table tile row -> row of the domain; nullptr: local0 + r
-    bool is_live;
-    __device__ __forceinline__ int lrow(int r) const { return rmap ? rmap[r] : local0 + r; }
+    __device__ __forceinline__ int lrow(int r) const { return local0 + r; }
     __device__ __forceinline__ long long grow(int r) const { return base + lrow(r); }
 };
-__device__ __forceinline__ BTile btile_bwd(const BGeom& tg, int tile, int* __restrict__ rmap) {
+__device__ __forceinline__ BTile btile_bwd(const BGeom& tg, int tile) {
     BTile t;
-    t.rmap = nullptr; t.is_live = true;
-    if (tg.live == nullptr) {
-        long long row0;
-        btile(tg, tile, t.g, row0, t.nrows, t.local0);
-        t.base = (long long)t.g * tg.M;
-        t.slot = tile;
-        return t;
-    }
-    const int B = tg.B, T = tg.T, k = tg.rows_per_tile / T, tpg = tg.tiles_per_group;
-    const int n0 = tg.live[B];
-    const int tiles0 = (n0 + k - 1) / k, tiles1 = (B - n0 + k - 1) / k;
-    int g, tl;
-    if (tile < tiles0) { g = 0; tl = tile; }
-    else if (tile < tiles0 + tiles1) { g = 1; tl = tile - tiles0; }
-    else {                                                           // a slot no live tile fills
-        t.is_live = false;
-        const int d = tile - tiles0 - tiles1;
-        if (d < tpg - tiles0) { g = 0; tl = tiles0 + d; } else { g = 1; tl = tiles1 + d - (tpg - tiles0); }
-    }
-    t.g = g; t.slot = g * tpg + tl; t.base = (long long)g * tg.M; t.local0 = 0; t.nrows = 0;
-    if (!t.is_live) return t;
-    const int ng = g == 0 ? n0 : B - n0, s0 = g == 0 ? 0 : n0;
-    const int nseq = min(k, ng - tl * k);
-    t.nrows = nseq * T;
-    for (int r = threadIdx.x; r < t.nrows; r += blockDim.x) {
-        const int sq = r / T;
-        rmap[r] = tg.live[s0 + tl * k + sq] * T + (r - sq * T);
-    }
-    __syncthreads();
-    t.rmap = rmap;
+    long long row0;
+    btile(tg, tile, t.g, row0, t.nrows, t.local0);
+    t.base = (long long)t.g * tg.M;
+    t.slot = tile;
     return t;
 }
 
@@ -331,12 +295,10 @@ struct BFfn2BwdArgs {
 };
 __global__ __launch_bounds__(GEMM_THREADS) void bert_ffn2_bwd_kernel(const BFfn2BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ int rmap_s[TILE_ROWS];
     using RP = RowPass<BD>;
     float* As = smem;
     float* Ws = smem + TileCfg<BD>::A_FLOATS;
-    const BTile tr = btile_bwd(a.tg, blockIdx.x, rmap_s);
-    if (!tr.is_live) return;                                // dz / dpre of dead sequences are read by nobody (the consumers take the same hint)
+    const BTile tr = btile_bwd(a.tg, blockIdx.x);
     const int g = tr.g, nrows = tr.nrows;
     auto rowf = [&](int r) { return tr.grow(r); };
     const int sub = RP::sub();
@@ -393,12 +355,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_ffn1_bwd_kernel(const BFfn1
     float* As = smem;
     float* Ws = smem + TileCfg<BD>::A_FLOATS;
     float* Cs = Ws;
-    __shared__ int rmap_s[TILE_ROWS];
-    const BTile tr = btile_bwd(a.tg, blockIdx.x, rmap_s);
-    if (!tr.is_live) {                                      // only the LayerNorm-partial slot it would have filled is read (fixed-order reduce)
-        for (int i = threadIdx.x; i < 2 * BD; i += GEMM_THREADS) a.ln_part[(long long)tr.slot * 2 * BD + i] = 0.f;
-        return;
-    }
+    const BTile tr = btile_bwd(a.tg, blockIdx.x);
     const int g = tr.g, nrows = tr.nrows;
     auto rowf = [&](int r) { return tr.grow(r); };
     const int sub = RP::sub();
@@ -468,21 +425,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_qkv_bwd_kernel(const BQkvBw
     float* As = smem;
     float* Ws = smem + TileCfg<BD>::A_FLOATS;
     float* Cs = Ws;
-    __shared__ int rmap_s[TILE_ROWS];
-    const BTile tr = btile_bwd(a.tg, blockIdx.x, rmap_s);
-    if (!tr.is_live) {
-        for (int i = threadIdx.x; i < 2 * BD; i += GEMM_THREADS) a.ln_part[(long long)tr.slot * 2 * BD + i] = 0.f;
-        return;
-    }
+    const BTile tr = btile_bwd(a.tg, blockIdx.x);
     const int g = tr.g, nrows = tr.nrows;
     auto rowf = [&](int r) { return tr.grow(r); };
-    if (tr.rmap != nullptr) {
-        // dx feeds the embedding gradient of EVERY position (layer 0): sample b is live in domain g and dead in the other one --
-        // this tile writes the exact zeros of its sequences' counterparts (same local rows, the other domain's half)
-        const long long other = (long long)(1 - g) * a.tg.M;
-        for (int i = threadIdx.x; i < nrows * (BD / 4); i += GEMM_THREADS)
-            st4(a.dx + (other + tr.lrow(i / (BD / 4))) * BD + 4 * (i % (BD / 4)), make_float4(0.f, 0.f, 0.f, 0.f));
-    }
     const int sub = RP::sub();
     const float* src[3] = {a.dq, a.dk, a.dv};
     TileRegs<BD> ar, xr, rr;
@@ -677,15 +622,9 @@ __global__ __launch_bounds__(256) void transpose_rect_kernel(const BTransArgs a)
 using namespace amid;
 
 static constexpr size_t bert_lds() { return (size_t)(TileCfg<BD>::A_FLOATS + TileCfg<BD>::W_FLOATS) * sizeof(float); }
-static int bgeom(int M, int rpt, BGeom* tg, const int* live = nullptr, int B = 0, int T = 0) {
+static int bgeom(int M, int rpt, BGeom* tg) {
     if (M <= 0 || rpt <= 0 || rpt > TILE_ROWS) return AMID_ERR_ARG;
     tg->M = M; tg->rows_per_tile = rpt; tg->tiles_per_group = (M + rpt - 1) / rpt;
-    tg->live = nullptr; tg->B = 0; tg->T = 0;
-    if (live) {                                // whole live sequences per tile; worst case: every sample in one domain
-        if (B <= 0 || T <= 0 || (long long)B * T != M || rpt % T != 0) return AMID_ERR_ARG;
-        tg->live = live; tg->B = B; tg->T = T;
-        tg->tiles_per_group = (B + rpt / T - 1) / (rpt / T);
-    }
     return AMID_OK;
 }
 static DropCfg bdropcfg(const void* st, int train, float p, int layer) {
@@ -755,76 +694,39 @@ extern "C" int AMID_ENTRY(amid_bert_ffn2_fwd_f32)(const float* h, const float* x
     return AMID_OK;
 }
 
-static int bert_ffn2_bwd(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                         const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live, int B, int T,
-                         void* stream) {
+extern "C" int AMID_ENTRY(amid_bert_ffn2_bwd_f32)(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
+                                      const void* step_state, int train, float p_drop, float* dz, float* dpre, void* stream) {
     AMID_CHECK_ARG(dx2 && pre && w2T && dz && dpre && (!train || step_state));
     BFfn2BwdArgs a;
     a.dx2 = dx2; a.pre = pre; a.dz = dz; a.dpre = dpre; a.dc = bdropcfg(step_state, train, p_drop, layer);
     for (int g = 0; g < 2; ++g) a.w2T[g] = w2T[g];
-    if (int e = bgeom(M, rows_per_tile, &a.tg, live, B, T)) return e;
+    if (int e = bgeom(M, rows_per_tile, &a.tg)) return e;
     BERT_LAUNCH(bert_ffn2_bwd_kernel, a);
     return AMID_OK;
 }
-extern "C" int AMID_ENTRY(amid_bert_ffn2_bwd_f32)(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                      const void* step_state, int train, float p_drop, float* dz, float* dpre, void* stream) {
-    return bert_ffn2_bwd(dx2, pre, w2T, M, rows_per_tile, layer, step_state, train, p_drop, dz, dpre, nullptr, 0, 0, stream);
-}
-// the three backward kernels over the live sequences only: live = amid_live_list_i32's list of the batch, M = B * T, rows_per_tile a
-// multiple of T (a tile holds rows_per_tile / T whole live sequences, gathered from wherever they sit; see BGeom)
-extern "C" int AMID_ENTRY(amid_bert_ffn2_bwd_rows_f32)(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                      const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live,
-                                      int B, int T, void* stream) {
-    AMID_CHECK_ARG(live != nullptr);
-    return bert_ffn2_bwd(dx2, pre, w2T, M, rows_per_tile, layer, step_state, train, p_drop, dz, dpre, live, B, T, stream);
-}
 
-static int bert_ffn1_bwd(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
-                         const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                         float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const int* live, int B, int T,
-                         void* stream) {
+extern "C" int AMID_ENTRY(amid_bert_ffn1_bwd_f32)(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
+                                      const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
+                                      float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, void* stream) {
     AMID_CHECK_ARG(dpre && dx2 && x1 && ln_a && w1T && woT && dx1 && dt && d_o && ln_part && (!train || step_state));
     BFfn1BwdArgs a;
     a.dpre = dpre; a.dx2 = dx2; a.x1 = x1; a.dx1 = dx1; a.dt = dt; a.d_o = d_o; a.ln_part = ln_part;
     a.dc = bdropcfg(step_state, train, p_drop, layer);
     for (int g = 0; g < 2; ++g) { a.la[g] = ln_a[g]; a.w1T[g] = w1T[g]; a.woT[g] = woT[g]; }
-    if (int e = bgeom(M, rows_per_tile, &a.tg, live, B, T)) return e;
+    if (int e = bgeom(M, rows_per_tile, &a.tg)) return e;
     BERT_LAUNCH(bert_ffn1_bwd_kernel, a);
     return AMID_OK;
 }
-extern "C" int AMID_ENTRY(amid_bert_ffn1_bwd_f32)(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
-                                      const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                                      float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, void* stream) {
-    return bert_ffn1_bwd(dpre, dx2, x1, ln_a, w1T, woT, M, rows_per_tile, layer, step_state, train, p_drop, dx1, dt, d_o, ln_part, nullptr, 0, 0, stream);
-}
-extern "C" int AMID_ENTRY(amid_bert_ffn1_bwd_rows_f32)(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a,
-                                      const float* const* w1T, const float* const* woT, int M, int rows_per_tile, int layer,
-                                      const void* step_state, int train, float p_drop, float* dx1, float* dt, float* d_o, float* ln_part,
-                                      const int* live, int B, int T, void* stream) {
-    AMID_CHECK_ARG(live != nullptr);
-    return bert_ffn1_bwd(dpre, dx2, x1, ln_a, w1T, woT, M, rows_per_tile, layer, step_state, train, p_drop, dx1, dt, d_o, ln_part, live, B, T, stream);
-}
 
-static int bert_qkv_bwd(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                        const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const int* live, int B,
-                        int T, void* stream) {
+extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
+                                     const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream) {
     AMID_CHECK_ARG(dq && dk && dv && dx1 && x && ln_a && wT3x2 && dx && ln_part);
     BQkvBwdArgs a;
     a.dq = dq; a.dk = dk; a.dv = dv; a.dx1 = dx1; a.x = x; a.dx = dx; a.ln_part = ln_part;
     for (int g = 0; g < 2; ++g) { a.la[g] = ln_a[g]; for (int j = 0; j < 3; ++j) a.wT[j][g] = wT3x2[j * 2 + g]; }
-    if (int e = bgeom(M, rows_per_tile, &a.tg, live, B, T)) return e;
+    if (int e = bgeom(M, rows_per_tile, &a.tg)) return e;
     BERT_LAUNCH(bert_qkv_bwd_kernel, a);
     return AMID_OK;
-}
-extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_f32)(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                                     const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream) {
-    return bert_qkv_bwd(dq, dk, dv, dx1, x, ln_a, wT3x2, M, rows_per_tile, dx, ln_part, nullptr, 0, 0, stream);
-}
-extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_rows_f32)(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x,
-                                     const float* const* ln_a, const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part,
-                                     const int* live, int B, int T, void* stream) {
-    AMID_CHECK_ARG(live != nullptr);
-    return bert_qkv_bwd(dq, dk, dv, dx1, x, ln_a, wT3x2, M, rows_per_tile, dx, ln_part, live, B, T, stream);
 }
 
 // n_ent (<= 12) output tiles of 128 x 128; dy / x: host arrays of n_ent device pointers (column offsets folded in), ld*: row strides.

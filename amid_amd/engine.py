@@ -391,7 +391,7 @@ class SasrecEngine:
     HEADS = SASREC_HEADS
     PLAN_CLS = SasrecPlan
     EMB_DIMS = (64, 128)
-    SHORT_TILE_BUILDS = True     # the row-tile kernels of this encoder also exist as *_rt3 / *_rt5 (48- / 80-row tiles, csrc/Makefile)
+    SHORT_TILE_BUILDS = False    # (BERT4Rec's row-tile kernels also exist as *_rt3 / *_rt4 / *_rt5: 48- / 64- / 80-row tiles, csrc/Makefile)
     STRIP_KERNELS = True         # fp32: the layer's GEMM chains run as register-resident strip kernels (csrc/sasrec_strip.hip)
     BF16_STRIP = os.environ.get("AMID_BF16_STRIP", "1") != "0"      # compute = "bf16" on the strip path (the forward's products in bf16)
 

@@ -70,19 +70,8 @@ class BertPlan(SasrecPlan):
 
     def _alloc_model_bwd(self, eng, f) -> None:
         M, D, F = self.shape.M, eng.D, BERT_FF
-        # In a train step the three backward row-tile kernels walk the LIVE sequences only (bert.hip BGeom::live: the loss sends no
-        # gradient into the other domain's encoder of a sample): a tile gathers rows_per_tile / T whole live sequences of one domain.
-        # These kernels are bound by the 256 KB of weights every tile streams, so the fullest tile wins: the 112-row build with
-        # 112 // T sequences (T = 50: 2, T = 20: 5) -- half as many tiles as over all rows.
-        T = self.shape.Tenc
-        k = 112 // T
-        self.live_tiles = bool(eng.LIVE_TILES_BWD and k >= 1)
-        if self.live_tiles:
-            self.rpt_b, self.rt_suffix_b = k * T, ""
-            self.tpg_b = (self.shape.B + k - 1) // k               # worst case: every sample in one domain
-        else:
-            self.rpt_b, self.rt_suffix_b = self.rpt, self.rt_suffix
-            self.tpg_b = (M + self.rpt_b - 1) // self.rpt_b
+        self.rpt_b, self.rt_suffix_b = self.rpt, self.rt_suffix
+        self.tpg_b = (M + self.rpt_b - 1) // self.rpt_b
         self.ln1_part = [f(2 * self.tpg_b, 2, D) for _ in range(2)]       # one slot per backward tile
         self.ln2_part = [f(2 * self.tpg_b, 2, D) for _ in range(2)]
         self.dz, self.dt, self.dx1 = f(2 * M, D), f(2 * M, D), f(2 * M, D)
@@ -126,13 +115,6 @@ class Bert4recEngine(SasrecEngine):
     SHORT_TILE_BUILDS = True
     STRIP_KERNELS = False        # its encoder launches are bert.hip's row-tile kernels
     SORT_FORK = "catchup"        # the side-stream sort runs beside the forward (no launch of this encoder fills every CU)
-    # The train step's backward row-tile kernels can walk tiles of LIVE sequences only (BertPlan._alloc_model_bwd, bert.hip
-    # BGeom::live: half the tiles).  Off: measured at cfg 2, 128 gathered 100-row tiles take as long as the 256 tiles over every
-    # row (ffn2_bwd 67.8 vs 71.5 us, ffn1_bwd 57.6 vs 60.9, qkv_bwd 40.3 vs 41.4) -- either way the launch is ONE round of
-    # workgroups and lasts as long as a single tile's chain of weight slabs (global -> registers -> LDS -> barrier per 128 x 128
-    # slab); at cfg 4 the 100-row tiles lose to the 48-row build's shorter chains (0.74 vs 0.60 ms per step).  What would speed
-    # these kernels up is the strip kernels' LDS-DMA weight ring (csrc/strip_gemm.h), not fewer rows.
-    LIVE_TILES_BWD = False
 
     def __init__(self, *args, comp: str = "", comp_bs: int = 0, comp_threshold: float = 0.5, **kw):
         """comp = "inc" / "itc": BERT4Rec(isInC=True) / (isItC=True) with bs = comp_bs and threshold1 / threshold2 = comp_threshold:
@@ -256,21 +238,15 @@ class Bert4recEngine(SasrecEngine):
                fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(),
                pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, T, NI, D, self.hid, 0.0, pl.dxbuf.data_ptr(), ditems, None,
                pl.sc_part.data_ptr(), None, None, 0, s)
-        # the train step's own backward: tiles of live sequences (BertPlan._alloc_model_bwd); a backward driven by someone else's
-        # loss (the autograd path) walks every row, in tiles of the same height
-        live_tiles = pl.live_tiles and self._own_rows(pl) is not None
-        if live_tiles:
-            L.call("amid_live_list_i32", pl.domain.data_ptr(), B, pl.live.data_ptr(), s)
         for l in (1, 0):
             pre = f"transform{{d}}.{l}"
             wsq = lambda j: ptr_array([self.wT_sq[l, g, j].data_ptr() for g in (0, 1)])      # noqa: E731
-            rows, hint = ("_rows", (pl.live.data_ptr(), B, T)) if live_tiles else ("", ())
-            L.call("amid_bert_ffn2_bwd" + rows + "_f32" + pl.rt_suffix_b, pl.dxbuf.data_ptr(), pl.pre[l].data_ptr(),
+            L.call("amid_bert_ffn2_bwd_f32" + pl.rt_suffix_b, pl.dxbuf.data_ptr(), pl.pre[l].data_ptr(),
                    ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]), M, pl.rpt_b, l, st, tr, BERT_P_DROP, pl.dz.data_ptr(), pl.dpre.data_ptr(),
-                   *hint, s)
-            L.call("amid_bert_ffn1_bwd" + rows + "_f32" + pl.rt_suffix_b, pl.dpre.data_ptr(), pl.dxbuf.data_ptr(), pl.x1[l].data_ptr(),
+                   s)
+            L.call("amid_bert_ffn1_bwd_f32" + pl.rt_suffix_b, pl.dpre.data_ptr(), pl.dxbuf.data_ptr(), pl.x1[l].data_ptr(),
                    self._pp(pre + ".output_sublayer.norm.a_2"), ptr_array([self.w1T[l, g].data_ptr() for g in (0, 1)]), wsq(3), M, pl.rpt_b, l, st, tr,
-                   BERT_P_DROP, pl.dx1.data_ptr(), pl.dt.data_ptr(), pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), *hint, s)
+                   BERT_P_DROP, pl.dx1.data_ptr(), pl.dt.data_ptr(), pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), s)
             L.call("amid_attn_bwd_rows_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(), pl.stats[l].data_ptr(),
                    pl.d_o.data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l, st, tr, BERT_P_DROP, pl.dq.data_ptr(), pl.dk.data_ptr(),
                    pl.dv.data_ptr(), self._own_rows(pl), s)
@@ -288,9 +264,9 @@ class Bert4recEngine(SasrecEngine):
             L.call("amid_bert_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), (ctypes.c_int * N_ENT)(*ldy), (ctypes.c_int * N_ENT)(*ldx),
                    (ctypes.c_int * N_ENT)(*old), (ctypes.c_int * N_ENT)(*ogr), (ctypes.c_int * N_ENT)(*oco), N_ENT, M,
                    pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), self._own_rows(pl), B, T, s)
-            L.call("amid_bert_qkv_bwd" + rows + "_f32" + pl.rt_suffix_b, pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(),
+            L.call("amid_bert_qkv_bwd_f32" + pl.rt_suffix_b, pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(),
                    pl.x[l].data_ptr(), self._pp(pre + ".input_sublayer.norm.a_2"), wT3, M, pl.rpt_b, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(),
-                   *hint, s)
+                   s)
         if self.comp:      # the comp modules' parameter gradients; the rows' own halves + their share of the token group -> dxg
             c, G = self.comp, self.dense.grad
             L.call("amid_bert_comp_bwd_f32", pl.xg.data_ptr(), pl.dx0.data_ptr(), pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(),

@@ -344,16 +344,6 @@ int amid_bert_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, con
  * tile holds rows_per_tile / T whole live sequences of one domain, gathered from wherever they sit in the batch (half the tiles;
  * these kernels are bound by the weights every tile streams).  qkv also writes the exact-zero dx rows of its sequences'
  * counterparts in the other domain; LayerNorm partials: 2 * ceil(B / (rows_per_tile / T)) slots. */
-int amid_bert_ffn2_bwd_rows_f32(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live, int B,
-                                int T, void* stream);
-int amid_bert_ffn1_bwd_rows_f32(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
-                                const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const int* live, int B, int T,
-                                void* stream);
-int amid_bert_qkv_bwd_rows_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const int* live,
-                               int B, int T, void* stream);
 /* n_ent (<= 12) weight-gradient tiles of 128 x 128 as split partials: w_part [2][n_ent][splits][128*128], b_part [2][n_ent][splits][128];
  * tile e lands in w_part[domain][out_group[e]][split] at column out_col[e] with row stride out_ld[e] (standalone tile: 128, e, 0; the
  * out_ld/128 tiles of one [128, out_ld] matrix share out_group so its partials are one contiguous [splits][128*out_ld] block) */
@@ -441,76 +431,11 @@ int amid_bert_comp_bwd_f32(const float* xg, const float* dx0, const float* gate,
                            float* const* db_bs, float* dxg, void* stream);
 int amid_key_keep_tiled_u8(const long long* seq, int B, int T, int reps, unsigned char* keep, void* stream);
 
-/* ---- the same row-tile entry points built with shorter tiles (3 or 5 MFMA row tiles per workgroup instead of 7) --------------
+/* ---- the BERT4Rec row-tile entry points built with shorter tiles (3 / 4 / 5 MFMA row tiles per workgroup instead of 7) ----------------
  * Identical signatures and semantics; callers use *_rt3 when rows_per_tile <= 48 (seq_len 20 at batch 256: the mybank shape of
- * BASELINE.json configs[3]) and *_rt5 when rows_per_tile <= 80, where the 112-row build would spend much of its matrix work on zero
- * rows (csrc/tile_gemm.h). */
-int amid_sas_qkv_fwd_f32_rt3(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
-                         const float* const* b_in, float ln_eps, int M, int D, int rows_per_tile, float* qn, float* q, float* k, float* v,
-                         int mma_bf16, void* stream);
-int amid_sas_oproj_fwd_f32_rt3(const float* o, const float* const* w_o, const float* const* b_o, const float* qn, const float* const* ln_w,
-                           const float* const* ln_b, float ln_eps, int M, int D, int rows_per_tile, float* r, float* y, int mma_bf16, void* stream);
-int amid_sas_ffn_fwd_f32_rt3(const float* y, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
-                         const unsigned char* tmq, int M, int D, int rows_per_tile, int layer, const void* step_state, int train,
-                         float p_drop, float* h, float* xo, int mma_bf16, void* stream);
-int amid_sas_oproj_ffn_fwd_f32_rt3(const float* o, const float* qn, const float* const* w_o, const float* const* b_o, const float* const* ln_w,
-                               const float* const* ln_b, const float* const* w1, const float* const* b1, const float* const* w2,
-                               const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D, int rows_per_tile, int layer,
-                               const void* step_state, int train, float p_drop, float* r, float* y, float* h, float* xo, int mma_bf16,
-                               void* stream);
-int amid_sas_oproj_ffn_qkv_fwd_f32_rt3(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
-                                   const float* const* ln_w, const float* const* ln_b, const float* const* w1, const float* const* b1,
-                                   const float* const* w2, const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D,
-                                   int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* r, float* y, float* h,
-                                   float* xo, const float* const* nln_w, const float* const* nln_b, const float* const* nw_in,
-                                   const float* const* nb_in, float* nqn, float* nq, float* nk, float* nv, int mma_bf16, void* stream);
-int amid_sas_ffn_bwd_f32_rt3(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
-                         const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
-                         int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
-                         float* dr, float* d_o, float* ln_part /* [tiles][2][D] */, int mma_bf16, void* stream);
-int amid_sas_qkv_bwd_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
-                         const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
-                         int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream);
-int amid_sas_qkv_ffn_bwd_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
-                             const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
-                             int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
-                             const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
-                             int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
-                             float* fd_o, float* fln_part, int mma_bf16, void* stream);
-int amid_sas_qkv_fwd_f32_rt5(const float* x, const float* const* ln_w, const float* const* ln_b, const float* const* w_in,
-                         const float* const* b_in, float ln_eps, int M, int D, int rows_per_tile, float* qn, float* q, float* k, float* v,
-                         int mma_bf16, void* stream);
-int amid_sas_oproj_fwd_f32_rt5(const float* o, const float* const* w_o, const float* const* b_o, const float* qn, const float* const* ln_w,
-                           const float* const* ln_b, float ln_eps, int M, int D, int rows_per_tile, float* r, float* y, int mma_bf16, void* stream);
-int amid_sas_ffn_fwd_f32_rt5(const float* y, const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
-                         const unsigned char* tmq, int M, int D, int rows_per_tile, int layer, const void* step_state, int train,
-                         float p_drop, float* h, float* xo, int mma_bf16, void* stream);
-int amid_sas_oproj_ffn_fwd_f32_rt5(const float* o, const float* qn, const float* const* w_o, const float* const* b_o, const float* const* ln_w,
-                               const float* const* ln_b, const float* const* w1, const float* const* b1, const float* const* w2,
-                               const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D, int rows_per_tile, int layer,
-                               const void* step_state, int train, float p_drop, float* r, float* y, float* h, float* xo, int mma_bf16,
-                               void* stream);
-int amid_sas_oproj_ffn_qkv_fwd_f32_rt5(const float* o, const float* qn, const float* const* w_o, const float* const* b_o,
-                                   const float* const* ln_w, const float* const* ln_b, const float* const* w1, const float* const* b1,
-                                   const float* const* w2, const float* const* b2, const unsigned char* tmq, float ln_eps, int M, int D,
-                                   int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* r, float* y, float* h,
-                                   float* xo, const float* const* nln_w, const float* const* nln_b, const float* const* nw_in,
-                                   const float* const* nb_in, float* nqn, float* nq, float* nk, float* nv, int mma_bf16, void* stream);
-int amid_sas_ffn_bwd_f32_rt5(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
-                         const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
-                         int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
-                         float* dr, float* d_o, float* ln_part /* [tiles][2][D] */, int mma_bf16, void* stream);
-int amid_sas_qkv_bwd_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
-                         const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
-                         int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream);
-int amid_sas_qkv_ffn_bwd_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
-                             const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
-                             int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
-                             const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
-                             int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
-                             float* fd_o, float* fln_part, int mma_bf16, void* stream);
-
-/* ... and of the BERT4Rec row-tile entry points */
+ * BASELINE.json configs[3]), *_rt4 when <= 64 and *_rt5 when <= 80, where the 112-row build would spend much of its matrix work on zero
+ * rows (csrc/tile_gemm.h).  (The SASRec row-tile kernels exist in the 112-row build only: every SASRec shape of BASELINE.json runs the
+ * strip kernels; the row-tile kernels remain for bf16 operands beyond 64 tokens and for activations beyond 2 GiB.) */
 int amid_bert_qkv_fwd_f32_rt3(const float* x, const float* const* ln_a, const float* const* ln_b, const float* const* w3x2,
                           const float* const* b3x2, int M, int rows_per_tile, float* y, float* q, float* k, float* v, void* stream);
 int amid_bert_qkv_fwd_f32_rt5(const float* x, const float* const* ln_a, const float* const* ln_b, const float* const* w3x2,
@@ -561,19 +486,10 @@ int amid_event_destroy(void* ev);
  * sequences b with (row_domain[b] != 0) == g receive a gradient, everything else in its backward is exact zeros.  These entry points
  * take the batch's domain ids and tile those sequences' rows only (M = B * T; rows_per_tile counts live rows; ln_part needs
  * 2 * ceil(M / rows_per_tile) slots, the unused ones are zeroed); rows of the dead sequences are neither read nor written.
- * Same arguments as the plain entry points otherwise; *_rt5 / *_rt4 / *_rt3: the 80- / 64- / 48-row builds. */
+ * Same arguments as the plain entry points otherwise. */
 int amid_sas_ffn_bwd_rows_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w, const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
-int amid_sas_ffn_bwd_rows_f32_rt5(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w, const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
-int amid_sas_ffn_bwd_rows_f32_rt4(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w, const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
-int amid_sas_ffn_bwd_rows_f32_rt3(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w, const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D, int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
 int amid_sas_qkv_bwd_rows_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
-int amid_sas_qkv_bwd_rows_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
-int amid_sas_qkv_bwd_rows_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
-int amid_sas_qkv_bwd_rows_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
 int amid_sas_qkv_ffn_bwd_rows_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
-int amid_sas_qkv_ffn_bwd_rows_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
-int amid_sas_qkv_ffn_bwd_rows_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
-int amid_sas_qkv_ffn_bwd_rows_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w, const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D, int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, int mma_bf16, const long long* row_domain, int B, int T, void* stream);
 
 /* ---- the whole encoder forward of a sequence in ONE launch (csrc/sasrec_seq.hip) ------------------------------------------------------
  * replaces: Log2feats.forward model_seq.py:371-383 for n_layers layers, the attention core of nn.MultiheadAttention (:374) included --
@@ -716,19 +632,6 @@ int amid_embed_bwd_rows_f32(float* dxg, const unsigned char* tmq, int B, int T, 
                             int train, float p_drop, const long long* row_domain, void* stream);   /* amid_embed_bwd_f32 behind the *_rows kernels: the dead sequences' rows are zero-filled, not read */
 
 /* the 64-row (_rt4) build exists for the backward row-tile kernels only (the live-row backward of the headline shape: 50 rows per tile) */
-int amid_sas_ffn_bwd_f32_rt4(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
-                         const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int M, int D,
-                         int rows_per_tile, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
-                         float* dr, float* d_o, float* ln_part /* [tiles][2][D] */, int mma_bf16, void* stream);
-int amid_sas_qkv_bwd_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
-                         const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
-                         int rows_per_tile, float* dx, float* ln_part, int mma_bf16, void* stream);
-int amid_sas_qkv_ffn_bwd_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
-                             const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int M, int D,
-                             int rows_per_tile, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
-                             const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
-                             int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
-                             float* fd_o, float* fln_part, int mma_bf16, void* stream);
 
 /* amid_bert_wgrad_f32 over the live sequences only (see amid_sas_wgrad_rows_f32) */
 int amid_bert_wgrad_rows_f32(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
@@ -753,36 +656,6 @@ int amid_bert_ffn1_bwd_f32_rt4(const float* dpre, const float* dx2, const float*
                            float* dx1, float* dt, float* d_o, float* ln_part, void* stream);
 int amid_bert_qkv_bwd_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
                           const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream);
-int amid_bert_ffn2_bwd_rows_f32_rt4(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live, int B,
-                                int T, void* stream);
-int amid_bert_ffn1_bwd_rows_f32_rt4(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
-                                const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const int* live, int B, int T,
-                                void* stream);
-int amid_bert_qkv_bwd_rows_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const int* live,
-                               int B, int T, void* stream);
-int amid_bert_ffn2_bwd_rows_f32_rt3(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live, int B,
-                                int T, void* stream);
-int amid_bert_ffn1_bwd_rows_f32_rt3(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
-                                const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const int* live, int B, int T,
-                                void* stream);
-int amid_bert_qkv_bwd_rows_f32_rt3(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const int* live,
-                               int B, int T, void* stream);
-int amid_bert_ffn2_bwd_rows_f32_rt5(const float* dx2, const float* pre, const float* const* w2T, int M, int rows_per_tile, int layer,
-                                const void* step_state, int train, float p_drop, float* dz, float* dpre, const int* live, int B,
-                                int T, void* stream);
-int amid_bert_ffn1_bwd_rows_f32_rt5(const float* dpre, const float* dx2, const float* x1, const float* const* ln_a, const float* const* w1T,
-                                const float* const* woT, int M, int rows_per_tile, int layer, const void* step_state, int train,
-                                float p_drop, float* dx1, float* dt, float* d_o, float* ln_part, const int* live, int B, int T,
-                                void* stream);
-int amid_bert_qkv_bwd_rows_f32_rt5(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
-                               const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, const int* live,
-                               int B, int T, void* stream);
 
 #ifdef __cplusplus
 }

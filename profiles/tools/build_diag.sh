@@ -13,7 +13,7 @@ for f in *.hip; do
   objs="$objs $O/obj/${f%.hip}.o"
 done
 for v in 3 4 5; do
-  for f in sasrec_bwd bert $( [ $v != 4 ] && echo sasrec_fwd ); do
+  for f in bert; do
     /opt/rocm/bin/hipcc $FL -DAMID_TILE_RT=$v -Damid=amid_rt$v -DAMID_ENTRY_SUFFIX=_rt$v -c $f.hip -o $O/obj/${f}_rt$v.o &
     objs="$objs $O/obj/${f}_rt$v.o"
   done

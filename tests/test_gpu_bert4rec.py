@@ -161,29 +161,19 @@ def test_backward_golden_bert4rec_grads():
     grads_check("golden g4 bert", eng, pl, G, 5e-4, 5e-4)
 
 
-@pytest.mark.parametrize("live_tiles,T,Bn", [(False, 20, 16), (True, 20, 16), (True, 50, 12), (True, 13, 9)])
-def test_train_steps_track_dense_adam_reference(live_tiles, T, Bn):
-    """K full steps (dropout on, lazy table Adam) against the oracle's dense-Adam trajectory.  live_tiles: the backward row-tile
-    kernels tile whole sequences and skip the tiles without a live one (amid_bert_*_bwd_rows_f32; off by default, see
-    Bert4recEngine.LIVE_TILES_BWD)."""
-    from amid_amd.engine_bert import Bert4recEngine
+@pytest.mark.parametrize("T,Bn", [(20, 16), (50, 12), (13, 9)])
+def test_train_steps_track_dense_adam_reference(T, Bn):
+    """K full steps (dropout on, lazy table Adam) against the oracle's dense-Adam trajectory."""
     hid, n_items, K = 32, 300, 5
     P = orc.random_params(orc.bert4rec_param_shapes(n_items, hid), seed=31)
-    seed = 4242
-    prev = Bert4recEngine.LIVE_TILES_BWD
-    Bert4recEngine.LIVE_TILES_BWD = live_tiles
-    try:
-        _bert_traj(P, T, Bn, hid, n_items, K, seed, live_tiles)
-    finally:
-        Bert4recEngine.LIVE_TILES_BWD = prev
+    _bert_traj(P, T, Bn, hid, n_items, K, 4242)
 
 
-def _bert_traj(P, T, Bn, hid, n_items, K, seed, live_tiles):
+def _bert_traj(P, T, Bn, hid, n_items, K, seed):
     eng = make_engine(P, T, lr=1e-3, seed=seed)
     Po = {k: v.clone() for k, v in P.items()}
     opt = orc.DenseAdam(Po, lr=1e-3)
     pl = eng.plan(Bn, T, 2, need_grad=True)
-    assert pl.live_tiles == live_tiles and (not live_tiles or pl.rpt_b % T == 0)
     for t in range(1, K + 1):
         batch = batch_with_masked_keys(Bn, T, 60 if t in (1, 2, 5) else n_items, seed=100 + t)
         masks = orc.philox_masks_bert4rec(Bn, T, seed=seed, step=t)
