@@ -18,6 +18,7 @@
 #include "strip_gemm.h"
 #include "sort_phases.h"
 #include "attention_mfma.h"
+#include <type_traits>
 
 namespace amid {
 
@@ -74,14 +75,17 @@ __device__ __forceinline__ void to_regs(StripRegs<D>& dst, const f32x4 (&acc)[D 
 // a running two-slab ring.  next() returns the slab whose fetch was started one slab ago: it waits for this wave's DMAs, then meets
 // the other waves at the workgroup barrier -- the slab has landed for everybody, and everybody is done reading the OTHER buffer,
 // which the pieces issued from inside the coming MFMA loop (fetch()) overwrite.
-template <int D> struct Ring {
-    float* buf; int s; WDma<D> dma;
+template <int D, bool BF = false> struct Ring {
+    static constexpr bool BF16 = BF;                    // bf16 fragment images (strip_gemm.h WDma16): slabs of D D / 2 floats
+    static constexpr int SLAB = BF ? D * D / 2 : D * D;
+    using Dma = typename std::conditional<BF, WDma16<D>, WDma<D>>::type;
+    float* buf; int s; Dma dma;
     __device__ __forceinline__ explicit Ring(float* lds) : buf(lds), s(0) {}
     __device__ __forceinline__ void first(const float* __restrict__ W0) { dma.all(buf, W0); }
     __device__ __forceinline__ const float* next() {
         w_ring_wait();
         __syncthreads();
-        const float* cur = buf + (s & 1) * D * D;
+        const float* cur = buf + (s & 1) * SLAB;
         ++s;
         return cur;
     }
@@ -90,9 +94,9 @@ template <int D> struct Ring {
     __device__ __forceinline__ void fetch(const float* __restrict__ W, int ct, int j) const {
         // all of them in the FIRST half of the loop: a piece takes a couple of thousand cycles to land, and the next slab starts
         // with a wait for every one of them
-        constexpr int SLOTS = 8 * (D / 16), EVERY = (SLOTS / 2) / WDma<D>::PER_WAVE;
+        constexpr int SLOTS = 8 * (D / 16), EVERY = (SLOTS / 2) / Dma::PER_WAVE;
         const int slot = ct * 8 + j;
-        if (slot % EVERY == 0 && slot / EVERY < WDma<D>::PER_WAVE) dma.piece(buf + (s & 1) * D * D, W, slot / EVERY);
+        if (slot % EVERY == 0 && slot / EVERY < Dma::PER_WAVE) dma.piece(buf + (s & 1) * SLAB, W, slot / EVERY);
     }
 };
 
@@ -310,8 +314,8 @@ __device__ __forceinline__ void ffn_bwd_prefetch(FfnBwdPre<D>& p, const StripFfn
 // d x' (DZ, in registers) -> dpre2, dpre1, dr, d_o of this layer; the ring's current fetch must be w2T.  TAIL: a slab (`tail`) is
 // fetched under the last MFMA loop (a fused successor's first weight)
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int D, bool TAIL = false, class Hook = NoHook>
-__device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const StripGeom& sg, Ring<D>& ring, const StripRow& row, int g,
+template <int D, bool TAIL = false, class Hook = NoHook, class RingT = Ring<D>>
+__device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const StripGeom& sg, RingT& ring, const StripRow& row, int g,
                                               StripRegs<D>& DZ, FfnBwdPre<D>& pre, float* __restrict__ scratch,
                                               const float* __restrict__ tail = nullptr, const Hook& before_last = NoHook()) {
     constexpr int NT = D / 16;
@@ -329,7 +333,7 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
         const float* buf = ring.next();
         strip_load<D>(Rs, GBuf(a.r, sg.act_bytes), row);               // LN2 input rows: needed two slabs from now
         strip_zero<D>(acc);
-        strip_mma<D>(acc, P, buf, [&](int ct, int j) { ring.fetch(a.w1T[g], ct, j); store_spread<D>(gp2, row, P, ct, j); });
+        strip_mma_sel<D, RingT::BF16>(acc, P, buf, [&](int ct, int j) { ring.fetch(a.w1T[g], ct, j); store_spread<D>(gp2, row, P, ct, j); });
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -339,7 +343,7 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
     {   // dy = dpre1 C1 + dz ; dr = LN2'(dy ; r)
         const float* buf = ring.next();
         strip_zero<D>(acc);
-        strip_mma<D>(acc, P, buf, [&](int ct, int j) { ring.fetch(a.woT[g], ct, j); store_spread<D>(gp1, row, P, ct, j); });
+        strip_mma_sel<D, RingT::BF16>(acc, P, buf, [&](int ct, int j) { ring.fetch(a.woT[g], ct, j); store_spread<D>(gp1, row, P, ct, j); });
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) Hs.v[ct] = acc[ct] + DZ.v[ct];
         strip_ln_bwd<D>(DR, Hs, Rs, pre.gam, a.ln_eps, dgam, dbet);
@@ -348,7 +352,7 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
         const float* buf = ring.next();
         before_last();                  // (a fused successor requests operands here: they fly under this product)
         strip_zero<D>(acc);
-        strip_mma<D>(acc, DR, buf, [&](int ct, int j) {
+        strip_mma_sel<D, RingT::BF16>(acc, DR, buf, [&](int ct, int j) {
             if constexpr (TAIL) ring.fetch(tail, ct, j);
             store_spread<D>(gdr, row, DR, ct, j);
         });
@@ -360,8 +364,8 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
 
 // dq, dk, dv, dr of a layer -> d x (left in DX); the ring's current fetch must be wkT.  TAIL: a slab (`tail`) is fetched behind wqT;
 // `before_last()` runs in front of the last MFMA loop (a fused successor issues its first loads there).
-template <int D, bool TAIL, class Hook>
-__device__ __forceinline__ void qkv_bwd_chain(const StripQkvBwdArgs& a, const StripGeom& sg, Ring<D>& ring, const StripRow& row, int g,
+template <int D, bool TAIL, class Hook, class RingT>
+__device__ __forceinline__ void qkv_bwd_chain(const StripQkvBwdArgs& a, const StripGeom& sg, RingT& ring, const StripRow& row, int g,
                                               StripRegs<D>& DX, float* __restrict__ scratch, const float* __restrict__ tail, const Hook& before_last) {
     constexpr int NT = D / 16;
     StripRegs<D> Dk, Dv, Dq, Drs, Xs;
@@ -373,21 +377,21 @@ __device__ __forceinline__ void qkv_bwd_chain(const StripQkvBwdArgs& a, const St
     {   // dk Wk          (every operand is requested one slab ahead of its use: the loads fly under the MFMAs in between)
         const float* buf = ring.next();
         strip_load<D>(Dq, GBuf(a.dq, sg.act_bytes), row);
-        strip_mma<D>(acc_kv, Dk, buf, [&](int ct, int j) { ring.fetch(a.wvT[g], ct, j); });
+        strip_mma_sel<D, RingT::BF16>(acc_kv, Dk, buf, [&](int ct, int j) { ring.fetch(a.wvT[g], ct, j); });
     }
     {   // + dv Wv
         const float* buf = ring.next();
         strip_load<D>(Drs, GBuf(a.dr, sg.act_bytes), row);             // residual-path gradient of the normed query
         strip_load<D>(Xs, GBuf(a.x, sg.act_bytes), row);               // LN1 input rows
         gam.load(a.ln_w[g]);
-        strip_mma<D>(acc_kv, Dv, buf, [&](int ct, int j) { ring.fetch(a.wqT[g], ct, j); });
+        strip_mma_sel<D, RingT::BF16>(acc_kv, Dv, buf, [&](int ct, int j) { ring.fetch(a.wqT[g], ct, j); });
     }
     StripRegs<D> dgam, dbet;
     {   // dqn = dq Wq + dr ; dx = LN1'(dqn ; x) + (dk Wk + dv Wv)
         const float* buf = ring.next();
         before_last();
         strip_zero<D>(acc);
-        strip_mma<D>(acc, Dq, buf, [&](int ct, int j) { if constexpr (TAIL) ring.fetch(tail, ct, j); });
+        strip_mma_sel<D, RingT::BF16>(acc, Dq, buf, [&](int ct, int j) { if constexpr (TAIL) ring.fetch(tail, ct, j); });
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) Drs.v[ct] += acc[ct];
         strip_ln_bwd<D>(DX, Drs, Xs, gam, a.ln_eps, dgam, dbet);
@@ -404,7 +408,7 @@ __device__ __forceinline__ void zero_slot(float* __restrict__ part, int slot) {
 
 // RIDER: 0, or the phase of the step's index sort (sort_phases.h) that the first rd.plan.nblk workgroups run, on CUs the live tiles
 // leave free (this launch: phase 2, the scatter of pass 0)
-template <int D, int RIDER>
+template <int D, int RIDER, bool BF = false>
 __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const StripFfnBwdArgs a, const StripGeom sg, const SortRider rd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const Stri
         if (bid < rd.plan.nblk) { sort_phase_ct<1024, RIDER>(rd.plan, bid); return; }
         bid -= rd.plan.nblk;
     }
-    Ring<D> ring(smem);
+    Ring<D, BF> ring(smem);
     ring.first(a.w2T[strip_domain(bid)]);
     const StripTile t = strip_tile(sg, bid);
     if (!t.live) { zero_slot<D>(a.ln_part, t.slot); w_ring_wait(); return; }
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const Stri
 
 // FFN = true: the layer below's feed-forward / out-projection backward continues on d x in registers (d x is then never stored)
 // RIDER: as strip_ffn_bwd_kernel (with FFN: phase 3, pass 1's counts; without: phase 4, the scatter of pass 1)
-template <int D, bool FFN, int RIDER>
+template <int D, bool FFN, int RIDER, bool BF = false>
 __global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const StripQkvBwdArgs a, const StripFfnBwdArgs f, const StripGeom sg,
                                                                       const SortRider rd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const Stri
         if (bid < rd.plan.nblk) { sort_phase_ct<1024, RIDER>(rd.plan, bid); return; }
         bid -= rd.plan.nblk;
     }
-    Ring<D> ring(smem);
+    Ring<D, BF> ring(smem);
     ring.first(a.wkT[strip_domain(bid)]);
     const StripTile t = strip_tile(sg, bid);
     if (!t.live) {
@@ -479,7 +483,7 @@ struct SeqBwdLayer {
 };
 struct SeqBwdArgs { SeqBwdLayer L[2]; int n_layers; };
 
-template <int D>
+template <int D, bool BF = false>
 __global__ __launch_bounds__(STRIP_THREADS) void seq_bwd_kernel(const SeqBwdArgs a, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_bwd_kernel(const SeqBwdArgs
     const int g = bid >= n0 ? 1 : 0;
     const int tl = bid - (g ? n0 : 0);
     const int top = a.n_layers - 1;
-    Ring<D> ring(smem);
+    Ring<D, BF> ring(smem);
     ring.first(a.L[top].f.w2T[g]);
     const int b = sg.live[bid];
     const int slot = g * B + tl;
@@ -686,8 +690,9 @@ static void fill_ffn_bwd(StripFfnBwdArgs& a, const float* dxo, const unsigned ch
 static int strip_ffn_bwd(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
                          const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T,
                          int D, const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2,
-                         float* dpre1, float* dr, float* d_o, float* ln_part, const void* sort_plan, int sort_phase, void* stream) {
+                         float* dpre1, float* dr, float* d_o, float* ln_part, const void* sort_plan, int sort_phase, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(dxo && h && r && ln_w && w1T && w2T && woT && dpre2 && dpre1 && dr && d_o && ln_part && (!train || step_state));
+    if (mma_bf16 && D != 128) return AMID_ERR_UNSUPPORTED;
     StripFfnBwdArgs a;
     fill_ffn_bwd(a, dxo, tmq, h, r, ln_w, w1T, w2T, woT, ln_eps, layer, step_state, train, p_drop, dpre2, dpre1, dr, d_o, ln_part);
     StripGeom sg;
@@ -695,6 +700,8 @@ static int strip_ffn_bwd(const float* dxo, const unsigned char* tmq, const float
     SortRider rd;
     if (int e = make_rider(rd, sort_plan, sort_phase)) return e;
     if (rd.phase != 0 && rd.phase != 2) return AMID_ERR_UNSUPPORTED;           // this launch carries phase 2
+    if (D == 128 && mma_bf16) return rd.phase ? launch_strip_rider<strip_ffn_bwd_kernel<128, 2, true>, 128>(sg, rd, stream, a)
+                                              : launch_strip_rider<strip_ffn_bwd_kernel<128, 0, true>, 128>(sg, rd, stream, a);
     if (D == 128 && rd.phase) return launch_strip_rider<strip_ffn_bwd_kernel<128, 2>, 128>(sg, rd, stream, a);
     if (D == 128) return launch_strip_rider<strip_ffn_bwd_kernel<128, 0>, 128>(sg, rd, stream, a);
     if (D == 64 && rd.phase) return launch_strip_rider<strip_ffn_bwd_kernel<64, 2>, 64>(sg, rd, stream, a);
@@ -705,9 +712,9 @@ static int strip_ffn_bwd(const float* dxo, const unsigned char* tmq, const float
 extern "C" int amid_sas_strip_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
                                           const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T,
                                           int D, const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2,
-                                          float* dpre1, float* dr, float* d_o, float* ln_part, void* stream) {
+                                          float* dpre1, float* dr, float* d_o, float* ln_part, int mma_bf16, void* stream) {
     return strip_ffn_bwd(dxo, tmq, h, r, ln_w, w1T, w2T, woT, ln_eps, B, T, D, live, layer, step_state, train, p_drop, dpre2, dpre1, dr, d_o,
-                         ln_part, nullptr, 0, stream);
+                         ln_part, nullptr, 0, mma_bf16, stream);
 }
 
 // ... carrying phase `sort_phase` (1 .. 4) of a sort plan (amid_sort_plan_pack) as extra workgroups in front of the tiles'
@@ -715,10 +722,10 @@ extern "C" int amid_sas_strip_ffn_bwd_sort_f32(const float* dxo, const unsigned 
                                                const float* const* ln_w, const float* const* w1T, const float* const* w2T,
                                                const float* const* woT, float ln_eps, int B, int T, int D, const int* live, int layer,
                                                const void* step_state, int train, float p_drop, float* dpre2, float* dpre1, float* dr,
-                                               float* d_o, float* ln_part, const void* sort_plan, int sort_phase, void* stream) {
+                                               float* d_o, float* ln_part, const void* sort_plan, int sort_phase, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(sort_plan != nullptr);
     return strip_ffn_bwd(dxo, tmq, h, r, ln_w, w1T, w2T, woT, ln_eps, B, T, D, live, layer, step_state, train, p_drop, dpre2, dpre1, dr, d_o,
-                         ln_part, sort_plan, sort_phase, stream);
+                         ln_part, sort_plan, sort_phase, mma_bf16, stream);
 }
 
 // fh != NULL: the layer below's feed-forward / out-projection backward (f* arguments) runs on d x in the same launch; dx is then not written
@@ -728,8 +735,9 @@ static int strip_qkv_bwd(const float* dq, const float* dk, const float* dv, cons
                          const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
                          const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
                          const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
-                         float* fd_o, float* fln_part, const void* sort_plan, int sort_phase, void* stream) {
+                         float* fd_o, float* fln_part, const void* sort_plan, int sort_phase, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && ln_part);
+    if (mma_bf16 && D != 128) return AMID_ERR_UNSUPPORTED;
     const bool ffn = fh != nullptr;
     AMID_CHECK_ARG(ffn || dx);
     AMID_CHECK_ARG(!ffn || (fr && fln_w && fw1T && fw2T && fwoT && fdpre2 && fdpre1 && fdr && fd_o && fln_part && (!train || step_state)));
@@ -744,6 +752,10 @@ static int strip_qkv_bwd(const float* dq, const float* dk, const float* dv, cons
     if (int e = make_rider(rd, sort_plan, sort_phase)) return e;
     if (rd.phase != 0 && rd.phase != (ffn ? 3 : 4)) return AMID_ERR_UNSUPPORTED;      // phase 3 with the fused feed-forward backward, 4 without
     const bool ride = rd.phase != 0;
+    if (D == 128 && mma_bf16 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3, true>, 128>(sg, rd, stream, a, f)
+                                                 : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0, true>, 128>(sg, rd, stream, a, f);
+    if (D == 128 && mma_bf16) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4, true>, 128>(sg, rd, stream, a, f)
+                                          : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0, true>, 128>(sg, rd, stream, a, f);
     if (D == 128 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3>, 128>(sg, rd, stream, a, f)
                                      : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0>, 128>(sg, rd, stream, a, f);
     if (D == 128) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4>, 128>(sg, rd, stream, a, f)
@@ -761,9 +773,9 @@ extern "C" int amid_sas_strip_qkv_bwd_f32(const float* dq, const float* dk, cons
                                           const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
                                           const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
                                           const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
-                                          float* fd_o, float* fln_part, void* stream) {
+                                          float* fd_o, float* fln_part, int mma_bf16, void* stream) {
     return strip_qkv_bwd(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, B, T, D, live, dx, ln_part, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, flayer,
-                         step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, nullptr, 0, stream);
+                         step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, nullptr, 0, mma_bf16, stream);
 }
 
 // ... carrying phase `sort_phase` (1 .. 4) of a sort plan (amid_sort_plan_pack) as extra workgroups in front of the tiles'
@@ -774,10 +786,10 @@ extern "C" int amid_sas_strip_qkv_bwd_sort_f32(const float* dq, const float* dk,
                                                const float* const* fln_w, const float* const* fw1T, const float* const* fw2T,
                                                const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop,
                                                float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part, const void* sort_plan,
-                                               int sort_phase, void* stream) {
+                                               int sort_phase, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(sort_plan != nullptr);
     return strip_qkv_bwd(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, B, T, D, live, dx, ln_part, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, flayer,
-                         step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, sort_plan, sort_phase, stream);
+                         step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, sort_plan, sort_phase, mma_bf16, stream);
 }
 
 // ---- the fused per-sequence backward ------------------------------------------------------------------------------------------------
@@ -801,7 +813,7 @@ extern "C" int amid_sas_seq_bwd_f32(int n_layers, const float* dxo, const unsign
                                     const float* const* woT, const float* const* w1T, const float* const* w2T, float ln_eps, int B, int T,
                                     int D, int H, const int* live, const void* step_state, int train, float p_drop, float* const* dpre2,
                                     float* const* dpre1, float* const* dr, float* d_o, float* const* dq, float* const* dk, float* const* dv,
-                                    float* dx, float* const* ln1_part, float* const* ln2_part, void* stream) {
+                                    float* dx, float* const* ln1_part, float* const* ln2_part, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(n_layers >= 1 && n_layers <= 2 && dxo && h && r && x && q && k && v && o && stats && ln1_w && ln2_w && wqT && wkT && wvT &&
                    woT && w1T && w2T && live && dpre2 && dpre1 && dr && d_o && dq && dk && dv && dx && ln1_part && ln2_part &&
                    (!train || step_state));
@@ -838,11 +850,13 @@ extern "C" int amid_sas_seq_bwd_f32(int n_layers, const float* dxo, const unsign
     if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)seq_bwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_bwd_lds_bytes<128>());
+        hipError_t e = hipFuncSetAttribute((const void*)seq_bwd_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_bwd_lds_bytes<128>());
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)seq_bwd_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_bwd_lds_bytes<128>());
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    seq_bwd_kernel<128><<<B, STRIP_THREADS, seq_bwd_lds_bytes<128>(), (hipStream_t)stream>>>(a, sg);
+    if (mma_bf16) seq_bwd_kernel<128, true><<<B, STRIP_THREADS, seq_bwd_lds_bytes<128>(), (hipStream_t)stream>>>(a, sg);
+    else seq_bwd_kernel<128, false><<<B, STRIP_THREADS, seq_bwd_lds_bytes<128>(), (hipStream_t)stream>>>(a, sg);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? AMID_OK : (int)e;
 }

@@ -362,6 +362,77 @@ __device__ __forceinline__ void strip_mma(f32x4 (&acc)[D / 16], const StripRegs<
     }
 }
 
+// ---- bf16 matrix products on a strip (BASELINE.json configs[2]) -------------------------------------------------------------------------
+// Weights arrive as bf16 FRAGMENT IMAGES (amid_sas_weights_bf16): row n = D bf16 = D / 8 chunks of 16 bytes, chunk 4 s + g = the eight k
+// lane group g supplies in k-step s of v_mfma_f32_16x16x32_bf16 when the operand sits in the C layout: k = 32 s + 4 g + 0..3 (column tile
+// 2 s) and 32 s + 16 + 4 g + 0..3 (column tile 2 s + 1).  A slab is D D / 2 floats (32 KB at D = 128); in LDS chunk c of row n sits at
+// chunk position c ^ (n & 15), applied on the DMA's source address: conflict-free ds_read_b128 fragments.  The operand's values are
+// rounded to bf16 (nearest even) on the fly, accumulation stays fp32.
+template <int D> struct WDma16 {
+    static constexpr int CPR = D / 8;
+    static constexpr int PER_WAVE = D * CPR / 64 / STRIP_WAVES;
+    unsigned off0;
+    int w;
+    __device__ __forceinline__ WDma16() {
+        w = wave_id();
+        const int p = w * 64 + lane_id();
+        const int n = p / CPR, pos = p % CPR;
+        off0 = (unsigned)(n * D * 2 + ((pos ^ (n & 15)) * 16));
+    }
+    __device__ __forceinline__ void piece(float* __restrict__ buf, const float* __restrict__ W, int k0) const {
+        const unsigned voff = off0 + (unsigned)k0 * (unsigned)(STRIP_WAVES * 64 / CPR) * (unsigned)(D * 2);      // 16 rows further: n & 15 unchanged
+        const unsigned lds = __builtin_amdgcn_readfirstlane(
+            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(buf + (k0 * STRIP_WAVES + w) * 256));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
+    }
+    __device__ __forceinline__ void all(float* __restrict__ buf, const float* __restrict__ W) const {
+#pragma unroll
+        for (int k0 = 0; k0 < PER_WAVE; ++k0) piece(buf, W, k0);
+    }
+};
+
+typedef __bf16 strip_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 strip_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float strip_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned strip_pack2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(strip_f32x2{a, b}, strip_bf16x2));
+}
+// acc[co] += A W^T with bf16 operands; `hook(ct, j)` is called for every slot of the fp32 loop IN FRONT of the 4 x D / 16 MFMAs (the
+// next slab's DMA pieces and the deferred stores the callers place in the loop: there is no long loop to spread them under)
+template <int D, class Hook = NoDeferred>
+__device__ __forceinline__ void strip_mma16(f32x4 (&acc)[D / 16], const StripRegs<D>& A, const float* __restrict__ buf, const Hook& hook = NoDeferred()) {
+    constexpr int NT = D / 16, KS = D / 32;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hook(ct, j);
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const float* rowp = buf + i * (D / 2);
+    amid_v4u a16[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        a16[s] = amid_v4u{strip_pack2(A.v[2 * s][0], A.v[2 * s][1]), strip_pack2(A.v[2 * s][2], A.v[2 * s][3]),
+                          strip_pack2(A.v[2 * s + 1][0], A.v[2 * s + 1][1]), strip_pack2(A.v[2 * s + 1][2], A.v[2 * s + 1][3])};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float4 wf[NT];
+#pragma unroll
+        for (int co = 0; co < NT; ++co) wf[co] = ld4(rowp + co * 16 * (D / 2) + 4 * ((4 * s + g) ^ i));
+#pragma unroll
+        for (int co = 0; co < NT; ++co)
+            acc[co] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(strip_bf16x8, wf[co]), __builtin_bit_cast(strip_bf16x8, a16[s]),
+                                                              acc[co], 0, 0, 0);
+    }
+}
+// fp32 or bf16 products, chosen at compile time
+template <int D, bool BF, class Hook = NoDeferred>
+__device__ __forceinline__ void strip_mma_sel(f32x4 (&acc)[D / 16], const StripRegs<D>& A, const float* __restrict__ buf, const Hook& hook = NoDeferred()) {
+    if constexpr (BF) strip_mma16<D, Hook>(acc, A, buf, hook); else strip_mma<D, Hook>(acc, A, buf, hook);
+}
+
 template <int D>
 __device__ __forceinline__ void strip_zero(f32x4 (&acc)[D / 16]) {
 #pragma unroll

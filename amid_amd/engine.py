@@ -25,372 +25,27 @@ import torch
 
 from ._lib import lib, ptr_array
 
-SASREC_HEADS = 8          # model_seq.py:348-350
-SASREC_P_DROP = 0.5       # model_seq.py:335,350,356
-SASREC_LN_EPS = 1e-8      # model_seq.py:342-353
+from .engine_dp import DataParallelMixin, HipMergeBackend      # noqa: F401  (re-exported)
+from .engine_graph import GraphMixin
+from .engine_io import InputMixin
+from .plan import (DR_HEADS, SASREC_HEADS, SASREC_LN_EPS, SASREC_P_DROP, FlatParams, SasrecPlan, Shape,      # noqa: F401  (re-exported)
+                   sasrec_dense_names)
 
 
-def sasrec_dense_names(T: int, D: int, hid: int, itc_bs: int = 0, dr: bool = False, inc_bs: int = 0) -> List[Tuple[str, Tuple[int, ...]]]:
-    """Non-table parameters in the reference's state_dict order; itc_bs > 0: with the InterComp
-    modules of SASRec(isItC=True, bs=itc_bs) (model_seq.py:403-405, :478-480); inc_bs > 0: with the InnerComp modules of
-    isInC=True (:398-401; T is then the doubled pos_emb length)."""
-    out: List[Tuple[str, Tuple[int, ...]]] = []
-    if inc_bs:
-        for d in (1, 2):
-            out.append((f"inc_d{d}.trans_nn.weight", (D, D)))
-            out.append((f"inc_d{d}.trans_nn.bias", (D,)))
-            out.append((f"inc_d{d}.trans_bs.weight", (1, inc_bs)))
-            out.append((f"inc_d{d}.trans_bs.bias", (1,)))
-    if itc_bs:
-        for d in (1, 2):
-            out.append((f"itc_d{d}.trans_nn.weight", (D, D)))
-            out.append((f"itc_d{d}.trans_nn.bias", (D,)))
-            out.append((f"itc_d{d}.trans_bs.weight", (1, itc_bs)))
-            out.append((f"itc_d{d}.trans_bs.bias", (1,)))
-    for d in (1, 2):
-        pre = f"sac{d}"
-        out.append((f"{pre}.pos_emb.weight", (T, D)))
-        out.append((f"{pre}.attention_layernorms.0.weight", (D,)))
-        out.append((f"{pre}.attention_layernorms.0.bias", (D,)))
-        out.append((f"{pre}.attention_layernorms.1.weight", (D,)))
-        out.append((f"{pre}.attention_layernorms.1.bias", (D,)))
-        for l in (0, 1):
-            out.append((f"{pre}.attention_layers.{l}.in_proj_weight", (3 * D, D)))
-            out.append((f"{pre}.attention_layers.{l}.in_proj_bias", (3 * D,)))
-            out.append((f"{pre}.attention_layers.{l}.out_proj.weight", (D, D)))
-            out.append((f"{pre}.attention_layers.{l}.out_proj.bias", (D,)))
-        out.append((f"{pre}.forward_layernorms.0.weight", (D,)))
-        out.append((f"{pre}.forward_layernorms.0.bias", (D,)))
-        out.append((f"{pre}.forward_layernorms.1.weight", (D,)))
-        out.append((f"{pre}.forward_layernorms.1.bias", (D,)))
-        for l in (0, 1):
-            out.append((f"{pre}.forward_layers.{l}.conv1.weight", (D, D, 1)))
-            out.append((f"{pre}.forward_layers.{l}.conv1.bias", (D,)))
-            out.append((f"{pre}.forward_layers.{l}.conv2.weight", (D, D, 1)))
-            out.append((f"{pre}.forward_layers.{l}.conv2.bias", (D,)))
-        out.append((f"{pre}.last_layernorm.weight", (D,)))
-        out.append((f"{pre}.last_layernorm.bias", (D,)))
-    for head in ("predictModule",) + (("predict_ips", "predict_gfunc") if dr else ()):      # isDR heads: model_seq.py:411-414
-        out.append((f"{head}.fc.0.weight", (hid, 2 * D)))
-        out.append((f"{head}.fc.0.bias", (hid,)))
-        out.append((f"{head}.fc.2.weight", (1, hid)))
-        out.append((f"{head}.fc.2.bias", (1,)))
-    return out
-
-
-DR_HEADS = ("predictModule", "predict_ips", "predict_gfunc")
-
-
-class FlatParams:
-    """One flat fp32 buffer with named views (each slot padded to 4 floats = 16 B)."""
-
-    def __init__(self, names: List[Tuple[str, Tuple[int, ...]]], device):
-        self.slots: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
-        off = 0
-        for n, shp in names:
-            numel = 1
-            for s in shp:
-                numel *= s
-            self.slots[n] = (off, shp)
-            off += (numel + 3) & ~3
-        self.numel = off
-        self.data = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grad = torch.zeros_like(self.data)
-        self.m = torch.zeros_like(self.data)
-        self.v = torch.zeros_like(self.data)
-
-    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
-        off, shp = self.slots[name]
-        numel = 1
-        for s in shp:
-            numel *= s
-        return (self.data if buf is None else buf)[off: off + numel].view(*shp)
-
-    def ptr(self, name: str, buf: Optional[torch.Tensor] = None, extra: int = 0) -> int:
-        off, _ = self.slots[name]
-        return (self.data if buf is None else buf).data_ptr() + 4 * (off + extra)
-
-
-@dataclass
-class Shape:
-    B: int
-    T: int
-    NI: int          # items scored per row: 1 positive + negatives
-    Te: int = 0      # tokens per sequence inside the encoder when it differs from T (isInC appends T tokens: 2T); 0 = T
-
-    @property
-    def Tenc(self) -> int:
-        return self.Te or self.T
-
-    @property
-    def M(self) -> int:
-        """Encoder rows per domain."""
-        return self.B * self.Tenc
-
-    @property
-    def Mi(self) -> int:
-        """Gathered sequence rows per domain (index layout)."""
-        return self.B * self.T
-
-    @property
-    def n_idx(self) -> int:
-        return 2 * self.B * self.T + self.B * self.NI
-
-
-class SasrecPlan:
-    """Workspace for one batch shape: saved activations, gradient scratch, index workspaces."""
-
-    def __init__(self, eng: "SasrecEngine", shp: Shape, need_grad: bool):
-        L = lib()
-        self.shape = shp
-        self.need_grad = need_grad
-        dev, D, H, hid = eng.device, eng.D, eng.H, eng.hid
-        B, T, NI, M, N = shp.B, shp.T, shp.NI, shp.M, shp.n_idx
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
-        self.rpt = L.value("amid_rows_per_tile", M)
-        self.tpg = (M + self.rpt - 1) // self.rpt
-        # the encoder's GEMM chains as register-resident strip kernels (csrc/sasrec_strip.hip): fp32, activations up to 2 GiB each;
-        # one tile geometry (64-row tiles) for every sequence and for the live sequences of a train step alike
-        # compute = "bf16": the strip path when the one-launch forward covers the shape -- its twelve projection products then run on the
-        # bf16 matrix cores (amid_sas_seq_fwd_bf16w_f32); other shapes keep the row-tile kernels' bf16 mode
-        self.strip = bool(eng.STRIP_KERNELS and 2 * M * D * 4 <= 0x7FFFFFF0 and
-                          (eng.compute == "f32" or (eng.BF16_STRIP and not getattr(eng, "inc_bs", 0)
-                                                    and L.value("amid_sas_seq_supported", B, shp.Tenc, D, H))))
-        if self.strip:
-            self.stpg = -(-M // L.value("amid_sas_strip_tile_rows"))
-        self.live = torch.zeros(B + 1, dtype=torch.int32, device=dev)       # amid_live_list_i32: the step's live sequences
-        # the train step's compact index list over the live sequences + items (amid_lazy_adam_catchup_live_f32): ids and, for every
-        # entry, the row of its gradient in the full [2 B T + items] layout
-        self.n_compact = B * self.shape.T + B * self.shape.NI
-        self.idx_c = torch.zeros(self.n_compact, dtype=torch.int32, device=dev)
-        self.row_c = torch.zeros(self.n_compact, dtype=torch.int32, device=dev)
-        self.compact = False             # set per step by enqueue_prepare
-        # short tiles (seq_len 20 at batch 256: 40 rows per CU) run the 48- / 80-row builds of the row-tile kernels (csrc/tile_gemm.h)
-        self.rt_suffix = ("_rt3" if self.rpt <= 48 else "_rt5" if self.rpt <= 80 else "") if eng.SHORT_TILE_BUILDS else ""
-        # static inputs (graph-replay safe): ONE int64 buffer so a batch arrives with a single copy
-        #   [i_node B | neg B*(NI-1) | seq_d1 B*T | seq_d2 B*T | domain B | labels B*NI fp32 (packed two per word)]
-        n_lab_words = (B * NI + 1) // 2
-        dr = bool(getattr(eng, "dr", False))
-        self.in_words = B + B * (NI - 1) + 2 * B * T + B + n_lab_words + (B if dr else 0)       # DR: + ob_label [B] at the end
-        self.in_pack = torch.zeros(self.in_words, dtype=torch.int64, device=dev)
-        o = 0
-        self.in_i_node = self.in_pack[o:o + B]; o += B
-        self.in_neg = self.in_pack[o:o + B * (NI - 1)].view(B, NI - 1); o += B * (NI - 1)
-        self.in_seq_d1 = self.in_pack[o:o + B * T].view(B, T); o += B * T
-        self.in_seq_d2 = self.in_pack[o:o + B * T].view(B, T); o += B * T
-        self.domain = self.in_pack[o:o + B]; o += B
-        self.labels = self.in_pack[o:o + n_lab_words].view(torch.float32)[: B * NI].view(B, NI); o += n_lab_words
-        self.in_ob = self.in_pack[o:o + B] if dr else None
-        self.pools = {}                               # SasrecEngine.set_input_pool: (Adam state, objective) -> [pool, phase]
-        self.idx_all = torch.zeros(N, dtype=torch.int32, device=dev)
-        self.err = torch.zeros(1, dtype=torch.int32, device=dev)
-        # forward
-        self.xg = f(N, D)
-        inc = int(getattr(eng, "inc_bs", 0))
-        # the gathered seq rows ARE the encoder input, except with isInC (the encoder input has 2T tokens per row)
-        self.x = [self.xg[: 2 * M] if not inc else f(2 * M, D), f(2 * M, D), f(2 * M, D)]
-        if inc:
-            if B != inc:
-                raise ValueError(f"isInC: the batch must hold exactly bs = {inc} rows (trans_bs is Linear(bs, 1) over the batch, "
-                                 f"model_seq.py:457), got {B}")
-            self.inc_s, self.inc_gate, self.inc_sw = f(2, B), f(2, B), f(2)
-            self.inc_S, self.inc_Z = f(2, T, D), f(2, T, D)
-        self.q = [f(2 * M, D) for _ in range(2)]
-        self.k = [f(2 * M, D) for _ in range(2)]
-        self.v = [f(2 * M, D) for _ in range(2)]
-        self.o = [f(2 * M, D) for _ in range(2)]
-        self.stats = [f(2 * M, H, 2) for _ in range(2)]
-        self._alloc_model_fwd(eng, f)
-        self.u = f(2, B, D)
-        if getattr(eng, "itc_bs", 0):
-            if B != eng.itc_bs:
-                raise ValueError(f"isItC: the batch must hold exactly bs = {eng.itc_bs} rows (trans_bs is Linear(bs, 1) over the batch, "
-                                 f"model_seq.py:480), got {B}")
-            self.u_raw, self.du_raw = f(2, B, D), f(2, B, D)
-            self.itc_s, self.itc_gate, self.itc_z, self.itc_sw = f(B), f(B), f(2, D), f(2)
-        self.p1 = f(B, NI)
-        self.p2 = f(B, NI)
-        self.dp1 = torch.zeros(B, NI, dtype=torch.float32, device=dev)
-        self.dp2 = torch.zeros(B, NI, dtype=torch.float32, device=dev)
-        self.loss_part = torch.zeros(B, dtype=torch.float32, device=dev)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        if dr:            # the two extra heads' outputs / output gradients, and per-row partials of (loss_cls, loss_dr_e, loss_dr_r)
-            self.ips1, self.ips2, self.g1, self.g2 = (f(B, NI) for _ in range(4))
-            self.dips1, self.dips2, self.dg1, self.dg2 = (torch.zeros(B, NI, dtype=torch.float32, device=dev) for _ in range(4))
-            self.dr_loss_part = torch.zeros(B, 3, dtype=torch.float32, device=dev)
-            self.dr_losses = torch.zeros(3, dtype=torch.float32, device=dev)
-        if not need_grad:
-            return
-        # backward
-        self.dxg = f(N, D)
-        if inc:
-            self.dx0 = f(2 * M, D)                      # encoder-input gradient; its first halves + InnerComp's share -> dxg
-            self.inc_dZ, self.inc_dS, self.inc_rows = f(2, T, D), f(2, T, D), f(2, T, 2)
-        self.dxbuf = f(2 * M, D)
-        self.du = f(2, B, D)
-        self.d_o = f(2 * M, D)
-        self.dq, self.dk, self.dv = f(2 * M, D), f(2 * M, D), f(2 * M, D)
-        tpg_ln = self.stpg if self.strip else self.tpg
-        self.ln1_part = [f(2 * tpg_ln, 2, D) for _ in range(2)]
-        self.ln2_part = [f(2 * tpg_ln, 2, D) for _ in range(2)]
-        # the train step's own backward walks the LIVE sequences only (engine._own_rows): half the rows, re-tiled over the CUs
-        # (csrc/sasrec_bwd.hip TileGeomB::row_domain); its LayerNorm partials have their own slots and reduce table
-        self.live_rows = bool(self.LIVE_ROWS_BWD)
-        if self.live_rows and self.strip:          # the strip kernels tile live and all rows alike: same partial slots, same reduce table
-            self.ln1_part_v, self.ln2_part_v = self.ln1_part, self.ln2_part
-        elif self.live_rows:
-            self.rpt_v = L.value("amid_rows_per_tile", (M + 1) // 2)
-            self.tpg_v = (M + self.rpt_v - 1) // self.rpt_v
-            self.rt_suffix_v = (("_rt3" if self.rpt_v <= 48 else "_rt4" if self.rpt_v <= 64 else "_rt5" if self.rpt_v <= 80 else "")
-                                if eng.SHORT_TILE_BUILDS else "")
-            self.ln1_part_v = [f(2 * self.tpg_v, 2, D) for _ in range(2)]
-            self.ln2_part_v = [f(2 * self.tpg_v, 2, D) for _ in range(2)]
-        # the fused per-sequence backward (csrc/sasrec_strip.hip seq_bwd_kernel) tiles one live sequence per workgroup: its LayerNorm
-        # partials have a slot per sequence and their own reduce table
-        self.seq_bwd = bool(self.strip and self.live_rows and getattr(eng, "SEQ_BACKWARD", "0") not in ("0", False) and not inc
-                            and L.value("amid_sas_seq_bwd_supported", B, shp.Tenc, D, H))
-        if self.seq_bwd:
-            self.ln1_part_s = [f(2 * B, 2, D) for _ in range(2)]
-            self.ln2_part_s = [f(2 * B, 2, D) for _ in range(2)]
-        self.last_part = f(2 * B, 2, D)
-        self._alloc_model_bwd(eng, f)
-        self.sc_P = L.value("amid_scorer_part_floats", D, hid)
-        self.sc_part = f(B, self.sc_P)
-        if dr:
-            self.sc_part_ips, self.sc_part_g = f(B, self.sc_P), f(B, self.sc_P)
-        # sparse side
-        self.sort_ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", N), dtype=torch.uint8, device=dev)
-        self.pos_sorted = torch.zeros(N, dtype=torch.int32, device=dev)
-        self.uniq_ids = torch.zeros(N, dtype=torch.int32, device=dev)
-        self.seg_off = torch.zeros(N + 1, dtype=torch.int32, device=dev)
-        self.seg_of = torch.zeros(N, dtype=torch.int32, device=dev)
-        self.n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", N, D), dtype=torch.uint8, device=dev)
-        self.uniq_grad = f(N, D)
-        self.red_entries, self.red_n, self.red_max = self._build_reduce_table(eng)
-        if self.live_rows and self.strip:
-            self.red_entries_v, self.red_n_v, self.red_max_v = self.red_entries, self.red_n, self.red_max
-        elif self.live_rows:
-            self.red_entries_v, self.red_n_v, self.red_max_v = self._build_reduce_table(eng, live=True)
-        if self.seq_bwd:
-            self.red_entries_s, self.red_n_s, self.red_max_s = self._build_reduce_table(eng, live=True, seq=True)
-        self.graph = None
-        self.graphs = {}
-
-    # ---- model-specific pieces (BertPlan overrides these three) -------------------------------------
-    def _alloc_model_fwd(self, eng: "SasrecEngine", f) -> None:
-        M, D = self.shape.M, eng.D
-        self.tmq = torch.zeros(2 * M, D // 4, dtype=torch.uint8, device=eng.device)
-        self.qn = [f(2 * M, D) for _ in range(2)]
-        self.r = [f(2 * M, D) for _ in range(2)]
-        self.y = [f(2 * M, D) for _ in range(2)]
-        self.h = [f(2 * M, D) for _ in range(2)]
-
-    def _alloc_model_bwd(self, eng: "SasrecEngine", f) -> None:
-        M, D, B, T = self.shape.M, eng.D, self.shape.B, self.shape.Tenc
-        # per LAYER copies of the six dY tensors of the weight gradients: both layers' weight gradients run as one launch at the
-        # end of backward (2 layers x 2 domains x 6 weights x 21 splits = 504 workgroups, two per CU)
-        self.dpre1, self.dpre2, self.dr = ([f(2 * M, D), f(2 * M, D)] for _ in range(3))
-        self.dq_l, self.dk_l, self.dv_l = [self.dq, f(2 * M, D)], [self.dk, f(2 * M, D)], [self.dv, f(2 * M, D)]
-        self.splits = max(1, min(21, M // 128))
-        self.w_part = [f(2, 6, self.splits, D * D) for _ in range(2)]
-        self.b_part = [f(2, 6, self.splits, D) for _ in range(2)]
-        self.pos_splits = max(1, min(8, B // 16))
-        self.dpos_part = f(self.pos_splits, 2, T, D)
-
-    LIVE_ROWS_BWD = True       # BertPlan: False (its backward kernels take no row_domain hint)
-
-    def _build_reduce_table(self, eng: "SasrecEngine", live: bool = False, seq: bool = False):
-        L = lib()
-        D, hid, B = eng.D, eng.hid, self.shape.B
-        fp, G = eng.dense, eng.dense.grad
-        ent: List[Tuple[int, int, int, int, int]] = []      # src_ptr, dst_ptr, stride, n_part, count
-
-        def add(src_t: torch.Tensor, src_off: int, dst_ptr: int, stride: int, n_part: int, count: int):
-            ent.append((src_t.data_ptr() + 4 * src_off, dst_ptr, stride, n_part, count))
-
-        if seq:
-            self._model_reduce_entries(eng, add, seq=True)
-        elif live:
-            self._model_reduce_entries(eng, add, live=True)
-        else:
-            self._model_reduce_entries(eng, add)
-        P = self.sc_P
-        heads = [("predictModule", self.sc_part)]
-        if getattr(eng, "dr", False):
-            heads += [("predict_ips", self.sc_part_ips), ("predict_gfunc", self.sc_part_g)]
-            for c in range(3):                                                           # loss_cls, loss_dr_e, loss_dr_r
-                ent.append((self.dr_loss_part.data_ptr() + 4 * c, self.dr_losses.data_ptr() + 4 * c, 3, B, 1))
-        else:
-            ent.append((self.loss_part.data_ptr(), self.loss.data_ptr(), 1, B, 1))      # loss = sum of the per-row partials
-        for head, part in heads:
-            add(part, 0, fp.ptr(f"{head}.fc.0.weight", G), P, B, hid * 2 * D)
-            add(part, hid * 2 * D, fp.ptr(f"{head}.fc.0.bias", G), P, B, hid)
-            add(part, hid * 2 * D + hid, fp.ptr(f"{head}.fc.2.weight", G), P, B, hid)
-            add(part, hid * 2 * D + 2 * hid, fp.ptr(f"{head}.fc.2.bias", G), P, B, 1)
-        # the blocks of an entry with many partials (the head's per-row partials: one per batch row) run the longest chains of
-        # dependent loads: dispatch them first, so that they do not form the tail of the launch
-        ent.sort(key=lambda e: -e[3])
-        # algorithmic HBM bytes of the partial-sum reduce (every partial read once, every sum written once): bench.py prices the launch
-        sfx = "_s" if seq else "_v" if live else ""
-        setattr(self, "red_bytes" + sfx, sum(4 * (n + 1) * c for *_, n, c in ent))
-        esz = L.value("amid_reduce_entry_bytes")
-        host = (ctypes.c_ubyte * (esz * len(ent)))()
-        for i, (s, d, st, n, c) in enumerate(ent):
-            L.call("amid_reduce_entry_pack", ctypes.addressof(host), i, s, d, st, n, c)
-        # blocks per entry for the gradient tail (amid_grad_tail_f32 blk_off): what the entry's size needs -- 1024 elements per block
-        # when it has at most 32 aligned partials (csrc/reduce_partials.h), 128 otherwise
-        off = [0]
-        for s, d, st, n, c in ent:
-            per = 1024 if (n <= 32 and c % 4 == 0 and st % 4 == 0 and s % 16 == 0 and d % 16 == 0) else 128
-            off.append(off[-1] + min(512, (c + per - 1) // per))
-        blk = torch.tensor(off, dtype=torch.int32).to(eng.device)
-        setattr(self, "red_blk" + sfx, (blk, off[-1]))
-        return torch.frombuffer(bytearray(host), dtype=torch.uint8).to(eng.device), len(ent), max(c for *_, c in ent)
-
-    def _model_reduce_entries(self, eng: "SasrecEngine", add, live: bool = False, seq: bool = False) -> None:
-        D, B = eng.D, self.shape.B
-        fp, G = eng.dense, eng.dense.grad
-        S = self.splits
-        ln1, ln2, tpg = (self.ln1_part_v, self.ln2_part_v, self.tpg_v) if live else (self.ln1_part, self.ln2_part, self.tpg)
-        if getattr(self, "strip", False):
-            tpg = self.stpg
-        if seq:             # one slot per sequence and domain (amid_sas_seq_bwd_f32)
-            ln1, ln2, tpg = self.ln1_part_s, self.ln2_part_s, B
-        for l in (0, 1):
-            for g in (0, 1):
-                pre = f"sac{g + 1}"
-                wbase = lambda w: ((g * 6 + w) * S) * D * D      # noqa: E731
-                bbase = lambda w: ((g * 6 + w) * S) * D          # noqa: E731
-                for j in range(3):
-                    add(self.w_part[l], wbase(j), fp.ptr(f"{pre}.attention_layers.{l}.in_proj_weight", G, j * D * D), D * D, S, D * D)
-                    add(self.b_part[l], bbase(j), fp.ptr(f"{pre}.attention_layers.{l}.in_proj_bias", G, j * D), D, S, D)
-                add(self.w_part[l], wbase(3), fp.ptr(f"{pre}.attention_layers.{l}.out_proj.weight", G), D * D, S, D * D)
-                add(self.b_part[l], bbase(3), fp.ptr(f"{pre}.attention_layers.{l}.out_proj.bias", G), D, S, D)
-                add(self.w_part[l], wbase(4), fp.ptr(f"{pre}.forward_layers.{l}.conv1.weight", G), D * D, S, D * D)
-                add(self.b_part[l], bbase(4), fp.ptr(f"{pre}.forward_layers.{l}.conv1.bias", G), D, S, D)
-                add(self.w_part[l], wbase(5), fp.ptr(f"{pre}.forward_layers.{l}.conv2.weight", G), D * D, S, D * D)
-                add(self.b_part[l], bbase(5), fp.ptr(f"{pre}.forward_layers.{l}.conv2.bias", G), D, S, D)
-                tb = g * tpg * 2 * D
-                add(ln1[l], tb, fp.ptr(f"{pre}.attention_layernorms.{l}.weight", G), 2 * D, tpg, D)
-                add(ln1[l], tb + D, fp.ptr(f"{pre}.attention_layernorms.{l}.bias", G), 2 * D, tpg, D)
-                add(ln2[l], tb, fp.ptr(f"{pre}.forward_layernorms.{l}.weight", G), 2 * D, tpg, D)
-                add(ln2[l], tb + D, fp.ptr(f"{pre}.forward_layernorms.{l}.bias", G), 2 * D, tpg, D)
-        for g in (0, 1):
-            pre = f"sac{g + 1}"
-            add(self.last_part, g * B * 2 * D, fp.ptr(f"{pre}.last_layernorm.weight", G), 2 * D, B, D)
-            add(self.last_part, g * B * 2 * D + D, fp.ptr(f"{pre}.last_layernorm.bias", G), 2 * D, B, D)
-        T = self.shape.Tenc
-        for g in (0, 1):
-            add(self.dpos_part, g * T * D, fp.ptr(f"sac{g + 1}.pos_emb.weight", G), 2 * T * D, self.pos_splits, T * D)
-
-
-class SasrecEngine:
+class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     """Parameters, optimizer state and launch sequences for SASRec (isInC = isItC = isDR = False)."""
 
     HEADS = SASREC_HEADS
     PLAN_CLS = SasrecPlan
     EMB_DIMS = (64, 128)
+    # ---- path switches (class attributes so that tests and the A/B tools can force a path; production never touches them) -----------
+    #   STRIP_KERNELS / BF16_STRIP   the encoder on the register-resident strip kernels (fp32 / compute = "bf16")          [here]
+    #   SEQ_FORWARD, LIVE_FORWARD    the forward as ONE launch; over the live sequences only in a train step            [at _live_list]
+    #   SEQ_BACKWARD                 the backward's data gradients as ONE launch ("auto": n_CU < B <= 2 n_CU)          [at _seq_backward]
+    #   FUSED_HEAD                   head forward + backward as one launch                                              [at _enqueue_fwd_bwd]
+    #   SORT_RIDERS                  the step's index sort as extra workgroups of five main-stream launches             [at enqueue_sort]
+    #   COMPACT_LIVE, COMPACT_MIN_IDX  the sparse side on the live sequences' positions only, for long index lists      [at live_forward_ok]
+    #   DENSE_EXCHANGE               how the dense gradient crosses the ranks (engine_dp.DataParallelMixin)
     SHORT_TILE_BUILDS = False    # (BERT4Rec's row-tile kernels also exist as *_rt3 / *_rt4 / *_rt5: 48- / 64- / 80-row tiles, csrc/Makefile)
     STRIP_KERNELS = True         # fp32: the layer's GEMM chains run as register-resident strip kernels (csrc/sasrec_strip.hip)
     BF16_STRIP = os.environ.get("AMID_BF16_STRIP", "1") != "0"      # compute = "bf16" on the strip path (the forward's products in bf16)
@@ -431,7 +86,7 @@ class SasrecEngine:
         # every kernel of the engine runs on this (non-default, hence capturable) HIP stream
         self.stream = torch.cuda.Stream(device=self.device)
         # the index sort only feeds the segment reduce after backward: it runs on this side stream, beside the forward pass
-        self.side = self.stream if os.environ.get("AMID_SORT_SERIAL") else torch.cuda.Stream(device=self.device)
+        self.side = torch.cuda.Stream(device=self.device)
         self.ev_idx = torch.cuda.Event()
         self.ev_sorted = torch.cuda.Event()
         self.n_rows, self.D, self.T, self.hid, self.H = int(item_length), int(emb_dim), int(seq_len), int(hid_dim), self.HEADS
@@ -544,98 +199,20 @@ class SasrecEngine:
         return c
 
     def _wT(self, layer: int, which: int):
-        key = ("wT", layer, which)
+        """Host array (domain 0, domain 1) of the transposed projection weight `which` (q, k, v, o, c1, c2) of `layer`: fp32 transposes,
+        or -- pl.strip with compute = "bf16" -- their bf16 fragment images (amid_sas_weights_bf16, refreshed by enqueue_backward)."""
+        bf = self._bf16_bwd
+        key = ("wT16" if bf else "wT", layer, which)
         c = self._ptr_cache.get(key)
         if c is None:
-            c = ptr_array([self.wT[layer, g, which].data_ptr() for g in (0, 1)])
+            buf = self.wT16 if bf else self.wT
+            c = ptr_array([buf[layer, g, which].data_ptr() for g in (0, 1)])
             self._ptr_cache[key] = c
         return c
 
+    _bf16_bwd = False          # set per backward: the strip backward's products take bf16 images (compute = "bf16" on the strip path)
+
     # ------------------------------------------------------------------ launch sequences
-    def load_batch(self, pl: SasrecPlan, i_node, neg_samples, seq_d1, seq_d2, labels=None, domain_id=None, ob_label=None) -> None:
-        """Copy a batch into the plan's static input buffers (async on the engine stream)."""
-        if self.input_pool(pl) is not None:
-            raise RuntimeError("this plan reads its batches from an installed input pool (set_input_pool); drop the pool before loading single batches")
-        with torch.cuda.stream(self.stream):
-            pl.in_i_node.copy_(i_node.reshape(-1), non_blocking=True)
-            pl.in_neg.copy_(neg_samples.reshape(pl.shape.B, -1), non_blocking=True)
-            pl.in_seq_d1.copy_(seq_d1, non_blocking=True)
-            pl.in_seq_d2.copy_(seq_d2, non_blocking=True)
-            if labels is not None:
-                pl.labels.copy_(labels.reshape(pl.shape.B, -1), non_blocking=True)
-                pl.domain.copy_(domain_id.reshape(-1), non_blocking=True)
-            if ob_label is not None:
-                pl.in_ob.copy_(ob_label.reshape(-1), non_blocking=True)
-
-    def pack_batch(self, pl: SasrecPlan, i_node, neg_samples, seq_d1, seq_d2, labels, domain_id) -> torch.Tensor:
-        """Pre-pack a batch into the plan's input layout (one contiguous int64 tensor) for load_packed()."""
-        B, NI = pl.shape.B, pl.shape.NI
-        lab = torch.zeros(2 * ((B * NI + 1) // 2), dtype=torch.float32, device=labels.device)
-        lab[: B * NI] = labels.reshape(-1).float()
-        return torch.cat((i_node.reshape(-1).long(), neg_samples.reshape(-1).long(), seq_d1.reshape(-1).long(), seq_d2.reshape(-1).long(),
-                          domain_id.reshape(-1).long(), lab.view(torch.int64))).contiguous()
-
-    def pack_epoch(self, pl: SasrecPlan, i_node, neg_samples, seq_d1, seq_d2, labels, domain_id, ob_label=None) -> torch.Tensor:
-        """pack_batch() for n batches at once: i_node [n, B], neg_samples [n, B, NI-1], seq_d* [n, B, T], domain_id [n, B] (ob_label
-        [n, B] for isDR plans), labels [B, NI] shared by every batch (dataset_seq.py:191,199) -> [n, in_words] int64, the layout
-        set_input_pool() takes.  A handful of device ops for a whole epoch instead of four copies per step."""
-        B, NI = pl.shape.B, pl.shape.NI
-        n = i_node.shape[0]
-        lab = torch.zeros(2 * ((B * NI + 1) // 2), dtype=torch.float32, device=i_node.device)
-        lab[: B * NI] = labels.reshape(-1).float()
-        parts = [i_node.reshape(n, -1).long(), neg_samples.reshape(n, -1).long(), seq_d1.reshape(n, -1).long(), seq_d2.reshape(n, -1).long(),
-                 domain_id.reshape(n, -1).long(), lab.view(torch.int64).unsqueeze(0).expand(n, -1)]
-        if pl.in_ob is not None:
-            parts.append((ob_label if ob_label is not None else torch.zeros_like(domain_id)).reshape(n, -1).long())
-        out = torch.cat(parts, 1).contiguous()
-        if out.shape[1] != pl.in_words:
-            raise ValueError(f"packed row has {out.shape[1]} words, the plan expects {pl.in_words}")
-        return out
-
-    def set_input_pool(self, pl: SasrecPlan, pool: Optional[torch.Tensor]) -> None:
-        """Make `pool` ([n_pool, in_words] int64, rows = pack_batch() images, resident in HBM) the plan's input: every following
-        train step consumes the next row, chosen ON THE DEVICE by the step counter, so the replayed graph needs no per-step input
-        copy (train_sr.py:185-199 moves each batch inside the loop).  None returns to load_batch()/load_packed().  Graphs of the
-        plan are re-captured."""
-        key = self._graph_key()                       # like the graphs, a pool belongs to (Adam state, objective): the DR trainer's
-        if pool is not None:                          # two loops each keep their own (train_sr_dr.py:191-229 / :363-402)
-            if pool.dtype != torch.int64 or pool.dim() != 2 or pool.shape[1] != pl.in_words or pool.stride(1) != 1 \
-                    or pool.device != pl.in_pack.device:
-                raise ValueError(f"input pool must be a device int64 [n, {pl.in_words}] tensor with contiguous rows")
-            pl.pools[key] = [pool, (-self.step) % pool.shape[0]]
-        else:
-            pl.pools.pop(key, None)
-        torch.cuda.synchronize(self.device)
-        if getattr(pl, "graphs", None):               # the pool pointer is baked into captured launches
-            pl.graphs.pop(key, None)
-        if getattr(pl, "graphs_n", None):
-            for k in [k for k in pl.graphs_n if k[0] == key]:
-                pl.graphs_n.pop(k)
-        if getattr(pl, "dp_graphs", None):
-            pl.dp_graphs.clear()
-        pl.graph_local = None
-
-    def input_pool(self, pl: SasrecPlan):
-        """[pool, phase] installed for the current (Adam state, objective), or None."""
-        return pl.pools.get(self._graph_key()) if getattr(pl, "pools", None) else None
-
-    def refill_input_pool(self, pl: SasrecPlan, pool: torch.Tensor) -> bool:
-        """Overwrite the installed pool's contents with `pool` (next epoch) keeping every captured graph; possible when the shape is
-        unchanged and the step counter sits on a pool boundary (the phase baked into the captured launch still holds).  False:
-        the caller installs the new pool with set_input_pool()."""
-        ent = self.input_pool(pl)
-        if ent is None or ent[0].shape != pool.shape or (-self.step) % pool.shape[0] != ent[1]:
-            return False
-        with torch.cuda.stream(self.stream):
-            ent[0].copy_(pool, non_blocking=True)
-        return True
-
-    def load_packed(self, pl: SasrecPlan, packed: torch.Tensor) -> None:
-        if self.input_pool(pl) is not None:
-            raise RuntimeError("this plan reads its batches from an installed input pool (set_input_pool); drop the pool before loading single batches")
-        with torch.cuda.stream(self.stream):
-            pl.in_pack.copy_(packed, non_blocking=True)
-
     def enqueue_prepare(self, pl: SasrecPlan, sparse: bool, bump_step: bool = False, defer_sort: bool = False) -> None:
         """defer_sort: only mark the fork point; the caller launches the sort with enqueue_sort() AFTER the main stream's next
         kernel.  (In the captured graph the branch that is enqueued first is dispatched first: with the sort ahead of the catch-up
@@ -801,7 +378,7 @@ class SasrecEngine:
             L.call("amid_embed_fwd_live_compact_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"),
                    fp.ptr("sac2.pos_emb.weight"), B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, lf,
                    pl.idx_c.data_ptr(), pl.row_c.data_ptr(), s)
-            if self.SORT_FORK == "catchup" and getattr(self, "_sort_owed", False):
+            if getattr(self, "_sort_owed", False):
                 self.ev_idx.record(self.stream)
                 self.enqueue_sort(pl)
         elif live_fwd:
@@ -1017,6 +594,14 @@ class SasrecEngine:
                 src.append(fp.ptr(f"{pre}.forward_layers.{l}.conv1.weight"))
                 src.append(fp.ptr(f"{pre}.forward_layers.{l}.conv2.weight"))
                 dst += [self.wT[l, g, w].data_ptr() for w in range(6)]
+        # compute = "bf16" on the strip path: the strip backward's data-gradient products take bf16 fragment images of the transposed weights
+        # (the fp32 transposes are still refreshed: the row-tile fallbacks and tests read them)
+        self._bf16_bwd = bool(self.compute == "bf16" and pl.strip)
+        bf = 1 if self._bf16_bwd else 0
+        if self._bf16_bwd:
+            if not hasattr(self, "wT16"):
+                self.wT16 = torch.empty(2, 2, 6, D * D, dtype=torch.bfloat16, device=self.device)
+            L.call("amid_sas_weights_bf16", ptr_array(src), len(src), D, 1, self.wT16.data_ptr(), s)
         items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
         ditems = pl.dxg.data_ptr() + 4 * 2 * shp.Mi * D
         if (self.dr or self.itc_bs) and getattr(self, "_fuse_scorers", False):
@@ -1067,11 +652,11 @@ class SasrecEngine:
         if seq:
             # the five launches below as one workgroup-long chain per live sequence
             pa = lambda ts: ptr_array([t.data_ptr() for t in ts])          # noqa: E731
-            key = ("seq_bwd", id(pl))
+            key = ("seq_bwd", id(pl), bf)
             c = self._ptr_cache.get(key)
             if c is None:
                 def wts(which):
-                    return ptr_array([self.wT[l, g, which].data_ptr() for l in (0, 1) for g in (0, 1)])
+                    return ptr_array([(self.wT16 if bf else self.wT)[l, g, which].data_ptr() for l in (0, 1) for g in (0, 1)])
                 def lnw(fmt):
                     return ptr_array([fp.ptr(fmt.format(d=g + 1, l=l)) for l in (0, 1) for g in (0, 1)])
                 c = dict(h=pa(pl.h), r=pa(pl.r), x=pa(pl.x[:2]), q=pa(pl.q), k=pa(pl.k), v=pa(pl.v), o=pa(pl.o), stats=pa(pl.stats),
@@ -1081,7 +666,7 @@ class SasrecEngine:
                 self._ptr_cache[key] = c
             L.call("amid_sas_seq_bwd_f32", 2, pl.dxbuf.data_ptr(), tm, c["h"], c["r"], c["x"], c["q"], c["k"], c["v"], c["o"], c["stats"],
                    c["ln1"], c["ln2"], c["wq"], c["wk"], c["wv"], c["wo"], c["w1"], c["w2"], SASREC_LN_EPS, B, T, D, self.H, lv, st, tr,
-                   SASREC_P_DROP, c["dpre2"], c["dpre1"], c["dr"], pl.d_o.data_ptr(), c["dq"], c["dk"], c["dv"], dx_in, c["ln1p"], c["ln2p"], s)
+                   SASREC_P_DROP, c["dpre2"], c["dpre1"], c["dr"], pl.d_o.data_ptr(), c["dq"], c["dk"], c["dv"], dx_in, c["ln1p"], c["ln2p"], bf, s)
         elif pl.strip:
             ln1p, ln2p = pl.ln1_part, pl.ln2_part
             # a train step's index sort rides in these three launches (phases 2, 3, 4; phase 1 rode in the catch-up launch)
@@ -1090,18 +675,18 @@ class SasrecEngine:
             ride = lambda ph: (self._sort_plan(pl), ph) if riding else ()      # noqa: E731
             L.call(f"amid_sas_strip_ffn_bwd{sfx}_f32", pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, B, T, D, lv, 1, st, tr,
                    SASREC_P_DROP, pl.dpre2[1].data_ptr(), pl.dpre1[1].data_ptr(), pl.dr[1].data_ptr(), pl.d_o.data_ptr(), ln2p[1].data_ptr(),
-                   *ride(2), s)
+                   *ride(2), bf, s)
             attn_bwd(1)
             # layer 1's q / k / v + LayerNorm1 backward and layer 0's feed-forward / out-projection backward: one launch
             L.call(f"amid_sas_strip_qkv_bwd{sfx}_f32", pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
                    pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
                    SASREC_LN_EPS, B, T, D, lv, None, ln1p[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr, SASREC_P_DROP,
-                   pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(), ln2p[0].data_ptr(), *ride(3), s)
+                   pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(), ln2p[0].data_ptr(), *ride(3), bf, s)
             attn_bwd(0)
             L.call(f"amid_sas_strip_qkv_bwd{sfx}_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
                    pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
                    SASREC_LN_EPS, B, T, D, lv, dx_in, ln1p[0].data_ptr(), None, None, None, None, None, None, None, 0, None, 0, 0.0, None,
-                   None, None, None, None, *ride(4), s)
+                   None, None, None, None, *ride(4), bf, s)
         else:
             rows, suf, rpt = ("_rows", pl.rt_suffix_v, pl.rpt_v) if live else ("", pl.rt_suffix, pl.rpt)
             ln1p, ln2p = (pl.ln1_part_v, pl.ln2_part_v) if live else (pl.ln1_part, pl.ln2_part)
@@ -1126,7 +711,6 @@ class SasrecEngine:
                    pl.dpre2[l].data_ptr()]
             xx += [pl.qn[l].data_ptr(), pl.x[l].data_ptr(), pl.x[l].data_ptr(), pl.o[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr()]
         # NOTE: pl.x[0] is the gathered-row buffer xg, still intact here (its gradient lives in dxg)
-        self._fork_sort(pl, "wgrad")
         L.call("amid_sas_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
                ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), self._own_rows(pl), B, T, s)
         if getattr(pl, "riding", False):     # the last phase of the step's index sort (run heads) rides here
@@ -1188,20 +772,6 @@ class SasrecEngine:
                self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), ids.data_ptr(),
                nu.data_ptr(), cap, rows.data_ptr(), self.D, self.grad_scale, self.step_state.data_ptr(), s)
 
-    def enqueue_optimizer_gathered(self, be: "HipMergeBackend", recv: torch.Tensor, world: int, umax: int, dense_in_chunk: bool = True) -> None:
-        """The data-parallel optimizer: ONE launch over the world's gathered chunks (ids | rows | dense gradient per rank) -- the
-        rank-ordered sums of the dense parts and of the rows of equal ids happen inside it (amid_optimizer_step_gathered_f32), so
-        the step needs no merge / segment-reduce launches after the all-gather.  dense_in_chunk=False: the chunks hold ids | rows
-        only and dense.grad already is the world's sum (the caller's all-reduce)."""
-        from .dist import packed_rows
-        self._ensure_opt_state()
-        fp, D = self.dense, self.D
-        id_rows, rows = packed_rows(umax, D)
-        lib().call("amid_optimizer_step_gathered_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel,
-                   self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), recv.data_ptr(),
-                   world, umax, be.chunk_rows(umax, fp.grad if dense_in_chunk else None) * D, id_rows, rows * D if dense_in_chunk else -1, D,
-                   self.n_rows, self.grad_scale, self.step_state.data_ptr(), self.s)
-
     def enqueue_step_begin(self) -> None:
         lib().call("amid_step_begin", self.step_state.data_ptr(), self.s)
         self.step += 1
@@ -1222,17 +792,12 @@ class SasrecEngine:
         self._fork_sort(pl)
         self._enqueue_fwd_bwd(pl)
 
-    # where the side-stream sort of a train step starts (the gradient tail joins it): "catchup" = beside the forward, "forward" =
-    # when the forward has finished, "wgrad" = beside the weight-gradient launch
-    SORT_FORK = os.environ.get("AMID_SORT_FORK", "catchup")
-
-    def _fork_sort(self, pl: SasrecPlan, at: str = "catchup") -> None:
-        """Start the side-stream sort if `at` is this engine's fork point."""
-        if at == "catchup" and getattr(pl, "compact", False):
+    def _fork_sort(self, pl: SasrecPlan) -> None:
+        """Start the side-stream sort behind the catch-up launch, beside the forward (forks behind the forward or beside the weight
+        gradients were measured and lost: DESIGN.md section 5)."""
+        if getattr(pl, "compact", False):
             return                                    # the compact index list is K1's by-product: enqueue_forward forks behind K1
-        if self.SORT_FORK == at and getattr(self, "_sort_owed", False):
-            if at != "catchup":
-                self.ev_idx.record(self.stream)       # the side stream starts when the main stream's work so far has finished
+        if getattr(self, "_sort_owed", False):
             self.enqueue_sort(pl)
 
     FUSED_HEAD = True          # the plain SASRec head (no isItC / isDR) can run forward + backward as one launch
@@ -1251,7 +816,6 @@ class SasrecEngine:
         self._live_fwd = self._own_domain_only and self._fuse_head and self.live_forward_ok(pl)
         try:
             self.enqueue_forward(pl, train=True, with_loss=True, sum_loss=False)
-            self._fork_sort(pl, "forward")
             self.enqueue_backward(pl, train=True)
         finally:
             self._fuse_head = self._fuse_scorers = self._own_domain_only = self._live_fwd = False
@@ -1269,187 +833,6 @@ class SasrecEngine:
         _enqueue_fwd_bwd), else None: a backward driven by someone else's loss (the autograd path) makes no such promise."""
         return pl.domain.data_ptr() if getattr(self, "_own_domain_only", False) else None
 
-    def capture_local_grads(self, pl: SasrecPlan) -> None:
-        L = lib()
-        self._ensure_opt_state()
-        saved = self.snapshot()
-        self.enqueue_local_grads(pl)
-        self.sync()
-        self.restore(saved)
-        self.sync()
-        step0 = self.step
-        L.call("amid_graph_capture_begin", self.s)
-        try:
-            self.enqueue_local_grads(pl)
-        finally:
-            out = ctypes.c_void_p()
-            L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
-        self.step = step0
-        pl.graph_local = out.value
-
-    # How the 1.7 MB flat dense gradient crosses the ranks in the graph-pair step: "gather" = behind the sparse rows inside the step's ONE
-    # all-gather (every rank sums the world's copies in rank order: one collective's latency, world x 1.7 MB received per rank);
-    # "allreduce" = its own RCCL all-reduce next to the all-gather of the sparse rows (two collectives, ~2 x 1.7 MB on the wire per
-    # rank whatever the world size) -- what BASELINE.json's north_star words ("RCCL all-reduce of dense parameter grads").  Both are
-    # bit-identical across replicas; bench.py --dense-exchange measures either.
-    DENSE_EXCHANGE = os.environ.get("AMID_DENSE_EXCHANGE", "gather")
-
-    def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False, umax: Optional[int] = None, dense: Optional[str] = None) -> None:
-        """One data-parallel step: local grads -> dense all-reduce + ONE sparse all-gather -> merge -> Adam.
-        umax: a bound on the world's largest unique-row count of this step if the host knows one (no host sync then, see
-        dist.py) -- it MUST cover every rank's count: a step that finds more raises AMID_FLAG_UMAX_EXCEEDED in the plan's error word
-        (check_index_error).  With use_graph and a known umax the step is graph A (local gradients + packing of this rank's chunk: ids,
-        rows and, with dense="gather", the flat dense gradient behind them), the collective(s), graph B (rank-ordered sum of the dense
-        parts, merge of the sparse parts, Adam): three or four host calls, and replicas that are bit-identical by construction; the
-        pair of graphs is captured per distinct (umax, dense), so callers should pass a bucketed bound (bench.py: the pool's maximum).
-        dense: "gather" | "allreduce" (default: DENSE_EXCHANGE)."""
-        if (self.itc_bs or self.inc_bs) and exchange.active:
-            raise NotImplementedError("isItC / isInC couple the rows of a batch (softmax and Linear(bs, 1) over the batch, "
-                                      "model_seq.py:465-469, :490-494): data-parallel sharding would change the model; train them on one GPU")
-        dense = dense or self.DENSE_EXCHANGE
-        if dense not in ("gather", "allreduce"):
-            raise ValueError(f"dense exchange must be 'gather' or 'allreduce', got {dense!r}")
-        L = lib()
-        if umax is not None:                   # a caller's bound may be rounded up past the plan's index count (e.g. to a multiple of 256):
-            umax = max(1, min(int(umax), self.n_sparse_train(pl)))      # clamp BEFORE it keys the captured graph pair (as dist.exchange_sparse does)
-        with torch.cuda.stream(self.stream):
-            self.grad_scale = exchange.grad_scale
-            fast = (use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")
-                    and not exchange.use_owner(umax, self.D))      # the owner-bucketed exchange sizes its buffers per step: eager
-            pair = getattr(pl, "dp_graphs", {}).get((umax, dense)) if fast else None
-            if pair is not None:       # graph A, the collective(s), graph B
-                L.call("amid_graph_launch", pair[0], self.s)
-                self.step += 1
-                exchange.all_gather_packed(pair[2], pair[3])
-                if dense == "allreduce":
-                    exchange.all_reduce_dense(self.dense.grad)
-                L.call("amid_graph_launch", pair[1], self.s)
-                return
-            if use_graph:
-                L.call("amid_graph_launch", pl.graph_local, self.s)
-                self.step += 1
-            else:
-                self.enqueue_local_grads(pl)
-            exchange.all_reduce_dense(self.dense.grad)
-            merged = exchange.exchange_sparse(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax=umax)
-            self.enqueue_optimizer(pl, sparse=merged if exchange.active else None)
-        if fast:                               # this step ran eagerly (it also warmed every kernel up); capture the pair for the next ones
-            self._capture_dp_pair(pl, exchange, int(umax), dense)
-
-    def _capture_dp_pair(self, pl: SasrecPlan, exchange, umax: int, dense: str = "gather") -> None:
-        L, be = lib(), exchange.backend
-        self.sync()
-        if int(pl.n_uniq.item()) > umax:       # the eager step just ran with this bound: a bound that is already too small never gets captured
-            raise ValueError(f"train_step_dp: umax = {umax} is smaller than this step's {int(pl.n_uniq.item())} unique rows")
-        step0 = self.step
-        in_chunk = dense == "gather"
-        dgrad = self.dense.grad if in_chunk else None
-        be.gather_buffer(exchange.world, umax, dense=dgrad)   # capacity errors are raised here, not in the middle of a stream capture
-        if in_chunk:
-            be.prepare_dense(exchange.world, umax, self.dense.grad)      # device tables are built here, not under capture
-        graphs = []
-        for part in (0, 1):
-            L.call("amid_graph_capture_begin", self.s)
-            try:
-                if part == 0:          # the tail of backward packs the chunk itself: no padding launch (amid_grad_tail_pack_f32)
-                    send = be.send[: be.chunk_rows(umax, dgrad) * self.D]
-                    self._tail_pack = (send, umax, in_chunk)
-                    try:
-                        self.enqueue_local_grads(pl)
-                    finally:
-                        self._tail_pack = None
-                else:
-                    recv = be.gather_buffer(exchange.world, umax, dense=dgrad)
-                    self.enqueue_optimizer_gathered(be, recv, exchange.world, umax, dense_in_chunk=in_chunk)
-            finally:
-                out = ctypes.c_void_p()
-                L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
-            graphs.append(out.value)
-        self.step = step0                      # capture does not execute
-        if not hasattr(pl, "dp_graphs"):
-            pl.dp_graphs = {}
-        pl.dp_graphs[(umax, dense)] = (graphs[0], graphs[1], send, recv)
-
-    # ------------------------------------------------------------------ graph replay
-    def capture_train_step(self, pl: SasrecPlan) -> None:
-        """Capture one train step into a hipGraph (inputs = the plan's static buffers)."""
-        L = lib()
-        self._ensure_opt_state()
-        # warm-up outside capture: sets the dynamic-LDS attributes, pages code objects in
-        saved = self.snapshot()
-        self.enqueue_train_step(pl)
-        self.sync()
-        self.restore(saved)
-        self.sync()
-        s = self.s
-        step0 = self.step
-        L.call("amid_graph_capture_begin", s)
-        try:
-            self.enqueue_train_step(pl)
-        finally:
-            out = ctypes.c_void_p()
-            L.call("amid_graph_capture_end", s, ctypes.byref(out))
-        self.step = step0          # capture does not execute; the device counter did not move
-        if not hasattr(pl, "graphs"):
-            pl.graphs = {}
-        pl.graphs[self._graph_key()] = out.value       # the Adam state's buffers and the DR objective are baked into a graph
-        pl.graph = pl.graphs.get((0, 0), out.value)
-
-    def capture_train_steps(self, pl: SasrecPlan, n_steps: int) -> None:
-        """n_steps consecutive train steps as ONE hipGraph (replay_train_steps).  Only with an input pool: every step's first kernel
-        picks its batch by the device step counter, so the steps of a graph see consecutive batches; a replayed graph costs ~8 us of
-        idle device time between two launches, which a graph of several steps pays once."""
-        if self.input_pool(pl) is None:
-            raise ValueError("a graph of several train steps needs an input pool (set_input_pool)")
-        L = lib()
-        if not self.has_graph(pl):
-            self.capture_train_step(pl)              # (also the warm-up outside capture)
-        s, step0 = self.s, self.step
-        L.call("amid_graph_capture_begin", s)
-        try:
-            for _ in range(n_steps):
-                self.enqueue_train_step(pl)
-        finally:
-            out = ctypes.c_void_p()
-            L.call("amid_graph_capture_end", s, ctypes.byref(out))
-        self.step = step0
-        if not hasattr(pl, "graphs_n"):
-            pl.graphs_n = {}
-        pl.graphs_n[(self._graph_key(), n_steps)] = out.value
-
-    def replay_train_steps(self, pl: SasrecPlan, n_steps: int) -> None:
-        lib().call("amid_graph_launch", pl.graphs_n[(self._graph_key(), n_steps)], self.s)
-        self.step += n_steps
-
-    def has_graph(self, pl: SasrecPlan) -> bool:
-        return self._graph_key() in getattr(pl, "graphs", {})
-
-    def replay_train_step(self, pl: SasrecPlan) -> None:
-        lib().call("amid_graph_launch", pl.graphs[self._graph_key()], self.s)
-        self.step += 1
-
-    def flush_table(self) -> None:
-        """Apply every pending zero-gradient Adam step (before eval / checkpoint / parity dumps)."""
-        if self.table_m is None:
-            return
-        lib().call("amid_lazy_adam_flush_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
-                   self.table_last.data_ptr(), self.n_rows, self.D, self.step_state.data_ptr(), self.s)
-
-    # ------------------------------------------------------------------ snapshots (tests / warm-up)
-    def snapshot(self):
-        self._ensure_opt_state()
-        self.sync()
-        fp = self.dense
-        return dict(step=self.step, seed=self.seed, data=fp.data.clone(), m=fp.m.clone(), v=fp.v.clone(), table=self.table.clone(),
-                    tm=self.table_m.clone(), tv=self.table_v.clone(), tl=self.table_last.clone())
-
-    def restore(self, snap) -> None:
-        fp = self.dense
-        with torch.cuda.stream(self.stream):
-            fp.data.copy_(snap["data"]); fp.m.copy_(snap["m"]); fp.v.copy_(snap["v"])
-            self.table.copy_(snap["table"]); self.table_m.copy_(snap["tm"]); self.table_v.copy_(snap["tv"]); self.table_last.copy_(snap["tl"])
-        self.set_step(snap["step"], snap["seed"])
-
     # ------------------------------------------------------------------ parameter interchange
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         with torch.no_grad(), torch.cuda.stream(self.stream):
@@ -1464,9 +847,6 @@ class SasrecEngine:
             out[name] = self.dense.view(name)
         return out
 
-    def merge_backend(self, capacity: int) -> "HipMergeBackend":
-        return HipMergeBackend(self, capacity)
-
     def check_index_error(self, pl: SasrecPlan) -> None:
         flags = int(pl.err.item())
         if flags != 0:
@@ -1475,152 +855,3 @@ class SasrecEngine:
                 raise RuntimeError("amid_amd: a data-parallel step found more unique rows than the bound umax it was given "
                                    "(train_step_dp): its exchange chunk is corrupt")
             raise IndexError("amid_amd: item index out of range in the batch (nn.Embedding would raise here, model_seq.py:27-29)")
-
-
-class HipMergeBackend:
-    """Merges the world's (ids, rows) lists with the same sort-unique + segment-reduce kernels the
-    local backward uses (amid_amd.dist.MergeBackend on the GPU)."""
-
-    def __init__(self, eng: SasrecEngine, capacity: int):
-        L = lib()
-        self.eng, self.cap = eng, int(capacity)
-        dev, D = eng.device, eng.D
-        self.sort_ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", self.cap), dtype=torch.uint8, device=dev)
-        self.pos_sorted = torch.zeros(self.cap, dtype=torch.int32, device=dev)
-        self.uniq_ids = torch.zeros(self.cap, dtype=torch.int32, device=dev)
-        self.seg_off = torch.zeros(self.cap + 1, dtype=torch.int32, device=dev)
-        self.seg_of = torch.zeros(self.cap, dtype=torch.int32, device=dev)
-        self.n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", self.cap, D), dtype=torch.uint8, device=dev)
-        self.uniq_rows = torch.empty(self.cap, D, dtype=torch.float32, device=dev)
-        # exchange buffers: this rank's packed chunk and the world's gathered chunks (sliced per step, never reallocated);
-        # capacity counts entries, so the id rows of the packed layout come on top (dist.packed_rows)
-        # (+ the flat dense gradient, which rides behind the rows in the one-collective step: up to MAX_WORLD chunks of it)
-        self.dense_rows = (eng.dense.numel + D - 1) // D
-        self.send = torch.zeros((self.cap + (self.cap + D - 1) // D + 16 + self.dense_rows) * D, dtype=torch.float32, device=dev)
-        self.all = torch.zeros((self.cap + (self.cap + D - 1) // D + 16 * 16 + self.MAX_WORLD * self.dense_rows) * D, dtype=torch.float32,
-                               device=dev)
-        self._entries = {}
-        # owner-bucketed exchange (dist.SparseDenseExchange._exchange_owner): per-owner counts (+ the fill's overflow flag)
-        self.owner_ws = torch.empty(L.value("amid_owner_workspace_bytes", self.cap), dtype=torch.uint8, device=dev)
-        self.owner_counts = torch.zeros(self.MAX_WORLD + 1, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize(dev)
-
-    MAX_WORLD = 16
-
-    @property
-    def capacity(self) -> int:
-        return self.cap
-
-    def bucket_counts(self, uniq_ids: torch.Tensor, n_uniq: torch.Tensor, world: int) -> torch.Tensor:
-        """[world] int32: how many of this rank's unique ids each owner (id % world) gets; also prepares fill_buckets()."""
-        lib().call("amid_owner_count_i32", uniq_ids.data_ptr(), n_uniq.data_ptr(), uniq_ids.numel(), world, self.owner_ws.data_ptr(),
-                   self.owner_counts.data_ptr(), self.eng.s)
-        return self.owner_counts[:world]
-
-    def fill_buckets(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, world: int, bmax: int) -> torch.Tensor:
-        """The stable split of (ids, rows) by owner into `world` packed chunks of bmax entries (after bucket_counts() on the same list)."""
-        from .dist import packed_rows
-        D = self.eng.D
-        id_rows, rows = packed_rows(bmax, D)
-        if world * rows * D > self.send.numel():
-            raise ValueError(f"{world} buckets of {bmax} entries exceed the backend capacity {self.cap}")
-        send = self.send[: world * rows * D]
-        lib().call("amid_owner_buckets_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), uniq_ids.numel(), D, world, bmax,
-                   self.eng.n_rows, self.owner_ws.data_ptr(), send.data_ptr(), rows * D, id_rows, self.owner_counts.data_ptr(), self.eng.s)
-        return send
-
-    def _entry(self, key, src: int, dst: int, stride: int, n_part: int, count: int) -> torch.Tensor:
-        """A one-entry table for amid_reduce_partials_f32 (device resident, cached: captured graphs keep pointing at it)."""
-        ent = self._entries.get(key)
-        if ent is None:
-            L = lib()
-            host = (ctypes.c_ubyte * L.value("amid_reduce_entry_bytes"))()
-            L.call("amid_reduce_entry_pack", ctypes.addressof(host), 0, src, dst, stride, n_part, count)
-            ent = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(self.eng.device)
-            torch.cuda.synchronize(self.eng.device)
-            self._entries[key] = ent
-        return ent
-
-    def prepare_dense(self, world: int, umax: int, dense: torch.Tensor) -> None:
-        """Build the reduce tables pad_packed(dense=...) / sum_dense() will use for this (world, umax): they copy to the device and
-        synchronise, which is not allowed while a stream is being captured."""
-        from .dist import packed_rows
-        D = self.eng.D
-        rows = packed_rows(umax, D)[1]
-        self._entry(("copy", umax), dense.data_ptr(), self.send.data_ptr() + 4 * rows * D, 0, 1, dense.numel())
-        self._entry(("sum", self.all.data_ptr(), world, umax), self.all.data_ptr() + 4 * rows * D, dense.data_ptr(),
-                    self.chunk_rows(umax, dense) * D, world, dense.numel())
-
-    def chunk_rows(self, umax: int, dense: Optional[torch.Tensor]) -> int:
-        from .dist import packed_rows
-        return packed_rows(umax, self.eng.D)[1] + (self.dense_rows if dense is not None else 0)
-
-    def sum_dense(self, gathered: torch.Tensor, world: int, umax: int, dense: torch.Tensor) -> None:
-        """dense <- sum over the ranks, in rank order, of the dense parts that travelled behind the sparse rows."""
-        from .dist import packed_rows
-        D = self.eng.D
-        off = packed_rows(umax, D)[1] * D
-        stride = self.chunk_rows(umax, dense) * D
-        ent = self._entry(("sum", gathered.data_ptr(), world, umax), gathered.data_ptr() + 4 * off, dense.data_ptr(), stride, world, dense.numel())
-        lib().call("amid_reduce_partials_f32", ent.data_ptr(), 1, dense.numel(), self.eng.s)
-
-    def pad_packed(self, uniq_ids: torch.Tensor, uniq_rows: torch.Tensor, n_uniq: torch.Tensor, umax: int,
-                   dense: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """dense: also append this flat fp32 buffer (the dense gradient) behind the rows, so that ONE all-gather moves everything."""
-        from .dist import packed_rows
-        D = self.eng.D
-        id_rows, rows = packed_rows(umax, D)
-        send = self.send[: self.chunk_rows(umax, dense) * D]
-        # sentinel padding (one past the last table row) keeps every rank's list sorted, so merge_packed() is a merge, not a sort
-        if dense is not None:          # the copy of the flat dense gradient behind the rows rides in the padding launch
-            ent = self._entry(("copy", umax), dense.data_ptr(), send.data_ptr() + 4 * rows * D, 0, 1, dense.numel())
-            lib().call("amid_sparse_pad_sum_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), umax, D, self.eng.n_rows,
-                       send.data_ptr(), send.data_ptr() + 4 * id_rows * D, ent.data_ptr(), 1, dense.numel(), self.eng.s)
-        else:
-            lib().call("amid_sparse_pad_f32", uniq_ids.data_ptr(), uniq_rows.data_ptr(), n_uniq.data_ptr(), umax, D, self.eng.n_rows,
-                       send.data_ptr(), send.data_ptr() + 4 * id_rows * D, self.eng.s)
-        return send
-
-    def gather_buffer(self, world: int, umax: int, dense: Optional[torch.Tensor] = None) -> torch.Tensor:
-        n = world * self.chunk_rows(umax, dense) * self.eng.D
-        if n > self.all.numel() or world * umax > self.cap or (dense is not None and world > self.MAX_WORLD):
-            raise ValueError(f"gather of {world} x {umax} entries exceeds the backend capacity {self.cap}")
-        return self.all[:n]
-
-    def merge_packed(self, gathered: torch.Tensor, world: int, umax: int, dense: Optional[torch.Tensor] = None, sum_dense: bool = False):
-        """`world` packed chunks (sorted, sentinel-padded ids + rows [+ a dense tail the merge skips]) -> 2-launch stable merge +
-        segment reduce.  sum_dense: the rank-ordered sum of the dense tails into `dense` (what sum_dense() does) rides in the
-        merge's first launch."""
-        from .dist import packed_rows
-        L, eng = lib(), self.eng
-        D = eng.D
-        id_rows, _ = packed_rows(umax, D)
-        rows = self.chunk_rows(umax, dense)
-        n = world * umax
-        if sum_dense and dense is not None:
-            off = packed_rows(umax, D)[1] * D
-            ent = self._entry(("sum", gathered.data_ptr(), world, umax), gathered.data_ptr() + 4 * off, dense.data_ptr(), rows * D, world,
-                              dense.numel())
-            L.call("amid_merge_sorted_lists_sum_i32", gathered.data_ptr(), world, umax, rows * D, id_rows, rows, eng.n_rows,
-                   self.sort_ws.data_ptr(), self.pos_sorted.data_ptr(), self.uniq_ids.data_ptr(), self.seg_off.data_ptr(),
-                   self.seg_of.data_ptr(), self.n_uniq.data_ptr(), ent.data_ptr(), 1, dense.numel(), eng.s)
-        else:
-            L.call("amid_merge_sorted_lists_i32", gathered.data_ptr(), world, umax, rows * D, id_rows, rows, eng.n_rows, self.sort_ws.data_ptr(),
-                   self.pos_sorted.data_ptr(), self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
-                   self.n_uniq.data_ptr(), eng.s)
-        L.call("amid_embgrad_segreduce_f32", gathered.data_ptr(), self.pos_sorted.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
-               n, D, self.seg_ws.data_ptr(), self.uniq_rows.data_ptr(), eng.s)
-        return self.uniq_ids[:n], self.uniq_rows[:n], self.n_uniq
-
-    def merge(self, ids: torch.Tensor, rows: torch.Tensor):
-        """Arbitrary (unsorted) ids -> full radix sort + segment reduce."""
-        L, eng = lib(), self.eng
-        n = ids.numel()
-        if n > self.cap:
-            raise ValueError(f"merge of {n} entries exceeds the backend capacity {self.cap}")
-        L.call("amid_sort_unique_i32", ids.data_ptr(), n, eng.n_rows, self.sort_ws.data_ptr(), self.pos_sorted.data_ptr(),
-               self.uniq_ids.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(), self.n_uniq.data_ptr(), eng.s)
-        L.call("amid_embgrad_segreduce_f32", rows.data_ptr(), self.pos_sorted.data_ptr(), self.seg_off.data_ptr(), self.seg_of.data_ptr(),
-               n, eng.D, self.seg_ws.data_ptr(), self.uniq_rows.data_ptr(), eng.s)
-        return self.uniq_ids[:n], self.uniq_rows[:n], self.n_uniq

@@ -114,7 +114,6 @@ class Bert4recEngine(SasrecEngine):
     EMB_DIMS = (BERT_HIDDEN,)
     SHORT_TILE_BUILDS = True
     STRIP_KERNELS = False        # its encoder launches are bert.hip's row-tile kernels
-    SORT_FORK = "catchup"        # the side-stream sort runs beside the forward (no launch of this encoder fills every CU)
 
     def __init__(self, *args, comp: str = "", comp_bs: int = 0, comp_threshold: float = 0.5, **kw):
         """comp = "inc" / "itc": BERT4Rec(isInC=True) / (isItC=True) with bs = comp_bs and threshold1 / threshold2 = comp_threshold:

@@ -542,7 +542,7 @@ int amid_sas_seq_bwd_f32(int n_layers, const float* dxo, const unsigned char* tm
                          const float* const* w1T, const float* const* w2T, float ln_eps, int B, int T, int D, int H, const int* live,
                          const void* step_state, int train, float p_drop, float* const* dpre2, float* const* dpre1, float* const* dr,
                          float* d_o, float* const* dq, float* const* dk, float* const* dv, float* dx, float* const* ln1_part,
-                         float* const* ln2_part, void* stream);
+                         float* const* ln2_part, int mma_bf16, void* stream);
 
 /* ---- the fused train step over the LIVE sequences -------------------------------------------------------------------------------
  * train_sr.py:205-211 multiplies the BCE terms of domain 1 - domain_id[b] of every sample b by zero: of the 2 B sequences a step
@@ -604,29 +604,33 @@ int amid_sas_strip_oproj_ffn_fwd_f32(const float* o, const float* qn, const floa
                                      int D, const int* live, int layer, const void* step_state, int train, float p_drop, float* r, float* y,
                                      float* h, float* xo, const float* const* nln_w, const float* const* nln_b, const float* const* nw_in,
                                      const float* const* nb_in, float* nqn, float* nq, float* nk, float* nv, void* stream);
+/* The backward strip entry points (and amid_sas_seq_bwd_f32) take mma_bf16: 1 = the data-gradient products on
+ * v_mfma_f32_16x16x32_bf16 (operands rounded to bf16, fp32 accumulation, everything else fp32; D = 128) -- the w*T pointer arguments then
+ * hold the bf16 fragment images of the TRANSPOSED weights (amid_sas_weights_bf16(..., transposed = 1, ...), 2 D D bytes each) instead of
+ * fp32 transposes; 0 = exact fp32 products. */
 int amid_sas_strip_ffn_bwd_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
                                const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T, int D,
                                const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
-                               float* dr, float* d_o, float* ln_part, void* stream);
+                               float* dr, float* d_o, float* ln_part, int mma_bf16, void* stream);
 /* fh != NULL: the layer below's amid_sas_strip_ffn_bwd_f32 (f* arguments) continues on d x in registers; dx is then not written */
 int amid_sas_strip_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
                                const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int B, int T, int D,
                                const int* live, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
                                const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
                                int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
-                               float* fd_o, float* fln_part, void* stream);
+                               float* fd_o, float* fln_part, int mma_bf16, void* stream);
 /* the backward strip launches carrying a phase of a sort plan (amid_sort_plan_pack; ffn: 2, qkv with / without the fused
  * feed-forward backward: 3 / 4) as extra workgroups in front of the tiles' (the live tiles leave CUs free) */
 int amid_sas_strip_ffn_bwd_sort_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
                                const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T, int D,
                                const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
-                               float* dr, float* d_o, float* ln_part, const void* sort_plan, int sort_phase, void* stream);
+                               float* dr, float* d_o, float* ln_part, const void* sort_plan, int sort_phase, int mma_bf16, void* stream);
 int amid_sas_strip_qkv_bwd_sort_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
                                const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int B, int T, int D,
                                const int* live, float* dx, float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
                                const float* const* fln_w, const float* const* fw1T, const float* const* fw2T, const float* const* fwoT,
                                int flayer, const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
-                               float* fd_o, float* fln_part, const void* sort_plan, int sort_phase, void* stream);
+                               float* fd_o, float* fln_part, const void* sort_plan, int sort_phase, int mma_bf16, void* stream);
 
 int amid_embed_bwd_rows_f32(float* dxg, const unsigned char* tmq, int B, int T, int D, int nsplit, float* dpos_part, const void* rng_state,
                             int train, float p_drop, const long long* row_domain, void* stream);   /* amid_embed_bwd_f32 behind the *_rows kernels: the dead sequences' rows are zero-filled, not read */

@@ -46,7 +46,7 @@ d0, d1 = torch.nonzero(dom == 0).flatten(), torch.nonzero(dom != 0).flatten()
 live = torch.cat((d0, d1, torch.tensor([d0.numel()]))).int().to(dev)
 f = L.amid_sas_seq_bwd_f32
 vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
-f.argtypes = [ci] + [vp] * 18 + [cf, ci, ci, ci, ci, vp, vp, ci, cf] + [vp] * 11
+f.argtypes = [ci] + [vp] * 18 + [cf, ci, ci, ci, ci, vp, vp, ci, cf] + [vp] * 10 + [ci, vp]
 P = per_layer
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(6):
@@ -55,7 +55,7 @@ for it in range(6):
     rc = f(2, dxo.data_ptr(), tmq.data_ptr(), arr(P["h"]), arr(P["r"]), arr(P["x"]), arr(P["q"]), arr(P["k"]), arr(P["v"]), arr(P["o"]),
            arr(stats), arr(lnw["ln1"]), arr(lnw["ln2"]), arr(per_dom["wq"]), arr(per_dom["wk"]), arr(per_dom["wv"]), arr(per_dom["wo"]),
            arr(per_dom["w1"]), arr(per_dom["w2"]), 1e-8, B, T, D, H, live.data_ptr(), None, 0, 0.5, arr(P["dpre2"]), arr(P["dpre1"]),
-           arr(P["dr"]), d_o.data_ptr(), arr(P["dq"]), arr(P["dk"]), arr(P["dv"]), dx.data_ptr(), arr(ln1p), arr(ln2p), None)
+           arr(P["dr"]), d_o.data_ptr(), arr(P["dq"]), arr(P["dk"]), arr(P["dv"]), dx.data_ptr(), arr(ln1p), arr(ln2p), 0, None)
     assert rc == 0, rc
     if it == 5:
         ev1.record()

@@ -140,7 +140,7 @@ def test_strip_backward_equals_row_tile_kernels(B, T, D, live):
         L.call("amid_sas_ffn_bwd_f32", dxo.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), P(w1T), P(w2T), P(woT), 1e-8, M, D,
                c.rpt, 1, c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in ref], pr.data_ptr(), 0, s)
         L.call("amid_sas_strip_ffn_bwd_f32", dxo.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), P(w1T), P(w2T), P(woT), 1e-8,
-               B, T, D, c.lp(), 1, c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in got], pg.data_ptr(), s)
+               B, T, D, c.lp(), 1, c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in got], pg.data_ptr(), 0, s)
         torch.cuda.synchronize()
         for n, a, b in zip("dpre2 dpre1 dr d_o".split(), got, ref):
             c.check_rows(f"ffn_bwd train={train} {n}", a, b, tol=5e-6)
@@ -153,7 +153,7 @@ def test_strip_backward_equals_row_tile_kernels(B, T, D, live):
     L.call("amid_sas_qkv_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), P(wq), P(wk), P(wv), 1e-8,
            M, D, c.rpt, ref.data_ptr(), pr.data_ptr(), 0, s)
     L.call("amid_sas_strip_qkv_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), P(wq), P(wk), P(wv),
-           1e-8, B, T, D, c.lp(), got.data_ptr(), pg.data_ptr(), *([None] * 7), 0, None, 0, 0.0, *([None] * 5), s)
+           1e-8, B, T, D, c.lp(), got.data_ptr(), pg.data_ptr(), *([None] * 7), 0, None, 0, 0.0, *([None] * 5), 0, s)
     torch.cuda.synchronize()
     c.check_rows("qkv_bwd dx", got, ref, tol=5e-6)
     c.check_parts("qkv_bwd ln_part", pg, pr)
@@ -165,9 +165,60 @@ def test_strip_backward_equals_row_tile_kernels(B, T, D, live):
                c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in ref], fpr.data_ptr(), 0, s)
         L.call("amid_sas_strip_qkv_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), P(wq), P(wk), P(wv),
                1e-8, B, T, D, c.lp(), None, pg.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), P(w1T), P(w2T), P(woT), 0,
-               c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in got], fpg.data_ptr(), s)
+               c.st.data_ptr(), train, 0.5, *[t.data_ptr() for t in got], fpg.data_ptr(), 0, s)
         torch.cuda.synchronize()
         for n, a, b in zip("dpre2 dpre1 dr d_o".split(), got, ref):
             c.check_rows(f"qkv_ffn_bwd train={train} {n}", a, b, tol=1e-5)
         c.check_parts(f"qkv_ffn_bwd train={train} ln1_part", pg, pr)
         c.check_parts(f"qkv_ffn_bwd train={train} ln2_part", fpg, fpr)
+
+
+@pytest.mark.parametrize("B,T", [(64, 50), (37, 20), (256, 50)])
+@pytest.mark.parametrize("live", [None, "mixed"])
+def test_strip_backward_bf16_products_within_bf16_rounding_of_fp32(B, T, live):
+    """mma_bf16 = 1 (BASELINE.json configs[2]): the data-gradient products of the strip backward kernels on the bf16 matrix cores, from
+    amid_sas_weights_bf16 images of the TRANSPOSED weights, against the fp32 strip kernels on the same inputs: every output within 2e-2
+    of its tensor's norm, and visibly different (the mode is on)."""
+    D = 128
+    c = Ctx(B, T, D, seed=B * 5 + T, live=live)
+    L, pa, s, M = c.L, c.pa, c.s, c.M
+    P = lambda t: pa([t[0].data_ptr(), t[1].data_ptr()])      # noqa: E731
+    lo = live is not None
+    part_s = lambda: torch.full((2 * c.stpg, 2, D), float("nan"), device="cuda")      # noqa: E731
+    lnw = c.vec(1.0)
+    dxo, h, r = c.act(live_only=lo), c.act().relu(), c.act()
+    dq, dk, dv, dr = (c.act(live_only=lo) for _ in range(4))
+    x = c.act()
+    mats = [c.mat() for _ in range(6)]                   # w1T, w2T, woT, wqT, wkT, wvT as the fp32 kernels take them: W^T [in][out] per domain
+    # the bf16 images of the same matrices: amid_sas_weights_bf16 of the UN-transposed weights with transposed = 1, i.e. of (W^T)^T ... the
+    # kernels' operand is the matrix they are handed, so image(W^T) = weights_bf16(src = W^T, transposed = 0)
+    img = torch.empty(12, D * D, dtype=torch.bfloat16, device="cuda")
+    L.call("amid_sas_weights_bf16", pa([m[g].data_ptr() for m in mats for g in (0, 1)]), 12, D, 0, img.data_ptr(), s)
+    I = lambda k: pa([img[2 * k].data_ptr(), img[2 * k + 1].data_ptr()])      # noqa: E731
+
+    def run(bf):
+        W = (lambda k: I(k)) if bf else (lambda k: P(mats[k]))
+        out = [c.out() for _ in range(4)]
+        pg = part_s()
+        L.call("amid_sas_strip_ffn_bwd_f32", dxo.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), W(0), W(1), W(2), 1e-8,
+               B, T, D, c.lp(), 1, c.st.data_ptr(), 1, 0.5, *[t.data_ptr() for t in out], pg.data_ptr(), bf, s)
+        dx, pg1 = c.out(), part_s()
+        L.call("amid_sas_strip_qkv_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), W(3), W(4), W(5),
+               1e-8, B, T, D, c.lp(), dx.data_ptr(), pg1.data_ptr(), *([None] * 7), 0, None, 0, 0.0, *([None] * 5), bf, s)
+        out2 = [c.out() for _ in range(4)]
+        pg2, fpg2 = part_s(), part_s()
+        L.call("amid_sas_strip_qkv_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), W(3), W(4), W(5),
+               1e-8, B, T, D, c.lp(), None, pg2.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), W(0), W(1), W(2), 0,
+               c.st.data_ptr(), 1, 0.5, *[t.data_ptr() for t in out2], fpg2.data_ptr(), bf, s)
+        torch.cuda.synchronize()
+        return out + [dx] + out2
+    ref, got = run(0), run(1)
+    rl = c.row_live.cuda()
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(got, ref)):
+        a, b = a[rl].double(), b[rl].double()
+        assert torch.isfinite(a).all(), i
+        e = float((a - b).norm() / (b.norm() + 1e-30))
+        worst = max(worst, e)
+        assert e < 2e-2, (i, e)
+    assert worst > 1e-4
