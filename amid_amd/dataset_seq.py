@@ -94,6 +94,15 @@ class DualDomainSeqDataset:
         ds.rng = np.random.default_rng(seed)
         return ds
 
+    def max_item_id(self) -> int:
+        """Largest table row this dataset can ask for: its items, its sequences' ids other than the pad id, its negative pools."""
+        tops = [int(self.i_node.max())] + [int(p.max()) for p in self.pool if len(p)]
+        for a in (self.seq_d1, self.seq_d2):
+            real = a[a != self.pad_id]
+            if real.size:
+                tops.append(int(real.max()))
+        return max(tops)
+
     def shift_items(self, offset: int) -> "DualDomainSeqDataset":
         """Move every item id except the pad id by `offset` (in place; returns self): the joint mode puts a second dataset's items
         behind the first one's in the shared table (cfg 4)."""

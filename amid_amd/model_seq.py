@@ -344,6 +344,8 @@ class _GatherFunction(torch.autograd.Function):
         ctx.shape = weight.shape
         return out.reshape(*idx.shape, weight.shape[1])
 
+    _sort_ws = {}          # (device, n) -> the zero-filled sort workspace of backward
+
     @staticmethod
     def backward(ctx, g):
         (flat,) = ctx.saved_tensors
@@ -354,7 +356,11 @@ class _GatherFunction(torch.autograd.Function):
         dev = g.device
         idx32 = flat.to(torch.int32)
         rows = g.reshape(n, D).contiguous()
-        ws = torch.zeros(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device=dev)
+        # the sort's workspace starts with a fixed ~8.4 MB head that must be zero once and that every call leaves consistent: one
+        # zero-filled workspace per (device, n) for the life of the process instead of an allocation + memset per backward
+        ws = _GatherFunction._sort_ws.get((dev, n))
+        if ws is None:
+            ws = _GatherFunction._sort_ws[(dev, n)] = torch.zeros(L.value("amid_sort_unique_workspace_bytes", n), dtype=torch.uint8, device=dev)
         pos, uniq = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
         seg, nu = torch.empty(n + 1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
         sof = torch.empty(n, dtype=torch.int32, device=dev)

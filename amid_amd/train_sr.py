@@ -145,7 +145,10 @@ def train(model, train_batches, args, val_batches, exchange=None):
                                         use_graph=not args.no_graph, exchange=exchange)
                 n_done = 1
             n_samples += n_done * args.bs * (exchange.world if exchange is not None else 1)
-            if (i + 1) % 20 == 0 or i == 0:                                               # train_sr.py:217-219 (the only host sync)
+            # the reference looks at the loss of iterations 0, 20, 40, ... (train_sr.py:217-219): logged here when the replayed chunk
+            # [i + 1 - n_done, i] holds such an iteration, with the loss of the chunk's LAST step (the steps of a graph leave one loss
+            # behind) -- the only host sync of the loop
+            if (i // 20) * 20 > i - n_done:
                 if pooled:
                     model.engine.sync()
                 stats.update(loss=loss.item(), loss_cls=loss.item())
@@ -222,6 +225,14 @@ def main(argv=None):
                 ds_val.shift_items(item_length + 2)
             trains.append(DeviceBatches(ds_train, args.bs, shuffle=True, device=args.device, seed=i, rank=rank, world=world))
             vals.append(DeviceBatches(ds_val, args.bs, shuffle=False, device=args.device, seed=i))
+        if len(parts) == 2:
+            # joint mode: the second dataset's ids sit item_length + 2 rows behind the first's in the reference-sized table of
+            # 2 * item_length rows (train_sr.py:456) -- checked here, on the host, before any step runs (the fused step would only flag an
+            # out-of-range id at its next log point)
+            top = max(int(t.ds.max_item_id()) for t in (trains[1], vals[1]))
+            if top >= 2 * item_length:
+                raise SystemExit(f"-dm {args.domain_type}: item id {top - (item_length + 2)} of the second dataset lands on row {top} of a "
+                                 f"{2 * item_length}-row table (ids up to {item_length - 3} fit)")
         train_batches = trains[0] if len(parts) == 1 else JointBatches(*trains)
         val_batches = vals[0] if len(parts) == 1 else JointBatches(*vals)
         item_length *= 2                                                                  # train_sr.py:456 ("for pad id")

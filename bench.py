@@ -119,6 +119,7 @@ def real_batches(workload, Bw, device, rank, world, seed=0):
     dss = [DualDomainSeqDataset.from_tokenised(os.path.join(FIXTURES, f"tok_{n}.npz")) for n in names]
     if len(dss) == 2:
         dss[1].shift_items(JOINT_OFFSET)
+        assert dss[1].max_item_id() < N_ROWS, "joint mode: the second dataset's shifted ids must fit the 2 x item_length table"
     loaders = [DeviceBatches(d, Bw, shuffle=True, device=device, seed=seed, rank=rank, world=world, negatives="fixture") for d in dss]
     ld = loaders[0] if len(loaders) == 1 else JointBatches(*loaders)
     desc = " + ".join(names) + f" ({sum(len(d) for d in dss)} rows, tokenised by the reference's DualDomainSeqDataset; negatives: its draw)"

@@ -30,22 +30,18 @@ def single(n):
         eng.replay_train_step(pl)
     eng.sync(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
-def run(n, umax_known):
+cap = (max(cnt) + 255) // 256 * 256          # one bound for the whole run, as bench.py's (a per-step bound must follow the pool's phase)
+def run(n, umax_known, dense="gather"):
     eng.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(n):
-        eng.train_step_dp(pl, ex, use_graph=True, umax=cnt[i % 30] if umax_known else None)
+        eng.train_step_dp(pl, ex, use_graph=True, umax=cap if umax_known else None, dense=dense)
     eng.sync(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 eng.capture_train_step(pl)
 single(30)
 print("single-GPU whole-step graph : %.4f ms/step" % single(300))
-run(20, True)
-print("dp path, host knows umax : %.4f ms/step" % run(200, True))
-cap = (max(cnt) + 255) // 256 * 256
-cnt_b = cnt
-cnt = [cap] * len(cnt)
-run(5, True)
-print("dp path, fixed bound %d, graph pair : %.4f ms/step" % (cap, run(200, True)))
-cnt = cnt_b
+for dense in ("gather", "allreduce"):
+    run(5, True, dense)
+    print("dp path, fixed bound %d, graph pair, dense exchange = %s : %.4f ms/step" % (cap, dense, run(200, True, dense)))
 print("dp path, host sync / step: %.4f ms/step" % run(200, False))
 eng.sync(); torch.cuda.synchronize(); dist.barrier(); dist.destroy_process_group()
