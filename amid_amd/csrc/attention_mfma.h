@@ -330,7 +330,10 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
     for (int qi = 0; qi < NT; ++qi) {
         const int q = qi * 16 + m;
         const float4 qf = o.qfr[qi], dof = o.dofr[qi];
-        const float delta = quad_group_sum(f4hsum(f4mul(dof, o.ofr[qi])));
+        // (an explicit fma chain: every kernel this core is compiled into -- the standalone launch, the two fused backward builds -- gets
+        // the same bits, whatever its surroundings make of a * b + c)
+        const float4 of = o.ofr[qi];
+        const float delta = quad_group_sum(fmaf(dof.w, of.w, fmaf(dof.z, of.z, fmaf(dof.y, of.y, dof.x * of.x))));
         const float ml = o.str[qi].x * LOG2E, c1 = o.str[qi].y * a.dscale, dr = delta * o.str[qi].y;
         const unsigned long long kw = shfl64(o.kw_own, q);
         const unsigned kwh[2] = {(unsigned)kw, (unsigned)(kw >> 32)};

@@ -22,18 +22,11 @@
 #include "strip_gemm.h"
 #include "attention_mfma.h"
 #include "seq_fwd.h"
+#include "seqn_parts.h"
 #include <type_traits>
 
 namespace amid {
 
-typedef __attribute__((address_space(3))) float lds_f;
-typedef float lds_v4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 lds_ld4(const float* p) {
-    const lds_v4 t = *(const __attribute__((address_space(3))) lds_v4*)(p);
-    return make_float4(t.x, t.y, t.z, t.w);
-}
-__device__ __forceinline__ void lds_st4(float* p, f32x4 v) { *(__attribute__((address_space(3))) lds_v4*)(p) = lds_v4{v[0], v[1], v[2], v[3]}; }
-__device__ __forceinline__ void lds_st1(float* p, float v) { *(__attribute__((address_space(3))) float*)(p) = v; }
 
 #ifdef AMID_STRIP_STAMPS
 static __device__ unsigned long long amid_seqn_stamp_buf[8 * 64];
@@ -44,222 +37,6 @@ static __device__ unsigned long long amid_seqn_stamp_buf[8 * 64];
 #define SEQN_STAMP0(i) do { } while (0)
 #endif
 
-// ---- weight ring for NW waves (strip_gemm.h's WDma with the wave count as a parameter) ----------------------------------------------
-template <int D, int NW> struct WDmaN {
-    static constexpr int CPR = D / 4;
-    static constexpr int PER_WAVE = D * CPR / 64 / NW;
-    static constexpr unsigned STRIDE2 = 2u * (NW * 64 / CPR) * D * 4;      // bytes between pieces k0 and k0 + 2
-    unsigned off[2];
-    int w;
-    __device__ __forceinline__ WDmaN() {
-        const int lane = lane_id();
-        w = wave_id();
-#pragma unroll
-        for (int k0 = 0; k0 < 2; ++k0) {
-            const int p = (k0 * NW + w) * 64 + lane;
-            const int n = p / CPR, pos = p % CPR;
-            off[k0] = (unsigned)((n * D + ((pos ^ (n & 15)) * 4)) * 4);
-        }
-    }
-    __device__ __forceinline__ void piece(float* __restrict__ buf, const float* __restrict__ W, int k0) const {
-        const unsigned voff = off[k0 & 1] + (unsigned)(k0 >> 1) * STRIDE2;
-        const unsigned lds = __builtin_amdgcn_readfirstlane(
-            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(buf + (k0 * NW + w) * 256));
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
-    }
-};
-
-template <int D, int NW> struct SeqRingN {
-    float* buf; int s; WDmaN<D, NW> dma;
-    static constexpr int SLOTS = 4 * (D / 16);
-    __device__ __forceinline__ explicit SeqRingN(float* lds) : buf(lds), s(0) {}
-    __device__ __forceinline__ void first(const float* __restrict__ W0) {
-#pragma unroll
-        for (int k0 = 0; k0 < WDmaN<D, NW>::PER_WAVE; ++k0) dma.piece(buf, W0, k0);
-    }
-    __device__ __forceinline__ float* next() {
-        w_ring_wait();
-        __syncthreads();
-        float* cur = buf + (s & 1) * D * D;
-        ++s;
-        return cur;
-    }
-    // slot = ct * 4 + j of the product that reads slab s - 1; pieces go into the other buffer over the first half of the loop
-    __device__ __forceinline__ void fetch(const float* __restrict__ W, int ct, int j) const {
-        constexpr int PW = WDmaN<D, NW>::PER_WAVE, EVERY = (SLOTS / 2) / PW > 0 ? (SLOTS / 2) / PW : 1;
-        const int slot = ct * 4 + j;
-        if (slot % EVERY == 0 && slot / EVERY < PW) dma.piece(buf + (s & 1) * D * D, W, slot / EVERY);
-    }
-};
-
-// ---- bf16 weight images (amid_sas_weights_bf16): row n = D bf16 = D / 8 chunks of 16 bytes; chunk 4 s + g of a row holds the eight k
-// values lane group g supplies in k-step s of v_mfma_f32_16x16x32_bf16 when the operand sits in the C layout: k = 32 s + 4 g + r
-// (column tile 2 s, elements 0..3) and k = 32 s + 16 + 4 g + r (column tile 2 s + 1, elements 4..7).  In LDS chunk c of row n sits at
-// chunk position c ^ (n & 15), applied on the DMA's source address as for the fp32 images: conflict-free ds_read_b128 fragments.
-template <int D, int NW> struct SeqRing16 {
-    static constexpr int CPR = D / 8;                                   // 16-byte chunks per row
-    static constexpr int PIECES = D * CPR / 64, PER_WAVE = PIECES / NW;
-    static constexpr int SLAB = D * D / 2;                              // floats per slab (32 KB at D = 128)
-    float* buf; int s; unsigned off0; int w;
-    __device__ __forceinline__ explicit SeqRing16(float* lds) : buf(lds), s(0) {
-        w = wave_id();
-        const int p = w * 64 + lane_id();
-        const int n = p / CPR, pos = p % CPR;
-        off0 = (unsigned)(n * D * 2 + ((pos ^ (n & 15)) * 16));
-    }
-    __device__ __forceinline__ void piece(float* __restrict__ dst, const unsigned short* __restrict__ W, int k0) const {
-        const unsigned voff = off0 + (unsigned)k0 * (unsigned)(NW * 64 / CPR) * (unsigned)(D * 2);      // NW * 4 rows further: n & 15 unchanged
-        const unsigned lds = __builtin_amdgcn_readfirstlane(
-            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(dst + (k0 * NW + w) * 256));
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
-    }
-    __device__ __forceinline__ void first(const unsigned short* __restrict__ W0) {
-#pragma unroll
-        for (int k0 = 0; k0 < PER_WAVE; ++k0) piece(buf, W0, k0);
-    }
-    __device__ __forceinline__ float* next() {
-        w_ring_wait();
-        __syncthreads();
-        float* cur = buf + (s & 1) * SLAB;
-        ++s;
-        return cur;
-    }
-    __device__ __forceinline__ void fetch_all(const unsigned short* __restrict__ W) const {
-#pragma unroll
-        for (int k0 = 0; k0 < PER_WAVE; ++k0) piece(buf + (s & 1) * SLAB, W, k0);
-    }
-};
-
-typedef __bf16 seqn_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 seqn_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float seqn_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned seqn_pack2(float a, float b) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(seqn_f32x2{a, b}, seqn_bf16x2));       // v_cvt_pk_bf16_f32: round to nearest even
-}
-// acc[c] += A W^T over the own column tiles with bf16 operands: 4 k-steps of 32; the operand's eight values of step s are the lane's
-// elements of column tiles 2 s and 2 s + 1
-template <int D, int NCT>
-__device__ __forceinline__ void part_mma16(f32x4 (&acc)[NCT], const StripRegs<D>& A, const float* __restrict__ buf, int c0) {
-    constexpr int KS = D / 32;
-    const int lane = lane_id();
-    const int i = lane & 15, g = lane >> 4;
-    const float* rowp = buf + (c0 * 16 + i) * (D / 2);                  // a row = D bf16 = D / 2 floats
-    amid_v4u a16[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-        a16[s] = amid_v4u{seqn_pack2(A.v[2 * s][0], A.v[2 * s][1]), seqn_pack2(A.v[2 * s][2], A.v[2 * s][3]),
-                          seqn_pack2(A.v[2 * s + 1][0], A.v[2 * s + 1][1]), seqn_pack2(A.v[2 * s + 1][2], A.v[2 * s + 1][3])};
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        float4 wf[NCT];
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) wf[c] = lds_ld4(rowp + c * 16 * (D / 2) + 4 * ((4 * s + g) ^ i));
-#pragma unroll
-        for (int c = 0; c < NCT; ++c)
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(seqn_bf16x8, wf[c]), __builtin_bit_cast(seqn_bf16x8, a16[s]),
-                                                             acc[c], 0, 0, 0);
-    }
-}
-
-// ---- the own columns of a strip ---------------------------------------------------------------------------------------------------
-template <int NCT> struct PartRegs { f32x4 v[NCT]; };
-
-template <int NCT>
-__device__ __forceinline__ void part_load(PartRegs<NCT>& x, const GBuf& g, unsigned off_own) {
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) x.v[c] = g.load4(off_own + c * 64);
-}
-template <int NCT>
-__device__ __forceinline__ void part_store(const GBuf& g, unsigned off_own, const PartRegs<NCT>& x) {
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) g.store4(off_own + c * 64, x.v[c]);
-}
-// one column tile per call, from inside an MFMA loop: tensor `x` leaves in groups j == phase of the first NCT k tiles
-template <int NCT>
-__device__ __forceinline__ void part_spread(const GBuf& g, unsigned off_own, const PartRegs<NCT>& x, int ct, int j, int phase) {
-    if (ct < NCT && j == phase) g.store4(off_own + ct * 64, x.v[ct]);
-}
-template <int NCT>
-__device__ __forceinline__ void part_cols(PartRegs<NCT>& v, const float* __restrict__ p, int c0) {
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) v.v[c] = col4(p, c0 + c);
-}
-
-// exchange: own parts -> xb[column tile][lane]; after a barrier every wave of the strip reads all D / 16 tiles
-template <int NCT>
-__device__ __forceinline__ void xchg_write(float* __restrict__ xb, int c0, const PartRegs<NCT>& x) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) lds_st4(xb + ((c0 + c) * 64 + lane) * 4, x.v[c]);
-}
-template <int D>
-__device__ __forceinline__ void xchg_read(StripRegs<D>& full, const float* __restrict__ xb) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int ct = 0; ct < D / 16; ++ct) {
-        const float4 t = lds_ld4(xb + (ct * 64 + lane) * 4);
-        full.v[ct] = f32x4{t.x, t.y, t.z, t.w};
-    }
-}
-
-// acc[c] += sum_k A[.][k] W[(c0 + c) * 16 + .][k]: strip_mma for the own column tiles.  4 groups per k tile (one per element r of the
-// operand quad): NCT MFMAs on different accumulators + one fragment read of the next k tile; hook(ct, j) behind group j.
-template <int D, int NCT, class Hook>
-__device__ __forceinline__ void part_mma(f32x4 (&acc)[NCT], const StripRegs<D>& A, const float* __restrict__ buf, int c0, const Hook& hook) {
-    constexpr int NT = D / 16;
-    const int lane = lane_id();
-    const int i = lane & 15, g = lane >> 4;
-    const int xl = g ^ i;
-    const float* rowp = buf + (c0 * 16 + i) * D;
-    float4 wf[2][NCT];
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) wf[0][c] = lds_ld4(rowp + c * 16 * D + 4 * xl);
-    AMID_STRIP_FENCE();
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
-        const float* nxt = rowp + 4 * (((ct + 1) * 4) ^ xl);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                const float4 w = wf[ct & 1][c];
-                const float wr = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, A.v[ct][j], acc[c], 0, 0, 0);
-            }
-            // the next k tile's fragments: two behind group 0, one behind groups 1 and 2 -- the last one has a whole group (128 cycles)
-            // + three MFMAs in front of its use instead of three MFMAs
-            if (ct + 1 < NT) {
-                if (j == 0) {
-                    wf[(ct + 1) & 1][0] = lds_ld4(nxt);
-                    if (NCT > 1) wf[(ct + 1) & 1][1] = lds_ld4(nxt + 16 * D);
-                } else if (j + 1 < NCT) {
-                    wf[(ct + 1) & 1][j + 1] = lds_ld4(nxt + (j + 1) * 16 * D);
-                }
-            }
-            hook(ct, j);
-            AMID_STRIP_FENCE();
-        }
-    }
-}
-
-// keep multipliers of the own columns of row `local` at `site` (p = 0.5: the row's ONE Philox call, requested ahead: `rr`)
-template <int NCT>
-__device__ __forceinline__ void part_dropout(PartRegs<NCT>& x, const uint4 rr, int c0, unsigned spec, float scale) {
-    const int g4 = 4 * (lane_id() >> 4);
-    const bool all = spec_thr(spec) == 0;
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) {
-        const int f = (c0 + c) * 16 + g4;
-        const unsigned wlo = (f & 64) ? rr.z : rr.x, whi = (f & 64) ? rr.w : rr.y;
-        const unsigned w = ((f & 32) ? whi : wlo) >> (f & 31);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x.v[c][r] = (all || ((w >> r) & 1u)) ? x.v[c][r] * scale : 0.f;
-    }
-}
 
 // attention of the wave's 16 query rows over its own heads h = c0 .. c0 + NCT - 1; K / V^T images of the whole sequence in LDS
 constexpr int NIMG_KEYS = 64;
@@ -351,44 +128,6 @@ __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)
     }
 }
 
-// one product of the chain on the own column tiles: fp32 -- strip MFMA loop with the next slab's DMA pieces and the deferred stores
-// (`stores(ct, j)`) in its groups; bf16 -- the next slab requested up front, 16 MFMAs, the deferred stores behind them
-struct NoLate { __device__ __forceinline__ void operator()() const {} };
-// `late()` runs half way through the loop: loads the epilogue needs (LayerNorm gains: 64 registers) are requested there --
-// early enough to land under the remaining MFMAs, late enough not to be carried through the whole loop (vector-memory instructions do
-// not cross the loop's scheduling fences)
-template <int D, int NCT, bool BF, class Ring, class Stores, class Late = NoLate>
-__device__ __forceinline__ void seqn_product(f32x4 (&acc)[NCT], const StripRegs<D>& A, const float* __restrict__ buf, const Ring& ring,
-                                             const float* __restrict__ wn32, const unsigned short* __restrict__ wn16, int c0, const Stores& stores,
-                                             const Late& late = NoLate()) {
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (BF) {
-        ring.fetch_all(wn16);
-        late();
-        part_mma16<D, NCT>(acc, A, buf, c0);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) { stores(ct, 1); stores(ct, 3); }
-    } else {
-        part_mma<D, NCT>(acc, A, buf, c0, [&](int ct, int j) {
-            ring.fetch(wn32, ct, j);
-            stores(ct, j);
-            if (ct == D / 16 / 2 && j == 0) late();
-        });
-    }
-}
-
-// the own column tiles of a per-column vector held whole: two parts -- selects on the wave-uniform part index; more parts -- loaded
-// (select chains over four or eight candidates end up as scratch arrays)
-template <int D, int NCT>
-__device__ __forceinline__ void own_cols(PartRegs<NCT>& o, const ColVec<D>& full, const float* __restrict__ p, int part, int c0) {
-    if constexpr ((D / 16) / NCT == 2) {
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) o.v[c] = part ? full.v[NCT + c] : full.v[c];
-    } else {
-        part_cols<NCT>(o, p, c0);
-    }
-}
 
 template <int D, int WPS, int NS, bool BF>
 __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArgs a, const SeqGeom sg) {
@@ -671,6 +410,7 @@ static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
 // variant: 0 = the default split for the shape; 42 / 22 / 24 / 14 / 18 = WPS, NS spelled out (diagnostics and tests)
 int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int variant, void* stream) {
     const int T = sg.T;
+    if (a.train && spec_bits(a.spec) != 1) return AMID_ERR_UNSUPPORTED;      // part_dropout: the one-bit keep decisions of p = 0.5 (the reference's rate)
     const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4;
     if (variant == 0) variant = wps == 4 ? 42 : wps == 2 ? 24 : 14;
     if (variant / 10 != wps) return AMID_ERR_UNSUPPORTED;

@@ -1,0 +1,356 @@
+// The one-launch backward of the SASRec encoder, N-split build: the data gradients of a train step for the LIVE sequences, a workgroup
+// per sequence as seq_bwd_kernel (sasrec_strip.hip), but with EIGHT waves -- two per 16-row strip, each owning D / 2 output columns of
+// every product (seqn_parts.h, as the forward of sasrec_seqn.hip) -- and a wave per head in the attention core.  Same operations,
+// operands, dropout counters, outputs and summation orders as seq_bwd_kernel: the two builds agree bit for bit
+// (tests/test_gpu_strip.py).  Reference: autograd of Log2feats.forward (model_seq.py:371-383) under loss.backward(), train_sr.py:214.
+//
+// Why: in seq_bwd_kernel a SIMD holds ONE wave whose chain is 12 weight slabs x 256 MFMAs + two heads of the attention core per
+// layer, and nothing covers its epilogues (LayerNorm backward, masks, stores), barriers and first-touch loads.  Here a SIMD holds two
+// waves with 128 MFMAs per slab each -- one's epilogue under the other's matrix work -- and the attention core is one head per wave.
+//   * a product needs the whole row of its operand: the operands made inside the chain (dpre2, dpre1, dy, dqn) are exchanged between
+//     the strip's two waves through LDS ([strip][column tile][lane] float4); the ones that come from memory (dq, dk, dv) are loaded
+//     whole by both.  Row sums of the LayerNorm backward are taken over the whole row by both waves (same order as the strip build);
+//     element-wise work and stores cover the own columns.
+//   * LDS (fp32): ring 2 x 64 KB + exchange 32 KB = the whole CU.  While the exchange is idle (between the feed-forward chain's last
+//     product and the q / k / v chain) it holds the attention core's per-wave transpose tiles and the LayerNorm partial sums of the four
+//     strips: the partial sums of the q / k / v chain are carried in registers to that point of the NEXT layer (the last one has its own
+//     barrier pair), so the chains pay no barrier for them.
+#include "common.h"
+#include "rng.h"
+#include "strip_gemm.h"
+#include "attention_mfma.h"
+#include "seq_fwd.h"
+#include "seqn_parts.h"
+#include "seq_bwd.h"
+#include <type_traits>
+
+namespace amid {
+
+#ifdef AMID_STRIP_STAMPS
+static __device__ unsigned long long amid_seqnb_stamp_buf[8 * 64];
+#define SEQNB_STAMP(i) do { if (blockIdx.x == 0 && lane_id() == 0 && (i) < 64) amid_seqnb_stamp_buf[wave_id() * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SEQNB_STAMP(i) do { } while (0)
+#endif
+
+template <int D, int NCT>
+__device__ __forceinline__ void own_of(PartRegs<NCT>& o, const StripRegs<D>& full, int part) {
+    static_assert(D / 16 == 2 * NCT, "two column parts");
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) o.v[c] = part ? full.v[NCT + c] : full.v[c];
+}
+
+// row statistics of the LayerNorm backward over the WHOLE row, in strip_ln_bwd's order: mean / rstd of the input row, c1 = mean(gam dy),
+// c2 = mean(gam dy xh)
+template <int D>
+__device__ __forceinline__ void ln_bwd_sums(const StripRegs<D>& dy, const StripRegs<D>& x, const ColVec<D>& gam, float eps, float& mean, float& rstd,
+                                            float& c1, float& c2) {
+    strip_stats<D>(x, eps, mean, rstd);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < D / 16; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xh = (x.v[ct][r] - mean) * rstd;
+            float gy = gam.v[ct][r] * dy.v[ct][r];
+            asm volatile("" : "+v"(gy));               // the rounded product, as strip_ln_bwd
+            s1 += gy;
+            s2 = fmaf(gy, xh, s2);
+        }
+    }
+    c1 = row_sum4(s1) * (1.0f / D);
+    c2 = row_sum4(s2) * (1.0f / D);
+}
+
+// column sums of the strip's 16 rows of the own column tiles -> scratch [strip][2][D] (the layout of ln_partials_wave for four waves)
+template <int D, int NCT>
+__device__ __forceinline__ void ln_partials_part(float* __restrict__ scratch, int si, int c0, const PartRegs<NCT>& dgam, const PartRegs<NCT>& dbet) {
+    const int lane = lane_id();
+    float* mine = scratch + si * 2 * D;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        f32x4 a, b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = col_sum16(dgam.v[c][r]); b[r] = col_sum16(dbet.v[c][r]); }
+        if ((lane & 15) == 0) {
+            lds_st4(mine + (c0 + c) * 16 + 4 * (lane >> 4), a);
+            lds_st4(mine + D + (c0 + c) * 16 + 4 * (lane >> 4), b);
+        }
+    }
+}
+
+// what the feed-forward chain needs first: requested a product ahead by the caller
+template <int D, int NCT> struct FfnPreN { PartRegs<NCT> Ho; unsigned tmw[NCT]; ColVec<D> gam; uint4 rr2; };
+
+template <int D, bool BF>
+__global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const StripGeom sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = D / 16, WPS = 4, NW = 8, NCT = NT / 2;
+    static_assert(D == 128, "");
+    const int bid = blockIdx.x;
+    const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    const int part = w / WPS, si = w % WPS, c0 = part * NCT;
+    const int B = sg.B, T = sg.T;
+    // workgroup -> live sequence: the live list holds domain 0's batch rows, then domain 1's
+    const int n0 = sg.live[B], n1 = B - n0;
+    const int g = bid >= n0 ? 1 : 0;
+    const int tl = bid - (g ? n0 : 0);
+    const int top = a.n_layers - 1;
+    using RingT = typename std::conditional<BF, SeqRing16<D, NW>, SeqRingN<D, NW>>::type;
+    RingT ring(smem);
+    auto W16 = [](const float* p) { return reinterpret_cast<const unsigned short*>(p); };
+    if constexpr (BF) ring.first(W16(a.L[top].f.w2T[g])); else ring.first(a.L[top].f.w2T[g]);
+    const int b = sg.live[bid];
+    const int slot = g * B + tl;
+    {   // the B slots without a live sequence hold zeros: workgroup j writes dead slot j (threads 0..255: the feed-forward LayerNorm's, 256..511: the other)
+        const int dslot = bid < n1 ? n0 + bid : B + n1 + (bid - n1);
+        const int e = threadIdx.x & (2 * D - 1);
+        for (int l = 0; l <= top; ++l) {
+            float* p = threadIdx.x < 2 * D ? a.L[l].f.ln_part : a.L[l].a.ln_part;
+            p[(long long)dslot * 2 * D + e] = 0.f;
+        }
+    }
+    float* const E = smem + (BF ? D * D : 2 * D * D);                          // the exchange: [strip][column tile][lane] float4
+    float* const xb = E + si * (NT * 64 * 4);
+    float* const S_f = E;                                                      // while the exchange is idle: LayerNorm partial sums [4][2][D] of
+    float* const S_a = E + 8 * D;                                              // the feed-forward chain / of the layer above's q / k / v chain,
+    float* const att_lds = E + 16 * D + w * (ATTN_BWD_LDS_PER_WAVE / 4);       // and this wave's transpose tiles of the attention core
+    const int t = si * 16 + m;
+    StripRow row;
+    row.ok = t < T;
+    row.local = b * T + min(t, T - 1);
+    const unsigned phys = (unsigned)g * (unsigned)sg.M + (unsigned)(b * T + t);
+    row.off = row.ok ? phys * (unsigned)(D * 4) + 16u * (unsigned)gq : STRIP_OOB;
+    const unsigned off_own = row.ok ? row.off + (unsigned)c0 * 64u : STRIP_OOB;
+    const unsigned tm_own = row.ok ? phys * (unsigned)(D / 4) + (unsigned)c0 * 4u : STRIP_OOB;
+    const long long rowbase = (long long)g * sg.M + (long long)b * T;
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.L[top].f.train) { seed = a.L[top].f.st->seed; step = (unsigned)a.L[top].f.st->step; }
+
+    auto ffn_prefetch = [&](FfnPreN<D, NCT>& p, const StripFfnBwdArgs& f) {
+        part_load<NCT>(p.Ho, GBuf(f.h, sg.act_bytes), off_own);
+        if (f.tmq != nullptr) {
+            const GBuf gtm(f.tmq, sg.tm_bytes);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) p.tmw[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(gtm.r, (int)(tm_own + 4 * c), 0, 0);
+        }
+        p.gam.load(f.ln_w[g]);
+        p.rr2 = make_uint4(0, 0, 0, 0);
+        if (f.train) p.rr2 = rng_call(seed, (unsigned long long)row.local * D >> 7, site_id(g, f.layer, SITE_FFN2), step);
+    };
+
+    SEQNB_STAMP(0);
+    PartRegs<NCT> DZo;                                      // d x' of the layer in hand, own columns
+    PartRegs<NCT> dgam_a, dbet_a;                           // LayerNorm-1 partial sums of the layer above (carried to this layer's idle point)
+    FfnPreN<D, NCT> pre;
+    part_load<NCT>(DZo, GBuf(a.L[top].f.dxo, sg.act_bytes), off_own);
+    ffn_prefetch(pre, a.L[top].f);
+    f32x4 acc[NCT];
+    StripRegs<D> F;                                         // the whole-row operand of the next product
+#pragma unroll 1
+    for (int l = top; l >= 0; --l) {
+        const SeqBwdLayer& P = a.L[l];
+        const SeqBwdLayer& Pn = a.L[l > 0 ? l - 1 : 0];
+        const StripFfnBwdArgs& f = P.f;
+        const StripQkvBwdArgs& q = P.a;
+        [[maybe_unused]] const int sb = 1 + 8 * (top - l);
+        AttnBwdOps oa;
+        const bool nt4 = T > 48;
+        PartRegs<NCT> dgam_f, dbet_f;
+        // ---------------------------------------------------------------- feed-forward / out-projection chain: DZo -> dpre2, dpre1, dr, d_o
+        {
+            const GBuf gp2(f.dpre2, sg.act_bytes), gp1(f.dpre1, sg.act_bytes), gdr(f.dr, sg.act_bytes), gdo(f.d_o, sg.act_bytes);
+            if (f.tmq != nullptr) {                         // dz = dx' * ~tm
+                const int sh = 8 * gq;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                    const unsigned bits = pre.tmw[c] >> sh;
+                    DZo.v[c][0] = (bits & 1u) ? 0.f : DZo.v[c][0];
+                    DZo.v[c][1] = (bits & 2u) ? 0.f : DZo.v[c][1];
+                    DZo.v[c][2] = (bits & 4u) ? 0.f : DZo.v[c][2];
+                    DZo.v[c][3] = (bits & 8u) ? 0.f : DZo.v[c][3];
+                }
+            }
+            PartRegs<NCT> Po = DZo;                         // dpre2 = dz * drop2
+            if (f.train) part_dropout<NCT>(Po, pre.rr2, c0, f.spec, f.scale);
+            lds_barrier();                                  // the partner has read this wave's slots of the previous exchange
+            xchg_write<NCT>(xb, c0, Po);
+            StripRegs<D> Rs;
+            {   // dh = dpre2 C2 ; dpre1 = dh * relu'(h) * drop1   (h > 0 implies the unit was kept by drop1)
+                const float* buf = ring.next();
+                xchg_read<D>(F, xb);
+                seqn_product<D, NCT, BF>(acc, F, buf, ring, f.w1T[g], W16(f.w1T[g]), c0,
+                                         [&](int ct, int j) { part_spread<NCT>(gp2, off_own, Po, ct, j, 1); },
+                                         [&]() { strip_load<D>(Rs, GBuf(f.r, sg.act_bytes), row); });      // LN2 input rows: needed a slab from now
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Po.v[c][r] = pre.Ho.v[c][r] > 0.f ? acc[c][r] * f.scale : 0.f;
+            }
+            SEQNB_STAMP(sb);
+            lds_barrier();
+            xchg_write<NCT>(xb, c0, Po);
+            {   // dy = dpre1 C1 + dz
+                const float* buf = ring.next();
+                xchg_read<D>(F, xb);
+                seqn_product<D, NCT, BF>(acc, F, buf, ring, f.woT[g], W16(f.woT[g]), c0,
+                                         [&](int ct, int j) { part_spread<NCT>(gp1, off_own, Po, ct, j, 1); });
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) Po.v[c] = acc[c] + DZo.v[c];
+            }
+            SEQNB_STAMP(sb + 1);
+            lds_barrier();
+            xchg_write<NCT>(xb, c0, Po);
+            {   // dr = LN2'(dy ; r) ; d_o = dr Wo
+                const float* buf = ring.next();
+                xchg_read<D>(F, xb);                        // the whole row of dy
+                float mean, rstd, c1, c2;
+                ln_bwd_sums<D>(F, Rs, pre.gam, f.ln_eps, mean, rstd, c1, c2);
+                PartRegs<NCT> Ro;
+                own_of<D, NCT>(Ro, Rs, part);
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (Ro.v[c][r] - mean) * rstd;
+                        float dg = Po.v[c][r] * xh;
+                        asm volatile("" : "+v"(dg));           // (rounded, as strip_ln_bwd)
+                        dgam_f.v[c][r] = dg;
+                        dbet_f.v[c][r] = Po.v[c][r];
+                    }
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (Rs.v[ct][r] - mean) * rstd;
+                        float gy = pre.gam.v[ct][r] * F.v[ct][r];
+                        asm volatile("" : "+v"(gy));          // the rounded product, as strip_ln_bwd keeps it (not contracted into the subtraction)
+                        F.v[ct][r] = rstd * (gy - c1 - xh * c2);
+                    }
+                own_of<D, NCT>(Po, F, part);                // dr, own columns (stored under the product)
+                // the attention core's saved operands of this wave's head: they come from HBM -- requested under this product
+                if (nt4) attn_bwd_load_saved<4>(oa, P.at, g, b, rowbase, w); else attn_bwd_load_saved<3>(oa, P.at, g, b, rowbase, w);
+                seqn_product<D, NCT, BF>(acc, F, buf, ring, q.wkT[g], W16(q.wkT[g]), c0,
+                                         [&](int ct, int j) { part_spread<NCT>(gdr, off_own, Po, ct, j, 1); });
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) gdo.store4(off_own + c * 64, acc[c]);
+            }
+        }
+        SEQNB_STAMP(sb + 2);
+        w_ring_wait();                  // d_o has reached L2 (the Wk slab has landed as well)
+        __syncthreads();                // ... and nobody reads the exchange any more
+        ln_partials_part<D, NCT>(S_f, si, c0, dgam_f, dbet_f);
+        if (l < top) ln_partials_part<D, NCT>(S_a, si, c0, dgam_a, dbet_a);
+        // ---------------------------------------------------------------- attention core: head w
+        if (nt4) { attn_bwd_load_dout<4>(oa, P.at, rowbase, w); attn_bwd_compute<4>(oa, P.at, rowbase, w, att_lds); }
+        else { attn_bwd_load_dout<3>(oa, P.at, rowbase, w); attn_bwd_compute<3>(oa, P.at, rowbase, w, att_lds); }
+        SEQNB_STAMP(sb + 3);
+        w_ring_wait();                  // dq / dk / dv have reached L2
+        __syncthreads();
+        {   // the four strips' partial sums -> this sequence's slot (fixed order)
+            const int e = threadIdx.x & (2 * D - 1);
+            if (threadIdx.x < 2 * D) f.ln_part[(long long)slot * 2 * D + e] = (S_f[e] + S_f[2 * D + e]) + (S_f[4 * D + e] + S_f[6 * D + e]);
+            else if (l < top) a.L[l + 1].a.ln_part[(long long)slot * 2 * D + e] = (S_a[e] + S_a[2 * D + e]) + (S_a[4 * D + e] + S_a[6 * D + e]);
+        }
+        SEQNB_STAMP(sb + 4);
+        // ---------------------------------------------------------------- q / k / v + LayerNorm-1 chain: dq, dk, dv, dr -> d x (own columns)
+        {
+            StripRegs<D> A2;
+            ColVec<D> gam;
+            PartRegs<NCT> Dro;
+            f32x4 acc_kv[NCT];
+            strip_load<D>(F, GBuf(q.dk, sg.act_bytes), row);
+            {   // dk Wk
+                const float* buf = ring.next();
+                seqn_product<D, NCT, BF>(acc_kv, F, buf, ring, q.wvT[g], W16(q.wvT[g]), c0, [](int, int) {},
+                                         [&]() { strip_load<D>(A2, GBuf(q.dv, sg.act_bytes), row); });
+            }
+            SEQNB_STAMP(sb + 5);
+            {   // + dv Wv
+                const float* buf = ring.next();
+                seqn_product<D, NCT, BF, false>(acc_kv, A2, buf, ring, q.wqT[g], W16(q.wqT[g]), c0, [](int, int) {},
+                                                [&]() { strip_load<D>(F, GBuf(q.dq, sg.act_bytes), row); });
+            }
+            SEQNB_STAMP(sb + 6);
+            {   // dqn = dq Wq + dr ; dx = LN1'(dqn ; x) + (dk Wk + dv Wv)
+                const float* buf = ring.next();
+                part_load<NCT>(Dro, GBuf(q.dr, sg.act_bytes), off_own);              // residual-path gradient of the normed query
+                strip_load<D>(A2, GBuf(q.x, sg.act_bytes), row);                     // LN1 input rows
+                gam.load(q.ln_w[g]);
+                seqn_product<D, NCT, BF>(acc, F, buf, ring, Pn.f.w2T[g], W16(Pn.f.w2T[g]), c0, [](int, int) {},
+                                         [&]() { ffn_prefetch(pre, Pn.f); });        // (layer 0 "prefetches" its own: harmless, dead afterwards)
+                PartRegs<NCT> Qo;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) Qo.v[c] = Dro.v[c] + acc[c];
+                xchg_write<NCT>(xb, c0, Qo);               // (the exchange's last readers sit behind the attention core's barriers)
+                lds_barrier();
+                xchg_read<D>(F, xb);                        // the whole row of dqn
+                float mean, rstd, c1, c2;
+                ln_bwd_sums<D>(F, A2, gam, q.ln_eps, mean, rstd, c1, c2);
+                PartRegs<NCT> Xo, Go;
+                own_of<D, NCT>(Xo, A2, part);
+                own_cols<D, NCT>(Go, gam, q.ln_w[g], part, c0);
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (Xo.v[c][r] - mean) * rstd;
+                        float gy = Go.v[c][r] * Qo.v[c][r];
+                        asm volatile("" : "+v"(gy));
+                        float dg = Qo.v[c][r] * xh;
+                        asm volatile("" : "+v"(dg));
+                        dgam_a.v[c][r] = dg;
+                        dbet_a.v[c][r] = Qo.v[c][r];
+                        DZo.v[c][r] = rstd * (gy - c1 - xh * c2);
+                    }
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) DZo.v[c] += acc_kv[c];
+            }
+            if (l == 0) part_store<NCT>(GBuf(q.dx, sg.act_bytes), off_own, DZo);
+        }
+        SEQNB_STAMP(sb + 7);
+    }
+    // the last chain's LayerNorm partial sums
+    __syncthreads();                    // every wave has read its row of dqn
+    ln_partials_part<D, NCT>(S_a, si, c0, dgam_a, dbet_a);
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+        const int e = threadIdx.x;
+        a.L[0].a.ln_part[(long long)slot * 2 * D + e] = (S_a[e] + S_a[2 * D + e]) + (S_a[4 * D + e] + S_a[6 * D + e]);
+    }
+    SEQNB_STAMP(63);
+    w_ring_wait();                      // the last (redundant) weight fetch targets this workgroup's LDS
+}
+
+template <bool BF> static constexpr size_t seqn_bwd_lds_bytes() {
+    return (size_t)((BF ? 128 * 128 : 2 * 128 * 128) + 4 * 8 * 64 * 4) * sizeof(float);
+}
+
+template <bool BF>
+static int seqn_bwd_launch_t(const SeqBwdArgs& a, const StripGeom& sg, void* stream) {
+    constexpr size_t lds = seqn_bwd_lds_bytes<BF>();
+    auto kern = seqn_bwd_kernel<128, BF>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    kern<<<sg.B, 512, lds, (hipStream_t)stream>>>(a, sg);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? AMID_OK : (int)e;
+}
+
+int launch_seqn_bwd(const SeqBwdArgs& a, const StripGeom& sg, int mma_bf16, void* stream) {
+    const StripFfnBwdArgs& f = a.L[a.n_layers - 1].f;
+    if (f.train && spec_bits(f.spec) != 1) return AMID_ERR_UNSUPPORTED;      // part_dropout: the one-bit keep decisions of p = 0.5 (the reference's rate)
+    return mma_bf16 ? seqn_bwd_launch_t<true>(a, sg, stream) : seqn_bwd_launch_t<false>(a, sg, stream);
+}
+
+}  // namespace amid
+
+#ifdef AMID_STRIP_STAMPS
+extern "C" int amid_seqnb_stamps_read(unsigned long long* host) {      // diagnostic library only
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(amid::amid_seqnb_stamp_buf), sizeof(unsigned long long) * 8 * 64);
+}
+#endif

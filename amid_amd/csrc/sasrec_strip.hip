@@ -18,6 +18,7 @@
 #include "strip_gemm.h"
 #include "sort_phases.h"
 #include "attention_mfma.h"
+#include "seq_bwd.h"
 #include <type_traits>
 
 namespace amid {
@@ -38,27 +39,6 @@ struct StripOffArgs {
     float* r; float* y; float* h; float* xo;
     float ln_eps;
     const StepState* st; int train; unsigned spec; float scale; int layer;
-};
-
-struct StripFfnBwdArgs {
-    const float* dxo;                   // [2M, D] gradient of the layer output
-    const unsigned char* tmq;
-    const float* h; const float* r;     // saved relu output, saved LN2 input
-    const float* ln_w[2];
-    const float* w1T[2]; const float* w2T[2]; const float* woT[2];
-    float* dpre2; float* dpre1; float* dr; float* d_o;
-    float* ln_part;                     // [2 tpg][2][D]
-    float ln_eps;
-    const StepState* st; int train; unsigned spec; float scale; int layer;
-};
-
-struct StripQkvBwdArgs {
-    const float* dq; const float* dk; const float* dv; const float* dr; const float* x;
-    const float* ln_w[2];
-    const float* wqT[2]; const float* wkT[2]; const float* wvT[2];
-    float* dx;
-    float* ln_part;                     // [2 tpg][2][D]
-    float ln_eps;
 };
 
 template <int D>
@@ -258,10 +238,14 @@ __device__ __forceinline__ void strip_ln_bwd(StripRegs<D>& dx, const StripRegs<D
     for (int ct = 0; ct < D / 16; ++ct) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float xh = (x.v[ct][r] - mean) * rstd, gy = gam.v[ct][r] * dy.v[ct][r];
-            s1 += gy;
+            const float xh = (x.v[ct][r] - mean) * rstd;
+            float gy = gam.v[ct][r] * dy.v[ct][r];
+            asm volatile("" : "+v"(gy));               // the ROUNDED product everywhere below (never contracted into a sum: the N-split build
+            s1 += gy;                                  // of the fused backward, sasrec_seqn_bwd.hip, reproduces these bits)
             s2 = fmaf(gy, xh, s2);
-            dgam.v[ct][r] = dy.v[ct][r] * xh;          // first (and only) row of this lane
+            float dg = dy.v[ct][r] * xh;               // first (and only) row of this lane
+            asm volatile("" : "+v"(dg));               // (rounded: not contracted into the column sums' first addition)
+            dgam.v[ct][r] = dg;
             dbet.v[ct][r] = dy.v[ct][r];
             dx.v[ct][r] = gy;                          // finished below
         }
@@ -476,13 +460,6 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const Stri
 // copies anyway): a workgroup barrier behind a vmcnt(0) makes a workgroup's stores visible to its own loads (same CU, same L1).
 // What it saves is every launch boundary's tail and head -- the last stores, the launch, the first weight slab, the first
 // operand loads: the next chain's first slab lands under the attention core and its operands are L2 hits.
-struct SeqBwdLayer {
-    StripFfnBwdArgs f;                  // f.dxo: the top layer's only; f.ln_part / a.ln_part: [2 B][2][D], slot g * B + (index in the domain's live list)
-    StripQkvBwdArgs a;                  // a.dx: layer 0's only
-    AttnArgs at;
-};
-struct SeqBwdArgs { SeqBwdLayer L[2]; int n_layers; };
-
 template <int D, bool BF = false>
 __global__ __launch_bounds__(STRIP_THREADS) void seq_bwd_kernel(const SeqBwdArgs a, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -801,7 +778,16 @@ extern "C" int amid_sas_seq_bwd_supported(int B, int T, int D, int H) {
     return (D == 128 && H == 8 && T > 32 && T <= 64 && B > 0 && 2LL * B * T * D * 4 <= 0x7FFFFFF0LL) ? 1 : 0;
 }
 
-// The data gradients of the encoder for the live sequences of a train step in one launch (seq_bwd_kernel).  Per-layer arrays hold
+// Which build of the one-launch backward runs: 0 = auto, 1 = a wave per strip (seq_bwd_kernel), 2 = the N-split build (two waves per
+// strip, a wave per head in the attention core: sasrec_seqn_bwd.hip).  v < 0 only queries.  Returns the previous value.
+static int g_seq_bwd_variant = 0;
+extern "C" int amid_sas_seq_bwd_variant(int v) {
+    const int prev = g_seq_bwd_variant;
+    if (v >= 0) g_seq_bwd_variant = v;
+    return prev;
+}
+
+// The data gradients of the encoder for the live sequences of a train step in one launch (seq_bwd_kernel / seqn_bwd_kernel).  Per-layer arrays hold
 // n_layers entries (saved tensors, gradient outputs, LayerNorm partials) or 2 * n_layers ordered [layer][domain] (parameters and
 // transposed weights).  dxo: gradient of the last layer's output; dx: gradient of layer 0's input (rows of live sequences only; the
 // others are not touched).  ln1_part / ln2_part: per layer [2 B][2][D], domain g's slots are [g B, (g + 1) B), the first n_g of them
@@ -848,6 +834,10 @@ extern "C" int amid_sas_seq_bwd_f32(int n_layers, const float* dxo, const unsign
     }
     StripGeom sg;
     if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
+    if (g_seq_bwd_variant != 1) {
+        const int rc = launch_seqn_bwd(a, sg, mma_bf16, stream);
+        if (rc != AMID_ERR_UNSUPPORTED) return rc;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)seq_bwd_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_bwd_lds_bytes<128>());

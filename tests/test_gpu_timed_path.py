@@ -151,6 +151,43 @@ def test_timed_path_fused_backward_vs_oracle(Bn, T, D, split, force):
     _timed_vs_oracle(Bn, T, D, None, split, compact_min=None, seq_backward=force)
 
 
+@pytest.mark.parametrize("Bn,T,split", [(256, 50, "mixed"), (300, 40, "mixed"), (64, 33, "mixed"), (200, 50, "one0"), (256, 64, "all1")])
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_n_split_fused_backward_is_bit_identical_to_the_strip_build(Bn, T, split, compute):
+    """amid_sas_seq_bwd_f32's two builds (csrc/sasrec_strip.hip seq_bwd_kernel: a wave per 16-row strip; csrc/sasrec_seqn_bwd.hip: two waves
+    per strip with half the columns each, a wave per head in the attention core) sum every product and every row / column sum in the
+    same order: the step's dense gradients, the saved gradient tensors the weight gradients read and the table-row gradients agree bit
+    for bit (the strip build itself is held to the oracle above)."""
+    from amid_amd._lib import lib
+    L = lib()
+    D, hid, n_items = 128, 32, 3000
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=300 + D + Bn)
+    batch = split_batch(Bn, T, n_items, seed=Bn + T, split=split)
+    seed, step = 21, 4
+    got = {}
+    prev = L.value("amid_sas_seq_bwd_variant", -1)
+    try:
+        for v in (1, 2):
+            L.value("amid_sas_seq_bwd_variant", v)
+            eng = make_engine(P, T, seed=seed, compute=compute)
+            eng.SEQ_BACKWARD = "1"
+            pl = eng.plan(Bn, T, 2, need_grad=True)
+            for ts in (pl.dq_l, pl.dk_l, pl.dv_l, pl.dpre1, pl.dpre2, pl.dr):       # rows outside the live sequences are never written
+                for t_ in ts:
+                    t_.zero_()
+            pl.dxbuf.zero_()
+            timed_local_grads(eng, pl, batch, step, seed)
+            assert eng._seq_backward(pl)
+            n = int(pl.n_uniq.item())
+            got[v] = dict(rows=pl.uniq_grad[:n].clone(), dx=pl.dxbuf.clone(), **{name: eng.dense.view(name, eng.dense.grad).clone() for name in eng.dense.slots},
+                          **{f"{k}{l}": getattr(pl, k)[l].clone() for k in ("dq_l", "dk_l", "dv_l", "dpre1", "dpre2", "dr") for l in (0, 1)})
+    finally:
+        L.value("amid_sas_seq_bwd_variant", prev)
+    bad = {name: float((got[2][name] - want).abs().max()) for name, want in got[1].items() if not torch.equal(got[2][name], want)}
+    assert all(bool(torch.isfinite(t_).all()) for t_ in got[1].values())
+    assert not bad, " ".join(f"{k}:{v:.1e}" for k, v in bad.items())
+
+
 @pytest.mark.parametrize("Bn,T", [(512, 50), (256, 20)])
 def test_timed_path_bf16_products_vs_fp32_oracle(Bn, T):
     """compute="bf16" (BASELINE.json configs[2]: batch 512, bf16 with an fp32 reference tolerance check) THROUGH THE TIMED PATH: the
