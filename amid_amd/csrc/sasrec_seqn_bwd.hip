@@ -2,7 +2,7 @@
 // per sequence as seq_bwd_kernel (sasrec_strip.hip), but with EIGHT waves -- two per 16-row strip, each owning D / 2 output columns of
 // every product (seqn_parts.h, as the forward of sasrec_seqn.hip) -- and a wave per head in the attention core.  Same operations,
 // operands, dropout counters, outputs and summation orders as seq_bwd_kernel: the two builds agree bit for bit
-// (tests/test_gpu_strip.py).  Reference: autograd of Log2feats.forward (model_seq.py:371-383) under loss.backward(), train_sr.py:214.
+// (tests/test_gpu_timed_path.py::test_n_split_fused_backward_*).  Reference: autograd of Log2feats.forward (model_seq.py:371-383) under loss.backward(), train_sr.py:214.
 //
 // Why: in seq_bwd_kernel a SIMD holds ONE wave whose chain is 12 weight slabs x 256 MFMAs + two heads of the attention core per
 // layer, and nothing covers its epilogues (LayerNorm backward, masks, stores), barriers and first-touch loads.  Here a SIMD holds two
@@ -11,6 +11,11 @@
 //     the strip's two waves through LDS ([strip][column tile][lane] float4); the ones that come from memory (dq, dk, dv) are loaded
 //     whole by both.  Row sums of the LayerNorm backward are taken over the whole row by both waves (same order as the strip build);
 //     element-wise work and stores cover the own columns.
+//   Measured (profiles/tools/seqn_bwd_stamps.py, bench.py with AMID_SEQ_BACKWARD=1 AMID_SEQ_BWD_VARIANT=1|2): the products themselves run at
+//   the matrix pipe's rate here (2.9 - 3.4 us per 64 x 128 x 128 slab pair against 6.5 in the strip build), but what surrounds them does not
+//   shrink: the attention core's operand requests (24 per wave, 4.4 us for the eight waves of a CU), the barriers' skew, the first-use
+//   round trips of dk / d_o.  In-kernel 112 - 116 us against 109; launch 124 - 128 against 124 - 126 us at cfg 2, 240.8 against 238.8 at
+//   cfg 3: no gain, so "auto" stays the strip build and this one is the switchable, bit-identical alternative.
 //   * LDS (fp32): ring 2 x 64 KB + exchange 32 KB = the whole CU.  While the exchange is idle (between the feed-forward chain's last
 //     product and the q / k / v chain) it holds the attention core's per-wave transpose tiles and the LayerNorm partial sums of the four
 //     strips: the partial sums of the q / k / v chain are carried in registers to that point of the NEXT layer (the last one has its own
@@ -62,21 +67,29 @@ __device__ __forceinline__ void ln_bwd_sums(const StripRegs<D>& dy, const StripR
     c2 = row_sum4(s2) * (1.0f / D);
 }
 
-// column sums of the strip's 16 rows of the own column tiles -> scratch [strip][2][D] (the layout of ln_partials_wave for four waves)
-template <int D, int NCT>
-__device__ __forceinline__ void ln_partials_part(float* __restrict__ scratch, int si, int c0, const PartRegs<NCT>& dgam, const PartRegs<NCT>& dbet) {
-    const int lane = lane_id();
-    float* mine = scratch + si * 2 * D;
+// column sums over the strip's 16 rows of the own column tiles (NCT * 4 = 16 per lane), compacted: lane (m, g) keeps the sum of column
+// (c0 + (m >> 2)) * 16 + 4 g + (m & 3) -- one register instead of sixteen for a tensor that waits for its LDS slot
+template <int NCT>
+__device__ __forceinline__ float col_sums_compact(const PartRegs<NCT>& x) {
+    static_assert(NCT == 4, "sixteen values over sixteen lanes");
+    const int m = lane_id() & 15;
+    float out = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) {
-        f32x4 a, b;
+    for (int c = 0; c < NCT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { a[r] = col_sum16(dgam.v[c][r]); b[r] = col_sum16(dbet.v[c][r]); }
-        if ((lane & 15) == 0) {
-            lds_st4(mine + (c0 + c) * 16 + 4 * (lane >> 4), a);
-            lds_st4(mine + D + (c0 + c) * 16 + 4 * (lane >> 4), b);
+        for (int r = 0; r < 4; ++r) {
+            const float sum = col_sum16(x.v[c][r]);
+            out = (m == c * 4 + r) ? sum : out;
         }
-    }
+    return out;
+}
+// -> scratch [strip][2][D] (the layout of ln_partials_wave for four waves)
+template <int D>
+__device__ __forceinline__ void ln_partials_put(float* __restrict__ scratch, int si, int c0, float dgam, float dbet) {
+    const int lane = lane_id(), m = lane & 15;
+    float* p = scratch + si * 2 * D + (c0 + (m >> 2)) * 16 + 4 * (lane >> 4) + (m & 3);
+    lds_st1(p, dgam);
+    lds_st1(p + D, dbet);
 }
 
 // what the feed-forward chain needs first: requested a product ahead by the caller
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
 
     SEQNB_STAMP(0);
     PartRegs<NCT> DZo;                                      // d x' of the layer in hand, own columns
-    PartRegs<NCT> dgam_a, dbet_a;                           // LayerNorm-1 partial sums of the layer above (carried to this layer's idle point)
+    float dgam_a = 0.f, dbet_a = 0.f;                       // LayerNorm-1 partial sums of the layer above (compact; carried to this layer's idle point)
     FfnPreN<D, NCT> pre;
     part_load<NCT>(DZo, GBuf(a.L[top].f.dxo, sg.act_bytes), off_own);
     ffn_prefetch(pre, a.L[top].f);
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
         [[maybe_unused]] const int sb = 1 + 8 * (top - l);
         AttnBwdOps oa;
         const bool nt4 = T > 48;
-        PartRegs<NCT> dgam_f, dbet_f;
+        float dgam_f, dbet_f;
         // ---------------------------------------------------------------- feed-forward / out-projection chain: DZo -> dpre2, dpre1, dr, d_o
         {
             const GBuf gp2(f.dpre2, sg.act_bytes), gp1(f.dpre1, sg.act_bytes), gdr(f.dr, sg.act_bytes), gdo(f.d_o, sg.act_bytes);
@@ -204,20 +217,24 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
             {   // dr = LN2'(dy ; r) ; d_o = dr Wo
                 const float* buf = ring.next();
                 xchg_read<D>(F, xb);                        // the whole row of dy
+                if (l == 0) SEQNB_STAMP(32);
                 float mean, rstd, c1, c2;
                 ln_bwd_sums<D>(F, Rs, pre.gam, f.ln_eps, mean, rstd, c1, c2);
-                PartRegs<NCT> Ro;
-                own_of<D, NCT>(Ro, Rs, part);
+                {
+                    PartRegs<NCT> Ro;
+                    own_of<D, NCT>(Ro, Rs, part);
+                    dbet_f = col_sums_compact<NCT>(Po);
 #pragma unroll
-                for (int c = 0; c < NCT; ++c)
+                    for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float xh = (Ro.v[c][r] - mean) * rstd;
-                        float dg = Po.v[c][r] * xh;
-                        asm volatile("" : "+v"(dg));           // (rounded, as strip_ln_bwd)
-                        dgam_f.v[c][r] = dg;
-                        dbet_f.v[c][r] = Po.v[c][r];
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const float xh = (Ro.v[c][r] - mean) * rstd;
+                            float dg = Po.v[c][r] * xh;
+                            asm volatile("" : "+v"(dg));       // (rounded, as strip_ln_bwd)
+                            Ro.v[c][r] = dg;
+                        }
+                    dgam_f = col_sums_compact<NCT>(Ro);
+                }
 #pragma unroll
                 for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -228,8 +245,10 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                         F.v[ct][r] = rstd * (gy - c1 - xh * c2);
                     }
                 own_of<D, NCT>(Po, F, part);                // dr, own columns (stored under the product)
+                if (l == 0) SEQNB_STAMP(33);
                 // the attention core's saved operands of this wave's head: they come from HBM -- requested under this product
                 if (nt4) attn_bwd_load_saved<4>(oa, P.at, g, b, rowbase, w); else attn_bwd_load_saved<3>(oa, P.at, g, b, rowbase, w);
+                if (l == 0) SEQNB_STAMP(34);
                 seqn_product<D, NCT, BF>(acc, F, buf, ring, q.wkT[g], W16(q.wkT[g]), c0,
                                          [&](int ct, int j) { part_spread<NCT>(gdr, off_own, Po, ct, j, 1); });
 #pragma unroll
@@ -239,14 +258,18 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
         SEQNB_STAMP(sb + 2);
         w_ring_wait();                  // d_o has reached L2 (the Wk slab has landed as well)
         __syncthreads();                // ... and nobody reads the exchange any more
-        ln_partials_part<D, NCT>(S_f, si, c0, dgam_f, dbet_f);
-        if (l < top) ln_partials_part<D, NCT>(S_a, si, c0, dgam_a, dbet_a);
+        if (l == 0) SEQNB_STAMP(35);
+        ln_partials_put<D>(S_f, si, c0, dgam_f, dbet_f);
+        if (l < top) ln_partials_put<D>(S_a, si, c0, dgam_a, dbet_a);
+        if (l == 0) SEQNB_STAMP(36);
         // ---------------------------------------------------------------- attention core: head w
         if (nt4) { attn_bwd_load_dout<4>(oa, P.at, rowbase, w); attn_bwd_compute<4>(oa, P.at, rowbase, w, att_lds); }
         else { attn_bwd_load_dout<3>(oa, P.at, rowbase, w); attn_bwd_compute<3>(oa, P.at, rowbase, w, att_lds); }
         SEQNB_STAMP(sb + 3);
         w_ring_wait();                  // dq / dk / dv have reached L2
+        if (l == 0) SEQNB_STAMP(37);
         __syncthreads();
+        strip_load<D>(F, GBuf(q.dk, sg.act_bytes), row);      // the next chain's first operand: its round trip under the sums below
         {   // the four strips' partial sums -> this sequence's slot (fixed order)
             const int e = threadIdx.x & (2 * D - 1);
             if (threadIdx.x < 2 * D) f.ln_part[(long long)slot * 2 * D + e] = (S_f[e] + S_f[2 * D + e]) + (S_f[4 * D + e] + S_f[6 * D + e]);
@@ -255,11 +278,12 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
         SEQNB_STAMP(sb + 4);
         // ---------------------------------------------------------------- q / k / v + LayerNorm-1 chain: dq, dk, dv, dr -> d x (own columns)
         {
-            StripRegs<D> A2;
+            // (every operand is requested a product ahead of its use.  Tried: one request per slot of the MFMA loop in between instead of
+            // eight at once, the attention core's 24 included -- the same microseconds move into the loop: 240.8 -> 252.3 us at cfg 3)
+            StripRegs<D> A2, Xs;
             ColVec<D> gam;
             PartRegs<NCT> Dro;
             f32x4 acc_kv[NCT];
-            strip_load<D>(F, GBuf(q.dk, sg.act_bytes), row);
             {   // dk Wk
                 const float* buf = ring.next();
                 seqn_product<D, NCT, BF>(acc_kv, F, buf, ring, q.wvT[g], W16(q.wvT[g]), c0, [](int, int) {},
@@ -268,28 +292,33 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
             SEQNB_STAMP(sb + 5);
             {   // + dv Wv
                 const float* buf = ring.next();
-                seqn_product<D, NCT, BF, false>(acc_kv, A2, buf, ring, q.wqT[g], W16(q.wqT[g]), c0, [](int, int) {},
-                                                [&]() { strip_load<D>(F, GBuf(q.dq, sg.act_bytes), row); });
+                seqn_product<D, NCT, BF, false>(acc_kv, A2, buf, ring, q.wqT[g], W16(q.wqT[g]), c0, [](int, int) {}, [&]() {
+                    strip_load<D>(F, GBuf(q.dq, sg.act_bytes), row);
+                    strip_load<D>(Xs, GBuf(q.x, sg.act_bytes), row);                 // LN1 input rows
+                });
             }
             SEQNB_STAMP(sb + 6);
             {   // dqn = dq Wq + dr ; dx = LN1'(dqn ; x) + (dk Wk + dv Wv)
                 const float* buf = ring.next();
                 part_load<NCT>(Dro, GBuf(q.dr, sg.act_bytes), off_own);              // residual-path gradient of the normed query
-                strip_load<D>(A2, GBuf(q.x, sg.act_bytes), row);                     // LN1 input rows
                 gam.load(q.ln_w[g]);
+                if (l == 0) SEQNB_STAMP(38);
                 seqn_product<D, NCT, BF>(acc, F, buf, ring, Pn.f.w2T[g], W16(Pn.f.w2T[g]), c0, [](int, int) {},
                                          [&]() { ffn_prefetch(pre, Pn.f); });        // (layer 0 "prefetches" its own: harmless, dead afterwards)
                 PartRegs<NCT> Qo;
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) Qo.v[c] = Dro.v[c] + acc[c];
+                if (l == 0) SEQNB_STAMP(39);
                 xchg_write<NCT>(xb, c0, Qo);               // (the exchange's last readers sit behind the attention core's barriers)
                 lds_barrier();
                 xchg_read<D>(F, xb);                        // the whole row of dqn
+                if (l == 0) SEQNB_STAMP(40);
                 float mean, rstd, c1, c2;
-                ln_bwd_sums<D>(F, A2, gam, q.ln_eps, mean, rstd, c1, c2);
+                ln_bwd_sums<D>(F, Xs, gam, q.ln_eps, mean, rstd, c1, c2);
                 PartRegs<NCT> Xo, Go;
-                own_of<D, NCT>(Xo, A2, part);
+                own_of<D, NCT>(Xo, Xs, part);
                 own_cols<D, NCT>(Go, gam, q.ln_w[g], part, c0);
+                dbet_a = col_sums_compact<NCT>(Qo);
 #pragma unroll
                 for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -299,10 +328,10 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                         asm volatile("" : "+v"(gy));
                         float dg = Qo.v[c][r] * xh;
                         asm volatile("" : "+v"(dg));
-                        dgam_a.v[c][r] = dg;
-                        dbet_a.v[c][r] = Qo.v[c][r];
+                        Xo.v[c][r] = dg;
                         DZo.v[c][r] = rstd * (gy - c1 - xh * c2);
                     }
+                dgam_a = col_sums_compact<NCT>(Xo);
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) DZo.v[c] += acc_kv[c];
             }
@@ -312,7 +341,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
     }
     // the last chain's LayerNorm partial sums
     __syncthreads();                    // every wave has read its row of dqn
-    ln_partials_part<D, NCT>(S_a, si, c0, dgam_a, dbet_a);
+    ln_partials_put<D>(S_a, si, c0, dgam_a, dbet_a);
     __syncthreads();
     if (threadIdx.x < 2 * D) {
         const int e = threadIdx.x;

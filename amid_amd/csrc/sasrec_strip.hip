@@ -778,7 +778,7 @@ extern "C" int amid_sas_seq_bwd_supported(int B, int T, int D, int H) {
     return (D == 128 && H == 8 && T > 32 && T <= 64 && B > 0 && 2LL * B * T * D * 4 <= 0x7FFFFFF0LL) ? 1 : 0;
 }
 
-// Which build of the one-launch backward runs: 0 = auto, 1 = a wave per strip (seq_bwd_kernel), 2 = the N-split build (two waves per
+// Which build of the one-launch backward runs: 0 = auto (= 1), 1 = a wave per strip (seq_bwd_kernel), 2 = the N-split build (two waves per
 // strip, a wave per head in the attention core: sasrec_seqn_bwd.hip).  v < 0 only queries.  Returns the previous value.
 static int g_seq_bwd_variant = 0;
 extern "C" int amid_sas_seq_bwd_variant(int v) {
@@ -834,7 +834,7 @@ extern "C" int amid_sas_seq_bwd_f32(int n_layers, const float* dxo, const unsign
     }
     StripGeom sg;
     if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
-    if (g_seq_bwd_variant != 1) {
+    if (g_seq_bwd_variant == 2) {       // (auto = the strip build: the two measure the same -- DESIGN.md section 5.0)
         const int rc = launch_seqn_bwd(a, sg, mma_bf16, stream);
         if (rc != AMID_ERR_UNSUPPORTED) return rc;
     }

@@ -66,6 +66,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         L = lib()        # raises AmidLibraryError when the HIP library is missing: no fallback
         if os.environ.get("AMID_SEQ_FWD_VARIANT"):          # A/B measurements of the fused forward's builds (amid_sas_seq_fwd_variant)
             L.value("amid_sas_seq_fwd_variant", int(os.environ["AMID_SEQ_FWD_VARIANT"]))
+        if os.environ.get("AMID_SEQ_BWD_VARIANT"):          # ... and of the fused backward's (amid_sas_seq_bwd_variant)
+            L.value("amid_sas_seq_bwd_variant", int(os.environ["AMID_SEQ_BWD_VARIANT"]))
         self.itc_bs, self.itc_threshold = int(itc_bs), float(itc_threshold)
         # inc_bs > 0: SASRec(isInC=True, bs=inc_bs, threshold1=inc_threshold) -- InnerComp on the gathered rows before the encoders,
         # which then see 2 * seq_len tokens per row (model_seq.py:398-401, :422-424; csrc/innercomp.hip); batches of exactly inc_bs rows

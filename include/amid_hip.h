@@ -535,7 +535,7 @@ int amid_sas_weights_bf16(const float* const* src, int n, int D, int transposed,
  * ln1_part / ln2_part[l]: [2 B][2][D] -- domain g's slots are [g B, (g + 1) B): its live sequences' partial sums first, then zeros.
  * live: amid_live_list_i32 (required).  The weight gradients (amid_sas_wgrad_rows_f32) read dq / dk / dv / dr / dpre1 / dpre2 as before. */
 int amid_sas_seq_bwd_supported(int B, int T, int D, int H);
-/* Which build of the one-launch backward runs (diagnostics, tests, A/B measurements): 0 = auto, 1 = a wave per 16-row strip
+/* Which build of the one-launch backward runs (diagnostics, tests, A/B measurements): 0 = auto (= 1: the two measure the same), 1 = a wave per 16-row strip
  * (csrc/sasrec_strip.hip seq_bwd_kernel), 2 = the N-split build (csrc/sasrec_seqn_bwd.hip: eight waves per sequence, two per strip with
  * half the columns each, a wave per head in the attention core; same bits).  v < 0 only queries.  Returns the previous value.  Host state. */
 int amid_sas_seq_bwd_variant(int v);
