@@ -38,6 +38,8 @@ static __device__ unsigned long long amid_seqnb_stamp_buf[8 * 64];
 #define SEQNB_STAMP(i) do { } while (0)
 #endif
 
+// the own column tiles of a whole row held in registers (two parts: selects on the wave-uniform part index; more parts would turn into
+// scratch arrays -- those builds load their columns from memory instead, see the call sites)
 template <int D, int NCT>
 __device__ __forceinline__ void own_of(PartRegs<NCT>& o, const StripRegs<D>& full, int part) {
     static_assert(D / 16 == 2 * NCT, "two column parts");
@@ -67,11 +69,11 @@ __device__ __forceinline__ void ln_bwd_sums(const StripRegs<D>& dy, const StripR
     c2 = row_sum4(s2) * (1.0f / D);
 }
 
-// column sums over the strip's 16 rows of the own column tiles (NCT * 4 = 16 per lane), compacted: lane (m, g) keeps the sum of column
-// (c0 + (m >> 2)) * 16 + 4 g + (m & 3) -- one register instead of sixteen for a tensor that waits for its LDS slot
+// column sums over the strip's 16 rows of the own column tiles (4 NCT <= 16 per lane), compacted: lane (m, g), m < 4 NCT, keeps the sum of
+// column (c0 + (m >> 2)) * 16 + 4 g + (m & 3) -- one register instead of up to sixteen for a tensor that waits for its LDS slot
 template <int NCT>
 __device__ __forceinline__ float col_sums_compact(const PartRegs<NCT>& x) {
-    static_assert(NCT == 4, "sixteen values over sixteen lanes");
+    static_assert(NCT <= 4, "at most sixteen values over sixteen lanes");
     const int m = lane_id() & 15;
     float out = 0.f;
 #pragma unroll
@@ -83,23 +85,47 @@ __device__ __forceinline__ float col_sums_compact(const PartRegs<NCT>& x) {
         }
     return out;
 }
-// -> scratch [strip][2][D] (the layout of ln_partials_wave for four waves)
-template <int D>
+// -> scratch [strip][2][D] (the layout of ln_partials_wave)
+template <int D, int NCT>
 __device__ __forceinline__ void ln_partials_put(float* __restrict__ scratch, int si, int c0, float dgam, float dbet) {
     const int lane = lane_id(), m = lane & 15;
+    if (m >= 4 * NCT) return;
     float* p = scratch + si * 2 * D + (c0 + (m >> 2)) * 16 + 4 * (lane >> 4) + (m & 3);
     lds_st1(p, dgam);
     lds_st1(p + D, dbet);
+}
+// the strips' partial sums of element e, in strip order
+template <int D, int WPS>
+__device__ __forceinline__ float ln_partials_sum(const float* __restrict__ S, int e) {
+    if constexpr (WPS == 4) return (S[e] + S[2 * D + e]) + (S[4 * D + e] + S[6 * D + e]);      // (ln_partials_out's order)
+    else if constexpr (WPS == 2) return S[e] + S[2 * D + e];
+    else return S[e];
+}
+
+// the attention core's tile count for T rows in WPS strips, as a compile-time constant handed to f
+template <int WPS, class F>
+__device__ __forceinline__ void with_tiles(int T, const F& f) {
+    if constexpr (WPS == 4) { if (T > 48) f(std::integral_constant<int, 4>()); else f(std::integral_constant<int, 3>()); }
+    else if constexpr (WPS == 2) { if (T > 16) f(std::integral_constant<int, 2>()); else f(std::integral_constant<int, 1>()); }
+    else f(std::integral_constant<int, 1>());
 }
 
 // what the feed-forward chain needs first: requested a product ahead by the caller
 template <int D, int NCT> struct FfnPreN { PartRegs<NCT> Ho; unsigned tmw[NCT]; ColVec<D> gam; uint4 rr2; };
 
-template <int D, bool BF>
+// floats of the exchange area: WPS strips x D / 16 tiles x 64 lanes x float4 -- or, while it is idle, two blocks of LayerNorm partial sums
+// [WPS][2][D] and the eight waves' transpose tiles of the attention core
+template <int D, int WPS> constexpr int seqn_bwd_exchange_floats() {
+    constexpr int x = WPS * (D / 16) * 64 * 4, s = 2 * WPS * 2 * D + 8 * (ATTN_BWD_LDS_PER_WAVE / 4);
+    return x > s ? x : s;
+}
+
+// WPS strips per sequence (T <= 16 WPS) x NS column parts = 8 waves: (4, 2) for 32 < T <= 64, (2, 4) for 16 < T <= 32, (1, 8) below
+template <int D, int WPS, int NS, bool BF>
 __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NT = D / 16, WPS = 4, NW = 8, NCT = NT / 2;
-    static_assert(D == 128, "");
+    constexpr int NT = D / 16, NW = WPS * NS, NCT = NT / NS;
+    static_assert(D == 128 && NW == 8 && NCT >= 1, "eight waves: one per head in the attention core");
     const int bid = blockIdx.x;
     const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
     const int part = w / WPS, si = w % WPS, c0 = part * NCT;
@@ -125,9 +151,9 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
     }
     float* const E = smem + (BF ? D * D : 2 * D * D);                          // the exchange: [strip][column tile][lane] float4
     float* const xb = E + si * (NT * 64 * 4);
-    float* const S_f = E;                                                      // while the exchange is idle: LayerNorm partial sums [4][2][D] of
-    float* const S_a = E + 8 * D;                                              // the feed-forward chain / of the layer above's q / k / v chain,
-    float* const att_lds = E + 16 * D + w * (ATTN_BWD_LDS_PER_WAVE / 4);       // and this wave's transpose tiles of the attention core
+    float* const S_f = E;                                                      // while the exchange is idle: LayerNorm partial sums [WPS][2][D] of
+    float* const S_a = E + WPS * 2 * D;                                        // the feed-forward chain / of the layer above's q / k / v chain,
+    float* const att_lds = E + 2 * WPS * 2 * D + w * (ATTN_BWD_LDS_PER_WAVE / 4);      // and this wave's transpose tiles of the attention core
     const int t = si * 16 + m;
     StripRow row;
     row.ok = t < T;
@@ -168,7 +194,6 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
         const StripQkvBwdArgs& q = P.a;
         [[maybe_unused]] const int sb = 1 + 8 * (top - l);
         AttnBwdOps oa;
-        const bool nt4 = T > 48;
         float dgam_f, dbet_f;
         // ---------------------------------------------------------------- feed-forward / out-projection chain: DZo -> dpre2, dpre1, dr, d_o
         {
@@ -189,12 +214,15 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
             lds_barrier();                                  // the partner has read this wave's slots of the previous exchange
             xchg_write<NCT>(xb, c0, Po);
             StripRegs<D> Rs;
+            PartRegs<NCT> Ro, Go;                           // own columns of r and of the LayerNorm gain
             {   // dh = dpre2 C2 ; dpre1 = dh * relu'(h) * drop1   (h > 0 implies the unit was kept by drop1)
                 const float* buf = ring.next();
                 xchg_read<D>(F, xb);
                 seqn_product<D, NCT, BF>(acc, F, buf, ring, f.w1T[g], W16(f.w1T[g]), c0,
-                                         [&](int ct, int j) { part_spread<NCT>(gp2, off_own, Po, ct, j, 1); },
-                                         [&]() { strip_load<D>(Rs, GBuf(f.r, sg.act_bytes), row); });      // LN2 input rows: needed a slab from now
+                                         [&](int ct, int j) { part_spread<NCT>(gp2, off_own, Po, ct, j, 1); }, [&]() {
+                    strip_load<D>(Rs, GBuf(f.r, sg.act_bytes), row);                 // LN2 input rows: needed a slab from now
+                    if constexpr (NS != 2) { part_load<NCT>(Ro, GBuf(f.r, sg.act_bytes), off_own); part_cols<NCT>(Go, f.ln_w[g], c0); }
+                });
 #pragma unroll
                 for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -220,10 +248,10 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                 if (l == 0) SEQNB_STAMP(32);
                 float mean, rstd, c1, c2;
                 ln_bwd_sums<D>(F, Rs, pre.gam, f.ln_eps, mean, rstd, c1, c2);
+                if constexpr (NS == 2) { own_of<D, NCT>(Ro, Rs, part); own_cols<D, NCT>(Go, pre.gam, f.ln_w[g], part, c0); }
+                dbet_f = col_sums_compact<NCT>(Po);
                 {
-                    PartRegs<NCT> Ro;
-                    own_of<D, NCT>(Ro, Rs, part);
-                    dbet_f = col_sums_compact<NCT>(Po);
+                    PartRegs<NCT> Dg;
 #pragma unroll
                     for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -231,9 +259,12 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                             const float xh = (Ro.v[c][r] - mean) * rstd;
                             float dg = Po.v[c][r] * xh;
                             asm volatile("" : "+v"(dg));       // (rounded, as strip_ln_bwd)
-                            Ro.v[c][r] = dg;
+                            Dg.v[c][r] = dg;
+                            float gy = Go.v[c][r] * Po.v[c][r];
+                            asm volatile("" : "+v"(gy));
+                            Po.v[c][r] = rstd * (gy - c1 - xh * c2);      // dr, own columns (stored under the product)
                         }
-                    dgam_f = col_sums_compact<NCT>(Ro);
+                    dgam_f = col_sums_compact<NCT>(Dg);
                 }
 #pragma unroll
                 for (int ct = 0; ct < NT; ++ct)
@@ -244,10 +275,9 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                         asm volatile("" : "+v"(gy));          // the rounded product, as strip_ln_bwd keeps it (not contracted into the subtraction)
                         F.v[ct][r] = rstd * (gy - c1 - xh * c2);
                     }
-                own_of<D, NCT>(Po, F, part);                // dr, own columns (stored under the product)
                 if (l == 0) SEQNB_STAMP(33);
                 // the attention core's saved operands of this wave's head: they come from HBM -- requested under this product
-                if (nt4) attn_bwd_load_saved<4>(oa, P.at, g, b, rowbase, w); else attn_bwd_load_saved<3>(oa, P.at, g, b, rowbase, w);
+                with_tiles<WPS>(T, [&](auto nt) { attn_bwd_load_saved<decltype(nt)::value>(oa, P.at, g, b, rowbase, w); });
                 if (l == 0) SEQNB_STAMP(34);
                 seqn_product<D, NCT, BF>(acc, F, buf, ring, q.wkT[g], W16(q.wkT[g]), c0,
                                          [&](int ct, int j) { part_spread<NCT>(gdr, off_own, Po, ct, j, 1); });
@@ -259,21 +289,23 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
         w_ring_wait();                  // d_o has reached L2 (the Wk slab has landed as well)
         __syncthreads();                // ... and nobody reads the exchange any more
         if (l == 0) SEQNB_STAMP(35);
-        ln_partials_put<D>(S_f, si, c0, dgam_f, dbet_f);
-        if (l < top) ln_partials_put<D>(S_a, si, c0, dgam_a, dbet_a);
+        ln_partials_put<D, NCT>(S_f, si, c0, dgam_f, dbet_f);
+        if (l < top) ln_partials_put<D, NCT>(S_a, si, c0, dgam_a, dbet_a);
         if (l == 0) SEQNB_STAMP(36);
         // ---------------------------------------------------------------- attention core: head w
-        if (nt4) { attn_bwd_load_dout<4>(oa, P.at, rowbase, w); attn_bwd_compute<4>(oa, P.at, rowbase, w, att_lds); }
-        else { attn_bwd_load_dout<3>(oa, P.at, rowbase, w); attn_bwd_compute<3>(oa, P.at, rowbase, w, att_lds); }
+        with_tiles<WPS>(T, [&](auto nt) {
+            attn_bwd_load_dout<decltype(nt)::value>(oa, P.at, rowbase, w);
+            attn_bwd_compute<decltype(nt)::value>(oa, P.at, rowbase, w, att_lds);
+        });
         SEQNB_STAMP(sb + 3);
         w_ring_wait();                  // dq / dk / dv have reached L2
         if (l == 0) SEQNB_STAMP(37);
         __syncthreads();
         strip_load<D>(F, GBuf(q.dk, sg.act_bytes), row);      // the next chain's first operand: its round trip under the sums below
-        {   // the four strips' partial sums -> this sequence's slot (fixed order)
+        {   // the strips' partial sums -> this sequence's slot (fixed order)
             const int e = threadIdx.x & (2 * D - 1);
-            if (threadIdx.x < 2 * D) f.ln_part[(long long)slot * 2 * D + e] = (S_f[e] + S_f[2 * D + e]) + (S_f[4 * D + e] + S_f[6 * D + e]);
-            else if (l < top) a.L[l + 1].a.ln_part[(long long)slot * 2 * D + e] = (S_a[e] + S_a[2 * D + e]) + (S_a[4 * D + e] + S_a[6 * D + e]);
+            if (threadIdx.x < 2 * D) f.ln_part[(long long)slot * 2 * D + e] = ln_partials_sum<D, WPS>(S_f, e);
+            else if (l < top) a.L[l + 1].a.ln_part[(long long)slot * 2 * D + e] = ln_partials_sum<D, WPS>(S_a, e);
         }
         SEQNB_STAMP(sb + 4);
         // ---------------------------------------------------------------- q / k / v + LayerNorm-1 chain: dq, dk, dv, dr -> d x (own columns)
@@ -282,7 +314,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
             // eight at once, the attention core's 24 included -- the same microseconds move into the loop: 240.8 -> 252.3 us at cfg 3)
             StripRegs<D> A2, Xs;
             ColVec<D> gam;
-            PartRegs<NCT> Dro;
+            PartRegs<NCT> Dro, Xo, Go;
             f32x4 acc_kv[NCT];
             {   // dk Wk
                 const float* buf = ring.next();
@@ -295,6 +327,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                 seqn_product<D, NCT, BF, false>(acc_kv, A2, buf, ring, q.wqT[g], W16(q.wqT[g]), c0, [](int, int) {}, [&]() {
                     strip_load<D>(F, GBuf(q.dq, sg.act_bytes), row);
                     strip_load<D>(Xs, GBuf(q.x, sg.act_bytes), row);                 // LN1 input rows
+                    if constexpr (NS != 2) part_load<NCT>(Xo, GBuf(q.x, sg.act_bytes), off_own);
                 });
             }
             SEQNB_STAMP(sb + 6);
@@ -302,6 +335,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                 const float* buf = ring.next();
                 part_load<NCT>(Dro, GBuf(q.dr, sg.act_bytes), off_own);              // residual-path gradient of the normed query
                 gam.load(q.ln_w[g]);
+                if constexpr (NS != 2) part_cols<NCT>(Go, q.ln_w[g], c0);
                 if (l == 0) SEQNB_STAMP(38);
                 seqn_product<D, NCT, BF>(acc, F, buf, ring, Pn.f.w2T[g], W16(Pn.f.w2T[g]), c0, [](int, int) {},
                                          [&]() { ffn_prefetch(pre, Pn.f); });        // (layer 0 "prefetches" its own: harmless, dead afterwards)
@@ -315,9 +349,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                 if (l == 0) SEQNB_STAMP(40);
                 float mean, rstd, c1, c2;
                 ln_bwd_sums<D>(F, Xs, gam, q.ln_eps, mean, rstd, c1, c2);
-                PartRegs<NCT> Xo, Go;
-                own_of<D, NCT>(Xo, Xs, part);
-                own_cols<D, NCT>(Go, gam, q.ln_w[g], part, c0);
+                if constexpr (NS == 2) { own_of<D, NCT>(Xo, Xs, part); own_cols<D, NCT>(Go, gam, q.ln_w[g], part, c0); }
                 dbet_a = col_sums_compact<NCT>(Qo);
 #pragma unroll
                 for (int c = 0; c < NCT; ++c)
@@ -341,24 +373,24 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
     }
     // the last chain's LayerNorm partial sums
     __syncthreads();                    // every wave has read its row of dqn
-    ln_partials_put<D>(S_a, si, c0, dgam_a, dbet_a);
+    ln_partials_put<D, NCT>(S_a, si, c0, dgam_a, dbet_a);
     __syncthreads();
     if (threadIdx.x < 2 * D) {
         const int e = threadIdx.x;
-        a.L[0].a.ln_part[(long long)slot * 2 * D + e] = (S_a[e] + S_a[2 * D + e]) + (S_a[4 * D + e] + S_a[6 * D + e]);
+        a.L[0].a.ln_part[(long long)slot * 2 * D + e] = ln_partials_sum<D, WPS>(S_a, e);
     }
     SEQNB_STAMP(63);
     w_ring_wait();                      // the last (redundant) weight fetch targets this workgroup's LDS
 }
 
-template <bool BF> static constexpr size_t seqn_bwd_lds_bytes() {
-    return (size_t)((BF ? 128 * 128 : 2 * 128 * 128) + 4 * 8 * 64 * 4) * sizeof(float);
+template <int WPS, bool BF> static constexpr size_t seqn_bwd_lds_bytes() {
+    return (size_t)((BF ? 128 * 128 : 2 * 128 * 128) + seqn_bwd_exchange_floats<128, WPS>()) * sizeof(float);
 }
 
-template <bool BF>
+template <int WPS, int NS, bool BF>
 static int seqn_bwd_launch_t(const SeqBwdArgs& a, const StripGeom& sg, void* stream) {
-    constexpr size_t lds = seqn_bwd_lds_bytes<BF>();
-    auto kern = seqn_bwd_kernel<128, BF>;
+    constexpr size_t lds = seqn_bwd_lds_bytes<WPS, BF>();
+    auto kern = seqn_bwd_kernel<128, WPS, NS, BF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -373,7 +405,10 @@ static int seqn_bwd_launch_t(const SeqBwdArgs& a, const StripGeom& sg, void* str
 int launch_seqn_bwd(const SeqBwdArgs& a, const StripGeom& sg, int mma_bf16, void* stream) {
     const StripFfnBwdArgs& f = a.L[a.n_layers - 1].f;
     if (f.train && spec_bits(f.spec) != 1) return AMID_ERR_UNSUPPORTED;      // part_dropout: the one-bit keep decisions of p = 0.5 (the reference's rate)
-    return mma_bf16 ? seqn_bwd_launch_t<true>(a, sg, stream) : seqn_bwd_launch_t<false>(a, sg, stream);
+    if (sg.T > 64) return AMID_ERR_UNSUPPORTED;
+    if (sg.T > 32) return mma_bf16 ? seqn_bwd_launch_t<4, 2, true>(a, sg, stream) : seqn_bwd_launch_t<4, 2, false>(a, sg, stream);
+    if (sg.T > 16) return mma_bf16 ? seqn_bwd_launch_t<2, 4, true>(a, sg, stream) : seqn_bwd_launch_t<2, 4, false>(a, sg, stream);
+    return mma_bf16 ? seqn_bwd_launch_t<1, 8, true>(a, sg, stream) : seqn_bwd_launch_t<1, 8, false>(a, sg, stream);
 }
 
 }  // namespace amid

@@ -300,7 +300,9 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # riders find no free CU in it and the sort goes back to the side stream (a fork and a join, ~10 us of a replayed graph).  Measured
     # (MI355X, T 50): B 256 = one round of workgroups either way, a tie (0.391 against 0.389 ms with the riders); B 512 = two full
     # rounds against 400 row tiles in two uneven ones, 0.690 against 0.740 ms; B 4096 = 16 rounds against 12.5 rounds of denser row
-    # tiles, 4.75 against 4.48 ms.  So: more live sequences than CUs, at most two rounds.  AMID_SEQ_BACKWARD = 1 / 0 forces it on / off.
+    # tiles, 4.75 against 4.48 ms.  So: more live sequences than CUs, at most two rounds.  T <= 32 (csrc/sasrec_seqn_bwd.hip: two strips x
+    # four column parts per sequence): B 256, T 20 runs 80 strip tiles per launch on 256 CUs -- 111 us in five launches against 67.8 in one,
+    # 0.267 -> 0.243 ms per step with the sort back on its side stream; taken for B <= n_CU.  AMID_SEQ_BACKWARD = 1 / 0 forces it on / off.
     SEQ_BACKWARD = os.environ.get("AMID_SEQ_BACKWARD", "auto")
 
     def _seq_backward(self, pl: SasrecPlan) -> bool:
@@ -309,6 +311,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         if self.SEQ_BACKWARD in ("1", True):
             return True
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if pl.shape.Tenc <= 32:         # short sequences: the strip launches fill a third of the chip, a workgroup per sequence all of it
+            return pl.shape.B <= n_cu
         return n_cu < pl.shape.B <= 2 * n_cu
 
     def _sort_plan(self, pl: SasrecPlan):

@@ -529,7 +529,8 @@ int amid_sas_weights_bf16(const float* const* src, int n, int D, int transposed,
 /* ---- the encoder's data gradients of the live sequences in ONE launch (csrc/sasrec_strip.hip: seq_bwd_kernel) -------------------------
  * replaces: autograd of Log2feats.forward model_seq.py:371-383 under loss.backward() (train_sr.py:214) -- per layer, top down,
  * amid_sas_strip_ffn_bwd_f32 + amid_attn_bwd_live_f32 + amid_sas_strip_qkv_bwd_f32 as one workgroup-long chain per live sequence.
- * Shapes: amid_sas_seq_bwd_supported (D 128, 8 heads of 16, 32 < T <= 64).  Saved tensors / gradient outputs / LayerNorm partials:
+ * Shapes: amid_sas_seq_bwd_supported (D 128, 8 heads of 16, T <= 64; T <= 32 runs the N-split build of csrc/sasrec_seqn_bwd.hip -- two strips x
+ * four column parts, or one x eight -- which needs p_drop = 0.5 or eval mode: AMID_ERR_UNSUPPORTED otherwise).  Saved tensors / gradient outputs / LayerNorm partials:
  * n_layers pointers each; parameters and transposed weights: 2 * n_layers pointers ordered [layer][domain].  dxo: gradient of the last
  * layer's output; dx: gradient of layer 0's input (rows of the live sequences; the others are not touched); d_o: scratch [2 B T, D].
  * ln1_part / ln2_part[l]: [2 B][2][D] -- domain g's slots are [g B, (g + 1) B): its live sequences' partial sums first, then zeros.

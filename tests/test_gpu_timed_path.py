@@ -146,7 +146,10 @@ def test_timed_path_with_compact_index_list_vs_oracle(Bn, T, D, build, split):
 # splits, three key tiles (T 40) and many rounds, and forced off for a shape "auto" would take.
 @pytest.mark.parametrize("Bn,T,D,split,force", [(256, 50, 128, "mixed", "1"), (256, 50, 128, "all0", "1"), (256, 50, 128, "all1", "1"),
                                                 (200, 50, 128, "one0", "1"), (300, 40, 128, "mixed", "1"), (64, 33, 128, "mixed", "1"),
-                                                (1100, 50, 128, "mixed", "1"), (512, 50, 128, "mixed", "0")])
+                                                (1100, 50, 128, "mixed", "1"), (512, 50, 128, "mixed", "0"),
+                                                # T <= 32: the N-split build's two-strip / one-strip shapes (csrc/sasrec_seqn_bwd.hip)
+                                                (256, 20, 128, "mixed", "1"), (300, 32, 128, "mixed", "1"), (64, 17, 128, "one0", "1"),
+                                                (64, 16, 128, "mixed", "1"), (300, 9, 128, "mixed", "1"), (5, 1, 128, "all1", "1")])
 def test_timed_path_fused_backward_vs_oracle(Bn, T, D, split, force):
     _timed_vs_oracle(Bn, T, D, None, split, compact_min=None, seq_backward=force)
 
