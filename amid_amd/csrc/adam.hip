@@ -48,6 +48,22 @@ __device__ __forceinline__ AdamCoef adam_coef(const StepState& st, double b1pow,
     return c;
 }
 
+// The two coefficients the zero-gradient replay reads, for a step OLDER than the coefficient table (a row idle for more than COEF_TAB
+// steps), from the running powers: the bias corrections in double, rounded to float, then the hardware reciprocal / reciprocal square
+// root (<= 1 ulp each, as the replay's own sqrt / rcp) instead of adam_coef's double division, square root and second division --
+// those ~150 fp64 instructions per replayed step and lane were most of a long gap's cost (cfg 4 in steady state: gaps of 480 steps).
+__device__ __forceinline__ AdamCoef adam_coef_idle(const StepState& st, double b1pow, double b2pow) {
+    AdamCoef c;
+    c.w1 = (float)(1.0 - st.beta1);
+    c.beta2 = (float)st.beta2;
+    c.w2 = 0.f;
+    c.neg_step_size = -(float)st.lr * __builtin_amdgcn_rcpf((float)(1.0 - b1pow));
+    c.inv_bc2_sqrt = __builtin_amdgcn_rsqf((float)(1.0 - b2pow));
+    c.bc2_sqrt = 0.f;              // (not read by the idle step)
+    c.eps = (float)st.eps;
+    return c;
+}
+
 __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, const AdamCoef& c) {
     m = __fmaf_rn(c.w1, __fsub_rn(g, m), m);                                   // exp_avg.lerp_(grad, 1 - beta1)
     v = __fadd_rn(__fmul_rn(v, c.beta2), __fmul_rn(__fmul_rn(c.w2, g), g));    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
@@ -71,7 +87,6 @@ __device__ __forceinline__ void adam_quad_idle(float4& p, float4& m, float4& v, 
     adam_elem_idle(p.z, m.z, v.z, c);
     adam_elem_idle(p.w, m.w, v.w, c);
 }
-
 __device__ __forceinline__ void adam_quad(float4& p, float4& m, float4& v, float4 g, const AdamCoef& c) {
     adam_elem(p.x, m.x, v.x, g.x, c);
     adam_elem(p.y, m.y, v.y, g.y, c);
@@ -103,20 +118,86 @@ __device__ __forceinline__ AdamCoef coef_at(const AdamCoef* tab, const StepState
 // from running powers beta^s = beta^(s-1) * beta in double -- one pow() at the start of the gap instead of two per step, which
 // made a single long-idle row cost tens of microseconds; the product chain differs from pow() by ~gap * 1e-16, far below the
 // float the coefficient is rounded to.
-__device__ __forceinline__ void replay_quad(float4& p, float4& m, float4& v, long long from, long long to, const StepState& st,
-                                            const AdamCoef* tab) {
+//
+// The parameter's part of a step stops mattering long before the gap ends: the increment shrinks by ~beta1 per step (|m| does, the
+// denominator and the bias corrections barely move), so after ~120 steps at beta1 = 0.9 it is below half an ulp of the parameter and
+// `p + increment` returns p -- from then on for every later step too (the increments decrease monotonically: see DESIGN.md).  A lane
+// whose four parameters did not change in a step therefore skips the parameter arithmetic (square root, reciprocal: the quarter-rate
+// instructions that bound this kernel) for the rest of the gap and only carries m and v on, two full-rate instructions per element
+// and step -- the SAME bits as the full replay, at a fraction of its cost for the long gaps of rarely seen items.
+// K consecutive zero-gradient steps with coefficients c[0..K-1] on N elements; returns whether the LAST of them moved a parameter.  The
+// moments first (two short chains), then the K denominators of an element -- independent square roots / reciprocals the hardware
+// overlaps --, then the parameter's K additions in step order: the same operations on the same values as K calls of adam_elem_idle.
+template <int N, int K>
+__device__ __forceinline__ bool idle_steps(float (&p)[N], float (&m)[N], float (&v)[N], const AdamCoef (&c)[K]) {
+    bool moved = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float mk[K], rk[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            m[i] = __fmaf_rn(c[k].w1, -m[i], m[i]);
+            v[i] = __fmul_rn(v[i], c[k].beta2);
+            mk[k] = m[i];
+            rk[k] = __builtin_amdgcn_rcpf(__fmaf_rn(__builtin_amdgcn_sqrtf(v[i]), c[k].inv_bc2_sqrt, c[k].eps));
+        }
+        float before = p[i];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            before = p[i];
+            p[i] = __fmaf_rn(__fmul_rn(c[k].neg_step_size, mk[k]), rk[k], p[i]);
+        }
+        moved |= p[i] != before;
+    }
+    return moved;
+}
+
+template <int N>
+__device__ __forceinline__ void replay_elems(float (&p)[N], float (&m)[N], float (&v)[N], long long from, long long to, const StepState& st,
+                                             const AdamCoef* tab) {
+    constexpr int K = 4;                               // steps per chunk (the "did it move" test looks at a chunk's last step)
     long long s = from;
     const long long tab_first = st.step - (COEF_TAB - 1);
+    bool live = true;                                  // this lane's parameters still move
     if (s < tab_first) {
         double b1p = pow_step(st.beta1, s), b2p = pow_step(st.beta2, s);
         const long long stop = (to + 1 < tab_first) ? to + 1 : tab_first;
-        for (; s < stop; ++s) {
-            adam_quad_idle(p, m, v, adam_coef(st, b1p, b2p));
+        for (; s + K <= stop && live; s += K) {
+            AdamCoef c[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { c[k] = adam_coef_idle(st, b1p, b2p); b1p *= st.beta1; b2p *= st.beta2; }
+            live = idle_steps<N, K>(p, m, v, c);
+        }
+        for (; s < stop && live; ++s) {
+            const AdamCoef c[1] = {adam_coef_idle(st, b1p, b2p)};
+            live = idle_steps<N, 1>(p, m, v, c);
             b1p *= st.beta1;
             b2p *= st.beta2;
         }
     }
-    for (; s <= to; ++s) adam_quad_idle(p, m, v, tab[s - tab_first]);
+    if (s >= tab_first) {
+        for (; s + K - 1 <= to && live; s += K) {
+            AdamCoef c[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) c[k] = tab[s + k - tab_first];
+            live = idle_steps<N, K>(p, m, v, c);
+        }
+        for (; s <= to && live; ++s) {
+            const AdamCoef c[1] = {tab[s - tab_first]};
+            live = idle_steps<N, 1>(p, m, v, c);
+        }
+    }
+    const float w1 = (float)(1.0 - st.beta1), beta2 = (float)st.beta2;      // (AdamCoef::w1, ::beta2 of every step)
+    for (; s <= to; ++s) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { m[i] = __fmaf_rn(w1, -m[i], m[i]); v[i] = __fmul_rn(v[i], beta2); }
+    }
+}
+__device__ __forceinline__ void replay_quad(float4& p, float4& m, float4& v, long long from, long long to, const StepState& st,
+                                            const AdamCoef* tab) {
+    float pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
+    replay_elems<4>(pp, mm, vv, from, to, st, tab);
+    p = make_float4(pp[0], pp[1], pp[2], pp[3]); m = make_float4(mm[0], mm[1], mm[2], mm[3]); v = make_float4(vv[0], vv[1], vv[2], vv[3]);
 }
 
 // mode 0: catch-up (steps last+1 .. t-1, g = 0)   mode 1: apply (catch-up if needed, then step t with g)
@@ -170,35 +251,47 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_pos_kernel(float* __res
     __shared__ int any_lag;
     const StepState st = *stp;
     const long long t = st.step;
-    const int sub = threadIdx.x & 31;
-    const int q = D >> 2;
-    const int hw0 = bid * (blockDim.x >> 5) + (threadIdx.x >> 5), n_hw = nbk * (blockDim.x >> 5);
-    // first sweep: does this block have any lagging row at all? (usually not: skip the coefficient table)
+    const int lane = threadIdx.x & 63;
+    // replay row r from its stamp l (claimed by this wave): two elements per lane -- a replay is a chain of dependent steps bound by the
+    // quarter-rate sqrt / rcp, the fewer elements a lane carries the shorter the chain
+    auto replay_row = [&](long long r, int l) {
+        for (int c = lane; c < (D >> 1); c += 64) {
+            const long long off = r * D + 2 * c;
+            const float2 p2 = *reinterpret_cast<const float2*>(table + off), m2 = *reinterpret_cast<const float2*>(m_tab + off),
+                         v2 = *reinterpret_cast<const float2*>(v_tab + off);
+            float p[2] = {p2.x, p2.y}, m[2] = {m2.x, m2.y}, v[2] = {v2.x, v2.y};
+            replay_elems<2>(p, m, v, (long long)l + 1, t - 1, st, tab);
+            *reinterpret_cast<float2*>(table + off) = make_float2(p[0], p[1]);
+            *reinterpret_cast<float2*>(m_tab + off) = make_float2(m[0], m[1]);
+            *reinterpret_cast<float2*>(v_tab + off) = make_float2(v[0], v[1]);
+        }
+    };
+    // a WAVE per position (w0, w0 + n_w, ...): a replay is a chain of dependent steps bound by the quarter-rate
+    // sqrt / rcp, and a step's lagging rows are about as many as the chip has SIMDs -- the fewer elements a lane carries, the shorter
+    // the chain
+    const int w0 = bid * (blockDim.x >> 6) + (threadIdx.x >> 6), n_w = nbk * (blockDim.x >> 6);
+    // first sweep: does this block have any lagging row at all? (usually not: skip the coefficient table); a wave's lanes look at
+    // the wave's own positions, 64 at a time
     if (threadIdx.x == 0) any_lag = 0;
     __syncthreads();
     bool mine = false;
-    for (int i = hw0; i < n_idx; i += n_hw) {
+    for (long long i = w0 + (long long)lane * n_w; i < n_idx; i += 64LL * n_w) {
         const long long l = last[idx[i]];
         if (l > 0 && l < t - 1) mine = true;
     }
-    if (mine && sub == 0) any_lag = 1;
+    if (mine) any_lag = 1;
     __syncthreads();
     if (!any_lag) return;
     fill_coef_table(tab, st);
-    for (int i = hw0; i < n_idx; i += n_hw) {
+    for (int i = w0; i < n_idx; i += n_w) {
         const long long r = idx[i];
         const int l = last[r];
         if (!(l > 0 && l < t - 1)) continue;
         int won = 0;
-        if (sub == 0) won = (atomicCAS(&last[r], l, (int)(t - 1)) == l) ? 1 : 0;      // claim the row for this half-wave
-        won = __shfl(won, threadIdx.x & 32, 64);
+        if (lane == 0) won = (atomicCAS(&last[r], l, (int)(t - 1)) == l) ? 1 : 0;     // claim the row for this wave
+        won = __builtin_amdgcn_readfirstlane(won);
         if (!won) continue;
-        for (int c = sub; c < q; c += 32) {
-            const long long off = r * D + 4 * c;
-            float4 p = ld4(table + off), m = ld4(m_tab + off), v = ld4(v_tab + off);
-            replay_quad(p, m, v, (long long)l + 1, t - 1, st, tab);
-            st4(table + off, p); st4(m_tab + off, m); st4(v_tab + off, v);
-        }
+        replay_row(r, l);
     }
 }
 
@@ -491,9 +584,10 @@ extern "C" int amid_optimizer_step_gathered_f32(float* p, float* m, float* v, fl
 static int catchup_positions(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D, const void* step_state,
                              const void* sort_plan, int sort_phase, void* stream) {
     AMID_CHECK_ARG(table && m && v && last && idx && step_state && D > 0 && (D % 4) == 0 && n_idx > 0);
-    // one position per half-wave up to 64 blocks per CU: the kernel is a chain of dependent loads (idx -> stamp -> row), more
-    // waves in flight beat fewer, fatter ones (measured: 2048-block cap 24.8 us at cfg 2 / 388 us at cfg 5, 16384: 22.4 / 341)
-    long long blocks = ((long long)n_idx + 7) / 8;
+    // the kernel is a chain of dependent loads (idx -> stamp -> row) and then, for a lagging row, a long serial replay: more waves in
+    // flight beat fewer, fatter ones (measured: 2048-block cap 24.8 us at cfg 2 / 388 us at cfg 5, 16384: 22.4 / 341; cfg 4 in steady
+    // state, 480-step gaps: 8 positions per block 0.2596 ms per step, 4: 0.2533, 16: 0.2634)
+    long long blocks = ((long long)n_idx + 3) / 4;      // a position per wave: a wave that got two lagging rows would replay them one after the other
     if (blocks > 16384) blocks = 16384;
     SortRider rd;
     rd.phase = 0;

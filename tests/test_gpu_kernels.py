@@ -526,6 +526,57 @@ def test_lazy_adam_long_idle_gap_beyond_coefficient_table(L):
     assert float((tab.cpu() - P["t"]).abs().max()) < 5e-6
 
 
+@pytest.mark.parametrize("n_idx,n_lag", [(10752, 1500), (26112, 2900), (37, 20), (4097, 4000)])
+def test_lazy_adam_catchup_by_positions_long_list_mixed_gaps(L, n_idx, n_lag):
+    """The catch-up over a train step's list shape: most positions the pad row (touched every step), the lagging rows scattered over the
+    list with duplicates, gaps from 1 to 700 steps (inside and beyond the 256-step coefficient table, short of and beyond the point where
+    the increments stop moving the parameters) -- every row must land on the trajectory of a dense Adam that took all those zero-gradient
+    steps; a second and third launch find every row current."""
+    g = torch.Generator().manual_seed(n_idx)
+    D, n_rows, t = 128, 6000, 1500
+    tab0 = torch.randn(n_rows, D, generator=g)
+    gr = torch.randn(n_rows, D, generator=g) * torch.logspace(-4, 0, n_rows)[:, None]
+    rows = torch.randperm(n_rows - 1, generator=g)[:n_lag]
+    gaps = torch.randint(1, 701, (n_lag,), generator=g)
+    gaps[:4] = torch.tensor([1, 255, 256, 700])[: min(4, n_lag)]
+    # reference: a dense Adam per distinct "last touched" step -- every lagging row got ONE real gradient at step t - 1 - gap, zeros since
+    want = tab0.clone()
+    m0, v0 = torch.zeros(n_rows, D), torch.zeros(n_rows, D)
+    b1, b2, lr, eps = 0.9, 0.999, 5e-4, 1e-8
+    l_of = (t - 1 - gaps)
+    s0 = l_of.double()[:, None]
+    gvec = gr[rows].double()
+    mm, vv = (1 - b1) * gvec, (1 - b2) * gvec * gvec
+    pp = tab0[rows].double() - lr / (1 - b1 ** s0) * mm / (vv.sqrt() / (1 - b2 ** s0).sqrt() + eps)
+    m0[rows], v0[rows], tab0[rows] = mm.float(), vv.float(), pp.float()             # the state the kernel starts from (fp32, as stored)
+    mm, vv, pp = m0[rows].double(), v0[rows].double(), tab0[rows].double()
+    for sstep in range(int(l_of.min()) + 1, t):                                    # all rows at once: row j moves at steps > l_of[j]
+        on = (sstep > l_of)[:, None].double()
+        mm = torch.where(on > 0, b1 * mm, mm)
+        vv = torch.where(on > 0, b2 * vv, vv)
+        pp = pp - on * (lr / (1 - b1 ** sstep) * mm / (vv.sqrt() / (1 - b2 ** sstep) ** 0.5 + eps))
+    want[rows] = pp.float()
+    tab, m, v = dev(tab0.clone()), dev(m0.clone()), dev(v0.clone())
+    last = torch.zeros(n_rows, dtype=torch.int32)
+    last[rows] = l_of.int()
+    last[n_rows - 1] = t - 1                                  # the pad row: current
+    pos = torch.full((n_idx,), n_rows - 1, dtype=torch.int32)
+    where = torch.randperm(n_idx, generator=g)[: min(n_idx, 2 * n_lag)]
+    pos[where] = rows[torch.arange(where.numel()) % n_lag].int()             # every lagging row once or twice
+    last, pos = dev(last), dev(pos)
+    st = step_state(L, 0, t, lr=lr)
+    for rep in range(3):
+        L.call("amid_lazy_adam_catchup_positions_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), pos.data_ptr(), n_idx, D,
+               st.data_ptr(), stream())
+        torch.cuda.synchronize()
+        touched = torch.unique(pos.cpu().long())
+        assert float((tab.cpu()[touched] - want[touched]).abs().max()) < 5e-6, rep
+        assert bool((last.cpu()[touched] == t - 1).all())
+    untouched = torch.ones(n_rows, dtype=torch.bool)
+    untouched[touched] = False
+    assert torch.equal(tab.cpu()[untouched], tab0[untouched])
+
+
 @pytest.mark.parametrize("shape", ["sasrec", "bert"])
 @pytest.mark.parametrize("B", [5, 130, 1030])          # 1030 > 1024: the kernels keep the identity slot -> sequence mapping
 def test_attention_bwd_rows_hint_equals_plain_backward(L, shape, B):
