@@ -27,6 +27,11 @@ AMID_SEQ_FWD_VARIANT=1 python3 bench.py --no-cpu-baseline --no-stress > $O/bench
 python3 profiles/tools/dp_overhead.py 2>&1 | grep "ms/step" > $O/dp_overhead.txt
 python3 profiles/tools/k1_time.py 2>&1 | grep "TB/s" > $O/k1_time.txt
 python3 profiles/tools/seqn_stamps.py 2>&1 | grep -v amdgpu > $O/seqn_stamps.txt
+# cfg 4 past its first epoch (480 batches): the lazy-Adam catch-up then replays 480-step gaps -- the default window (20 + 200 steps) never gets there
+python3 bench.py --workload cfg4 --steps 480 --warmup 520 --no-cpu-baseline --no-stress > $O/bench_cfg4_steady.json 2> $O/bench_cfg4_steady.err
+AMID_SEQ_BACKWARD=0 python3 bench.py --workload cfg4 --no-cpu-baseline --no-stress > $O/bench_cfg4_strip_backward.json 2> $O/bench_cfg4_strip_backward.err
+python3 profiles/tools/seqn_bwd_stamps.py 2>&1 | grep -v amdgpu > $O/seqn_bwd_stamps.txt
+python3 profiles/tools/probe/catchup_gap.py 2>&1 | grep "gap" > $O/catchup_gap.txt
 ls -la $O
 tail -3 $O/smoke.log
 tail -c 400 $O/bench.json
