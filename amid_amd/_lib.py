@@ -121,10 +121,17 @@ class KernelTimer:
     """Brackets every kernel-launching C-ABI call with HIP events recorded on the stream the kernels
     run on (the last argument of every launching entry point); durations are read after a sync."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []      # (name, start_event, stop_event)
+        self.only = only       # optional set of entry names: the others are launched without events (a queue that stays full)
 
     def timed_call(self, L: "_Lib", name: str, args) -> None:
+        if self.only is not None and name not in self.only:
+            code = L._fn[name](*args)
+            if code != 0:
+                text = L._fn["amid_error_string"](code)
+                raise AmidError(name, code, text.decode() if text else "?")
+            return
         stream = args[-1]
         e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
         L._fn["amid_event_create"](ctypes.byref(e0))

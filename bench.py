@@ -550,9 +550,36 @@ def main():
                 ent["frac"] = round(ent["achieved"] / ent["peak"], 4)
             kernels[name] = ent
         dom = max((k for k in kernels if k in work), key=lambda k: kernels[k]["ms_per_step"])      # most time per step
+        # The dominant kernel once more with the queue kept full, as in the timed region: the pass above synchronises after every step
+        # (it brackets EVERY launch with events), so each step starts on an idle device; here only the dominant kernel's launches carry
+        # events and the steps are enqueued back to back.  This average prices the roofline; the per-step-synchronised one stays beside it.
+        dom_entry = [n for n in durs if (n[:-4] if n.endswith(("_rt3", "_rt4", "_rt5")) else n) == dom or n.split("#")[0] == dom]
+        hot_us = None
+        if use_pool and dom_entry:
+            L.timer = KernelTimer(only={n.split("#")[0] for n in dom_entry})
+            for i in range(n_prof):
+                if world == 1:
+                    eng.enqueue_train_step(pl)
+                else:
+                    eng.enqueue_local_grads(pl)
+                    eng.enqueue_optimizer(pl)
+            eng.sync()
+            hot = L.timer.collect(L)
+            L.timer = None
+            hv = [x for v in hot.values() for x in v]
+            if hv:
+                hot_us = 1e3 * sum(hv) / len(hv)
         roof = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"], "peak": kernels[dom]["peak"],
                 "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"], "traffic": None,
                 "avg_launch_us": kernels[dom]["avg_launch_us"], "sum_kernel_ms_per_step": round(total_ms, 4)}
+        if hot_us is not None:
+            amount = work[dom][1]
+            scale = 1e9 if roof["bound"] == "hbm" else 1e12
+            roof["avg_launch_us_synced_steps"] = roof["avg_launch_us"]
+            roof["avg_launch_us"] = round(hot_us, 2)
+            roof["achieved"] = round(amount / (hot_us * 1e-6) / scale, 1 if roof["bound"] == "hbm" else 2)
+            roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+            roof["timing"] = "HIP events around this kernel's launches only, 20 steps enqueued back to back (the queue stays full, as in the timed region)"
         roof["traffic"], src = pmc_traffic(dom, f"{args.workload}_{args.model}_{args.dtype}")
         if src:
             roof["traffic_unit"] = "bytes/launch"
