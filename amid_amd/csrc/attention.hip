@@ -296,7 +296,11 @@ using namespace amid;
 // attention_mfma.hip: matrix-core kernels for the causal head-dim-16 T <= 64 case
 int amid_attn_mfma_fwd_launch(const void* args, void* stream);
 int amid_attn_mfma_bwd_launch(const void* args, void* stream);
-static bool mfma_shape(const AttnArgs& a) { return a.causal && a.key_keep == nullptr && a.D / a.H == 16 && a.T <= 64 && a.H <= 8; }
+// (head dim 8 -- the reference's default --emb_dim 64 with 8 heads -- runs as pairs of heads per 16-column tile)
+static bool mfma_shape(const AttnArgs& a) {
+    const int hd = a.D / a.H;
+    return a.causal && a.key_keep == nullptr && a.T <= 64 && a.D % a.H == 0 && a.H <= 8 && (hd == 16 || (hd == 8 && a.H % 2 == 0));
+}
 // attention_mfma_long.hip: the same shape at 64 < T <= 256, queries and keys walked in blocks of 64
 int amid_attn_long_fwd_launch(const void* args, void* stream);
 int amid_attn_long_bwd_launch(const void* args, void* stream);
@@ -385,7 +389,8 @@ extern "C" int amid_attn_bwd_f32(const float* q, const float* k, const float* v,
 // the fused train step, whose loss never reads the other domain's logits of a sample (train_sr.py:205-211).  Shapes outside the
 // matrix-core kernels' range (causal, head dim 16, T <= 64) are refused: the caller then encodes every sequence.
 extern "C" int amid_attn_live_supported(int T, int D, int H, int causal) {
-    return (causal && H > 0 && H <= 8 && D % H == 0 && D / H == 16 && T > 0 && T <= 64) ? 1 : 0;
+    if (!(causal && H > 0 && D % H == 0 && T > 0 && T <= 64)) return 0;
+    return (H <= 8 && (D / H == 16 || (D / H == 8 && H % 2 == 0))) ? 1 : 0;
 }
 extern "C" int amid_attn_fwd_live_f32(const float* q, const float* k, const float* v, int B, int T, int D, int H, int causal, int layer,
                                       const void* step_state, int train, float p_drop, float* o, float* stats, const int* live, void* stream) {

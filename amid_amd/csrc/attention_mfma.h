@@ -134,12 +134,19 @@ __device__ __forceinline__ unsigned long long row_keep_word(unsigned long long s
 }
 
 // forward of ONE head h of ONE sequence (domain g, batch row b, rows rowbase .. rowbase + T) by the calling wave; used by the
-// standalone kernel below and by the fused per-layer forward kernel (sasrec_fwd.hip)
+// standalone kernel below and by the fused per-layer forward kernel (sasrec_fwd.hip).
+// PAIR (head dim 8: the reference's default --emb_dim 64 with its 8 heads, train_sr.py:364): h is a 16-column tile = the heads 2 h and
+// 2 h + 1.  The tile is loaded as one head of 16 dims would be; lane groups 0, 1 hold head 2 h's dims, groups 2, 3 head 2 h + 1's.  Per
+// head the K operand of S = Qs K^T is zeroed in the other head's lane groups (the matrix instruction contracts over the lane groups), and
+// P~ V is computed for all 16 dims with that head's P~ -- a lane keeps the result of its own head.  Twice the matrix instructions of a
+// 16-dim head per tile, half of each used: the core is latency-bound either way.
+template <bool PAIR = false>
 __device__ __forceinline__ void attn_fwd_head(const AttnArgs& a, int g, int b, long long rowbase, int h) {
     const int T = a.T, D = a.D, H = a.H;
     const int lane = lane_id();
     const int m = lane & 15, gq = lane >> 4;
     const int NT = (T + 15) >> 4;
+    constexpr int NE = PAIR ? 2 : 1;
     const int col4 = h * AHD + 4 * gq, colm = h * AHD + m;
     // operands that every query tile reuses
     float4 kf[4];
@@ -150,11 +157,15 @@ __device__ __forceinline__ void attn_fwd_head(const AttnArgs& a, int g, int b, l
 #pragma unroll
         for (int r = 0; r < 4; ++r) vt[kj][r] = ld1_row(a.v, rowbase, kj * 16 + 4 * gq + r, T, D, colm);
     }
-    unsigned long long kw_own = ~0ull;
-    if (a.train) {
-        const int qrow = min(gq * 16 + m, T - 1);
-        kw_own = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step,
-                               (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
+    unsigned long long kw_own[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        kw_own[e] = ~0ull;
+        if (a.train) {
+            const int qrow = min(gq * 16 + m, T - 1);
+            kw_own[e] = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step,
+                                      (unsigned long long)(b * H + (PAIR ? 2 * h + e : h)) * T + qrow, T, a.thr16);
+        }
     }
     float4 qfr[4];
 #pragma unroll
@@ -164,47 +175,52 @@ __device__ __forceinline__ void attn_fwd_head(const AttnArgs& a, int g, int b, l
         if (qi >= NT) break;
         const int q = qi * 16 + m;
         const float4 qf = qfr[qi];
-        const unsigned long long kw = shfl64(kw_own, qi * 16 + m);
-        f32x4 s[4];
-        float mx = -INFINITY;
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int kj = 0; kj < 4; ++kj) {
-            s[kj] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kj <= qi) {
-                s[kj] = mfma_frag(kf[kj], qf, s[kj]);
+        for (int e = 0; e < NE; ++e) {
+            const bool mine = !PAIR || (gq >> 1) == e;         // this lane's dims belong to head e
+            const unsigned long long kw = shfl64(kw_own[e], qi * 16 + m);
+            f32x4 s[4];
+            float mx = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = kj * 16 + 4 * gq + r;
-                    s[kj][r] = (n > q) ? -INFINITY : s[kj][r];
-                    mx = fmaxf(mx, s[kj][r]);
+            for (int kj = 0; kj < 4; ++kj) {
+                s[kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kj <= qi) {
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    s[kj] = mfma_frag(mine ? kf[kj] : z, qf, s[kj]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = kj * 16 + 4 * gq + r;
+                        s[kj][r] = (n > q) ? -INFINITY : s[kj][r];
+                        mx = fmaxf(mx, s[kj][r]);
+                    }
                 }
             }
-        }
-        mx = quad_group_max(mx);
-        float l = 0.f;
-        f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
+            mx = quad_group_max(mx);
+            float l = 0.f;
+            f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kj = 0; kj < 4; ++kj) {
-            if (kj <= qi) {
+            for (int kj = 0; kj < 4; ++kj) {
+                if (kj <= qi) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = kj * 16 + 4 * gq + r;
-                    const float p = fast_exp(s[kj][r] - mx);
-                    l += p;
-                    const float pd = ((kw >> n) & 1ull) ? p * a.dscale : 0.f;
-                    oacc = mfma4(vt[kj][r], pd, oacc);
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = kj * 16 + 4 * gq + r;
+                        const float p = fast_exp(s[kj][r] - mx);
+                        l += p;
+                        const float pd = ((kw >> n) & 1ull) ? p * a.dscale : 0.f;
+                        oacc = mfma4(vt[kj][r], pd, oacc);
+                    }
                 }
             }
-        }
-        l = quad_group_sum(l);
-        const float rl = 1.0f / l;
-        if (q < T) {
-            st4(a.o + (rowbase + q) * D + col4, make_float4(oacc[0] * rl, oacc[1] * rl, oacc[2] * rl, oacc[3] * rl));
-            if (gq == 0 && a.stats) {
-                float* sp = a.stats + ((rowbase + q) * H + h) * 2;
+            l = quad_group_sum(l);
+            const float rl = 1.0f / l;
+            if (mine) out = make_float4(oacc[0] * rl, oacc[1] * rl, oacc[2] * rl, oacc[3] * rl);
+            if (q < T && gq == (PAIR ? 2 * e : 0) && a.stats) {
+                float* sp = a.stats + ((rowbase + q) * H + (PAIR ? 2 * h + e : h)) * 2;
                 sp[0] = mx; sp[1] = rl;
             }
         }
+        if (q < T) st4(a.o + (rowbase + q) * D + col4, out);
     }
 }
 
@@ -246,17 +262,21 @@ struct AttnBwdOps {
     float2 str[4];
     float kt[4][4], qts[4][4], dots[4][4];
     unsigned long long kw_own;                          // dropout keep word (64 keys) of query row `lane`
+    float2 str2[4];                                     // head-dim-8 pairs only (PAIR): the tile's second head
+    unsigned long long kw_own2;
 };
 
 // Every operand of BOTH phases is requested up front, without a wait, in two parts: what the forward saved (q, k, v, o, row statistics;
 // the dropout keep word is drawn here too) and what the backward's predecessor produces (d_o).  A caller with registers to spare requests
 // the saved part long before d_o exists (the fused per-sequence backward: under the last product of the chain that computes d_o).
 // (A wave has at most 63 vector-memory operations in flight; a head's two parts are 28.)
-template <int NT>
+// (PAIR: h is a 16-column tile = the head-dim-8 heads 2 h and 2 h + 1, see attn_fwd_head)
+template <int NT, bool PAIR = false>
 __device__ __forceinline__ void attn_bwd_load_saved(AttnBwdOps& o, const AttnArgs& a, int g, int b, long long rowbase, int h) {
     const int T = a.T, D = a.D, H = a.H;
     const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
     const int col4 = h * AHD + 4 * gq;
+    const int h0 = PAIR ? 2 * h : h;
     const SeqBuf bq(a.q, rowbase, T, D), bk(a.k, rowbase, T, D), bv(a.v, rowbase, T, D), bo(a.o, rowbase, T, D), bst(a.stats, rowbase, T, 2 * H);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -265,13 +285,18 @@ __device__ __forceinline__ void attn_bwd_load_saved(AttnBwdOps& o, const AttnArg
         o.qfr[t] = bq.ld4(t * 16 + m, col4);
         o.ofr[t] = bo.ld4(t * 16 + m, col4);
         // (two dword loads: hipcc 7.2 drops the second half of a raw_buffer_load_b64 here)
-        o.str[t] = make_float2(bst.ld1(t * 16 + m, 2 * h), bst.ld1(t * 16 + m, 2 * h + 1));
+        o.str[t] = make_float2(bst.ld1(t * 16 + m, 2 * h0), bst.ld1(t * 16 + m, 2 * h0 + 1));
+        if constexpr (PAIR) o.str2[t] = make_float2(bst.ld1(t * 16 + m, 2 * h0 + 2), bst.ld1(t * 16 + m, 2 * h0 + 3));
     }
     o.kw_own = ~0ull;
+    o.kw_own2 = ~0ull;
     if (a.train) {
         const int qrow = min(lane, T - 1);
         o.kw_own = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step,
-                                 (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
+                                 (unsigned long long)(b * H + h0) * T + qrow, T, a.thr16);
+        if constexpr (PAIR)
+            o.kw_own2 = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step,
+                                      (unsigned long long)(b * H + h0 + 1) * T + qrow, T, a.thr16);
     }
 }
 template <int NT>
@@ -307,7 +332,10 @@ __device__ __forceinline__ void tile_transpose(float* __restrict__ tile, const f
 // 16-byte write and four dword reads each) -- the first version recomputed S^T and dP~^T in a second pass with lanes = keys: 8 more
 // matrix instructions and a second exponential per element, and the row statistics of every query travelled through LDS.
 // 20 matrix instructions per pair instead of 28; dK / dV accumulate per key tile across the query tiles.
-template <int NT>
+// PAIR (head dim 8, see attn_fwd_head): two passes over the pairs, one per head of the tile -- the K and V operands of S and dP~ zeroed
+// in the other head's lane groups, that head's row statistics / keep word / delta; dq, dk, dv come out for all 16 dims and the lanes of the
+// pass's head store theirs.
+template <int NT, bool PAIR = false>
 __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& a, long long rowbase, int h, float* __restrict__ lds) {
     const int T = a.T, D = a.D;
     const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
@@ -323,6 +351,16 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
         tile_transpose(tile2, o.qfr[t], o.qts[t]);
         tile_transpose(tile, o.dofr[t], o.dots[t]);
     }
+#pragma unroll
+  for (int e = 0; e < (PAIR ? 2 : 1); ++e) {
+    const bool mine = !PAIR || (gq >> 1) == e;             // this lane's dims belong to the pass's head
+    float4 kfm[4], vfm[4];                                 // K / V row fragments of the pass's head (zeros in the other head's lane groups)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        kfm[t] = mine ? o.kfr[t] : z;
+        vfm[t] = mine ? o.vfr[t] : z;
+    }
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int kj = 0; kj < NT; ++kj) { dk[kj] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kj] = dk[kj]; }
@@ -333,9 +371,18 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
         // (an explicit fma chain: every kernel this core is compiled into -- the standalone launch, the two fused backward builds -- gets
         // the same bits, whatever its surroundings make of a * b + c)
         const float4 of = o.ofr[qi];
-        const float delta = quad_group_sum(fmaf(dof.w, of.w, fmaf(dof.z, of.z, fmaf(dof.y, of.y, dof.x * of.x))));
-        const float ml = o.str[qi].x * LOG2E, c1 = o.str[qi].y * a.dscale, dr = delta * o.str[qi].y;
-        const unsigned long long kw = shfl64(o.kw_own, q);
+        const float dpart = fmaf(dof.w, of.w, fmaf(dof.z, of.z, fmaf(dof.y, of.y, dof.x * of.x)));
+        float delta;
+        if constexpr (PAIR) {                              // a head's dims sit in two lane groups: sum those, fetch the other head's from across
+            const float own = dpart + __shfl_xor(dpart, 16, 64);
+            const float other = __shfl_xor(own, 32, 64);
+            delta = mine ? own : other;
+        } else {
+            delta = quad_group_sum(dpart);
+        }
+        const float2 st = (PAIR && e == 1) ? o.str2[qi] : o.str[qi];
+        const float ml = st.x * LOG2E, c1 = st.y * a.dscale, dr = delta * st.y;
+        const unsigned long long kw = shfl64((PAIR && e == 1) ? o.kw_own2 : o.kw_own, q);
         const unsigned kwh[2] = {(unsigned)kw, (unsigned)(kw >> 32)};
         f32x4 s[4], dp[4];
 #pragma unroll
@@ -344,8 +391,8 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int kj = 0; kj <= qi; ++kj) {
-                s[kj] = mfma4(f4comp(o.kfr[kj], c), f4comp(qf, c), s[kj]);
-                dp[kj] = mfma4(f4comp(o.vfr[kj], c), f4comp(dof, c), dp[kj]);
+                s[kj] = mfma4(f4comp(kfm[kj], c), f4comp(qf, c), s[kj]);
+                dp[kj] = mfma4(f4comp(vfm[kj], c), f4comp(dof, c), dp[kj]);
             }
         f32x4 dqa = f32x4{0.f, 0.f, 0.f, 0.f}, dqb = dqa;
 #pragma unroll
@@ -374,24 +421,26 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
             }
         }
         dqa += dqb;
-        bdq.st4(q, col4, make_float4(dqa[0] * a.scale, dqa[1] * a.scale, dqa[2] * a.scale, dqa[3] * a.scale));
+        // (a lane outside the pass's head stores to row T: past the descriptor's range, i.e. nowhere)
+        bdq.st4(mine ? q : T, col4, make_float4(dqa[0] * a.scale, dqa[1] * a.scale, dqa[2] * a.scale, dqa[3] * a.scale));
     }
 #pragma unroll
     for (int kj = 0; kj < NT; ++kj) {
-        const int key = kj * 16 + m;
+        const int key = mine ? kj * 16 + m : T;
         bdk.st4(key, col4, make_float4(dk[kj][0], dk[kj][1], dk[kj][2], dk[kj][3]));
         bdv.st4(key, col4, make_float4(dv[kj][0], dv[kj][1], dv[kj][2], dv[kj][3]));
     }
+  }
 }
 
-template <int NT>
+template <int NT, bool PAIR = false>
 __device__ __forceinline__ void attn_bwd_head(const AttnArgs& a, int g, int b, long long rowbase, int h, float* __restrict__ lds) {
     AttnBwdOps o;
     STRIP_RSTAMP(16);                                   // (diagnostic builds of sasrec_strip.hip only)
-    attn_bwd_load_saved<NT>(o, a, g, b, rowbase, h);
+    attn_bwd_load_saved<NT, PAIR>(o, a, g, b, rowbase, h);
     attn_bwd_load_dout<NT>(o, a, rowbase, h);
     STRIP_RSTAMP(17);
-    attn_bwd_compute<NT>(o, a, rowbase, h, lds);
+    attn_bwd_compute<NT, PAIR>(o, a, rowbase, h, lds);
 }
 
 }  // namespace amid

@@ -21,13 +21,18 @@
 
 namespace amid {
 
+// a wave's unit of work: a head of 16 dims, or a 16-column tile = two heads of 8 dims (attention_mfma.h PAIR)
+__device__ __forceinline__ bool attn_pairs(const AttnArgs& a) { return a.D / a.H == 8; }
+__device__ __forceinline__ int attn_units(const AttnArgs& a) { return attn_pairs(a) ? a.H / 2 : a.H; }
+
 __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(const AttnArgs a) {
-    const int hw = blockDim.x >> 6, parts = a.H / hw;
+    const int hw = blockDim.x >> 6, parts = attn_units(a) / hw;
     int seq = blockIdx.x / parts;
     const int part = blockIdx.x - seq * parts;
     if (a.live != nullptr) seq = (seq >= a.live[a.B] ? a.B : 0) + a.live[seq];      // slot -> (g, b) of the live list
     const int g = seq / a.B, b = seq - g * a.B;
-    attn_fwd_head(a, g, b, (long long)seq * a.T, part * hw + wave_id());
+    if (attn_pairs(a)) attn_fwd_head<true>(a, g, b, (long long)seq * a.T, part * hw + wave_id());
+    else attn_fwd_head<false>(a, g, b, (long long)seq * a.T, part * hw + wave_id());
 }
 
 __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
@@ -36,7 +41,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
     // a workgroup = `hw` heads of one sequence (hw = blockDim / 64): with 4 heads per workgroup two workgroups fit a CU at
     // this kernel's ~190 VGPRs, and the second residents of the first wave of workgroups start late (below), so that from then
     // on one workgroup's loads run under the other's MFMAs (one 8-head workgroup per CU ran load -> compute -> load -> compute)
-    const int hw = blockDim.x >> 6, parts = H / hw;
+    const int hw = blockDim.x >> 6, parts = attn_units(a) / hw;
     const int slot = blockIdx.x / parts, part = blockIdx.x - slot * parts;
     bool live = true;
     const int seq = a.live != nullptr ? (slot >= a.live[a.B] ? a.B : 0) + a.live[slot]
@@ -58,6 +63,15 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
         for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);       // 127 x 64 clocks each
     }
 
+    if (attn_pairs(a)) {
+        switch ((T + 15) >> 4) {
+            case 1: attn_bwd_head<1, true>(a, g, b, rowbase, h, lds); break;
+            case 2: attn_bwd_head<2, true>(a, g, b, rowbase, h, lds); break;
+            case 3: attn_bwd_head<3, true>(a, g, b, rowbase, h, lds); break;
+            default: attn_bwd_head<4, true>(a, g, b, rowbase, h, lds); break;
+        }
+        return;
+    }
     switch ((T + 15) >> 4) {
         case 1: attn_bwd_head<1>(a, g, b, rowbase, h, lds); break;
         case 2: attn_bwd_head<2>(a, g, b, rowbase, h, lds); break;
@@ -79,8 +93,9 @@ static int cu_count() {
 
 int amid_attn_mfma_fwd_launch(const void* args, void* stream) {
     AttnArgs a = *(const AttnArgs*)args;
-    const int hw = (a.H % 4 == 0) ? 4 : a.H;                   // heads per workgroup
-    const int parts = a.H / hw, grid = (a.live != nullptr ? 1 : 2) * a.B * parts;
+    const int units = (a.D / a.H == 8) ? a.H / 2 : a.H;        // waves per sequence: heads of 16 dims, or pairs of heads of 8
+    const int hw = (units % 4 == 0) ? 4 : units;               // ... per workgroup
+    const int parts = units / hw, grid = (a.live != nullptr ? 1 : 2) * a.B * parts;
     a.stagger_from = -1;                                       // measured: any stagger only delays the forward kernel (20.6 -> 22.5+ us)
     a.stagger_sleeps = 0;
     attn_fwd_mfma_kernel<<<grid, hw * 64, 0, (hipStream_t)stream>>>(a);
@@ -90,8 +105,9 @@ int amid_attn_mfma_fwd_launch(const void* args, void* stream) {
 
 int amid_attn_mfma_bwd_launch(const void* args, void* stream) {
     AttnArgs a = *(const AttnArgs*)args;
-    const int hw = (a.H % 4 == 0) ? 4 : a.H;                   // heads per workgroup
-    const int parts = a.H / hw, grid = (a.live != nullptr ? 1 : 2) * a.B * parts;
+    const int units = (a.D / a.H == 8) ? a.H / 2 : a.H;
+    const int hw = (units % 4 == 0) ? 4 : units;               // waves (heads / head pairs) per workgroup
+    const int parts = units / hw, grid = (a.live != nullptr ? 1 : 2) * a.B * parts;
     // workgroups are handed out one per CU first, so with more than 256 of them [256, 512) are the second residents of the CUs:
     // they wait ~8 us (their neighbour's load phase) before requesting their own operands
     const int n_cu = cu_count();

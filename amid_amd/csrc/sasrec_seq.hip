@@ -425,9 +425,10 @@ extern "C" int amid_sas_seq_fwd_variant(int v) {
     return prev;
 }
 
-// 1 when the fused per-sequence forward covers this shape: head dim 16 with D = 128, T <= 64, activations within 2 GiB
+// 1 when the fused per-sequence forward covers this shape: 8 heads with D = 128 (head dim 16) or D = 64 (head dim 8: the N-split build only,
+// fp32 products, p_drop = 0.5 or eval mode), T <= 64, activations within 2 GiB
 extern "C" int amid_sas_seq_supported(int B, int T, int D, int H) {
-    return (D == 128 && H == 8 && T > 0 && T <= 64 && B > 0 && 2LL * B * T * D * 4 <= 0x7FFFFFF0LL) ? 1 : 0;
+    return ((D == 128 || D == 64) && H == 8 && T > 0 && T <= 64 && B > 0 && 2LL * B * T * D * 4 <= 0x7FFFFFF0LL) ? 1 : 0;
 }
 
 // Per-layer pointer arrays: the per-domain parameter families hold 2 * n_layers entries ordered [layer][domain], the saved-tensor
@@ -472,10 +473,11 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
         if (v == 0) v = 2;                                 // auto: the N-split build wins at every measured shape (profiles/r03_*)
         if (w16 != nullptr && v == 1) return AMID_ERR_UNSUPPORTED;      // the whole-row build has no bf16 products
         if (v != 1) {
-            int rc = launch_seqn_fwd(a, sg, v == 2 ? 0 : v, stream);
-            if (rc == AMID_ERR_UNSUPPORTED && w16 != nullptr) rc = launch_seqn_fwd(a, sg, 0, stream);
+            int rc = launch_seqn_fwd(a, sg, D, v == 2 ? 0 : v, stream);
+            if (rc == AMID_ERR_UNSUPPORTED && w16 != nullptr) rc = launch_seqn_fwd(a, sg, D, 0, stream);
             if (rc != AMID_ERR_UNSUPPORTED || w16 != nullptr) return rc;
         }
+        if (D != 128) return AMID_ERR_UNSUPPORTED;          // the whole-row build below: D = 128 only
     }
     const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4, spw = STRIP_WAVES / wps;
     const int tiles = (B + spw - 1) / spw;

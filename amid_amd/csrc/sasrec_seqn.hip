@@ -40,20 +40,26 @@ static __device__ unsigned long long amid_seqn_stamp_buf[8 * 64];
 
 // attention of the wave's 16 query rows over its own heads h = c0 .. c0 + NCT - 1; K / V^T images of the whole sequence in LDS
 constexpr int NIMG_KEYS = 64;
-template <int D, int WPS, int NCT>
-__device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)[NCT], float (&st_rl)[NCT], const PartRegs<NCT>& Q,
-                                               const float* __restrict__ kimg, const float* __restrict__ vimg, int c0, int si, int m, int gq, int t, int T,
-                                               unsigned long long rowbase_bh, float scale, int train, unsigned long long seed, unsigned site,
-                                               unsigned step, unsigned spec, float dscale) {
+// PAIR (D = 64 with the reference's 8 heads: head dim 8): an own column tile is TWO heads.  Per head the K operand is zeroed in the other
+// head's lane groups (the matrix instruction contracts over the lane groups: groups 0, 1 carry the first head's dims, 2, 3 the
+// second's), P~ V is computed for all 16 dims of the tile and a lane keeps its own head's result (attention_mfma.h attn_fwd_head<true>).
+// st_max / st_rl: per own head, NCT (x 2) of them.
+template <int D, int WPS, int NCT, bool PAIR>
+__device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)[PAIR ? 2 * NCT : NCT], float (&st_rl)[PAIR ? 2 * NCT : NCT],
+                                               const PartRegs<NCT>& Q, const float* __restrict__ kimg, const float* __restrict__ vimg, int c0,
+                                               int si, int m, int gq, int t, int T, unsigned long long rowbase_bh, float scale, int train,
+                                               unsigned long long seed, unsigned site, unsigned step, unsigned spec, float dscale) {
+    constexpr int NE = PAIR ? 2 : 1, NH = NE * NCT;
+    static_assert(NH <= 4, "a lane group draws the keep word of one own head");
     const int qrow = min(t, T - 1);
     f32x4 mdiag;                                           // causal mask of the diagonal tile (kt = si) as the accumulators' initial value
 #pragma unroll
     for (int r = 0; r < 4; ++r) mdiag[r] = (4 * gq + r > m) ? -INFINITY : 0.f;
-    // dropout keep word (64 keys) of this lane's query row for head c0 + gq (lane groups past the own heads idle); head hl's word is
-    // then fetched from group hl
+    // dropout keep word (64 keys) of this lane's query row for own head gq (lane groups past the own heads idle); own head lh's word is
+    // then fetched from group lh
     unsigned kwl = ~0u, kwh = ~0u;
-    if (train && gq < NCT) {
-        const unsigned long long kw = row_keep_word(seed, site, step, (rowbase_bh + c0 + gq) * T + qrow, T, spec);
+    if (train && gq < NH) {
+        const unsigned long long kw = row_keep_word(seed, site, step, (rowbase_bh + NE * c0 + gq) * T + qrow, T, spec);
         kwl = (unsigned)kw; kwh = (unsigned)(kw >> 32);
     }
     const float qscale = scale * LOG2E;
@@ -70,7 +76,11 @@ __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)
                 vf[kt] = lds_ld4(vimg + (h * 16 + m) * NIMG_KEYS + 4 * ((kt * 4 + gq) ^ m));
             }
         }
-        const unsigned kl = train ? bcast_group(kwl, hl) : ~0u, kh = train ? bcast_group(kwh, hl) : ~0u;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int lh = NE * hl + e;
+        const bool mine = !PAIR || (gq >> 1) == e;         // this lane's dims belong to head e of the tile
+        const unsigned kl = train ? bcast_group(kwl, lh) : ~0u, kh = train ? bcast_group(kwh, lh) : ~0u;
         f32x4 s[WPS];
 #pragma unroll
         for (int kt = 0; kt < WPS; ++kt) s[kt] = (kt == si) ? mdiag : (kt < si) ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -81,7 +91,8 @@ __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)
             for (int kt = 0; kt < WPS; ++kt) {
                 if (kt <= si) {
                     const float4 k4 = kf[kt];
-                    s[kt] = mfma4(r == 0 ? k4.x : r == 1 ? k4.y : r == 2 ? k4.z : k4.w, qs, s[kt]);
+                    const float kr = r == 0 ? k4.x : r == 1 ? k4.y : r == 2 ? k4.z : k4.w;
+                    s[kt] = mfma4(mine ? kr : 0.f, qs, s[kt]);
                 }
             }
         }
@@ -122,9 +133,10 @@ __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)
         o = oacc[0];
 #pragma unroll
         for (int kt = 1; kt < WPS; ++kt) o += oacc[kt];
-        O.v[hl] = f32x4{o[0] * ro, o[1] * ro, o[2] * ro, o[3] * ro};
-        st_max[hl] = mx * (1.0f / LOG2E);
-        st_rl[hl] = rl;
+        if (mine) O.v[hl] = f32x4{o[0] * ro, o[1] * ro, o[2] * ro, o[3] * ro};
+        st_max[lh] = mx * (1.0f / LOG2E);
+        st_rl[lh] = rl;
+      }
     }
 }
 
@@ -132,8 +144,10 @@ __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)
 template <int D, int WPS, int NS, bool BF>
 __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArgs a, const SeqGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NT = D / 16, H = D / 16, NW = WPS * NS, NCT = NT / NS;
-    static_assert(D == 128 && NT % NS == 0 && NCT >= 1, "");
+    constexpr int NT = D / 16, NW = WPS * NS, NCT = NT / NS;
+    constexpr bool PAIR = D == 64;                         // 8 heads of 8 dims: two per column tile (seqn_attention)
+    constexpr int H = PAIR ? 2 * NT : NT, NH = PAIR ? 2 * NCT : NCT;        // heads; own heads of a wave
+    static_assert((D == 128 || D == 64) && NT % NS == 0 && NCT >= 1 && (!BF || D == 128), "");
     const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
     // waves w and w + 4 share a SIMD: strip si beside strip WPS - 1 - si (the causal attention core costs si + 1 key tiles per head)
     const int part = w / WPS;
@@ -157,8 +171,12 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
     Ring ring(smem);
     auto w16 = [&](int layer, int which) { return a.w16 + ((size_t)((layer * 2 + g) * 6 + which)) * D * D; };     // q, k, v, o, c1, c2
     if constexpr (BF) ring.first(w16(0, 1)); else ring.first(a.L[0].w_in[g] + 1LL * D * D);
-    float* const img16 = smem + D * D;
-    float* xb = smem + (BF ? D * D + 2 * NIMG_KEYS * D : 2 * D * D) + si * (NT * 64 * 4);      // this strip's exchange slots
+    // (the images of 64 keys -- 2 x 64 D floats -- fit the idle 64 KB slab of the fp32 ring at D = 128 only: bf16 slabs and D = 64's 16 KB
+    // slabs are too small, those builds keep a region of their own behind the ring)
+    constexpr bool SEP_IMG = BF || D == 64;
+    constexpr int RING_F = BF ? D * D : 2 * D * D;
+    float* const img16 = smem + RING_F;
+    float* xb = smem + RING_F + (SEP_IMG ? 2 * NIMG_KEYS * D : 0) + si * (NT * 64 * 4);      // this strip's exchange slots
     const int t = si * 16 + m;
     const bool row_ok = t < sg.T;
     const int local = b * sg.T + min(t, sg.T - 1);
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
         {   // q = Qn Wq^T + bq
             float* buf = ring.next();
             SEQN_STAMP(6);
-            img = BF ? img16 : buf;
+            img = SEP_IMG ? img16 : buf;
             part_cols<NCT>(bias, P.b_in[g], c0);
             seqn_product<D, NCT, BF>(acc, Qn, buf, ring, P.w_o[g], BF ? w16(l, 3) : nullptr, c0,
                                      [&](int ct, int j) { part_spread<NCT>(gv, off_own, Vo, ct, j, 1); });
@@ -277,17 +295,17 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
         }
         lds_barrier();
         SEQN_STAMP(8);
-        float st_max[NCT], st_rl[NCT];
-        seqn_attention<D, WPS, NCT>(Oo, st_max, st_rl, Qo, kimg, vimg, c0, si, m_, gl_, si * 16 + m_, sg.T, (unsigned long long)b * H, a.att_scale, a.train, seed,
+        float st_max[NH], st_rl[NH];
+        seqn_attention<D, WPS, NCT, PAIR>(Oo, st_max, st_rl, Qo, kimg, vimg, c0, si, m_, gl_, si * 16 + m_, sg.T, (unsigned long long)b * H, a.att_scale, a.train, seed,
                                     site_id(g, l, SITE_ATTN), step, a.spec, a.dscale);
         SEQN_STAMP(9);
         {   // row statistics of the own heads: [2M][H][2] floats
-            const unsigned so = row_ok ? phys * (unsigned)(H * 8) + (unsigned)c0 * 8u : STRIP_OOB;
-            if constexpr (NCT >= 2) {
+            const unsigned so = row_ok ? phys * (unsigned)(H * 8) + (unsigned)(PAIR ? 2 * c0 : c0) * 8u : STRIP_OOB;
+            if constexpr (NH >= 2) {
                 f32x4 sv = f32x4{st_max[0], st_rl[0], st_max[1], st_rl[1]};
 #pragma unroll
-                for (int k = 1; k < NCT / 2; ++k) sv = (gq == k) ? f32x4{st_max[2 * k], st_rl[2 * k], st_max[2 * k + 1], st_rl[2 * k + 1]} : sv;
-                gst.store4(gq < NCT / 2 ? so + 16u * (unsigned)gq : STRIP_OOB, sv);
+                for (int k = 1; k < NH / 2; ++k) sv = (gq == k) ? f32x4{st_max[2 * k], st_rl[2 * k], st_max[2 * k + 1], st_rl[2 * k + 1]} : sv;
+                gst.store4(gq < NH / 2 ? so + 16u * (unsigned)gq : STRIP_OOB, sv);
             } else {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gq == 0 ? st_max[0] : st_rl[0]), gst.r,
                                                       (int)(gq < 2 ? so + 4u * (unsigned)gq : STRIP_OOB), 0, 0);
@@ -338,7 +356,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
                                      [&](int ct, int j) { part_spread<NCT>(gr, off_own, Ro, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ho.v[c] = acc[c] + bias.v[c];
-            if (a.train) part_dropout<NCT>(Ho, rr1, c0, a.spec, a.ffn_scale);
+            if (a.train) part_dropout<NCT>(Ho, rr1, c0, a.spec, a.ffn_scale, (local * D) & 127);
 #pragma unroll
             for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
             }, [&]() { if (!last) { lw.load(Pn.ln1_w[g]); lb.load(Pn.ln1_b[g]); } });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Xo.v[c] = acc[c] + bias.v[c];
-            if (a.train) part_dropout<NCT>(Xo, rr2, c0, a.spec, a.ffn_scale);
+            if (a.train) part_dropout<NCT>(Xo, rr2, c0, a.spec, a.ffn_scale, (local * D) & 127);
             const int sh = 8 * gq;
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
@@ -387,13 +405,13 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
 }
 
 template <int D, int WPS, bool BF> static constexpr size_t seqn_lds_bytes() {
-    return (size_t)((BF ? D * D + 2 * NIMG_KEYS * D : 2 * D * D) + WPS * (D / 16) * 64 * 4) * sizeof(float);
+    return (size_t)((BF ? D * D : 2 * D * D) + ((BF || D == 64) ? 2 * NIMG_KEYS * D : 0) + WPS * (D / 16) * 64 * 4) * sizeof(float);
 }
 
-template <int WPS, int NS, bool BF>
+template <int D, int WPS, int NS, bool BF>
 static int seqn_launch_t(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
-    constexpr size_t lds = seqn_lds_bytes<128, WPS, BF>();
-    auto kern = seqn_fwd_kernel<128, WPS, NS, BF>;
+    constexpr size_t lds = seqn_lds_bytes<D, WPS, BF>();
+    auto kern = seqn_fwd_kernel<D, WPS, NS, BF>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int grid = sg.live != nullptr ? sg.B : 2 * sg.B;
@@ -404,14 +422,23 @@ static int seqn_launch_t(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
 
 template <int WPS, int NS>
 static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
-    return a.w16 != nullptr ? seqn_launch_t<WPS, NS, true>(a, sg, stream) : seqn_launch_t<WPS, NS, false>(a, sg, stream);
+    return a.w16 != nullptr ? seqn_launch_t<128, WPS, NS, true>(a, sg, stream) : seqn_launch_t<128, WPS, NS, false>(a, sg, stream);
 }
 
-// variant: 0 = the default split for the shape; 42 / 22 / 24 / 14 / 18 = WPS, NS spelled out (diagnostics and tests)
-int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int variant, void* stream) {
+// variant: 0 = the default split for the shape; 42 / 22 / 24 / 14 / 18 = WPS, NS spelled out (diagnostics and tests).
+// D = 64 (8 heads of 8 dims, two per column tile: the reference's default --emb_dim, train_sr.py:364): four column tiles, so two parts
+// at four strips, four below; fp32 products only.
+int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int D, int variant, void* stream) {
     const int T = sg.T;
     if (a.train && spec_bits(a.spec) != 1) return AMID_ERR_UNSUPPORTED;      // part_dropout: the one-bit keep decisions of p = 0.5 (the reference's rate)
     const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4;
+    if (D == 64) {
+        if (a.w16 != nullptr || (variant != 0 && variant != 2)) return AMID_ERR_UNSUPPORTED;
+        if (wps == 4) return seqn_launch_t<64, 4, 2, false>(a, sg, stream);
+        if (wps == 2) return seqn_launch_t<64, 2, 4, false>(a, sg, stream);
+        return seqn_launch_t<64, 1, 4, false>(a, sg, stream);
+    }
+    if (D != 128) return AMID_ERR_UNSUPPORTED;
     if (variant == 0) variant = wps == 4 ? 42 : wps == 2 ? 24 : 14;
     if (variant / 10 != wps) return AMID_ERR_UNSUPPORTED;
     switch (variant) {

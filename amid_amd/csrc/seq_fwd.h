@@ -51,6 +51,6 @@ __device__ __forceinline__ unsigned bcast_group(unsigned v, int SRC) {
 
 
 // sasrec_seqn.hip: the N-split kernels.  variant: 0 = auto.  Returns AMID_ERR_UNSUPPORTED when no N-split build covers the shape.
-int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int variant, void* stream);
+int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int D, int variant, void* stream);
 
 }  // namespace amid

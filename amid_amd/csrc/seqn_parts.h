@@ -222,13 +222,14 @@ __device__ __forceinline__ void part_mma(f32x4 (&acc)[NCT], const StripRegs<D>& 
 }
 
 // keep multipliers of the own columns of row `local` at `site` (p = 0.5: the row's ONE Philox call, requested ahead: `rr`)
+// (f0: the row's first field inside the call -- 0 at D = 128, where a call is a row; 0 or 64 at D = 64, two rows per call)
 template <int NCT>
-__device__ __forceinline__ void part_dropout(PartRegs<NCT>& x, const uint4 rr, int c0, unsigned spec, float scale) {
+__device__ __forceinline__ void part_dropout(PartRegs<NCT>& x, const uint4 rr, int c0, unsigned spec, float scale, int f0 = 0) {
     const int g4 = 4 * (lane_id() >> 4);
     const bool all = spec_thr(spec) == 0;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
-        const int f = (c0 + c) * 16 + g4;
+        const int f = f0 + (c0 + c) * 16 + g4;
         const unsigned wlo = (f & 64) ? rr.z : rr.x, whi = (f & 64) ? rr.w : rr.y;
         const unsigned w = ((f & 32) ? whi : wlo) >> (f & 31);
 #pragma unroll

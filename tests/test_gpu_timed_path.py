@@ -126,6 +126,10 @@ TIMED_CASES = [
     (64, 16, 128, "_rt3", "mixed"),       # T <= 16 at D 128: the one-strip builds of the fused forward (seq_fwd_kernel<128, 1>, seqn <1, 4>)
     (300, 9, 128, "_rt3", "mixed"),       # ... with a ragged strip
     (256, 32, 128, "_rt3", "mixed"),      # T = 32: two full strips
+    # D = 64 (the reference's default --emb_dim: 8 heads of 8 dims, two per column tile in the matrix-core attention and in the fused
+    # forward, csrc/sasrec_seqn.hip <64, ...>): the two-strip x four-part build and a full 64-token sequence (cases 4 and 8 above: <64, 4, 2> / <64, 1, 4>)
+    (300, 20, 64, "_rt3", "mixed"),
+    (64, 64, 64, "_rt4", "all1"),
 ]
 
 
