@@ -221,7 +221,9 @@ int amid_sas_oproj_ffn_qkv_fwd_f32(const float* o, const float* qn, const float*
 /* ---- K2 attention core ------------------------------------------------------------------------
  * replaces: softmax(q k^T + mask) dropout v inside nn.MultiheadAttention (model_seq.py:374, causal=1) and
  * Attention.forward of BERT4Rec (model_seq.py:149-162, causal=0 with key_keep [B,T] from seq_d2 > 0, :288).
- * stats: [2M, H, 2] (row max, 1/row sum) saved for backward. */
+ * stats: [2M, H, 2] (row max, 1/row sum) saved for backward.  Causal, T <= 64, H <= 8, head dim 16 or 8 (D = 64 with the reference's 8
+ * heads, train_sr.py:364: a 16-column tile is then a PAIR of heads) run on the matrix cores (csrc/attention_mfma.h); 64 < T <= 256 at head
+ * dim 16 their blocked form; BERT4Rec's shape its own matrix-core kernels; everything else the general VALU kernels. */
 int amid_attn_fwd_f32(const float* q, const float* k, const float* v, const unsigned char* key_keep, int B, int T, int D, int H, int causal,
                       int layer, const void* step_state, int train, float p_drop, float* o, float* stats, void* stream);
 int amid_attn_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* stats, const float* d_o,
@@ -494,7 +496,8 @@ int amid_sas_qkv_ffn_bwd_rows_f32(const float* dq, const float* dk, const float*
 /* ---- the whole encoder forward of a sequence in ONE launch (csrc/sasrec_seq.hip) ------------------------------------------------------
  * replaces: Log2feats.forward model_seq.py:371-383 for n_layers layers, the attention core of nn.MultiheadAttention (:374) included --
  * amid_sas_strip_qkv_fwd_f32 + amid_attn_fwd_f32 + amid_sas_strip_oproj_ffn_fwd_f32 per layer, with q / k / v / o never re-read.
- * Shapes: amid_sas_seq_supported (D 128, 8 heads of 16, T <= 64).  Per-domain parameter families: 2 * n_layers pointers ordered
+ * Shapes: amid_sas_seq_supported (8 heads, T <= 64, D 128 -- or D 64, head dim 8: csrc/sasrec_seqn.hip's N-split builds only, fp32 products,
+ * p_drop 0.5 or eval mode).  Per-domain parameter families: 2 * n_layers pointers ordered
  * [layer][domain]; saved-tensor families: n_layers pointers; x_in[l] = layer l's input rows (x_in[0] read, the others written),
  * xout = the last layer's output; stats [2 B T, H, 2]; live as for the strip kernels. */
 int amid_sas_seq_supported(int B, int T, int D, int H);
@@ -576,6 +579,7 @@ int amid_embed_fwd_live_f32(const float* table, const int* idx_all, const float*
 int amid_embed_fwd_live_compact_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
                                     int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
                                     const int* live, int* idx_c, int* row_c, void* stream);
+/* 1 when the matrix-core attention kernels cover the shape (causal, T <= 64, H <= 8, head dim 16 or 8): the live-list entries below */
 int amid_attn_live_supported(int T, int D, int H, int causal);
 int amid_attn_fwd_live_f32(const float* q, const float* k, const float* v, int B, int T, int D, int H, int causal, int layer,
                            const void* step_state, int train, float p_drop, float* o, float* stats, const int* live, void* stream);

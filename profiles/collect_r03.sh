@@ -16,5 +16,5 @@ python3 $P/summarize.py stats $O/prof/p_kernel_stats.csv $P/r03_bench_kernel_sta
   "One MI355X box, ROCm 7.2; produced by bash profiles/r03_profile_cmd.sh $TAG. The replayed step's kernels are the 15 rows with ~100+ calls; seqn_fwd_kernel = amid_sas_seq_fwd_f32 (the N-split build)."
 python3 $P/summarize.py traffic $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv $P/r03_cfg2_sasrec_f32_hbm_traffic.json
 cp $O/sq_counters.md $P/r03_sq_counters.md
-for f in step_timeline seqn_stamps seqn_bwd_stamps variant_steps dp_overhead k1_time catchup_gap; do cp $O/$f.txt $P/r03_$f.txt; done
+for f in step_timeline seqn_stamps seqn_bwd_stamps variant_steps dp_overhead k1_time catchup_gap d64_probe; do cp $O/$f.txt $P/r03_$f.txt; done
 ls -la $P/r03_*

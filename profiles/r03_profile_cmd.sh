@@ -32,6 +32,7 @@ python3 bench.py --workload cfg4 --steps 480 --warmup 520 --no-cpu-baseline --no
 AMID_SEQ_BACKWARD=0 python3 bench.py --workload cfg4 --no-cpu-baseline --no-stress > $O/bench_cfg4_strip_backward.json 2> $O/bench_cfg4_strip_backward.err
 python3 profiles/tools/seqn_bwd_stamps.py 2>&1 | grep -v amdgpu > $O/seqn_bwd_stamps.txt
 python3 profiles/tools/probe/catchup_gap.py 2>&1 | grep "gap" > $O/catchup_gap.txt
+(echo "# python profiles/tools/probe/d64_probe.py (B 256, T 50, synthetic batch; eager kernel list us/launches, then 200 replayed steps)"; python3 profiles/tools/probe/d64_probe.py 2>&1 | grep "D="; echo "# PROBE_D=128, the same script"; PROBE_D=128 python3 profiles/tools/probe/d64_probe.py 2>&1 | grep "D=") > $O/d64_probe.txt
 ls -la $O
 tail -3 $O/smoke.log
 tail -c 400 $O/bench.json
