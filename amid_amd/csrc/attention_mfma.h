@@ -335,8 +335,9 @@ __device__ __forceinline__ void tile_transpose(float* __restrict__ tile, const f
 // PAIR (head dim 8, see attn_fwd_head): two passes over the pairs, one per head of the tile -- the K and V operands of S and dP~ zeroed
 // in the other head's lane groups, that head's row statistics / keep word / delta; dq, dk, dv come out for all 16 dims and the lanes of the
 // pass's head store theirs.
+// (e_only >= 0, PAIR: only that head's pass -- a caller with a wave per HEAD runs the two passes of a tile on two waves side by side)
 template <int NT, bool PAIR = false>
-__device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& a, long long rowbase, int h, float* __restrict__ lds) {
+__device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& a, long long rowbase, int h, float* __restrict__ lds, int e_only = -1) {
     const int T = a.T, D = a.D;
     const int lane = lane_id(), m = lane & 15, gq = lane >> 4;
     const int col4 = h * AHD + 4 * gq;
@@ -353,6 +354,7 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
     }
 #pragma unroll
   for (int e = 0; e < (PAIR ? 2 : 1); ++e) {
+    if (PAIR && e_only >= 0 && e != e_only) continue;      // (wave-uniform)
     const bool mine = !PAIR || (gq >> 1) == e;             // this lane's dims belong to the pass's head
     float4 kfm[4], vfm[4];                                 // K / V row fragments of the pass's head (zeros in the other head's lane groups)
 #pragma unroll
@@ -434,13 +436,13 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
 }
 
 template <int NT, bool PAIR = false>
-__device__ __forceinline__ void attn_bwd_head(const AttnArgs& a, int g, int b, long long rowbase, int h, float* __restrict__ lds) {
+__device__ __forceinline__ void attn_bwd_head(const AttnArgs& a, int g, int b, long long rowbase, int h, float* __restrict__ lds, int e_only = -1) {
     AttnBwdOps o;
     STRIP_RSTAMP(16);                                   // (diagnostic builds of sasrec_strip.hip only)
     attn_bwd_load_saved<NT, PAIR>(o, a, g, b, rowbase, h);
     attn_bwd_load_dout<NT>(o, a, rowbase, h);
     STRIP_RSTAMP(17);
-    attn_bwd_compute<NT, PAIR>(o, a, rowbase, h, lds);
+    attn_bwd_compute<NT, PAIR>(o, a, rowbase, h, lds, e_only);
 }
 
 }  // namespace amid

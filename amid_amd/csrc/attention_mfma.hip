@@ -41,20 +41,25 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
     // a workgroup = `hw` heads of one sequence (hw = blockDim / 64): with 4 heads per workgroup two workgroups fit a CU at
     // this kernel's ~190 VGPRs, and the second residents of the first wave of workgroups start late (below), so that from then
     // on one workgroup's loads run under the other's MFMAs (one 8-head workgroup per CU ran load -> compute -> load -> compute)
-    const int hw = blockDim.x >> 6, parts = attn_units(a) / hw;
+    // (head dim 8: a wave per HEAD here -- the two heads of a tile run their passes on two waves, each loading the tile)
+    const int hw = blockDim.x >> 6, parts = H / hw;
     const int slot = blockIdx.x / parts, part = blockIdx.x - slot * parts;
     bool live = true;
     const int seq = a.live != nullptr ? (slot >= a.live[a.B] ? a.B : 0) + a.live[slot]
                   : a.row_domain != nullptr ? live_rows_remap(a.row_domain, a.B, slot, live) : slot;
     const int g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
-    const int wv = wave_id(), h = part * hw + wv, lane = lane_id();
+    const int wv = wave_id(), unit = part * hw + wv, lane = lane_id();
+    const bool pairs = attn_pairs(a);
+    const int h = pairs ? unit >> 1 : unit, e_only = pairs ? unit & 1 : -1;       // column tile; the tile's head in pair mode
     float* lds = smem + wv * (ATTN_BWD_LDS_PER_WAVE / 4);                                 // this wave's scratch block (attention_mfma.h)
     if (!live) {                                                                       // no gradient reaches this sequence: exact zeros
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = lane; i < T * (AHD / 4); i += 64) {
-            const long long off = (rowbase + i / (AHD / 4)) * D + h * AHD + 4 * (i % (AHD / 4));
-            st4(a.dq + off, z); st4(a.dk + off, z); st4(a.dv + off, z);
+        if (e_only <= 0) {                                                             // (pair mode: the tile's first wave writes its zeros)
+            for (int i = lane; i < T * (AHD / 4); i += 64) {
+                const long long off = (rowbase + i / (AHD / 4)) * D + h * AHD + 4 * (i % (AHD / 4));
+                st4(a.dq + off, z); st4(a.dk + off, z); st4(a.dv + off, z);
+            }
         }
         return;
     }
@@ -63,12 +68,12 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const AttnArgs a) {
         for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);       // 127 x 64 clocks each
     }
 
-    if (attn_pairs(a)) {
+    if (pairs) {
         switch ((T + 15) >> 4) {
-            case 1: attn_bwd_head<1, true>(a, g, b, rowbase, h, lds); break;
-            case 2: attn_bwd_head<2, true>(a, g, b, rowbase, h, lds); break;
-            case 3: attn_bwd_head<3, true>(a, g, b, rowbase, h, lds); break;
-            default: attn_bwd_head<4, true>(a, g, b, rowbase, h, lds); break;
+            case 1: attn_bwd_head<1, true>(a, g, b, rowbase, h, lds, e_only); break;
+            case 2: attn_bwd_head<2, true>(a, g, b, rowbase, h, lds, e_only); break;
+            case 3: attn_bwd_head<3, true>(a, g, b, rowbase, h, lds, e_only); break;
+            default: attn_bwd_head<4, true>(a, g, b, rowbase, h, lds, e_only); break;
         }
         return;
     }
@@ -105,8 +110,8 @@ int amid_attn_mfma_fwd_launch(const void* args, void* stream) {
 
 int amid_attn_mfma_bwd_launch(const void* args, void* stream) {
     AttnArgs a = *(const AttnArgs*)args;
-    const int units = (a.D / a.H == 8) ? a.H / 2 : a.H;
-    const int hw = (units % 4 == 0) ? 4 : units;               // waves (heads / head pairs) per workgroup
+    const int units = a.H;                                     // a wave per head (head dim 8: the two heads of a tile on two waves)
+    const int hw = (units % 4 == 0) ? 4 : units;               // waves per workgroup
     const int parts = units / hw, grid = (a.live != nullptr ? 1 : 2) * a.B * parts;
     // workgroups are handed out one per CU first, so with more than 256 of them [256, 512) are the second residents of the CUs:
     // they wait ~8 us (their neighbour's load phase) before requesting their own operands
