@@ -52,6 +52,10 @@ PEAK_HBM_GBPS = 8000.0
 # batch 4096 per GPU): reported in DESIGN.md / profiles/, never the headline line.
 CFG5_ROWS = 10_000_000
 WORKLOADS = {
+    # BASELINE.json configs[0]: the reference's CPU-runnable plumbing case, at its defaults -- batch 64, emb_dim 64 (8 heads of 8 dims;
+    # train_sr.py:360-364) -- on the real cloth_sport_train25 epoch.  A side measurement like cfg3..cfg5
+    "cfg1": dict(B=64, D=64, n_rows=N_ROWS, pad_id=PAD_ID, max_id=MAX_REAL_ID, kind="real",
+                 label="cloth_sport_train25 SASRec train step at the reference's defaults, batch 64, emb_dim 64 (BASELINE.json configs[0])"),
     "cfg2": dict(B=256, n_rows=N_ROWS, pad_id=PAD_ID, max_id=MAX_REAL_ID, kind="real",
                  label="cloth_sport_train75-shaped SASRec train step (BASELINE.json configs[1])"),
     # BASELINE.json configs[2] / [3], shaped after the data statistics of SURVEY.md section 8(d); side measurements like cfg5
@@ -104,6 +108,7 @@ def synth_batch(gen, device, wl=None):
 
 FIXTURES = os.path.join(ROOT, "tests", "golden")
 REAL = {   # --workload -> tokenised fixtures (tests/golden/make_tokenised.py: the arrays the reference's own DualDomainSeqDataset produced)
+    "cfg1": ("cloth_sport_train25",),
     "cfg2": ("cloth_sport_train75",),
     "cfg3": ("phone_elec_train25",),          # phone_elec_train75 is not in the reference checkout (.MISSING_LARGE_BLOBS): BASELINE.md section 4
     "cfg4": ("loan_fund_train75", "loan_account_train75"),      # joint mode: SURVEY.md section 8(d)
@@ -407,6 +412,7 @@ def main():
     wl = WORKLOADS[args.workload]
     Bw = wl["B"]
     T = wl.get("T", globals()["T"])
+    globals()["D"] = wl.get("D", D)          # (cfg1: emb_dim 64; every formula below reads the module's D)
     if args.model == "bert4rec":
         from amid_amd.engine_bert import Bert4recEngine
         eng = Bert4recEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234)

@@ -7,7 +7,7 @@ O=$R/gpurun_out/$TAG
 P=$R/profiles
 last() { tail -n 1 "$1" > "$2"; }
 last $O/bench.json $P/r03_bench.json
-for w in cfg3 cfg4 cfg3_bf16 cfg2_bf16 bert4rec whole_row_forward cfg4_steady cfg4_strip_backward; do last $O/bench_$w.json $P/r03_bench_$w.json; done
+for w in cfg1 cfg3 cfg4 cfg3_bf16 cfg2_bf16 bert4rec whole_row_forward cfg4_steady cfg4_strip_backward; do last $O/bench_$w.json $P/r03_bench_$w.json; done
 last $O/bench_cfg5-uniform.json $P/r03_bench_cfg5_uniform.json
 last $O/bench_cfg5-real.json $P/r03_bench_cfg5_real.json
 cp $O/prof/p_kernel_stats.csv $P/r03_bench_kernel_stats.csv

@@ -18,7 +18,7 @@ python3 profiles/tools/step_timeline.py $O/tl/tl_results.db > $O/step_timeline.t
 rm -rf $O/tl
 bash profiles/tools/sq_counters.sh $TAG > $O/sq.log 2>&1
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
-for w in cfg5-uniform cfg5-real cfg4 cfg3; do python3 bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
+for w in cfg5-uniform cfg5-real cfg4 cfg3 cfg1; do python3 bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
 python3 bench.py --model bert4rec --no-cpu-baseline > $O/bench_bert4rec.json 2> $O/bench_bert4rec.err
 python3 bench.py --dtype bf16 --no-cpu-baseline > $O/bench_cfg2_bf16.json 2> $O/bench_cfg2_bf16.err
 python3 bench.py --workload cfg3 --dtype bf16 --no-cpu-baseline > $O/bench_cfg3_bf16.json 2> $O/bench_cfg3_bf16.err
