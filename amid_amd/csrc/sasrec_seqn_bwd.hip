@@ -125,7 +125,8 @@ template <int D, int WPS, int NS, bool BF>
 __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = D / 16, NW = WPS * NS, NCT = NT / NS;
-    static_assert(D == 128 && NW == 8 && NCT >= 1, "eight waves: one per head in the attention core");
+    static_assert((D == 128 || D == 64) && NW == 8 && NCT >= 1 && (!BF || D == 128), "eight waves: one per head in the attention core");
+    constexpr bool PAIR = D == 64;                          // 8 heads of 8 dims: two per 16-column tile (attention_mfma.h), a wave per head
     const int bid = blockIdx.x;
     const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
     const int part = w / WPS, si = w % WPS, c0 = part * NCT;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                 }
             }
             PartRegs<NCT> Po = DZo;                         // dpre2 = dz * drop2
-            if (f.train) part_dropout<NCT>(Po, pre.rr2, c0, f.spec, f.scale);
+            if (f.train) part_dropout<NCT>(Po, pre.rr2, c0, f.spec, f.scale, (row.local * D) & 127);
             lds_barrier();                                  // the partner has read this wave's slots of the previous exchange
             xchg_write<NCT>(xb, c0, Po);
             StripRegs<D> Rs;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                     }
                 if (l == 0) SEQNB_STAMP(33);
                 // the attention core's saved operands of this wave's head: they come from HBM -- requested under this product
-                with_tiles<WPS>(T, [&](auto nt) { attn_bwd_load_saved<decltype(nt)::value>(oa, P.at, g, b, rowbase, w); });
+                with_tiles<WPS>(T, [&](auto nt) { attn_bwd_load_saved<decltype(nt)::value, PAIR>(oa, P.at, g, b, rowbase, PAIR ? w >> 1 : w); });
                 if (l == 0) SEQNB_STAMP(34);
                 seqn_product<D, NCT, BF>(acc, F, buf, ring, q.wkT[g], W16(q.wkT[g]), c0,
                                          [&](int ct, int j) { part_spread<NCT>(gdr, off_own, Po, ct, j, 1); });
@@ -293,9 +294,9 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
         if (l < top) ln_partials_put<D, NCT>(S_a, si, c0, dgam_a, dbet_a);
         if (l == 0) SEQNB_STAMP(36);
         // ---------------------------------------------------------------- attention core: head w
-        with_tiles<WPS>(T, [&](auto nt) {
-            attn_bwd_load_dout<decltype(nt)::value>(oa, P.at, rowbase, w);
-            attn_bwd_compute<decltype(nt)::value>(oa, P.at, rowbase, w, att_lds);
+        with_tiles<WPS>(T, [&](auto nt) {                   // (D = 64: wave w runs head w & 1 of tile w >> 1)
+            attn_bwd_load_dout<decltype(nt)::value>(oa, P.at, rowbase, PAIR ? w >> 1 : w);
+            attn_bwd_compute<decltype(nt)::value, PAIR>(oa, P.at, rowbase, PAIR ? w >> 1 : w, att_lds, PAIR ? (w & 1) : -1);
         });
         SEQNB_STAMP(sb + 3);
         w_ring_wait();                  // dq / dk / dv have reached L2
@@ -383,14 +384,14 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
     w_ring_wait();                      // the last (redundant) weight fetch targets this workgroup's LDS
 }
 
-template <int WPS, bool BF> static constexpr size_t seqn_bwd_lds_bytes() {
-    return (size_t)((BF ? 128 * 128 : 2 * 128 * 128) + seqn_bwd_exchange_floats<128, WPS>()) * sizeof(float);
+template <int D, int WPS, bool BF> static constexpr size_t seqn_bwd_lds_bytes() {
+    return (size_t)((BF ? D * D : 2 * D * D) + seqn_bwd_exchange_floats<D, WPS>()) * sizeof(float);
 }
 
-template <int WPS, int NS, bool BF>
+template <int D, int WPS, int NS, bool BF>
 static int seqn_bwd_launch_t(const SeqBwdArgs& a, const StripGeom& sg, void* stream) {
-    constexpr size_t lds = seqn_bwd_lds_bytes<WPS, BF>();
-    auto kern = seqn_bwd_kernel<128, WPS, NS, BF>;
+    constexpr size_t lds = seqn_bwd_lds_bytes<D, WPS, BF>();
+    auto kern = seqn_bwd_kernel<D, WPS, NS, BF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -402,13 +403,20 @@ static int seqn_bwd_launch_t(const SeqBwdArgs& a, const StripGeom& sg, void* str
     return e == hipSuccess ? AMID_OK : (int)e;
 }
 
-int launch_seqn_bwd(const SeqBwdArgs& a, const StripGeom& sg, int mma_bf16, void* stream) {
+// D = 64 (8 heads of 8 dims): four column tiles -- two parts at four strips, four at two, eight waves either way; fp32 products only
+int launch_seqn_bwd(const SeqBwdArgs& a, const StripGeom& sg, int D, int mma_bf16, void* stream) {
     const StripFfnBwdArgs& f = a.L[a.n_layers - 1].f;
     if (f.train && spec_bits(f.spec) != 1) return AMID_ERR_UNSUPPORTED;      // part_dropout: the one-bit keep decisions of p = 0.5 (the reference's rate)
     if (sg.T > 64) return AMID_ERR_UNSUPPORTED;
-    if (sg.T > 32) return mma_bf16 ? seqn_bwd_launch_t<4, 2, true>(a, sg, stream) : seqn_bwd_launch_t<4, 2, false>(a, sg, stream);
-    if (sg.T > 16) return mma_bf16 ? seqn_bwd_launch_t<2, 4, true>(a, sg, stream) : seqn_bwd_launch_t<2, 4, false>(a, sg, stream);
-    return mma_bf16 ? seqn_bwd_launch_t<1, 8, true>(a, sg, stream) : seqn_bwd_launch_t<1, 8, false>(a, sg, stream);
+    if (D == 64) {
+        if (mma_bf16) return AMID_ERR_UNSUPPORTED;
+        if (sg.T > 32) return seqn_bwd_launch_t<64, 4, 2, false>(a, sg, stream);
+        return seqn_bwd_launch_t<64, 2, 4, false>(a, sg, stream);            // (T <= 16 too: one strip stays empty)
+    }
+    if (D != 128) return AMID_ERR_UNSUPPORTED;
+    if (sg.T > 32) return mma_bf16 ? seqn_bwd_launch_t<128, 4, 2, true>(a, sg, stream) : seqn_bwd_launch_t<128, 4, 2, false>(a, sg, stream);
+    if (sg.T > 16) return mma_bf16 ? seqn_bwd_launch_t<128, 2, 4, true>(a, sg, stream) : seqn_bwd_launch_t<128, 2, 4, false>(a, sg, stream);
+    return mma_bf16 ? seqn_bwd_launch_t<128, 1, 8, true>(a, sg, stream) : seqn_bwd_launch_t<128, 1, 8, false>(a, sg, stream);
 }
 
 }  // namespace amid

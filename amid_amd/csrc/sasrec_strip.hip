@@ -772,10 +772,10 @@ extern "C" int amid_sas_strip_qkv_bwd_sort_f32(const float* dq, const float* dk,
 // ---- the fused per-sequence backward ------------------------------------------------------------------------------------------------
 template <int D> static constexpr size_t seq_bwd_lds_bytes() { return strip_lds_bytes<D>() + (size_t)STRIP_WAVES * ATTN_BWD_LDS_PER_WAVE; }
 
-// 1 when amid_sas_seq_bwd_f32 covers the shape: D = 128 with 8 heads of 16, T <= 64 (one sequence per workgroup; T <= 32: the N-split
-// build only, which needs p_drop = 0.5 or eval mode), activations within 2 GiB
+// 1 when amid_sas_seq_bwd_f32 covers the shape: 8 heads with D = 128 or D = 64, T <= 64 (one sequence per workgroup; T <= 32 and D = 64:
+// the N-split build only, which needs p_drop = 0.5 or eval mode and has no bf16 products at D 64), activations within 2 GiB
 extern "C" int amid_sas_seq_bwd_supported(int B, int T, int D, int H) {
-    return (D == 128 && H == 8 && T > 0 && T <= 64 && B > 0 && 2LL * B * T * D * 4 <= 0x7FFFFFF0LL) ? 1 : 0;
+    return ((D == 128 || D == 64) && H == 8 && T > 0 && T <= 64 && B > 0 && 2LL * B * T * D * 4 <= 0x7FFFFFF0LL) ? 1 : 0;
 }
 
 // Which build of the one-launch backward runs: 0 = auto (= 1), 1 = a wave per strip (seq_bwd_kernel), 2 = the N-split build (two waves per
@@ -834,9 +834,9 @@ extern "C" int amid_sas_seq_bwd_f32(int n_layers, const float* dxo, const unsign
     }
     StripGeom sg;
     if (int e = make_strip_geom(B, T, D, live, &sg)) return e;
-    if (g_seq_bwd_variant == 2 || T <= 32) {    // (T > 32: auto = the strip build, the two measure the same -- DESIGN.md section 5.0; T <= 32:
-        const int rc = launch_seqn_bwd(a, sg, mma_bf16, stream);      // two strips x four column parts / one strip x eight, the N-split build only)
-        if (rc != AMID_ERR_UNSUPPORTED || T <= 32) return rc;
+    if (g_seq_bwd_variant == 2 || T <= 32 || D != 128) {      // (T > 32 at D 128: auto = the strip build, the two measure the same -- DESIGN.md
+        const int rc = launch_seqn_bwd(a, sg, D, mma_bf16, stream);      // section 5.0; T <= 32 and D 64: the N-split build only)
+        if (rc != AMID_ERR_UNSUPPORTED || T <= 32 || D != 128) return rc;
     }
     static bool attr_set = false;
     if (!attr_set) {

@@ -36,6 +36,6 @@ struct SeqBwdLayer {
 struct SeqBwdArgs { SeqBwdLayer L[2]; int n_layers; };
 
 // the N-split build of the one-launch backward (sasrec_seqn_bwd.hip); AMID_ERR_UNSUPPORTED when it does not cover the arguments
-int launch_seqn_bwd(const SeqBwdArgs& a, const StripGeom& sg, int mma_bf16, void* stream);
+int launch_seqn_bwd(const SeqBwdArgs& a, const StripGeom& sg, int D, int mma_bf16, void* stream);
 
 }  // namespace amid

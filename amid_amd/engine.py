@@ -313,6 +313,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
         if pl.shape.Tenc <= 32:         # short sequences: the strip launches fill a third of the chip, a workgroup per sequence all of it
             return pl.shape.B <= n_cu
+        if self.D != 128:               # D 64 at T 50: the five strip launches win (B 512: 0.352 against 0.393 ms; B 256: a tie)
+            return False
         return n_cu < pl.shape.B <= 2 * n_cu
 
     def _sort_plan(self, pl: SasrecPlan):

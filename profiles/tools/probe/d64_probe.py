@@ -6,7 +6,7 @@ from amid_amd.engine import SasrecEngine
 from amid_amd._lib import KernelTimer, lib
 D = int(os.environ.get("PROBE_D", "64"))
 bench.D = D
-B, T = 256, 50
+B, T = int(os.environ.get("PROBE_B", "256")), int(os.environ.get("PROBE_T", "50"))
 eng = SasrecEngine(bench.N_ROWS, D, T, bench.HID, lr=5e-4, seed=1)
 bench.D = D
 import types
@@ -14,7 +14,7 @@ import types
 bench.init_params(eng, seed=0)
 pl = eng.plan(B, T, 2, need_grad=True)
 g = torch.Generator().manual_seed(0)
-b = bench.synth_batch(g, "cuda")
+b = bench.synth_batch(g, "cuda", dict(B=B, T=T, pad_id=bench.PAD_ID, max_id=bench.MAX_REAL_ID, kind="real"))
 eng.load_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"])
 L = lib()
 eng.enqueue_train_step(pl); eng.sync()

@@ -153,7 +153,10 @@ def test_timed_path_with_compact_index_list_vs_oracle(Bn, T, D, build, split):
                                                 (1100, 50, 128, "mixed", "1"), (512, 50, 128, "mixed", "0"),
                                                 # T <= 32: the N-split build's two-strip / one-strip shapes (csrc/sasrec_seqn_bwd.hip)
                                                 (256, 20, 128, "mixed", "1"), (300, 32, 128, "mixed", "1"), (64, 17, 128, "one0", "1"),
-                                                (64, 16, 128, "mixed", "1"), (300, 9, 128, "mixed", "1"), (5, 1, 128, "all1", "1")])
+                                                (64, 16, 128, "mixed", "1"), (300, 9, 128, "mixed", "1"), (5, 1, 128, "all1", "1"),
+                                                # D = 64 (8 heads of 8 dims: a wave per head, two per column tile, in the attention core)
+                                                (256, 50, 64, "mixed", "1"), (300, 20, 64, "mixed", "1"), (64, 64, 64, "all1", "1"),
+                                                (37, 13, 64, "one0", "1")])
 def test_timed_path_fused_backward_vs_oracle(Bn, T, D, split, force):
     _timed_vs_oracle(Bn, T, D, None, split, compact_min=None, seq_backward=force)
 
