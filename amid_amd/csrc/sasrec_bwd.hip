@@ -387,6 +387,7 @@ struct WgradArgs {
 };
 
 constexpr int WG_ROWS = 64;    // rows staged per step
+__device__ __forceinline__ float f4comp_w(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 // diagnostic builds only (profiles/tools/wgrad_stamps.py compiles this file with -DAMID_WGRAD_STAMPS into its own library): real-time
 // (100 MHz) stamps of workgroup 0's phases and every workgroup's start / end, in buffers no kernel reads
 #if defined(AMID_WGRAD_STAMPS) && AMID_TILE_RT == 7
@@ -540,6 +541,129 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad_kernel(const WgradA
     }
     WG_STAMP(41);
     WG_SCHED(1);
+}
+
+// The same weight gradients with bf16 operands (compute = "bf16": BASELINE.json configs[2]; fp32 accumulation, fp32 partial sums, fp32
+// bias sums from the unrounded rows): dW = dY^T X contracts over ROWS, and v_mfma_f32_16x16x32_bf16 wants eight consecutive k per lane,
+// so a chunk is staged TRANSPOSED -- Yt / Xt [column][64 rows] bf16, 144 bytes per column (16-byte chunks of eight rows, chunk c of column
+// col at position c ^ ((col >> 2) & 7): a thread packs its four consecutive rows of a column into one 8-byte write, an operand fragment
+// is one 16-byte read).  16 matrix instructions per wave and chunk instead of 128: the launch is then bound by its 157 MB of operands.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wg_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned wg_pack2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(wg_f32x2{a, b}, wg_bf16x2));       // v_cvt_pk_bf16_f32: round to nearest even
+}
+constexpr int WG16_COL_BYTES = 144;                    // 64 rows x 2 bytes + 16: a column of the transposed image
+
+template <int D>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad16_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(D == 128, "eight waves = eight 16-row tiles of dW");
+    constexpr int NTn = D / 16;
+    char* const Yt = reinterpret_cast<char*>(smem);
+    char* const Xt = Yt + D * WG16_COL_BYTES;
+    float* const scratch = reinterpret_cast<float*>(Xt + D * WG16_COL_BYTES);             // [16][D] bias-sum scratch, then the live window
+    int* live = reinterpret_cast<int*>(scratch + 16 * D);
+    const int split = blockIdx.x, wsel = blockIdx.y, g = blockIdx.z;
+    const int layer = wsel / 6, wi = wsel - layer * 6;
+    const float* __restrict__ dy = a.dy[wsel];
+    const float* __restrict__ xin = a.xin[wsel];
+    const int w = wave_id(), lane = lane_id();
+    const bool hint = a.row_domain != nullptr;
+    int local_beg = split * a.rows_per_split;
+    int local_end = min(a.M, local_beg + a.rows_per_split);
+    int sq0 = 0;
+    if (hint) {                // wave 0 counts the domain's live sequences, then lists the window of them this split walks (as sas_wgrad_kernel)
+        __shared__ int hd[3];
+        if (w == 0) {
+            int nl = 0;
+            for (int c = 0; c < a.B; c += 64) nl += __popcll(__ballot(c + lane < a.B && ((a.row_domain[c + lane] != 0 ? 1 : 0) == g)));
+            const int mv = nl * a.T, rps = (mv + a.splits - 1) / a.splits;
+            const int lb = min(mv, split * rps), le = min(mv, lb + rps);
+            const int s0 = lb / a.T, s1 = le > lb ? (le - 1) / a.T : s0 - 1;
+            int n = 0;
+            for (int c = 0; c < a.B && n <= s1; c += 64) {
+                const int b = c + lane;
+                const bool f = b < a.B && ((a.row_domain[b] != 0 ? 1 : 0) == g);
+                const unsigned long long m = __ballot(f);
+                const int k = n + __popcll(m & ((1ull << lane) - 1ull));
+                if (f && k >= s0 && k <= s1) live[k - s0] = b;
+                n += __popcll(m);
+            }
+            if (lane == 0) { hd[0] = lb; hd[1] = le; hd[2] = s0; }
+        }
+        __syncthreads();
+        local_beg = hd[0]; local_end = hd[1]; sq0 = hd[2];
+    }
+    const int i = lane & 15, gq = lane >> 4;
+    const int sub = threadIdx.x & 31, rl = threadIdx.x >> 5;       // column quad 0..31; rows 4 rl .. 4 rl + 3 of the chunk
+    f32x4 acc[NTn];
+#pragma unroll
+    for (int t = 0; t < NTn; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 py[4], px[4];
+    auto fetch = [&](int c0) {                         // issue every load of chunk c0 (zeros beyond the split's range)
+        const int nr = min(WG_ROWS, local_end - c0);
+        const long long grow = (long long)g * a.M + c0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 4 * rl + k;
+            const bool ok = r < nr;
+            long long row = grow + r;
+            if (hint && ok) {                          // virtual row -> (live sequence, position) -> row of the domain
+                const int v = c0 + r, sq = v / a.T;
+                row = (long long)g * a.M + (long long)live[sq - sq0] * a.T + (v - sq * a.T);
+            }
+            py[k] = ok ? ld4(dy + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            px[k] = ok ? ld4(xin + row * D + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // this thread's 8-byte slot in column 4 sub + j: rows 4 rl .. 4 rl + 3 = half (rl & 1) of chunk rl >> 1
+    const int wr_off = (((rl >> 1) ^ (sub & 7)) << 4) + ((rl & 1) << 3);
+    if (local_beg < local_end) fetch(local_beg);
+    for (int c0 = local_beg; c0 < local_end; c0 += WG_ROWS) {
+        __syncthreads();                               // previous chunk fully consumed
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bsum = f4add(bsum, py[k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 4 * sub + j;
+            const float y0 = f4comp_w(py[0], j), y1 = f4comp_w(py[1], j), y2 = f4comp_w(py[2], j), y3 = f4comp_w(py[3], j);
+            const float x0 = f4comp_w(px[0], j), x1 = f4comp_w(px[1], j), x2 = f4comp_w(px[2], j), x3 = f4comp_w(px[3], j);
+            *reinterpret_cast<uint2*>(Yt + col * WG16_COL_BYTES + wr_off) = make_uint2(wg_pack2(y0, y1), wg_pack2(y2, y3));
+            *reinterpret_cast<uint2*>(Xt + col * WG16_COL_BYTES + wr_off) = make_uint2(wg_pack2(x0, x1), wg_pack2(x2, x3));
+        }
+        __syncthreads();
+        if (c0 + WG_ROWS < local_end) fetch(c0 + WG_ROWS);     // next chunk flies under this chunk's MFMAs
+#pragma unroll
+        for (int s = 0; s < WG_ROWS / 32; ++s) {       // two k-steps of 32 rows: lane group gq supplies rows 32 s + 8 gq .. + 7
+            const int ycol = w * 16 + i;
+            const wg_v4u af = *reinterpret_cast<const wg_v4u*>(Yt + ycol * WG16_COL_BYTES + (((4 * s + gq) ^ ((ycol >> 2) & 7)) << 4));
+#pragma unroll
+            for (int t = 0; t < NTn; ++t) {
+                const int xcol = t * 16 + i;
+                const wg_v4u bf = *reinterpret_cast<const wg_v4u*>(Xt + xcol * WG16_COL_BYTES + (((4 * s + gq) ^ ((xcol >> 2) & 7)) << 4));
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8, af), __builtin_bit_cast(wg_bf16x8, bf), acc[t], 0, 0, 0);
+            }
+        }
+    }
+    float* wp = a.w_part[layer] + (((long long)g * 6 + wi) * a.splits + split) * D * D;
+#pragma unroll
+    for (int t = 0; t < NTn; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wp[(long long)(w * 16 + gq * 4 + r) * D + t * 16 + i] = acc[t][r];
+    __syncthreads();
+    st4(scratch + rl * D + 4 * sub, bsum);             // [16][D]
+    __syncthreads();
+    float* bp = a.b_part[layer] + (((long long)g * 6 + wi) * a.splits + split) * D;
+    for (int e = threadIdx.x; e < D; e += GEMM_THREADS) {
+        float sum = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) sum += scratch[k * D + e];
+        bp[e] = sum;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -723,7 +847,7 @@ extern "C" int AMID_ENTRY(amid_sas_qkv_ffn_bwd_rows_f32)(const float* dq, const 
 
 #if AMID_TILE_RT == 7      // everything below is independent of the row-tile height: one copy only
 static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
-                     float* const* b_part, const long long* row_domain, int B, int T, void* stream) {
+                     float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, void* stream) {
     AMID_CHECK_ARG(dy && x && w_part && b_part && (n_layers == 1 || n_layers == 2) && M > 0 && splits > 0);
     AMID_CHECK_ARG(!row_domain || (B > 0 && T > 0 && (long long)B * T == M));
     WgradArgs a;
@@ -737,6 +861,13 @@ static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers
     a.row_domain = (row_domain && win <= WG_LIVE_MAX) ? row_domain : nullptr; a.B = B; a.T = T;
     const size_t live_bytes = a.row_domain ? (size_t)((win + 3) & ~3) * sizeof(int) : 0;
     const dim3 grid(splits, 6 * n_layers, 2);
+    if (mma_bf16) {                 // bf16 operands (csrc: sas_wgrad16_kernel): D = 128 only
+        if (D != 128) return AMID_ERR_UNSUPPORTED;
+        const size_t lds = (size_t)2 * 128 * WG16_COL_BYTES + (size_t)16 * 128 * sizeof(float) + live_bytes;
+        sas_wgrad16_kernel<128><<<grid, GEMM_THREADS, lds, (hipStream_t)stream>>>(a);
+        AMID_LAUNCH_CHECK();
+        return AMID_OK;
+    }
     if (D == 128) {
         const size_t lds = (size_t)2 * WG_ROWS * (128 + 16) * sizeof(float) + live_bytes;
         static size_t set128 = 0;
@@ -761,16 +892,16 @@ extern "C" int amid_wgrad_stamps_read(unsigned long long* host) {       // diagn
 #endif
 
 extern "C" int amid_sas_wgrad_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits,
-                                  float* const* w_part, float* const* b_part, void* stream) {
-    return sas_wgrad(dy, x, n_layers, M, D, splits, w_part, b_part, nullptr, 0, 0, stream);
+                                  float* const* w_part, float* const* b_part, int mma_bf16, void* stream) {
+    return sas_wgrad(dy, x, n_layers, M, D, splits, w_part, b_part, nullptr, 0, 0, mma_bf16, stream);
 }
 
 // the same with the loss structure as a hint (see WgradArgs::row_domain): M = B * T rows per domain, row_domain [B] = the batch's
 // domain ids; the rows of the sequences whose dY is zero by construction are skipped -- same partial sums up to the zeros left out
 extern "C" int amid_sas_wgrad_rows_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits,
                                        float* const* w_part, float* const* b_part, const long long* row_domain, int B, int T,
-                                       void* stream) {
-    return sas_wgrad(dy, x, n_layers, M, D, splits, w_part, b_part, row_domain, B, T, stream);
+                                       int mma_bf16, void* stream) {
+    return sas_wgrad(dy, x, n_layers, M, D, splits, w_part, b_part, row_domain, B, T, mma_bf16, stream);
 }
 
 extern "C" int amid_transpose_weights_f32(const float* const* src, float* const* dst, int n, int D, void* stream) {

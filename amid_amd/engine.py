@@ -295,6 +295,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self._sort_pending = False
 
     SORT_RIDERS = os.environ.get("AMID_SORT_RIDERS", "1") != "0"
+    # compute = "bf16": the weight gradients' products on the bf16 matrix cores too (amid_sas_wgrad_rows_f32 mma_bf16); 0: fp32 products
+    BF16_WGRAD = os.environ.get("AMID_BF16_WGRAD", "1") != "0"
     # The train step's encoder backward (data gradients) as ONE launch over the live sequences where csrc/sasrec_strip.hip covers the
     # shape (amid_sas_seq_bwd_f32): "auto" = where it wins.  It tiles one sequence per workgroup, a whole CU each, so the step's sort
     # riders find no free CU in it and the sort goes back to the side stream (a fork and a join, ~10 us of a replayed graph).  Measured
@@ -720,7 +722,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             xx += [pl.qn[l].data_ptr(), pl.x[l].data_ptr(), pl.x[l].data_ptr(), pl.o[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr()]
         # NOTE: pl.x[0] is the gathered-row buffer xg, still intact here (its gradient lives in dxg)
         L.call("amid_sas_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
-               ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), self._own_rows(pl), B, T, s)
+               ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), self._own_rows(pl), B, T,
+               1 if (self.BF16_WGRAD and getattr(self, "_bf16_bwd", False) and D == 128) else 0, s)
         if getattr(pl, "riding", False):     # the last phase of the step's index sort (run heads) rides here
             L.call("amid_embed_bwd_sort_f32", (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits,
                    pl.dpos_part.data_ptr(), st, tr, SASREC_P_DROP, dom if live else None, self._sort_plan(pl), 5, s)

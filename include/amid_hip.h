@@ -256,13 +256,15 @@ int amid_sas_qkv_ffn_bwd_f32(const float* dq, const float* dk, const float* dv, 
 /* the six weight + bias gradients of n_layers (1 or 2) layers as split partials, ONE launch (two workgroups per CU): dy / x are host
  * arrays of 6 * n_layers device pointers, per layer in the order in_proj q, k, v, out_proj, conv1, conv2; w_part / b_part are host
  * arrays of n_layers device pointers to [2][6][splits][D*D] and [2][6][splits][D] */
+/* mma_bf16 != 0 (compute = "bf16", D 128): the products' operands rounded to bf16 on the way into LDS, v_mfma_f32_16x16x32_bf16 with fp32
+ * accumulation; partial sums and the bias sums (taken from the unrounded rows) stay fp32 */
 int amid_sas_wgrad_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
-                       float* const* b_part, void* stream);
+                       float* const* b_part, int mma_bf16, void* stream);
 /* with the loss structure as a hint (row_domain [B] = the batch's domain_id, M = B * T): of domain g only the sequences b with
  * (row_domain[b] != 0) == g have non-zero dY rows (train_sr.py:205-211 multiplies the other domain's BCE by zero), and only those
  * rows are read -- the K dimension of every weight-gradient product halves.  Same results as amid_sas_wgrad_f32 (zeros left out). */
 int amid_sas_wgrad_rows_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
-                            float* const* b_part, const long long* row_domain, int B, int T, void* stream);
+                            float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, void* stream);
 /* fixed-order reduction of partial buffers; entries are packed on the host then copied to the device by the caller */
 int amid_reduce_entry_bytes(void);
 int amid_reduce_entry_pack(void* host_buf, int index, const float* src, float* dst, long long stride, int n_part, int count);
@@ -532,8 +534,8 @@ int amid_sas_weights_bf16(const float* const* src, int n, int D, int transposed,
 /* ---- the encoder's data gradients of the live sequences in ONE launch (csrc/sasrec_strip.hip: seq_bwd_kernel) -------------------------
  * replaces: autograd of Log2feats.forward model_seq.py:371-383 under loss.backward() (train_sr.py:214) -- per layer, top down,
  * amid_sas_strip_ffn_bwd_f32 + amid_attn_bwd_live_f32 + amid_sas_strip_qkv_bwd_f32 as one workgroup-long chain per live sequence.
- * Shapes: amid_sas_seq_bwd_supported (D 128, 8 heads of 16, T <= 64; T <= 32 runs the N-split build of csrc/sasrec_seqn_bwd.hip -- two strips x
- * four column parts, or one x eight -- which needs p_drop = 0.5 or eval mode: AMID_ERR_UNSUPPORTED otherwise).  Saved tensors / gradient outputs / LayerNorm partials:
+ * Shapes: amid_sas_seq_bwd_supported (8 heads, D 128 or 64, T <= 64; T <= 32 and D 64 run the N-split build of csrc/sasrec_seqn_bwd.hip -- two
+ * strips x four column parts, or one x eight -- which needs p_drop = 0.5 or eval mode: AMID_ERR_UNSUPPORTED otherwise).  Saved tensors / gradient outputs / LayerNorm partials:
  * n_layers pointers each; parameters and transposed weights: 2 * n_layers pointers ordered [layer][domain].  dxo: gradient of the last
  * layer's output; dx: gradient of layer 0's input (rows of the live sequences; the others are not touched); d_o: scratch [2 B T, D].
  * ln1_part / ln2_part[l]: [2 B][2][D] -- domain g's slots are [g B, (g + 1) B): its live sequences' partial sums first, then zeros.

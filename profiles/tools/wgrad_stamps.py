@@ -27,12 +27,12 @@ dom = (torch.rand(B, generator=g) < 0.5).long().to(dev)
 pa = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])     # noqa: E731
 f = L.amid_sas_wgrad_rows_f32
 vp, ci = ctypes.c_void_p, ctypes.c_int
-f.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp]
+f.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, ci, ci, vp]
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(6):
     if it == 5:
         ev0.record()
-    rc = f(pa(dy), pa(xx), 2, M, D, S, pa(wpart), pa(bpart), dom.data_ptr(), B, T, None)
+    rc = f(pa(dy), pa(xx), 2, M, D, S, pa(wpart), pa(bpart), dom.data_ptr(), B, T, 0, None)
     assert rc == 0, rc
     if it == 5:
         ev1.record()

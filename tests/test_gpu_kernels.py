@@ -633,9 +633,9 @@ def test_wgrad_rows_hint_equals_plain(L, B, T):
         args = (ptr_array([t.data_ptr() for t in dy]), ptr_array([t.data_ptr() for t in xx]), 1, M, D, splits, ptr_array([wp.data_ptr()]),
                 ptr_array([bp.data_ptr()]))
         if hint:
-            L.call("amid_sas_wgrad_rows_f32", *args, dev(dom).data_ptr(), B, T, stream())
+            L.call("amid_sas_wgrad_rows_f32", *args, dev(dom).data_ptr(), B, T, 0, stream())
         else:
-            L.call("amid_sas_wgrad_f32", *args, stream())
+            L.call("amid_sas_wgrad_f32", *args, 0, stream())
         torch.cuda.synchronize()
         outs.append((wp.sum(2).cpu(), bp.sum(2).cpu()))
     for a, b_ in zip(*outs):
@@ -644,6 +644,40 @@ def test_wgrad_rows_hint_equals_plain(L, B, T):
     for gdom in range(2):          # against the plain definition dW = dY^T X
         want = dy[0][gdom * M:(gdom + 1) * M].double().t() @ xx[0][gdom * M:(gdom + 1) * M].double()
         assert relmax(outs[1][0][gdom, 0].view(D, D), want) < 1e-5
+
+
+@pytest.mark.parametrize("B,T,hint", [(6, 50, True), (37, 20, False), (256, 50, True), (300, 33, True)])
+def test_wgrad_bf16_products_against_fp32(L, B, T, hint):
+    """amid_sas_wgrad(_rows)_f32 with mma_bf16 = 1 (compute = "bf16": operands rounded to bf16 on the way into LDS, fp32 accumulation)
+    against the products of the bf16-ROUNDED operands in fp64 (what the kernel computes, up to fp32 summation order: 2e-5 of the largest
+    entry) and against the fp32 products (bf16's rounding: 2e-2 relative in the L2 sense); the bias sums come from the unrounded rows."""
+    D, M, splits = 128, B * T, 5
+    g = torch.Generator().manual_seed(B * 3 + T)
+    dom = (torch.rand(B, generator=g) < 0.5).long()
+    live = torch.cat((dom == 0, dom == 1)).float().repeat_interleave(T) if hint else torch.ones(2 * M)
+    dy = [dev(torch.randn(2 * M, D, generator=g) * live[:, None]) for _ in range(6)]
+    xx = [dev(torch.randn(2 * M, D, generator=g)) for _ in range(6)]
+    from amid_amd._lib import ptr_array
+    wp = torch.full((2, 6, splits, D * D), float("nan"), device="cuda"); bp = torch.full((2, 6, splits, D), float("nan"), device="cuda")
+    args = (ptr_array([t.data_ptr() for t in dy]), ptr_array([t.data_ptr() for t in xx]), 1, M, D, splits, ptr_array([wp.data_ptr()]),
+            ptr_array([bp.data_ptr()]))
+    if hint:
+        L.call("amid_sas_wgrad_rows_f32", *args, dev(dom).data_ptr(), B, T, 1, stream())
+    else:
+        L.call("amid_sas_wgrad_f32", *args, 1, stream())
+    torch.cuda.synchronize()
+    got_w, got_b = wp.sum(2).cpu(), bp.sum(2).cpu()
+    assert torch.isfinite(got_w).all() and torch.isfinite(got_b).all()
+    for wi in range(6):
+        for gdom in range(2):
+            y, x = dy[wi][gdom * M:(gdom + 1) * M].cpu(), xx[wi][gdom * M:(gdom + 1) * M].cpu()
+            exact = y.to(torch.bfloat16).double().t() @ x.to(torch.bfloat16).double()
+            full = y.double().t() @ x.double()
+            gw = got_w[gdom, wi].view(D, D).double()
+            assert float((gw - exact).abs().max()) < 2e-5 * float(exact.abs().max()) + 1e-6, (wi, gdom)
+            assert float((gw - full).norm() / full.norm()) < 2e-2
+            assert float((gw - full).abs().max()) > 0.0                      # the mode is on
+            assert float((got_b[gdom, wi].double() - y.double().sum(0)).abs().max()) < 1e-4 * max(1.0, float(y.abs().sum(0).max()))
 
 
 @pytest.mark.parametrize("n,world,D", [(1, 2, 64), (300, 2, 128), (5000, 4, 128), (70000, 8, 128), (2049, 16, 64), (777, 3, 128)])
