@@ -45,6 +45,7 @@ N_ROWS = 2 * ITEM_LENGTH          # train_sr.py:456
 PAD_ID = ITEM_LENGTH + 1          # train_sr.py:451
 MAX_REAL_ID = 42441               # largest id in cloth_sport_train75
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBPS = 8000.0
 
 # --workload: the default is the configuration BASELINE.json's metric is quoted on (configs[1]); the two cfg5 entries are the
@@ -170,6 +171,8 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         # strip kernels of the fused step ("#k": k-th launch of that entry in a step -- the fused cross-layer launch comes first)
         # the whole encoder forward, both layers: 12 projections over the live rows + the two attention cores (4 T^2 hd per head)
         "amid_sas_seq_fwd_f32": ("mfma", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
+        # compute=bf16: the same launch with bf16 operands on the projections (fp32 accumulation; the attention core stays fp32): priced on the bf16 peak
+        "amid_sas_seq_fwd_bf16w_f32": ("mfma16", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
         "amid_sas_strip_qkv_fwd_f32": ("mfma", 3 * gl),
         "amid_sas_strip_oproj_ffn_fwd_f32#0": ("mfma", 6 * gl),       # layer 0's out-proj + FFN, layer 1's q / k / v
         "amid_sas_strip_oproj_ffn_fwd_f32#1": ("mfma", 3 * gl),
@@ -230,7 +233,8 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_qkv_ffn_bwd_f32": "sas_qkv_ffn_bwd_kernel", "amid_sas_oproj_ffn_qkv_fwd_f32": "sas_oproj_ffn_qkv_fwd_kernel",
     "amid_sas_oproj_ffn_fwd_f32": "sas_oproj_ffn_fwd_kernel",
     "amid_attn_fwd_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_f32": "embed_fwd_kernel",
-    "amid_sas_seq_fwd_f32": ("seqn_fwd_kernel", "seq_fwd_kernel"), "amid_sas_seq_bwd_f32": "seq_bwd_kernel", "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
+    "amid_sas_seq_fwd_f32": ("seqn_fwd_kernel", "seq_fwd_kernel"), "amid_sas_seq_fwd_bf16w_f32": ("seqn_fwd_kernel", "seq_fwd_kernel"),
+    "amid_sas_seq_bwd_f32": ("seqn_bwd_kernel", "seq_bwd_kernel"), "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
     "amid_sas_strip_oproj_ffn_fwd_f32#1": "strip_oproj_ffn_fwd_kernelILi128ELb0", "amid_sas_strip_ffn_bwd_f32": "strip_ffn_bwd_kernel",
     "amid_sas_strip_qkv_bwd_f32#0": "strip_qkv_bwd_kernelILi128ELb1", "amid_sas_strip_qkv_bwd_f32#1": "strip_qkv_bwd_kernelILi128ELb0",
     "amid_attn_fwd_live_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_live_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_live_f32": "embed_fwd_kernel", "amid_embed_fwd_live_compact_f32": "embed_fwd_kernel",
@@ -299,6 +303,20 @@ def gather_stress(device, n_steps=6):
     del eng, pl
     torch.cuda.empty_cache()
     return out
+
+
+PREWARM_MS = 100.0
+
+
+def steps_per_graph_for(requested: int, steps: int, graphable: bool) -> int:
+    """Consecutive train steps per replayed hipGraph in the timed region: the CLI's train loop replays graphs of STEPS_PER_GRAPH = 4
+    (amid_amd/train_sr.py), so the bench does too whenever the K timed steps are whole graphs -- the warm-up is rounded UP to whole
+    graphs instead of shrinking the graph (the driver's --steps 20 --warmup 5 keeps 4).  Only a K that is not a multiple falls back
+    to the largest divisor below."""
+    spg = max(1, requested) if graphable else 1
+    while spg > 1 and steps % spg:
+        spg -= 1
+    return spg
 
 
 def usable_cpus() -> int:
@@ -461,11 +479,7 @@ def main():
             eng.load_packed(pl, pool[i % n_pool])
 
     use_graph = not args.no_graph
-    # steps per replayed graph: a graph of several consecutive steps (each picks its batch by the device step counter) pays the idle
-    # time between two graph launches once; K timed steps are still K steps
-    spg = args.steps_per_graph if (use_graph and use_pool and world == 1) else 1
-    while spg > 1 and (args.steps % spg or args.warmup % spg):
-        spg -= 1
+    spg = steps_per_graph_for(args.steps_per_graph, args.steps, use_graph and use_pool and world == 1)
     exchange = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=(backend != "nccl")) if world > 1 else None
     load(0)
     if use_graph:
@@ -496,20 +510,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    done = 0                                   # steps enqueued so far (a graph of spg steps counts spg): `step` is called with a running index
+
+    def run(n):
+        nonlocal done
+        for _ in range(n):
+            step(done)
+            done += 1
+
+    def window(n):
+        """n steps between two barriers; the MAX over the ranks, seconds."""
+        barrier()
+        t0 = time.perf_counter()
+        run(n)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    # W untimed warm-up steps, in whole graphs: ceil(W / spg) replays (never fewer than W steps)
+    run(-(-args.warmup // spg) * spg)
     barrier()
+    # pre-warm, not declared in `warmup`: a fresh lease runs its first milliseconds at idle clocks and cold caches, and the driver's
+    # --warmup 5 is 2 ms of work; replay whole graphs until PREWARM_MS of wall time have gone by (the same on every rank: the
+    # count of replays is agreed on from rank 0's clock), reported as prewarm_ms / prewarm_steps
+    prewarm_steps, t_pw = 0, time.perf_counter()
+    while True:
+        run(spg * 8)
+        prewarm_steps += spg * 8
+        barrier()
+        go_on = (time.perf_counter() - t_pw) * 1e3 < PREWARM_MS
+        if world > 1:
+            flag = torch.tensor([int(go_on)], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+            dist.broadcast(flag, src=0)
+            go_on = bool(int(flag.item()))
+        if not go_on:
+            break
+    prewarm_ms = (time.perf_counter() - t_pw) * 1e3
     ex0 = dict(exchange.stats) if exchange is not None else None
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = window(args.steps)                    # THE timed region: exactly K steps between two barriers
     ex1 = dict(exchange.stats) if exchange is not None else None
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    # four more identical windows behind the headline one (the headline stays window 0): the spread of one 8-ms window on this box
+    windows = [dt] + [window(args.steps) for _ in range(4)]
     loss_last = float(pl.loss.item())
 
     # ---- per-kernel durations, measured live with HIP events on the engine's stream (eager launches) ----
@@ -551,6 +596,8 @@ def main():
                 avg_s = per_step / max(calls, 1) * 1e-3
                 if kind == "hbm":
                     ent.update(bound="hbm", achieved=round(amount / avg_s / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s")
+                elif kind == "mfma16":
+                    ent.update(bound="mfma", achieved=round(amount / avg_s / 1e12, 2), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", operands="bf16")
                 else:
                     ent.update(bound="mfma", achieved=round(amount / avg_s / 1e12, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
                 ent["frac"] = round(ent["achieved"] / ent["peak"], 4)
@@ -646,6 +693,8 @@ def main():
                        "dropout": "on (p=0.5)" if args.model == "sasrec" else "on (p=0.1)", "optimizer": "Adam (dense-equivalent lazy rows)", "graph": use_graph, "steps_per_graph": spg,
                        "parallelism": f"dp{world}"},
             "loss_last": round(loss_last, 6),
+            "prewarm_ms": round(prewarm_ms, 1), "prewarm_steps": prewarm_steps,
+            "window_ms_per_step": [round(1e3 * w / args.steps, 4) for w in windows],
             "roofline": roof,
             "kernels": kernels,
         }

@@ -74,3 +74,16 @@ def test_bench_two_ranks_self_launched_on_one_gpu(dense):
     want = d["sparse_chunk_bytes_per_rank"] * 2 + d["dense_bytes_received_per_step"][dense]
     assert abs(d["bytes_received_per_step_per_rank"] - want) <= 2 * 4 * 128 * 2, (d, want)
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+def test_driver_arguments_keep_four_step_graphs():
+    """The driver runs `bench.py --steps 20 --warmup 5`: the timed region must replay the graphs the CLI's train loop replays
+    (amid_amd/train_sr.py STEPS_PER_GRAPH = 4), the warm-up is rounded up to whole graphs instead of shrinking the graph."""
+    import bench
+    from amid_amd.train_sr import STEPS_PER_GRAPH
+    assert STEPS_PER_GRAPH == 4
+    assert bench.steps_per_graph_for(4, 20, True) == 4          # the driver's arguments
+    assert bench.steps_per_graph_for(4, 200, True) == 4         # the defaults
+    assert bench.steps_per_graph_for(4, 10, True) == 2          # K not a multiple: the largest divisor below
+    assert bench.steps_per_graph_for(4, 7, True) == 1
+    assert bench.steps_per_graph_for(4, 20, False) == 1         # eager / copy input / N > 1: single steps
