@@ -412,6 +412,31 @@ extern "C" int amid_attn_bwd_live_f32(const float* q, const float* k, const floa
     return amid_attn_mfma_bwd_launch(&a, stream);
 }
 
+// ... and the BERT4Rec shape (bidirectional, key mask from seq_d2 > 0 for both encoders, 4 heads of 32, T <= 64: attention_mfma_bert.hip)
+// over a live list: nothing of the other sequences is read or written
+extern "C" int amid_attn_bert_live_supported(int T, int D, int H) { return (T > 0 && T <= 64 && H == 4 && D == 128) ? 1 : 0; }
+extern "C" int amid_attn_bert_fwd_live_f32(const float* q, const float* k, const float* v, const unsigned char* key_keep, int B, int T, int D,
+                                           int H, int layer, const void* step_state, int train, float p_drop, float* o, float* stats,
+                                           const int* live, void* stream) {
+    AttnArgs a = {};
+    if (int e = attn_fill(a, q, k, v, key_keep, B, T, D, H, 0, layer, step_state, train, p_drop)) return e;
+    AMID_CHECK_ARG(o && live);
+    a.o = o; a.stats = stats; a.live = live;
+    if (!amid_attn_bert_live_supported(T, D, H) || !bert_shape(a)) return AMID_ERR_UNSUPPORTED;
+    return amid_attn_bert_fwd_launch(&a, stream);
+}
+extern "C" int amid_attn_bert_bwd_live_f32(const float* q, const float* k, const float* v, const float* o, const float* stats,
+                                           const float* d_o, const unsigned char* key_keep, int B, int T, int D, int H, int layer,
+                                           const void* step_state, int train, float p_drop, float* dq, float* dk, float* dv,
+                                           const int* live, void* stream) {
+    AttnArgs a = {};
+    if (int e = attn_fill(a, q, k, v, key_keep, B, T, D, H, 0, layer, step_state, train, p_drop)) return e;
+    AMID_CHECK_ARG(o && stats && d_o && dq && dk && dv && live);
+    a.o = const_cast<float*>(o); a.stats = const_cast<float*>(stats); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv; a.live = live;
+    if (!amid_attn_bert_live_supported(T, D, H) || !bert_shape(a)) return AMID_ERR_UNSUPPORTED;
+    return amid_attn_bert_bwd_launch(&a, stream);
+}
+
 // the same with the training loss's structure handed in: train_sr.py:205-211 masks row b's BCE of domain 1 - domain_id[b] with
 // zero, so the sequence (g, b) with g != domain_id[b] receives an all-zero d_o and its dq / dk / dv are exact zeros -- the
 // matrix-core kernels write those zeros without loading or computing anything (half of all sequences); the other kernels ignore

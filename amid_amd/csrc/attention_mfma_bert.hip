@@ -33,9 +33,15 @@ __device__ __forceinline__ void key_bits(const unsigned char* __restrict__ kk, i
         }
 }
 
+// a.live (amid_live_list_i32): the launch covers the B listed sequences only -- workgroup j < live[B]: (0, live[j]), else (1, live[j])
+__device__ __forceinline__ int bert_live_seq(const AttnArgs& a, int j) {
+    const int n0 = a.live[a.B];
+    return (j >= n0 ? a.B : 0) + a.live[j];
+}
+
 __global__ __launch_bounds__(512) void attn_fwd_bert_kernel(const AttnArgs a) {
     const int T = a.T, D = a.D, H = a.H;
-    const int seq = blockIdx.x, g = seq / a.B, b = seq - g * a.B;
+    const int seq = a.live != nullptr ? bert_live_seq(a, blockIdx.x) : (int)blockIdx.x, g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
     const int h = wave_id(), lane = lane_id();
     const int m = lane & 15, gq = lane >> 4;
@@ -239,7 +245,8 @@ __global__ __launch_bounds__(512) void attn_bwd_bert_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, D = a.D, H = a.H;
     bool live = true;
-    const int seq = a.row_domain != nullptr ? live_rows_remap(a.row_domain, a.B, blockIdx.x, live) : (int)blockIdx.x;
+    const int seq = a.live != nullptr ? bert_live_seq(a, blockIdx.x)
+                  : a.row_domain != nullptr ? live_rows_remap(a.row_domain, a.B, blockIdx.x, live) : (int)blockIdx.x;
     const int g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
     const int h = wave_id(), lane = lane_id();
@@ -268,7 +275,7 @@ using namespace amid;
 // called by the entry points in attention.hip when the shape fits (bidirectional, head dim 32, T <= 64)
 int amid_attn_bert_fwd_launch(const void* args, void* stream) {
     const AttnArgs& a = *(const AttnArgs*)args;
-    attn_fwd_bert_kernel<<<2 * a.B, a.H * 64, 0, (hipStream_t)stream>>>(a);
+    attn_fwd_bert_kernel<<<a.live != nullptr ? a.B : 2 * a.B, a.H * 64, 0, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
@@ -276,7 +283,7 @@ int amid_attn_bert_fwd_launch(const void* args, void* stream) {
 int amid_attn_bert_bwd_launch(const void* args, void* stream) {
     const AttnArgs& a = *(const AttnArgs*)args;
     const size_t lds = (size_t)a.H * BERT_BWD_LDS_PER_WAVE;
-    attn_bwd_bert_kernel<<<2 * a.B, a.H * 64, lds, (hipStream_t)stream>>>(a);
+    attn_bwd_bert_kernel<<<a.live != nullptr ? a.B : 2 * a.B, a.H * 64, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

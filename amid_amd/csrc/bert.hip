@@ -12,12 +12,12 @@
 #include "common.h"
 #include "rng.h"
 #include "tile_gemm.h"
+#include "bert_math.h"
 
 namespace amid {
 
 constexpr int BD = 128;      // hidden
 constexpr int BF = 512;      // feed-forward
-constexpr float BERT_EPS = 1e-6f;
 
 struct BGeom { int M; int rows_per_tile; int tiles_per_group; };
 __device__ __forceinline__ void btile(const BGeom& tg, int tile, int& g, long long& row0, int& nrows, int& local0) {
@@ -71,19 +71,6 @@ __device__ __forceinline__ float4 lnb_bwd(float4 dy, float4 x, float4 a, float4&
     da = f4add(da, f4scale(f4mul(dy, xc), r));
     db = f4add(db, dy);
     return make_float4(r * (gg.x - gm) - c * xc.x, r * (gg.y - gm) - c * xc.y, r * (gg.z - gm) - c * xc.z, r * (gg.w - gm) - c * xc.w);
-}
-
-// tanh GELU (model_seq.py:204) through the identity 0.5 (1 + tanh u) = sigmoid(2u): one v_exp_f32 and one v_rcp_f32 per element,
-// no cancellation anywhere (libm's tanhf is ~40 instructions over two divergent branches; the feed-forward kernels evaluate
-// 13 M of these per launch).  gelu'(x) = s + 2 x s (1 - s) u'(x) with s = sigmoid(2u), since 1 - tanh^2 u = 4 s (1 - s).
-__device__ __forceinline__ float gelu_sig(float x) {
-    const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);         // 2 u
-    return __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
-}
-__device__ __forceinline__ float gelu_f(float x) { return x * gelu_sig(x); }
-__device__ __forceinline__ float gelu_df(float x) {
-    const float sg = gelu_sig(x);
-    return sg + 2.0f * x * sg * (1.0f - sg) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
 }
 
 // visit the accumulator tiles of a wave: f(row r in tile, first column n, float4 value)

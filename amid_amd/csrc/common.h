@@ -72,4 +72,17 @@ __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float f4hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
+// dynamic LDS above 64 KB needs the kernel's limit raised -- once per DEVICE (the attribute belongs to the device's code object: a
+// process-wide flag left a second device of the same process at the default limit); `done`: the caller's per-kernel device mask
+static inline int lds_attr_once(const void* kern, size_t bytes, unsigned long long& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 64 && ((done >> dev) & 1ull)) return AMID_OK;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 64) done |= 1ull << dev;
+    return AMID_OK;
+}
+
 }  // namespace amid

@@ -412,11 +412,11 @@ template <int D, int WPS, int NS, bool BF>
 static int seqn_launch_t(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
     constexpr size_t lds = seqn_lds_bytes<D, WPS, BF>();
     auto kern = seqn_fwd_kernel<D, WPS, NS, BF>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    static unsigned long long attr_done = 0;          // per device (common.h lds_attr_once): the same scheme as the backward's launcher
+    if (int rc = lds_attr_once((const void*)kern, lds, attr_done)) return rc;
     const int grid = sg.live != nullptr ? sg.B : 2 * sg.B;
     kern<<<grid, 64 * WPS * NS, lds, (hipStream_t)stream>>>(a, sg);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     return e == hipSuccess ? AMID_OK : (int)e;
 }
 

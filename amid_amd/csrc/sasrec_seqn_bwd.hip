@@ -392,12 +392,8 @@ template <int D, int WPS, int NS, bool BF>
 static int seqn_bwd_launch_t(const SeqBwdArgs& a, const StripGeom& sg, void* stream) {
     constexpr size_t lds = seqn_bwd_lds_bytes<D, WPS, BF>();
     auto kern = seqn_bwd_kernel<D, WPS, NS, BF>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;          // per device, as the strip launches (common.h lds_attr_once)
+    if (int rc = lds_attr_once((const void*)kern, lds, attr_done)) return rc;
     kern<<<sg.B, 512, lds, (hipStream_t)stream>>>(a, sg);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? AMID_OK : (int)e;

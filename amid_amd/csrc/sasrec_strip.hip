@@ -16,6 +16,7 @@
 #include "common.h"
 #include "rng.h"
 #include "strip_gemm.h"
+#include "strip_chain.h"
 #include "sort_phases.h"
 #include "attention_mfma.h"
 #include "seq_bwd.h"
@@ -40,53 +41,6 @@ struct StripOffArgs {
     float ln_eps;
     const StepState* st; int train; unsigned spec; float scale; int layer;
 };
-
-template <int D>
-__device__ __forceinline__ void add_bias(f32x4 (&acc)[D / 16], const ColVec<D>& b) {
-#pragma unroll
-    for (int ct = 0; ct < D / 16; ++ct) acc[ct] += b.v[ct];
-}
-template <int D>
-__device__ __forceinline__ void to_regs(StripRegs<D>& dst, const f32x4 (&acc)[D / 16]) {
-#pragma unroll
-    for (int ct = 0; ct < D / 16; ++ct) dst.v[ct] = acc[ct];
-}
-
-// a running two-slab ring.  next() returns the slab whose fetch was started one slab ago: it waits for this wave's DMAs, then meets
-// the other waves at the workgroup barrier -- the slab has landed for everybody, and everybody is done reading the OTHER buffer,
-// which the pieces issued from inside the coming MFMA loop (fetch()) overwrite.
-template <int D, bool BF = false> struct Ring {
-    static constexpr bool BF16 = BF;                    // bf16 fragment images (strip_gemm.h WDma16): slabs of D D / 2 floats
-    static constexpr int SLAB = BF ? D * D / 2 : D * D;
-    using Dma = typename std::conditional<BF, WDma16<D>, WDma<D>>::type;
-    float* buf; int s; Dma dma;
-    __device__ __forceinline__ explicit Ring(float* lds) : buf(lds), s(0) {}
-    __device__ __forceinline__ void first(const float* __restrict__ W0) { dma.all(buf, W0); }
-    __device__ __forceinline__ const float* next() {
-        w_ring_wait();
-        __syncthreads();
-        const float* cur = buf + (s & 1) * SLAB;
-        ++s;
-        return cur;
-    }
-    // group (ct, j) of the current MFMA loop: this wave's share of slab W's DMA, one piece every few groups (address arithmetic and
-    // issue slide under the matrix work instead of standing in front of the loop)
-    __device__ __forceinline__ void fetch(const float* __restrict__ W, int ct, int j) const {
-        // all of them in the FIRST half of the loop: a piece takes a couple of thousand cycles to land, and the next slab starts
-        // with a wait for every one of them
-        constexpr int SLOTS = 8 * (D / 16), EVERY = (SLOTS / 2) / Dma::PER_WAVE;
-        const int slot = ct * 8 + j;
-        if (slot % EVERY == 0 && slot / EVERY < Dma::PER_WAVE) dma.piece(buf + (s & 1) * SLAB, W, slot / EVERY);
-    }
-};
-
-// stores of a finished strip leave under the FIRST half of the next MFMA loop, one column tile every fourth group: by the end of the
-// loop they have long been acknowledged, so the ring's vmcnt(0) in front of the next slab costs nothing
-template <int D>
-__device__ __forceinline__ void store_spread(const GBuf& g, const StripRow& row, const StripRegs<D>& x, int ct, int j) {
-    constexpr int NT = D / 16;
-    if (ct < NT / 2 && (j & 3) == 1) strip_store_ct<D>(g, row, x, 2 * ct + (j >> 2));
-}
 
 // ================================================================================================================ forward
 // q / k / v of one layer on the strip X (in registers).  The ring's current fetch must be Wk of this layer (started by the caller).
@@ -260,32 +214,6 @@ __device__ __forceinline__ void strip_ln_bwd(StripRegs<D>& dx, const StripRegs<D
         }
 }
 
-// column sums of the strip's 16 rows (DPP inside each row of 16 lanes) -> this wave's slice of the LDS scratch [4 waves][2][D]
-template <int D>
-__device__ __forceinline__ void ln_partials_wave(float* __restrict__ scratch, const StripRegs<D>& dgam, const StripRegs<D>& dbet) {
-    const int lane = lane_id(), w = wave_id();
-    float* mine = scratch + w * 2 * D;
-#pragma unroll
-    for (int ct = 0; ct < D / 16; ++ct) {
-        f32x4 a, b;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { a[r] = col_sum16(dgam.v[ct][r]); b[r] = col_sum16(dbet.v[ct][r]); }
-        if ((lane & 15) == 0) {
-            st4(mine + ct * 16 + 4 * (lane >> 4), make_float4(a[0], a[1], a[2], a[3]));
-            st4(mine + D + ct * 16 + 4 * (lane >> 4), make_float4(b[0], b[1], b[2], b[3]));
-        }
-    }
-}
-// after a workgroup barrier: the four waves' slices -> part[2][D] in global memory (fixed order)
-template <int D>
-__device__ __forceinline__ void ln_partials_out(const float* __restrict__ scratch, float* __restrict__ part) {
-    for (int e = threadIdx.x; e < 2 * D; e += STRIP_THREADS)
-        part[e] = (scratch[e] + scratch[2 * D + e]) + (scratch[4 * D + e] + scratch[6 * D + e]);
-}
-
-// LDS: [ring: 2 slabs][LayerNorm-partial scratch A: 4 x 2 x D][scratch B: 4 x 2 x D]
-template <int D> __device__ __forceinline__ float* ln_scratch(float* smem, int which) { return smem + 2 * D * D + which * 8 * D; }
-
 // the loads the feed-forward backward needs first (relu output, "== 0" bits, LayerNorm gain): issued by the caller a slab ahead
 template <int D> struct FfnBwdPre { StripRegs<D> Hs; StripTm<D> tm; ColVec<D> gam; };
 template <int D>
@@ -383,11 +311,6 @@ __device__ __forceinline__ void qkv_bwd_chain(const StripQkvBwdArgs& a, const St
         for (int ct = 0; ct < NT; ++ct) DX.v[ct] += acc_kv[ct];
     }
     ln_partials_wave<D>(scratch, dgam, dbet);
-}
-
-template <int D>
-__device__ __forceinline__ void zero_slot(float* __restrict__ part, int slot) {
-    for (int e = threadIdx.x; e < 2 * D; e += STRIP_THREADS) part[(long long)slot * 2 * D + e] = 0.f;
 }
 
 // RIDER: 0, or the phase of the step's index sort (sort_phases.h) that the first rd.plan.nblk workgroups run, on CUs the live tiles
@@ -547,19 +470,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void seq_bwd_kernel(const SeqBwdArgs
 }  // namespace amid
 
 using namespace amid;
-
-template <int D> static constexpr size_t strip_lds_bytes() { return (size_t)(2 * D * D + 16 * D) * sizeof(float); }
-
-static int make_strip_geom(int B, int T, int D, const int* live, StripGeom* sg) {
-    if (B <= 0 || T <= 0) return AMID_ERR_ARG;
-    const long long bytes = 2LL * B * T * D * 4;
-    if (bytes > 0x7FFFFFF0LL) return AMID_ERR_UNSUPPORTED;          // buffer descriptors: 32-bit offsets, out-of-range marker at 2 GiB
-    sg->B = B; sg->T = T; sg->M = B * T;
-    sg->act_bytes = (unsigned)bytes; sg->tm_bytes = (unsigned)(bytes / 16);
-    sg->tpg = (sg->M + STRIP_TILE - 1) / STRIP_TILE;
-    sg->live = live;
-    return AMID_OK;
-}
+using namespace amid_strip_host;
 
 static int make_rider(SortRider& rd, const void* sort_plan, int sort_phase) {
     rd.phase = 0;
@@ -573,26 +484,9 @@ static int make_rider(SortRider& rd, const void* sort_plan, int sort_phase) {
 // a strip launch with a sort rider: rd.plan.nblk extra workgroups in front of the tiles'
 template <auto KERNEL, int DVAL, class... Args>
 static int launch_strip_rider(const StripGeom& sg, const SortRider& rd, void* stream, const Args&... args) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds_bytes<DVAL>());
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int rc = lds_attr_once((const void*)KERNEL, strip_lds_bytes<DVAL>(), attr_done)) return rc;
     KERNEL<<<2 * sg.tpg + rider_blocks_host(rd), STRIP_THREADS, strip_lds_bytes<DVAL>(), (hipStream_t)stream>>>(args..., sg, rd);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? AMID_OK : (int)e;
-}
-
-template <auto KERNEL, int DVAL, class... Args>
-static int launch_strip(const StripGeom& sg, void* stream, const Args&... args) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds_bytes<DVAL>());
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    KERNEL<<<2 * sg.tpg, STRIP_THREADS, strip_lds_bytes<DVAL>(), (hipStream_t)stream>>>(args..., sg);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? AMID_OK : (int)e;
 }
@@ -838,13 +732,9 @@ extern "C" int amid_sas_seq_bwd_f32(int n_layers, const float* dxo, const unsign
         const int rc = launch_seqn_bwd(a, sg, D, mma_bf16, stream);      // section 5.0; T <= 32 and D 64: the N-split build only)
         if (rc != AMID_ERR_UNSUPPORTED || T <= 32 || D != 128) return rc;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)seq_bwd_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_bwd_lds_bytes<128>());
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)seq_bwd_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_bwd_lds_bytes<128>());
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done[2] = {0, 0};
+    if (int rc = mma_bf16 ? lds_attr_once((const void*)seq_bwd_kernel<128, true>, seq_bwd_lds_bytes<128>(), attr_done[1])
+                          : lds_attr_once((const void*)seq_bwd_kernel<128, false>, seq_bwd_lds_bytes<128>(), attr_done[0])) return rc;
     if (mma_bf16) seq_bwd_kernel<128, true><<<B, STRIP_THREADS, seq_bwd_lds_bytes<128>(), (hipStream_t)stream>>>(a, sg);
     else seq_bwd_kernel<128, false><<<B, STRIP_THREADS, seq_bwd_lds_bytes<128>(), (hipStream_t)stream>>>(a, sg);
     hipError_t e = hipGetLastError();

@@ -7,6 +7,7 @@ Reference quirks kept: hidden size 128 / 4 heads / FFN 512 / dropout 0.1 are har
 taken from ``seq_d2 > 0``, is applied to BOTH encoders (model_seq.py:288, :295-298)."""
 from __future__ import annotations
 
+import ctypes
 from typing import List, Tuple
 
 import torch
@@ -61,6 +62,9 @@ class BertPlan(SasrecPlan):
 
     def _alloc_model_fwd(self, eng, f) -> None:
         M, D, F = self.shape.M, eng.D, BERT_FF
+        # the block's GEMM chains as register-resident strip kernels (csrc/bert_strip.hip) wherever the [2M, 512] tensors fit a buffer
+        # descriptor; the row-tile kernels of csrc/bert.hip beyond
+        self.strip = bool(self.strip and lib().value("amid_bert_strip_supported", self.shape.B, self.shape.Tenc, D))
         self.key_keep = torch.zeros(self.shape.B, self.shape.Tenc, dtype=torch.uint8, device=eng.device)
         self.y = [f(2 * M, D) for _ in range(2)]        # LNb_in(x)
         self.x1 = [f(2 * M, D) for _ in range(2)]
@@ -71,7 +75,7 @@ class BertPlan(SasrecPlan):
     def _alloc_model_bwd(self, eng, f) -> None:
         M, D, F = self.shape.M, eng.D, BERT_FF
         self.rpt_b, self.rt_suffix_b = self.rpt, self.rt_suffix
-        self.tpg_b = (M + self.rpt_b - 1) // self.rpt_b
+        self.tpg_b = self.stpg if self.strip else (M + self.rpt_b - 1) // self.rpt_b          # strip kernels: 64-row tiles
         self.ln1_part = [f(2 * self.tpg_b, 2, D) for _ in range(2)]       # one slot per backward tile
         self.ln2_part = [f(2 * self.tpg_b, 2, D) for _ in range(2)]
         self.dz, self.dt, self.dx1 = f(2 * M, D), f(2 * M, D), f(2 * M, D)
@@ -113,7 +117,15 @@ class Bert4recEngine(SasrecEngine):
     PLAN_CLS = BertPlan
     EMB_DIMS = (BERT_HIDDEN,)
     SHORT_TILE_BUILDS = True
-    STRIP_KERNELS = False        # its encoder launches are bert.hip's row-tile kernels
+    STRIP_KERNELS = True         # the block's GEMM chains on csrc/bert_strip.hip (BertPlan.strip); bert.hip's row-tile kernels beyond 2 GiB
+    SORT_RIDERS = False          # (the riders' host launches are the SASRec strip backward's)
+
+    def live_forward_ok(self, pl) -> bool:
+        """Whether this engine's train step on `pl` encodes the live sequences only (engine._enqueue_fwd_bwd): the plain head, no
+        comp module in front of the encoders, the matrix-core attention kernel's shape."""
+        shp = pl.shape
+        return bool(getattr(pl, "strip", False) and not self.comp and not self.dr and self.FUSED_HEAD and self.LIVE_FORWARD
+                    and lib().value("amid_attn_bert_live_supported", shp.Tenc, self.D, self.H))
 
     def __init__(self, *args, comp: str = "", comp_bs: int = 0, comp_threshold: float = 0.5, **kw):
         """comp = "inc" / "itc": BERT4Rec(isInC=True) / (isItC=True) with bs = comp_bs and threshold1 / threshold2 = comp_threshold:
@@ -154,6 +166,13 @@ class Bert4recEngine(SasrecEngine):
         st = self.step_state.data_ptr()
         tr = 1 if train else 0
         fp = self.dense
+        # the train step's own loss reads only the sequence (domain_id[b], b) of every sample (engine._enqueue_fwd_bwd): with live_fwd the
+        # forward encodes nothing else
+        lv = self._live_list(pl)
+        live_fwd = lv is not None and getattr(self, "_live_fwd", False)
+        lf = lv if live_fwd else None
+        if lv is not None and not getattr(pl, "live_packed", False):
+            L.call("amid_live_list_i32", pl.domain.data_ptr(), B, pl.live.data_ptr(), s)
         # model_seq.py:288: ONE mask, from domain 2, for both encoders
         if self.comp:      # :286 / :294 the T-token mask tiled twice over the 2T keys; the comp module's token group behind each row
             c = self.comp
@@ -166,23 +185,22 @@ class Bert4recEngine(SasrecEngine):
                    pl.inc_sw.data_ptr(), pl.x[0].data_ptr(), s)
         else:
             L.call("amid_key_keep_u8", pl.in_seq_d2.data_ptr(), B * T, pl.key_keep.data_ptr(), s)
-            L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI, pl.xg.data_ptr(), None, st, 0,
-                   0.0, s)
-        for l in (0, 1):
-            pre = f"transform{{d}}.{l}"
-            w3 = ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.weight") for j in range(3) for d in (1, 2)])
-            b3 = ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.bias") for j in range(3) for d in (1, 2)])
-            L.call("amid_bert_qkv_fwd_f32" + pl.rt_suffix, pl.x[l].data_ptr(), self._pp(pre + ".input_sublayer.norm.a_2"), self._pp(pre + ".input_sublayer.norm.b_2"),
-                   w3, b3, M, pl.rpt, pl.y[l].data_ptr(), pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), s)
-            L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l,
-                   st, tr, BERT_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
-            L.call("amid_bert_oproj_fwd_f32" + pl.rt_suffix, pl.o[l].data_ptr(), pl.x[l].data_ptr(), self._pp(pre + ".attention.output_linear.weight"),
-                   self._pp(pre + ".attention.output_linear.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x1[l].data_ptr(), s)
-            L.call("amid_bert_ffn1_fwd_f32" + pl.rt_suffix, pl.x1[l].data_ptr(), self._pp(pre + ".output_sublayer.norm.a_2"), self._pp(pre + ".output_sublayer.norm.b_2"),
-                   self._pp(pre + ".feed_forward.w_1.weight"), self._pp(pre + ".feed_forward.w_1.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP,
-                   pl.y2[l].data_ptr(), pl.pre[l].data_ptr(), pl.h[l].data_ptr(), s)
-            L.call("amid_bert_ffn2_fwd_f32" + pl.rt_suffix, pl.h[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".feed_forward.w_2.weight"),
-                   self._pp(pre + ".feed_forward.w_2.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x[l + 1].data_ptr(), s)
+            if live_fwd and getattr(pl, "compact", False):      # K1 also writes the step's compact index list: the deferred sort starts behind it
+                L.call("amid_embed_fwd_live_compact_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI,
+                       pl.xg.data_ptr(), None, st, 0, 0.0, lf, pl.idx_c.data_ptr(), pl.row_c.data_ptr(), s)
+                if getattr(self, "_sort_owed", False):
+                    self.ev_idx.record(self.stream)
+                    self.enqueue_sort(pl)
+            elif live_fwd:
+                L.call("amid_embed_fwd_live_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI, pl.xg.data_ptr(),
+                       None, st, 0, 0.0, lf, s)
+            else:
+                L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI, pl.xg.data_ptr(), None,
+                       st, 0, 0.0, s)
+        if pl.strip:
+            self._enqueue_blocks_strip(pl, lf, st, tr)
+        else:
+            self._enqueue_blocks_rowtile(pl, st, tr)
         items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
         if self.dr:                                  # three heads (model_seq.py:301-305) on the plain means
             if getattr(self, "_fuse_scorers", False) and with_loss and not sum_loss:
@@ -200,6 +218,66 @@ class Bert4recEngine(SasrecEngine):
         if with_loss and sum_loss:
             L.call("amid_sum_vector_f32", pl.loss_part.data_ptr(), B, pl.loss.data_ptr(), s)
 
+    def _block_ptrs(self, l: int):
+        """Host pointer arrays (domain 0, domain 1) of block l's forward parameters (cached)."""
+        key = ("bert_blk", l)
+        c = self._ptr_cache.get(key)
+        if c is None:
+            fp = self.dense
+            pre = f"transform{{d}}.{l}"
+            c = dict(la1=self._pp(pre + ".input_sublayer.norm.a_2"), lb1=self._pp(pre + ".input_sublayer.norm.b_2"),
+                     w3=ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.weight") for j in range(3) for d in (1, 2)]),
+                     b3=ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.bias") for j in range(3) for d in (1, 2)]),
+                     wo=self._pp(pre + ".attention.output_linear.weight"), bo=self._pp(pre + ".attention.output_linear.bias"),
+                     la2=self._pp(pre + ".output_sublayer.norm.a_2"), lb2=self._pp(pre + ".output_sublayer.norm.b_2"),
+                     w1=self._pp(pre + ".feed_forward.w_1.weight"), b1=self._pp(pre + ".feed_forward.w_1.bias"),
+                     w2=self._pp(pre + ".feed_forward.w_2.weight"), b2=self._pp(pre + ".feed_forward.w_2.bias"))
+            self._ptr_cache[key] = c
+        return c
+
+    def _enqueue_blocks_strip(self, pl: BertPlan, lf, st, tr) -> None:
+        """Both blocks on the strip kernels (csrc/bert_strip.hip): q / k / v of block 0, then per block the attention core and ONE launch
+        for the out-projection, the feed-forward and -- block 0 -- the next block's LayerNorm + q / k / v.  lf: the live list (a train
+        step over the own-domain sequences) or None."""
+        L, s, shp, D = lib(), self.s, pl.shape, self.D
+        B, T = shp.B, shp.Tenc
+        live_attn = lf is not None
+        p0, p1 = self._block_ptrs(0), self._block_ptrs(1)
+        L.call("amid_bert_strip_qkv_fwd_f32", pl.x[0].data_ptr(), p0["la1"], p0["lb1"], p0["w3"], p0["b3"], B, T, lf, pl.y[0].data_ptr(),
+               pl.q[0].data_ptr(), pl.k[0].data_ptr(), pl.v[0].data_ptr(), s)
+        for l, p in ((0, p0), (1, p1)):
+            if live_attn:
+                L.call("amid_attn_bert_fwd_live_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.key_keep.data_ptr(), B, T, D,
+                       self.H, l, st, tr, BERT_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), lf, s)
+            else:
+                L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H,
+                       0, l, st, tr, BERT_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
+            nxt = ((p1["la1"], p1["lb1"], p1["w3"], p1["b3"], pl.y[1].data_ptr(), pl.q[1].data_ptr(), pl.k[1].data_ptr(), pl.v[1].data_ptr())
+                   if l == 0 else (None,) * 8)
+            L.call("amid_bert_strip_oproj_ffn_fwd_f32", pl.o[l].data_ptr(), pl.x[l].data_ptr(), p["wo"], p["bo"], p["la2"], p["lb2"], p["w1"],
+                   p["b1"], p["w2"], p["b2"], B, T, lf, l, st, tr, BERT_P_DROP, pl.x1[l].data_ptr(), pl.y2[l].data_ptr(), pl.pre[l].data_ptr(),
+                   pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(), *nxt, s)
+
+    def _enqueue_blocks_rowtile(self, pl: BertPlan, st, tr) -> None:
+        L, s, shp, D = lib(), self.s, pl.shape, self.D
+        B, T, M = shp.B, shp.Tenc, shp.M
+        fp = self.dense
+        for l in (0, 1):
+            pre = f"transform{{d}}.{l}"
+            w3 = ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.weight") for j in range(3) for d in (1, 2)])
+            b3 = ptr_array([fp.ptr(f"transform{d}.{l}.attention.linear_layers.{j}.bias") for j in range(3) for d in (1, 2)])
+            L.call("amid_bert_qkv_fwd_f32" + pl.rt_suffix, pl.x[l].data_ptr(), self._pp(pre + ".input_sublayer.norm.a_2"), self._pp(pre + ".input_sublayer.norm.b_2"),
+                   w3, b3, M, pl.rpt, pl.y[l].data_ptr(), pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), s)
+            L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l,
+                   st, tr, BERT_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
+            L.call("amid_bert_oproj_fwd_f32" + pl.rt_suffix, pl.o[l].data_ptr(), pl.x[l].data_ptr(), self._pp(pre + ".attention.output_linear.weight"),
+                   self._pp(pre + ".attention.output_linear.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x1[l].data_ptr(), s)
+            L.call("amid_bert_ffn1_fwd_f32" + pl.rt_suffix, pl.x1[l].data_ptr(), self._pp(pre + ".output_sublayer.norm.a_2"), self._pp(pre + ".output_sublayer.norm.b_2"),
+                   self._pp(pre + ".feed_forward.w_1.weight"), self._pp(pre + ".feed_forward.w_1.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP,
+                   pl.y2[l].data_ptr(), pl.pre[l].data_ptr(), pl.h[l].data_ptr(), s)
+            L.call("amid_bert_ffn2_fwd_f32" + pl.rt_suffix, pl.h[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(pre + ".feed_forward.w_2.weight"),
+                   self._pp(pre + ".feed_forward.w_2.bias"), M, pl.rpt, l, st, tr, BERT_P_DROP, pl.x[l + 1].data_ptr(), s)
+
     def enqueue_backward(self, pl: BertPlan, train: bool) -> None:
         L, s, shp, D, F = lib(), self.s, pl.shape, self.D, BERT_FF
         B, T, NI, M = shp.B, shp.Tenc, shp.NI, shp.M
@@ -216,7 +294,6 @@ class Bert4recEngine(SasrecEngine):
                 src.append(fp.ptr(f"{pre}.attention.output_linear.weight")); dst.append(self.wT_sq[l, g, 3].data_ptr()); rows.append(D); cols.append(D)
                 src.append(fp.ptr(f"{pre}.feed_forward.w_1.weight")); dst.append(self.w1T[l, g].data_ptr()); rows.append(F); cols.append(D)
                 src.append(fp.ptr(f"{pre}.feed_forward.w_2.weight")); dst.append(self.w2T[l, g].data_ptr()); rows.append(D); cols.append(F)
-        import ctypes
         L.call("amid_transpose_rect_f32", ptr_array(src), ptr_array(dst), (ctypes.c_int * len(rows))(*rows), (ctypes.c_int * len(cols))(*cols),
                len(src), s)
         items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
@@ -227,7 +304,8 @@ class Bert4recEngine(SasrecEngine):
         elif self.dr:
             self._enqueue_head_dr_bwd(pl, items, ditems)
         elif getattr(self, "_fuse_head", False):
-            L.call("amid_head_fwd_bwd_f32", pl.x[2].data_ptr(), None, None, items, fp.ptr("predictModule.fc.0.weight"),
+            own = getattr(self, "_live_fwd", False) and self._live_list(pl) is not None      # only the own-domain sequences were encoded
+            L.call("amid_head_fwd_bwd_own_f32" if own else "amid_head_fwd_bwd_f32", pl.x[2].data_ptr(), None, None, items, fp.ptr("predictModule.fc.0.weight"),
                    fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"),
                    pl.labels.data_ptr(), pl.domain.data_ptr(), B, T, NI, D, self.hid, 0.0, pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(),
                    pl.dp1.data_ptr(), pl.dp2.data_ptr(), pl.loss_part.data_ptr(), pl.dxbuf.data_ptr(), ditems, None, pl.sc_part.data_ptr(),
@@ -237,21 +315,23 @@ class Bert4recEngine(SasrecEngine):
                fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.p1.data_ptr(),
                pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), B, T, NI, D, self.hid, 0.0, pl.dxbuf.data_ptr(), ditems, None,
                pl.sc_part.data_ptr(), None, None, 0, s)
-        for l in (1, 0):
-            pre = f"transform{{d}}.{l}"
-            wsq = lambda j: ptr_array([self.wT_sq[l, g, j].data_ptr() for g in (0, 1)])      # noqa: E731
-            L.call("amid_bert_ffn2_bwd_f32" + pl.rt_suffix_b, pl.dxbuf.data_ptr(), pl.pre[l].data_ptr(),
-                   ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]), M, pl.rpt_b, l, st, tr, BERT_P_DROP, pl.dz.data_ptr(), pl.dpre.data_ptr(),
-                   s)
-            L.call("amid_bert_ffn1_bwd_f32" + pl.rt_suffix_b, pl.dpre.data_ptr(), pl.dxbuf.data_ptr(), pl.x1[l].data_ptr(),
-                   self._pp(pre + ".output_sublayer.norm.a_2"), ptr_array([self.w1T[l, g].data_ptr() for g in (0, 1)]), wsq(3), M, pl.rpt_b, l, st, tr,
-                   BERT_P_DROP, pl.dx1.data_ptr(), pl.dt.data_ptr(), pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), s)
-            L.call("amid_attn_bwd_rows_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(), pl.stats[l].data_ptr(),
-                   pl.d_o.data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l, st, tr, BERT_P_DROP, pl.dq.data_ptr(), pl.dk.data_ptr(),
-                   pl.dv.data_ptr(), self._own_rows(pl), s)
-            dx_out = (pl.dx0 if self.comp else pl.dxg) if l == 0 else pl.dxbuf
-            wT3 = ptr_array([self.wT_sq[l, g, j].data_ptr() for j in range(3) for g in (0, 1)])
-            # weight-gradient tiles need dx-independent operands only: launch before qkv_bwd overwrites dxbuf
+        # the train step's own backward walks the LIVE sequences only (the loss sends no gradient into the other domain's encoder of a
+        # sample); a comp module in front of the encoders reads the gradient of EVERY encoder-input row: all rows then
+        lv = None if self.comp else self._live_list(pl)
+        live_attn = lv is not None and bool(L.value("amid_attn_bert_live_supported", T, D, self.H))
+
+        def attn_bwd(l):
+            if live_attn:
+                L.call("amid_attn_bert_bwd_live_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(),
+                       pl.stats[l].data_ptr(), pl.d_o.data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, l, st, tr, BERT_P_DROP,
+                       pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), lv, s)
+            else:
+                L.call("amid_attn_bwd_rows_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.o[l].data_ptr(), pl.stats[l].data_ptr(),
+                       pl.d_o.data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H, 0, l, st, tr, BERT_P_DROP, pl.dq.data_ptr(), pl.dk.data_ptr(),
+                       pl.dv.data_ptr(), self._own_rows(pl), s)
+
+        def wgrad(l):
+            # weight-gradient tiles need dx-independent operands only: launched before the q / k / v backward overwrites its buffers
             dy = [pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dt.data_ptr()]
             xx = [pl.y[l].data_ptr()] * 3 + [pl.o[l].data_ptr()]
             ldy, ldx = [D] * 4, [D] * 4
@@ -263,6 +343,45 @@ class Bert4recEngine(SasrecEngine):
             L.call("amid_bert_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), (ctypes.c_int * N_ENT)(*ldy), (ctypes.c_int * N_ENT)(*ldx),
                    (ctypes.c_int * N_ENT)(*old), (ctypes.c_int * N_ENT)(*ogr), (ctypes.c_int * N_ENT)(*oco), N_ENT, M,
                    pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), self._own_rows(pl), B, T, s)
+
+        if pl.strip:
+            # csrc/bert_strip.hip: block 1's feed-forward / out-projection chain, its attention core and weight gradients, then ONE launch
+            # for block 1's q / k / v + LayerNorm backward and block 0's feed-forward / out-projection chain, ..., block 0's q / k / v
+            def ffn_args(l):
+                return (pl.pre[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(f"transform{{d}}.{l}.output_sublayer.norm.a_2"),
+                        ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]), ptr_array([self.w1T[l, g].data_ptr() for g in (0, 1)]),
+                        ptr_array([self.wT_sq[l, g, 3].data_ptr() for g in (0, 1)]))
+            ffn_out = (pl.dz.data_ptr(), pl.dpre.data_ptr(), pl.dx1.data_ptr(), pl.dt.data_ptr(), pl.d_o.data_ptr())
+            pre1, x11, la21, w2T1, w1T1, woT1 = ffn_args(1)
+            L.call("amid_bert_strip_ffn_bwd_f32", pl.dxbuf.data_ptr(), pre1, x11, la21, w2T1, w1T1, woT1, B, T, lv, 1, st, tr, BERT_P_DROP, *ffn_out,
+                   pl.ln2_part[1].data_ptr(), s)
+            for l in (1, 0):
+                attn_bwd(l)
+                wgrad(l)
+                wT3 = ptr_array([self.wT_sq[l, g, j].data_ptr() for j in range(3) for g in (0, 1)])
+                la1 = self._pp(f"transform{{d}}.{l}.input_sublayer.norm.a_2")
+                if l == 1:
+                    L.call("amid_bert_strip_qkv_bwd_f32", pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[1].data_ptr(),
+                           la1, wT3, B, T, lv, None, 0, pl.ln1_part[1].data_ptr(), *ffn_args(0), 0, st, tr, BERT_P_DROP, *ffn_out,
+                           pl.ln2_part[0].data_ptr(), s)
+                else:
+                    dx_out = pl.dx0 if self.comp else pl.dxg
+                    L.call("amid_bert_strip_qkv_bwd_f32", pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[0].data_ptr(),
+                           la1, wT3, B, T, lv, dx_out.data_ptr(), 1 if lv is not None else 0, pl.ln1_part[0].data_ptr(), None, None, None, None,
+                           None, None, 0, None, 0, 0.0, None, None, None, None, None, None, s)
+        for l in ((1, 0) if not pl.strip else ()):
+            pre = f"transform{{d}}.{l}"
+            wsq = lambda j: ptr_array([self.wT_sq[l, g, j].data_ptr() for g in (0, 1)])      # noqa: E731
+            L.call("amid_bert_ffn2_bwd_f32" + pl.rt_suffix_b, pl.dxbuf.data_ptr(), pl.pre[l].data_ptr(),
+                   ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]), M, pl.rpt_b, l, st, tr, BERT_P_DROP, pl.dz.data_ptr(), pl.dpre.data_ptr(),
+                   s)
+            L.call("amid_bert_ffn1_bwd_f32" + pl.rt_suffix_b, pl.dpre.data_ptr(), pl.dxbuf.data_ptr(), pl.x1[l].data_ptr(),
+                   self._pp(pre + ".output_sublayer.norm.a_2"), ptr_array([self.w1T[l, g].data_ptr() for g in (0, 1)]), wsq(3), M, pl.rpt_b, l, st, tr,
+                   BERT_P_DROP, pl.dx1.data_ptr(), pl.dt.data_ptr(), pl.d_o.data_ptr(), pl.ln2_part[l].data_ptr(), s)
+            attn_bwd(l)
+            dx_out = (pl.dx0 if self.comp else pl.dxg) if l == 0 else pl.dxbuf
+            wT3 = ptr_array([self.wT_sq[l, g, j].data_ptr() for j in range(3) for g in (0, 1)])
+            wgrad(l)
             L.call("amid_bert_qkv_bwd_f32" + pl.rt_suffix_b, pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(),
                    pl.x[l].data_ptr(), self._pp(pre + ".input_sublayer.norm.a_2"), wT3, M, pl.rpt_b, dx_out.data_ptr(), pl.ln1_part[l].data_ptr(),
                    s)

@@ -485,6 +485,52 @@ int amid_event_elapsed_ms(void* start, void* stop, float* ms_out);
 int amid_event_destroy(void* ev);
 
 
+/* ---- the BERT4Rec block as register-resident STRIP kernels (csrc/bert_strip.hip; machinery: csrc/strip_gemm.h, strip_chain.h) -------------
+ * replace: TransformerBlock.forward model_seq.py:242-245 (SublayerConnection :140-142, the reference LayerNorm :124-127,
+ * MultiHeadedAttention's projections :183-196, PositionwiseFeedForward :216-217 with the tanh GELU :204) and its autograd
+ * (loss.backward(), train_sr.py:214), like the amid_bert_*_f32 row-tile entry points, same operations, dropout counters and saved
+ * tensors; hidden 128 / feed-forward 512 as hard-coded by the reference (:264-267).  Activations [2 * B * T, 128] and [2 * B * T, 512]
+ * (domain 0's rows, then domain 1's), the wide ones at most 2 GiB (amid_bert_strip_supported).  live: as the amid_sas_strip_* entry
+ * points (NULL = every sequence; else amid_live_list_i32: only the listed sequences are read / written).  Per-domain parameters: host
+ * arrays of two device pointers; w3 / b3 / wT3: six, ordered [q, k, v][domain].  ln_part: [2 * ceil(B * T /
+ * amid_sas_strip_tile_rows())][2][128], domain g owns the slots [g * tpg, (g + 1) * tpg), unused ones are zeroed. */
+int amid_bert_strip_supported(int B, int T, int D);
+int amid_bert_strip_qkv_fwd_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3,
+                                const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k, float* v,
+                                void* stream);
+/* nla != NULL: block l + 1's amid_bert_strip_qkv_fwd_f32 (n* arguments) continues on the block output x2 in registers */
+int amid_bert_strip_oproj_ffn_fwd_f32(const float* o, const float* x, const float* const* wo, const float* const* bo,
+                                      const float* const* la, const float* const* lb, const float* const* w1,
+                                      const float* const* b1, const float* const* w2, const float* const* b2, int B, int T,
+                                      const int* live, int layer, const void* step_state, int train, float p_drop, float* x1,
+                                      float* y2, float* pre, float* h, float* x2, const float* const* nla,
+                                      const float* const* nlb, const float* const* nw3, const float* const* nb3, float* ny,
+                                      float* nq, float* nk, float* nv, void* stream);
+/* w2T [512, 128], w1T [128, 512], woT [128, 128]: the transposed weights (amid_transpose_rect_f32) */
+int amid_bert_strip_ffn_bwd_f32(const float* dx2, const float* pre, const float* x1, const float* const* la,
+                                const float* const* w2T, const float* const* w1T, const float* const* woT, int B, int T,
+                                const int* live, int layer, const void* step_state, int train, float p_drop, float* dz,
+                                float* dpre, float* dx1, float* dt, float* d_o, float* ln_part, void* stream);
+/* fpre != NULL: the block below's amid_bert_strip_ffn_bwd_f32 (f* arguments) continues on d x in registers; dx is then not written.
+ * zero_dead (with a live list and dx): the rows of dx of the sequences NOT on the list are zero-filled (their gradient is exactly
+ * zero, train_sr.py:205-211; the segment reduce of the table-row gradients reads every row) */
+int amid_bert_strip_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x,
+                                const float* const* la, const float* const* wT3, int B, int T, const int* live, float* dx,
+                                int zero_dead, float* ln_part, const float* fpre, const float* fx1, const float* const* fla,
+                                const float* const* fw2T, const float* const* fw1T, const float* const* fwoT, int flayer,
+                                const void* step_state, int train, float p_drop, float* fdz, float* fdpre, float* fdx1,
+                                float* fdt, float* fd_o, float* fln_part, void* stream);
+/* the BERT4Rec attention core (bidirectional, ONE key mask from seq_d2 > 0 for both encoders model_seq.py:288, 4 heads of 32, T <= 64:
+ * csrc/attention_mfma_bert.hip) over the sequences of a live list only */
+int amid_attn_bert_live_supported(int T, int D, int H);
+int amid_attn_bert_fwd_live_f32(const float* q, const float* k, const float* v, const unsigned char* key_keep, int B, int T, int D,
+                                int H, int layer, const void* step_state, int train, float p_drop, float* o, float* stats,
+                                const int* live, void* stream);
+int amid_attn_bert_bwd_live_f32(const float* q, const float* k, const float* v, const float* o, const float* stats,
+                                const float* d_o, const unsigned char* key_keep, int B, int T, int D, int H, int layer,
+                                const void* step_state, int train, float p_drop, float* dq, float* dk, float* dv,
+                                const int* live, void* stream);
+
 /* ---- the three SASRec backward row-tile kernels over the LIVE sequences only ------------------------------------------------
  * The train step's own loss multiplies the other domain's BCE of every sample by zero (train_sr.py:205-211): of encoder g only the
  * sequences b with (row_domain[b] != 0) == g receive a gradient, everything else in its backward is exact zeros.  These entry points
