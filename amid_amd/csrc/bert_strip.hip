@@ -52,7 +52,7 @@ template <int D, int LD> struct WDmaLd {
         const unsigned lds = __builtin_amdgcn_readfirstlane(
             (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(buf + (k0 * STRIP_WAVES + w) * 256));
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
     }
 };
@@ -131,20 +131,66 @@ __device__ __forceinline__ void strip_lnb_bwd(StripRegs<BSD>& dx, const StripReg
         for (int e = 0; e < 4; ++e) dx.v[ct][e] = r * (dx.v[ct][e] - gm) - c * (x.v[ct][e] - mean);
 }
 
-// ---- dropout on a strip: the keep bits of this lane's 32 elements (bit 4 ct + e <-> column 16 ct + 4 g + e), drawn AHEAD of the
-// product whose epilogue applies them (the counters do not depend on data: the Philox rounds slide under the matrix instructions) ----
+// ---- dropout on a strip: the keep bits of this lane's 32 elements (bit 4 ct + e <-> column 16 ct + 4 g + e) -------------------------------
+// p = 0.1 takes 16-bit decisions (rng.h): ONE Philox call decides 8 consecutive elements = the column quads of lanes (m, 2h) and
+// (m, 2h + 1) of one column tile.  Lane (m, g) draws the calls of the column tiles ct with (ct & 1) == (g & 1), keeps its own quad's
+// four decisions and hands the partner (lane ^ 16) the other four: four calls per lane and site instead of eight.  And the calls are
+// drawn INSIDE the matrix loop in front of the epilogue that applies them, a round per MFMA group (slot()): the counters do not depend
+// on data, a round is two quarter-rate multiplies + five plain instructions, a group's four matrix instructions cover them.
+// (measured, cfg 2: with every lane drawing its eight calls ahead of the loop the counters cost 87 us of a 0.725 ms step)
 struct BDrop { int train; unsigned spec; float scale; unsigned long long seed; unsigned step; int layer; };
-__device__ __forceinline__ unsigned keep_bits(const BDrop& d, int g, int kind, unsigned long long e_row) {
-    if (!d.train) return ~0u;
-    const int g4 = 4 * (lane_id() >> 4);
-    const unsigned site = site_id(g, d.layer, kind);
-    unsigned bits = 0u;
-#pragma unroll
-    for (int ct = 0; ct < BNT; ++ct) {
-        const float4 m = dropout_mult4(d.seed, site, d.step, e_row + ct * 16 + g4, d.spec, 1.0f);
-        bits |= ((m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 2u : 0u) | (m.z != 0.f ? 4u : 0u) | (m.w != 0.f ? 8u : 0u)) << (4 * ct);
+struct KeepGen {
+    uint4 c; unsigned k0, k1, own, give;
+    unsigned long long call0; unsigned site, step, key0, key1, thr; int godd, train;
+    // e_row: the row's first element (a multiple of 128: call-aligned)
+    __device__ __forceinline__ void begin(const BDrop& d, int g, int kind, unsigned long long e_row) {
+        const int gq = lane_id() >> 4;
+        godd = gq & 1;
+        call0 = (e_row >> 3) + (unsigned)(gq >> 1);            // call of column tile ct: call0 + 2 ct
+        site = site_id(g, d.layer, kind); step = d.step; key0 = (unsigned)d.seed; key1 = (unsigned)(d.seed >> 32);
+        thr = spec_thr(d.spec); train = d.train;
+        own = 0u; give = 0u;
     }
-    return bits;
+    // slot s = 0 .. 63 of an MFMA loop (8 ct + j): call i = s / 16 in phases s % 16 = 0 (counter), 1 .. 10 (rounds), 11 (decisions)
+    __device__ __forceinline__ void slot(int s) {
+        const int i = s >> 4, ph = s & 15;
+        const int ct = 2 * i + godd;
+        if (ph == 0) {
+            const unsigned long long call = call0 + 2u * (unsigned)ct;
+            c = make_uint4((unsigned)call, (unsigned)(call >> 32), site, step);
+            k0 = key0; k1 = key1;
+        } else if (ph <= 10) {
+#ifdef AMID_BS_ABLATE_PHILOX          // timing-only diagnostic build (profiles/tools/probe/bert_ablate.sh): what the rounds cost
+            return;
+#endif
+            const unsigned long long p0 = mul_wide(0xD2511F53u, c.x), p1 = mul_wide(0xCD9E8D57u, c.z);
+            c = make_uint4((unsigned)(p1 >> 32) ^ c.y ^ k0, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k1, (unsigned)p0);
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        } else if (ph == 11) {
+            const unsigned lo4 = ((c.x & 0xFFFFu) >= thr ? 1u : 0u) | ((c.x >> 16) >= thr ? 2u : 0u) | ((c.y & 0xFFFFu) >= thr ? 4u : 0u) | ((c.y >> 16) >= thr ? 8u : 0u);
+            const unsigned hi4 = ((c.z & 0xFFFFu) >= thr ? 1u : 0u) | ((c.w >> 16) >= thr ? 8u : 0u) | ((c.z >> 16) >= thr ? 2u : 0u) | ((c.w & 0xFFFFu) >= thr ? 4u : 0u);
+            own |= (godd ? hi4 : lo4) << (4 * ct);
+            give |= (godd ? lo4 : hi4) << (4 * ct);
+        }
+    }
+    __device__ __forceinline__ void hook(int ct, int j) { slot(ct * 8 + j); }
+    // all four calls at once (no loop to hide them in)
+    __device__ __forceinline__ void all() {
+#pragma unroll
+        for (int s = 0; s < 64; ++s) slot(s);
+    }
+    __device__ __forceinline__ unsigned finish() const {
+        float a = __builtin_bit_cast(float, give), b = a;
+        swap16(a, b);                                           // a: (r0, r0, r2, r2), b: (r1, r1, r3, r3) of `give` by lane row
+        const unsigned got = __builtin_bit_cast(unsigned, godd ? a : b);
+        return train ? (own | got) : ~0u;
+    }
+};
+__device__ __forceinline__ unsigned keep_bits(const BDrop& d, int g, int kind, unsigned long long e_row) {
+    KeepGen kg;
+    kg.begin(d, g, kind, e_row);
+    kg.all();
+    return kg.finish();
 }
 __device__ __forceinline__ void apply_keep(StripRegs<BSD>& x, unsigned bits, float scale) {
 #pragma unroll
@@ -261,50 +307,62 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_oproj_ffn_fwd_kernel
     strip_load<BSD>(X1, GBuf(a.x, sg.act_bytes), row);
     bias.load(a.bo[g]); la.load(a.la[g]); lb.load(a.lb[g]);
     f32x4 acc[BNT], acc2[BNT];
+    KeepGen kg;
     {   // x1 = x + drop_in(o Wo^T + bo) ; y2 = LNb_out(x1)
-        const unsigned kb = keep_bits(dc, g, SITE_SUB_IN, e128);
+        kg.begin(dc, g, SITE_SUB_IN, e128);
         const float* buf = ring.next();
         strip_zero<BSD>(acc);
-        strip_mma<BSD>(acc, A, buf, [&](int ct, int j) { ring.fetch(a.w1[g], ct, j); });
+        strip_mma<BSD>(acc, A, buf, [&](int ct, int j) { ring.fetch(a.w1[g], ct, j); kg.hook(ct, j); });
         add_bias<BSD>(acc, bias);
         to_regs<BSD>(A, acc);
-        apply_keep(A, kb, dc.scale);
+        apply_keep(A, kg.finish(), dc.scale);
 #pragma unroll
         for (int ct = 0; ct < BNT; ++ct) X1.v[ct] += A.v[ct];
         strip_lnb(Y2, X1, la, lb);
     }
     strip_zero<BSD>(acc2);
+    unsigned kb1 = ~0u, kb2 = ~0u;
 #pragma unroll
     for (int c = 0; c < BSC; ++c) {
         {   // pre_c = y2 W1_c^T + b1_c ; h_c = drop_ffn(gelu(pre_c))
-            const unsigned kb = keep_bits(dc, g, SITE_FFN1, e512 + c * BSD);
+            kg.begin(dc, g, SITE_FFN1, e512 + c * BSD);
             const float* buf = ring.next();
             bias.load(a.b1[g] + c * BSD);
             strip_zero<BSD>(acc);
             strip_mma<BSD>(acc, Y2, buf, [&](int ct, int j) {
                 ring.fetch_ld(a.w2[g] + c * BSD, ct, j);
                 if (c == 0) { spread_at(gx1, row, X1, ct, j, 1); spread_at(gy2, row, Y2, ct, j, 3); }
+                kg.hook(ct, j);
             });
+            const unsigned kb = kg.finish();
             add_bias<BSD>(acc, bias);
             to_regs<BSD>(P, acc);
 #pragma unroll
             for (int ct = 0; ct < BNT; ++ct)
 #pragma unroll
+#ifdef AMID_BS_ABLATE_GELU
+                for (int e = 0; e < 4; ++e) Hc.v[ct][e] = P.v[ct][e] * 0.5f;
+#else
                 for (int e = 0; e < 4; ++e) Hc.v[ct][e] = gelu_f(P.v[ct][e]);
+#endif
             apply_keep(Hc, kb, dc.scale);
         }
-        {   // z += h_c W2_c^T ; pre_c's and h_c's global copies leave under these MFMAs
+        {   // z += h_c W2_c^T ; pre_c's and h_c's global copies leave under these MFMAs (chunks 0 / 1: the decisions of the block's last two sites)
+            if (c == 0) kg.begin(dc, g, SITE_SUB_OUT, e128);
+            if (c == 1) kg.begin(dc, g, SITE_BLOCK, e128);
             const float* buf = ring.next();
-            const float* nxt = c + 1 < BSC ? a.w1[g] + (long long)(c + 1) * BSD * BSD : (NEXT ? nx.w[0][g] : nullptr);
+            const float* nxt = c + 1 < BSC ? a.w1[g] + (long long)(c + 1) * BSD * BSD : nx.w[0][g];
             strip_mma<BSD>(acc2, Hc, buf, [&](int ct, int j) {
-                if (nxt != nullptr) ring.fetch(nxt, ct, j);
+                if (NEXT || c + 1 < BSC) ring.fetch(nxt, ct, j);
                 wide_spread(gpre, offw, c, P, ct, j, 1);
                 wide_spread(gh, offw, c, Hc, ct, j, 3);
+                if (c < 2) kg.hook(ct, j);
             });
+            if (c == 0) kb1 = kg.finish();
+            if (c == 1) kb2 = kg.finish();
         }
     }
     {   // x2 = drop_block(x1 + drop_out(z + b2))
-        const unsigned kb1 = keep_bits(dc, g, SITE_SUB_OUT, e128), kb2 = keep_bits(dc, g, SITE_BLOCK, e128);
         bias.load(a.b2[g]);
         if constexpr (NEXT) { la.load(nx.la[g]); lb.load(nx.lb[g]); }
         add_bias<BSD>(acc2, bias);
@@ -349,10 +407,16 @@ __device__ __forceinline__ void zero_dead_rows(float* __restrict__ dx, const Str
 
 // d x2 (DX2, in registers) -> dz, dpre, dx1, dt, d_o of this block; the ring's current fetch must be chunk 0 of w2T.
 // TAIL: a slab (`tail`) is fetched under the last MFMA loop (a fused successor's first weight).
-__device__ __forceinline__ void bffn_bwd_chain(const BStripFfnBwdArgs& a, const StripGeom& sg, BRing& ring, const StripRow& row, int g,
-                                               StripRegs<BSD>& DX2, float* __restrict__ scratch) {
+// kb_block / kb_out: the keep bits of the block's last two dropout sites (bffn_drop(a) + keep_bits, or drawn by a fused predecessor
+// under its own matrix loops)
+__device__ __forceinline__ BDrop bffn_drop(const BStripFfnBwdArgs& a) {
     BDrop dc = {a.train, a.spec, a.scale, 0ull, 0u, a.layer};
     if (a.train) { dc.seed = a.st->seed; dc.step = (unsigned)a.st->step; }
+    return dc;
+}
+__device__ __forceinline__ void bffn_bwd_chain(const BStripFfnBwdArgs& a, const StripGeom& sg, BRing& ring, const StripRow& row, int g,
+                                               StripRegs<BSD>& DX2, float* __restrict__ scratch, unsigned kb_block, unsigned kb_out) {
+    const BDrop dc = bffn_drop(a);
     const unsigned long long e128 = (unsigned long long)row.local * BSD, e512 = (unsigned long long)row.local * BSF;
     const unsigned wide_bytes = sg.act_bytes * 4u;
     const GBuf gpre(a.pre, wide_bytes), gdpre(a.dpre, wide_bytes), gdz(a.dz, sg.act_bytes), gdx1(a.dx1, sg.act_bytes), gdt(a.dt, sg.act_bytes);
@@ -360,39 +424,53 @@ __device__ __forceinline__ void bffn_bwd_chain(const BStripFfnBwdArgs& a, const 
     StripRegs<BSD> DZ, DP, PRE, X1;
     ColVec<BSD> gam;
     // dr = dx2 * drop_block (kept in DX2: the residual path into x1) ; dz = dr * drop_out
-    apply_keep(DX2, keep_bits(dc, g, SITE_BLOCK, e128), dc.scale);
+    apply_keep(DX2, kb_block, dc.scale);
     DZ = DX2;
-    apply_keep(DZ, keep_bits(dc, g, SITE_SUB_OUT, e128), dc.scale);
+    apply_keep(DZ, kb_out, dc.scale);
+    KeepGen kg;
+    unsigned kb_in = ~0u;
     f32x4 acc[BNT], accy[BNT];
     strip_zero<BSD>(accy);
 #pragma unroll
     for (int c = 0; c < BSC; ++c) {
         {   // dh_c = dz W2_c ; dpre_c = dh_c * drop_ffn * gelu'(pre_c)
-            const unsigned kb = keep_bits(dc, g, SITE_FFN1, e512 + c * BSD);
+            kg.begin(dc, g, SITE_FFN1, e512 + c * BSD);
             const float* buf = ring.next();
             wide_load(PRE, gpre, offw, c);
             strip_zero<BSD>(acc);
             strip_mma<BSD>(acc, DZ, buf, [&](int ct, int j) {
                 ring.fetch_ld(a.w1T[g] + c * BSD, ct, j);
                 if (c == 0) spread_at(gdz, row, DZ, ct, j, 1);
+                kg.hook(ct, j);
             });
+            const unsigned kb = kg.finish();
             to_regs<BSD>(DP, acc);
             apply_keep(DP, kb, dc.scale);
 #pragma unroll
             for (int ct = 0; ct < BNT; ++ct)
 #pragma unroll
+#ifdef AMID_BS_ABLATE_GELU
+                for (int e = 0; e < 4; ++e) DP.v[ct][e] *= PRE.v[ct][e];
+#else
                 for (int e = 0; e < 4; ++e) DP.v[ct][e] *= gelu_df(PRE.v[ct][e]);
+#endif
         }
         {   // dy2 += dpre_c W1_c
             const float* buf = ring.next();
             const float* nxt = c + 1 < BSC ? a.w2T[g] + (long long)(c + 1) * BSD * BSD : a.woT[g];
             if (c + 1 == BSC) { strip_load<BSD>(X1, GBuf(a.x1, sg.act_bytes), row); gam.load(a.la[g]); }
-            strip_mma<BSD>(accy, DP, buf, [&](int ct, int j) { ring.fetch(nxt, ct, j); wide_spread(gdpre, offw, c, DP, ct, j, 1); });
+            if (c == 0) kg.begin(dc, g, SITE_SUB_IN, e128);
+            strip_mma<BSD>(accy, DP, buf, [&](int ct, int j) {
+                ring.fetch(nxt, ct, j);
+                wide_spread(gdpre, offw, c, DP, ct, j, 1);
+                if (c == 0) kg.hook(ct, j);
+            });
+            if (c == 0) kb_in = kg.finish();
         }
     }
     StripRegs<BSD> dgam, dbet;
     {   // dx1 = LNb_out'(dy2 ; x1) + dr ; dt = dx1 * drop_in ; d_o = dt Wo
-        const unsigned kb = keep_bits(dc, g, SITE_SUB_IN, e128);
+        const unsigned kb = kb_in;
         to_regs<BSD>(DZ, accy);
         strip_lnb_bwd(DP, DZ, X1, gam, dgam, dbet);
 #pragma unroll
@@ -417,7 +495,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_ffn_bwd_kernel(const
     const StripRow row = strip_row<BSD>(sg, t);
     StripRegs<BSD> DX2;
     strip_load<BSD>(DX2, GBuf(a.dx2, sg.act_bytes), row);
-    bffn_bwd_chain(a, sg, ring, row, t.g, DX2, ln_scratch<BSD>(smem, 0));
+    const BDrop dc = bffn_drop(a);          // (the first slab is still landing: these two sites' counters cost no matrix time)
+    const unsigned long long e128 = (unsigned long long)row.local * BSD;
+    const unsigned kb_block = keep_bits(dc, t.g, SITE_BLOCK, e128), kb_out = keep_bits(dc, t.g, SITE_SUB_OUT, e128);
+    bffn_bwd_chain(a, sg, ring, row, t.g, DX2, ln_scratch<BSD>(smem, 0), kb_block, kb_out);
     __syncthreads();
     ln_partials_out<BSD>(ln_scratch<BSD>(smem, 0), a.ln_part + (long long)t.slot * 2 * BSD);
 }
@@ -445,15 +526,25 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_qkv_bwd_kernel(const
     strip_load<BSD>(D0, GBuf(a.dq, sg.act_bytes), row);
     f32x4 acc[BNT];
     strip_zero<BSD>(acc);
+    // FFN: the keep bits of the block below's last two dropout sites are drawn under this chain's first two products
+    KeepGen kg;
+    unsigned kb_block = ~0u, kb_out = ~0u;
+    BDrop fdc = {0, 0u, 1.f, 0ull, 0u, 0};
+    if constexpr (FFN) fdc = bffn_drop(f);
+    const unsigned long long e128 = (unsigned long long)row.local * BSD;
     {   // dq Wq          (every operand is requested one slab ahead of its use)
+        if constexpr (FFN) kg.begin(fdc, g, SITE_BLOCK, e128);
         const float* buf = ring.next();
         strip_load<BSD>(D1, GBuf(a.dk, sg.act_bytes), row);
-        strip_mma<BSD>(acc, D0, buf, [&](int ct, int j) { ring.fetch(a.wT[1][g], ct, j); });
+        strip_mma<BSD>(acc, D0, buf, [&](int ct, int j) { ring.fetch(a.wT[1][g], ct, j); if constexpr (FFN) kg.hook(ct, j); });
+        if constexpr (FFN) kb_block = kg.finish();
     }
     {   // + dk Wk
+        if constexpr (FFN) kg.begin(fdc, g, SITE_SUB_OUT, e128);
         const float* buf = ring.next();
         strip_load<BSD>(D0, GBuf(a.dv, sg.act_bytes), row);
-        strip_mma<BSD>(acc, D1, buf, [&](int ct, int j) { ring.fetch(a.wT[2][g], ct, j); });
+        strip_mma<BSD>(acc, D1, buf, [&](int ct, int j) { ring.fetch(a.wT[2][g], ct, j); if constexpr (FFN) kg.hook(ct, j); });
+        if constexpr (FFN) kb_out = kg.finish();
     }
     StripRegs<BSD> dgam, dbet;
     {   // + dv Wv ; dx = LNb_in'(. ; x) + dx1
@@ -469,7 +560,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_qkv_bwd_kernel(const
     }
     ln_partials_wave<BSD>(ln_scratch<BSD>(smem, 0), dgam, dbet);
     if constexpr (FFN) {
-        bffn_bwd_chain(f, sg, ring, row, g, DX, ln_scratch<BSD>(smem, 1));
+        bffn_bwd_chain(f, sg, ring, row, g, DX, ln_scratch<BSD>(smem, 1), kb_block, kb_out);
     } else {
         strip_store<BSD>(GBuf(a.dx, sg.act_bytes), row, DX);
     }
@@ -534,6 +625,7 @@ extern "C" int amid_bert_strip_oproj_ffn_fwd_f32(const float* o, const float* x,
     a.st = (const StepState*)step_state; a.layer = layer;
     a.train = (train && p_drop > 0.f) ? 1 : 0;
     a.spec = drop_spec(p_drop);
+    if (a.train && spec_bits(a.spec) != 16) return AMID_ERR_UNSUPPORTED;      // KeepGen: the 16-bit decisions of p = 0.1 (the reference's rate, model_seq.py:267)
     a.scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
     for (int g = 0; g < 2; ++g) {
         a.wo[g] = wo[g]; a.bo[g] = bo[g]; a.la[g] = la[g]; a.lb[g] = lb[g];
@@ -555,6 +647,7 @@ static int fill_bffn_bwd(BStripFfnBwdArgs& a, const float* dx2, const float* pre
     a.st = (const StepState*)step_state; a.layer = layer;
     a.train = (train && p_drop > 0.f) ? 1 : 0;
     a.spec = drop_spec(p_drop);
+    if (a.train && spec_bits(a.spec) != 16) return AMID_ERR_UNSUPPORTED;
     a.scale = a.train ? 1.0f / (1.0f - p_drop) : 1.0f;
     for (int g = 0; g < 2; ++g) { a.la[g] = la[g]; a.w2T[g] = w2T[g]; a.w1T[g] = w1T[g]; a.woT[g] = woT[g]; }
     return AMID_OK;

@@ -18,12 +18,16 @@ using RngState = StepState;
 enum Site { SITE_EMB = 0, SITE_ATTN = 1, SITE_FFN1 = 2, SITE_FFN2 = 3, SITE_SUB_IN = 4, SITE_SUB_OUT = 5, SITE_BLOCK = 6 };
 __host__ __device__ __forceinline__ unsigned site_id(int domain, int layer, int kind) { return (unsigned)((domain * 2 + layer) * 8 + kind); }
 
+// (each round's two 32 x 32 -> 64-bit products written as 64-bit multiplies: hipcc then selects ONE v_mad_u64_u32 each -- high and low
+// word together -- instead of the v_mul_hi_u32 + v_mul_lo_u32 pair it emits for __umulhi() and a separate product; integer multiplies
+// issue at a quarter of the plain rate and are most of a call's cost.  Written as inline asm with the carry-out in vcc the same
+// instruction faulted inside the strip kernels' matrix loops -- left to the compiler.)
+__device__ __forceinline__ unsigned long long mul_wide(unsigned a, unsigned b) { return (unsigned long long)a * b; }
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, unsigned k0, unsigned k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        const unsigned long long p0 = mul_wide(0xD2511F53u, c.x), p1 = mul_wide(0xCD9E8D57u, c.z);
+        c = make_uint4((unsigned)(p1 >> 32) ^ c.y ^ k0, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k1, (unsigned)p0);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }

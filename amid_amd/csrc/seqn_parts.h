@@ -41,7 +41,7 @@ template <int D, int NW> struct WDmaN {
         const unsigned lds = __builtin_amdgcn_readfirstlane(
             (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(buf + (k0 * NW + w) * 256));
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
     }
 };
@@ -89,7 +89,7 @@ template <int D, int NW> struct SeqRing16 {
         const unsigned lds = __builtin_amdgcn_readfirstlane(
             (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(dst + (k0 * NW + w) * 256));
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
     }
     __device__ __forceinline__ void first(const unsigned short* __restrict__ W0) {
