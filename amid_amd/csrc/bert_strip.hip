@@ -272,8 +272,50 @@ __device__ __forceinline__ void bqkv_fwd_chain(const BStripQkvArgs& a, const Str
     }
 }
 
-__global__ __launch_bounds__(STRIP_THREADS) void bert_strip_qkv_fwd_kernel(const BStripQkvArgs a, const StripGeom sg) {
+// Riders of the step's FIRST strip launch (workgroups behind the tiles'; the live tiles of a train step leave a fifth of the CUs free):
+// the key mask of both encoders (model_seq.py:288: seq_d2 > 0) for the attention launch that follows, and the transposed weights the
+// backward's data gradients multiply with -- two launches of their own until now (amid_key_keep_u8, amid_transpose_rect_f32).
+constexpr int BPRO_MAX = 24;
+struct BPrologue {
+    const long long* seq; unsigned char* keep; int n_keys;       // keep[i] = seq[i] > 0; seq == nullptr: none
+    const float* src[BPRO_MAX]; float* dst[BPRO_MAX]; int rows[BPRO_MAX], cols[BPRO_MAX]; int n;      // dst[c][r] = src[r][c]; rows, cols multiples of 64
+    int blocks;
+};
+__device__ __forceinline__ void bert_prologue_block(const BPrologue& p, int blk, float* __restrict__ lds) {
+    if (p.seq != nullptr)
+        for (int i = blk * STRIP_THREADS + threadIdx.x; i < p.n_keys; i += p.blocks * STRIP_THREADS) p.keep[i] = p.seq[i] > 0 ? 1 : 0;
+    float (*tile)[65] = (float (*)[65])lds;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    int unit0 = 0;                                               // 64 x 64 units of all matrices, dealt round-robin over the rider blocks
+    for (int m = 0; m < p.n; ++m) {
+        const int R = p.rows[m], C = p.cols[m];
+        const int tilesx = C / 64, tiles = tilesx * (R / 64);
+        const int first = (blk - unit0 % p.blocks + p.blocks) % p.blocks;
+        for (int tt = first; tt < tiles; tt += p.blocks) {
+            const int bx = (tt % tilesx) * 64, by = (tt / tilesx) * 64;
+            __syncthreads();
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                          // sixteen loads in flight per thread
+                const float* sp = p.src[m] + (long long)(by + ty + 8 * k) * C + bx + tx;
+                v[2 * k] = sp[0]; v[2 * k + 1] = sp[32];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { tile[ty + 8 * k][tx] = v[2 * k]; tile[ty + 8 * k][tx + 32] = v[2 * k + 1]; }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float* dp = p.dst[m] + (long long)(bx + ty + 8 * k) * R + by + tx;
+                dp[0] = tile[tx][ty + 8 * k]; dp[32] = tile[tx + 32][ty + 8 * k];
+            }
+        }
+        unit0 += tiles;
+    }
+}
+
+__global__ __launch_bounds__(STRIP_THREADS) void bert_strip_qkv_fwd_kernel(const BStripQkvArgs a, const StripGeom sg, const BPrologue pro) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x >= 2 * sg.tpg) { bert_prologue_block(pro, blockIdx.x - 2 * sg.tpg, smem); return; }
     BRing ring(smem);
     ring.first(a.w[0][strip_domain(blockIdx.x)]);
     const StripTile t = strip_tile(sg, blockIdx.x);
@@ -596,16 +638,46 @@ static void fill_bqkv(BStripQkvArgs& a, const float* x, const float* const* la, 
     }
 }
 
-// w3 / b3: host arrays of six device pointers ordered [q, k, v][domain] (as amid_bert_qkv_fwd_f32)
-extern "C" int amid_bert_strip_qkv_fwd_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3,
-                                           const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k, float* v,
-                                           void* stream) {
+static int bqkv_fwd(const float* x, const float* const* la, const float* const* lb, const float* const* w3, const float* const* b3, int B,
+                    int T, const int* live, float* y, float* q, float* k, float* v, const BPrologue& pro, void* stream) {
     AMID_CHECK_ARG(x && la && lb && w3 && b3 && y && q && k && v);
     BStripQkvArgs a;
     fill_bqkv(a, x, la, lb, w3, b3, y, q, k, v);
     StripGeom sg;
     if (int e = bert_strip_geom(B, T, live, &sg)) return e;
-    return launch_strip<bert_strip_qkv_fwd_kernel, BSD>(sg, stream, a);
+    static unsigned long long attr_done = 0;
+    if (int rc = lds_attr_once((const void*)bert_strip_qkv_fwd_kernel, strip_lds_bytes<BSD>(), attr_done)) return rc;
+    bert_strip_qkv_fwd_kernel<<<2 * sg.tpg + pro.blocks, STRIP_THREADS, strip_lds_bytes<BSD>(), (hipStream_t)stream>>>(a, sg, pro);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? AMID_OK : (int)e;
+}
+
+// w3 / b3: host arrays of six device pointers ordered [q, k, v][domain] (as amid_bert_qkv_fwd_f32)
+extern "C" int amid_bert_strip_qkv_fwd_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3,
+                                           const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k, float* v,
+                                           void* stream) {
+    BPrologue pro = {};
+    return bqkv_fwd(x, la, lb, w3, b3, B, T, live, y, q, k, v, pro, stream);
+}
+
+// ... with the step's prologue riding as extra workgroups: key_keep[i] = seq_d2[i] > 0 for i < n_keys (seq_d2 == NULL: none), and
+// tr_dst[m][c][r] = tr_src[m][r][c] for n_tr <= 24 matrices of tr_rows[m] x tr_cols[m] floats (multiples of 64) -- what
+// amid_key_keep_u8 and amid_transpose_rect_f32 do in launches of their own
+extern "C" int amid_bert_strip_qkv_fwd_pro_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3,
+                                               const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k,
+                                               float* v, const long long* seq_d2, int n_keys, unsigned char* key_keep,
+                                               const float* const* tr_src, float* const* tr_dst, const int* tr_rows, const int* tr_cols,
+                                               int n_tr, void* stream) {
+    AMID_CHECK_ARG(n_tr >= 0 && n_tr <= BPRO_MAX && (n_tr == 0 || (tr_src && tr_dst && tr_rows && tr_cols)));
+    AMID_CHECK_ARG(seq_d2 == nullptr || (key_keep != nullptr && n_keys > 0));
+    BPrologue pro = {};
+    pro.seq = seq_d2; pro.keep = key_keep; pro.n_keys = n_keys; pro.n = n_tr;
+    for (int i = 0; i < n_tr; ++i) {
+        AMID_CHECK_ARG(tr_src[i] && tr_dst[i] && tr_rows[i] > 0 && tr_cols[i] > 0 && tr_rows[i] % 64 == 0 && tr_cols[i] % 64 == 0);
+        pro.src[i] = tr_src[i]; pro.dst[i] = tr_dst[i]; pro.rows[i] = tr_rows[i]; pro.cols[i] = tr_cols[i];
+    }
+    pro.blocks = (seq_d2 != nullptr || n_tr > 0) ? 96 : 0;
+    return bqkv_fwd(x, la, lb, w3, b3, B, T, live, y, q, k, v, pro, stream);
 }
 
 // out-projection + feed-forward of a block; nla != NULL: the next block's LayerNorm + q / k / v on x2 in the same launch (x2 is

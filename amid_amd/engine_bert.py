@@ -184,7 +184,8 @@ class Bert4recEngine(SasrecEngine):
                    self.inc_threshold, self.comp_cross, B, shp.T, D, pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(), pl.inc_Z.data_ptr(),
                    pl.inc_sw.data_ptr(), pl.x[0].data_ptr(), s)
         else:
-            L.call("amid_key_keep_u8", pl.in_seq_d2.data_ptr(), B * T, pl.key_keep.data_ptr(), s)
+            if not pl.strip:      # (strip path: the key mask rides in the first strip launch, _enqueue_blocks_strip)
+                L.call("amid_key_keep_u8", pl.in_seq_d2.data_ptr(), B * T, pl.key_keep.data_ptr(), s)
             if live_fwd and getattr(pl, "compact", False):      # K1 also writes the step's compact index list: the deferred sort starts behind it
                 L.call("amid_embed_fwd_live_compact_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI,
                        pl.xg.data_ptr(), None, st, 0, 0.0, lf, pl.idx_c.data_ptr(), pl.row_c.data_ptr(), s)
@@ -235,6 +236,24 @@ class Bert4recEngine(SasrecEngine):
             self._ptr_cache[key] = c
         return c
 
+    def _transpose_lists(self):
+        """(src pointers, dst pointers, rows, cols) of the 24 weight transposes of a step (cached host arrays)."""
+        c = self._ptr_cache.get("bert_tr")
+        if c is None:
+            fp, D, F = self.dense, self.D, BERT_FF
+            src, dst, rows, cols = [], [], [], []
+            for l in (0, 1):
+                for g in (0, 1):
+                    pre = f"transform{g + 1}.{l}"
+                    for j in range(3):
+                        src.append(fp.ptr(f"{pre}.attention.linear_layers.{j}.weight")); dst.append(self.wT_sq[l, g, j].data_ptr()); rows.append(D); cols.append(D)
+                    src.append(fp.ptr(f"{pre}.attention.output_linear.weight")); dst.append(self.wT_sq[l, g, 3].data_ptr()); rows.append(D); cols.append(D)
+                    src.append(fp.ptr(f"{pre}.feed_forward.w_1.weight")); dst.append(self.w1T[l, g].data_ptr()); rows.append(F); cols.append(D)
+                    src.append(fp.ptr(f"{pre}.feed_forward.w_2.weight")); dst.append(self.w2T[l, g].data_ptr()); rows.append(D); cols.append(F)
+            c = (ptr_array(src), ptr_array(dst), (ctypes.c_int * len(rows))(*rows), (ctypes.c_int * len(cols))(*cols))
+            self._ptr_cache["bert_tr"] = c
+        return c
+
     def _enqueue_blocks_strip(self, pl: BertPlan, lf, st, tr) -> None:
         """Both blocks on the strip kernels (csrc/bert_strip.hip): q / k / v of block 0, then per block the attention core and ONE launch
         for the out-projection, the feed-forward and -- block 0 -- the next block's LayerNorm + q / k / v.  lf: the live list (a train
@@ -243,8 +262,14 @@ class Bert4recEngine(SasrecEngine):
         B, T = shp.B, shp.Tenc
         live_attn = lf is not None
         p0, p1 = self._block_ptrs(0), self._block_ptrs(1)
-        L.call("amid_bert_strip_qkv_fwd_f32", pl.x[0].data_ptr(), p0["la1"], p0["lb1"], p0["w3"], p0["b3"], B, T, lf, pl.y[0].data_ptr(),
-               pl.q[0].data_ptr(), pl.k[0].data_ptr(), pl.v[0].data_ptr(), s)
+        # the step's prologue rides in this launch: the key mask (not with a comp module: its tiled mask has a launch of its own) and,
+        # when a backward will follow, the transposed weights
+        trl = self._transpose_lists() if pl.need_grad else None
+        pl.transposed_in_forward = trl is not None
+        n_tr = len(trl[2]) if trl else 0
+        L.call("amid_bert_strip_qkv_fwd_pro_f32", pl.x[0].data_ptr(), p0["la1"], p0["lb1"], p0["w3"], p0["b3"], B, T, lf, pl.y[0].data_ptr(),
+               pl.q[0].data_ptr(), pl.k[0].data_ptr(), pl.v[0].data_ptr(), None if self.comp else pl.in_seq_d2.data_ptr(), B * T,
+               pl.key_keep.data_ptr(), trl[0] if trl else None, trl[1] if trl else None, trl[2] if trl else None, trl[3] if trl else None, n_tr, s)
         for l, p in ((0, p0), (1, p1)):
             if live_attn:
                 L.call("amid_attn_bert_fwd_live_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.key_keep.data_ptr(), B, T, D,
@@ -284,18 +309,11 @@ class Bert4recEngine(SasrecEngine):
         st = self.step_state.data_ptr()
         tr = 1 if train else 0
         fp = self.dense
-        # transposed weights (rectangular ones included)
-        src, dst, rows, cols = [], [], [], []
-        for l in (0, 1):
-            for g in (0, 1):
-                pre = f"transform{g + 1}.{l}"
-                for j in range(3):
-                    src.append(fp.ptr(f"{pre}.attention.linear_layers.{j}.weight")); dst.append(self.wT_sq[l, g, j].data_ptr()); rows.append(D); cols.append(D)
-                src.append(fp.ptr(f"{pre}.attention.output_linear.weight")); dst.append(self.wT_sq[l, g, 3].data_ptr()); rows.append(D); cols.append(D)
-                src.append(fp.ptr(f"{pre}.feed_forward.w_1.weight")); dst.append(self.w1T[l, g].data_ptr()); rows.append(F); cols.append(D)
-                src.append(fp.ptr(f"{pre}.feed_forward.w_2.weight")); dst.append(self.w2T[l, g].data_ptr()); rows.append(D); cols.append(F)
-        L.call("amid_transpose_rect_f32", ptr_array(src), ptr_array(dst), (ctypes.c_int * len(rows))(*rows), (ctypes.c_int * len(cols))(*cols),
-               len(src), s)
+        # transposed weights (rectangular ones included) -- unless this step's forward already made them (strip path: riders of its first launch)
+        if not getattr(pl, "transposed_in_forward", False):
+            tsrc, tdst, trows, tcols = self._transpose_lists()
+            L.call("amid_transpose_rect_f32", tsrc, tdst, trows, tcols, len(trows), s)
+        pl.transposed_in_forward = False
         items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
         ditems = pl.dxg.data_ptr() + 4 * 2 * shp.Mi * D
         if self.dr and getattr(self, "_fuse_scorers", False):

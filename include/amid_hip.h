@@ -498,6 +498,14 @@ int amid_bert_strip_supported(int B, int T, int D);
 int amid_bert_strip_qkv_fwd_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3,
                                 const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k, float* v,
                                 void* stream);
+/* the same launch with the step's prologue riding as extra workgroups: key_keep[i] = seq_d2[i] > 0, i < n_keys (the ONE key mask of
+ * both encoders, model_seq.py:288; seq_d2 == NULL: none) and tr_dst[m][c][r] = tr_src[m][r][c] for n_tr <= 24 matrices of
+ * tr_rows[m] x tr_cols[m] floats (multiples of 64): what amid_key_keep_u8 and amid_transpose_rect_f32 do in launches of their own */
+int amid_bert_strip_qkv_fwd_pro_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3,
+                                    const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k,
+                                    float* v, const long long* seq_d2, int n_keys, unsigned char* key_keep,
+                                    const float* const* tr_src, float* const* tr_dst, const int* tr_rows, const int* tr_cols,
+                                    int n_tr, void* stream);
 /* nla != NULL: block l + 1's amid_bert_strip_qkv_fwd_f32 (n* arguments) continues on the block output x2 in registers */
 int amid_bert_strip_oproj_ffn_fwd_f32(const float* o, const float* x, const float* const* wo, const float* const* bo,
                                       const float* const* la, const float* const* lb, const float* const* w1,
