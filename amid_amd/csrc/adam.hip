@@ -10,195 +10,9 @@
 #include "common.h"
 #include "rng.h"
 #include "sort_phases.h"
+#include "adam_replay.h"
 
 namespace amid {
-
-struct AdamCoef {              // per-step scalars, as torch computes them (double -> float at the op)
-    float w1;                  // 1 - beta1                     (lerp weight)
-    float beta2, w2;           // beta2, 1 - beta2
-    float neg_step_size;       // -(lr / (1 - beta1^t))
-    float bc2_sqrt;            // sqrt(1 - beta2^t)
-    float inv_bc2_sqrt;        // 1 / bc2_sqrt (replay fast path)
-    float eps;
-};
-
-// beta^s for an integer step count by repeated squaring: <= 2 log2(s) double multiplies (relative error < 1e-14, invisible after
-// the coefficients are rounded to float) instead of libm's pow(double, double), several hundred fp64 instructions per call --
-// every workgroup of the catch-up / row kernels fills a 256-entry coefficient table with two of these per entry, and that fill,
-// not the row traffic, was most of those kernels' time.
-__device__ __forceinline__ double pow_step(double b, long long s) {
-    double r = 1.0;
-    while (s > 0) {
-        if (s & 1) r *= b;
-        b *= b;
-        s >>= 1;
-    }
-    return r;
-}
-
-__device__ __forceinline__ AdamCoef adam_coef(const StepState& st, double b1pow, double b2pow) {
-    AdamCoef c;
-    c.w1 = (float)(1.0 - st.beta1);
-    c.beta2 = (float)st.beta2;
-    c.w2 = (float)(1.0 - st.beta2);
-    c.neg_step_size = (float)(-(st.lr / (1.0 - b1pow)));
-    c.bc2_sqrt = (float)sqrt(1.0 - b2pow);
-    c.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2pow));
-    c.eps = (float)st.eps;
-    return c;
-}
-
-// The two coefficients the zero-gradient replay reads, for a step OLDER than the coefficient table (a row idle for more than COEF_TAB
-// steps), from the running powers: the bias corrections in double, rounded to float, then the hardware reciprocal / reciprocal square
-// root (<= 1 ulp each, as the replay's own sqrt / rcp) instead of adam_coef's double division, square root and second division --
-// those ~150 fp64 instructions per replayed step and lane were most of a long gap's cost (cfg 4 in steady state: gaps of 480 steps).
-__device__ __forceinline__ AdamCoef adam_coef_idle(const StepState& st, double b1pow, double b2pow) {
-    AdamCoef c;
-    c.w1 = (float)(1.0 - st.beta1);
-    c.beta2 = (float)st.beta2;
-    c.w2 = 0.f;
-    c.neg_step_size = -(float)st.lr * __builtin_amdgcn_rcpf((float)(1.0 - b1pow));
-    c.inv_bc2_sqrt = __builtin_amdgcn_rsqf((float)(1.0 - b2pow));
-    c.bc2_sqrt = 0.f;              // (not read by the idle step)
-    c.eps = (float)st.eps;
-    return c;
-}
-
-__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, const AdamCoef& c) {
-    m = __fmaf_rn(c.w1, __fsub_rn(g, m), m);                                   // exp_avg.lerp_(grad, 1 - beta1)
-    v = __fadd_rn(__fmul_rn(v, c.beta2), __fmul_rn(__fmul_rn(c.w2, g), g));    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), c.bc2_sqrt), c.eps); // (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps)
-    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(c.neg_step_size, m), denom));          // param.addcdiv_(exp_avg, denom, value=-step_size)
-}
-
-// Zero-gradient step used by the lazy replay: same recurrences for m and v (exact: one fma / one multiply), the
-// parameter increment through the hardware sqrt / reciprocal (<= 1 ulp each) instead of the IEEE divide sequences --
-// a row idle for g steps replays g of these, and the precise divides made the catch-up kernel throughput-bound
-// (31 us per step at a 60-step gap).  The real-gradient step of every touched row stays on the exact path.
-__device__ __forceinline__ void adam_elem_idle(float& p, float& m, float& v, const AdamCoef& c) {
-    m = __fmaf_rn(c.w1, -m, m);
-    v = __fmul_rn(v, c.beta2);
-    const float denom = __fmaf_rn(__builtin_amdgcn_sqrtf(v), c.inv_bc2_sqrt, c.eps);
-    p = __fmaf_rn(__fmul_rn(c.neg_step_size, m), __builtin_amdgcn_rcpf(denom), p);
-}
-__device__ __forceinline__ void adam_quad_idle(float4& p, float4& m, float4& v, const AdamCoef& c) {
-    adam_elem_idle(p.x, m.x, v.x, c);
-    adam_elem_idle(p.y, m.y, v.y, c);
-    adam_elem_idle(p.z, m.z, v.z, c);
-    adam_elem_idle(p.w, m.w, v.w, c);
-}
-__device__ __forceinline__ void adam_quad(float4& p, float4& m, float4& v, float4 g, const AdamCoef& c) {
-    adam_elem(p.x, m.x, v.x, g.x, c);
-    adam_elem(p.y, m.y, v.y, g.y, c);
-    adam_elem(p.z, m.z, v.z, g.z, c);
-    adam_elem(p.w, m.w, v.w, g.w, c);
-}
-
-// Per-step coefficients of the last COEF_TAB steps (t - COEF_TAB + 1 .. t), computed once per block:
-// a row that was idle for g steps replays g zero-gradient steps, and evaluating pow / sqrt / divide in double
-// for every replayed step in every lane dominated the catch-up kernel (31 us -> a few us at a 60-step gap).
-constexpr int COEF_TAB = 256;
-
-__device__ __forceinline__ void fill_coef_table(AdamCoef* tab, const StepState& st) {
-    for (int i = threadIdx.x; i < COEF_TAB; i += blockDim.x) {
-        const long long s = st.step - (COEF_TAB - 1) + i;
-        if (s >= 1) tab[i] = adam_coef(st, pow_step(st.beta1, s), pow_step(st.beta2, s));
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ AdamCoef coef_at(const AdamCoef* tab, const StepState& st, long long s) {
-    const long long i = s - (st.step - (COEF_TAB - 1));
-    if (i >= 0) return tab[i];
-    return adam_coef(st, pow_step(st.beta1, s), pow_step(st.beta2, s));     // gaps longer than the table: slow path
-}
-
-// replay zero-gradient steps s = from .. to (inclusive) on one float4 of a row.  Steps older than the table (a row idle for
-// more than COEF_TAB steps: rare items, e.g. an item that only ever shows up as a sampled negative) take their bias corrections
-// from running powers beta^s = beta^(s-1) * beta in double -- one pow() at the start of the gap instead of two per step, which
-// made a single long-idle row cost tens of microseconds; the product chain differs from pow() by ~gap * 1e-16, far below the
-// float the coefficient is rounded to.
-//
-// The parameter's part of a step stops mattering long before the gap ends: the increment shrinks by ~beta1 per step (|m| does, the
-// denominator and the bias corrections barely move), so after ~120 steps at beta1 = 0.9 it is below half an ulp of the parameter and
-// `p + increment` returns p -- from then on for every later step too (the increments decrease monotonically: see DESIGN.md).  A lane
-// whose four parameters did not change in a step therefore skips the parameter arithmetic (square root, reciprocal: the quarter-rate
-// instructions that bound this kernel) for the rest of the gap and only carries m and v on, two full-rate instructions per element
-// and step -- the SAME bits as the full replay, at a fraction of its cost for the long gaps of rarely seen items.
-// K consecutive zero-gradient steps with coefficients c[0..K-1] on N elements; returns whether the LAST of them moved a parameter.  The
-// moments first (two short chains), then the K denominators of an element -- independent square roots / reciprocals the hardware
-// overlaps --, then the parameter's K additions in step order: the same operations on the same values as K calls of adam_elem_idle.
-template <int N, int K>
-__device__ __forceinline__ bool idle_steps(float (&p)[N], float (&m)[N], float (&v)[N], const AdamCoef (&c)[K]) {
-    bool moved = false;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        float mk[K], rk[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            m[i] = __fmaf_rn(c[k].w1, -m[i], m[i]);
-            v[i] = __fmul_rn(v[i], c[k].beta2);
-            mk[k] = m[i];
-            rk[k] = __builtin_amdgcn_rcpf(__fmaf_rn(__builtin_amdgcn_sqrtf(v[i]), c[k].inv_bc2_sqrt, c[k].eps));
-        }
-        float before = p[i];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            before = p[i];
-            p[i] = __fmaf_rn(__fmul_rn(c[k].neg_step_size, mk[k]), rk[k], p[i]);
-        }
-        moved |= p[i] != before;
-    }
-    return moved;
-}
-
-template <int N>
-__device__ __forceinline__ void replay_elems(float (&p)[N], float (&m)[N], float (&v)[N], long long from, long long to, const StepState& st,
-                                             const AdamCoef* tab) {
-    constexpr int K = 4;                               // steps per chunk (the "did it move" test looks at a chunk's last step)
-    long long s = from;
-    const long long tab_first = st.step - (COEF_TAB - 1);
-    bool live = true;                                  // this lane's parameters still move
-    if (s < tab_first) {
-        double b1p = pow_step(st.beta1, s), b2p = pow_step(st.beta2, s);
-        const long long stop = (to + 1 < tab_first) ? to + 1 : tab_first;
-        for (; s + K <= stop && live; s += K) {
-            AdamCoef c[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) { c[k] = adam_coef_idle(st, b1p, b2p); b1p *= st.beta1; b2p *= st.beta2; }
-            live = idle_steps<N, K>(p, m, v, c);
-        }
-        for (; s < stop && live; ++s) {
-            const AdamCoef c[1] = {adam_coef_idle(st, b1p, b2p)};
-            live = idle_steps<N, 1>(p, m, v, c);
-            b1p *= st.beta1;
-            b2p *= st.beta2;
-        }
-    }
-    if (s >= tab_first) {
-        for (; s + K - 1 <= to && live; s += K) {
-            AdamCoef c[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) c[k] = tab[s + k - tab_first];
-            live = idle_steps<N, K>(p, m, v, c);
-        }
-        for (; s <= to && live; ++s) {
-            const AdamCoef c[1] = {tab[s - tab_first]};
-            live = idle_steps<N, 1>(p, m, v, c);
-        }
-    }
-    const float w1 = (float)(1.0 - st.beta1), beta2 = (float)st.beta2;      // (AdamCoef::w1, ::beta2 of every step)
-    for (; s <= to; ++s) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) { m[i] = __fmaf_rn(w1, -m[i], m[i]); v[i] = __fmul_rn(v[i], beta2); }
-    }
-}
-__device__ __forceinline__ void replay_quad(float4& p, float4& m, float4& v, long long from, long long to, const StepState& st,
-                                            const AdamCoef* tab) {
-    float pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
-    replay_elems<4>(pp, mm, vv, from, to, st, tab);
-    p = make_float4(pp[0], pp[1], pp[2], pp[3]); m = make_float4(mm[0], mm[1], mm[2], mm[3]); v = make_float4(vv[0], vv[1], vv[2], vv[3]);
-}
 
 // mode 0: catch-up (steps last+1 .. t-1, g = 0)   mode 1: apply (catch-up if needed, then step t with g)
 template <int MODE>
@@ -206,7 +20,7 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(float* __restrict__
                                                              int* __restrict__ last, const int* __restrict__ uniq_ids,
                                                              const int* __restrict__ n_uniq_p, const float* __restrict__ uniq_grad, int D,
                                                              const StepState* __restrict__ stp, float grad_scale) {
-    __shared__ AdamCoef tab[COEF_TAB];
+    __shared__ IdleCoef tab[COEF_TAB];
     const StepState st = *stp;
     const long long t = st.step;
     const int U = *n_uniq_p;
@@ -215,6 +29,7 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(float* __restrict__
     const int hw0 = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), n_hw = gridDim.x * (blockDim.x >> 5);
     if (blockIdx.x * (blockDim.x >> 5) >= U) return;              // block-uniform: nothing to do for this block
     fill_coef_table(tab, st);
+    const AdamCoef cnow = adam_coef_now(st);
     for (int u = hw0; u < U; u += n_hw) {
         const long long r = uniq_ids[u];
         const long long l = last[r];
@@ -226,7 +41,7 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(float* __restrict__
             if (lag) replay_quad(p, m, v, l + 1, t - 1, st, tab);
             if (MODE == 1) {
                 const float4 g = f4scale(ld4(uniq_grad + (long long)u * D + 4 * c), grad_scale);
-                adam_quad(p, m, v, g, tab[COEF_TAB - 1]);
+                adam_quad(p, m, v, g, cnow);
             }
             st4(table + off, p); st4(m_tab + off, m); st4(v_tab + off, v);
         }
@@ -247,7 +62,7 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_pos_kernel(float* __res
     const int nrb = rider_blocks(rd);
     if ((int)blockIdx.x < nrb) { sort_phase_ct<1024, 1>(rd.plan, blockIdx.x); return; }
     const int bid = blockIdx.x - nrb, nbk = gridDim.x - nrb;
-    __shared__ AdamCoef tab[COEF_TAB];
+    __shared__ IdleCoef tab[COEF_TAB];
     __shared__ int any_lag;
     const StepState st = *stp;
     const long long t = st.step;
@@ -298,7 +113,7 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_pos_kernel(float* __res
 // bring every row with pending zero-gradient steps up to date (before eval / checkpoint / parity dumps)
 __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
                                                               int* __restrict__ last, long long n_rows, int D, const StepState* __restrict__ stp) {
-    __shared__ AdamCoef tab[COEF_TAB];
+    __shared__ IdleCoef tab[COEF_TAB];
     const StepState st = *stp;
     const long long t = st.step;
     const int sub = threadIdx.x & 31;
@@ -324,7 +139,7 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, 
                                                          const float* __restrict__ g, long long n, const StepState* __restrict__ stp,
                                                          float grad_scale) {
     const StepState st = *stp;
-    const AdamCoef c = adam_coef(st, pow_step(st.beta1, st.step), pow_step(st.beta2, st.step));
+    const AdamCoef c = adam_coef_now(st);
     const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const long long stride = (long long)gridDim.x * blockDim.x * 4;
     for (long long i = i0; i < n; i += stride) {
@@ -348,10 +163,10 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(float* __restrict__
                                                              int* __restrict__ last, const int* __restrict__ uniq_ids,
                                                              const int* __restrict__ n_uniq_p, const float* __restrict__ uniq_grad, int D,
                                                              const StepState* __restrict__ stp, float grad_scale) {
-    __shared__ AdamCoef tab[COEF_TAB];
+    __shared__ IdleCoef tab[COEF_TAB];
     const StepState st = *stp;
     if ((int)blockIdx.x < dense_blocks) {
-        const AdamCoef c = adam_coef(st, pow_step(st.beta1, st.step), pow_step(st.beta2, st.step));
+        const AdamCoef c = adam_coef_now(st);
         const long long stride = (long long)dense_blocks * blockDim.x * 4;
         for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
             if (i + 4 <= n) {
@@ -369,6 +184,7 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(float* __restrict__
     const int rb = blockIdx.x - dense_blocks, n_rb = gridDim.x - dense_blocks;
     if (rb * 8 >= U) return;
     fill_coef_table(tab, st);
+    const AdamCoef cnow = adam_coef_now(st);
     const int sub = threadIdx.x & 31;
     const int q = D >> 2;
     for (int u = rb * 8 + (threadIdx.x >> 5); u < U; u += n_rb * 8) {
@@ -379,7 +195,7 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(float* __restrict__
             const long long off = r * D + 4 * c;
             float4 pp = ld4(table + off), mm = ld4(m_tab + off), vv = ld4(v_tab + off);
             if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
-            adam_quad(pp, mm, vv, f4scale(ld4(uniq_grad + (long long)u * D + 4 * c), grad_scale), tab[COEF_TAB - 1]);
+            adam_quad(pp, mm, vv, f4scale(ld4(uniq_grad + (long long)u * D + 4 * c), grad_scale), cnow);
             st4(table + off, pp); st4(m_tab + off, mm); st4(v_tab + off, vv);
         }
         __builtin_amdgcn_wave_barrier();
@@ -407,10 +223,10 @@ __global__ __launch_bounds__(256) void optimizer_gathered_kernel(float* __restri
                                                                  int* __restrict__ last, const float* __restrict__ gathered, int world, int umax,
                                                                  long long chunk_floats, int id_rows, long long dense_off, int D, int sentinel,
                                                                  const StepState* __restrict__ stp, float grad_scale) {
-    __shared__ AdamCoef tab[COEF_TAB];
+    __shared__ IdleCoef tab[COEF_TAB];
     const StepState st = *stp;
     if ((int)blockIdx.x < dense_blocks) {
-        const AdamCoef c = adam_coef(st, pow_step(st.beta1, st.step), pow_step(st.beta2, st.step));
+        const AdamCoef c = adam_coef_now(st);
         const long long stride = (long long)dense_blocks * blockDim.x * 4;
         const float* d0 = gathered + dense_off;
         for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -445,6 +261,7 @@ __global__ __launch_bounds__(256) void optimizer_gathered_kernel(float* __restri
     const int total = world * umax;
     if (rb * 8 >= total) return;
     fill_coef_table(tab, st);
+    const AdamCoef cnow = adam_coef_now(st);
     const int sub = threadIdx.x & 31;
     const int q = D >> 2;
     for (int u = rb * 8 + (threadIdx.x >> 5); u < total; u += n_rb * 8) {
@@ -472,7 +289,7 @@ __global__ __launch_bounds__(256) void optimizer_gathered_kernel(float* __restri
             const long long off = row * D + 4 * c;
             float4 pp = ld4(table + off), mm = ld4(m_tab + off), vv = ld4(v_tab + off);
             if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
-            adam_quad(pp, mm, vv, f4scale(gg, grad_scale), tab[COEF_TAB - 1]);
+            adam_quad(pp, mm, vv, f4scale(gg, grad_scale), cnow);
             st4(table + off, pp); st4(m_tab + off, mm); st4(v_tab + off, vv);
         }
         __builtin_amdgcn_wave_barrier();

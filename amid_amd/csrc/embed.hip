@@ -15,6 +15,7 @@
 #include "common.h"
 #include "rng.h"
 #include "sort_phases.h"
+#include "adam_replay.h"
 
 namespace amid {
 
@@ -167,10 +168,17 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
                                                         int B, int T, int D, int n_item_rows,
                                                         float* __restrict__ xg, unsigned char* __restrict__ tmq,
                                                         const RngState* __restrict__ rng, int train, unsigned thr16, float scale,
-                                                        const int* __restrict__ live, int* __restrict__ idx_c, int* __restrict__ row_c, int chunk) {
+                                                        const int* __restrict__ live, int* __restrict__ idx_c, int* __restrict__ row_c, int chunk,
+                                                        const float* __restrict__ m_tab, const float* __restrict__ v_tab,
+                                                        const int* __restrict__ last, const StepState* __restrict__ adam_st, const SortRider rd) {
+    // rider: the first workgroups run phase 1 of the step's index sort (sort_phases.h) beside the gather (it rode in the catch-up
+    // launch while that launch existed)
+    const int nrb = rider_blocks(rd);
+    if ((int)blockIdx.x < nrb) { sort_phase_ct<1024, 1>(rd.plan, blockIdx.x); return; }
+    const int bid = blockIdx.x - nrb;
     const int sub = threadIdx.x & 31;
-    const int hw = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
-    const int n_hw = gridDim.x * (blockDim.x >> 5);
+    const int hw = bid * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    const int n_hw = (gridDim.x - nrb) * (blockDim.x >> 5);
     const int q = D >> 2;
     const int M = B * T;
     const int n_idx = 2 * M + n_item_rows;
@@ -181,13 +189,41 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
     unsigned long long seed = 0;
     unsigned step = 0;
     if (train) { seed = rng->seed; step = (unsigned)rng->step; }
+    // last != nullptr: the lazy-Adam catch-up folded into the gather.  A row whose stamp lags (0 < last < t - 1) owes zero-gradient Adam
+    // steps last + 1 .. t - 1 (adam.hip): they are replayed HERE, in registers, for the value the forward reads -- nothing is written;
+    // the optimizer launch of this step, which visits exactly the rows that were gathered, replays the same steps again (the same bits:
+    // adam_replay.h) in front of the real step and stamps the row.  No launch of its own, no ordering between workgroups.
+    __shared__ IdleCoef ctab[COEF_TAB];
+    const bool replay = last != nullptr;
+    StepState stv = {};
+    long long t_now = 0;
+    bool any_lag = false;
+    if (replay) {
+        stv = *adam_st;
+        t_now = stv.step;
+        bool mine_lag = false;                          // first sweep: does any position of this block lag at all? (usually not)
+        for (int c0 = hw * chunk; c0 < n_walk; c0 += n_hw * chunk) {
+            const int mine = c0 + sub;
+            if (sub < chunk && mine < n_walk) {
+                int r = mine;
+                if (live != nullptr) {
+                    if (r < M) { const int sq = r / T; r = (sq >= n0 ? M : 0) + live[sq] * T + (r - sq * T); }
+                    else r += M;
+                }
+                const int l = last[idx_all[r]];
+                if (l > 0 && l < t_now - 1) mine_lag = true;
+            }
+        }
+        any_lag = __syncthreads_or(mine_lag ? 1 : 0) != 0;
+        if (any_lag) fill_coef_table(ctab, stv);
+    }
     // A half-wave owns a chunk of `chunk` (4 .. 32) walk positions: lane j < chunk resolves position j's (row, id) -- the dependent
     // chain live -> index -> table row is paid once per chunk, in parallel across the lanes, not once per row --, then the rows are
     // moved RIF at a time with every lane on its float4 column.  Long lists take chunks of 32, short ones small chunks (more waves).
     const int half = threadIdx.x & 32;
     for (int c0 = hw * chunk; c0 < n_walk; c0 += n_hw * chunk) {
         const int mine = c0 + sub;
-        int my_row = 0, my_src = 0;
+        int my_row = 0, my_src = 0, my_last = 0;
         if (sub < chunk && mine < n_walk) {
             int r = mine;
             if (live != nullptr) {
@@ -196,6 +232,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
             }
             my_row = r;
             my_src = idx_all[r];
+            if (any_lag) my_last = last[my_src];
             // the walk over the live sequences is the step's compact index list: the id at every walk position and the row of the
             // full layout its gradient will stand in (what the sort, the segment reduce and the row Adam of the step then run on)
             if (idx_c != nullptr) { idx_c[mine] = my_src; row_c[mine] = r; }
@@ -211,11 +248,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
         const int n_here = min(chunk, n_walk - c0);
         for (int u0 = 0; u0 < n_here; u0 += RIF) {
             long long src[RIF];
-            int row[RIF];
+            int row[RIF], lst[RIF];
 #pragma unroll
             for (int u = 0; u < RIF; ++u) {
                 src[u] = __shfl(my_src, half + ((u0 + u) & 31), 64);
                 row[u] = __shfl(my_row, half + ((u0 + u) & 31), 64);
+                lst[u] = any_lag ? __shfl(my_last, half + ((u0 + u) & 31), 64) : 0;
             }
             unsigned kbits[RIF];                       // the 32-bit word of row u's call that holds this lane's column quad (c = sub)
 #pragma unroll
@@ -237,6 +275,15 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
                     // behind the catch-up's footprint, 59.1 -> 55.2 us (profiles/tools/probe/k1_instep.py)
                     const f32x4 t = __builtin_nontemporal_load((const f32x4*)(table + src[u] * D + 4 * c));
                     v[u] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+                if (any_lag) {
+#pragma unroll
+                    for (int u = 0; u < RIF; ++u) {
+                        if (u0 + u < n_here && lst[u] > 0 && lst[u] < t_now - 1) {      // (uniform over the half-wave: it shares the row)
+                            float4 mq = ld4(m_tab + src[u] * D + 4 * c), vq = ld4(v_tab + src[u] * D + 4 * c);
+                            replay_quad(v[u], mq, vq, (long long)lst[u] + 1, t_now - 1, stv, ctab);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < RIF; ++u) {
@@ -489,7 +536,16 @@ extern "C" int amid_pack_indices_pool_live(const long long* pool, long long pool
 
 static int embed_fwd(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
                      int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop, const int* live,
-                     int* idx_c, int* row_c, void* stream) {
+                     int* idx_c, int* row_c, void* stream, const float* m_tab = nullptr, const float* v_tab = nullptr, const int* last = nullptr,
+                     const void* adam_state = nullptr, const void* sort_plan = nullptr, int sort_phase = 0) {
+    AMID_CHECK_ARG(last == nullptr || (m_tab && v_tab && adam_state));
+    SortRider rd;
+    rd.phase = 0;
+    if (sort_plan != nullptr) {
+        if (sort_phase != 1) return AMID_ERR_UNSUPPORTED;          // this launch carries phase 1
+        rd.plan = *(const SortPlan*)sort_plan;
+        rd.phase = sort_phase;
+    }
     AMID_CHECK_ARG((idx_c == nullptr) == (row_c == nullptr) && (idx_c == nullptr || live != nullptr));
     AMID_CHECK_ARG(table && idx_all && xg && B > 0 && T > 0 && D > 0 && (D % 4) == 0 && n_item_rows >= 0);
     AMID_CHECK_ARG((pos0 == nullptr) == (pos1 == nullptr));
@@ -498,9 +554,9 @@ static int embed_fwd(const float* table, const int* idx_all, const float* pos0, 
     const long long n_walk = (live != nullptr ? 1LL : 2LL) * B * T + n_item_rows;
     const int tr = (train && pos0 != nullptr && p_drop > 0.f) ? 1 : 0;
     const int chunk = embed_chunk(n_walk);
-    embed_fwd_kernel<EMBED_RIF><<<embed_grid(n_walk, chunk), 256, 0, (hipStream_t)stream>>>(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq,
-                                                                                            (const RngState*)rng_state, tr, keep_thr16(p_drop),
-                                                                                            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk);
+    embed_fwd_kernel<EMBED_RIF><<<embed_grid(n_walk, chunk) + rider_blocks_host(rd), 256, 0, (hipStream_t)stream>>>(
+        table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, (const RngState*)rng_state, tr, keep_thr16(p_drop),
+        tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
@@ -526,6 +582,19 @@ extern "C" int amid_embed_fwd_live_compact_f32(const float* table, const int* id
                                                float p_drop, const int* live, int* idx_c, int* row_c, void* stream) {
     AMID_CHECK_ARG(live != nullptr && idx_c != nullptr && row_c != nullptr);
     return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, live, idx_c, row_c, stream);
+}
+
+// K1 with the lazy-Adam catch-up folded in (and, optionally, phase 1 of the step's index sort riding as extra workgroups): every
+// gathered row whose stamp last[id] lags behind step t - 1 (t = adam_state's step) has its pending zero-gradient Adam steps replayed in
+// registers for the value written to xg; table, m, v and last are only READ (amid_optimizer_step_f32 replays the same steps in front
+// of the real step).  live / idx_c / row_c: as the live and compact entry points (NULL: every sequence / no compact list).
+extern "C" int amid_embed_fwd_replay_f32(const float* table, const float* m_tab, const float* v_tab, const int* last, const int* idx_all,
+                                         const float* pos0, const float* pos1, int B, int T, int D, int n_item_rows, float* xg,
+                                         unsigned char* tmq, const void* rng_state, int train, float p_drop, const int* live, int* idx_c,
+                                         int* row_c, const void* adam_state, const void* sort_plan, int sort_phase, void* stream) {
+    AMID_CHECK_ARG(m_tab && v_tab && last && adam_state);
+    return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, live, idx_c, row_c, stream, m_tab,
+                     v_tab, last, adam_state, sort_plan, sort_phase);
 }
 
 extern "C" int amid_live_list_i32(const long long* domain, int B, int* live, void* stream) {

@@ -350,9 +350,61 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         """Entries of the step's index list as the sparse side (sort, segment reduce, row Adam) sees it."""
         return pl.n_compact if getattr(pl, "compact", False) else pl.shape.n_idx
 
+    # The lazy-Adam catch-up of a step can be FOLDED into the gather K1 (amid_embed_fwd_replay_f32): a lagging row's owed zero-gradient steps
+    # are replayed in registers for the value the forward reads, and once more by the optimizer launch (which replays lagging rows anyway)
+    # in front of the real step -- one launch less, the replay done twice.  MEASURED (MI355X, cfg 2: ~2.5 k rows of a step lag by ~60 steps,
+    # an epoch is 60 batches): the catch-up launch is not latency but replay arithmetic (two quarter-rate instructions per element and
+    # step), so doing it twice LOSES -- catch-up 14.4 + K1 8.1 us -> K1 24.5 us, optimizer 7.4 -> 15.6 us, 0.3695 -> 0.3829 ms per step;
+    # cfg 4 0.239 -> 0.268.  Off by default; "auto" folds only where the replay is next to nothing (an epoch of at most FOLD_MAX_GAP
+    # batches, e.g. a handful of batches replayed over and over), "1" always.
+    FOLD_CATCHUP = os.environ.get("AMID_FOLD_CATCHUP", "0")
+    FOLD_MAX_GAP = 8
+    catchup_gap_hint: Optional[int] = None          # batches per epoch when no input pool says so (the CLI's per-batch path)
+
+    def _fold_catchup(self, pl: SasrecPlan) -> bool:
+        if self.inc_bs or getattr(self, "comp", "") or self.FOLD_CATCHUP in ("0", False):
+            return False                             # (InnerComp / BERT4Rec comp gather with amid_gather_rows_f32: no replay there)
+        if self.FOLD_CATCHUP in ("1", True):
+            return True
+        ent = self.input_pool(pl)
+        gap = ent[0].shape[0] if ent is not None else self.catchup_gap_hint
+        return gap is not None and gap <= self.FOLD_MAX_GAP
+
+    def _enqueue_k1(self, pl: SasrecPlan, pos0, pos1, tmq, tr: int, p_drop: float, lf) -> None:
+        """The gather K1 of a forward in the variant the step needs: over every sequence or the live list `lf`, writing the compact index
+        list, with the folded catch-up (+ phase 1 of a riding sort)."""
+        L, s, shp, D = lib(), self.s, pl.shape, self.D
+        B, T, NI = shp.B, shp.Tenc, shp.NI
+        st = self.step_state.data_ptr()
+        compact = lf is not None and getattr(pl, "compact", False)
+        ic, rc = (pl.idx_c.data_ptr(), pl.row_c.data_ptr()) if compact else (None, None)
+        if getattr(pl, "fold_catchup", False):
+            pl.fold_catchup = False
+            ride = getattr(pl, "riding", False)
+            L.call("amid_embed_fwd_replay_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
+                   pl.idx_all.data_ptr(), pos0, pos1, B, T, D, B * NI, pl.xg.data_ptr(), tmq, st, tr, p_drop, lf, ic, rc, st,
+                   self._sort_plan(pl) if ride else None, 1 if ride else 0, s)
+        elif compact:
+            L.call("amid_embed_fwd_live_compact_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), pos0, pos1, B, T, D, B * NI, pl.xg.data_ptr(),
+                   tmq, st, tr, p_drop, lf, ic, rc, s)
+        elif lf is not None:
+            L.call("amid_embed_fwd_live_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), pos0, pos1, B, T, D, B * NI, pl.xg.data_ptr(), tmq, st,
+                   tr, p_drop, lf, s)
+        else:
+            L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), pos0, pos1, B, T, D, B * NI, pl.xg.data_ptr(), tmq, st, tr,
+                   p_drop, s)
+        if getattr(self, "_sort_owed", False):      # a deferred side-stream sort starts behind K1 (the compact list is K1's by-product; with
+            if compact:                              # the folded catch-up the fork waited so that the main branch is captured first)
+                self.ev_idx.record(self.stream)
+            self.enqueue_sort(pl)
+
     def enqueue_catchup(self, pl: SasrecPlan) -> None:
-        """Replay pending zero-gradient Adam steps of the rows this batch is about to gather (by position: no sort needed)."""
+        """Replay pending zero-gradient Adam steps of the rows this batch is about to gather (by position: no sort needed) -- as a
+        launch of its own, or folded into the gather that follows (_fold_catchup)."""
         self._ensure_opt_state()
+        pl.fold_catchup = self._fold_catchup(pl)
+        if pl.fold_catchup:
+            return
         if getattr(pl, "riding", False):          # phase 1 of the step's sort rides here
             lib().call("amid_lazy_adam_catchup_positions_sort_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
                        self.table_last.data_ptr(), pl.idx_all.data_ptr(), pl.shape.n_idx, self.D, self.step_state.data_ptr(),
@@ -382,21 +434,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                    self.inc_threshold, fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), B, shp.T, D, pl.inc_gate.data_ptr(),
                    pl.inc_S.data_ptr(), pl.inc_Z.data_ptr(), pl.inc_sw.data_ptr(), pl.x[0].data_ptr(), pl.tmq.data_ptr(), st, tr,
                    SASREC_P_DROP, s)
-        elif live_fwd and getattr(pl, "compact", False):
-            # K1 also writes the step's compact index list (ids + gradient rows of the live sequences' positions and the items): the
-            # deferred sort can start behind it
-            L.call("amid_embed_fwd_live_compact_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"),
-                   fp.ptr("sac2.pos_emb.weight"), B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, lf,
-                   pl.idx_c.data_ptr(), pl.row_c.data_ptr(), s)
-            if getattr(self, "_sort_owed", False):
-                self.ev_idx.record(self.stream)
-                self.enqueue_sort(pl)
-        elif live_fwd:
-            L.call("amid_embed_fwd_live_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"),
-                   fp.ptr("sac2.pos_emb.weight"), B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, lf, s)
         else:
-            L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"),
-                   fp.ptr("sac2.pos_emb.weight"), B, T, D, B * NI, pl.xg.data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, s)
+            self._enqueue_k1(pl, fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), pl.tmq.data_ptr(), tr, SASREC_P_DROP, lf)
         def layer_ptrs(l):
             pre = f"sac{{d}}"
             return ((self._pp(f"{pre}.attention_layernorms.{l}.weight"), self._pp(f"{pre}.attention_layernorms.{l}.bias"),
@@ -806,8 +845,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     def _fork_sort(self, pl: SasrecPlan) -> None:
         """Start the side-stream sort behind the catch-up launch, beside the forward (forks behind the forward or beside the weight
         gradients were measured and lost: DESIGN.md section 5)."""
-        if getattr(pl, "compact", False):
-            return                                    # the compact index list is K1's by-product: enqueue_forward forks behind K1
+        if getattr(pl, "compact", False) or getattr(pl, "fold_catchup", False):
+            return                                    # the compact index list is K1's by-product / no catch-up launch: the fork follows K1
         if getattr(self, "_sort_owed", False):
             self.enqueue_sort(pl)
 

@@ -186,18 +186,7 @@ class Bert4recEngine(SasrecEngine):
         else:
             if not pl.strip:      # (strip path: the key mask rides in the first strip launch, _enqueue_blocks_strip)
                 L.call("amid_key_keep_u8", pl.in_seq_d2.data_ptr(), B * T, pl.key_keep.data_ptr(), s)
-            if live_fwd and getattr(pl, "compact", False):      # K1 also writes the step's compact index list: the deferred sort starts behind it
-                L.call("amid_embed_fwd_live_compact_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI,
-                       pl.xg.data_ptr(), None, st, 0, 0.0, lf, pl.idx_c.data_ptr(), pl.row_c.data_ptr(), s)
-                if getattr(self, "_sort_owed", False):
-                    self.ev_idx.record(self.stream)
-                    self.enqueue_sort(pl)
-            elif live_fwd:
-                L.call("amid_embed_fwd_live_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI, pl.xg.data_ptr(),
-                       None, st, 0, 0.0, lf, s)
-            else:
-                L.call("amid_embed_fwd_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, B, T, D, B * NI, pl.xg.data_ptr(), None,
-                       st, 0, 0.0, s)
+            self._enqueue_k1(pl, None, None, None, 0, 0.0, lf)      # plain gather: no positional table, no embedding dropout, no "== 0" mask
         if pl.strip:
             self._enqueue_blocks_strip(pl, lf, st, tr)
         else:

@@ -183,6 +183,8 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_attn_fwd_live_f32": ("mfma", 4.0 * T * T * hd * Bw * H),
         "amid_attn_bwd_live_f32": ("mfma", 10.0 * T * T * hd * Bw * H),
         "amid_embed_fwd_live_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (4 + 2 * D * 4) + Bw * T * (D // 4)),
+        # K1 with the lazy-Adam catch-up folded in: + the stamp of every gathered position (m and v of the few lagging rows: not counted)
+        "amid_embed_fwd_replay_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (8 + 2 * D * 4) + Bw * T * (D // 4)),
         "amid_embed_fwd_live_compact_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (12 + 2 * D * 4) + Bw * T * (D // 4)),
         "amid_sas_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_sas_oproj_fwd_f32": ("mfma", gemm),
@@ -200,6 +202,15 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_sas_qkv_bwd_rows_f32": ("mfma", 1.5 * gemm),
         "amid_sas_qkv_ffn_bwd_rows_f32": ("mfma", 3 * gemm),
         "amid_attn_bwd_rows_f32": ("mfma", 10.0 * T * T * hd * Bw * H),
+        # BERT4Rec on the strip kernels over the live rows (csrc/bert_strip.hip): 128 x 128 products over B T rows
+        "amid_bert_strip_qkv_fwd_pro_f32": ("mfma", 3 * gl), "amid_bert_strip_qkv_fwd_f32": ("mfma", 3 * gl),
+        "amid_bert_strip_oproj_ffn_fwd_f32#0": ("mfma", 12 * gl),      # block 0's out-projection + feed-forward (1 + 4 + 4) and block 1's q / k / v
+        "amid_bert_strip_oproj_ffn_fwd_f32#1": ("mfma", 9 * gl),
+        "amid_bert_strip_ffn_bwd_f32": ("mfma", 9 * gl),
+        "amid_bert_strip_qkv_bwd_f32#0": ("mfma", 12 * gl),            # block 1's q / k / v backward + block 0's feed-forward / out-projection backward
+        "amid_bert_strip_qkv_bwd_f32#1": ("mfma", 3 * gl),
+        "amid_attn_bert_fwd_live_f32": ("mfma", 4.0 * T * T * (D // 4) * Bw * 4),
+        "amid_attn_bert_bwd_live_f32": ("mfma", 10.0 * T * T * (D // 4) * Bw * 4),
         "amid_bert_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_bert_oproj_fwd_f32": ("mfma", gemm),
         "amid_bert_ffn1_fwd_f32": ("mfma", 4 * gemm),       # [M, 128] x [128, 512]
@@ -237,8 +248,12 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_seq_bwd_f32": ("seqn_bwd_kernel", "seq_bwd_kernel"), "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
     "amid_sas_strip_oproj_ffn_fwd_f32#1": "strip_oproj_ffn_fwd_kernelILi128ELb0", "amid_sas_strip_ffn_bwd_f32": "strip_ffn_bwd_kernel",
     "amid_sas_strip_qkv_bwd_f32#0": "strip_qkv_bwd_kernelILi128ELb1", "amid_sas_strip_qkv_bwd_f32#1": "strip_qkv_bwd_kernelILi128ELb0",
-    "amid_attn_fwd_live_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_live_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_live_f32": "embed_fwd_kernel", "amid_embed_fwd_live_compact_f32": "embed_fwd_kernel",
+    "amid_attn_fwd_live_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_live_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_live_f32": "embed_fwd_kernel", "amid_embed_fwd_live_compact_f32": "embed_fwd_kernel", "amid_embed_fwd_replay_f32": "embed_fwd_kernel",
     "amid_embgrad_segreduce_f32": "segreduce_chunks_kernel",
+    "amid_bert_strip_qkv_fwd_pro_f32": "bert_strip_qkv_fwd_kernel", "amid_bert_strip_oproj_ffn_fwd_f32#0": "bert_strip_oproj_ffn_fwd_kernelILb1",
+    "amid_bert_strip_oproj_ffn_fwd_f32#1": "bert_strip_oproj_ffn_fwd_kernelILb0", "amid_bert_strip_ffn_bwd_f32": "bert_strip_ffn_bwd_kernel",
+    "amid_bert_strip_qkv_bwd_f32#0": "bert_strip_qkv_bwd_kernelILb1", "amid_bert_strip_qkv_bwd_f32#1": "bert_strip_qkv_bwd_kernelILb0",
+    "amid_attn_bert_fwd_live_f32": "attn_fwd_bert_kernel", "amid_attn_bert_bwd_live_f32": "attn_bwd_bert_kernel",
 }
 
 
@@ -290,6 +305,7 @@ def gather_stress(device, n_steps=6):
         work["amid_grad_tail_f32"] = ("hbm", work[k3][1] + pl.red_bytes)
     role = {"amid_embed_fwd_live_f32": "K1 gather (live sequences)", "amid_embed_fwd_f32": "K1 gather",
             "amid_embed_fwd_live_compact_f32": "K1 gather (live sequences; writes the compact index list)",
+            "amid_embed_fwd_replay_f32": "K1 gather (live sequences; lazy-Adam catch-up folded in: lagging rows replayed in registers)",
             "amid_lazy_adam_catchup_live_f32": "K4a lazy-Adam catch-up (live sequences)",
             "amid_grad_tail_f32": "K3 segment reduce + dense partial sums", "amid_embgrad_segreduce_f32": "K3 segment reduce",
             "amid_lazy_adam_catchup_positions_f32": "K4a lazy-Adam catch-up", "amid_optimizer_step_f32": "K4b Adam (dense + unique rows)"}
@@ -573,7 +589,8 @@ def main():
             eng.sync()
         durs = L.timer.collect(L)
         L.timer = None
-        for name in ("amid_sas_strip_oproj_ffn_fwd_f32", "amid_sas_strip_qkv_bwd_f32"):      # two different launches per step under one entry
+        for name in ("amid_sas_strip_oproj_ffn_fwd_f32", "amid_sas_strip_qkv_bwd_f32", "amid_bert_strip_oproj_ffn_fwd_f32",
+                     "amid_bert_strip_qkv_bwd_f32"):      # two different launches per step under one entry
             v = durs.pop(name, None)
             if v is not None and len(v) == 2 * n_prof:
                 durs[name + "#0"], durs[name + "#1"] = v[0::2], v[1::2]

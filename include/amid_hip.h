@@ -635,6 +635,16 @@ int amid_embed_fwd_live_f32(const float* table, const int* idx_all, const float*
 int amid_embed_fwd_live_compact_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
                                     int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
                                     const int* live, int* idx_c, int* row_c, void* stream);
+/* K1 with the lazy-Adam catch-up folded in (replaces amid_lazy_adam_catchup_positions_f32 + amid_embed_fwd*_f32 of a train step;
+ * reference: the dense torch.optim.Adam of train_sr.py:480 moves every row every step, so a row idle since step `last` owes the
+ * zero-gradient steps last + 1 .. t - 1 before model_seq.py:418-421 reads it): the owed steps are replayed IN REGISTERS for the value
+ * written to xg; table / m / v / last are only read -- amid_optimizer_step_f32 of the same step replays them again (bit-identically) in
+ * front of the real step.  sort_plan != NULL: phase 1 of the step's index sort rides as extra workgroups.  live, idx_c, row_c: NULL or
+ * as amid_embed_fwd_live_f32 / amid_embed_fwd_live_compact_f32. */
+int amid_embed_fwd_replay_f32(const float* table, const float* m_tab, const float* v_tab, const int* last, const int* idx_all,
+                              const float* pos0, const float* pos1, int B, int T, int D, int n_item_rows, float* xg,
+                              unsigned char* tmq, const void* rng_state, int train, float p_drop, const int* live, int* idx_c,
+                              int* row_c, const void* adam_state, const void* sort_plan, int sort_phase, void* stream);
 /* 1 when the matrix-core attention kernels cover the shape (causal, T <= 64, H <= 8, head dim 16 or 8): the live-list entries below */
 int amid_attn_live_supported(int T, int D, int H, int causal);
 int amid_attn_fwd_live_f32(const float* q, const float* k, const float* v, int B, int T, int D, int H, int causal, int layer,

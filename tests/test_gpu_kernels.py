@@ -580,6 +580,109 @@ def test_lazy_adam_catchup_by_positions_long_list_mixed_gaps(L, n_idx, n_lag):
     assert torch.equal(tab.cpu()[untouched], tab0[untouched])
 
 
+def _lagging_state(seed, n_rows, D, t, n_lag, max_gap):
+    """A table state with n_lag rows that each took ONE real step some 1 .. max_gap steps before t - 1 and owe the steps since."""
+    g = torch.Generator().manual_seed(seed)
+    tab0 = torch.randn(n_rows, D, generator=g)
+    m0 = torch.zeros(n_rows, D)
+    v0 = torch.zeros(n_rows, D)
+    rows = torch.randperm(n_rows - 1, generator=g)[:n_lag]
+    gaps = torch.randint(1, max_gap + 1, (n_lag,), generator=g)
+    gaps[:6] = torch.tensor([1, 63, 64, 255, 256, max_gap])[: min(6, n_lag)]
+    gr = torch.randn(n_lag, D, generator=g) * torch.logspace(-4, 0, n_lag)[:, None]
+    m0[rows], v0[rows] = 0.1 * gr, 0.001 * gr * gr
+    last = torch.zeros(n_rows, dtype=torch.int32)
+    last[rows] = (t - 1 - gaps).int()
+    last[n_rows - 1] = t - 1
+    return tab0, m0, v0, last, rows
+
+
+def test_lazy_adam_split_replay_is_bit_identical_to_one_replay(L):
+    """A zero-gradient step's coefficients depend on the step number alone (csrc/adam_replay.h): rows flushed at step t1 (before an
+    evaluation, a checkpoint) and caught up at t2 land on the SAME BITS as rows caught up at t2 in one go -- gaps inside and beyond the
+    256-step coefficient table, across the 64-step anchors of the running powers (they used to differ)."""
+    D, n_rows, t1, t2 = 128, 3000, 1333, 1700
+    tab0, m0, v0, last0, rows = _lagging_state(5, n_rows, D, t1, 400, 900)
+    pos = dev(torch.cat([rows.int(), torch.full((7,), n_rows - 1, dtype=torch.int32)]))
+    outs = []
+    for split in (False, True):
+        tab, m, v, last = dev(tab0.clone()), dev(m0.clone()), dev(v0.clone()), dev(last0.clone())
+        if split:        # flush everything at t1 (stamps -> t1), then the catch-up of step t2
+            st1 = step_state(L, 0, t1)
+            L.call("amid_lazy_adam_flush_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), n_rows, D, st1.data_ptr(), stream())
+        st2 = step_state(L, 0, t2)
+        L.call("amid_lazy_adam_catchup_positions_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), pos.data_ptr(), pos.numel(), D,
+               st2.data_ptr(), stream())
+        torch.cuda.synchronize()
+        outs.append((tab.cpu()[rows], m.cpu()[rows], v.cpu()[rows], last.cpu()[rows]))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float((outs[0][0] - tab0[rows]).abs().max()) > 0          # the replay did move the rows
+
+
+@pytest.mark.parametrize("live", [False, True])
+def test_gather_with_folded_catchup_equals_catchup_then_gather(L, live):
+    """amid_embed_fwd_replay_f32 (the catch-up folded into K1: owed steps replayed in registers, nothing written) hands the forward the
+    same bits as the catch-up launch followed by the plain gather -- SASRec form (positional table, dropout, "== 0" mask) and plain
+    gather; the optimizer launch then replays the same rows from the untouched state and lands where the two-launch path does."""
+    B, T, D, NI, n_rows, t = 24, 50, 128, 2, 4000, 900
+    tab0, m0, v0, last0, rows = _lagging_state(9, n_rows, D, t, 300, 600)
+    g = torch.Generator().manual_seed(3)
+    idx = torch.full((2 * B * T + B * NI,), n_rows - 1, dtype=torch.int32)
+    where = torch.randperm(idx.numel(), generator=g)[:700]
+    idx[where] = rows[torch.randint(0, rows.numel(), (700,), generator=g)].int()
+    idx = dev(idx)
+    pos0, pos1 = dev(torch.randn(T, D, generator=g)), dev(torch.randn(T, D, generator=g))
+    dom = dev((torch.rand(B, generator=g) < 0.5).long())
+    lv = dev(torch.zeros(B + 1, dtype=torch.int32))
+    L.call("amid_live_list_i32", dom.data_ptr(), B, lv.data_ptr(), stream())
+    lf = lv.data_ptr() if live else None
+    st = step_state(L, 77, t)
+    for pos in ((pos0, pos1), (None, None)):
+        p0, p1 = (pos[0].data_ptr(), pos[1].data_ptr()) if pos[0] is not None else (None, None)
+        res = []
+        for fold in (False, True):
+            tab, m, v, last = dev(tab0.clone()), dev(m0.clone()), dev(v0.clone()), dev(last0.clone())
+            xg = dev(torch.zeros(idx.numel(), D))
+            tmq = dev(torch.zeros(2 * B * T, D // 4, dtype=torch.uint8))
+            tm = tmq.data_ptr() if p0 is not None else None
+            if fold:
+                L.call("amid_embed_fwd_replay_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), idx.data_ptr(), p0, p1, B, T, D,
+                       B * NI, xg.data_ptr(), tm, st.data_ptr(), 1, 0.5, lf, None, None, st.data_ptr(), None, 0, stream())
+                torch.cuda.synchronize()
+                assert torch.equal(tab.cpu(), tab0) and torch.equal(last.cpu(), last0)            # nothing written
+            else:
+                L.call("amid_lazy_adam_catchup_positions_f32", tab.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), idx.data_ptr(),
+                       idx.numel(), D, st.data_ptr(), stream())
+                if live:
+                    L.call("amid_embed_fwd_live_f32", tab.data_ptr(), idx.data_ptr(), p0, p1, B, T, D, B * NI, xg.data_ptr(), tm, st.data_ptr(), 1,
+                           0.5, lf, stream())
+                else:
+                    L.call("amid_embed_fwd_f32", tab.data_ptr(), idx.data_ptr(), p0, p1, B, T, D, B * NI, xg.data_ptr(), tm, st.data_ptr(), 1, 0.5,
+                           stream())
+            # the step's optimizer launch on the gathered rows (a gradient of ones): replays what still lags, then the real step
+            ids = torch.unique(idx.cpu().long()).int()
+            uid, nu = dev(ids), dev(torch.tensor([ids.numel()], dtype=torch.int32))
+            ug = dev(torch.ones(ids.numel(), D))
+            dp, dm, dv, dg = (dev(torch.zeros(8)) for _ in range(4))
+            L.call("amid_optimizer_step_f32", dp.data_ptr(), dm.data_ptr(), dv.data_ptr(), dg.data_ptr(), 8, tab.data_ptr(), m.data_ptr(),
+                   v.data_ptr(), last.data_ptr(), uid.data_ptr(), nu.data_ptr(), ids.numel(), ug.data_ptr(), D, 1.0, st.data_ptr(), stream())
+            torch.cuda.synchronize()
+            res.append((xg.cpu(), tab.cpu(), m.cpu(), v.cpu(), last.cpu()))
+        if live:           # only the live sequences' rows and the items are written
+            n0 = int(lv.cpu()[B])
+            keep = torch.zeros(idx.numel(), dtype=torch.bool)
+            for j, b in enumerate(lv.cpu()[:B].tolist()):
+                gdom = 0 if j < n0 else 1
+                keep[gdom * B * T + b * T: gdom * B * T + (b + 1) * T] = True
+            keep[2 * B * T:] = True
+            assert torch.equal(res[0][0][keep], res[1][0][keep])
+        else:
+            assert torch.equal(res[0][0], res[1][0])
+        for a, b in zip(res[0][1:], res[1][1:]):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("shape", ["sasrec", "bert", "sasrec64"])       # sasrec64: head dim 8, pairs of heads per tile
 @pytest.mark.parametrize("B", [5, 130, 1030])          # 1030 > 1024: the kernels keep the identity slot -> sequence mapping
 def test_attention_bwd_rows_hint_equals_plain_backward(L, shape, B):
