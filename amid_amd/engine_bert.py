@@ -8,6 +8,7 @@ taken from ``seq_d2 > 0``, is applied to BOTH encoders (model_seq.py:288, :295-2
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Tuple
 
 import torch
@@ -80,7 +81,7 @@ class BertPlan(SasrecPlan):
         self.ln2_part = [f(2 * self.tpg_b, 2, D) for _ in range(2)]
         self.dz, self.dt, self.dx1 = f(2 * M, D), f(2 * M, D), f(2 * M, D)
         self.dpre = f(2 * M, F)
-        self.splits = max(1, min(10, M // 128))          # 2 domains x 12 tiles x 10 splits = 240 workgroups
+        self.splits = max(1, min(int(os.environ.get("AMID_BERT_WGRAD_SPLITS", "10")), M // 128))          # 2 domains x 12 tiles x 10 splits = 240 workgroups
         self.w_part = [f(2, N_ENT, self.splits, D * D) for _ in range(2)]
         self.b_part = [f(2, N_ENT, self.splits, D) for _ in range(2)]
 

@@ -202,9 +202,11 @@ def test_n_split_fused_backward_is_bit_identical_to_the_strip_build(Bn, T, split
 def test_timed_path_bf16_products_vs_fp32_oracle(Bn, T):
     """compute="bf16" (BASELINE.json configs[2]: batch 512, bf16 with an fp32 reference tolerance check) THROUGH THE TIMED PATH: the
     fused step over the live sequences with the forward's twelve projection products on the bf16 matrix cores
-    (amid_sas_seq_fwd_bf16w_f32; everything else, the backward's products included, fp32): own logits within 2e-2 relative of the fp32
-    oracle (the bar SURVEY.md section 8(c) sets), the loss within 2e-3, gradients close in the L2 sense -- and not fp32-exact (the mode
-    is on).  The relu decisions are the GPU's (bf16 rounding flips pre-activations near zero)."""
+    (amid_sas_seq_fwd_bf16w_f32), the strip backward's data-gradient products and the weight gradients' products too (bf16 operands,
+    fp32 accumulation; LayerNorm, the attention core, residuals, dropout, the partial sums and Adam stay fp32): own logits within 2e-2
+    relative of the fp32 oracle (the bar SURVEY.md section 8(c) sets), the loss within 2e-3, every gradient tensor within 2 x the relative
+    L2 error measured for its kind (BF16_GRAD_BARS) -- and not fp32-exact (the mode is on).  The relu decisions are the GPU's (bf16
+    rounding flips pre-activations near zero)."""
     D, hid, n_items = 128, 32, 3000
     P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=300 + D + Bn)
     batch = split_batch(Bn, T, n_items, seed=Bn + T, split="mixed")
@@ -223,17 +225,47 @@ def test_timed_path_bf16_products_vs_fp32_oracle(Bn, T):
     e = relmax(own, want)
     log(f"timed bf16 B={Bn} T={T}: own logits relmax {e:.3e}")
     assert 1e-5 < e < 2e-2
-    worst = 0.0
+    # every gradient tensor against ITS OWN bar: 2 x the relative L2 error measured for its kind on MI355X (BF16_GRAD_BARS; the
+    # measured values are logged to gpurun_out/parity.log on every run) -- a dropped bias-gradient term, a wrong fragment layout in one of
+    # the six transposed bf16 weight images or a skipped k-step of the bf16 weight-gradient kernel moves a tensor by O(1), far outside
+    measured = {}
     for name in eng.dense.slots:
-        if name.endswith("in_proj_bias"):
-            continue
-        e2 = rel_l2(eng.dense.view(name, eng.dense.grad), grads[name])
-        worst = max(worst, e2)
-        assert e2 < 1e-1, (name, e2)          # (train mode: the dropout scale 2 doubles what the eval-mode bf16 test of test_gpu_sasrec.py sees)
+        if name.endswith("in_proj_bias"):      # (the key third of it is analytically zero: checked by kind below on the q and v thirds)
+            n3 = grads[name].numel() // 3
+            got3, want3 = eng.dense.view(name, eng.dense.grad).cpu(), grads[name]
+            sel = torch.cat([torch.arange(0, n3), torch.arange(2 * n3, 3 * n3)])
+            e2 = rel_l2(got3[sel], want3[sel])
+        else:
+            e2 = rel_l2(eng.dense.view(name, eng.dense.grad), grads[name])
+        kind = bf16_grad_kind(name)
+        measured[kind] = max(measured.get(kind, 0.0), e2)
+        assert e2 < BF16_GRAD_BARS[kind], (name, kind, e2, BF16_GRAD_BARS[kind])
     tg = dense_table_grad(eng, pl)
     e2 = rel_l2(tg, grads["item_emb_layer.emb_item.weight"])
-    log(f"timed bf16 B={Bn} T={T}: worst dense grad rel L2 {worst:.3e}, table {e2:.3e}")
-    assert e2 < 1e-1
+    measured["table"] = e2
+    log(f"timed bf16 B={Bn} T={T}: grad rel L2 by kind " + " ".join(f"{k}:{v:.2e}" for k, v in sorted(measured.items())))
+    assert e2 < BF16_GRAD_BARS["table"]
+
+
+def bf16_grad_kind(name: str) -> str:
+    if name.startswith("predictModule"):
+        return "scorer"
+    for key, kind in (("pos_emb", "pos_emb"), ("in_proj_weight", "in_proj_w"), ("in_proj_bias", "in_proj_b"), ("out_proj.weight", "out_proj_w"),
+                      ("out_proj.bias", "out_proj_b"), ("conv1.weight", "conv1_w"), ("conv1.bias", "conv1_b"), ("conv2.weight", "conv2_w"),
+                      ("conv2.bias", "conv2_b"), ("attention_layernorms", "ln1"), ("forward_layernorms", "ln2"), ("last_layernorm", "ln_last")):
+        if key in name:
+            return kind
+    raise KeyError(name)
+
+
+# 2 x the largest relative L2 error of a gradient tensor of the kind against the fp32 oracle, measured on MI355X over both shapes of
+# test_timed_path_bf16_products_vs_fp32_oracle (gpurun_out/parity.log, round 4: B 512 x T 50 is the larger -- conv1_b 2.8e-2, conv1_w 4.0e-2,
+# conv2_b 2.1e-2, conv2_w 2.9e-2, in_proj_b 3.5e-2, in_proj_w 4.2e-2, ln1 5.6e-2, ln2 4.0e-2, ln_last 2.0e-2, out_proj_b 2.4e-2,
+# out_proj_w 3.3e-2, pos_emb 6.2e-2, scorer 3.2e-2, table 3.7e-2; twelve bf16 products forward and twelve backward under a dropout
+# scale of 2).  A term missing from a sum or a wrong operand image moves its tensor by tens of percent.
+BF16_GRAD_BARS = {"conv1_b": 5.6e-2, "conv1_w": 7.9e-2, "conv2_b": 4.2e-2, "conv2_w": 5.8e-2, "in_proj_b": 6.9e-2, "in_proj_w": 8.4e-2,
+                  "ln1": 1.1e-1, "ln2": 8.0e-2, "ln_last": 4.0e-2, "out_proj_b": 4.9e-2, "out_proj_w": 6.7e-2, "pos_emb": 1.2e-1,
+                  "scorer": 6.3e-2, "table": 7.3e-2}
 
 
 def _timed_vs_oracle(Bn, T, D, build, split, compact_min, seq_backward=None):
@@ -267,6 +299,32 @@ def _timed_vs_oracle(Bn, T, D, build, split, compact_min, seq_backward=None):
     want = torch.where(dom[:, None] == 0, p1, p2)
     assert relmax(own, want) < 1e-4
     check_grads(f"timed B={Bn} T={T} D={D} {split}", eng, pl, grads, 2e-4, 5e-5)
+
+
+def _fuzz_cases(seed: int, n: int):
+    """The draw of profiles/tools/probe/fuzz_timed.py: (B, T, D, domain split, fused backward forced on / off / auto)."""
+    import random
+    rng = random.Random(seed)
+    cases = []
+    for _ in range(n):
+        D = rng.choice([64, 128])
+        T = rng.choice([1, 2, 7, 15, 16, 17, 20, 31, 32, 33, 40, 47, 48, 49, 50, 63, 64])
+        B = rng.choice([1, 3, 37, 64, 130, 256, 300])
+        split = rng.choice(["mixed", "mixed", "all0", "all1", "one0"])
+        force = rng.choice([None, "1", "0"])
+        cases.append((B, T, D, split, force))
+    return cases
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("case", _fuzz_cases(4, 24), ids=lambda c: "-".join(str(x) for x in c))
+def test_timed_path_randomised_shapes_vs_oracle(case):
+    """A seeded 24-draw subset of the randomised sweep of profiles/tools/probe/fuzz_timed.py (round 3 ran 160 draws by hand): the timed
+    step -- loss, own logits, every dense gradient, the table-row gradients -- against the oracle at random (B, T, D, domain split) with
+    the fused per-sequence backward forced on, off or left to the engine.  T = 1 .. 64 crosses every build boundary of the one-launch
+    kernels (16 / 32 / 48 rows), B = 1 .. 300 both sides of the CU count, D 64 the head-pair attention."""
+    B, T, D, split, force = case
+    _timed_vs_oracle(B, T, D, None, split, compact_min=None, seq_backward=force)
 
 
 @pytest.mark.parametrize("Bn,T,D", [(256, 50, 128), (256, 20, 128), (320, 50, 128)])     # (320: the fused per-sequence backward, side-stream sort)
@@ -399,6 +457,68 @@ def test_timed_path_equals_plain_path(Bn, T, n_items):
                                 orc.philox_masks_sasrec(S, T, D, seed=seed, step=step))
     want = torch.where(dom[:S, None] == 0, p1, p2)
     assert relmax(t_own[:S], want) < 1e-4
+
+
+@pytest.mark.timeout(1800)
+def test_timed_path_cfg5_batch_every_gradient_vs_oracle():
+    """BASELINE.json configs[4]'s per-GPU step at FULL size -- batch 4096, seq 50, dim 128, a 10 M-row table, S-uniform ids (no pads: ~417 k
+    index positions, ~210 k distinct rows) -- through the timed path (compact index list, side-stream sort, live sequences) against the
+    oracle: loss, own logits, EVERY dense gradient and the table-row gradients.  The oracle runs on the table remapped to the rows the
+    batch touches (a dense 10 M-row embedding gradient is 5 GB of zeros); dropout counters are indexed by (row, position), not by id."""
+    Bn, T, D, hid, n_items = 4096, 50, 128, 32, 10_000_000
+    seed, step = 5, 3
+    P = orc.random_params(orc.sasrec_param_shapes(8, D, T, hid), seed=77)
+    from amid_amd.engine import SasrecEngine
+    eng = SasrecEngine(n_items, D, T, hid, seed=seed)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    eng.table.copy_(torch.randn(n_items, D, generator=g, device="cuda"))
+    with torch.no_grad():
+        for name in eng.dense.slots:
+            eng.dense.view(name).copy_(P[name].cuda())
+    torch.cuda.synchronize()
+    gb = torch.Generator().manual_seed(Bn)
+    batch = orc.synthetic_batch(Bn, T, n_items - 2, pad_id=n_items - 1, neg=1, seed=9)
+    batch["seq_d1"] = torch.randint(0, n_items, (Bn, T), generator=gb)
+    batch["seq_d2"] = torch.randint(0, n_items, (Bn, T), generator=gb)
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    timed_local_grads(eng, pl, batch, step, seed)
+    assert pl.compact                                  # the long-list form of the sparse side
+    keys = ("i_node", "neg_samples", "seq_d1", "seq_d2")
+    ids = torch.cat([batch[k].reshape(-1) for k in keys])
+    uniq, inv = torch.unique(ids, return_inverse=True)
+    Ps = dict(P)
+    Ps["item_emb_layer.emb_item.weight"] = eng.table[uniq.cuda()].cpu()
+    sub = dict(batch)
+    o = 0
+    for k in keys:
+        n = batch[k].numel()
+        sub[k] = inv[o:o + n].reshape(batch[k].shape); o += n
+    masks = orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=step)
+    keep = gpu_relu_keep(eng, pl, batch)
+    loss, (p1, p2), grads = orc.loss_and_grads("sasrec", Ps, sub, masks, relu_keep=keep)
+    assert abs(float(pl.loss.item()) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    dom = batch["domain_id"]
+    own = torch.where(dom[:, None] == 0, pl.p1.cpu(), pl.p2.cpu())
+    assert relmax(own, torch.where(dom[:, None] == 0, p1, p2)) < 1e-4
+    worst = worst2 = 0.0
+    for name in eng.dense.slots:
+        got, want = eng.dense.view(name, eng.dense.grad).cpu().clone(), grads[name].clone()
+        if name.endswith("in_proj_bias"):
+            n3 = got.numel() // 3
+            got[n3:2 * n3] = 0; want[n3:2 * n3] = 0
+        e, e2 = relmax(got, want), rel_l2(got, want)
+        worst, worst2 = max(worst, e), max(worst2, e2)
+        assert e < 2e-4 and e2 < 5e-5, (name, e, e2)
+    U = int(pl.n_uniq.item())
+    got_ids, got_rows = pl.uniq_ids[:U].cpu().long(), pl.uniq_grad[:U].cpu()
+    want_tab = grads["item_emb_layer.emb_item.weight"]                       # [n unique, D], row j <-> id uniq[j]
+    tab = torch.zeros_like(want_tab)
+    where = torch.searchsorted(uniq, got_ids)
+    assert bool((uniq[where] == got_ids).all())          # the step's unique list holds ids of the batch only
+    tab[where] = got_rows
+    e, e2 = relmax(tab, want_tab), rel_l2(tab, want_tab)
+    log(f"cfg5 batch (B 4096, {uniq.numel()} distinct rows): worst dense grad relmax {worst:.3e} l2 {worst2:.3e}; table relmax {e:.3e} l2 {e2:.3e}")
+    assert e < 2e-4 and e2 < 5e-5
 
 
 # ---------------------------------------------------------------------------- kernel level: the three row-tile kernels at several tile heights
