@@ -547,9 +547,30 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         else:            # the pair-max kernel has every LayerNorm'd row of (b) in LDS: it emits the means too
             L.call("amid_itc_pairmax_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
                    B, T, D, SASREC_LN_EPS, pl.itc_s.data_ptr(), pl.u_raw.data_ptr(), s)
-            L.call("amid_itc_mix_fwd_f32", pl.u_raw.data_ptr(), pl.itc_s.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"),
+            u_raw, itc_s, u_out, Bm = pl.u_raw, pl.itc_s, pl.u, B
+            if pl.itc_world > 1:
+                # data parallel: the module couples the rows of the GLOBAL batch (softmax over the batch model_seq.py:491, Linear(bs, 1)
+                # over it :495).  Every rank gathers the shards' pair-max scalars and user vectors (rank r holds rows [r B, (r + 1) B)) and
+                # evaluates the module on all bs rows -- the same arithmetic on the same values on every rank --, then keeps its rows.
+                ex = self._itc_exchange(pl)
+                for g in (0, 1):
+                    ex.all_gather_packed(pl.u_raw[g].reshape(-1), pl.u_raw_g[g].reshape(-1))
+                ex.all_gather_packed(pl.itc_s, pl.itc_s_g)
+                u_raw, itc_s, u_out, Bm = pl.u_raw_g, pl.itc_s_g, pl.u_g, self.itc_bs
+            L.call("amid_itc_mix_fwd_f32", u_raw.data_ptr(), itc_s.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"),
                    self._pp("itc_d{d}.trans_nn.bias"), self._pp("itc_d{d}.trans_bs.weight"), self._pp("itc_d{d}.trans_bs.bias"),
-                   self.itc_threshold, B, D, pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(), pl.itc_sw.data_ptr(), pl.u.data_ptr(), s)
+                   self.itc_threshold, Bm, D, pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(), pl.itc_sw.data_ptr(), u_out.data_ptr(), s)
+            if pl.itc_world > 1:
+                r = self._itc_exchange(pl).rank
+                pl.u.copy_(pl.u_g[:, r * B:(r + 1) * B])
+
+    def _itc_exchange(self, pl: SasrecPlan):
+        """The exchange of the running data-parallel step (train_step_dp) for a plan that holds a shard of InterComp's global batch."""
+        ex = getattr(self, "_dp_exchange", None)
+        if ex is None or ex.world != pl.itc_world:
+            raise RuntimeError(f"isItC: this plan holds 1 / {pl.itc_world} of the module's batch of {self.itc_bs} rows -- it can only be stepped "
+                               f"by train_step_dp with an exchange over {pl.itc_world} ranks")
+        return ex
 
     def _enqueue_user_vectors_bwd(self, pl: SasrecPlan) -> None:
         """pl.du (gradient of pl.u) -> InterComp parameter gradients (isItC) -> dx of the last layer's output + LayerNorm partials."""
@@ -558,10 +579,27 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         fp, G = self.dense, self.dense.grad
         du = pl.du
         if self.itc_bs:
-            L.call("amid_itc_mix_bwd_f32", pl.du.data_ptr(), pl.u_raw.data_ptr(), pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(),
+            du_in, u_raw, du_out, Bm = pl.du, pl.u_raw, pl.du_raw, B
+            if pl.itc_world > 1:
+                # data parallel: the gradients of every shard's user vectors are gathered and the module's backward runs on the global
+                # batch on every rank: each rank's own rows of d u_raw then carry the terms of ALL ranks' losses (the group token is built
+                # from everybody's rows), which that rank alone can send on through its encoders
+                ex = self._itc_exchange(pl)
+                for g in (0, 1):
+                    ex.all_gather_packed(pl.du[g].reshape(-1), pl.du_g[g].reshape(-1))
+                du_in, u_raw, du_out, Bm = pl.du_g, pl.u_raw_g, pl.du_raw_g, self.itc_bs
+            L.call("amid_itc_mix_bwd_f32", du_in.data_ptr(), u_raw.data_ptr(), pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(),
                    pl.itc_sw.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"), self._pp("itc_d{d}.trans_nn.bias"),
-                   self._pp("itc_d{d}.trans_bs.weight"), B, D, pl.du_raw.data_ptr(), self._pp("itc_d{d}.trans_nn.weight", G),
+                   self._pp("itc_d{d}.trans_bs.weight"), Bm, D, du_out.data_ptr(), self._pp("itc_d{d}.trans_nn.weight", G),
                    self._pp("itc_d{d}.trans_nn.bias", G), self._pp("itc_d{d}.trans_bs.weight", G), self._pp("itc_d{d}.trans_bs.bias", G), s)
+            if pl.itc_world > 1:
+                ex = self._itc_exchange(pl)
+                pl.du_raw.copy_(pl.du_raw_g[:, ex.rank * B:(ex.rank + 1) * B])
+                # the module's own parameter gradients came out of the GLOBAL batch, identically on every rank: the step's dense exchange
+                # sums the ranks' gradients, so each rank contributes its 1 / world share
+                for d in (1, 2):
+                    for name in ("trans_nn.weight", "trans_nn.bias", "trans_bs.weight", "trans_bs.bias"):
+                        self.dense.view(f"itc_d{d}.{name}", G).mul_(1.0 / ex.world)
             du = pl.du_raw
         L.call("amid_lnmean_bwd_f32", pl.x[2].data_ptr(), du.data_ptr(), fp.ptr("sac1.last_layernorm.weight"),
                fp.ptr("sac2.last_layernorm.weight"), B, T, D, SASREC_LN_EPS, pl.dxbuf.data_ptr(), pl.last_part.data_ptr(), s)

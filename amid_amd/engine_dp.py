@@ -46,9 +46,25 @@ class DataParallelMixin:
         parts, merge of the sparse parts, Adam): three or four host calls, and replicas that are bit-identical by construction; the
         pair of graphs is captured per distinct (umax, dense), so callers should pass a bucketed bound (bench.py: the pool's maximum).
         dense: "gather" | "allreduce" (default: DENSE_EXCHANGE)."""
-        if (self.itc_bs or self.inc_bs) and exchange.active:
-            raise NotImplementedError("isItC / isInC couple the rows of a batch (softmax and Linear(bs, 1) over the batch, "
-                                      "model_seq.py:465-469, :490-494): data-parallel sharding would change the model; train them on one GPU")
+        if self.inc_bs and exchange.active:
+            raise NotImplementedError("isInC couples the rows of a batch IN FRONT of the encoders (softmax and Linear(bs, 1) over the batch on "
+                                      "the gathered [B, T, D] rows, model_seq.py:459-472): sharding it needs the all-gather of every rank's "
+                                      "gathered rows; train it on one GPU (isItC, the module run.sh trains, is data-parallel)")
+        itc_dp = bool(self.itc_bs and exchange.active)
+        if itc_dp:
+            # InterComp under data parallel (SURVEY.md section 8(f) next-1): bs is the GLOBAL batch, the plan a shard of it; the module's
+            # softmax / Linear(bs, 1) over the batch run on gathered scalars and user vectors in the MIDDLE of forward and backward
+            # (engine._enqueue_user_vectors*), so the step is enqueued eagerly -- collectives cannot sit inside a captured graph
+            if getattr(pl, "itc_world", 1) != exchange.world:
+                raise ValueError(f"isItC data parallel: bs = {self.itc_bs} must be world x the per-rank batch ({exchange.world} x {pl.shape.B})")
+            use_graph = False
+        self._dp_exchange = exchange if itc_dp else None
+        try:
+            self._train_step_dp(pl, exchange, use_graph, umax, dense)
+        finally:
+            self._dp_exchange = None
+
+    def _train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool, umax: Optional[int], dense: Optional[str]) -> None:
         dense = dense or self.DENSE_EXCHANGE
         if dense not in ("gather", "allreduce"):
             raise ValueError(f"dense exchange must be 'gather' or 'allreduce', got {dense!r}")
@@ -59,7 +75,7 @@ class DataParallelMixin:
             self.grad_scale = exchange.grad_scale
             fast = (use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")
                     and not exchange.use_owner(umax, self.D))      # the owner-bucketed exchange sizes its buffers per step: eager
-            pair = getattr(pl, "dp_graphs", {}).get((umax, dense)) if fast else None
+            pair = getattr(pl, "dp_graphs", {}).get((self._graph_key(), umax, dense)) if fast else None
             if pair is not None:       # graph A, the collective(s), graph B
                 L.call("amid_graph_launch", pair[0], self.s)
                 self.step += 1
@@ -69,7 +85,7 @@ class DataParallelMixin:
                 L.call("amid_graph_launch", pair[1], self.s)
                 return
             if use_graph:
-                L.call("amid_graph_launch", pl.graph_local, self.s)
+                L.call("amid_graph_launch", pl.graphs_local[self._graph_key()], self.s)
                 self.step += 1
             else:
                 self.enqueue_local_grads(pl)
@@ -111,7 +127,7 @@ class DataParallelMixin:
         self.step = step0                      # capture does not execute
         if not hasattr(pl, "dp_graphs"):
             pl.dp_graphs = {}
-        pl.dp_graphs[(umax, dense)] = (graphs[0], graphs[1], send, recv)
+        pl.dp_graphs[(self._graph_key(), umax, dense)] = (graphs[0], graphs[1], send, recv)
 
     def merge_backend(self, capacity: int) -> "HipMergeBackend":
         return HipMergeBackend(self, capacity)

@@ -30,7 +30,12 @@ class GraphMixin:
             out = ctypes.c_void_p()
             L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
         self.step = step0
-        pl.graph_local = out.value
+        if not isinstance(getattr(pl, "graphs_local", None), dict):
+            pl.graphs_local = {}
+        pl.graphs_local[self._graph_key()] = out.value      # (keyed like the train-step graphs: the Adam state and the DR objective are baked in)
+
+    def has_local_graph(self, pl: SasrecPlan) -> bool:
+        return self._graph_key() in (getattr(pl, "graphs_local", None) or {})
 
 
     # ------------------------------------------------------------------ graph replay

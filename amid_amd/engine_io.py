@@ -77,7 +77,7 @@ class InputMixin:
                 pl.graphs_n.pop(k)
         if getattr(pl, "dp_graphs", None):
             pl.dp_graphs.clear()
-        pl.graph_local = None
+        pl.graphs_local = {}
 
     def input_pool(self, pl: SasrecPlan):
         """[pool, phase] installed for the current (Adam state, objective), or None."""

@@ -190,11 +190,18 @@ class SasrecPlan:
         self._alloc_model_fwd(eng, f)
         self.u = f(2, B, D)
         if getattr(eng, "itc_bs", 0):
-            if B != eng.itc_bs:
+            # B == bs: the whole batch on this GPU.  world * B == bs: a data-parallel shard of a global batch of bs rows (InterComp's softmax
+            # and Linear(bs, 1) run over the GLOBAL batch: the ranks all-gather the B pair-max scalars and user vectors of every shard and
+            # each evaluates the module on all bs rows, engine._enqueue_user_vectors)
+            if B != eng.itc_bs and (eng.itc_bs % B or eng.itc_bs // B > 64):
                 raise ValueError(f"isItC: the batch must hold exactly bs = {eng.itc_bs} rows (trans_bs is Linear(bs, 1) over the batch, "
-                                 f"model_seq.py:480), got {B}")
+                                 f"model_seq.py:480) or an equal data-parallel shard of them, got {B}")
+            self.itc_world = eng.itc_bs // B
+            Bg = eng.itc_bs
             self.u_raw, self.du_raw = f(2, B, D), f(2, B, D)
-            self.itc_s, self.itc_gate, self.itc_z, self.itc_sw = f(B), f(B), f(2, D), f(2)
+            self.itc_s, self.itc_gate, self.itc_z, self.itc_sw = f(B), f(Bg), f(2, D), f(2)
+            if self.itc_world > 1:      # the global batch's copies: gathered inputs, the module's outputs for all bs rows
+                self.u_raw_g, self.u_g, self.du_g, self.du_raw_g, self.itc_s_g = f(2, Bg, D), f(2, Bg, D), f(2, Bg, D), f(2, Bg, D), f(Bg)
         self.p1 = f(B, NI)
         self.p2 = f(B, NI)
         self.dp1 = torch.zeros(B, NI, dtype=torch.float32, device=dev)

@@ -40,9 +40,10 @@ def build_parser():
     return p
 
 
-def train(model, train_batches, train_batches_dr, args, val_batches):
+def train(model, train_batches, train_batches_dr, args, val_batches, exchange=None):
     best = {}
     eng = model.engine
+    world = exchange.world if exchange is not None else 1
     for epoch in range(args.epoch):
         stats = AverageMeter("loss_cls", "loss_dr_e", "loss_dr_r")
         model.train()
@@ -50,16 +51,16 @@ def train(model, train_batches, train_batches_dr, args, val_batches):
         eng.select_optimizer(0, lr=args.lr)                                              # optimizer   (train_sr_dr.py:668)
         pooled = not args.no_pool        # each loop's epoch resident in HBM, one graph replay per step (see train_sr.py of this repo)
         t_pool = time.perf_counter()
-        steps = ((None, None) for _ in range(model.begin_epoch_pool(train_batches.epoch_tensors(), dr_objective=0))) if pooled \
+        steps = ((None, None) for _ in range(model.begin_epoch_pool(train_batches.epoch_tensors(), exchange=exchange, dr_objective=0))) if pooled \
             else enumerate(train_batches)
         t_pool = time.perf_counter() - t_pool
         for i, (_, b) in enumerate(steps):
             if pooled:
-                losses = model.pool_step(use_graph=not args.no_graph, dr_objective=0)
+                losses = model.pool_step(use_graph=not args.no_graph, exchange=exchange, dr_objective=0)
             else:
                 losses = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
-                                          use_graph=not args.no_graph, dr_objective=0)
-            n_samples += args.bs
+                                          use_graph=not args.no_graph, exchange=exchange, dr_objective=0)
+            n_samples += args.bs * world
             if i % 20 == 0:                                                               # train_sr_dr.py:226-227
                 eng.sync()
                 lc, le, _ = losses.tolist()
@@ -80,16 +81,16 @@ def train(model, train_batches, train_batches_dr, args, val_batches):
         eng.select_optimizer(1, lr=args.lr * args.lr2)                                   # optimizer2  (train_sr_dr.py:669)
         t_sw = time.perf_counter() - t_sw
         t0p = time.perf_counter()
-        steps = ((None, None) for _ in range(model.begin_epoch_pool(train_batches_dr.epoch_tensors(), dr_objective=1))) if pooled \
+        steps = ((None, None) for _ in range(model.begin_epoch_pool(train_batches_dr.epoch_tensors(), exchange=exchange, dr_objective=1))) if pooled \
             else enumerate(train_batches_dr)
         t_pool += time.perf_counter() - t0p
         for i, (_, b) in enumerate(steps):
             if pooled:
-                losses = model.pool_step(use_graph=not args.no_graph, dr_objective=1)
+                losses = model.pool_step(use_graph=not args.no_graph, exchange=exchange, dr_objective=1)
             else:
                 losses = model.train_step(b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"],
-                                          use_graph=not args.no_graph, ob_label=b["ob_label"], dr_objective=1)
-            n_samples += args.bs
+                                          use_graph=not args.no_graph, exchange=exchange, ob_label=b["ob_label"], dr_objective=1)
+            n_samples += args.bs * world
             if i % 20 == 0:                                                               # train_sr_dr.py:400-402
                 eng.sync()
                 stats.update(loss_dr_r=losses.tolist()[2])
@@ -123,6 +124,13 @@ def main(argv=None):
                          "use train_sr.py without them")
     if args.model.lower() not in ("sasrec", "bert4rec"):
         raise SystemExit("the doubly-robust heads are built for --model sasrec (what run.sh trains) and bert4rec")
+    # one process per GPU under `python -m torch.distributed.run --nproc-per-node N train_sr_dr.py ...` (the reference is single-GPU):
+    # --bs is the batch PER GPU, both loops shard their batches by rank and exchange gradients every step (amid_amd/dist.py); with
+    # --isItC (run.sh) InterComp's Linear(bs, 1) spans the GLOBAL batch of world x --bs rows (engine._enqueue_user_vectors)
+    rank, world = base.init_data_parallel(args)
+    if world > 1 and args.model.lower() != "sasrec":
+        raise SystemExit("data-parallel train_sr_dr.py: --model sasrec")
+    gbs = args.bs * (world if args.isItC else 1)
     summary = []
     for i in range(args.seeds):
         torch.manual_seed(i); np.random.seed(i); random.seed(i)                           # train_sr_dr.py:624-627
@@ -134,22 +142,32 @@ def main(argv=None):
                                                                long_length=args.long_length, pad_id=item_length + 1, seed=seed, csv_path=path)
         ds_train, ds_dr = mk(stem + ".csv", True, i), mk(stem + "_DR.csv", True, 500 + i)            # :635-640
         ds_val = mk(os.path.join(root, f"{args.domain_type}_test.csv"), False, 1000 + i)
-        train_batches = DeviceBatches(ds_train, args.bs, shuffle=True, device=args.device, seed=i)
-        train_batches_dr = DeviceBatches(ds_dr, args.bs, shuffle=True, device=args.device, seed=500 + i)
-        val_batches = DeviceBatches(ds_val, args.bs, shuffle=False, device=args.device, seed=i)
+        train_batches = DeviceBatches(ds_train, args.bs, shuffle=True, device=args.device, seed=i, rank=rank, world=world)
+        train_batches_dr = DeviceBatches(ds_dr, args.bs, shuffle=True, device=args.device, seed=500 + i, rank=rank, world=world)
+        val_batches = DeviceBatches(ds_val, gbs, shuffle=False, device=args.device, seed=i)
         torch.cuda.set_device(torch.device(args.device))
         model = (SASRec if args.model.lower() == "sasrec" else BERT4Rec)(user_length=2 * user_length, user_emb_dim=args.emb_dim, item_length=2 * item_length, item_emb_dim=args.emb_dim,
-                       seq_len=args.seq_len, hid_dim=args.hid_dim, bs=args.bs, isInC=args.isInC, isItC=args.isItC, threshold1=args.ts1,
+                       seq_len=args.seq_len, hid_dim=args.hid_dim, bs=gbs, isInC=args.isInC, isItC=args.isItC, threshold1=args.ts1,
                        threshold2=args.ts2, isDR=True, lr=args.lr, seed=i, **({"compute": "bf16"} if args.dtype == "bf16" else {}))
         model.engine.dr_e_w = float(args.dr_e_w)
-        init_logger(args.model_dir, args.log_file)
+        exchange = None
+        if world > 1:      # identical replicas (weights from seed i on every rank), each rank's own dropout stream (as train_sr.py)
+            model.engine.set_step(model.engine.step, seed=model.engine.rank_seed(i, rank))
+            from .dist import SparseDenseExchange
+            n_idx = args.bs * (2 * args.seq_len + 2)
+            exchange = SparseDenseExchange(model.engine.merge_backend(world * n_idx),
+                                           host_staging=os.environ.get("AMID_DIST_BACKEND", "nccl") != "nccl")
+        init_logger(args.model_dir if rank == 0 else os.path.join(args.model_dir, f"rank{rank}"), args.log_file)
         logger.info(vars(args))
-        summary.append(train(model, train_batches, train_batches_dr, args, val_batches))
+        summary.append(train(model, train_batches, train_batches_dr, args, val_batches, exchange))
     keys = sorted(summary[0]) if summary else []
-    init_logger(args.model_dir, "log_all.txt")
+    init_logger(args.model_dir if rank == 0 else os.path.join(args.model_dir, f"rank{rank}"), "log_all.txt")
     for k in keys:
         v = np.array([s[k] for s in summary])
         logger.info(f"{k[0]} {k[1]}: mean {v.mean():.4f} std {v.std():.4f}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     return summary
 
 

@@ -153,6 +153,147 @@ def test_two_rank_dp_over_rccl_two_gpus(owner, dense):
         assert (outs[0][1][k] == outs[1][1][k]).all(), f"replicas diverged on {k}"
 
 
+ITC = dict(n_items=300, D=64, T=20, hid=16, B=8, K=3, seed=13, lr=1e-3, ts2=0.15)
+
+
+def _itc_params_and_batches():
+    c = ITC
+    P = orc.random_params(orc.sasrec_param_shapes(c["n_items"], c["D"], c["T"], c["hid"], itc_bs=c["B"]), seed=47)
+    for d in (1, 2):
+        P[f"sac{d}.last_layernorm.weight"] *= 0.3          # keeps the batch softmax of the pair-max scores away from one-hot
+    batches = []
+    for t in range(c["K"]):
+        g = torch.Generator().manual_seed(70 + t)
+        b = orc.synthetic_batch(c["B"], c["T"], c["n_items"] - 1, pad_id=c["n_items"] - 1, neg=1, seed=600 + t)
+        b["seq_d1"] = torch.randint(1, c["n_items"] - 1, (c["B"], c["T"]), generator=g)      # no shared pad positions: distinct pair-max scores
+        b["seq_d2"] = torch.randint(1, c["n_items"] - 1, (c["B"], c["T"]), generator=g)
+        batches.append(b)
+    return P, batches
+
+
+def _itc_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from amid_amd.dist import SparseDenseExchange, shard_batch
+        from amid_amd.engine import SasrecEngine
+        c = ITC
+        torch.cuda.set_device(0)
+        P, batches = _itc_params_and_batches()
+        # bs = the GLOBAL batch: InterComp's Linear(bs, 1) and its softmax span every rank's rows
+        eng = SasrecEngine(c["n_items"], c["D"], c["T"], c["hid"], device="cuda:0", lr=c["lr"], seed=SasrecEngine.rank_seed(c["seed"], rank),
+                           itc_bs=c["B"], itc_threshold=c["ts2"])
+        eng.load_state_dict(P)
+        Bl = c["B"] // world
+        pl = eng.plan(Bl, c["T"], 2, need_grad=True)
+        assert pl.itc_world == world
+        ex = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=True)
+        gates = []
+        for batch in batches:
+            local = {k: v.cuda() for k, v in shard_batch(batch, rank, world).items()}
+            eng.load_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"], local["domain_id"])
+            eng.train_step_dp(pl, ex, use_graph=True)          # (asked for graphs: the step must fall back to eager launches by itself)
+            eng.sync()
+            gates.append(pl.itc_gate.cpu().clone())
+        eng.flush_table()
+        eng.sync()
+        q.put((rank, {k: v.cpu().numpy().copy() for k, v in eng.state_dict().items()}, [g.numpy().copy() for g in gates], float(pl.loss.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_dp_with_intercomp_matches_global_batch_oracle():
+    """isItC (what run.sh trains, /root/reference/run.sh:1) under data parallel: InterComp's softmax over the batch and Linear(bs, 1)
+    (model_seq.py:490-495) span the GLOBAL batch -- each rank holds half of its rows, the ranks all-gather pair-max scalars, user
+    vectors and their gradients in the middle of the step.  Both replicas end bit-identical and equal to ONE process stepping the
+    oracle (isItC=True, dense Adam) over the global batches; the gates are those of the global softmax."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_itc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    c = ITC
+    P, batches = _itc_params_and_batches()
+    opt = orc.DenseAdam(P, lr=c["lr"])
+    Bl = c["B"] // world
+    from amid_amd.engine import SasrecEngine
+    for t, batch in enumerate(batches, start=1):
+        per_rank = [orc.philox_masks_sasrec(Bl, c["T"], c["D"], seed=SasrecEngine.rank_seed(c["seed"], r), step=t) for r in range(world)]
+        masks = {k: torch.cat([m[k] for m in per_rank], 0) for k in per_rank[0]}
+        taps = {}
+        orc.sasrec_forward(P, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], masks, taps, isItC=True, threshold2=c["ts2"])
+        gate = taps["itc_d1"]["gate"]
+        assert 0 < int(gate.sum()) < c["B"] and taps["itc_d1"]["margin"] > 1e-4, (gate, taps["itc_d1"]["margin"])
+        for o in outs:
+            assert torch.equal(torch.from_numpy(o[2][t - 1]), gate), (t, o[0])
+        orc.train_step("sasrec", P, opt, batch, masks, isItC=True, threshold2=c["ts2"])
+    sd0, sd1 = ({k: torch.from_numpy(v) for k, v in o[1].items()} for o in outs)
+    for k, v in P.items():
+        assert torch.equal(sd0[k], sd1[k]), f"replicas diverged on {k}"
+        d = (sd0[k] - v).abs()
+        if k.endswith("in_proj_bias"):
+            n = v.numel() // 3
+            d = torch.cat((d[:n], d[2 * n:]))
+        assert float(d.max()) < 1e-4, (k, float(d.max()))
+
+
+def _dr_cli_worker(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD_SIZE=str(world),
+                      RANK=str(rank), LOCAL_RANK=str(rank), AMID_DIST_BACKEND="gloo")
+    import amid_amd.train_sr_dr as tdr
+    captured = {}
+    real_train = tdr.train
+
+    def spy(model, *a, **k):
+        out = real_train(model, *a, **k)
+        model.engine.flush_table(); model.engine.sync()
+        captured["sd"] = {n: v.detach().cpu().numpy().copy() for n, v in model.state_dict().items()}
+        return out
+
+    tdr.train = spy
+    summary = tdr.main(["--data_root", root, "-ds", "amazon", "-dm", "toy", "--overlap_ratio", "0.75", "--model", "sasrec", "--bs", "8",
+                        "--seq_len", "20", "--emb_dim", "64", "--hid_dim", "16", "--epoch", "1", "--neg_nums", "19", "--seeds", "1",
+                        "--device", "cuda:0", "-md", os.path.join(root, "model"), "--isItC", "True", "--ts2", "0.05", "--lr2", "0.01",
+                        "--dr_e_w", "0.01", "--max_steps", "5"])
+    q.put((rank, captured["sd"], {f"{k[0]}/{k[1]}": float(v) for k, v in summary[0].items()}))
+
+
+@pytest.mark.timeout(900)
+def test_train_sr_dr_cli_isitc_data_parallel_two_ranks(tmp_path):
+    """run.sh's own configuration -- train_sr_dr.py --isItC True (the doubly-robust trainer: two objectives, two Adam states) -- under a
+    two-process launch: InterComp is built for the global batch of 2 x --bs rows, both loops shard their batches and exchange
+    gradients every step; the replicas must end bit-identical with identical metrics."""
+    import numpy as np
+    from tests.test_gpu_module import _write_csv
+    rng = np.random.default_rng(3)
+    root = tmp_path / "amazon_dataset"
+    root.mkdir()
+    _write_csv(root / "toy_train75.csv", 120, rng, 1, 400, 400, 900)
+    _write_csv(root / "toy_train75_DR.csv", 120, rng, 1, 400, 400, 900, ob_label=True)
+    _write_csv(root / "toy_test.csv", 48, rng, 1, 400, 400, 900)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dr_cli_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([_get(q, procs, 800) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, sd0, m0), (_, sd1, m1) = outs
+    assert any(k.startswith("itc_d1.trans_bs") and v.shape[-1] == 16 for k, v in sd0.items())       # Linear(bs, 1) over the GLOBAL batch
+    for k in sd0:
+        assert np.array_equal(sd0[k], sd1[k]), k
+    assert m0 == m1 and all(0.0 <= v <= 1.0 for v in m0.values())
+
+
 def _cli_worker(rank, world, port, root, q, dm="toy", extra=()):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD_SIZE=str(world),
                       RANK=str(rank), LOCAL_RANK=str(rank), AMID_DIST_BACKEND="gloo")
