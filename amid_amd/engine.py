@@ -568,8 +568,9 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         """The exchange of the running data-parallel step (train_step_dp) for a plan that holds a shard of InterComp's global batch."""
         ex = getattr(self, "_dp_exchange", None)
         if ex is None or ex.world != pl.itc_world:
-            raise RuntimeError(f"isItC: this plan holds 1 / {pl.itc_world} of the module's batch of {self.itc_bs} rows -- it can only be stepped "
-                               f"by train_step_dp with an exchange over {pl.itc_world} ranks")
+            raise ValueError(f"isItC: the batch must hold exactly bs = {self.itc_bs} rows (trans_bs is Linear(bs, 1) over the batch, "
+                             f"model_seq.py:480); a batch of 1 / {pl.itc_world} of them is a data-parallel shard and can only be stepped by "
+                             f"train_step_dp with an exchange over {pl.itc_world} ranks")
         return ex
 
     def _enqueue_user_vectors_bwd(self, pl: SasrecPlan) -> None:
