@@ -344,6 +344,17 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
     const SeqBuf bdq(a.dq, rowbase, T, D), bdk(a.dk, rowbase, T, D), bdv(a.dv, rowbase, T, D);
     float* tile = lds;
     float* tile2 = lds + ATTN_BWD_TILE_FLOATS;
+    // a query row's share of delta = sum dO . O, as soon as both are here: the O fragments (16 registers) are dead from then on -- with them
+    // held through the core the standalone launch, at 256 registers per wave, spilled ten registers to scratch
+    // (an explicit fma chain: every kernel this core is compiled into -- the standalone launch, the two fused backward builds -- gets
+    // the same bits, whatever its surroundings make of a * b + c)
+    float dparts[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4 dof = o.dofr[t], of = o.ofr[t];
+        dparts[t] = fmaf(dof.w, of.w, fmaf(dof.z, of.z, fmaf(dof.y, of.y, dof.x * of.x)));
+        asm volatile("" : "+v"(dparts[t]));
+    }
     // the transposed operand fragments K^T, Qs^T, dO^T from the row fragments
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -370,10 +381,7 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
     for (int qi = 0; qi < NT; ++qi) {
         const int q = qi * 16 + m;
         const float4 qf = o.qfr[qi], dof = o.dofr[qi];
-        // (an explicit fma chain: every kernel this core is compiled into -- the standalone launch, the two fused backward builds -- gets
-        // the same bits, whatever its surroundings make of a * b + c)
-        const float4 of = o.ofr[qi];
-        const float dpart = fmaf(dof.w, of.w, fmaf(dof.z, of.z, fmaf(dof.y, of.y, dof.x * of.x)));
+        const float dpart = dparts[qi];
         float delta;
         if constexpr (PAIR) {                              // a head's dims sit in two lane groups: sum those, fetch the other head's from across
             const float own = dpart + __shfl_xor(dpart, 16, 64);

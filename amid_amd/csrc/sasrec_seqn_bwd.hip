@@ -111,7 +111,7 @@ __device__ __forceinline__ void with_tiles(int T, const F& f) {
 }
 
 // what the feed-forward chain needs first: requested a product ahead by the caller
-template <int D, int NCT> struct FfnPreN { PartRegs<NCT> Ho; unsigned tmw[NCT]; ColVec<D> gam; uint4 rr2; };
+template <int D, int NCT> struct FfnPreN { PartRegs<NCT> Ho; unsigned tmw[NCT]; uint4 rr2; };
 
 // floats of the exchange area: WPS strips x D / 16 tiles x 64 lanes x float4 -- or, while it is idle, two blocks of LayerNorm partial sums
 // [WPS][2][D] and the eight waves' transpose tiles of the attention core
@@ -174,7 +174,6 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
 #pragma unroll
             for (int c = 0; c < NCT; ++c) p.tmw[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(gtm.r, (int)(tm_own + 4 * c), 0, 0);
         }
-        p.gam.load(f.ln_w[g]);
         p.rr2 = make_uint4(0, 0, 0, 0);
         if (f.train) p.rr2 = rng_call(seed, (unsigned long long)row.local * D >> 7, site_id(g, f.layer, SITE_FFN2), step);
     };
@@ -215,6 +214,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
             lds_barrier();                                  // the partner has read this wave's slots of the previous exchange
             xchg_write<NCT>(xb, c0, Po);
             StripRegs<D> Rs;
+            ColVec<D> gam2;                                 // LayerNorm-2 gain: requested under the dy product, a product ahead of its use
             PartRegs<NCT> Ro, Go;                           // own columns of r and of the LayerNorm gain
             {   // dh = dpre2 C2 ; dpre1 = dh * relu'(h) * drop1   (h > 0 implies the unit was kept by drop1)
                 const float* buf = ring.next();
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                 const float* buf = ring.next();
                 xchg_read<D>(F, xb);
                 seqn_product<D, NCT, BF>(acc, F, buf, ring, f.woT[g], W16(f.woT[g]), c0,
-                                         [&](int ct, int j) { part_spread<NCT>(gp1, off_own, Po, ct, j, 1); });
+                                         [&](int ct, int j) { part_spread<NCT>(gp1, off_own, Po, ct, j, 1); }, [&]() { gam2.load(f.ln_w[g]); });
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) Po.v[c] = acc[c] + DZo.v[c];
             }
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
                 xchg_read<D>(F, xb);                        // the whole row of dy
                 if (l == 0) SEQNB_STAMP(32);
                 float mean, rstd, c1, c2;
-                ln_bwd_sums<D>(F, Rs, pre.gam, f.ln_eps, mean, rstd, c1, c2);
-                if constexpr (NS == 2) { own_of<D, NCT>(Ro, Rs, part); own_cols<D, NCT>(Go, pre.gam, f.ln_w[g], part, c0); }
+                ln_bwd_sums<D>(F, Rs, gam2, f.ln_eps, mean, rstd, c1, c2);
+                if constexpr (NS == 2) { own_of<D, NCT>(Ro, Rs, part); own_cols<D, NCT>(Go, gam2, f.ln_w[g], part, c0); }
                 dbet_f = col_sums_compact<NCT>(Po);
                 {
                     PartRegs<NCT> Dg;
@@ -272,12 +272,17 @@ __global__ __launch_bounds__(512) void seqn_bwd_kernel(const SeqBwdArgs a, const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float xh = (Rs.v[ct][r] - mean) * rstd;
-                        float gy = pre.gam.v[ct][r] * F.v[ct][r];
+                        float gy = gam2.v[ct][r] * F.v[ct][r];
                         asm volatile("" : "+v"(gy));          // the rounded product, as strip_ln_bwd keeps it (not contracted into the subtraction)
                         F.v[ct][r] = rstd * (gy - c1 - xh * c2);
                     }
                 if (l == 0) SEQNB_STAMP(33);
-                // the attention core's saved operands of this wave's head: they come from HBM -- requested under this product
+                // the attention core's saved operands of this wave's head: they come from HBM -- requested under this product.  (They hold 72
+                // registers through the matrix loop: with the core's own ~220 the (4, 2) build spills 75 of them, 300 B per lane of scratch.
+                // Requested BEHIND the product instead the build spills 23 (fp32) / 3 (bf16) -- measured, round 4: cfg 2 0.3761 ms per step
+                // against 0.3763 with the five strip launches, a tie as before; cfg 3 0.658 against 0.665 for the strip-build fused kernel --
+                // but the core's contractions then round differently from the strip build's (1 ulp on dq / dk / dv), and the bit-identity
+                // of the two builds is worth more than 1 % at one shape: not adopted; "auto" never takes this build at T > 32.)
                 with_tiles<WPS>(T, [&](auto nt) { attn_bwd_load_saved<decltype(nt)::value, PAIR>(oa, P.at, g, b, rowbase, PAIR ? w >> 1 : w); });
                 if (l == 0) SEQNB_STAMP(34);
                 seqn_product<D, NCT, BF>(acc, F, buf, ring, q.wkT[g], W16(q.wkT[g]), c0,
