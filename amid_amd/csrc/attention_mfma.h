@@ -113,6 +113,26 @@ __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int s
 __device__ __forceinline__ float quad_group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float quad_group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
+// 16-bit decisions (p = 0.1: the BERT4Rec rate): a call decides eight keys.  The calls c0 <= c < c1 of the row (c < ceil(T / 8)), unrolled,
+// eight compares per call, the word built in two 32-bit halves -- the generic loop below (runtime field width, 64-bit shifts) took 6 us of
+// a 21 us attention launch.  A caller may split a row's calls over two lanes (c0 / c1) and OR the parts.
+__device__ __forceinline__ unsigned long long row_keep_word16(unsigned long long seed, unsigned site, unsigned step, unsigned long long row, int T,
+                                                              unsigned thr, int c0, int c1) {
+    const int calls = (T + 7) >> 3;
+    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (c >= c0 && c < c1 && c < calls) {              // (wave-uniform)
+            const uint4 r = rng_call(seed, row * calls + c, site, step);
+            const unsigned b8 = ((r.x & 0xFFFFu) >= thr ? 1u : 0u) | ((r.x >> 16) >= thr ? 2u : 0u) | ((r.y & 0xFFFFu) >= thr ? 4u : 0u) |
+                                ((r.y >> 16) >= thr ? 8u : 0u) | ((r.z & 0xFFFFu) >= thr ? 16u : 0u) | ((r.z >> 16) >= thr ? 32u : 0u) |
+                                ((r.w & 0xFFFFu) >= thr ? 64u : 0u) | ((r.w >> 16) >= thr ? 128u : 0u);
+            if (c < 4) lo |= b8 << (8 * c); else hi |= b8 << (8 * (c - 4));
+        }
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // keep bits (1 = keep) of keys 0..63 of attention row `row` (row-major [b, h, i]); same indexing as attention.hip / the oracle
 __device__ __forceinline__ unsigned long long row_keep_word(unsigned long long seed, unsigned site, unsigned step, unsigned long long row, int T,
                                                             unsigned spec) {
@@ -124,6 +144,7 @@ __device__ __forceinline__ unsigned long long row_keep_word(unsigned long long s
         const unsigned long long w = ((unsigned long long)r.y << 32) | r.x;
         return thr ? w : ~0ull;
     }
+    if (b == 16) return row_keep_word16(seed, site, step, row, T, thr, 0, 8);      // the BERT4Rec case (p = 0.1)
     unsigned long long w = 0;
     for (int c = 0; c * per < 64 && c < calls; ++c) {
         const uint4 r = rng_call(seed, row * calls + c, site, step);

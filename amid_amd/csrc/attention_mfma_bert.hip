@@ -20,16 +20,22 @@ __device__ __forceinline__ f32x4 frag2(const float4 (&a)[2], const float4 (&b)[2
 
 // bit (kj * 4 + r) of the result: key n = kj * 16 + 4 gq + r is inside the sequence (valid) / also visible (ok)
 __device__ __forceinline__ void key_bits(const unsigned char* __restrict__ kk, int T, int gq, unsigned& valid, unsigned& ok) {
+    // (the sixteen mask bytes of the lane are requested back to back, clamped instead of branched around: behind a branch per key each
+    // byte load waited out its own round trip -- sixteen dependent L2 latencies at the head of every wave)
+    unsigned char kb[16];
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kb[kj * 4 + r] = kk != nullptr ? kk[min(kj * 16 + 4 * gq + r, T - 1)] : (unsigned char)1;
     valid = 0; ok = 0;
 #pragma unroll
     for (int kj = 0; kj < 4; ++kj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = kj * 16 + 4 * gq + r;
-            if (n < T) {
-                valid |= 1u << (kj * 4 + r);
-                if (kk == nullptr || kk[n] != 0) ok |= 1u << (kj * 4 + r);
-            }
+            const unsigned bit = n < T ? 1u << (kj * 4 + r) : 0u;
+            valid |= bit;
+            ok |= kb[kj * 4 + r] != 0 ? bit : 0u;
         }
 }
 
@@ -39,46 +45,80 @@ __device__ __forceinline__ int bert_live_seq(const AttnArgs& a, int j) {
     return (j >= n0 ? a.B : 0) + a.live[j];
 }
 
+template <int WPH>                                         // waves per head: 2 (H <= 4: eight waves per sequence) or 1
 __global__ __launch_bounds__(512) void attn_fwd_bert_kernel(const AttnArgs a) {
+    constexpr int TPW = 4 / WPH;                           // query tiles per wave
     const int T = a.T, D = a.D, H = a.H;
     const int seq = a.live != nullptr ? bert_live_seq(a, blockIdx.x) : (int)blockIdx.x, g = seq / a.B, b = seq - g * a.B;
     const long long rowbase = (long long)seq * T;
-    const int h = wave_id(), lane = lane_id();
+    // TWO waves per head (eight per sequence): wave w serves head w % H with the query tiles {0, 1} (w < H) or {2, 3}; both load the
+    // head's K / V (L2 hits the second time).  With one wave per head a CU held four waves and every query tile's chain -- scores,
+    // softmax, P~ V -- ran behind the previous one's: 21 us per launch at B 256, T 50.
+    const int h = wave_id() % H, qhalf = wave_id() / H, lane = lane_id();
     const int m = lane & 15, gq = lane >> 4;
     const int NT = (T + 15) >> 4;
     const float inv = 1.0f / a.scale;
     const unsigned char* kk = a.key_keep ? a.key_keep + (long long)b * T : nullptr;
+    if (TPW * qhalf >= NT) return;                         // (T <= 32: the second wave of a head has no query tile)
     float4 kf[4][2];
     float vt[4][4][2];
+    {   // K as row fragments; V^T (lane (m, g): key 16 kj + 4 g + r, dim 16 c + m) from V's row fragments by a 16 x 16 transpose through the
+        // wave's LDS tile -- as loads the transposed fragments were 32 four-byte requests per lane, each touching four 64-byte segments
+        extern __shared__ __attribute__((aligned(16))) float fsmem[];
+        float* tile = fsmem + wave_id() * ATTN_BWD_TILE_FLOATS;
+        float4 vf[4][2];
 #pragma unroll
-    for (int kj = 0; kj < 4; ++kj)
+        for (int kj = 0; kj < 4; ++kj)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            kf[kj][c] = ld4_row(a.k, rowbase, kj * 16 + m, T, D, h * BHD + 16 * c + 4 * gq);
+            for (int c = 0; c < 2; ++c) {
+                kf[kj][c] = ld4_row(a.k, rowbase, kj * 16 + m, T, D, h * BHD + 16 * c + 4 * gq);
+                vf[kj][c] = ld4_row(a.v, rowbase, kj * 16 + m, T, D, h * BHD + 16 * c + 4 * gq);
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vt[kj][r][c] = ld1_row(a.v, rowbase, kj * 16 + 4 * gq + r, T, D, h * BHD + 16 * c + m);
-        }
+        for (int kj = 0; kj < 4; ++kj)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float t4[4];
+                tile_transpose(tile, vf[kj][c], t4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vt[kj][r][c] = t4[r];
+            }
+    }
     unsigned valid, okb;
     key_bits(kk, T, gq, valid, okb);
+    // dropout keep words (64 keys) of the wave's query rows.  WPH = 1: lane l draws row l's.  WPH = 2: the wave owns 32 query rows; lane l
+    // draws the first four calls (keys 0 .. 31) of row 32 qhalf + (l & 31) if l < 32, the others (keys 32 .. 63) if not -- half the
+    // Philox calls per lane --, and the row loop below puts a row's word together from its two lanes
     unsigned long long kw_own = ~0ull;
     if (a.train) {
-        const int qrow = min(gq * 16 + m, T - 1);
-        kw_own = row_keep_word(a.st->seed, site_id(g, a.layer, SITE_ATTN), (unsigned)a.st->step,
-                               (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
+        const unsigned site = site_id(g, a.layer, SITE_ATTN), step = (unsigned)a.st->step;
+        if constexpr (WPH == 2) {
+            const int qrow = min(32 * qhalf + (lane & 31), T - 1);
+            kw_own = row_keep_word16(a.st->seed, site, step, (unsigned long long)(b * H + h) * T + qrow, T, spec_thr(a.thr16), lane < 32 ? 0 : 4,
+                                     lane < 32 ? 4 : 8);
+            if (spec_bits(a.thr16) != 16)                  // (other rates: the whole word on both lanes)
+                kw_own = row_keep_word(a.st->seed, site, step, (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
+        } else {
+            const int qrow = min(gq * 16 + m, T - 1);
+            kw_own = row_keep_word(a.st->seed, site, step, (unsigned long long)(b * H + h) * T + qrow, T, a.thr16);
+        }
     }
-    float4 qall[4][2];                   // every query tile's rows requested up front (inside the loop each tile waited out its own round trip)
+    float4 qall[TPW][2];                 // the wave's query tiles' rows requested up front (inside the loop each tile waited out its own round trip)
 #pragma unroll
-    for (int qi = 0; qi < 4; ++qi)
+    for (int qq = 0; qq < TPW; ++qq)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) qall[qi][c] = ld4_row(a.q, rowbase, qi * 16 + m, T, D, h * BHD + 16 * c + 4 * gq);
+        for (int c = 0; c < 2; ++c) qall[qq][c] = ld4_row(a.q, rowbase, (TPW * qhalf + qq) * 16 + m, T, D, h * BHD + 16 * c + 4 * gq);
 #pragma unroll
-    for (int qi = 0; qi < 4; ++qi) {
+    for (int qq = 0; qq < TPW; ++qq) {
+        const int qi = TPW * qhalf + qq;
         if (qi >= NT) break;
         const int q = qi * 16 + m;
         float4 qf[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) qf[c] = f4scale(qall[qi][c], inv);
-        const unsigned long long kw = shfl64(kw_own, qi * 16 + m);
+        for (int c = 0; c < 2; ++c) qf[c] = f4scale(qall[qq][c], inv);
+        unsigned long long kw;
+        if constexpr (WPH == 2) kw = shfl64(kw_own, qq * 16 + m) | shfl64(kw_own, 32 + qq * 16 + m);      // (both hold the whole word at other rates)
+        else kw = shfl64(kw_own, qi * 16 + m);
         f32x4 s[4];
         float mx = -INFINITY;
 #pragma unroll
@@ -275,7 +315,9 @@ using namespace amid;
 // called by the entry points in attention.hip when the shape fits (bidirectional, head dim 32, T <= 64)
 int amid_attn_bert_fwd_launch(const void* args, void* stream) {
     const AttnArgs& a = *(const AttnArgs*)args;
-    attn_fwd_bert_kernel<<<a.live != nullptr ? a.B : 2 * a.B, a.H * 64, 0, (hipStream_t)stream>>>(a);
+    const size_t lds = (size_t)(a.H <= 4 ? 2 : 1) * a.H * ATTN_BWD_TILE_FLOATS * sizeof(float);      // a transpose tile per wave
+    if (a.H <= 4) attn_fwd_bert_kernel<2><<<a.live != nullptr ? a.B : 2 * a.B, 2 * a.H * 64, lds, (hipStream_t)stream>>>(a);
+    else attn_fwd_bert_kernel<1><<<a.live != nullptr ? a.B : 2 * a.B, a.H * 64, lds, (hipStream_t)stream>>>(a);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
