@@ -364,6 +364,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_oproj_ffn_fwd_kernel
     }
     strip_zero<BSD>(acc2);
     unsigned kb1 = ~0u, kb2 = ~0u;
+    // (Tried, round 4: the eight products software-pipelined -- W1_0, W1_1, W2_0, W1_2, ... -- with chunk c's GELU + dropout inside the matrix
+    // loop of the next product that does not need them, a column tile or an element per slot, forward and backward: the loops already carry
+    // the dropout counters' rounds, the DMA pieces and the deferred stores, and the extra vector work stretches them by more than it saves
+    // between them -- 0.6548 -> 0.6782 / 0.6657 ms per step; left as the plain chain.)
 #pragma unroll
     for (int c = 0; c < BSC; ++c) {
         {   // pre_c = y2 W1_c^T + b1_c ; h_c = drop_ffn(gelu(pre_c))
