@@ -288,6 +288,15 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         self._sort_pending = True
         self._sort_owed = False
 
+    def _wgrad_mode(self, D: int) -> int:
+        """The mma mode of amid_sas_wgrad(_rows)_f32: 1 = operands rounded to bf16 (compute "bf16"), 2 / 3 = fp32 operands as three bf16
+        pieces (nine / six piece pairs), 0 = fp32 matrix instructions."""
+        if D != 128:
+            return 0
+        if self.BF16_WGRAD and getattr(self, "_bf16_bwd", False):
+            return 1
+        return {"9": 2, "6": 3}.get(self.WGRAD_SPLIT, 0)
+
     def join_sort(self) -> None:
         """Make the main stream wait for the side-stream sort (no-op if nothing is pending)."""
         if getattr(self, "_sort_pending", False):
@@ -297,6 +306,10 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     SORT_RIDERS = os.environ.get("AMID_SORT_RIDERS", "1") != "0"
     # compute = "bf16": the weight gradients' products on the bf16 matrix cores too (amid_sas_wgrad_rows_f32 mma_bf16); 0: fp32 products
     BF16_WGRAD = os.environ.get("AMID_BF16_WGRAD", "1") != "0"
+    # compute = "fp32": the weight gradients' products on the bf16 matrix cores at fp32 accuracy -- every operand element as three bf16
+    # pieces, six ("6", the default) or nine ("9") piece pairs (csrc/sasrec_bwd.hip sas_wgrad_split_kernel; D = 128); "0": fp32 matrix
+    # instructions.  Error against the fp64 product 3.8e-7 of the largest entry either way, 4.4e-7 for the fp32 instructions.
+    WGRAD_SPLIT = os.environ.get("AMID_WGRAD_SPLIT", "6")
     # The train step's encoder backward (data gradients) as ONE launch over the live sequences where csrc/sasrec_strip.hip covers the
     # shape (amid_sas_seq_bwd_f32): "auto" = where it wins.  It tiles one sequence per workgroup, a whole CU each, so the step's sort
     # riders find no free CU in it and the sort goes back to the side stream (a fork and a join, ~10 us of a replayed graph).  Measured
@@ -801,7 +814,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         # NOTE: pl.x[0] is the gathered-row buffer xg, still intact here (its gradient lives in dxg)
         L.call("amid_sas_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
                ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), self._own_rows(pl), B, T,
-               1 if (self.BF16_WGRAD and getattr(self, "_bf16_bwd", False) and D == 128) else 0, s)
+               self._wgrad_mode(D), s)
         if getattr(pl, "riding", False):     # the last phase of the step's index sort (run heads) rides here
             L.call("amid_embed_bwd_sort_f32", (pl.dx0 if self.inc_bs else pl.dxg).data_ptr(), pl.tmq.data_ptr(), B, T, D, pl.pos_splits,
                    pl.dpos_part.data_ptr(), st, tr, SASREC_P_DROP, dom if live else None, self._sort_plan(pl), 5, s)

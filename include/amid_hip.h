@@ -256,8 +256,10 @@ int amid_sas_qkv_ffn_bwd_f32(const float* dq, const float* dk, const float* dv, 
 /* the six weight + bias gradients of n_layers (1 or 2) layers as split partials, ONE launch (two workgroups per CU): dy / x are host
  * arrays of 6 * n_layers device pointers, per layer in the order in_proj q, k, v, out_proj, conv1, conv2; w_part / b_part are host
  * arrays of n_layers device pointers to [2][6][splits][D*D] and [2][6][splits][D] */
-/* mma_bf16 != 0 (compute = "bf16", D 128): the products' operands rounded to bf16 on the way into LDS, v_mfma_f32_16x16x32_bf16 with fp32
- * accumulation; partial sums and the bias sums (taken from the unrounded rows) stay fp32 */
+/* mma_bf16 (D 128 only beyond 0): 0 = fp32 matrix instructions; 1 (compute = "bf16") = the products' operands rounded to bf16 on the way
+ * into LDS, v_mfma_f32_16x16x32_bf16 with fp32 accumulation; 2 / 3 (compute = "fp32") = every fp32 operand as three bf16 pieces whose sum
+ * is the operand exactly, nine / six piece pairs on the same instruction -- fp32 accuracy (3.8e-7 of the largest entry against the
+ * fp64 product, 4.4e-7 for mode 0) at 46 us instead of 69.  Partial sums and the bias sums (taken from the unrounded rows) stay fp32 */
 int amid_sas_wgrad_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
                        float* const* b_part, int mma_bf16, void* stream);
 /* with the loss structure as a hint (row_domain [B] = the batch's domain_id, M = B * T): of domain g only the sequences b with

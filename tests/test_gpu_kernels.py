@@ -783,6 +783,75 @@ def test_wgrad_bf16_products_against_fp32(L, B, T, hint):
             assert float((got_b[gdom, wi].double() - y.double().sum(0)).abs().max()) < 1e-4 * max(1.0, float(y.abs().sum(0).max()))
 
 
+def _wgrad_case(B, T, hint, n_ent, seed, spread=False):
+    D, M = 128, B * T
+    g = torch.Generator().manual_seed(seed)
+    dom = (torch.rand(B, generator=g) < 0.5).long()
+    live = torch.cat((dom == 0, dom == 1)).float().repeat_interleave(T) if hint else torch.ones(2 * M)
+
+    def one(mask):
+        t = torch.randn(2 * M, D, generator=g)
+        if spread:                                    # magnitudes over six decades, as gradients have them
+            t = t * torch.pow(10.0, -6.0 * torch.rand(2 * M, D, generator=g))
+        return dev(t * live[:, None] if mask else t)
+    return dom, [one(True) for _ in range(n_ent)], [one(False) for _ in range(n_ent)]
+
+
+def _wgrad_run(L, dy, xx, dom, B, T, splits, mode, hint):
+    from amid_amd._lib import ptr_array
+    D, M, nl = 128, B * T, len(dy) // 6
+    wp = [torch.full((2, 6, splits, D * D), float("nan"), device="cuda") for _ in range(nl)]
+    bp = [torch.full((2, 6, splits, D), float("nan"), device="cuda") for _ in range(nl)]
+    args = (ptr_array([t.data_ptr() for t in dy]), ptr_array([t.data_ptr() for t in xx]), nl, M, D, splits,
+            ptr_array([t.data_ptr() for t in wp]), ptr_array([t.data_ptr() for t in bp]))
+    if hint:
+        L.call("amid_sas_wgrad_rows_f32", *args, dev(dom).data_ptr(), B, T, mode, stream())
+    else:
+        L.call("amid_sas_wgrad_f32", *args, mode, stream())
+    torch.cuda.synchronize()
+    return [w.double().sum(2) for w in wp], [b_.double().sum(2) for b_ in bp]
+
+
+@pytest.mark.parametrize("B,T,hint,spread", [(6, 50, True, False), (37, 20, False, True), (256, 50, True, True), (300, 33, True, False),
+                                              (1500, 8, True, False), (3, 7, False, False)])
+def test_wgrad_split_products_have_fp32_accuracy(L, B, T, hint, spread):
+    """amid_sas_wgrad(_rows)_f32 in modes 2 and 3 (compute = "fp32": every operand as three bf16 pieces, nine / six piece pairs on
+    v_mfma_f32_16x16x32_bf16) against the fp64 product dY^T X: within 1e-6 of the largest entry, and no worse than 1.5 x the error of
+    mode 0 (the fp32 matrix instructions) on the same operands + 1e-7; bias sums as mode 0's."""
+    D, M, splits = 128, B * T, 5
+    dom, dy, xx = _wgrad_case(B, T, hint, 6, B * 5 + T, spread)
+    want = [[dy[wi][gd * M:(gd + 1) * M].double().t() @ xx[wi][gd * M:(gd + 1) * M].double() for gd in range(2)] for wi in range(6)]
+    errs = {}
+    for mode in (0, 2, 3):
+        (w,), (b_,) = _wgrad_run(L, dy, xx, dom, B, T, splits, mode, hint)
+        assert torch.isfinite(w).all() and torch.isfinite(b_).all()
+        errs[mode] = max(float((w[gd, wi].view(D, D) - want[wi][gd]).abs().max() / want[wi][gd].abs().max().clamp_min(1e-30))
+                         for wi in range(6) for gd in range(2))
+        for wi in range(6):
+            for gd in range(2):
+                y = dy[wi][gd * M:(gd + 1) * M].double()
+                assert float((b_[gd, wi] - y.sum(0)).abs().max()) < 1e-4 * max(1.0, float(y.abs().sum(0).max()))
+    assert errs[2] < 1e-6 and errs[3] < 1e-6, errs
+    assert errs[2] <= 1.5 * errs[0] + 1e-7 and errs[3] <= 1.5 * errs[0] + 1e-7, errs
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_wgrad_split_two_workgroups_per_cu_repeated(L, mode):
+    """The train step's launch shape (2 layers x 6 weights x 21 splits x 2 domains = 504 workgroups, two per CU, B 256 x T 50 with the
+    live-row hint), 25 times over: every one of the 24 summed gradients within 2e-6 of the fp64 product each time (a build of this
+    kernel that zeroed the rows past a split's end by multiplication failed this in 239 of 240 launches, csrc/sasrec_bwd.hip)."""
+    B, T, D, splits = 256, 50, 128, 21
+    M = B * T
+    dom, dy, xx = _wgrad_case(B, T, True, 12, 99)
+    want = [[dy[wi][gd * M:(gd + 1) * M].double().t() @ xx[wi][gd * M:(gd + 1) * M].double() for gd in range(2)] for wi in range(12)]
+    for rep in range(25):
+        w, _ = _wgrad_run(L, dy, xx, dom, B, T, splits, mode, True)
+        for wi in range(12):
+            for gd in range(2):
+                e = float((w[wi // 6][gd, wi % 6].view(D, D) - want[wi][gd]).abs().max() / want[wi][gd].abs().max())
+                assert e < 2e-6, (rep, wi, gd, e)
+
+
 @pytest.mark.parametrize("n,world,D", [(1, 2, 64), (300, 2, 128), (5000, 4, 128), (70000, 8, 128), (2049, 16, 64), (777, 3, 128)])
 def test_owner_buckets_equal_torch_split(L, n, world, D):
     """amid_owner_count_i32 / amid_owner_buckets_f32 (the split of the owner-bucketed exchange) against the
