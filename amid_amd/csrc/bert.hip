@@ -12,6 +12,7 @@
 #include "common.h"
 #include "rng.h"
 #include "tile_gemm.h"
+#include "wgrad_split.h"
 #include "bert_math.h"
 
 namespace amid {
@@ -587,6 +588,27 @@ __global__ __launch_bounds__(GEMM_THREADS) void bert_wgrad_kernel(const BWgradAr
     }
 }
 
+#if AMID_TILE_RT == 7
+// the same tiles on the bf16 matrix cores at fp32 accuracy (csrc/wgrad_split.h): mode 2 / 3 of amid_bert_wgrad_mode_f32
+template <int NTERM, bool HINT>
+__global__ __launch_bounds__(GEMM_THREADS, 4) void bert_wgrad_split_kernel(const BWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = BD;
+    const int split = blockIdx.x, e = blockIdx.y, g = blockIdx.z;
+    const WgsRows rw{a.M, a.splits, a.rows_per_split, a.row_domain, a.B, a.T};
+    f32x4 acc[8];
+    wgrad_split_tile<NTERM, HINT>(smem, a.dy[e], a.ldy[e], a.x[e], a.ldx[e], g, split, rw, acc,
+                                  a.b_part + (((long long)g * a.n_ent + e) * a.splits + split) * D);
+    const int w = wave_id(), lane = lane_id(), i = lane & 15, gq = lane >> 4;
+    const int ldw = a.ldw[e];
+    float* wp = a.w_part + ((long long)g * a.n_ent + a.wgrp[e]) * a.splits * D * D + (long long)split * ldw * D + a.wcol[e];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wp[(long long)(w * 16 + gq * 4 + r) * ldw + t * 16 + i] = acc[t][r];
+}
+#endif
+
 // out[c][r] = in[r][c] for rectangular matrices (rows, cols multiples of 32)
 struct BTransArgs { const float* src[32]; float* dst[32]; int rows[32], cols[32]; int n; };
 __global__ __launch_bounds__(256) void transpose_rect_kernel(const BTransArgs a) {
@@ -723,7 +745,7 @@ extern "C" int AMID_ENTRY(amid_bert_qkv_bwd_f32)(const float* dq, const float* d
 #if AMID_TILE_RT == 7      // independent of the row-tile height: one copy only
 static int bert_wgrad(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
                       const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part, float* b_part,
-                      const long long* row_domain, int B, int T, void* stream) {
+                      const long long* row_domain, int B, int T, void* stream, int mode = 0) {
     AMID_CHECK_ARG(dy && x && ldy && ldx && out_ld && out_group && out_col && w_part && b_part && n_ent > 0 && n_ent <= BW_MAX && M > 0 &&
                    splits > 0);
     BWgradArgs a;
@@ -736,6 +758,24 @@ static int bert_wgrad(const float* const* dy, const float* const* x, const int* 
     a.w_part = w_part; a.b_part = b_part; a.n_ent = n_ent; a.M = M; a.splits = splits; a.rows_per_split = (M + splits - 1) / splits;
     AMID_CHECK_ARG(!row_domain || (B > 0 && T > 0 && (long long)B * T == M));
     a.row_domain = (row_domain && a.rows_per_split / T + 2 <= BWG_LIVE_MAX) ? row_domain : nullptr; a.B = B; a.T = T;
+    if (mode == 2 || mode == 3) {          // fp32 operands as three bf16 pieces each, nine / six piece pairs
+        static_assert(BWG_LIVE_MAX == WGS_LIVE_MAX, "one window size");
+        const size_t lds = WGS_LDS_FIXED + WGS_LIVE_MAX * sizeof(int);
+        static unsigned long long done[4] = {0, 0, 0, 0};
+        const dim3 grid(splits, n_ent, 2);
+#define AMID_BWGS_LAUNCH(NT, H, SLOT)                                                                                              \
+        do {                                                                                                                   \
+            if (int e = lds_attr_once((const void*)bert_wgrad_split_kernel<NT, H>, lds, done[SLOT])) return e;                    \
+            bert_wgrad_split_kernel<NT, H><<<grid, GEMM_THREADS, lds, (hipStream_t)stream>>>(a);                                   \
+        } while (0)
+        const bool h = a.row_domain != nullptr;
+        if (mode == 2) { if (h) AMID_BWGS_LAUNCH(9, true, 0); else AMID_BWGS_LAUNCH(9, false, 1); }
+        else { if (h) AMID_BWGS_LAUNCH(6, true, 2); else AMID_BWGS_LAUNCH(6, false, 3); }
+#undef AMID_BWGS_LAUNCH
+        AMID_LAUNCH_CHECK();
+        return AMID_OK;
+    }
+    if (mode != 0) return AMID_ERR_ARG;
     const size_t lds = (size_t)2 * BWG_ROWS * (BD + 16) * sizeof(float) + BWG_LIVE_MAX * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
@@ -759,6 +799,14 @@ extern "C" int amid_bert_wgrad_rows_f32(const float* const* dy, const float* con
                                         const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part,
                                         float* b_part, const long long* row_domain, int B, int T, void* stream) {
     return bert_wgrad(dy, x, ldy, ldx, out_ld, out_group, out_col, n_ent, M, splits, w_part, b_part, row_domain, B, T, stream);
+}
+
+// either of the two with the products' mode: 0 = fp32 matrix instructions (as above), 2 / 3 = every fp32 operand as three bf16 pieces,
+// nine / six piece pairs on v_mfma_f32_16x16x32_bf16 (csrc/wgrad_split.h); row_domain may be NULL (every row walked)
+extern "C" int amid_bert_wgrad_mode_f32(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
+                                        const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part,
+                                        float* b_part, const long long* row_domain, int B, int T, int mode, void* stream) {
+    return bert_wgrad(dy, x, ldy, ldx, out_ld, out_group, out_col, n_ent, M, splits, w_part, b_part, row_domain, B, T, stream, mode);
 }
 
 extern "C" int amid_transpose_rect_f32(const float* const* src, float* const* dst, const int* rows, const int* cols, int n, void* stream) {

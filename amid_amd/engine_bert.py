@@ -81,7 +81,10 @@ class BertPlan(SasrecPlan):
         self.ln2_part = [f(2 * self.tpg_b, 2, D) for _ in range(2)]
         self.dz, self.dt, self.dx1 = f(2 * M, D), f(2 * M, D), f(2 * M, D)
         self.dpre = f(2 * M, F)
-        self.splits = max(1, min(int(os.environ.get("AMID_BERT_WGRAD_SPLITS", "10")), M // 128))          # 2 domains x 12 tiles x 10 splits = 240 workgroups
+        # 2 domains x 12 tiles x splits workgroups: 21 splits = 504, two per CU, for the bf16-piece products (72 KB of LDS each); 10 = 240,
+        # one per CU, for the fp32 matrix instructions (AMID_WGRAD_SPLIT=0).  Measured step 0.6239 (21) / 0.6252 (10) / 0.6398 (14) ms
+        default_splits = "21" if os.environ.get("AMID_WGRAD_SPLIT", "6") in ("6", "9") else "10"
+        self.splits = max(1, min(int(os.environ.get("AMID_BERT_WGRAD_SPLITS", default_splits)), M // 128))
         self.w_part = [f(2, N_ENT, self.splits, D * D) for _ in range(2)]
         self.b_part = [f(2, N_ENT, self.splits, D) for _ in range(2)]
 
@@ -348,9 +351,10 @@ class Bert4recEngine(SasrecEngine):
                 dy.append(pl.dpre.data_ptr() + 4 * c * D); xx.append(pl.y2[l].data_ptr()); ldy.append(F); ldx.append(D)
             for c in range(4):                                   # w_2 tile c: dY = dz, X = h[:, c*128:]
                 dy.append(pl.dz.data_ptr()); xx.append(pl.h[l].data_ptr() + 4 * c * D); ldy.append(D); ldx.append(F)
-            L.call("amid_bert_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), (ctypes.c_int * N_ENT)(*ldy), (ctypes.c_int * N_ENT)(*ldx),
+            L.call("amid_bert_wgrad_mode_f32", ptr_array(dy), ptr_array(xx), (ctypes.c_int * N_ENT)(*ldy), (ctypes.c_int * N_ENT)(*ldx),
                    (ctypes.c_int * N_ENT)(*old), (ctypes.c_int * N_ENT)(*ogr), (ctypes.c_int * N_ENT)(*oco), N_ENT, M,
-                   pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), self._own_rows(pl), B, T, s)
+                   pl.splits, pl.w_part[l].data_ptr(), pl.b_part[l].data_ptr(), self._own_rows(pl), B, T,
+                   {"9": 2, "6": 3}.get(self.WGRAD_SPLIT, 0), s)
 
         if pl.strip:
             # csrc/bert_strip.hip: block 1's feed-forward / out-projection chain, its attention core and weight gradients, then ONE launch

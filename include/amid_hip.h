@@ -720,6 +720,13 @@ int amid_bert_wgrad_rows_f32(const float* const* dy, const float* const* x, cons
                              const long long* row_domain, int B, int T, void* stream);
 
 
+/* amid_bert_wgrad(_rows)_f32 with the products' mode: 0 = fp32 matrix instructions; 2 / 3 = every fp32 operand as three bf16 pieces whose
+ * sum is the operand exactly, nine / six piece pairs on v_mfma_f32_16x16x32_bf16 (csrc/wgrad_split.h; fp32 accuracy, see amid_sas_wgrad_f32).
+ * row_domain may be NULL (every row is walked) */
+int amid_bert_wgrad_mode_f32(const float* const* dy, const float* const* x, const int* ldy, const int* ldx, const int* out_ld,
+                             const int* out_group, const int* out_col, int n_ent, int M, int splits, float* w_part, float* b_part,
+                             const long long* row_domain, int B, int T, int mode, void* stream);
+
 /* the 64-row build of the BERT4Rec row-tile entry points (_rt4) and the *_rows entry points in every build */
 int amid_bert_qkv_fwd_f32_rt4(const float* x, const float* const* ln_a, const float* const* ln_b, const float* const* w3x2,
                           const float* const* b3x2, int M, int rows_per_tile, float* y, float* q, float* k, float* v, void* stream);

@@ -852,6 +852,55 @@ def test_wgrad_split_two_workgroups_per_cu_repeated(L, mode):
                 assert e < 2e-6, (rep, wi, gd, e)
 
 
+@pytest.mark.parametrize("B,T,hint", [(8, 50, True), (37, 20, False), (256, 50, True)])
+def test_bert_wgrad_modes_against_fp64(L, B, T, hint):
+    """amid_bert_wgrad_mode_f32 -- BERT4Rec's twelve 128 x 128 weight-gradient tiles of a block (q, k, v, out-projection; four column
+    tiles of w_1 [512, 128] read dY with row stride 512; four of w_2 [128, 512] read X with row stride 512 and land side by side in one
+    [128, 512] partial) -- in mode 0 (fp32 matrix instructions) and modes 2 / 3 (three bf16 pieces per operand, nine / six piece pairs):
+    every summed tile and bias within 2e-6 of the fp64 product's largest entry (1280-row splits: mode 0 measures 1.2e-6, modes 2 / 3
+    8.7e-7), modes 2 / 3 no worse than 1.5 x mode 0 + 1e-7."""
+    import ctypes
+    from amid_amd._lib import ptr_array
+    D, F, M, splits, N = 128, 512, B * T, 5, 12
+    g = torch.Generator().manual_seed(B + 7 * T)
+    dom = (torch.rand(B, generator=g) < 0.5).long()
+    live = (torch.cat((dom == 0, dom == 1)).float().repeat_interleave(T) if hint else torch.ones(2 * M))[:, None]
+    dq, dk, dv, dt, dz = (dev(torch.randn(2 * M, D, generator=g) * live) for _ in range(5))
+    dpre = dev(torch.randn(2 * M, F, generator=g) * live)
+    y, o, y2 = (dev(torch.randn(2 * M, D, generator=g)) for _ in range(3))
+    h = dev(torch.randn(2 * M, F, generator=g))
+    dy = [dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dt.data_ptr()]; xx = [y.data_ptr()] * 3 + [o.data_ptr()]
+    pairs = [(dq, y), (dk, y), (dv, y), (dt, o)]
+    ldy, ldx = [D] * 4, [D] * 4
+    old, ogr, oco = [D] * 8 + [F] * 4, list(range(8)) + [8] * 4, [0] * 8 + [c * D for c in range(4)]
+    for c in range(4):
+        dy.append(dpre.data_ptr() + 4 * c * D); xx.append(y2.data_ptr()); ldy.append(F); ldx.append(D); pairs.append((dpre[:, c * D:(c + 1) * D], y2))
+    for c in range(4):
+        dy.append(dz.data_ptr()); xx.append(h.data_ptr() + 4 * c * D); ldy.append(D); ldx.append(F); pairs.append((dz, h[:, c * D:(c + 1) * D]))
+    ci = lambda v: (ctypes.c_int * N)(*v)
+    errs = {}
+    for mode in (0, 2, 3):
+        wp = torch.full((2, N, splits, D * D), float("nan"), device="cuda"); bp = torch.full((2, N, splits, D), float("nan"), device="cuda")
+        L.call("amid_bert_wgrad_mode_f32", ptr_array(dy), ptr_array(xx), ci(ldy), ci(ldx), ci(old), ci(ogr), ci(oco), N, M, splits,
+               wp.data_ptr(), bp.data_ptr(), dev(dom).data_ptr() if hint else None, B, T, mode, stream())
+        torch.cuda.synchronize()
+        worst = 0.0
+        for e, (a_, b_) in enumerate(pairs):
+            for gd in range(2):
+                want = a_[gd * M:(gd + 1) * M].double().t() @ b_[gd * M:(gd + 1) * M].double()
+                if e < 8:
+                    got = wp[gd, e].double().sum(0).view(D, D)
+                else:                                 # the four w_2 tiles share one [splits][128][512] partial starting at entry 8
+                    got = wp[gd, 8:12].reshape(splits, D, F).double().sum(0)[:, (e - 8) * D:(e - 7) * D]
+                assert torch.isfinite(got).all(), (mode, e, gd)
+                worst = max(worst, float((got - want).abs().max() / want.abs().max().clamp_min(1e-30)))
+                bs = a_[gd * M:(gd + 1) * M].double().sum(0)
+                assert float((bp[gd, e].double().sum(0) - bs).abs().max()) < 1e-4 * max(1.0, float(a_.abs().sum(0).max())), (mode, e, gd)
+        errs[mode] = worst
+    assert all(v < 2e-6 for v in errs.values()), errs
+    assert errs[2] <= 1.5 * errs[0] + 1e-7 and errs[3] <= 1.5 * errs[0] + 1e-7, errs
+
+
 @pytest.mark.parametrize("n,world,D", [(1, 2, 64), (300, 2, 128), (5000, 4, 128), (70000, 8, 128), (2049, 16, 64), (777, 3, 128)])
 def test_owner_buckets_equal_torch_split(L, n, world, D):
     """amid_owner_count_i32 / amid_owner_buckets_f32 (the split of the owner-bucketed exchange) against the
