@@ -162,7 +162,9 @@ __global__ void pack_indices_pool_kernel(const long long* __restrict__ pool, lon
 // re-masking (model_seq.py:383) and for backward.  pos == nullptr (BERT4Rec: no positional table,
 // no embedding dropout, no mask) degrades to the plain gather for every row.
 // ---------------------------------------------------------------------------------------------
-template <int RIF>
+// FOLD: the lazy-Adam replay and the sort rider compiled in (amid_embed_fwd_replay_f32).  The plain build must not carry them: with both
+// in one kernel the gather ran at 178 VGPRs / 6.4 KB of LDS instead of 109 / 0 and cfg 5's K1 went from 52.8 to 81.4 us.
+template <int RIF, bool FOLD>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ table, const int* __restrict__ idx_all,
                                                         const float* __restrict__ pos0, const float* __restrict__ pos1,
                                                         int B, int T, int D, int n_item_rows,
@@ -173,8 +175,11 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
                                                         const int* __restrict__ last, const StepState* __restrict__ adam_st, const SortRider rd) {
     // rider: the first workgroups run phase 1 of the step's index sort (sort_phases.h) beside the gather (it rode in the catch-up
     // launch while that launch existed)
-    const int nrb = rider_blocks(rd);
-    if ((int)blockIdx.x < nrb) { sort_phase_ct<1024, 1>(rd.plan, blockIdx.x); return; }
+    int nrb = 0;
+    if constexpr (FOLD) {
+        nrb = rider_blocks(rd);
+        if ((int)blockIdx.x < nrb) { sort_phase_ct<1024, 1>(rd.plan, blockIdx.x); return; }
+    }
     const int bid = blockIdx.x - nrb;
     const int sub = threadIdx.x & 31;
     const int hw = bid * (blockDim.x >> 5) + (threadIdx.x >> 5);
@@ -193,12 +198,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
     // steps last + 1 .. t - 1 (adam.hip): they are replayed HERE, in registers, for the value the forward reads -- nothing is written;
     // the optimizer launch of this step, which visits exactly the rows that were gathered, replays the same steps again (the same bits:
     // adam_replay.h) in front of the real step and stamps the row.  No launch of its own, no ordering between workgroups.
-    __shared__ IdleCoef ctab[COEF_TAB];
-    const bool replay = last != nullptr;
     StepState stv = {};
     long long t_now = 0;
     bool any_lag = false;
-    if (replay) {
+    [[maybe_unused]] IdleCoef* ctab = nullptr;
+    if constexpr (FOLD) {
+        __shared__ IdleCoef ctab_s[COEF_TAB];
+        ctab = ctab_s;
         stv = *adam_st;
         t_now = stv.step;
         bool mine_lag = false;                          // first sweep: does any position of this block lag at all? (usually not)
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
             }
             my_row = r;
             my_src = idx_all[r];
-            if (any_lag) my_last = last[my_src];
+            if constexpr (FOLD) { if (any_lag) my_last = last[my_src]; }
             // the walk over the live sequences is the step's compact index list: the id at every walk position and the row of the
             // full layout its gradient will stand in (what the sort, the segment reduce and the row Adam of the step then run on)
             if (idx_c != nullptr) { idx_c[mine] = my_src; row_c[mine] = r; }
@@ -248,12 +254,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
         const int n_here = min(chunk, n_walk - c0);
         for (int u0 = 0; u0 < n_here; u0 += RIF) {
             long long src[RIF];
-            int row[RIF], lst[RIF];
+            int row[RIF];
+            [[maybe_unused]] int lst[RIF];
 #pragma unroll
             for (int u = 0; u < RIF; ++u) {
                 src[u] = __shfl(my_src, half + ((u0 + u) & 31), 64);
                 row[u] = __shfl(my_row, half + ((u0 + u) & 31), 64);
-                lst[u] = any_lag ? __shfl(my_last, half + ((u0 + u) & 31), 64) : 0;
+                if constexpr (FOLD) lst[u] = any_lag ? __shfl(my_last, half + ((u0 + u) & 31), 64) : 0;
             }
             unsigned kbits[RIF];                       // the 32-bit word of row u's call that holds this lane's column quad (c = sub)
 #pragma unroll
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
                     const f32x4 t = __builtin_nontemporal_load((const f32x4*)(table + src[u] * D + 4 * c));
                     v[u] = make_float4(t[0], t[1], t[2], t[3]);
                 }
-                if (any_lag) {
+                if constexpr (FOLD) if (any_lag) {
 #pragma unroll
                     for (int u = 0; u < RIF; ++u) {
                         if (u0 + u < n_here && lst[u] > 0 && lst[u] < t_now - 1) {      // (uniform over the half-wave: it shares the row)
@@ -554,9 +561,14 @@ static int embed_fwd(const float* table, const int* idx_all, const float* pos0, 
     const long long n_walk = (live != nullptr ? 1LL : 2LL) * B * T + n_item_rows;
     const int tr = (train && pos0 != nullptr && p_drop > 0.f) ? 1 : 0;
     const int chunk = embed_chunk(n_walk);
-    embed_fwd_kernel<EMBED_RIF><<<embed_grid(n_walk, chunk) + rider_blocks_host(rd), 256, 0, (hipStream_t)stream>>>(
-        table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, (const RngState*)rng_state, tr, keep_thr16(p_drop),
-        tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd);
+    if (last != nullptr || rd.phase != 0)
+        embed_fwd_kernel<EMBED_RIF, true><<<embed_grid(n_walk, chunk) + rider_blocks_host(rd), 256, 0, (hipStream_t)stream>>>(
+            table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, (const RngState*)rng_state, tr, keep_thr16(p_drop),
+            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd);
+    else
+        embed_fwd_kernel<EMBED_RIF, false><<<embed_grid(n_walk, chunk), 256, 0, (hipStream_t)stream>>>(
+            table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, (const RngState*)rng_state, tr, keep_thr16(p_drop),
+            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -45,6 +45,8 @@ N_ROWS = 2 * ITEM_LENGTH          # train_sr.py:456
 PAD_ID = ITEM_LENGTH + 1          # train_sr.py:451
 MAX_REAL_ID = 42441               # largest id in cloth_sport_train75
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+# the weight gradients' products (engine.SasrecEngine.WGRAD_SPLIT): six bf16 piece pairs per fp32 product by default
+WGRAD_KIND = {"6": "mfma16x6", "9": "mfma16x9"}.get(os.environ.get("AMID_WGRAD_SPLIT", "6"), "mfma")
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBPS = 8000.0
 
@@ -194,10 +196,10 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_sas_ffn_bwd_f32": ("mfma", 3 * gemm),
         "amid_sas_qkv_bwd_f32": ("mfma", 3 * gemm),
         "amid_sas_qkv_ffn_bwd_f32": ("mfma", 6 * gemm),
-        "amid_sas_wgrad_f32": ("mfma", 12 * gemm),          # both layers in one launch
+        "amid_sas_wgrad_f32": (WGRAD_KIND, 12 * gemm),          # both layers in one launch
         # the train step's own backward: of each domain only the samples of that domain carry a gradient (the loss multiplies the
         # other domain's BCE by zero, train_sr.py:205-211), the kernels walk those sequences only -- half the rows, priced as such
-        "amid_sas_wgrad_rows_f32": ("mfma", 6 * gemm),
+        "amid_sas_wgrad_rows_f32": (WGRAD_KIND, 6 * gemm),
         "amid_sas_ffn_bwd_rows_f32": ("mfma", 1.5 * gemm),
         "amid_sas_qkv_bwd_rows_f32": ("mfma", 1.5 * gemm),
         "amid_sas_qkv_ffn_bwd_rows_f32": ("mfma", 3 * gemm),
@@ -220,6 +222,7 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_bert_qkv_bwd_f32": ("mfma", 3 * gemm),
         "amid_bert_wgrad_f32": ("mfma", 12 * gemm),         # one layer per launch: q, k, v, o and the 4 + 4 tiles of w_1, w_2
         "amid_bert_wgrad_rows_f32": ("mfma", 6 * gemm),      # the live sequences only (see amid_sas_wgrad_rows_f32)
+        "amid_bert_wgrad_mode_f32": (WGRAD_KIND, 6 * gemm),  # the engine's call: live sequences, products on bf16 pieces by default
         # matrix-core kernels (H hd = D either way: SASRec 8 x 16, BERT4Rec 4 x 32); unpadded T x T products
         "amid_attn_fwd_f32": ("mfma", 4.0 * T * T * hd * 2 * Bw * H),
         "amid_attn_bwd_f32": ("mfma", 10.0 * T * T * hd * 2 * Bw * H),
@@ -238,7 +241,7 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
 KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's name in rocprofv3 output
     "amid_sas_qkv_fwd_f32": "sas_qkv_fwd_kernel", "amid_sas_oproj_fwd_f32": "sas_oproj_fwd_kernel", "amid_sas_ffn_fwd_f32": "sas_ffn_fwd_kernel",
     "amid_sas_ffn_bwd_f32": "sas_ffn_bwd_kernel", "amid_sas_qkv_bwd_f32": "sas_qkv_bwd_kernel", "amid_sas_wgrad_f32": "sas_wgrad_kernel",
-    "amid_sas_wgrad_rows_f32": "sas_wgrad_kernel", "amid_attn_bwd_rows_f32": "attn_bwd_mfma_kernel",
+    "amid_sas_wgrad_rows_f32": ("sas_wgrad_split_kernel", "sas_wgrad_kernel", "sas_wgrad16_kernel"), "amid_bert_wgrad_mode_f32": ("bert_wgrad_split_kernel", "bert_wgrad_kernel"), "amid_attn_bwd_rows_f32": "attn_bwd_mfma_kernel",
     "amid_sas_ffn_bwd_rows_f32": "sas_ffn_bwd_kernel", "amid_sas_qkv_bwd_rows_f32": "sas_qkv_bwd_kernel",
     "amid_sas_qkv_ffn_bwd_rows_f32": "sas_qkv_ffn_bwd_kernel",
     "amid_sas_qkv_ffn_bwd_f32": "sas_qkv_ffn_bwd_kernel", "amid_sas_oproj_ffn_qkv_fwd_f32": "sas_oproj_ffn_qkv_fwd_kernel",
@@ -615,6 +618,10 @@ def main():
                     ent.update(bound="hbm", achieved=round(amount / avg_s / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s")
                 elif kind == "mfma16":
                     ent.update(bound="mfma", achieved=round(amount / avg_s / 1e12, 2), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", operands="bf16")
+                elif kind.startswith("mfma16x"):    # an fp32 product as six (nine) bf16 piece products: the bf16 pipe executes 6 (9) x the algorithmic FLOP
+                    n = int(kind[7:])
+                    ent.update(bound="mfma", achieved=round(amount / avg_s / 1e12, 2), peak=round(PEAK_BF16_MFMA_TFLOPS / n, 1), unit="TFLOP/s",
+                               operands=f"fp32 as three bf16 pieces, {n} piece pairs (peak = the bf16 matrix peak / {n})")
                 else:
                     ent.update(bound="mfma", achieved=round(amount / avg_s / 1e12, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
                 ent["frac"] = round(ent["achieved"] / ent["peak"], 4)
