@@ -72,6 +72,10 @@ struct IncFwdArgs {
     float* S;                            // [2, T, D]
     float* Z;                            // [2, T, D]
     float* sw;                           // [2]
+    // data-parallel shard (amid_inc_embed_fwd_shard_f32): the B rows are samples j0 .. j0 + B - 1 of a global batch of Bg; s then holds
+    // the GLOBAL scores [2, Bg], w_bs spans Bg, and the launch is cut at the all-reduce of S: phase 1 = gates + this shard's partial S,
+    // phase 2 = Z from the summed S.  One GPU: Bg = B, j0 = 0, phase 0 (both).
+    int Bg, j0, phase;
 };
 
 __device__ __forceinline__ float block_sum256(float v, float* red) {
@@ -99,22 +103,27 @@ __global__ __launch_bounds__(256) void inc_mix_fwd_kernel(const IncFwdArgs a) {
     float* cj = smem;
     float* part = smem + ((B + 3) & ~3);
     float* Srow = part + 8 * D;
-    const float* sg = a.s + g * B;
+    const int Bg = a.Bg, j0 = a.j0;
+    const float* sg = a.s + g * Bg;                      // the softmax runs over the GLOBAL batch
+    float wsum = 0.f;
+    if (a.phase != 2) {
     float mx = -INFINITY;
-    for (int j = threadIdx.x; j < B; j += 256) mx = fmaxf(mx, sg[j]);
+    for (int j = threadIdx.x; j < Bg; j += 256) mx = fmaxf(mx, sg[j]);
     mx = block_max256(mx, red);
-    float sum = 0.f, wsum = 0.f;
-    for (int j = threadIdx.x; j < B; j += 256) { sum += expf(sg[j] - mx); wsum += a.w_bs[g][j]; }
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < Bg; j += 256) { sum += expf(sg[j] - mx); wsum += a.w_bs[g][j]; }
     sum = block_sum256(sum, red);
     wsum = block_sum256(wsum, red);
     for (int j = threadIdx.x; j < B; j += 256) {
-        const float gt = (expf(sg[j] - mx) / sum > a.threshold) ? 1.f : 0.f;
-        cj[j] = a.w_bs[g][j] * gt;
+        const float gt = (expf(sg[j0 + j] - mx) / sum > a.threshold) ? 1.f : 0.f;
+        cj[j] = a.w_bs[g][j0 + j] * gt;
         if (t == 0) a.gate[g * B + j] = gt;
     }
     if (t == 0 && threadIdx.x == 0) a.sw[g] = wsum;
     __syncthreads();
+    }
     const int sub = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    if (a.phase != 2)
     for (int c = sub; c < q; c += 32) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = rg; j < B; j += 8) {
@@ -127,12 +136,18 @@ __global__ __launch_bounds__(256) void inc_mix_fwd_kernel(const IncFwdArgs a) {
         st4(part + rg * D + 4 * c, acc);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256) {
-        float v = 0.f;
+    if (a.phase != 2) {
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v += part[k * D + d];
-        Srow[d] = v;
-        a.S[((long long)g * T + t) * D + d] = v;
+            for (int k = 0; k < 8; ++k) v += part[k * D + d];
+            Srow[d] = v;
+            a.S[((long long)g * T + t) * D + d] = v;
+        }
+        if (a.phase == 1) return;                        // the shards' partial sums are added by the caller's all-reduce
+    } else {
+        for (int d = threadIdx.x; d < D; d += 256) Srow[d] = a.S[((long long)g * T + t) * D + d];
+        wsum = a.sw[g];
     }
     __syncthreads();
     const float bias_bs = a.b_bs[g][0];
@@ -193,6 +208,11 @@ struct IncBwdArgs {
     float* rows;                         // [2, T, 2]: (sum_d dZ[t][d], sum_d dZ[t][d] b_nn[d])
     float* dw_nn[2]; float* db_nn[2]; float* dw_bs[2]; float* db_bs[2];
     float* dxg;                          // [2, B, T, D] table-row gradients (seq rows)
+    // data-parallel shard (amid_inc_bwd_shard_f32; as IncFwdArgs): phase 1 = this shard's dZ only, phase 2 = everything behind the
+    // all-reduce of dZ; gscale = 1 / world on the gradients every rank computes alike from global operands (W_nn, b_nn, b_bs -- the
+    // step's dense exchange sums the ranks); w_bs's gradient is written for the shard's own Bg-slice (the rest zeroed by the host side)
+    int Bg, j0, phase;
+    float gscale;
 };
 
 // ---- grid (T, 2): dZ[t] (fixed-order sum of the partials), dS[t] = dZ[t] W_nn, the two row sums ----
@@ -201,6 +221,9 @@ __global__ __launch_bounds__(256) void inc_dz_kernel(const IncBwdArgs a) {
     __shared__ float red[4];
     const int B = a.B, T = a.T, D = a.D;
     const int t = blockIdx.x, g = blockIdx.y;
+    if (a.phase == 2) {                  // dZ is already the world's sum
+        for (int d = threadIdx.x; d < D; d += 256) smem[d] = a.dZ[((long long)g * T + t) * D + d];
+    } else
     if (!a.dpos_part) {                  // fixed-order column sum over the batch, 256 / D interleaved partial sums per column
         const int nh = 256 / D > 0 ? 256 / D : 1;
         float* cp = smem + D;
@@ -215,17 +238,22 @@ __global__ __launch_bounds__(256) void inc_dz_kernel(const IncBwdArgs a) {
     float rs = 0.f, rb = 0.f;
     for (int d = threadIdx.x; d < D; d += 256) {
         float v = 0.f;
-        if (a.dpos_part) {
-            for (int z = 0; z < a.nsplit; ++z) v += a.dpos_part[(((long long)z * 2 + g) * 2 * T + T + t) * D + d];
+        if (a.phase == 2) {
+            v = smem[d];
         } else {
-            const int nh = 256 / D > 0 ? 256 / D : 1;
-            for (int h = 0; h < nh; ++h) v += smem[D + h * D + d];
+            if (a.dpos_part) {
+                for (int z = 0; z < a.nsplit; ++z) v += a.dpos_part[(((long long)z * 2 + g) * 2 * T + T + t) * D + d];
+            } else {
+                const int nh = 256 / D > 0 ? 256 / D : 1;
+                for (int h = 0; h < nh; ++h) v += smem[D + h * D + d];
+            }
+            smem[d] = v;
+            a.dZ[((long long)g * T + t) * D + d] = v;
         }
-        smem[d] = v;
-        a.dZ[((long long)g * T + t) * D + d] = v;
         rs += v;
         rb = fmaf(v, a.b_nn[g][d], rb);
     }
+    if (a.phase == 1) return;            // (uniform over the workgroup)
     rs = block_sum256(rs, red);
     rb = block_sum256(rb, red);
     if (threadIdx.x == 0) { a.rows[(g * T + t) * 2] = rs; a.rows[(g * T + t) * 2 + 1] = rb; }
@@ -245,17 +273,17 @@ __global__ __launch_bounds__(256) void inc_wgrad_kernel(const IncBwdArgs a) {
     for (int k = threadIdx.x; k < D; k += 256) {
         float acc = 0.f;
         for (int t = 0; t < T; ++t) acc = fmaf(a.dZ[((long long)g * T + t) * D + d], a.S[((long long)g * T + t) * D + k], acc);
-        a.dw_nn[g][(long long)d * D + k] = acc;
+        a.dw_nn[g][(long long)d * D + k] = acc * a.gscale;
     }
     float cs = 0.f;
     for (int t = threadIdx.x; t < T; t += 256) cs += a.dZ[((long long)g * T + t) * D + d];
     cs = block_sum256(cs, red);
-    if (threadIdx.x == 0) a.db_nn[g][d] = cs * a.sw[g];
+    if (threadIdx.x == 0) a.db_nn[g][d] = cs * a.sw[g] * a.gscale;
     if (d == 0) {
         float all = 0.f;
         for (int t = threadIdx.x; t < T; t += 256) all += a.rows[(g * T + t) * 2];
         all = block_sum256(all, red);
-        if (threadIdx.x == 0) a.db_bs[g][0] = all;
+        if (threadIdx.x == 0) a.db_bs[g][0] = all * a.gscale;
     }
 }
 
@@ -267,7 +295,7 @@ __global__ __launch_bounds__(256) void inc_scatter_bwd_kernel(const IncBwdArgs a
     const int j = blockIdx.x, g = blockIdx.y;
     const int sd = a.cross ? 1 - g : g;
     const float gt = a.gate[g * B + j];
-    const float cj = a.w_bs[g][j] * gt;
+    const float cj = a.w_bs[g][a.j0 + j] * gt;
     const float* e = a.xg + ((long long)sd * B + j) * T * D;
     const float* dx = a.dx0 + ((long long)sd * B + j) * 2 * T * D;     // the row's own half: tokens 0..T-1 of its 2T
     float* out = a.dxg + ((long long)sd * B + j) * T * D;
@@ -282,7 +310,7 @@ __global__ __launch_bounds__(256) void inc_scatter_bwd_kernel(const IncBwdArgs a
     float cb = 0.f;
     for (int t = threadIdx.x; t < T; t += 256) cb += a.rows[(g * T + t) * 2 + 1];
     cb = block_sum256(cb, red);
-    if (threadIdx.x == 0) a.dw_bs[g][j] = gt * dot + cb;
+    if (threadIdx.x == 0) a.dw_bs[g][a.j0 + j] = gt * dot + cb;
 }
 
 }  // namespace amid
@@ -305,10 +333,13 @@ static int comp_score(const float* xg, int B, int T, int D, int cross, float* s,
 static int comp_tokens_fwd(const float* xg, const float* s, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs,
                            const float* const* b_bs, float threshold, int cross, const float* pos0, const float* pos1, int B, int T, int D,
                            float* gate, float* S, float* Z, float* sw, float* x0, unsigned char* tmq, const void* step_state, int train,
-                           float p_drop, void* stream) {
+                           float p_drop, void* stream, int Bg = 0, int j0 = 0, int phase = 0) {
     AMID_CHECK_ARG(xg && s && w_nn && b_nn && w_bs && b_bs && gate && S && Z && sw && x0 && (!pos0 == !pos1));
     AMID_CHECK_ARG(B > 0 && T > 0 && D > 0 && (D % 4) == 0 && D <= 256 && (!train || step_state));
+    if (Bg == 0) Bg = B;
+    AMID_CHECK_ARG(phase >= 0 && phase <= 2 && j0 >= 0 && j0 + B <= Bg && (Bg == B || !cross));
     IncFwdArgs a;
+    a.Bg = Bg; a.j0 = j0; a.phase = phase;
     a.xg = xg; a.s = s; a.threshold = threshold; a.B = B; a.T = T; a.D = D; a.cross = cross ? 1 : 0; a.gate = gate; a.S = S; a.Z = Z; a.sw = sw;
     for (int g = 0; g < 2; ++g) {
         AMID_CHECK_ARG(w_nn[g] && b_nn[g] && w_bs[g] && b_bs[g]);
@@ -319,6 +350,7 @@ static int comp_tokens_fwd(const float* xg, const float* s, const float* const* 
     hipStream_t st = (hipStream_t)stream;
     inc_mix_fwd_kernel<<<dim3(T, 2), 256, lds, st>>>(a);
     AMID_LAUNCH_CHECK();
+    if (phase == 1) return AMID_OK;
     const int tr = (train && p_drop > 0.f) ? 1 : 0;
     long long blocks = ((long long)4 * B * T + 7) / 8;
     if (blocks > 16384) blocks = 16384;
@@ -331,10 +363,13 @@ static int comp_tokens_fwd(const float* xg, const float* s, const float* const* 
 static int comp_tokens_bwd(const float* dpos_part, int nsplit, int cross, const float* xg, const float* dx0, const float* gate, const float* S,
                            const float* sw, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int T,
                            int D, float* dZ, float* dS, float* rows, float* const* dw_nn, float* const* db_nn, float* const* dw_bs,
-                           float* const* db_bs, float* dxg, void* stream) {
+                           float* const* db_bs, float* dxg, void* stream, int Bg = 0, int j0 = 0, int phase = 0, float gscale = 1.f) {
     AMID_CHECK_ARG((!dpos_part || nsplit > 0) && xg && dx0 && gate && S && sw && w_nn && b_nn && w_bs && dZ && dS && rows && dw_nn && db_nn &&
                    dw_bs && db_bs && dxg && B > 0 && T > 0 && D > 0 && (D % 4) == 0 && D <= 256);
+    if (Bg == 0) Bg = B;
+    AMID_CHECK_ARG(phase >= 0 && phase <= 2 && j0 >= 0 && j0 + B <= Bg && (Bg == B || !cross));
     IncBwdArgs a;
+    a.Bg = Bg; a.j0 = j0; a.phase = phase; a.gscale = gscale;
     a.dpos_part = dpos_part; a.nsplit = nsplit; a.cross = cross ? 1 : 0; a.xg = xg; a.dx0 = dx0; a.gate = gate; a.S = S; a.sw = sw;
     a.B = B; a.T = T; a.D = D; a.dZ = dZ; a.dS = dS; a.rows = rows; a.dxg = dxg;
     for (int g = 0; g < 2; ++g) {
@@ -346,6 +381,12 @@ static int comp_tokens_bwd(const float* dpos_part, int nsplit, int cross, const 
     const int nh = 256 / D > 0 ? 256 / D : 1;
     inc_dz_kernel<<<dim3(T, 2), 256, (size_t)(1 + nh) * D * sizeof(float), st>>>(a);
     AMID_LAUNCH_CHECK();
+    if (phase == 1) return AMID_OK;
+    if (Bg > B)              // the other shards' entries of d w_bs are theirs to fill: zeros here (the dense exchange sums the ranks)
+        for (int g = 0; g < 2; ++g) {
+            hipError_t e = hipMemsetAsync(dw_bs[g], 0, (size_t)Bg * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
     inc_wgrad_kernel<<<dim3(D, 2), 256, 0, st>>>(a);
     AMID_LAUNCH_CHECK();
     inc_scatter_bwd_kernel<<<dim3(B, 2), 256, 0, st>>>(a);
@@ -373,6 +414,31 @@ extern "C" int amid_inc_bwd_f32(const float* dpos_part, int nsplit, const float*
     AMID_CHECK_ARG(dpos_part);
     return comp_tokens_bwd(dpos_part, nsplit, 0, xg, dx0, gate, S, sw, w_nn, b_nn, w_bs, B, T, D, dZ, dS, rows, dw_nn, db_nn, dw_bs, db_bs, dxg,
                            stream);
+}
+
+// ---- a data-parallel shard of the batch (B rows = samples j0 .. j0 + B - 1 of a global batch of Bg = len(trans_bs.weight)): the softmax
+// over the batch takes the GLOBAL scores s_all [2, Bg] (the ranks' amid_inc_score_f32 outputs, all-gathered per domain), S is summed
+// over the ranks between phase 1 (gates, this shard's partial S, sw) and phase 2 (Z, the encoder input); backward: phase 1 = this
+// shard's dZ, the caller all-reduces it, phase 2 = dS, the parameter gradients (W_nn, b_nn, b_bs scaled by gscale = 1 / world -- every
+// rank computes them alike and the dense exchange sums the ranks --, w_bs's own slice, zeros elsewhere) and the table-row gradients.
+extern "C" int amid_inc_embed_fwd_shard_f32(const float* xg, const float* s_all, const float* const* w_nn, const float* const* b_nn,
+                                            const float* const* w_bs, const float* const* b_bs, float threshold, const float* pos0,
+                                            const float* pos1, int B, int T, int D, int Bg, int j0, int phase, float* gate, float* S, float* Z,
+                                            float* sw, float* x0, unsigned char* tmq, const void* step_state, int train, float p_drop,
+                                            void* stream) {
+    AMID_CHECK_ARG(pos0 && pos1 && tmq && (phase == 1 || phase == 2));
+    return comp_tokens_fwd(xg, s_all, w_nn, b_nn, w_bs, b_bs, threshold, 0, pos0, pos1, B, T, D, gate, S, Z, sw, x0, tmq, step_state, train,
+                           p_drop, stream, Bg, j0, phase);
+}
+
+extern "C" int amid_inc_bwd_shard_f32(const float* dpos_part, int nsplit, const float* xg, const float* dx0, const float* gate, const float* S,
+                                      const float* sw, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B,
+                                      int T, int D, int Bg, int j0, int phase, float gscale, float* dZ, float* dS, float* rows,
+                                      float* const* dw_nn, float* const* db_nn, float* const* dw_bs, float* const* db_bs, float* dxg,
+                                      void* stream) {
+    AMID_CHECK_ARG(dpos_part && (phase == 1 || phase == 2));
+    return comp_tokens_bwd(dpos_part, nsplit, 0, xg, dx0, gate, S, sw, w_nn, b_nn, w_bs, B, T, D, dZ, dS, rows, dw_nn, db_nn, dw_bs, db_bs, dxg,
+                           stream, Bg, j0, phase, gscale);
 }
 
 // ---- the same token group in front of BERT4Rec's encoders (model_seq.py:283-294): no positional rows, no input dropout ----

@@ -442,11 +442,26 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         if self.inc_bs:      # plain gather, InnerComp's token group, then the 2T-token encoder input (csrc/innercomp.hip)
             L.call("amid_gather_rows_f32", self.table.data_ptr(), self.n_rows, D, pl.idx_all.data_ptr(), 0, shp.n_idx, pl.xg.data_ptr(), None, s)
             L.call("amid_inc_score_f32", pl.xg.data_ptr(), B, shp.T, D, pl.inc_s.data_ptr(), s)
-            L.call("amid_inc_embed_fwd_f32", pl.xg.data_ptr(), pl.inc_s.data_ptr(), self._pp("inc_d{d}.trans_nn.weight"),
-                   self._pp("inc_d{d}.trans_nn.bias"), self._pp("inc_d{d}.trans_bs.weight"), self._pp("inc_d{d}.trans_bs.bias"),
-                   self.inc_threshold, fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), B, shp.T, D, pl.inc_gate.data_ptr(),
-                   pl.inc_S.data_ptr(), pl.inc_Z.data_ptr(), pl.inc_sw.data_ptr(), pl.x[0].data_ptr(), pl.tmq.data_ptr(), st, tr,
-                   SASREC_P_DROP, s)
+            wts = (self._pp("inc_d{d}.trans_nn.weight"), self._pp("inc_d{d}.trans_nn.bias"), self._pp("inc_d{d}.trans_bs.weight"),
+                   self._pp("inc_d{d}.trans_bs.bias"))
+            out = (pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(), pl.inc_Z.data_ptr(), pl.inc_sw.data_ptr(), pl.x[0].data_ptr(),
+                   pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, s)
+            if getattr(pl, "inc_world", 1) > 1:
+                # data parallel: the softmax over the batch and Linear(bs, 1) span the GLOBAL batch (model_seq.py:465-469).  The ranks
+                # all-gather their scores (per domain, rank order = sample order), each forms the gates of its own rows and its partial
+                # token sums S, the partial sums are all-reduced, and every rank finishes Z -- the same group on every rank
+                ex = self._inc_exchange(pl)
+                for g in (0, 1):
+                    ex.all_gather_packed(pl.inc_s[g], pl.inc_s_g[g])
+                shard = (B, shp.T, D, self.inc_bs, ex.rank * B)
+                L.call("amid_inc_embed_fwd_shard_f32", pl.xg.data_ptr(), pl.inc_s_g.data_ptr(), *wts, self.inc_threshold,
+                       fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), *shard, 1, *out)
+                ex.all_reduce_dense(pl.inc_S)
+                L.call("amid_inc_embed_fwd_shard_f32", pl.xg.data_ptr(), pl.inc_s_g.data_ptr(), *wts, self.inc_threshold,
+                       fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), *shard, 2, *out)
+            else:
+                L.call("amid_inc_embed_fwd_f32", pl.xg.data_ptr(), pl.inc_s.data_ptr(), *wts, self.inc_threshold,
+                       fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), B, shp.T, D, *out)
         else:
             self._enqueue_k1(pl, fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), pl.tmq.data_ptr(), tr, SASREC_P_DROP, lf)
         def layer_ptrs(l):
@@ -576,6 +591,15 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             if pl.itc_world > 1:
                 r = self._itc_exchange(pl).rank
                 pl.u.copy_(pl.u_g[:, r * B:(r + 1) * B])
+
+    def _inc_exchange(self, pl: SasrecPlan):
+        """The exchange of the running data-parallel step (train_step_dp) for a plan that holds a shard of InnerComp's global batch."""
+        ex = getattr(self, "_dp_exchange", None)
+        if ex is None or ex.world != pl.inc_world:
+            raise ValueError(f"isInC: the batch must hold exactly bs = {self.inc_bs} rows (trans_bs is Linear(bs, 1) over the batch, "
+                             f"model_seq.py:457); a batch of 1 / {pl.inc_world} of them is a data-parallel shard and can only be stepped by "
+                             f"train_step_dp with an exchange over {pl.inc_world} ranks")
+        return ex
 
     def _itc_exchange(self, pl: SasrecPlan):
         """The exchange of the running data-parallel step (train_step_dp) for a plan that holds a shard of InterComp's global batch."""
@@ -826,11 +850,23 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                    pl.dpos_part.data_ptr(), st, tr, SASREC_P_DROP, s)
         if self.inc_bs:      # InnerComp's parameter gradients; the rows' own halves + its share -> the table-row gradient buffer
             G = self.dense.grad
-            L.call("amid_inc_bwd_f32", pl.dpos_part.data_ptr(), pl.pos_splits, pl.xg.data_ptr(), pl.dx0.data_ptr(), pl.inc_gate.data_ptr(),
-                   pl.inc_S.data_ptr(), pl.inc_sw.data_ptr(), self._pp("inc_d{d}.trans_nn.weight"), self._pp("inc_d{d}.trans_nn.bias"),
-                   self._pp("inc_d{d}.trans_bs.weight"), B, shp.T, D, pl.inc_dZ.data_ptr(), pl.inc_dS.data_ptr(), pl.inc_rows.data_ptr(),
-                   self._pp("inc_d{d}.trans_nn.weight", G), self._pp("inc_d{d}.trans_nn.bias", G), self._pp("inc_d{d}.trans_bs.weight", G),
-                   self._pp("inc_d{d}.trans_bs.bias", G), pl.dxg.data_ptr(), s)
+            head = (pl.dpos_part.data_ptr(), pl.pos_splits, pl.xg.data_ptr(), pl.dx0.data_ptr(), pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(),
+                    pl.inc_sw.data_ptr(), self._pp("inc_d{d}.trans_nn.weight"), self._pp("inc_d{d}.trans_nn.bias"),
+                    self._pp("inc_d{d}.trans_bs.weight"), B, shp.T, D)
+            outs = (pl.inc_dZ.data_ptr(), pl.inc_dS.data_ptr(), pl.inc_rows.data_ptr(), self._pp("inc_d{d}.trans_nn.weight", G),
+                    self._pp("inc_d{d}.trans_nn.bias", G), self._pp("inc_d{d}.trans_bs.weight", G), self._pp("inc_d{d}.trans_bs.bias", G),
+                    pl.dxg.data_ptr(), s)
+            if getattr(pl, "inc_world", 1) > 1:
+                # data parallel: the token group is shared by the GLOBAL batch, so its gradient dZ is the sum of every rank's pos_emb
+                # partials of rows T .. 2T - 1: all-reduced between the two phases.  W_nn / b_nn / b_bs gradients then come out alike on
+                # every rank (1 / world each: the dense exchange sums the ranks); trans_bs.weight's gradient is this rank's slice
+                ex = self._inc_exchange(pl)
+                shard = (self.inc_bs, ex.rank * B)
+                L.call("amid_inc_bwd_shard_f32", *head, *shard, 1, 1.0 / ex.world, *outs)
+                ex.all_reduce_dense(pl.inc_dZ)
+                L.call("amid_inc_bwd_shard_f32", *head, *shard, 2, 1.0 / ex.world, *outs)
+            else:
+                L.call("amid_inc_bwd_f32", *head, *outs)
         self._enqueue_grad_tail(pl, live, seq)
 
     def _enqueue_grad_tail(self, pl: SasrecPlan, live: bool = False, seq: bool = False) -> None:

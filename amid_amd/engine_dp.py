@@ -46,10 +46,17 @@ class DataParallelMixin:
         parts, merge of the sparse parts, Adam): three or four host calls, and replicas that are bit-identical by construction; the
         pair of graphs is captured per distinct (umax, dense), so callers should pass a bucketed bound (bench.py: the pool's maximum).
         dense: "gather" | "allreduce" (default: DENSE_EXCHANGE)."""
-        if self.inc_bs and exchange.active:
-            raise NotImplementedError("isInC couples the rows of a batch IN FRONT of the encoders (softmax and Linear(bs, 1) over the batch on "
-                                      "the gathered [B, T, D] rows, model_seq.py:459-472): sharding it needs the all-gather of every rank's "
-                                      "gathered rows; train it on one GPU (isItC, the module run.sh trains, is data-parallel)")
+        inc_dp = bool(self.inc_bs and exchange.active)
+        if inc_dp:
+            # InnerComp under data parallel: bs is the GLOBAL batch, the plan a shard of it; the module's softmax / Linear(bs, 1) over the
+            # batch run IN FRONT of the encoders on all-gathered scores and all-reduced token sums, and the group's gradient is all-reduced
+            # at the end of backward (engine.enqueue_train_step's isInC branches) -- collectives cannot sit inside a captured graph
+            if getattr(self, "comp", ""):
+                raise NotImplementedError("BERT4Rec(isInC / isItC) under data parallel: the token group in front of BERT4Rec's encoders is "
+                                          "sharded for SASRec only (amid_inc_*_shard_f32)")
+            if getattr(pl, "inc_world", 1) != exchange.world:
+                raise ValueError(f"isInC data parallel: bs = {self.inc_bs} must be world x the per-rank batch ({exchange.world} x {pl.shape.B})")
+            use_graph = False
         itc_dp = bool(self.itc_bs and exchange.active)
         if itc_dp:
             # InterComp under data parallel (SURVEY.md section 8(f) next-1): bs is the GLOBAL batch, the plan a shard of it; the module's
@@ -58,7 +65,7 @@ class DataParallelMixin:
             if getattr(pl, "itc_world", 1) != exchange.world:
                 raise ValueError(f"isItC data parallel: bs = {self.itc_bs} must be world x the per-rank batch ({exchange.world} x {pl.shape.B})")
             use_graph = False
-        self._dp_exchange = exchange if itc_dp else None
+        self._dp_exchange = exchange if (itc_dp or inc_dp) else None
         try:
             self._train_step_dp(pl, exchange, use_graph, umax, dense)
         finally:

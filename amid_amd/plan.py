@@ -177,9 +177,15 @@ class SasrecPlan:
         # the gathered seq rows ARE the encoder input, except with isInC (the encoder input has 2T tokens per row)
         self.x = [self.xg[: 2 * M] if not inc else f(2 * M, D), f(2 * M, D), f(2 * M, D)]
         if inc:
-            if B != inc:
+            # B == bs: the whole batch on this GPU.  world * B == bs: a data-parallel shard of a global batch of bs rows -- the module's
+            # softmax over the batch and Linear(bs, 1) span the GLOBAL batch (engine._enqueue_inc_fwd / _bwd: the ranks all-gather
+            # their scores and all-reduce the partial token sums S and dZ)
+            if B != inc and (inc % B or inc // B > 64):
                 raise ValueError(f"isInC: the batch must hold exactly bs = {inc} rows (trans_bs is Linear(bs, 1) over the batch, "
-                                 f"model_seq.py:457), got {B}")
+                                 f"model_seq.py:457) or an equal data-parallel shard of them, got {B}")
+            self.inc_world = inc // B
+            if self.inc_world > 1:
+                self.inc_s_g = f(2, inc)
             self.inc_s, self.inc_gate, self.inc_sw = f(2, B), f(2, B), f(2)
             self.inc_S, self.inc_Z = f(2, T, D), f(2, T, D)
         self.q = [f(2 * M, D) for _ in range(2)]

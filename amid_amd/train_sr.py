@@ -226,7 +226,7 @@ def main(argv=None):
             trains.append(DeviceBatches(ds_train, args.bs, shuffle=True, device=args.device, seed=i, rank=rank, world=world))
             # (isItC under data parallel: InterComp's Linear(bs, 1) is built for the GLOBAL batch of world x --bs rows, so the
             # evaluation, which every rank runs whole, steps through batches of that size)
-            vals.append(DeviceBatches(ds_val, args.bs * (world if args.isItC else 1), shuffle=False, device=args.device, seed=i))
+            vals.append(DeviceBatches(ds_val, args.bs * (world if (args.isItC or args.isInC) else 1), shuffle=False, device=args.device, seed=i))
         if len(parts) == 2:
             # joint mode: the second dataset's ids sit item_length + 2 rows behind the first's in the reference-sized table of
             # 2 * item_length rows (train_sr.py:456) -- checked here, on the host, before any step runs (the fused step would only flag an
@@ -244,7 +244,7 @@ def main(argv=None):
             raise SystemExit(f"unknown --model {args.model!r} (gru4rec | sasrec | bert4rec)")
         torch.cuda.set_device(torch.device(args.device))
         model = cls(user_length=user_length, user_emb_dim=args.emb_dim, item_length=item_length, item_emb_dim=args.emb_dim,
-                    seq_len=args.seq_len, hid_dim=args.hid_dim, bs=args.bs * (world if args.isItC else 1), isInC=args.isInC, isItC=args.isItC,
+                    seq_len=args.seq_len, hid_dim=args.hid_dim, bs=args.bs * (world if (args.isItC or args.isInC) else 1), isInC=args.isInC, isItC=args.isItC,
                     threshold1=args.ts1,
                     threshold2=args.ts2, lr=args.lr, seed=i, **({"compute": "bf16"} if args.dtype == "bf16" else {}))
         exchange = None

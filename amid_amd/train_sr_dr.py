@@ -130,7 +130,7 @@ def main(argv=None):
     rank, world = base.init_data_parallel(args)
     if world > 1 and args.model.lower() != "sasrec":
         raise SystemExit("data-parallel train_sr_dr.py: --model sasrec")
-    gbs = args.bs * (world if args.isItC else 1)
+    gbs = args.bs * (world if (args.isItC or args.isInC) else 1)
     summary = []
     for i in range(args.seeds):
         torch.manual_seed(i); np.random.seed(i); random.seed(i)                           # train_sr_dr.py:624-627

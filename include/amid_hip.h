@@ -417,6 +417,19 @@ int amid_inc_bwd_f32(const float* dpos_part, int nsplit, const float* xg, const 
                      const float* sw, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int T,
                      int D, float* dZ, float* dS, float* rows, float* const* dw_nn, float* const* db_nn, float* const* dw_bs,
                      float* const* db_bs, float* dxg, void* stream);
+/* a data-parallel shard of InnerComp's batch (B rows = samples j0 .. j0 + B - 1 of the Bg = len(trans_bs.weight) rows the module spans,
+ * model_seq.py:457): s_all [2, Bg] = the ranks' amid_inc_score_f32 outputs all-gathered per domain.  phase 1: gates, this shard's partial S
+ * [2, T, D], sw; the caller all-reduces S; phase 2: Z and the encoder input.  Backward: phase 1 = this shard's dZ [2, T, D]; the caller
+ * all-reduces it; phase 2 = dS, the parameter gradients (W_nn, b_nn, b_bs times gscale = 1 / world: every rank computes them alike and
+ * the dense exchange sums the ranks; w_bs: this shard's slice, zeros elsewhere) and the table-row gradients */
+int amid_inc_embed_fwd_shard_f32(const float* xg, const float* s_all, const float* const* w_nn, const float* const* b_nn,
+                                 const float* const* w_bs, const float* const* b_bs, float threshold, const float* pos0, const float* pos1,
+                                 int B, int T, int D, int Bg, int j0, int phase, float* gate, float* S, float* Z, float* sw, float* x0,
+                                 unsigned char* tmq, const void* step_state, int train, float p_drop, void* stream);
+int amid_inc_bwd_shard_f32(const float* dpos_part, int nsplit, const float* xg, const float* dx0, const float* gate, const float* S,
+                           const float* sw, const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int B, int T, int D,
+                           int Bg, int j0, int phase, float gscale, float* dZ, float* dS, float* rows, float* const* dw_nn,
+                           float* const* db_nn, float* const* dw_bs, float* const* db_bs, float* dxg, void* stream);
 
 /* ---- the comp modules in front of BERT4Rec's encoders (isInC model_seq.py:283-286, isItC :289-294) -------------------------
  * replaces: InnerComp.forward (:459-472) / InterComp.forward (:483-497) as BERT4Rec calls them -- on the gathered rows, before

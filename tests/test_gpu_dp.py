@@ -243,6 +243,106 @@ def test_two_rank_dp_with_intercomp_matches_global_batch_oracle():
         assert float(d.max()) < 1e-4, (k, float(d.max()))
 
 
+INC = dict(n_items=300, D=64, T=20, hid=16, B=8, K=3, seed=17, lr=1e-3, ts1=0.13)
+
+
+def _inc_params_and_batches():
+    c = INC
+    P = orc.random_params(orc.sasrec_param_shapes(c["n_items"], c["D"], c["T"], c["hid"], inc_bs=c["B"]), seed=50 + c["D"] + c["T"])
+    P["item_emb_layer.emb_item.weight"] *= 3.0          # self pair-max scores a few units apart: the batch softmax is not flat
+    batches = []
+    for t in range(c["K"]):
+        g = torch.Generator().manual_seed(90 + t)
+        b = orc.synthetic_batch(c["B"], c["T"], c["n_items"] - 1, pad_id=c["n_items"] - 1, neg=1, seed=700 + t)
+        b["seq_d1"] = torch.randint(1, c["n_items"] - 1, (c["B"], c["T"]), generator=g)
+        b["seq_d2"] = torch.randint(1, c["n_items"] - 1, (c["B"], c["T"]), generator=g)
+        batches.append(b)
+    return P, batches
+
+
+def _inc_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from amid_amd.dist import SparseDenseExchange, shard_batch
+        from amid_amd.engine import SasrecEngine
+        c = INC
+        torch.cuda.set_device(0)
+        P, batches = _inc_params_and_batches()
+        # bs = the GLOBAL batch: InnerComp's Linear(bs, 1) and its softmax span every rank's rows
+        eng = SasrecEngine(c["n_items"], c["D"], c["T"], c["hid"], device="cuda:0", lr=c["lr"], seed=SasrecEngine.rank_seed(c["seed"], rank),
+                           inc_bs=c["B"], inc_threshold=c["ts1"])
+        eng.load_state_dict(P)
+        Bl = c["B"] // world
+        pl = eng.plan(Bl, c["T"], 2, need_grad=True)
+        assert pl.inc_world == world
+        ex = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=True)
+        gates = []
+        for batch in batches:
+            local = {k: v.cuda() for k, v in shard_batch(batch, rank, world).items()}
+            eng.load_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"], local["domain_id"])
+            eng.train_step_dp(pl, ex, use_graph=True)          # (asked for graphs: the step must fall back to eager launches by itself)
+            eng.sync()
+            gates.append(pl.inc_gate.cpu().clone())
+        eng.flush_table()
+        eng.sync()
+        sd = {k: v.cpu().numpy().copy() for k, v in eng.state_dict().items()}
+        try:                                                   # a shard outside a data-parallel step is refused, loudly
+            eng.enqueue_train_step(pl)
+            refused = False
+        except ValueError:
+            refused = True
+        eng.sync()
+        q.put((rank, sd, [g.numpy().copy() for g in gates], refused))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_dp_with_innercomp_matches_global_batch_oracle():
+    """isInC under data parallel: InnerComp's softmax over the batch and Linear(bs, 1) (model_seq.py:459-472) span the GLOBAL batch IN
+    FRONT of the encoders -- each rank holds half of the rows; the ranks all-gather their self pair-max scores, all-reduce the partial
+    token sums S forward and the group's gradient dZ backward (amid_inc_*_shard_f32).  Both replicas end bit-identical and equal to
+    ONE process stepping the oracle (isInC=True, dense Adam) over the global batches; every rank's gates are its rows of the global
+    softmax's."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_inc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    c = INC
+    P, batches = _inc_params_and_batches()
+    opt = orc.DenseAdam(P, lr=c["lr"])
+    Bl = c["B"] // world
+    from amid_amd.engine import SasrecEngine
+    for t, batch in enumerate(batches, start=1):
+        per_rank = [orc.philox_masks_sasrec(Bl, 2 * c["T"], c["D"], seed=SasrecEngine.rank_seed(c["seed"], r), step=t) for r in range(world)]
+        masks = {k: torch.cat([m[k] for m in per_rank], 0) for k in per_rank[0]}
+        taps = {}
+        orc.sasrec_forward(P, batch["i_node"], batch["neg_samples"], batch["seq_d1"], batch["seq_d2"], masks, taps, isInC=True, threshold1=c["ts1"])
+        for d in (1, 2):
+            gate = taps[f"inc_d{d}"]["gate"]
+            assert 0 < int(gate.sum()) < c["B"] and taps[f"inc_d{d}"]["margin"] > 1e-4, (gate, taps[f"inc_d{d}"]["margin"])
+            for o in outs:
+                r = o[0]
+                assert torch.equal(torch.from_numpy(o[2][t - 1][d - 1]), gate[r * Bl:(r + 1) * Bl]), (t, d, r)
+        orc.train_step("sasrec", P, opt, batch, masks, isInC=True, threshold1=c["ts1"])
+    assert all(o[3] for o in outs)
+    sd0, sd1 = ({k: torch.from_numpy(v) for k, v in o[1].items()} for o in outs)
+    for k, v in P.items():
+        assert torch.equal(sd0[k], sd1[k]), f"replicas diverged on {k}"
+        d = (sd0[k] - v).abs()
+        if k.endswith("in_proj_bias"):
+            n = v.numel() // 3
+            d = torch.cat((d[:n], d[2 * n:]))
+        assert float(d.max()) < 1e-4, (k, float(d.max()))
+
+
 def _dr_cli_worker(rank, world, port, root, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD_SIZE=str(world),
                       RANK=str(rank), LOCAL_RANK=str(rank), AMID_DIST_BACKEND="gloo")
@@ -314,9 +414,11 @@ def _cli_worker(rank, world, port, root, q, dm="toy", extra=()):
 
 
 @pytest.mark.timeout(600)
-def test_train_sr_cli_data_parallel_two_ranks(tmp_path):
+@pytest.mark.parametrize("extra", [(), ("--isInC", "True", "--ts1", "0.02"), ("--isItC", "True", "--ts2", "0.02")], ids=["plain", "isInC", "isItC"])
+def test_train_sr_cli_data_parallel_two_ranks(tmp_path, extra):
     """The CLI under a two-process launch (what torch.distributed.run sets up): ranks shard every global batch, exchange
-    gradients each step and must end with bit-identical parameters and identical metrics."""
+    gradients each step and must end with bit-identical parameters and identical metrics -- plain, with --isInC and with --isItC
+    (the comp module then spans the GLOBAL batch of world x --bs rows; the evaluation steps through batches of that size)."""
     import numpy as np
     from tests.test_gpu_module import _write_csv
     rng = np.random.default_rng(1)
@@ -327,7 +429,7 @@ def test_train_sr_cli_data_parallel_two_ranks(tmp_path):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_cli_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_cli_worker, args=(r, world, port, str(tmp_path), q, "toy", extra)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])
@@ -337,6 +439,8 @@ def test_train_sr_cli_data_parallel_two_ranks(tmp_path):
     (_, sd0, m0), (_, sd1, m1) = outs
     for k in sd0:
         assert np.array_equal(sd0[k], sd1[k]), k
+    if extra and extra[0] == "--isInC":
+        assert sd0["inc_d1.trans_bs.weight"].shape[-1] == 2 * 16 and sd0["sac1.pos_emb.weight"].shape[0] == 2 * 20
     assert m0 == m1 and all(0.0 <= v <= 1.0 for v in m0.values())
 
 
