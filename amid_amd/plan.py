@@ -292,7 +292,7 @@ class SasrecPlan:
         # end of backward (2 layers x 2 domains x 6 weights x 21 splits = 504 workgroups, two per CU)
         self.dpre1, self.dpre2, self.dr = ([f(2 * M, D), f(2 * M, D)] for _ in range(3))
         self.dq_l, self.dk_l, self.dv_l = [self.dq, f(2 * M, D)], [self.dk, f(2 * M, D)], [self.dv, f(2 * M, D)]
-        self.splits = max(1, min(21, M // 128))
+        self.splits = max(1, min(int(os.environ.get("AMID_WGRAD_SPLITS", "21")), M // 128))
         self.w_part = [f(2, 6, self.splits, D * D) for _ in range(2)]
         self.b_part = [f(2, 6, self.splits, D) for _ in range(2)]
         self.pos_splits = max(1, min(8, B // 16))
