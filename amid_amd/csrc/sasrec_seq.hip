@@ -23,6 +23,7 @@
 #include "strip_gemm.h"
 #include "attention_mfma.h"
 #include "seq_fwd.h"
+#include "bf16_pieces.h"
 
 namespace amid {
 
@@ -439,7 +440,7 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
                         const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
                         float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
                         const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
-                        const void* step_state, int train, float p_drop, const void* w16, void* stream) {
+                        const void* step_state, int train, float p_drop, const void* w16, void* stream, int w16_planes = 1) {
     AMID_CHECK_ARG(n_layers >= 1 && n_layers <= 2 && x_in && xout && ln1_w && ln1_b && w_in && b_in && w_o && b_o && ln2_w && ln2_b && w1 && b1 &&
                    w2 && b2 && qn && q && k && v && o && stats && r && y && h && (!train || step_state));
     if (!amid_sas_seq_supported(B, T, D, H)) return AMID_ERR_UNSUPPORTED;
@@ -458,7 +459,7 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
         P.r = r[l]; P.y = y[l]; P.h = h[l];
     }
     a.x0 = x_in[0]; a.xout = xout; a.tmq = tmq; a.ln_eps = ln_eps;
-    a.w16 = (const unsigned short*)w16;
+    a.w16 = (const unsigned short*)w16; a.w16_planes = w16_planes;
     a.att_scale = sqrtf(1.0f / (float)(D / H));
     a.st = (const StepState*)step_state;
     a.train = (train && p_drop > 0.f) ? 1 : 0;
@@ -526,14 +527,15 @@ extern "C" int amid_sas_seq_fwd_bf16w_f32(int n_layers, const float* const* x_in
 // group supplies in k-step s of v_mfma_f32_16x16x32_bf16 when the other operand sits in the strip kernels' C layout (csrc/sasrec_seqn.hip).
 namespace amid {
 struct W16Args { const float* src[48]; int n; };
-__global__ __launch_bounds__(256) void weights_bf16_kernel(const W16Args a, unsigned short* __restrict__ dst, int D, int transposed) {
+// planes = 3: every element as hi + mid + lo (csrc/bf16_pieces.h), one image per piece: dst [n][3][D][D] bf16
+__global__ __launch_bounds__(256) void weights_bf16_kernel(const W16Args a, unsigned short* __restrict__ dst, int D, int transposed, int planes) {
     const float* __restrict__ W = a.src[blockIdx.y];
-    unsigned short* __restrict__ out = dst + (size_t)blockIdx.y * D * D;
+    unsigned short* __restrict__ out = dst + (size_t)blockIdx.y * planes * D * D;
     const int cpr = D / 8;
     for (int q = blockIdx.x * 256 + threadIdx.x; q < D * cpr; q += gridDim.x * 256) {
         const int n = q / cpr, c = q % cpr;
         const int s = c >> 2, g = c & 3;
-        unsigned pk[4];
+        unsigned pk[3][4];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -541,22 +543,47 @@ __global__ __launch_bounds__(256) void weights_bf16_kernel(const W16Args a, unsi
                 const int k = 32 * s + 16 * h + 4 * g + 2 * e;
                 const float v0 = transposed ? W[(size_t)k * D + n] : W[(size_t)n * D + k];
                 const float v1 = transposed ? W[(size_t)(k + 1) * D + n] : W[(size_t)n * D + k + 1];
-                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                pk[2 * h + e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{v0, v1}, bf2));
+                const WgSplit2 sp = wg_split3(v0, v1);        // (hi = the round-to-nearest-even bf16 pair of the one-plane image)
+                pk[0][2 * h + e] = sp.hi; pk[1][2 * h + e] = sp.mid; pk[2][2 * h + e] = sp.lo;
             }
-        *reinterpret_cast<uint4*>(out + (size_t)q * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        for (int p = 0; p < planes; ++p)
+            *reinterpret_cast<uint4*>(out + (size_t)p * D * D + (size_t)q * 8) = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
     }
 }
 }  // namespace amid
 
-extern "C" int amid_sas_weights_bf16(const float* const* src, int n, int D, int transposed, void* dst16, void* stream) {
-    AMID_CHECK_ARG(src && dst16 && n > 0 && n <= 48 && D > 0 && (D % 32) == 0);
+static int weights_bf16(const float* const* src, int n, int D, int transposed, int planes, void* dst16, void* stream) {
+    AMID_CHECK_ARG(src && dst16 && n > 0 && n <= 48 && D > 0 && (D % 32) == 0 && (planes == 1 || planes == 3));
     amid::W16Args a;
     a.n = n;
     for (int i = 0; i < n; ++i) { AMID_CHECK_ARG(src[i]); a.src[i] = src[i]; }
     const int per = (D * (D / 8) + 255) / 256;
-    amid::weights_bf16_kernel<<<dim3(per, n), 256, 0, (hipStream_t)stream>>>(a, (unsigned short*)dst16, D, transposed);
+    amid::weights_bf16_kernel<<<dim3(per, n), 256, 0, (hipStream_t)stream>>>(a, (unsigned short*)dst16, D, transposed, planes);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+
+extern "C" int amid_sas_weights_bf16(const float* const* src, int n, int D, int transposed, void* dst16, void* stream) {
+    return weights_bf16(src, n, D, transposed, 1, dst16, stream);
+}
+
+// planes = 3: three images per matrix, dst16 [n][3][D][D] bf16 -- every element as hi + mid + lo, three bf16 pieces whose sum is the
+// fp32 element exactly (csrc/bf16_pieces.h): what amid_sas_seq_fwd_split_f32 consumes
+extern "C" int amid_sas_weights_bf16_planes(const float* const* src, int n, int D, int transposed, int planes, void* dst16, void* stream) {
+    return weights_bf16(src, n, D, transposed, planes, dst16, stream);
+}
+
+// amid_sas_seq_fwd_f32 with the twelve projections' products on the bf16 matrix cores AT FP32 ACCURACY: every operand element as three
+// bf16 pieces, six piece pairs per product (csrc/seqn_parts.h SeqRing16x3 / part_mma16x6); w16x3 = amid_sas_weights_bf16_planes(...,
+// planes = 3, ...) images of THIS step's weights, [layer][domain][q, k, v, o, conv1, conv2][3][D][D] bf16.  N-split builds only (D 128).
+extern "C" int amid_sas_seq_fwd_split_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                          const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                          const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                          const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
+                                          float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
+                                          const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                                          const void* step_state, int train, float p_drop, const void* w16x3, void* stream) {
+    AMID_CHECK_ARG(w16x3 != nullptr);
+    return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, qn, q, k, v, o, stats, r, y, h, tmq,
+                        ln_eps, B, T, D, H, live, step_state, train, p_drop, w16x3, stream, 3);
 }

@@ -141,13 +141,15 @@ __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)
 }
 
 
-template <int D, int WPS, int NS, bool BF>
+// P3 (with BF): the weight images are three bf16 planes per weight and the products run on six piece pairs -- fp32 accuracy
+// (seqn_parts.h SeqRing16x3, part_mma16x6)
+template <int D, int WPS, int NS, bool BF, bool P3 = false>
 __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArgs a, const SeqGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = D / 16, NW = WPS * NS, NCT = NT / NS;
     constexpr bool PAIR = D == 64;                         // 8 heads of 8 dims: two per column tile (seqn_attention)
     constexpr int H = PAIR ? 2 * NT : NT, NH = PAIR ? 2 * NCT : NCT;        // heads; own heads of a wave
-    static_assert((D == 128 || D == 64) && NT % NS == 0 && NCT >= 1 && (!BF || D == 128), "");
+    static_assert((D == 128 || D == 64) && NT % NS == 0 && NCT >= 1 && (!BF || D == 128) && (!P3 || BF), "");
     const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
     // waves w and w + 4 share a SIMD: strip si beside strip WPS - 1 - si (the causal attention core costs si + 1 key tiles per head)
     const int part = w / WPS;
@@ -167,14 +169,14 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
     }
     // LDS: fp32 -- [ring 2 x D D floats][exchange]; the attention images alias the ring's idle slab.  bf16 -- [ring 2 x D D / 2][images
     // 2 x 64 D floats][exchange]: a 32 KB slab cannot hold them
-    using Ring = typename std::conditional<BF, SeqRing16<D, NW>, SeqRingN<D, NW>>::type;
+    using Ring = typename std::conditional<P3, SeqRing16x3<D, NW>, typename std::conditional<BF, SeqRing16<D, NW>, SeqRingN<D, NW>>::type>::type;
     Ring ring(smem);
-    auto w16 = [&](int layer, int which) { return a.w16 + ((size_t)((layer * 2 + g) * 6 + which)) * D * D; };     // q, k, v, o, c1, c2
+    auto w16 = [&](int layer, int which) { return a.w16 + ((size_t)((layer * 2 + g) * 6 + which)) * (P3 ? 3 : 1) * D * D; };     // q, k, v, o, c1, c2
     if constexpr (BF) ring.first(w16(0, 1)); else ring.first(a.L[0].w_in[g] + 1LL * D * D);
     // (the images of 64 keys -- 2 x 64 D floats -- fit the idle 64 KB slab of the fp32 ring at D = 128 only: bf16 slabs and D = 64's 16 KB
     // slabs are too small, those builds keep a region of their own behind the ring)
-    constexpr bool SEP_IMG = BF || D == 64;
-    constexpr int RING_F = BF ? D * D : 2 * D * D;
+    constexpr bool SEP_IMG = (BF && !P3) || D == 64;          // (P3: the images alias the ring's M + L plane slots)
+    constexpr int RING_F = (BF && !P3) ? D * D : 2 * D * D;
     float* const img16 = smem + RING_F;
     float* xb = smem + RING_F + (SEP_IMG ? 2 * NIMG_KEYS * D : 0) + si * (NT * 64 * 4);      // this strip's exchange slots
     const int t = si * 16 + m;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
         {   // q = Qn Wq^T + bq
             float* buf = ring.next();
             SEQN_STAMP(6);
-            img = SEP_IMG ? img16 : buf;
+            if constexpr (P3) { img = ring.images(); ring.hold_next = true; } else img = SEP_IMG ? img16 : buf;
             part_cols<NCT>(bias, P.b_in[g], c0);
             seqn_product<D, NCT, BF>(acc, Qn, buf, ring, P.w_o[g], BF ? w16(l, 3) : nullptr, c0,
                                      [&](int ct, int j) { part_spread<NCT>(gv, off_own, Vo, ct, j, 1); });
@@ -404,14 +406,14 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
     w_ring_wait();                                          // the last (redundant) weight fetch targets this workgroup's LDS
 }
 
-template <int D, int WPS, bool BF> static constexpr size_t seqn_lds_bytes() {
-    return (size_t)((BF ? D * D : 2 * D * D) + ((BF || D == 64) ? 2 * NIMG_KEYS * D : 0) + WPS * (D / 16) * 64 * 4) * sizeof(float);
+template <int D, int WPS, bool BF, bool P3 = false> static constexpr size_t seqn_lds_bytes() {
+    return (size_t)(((BF && !P3) ? D * D : 2 * D * D) + (((BF && !P3) || D == 64) ? 2 * NIMG_KEYS * D : 0) + WPS * (D / 16) * 64 * 4) * sizeof(float);
 }
 
-template <int D, int WPS, int NS, bool BF>
+template <int D, int WPS, int NS, bool BF, bool P3 = false>
 static int seqn_launch_t(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
-    constexpr size_t lds = seqn_lds_bytes<D, WPS, BF>();
-    auto kern = seqn_fwd_kernel<D, WPS, NS, BF>;
+    constexpr size_t lds = seqn_lds_bytes<D, WPS, BF, P3>();
+    auto kern = seqn_fwd_kernel<D, WPS, NS, BF, P3>;
     static unsigned long long attr_done = 0;          // per device (common.h lds_attr_once): the same scheme as the backward's launcher
     if (int rc = lds_attr_once((const void*)kern, lds, attr_done)) return rc;
     const int grid = sg.live != nullptr ? sg.B : 2 * sg.B;
@@ -422,6 +424,7 @@ static int seqn_launch_t(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
 
 template <int WPS, int NS>
 static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
+    if (a.w16 != nullptr && a.w16_planes == 3) return seqn_launch_t<128, WPS, NS, true, true>(a, sg, stream);
     return a.w16 != nullptr ? seqn_launch_t<128, WPS, NS, true>(a, sg, stream) : seqn_launch_t<128, WPS, NS, false>(a, sg, stream);
 }
 

@@ -26,6 +26,7 @@ struct SeqFwdArgs {
     // bf16 matrix products (sasrec_seqn.hip only): the projection weights as bf16 fragment images [layer][domain][q, k, v, o, c1, c2]
     // [D][D] written by amid_sas_weights_bf16 for THIS step's weights; nullptr = exact fp32 products
     const unsigned short* w16;
+    int w16_planes;                      // 1: bf16 products (operands rounded); 3: fp32 products on three bf16 pieces per operand
 };
 
 struct SeqGeom {

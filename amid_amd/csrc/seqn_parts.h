@@ -6,6 +6,8 @@
 #include "common.h"
 #include "rng.h"
 #include "strip_gemm.h"
+#include "bf16_pieces.h"
+#include <type_traits>
 #include "seq_fwd.h"
 
 namespace amid {
@@ -47,6 +49,7 @@ template <int D, int NW> struct WDmaN {
 };
 
 template <int D, int NW> struct SeqRingN {
+    static constexpr int NWAVES = NW;
     float* buf; int s; WDmaN<D, NW> dma;
     static constexpr int SLOTS = 4 * (D / 16);
     __device__ __forceinline__ explicit SeqRingN(float* lds) : buf(lds), s(0) {}
@@ -74,6 +77,7 @@ template <int D, int NW> struct SeqRingN {
 // (column tile 2 s, elements 0..3) and k = 32 s + 16 + 4 g + r (column tile 2 s + 1, elements 4..7).  In LDS chunk c of row n sits at
 // chunk position c ^ (n & 15), applied on the DMA's source address as for the fp32 images: conflict-free ds_read_b128 fragments.
 template <int D, int NW> struct SeqRing16 {
+    static constexpr int NWAVES = NW;
     static constexpr int CPR = D / 8;                                   // 16-byte chunks per row
     static constexpr int PIECES = D * CPR / 64, PER_WAVE = PIECES / NW;
     static constexpr int SLAB = D * D / 2;                              // floats per slab (32 KB at D = 128)
@@ -109,6 +113,75 @@ template <int D, int NW> struct SeqRing16 {
     }
 };
 
+// ---- fp32 products on the bf16 matrix cores (compute = "fp32", three bf16 pieces per operand: csrc/bf16_pieces.h has the arithmetic).
+// The weights arrive as THREE bf16 fragment images each (planes hi, mid, lo: amid_sas_weights_bf16_planes) = 96 KB per weight, and two
+// whole weights do not fit the 128 KB the ring has.  So the ring is four 32 KB plane slots [M][L][H0][H1] and a product walks its
+// weight plane by plane -- lo x hi and mid x (mid, hi) of the operand first, ONE barrier, then hi x (lo, mid, hi): the six piece pairs,
+// 96 matrix instructions of 16 cycles per wave instead of 128 of 32.  Every plane is requested well ahead of its pass: the hi plane of
+// product j + 1 when product j begins (the other H slot is free then), its mid and lo planes behind product j's barrier (M and L are
+// free then: a hi pass + the epilogue ahead of their use).  The attention images (64 KB) take H0 + H1 between the q and the
+// out-projection products: the q product does not prefetch (`hold_next`), the out-projection requests its own hi plane when it begins
+// and waits for it at its barrier.
+template <int D, int NW> struct SeqRing16x3 {
+    static constexpr int NWAVES = NW;
+    static constexpr int CPR = D / 8;
+    static constexpr int PIECES = D * CPR / 64, PER_WAVE = PIECES / NW;
+    static constexpr int SLAB = D * D / 2;                              // floats per plane slot (32 KB at D = 128)
+    float* buf; int s; unsigned off0; int w;
+    const unsigned short* cur; const unsigned short* nxt;
+    bool cur_hi_ready, nxt_hi_ready, hi_late, hold_next;
+    __device__ __forceinline__ explicit SeqRing16x3(float* lds)
+        : buf(lds), s(0), cur(nullptr), nxt(nullptr), cur_hi_ready(false), nxt_hi_ready(false), hi_late(false), hold_next(false) {
+        w = wave_id();
+        const int p = w * 64 + lane_id();
+        const int n = p / CPR, pos = p % CPR;
+        off0 = (unsigned)(n * D * 2 + ((pos ^ (n & 15)) * 16));
+    }
+    __device__ __forceinline__ float* mslot() const { return buf; }
+    __device__ __forceinline__ float* lslot() const { return buf + SLAB; }
+    __device__ __forceinline__ float* hslot(int k) const { return buf + (2 + (k & 1)) * SLAB; }
+    __device__ __forceinline__ float* images() const { return buf + 2 * SLAB; }        // H0 + H1
+    __device__ __forceinline__ float* hcur() const { return hslot(s - 1); }
+    __device__ __forceinline__ void piece(float* __restrict__ dst, const unsigned short* __restrict__ W, int k0) const {
+        const unsigned voff = off0 + (unsigned)k0 * (unsigned)(NW * 64 / CPR) * (unsigned)(D * 2);
+        const unsigned lds = __builtin_amdgcn_readfirstlane(
+            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(dst + (k0 * NW + w) * 256));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
+    }
+    __device__ __forceinline__ void plane(float* __restrict__ dst, const unsigned short* __restrict__ Wp) const {
+#pragma unroll
+        for (int k0 = 0; k0 < PER_WAVE; ++k0) piece(dst, Wp, k0);
+    }
+    __device__ __forceinline__ void first(const unsigned short* __restrict__ W0) {
+        cur = W0; cur_hi_ready = true;
+        plane(hslot(0), W0); plane(mslot(), W0 + (size_t)D * D); plane(lslot(), W0 + (size_t)2 * D * D);
+    }
+    __device__ __forceinline__ float* next() {              // product s begins: every wave is past product s - 1 (and the images)
+        w_ring_wait();
+        __syncthreads();
+        ++s;
+        return hslot(s - 1);
+    }
+    __device__ __forceinline__ void begin(const unsigned short* __restrict__ Wnext) {
+        nxt = Wnext;
+        hi_late = !cur_hi_ready;
+        if (hi_late) plane(hslot(s - 1), cur);             // (the product behind the attention core: its H slot held an image)
+        nxt_hi_ready = !hold_next;
+        if (nxt_hi_ready) plane(hslot(s), nxt);
+        hold_next = false;
+    }
+    // behind the lo / mid passes: M and L are free for the next weight's planes
+    __device__ __forceinline__ void mid_sync() {
+        if (hi_late) w_ring_wait();
+        __syncthreads();
+        plane(mslot(), nxt + (size_t)D * D);
+        plane(lslot(), nxt + (size_t)2 * D * D);
+        cur = nxt; cur_hi_ready = nxt_hi_ready;
+    }
+};
+
 typedef __bf16 seqn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 seqn_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float seqn_f32x2 __attribute__((ext_vector_type(2)));
@@ -137,6 +210,58 @@ __device__ __forceinline__ void part_mma16(f32x4 (&acc)[NCT], const StripRegs<D>
         for (int c = 0; c < NCT; ++c)
             acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(seqn_bf16x8, wf[c]), __builtin_bit_cast(seqn_bf16x8, a16[s]),
                                                              acc[c], 0, 0, 0);
+    }
+}
+
+// acc[c] += A W^T over the own column tiles, fp32 operands as three bf16 pieces each, six piece pairs (SeqRing16x3)
+template <int D, int NCT, class Ring>
+__device__ __forceinline__ void part_mma16x6(f32x4 (&acc)[NCT], const StripRegs<D>& A, Ring& ring, int c0) {
+    constexpr int KS = D / 32;
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int rowo = (c0 * 16 + i) * (D / 2);                          // a row = D bf16 = D / 2 floats
+    auto frag = [&](const float* plane, int c, int s) { return lds_ld4(plane + rowo + c * 16 * (D / 2) + 4 * ((4 * s + g) ^ i)); };
+    auto mma = [&](const float4& wf, const amid_v4u& a16, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(seqn_bf16x8, wf), __builtin_bit_cast(seqn_bf16x8, a16), c, 0, 0, 0);
+    };
+    const float* mbuf = ring.mslot();
+    const float* lbuf = ring.lslot();
+    // (fragments are read one column tile ahead, not a k-step's worth at once: the kernel sits at the register limit, and a build that
+    // held four tiles' fragments beside the three pieces spilled -- 16.5 k cycles for the last product instead of 8.9 k)
+    // pass 1: the lo plane against the operand's hi piece, the mid plane against (mid, hi)
+    float4 wm = frag(mbuf, 0, 0), wl = frag(lbuf, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const WgSplit2 p0 = wg_split3(A.v[2 * s][0], A.v[2 * s][1]), p1 = wg_split3(A.v[2 * s][2], A.v[2 * s][3]);
+        const WgSplit2 p2 = wg_split3(A.v[2 * s + 1][0], A.v[2 * s + 1][1]), p3 = wg_split3(A.v[2 * s + 1][2], A.v[2 * s + 1][3]);
+        const amid_v4u ah = amid_v4u{p0.hi, p1.hi, p2.hi, p3.hi}, am = amid_v4u{p0.mid, p1.mid, p2.mid, p3.mid};
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const float4 cm = wm, cl = wl;
+            const int cn = c + 1 < NCT ? c + 1 : 0, sn = c + 1 < NCT ? s : s + 1;
+            if (sn < KS) { wm = frag(mbuf, cn, sn); wl = frag(lbuf, cn, sn); }
+            acc[c] = mma(cl, ah, acc[c]); acc[c] = mma(cm, am, acc[c]); acc[c] = mma(cm, ah, acc[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                 // (keeps a k-step's pieces and fragments from being hoisted over the previous one's)
+    }
+    const float* hbuf = ring.hcur();
+    ring.mid_sync();
+    // pass 2: the hi plane against the operand's three pieces
+    float4 wf = frag(hbuf, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const WgSplit2 p0 = wg_split3(A.v[2 * s][0], A.v[2 * s][1]), p1 = wg_split3(A.v[2 * s][2], A.v[2 * s][3]);
+        const WgSplit2 p2 = wg_split3(A.v[2 * s + 1][0], A.v[2 * s + 1][1]), p3 = wg_split3(A.v[2 * s + 1][2], A.v[2 * s + 1][3]);
+        const amid_v4u ah = amid_v4u{p0.hi, p1.hi, p2.hi, p3.hi}, am = amid_v4u{p0.mid, p1.mid, p2.mid, p3.mid},
+                       al = amid_v4u{p0.lo, p1.lo, p2.lo, p3.lo};
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const float4 cf = wf;
+            const int cn = c + 1 < NCT ? c + 1 : 0, sn = c + 1 < NCT ? s : s + 1;
+            if (sn < KS) wf = frag(hbuf, cn, sn);
+            acc[c] = mma(cf, al, acc[c]); acc[c] = mma(cf, am, acc[c]); acc[c] = mma(cf, ah, acc[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -245,14 +370,20 @@ struct NoLate { __device__ __forceinline__ void operator()() const {} };
 // not cross the loop's scheduling fences)
 // ZERO = false: the product is added to what `acc` holds (the MFMA chain goes on: same bits as one product over the joined k range)
 template <int D, int NCT, bool BF, bool ZERO = true, class Ring, class Stores, class Late = NoLate>
-__device__ __forceinline__ void seqn_product(f32x4 (&acc)[NCT], const StripRegs<D>& A, const float* __restrict__ buf, const Ring& ring,
+__device__ __forceinline__ void seqn_product(f32x4 (&acc)[NCT], const StripRegs<D>& A, const float* __restrict__ buf, Ring& ring,
                                              const float* __restrict__ wn32, const unsigned short* __restrict__ wn16, int c0, const Stores& stores,
                                              const Late& late = NoLate()) {
     if constexpr (ZERO) {
 #pragma unroll
         for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if constexpr (BF) {
+    if constexpr (std::is_same<Ring, SeqRing16x3<D, Ring::NWAVES>>::value) {
+        ring.begin(wn16);
+        late();
+        part_mma16x6<D, NCT>(acc, A, ring, c0);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) { stores(ct, 1); stores(ct, 3); }
+    } else if constexpr (BF) {
         ring.fetch_all(wn16);
         late();
         part_mma16<D, NCT>(acc, A, buf, c0);

@@ -3,16 +3,10 @@
 #pragma once
 #include "common.h"
 #include "tile_gemm.h"
+#include "bf16_pieces.h"
 
 namespace amid {
 
-typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned wg_v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned wg_pack2(float a, float b) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(wg_f32x2{a, b}, wg_bf16x2));       // v_cvt_pk_bf16_f32: round to nearest even
-}
 __device__ __forceinline__ float f4comp_w(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
 // compute = "fp32" (mma mode 2 / 3 of amid_sas_wgrad*_f32, amid_bert_wgrad_mode_f32): every operand element is split into three bf16
@@ -30,16 +24,6 @@ __device__ __forceinline__ float f4comp_w(const float4& v, int i) { return i == 
 // (profiles/tools/probe/wgrad_split_probe.py).  cfg 2 step 0.3725 -> 0.3558 ms.
 constexpr int WGS_ROWS = 32;
 constexpr int WGS_COL_BYTES = 80;
-struct WgSplit2 { unsigned hi, mid, lo; };          // two elements, packed bf16 pairs (first element in the low half)
-__device__ __forceinline__ WgSplit2 wg_split3(float a, float b) {
-    WgSplit2 s;
-    s.hi = wg_pack2(a, b);
-    const float a1 = a - __uint_as_float(s.hi << 16), b1 = b - __uint_as_float(s.hi & 0xffff0000u);       // exact
-    s.mid = wg_pack2(a1, b1);
-    const float a2 = a1 - __uint_as_float(s.mid << 16), b2 = b1 - __uint_as_float(s.mid & 0xffff0000u);   // exact
-    s.lo = wg_pack2(a2, b2);
-    return s;
-}
 __device__ __forceinline__ f32x4 wg_mma16(const wg_v4u& x, const wg_v4u& y, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8, x), __builtin_bit_cast(wg_bf16x8, y), c, 0, 0, 0);
 }

@@ -310,6 +310,13 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # pieces, six ("6", the default) or nine ("9") piece pairs (csrc/sasrec_bwd.hip sas_wgrad_split_kernel; D = 128); "0": fp32 matrix
     # instructions.  Error against the fp64 product 3.8e-7 of the largest entry either way, 4.4e-7 for the fp32 instructions.
     WGRAD_SPLIT = os.environ.get("AMID_WGRAD_SPLIT", "6")
+    # compute = "fp32": the one-launch forward's twelve projections on the bf16 matrix cores at fp32 accuracy too (three bf16 pieces per
+    # operand, six piece pairs: amid_sas_seq_fwd_split_f32, csrc/seqn_parts.h SeqRing16x3).  Built, parity-tested (3e-6 of every saved
+    # tensor's largest entry against the fp32 build) and measured SLOWER so far -- 0.3738 against 0.3564 ms/step at cfg 2: the products'
+    # matrix time drops from 8192 to 3072 cycles per SIMD, but a 96 KB weight walks through the 128 KB ring plane by plane (a second
+    # barrier per product), the operand is split twice and the fragment reads are not pipelined across k-steps: 8-10 k cycles per
+    # product against 9.3 k.  Off by default; "1" turns it on.
+    FWD_SPLIT = os.environ.get("AMID_FWD_SPLIT", "0") != "0"
     # The train step's encoder backward (data gradients) as ONE launch over the live sequences where csrc/sasrec_strip.hip covers the
     # shape (amid_sas_seq_bwd_f32): "auto" = where it wins.  It tiles one sequence per workgroup, a whole CU each, so the step's sort
     # riders find no free CU in it and the sort goes back to the side stream (a fork and a join, ~10 us of a replayed graph).  Measured
@@ -499,9 +506,12 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                      fam("sac{d}.forward_layers.{l}.conv2.weight"), fam("sac{d}.forward_layers.{l}.conv2.bias"),
                      tl(pl.qn), tl(pl.q), tl(pl.k), tl(pl.v), tl(pl.o), tl(pl.stats), tl(pl.r), tl(pl.y), tl(pl.h))
                 self._ptr_cache[key] = c
-            if self.compute == "bf16":       # this step's weights as bf16 fragment images, then the forward with bf16 products
-                if not hasattr(self, "w16"):
-                    self.w16 = torch.empty(2, 2, 6, D * D, dtype=torch.bfloat16, device=self.device)
+            split = self.compute != "bf16" and self.FWD_SPLIT and D == 128
+            if self.compute == "bf16" or split:       # this step's weights as bf16 fragment images (one plane: operands rounded to bf16;
+                planes = 3 if split else 1            # three: hi + mid + lo = the fp32 weight exactly), then the forward on them
+                if getattr(self, "_w16_planes", 0) != planes:
+                    self.w16 = torch.empty(2, 2, 6, planes, D * D, dtype=torch.bfloat16, device=self.device)
+                    self._w16_planes = planes
                     srcs = []
                     for l in (0, 1):
                         for g in (1, 2):
@@ -509,9 +519,9 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                             srcs += [fp.ptr(f"sac{g}.attention_layers.{l}.out_proj.weight"), fp.ptr(f"sac{g}.forward_layers.{l}.conv1.weight"),
                                      fp.ptr(f"sac{g}.forward_layers.{l}.conv2.weight")]
                     self._w16_src = ptr_array(srcs)
-                L.call("amid_sas_weights_bf16", self._w16_src, 24, D, 0, self.w16.data_ptr(), s)
-                L.call("amid_sas_seq_fwd_bf16w_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:], pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr,
-                       SASREC_P_DROP, self.w16.data_ptr(), s)
+                L.call("amid_sas_weights_bf16_planes", self._w16_src, 24, D, 0, planes, self.w16.data_ptr(), s)
+                L.call("amid_sas_seq_fwd_split_f32" if split else "amid_sas_seq_fwd_bf16w_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:],
+                       pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, self.w16.data_ptr(), s)
             else:
                 L.call("amid_sas_seq_fwd_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:], pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr,
                        SASREC_P_DROP, s)

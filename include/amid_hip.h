@@ -599,6 +599,20 @@ int amid_sas_seq_fwd_bf16w_f32(int n_layers, const float* const* x_in, float* xo
  * backward data-gradient products): dst16 [n][D][D] bf16 with the in-features of a row permuted into the order the bf16 MFMA's lanes
  * consume them (csrc/sasrec_seq.hip weights_bf16_kernel).  Once per step, before the forward. */
 int amid_sas_weights_bf16(const float* const* src, int n, int D, int transposed, void* dst16, void* stream);
+/* planes = 3: three images per matrix, dst16 [n][3][D][D] bf16 -- every element as hi + mid + lo, three bf16 pieces (each rounded to
+ * nearest even) whose sum is the fp32 element exactly; planes = 1: amid_sas_weights_bf16 */
+int amid_sas_weights_bf16_planes(const float* const* src, int n, int D, int transposed, int planes, void* dst16, void* stream);
+/* amid_sas_seq_fwd_f32 (Log2feats.forward, model_seq.py:371-383) with the twelve projections' products on the bf16 matrix cores at FP32
+ * ACCURACY: every operand element as three bf16 pieces, six piece pairs per product on v_mfma_f32_16x16x32_bf16 (96 x 16 cycles per wave
+ * and product instead of 128 x 32); LayerNorm, the attention core, residuals, dropout and everything stored as in the fp32 build.
+ * w16x3 = amid_sas_weights_bf16_planes(..., planes = 3, ...) images of THIS step's weights, [layer][domain][q, k, v, o, conv1, conv2][3][D][D] */
+int amid_sas_seq_fwd_split_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                               const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                               const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                               const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
+                               float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
+                               const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                               const void* step_state, int train, float p_drop, const void* w16x3, void* stream);
 
 /* ---- the encoder's data gradients of the live sequences in ONE launch (csrc/sasrec_strip.hip: seq_bwd_kernel) -------------------------
  * replaces: autograd of Log2feats.forward model_seq.py:371-383 under loss.backward() (train_sr.py:214) -- per layer, top down,

@@ -55,13 +55,14 @@ def _run(L, pa, variant, B, T, st, lv, P, x0, tmq, train, bf16=False):
                 *[tl(saved[k]) for k in "qn q k v o stats r y h".split()], tmq.data_ptr(), 1e-8, B, T, D, H,
                 lv.data_ptr() if lv is not None else None, st.data_ptr(), train, 0.5)
         s = torch.cuda.current_stream().cuda_stream
-        if bf16:        # the weights' bf16 fragment images, [layer][domain][q, k, v, o, c1, c2]
-            w16 = torch.empty(2, 2, 6, D * D, dtype=torch.bfloat16, device="cuda")
+        if bf16:        # the weights' bf16 fragment images, [layer][domain][q, k, v, o, c1, c2]; bf16 = 3: three planes (hi, mid, lo) each
+            planes = 3 if bf16 == 3 else 1
+            w16 = torch.empty(2, 2, 6, planes, D * D, dtype=torch.bfloat16, device="cuda")
             srcs = []
             for i in range(4):
                 srcs += [P["w_in"][i].data_ptr() + 4 * j * D * D for j in range(3)] + [P["w_o"][i].data_ptr(), P["w1"][i].data_ptr(), P["w2"][i].data_ptr()]
-            L.call("amid_sas_weights_bf16", pa(srcs), 24, D, 0, w16.data_ptr(), s)
-            L.call("amid_sas_seq_fwd_bf16w_f32", *args, w16.data_ptr(), s)
+            L.call("amid_sas_weights_bf16_planes", pa(srcs), 24, D, 0, planes, w16.data_ptr(), s)
+            L.call("amid_sas_seq_fwd_split_f32" if planes == 3 else "amid_sas_seq_fwd_bf16w_f32", *args, w16.data_ptr(), s)
         else:
             L.call("amid_sas_seq_fwd_f32", *args, s)
         torch.cuda.synchronize()
@@ -87,6 +88,61 @@ def test_n_split_forward_is_bit_identical_to_whole_row_forward(B, T, variants, l
             assert torch.equal(a[rl], b[rl]), (v, name, float((a[rl] - b[rl]).abs().max()))
             if bool((~rl).any()):
                 assert torch.isnan(a[~rl]).all(), f"variant {v} {name}: rows outside the live list were written"
+
+
+@pytest.mark.parametrize("B,T,variants", CASES)
+@pytest.mark.parametrize("live", [None, "mixed"])
+@pytest.mark.parametrize("train", [0, 1])
+def test_forward_on_bf16_pieces_has_fp32_accuracy(B, T, variants, live, train):
+    """amid_sas_seq_fwd_split_f32 -- the twelve projections as six bf16 piece-pair products per fp32 product (three pieces per operand
+    element, their sum the element exactly) -- against amid_sas_seq_fwd_f32 (fp32 matrix instructions) on the same inputs, dropout
+    counters and live list: every saved tensor and the output within 3e-6 of the tensor's largest entry (two fp32 evaluations of the
+    same chain in different summation orders differ by as much), row statistics within 1e-5, rows outside the live list untouched.
+    A product with bf16-ROUNDED operands is off by 3e-3 on the same data (asserted: the one-plane build is not what runs)."""
+    L, pa, st, lv, row_live, P, x0, tmq = _setup(B, T, seed=B * 7 + T, live=live)
+    rl = row_live.cuda()
+    for v in variants:
+        ref = _run(L, pa, v, B, T, st, lv, P, x0, tmq, train)
+        got = _run(L, pa, v, B, T, st, lv, P, x0, tmq, train, bf16=3)
+        worst = 0.0
+        for name, want in ref.items():
+            a, b = got[name][rl], want[rl]
+            assert torch.isfinite(a).all(), (v, name)
+            bar = (1e-5 if name.startswith("stats") else 3e-6) * max(1.0, float(b.abs().max()))
+            err = float((a - b).abs().max())
+            worst = max(worst, err / max(1.0, float(b.abs().max())))
+            assert err < bar, (v, name, err, bar)
+            if bool((~rl).any()):
+                assert torch.isnan(got[name][~rl]).all(), f"variant {v} {name}: rows outside the live list were written"
+        if (B, T) == (256, 50):
+            one = _run(L, pa, v, B, T, st, lv, P, x0, tmq, train, bf16=1)
+            e1 = float((one["xout"][rl] - ref["xout"][rl]).abs().max() / ref["xout"][rl].abs().max())
+            assert e1 > 100 * worst, (e1, worst)
+
+
+def test_three_plane_weight_images_sum_to_the_weights_exactly():
+    """amid_sas_weights_bf16_planes(planes = 3): hi + mid + lo (each a bf16, summed in fp32 in that order... exactly representable steps)
+    reproduces every fp32 weight bit for bit, plane 0 is the one-plane (round-to-nearest-even) image, all three in fragment order."""
+    from amid_amd._lib import lib, ptr_array
+    L = lib()
+    g = torch.Generator().manual_seed(6)
+    W = [(torch.randn(D, D, generator=g) * torch.pow(10.0, -4.0 * torch.rand(D, D, generator=g))).cuda() for _ in range(2)]
+    k = torch.arange(D)
+    s_, h_, g_, r_ = k >> 5, (k >> 4) & 1, (k >> 2) & 3, k & 3
+    pos = (4 * s_ + g_) * 8 + 4 * h_ + r_
+    s = torch.cuda.current_stream().cuda_stream
+    for tr in (0, 1):
+        out3 = torch.zeros(2, 3, D, D, dtype=torch.bfloat16, device="cuda")
+        out1 = torch.zeros(2, D, D, dtype=torch.bfloat16, device="cuda")
+        L.call("amid_sas_weights_bf16_planes", ptr_array([w.data_ptr() for w in W]), 2, D, tr, 3, out3.data_ptr(), s)
+        L.call("amid_sas_weights_bf16", ptr_array([w.data_ptr() for w in W]), 2, D, tr, out1.data_ptr(), s)
+        torch.cuda.synchronize()
+        for i in range(2):
+            src = (W[i].t() if tr else W[i]).cpu().contiguous()
+            assert torch.equal(out3[i, 0].cpu(), out1[i].cpu())
+            planes = out3[i].cpu()[:, :, pos].double()             # back to [plane][n][k]
+            assert torch.equal((planes[0] + planes[1] + planes[2]).float(), src), tr
+            assert float((planes[1].abs() - planes[0].abs() * 2.0 ** -8).max()) <= 0.0 and float((planes[2].abs() - planes[0].abs() * 2.0 ** -16).max()) <= 0.0
 
 
 def test_variant_switch_round_trips_and_refuses_a_split_that_does_not_cover_t():
