@@ -380,16 +380,22 @@ def cpu_baseline(budget_s=25.0):
 def self_launch(n: int) -> int:
     """python bench.py --gpus N without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a
     child of this process (which has not touched the GPU: importing torch does not initialise HIP) and relay its output."""
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    rc = 1
+    for attempt in range(3):        # the port is picked by bind / close / reuse: another process may take it in between -- a launcher that
+        sock = socket.socket()      # dies within seconds is retried on a fresh port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        t0 = time.perf_counter()
+        rc = subprocess.run(cmd, env=env).returncode
+        if rc == 0 or time.perf_counter() - t0 > 15.0:
+            break
+    return rc
 
 
 def main():
