@@ -189,7 +189,6 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
 
     StripRegs<D> F;                                         // the whole-row operand of the next product
-    StripRegs<D> Qn;
     PartRegs<NCT> Xo, Qno, Ko, Vo, Qo, Oo, Ro, Yo, Ho, bias;
     ColVec<D> lw, lb;
     {
@@ -225,14 +224,11 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
                 Xo.v[c] = f32x4{t4.x, t4.y, t4.z, t4.w};
             }
         }
-        {   // Qn = LN1(x): whole row for the q product, own columns for the residual and the saved copy
+        {   // Qn = LN1(x): the own columns only -- for the residual, the saved copy and, through the exchange slots behind the k
+            // product, the whole row of the q product (held in registers through the k and v products it cost 32 VGPRs)
             // (the gains were requested late in the previous product -- the prologue for layer 0)
             float mean, rstd;
             strip_stats<D>(F, a.ln_eps, mean, rstd);
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Qn.v[ct][r] = (F.v[ct][r] - mean) * rstd * lw.v[ct][r] + lb.v[ct][r];
             PartRegs<NCT> lwo, lbo;
             own_cols<D, NCT>(lwo, lw, P.ln1_w[g], part, c0); own_cols<D, NCT>(lbo, lb, P.ln1_b[g], part, c0);
 #pragma unroll
@@ -248,6 +244,9 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ko.v[c] = acc[c] + bias.v[c];
         }
+        // every wave of the strip is past its reads of the exchange slots (the v product's ring barrier lies between this write and
+        // the q product's read)
+        xchg_write<NCT>(xb, c0, Qno);
         SEQN_STAMP(3);
         {   // v = x Wv^T + bv
             const float* buf = ring.next();
@@ -265,7 +264,8 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
             SEQN_STAMP(6);
             if constexpr (P3) { img = ring.images(); ring.hold_next = true; } else img = SEP_IMG ? img16 : buf;
             part_cols<NCT>(bias, P.b_in[g], c0);
-            seqn_product<D, NCT, BF>(acc, Qn, buf, ring, P.w_o[g], BF ? w16(l, 3) : nullptr, c0,
+            xchg_read<D>(F, xb);                           // the whole row of Qn (x is dead behind the v product)
+            seqn_product<D, NCT, BF>(acc, F, buf, ring, P.w_o[g], BF ? w16(l, 3) : nullptr, c0,
                                      [&](int ct, int j) { part_spread<NCT>(gv, off_own, Vo, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Qo.v[c] = acc[c] + bias.v[c];
