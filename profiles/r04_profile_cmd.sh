@@ -35,6 +35,8 @@ AMID_WGRAD_SPLIT=0 python3 bench.py --model bert4rec --no-cpu-baseline --no-stre
 AMID_FOLD_CATCHUP=1 python3 bench.py --no-cpu-baseline --no-stress > $O/bench_fold_catchup.json 2> $O/bench_fold_catchup.err
 python3 profiles/tools/probe/wgrad_split_probe.py 2>&1 | grep -v amdgpu > $O/wgrad_split_probe.txt
 (echo "# python profiles/tools/variant_steps.py (cfg 2 shape: B 256, T 50, D 128, hid 32, neg 1; hipGraph replay, 200 steps)"; python3 profiles/tools/variant_steps.py 2>&1 | grep "ms/step"; echo "# VARIANT_T=20 (the mybank shape run.sh trains on)"; VARIANT_T=20 python3 profiles/tools/variant_steps.py 2>&1 | grep "ms/step") > $O/variant_steps.txt
+(echo "# VARIANT_KERNELS=1 python profiles/tools/variant_steps.py: every variant's eager step, entry point by entry point (us per step / launches)"; VARIANT_KERNELS=1 python3 profiles/tools/variant_steps.py 2>&1 | grep -E "^  |ms/step") > $O/variant_kernels.txt
+AMID_FWD_SPLIT=1 python3 bench.py --no-cpu-baseline --no-stress > $O/bench_forward_on_pieces.json 2> $O/bench_forward_on_pieces.err
 python3 profiles/tools/dp_overhead.py 2>&1 | grep "ms/step" > $O/dp_overhead.txt
 python3 profiles/tools/k1_time.py 2>&1 | grep "TB/s" > $O/k1_time.txt
 python3 profiles/tools/seqn_stamps.py 2>&1 | grep -v amdgpu > $O/seqn_stamps.txt
