@@ -16,6 +16,7 @@
 #include "rng.h"
 #include "sort_phases.h"
 #include "adam_replay.h"
+#include "weights_image.h"
 
 namespace amid {
 
@@ -164,7 +165,10 @@ __global__ void pack_indices_pool_kernel(const long long* __restrict__ pool, lon
 // ---------------------------------------------------------------------------------------------
 // FOLD: the lazy-Adam replay and the sort rider compiled in (amid_embed_fwd_replay_f32).  The plain build must not carry them: with both
 // in one kernel the gather ran at 178 VGPRs / 6.4 KB of LDS instead of 109 / 0 and cfg 5's K1 went from 52.8 to 81.4 us.
-template <int RIF, bool FOLD>
+// W16: the first workgroups write this step's bf16 fragment images of the encoder weights (the one-launch forward on bf16 pieces reads them;
+// as a launch of its own the 72 planes cost 4.9 us of a 0.355 ms step)
+struct W16Rider { const float* src[24]; unsigned short* dst; int n, planes, per, D; };
+template <int RIF, bool FOLD, bool W16 = false>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ table, const int* __restrict__ idx_all,
                                                         const float* __restrict__ pos0, const float* __restrict__ pos1,
                                                         int B, int T, int D, int n_item_rows,
@@ -172,13 +176,23 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
                                                         const RngState* __restrict__ rng, int train, unsigned thr16, float scale,
                                                         const int* __restrict__ live, int* __restrict__ idx_c, int* __restrict__ row_c, int chunk,
                                                         const float* __restrict__ m_tab, const float* __restrict__ v_tab,
-                                                        const int* __restrict__ last, const StepState* __restrict__ adam_st, const SortRider rd) {
+                                                        const int* __restrict__ last, const StepState* __restrict__ adam_st, const SortRider rd,
+                                                        const W16Rider wr) {
     // rider: the first workgroups run phase 1 of the step's index sort (sort_phases.h) beside the gather (it rode in the catch-up
     // launch while that launch existed)
     int nrb = 0;
+    if constexpr (W16) {
+        nrb = wr.n * wr.per;
+        if ((int)blockIdx.x < nrb) {
+            const int wi = blockIdx.x / wr.per;
+            weights_image_block(wr.src[wi], wr.dst + (size_t)wi * wr.planes * wr.D * wr.D, wr.D, 0, wr.planes, blockIdx.x - wi * wr.per, wr.per);
+            return;
+        }
+    }
     if constexpr (FOLD) {
-        nrb = rider_blocks(rd);
-        if ((int)blockIdx.x < nrb) { sort_phase_ct<1024, 1>(rd.plan, blockIdx.x); return; }
+        const int nsb = rider_blocks(rd);
+        if ((int)blockIdx.x - nrb < nsb) { sort_phase_ct<1024, 1>(rd.plan, blockIdx.x - nrb); return; }
+        nrb += nsb;
     }
     const int bid = blockIdx.x - nrb;
     const int sub = threadIdx.x & 31;
@@ -544,8 +558,15 @@ extern "C" int amid_pack_indices_pool_live(const long long* pool, long long pool
 static int embed_fwd(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
                      int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop, const int* live,
                      int* idx_c, int* row_c, void* stream, const float* m_tab = nullptr, const float* v_tab = nullptr, const int* last = nullptr,
-                     const void* adam_state = nullptr, const void* sort_plan = nullptr, int sort_phase = 0) {
+                     const void* adam_state = nullptr, const void* sort_plan = nullptr, int sort_phase = 0, const float* const* w_src = nullptr,
+                     int n_w = 0, int w_planes = 0, void* w16_dst = nullptr) {
     AMID_CHECK_ARG(last == nullptr || (m_tab && v_tab && adam_state));
+    W16Rider wr = {};
+    if (w_src != nullptr) {
+        AMID_CHECK_ARG(n_w > 0 && n_w <= 24 && (w_planes == 1 || w_planes == 3) && w16_dst && D == 128 && last == nullptr && sort_plan == nullptr);
+        for (int i = 0; i < n_w; ++i) { AMID_CHECK_ARG(w_src[i]); wr.src[i] = w_src[i]; }
+        wr.dst = (unsigned short*)w16_dst; wr.n = n_w; wr.planes = w_planes; wr.D = D; wr.per = (D * (D / 8) + 255) / 256;
+    }
     SortRider rd;
     rd.phase = 0;
     if (sort_plan != nullptr) {
@@ -564,11 +585,15 @@ static int embed_fwd(const float* table, const int* idx_all, const float* pos0, 
     if (last != nullptr || rd.phase != 0)
         embed_fwd_kernel<EMBED_RIF, true><<<embed_grid(n_walk, chunk) + rider_blocks_host(rd), 256, 0, (hipStream_t)stream>>>(
             table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, (const RngState*)rng_state, tr, keep_thr16(p_drop),
-            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd);
+            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd, wr);
+    else if (wr.n > 0)
+        embed_fwd_kernel<EMBED_RIF, false, true><<<embed_grid(n_walk, chunk) + wr.n * wr.per, 256, 0, (hipStream_t)stream>>>(
+            table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, (const RngState*)rng_state, tr, keep_thr16(p_drop),
+            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd, wr);
     else
         embed_fwd_kernel<EMBED_RIF, false><<<embed_grid(n_walk, chunk), 256, 0, (hipStream_t)stream>>>(
             table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, (const RngState*)rng_state, tr, keep_thr16(p_drop),
-            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd);
+            tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd, wr);
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }
@@ -607,6 +632,18 @@ extern "C" int amid_embed_fwd_replay_f32(const float* table, const float* m_tab,
     AMID_CHECK_ARG(m_tab && v_tab && last && adam_state);
     return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, live, idx_c, row_c, stream, m_tab,
                      v_tab, last, adam_state, sort_plan, sort_phase);
+}
+
+// K1 (live / idx_c / row_c as the three entry points above: NULL = every sequence / no compact list) with this step's bf16 fragment
+// images of n_w square [D][D] weights written by extra workgroups of the same launch: w16_dst [n_w][planes][D][D] bf16, planes = 1 or 3
+// (amid_sas_weights_bf16_planes is the launch this saves).  D = 128.
+extern "C" int amid_embed_fwd_w16_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
+                                      int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
+                                      const int* live, int* idx_c, int* row_c, const float* const* w_src, int n_w, int w_planes, void* w16_dst,
+                                      void* stream) {
+    AMID_CHECK_ARG(w_src != nullptr);
+    return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, live, idx_c, row_c, stream, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, 0, w_src, n_w, w_planes, w16_dst);
 }
 
 extern "C" int amid_live_list_i32(const long long* domain, int B, int* live, void* stream) {

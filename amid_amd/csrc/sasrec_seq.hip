@@ -23,7 +23,7 @@
 #include "strip_gemm.h"
 #include "attention_mfma.h"
 #include "seq_fwd.h"
-#include "bf16_pieces.h"
+#include "weights_image.h"
 
 namespace amid {
 
@@ -529,26 +529,7 @@ namespace amid {
 struct W16Args { const float* src[48]; int n; };
 // planes = 3: every element as hi + mid + lo (csrc/bf16_pieces.h), one image per piece: dst [n][3][D][D] bf16
 __global__ __launch_bounds__(256) void weights_bf16_kernel(const W16Args a, unsigned short* __restrict__ dst, int D, int transposed, int planes) {
-    const float* __restrict__ W = a.src[blockIdx.y];
-    unsigned short* __restrict__ out = dst + (size_t)blockIdx.y * planes * D * D;
-    const int cpr = D / 8;
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < D * cpr; q += gridDim.x * 256) {
-        const int n = q / cpr, c = q % cpr;
-        const int s = c >> 2, g = c & 3;
-        unsigned pk[3][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int k = 32 * s + 16 * h + 4 * g + 2 * e;
-                const float v0 = transposed ? W[(size_t)k * D + n] : W[(size_t)n * D + k];
-                const float v1 = transposed ? W[(size_t)(k + 1) * D + n] : W[(size_t)n * D + k + 1];
-                const WgSplit2 sp = wg_split3(v0, v1);        // (hi = the round-to-nearest-even bf16 pair of the one-plane image)
-                pk[0][2 * h + e] = sp.hi; pk[1][2 * h + e] = sp.mid; pk[2][2 * h + e] = sp.lo;
-            }
-        for (int p = 0; p < planes; ++p)
-            *reinterpret_cast<uint4*>(out + (size_t)p * D * D + (size_t)q * 8) = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
-    }
+    weights_image_block(a.src[blockIdx.y], dst + (size_t)blockIdx.y * planes * D * D, D, transposed, planes, blockIdx.x, gridDim.x);
 }
 }  // namespace amid
 

@@ -406,6 +406,254 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
     w_ring_wait();                                          // the last (redundant) weight fetch targets this workgroup's LDS
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The same forward, products on bf16 pieces (fp32 accuracy), with the pieces made by the PRODUCER of every operand: the exchange between
+// the column parts of a strip carries operand fragments of pieces (seqn_parts.h SeqRing3 / xp_write / part_mma_xp).  LDS: three 32 KB
+// plane slots [M][L][H] + WPS x 12 KB of exchange; the attention images take M + L between the q and out-projection products.
+// LayerNorm statistics come from the row put back together (hi + mid + lo is the value exactly); only the own columns' gains are held.
+template <int D, int WPS, int NS>
+__global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwdArgs a, const SeqGeom sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = D / 16, NW = WPS * NS, NCT = NT / NS;
+    constexpr int H = NT, NH = NCT;
+    static_assert(D == 128 && NCT >= 2 && NCT % 2 == 0, "a wave owns whole k-steps of the next product's operand");
+    const int w = wave_id(), lane = lane_id(), m = lane & 15, gq = lane >> 4;
+    const int part = w / WPS;
+    const int si = (NW == 8 && w >= 4) ? WPS - 1 - (w % WPS) : w % WPS;
+    const int c0 = part * NCT;
+    int n0 = sg.B, b = 0, g = 0;
+    if (sg.live != nullptr) {
+        n0 = sg.live[sg.B];
+        b = sg.live[min((int)blockIdx.x, sg.B - 1)];
+        if ((int)blockIdx.x >= sg.B) return;
+        g = (int)blockIdx.x >= n0 ? 1 : 0;
+    } else {
+        g = (int)blockIdx.x >= sg.B ? 1 : 0;
+        b = (int)blockIdx.x - g * sg.B;
+    }
+    using Ring = SeqRing3<D, NW>;
+    Ring ring(smem);
+    auto w16 = [&](int layer, int which) { return a.w16 + ((size_t)((layer * 2 + g) * 6 + which)) * 3 * D * D; };     // q, k, v, o, c1, c2
+    ring.first(w16(0, 1));
+    float* const xps = smem + 3 * Ring::SLAB + si * XpStrip<D>::FLOATS;         // this strip's exchange slots
+    float* const stat = smem + 3 * Ring::SLAB + WPS * XpStrip<D>::FLOATS;        // [2][strip][part][16 rows] LayerNorm row sums
+    const int t = si * 16 + m;
+    const bool row_ok = t < sg.T;
+    const int local = b * sg.T + min(t, sg.T - 1);
+    const unsigned phys = (unsigned)g * (unsigned)sg.M + (unsigned)(b * sg.T + t);
+    const unsigned off_full = row_ok ? phys * (unsigned)(D * 4) + 16u * (unsigned)gq : STRIP_OOB;
+    const unsigned off_own = row_ok ? off_full + (unsigned)c0 * 64u : STRIP_OOB;
+    unsigned long long seed = 0; unsigned step = 0;
+    if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
+
+    PartRegs<NCT> Xo, Qno, Ko, Vo, Qo, Oo, Ro, Yo, Ho, bias, lwo, lbo;
+    part_load<NCT>(Xo, GBuf(a.x0, sg.act_bytes), off_own);
+    unsigned tmw[NCT];
+    const bool has_tm = a.tmq != nullptr;
+    if (has_tm) {
+        const GBuf gtm(a.tmq, sg.tm_bytes);
+        const unsigned tbase = row_ok ? phys * (unsigned)(D / 4) + (unsigned)c0 * 4u : STRIP_OOB;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) tmw[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(gtm.r, (int)(tbase + 4 * c), 0, 0);
+    }
+    xp_write<NCT>(xps, c0, Xo);                             // (rows past T arrive as zeros: the buffer descriptor's out-of-range reads)
+    f32x4 acc[NCT];
+    SEQN_STAMP0(62);
+#pragma unroll 1
+    for (int l = 0; l < a.n_layers; ++l) {
+        const SeqLayer& P = a.L[l];
+        const bool last = l + 1 == a.n_layers;
+        const GBuf gqn(P.qn, sg.act_bytes), gq_(P.q, sg.act_bytes), gk(P.k, sg.act_bytes), gv(P.v, sg.act_bytes),
+                   go(P.o, sg.act_bytes), gst(P.stats, sg.stats_bytes), gr(P.r, sg.act_bytes), gy(P.y, sg.act_bytes), gh(P.h, sg.act_bytes);
+        part_cols<NCT>(lwo, P.ln1_w[g], c0); part_cols<NCT>(lbo, P.ln1_b[g], c0);
+        SEQN_STAMP(0);
+        ring.next();                                       // Wk has landed; the row of x is in the exchange slots
+        SEQN_STAMP(1);
+        {   // Qn = LN1(x) on the own columns
+            StripRegs<D> F;
+            xp_row<D>(F, xps);
+            float mean, rstd;
+            strip_stats<D>(F, a.ln_eps, mean, rstd);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Qno.v[c][r] = (Xo.v[c][r] - mean) * rstd * lwo.v[c][r] + lbo.v[c][r];
+        }
+        SEQN_STAMP(2);
+        {   // k = x Wk^T + bk
+            part_cols<NCT>(bias, P.b_in[g] + D, c0);
+            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 2), c0, [&](int ct, int j) { part_spread<NCT>(gqn, off_own, Qno, ct, j, 1); });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Ko.v[c] = acc[c] + bias.v[c];
+        }
+        SEQN_STAMP(3);
+        {   // v = x Wv^T + bv
+            ring.next();
+            SEQN_STAMP(4);
+            part_cols<NCT>(bias, P.b_in[g] + 2 * D, c0);
+            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 0), c0, [&](int ct, int j) { part_spread<NCT>(gk, off_own, Ko, ct, j, 1); });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Vo.v[c] = acc[c] + bias.v[c];
+        }
+        SEQN_STAMP(5);
+        lds_barrier();                                     // every wave of the strip has read the last fragment of x
+        xp_write<NCT>(xps, c0, Qno);
+        {   // q = Qn Wq^T + bq
+            ring.next();
+            SEQN_STAMP(6);
+            ring.hold_next = true;                         // M + L hold the attention images behind this product
+            part_cols<NCT>(bias, P.b_in[g], c0);
+            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 3), c0, [&](int ct, int j) { part_spread<NCT>(gv, off_own, Vo, ct, j, 1); });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Qo.v[c] = acc[c] + bias.v[c];
+        }
+        SEQN_STAMP(7);
+        part_store<NCT>(gq_, off_own, Qo);
+        float* kimg = ring.images();
+        float* vimg = kimg + NIMG_KEYS * D;
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const int m_ = lane_l & 15, gl_ = lane_l >> 4;
+        lds_barrier();                                     // (M / L were read in the q product's first pass, two barriers ago; kept for the images' sake)
+        {
+            const int R = si * 16 + m_;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int h = c0 + c;
+                lds_st4(kimg + R * D + 4 * ((4 * h + gl_) ^ m_), Ko.v[c]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = h * 16 + 4 * gl_ + r;
+                    lds_st1(vimg + d * NIMG_KEYS + (((R >> 2) ^ (d & 15)) * 4) + (R & 3), Vo.v[c][r]);
+                }
+            }
+        }
+        lds_barrier();
+        SEQN_STAMP(8);
+        float st_max[NH], st_rl[NH];
+        seqn_attention<D, WPS, NCT, false>(Oo, st_max, st_rl, Qo, kimg, vimg, c0, si, m_, gl_, si * 16 + m_, sg.T, (unsigned long long)b * H, a.att_scale,
+                                           a.train, seed, site_id(g, l, SITE_ATTN), step, a.spec, a.dscale);
+        SEQN_STAMP(9);
+        {
+            const unsigned so = row_ok ? phys * (unsigned)(H * 8) + (unsigned)c0 * 8u : STRIP_OOB;
+            f32x4 sv = f32x4{st_max[0], st_rl[0], st_max[1], st_rl[1]};
+#pragma unroll
+            for (int k = 1; k < NH / 2; ++k) sv = (gq == k) ? f32x4{st_max[2 * k], st_rl[2 * k], st_max[2 * k + 1], st_rl[2 * k + 1]} : sv;
+            gst.store4(gq < NH / 2 ? so + 16u * (unsigned)gq : STRIP_OOB, sv);
+        }
+        // ---- r = Qn + (o Wo^T + bo) ; y = LN2(r)
+        xp_write<NCT>(xps, c0, Oo);                        // (the q product's reads of the slots lie behind the core's barriers)
+        part_cols<NCT>(bias, P.b_o[g], c0);
+        {
+            ring.next();
+            SEQN_STAMP(10);
+            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 4), c0, [&](int ct, int j) { part_spread<NCT>(go, off_own, Oo, ct, j, 1); });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Ro.v[c] = Qno.v[c] + (acc[c] + bias.v[c]);
+        }
+        SEQN_STAMP(11);
+        part_cols<NCT>(lwo, P.ln2_w[g], c0); part_cols<NCT>(lbo, P.ln2_b[g], c0);
+        uint4 rr1 = make_uint4(0, 0, 0, 0), rr2 = rr1;
+        if (a.train) {
+            rr1 = rng_call(seed, (unsigned long long)local * D >> 7, site_id(g, l, SITE_FFN1), step);
+            rr2 = rng_call(seed, (unsigned long long)local * D >> 7, site_id(g, l, SITE_FFN2), step);
+        }
+        SEQN_STAMP(12);
+        {   // y = LN2(r) on the own columns: r itself is nobody's operand, so only the row sums cross the column parts (two floats per row and
+            // part through `stat`; the sums are taken in the order strip_stats takes them over a whole row, part by part)
+            float sm = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) sm += (Ro.v[c][0] + Ro.v[c][1]) + (Ro.v[c][2] + Ro.v[c][3]);
+            sm = row_sum4(sm);
+            if (gq == 0) lds_st1(stat + (si * NS + part) * 16 + m, sm);
+            lds_barrier();
+            float tot = 0.f;
+#pragma unroll
+            for (int p2 = 0; p2 < NS; ++p2) tot += *(__attribute__((address_space(3))) float*)(stat + (si * NS + p2) * 16 + m);
+            const float mean = tot * (1.0f / D);
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = Ro.v[c][r] - mean; q = fmaf(d, d, q); }
+            q = row_sum4(q);
+            if (gq == 0) lds_st1(stat + (WPS * NS + si * NS + part) * 16 + m, q);
+            lds_barrier();
+            float qt = 0.f;
+#pragma unroll
+            for (int p2 = 0; p2 < NS; ++p2) qt += *(__attribute__((address_space(3))) float*)(stat + (WPS * NS + si * NS + p2) * 16 + m);
+            const float rstd = 1.0f / sqrtf(qt * (1.0f / D) + a.ln_eps);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Yo.v[c][r] = (Ro.v[c][r] - mean) * rstd * lwo.v[c][r] + lbo.v[c][r];
+        }
+        xp_write<NCT>(xps, c0, Yo);                         // (the o fragments were read two barriers ago)
+        {   // h = relu(drop1(y C1^T + c1))
+            ring.next();
+            SEQN_STAMP(13);
+            part_cols<NCT>(bias, P.b1[g], c0);
+            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 5), c0, [&](int ct, int j) { part_spread<NCT>(gr, off_own, Ro, ct, j, 1); });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Ho.v[c] = acc[c] + bias.v[c];
+            if (a.train) part_dropout<NCT>(Ho, rr1, c0, a.spec, a.ffn_scale, (local * D) & 127);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ho.v[c][r] = fmaxf(Ho.v[c][r], 0.f);
+        }
+        SEQN_STAMP(14);
+        lds_barrier();
+        xp_write<NCT>(xps, c0, Ho);
+        {   // x' = (drop2(h C2^T + c2) + y) * ~tm
+            ring.next();
+            SEQN_STAMP(15);
+            part_cols<NCT>(bias, P.b2[g], c0);
+            seqn_product_xp<D, NCT>(acc, xps, ring, w16(last ? l : l + 1, 1), c0, [&](int ct, int j) {
+                part_spread<NCT>(gy, off_own, Yo, ct, j, 1);
+                part_spread<NCT>(gh, off_own, Ho, ct, j, 3);
+            });
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Xo.v[c] = acc[c] + bias.v[c];
+            if (a.train) part_dropout<NCT>(Xo, rr2, c0, a.spec, a.ffn_scale, (local * D) & 127);
+            const int sh = 8 * gq;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                Xo.v[c] += Yo.v[c];
+                if (has_tm) {
+                    const unsigned bits = tmw[c] >> sh;
+                    Xo.v[c][0] = (bits & 1u) ? 0.f : Xo.v[c][0];
+                    Xo.v[c][1] = (bits & 2u) ? 0.f : Xo.v[c][1];
+                    Xo.v[c][2] = (bits & 4u) ? 0.f : Xo.v[c][2];
+                    Xo.v[c][3] = (bits & 8u) ? 0.f : Xo.v[c][3];
+                }
+            }
+        }
+        SEQN_STAMP(16);
+        if (!last) {
+            lds_barrier();
+            xp_write<NCT>(xps, c0, Xo);
+            part_store<NCT>(GBuf(a.L[l + 1].x, sg.act_bytes), off_own, Xo);
+        } else {
+            part_store<NCT>(GBuf(a.xout, sg.act_bytes), off_own, Xo);
+        }
+    }
+    SEQN_STAMP0(63);
+    w_ring_wait();
+}
+
+template <int D, int WPS, int NS>
+static int seqn_launch_px(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
+    constexpr size_t lds = (size_t)(3 * (D * D / 2) + WPS * XpStrip<D>::FLOATS + 2 * WPS * NS * 16) * sizeof(float);
+    auto kern = seqn_fwd_px_kernel<D, WPS, NS>;
+    static unsigned long long attr_done = 0;
+    if (int rc = lds_attr_once((const void*)kern, lds, attr_done)) return rc;
+    const int grid = sg.live != nullptr ? sg.B : 2 * sg.B;
+    kern<<<grid, 64 * WPS * NS, lds, (hipStream_t)stream>>>(a, sg);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? AMID_OK : (int)e;
+}
+
 template <int D, int WPS, bool BF, bool P3 = false> static constexpr size_t seqn_lds_bytes() {
     return (size_t)(((BF && !P3) ? D * D : 2 * D * D) + (((BF && !P3) || D == 64) ? 2 * NIMG_KEYS * D : 0) + WPS * (D / 16) * 64 * 4) * sizeof(float);
 }
@@ -422,9 +670,14 @@ static int seqn_launch_t(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
     return e == hipSuccess ? AMID_OK : (int)e;
 }
 
+static int g_seqn_px = 1;       // planes == 3: 1 = the producer-side pieces build (seqn_fwd_px_kernel), 0 = SeqRing16x3's (amid_sas_seq_fwd_split_build)
+
 template <int WPS, int NS>
 static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
-    if (a.w16 != nullptr && a.w16_planes == 3) return seqn_launch_t<128, WPS, NS, true, true>(a, sg, stream);
+    if (a.w16 != nullptr && a.w16_planes == 3) {
+        if constexpr ((128 / 16 / NS) % 2 == 0) { if (g_seqn_px) return seqn_launch_px<128, WPS, NS>(a, sg, stream); }
+        return seqn_launch_t<128, WPS, NS, true, true>(a, sg, stream);
+    }
     return a.w16 != nullptr ? seqn_launch_t<128, WPS, NS, true>(a, sg, stream) : seqn_launch_t<128, WPS, NS, false>(a, sg, stream);
 }
 

@@ -398,6 +398,172 @@ __device__ __forceinline__ void seqn_product(f32x4 (&acc)[NCT], const StripRegs<
     }
 }
 
+// ---- the same products with the operand's pieces made ONCE, by the wave that produced the operand (seqn_fwd_px_kernel) ----------------
+// In SeqRing16x3's build every wave splits the whole row of its strip into pieces itself, in both passes: eight splits of eight values
+// per product, more vector issue slots than the 96 matrix instructions leave free, and a 32-register operand on top of the pieces.
+// Here the exchange between the column parts of a strip carries bf16 PIECES: a wave splits its own D / NS columns once per product and
+// writes whole operand fragments ([strip][k-step][piece][lane] x 16 bytes: the eight values a lane supplies in a k-step are its elements
+// of column tiles 2 s and 2 s + 1), the products read fragments -- no split, no whole-row operand in registers.  48 KB of exchange
+// (WPS = 4) beside THREE 32 KB plane slots [M][L][H]: with one H slot a product's hi plane is requested when the product begins and
+// awaited behind its first pass; its mid / lo planes were requested behind the previous product's first pass.
+template <int D, int NW> struct SeqRing3 {
+    static constexpr int NWAVES = NW;
+    static constexpr int CPR = D / 8;
+    static constexpr int PIECES = D * CPR / 64, PER_WAVE = PIECES / NW;
+    static constexpr int SLAB = D * D / 2;
+    float* buf; unsigned off0; int w;
+    const unsigned short* cur; const unsigned short* nxt;
+    bool hi_ready, rest_ready, rest_late, hold_next;
+    __device__ __forceinline__ explicit SeqRing3(float* lds)
+        : buf(lds), cur(nullptr), nxt(nullptr), hi_ready(false), rest_ready(false), rest_late(false), hold_next(false) {
+        w = wave_id();
+        const int p = w * 64 + lane_id();
+        const int n = p / CPR, pos = p % CPR;
+        off0 = (unsigned)(n * D * 2 + ((pos ^ (n & 15)) * 16));
+    }
+    __device__ __forceinline__ float* mslot() const { return buf; }
+    __device__ __forceinline__ float* lslot() const { return buf + SLAB; }
+    __device__ __forceinline__ float* hslot() const { return buf + 2 * SLAB; }
+    __device__ __forceinline__ float* images() const { return buf; }                 // M + L
+    __device__ __forceinline__ void piece(float* __restrict__ dst, const unsigned short* __restrict__ W, int k0) const {
+        const unsigned voff = off0 + (unsigned)k0 * (unsigned)(NW * 64 / CPR) * (unsigned)(D * 2);
+        const unsigned lds = __builtin_amdgcn_readfirstlane(
+            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(dst + (k0 * NW + w) * 256));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
+    }
+    __device__ __forceinline__ void plane(float* __restrict__ dst, const unsigned short* __restrict__ Wp) const {
+#pragma unroll
+        for (int k0 = 0; k0 < PER_WAVE; ++k0) piece(dst, Wp, k0);
+    }
+    __device__ __forceinline__ void first(const unsigned short* __restrict__ W0) {
+        cur = W0; hi_ready = true; rest_ready = true;
+        plane(hslot(), W0); plane(mslot(), W0 + (size_t)D * D); plane(lslot(), W0 + (size_t)2 * D * D);
+    }
+    __device__ __forceinline__ void next() {                 // a product begins: every wave is past the previous one (and the images)
+        w_ring_wait();
+        __syncthreads();
+        if (!hi_ready) plane(hslot(), cur);
+        rest_late = !rest_ready;
+        if (rest_late) { plane(mslot(), cur + (size_t)D * D); plane(lslot(), cur + (size_t)2 * D * D); }
+    }
+    __device__ __forceinline__ void begin(const unsigned short* __restrict__ Wnext) { nxt = Wnext; }
+    __device__ __forceinline__ void pre_pass1() {            // (the product behind the attention core: its planes were requested just now)
+        if (rest_late) { w_ring_wait(); __syncthreads(); }
+    }
+    __device__ __forceinline__ void mid_sync() {             // behind the first pass: the hi plane has landed, M / L take the next weight's planes
+#ifndef AMID_XNOWAIT
+        w_ring_wait();
+#endif
+        __syncthreads();
+        rest_ready = !hold_next;
+        if (rest_ready) { plane(mslot(), nxt + (size_t)D * D); plane(lslot(), nxt + (size_t)2 * D * D); }
+        hold_next = false;
+        cur = nxt; hi_ready = false;
+    }
+};
+
+// a strip's exchange slots of pieces: [k-step][piece][lane] x 16 bytes
+template <int D> struct XpStrip { static constexpr int FLOATS = (D / 32) * 3 * 64 * 4; };
+template <int NCT>
+__device__ __forceinline__ void xp_write(float* __restrict__ xps, int c0, const PartRegs<NCT>& x) {
+    static_assert(NCT % 2 == 0, "a wave owns whole k-steps (pairs of column tiles)");
+    const int lane = lane_id();
+#pragma unroll
+    for (int e = 0; e < NCT / 2; ++e) {
+        const int s = c0 / 2 + e;
+        const WgSplit2 p0 = wg_split3(x.v[2 * e][0], x.v[2 * e][1]), p1 = wg_split3(x.v[2 * e][2], x.v[2 * e][3]);
+        const WgSplit2 p2 = wg_split3(x.v[2 * e + 1][0], x.v[2 * e + 1][1]), p3 = wg_split3(x.v[2 * e + 1][2], x.v[2 * e + 1][3]);
+        lds_st4(xps + ((s * 3 + 0) * 64 + lane) * 4, __builtin_bit_cast(f32x4, amid_v4u{p0.hi, p1.hi, p2.hi, p3.hi}));
+        lds_st4(xps + ((s * 3 + 1) * 64 + lane) * 4, __builtin_bit_cast(f32x4, amid_v4u{p0.mid, p1.mid, p2.mid, p3.mid}));
+        lds_st4(xps + ((s * 3 + 2) * 64 + lane) * 4, __builtin_bit_cast(f32x4, amid_v4u{p0.lo, p1.lo, p2.lo, p3.lo}));
+    }
+}
+__device__ __forceinline__ amid_v4u xp_frag(const float* __restrict__ xps, int s, int p) {
+    const float4 t = lds_ld4(xps + ((s * 3 + p) * 64 + lane_id()) * 4);
+    return __builtin_bit_cast(amid_v4u, t);
+}
+// the strip's whole row back in fp32 (hi + mid + lo is the value exactly): LayerNorm statistics
+template <int D>
+__device__ __forceinline__ void xp_row(StripRegs<D>& full, const float* __restrict__ xps) {
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+        const amid_v4u h = xp_frag(xps, s, 0), m = xp_frag(xps, s, 1), l = xp_frag(xps, s, 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = (__uint_as_float(h[j] << 16) + __uint_as_float(m[j] << 16)) + __uint_as_float(l[j] << 16);
+            const float hi = (__uint_as_float(h[j] & 0xffff0000u) + __uint_as_float(m[j] & 0xffff0000u)) + __uint_as_float(l[j] & 0xffff0000u);
+            full.v[2 * s + (j >> 1)][2 * (j & 1)] = lo;
+            full.v[2 * s + (j >> 1)][2 * (j & 1) + 1] = hi;
+        }
+    }
+}
+
+// acc[c] += A W^T over the own column tiles: operand fragments from the strip's exchange slots, weight planes from SeqRing3
+template <int D, int NCT, class Ring>
+__device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __restrict__ xps, Ring& ring, int c0) {
+    constexpr int KS = D / 32;
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int rowo = (c0 * 16 + i) * (D / 2);
+    auto frag = [&](const float* plane, int c, int s) { return lds_ld4(plane + rowo + c * 16 * (D / 2) + 4 * ((4 * s + g) ^ i)); };
+    auto mma = [&](const float4& wf, const amid_v4u& a16, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(seqn_bf16x8, wf), __builtin_bit_cast(seqn_bf16x8, a16), c, 0, 0, 0);
+    };
+    const float* mbuf = ring.mslot();
+    const float* lbuf = ring.lslot();
+    ring.pre_pass1();
+    // pass 1: the lo plane against the operand's hi piece, the mid plane against (mid, hi)
+    {
+        float4 wm = frag(mbuf, 0, 0), wl = frag(lbuf, 0, 0);
+        amid_v4u ah = xp_frag(xps, 0, 0), am = xp_frag(xps, 0, 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const amid_v4u ch = ah, cmid = am;
+            if (s + 1 < KS) { ah = xp_frag(xps, s + 1, 0); am = xp_frag(xps, s + 1, 1); }
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float4 cm = wm, cl = wl;
+                const int cn = c + 1 < NCT ? c + 1 : 0, sn = c + 1 < NCT ? s : s + 1;
+                if (sn < KS) { wm = frag(mbuf, cn, sn); wl = frag(lbuf, cn, sn); }
+                acc[c] = mma(cl, ch, acc[c]); acc[c] = mma(cm, cmid, acc[c]); acc[c] = mma(cm, ch, acc[c]);
+            }
+        }
+    }
+    const float* hbuf = ring.hslot();
+    ring.mid_sync();
+    // pass 2: the hi plane against the operand's three pieces
+    {
+        float4 wf = frag(hbuf, 0, 0);
+        amid_v4u ah = xp_frag(xps, 0, 0), am = xp_frag(xps, 0, 1), al = xp_frag(xps, 0, 2);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const amid_v4u ch = ah, cmid = am, clo = al;
+            if (s + 1 < KS) { ah = xp_frag(xps, s + 1, 0); am = xp_frag(xps, s + 1, 1); al = xp_frag(xps, s + 1, 2); }
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float4 cf = wf;
+                const int cn = c + 1 < NCT ? c + 1 : 0, sn = c + 1 < NCT ? s : s + 1;
+                if (sn < KS) wf = frag(hbuf, cn, sn);
+                acc[c] = mma(cf, clo, acc[c]); acc[c] = mma(cf, cmid, acc[c]); acc[c] = mma(cf, ch, acc[c]);
+            }
+        }
+    }
+}
+
+// one product of seqn_fwd_px_kernel: the next weight is announced, the deferred stores leave behind the matrix instructions
+template <int D, int NCT, class Ring, class Stores>
+__device__ __forceinline__ void seqn_product_xp(f32x4 (&acc)[NCT], const float* __restrict__ xps, Ring& ring, const unsigned short* __restrict__ wn16,
+                                                int c0, const Stores& stores) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ring.begin(wn16);
+    part_mma_xp<D, NCT>(acc, xps, ring, c0);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) { stores(ct, 1); stores(ct, 3); }
+}
+
 // the own column tiles of a per-column vector held whole: two parts -- selects on the wave-uniform part index; more parts -- loaded
 // (select chains over four or eight candidates end up as scratch arrays)
 template <int D, int NCT>

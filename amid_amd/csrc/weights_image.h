@@ -1,0 +1,33 @@
+// bf16 fragment images of square [D][D] fp32 matrices (see amid_sas_weights_bf16 in sasrec_seq.hip for the layout): one 256-thread block's
+// share of one matrix -- shared by the standalone launch and by the riders of the gather K1 (embed.hip).
+#pragma once
+#include "common.h"
+#include "bf16_pieces.h"
+
+namespace amid {
+
+// chunk q = n * (D / 8) + c of the image: row n, chunk c = 4 s + g = W[n][32 s + 4 g + 0..3], W[n][32 s + 16 + 4 g + 0..3];
+// planes = 3: every element as hi + mid + lo, one image per piece ([3][D][D] bf16 per matrix)
+__device__ __forceinline__ void weights_image_block(const float* __restrict__ W, unsigned short* __restrict__ out, int D, int transposed,
+                                                    int planes, int block, int nblocks) {
+    const int cpr = D / 8;
+    for (int q = block * 256 + threadIdx.x; q < D * cpr; q += nblocks * 256) {
+        const int n = q / cpr, c = q % cpr;
+        const int s = c >> 2, g = c & 3;
+        unsigned pk[3][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = 32 * s + 16 * h + 4 * g + 2 * e;
+                const float v0 = transposed ? W[(size_t)k * D + n] : W[(size_t)n * D + k];
+                const float v1 = transposed ? W[(size_t)(k + 1) * D + n] : W[(size_t)n * D + k + 1];
+                const WgSplit2 sp = wg_split3(v0, v1);        // (hi = the round-to-nearest-even bf16 pair of the one-plane image)
+                pk[0][2 * h + e] = sp.hi; pk[1][2 * h + e] = sp.mid; pk[2][2 * h + e] = sp.lo;
+            }
+        for (int p = 0; p < planes; ++p)
+            *reinterpret_cast<uint4*>(out + (size_t)p * D * D + (size_t)q * 8) = make_uint4(pk[p][0], pk[p][1], pk[p][2], pk[p][3]);
+    }
+}
+
+}  // namespace amid

@@ -311,12 +311,11 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # instructions.  Error against the fp64 product 3.8e-7 of the largest entry either way, 4.4e-7 for the fp32 instructions.
     WGRAD_SPLIT = os.environ.get("AMID_WGRAD_SPLIT", "6")
     # compute = "fp32": the one-launch forward's twelve projections on the bf16 matrix cores at fp32 accuracy too (three bf16 pieces per
-    # operand, six piece pairs: amid_sas_seq_fwd_split_f32, csrc/seqn_parts.h SeqRing16x3).  Built, parity-tested (3e-6 of every saved
-    # tensor's largest entry against the fp32 build) and measured SLOWER so far -- 0.3738 against 0.3564 ms/step at cfg 2: the products'
-    # matrix time drops from 8192 to 3072 cycles per SIMD, but a 96 KB weight walks through the 128 KB ring plane by plane (a second
-    # barrier per product), the operand is split twice and the fragment reads are not pipelined across k-steps: 8-10 k cycles per
-    # product against 9.3 k.  Off by default; "1" turns it on.
-    FWD_SPLIT = os.environ.get("AMID_FWD_SPLIT", "0") != "0"
+    # operand, six piece pairs; the pieces are made once, by the wave that produced the operand, and cross the strip's column parts as
+    # operand fragments: amid_sas_seq_fwd_split_f32, csrc/sasrec_seqn.hip seqn_fwd_px_kernel; weight images by the gather's extra
+    # workgroups).  Every saved tensor within 3e-6 of the fp32 build's; 153 k cycles against 187 k, step 0.3562 -> 0.3510 ms at cfg 2 (the
+    # bf16-dense kernel runs at a lower clock: 15 % fewer cycles, 7 % less time).  "0": fp32 matrix instructions.
+    FWD_SPLIT = os.environ.get("AMID_FWD_SPLIT", "1") != "0"
     # The train step's encoder backward (data gradients) as ONE launch over the live sequences where csrc/sasrec_strip.hip covers the
     # shape (amid_sas_seq_bwd_f32): "auto" = where it wins.  It tiles one sequence per workgroup, a whole CU each, so the step's sort
     # riders find no free CU in it and the sort goes back to the side stream (a fork and a join, ~10 us of a replayed graph).  Measured
@@ -390,6 +389,27 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         gap = ent[0].shape[0] if ent is not None else self.catchup_gap_hint
         return gap is not None and gap <= self.FOLD_MAX_GAP
 
+    def _w16_images(self, planes: int):
+        """(host pointer array of the 24 encoder weights [layer][domain][q, k, v, o, conv1, conv2], the image buffer) for `planes` bf16
+        planes per weight (1: operands rounded to bf16; 3: hi + mid + lo = the fp32 weight exactly)."""
+        D, fp = self.D, self.dense
+        if getattr(self, "_w16_planes", 0) != planes:
+            self.w16 = torch.empty(2, 2, 6, planes, D * D, dtype=torch.bfloat16, device=self.device)
+            self._w16_planes = planes
+            srcs = []
+            for l in (0, 1):
+                for g in (1, 2):
+                    srcs += [fp.ptr(f"sac{g}.attention_layers.{l}.in_proj_weight", None, j * D * D) for j in range(3)]
+                    srcs += [fp.ptr(f"sac{g}.attention_layers.{l}.out_proj.weight"), fp.ptr(f"sac{g}.forward_layers.{l}.conv1.weight"),
+                             fp.ptr(f"sac{g}.forward_layers.{l}.conv2.weight")]
+            self._w16_src = ptr_array(srcs)
+        return self._w16_src, self.w16
+
+    def _fwd_on_pieces(self, pl: SasrecPlan, B: int, T: int) -> bool:
+        """Whether this step's encoder forward is the one-launch kernel with its products on bf16 pieces (amid_sas_seq_fwd_split_f32)."""
+        return bool(self.compute != "bf16" and self.FWD_SPLIT and self.D == 128 and pl.strip and self.SEQ_FORWARD and not self.inc_bs
+                    and lib().value("amid_sas_seq_supported", B, T, self.D, self.H))
+
     def _enqueue_k1(self, pl: SasrecPlan, pos0, pos1, tmq, tr: int, p_drop: float, lf) -> None:
         """The gather K1 of a forward in the variant the step needs: over every sequence or the live list `lf`, writing the compact index
         list, with the folded catch-up (+ phase 1 of a riding sort)."""
@@ -404,6 +424,11 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             L.call("amid_embed_fwd_replay_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
                    pl.idx_all.data_ptr(), pos0, pos1, B, T, D, B * NI, pl.xg.data_ptr(), tmq, st, tr, p_drop, lf, ic, rc, st,
                    self._sort_plan(pl) if ride else None, 1 if ride else 0, s)
+        elif self._fwd_on_pieces(pl, B, T):          # the gather's extra workgroups write this step's weight images (three bf16 planes each)
+            src, w16 = self._w16_images(3)
+            L.call("amid_embed_fwd_w16_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), pos0, pos1, B, T, D, B * NI, pl.xg.data_ptr(), tmq, st,
+                   tr, p_drop, lf, ic, rc, src, 24, 3, w16.data_ptr(), s)
+            pl.w16_written = True
         elif compact:
             L.call("amid_embed_fwd_live_compact_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), pos0, pos1, B, T, D, B * NI, pl.xg.data_ptr(),
                    tmq, st, tr, p_drop, lf, ic, rc, s)
@@ -506,22 +531,15 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                      fam("sac{d}.forward_layers.{l}.conv2.weight"), fam("sac{d}.forward_layers.{l}.conv2.bias"),
                      tl(pl.qn), tl(pl.q), tl(pl.k), tl(pl.v), tl(pl.o), tl(pl.stats), tl(pl.r), tl(pl.y), tl(pl.h))
                 self._ptr_cache[key] = c
-            split = self.compute != "bf16" and self.FWD_SPLIT and D == 128
+            split = self._fwd_on_pieces(pl, B, T)
             if self.compute == "bf16" or split:       # this step's weights as bf16 fragment images (one plane: operands rounded to bf16;
                 planes = 3 if split else 1            # three: hi + mid + lo = the fp32 weight exactly), then the forward on them
-                if getattr(self, "_w16_planes", 0) != planes:
-                    self.w16 = torch.empty(2, 2, 6, planes, D * D, dtype=torch.bfloat16, device=self.device)
-                    self._w16_planes = planes
-                    srcs = []
-                    for l in (0, 1):
-                        for g in (1, 2):
-                            srcs += [fp.ptr(f"sac{g}.attention_layers.{l}.in_proj_weight", None, j * D * D) for j in range(3)]
-                            srcs += [fp.ptr(f"sac{g}.attention_layers.{l}.out_proj.weight"), fp.ptr(f"sac{g}.forward_layers.{l}.conv1.weight"),
-                                     fp.ptr(f"sac{g}.forward_layers.{l}.conv2.weight")]
-                    self._w16_src = ptr_array(srcs)
-                L.call("amid_sas_weights_bf16_planes", self._w16_src, 24, D, 0, planes, self.w16.data_ptr(), s)
+                src, w16 = self._w16_images(planes)
+                if not getattr(pl, "w16_written", False):      # (the train step's gather K1 wrote them with extra workgroups)
+                    L.call("amid_sas_weights_bf16_planes", src, 24, D, 0, planes, w16.data_ptr(), s)
+                pl.w16_written = False
                 L.call("amid_sas_seq_fwd_split_f32" if split else "amid_sas_seq_fwd_bf16w_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:],
-                       pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, self.w16.data_ptr(), s)
+                       pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(), s)
             else:
                 L.call("amid_sas_seq_fwd_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:], pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr,
                        SASREC_P_DROP, s)

@@ -175,6 +175,8 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_sas_seq_fwd_f32": ("mfma", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
         # compute=bf16: the same launch with bf16 operands on the projections (fp32 accumulation; the attention core stays fp32): priced on the bf16 peak
         "amid_sas_seq_fwd_bf16w_f32": ("mfma16", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
+        # the default forward: its twelve projections as six bf16 piece-pair products each (fp32 accuracy), the attention core on fp32 MFMA
+        "amid_sas_seq_fwd_split_f32": ("mfma16x6", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
         "amid_sas_strip_qkv_fwd_f32": ("mfma", 3 * gl),
         "amid_sas_strip_oproj_ffn_fwd_f32#0": ("mfma", 6 * gl),       # layer 0's out-proj + FFN, layer 1's q / k / v
         "amid_sas_strip_oproj_ffn_fwd_f32#1": ("mfma", 3 * gl),
@@ -188,6 +190,8 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         # K1 with the lazy-Adam catch-up folded in: + the stamp of every gathered position (m and v of the few lagging rows: not counted)
         "amid_embed_fwd_replay_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (8 + 2 * D * 4) + Bw * T * (D // 4)),
         "amid_embed_fwd_live_compact_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (12 + 2 * D * 4) + Bw * T * (D // 4)),
+        # the same gather + 24 weights read and written as three bf16 planes by its extra workgroups (the forward's weight images)
+        "amid_embed_fwd_w16_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (12 + 2 * D * 4) + Bw * T * (D // 4) + 24 * D * D * 10),
         "amid_sas_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_sas_oproj_fwd_f32": ("mfma", gemm),
         "amid_sas_oproj_ffn_fwd_f32": ("mfma", 3 * gemm),
@@ -247,7 +251,8 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_qkv_ffn_bwd_f32": "sas_qkv_ffn_bwd_kernel", "amid_sas_oproj_ffn_qkv_fwd_f32": "sas_oproj_ffn_qkv_fwd_kernel",
     "amid_sas_oproj_ffn_fwd_f32": "sas_oproj_ffn_fwd_kernel",
     "amid_attn_fwd_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_f32": "embed_fwd_kernel",
-    "amid_sas_seq_fwd_f32": ("seqn_fwd_kernel", "seq_fwd_kernel"), "amid_sas_seq_fwd_bf16w_f32": ("seqn_fwd_kernel", "seq_fwd_kernel"),
+    "amid_sas_seq_fwd_f32": ("seqn_fwd_kernel", "seq_fwd_kernel"), "amid_sas_seq_fwd_bf16w_f32": ("seqn_fwd_kernel", "seq_fwd_kernel"), "amid_sas_seq_fwd_split_f32": ("seqn_fwd_px_kernel", "seqn_fwd_kernel"),
+    "amid_embed_fwd_w16_f32": "embed_fwd_kernel",
     "amid_sas_seq_bwd_f32": ("seqn_bwd_kernel", "seq_bwd_kernel"), "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
     "amid_sas_strip_oproj_ffn_fwd_f32#1": "strip_oproj_ffn_fwd_kernelILi128ELb0", "amid_sas_strip_ffn_bwd_f32": "strip_ffn_bwd_kernel",
     "amid_sas_strip_qkv_bwd_f32#0": "strip_qkv_bwd_kernelILi128ELb1", "amid_sas_strip_qkv_bwd_f32#1": "strip_qkv_bwd_kernelILi128ELb0",
@@ -309,6 +314,7 @@ def gather_stress(device, n_steps=6):
     role = {"amid_embed_fwd_live_f32": "K1 gather (live sequences)", "amid_embed_fwd_f32": "K1 gather",
             "amid_embed_fwd_live_compact_f32": "K1 gather (live sequences; writes the compact index list)",
             "amid_embed_fwd_replay_f32": "K1 gather (live sequences; lazy-Adam catch-up folded in: lagging rows replayed in registers)",
+            "amid_embed_fwd_w16_f32": "K1 gather (live sequences; compact index list; + the forward's 72 weight-image planes by extra workgroups)",
             "amid_lazy_adam_catchup_live_f32": "K4a lazy-Adam catch-up (live sequences)",
             "amid_grad_tail_f32": "K3 segment reduce + dense partial sums", "amid_embgrad_segreduce_f32": "K3 segment reduce",
             "amid_lazy_adam_catchup_positions_f32": "K4a lazy-Adam catch-up", "amid_optimizer_step_f32": "K4b Adam (dense + unique rows)"}
@@ -627,7 +633,8 @@ def main():
                 elif kind.startswith("mfma16x"):    # an fp32 product as six (nine) bf16 piece products: the bf16 pipe executes 6 (9) x the algorithmic FLOP
                     n = int(kind[7:])
                     ent.update(bound="mfma", achieved=round(amount / avg_s / 1e12, 2), peak=round(PEAK_BF16_MFMA_TFLOPS / n, 1), unit="TFLOP/s",
-                               operands=f"fp32 as three bf16 pieces, {n} piece pairs (peak = the bf16 matrix peak / {n})")
+                               operands=f"fp32 as three bf16 pieces, {n} piece pairs (peak = the bf16 matrix peak / {n})",
+                               frac_of_fp32_mfma_peak=round(amount / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
                 else:
                     ent.update(bound="mfma", achieved=round(amount / avg_s / 1e12, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
                 ent["frac"] = round(ent["achieved"] / ent["peak"], 4)
@@ -662,6 +669,9 @@ def main():
             roof["avg_launch_us"] = round(hot_us, 2)
             roof["achieved"] = round(amount / (hot_us * 1e-6) / scale, 1 if roof["bound"] == "hbm" else 2)
             roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+            if "frac_of_fp32_mfma_peak" in kernels[dom]:       # (the fp32 products run on the bf16 pipe: what the fp32 pipe's peak would make of it)
+                roof["frac_of_fp32_mfma_peak"] = round(roof["achieved"] / PEAK_F32_MFMA_TFLOPS, 4)
+                roof["operands"] = kernels[dom]["operands"]
             roof["timing"] = "HIP events around this kernel's launches only, 20 steps enqueued back to back (the queue stays full, as in the timed region)"
         roof["traffic"], src = pmc_traffic(dom, f"{args.workload}_{args.model}_{args.dtype}")
         if src:
