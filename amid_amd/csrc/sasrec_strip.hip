@@ -245,7 +245,7 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
         const float* buf = ring.next();
         strip_load<D>(Rs, GBuf(a.r, sg.act_bytes), row);               // LN2 input rows: needed two slabs from now
         strip_zero<D>(acc);
-        strip_mma_sel<D, RingT::BF16>(acc, P, buf, [&](int ct, int j) { ring.fetch(a.w1T[g], ct, j); store_spread<D>(gp2, row, P, ct, j); });
+        strip_product<D>(acc, P, buf, ring, [&](int ct, int j) { ring.fetch(a.w1T[g], ct, j); store_spread<D>(gp2, row, P, ct, j); });
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -255,7 +255,7 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
     {   // dy = dpre1 C1 + dz ; dr = LN2'(dy ; r)
         const float* buf = ring.next();
         strip_zero<D>(acc);
-        strip_mma_sel<D, RingT::BF16>(acc, P, buf, [&](int ct, int j) { ring.fetch(a.woT[g], ct, j); store_spread<D>(gp1, row, P, ct, j); });
+        strip_product<D>(acc, P, buf, ring, [&](int ct, int j) { ring.fetch(a.woT[g], ct, j); store_spread<D>(gp1, row, P, ct, j); });
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) Hs.v[ct] = acc[ct] + DZ.v[ct];
         strip_ln_bwd<D>(DR, Hs, Rs, pre.gam, a.ln_eps, dgam, dbet);
@@ -264,7 +264,7 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
         const float* buf = ring.next();
         before_last();                  // (a fused successor requests operands here: they fly under this product)
         strip_zero<D>(acc);
-        strip_mma_sel<D, RingT::BF16>(acc, DR, buf, [&](int ct, int j) {
+        strip_product<D>(acc, DR, buf, ring, [&](int ct, int j) {
             if constexpr (TAIL) ring.fetch(tail, ct, j);
             store_spread<D>(gdr, row, DR, ct, j);
         });
@@ -289,21 +289,21 @@ __device__ __forceinline__ void qkv_bwd_chain(const StripQkvBwdArgs& a, const St
     {   // dk Wk          (every operand is requested one slab ahead of its use: the loads fly under the MFMAs in between)
         const float* buf = ring.next();
         strip_load<D>(Dq, GBuf(a.dq, sg.act_bytes), row);
-        strip_mma_sel<D, RingT::BF16>(acc_kv, Dk, buf, [&](int ct, int j) { ring.fetch(a.wvT[g], ct, j); });
+        strip_product<D>(acc_kv, Dk, buf, ring, [&](int ct, int j) { ring.fetch(a.wvT[g], ct, j); });
     }
     {   // + dv Wv
         const float* buf = ring.next();
         strip_load<D>(Drs, GBuf(a.dr, sg.act_bytes), row);             // residual-path gradient of the normed query
         strip_load<D>(Xs, GBuf(a.x, sg.act_bytes), row);               // LN1 input rows
         gam.load(a.ln_w[g]);
-        strip_mma_sel<D, RingT::BF16>(acc_kv, Dv, buf, [&](int ct, int j) { ring.fetch(a.wqT[g], ct, j); });
+        strip_product<D>(acc_kv, Dv, buf, ring, [&](int ct, int j) { ring.fetch(a.wqT[g], ct, j); });
     }
     StripRegs<D> dgam, dbet;
     {   // dqn = dq Wq + dr ; dx = LN1'(dqn ; x) + (dk Wk + dv Wv)
         const float* buf = ring.next();
         before_last();
         strip_zero<D>(acc);
-        strip_mma_sel<D, RingT::BF16>(acc, Dq, buf, [&](int ct, int j) { if constexpr (TAIL) ring.fetch(tail, ct, j); });
+        strip_product<D>(acc, Dq, buf, ring, [&](int ct, int j) { if constexpr (TAIL) ring.fetch(tail, ct, j); });
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) Drs.v[ct] += acc[ct];
         strip_ln_bwd<D>(DX, Drs, Xs, gam, a.ln_eps, dgam, dbet);
@@ -315,7 +315,7 @@ __device__ __forceinline__ void qkv_bwd_chain(const StripQkvBwdArgs& a, const St
 
 // RIDER: 0, or the phase of the step's index sort (sort_phases.h) that the first rd.plan.nblk workgroups run, on CUs the live tiles
 // leave free (this launch: phase 2, the scatter of pass 0)
-template <int D, int RIDER, bool BF = false>
+template <int D, int RIDER, int BF = 0>
 __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const StripFfnBwdArgs a, const StripGeom sg, const SortRider rd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const Stri
         if (bid < rd.plan.nblk) { sort_phase_ct<1024, RIDER>(rd.plan, bid); return; }
         bid -= rd.plan.nblk;
     }
-    Ring<D, BF> ring(smem);
+    typename RingSel<D, BF>::type ring(smem);
     ring.first(a.w2T[strip_domain(bid)]);
     const StripTile t = strip_tile(sg, bid);
     if (!t.live) { zero_slot<D>(a.ln_part, t.slot); w_ring_wait(); return; }
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const Stri
 
 // FFN = true: the layer below's feed-forward / out-projection backward continues on d x in registers (d x is then never stored)
 // RIDER: as strip_ffn_bwd_kernel (with FFN: phase 3, pass 1's counts; without: phase 4, the scatter of pass 1)
-template <int D, bool FFN, int RIDER, bool BF = false>
+template <int D, bool FFN, int RIDER, int BF = 0>
 __global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const StripQkvBwdArgs a, const StripFfnBwdArgs f, const StripGeom sg,
                                                                       const SortRider rd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const Stri
         if (bid < rd.plan.nblk) { sort_phase_ct<1024, RIDER>(rd.plan, bid); return; }
         bid -= rd.plan.nblk;
     }
-    Ring<D, BF> ring(smem);
+    typename RingSel<D, BF>::type ring(smem);
     ring.first(a.wkT[strip_domain(bid)]);
     const StripTile t = strip_tile(sg, bid);
     if (!t.live) {
@@ -571,8 +571,10 @@ static int strip_ffn_bwd(const float* dxo, const unsigned char* tmq, const float
     SortRider rd;
     if (int e = make_rider(rd, sort_plan, sort_phase)) return e;
     if (rd.phase != 0 && rd.phase != 2) return AMID_ERR_UNSUPPORTED;           // this launch carries phase 2
-    if (D == 128 && mma_bf16) return rd.phase ? launch_strip_rider<strip_ffn_bwd_kernel<128, 2, true>, 128>(sg, rd, stream, a)
-                                              : launch_strip_rider<strip_ffn_bwd_kernel<128, 0, true>, 128>(sg, rd, stream, a);
+    if (D == 128 && mma_bf16 == 3) return rd.phase ? launch_strip_rider<strip_ffn_bwd_kernel<128, 2, 3>, 128>(sg, rd, stream, a)
+                                                   : launch_strip_rider<strip_ffn_bwd_kernel<128, 0, 3>, 128>(sg, rd, stream, a);
+    if (D == 128 && mma_bf16) return rd.phase ? launch_strip_rider<strip_ffn_bwd_kernel<128, 2, 1>, 128>(sg, rd, stream, a)
+                                              : launch_strip_rider<strip_ffn_bwd_kernel<128, 0, 1>, 128>(sg, rd, stream, a);
     if (D == 128 && rd.phase) return launch_strip_rider<strip_ffn_bwd_kernel<128, 2>, 128>(sg, rd, stream, a);
     if (D == 128) return launch_strip_rider<strip_ffn_bwd_kernel<128, 0>, 128>(sg, rd, stream, a);
     if (D == 64 && rd.phase) return launch_strip_rider<strip_ffn_bwd_kernel<64, 2>, 64>(sg, rd, stream, a);
@@ -623,10 +625,14 @@ static int strip_qkv_bwd(const float* dq, const float* dk, const float* dv, cons
     if (int e = make_rider(rd, sort_plan, sort_phase)) return e;
     if (rd.phase != 0 && rd.phase != (ffn ? 3 : 4)) return AMID_ERR_UNSUPPORTED;      // phase 3 with the fused feed-forward backward, 4 without
     const bool ride = rd.phase != 0;
-    if (D == 128 && mma_bf16 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3, true>, 128>(sg, rd, stream, a, f)
-                                                 : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0, true>, 128>(sg, rd, stream, a, f);
-    if (D == 128 && mma_bf16) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4, true>, 128>(sg, rd, stream, a, f)
-                                          : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0, true>, 128>(sg, rd, stream, a, f);
+    if (D == 128 && mma_bf16 == 3 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3, 3>, 128>(sg, rd, stream, a, f)
+                                                      : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0, 3>, 128>(sg, rd, stream, a, f);
+    if (D == 128 && mma_bf16 == 3) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4, 3>, 128>(sg, rd, stream, a, f)
+                                               : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0, 3>, 128>(sg, rd, stream, a, f);
+    if (D == 128 && mma_bf16 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3, 1>, 128>(sg, rd, stream, a, f)
+                                                 : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0, 1>, 128>(sg, rd, stream, a, f);
+    if (D == 128 && mma_bf16) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4, 1>, 128>(sg, rd, stream, a, f)
+                                          : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0, 1>, 128>(sg, rd, stream, a, f);
     if (D == 128 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3>, 128>(sg, rd, stream, a, f)
                                      : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0>, 128>(sg, rd, stream, a, f);
     if (D == 128) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4>, 128>(sg, rd, stream, a, f)

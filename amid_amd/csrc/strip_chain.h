@@ -48,6 +48,57 @@ template <int D, bool BF = false> struct Ring {
     }
 };
 
+// The ring of the products on bf16 pieces (strip_gemm.h strip_mma16x6): a weight is three 32 KB fragment images (planes hi, mid, lo,
+// [3][D][D] bf16 behind one pointer), two whole weights do not fit the ring's 128 KB: four plane slots [M][L][H0][H1], every plane
+// requested well ahead of its pass -- the next weight's hi plane when a product begins (the other H slot is free then), its mid / lo
+// planes behind the product's barrier (M and L are free then).  The next weight is whatever the product's hooks fetch().
+template <int D> struct RingP3 {
+    static constexpr bool BF16 = true, P3 = true;
+    static constexpr int SLAB = D * D / 2;
+    float* buf; int s; WDma16<D> dma;
+    const float* cur; const float* nxt;
+    bool cur_hi_ready, hi_late, have_next;
+    __device__ __forceinline__ explicit RingP3(float* lds) : buf(lds), s(0), cur(nullptr), nxt(nullptr), cur_hi_ready(false), hi_late(false), have_next(false) {}
+    __device__ __forceinline__ float* mslot() const { return buf; }
+    __device__ __forceinline__ float* lslot() const { return buf + SLAB; }
+    __device__ __forceinline__ float* hslot(int k) const { return buf + (2 + (k & 1)) * SLAB; }
+    __device__ __forceinline__ const float* hcur() const { return hslot(s - 1); }
+    __device__ __forceinline__ void first(const float* __restrict__ W0) {
+        cur = W0; cur_hi_ready = true;
+        dma.all(hslot(0), W0); dma.all(mslot(), W0 + SLAB); dma.all(lslot(), W0 + 2 * SLAB);
+    }
+    __device__ __forceinline__ const float* next() {
+        w_ring_wait();
+        __syncthreads();
+        ++s;
+        have_next = false;
+        return hslot(s - 1);
+    }
+    __device__ __forceinline__ void fetch(const float* __restrict__ W, int ct, int j) { if (ct == 0 && j == 0) { nxt = W; have_next = true; } }
+    __device__ __forceinline__ void begin() {
+        hi_late = !cur_hi_ready;
+        if (hi_late) dma.all(hslot(s - 1), cur);
+        if (have_next) dma.all(hslot(s), nxt);
+    }
+    __device__ __forceinline__ void mid_sync() {
+        if (hi_late) w_ring_wait();
+        __syncthreads();
+        if (have_next) { dma.all(mslot(), nxt + SLAB); dma.all(lslot(), nxt + 2 * SLAB); cur = nxt; cur_hi_ready = true; }
+        else cur_hi_ready = false;
+    }
+};
+// MODE 0: fp32 matrix instructions, 1: operands rounded to bf16, 3: fp32 operands as three bf16 pieces
+template <int D, int MODE> struct RingSel { using type = Ring<D, MODE != 0>; };
+template <int D> struct RingSel<D, 3> { using type = RingP3<D>; };
+template <class R> struct ring_is_p3 { static constexpr bool value = false; };
+template <int D> struct ring_is_p3<RingP3<D>> { static constexpr bool value = true; };
+// one product of a chain on whichever ring the kernel was built with
+template <int D, class RingT, class Hook>
+__device__ __forceinline__ void strip_product(f32x4 (&acc)[D / 16], const StripRegs<D>& A, const float* __restrict__ buf, RingT& ring, const Hook& hook) {
+    if constexpr (ring_is_p3<RingT>::value) strip_mma16x6<D>(acc, A, ring, hook);
+    else strip_mma_sel<D, RingT::BF16>(acc, A, buf, hook);
+}
+
 // stores of a finished strip leave under the FIRST half of the next MFMA loop, one column tile every fourth group: by the end of the
 // loop they have long been acknowledged, so the ring's vmcnt(0) in front of the next slab costs nothing
 template <int D>

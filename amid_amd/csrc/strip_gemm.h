@@ -26,6 +26,7 @@
 // to back -- and a lane maps its virtual row to the row of the [2, B, T] activation layout once per kernel (StripRow).
 #pragma once
 #include "common.h"
+#include "bf16_pieces.h"
 #include "rng.h"
 
 #define STRIP_STAMP_WAVES 4
@@ -427,6 +428,62 @@ __device__ __forceinline__ void strip_mma16(f32x4 (&acc)[D / 16], const StripReg
                                                               acc[co], 0, 0, 0);
     }
 }
+// acc[co] += A W^T, fp32 operands as three bf16 pieces each (csrc/bf16_pieces.h), six piece pairs: 192 matrix instructions of 16 cycles
+// instead of 256 of 32.  The weight is three fragment images (planes hi, mid, lo) walked plane by plane through strip_chain.h's
+// RingP3: lo x hi and mid x (mid, hi) of the operand, the ring's barrier, then hi x (lo, mid, hi).  A whole-row strip splits its operand
+// ONCE (every wave multiplies its own 16 rows by the whole weight: 176 vector instructions beside 192 matrix instructions).
+template <int D, class RingT, class Hook = NoDeferred>
+__device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripRegs<D>& A, RingT& ring, const Hook& hook = NoDeferred()) {
+    constexpr int NT = D / 16, KS = D / 32;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hook(ct, j);           // (deferred stores; the ring learns the next weight from its fetch() calls)
+    ring.begin();
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int rowo = i * (D / 2);
+    auto frag = [&](const float* plane, int co, int s) { return ld4(plane + rowo + co * 16 * (D / 2) + 4 * ((4 * s + g) ^ i)); };
+    auto mma = [&](const float4& wf, const amid_v4u& a16, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(strip_bf16x8, wf), __builtin_bit_cast(strip_bf16x8, a16), c, 0, 0, 0);
+    };
+    amid_v4u ah[KS], am[KS], al[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const WgSplit2 p0 = wg_split3(A.v[2 * s][0], A.v[2 * s][1]), p1 = wg_split3(A.v[2 * s][2], A.v[2 * s][3]);
+        const WgSplit2 p2 = wg_split3(A.v[2 * s + 1][0], A.v[2 * s + 1][1]), p3 = wg_split3(A.v[2 * s + 1][2], A.v[2 * s + 1][3]);
+        ah[s] = amid_v4u{p0.hi, p1.hi, p2.hi, p3.hi}; am[s] = amid_v4u{p0.mid, p1.mid, p2.mid, p3.mid}; al[s] = amid_v4u{p0.lo, p1.lo, p2.lo, p3.lo};
+    }
+    {
+        const float* mbuf = ring.mslot();
+        const float* lbuf = ring.lslot();
+        float4 wm = frag(mbuf, 0, 0), wl = frag(lbuf, 0, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int co = 0; co < NT; ++co) {
+                const float4 cm = wm, cl = wl;
+                const int cn = co + 1 < NT ? co + 1 : 0, sn = co + 1 < NT ? s : s + 1;
+                if (sn < KS) { wm = frag(mbuf, cn, sn); wl = frag(lbuf, cn, sn); }
+                acc[co] = mma(cl, ah[s], acc[co]); acc[co] = mma(cm, am[s], acc[co]); acc[co] = mma(cm, ah[s], acc[co]);
+            }
+    }
+    const float* hbuf = ring.hcur();
+    ring.mid_sync();
+    {
+        float4 wf = frag(hbuf, 0, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int co = 0; co < NT; ++co) {
+                const float4 cf = wf;
+                const int cn = co + 1 < NT ? co + 1 : 0, sn = co + 1 < NT ? s : s + 1;
+                if (sn < KS) wf = frag(hbuf, cn, sn);
+                acc[co] = mma(cf, al[s], acc[co]); acc[co] = mma(cf, am[s], acc[co]); acc[co] = mma(cf, ah[s], acc[co]);
+            }
+    }
+}
+
 // fp32 or bf16 products, chosen at compile time
 template <int D, bool BF, class Hook = NoDeferred>
 __device__ __forceinline__ void strip_mma_sel(f32x4 (&acc)[D / 16], const StripRegs<D>& A, const float* __restrict__ buf, const Hook& hook = NoDeferred()) {

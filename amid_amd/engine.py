@@ -204,15 +204,21 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         """Host array (domain 0, domain 1) of the transposed projection weight `which` (q, k, v, o, c1, c2) of `layer`: fp32 transposes,
         or -- pl.strip with compute = "bf16" -- their bf16 fragment images (amid_sas_weights_bf16, refreshed by enqueue_backward)."""
         bf = self._bf16_bwd
-        key = ("wT16" if bf else "wT", layer, which)
+        p3 = self._p3_bwd
+        key = ("wT16x3" if p3 else "wT16" if bf else "wT", layer, which)
         c = self._ptr_cache.get(key)
         if c is None:
-            buf = self.wT16 if bf else self.wT
+            buf = self.wT16x3 if p3 else self.wT16 if bf else self.wT
             c = ptr_array([buf[layer, g, which].data_ptr() for g in (0, 1)])
             self._ptr_cache[key] = c
         return c
 
     _bf16_bwd = False          # set per backward: the strip backward's products take bf16 images (compute = "bf16" on the strip path)
+    _p3_bwd = False            # set per backward: ... three-plane images (compute = "fp32", products on bf16 pieces)
+    # compute = "fp32": the strip backward's data-gradient products on the bf16 matrix cores at fp32 accuracy (three bf16 pieces per operand,
+    # six piece pairs: csrc/strip_gemm.h strip_mma16x6, strip_chain.h RingP3), from three-plane images of the TRANSPOSED weights; "0": fp32
+    # matrix instructions
+    BWD_SPLIT = os.environ.get("AMID_BWD_SPLIT", "1") != "0"
 
     # ------------------------------------------------------------------ launch sequences
     def enqueue_prepare(self, pl: SasrecPlan, sparse: bool, bump_step: bool = False, defer_sort: bool = False) -> None:
@@ -405,6 +411,15 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self._w16_src = ptr_array(srcs)
         return self._w16_src, self.w16
 
+    def _p3_bwd_for(self, pl: SasrecPlan) -> bool:
+        """Whether this plan's backward strips take their data-gradient products on bf16 pieces (three-plane images of the transposes)."""
+        return bool(self.compute != "bf16" and self.BWD_SPLIT and pl.strip and self.D == 128 and not self.inc_bs and not self._seq_backward(pl))
+
+    def _wT16x3_buf(self):
+        if not hasattr(self, "wT16x3"):
+            self.wT16x3 = torch.empty(2, 2, 6, 3, self.D * self.D, dtype=torch.bfloat16, device=self.device)
+        return self.wT16x3
+
     def _fwd_on_pieces(self, pl: SasrecPlan, B: int, T: int) -> bool:
         """Whether this step's encoder forward is the one-launch kernel with its products on bf16 pieces (amid_sas_seq_fwd_split_f32)."""
         return bool(self.compute != "bf16" and self.FWD_SPLIT and self.D == 128 and pl.strip and self.SEQ_FORWARD and not self.inc_bs
@@ -426,9 +441,11 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                    self._sort_plan(pl) if ride else None, 1 if ride else 0, s)
         elif self._fwd_on_pieces(pl, B, T):          # the gather's extra workgroups write this step's weight images (three bf16 planes each)
             src, w16 = self._w16_images(3)
+            wt = self._wT16x3_buf() if tr and self._p3_bwd_for(pl) else None     # (+ the transposes' images for this step's backward strips)
             L.call("amid_embed_fwd_w16_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), pos0, pos1, B, T, D, B * NI, pl.xg.data_ptr(), tmq, st,
-                   tr, p_drop, lf, ic, rc, src, 24, 3, w16.data_ptr(), s)
+                   tr, p_drop, lf, ic, rc, src, 24, 3, w16.data_ptr(), wt.data_ptr() if wt is not None else None, s)
             pl.w16_written = True
+            pl.wT16x3_written = wt is not None
         elif compact:
             L.call("amid_embed_fwd_live_compact_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), pos0, pos1, B, T, D, B * NI, pl.xg.data_ptr(),
                    tmq, st, tr, p_drop, lf, ic, rc, s)
@@ -750,11 +767,17 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         # compute = "bf16" on the strip path: the strip backward's data-gradient products take bf16 fragment images of the transposed weights
         # (the fp32 transposes are still refreshed: the row-tile fallbacks and tests read them)
         self._bf16_bwd = bool(self.compute == "bf16" and pl.strip)
-        bf = 1 if self._bf16_bwd else 0
+        # (the fused per-sequence backward -- amid_sas_seq_bwd_f32 -- keeps the fp32 matrix instructions)
+        self._p3_bwd = self._p3_bwd_for(pl)
+        bf = 3 if self._p3_bwd else 1 if self._bf16_bwd else 0
         if self._bf16_bwd:
             if not hasattr(self, "wT16"):
                 self.wT16 = torch.empty(2, 2, 6, D * D, dtype=torch.bfloat16, device=self.device)
             L.call("amid_sas_weights_bf16", ptr_array(src), len(src), D, 1, self.wT16.data_ptr(), s)
+        if self._p3_bwd:
+            if not getattr(pl, "wT16x3_written", False):           # (the train step's gather K1 wrote them with extra workgroups)
+                L.call("amid_sas_weights_bf16_planes", ptr_array(src), len(src), D, 1, 3, self._wT16x3_buf().data_ptr(), s)
+            pl.wT16x3_written = False
         items = pl.xg.data_ptr() + 4 * 2 * shp.Mi * D
         ditems = pl.dxg.data_ptr() + 4 * 2 * shp.Mi * D
         if (self.dr or self.itc_bs) and getattr(self, "_fuse_scorers", False):

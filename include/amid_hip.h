@@ -676,10 +676,11 @@ int amid_embed_fwd_replay_f32(const float* table, const float* m_tab, const floa
                               int* row_c, const void* adam_state, const void* sort_plan, int sort_phase, void* stream);
 /* K1 (the gather: live / idx_c / row_c as amid_embed_fwd_live(_compact)_f32, NULL = every sequence / no compact list) with this step's bf16
  * fragment images of n_w (<= 24) square [D][D] weights written by extra workgroups of the same launch (what amid_sas_weights_bf16_planes
- * does as a launch of its own): w16_dst [n_w][planes][D][D] bf16, planes = 1 or 3.  D = 128. */
+ * does as a launch of its own): w16_dst [n_w][planes][D][D] bf16, planes = 1 or 3; w16t_dst: NULL, or the same for the weights' TRANSPOSES
+ * (the operands of the backward strips, amid_sas_strip_*_bwd_* with mma_bf16 = 3).  D = 128. */
 int amid_embed_fwd_w16_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D, int n_item_rows,
                            float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop, const int* live, int* idx_c,
-                           int* row_c, const float* const* w_src, int n_w, int w_planes, void* w16_dst, void* stream);
+                           int* row_c, const float* const* w_src, int n_w, int w_planes, void* w16_dst, void* w16t_dst, void* stream);
 /* 1 when the matrix-core attention kernels cover the shape (causal, T <= 64, H <= 8, head dim 16 or 8): the live-list entries below */
 int amid_attn_live_supported(int T, int D, int H, int causal);
 int amid_attn_fwd_live_f32(const float* q, const float* k, const float* v, int B, int T, int D, int H, int causal, int layer,

@@ -222,3 +222,55 @@ def test_strip_backward_bf16_products_within_bf16_rounding_of_fp32(B, T, live):
         worst = max(worst, e)
         assert e < 2e-2, (i, e)
     assert worst > 1e-4
+
+
+@pytest.mark.parametrize("B,T", [(64, 50), (37, 20), (256, 50)])
+@pytest.mark.parametrize("live", [None, "mixed"])
+def test_strip_backward_on_bf16_pieces_has_fp32_accuracy(B, T, live):
+    """mma_bf16 = 3 (the fp32 step's default at D 128): the data-gradient products of the strip backward kernels as six bf16 piece-pair
+    products (every fp32 operand = hi + mid + lo exactly; amid_sas_weights_bf16_planes images of the transposed weights) against the fp32
+    matrix instructions on the same inputs: every output within 4e-6 of its tensor's largest entry -- the spread of two fp32 summation
+    orders, three decades below mma_bf16 = 1 (test above)."""
+    D = 128
+    c = Ctx(B, T, D, seed=B * 7 + T, live=live)
+    L, pa, s = c.L, c.pa, c.s
+    P = lambda t: pa([t[0].data_ptr(), t[1].data_ptr()])      # noqa: E731
+    lo = live is not None
+    part_s = lambda: torch.full((2 * c.stpg, 2, D), float("nan"), device="cuda")      # noqa: E731
+    lnw = c.vec(1.0)
+    dxo, h, r = c.act(live_only=lo), c.act().relu(), c.act()
+    dq, dk, dv, dr = (c.act(live_only=lo) for _ in range(4))
+    x = c.act()
+    mats = [c.mat() for _ in range(6)]                   # w1T, w2T, woT, wqT, wkT, wvT: W^T [in][out] per domain
+    img = torch.empty(12, 3, D * D, dtype=torch.bfloat16, device="cuda")
+    L.call("amid_sas_weights_bf16_planes", pa([m[g].data_ptr() for m in mats for g in (0, 1)]), 12, D, 0, 3, img.data_ptr(), s)
+    I = lambda k: pa([img[2 * k].data_ptr(), img[2 * k + 1].data_ptr()])      # noqa: E731
+
+    def run(bf):
+        W = (lambda k: I(k)) if bf else (lambda k: P(mats[k]))
+        out = [c.out() for _ in range(4)]
+        pg = part_s()
+        L.call("amid_sas_strip_ffn_bwd_f32", dxo.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), W(0), W(1), W(2), 1e-8,
+               B, T, D, c.lp(), 1, c.st.data_ptr(), 1, 0.5, *[t.data_ptr() for t in out], pg.data_ptr(), bf, s)
+        dx, pg1 = c.out(), part_s()
+        L.call("amid_sas_strip_qkv_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), W(3), W(4), W(5),
+               1e-8, B, T, D, c.lp(), dx.data_ptr(), pg1.data_ptr(), *([None] * 7), 0, None, 0, 0.0, *([None] * 5), bf, s)
+        out2 = [c.out() for _ in range(4)]
+        pg2, fpg2 = part_s(), part_s()
+        L.call("amid_sas_strip_qkv_bwd_f32", dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dr.data_ptr(), x.data_ptr(), P(lnw), W(3), W(4), W(5),
+               1e-8, B, T, D, c.lp(), None, pg2.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), W(0), W(1), W(2), 0,
+               c.st.data_ptr(), 1, 0.5, *[t.data_ptr() for t in out2], fpg2.data_ptr(), bf, s)
+        torch.cuda.synchronize()
+        return out + [dx] + out2 + [pg, pg1, pg2, fpg2]
+    ref, got = run(0), run(3)
+    rl = c.row_live.cuda()
+    for i, (a, b) in enumerate(zip(got, ref)):
+        if i < 9:
+            a, b = a[rl].double(), b[rl].double()
+        else:                                            # LayerNorm partial sums: the slots of live strips only (the others stay NaN in both)
+            ok = torch.isfinite(b)
+            assert bool((torch.isfinite(a) == ok).all()), i
+            a, b = a[ok].double(), b[ok].double()
+        assert torch.isfinite(a).all(), i
+        e = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        assert e < 4e-6, (i, e)
