@@ -31,7 +31,11 @@ namespace amid {
 #ifdef AMID_STRIP_STAMPS
 static __device__ unsigned long long amid_seqn_stamp_buf[8 * 64];
 #define SEQN_STAMP(i) do { if (blockIdx.x == 0 && lane_id() == 0 && l == 1) amid_seqn_stamp_buf[wave_id() * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define SEQN_STAMP0(i) do { if (blockIdx.x == 0 && lane_id() == 0) amid_seqn_stamp_buf[wave_id() * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// (slots 62 / 63: the kernel's first / last instruction; slots 60 / 61 the same moments on the constant 100 MHz clock, and the LAST workgroup
+// stamps slots 58 / 59 with that clock too: the shader clock during the kernel, and how long after workgroup 0 the last one ends)
+#define SEQN_STAMP0(i) do { if (lane_id() == 0) { if (blockIdx.x == 0) { amid_seqn_stamp_buf[wave_id() * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+    amid_seqn_stamp_buf[wave_id() * 64 + (i) - 2] = __builtin_amdgcn_s_memrealtime(); } \
+    else if (blockIdx.x == gridDim.x - 1) amid_seqn_stamp_buf[wave_id() * 64 + (i) - 4] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define SEQN_STAMP(i) do { } while (0)
 #define SEQN_STAMP0(i) do { } while (0)

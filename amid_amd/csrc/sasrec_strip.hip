@@ -242,10 +242,13 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
     if (a.train) strip_dropout<D>(P, seed, site_id(g, a.layer, SITE_FFN2), step, row.local, a.spec, a.scale);
     f32x4 acc[NT];
     {   // dh = dpre2 C2 ; dpre1 = dh * relu'(h) * drop1   (h > 0 implies the unit was kept by drop1)
+        STRIP_STAMP(18);
         const float* buf = ring.next();
+        STRIP_STAMP(19);
         strip_load<D>(Rs, GBuf(a.r, sg.act_bytes), row);               // LN2 input rows: needed two slabs from now
         strip_zero<D>(acc);
         strip_product<D>(acc, P, buf, ring, [&](int ct, int j) { ring.fetch(a.w1T[g], ct, j); store_spread<D>(gp2, row, P, ct, j); });
+        STRIP_STAMP(20);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -254,24 +257,30 @@ __device__ __forceinline__ void ffn_bwd_chain(const StripFfnBwdArgs& a, const St
     StripRegs<D> DR, dgam, dbet;
     {   // dy = dpre1 C1 + dz ; dr = LN2'(dy ; r)
         const float* buf = ring.next();
+        STRIP_STAMP(21);
         strip_zero<D>(acc);
         strip_product<D>(acc, P, buf, ring, [&](int ct, int j) { ring.fetch(a.woT[g], ct, j); store_spread<D>(gp1, row, P, ct, j); });
+        STRIP_STAMP(22);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) Hs.v[ct] = acc[ct] + DZ.v[ct];
         strip_ln_bwd<D>(DR, Hs, Rs, pre.gam, a.ln_eps, dgam, dbet);
+        STRIP_STAMP(23);
     }
     {   // d_o = dr Wo
         const float* buf = ring.next();
+        STRIP_STAMP(24);
         before_last();                  // (a fused successor requests operands here: they fly under this product)
         strip_zero<D>(acc);
         strip_product<D>(acc, DR, buf, ring, [&](int ct, int j) {
             if constexpr (TAIL) ring.fetch(tail, ct, j);
             store_spread<D>(gdr, row, DR, ct, j);
         });
+        STRIP_STAMP(25);
         to_regs<D>(P, acc);
         strip_store<D>(gdo, row, P);
     }
     ln_partials_wave<D>(scratch, dgam, dbet);
+    STRIP_STAMP(26);
 }
 
 // dq, dk, dv, dr of a layer -> d x (left in DX); the ring's current fetch must be wkT.  TAIL: a slab (`tail`) is fetched behind wqT;
@@ -323,6 +332,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const Stri
         if (bid < rd.plan.nblk) { sort_phase_ct<1024, RIDER>(rd.plan, bid); return; }
         bid -= rd.plan.nblk;
     }
+    STRIP_STAMP(16);
     typename RingSel<D, BF>::type ring(smem);
     ring.first(a.w2T[strip_domain(bid)]);
     const StripTile t = strip_tile(sg, bid);
@@ -332,9 +342,11 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const Stri
     FfnBwdPre<D> pre;
     strip_load<D>(DZ, GBuf(a.dxo, sg.act_bytes), row);
     ffn_bwd_prefetch<D>(pre, a, sg, row, t.g);
+    STRIP_STAMP(17);
     ffn_bwd_chain<D>(a, sg, ring, row, t.g, DZ, pre, ln_scratch<D>(smem, 0));
     __syncthreads();
     ln_partials_out<D>(ln_scratch<D>(smem, 0), a.ln_part + (long long)t.slot * 2 * D);
+    STRIP_STAMP(27);
 }
 
 // FFN = true: the layer below's feed-forward / out-projection backward continues on d x in registers (d x is then never stored)

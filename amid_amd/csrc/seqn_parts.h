@@ -500,55 +500,82 @@ __device__ __forceinline__ void xp_row(StripRegs<D>& full, const float* __restri
     }
 }
 
-// acc[c] += A W^T over the own column tiles: operand fragments from the strip's exchange slots, weight planes from SeqRing3
+// acc[c] += A W^T over the own column tiles: operand fragments from the strip's exchange slots, weight planes from SeqRing3.
+// The fragment reads are placed by hand (strip_gemm.h lds_frag_issue / lds_frag_wait): left to the compiler every read sat just in front
+// of its first use (lgkmcnt(1) / (0) in front of most matrix instructions).  A step = one column tile of one k-step: two weight fragments
+// (pass 1: mid, lo planes) or one (pass 2: hi plane), three matrix instructions; a k-step's first step also reads the operand's pieces
+// (two / three fragments).  Reads run PD steps ahead; LDS operations return in order, so a step waits until only the reads issued
+// behind its own are outstanding.
+template <int NCT, int PER_STEP, int PER_KSTEP> struct XpReadCount {
+    // reads issued in front of step u's own (issue order: a k-step's operand fragments, then the step's weight fragments)
+    static constexpr int before(int u) { return PER_STEP * u + PER_KSTEP * ((u + NCT - 1) / NCT); }
+};
 template <int D, int NCT, class Ring>
 __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __restrict__ xps, Ring& ring, int c0) {
-    constexpr int KS = D / 32;
+    constexpr int KS = D / 32, NSTEP = KS * NCT, CT_BYTES = 16 * (D / 2) * 4, PLANE_BYTES = Ring::SLAB * 4;
+#ifndef AMID_XP_PD1
+#define AMID_XP_PD1 3
+#define AMID_XP_PD2 4
+#endif
+    constexpr int PD1 = AMID_XP_PD1 < NCT ? AMID_XP_PD1 : NCT, PD2 = AMID_XP_PD2 < NCT ? AMID_XP_PD2 : NCT;      // (a k-step's operand fragments are double-buffered)
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;
-    const int rowo = (c0 * 16 + i) * (D / 2);
-    auto frag = [&](const float* plane, int c, int s) { return lds_ld4(plane + rowo + c * 16 * (D / 2) + 4 * ((4 * s + g) ^ i)); };
-    auto mma = [&](const float4& wf, const amid_v4u& a16, const f32x4& c) {
+    auto lds_addr = [](const float* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)p; };
+    auto mma = [&](const f32x4& wf, const f32x4& a16, const f32x4& c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(seqn_bf16x8, wf), __builtin_bit_cast(seqn_bf16x8, a16), c, 0, 0, 0);
     };
-    const float* mbuf = ring.mslot();
-    const float* lbuf = ring.lslot();
+    unsigned fo[KS];                                          // this lane's fragment of k-step s in a plane, own column tile 0
+#pragma unroll
+    for (int s = 0; s < KS; ++s) fo[s] = (unsigned)((((c0 * 16 + i) * (D / 2)) + 4 * ((4 * s + g) ^ i)) * 4);
+    const unsigned xa = lds_addr(xps) + (unsigned)lane * 16u;  // operand fragments: [k-step][piece][lane] x 16 bytes
+    const unsigned mbase = lds_addr(ring.mslot());
+    static_assert(CT_BYTES * (NCT - 1) + PLANE_BYTES < 65536, "the lo plane is reached through the offset field");
+    const unsigned hbase = mbase + 2u * PLANE_BYTES;
     ring.pre_pass1();
-    // pass 1: the lo plane against the operand's hi piece, the mid plane against (mid, hi)
-    {
-        float4 wm = frag(mbuf, 0, 0), wl = frag(lbuf, 0, 0);
-        amid_v4u ah = xp_frag(xps, 0, 0), am = xp_frag(xps, 0, 1);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const amid_v4u ch = ah, cmid = am;
-            if (s + 1 < KS) { ah = xp_frag(xps, s + 1, 0); am = xp_frag(xps, s + 1, 1); }
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                const float4 cm = wm, cl = wl;
-                const int cn = c + 1 < NCT ? c + 1 : 0, sn = c + 1 < NCT ? s : s + 1;
-                if (sn < KS) { wm = frag(mbuf, cn, sn); wl = frag(lbuf, cn, sn); }
-                acc[c] = mma(cl, ch, acc[c]); acc[c] = mma(cm, cmid, acc[c]); acc[c] = mma(cm, ch, acc[c]);
+    {   // pass 1: the lo plane against the operand's hi piece, the mid plane against (mid, hi)
+        using Cnt = XpReadCount<NCT, 2, 2>;
+        f32x4 wm[PD1 + 1], wl[PD1 + 1], ah[2], am[2];
+        auto issue = [&](auto U) {
+            constexpr int u = decltype(U)::value, s = u / NCT, c = u % NCT, k = u % (PD1 + 1);
+            if constexpr (c == 0) {
+                lds_frag_issue<(s * 3 + 0) * 1024>(ah[s & 1], xa);
+                lds_frag_issue<(s * 3 + 1) * 1024>(am[s & 1], xa);
             }
-        }
+            lds_frag_issue<c * CT_BYTES>(wm[k], mbase + fo[s]);
+            lds_frag_issue<c * CT_BYTES + PLANE_BYTES>(wl[k], mbase + fo[s]);
+        };
+        static_for<PD1>(issue);
+        static_for<NSTEP>([&](auto T) {
+            constexpr int t = decltype(T)::value, s = t / NCT, c = t % NCT, k = t % (PD1 + 1);
+            if constexpr (t + PD1 < NSTEP) issue(std::integral_constant<int, t + PD1>{});
+            constexpr int last = t + PD1 < NSTEP ? t + PD1 : NSTEP - 1;
+            constexpr int younger = Cnt::before(last + 1) - Cnt::before(t + 1);
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wm[k]), "+v"(wl[k]), "+v"(ah[s & 1]), "+v"(am[s & 1]) : "n"(younger));
+            acc[c] = mma(wl[k], ah[s & 1], acc[c]); acc[c] = mma(wm[k], am[s & 1], acc[c]); acc[c] = mma(wm[k], ah[s & 1], acc[c]);
+        });
     }
-    const float* hbuf = ring.hslot();
     ring.mid_sync();
-    // pass 2: the hi plane against the operand's three pieces
-    {
-        float4 wf = frag(hbuf, 0, 0);
-        amid_v4u ah = xp_frag(xps, 0, 0), am = xp_frag(xps, 0, 1), al = xp_frag(xps, 0, 2);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const amid_v4u ch = ah, cmid = am, clo = al;
-            if (s + 1 < KS) { ah = xp_frag(xps, s + 1, 0); am = xp_frag(xps, s + 1, 1); al = xp_frag(xps, s + 1, 2); }
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                const float4 cf = wf;
-                const int cn = c + 1 < NCT ? c + 1 : 0, sn = c + 1 < NCT ? s : s + 1;
-                if (sn < KS) wf = frag(hbuf, cn, sn);
-                acc[c] = mma(cf, clo, acc[c]); acc[c] = mma(cf, cmid, acc[c]); acc[c] = mma(cf, ch, acc[c]);
+    {   // pass 2: the hi plane against the operand's three pieces
+        using Cnt = XpReadCount<NCT, 1, 3>;
+        f32x4 wf[PD2 + 1], ah[2], am[2], al[2];
+        auto issue = [&](auto U) {
+            constexpr int u = decltype(U)::value, s = u / NCT, c = u % NCT, k = u % (PD2 + 1);
+            if constexpr (c == 0) {
+                lds_frag_issue<(s * 3 + 0) * 1024>(ah[s & 1], xa);
+                lds_frag_issue<(s * 3 + 1) * 1024>(am[s & 1], xa);
+                lds_frag_issue<(s * 3 + 2) * 1024>(al[s & 1], xa);
             }
-        }
+            lds_frag_issue<c * CT_BYTES>(wf[k], hbase + fo[s]);
+        };
+        static_for<PD2>(issue);
+        static_for<NSTEP>([&](auto T) {
+            constexpr int t = decltype(T)::value, s = t / NCT, c = t % NCT, k = t % (PD2 + 1);
+            if constexpr (t + PD2 < NSTEP) issue(std::integral_constant<int, t + PD2>{});
+            constexpr int last = t + PD2 < NSTEP ? t + PD2 : NSTEP - 1;
+            constexpr int younger = Cnt::before(last + 1) - Cnt::before(t + 1);
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wf[k]), "+v"(ah[s & 1]), "+v"(am[s & 1]), "+v"(al[s & 1]) : "n"(younger));
+            acc[c] = mma(wf[k], al[s & 1], acc[c]); acc[c] = mma(wf[k], am[s & 1], acc[c]); acc[c] = mma(wf[k], ah[s & 1], acc[c]);
+        });
     }
 }
 

@@ -28,6 +28,8 @@
 #include "common.h"
 #include "bf16_pieces.h"
 #include "rng.h"
+#include <type_traits>
+#include <utility>
 
 #define STRIP_STAMP_WAVES 4
 
@@ -432,6 +434,24 @@ __device__ __forceinline__ void strip_mma16(f32x4 (&acc)[D / 16], const StripReg
 // instead of 256 of 32.  The weight is three fragment images (planes hi, mid, lo) walked plane by plane through strip_chain.h's
 // RingP3: lo x hi and mid x (mid, hi) of the operand, the ring's barrier, then hi x (lo, mid, hi).  A whole-row strip splits its operand
 // ONCE (every wave multiplies its own 16 rows by the whole weight: 176 vector instructions beside 192 matrix instructions).
+// Hand-placed LDS fragment reads: the compiler, at this kernel's register pressure, sinks every ds_read to just in front of its first
+// use -- read, a full LDS round trip, three matrix instructions, read ... (a wave is alone on its SIMD in the strip kernels: nobody fills
+// the wait; measured 7 - 11 k cycles per product against 3 072 of matrix issue, and sched_group_barrier did not move it).  So the reads
+// are inline asm issued PD steps ahead and the wait is an asm that RETURNS the fragment: its users cannot be scheduled in front of it.
+// LDS operations return in order: lgkmcnt(N) = everything but the N youngest is back (operations the compiler adds only make it wait more).
+template <int OFF> __device__ __forceinline__ void lds_frag_issue(f32x4& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int YOUNGER> __device__ __forceinline__ void lds_frag_wait(f32x4& d) {
+    static_assert(YOUNGER >= 0 && YOUNGER < 16, "lgkmcnt field");
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(YOUNGER));
+}
+template <class F, int... Is> __device__ __forceinline__ void static_for_impl(const F& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(const F& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 template <int D, class RingT, class Hook = NoDeferred>
 __device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripRegs<D>& A, RingT& ring, const Hook& hook = NoDeferred()) {
     constexpr int NT = D / 16, KS = D / 32;
@@ -442,9 +462,7 @@ __device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripR
     ring.begin();
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;
-    const int rowo = i * (D / 2);
-    auto frag = [&](const float* plane, int co, int s) { return ld4(plane + rowo + co * 16 * (D / 2) + 4 * ((4 * s + g) ^ i)); };
-    auto mma = [&](const float4& wf, const amid_v4u& a16, const f32x4& c) {
+    auto mma = [&](const f32x4& wf, const amid_v4u& a16, const f32x4& c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(strip_bf16x8, wf), __builtin_bit_cast(strip_bf16x8, a16), c, 0, 0, 0);
     };
     amid_v4u ah[KS], am[KS], al[KS];
@@ -454,34 +472,58 @@ __device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripR
         const WgSplit2 p2 = wg_split3(A.v[2 * s + 1][0], A.v[2 * s + 1][1]), p3 = wg_split3(A.v[2 * s + 1][2], A.v[2 * s + 1][3]);
         ah[s] = amid_v4u{p0.hi, p1.hi, p2.hi, p3.hi}; am[s] = amid_v4u{p0.mid, p1.mid, p2.mid, p3.mid}; al[s] = amid_v4u{p0.lo, p1.lo, p2.lo, p3.lo};
     }
-    {
-        const float* mbuf = ring.mslot();
-        const float* lbuf = ring.lslot();
-        float4 wm = frag(mbuf, 0, 0), wl = frag(lbuf, 0, 0);
+    // byte offset of this lane's fragment of k-step s inside a plane (row i of column tile 0; a column tile further = 16 rows = +4 KB)
+    unsigned fo[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int co = 0; co < NT; ++co) {
-                const float4 cm = wm, cl = wl;
-                const int cn = co + 1 < NT ? co + 1 : 0, sn = co + 1 < NT ? s : s + 1;
-                if (sn < KS) { wm = frag(mbuf, cn, sn); wl = frag(lbuf, cn, sn); }
-                acc[co] = mma(cl, ah[s], acc[co]); acc[co] = mma(cm, am[s], acc[co]); acc[co] = mma(cm, ah[s], acc[co]);
-            }
+    for (int s = 0; s < KS; ++s) fo[s] = (unsigned)((i * (D / 2) + 4 * ((4 * s + g) ^ i)) * 4);
+    STRIP_STAMP(28);
+    constexpr int NSTEP = KS * NT, CT_BYTES = 16 * (D / 2) * 4, PLANE_BYTES = RingT::SLAB * 4;
+#ifndef AMID_PD1
+#define AMID_PD1 3
+#define AMID_PD2 4
+#endif
+    constexpr int PD1 = AMID_PD1, PD2 = AMID_PD2;          // steps a read runs ahead of its matrix instructions
+    auto lds_addr = [](const float* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)p; };
+    {   // pass 1: lo x hi, mid x (mid, hi) -- the lo plane sits one slot (32 KB) behind the mid plane: one address, two offsets
+        static_assert(CT_BYTES * (NT - 1) + PLANE_BYTES < 65536, "the lo plane is reached through the offset field");
+        const unsigned base = lds_addr(ring.mslot());
+        f32x4 wm[PD1 + 1], wl[PD1 + 1];
+        auto issue = [&](auto U) {
+            constexpr int u = decltype(U)::value, k = u % (PD1 + 1);
+            lds_frag_issue<(u % NT) * CT_BYTES>(wm[k], base + fo[u / NT]);
+            lds_frag_issue<(u % NT) * CT_BYTES + PLANE_BYTES>(wl[k], base + fo[u / NT]);
+        };
+        static_for<PD1>(issue);
+        static_for<NSTEP>([&](auto T) {
+            constexpr int t = decltype(T)::value, s = t / NT, co = t % NT, k = t % (PD1 + 1);
+            if constexpr (t + PD1 < NSTEP) issue(std::integral_constant<int, t + PD1>{});      // (into the slot step t - 1 is done with)
+            constexpr int last = t + PD1 < NSTEP ? t + PD1 : NSTEP - 1;
+            lds_frag_wait<2 * (last - t) + 1>(wm[k]);
+            acc[co] = mma(wm[k], am[s], acc[co]);
+            lds_frag_wait<2 * (last - t)>(wl[k]);
+            acc[co] = mma(wl[k], ah[s], acc[co]); acc[co] = mma(wm[k], ah[s], acc[co]);
+        });
     }
-    const float* hbuf = ring.hcur();
+    STRIP_STAMP(29);
+    const unsigned hbase = lds_addr(ring.hcur());
     ring.mid_sync();
-    {
-        float4 wf = frag(hbuf, 0, 0);
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int co = 0; co < NT; ++co) {
-                const float4 cf = wf;
-                const int cn = co + 1 < NT ? co + 1 : 0, sn = co + 1 < NT ? s : s + 1;
-                if (sn < KS) wf = frag(hbuf, cn, sn);
-                acc[co] = mma(cf, al[s], acc[co]); acc[co] = mma(cf, am[s], acc[co]); acc[co] = mma(cf, ah[s], acc[co]);
-            }
+    STRIP_STAMP(30);
+    {   // pass 2: hi x (lo, mid, hi)
+        f32x4 wf[PD2 + 1];
+        auto issue = [&](auto U) {
+            constexpr int u = decltype(U)::value;
+            lds_frag_issue<(u % NT) * CT_BYTES>(wf[u % (PD2 + 1)], hbase + fo[u / NT]);
+        };
+        static_for<PD2>(issue);
+        static_for<NSTEP>([&](auto T) {
+            constexpr int t = decltype(T)::value, s = t / NT, co = t % NT, k = t % (PD2 + 1);
+            if constexpr (t + PD2 < NSTEP) issue(std::integral_constant<int, t + PD2>{});
+            constexpr int last = t + PD2 < NSTEP ? t + PD2 : NSTEP - 1;
+            lds_frag_wait<last - t>(wf[k]);
+            acc[co] = mma(wf[k], al[s], acc[co]); acc[co] = mma(wf[k], am[s], acc[co]); acc[co] = mma(wf[k], ah[s], acc[co]);
+        });
     }
+    STRIP_STAMP(31);
 }
 
 // fp32 or bf16 products, chosen at compile time

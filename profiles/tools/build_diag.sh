@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 O=$R/profiles/tools/_diag
 mkdir -p $O/obj
 cd $R/amid_amd/csrc
-FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -DAMID_STRIP_STAMPS"
+FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -DAMID_STRIP_STAMPS $AMID_DIAG_EXTRA"
 objs=""
 for f in *.hip; do
   /opt/rocm/bin/hipcc $FL -c $f -o $O/obj/${f%.hip}.o &

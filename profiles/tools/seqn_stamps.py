@@ -38,4 +38,8 @@ nw = {42: 8, 22: 4, 24: 8, 14: 4, 18: 8}[int(os.environ["AMID_SEQ_FWD_VARIANT"])
 for w in range(nw):
     t = [host[w * 64 + i] for i in order]
     tot = host[w * 64 + 63] - host[w * 64 + 62]
+    rt = host[w * 64 + 61] - host[w * 64 + 60]            # the same interval on the constant 100 MHz clock
+    if w == 0 and rt > 0:
+        print(f"workgroup 0: {tot} cycles in {rt / 100:.2f} us = {tot / rt / 10:.3f} GHz; the last workgroup starts "
+              f"{(host[58] - host[60]) / 100:+.2f} us after workgroup 0 and ends {(host[59] - host[61]) / 100:+.2f} us after it")
     print(f"wave {w}: kernel {tot} cycles; last layer {t[-1] - t[0]}: " + ", ".join(f"{names[i]} +{t[i + 1] - t[i]}" for i in range(16)))
