@@ -674,13 +674,13 @@ static int seqn_launch_t(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
     return e == hipSuccess ? AMID_OK : (int)e;
 }
 
-static int g_seqn_px = 1;       // planes == 3: 1 = the producer-side pieces build (seqn_fwd_px_kernel), 0 = SeqRing16x3's (amid_sas_seq_fwd_split_build)
-
 template <int WPS, int NS>
 static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
     if (a.w16 != nullptr && a.w16_planes == 3) {
-        if constexpr ((128 / 16 / NS) % 2 == 0) { if (g_seqn_px) return seqn_launch_px<128, WPS, NS>(a, sg, stream); }
-        return seqn_launch_t<128, WPS, NS, true, true>(a, sg, stream);
+        // the producer-side pieces build (seqn_fwd_px_kernel) wherever a wave owns whole k-steps (an even number of column tiles);
+        // SeqRing16x3's build -- every wave splits its strip's whole row itself -- for the one-tile parts of the diagnostic variant 18
+        if constexpr ((128 / 16 / NS) % 2 == 0) return seqn_launch_px<128, WPS, NS>(a, sg, stream);
+        else return seqn_launch_t<128, WPS, NS, true, true>(a, sg, stream);
     }
     return a.w16 != nullptr ? seqn_launch_t<128, WPS, NS, true>(a, sg, stream) : seqn_launch_t<128, WPS, NS, false>(a, sg, stream);
 }

@@ -191,7 +191,7 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_embed_fwd_replay_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (8 + 2 * D * 4) + Bw * T * (D // 4)),
         "amid_embed_fwd_live_compact_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (12 + 2 * D * 4) + Bw * T * (D // 4)),
         # the same gather + 24 weights read and written as three bf16 planes by its extra workgroups (the forward's weight images)
-        "amid_embed_fwd_w16_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (12 + 2 * D * 4) + Bw * T * (D // 4) + 24 * D * D * 10),
+        "amid_embed_fwd_w16_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (12 + 2 * D * 4) + Bw * T * (D // 4) + 48 * D * D * 10),
         "amid_sas_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_sas_oproj_fwd_f32": ("mfma", gemm),
         "amid_sas_oproj_ffn_fwd_f32": ("mfma", 3 * gemm),
@@ -314,7 +314,7 @@ def gather_stress(device, n_steps=6):
     role = {"amid_embed_fwd_live_f32": "K1 gather (live sequences)", "amid_embed_fwd_f32": "K1 gather",
             "amid_embed_fwd_live_compact_f32": "K1 gather (live sequences; writes the compact index list)",
             "amid_embed_fwd_replay_f32": "K1 gather (live sequences; lazy-Adam catch-up folded in: lagging rows replayed in registers)",
-            "amid_embed_fwd_w16_f32": "K1 gather (live sequences; compact index list; + the forward's 72 weight-image planes by extra workgroups)",
+            "amid_embed_fwd_w16_f32": "K1 gather (live sequences; compact index list; + the step's 144 weight-image planes -- forward and backward strips -- by extra workgroups)",
             "amid_lazy_adam_catchup_live_f32": "K4a lazy-Adam catch-up (live sequences)",
             "amid_grad_tail_f32": "K3 segment reduce + dense partial sums", "amid_embgrad_segreduce_f32": "K3 segment reduce",
             "amid_lazy_adam_catchup_positions_f32": "K4a lazy-Adam catch-up", "amid_optimizer_step_f32": "K4b Adam (dense + unique rows)"}

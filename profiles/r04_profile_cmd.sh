@@ -36,10 +36,15 @@ AMID_FOLD_CATCHUP=1 python3 bench.py --no-cpu-baseline --no-stress > $O/bench_fo
 python3 profiles/tools/probe/wgrad_split_probe.py 2>&1 | grep -v amdgpu > $O/wgrad_split_probe.txt
 (echo "# python profiles/tools/variant_steps.py (cfg 2 shape: B 256, T 50, D 128, hid 32, neg 1; hipGraph replay, 200 steps)"; python3 profiles/tools/variant_steps.py 2>&1 | grep "ms/step"; echo "# VARIANT_T=20 (the mybank shape run.sh trains on)"; VARIANT_T=20 python3 profiles/tools/variant_steps.py 2>&1 | grep "ms/step") > $O/variant_steps.txt
 (echo "# VARIANT_KERNELS=1 python profiles/tools/variant_steps.py: every variant's eager step, entry point by entry point (us per step / launches)"; VARIANT_KERNELS=1 python3 profiles/tools/variant_steps.py 2>&1 | grep -E "^  |ms/step") > $O/variant_kernels.txt
-AMID_FWD_SPLIT=1 python3 bench.py --no-cpu-baseline --no-stress > $O/bench_forward_on_pieces.json 2> $O/bench_forward_on_pieces.err
+# A/B on this box: the forward's / the backward strips' products on the fp32 matrix instructions (round 3's kernels)
+AMID_FWD_SPLIT=0 python3 bench.py --no-cpu-baseline --no-stress > $O/bench_fp32_forward.json 2> $O/bench_fp32_forward.err
+AMID_BWD_SPLIT=0 python3 bench.py --no-cpu-baseline --no-stress > $O/bench_fp32_bwd_strips.json 2> $O/bench_fp32_bwd_strips.err
+AMID_FWD_SPLIT=0 AMID_BWD_SPLIT=0 AMID_WGRAD_SPLIT=0 python3 bench.py --no-cpu-baseline --no-stress > $O/bench_fp32_everything.json 2> $O/bench_fp32_everything.err
 python3 profiles/tools/dp_overhead.py 2>&1 | grep "ms/step" > $O/dp_overhead.txt
 python3 profiles/tools/k1_time.py 2>&1 | grep "TB/s" > $O/k1_time.txt
 python3 profiles/tools/seqn_stamps.py 2>&1 | grep -v amdgpu > $O/seqn_stamps.txt
+(echo "# AMID_FWD_SPLIT=0: the fp32 build (seqn_fwd_kernel)"; AMID_FWD_SPLIT=0 python3 profiles/tools/seqn_stamps.py 2>&1 | grep -v amdgpu) >> $O/seqn_stamps.txt
+python3 profiles/tools/strip_bwd_stamps.py 2>&1 | grep -v amdgpu > $O/strip_bwd_stamps.txt
 python3 bench.py --workload cfg4 --steps 480 --warmup 520 --no-cpu-baseline --no-stress > $O/bench_cfg4_steady.json 2> $O/bench_cfg4_steady.err
 ls -la $O
 tail -3 $O/smoke.log
