@@ -38,10 +38,10 @@ if bench:
     work = B.algorithmic_work(cfg["batch_per_gpu"], cfg.get("unique_rows_last_step"), cfg["seq_len"])
     for entry, (kind, amount) in work.items():
         sym = B.KERNEL_SYMBOL.get(entry)
-        if sym and kind == "mfma" and entry in bench.get("kernels", {}):
+        if sym and kind.startswith("mfma") and entry in bench.get("kernels", {}):
             for one in (sym if isinstance(sym, tuple) else (sym,)):
                 algo[one] = (entry, amount)
-print("| kernel | launches | MFMA busy / (4 x CU busy) | executed matrix GFLOP / launch (512 x MOPS_F32) | algorithmic GFLOP / launch | executed / algorithmic | "
+print("| kernel | launches | MFMA busy / (4 x CU busy) | executed matrix GFLOP / launch (512 x (MOPS_F32 + MOPS_BF16)) | algorithmic GFLOP / launch | executed / algorithmic | "
       "LDS conflict cycles / LDS active cycles | WAIT_ANY / WAVE_CYCLES |")
 print("|---|---|---|---|---|---|---|---|")
 for k, c in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CU_CYCLES", 0)):
