@@ -683,6 +683,55 @@ def test_gather_with_folded_catchup_equals_catchup_then_gather(L, live):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("live", [False, True])
+@pytest.mark.parametrize("with_transposes", [False, True])
+def test_gather_with_weight_image_riders_equals_gather_and_image_launches(L, live, with_transposes):
+    """amid_embed_fwd_w16_f32 (K1 whose extra workgroups write the step's three-plane bf16 images of the encoder weights and, optionally, of
+    their transposes) against the launches it replaces: the gathered rows, mask bytes and compact index list bit for bit those of
+    amid_embed_fwd_live_compact_f32 / amid_embed_fwd_f32, the images bit for bit those of amid_sas_weights_bf16_planes."""
+    from amid_amd._lib import ptr_array
+    B, T, D, NI, n_rows, n_w = 37, 50, 128, 2, 5000, 24
+    g = torch.Generator().manual_seed(11)
+    tab = dev(torch.randn(n_rows, D, generator=g))
+    idx = torch.randint(0, n_rows - 1, (2 * B * T + B * NI,), generator=g).int()
+    idx[torch.rand(idx.numel(), generator=g) < 0.4] = n_rows - 1
+    idx = dev(idx)
+    pos0, pos1 = dev(torch.randn(T, D, generator=g)), dev(torch.randn(T, D, generator=g))
+    dom = dev((torch.rand(B, generator=g) < 0.5).long())
+    lv = dev(torch.zeros(B + 1, dtype=torch.int32))
+    L.call("amid_live_list_i32", dom.data_ptr(), B, lv.data_ptr(), stream())
+    st = step_state(L, 5, 3)
+    W = [dev(torch.randn(D, D, generator=g) * 10.0 ** float(-3 * torch.rand(1, generator=g))) for _ in range(n_w)]
+    src = ptr_array([w.data_ptr() for w in W])
+    outs = []
+    for riders in (False, True):
+        xg = dev(torch.zeros(idx.numel(), D))
+        tmq = dev(torch.zeros(2 * B * T, D // 4, dtype=torch.uint8))
+        ic, rc = dev(torch.full((idx.numel() + 1,), -7, dtype=torch.int32)), dev(torch.full((idx.numel(),), -7, dtype=torch.int32))
+        img, imgT = (dev(torch.zeros(n_w, 3, D * D, dtype=torch.bfloat16)) for _ in range(2))
+        lf, icp, rcp = (lv.data_ptr(), ic.data_ptr(), rc.data_ptr()) if live else (None, None, None)
+        if riders:
+            L.call("amid_embed_fwd_w16_f32", tab.data_ptr(), idx.data_ptr(), pos0.data_ptr(), pos1.data_ptr(), B, T, D, B * NI, xg.data_ptr(),
+                   tmq.data_ptr(), st.data_ptr(), 1, 0.5, lf, icp, rcp, src, n_w, 3, img.data_ptr(),
+                   imgT.data_ptr() if with_transposes else None, stream())
+        else:
+            if live:
+                L.call("amid_embed_fwd_live_compact_f32", tab.data_ptr(), idx.data_ptr(), pos0.data_ptr(), pos1.data_ptr(), B, T, D, B * NI,
+                       xg.data_ptr(), tmq.data_ptr(), st.data_ptr(), 1, 0.5, lf, icp, rcp, stream())
+            else:
+                L.call("amid_embed_fwd_f32", tab.data_ptr(), idx.data_ptr(), pos0.data_ptr(), pos1.data_ptr(), B, T, D, B * NI, xg.data_ptr(),
+                       tmq.data_ptr(), st.data_ptr(), 1, 0.5, stream())
+            L.call("amid_sas_weights_bf16_planes", src, n_w, D, 0, 3, img.data_ptr(), stream())
+            if with_transposes:
+                L.call("amid_sas_weights_bf16_planes", src, n_w, D, 1, 3, imgT.data_ptr(), stream())
+        torch.cuda.synchronize()
+        outs.append([t.cpu() for t in (xg, tmq, ic, rc)] + [img.cpu().view(torch.int16), imgT.cpu().view(torch.int16)])
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), k
+    assert int(outs[1][4].ne(0).sum()) > n_w * D * D            # the images were written ...
+    assert (int(outs[1][5].ne(0).sum()) > 0) == with_transposes  # ... the transposes' only when asked for
+
+
 @pytest.mark.parametrize("shape", ["sasrec", "bert", "sasrec64"])       # sasrec64: head dim 8, pairs of heads per tile
 @pytest.mark.parametrize("B", [5, 130, 1030])          # 1030 > 1024: the kernels keep the identity slot -> sequence mapping
 def test_attention_bwd_rows_hint_equals_plain_backward(L, shape, B):
