@@ -487,27 +487,24 @@ __device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripR
     {   // pass 1: lo x hi, mid x (mid, hi) -- the lo plane sits one slot (32 KB) behind the mid plane: one address, two offsets
         static_assert(CT_BYTES * (NT - 1) + PLANE_BYTES < 65536, "the lo plane is reached through the offset field");
         const unsigned base = lds_addr(ring.mslot());
-        // two column tiles per round, their matrix instructions interleaved: consecutive instructions on ONE accumulator wait for each
-        // other's result (a wave is alone on its SIMD: nobody fills the gap)
-        f32x4 wm[PD1 + 2], wl[PD1 + 2];
+        // a step = (column tile co, k-step s), s fastest: the twelve matrix instructions of a column tile run back to back on ONE
+        // accumulator -- measured (profiles/tools/probe/mfma_rate_probe.hip, a wave alone on its SIMD): 16.5 cycles per instruction in a
+        // chain on one accumulator, 18.1 when the accumulator changes every one to three instructions
+        f32x4 wm[PD1 + 1], wl[PD1 + 1];
         auto issue = [&](auto U) {
-            constexpr int u = decltype(U)::value, k = u % (PD1 + 2);
-            lds_frag_issue<(u % NT) * CT_BYTES>(wm[k], base + fo[u / NT]);
-            lds_frag_issue<(u % NT) * CT_BYTES + PLANE_BYTES>(wl[k], base + fo[u / NT]);
+            constexpr int u = decltype(U)::value, k = u % (PD1 + 1);
+            lds_frag_issue<(u / KS) * CT_BYTES>(wm[k], base + fo[u % KS]);
+            lds_frag_issue<(u / KS) * CT_BYTES + PLANE_BYTES>(wl[k], base + fo[u % KS]);
         };
         static_for<PD1>(issue);
-        static_for<NSTEP / 2>([&](auto T) {
-            constexpr int t = 2 * decltype(T)::value, s = t / NT, co = t % NT, k0 = t % (PD1 + 2), k1 = (t + 1) % (PD1 + 2);
-            if constexpr (t + PD1 < NSTEP) issue(std::integral_constant<int, t + PD1>{});
-            if constexpr (t + 1 + PD1 < NSTEP) issue(std::integral_constant<int, t + 1 + PD1>{});
-            constexpr int last = t + 1 + PD1 < NSTEP ? t + 1 + PD1 : NSTEP - 1;
-            lds_frag_wait<2 * (last - t) + 1>(wm[k0]);
-            lds_frag_wait<2 * (last - t)>(wl[k0]);
-            lds_frag_wait<2 * (last - t - 1) + 1>(wm[k1]);
-            lds_frag_wait<2 * (last - t - 1)>(wl[k1]);
-            acc[co] = mma(wm[k0], am[s], acc[co]); acc[co + 1] = mma(wm[k1], am[s], acc[co + 1]);
-            acc[co] = mma(wl[k0], ah[s], acc[co]); acc[co + 1] = mma(wl[k1], ah[s], acc[co + 1]);
-            acc[co] = mma(wm[k0], ah[s], acc[co]); acc[co + 1] = mma(wm[k1], ah[s], acc[co + 1]);
+        static_for<NSTEP>([&](auto T) {
+            constexpr int t = decltype(T)::value, co = t / KS, s = t % KS, k = t % (PD1 + 1);
+            if constexpr (t + PD1 < NSTEP) issue(std::integral_constant<int, t + PD1>{});      // (into the slot step t - 1 is done with)
+            constexpr int last = t + PD1 < NSTEP ? t + PD1 : NSTEP - 1;
+            lds_frag_wait<2 * (last - t) + 1>(wm[k]);
+            acc[co] = mma(wm[k], am[s], acc[co]);
+            lds_frag_wait<2 * (last - t)>(wl[k]);
+            acc[co] = mma(wl[k], ah[s], acc[co]); acc[co] = mma(wm[k], ah[s], acc[co]);
         });
     }
     STRIP_STAMP(29);
@@ -515,22 +512,18 @@ __device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripR
     ring.mid_sync();
     STRIP_STAMP(30);
     {   // pass 2: hi x (lo, mid, hi)
-        f32x4 wf[PD2 + 2];
+        f32x4 wf[PD2 + 1];
         auto issue = [&](auto U) {
             constexpr int u = decltype(U)::value;
-            lds_frag_issue<(u % NT) * CT_BYTES>(wf[u % (PD2 + 2)], hbase + fo[u / NT]);
+            lds_frag_issue<(u / KS) * CT_BYTES>(wf[u % (PD2 + 1)], hbase + fo[u % KS]);
         };
         static_for<PD2>(issue);
-        static_for<NSTEP / 2>([&](auto T) {
-            constexpr int t = 2 * decltype(T)::value, s = t / NT, co = t % NT, k0 = t % (PD2 + 2), k1 = (t + 1) % (PD2 + 2);
+        static_for<NSTEP>([&](auto T) {
+            constexpr int t = decltype(T)::value, co = t / KS, s = t % KS, k = t % (PD2 + 1);
             if constexpr (t + PD2 < NSTEP) issue(std::integral_constant<int, t + PD2>{});
-            if constexpr (t + 1 + PD2 < NSTEP) issue(std::integral_constant<int, t + 1 + PD2>{});
-            constexpr int last = t + 1 + PD2 < NSTEP ? t + 1 + PD2 : NSTEP - 1;
-            lds_frag_wait<last - t>(wf[k0]);
-            lds_frag_wait<last - t - 1>(wf[k1]);
-            acc[co] = mma(wf[k0], al[s], acc[co]); acc[co + 1] = mma(wf[k1], al[s], acc[co + 1]);
-            acc[co] = mma(wf[k0], am[s], acc[co]); acc[co + 1] = mma(wf[k1], am[s], acc[co + 1]);
-            acc[co] = mma(wf[k0], ah[s], acc[co]); acc[co + 1] = mma(wf[k1], ah[s], acc[co + 1]);
+            constexpr int last = t + PD2 < NSTEP ? t + PD2 : NSTEP - 1;
+            lds_frag_wait<last - t>(wf[k]);
+            acc[co] = mma(wf[k], al[s], acc[co]); acc[co] = mma(wf[k], am[s], acc[co]); acc[co] = mma(wf[k], ah[s], acc[co]);
         });
     }
     STRIP_STAMP(31);
