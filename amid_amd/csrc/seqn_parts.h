@@ -503,13 +503,8 @@ __device__ __forceinline__ void xp_row(StripRegs<D>& full, const float* __restri
 // acc[c] += A W^T over the own column tiles: operand fragments from the strip's exchange slots, weight planes from SeqRing3.
 // The fragment reads are placed by hand (strip_gemm.h lds_frag_issue / lds_frag_wait): left to the compiler every read sat just in front
 // of its first use (lgkmcnt(1) / (0) in front of most matrix instructions).  A step = one column tile of one k-step: two weight fragments
-// (pass 1: mid, lo planes) or one (pass 2: hi plane), three matrix instructions; a k-step's first step also reads the operand's pieces
-// (two / three fragments).  Reads run PD steps ahead; LDS operations return in order, so a step waits until only the reads issued
-// behind its own are outstanding.
-template <int NCT, int PER_STEP, int PER_KSTEP> struct XpReadCount {
-    // reads issued in front of step u's own (issue order: a k-step's operand fragments, then the step's weight fragments)
-    static constexpr int before(int u) { return PER_STEP * u + PER_KSTEP * ((u + NCT - 1) / NCT); }
-};
+// (pass 1: mid, lo planes) or one (pass 2: hi plane), three matrix instructions.  Weight reads run PD steps ahead; LDS operations return
+// in order, so a step waits until only the reads issued behind its own are outstanding.
 template <int D, int NCT, class Ring>
 __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __restrict__ xps, Ring& ring, int c0) {
     constexpr int KS = D / 32, NSTEP = KS * NCT, CT_BYTES = 16 * (D / 2) * 4, PLANE_BYTES = Ring::SLAB * 4;
@@ -517,7 +512,8 @@ __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __re
 #define AMID_XP_PD1 3
 #define AMID_XP_PD2 4
 #endif
-    constexpr int PD1 = AMID_XP_PD1 < NCT ? AMID_XP_PD1 : NCT, PD2 = AMID_XP_PD2 < NCT ? AMID_XP_PD2 : NCT;      // (a k-step's operand fragments are double-buffered)
+    constexpr int PD1 = AMID_XP_PD1, PD2 = AMID_XP_PD2;
+    static_assert(PD1 < NSTEP && PD2 < NSTEP && 2 * PD1 + 2 < 16, "read-ahead against the step count and the lgkmcnt field");
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;
     auto lds_addr = [](const float* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)p; };
@@ -532,49 +528,50 @@ __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __re
     static_assert(CT_BYTES * (NCT - 1) + PLANE_BYTES < 65536, "the lo plane is reached through the offset field");
     const unsigned hbase = mbase + 2u * PLANE_BYTES;
     ring.pre_pass1();
+    // a step = (own column tile c, k-step s), s fastest: a column tile's twelve matrix instructions per pass run back to back on its
+    // accumulator (profiles/r04_mfma_rate_probe.txt: a chain on one accumulator issues faster than instructions that change accumulator;
+    // 77.7 -> 76.1 us by HIP events on one box); the operand's fragments of all four k-steps are read up front
     {   // pass 1: the lo plane against the operand's hi piece, the mid plane against (mid, hi)
-        using Cnt = XpReadCount<NCT, 2, 2>;
-        f32x4 wm[PD1 + 1], wl[PD1 + 1], ah[2], am[2];
+        f32x4 wm[PD1 + 1], wl[PD1 + 1], ah[KS], am[KS];
+        static_for<KS>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            lds_frag_issue<(s * 3 + 0) * 1024>(ah[s], xa);
+            lds_frag_issue<(s * 3 + 1) * 1024>(am[s], xa);
+        });
         auto issue = [&](auto U) {
-            constexpr int u = decltype(U)::value, s = u / NCT, c = u % NCT, k = u % (PD1 + 1);
-            if constexpr (c == 0) {
-                lds_frag_issue<(s * 3 + 0) * 1024>(ah[s & 1], xa);
-                lds_frag_issue<(s * 3 + 1) * 1024>(am[s & 1], xa);
-            }
+            constexpr int u = decltype(U)::value, c = u / KS, s = u % KS, k = u % (PD1 + 1);
             lds_frag_issue<c * CT_BYTES>(wm[k], mbase + fo[s]);
             lds_frag_issue<c * CT_BYTES + PLANE_BYTES>(wl[k], mbase + fo[s]);
         };
         static_for<PD1>(issue);
         static_for<NSTEP>([&](auto T) {
-            constexpr int t = decltype(T)::value, s = t / NCT, c = t % NCT, k = t % (PD1 + 1);
+            constexpr int t = decltype(T)::value, c = t / KS, s = t % KS, k = t % (PD1 + 1);
             if constexpr (t + PD1 < NSTEP) issue(std::integral_constant<int, t + PD1>{});
             constexpr int last = t + PD1 < NSTEP ? t + PD1 : NSTEP - 1;
-            constexpr int younger = Cnt::before(last + 1) - Cnt::before(t + 1);
-            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wm[k]), "+v"(wl[k]), "+v"(ah[s & 1]), "+v"(am[s & 1]) : "n"(younger));
-            acc[c] = mma(wl[k], ah[s & 1], acc[c]); acc[c] = mma(wm[k], am[s & 1], acc[c]); acc[c] = mma(wm[k], ah[s & 1], acc[c]);
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wm[k]), "+v"(wl[k]), "+v"(ah[s]), "+v"(am[s]) : "n"(2 * (last - t)));
+            acc[c] = mma(wl[k], ah[s], acc[c]); acc[c] = mma(wm[k], am[s], acc[c]); acc[c] = mma(wm[k], ah[s], acc[c]);
         });
     }
     ring.mid_sync();
     {   // pass 2: the hi plane against the operand's three pieces
-        using Cnt = XpReadCount<NCT, 1, 3>;
-        f32x4 wf[PD2 + 1], ah[2], am[2], al[2];
+        f32x4 wf[PD2 + 1], ah[KS], am[KS], al[KS];
+        static_for<KS>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            lds_frag_issue<(s * 3 + 0) * 1024>(ah[s], xa);
+            lds_frag_issue<(s * 3 + 1) * 1024>(am[s], xa);
+            lds_frag_issue<(s * 3 + 2) * 1024>(al[s], xa);
+        });
         auto issue = [&](auto U) {
-            constexpr int u = decltype(U)::value, s = u / NCT, c = u % NCT, k = u % (PD2 + 1);
-            if constexpr (c == 0) {
-                lds_frag_issue<(s * 3 + 0) * 1024>(ah[s & 1], xa);
-                lds_frag_issue<(s * 3 + 1) * 1024>(am[s & 1], xa);
-                lds_frag_issue<(s * 3 + 2) * 1024>(al[s & 1], xa);
-            }
-            lds_frag_issue<c * CT_BYTES>(wf[k], hbase + fo[s]);
+            constexpr int u = decltype(U)::value, c = u / KS, s = u % KS;
+            lds_frag_issue<c * CT_BYTES>(wf[u % (PD2 + 1)], hbase + fo[s]);
         };
         static_for<PD2>(issue);
         static_for<NSTEP>([&](auto T) {
-            constexpr int t = decltype(T)::value, s = t / NCT, c = t % NCT, k = t % (PD2 + 1);
+            constexpr int t = decltype(T)::value, c = t / KS, s = t % KS, k = t % (PD2 + 1);
             if constexpr (t + PD2 < NSTEP) issue(std::integral_constant<int, t + PD2>{});
             constexpr int last = t + PD2 < NSTEP ? t + PD2 : NSTEP - 1;
-            constexpr int younger = Cnt::before(last + 1) - Cnt::before(t + 1);
-            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wf[k]), "+v"(ah[s & 1]), "+v"(am[s & 1]), "+v"(al[s & 1]) : "n"(younger));
-            acc[c] = mma(wf[k], al[s & 1], acc[c]); acc[c] = mma(wf[k], am[s & 1], acc[c]); acc[c] = mma(wf[k], ah[s & 1], acc[c]);
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wf[k]), "+v"(ah[s]), "+v"(am[s]), "+v"(al[s]) : "n"(last - t));
+            acc[c] = mma(wf[k], al[s], acc[c]); acc[c] = mma(wf[k], am[s], acc[c]); acc[c] = mma(wf[k], ah[s], acc[c]);
         });
     }
 }
