@@ -1,5 +1,6 @@
 """Per-step kernel timeline from a rocprofv3 rocpd database (rocprofv3 --kernel-trace -d DIR -o NAME -- python3 bench.py ...):
-prints, for one replayed step in the middle of the run, every kernel's start (us, relative to the step's first kernel), duration and
+prints, for one replayed step in the middle of the run (of the eight around the middle the shortest: under the profiler the last step of
+a four-step graph carries the gap to the next graph launch), every kernel's start (us, relative to the step's first kernel), duration and
 stream, so that gaps and overlaps between the main branch and the side-stream sort can be read off.
     python profiles/tools/step_timeline.py gpurun_out/tl/x_results.db [anchor-kernel-substring]"""
 import sqlite3
@@ -11,7 +12,10 @@ rows = db.execute("select name, start, end, stream_id, grid_x * grid_y * grid_z,
 starts = [i for i, r in enumerate(rows) if anchor in r[0]]
 if len(starts) < 4:
     raise SystemExit(f"anchor {anchor!r} found {len(starts)} times")
-i0, i1 = starts[len(starts) // 2], starts[len(starts) // 2 + 1]
+mid = len(starts) // 2
+cand = [(rows[starts[k + 1]][1] - rows[starts[k]][1], k) for k in range(max(0, mid - 4), min(len(starts) - 1, mid + 4))]
+k = min(cand)[1]
+i0, i1 = starts[k], starts[k + 1]
 t0 = rows[i0][1]
 print(f"step of {(rows[i1][1] - t0) / 1e3:.1f} us, {i1 - i0} kernels")
 for name, s, e, st, gx, wx, lds in rows[i0:i1]:
