@@ -120,6 +120,23 @@ def test_forward_on_bf16_pieces_has_fp32_accuracy(B, T, variants, live, train):
             assert e1 > 100 * worst, (e1, worst)
 
 
+@pytest.mark.parametrize("B,T,variant", [(256, 50, 42), (300, 50, 42), (256, 20, 24), (64, 9, 14)])
+def test_forward_on_bf16_pieces_repeats_bit_for_bit(B, T, variant):
+    """A race screen for the hand-placed LDS reads, the plane ring's DMA and the piece exchange of seqn_fwd_px_kernel: 25 launches on the
+    same inputs (train mode, mixed live list; B 300 > the CU count: workgroups of two rounds share CUs) give the same bits in every saved
+    tensor.  (A read that passes its data, a fragment register refilled under a matrix instruction or a plane overwritten early would
+    show up as rare differing tiles.)"""
+    L, pa, st, lv, row_live, P, x0, tmq = _setup(B, T, seed=B + 3 * T, live="mixed")
+    rl = row_live.cuda()
+    first = _run(L, pa, variant, B, T, st, lv, P, x0, tmq, 1, bf16=3)
+    for name, t in first.items():
+        assert torch.isfinite(t[rl]).all(), name
+    for rep in range(24):
+        got = _run(L, pa, variant, B, T, st, lv, P, x0, tmq, 1, bf16=3)
+        for name, want in first.items():
+            assert torch.equal(got[name][rl], want[rl]), (rep, name, float((got[name][rl] - want[rl]).abs().max()))
+
+
 def test_three_plane_weight_images_sum_to_the_weights_exactly():
     """amid_sas_weights_bf16_planes(planes = 3): hi + mid + lo (each a bf16, summed in fp32 in that order... exactly representable steps)
     reproduces every fp32 weight bit for bit, plane 0 is the one-plane (round-to-nearest-even) image, all three in fragment order."""

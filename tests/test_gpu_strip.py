@@ -264,6 +264,12 @@ def test_strip_backward_on_bf16_pieces_has_fp32_accuracy(B, T, live):
         return out + [dx] + out2 + [pg, pg1, pg2, fpg2]
     ref, got = run(0), run(3)
     rl = c.row_live.cuda()
+    if (B, T) == (256, 50):        # a race screen for the hand-placed LDS reads and the four-slot plane ring: the same bits every time
+        for rep in range(20):
+            again = run(3)
+            for i, (a, b) in enumerate(zip(again, got)):
+                a, b = (a[rl], b[rl]) if i < 9 else (a, b)
+                assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)), (rep, i)
     for i, (a, b) in enumerate(zip(got, ref)):
         if i < 9:
             a, b = a[rl].double(), b[rl].double()
