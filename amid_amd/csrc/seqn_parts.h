@@ -508,11 +508,7 @@ __device__ __forceinline__ void xp_row(StripRegs<D>& full, const float* __restri
 template <int D, int NCT, class Ring>
 __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __restrict__ xps, Ring& ring, int c0) {
     constexpr int KS = D / 32, NSTEP = KS * NCT, CT_BYTES = 16 * (D / 2) * 4, PLANE_BYTES = Ring::SLAB * 4;
-#ifndef AMID_XP_PD1
-#define AMID_XP_PD1 3
-#define AMID_XP_PD2 4
-#endif
-    constexpr int PD1 = AMID_XP_PD1, PD2 = AMID_XP_PD2;
+    constexpr int PD1 = FRAG_AHEAD_2, PD2 = FRAG_AHEAD_1;
     static_assert(PD1 < NSTEP && PD2 < NSTEP && 2 * PD1 + 2 < 16, "read-ahead against the step count and the lgkmcnt field");
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;

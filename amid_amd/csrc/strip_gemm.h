@@ -439,6 +439,15 @@ __device__ __forceinline__ void strip_mma16(f32x4 (&acc)[D / 16], const StripReg
 // the wait; measured 7 - 11 k cycles per product against 3 072 of matrix issue, and sched_group_barrier did not move it).  So the reads
 // are inline asm issued PD steps ahead and the wait is an asm that RETURNS the fragment: its users cannot be scheduled in front of it.
 // LDS operations return in order: lgkmcnt(N) = everything but the N youngest is back (operations the compiler adds only make it wait more).
+// steps (one column tile of one k-step: three matrix instructions) a fragment read runs ahead of its use, for passes that read two
+// fragments per step / one: depths 1 ... 8 measure the same in the step; -DAMID_FRAG_AHEAD_2 / _1 for A/B builds
+#ifndef AMID_FRAG_AHEAD_2
+#define AMID_FRAG_AHEAD_2 3
+#endif
+#ifndef AMID_FRAG_AHEAD_1
+#define AMID_FRAG_AHEAD_1 4
+#endif
+constexpr int FRAG_AHEAD_2 = AMID_FRAG_AHEAD_2, FRAG_AHEAD_1 = AMID_FRAG_AHEAD_1;
 template <int OFF> __device__ __forceinline__ void lds_frag_issue(f32x4& d, unsigned addr) {
     static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
@@ -478,11 +487,7 @@ __device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripR
     for (int s = 0; s < KS; ++s) fo[s] = (unsigned)((i * (D / 2) + 4 * ((4 * s + g) ^ i)) * 4);
     STRIP_STAMP(28);
     constexpr int NSTEP = KS * NT, CT_BYTES = 16 * (D / 2) * 4, PLANE_BYTES = RingT::SLAB * 4;
-#ifndef AMID_PD1
-#define AMID_PD1 3
-#define AMID_PD2 4
-#endif
-    constexpr int PD1 = AMID_PD1, PD2 = AMID_PD2;          // steps a read runs ahead of its matrix instructions
+    constexpr int PD1 = FRAG_AHEAD_2, PD2 = FRAG_AHEAD_1;  // steps a read runs ahead of its matrix instructions
     auto lds_addr = [](const float* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)p; };
     {   // pass 1: lo x hi, mid x (mid, hi) -- the lo plane sits one slot (32 KB) behind the mid plane: one address, two offsets
         static_assert(CT_BYTES * (NT - 1) + PLANE_BYTES < 65536, "the lo plane is reached through the offset field");
