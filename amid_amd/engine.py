@@ -413,7 +413,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
 
     def _p3_bwd_for(self, pl: SasrecPlan) -> bool:
         """Whether this plan's backward strips take their data-gradient products on bf16 pieces (three-plane images of the transposes)."""
-        return bool(self.compute != "bf16" and self.BWD_SPLIT and pl.strip and self.D == 128 and not self.inc_bs and not self._seq_backward(pl))
+        return bool(self.compute != "bf16" and self.BWD_SPLIT and pl.strip and self.D == 128 and not self._seq_backward(pl))
 
     def _wT16x3_buf(self):
         if not hasattr(self, "wT16x3"):
