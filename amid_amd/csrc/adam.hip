@@ -11,6 +11,8 @@
 #include "rng.h"
 #include "sort_phases.h"
 #include "adam_replay.h"
+#include "live_list.h"
+#include "seg_spans.h"
 
 namespace amid {
 
@@ -110,6 +112,138 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_pos_kernel(float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The HEAD of a train step in ONE launch (amid_step_head_f32; the live-sequence step on an input pool): what amid_pack_indices_pool_live,
+// the catch-up launch and phase 1 of the step's index sort did in two launches.  Three roles by workgroup index:
+//   [0, nrb)          phase 1 of the sort of the step's COMPACT index list (the ids of every sample's own-domain sequence + its items:
+//                     half the positions of the full list -- the other domain's sequence of a sample carries no gradient and is not read
+//                     by the live forward, train_sr.py:205-211), keys read straight from the batch image
+//   [nrb, nrb + npk)  the packing: the image mirrored into the plan's static input words, the full index list (the gather K1 and the head
+//                     read it), the compact list (ids + rows of the full layout: what the sort's later phases, the segment reduce and the
+//                     row Adam run on), the live-sequence list (last packing workgroup)
+//   the rest          the lazy-Adam catch-up of the compact list's rows, a wave per position (lazy_adam_catchup_pos_kernel's arithmetic)
+// Nobody waits for anybody: every role reads the batch image, which is input.  The step counter: every workgroup takes t - 1 from
+// StepState::step_done and one thread writes `step` = t, which no workgroup of this launch reads (rng.h) -- no ticket, no atomic.
+struct PoolBatch {          // a packed batch image (engine_io.py pack_epoch): [i_node B][neg B n_neg][seq_d1 B T][seq_d2 B T][domain B] ...
+    const long long* __restrict__ src;
+    int B, T, n_neg;
+    long long n_rows;
+    __device__ __forceinline__ int n_compact() const { return B * T + B * (1 + n_neg); }
+    // compact position p: sample b's own-domain sequence at p = b T + t, then the items.  Returns the id (0 when out of range, as the
+    // packing launches do -- they raise the flag) and the row of the full [2 B T + B NI] layout its gradient stands in
+    __device__ __forceinline__ int at(int p, int& row) const {
+        const int M = B * T, NI = 1 + n_neg, items0 = B + B * n_neg;
+        int word;
+        if (p < M) {
+            const int b = p / T;
+            const int dom = src[items0 + 2 * M + b] != 0 ? 1 : 0;
+            word = items0 + dom * M + p;
+            row = dom * M + p;
+        } else {
+            const int j = p - M, b = j / NI, k = j - b * NI;
+            word = k == 0 ? b : B + b * n_neg + (k - 1);
+            row = 2 * M + j;
+        }
+        const long long v = src[word];
+        return (v < 0 || v >= n_rows) ? 0 : (int)v;
+    }
+};
+struct PoolKeys { PoolBatch pb; __device__ __forceinline__ int operator()(int k) const { int row; return pb.at(k, row); } };
+
+struct StepHeadArgs {
+    const long long* pool; long long stride; int n_pool; long long phase;
+    long long* in_pack; int in_words;
+    int B, T, n_neg; long long n_rows;
+    int* idx_all; int* idx_c; int* row_c; int* live; int* err;
+    float* table; float* m_tab; float* v_tab; int* last; int D;
+    StepState* st;
+    int npk;
+};
+
+__global__ __launch_bounds__(256) void step_head_kernel(const StepHeadArgs a, const SortRider rd) {
+    const long long t_pre = a.st->step_done;
+    long long which = (t_pre + a.phase) % a.n_pool;
+    if (which < 0) which += a.n_pool;
+    PoolBatch pb;
+    pb.src = a.pool + which * a.stride; pb.B = a.B; pb.T = a.T; pb.n_neg = a.n_neg; pb.n_rows = a.n_rows;
+    const int nrb = rider_blocks(rd);
+    if ((int)blockIdx.x < nrb) {
+        const SortPlan& sp = rd.plan;
+        os_count_block<1024>(blockIdx.x, sp.nblk, PoolKeys{pb}, sp.g0, sp.state, sp.counts0, sp.stot0, sp.stot0_copy, sp.n_zero_a, sp.counts1,
+                             sp.n_counts1, sp.stot1, sp.n_stot1, (int*)sp.hstatus);
+        return;
+    }
+    const int M = a.B * a.T, NI = 1 + a.n_neg, n_items = a.B * a.n_neg, n_index_words = a.B + n_items + 2 * M;
+    const int n_c = pb.n_compact();
+    if ((int)blockIdx.x < nrb + a.npk) {
+        const int pk = blockIdx.x - nrb;
+        if (pk == 0 && threadIdx.x == 0) a.st->step = t_pre + 1;           // (no workgroup of this launch reads `step`)
+        if (pk == a.npk - 1) live_list_block(pb.src + n_index_words, a.B, a.live);
+        for (int i = pk * 256 + threadIdx.x; i < a.in_words; i += a.npk * 256) {
+            long long v = pb.src[i];
+            a.in_pack[i] = v;
+            if (i < n_index_words) {
+                int dst;
+                if (i < a.B) dst = 2 * M + i * NI;
+                else if (i < a.B + n_items) { const int j = i - a.B; dst = 2 * M + (j / a.n_neg) * NI + 1 + (j % a.n_neg); }
+                else dst = i - a.B - n_items;
+                if (v < 0 || v >= a.n_rows) { atomicOr(a.err, 1); v = 0; }
+                a.idx_all[dst] = (int)v;
+            }
+        }
+        for (int p = pk * 256 + threadIdx.x; p < n_c; p += a.npk * 256) {
+            int row;
+            a.idx_c[p] = pb.at(p, row);
+            a.row_c[p] = row;
+        }
+        return;
+    }
+    // ---- catch-up over the compact positions (lazy_adam_catchup_pos_kernel with the ids read from the image) ----
+    const int bid = blockIdx.x - nrb - a.npk, nbk = gridDim.x - nrb - a.npk;
+    __shared__ IdleCoef tab[COEF_TAB];
+    __shared__ int any_lag;
+    StepState st = *a.st;
+    st.step = t_pre + 1;                         // (the copy's own `step` word may or may not have been written yet: not used)
+    const long long t = st.step;
+    const int lane = threadIdx.x & 63, D = a.D;
+    auto replay_row = [&](long long r, int l) {
+        for (int c = lane; c < (D >> 1); c += 64) {
+            const long long off = r * D + 2 * c;
+            const float2 p2 = *reinterpret_cast<const float2*>(a.table + off), m2 = *reinterpret_cast<const float2*>(a.m_tab + off),
+                         v2 = *reinterpret_cast<const float2*>(a.v_tab + off);
+            float p[2] = {p2.x, p2.y}, m[2] = {m2.x, m2.y}, v[2] = {v2.x, v2.y};
+            replay_elems<2>(p, m, v, (long long)l + 1, t - 1, st, tab);
+            *reinterpret_cast<float2*>(a.table + off) = make_float2(p[0], p[1]);
+            *reinterpret_cast<float2*>(a.m_tab + off) = make_float2(m[0], m[1]);
+            *reinterpret_cast<float2*>(a.v_tab + off) = make_float2(v[0], v[1]);
+        }
+    };
+    const int w0 = bid * (blockDim.x >> 6) + (threadIdx.x >> 6), n_w = nbk * (blockDim.x >> 6);
+    if (threadIdx.x == 0) any_lag = 0;
+    __syncthreads();
+    bool mine = false;
+    for (long long i = w0 + (long long)lane * n_w; i < n_c; i += 64LL * n_w) {
+        int row;
+        const long long l = a.last[pb.at((int)i, row)];
+        if (l > 0 && l < t - 1) mine = true;
+    }
+    if (mine) any_lag = 1;
+    __syncthreads();
+    if (!any_lag) return;
+    fill_coef_table(tab, st);
+    for (int i = w0; i < n_c; i += n_w) {
+        int row;
+        const long long r = pb.at(i, row);
+        const int l = a.last[r];
+        if (!(l > 0 && l < t - 1)) continue;
+        int won = 0;
+        if (lane == 0) won = (atomicCAS(&a.last[r], l, (int)(t - 1)) == l) ? 1 : 0;     // claim the row for this wave
+        won = __builtin_amdgcn_readfirstlane(won);
+        if (!won) continue;
+        replay_row(r, l);
+    }
+}
+
 // bring every row with pending zero-gradient steps up to date (before eval / checkpoint / parity dumps)
 __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
                                                               int* __restrict__ last, long long n_rows, int D, const StepState* __restrict__ stp) {
@@ -153,7 +287,7 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, 
     }
 }
 
-__global__ void step_begin_kernel(StepState* st) { st->step += 1; }
+__global__ void step_begin_kernel(StepState* st) { st->step += 1; st->step_done = st->step; }
 
 // One launch for the whole optimizer: blocks [0, dense_blocks) run dense Adam over the flat buffer, the rest apply the
 // lazy row Adam to the touched table rows (independent memory, so the two roles need no ordering).
@@ -188,6 +322,88 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(float* __restrict__
     const int sub = threadIdx.x & 31;
     const int q = D >> 2;
     for (int u = rb * 8 + (threadIdx.x >> 5); u < U; u += n_rb * 8) {
+        const long long r = uniq_ids[u];
+        const long long l = last[r];
+        const bool lag = (l > 0 && l < t - 1);
+        for (int c = sub; c < q; c += 32) {
+            const long long off = r * D + 4 * c;
+            float4 pp = ld4(table + off), mm = ld4(m_tab + off), vv = ld4(v_tab + off);
+            if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
+            adam_quad(pp, mm, vv, f4scale(ld4(uniq_grad + (long long)u * D + 4 * c), grad_scale), cnow);
+            st4(table + off, pp); st4(m_tab + off, mm); st4(v_tab + off, vv);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (sub == 0) last[r] = (int)t;
+    }
+}
+
+// optimizer_step_kernel with phase B of the segment reduce riding in front (the live-sequence step: amid_grad_tail_live_f32 runs phase A
+// only).  Workgroups [0, nch): chunk c of the sorted list -- if it owns a run that crosses chunk borders (seg_spans.h: the pad row's, a
+// few others) it adds the run's partial rows up (the same additions in the same order as segreduce_spans_kernel: the same bits), writes
+// the sum to uniq_grad and applies the row's Adam step on the spot; the row workgroups skip those runs.  [nch, nch + dense_blocks): dense
+// Adam; the rest: the rows whose runs phase A finished.
+template <int VEC>
+__global__ __launch_bounds__(256) void optimizer_step_spans_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                                   const float* __restrict__ g, long long n, int dense_blocks,
+                                                                   float* __restrict__ table, float* __restrict__ m_tab, float* __restrict__ v_tab,
+                                                                   int* __restrict__ last, const int* __restrict__ uniq_ids,
+                                                                   const int* __restrict__ n_uniq_p, float* __restrict__ uniq_grad,
+                                                                   const StepState* __restrict__ stp, float grad_scale,
+                                                                   const int* __restrict__ seg_off, const int* __restrict__ seg_of, int n_sorted,
+                                                                   const float* __restrict__ partial, int nch) {
+    constexpr int D = VEC * 64;
+    __shared__ IdleCoef tab[COEF_TAB];
+    const StepState st = *stp;
+    if ((int)blockIdx.x < nch) {
+        __shared__ float red[16][D];
+        int u, c_last;
+        if (!spans_owner(blockIdx.x, seg_off, seg_of, n_sorted, SEG_CHUNK, u, c_last)) return;
+        const long long t = st.step;
+        const long long r = uniq_ids[u];
+        const long long l = last[r];
+        const bool lag = (l > 0 && l < t - 1);                       // (block-uniform: one row.  The pad row, the usual owner, never lags)
+        spans_partials<VEC, 4>(red, blockIdx.x, c_last, partial);
+        if (lag) fill_coef_table(tab, st);
+        __syncthreads();                                             // red is complete
+        const AdamCoef cnow = adam_coef_now(st);
+        for (int c = threadIdx.x; c < D / 4; c += blockDim.x) {
+            const float4 gs = make_float4(spans_total<VEC>(red, 4 * c), spans_total<VEC>(red, 4 * c + 1), spans_total<VEC>(red, 4 * c + 2),
+                                          spans_total<VEC>(red, 4 * c + 3));
+            st4(uniq_grad + (long long)u * D + 4 * c, gs);
+            const long long off = r * D + 4 * c;
+            float4 pp = ld4(table + off), mm = ld4(m_tab + off), vv = ld4(v_tab + off);
+            if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
+            adam_quad(pp, mm, vv, f4scale(gs, grad_scale), cnow);
+            st4(table + off, pp); st4(m_tab + off, mm); st4(v_tab + off, vv);
+        }
+        if (threadIdx.x == 0) last[r] = (int)t;
+        return;
+    }
+    const int bid = blockIdx.x - nch;
+    if (bid < dense_blocks) {
+        const AdamCoef c = adam_coef_now(st);
+        const long long stride = (long long)dense_blocks * blockDim.x * 4;
+        for (long long i = ((long long)bid * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+            if (i + 4 <= n) {
+                float4 pp = ld4(p + i), mm = ld4(m + i), vv = ld4(v + i);
+                adam_quad(pp, mm, vv, f4scale(ld4(g + i), grad_scale), c);
+                st4(p + i, pp); st4(m + i, mm); st4(v + i, vv);
+            } else {
+                for (long long k = i; k < n; ++k) adam_elem(p[k], m[k], v[k], g[k] * grad_scale, c);
+            }
+        }
+        return;
+    }
+    const long long t = st.step;
+    const int U = *n_uniq_p;
+    const int rb = bid - dense_blocks, n_rb = gridDim.x - nch - dense_blocks;
+    if (rb * 8 >= U) return;
+    fill_coef_table(tab, st);
+    const AdamCoef cnow = adam_coef_now(st);
+    const int sub = threadIdx.x & 31;
+    const int q = D >> 2;
+    for (int u = rb * 8 + (threadIdx.x >> 5); u < U; u += n_rb * 8) {
+        if (seg_off[u] / SEG_CHUNK != (seg_off[u + 1] - 1) / SEG_CHUNK) continue;      // crosses chunks: a spans workgroup's (above)
         const long long r = uniq_ids[u];
         const long long l = last[r];
         const bool lag = (l > 0 && l < t - 1);
@@ -307,7 +523,7 @@ extern "C" int amid_step_state_bytes(void) { return (int)sizeof(StepState); }
 extern "C" int amid_step_state_pack(void* host_buf, unsigned long long seed, long long step, double lr, double beta1, double beta2, double eps) {
     AMID_CHECK_ARG(host_buf);
     StepState s;
-    s.seed = seed; s.step = step; s.lr = lr; s.beta1 = beta1; s.beta2 = beta2; s.eps = eps; s.ticket = 0; s.pad_ = 0;
+    s.seed = seed; s.step = step; s.lr = lr; s.beta1 = beta1; s.beta2 = beta2; s.eps = eps; s.ticket = 0; s.pad_ = 0; s.step_done = step;
     *(StepState*)host_buf = s;
     return AMID_OK;
 }
@@ -429,4 +645,63 @@ extern "C" int amid_lazy_adam_catchup_positions_sort_f32(float* table, float* m,
                                                          const void* step_state, const void* sort_plan, int sort_phase, void* stream) {
     AMID_CHECK_ARG(sort_plan != nullptr);
     return catchup_positions(table, m, v, last, idx, n_idx, D, step_state, sort_plan, sort_phase, stream);
+}
+
+// The head of a train step on an input pool as ONE launch (step_head_kernel): batch picked by the device step counter, mirrored into the
+// plan's input words, full index list, live list, COMPACT index list (idx_c / row_c: B T + B (1 + n_neg) entries -- every sample's
+// own-domain sequence, then the items), the lazy-Adam catch-up of the compact list's rows, phase 1 of the sort plan built on
+// (idx_c, row_c) (amid_sort_plan_pack), and the step counter's bump (StepState::step; the caller's next launch must be an embed_fwd
+// launch, which re-joins StepState::step_done).  replaces: amid_pack_indices_pool_live + amid_lazy_adam_catchup_positions_sort_f32.
+extern "C" int amid_step_head_f32(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack, int in_words,
+                                  int B, int T, int n_neg, long long n_rows, int* idx_all, int* idx_c, int* row_c, int* live, int* err_flag,
+                                  float* table, float* m, float* v, int* last, int D, void* step_state, const void* sort_plan, void* stream) {
+    AMID_CHECK_ARG(pool && n_pool > 0 && in_pack && idx_all && idx_c && row_c && live && err_flag && table && m && v && last && step_state &&
+                   B > 0 && T > 0 && n_neg > 0 && D > 0 && (D % 4) == 0);
+    AMID_CHECK_ARG(in_words >= B + B * n_neg + 2 * B * T + B);
+    StepHeadArgs a;
+    a.pool = pool; a.stride = pool_stride; a.n_pool = n_pool; a.phase = phase; a.in_pack = in_pack; a.in_words = in_words;
+    a.B = B; a.T = T; a.n_neg = n_neg; a.n_rows = n_rows; a.idx_all = idx_all; a.idx_c = idx_c; a.row_c = row_c; a.live = live; a.err = err_flag;
+    a.table = table; a.m_tab = m; a.v_tab = v; a.last = last; a.D = D; a.st = (StepState*)step_state;
+    int npk = (in_words + 1023) / 1024;
+    if (npk < 2) npk = 2;
+    if (npk > 64) npk = 64;
+    a.npk = npk;
+    SortRider rd;
+    rd.phase = 0;
+    const int n_c = B * T + B * (1 + n_neg);
+    if (sort_plan != nullptr) {
+        rd.plan = *(const SortPlan*)sort_plan;
+        rd.phase = 1;
+        if (rd.plan.n != n_c) return AMID_ERR_ARG;                  // the plan must be the compact list's
+    }
+    long long blocks = ((long long)n_c + 3) / 4;                    // a position per wave (catchup_positions)
+    if (blocks > 16384) blocks = 16384;
+    step_head_kernel<<<rider_blocks_host(rd) + npk + (int)blocks, 256, 0, (hipStream_t)stream>>>(a, rd);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// amid_optimizer_step_f32 for a step whose gradient tail ran phase A of the segment reduce only (amid_grad_tail_live_f32): the runs of
+// the sorted list (seg_off / seg_of, n_sorted entries; workspace = the tail's) that cross chunk borders are summed from their partial rows
+// by extra workgroups of this launch, written to uniq_grad and applied; everything else as amid_optimizer_step_f32.  D = 64 / 128 / 256.
+extern "C" int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const float* g, long long n, float* table, float* m_tab, float* v_tab,
+                                             int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max, float* uniq_grad, int D,
+                                             float grad_scale, const void* step_state, const int* seg_off, const int* seg_of, int n_sorted,
+                                             const void* workspace, void* stream) {
+    AMID_CHECK_ARG(p && m && v && g && n > 0 && table && m_tab && v_tab && last && uniq_ids && n_uniq && uniq_grad && step_state &&
+                   n_uniq_max > 0 && seg_off && seg_of && n_sorted > 0 && workspace);
+    if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
+    long long db = (n / 4 + 255) / 256;
+    if (db < 1) db = 1;
+    if (db > 1024) db = 1024;
+    const int rb = rows_grid(n_uniq_max);
+    const int nch = (n_sorted + SEG_CHUNK - 1) / SEG_CHUNK;
+#define AMID_OPT_LAUNCH(VEC)                                                                                                              \
+    optimizer_step_spans_kernel<VEC><<<nch + (int)db + rb, 256, 0, (hipStream_t)stream>>>(p, m, v, g, n, (int)db, table, m_tab, v_tab, last, uniq_ids, \
+                                                                                          n_uniq, uniq_grad, (const StepState*)step_state, grad_scale, \
+                                                                                          seg_off, seg_of, n_sorted, (const float*)workspace, nch);
+    if (D == 64) { AMID_OPT_LAUNCH(1) } else if (D == 128) { AMID_OPT_LAUNCH(2) } else { AMID_OPT_LAUNCH(4) }
+#undef AMID_OPT_LAUNCH
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
 }

@@ -13,6 +13,7 @@
 // rows in flight x grid cap = 1 x 4096: 140 us, 4 x 4096: 129 us, 2 x 4096: 115 us, 2 x 16384: 110 us (4.0 TB/s of
 // algorithmic read + write) -- many light waves beat few heavy ones here.
 #include "common.h"
+#include "live_list.h"
 #include "rng.h"
 #include "sort_phases.h"
 #include "adam_replay.h"
@@ -60,39 +61,6 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // (train_sr.py:205-211: the other domain's BCE terms are multiplied by zero), so encoder work is enumerated through this list.
 // One workgroup; ballots + popcounts (a few microseconds even at B = 4096).
 // ---------------------------------------------------------------------------------------------
-// body for one 256-thread workgroup
-__device__ __forceinline__ void live_list_block(const long long* __restrict__ domain, int B, int* __restrict__ live) {
-    __shared__ int tot[2][4];
-    const int lane = lane_id(), w = wave_id();
-    const int chunks = (B + 63) / 64, per = (chunks + 3) / 4;          // chunks of 64 batch rows, `per` consecutive chunks per wave
-    const int c_beg = w * per, c_end = min(chunks, c_beg + per);
-    int n0w = 0, n1w = 0;
-    for (int c = c_beg; c < c_end; ++c) {
-        const int b = c * 64 + lane;
-        const bool in = b < B;
-        const bool d = in && domain[b] != 0;
-        n0w += __popcll(__ballot(in && !d));
-        n1w += __popcll(__ballot(d));
-    }
-    if (lane == 0) { tot[0][w] = n0w; tot[1][w] = n1w; }
-    __syncthreads();
-    const int n0 = tot[0][0] + tot[0][1] + tot[0][2] + tot[0][3];
-    int off0 = 0, off1 = n0;
-    for (int ww = 0; ww < w; ++ww) { off0 += tot[0][ww]; off1 += tot[1][ww]; }
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int c = c_beg; c < c_end; ++c) {
-        const int b = c * 64 + lane;
-        const bool in = b < B;
-        const bool d = in && domain[b] != 0;
-        const unsigned long long m0 = __ballot(in && !d), m1 = __ballot(d);
-        if (in && !d) live[off0 + __popcll(m0 & below)] = b;
-        if (d) live[off1 + __popcll(m1 & below)] = b;
-        off0 += __popcll(m0);
-        off1 += __popcll(m1);
-    }
-    if (threadIdx.x == 0) live[B] = n0;
-}
-
 __global__ __launch_bounds__(256) void live_list_kernel(const long long* __restrict__ domain, int B, int* __restrict__ live) {
     live_list_block(domain, B, live);
 }
@@ -104,7 +72,7 @@ __global__ void pack_indices_kernel(const long long* __restrict__ i_node, const 
                                     const long long* __restrict__ seq_d1, const long long* __restrict__ seq_d2,
                                     int B, int T, int n_neg, long long n_rows, int* __restrict__ idx_all, int* __restrict__ err,
                                     StepState* __restrict__ bump, const long long* __restrict__ domain, int* __restrict__ live) {
-    if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) bump->step += 1;      // folded amid_step_begin (nobody in this launch reads it)
+    if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { bump->step += 1; bump->step_done = bump->step; }      // folded amid_step_begin (nobody in this launch reads it)
     if (live != nullptr && blockIdx.x == gridDim.x - 1) live_list_block(domain, B, live);        // folded amid_live_list_i32
     const int M = B * T, NI = 1 + n_neg;
     const int n = 2 * M + B * NI;
@@ -152,7 +120,7 @@ __global__ void pack_indices_pool_kernel(const long long* __restrict__ pool, lon
     __syncthreads();
     // (no __threadfence: the only access that must precede the ticket is this block's READ of the step, and its value has been
     // consumed -- it addresses every load above; a fence per block writes the L2 back and was most of this launch's time)
-    if (threadIdx.x == 0 && atomicInc(&st->ticket, gridDim.x - 1) == gridDim.x - 1) st->step = t_pre + 1;
+    if (threadIdx.x == 0 && atomicInc(&st->ticket, gridDim.x - 1) == gridDim.x - 1) { st->step = t_pre + 1; st->step_done = t_pre + 1; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -198,6 +166,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
         nrb += nsb;
     }
     const int bid = blockIdx.x - nrb;
+    // the step's counters re-joined (rng.h StepState::step_done): behind a one-launch step head `step` is one ahead of `step_done`; no
+    // block of this launch reads step_done, so one thread may write it
+    if (rng != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) const_cast<RngState*>(rng)->step_done = rng->step;
     const int sub = threadIdx.x & 31;
     const int hw = bid * (blockDim.x >> 5) + (threadIdx.x >> 5);
     const int n_hw = (gridDim.x - nrb) * (blockDim.x >> 5);

@@ -48,10 +48,15 @@ struct Tg { int tid, n; };
 __device__ __forceinline__ Tg whole_block() { return Tg{(int)threadIdx.x, (int)blockDim.x}; }
 
 __device__ __forceinline__ void stage_w1t(float* __restrict__ w1t, const float* __restrict__ w1, int D2, int hid, const Tg tg) {
-    // w1t[e][j] = w1[j][e], row stride hid + 1
-    const int q = D2 >> 2;
-    for (int i = tg.tid; i < hid * q; i += tg.n) {
-        const int j = i / q, c = i - j * q;
+    // w1t[e][j] = w1[j][e], row stride hid + 1.  A half-wave covers 4 rows j x 8 column quads c: its 32 stores of one component fall on
+    // banks (4 c (hid + 1) + j) mod 32 = (4 c' + j') mod 32 (hid = 32 or 64), c' < 8, j' < 4 -- every bank once.  (Round 4 walked the quads
+    // of ONE row with consecutive lanes: stride 4 (hid + 1), eight banks, every store four-way conflicted: a third of the kernel's LDS cycles.)
+    const int q = D2 >> 2;                            // column quads per row: a multiple of 8
+    const int l = tg.tid & 31, hw = tg.tid >> 5, n_hw = tg.n >> 5;
+    const int qb = q >> 3;                            // blocks of 8 quads per row
+    for (int blk = hw; blk < (hid >> 2) * qb; blk += n_hw) {
+        const int jb = blk / qb, cb = blk - jb * qb;
+        const int j = 4 * jb + (l >> 3), c = 8 * cb + (l & 7);
         const float4 v = ld4(w1 + (long long)j * D2 + 4 * c);
         float* o = w1t + (4 * c) * (hid + 1) + j;
         o[0] = v.x; o[hid + 1] = v.y; o[2 * (hid + 1)] = v.z; o[3 * (hid + 1)] = v.w;
@@ -172,6 +177,119 @@ __device__ __forceinline__ void lnmean_rows_own(const HeadArgs& a, int b, float*
         a.u[((long long)g2 * a.B + b) * D + e] = s;
     }
     __syncthreads();
+}
+
+// ---- own_only, forward + backward in one workgroup: the T rows of (domain[b], b) are loaded ONCE.  The loads are issued first (W1^T is
+// staged while they fly), the rows are kept normalised in registers (xh = (x - mean) rstd; with 16 row groups a thread holds at most
+// HEAD_CHUNK / 2 of them) together with their rstd, and the LayerNorm backward at the end of the workgroup's life reads them from there:
+// no second pass over x, no second mean / variance.  Same operations in the same order as lnmean_rows_own / lnmean_rows_bwd_own: same bits.
+struct OwnRows { float4 xh[HEAD_CHUNK / 2]; float rstd[HEAD_CHUNK / 2]; };
+
+__device__ __forceinline__ void own_rows_load(const HeadArgs& a, int b, OwnRows& R) {
+    const int D = a.D, T = a.T, q = D >> 2;
+    const int own = a.domain[b] != 0 ? 1 : 0;
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const bool on = c < q;
+    const float* xb = a.x + ((long long)own * a.B + b) * T * D;
+#pragma unroll
+    for (int i = 0; i < HEAD_CHUNK / 2; ++i) {
+        const int t = rg + 16 * i;
+        R.xh[i] = (t < T && on) ? ld4(xb + (long long)t * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        R.rstd[i] = 0.f;
+    }
+}
+
+// T <= 16 * HEAD_CHUNK / 2 rows (the caller checks); red [16][D]
+__device__ __forceinline__ void own_rows_lnmean(const HeadArgs& a, int b, OwnRows& R, float* __restrict__ red, float* __restrict__ u_all) {
+    const int D = a.D, T = a.T, q = D >> 2;
+    const int own = a.domain[b] != 0 ? 1 : 0;
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const bool on = c < q;
+    const bool use_ln = a.lnw[0] != nullptr;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ww = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (use_ln && on) { ww = ld4(a.lnw[own] + 4 * c); b4 = ld4(a.lnb[own] + 4 * c); }
+#pragma unroll
+    for (int i = 0; i < HEAD_CHUNK / 2; ++i) {
+        const int t = rg + 16 * i;
+        if (t < T) {                                  // uniform over the 32 lanes of the row group
+            float4 y = R.xh[i];
+            if (use_ln) {
+                const float mean = group_sum<32>(f4hsum(y)) / D;
+                float4 d4 = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
+                if (!on) d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float rstd = 1.0f / sqrtf(group_sum<32>(f4hsum(f4mul(d4, d4))) / D + a.eps);
+                R.rstd[i] = rstd;
+                R.xh[i] = f4scale(d4, rstd);
+                y = make_float4(d4.x * rstd * ww.x + b4.x, d4.y * rstd * ww.y + b4.y, d4.z * rstd * ww.z + b4.z, d4.w * rstd * ww.w + b4.w);
+            }
+            acc = f4add(acc, y);
+        }
+    }
+    if (on) st4(red + rg * D + 4 * c, acc);
+    __syncthreads();
+    for (int ge = threadIdx.x; ge < 2 * D; ge += blockDim.x) {
+        const int g2 = ge / D, e = ge - g2 * D;
+        float s = 0.f;
+        if (g2 == own) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += red[k * D + e];
+            s /= T;
+        }
+        u_all[ge] = s;
+        a.u[((long long)g2 * a.B + b) * D + e] = s;
+    }
+    __syncthreads();
+}
+
+// red [16][2][D]
+__device__ __forceinline__ void own_rows_ln_bwd(const HeadArgs& a, int b, const OwnRows& R, const float* __restrict__ du_all, float* __restrict__ red) {
+    const int D = a.D, T = a.T, q = D >> 2;
+    const int own = a.domain[b] != 0 ? 1 : 0;
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const bool on = c < q;
+    const float* du_s = du_all + own * D;
+    const bool use_ln = a.lnw[0] != nullptr;
+    const float invT = 1.0f / T;
+    const long long base = ((long long)own * a.B + b) * T * D;
+    float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam;
+    const float4 dy = on ? f4scale(ld4(du_s + 4 * c), invT) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gy = dy;
+    if (use_ln && on) gy = f4mul(dy, ld4(a.lnw[own] + 4 * c));
+    const float c1 = use_ln ? group_sum<32>(f4hsum(gy)) / D : 0.f;
+#pragma unroll
+    for (int i = 0; i < HEAD_CHUNK / 2; ++i) {
+        const int t = rg + 16 * i;
+        if (t < T) {
+            float4 out = dy;
+            if (use_ln) {
+                const float4 xh = R.xh[i];
+                const float rstd = R.rstd[i];
+                const float c2 = group_sum<32>(f4hsum(f4mul(gy, xh))) / D;
+                out = make_float4(rstd * (gy.x - c1 - xh.x * c2), rstd * (gy.y - c1 - xh.y * c2), rstd * (gy.z - c1 - xh.z * c2),
+                                  rstd * (gy.w - c1 - xh.w * c2));
+                dgam = f4add(dgam, f4mul(dy, xh));
+                dbet = f4add(dbet, dy);
+            }
+            if (on) st4(a.dx + base + (long long)t * D + 4 * c, out);
+        }
+    }
+    if (on) {
+        st4(red + rg * 2 * D + 4 * c, dgam);
+        st4(red + rg * 2 * D + D + 4 * c, dbet);
+    }
+    __syncthreads();
+    if (use_ln) {
+        for (int ge = threadIdx.x; ge < 4 * D; ge += blockDim.x) {
+            const int g2 = ge / (2 * D), e = ge - g2 * 2 * D;
+            float sacc = 0.f;
+            if (g2 == own) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sacc += red[k * 2 * D + e];
+            }
+            a.ln_part[((long long)g2 * a.B + b) * 2 * D + e] = sacc;
+        }
+    }
 }
 
 // LDS carve (floats): w1t [2D][hid+1] | u_s [2][D] | au [2][hid] | da [2][hid] | dw2 [hid+4] | ci [64][hid+1] | dc [64][hid+1] | scratch [16][D]
@@ -570,6 +688,28 @@ __global__ __launch_bounds__(512) void head_bwd_kernel(const HeadArgs a) {
 // intact, backward; the extra workgroups (blockIdx >= B) only transpose the projection weights
 __global__ __launch_bounds__(512) void head_fwd_bwd_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    if ((int)blockIdx.x < a.B && a.own_only && a.T <= 16 * (HEAD_CHUNK / 2)) {
+        // the live-sequence train step: the sample's own sequence, loaded once and kept in registers from the forward LayerNorm to its backward
+        const HeadLds s(sm, a.D, a.hid);
+        const int b = blockIdx.x;
+        HEAD_STAMP(0);
+        OwnRows R;
+        own_rows_load(a, b, R);
+        stage_w1t(s.w1t, a.w1, 2 * a.D, a.hid, whole_block());
+        HEAD_STAMP(1);
+        own_rows_lnmean(a, b, R, s.scr, s.u_s);
+        HEAD_STAMP(2);
+        scorer_fwd_part(a, s, b, whole_block());
+        HEAD_STAMP(6);
+        __threadfence_block();                            // dLoss/dp written above is read by other threads of this workgroup below
+        __syncthreads();
+        HEAD_STAMP(7);
+        float* du_s = scorer_bwd_part<true, false>(a, s, b, whole_block());
+        HEAD_STAMP(10);
+        own_rows_ln_bwd(a, b, R, du_s, s.scr);
+        HEAD_STAMP(11);
+        return;
+    }
     if ((int)blockIdx.x < a.B) {
         head_fwd_body(a, sm, blockIdx.x);
         __threadfence_block();                            // dLoss/dp written above is read by other threads of this workgroup below

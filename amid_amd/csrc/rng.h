@@ -12,6 +12,9 @@ struct StepState {         // lives in device memory so that hipGraph replays se
     long long step;            // 1-based global step t: dropout counter and Adam bias correction; bumped by amid_step_begin
     double lr, beta1, beta2, eps;   // torch.optim.Adam hyper-parameters (train_sr.py:480: lr only, rest defaults)
     unsigned ticket, pad_;     // "last block out" counter of the pool-input pack kernel (embed.hip); wraps to 0 by itself
+    long long step_done;       // steps completed: equals `step` whenever a step's first launch starts.  The one-launch step head (adam.hip
+                               // step_head_kernel) reads t - 1 HERE while one of its threads writes `step` = t (no block of that launch reads
+                               // `step`, so no ticket is needed); the gather K1 behind it copies `step` back here (nobody reads it there)
 };
 using RngState = StepState;
 

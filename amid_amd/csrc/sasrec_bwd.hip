@@ -13,6 +13,7 @@
 #include "tile_gemm.h"
 #include "reduce_partials.h"
 #include "wgrad_split.h"
+#include "sort_phases.h"
 
 namespace amid {
 
@@ -678,10 +679,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad16_kernel(const Wgra
 }
 
 // the same on the bf16 matrix cores at fp32 accuracy (mma mode 2 / 3): csrc/wgrad_split.h
-template <int D, int NTERM, bool HINT>
-__global__ __launch_bounds__(GEMM_THREADS, 4) void sas_wgrad_split_kernel(const WgradArgs a) {
+// RIDER: the launch has one more z-slice whose first rd.plan.nblk workgroups run the LAST phase of the step's index sort (sort_phases.h:
+// run heads; it rode in the embedding-backward launch while the live-sequence step had one): waves 0 .. 3 of a 512-thread workgroup --
+// the others leave at once (a barrier counts the waves that have not ended)
+template <int D, int NTERM, bool HINT, bool RIDER = false>
+__global__ __launch_bounds__(GEMM_THREADS, 4) void sas_wgrad_split_kernel(const WgradArgs a, const SortRider rd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(D == 128, "eight waves = eight 16-row tiles of dW");
+    if constexpr (RIDER) {
+        if (blockIdx.z == 2) {
+            const int rb = blockIdx.y * gridDim.x + blockIdx.x;
+            if (rb < rd.plan.nblk && threadIdx.x < SORT_THREADS) sort_phase_ct<1024, 5>(rd.plan, rb);
+            return;
+        }
+    }
     const int split = blockIdx.x, wsel = blockIdx.y, g = blockIdx.z;
     const int layer = wsel / 6, wi = wsel - layer * 6;
     const WgsRows rw{a.M, a.splits, a.rows_per_split, a.row_domain, a.B, a.T};
@@ -877,7 +888,8 @@ extern "C" int AMID_ENTRY(amid_sas_qkv_ffn_bwd_rows_f32)(const float* dq, const 
 
 #if AMID_TILE_RT == 7      // everything below is independent of the row-tile height: one copy only
 static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
-                     float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, void* stream) {
+                     float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, void* stream,
+                     const void* sort_plan = nullptr) {
     AMID_CHECK_ARG(dy && x && w_part && b_part && (n_layers == 1 || n_layers == 2) && M > 0 && splits > 0);
     AMID_CHECK_ARG(!row_domain || (B > 0 && T > 0 && (long long)B * T == M));
     WgradArgs a;
@@ -891,6 +903,18 @@ static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers
     a.row_domain = (row_domain && win <= WG_LIVE_MAX) ? row_domain : nullptr; a.B = B; a.T = T;
     const size_t live_bytes = a.row_domain ? (size_t)((win + 3) & ~3) * sizeof(int) : 0;
     const dim3 grid(splits, 6 * n_layers, 2);
+    SortRider rd;
+    rd.phase = 0;
+    if (sort_plan != nullptr) {      // the last phase of a sort plan rides in a third z-slice: the six-pair build with the live-row hint only
+        rd.plan = *(const SortPlan*)sort_plan;
+        rd.phase = 5;
+        if (!(mma_bf16 == 3 && D == 128 && a.row_domain != nullptr && splits * 6 * n_layers >= rd.plan.nblk)) return AMID_ERR_UNSUPPORTED;
+        static unsigned long long done_r = 0;
+        if (int e = lds_attr_once((const void*)sas_wgrad_split_kernel<128, 6, true, true>, WGS_LDS_FIXED + WG_LIVE_MAX * sizeof(int), done_r)) return e;
+        sas_wgrad_split_kernel<128, 6, true, true><<<dim3(splits, 6 * n_layers, 3), GEMM_THREADS, WGS_LDS_FIXED + live_bytes, (hipStream_t)stream>>>(a, rd);
+        AMID_LAUNCH_CHECK();
+        return AMID_OK;
+    }
     if (mma_bf16 >= 2) {      // fp32 operands as three bf16 pieces each (csrc: sas_wgrad_split_kernel): D = 128 only
         if (D != 128) return AMID_ERR_UNSUPPORTED;
         const size_t fixed = WGS_LDS_FIXED;
@@ -898,7 +922,7 @@ static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers
 #define AMID_WGS_LAUNCH(NT, H, SLOT)                                                                                                  \
         do {                                                                                                                      \
             if (int e = lds_attr_once((const void*)sas_wgrad_split_kernel<128, NT, H>, fixed + WG_LIVE_MAX * sizeof(int), done[SLOT])) return e; \
-            sas_wgrad_split_kernel<128, NT, H><<<grid, GEMM_THREADS, fixed + live_bytes, (hipStream_t)stream>>>(a);                    \
+            sas_wgrad_split_kernel<128, NT, H><<<grid, GEMM_THREADS, fixed + live_bytes, (hipStream_t)stream>>>(a, rd);                   \
         } while (0)
         const bool h = a.row_domain != nullptr;
         if (mma_bf16 == 2) { if (h) AMID_WGS_LAUNCH(9, true, 0); else AMID_WGS_LAUNCH(9, false, 1); }
@@ -949,6 +973,14 @@ extern "C" int amid_sas_wgrad_rows_f32(const float* const* dy, const float* cons
                                        float* const* w_part, float* const* b_part, const long long* row_domain, int B, int T,
                                        int mma_bf16, void* stream) {
     return sas_wgrad(dy, x, n_layers, M, D, splits, w_part, b_part, row_domain, B, T, mma_bf16, stream);
+}
+
+// ... carrying the LAST phase (5: run heads) of a sort plan (amid_sort_plan_pack) as extra workgroups; mma_bf16 = 3, D = 128
+extern "C" int amid_sas_wgrad_rows_sort_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits,
+                                            float* const* w_part, float* const* b_part, const long long* row_domain, int B, int T,
+                                            int mma_bf16, const void* sort_plan, void* stream) {
+    AMID_CHECK_ARG(sort_plan != nullptr && row_domain != nullptr);
+    return sas_wgrad(dy, x, n_layers, M, D, splits, w_part, b_part, row_domain, B, T, mma_bf16, stream, sort_plan);
 }
 
 extern "C" int amid_transpose_weights_f32(const float* const* src, float* const* dst, int n, int D, void* stream) {

@@ -376,7 +376,14 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const Stri
         qkv_bwd_chain<D, true>(a, sg, ring, row, t.g, DX, ln_scratch<D>(smem, 0), f.w2T[t.g], [&]() { ffn_bwd_prefetch<D>(pre, f, sg, row, t.g); });
         ffn_bwd_chain<D>(f, sg, ring, row, t.g, DX, pre, ln_scratch<D>(smem, 1));
     } else {
-        qkv_bwd_chain<D, false>(a, sg, ring, row, t.g, DX, ln_scratch<D>(smem, 0), nullptr, []() {});
+        const bool emb = a.emb_tmq != nullptr;                 // (uniform) the embedding layer's backward on the strip: see StripQkvBwdArgs
+        StripTm<D> etm;
+        qkv_bwd_chain<D, false>(a, sg, ring, row, t.g, DX, ln_scratch<D>(smem, 0), nullptr,
+                                [&]() { if (emb) strip_tm_load<D>(etm, GBuf(a.emb_tmq, sg.tm_bytes), row); });
+        if (emb) {
+            if (a.emb_train) strip_dropout<D>(DX, a.emb_st->seed, site_id(t.g, 0, SITE_EMB), (unsigned)a.emb_st->step, row.local, a.emb_spec, a.emb_scale);
+            strip_apply_tm<D>(DX, etm);
+        }
         strip_store<D>(GBuf(a.dx, sg.act_bytes), row, DX);
     }
     __syncthreads();
@@ -620,15 +627,21 @@ static int strip_qkv_bwd(const float* dq, const float* dk, const float* dv, cons
                          const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
                          const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
                          const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
-                         float* fd_o, float* fln_part, const void* sort_plan, int sort_phase, int mma_bf16, void* stream) {
+                         float* fd_o, float* fln_part, const void* sort_plan, int sort_phase, int mma_bf16, void* stream,
+                         const unsigned char* emb_tmq = nullptr, float emb_p_drop = 0.f) {
     AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && ln_part);
     if (mma_bf16 && D != 128) return AMID_ERR_UNSUPPORTED;
     const bool ffn = fh != nullptr;
+    AMID_CHECK_ARG(emb_tmq == nullptr || (!ffn && (!train || step_state)));
     AMID_CHECK_ARG(ffn || dx);
     AMID_CHECK_ARG(!ffn || (fr && fln_w && fw1T && fw2T && fwoT && fdpre2 && fdpre1 && fdr && fd_o && fln_part && (!train || step_state)));
     StripQkvBwdArgs a;
     a.dq = dq; a.dk = dk; a.dv = dv; a.dr = dr; a.x = x; a.dx = dx; a.ln_part = ln_part; a.ln_eps = ln_eps;
     for (int g = 0; g < 2; ++g) { a.ln_w[g] = ln_w[g]; a.wqT[g] = wqT[g]; a.wkT[g] = wkT[g]; a.wvT[g] = wvT[g]; }
+    a.emb_tmq = emb_tmq; a.emb_st = (const StepState*)step_state;
+    a.emb_train = (emb_tmq && train && emb_p_drop > 0.f) ? 1 : 0;
+    a.emb_spec = drop_spec(emb_p_drop);
+    a.emb_scale = a.emb_train ? 1.0f / (1.0f - emb_p_drop) : 1.0f;
     StripFfnBwdArgs f = {};
     if (ffn) fill_ffn_bwd(f, nullptr, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, ln_eps, flayer, step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part);
     StripGeom sg;
@@ -679,6 +692,21 @@ extern "C" int amid_sas_strip_qkv_bwd_sort_f32(const float* dq, const float* dk,
     AMID_CHECK_ARG(sort_plan != nullptr);
     return strip_qkv_bwd(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, B, T, D, live, dx, ln_part, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, flayer,
                          step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, sort_plan, sort_phase, mma_bf16, stream);
+}
+
+// layer 0's launch of the live-sequence train step with the embedding layer's backward on the strip (StripQkvBwdArgs::emb_tmq): dx = the
+// gradient of the gathered rows (dropout keep bits of site SITE_EMB redrawn from step_state, then the "== 0" bits of emb_tmq applied) --
+// amid_sas_strip_qkv_bwd(_sort)_f32 without the fused feed-forward followed by amid_embed_bwd_f32's element-wise part, in one launch
+// (the position rows' gradient sums: amid_grad_tail_live_f32).  sort_plan may be NULL (no rider); with a plan the launch carries phase 4.
+extern "C" int amid_sas_strip_qkv_bwd_emb_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                              const float* const* ln_w, const float* const* wqT, const float* const* wkT,
+                                              const float* const* wvT, float ln_eps, int B, int T, int D, const int* live, float* dx,
+                                              float* ln_part, const unsigned char* emb_tmq, const void* step_state, int train,
+                                              float emb_p_drop, const void* sort_plan, int sort_phase, int mma_bf16, void* stream) {
+    AMID_CHECK_ARG(emb_tmq != nullptr && dx != nullptr);
+    return strip_qkv_bwd(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, B, T, D, live, dx, ln_part, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, nullptr, 0, step_state, train, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, sort_plan, sort_phase, mma_bf16,
+                         stream, emb_tmq, emb_p_drop);
 }
 
 // ---- the fused per-sequence backward ------------------------------------------------------------------------------------------------

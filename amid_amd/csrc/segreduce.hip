@@ -11,41 +11,9 @@
 // partial per chunk, and the chunk in which the run starts adds the partials up in chunk order.
 #include "common.h"
 #include "reduce_partials.h"
+#include "seg_spans.h"
 
 namespace amid {
-
-constexpr int SEG_CHUNK = 64;        // entries per wave in phase A (the step's own lists: the pad run spans ~360 of these chunks)
-constexpr int SEG_CHUNK_SHORT = 16;  // ... for short lists without long runs (the data-parallel merge: <= world duplicates per id): 4x the waves
-constexpr int SEG_BATCH = 16;      // rows a wave requests before folding them (8: 8 dependent round trips per chunk, 16: 4)
-
-__device__ __forceinline__ int seg_of_entry(const int* __restrict__ seg_off, int U, int e) {
-    // largest u in [0,U) with seg_off[u] <= e
-    int lo = 0, hi = U - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (seg_off[mid] <= e) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
-template <int VEC> struct RowVec { float v[VEC]; };
-
-template <int VEC>
-__device__ __forceinline__ RowVec<VEC> load_row(const float* __restrict__ base, long long row, int D, int lane) {
-    RowVec<VEC> r;
-    const float* p = base + row * D + lane * VEC;
-    if constexpr (VEC == 4) { float4 t = ld4(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
-    else if constexpr (VEC == 2) { float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
-    else { r.v[0] = *p; }
-    return r;
-}
-template <int VEC>
-__device__ __forceinline__ void store_row(float* __restrict__ base, long long row, int D, int lane, const RowVec<VEC>& r) {
-    float* p = base + row * D + lane * VEC;
-    if constexpr (VEC == 4) st4(p, make_float4(r.v[0], r.v[1], r.v[2], r.v[3]));
-    else if constexpr (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1]);
-    else *p = r.v[0];
-}
 
 // phase A: one wave per 64-entry chunk of the sorted list.  Lane l keeps (position, run index) of entry e0 + l; rows
 // are fetched SEG_BATCH at a time whatever runs they belong to (independent loads), then folded in order, flushing at
@@ -132,50 +100,84 @@ __global__ __launch_bounds__(256) void grad_tail_kernel(const float* __restrict_
     reduce_partials_block(entries[lo], rb - blk_off[lo], blk_off[lo + 1] - blk_off[lo]);
 }
 
-// phase B: the chunk in which a border-crossing run STARTS owns its final sum
+// ---- the gradient tail of the live-sequence train step (amid_grad_tail_live_f32) ----------------------------------------------------------
+// grad_tail_kernel's two roles over the step's COMPACT sorted list, plus a third: the position rows' gradients.  The embedding layer's
+// element-wise backward ran on the last strip launch (sasrec_strip.hip StripQkvBwdArgs::emb_tmq), so dP_g[t] = sum over the LIVE sequences
+// b of domain g of grad_rows[(g B + b) T + t] is a fixed-order sum over rows that are already final: 256 threads = 32 float4 columns x 8
+// groups of sequences (group p adds live sequences p, p + 8, ... in order, eight loads in flight), the eight group sums added in order.
+// The dead sequences' rows are neither written nor read by anybody.  Phase B of the segment reduce rides in the optimizer launch
+// (adam.hip optimizer_step_spans_kernel).
+struct PosSum { const float* rows; const int* live; int B, T; float* dst[2]; int nblk; };
+
+__device__ __forceinline__ void pos_sum_block(const PosSum& ps, int D, int g, int bx, int nbx) {
+    __shared__ float4 pred[8][33];
+    const int el = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    const int n0 = ps.live[ps.B];
+    const int s0 = g ? n0 : 0, n = g ? ps.B - n0 : n0;
+    const int count = ps.T * D;
+    const long long seq = (long long)ps.T * D;
+    const float* __restrict__ base = ps.rows + (long long)g * ps.B * seq;
+    const int* __restrict__ lv = ps.live + s0;
+    for (int e0 = bx * 128; e0 < count; e0 += nbx * 128) {        // block-uniform
+        const int e = e0 + 4 * el;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < count) {
+            int k = pg;
+            for (; k + 56 < n; k += 64) {
+                int b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = lv[k + 8 * j];
+                float4 r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = ld4(base + b[j] * seq + e);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s = f4add(s, r[j]);
+            }
+            for (; k < n; k += 8) s = f4add(s, ld4(base + lv[k] * seq + e));
+        }
+        pred[pg][el] = s;
+        __syncthreads();
+        if (pg == 0 && e < count) {
+            float4 t = pred[0][el];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) t = f4add(t, pred[q][el]);
+            st4(ps.dst[g] + e, t);
+        }
+        __syncthreads();
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void grad_tail_live_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
+                                                             const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
+                                                             float* __restrict__ partial, int n_seg, const ReduceEntry* __restrict__ entries,
+                                                             const int* __restrict__ blk_off, int n_entries, int n_red, const PosSum ps) {
+    if ((int)blockIdx.x < n_seg) { segreduce_chunks_block<VEC>(grad_rows, pos_sorted, seg_of, n, uniq_grad, partial, blockIdx.x); return; }
+    const int rb = blockIdx.x - n_seg;
+    if (rb >= n_red) {
+        const int pb = rb - n_red;
+        pos_sum_block(ps, VEC * 64, pb / ps.nblk, pb % ps.nblk, ps.nblk);
+        return;
+    }
+    int lo = 0, hi = n_entries;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blk_off[mid] <= rb) lo = mid; else hi = mid;
+    }
+    reduce_partials_block(entries[lo], rb - blk_off[lo], blk_off[lo + 1] - blk_off[lo]);
+}
+
+// phase B: the chunk in which a border-crossing run STARTS owns its final sum (seg_spans.h)
 template <int VEC>
 __device__ __forceinline__ void segreduce_spans_block(int c, const int* __restrict__ seg_off, const int* __restrict__ seg_of, int n,
                                                       const float* __restrict__ partial, float* __restrict__ uniq_grad, int chunk) {
     const int D = VEC * 64;
     __shared__ float red[16][VEC * 64];
-    const int e0 = c * chunk;
-    if (e0 >= n) return;
-    const int e_end = min(e0 + chunk, n);
-    if (e_end >= n) return;                           // the last chunk's tail run cannot continue
-    const int u = seg_of[e_end - 1];
-    if (seg_of[e_end] != u) return;                   // block-uniform: the tail run ends inside this chunk
-    const int s_beg = seg_off[u], s_end = seg_off[u + 1];
-    if (s_beg < e0) return;                           // started in an earlier chunk: that chunk owns the sum
-    const int c_last = (s_end - 1) / chunk;
-    const int lane = lane_id(), w = wave_id();
-    RowVec<VEC> acc;
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
-    // wave w sums chunks c + w, c + w + 16, ... (first chunk: tail slot 1, later chunks: head slot 0)
-    int cc = c + w;
-    for (; cc + 48 <= c_last; cc += 64) {
-        RowVec<VEC> r[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int ci = cc + 16 * j; r[j] = load_row<VEC>(partial, (long long)ci * 2 + (ci == c ? 1 : 0), D, lane); }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc.v[k] += r[j].v[k];
-    }
-    for (; cc <= c_last; cc += 16) {
-        const RowVec<VEC> r = load_row<VEC>(partial, (long long)cc * 2 + (cc == c ? 1 : 0), D, lane);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc.v[k] += r.v[k];
-    }
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) red[w][lane * VEC + k] = acc.v[k];
+    int u, c_last;
+    if (!spans_owner(c, seg_off, seg_of, n, chunk, u, c_last)) return;
+    spans_partials<VEC, 16>(red, c, c_last, partial);
     __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 1024) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += red[k][d];
-        uniq_grad[(long long)u * D + d] = s;
-    }
+    for (int d = threadIdx.x; d < D; d += 1024) uniq_grad[(long long)u * D + d] = spans_total<VEC>(red, d);
 }
 
 template <int VEC>
@@ -284,6 +286,33 @@ extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted,
     grad_tail_kernel<VEC><<<n_seg + (blk_off ? total_blocks : bx * n_entries), 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, \
                                                                                            partial, n_seg, en, bx, blk_off, n_entries);     \
     segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad);
+    if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }
+#undef AMID_TAIL_LAUNCH
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// The gradient tail of the live-sequence step in ONE launch (grad_tail_live_kernel): phase A of the segment reduce over the step's
+// compact sorted list (pos_sorted holds rows of grad_rows), the fixed-order partial sums of `entries` (blk_off: blocks per entry, as
+// amid_grad_tail_f32) and the position rows' gradients dpos[g] [T, D] summed over the live sequences (live: amid_live_list_i32) straight
+// from grad_rows.  Phase B of the segment reduce is NOT run here: amid_optimizer_step_spans_f32 finishes the runs that cross chunks.
+extern "C" int amid_grad_tail_live_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                                       void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off,
+                                       int total_blocks, const int* live, int B, int T, float* dpos0, float* dpos1, void* stream) {
+    AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
+                   blk_off && total_blocks > 0 && live && B > 0 && T > 0 && dpos0 && dpos1);
+    AMID_CHECK_ARG(((((unsigned long long)dpos0) | ((unsigned long long)dpos1) | ((unsigned long long)grad_rows)) & 15) == 0);
+    if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK, n_seg = (nch + 3) / 4;
+    PosSum ps;
+    ps.rows = grad_rows; ps.live = live; ps.B = B; ps.T = T; ps.dst[0] = dpos0; ps.dst[1] = dpos1;
+    ps.nblk = (T * D + 127) / 128;
+    float* partial = (float*)workspace;
+    const ReduceEntry* en = (const ReduceEntry*)entries_dev;
+#define AMID_TAIL_LAUNCH(VEC)                                                                                                       \
+    grad_tail_live_kernel<VEC><<<n_seg + total_blocks + 2 * ps.nblk, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial, n_seg, \
+                                                                                  en, blk_off, n_entries, total_blocks, ps);
     if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }
 #undef AMID_TAIL_LAUNCH
     AMID_LAUNCH_CHECK();

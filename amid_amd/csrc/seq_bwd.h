@@ -26,6 +26,10 @@ struct StripQkvBwdArgs {
     float* dx;
     float* ln_part;                     // [2 tpg][2][D]
     float ln_eps;
+    // layer 0's launch of the live-sequence train step (strip_qkv_bwd_kernel without the fused feed-forward): d x is the gradient of the
+    // encoder INPUT -- with emb_tmq set the embedding layer's own backward runs on the strip before it is stored (the input dropout's keep
+    // bits redrawn, the "== 0" mask, model_seq.py:361-366): what amid_embed_bwd_f32 did in a pass of its own over the stored rows
+    const unsigned char* emb_tmq; const StepState* emb_st; int emb_train; unsigned emb_spec; float emb_scale;
 };
 
 struct SeqBwdLayer {

@@ -51,8 +51,11 @@ __device__ __forceinline__ unsigned long long match_bits(unsigned d, bool valid,
 
 // BINS: LDS is sized for 1024 bins when both digits have at most 10 bits (every table below 2^20 rows: 12 KB in the scatter) -- small
 // enough to share a CU with a one-workgroup-per-CU kernel of the main stream (the fused forward holds 144 of the 160 KB).
-template <int BINS>
-__device__ __forceinline__ void os_count_block(const int blk, const int nblk, const int* __restrict__ keys, OsGeom g, int* __restrict__ state,
+// keys of the first pass as a function of the position: the list itself, or -- the one-launch step head, where the list is written by other
+// workgroups of the same launch -- straight from the batch's packed image (adam.hip PoolBatch)
+struct ArrayKeys { const int* __restrict__ p; __device__ __forceinline__ int operator()(int k) const { return p[k]; } };
+template <int BINS, class Keys>
+__device__ __forceinline__ void os_count_block(const int blk, const int nblk, const Keys keys, OsGeom g, int* __restrict__ state,
                                                                 int* __restrict__ counts0, int* __restrict__ stot0, int stot0_copy, int n_stot0,
                                                                 int* __restrict__ counts1, long long n_counts1, int* __restrict__ stot1,
                                                                 int n_stot1, int* __restrict__ hstatus) {
@@ -67,7 +70,7 @@ __device__ __forceinline__ void os_count_block(const int blk, const int nblk, co
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const int k = base + i * 64 + lane;
         const bool valid = k < g.n;
-        const unsigned d0 = valid ? (((unsigned)keys[k] >> g.shift) & mask0) : 0u;
+        const unsigned d0 = valid ? (((unsigned)keys(k) >> g.shift) & mask0) : 0u;
         const unsigned long long peers = match_bits(d0, valid, g.bits);
         if (valid && (__ffsll((long long)peers) - 1) == lane) atomicAdd(&hist0[d0], __popcll(peers));
     }
@@ -376,7 +379,7 @@ template <int BINS, int PHASE>
 __device__ __forceinline__ void sort_phase_ct(const SortPlan& sp, int blk) {
     // the riders' schedule, five phases: count 0, scatter 0, count 1, scatter 1, run heads
     if constexpr (PHASE == 1)
-        os_count_block<BINS>(blk, sp.nblk, sp.idx, sp.g0, sp.state, sp.counts0, sp.stot0, sp.stot0_copy, sp.n_zero_a, sp.counts1, sp.n_counts1, sp.stot1,
+        os_count_block<BINS>(blk, sp.nblk, ArrayKeys{sp.idx}, sp.g0, sp.state, sp.counts0, sp.stot0, sp.stot0_copy, sp.n_zero_a, sp.counts1, sp.n_counts1, sp.stot1,
                              sp.n_stot1, (int*)sp.hstatus);
     else if constexpr (PHASE == 2)
         os_scatter_block<false, BINS>(blk, sp.nblk, sp.idx, sp.rows, sp.keys0, sp.vals0, sp.g0, sp.counts0,

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(SORT_THREADS) void os_count_kernel(const int* __res
                                                                 int* __restrict__ counts0, int* __restrict__ stot0, int stot0_copy, int n_stot0,
                                                                 int* __restrict__ counts1, long long n_counts1, int* __restrict__ stot1,
                                                                 int n_stot1, int* __restrict__ hstatus) {
-    os_count_block<BINS>(blockIdx.x, gridDim.x, keys, g, state, counts0, stot0, stot0_copy, n_stot0, counts1, n_counts1, stot1, n_stot1, hstatus);
+    os_count_block<BINS>(blockIdx.x, gridDim.x, ArrayKeys{keys}, g, state, counts0, stot0, stot0_copy, n_stot0, counts1, n_counts1, stot1, n_stot1, hstatus);
 }
 template <bool COUNT_NEXT, int BINS>
 __global__ __launch_bounds__(SORT_THREADS) void os_scatter_kernel(const int* __restrict__ keys_in, const int* __restrict__ vals_in,

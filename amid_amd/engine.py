@@ -240,6 +240,20 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                          and not self._seq_backward(pl)             # (the fused backward is one launch: three of the riders' hosts are gone)
                          and (shp.n_idx + 2047) // 2048 <= 2 * shp.Tenc and self._sort_plan(pl) is not None)
         ent = self.input_pool(pl)
+        # the live-sequence step on an input pool in twelve launches (FUSED_TAIL): packing, catch-up and phase 1 of the sort of the COMPACT
+        # index list are one launch; the later phases ride in the backward strips and the weight gradients; no embedding-backward launch
+        pl.tail2 = bool(ent is not None and bump_step and sparse and defer_sort and with_live and self._tail2_ok(pl))
+        if pl.tail2:
+            pool, phase = ent
+            self._ensure_opt_state()
+            L.call("amid_step_head_f32", pool.data_ptr(), pool.stride(0), pool.shape[0], phase, pl.in_pack.data_ptr(), pl.in_words, shp.B, shp.T,
+                   shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.idx_c.data_ptr(), pl.row_c.data_ptr(), pl.live.data_ptr(), pl.err.data_ptr(),
+                   self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), self.D,
+                   self.step_state.data_ptr(), self._sort_plan_c(pl), s)
+            self.step += 1
+            pl.compact, pl.riding = True, True
+            self._sort_owed = False
+            return
         if ent is not None:
             pool, phase = ent
             if not bump_step:
@@ -355,6 +369,40 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             pl._sort_plan_buf = buf if rc == 0 else None
         return ctypes.addressof(pl._sort_plan_buf) if pl._sort_plan_buf is not None else None
 
+    def _sort_plan_c(self, pl: SasrecPlan):
+        """Host address of the sort plan over the plan's COMPACT list (idx_c, row_c), or None when the riders do not cover it."""
+        if not hasattr(pl, "_sort_plan_c_buf"):
+            L = lib()
+            buf = (ctypes.c_ubyte * L.value("amid_sort_plan_bytes"))()
+            rc = L._fn["amid_sort_plan_pack"](ctypes.addressof(buf), pl.idx_c.data_ptr(), pl.row_c.data_ptr(), pl.n_compact, self.n_rows,
+                                              pl.sort_ws.data_ptr(), pl.pos_sorted.data_ptr(), pl.uniq_ids.data_ptr(), pl.seg_off.data_ptr(),
+                                              pl.seg_of.data_ptr(), pl.n_uniq.data_ptr())
+            pl._sort_plan_c_buf = buf if rc == 0 else None
+        return ctypes.addressof(pl._sort_plan_c_buf) if pl._sort_plan_c_buf is not None else None
+
+    # The live-sequence train step on an input pool with its head and tail folded (round 5): amid_step_head_f32 (packing + catch-up + sort
+    # phase 1 over the compact list), the embedding backward on the last strip launch (amid_sas_strip_qkv_bwd_emb_f32), the sort's last
+    # phase in the weight-gradient launch, the position rows' gradients in the gradient tail (amid_grad_tail_live_f32) and the segment
+    # reduce's second phase in the optimizer launch (amid_optimizer_step_spans_f32): 12 launches instead of 15.  False: round 4's sequence
+    # (tests compare the two).
+    FUSED_TAIL = True
+
+    def _tail2_ok(self, pl: SasrecPlan) -> bool:
+        shp = pl.shape
+        # (only inside enqueue_train_step: the segment reduce's runs across chunks are finished by THIS step's optimizer launch, so the
+        # row gradients of enqueue_local_grads alone -- what a data-parallel exchange ships -- would be incomplete)
+        return bool(self.FUSED_TAIL and getattr(self, "_in_train_step", False) and self.SORT_RIDERS and pl.need_grad and self.D == 128 and self.compute == "f32" and not self.dr
+                    and not self.itc_bs and not self.inc_bs and not getattr(self, "comp", "") and getattr(self, "_tail_pack", None) is None
+                    and self.FUSED_HEAD and self.live_forward_ok(pl) and self._p3_bwd_for(pl) and self._wgrad_mode(self.D) == 3
+                    and not self._fold_catchup(pl) and self._sort_plan_c(pl) is not None
+                    and (pl.n_compact + 2047) // 2048 <= 12 * pl.splits)
+
+    def _tail2_table(self, pl: SasrecPlan):
+        """The gradient tail's reduce table without the position rows' partial sums (amid_grad_tail_live_f32 sums them from the rows)."""
+        if not hasattr(pl, "red_entries_t"):
+            pl.red_entries_t, pl.red_n_t, pl.red_max_t = pl._build_reduce_table(self, live=True, pos=False)
+        return pl.red_entries_t, pl.red_n_t, pl.red_blk_t
+
     COMPACT_LIVE = True
     COMPACT_MIN_IDX = 65536    # shorter index lists gain nothing from the compact list (the tail is bound by the dense partial sums,
                                # the row Adam by its dense half) and lose the early fork of the side-stream sort: cfg 2 keeps the full list
@@ -431,7 +479,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         L, s, shp, D = lib(), self.s, pl.shape, self.D
         B, T, NI = shp.B, shp.Tenc, shp.NI
         st = self.step_state.data_ptr()
-        compact = lf is not None and getattr(pl, "compact", False)
+        compact = lf is not None and getattr(pl, "compact", False) and not getattr(pl, "tail2", False)      # (tail2: the step head wrote the list)
         ic, rc = (pl.idx_c.data_ptr(), pl.row_c.data_ptr()) if compact else (None, None)
         if getattr(pl, "fold_catchup", False):
             pl.fold_catchup = False
@@ -464,6 +512,9 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         """Replay pending zero-gradient Adam steps of the rows this batch is about to gather (by position: no sort needed) -- as a
         launch of its own, or folded into the gather that follows (_fold_catchup)."""
         self._ensure_opt_state()
+        if getattr(pl, "tail2", False):           # the step head replayed them
+            pl.fold_catchup = False
+            return
         pl.fold_catchup = self._fold_catchup(pl)
         if pl.fold_catchup:
             return
@@ -848,7 +899,9 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             # a train step's index sort rides in these three launches (phases 2, 3, 4; phase 1 rode in the catch-up launch)
             riding = getattr(pl, "riding", False)
             sfx = "_sort" if riding else ""
-            ride = lambda ph: (self._sort_plan(pl), ph) if riding else ()      # noqa: E731
+            t2 = getattr(pl, "tail2", False)
+            plan_addr = (self._sort_plan_c(pl) if t2 else self._sort_plan(pl)) if riding else None
+            ride = lambda ph: (plan_addr, ph) if riding else ()      # noqa: E731
             L.call(f"amid_sas_strip_ffn_bwd{sfx}_f32", pl.dxbuf.data_ptr(), tm, h1, r1, lnw1, w1T1, w2T1, woT1, SASREC_LN_EPS, B, T, D, lv, 1, st, tr,
                    SASREC_P_DROP, pl.dpre2[1].data_ptr(), pl.dpre1[1].data_ptr(), pl.dr[1].data_ptr(), pl.d_o.data_ptr(), ln2p[1].data_ptr(),
                    *ride(2), bf, s)
@@ -859,10 +912,15 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                    SASREC_LN_EPS, B, T, D, lv, None, ln1p[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr, SASREC_P_DROP,
                    pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(), ln2p[0].data_ptr(), *ride(3), bf, s)
             attn_bwd(0)
-            L.call(f"amid_sas_strip_qkv_bwd{sfx}_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
-                   pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
-                   SASREC_LN_EPS, B, T, D, lv, dx_in, ln1p[0].data_ptr(), None, None, None, None, None, None, None, 0, None, 0, 0.0, None,
-                   None, None, None, None, *ride(4), bf, s)
+            if t2:      # ... with the embedding layer's backward applied on the strip (no amid_embed_bwd launch)
+                L.call("amid_sas_strip_qkv_bwd_emb_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
+                       pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
+                       SASREC_LN_EPS, B, T, D, lv, dx_in, ln1p[0].data_ptr(), pl.tmq.data_ptr(), st, tr, SASREC_P_DROP, plan_addr, 4, bf, s)
+            else:
+                L.call(f"amid_sas_strip_qkv_bwd{sfx}_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
+                       pl.x[0].data_ptr(), self._pp("sac{d}.attention_layernorms.0.weight"), self._wT(0, 0), self._wT(0, 1), self._wT(0, 2),
+                       SASREC_LN_EPS, B, T, D, lv, dx_in, ln1p[0].data_ptr(), None, None, None, None, None, None, None, 0, None, 0, 0.0, None,
+                       None, None, None, None, *ride(4), bf, s)
         else:
             rows, suf, rpt = ("_rows", pl.rt_suffix_v, pl.rpt_v) if live else ("", pl.rt_suffix, pl.rpt)
             ln1p, ln2p = (pl.ln1_part_v, pl.ln2_part_v) if live else (pl.ln1_part, pl.ln2_part)
@@ -887,6 +945,13 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                    pl.dpre2[l].data_ptr()]
             xx += [pl.qn[l].data_ptr(), pl.x[l].data_ptr(), pl.x[l].data_ptr(), pl.o[l].data_ptr(), pl.y[l].data_ptr(), pl.h[l].data_ptr()]
         # NOTE: pl.x[0] is the gathered-row buffer xg, still intact here (its gradient lives in dxg)
+        t2 = bool(getattr(pl, "tail2", False) and pl.strip and not seq)
+        if t2:      # the last phase of the step's index sort (run heads) rides in the weight gradients; the embedding backward is done
+            L.call("amid_sas_wgrad_rows_sort_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits,
+                   ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]), ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]),
+                   self._own_rows(pl), B, T, self._wgrad_mode(D), self._sort_plan_c(pl), s)
+            self._enqueue_grad_tail(pl, live, seq)
+            return
         L.call("amid_sas_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),
                ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]), self._own_rows(pl), B, T,
                self._wgrad_mode(D), s)
@@ -931,6 +996,13 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         blk = (pl.red_blk_s if seq else getattr(pl, "red_blk_v", None) if live else None) or pl.red_blk   # per-entry block ranges of the partial sums
         ent, n_ent, ent_max = ((pl.red_entries_s, pl.red_n_s, pl.red_max_s) if seq else (pl.red_entries_v, pl.red_n_v, pl.red_max_v) if live
                                else (pl.red_entries, pl.red_n, pl.red_max))
+        if getattr(pl, "tail2", False):
+            ent_t, n_ent_t, blk_t = self._tail2_table(pl)
+            fp = self.dense
+            L.call("amid_grad_tail_live_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_compact,
+                   self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), ent_t.data_ptr(), n_ent_t, blk_t[0].data_ptr(), blk_t[1],
+                   pl.live.data_ptr(), shp.B, shp.Tenc, fp.ptr("sac1.pos_emb.weight", fp.grad), fp.ptr("sac2.pos_emb.weight", fp.grad), s)
+            return
         pk = getattr(self, "_tail_pack", None)
         if pk is not None:       # graph A of the data-parallel step: the tail also packs this rank's exchange chunk (ids | rows | dense)
             from .dist import packed_rows
@@ -957,6 +1029,12 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         else:
             ids, rows, nu = sparse
             cap = ids.numel()
+        if sparse is None and getattr(pl, "tail2", False):      # the segment reduce's runs across chunks are finished (and applied) here
+            L.call("amid_optimizer_step_spans_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel,
+                   self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), ids.data_ptr(),
+                   nu.data_ptr(), cap, rows.data_ptr(), self.D, self.grad_scale, self.step_state.data_ptr(), pl.seg_off.data_ptr(),
+                   pl.seg_of.data_ptr(), pl.n_compact, pl.seg_ws.data_ptr(), s)
+            return
         L.call("amid_optimizer_step_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel,
                self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), ids.data_ptr(),
                nu.data_ptr(), cap, rows.data_ptr(), self.D, self.grad_scale, self.step_state.data_ptr(), s)
@@ -967,11 +1045,15 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
 
     def enqueue_train_step(self, pl: SasrecPlan) -> None:
         """Whole step t on the current stream: t += 1; unique; catch-up; forward; loss; backward; Adam."""
-        self.enqueue_prepare(pl, sparse=True, bump_step=True, defer_sort=True)
-        self.enqueue_catchup(pl)
-        self._fork_sort(pl)
-        self._enqueue_fwd_bwd(pl)
-        self.enqueue_optimizer(pl)
+        self._in_train_step = True
+        try:
+            self.enqueue_prepare(pl, sparse=True, bump_step=True, defer_sort=True)
+            self.enqueue_catchup(pl)
+            self._fork_sort(pl)
+            self._enqueue_fwd_bwd(pl)
+            self.enqueue_optimizer(pl)
+        finally:
+            self._in_train_step = False
 
     # ------------------------------------------------------------------ data parallel (one process per GPU)
     def enqueue_local_grads(self, pl: SasrecPlan) -> None:

@@ -123,6 +123,7 @@ class Bert4recEngine(SasrecEngine):
     SHORT_TILE_BUILDS = True
     STRIP_KERNELS = True         # the block's GEMM chains on csrc/bert_strip.hip (BertPlan.strip); bert.hip's row-tile kernels beyond 2 GiB
     SORT_RIDERS = False          # (the riders' host launches are the SASRec strip backward's)
+    FUSED_TAIL = False           # (the one-launch step head and the folded tail are the SASRec step's)
 
     def live_forward_ok(self, pl) -> bool:
         """Whether this engine's train step on `pl` encodes the live sequences only (engine._enqueue_fwd_bwd): the plain head, no

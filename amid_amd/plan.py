@@ -300,7 +300,7 @@ class SasrecPlan:
 
     LIVE_ROWS_BWD = True       # BertPlan: False (its backward kernels take no row_domain hint)
 
-    def _build_reduce_table(self, eng: "SasrecEngine", live: bool = False, seq: bool = False):
+    def _build_reduce_table(self, eng: "SasrecEngine", live: bool = False, seq: bool = False, pos: bool = True):
         L = lib()
         D, hid, B = eng.D, eng.hid, self.shape.B
         fp, G = eng.dense, eng.dense.grad
@@ -309,7 +309,9 @@ class SasrecPlan:
         def add(src_t: torch.Tensor, src_off: int, dst_ptr: int, stride: int, n_part: int, count: int):
             ent.append((src_t.data_ptr() + 4 * src_off, dst_ptr, stride, n_part, count))
 
-        if seq:
+        if not pos:         # (the live-sequence step's tail sums the position rows' gradients from the rows: amid_grad_tail_live_f32)
+            self._model_reduce_entries(eng, add, pos=False)      # (strip plans: the live tiles share the slots of the full tiling)
+        elif seq:
             self._model_reduce_entries(eng, add, seq=True)
         elif live:
             self._model_reduce_entries(eng, add, live=True)
@@ -332,7 +334,7 @@ class SasrecPlan:
         # dependent loads: dispatch them first, so that they do not form the tail of the launch
         ent.sort(key=lambda e: -e[3])
         # algorithmic HBM bytes of the partial-sum reduce (every partial read once, every sum written once): bench.py prices the launch
-        sfx = "_s" if seq else "_v" if live else ""
+        sfx = "_t" if not pos else "_s" if seq else "_v" if live else ""
         setattr(self, "red_bytes" + sfx, sum(4 * (n + 1) * c for *_, n, c in ent))
         esz = L.value("amid_reduce_entry_bytes")
         host = (ctypes.c_ubyte * (esz * len(ent)))()
@@ -348,7 +350,7 @@ class SasrecPlan:
         setattr(self, "red_blk" + sfx, (blk, off[-1]))
         return torch.frombuffer(bytearray(host), dtype=torch.uint8).to(eng.device), len(ent), max(c for *_, c in ent)
 
-    def _model_reduce_entries(self, eng: "SasrecEngine", add, live: bool = False, seq: bool = False) -> None:
+    def _model_reduce_entries(self, eng: "SasrecEngine", add, live: bool = False, seq: bool = False, pos: bool = True) -> None:
         D, B = eng.D, self.shape.B
         fp, G = eng.dense, eng.dense.grad
         S = self.splits
@@ -382,4 +384,5 @@ class SasrecPlan:
             add(self.last_part, g * B * 2 * D + D, fp.ptr(f"{pre}.last_layernorm.bias", G), 2 * D, B, D)
         T = self.shape.Tenc
         for g in (0, 1):
-            add(self.dpos_part, g * T * D, fp.ptr(f"sac{g + 1}.pos_emb.weight", G), 2 * T * D, self.pos_splits, T * D)
+            if pos:
+                add(self.dpos_part, g * T * D, fp.ptr(f"sac{g + 1}.pos_emb.weight", G), 2 * T * D, self.pos_splits, T * D)

@@ -45,8 +45,15 @@ N_ROWS = 2 * ITEM_LENGTH          # train_sr.py:456
 PAD_ID = ITEM_LENGTH + 1          # train_sr.py:451
 MAX_REAL_ID = 42441               # largest id in cloth_sport_train75
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
-# the weight gradients' products (engine.SasrecEngine.WGRAD_SPLIT): six bf16 piece pairs per fp32 product by default
-WGRAD_KIND = {"6": "mfma16x6", "9": "mfma16x9"}.get(os.environ.get("AMID_WGRAD_SPLIT", "6"), "mfma")
+# how the weight gradients' products run, taken from the ENGINE once a step has run (wgrad_kind_of below): six bf16 piece pairs per fp32
+# product by default, operands rounded to bf16 with --dtype bf16, fp32 matrix instructions where the engine says so
+WGRAD_KIND = "mfma16x6"
+
+
+def wgrad_kind_of(eng, model: str) -> str:
+    if model == "bert4rec":
+        return {"9": "mfma16x9", "6": "mfma16x6"}.get(eng.WGRAD_SPLIT, "mfma")
+    return {1: "mfma16", 2: "mfma16x9", 3: "mfma16x6"}.get(eng._wgrad_mode(eng.D), "mfma")
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBPS = 8000.0
 
@@ -239,6 +246,12 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_lazy_adam_catchup_live_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * 12 + U * (D * 4 * 6 + 8)),
         "amid_lazy_adam_catchup_positions_f32": ("hbm", n_idx * 4 + U * (D * 4 * 6 + 8)),
         "amid_optimizer_step_f32": ("hbm", U * (D * 4 * 7 + 8)),
+        # round 5, the folded step: packing + catch-up (+ sort phase 1) over the compact list in one launch; the last strip launch with the
+        # embedding backward on the strip; the weight gradients carrying the sort's last phase; the optimizer finishing the segment reduce
+        "amid_step_head_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * 28 + (2 * Bw * T + 2 * Bw * (1 + NEG)) * 20 + U * (D * 4 * 6 + 8)),
+        "amid_sas_strip_qkv_bwd_emb_f32": ("mfma", 3 * gl),
+        "amid_sas_wgrad_rows_sort_f32": (WGRAD_KIND, 6 * gemm),
+        "amid_optimizer_step_spans_f32": ("hbm", U * (D * 4 * 7 + 8)),
     }
 
 
@@ -257,7 +270,9 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_strip_oproj_ffn_fwd_f32#1": "strip_oproj_ffn_fwd_kernelILi128ELb0", "amid_sas_strip_ffn_bwd_f32": "strip_ffn_bwd_kernel",
     "amid_sas_strip_qkv_bwd_f32#0": "strip_qkv_bwd_kernelILi128ELb1", "amid_sas_strip_qkv_bwd_f32#1": "strip_qkv_bwd_kernelILi128ELb0",
     "amid_attn_fwd_live_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_live_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_live_f32": "embed_fwd_kernel", "amid_embed_fwd_live_compact_f32": "embed_fwd_kernel", "amid_embed_fwd_replay_f32": "embed_fwd_kernel",
-    "amid_embgrad_segreduce_f32": "segreduce_chunks_kernel",
+    "amid_embgrad_segreduce_f32": "segreduce_chunks_kernel", "amid_sas_wgrad_rows_sort_f32": "sas_wgrad_split_kernel",
+    "amid_sas_strip_qkv_bwd_emb_f32": "strip_qkv_bwd_kernelILi128ELb0", "amid_step_head_f32": "step_head_kernel",
+    "amid_grad_tail_live_f32": "grad_tail_live_kernel", "amid_optimizer_step_spans_f32": "optimizer_step_spans_kernel",
     "amid_bert_strip_qkv_fwd_pro_f32": "bert_strip_qkv_fwd_kernel", "amid_bert_strip_oproj_ffn_fwd_f32#0": "bert_strip_oproj_ffn_fwd_kernelILb1",
     "amid_bert_strip_oproj_ffn_fwd_f32#1": "bert_strip_oproj_ffn_fwd_kernelILb0", "amid_bert_strip_ffn_bwd_f32": "bert_strip_ffn_bwd_kernel",
     "amid_bert_strip_qkv_bwd_f32#0": "bert_strip_qkv_bwd_kernelILb1", "amid_bert_strip_qkv_bwd_f32#1": "bert_strip_qkv_bwd_kernelILb0",
@@ -427,6 +442,8 @@ def main():
                     help="consecutive train steps captured into one replayed hipGraph (single GPU, pool input; default 4 = what the "
                          "CLI's train loop replays, amid_amd/train_sr.py STEPS_PER_GRAPH)")
     ap.add_argument("--no-stress", action="store_true", help="skip the cfg5 gather / scatter stress appended to the headline line")
+    ap.add_argument("--no-fused-tail", action="store_true",
+                    help="A/B: round 4's fifteen-launch step (SasrecEngine.FUSED_TAIL = False) instead of the folded twelve-launch one")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
                     help="cfg2 = the headline configuration (default); cfg5-* = synthetic gather / scatter stress (SURVEY.md 8(d))")
     ap.add_argument("--dense-exchange", default=os.environ.get("AMID_DENSE_EXCHANGE", "gather"), choices=("gather", "allreduce"),
@@ -466,6 +483,8 @@ def main():
         from amid_amd.engine_bert import Bert4recEngine
         eng = Bert4recEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234)
     else:
+        if args.no_fused_tail:
+            SasrecEngine.FUSED_TAIL = False
         eng = SasrecEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234, compute=args.dtype)
     init_params(eng, seed=0)                  # identical replicas on every rank
     pl = eng.plan(Bw, T, 1 + NEG, need_grad=True)
@@ -611,11 +630,15 @@ def main():
                 durs[name + "#0"], durs[name + "#1"] = v[0::2], v[1::2]
             elif v is not None:
                 durs[name] = v
+        globals()["WGRAD_KIND"] = wgrad_kind_of(eng, args.model)
         work = algorithmic_work(Bw, int(pl.n_uniq.item()), T)
         red_bytes = (getattr(pl, "red_bytes_s", None) if eng._seq_backward(pl) else None) or getattr(pl, "red_bytes_v", None) or getattr(pl, "red_bytes", None)
         if red_bytes:         # K3 (the segment reduce of the row gradients) + the reduce of every dense partial sum, one launch
             k3 = "amid_embgrad_segreduce_live" if getattr(pl, "compact", False) else "amid_embgrad_segreduce_f32"
             work["amid_grad_tail_f32"] = ("hbm", work[k3][1] + red_bytes)
+            if getattr(pl, "tail2", False):      # the folded step's tail: compact list, the position rows summed from the rows, no second phase
+                work["amid_grad_tail_live_f32"] = ("hbm", work["amid_embgrad_segreduce_live"][1] + getattr(pl, "red_bytes_t", red_bytes)
+                                                   + Bw * T * D * 4 + 2 * T * D * 4)
         total_ms = 0.0
         for name, v in durs.items():
             name = name[:-4] if name.endswith(("_rt3", "_rt4", "_rt5")) else name        # the 48- / 64- / 80-row builds of the row-tile kernels

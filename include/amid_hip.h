@@ -779,6 +779,45 @@ int amid_bert_ffn1_bwd_f32_rt4(const float* dpre, const float* dx2, const float*
 int amid_bert_qkv_bwd_f32_rt4(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x, const float* const* ln_a,
                           const float* const* wT3x2, int M, int rows_per_tile, float* dx, float* ln_part, void* stream);
 
+/* ---- round 5: the live-sequence train step on an input pool in twelve launches (was fifteen) ------------------------------------------
+ * replaces, inside the loop body of train() (train_sr.py:190-217): the batch marshal (:191-200) + the catch-up of the lazy dense-equivalent
+ * Adam (torch.optim.Adam over the whole table, :480) as ONE launch; the embedding layer's backward (autograd of model_seq.py:361-366) on
+ * the last strip launch; the second phase of the embedding-gradient reduction (autograd of :27-29) inside the optimizer launch.
+ *
+ * amid_step_head_f32: the batch (step_done + phase) % n_pool of the pool (rows = SasrecEngine.pack_batch images) mirrored into in_pack, the
+ * full index list idx_all [2 B T + B (1 + n_neg)], the live list (amid_live_list_i32), the COMPACT list idx_c / row_c [B T + B (1 + n_neg)]
+ * (every sample's own-domain sequence then the items; row_c = the entry's row in the full layout), the lazy-Adam catch-up of the compact
+ * list's rows, phase 1 of sort_plan (a plan packed on (idx_c, row_c); NULL: no rider) and the step counter's bump.  The caller's next
+ * launch on the stream must be one of amid_embed_fwd*_f32 (it re-joins the step state's two counters).
+ * replaces: amid_pack_indices_pool_live + amid_lazy_adam_catchup_positions_sort_f32. */
+int amid_step_head_f32(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack, int in_words, int B, int T,
+                       int n_neg, long long n_rows, int* idx_all, int* idx_c, int* row_c, int* live, int* err_flag, float* table, float* m,
+                       float* v, int* last, int D, void* step_state, const void* sort_plan, void* stream);
+/* amid_sas_strip_qkv_bwd(_sort)_f32 without the fused feed-forward backward, with the embedding layer's element-wise backward applied to dx
+ * before it is stored: the input dropout's keep bits (site SITE_EMB, p = emb_p_drop) redrawn from step_state and the "== 0" bits of
+ * emb_tmq (model_seq.py:361-366) -- what amid_embed_bwd_f32 does in a pass of its own.  sort_plan NULL or a plan whose phase 4 rides. */
+int amid_sas_strip_qkv_bwd_emb_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x, const float* const* ln_w,
+                                   const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int B, int T, int D,
+                                   const int* live, float* dx, float* ln_part, const unsigned char* emb_tmq, const void* step_state, int train,
+                                   float emb_p_drop, const void* sort_plan, int sort_phase, int mma_bf16, void* stream);
+/* amid_sas_wgrad_rows_f32 (mma_bf16 = 3, D = 128) carrying the LAST phase (5: run heads) of a sort plan as extra workgroups */
+int amid_sas_wgrad_rows_sort_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
+                                 float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, const void* sort_plan,
+                                 void* stream);
+/* amid_grad_tail_f32's first launch over a compact sorted list (pos_sorted = rows of grad_rows) + the position rows' gradients
+ * dpos0 / dpos1 [T, D] = the sum over the live sequences of a domain (live: amid_live_list_i32) of their rows of grad_rows, in list order.
+ * Phase B of the segment reduce is left to amid_optimizer_step_spans_f32. */
+int amid_grad_tail_live_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                            void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off, int total_blocks,
+                            const int* live, int B, int T, float* dpos0, float* dpos1, void* stream);
+/* amid_optimizer_step_f32 behind amid_grad_tail_live_f32: the runs of the sorted list that cross 64-entry chunks are summed from the tail's
+ * partial rows (workspace) by extra workgroups -- the additions of amid_embgrad_segreduce_f32's second launch in the same order --, written
+ * to uniq_grad and applied on the spot.  D = 64 / 128 / 256. */
+int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const float* g, long long n, float* table, float* m_tab, float* v_tab, int* last,
+                                  const int* uniq_ids, const int* n_uniq, int n_uniq_max, float* uniq_grad, int D, float grad_scale,
+                                  const void* step_state, const int* seg_off, const int* seg_of, int n_sorted, const void* workspace,
+                                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

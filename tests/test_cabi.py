@@ -33,7 +33,7 @@ def test_library_loads_and_answers_host_only_queries():
     assert L.value("amid_version") >= 100
     assert L.value("amid_rows_per_tile", 12800) == 100          # 25 600 rows over 256 CUs
     assert L.value("amid_rows_per_tile", 400) == 16
-    assert L.value("amid_step_state_bytes") == 56          # seed, step, 4 doubles, ticket + pad
+    assert L.value("amid_step_state_bytes") == 64          # seed, step, 4 doubles, ticket + pad, step_done
     assert L.value("amid_sort_unique_workspace_bytes", 26112) > 4 * 26112 * 4
     assert L.raw("amid_error_string")(-2).decode().startswith("amid: shape not supported")
 
