@@ -221,20 +221,32 @@ __global__ __launch_bounds__(256) void step_head_kernel(const StepHeadArgs a, co
     const int w0 = bid * (blockDim.x >> 6) + (threadIdx.x >> 6), n_w = nbk * (blockDim.x >> 6);
     if (threadIdx.x == 0) any_lag = 0;
     __syncthreads();
+    // the wave's FIRST position (its only one unless the list is longer than the grid: a wave per position) is resolved once -- image ->
+    // id -> stamp is a chain of three dependent loads -- and kept for the replay; lanes 1 .. 63 look at the wave's further positions
     bool mine = false;
+    long long r0 = 0;
+    int l0 = 0;
     for (long long i = w0 + (long long)lane * n_w; i < n_c; i += 64LL * n_w) {
         int row;
-        const long long l = a.last[pb.at((int)i, row)];
+        const int id = pb.at((int)i, row);
+        const int l = a.last[id];
+        if (i == w0) { r0 = id; l0 = l; }
         if (l > 0 && l < t - 1) mine = true;
     }
+    r0 = __builtin_amdgcn_readfirstlane((int)r0);
+    l0 = __builtin_amdgcn_readfirstlane(l0);
     if (mine) any_lag = 1;
     __syncthreads();
     if (!any_lag) return;
     fill_coef_table(tab, st);
     for (int i = w0; i < n_c; i += n_w) {
-        int row;
-        const long long r = pb.at(i, row);
-        const int l = a.last[r];
+        long long r = r0;
+        int l = l0;
+        if (i != w0) {
+            int row;
+            r = pb.at(i, row);
+            l = a.last[r];
+        }
         if (!(l > 0 && l < t - 1)) continue;
         int won = 0;
         if (lane == 0) won = (atomicCAS(&a.last[r], l, (int)(t - 1)) == l) ? 1 : 0;     // claim the row for this wave

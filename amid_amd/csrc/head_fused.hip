@@ -38,6 +38,9 @@ struct HeadArgs {
     const float* tr_src[32]; float* tr_dst[32]; int n_tr;   // square D x D transposes done by the extra blocks
     int B, T, NI, D, hid;
     float eps;
+    float* hidg;               // optional [B][amid_scorer_vec_floats]: instead of the per-sample weight-gradient partials sc_part (32 KB a sample)
+                               // only the sample's hidden gradients leave the workgroup -- da [2][hid], dc [NI][hid], dW2's [hid], db2's --
+                               // and the gradient tail forms dW1 = sum_b da (x) u + dc (x) items itself (amid_grad_tail_live_f32)
     int own_only;              // fused train step over the live sequences: of row b only the sequence of its OWN domain (domain[b]) was
                                // encoded; the other domain's user vector reads as 0, gets no gradient and its rows are not touched
 };
@@ -629,7 +632,12 @@ __device__ __forceinline__ float* scorer_bwd_part(const HeadArgs& a, const HeadL
             float* dst = a.ditems + ((long long)b * NI + n0 + n) * D + e;
             *dst = ACC ? *dst + acc : acc;
         }
+        if (a.hidg != nullptr) {                   // (single chunk: the launcher checks NI <= chunk) dc of every item: the tail multiplies
+            float* hg = a.hidg + (long long)b * (((3 + NI) * hid + 1 + 3) & ~3) + 2 * hid;
+            for (int nj = tg.tid; nj < nn * hid; nj += tg.n) hg[nj] = s.dc[(nj / hid) * (hid + 1) + (nj % hid)];
+        }
         // dW1[j][D+e] (+)= sum_n dc[n][j] item[n][e]
+        if (a.hidg == nullptr)
         for (int je = tg.tid; je < hid * D; je += tg.n) {
             const int j = je / D, e = je - j * D;
             float acc = 0.f;
@@ -648,6 +656,13 @@ __device__ __forceinline__ float* scorer_bwd_part(const HeadArgs& a, const HeadL
         const float* wp = s.w1t + e * (hid + 1);
         for (int j = 0; j < hid; ++j) acc = fmaf(s.da[d * hid + j], wp[j], acc);
         du_s[de] = acc;
+    }
+    if (a.hidg != nullptr) {
+        float* hg = a.hidg + (long long)b * (((3 + NI) * hid + 1 + 3) & ~3);
+        for (int j = tg.tid; j < 2 * hid; j += tg.n) hg[j] = s.da[j];
+        for (int j = tg.tid; j < hid + 1; j += tg.n) hg[(2 + NI) * hid + j] = s.dw2[j];
+        __syncthreads();
+        return du_s;
     }
     for (int je = tg.tid; je < hid * D; je += tg.n) {
         const int j = je / D, e = je - j * D;
@@ -895,12 +910,14 @@ static int head_fwd_bwd(int own_only, const float* x, const float* const* ln_w, 
                                      const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id,
                                      int B, int T, int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1, float* dp2,
                                      float* loss_part, float* dx, float* ditems, float* ln_part, float* sc_part,
-                                     const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream) {
+                                     const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream, float* hidg = nullptr) {
     HeadArgs a = {};
     if (int e = head_fill(a, x, ln_w, ln_b, items, w1, b1, w2, b2, B, T, NI, D, hid, eps)) return e;
     a.own_only = own_only;
-    AMID_CHECK_ARG(labels && domain_id && u && p1 && p2 && dp1 && dp2 && loss_part && dx && ditems && sc_part && (!ln_w || ln_part) &&
+    a.hidg = hidg;
+    AMID_CHECK_ARG(labels && domain_id && u && p1 && p2 && dp1 && dp2 && loss_part && dx && ditems && (sc_part || hidg) && (!ln_w || ln_part) &&
                    n_tr >= 0 && n_tr <= 32);
+    AMID_CHECK_ARG(hidg == nullptr || NI <= 64);
     a.labels = labels; a.domain = domain_id; a.u = u; a.p1 = p1; a.p2 = p2; a.dp1 = dp1; a.dp2 = dp2; a.loss_part = loss_part;
     a.dx = dx; a.ditems = ditems; a.ln_part = ln_part; a.sc_part = sc_part; a.n_tr = n_tr;
     for (int i = 0; i < n_tr; ++i) { AMID_CHECK_ARG(tr_src && tr_dst && tr_src[i] && tr_dst[i]); a.tr_src[i] = tr_src[i]; a.tr_dst[i] = tr_dst[i]; }
@@ -932,6 +949,20 @@ extern "C" int amid_head_fwd_bwd_own_f32(const float* x, const float* const* ln_
                                          const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream) {
     return head_fwd_bwd(1, x, ln_w, ln_b, items, w1, b1, w2, b2, labels, domain_id, B, T, NI, D, hid, eps, u, p1, p2, dp1, dp2, loss_part, dx,
                         ditems, ln_part, sc_part, tr_src, tr_dst, n_tr, stream);
+}
+
+// amid_head_fwd_bwd_own_f32 that hands the scorer's weight gradients on as per-sample HIDDEN gradients (hidg [B][amid_scorer_vec_floats(NI, hid)]:
+// da [2][hid] | dc [NI][hid] | dW2's [hid] | db2's) instead of per-sample partials of every weight (sc_part: 32 KB a sample, 8.5 MB a step
+// written here and read back by the gradient tail): amid_grad_tail_live_f32 forms dW1 = sum_b da_b (x) u_b + dc_b (x) items_b itself.  NI <= 64.
+extern "C" long long amid_scorer_vec_floats(int NI, int hid) { return ((long long)(3 + NI) * hid + 1 + 3) & ~3LL; }
+extern "C" int amid_head_fwd_bwd_own_vec_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
+                                             const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id,
+                                             int B, int T, int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1,
+                                             float* dp2, float* loss_part, float* dx, float* ditems, float* ln_part, float* hidg,
+                                             const float* const* tr_src, float* const* tr_dst, int n_tr, void* stream) {
+    AMID_CHECK_ARG(hidg != nullptr);
+    return head_fwd_bwd(1, x, ln_w, ln_b, items, w1, b1, w2, b2, labels, domain_id, B, T, NI, D, hid, eps, u, p1, p2, dp1, dp2, loss_part, dx,
+                        ditems, ln_part, nullptr, tr_src, tr_dst, n_tr, stream, hidg);
 }
 
 // Up to three scorers forward + loss + backward in ONE launch on given user vectors u [2, B, D] (the isItC / isDR train step, see

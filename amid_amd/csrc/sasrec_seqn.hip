@@ -435,6 +435,9 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwd
         g = (int)blockIdx.x >= sg.B ? 1 : 0;
         b = (int)blockIdx.x - g * sg.B;
     }
+#ifdef AMID_EXP_SETPRIO           // (diagnostic builds: static priority for the second-dispatched half, MI355X_MICROARCH.md "Two waves per SIMD" item 4)
+    if (w >= NW / 2) __builtin_amdgcn_s_setprio(AMID_EXP_SETPRIO);
+#endif
     using Ring = SeqRing3<D, NW>;
     Ring ring(smem);
     auto w16 = [&](int layer, int which) { return a.w16 + ((size_t)((layer * 2 + g) * 6 + which)) * 3 * D * D; };     // q, k, v, o, c1, c2
@@ -486,7 +489,11 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwd
         SEQN_STAMP(2);
         {   // k = x Wk^T + bk
             part_cols<NCT>(bias, P.b_in[g] + D, c0);
+#ifdef AMID_EXP_NO_QN_Y          // (diagnostic builds: what the launch would gain if qn / y were not stored -- the weight gradients read them)
+            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 2), c0, [&](int ct, int j) { (void)ct; (void)j; });
+#else
             seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 2), c0, [&](int ct, int j) { part_spread<NCT>(gqn, off_own, Qno, ct, j, 1); });
+#endif
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ko.v[c] = acc[c] + bias.v[c];
         }
@@ -614,7 +621,9 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwd
             SEQN_STAMP(15);
             part_cols<NCT>(bias, P.b2[g], c0);
             seqn_product_xp<D, NCT>(acc, xps, ring, w16(last ? l : l + 1, 1), c0, [&](int ct, int j) {
+#ifndef AMID_EXP_NO_QN_Y
                 part_spread<NCT>(gy, off_own, Yo, ct, j, 1);
+#endif
                 part_spread<NCT>(gh, off_own, Ho, ct, j, 3);
             });
 #pragma unroll

@@ -20,6 +20,7 @@
 #include "sort_phases.h"
 #include "attention_mfma.h"
 #include "seq_bwd.h"
+#include "scorer_sum.h"
 #include <type_traits>
 
 namespace amid {
@@ -352,10 +353,16 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const Stri
 // FFN = true: the layer below's feed-forward / out-projection backward continues on d x in registers (d x is then never stored)
 // RIDER: as strip_ffn_bwd_kernel (with FFN: phase 3, pass 1's counts; without: phase 4, the scatter of pass 1)
 template <int D, bool FFN, int RIDER, int BF = 0>
-__global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const StripQkvBwdArgs a, const StripFfnBwdArgs f, const StripGeom sg,
-                                                                      const SortRider rd) {
+__global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const StripQkvBwdArgs a, const StripFfnBwdArgs f, const ScorerSum ss,
+                                                                      const StripGeom sg, const SortRider rd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
+    if constexpr (RIDER != 0 && FFN) {
+        // riders BEHIND the tiles (the last ss.nblk workgroups: they fill the CUs the dead tiles leave at once; in front they would take CUs
+        // from live tiles): the scorer's weight gradients from the head's per-sample hidden gradients (scorer_sum.h)
+        const int first = (int)gridDim.x - ss.nblk;
+        if (bid >= first) { scorer_sum_block(ss, bid - first, (scorer_lds_f4*)smem); return; }
+    }
     if constexpr (RIDER != 0) {
         if (bid < rd.plan.nblk) { sort_phase_ct<1024, RIDER>(rd.plan, bid); return; }
         bid -= rd.plan.nblk;
@@ -501,6 +508,15 @@ static int make_rider(SortRider& rd, const void* sort_plan, int sort_phase) {
 }
 
 // a strip launch with a sort rider: rd.plan.nblk extra workgroups in front of the tiles'
+// (extra: further rider workgroups behind the sort's -- the scorer sums of strip_qkv_bwd_kernel)
+template <auto KERNEL, int DVAL, class... Args>
+static int launch_strip_rider_x(const StripGeom& sg, const SortRider& rd, int extra, void* stream, const Args&... args) {
+    static unsigned long long attr_done = 0;
+    if (int rc = lds_attr_once((const void*)KERNEL, strip_lds_bytes<DVAL>(), attr_done)) return rc;
+    KERNEL<<<2 * sg.tpg + rider_blocks_host(rd) + extra, STRIP_THREADS, strip_lds_bytes<DVAL>(), (hipStream_t)stream>>>(args..., sg, rd);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? AMID_OK : (int)e;
+}
 template <auto KERNEL, int DVAL, class... Args>
 static int launch_strip_rider(const StripGeom& sg, const SortRider& rd, void* stream, const Args&... args) {
     static unsigned long long attr_done = 0;
@@ -628,7 +644,7 @@ static int strip_qkv_bwd(const float* dq, const float* dk, const float* dv, cons
                          const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
                          const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
                          float* fd_o, float* fln_part, const void* sort_plan, int sort_phase, int mma_bf16, void* stream,
-                         const unsigned char* emb_tmq = nullptr, float emb_p_drop = 0.f) {
+                         const unsigned char* emb_tmq = nullptr, float emb_p_drop = 0.f, const ScorerSum* scorer = nullptr) {
     AMID_CHECK_ARG(dq && dk && dv && dr && x && ln_w && wqT && wkT && wvT && ln_part);
     if (mma_bf16 && D != 128) return AMID_ERR_UNSUPPORTED;
     const bool ffn = fh != nullptr;
@@ -650,22 +666,27 @@ static int strip_qkv_bwd(const float* dq, const float* dk, const float* dv, cons
     if (int e = make_rider(rd, sort_plan, sort_phase)) return e;
     if (rd.phase != 0 && rd.phase != (ffn ? 3 : 4)) return AMID_ERR_UNSUPPORTED;      // phase 3 with the fused feed-forward backward, 4 without
     const bool ride = rd.phase != 0;
-    if (D == 128 && mma_bf16 == 3 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3, 3>, 128>(sg, rd, stream, a, f)
-                                                      : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0, 3>, 128>(sg, rd, stream, a, f);
-    if (D == 128 && mma_bf16 == 3) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4, 3>, 128>(sg, rd, stream, a, f)
-                                               : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0, 3>, 128>(sg, rd, stream, a, f);
-    if (D == 128 && mma_bf16 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3, 1>, 128>(sg, rd, stream, a, f)
-                                                 : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0, 1>, 128>(sg, rd, stream, a, f);
-    if (D == 128 && mma_bf16) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4, 1>, 128>(sg, rd, stream, a, f)
-                                          : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0, 1>, 128>(sg, rd, stream, a, f);
-    if (D == 128 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3>, 128>(sg, rd, stream, a, f)
-                                     : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0>, 128>(sg, rd, stream, a, f);
-    if (D == 128) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4>, 128>(sg, rd, stream, a, f)
-                              : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0>, 128>(sg, rd, stream, a, f);
-    if (D == 64 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<64, true, 3>, 64>(sg, rd, stream, a, f)
-                                    : launch_strip_rider<strip_qkv_bwd_kernel<64, true, 0>, 64>(sg, rd, stream, a, f);
-    if (D == 64) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<64, false, 4>, 64>(sg, rd, stream, a, f)
-                             : launch_strip_rider<strip_qkv_bwd_kernel<64, false, 0>, 64>(sg, rd, stream, a, f);
+    ScorerSum ss = {};
+    if (scorer != nullptr) {
+        if (!(ride && ffn && D == 128 && mma_bf16 == 3)) return AMID_ERR_UNSUPPORTED;       // the riders' host: the middle launch on bf16 pieces
+        ss = *scorer;
+    }
+    if (D == 128 && mma_bf16 == 3 && ffn) return ride ? launch_strip_rider_x<strip_qkv_bwd_kernel<128, true, 3, 3>, 128>(sg, rd, ss.nblk, stream, a, f, ss)
+                                                      : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0, 3>, 128>(sg, rd, stream, a, f, ss);
+    if (D == 128 && mma_bf16 == 3) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4, 3>, 128>(sg, rd, stream, a, f, ss)
+                                               : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0, 3>, 128>(sg, rd, stream, a, f, ss);
+    if (D == 128 && mma_bf16 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3, 1>, 128>(sg, rd, stream, a, f, ss)
+                                                 : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0, 1>, 128>(sg, rd, stream, a, f, ss);
+    if (D == 128 && mma_bf16) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4, 1>, 128>(sg, rd, stream, a, f, ss)
+                                          : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0, 1>, 128>(sg, rd, stream, a, f, ss);
+    if (D == 128 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3>, 128>(sg, rd, stream, a, f, ss)
+                                     : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0>, 128>(sg, rd, stream, a, f, ss);
+    if (D == 128) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4>, 128>(sg, rd, stream, a, f, ss)
+                              : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0>, 128>(sg, rd, stream, a, f, ss);
+    if (D == 64 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<64, true, 3>, 64>(sg, rd, stream, a, f, ss)
+                                    : launch_strip_rider<strip_qkv_bwd_kernel<64, true, 0>, 64>(sg, rd, stream, a, f, ss);
+    if (D == 64) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<64, false, 4>, 64>(sg, rd, stream, a, f, ss)
+                             : launch_strip_rider<strip_qkv_bwd_kernel<64, false, 0>, 64>(sg, rd, stream, a, f, ss);
     return AMID_ERR_UNSUPPORTED;
 }
 
@@ -692,6 +713,27 @@ extern "C" int amid_sas_strip_qkv_bwd_sort_f32(const float* dq, const float* dk,
     AMID_CHECK_ARG(sort_plan != nullptr);
     return strip_qkv_bwd(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, B, T, D, live, dx, ln_part, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, flayer,
                          step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, sort_plan, sort_phase, mma_bf16, stream);
+}
+
+// amid_sas_strip_qkv_bwd_sort_f32 (with the fused feed-forward backward: phase 3 of the sort plan) carrying, as further extra workgroups,
+// the scorer's weight gradients summed over the batch from the per-sample hidden gradients of amid_head_fwd_bwd_own_vec_f32 (hidg [B]
+// [amid_scorer_vec_floats(NI, hid)]; u [2, B, D]; items [B, NI, D]): dW1 [hid, 2 D], db1 [hid], dW2 [hid], db2 [1].  The launch's live
+// tiles leave CUs free at the headline shape; the sums depend on the head launch only.  D = 128, mma_bf16 = 3.
+extern "C" int amid_sas_strip_qkv_bwd_sort_scorer_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                                      const float* const* ln_w, const float* const* wqT, const float* const* wkT,
+                                                      const float* const* wvT, float ln_eps, int B, int T, int D, const int* live,
+                                                      float* ln_part, const unsigned char* tmq, const float* fh, const float* fr,
+                                                      const float* const* fln_w, const float* const* fw1T, const float* const* fw2T,
+                                                      const float* const* fwoT, int flayer, const void* step_state, int train, float p_drop,
+                                                      float* fdpre2, float* fdpre1, float* fdr, float* fd_o, float* fln_part,
+                                                      const void* sort_plan, int sort_phase, int mma_bf16, const float* hidg, const float* u,
+                                                      const float* items, int NI, int hid, float* dW1, float* db1, float* dW2, float* db2,
+                                                      void* stream) {
+    AMID_CHECK_ARG(sort_plan != nullptr && fh != nullptr && hidg && u && items && NI > 0 && hid > 0 && dW1 && db1 && dW2 && db2);
+    AMID_CHECK_ARG(((((unsigned long long)dW1) | ((unsigned long long)u) | ((unsigned long long)items)) & 15) == 0);
+    const ScorerSum ss = scorer_sum_args(hidg, u, items, B, NI, D, hid, dW1, db1, dW2, db2);
+    return strip_qkv_bwd(dq, dk, dv, dr, x, ln_w, wqT, wkT, wvT, ln_eps, B, T, D, live, nullptr, ln_part, tmq, fh, fr, fln_w, fw1T, fw2T, fwoT, flayer,
+                         step_state, train, p_drop, fdpre2, fdpre1, fdr, fd_o, fln_part, sort_plan, sort_phase, mma_bf16, stream, nullptr, 0.f, &ss);
 }
 
 // layer 0's launch of the live-sequence train step with the embedding layer's backward on the strip (StripQkvBwdArgs::emb_tmq): dx = the

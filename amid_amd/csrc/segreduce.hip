@@ -12,6 +12,7 @@
 #include "common.h"
 #include "reduce_partials.h"
 #include "seg_spans.h"
+#include "scorer_sum.h"
 
 namespace amid {
 
@@ -151,9 +152,17 @@ template <int VEC>
 __global__ __launch_bounds__(256) void grad_tail_live_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
                                                              const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
                                                              float* __restrict__ partial, int n_seg, const ReduceEntry* __restrict__ entries,
-                                                             const int* __restrict__ blk_off, int n_entries, int n_red, const PosSum ps) {
-    if ((int)blockIdx.x < n_seg) { segreduce_chunks_block<VEC>(grad_rows, pos_sorted, seg_of, n, uniq_grad, partial, blockIdx.x); return; }
-    const int rb = blockIdx.x - n_seg;
+                                                             const int* __restrict__ blk_off, int n_entries, int n_red, const PosSum ps,
+                                                             const ScorerSum ss) {
+    // the scorer sums first: their workgroups run the longest chains (B samples in eight groups)
+    if ((int)blockIdx.x < ss.nblk) {
+        __shared__ f32x4 sred[8 * 33];
+        scorer_sum_block(ss, blockIdx.x, (scorer_lds_f4*)sred);
+        return;
+    }
+    const int bid = blockIdx.x - ss.nblk;
+    if (bid < n_seg) { segreduce_chunks_block<VEC>(grad_rows, pos_sorted, seg_of, n, uniq_grad, partial, bid); return; }
+    const int rb = bid - n_seg;
     if (rb >= n_red) {
         const int pb = rb - n_red;
         pos_sum_block(ps, VEC * 64, pb / ps.nblk, pb % ps.nblk, ps.nblk);
@@ -296,11 +305,17 @@ extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted,
 // compact sorted list (pos_sorted holds rows of grad_rows), the fixed-order partial sums of `entries` (blk_off: blocks per entry, as
 // amid_grad_tail_f32) and the position rows' gradients dpos[g] [T, D] summed over the live sequences (live: amid_live_list_i32) straight
 // from grad_rows.  Phase B of the segment reduce is NOT run here: amid_optimizer_step_spans_f32 finishes the runs that cross chunks.
+// hidg != NULL (amid_head_fwd_bwd_own_vec_f32's per-sample hidden gradients; u [2, B, D], items [B, NI, D]): the scorer's weight gradients
+// dW1 [hid, 2 D], db1 [hid], dW2 [hid], db2 [1] are formed here too (D <= 128).
 extern "C" int amid_grad_tail_live_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
                                        void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off,
-                                       int total_blocks, const int* live, int B, int T, float* dpos0, float* dpos1, void* stream) {
+                                       int total_blocks, const int* live, int B, int T, float* dpos0, float* dpos1, const float* hidg,
+                                       const float* u, const float* items, int NI, int hid, float* dW1, float* db1, float* dW2, float* db2,
+                                       void* stream) {
     AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
                    blk_off && total_blocks > 0 && live && B > 0 && T > 0 && dpos0 && dpos1);
+    AMID_CHECK_ARG(hidg == nullptr || (u && items && NI > 0 && hid > 0 && dW1 && db1 && dW2 && db2 && D <= 128 &&
+                                       ((((unsigned long long)dW1) | ((unsigned long long)u) | ((unsigned long long)items)) & 15) == 0));
     AMID_CHECK_ARG(((((unsigned long long)dpos0) | ((unsigned long long)dpos1) | ((unsigned long long)grad_rows)) & 15) == 0);
     if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -308,11 +323,12 @@ extern "C" int amid_grad_tail_live_f32(const float* grad_rows, const int* pos_so
     PosSum ps;
     ps.rows = grad_rows; ps.live = live; ps.B = B; ps.T = T; ps.dst[0] = dpos0; ps.dst[1] = dpos1;
     ps.nblk = (T * D + 127) / 128;
+    const ScorerSum ss = scorer_sum_args(hidg, u, items, B, NI, D, hid, dW1, db1, dW2, db2);
     float* partial = (float*)workspace;
     const ReduceEntry* en = (const ReduceEntry*)entries_dev;
 #define AMID_TAIL_LAUNCH(VEC)                                                                                                       \
-    grad_tail_live_kernel<VEC><<<n_seg + total_blocks + 2 * ps.nblk, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial, n_seg, \
-                                                                                  en, blk_off, n_entries, total_blocks, ps);
+    grad_tail_live_kernel<VEC><<<ss.nblk + n_seg + total_blocks + 2 * ps.nblk, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial, \
+                                                                                            n_seg, en, blk_off, n_entries, total_blocks, ps, ss);
     if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }
 #undef AMID_TAIL_LAUNCH
     AMID_LAUNCH_CHECK();

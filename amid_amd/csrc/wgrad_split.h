@@ -114,7 +114,12 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
             // the rows past the split's end, by selection.  (History: zeroing by a multiplication with a 0 / 1 factor -- v_pk_mul_f32 / v_pk_fma_f32 with op_sel on the
             // freshly loaded pairs -- gave wrong sums in 239 of 240 launches whenever two workgroups shared a CU and right ones with
             // one per CU; not explained.  tests/test_gpu_kernels.py repeats the two-per-CU launch against the fp64 product.)
+#ifdef AMID_WGS_ZERO_BY_MUL      // diagnostic builds only (profiles/tools/probe/wgrad_opsel_repro.sh): the form that miscompared
+            const float keep = (c0 + 2 * rr + k < local_end) ? 1.f : 0.f;
+            py[k] = f4scale(py[k], keep); px[k] = f4scale(px[k], keep);
+#else
             if (c0 + 2 * rr + k >= local_end) { py[k] = make_float4(0.f, 0.f, 0.f, 0.f); px[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+#endif
         }
         bsum = f4add(bsum, f4add(py[0], py[1]));
 #pragma unroll

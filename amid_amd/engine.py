@@ -398,10 +398,16 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                     and (pl.n_compact + 2047) // 2048 <= 12 * pl.splits)
 
     def _tail2_table(self, pl: SasrecPlan):
-        """The gradient tail's reduce table without the position rows' partial sums (amid_grad_tail_live_f32 sums them from the rows)."""
+        """The gradient tail's reduce table without the position rows' partial sums and without the scorer's per-sample partials
+        (amid_grad_tail_live_f32 sums the former from the rows and forms the latter from the head's per-sample hidden gradients)."""
         if not hasattr(pl, "red_entries_t"):
             pl.red_entries_t, pl.red_n_t, pl.red_max_t = pl._build_reduce_table(self, live=True, pos=False)
         return pl.red_entries_t, pl.red_n_t, pl.red_blk_t
+
+    def _hidg(self, pl: SasrecPlan) -> torch.Tensor:
+        if not hasattr(pl, "hidg"):
+            pl.hidg = torch.zeros(pl.shape.B, lib().value("amid_scorer_vec_floats", pl.shape.NI, self.hid), dtype=torch.float32, device=self.device)
+        return pl.hidg
 
     COMPACT_LIVE = True
     COMPACT_MIN_IDX = 65536    # shorter index lists gain nothing from the compact list (the tail is bound by the dense partial sums,
@@ -479,6 +485,9 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         L, s, shp, D = lib(), self.s, pl.shape, self.D
         B, T, NI = shp.B, shp.Tenc, shp.NI
         st = self.step_state.data_ptr()
+        # what this launch's riders write is decided HERE: a flag left by an earlier forward (e.g. a train-mode forward without a backward)
+        # must not make the next backward skip its images
+        pl.w16_written = pl.wT16x3_written = False
         compact = lf is not None and getattr(pl, "compact", False) and not getattr(pl, "tail2", False)      # (tail2: the step head wrote the list)
         ic, rc = (pl.idx_c.data_ptr(), pl.row_c.data_ptr()) if compact else (None, None)
         if getattr(pl, "fold_catchup", False):
@@ -532,6 +541,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         st = self.step_state.data_ptr()
         tr = 1 if train else 0
         fp = self.dense
+        pl.w16_written = pl.wT16x3_written = False      # (set again by the gather K1 of THIS forward when its riders write the images)
         # the train step's own loss reads only the sequence (domain_id[b], b) of every sample (see _enqueue_fwd_bwd): those B "live"
         # sequences are listed on the device; with live_fwd the forward encodes nothing else
         lv = self._live_list(pl)
@@ -840,6 +850,14 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         elif self.itc_bs:
             L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
             self._enqueue_head_itc_bwd(pl, items, ditems)
+        elif getattr(self, "_fuse_head", False) and getattr(pl, "tail2", False) and getattr(self, "_live_fwd", False) and self._live_list(pl) is not None:
+            # the folded step: the scorer's weight gradients leave the head as per-sample hidden gradients (pl.hidg; the gradient tail sums
+            # them, amid_grad_tail_live_f32) and the fp32 transposes are not refreshed (this step's strips read the three-plane images)
+            L.call("amid_head_fwd_bwd_own_vec_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
+                   items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
+                   fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr(), pl.domain.data_ptr(), B, T, NI, D, self.hid, SASREC_LN_EPS,
+                   pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr(), pl.dp2.data_ptr(), pl.loss_part.data_ptr(),
+                   pl.dxbuf.data_ptr(), ditems, pl.last_part.data_ptr(), self._hidg(pl).data_ptr(), None, None, 0, s)
         elif getattr(self, "_fuse_head", False):
             L.call("amid_head_fwd_bwd_own_f32" if getattr(self, "_live_fwd", False) and self._live_list(pl) is not None else "amid_head_fwd_bwd_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
                    items, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"),
@@ -907,10 +925,19 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                    *ride(2), bf, s)
             attn_bwd(1)
             # layer 1's q / k / v + LayerNorm1 backward and layer 0's feed-forward / out-projection backward: one launch
-            L.call(f"amid_sas_strip_qkv_bwd{sfx}_f32", pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
-                   pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
-                   SASREC_LN_EPS, B, T, D, lv, None, ln1p[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr, SASREC_P_DROP,
-                   pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(), ln2p[0].data_ptr(), *ride(3), bf, s)
+            if t2:      # ... whose idle CUs also sum the scorer's weight gradients from the head's per-sample hidden gradients
+                G = fp.grad
+                L.call("amid_sas_strip_qkv_bwd_sort_scorer_f32", pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
+                       pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
+                       SASREC_LN_EPS, B, T, D, lv, ln1p[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr, SASREC_P_DROP,
+                       pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(), ln2p[0].data_ptr(), plan_addr, 3, bf,
+                       self._hidg(pl).data_ptr(), pl.u.data_ptr(), items, NI, self.hid, fp.ptr("predictModule.fc.0.weight", G),
+                       fp.ptr("predictModule.fc.0.bias", G), fp.ptr("predictModule.fc.2.weight", G), fp.ptr("predictModule.fc.2.bias", G), s)
+            else:
+                L.call(f"amid_sas_strip_qkv_bwd{sfx}_f32", pl.dq_l[1].data_ptr(), pl.dk_l[1].data_ptr(), pl.dv_l[1].data_ptr(), pl.dr[1].data_ptr(),
+                       pl.x[1].data_ptr(), self._pp("sac{d}.attention_layernorms.1.weight"), self._wT(1, 0), self._wT(1, 1), self._wT(1, 2),
+                       SASREC_LN_EPS, B, T, D, lv, None, ln1p[1].data_ptr(), tm, h0, r0, lnw0, w1T0, w2T0, woT0, 0, st, tr, SASREC_P_DROP,
+                       pl.dpre2[0].data_ptr(), pl.dpre1[0].data_ptr(), pl.dr[0].data_ptr(), pl.d_o.data_ptr(), ln2p[0].data_ptr(), *ride(3), bf, s)
             attn_bwd(0)
             if t2:      # ... with the embedding layer's backward applied on the strip (no amid_embed_bwd launch)
                 L.call("amid_sas_strip_qkv_bwd_emb_f32", pl.dq_l[0].data_ptr(), pl.dk_l[0].data_ptr(), pl.dv_l[0].data_ptr(), pl.dr[0].data_ptr(),
@@ -1001,7 +1028,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             fp = self.dense
             L.call("amid_grad_tail_live_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_compact,
                    self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), ent_t.data_ptr(), n_ent_t, blk_t[0].data_ptr(), blk_t[1],
-                   pl.live.data_ptr(), shp.B, shp.Tenc, fp.ptr("sac1.pos_emb.weight", fp.grad), fp.ptr("sac2.pos_emb.weight", fp.grad), s)
+                   pl.live.data_ptr(), shp.B, shp.Tenc, fp.ptr("sac1.pos_emb.weight", fp.grad), fp.ptr("sac2.pos_emb.weight", fp.grad),
+                   None, None, None, 0, 0, None, None, None, None, s)      # (the scorer sums rode in the middle strip launch)
             return
         pk = getattr(self, "_tail_pack", None)
         if pk is not None:       # graph A of the data-parallel step: the tail also packs this rank's exchange chunk (ids | rows | dense)

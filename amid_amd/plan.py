@@ -326,6 +326,8 @@ class SasrecPlan:
         else:
             ent.append((self.loss_part.data_ptr(), self.loss.data_ptr(), 1, B, 1))      # loss = sum of the per-row partials
         for head, part in heads:
+            if not pos:         # (the folded step: the gradient tail forms the scorer's weight gradients from per-sample hidden gradients)
+                continue
             add(part, 0, fp.ptr(f"{head}.fc.0.weight", G), P, B, hid * 2 * D)
             add(part, hid * 2 * D, fp.ptr(f"{head}.fc.0.bias", G), P, B, hid)
             add(part, hid * 2 * D + hid, fp.ptr(f"{head}.fc.2.weight", G), P, B, hid)

@@ -371,6 +371,79 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+EVAL_NEG = 999          # run.sh:1 evaluates with --neg_nums 999: 1 000 candidates per row
+
+
+def eval_batch(gen, device, Bw):
+    """A test() batch (train_sr.py:31-128): synth_batch's sequences with EVAL_NEG negatives per row."""
+    wl = dict(WORKLOADS["cfg2"], B=Bw)
+    b = synth_batch(gen, "cpu", wl)
+    b["neg_samples"] = torch.randint(1, wl["max_id"] + 1, (Bw, EVAL_NEG), generator=gen)
+    b["label"] = torch.zeros(Bw, 1 + EVAL_NEG)
+    b["label"][:, 0] = 1.0
+    return {k: v.to(device) for k, v in b.items()}
+
+
+def eval_throughput(eng, device, Bw, T, n_batches=32):
+    """The evaluation loop's throughput (what test() does per batch, train_sr.py:31-128, at run.sh's 999 negatives): the eval-mode
+    forward over BOTH domains' sequences with 1 000 candidates per row, then the positive's rank of every row on the device
+    (amid_positive_rank_f32: choose_predict + the double argsort of get_sample_scores, utils.py:21-40 / :296-312, fix_value tie rule);
+    B ints per batch are what the host would read.  Eager launches, as the CLI's test() runs them."""
+    from amid_amd.utils import device_positive_ranks
+    gen = torch.Generator().manual_seed(4321)
+    batches = [eval_batch(gen, device, Bw) for _ in range(4)]
+    pl = eng.plan(Bw, T, 1 + EVAL_NEG, need_grad=False)
+    eng.flush_table()
+    eng.sync()
+    cur = torch.cuda.current_stream()
+
+    def one(b):
+        eng.stream.wait_stream(cur)
+        eng.load_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"])
+        eng.enqueue_prepare(pl, sparse=False)
+        eng.enqueue_forward(pl, train=False, with_loss=False)
+        cur.wait_stream(eng.stream)
+        return device_positive_ranks(pl.p1, pl.p2, b["domain_id"], 1e-7)
+
+    for i in range(3):
+        r = one(batches[i % 4])
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(n_batches):
+        r = one(batches[i % 4])
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    eng.check_index_error(pl)
+    return {"metric": "eval samples/sec (test(): forward at 1 + neg candidates per row + the positive's rank on the device)",
+            "value": round(Bw * n_batches / dt, 1), "unit": "samples/s", "batches_per_s": round(n_batches / dt, 2),
+            "ms_per_batch": round(1e3 * dt / n_batches, 4), "batch": Bw, "seq_len": T, "neg_nums": EVAL_NEG, "batches_timed": n_batches,
+            "mean_rank_last_batch": round(float(r.float().mean().item()), 2),
+            "what": "eager launches per batch: index marshal, gather of 2 B T + 1 000 B rows, both encoders over every sequence, "
+                    "scorer over 1 000 candidates per row, rank kernel; synthetic cloth_sport-shaped batches"}
+
+
+def cpu_eval_baseline(P, budget_s=8.0):
+    """The oracle's eval forward + the reference's rank arithmetic (get_sample_scores) on this host's cores, same batch shape."""
+    from oracle import amid_oracle as orc
+    gen = torch.Generator().manual_seed(4321)
+    ts = []
+    t_begin = time.perf_counter()
+    with torch.no_grad():
+        while len(ts) < 6 and (len(ts) < 2 or time.perf_counter() - t_begin < budget_s):
+            b = eval_batch(gen, "cpu", B)
+            t0 = time.perf_counter()
+            p1, p2 = orc.sasrec_forward(P, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"])
+            pred = torch.where(b["domain_id"][:, None] == 0, p1.reshape(B, -1), p2.reshape(B, -1)).numpy().copy()
+            pred[:, 0] -= 1e-7
+            orc.get_sample_scores(pred)
+            ts.append(time.perf_counter() - t0)
+    timed = sorted(ts[1:])
+    med = timed[len(timed) // 2]
+    return {"value": round(B / med, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port", "ms_per_batch": round(med * 1e3, 1),
+            "sample": f"{len(timed)} timed batches (+1 warm-up, <= {budget_s:.0f} s) of oracle sasrec_forward + get_sample_scores at batch {B} x seq {T} "
+                      f"x {1 + EVAL_NEG} candidates, median"}
+
+
 def cpu_baseline(budget_s=25.0):
     """The oracle (CPU restatement of the reference path: dense embedding grads + dense Adam over the
     894 820-row table) timed on this host's cores on a bounded sample of the same workload."""
@@ -391,7 +464,11 @@ def cpu_baseline(budget_s=25.0):
         ts.append(time.perf_counter() - t0)
     timed = sorted(ts[2:])                             # two warm-up steps (allocator, thread pool, first-touch of 1.4 GB of state)
     med = timed[len(timed) // 2]
-    return {"value": round(B / med, 2), "unit": "samples/s", "cores": threads, "kind": "port",
+    try:
+        cpu_eval = cpu_eval_baseline(P)
+    except Exception as e:                                  # a side measurement must never cost the headline's baseline
+        cpu_eval = {"error": f"{type(e).__name__}: {e}"}
+    return {"value": round(B / med, 2), "unit": "samples/s", "cores": threads, "kind": "port", "eval": cpu_eval,
             "ms_per_step": round(med * 1e3, 1),
             "sample": f"{len(timed)} timed steps (+2 warm-up, <= {budget_s:.0f} s) of oracle/amid_oracle.py train_step at the same "
                       f"batch {B} x seq {T} x dim {D}, dense Adam over the {N_ROWS}-row table, median; host reports "
@@ -784,10 +861,18 @@ def main():
                 out["gather_stress"] = gather_stress(device)
             except Exception as e:              # a side measurement must never cost the headline line
                 out["gather_stress"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and args.workload == "cfg2" and args.model == "sasrec" and args.dtype == "f32" and not args.no_stress:
+            try:
+                out["eval"] = eval_throughput(eng, device, Bw, T)
+            except Exception as e:
+                out["eval"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
             try:
                 out["cpu_baseline"] = cpu_baseline()
                 out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+                cpu_eval = out["cpu_baseline"].pop("eval", None)
+                if cpu_eval is not None and isinstance(out.get("eval"), dict):
+                    out["eval"]["cpu_baseline"] = cpu_eval
             except Exception as e:
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))

@@ -809,7 +809,30 @@ int amid_sas_wgrad_rows_sort_f32(const float* const* dy, const float* const* x, 
  * Phase B of the segment reduce is left to amid_optimizer_step_spans_f32. */
 int amid_grad_tail_live_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
                             void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off, int total_blocks,
-                            const int* live, int B, int T, float* dpos0, float* dpos1, void* stream);
+                            const int* live, int B, int T, float* dpos0, float* dpos1, const float* hidg, const float* u,
+                            const float* items, int NI, int hid, float* dW1, float* db1, float* dW2, float* db2, void* stream);
+/* hidg (optional; with it u [2, B, D], items [B, NI, D] and the four gradient outputs): the scorer's weight gradients (autograd of
+ * predictModule.forward, model_seq.py:40-54) summed over the batch from the per-sample hidden gradients of amid_head_fwd_bwd_own_vec_f32
+ * -- hidg [B][amid_scorer_vec_floats(NI, hid)] = da [2][hid] | dc [NI][hid] | dW2's [hid] | db2's: dW1 = sum_b da_b (x) u_b + dc_b (x) items_b.
+ * amid_head_fwd_bwd_own_vec_f32 = amid_head_fwd_bwd_own_f32 writing hidg instead of the 32 KB-per-sample partials sc_part. */
+long long amid_scorer_vec_floats(int NI, int hid);
+/* amid_sas_strip_qkv_bwd_sort_f32 with the fused feed-forward backward (phase 3 of the sort plan) that ALSO carries the scorer sums above as
+ * extra workgroups (the launch's live tiles leave CUs idle at the headline shape, and the sums depend on the head launch only): then
+ * amid_grad_tail_live_f32 is called with hidg = NULL.  D = 128, mma_bf16 = 3. */
+int amid_sas_strip_qkv_bwd_sort_scorer_f32(const float* dq, const float* dk, const float* dv, const float* dr, const float* x,
+                                           const float* const* ln_w, const float* const* wqT, const float* const* wkT,
+                                           const float* const* wvT, float ln_eps, int B, int T, int D, const int* live, float* ln_part,
+                                           const unsigned char* tmq, const float* fh, const float* fr, const float* const* fln_w,
+                                           const float* const* fw1T, const float* const* fw2T, const float* const* fwoT, int flayer,
+                                           const void* step_state, int train, float p_drop, float* fdpre2, float* fdpre1, float* fdr,
+                                           float* fd_o, float* fln_part, const void* sort_plan, int sort_phase, int mma_bf16,
+                                           const float* hidg, const float* u, const float* items, int NI, int hid, float* dW1, float* db1,
+                                           float* dW2, float* db2, void* stream);
+int amid_head_fwd_bwd_own_vec_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* items, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id, int B,
+                                  int T, int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1, float* dp2,
+                                  float* loss_part, float* dx, float* ditems, float* ln_part, float* hidg, const float* const* tr_src,
+                                  float* const* tr_dst, int n_tr, void* stream);
 /* amid_optimizer_step_f32 behind amid_grad_tail_live_f32: the runs of the sorted list that cross 64-entry chunks are summed from the tail's
  * partial rows (workspace) by extra workgroups -- the additions of amid_embgrad_segreduce_f32's second launch in the same order --, written
  * to uniq_grad and applied on the spot.  D = 64 / 128 / 256. */
