@@ -917,7 +917,11 @@ static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers
     }
     if (mma_bf16 >= 2) {      // fp32 operands as three bf16 pieces each (csrc: sas_wgrad_split_kernel): D = 128 only
         if (D != 128) return AMID_ERR_UNSUPPORTED;
+#ifdef AMID_WGS_LDS_GUARD        // diagnostic builds (profiles/tools/probe/wgrad_opsel_repro.sh): unused LDS behind every workgroup's allocation
+        const size_t fixed = WGS_LDS_FIXED + AMID_WGS_LDS_GUARD;
+#else
         const size_t fixed = WGS_LDS_FIXED;
+#endif
         static unsigned long long done[4] = {0, 0, 0, 0};
 #define AMID_WGS_LAUNCH(NT, H, SLOT)                                                                                                  \
         do {                                                                                                                      \
