@@ -48,11 +48,15 @@ constexpr int NIMG_KEYS = 64;
 // head's lane groups (the matrix instruction contracts over the lane groups: groups 0, 1 carry the first head's dims, 2, 3 the
 // second's), P~ V is computed for all 16 dims of the tile and a lane keeps its own head's result (attention_mfma.h attn_fwd_head<true>).
 // st_max / st_rl: per own head, NCT (x 2) of them.
-template <int D, int WPS, int NCT, bool PAIR>
+template <int D, int WPS, int NCT, bool PAIR, int SI = -1>
 __device__ __forceinline__ void seqn_attention(PartRegs<NCT>& O, float (&st_max)[PAIR ? 2 * NCT : NCT], float (&st_rl)[PAIR ? 2 * NCT : NCT],
                                                const PartRegs<NCT>& Q, const float* __restrict__ kimg, const float* __restrict__ vimg, int c0,
-                                               int si, int m, int gq, int t, int T, unsigned long long rowbase_bh, float scale, int train,
+                                               int si_rt, int m, int gq, int t, int T, unsigned long long rowbase_bh, float scale, int train,
                                                unsigned long long seed, unsigned site, unsigned step, unsigned spec, float dscale) {
+    // SI >= 0: the wave's strip index as a compile-time constant (the caller switches on it): every `kt <= si` below folds, the four heads
+    // become ONE straight-line region and the scheduler overlaps a head's softmax with its neighbour's matrix instructions (with the
+    // runtime index every tile sits behind a branch)
+    const int si = SI >= 0 ? SI : si_rt;
     constexpr int NE = PAIR ? 2 : 1, NH = NE * NCT;
     static_assert(NH <= 4, "a lane group draws the keep word of one own head");
     const int qrow = min(t, T - 1);
@@ -435,9 +439,6 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwd
         g = (int)blockIdx.x >= sg.B ? 1 : 0;
         b = (int)blockIdx.x - g * sg.B;
     }
-#ifdef AMID_EXP_SETPRIO           // (diagnostic builds: static priority for the second-dispatched half, MI355X_MICROARCH.md "Two waves per SIMD" item 4)
-    if (w >= NW / 2) __builtin_amdgcn_s_setprio(AMID_EXP_SETPRIO);
-#endif
     using Ring = SeqRing3<D, NW>;
     Ring ring(smem);
     auto w16 = [&](int layer, int which) { return a.w16 + ((size_t)((layer * 2 + g) * 6 + which)) * 3 * D * D; };     // q, k, v, o, c1, c2
@@ -542,8 +543,18 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwd
         lds_barrier();
         SEQN_STAMP(8);
         float st_max[NH], st_rl[NH];
-        seqn_attention<D, WPS, NCT, false>(Oo, st_max, st_rl, Qo, kimg, vimg, c0, si, m_, gl_, si * 16 + m_, sg.T, (unsigned long long)b * H, a.att_scale,
-                                           a.train, seed, site_id(g, l, SITE_ATTN), step, a.spec, a.dscale);
+        {   // the strip index as a compile-time constant of the core (seqn_attention SI): 8.9 - 16.2 k cycles -> 5.1 - 12.6 k per layer
+            auto att = [&](auto SIC) {
+                seqn_attention<D, WPS, NCT, false, decltype(SIC)::value>(Oo, st_max, st_rl, Qo, kimg, vimg, c0, si, m_, gl_, si * 16 + m_, sg.T, (unsigned long long)b * H,
+                                                                          a.att_scale, a.train, seed, site_id(g, l, SITE_ATTN), step, a.spec, a.dscale);
+            };
+            if constexpr (WPS == 4) {
+                if (si == 0) att(std::integral_constant<int, 0>{}); else if (si == 1) att(std::integral_constant<int, 1>{});
+                else if (si == 2) att(std::integral_constant<int, 2>{}); else att(std::integral_constant<int, 3>{});
+            } else if constexpr (WPS == 2) {
+                if (si == 0) att(std::integral_constant<int, 0>{}); else att(std::integral_constant<int, 1>{});
+            } else att(std::integral_constant<int, 0>{});
+        }
         SEQN_STAMP(9);
         {
             const unsigned so = row_ok ? phys * (unsigned)(H * 8) + (unsigned)c0 * 8u : STRIP_OOB;

@@ -441,26 +441,35 @@ template <int D, int NW> struct SeqRing3 {
         cur = W0; hi_ready = true; rest_ready = true;
         plane(hslot(), W0); plane(mslot(), W0 + (size_t)D * D); plane(lslot(), W0 + (size_t)2 * D * D);
     }
-    __device__ __forceinline__ void next() {                 // a product begins: every wave is past the previous one (and the images)
+    // Round 5: a product walks its HI plane first.  Schedule of product i (weight cur):
+    //   next()      everything requested so far has landed and every wave is past product i - 1 (and past the attention images, which live in
+    //               M + L between the q product and the out-projection): the mid / lo planes of cur are requested NOW and land under the
+    //               hi pass; the hi plane was requested half a product ago (mid_sync of product i - 1) and is here
+    //   pass H      hi plane x the operand's (lo, mid, hi)
+    //   mid_sync()  mid / lo have landed, every wave is done with H: the NEXT weight's hi plane is requested into H and lands under the
+    //   pass M/L    lo x hi, mid x (mid, hi)
+    // Round 4 walked mid / lo first: the product behind the attention core then found its mid / lo planes only requested when it began (M + L
+    // held the images) and sat out the whole DMA -- 2.7 - 9 k cycles per layer (profiles/r04_seqn_stamps.txt "stats + o parts out + ring
+    // wait").  With the hi plane first that product's first pass runs on a plane requested before the attention core.
+    __device__ __forceinline__ void next() {
         w_ring_wait();
         __syncthreads();
-        if (!hi_ready) plane(hslot(), cur);
-        rest_late = !rest_ready;
-        if (rest_late) { plane(mslot(), cur + (size_t)D * D); plane(lslot(), cur + (size_t)2 * D * D); }
+        if (!hi_ready) plane(hslot(), cur);                  // (never in steady state: kept for a ring that is started without first())
+        rest_late = !hi_ready;
+        if (!rest_ready) { plane(mslot(), cur + (size_t)D * D); plane(lslot(), cur + (size_t)2 * D * D); }
     }
     __device__ __forceinline__ void begin(const unsigned short* __restrict__ Wnext) { nxt = Wnext; }
-    __device__ __forceinline__ void pre_pass1() {            // (the product behind the attention core: its planes were requested just now)
+    __device__ __forceinline__ void pre_pass1() {            // (only when the hi plane was requested by next() itself)
         if (rest_late) { w_ring_wait(); __syncthreads(); }
     }
-    __device__ __forceinline__ void mid_sync() {             // behind the first pass: the hi plane has landed, M / L take the next weight's planes
+    __device__ __forceinline__ void mid_sync() {             // behind the hi pass: mid / lo have landed; H takes the next weight's hi plane
 #ifndef AMID_XNOWAIT
         w_ring_wait();
 #endif
         __syncthreads();
-        rest_ready = !hold_next;
-        if (rest_ready) { plane(mslot(), nxt + (size_t)D * D); plane(lslot(), nxt + (size_t)2 * D * D); }
+        plane(hslot(), nxt);
+        cur = nxt; hi_ready = true; rest_ready = false;
         hold_next = false;
-        cur = nxt; hi_ready = false;
     }
 };
 
@@ -527,29 +536,7 @@ __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __re
     // a step = (own column tile c, k-step s), s fastest: a column tile's twelve matrix instructions per pass run back to back on its
     // accumulator (profiles/r04_mfma_rate_probe.txt: a chain on one accumulator issues faster than instructions that change accumulator;
     // 77.7 -> 76.1 us by HIP events on one box); the operand's fragments of all four k-steps are read up front
-    {   // pass 1: the lo plane against the operand's hi piece, the mid plane against (mid, hi)
-        f32x4 wm[PD1 + 1], wl[PD1 + 1], ah[KS], am[KS];
-        static_for<KS>([&](auto S) {
-            constexpr int s = decltype(S)::value;
-            lds_frag_issue<(s * 3 + 0) * 1024>(ah[s], xa);
-            lds_frag_issue<(s * 3 + 1) * 1024>(am[s], xa);
-        });
-        auto issue = [&](auto U) {
-            constexpr int u = decltype(U)::value, c = u / KS, s = u % KS, k = u % (PD1 + 1);
-            lds_frag_issue<c * CT_BYTES>(wm[k], mbase + fo[s]);
-            lds_frag_issue<c * CT_BYTES + PLANE_BYTES>(wl[k], mbase + fo[s]);
-        };
-        static_for<PD1>(issue);
-        static_for<NSTEP>([&](auto T) {
-            constexpr int t = decltype(T)::value, c = t / KS, s = t % KS, k = t % (PD1 + 1);
-            if constexpr (t + PD1 < NSTEP) issue(std::integral_constant<int, t + PD1>{});
-            constexpr int last = t + PD1 < NSTEP ? t + PD1 : NSTEP - 1;
-            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wm[k]), "+v"(wl[k]), "+v"(ah[s]), "+v"(am[s]) : "n"(2 * (last - t)));
-            acc[c] = mma(wl[k], ah[s], acc[c]); acc[c] = mma(wm[k], am[s], acc[c]); acc[c] = mma(wm[k], ah[s], acc[c]);
-        });
-    }
-    ring.mid_sync();
-    {   // pass 2: the hi plane against the operand's three pieces
+    {   // first pass: the hi plane against the operand's three pieces (the plane was requested half a product ago)
         f32x4 wf[PD2 + 1], ah[KS], am[KS], al[KS];
         static_for<KS>([&](auto S) {
             constexpr int s = decltype(S)::value;
@@ -568,6 +555,28 @@ __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __re
             constexpr int last = t + PD2 < NSTEP ? t + PD2 : NSTEP - 1;
             asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wf[k]), "+v"(ah[s]), "+v"(am[s]), "+v"(al[s]) : "n"(last - t));
             acc[c] = mma(wf[k], al[s], acc[c]); acc[c] = mma(wf[k], am[s], acc[c]); acc[c] = mma(wf[k], ah[s], acc[c]);
+        });
+    }
+    ring.mid_sync();
+    {   // second pass: the lo plane against the operand's hi piece, the mid plane against (mid, hi)
+        f32x4 wm[PD1 + 1], wl[PD1 + 1], ah[KS], am[KS];
+        static_for<KS>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            lds_frag_issue<(s * 3 + 0) * 1024>(ah[s], xa);
+            lds_frag_issue<(s * 3 + 1) * 1024>(am[s], xa);
+        });
+        auto issue = [&](auto U) {
+            constexpr int u = decltype(U)::value, c = u / KS, s = u % KS, k = u % (PD1 + 1);
+            lds_frag_issue<c * CT_BYTES>(wm[k], mbase + fo[s]);
+            lds_frag_issue<c * CT_BYTES + PLANE_BYTES>(wl[k], mbase + fo[s]);
+        };
+        static_for<PD1>(issue);
+        static_for<NSTEP>([&](auto T) {
+            constexpr int t = decltype(T)::value, c = t / KS, s = t % KS, k = t % (PD1 + 1);
+            if constexpr (t + PD1 < NSTEP) issue(std::integral_constant<int, t + PD1>{});
+            constexpr int last = t + PD1 < NSTEP ? t + PD1 : NSTEP - 1;
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wm[k]), "+v"(wl[k]), "+v"(ah[s]), "+v"(am[s]) : "n"(2 * (last - t)));
+            acc[c] = mma(wl[k], ah[s], acc[c]); acc[c] = mma(wm[k], am[s], acc[c]); acc[c] = mma(wm[k], ah[s], acc[c]);
         });
     }
 }

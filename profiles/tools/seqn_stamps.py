@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("AMID_SEQ_FWD_VARIANT", "42")
 import amid_amd._lib as _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "profiles", "tools", "_diag", "libamid_hip_diag.so")
+_lib.LIB_PATH = os.environ.get("AMID_DIAG_LIB") or os.path.join(ROOT, "profiles", "tools", "_diag", "libamid_hip_diag.so")
 import torch  # noqa: E402
 from amid_amd.engine import SasrecEngine  # noqa: E402
 from oracle import amid_oracle as orc  # noqa: E402
