@@ -386,6 +386,10 @@ struct WgradArgs {
     // (the loss masks the other domain of every sample, train_sr.py:205-211); the M = B * T rows of a domain are then walked as
     // n_live * T "virtual" rows -- the live sequences back to back -- and the dead half is never read
     const long long* row_domain; int B, T;
+    // optional (amid_sas_wgrad_rows_sort_ln_f32; the six-pair build only): per layer [2M][4] row statistics of a forward that did not store
+    // qn and y (seq_fwd.h SeqLayer::ln_stat) -- xin of weights 0 (q) and 4 (conv1) then points at x / r and the operand is rebuilt while staged
+    const float* ln_stat[2];
+    const float* ln1_w[2][2]; const float* ln1_b[2][2]; const float* ln2_w[2][2]; const float* ln2_b[2][2];      // [layer][domain]
 };
 
 constexpr int WG_ROWS = 64;    // rows staged per step
@@ -696,9 +700,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void sas_wgrad_split_kernel(const 
     const int split = blockIdx.x, wsel = blockIdx.y, g = blockIdx.z;
     const int layer = wsel / 6, wi = wsel - layer * 6;
     const WgsRows rw{a.M, a.splits, a.rows_per_split, a.row_domain, a.B, a.T};
+    WgsLn ln{nullptr, 0, nullptr, nullptr};
+    if (a.ln_stat[layer] != nullptr && (wi == 0 || wi == 4))       // (block-uniform) q: LN1 over x; conv1: LN2 over r
+        ln = wi == 0 ? WgsLn{a.ln_stat[layer], 4, a.ln1_w[layer][g], a.ln1_b[layer][g]} : WgsLn{a.ln_stat[layer] + 2, 4, a.ln2_w[layer][g], a.ln2_b[layer][g]};
     f32x4 acc[8];
     wgrad_split_tile<NTERM, HINT>(smem, a.dy[wsel], D, a.xin[wsel], D, g, split, rw, acc,
-                                  a.b_part[layer] + (((long long)g * 6 + wi) * a.splits + split) * D);
+                                  a.b_part[layer] + (((long long)g * 6 + wi) * a.splits + split) * D, ln);
     const int w = wave_id(), lane = lane_id(), i = lane & 15, gq = lane >> 4;
     float* wp = a.w_part[layer] + (((long long)g * 6 + wi) * a.splits + split) * D * D;
 #pragma unroll
@@ -889,10 +896,22 @@ extern "C" int AMID_ENTRY(amid_sas_qkv_ffn_bwd_rows_f32)(const float* dq, const 
 #if AMID_TILE_RT == 7      // everything below is independent of the row-tile height: one copy only
 static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
                      float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, void* stream,
-                     const void* sort_plan = nullptr) {
+                     const void* sort_plan = nullptr, const float* const* ln_stat = nullptr, const float* const* ln1_w = nullptr,
+                     const float* const* ln1_b = nullptr, const float* const* ln2_w = nullptr, const float* const* ln2_b = nullptr) {
     AMID_CHECK_ARG(dy && x && w_part && b_part && (n_layers == 1 || n_layers == 2) && M > 0 && splits > 0);
     AMID_CHECK_ARG(!row_domain || (B > 0 && T > 0 && (long long)B * T == M));
-    WgradArgs a;
+    WgradArgs a = {};
+    if (ln_stat != nullptr) {          // (the six-pair build with the rider: checked below)
+        AMID_CHECK_ARG(ln1_w && ln1_b && ln2_w && ln2_b && sort_plan != nullptr);
+        for (int l = 0; l < n_layers; ++l) {
+            AMID_CHECK_ARG(ln_stat[l] != nullptr);
+            a.ln_stat[l] = ln_stat[l];
+            for (int g = 0; g < 2; ++g) {
+                AMID_CHECK_ARG(ln1_w[2 * l + g] && ln1_b[2 * l + g] && ln2_w[2 * l + g] && ln2_b[2 * l + g]);
+                a.ln1_w[l][g] = ln1_w[2 * l + g]; a.ln1_b[l][g] = ln1_b[2 * l + g]; a.ln2_w[l][g] = ln2_w[2 * l + g]; a.ln2_b[l][g] = ln2_b[2 * l + g];
+            }
+        }
+    }
     for (int i = 0; i < 6 * n_layers; ++i) { AMID_CHECK_ARG(dy[i] && x[i]); a.dy[i] = dy[i]; a.xin[i] = x[i]; }
     for (int l = 0; l < n_layers; ++l) { AMID_CHECK_ARG(w_part[l] && b_part[l]); a.w_part[l] = w_part[l]; a.b_part[l] = b_part[l]; }
     a.M = M; a.splits = splits;
@@ -985,6 +1004,17 @@ extern "C" int amid_sas_wgrad_rows_sort_f32(const float* const* dy, const float*
                                             int mma_bf16, const void* sort_plan, void* stream) {
     AMID_CHECK_ARG(sort_plan != nullptr && row_domain != nullptr);
     return sas_wgrad(dy, x, n_layers, M, D, splits, w_part, b_part, row_domain, B, T, mma_bf16, stream, sort_plan);
+}
+
+// ... behind amid_sas_seq_fwd_split_lnstat_f32 (a forward that stored row statistics instead of qn = LN1(x) and y = LN2(r)): x[6 l + 0] is the
+// layer's x, x[6 l + 4] its r, and the two operands are rebuilt as (row - mean) rstd gamma + beta while they are staged; ln_stat: n_layers
+// pointers to [2 M][4] (mean1, rstd1, mean2, rstd2); ln1_w / ln1_b / ln2_w / ln2_b: 2 n_layers pointers ordered [layer][domain]
+extern "C" int amid_sas_wgrad_rows_sort_ln_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits,
+                                               float* const* w_part, float* const* b_part, const long long* row_domain, int B, int T,
+                                               int mma_bf16, const void* sort_plan, const float* const* ln_stat, const float* const* ln1_w,
+                                               const float* const* ln1_b, const float* const* ln2_w, const float* const* ln2_b, void* stream) {
+    AMID_CHECK_ARG(sort_plan != nullptr && row_domain != nullptr && ln_stat != nullptr);
+    return sas_wgrad(dy, x, n_layers, M, D, splits, w_part, b_part, row_domain, B, T, mma_bf16, stream, sort_plan, ln_stat, ln1_w, ln1_b, ln2_w, ln2_b);
 }
 
 extern "C" int amid_transpose_weights_f32(const float* const* src, float* const* dst, int n, int D, void* stream) {

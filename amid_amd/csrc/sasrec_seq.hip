@@ -440,9 +440,11 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
                         const float* const* w2, const float* const* b2, float* const* qn, float* const* q, float* const* k,
                         float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
                         const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
-                        const void* step_state, int train, float p_drop, const void* w16, void* stream, int w16_planes = 1) {
+                        const void* step_state, int train, float p_drop, const void* w16, void* stream, int w16_planes = 1,
+                        float* const* ln_stat = nullptr) {
     AMID_CHECK_ARG(n_layers >= 1 && n_layers <= 2 && x_in && xout && ln1_w && ln1_b && w_in && b_in && w_o && b_o && ln2_w && ln2_b && w1 && b1 &&
-                   w2 && b2 && qn && q && k && v && o && stats && r && y && h && (!train || step_state));
+                   w2 && b2 && (ln_stat || (qn && y)) && q && k && v && o && stats && r && h && (!train || step_state));
+    if (ln_stat != nullptr && !(w16 != nullptr && w16_planes == 3 && D == 128)) return AMID_ERR_UNSUPPORTED;      // the piece forward only
     if (!amid_sas_seq_supported(B, T, D, H)) return AMID_ERR_UNSUPPORTED;
     SeqFwdArgs a = {};
     a.n_layers = n_layers;
@@ -454,9 +456,9 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
             P.ln1_w[g] = ln1_w[i]; P.ln1_b[g] = ln1_b[i]; P.w_in[g] = w_in[i]; P.b_in[g] = b_in[i]; P.w_o[g] = w_o[i]; P.b_o[g] = b_o[i];
             P.ln2_w[g] = ln2_w[i]; P.ln2_b[g] = ln2_b[i]; P.w1[g] = w1[i]; P.b1[g] = b1[i]; P.w2[g] = w2[i]; P.b2[g] = b2[i];
         }
-        AMID_CHECK_ARG(x_in[l] && qn[l] && q[l] && k[l] && v[l] && o[l] && stats[l] && r[l] && y[l] && h[l]);
-        P.x = const_cast<float*>(x_in[l]); P.qn = qn[l]; P.q = q[l]; P.k = k[l]; P.v = v[l]; P.o = o[l]; P.stats = stats[l];
-        P.r = r[l]; P.y = y[l]; P.h = h[l];
+        AMID_CHECK_ARG(x_in[l] && q[l] && k[l] && v[l] && o[l] && stats[l] && r[l] && h[l] && (ln_stat ? ln_stat[l] != nullptr : (qn[l] && y[l])));
+        P.x = const_cast<float*>(x_in[l]); P.qn = ln_stat ? nullptr : qn[l]; P.q = q[l]; P.k = k[l]; P.v = v[l]; P.o = o[l]; P.stats = stats[l];
+        P.r = r[l]; P.y = ln_stat ? nullptr : y[l]; P.h = h[l]; P.ln_stat = ln_stat ? ln_stat[l] : nullptr;
     }
     a.x0 = x_in[0]; a.xout = xout; a.tmq = tmq; a.ln_eps = ln_eps;
     a.w16 = (const unsigned short*)w16; a.w16_planes = w16_planes;
@@ -567,4 +569,21 @@ extern "C" int amid_sas_seq_fwd_split_f32(int n_layers, const float* const* x_in
     AMID_CHECK_ARG(w16x3 != nullptr);
     return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, qn, q, k, v, o, stats, r, y, h, tmq,
                         ln_eps, B, T, D, H, live, step_state, train, p_drop, w16x3, stream, 3);
+}
+
+// amid_sas_seq_fwd_split_f32 that saves SEVEN tensors per layer instead of nine: qn = LN1(x) and y = LN2(r) are not stored; ln_stat[l]
+// [2 B T][4] receives every row's (mean, rstd) of LayerNorm 1 and of LayerNorm 2 instead (the backward strips rebuild the normalised rows
+// from x / r already; amid_sas_wgrad_rows_sort_ln_f32 applies (row - mean) rstd gamma + beta while it stages the operand).  D = 128.
+extern "C" int amid_sas_seq_fwd_split_lnstat_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w,
+                                                 const float* const* ln1_b, const float* const* w_in, const float* const* b_in,
+                                                 const float* const* w_o, const float* const* b_o, const float* const* ln2_w,
+                                                 const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                                 const float* const* w2, const float* const* b2, float* const* ln_stat, float* const* q,
+                                                 float* const* k, float* const* v, float* const* o, float* const* stats, float* const* r,
+                                                 float* const* h, const unsigned char* tmq, float ln_eps, int B, int T, int D, int H,
+                                                 const int* live, const void* step_state, int train, float p_drop, const void* w16x3,
+                                                 void* stream) {
+    AMID_CHECK_ARG(w16x3 != nullptr && ln_stat != nullptr);
+    return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, nullptr, q, k, v, o, stats, r, nullptr, h,
+                        tmq, ln_eps, B, T, D, H, live, step_state, train, p_drop, w16x3, stream, 3, ln_stat);
 }

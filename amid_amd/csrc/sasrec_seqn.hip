@@ -477,6 +477,10 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwd
         SEQN_STAMP(0);
         ring.next();                                       // Wk has landed; the row of x is in the exchange slots
         SEQN_STAMP(1);
+        // P.ln_stat: qn and y are not stored (SeqLayer::ln_stat); one lane per row (group 0 of column part 0) stores the row's statistics
+        const bool lnst = P.ln_stat != nullptr;
+        const GBuf gls(P.ln_stat, lnst ? sg.act_bytes / (unsigned)(D / 4) : 0u);
+        const unsigned so_ln = (lnst && row_ok && gq == 0 && part == 0) ? phys * 16u : STRIP_OOB;
         {   // Qn = LN1(x) on the own columns
             StripRegs<D> F;
             xp_row<D>(F, xps);
@@ -486,15 +490,13 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwd
             for (int c = 0; c < NCT; ++c)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Qno.v[c][r] = (Xo.v[c][r] - mean) * rstd * lwo.v[c][r] + lbo.v[c][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mean), gls.r, (int)so_ln, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rstd), gls.r, (int)(so_ln + (so_ln == STRIP_OOB ? 0u : 4u)), 0, 0);
         }
         SEQN_STAMP(2);
         {   // k = x Wk^T + bk
             part_cols<NCT>(bias, P.b_in[g] + D, c0);
-#ifdef AMID_EXP_NO_QN_Y          // (diagnostic builds: what the launch would gain if qn / y were not stored -- the weight gradients read them)
-            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 2), c0, [&](int ct, int j) { (void)ct; (void)j; });
-#else
-            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 2), c0, [&](int ct, int j) { part_spread<NCT>(gqn, off_own, Qno, ct, j, 1); });
-#endif
+            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 2), c0, [&](int ct, int j) { if (!lnst) part_spread<NCT>(gqn, off_own, Qno, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ko.v[c] = acc[c] + bias.v[c];
         }
@@ -609,6 +611,8 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwd
             for (int c = 0; c < NCT; ++c)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Yo.v[c][r] = (Ro.v[c][r] - mean) * rstd * lwo.v[c][r] + lbo.v[c][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mean), gls.r, (int)(so_ln + (so_ln == STRIP_OOB ? 0u : 8u)), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rstd), gls.r, (int)(so_ln + (so_ln == STRIP_OOB ? 0u : 12u)), 0, 0);
         }
         xp_write<NCT>(xps, c0, Yo);                         // (the o fragments were read two barriers ago)
         {   // h = relu(drop1(y C1^T + c1))
@@ -632,9 +636,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwd
             SEQN_STAMP(15);
             part_cols<NCT>(bias, P.b2[g], c0);
             seqn_product_xp<D, NCT>(acc, xps, ring, w16(last ? l : l + 1, 1), c0, [&](int ct, int j) {
-#ifndef AMID_EXP_NO_QN_Y
-                part_spread<NCT>(gy, off_own, Yo, ct, j, 1);
-#endif
+                if (!lnst) part_spread<NCT>(gy, off_own, Yo, ct, j, 1);
                 part_spread<NCT>(gh, off_own, Ho, ct, j, 3);
             });
 #pragma unroll

@@ -13,6 +13,10 @@ struct SeqLayer {
     const float* w1[2]; const float* b1[2]; const float* w2[2]; const float* b2[2];
     float* x;                           // this layer's INPUT rows (written for layers >= 1: the previous layer's output)
     float* qn; float* q; float* k; float* v; float* o; float* stats; float* r; float* y; float* h;
+    // optional [2M][4] (seqn_fwd_px_kernel only): with it the layer does NOT store qn and y (two of its nine saved tensors: 13 MB at the
+    // headline shape) but the row statistics they are rebuilt from -- (mean, rstd) of LayerNorm 1 over x and of LayerNorm 2 over r; the
+    // backward strips rebuild them from x / r anyway, and the weight gradients apply the affine map while staging their operand
+    float* ln_stat;
 };
 
 struct SeqFwdArgs {

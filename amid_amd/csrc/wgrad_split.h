@@ -39,12 +39,17 @@ constexpr size_t WGS_LDS_FIXED = (size_t)6 * 128 * WGS_COL_BYTES + (size_t)16 * 
 
 // the rows a launch walks: M rows per domain in `splits` ranges, or -- row_domain != nullptr -- only the live sequences' (see WgradArgs)
 struct WgsRows { int M, splits, rows_per_split; const long long* row_domain; int B, T; };
+// optional: the X operand is a LayerNorm output that was not stored (seq_fwd.h SeqLayer::ln_stat) -- xin points at the LayerNorm's INPUT rows,
+// stat at the rows' (mean, rstd) pairs (row stride stat_ld floats), gam / bet at the gain and bias: the staged value is
+// (x - mean) rstd gam + bet, the forward's own expression
+struct WgsLn { const float* stat; int stat_ld; const float* gam; const float* bet; };
 
 // One workgroup (eight waves) = one 128 x 128 tile over the rows of (domain g, split): acc = this wave's 16 x 128 block (rows 16 w ..,
 // MFMA C layout, eight column tiles); the column sums of dY go to bias_out [128].  dy / xin point at the tile's first column.
 template <int NTERM, bool HINT>
 __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __restrict__ dy, int ldy, const float* __restrict__ xin, int ldx,
-                                                 int g, int split, const WgsRows& a, f32x4 (&acc)[8], float* __restrict__ bias_out) {
+                                                 int g, int split, const WgsRows& a, f32x4 (&acc)[8], float* __restrict__ bias_out,
+                                                 const WgsLn ln = WgsLn{nullptr, 0, nullptr, nullptr}) {
     constexpr int D = 128;
     static_assert(NTERM == 6 || NTERM == 9, "piece pairs kept");
     constexpr int NTn = D / 16;
@@ -85,10 +90,13 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
     for (int t = 0; t < NTn; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 pyA[2], pxA[2], pyB[2], pxB[2];              // two chunks in flight: a chunk's MFMA phase alone is too short to cover a load's latency
+    float2 lsA[2], lsB[2];                              // (WgsLn: the rows' statistics travel with them)
+    const bool has_ln = ln.stat != nullptr;             // (block-uniform)
+    float4 lgam = make_float4(1.f, 1.f, 1.f, 1.f), lbet = make_float4(0.f, 0.f, 0.f, 0.f);
     const float inv_T = HINT ? 1.0f / (float)a.T : 0.f;
     // every load of chunk c0, unconditionally and branch-free (a branch around a load makes the compiler wait for it on the spot): rows
     // beyond the split's range re-read its last row and are zeroed when the chunk is staged
-    auto fetch = [&](int c0, float4 (&py)[2], float4 (&px)[2]) {
+    auto fetch = [&](int c0, float4 (&py)[2], float4 (&px)[2], float2 (&ls)[2]) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int v = min(c0 + 2 * rr + k, local_end - 1);
@@ -101,14 +109,21 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
             }
             py[k] = ld4(dy + row * ldy + 4 * cq);
             px[k] = ld4(xin + row * ldx + 4 * cq);
+            ls[k] = has_ln ? *reinterpret_cast<const float2*>(ln.stat + row * ln.stat_ld) : make_float2(0.f, 1.f);
         }
     };
     // this thread's 4-byte slot in column 4 cq (+ j columns): k-group rr >> 2 of the column, swizzled (columns 4 cq .. 4 cq + 3 share pi)
     const int wr_off = 4 * cq * WGS_COL_BYTES + 16 * ((rr >> 2) ^ wgs_pi(cq & 3)) + 4 * (rr & 3);
     const int rd_sw = 16 * (gq ^ wgs_pi(i >> 2));
     const int rd_y = (w * 16 + i) * WGS_COL_BYTES + rd_sw, rd_x = i * WGS_COL_BYTES + rd_sw;
-    auto chunk = [&](int c0, float4 (&py)[2], float4 (&px)[2]) {       // stage chunk c0 (in py / px), refill them with chunk c0 + 2, multiply
+    auto chunk = [&](int c0, float4 (&py)[2], float4 (&px)[2], float2 (&ls)[2]) {       // stage chunk c0 (in py / px), refill them with chunk c0 + 2, multiply
         __syncthreads();                               // previous chunk fully consumed
+        if (has_ln) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                px[k] = make_float4((px[k].x - ls[k].x) * ls[k].y * lgam.x + lbet.x, (px[k].y - ls[k].x) * ls[k].y * lgam.y + lbet.y,
+                                    (px[k].z - ls[k].x) * ls[k].y * lgam.z + lbet.z, (px[k].w - ls[k].x) * ls[k].y * lgam.w + lbet.w);
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             // the rows past the split's end, by selection.  (History: zeroing by a multiplication with a 0 / 1 factor -- v_pk_mul_f32 / v_pk_fma_f32 with op_sel on the
@@ -132,7 +147,7 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
             *reinterpret_cast<unsigned*>(xq) = sx.hi; *reinterpret_cast<unsigned*>(xq + PLANE) = sx.mid; *reinterpret_cast<unsigned*>(xq + 2 * PLANE) = sx.lo;
         }
         __syncthreads();
-        fetch(c0 + 2 * WGS_ROWS, py, px);               // unconditionally (a skipped refill would cost a register copy and a wait here)
+        fetch(c0 + 2 * WGS_ROWS, py, px, ls);           // unconditionally (a skipped refill would cost a register copy and a wait here)
         const wg_v4u y0 = *reinterpret_cast<const wg_v4u*>(Yt + rd_y), y1 = *reinterpret_cast<const wg_v4u*>(Yt + PLANE + rd_y),
                      y2 = *reinterpret_cast<const wg_v4u*>(Yt + 2 * PLANE + rd_y);
 #pragma unroll
@@ -147,10 +162,11 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
             acc[t] = c;
         }
     };
-    if (local_beg < local_end) { fetch(local_beg, pyA, pxA); fetch(local_beg + WGS_ROWS, pyB, pxB); }
+    if (has_ln) { lgam = ld4(ln.gam + 4 * cq); lbet = ld4(ln.bet + 4 * cq); }      // this thread's four columns, every chunk
+    if (local_beg < local_end) { fetch(local_beg, pyA, pxA, lsA); fetch(local_beg + WGS_ROWS, pyB, pxB, lsB); }
     for (int c0 = local_beg; c0 < local_end; c0 += 2 * WGS_ROWS) {      // an odd chunk count multiplies one chunk of zeros
-        chunk(c0, pyA, pxA);
-        chunk(c0 + WGS_ROWS, pyB, pxB);
+        chunk(c0, pyA, pxA, lsA);
+        chunk(c0 + WGS_ROWS, pyB, pxB, lsB);
     }
     __syncthreads();
     st4(scratch + rr * D + 4 * cq, bsum);              // [16][D]

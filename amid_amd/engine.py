@@ -404,6 +404,13 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             pl.red_entries_t, pl.red_n_t, pl.red_max_t = pl._build_reduce_table(self, live=True, pos=False)
         return pl.red_entries_t, pl.red_n_t, pl.red_blk_t
 
+    def _ln_stat(self, pl: SasrecPlan):
+        """(tensors, host pointer array) of the per-layer row statistics [2 M][4] a forward stores instead of qn / y."""
+        if not hasattr(pl, "ln_stat"):
+            pl.ln_stat = [torch.zeros(2 * pl.shape.M, 4, dtype=torch.float32, device=self.device) for _ in range(2)]
+            pl._ln_stat_ptrs = ptr_array([t.data_ptr() for t in pl.ln_stat])
+        return pl.ln_stat, pl._ln_stat_ptrs
+
     def _hidg(self, pl: SasrecPlan) -> torch.Tensor:
         if not hasattr(pl, "hidg"):
             pl.hidg = torch.zeros(pl.shape.B, lib().value("amid_scorer_vec_floats", pl.shape.NI, self.hid), dtype=torch.float32, device=self.device)
@@ -616,8 +623,16 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 if not getattr(pl, "w16_written", False):      # (the train step's gather K1 wrote them with extra workgroups)
                     L.call("amid_sas_weights_bf16_planes", src, 24, D, 0, planes, w16.data_ptr(), s)
                 pl.w16_written = False
-                L.call("amid_sas_seq_fwd_split_f32" if split else "amid_sas_seq_fwd_bf16w_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:],
-                       pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(), s)
+                if split and getattr(pl, "tail2", False) and lf is not None:
+                    # the folded step: qn / y are not stored -- row statistics instead (pl.ln_stat); the weight gradients rebuild them
+                    # (c: x, 12 parameter families, qn, q, k, v, o, stats, r, y, h)
+                    L.call("amid_sas_seq_fwd_split_lnstat_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
+                           pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(), s)
+                    pl.lnstat_fwd = True
+                else:
+                    pl.lnstat_fwd = False
+                    L.call("amid_sas_seq_fwd_split_f32" if split else "amid_sas_seq_fwd_bf16w_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:],
+                           pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(), s)
             else:
                 L.call("amid_sas_seq_fwd_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:], pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr,
                        SASREC_P_DROP, s)
@@ -974,9 +989,19 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         # NOTE: pl.x[0] is the gathered-row buffer xg, still intact here (its gradient lives in dxg)
         t2 = bool(getattr(pl, "tail2", False) and pl.strip and not seq)
         if t2:      # the last phase of the step's index sort (run heads) rides in the weight gradients; the embedding backward is done
-            L.call("amid_sas_wgrad_rows_sort_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits,
-                   ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]), ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]),
-                   self._own_rows(pl), B, T, self._wgrad_mode(D), self._sort_plan_c(pl), s)
+            if getattr(pl, "lnstat_fwd", False):      # the forward stored row statistics instead of qn / y: the operands of q's and conv1's
+                for l in (0, 1):                       # gradients are rebuilt from x / r while they are staged
+                    xx[6 * l + 0], xx[6 * l + 4] = pl.x[l].data_ptr(), pl.r[l].data_ptr()
+                fam = lambda fmt: ptr_array([fp.ptr(fmt.format(d=d, l=l)) for l in (0, 1) for d in (1, 2)])      # noqa: E731  [layer][domain]
+                L.call("amid_sas_wgrad_rows_sort_ln_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits,
+                       ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]), ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]),
+                       self._own_rows(pl), B, T, self._wgrad_mode(D), self._sort_plan_c(pl), self._ln_stat(pl)[1],
+                       fam("sac{d}.attention_layernorms.{l}.weight"), fam("sac{d}.attention_layernorms.{l}.bias"),
+                       fam("sac{d}.forward_layernorms.{l}.weight"), fam("sac{d}.forward_layernorms.{l}.bias"), s)
+            else:
+                L.call("amid_sas_wgrad_rows_sort_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits,
+                       ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]), ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]),
+                       self._own_rows(pl), B, T, self._wgrad_mode(D), self._sort_plan_c(pl), s)
             self._enqueue_grad_tail(pl, live, seq)
             return
         L.call("amid_sas_wgrad_rows_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits, ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]),

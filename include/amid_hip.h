@@ -804,6 +804,21 @@ int amid_sas_strip_qkv_bwd_emb_f32(const float* dq, const float* dk, const float
 int amid_sas_wgrad_rows_sort_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
                                  float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, const void* sort_plan,
                                  void* stream);
+/* The one-launch forward on bf16 pieces saving SEVEN tensors per layer instead of nine: qn = LN1(x) and y = LN2(r) (model_seq.py:373, :381)
+ * are not stored, ln_stat[l] [2 B T][4] receives every row's (mean, rstd) of the two LayerNorms instead.  The backward strips rebuild the
+ * normalised rows from x / r anyway; amid_sas_wgrad_rows_sort_ln_f32 (x[6 l + 0] = the layer's x, x[6 l + 4] = its r; ln1_* / ln2_*: 2 n_layers
+ * pointers [layer][domain]) rebuilds the two operands as (row - mean) rstd gamma + beta while it stages them.  D = 128. */
+int amid_sas_seq_fwd_split_lnstat_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                      const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                      const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                      const float* const* w2, const float* const* b2, float* const* ln_stat, float* const* q, float* const* k,
+                                      float* const* v, float* const* o, float* const* stats, float* const* r, float* const* h,
+                                      const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                                      const void* step_state, int train, float p_drop, const void* w16x3, void* stream);
+int amid_sas_wgrad_rows_sort_ln_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
+                                    float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, const void* sort_plan,
+                                    const float* const* ln_stat, const float* const* ln1_w, const float* const* ln1_b,
+                                    const float* const* ln2_w, const float* const* ln2_b, void* stream);
 /* amid_grad_tail_f32's first launch over a compact sorted list (pos_sorted = rows of grad_rows) + the position rows' gradients
  * dpos0 / dpos1 [T, D] = the sum over the live sequences of a domain (live: amid_live_list_i32) of their rows of grad_rows, in list order.
  * Phase B of the segment reduce is left to amid_optimizer_step_spans_f32. */
