@@ -457,6 +457,7 @@ template <int D, int NW> struct SeqRing3 {
         if (!hi_ready) plane(hslot(), cur);                  // (never in steady state: kept for a ring that is started without first())
         rest_late = !hi_ready;
         if (!rest_ready) { plane(mslot(), cur + (size_t)D * D); plane(lslot(), cur + (size_t)2 * D * D); }
+        hold_next = false;
     }
     __device__ __forceinline__ void begin(const unsigned short* __restrict__ Wnext) { nxt = Wnext; }
     __device__ __forceinline__ void pre_pass1() {            // (only when the hi plane was requested by next() itself)
@@ -469,7 +470,6 @@ template <int D, int NW> struct SeqRing3 {
         __syncthreads();
         plane(hslot(), nxt);
         cur = nxt; hi_ready = true; rest_ready = false;
-        hold_next = false;
     }
 };
 
@@ -588,9 +588,18 @@ __device__ __forceinline__ void seqn_product_xp(f32x4 (&acc)[NCT], const float* 
 #pragma unroll
     for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     ring.begin(wn16);
-    part_mma_xp<D, NCT>(acc, xps, ring, c0);
+#ifndef AMID_EXP_STORES_LAST
+    // the deferred stores (an earlier product's result) leave IN FRONT of the matrix instructions: the ring's waits are vmcnt(0), and stores
+    // issued behind the product were the youngest operations every next() then sat out (a store's acknowledgement takes 1 - 2 k cycles);
+    // issued here they have the whole hi pass to complete before mid_sync's wait
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) { stores(ct, 1); stores(ct, 3); }
+#endif
+    part_mma_xp<D, NCT>(acc, xps, ring, c0);
+#ifdef AMID_EXP_STORES_LAST
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) { stores(ct, 1); stores(ct, 3); }
+#endif
 }
 
 // the own column tiles of a per-column vector held whole: two parts -- selects on the wave-uniform part index; more parts -- loaded

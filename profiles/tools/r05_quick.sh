@@ -1,6 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_timed_path.py -x -q -k "folded or fifteen or trajectory or real_tokenised" 2>&1 | tail -12 | cut -c1-250
-bash profiles/tools/timeline_quick.sh r5h > /dev/null 2>&1; cat gpurun_out/r5h/step_timeline.txt
-python3 bench.py --no-cpu-baseline --no-stress > gpurun_out/bench_lnstat.json 2>/dev/null; python3 -c "
-import json; d=json.load(open('gpurun_out/bench_lnstat.json')); print(d['ms_per_step'], d['window_ms_per_step'], d['kernels']['amid_sas_seq_fwd_split_lnstat_f32']['avg_launch_us'])"
+AMID_LIB_PATH=$GRAFT_REPO_ROOT/profiles/tools/_diag/libamid_hip_ringearly.so timeout 900 python -m pytest tests/test_gpu_seqn.py -x -q 2>&1 | tail -2
+for v in stamp0 stamp1 stamp0 stamp1; do echo "== $v"; AMID_DIAG_LIB=$GRAFT_REPO_ROOT/profiles/tools/_diag/libamid_hip_$v.so python3 profiles/tools/seqn_stamps.py 2>&1 | grep -v amdgpu | cut -c1-900; done | tee gpurun_out/stamps_ringearly.txt
+bash profiles/tools/ab_variants.sh ringearly
