@@ -11,7 +11,7 @@
 //     the strip's two waves through LDS ([strip][column tile][lane] float4); the ones that come from memory (dq, dk, dv) are loaded
 //     whole by both.  Row sums of the LayerNorm backward are taken over the whole row by both waves (same order as the strip build);
 //     element-wise work and stores cover the own columns.
-//   Measured (profiles/tools/seqn_bwd_stamps.py, bench.py with AMID_SEQ_BACKWARD=1 AMID_SEQ_BWD_VARIANT=1|2): the products themselves run at
+//   Measured (profiles/tools/seqn_bwd_stamps.py, bench.py --set SEQ_BACKWARD=1 --set SEQ_BWD_VARIANT=1|2 on the diagnostic library): the products themselves run at
 //   the matrix pipe's rate here (2.9 - 3.4 us per 64 x 128 x 128 slab pair against 6.5 in the strip build), but what surrounds them does not
 //   shrink: the attention core's operand requests (24 per wave, 4.4 us for the eight waves of a CU), the barriers' skew, the first-use
 //   round trips of dk / d_o.  In-kernel 112 - 116 us against 109; launch 124 - 128 against 124 - 126 us at cfg 2, 240.8 against 238.8 at
@@ -415,7 +415,11 @@ int launch_seqn_bwd(const SeqBwdArgs& a, const StripGeom& sg, int D, int mma_bf1
         return seqn_bwd_launch_t<64, 2, 4, false>(a, sg, stream);            // (T <= 16 too: one strip stays empty)
     }
     if (D != 128) return AMID_ERR_UNSUPPORTED;
+#ifdef AMID_DIAG_VARIANTS     // four strips at D 128: measured level with the strip build and over the register budget --
     if (sg.T > 32) return mma_bf16 ? seqn_bwd_launch_t<128, 4, 2, true>(a, sg, stream) : seqn_bwd_launch_t<128, 4, 2, false>(a, sg, stream);
+#else                         // built into the diagnostic library only (profiles/tools/build_diag.sh); the product runs seq_bwd_kernel there
+    if (sg.T > 32) return AMID_ERR_UNSUPPORTED;
+#endif
     if (sg.T > 16) return mma_bf16 ? seqn_bwd_launch_t<128, 2, 4, true>(a, sg, stream) : seqn_bwd_launch_t<128, 2, 4, false>(a, sg, stream);
     return mma_bf16 ? seqn_bwd_launch_t<128, 1, 8, true>(a, sg, stream) : seqn_bwd_launch_t<128, 1, 8, false>(a, sg, stream);
 }

@@ -761,7 +761,15 @@ extern "C" int amid_sas_seq_bwd_supported(int B, int T, int D, int H) {
 }
 
 // Which build of the one-launch backward runs: 0 = auto (= 1), 1 = a wave per strip (seq_bwd_kernel), 2 = the N-split build (two waves per
-// strip, a wave per head in the attention core: sasrec_seqn_bwd.hip).  v < 0 only queries.  Returns the previous value.
+// strip, a wave per head in the attention core: sasrec_seqn_bwd.hip; at T > 32, D 128 that build exists in the diagnostic library only
+// -- -DAMID_DIAG_VARIANTS -- and the product answers 2 with the strip build).  v < 0 only queries.  Returns the previous value.
+extern "C" int amid_diag_variants(void) {
+#ifdef AMID_DIAG_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 static int g_seq_bwd_variant = 0;
 extern "C" int amid_sas_seq_bwd_variant(int v) {
     const int prev = g_seq_bwd_variant;

@@ -17,7 +17,6 @@ Memory layout (all fp32, resident in HBM for the life of the engine):
 from __future__ import annotations
 
 import ctypes
-import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -48,7 +47,11 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     #   DENSE_EXCHANGE               how the dense gradient crosses the ranks (engine_dp.DataParallelMixin)
     SHORT_TILE_BUILDS = False    # (BERT4Rec's row-tile kernels also exist as *_rt3 / *_rt4 / *_rt5: 48- / 64- / 80-row tiles, csrc/Makefile)
     STRIP_KERNELS = True         # fp32: the layer's GEMM chains run as register-resident strip kernels (csrc/sasrec_strip.hip)
-    BF16_STRIP = os.environ.get("AMID_BF16_STRIP", "1") != "0"      # compute = "bf16" on the strip path (the forward's products in bf16)
+    BF16_STRIP = True            # compute = "bf16" on the strip path (the forward's products in bf16)
+    # (No path switch is read from the environment: A/B tools and tests set these class attributes -- bench.py --set NAME=VALUE,
+    # profiles/tools/*.py -- and diagnostic BUILDS of the library are selected with AMID_LIB_PATH, amid_amd/_lib.py.)
+    SEQ_FWD_VARIANT = 0          # != 0: amid_sas_seq_fwd_variant (which build of the one-launch forward runs: diagnostics)
+    SEQ_BWD_VARIANT = 0          # != 0: amid_sas_seq_bwd_variant
 
     def _dense_names(self) -> List[Tuple[str, Tuple[int, ...]]]:
         return sasrec_dense_names(self.Tpos, self.D, self.hid, self.itc_bs, self.dr, self.inc_bs)
@@ -64,10 +67,10 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         """itc_bs > 0: SASRec(isItC=True, bs=itc_bs, threshold2=itc_threshold) -- InterComp after the encoders
         (model_seq.py:426-431); every batch must then hold exactly itc_bs rows (trans_bs is Linear(bs, 1) over the batch)."""
         L = lib()        # raises AmidLibraryError when the HIP library is missing: no fallback
-        if os.environ.get("AMID_SEQ_FWD_VARIANT"):          # A/B measurements of the fused forward's builds (amid_sas_seq_fwd_variant)
-            L.value("amid_sas_seq_fwd_variant", int(os.environ["AMID_SEQ_FWD_VARIANT"]))
-        if os.environ.get("AMID_SEQ_BWD_VARIANT"):          # ... and of the fused backward's (amid_sas_seq_bwd_variant)
-            L.value("amid_sas_seq_bwd_variant", int(os.environ["AMID_SEQ_BWD_VARIANT"]))
+        if self.SEQ_FWD_VARIANT:          # A/B measurements of the fused forward's builds (amid_sas_seq_fwd_variant)
+            L.value("amid_sas_seq_fwd_variant", int(self.SEQ_FWD_VARIANT))
+        if self.SEQ_BWD_VARIANT:          # ... and of the fused backward's (amid_sas_seq_bwd_variant)
+            L.value("amid_sas_seq_bwd_variant", int(self.SEQ_BWD_VARIANT))
         self.itc_bs, self.itc_threshold = int(itc_bs), float(itc_threshold)
         # inc_bs > 0: SASRec(isInC=True, bs=inc_bs, threshold1=inc_threshold) -- InnerComp on the gathered rows before the encoders,
         # which then see 2 * seq_len tokens per row (model_seq.py:398-401, :422-424; csrc/innercomp.hip); batches of exactly inc_bs rows
@@ -218,7 +221,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # compute = "fp32": the strip backward's data-gradient products on the bf16 matrix cores at fp32 accuracy (three bf16 pieces per operand,
     # six piece pairs: csrc/strip_gemm.h strip_mma16x6, strip_chain.h RingP3), from three-plane images of the TRANSPOSED weights; "0": fp32
     # matrix instructions
-    BWD_SPLIT = os.environ.get("AMID_BWD_SPLIT", "1") != "0"
+    BWD_SPLIT = True
 
     # ------------------------------------------------------------------ launch sequences
     def enqueue_prepare(self, pl: SasrecPlan, sparse: bool, bump_step: bool = False, defer_sort: bool = False) -> None:
@@ -323,19 +326,19 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self.stream.wait_event(self.ev_sorted)
             self._sort_pending = False
 
-    SORT_RIDERS = os.environ.get("AMID_SORT_RIDERS", "1") != "0"
+    SORT_RIDERS = True
     # compute = "bf16": the weight gradients' products on the bf16 matrix cores too (amid_sas_wgrad_rows_f32 mma_bf16); 0: fp32 products
-    BF16_WGRAD = os.environ.get("AMID_BF16_WGRAD", "1") != "0"
+    BF16_WGRAD = True
     # compute = "fp32": the weight gradients' products on the bf16 matrix cores at fp32 accuracy -- every operand element as three bf16
     # pieces, six ("6", the default) or nine ("9") piece pairs (csrc/sasrec_bwd.hip sas_wgrad_split_kernel; D = 128); "0": fp32 matrix
     # instructions.  Error against the fp64 product 3.8e-7 of the largest entry either way, 4.4e-7 for the fp32 instructions.
-    WGRAD_SPLIT = os.environ.get("AMID_WGRAD_SPLIT", "6")
+    WGRAD_SPLIT = "6"
     # compute = "fp32": the one-launch forward's twelve projections on the bf16 matrix cores at fp32 accuracy too (three bf16 pieces per
     # operand, six piece pairs; the pieces are made once, by the wave that produced the operand, and cross the strip's column parts as
     # operand fragments: amid_sas_seq_fwd_split_f32, csrc/sasrec_seqn.hip seqn_fwd_px_kernel; weight images by the gather's extra
     # workgroups).  Every saved tensor within 3e-6 of the fp32 build's; 153 k cycles against 187 k, step 0.3562 -> 0.3510 ms at cfg 2 (the
     # bf16-dense kernel runs at a lower clock: 15 % fewer cycles, 7 % less time).  "0": fp32 matrix instructions.
-    FWD_SPLIT = os.environ.get("AMID_FWD_SPLIT", "1") != "0"
+    FWD_SPLIT = True
     # The train step's encoder backward (data gradients) as ONE launch over the live sequences where csrc/sasrec_strip.hip covers the
     # shape (amid_sas_seq_bwd_f32): "auto" = where it wins.  It tiles one sequence per workgroup, a whole CU each, so the step's sort
     # riders find no free CU in it and the sort goes back to the side stream (a fork and a join, ~10 us of a replayed graph).  Measured
@@ -343,8 +346,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # rounds against 400 row tiles in two uneven ones, 0.690 against 0.740 ms; B 4096 = 16 rounds against 12.5 rounds of denser row
     # tiles, 4.75 against 4.48 ms.  So: more live sequences than CUs, at most two rounds.  T <= 32 (csrc/sasrec_seqn_bwd.hip: two strips x
     # four column parts per sequence): B 256, T 20 runs 80 strip tiles per launch on 256 CUs -- 111 us in five launches against 67.8 in one,
-    # 0.267 -> 0.243 ms per step with the sort back on its side stream; taken for B <= n_CU.  AMID_SEQ_BACKWARD = 1 / 0 forces it on / off.
-    SEQ_BACKWARD = os.environ.get("AMID_SEQ_BACKWARD", "auto")
+    # 0.267 -> 0.243 ms per step with the sort back on its side stream; taken for B <= n_CU.  SEQ_BACKWARD = "1" / "0" forces it on / off.
+    SEQ_BACKWARD = "auto"
 
     def _seq_backward(self, pl: SasrecPlan) -> bool:
         if not getattr(pl, "seq_bwd", False) or self.itc_bs or self.SEQ_BACKWARD in ("0", False):
@@ -443,7 +446,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # step), so doing it twice LOSES -- catch-up 14.4 + K1 8.1 us -> K1 24.5 us, optimizer 7.4 -> 15.6 us, 0.3695 -> 0.3829 ms per step;
     # cfg 4 0.239 -> 0.268.  Off by default; "auto" folds only where the replay is next to nothing (an epoch of at most FOLD_MAX_GAP
     # batches, e.g. a handful of batches replayed over and over), "1" always.
-    FOLD_CATCHUP = os.environ.get("AMID_FOLD_CATCHUP", "0")
+    FOLD_CATCHUP = "0"
     FOLD_MAX_GAP = 8
     catchup_gap_hint: Optional[int] = None          # batches per epoch when no input pool says so (the CLI's per-batch path)
 

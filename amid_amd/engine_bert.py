@@ -83,8 +83,8 @@ class BertPlan(SasrecPlan):
         self.dpre = f(2 * M, F)
         # 2 domains x 12 tiles x splits workgroups: 21 splits = 504, two per CU, for the bf16-piece products (72 KB of LDS each); 10 = 240,
         # one per CU, for the fp32 matrix instructions (AMID_WGRAD_SPLIT=0).  Measured step 0.6239 (21) / 0.6252 (10) / 0.6398 (14) ms
-        default_splits = "21" if os.environ.get("AMID_WGRAD_SPLIT", "6") in ("6", "9") else "10"
-        self.splits = max(1, min(int(os.environ.get("AMID_BERT_WGRAD_SPLITS", default_splits)), M // 128))
+        default_splits = 21 if eng.WGRAD_SPLIT in ("6", "9") else 10
+        self.splits = max(1, min(int(self.WGRAD_SPLITS or default_splits), M // 128))
         self.w_part = [f(2, N_ENT, self.splits, D * D) for _ in range(2)]
         self.b_part = [f(2, N_ENT, self.splits, D) for _ in range(2)]
 

@@ -35,7 +35,7 @@ class DataParallelMixin:
     # "allreduce" = its own RCCL all-reduce next to the all-gather of the sparse rows (two collectives, ~2 x 1.7 MB on the wire per
     # rank whatever the world size) -- what BASELINE.json's north_star words ("RCCL all-reduce of dense parameter grads").  Both are
     # bit-identical across replicas; bench.py --dense-exchange measures either.
-    DENSE_EXCHANGE = os.environ.get("AMID_DENSE_EXCHANGE", "gather")
+    DENSE_EXCHANGE = "gather"
 
     def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False, umax: Optional[int] = None, dense: Optional[str] = None) -> None:
         """One data-parallel step: local grads -> dense all-reduce + ONE sparse all-gather -> merge -> Adam.

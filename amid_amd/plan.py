@@ -292,13 +292,14 @@ class SasrecPlan:
         # end of backward (2 layers x 2 domains x 6 weights x 21 splits = 504 workgroups, two per CU)
         self.dpre1, self.dpre2, self.dr = ([f(2 * M, D), f(2 * M, D)] for _ in range(3))
         self.dq_l, self.dk_l, self.dv_l = [self.dq, f(2 * M, D)], [self.dk, f(2 * M, D)], [self.dv, f(2 * M, D)]
-        self.splits = max(1, min(int(os.environ.get("AMID_WGRAD_SPLITS", "21")), M // 128))
+        self.splits = max(1, min(int(self.WGRAD_SPLITS or 21), M // 128))
         self.w_part = [f(2, 6, self.splits, D * D) for _ in range(2)]
         self.b_part = [f(2, 6, self.splits, D) for _ in range(2)]
         self.pos_splits = max(1, min(8, B // 16))
         self.dpos_part = f(self.pos_splits, 2, T, D)
 
     LIVE_ROWS_BWD = True       # BertPlan: False (its backward kernels take no row_domain hint)
+    WGRAD_SPLITS = 0           # row splits of the weight-gradient launch (0: the default, 21 -- BertPlan: 21 / 10 by the products' mode)
 
     def _build_reduce_table(self, eng: "SasrecEngine", live: bool = False, seq: bool = False, pos: bool = True):
         L = lib()

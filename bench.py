@@ -521,15 +521,18 @@ def main():
     ap.add_argument("--data", default="real", choices=("real", "synthetic"),
                     help="real (default where the workload has a fixture: cfg2, cfg3, cfg4): the reference's training CSV as tokenised by "
                          "its own dataset class (tests/golden/tok_*.npz); synthetic: batches drawn to the file's statistics")
-    ap.add_argument("--steps-per-graph", type=int, default=int(os.environ.get("AMID_STEPS_PER_GRAPH", "4")),
+    ap.add_argument("--steps-per-graph", type=int, default=4,
                     help="consecutive train steps captured into one replayed hipGraph (single GPU, pool input; default 4 = what the "
                          "CLI's train loop replays, amid_amd/train_sr.py STEPS_PER_GRAPH)")
     ap.add_argument("--no-stress", action="store_true", help="skip the cfg5 gather / scatter stress appended to the headline line")
     ap.add_argument("--no-fused-tail", action="store_true",
                     help="A/B: round 4's fifteen-launch step (SasrecEngine.FUSED_TAIL = False) instead of the folded twelve-launch one")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B: set a path switch of the engine class before it is built (SasrecEngine.NAME, e.g. SEQ_BACKWARD=0, "
+                         "FWD_SPLIT=False, SEQ_FWD_VARIANT=42); the line then carries config.switches and is not the headline")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
                     help="cfg2 = the headline configuration (default); cfg5-* = synthetic gather / scatter stress (SURVEY.md 8(d))")
-    ap.add_argument("--dense-exchange", default=os.environ.get("AMID_DENSE_EXCHANGE", "gather"), choices=("gather", "allreduce"),
+    ap.add_argument("--dense-exchange", default="gather", choices=("gather", "allreduce"),
                     help="N > 1: how the flat dense gradient crosses the ranks -- gather: behind the sparse rows in the step's one "
                          "all-gather; allreduce: its own RCCL all-reduce next to it (amid_amd/engine.py DENSE_EXCHANGE)")
     args = ap.parse_args()
@@ -562,12 +565,24 @@ def main():
     Bw = wl["B"]
     T = wl.get("T", globals()["T"])
     globals()["D"] = wl.get("D", D)          # (cfg1: emb_dim 64; every formula below reads the module's D)
+    switches = {}
+    for kv in args.set:                       # A/B only: class attributes of the engine (and of its plan for WGRAD_SPLITS)
+        name, _, val = kv.partition("=")
+        from amid_amd.plan import SasrecPlan
+        holder = SasrecPlan if name == "WGRAD_SPLITS" else SasrecEngine
+        if not hasattr(holder, name):
+            raise SystemExit(f"--set {kv}: {holder.__name__} has no switch {name}")
+        cur = getattr(holder, name)
+        new = (val not in ("0", "False", "false")) if isinstance(cur, bool) else type(cur)(val)
+        setattr(holder, name, new)
+        switches[name] = new
+    if args.no_fused_tail:
+        SasrecEngine.FUSED_TAIL = False
+        switches["FUSED_TAIL"] = False
     if args.model == "bert4rec":
         from amid_amd.engine_bert import Bert4recEngine
         eng = Bert4recEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234)
     else:
-        if args.no_fused_tail:
-            SasrecEngine.FUSED_TAIL = False
         eng = SasrecEngine(wl["n_rows"], D, T, HID, device=device, lr=5e-4, seed=1234, compute=args.dtype)
     init_params(eng, seed=0)                  # identical replicas on every rank
     pl = eng.plan(Bw, T, 1 + NEG, need_grad=True)
@@ -844,6 +859,8 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
+        if switches:
+            out["config"]["switches"] = {k: str(v) for k, v in switches.items()}          # an A/B line, not the headline
         if loader_incl:
             out["samples_per_s_loader_included"] = loader_incl
         if world > 1:

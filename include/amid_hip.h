@@ -626,8 +626,10 @@ int amid_sas_seq_fwd_split_f32(int n_layers, const float* const* x_in, float* xo
 int amid_sas_seq_bwd_supported(int B, int T, int D, int H);
 /* Which build of the one-launch backward runs (diagnostics, tests, A/B measurements): 0 = auto (= 1: the two measure the same), 1 = a wave per 16-row strip
  * (csrc/sasrec_strip.hip seq_bwd_kernel), 2 = the N-split build (csrc/sasrec_seqn_bwd.hip: eight waves per sequence, two per strip with
- * half the columns each, a wave per head in the attention core; same bits).  v < 0 only queries.  Returns the previous value.  Host state. */
+ * half the columns each, a wave per head in the attention core; same bits -- at T > 32, D 128 that build is compiled into the diagnostic
+ * library only, amid_diag_variants() = 1, and the product answers 2 with build 1).  v < 0 only queries.  Returns the previous value.  Host state. */
 int amid_sas_seq_bwd_variant(int v);
+int amid_diag_variants(void);      /* 1: a diagnostic build of the library (profiles/tools/build_diag.sh, -DAMID_DIAG_VARIANTS); the product: 0 */
 int amid_sas_seq_bwd_f32(int n_layers, const float* dxo, const unsigned char* tmq, const float* const* h, const float* const* r,
                          const float* const* x, const float* const* q, const float* const* k, const float* const* v,
                          const float* const* o, const float* const* stats, const float* const* ln1_w, const float* const* ln2_w,

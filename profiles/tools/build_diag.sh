@@ -1,12 +1,13 @@
 #!/bin/bash
 # Diagnostic build of the whole library with in-kernel s_memtime stamps (-DAMID_STRIP_STAMPS) into profiles/tools/_diag/ (git-ignored
-# like every .so; it travels to the GPU box with the snapshot).  The product library carries no stamps.
+# like every .so; it travels to the GPU box with the snapshot).  The product library carries no stamps and none of the builds only
+# A/B measurements reach (-DAMID_DIAG_VARIANTS: the four-strip N-split backward at D 128).
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd)
 O=$R/profiles/tools/_diag
 mkdir -p $O/obj
 cd $R/amid_amd/csrc
-FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -DAMID_STRIP_STAMPS $AMID_DIAG_EXTRA"
+FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -DAMID_STRIP_STAMPS -DAMID_DIAG_VARIANTS $AMID_DIAG_EXTRA"
 objs=""
 for f in *.hip; do
   /opt/rocm/bin/hipcc $FL -c $f -o $O/obj/${f%.hip}.o &

@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
 """Where the N-split fused forward's cycles go (csrc/sasrec_seqn.hip): a train step of the headline shape on the DIAGNOSTIC library
 (profiles/tools/build_diag.sh: s_memtime stamps of workgroup 0, last layer) -- per wave: ring wait, LayerNorm, every product, the
-attention core.  AMID_SEQ_FWD_VARIANT picks the build (default 42)."""
+attention core.  STAMP_VARIANT picks the build (default 42; set on the class, SasrecEngine.SEQ_FWD_VARIANT)."""
 import ctypes
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("AMID_SEQ_FWD_VARIANT", "42")
+VARIANT = int(os.environ.get("STAMP_VARIANT", "42"))
 import amid_amd._lib as _lib  # noqa: E402
 
 _lib.LIB_PATH = os.environ.get("AMID_DIAG_LIB") or os.path.join(ROOT, "profiles", "tools", "_diag", "libamid_hip_diag.so")
 import torch  # noqa: E402
 from amid_amd.engine import SasrecEngine  # noqa: E402
+
+SasrecEngine.SEQ_FWD_VARIANT = VARIANT
 from oracle import amid_oracle as orc  # noqa: E402
 
 B, T, D, hid, n_items = int(os.environ.get("STAMP_B", "256")), int(os.environ.get("STAMP_T", "50")), 128, 32, 3000
@@ -34,7 +36,7 @@ names = ["k:ring wait", "x read + LN1", "k product", "v: ring wait", "v product"
          "attention core", "stats + o parts out + ring wait", "o read + product + residual", "r out + ring wait", "r read + LN2",
          "c1 product + dropout + relu", "h out + ring wait", "h read + c2 product + epilogue"]
 order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
-nw = {42: 8, 22: 4, 24: 8, 14: 4, 18: 8}[int(os.environ["AMID_SEQ_FWD_VARIANT"])]
+nw = {42: 8, 22: 4, 24: 8, 14: 4, 18: 8}[VARIANT]
 for w in range(nw):
     t = [host[w * 64 + i] for i in order]
     tot = host[w * 64 + 63] - host[w * 64 + 62]
