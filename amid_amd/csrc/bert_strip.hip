@@ -50,7 +50,7 @@ template <int D, int LD> struct WDmaLd {
     __device__ __forceinline__ void piece(float* __restrict__ buf, const float* __restrict__ W, int k0) const {
         const unsigned voff = off[k0 & 1] + (unsigned)(k0 >> 1) * STRIDE2;
         const unsigned lds = __builtin_amdgcn_readfirstlane(
-            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(buf + (k0 * STRIP_WAVES + w) * 256));
+            lds_offset(buf + (k0 * STRIP_WAVES + w) * 256));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");

@@ -20,6 +20,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// The LDS byte offset of a pointer into the workgroup's shared memory, for instructions that take the address as a number (ds_read through
+// inline asm, M0 of the LDS-DMA loads).  A flat LDS address is { shared aperture, offset }: the low word IS the offset.  (The address-space
+// cast `(__attribute__((address_space(3))) T*)p` computes the same number behind a null check; where the compiler could not fold that check
+// it compared the aperture register itself -- "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base", a crash of the gfx950
+// backend that came and went with unrelated edits of sasrec_strip.hip.)
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(unsigned long long)p; }
 // wave index made provably wave-uniform for the compiler (scalar addressing, no waterfall loops)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 

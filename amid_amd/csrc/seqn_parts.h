@@ -41,7 +41,7 @@ template <int D, int NW> struct WDmaN {
     __device__ __forceinline__ void piece(float* __restrict__ buf, const float* __restrict__ W, int k0) const {
         const unsigned voff = off[k0 & 1] + (unsigned)(k0 >> 1) * STRIDE2;
         const unsigned lds = __builtin_amdgcn_readfirstlane(
-            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(buf + (k0 * NW + w) * 256));
+            lds_offset(buf + (k0 * NW + w) * 256));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
@@ -91,7 +91,7 @@ template <int D, int NW> struct SeqRing16 {
     __device__ __forceinline__ void piece(float* __restrict__ dst, const unsigned short* __restrict__ W, int k0) const {
         const unsigned voff = off0 + (unsigned)k0 * (unsigned)(NW * 64 / CPR) * (unsigned)(D * 2);      // NW * 4 rows further: n & 15 unchanged
         const unsigned lds = __builtin_amdgcn_readfirstlane(
-            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(dst + (k0 * NW + w) * 256));
+            lds_offset(dst + (k0 * NW + w) * 256));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
@@ -145,7 +145,7 @@ template <int D, int NW> struct SeqRing16x3 {
     __device__ __forceinline__ void piece(float* __restrict__ dst, const unsigned short* __restrict__ W, int k0) const {
         const unsigned voff = off0 + (unsigned)k0 * (unsigned)(NW * 64 / CPR) * (unsigned)(D * 2);
         const unsigned lds = __builtin_amdgcn_readfirstlane(
-            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(dst + (k0 * NW + w) * 256));
+            lds_offset(dst + (k0 * NW + w) * 256));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
@@ -428,7 +428,7 @@ template <int D, int NW> struct SeqRing3 {
     __device__ __forceinline__ void piece(float* __restrict__ dst, const unsigned short* __restrict__ W, int k0) const {
         const unsigned voff = off0 + (unsigned)k0 * (unsigned)(NW * 64 / CPR) * (unsigned)(D * 2);
         const unsigned lds = __builtin_amdgcn_readfirstlane(
-            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(dst + (k0 * NW + w) * 256));
+            lds_offset(dst + (k0 * NW + w) * 256));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
@@ -521,7 +521,7 @@ __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __re
     static_assert(PD1 < NSTEP && PD2 < NSTEP && 2 * PD1 + 2 < 16, "read-ahead against the step count and the lgkmcnt field");
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;
-    auto lds_addr = [](const float* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)p; };
+    auto lds_addr = [](const float* p) { return lds_offset(p); };
     auto mma = [&](const f32x4& wf, const f32x4& a16, const f32x4& c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(seqn_bf16x8, wf), __builtin_bit_cast(seqn_bf16x8, a16), c, 0, 0, 0);
     };

@@ -308,7 +308,7 @@ template <int D> struct WDma {
     __device__ __forceinline__ void piece(float* __restrict__ buf, const float* __restrict__ W, int k0) const {
         const unsigned voff = off[k0 & 1] + (unsigned)(k0 >> 1) * STRIDE2;
         const unsigned lds = __builtin_amdgcn_readfirstlane(
-            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(buf + (k0 * STRIP_WAVES + w) * 256));
+            lds_offset(buf + (k0 * STRIP_WAVES + w) * 256));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
@@ -385,7 +385,7 @@ template <int D> struct WDma16 {
     __device__ __forceinline__ void piece(float* __restrict__ buf, const float* __restrict__ W, int k0) const {
         const unsigned voff = off0 + (unsigned)k0 * (unsigned)(STRIP_WAVES * 64 / CPR) * (unsigned)(D * 2);      // 16 rows further: n & 15 unchanged
         const unsigned lds = __builtin_amdgcn_readfirstlane(
-            (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(buf + (k0 * STRIP_WAVES + w) * 256));
+            lds_offset(buf + (k0 * STRIP_WAVES + w) * 256));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(W), "s"(lds) : "memory");
@@ -488,7 +488,7 @@ __device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripR
     STRIP_STAMP(28);
     constexpr int NSTEP = KS * NT, CT_BYTES = 16 * (D / 2) * 4, PLANE_BYTES = RingT::SLAB * 4;
     constexpr int PD1 = FRAG_AHEAD_2, PD2 = FRAG_AHEAD_1;  // steps a read runs ahead of its matrix instructions
-    auto lds_addr = [](const float* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)p; };
+    auto lds_addr = [](const float* p) { return lds_offset(p); };
     {   // pass 1: lo x hi, mid x (mid, hi) -- the lo plane sits one slot (32 KB) behind the mid plane: one address, two offsets
         static_assert(CT_BYTES * (NT - 1) + PLANE_BYTES < 65536, "the lo plane is reached through the offset field");
         const unsigned base = lds_addr(ring.mslot());
