@@ -7,8 +7,9 @@ import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-anchor = sys.argv[2] if len(sys.argv) > 2 else "pack_indices"
 rows = db.execute("select name, start, end, stream_id, grid_x * grid_y * grid_z, workgroup_x * workgroup_y * workgroup_z, lds_size from kernels order by start").fetchall()
+# the step's first kernel: the step head of the folded step (round 5), else the packing launch
+anchor = sys.argv[2] if len(sys.argv) > 2 else ("step_head" if any("step_head" in r[0] for r in rows) else "pack_indices")
 starts = [i for i, r in enumerate(rows) if anchor in r[0]]
 if len(starts) < 4:
     raise SystemExit(f"anchor {anchor!r} found {len(starts)} times")
