@@ -218,41 +218,42 @@ __global__ __launch_bounds__(256) void step_head_kernel(const StepHeadArgs a, co
             *reinterpret_cast<float2*>(a.v_tab + off) = make_float2(v[0], v[1]);
         }
     };
-    const int w0 = bid * (blockDim.x >> 6) + (threadIdx.x >> 6), n_w = nbk * (blockDim.x >> 6);
+    const int n_w = nbk * (blockDim.x >> 6);
     if (threadIdx.x == 0) any_lag = 0;
     __syncthreads();
-    // the wave's FIRST position (its only one unless the list is longer than the grid: a wave per position) is resolved once -- image ->
-    // id -> stamp is a chain of three dependent loads -- and kept for the replay; lanes 1 .. 63 look at the wave's further positions
-    bool mine = false;
-    long long r0 = 0;
-    int l0 = 0;
-    for (long long i = w0 + (long long)lane * n_w; i < n_c; i += 64LL * n_w) {
-        int row;
-        const int id = pb.at((int)i, row);
-        const int l = a.last[id];
-        if (i == w0) { r0 = id; l0 = l; }
-        if (l > 0 && l < t - 1) mine = true;
-    }
-    r0 = __builtin_amdgcn_readfirstlane((int)r0);
-    l0 = __builtin_amdgcn_readfirstlane(l0);
-    if (mine) any_lag = 1;
-    __syncthreads();
-    if (!any_lag) return;
-    fill_coef_table(tab, st);
-    for (int i = w0; i < n_c; i += n_w) {
-        long long r = r0;
-        int l = l0;
-        if (i != w0) {
+    // Every position of the wave is resolved ONCE, lane j the wave's j-th (image -> id -> stamp is a chain of three dependent loads: paid
+    // side by side, not once per position); the replay loop below reads (id, stamp) back from lane j.  The grid is one round of resident
+    // workgroups (amid_step_head_f32): at the headline shape a wave has two positions, a second ROUND of workgroups would pay the whole
+    // chain again behind the first.  (Lists of more than 64 positions per wave: the loop repeats per 64.)
+    const int wv = threadIdx.x >> 6;
+    bool filled = false;                                 // (block-uniform)
+    for (long long base = (long long)bid * (blockDim.x >> 6); base < n_c; base += 64LL * n_w) {      // (block-uniform trip count)
+        const long long i = base + wv + (long long)lane * n_w;
+        int id = 0, l = 0;
+        if (i < n_c) {
             int row;
-            r = pb.at(i, row);
-            l = a.last[r];
+            id = pb.at((int)i, row);
+            l = a.last[id];
         }
-        if (!(l > 0 && l < t - 1)) continue;
-        int won = 0;
-        if (lane == 0) won = (atomicCAS(&a.last[r], l, (int)(t - 1)) == l) ? 1 : 0;     // claim the row for this wave
-        won = __builtin_amdgcn_readfirstlane(won);
-        if (!won) continue;
-        replay_row(r, l);
+        const bool lag = l > 0 && l < t - 1;
+        const unsigned long long lagging = __ballot(lag);
+        if (lagging != 0ull && lane == 0) any_lag = 1;
+        // (the table is needed by the waves that replay; a block whose waves all find nothing skips it)
+        __syncthreads();
+        if (any_lag && !filled) { fill_coef_table(tab, st); filled = true; }
+        unsigned long long todo = lagging;
+        while (todo != 0ull) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const long long r = __builtin_amdgcn_readlane(id, j);
+            const int lj = __builtin_amdgcn_readlane(l, j);
+            int won = 0;
+            if (lane == 0) won = (atomicCAS(&a.last[r], lj, (int)(t - 1)) == lj) ? 1 : 0;     // claim the row for this wave
+            won = __builtin_amdgcn_readfirstlane(won);
+            if (!won) continue;
+            replay_row(r, lj);
+        }
+        if (base + 64LL * n_w < n_c) __syncthreads();    // (a wave of the next round must not raise any_lag while a slow one still reads it)
     }
 }
 
@@ -686,7 +687,14 @@ extern "C" int amid_step_head_f32(const long long* pool, long long pool_stride, 
         rd.phase = 1;
         if (rd.plan.n != n_c) return AMID_ERR_ARG;                  // the plan must be the compact list's
     }
-    long long blocks = ((long long)n_c + 3) / 4;                    // a position per wave (catchup_positions)
+    long long blocks = ((long long)n_c + 3) / 4;                    // a position per wave ...
+    static int resident = 0;                                        // ... up to ONE round of resident workgroups (8 of 256 threads per CU)
+    if (resident == 0) {
+        int dev = 0; hipDeviceProp_t pr;
+        resident = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? 8 * pr.multiProcessorCount : 2048;
+    }
+    const long long room = resident - rider_blocks_host(rd) - npk;
+    if (room >= 256 && blocks > room) blocks = room;
     if (blocks > 16384) blocks = 16384;
     step_head_kernel<<<rider_blocks_host(rd) + npk + (int)blocks, 256, 0, (hipStream_t)stream>>>(a, rd);
     AMID_LAUNCH_CHECK();

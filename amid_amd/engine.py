@@ -359,6 +359,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             return pl.shape.B <= n_cu
         if self.D != 128:               # D 64 at T 50: the five strip launches win (B 512: 0.352 against 0.393 ms; B 256: a tie)
             return False
+        if self._folded_step_shape(pl):      # the strips host the folded step's riders (round 5; cfg 3, B 512: 0.6006 against 0.6144 ms
+            return False                    # for the one-launch backward in front of the fifteen-launch tail)
         return n_cu < pl.shape.B <= 2 * n_cu
 
     def _sort_plan(self, pl: SasrecPlan):
@@ -389,6 +391,14 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # reduce's second phase in the optimizer launch (amid_optimizer_step_spans_f32): 12 launches instead of 15.  False: round 4's sequence
     # (tests compare the two).
     FUSED_TAIL = True
+
+    def _folded_step_shape(self, pl: SasrecPlan) -> bool:
+        """The conditions of the folded twelve-launch step that do not depend on how the backward runs (_tail2_ok adds those)."""
+        return bool(self.FUSED_TAIL and getattr(self, "_in_train_step", False) and self.SORT_RIDERS and pl.need_grad and self.D == 128
+                    and self.compute == "f32" and not self.dr and not self.itc_bs and not self.inc_bs and not getattr(self, "comp", "")
+                    and getattr(self, "_tail_pack", None) is None and self.FUSED_HEAD and self.BWD_SPLIT and pl.strip
+                    and self.input_pool(pl) is not None and self.live_forward_ok(pl) and self._wgrad_mode(self.D) == 3
+                    and not self._fold_catchup(pl) and self._sort_plan_c(pl) is not None and (pl.n_compact + 2047) // 2048 <= 12 * pl.splits)
 
     def _tail2_ok(self, pl: SasrecPlan) -> bool:
         shp = pl.shape

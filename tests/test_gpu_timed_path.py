@@ -327,8 +327,8 @@ def _timed_vs_oracle(Bn, T, D, build, split, compact_min, seq_backward=None, poo
 # strip launch, the position rows' gradients in the gradient tail, the segment reduce finished inside the optimizer launch.  The domain
 # splits leave a domain without any live sequence (all0 / all1) or with one (one0); B 1100 = the pad run spans ~800 chunks; B 5 = a single
 # chunk-crossing run at most.
-@pytest.mark.parametrize("Bn,T,split", [(256, 50, "mixed"), (256, 50, "all0"), (256, 50, "all1"), (200, 50, "one0"), (250, 40, "mixed"),
-                                        (64, 33, "mixed"), (1100, 50, "mixed"), (37, 47, "mixed"), (5, 64, "all1"), (130, 64, "one0")])
+@pytest.mark.parametrize("Bn,T,split", [(256, 50, "mixed"), (256, 50, "all0"), (256, 50, "all1"), (200, 50, "one0"), (250, 40, "mixed"), (300, 40, "mixed"),
+                                        (512, 50, "mixed"), (64, 33, "mixed"), (1100, 50, "mixed"), (37, 47, "mixed"), (5, 64, "all1"), (130, 64, "one0")])
 def test_timed_path_folded_step_vs_oracle(Bn, T, split):
     _timed_vs_oracle(Bn, T, 128, None, split, compact_min=None, pool=True)
 
