@@ -199,6 +199,9 @@ __global__ __launch_bounds__(256) void step_head_kernel(const StepHeadArgs a, co
         return;
     }
     // ---- catch-up over the compact positions (lazy_adam_catchup_pos_kernel with the ids read from the image) ----
+#ifdef AMID_EXP_HEAD_NO_CATCHUP     // (variant libraries only, profiles/tools/build_variant.sh: what the launch costs without this role -- 13.1 of 16.6 us)
+    return;
+#endif
     const int bid = blockIdx.x - nrb - a.npk, nbk = gridDim.x - nrb - a.npk;
     __shared__ IdleCoef tab[COEF_TAB];
     __shared__ int any_lag;
