@@ -22,6 +22,7 @@
 #include "strip_gemm.h"
 #include "strip_chain.h"
 #include "bert_math.h"
+#include "weights_image.h"
 
 namespace amid {
 
@@ -60,6 +61,7 @@ template <int D, int LD> struct WDmaLd {
 // the two-slab ring of strip_chain.h with a second source stride: fetch() takes a [128][128] tile with contiguous rows, fetch_ld() a
 // column block of a [128][512] matrix
 struct BRing {
+    static constexpr bool BF16 = false;
     static constexpr int SLAB = BSD * BSD;
     float* buf; int s; WDma<BSD> dma; WDmaLd<BSD, BSF> dml;
     __device__ __forceinline__ explicit BRing(float* lds) : buf(lds), s(0) {}
@@ -81,6 +83,27 @@ struct BRing {
         if (slot % EVERY == 0 && slot / EVERY < WDma<BSD>::PER_WAVE) dml.piece(buf + (s & 1) * SLAB, W, slot / EVERY);
     }
 };
+
+// MODE 3 (round 5): the products on bf16 pieces -- fp32 operands as hi + mid + lo, six piece pairs of v_mfma_f32_16x16x32_bf16, fp32
+// accuracy (strip_gemm.h strip_mma16x6, strip_chain.h RingP3; what SASRec's strips run on since round 4).  Every 128 x 128 weight TILE
+// the chains multiply with is then a three-plane fragment image (amid_bert_weight_images_f32): the weight arguments of the kernels point
+// at images, a feed-forward weight at its four tiles' images one behind the other.
+#ifndef AMID_BS_SPREAD
+#define AMID_BS_SPREAD 1
+#endif
+constexpr bool BSPREAD = AMID_BS_SPREAD != 0;      // the hooks' slots between the piece products' matrix instructions (strip_gemm.h strip_mma16x6 SPREAD)
+constexpr int BIMG = 3 * (BSD * BSD / 2);            // floats per tile image (three 32 KB planes)
+template <int MODE> struct BRingSel { using type = BRing; };
+template <> struct BRingSel<3> { using type = RingP3<BSD>; };
+// tile c of a feed-forward weight whose tiles are ROW blocks of the fp32 matrix (w_1 [512][128], w_2^T [512][128]) ...
+template <class R> __device__ __forceinline__ const float* btile_rows(const float* base, int c) {
+    return base + (long long)c * (ring_is_p3<R>::value ? BIMG : BSD * BSD);
+}
+// ... and whose tiles are COLUMN blocks (w_2 [128][512], w_1^T [128][512]): fetched with the wide stride, or as the c-th image
+template <class R> __device__ __forceinline__ void bfetch_cols(R& ring, const float* base, int c, int ct, int j) {
+    if constexpr (ring_is_p3<R>::value) ring.fetch(base + (long long)c * BIMG, ct, j);
+    else ring.fetch_ld(base + c * BSD, ct, j);
+}
 
 // ---- the reference LayerNorm on a strip: a (x - mean) / (std_unbiased + eps) + b -----------------------------------------------------
 __device__ __forceinline__ void lnb_stats(const StripRegs<BSD>& x, float& mean, float& sd, float& r) {
@@ -231,8 +254,8 @@ struct BStripOffArgs {
 
 // q / k / v of one block on the strip X (in registers).  The ring's current fetch must be Wq of this block (started by the caller).
 // XSTORE: X is also written to a.x (a fused predecessor produced it: the saved block input).
-template <bool XSTORE>
-__device__ __forceinline__ void bqkv_fwd_chain(const BStripQkvArgs& a, const StripGeom& sg, BRing& ring, const StripRow& row, int g,
+template <bool XSTORE, class R>
+__device__ __forceinline__ void bqkv_fwd_chain(const BStripQkvArgs& a, const StripGeom& sg, R& ring, const StripRow& row, int g,
                                                const StripRegs<BSD>& X, const ColVec<BSD>& la, const ColVec<BSD>& lb) {
     const GBuf gx(a.x, sg.act_bytes), gy(a.y, sg.act_bytes);
     StripRegs<BSD> Y, P0, P1;
@@ -243,7 +266,7 @@ __device__ __forceinline__ void bqkv_fwd_chain(const BStripQkvArgs& a, const Str
         const float* buf = ring.next();
         bias.load(a.b[0][g]);
         strip_zero<BSD>(acc);
-        strip_mma<BSD>(acc, Y, buf, [&](int ct, int j) {
+        strip_product<BSD, BSPREAD>(acc, Y, buf, ring, [&](int ct, int j) {
             ring.fetch(a.w[1][g], ct, j);
             if constexpr (XSTORE) spread_at(gx, row, X, ct, j, 3);
             spread_at(gy, row, Y, ct, j, 1);
@@ -256,7 +279,7 @@ __device__ __forceinline__ void bqkv_fwd_chain(const BStripQkvArgs& a, const Str
         bias.load(a.b[1][g]);
         strip_zero<BSD>(acc);
         const GBuf gq(a.out[0], sg.act_bytes);
-        strip_mma<BSD>(acc, Y, buf, [&](int ct, int j) { ring.fetch(a.w[2][g], ct, j); spread_at(gq, row, P0, ct, j, 1); });
+        strip_product<BSD, BSPREAD>(acc, Y, buf, ring, [&](int ct, int j) { ring.fetch(a.w[2][g], ct, j); spread_at(gq, row, P0, ct, j, 1); });
         add_bias<BSD>(acc, bias);
         to_regs<BSD>(P1, acc);
     }
@@ -265,7 +288,7 @@ __device__ __forceinline__ void bqkv_fwd_chain(const BStripQkvArgs& a, const Str
         bias.load(a.b[2][g]);
         strip_zero<BSD>(acc);
         const GBuf gk(a.out[1], sg.act_bytes);
-        strip_mma<BSD>(acc, Y, buf, [&](int ct, int j) { spread_at(gk, row, P1, ct, j, 1); });
+        strip_product<BSD, BSPREAD>(acc, Y, buf, ring, [&](int ct, int j) { spread_at(gk, row, P1, ct, j, 1); });
         add_bias<BSD>(acc, bias);
         to_regs<BSD>(P0, acc);
         strip_store<BSD>(GBuf(a.out[2], sg.act_bytes), row, P0);
@@ -313,10 +336,11 @@ __device__ __forceinline__ void bert_prologue_block(const BPrologue& p, int blk,
     }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_qkv_fwd_kernel(const BStripQkvArgs a, const StripGeom sg, const BPrologue pro) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x >= 2 * sg.tpg) { bert_prologue_block(pro, blockIdx.x - 2 * sg.tpg, smem); return; }
-    BRing ring(smem);
+    typename BRingSel<MODE>::type ring(smem);
     ring.first(a.w[0][strip_domain(blockIdx.x)]);
     const StripTile t = strip_tile(sg, blockIdx.x);
     if (!t.live) { w_ring_wait(); return; }
@@ -328,10 +352,11 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_qkv_fwd_kernel(const
     bqkv_fwd_chain<false>(a, sg, ring, row, t.g, X, la, lb);
 }
 
-template <bool NEXT>
+template <bool NEXT, int MODE>
 __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_oproj_ffn_fwd_kernel(const BStripOffArgs a, const BStripQkvArgs nx, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    BRing ring(smem);
+    using R = typename BRingSel<MODE>::type;
+    R ring(smem);
     ring.first(a.wo[strip_domain(blockIdx.x)]);
     const StripTile t = strip_tile(sg, blockIdx.x);
     if (!t.live) { w_ring_wait(); return; }
@@ -354,7 +379,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_oproj_ffn_fwd_kernel
         kg.begin(dc, g, SITE_SUB_IN, e128);
         const float* buf = ring.next();
         strip_zero<BSD>(acc);
-        strip_mma<BSD>(acc, A, buf, [&](int ct, int j) { ring.fetch(a.w1[g], ct, j); kg.hook(ct, j); });
+        strip_product<BSD, BSPREAD>(acc, A, buf, ring, [&](int ct, int j) { ring.fetch(a.w1[g], ct, j); kg.hook(ct, j); });
         add_bias<BSD>(acc, bias);
         to_regs<BSD>(A, acc);
         apply_keep(A, kg.finish(), dc.scale);
@@ -375,8 +400,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_oproj_ffn_fwd_kernel
             const float* buf = ring.next();
             bias.load(a.b1[g] + c * BSD);
             strip_zero<BSD>(acc);
-            strip_mma<BSD>(acc, Y2, buf, [&](int ct, int j) {
-                ring.fetch_ld(a.w2[g] + c * BSD, ct, j);
+            strip_product<BSD, BSPREAD>(acc, Y2, buf, ring, [&](int ct, int j) {
+                bfetch_cols(ring, a.w2[g], c, ct, j);
                 if (c == 0) { spread_at(gx1, row, X1, ct, j, 1); spread_at(gy2, row, Y2, ct, j, 3); }
                 kg.hook(ct, j);
             });
@@ -397,8 +422,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_oproj_ffn_fwd_kernel
             if (c == 0) kg.begin(dc, g, SITE_SUB_OUT, e128);
             if (c == 1) kg.begin(dc, g, SITE_BLOCK, e128);
             const float* buf = ring.next();
-            const float* nxt = c + 1 < BSC ? a.w1[g] + (long long)(c + 1) * BSD * BSD : nx.w[0][g];
-            strip_mma<BSD>(acc2, Hc, buf, [&](int ct, int j) {
+            const float* nxt = c + 1 < BSC ? btile_rows<R>(a.w1[g], c + 1) : nx.w[0][g];
+            strip_product<BSD, BSPREAD>(acc2, Hc, buf, ring, [&](int ct, int j) {
                 if (NEXT || c + 1 < BSC) ring.fetch(nxt, ct, j);
                 wide_spread(gpre, offw, c, P, ct, j, 1);
                 wide_spread(gh, offw, c, Hc, ct, j, 3);
@@ -460,7 +485,8 @@ __device__ __forceinline__ BDrop bffn_drop(const BStripFfnBwdArgs& a) {
     if (a.train) { dc.seed = a.st->seed; dc.step = (unsigned)a.st->step; }
     return dc;
 }
-__device__ __forceinline__ void bffn_bwd_chain(const BStripFfnBwdArgs& a, const StripGeom& sg, BRing& ring, const StripRow& row, int g,
+template <class R>
+__device__ __forceinline__ void bffn_bwd_chain(const BStripFfnBwdArgs& a, const StripGeom& sg, R& ring, const StripRow& row, int g,
                                                StripRegs<BSD>& DX2, float* __restrict__ scratch, unsigned kb_block, unsigned kb_out) {
     const BDrop dc = bffn_drop(a);
     const unsigned long long e128 = (unsigned long long)row.local * BSD, e512 = (unsigned long long)row.local * BSF;
@@ -484,8 +510,8 @@ __device__ __forceinline__ void bffn_bwd_chain(const BStripFfnBwdArgs& a, const 
             const float* buf = ring.next();
             wide_load(PRE, gpre, offw, c);
             strip_zero<BSD>(acc);
-            strip_mma<BSD>(acc, DZ, buf, [&](int ct, int j) {
-                ring.fetch_ld(a.w1T[g] + c * BSD, ct, j);
+            strip_product<BSD, BSPREAD>(acc, DZ, buf, ring, [&](int ct, int j) {
+                bfetch_cols(ring, a.w1T[g], c, ct, j);
                 if (c == 0) spread_at(gdz, row, DZ, ct, j, 1);
                 kg.hook(ct, j);
             });
@@ -503,10 +529,10 @@ __device__ __forceinline__ void bffn_bwd_chain(const BStripFfnBwdArgs& a, const 
         }
         {   // dy2 += dpre_c W1_c
             const float* buf = ring.next();
-            const float* nxt = c + 1 < BSC ? a.w2T[g] + (long long)(c + 1) * BSD * BSD : a.woT[g];
+            const float* nxt = c + 1 < BSC ? btile_rows<R>(a.w2T[g], c + 1) : a.woT[g];
             if (c + 1 == BSC) { strip_load<BSD>(X1, GBuf(a.x1, sg.act_bytes), row); gam.load(a.la[g]); }
             if (c == 0) kg.begin(dc, g, SITE_SUB_IN, e128);
-            strip_mma<BSD>(accy, DP, buf, [&](int ct, int j) {
+            strip_product<BSD, BSPREAD>(accy, DP, buf, ring, [&](int ct, int j) {
                 ring.fetch(nxt, ct, j);
                 wide_spread(gdpre, offw, c, DP, ct, j, 1);
                 if (c == 0) kg.hook(ct, j);
@@ -525,16 +551,17 @@ __device__ __forceinline__ void bffn_bwd_chain(const BStripFfnBwdArgs& a, const 
         apply_keep(DZ, kb, dc.scale);
         const float* buf = ring.next();
         strip_zero<BSD>(acc);
-        strip_mma<BSD>(acc, DZ, buf, [&](int ct, int j) { spread_at(gdx1, row, DP, ct, j, 1); spread_at(gdt, row, DZ, ct, j, 3); });
+        strip_product<BSD, BSPREAD>(acc, DZ, buf, ring, [&](int ct, int j) { spread_at(gdx1, row, DP, ct, j, 1); spread_at(gdt, row, DZ, ct, j, 3); });
         to_regs<BSD>(PRE, acc);
         strip_store<BSD>(GBuf(a.d_o, sg.act_bytes), row, PRE);
     }
     ln_partials_wave<BSD>(scratch, dgam, dbet);
 }
 
+template <int MODE>
 __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_ffn_bwd_kernel(const BStripFfnBwdArgs a, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    BRing ring(smem);
+    typename BRingSel<MODE>::type ring(smem);
     ring.first(a.w2T[strip_domain(blockIdx.x)]);
     const StripTile t = strip_tile(sg, blockIdx.x);
     if (!t.live) { zero_slot<BSD>(a.ln_part, t.slot); w_ring_wait(); return; }
@@ -550,13 +577,13 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_ffn_bwd_kernel(const
 }
 
 // FFN = true: the block below's feed-forward / out-projection backward continues on d x in registers (d x is then never stored)
-template <bool FFN>
+template <bool FFN, int MODE>
 __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_qkv_bwd_kernel(const BStripQkvBwdArgs a, const BStripFfnBwdArgs f, const StripGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (!FFN) {
         if ((int)blockIdx.x >= 2 * sg.tpg) { zero_dead_rows(a.dx, sg, blockIdx.x - 2 * sg.tpg, a.zero_blocks); return; }
     }
-    BRing ring(smem);
+    typename BRingSel<MODE>::type ring(smem);
     ring.first(a.wT[0][strip_domain(blockIdx.x)]);
     const StripTile t = strip_tile(sg, blockIdx.x);
     if (!t.live) {
@@ -582,14 +609,14 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_qkv_bwd_kernel(const
         if constexpr (FFN) kg.begin(fdc, g, SITE_BLOCK, e128);
         const float* buf = ring.next();
         strip_load<BSD>(D1, GBuf(a.dk, sg.act_bytes), row);
-        strip_mma<BSD>(acc, D0, buf, [&](int ct, int j) { ring.fetch(a.wT[1][g], ct, j); if constexpr (FFN) kg.hook(ct, j); });
+        strip_product<BSD, BSPREAD>(acc, D0, buf, ring, [&](int ct, int j) { ring.fetch(a.wT[1][g], ct, j); if constexpr (FFN) kg.hook(ct, j); });
         if constexpr (FFN) kb_block = kg.finish();
     }
     {   // + dk Wk
         if constexpr (FFN) kg.begin(fdc, g, SITE_SUB_OUT, e128);
         const float* buf = ring.next();
         strip_load<BSD>(D0, GBuf(a.dv, sg.act_bytes), row);
-        strip_mma<BSD>(acc, D1, buf, [&](int ct, int j) { ring.fetch(a.wT[2][g], ct, j); if constexpr (FFN) kg.hook(ct, j); });
+        strip_product<BSD, BSPREAD>(acc, D1, buf, ring, [&](int ct, int j) { ring.fetch(a.wT[2][g], ct, j); if constexpr (FFN) kg.hook(ct, j); });
         if constexpr (FFN) kb_out = kg.finish();
     }
     StripRegs<BSD> dgam, dbet;
@@ -598,7 +625,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void bert_strip_qkv_bwd_kernel(const
         strip_load<BSD>(Xs, GBuf(a.x, sg.act_bytes), row);
         strip_load<BSD>(D1, GBuf(a.dx1, sg.act_bytes), row);
         gam.load(a.la[g]);
-        strip_mma<BSD>(acc, D0, buf, [&](int ct, int j) { if constexpr (FFN) ring.fetch(f.w2T[g], ct, j); });
+        strip_product<BSD, BSPREAD>(acc, D0, buf, ring, [&](int ct, int j) { if constexpr (FFN) ring.fetch(f.w2T[g], ct, j); });
         to_regs<BSD>(D0, acc);
         strip_lnb_bwd(DX, D0, Xs, gam, dgam, dbet);
 #pragma unroll
@@ -643,15 +670,20 @@ static void fill_bqkv(BStripQkvArgs& a, const float* x, const float* const* la, 
 }
 
 static int bqkv_fwd(const float* x, const float* const* la, const float* const* lb, const float* const* w3, const float* const* b3, int B,
-                    int T, const int* live, float* y, float* q, float* k, float* v, const BPrologue& pro, void* stream) {
+                    int T, const int* live, float* y, float* q, float* k, float* v, const BPrologue& pro, void* stream, int mode = 0) {
     AMID_CHECK_ARG(x && la && lb && w3 && b3 && y && q && k && v);
     BStripQkvArgs a;
     fill_bqkv(a, x, la, lb, w3, b3, y, q, k, v);
     StripGeom sg;
     if (int e = bert_strip_geom(B, T, live, &sg)) return e;
-    static unsigned long long attr_done = 0;
-    if (int rc = lds_attr_once((const void*)bert_strip_qkv_fwd_kernel, strip_lds_bytes<BSD>(), attr_done)) return rc;
-    bert_strip_qkv_fwd_kernel<<<2 * sg.tpg + pro.blocks, STRIP_THREADS, strip_lds_bytes<BSD>(), (hipStream_t)stream>>>(a, sg, pro);
+    static unsigned long long attr_done[2] = {0, 0};
+    if (mode == 3) {
+        if (int rc = lds_attr_once((const void*)bert_strip_qkv_fwd_kernel<3>, strip_lds_bytes<BSD>(), attr_done[1])) return rc;
+        bert_strip_qkv_fwd_kernel<3><<<2 * sg.tpg + pro.blocks, STRIP_THREADS, strip_lds_bytes<BSD>(), (hipStream_t)stream>>>(a, sg, pro);
+    } else {
+        if (int rc = lds_attr_once((const void*)bert_strip_qkv_fwd_kernel<0>, strip_lds_bytes<BSD>(), attr_done[0])) return rc;
+        bert_strip_qkv_fwd_kernel<0><<<2 * sg.tpg + pro.blocks, STRIP_THREADS, strip_lds_bytes<BSD>(), (hipStream_t)stream>>>(a, sg, pro);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? AMID_OK : (int)e;
 }
@@ -667,11 +699,11 @@ extern "C" int amid_bert_strip_qkv_fwd_f32(const float* x, const float* const* l
 // ... with the step's prologue riding as extra workgroups: key_keep[i] = seq_d2[i] > 0 for i < n_keys (seq_d2 == NULL: none), and
 // tr_dst[m][c][r] = tr_src[m][r][c] for n_tr <= 24 matrices of tr_rows[m] x tr_cols[m] floats (multiples of 64) -- what
 // amid_key_keep_u8 and amid_transpose_rect_f32 do in launches of their own
-extern "C" int amid_bert_strip_qkv_fwd_pro_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3,
-                                               const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k,
-                                               float* v, const long long* seq_d2, int n_keys, unsigned char* key_keep,
-                                               const float* const* tr_src, float* const* tr_dst, const int* tr_rows, const int* tr_cols,
-                                               int n_tr, void* stream) {
+static int bqkv_fwd_pro(const float* x, const float* const* la, const float* const* lb, const float* const* w3,
+                        const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k,
+                        float* v, const long long* seq_d2, int n_keys, unsigned char* key_keep,
+                        const float* const* tr_src, float* const* tr_dst, const int* tr_rows, const int* tr_cols,
+                        int n_tr, void* stream, int mode) {
     AMID_CHECK_ARG(n_tr >= 0 && n_tr <= BPRO_MAX && (n_tr == 0 || (tr_src && tr_dst && tr_rows && tr_cols)));
     AMID_CHECK_ARG(seq_d2 == nullptr || (key_keep != nullptr && n_keys > 0));
     BPrologue pro = {};
@@ -681,18 +713,33 @@ extern "C" int amid_bert_strip_qkv_fwd_pro_f32(const float* x, const float* cons
         pro.src[i] = tr_src[i]; pro.dst[i] = tr_dst[i]; pro.rows[i] = tr_rows[i]; pro.cols[i] = tr_cols[i];
     }
     pro.blocks = (seq_d2 != nullptr || n_tr > 0) ? 96 : 0;
-    return bqkv_fwd(x, la, lb, w3, b3, B, T, live, y, q, k, v, pro, stream);
+    return bqkv_fwd(x, la, lb, w3, b3, B, T, live, y, q, k, v, pro, stream, mode);
+}
+extern "C" int amid_bert_strip_qkv_fwd_pro_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3,
+                                               const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k,
+                                               float* v, const long long* seq_d2, int n_keys, unsigned char* key_keep,
+                                               const float* const* tr_src, float* const* tr_dst, const int* tr_rows, const int* tr_cols,
+                                               int n_tr, void* stream) {
+    return bqkv_fwd_pro(x, la, lb, w3, b3, B, T, live, y, q, k, v, seq_d2, n_keys, key_keep, tr_src, tr_dst, tr_rows, tr_cols, n_tr, stream, 0);
+}
+// ... on bf16 pieces: w3 = the tiles' three-plane images (amid_bert_weight_images_f32), everything else as above
+extern "C" int amid_bert_strip_qkv_fwd_pro_p3_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3_img,
+                                                  const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k,
+                                                  float* v, const long long* seq_d2, int n_keys, unsigned char* key_keep,
+                                                  const float* const* tr_src, float* const* tr_dst, const int* tr_rows, const int* tr_cols,
+                                                  int n_tr, void* stream) {
+    return bqkv_fwd_pro(x, la, lb, w3_img, b3, B, T, live, y, q, k, v, seq_d2, n_keys, key_keep, tr_src, tr_dst, tr_rows, tr_cols, n_tr, stream, 3);
 }
 
 // out-projection + feed-forward of a block; nla != NULL: the next block's LayerNorm + q / k / v on x2 in the same launch (x2 is
 // then also the next block's saved input)
-extern "C" int amid_bert_strip_oproj_ffn_fwd_f32(const float* o, const float* x, const float* const* wo, const float* const* bo,
-                                                 const float* const* la, const float* const* lb, const float* const* w1,
-                                                 const float* const* b1, const float* const* w2, const float* const* b2, int B, int T,
-                                                 const int* live, int layer, const void* step_state, int train, float p_drop, float* x1,
-                                                 float* y2, float* pre, float* h, float* x2, const float* const* nla,
-                                                 const float* const* nlb, const float* const* nw3, const float* const* nb3, float* ny,
-                                                 float* nq, float* nk, float* nv, void* stream) {
+static int boproj_ffn_fwd(const float* o, const float* x, const float* const* wo, const float* const* bo,
+                          const float* const* la, const float* const* lb, const float* const* w1,
+                          const float* const* b1, const float* const* w2, const float* const* b2, int B, int T,
+                          const int* live, int layer, const void* step_state, int train, float p_drop, float* x1,
+                          float* y2, float* pre, float* h, float* x2, const float* const* nla,
+                          const float* const* nlb, const float* const* nw3, const float* const* nb3, float* ny,
+                          float* nq, float* nk, float* nv, void* stream, int mode) {
     AMID_CHECK_ARG(o && x && wo && bo && la && lb && w1 && b1 && w2 && b2 && x1 && y2 && pre && h && x2 && (!train || step_state));
     const bool next = nla != nullptr;
     AMID_CHECK_ARG(!next || (nlb && nw3 && nb3 && ny && nq && nk && nv));
@@ -711,8 +758,32 @@ extern "C" int amid_bert_strip_oproj_ffn_fwd_f32(const float* o, const float* x,
     if (next) fill_bqkv(nx, x2, nla, nlb, nw3, nb3, ny, nq, nk, nv);
     StripGeom sg;
     if (int e = bert_strip_geom(B, T, live, &sg)) return e;
-    return next ? launch_strip<bert_strip_oproj_ffn_fwd_kernel<true>, BSD>(sg, stream, a, nx)
-                : launch_strip<bert_strip_oproj_ffn_fwd_kernel<false>, BSD>(sg, stream, a, nx);
+    if (mode == 3)
+        return next ? launch_strip<bert_strip_oproj_ffn_fwd_kernel<true, 3>, BSD>(sg, stream, a, nx)
+                    : launch_strip<bert_strip_oproj_ffn_fwd_kernel<false, 3>, BSD>(sg, stream, a, nx);
+    return next ? launch_strip<bert_strip_oproj_ffn_fwd_kernel<true, 0>, BSD>(sg, stream, a, nx)
+                : launch_strip<bert_strip_oproj_ffn_fwd_kernel<false, 0>, BSD>(sg, stream, a, nx);
+}
+extern "C" int amid_bert_strip_oproj_ffn_fwd_f32(const float* o, const float* x, const float* const* wo, const float* const* bo,
+                                                 const float* const* la, const float* const* lb, const float* const* w1,
+                                                 const float* const* b1, const float* const* w2, const float* const* b2, int B, int T,
+                                                 const int* live, int layer, const void* step_state, int train, float p_drop, float* x1,
+                                                 float* y2, float* pre, float* h, float* x2, const float* const* nla,
+                                                 const float* const* nlb, const float* const* nw3, const float* const* nb3, float* ny,
+                                                 float* nq, float* nk, float* nv, void* stream) {
+    return boproj_ffn_fwd(o, x, wo, bo, la, lb, w1, b1, w2, b2, B, T, live, layer, step_state, train, p_drop, x1, y2, pre, h, x2, nla, nlb, nw3, nb3,
+                          ny, nq, nk, nv, stream, 0);
+}
+// ... on bf16 pieces: wo / nw3 = tile images, w1 / w2 = the first of their four tiles' images (one behind the other)
+extern "C" int amid_bert_strip_oproj_ffn_fwd_p3_f32(const float* o, const float* x, const float* const* wo_img, const float* const* bo,
+                                                    const float* const* la, const float* const* lb, const float* const* w1_img,
+                                                    const float* const* b1, const float* const* w2_img, const float* const* b2, int B, int T,
+                                                    const int* live, int layer, const void* step_state, int train, float p_drop, float* x1,
+                                                    float* y2, float* pre, float* h, float* x2, const float* const* nla,
+                                                    const float* const* nlb, const float* const* nw3_img, const float* const* nb3, float* ny,
+                                                    float* nq, float* nk, float* nv, void* stream) {
+    return boproj_ffn_fwd(o, x, wo_img, bo, la, lb, w1_img, b1, w2_img, b2, B, T, live, layer, step_state, train, p_drop, x1, y2, pre, h, x2, nla, nlb,
+                          nw3_img, nb3, ny, nq, nk, nv, stream, 3);
 }
 
 static int fill_bffn_bwd(BStripFfnBwdArgs& a, const float* dx2, const float* pre, const float* x1, const float* const* la,
@@ -730,27 +801,40 @@ static int fill_bffn_bwd(BStripFfnBwdArgs& a, const float* dx2, const float* pre
 }
 
 // ln_part: [2 * ceil(B T / amid_sas_strip_tile_rows())][2][128]; domain g's partial sums are slots [g * tpg, (g + 1) * tpg)
-extern "C" int amid_bert_strip_ffn_bwd_f32(const float* dx2, const float* pre, const float* x1, const float* const* la,
-                                           const float* const* w2T, const float* const* w1T, const float* const* woT, int B, int T,
-                                           const int* live, int layer, const void* step_state, int train, float p_drop, float* dz,
-                                           float* dpre, float* dx1, float* dt, float* d_o, float* ln_part, void* stream) {
+static int bffn_bwd(const float* dx2, const float* pre, const float* x1, const float* const* la,
+                    const float* const* w2T, const float* const* w1T, const float* const* woT, int B, int T,
+                    const int* live, int layer, const void* step_state, int train, float p_drop, float* dz,
+                    float* dpre, float* dx1, float* dt, float* d_o, float* ln_part, void* stream, int mode) {
     AMID_CHECK_ARG(dx2);
     BStripFfnBwdArgs a;
     if (int e = fill_bffn_bwd(a, dx2, pre, x1, la, w2T, w1T, woT, layer, step_state, train, p_drop, dz, dpre, dx1, dt, d_o, ln_part)) return e;
     StripGeom sg;
     if (int e = bert_strip_geom(B, T, live, &sg)) return e;
-    return launch_strip<bert_strip_ffn_bwd_kernel, BSD>(sg, stream, a);
+    return mode == 3 ? launch_strip<bert_strip_ffn_bwd_kernel<3>, BSD>(sg, stream, a) : launch_strip<bert_strip_ffn_bwd_kernel<0>, BSD>(sg, stream, a);
+}
+extern "C" int amid_bert_strip_ffn_bwd_f32(const float* dx2, const float* pre, const float* x1, const float* const* la,
+                                           const float* const* w2T, const float* const* w1T, const float* const* woT, int B, int T,
+                                           const int* live, int layer, const void* step_state, int train, float p_drop, float* dz,
+                                           float* dpre, float* dx1, float* dt, float* d_o, float* ln_part, void* stream) {
+    return bffn_bwd(dx2, pre, x1, la, w2T, w1T, woT, B, T, live, layer, step_state, train, p_drop, dz, dpre, dx1, dt, d_o, ln_part, stream, 0);
+}
+// ... on bf16 pieces: w2T / w1T = the first of the four TRANSPOSED tiles' images, woT = the transposed tile's image
+extern "C" int amid_bert_strip_ffn_bwd_p3_f32(const float* dx2, const float* pre, const float* x1, const float* const* la,
+                                              const float* const* w2T_img, const float* const* w1T_img, const float* const* woT_img, int B, int T,
+                                              const int* live, int layer, const void* step_state, int train, float p_drop, float* dz,
+                                              float* dpre, float* dx1, float* dt, float* d_o, float* ln_part, void* stream) {
+    return bffn_bwd(dx2, pre, x1, la, w2T_img, w1T_img, woT_img, B, T, live, layer, step_state, train, p_drop, dz, dpre, dx1, dt, d_o, ln_part, stream, 3);
 }
 
 // wT3: six device pointers ordered [q, k, v][domain] (transposed weights).  fpre != NULL: the block below's feed-forward /
 // out-projection backward (f* arguments, as amid_bert_strip_ffn_bwd_f32 without dx2) runs on d x in the same launch; dx is then not written.
 // zero_dead (with a live list and dx): the rows of dx that belong to the sequences NOT on the list are zero-filled by extra workgroups
-extern "C" int amid_bert_strip_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x,
-                                           const float* const* la, const float* const* wT3, int B, int T, const int* live, float* dx,
-                                           int zero_dead, float* ln_part, const float* fpre, const float* fx1, const float* const* fla,
-                                           const float* const* fw2T, const float* const* fw1T, const float* const* fwoT, int flayer,
-                                           const void* step_state, int train, float p_drop, float* fdz, float* fdpre, float* fdx1,
-                                           float* fdt, float* fd_o, float* fln_part, void* stream) {
+static int bqkv_bwd(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x,
+                    const float* const* la, const float* const* wT3, int B, int T, const int* live, float* dx,
+                    int zero_dead, float* ln_part, const float* fpre, const float* fx1, const float* const* fla,
+                    const float* const* fw2T, const float* const* fw1T, const float* const* fwoT, int flayer,
+                    const void* step_state, int train, float p_drop, float* fdz, float* fdpre, float* fdx1,
+                    float* fdt, float* fd_o, float* fln_part, void* stream, int mode) {
     AMID_CHECK_ARG(dq && dk && dv && dx1 && x && la && wT3 && ln_part);
     const bool ffn = fpre != nullptr;
     AMID_CHECK_ARG(ffn || dx);
@@ -765,10 +849,57 @@ extern "C" int amid_bert_strip_qkv_bwd_f32(const float* dq, const float* dk, con
     StripGeom sg;
     if (int e = bert_strip_geom(B, T, live, &sg)) return e;
     a.zero_blocks = (zero_dead && live != nullptr && !ffn) ? (B < 256 ? B : 256) : 0;
-    if (ffn) return launch_strip<bert_strip_qkv_bwd_kernel<true>, BSD>(sg, stream, a, f);
-    static unsigned long long attr_done = 0;
-    if (int rc = lds_attr_once((const void*)bert_strip_qkv_bwd_kernel<false>, strip_lds_bytes<BSD>(), attr_done)) return rc;
-    bert_strip_qkv_bwd_kernel<false><<<2 * sg.tpg + a.zero_blocks, STRIP_THREADS, strip_lds_bytes<BSD>(), (hipStream_t)stream>>>(a, f, sg);
+    if (ffn) return mode == 3 ? launch_strip<bert_strip_qkv_bwd_kernel<true, 3>, BSD>(sg, stream, a, f)
+                              : launch_strip<bert_strip_qkv_bwd_kernel<true, 0>, BSD>(sg, stream, a, f);
+    static unsigned long long attr_done[2] = {0, 0};
+    if (mode == 3) {
+        if (int rc = lds_attr_once((const void*)bert_strip_qkv_bwd_kernel<false, 3>, strip_lds_bytes<BSD>(), attr_done[1])) return rc;
+        bert_strip_qkv_bwd_kernel<false, 3><<<2 * sg.tpg + a.zero_blocks, STRIP_THREADS, strip_lds_bytes<BSD>(), (hipStream_t)stream>>>(a, f, sg);
+    } else {
+        if (int rc = lds_attr_once((const void*)bert_strip_qkv_bwd_kernel<false, 0>, strip_lds_bytes<BSD>(), attr_done[0])) return rc;
+        bert_strip_qkv_bwd_kernel<false, 0><<<2 * sg.tpg + a.zero_blocks, STRIP_THREADS, strip_lds_bytes<BSD>(), (hipStream_t)stream>>>(a, f, sg);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? AMID_OK : (int)e;
+}
+extern "C" int amid_bert_strip_qkv_bwd_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x,
+                                           const float* const* la, const float* const* wT3, int B, int T, const int* live, float* dx,
+                                           int zero_dead, float* ln_part, const float* fpre, const float* fx1, const float* const* fla,
+                                           const float* const* fw2T, const float* const* fw1T, const float* const* fwoT, int flayer,
+                                           const void* step_state, int train, float p_drop, float* fdz, float* fdpre, float* fdx1,
+                                           float* fdt, float* fd_o, float* fln_part, void* stream) {
+    return bqkv_bwd(dq, dk, dv, dx1, x, la, wT3, B, T, live, dx, zero_dead, ln_part, fpre, fx1, fla, fw2T, fw1T, fwoT, flayer, step_state, train, p_drop,
+                    fdz, fdpre, fdx1, fdt, fd_o, fln_part, stream, 0);
+}
+// ... on bf16 pieces: every weight argument = transposed tile images (as amid_bert_strip_ffn_bwd_p3_f32)
+extern "C" int amid_bert_strip_qkv_bwd_p3_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x,
+                                              const float* const* la, const float* const* wT3_img, int B, int T, const int* live, float* dx,
+                                              int zero_dead, float* ln_part, const float* fpre, const float* fx1, const float* const* fla,
+                                              const float* const* fw2T_img, const float* const* fw1T_img, const float* const* fwoT_img, int flayer,
+                                              const void* step_state, int train, float p_drop, float* fdz, float* fdpre, float* fdx1,
+                                              float* fdt, float* fd_o, float* fln_part, void* stream) {
+    return bqkv_bwd(dq, dk, dv, dx1, x, la, wT3_img, B, T, live, dx, zero_dead, ln_part, fpre, fx1, fla, fw2T_img, fw1T_img, fwoT_img, flayer, step_state,
+                    train, p_drop, fdz, fdpre, fdx1, fdt, fd_o, fln_part, stream, 3);
+}
+
+// Three-plane bf16 fragment images (weights_image.h: hi + mid + lo = the fp32 element exactly) of n <= 96 weight TILES of 128 x 128: tile i
+// is src[i][r * ld[i] + c] (tr[i] = 0) or its transpose src[i][c * ld[i] + r] (tr[i] != 0), r, c < 128; dst16: [n][3][128][128] bf16.
+// One launch per step in front of the first strip launch (what SASRec's gather carries as riders).
+constexpr int BIMG_MAX = 96;
+struct BImgArgs { const float* src[BIMG_MAX]; unsigned short ld[BIMG_MAX]; unsigned char tr[BIMG_MAX]; int n, per; unsigned short* dst; };
+__global__ __launch_bounds__(256) void bert_weight_images_kernel(const BImgArgs a) {
+    const int wi = blockIdx.x / a.per, b = blockIdx.x - wi * a.per;
+    weights_image_block(a.src[wi], a.dst + (size_t)wi * 3 * BSD * BSD, BSD, a.tr[wi], 3, b, a.per, a.ld[wi]);
+}
+extern "C" int amid_bert_weight_images_f32(const float* const* src, const int* ld, const int* tr, int n, void* dst16, void* stream) {
+    AMID_CHECK_ARG(src && ld && tr && dst16 && n > 0 && n <= BIMG_MAX);
+    BImgArgs a;
+    for (int i = 0; i < n; ++i) {
+        AMID_CHECK_ARG(src[i] && ld[i] >= BSD && ld[i] < 65536);
+        a.src[i] = src[i]; a.ld[i] = (unsigned short)ld[i]; a.tr[i] = tr[i] ? 1 : 0;
+    }
+    a.n = n; a.per = 4; a.dst = (unsigned short*)dst16;
+    bert_weight_images_kernel<<<n * a.per, 256, 0, (hipStream_t)stream>>>(a);
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
 }

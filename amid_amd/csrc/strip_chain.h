@@ -93,9 +93,9 @@ template <int D> struct RingSel<D, 3> { using type = RingP3<D>; };
 template <class R> struct ring_is_p3 { static constexpr bool value = false; };
 template <int D> struct ring_is_p3<RingP3<D>> { static constexpr bool value = true; };
 // one product of a chain on whichever ring the kernel was built with
-template <int D, class RingT, class Hook>
+template <int D, bool SPREAD = false, class RingT, class Hook>
 __device__ __forceinline__ void strip_product(f32x4 (&acc)[D / 16], const StripRegs<D>& A, const float* __restrict__ buf, RingT& ring, const Hook& hook) {
-    if constexpr (ring_is_p3<RingT>::value) strip_mma16x6<D>(acc, A, ring, hook);
+    if constexpr (ring_is_p3<RingT>::value) strip_mma16x6<D, RingT, Hook, SPREAD>(acc, A, ring, hook);
     else strip_mma_sel<D, RingT::BF16>(acc, A, buf, hook);
 }
 

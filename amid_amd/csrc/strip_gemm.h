@@ -383,6 +383,9 @@ template <int D> struct WDma16 {
         off0 = (unsigned)(n * D * 2 + ((pos ^ (n & 15)) * 16));
     }
     __device__ __forceinline__ void piece(float* __restrict__ buf, const float* __restrict__ W, int k0) const {
+#ifdef AMID_EXP_NO_DMA      // (variant libraries only: what a launch costs when its weight stream is free -- results are garbage)
+        return;
+#endif
         const unsigned voff = off0 + (unsigned)k0 * (unsigned)(STRIP_WAVES * 64 / CPR) * (unsigned)(D * 2);      // 16 rows further: n & 15 unchanged
         const unsigned lds = __builtin_amdgcn_readfirstlane(
             lds_offset(buf + (k0 * STRIP_WAVES + w) * 256));
@@ -461,13 +464,21 @@ template <class F, int... Is> __device__ __forceinline__ void static_for_impl(co
 }
 template <int N, class F> __device__ __forceinline__ void static_for(const F& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-template <int D, class RingT, class Hook = NoDeferred>
+// SPREAD: the hook's 8 D / 16 slots run one per step INSIDE the two passes (slot 0 -- the ring's fetch() registration -- in front):
+// BERT4Rec's chains carry the dropout counters' Philox rounds in their hooks (bert_strip.hip KeepGen: ~84 vector cycles per slot), which
+// a lone wave issues beside its matrix instructions when they stand between them and in front of them when they stand in front.
+template <int D, class RingT, class Hook = NoDeferred, bool SPREAD = false>
 __device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripRegs<D>& A, RingT& ring, const Hook& hook = NoDeferred()) {
     constexpr int NT = D / 16, KS = D / 32;
+    static_assert(!SPREAD || KS * NT * 2 == 8 * NT, "one hook slot per step of the two passes");
+    if constexpr (SPREAD) {
+        hook(0, 0);
+    } else {
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
+        for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hook(ct, j);           // (deferred stores; the ring learns the next weight from its fetch() calls)
+            for (int j = 0; j < 8; ++j) hook(ct, j);       // (deferred stores; the ring learns the next weight from its fetch() calls)
+    }
     ring.begin();
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;
@@ -510,6 +521,7 @@ __device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripR
             acc[co] = mma(wm[k], am[s], acc[co]);
             lds_frag_wait<2 * (last - t)>(wl[k]);
             acc[co] = mma(wl[k], ah[s], acc[co]); acc[co] = mma(wm[k], ah[s], acc[co]);
+            if constexpr (SPREAD && t > 0) hook(t / 8, t % 8);                                  // slots 1 .. NSTEP - 1
         });
     }
     STRIP_STAMP(29);
@@ -529,6 +541,7 @@ __device__ __forceinline__ void strip_mma16x6(f32x4 (&acc)[D / 16], const StripR
             constexpr int last = t + PD2 < NSTEP ? t + PD2 : NSTEP - 1;
             lds_frag_wait<last - t>(wf[k]);
             acc[co] = mma(wf[k], al[s], acc[co]); acc[co] = mma(wf[k], am[s], acc[co]); acc[co] = mma(wf[k], ah[s], acc[co]);
+            if constexpr (SPREAD) hook((NSTEP + t) / 8, (NSTEP + t) % 8);                       // slots NSTEP .. 2 NSTEP - 1
         });
     }
     STRIP_STAMP(31);

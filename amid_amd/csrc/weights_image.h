@@ -8,8 +8,11 @@ namespace amid {
 
 // chunk q = n * (D / 8) + c of the image: row n, chunk c = 4 s + g = W[n][32 s + 4 g + 0..3], W[n][32 s + 16 + 4 g + 0..3];
 // planes = 3: every element as hi + mid + lo, one image per piece ([3][D][D] bf16 per matrix)
+// ld: floats between the source's rows (0: D -- a [D][D] matrix of its own; BERT4Rec's feed-forward weights are walked as D x D blocks of
+// a [512][128] / [128][512] matrix: bert_strip.hip)
 __device__ __forceinline__ void weights_image_block(const float* __restrict__ W, unsigned short* __restrict__ out, int D, int transposed,
-                                                    int planes, int block, int nblocks) {
+                                                    int planes, int block, int nblocks, int ld = 0) {
+    if (ld == 0) ld = D;
     const int cpr = D / 8;
     for (int q = block * 256 + threadIdx.x; q < D * cpr; q += nblocks * 256) {
         const int n = q / cpr, c = q % cpr;
@@ -20,8 +23,8 @@ __device__ __forceinline__ void weights_image_block(const float* __restrict__ W,
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int k = 32 * s + 16 * h + 4 * g + 2 * e;
-                const float v0 = transposed ? W[(size_t)k * D + n] : W[(size_t)n * D + k];
-                const float v1 = transposed ? W[(size_t)(k + 1) * D + n] : W[(size_t)n * D + k + 1];
+                const float v0 = transposed ? W[(size_t)k * ld + n] : W[(size_t)n * ld + k];
+                const float v1 = transposed ? W[(size_t)(k + 1) * ld + n] : W[(size_t)n * ld + k + 1];
                 const WgSplit2 sp = wg_split3(v0, v1);        // (hi = the round-to-nearest-even bf16 pair of the one-plane image)
                 pk[0][2 * h + e] = sp.hi; pk[1][2 * h + e] = sp.mid; pk[2][2 * h + e] = sp.lo;
             }

@@ -124,6 +124,7 @@ class Bert4recEngine(SasrecEngine):
     STRIP_KERNELS = True         # the block's GEMM chains on csrc/bert_strip.hip (BertPlan.strip); bert.hip's row-tile kernels beyond 2 GiB
     SORT_RIDERS = False          # (the riders' host launches are the SASRec strip backward's)
     FUSED_TAIL = False           # (the one-launch step head and the folded tail are the SASRec step's)
+    STRIP_P3 = True              # the strips' products on bf16 pieces at fp32 accuracy (csrc/bert_strip.hip MODE 3; False: fp32 matrix instructions)
 
     def live_forward_ok(self, pl) -> bool:
         """Whether this engine's train step on `pl` encodes the live sequences only (engine._enqueue_fwd_bwd): the plain head, no
@@ -248,6 +249,57 @@ class Bert4recEngine(SasrecEngine):
             self._ptr_cache["bert_tr"] = c
         return c
 
+    N_TILE_IMG = 24              # tile images per (block, domain): q k v o | w_1's four | w_2's four | the same twelve transposed
+
+    def _p3(self, pl) -> bool:
+        return bool(self.STRIP_P3 and pl.strip and self.compute == "f32")
+
+    def _tile_images(self):
+        """(host spec arrays of the step's 96 weight-tile images, the image buffer [2 blocks][2 domains][24][3][D D] bf16): tile order per
+        (block, domain) = Wq Wk Wv Wo, W1's four row blocks, W2's four column blocks, then the transposes of the same twelve
+        (include/amid_hip.h amid_bert_weight_images_f32)."""
+        c = self._ptr_cache.get("bert_img")
+        if c is None:
+            fp, D, F = self.dense, self.D, BERT_FF
+            buf = torch.empty(2, 2, self.N_TILE_IMG, 3, D * D, dtype=torch.bfloat16, device=self.device)
+            src, ld, trn = [], [], []
+            for l in (0, 1):
+                for g in (0, 1):
+                    pre = f"transform{g + 1}.{l}"
+                    w1, w2 = fp.ptr(f"{pre}.feed_forward.w_1.weight"), fp.ptr(f"{pre}.feed_forward.w_2.weight")
+                    for t in (0, 1):
+                        for j in range(3):
+                            src.append(fp.ptr(f"{pre}.attention.linear_layers.{j}.weight")); ld.append(D); trn.append(t)
+                        src.append(fp.ptr(f"{pre}.attention.output_linear.weight")); ld.append(D); trn.append(t)
+                        for k in range(4):
+                            src.append(w1 + 4 * k * D * D); ld.append(D); trn.append(t)          # w_1 [512][128]: rows 128 k ...
+                        for k in range(4):
+                            src.append(w2 + 4 * k * D); ld.append(F); trn.append(t)              # w_2 [128][512]: columns 128 k ...
+            n = len(src)
+            c = (ptr_array(src), (ctypes.c_int * n)(*ld), (ctypes.c_int * n)(*trn), n, buf)
+            self._ptr_cache["bert_img"] = c
+        return c
+
+    def _img(self, l: int, g: int, i: int) -> int:
+        """Device address of tile image i of (block l, domain g)."""
+        return self._tile_images()[4][l, g, i].data_ptr()
+
+    def _enqueue_tile_images(self) -> None:
+        src, ld, trn, n, buf = self._tile_images()
+        lib().call("amid_bert_weight_images_f32", src, ld, trn, n, buf.data_ptr(), self.s)
+
+    def _block_img_ptrs(self, l: int):
+        key = ("bert_blk_img", l)
+        c = self._ptr_cache.get(key)
+        if c is None:
+            I = self._img
+            c = dict(w3=ptr_array([I(l, g, j) for j in range(3) for g in (0, 1)]), wo=ptr_array([I(l, g, 3) for g in (0, 1)]),
+                     w1=ptr_array([I(l, g, 4) for g in (0, 1)]), w2=ptr_array([I(l, g, 8) for g in (0, 1)]),
+                     wT3=ptr_array([I(l, g, 12 + j) for j in range(3) for g in (0, 1)]), woT=ptr_array([I(l, g, 15) for g in (0, 1)]),
+                     w1T=ptr_array([I(l, g, 16) for g in (0, 1)]), w2T=ptr_array([I(l, g, 20) for g in (0, 1)]))
+            self._ptr_cache[key] = c
+        return c
+
     def _enqueue_blocks_strip(self, pl: BertPlan, lf, st, tr) -> None:
         """Both blocks on the strip kernels (csrc/bert_strip.hip): q / k / v of block 0, then per block the attention core and ONE launch
         for the out-projection, the feed-forward and -- block 0 -- the next block's LayerNorm + q / k / v.  lf: the live list (a train
@@ -258,10 +310,16 @@ class Bert4recEngine(SasrecEngine):
         p0, p1 = self._block_ptrs(0), self._block_ptrs(1)
         # the step's prologue rides in this launch: the key mask (not with a comp module: its tiled mask has a launch of its own) and,
         # when a backward will follow, the transposed weights
-        trl = self._transpose_lists() if pl.need_grad else None
-        pl.transposed_in_forward = trl is not None
+        p3 = self._p3(pl)
+        pl.p3_fwd = p3
+        if p3:                       # this step's weight tiles as three-plane images (forward tiles and, for the backward, their transposes)
+            self._enqueue_tile_images()
+            i0, i1 = self._block_img_ptrs(0), self._block_img_ptrs(1)
+        sfx = "_p3_f32" if p3 else "_f32"
+        trl = self._transpose_lists() if pl.need_grad and not p3 else None
+        pl.transposed_in_forward = trl is not None or p3
         n_tr = len(trl[2]) if trl else 0
-        L.call("amid_bert_strip_qkv_fwd_pro_f32", pl.x[0].data_ptr(), p0["la1"], p0["lb1"], p0["w3"], p0["b3"], B, T, lf, pl.y[0].data_ptr(),
+        L.call("amid_bert_strip_qkv_fwd_pro" + sfx, pl.x[0].data_ptr(), p0["la1"], p0["lb1"], i0["w3"] if p3 else p0["w3"], p0["b3"], B, T, lf, pl.y[0].data_ptr(),
                pl.q[0].data_ptr(), pl.k[0].data_ptr(), pl.v[0].data_ptr(), None if self.comp else pl.in_seq_d2.data_ptr(), B * T,
                pl.key_keep.data_ptr(), trl[0] if trl else None, trl[1] if trl else None, trl[2] if trl else None, trl[3] if trl else None, n_tr, s)
         for l, p in ((0, p0), (1, p1)):
@@ -271,10 +329,11 @@ class Bert4recEngine(SasrecEngine):
             else:
                 L.call("amid_attn_fwd_f32", pl.q[l].data_ptr(), pl.k[l].data_ptr(), pl.v[l].data_ptr(), pl.key_keep.data_ptr(), B, T, D, self.H,
                        0, l, st, tr, BERT_P_DROP, pl.o[l].data_ptr(), pl.stats[l].data_ptr(), s)
-            nxt = ((p1["la1"], p1["lb1"], p1["w3"], p1["b3"], pl.y[1].data_ptr(), pl.q[1].data_ptr(), pl.k[1].data_ptr(), pl.v[1].data_ptr())
+            nxt = ((p1["la1"], p1["lb1"], i1["w3"] if p3 else p1["w3"], p1["b3"], pl.y[1].data_ptr(), pl.q[1].data_ptr(), pl.k[1].data_ptr(), pl.v[1].data_ptr())
                    if l == 0 else (None,) * 8)
-            L.call("amid_bert_strip_oproj_ffn_fwd_f32", pl.o[l].data_ptr(), pl.x[l].data_ptr(), p["wo"], p["bo"], p["la2"], p["lb2"], p["w1"],
-                   p["b1"], p["w2"], p["b2"], B, T, lf, l, st, tr, BERT_P_DROP, pl.x1[l].data_ptr(), pl.y2[l].data_ptr(), pl.pre[l].data_ptr(),
+            w = (i0, i1)[l] if p3 else p
+            L.call("amid_bert_strip_oproj_ffn_fwd" + sfx, pl.o[l].data_ptr(), pl.x[l].data_ptr(), w["wo"], p["bo"], p["la2"], p["lb2"], w["w1"],
+                   p["b1"], w["w2"], p["b2"], B, T, lf, l, st, tr, BERT_P_DROP, pl.x1[l].data_ptr(), pl.y2[l].data_ptr(), pl.pre[l].data_ptr(),
                    pl.h[l].data_ptr(), pl.x[l + 1].data_ptr(), *nxt, s)
 
     def _enqueue_blocks_rowtile(self, pl: BertPlan, st, tr) -> None:
@@ -360,28 +419,37 @@ class Bert4recEngine(SasrecEngine):
         if pl.strip:
             # csrc/bert_strip.hip: block 1's feed-forward / out-projection chain, its attention core and weight gradients, then ONE launch
             # for block 1's q / k / v + LayerNorm backward and block 0's feed-forward / out-projection chain, ..., block 0's q / k / v
+            p3 = bool(getattr(pl, "p3_fwd", False) and self._p3(pl))     # (this step's forward wrote the tile images, transposes included)
+            sfx = "_p3_f32" if p3 else "_f32"
+
             def ffn_args(l):
+                if p3:
+                    im = self._block_img_ptrs(l)
+                    return (pl.pre[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(f"transform{{d}}.{l}.output_sublayer.norm.a_2"),
+                            im["w2T"], im["w1T"], im["woT"])
                 return (pl.pre[l].data_ptr(), pl.x1[l].data_ptr(), self._pp(f"transform{{d}}.{l}.output_sublayer.norm.a_2"),
                         ptr_array([self.w2T[l, g].data_ptr() for g in (0, 1)]), ptr_array([self.w1T[l, g].data_ptr() for g in (0, 1)]),
                         ptr_array([self.wT_sq[l, g, 3].data_ptr() for g in (0, 1)]))
             ffn_out = (pl.dz.data_ptr(), pl.dpre.data_ptr(), pl.dx1.data_ptr(), pl.dt.data_ptr(), pl.d_o.data_ptr())
             pre1, x11, la21, w2T1, w1T1, woT1 = ffn_args(1)
-            L.call("amid_bert_strip_ffn_bwd_f32", pl.dxbuf.data_ptr(), pre1, x11, la21, w2T1, w1T1, woT1, B, T, lv, 1, st, tr, BERT_P_DROP, *ffn_out,
+            L.call("amid_bert_strip_ffn_bwd" + sfx, pl.dxbuf.data_ptr(), pre1, x11, la21, w2T1, w1T1, woT1, B, T, lv, 1, st, tr, BERT_P_DROP, *ffn_out,
                    pl.ln2_part[1].data_ptr(), s)
             for l in (1, 0):
                 attn_bwd(l)
                 wgrad(l)
-                wT3 = ptr_array([self.wT_sq[l, g, j].data_ptr() for j in range(3) for g in (0, 1)])
+                wT3 = (self._block_img_ptrs(l)["wT3"] if p3 else
+                       ptr_array([self.wT_sq[l, g, j].data_ptr() for j in range(3) for g in (0, 1)]))
                 la1 = self._pp(f"transform{{d}}.{l}.input_sublayer.norm.a_2")
                 if l == 1:
-                    L.call("amid_bert_strip_qkv_bwd_f32", pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[1].data_ptr(),
+                    L.call("amid_bert_strip_qkv_bwd" + sfx, pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[1].data_ptr(),
                            la1, wT3, B, T, lv, None, 0, pl.ln1_part[1].data_ptr(), *ffn_args(0), 0, st, tr, BERT_P_DROP, *ffn_out,
                            pl.ln2_part[0].data_ptr(), s)
                 else:
                     dx_out = pl.dx0 if self.comp else pl.dxg
-                    L.call("amid_bert_strip_qkv_bwd_f32", pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[0].data_ptr(),
+                    L.call("amid_bert_strip_qkv_bwd" + sfx, pl.dq.data_ptr(), pl.dk.data_ptr(), pl.dv.data_ptr(), pl.dx1.data_ptr(), pl.x[0].data_ptr(),
                            la1, wT3, B, T, lv, dx_out.data_ptr(), 1 if lv is not None else 0, pl.ln1_part[0].data_ptr(), None, None, None, None,
                            None, None, 0, None, 0, 0.0, None, None, None, None, None, None, s)
+            pl.p3_fwd = False
         for l in ((1, 0) if not pl.strip else ()):
             pre = f"transform{{d}}.{l}"
             wsq = lambda j: ptr_array([self.wT_sq[l, g, j].data_ptr() for g in (0, 1)])      # noqa: E731

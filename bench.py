@@ -222,6 +222,11 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_bert_strip_ffn_bwd_f32": ("mfma", 9 * gl),
         "amid_bert_strip_qkv_bwd_f32#0": ("mfma", 12 * gl),            # block 1's q / k / v backward + block 0's feed-forward / out-projection backward
         "amid_bert_strip_qkv_bwd_f32#1": ("mfma", 3 * gl),
+        # ... with every product as six bf16 piece pairs (round 5, Bert4recEngine.STRIP_P3): the same algorithmic FLOP against the bf16 peak / 6
+        "amid_bert_strip_qkv_fwd_pro_p3_f32": ("mfma16x6", 3 * gl),
+        "amid_bert_strip_oproj_ffn_fwd_p3_f32#0": ("mfma16x6", 12 * gl), "amid_bert_strip_oproj_ffn_fwd_p3_f32#1": ("mfma16x6", 9 * gl),
+        "amid_bert_strip_ffn_bwd_p3_f32": ("mfma16x6", 9 * gl),
+        "amid_bert_strip_qkv_bwd_p3_f32#0": ("mfma16x6", 12 * gl), "amid_bert_strip_qkv_bwd_p3_f32#1": ("mfma16x6", 3 * gl),
         "amid_attn_bert_fwd_live_f32": ("mfma", 4.0 * T * T * (D // 4) * Bw * 4),
         "amid_attn_bert_bwd_live_f32": ("mfma", 10.0 * T * T * (D // 4) * Bw * 4),
         "amid_bert_qkv_fwd_f32": ("mfma", 3 * gemm),
@@ -279,6 +284,9 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_seq_fwd_split_lnstat_f32": ("seqn_fwd_px_kernel",), "amid_sas_wgrad_rows_sort_ln_f32": "sas_wgrad_split_kernel",
     "amid_sas_strip_qkv_bwd_sort_scorer_f32": "strip_qkv_bwd_kernelILi128ELb1", "amid_head_fwd_bwd_own_vec_f32": "head_fwd_bwd_kernel",
     "amid_grad_tail_live_f32": "grad_tail_live_kernel", "amid_optimizer_step_spans_f32": "optimizer_step_spans_kernel",
+    "amid_bert_strip_qkv_fwd_pro_p3_f32": "bert_strip_qkv_fwd_kernel", "amid_bert_strip_oproj_ffn_fwd_p3_f32#0": "bert_strip_oproj_ffn_fwd_kernelILb1",
+    "amid_bert_strip_oproj_ffn_fwd_p3_f32#1": "bert_strip_oproj_ffn_fwd_kernelILb0", "amid_bert_strip_ffn_bwd_p3_f32": "bert_strip_ffn_bwd_kernel",
+    "amid_bert_strip_qkv_bwd_p3_f32#0": "bert_strip_qkv_bwd_kernelILb1", "amid_bert_strip_qkv_bwd_p3_f32#1": "bert_strip_qkv_bwd_kernelILb0",
     "amid_bert_strip_qkv_fwd_pro_f32": "bert_strip_qkv_fwd_kernel", "amid_bert_strip_oproj_ffn_fwd_f32#0": "bert_strip_oproj_ffn_fwd_kernelILb1",
     "amid_bert_strip_oproj_ffn_fwd_f32#1": "bert_strip_oproj_ffn_fwd_kernelILb0", "amid_bert_strip_ffn_bwd_f32": "bert_strip_ffn_bwd_kernel",
     "amid_bert_strip_qkv_bwd_f32#0": "bert_strip_qkv_bwd_kernelILb1", "amid_bert_strip_qkv_bwd_f32#1": "bert_strip_qkv_bwd_kernelILb0",
@@ -570,6 +578,8 @@ def main():
         name, _, val = kv.partition("=")
         from amid_amd.plan import SasrecPlan
         holder = SasrecPlan if name == "WGRAD_SPLITS" else SasrecEngine
+        if not hasattr(holder, name) and args.model == "bert4rec":
+            from amid_amd.engine_bert import Bert4recEngine as holder        # (its own switches: STRIP_P3)
         if not hasattr(holder, name):
             raise SystemExit(f"--set {kv}: {holder.__name__} has no switch {name}")
         cur = getattr(holder, name)
@@ -722,7 +732,7 @@ def main():
         durs = L.timer.collect(L)
         L.timer = None
         for name in ("amid_sas_strip_oproj_ffn_fwd_f32", "amid_sas_strip_qkv_bwd_f32", "amid_bert_strip_oproj_ffn_fwd_f32",
-                     "amid_bert_strip_qkv_bwd_f32"):      # two different launches per step under one entry
+                     "amid_bert_strip_qkv_bwd_f32", "amid_bert_strip_oproj_ffn_fwd_p3_f32", "amid_bert_strip_qkv_bwd_p3_f32"):      # two different launches per step under one entry
             v = durs.pop(name, None)
             if v is not None and len(v) == 2 * n_prof:
                 durs[name + "#0"], durs[name + "#1"] = v[0::2], v[1::2]

@@ -858,6 +858,36 @@ int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const float* g, 
                                   const void* step_state, const int* seg_off, const int* seg_of, int n_sorted, const void* workspace,
                                   void* stream);
 
+/* ---- BERT4Rec strips on bf16 pieces (round 5; csrc/bert_strip.hip MODE 3) ------------------------------------------------------------------
+ * The strip launches of a TransformerBlock (model_seq.py:242-245 and its autograd) with every product as six bf16 piece pairs at fp32
+ * accuracy -- what SASRec's strips run on since round 4.  Each 128 x 128 weight TILE a chain multiplies with is a three-plane fragment image
+ * (hi + mid + lo = the fp32 element exactly) written once per step by amid_bert_weight_images_f32: tile i = src[i][r * ld[i] + c] (tr[i] = 0)
+ * or its transpose (tr[i] != 0), r, c < 128, n <= 96 tiles, dst16 [n][3][128][128] bf16.  The *_p3 entry points take the argument lists of
+ * their fp32 twins with every weight pointer replaced by a pointer to tile images (as float*): w3 / wo / wT3 / woT -- one image each; w1, w2,
+ * w1T, w2T -- the FIRST of the matrix's four tiles' images, the others 3 * 128 * 128 bf16 further each (w_1 [512][128] and w_2^T: row blocks;
+ * w_2 [128][512] and w_1^T: column blocks). */
+int amid_bert_weight_images_f32(const float* const* src, const int* ld, const int* tr, int n, void* dst16, void* stream);
+int amid_bert_strip_qkv_fwd_pro_p3_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3_img,
+                                       const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k, float* v,
+                                       const long long* seq_d2, int n_keys, unsigned char* key_keep, const float* const* tr_src,
+                                       float* const* tr_dst, const int* tr_rows, const int* tr_cols, int n_tr, void* stream);
+int amid_bert_strip_oproj_ffn_fwd_p3_f32(const float* o, const float* x, const float* const* wo_img, const float* const* bo,
+                                         const float* const* la, const float* const* lb, const float* const* w1_img, const float* const* b1,
+                                         const float* const* w2_img, const float* const* b2, int B, int T, const int* live, int layer,
+                                         const void* step_state, int train, float p_drop, float* x1, float* y2, float* pre, float* h,
+                                         float* x2, const float* const* nla, const float* const* nlb, const float* const* nw3_img,
+                                         const float* const* nb3, float* ny, float* nq, float* nk, float* nv, void* stream);
+int amid_bert_strip_ffn_bwd_p3_f32(const float* dx2, const float* pre, const float* x1, const float* const* la, const float* const* w2T_img,
+                                   const float* const* w1T_img, const float* const* woT_img, int B, int T, const int* live, int layer,
+                                   const void* step_state, int train, float p_drop, float* dz, float* dpre, float* dx1, float* dt,
+                                   float* d_o, float* ln_part, void* stream);
+int amid_bert_strip_qkv_bwd_p3_f32(const float* dq, const float* dk, const float* dv, const float* dx1, const float* x,
+                                   const float* const* la, const float* const* wT3_img, int B, int T, const int* live, float* dx,
+                                   int zero_dead, float* ln_part, const float* fpre, const float* fx1, const float* const* fla,
+                                   const float* const* fw2T_img, const float* const* fw1T_img, const float* const* fwoT_img, int flayer,
+                                   const void* step_state, int train, float p_drop, float* fdz, float* fdpre, float* fdx1, float* fdt,
+                                   float* fd_o, float* fln_part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

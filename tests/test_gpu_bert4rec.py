@@ -124,6 +124,46 @@ def test_backward_grads_vs_oracle(train):
     grads_check(f"bert bwd train={train}", eng, pl, grads, 2e-4, 2e-4)          # GELU is smooth: no knife edge here
 
 
+@pytest.mark.parametrize("Bn,T", [(64, 50), (256, 20), (9, 13)])
+def test_strips_on_bf16_pieces_have_fp32_accuracy(Bn, T):
+    """Bert4recEngine.STRIP_P3 (csrc/bert_strip.hip MODE 3: every strip product as six bf16 piece pairs over three-plane tile images,
+    amid_bert_weight_images_f32) against the fp32 matrix instructions on the same step, dropout on: every saved activation and every
+    gradient within 4e-6 of its tensor's largest entry (the bar of SASRec's strips on pieces, tests/test_gpu_seqn.py); operands ROUNDED to
+    bf16 would sit at 3e-3.  The three-plane images sum to the weight tiles exactly."""
+    hid, n_items = 32, 900
+    P = orc.random_params(orc.bert4rec_param_shapes(n_items, hid), seed=70 + T)
+    batch = batch_with_masked_keys(Bn, T, n_items, seed=12)
+    seed, step = 17, 6
+    out = {}
+    for p3 in (False, True):
+        eng = make_engine(P, T, seed=seed)
+        eng.STRIP_P3 = p3
+        pl = run_forward(eng, batch, train=True, with_loss=True, step=step, seed=seed)
+        assert pl.strip and bool(getattr(pl, "p3_fwd", False)) == p3
+        eng.enqueue_backward(pl, train=True)
+        eng.sync()
+        rec = {f"{k}{l}": getattr(pl, k)[l].clone() for k in ("q", "k", "v", "x1", "y2", "pre", "h") for l in (0, 1)}
+        rec.update(x1_=pl.x[1].clone(), x2_=pl.x[2].clone(), loss=pl.loss.clone(), rows=dense_table_grad(eng, pl))
+        rec.update({"g:" + n: eng.dense.view(n, eng.dense.grad).clone() for n in eng.dense.slots})
+        out[p3] = rec
+        if p3:      # hi + mid + lo of every tile image = the fp32 tile, bit for bit
+            src, ld, trn, n, buf = eng._tile_images()
+            img = buf.float().sum(3).cpu()                  # [2][2][24][D D] in fragment order: compare as multisets per tile
+            w = eng.dense.view("transform1.0.attention.linear_layers.0.weight", eng.dense.data).float().cpu().reshape(-1)
+            assert torch.equal(torch.sort(img[0, 0, 0]).values, torch.sort(w).values)
+            assert torch.equal(torch.sort(img[0, 0, 12]).values, torch.sort(w).values)
+    worst = 0.0
+    for name, want in out[False].items():
+        got = out[True][name]
+        if name.endswith("linear_layers.1.bias"):
+            continue                                         # (analytically zero: rounding noise on both sides)
+        live = want.abs().max()
+        e = float((got - want).abs().max() / live.clamp(min=1e-30))
+        worst = max(worst, e)
+        assert e < 4e-6, (name, e)
+    log(f"bert strips on pieces B={Bn} T={T}: worst deviation from the fp32 instructions {worst:.2e} of a tensor's largest entry")
+
+
 @pytest.mark.parametrize("Bn,T,build", [(256, 50, ""), (128, 50, "_rt5"), (256, 20, "_rt3")])
 def test_tile_builds_forward_backward_vs_oracle(Bn, T, build):
     """The three builds of the row-tile kernels (112 / 80 / 48 rows per workgroup: the headline batch, half of it, the mybank
