@@ -135,7 +135,10 @@ __global__ void pack_indices_pool_kernel(const long long* __restrict__ pool, lon
 // in one kernel the gather ran at 178 VGPRs / 6.4 KB of LDS instead of 109 / 0 and cfg 5's K1 went from 52.8 to 81.4 us.
 // W16: the first workgroups write this step's bf16 fragment images of the encoder weights (the one-launch forward on bf16 pieces reads them;
 // as a launch of its own the 72 planes cost 4.9 us of a 0.355 ms step)
-struct W16Rider { const float* src[24]; unsigned short* dst; unsigned short* dstT; int n, planes, per, D; };   // dstT: images of the TRANSPOSES too (or NULL)
+// n tiles of D x D floats: tile i = src[i][r * ld[i] + c] (tr[i] = 0) or its transpose; the first n_fwd images go to dst, the others to dstT
+// (SASRec: 24 weights + the same 24 transposed into a buffer of their own; BERT4Rec: 96 tiles of its 16 weights, bert_strip.hip)
+constexpr int W16_MAX = 96;
+struct W16Rider { const float* src[W16_MAX]; unsigned short ld[W16_MAX]; unsigned char tr[W16_MAX]; unsigned short* dst; unsigned short* dstT; int n, n_fwd, planes, per, D; };
 template <int RIF, bool FOLD, bool W16 = false>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ table, const int* __restrict__ idx_all,
                                                         const float* __restrict__ pos0, const float* __restrict__ pos1,
@@ -150,13 +153,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
     // launch while that launch existed)
     int nrb = 0;
     if constexpr (W16) {
-        const int nfw = wr.n * wr.per;
-        nrb = wr.dstT != nullptr ? 2 * nfw : nfw;
+        nrb = wr.n * wr.per;
         if ((int)blockIdx.x < nrb) {
-            const int tr = (int)blockIdx.x >= nfw ? 1 : 0;          // second half: the transposes' images (the backward strips read those)
-            const int b = blockIdx.x - tr * nfw, wi = b / wr.per;
-            weights_image_block(wr.src[wi], (tr ? wr.dstT : wr.dst) + (size_t)wi * wr.planes * wr.D * wr.D, wr.D, tr, wr.planes, b - wi * wr.per,
-                                wr.per);
+            const int wi = blockIdx.x / wr.per;
+            unsigned short* out = wi < wr.n_fwd ? wr.dst + (size_t)wi * wr.planes * wr.D * wr.D
+                                                : wr.dstT + (size_t)(wi - wr.n_fwd) * wr.planes * wr.D * wr.D;
+            weights_image_block(wr.src[wi], out, wr.D, wr.tr[wi], wr.planes, blockIdx.x - wi * wr.per, wr.per, wr.ld[wi]);
             return;
         }
     }
@@ -533,13 +535,23 @@ static int embed_fwd(const float* table, const int* idx_all, const float* pos0, 
                      int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop, const int* live,
                      int* idx_c, int* row_c, void* stream, const float* m_tab = nullptr, const float* v_tab = nullptr, const int* last = nullptr,
                      const void* adam_state = nullptr, const void* sort_plan = nullptr, int sort_phase = 0, const float* const* w_src = nullptr,
-                     int n_w = 0, int w_planes = 0, void* w16_dst = nullptr, void* w16t_dst = nullptr) {
+                     int n_w = 0, int w_planes = 0, void* w16_dst = nullptr, void* w16t_dst = nullptr, const int* w_ld = nullptr,
+                     const int* w_tr = nullptr) {
     AMID_CHECK_ARG(last == nullptr || (m_tab && v_tab && adam_state));
     W16Rider wr = {};
     if (w_src != nullptr) {
-        AMID_CHECK_ARG(n_w > 0 && n_w <= 24 && (w_planes == 1 || w_planes == 3) && w16_dst && D == 128 && last == nullptr && sort_plan == nullptr);
-        for (int i = 0; i < n_w; ++i) { AMID_CHECK_ARG(w_src[i]); wr.src[i] = w_src[i]; }
-        wr.dst = (unsigned short*)w16_dst; wr.dstT = (unsigned short*)w16t_dst; wr.n = n_w; wr.planes = w_planes; wr.D = D; wr.per = (D * (D / 8) + 255) / 256;
+        AMID_CHECK_ARG(n_w > 0 && (w_planes == 1 || w_planes == 3) && w16_dst && D == 128 && last == nullptr && sort_plan == nullptr);
+        AMID_CHECK_ARG((w_ld == nullptr) == (w_tr == nullptr) && n_w * (w_ld == nullptr && w16t_dst ? 2 : 1) <= W16_MAX && (w_ld == nullptr || !w16t_dst));
+        for (int i = 0; i < n_w; ++i) {
+            AMID_CHECK_ARG(w_src[i] && (w_ld == nullptr || (w_ld[i] >= D && w_ld[i] < 65536)));
+            wr.src[i] = w_src[i]; wr.ld[i] = (unsigned short)(w_ld ? w_ld[i] : D); wr.tr[i] = (unsigned char)(w_tr && w_tr[i] ? 1 : 0);
+        }
+        wr.n = wr.n_fwd = n_w;
+        if (w16t_dst != nullptr) {                     // the same matrices transposed, into their own buffer
+            for (int i = 0; i < n_w; ++i) { wr.src[n_w + i] = w_src[i]; wr.ld[n_w + i] = (unsigned short)D; wr.tr[n_w + i] = 1; }
+            wr.n = 2 * n_w;
+        }
+        wr.dst = (unsigned short*)w16_dst; wr.dstT = (unsigned short*)w16t_dst; wr.planes = w_planes; wr.D = D; wr.per = (D * (D / 8) + 255) / 256;
     }
     SortRider rd;
     rd.phase = 0;
@@ -561,7 +573,7 @@ static int embed_fwd(const float* table, const int* idx_all, const float* pos0, 
             table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, (const RngState*)rng_state, tr, keep_thr16(p_drop),
             tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd, wr);
     else if (wr.n > 0)
-        embed_fwd_kernel<EMBED_RIF, false, true><<<embed_grid(n_walk, chunk) + wr.n * wr.per * (wr.dstT ? 2 : 1), 256, 0, (hipStream_t)stream>>>(
+        embed_fwd_kernel<EMBED_RIF, false, true><<<embed_grid(n_walk, chunk) + wr.n * wr.per, 256, 0, (hipStream_t)stream>>>(
             table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, (const RngState*)rng_state, tr, keep_thr16(p_drop),
             tr ? 1.0f / (1.0f - p_drop) : 1.0f, live, idx_c, row_c, chunk, m_tab, v_tab, last, (const StepState*)adam_state, rd, wr);
     else
@@ -619,6 +631,17 @@ extern "C" int amid_embed_fwd_w16_f32(const float* table, const int* idx_all, co
     AMID_CHECK_ARG(w_src != nullptr);
     return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, live, idx_c, row_c, stream, nullptr,
                      nullptr, nullptr, nullptr, nullptr, 0, w_src, n_w, w_planes, w16_dst, w16t_dst);
+}
+
+// ... with the riders' tiles spelled out: tile i = w_src[i][r * w_ld[i] + c] or (w_tr[i] != 0) its transpose, r, c < D = 128, n_w <= 96 tiles,
+// images to w16_dst [n_w][planes][D][D] bf16 (amid_bert_weight_images_f32 is the launch this saves: BERT4Rec's strips on bf16 pieces)
+extern "C" int amid_embed_fwd_tiles_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D,
+                                        int n_item_rows, float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop,
+                                        const int* live, const float* const* w_src, const int* w_ld, const int* w_tr, int n_w, int w_planes,
+                                        void* w16_dst, void* stream) {
+    AMID_CHECK_ARG(w_src != nullptr && w_ld != nullptr && w_tr != nullptr);
+    return embed_fwd(table, idx_all, pos0, pos1, B, T, D, n_item_rows, xg, tmq, rng_state, train, p_drop, live, nullptr, nullptr, stream, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, 0, w_src, n_w, w_planes, w16_dst, nullptr, w_ld, w_tr);
 }
 
 extern "C" int amid_live_list_i32(const long long* domain, int B, int* live, void* stream) {

@@ -284,6 +284,20 @@ class Bert4recEngine(SasrecEngine):
         """Device address of tile image i of (block l, domain g)."""
         return self._tile_images()[4][l, g, i].data_ptr()
 
+    def _enqueue_k1(self, pl, pos0, pos1, tmq, tr: int, p_drop: float, lf) -> None:
+        """The plain gather; with the strips on bf16 pieces its extra workgroups write the step's 96 tile images (amid_embed_fwd_tiles_f32:
+        what amid_bert_weight_images_f32 does in a launch of its own, 11 - 13 us)."""
+        if not (self._p3(pl) and pos0 is None) or (lf is not None and getattr(pl, "compact", False)) or getattr(pl, "fold_catchup", False):
+            pl.tiles_written = False            # (long lists: K1 also writes the compact index list -- the tiles take their own launch)
+            return super()._enqueue_k1(pl, pos0, pos1, tmq, tr, p_drop, lf)
+        shp = pl.shape
+        src, ld, trn, n, buf = self._tile_images()
+        lib().call("amid_embed_fwd_tiles_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), None, None, shp.B, shp.Tenc, self.D, shp.B * shp.NI,
+                   pl.xg.data_ptr(), None, self.step_state.data_ptr(), 0, 0.0, lf, src, ld, trn, n, 3, buf.data_ptr(), self.s)
+        pl.tiles_written = True
+        if getattr(self, "_sort_owed", False):      # (engine.py _enqueue_k1: a deferred side-stream sort starts behind K1)
+            self.enqueue_sort(pl)
+
     def _enqueue_tile_images(self) -> None:
         src, ld, trn, n, buf = self._tile_images()
         lib().call("amid_bert_weight_images_f32", src, ld, trn, n, buf.data_ptr(), self.s)
@@ -313,7 +327,9 @@ class Bert4recEngine(SasrecEngine):
         p3 = self._p3(pl)
         pl.p3_fwd = p3
         if p3:                       # this step's weight tiles as three-plane images (forward tiles and, for the backward, their transposes)
-            self._enqueue_tile_images()
+            if not getattr(pl, "tiles_written", False):      # (the gather K1 of this forward wrote them with extra workgroups)
+                self._enqueue_tile_images()
+            pl.tiles_written = False
             i0, i1 = self._block_img_ptrs(0), self._block_img_ptrs(1)
         sfx = "_p3_f32" if p3 else "_f32"
         trl = self._transpose_lists() if pl.need_grad and not p3 else None

@@ -867,6 +867,10 @@ int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const float* g, 
  * w1T, w2T -- the FIRST of the matrix's four tiles' images, the others 3 * 128 * 128 bf16 further each (w_1 [512][128] and w_2^T: row blocks;
  * w_2 [128][512] and w_1^T: column blocks). */
 int amid_bert_weight_images_f32(const float* const* src, const int* ld, const int* tr, int n, void* dst16, void* stream);
+/* K1 (amid_embed_fwd_live_f32 / amid_embed_fwd_f32 by `live`) carrying amid_bert_weight_images_f32's tiles as extra workgroups of the gather */
+int amid_embed_fwd_tiles_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D, int n_item_rows,
+                             float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop, const int* live,
+                             const float* const* w_src, const int* w_ld, const int* w_tr, int n_w, int w_planes, void* w16_dst, void* stream);
 int amid_bert_strip_qkv_fwd_pro_p3_f32(const float* x, const float* const* la, const float* const* lb, const float* const* w3_img,
                                        const float* const* b3, int B, int T, const int* live, float* y, float* q, float* k, float* v,
                                        const long long* seq_d2, int n_keys, unsigned char* key_keep, const float* const* tr_src,
