@@ -392,6 +392,22 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # (tests compare the two).
     FUSED_TAIL = True
 
+    def _coll(self, fn) -> None:
+        """A collective in the MIDDLE of a step (InterComp's / InnerComp's gathers and reductions under data parallel).  Eagerly: run it.
+        While engine_dp captures the step in segments (_seg_capture: a list), a collective cannot sit inside a captured graph: the capture
+        ends here, the graph so far and the collective are recorded in order, and a new capture begins behind it -- the replay launches
+        graph | collective | graph | ... (engine_dp.train_step_dp)."""
+        seg = getattr(self, "_seg_capture", None)
+        if seg is None:
+            fn()
+            return
+        L = lib()
+        out = ctypes.c_void_p()
+        L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
+        seg.append(("graph", out.value))
+        seg.append(("call", fn))
+        L.call("amid_graph_capture_begin", self.s)
+
     def _folded_step_shape(self, pl: SasrecPlan) -> bool:
         """The conditions of the folded twelve-launch step that do not depend on how the backward runs (_tail2_ok adds those)."""
         return bool(self.FUSED_TAIL and getattr(self, "_in_train_step", False) and self.SORT_RIDERS and pl.need_grad and self.D == 128
@@ -581,12 +597,11 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 # all-gather their scores (per domain, rank order = sample order), each forms the gates of its own rows and its partial
                 # token sums S, the partial sums are all-reduced, and every rank finishes Z -- the same group on every rank
                 ex = self._inc_exchange(pl)
-                for g in (0, 1):
-                    ex.all_gather_packed(pl.inc_s[g], pl.inc_s_g[g])
+                self._coll(lambda: [ex.all_gather_packed(pl.inc_s[g], pl.inc_s_g[g]) for g in (0, 1)])
                 shard = (B, shp.T, D, self.inc_bs, ex.rank * B)
                 L.call("amid_inc_embed_fwd_shard_f32", pl.xg.data_ptr(), pl.inc_s_g.data_ptr(), *wts, self.inc_threshold,
                        fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), *shard, 1, *out)
-                ex.all_reduce_dense(pl.inc_S)
+                self._coll(lambda: ex.all_reduce_dense(pl.inc_S))
                 L.call("amid_inc_embed_fwd_shard_f32", pl.xg.data_ptr(), pl.inc_s_g.data_ptr(), *wts, self.inc_threshold,
                        fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), *shard, 2, *out)
             else:
@@ -715,9 +730,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 # over it :495).  Every rank gathers the shards' pair-max scalars and user vectors (rank r holds rows [r B, (r + 1) B)) and
                 # evaluates the module on all bs rows -- the same arithmetic on the same values on every rank --, then keeps its rows.
                 ex = self._itc_exchange(pl)
-                for g in (0, 1):
-                    ex.all_gather_packed(pl.u_raw[g].reshape(-1), pl.u_raw_g[g].reshape(-1))
-                ex.all_gather_packed(pl.itc_s, pl.itc_s_g)
+                self._coll(lambda: [ex.all_gather_packed(pl.u_raw[g].reshape(-1), pl.u_raw_g[g].reshape(-1)) for g in (0, 1)]
+                           + [ex.all_gather_packed(pl.itc_s, pl.itc_s_g)])
                 u_raw, itc_s, u_out, Bm = pl.u_raw_g, pl.itc_s_g, pl.u_g, self.itc_bs
             L.call("amid_itc_mix_fwd_f32", u_raw.data_ptr(), itc_s.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"),
                    self._pp("itc_d{d}.trans_nn.bias"), self._pp("itc_d{d}.trans_bs.weight"), self._pp("itc_d{d}.trans_bs.bias"),
@@ -757,8 +771,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 # batch on every rank: each rank's own rows of d u_raw then carry the terms of ALL ranks' losses (the group token is built
                 # from everybody's rows), which that rank alone can send on through its encoders
                 ex = self._itc_exchange(pl)
-                for g in (0, 1):
-                    ex.all_gather_packed(pl.du[g].reshape(-1), pl.du_g[g].reshape(-1))
+                self._coll(lambda: [ex.all_gather_packed(pl.du[g].reshape(-1), pl.du_g[g].reshape(-1)) for g in (0, 1)])
                 du_in, u_raw, du_out, Bm = pl.du_g, pl.u_raw_g, pl.du_raw_g, self.itc_bs
             L.call("amid_itc_mix_bwd_f32", du_in.data_ptr(), u_raw.data_ptr(), pl.itc_gate.data_ptr(), pl.itc_z.data_ptr(),
                    pl.itc_sw.data_ptr(), self._pp("itc_d{d}.trans_nn.weight"), self._pp("itc_d{d}.trans_nn.bias"),
@@ -1044,7 +1057,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 ex = self._inc_exchange(pl)
                 shard = (self.inc_bs, ex.rank * B)
                 L.call("amid_inc_bwd_shard_f32", *head, *shard, 1, 1.0 / ex.world, *outs)
-                ex.all_reduce_dense(pl.inc_dZ)
+                self._coll(lambda: ex.all_reduce_dense(pl.inc_dZ))
                 L.call("amid_inc_bwd_shard_f32", *head, *shard, 2, 1.0 / ex.world, *outs)
             else:
                 L.call("amid_inc_bwd_f32", *head, *outs)

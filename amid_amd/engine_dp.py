@@ -50,21 +50,23 @@ class DataParallelMixin:
         if inc_dp:
             # InnerComp under data parallel: bs is the GLOBAL batch, the plan a shard of it; the module's softmax / Linear(bs, 1) over the
             # batch run IN FRONT of the encoders on all-gathered scores and all-reduced token sums, and the group's gradient is all-reduced
-            # at the end of backward (engine.enqueue_train_step's isInC branches) -- collectives cannot sit inside a captured graph
+            # at the end of backward (engine.enqueue_train_step's isInC branches) -- collectives cannot sit inside a captured graph: the step is
+            # captured in segments (below)
             if getattr(self, "comp", ""):
                 raise NotImplementedError("BERT4Rec(isInC / isItC) under data parallel: the token group in front of BERT4Rec's encoders is "
                                           "sharded for SASRec only (amid_inc_*_shard_f32)")
             if getattr(pl, "inc_world", 1) != exchange.world:
                 raise ValueError(f"isInC data parallel: bs = {self.inc_bs} must be world x the per-rank batch ({exchange.world} x {pl.shape.B})")
-            use_graph = False
         itc_dp = bool(self.itc_bs and exchange.active)
         if itc_dp:
             # InterComp under data parallel: bs is the GLOBAL batch, the plan a shard of it; the module's
             # softmax / Linear(bs, 1) over the batch run on gathered scalars and user vectors in the MIDDLE of forward and backward
-            # (engine._enqueue_user_vectors*), so the step is enqueued eagerly -- collectives cannot sit inside a captured graph
+            # (engine._enqueue_user_vectors*) -- collectives cannot sit inside a captured graph: the step is captured in segments (below)
             if getattr(pl, "itc_world", 1) != exchange.world:
                 raise ValueError(f"isItC data parallel: bs = {self.itc_bs} must be world x the per-rank batch ({exchange.world} x {pl.shape.B})")
-            use_graph = False
+        # (round 5) with a known bound the comp steps are captured too, in SEGMENTS cut at their mid-step collectives (engine._coll):
+        # graph | gathers | graph | ... | the step's exchange | graph B; without a bound (or before the capture) they run eagerly
+        self._dp_mid_collectives = bool(itc_dp or inc_dp)
         self._dp_exchange = exchange if (itc_dp or inc_dp) else None
         try:
             self._train_step_dp(pl, exchange, use_graph, umax, dense)
@@ -83,15 +85,22 @@ class DataParallelMixin:
             fast = (use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")
                     and not exchange.use_owner(umax, self.D))      # the owner-bucketed exchange sizes its buffers per step: eager
             pair = getattr(pl, "dp_graphs", {}).get((self._graph_key(), umax, dense)) if fast else None
-            if pair is not None:       # graph A, the collective(s), graph B
-                L.call("amid_graph_launch", pair[0], self.s)
+            if pair is not None:       # graph A (comp models: its segments with their collectives between them), the collective(s), graph B
+                if isinstance(pair[0], list):
+                    for kind, item in pair[0]:
+                        if kind == "graph":
+                            L.call("amid_graph_launch", item, self.s)
+                        else:
+                            item()
+                else:
+                    L.call("amid_graph_launch", pair[0], self.s)
                 self.step += 1
                 exchange.all_gather_packed(pair[2], pair[3])
                 if dense == "allreduce":
                     exchange.all_reduce_dense(self.dense.grad)
                 L.call("amid_graph_launch", pair[1], self.s)
                 return
-            if use_graph:
+            if use_graph and not getattr(self, "_dp_mid_collectives", False):
                 L.call("amid_graph_launch", pl.graphs_local[self._graph_key()], self.s)
                 self.step += 1
             else:
@@ -100,7 +109,8 @@ class DataParallelMixin:
             merged = exchange.exchange_sparse(pl.uniq_ids, pl.uniq_grad, pl.n_uniq, umax=umax)
             self.enqueue_optimizer(pl, sparse=merged if exchange.active else None)
         if fast:                               # this step ran eagerly (it also warmed every kernel up); capture the pair for the next ones
-            self._capture_dp_pair(pl, exchange, int(umax), dense)
+            with torch.cuda.stream(self.stream):      # (the comp models' steps hold torch copies: they must land on the capturing stream)
+                self._capture_dp_pair(pl, exchange, int(umax), dense)
 
     def _capture_dp_pair(self, pl: SasrecPlan, exchange, umax: int, dense: str = "gather") -> None:
         L, be = lib(), exchange.backend
@@ -120,17 +130,24 @@ class DataParallelMixin:
                 if part == 0:          # the tail of backward packs the chunk itself: no padding launch (amid_grad_tail_pack_f32)
                     send = be.send[: be.chunk_rows(umax, dgrad) * self.D]
                     self._tail_pack = (send, umax, in_chunk)
+                    segs = [] if getattr(self, "_dp_mid_collectives", False) else None
+                    self._seg_capture = segs          # (engine._coll cuts the capture at every mid-step collective)
                     try:
                         self.enqueue_local_grads(pl)
                     finally:
                         self._tail_pack = None
+                        self._seg_capture = None
                 else:
                     recv = be.gather_buffer(exchange.world, umax, dense=dgrad)
                     self.enqueue_optimizer_gathered(be, recv, exchange.world, umax, dense_in_chunk=in_chunk)
             finally:
                 out = ctypes.c_void_p()
                 L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
-            graphs.append(out.value)
+            if part == 0 and segs is not None:
+                segs.append(("graph", out.value))
+                graphs.append(segs)
+            else:
+                graphs.append(out.value)
         self.step = step0                      # capture does not execute
         if not hasattr(pl, "dp_graphs"):
             pl.dp_graphs = {}

@@ -44,4 +44,21 @@ for dense in ("gather", "allreduce"):
     run(5, True, dense)
     print("dp path, fixed bound %d, graph pair, dense exchange = %s : %.4f ms/step" % (cap, dense, run(200, True, dense)))
 print("dp path, host sync / step: %.4f ms/step" % run(200, False))
+# round 5: isItC under the data-parallel path -- the step used to be enqueued eagerly (collectives in the middle of forward and backward);
+# with a known bound it is now captured in segments cut at those collectives (engine._coll) and replayed
+eng2 = SasrecEngine(bench.N_ROWS, bench.D, bench.T, bench.HID, lr=5e-4, seed=1, itc_bs=bench.B, itc_threshold=0.2)
+bench.init_params(eng2, 0)
+pl2 = eng2.plan(bench.B, bench.T, 2, True)
+ex2 = SparseDenseExchange(eng2.merge_backend(pl2.shape.n_idx), always=True)
+eng2.set_input_pool(pl2, torch.stack([eng2.pack_batch(pl2, *[bench.synth_batch(gen, "cuda")[k] for k in ("i_node", "neg_samples", "seq_d1", "seq_d2", "label", "domain_id")]) for _ in range(30)]))
+def run2(n, use_graph):
+    eng2.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(n):
+        eng2.train_step_dp(pl2, ex2, use_graph=use_graph, umax=eng2.n_sparse_train(pl2))
+    eng2.sync(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+run2(5, False)
+print("isItC dp path, eager launches : %.4f ms/step" % run2(100, False))
+run2(5, True)
+print("isItC dp path, graph segments : %.4f ms/step" % run2(100, True))
 eng.sync(); torch.cuda.synchronize(); dist.barrier(); dist.destroy_process_group()

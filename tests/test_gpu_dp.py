@@ -192,8 +192,11 @@ def _itc_worker(rank, world, port, q):
         for batch in batches:
             local = {k: v.cuda() for k, v in shard_batch(batch, rank, world).items()}
             eng.load_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"], local["domain_id"])
-            eng.train_step_dp(pl, ex, use_graph=True)          # (asked for graphs: the step must fall back to eager launches by itself)
+            # a bound the host knows (here the largest possible): from the second step on the step replays graph segments cut at InterComp's
+            # mid-step collectives (engine._coll); the first step runs eagerly and captures them
+            eng.train_step_dp(pl, ex, use_graph=True, umax=eng.n_sparse_train(pl))
             eng.sync()
+            assert any(isinstance(v[0], list) and len(v[0]) >= 5 for v in getattr(pl, "dp_graphs", {}).values()), "the step was not captured in segments"
             gates.append(pl.itc_gate.cpu().clone())
         eng.flush_table()
         eng.sync()
@@ -281,8 +284,10 @@ def _inc_worker(rank, world, port, q):
         for batch in batches:
             local = {k: v.cuda() for k, v in shard_batch(batch, rank, world).items()}
             eng.load_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"], local["domain_id"])
-            eng.train_step_dp(pl, ex, use_graph=True)          # (asked for graphs: the step must fall back to eager launches by itself)
+            # (as the InterComp worker: eager first step, then graph segments cut at InnerComp's gather and its two all-reduces)
+            eng.train_step_dp(pl, ex, use_graph=True, umax=eng.n_sparse_train(pl))
             eng.sync()
+            assert any(isinstance(v[0], list) and len(v[0]) >= 7 for v in getattr(pl, "dp_graphs", {}).values()), "the step was not captured in segments"
             gates.append(pl.inc_gate.cpu().clone())
         eng.flush_table()
         eng.sync()
