@@ -228,8 +228,8 @@ class SASRec(nn.Module):
                 ob_label = torch.zeros(B, dtype=torch.int64, device=seq_d1.device)
         eng.load_batch(pl, i_node, neg, seq_d1, seq_d2, labels, domain_id, ob_label if eng.dr else None)
         if exchange is not None and exchange.world > 1:
-            use_graph = use_graph and not (eng.itc_bs or eng.inc_bs)      # (isItC / isInC: collectives inside the step, train_step_dp enqueues it eagerly)
-            if use_graph and not eng.has_local_graph(pl):
+            # (isItC / isInC: collectives inside the step -- no local graph; train_step_dp replays graph segments once it knows a bound)
+            if use_graph and not (eng.itc_bs or eng.inc_bs) and not eng.has_local_graph(pl):
                 eng.capture_local_grads(pl)
             eng.train_step_dp(pl, exchange, use_graph=use_graph)
         elif use_graph:
@@ -283,8 +283,9 @@ class SASRec(nn.Module):
                 eng.capture_train_steps(pl, n_steps)
             eng.replay_train_steps(pl, n_steps)
         elif exchange is not None and exchange.world > 1:
-            use_graph = use_graph and not (eng.itc_bs or eng.inc_bs)      # (isItC / isInC: collectives inside the step, train_step_dp enqueues it eagerly)
-            if use_graph and not eng.has_local_graph(pl):
+            # (isItC / isInC: collectives inside the step -- no local graph; with the epoch's bound train_step_dp replays graph SEGMENTS
+            # cut at those collectives, engine._coll)
+            if use_graph and not (eng.itc_bs or eng.inc_bs) and not eng.has_local_graph(pl):
                 eng.capture_local_grads(pl)
             eng.train_step_dp(pl, exchange, use_graph=use_graph, umax=self._pool_umax)
         elif use_graph:
