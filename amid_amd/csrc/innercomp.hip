@@ -337,7 +337,7 @@ static int comp_tokens_fwd(const float* xg, const float* s, const float* const* 
     AMID_CHECK_ARG(xg && s && w_nn && b_nn && w_bs && b_bs && gate && S && Z && sw && x0 && (!pos0 == !pos1));
     AMID_CHECK_ARG(B > 0 && T > 0 && D > 0 && (D % 4) == 0 && D <= 256 && (!train || step_state));
     if (Bg == 0) Bg = B;
-    AMID_CHECK_ARG(phase >= 0 && phase <= 2 && j0 >= 0 && j0 + B <= Bg && (Bg == B || !cross));
+    AMID_CHECK_ARG(phase >= 0 && phase <= 2 && j0 >= 0 && j0 + B <= Bg);
     IncFwdArgs a;
     a.Bg = Bg; a.j0 = j0; a.phase = phase;
     a.xg = xg; a.s = s; a.threshold = threshold; a.B = B; a.T = T; a.D = D; a.cross = cross ? 1 : 0; a.gate = gate; a.S = S; a.Z = Z; a.sw = sw;
@@ -367,7 +367,7 @@ static int comp_tokens_bwd(const float* dpos_part, int nsplit, int cross, const 
     AMID_CHECK_ARG((!dpos_part || nsplit > 0) && xg && dx0 && gate && S && sw && w_nn && b_nn && w_bs && dZ && dS && rows && dw_nn && db_nn &&
                    dw_bs && db_bs && dxg && B > 0 && T > 0 && D > 0 && (D % 4) == 0 && D <= 256);
     if (Bg == 0) Bg = B;
-    AMID_CHECK_ARG(phase >= 0 && phase <= 2 && j0 >= 0 && j0 + B <= Bg && (Bg == B || !cross));
+    AMID_CHECK_ARG(phase >= 0 && phase <= 2 && j0 >= 0 && j0 + B <= Bg);
     IncBwdArgs a;
     a.Bg = Bg; a.j0 = j0; a.phase = phase; a.gscale = gscale;
     a.dpos_part = dpos_part; a.nsplit = nsplit; a.cross = cross ? 1 : 0; a.xg = xg; a.dx0 = dx0; a.gate = gate; a.S = S; a.sw = sw;
@@ -459,4 +459,26 @@ extern "C" int amid_bert_comp_bwd_f32(const float* xg, const float* dx0, const f
                                       float* const* db_bs, float* dxg, void* stream) {
     return comp_tokens_bwd(nullptr, 0, cross, xg, dx0, gate, S, sw, w_nn, b_nn, w_bs, B, T, D, dZ, dS, rows, dw_nn, db_nn, dw_bs, db_bs, dxg,
                            stream);
+}
+
+// ... as data-parallel shards (amid_inc_embed_fwd_shard_f32 / amid_inc_bwd_shard_f32 without the positional rows and the input dropout):
+// B rows = samples j0 .. j0 + B - 1 of a global batch of Bg; s_all [2, Bg] = the ranks' amid_bert_comp_score_f32 outputs all-gathered per
+// domain; forward phase 1 (gates, this shard's partial S, sw) | all-reduce S | phase 2 (Z, the encoder input); backward phase 1 (this
+// shard's dZ) | all-reduce dZ | phase 2 (dS, parameter gradients scaled by gscale = 1 / world, w_bs's own slice, table-row gradients).
+extern "C" int amid_bert_comp_fwd_shard_f32(const float* xg, const float* s_all, const float* const* w_nn, const float* const* b_nn,
+                                            const float* const* w_bs, const float* const* b_bs, float threshold, int cross, int B, int T, int D,
+                                            int Bg, int j0, int phase, float* gate, float* S, float* Z, float* sw, float* x0, void* stream) {
+    AMID_CHECK_ARG(phase == 1 || phase == 2);
+    return comp_tokens_fwd(xg, s_all, w_nn, b_nn, w_bs, b_bs, threshold, cross, nullptr, nullptr, B, T, D, gate, S, Z, sw, x0, nullptr, nullptr, 0, 0.f,
+                           stream, Bg, j0, phase);
+}
+
+extern "C" int amid_bert_comp_bwd_shard_f32(const float* xg, const float* dx0, const float* gate, const float* S, const float* sw,
+                                            const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int cross, int B, int T,
+                                            int D, int Bg, int j0, int phase, float gscale, float* dZ, float* dS, float* rows,
+                                            float* const* dw_nn, float* const* db_nn, float* const* dw_bs, float* const* db_bs, float* dxg,
+                                            void* stream) {
+    AMID_CHECK_ARG(phase == 1 || phase == 2);
+    return comp_tokens_bwd(nullptr, 0, cross, xg, dx0, gate, S, sw, w_nn, b_nn, w_bs, B, T, D, dZ, dS, rows, dw_nn, db_nn, dw_bs, db_bs, dxg,
+                           stream, Bg, j0, phase, gscale);
 }

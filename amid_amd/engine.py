@@ -402,6 +402,10 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             fn()
             return
         L = lib()
+        if getattr(self, "_sort_owed", False):      # a deferred side-stream sort whose fork point has not come yet: start it now ...
+            self.ev_idx.record(self.stream)
+            self.enqueue_sort(self._seg_plan)
+        self.join_sort()                            # ... and join it: a capture cannot end with forked work (the segment then holds the whole sort)
         out = ctypes.c_void_p()
         L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
         seg.append(("graph", out.value))

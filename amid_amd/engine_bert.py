@@ -185,10 +185,20 @@ class Bert4recEngine(SasrecEngine):
             L.call("amid_key_keep_tiled_u8", pl.in_seq_d2.data_ptr(), B, shp.T, 2, pl.key_keep.data_ptr(), s)
             L.call("amid_gather_rows_f32", self.table.data_ptr(), self.n_rows, D, pl.idx_all.data_ptr(), 0, shp.n_idx, pl.xg.data_ptr(), None, s)
             L.call("amid_bert_comp_score_f32", pl.xg.data_ptr(), B, shp.T, D, self.comp_cross, pl.inc_s.data_ptr(), s)
-            L.call("amid_bert_comp_fwd_f32", pl.xg.data_ptr(), pl.inc_s.data_ptr(), self._pp(c + "_d{d}.trans_nn.weight"),
-                   self._pp(c + "_d{d}.trans_nn.bias"), self._pp(c + "_d{d}.trans_bs.weight"), self._pp(c + "_d{d}.trans_bs.bias"),
-                   self.inc_threshold, self.comp_cross, B, shp.T, D, pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(), pl.inc_Z.data_ptr(),
-                   pl.inc_sw.data_ptr(), pl.x[0].data_ptr(), s)
+            wts = (self._pp(c + "_d{d}.trans_nn.weight"), self._pp(c + "_d{d}.trans_nn.bias"), self._pp(c + "_d{d}.trans_bs.weight"),
+                   self._pp(c + "_d{d}.trans_bs.bias"))
+            out = (pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(), pl.inc_Z.data_ptr(), pl.inc_sw.data_ptr(), pl.x[0].data_ptr(), s)
+            if getattr(pl, "inc_world", 1) > 1:
+                # data parallel (as SasrecEngine's isInC branch): the softmax over the batch and Linear(bs, 1) span the GLOBAL batch -- the
+                # ranks all-gather their scores, form their rows' gates and partial token sums, all-reduce the sums and finish Z alike
+                ex = self._inc_exchange(pl)
+                self._coll(lambda: [ex.all_gather_packed(pl.inc_s[g], pl.inc_s_g[g]) for g in (0, 1)])
+                shard = (B, shp.T, D, self.inc_bs, ex.rank * B)
+                L.call("amid_bert_comp_fwd_shard_f32", pl.xg.data_ptr(), pl.inc_s_g.data_ptr(), *wts, self.inc_threshold, self.comp_cross, *shard, 1, *out)
+                self._coll(lambda: ex.all_reduce_dense(pl.inc_S))
+                L.call("amid_bert_comp_fwd_shard_f32", pl.xg.data_ptr(), pl.inc_s_g.data_ptr(), *wts, self.inc_threshold, self.comp_cross, *shard, 2, *out)
+            else:
+                L.call("amid_bert_comp_fwd_f32", pl.xg.data_ptr(), pl.inc_s.data_ptr(), *wts, self.inc_threshold, self.comp_cross, B, shp.T, D, *out)
         else:
             if not pl.strip:      # (strip path: the key mask rides in the first strip launch, _enqueue_blocks_strip)
                 L.call("amid_key_keep_u8", pl.in_seq_d2.data_ptr(), B * T, pl.key_keep.data_ptr(), s)
@@ -484,9 +494,18 @@ class Bert4recEngine(SasrecEngine):
                    s)
         if self.comp:      # the comp modules' parameter gradients; the rows' own halves + their share of the token group -> dxg
             c, G = self.comp, self.dense.grad
-            L.call("amid_bert_comp_bwd_f32", pl.xg.data_ptr(), pl.dx0.data_ptr(), pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(),
-                   pl.inc_sw.data_ptr(), self._pp(c + "_d{d}.trans_nn.weight"), self._pp(c + "_d{d}.trans_nn.bias"),
-                   self._pp(c + "_d{d}.trans_bs.weight"), self.comp_cross, B, shp.T, D, pl.inc_dZ.data_ptr(), pl.inc_dS.data_ptr(),
-                   pl.inc_rows.data_ptr(), self._pp(c + "_d{d}.trans_nn.weight", G), self._pp(c + "_d{d}.trans_nn.bias", G),
-                   self._pp(c + "_d{d}.trans_bs.weight", G), self._pp(c + "_d{d}.trans_bs.bias", G), pl.dxg.data_ptr(), s)
+            head = (pl.xg.data_ptr(), pl.dx0.data_ptr(), pl.inc_gate.data_ptr(), pl.inc_S.data_ptr(), pl.inc_sw.data_ptr(),
+                    self._pp(c + "_d{d}.trans_nn.weight"), self._pp(c + "_d{d}.trans_nn.bias"), self._pp(c + "_d{d}.trans_bs.weight"),
+                    self.comp_cross, B, shp.T, D)
+            outs = (pl.inc_dZ.data_ptr(), pl.inc_dS.data_ptr(), pl.inc_rows.data_ptr(), self._pp(c + "_d{d}.trans_nn.weight", G),
+                    self._pp(c + "_d{d}.trans_nn.bias", G), self._pp(c + "_d{d}.trans_bs.weight", G), self._pp(c + "_d{d}.trans_bs.bias", G),
+                    pl.dxg.data_ptr(), s)
+            if getattr(pl, "inc_world", 1) > 1:      # data parallel: the group's gradient dZ is the sum over every rank's rows (engine.py, isInC)
+                ex = self._inc_exchange(pl)
+                shard = (self.inc_bs, ex.rank * B)
+                L.call("amid_bert_comp_bwd_shard_f32", *head, *shard, 1, 1.0 / ex.world, *outs)
+                self._coll(lambda: ex.all_reduce_dense(pl.inc_dZ))
+                L.call("amid_bert_comp_bwd_shard_f32", *head, *shard, 2, 1.0 / ex.world, *outs)
+            else:
+                L.call("amid_bert_comp_bwd_f32", *head, *outs)
         self._enqueue_grad_tail(pl)

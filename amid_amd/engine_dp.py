@@ -52,9 +52,6 @@ class DataParallelMixin:
             # batch run IN FRONT of the encoders on all-gathered scores and all-reduced token sums, and the group's gradient is all-reduced
             # at the end of backward (engine.enqueue_train_step's isInC branches) -- collectives cannot sit inside a captured graph: the step is
             # captured in segments (below)
-            if getattr(self, "comp", ""):
-                raise NotImplementedError("BERT4Rec(isInC / isItC) under data parallel: the token group in front of BERT4Rec's encoders is "
-                                          "sharded for SASRec only (amid_inc_*_shard_f32)")
             if getattr(pl, "inc_world", 1) != exchange.world:
                 raise ValueError(f"isInC data parallel: bs = {self.inc_bs} must be world x the per-rank batch ({exchange.world} x {pl.shape.B})")
         itc_dp = bool(self.itc_bs and exchange.active)
@@ -131,7 +128,7 @@ class DataParallelMixin:
                     send = be.send[: be.chunk_rows(umax, dgrad) * self.D]
                     self._tail_pack = (send, umax, in_chunk)
                     segs = [] if getattr(self, "_dp_mid_collectives", False) else None
-                    self._seg_capture = segs          # (engine._coll cuts the capture at every mid-step collective)
+                    self._seg_capture, self._seg_plan = segs, pl      # (engine._coll cuts the capture at every mid-step collective)
                     try:
                         self.enqueue_local_grads(pl)
                     finally:

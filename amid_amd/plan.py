@@ -180,7 +180,7 @@ class SasrecPlan:
             # B == bs: the whole batch on this GPU.  world * B == bs: a data-parallel shard of a global batch of bs rows -- the module's
             # softmax over the batch and Linear(bs, 1) span the GLOBAL batch (engine._enqueue_inc_fwd / _bwd: the ranks all-gather
             # their scores and all-reduce the partial token sums S and dZ)
-            if B != inc and (inc % B or inc // B > 64 or getattr(eng, "comp", "")):     # (BERT4Rec's comp modules: one GPU only)
+            if B != inc and (inc % B or inc // B > 64):
                 raise ValueError(f"isInC: the batch must hold exactly bs = {inc} rows (trans_bs is Linear(bs, 1) over the batch, "
                                  f"model_seq.py:457) or an equal data-parallel shard of them, got {B}")
             self.inc_world = inc // B

@@ -867,6 +867,16 @@ int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const float* g, 
  * w1T, w2T -- the FIRST of the matrix's four tiles' images, the others 3 * 128 * 128 bf16 further each (w_1 [512][128] and w_2^T: row blocks;
  * w_2 [128][512] and w_1^T: column blocks). */
 int amid_bert_weight_images_f32(const float* const* src, const int* ld, const int* tr, int n, void* dst16, void* stream);
+/* BERT4Rec(isInC / isItC) under data parallel (round 5): amid_bert_comp_fwd_f32 / _bwd_f32 (model_seq.py:283-294 and its autograd) on a
+ * shard of the global batch, cut at the all-reduces of the token sums S (forward) and of their gradient dZ (backward) exactly as
+ * amid_inc_embed_fwd_shard_f32 / amid_inc_bwd_shard_f32: B rows = samples j0 .. j0 + B - 1 of Bg, s_all [2, Bg] the all-gathered scores. */
+int amid_bert_comp_fwd_shard_f32(const float* xg, const float* s_all, const float* const* w_nn, const float* const* b_nn,
+                                 const float* const* w_bs, const float* const* b_bs, float threshold, int cross, int B, int T, int D, int Bg,
+                                 int j0, int phase, float* gate, float* S, float* Z, float* sw, float* x0, void* stream);
+int amid_bert_comp_bwd_shard_f32(const float* xg, const float* dx0, const float* gate, const float* S, const float* sw,
+                                 const float* const* w_nn, const float* const* b_nn, const float* const* w_bs, int cross, int B, int T, int D,
+                                 int Bg, int j0, int phase, float gscale, float* dZ, float* dS, float* rows, float* const* dw_nn,
+                                 float* const* db_nn, float* const* dw_bs, float* const* db_bs, float* dxg, void* stream);
 /* K1 (amid_embed_fwd_live_f32 / amid_embed_fwd_f32 by `live`) carrying amid_bert_weight_images_f32's tiles as extra workgroups of the gather */
 int amid_embed_fwd_tiles_f32(const float* table, const int* idx_all, const float* pos0, const float* pos1, int B, int T, int D, int n_item_rows,
                              float* xg, unsigned char* tmq, const void* rng_state, int train, float p_drop, const int* live,

@@ -348,6 +348,101 @@ def test_two_rank_dp_with_innercomp_matches_global_batch_oracle():
         assert float(d.max()) < 1e-4, (k, float(d.max()))
 
 
+BCOMP = dict(n_items=400, T=12, hid=16, B=8, K=3, seed=23, lr=1e-3)
+
+
+def _bcomp_setup(kind):
+    """Parameters, global batches and a threshold in the widest gap of the first batch's global batch softmax (tests/test_gpu_bert4rec.py)."""
+    from tests.test_gpu_bert4rec import batch_with_masked_keys, comp_fwd_kw
+    c = BCOMP
+    P = orc.random_params(orc.bert4rec_param_shapes(c["n_items"], c["hid"], inc_bs=c["B"] if kind == "inc" else 0,
+                                                    itc_bs=c["B"] if kind == "itc" else 0), seed=31)
+    P["item_emb_layer.emb_item.weight"] = P["item_emb_layer.emb_item.weight"] * 0.1
+    batches = [batch_with_masked_keys(c["B"], c["T"], c["n_items"], 900 + t) for t in range(c["K"])]
+    taps = {}
+    orc.bert4rec_forward(P, batches[0]["i_node"], batches[0]["neg_samples"], batches[0]["seq_d1"], batches[0]["seq_d2"], None, taps=taps,
+                         **comp_fwd_kw(kind, 0.5))
+    sm = torch.sort(torch.cat([taps[f"{kind}_d{d}"]["softmax"] for d in (1, 2)])).values
+    i = int(torch.argmax(sm[1:] - sm[:-1]))
+    return P, batches, float((sm[i] + sm[i + 1]) / 2)
+
+
+def _bcomp_worker(rank, world, port, q, kind):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from amid_amd.dist import SparseDenseExchange, shard_batch
+        from amid_amd.engine import SasrecEngine
+        from amid_amd.engine_bert import Bert4recEngine
+        c = BCOMP
+        torch.cuda.set_device(0)
+        P, batches, thr = _bcomp_setup(kind)
+        # comp_bs = the GLOBAL batch: the module's Linear(bs, 1) and its softmax span every rank's rows
+        eng = Bert4recEngine(c["n_items"], 128, c["T"], c["hid"], device="cuda:0", lr=c["lr"], seed=SasrecEngine.rank_seed(c["seed"], rank),
+                             comp=kind, comp_bs=c["B"], comp_threshold=thr)
+        eng.load_state_dict(P)
+        pl = eng.plan(c["B"] // world, c["T"], 2, need_grad=True)
+        assert pl.inc_world == world
+        ex = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=True)
+        gates = []
+        for batch in batches:
+            local = {k: v.cuda() for k, v in shard_batch(batch, rank, world).items()}
+            eng.load_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"], local["domain_id"])
+            eng.train_step_dp(pl, ex, use_graph=True, umax=eng.n_sparse_train(pl))      # (eager first step, then graph segments)
+            eng.sync()
+            gates.append(pl.inc_gate.cpu().clone())
+        eng.flush_table()
+        eng.sync()
+        q.put((rank, {k: v.cpu().numpy().copy() for k, v in eng.state_dict().items()}, [g.numpy().copy() for g in gates]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kind", ["inc", "itc"])
+def test_two_rank_dp_with_bert4rec_comp_matches_global_batch_oracle(kind):
+    """BERT4Rec(isInC) / (isItC) under data parallel (round 5): the token group in front of BERT4Rec's encoders (model_seq.py:283-294) spans the
+    GLOBAL batch -- each rank holds half of the rows, the ranks all-gather their scores and all-reduce the token sums S forward and
+    their gradient dZ backward (amid_bert_comp_*_shard_f32).  Both replicas end bit-identical and track ONE process stepping the oracle
+    over the global batches; every rank's gates are its rows of the global softmax's."""
+    from tests.test_gpu_bert4rec import comp_fwd_kw
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcomp_worker, args=(r, world, port, q, kind)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    c = BCOMP
+    P, batches, thr = _bcomp_setup(kind)
+    opt = orc.DenseAdam(P, lr=c["lr"])
+    Bl = c["B"] // world
+    from amid_amd.engine import SasrecEngine
+    for t, batch in enumerate(batches, start=1):
+        per_rank = [orc.philox_masks_bert4rec(Bl, 2 * c["T"], seed=SasrecEngine.rank_seed(c["seed"], r), step=t) for r in range(world)]
+        masks = {k: torch.cat([m[k] for m in per_rank], 0) for k in per_rank[0]}
+        taps = {}
+        loss, _, grads = orc.loss_and_grads("bert4rec", P, batch, masks, taps=taps, **comp_fwd_kw(kind, thr))
+        for d in (1, 2):
+            gate, margin = taps[f"{kind}_d{d}"]["gate"], taps[f"{kind}_d{d}"]["margin"]
+            if margin < 1e-5:
+                pytest.skip(f"a batch-softmax value sits within {margin:.2e} of the threshold: the gate is rounding-dependent")
+            for o in outs:
+                r = o[0]
+                assert torch.equal(torch.from_numpy(o[2][t - 1][d - 1]).bool(), gate[r * Bl:(r + 1) * Bl].bool()), (t, d, r)
+        opt.step(P, grads)
+    sd0, sd1 = ({k: torch.from_numpy(v) for k, v in o[1].items()} for o in outs)
+    for k, v in P.items():
+        assert torch.equal(sd0[k], sd1[k]), f"replicas diverged on {k}"
+        if k.endswith("linear_layers.1.bias"):
+            continue
+        d = (sd0[k] - v).abs()
+        assert float((d > 3e-4).float().mean()) < 2e-3 and float(d.max()) < 3.5e-3, (k, float(d.max()), float((d > 3e-4).float().mean()))
+
+
 def _dr_cli_worker(rank, world, port, root, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD_SIZE=str(world),
                       RANK=str(rank), LOCAL_RANK=str(rank), AMID_DIST_BACKEND="gloo")
