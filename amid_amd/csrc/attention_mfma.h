@@ -267,6 +267,9 @@ struct SeqBuf {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (row * ld + col) * 4, 0, 0));
     }
     __device__ __forceinline__ void st4(int row, int col, float4 v) const {
+#ifdef AMID_EXP_ATTN_NOSTORE      // (variant libraries only, results garbage: the backward launch without its stores -- and, the compiler
+        return;                   // dropping what feeds them, without its products: 6.1 of 20.5 us)
+#endif
         const f32x4 t = {v.x, v.y, v.z, v.w};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(attn_v4u, t), r, (row * ld + col) * 4, 0, 0);
     }
@@ -400,6 +403,9 @@ __device__ __forceinline__ void attn_bwd_compute(AttnBwdOps& o, const AttnArgs& 
     for (int kj = 0; kj < NT; ++kj) { dk[kj] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kj] = dk[kj]; }
 #pragma unroll
     for (int qi = 0; qi < NT; ++qi) {
+#ifdef AMID_EXP_ATTN_NOCOMPUTE    // (variant libraries only: loads, transposes and stores, no tile pair: 13.4 of 20.5 us)
+        if (a.T > 0) continue;
+#endif
         const int q = qi * 16 + m;
         const float4 qf = o.qfr[qi], dof = o.dofr[qi];
         const float dpart = dparts[qi];
