@@ -198,6 +198,8 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         "amid_embed_fwd_replay_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (8 + 2 * D * 4) + Bw * T * (D // 4)),
         "amid_embed_fwd_live_compact_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (12 + 2 * D * 4) + Bw * T * (D // 4)),
         # the same gather + 24 weights read and written as three bf16 planes by its extra workgroups (the forward's weight images)
+        # BERT4Rec's K1: the plain gather of the live sequences + items, and the step's 96 weight-tile images (fp32 read, three bf16 planes written)
+        "amid_embed_fwd_tiles_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (4 + 2 * D * 4) + 96 * D * D * 10),
         "amid_embed_fwd_w16_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * (12 + 2 * D * 4) + Bw * T * (D // 4) + 48 * D * D * 10),
         "amid_sas_qkv_fwd_f32": ("mfma", 3 * gemm),
         "amid_sas_oproj_fwd_f32": ("mfma", gemm),
@@ -274,7 +276,7 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_oproj_ffn_fwd_f32": "sas_oproj_ffn_fwd_kernel",
     "amid_attn_fwd_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_f32": "embed_fwd_kernel",
     "amid_sas_seq_fwd_f32": ("seqn_fwd_kernel", "seq_fwd_kernel"), "amid_sas_seq_fwd_bf16w_f32": ("seqn_fwd_kernel", "seq_fwd_kernel"), "amid_sas_seq_fwd_split_f32": ("seqn_fwd_px_kernel", "seqn_fwd_kernel"),
-    "amid_embed_fwd_w16_f32": "embed_fwd_kernel",
+    "amid_embed_fwd_w16_f32": "embed_fwd_kernel", "amid_embed_fwd_tiles_f32": "embed_fwd_kernel",
     "amid_sas_seq_bwd_f32": ("seqn_bwd_kernel", "seq_bwd_kernel"), "amid_sas_strip_qkv_fwd_f32": "strip_qkv_fwd_kernel", "amid_sas_strip_oproj_ffn_fwd_f32#0": "strip_oproj_ffn_fwd_kernelILi128ELb1",
     "amid_sas_strip_oproj_ffn_fwd_f32#1": "strip_oproj_ffn_fwd_kernelILi128ELb0", "amid_sas_strip_ffn_bwd_f32": "strip_ffn_bwd_kernel",
     "amid_sas_strip_qkv_bwd_f32#0": "strip_qkv_bwd_kernelILi128ELb1", "amid_sas_strip_qkv_bwd_f32#1": "strip_qkv_bwd_kernelILi128ELb0",

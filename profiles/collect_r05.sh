@@ -8,7 +8,7 @@ P=$R/profiles
 last() { tail -n 1 "$1" > "$2"; }
 last $O/bench.json $P/r05_bench.json
 last $O/bench_driver_args.json $P/r05_bench_driver_args.json
-for w in cfg1 cfg3 cfg4 cfg3_bf16 cfg2_bf16 bert4rec cfg4_steady fifteen_launches fp32_wgrad fp32_forward fp32_bwd_strips; do last $O/bench_$w.json $P/r05_bench_$w.json; done
+for w in cfg1 cfg3 cfg4 cfg3_bf16 cfg2_bf16 bert4rec bert4rec_fp32_strips cfg4_steady fifteen_launches fp32_wgrad fp32_forward fp32_bwd_strips; do last $O/bench_$w.json $P/r05_bench_$w.json; done
 last $O/bench_cfg5-uniform.json $P/r05_bench_cfg5_uniform.json
 last $O/bench_cfg5-real.json $P/r05_bench_cfg5_real.json
 cp $O/prof/p_kernel_stats.csv $P/r05_bench_kernel_stats.csv

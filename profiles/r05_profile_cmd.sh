@@ -37,6 +37,7 @@ python3 bench.py --no-fused-tail --no-cpu-baseline --no-stress > $O/bench_fiftee
 python3 bench.py --set WGRAD_SPLIT=0 --no-cpu-baseline --no-stress > $O/bench_fp32_wgrad.json 2> $O/bench_fp32_wgrad.err
 python3 bench.py --set FWD_SPLIT=0 --no-cpu-baseline --no-stress > $O/bench_fp32_forward.json 2> $O/bench_fp32_forward.err
 python3 bench.py --set BWD_SPLIT=0 --no-cpu-baseline --no-stress > $O/bench_fp32_bwd_strips.json 2> $O/bench_fp32_bwd_strips.err
+python3 bench.py --model bert4rec --set STRIP_P3=0 --no-cpu-baseline --no-stress > $O/bench_bert4rec_fp32_strips.json 2> $O/bench_bert4rec_fp32_strips.err
 (echo "# python profiles/tools/variant_steps.py (cfg 2 shape: B 256, T 50, D 128, hid 32, neg 1; hipGraph replay, 200 steps)"; python3 profiles/tools/variant_steps.py 2>&1 | grep "ms/step"; echo "# VARIANT_T=20 (the mybank shape run.sh trains on)"; VARIANT_T=20 python3 profiles/tools/variant_steps.py 2>&1 | grep "ms/step") > $O/variant_steps.txt
 python3 profiles/tools/dp_overhead.py 2>&1 | grep "ms/step" > $O/dp_overhead.txt
 python3 profiles/tools/k1_time.py 2>&1 | grep "TB/s" > $O/k1_time.txt
