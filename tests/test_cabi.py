@@ -42,3 +42,25 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libamid_hip.so")
     with pytest.raises(_lib.AmidLibraryError):
         _lib._Lib()
+
+
+def test_round5_entry_points_refuse_bad_arguments_without_a_gpu():
+    """The argument checks of the round's new entry points return AMID_ERR_ARG (-1) / AMID_ERR_UNSUPPORTED before anything touches a device:
+    null pointers, tile counts past the riders' table, a sort plan of another list, shard phases outside 1 / 2."""
+    import ctypes
+    L = _lib.lib()
+    d = L._dll
+    null = None
+    one = (ctypes.c_int * 1)(128)
+    ptrs = (ctypes.c_void_p * 1)(0)
+    assert d.amid_diag_variants() == 0                                     # the product library carries no diagnostic build
+    assert d.amid_bert_weight_images_f32(null, one, one, 1, null, null) == -1
+    assert d.amid_bert_weight_images_f32(ptrs, one, one, 0, ptrs, null) == -1
+    assert d.amid_bert_weight_images_f32(ptrs, one, one, 97, ptrs, null) == -1            # at most 96 tiles
+    assert L.value("amid_scorer_vec_floats", 2, 32) == (2 * 32 + 2 * 32 + 32 + 1 + 3) // 4 * 4      # da [2][hid] | dc [NI][hid] | dw2 [hid] | db2, padded to 16 B
+    # amid_step_head_f32: null pool
+    rc = L._fn["amid_step_head_f32"](null, 0, 0, 0, null, 0, 4, 4, 1, 10, null, null, null, null, null, null, null, null, null, 128, null, null, null)
+    assert rc == -1
+    # the comp shards: a phase outside 1 / 2
+    rc = L._fn["amid_bert_comp_fwd_shard_f32"](null, null, null, null, null, null, 0.5, 0, 4, 4, 128, 8, 0, 3, null, null, null, null, null, null)
+    assert rc == -1
