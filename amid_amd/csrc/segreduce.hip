@@ -278,9 +278,10 @@ extern "C" int amid_embgrad_segreduce_f32(const float* grad_rows, const int* pos
 }
 
 // amid_embgrad_segreduce_f32 and amid_reduce_partials_f32 (sasrec_bwd.hip) with their first phases in ONE launch
-extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
-                                  void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count,
-                                  const int* blk_off, int total_blocks, void* stream) {
+// (spans = false, amid_grad_tail_nospans_f32: phase B of the segment reduce is left to amid_optimizer_step_spans_f32)
+static int grad_tail(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                     void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count,
+                     const int* blk_off, int total_blocks, void* stream, bool spans) {
     AMID_CHECK_ARG(blk_off == nullptr || total_blocks > 0);
     AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
                    max_count > 0);
@@ -294,11 +295,24 @@ extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted,
 #define AMID_TAIL_LAUNCH(VEC)                                                                                                       \
     grad_tail_kernel<VEC><<<n_seg + (blk_off ? total_blocks : bx * n_entries), 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, \
                                                                                            partial, n_seg, en, bx, blk_off, n_entries);     \
-    segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad);
+    if (spans) segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad);
     if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }
 #undef AMID_TAIL_LAUNCH
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+extern "C" int amid_grad_tail_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                                  void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count,
+                                  const int* blk_off, int total_blocks, void* stream) {
+    return grad_tail(grad_rows, pos_sorted, seg_off, seg_of, n_idx, D, workspace, uniq_grad, entries_dev, n_entries, max_count, blk_off, total_blocks, stream, true);
+}
+// ... without the second launch: the runs of the sorted list that cross 64-entry chunks stay as partial rows in `workspace`, and the caller's
+// next launch is amid_optimizer_step_spans_f32 (same seg_off / seg_of / n_idx / workspace), which sums them in the same order and applies
+// them on the spot -- one launch less in every single-GPU train step whose optimizer follows its gradient tail (round 5)
+extern "C" int amid_grad_tail_nospans_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                                          void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count,
+                                          const int* blk_off, int total_blocks, void* stream) {
+    return grad_tail(grad_rows, pos_sorted, seg_off, seg_of, n_idx, D, workspace, uniq_grad, entries_dev, n_entries, max_count, blk_off, total_blocks, stream, false);
 }
 
 // The gradient tail of the live-sequence step in ONE launch (grad_tail_live_kernel): phase A of the segment reduce over the step's

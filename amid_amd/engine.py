@@ -390,6 +390,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # phase in the weight-gradient launch, the position rows' gradients in the gradient tail (amid_grad_tail_live_f32) and the segment
     # reduce's second phase in the optimizer launch (amid_optimizer_step_spans_f32): 12 launches instead of 15.  False: round 4's sequence
     # (tests compare the two).
+    FUSED_SPANS = True           # every single-GPU train step: the segment reduce's second phase inside the optimizer launch (round 5)
     FUSED_TAIL = True
 
     def _coll(self, fn) -> None:
@@ -1098,8 +1099,13 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                    send.data_ptr() + 4 * rows * self.D if with_dense else None, self.dense.numel if with_dense else 0,
                    pl.err.data_ptr(), blk[0].data_ptr(), blk[1], s)
             return
-        L.call("amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), self.n_sparse(pl),
-               self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), ent.data_ptr(), n_ent, ent_max, blk[0].data_ptr(), blk[1], s)
+        # a single-GPU train step's optimizer launch follows: it finishes the runs that cross chunks itself (amid_optimizer_step_spans_f32;
+        # the same additions in the same order as the spans launch this saves).  Not for enqueue_local_grads: the exchange ships uniq_grad
+        spans_later = bool(self.FUSED_SPANS and getattr(self, "_in_train_step", False) and self.D in (64, 128, 256))
+        pl.spans_owed = self.n_sparse(pl) if spans_later else 0
+        L.call("amid_grad_tail_nospans_f32" if spans_later else "amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(),
+               pl.seg_of.data_ptr(), self.n_sparse(pl), self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), ent.data_ptr(), n_ent, ent_max,
+               blk[0].data_ptr(), blk[1], s)
 
     def enqueue_optimizer(self, pl: SasrecPlan, sparse=None) -> None:
         """Dense Adam on the flat buffer + lazy row Adam on (uniq_ids, uniq_grad, n_uniq); `sparse`
@@ -1112,12 +1118,16 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         else:
             ids, rows, nu = sparse
             cap = ids.numel()
-        if sparse is None and getattr(pl, "tail2", False):      # the segment reduce's runs across chunks are finished (and applied) here
+        owed = int(getattr(pl, "spans_owed", 0))
+        pl.spans_owed = 0
+        if sparse is None and (getattr(pl, "tail2", False) or owed):      # the segment reduce's runs across chunks are finished (and applied) here
             L.call("amid_optimizer_step_spans_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel,
                    self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), ids.data_ptr(),
                    nu.data_ptr(), cap, rows.data_ptr(), self.D, self.grad_scale, self.step_state.data_ptr(), pl.seg_off.data_ptr(),
-                   pl.seg_of.data_ptr(), pl.n_compact, pl.seg_ws.data_ptr(), s)
+                   pl.seg_of.data_ptr(), pl.n_compact if getattr(pl, "tail2", False) else owed, pl.seg_ws.data_ptr(), s)
             return
+        if owed:
+            raise RuntimeError("the gradient tail left the chunk-crossing runs to an optimizer launch that takes merged lists")
         L.call("amid_optimizer_step_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel,
                self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), ids.data_ptr(),
                nu.data_ptr(), cap, rows.data_ptr(), self.D, self.grad_scale, self.step_state.data_ptr(), s)

@@ -285,7 +285,7 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_strip_qkv_bwd_emb_f32": "strip_qkv_bwd_kernelILi128ELb0", "amid_step_head_f32": "step_head_kernel",
     "amid_sas_seq_fwd_split_lnstat_f32": ("seqn_fwd_px_kernel",), "amid_sas_wgrad_rows_sort_ln_f32": "sas_wgrad_split_kernel",
     "amid_sas_strip_qkv_bwd_sort_scorer_f32": "strip_qkv_bwd_kernelILi128ELb1", "amid_head_fwd_bwd_own_vec_f32": "head_fwd_bwd_kernel",
-    "amid_grad_tail_live_f32": "grad_tail_live_kernel", "amid_optimizer_step_spans_f32": "optimizer_step_spans_kernel",
+    "amid_grad_tail_live_f32": "grad_tail_live_kernel", "amid_grad_tail_nospans_f32": "grad_tail_kernel", "amid_optimizer_step_spans_f32": "optimizer_step_spans_kernel",
     "amid_bert_strip_qkv_fwd_pro_p3_f32": "bert_strip_qkv_fwd_kernel", "amid_bert_strip_oproj_ffn_fwd_p3_f32#0": "bert_strip_oproj_ffn_fwd_kernelILb1",
     "amid_bert_strip_oproj_ffn_fwd_p3_f32#1": "bert_strip_oproj_ffn_fwd_kernelILb0", "amid_bert_strip_ffn_bwd_p3_f32": "bert_strip_ffn_bwd_kernel",
     "amid_bert_strip_qkv_bwd_p3_f32#0": "bert_strip_qkv_bwd_kernelILb1", "amid_bert_strip_qkv_bwd_p3_f32#1": "bert_strip_qkv_bwd_kernelILb0",
@@ -746,6 +746,7 @@ def main():
         if red_bytes:         # K3 (the segment reduce of the row gradients) + the reduce of every dense partial sum, one launch
             k3 = "amid_embgrad_segreduce_live" if getattr(pl, "compact", False) else "amid_embgrad_segreduce_f32"
             work["amid_grad_tail_f32"] = ("hbm", work[k3][1] + red_bytes)
+            work["amid_grad_tail_nospans_f32"] = work["amid_grad_tail_f32"]      # (its second phase rides in the optimizer launch)
             if getattr(pl, "tail2", False):      # the folded step's tail: compact list, the position rows summed from the rows, no second phase
                 work["amid_grad_tail_live_f32"] = ("hbm", work["amid_embgrad_segreduce_live"][1] + getattr(pl, "red_bytes_t", red_bytes)
                                                    + Bw * T * D * 4 + 2 * T * D * 4)

@@ -850,7 +850,12 @@ int amid_head_fwd_bwd_own_vec_f32(const float* x, const float* const* ln_w, cons
                                   int T, int NI, int D, int hid, float eps, float* u, float* p1, float* p2, float* dp1, float* dp2,
                                   float* loss_part, float* dx, float* ditems, float* ln_part, float* hidg, const float* const* tr_src,
                                   float* const* tr_dst, int n_tr, void* stream);
-/* amid_optimizer_step_f32 behind amid_grad_tail_live_f32: the runs of the sorted list that cross 64-entry chunks are summed from the tail's
+/* amid_grad_tail_f32 without its second launch (phase B of the segment reduce): for a caller whose NEXT launch is
+ * amid_optimizer_step_spans_f32 on the same (seg_off, seg_of, n_idx, workspace) */
+int amid_grad_tail_nospans_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                               void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count, const int* blk_off,
+                               int total_blocks, void* stream);
+/* amid_optimizer_step_f32 behind amid_grad_tail_live_f32 / amid_grad_tail_nospans_f32: the runs of the sorted list that cross 64-entry chunks are summed from the tail's
  * partial rows (workspace) by extra workgroups -- the additions of amid_embgrad_segreduce_f32's second launch in the same order --, written
  * to uniq_grad and applied on the spot.  D = 64 / 128 / 256. */
 int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const float* g, long long n, float* table, float* m_tab, float* v_tab, int* last,
