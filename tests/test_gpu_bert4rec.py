@@ -164,6 +164,33 @@ def test_strips_on_bf16_pieces_have_fp32_accuracy(Bn, T):
     log(f"bert strips on pieces B={Bn} T={T}: worst deviation from the fp32 instructions {worst:.2e} of a tensor's largest entry")
 
 
+def test_tile_images_by_the_gather_riders_equal_the_standalone_launch():
+    """The step's 96 weight-tile images written by extra workgroups of the gather K1 (amid_embed_fwd_tiles_f32) are, bit for bit, what
+    amid_bert_weight_images_f32 writes in a launch of its own; the gather's rows are unchanged by the riders; and every image's three planes
+    sum to the fp32 tile (or its transpose) exactly -- checked on w_2's column blocks, the tiles with a source stride of 512."""
+    from amid_amd._lib import lib
+    hid, n_items, T, Bn = 32, 700, 20, 16
+    P = orc.random_params(orc.bert4rec_param_shapes(n_items, hid), seed=5)
+    eng = make_engine(P, T, seed=1)
+    batch = batch_with_masked_keys(Bn, T, n_items, seed=3)
+    pl = run_forward(eng, batch, train=False, with_loss=False)            # (K1 of this forward wrote the images: strips on pieces by default)
+    assert pl.strip and eng.STRIP_P3
+    src, ld, trn, n, buf = eng._tile_images()
+    by_riders, rows = buf.clone(), pl.xg.clone()
+    buf.zero_()
+    lib().call("amid_bert_weight_images_f32", src, ld, trn, n, buf.data_ptr(), eng.s)
+    eng.sync()
+    assert torch.equal(by_riders.view(torch.int16), buf.view(torch.int16))
+    want_rows = eng.table[pl.idx_all.long()]
+    assert torch.equal(rows[: want_rows.shape[0]], want_rows)
+    w2 = eng.dense.view("transform1.0.feed_forward.w_2.weight", eng.dense.data).float().cpu()       # [128][512]
+    for c in range(4):
+        tile = w2[:, 128 * c: 128 * (c + 1)]
+        for tr, i in ((0, 8 + c), (1, 20 + c)):
+            img = buf[0, 0, i].float().sum(0).cpu()          # fragment order: compare as multisets
+            assert torch.equal(torch.sort(img).values, torch.sort((tile.t() if tr else tile).reshape(-1)).values), (c, tr)
+
+
 @pytest.mark.parametrize("Bn,T,build", [(256, 50, ""), (128, 50, "_rt5"), (256, 20, "_rt3")])
 def test_tile_builds_forward_backward_vs_oracle(Bn, T, build):
     """The three builds of the row-tile kernels (112 / 80 / 48 rows per workgroup: the headline batch, half of it, the mybank
