@@ -92,7 +92,9 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
     float4 pyA[2], pxA[2], pyB[2], pxB[2];              // two chunks in flight: a chunk's MFMA phase alone is too short to cover a load's latency
     float2 lsA[2], lsB[2];                              // (WgsLn: the rows' statistics travel with them)
     const bool has_ln = ln.stat != nullptr;             // (block-uniform)
-    float4 lgam = make_float4(1.f, 1.f, 1.f, 1.f), lbet = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (WgsLn: the gain and bias of this thread's four columns are read from LDS in every chunk -- the bias-sum scratch is idle until the
+    // chunks are done --: held in registers next to the statistics they took the kernel over its 128 and 24 bytes per lane into scratch)
+    float* const lnv = scratch;                         // [2][D]
     const float inv_T = HINT ? 1.0f / (float)a.T : 0.f;
     // every load of chunk c0, unconditionally and branch-free (a branch around a load makes the compiler wait for it on the spot): rows
     // beyond the split's range re-read its last row and are zeroed when the chunk is staged
@@ -119,6 +121,7 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
     auto chunk = [&](int c0, float4 (&py)[2], float4 (&px)[2], float2 (&ls)[2]) {       // stage chunk c0 (in py / px), refill them with chunk c0 + 2, multiply
         __syncthreads();                               // previous chunk fully consumed
         if (has_ln) {
+            const float4 lgam = *reinterpret_cast<const float4*>(lnv + 4 * cq), lbet = *reinterpret_cast<const float4*>(lnv + D + 4 * cq);
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 px[k] = make_float4((px[k].x - ls[k].x) * ls[k].y * lgam.x + lbet.x, (px[k].y - ls[k].x) * ls[k].y * lgam.y + lbet.y,
@@ -162,7 +165,11 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
             acc[t] = c;
         }
     };
-    if (has_ln) { lgam = ld4(ln.gam + 4 * cq); lbet = ld4(ln.bet + 4 * cq); }      // this thread's four columns, every chunk
+    if (has_ln && threadIdx.x < 64) {                  // (visible behind the first chunk's barrier)
+        const int c = threadIdx.x & 31, which = threadIdx.x >> 5;
+        const float4 v = ld4((which ? ln.bet : ln.gam) + 4 * c);
+        *reinterpret_cast<float4*>(lnv + which * D + 4 * c) = v;
+    }
     if (local_beg < local_end) { fetch(local_beg, pyA, pxA, lsA); fetch(local_beg + WGS_ROWS, pyB, pxB, lsB); }
     for (int c0 = local_beg; c0 < local_end; c0 += 2 * WGS_ROWS) {      // an odd chunk count multiplies one chunk of zeros
         chunk(c0, pyA, pxA, lsA);

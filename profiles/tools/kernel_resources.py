@@ -9,10 +9,20 @@ SRC = os.path.join(ROOT, "amid_amd", "csrc")
 FILT = "/usr/bin/c++filt"
 
 
+def file_flags(path):
+    """The per-file flags of the product build (csrc/Makefile FLAGS_<stem> = ...): the listing must describe the kernels that ship."""
+    stem = os.path.splitext(os.path.basename(path))[0]
+    for ln in open(os.path.join(SRC, "Makefile")):
+        m = re.match(r"FLAGS_" + re.escape(stem) + r"\s*=\s*(.*)", ln)
+        if m:
+            return m.group(1).split()
+    return []
+
+
 def one(path):
     with tempfile.NamedTemporaryFile(suffix=".o") as tmp:
         r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
-                            "-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", tmp.name], capture_output=True, text=True, cwd=SRC)
+                            *file_flags(path), "-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", tmp.name], capture_output=True, text=True, cwd=SRC)
     rows, cur = [], None
     for ln in r.stderr.splitlines():
         m = re.search(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", ln)
