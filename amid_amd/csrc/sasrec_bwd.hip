@@ -13,6 +13,7 @@
 #include "tile_gemm.h"
 #include "reduce_partials.h"
 #include "wgrad_split.h"
+#include "wgrad_args.h"
 #include "sort_phases.h"
 
 namespace amid {
@@ -375,22 +376,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void sas_qkv_ffn_bwd_kernel(const Qkv
 // ---------------------------------------------------------------------------------------------
 // weight gradients of up to two layers in one launch: blockIdx = (split, layer * 6 + weight 0..5, domain)
 // ---------------------------------------------------------------------------------------------
-constexpr int WG_MAX = 12;
-struct WgradArgs {
-    const float* dy[WG_MAX];   // per layer: dq, dk, dv, dr, dpre1, dpre2   [2M, D]
-    const float* xin[WG_MAX];  // per layer: qn, x,  x,  o,  y,     h       [2M, D]
-    float* w_part[2];          // per layer: [2][6][splits][D*D]
-    float* b_part[2];          // per layer: [2][6][splits][D]
-    int M, splits, rows_per_split;
-    // optional hint (amid_sas_wgrad_rows_f32): only the sequences b of domain g with (row_domain[b] != 0) == g have non-zero dY rows
-    // (the loss masks the other domain of every sample, train_sr.py:205-211); the M = B * T rows of a domain are then walked as
-    // n_live * T "virtual" rows -- the live sequences back to back -- and the dead half is never read
-    const long long* row_domain; int B, T;
-    // optional (amid_sas_wgrad_rows_sort_ln_f32; the six-pair build only): per layer [2M][4] row statistics of a forward that did not store
-    // qn and y (seq_fwd.h SeqLayer::ln_stat) -- xin of weights 0 (q) and 4 (conv1) then points at x / r and the operand is rebuilt while staged
-    const float* ln_stat[2];
-    const float* ln1_w[2][2]; const float* ln1_b[2][2]; const float* ln2_w[2][2]; const float* ln2_b[2][2];      // [layer][domain]
-};
+// (WG_MAX, WgradArgs: wgrad_args.h)
 
 constexpr int WG_ROWS = 64;    // rows staged per step
 // diagnostic builds only (profiles/tools/wgrad_stamps.py compiles this file with -DAMID_WGRAD_STAMPS into its own library): real-time
@@ -404,7 +390,7 @@ static __device__ unsigned long long amid_wgrad_sched_buf[1024 * 2];     // per 
 #define WG_STAMP(i) do { } while (0)
 #define WG_SCHED(slot) do { } while (0)
 #endif
-[[maybe_unused]] constexpr int WG_LIVE_MAX = 1024;      // live sequences a split's window may hold (LDS, one int each)
+// (WG_LIVE_MAX: wgrad_args.h)
 
 // One workgroup = one (domain, weight, row split): it streams its rows of (dY, X) in 64-row chunks through LDS and
 // accumulates dW = dY^T X on the matrix cores (one wave per 16 output rows at D = 128).  Single LDS buffer (74 KB at
@@ -682,37 +668,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void sas_wgrad16_kernel(const Wgra
     }
 }
 
-// the same on the bf16 matrix cores at fp32 accuracy (mma mode 2 / 3): csrc/wgrad_split.h
-// RIDER: the launch has one more z-slice whose first rd.plan.nblk workgroups run the LAST phase of the step's index sort (sort_phases.h:
-// run heads; it rode in the embedding-backward launch while the live-sequence step had one): waves 0 .. 3 of a 512-thread workgroup --
-// the others leave at once (a barrier counts the waves that have not ended)
-template <int D, int NTERM, bool HINT, bool RIDER = false>
-__global__ __launch_bounds__(GEMM_THREADS, 4) void sas_wgrad_split_kernel(const WgradArgs a, const SortRider rd) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    static_assert(D == 128, "eight waves = eight 16-row tiles of dW");
-    if constexpr (RIDER) {
-        if (blockIdx.z == 2) {
-            const int rb = blockIdx.y * gridDim.x + blockIdx.x;
-            if (rb < rd.plan.nblk && threadIdx.x < SORT_THREADS) sort_phase_ct<1024, 5>(rd.plan, rb);
-            return;
-        }
-    }
-    const int split = blockIdx.x, wsel = blockIdx.y, g = blockIdx.z;
-    const int layer = wsel / 6, wi = wsel - layer * 6;
-    const WgsRows rw{a.M, a.splits, a.rows_per_split, a.row_domain, a.B, a.T};
-    WgsLn ln{nullptr, 0, nullptr, nullptr};
-    if (a.ln_stat[layer] != nullptr && (wi == 0 || wi == 4))       // (block-uniform) q: LN1 over x; conv1: LN2 over r
-        ln = wi == 0 ? WgsLn{a.ln_stat[layer], 4, a.ln1_w[layer][g], a.ln1_b[layer][g]} : WgsLn{a.ln_stat[layer] + 2, 4, a.ln2_w[layer][g], a.ln2_b[layer][g]};
-    f32x4 acc[8];
-    wgrad_split_tile<NTERM, HINT>(smem, a.dy[wsel], D, a.xin[wsel], D, g, split, rw, acc,
-                                  a.b_part[layer] + (((long long)g * 6 + wi) * a.splits + split) * D, ln);
-    const int w = wave_id(), lane = lane_id(), i = lane & 15, gq = lane >> 4;
-    float* wp = a.w_part[layer] + (((long long)g * 6 + wi) * a.splits + split) * D * D;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wp[(long long)(w * 16 + gq * 4 + r) * D + t * 16 + i] = acc[t][r];
-}
+// (sas_wgrad_split_kernel -- the same on the bf16 matrix cores at fp32 accuracy, mma mode 2 / 3 -- lives in sasrec_wgrad_split.hip: built
+// without the SLP vectorizer, DESIGN.md section 5.0 "The wgrad finding"; this file keeps the default flags)
 
 // ---------------------------------------------------------------------------------------------
 // out[j][i] = in[i][j] for a batch of square D x D matrices (per-step refresh of the transposed weights)
@@ -922,38 +879,17 @@ static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers
     a.row_domain = (row_domain && win <= WG_LIVE_MAX) ? row_domain : nullptr; a.B = B; a.T = T;
     const size_t live_bytes = a.row_domain ? (size_t)((win + 3) & ~3) * sizeof(int) : 0;
     const dim3 grid(splits, 6 * n_layers, 2);
-    SortRider rd;
-    rd.phase = 0;
     if (sort_plan != nullptr) {      // the last phase of a sort plan rides in a third z-slice: the six-pair build with the live-row hint only
+        SortRider rd;
         rd.plan = *(const SortPlan*)sort_plan;
         rd.phase = 5;
         if (!(mma_bf16 == 3 && D == 128 && a.row_domain != nullptr && splits * 6 * n_layers >= rd.plan.nblk)) return AMID_ERR_UNSUPPORTED;
-        static unsigned long long done_r = 0;
-        if (int e = lds_attr_once((const void*)sas_wgrad_split_kernel<128, 6, true, true>, WGS_LDS_FIXED + WG_LIVE_MAX * sizeof(int), done_r)) return e;
-        sas_wgrad_split_kernel<128, 6, true, true><<<dim3(splits, 6 * n_layers, 3), GEMM_THREADS, WGS_LDS_FIXED + live_bytes, (hipStream_t)stream>>>(a, rd);
-        AMID_LAUNCH_CHECK();
-        return AMID_OK;
+        return launch_sas_wgrad_split(a, &rd, n_layers, 3, live_bytes, stream);
     }
-    if (mma_bf16 >= 2) {      // fp32 operands as three bf16 pieces each (csrc: sas_wgrad_split_kernel): D = 128 only
+    if (mma_bf16 >= 2) {      // fp32 operands as three bf16 pieces each (sasrec_wgrad_split.hip): D = 128 only
         if (D != 128) return AMID_ERR_UNSUPPORTED;
-#ifdef AMID_WGS_LDS_GUARD        // diagnostic builds (profiles/tools/probe/wgrad_opsel_repro.sh): unused LDS behind every workgroup's allocation
-        const size_t fixed = WGS_LDS_FIXED + AMID_WGS_LDS_GUARD;
-#else
-        const size_t fixed = WGS_LDS_FIXED;
-#endif
-        static unsigned long long done[4] = {0, 0, 0, 0};
-#define AMID_WGS_LAUNCH(NT, H, SLOT)                                                                                                  \
-        do {                                                                                                                      \
-            if (int e = lds_attr_once((const void*)sas_wgrad_split_kernel<128, NT, H>, fixed + WG_LIVE_MAX * sizeof(int), done[SLOT])) return e; \
-            sas_wgrad_split_kernel<128, NT, H><<<grid, GEMM_THREADS, fixed + live_bytes, (hipStream_t)stream>>>(a, rd);                   \
-        } while (0)
-        const bool h = a.row_domain != nullptr;
-        if (mma_bf16 == 2) { if (h) AMID_WGS_LAUNCH(9, true, 0); else AMID_WGS_LAUNCH(9, false, 1); }
-        else if (mma_bf16 == 3) { if (h) AMID_WGS_LAUNCH(6, true, 2); else AMID_WGS_LAUNCH(6, false, 3); }
-        else return AMID_ERR_ARG;
-#undef AMID_WGS_LAUNCH
-        AMID_LAUNCH_CHECK();
-        return AMID_OK;
+        if (mma_bf16 > 3) return AMID_ERR_ARG;
+        return launch_sas_wgrad_split(a, nullptr, n_layers, mma_bf16, live_bytes, stream);
     }
     if (mma_bf16) {                 // bf16 operands (csrc: sas_wgrad16_kernel): D = 128 only
         if (D != 128) return AMID_ERR_UNSUPPORTED;

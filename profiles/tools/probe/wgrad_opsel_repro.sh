@@ -11,10 +11,10 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 cd "$R"
 if [ "${1:-run}" = build ]; then
   (cd amid_amd/csrc && make -j8 > /dev/null)
-  bash profiles/tools/build_variant.sh zeromul "-DAMID_WGS_ZERO_BY_MUL" sasrec_bwd.hip bert.hip
+  bash profiles/tools/build_variant.sh zeromul "-DAMID_WGS_ZERO_BY_MUL" sasrec_wgrad_split.hip bert.hip
   for v in sel mul; do
     F=""; [ $v = mul ] && F="-DAMID_WGS_ZERO_BY_MUL"
-    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude --cuda-device-only -S -Wno-unused-command-line-argument $F -o /tmp/wg_$v.s amid_amd/csrc/sasrec_bwd.hip
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude --cuda-device-only -S -Wno-unused-command-line-argument $F -o /tmp/wg_$v.s amid_amd/csrc/sasrec_wgrad_split.hip
     python3 profiles/tools/probe/vmcnt_model.py /tmp/wg_$v.s sas_wgrad_split_kernelILi128ELi6ELb1ELb0
   done
   exit 0
