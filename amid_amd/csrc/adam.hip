@@ -83,32 +83,36 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_pos_kernel(float* __res
             *reinterpret_cast<float2*>(v_tab + off) = make_float2(v[0], v[1]);
         }
     };
-    // a WAVE per position (w0, w0 + n_w, ...): a replay is a chain of dependent steps bound by the quarter-rate
-    // sqrt / rcp, and a step's lagging rows are about as many as the chip has SIMDs -- the fewer elements a lane carries, the shorter
-    // the chain
-    const int w0 = bid * (blockDim.x >> 6) + (threadIdx.x >> 6), n_w = nbk * (blockDim.x >> 6);
-    // first sweep: does this block have any lagging row at all? (usually not: skip the coefficient table); a wave's lanes look at
-    // the wave's own positions, 64 at a time
+    // a WAVE per lagging row (a replay is a chain of dependent steps bound by the quarter-rate sqrt / rcp: the fewer elements a lane carries,
+    // the shorter the chain), but the wave's positions are RESOLVED side by side first -- lane j the wave's j-th: index -> stamp is a chain
+    // of two dependent loads, paid once per 64 positions instead of once per position (round 5, as step_head_kernel: at the cfg 5 stress
+    // every wave walks six to seven positions and the launch was a chain of round trips, 168 us for 650 MB)
+    const int n_w = nbk * (blockDim.x >> 6), wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) any_lag = 0;
     __syncthreads();
-    bool mine = false;
-    for (long long i = w0 + (long long)lane * n_w; i < n_idx; i += 64LL * n_w) {
-        const long long l = last[idx[i]];
-        if (l > 0 && l < t - 1) mine = true;
-    }
-    if (mine) any_lag = 1;
-    __syncthreads();
-    if (!any_lag) return;
-    fill_coef_table(tab, st);
-    for (int i = w0; i < n_idx; i += n_w) {
-        const long long r = idx[i];
-        const int l = last[r];
-        if (!(l > 0 && l < t - 1)) continue;
-        int won = 0;
-        if (lane == 0) won = (atomicCAS(&last[r], l, (int)(t - 1)) == l) ? 1 : 0;     // claim the row for this wave
-        won = __builtin_amdgcn_readfirstlane(won);
-        if (!won) continue;
-        replay_row(r, l);
+    bool filled = false;                                 // (block-uniform)
+    for (long long base = (long long)bid * (blockDim.x >> 6); base < n_idx; base += 64LL * n_w) {      // (block-uniform trip count)
+        const long long i = base + wv + (long long)lane * n_w;
+        int id = 0, l = 0;
+        if (i < n_idx) { id = idx[i]; l = last[id]; }
+        const bool lag = l > 0 && l < t - 1;
+        const unsigned long long lagging = __ballot(lag);
+        if (lagging != 0ull && lane == 0) any_lag = 1;
+        __syncthreads();
+        if (any_lag && !filled) { fill_coef_table(tab, st); filled = true; }      // (usually no row of a block lags: no table)
+        unsigned long long todo = lagging;
+        while (todo != 0ull) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const long long r = __builtin_amdgcn_readlane(id, j);
+            const int lj = __builtin_amdgcn_readlane(l, j);
+            int won = 0;
+            if (lane == 0) won = (atomicCAS(&last[r], lj, (int)(t - 1)) == lj) ? 1 : 0;     // claim the row for this wave
+            won = __builtin_amdgcn_readfirstlane(won);
+            if (!won) continue;
+            replay_row(r, lj);
+        }
+        if (base + 64LL * n_w < n_idx) __syncthreads();    // (a wave of the next round must not raise any_lag while a slow one still reads it)
     }
 }
 
