@@ -5,7 +5,7 @@ TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 P=$R/profiles
-last() { tail -n 1 "$1" > "$2"; }
+last() { [ -s "$1" ] || { echo "collect_r05: $1 is missing or empty -- nothing copied" >&2; exit 1; }; tail -n 1 "$1" > "$2"; }
 last $O/bench.json $P/r05_bench.json
 last $O/bench_driver_args.json $P/r05_bench_driver_args.json
 for w in cfg1 cfg3 cfg4 cfg3_bf16 cfg2_bf16 bert4rec bert4rec_fp32_strips cfg4_steady fifteen_launches fp32_wgrad fp32_forward fp32_bwd_strips; do last $O/bench_$w.json $P/r05_bench_$w.json; done
