@@ -24,6 +24,7 @@
 #include "attention_mfma.h"
 #include "seq_fwd.h"
 #include "weights_image.h"
+#include "head_parts.h"
 
 namespace amid {
 
@@ -441,8 +442,8 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
                         float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
                         const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
                         const void* step_state, int train, float p_drop, const void* w16, void* stream, int w16_planes = 1,
-                        float* const* ln_stat = nullptr) {
-    AMID_CHECK_ARG(n_layers >= 1 && n_layers <= 2 && x_in && xout && ln1_w && ln1_b && w_in && b_in && w_o && b_o && ln2_w && ln2_b && w1 && b1 &&
+                        float* const* ln_stat = nullptr, const HeadArgs* head = nullptr) {
+    AMID_CHECK_ARG(n_layers >= 1 && n_layers <= 2 && x_in && (xout || head) && ln1_w && ln1_b && w_in && b_in && w_o && b_o && ln2_w && ln2_b && w1 && b1 &&
                    w2 && b2 && (ln_stat || (qn && y)) && q && k && v && o && stats && r && h && (!train || step_state));
     if (ln_stat != nullptr && !(w16 != nullptr && w16_planes == 3 && D == 128)) return AMID_ERR_UNSUPPORTED;      // the piece forward only
     if (!amid_sas_seq_supported(B, T, D, H)) return AMID_ERR_UNSUPPORTED;
@@ -471,6 +472,7 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
     sg.B = B; sg.T = T; sg.M = B * T; sg.live = live;
     const long long bytes = 2LL * B * T * D * 4;
     sg.act_bytes = (unsigned)bytes; sg.tm_bytes = (unsigned)(bytes / 16); sg.stats_bytes = (unsigned)(2LL * B * T * H * 8);
+    if (head != nullptr) return launch_seqn_fwd(a, sg, D, 0, stream, head);       // (the default N-split build or nothing)
     {
         int v = g_seq_fwd_variant;
         if (v == 0) v = 2;                                 // auto: the N-split build wins at every measured shape (profiles/r03_*)
@@ -507,6 +509,33 @@ extern "C" int amid_sas_seq_fwd_f32(int n_layers, const float* const* x_in, floa
                                     const void* step_state, int train, float p_drop, void* stream) {
     return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, qn, q, k, v, o, stats, r, y, h, tmq,
                         ln_eps, B, T, D, H, live, step_state, train, p_drop, nullptr, stream);
+}
+
+// amid_sas_seq_fwd_split_lnstat_f32 with the train step's head (amid_head_fwd_bwd_own_vec_f32: LN_last + mean over T -- model_seq.py:385,
+// :432-434 --, predictModule.forward -- :40-54 --, the masked BCE term and dLoss/dp -- train_sr.py:203-212 --, the scorer's backward and
+// LN_last') on the tail of every workgroup: a live sequence IS a sample, so the head of sample b runs where its rows were just computed.
+// The last layer's output is stored only when xout != NULL (only the head read it; tests ask for it).  Same arithmetic in the same order as the two launches: same bits.
+// T 33 ... 64, D 128, live != NULL, head_lds_floats(D, hid) within the forward's plane slots (hid <= 32); otherwise AMID_ERR_UNSUPPORTED
+// and nothing is enqueued.
+extern "C" int amid_sas_seq_fwd_split_lnstat_head_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                                      const float* const* w_in, const float* const* b_in, const float* const* w_o,
+                                                      const float* const* b_o, const float* const* ln2_w, const float* const* ln2_b,
+                                                      const float* const* w1, const float* const* b1, const float* const* w2,
+                                                      const float* const* b2, float* const* ln_stat, float* const* q, float* const* k,
+                                                      float* const* v, float* const* o, float* const* stats, float* const* r, float* const* h,
+                                                      const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                                                      const void* step_state, int train, float p_drop, const void* w16x3,
+                                                      const float* const* last_ln_w, const float* const* last_ln_b, const float* items,
+                                                      const float* sw1, const float* sb1, const float* sw2, const float* sb2, const float* labels,
+                                                      const long long* domain_id, int NI, int hid, float* u, float* p1, float* p2, float* dp1,
+                                                      float* dp2, float* loss_part, float* dx, float* ditems, float* ln_part, float* hidg,
+                                                      void* stream) {
+    AMID_CHECK_ARG(w16x3 != nullptr && ln_stat != nullptr && live != nullptr && last_ln_w != nullptr && last_ln_b != nullptr);
+    HeadArgs ha;
+    if (int e = head_own_vec_args(ha, last_ln_w, last_ln_b, items, sw1, sb1, sw2, sb2, labels, domain_id, B, T, NI, D, hid, ln_eps, u, p1, p2, dp1,
+                                  dp2, loss_part, dx, ditems, ln_part, hidg)) return e;
+    return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, nullptr, q, k, v, o, stats, r, nullptr,
+                        h, tmq, ln_eps, B, T, D, H, live, step_state, train, p_drop, w16x3, stream, 3, ln_stat, &ha);
 }
 
 // The same forward with the twelve projections' matrix products on v_mfma_f32_16x16x32_bf16 (operands rounded to bf16, fp32

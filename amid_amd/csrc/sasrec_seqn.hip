@@ -23,6 +23,7 @@
 #include "attention_mfma.h"
 #include "seq_fwd.h"
 #include "seqn_parts.h"
+#include "head_parts.h"
 #include <type_traits>
 
 namespace amid {
@@ -419,9 +420,10 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
 // the column parts of a strip carries operand fragments of pieces (seqn_parts.h SeqRing3 / xp_write / part_mma_xp).  LDS: three 32 KB
 // plane slots [M][L][H] + WPS x 12 KB of exchange; the attention images take M + L between the q and out-projection products.
 // LayerNorm statistics come from the row put back together (hi + mid + lo is the value exactly); only the own columns' gains are held.
-template <int D, int WPS, int NS>
-__global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwdArgs a, const SeqGeom sg) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// HEAD: the train step's head on the workgroup's tail (seqn_fwd_px_head_kernel below) -- the last layer's output goes to an LDS image instead
+// of a.xout and head_own_rows_body (csrc/head_parts.h) runs on it.
+template <int D, int WPS, int NS, bool HEAD>
+__device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqGeom& sg, float* const smem, const HeadArgs* ha) {
     constexpr int NT = D / 16, NW = WPS * NS, NCT = NT / NS;
     constexpr int H = NT, NH = NCT;
     static_assert(D == 128 && NCT >= 2 && NCT % 2 == 0, "a wave owns whole k-steps of the next product's operand");
@@ -660,21 +662,66 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwd
             lds_barrier();
             xp_write<NCT>(xps, c0, Xo);
             part_store<NCT>(GBuf(a.L[l + 1].x, sg.act_bytes), off_own, Xo);
-        } else {
+        } else if (!HEAD || a.xout != nullptr) {             // (with the head on the tail only its tests ask for the rows)
             part_store<NCT>(GBuf(a.xout, sg.act_bytes), off_own, Xo);
         }
     }
     SEQN_STAMP0(63);
     w_ring_wait();
+    if constexpr (HEAD) {
+        // The sample's head where its sequence was encoded: LN_last + mean over T, the scorer, the masked loss term, the scorer's backward
+        // and LN_last' -- what amid_head_fwd_bwd_own_vec_f32's workgroup of sample b does, on the rows this workgroup still holds (no
+        // xout round trip, no launch).  Every wave's weight DMA has landed (above) and behind the barrier nobody reads the plane slots or
+        // the exchange slots any more: the head's LDS carve takes the former, the rows' image xl [WPS 16][D + 4] the latter.
+        static_assert(NW == 8, "the head's phases are written for 512 threads");
+        lds_barrier();
+        float* const xl = smem + 3 * Ring::SLAB;
+        constexpr int XLD = D + 4;
+        static_assert(WPS * 16 * XLD <= WPS * XpStrip<D>::FLOATS, "the rows' image fits in the exchange slots");
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) lds_st4(xl + t * XLD + (c0 + c) * 16 + 4 * gq, Xo.v[c]);
+        __syncthreads();
+        OwnRows R;
+        own_rows_take_lds(xl, XLD, sg.T, D, R);
+        head_own_rows_body<true>(*ha, smem, b, g, R);
+    }
 }
 
 template <int D, int WPS, int NS>
-static int seqn_launch_px(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
+__global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwdArgs a, const SeqGeom sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    seqn_fwd_px_body<D, WPS, NS, false>(a, sg, smem, nullptr);
+}
+
+template <int D, int WPS, int NS>
+__global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_head_kernel(const SeqFwdArgs a, const SeqGeom sg, const HeadArgs ha) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    seqn_fwd_px_body<D, WPS, NS, true>(a, sg, smem, &ha);
+}
+
+template <int D, int WPS, int NS>
+static int seqn_launch_px(const SeqFwdArgs& a, const SeqGeom& sg, void* stream, const HeadArgs* head = nullptr) {
     constexpr size_t lds = (size_t)(3 * (D * D / 2) + WPS * XpStrip<D>::FLOATS + 2 * WPS * NS * 16) * sizeof(float);
+    const int grid = sg.live != nullptr ? sg.B : 2 * sg.B;
+    if (head != nullptr) {
+        if constexpr (WPS * NS == 8) {
+            // (the head's carve inside the three plane slots, its rows T <= 16 HEAD_CHUNK / 2, a workgroup per LIVE sequence = per sample)
+            if (sg.live == nullptr || head_lds_floats(D, head->hid) > (size_t)3 * (D * D / 2) || sg.T > 16 * (HEAD_CHUNK / 2) || head->D != D ||
+                head->B != sg.B || head->T != sg.T)
+                return AMID_ERR_UNSUPPORTED;
+            auto kern = seqn_fwd_px_head_kernel<D, WPS, NS>;
+            static unsigned long long attr_done = 0;
+            if (int rc = lds_attr_once((const void*)kern, lds, attr_done)) return rc;
+            kern<<<grid, 64 * WPS * NS, lds, (hipStream_t)stream>>>(a, sg, *head);
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? AMID_OK : (int)e;
+        } else {
+            return AMID_ERR_UNSUPPORTED;
+        }
+    }
     auto kern = seqn_fwd_px_kernel<D, WPS, NS>;
     static unsigned long long attr_done = 0;
     if (int rc = lds_attr_once((const void*)kern, lds, attr_done)) return rc;
-    const int grid = sg.live != nullptr ? sg.B : 2 * sg.B;
     kern<<<grid, 64 * WPS * NS, lds, (hipStream_t)stream>>>(a, sg);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? AMID_OK : (int)e;
@@ -697,7 +744,11 @@ static int seqn_launch_t(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
 }
 
 template <int WPS, int NS>
-static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
+static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream, const HeadArgs* head = nullptr) {
+    if (head != nullptr) {        // the head rides on the producer-side pieces build only
+        if constexpr ((128 / 16 / NS) % 2 == 0) { if (a.w16 != nullptr && a.w16_planes == 3) return seqn_launch_px<128, WPS, NS>(a, sg, stream, head); }
+        return AMID_ERR_UNSUPPORTED;
+    }
     if (a.w16 != nullptr && a.w16_planes == 3) {
         // the producer-side pieces build (seqn_fwd_px_kernel) wherever a wave owns whole k-steps (an even number of column tiles);
         // SeqRing16x3's build -- every wave splits its strip's whole row itself -- for the one-tile parts of the diagnostic variant 18
@@ -710,8 +761,13 @@ static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream) {
 // variant: 0 = the default split for the shape; 42 / 22 / 24 / 14 / 18 = WPS, NS spelled out (diagnostics and tests).
 // D = 64 (8 heads of 8 dims, two per column tile: the reference's default --emb_dim, train_sr.py:364): four column tiles, so two parts
 // at four strips, four below; fp32 products only.
-int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int D, int variant, void* stream) {
+int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int D, int variant, void* stream, const HeadArgs* head) {
     const int T = sg.T;
+    if (head != nullptr) {
+        if (D != 128 || T <= 32 || T > 64 || (variant != 0 && variant != 42)) return AMID_ERR_UNSUPPORTED;
+        if (a.train && spec_bits(a.spec) != 1) return AMID_ERR_UNSUPPORTED;
+        return seqn_launch<4, 2>(a, sg, stream, head);
+    }
     if (a.train && spec_bits(a.spec) != 1) return AMID_ERR_UNSUPPORTED;      // part_dropout: the one-bit keep decisions of p = 0.5 (the reference's rate)
     const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4;
     if (D == 64) {

@@ -56,6 +56,8 @@ __device__ __forceinline__ unsigned bcast_group(unsigned v, int SRC) {
 
 
 // sasrec_seqn.hip: the N-split kernels.  variant: 0 = auto.  Returns AMID_ERR_UNSUPPORTED when no N-split build covers the shape.
-int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int D, int variant, void* stream);
+// head != nullptr: the train step's head on the tail of every workgroup (csrc/head_parts.h head_own_rows_body; T 33 ... 64, live sequences, pieces)
+struct HeadArgs;
+int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int D, int variant, void* stream, const HeadArgs* head = nullptr);
 
 }  // namespace amid

@@ -656,11 +656,26 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 if not getattr(pl, "w16_written", False):      # (the train step's gather K1 wrote them with extra workgroups)
                     L.call("amid_sas_weights_bf16_planes", src, 24, D, 0, planes, w16.data_ptr(), s)
                 pl.w16_written = False
+                pl.head_done = False
                 if split and getattr(pl, "tail2", False) and lf is not None:
                     # the folded step: qn / y are not stored -- row statistics instead (pl.ln_stat); the weight gradients rebuild them
                     # (c: x, 12 parameter families, qn, q, k, v, o, stats, r, y, h)
-                    L.call("amid_sas_seq_fwd_split_lnstat_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
-                           pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(), s)
+                    if (self.HEAD_ON_FWD and getattr(self, "_fuse_head", False) and with_loss and not sum_loss and 32 < T <= 64
+                            and self.hid <= 32 and NI <= 64):
+                        # ... and a live sequence is a sample: its workgroup finishes with the sample's head (forward + loss + backward,
+                        # what amid_head_fwd_bwd_own_vec_f32 does in enqueue_backward otherwise); the last layer's output is not stored
+                        L.call("amid_sas_seq_fwd_split_lnstat_head_f32", 2, c[0], pl.x[2].data_ptr() if self.HEAD_ON_FWD_KEEPS_X else None, *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
+                               pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(),
+                               self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
+                               pl.xg.data_ptr() + 4 * 2 * shp.Mi * D, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
+                               fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr(),
+                               pl.domain.data_ptr(), NI, self.hid, pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr(),
+                               pl.dp2.data_ptr(), pl.loss_part.data_ptr(), pl.dxbuf.data_ptr(), pl.dxg.data_ptr() + 4 * 2 * shp.Mi * D,
+                               pl.last_part.data_ptr(), self._hidg(pl).data_ptr(), s)
+                        pl.head_done = True
+                    else:
+                        L.call("amid_sas_seq_fwd_split_lnstat_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
+                               pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(), s)
                     pl.lnstat_fwd = True
                 else:
                     pl.lnstat_fwd = False
@@ -896,6 +911,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         elif self.itc_bs:
             L.call("amid_transpose_weights_f32", ptr_array(src), ptr_array(dst), len(src), D, s)
             self._enqueue_head_itc_bwd(pl, items, ditems)
+        elif getattr(pl, "head_done", False):
+            pl.head_done = False          # (the forward's workgroups ran the head: amid_sas_seq_fwd_split_lnstat_head_f32 in enqueue_forward)
         elif getattr(self, "_fuse_head", False) and getattr(pl, "tail2", False) and getattr(self, "_live_fwd", False) and self._live_list(pl) is not None:
             # the folded step: the scorer's weight gradients leave the head as per-sample hidden gradients (pl.hidg; the gradient tail sums
             # them, amid_grad_tail_live_f32) and the fp32 transposes are not refreshed (this step's strips read the three-plane images)
@@ -1165,6 +1182,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self.enqueue_sort(pl)
 
     FUSED_HEAD = True          # the plain SASRec head (no isItC / isDR) can run forward + backward as one launch
+    HEAD_ON_FWD = True         # the folded step's head on the tail of the forward's workgroups (one launch fewer: eleven)
+    HEAD_ON_FWD_KEEPS_X = False   # (tests: the last layer's output is stored all the same)
 
     def _enqueue_fwd_bwd(self, pl: SasrecPlan) -> None:
         """Forward (loss included; its sum rides in the gradient tail) + backward of a training step."""

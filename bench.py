@@ -257,6 +257,8 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         # embedding backward on the strip; the weight gradients carrying the sort's last phase; the optimizer finishing the segment reduce
         # the folded step's forward (row statistics instead of qn / y: seven saved tensors per layer) and its weight gradients
         "amid_sas_seq_fwd_split_lnstat_f32": ("mfma16x6", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
+        # ... with the step's head on the tail of its workgroups (the head's own arithmetic -- 2 x 0.13 MFLOP a sample -- is not counted)
+        "amid_sas_seq_fwd_split_lnstat_head_f32": ("mfma16x6", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
         "amid_sas_wgrad_rows_sort_ln_f32": (WGRAD_KIND, 6 * gemm),
         "amid_sas_strip_qkv_bwd_sort_scorer_f32": ("mfma", 6 * gl),     # layer 1's q / k / v backward + layer 0's feed-forward backward (+ riders)
         "amid_step_head_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * 28 + (2 * Bw * T + 2 * Bw * (1 + NEG)) * 20 + U * (D * 4 * 6 + 8)),
@@ -283,7 +285,7 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_attn_fwd_live_f32": "attn_fwd_mfma_kernel", "amid_attn_bwd_live_f32": "attn_bwd_mfma_kernel", "amid_embed_fwd_live_f32": "embed_fwd_kernel", "amid_embed_fwd_live_compact_f32": "embed_fwd_kernel", "amid_embed_fwd_replay_f32": "embed_fwd_kernel",
     "amid_embgrad_segreduce_f32": "segreduce_chunks_kernel", "amid_sas_wgrad_rows_sort_f32": "sas_wgrad_split_kernel",
     "amid_sas_strip_qkv_bwd_emb_f32": "strip_qkv_bwd_kernelILi128ELb0", "amid_step_head_f32": "step_head_kernel",
-    "amid_sas_seq_fwd_split_lnstat_f32": ("seqn_fwd_px_kernel",), "amid_sas_wgrad_rows_sort_ln_f32": "sas_wgrad_split_kernel",
+    "amid_sas_seq_fwd_split_lnstat_f32": ("seqn_fwd_px_kernel",), "amid_sas_seq_fwd_split_lnstat_head_f32": ("seqn_fwd_px_head_kernel",), "amid_sas_wgrad_rows_sort_ln_f32": "sas_wgrad_split_kernel",
     "amid_sas_strip_qkv_bwd_sort_scorer_f32": "strip_qkv_bwd_kernelILi128ELb1", "amid_head_fwd_bwd_own_vec_f32": "head_fwd_bwd_kernel",
     "amid_grad_tail_live_f32": "grad_tail_live_kernel", "amid_grad_tail_nospans_f32": "grad_tail_kernel", "amid_optimizer_step_spans_f32": "optimizer_step_spans_kernel",
     "amid_bert_strip_qkv_fwd_pro_p3_f32": "bert_strip_qkv_fwd_kernel", "amid_bert_strip_oproj_ffn_fwd_p3_f32#0": "bert_strip_oproj_ffn_fwd_kernelILb1",

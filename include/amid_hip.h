@@ -817,6 +817,23 @@ int amid_sas_seq_fwd_split_lnstat_f32(int n_layers, const float* const* x_in, fl
                                       float* const* v, float* const* o, float* const* stats, float* const* r, float* const* h,
                                       const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
                                       const void* step_state, int train, float p_drop, const void* w16x3, void* stream);
+/* amid_sas_seq_fwd_split_lnstat_f32 + amid_head_fwd_bwd_own_vec_f32 in ONE launch: a live sequence is a sample, so the workgroup that encoded
+ * the sequence of sample b finishes with that sample's head -- LN_last + mean over T (model_seq.py:385, :432-434), predictModule.forward
+ * (model_seq.py:40-54), the masked BCE term and dLoss/dp (train_sr.py:203-212), the scorer's backward, LN_last' -- on the rows it still holds.
+ * The last layer's output is stored only if xout != NULL (nothing of the step reads it).  Arguments: the forward's, then the head's (without x and the transposes; last_ln_w /
+ * last_ln_b: 2 pointers, one per domain).  Same additions in the same order as the two launches.  T 33 ... 64, D 128, live != NULL, hid <= 32,
+ * NI <= 64; AMID_ERR_UNSUPPORTED (nothing enqueued) otherwise. */
+int amid_sas_seq_fwd_split_lnstat_head_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                           const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                           const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                           const float* const* w2, const float* const* b2, float* const* ln_stat, float* const* q,
+                                           float* const* k, float* const* v, float* const* o, float* const* stats, float* const* r,
+                                           float* const* h, const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                                           const void* step_state, int train, float p_drop, const void* w16x3,
+                                           const float* const* last_ln_w, const float* const* last_ln_b, const float* items, const float* sw1,
+                                           const float* sb1, const float* sw2, const float* sb2, const float* labels, const long long* domain_id,
+                                           int NI, int hid, float* u, float* p1, float* p2, float* dp1, float* dp2, float* loss_part, float* dx,
+                                           float* ditems, float* ln_part, float* hidg, void* stream);
 int amid_sas_wgrad_rows_sort_ln_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
                                     float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, const void* sort_plan,
                                     const float* const* ln_stat, const float* const* ln1_w, const float* const* ln1_b,

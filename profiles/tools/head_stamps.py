@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the fused head's time goes: builds csrc/head_fused.hip with -DAMID_HEAD_STAMPS into a DIAGNOSTIC library
-(gpurun_out/libhead_diag.so; the product library carries no stamps), runs amid_head_fwd_bwd_own_f32 at the headline shape (B 256, T 50,
-D 128, hid 32, 2 items per row, 24 transposes by the extra workgroups) and prints the real-time-counter (100 MHz) deltas between the
+(gpurun_out/libhead_diag.so; the product library carries no stamps), runs amid_head_fwd_bwd_own_vec_f32 (the folded step's head) at the headline shape (B 256, T 50,
+D 128, hid 32, 2 items per row) and prints the real-time-counter (100 MHz) deltas between the
 phase boundaries of workgroup 0."""
 import ctypes
 import os
@@ -38,7 +38,9 @@ sc_part = torch.empty(B, P, device=dev)
 src = [r(D, D) for _ in range(24)]
 dst = [torch.empty(D, D, device=dev) for _ in range(24)]
 pa = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])     # noqa: E731
-f = L.amid_head_fwd_bwd_own_f32
+f = L.amid_head_fwd_bwd_own_vec_f32
+L.amid_scorer_vec_floats.restype = ctypes.c_longlong
+hidg = torch.empty(B, L.amid_scorer_vec_floats(NI, hid), device=dev)
 vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 f.argtypes = [vp] * 10 + [ci] * 5 + [cf] + [vp] * 12 + [ci, vp]
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,7 +49,7 @@ for it in range(6):
         ev0.record()
     rc = f(x.data_ptr(), pa(lnw), pa(lnb), items.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), labels.data_ptr(),
            dom.data_ptr(), B, T, NI, D, hid, 1e-8, u.data_ptr(), p1.data_ptr(), p2.data_ptr(), dp1.data_ptr(), dp2.data_ptr(),
-           loss_part.data_ptr(), dx.data_ptr(), ditems.data_ptr(), ln_part.data_ptr(), sc_part.data_ptr(), pa(src), pa(dst), 24, None)
+           loss_part.data_ptr(), dx.data_ptr(), ditems.data_ptr(), ln_part.data_ptr(), hidg.data_ptr(), None, None, 0, None)
     assert rc == 0, rc
     if it == 5:
         ev1.record()

@@ -399,6 +399,65 @@ def test_folded_step_matches_the_fifteen_launch_step(Bn, T, split, use_graph):
         assert rel_l2(got, want) < 1e-3, (k, rel_l2(got, want), far)
 
 
+@pytest.mark.parametrize("Bn,T,split", [(256, 50, "mixed"), (200, 64, "one0"), (37, 33, "all0"), (300, 40, "mixed")])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_head_on_the_forward_workgroups_is_bit_identical_to_its_own_launch(Bn, T, split, use_graph):
+    """SasrecEngine.HEAD_ON_FWD on / off over the same pool: amid_sas_seq_fwd_split_lnstat_head_f32 runs the head's code on the rows the
+    forward's workgroup still holds -- the same operations in the same order as amid_head_fwd_bwd_own_vec_f32 on the stored rows -- so the
+    losses, logits, every gradient of the first step and the parameters after five steps agree BIT FOR BIT, and the step is one launch
+    shorter."""
+    from amid_amd._lib import lib
+    D, hid, n_items, K = 128, 32, 3000, 5
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=5 + Bn)
+    batches = [split_batch(Bn, T, n_items, seed=400 + t, split=split) for t in range(3)]
+    out = {}
+    for on in (False, True):
+        eng = make_engine(P, T, lr=1e-3, seed=78)
+        eng.HEAD_ON_FWD = on
+        pl = eng.plan(Bn, T, 2, need_grad=True)
+        packed = []
+        for b in batches:
+            cu = {k: v.cuda() for k, v in b.items()}
+            packed.append(eng.pack_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"]))
+        eng.set_input_pool(pl, torch.stack(packed))
+        names = []
+        L = lib()
+        orig = L.call
+        L.call = lambda name, *a: (names.append(name), orig(name, *a))[1]        # (a spy on the C-ABI calls of this one step)
+        try:
+            eng.enqueue_train_step(pl)
+            eng.sync()
+        finally:
+            del L.call
+        assert pl.tail2
+        assert ("amid_sas_seq_fwd_split_lnstat_head_f32" in names) == on and ("amid_head_fwd_bwd_own_vec_f32" in names) == (not on), names
+        rec = dict(n_calls=len(names), loss=[float(pl.loss.item())], p1=pl.p1.clone(), p2=pl.p2.clone(), u=pl.u.clone(),
+                   table=dense_table_grad(eng, pl), **{name: eng.dense.view(name, eng.dense.grad).clone() for name in eng.dense.slots})
+        if use_graph:
+            eng.capture_train_step(pl)
+        for t in range(1, K):
+            if use_graph:
+                eng.replay_train_step(pl)
+            else:
+                eng.enqueue_train_step(pl)
+            eng.sync()
+            rec["loss"].append(float(pl.loss.item()))
+        eng.check_index_error(pl)
+        eng.flush_table()
+        eng.sync()
+        rec["params"] = {k: v.cpu().clone() for k, v in eng.state_dict().items()}
+        out[on] = rec
+    a, b = out[False], out[True]
+    assert b["n_calls"] == a["n_calls"] - 1
+    assert a["loss"] == b["loss"], (a["loss"], b["loss"])
+    for name, want in a.items():
+        if name in ("n_calls", "loss", "params"):
+            continue
+        assert torch.equal(b[name], want), (name, relmax(b[name], want))
+    for k, want in a["params"].items():
+        assert torch.equal(b["params"][k], want), (k, rel_l2(b["params"][k], want))
+
+
 def test_timed_path_real_tokenised_batches_vs_oracle():
     """BASELINE.json configs[1] on the DATA bench.py times, not only its shape: the first two batches of cloth_sport_train75 as the
     reference's own DualDomainSeqDataset tokenised them (tests/golden/tok_cloth_sport_train75.npz: its left-padding, its pad id 447 411,
