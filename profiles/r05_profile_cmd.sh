@@ -20,19 +20,22 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o
 rocprofv3 --kernel-trace -d $O/tl -o tl -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-stress > /dev/null 2>&1
 rocprofv3 --kernel-trace -d $O/tlb -o tl -- python3 $R/bench.py --model bert4rec --steps 60 --warmup 10 --no-cpu-baseline --no-stress > /dev/null 2>&1
 rocprofv3 --kernel-trace -d $O/tl4 -o tl -- python3 $R/bench.py --no-fused-tail --steps 60 --warmup 10 --no-cpu-baseline --no-stress > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $O/tl5 -o tl -- python3 $R/bench.py --set HEAD_ON_FWD=0 --steps 60 --warmup 10 --no-cpu-baseline --no-stress > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bert -o p -- python3 $R/bench.py --model bert4rec --steps 100 --warmup 10 --no-cpu-baseline --no-stress > $O/bench_bert_under_prof.json 2> $O/prof_bert_err.log
 cd "$R"
 rm -f $O/prof/*kernel_trace.csv $O/pmc_*/*kernel_trace.csv $O/prof_bert/*kernel_trace.csv
 python3 profiles/tools/step_timeline.py $O/tl/tl_results.db > $O/step_timeline.txt 2>&1
 python3 profiles/tools/step_timeline.py $O/tlb/tl_results.db > $O/bert_step_timeline.txt 2>&1
 python3 profiles/tools/step_timeline.py $O/tl4/tl_results.db > $O/step_timeline_fifteen_launches.txt 2>&1
-rm -rf $O/tl $O/tlb $O/tl4
+python3 profiles/tools/step_timeline.py $O/tl5/tl_results.db > $O/step_timeline_twelve_launches.txt 2>&1
+rm -rf $O/tl $O/tlb $O/tl4 $O/tl5
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
 for w in cfg5-uniform cfg5-real cfg4 cfg3 cfg1; do python3 bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
 python3 bench.py --model bert4rec --no-cpu-baseline > $O/bench_bert4rec.json 2> $O/bench_bert4rec.err
 python3 bench.py --dtype bf16 --no-cpu-baseline > $O/bench_cfg2_bf16.json 2> $O/bench_cfg2_bf16.err
 python3 bench.py --workload cfg3 --dtype bf16 --no-cpu-baseline > $O/bench_cfg3_bf16.json 2> $O/bench_cfg3_bf16.err
-# A/B on this box: round 4's fifteen-launch step; the products on the fp32 matrix instructions (round 3's kernels)
+# A/B on this box: the head as its own launch (twelve launches); round 4's fifteen-launch step; the products on the fp32 matrix instructions (round 3's kernels)
+python3 bench.py --set HEAD_ON_FWD=0 --no-cpu-baseline --no-stress > $O/bench_twelve_launches.json 2> $O/bench_twelve_launches.err
 python3 bench.py --no-fused-tail --no-cpu-baseline --no-stress > $O/bench_fifteen_launches.json 2> $O/bench_fifteen_launches.err
 python3 bench.py --set WGRAD_SPLIT=0 --no-cpu-baseline --no-stress > $O/bench_fp32_wgrad.json 2> $O/bench_fp32_wgrad.err
 python3 bench.py --set FWD_SPLIT=0 --no-cpu-baseline --no-stress > $O/bench_fp32_forward.json 2> $O/bench_fp32_forward.err
@@ -41,6 +44,7 @@ python3 bench.py --model bert4rec --set STRIP_P3=0 --no-cpu-baseline --no-stress
 (echo "# python profiles/tools/variant_steps.py (cfg 2 shape: B 256, T 50, D 128, hid 32, neg 1; hipGraph replay, 200 steps)"; python3 profiles/tools/variant_steps.py 2>&1 | grep "ms/step"; echo "# VARIANT_T=20 (the mybank shape run.sh trains on)"; VARIANT_T=20 python3 profiles/tools/variant_steps.py 2>&1 | grep "ms/step") > $O/variant_steps.txt
 python3 profiles/tools/dp_overhead.py 2>&1 | grep "ms/step" > $O/dp_overhead.txt
 python3 profiles/tools/k1_time.py 2>&1 | grep "TB/s" > $O/k1_time.txt
+python3 profiles/tools/head_stamps.py 2>&1 | grep -v amdgpu > $O/head_stamps.txt
 if [ -f profiles/tools/_diag/libamid_hip_diag.so ]; then
   python3 profiles/tools/seqn_stamps.py 2>&1 | grep -v amdgpu > $O/seqn_stamps.txt
   python3 profiles/tools/strip_bwd_stamps.py 2>&1 | grep -v amdgpu > $O/strip_bwd_stamps.txt

@@ -61,6 +61,10 @@ def test_round5_entry_points_refuse_bad_arguments_without_a_gpu():
     # amid_step_head_f32: null pool
     rc = L._fn["amid_step_head_f32"](null, 0, 0, 0, null, 0, 4, 4, 1, 10, null, null, null, null, null, null, null, null, null, 128, null, null, null)
     assert rc == -1
+    # the forward with the head on its tail: no piece images / no live list
+    rc = L._fn["amid_sas_seq_fwd_split_lnstat_head_f32"](2, *[null] * 23, 1e-8, 4, 40, 128, 8, null, null, 1, 0.5, null, *[null] * 9, 2, 32,
+                                                         *[null] * 10, null)
+    assert rc == -1
     # the comp shards: a phase outside 1 / 2
     rc = L._fn["amid_bert_comp_fwd_shard_f32"](null, null, null, null, null, null, 0.5, 0, 4, 4, 128, 8, 0, 3, null, null, null, null, null, null)
     assert rc == -1
