@@ -809,6 +809,10 @@ def main():
                 roof["frac_of_fp32_mfma_peak"] = round(roof["achieved"] / PEAK_F32_MFMA_TFLOPS, 4)
                 roof["operands"] = kernels[dom]["operands"]
             roof["timing"] = "HIP events around this kernel's launches only, 20 steps enqueued back to back (the queue stays full, as in the timed region)"
+        if dom == "amid_sas_seq_fwd_split_lnstat_head_f32":
+            roof["note"] = ("this launch also runs the train step's head on the tail of its workgroups (LN_last + mean, scorer, loss and their "
+                            "backward: ~6.5 us of its duration); `achieved` divides the ENCODER's algorithmic FLOP by the whole launch -- the forward "
+                            "alone is the dominant kernel of the line `bench.py --set HEAD_ON_FWD=0` (profiles/r05_bench_twelve_launches.json)")
         roof["traffic"], src = pmc_traffic(dom, f"{args.workload}_{args.model}_{args.dtype}")
         if src:
             roof["traffic_unit"] = "bytes/launch"
