@@ -15,8 +15,9 @@ __device__ __forceinline__ float4 h4mul(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float4 h4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float h4hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
-// workgroup barrier between LDS phases WITHOUT draining the vector-memory queue: __syncthreads() also waits for every global store in
-// flight (u, the logits, dLoss/dp, the hidden gradients, d items: an HBM write latency per barrier that follows one).
+// workgroup barrier between LDS phases that says what it waits for: the LDS queue only.  (hipcc 7.2 compiles __syncthreads() to the same
+// s_waitcnt lgkmcnt(0) + s_barrier for gfx950 -- no vmcnt(0) outside threadgroup-split mode, checked in the ISA -- so this changes no
+// timing; it keeps the staged path from depending on that.)
 __device__ __forceinline__ void head_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
