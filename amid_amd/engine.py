@@ -583,6 +583,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         tr = 1 if train else 0
         fp = self.dense
         pl.w16_written = pl.wT16x3_written = False      # (set again by the gather K1 of THIS forward when its riders write the images)
+        pl.head_done = False                            # (set by THIS forward when its workgroups run the head: HEAD_ON_FWD)
         # the train step's own loss reads only the sequence (domain_id[b], b) of every sample (see _enqueue_fwd_bwd): those B "live"
         # sequences are listed on the device; with live_fwd the forward encodes nothing else
         lv = self._live_list(pl)
@@ -656,7 +657,6 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 if not getattr(pl, "w16_written", False):      # (the train step's gather K1 wrote them with extra workgroups)
                     L.call("amid_sas_weights_bf16_planes", src, 24, D, 0, planes, w16.data_ptr(), s)
                 pl.w16_written = False
-                pl.head_done = False
                 if split and getattr(pl, "tail2", False) and lf is not None:
                     # the folded step: qn / y are not stored -- row statistics instead (pl.ln_stat); the weight gradients rebuild them
                     # (c: x, 12 parameter families, qn, q, k, v, o, stats, r, y, h)
