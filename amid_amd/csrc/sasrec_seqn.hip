@@ -704,7 +704,7 @@ static int seqn_launch_px(const SeqFwdArgs& a, const SeqGeom& sg, void* stream, 
     constexpr size_t lds = (size_t)(3 * (D * D / 2) + WPS * XpStrip<D>::FLOATS + 2 * WPS * NS * 16) * sizeof(float);
     const int grid = sg.live != nullptr ? sg.B : 2 * sg.B;
     if (head != nullptr) {
-        if constexpr (WPS * NS == 8) {
+        if constexpr (WPS == 4 && NS == 2) {              // (the one build launch_seqn_fwd asks the head for: T 33 ... 64)
             // (the head's carve inside the three plane slots, its rows T <= 16 HEAD_CHUNK / 2, a workgroup per LIVE sequence = per sample)
             if (sg.live == nullptr || head_lds_floats(D, head->hid) > (size_t)3 * (D * D / 2) || sg.T > 16 * (HEAD_CHUNK / 2) || head->D != D ||
                 head->B != sg.B || head->T != sg.T)
