@@ -406,7 +406,7 @@ __device__ __forceinline__ void scorer_fwd_part(const HeadArgs& a, const HeadLds
     const int CH = s.chunk;
     for (int n0 = 0; n0 < NI; n0 += CH) {
         const int nn = min(CH, NI - n0);
-        head_sync(s);
+        if (!(s.st.b1 != nullptr && n0 == 0)) head_sync(s);        // (staged: the first chunk's item half runs beside the user half -- nobody reads s.ci yet)
         item_half(a, s, b, n0, nn, tg);
         head_sync(s);
         HEAD_STAMP(4);
@@ -431,6 +431,7 @@ __device__ __forceinline__ void scorer_fwd_part(const HeadArgs& a, const HeadLds
                 const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.0f - p), -100.f);
                 const float inv = 1.0f / ((float)a.B * (float)NI);
                 lsum += -(y * lp + (1.f - y) * l1p) * md * inv;
+                if (s.st.b1 != nullptr && NI == 2) s.scr[nd] = lsum;      // (the logit's term: summed behind the caller's next barrier, head_loss_terms)
                 const float dp = md * inv * (p - y) / fmaxf((1.f - p) * p, 1e-12f);   // torch binary_cross_entropy_backward
                 (d ? a.dp2 : a.dp1)[o] = dp;
                 if (s.st.pd != nullptr) s.st.pd[8 + 4 * d + n] = dp;
@@ -438,13 +439,19 @@ __device__ __forceinline__ void scorer_fwd_part(const HeadArgs& a, const HeadLds
         }
     }
     HEAD_STAMP(5);
-    if (a.labels) {
+    if (a.labels && !(s.st.b1 != nullptr && NI == 2)) {
         head_sync(s);
         lsum = group_sum<64>(lsum);
         if (lane_id() == 0) s.scr[wave_id()] = lsum;
         head_sync(s);
         if (tg.tid == 0) a.loss_part[b] = ((s.scr[0] + s.scr[1]) + (s.scr[2] + s.scr[3])) + ((s.scr[4] + s.scr[5]) + (s.scr[6] + s.scr[7]));
     }
+}
+
+// the staged two-item path: the four logits' loss terms (s.scr[nd], nd = 2 item + domain) in the order the workgroup reduction above adds
+// them -- wave 0 holds the terms of item 0, wave 1 those of item 1, the other waves zeros: (t0 + t1) + (t2 + t3), the same bits
+__device__ __forceinline__ void head_loss_terms(const HeadArgs& a, const HeadLds& s, int b, const Tg tg) {
+    if (tg.tid == 0) a.loss_part[b] = (s.scr[0] + s.scr[1]) + (s.scr[2] + s.scr[3]);
 }
 
 __device__ __forceinline__ void head_fwd_body(const HeadArgs& a, float* __restrict__ sm, int b) {
@@ -634,9 +641,10 @@ __device__ __forceinline__ float* scorer_bwd_part(const HeadArgs& a, const HeadL
     const int CH = s.chunk;
     for (int n0 = 0; n0 < NI; n0 += CH) {
         const int nn = min(CH, NI - n0);
-        head_sync(s);
+        const bool one_pass = FUSED && NI <= CH && s.st.b1 != nullptr;       // (staged, one chunk: nothing happens between these barriers)
+        if (!one_pass) head_sync(s);
         if (!(FUSED && NI <= CH)) item_half(a, s, b, n0, nn, tg);
-        head_sync(s);
+        if (!one_pass) head_sync(s);
         if (tg.tid < hid) {                       // hidden unit j walks the chunk's items in order
             const int j = tg.tid;
             float s_da0 = 0.f, s_da1 = 0.f, s_w2 = 0.f;
@@ -667,6 +675,39 @@ __device__ __forceinline__ float* scorer_bwd_part(const HeadArgs& a, const HeadL
         }
         head_sync(s);
         HEAD_STAMP(8);
+        if (one_pass && a.hidg != nullptr && dit_lds == nullptr && !ACC && tg.n == 512 && nn * D <= 256 && 2 * D <= 256) {
+            // the training step's shape: d items on the first four waves, d u on the other four (both read only what the barrier above
+            // published; d u goes where the item pre-activations were), the hidden gradients leave, one barrier -- the same sums
+            float* du_s = s.ci;
+            if (tg.tid < 256) {
+                const int ne = tg.tid;
+                if (ne < nn * D) {
+                    const int n = ne / D, e = ne - n * D;
+                    float acc = 0.f;
+                    const float* wp = s.w1t + (D + e) * (hid + 1);
+#pragma unroll 8
+                    for (int j = 0; j < hid; ++j) acc = fmaf(s.dc[n * (hid + 1) + j], wp[j], acc);
+                    a.ditems[((long long)b * NI + n) * D + e] = acc;
+                }
+            } else {
+                const int de = tg.tid - 256;
+                if (de < 2 * D) {
+                    const int d = de / D, e = de - d * D;
+                    float acc = 0.f;
+                    const float* wp = s.w1t + e * (hid + 1);
+#pragma unroll 8
+                    for (int j = 0; j < hid; ++j) acc = fmaf(s.da[d * hid + j], wp[j], acc);
+                    du_s[de] = acc;
+                }
+            }
+            float* hg = a.hidg + (long long)b * (((3 + NI) * hid + 1 + 3) & ~3);
+            for (int nj = tg.tid; nj < nn * hid; nj += tg.n) hg[2 * hid + nj] = s.dc[(nj / hid) * (hid + 1) + (nj % hid)];
+            for (int j = tg.tid; j < 2 * hid; j += tg.n) hg[j] = s.da[j];
+            for (int j = tg.tid; j < hid + 1; j += tg.n) hg[(2 + NI) * hid + j] = s.dw2[j];
+            HEAD_STAMP(9);
+            head_sync(s);
+            return du_s;
+        }
         // d item[n][e] = sum_j dc[n][j] w1t[D+e][j]
         for (int ne = tg.tid; ne < nn * D; ne += tg.n) {
             const int n = ne / D, e = ne - n * D;
@@ -811,6 +852,7 @@ __device__ __forceinline__ void head_own_rows_impl(const HeadArgs& a, float* __r
     HEAD_STAMP(6);
     if (s.st.b1 != nullptr) {
         head_lds_barrier();                           // (p and dLoss/dp cross the threads through s.st.pd)
+        if (a.NI == 2) head_loss_terms(a, s, b, tg);
     } else {
         __threadfence_block();                        // dLoss/dp written above is read by other threads of this workgroup below
         __syncthreads();
