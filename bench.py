@@ -809,6 +809,26 @@ def main():
                 roof["frac_of_fp32_mfma_peak"] = round(roof["achieved"] / PEAK_F32_MFMA_TFLOPS, 4)
                 roof["operands"] = kernels[dom]["operands"]
             roof["timing"] = "HIP events around this kernel's launches only, 20 steps enqueued back to back (the queue stays full, as in the timed region)"
+        if dom == "amid_sas_seq_fwd_split_lnstat_head_f32" and use_pool and world == 1:
+            # like for like with the earlier rounds' lines: the encoder forward as its own launch (the head back in a launch of its own),
+            # timed the same way -- HIP events around that kernel's launches only, steps enqueued back to back -- behind the timed region
+            alone = "amid_sas_seq_fwd_split_lnstat_f32"
+            eng.HEAD_ON_FWD = False
+            try:
+                L.timer = KernelTimer(only={alone})
+                for i in range(n_prof):
+                    eng.enqueue_train_step(pl)
+                eng.sync()
+                hv = [x for v in L.timer.collect(L).values() for x in v]
+            finally:
+                L.timer = None
+                eng.HEAD_ON_FWD = True
+            if hv:
+                us = 1e3 * sum(hv) / len(hv)
+                ach = round(work[alone][1] / (us * 1e-6) / 1e12, 2)
+                roof["encoder_as_its_own_launch"] = {"kernel": alone, "avg_launch_us": round(us, 2), "achieved": ach, "unit": "TFLOP/s",
+                                                     "peak": roof["peak"], "frac": round(ach / roof["peak"], 4),
+                                                     "what": "the same forward without the head on its tail (SasrecEngine.HEAD_ON_FWD = False), same timing"}
         if dom == "amid_sas_seq_fwd_split_lnstat_head_f32":
             roof["note"] = ("this launch also runs the train step's head on the tail of its workgroups (LN_last + mean, scorer, loss and their "
                             "backward: ~6.5 us of its duration); `achieved` divides the ENCODER's algorithmic FLOP by the whole launch -- the forward "
