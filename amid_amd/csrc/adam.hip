@@ -698,10 +698,13 @@ extern "C" int amid_step_head_f32(const long long* pool, long long pool_stride, 
         if (rd.plan.n != n_c) return AMID_ERR_ARG;                  // the plan must be the compact list's
     }
     long long blocks = ((long long)n_c + 3) / 4;                    // a position per wave ...
-    static int resident = 0;                                        // ... up to ONE round of resident workgroups (8 of 256 threads per CU)
-    if (resident == 0) {
-        int dev = 0; hipDeviceProp_t pr;
-        resident = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? 8 * pr.multiProcessorCount : 2048;
+    // ... up to ONE round of resident workgroups (8 of 256 threads per CU) of the CURRENT device: an attribute query per call (no
+    // process-wide cache: a process may drive devices of different sizes from several threads; the query is legal under stream capture)
+    int resident = 2048;
+    {
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
+            resident = 8 * n_cu;
     }
     // (fewer, longer catch-up workgroups measured slower: 1 024 blocks 16.8 us as here, 512 19.4, 256 20.1)
     const long long room = resident - rider_blocks_host(rd) - npk;

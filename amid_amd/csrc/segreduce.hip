@@ -349,6 +349,48 @@ extern "C" int amid_grad_tail_live_f32(const float* grad_rows, const int* pos_so
     return AMID_OK;
 }
 
+// The folded step's gradient tail for a caller that SHIPS the row gradients (the data-parallel step, round 6): amid_grad_tail_live_f32's
+// launch, then phase B of the segment reduce as its own launch -- the optimizer that would finish it runs on another rank's chunks too --
+// either alone (n_out = 0: uniq_grad complete, what an eager exchange or the local-gradients graph reads) or with the packing of this
+// rank's exchange chunk riding in it (amid_grad_tail_pack_f32's second launch: ids padded to n_out, the flat dense gradient copied behind
+// the rows; uniq_grad points into the chunk).  Same additions in the same order as amid_grad_tail_live_f32 + amid_optimizer_step_spans_f32.
+extern "C" int amid_grad_tail_live_dp_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                                          void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off,
+                                          int total_blocks, const int* live, int B, int T, float* dpos0, float* dpos1, const int* uniq_ids,
+                                          const int* n_uniq, int n_out, int pad_id, int* out_ids, const float* dense_src, float* dense_dst,
+                                          long long dense_n, int* err_flag, void* stream) {
+    AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
+                   blk_off && total_blocks > 0 && live && B > 0 && T > 0 && dpos0 && dpos1);
+    AMID_CHECK_ARG(((((unsigned long long)dpos0) | ((unsigned long long)dpos1) | ((unsigned long long)grad_rows)) & 15) == 0);
+    AMID_CHECK_ARG(n_out >= 0 && n_out <= n_idx && dense_n >= 0);
+    AMID_CHECK_ARG(n_out == 0 || (uniq_ids && n_uniq && out_ids &&
+                                  (dense_n == 0 || (dense_src && dense_dst && ((((unsigned long long)dense_src) | ((unsigned long long)dense_dst)) & 15) == 0))));
+    if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK, n_seg = (nch + 3) / 4;
+    PosSum ps;
+    ps.rows = grad_rows; ps.live = live; ps.B = B; ps.T = T; ps.dst[0] = dpos0; ps.dst[1] = dpos1;
+    ps.nblk = (T * D + 127) / 128;
+    const ScorerSum ss = scorer_sum_args(nullptr, nullptr, nullptr, B, 0, D, 0, nullptr, nullptr, nullptr, nullptr);
+    float* partial = (float*)workspace;
+    const ReduceEntry* en = (const ReduceEntry*)entries_dev;
+    const int id_blocks = (n_out + 1023) / 1024;
+    long long cb = (dense_n / 4 + 1023) / 1024;
+    if (cb < 1) cb = 1;
+    if (cb > 256) cb = 256;
+    if (dense_n == 0 || n_out == 0) cb = 0;
+#define AMID_TAIL_LAUNCH(VEC)                                                                                                       \
+    grad_tail_live_kernel<VEC><<<ss.nblk + n_seg + total_blocks + 2 * ps.nblk, 256, 0, s>>>(grad_rows, pos_sorted, seg_of, n_idx, uniq_grad, partial, \
+                                                                                            n_seg, en, blk_off, n_entries, total_blocks, ps, ss); \
+    if (n_out == 0) segreduce_spans_kernel<VEC><<<nch, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad);                   \
+    else segreduce_spans_pack_kernel<VEC><<<nch + id_blocks + (int)cb, 1024, 0, s>>>(seg_off, seg_of, n_idx, partial, uniq_grad, nch, uniq_ids, n_uniq, \
+                                                                                   n_out, pad_id, out_ids, id_blocks, dense_src, dense_dst, dense_n, err_flag);
+    if (D == 64) { AMID_TAIL_LAUNCH(1) } else if (D == 128) { AMID_TAIL_LAUNCH(2) } else { AMID_TAIL_LAUNCH(4) }
+#undef AMID_TAIL_LAUNCH
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
 extern "C" int amid_grad_tail_pack_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
                                        void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, int max_count,
                                        const int* uniq_ids, const int* n_uniq, int n_out, int pad_id, int* out_ids, const float* dense_src,

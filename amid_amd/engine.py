@@ -409,24 +409,35 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         self.join_sort()                            # ... and join it: a capture cannot end with forked work (the segment then holds the whole sort)
         out = ctypes.c_void_p()
         L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
-        seg.append(("graph", out.value))
-        seg.append(("call", fn))
-        L.call("amid_graph_capture_begin", self.s)
+        try:
+            seg.append(("graph", out.value))
+            seg.append(("call", fn))
+        finally:      # the caller's `finally` ends a capture: the stream is capturing again whatever happened in between
+            L.call("amid_graph_capture_begin", self.s)
+
+    # The data-parallel step's local half (enqueue_local_grads: graph A of the graph pair, the local-gradients graph, the eager step) in the
+    # folded form too (round 6): step head, head on the forward's tail, embedding backward on the last strip, position rows in the tail; phase B
+    # of the segment reduce stays a launch (with the chunk's packing riding in it) because the exchange ships the finished rows.
+    FUSED_TAIL_DP = True
+
+    def _fold_ctx(self) -> bool:
+        """Whether the launches being enqueued belong to a step that may take the folded form."""
+        return bool(getattr(self, "_in_train_step", False) or (getattr(self, "_in_local_grads", False) and self.FUSED_TAIL_DP))
 
     def _folded_step_shape(self, pl: SasrecPlan) -> bool:
         """The conditions of the folded twelve-launch step that do not depend on how the backward runs (_tail2_ok adds those)."""
-        return bool(self.FUSED_TAIL and getattr(self, "_in_train_step", False) and self.SORT_RIDERS and pl.need_grad and self.D == 128
+        return bool(self.FUSED_TAIL and self._fold_ctx() and self.SORT_RIDERS and pl.need_grad and self.D == 128
                     and self.compute == "f32" and not self.dr and not self.itc_bs and not self.inc_bs and not getattr(self, "comp", "")
-                    and getattr(self, "_tail_pack", None) is None and self.FUSED_HEAD and self.BWD_SPLIT and pl.strip
+                    and pl.shape.NI > 1 and self.FUSED_HEAD and self.BWD_SPLIT and pl.strip
                     and self.input_pool(pl) is not None and self.live_forward_ok(pl) and self._wgrad_mode(self.D) == 3
                     and not self._fold_catchup(pl) and self._sort_plan_c(pl) is not None and (pl.n_compact + 2047) // 2048 <= 12 * pl.splits)
 
     def _tail2_ok(self, pl: SasrecPlan) -> bool:
         shp = pl.shape
-        # (only inside enqueue_train_step: the segment reduce's runs across chunks are finished by THIS step's optimizer launch, so the
-        # row gradients of enqueue_local_grads alone -- what a data-parallel exchange ships -- would be incomplete)
-        return bool(self.FUSED_TAIL and getattr(self, "_in_train_step", False) and self.SORT_RIDERS and pl.need_grad and self.D == 128 and self.compute == "f32" and not self.dr
-                    and not self.itc_bs and not self.inc_bs and not getattr(self, "comp", "") and getattr(self, "_tail_pack", None) is None
+        # (inside enqueue_train_step the segment reduce's runs across chunks are finished by THIS step's optimizer launch; inside
+        # enqueue_local_grads -- what a data-parallel exchange ships -- by a launch of their own behind the tail, amid_grad_tail_live_dp_f32)
+        return bool(self.FUSED_TAIL and self._fold_ctx() and self.SORT_RIDERS and pl.need_grad and self.D == 128 and self.compute == "f32" and not self.dr
+                    and not self.itc_bs and not self.inc_bs and not getattr(self, "comp", "") and pl.shape.NI > 1
                     and self.FUSED_HEAD and self.live_forward_ok(pl) and self._p3_bwd_for(pl) and self._wgrad_mode(self.D) == 3
                     and not self._fold_catchup(pl) and self._sort_plan_c(pl) is not None
                     and (pl.n_compact + 2047) // 2048 <= 12 * pl.splits)
@@ -459,9 +470,18 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         return bool(getattr(pl, "strip", False) and not self.itc_bs and not self.dr and not self.inc_bs and self.FUSED_HEAD and self.LIVE_FORWARD
                     and lib().value("amid_attn_live_supported", pl.shape.Tenc, self.D, self.H, 1))
 
-    def n_sparse_train(self, pl: SasrecPlan) -> int:
-        """n_sparse() of this engine's train steps on `pl` (known before the step is enqueued)."""
-        return pl.n_compact if self.compact_ok(pl) else pl.shape.n_idx
+    def n_sparse_train(self, pl: SasrecPlan, dp: bool = False) -> int:
+        """n_sparse() of this engine's train steps on `pl` (known before the step is enqueued); dp: of its data-parallel steps."""
+        if self.compact_ok(pl):
+            return pl.n_compact
+        flag = "_in_local_grads" if dp else "_in_train_step"      # (the folded step forces the compact list whatever the index count)
+        saved = getattr(self, flag, False)
+        setattr(self, flag, True)
+        try:
+            folded = self.input_pool(pl) is not None and self._tail2_ok(pl)
+        finally:
+            setattr(self, flag, saved)
+        return pl.n_compact if folded else pl.shape.n_idx
 
     def compact_ok(self, pl: SasrecPlan) -> bool:
         return bool(self.COMPACT_LIVE and pl.shape.n_idx >= self.COMPACT_MIN_IDX and self.live_forward_ok(pl))
@@ -584,6 +604,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         fp = self.dense
         pl.w16_written = pl.wT16x3_written = False      # (set again by the gather K1 of THIS forward when its riders write the images)
         pl.head_done = False                            # (set by THIS forward when its workgroups run the head: HEAD_ON_FWD)
+        pl.lnstat_fwd = False                           # (set by THIS forward when it stores row statistics instead of qn / y)
         # the train step's own loss reads only the sequence (domain_id[b], b) of every sample (see _enqueue_fwd_bwd): those B "live"
         # sequences are listed on the device; with live_fwd the forward encodes nothing else
         lv = self._live_list(pl)
@@ -957,6 +978,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         tm, h0, r0, lnw0, w1T0, w2T0, woT0 = ffn_bwd_args(0)
         dx_in = (pl.dx0 if self.inc_bs else pl.dxg).data_ptr()
         seq = bool(pl.strip and lv is not None and live and live_attn and self._seq_backward(pl))
+        pl.seq_bwd_used = seq              # (what THIS backward ran: _seq_backward() depends on the step being enqueued; bench.py and tests read this)
         if seq:
             # the five launches below as one workgroup-long chain per live sequence
             pa = lambda ts: ptr_array([t.data_ptr() for t in ts])          # noqa: E731
@@ -1096,6 +1118,29 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         blk = (pl.red_blk_s if seq else getattr(pl, "red_blk_v", None) if live else None) or pl.red_blk   # per-entry block ranges of the partial sums
         ent, n_ent, ent_max = ((pl.red_entries_s, pl.red_n_s, pl.red_max_s) if seq else (pl.red_entries_v, pl.red_n_v, pl.red_max_v) if live
                                else (pl.red_entries, pl.red_n, pl.red_max))
+        pk = getattr(self, "_tail_pack", None)
+        pl.spans_done = False
+        if getattr(pl, "tail2", False) and not getattr(self, "_in_train_step", False):
+            # the folded step under data parallel: the exchange ships finished rows, so phase B of the segment reduce is a launch of its own
+            # behind the tail -- and in graph A of the graph pair the packing of this rank's chunk (ids | rows | dense) rides in it
+            ent_t, n_ent_t, blk_t = self._tail2_table(pl)
+            fp = self.dense
+            head = (pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_compact, self.D,
+                    pl.seg_ws.data_ptr())
+            mid = (ent_t.data_ptr(), n_ent_t, blk_t[0].data_ptr(), blk_t[1], pl.live.data_ptr(), shp.B, shp.Tenc,
+                   fp.ptr("sac1.pos_emb.weight", fp.grad), fp.ptr("sac2.pos_emb.weight", fp.grad))
+            if pk is not None:
+                from .dist import packed_rows
+                send, umax, with_dense = pk
+                id_rows, rows = packed_rows(umax, self.D)
+                L.call("amid_grad_tail_live_dp_f32", *head, send.data_ptr() + 4 * id_rows * self.D, *mid, pl.uniq_ids.data_ptr(),
+                       pl.n_uniq.data_ptr(), umax, self.n_rows, send.data_ptr(), self.dense.grad.data_ptr() if with_dense else None,
+                       send.data_ptr() + 4 * rows * self.D if with_dense else None, self.dense.numel if with_dense else 0,
+                       pl.err.data_ptr(), s)
+            else:
+                L.call("amid_grad_tail_live_dp_f32", *head, pl.uniq_grad.data_ptr(), *mid, None, None, 0, 0, None, None, None, 0, None, s)
+            pl.spans_done = True
+            return
         if getattr(pl, "tail2", False):
             ent_t, n_ent_t, blk_t = self._tail2_table(pl)
             fp = self.dense
@@ -1104,7 +1149,6 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                    pl.live.data_ptr(), shp.B, shp.Tenc, fp.ptr("sac1.pos_emb.weight", fp.grad), fp.ptr("sac2.pos_emb.weight", fp.grad),
                    None, None, None, 0, 0, None, None, None, None, s)      # (the scorer sums rode in the middle strip launch)
             return
-        pk = getattr(self, "_tail_pack", None)
         if pk is not None:       # graph A of the data-parallel step: the tail also packs this rank's exchange chunk (ids | rows | dense)
             from .dist import packed_rows
             send, umax, with_dense = pk
@@ -1137,11 +1181,12 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             cap = ids.numel()
         owed = int(getattr(pl, "spans_owed", 0))
         pl.spans_owed = 0
-        if sparse is None and (getattr(pl, "tail2", False) or owed):      # the segment reduce's runs across chunks are finished (and applied) here
+        t2 = getattr(pl, "tail2", False) and not getattr(pl, "spans_done", False)
+        if sparse is None and (t2 or owed):      # the segment reduce's runs across chunks are finished (and applied) here
             L.call("amid_optimizer_step_spans_f32", fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel,
                    self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), ids.data_ptr(),
                    nu.data_ptr(), cap, rows.data_ptr(), self.D, self.grad_scale, self.step_state.data_ptr(), pl.seg_off.data_ptr(),
-                   pl.seg_of.data_ptr(), pl.n_compact if getattr(pl, "tail2", False) else owed, pl.seg_ws.data_ptr(), s)
+                   pl.seg_of.data_ptr(), pl.n_compact if t2 else owed, pl.seg_ws.data_ptr(), s)
             return
         if owed:
             raise RuntimeError("the gradient tail left the chunk-crossing runs to an optimizer launch that takes merged lists")
@@ -1168,10 +1213,14 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # ------------------------------------------------------------------ data parallel (one process per GPU)
     def enqueue_local_grads(self, pl: SasrecPlan) -> None:
         """Everything of step t that needs no communication: t += 1 .. local segment-reduced gradients."""
-        self.enqueue_prepare(pl, sparse=True, bump_step=True, defer_sort=True)
-        self.enqueue_catchup(pl)
-        self._fork_sort(pl)
-        self._enqueue_fwd_bwd(pl)
+        self._in_local_grads = True
+        try:
+            self.enqueue_prepare(pl, sparse=True, bump_step=True, defer_sort=True)
+            self.enqueue_catchup(pl)
+            self._fork_sort(pl)
+            self._enqueue_fwd_bwd(pl)
+        finally:
+            self._in_local_grads = False
 
     def _fork_sort(self, pl: SasrecPlan) -> None:
         """Start the side-stream sort behind the catch-up launch, beside the forward (forks behind the forward or beside the weight

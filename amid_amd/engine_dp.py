@@ -76,12 +76,13 @@ class DataParallelMixin:
             raise ValueError(f"dense exchange must be 'gather' or 'allreduce', got {dense!r}")
         L = lib()
         if umax is not None:                   # a caller's bound may be rounded up past the plan's index count (e.g. to a multiple of 256):
-            umax = max(1, min(int(umax), self.n_sparse_train(pl)))      # clamp BEFORE it keys the captured graph pair (as dist.exchange_sparse does)
+            umax = max(1, min(int(umax), self.n_sparse_train(pl, dp=True)))      # clamp BEFORE it keys the captured graph pair (as dist.exchange_sparse does)
         with torch.cuda.stream(self.stream):
             self.grad_scale = exchange.grad_scale
             fast = (use_graph and umax is not None and exchange.active and hasattr(exchange.backend, "merge_packed")
                     and not exchange.use_owner(umax, self.D))      # the owner-bucketed exchange sizes its buffers per step: eager
-            pair = getattr(pl, "dp_graphs", {}).get((self._graph_key(), umax, dense)) if fast else None
+            # (the segmented graph A's collectives are closures over the exchange of capture time: the pair is keyed by the exchange too)
+            pair = getattr(pl, "dp_graphs", {}).get((self._graph_key(), umax, dense, id(exchange))) if fast else None
             if pair is not None:       # graph A (comp models: its segments with their collectives between them), the collective(s), graph B
                 if isinstance(pair[0], list):
                     for kind, item in pair[0]:
@@ -121,34 +122,49 @@ class DataParallelMixin:
         if in_chunk:
             be.prepare_dense(exchange.world, umax, self.dense.grad)      # device tables are built here, not under capture
         graphs = []
-        for part in (0, 1):
-            L.call("amid_graph_capture_begin", self.s)
-            try:
-                if part == 0:          # the tail of backward packs the chunk itself: no padding launch (amid_grad_tail_pack_f32)
-                    send = be.send[: be.chunk_rows(umax, dgrad) * self.D]
-                    self._tail_pack = (send, umax, in_chunk)
-                    segs = [] if getattr(self, "_dp_mid_collectives", False) else None
-                    self._seg_capture, self._seg_plan = segs, pl      # (engine._coll cuts the capture at every mid-step collective)
-                    try:
-                        self.enqueue_local_grads(pl)
-                    finally:
-                        self._tail_pack = None
-                        self._seg_capture = None
+        segs = None
+
+        def drop(items):                       # a capture that failed half-way: the graphs instantiated so far are destroyed, not leaked
+            for g in items:
+                if isinstance(g, list):
+                    drop([item for kind, item in g if kind == "graph"])
+                elif g:
+                    L.call("amid_graph_destroy", g)
+
+        try:
+            for part in (0, 1):
+                L.call("amid_graph_capture_begin", self.s)
+                try:
+                    if part == 0:          # the tail of backward packs the chunk itself: no padding launch (amid_grad_tail_pack_f32)
+                        send = be.send[: be.chunk_rows(umax, dgrad) * self.D]
+                        self._tail_pack = (send, umax, in_chunk)
+                        segs = [] if getattr(self, "_dp_mid_collectives", False) else None
+                        self._seg_capture, self._seg_plan = segs, pl      # (engine._coll cuts the capture at every mid-step collective)
+                        try:
+                            self.enqueue_local_grads(pl)
+                        finally:
+                            self._tail_pack = None
+                            self._seg_capture = self._seg_plan = None
+                    else:
+                        recv = be.gather_buffer(exchange.world, umax, dense=dgrad)
+                        self.enqueue_optimizer_gathered(be, recv, exchange.world, umax, dense_in_chunk=in_chunk)
+                finally:
+                    out = ctypes.c_void_p()
+                    L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
+                if part == 0 and segs is not None:
+                    segs.append(("graph", out.value))
+                    graphs.append(segs)
+                    segs = None
                 else:
-                    recv = be.gather_buffer(exchange.world, umax, dense=dgrad)
-                    self.enqueue_optimizer_gathered(be, recv, exchange.world, umax, dense_in_chunk=in_chunk)
-            finally:
-                out = ctypes.c_void_p()
-                L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
-            if part == 0 and segs is not None:
-                segs.append(("graph", out.value))
-                graphs.append(segs)
-            else:
-                graphs.append(out.value)
+                    graphs.append(out.value)
+        except BaseException:
+            drop(graphs + ([segs] if segs else []))
+            self.step = step0
+            raise
         self.step = step0                      # capture does not execute
         if not hasattr(pl, "dp_graphs"):
             pl.dp_graphs = {}
-        pl.dp_graphs[(self._graph_key(), umax, dense)] = (graphs[0], graphs[1], send, recv)
+        pl.dp_graphs[(self._graph_key(), umax, dense, id(exchange))] = (graphs[0], graphs[1], send, recv)
 
     def merge_backend(self, capacity: int) -> "HipMergeBackend":
         return HipMergeBackend(self, capacity)

@@ -744,7 +744,7 @@ def main():
                 durs[name] = v
         globals()["WGRAD_KIND"] = wgrad_kind_of(eng, args.model)
         work = algorithmic_work(Bw, int(pl.n_uniq.item()), T)
-        red_bytes = (getattr(pl, "red_bytes_s", None) if eng._seq_backward(pl) else None) or getattr(pl, "red_bytes_v", None) or getattr(pl, "red_bytes", None)
+        red_bytes = (getattr(pl, "red_bytes_s", None) if getattr(pl, "seq_bwd_used", False) else None) or getattr(pl, "red_bytes_v", None) or getattr(pl, "red_bytes", None)
         if red_bytes:         # K3 (the segment reduce of the row gradients) + the reduce of every dense partial sum, one launch
             k3 = "amid_embgrad_segreduce_live" if getattr(pl, "compact", False) else "amid_embgrad_segreduce_f32"
             work["amid_grad_tail_f32"] = ("hbm", work[k3][1] + red_bytes)
@@ -907,7 +907,7 @@ def main():
             owner = ex1["owner_steps"] > ex0["owner_steps"]
             dense_bytes = eng.dense.numel * 4
             from amid_amd.dist import packed_rows
-            sparse_bytes = packed_rows(min(umax_pool[0], eng.n_sparse_train(pl)), D)[1] * D * 4
+            sparse_bytes = packed_rows(min(umax_pool[0], eng.n_sparse_train(pl, dp=True)), D)[1] * D * 4
             out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                            "collectives_per_step": per("collectives"), "bytes_sent_per_step_per_rank": per("bytes_out"),
                            "bytes_received_per_step_per_rank": per("bytes_in"),

@@ -845,6 +845,16 @@ int amid_grad_tail_live_f32(const float* grad_rows, const int* pos_sorted, const
                             void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off, int total_blocks,
                             const int* live, int B, int T, float* dpos0, float* dpos1, const float* hidg, const float* u,
                             const float* items, int NI, int hid, float* dW1, float* db1, float* dW2, float* db2, void* stream);
+/* amid_grad_tail_live_f32 (hidg = NULL) for a caller that SHIPS the row gradients -- the data-parallel step (no reference analogue:
+ * train_sr.py:473 has DataParallel commented out): phase B of the segment reduce follows as a second launch instead of
+ * riding in this rank's optimizer.  n_out = 0: that launch alone (uniq_grad complete).  n_out > 0: amid_grad_tail_pack_f32's second launch
+ * (uniq_grad points into the exchange chunk, out_ids <- ids padded with pad_id to n_out, dense_dst <- dense_src; err_flag gets
+ * AMID_FLAG_UMAX_EXCEEDED when *n_uniq > n_out).  The same additions in the same order as the single-GPU folded step's. */
+int amid_grad_tail_live_dp_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                               void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off, int total_blocks,
+                               const int* live, int B, int T, float* dpos0, float* dpos1, const int* uniq_ids, const int* n_uniq, int n_out,
+                               int pad_id, int* out_ids, const float* dense_src, float* dense_dst, long long dense_n, int* err_flag,
+                               void* stream);
 /* hidg (optional; with it u [2, B, D], items [B, NI, D] and the four gradient outputs): the scorer's weight gradients (autograd of
  * predictModule.forward, model_seq.py:40-54) summed over the batch from the per-sample hidden gradients of amid_head_fwd_bwd_own_vec_f32
  * -- hidg [B][amid_scorer_vec_floats(NI, hid)] = da [2][hid] | dc [NI][hid] | dW2's [hid] | db2's: dW1 = sum_b da_b (x) u_b + dc_b (x) items_b.

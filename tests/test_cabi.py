@@ -68,3 +68,11 @@ def test_round5_entry_points_refuse_bad_arguments_without_a_gpu():
     # the comp shards: a phase outside 1 / 2
     rc = L._fn["amid_bert_comp_fwd_shard_f32"](null, null, null, null, null, null, 0.5, 0, 4, 4, 128, 8, 0, 3, null, null, null, null, null, null)
     assert rc == -1
+
+
+def test_round6_entry_points_refuse_bad_arguments_without_a_gpu():
+    """The data-parallel form of the folded step's gradient tail: null lists, a bound past the list, a pack request without its id buffers."""
+    L = _lib.lib()
+    null = None
+    f = L._fn["amid_grad_tail_live_dp_f32"]
+    assert f(*[null] * 4, 64, 128, null, null, null, 1, null, 1, null, 4, 50, null, null, null, null, 0, 0, null, null, null, 0, null, null) == -1

@@ -153,6 +153,119 @@ def test_two_rank_dp_over_rccl_two_gpus(owner, dense):
         assert (outs[0][1][k] == outs[1][1][k]).all(), f"replicas diverged on {k}"
 
 
+# ---- the folded step under data parallel (round 6): D 128, T 50, an input pool -- the shape family the single-GPU eleven-launch step covers ----
+FOLD = dict(n_items=600, D=128, T=50, hid=32, B=24, K=4, seed=23, lr=1e-3)
+
+
+def _fold_batches():
+    c = FOLD
+    out = []
+    for t in range(3):            # a pool of three batches walked K = 4 times round: rows lag and come back
+        b = orc.synthetic_batch(c["B"], c["T"], c["n_items"] - 1, pad_id=c["n_items"] - 1, neg=1, seed=800 + t)
+        out.append(b)
+    return out
+
+
+def _fold_worker(rank, world, port, q, fused, mode):
+    """mode: "pair" = graph A | all-gather | graph B (bench.py's path), "local" = the local-gradients graph + eager exchange, "eager"."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from amid_amd.dist import SparseDenseExchange, shard_batch
+        from amid_amd.engine import SasrecEngine
+        c = FOLD
+        torch.cuda.set_device(0)
+        P = orc.random_params(orc.sasrec_param_shapes(c["n_items"], c["D"], c["T"], c["hid"]), seed=9)
+        eng = SasrecEngine(c["n_items"], c["D"], c["T"], c["hid"], device="cuda:0", lr=c["lr"], seed=SasrecEngine.rank_seed(c["seed"], rank))
+        eng.FUSED_TAIL_DP = fused
+        eng.load_state_dict(P)
+        Bl = c["B"] // world
+        pl = eng.plan(Bl, c["T"], 2, need_grad=True)
+        ex = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=True)
+        packed = []
+        for batch in _fold_batches():
+            local = {k: v.cuda() for k, v in shard_batch(batch, rank, world).items()}
+            packed.append(eng.pack_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"], local["domain_id"]))
+        eng.set_input_pool(pl, torch.stack(packed))
+        if mode == "local":
+            eng.capture_local_grads(pl)
+        umax = eng.n_sparse_train(pl, dp=True) if mode == "pair" else None
+        losses, first = [], None
+        for t in range(c["K"]):
+            eng.train_step_dp(pl, ex, use_graph=mode != "eager", umax=umax)
+            eng.sync()
+            eng.check_index_error(pl)
+            assert bool(pl.tail2) == fused, "the data-parallel step did not take the path the test names"
+            losses.append(float(pl.loss.item()))
+            if t == 0:
+                first = {name: eng.dense.view(name, eng.dense.grad).cpu().numpy().copy() for name in eng.dense.slots}
+        if mode == "pair":
+            assert len(getattr(pl, "dp_graphs", {})) == 1, "the graph pair was not captured"
+        eng.flush_table()
+        eng.sync()
+        q.put((rank, {k: v.cpu().numpy().copy() for k, v in eng.state_dict().items()}, losses, first))
+    finally:
+        dist.destroy_process_group()
+
+
+def _fold_run(fused, mode):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fold_worker, args=(r, world, port, q, fused, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return outs
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["pair", "local", "eager"])
+def test_two_rank_dp_folded_step_matches_fifteen_launch_step_and_oracle(mode):
+    """SasrecEngine.FUSED_TAIL_DP: every rank's local half of the data-parallel step in the single-GPU step's folded form (step head, head on
+    the forward's tail, embedding backward on the last strip, position rows in the tail; phase B of the segment reduce + the chunk's packing
+    as one launch, amid_grad_tail_live_dp_f32).  Held: the two replicas bit-identical; the first step's loss on every rank bit-identical
+    to the fifteen-launch data-parallel step's and its summed dense gradients to rounding; the parameters after K steps (rows that lag
+    and come back: a three-batch pool) to rounding of the fifteen-launch step's and within 1e-4 of ONE process stepping the oracle
+    (dense Adam) over the global batches."""
+    c = FOLD
+    world = 2
+    res = {fused: _fold_run(fused, mode) for fused in (False, True)}
+    for fused, outs in res.items():
+        for k in outs[0][1]:
+            assert (outs[0][1][k] == outs[1][1][k]).all(), f"replicas diverged on {k} (folded={fused})"
+    for r in range(world):
+        assert res[True][r][2][0] == res[False][r][2][0], (res[True][r][2], res[False][r][2])
+        for name, want in res[False][r][3].items():
+            got = res[True][r][3][name]
+            scale = max(float(abs(want).max()), 1e-30)
+            assert float(abs(got - want).max()) / scale < 2e-6, name
+    P = orc.random_params(orc.sasrec_param_shapes(c["n_items"], c["D"], c["T"], c["hid"]), seed=9)
+    opt = orc.DenseAdam(P, lr=c["lr"])
+    Bl = c["B"] // world
+    from amid_amd.engine import SasrecEngine
+    batches = _fold_batches()
+    for t in range(1, c["K"] + 1):
+        per_rank = [orc.philox_masks_sasrec(Bl, c["T"], c["D"], seed=SasrecEngine.rank_seed(c["seed"], r), step=t) for r in range(world)]
+        masks = {k: torch.cat([m[k] for m in per_rank], 0) for k in per_rank[0]}
+        orc.train_step("sasrec", P, opt, batches[(t - 1) % 3], masks)
+    for fused in (False, True):
+        sd = {k: torch.from_numpy(v) for k, v in res[fused][0][1].items()}
+        for k, v in P.items():
+            d = (sd[k] - v).abs()
+            if k.endswith("in_proj_bias"):
+                n = v.numel() // 3
+                d = torch.cat((d[:n], d[2 * n:]))
+            assert float(d.max()) < 1e-4, (fused, k, float(d.max()))
+    a, b = res[False][0][1], res[True][0][1]
+    for k in a:
+        ta, tb = torch.from_numpy(a[k]).double(), torch.from_numpy(b[k]).double()
+        assert float((ta - tb).norm() / ta.norm().clamp(min=1e-30)) < 1e-3, k
+
+
 ITC = dict(n_items=300, D=64, T=20, hid=16, B=8, K=3, seed=13, lr=1e-3, ts2=0.15)
 
 

@@ -191,7 +191,7 @@ def test_n_split_fused_backward_is_bit_identical_to_the_strip_build(Bn, T, split
                     t_.zero_()
             pl.dxbuf.zero_()
             timed_local_grads(eng, pl, batch, step, seed)
-            assert eng._seq_backward(pl)
+            assert pl.seq_bwd_used
             n = int(pl.n_uniq.item())
             got[v] = dict(rows=pl.uniq_grad[:n].clone(), dx=pl.dxbuf.clone(), **{name: eng.dense.view(name, eng.dense.grad).clone() for name in eng.dense.slots},
                           **{f"{k}{l}": getattr(pl, k)[l].clone() for k in ("dq_l", "dk_l", "dv_l", "dpre1", "dpre2", "dr") for l in (0, 1)})
@@ -304,7 +304,7 @@ def _timed_vs_oracle(Bn, T, D, build, split, compact_min, seq_backward=None, poo
     else:
         timed_local_grads(eng, pl, batch, step, seed)
     if seq_backward is not None:
-        assert eng._seq_backward(pl) == (seq_backward == "1")
+        assert pl.seq_bwd_used == (seq_backward == "1")
     assert pool or (pl.compact == eng.compact_ok(pl) and (compact_min != 0 or D != 128 or pl.compact))
     # the encoder's GEMM chains of the fused step run as strip kernels over the live sequences (csrc/sasrec_strip.hip); engines
     # built without them fall back to the live-row builds of the row-tile kernels named in the case
