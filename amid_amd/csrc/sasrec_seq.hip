@@ -442,10 +442,13 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
                         float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
                         const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
                         const void* step_state, int train, float p_drop, const void* w16, void* stream, int w16_planes = 1,
-                        float* const* ln_stat = nullptr, const HeadArgs* head = nullptr) {
+                        float* const* ln_stat = nullptr, const HeadArgs* head = nullptr, bool infer = false) {
     AMID_CHECK_ARG(n_layers >= 1 && n_layers <= 2 && x_in && (xout || head) && ln1_w && ln1_b && w_in && b_in && w_o && b_o && ln2_w && ln2_b && w1 && b1 &&
-                   w2 && b2 && (ln_stat || (qn && y)) && q && k && v && o && stats && r && h && (!train || step_state));
+                   w2 && b2 && (!train || step_state));
+    AMID_CHECK_ARG(infer || ((ln_stat || (qn && y)) && q && k && v && o && stats && r && h));
     if (ln_stat != nullptr && !(w16 != nullptr && w16_planes == 3 && D == 128)) return AMID_ERR_UNSUPPORTED;      // the piece forward only
+    // an inference forward saves nothing (SeqGeom::save_bytes = 0): the producer-side pieces build at D 128 only, T a multiple-of-16 strip count it tiles
+    if (infer && !(w16 != nullptr && w16_planes == 3 && D == 128 && !train && head == nullptr)) return AMID_ERR_UNSUPPORTED;
     if (!amid_sas_seq_supported(B, T, D, H)) return AMID_ERR_UNSUPPORTED;
     SeqFwdArgs a = {};
     a.n_layers = n_layers;
@@ -456,6 +459,12 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
             AMID_CHECK_ARG(ln1_w[i] && ln1_b[i] && w_in[i] && b_in[i] && w_o[i] && b_o[i] && ln2_w[i] && ln2_b[i] && w1[i] && b1[i] && w2[i] && b2[i]);
             P.ln1_w[g] = ln1_w[i]; P.ln1_b[g] = ln1_b[i]; P.w_in[g] = w_in[i]; P.b_in[g] = b_in[i]; P.w_o[g] = w_o[i]; P.b_o[g] = b_o[i];
             P.ln2_w[g] = ln2_w[i]; P.ln2_b[g] = ln2_b[i]; P.w1[g] = w1[i]; P.b1[g] = b1[i]; P.w2[g] = w2[i]; P.b2[g] = b2[i];
+        }
+        if (infer) {
+            AMID_CHECK_ARG(l > 0 || x_in[0]);
+            P.x = l == 0 ? const_cast<float*>(x_in[0]) : nullptr;
+            P.qn = P.q = P.k = P.v = P.o = P.stats = P.r = P.y = P.h = P.ln_stat = nullptr;
+            continue;
         }
         AMID_CHECK_ARG(x_in[l] && q[l] && k[l] && v[l] && o[l] && stats[l] && r[l] && h[l] && (ln_stat ? ln_stat[l] != nullptr : (qn[l] && y[l])));
         P.x = const_cast<float*>(x_in[l]); P.qn = ln_stat ? nullptr : qn[l]; P.q = q[l]; P.k = k[l]; P.v = v[l]; P.o = o[l]; P.stats = stats[l];
@@ -472,7 +481,9 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
     sg.B = B; sg.T = T; sg.M = B * T; sg.live = live;
     const long long bytes = 2LL * B * T * D * 4;
     sg.act_bytes = (unsigned)bytes; sg.tm_bytes = (unsigned)(bytes / 16); sg.stats_bytes = (unsigned)(2LL * B * T * H * 8);
+    sg.save_bytes = infer ? 0u : sg.act_bytes; sg.save_stats_bytes = infer ? 0u : sg.stats_bytes;
     if (head != nullptr) return launch_seqn_fwd(a, sg, D, 0, stream, head);       // (the default N-split build or nothing)
+    if (infer) return launch_seqn_fwd(a, sg, D, 0, stream, nullptr);             // (the default split of the pieces build or nothing)
     {
         int v = g_seq_fwd_variant;
         if (v == 0) v = 2;                                 // auto: the N-split build wins at every measured shape (profiles/r03_*)
@@ -598,6 +609,22 @@ extern "C" int amid_sas_seq_fwd_split_f32(int n_layers, const float* const* x_in
     AMID_CHECK_ARG(w16x3 != nullptr);
     return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, qn, q, k, v, o, stats, r, y, h, tmq,
                         ln_eps, B, T, D, H, live, step_state, train, p_drop, w16x3, stream, 3);
+}
+
+// amid_sas_seq_fwd_split_f32 as an INFERENCE forward (evaluation, train_sr.py:31-128: model(..., False) under no_grad): the same products
+// in the same order -- xout comes out bit-identical -- but none of the tensors a backward would read is stored (18 stores of 6.5 MB at the
+// headline shape); x0 = layer 0's input rows.  D = 128; no dropout.
+extern "C" int amid_sas_seq_fwd_split_infer_f32(int n_layers, const float* x0, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                                const float* const* w_in, const float* const* b_in, const float* const* w_o,
+                                                const float* const* b_o, const float* const* ln2_w, const float* const* ln2_b,
+                                                const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
+                                                const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                                                const void* w16x3, void* stream) {
+    AMID_CHECK_ARG(w16x3 != nullptr && x0 != nullptr && xout != nullptr);
+    const float* xin[2] = {x0, nullptr};
+    return seq_fwd_impl(n_layers, xin, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, tmq, ln_eps, B, T, D, H, live, nullptr, 0, 0.f, w16x3, stream, 3, nullptr, nullptr,
+                        true);
 }
 
 // amid_sas_seq_fwd_split_f32 that saves SEVEN tensors per layer instead of nine: qn = LN1(x) and y = LN2(r) are not stored; ln_stat[l]

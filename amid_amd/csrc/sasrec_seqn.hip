@@ -473,8 +473,8 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
     for (int l = 0; l < a.n_layers; ++l) {
         const SeqLayer& P = a.L[l];
         const bool last = l + 1 == a.n_layers;
-        const GBuf gqn(P.qn, sg.act_bytes), gq_(P.q, sg.act_bytes), gk(P.k, sg.act_bytes), gv(P.v, sg.act_bytes),
-                   go(P.o, sg.act_bytes), gst(P.stats, sg.stats_bytes), gr(P.r, sg.act_bytes), gy(P.y, sg.act_bytes), gh(P.h, sg.act_bytes);
+        const GBuf gqn(P.qn, sg.save_bytes), gq_(P.q, sg.save_bytes), gk(P.k, sg.save_bytes), gv(P.v, sg.save_bytes),
+                   go(P.o, sg.save_bytes), gst(P.stats, sg.save_stats_bytes), gr(P.r, sg.save_bytes), gy(P.y, sg.save_bytes), gh(P.h, sg.save_bytes);
         part_cols<NCT>(lwo, P.ln1_w[g], c0); part_cols<NCT>(lbo, P.ln1_b[g], c0);
         SEQN_STAMP(0);
         ring.next();                                       // Wk has landed; the row of x is in the exchange slots
@@ -661,7 +661,7 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
         if (!last) {
             lds_barrier();
             xp_write<NCT>(xps, c0, Xo);
-            part_store<NCT>(GBuf(a.L[l + 1].x, sg.act_bytes), off_own, Xo);
+            part_store<NCT>(GBuf(a.L[l + 1].x, sg.save_bytes), off_own, Xo);
         } else if (!HEAD || a.xout != nullptr) {             // (with the head on the tail only its tests ask for the rows)
             part_store<NCT>(GBuf(a.xout, sg.act_bytes), off_own, Xo);
         }

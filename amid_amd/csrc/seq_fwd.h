@@ -36,6 +36,10 @@ struct SeqFwdArgs {
 struct SeqGeom {
     int B, T, M;
     unsigned act_bytes, tm_bytes, stats_bytes;
+    // the sizes the SAVED tensors' buffer descriptors are built with (seqn_fwd_px_kernel): act_bytes / stats_bytes in a forward that a
+    // backward follows; 0 in an inference forward (amid_sas_seq_fwd_split_infer_f32) -- every store of a tensor only a backward would read
+    // falls outside its descriptor and is dropped by the memory pipeline: no HBM write, no buffer
+    unsigned save_bytes, save_stats_bytes;
     const int* live;                    // as StripGeom::live
 };
 

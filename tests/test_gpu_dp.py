@@ -187,7 +187,7 @@ def _fold_worker(rank, world, port, q, fused, mode):
             local = {k: v.cuda() for k, v in shard_batch(batch, rank, world).items()}
             packed.append(eng.pack_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"], local["domain_id"]))
         eng.set_input_pool(pl, torch.stack(packed))
-        if mode == "local":
+        if mode != "eager":           # (the graph pair's first step runs the local-gradients graph, then captures the pair)
             eng.capture_local_grads(pl)
         umax = eng.n_sparse_train(pl, dp=True) if mode == "pair" else None
         losses, first = [], None
