@@ -1265,6 +1265,122 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         _enqueue_fwd_bwd), else None: a backward driven by someone else's loss (the autograd path) makes no such promise."""
         return pl.domain.data_ptr() if getattr(self, "_own_domain_only", False) else None
 
+    # ------------------------------------------------------------------ evaluation: test(), train_sr.py:31-128
+    # The evaluation batch in four launches (round 6): index marshal + live list, K1 over the live sequences only (no candidate rows: the
+    # head gathers them), the inference forward over the live sequences (nothing saved), amid_eval_head_f32 (LN_last + mean, the scorer over
+    # the 1 + neg_nums candidates, masked BCE, the positive's rank).  test() reads only the own domain's logits of a sample (utils.py:21-40)
+    # and masks the other domain's loss terms (train_sr.py:63-64), so nothing else is computed; model.forward keeps returning both.
+    EVAL_FUSED = True
+
+    def eval_fused_ok(self, pl: SasrecPlan) -> bool:
+        return bool(self.EVAL_FUSED and not self.itc_bs and not self.inc_bs and not self.dr and not getattr(self, "comp", "") and pl.strip
+                    and self.SEQ_FORWARD and self.input_pool(pl) is None
+                    and lib().value("amid_sas_seq_supported", pl.shape.B, pl.shape.Tenc, self.D, self.H))
+
+    def _eval_out(self, pl: SasrecPlan):
+        """The batch's results, one int32 image [rank B | rank_raw B | loss_part B (fp32 bits)] (+ the scores, for tests)."""
+        if not hasattr(pl, "ev_out"):
+            B = pl.shape.B
+            pl.ev_out = torch.zeros(3 * B, dtype=torch.int32, device=self.device)
+            pl.ev_rank, pl.ev_rank_raw, pl.ev_loss_part = pl.ev_out[:B], pl.ev_out[B:2 * B], pl.ev_out[2 * B:].view(torch.float32)
+            pl.ev_p = torch.zeros(B, pl.shape.NI, dtype=torch.float32, device=self.device)
+            pl.ev_u = torch.zeros(B, self.D, dtype=torch.float32, device=self.device)
+        return pl.ev_out
+
+    def enqueue_eval(self, pl: SasrecPlan, fix_value: float, with_loss: bool = True, want_scores: bool = False) -> None:
+        """One test() batch from the plan's static inputs (load_batch / load_packed) to pl.ev_rank / ev_rank_raw / ev_loss_part."""
+        if not self.eval_fused_ok(pl):
+            raise ValueError("enqueue_eval: this model / shape evaluates through enqueue_forward (eval_fused_ok)")
+        L, s, shp, D = lib(), self.s, pl.shape, self.D
+        B, T, NI = shp.B, shp.Tenc, shp.NI
+        fp, st = self.dense, self.step_state.data_ptr()
+        self._eval_out(pl)
+        L.call("amid_pack_indices_live", pl.in_i_node.data_ptr(), pl.in_neg.data_ptr(), pl.in_seq_d1.data_ptr(), pl.in_seq_d2.data_ptr(),
+               B, shp.T, NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(), None, pl.domain.data_ptr(), pl.live.data_ptr(), s)
+        lf = pl.live.data_ptr()
+        pos = (fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"))
+        split = self._fwd_on_pieces(pl, B, T)
+        pl.w16_written = pl.wT16x3_written = False
+        if split:          # the gather's extra workgroups write the weights' three-plane images (the forward's operands)
+            src, w16 = self._w16_images(3)
+            L.call("amid_embed_fwd_w16_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), *pos, B, T, D, 0, pl.xg.data_ptr(), pl.tmq.data_ptr(),
+                   st, 0, SASREC_P_DROP, lf, None, None, src, 24, 3, w16.data_ptr(), None, s)
+        else:
+            L.call("amid_embed_fwd_live_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), *pos, B, T, D, 0, pl.xg.data_ptr(), pl.tmq.data_ptr(),
+                   st, 0, SASREC_P_DROP, lf, s)
+        fam = lambda fmt: ptr_array([fp.ptr(fmt.format(d=d, l=l)) for l in (0, 1) for d in (1, 2)])      # noqa: E731  [layer][domain]
+        key = ("eval_fwd", id(pl))
+        c = self._ptr_cache.get(key)
+        if c is None:
+            c = (fam("sac{d}.attention_layernorms.{l}.weight"), fam("sac{d}.attention_layernorms.{l}.bias"),
+                 fam("sac{d}.attention_layers.{l}.in_proj_weight"), fam("sac{d}.attention_layers.{l}.in_proj_bias"),
+                 fam("sac{d}.attention_layers.{l}.out_proj.weight"), fam("sac{d}.attention_layers.{l}.out_proj.bias"),
+                 fam("sac{d}.forward_layernorms.{l}.weight"), fam("sac{d}.forward_layernorms.{l}.bias"),
+                 fam("sac{d}.forward_layers.{l}.conv1.weight"), fam("sac{d}.forward_layers.{l}.conv1.bias"),
+                 fam("sac{d}.forward_layers.{l}.conv2.weight"), fam("sac{d}.forward_layers.{l}.conv2.bias"))
+            self._ptr_cache[key] = c
+        if split:
+            L.call("amid_sas_seq_fwd_split_infer_f32", 2, pl.x[0].data_ptr(), pl.x[2].data_ptr(), *c, pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D,
+                   self.H, lf, w16.data_ptr(), s)
+        else:              # D 64 / compute = "bf16" / FWD_SPLIT off: the saving forward over the live sequences
+            tl = lambda ts: ptr_array([t.data_ptr() for t in ts])      # noqa: E731
+            saved = (tl(pl.qn), tl(pl.q), tl(pl.k), tl(pl.v), tl(pl.o), tl(pl.stats), tl(pl.r), tl(pl.y), tl(pl.h))
+            if self.compute == "bf16":
+                src, w16 = self._w16_images(1)
+                L.call("amid_sas_weights_bf16_planes", src, 24, D, 0, 1, w16.data_ptr(), s)
+                L.call("amid_sas_seq_fwd_bf16w_f32", 2, tl(pl.x[:2]), pl.x[2].data_ptr(), *c, *saved, pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D,
+                       self.H, lf, st, 0, SASREC_P_DROP, w16.data_ptr(), s)
+            else:
+                L.call("amid_sas_seq_fwd_f32", 2, tl(pl.x[:2]), pl.x[2].data_ptr(), *c, *saved, pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H,
+                       lf, st, 0, SASREC_P_DROP, s)
+        L.call("amid_eval_head_f32", pl.x[2].data_ptr(), self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
+               self.table.data_ptr(), pl.idx_all.data_ptr() + 4 * 2 * shp.Mi, fp.ptr("predictModule.fc.0.weight"),
+               fp.ptr("predictModule.fc.0.bias"), fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"),
+               pl.labels.data_ptr() if with_loss else None, pl.domain.data_ptr(), B, T, NI, D, self.hid, SASREC_LN_EPS, float(fix_value),
+               pl.ev_u.data_ptr() if want_scores else None, pl.ev_p.data_ptr() if want_scores else None, pl.ev_rank.data_ptr(),
+               pl.ev_rank_raw.data_ptr(), pl.ev_loss_part.data_ptr() if with_loss else None, s)
+
+    def capture_eval(self, pl: SasrecPlan, fix_value: float, with_loss: bool = True) -> None:
+        """The evaluation batch as a hipGraph over the plan's static inputs (weights are read at replay time: the graph stays valid across
+        training steps; it is keyed by fix_value / with_loss)."""
+        L = lib()
+        self.enqueue_eval(pl, fix_value, with_loss)           # warm-up outside capture (dynamic-LDS attributes, code objects)
+        self.sync()
+        L.call("amid_graph_capture_begin", self.s)
+        try:
+            self.enqueue_eval(pl, fix_value, with_loss)
+        finally:
+            out = ctypes.c_void_p()
+            L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
+        if not hasattr(pl, "eval_graphs"):
+            pl.eval_graphs = {}
+        pl.eval_graphs[(float(fix_value), bool(with_loss))] = out.value
+
+    def eval_epoch(self, pl: SasrecPlan, packed: torch.Tensor, fix_value: float, with_loss: bool = True, use_graph: bool = True) -> torch.Tensor:
+        """Every batch of `packed` ([n_batches, in_words] int64: pack_epoch's images, resident in HBM) through the evaluation launches:
+        one device copy of the image into the plan's static inputs, one graph replay, one device copy of the 3 B result words out.
+        Returns [n_batches, 3 B] int32 (rank | rank_raw | loss_part bits) on the device; nothing is read back here."""
+        if packed.dtype != torch.int64 or packed.dim() != 2 or packed.shape[1] != pl.in_words:
+            raise ValueError(f"eval_epoch takes [n, {pl.in_words}] int64 batch images (pack_epoch)")
+        if self.table_m is not None:
+            self.flush_table()                   # rows with pending zero-gradient Adam steps must be current for evaluation
+        out = torch.empty(packed.shape[0], 3 * pl.shape.B, dtype=torch.int32, device=self.device)
+        key = (float(fix_value), bool(with_loss))
+        if use_graph and key not in getattr(pl, "eval_graphs", {}):
+            with torch.cuda.stream(self.stream):
+                pl.in_pack.copy_(packed[0], non_blocking=True)
+            self.capture_eval(pl, fix_value, with_loss)
+        L = lib()
+        with torch.cuda.stream(self.stream):
+            for i in range(packed.shape[0]):
+                pl.in_pack.copy_(packed[i], non_blocking=True)
+                if use_graph:
+                    L.call("amid_graph_launch", pl.eval_graphs[key], self.s)
+                else:
+                    self.enqueue_eval(pl, fix_value, with_loss)
+                out[i].copy_(self._eval_out(pl), non_blocking=True)
+        return out
+
     # ------------------------------------------------------------------ parameter interchange
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         with torch.no_grad(), torch.cuda.stream(self.stream):

@@ -124,6 +124,7 @@ class Bert4recEngine(SasrecEngine):
     STRIP_KERNELS = True         # the block's GEMM chains on csrc/bert_strip.hip (BertPlan.strip); bert.hip's row-tile kernels beyond 2 GiB
     SORT_RIDERS = False          # (the riders' host launches are the SASRec strip backward's)
     FUSED_TAIL = False           # (the one-launch step head and the folded tail are the SASRec step's)
+    EVAL_FUSED = False           # (the four-launch evaluation batch is the SASRec model's: engine.enqueue_eval)
     STRIP_P3 = True              # the strips' products on bf16 pieces at fp32 accuracy (csrc/bert_strip.hip MODE 3; False: fp32 matrix instructions)
 
     def live_forward_ok(self, pl) -> bool:

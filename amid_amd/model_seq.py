@@ -297,6 +297,26 @@ class SASRec(nn.Module):
         self._last_plan = pl
         return pl.dr_losses if eng.dr else pl.loss
 
+    def eval_ranks(self, ep: Dict[str, torch.Tensor], fix_value: float, use_graph: bool = True) -> Optional[Dict[str, torch.Tensor]]:
+        """test()'s arithmetic (train_sr.py:31-128) over a whole evaluation set resident in HBM (ep = DeviceBatches.epoch_tensors()):
+        per batch the eval-mode forward of every sample's OWN domain sequence, its 1 + neg_nums scores, the masked BCE mean (:63-64) and
+        the positive's rank with and without fix_value (:114-115; utils.py:21-40, :296-297) -- four launches replayed as one graph
+        (SasrecEngine.enqueue_eval).  Returns device tensors rank [n, B], rank_raw [n, B] (int32) and loss [n], or None when this model
+        evaluates through forward() (isItC / isInC / isDR, BERT4Rec, shapes the one-launch forward does not cover)."""
+        eng = self.engine
+        nb, B, T = ep["seq_d1"].shape
+        neg = ep["neg_samples"].reshape(nb, B, -1)
+        pl = eng.plan(B, T, 1 + neg.shape[2], need_grad=False)
+        if not eng.eval_fused_ok(pl):
+            return None
+        eng.stream.wait_stream(torch.cuda.current_stream())
+        packed = eng.pack_epoch(pl, ep["i_node"], neg, ep["seq_d1"], ep["seq_d2"], ep["label"], ep["domain_id"])
+        eng.stream.wait_stream(torch.cuda.current_stream())
+        out = eng.eval_epoch(pl, packed, fix_value, with_loss=True, use_graph=use_graph)
+        torch.cuda.current_stream().wait_stream(eng.stream)
+        eng.check_index_error(pl)
+        return {"rank": out[:, :B], "rank_raw": out[:, B:2 * B], "loss": out[:, 2 * B:].view(torch.float32).sum(1)}
+
     def check_indices(self) -> None:
         """Raise IndexError if any batch since the last check carried an item id outside the table (nn.Embedding raises on the spot,
         model_seq.py:27-29; the fused step flags it on the device and keeps going with row 0).  One device -> host read: call it

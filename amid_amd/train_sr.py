@@ -86,7 +86,20 @@ def test(model, args, val_batches):
     model.eval()
     stats = AverageMeter("loss", "loss_cls")
     ranks, ranks_raw, doms, ovs, losses = [], [], [], [], []
-    for b in val_batches:
+    # the plain SASRec model: the whole evaluation set resident in HBM, per batch four launches replayed as one graph -- the own domain's
+    # sequence only (the other domain's logits are never read: utils.py:21-40, train_sr.py:63-64), candidates gathered inside the scorer,
+    # BCE and both ranks in the same launch (SASRec.eval_ranks); every other model goes through model.forward below
+    fused = None
+    if hasattr(model, "eval_ranks") and hasattr(val_batches, "epoch_tensors") and len(val_batches) > 0:
+        ep = val_batches.epoch_tensors()
+        fused = model.eval_ranks(ep, FIX_VALUE)
+        if fused is not None:
+            losses = list(fused["loss"])
+            ranks, ranks_raw = [fused["rank"].reshape(-1)], [fused["rank_raw"].reshape(-1)]
+            doms, ovs = [ep["domain_id"].reshape(-1)], [ep["overlap_label"].reshape(-1)]
+        else:                                  # (the draw of this epoch's negatives is made: iterate the same batches)
+            val_batches = [{k: (v if k == "label" else v[i]) for k, v in ep.items()} for i in range(ep["seq_d1"].shape[0])]
+    for b in ([] if fused is not None else val_batches):
         outs = model(b["user_node"], b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["long_tail_mask_d1"],
                      b["long_tail_mask_d2"], False)
         p1, p2 = outs[0], outs[1]                                                         # isDR models return six outputs

@@ -402,42 +402,81 @@ def eval_batch(gen, device, Bw):
     return {k: v.to(device) for k, v in b.items()}
 
 
-def eval_throughput(eng, device, Bw, T, n_batches=32):
-    """The evaluation loop's throughput (what test() does per batch, train_sr.py:31-128, at run.sh's 999 negatives): the eval-mode
-    forward over BOTH domains' sequences with 1 000 candidates per row, then the positive's rank of every row on the device
-    (amid_positive_rank_f32: choose_predict + the double argsort of get_sample_scores, utils.py:21-40 / :296-312, fix_value tie rule);
-    B ints per batch are what the host would read.  Eager launches, as the CLI's test() runs them."""
-    from amid_amd.utils import device_positive_ranks
+def eval_throughput(eng, device, Bw, T, n_batches=64):
+    """The evaluation loop's throughput (what test() does per batch, train_sr.py:31-128, at run.sh's 999 negatives), as the CLI's test()
+    runs it since round 6 (SASRec.eval_ranks -> SasrecEngine.eval_epoch): the batches resident in HBM, per batch one device copy of the
+    packed image, FOUR launches replayed as one graph -- index marshal + live list, K1 over the own-domain sequences, the inference forward
+    over them (nothing saved), amid_eval_head_f32 (LN_last + mean, the scorer over the 1 000 candidates gathered in the launch, masked
+    BCE, the positive's rank with and without fix_value) -- and one device copy of the 3 B result words.  test() reads only the own
+    domain's logits (utils.py:21-40) and masks the other domain's loss terms (train_sr.py:63-64): nothing else is computed.
+    `kernels`: each launch timed with HIP events on the engine's stream, priced against the roof that bounds it."""
+    from amid_amd._lib import KernelTimer, lib
     gen = torch.Generator().manual_seed(4321)
     batches = [eval_batch(gen, device, Bw) for _ in range(4)]
     pl = eng.plan(Bw, T, 1 + EVAL_NEG, need_grad=False)
+    if not eng.eval_fused_ok(pl):
+        raise RuntimeError("the four-launch evaluation batch does not cover this engine / shape")
+    packed4 = torch.stack([eng.pack_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"], b["label"], b["domain_id"]) for b in batches])
+    packed = packed4[torch.arange(n_batches, device=device) % 4].contiguous()
+    torch.cuda.synchronize(device)
     eng.flush_table()
     eng.sync()
-    cur = torch.cuda.current_stream()
-
-    def one(b):
-        eng.stream.wait_stream(cur)
-        eng.load_batch(pl, b["i_node"], b["neg_samples"], b["seq_d1"], b["seq_d2"])
-        eng.enqueue_prepare(pl, sparse=False)
-        eng.enqueue_forward(pl, train=False, with_loss=False)
-        cur.wait_stream(eng.stream)
-        return device_positive_ranks(pl.p1, pl.p2, b["domain_id"], 1e-7)
-
-    for i in range(3):
-        r = one(batches[i % 4])
+    out = eng.eval_epoch(pl, packed[:8], 1e-7)            # warm-up + graph capture
+    eng.sync()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for i in range(n_batches):
-        r = one(batches[i % 4])
+    out = eng.eval_epoch(pl, packed, 1e-7)
+    eng.sync()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     eng.check_index_error(pl)
-    return {"metric": "eval samples/sec (test(): forward at 1 + neg candidates per row + the positive's rank on the device)",
+    rank = out[:, :Bw]
+    # per-launch durations (eager, HIP events on the engine's stream) and what bounds each launch
+    L = lib()
+    L.timer = KernelTimer()
+    n_prof = 10
+    try:
+        for i in range(n_prof):
+            eng.load_packed(pl, packed[i])
+            eng.enqueue_eval(pl, 1e-7)
+            eng.sync()
+        durs = L.timer.collect(L)
+    finally:
+        L.timer = None
+    NI = 1 + EVAL_NEG
+    gl = 2.0 * Bw * T * D * D
+    work = {
+        # the candidates' rows + their ids, the own sequences' last-layer rows; scores / ranks / loss stay in the workgroup
+        "amid_eval_head_f32": ("hbm", Bw * NI * (D * 4 + 4) + Bw * T * D * 4 + Bw * NI * 4),
+        "amid_sas_seq_fwd_split_infer_f32": ("mfma16x6", 12 * gl + 2 * 4.0 * T * T * (D // 8) * Bw * 8),
+        "amid_embed_fwd_w16_f32": ("hbm", Bw * T * (8 + 2 * D * 4) + Bw * T * (D // 4) + 24 * D * D * 10),
+        "amid_pack_indices_live": ("hbm", (2 * Bw * T + Bw * NI) * 12),
+    }
+    kernels = {}
+    for name, v in durs.items():
+        us = 1e3 * sum(v) / len(v)
+        ent = {"avg_launch_us": round(us, 2)}
+        if name in work:
+            kind, amount = work[name]
+            if kind == "hbm":
+                ent.update(bound="hbm", achieved=round(amount / (us * 1e-6) / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s")
+            else:
+                ent.update(bound="mfma", achieved=round(amount / (us * 1e-6) / 1e12, 2), peak=round(PEAK_BF16_MFMA_TFLOPS / 6, 1), unit="TFLOP/s",
+                           operands="fp32 as three bf16 pieces, 6 piece pairs")
+            ent["frac"] = round(ent["achieved"] / ent["peak"], 4)
+        kernels[name] = ent
+    head = kernels.get("amid_eval_head_f32", {})
+    if head:       # the scorer's chains: NI hid D fma per sample on the vector pipe, beside the gather
+        head["vector_fma_tflops"] = round(2.0 * Bw * NI * HID * D / (head["avg_launch_us"] * 1e-6) / 1e12, 2)
+    return {"metric": "eval samples/sec (test(): own-domain forward + 1 + neg candidates per row + loss + the positive's rank, on the device)",
             "value": round(Bw * n_batches / dt, 1), "unit": "samples/s", "batches_per_s": round(n_batches / dt, 2),
             "ms_per_batch": round(1e3 * dt / n_batches, 4), "batch": Bw, "seq_len": T, "neg_nums": EVAL_NEG, "batches_timed": n_batches,
-            "mean_rank_last_batch": round(float(r.float().mean().item()), 2),
-            "what": "eager launches per batch: index marshal, gather of 2 B T + 1 000 B rows, both encoders over every sequence, "
-                    "scorer over 1 000 candidates per row, rank kernel; synthetic cloth_sport-shaped batches"}
+            "mean_rank_last_batch": round(float(rank[-1].float().mean().item()), 2),
+            "launches_per_batch": sum(len(v) for v in durs.values()) // n_prof, "sum_kernel_us": round(sum(k["avg_launch_us"] for k in kernels.values()), 2),
+            "kernels": kernels,
+            "what": "per batch: one device copy of the packed batch, one replayed graph of four launches (index marshal + live list, gather of "
+                    "the B own-domain sequences, inference forward over them, eval head: gather of the 1 000 candidates per row inside the "
+                    "scorer + masked BCE + ranks), one device copy of 3 B result words; synthetic cloth_sport-shaped batches"}
 
 
 def cpu_eval_baseline(P, budget_s=8.0):

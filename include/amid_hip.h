@@ -890,6 +890,29 @@ int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const float* g, 
                                   const void* step_state, const int* seg_off, const int* seg_of, int n_sorted, const void* workspace,
                                   void* stream);
 
+/* ---- evaluation (round 6): test(), train_sr.py:31-128 ------------------------------------------------------------------------------------------
+ * replaces, for the plain SASRec model: model(u, i, neg, seq_d1, seq_d2, ..., False) under no_grad (train_sr.py:55-56) + the masked BCE
+ * (:63-64) + choose_predict / get_sample_scores' rank of column 0 (utils.py:21-40, :296-297; fix_value: train_sr.py:42, :114-115).
+ * test() reads of every sample only its OWN domain's logits and the loss masks the other domain's, so the forward below encodes the live
+ * sequences only (live: amid_live_list_i32) and the head forms only those NI logits.
+ * amid_sas_seq_fwd_split_infer_f32 = amid_sas_seq_fwd_split_f32 in eval mode that stores nothing but xout (bit-identical rows; x0 = layer 0's
+ * input rows [2 B T, D]); D = 128, T <= 64.
+ * amid_eval_head_f32: a workgroup per sample b -- u = mean_t LN_last(x[own, b]) (ln_w / ln_b: host arrays of 2 device pointers, or both NULL),
+ * p[n] = predictModule(u, table[ids[b][n]]) for the NI candidates (ids [B, NI] int32, column 0 the positive: the item part of the step's index
+ * list, range-checked by amid_pack_indices*; the rows are gathered from the table inside the launch), and from them rank[b] = #{n >= 1 :
+ * p[n] > p[0] - fix_value}, rank_raw[b] (fix_value = 0), loss_part[b] = sum_n BCE(p[n], labels[b][n]) / (B NI) (labels optional, with
+ * loss_part); u [B, D], p [B, NI], rank, rank_raw optional outputs.  Same operations in the same order as amid_head_fwd_f32 +
+ * amid_positive_rank_f32 on a forward over both domains: the same bits.  D <= 128 (% 32), hid <= 64 (% 4). */
+int amid_sas_seq_fwd_split_infer_f32(int n_layers, const float* x0, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                     const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                     const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                     const float* const* w2, const float* const* b2, const unsigned char* tmq, float ln_eps, int B, int T,
+                                     int D, int H, const int* live, const void* w16x3, void* stream);
+int amid_eval_head_f32(const float* x, const float* const* ln_w, const float* const* ln_b, const float* table, const int* ids,
+                       const float* w1, const float* b1, const float* w2, const float* b2, const float* labels, const long long* domain_id,
+                       int B, int T, int NI, int D, int hid, float eps, float fix_value, float* u, float* p, int* rank, int* rank_raw,
+                       float* loss_part, void* stream);
+
 /* ---- BERT4Rec strips on bf16 pieces (round 5; csrc/bert_strip.hip MODE 3) ------------------------------------------------------------------
  * The strip launches of a TransformerBlock (model_seq.py:242-245 and its autograd) with every product as six bf16 piece pairs at fp32
  * accuracy -- what SASRec's strips run on since round 4.  Each 128 x 128 weight TILE a chain multiplies with is a three-plane fragment image
