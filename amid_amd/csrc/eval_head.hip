@@ -195,16 +195,16 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_head_fast_kernel(const Eval
     eval_user_half(a, u_s, au);
     __syncthreads();
     const float w2j = a.w2[4 * jb + (part & 3)], auj = au[4 * jb + (part & 3)], b2 = a.b2[0];
+    const int pj = part & 3;
     for (int r = 0; r < rounds; ++r) {
         stage(r);
         if (r + 1 < rounds) fetch(r + 1);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot is wave-private: the wave's own stores have landed
         const float* sl = slot0 + (size_t)(r & 1) * EV_BATCH * D;
-#pragma unroll 2
-        for (int i = 0; i < EV_BATCH; ++i) {
-            const int ii = r * EV_BATCH + i;
-            if (ii >= per_wave) break;                          // wave-uniform
+        float zs = 0.f;                                         // lane 48 + i: the logit of the round's i-th candidate
+#pragma unroll
+        for (int i = 0; i < EV_BATCH; ++i) {                    // (a round's tail past per_wave scores the last row again: never stored)
             const float* ir = sl + i * D;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -218,19 +218,24 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_head_fast_kernel(const Eval
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) acc[jj] = group_sum<8>(acc[jj]);
-            // lanes part < 4 of hidden block jb take hidden unit j = 4 jb + part; the logit's tree over j = 0 .. 31 in group_sum<32>'s order:
-            // pairs, quads (inside the lane quad), the two quads of an eight (the neighbouring hidden block: lanes +- 8 of a 16-lane row),
-            // then rows 0 + 1 and 2 + 3, then the halves
-            const int pj = part & 3;
+            // lanes part < 4 of hidden block jb take hidden unit j = 4 jb + part (lanes part >= 4 mirror them); the logit's tree over
+            // j = 0 .. 31 in group_sum<32>'s order: pairs, quads (inside the lane quad), the two quads of an eight (the neighbouring hidden
+            // block: the lane 8 further in the 16-lane row), then rows 0 + 1 and 2 + 3 (row_bcast15), then the halves (row_bcast31): the
+            // total lands in row 3
             const float ci = pj == 0 ? acc[0] : pj == 1 ? acc[1] : pj == 2 ? acc[2] : acc[3];
             float zp = fmaf(w2j, fmaxf(auj + ci, 0.f), 0.f);
             zp = zp + dpp_move<0xB1>(zp);                       // j ^ 1
             zp = zp + dpp_move<0x4E>(zp);                       // j ^ 2
-            zp = zp + dpp_move<0x128>(zp);                      // row_ror 8: the other hidden block of the row (lanes part < 4 pair with lanes part < 4)
-            const float r0 = lane_value(zp, 0), r1 = lane_value(zp, 16), r2 = lane_value(zp, 32), r3 = lane_value(zp, 48);
-            const float z = ((r0 + r1) + (r2 + r3)) + b2;
-            const float p = 1.0f / (1.0f + expf(-z));
-            if (lane == 0) p_s[w + 8 * ii] = p;
+            zp = zp + dpp_move<0x128>(zp);                      // row_ror 8: the other hidden block of the row
+            zp = zp + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zp), 0x142, 0xA, 0xF, false));   // rows 1, 3 += rows 0, 2
+            zp = zp + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zp), 0x143, 0xC, 0xF, false));   // row 3 += row 1
+            zs = lane == 48 + i ? zp : zs;
+        }
+        // the round's eight logits side by side: lane 48 + i finishes candidate i
+        const int ii = r * EV_BATCH + (lane - 48);
+        if (lane >= 48 && lane < 48 + EV_BATCH && ii < per_wave) {
+            const float z = zs + b2;
+            p_s[w + 8 * ii] = 1.0f / (1.0f + expf(-z));
         }
     }
     __syncthreads();
