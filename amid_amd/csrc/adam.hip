@@ -13,6 +13,8 @@
 #include "adam_replay.h"
 #include "live_list.h"
 #include "seg_spans.h"
+#include "tail_parts.h"
+#include "reduce_partials.h"
 
 namespace amid {
 
@@ -536,6 +538,188 @@ __global__ __launch_bounds__(256) void optimizer_gathered_kernel(float* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The gradient tail WITH the optimizer (round 6, amid_grad_tail_opt_f32): the folded step's last two launches -- amid_grad_tail_live_f32 and
+// amid_optimizer_step_spans_f32 -- as one.  Every producer of a gradient slice applies Adam to it on the spot:
+//   row workers     a half-wave per unique row u whose run lies inside one 64-entry chunk of the sorted list: the run's gradient rows added in
+//                   list order (what phase A's chunk wave did), uniq_grad[u] written, the row's Adam step;
+//   chunk blocks    the pieces of the runs that CROSS chunk borders (the pad row's ~180 chunks, a few others), one wave per chunk, stored with
+//                   agent scope; the block that takes the last ticket finds the crossing runs' owner chunks, adds every run's pieces in
+//                   spans_partials' order (the additions of the spans launch, the same bits) and applies the rows -- nobody waits, nobody spins;
+//   partial sums    the fixed-order sum of every dense partial (reduce_partials.h) with dense Adam on the finished slice;
+//   position rows   pos_sum_block with dense Adam on the slice;
+//   the rest        dense Adam on the slots whose gradients an earlier launch finished (the scorer's: sasrec_strip.hip's riders).
+// Same additions in the same order and the same Adam arithmetic as the two launches: the same bits (tests/test_gpu_timed_path.py).
+struct DenseAdamSink {
+    float* p; float* m; float* v; const float* g0; long long n; AdamCoef c; float gs;
+    __device__ __forceinline__ void quad(float* dst, float4 g) const {
+        const long long off = dst - g0;
+        if (off < 0 || off + 4 > n) return;                   // (a sum that is no parameter's gradient: the loss)
+        float4 pp = ld4(p + off), mm = ld4(m + off), vv = ld4(v + off);
+        adam_quad(pp, mm, vv, f4scale(g, gs), c);
+        st4(p + off, pp); st4(m + off, mm); st4(v + off, vv);
+    }
+    __device__ __forceinline__ void one(float* dst, float g) const {
+        const long long off = dst - g0;
+        if (off < 0 || off >= n) return;
+        adam_elem(p[off], m[off], v[off], g * gs, c);
+    }
+};
+
+struct TailOptArgs {
+    const float* grad_rows; const int* pos_sorted; const int* seg_off; const int* seg_of; int n_sorted;
+    float* uniq_grad; float* partial; int n_seg, nch; int* ticket;
+    const ReduceEntry* entries; const int* blk_off; int n_entries, n_red;
+    PosSum ps;
+    float* p; float* m; float* v; float* g; long long n_dense; long long left_lo, left_hi; int left_blocks;
+    float* table; float* m_tab; float* v_tab; int* last; const int* uniq_ids; const int* n_uniq; int row_blocks;
+    const StepState* st; float grad_scale;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void grad_tail_opt_kernel(const TailOptArgs a) {
+    constexpr int D = VEC * 64;
+    __shared__ IdleCoef tab[COEF_TAB];
+    const StepState st = *a.st;
+    const long long t = st.step;
+    int bid = blockIdx.x;
+    if (bid < a.n_seg) {
+        // ---- chunk blocks: the cut pieces, then a ticket; the last block finishes the crossing runs
+        segreduce_chunks_block<VEC, true>(a.grad_rows, a.pos_sorted, a.seg_of, a.n_sorted, nullptr, a.partial, bid, SEG_CHUNK, a.seg_off);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's agent-scope stores are acknowledged
+        __shared__ int s_last, s_n;
+        __shared__ int owners[256];
+        __shared__ float red[16][D];
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = (atomicAdd(a.ticket, 1) == a.n_seg - 1) ? 1 : 0;
+        __syncthreads();
+        if (!s_last) return;
+        if (threadIdx.x == 0) *a.ticket = 0;                        // (for the next launch: nobody of this one reads it again)
+        const AdamCoef cnow = adam_coef_now(st);
+        bool tab_filled = false;
+        for (int c0 = 0; c0 < a.nch; c0 += 256) {                   // owner chunks, 256 candidates a round
+            if (threadIdx.x == 0) s_n = 0;
+            __syncthreads();
+            {
+                const int c = c0 + (int)threadIdx.x;
+                int u, cl;
+                if (c < a.nch && spans_owner(c, a.seg_off, a.seg_of, a.n_sorted, SEG_CHUNK, u, cl) && a.seg_off[u + 1] - a.seg_off[u] > SEG_CHUNK)
+                    owners[atomicAdd(&s_n, 1)] = c;                 // (a crossing run of at most a chunk's length is a row worker's)
+            }
+            __syncthreads();
+            const int n_own = s_n;
+            for (int k = 0; k < n_own; ++k) {                       // (block-uniform; the runs are independent rows: any order)
+                const int c = owners[k];
+                int u = 0, c_last = 0;
+                spans_owner(c, a.seg_off, a.seg_of, a.n_sorted, SEG_CHUNK, u, c_last);
+                const long long r = a.uniq_ids[u];
+                const long long l = a.last[r];
+                const bool lag = (l > 0 && l < t - 1);             // (block-uniform: one row.  The pad row, the usual owner, never lags)
+                // (the row's parameter and moments requested in front of the pieces: D / 4 <= 64 quads, one per thread of the first wave)
+                const int cq0 = threadIdx.x;
+                float4 pp0 = make_float4(0.f, 0.f, 0.f, 0.f), mm0 = pp0, vv0 = pp0;
+                if (cq0 < D / 4) { const long long off = r * D + 4 * cq0; pp0 = ld4(a.table + off); mm0 = ld4(a.m_tab + off); vv0 = ld4(a.v_tab + off); }
+                spans_partials<VEC, 4, true>(red, c, c_last, a.partial);
+                if (lag && !tab_filled) { fill_coef_table(tab, st); tab_filled = true; }
+                __syncthreads();                                     // red is complete
+                for (int cq = threadIdx.x; cq < D / 4; cq += blockDim.x) {
+                    const float4 gs = make_float4(spans_total<VEC>(red, 4 * cq), spans_total<VEC>(red, 4 * cq + 1), spans_total<VEC>(red, 4 * cq + 2),
+                                                  spans_total<VEC>(red, 4 * cq + 3));
+                    st4(a.uniq_grad + (long long)u * D + 4 * cq, gs);
+                    const long long off = r * D + 4 * cq;
+                    float4 pp = pp0, mm = mm0, vv = vv0;
+                    if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
+                    adam_quad(pp, mm, vv, f4scale(gs, a.grad_scale), cnow);
+                    st4(a.table + off, pp); st4(a.m_tab + off, mm); st4(a.v_tab + off, vv);
+                }
+                if (threadIdx.x == 0) a.last[r] = (int)t;
+                __syncthreads();                                     // red is free
+            }
+        }
+        return;
+    }
+    bid -= a.n_seg;
+    DenseAdamSink sink;
+    sink.p = a.p; sink.m = a.m; sink.v = a.v; sink.g0 = a.g; sink.n = a.n_dense; sink.c = adam_coef_now(st); sink.gs = a.grad_scale;
+    if (bid < a.n_red) {
+        int lo = 0, hi = a.n_entries;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.blk_off[mid] <= bid) lo = mid; else hi = mid;
+        }
+        reduce_partials_block(a.entries[lo], bid - a.blk_off[lo], a.blk_off[lo + 1] - a.blk_off[lo], sink);
+        return;
+    }
+    bid -= a.n_red;
+    if (bid < 2 * a.ps.nblk) {
+        pos_sum_block(a.ps, D, bid / a.ps.nblk, bid % a.ps.nblk, a.ps.nblk, sink);
+        return;
+    }
+    bid -= 2 * a.ps.nblk;
+    // ---- the dense slots an earlier launch finished: [left_lo, left_hi) of the flat buffer
+    if (bid < a.left_blocks) {
+        for (long long i = a.left_lo + ((long long)bid * blockDim.x + threadIdx.x) * 4; i < a.left_hi; i += (long long)a.left_blocks * blockDim.x * 4) {
+            if (i + 4 <= a.left_hi) sink.quad(a.g + i, ld4(a.g + i));
+            else for (long long k = i; k < a.left_hi; ++k) sink.one(a.g + k, a.g[k]);
+        }
+        return;
+    }
+    bid -= a.left_blocks;
+    {
+        // ---- row workers: the runs inside one chunk, summed and applied by a half-wave each
+        const int U = *a.n_uniq;
+        if (bid * 8 >= U) return;
+        fill_coef_table(tab, st);
+        const AdamCoef cnow = adam_coef_now(st);
+        const int sub = threadIdx.x & 31;
+        constexpr int q = D >> 2;
+        for (int u = bid * 8 + (threadIdx.x >> 5); u < U; u += a.row_blocks * 8) {
+            const int s0 = a.seg_off[u], s1 = a.seg_off[u + 1];
+            if (s1 - s0 > SEG_CHUNK) continue;                     // longer than a chunk: the chunk blocks' pieces, the last chunk block's sum (above)
+            // a run of at most a chunk's length lies inside one chunk or crosses ONE border: [s0, mid) and [mid, s1)
+            const int mid = min(s1, (s0 / SEG_CHUNK + 1) * SEG_CHUNK);
+            const long long r = a.uniq_ids[u];
+            const long long l = a.last[r];
+            const bool lag = (l > 0 && l < t - 1);
+            for (int c = sub; c < q; c += 32) {
+                const long long off = r * D + 4 * c;
+                float4 pp = ld4(a.table + off), mm = ld4(a.m_tab + off), vv = ld4(a.v_tab + off);      // (in flight under the run's rows)
+                auto piece = [&](int e, const int e_end) {         // rows e .. e_end - 1 added in list order from zero (a chunk wave's sum), eight in flight
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (; e + 8 <= e_end; e += 8) {
+                        int ps_[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ps_[j] = a.pos_sorted[e + j];
+                        float4 rw[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rw[j] = ld4(a.grad_rows + (long long)ps_[j] * D + 4 * c);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc = f4add(acc, rw[j]);
+                    }
+                    for (; e < e_end; ++e) acc = f4add(acc, ld4(a.grad_rows + (long long)a.pos_sorted[e] * D + 4 * c));
+                    return acc;
+                };
+                float4 gs = piece(s0, mid);
+                if (mid < s1) {
+                    // the spans launch's additions for a run of two pieces: red[0] = 0 + piece 0, red[1] = 0 + piece 1, total = ((0 + red[0]) +
+                    // red[1]) + fourteen zeros (seg_spans.h spans_partials / spans_total) -- spelled out, so that the bits are the same
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 r0 = f4add(z, gs), r1 = f4add(z, piece(mid, s1));
+                    gs = f4add(f4add(z, r0), r1);
+                }
+                st4(a.uniq_grad + (long long)u * D + 4 * c, gs);
+                if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
+                adam_quad(pp, mm, vv, f4scale(gs, a.grad_scale), cnow);
+                st4(a.table + off, pp); st4(a.m_tab + off, mm); st4(a.v_tab + off, vv);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (sub == 0) a.last[r] = (int)t;
+        }
+        return;
+    }
+}
+
 }  // namespace amid
 
 using namespace amid;
@@ -736,6 +920,42 @@ extern "C" int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const
                                                                                           seg_off, seg_of, n_sorted, (const float*)workspace, nch);
     if (D == 64) { AMID_OPT_LAUNCH(1) } else if (D == 128) { AMID_OPT_LAUNCH(2) } else { AMID_OPT_LAUNCH(4) }
 #undef AMID_OPT_LAUNCH
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+
+// amid_grad_tail_live_f32 (hidg = NULL) + amid_optimizer_step_spans_f32 as ONE launch (grad_tail_opt_kernel above).  ticket: one int32 of
+// device memory, zero before the first call (the launch leaves it zero).  [left_lo, left_hi): the floats of the flat dense buffer whose
+// gradients are already final in g when the launch starts (16-byte aligned bounds; left_lo = left_hi: none); every other dense gradient
+// must be the dst of one of `entries` or a position row.  D = 64 / 128 / 256.
+extern "C" int amid_grad_tail_opt_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                                      void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off,
+                                      int total_blocks, const int* live, int B, int T, float* dpos0, float* dpos1, float* p, float* m, float* v,
+                                      float* g, long long n, long long left_lo, long long left_hi, float* table, float* m_tab, float* v_tab,
+                                      int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max, float grad_scale,
+                                      const void* step_state, int* ticket, void* stream) {
+    AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
+                   blk_off && total_blocks > 0 && live && B > 0 && T > 0 && dpos0 && dpos1);
+    AMID_CHECK_ARG(p && m && v && g && n > 0 && table && m_tab && v_tab && last && uniq_ids && n_uniq && n_uniq_max > 0 && step_state && ticket);
+    AMID_CHECK_ARG(left_lo >= 0 && left_lo <= left_hi && left_hi <= n && (left_lo & 3) == 0);
+    AMID_CHECK_ARG(((((unsigned long long)dpos0) | ((unsigned long long)dpos1) | ((unsigned long long)grad_rows) | ((unsigned long long)p) |
+                     ((unsigned long long)m) | ((unsigned long long)v) | ((unsigned long long)g)) & 15) == 0);
+    if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
+    TailOptArgs a = {};
+    a.grad_rows = grad_rows; a.pos_sorted = pos_sorted; a.seg_off = seg_off; a.seg_of = seg_of; a.n_sorted = n_idx;
+    a.uniq_grad = uniq_grad; a.partial = (float*)workspace;
+    a.nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK; a.n_seg = (a.nch + 3) / 4; a.ticket = ticket;
+    a.entries = (const ReduceEntry*)entries_dev; a.blk_off = blk_off; a.n_entries = n_entries; a.n_red = total_blocks;
+    a.ps.rows = grad_rows; a.ps.live = live; a.ps.B = B; a.ps.T = T; a.ps.dst[0] = dpos0; a.ps.dst[1] = dpos1; a.ps.nblk = (T * D + 127) / 128;
+    a.p = p; a.m = m; a.v = v; a.g = g; a.n_dense = n; a.left_lo = left_lo; a.left_hi = left_hi;
+    a.left_blocks = (int)((left_hi - left_lo + 1023) / 1024);
+    a.table = table; a.m_tab = m_tab; a.v_tab = v_tab; a.last = last; a.uniq_ids = uniq_ids; a.n_uniq = n_uniq; a.row_blocks = rows_grid(n_uniq_max);
+    a.st = (const StepState*)step_state; a.grad_scale = grad_scale;
+    const int grid = a.n_seg + a.row_blocks + a.n_red + 2 * a.ps.nblk + a.left_blocks;
+#define AMID_TO_LAUNCH(VEC) grad_tail_opt_kernel<VEC><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    if (D == 64) { AMID_TO_LAUNCH(1) } else if (D == 128) { AMID_TO_LAUNCH(2) } else { AMID_TO_LAUNCH(4) }
+#undef AMID_TO_LAUNCH
     AMID_LAUNCH_CHECK();
     return AMID_OK;
 }

@@ -40,9 +40,15 @@ __device__ __forceinline__ AdamCoef adam_coef(const StepState& st, double b1pow,
 }
 __device__ __forceinline__ AdamCoef adam_coef_now(const StepState& st) { return adam_coef(st, pow_step(st.beta1, st.step), pow_step(st.beta2, st.step)); }
 
+// (contraction off for the step's own expressions: torch's addcmul_ / addcdiv_ are unfused, and every kernel that inlines this step must
+// produce the same bits)
+#pragma clang fp contract(off)
 __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, const AdamCoef& c) {
     m = __fmaf_rn(c.w1, __fsub_rn(g, m), m);                                   // exp_avg.lerp_(grad, 1 - beta1)
-    v = __fadd_rn(__fmul_rn(v, c.beta2), __fmul_rn(__fmul_rn(c.w2, g), g));    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2): three products and a sum, each rounded -- written with the language's own
+    // operators so that this file's `contract(off)` governs them (the __fmul_rn / __fadd_rn wrappers are plain `*` / `+` compiled where THEY
+    // are defined, under the default contraction: inlined into two different kernels they came out as an fma in one and not in the other)
+    v = (v * c.beta2) + ((c.w2 * g) * g);
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), c.bc2_sqrt), c.eps); // (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps)
     p = __fadd_rn(p, __fdiv_rn(__fmul_rn(c.neg_step_size, m), denom));          // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
@@ -52,6 +58,8 @@ __device__ __forceinline__ void adam_quad(float4& p, float4& m, float4& v, float
     adam_elem(p.z, m.z, v.z, g.z, c);
     adam_elem(p.w, m.w, v.w, g.w, c);
 }
+
+#pragma clang fp contract(fast)
 
 // ---- the zero-gradient step of the lazy replay ------------------------------------------------------------------------------------------
 // Same recurrences for m and v (exact: one fma / one multiply); the parameter's increment through the hardware sqrt / reciprocal

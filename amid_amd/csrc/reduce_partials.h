@@ -5,11 +5,17 @@
 namespace amid {
 
 struct ReduceEntry { const float* src; float* dst; long long stride; int n_part; int count; };
+// (sink: what else happens to a finished slice -- nothing, or the folded optimizer's Adam on the spot: tail_parts.h NoSink, adam.hip)
+struct ReduceNoSink {
+    __device__ __forceinline__ void quad(float*, float4) const {}
+    __device__ __forceinline__ void one(float*, float) const {}
+};
 
 // 256 threads = 32 consecutive elements (or float4s) x 8 partial groups; group pg sums partials pg, pg+8, ... with four (eight when
 // there are many partials) independent loads in flight, then the eight group sums are added in group order (fixed order => reproducible).
 // (bx, nbx): this block's index / the number of blocks along the element axis of entry `en`.
-__device__ __forceinline__ void reduce_partials_block(const ReduceEntry en, int bx, int nbx) {
+template <class Sink = ReduceNoSink>
+__device__ __forceinline__ void reduce_partials_block(const ReduceEntry en, int bx, int nbx, const Sink sink = Sink()) {
     __shared__ float4 red[8][33];
     const int el = threadIdx.x & 31, pg = threadIdx.x >> 5;
     // entries whose rows are whole, aligned float4s (every weight / bias matrix) move 16 bytes per lane: a wave covers two
@@ -29,6 +35,7 @@ __device__ __forceinline__ void reduce_partials_block(const ReduceEntry en, int 
                 for (int j = 0; j < 8; ++j) s4 = f4add(s4, r[j]);
             }
             st4(en.dst + e, s4);
+            sink.quad(en.dst + e, s4);
         }
         return;
     }
@@ -60,6 +67,7 @@ __device__ __forceinline__ void reduce_partials_block(const ReduceEntry en, int 
 #pragma unroll
                 for (int g = 1; g < 8; ++g) t = f4add(t, red[g][el]);
                 st4(en.dst + e, t);
+                sink.quad(en.dst + e, t);
             }
             __syncthreads();
         }
@@ -93,6 +101,7 @@ __device__ __forceinline__ void reduce_partials_block(const ReduceEntry en, int 
 #pragma unroll
             for (int g = 1; g < 8; ++g) t += reds[g * 33 + el];
             en.dst[e] = t;
+            sink.one(en.dst + e, t);
         }
         __syncthreads();
     }

@@ -59,7 +59,13 @@ __device__ __forceinline__ bool spans_owner(int c, const int* __restrict__ seg_o
 // lanes-of-rows: virtual wave k adds chunks c + k, c + k + 16, ... in order into red[k]; the caller adds red[0 .. 15] in order
 // (spans_total).  NW real waves share the sixteen (16: one each; 4: four each, one after the other) -- the same additions in the same
 // order either way, hence the same bits whichever launch finishes a run.
-template <int VEC, int NW>
+// AGENT: the partial rows were written by other workgroups of THIS launch (tail_parts.h store_row_agent): read with the same scope.
+template <int VEC> __device__ __forceinline__ RowVec<VEC> load_row_agent(const float* __restrict__ base, long long row, int D, int lane);
+template <int VEC, bool AGENT>
+__device__ __forceinline__ RowVec<VEC> load_partial_row(const float* __restrict__ base, long long row, int D, int lane) {
+    if constexpr (AGENT) return load_row_agent<VEC>(base, row, D, lane); else return load_row<VEC>(base, row, D, lane);
+}
+template <int VEC, int NW, bool AGENT = false>
 __device__ __forceinline__ void spans_partials(float (*red)[VEC * 64], int c, int c_last, const float* __restrict__ partial) {
     static_assert(16 % NW == 0, "virtual waves per real wave");
     constexpr int PER = 16 / NW;                      // this wave's virtual waves w, w + NW, ...: walked SIDE BY SIDE (their loads in flight together)
@@ -73,25 +79,51 @@ __device__ __forceinline__ void spans_partials(float (*red)[VEC * 64], int c, in
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[j].v[k] = 0.f;
     }
-    for (bool any = true; any;) {                     // four rows per virtual wave and round, while it has four left ...
+    // (AGENT -- one workgroup finishes the run behind every other's back, on the launch's critical path: eight rows per virtual wave and round)
+    constexpr int RPR = (AGENT && VEC <= 2) ? 8 : 4;
+    for (bool any = true; any;) {                     // RPR rows per virtual wave and round, while it has as many left ...
         any = false;
-        RowVec<VEC> r[PER][4];
+        RowVec<VEC> r[PER][RPR];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            if (cc[j] + 48 <= c_last) {               // (wave-uniform)
+            if (cc[j] + 16 * (RPR - 1) <= c_last) {   // (wave-uniform)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const int ci = cc[j] + 16 * i; r[j][i] = load_row<VEC>(partial, (long long)ci * 2 + (ci == c ? 1 : 0), D, lane); }
+                for (int i = 0; i < RPR; ++i) { const int ci = cc[j] + 16 * i; r[j][i] = load_partial_row<VEC, AGENT>(partial, (long long)ci * 2 + (ci == c ? 1 : 0), D, lane); }
             }
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            if (cc[j] + 48 <= c_last) {
+            if (cc[j] + 16 * (RPR - 1) <= c_last) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < RPR; ++i)
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[j].v[k] += r[j][i].v[k];
-                cc[j] += 64;
+                cc[j] += 16 * RPR;
                 any = true;
+            }
+        }
+    }
+    if constexpr (RPR == 8) {                         // ... then four at a time while it has four left ...
+        for (bool any = true; any;) {
+            any = false;
+            RowVec<VEC> r[PER][4];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (cc[j] + 48 <= c_last) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const int ci = cc[j] + 16 * i; r[j][i] = load_partial_row<VEC, AGENT>(partial, (long long)ci * 2 + (ci == c ? 1 : 0), D, lane); }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (cc[j] + 48 <= c_last) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[j].v[k] += r[j][i].v[k];
+                    cc[j] += 64;
+                    any = true;
+                }
             }
         }
     }
@@ -100,7 +132,7 @@ __device__ __forceinline__ void spans_partials(float (*red)[VEC * 64], int c, in
         RowVec<VEC> r[PER];
 #pragma unroll
         for (int j = 0; j < PER; ++j)
-            if (cc[j] <= c_last) r[j] = load_row<VEC>(partial, (long long)cc[j] * 2 + (cc[j] == c ? 1 : 0), D, lane);
+            if (cc[j] <= c_last) r[j] = load_partial_row<VEC, AGENT>(partial, (long long)cc[j] * 2 + (cc[j] == c ? 1 : 0), D, lane);
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             if (cc[j] <= c_last) {

@@ -12,65 +12,10 @@
 #include "common.h"
 #include "reduce_partials.h"
 #include "seg_spans.h"
+#include "tail_parts.h"
 #include "scorer_sum.h"
 
 namespace amid {
-
-// phase A: one wave per 64-entry chunk of the sorted list.  Lane l keeps (position, run index) of entry e0 + l; rows
-// are fetched SEG_BATCH at a time whatever runs they belong to (independent loads), then folded in order, flushing at
-// every run change: control flow is wave-uniform (run indices come from readlane-style shuffles), no global load
-// sits on the per-run critical path.
-template <int VEC>
-__device__ __forceinline__ void segreduce_chunks_block(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
-                                                       const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,
-                                                       float* __restrict__ partial, int block, int chunk = SEG_CHUNK) {
-    const int D = VEC * 64;
-    const int lane = lane_id();
-    const int c = block * 4 + wave_id();
-    const int e0 = c * chunk;
-    if (e0 >= n) return;
-    const int cnt = min(chunk, n - e0);
-    const bool valid = lane < cnt;
-    const int mypos = valid ? pos_sorted[e0 + lane] : 0;
-    const int mysg = valid ? seg_of[e0 + lane] : -1;
-    // lane indices below are wave-uniform: v_readlane (a few cycles) instead of a ds_bpermute round trip per row
-    const int first_sg = __builtin_amdgcn_readlane(mysg, 0), last_sg = __builtin_amdgcn_readlane(mysg, __builtin_amdgcn_readfirstlane(cnt - 1));
-    const bool starts_before = (e0 > 0) && (seg_of[e0 - 1] == first_sg);
-    const bool continues_after = (e0 + cnt < n) && (seg_of[e0 + cnt] == last_sg);
-    RowVec<VEC> acc;
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
-    int cur = first_sg;
-    auto flush = [&](int sg) {
-        const bool head_cut = (sg == first_sg) && starts_before;
-        const bool tail_cut = (sg == last_sg) && continues_after;
-        if (!head_cut && !tail_cut) store_row<VEC>(uniq_grad, sg, D, lane, acc);
-        else store_row<VEC>(partial, (long long)c * 2 + (head_cut ? 0 : 1), D, lane, acc);
-    };
-    for (int i = 0; i < cnt; i += SEG_BATCH) {
-        RowVec<VEC> r[SEG_BATCH];
-#pragma unroll
-        for (int j = 0; j < SEG_BATCH; ++j) {
-            const int src = min(i + j, cnt - 1);
-            r[j] = load_row<VEC>(grad_rows, __builtin_amdgcn_readlane(mypos, __builtin_amdgcn_readfirstlane(src)), D, lane);
-        }
-#pragma unroll
-        for (int j = 0; j < SEG_BATCH; ++j) {
-            if (i + j < cnt) {
-                const int sg = __builtin_amdgcn_readlane(mysg, __builtin_amdgcn_readfirstlane(i + j));
-                if (sg != cur) {
-                    flush(cur);
-                    cur = sg;
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
-                }
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc.v[k] += r[j].v[k];
-            }
-        }
-    }
-    flush(cur);
-}
 
 template <int VEC>
 __global__ __launch_bounds__(256) void segreduce_chunks_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
@@ -102,52 +47,8 @@ __global__ __launch_bounds__(256) void grad_tail_kernel(const float* __restrict_
 }
 
 // ---- the gradient tail of the live-sequence train step (amid_grad_tail_live_f32) ----------------------------------------------------------
-// grad_tail_kernel's two roles over the step's COMPACT sorted list, plus a third: the position rows' gradients.  The embedding layer's
-// element-wise backward ran on the last strip launch (sasrec_strip.hip StripQkvBwdArgs::emb_tmq), so dP_g[t] = sum over the LIVE sequences
-// b of domain g of grad_rows[(g B + b) T + t] is a fixed-order sum over rows that are already final: 256 threads = 32 float4 columns x 8
-// groups of sequences (group p adds live sequences p, p + 8, ... in order, eight loads in flight), the eight group sums added in order.
-// The dead sequences' rows are neither written nor read by anybody.  Phase B of the segment reduce rides in the optimizer launch
-// (adam.hip optimizer_step_spans_kernel).
-struct PosSum { const float* rows; const int* live; int B, T; float* dst[2]; int nblk; };
-
-__device__ __forceinline__ void pos_sum_block(const PosSum& ps, int D, int g, int bx, int nbx) {
-    __shared__ float4 pred[8][33];
-    const int el = threadIdx.x & 31, pg = threadIdx.x >> 5;
-    const int n0 = ps.live[ps.B];
-    const int s0 = g ? n0 : 0, n = g ? ps.B - n0 : n0;
-    const int count = ps.T * D;
-    const long long seq = (long long)ps.T * D;
-    const float* __restrict__ base = ps.rows + (long long)g * ps.B * seq;
-    const int* __restrict__ lv = ps.live + s0;
-    for (int e0 = bx * 128; e0 < count; e0 += nbx * 128) {        // block-uniform
-        const int e = e0 + 4 * el;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < count) {
-            int k = pg;
-            for (; k + 56 < n; k += 64) {
-                int b[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) b[j] = lv[k + 8 * j];
-                float4 r[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = ld4(base + b[j] * seq + e);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s = f4add(s, r[j]);
-            }
-            for (; k < n; k += 8) s = f4add(s, ld4(base + lv[k] * seq + e));
-        }
-        pred[pg][el] = s;
-        __syncthreads();
-        if (pg == 0 && e < count) {
-            float4 t = pred[0][el];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) t = f4add(t, pred[q][el]);
-            st4(ps.dst[g] + e, t);
-        }
-        __syncthreads();
-    }
-}
-
+// grad_tail_kernel's two roles over the step's COMPACT sorted list, plus a third: the position rows' gradients (tail_parts.h pos_sum_block).
+// Phase B of the segment reduce rides in the optimizer launch (adam.hip optimizer_step_spans_kernel).
 template <int VEC>
 __global__ __launch_bounds__(256) void grad_tail_live_kernel(const float* __restrict__ grad_rows, const int* __restrict__ pos_sorted,
                                                              const int* __restrict__ seg_of, int n, float* __restrict__ uniq_grad,

@@ -390,6 +390,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # phase in the weight-gradient launch, the position rows' gradients in the gradient tail (amid_grad_tail_live_f32) and the segment
     # reduce's second phase in the optimizer launch (amid_optimizer_step_spans_f32): 12 launches instead of 15.  False: round 4's sequence
     # (tests compare the two).
+    FUSED_OPT = True             # the folded step's optimizer inside its gradient tail: ten launches (round 6; False: eleven)
     FUSED_SPANS = True           # every single-GPU train step: the segment reduce's second phase inside the optimizer launch (round 5)
     FUSED_TAIL = True
 
@@ -1141,6 +1142,22 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 L.call("amid_grad_tail_live_dp_f32", *head, pl.uniq_grad.data_ptr(), *mid, None, None, 0, 0, None, None, None, 0, None, s)
             pl.spans_done = True
             return
+        pl.opt_done = False
+        if getattr(pl, "tail2", False) and self.FUSED_OPT and self.table_m is not None and not self.dr:
+            # the folded step's tail AND its optimizer as one launch (round 6): every producer of a gradient slice applies Adam on the spot
+            ent_t, n_ent_t, blk_t = self._tail2_table(pl)
+            fp = self.dense
+            if not hasattr(pl, "tail_ticket"):
+                pl.tail_ticket = torch.zeros(16, dtype=torch.int32, device=self.device)
+            left_lo = fp.slots["predictModule.fc.0.weight"][0]          # the scorer's slots (the flat buffer's tail): summed by the strip riders
+            L.call("amid_grad_tail_opt_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_compact,
+                   self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), ent_t.data_ptr(), n_ent_t, blk_t[0].data_ptr(), blk_t[1],
+                   pl.live.data_ptr(), shp.B, shp.Tenc, fp.ptr("sac1.pos_emb.weight", fp.grad), fp.ptr("sac2.pos_emb.weight", fp.grad),
+                   fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel, left_lo, fp.numel,
+                   self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), pl.uniq_ids.data_ptr(),
+                   pl.n_uniq.data_ptr(), pl.n_compact, self.grad_scale, self.step_state.data_ptr(), pl.tail_ticket.data_ptr(), s)
+            pl.opt_done = True
+            return
         if getattr(pl, "tail2", False):
             ent_t, n_ent_t, blk_t = self._tail2_table(pl)
             fp = self.dense
@@ -1179,6 +1196,11 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         else:
             ids, rows, nu = sparse
             cap = ids.numel()
+        if getattr(pl, "opt_done", False):          # the gradient tail applied the step (amid_grad_tail_opt_f32)
+            pl.opt_done = False
+            if sparse is not None:
+                raise RuntimeError("the gradient tail already applied this step's local gradients")
+            return
         owed = int(getattr(pl, "spans_owed", 0))
         pl.spans_owed = 0
         t2 = getattr(pl, "tail2", False) and not getattr(pl, "spans_done", False)

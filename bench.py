@@ -288,6 +288,7 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_sas_seq_fwd_split_lnstat_f32": ("seqn_fwd_px_kernel",), "amid_sas_seq_fwd_split_lnstat_head_f32": ("seqn_fwd_px_head_kernel",), "amid_sas_wgrad_rows_sort_ln_f32": "sas_wgrad_split_kernel",
     "amid_sas_strip_qkv_bwd_sort_scorer_f32": "strip_qkv_bwd_kernelILi128ELb1", "amid_head_fwd_bwd_own_vec_f32": "head_fwd_bwd_kernel",
     "amid_grad_tail_live_f32": "grad_tail_live_kernel", "amid_grad_tail_nospans_f32": "grad_tail_kernel", "amid_optimizer_step_spans_f32": "optimizer_step_spans_kernel",
+    "amid_grad_tail_opt_f32": "grad_tail_opt_kernel",
     "amid_bert_strip_qkv_fwd_pro_p3_f32": "bert_strip_qkv_fwd_kernel", "amid_bert_strip_oproj_ffn_fwd_p3_f32#0": "bert_strip_oproj_ffn_fwd_kernelILb1",
     "amid_bert_strip_oproj_ffn_fwd_p3_f32#1": "bert_strip_oproj_ffn_fwd_kernelILb0", "amid_bert_strip_ffn_bwd_p3_f32": "bert_strip_ffn_bwd_kernel",
     "amid_bert_strip_qkv_bwd_p3_f32#0": "bert_strip_qkv_bwd_kernelILb1", "amid_bert_strip_qkv_bwd_p3_f32#1": "bert_strip_qkv_bwd_kernelILb0",
@@ -791,6 +792,9 @@ def main():
             if getattr(pl, "tail2", False):      # the folded step's tail: compact list, the position rows summed from the rows, no second phase
                 work["amid_grad_tail_live_f32"] = ("hbm", work["amid_embgrad_segreduce_live"][1] + getattr(pl, "red_bytes_t", red_bytes)
                                                    + Bw * T * D * 4 + 2 * T * D * 4)
+                # ... with the optimizer folded in (round 6): + the rows' and the dense parameters' Adam traffic (p, m, v read and written)
+                work["amid_grad_tail_opt_f32"] = ("hbm", work["amid_grad_tail_live_f32"][1] + work["amid_optimizer_step_spans_f32"][1]
+                                                  + eng.dense.numel * 4 * 6)
         total_ms = 0.0
         for name, v in durs.items():
             name = name[:-4] if name.endswith(("_rt3", "_rt4", "_rt5")) else name        # the 48- / 64- / 80-row builds of the row-tile kernels

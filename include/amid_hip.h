@@ -890,6 +890,18 @@ int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const float* g, 
                                   const void* step_state, const int* seg_off, const int* seg_of, int n_sorted, const void* workspace,
                                   void* stream);
 
+/* amid_grad_tail_live_f32 (hidg = NULL) and amid_optimizer_step_spans_f32 as ONE launch (round 6): every producer of a gradient slice applies
+ * Adam to it on the spot -- the partial sums and the position rows their dense slices, a half-wave per unique row the rows whose runs lie
+ * inside a 64-entry chunk, and the chunk block that takes the LAST ticket the runs that cross chunks (their pieces travel with agent scope;
+ * nobody waits).  Replaces: optimizer.zero_grad(); loss.backward(); optimizer.step() 's tail, train_sr.py:213-215.  The same additions in the
+ * same order and the same Adam arithmetic as the two launches: the same bits.  ticket: one int32, zero before the first call (left zero).
+ * [left_lo, left_hi): floats of the flat dense buffer whose gradients are final before the launch (the scorer's, summed by the strip riders). */
+int amid_grad_tail_opt_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                           void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off, int total_blocks,
+                           const int* live, int B, int T, float* dpos0, float* dpos1, float* p, float* m, float* v, float* g, long long n,
+                           long long left_lo, long long left_hi, float* table, float* m_tab, float* v_tab, int* last, const int* uniq_ids,
+                           const int* n_uniq, int n_uniq_max, float grad_scale, const void* step_state, int* ticket, void* stream);
+
 /* ---- evaluation (round 6): test(), train_sr.py:31-128 ------------------------------------------------------------------------------------------
  * replaces, for the plain SASRec model: model(u, i, neg, seq_d1, seq_d2, ..., False) under no_grad (train_sr.py:55-56) + the masked BCE
  * (:63-64) + choose_predict / get_sample_scores' rank of column 0 (utils.py:21-40, :296-297; fix_value: train_sr.py:42, :114-115).

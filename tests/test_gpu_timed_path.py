@@ -458,6 +458,76 @@ def test_head_on_the_forward_workgroups_is_bit_identical_to_its_own_launch(Bn, T
         assert torch.equal(b["params"][k], want), (k, rel_l2(b["params"][k], want))
 
 
+@pytest.mark.parametrize("Bn,T,split,crowd", [(256, 50, "mixed", False), (200, 64, "one0", False), (37, 33, "all0", False), (300, 40, "mixed", True),
+                                               (1100, 50, "mixed", True)])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_optimizer_in_the_gradient_tail_is_bit_identical_to_its_own_launch(Bn, T, split, crowd, use_graph):
+    """SasrecEngine.FUSED_OPT on / off over the same pool: amid_grad_tail_opt_f32 makes the sums of amid_grad_tail_live_f32 and applies the
+    Adam steps of amid_optimizer_step_spans_f32 -- the same additions in the same order, the same update arithmetic -- in ONE launch (the
+    chunk-crossing runs by the chunk block that takes the last ticket, their pieces read with agent scope), so every gradient of the first
+    step and the parameters after K steps (rows that lag and come back: a three-batch pool walked K = 12 times round under graph replay)
+    agree BIT FOR BIT, step after step.  crowd: ids drawn from a few rows, so that many runs cross chunk borders (the last block's owner list
+    is long), beside the pad row's."""
+    from amid_amd._lib import lib
+    D, hid, n_items, K = 128, 32, 3000, 12
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=15 + Bn)
+    batches = [split_batch(Bn, T, n_items, seed=700 + t, split=split) for t in range(3)]
+    if crowd:
+        for b in batches:
+            for k in ("seq_d1", "seq_d2"):
+                b[k] = torch.where(b[k] == n_items - 1, b[k], 1 + b[k] % 23)
+    out = {}
+    for on in (False, True):
+        eng = make_engine(P, T, lr=1e-3, seed=79)
+        eng.FUSED_OPT = on
+        pl = eng.plan(Bn, T, 2, need_grad=True)
+        packed = []
+        for b in batches:
+            cu = {k: v.cuda() for k, v in b.items()}
+            packed.append(eng.pack_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"]))
+        eng.set_input_pool(pl, torch.stack(packed))
+        names = []
+        L = lib()
+        orig = L.call
+        L.call = lambda name, *a: (names.append(name), orig(name, *a))[1]        # (a spy on the C-ABI calls of this one step)
+        try:
+            eng.enqueue_train_step(pl)
+            eng.sync()
+        finally:
+            del L.call
+        assert pl.tail2
+        assert ("amid_grad_tail_opt_f32" in names) == on and ("amid_optimizer_step_spans_f32" in names) == (not on), names
+        rec = dict(n_calls=len(names), loss=[float(pl.loss.item())], table=dense_table_grad(eng, pl),
+                   **{name: eng.dense.view(name, eng.dense.grad).clone() for name in eng.dense.slots})
+        rec["after1"] = {k: v.clone() for k, v in eng.state_dict().items()}
+        if use_graph:
+            eng.capture_train_step(pl)
+        for t in range(1, K):
+            if use_graph:
+                eng.replay_train_step(pl)
+            else:
+                eng.enqueue_train_step(pl)
+            eng.sync()
+            rec["loss"].append(float(pl.loss.item()))
+        eng.check_index_error(pl)
+        assert int(pl.tail_ticket[0].item()) == 0 if on else True
+        eng.flush_table()
+        eng.sync()
+        rec["params"] = {k: v.cpu().clone() for k, v in eng.state_dict().items()}
+        out[on] = rec
+    a, b = out[False], out[True]
+    assert b["n_calls"] == a["n_calls"] - 1
+    assert a["loss"] == b["loss"], (a["loss"], b["loss"])
+    for name, want in a.items():
+        if name in ("n_calls", "loss", "params", "after1"):
+            continue
+        assert torch.equal(b[name], want), (name, relmax(b[name], want))
+    for k, want in a["after1"].items():
+        assert torch.equal(b["after1"][k], want), ("after one step", k)
+    for k, want in a["params"].items():
+        assert torch.equal(b["params"][k], want), (k, rel_l2(b["params"][k], want))
+
+
 def test_timed_path_real_tokenised_batches_vs_oracle():
     """BASELINE.json configs[1] on the DATA bench.py times, not only its shape: the first two batches of cloth_sport_train75 as the
     reference's own DualDomainSeqDataset tokenised them (tests/golden/tok_cloth_sport_train75.npz: its left-padding, its pad id 447 411,
