@@ -567,6 +567,22 @@ struct DenseAdamSink {
     }
 };
 
+// the data-parallel form (grad_tail_opt_kernel<VEC, false>): nothing is applied -- a finished dense slice is ALSO written into this rank's
+// exchange chunk (dst == nullptr: the caller all-reduces the dense gradient itself), the rows only go to uniq_grad (which points into the chunk)
+struct DenseShipSink {
+    const float* g0; long long n; float* dst;
+    __device__ __forceinline__ void quad(float* d, float4 g) const {
+        const long long off = d - g0;
+        if (dst == nullptr || off < 0 || off + 4 > n) return;
+        st4(dst + off, g);
+    }
+    __device__ __forceinline__ void one(float* d, float g) const {
+        const long long off = d - g0;
+        if (dst == nullptr || off < 0 || off >= n) return;
+        dst[off] = g;
+    }
+};
+
 struct TailOptArgs {
     const float* grad_rows; const int* pos_sorted; const int* seg_off; const int* seg_of; int n_sorted;
     float* uniq_grad; float* partial; int n_seg, nch; int* ticket;
@@ -575,13 +591,19 @@ struct TailOptArgs {
     float* p; float* m; float* v; float* g; long long n_dense; long long left_lo, left_hi; int left_blocks;
     float* table; float* m_tab; float* v_tab; int* last; const int* uniq_ids; const int* n_uniq; int row_blocks;
     const StepState* st; float grad_scale;
+    // ship mode: the exchange chunk's id part and dense part
+    float* dense_dst; int* out_ids; int n_out, pad_id, id_blocks; int* err;
 };
 
-template <int VEC>
+// APPLY: Adam on the spot (the single-GPU step).  !APPLY: the data-parallel step's local half -- the same sums, shipped instead of applied
+// (amid_grad_tail_live_dp_f32): rows to uniq_grad = the exchange chunk's row part, dense slices also to its dense part, and id_blocks more
+// workgroups pad the unique ids into its id part.
+template <int VEC, bool APPLY>
 __global__ __launch_bounds__(256) void grad_tail_opt_kernel(const TailOptArgs a) {
     constexpr int D = VEC * 64;
     __shared__ IdleCoef tab[COEF_TAB];
-    const StepState st = *a.st;
+    StepState st = {};
+    if constexpr (APPLY) st = *a.st;
     const long long t = st.step;
     int bid = blockIdx.x;
     if (bid < a.n_seg) {
@@ -596,7 +618,8 @@ __global__ __launch_bounds__(256) void grad_tail_opt_kernel(const TailOptArgs a)
         __syncthreads();
         if (!s_last) return;
         if (threadIdx.x == 0) *a.ticket = 0;                        // (for the next launch: nobody of this one reads it again)
-        const AdamCoef cnow = adam_coef_now(st);
+        AdamCoef cnow = {};
+        if constexpr (APPLY) cnow = adam_coef_now(st);
         bool tab_filled = false;
         for (int c0 = 0; c0 < a.nch; c0 += 256) {                   // owner chunks, 256 candidates a round
             if (threadIdx.x == 0) s_n = 0;
@@ -613,13 +636,15 @@ __global__ __launch_bounds__(256) void grad_tail_opt_kernel(const TailOptArgs a)
                 const int c = owners[k];
                 int u = 0, c_last = 0;
                 spans_owner(c, a.seg_off, a.seg_of, a.n_sorted, SEG_CHUNK, u, c_last);
-                const long long r = a.uniq_ids[u];
-                const long long l = a.last[r];
-                const bool lag = (l > 0 && l < t - 1);             // (block-uniform: one row.  The pad row, the usual owner, never lags)
+                long long r = 0, l = 0;
+                if constexpr (APPLY) { r = a.uniq_ids[u]; l = a.last[r]; }
+                const bool lag = APPLY && (l > 0 && l < t - 1);    // (block-uniform: one row.  The pad row, the usual owner, never lags)
                 // (the row's parameter and moments requested in front of the pieces: D / 4 <= 64 quads, one per thread of the first wave)
                 const int cq0 = threadIdx.x;
                 float4 pp0 = make_float4(0.f, 0.f, 0.f, 0.f), mm0 = pp0, vv0 = pp0;
-                if (cq0 < D / 4) { const long long off = r * D + 4 * cq0; pp0 = ld4(a.table + off); mm0 = ld4(a.m_tab + off); vv0 = ld4(a.v_tab + off); }
+                if constexpr (APPLY) {
+                    if (cq0 < D / 4) { const long long off = r * D + 4 * cq0; pp0 = ld4(a.table + off); mm0 = ld4(a.m_tab + off); vv0 = ld4(a.v_tab + off); }
+                }
                 spans_partials<VEC, 4, true>(red, c, c_last, a.partial);
                 if (lag && !tab_filled) { fill_coef_table(tab, st); tab_filled = true; }
                 __syncthreads();                                     // red is complete
@@ -627,21 +652,31 @@ __global__ __launch_bounds__(256) void grad_tail_opt_kernel(const TailOptArgs a)
                     const float4 gs = make_float4(spans_total<VEC>(red, 4 * cq), spans_total<VEC>(red, 4 * cq + 1), spans_total<VEC>(red, 4 * cq + 2),
                                                   spans_total<VEC>(red, 4 * cq + 3));
                     st4(a.uniq_grad + (long long)u * D + 4 * cq, gs);
-                    const long long off = r * D + 4 * cq;
-                    float4 pp = pp0, mm = mm0, vv = vv0;
-                    if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
-                    adam_quad(pp, mm, vv, f4scale(gs, a.grad_scale), cnow);
-                    st4(a.table + off, pp); st4(a.m_tab + off, mm); st4(a.v_tab + off, vv);
+                    if constexpr (APPLY) {
+                        const long long off = r * D + 4 * cq;
+                        float4 pp = pp0, mm = mm0, vv = vv0;
+                        if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
+                        adam_quad(pp, mm, vv, f4scale(gs, a.grad_scale), cnow);
+                        st4(a.table + off, pp); st4(a.m_tab + off, mm); st4(a.v_tab + off, vv);
+                    }
                 }
-                if (threadIdx.x == 0) a.last[r] = (int)t;
+                if constexpr (APPLY) { if (threadIdx.x == 0) a.last[r] = (int)t; }
                 __syncthreads();                                     // red is free
             }
         }
         return;
     }
     bid -= a.n_seg;
-    DenseAdamSink sink;
-    sink.p = a.p; sink.m = a.m; sink.v = a.v; sink.g0 = a.g; sink.n = a.n_dense; sink.c = adam_coef_now(st); sink.gs = a.grad_scale;
+    auto make_sink = [&]() {
+        if constexpr (APPLY) {
+            DenseAdamSink k;
+            k.p = a.p; k.m = a.m; k.v = a.v; k.g0 = a.g; k.n = a.n_dense; k.c = adam_coef_now(st); k.gs = a.grad_scale;
+            return k;
+        } else {
+            return DenseShipSink{a.g, a.n_dense, a.dense_dst};
+        }
+    };
+    const auto sink = make_sink();
     if (bid < a.n_red) {
         int lo = 0, hi = a.n_entries;
         while (hi - lo > 1) {
@@ -666,12 +701,23 @@ __global__ __launch_bounds__(256) void grad_tail_opt_kernel(const TailOptArgs a)
         return;
     }
     bid -= a.left_blocks;
+    if constexpr (!APPLY) {
+        // ---- the chunk's id part: the unique ids padded to n_out (segreduce.hip segreduce_spans_pack_kernel's role)
+        if (bid < a.id_blocks) {
+            const int rr = bid * 256 + (int)threadIdx.x;
+            if (rr < a.n_out) a.out_ids[rr] = rr < *a.n_uniq ? a.uniq_ids[rr] : a.pad_id;
+            // more unique rows than the caller's bound: rows were written past the chunk's row part -- the step is corrupt; say so
+            if (rr == 0 && a.err != nullptr && *a.n_uniq > a.n_out) atomicOr(a.err, AMID_FLAG_UMAX_EXCEEDED);
+            return;
+        }
+        bid -= a.id_blocks;
+    }
     {
         // ---- row workers: the runs inside one chunk, summed and applied by a half-wave each
         const int U = *a.n_uniq;
         if (bid * 8 >= U) return;
-        fill_coef_table(tab, st);
-        const AdamCoef cnow = adam_coef_now(st);
+        AdamCoef cnow = {};
+        if constexpr (APPLY) { fill_coef_table(tab, st); cnow = adam_coef_now(st); }
         const int sub = threadIdx.x & 31;
         constexpr int q = D >> 2;
         for (int u = bid * 8 + (threadIdx.x >> 5); u < U; u += a.row_blocks * 8) {
@@ -679,12 +725,13 @@ __global__ __launch_bounds__(256) void grad_tail_opt_kernel(const TailOptArgs a)
             if (s1 - s0 > SEG_CHUNK) continue;                     // longer than a chunk: the chunk blocks' pieces, the last chunk block's sum (above)
             // a run of at most a chunk's length lies inside one chunk or crosses ONE border: [s0, mid) and [mid, s1)
             const int mid = min(s1, (s0 / SEG_CHUNK + 1) * SEG_CHUNK);
-            const long long r = a.uniq_ids[u];
-            const long long l = a.last[r];
-            const bool lag = (l > 0 && l < t - 1);
+            long long r = 0, l = 0;
+            if constexpr (APPLY) { r = a.uniq_ids[u]; l = a.last[r]; }
+            const bool lag = APPLY && (l > 0 && l < t - 1);
             for (int c = sub; c < q; c += 32) {
                 const long long off = r * D + 4 * c;
-                float4 pp = ld4(a.table + off), mm = ld4(a.m_tab + off), vv = ld4(a.v_tab + off);      // (in flight under the run's rows)
+                float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), mm = pp, vv = pp;
+                if constexpr (APPLY) { pp = ld4(a.table + off); mm = ld4(a.m_tab + off); vv = ld4(a.v_tab + off); }      // (in flight under the run's rows)
                 auto piece = [&](int e, const int e_end) {         // rows e .. e_end - 1 added in list order from zero (a chunk wave's sum), eight in flight
                     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     for (; e + 8 <= e_end; e += 8) {
@@ -709,12 +756,16 @@ __global__ __launch_bounds__(256) void grad_tail_opt_kernel(const TailOptArgs a)
                     gs = f4add(f4add(z, r0), r1);
                 }
                 st4(a.uniq_grad + (long long)u * D + 4 * c, gs);
-                if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
-                adam_quad(pp, mm, vv, f4scale(gs, a.grad_scale), cnow);
-                st4(a.table + off, pp); st4(a.m_tab + off, mm); st4(a.v_tab + off, vv);
+                if constexpr (APPLY) {
+                    if (lag) replay_quad(pp, mm, vv, l + 1, t - 1, st, tab);
+                    adam_quad(pp, mm, vv, f4scale(gs, a.grad_scale), cnow);
+                    st4(a.table + off, pp); st4(a.m_tab + off, mm); st4(a.v_tab + off, vv);
+                }
             }
-            __builtin_amdgcn_wave_barrier();
-            if (sub == 0) a.last[r] = (int)t;
+            if constexpr (APPLY) {
+                __builtin_amdgcn_wave_barrier();
+                if (sub == 0) a.last[r] = (int)t;
+            }
         }
         return;
     }
@@ -929,31 +980,68 @@ extern "C" int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const
 // device memory, zero before the first call (the launch leaves it zero).  [left_lo, left_hi): the floats of the flat dense buffer whose
 // gradients are already final in g when the launch starts (16-byte aligned bounds; left_lo = left_hi: none); every other dense gradient
 // must be the dst of one of `entries` or a position row.  D = 64 / 128 / 256.
+static int tail_opt_common(TailOptArgs& a, const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                           void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off, int total_blocks,
+                           const int* live, int B, int T, float* dpos0, float* dpos1, float* g, long long n, long long left_lo, long long left_hi,
+                           const int* uniq_ids, const int* n_uniq, int n_uniq_max, int* ticket) {
+    AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
+                   blk_off && total_blocks > 0 && live && B > 0 && T > 0 && dpos0 && dpos1);
+    AMID_CHECK_ARG(g && n > 0 && uniq_ids && n_uniq && n_uniq_max > 0 && ticket);
+    AMID_CHECK_ARG(left_lo >= 0 && left_lo <= left_hi && left_hi <= n && (left_lo & 3) == 0);
+    AMID_CHECK_ARG(((((unsigned long long)dpos0) | ((unsigned long long)dpos1) | ((unsigned long long)grad_rows) | ((unsigned long long)g)) & 15) == 0);
+    if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
+    a.grad_rows = grad_rows; a.pos_sorted = pos_sorted; a.seg_off = seg_off; a.seg_of = seg_of; a.n_sorted = n_idx;
+    a.uniq_grad = uniq_grad; a.partial = (float*)workspace;
+    a.nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK; a.n_seg = (a.nch + 3) / 4; a.ticket = ticket;
+    a.entries = (const ReduceEntry*)entries_dev; a.blk_off = blk_off; a.n_entries = n_entries; a.n_red = total_blocks;
+    a.ps.rows = grad_rows; a.ps.live = live; a.ps.B = B; a.ps.T = T; a.ps.dst[0] = dpos0; a.ps.dst[1] = dpos1; a.ps.nblk = (T * D + 127) / 128;
+    a.g = g; a.n_dense = n; a.left_lo = left_lo; a.left_hi = left_hi;
+    a.left_blocks = (int)((left_hi - left_lo + 1023) / 1024);
+    a.uniq_ids = uniq_ids; a.n_uniq = n_uniq; a.row_blocks = rows_grid(n_uniq_max);
+    return AMID_OK;
+}
+
 extern "C" int amid_grad_tail_opt_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
                                       void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off,
                                       int total_blocks, const int* live, int B, int T, float* dpos0, float* dpos1, float* p, float* m, float* v,
                                       float* g, long long n, long long left_lo, long long left_hi, float* table, float* m_tab, float* v_tab,
                                       int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max, float grad_scale,
                                       const void* step_state, int* ticket, void* stream) {
-    AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
-                   blk_off && total_blocks > 0 && live && B > 0 && T > 0 && dpos0 && dpos1);
-    AMID_CHECK_ARG(p && m && v && g && n > 0 && table && m_tab && v_tab && last && uniq_ids && n_uniq && n_uniq_max > 0 && step_state && ticket);
-    AMID_CHECK_ARG(left_lo >= 0 && left_lo <= left_hi && left_hi <= n && (left_lo & 3) == 0);
-    AMID_CHECK_ARG(((((unsigned long long)dpos0) | ((unsigned long long)dpos1) | ((unsigned long long)grad_rows) | ((unsigned long long)p) |
-                     ((unsigned long long)m) | ((unsigned long long)v) | ((unsigned long long)g)) & 15) == 0);
-    if (!(D == 64 || D == 128 || D == 256)) return AMID_ERR_UNSUPPORTED;
+    AMID_CHECK_ARG(p && m && v && table && m_tab && v_tab && last && step_state);
+    AMID_CHECK_ARG(((((unsigned long long)p) | ((unsigned long long)m) | ((unsigned long long)v)) & 15) == 0);
     TailOptArgs a = {};
-    a.grad_rows = grad_rows; a.pos_sorted = pos_sorted; a.seg_off = seg_off; a.seg_of = seg_of; a.n_sorted = n_idx;
-    a.uniq_grad = uniq_grad; a.partial = (float*)workspace;
-    a.nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK; a.n_seg = (a.nch + 3) / 4; a.ticket = ticket;
-    a.entries = (const ReduceEntry*)entries_dev; a.blk_off = blk_off; a.n_entries = n_entries; a.n_red = total_blocks;
-    a.ps.rows = grad_rows; a.ps.live = live; a.ps.B = B; a.ps.T = T; a.ps.dst[0] = dpos0; a.ps.dst[1] = dpos1; a.ps.nblk = (T * D + 127) / 128;
-    a.p = p; a.m = m; a.v = v; a.g = g; a.n_dense = n; a.left_lo = left_lo; a.left_hi = left_hi;
-    a.left_blocks = (int)((left_hi - left_lo + 1023) / 1024);
-    a.table = table; a.m_tab = m_tab; a.v_tab = v_tab; a.last = last; a.uniq_ids = uniq_ids; a.n_uniq = n_uniq; a.row_blocks = rows_grid(n_uniq_max);
+    if (int e = tail_opt_common(a, grad_rows, pos_sorted, seg_off, seg_of, n_idx, D, workspace, uniq_grad, entries_dev, n_entries, blk_off, total_blocks,
+                                live, B, T, dpos0, dpos1, g, n, left_lo, left_hi, uniq_ids, n_uniq, n_uniq_max, ticket)) return e;
+    a.p = p; a.m = m; a.v = v;
+    a.table = table; a.m_tab = m_tab; a.v_tab = v_tab; a.last = last;
     a.st = (const StepState*)step_state; a.grad_scale = grad_scale;
     const int grid = a.n_seg + a.row_blocks + a.n_red + 2 * a.ps.nblk + a.left_blocks;
-#define AMID_TO_LAUNCH(VEC) grad_tail_opt_kernel<VEC><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+#define AMID_TO_LAUNCH(VEC) grad_tail_opt_kernel<VEC, true><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    if (D == 64) { AMID_TO_LAUNCH(1) } else if (D == 128) { AMID_TO_LAUNCH(2) } else { AMID_TO_LAUNCH(4) }
+#undef AMID_TO_LAUNCH
+    AMID_LAUNCH_CHECK();
+    return AMID_OK;
+}
+
+// The data-parallel form, ONE launch (round 6; it was amid_grad_tail_live_f32's launch + a spans / packing launch): the same sums, shipped
+// instead of applied -- uniq_grad (complete when the launch ends) points into this rank's exchange chunk or, n_out = 0, at the plan's own
+// buffer; n_out > 0: out_ids [n_out] <- the unique ids padded with pad_id, dense_dst (optional) <- every dense gradient this launch finishes
+// and the floats [left_lo, left_hi) of g (the caller keeps the slot padding of dense_dst zero), err_flag gets AMID_FLAG_UMAX_EXCEEDED when
+// *n_uniq > n_out.  g = the flat dense gradient buffer the entries' dst point into (n floats).
+extern "C" int amid_grad_tail_live_dp1_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                                           void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off,
+                                           int total_blocks, const int* live, int B, int T, float* dpos0, float* dpos1, float* g, long long n,
+                                           long long left_lo, long long left_hi, const int* uniq_ids, const int* n_uniq, int n_uniq_max,
+                                           int n_out, int pad_id, int* out_ids, float* dense_dst, int* err_flag, int* ticket, void* stream) {
+    AMID_CHECK_ARG(n_out >= 0 && n_out <= n_idx && (n_out == 0 || out_ids) && (dense_dst == nullptr || n_out > 0) &&
+                   (((unsigned long long)dense_dst) & 15) == 0);
+    TailOptArgs a = {};
+    if (int e = tail_opt_common(a, grad_rows, pos_sorted, seg_off, seg_of, n_idx, D, workspace, uniq_grad, entries_dev, n_entries, blk_off, total_blocks,
+                                live, B, T, dpos0, dpos1, g, n, left_lo, left_hi, uniq_ids, n_uniq, n_uniq_max, ticket)) return e;
+    a.dense_dst = dense_dst; a.out_ids = out_ids; a.n_out = n_out; a.pad_id = pad_id; a.id_blocks = (n_out + 255) / 256; a.err = err_flag;
+    if (dense_dst == nullptr) a.left_blocks = 0;
+    const int grid = a.n_seg + a.row_blocks + a.n_red + 2 * a.ps.nblk + a.left_blocks + a.id_blocks;
+#define AMID_TO_LAUNCH(VEC) grad_tail_opt_kernel<VEC, false><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     if (D == 64) { AMID_TO_LAUNCH(1) } else if (D == 128) { AMID_TO_LAUNCH(2) } else { AMID_TO_LAUNCH(4) }
 #undef AMID_TO_LAUNCH
     AMID_LAUNCH_CHECK();

@@ -1130,7 +1130,22 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                     pl.seg_ws.data_ptr())
             mid = (ent_t.data_ptr(), n_ent_t, blk_t[0].data_ptr(), blk_t[1], pl.live.data_ptr(), shp.B, shp.Tenc,
                    fp.ptr("sac1.pos_emb.weight", fp.grad), fp.ptr("sac2.pos_emb.weight", fp.grad))
-            if pk is not None:
+            if self.FUSED_OPT:        # ... all of it as ONE launch (amid_grad_tail_opt_f32's workgroups, shipping instead of applying)
+                if not hasattr(pl, "tail_ticket"):
+                    pl.tail_ticket = torch.zeros(16, dtype=torch.int32, device=self.device)
+                left_lo = fp.slots["predictModule.fc.0.weight"][0]      # the scorer's gradients: final before this launch (the strip riders)
+                dense = (fp.grad.data_ptr(), fp.numel, left_lo, fp.numel, pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), pl.n_compact)
+                if pk is not None:
+                    from .dist import packed_rows
+                    send, umax, with_dense = pk
+                    id_rows, rows = packed_rows(umax, self.D)
+                    L.call("amid_grad_tail_live_dp1_f32", *head, send.data_ptr() + 4 * id_rows * self.D, *mid, *dense, umax, self.n_rows,
+                           send.data_ptr(), send.data_ptr() + 4 * rows * self.D if with_dense else None, pl.err.data_ptr(),
+                           pl.tail_ticket.data_ptr(), s)
+                else:
+                    L.call("amid_grad_tail_live_dp1_f32", *head, pl.uniq_grad.data_ptr(), *mid, *dense, 0, 0, None, None, None,
+                           pl.tail_ticket.data_ptr(), s)
+            elif pk is not None:
                 from .dist import packed_rows
                 send, umax, with_dense = pk
                 id_rows, rows = packed_rows(umax, self.D)

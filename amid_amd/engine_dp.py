@@ -36,6 +36,7 @@ class DataParallelMixin:
     # rank whatever the world size) -- what BASELINE.json's north_star words ("RCCL all-reduce of dense parameter grads").  Both are
     # bit-identical across replicas; bench.py --dense-exchange measures either.
     DENSE_EXCHANGE = "gather"
+    DP_GRAPH_B = False           # the optimizer over the gathered chunks as a replayed one-kernel graph (True) or a plain launch (round 6)
 
     def train_step_dp(self, pl: SasrecPlan, exchange, use_graph: bool = False, umax: Optional[int] = None, dense: Optional[str] = None) -> None:
         """One data-parallel step: local grads -> dense all-reduce + ONE sparse all-gather -> merge -> Adam.
@@ -96,7 +97,10 @@ class DataParallelMixin:
                 exchange.all_gather_packed(pair[2], pair[3])
                 if dense == "allreduce":
                     exchange.all_reduce_dense(self.dense.grad)
-                L.call("amid_graph_launch", pair[1], self.s)
+                if self.DP_GRAPH_B:
+                    L.call("amid_graph_launch", pair[1], self.s)
+                else:          # graph B is ONE kernel: launched as such (a replayed graph starts ~10 us behind the collective, a plain launch less)
+                    self.enqueue_optimizer_gathered(exchange.backend, pair[3], exchange.world, umax, dense_in_chunk=(dense == "gather"))
                 return
             if use_graph and not getattr(self, "_dp_mid_collectives", False):
                 L.call("amid_graph_launch", pl.graphs_local[self._graph_key()], self.s)
@@ -121,6 +125,12 @@ class DataParallelMixin:
         be.gather_buffer(exchange.world, umax, dense=dgrad)   # capacity errors are raised here, not in the middle of a stream capture
         if in_chunk:
             be.prepare_dense(exchange.world, umax, self.dense.grad)      # device tables are built here, not under capture
+            # the one-launch tail writes the dense part of the chunk slice by slice as it finishes them: the 16-byte padding between the
+            # slots is never written and must read as zero on every rank (the receivers sum the whole part) -- cleared here, once per bound
+            from .dist import packed_rows
+            with torch.cuda.stream(self.stream):
+                be.send[packed_rows(umax, self.D)[1] * self.D: be.chunk_rows(umax, self.dense.grad) * self.D].zero_()
+            self.sync()
         graphs = []
         segs = None
 

@@ -902,6 +902,16 @@ int amid_grad_tail_opt_f32(const float* grad_rows, const int* pos_sorted, const 
                            long long left_lo, long long left_hi, float* table, float* m_tab, float* v_tab, int* last, const int* uniq_ids,
                            const int* n_uniq, int n_uniq_max, float grad_scale, const void* step_state, int* ticket, void* stream);
 
+/* amid_grad_tail_live_dp_f32 as ONE launch (amid_grad_tail_opt_f32's workgroups, shipping instead of applying; no reference analogue:
+ * train_sr.py:473): uniq_grad complete at the end of the launch; n_out > 0: out_ids [n_out] <- the unique ids padded with pad_id, dense_dst
+ * (optional, 16-byte aligned, laid out like g) <- every dense gradient the launch finishes + the floats [left_lo, left_hi) of g; err_flag gets
+ * AMID_FLAG_UMAX_EXCEEDED when *n_uniq > n_out.  ticket: one int32, zero before the first call (left zero).  The same bits as the two launches. */
+int amid_grad_tail_live_dp1_f32(const float* grad_rows, const int* pos_sorted, const int* seg_off, const int* seg_of, int n_idx, int D,
+                                void* workspace, float* uniq_grad, const void* entries_dev, int n_entries, const int* blk_off, int total_blocks,
+                                const int* live, int B, int T, float* dpos0, float* dpos1, float* g, long long n, long long left_lo,
+                                long long left_hi, const int* uniq_ids, const int* n_uniq, int n_uniq_max, int n_out, int pad_id, int* out_ids,
+                                float* dense_dst, int* err_flag, int* ticket, void* stream);
+
 /* ---- evaluation (round 6): test(), train_sr.py:31-128 ------------------------------------------------------------------------------------------
  * replaces, for the plain SASRec model: model(u, i, neg, seq_d1, seq_d2, ..., False) under no_grad (train_sr.py:55-56) + the masked BCE
  * (:63-64) + choose_predict / get_sample_scores' rank of column 0 (utils.py:21-40, :296-297; fix_value: train_sr.py:42, :114-115).

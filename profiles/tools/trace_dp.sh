@@ -9,8 +9,9 @@ import csv
 rows = list(csv.DictReader(open("gpurun_out/trdp/t_kernel_trace.csv")))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # steps start with the lazy-Adam catch-up (first kernel of the local-gradients graph); take one from the fixed-bound phase
-starts = [i for i, r in enumerate(rows) if "catchup_pos" in r["Kernel_Name"]]
-i0, i1 = starts[330], starts[331]
+# (round 6: the folded step's first kernel is the step head)
+starts = [i for i, r in enumerate(rows) if "step_head_kernel" in r["Kernel_Name"]]
+i0, i1 = starts[430], starts[431]
 t0 = int(rows[i0]["Start_Timestamp"])
 print("step span us", (int(rows[i1]["Start_Timestamp"]) - t0) / 1e3, "kernels", i1 - i0)
 prev = t0

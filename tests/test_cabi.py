@@ -80,6 +80,9 @@ def test_round6_entry_points_refuse_bad_arguments_without_a_gpu():
     f = L._fn["amid_grad_tail_opt_f32"]
     assert f(*[null] * 4, 64, 128, null, null, null, 1, null, 1, null, 4, 50, null, null, null, null, null, null, 100, 0, 100, null, null, null,
              null, null, null, 64, 1.0, null, null, null) == -1
+    f = L._fn["amid_grad_tail_live_dp1_f32"]
+    assert f(*[null] * 4, 64, 128, null, null, null, 1, null, 1, null, 4, 50, null, null, null, 100, 0, 100, null, null, 64, 0, 0, null, null, null,
+             null, null) == -1
     # the inference forward: no piece images ; the evaluation head: no table
     assert L._fn["amid_sas_seq_fwd_split_infer_f32"](2, null, null, *[null] * 12, null, 1e-8, 4, 40, 128, 8, null, null, null) == -1
     assert L._fn["amid_eval_head_f32"](*[null] * 11, 4, 40, 100, 128, 32, 1e-8, 1e-7, null, null, null, null, null, null) == -1
