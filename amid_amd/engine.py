@@ -1324,8 +1324,10 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             pl.ev_u = torch.zeros(B, self.D, dtype=torch.float32, device=self.device)
         return pl.ev_out
 
-    def enqueue_eval(self, pl: SasrecPlan, fix_value: float, with_loss: bool = True, want_scores: bool = False) -> None:
-        """One test() batch from the plan's static inputs (load_batch / load_packed) to pl.ev_rank / ev_rank_raw / ev_loss_part."""
+    def enqueue_eval(self, pl: SasrecPlan, fix_value: float, with_loss: bool = True, want_scores: bool = False, build_images: bool = True) -> None:
+        """One test() batch from the plan's static inputs (load_batch / load_packed) to pl.ev_rank / ev_rank_raw / ev_loss_part.
+        build_images=False: the forward's weight images are current (eval_epoch builds them once for all its batches: the weights do not
+        change inside an evaluation)."""
         if not self.eval_fused_ok(pl):
             raise ValueError("enqueue_eval: this model / shape evaluates through enqueue_forward (eval_fused_ok)")
         L, s, shp, D = lib(), self.s, pl.shape, self.D
@@ -1338,11 +1340,13 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         pos = (fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"))
         split = self._fwd_on_pieces(pl, B, T)
         pl.w16_written = pl.wT16x3_written = False
-        if split:          # the gather's extra workgroups write the weights' three-plane images (the forward's operands)
+        if split and build_images:          # the gather's extra workgroups write the weights' three-plane images (the forward's operands)
             src, w16 = self._w16_images(3)
             L.call("amid_embed_fwd_w16_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), *pos, B, T, D, 0, pl.xg.data_ptr(), pl.tmq.data_ptr(),
                    st, 0, SASREC_P_DROP, lf, None, None, src, 24, 3, w16.data_ptr(), None, s)
         else:
+            if split:
+                src, w16 = self._w16_images(3)
             L.call("amid_embed_fwd_live_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), *pos, B, T, D, 0, pl.xg.data_ptr(), pl.tmq.data_ptr(),
                    st, 0, SASREC_P_DROP, lf, s)
         fam = lambda fmt: ptr_array([fp.ptr(fmt.format(d=d, l=l)) for l in (0, 1) for d in (1, 2)])      # noqa: E731  [layer][domain]
@@ -1378,14 +1382,14 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                pl.ev_rank_raw.data_ptr(), pl.ev_loss_part.data_ptr() if with_loss else None, s)
 
     def capture_eval(self, pl: SasrecPlan, fix_value: float, with_loss: bool = True) -> None:
-        """The evaluation batch as a hipGraph over the plan's static inputs (weights are read at replay time: the graph stays valid across
-        training steps; it is keyed by fix_value / with_loss)."""
+        """The evaluation batch as a hipGraph over the plan's static inputs (parameters are read at replay time and the forward's weight
+        images are rebuilt by eval_epoch before its first replay: the graph stays valid across training steps; keyed by fix_value / with_loss)."""
         L = lib()
-        self.enqueue_eval(pl, fix_value, with_loss)           # warm-up outside capture (dynamic-LDS attributes, code objects)
+        self.enqueue_eval(pl, fix_value, with_loss)           # warm-up outside capture (dynamic-LDS attributes, code objects; builds the images)
         self.sync()
         L.call("amid_graph_capture_begin", self.s)
         try:
-            self.enqueue_eval(pl, fix_value, with_loss)
+            self.enqueue_eval(pl, fix_value, with_loss, build_images=False)
         finally:
             out = ctypes.c_void_p()
             L.call("amid_graph_capture_end", self.s, ctypes.byref(out))
@@ -1409,12 +1413,15 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self.capture_eval(pl, fix_value, with_loss)
         L = lib()
         with torch.cuda.stream(self.stream):
+            if self._fwd_on_pieces(pl, pl.shape.B, pl.shape.Tenc):      # this evaluation's weight images, once (the batches' launches only read them)
+                src, w16 = self._w16_images(3)
+                L.call("amid_sas_weights_bf16_planes", src, 24, self.D, 0, 3, w16.data_ptr(), self.s)
             for i in range(packed.shape[0]):
                 pl.in_pack.copy_(packed[i], non_blocking=True)
                 if use_graph:
                     L.call("amid_graph_launch", pl.eval_graphs[key], self.s)
                 else:
-                    self.enqueue_eval(pl, fix_value, with_loss)
+                    self.enqueue_eval(pl, fix_value, with_loss, build_images=False)
                 out[i].copy_(self._eval_out(pl), non_blocking=True)
         return out
 

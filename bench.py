@@ -439,7 +439,7 @@ def eval_throughput(eng, device, Bw, T, n_batches=64):
     try:
         for i in range(n_prof):
             eng.load_packed(pl, packed[i])
-            eng.enqueue_eval(pl, 1e-7)
+            eng.enqueue_eval(pl, 1e-7, build_images=False)      # (as the replayed graph: the weight images were built once, by eval_epoch)
             eng.sync()
         durs = L.timer.collect(L)
     finally:
@@ -450,7 +450,7 @@ def eval_throughput(eng, device, Bw, T, n_batches=64):
         # the candidates' rows + their ids, the own sequences' last-layer rows; scores / ranks / loss stay in the workgroup
         "amid_eval_head_f32": ("hbm", Bw * NI * (D * 4 + 4) + Bw * T * D * 4 + Bw * NI * 4),
         "amid_sas_seq_fwd_split_infer_f32": ("mfma16x6", 12 * gl + 2 * 4.0 * T * T * (D // 8) * Bw * 8),
-        "amid_embed_fwd_w16_f32": ("hbm", Bw * T * (8 + 2 * D * 4) + Bw * T * (D // 4) + 24 * D * D * 10),
+        "amid_embed_fwd_live_f32": ("hbm", Bw * T * (8 + 2 * D * 4) + Bw * T * (D // 4)),
         "amid_pack_indices_live": ("hbm", (2 * Bw * T + Bw * NI) * 12),
     }
     kernels = {}
