@@ -174,12 +174,12 @@ def train(model, train_batches, args, val_batches, exchange=None):
             model.end_epoch_pool()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        logger.info(f"epoch {epoch}: {n_samples} samples in {dt:.2f} s = {n_samples / dt:.0f} samples/s (loader included)")
+        logger.info(f"epoch {epoch}: {n_samples} samples in {dt:.4f} s = {n_samples / dt:.0f} samples/s (loader included)")
         t1 = time.perf_counter()
         res = test(model, args, val_batches)
         torch.cuda.synchronize()
         n_eval = len(val_batches) * args.bs
-        logger.info(f"epoch {epoch}: evaluated {n_eval} samples x {args.neg_nums + 1} candidates in {time.perf_counter() - t1:.2f} s "
+        logger.info(f"epoch {epoch}: evaluated {n_eval} samples x {args.neg_nums + 1} candidates in {time.perf_counter() - t1:.4f} s "
                     f"= {n_eval / (time.perf_counter() - t1):.0f} samples/s")
         names = ("HR@1", "NDCG@1", "HR@5", "NDCG@5", "HR@10", "NDCG@10", "MRR")
         msg = [f"Epoch: {epoch}/{args.epoch} \tTrain Loss: {stats.loss:.4f} \tVal loss: {res['loss']:.4f}"]
