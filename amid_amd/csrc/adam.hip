@@ -15,6 +15,7 @@
 #include "seg_spans.h"
 #include "tail_parts.h"
 #include "reduce_partials.h"
+#include "weights_image.h"
 
 namespace amid {
 
@@ -169,7 +170,14 @@ struct StepHeadArgs {
     int npk;
 };
 
-__global__ __launch_bounds__(256) void step_head_kernel(const StepHeadArgs a, const SortRider rd) {
+// W16: the step's weight images (the forward's and the backward strips' operands: 144 planes at the headline shape) written by the launch's LAST
+// workgroups -- the gather K1's riders, for a step whose gather is the forward's prologue (amid_step_head_w16_f32)
+template <bool W16>
+__global__ __launch_bounds__(256) void step_head_kernel(const StepHeadArgs a, const SortRider rd, const W16Rider wr) {
+    if constexpr (W16) {
+        const int first = (int)gridDim.x - wr.n * wr.per;
+        if ((int)blockIdx.x >= first) { w16_rider_block(wr, blockIdx.x - first); return; }
+    }
     const long long t_pre = a.st->step_done;
     long long which = (t_pre + a.phase) % a.n_pool;
     if (which < 0) which += a.n_pool;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256) void step_head_kernel(const StepHeadArgs a, co
 #ifdef AMID_EXP_HEAD_NO_CATCHUP     // (variant libraries only, profiles/tools/build_variant.sh: what the launch costs without this role -- 13.1 of 16.6 us)
     return;
 #endif
-    const int bid = blockIdx.x - nrb - a.npk, nbk = gridDim.x - nrb - a.npk;
+    const int bid = blockIdx.x - nrb - a.npk, nbk = (int)gridDim.x - nrb - a.npk - (W16 ? wr.n * wr.per : 0);
     __shared__ IdleCoef tab[COEF_TAB];
     __shared__ int any_lag;
     StepState st = *a.st;
@@ -910,9 +918,10 @@ extern "C" int amid_lazy_adam_catchup_positions_sort_f32(float* table, float* m,
 // own-domain sequence, then the items), the lazy-Adam catch-up of the compact list's rows, phase 1 of the sort plan built on
 // (idx_c, row_c) (amid_sort_plan_pack), and the step counter's bump (StepState::step; the caller's next launch must be an embed_fwd
 // launch, which re-joins StepState::step_done).  replaces: amid_pack_indices_pool_live + amid_lazy_adam_catchup_positions_sort_f32.
-extern "C" int amid_step_head_f32(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack, int in_words,
+static int step_head(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack, int in_words,
                                   int B, int T, int n_neg, long long n_rows, int* idx_all, int* idx_c, int* row_c, int* live, int* err_flag,
-                                  float* table, float* m, float* v, int* last, int D, void* step_state, const void* sort_plan, void* stream) {
+                                  float* table, float* m, float* v, int* last, int D, void* step_state, const void* sort_plan, void* stream,
+                                  const W16Rider* wrp) {
     AMID_CHECK_ARG(pool && n_pool > 0 && in_pack && idx_all && idx_c && row_c && live && err_flag && table && m && v && last && step_state &&
                    B > 0 && T > 0 && n_neg > 0 && D > 0 && (D % 4) == 0);
     AMID_CHECK_ARG(in_words >= B + B * n_neg + 2 * B * T + B);
@@ -945,9 +954,40 @@ extern "C" int amid_step_head_f32(const long long* pool, long long pool_stride, 
     const long long room = resident - rider_blocks_host(rd) - npk;
     if (room >= 256 && blocks > room) blocks = room;
     if (blocks > 16384) blocks = 16384;
-    step_head_kernel<<<rider_blocks_host(rd) + npk + (int)blocks, 256, 0, (hipStream_t)stream>>>(a, rd);
+    if (wrp != nullptr) {
+        const long long room2 = room - (long long)wrp->n * wrp->per;      // (the riders are resident workgroups too)
+        if (room2 >= 256 && blocks > room2) blocks = room2;
+        step_head_kernel<true><<<rider_blocks_host(rd) + npk + (int)blocks + wrp->n * wrp->per, 256, 0, (hipStream_t)stream>>>(a, rd, *wrp);
+    } else {
+        step_head_kernel<false><<<rider_blocks_host(rd) + npk + (int)blocks, 256, 0, (hipStream_t)stream>>>(a, rd, W16Rider{});
+    }
     AMID_LAUNCH_CHECK();
     return AMID_OK;
+}
+extern "C" int amid_step_head_f32(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack, int in_words,
+                                  int B, int T, int n_neg, long long n_rows, int* idx_all, int* idx_c, int* row_c, int* live, int* err_flag,
+                                  float* table, float* m, float* v, int* last, int D, void* step_state, const void* sort_plan, void* stream) {
+    return step_head(pool, pool_stride, n_pool, phase, in_pack, in_words, B, T, n_neg, n_rows, idx_all, idx_c, row_c, live, err_flag, table, m, v, last,
+                     D, step_state, sort_plan, stream, nullptr);
+}
+// amid_step_head_f32 + the step's weight images by extra workgroups (amid_embed_fwd_w16_f32's riders: w_src = n_w square [D][D] fp32 weights,
+// w16_dst [n_w][planes][D][D] bf16 their fragment images, w16t_dst (optional) the same of their transposes): for a step whose gather is the
+// prologue of its forward (amid_sas_seq_fwd_gather_*_f32), which re-joins StepState::step_done.  D = 128.
+extern "C" int amid_step_head_w16_f32(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack, int in_words,
+                                      int B, int T, int n_neg, long long n_rows, int* idx_all, int* idx_c, int* row_c, int* live, int* err_flag,
+                                      float* table, float* m, float* v, int* last, int D, void* step_state, const void* sort_plan,
+                                      const float* const* w_src, int n_w, int w_planes, void* w16_dst, void* w16t_dst, void* stream) {
+    AMID_CHECK_ARG(w_src && n_w > 0 && (w_planes == 1 || w_planes == 3) && w16_dst && D == 128 && n_w * (w16t_dst ? 2 : 1) <= W16_MAX);
+    W16Rider wr = {};
+    for (int i = 0; i < n_w; ++i) { AMID_CHECK_ARG(w_src[i]); wr.src[i] = w_src[i]; wr.ld[i] = (unsigned short)D; wr.tr[i] = 0; }
+    wr.n = wr.n_fwd = n_w;
+    if (w16t_dst != nullptr) {
+        for (int i = 0; i < n_w; ++i) { wr.src[n_w + i] = w_src[i]; wr.ld[n_w + i] = (unsigned short)D; wr.tr[n_w + i] = 1; }
+        wr.n = 2 * n_w;
+    }
+    wr.dst = (unsigned short*)w16_dst; wr.dstT = (unsigned short*)w16t_dst; wr.planes = w_planes; wr.D = D; wr.per = (D * (D / 8) + 255) / 256;
+    return step_head(pool, pool_stride, n_pool, phase, in_pack, in_words, B, T, n_neg, n_rows, idx_all, idx_c, row_c, live, err_flag, table, m, v, last,
+                     D, step_state, sort_plan, stream, &wr);
 }
 
 // amid_optimizer_step_f32 for a step whose gradient tail ran phase A of the segment reduce only (amid_grad_tail_live_f32): the runs of

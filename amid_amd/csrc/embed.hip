@@ -137,8 +137,6 @@ __global__ void pack_indices_pool_kernel(const long long* __restrict__ pool, lon
 // as a launch of its own the 72 planes cost 4.9 us of a 0.355 ms step)
 // n tiles of D x D floats: tile i = src[i][r * ld[i] + c] (tr[i] = 0) or its transpose; the first n_fwd images go to dst, the others to dstT
 // (SASRec: 24 weights + the same 24 transposed into a buffer of their own; BERT4Rec: 96 tiles of its 16 weights, bert_strip.hip)
-constexpr int W16_MAX = 96;
-struct W16Rider { const float* src[W16_MAX]; unsigned short ld[W16_MAX]; unsigned char tr[W16_MAX]; unsigned short* dst; unsigned short* dstT; int n, n_fwd, planes, per, D; };
 template <int RIF, bool FOLD, bool W16 = false>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ table, const int* __restrict__ idx_all,
                                                         const float* __restrict__ pos0, const float* __restrict__ pos1,

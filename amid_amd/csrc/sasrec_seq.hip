@@ -435,6 +435,11 @@ extern "C" int amid_sas_seq_supported(int B, int T, int D, int H) {
 
 // Per-layer pointer arrays: the per-domain parameter families hold 2 * n_layers entries ordered [layer][domain], the saved-tensor
 // families n_layers entries; x_in[l] = layer l's input rows (x_in[0] is read, x_in[l >= 1] written), xout = the last layer's output.
+// the gather K1 folded into the forward's prologue (seq_fwd.h SeqFwdArgs::g_*): table [n_rows, D], idx = the step's full index list
+// [seq_d1 B T | seq_d2 B T | items B ni], pos = the two position tables, items (optional) = where the samples' ni item rows go, done
+// (optional) = the step state whose step_done the launch re-joins
+struct SeqGather { const float* table; const int* idx; const float* pos[2]; float* items; int ni; StepState* done; };
+
 static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
                         const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
                         const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
@@ -442,7 +447,7 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
                         float* const* v, float* const* o, float* const* stats, float* const* r, float* const* y, float* const* h,
                         const unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
                         const void* step_state, int train, float p_drop, const void* w16, void* stream, int w16_planes = 1,
-                        float* const* ln_stat = nullptr, const HeadArgs* head = nullptr, bool infer = false) {
+                        float* const* ln_stat = nullptr, const HeadArgs* head = nullptr, bool infer = false, const SeqGather* gat = nullptr) {
     AMID_CHECK_ARG(n_layers >= 1 && n_layers <= 2 && x_in && (xout || head) && ln1_w && ln1_b && w_in && b_in && w_o && b_o && ln2_w && ln2_b && w1 && b1 &&
                    w2 && b2 && (!train || step_state));
     AMID_CHECK_ARG(infer || ((ln_stat || (qn && y)) && q && k && v && o && stats && r && h));
@@ -471,6 +476,13 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
         P.r = r[l]; P.y = ln_stat ? nullptr : y[l]; P.h = h[l]; P.ln_stat = ln_stat ? ln_stat[l] : nullptr;
     }
     a.x0 = x_in[0]; a.xout = xout; a.tmq = tmq; a.ln_eps = ln_eps;
+    if (gat != nullptr) {      // the gather as the workgroups' prologue: the producer-side pieces build, a live list, p = 0.5 or eval
+        if (!(w16 != nullptr && w16_planes == 3 && D == 128 && live != nullptr)) return AMID_ERR_UNSUPPORTED;
+        AMID_CHECK_ARG(gat->table && gat->idx && gat->pos[0] && gat->pos[1] && tmq && gat->ni >= 0 && (gat->items == nullptr || gat->ni > 0));
+        a.g_table = gat->table; a.g_idx = gat->idx; a.g_pos[0] = gat->pos[0]; a.g_pos[1] = gat->pos[1]; a.g_items = gat->items; a.g_ni = gat->ni;
+        a.g_scale = (train && p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+        a.g_done = gat->done;
+    }
     a.w16 = (const unsigned short*)w16; a.w16_planes = w16_planes;
     a.att_scale = sqrtf(1.0f / (float)(D / H));
     a.st = (const StepState*)step_state;
@@ -625,6 +637,61 @@ extern "C" int amid_sas_seq_fwd_split_infer_f32(int n_layers, const float* x0, f
     return seq_fwd_impl(n_layers, xin, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, nullptr, nullptr, nullptr, nullptr,
                         nullptr, nullptr, nullptr, nullptr, nullptr, tmq, ln_eps, B, T, D, H, live, nullptr, 0, 0.f, w16x3, stream, 3, nullptr, nullptr,
                         true);
+}
+
+// The three forwards of the folded step / the evaluation batch with the gather K1 as their workgroups' PROLOGUE (round 6): layer 0's input
+// rows are built from table[idx] + pos (dropout, == 0 mask: embed.hip's arithmetic, the same bits) by the workgroup that encodes the sequence
+// and stored to x_in[0] / tmq for the backward (not in the inference forward); the samples' item rows go to `items` (the head on the tail
+// and the scorer sums read them there); the launch re-joins StepState::step_done.  The weight images must be current when the launch starts
+// (amid_step_head_w16_f32's riders, amid_sas_weights_bf16_planes).  Replaces amid_embed_fwd_w16_f32 + the forward: one launch fewer.
+extern "C" int amid_sas_seq_fwd_gather_head_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                                const float* const* w_in, const float* const* b_in, const float* const* w_o,
+                                                const float* const* b_o, const float* const* ln2_w, const float* const* ln2_b,
+                                                const float* const* w1, const float* const* b1, const float* const* w2,
+                                                const float* const* b2, float* const* ln_stat, float* const* q, float* const* k,
+                                                float* const* v, float* const* o, float* const* stats, float* const* r, float* const* h,
+                                                unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                                                void* step_state, int train, float p_drop, const void* w16x3,
+                                                const float* const* last_ln_w, const float* const* last_ln_b, float* items,
+                                                const float* sw1, const float* sb1, const float* sw2, const float* sb2, const float* labels,
+                                                const long long* domain_id, int NI, int hid, float* u, float* p1, float* p2, float* dp1,
+                                                float* dp2, float* loss_part, float* dx, float* ditems, float* ln_part, float* hidg,
+                                                const float* table, const int* idx_all, const float* pos0, const float* pos1, void* stream) {
+    AMID_CHECK_ARG(w16x3 != nullptr && ln_stat != nullptr && live != nullptr && last_ln_w != nullptr && last_ln_b != nullptr && step_state);
+    HeadArgs ha;
+    if (int e = head_own_vec_args(ha, last_ln_w, last_ln_b, items, sw1, sb1, sw2, sb2, labels, domain_id, B, T, NI, D, hid, ln_eps, u, p1, p2, dp1,
+                                  dp2, loss_part, dx, ditems, ln_part, hidg)) return e;
+    const SeqGather gat{table, idx_all, {pos0, pos1}, items, NI, (StepState*)step_state};
+    return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, nullptr, q, k, v, o, stats, r, nullptr,
+                        h, tmq, ln_eps, B, T, D, H, live, step_state, train, p_drop, w16x3, stream, 3, ln_stat, &ha, false, &gat);
+}
+extern "C" int amid_sas_seq_fwd_gather_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w,
+                                           const float* const* ln1_b, const float* const* w_in, const float* const* b_in,
+                                           const float* const* w_o, const float* const* b_o, const float* const* ln2_w,
+                                           const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                           const float* const* w2, const float* const* b2, float* const* ln_stat, float* const* q,
+                                           float* const* k, float* const* v, float* const* o, float* const* stats, float* const* r,
+                                           float* const* h, unsigned char* tmq, float ln_eps, int B, int T, int D, int H,
+                                           const int* live, void* step_state, int train, float p_drop, const void* w16x3, float* items, int NI,
+                                           const float* table, const int* idx_all, const float* pos0, const float* pos1, void* stream) {
+    AMID_CHECK_ARG(w16x3 != nullptr && ln_stat != nullptr && step_state);
+    const SeqGather gat{table, idx_all, {pos0, pos1}, items, NI, (StepState*)step_state};
+    return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, nullptr, q, k, v, o, stats, r, nullptr, h,
+                        tmq, ln_eps, B, T, D, H, live, step_state, train, p_drop, w16x3, stream, 3, ln_stat, nullptr, false, &gat);
+}
+extern "C" int amid_sas_seq_fwd_gather_infer_f32(int n_layers, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                                 const float* const* w_in, const float* const* b_in, const float* const* w_o,
+                                                 const float* const* b_o, const float* const* ln2_w, const float* const* ln2_b,
+                                                 const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2,
+                                                 float ln_eps, int B, int T, int D, int H, const int* live, const void* w16x3,
+                                                 const float* table, const int* idx_all, const float* pos0, const float* pos1, void* stream) {
+    AMID_CHECK_ARG(w16x3 != nullptr && xout != nullptr);
+    // (nothing is stored but xout: x_in[0] and the mask bytes are only names here -- the mask word stays in registers)
+    const float* xin[2] = {xout, nullptr};
+    const SeqGather gat{table, idx_all, {pos0, pos1}, nullptr, 0, nullptr};
+    return seq_fwd_impl(n_layers, xin, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, (const unsigned char*)xout, ln_eps, B, T, D, H, live, nullptr, 0, 0.f, w16x3, stream, 3,
+                        nullptr, nullptr, true, &gat);
 }
 
 // amid_sas_seq_fwd_split_f32 that saves SEVEN tensors per layer instead of nine: qn = LN1(x) and y = LN2(r) are not stored; ln_stat[l]

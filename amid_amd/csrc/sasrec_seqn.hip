@@ -457,14 +457,61 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
     if (a.train) { seed = a.st->seed; step = (unsigned)a.st->step; }
 
     PartRegs<NCT> Xo, Qno, Ko, Vo, Qo, Oo, Ro, Yo, Ho, bias, lwo, lbo;
-    part_load<NCT>(Xo, GBuf(a.x0, sg.act_bytes), off_own);
     unsigned tmw[NCT];
     const bool has_tm = a.tmq != nullptr;
-    if (has_tm) {
-        const GBuf gtm(a.tmq, sg.tm_bytes);
-        const unsigned tbase = row_ok ? phys * (unsigned)(D / 4) + (unsigned)c0 * 4u : STRIP_OOB;
+    if (a.g_table != nullptr) {
+        // ---- the gather K1 as this workgroup's prologue (embed.hip embed_fwd_kernel's arithmetic for the rows of THIS sequence): lane (m, gq)
+        // builds its 16 bytes of row t in each own column tile -- x = table[id] + pos[t]; the == 0 bits; the row's ONE Philox call (p = 0.5:
+        // a bit per element) keeps or drops; masked elements zeroed -- keeps them as layer 0's input and its mask word, and (when a backward
+        // follows: save_bytes != 0) stores the row and the mask bytes where K1 put them
+        const int id = a.g_idx[(long long)g * sg.M + b * sg.T + min(t, sg.T - 1)];
+        const float* __restrict__ trow = a.g_table + (long long)id * D;
+        const float* __restrict__ prow = a.g_pos[g] + (long long)min(t, sg.T - 1) * D;
+        uint4 rb = make_uint4(0u, 0u, 0u, 0u);
+        if (a.train) rb = rng_call(seed, (unsigned long long)local, site_id(g, 0, SITE_EMB), step);
+        const GBuf gx0(a.x0, sg.save_bytes);
+        const GBuf gtmw(a.tmq, has_tm ? sg.save_bytes / 16u : 0u);
+        const float sc = a.g_scale;
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) tmw[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(gtm.r, (int)(tbase + 4 * c), 0, 0);
+        for (int c = 0; c < NCT; ++c) {
+            const int col = (c0 + c) * 16 + 4 * gq;
+            const float4 tv = ld4_global(trow + col), pv = ld4_global(prow + col);
+            float4 x = make_float4(tv.x + pv.x, tv.y + pv.y, tv.z + pv.z, tv.w + pv.w);
+            const unsigned bits = (x.x == 0.f ? 1u : 0u) | (x.y == 0.f ? 2u : 0u) | (x.z == 0.f ? 4u : 0u) | (x.w == 0.f ? 8u : 0u);
+            if (a.train) {
+                const unsigned wsel = rng_word(rb, (c0 + c) >> 1);
+                const unsigned kw = wsel >> ((((c0 + c) & 1) * 4 + gq) * 4);
+                x = make_float4((kw & 1u) ? x.x * sc : 0.f, (kw & 2u) ? x.y * sc : 0.f, (kw & 4u) ? x.z * sc : 0.f, (kw & 8u) ? x.w * sc : 0.f);
+            }
+            if (bits & 1u) x.x = 0.f;
+            if (bits & 2u) x.y = 0.f;
+            if (bits & 4u) x.z = 0.f;
+            if (bits & 8u) x.w = 0.f;
+            Xo.v[c] = row_ok ? f32x4{x.x, x.y, x.z, x.w} : f32x4{0.f, 0.f, 0.f, 0.f};
+            tmw[c] = row_ok ? bits << (8 * gq) : 0u;
+            gx0.store4(off_own + c * 64, Xo.v[c]);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, gtmw.r, row_ok ? (int)(phys * (unsigned)(D / 4) + (unsigned)((c0 + c) * 4 + gq)) : (int)STRIP_OOB, 0, 0);
+        }
+        if (a.g_items != nullptr) {                         // the sample's item rows: a plain gather (two rows a wave and pass)
+            const long long ibase = 2LL * sg.M + (long long)b * a.g_ni;
+            for (int n0 = 2 * w; n0 < a.g_ni; n0 += 2 * NW) {
+                const int n = n0 + (lane >> 5);
+                if (n < a.g_ni) {
+                    const long long iid = a.g_idx[ibase + n];
+                    const float4 v = ld4_global(a.g_table + iid * D + 4 * (lane & 31));
+                    st4_global(a.g_items + ((long long)b * a.g_ni + n) * D + 4 * (lane & 31), v);
+                }
+            }
+        }
+        if (a.g_done != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.g_done->step_done = a.g_done->step;
+    } else {
+        part_load<NCT>(Xo, GBuf(a.x0, sg.act_bytes), off_own);
+        if (has_tm) {
+            const GBuf gtm(a.tmq, sg.tm_bytes);
+            const unsigned tbase = row_ok ? phys * (unsigned)(D / 4) + (unsigned)c0 * 4u : STRIP_OOB;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) tmw[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(gtm.r, (int)(tbase + 4 * c), 0, 0);
+        }
     }
     xp_write<NCT>(xps, c0, Xo);                             // (rows past T arrive as zeros: the buffer descriptor's out-of-range reads)
     f32x4 acc[NCT];

@@ -31,6 +31,12 @@ struct SeqFwdArgs {
     // [D][D] written by amid_sas_weights_bf16 for THIS step's weights; nullptr = exact fp32 products
     const unsigned short* w16;
     int w16_planes;                      // 1: bf16 products (operands rounded); 3: fp32 products on three bf16 pieces per operand
+    // optional (seqn_fwd_px kernels, round 6): the gather K1 as the workgroup's PROLOGUE -- embItemLayerEnhance.forward + Log2feats' position
+    // add, embedding dropout and == 0 mask (model_seq.py:27-29, :361-366).  g_table != nullptr: layer 0's input rows are not read from x0 but
+    // built from table[g_idx[row]] + g_pos[domain][t] (K1's arithmetic, operation for operation: the same bits) and -- in a forward that a
+    // backward follows -- stored to x0 / tmq for it; wave 0 also gathers the sample's g_ni item rows into g_items (the head and the
+    // scorer sums read them there), and the launch's last workgroup re-joins StepState::step_done (K1 did).
+    const float* g_table; const int* g_idx; const float* g_pos[2]; float* g_items; int g_ni; float g_scale; StepState* g_done;
 };
 
 struct SeqGeom {

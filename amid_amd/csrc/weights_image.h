@@ -33,4 +33,14 @@ __device__ __forceinline__ void weights_image_block(const float* __restrict__ W,
     }
 }
 
+// a launch's weight-image riders (embed.hip: the gather K1; adam.hip: the step head): n tiles of D x D floats -- tile i = src[i][r * ld[i] + c]
+// (tr[i] = 0) or its transpose; the first n_fwd images go to dst, the others to dstT; `per` workgroups of 256 threads per tile
+constexpr int W16_MAX = 96;
+struct W16Rider { const float* src[W16_MAX]; unsigned short ld[W16_MAX]; unsigned char tr[W16_MAX]; unsigned short* dst; unsigned short* dstT; int n, n_fwd, planes, per, D; };
+__device__ __forceinline__ void w16_rider_block(const W16Rider& wr, int blk) {
+    const int wi = blk / wr.per;
+    unsigned short* out = wi < wr.n_fwd ? wr.dst + (size_t)wi * wr.planes * wr.D * wr.D : wr.dstT + (size_t)(wi - wr.n_fwd) * wr.planes * wr.D * wr.D;
+    weights_image_block(wr.src[wi], out, wr.D, wr.tr[wi], wr.planes, blk - wi * wr.per, wr.per, wr.ld[wi]);
+}
+
 }  // namespace amid

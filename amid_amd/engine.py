@@ -246,13 +246,22 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         # the live-sequence step on an input pool in twelve launches (FUSED_TAIL): packing, catch-up and phase 1 of the sort of the COMPACT
         # index list are one launch; the later phases ride in the backward strips and the weight gradients; no embedding-backward launch
         pl.tail2 = bool(ent is not None and bump_step and sparse and defer_sort and with_live and self._tail2_ok(pl))
+        pl.gather_on_fwd = False
         if pl.tail2:
             pool, phase = ent
             self._ensure_opt_state()
-            L.call("amid_step_head_f32", pool.data_ptr(), pool.stride(0), pool.shape[0], phase, pl.in_pack.data_ptr(), pl.in_words, shp.B, shp.T,
-                   shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.idx_c.data_ptr(), pl.row_c.data_ptr(), pl.live.data_ptr(), pl.err.data_ptr(),
-                   self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), self.D,
-                   self.step_state.data_ptr(), self._sort_plan_c(pl), s)
+            head = (pool.data_ptr(), pool.stride(0), pool.shape[0], phase, pl.in_pack.data_ptr(), pl.in_words, shp.B, shp.T,
+                    shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.idx_c.data_ptr(), pl.row_c.data_ptr(), pl.live.data_ptr(), pl.err.data_ptr(),
+                    self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), self.D,
+                    self.step_state.data_ptr(), self._sort_plan_c(pl))
+            # the step's gather as the prologue of its forward (amid_sas_seq_fwd_gather_*_f32): K1's riders -- the weight images of the forward
+            # and of the backward strips -- move to this launch's last workgroups
+            pl.gather_on_fwd = bool(self.GATHER_ON_FWD and self._fwd_on_pieces(pl, shp.B, shp.Tenc) and self._p3_bwd_for(pl) and shp.T == shp.Tenc)
+            if pl.gather_on_fwd:
+                src, w16 = self._w16_images(3)
+                L.call("amid_step_head_w16_f32", *head, src, 24, 3, w16.data_ptr(), self._wT16x3_buf().data_ptr(), s)
+            else:
+                L.call("amid_step_head_f32", *head, s)
             self.step += 1
             pl.compact, pl.riding = True, True
             self._sort_owed = False
@@ -391,6 +400,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     # reduce's second phase in the optimizer launch (amid_optimizer_step_spans_f32): 12 launches instead of 15.  False: round 4's sequence
     # (tests compare the two).
     FUSED_OPT = True             # the folded step's optimizer inside its gradient tail: ten launches (round 6; False: eleven)
+    GATHER_ON_FWD = True         # ... and its gather K1 as the prologue of the forward's workgroups: nine (the weight images by the step head's riders)
     FUSED_SPANS = True           # every single-GPU train step: the segment reduce's second phase inside the optimizer launch (round 5)
     FUSED_TAIL = True
 
@@ -636,7 +646,12 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 L.call("amid_inc_embed_fwd_f32", pl.xg.data_ptr(), pl.inc_s.data_ptr(), *wts, self.inc_threshold,
                        fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), B, shp.T, D, *out)
         else:
-            self._enqueue_k1(pl, fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), pl.tmq.data_ptr(), tr, SASREC_P_DROP, lf)
+            gat = bool(getattr(pl, "gather_on_fwd", False) and getattr(pl, "tail2", False) and lf is not None and tr)
+            pl.gather_on_fwd = False                    # (a decision of THIS step's enqueue_prepare)
+            if gat:                                     # the forward's workgroups gather their own rows; the step head wrote the images
+                pl.w16_written = pl.wT16x3_written = True
+            else:
+                self._enqueue_k1(pl, fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"), pl.tmq.data_ptr(), tr, SASREC_P_DROP, lf)
         def layer_ptrs(l):
             pre = f"sac{{d}}"
             return ((self._pp(f"{pre}.attention_layernorms.{l}.weight"), self._pp(f"{pre}.attention_layernorms.{l}.bias"),
@@ -682,19 +697,25 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 if split and getattr(pl, "tail2", False) and lf is not None:
                     # the folded step: qn / y are not stored -- row statistics instead (pl.ln_stat); the weight gradients rebuild them
                     # (c: x, 12 parameter families, qn, q, k, v, o, stats, r, y, h)
+                    gather = (self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"))
                     if (self.HEAD_ON_FWD and getattr(self, "_fuse_head", False) and with_loss and not sum_loss and 32 < T <= 64
                             and self.hid <= 32 and NI <= 64):
                         # ... and a live sequence is a sample: its workgroup finishes with the sample's head (forward + loss + backward,
                         # what amid_head_fwd_bwd_own_vec_f32 does in enqueue_backward otherwise); the last layer's output is not stored
-                        L.call("amid_sas_seq_fwd_split_lnstat_head_f32", 2, c[0], pl.x[2].data_ptr() if self.HEAD_ON_FWD_KEEPS_X else None, *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
+                        L.call("amid_sas_seq_fwd_gather_head_f32" if gat else "amid_sas_seq_fwd_split_lnstat_head_f32", 2, c[0],
+                               pl.x[2].data_ptr() if self.HEAD_ON_FWD_KEEPS_X else None, *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
                                pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(),
                                self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
                                pl.xg.data_ptr() + 4 * 2 * shp.Mi * D, fp.ptr("predictModule.fc.0.weight"), fp.ptr("predictModule.fc.0.bias"),
                                fp.ptr("predictModule.fc.2.weight"), fp.ptr("predictModule.fc.2.bias"), pl.labels.data_ptr(),
                                pl.domain.data_ptr(), NI, self.hid, pl.u.data_ptr(), pl.p1.data_ptr(), pl.p2.data_ptr(), pl.dp1.data_ptr(),
                                pl.dp2.data_ptr(), pl.loss_part.data_ptr(), pl.dxbuf.data_ptr(), pl.dxg.data_ptr() + 4 * 2 * shp.Mi * D,
-                               pl.last_part.data_ptr(), self._hidg(pl).data_ptr(), s)
+                               pl.last_part.data_ptr(), self._hidg(pl).data_ptr(), *(gather if gat else ()), s)
                         pl.head_done = True
+                    elif gat:
+                        L.call("amid_sas_seq_fwd_gather_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
+                               pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(),
+                               pl.xg.data_ptr() + 4 * 2 * shp.Mi * D, NI, *gather, s)
                     else:
                         L.call("amid_sas_seq_fwd_split_lnstat_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
                                pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(), s)
@@ -1340,7 +1361,12 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         pos = (fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"))
         split = self._fwd_on_pieces(pl, B, T)
         pl.w16_written = pl.wT16x3_written = False
-        if split and build_images:          # the gather's extra workgroups write the weights' three-plane images (the forward's operands)
+        gat = bool(split and self.GATHER_ON_FWD)          # the forward's workgroups gather their own rows: three launches a batch
+        if gat:
+            src, w16 = self._w16_images(3)
+            if build_images:
+                L.call("amid_sas_weights_bf16_planes", src, 24, D, 0, 3, w16.data_ptr(), s)
+        elif split and build_images:          # the gather's extra workgroups write the weights' three-plane images (the forward's operands)
             src, w16 = self._w16_images(3)
             L.call("amid_embed_fwd_w16_f32", self.table.data_ptr(), pl.idx_all.data_ptr(), *pos, B, T, D, 0, pl.xg.data_ptr(), pl.tmq.data_ptr(),
                    st, 0, SASREC_P_DROP, lf, None, None, src, 24, 3, w16.data_ptr(), None, s)
@@ -1360,7 +1386,10 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                  fam("sac{d}.forward_layers.{l}.conv1.weight"), fam("sac{d}.forward_layers.{l}.conv1.bias"),
                  fam("sac{d}.forward_layers.{l}.conv2.weight"), fam("sac{d}.forward_layers.{l}.conv2.bias"))
             self._ptr_cache[key] = c
-        if split:
+        if gat:
+            L.call("amid_sas_seq_fwd_gather_infer_f32", 2, pl.x[2].data_ptr(), *c, SASREC_LN_EPS, B, T, D, self.H, lf, w16.data_ptr(),
+                   self.table.data_ptr(), pl.idx_all.data_ptr(), *pos, s)
+        elif split:
             L.call("amid_sas_seq_fwd_split_infer_f32", 2, pl.x[0].data_ptr(), pl.x[2].data_ptr(), *c, pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D,
                    self.H, lf, w16.data_ptr(), s)
         else:              # D 64 / compute = "bf16" / FWD_SPLIT off: the saving forward over the live sequences

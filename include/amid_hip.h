@@ -890,6 +890,46 @@ int amid_optimizer_step_spans_f32(float* p, float* m, float* v, const float* g, 
                                   const void* step_state, const int* seg_off, const int* seg_of, int n_sorted, const void* workspace,
                                   void* stream);
 
+/* ---- the gather K1 as the prologue of the forward's workgroups (round 6) -----------------------------------------------------------------------
+ * replaces: amid_embed_fwd_w16_f32 (embItemLayerEnhance.forward model_seq.py:27-29 + Log2feats' position add / dropout / == 0 mask :361-366) as a
+ * launch of its own in the folded step and in the evaluation batch.  The workgroup that encodes a live sequence builds layer 0's input rows
+ * from table[idx_all[row]] + pos (K1's arithmetic: the same bits), stores them to x_in[0] and the mask bytes to tmq for the backward (the
+ * inference forward stores neither), gathers the sample's NI item rows into `items` [B, NI, D] and the launch re-joins StepState::step_done.
+ * idx_all: the step's full index list [seq_d1 B T | seq_d2 B T | items B NI]; the weight images w16x3 must be current (amid_step_head_w16_f32
+ * writes them with extra workgroups; evaluation: amid_sas_weights_bf16_planes once).  D = 128, 32 < T <= 64 with the head, T <= 64 without,
+ * p_drop = 0.5 or eval; otherwise AMID_ERR_UNSUPPORTED and nothing is enqueued.  The other arguments: as amid_sas_seq_fwd_split_lnstat(_head)_f32 /
+ * amid_sas_seq_fwd_split_infer_f32. */
+int amid_sas_seq_fwd_gather_head_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                     const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                     const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                     const float* const* w2, const float* const* b2, float* const* ln_stat, float* const* q, float* const* k,
+                                     float* const* v, float* const* o, float* const* stats, float* const* r, float* const* h, unsigned char* tmq,
+                                     float ln_eps, int B, int T, int D, int H, const int* live, void* step_state, int train, float p_drop,
+                                     const void* w16x3, const float* const* last_ln_w, const float* const* last_ln_b, float* items,
+                                     const float* sw1, const float* sb1, const float* sw2, const float* sb2, const float* labels,
+                                     const long long* domain_id, int NI, int hid, float* u, float* p1, float* p2, float* dp1, float* dp2,
+                                     float* loss_part, float* dx, float* ditems, float* ln_part, float* hidg, const float* table,
+                                     const int* idx_all, const float* pos0, const float* pos1, void* stream);
+int amid_sas_seq_fwd_gather_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                const float* const* w2, const float* const* b2, float* const* ln_stat, float* const* q, float* const* k,
+                                float* const* v, float* const* o, float* const* stats, float* const* r, float* const* h, unsigned char* tmq,
+                                float ln_eps, int B, int T, int D, int H, const int* live, void* step_state, int train, float p_drop,
+                                const void* w16x3, float* items, int NI, const float* table, const int* idx_all, const float* pos0,
+                                const float* pos1, void* stream);
+int amid_sas_seq_fwd_gather_infer_f32(int n_layers, float* xout, const float* const* ln1_w, const float* const* ln1_b, const float* const* w_in,
+                                      const float* const* b_in, const float* const* w_o, const float* const* b_o, const float* const* ln2_w,
+                                      const float* const* ln2_b, const float* const* w1, const float* const* b1, const float* const* w2,
+                                      const float* const* b2, float ln_eps, int B, int T, int D, int H, const int* live, const void* w16x3,
+                                      const float* table, const int* idx_all, const float* pos0, const float* pos1, void* stream);
+/* amid_step_head_f32 + the step's weight images by extra workgroups (amid_embed_fwd_w16_f32's riders): w_src = n_w square [D][D] fp32 weights,
+ * w16_dst [n_w][w_planes][D][D] bf16, w16t_dst (optional) the images of their transposes.  D = 128, n_w (x 2 with transposes) <= 96. */
+int amid_step_head_w16_f32(const long long* pool, long long pool_stride, int n_pool, long long phase, long long* in_pack, int in_words, int B, int T,
+                           int n_neg, long long n_rows, int* idx_all, int* idx_c, int* row_c, int* live, int* err_flag, float* table, float* m,
+                           float* v, int* last, int D, void* step_state, const void* sort_plan, const float* const* w_src, int n_w, int w_planes,
+                           void* w16_dst, void* w16t_dst, void* stream);
+
 /* amid_grad_tail_live_f32 (hidg = NULL) and amid_optimizer_step_spans_f32 as ONE launch (round 6): every producer of a gradient slice applies
  * Adam to it on the spot -- the partial sums and the position rows their dense slices, a half-wave per unique row the rows whose runs lie
  * inside a 64-entry chunk, and the chunk block that takes the LAST ticket the runs that cross chunks (their pieces travel with agent scope;

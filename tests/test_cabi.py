@@ -83,6 +83,12 @@ def test_round6_entry_points_refuse_bad_arguments_without_a_gpu():
     f = L._fn["amid_grad_tail_live_dp1_f32"]
     assert f(*[null] * 4, 64, 128, null, null, null, 1, null, 1, null, 4, 50, null, null, null, 100, 0, 100, null, null, 64, 0, 0, null, null, null,
              null, null) == -1
+    # the forwards with the gather as their prologue: no piece images; the step head with riders: no weights
+    assert L._fn["amid_sas_seq_fwd_gather_infer_f32"](2, null, *[null] * 12, 1e-8, 4, 40, 128, 8, null, null, null, null, null, null, null) == -1
+    assert L._fn["amid_sas_seq_fwd_gather_f32"](2, *[null] * 23, 1e-8, 4, 40, 128, 8, null, null, 1, 0.5, null, null, 2, null, null, null, null, null) == -1
+    rc = L._fn["amid_step_head_w16_f32"](null, 0, 0, 0, null, 0, 4, 4, 1, 10, null, null, null, null, null, null, null, null, null, 128, null, null, null, 0, 3,
+                                         null, null, null)
+    assert rc == -1
     # the inference forward: no piece images ; the evaluation head: no table
     assert L._fn["amid_sas_seq_fwd_split_infer_f32"](2, null, null, *[null] * 12, null, 1e-8, 4, 40, 128, 8, null, null, null) == -1
     assert L._fn["amid_eval_head_f32"](*[null] * 11, 4, 40, 100, 128, 32, 1e-8, 1e-7, null, null, null, null, null, null) == -1

@@ -430,7 +430,8 @@ def test_head_on_the_forward_workgroups_is_bit_identical_to_its_own_launch(Bn, T
         finally:
             del L.call
         assert pl.tail2
-        assert ("amid_sas_seq_fwd_split_lnstat_head_f32" in names) == on and ("amid_head_fwd_bwd_own_vec_f32" in names) == (not on), names
+        with_head = {"amid_sas_seq_fwd_split_lnstat_head_f32", "amid_sas_seq_fwd_gather_head_f32"}      # (the latter: the gather as the forward's prologue too)
+        assert bool(with_head & set(names)) == on and ("amid_head_fwd_bwd_own_vec_f32" in names) == (not on), names
         rec = dict(n_calls=len(names), loss=[float(pl.loss.item())], p1=pl.p1.clone(), p2=pl.p2.clone(), u=pl.u.clone(),
                    table=dense_table_grad(eng, pl), **{name: eng.dense.view(name, eng.dense.grad).clone() for name in eng.dense.slots})
         if use_graph:
@@ -524,6 +525,77 @@ def test_optimizer_in_the_gradient_tail_is_bit_identical_to_its_own_launch(Bn, T
         assert torch.equal(b[name], want), (name, relmax(b[name], want))
     for k, want in a["after1"].items():
         assert torch.equal(b["after1"][k], want), ("after one step", k)
+    for k, want in a["params"].items():
+        assert torch.equal(b["params"][k], want), (k, rel_l2(b["params"][k], want))
+
+
+@pytest.mark.parametrize("Bn,T,split,head_on_fwd", [(256, 50, "mixed", True), (200, 64, "one0", True), (37, 33, "all0", True), (300, 40, "mixed", False)])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_gather_in_the_forward_prologue_is_bit_identical_to_its_own_launch(Bn, T, split, head_on_fwd, use_graph):
+    """SasrecEngine.GATHER_ON_FWD on / off over the same pool: the forward's workgroups build their own input rows -- table[id] + pos, the row's
+    Philox keep bits, the == 0 mask: the gather K1's arithmetic -- and the step head's last workgroups write the weight images K1's riders
+    wrote.  The gathered rows, the mask bytes, the losses, every gradient of the first step and the parameters after six steps agree BIT FOR
+    BIT, and the step is one launch shorter.  (head_on_fwd False: the folded step's forward without the head on its tail.)"""
+    from amid_amd._lib import lib
+    D, hid, n_items, K = 128, 32, 3000, 6
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=25 + Bn)
+    for d in (1, 2):          # x = table + pos exactly zero on a whole row of either encoder: the == 0 mask fires
+        P[f"sac{d}.pos_emb.weight"][3] = -P["item_emb_layer.emb_item.weight"][7]
+    batches = [split_batch(Bn, T, n_items, seed=300 + t, split=split) for t in range(3)]
+    for b in batches:
+        b["seq_d1"][:, 3] = 7
+        b["seq_d2"][:, 3] = 7
+    out = {}
+    for on in (False, True):
+        eng = make_engine(P, T, lr=1e-3, seed=80)
+        eng.GATHER_ON_FWD = on
+        eng.HEAD_ON_FWD = head_on_fwd
+        pl = eng.plan(Bn, T, 2, need_grad=True)
+        packed = []
+        for b in batches:
+            cu = {k: v.cuda() for k, v in b.items()}
+            packed.append(eng.pack_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"]))
+        eng.set_input_pool(pl, torch.stack(packed))
+        names = []
+        L = lib()
+        orig = L.call
+        L.call = lambda name, *a: (names.append(name), orig(name, *a))[1]        # (a spy on the C-ABI calls of this one step)
+        try:
+            eng.enqueue_train_step(pl)
+            eng.sync()
+        finally:
+            del L.call
+        assert pl.tail2
+        assert any(n.startswith("amid_sas_seq_fwd_gather") for n in names) == on and any(n.startswith("amid_embed_fwd") for n in names) == (not on), names
+        live = pl.live[:Bn].long()
+        n0 = int(pl.live[Bn].item())
+        M = Bn * T
+        rows = torch.cat([(g * M + live[(0 if g == 0 else n0):(n0 if g == 0 else Bn)][:, None] * T + torch.arange(T, device="cuda")[None, :]).reshape(-1) for g in (0, 1)])
+        rec = dict(n_calls=len(names), loss=[float(pl.loss.item())], x0=pl.xg[rows].clone(), tm=pl.tmq[rows].clone(),
+                   items=pl.xg[2 * M:2 * M + 2 * Bn].clone(), table=dense_table_grad(eng, pl),
+                   **{name: eng.dense.view(name, eng.dense.grad).clone() for name in eng.dense.slots})
+        if use_graph:
+            eng.capture_train_step(pl)
+        for t in range(1, K):
+            if use_graph:
+                eng.replay_train_step(pl)
+            else:
+                eng.enqueue_train_step(pl)
+            eng.sync()
+            rec["loss"].append(float(pl.loss.item()))
+        eng.check_index_error(pl)
+        eng.flush_table()
+        eng.sync()
+        rec["params"] = {k: v.cpu().clone() for k, v in eng.state_dict().items()}
+        out[on] = rec
+    a, b = out[False], out[True]
+    assert b["n_calls"] == a["n_calls"] - 1
+    assert int(a["tm"].sum()) > 0, "the fixture's zero row did not reach the mask"
+    assert a["loss"] == b["loss"], (a["loss"], b["loss"])
+    for name, want in a.items():
+        if name in ("n_calls", "loss", "params"):
+            continue
+        assert torch.equal(b[name], want), (name, relmax(b[name].float(), want.float()))
     for k, want in a["params"].items():
         assert torch.equal(b["params"][k], want), (k, rel_l2(b["params"][k], want))
 
