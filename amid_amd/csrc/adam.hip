@@ -1025,7 +1025,9 @@ static int tail_opt_common(TailOptArgs& a, const float* grad_rows, const int* po
                            const int* live, int B, int T, float* dpos0, float* dpos1, float* g, long long n, long long left_lo, long long left_hi,
                            const int* uniq_ids, const int* n_uniq, int n_uniq_max, int* ticket) {
     AMID_CHECK_ARG(grad_rows && pos_sorted && seg_off && seg_of && workspace && uniq_grad && n_idx > 0 && entries_dev && n_entries > 0 &&
-                   blk_off && total_blocks > 0 && live && B > 0 && T > 0 && dpos0 && dpos1);
+                   blk_off && total_blocks > 0);
+    // live == NULL: no position rows are summed here (every dense gradient is an entry's: the steps outside the folded form)
+    AMID_CHECK_ARG(live == nullptr || (B > 0 && T > 0 && dpos0 && dpos1));
     AMID_CHECK_ARG(g && n > 0 && uniq_ids && n_uniq && n_uniq_max > 0 && ticket);
     AMID_CHECK_ARG(left_lo >= 0 && left_lo <= left_hi && left_hi <= n && (left_lo & 3) == 0);
     AMID_CHECK_ARG(((((unsigned long long)dpos0) | ((unsigned long long)dpos1) | ((unsigned long long)grad_rows) | ((unsigned long long)g)) & 15) == 0);
@@ -1034,7 +1036,8 @@ static int tail_opt_common(TailOptArgs& a, const float* grad_rows, const int* po
     a.uniq_grad = uniq_grad; a.partial = (float*)workspace;
     a.nch = (n_idx + SEG_CHUNK - 1) / SEG_CHUNK; a.n_seg = (a.nch + 3) / 4; a.ticket = ticket;
     a.entries = (const ReduceEntry*)entries_dev; a.blk_off = blk_off; a.n_entries = n_entries; a.n_red = total_blocks;
-    a.ps.rows = grad_rows; a.ps.live = live; a.ps.B = B; a.ps.T = T; a.ps.dst[0] = dpos0; a.ps.dst[1] = dpos1; a.ps.nblk = (T * D + 127) / 128;
+    a.ps.rows = grad_rows; a.ps.live = live; a.ps.B = B; a.ps.T = T; a.ps.dst[0] = dpos0; a.ps.dst[1] = dpos1;
+    a.ps.nblk = live != nullptr ? (T * D + 127) / 128 : 0;
     a.g = g; a.n_dense = n; a.left_lo = left_lo; a.left_hi = left_hi;
     a.left_blocks = (int)((left_hi - left_lo + 1023) / 1024);
     a.uniq_ids = uniq_ids; a.n_uniq = n_uniq; a.row_blocks = rows_grid(n_uniq_max);

@@ -107,7 +107,9 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         self.seed = int(seed)
         self.step = 0
         self._st_bytes = L.value("amid_step_state_bytes")
-        self.step_state = torch.zeros(self._st_bytes, dtype=torch.uint8, device=self.device)
+        # empty, not zeros: a zero fill on torch's stream is unordered against the copy _push_step_state issues on the engine's stream and
+        # could land after it (a step then ran with seed 0 and zero Adam coefficients: found by tests/test_gpu_fused_opt.py, round 6)
+        self.step_state = torch.empty(self._st_bytes, dtype=torch.uint8, device=self.device)
         self._push_step_state()
         self.plans: Dict[Tuple[int, int, int, bool], SasrecPlan] = {}
         self.grad_scale = 1.0
@@ -154,6 +156,9 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self.table_m = torch.zeros_like(self.table)
             self.table_v = torch.zeros_like(self.table)
             self.table_last = torch.zeros(self.n_rows, dtype=torch.int32, device=self.device)
+            # the zero fills run on torch's stream, the step that needs them on the engine's: without this a first step enqueued straight away
+            # read moments and stamps that were not zero yet (a catch-up replaying garbage gaps: found by tests/test_gpu_fused_opt.py, round 6)
+            torch.cuda.synchronize(self.device)
 
     def select_optimizer(self, k: int, lr: Optional[float] = None) -> None:
         """Switch to Adam state `k` (its own moments, step counter and learning rate over the SAME parameters): the reference's
@@ -171,7 +176,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         b = self._banks.get(k)
         if b is None:
             b = dict(m=torch.zeros_like(fp.m), v=torch.zeros_like(fp.v), tm=None, tv=None, tl=None,
-                     st=torch.zeros(self._st_bytes, dtype=torch.uint8, device=self.device), step=0,
+                     st=torch.empty(self._st_bytes, dtype=torch.uint8, device=self.device), step=0,
                      lr=self.hyper["lr"] if lr is None else float(lr), seed=self.seed + 0x9E3779B9 * k)
         fp.m, fp.v, self.table_m, self.table_v, self.table_last = b["m"], b["v"], b["tm"], b["tv"], b["tl"]
         self.step_state, self.step, self.seed = b["st"], b["step"], b["seed"]
@@ -465,11 +470,13 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         if not hasattr(pl, "ln_stat"):
             pl.ln_stat = [torch.zeros(2 * pl.shape.M, 4, dtype=torch.float32, device=self.device) for _ in range(2)]
             pl._ln_stat_ptrs = ptr_array([t.data_ptr() for t in pl.ln_stat])
+            torch.cuda.synchronize(self.device)      # zero-filled on torch's stream, used on the engine's
         return pl.ln_stat, pl._ln_stat_ptrs
 
     def _hidg(self, pl: SasrecPlan) -> torch.Tensor:
         if not hasattr(pl, "hidg"):
             pl.hidg = torch.zeros(pl.shape.B, lib().value("amid_scorer_vec_floats", pl.shape.NI, self.hid), dtype=torch.float32, device=self.device)
+            torch.cuda.synchronize(self.device)
         return pl.hidg
 
     COMPACT_LIVE = True
@@ -1152,8 +1159,6 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             mid = (ent_t.data_ptr(), n_ent_t, blk_t[0].data_ptr(), blk_t[1], pl.live.data_ptr(), shp.B, shp.Tenc,
                    fp.ptr("sac1.pos_emb.weight", fp.grad), fp.ptr("sac2.pos_emb.weight", fp.grad))
             if self.FUSED_OPT:        # ... all of it as ONE launch (amid_grad_tail_opt_f32's workgroups, shipping instead of applying)
-                if not hasattr(pl, "tail_ticket"):
-                    pl.tail_ticket = torch.zeros(16, dtype=torch.int32, device=self.device)
                 left_lo = fp.slots["predictModule.fc.0.weight"][0]      # the scorer's gradients: final before this launch (the strip riders)
                 dense = (fp.grad.data_ptr(), fp.numel, left_lo, fp.numel, pl.uniq_ids.data_ptr(), pl.n_uniq.data_ptr(), pl.n_compact)
                 if pk is not None:
@@ -1183,8 +1188,6 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             # the folded step's tail AND its optimizer as one launch (round 6): every producer of a gradient slice applies Adam on the spot
             ent_t, n_ent_t, blk_t = self._tail2_table(pl)
             fp = self.dense
-            if not hasattr(pl, "tail_ticket"):
-                pl.tail_ticket = torch.zeros(16, dtype=torch.int32, device=self.device)
             left_lo = fp.slots["predictModule.fc.0.weight"][0]          # the scorer's slots (the flat buffer's tail): summed by the strip riders
             L.call("amid_grad_tail_opt_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), pl.n_compact,
                    self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), ent_t.data_ptr(), n_ent_t, blk_t[0].data_ptr(), blk_t[1],
@@ -1216,6 +1219,18 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         # a single-GPU train step's optimizer launch follows: it finishes the runs that cross chunks itself (amid_optimizer_step_spans_f32;
         # the same additions in the same order as the spans launch this saves).  Not for enqueue_local_grads: the exchange ships uniq_grad
         spans_later = bool(self.FUSED_SPANS and getattr(self, "_in_train_step", False) and self.D in (64, 128, 256))
+        left = getattr(pl, "red_left_s" if seq else "red_left_v" if (live and hasattr(pl, "red_left_v")) else "red_left", None)
+        if spans_later and self.FUSED_OPT and self.table_m is not None and left is not None:
+            # ... and the optimizer itself: the tail's workgroups apply Adam to every slice they finish (amid_grad_tail_opt_f32 without its
+            # position-row role: here every dense gradient is an entry of the reduce table) -- one launch fewer in every single-GPU step
+            fp = self.dense
+            L.call("amid_grad_tail_opt_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(), pl.seg_of.data_ptr(), self.n_sparse(pl),
+                   self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), ent.data_ptr(), n_ent, blk[0].data_ptr(), blk[1],
+                   None, 0, 0, None, None, fp.data.data_ptr(), fp.m.data_ptr(), fp.v.data_ptr(), fp.grad.data_ptr(), fp.numel, *(left or (0, 0)),
+                   self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), pl.uniq_ids.data_ptr(),
+                   pl.n_uniq.data_ptr(), self.n_sparse(pl), self.grad_scale, self.step_state.data_ptr(), pl.tail_ticket.data_ptr(), s)
+            pl.opt_done = True
+            return
         pl.spans_owed = self.n_sparse(pl) if spans_later else 0
         L.call("amid_grad_tail_nospans_f32" if spans_later else "amid_grad_tail_f32", pl.dxg.data_ptr(), pl.pos_sorted.data_ptr(), pl.seg_off.data_ptr(),
                pl.seg_of.data_ptr(), self.n_sparse(pl), self.D, pl.seg_ws.data_ptr(), pl.uniq_grad.data_ptr(), ent.data_ptr(), n_ent, ent_max,
@@ -1343,6 +1358,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             pl.ev_rank, pl.ev_rank_raw, pl.ev_loss_part = pl.ev_out[:B], pl.ev_out[B:2 * B], pl.ev_out[2 * B:].view(torch.float32)
             pl.ev_p = torch.zeros(B, pl.shape.NI, dtype=torch.float32, device=self.device)
             pl.ev_u = torch.zeros(B, self.D, dtype=torch.float32, device=self.device)
+            torch.cuda.synchronize(self.device)
         return pl.ev_out
 
     def enqueue_eval(self, pl: SasrecPlan, fix_value: float, with_loss: bool = True, want_scores: bool = False, build_images: bool = True) -> None:

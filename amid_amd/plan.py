@@ -267,6 +267,7 @@ class SasrecPlan:
         self.n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
         self.seg_ws = torch.empty(L.value("amid_segreduce_workspace_bytes", N, D), dtype=torch.uint8, device=dev)
         self.uniq_grad = f(N, D)
+        self.tail_ticket = torch.zeros(16, dtype=torch.int32, device=dev)      # amid_grad_tail_opt_f32's "last chunk block" ticket: zero between launches
         self.red_entries, self.red_n, self.red_max = self._build_reduce_table(eng)
         if self.live_rows and self.strip:
             self.red_entries_v, self.red_n_v, self.red_max_v = self.red_entries, self.red_n, self.red_max
@@ -339,6 +340,31 @@ class SasrecPlan:
         # algorithmic HBM bytes of the partial-sum reduce (every partial read once, every sum written once): bench.py prices the launch
         sfx = "_t" if not pos else "_s" if seq else "_v" if live else ""
         setattr(self, "red_bytes" + sfx, sum(4 * (n + 1) * c for *_, n, c in ent))
+        # the parameters whose gradient NO entry of this table produces (kernels write them straight into dense.grad: the comp modules'),
+        # as ONE range of the flat buffer [lo, hi) -- what amid_grad_tail_opt_f32 applies Adam to beside the entries' slices; () when every
+        # parameter is covered, None when the uncovered slots do not form one run (the caller then keeps the optimizer launch)
+        import numpy as np
+        cov = np.zeros(fp.numel, dtype=bool)
+        g0 = G.data_ptr()
+        for s_, d_, st_, n_, c_ in ent:
+            o = (d_ - g0) // 4
+            if 0 <= o < fp.numel and (d_ - g0) % 4 == 0:
+                cov[o:o + c_] = True
+        names = list(fp.slots)
+        unc = []
+        for i, nm in enumerate(names):
+            off, shp_ = fp.slots[nm]
+            cnt = int(np.prod(shp_)) if len(shp_) else 1
+            if not cov[off:off + cnt].all():
+                unc.append(i)
+        if not unc:
+            left = ()
+        elif unc == list(range(unc[0], unc[-1] + 1)):
+            off_l, shp_l = fp.slots[names[unc[-1]]]
+            left = (fp.slots[names[unc[0]]][0], min(fp.numel, (off_l + (int(np.prod(shp_l)) if len(shp_l) else 1) + 3) & ~3))
+        else:
+            left = None
+        setattr(self, "red_left" + sfx, left)
         esz = L.value("amid_reduce_entry_bytes")
         host = (ctypes.c_ubyte * (esz * len(ent)))()
         for i, (s, d, st, n, c) in enumerate(ent):

@@ -55,6 +55,7 @@ def test_eval_launches_are_bit_identical_to_the_forward_and_rank_kernels(D, hid,
     assert eng.eval_fused_ok(pl)
     for seed in range(4):
         cu = {k: v.cuda() for k, v in eval_batch(B, T, n_items, NI, 40 + seed, dup_positive=NI > 4).items()}
+        torch.cuda.synchronize()          # (the engine's stream does not wait for torch's)
         own, r, r0 = old_path(eng, pl, cu)
         eng.load_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"])
         eng.enqueue_eval(pl, FIX, with_loss=True, want_scores=True)
@@ -81,6 +82,7 @@ def test_eval_ranks_over_32_random_batches_and_against_the_oracle():
     pl = eng.plan(B, T, NI, need_grad=False)
     batches = [eval_batch(B, T, n_items, NI, 900 + i) for i in range(32)]
     cus = [{k: v.cuda() for k, v in b.items()} for b in batches]
+    torch.cuda.synchronize()
     packed = torch.stack([eng.pack_batch(pl, c["i_node"], c["neg_samples"], c["seq_d1"], c["seq_d2"], c["label"], c["domain_id"]) for c in cus])
     out = eng.eval_epoch(pl, packed, FIX, with_loss=True, use_graph=True)
     eng.sync()
