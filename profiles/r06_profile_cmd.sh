@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stress > $O/pmc_write.json 2> $O/pmc_write_err.log
 rocprofv3 --kernel-trace -d $O/tl -o tl -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-stress > /dev/null 2>&1
 rocprofv3 --kernel-trace -d $O/tlb -o tl -- python3 $R/bench.py --model bert4rec --steps 60 --warmup 10 --no-cpu-baseline --no-stress > /dev/null 2>&1
-rocprofv3 --kernel-trace -d $O/tl5 -o tl -- python3 $R/bench.py --set FUSED_OPT=0 --steps 60 --warmup 10 --no-cpu-baseline --no-stress > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $O/tl5 -o tl -- python3 $R/bench.py --set GATHER_ON_FWD=0 --steps 60 --warmup 10 --no-cpu-baseline --no-stress > /dev/null 2>&1
 # the evaluation loop alone: kernel stats and HBM traffic
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_eval -o e -- python3 $R/profiles/tools/eval_bench.py 256 > $O/eval_under_prof.json 2> $O/prof_eval_err.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_eval_fetch -o f -- python3 $R/profiles/tools/eval_bench.py 16 > /dev/null 2> $O/pmc_eval_fetch_err.log
@@ -27,16 +27,18 @@ cd "$R"
 rm -f $O/prof/*kernel_trace.csv $O/pmc_*/*kernel_trace.csv $O/prof_eval/*kernel_trace.csv
 python3 profiles/tools/step_timeline.py $O/tl/tl_results.db > $O/step_timeline.txt 2>&1
 python3 profiles/tools/step_timeline.py $O/tlb/tl_results.db > $O/bert_step_timeline.txt 2>&1
-python3 profiles/tools/step_timeline.py $O/tl5/tl_results.db > $O/step_timeline_eleven_launches.txt 2>&1
+python3 profiles/tools/step_timeline.py $O/tl5/tl_results.db > $O/step_timeline_ten_launches.txt 2>&1
 rm -rf $O/tl $O/tlb $O/tl5
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
 for w in cfg5-uniform cfg5-real cfg4 cfg3 cfg1; do python3 bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
 python3 bench.py --model bert4rec --no-cpu-baseline > $O/bench_bert4rec.json 2> $O/bench_bert4rec.err
 python3 bench.py --dtype bf16 --no-cpu-baseline > $O/bench_cfg2_bf16.json 2> $O/bench_cfg2_bf16.err
 python3 bench.py --workload cfg3 --dtype bf16 --no-cpu-baseline > $O/bench_cfg3_bf16.json 2> $O/bench_cfg3_bf16.err
-# A/B on this box: the optimizer as its own launch (round 5's eleven launches); the head as its own launch too; round 4's fifteen launches
-python3 bench.py --set FUSED_OPT=0 --no-cpu-baseline --no-stress > $O/bench_eleven_launches.json 2> $O/bench_eleven_launches.err
-python3 bench.py --set FUSED_OPT=0 --set HEAD_ON_FWD=0 --no-cpu-baseline --no-stress > $O/bench_twelve_launches.json 2> $O/bench_twelve_launches.err
+# A/B on this box: the embedding gather as its own launch (ten launches); the optimizer as its own launch too (round 5's eleven launches);
+# the head as its own launch as well; round 4's fifteen launches
+python3 bench.py --set GATHER_ON_FWD=0 --no-cpu-baseline --no-stress > $O/bench_ten_launches.json 2> $O/bench_ten_launches.err
+python3 bench.py --set GATHER_ON_FWD=0 --set FUSED_OPT=0 --no-cpu-baseline --no-stress > $O/bench_eleven_launches.json 2> $O/bench_eleven_launches.err
+python3 bench.py --set GATHER_ON_FWD=0 --set FUSED_OPT=0 --set HEAD_ON_FWD=0 --no-cpu-baseline --no-stress > $O/bench_twelve_launches.json 2> $O/bench_twelve_launches.err
 python3 bench.py --no-fused-tail --no-cpu-baseline --no-stress > $O/bench_fifteen_launches.json 2> $O/bench_fifteen_launches.err
 (echo "# python profiles/tools/variant_steps.py (cfg 2 shape: B 256, T 50, D 128, hid 32, neg 1; hipGraph replay, 200 steps)"; python3 profiles/tools/variant_steps.py 2>&1 | grep "ms/step"; echo "# VARIANT_T=20 (the mybank shape run.sh trains on)"; VARIANT_T=20 python3 profiles/tools/variant_steps.py 2>&1 | grep "ms/step") > $O/variant_steps.txt
 python3 profiles/tools/dp_overhead.py 2>&1 | grep "ms/step" > $O/dp_overhead.txt
