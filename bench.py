@@ -481,8 +481,8 @@ def eval_throughput(eng, device, Bw, T, n_batches=64):
             "mean_rank_last_batch": round(float(rank[-1].float().mean().item()), 2),
             "launches_per_batch": sum(len(v) for v in durs.values()) // n_prof, "sum_kernel_us": round(sum(k["avg_launch_us"] for k in kernels.values()), 2),
             "kernels": kernels,
-            "what": "per batch: one device copy of the packed batch, one replayed graph of four launches (index marshal + live list, gather of "
-                    "the B own-domain sequences, inference forward over them, eval head: gather of the 1 000 candidates per row inside the "
+            "what": "per batch: one device copy of the packed batch, one replayed graph of three launches (index marshal + live list, inference "
+                    "forward over the B own-domain sequences with their rows gathered in its prologue, eval head: gather of the 1 000 candidates per row inside the "
                     "scorer + masked BCE + ranks), one device copy of 3 B result words; synthetic cloth_sport-shaped batches"}
 
 
