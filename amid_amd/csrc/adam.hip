@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_pos_kernel(float* __res
                                                                     const StepState* __restrict__ stp, const SortRider rd) {
     // rider: the first workgroups run a phase of the step's index sort (sort_phases.h) beside the catch-up
     const int nrb = rider_blocks(rd);
-    if ((int)blockIdx.x < nrb) { sort_phase_ct<1024, 1>(rd.plan, blockIdx.x); return; }
+    __shared__ __attribute__((aligned(16))) int sort_hist[OS_BINS_MAX];
+    if ((int)blockIdx.x < nrb) { sort_phase_ct<1>(rd.plan, blockIdx.x, sort_hist); return; }
     const int bid = blockIdx.x - nrb, nbk = gridDim.x - nrb;
     __shared__ IdleCoef tab[COEF_TAB];
     __shared__ int any_lag;
@@ -186,8 +187,13 @@ __global__ __launch_bounds__(256) void step_head_kernel(const StepHeadArgs a, co
     const int nrb = rider_blocks(rd);
     if ((int)blockIdx.x < nrb) {
         const SortPlan& sp = rd.plan;
-        os_count_block<1024>(blockIdx.x, sp.nblk, PoolKeys{pb}, sp.g0, sp.state, sp.counts0, sp.stot0, sp.stot0_copy, sp.n_zero_a, sp.counts1,
-                             sp.n_counts1, sp.stot1, sp.n_stot1, (int*)sp.hstatus);
+        __shared__ __attribute__((aligned(16))) int sort_hist[OS_BINS_MAX];
+        if (sp.g0.bits <= 10)      // (block-uniform: the digit width of the plan -- 1 024 bins below 2^20 rows, 4 096 up to 2^24)
+            os_count_block<1024>(blockIdx.x, sp.nblk, PoolKeys{pb}, sp.g0, sp.state, sp.counts0, sp.stot0, sp.stot0_copy, sp.n_zero_a, sp.counts1,
+                                 sp.n_counts1, sp.stot1, sp.n_stot1, (int*)sp.hstatus, sort_hist);
+        else
+            os_count_block<OS_BINS_MAX>(blockIdx.x, sp.nblk, PoolKeys{pb}, sp.g0, sp.state, sp.counts0, sp.stot0, sp.stot0_copy, sp.n_zero_a, sp.counts1,
+                                        sp.n_counts1, sp.stot1, sp.n_stot1, (int*)sp.hstatus, sort_hist);
         return;
     }
     const int M = a.B * a.T, NI = 1 + a.n_neg, n_items = a.B * a.n_neg, n_index_words = a.B + n_items + 2 * M;

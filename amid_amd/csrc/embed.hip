@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
     }
     if constexpr (FOLD) {
         const int nsb = rider_blocks(rd);
-        if ((int)blockIdx.x - nrb < nsb) { sort_phase_ct<1024, 1>(rd.plan, blockIdx.x - nrb); return; }
+        __shared__ __attribute__((aligned(16))) int sort_hist[OS_BINS_MAX];
+        if ((int)blockIdx.x - nrb < nsb) { sort_phase_ct<1>(rd.plan, blockIdx.x - nrb, sort_hist); return; }
         nrb += nsb;
     }
     const int bid = blockIdx.x - nrb;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(float* __restrict__ dxg,
     // index sort (sort_phases.h: run heads)
     if (rd.phase != 0 && (int)blockIdx.z == nsplit) {
         const int rb = blockIdx.y * gridDim.x + blockIdx.x;
-        if (rb < rd.plan.nblk) sort_phase_ct<1024, 5>(rd.plan, rb);
+        if (rb < rd.plan.nblk) sort_phase_ct<5>(rd.plan, rb, red);
         return;
     }
     const int t = blockIdx.x, g = blockIdx.y, z = blockIdx.z;

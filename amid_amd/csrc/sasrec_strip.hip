@@ -330,7 +330,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_ffn_bwd_kernel(const Stri
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
     if constexpr (RIDER != 0) {
-        if (bid < rd.plan.nblk) { sort_phase_ct<1024, RIDER>(rd.plan, bid); return; }
+        if (bid < rd.plan.nblk) { sort_phase_ct<RIDER>(rd.plan, bid, smem); return; }
         bid -= rd.plan.nblk;
     }
     STRIP_STAMP(16);
@@ -360,11 +360,17 @@ __global__ __launch_bounds__(STRIP_THREADS) void strip_qkv_bwd_kernel(const Stri
     if constexpr (RIDER != 0 && FFN) {
         // riders BEHIND the tiles (the last ss.nblk workgroups: they fill the CUs the dead tiles leave at once; in front they would take CUs
         // from live tiles): the scorer's weight gradients from the head's per-sample hidden gradients (scorer_sum.h)
-        const int first = (int)gridDim.x - ss.nblk;
-        if (bid >= first) { scorer_sum_block(ss, bid - first, (scorer_lds_f4*)smem); return; }
+        // (long batches: IN FRONT instead -- scorer_sum.h ScorerSum::front)
+        if (ss.front) {
+            if (bid < ss.nblk) { scorer_sum_block(ss, bid, (scorer_lds_f4*)smem); return; }
+            bid -= ss.nblk;
+        } else {
+            const int first = (int)gridDim.x - ss.nblk;
+            if (bid >= first) { scorer_sum_block(ss, bid - first, (scorer_lds_f4*)smem); return; }
+        }
     }
     if constexpr (RIDER != 0) {
-        if (bid < rd.plan.nblk) { sort_phase_ct<1024, RIDER>(rd.plan, bid); return; }
+        if (bid < rd.plan.nblk) { sort_phase_ct<RIDER>(rd.plan, bid, smem); return; }
         bid -= rd.plan.nblk;
     }
     typename RingSel<D, BF>::type ring(smem);
@@ -512,6 +518,8 @@ static int make_rider(SortRider& rd, const void* sort_plan, int sort_phase) {
 template <auto KERNEL, int DVAL, class... Args>
 static int launch_strip_rider_x(const StripGeom& sg, const SortRider& rd, int extra, void* stream, const Args&... args) {
     static unsigned long long attr_done = 0;
+    // (the rider workgroups run their sort phase on the head of the dynamic LDS: the 4 096-bin scatter needs 48 KB)
+    if (rd.phase != 0 && strip_lds_bytes<DVAL>() < (rd.plan.g0.bits > 10 ? sizeof(SortScatterLds<OS_BINS_MAX>) : sizeof(SortScatterLds<1024>))) return AMID_ERR_UNSUPPORTED;
     if (int rc = lds_attr_once((const void*)KERNEL, strip_lds_bytes<DVAL>(), attr_done)) return rc;
     KERNEL<<<2 * sg.tpg + rider_blocks_host(rd) + extra, STRIP_THREADS, strip_lds_bytes<DVAL>(), (hipStream_t)stream>>>(args..., sg, rd);
     hipError_t e = hipGetLastError();
@@ -520,6 +528,8 @@ static int launch_strip_rider_x(const StripGeom& sg, const SortRider& rd, int ex
 template <auto KERNEL, int DVAL, class... Args>
 static int launch_strip_rider(const StripGeom& sg, const SortRider& rd, void* stream, const Args&... args) {
     static unsigned long long attr_done = 0;
+    // (the rider workgroups run their sort phase on the head of the dynamic LDS: the 4 096-bin scatter needs 48 KB)
+    if (rd.phase != 0 && strip_lds_bytes<DVAL>() < (rd.plan.g0.bits > 10 ? sizeof(SortScatterLds<OS_BINS_MAX>) : sizeof(SortScatterLds<1024>))) return AMID_ERR_UNSUPPORTED;
     if (int rc = lds_attr_once((const void*)KERNEL, strip_lds_bytes<DVAL>(), attr_done)) return rc;
     KERNEL<<<2 * sg.tpg + rider_blocks_host(rd), STRIP_THREADS, strip_lds_bytes<DVAL>(), (hipStream_t)stream>>>(args..., sg, rd);
     hipError_t e = hipGetLastError();

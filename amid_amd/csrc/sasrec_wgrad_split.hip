@@ -23,7 +23,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void sas_wgrad_split_kernel(const 
     if constexpr (RIDER) {
         if (blockIdx.z == 2) {
             const int rb = blockIdx.y * gridDim.x + blockIdx.x;
-            if (rb < rd.plan.nblk && threadIdx.x < SORT_THREADS) sort_phase_ct<1024, 5>(rd.plan, rb);
+            if (rb < rd.plan.nblk && threadIdx.x < SORT_THREADS) sort_phase_ct<5>(rd.plan, rb, smem);
             return;
         }
     }

@@ -3,6 +3,7 @@
 // the gradient tail (segreduce.hip).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 #ifndef SCORER_FENCE
 #define SCORER_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -13,7 +14,9 @@ namespace amid {
 // HeadArgs::hidg: da [2][hid] | dc [NI][hid] | dW2's [hid] | db2's per sample) -- dW1[j][0 .. D) = sum_b da[b][0][j] u[0][b] + da[b][1][j] u[1][b],
 // dW1[j][D .. 2D) = sum_b sum_n dc[b][n][j] items[b][n], db1, dW2, db2 = sums over b: workgroup (j, half) = 32 float4 columns x 8 groups of
 // samples (group p takes b = p, p + 8, ... in order), the eight group sums added in order; a workgroup per 32 of the 2 hid + 1 scalars.
-struct ScorerSum { const float* hidg; const float* u; const float* items; int B, NI, D, hid, HG; float* dW1; float* db1; float* dW2; float* db2; int nblk; };
+struct ScorerSum { const float* hidg; const float* u; const float* items; int B, NI, D, hid, HG; float* dW1; float* db1; float* dW2; float* db2; int nblk; int front; };
+// front: the rider workgroups stand IN FRONT of the host launch's own (long batches: a workgroup walks B / 8 samples per group -- behind the tiles
+// of a many-round launch it would start when the last tile does and add its whole length to the launch: + 130 us at B 4096, round 6)
 
 // red: 8 x 33 float4 of LDS (the caller's: static in the gradient tail, a corner of the dynamic allocation in the strip launch -- hipcc 7.2
 // dies in instruction selection on a third static array beside a dynamic one there: "Illegal instruction detected ... $src_shared_base")
@@ -28,50 +31,39 @@ __device__ __forceinline__ void scorer_sum_block(const ScorerSum& ss, int blk, s
         const int j = blk >> 1, half = blk & 1;
         const bool on = el < (D >> 2);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        // NB pairs in flight per round trip: 8 at the headline batch, 32 for long batches (the sums add in the same order either way)
+        auto walk = [&](auto NBC, auto&& coef, auto&& row, int npair) {
+            constexpr int NB = decltype(NBC)::value;
+            for (int q0 = 0; q0 < npair; q0 += NB) {
+                float c[NB];
+                float4 r[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int q = min(q0 + k, npair - 1);
+                    c[k] = coef(q);
+                    r[k] = row(q);
+                }
+                SCORER_FENCE();
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    if (q0 + k < npair) { s.x = fmaf(c[k], r[k].x, s.x); s.y = fmaf(c[k], r[k].y, s.y); s.z = fmaf(c[k], r[k].z, s.z); s.w = fmaf(c[k], r[k].w, s.w); }
+                }
+            }
+        };
+        const int per = (B - pg + 7) / 8;               // samples of this group
         if (on && half == 0) {
-            // (sample, domain) pairs of the group flattened -- pair q <-> sample pg + 8 (q / 2), domain q % 2 -- eight at a time, as the item half below
-            // (sixteen samples' loads in one batch: the compiler sinks every load to its use again, one round trip per sample)
-            const int per = (B - pg + 7) / 8;
+            // (sample, domain) pairs of the group flattened -- pair q <-> sample pg + 8 (q / 2), domain q % 2 -- NB at a time, as the item half below
+            // (the loads of a batch are issued before its first use: the compiler sinks every load to its use again, one round trip per sample)
             const int npair = per * 2;
-            for (int q0 = 0; q0 < npair; q0 += 8) {
-                float c[8];
-                float4 r[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int q = min(q0 + k, npair - 1);
-                    const int d = q & 1;
-                    const long long b = pg + 8 * (q >> 1);
-                    c[k] = ss.hidg[b * HG + d * hid + j];
-                    r[k] = ld4(ss.u + ((long long)d * B + b) * D + 4 * el);
-                }
-                SCORER_FENCE();
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (q0 + k < npair) { s.x = fmaf(c[k], r[k].x, s.x); s.y = fmaf(c[k], r[k].y, s.y); s.z = fmaf(c[k], r[k].z, s.z); s.w = fmaf(c[k], r[k].w, s.w); }
-                }
-            }
+            auto coef = [&](int q) { return ss.hidg[(long long)(pg + 8 * (q >> 1)) * HG + (q & 1) * hid + j]; };
+            auto row = [&](int q) { return ld4(ss.u + ((long long)(q & 1) * B + (pg + 8 * (q >> 1))) * D + 4 * el); };
+            if (npair >= 256) walk(std::integral_constant<int, 32>{}, coef, row, npair); else walk(std::integral_constant<int, 8>{}, coef, row, npair);
         } else if (on) {
-            // (sample, item) pairs of the group flattened -- pair q <-> sample pg + 8 (q / NI), item q % NI -- and taken eight at a time: every
-            // load of a batch is issued before its first use (one pair per round trip took 32 dependent round trips at NI = 2)
-            const int per = (B - pg + 7) / 8;               // samples of this group
+            // (sample, item) pairs of the group flattened -- pair q <-> sample pg + 8 (q / NI), item q % NI
             const int npair = per * NI;
-            for (int q0 = 0; q0 < npair; q0 += 8) {
-                float c[8];
-                float4 r[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int q = min(q0 + k, npair - 1);
-                    const int bi = q / NI, n = q - bi * NI;
-                    const long long b = pg + 8 * bi;
-                    c[k] = ss.hidg[b * HG + (2 + n) * hid + j];
-                    r[k] = ld4(ss.items + (b * NI + n) * D + 4 * el);
-                }
-                SCORER_FENCE();
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (q0 + k < npair) { s.x = fmaf(c[k], r[k].x, s.x); s.y = fmaf(c[k], r[k].y, s.y); s.z = fmaf(c[k], r[k].z, s.z); s.w = fmaf(c[k], r[k].w, s.w); }
-                }
-            }
+            auto coef = [&](int q) { const int bi = q / NI, n = q - bi * NI; return ss.hidg[(long long)(pg + 8 * bi) * HG + (2 + n) * hid + j]; };
+            auto row = [&](int q) { const int bi = q / NI, n = q - bi * NI; return ld4(ss.items + ((long long)(pg + 8 * bi) * NI + n) * D + 4 * el); };
+            if (npair >= 256) walk(std::integral_constant<int, 32>{}, coef, row, npair); else walk(std::integral_constant<int, 8>{}, coef, row, npair);
         }
         sred[pg][el] = f32x4{s.x, s.y, s.z, s.w};
         __syncthreads();
@@ -120,6 +112,7 @@ static inline ScorerSum scorer_sum_args(const float* hidg, const float* u, const
     if (hidg != nullptr) {
         ss.hidg = hidg; ss.u = u; ss.items = items; ss.B = B; ss.NI = NI; ss.D = D; ss.hid = hid; ss.HG = ((3 + NI) * hid + 1 + 3) & ~3;
         ss.dW1 = dW1; ss.db1 = db1; ss.dW2 = dW2; ss.db2 = db2; ss.nblk = 2 * hid + (2 * hid + 1 + 31) / 32;
+        ss.front = B >= 1024 ? 1 : 0;
     }
     return ss;
 }

@@ -49,6 +49,17 @@ __device__ __forceinline__ unsigned long long match_bits(unsigned d, bool valid,
     return peers;
 }
 
+// The phases' LDS, handed in by the caller: launches of their own keep it as a static allocation (sortuniq.hip); riders alias the head of the
+// host kernel's dynamic allocation (the rider workgroups use nothing else of it) -- so a kernel that rides the 4 096-bin build (tables of
+// 2^20 rows and more: cfg 5's 10 M) does not add 48 KB of static LDS to every workgroup of its launch (round 6).
+// (the count phases: int hist[bins])
+template <int BINS> struct SortScatterLds {             // os_scatter_block
+    unsigned short woff[SORT_WAVES][BINS];              // per-wave digit counts, then running offsets inside the tile's bin
+    int tile_base[BINS];                                // output position of the tile's first key of every bin
+    int wsum[SORT_WAVES]; int pc[SORT_WAVES]; int pn[SORT_WAVES];
+};
+struct SortHeadsLds { int tile_s, excl_s; int wsum[SORT_WAVES]; };                           // os_heads_block
+
 // BINS: LDS is sized for 1024 bins when both digits have at most 10 bits (every table below 2^20 rows: 12 KB in the scatter) -- small
 // enough to share a CU with a one-workgroup-per-CU kernel of the main stream (the fused forward holds 144 of the 160 KB).
 // keys of the first pass as a function of the position: the list itself, or -- the one-launch step head, where the list is written by other
@@ -58,8 +69,7 @@ template <int BINS, class Keys>
 __device__ __forceinline__ void os_count_block(const int blk, const int nblk, const Keys keys, OsGeom g, int* __restrict__ state,
                                                                 int* __restrict__ counts0, int* __restrict__ stot0, int stot0_copy, int n_stot0,
                                                                 int* __restrict__ counts1, long long n_counts1, int* __restrict__ stot1,
-                                                                int n_stot1, int* __restrict__ hstatus) {
-    __shared__ int hist0[BINS];
+                                                                int n_stot1, int* __restrict__ hstatus, int* const hist0 /* LDS [BINS] */) {
     const int bins0 = 1 << g.bits;
     for (int d = threadIdx.x; d < bins0; d += SORT_THREADS) hist0[d] = 0;
     __syncthreads();
@@ -104,8 +114,7 @@ __device__ __forceinline__ void os_count_block(const int blk, const int nblk, co
 // 23 of its 34 us).  counts_1 by plain stores, stot_1 (zeroed by os_count_block) by one atomic per tile and non-empty bin.
 template <int BINS>
 __device__ __forceinline__ void os_count1_block(const int blk, const int* __restrict__ keys, OsGeom g, int* __restrict__ counts1,
-                                                int* __restrict__ stot1) {
-    __shared__ int hist1[BINS];
+                                                int* __restrict__ stot1, int* const hist1 /* LDS [BINS] */) {
     const int bins = 1 << g.bits;
     for (int d = threadIdx.x; d < bins; d += SORT_THREADS) hist1[d] = 0;
     __syncthreads();
@@ -134,10 +143,10 @@ template <bool COUNT_NEXT, int BINS>
 __device__ __forceinline__ void os_scatter_block(const int blk, const int nblk, const int* __restrict__ keys_in, const int* __restrict__ vals_in,
                                                                   int* __restrict__ keys_out, int* __restrict__ vals_out, OsGeom g,
                                                                   const int* __restrict__ counts, const int* __restrict__ stot, int nsup,
-                                                                  int* __restrict__ counts_next, int* __restrict__ stot_next) {
-    __shared__ unsigned short woff[SORT_WAVES][BINS];           // per-wave digit counts, then running offsets inside the tile's bin
-    __shared__ int tile_base[BINS];                             // output position of the tile's first key of every bin
-    __shared__ int wsum[SORT_WAVES];
+                                                                  int* __restrict__ counts_next, int* __restrict__ stot_next, SortScatterLds<BINS>& lds) {
+    unsigned short (&woff)[SORT_WAVES][BINS] = lds.woff;
+    int* const tile_base = lds.tile_base;
+    int* const wsum = lds.wsum;
     const int bins = 1 << g.bits;
     const unsigned mask = (unsigned)bins - 1u;
     const int w = wave_id(), lane = lane_id();
@@ -269,7 +278,7 @@ __device__ __forceinline__ void os_scatter_block(const int blk, const int nblk, 
         }
     }
     if (COUNT_NEXT) {           // the waves' carried counts: equal cells of the four waves merged, then one atomic each
-        __shared__ int pc[SORT_WAVES], pn[SORT_WAVES];
+        int* const pc = lds.pc; int* const pn = lds.pn;
         if (lane == 0) { pc[w] = pend_cell; pn[w] = pend_n; }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -291,10 +300,10 @@ __device__ __forceinline__ void os_scatter_block(const int blk, const int nblk, 
 constexpr unsigned OS_ST_AGG = 1u << 30, OS_ST_PRE = 2u << 30, OS_ST_VAL = (1u << 30) - 1u;
 __device__ __forceinline__ void os_heads_block(const int* __restrict__ keys, int n, int ntiles, int* __restrict__ state,
                                                                 unsigned* __restrict__ hstatus, int* __restrict__ n_uniq,
-                                                                int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of) {
-    __shared__ int tile_s, excl_s;
-
-    __shared__ int wsum[SORT_WAVES];
+                                                                int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of,
+                                                                SortHeadsLds& lds) {
+    int& tile_s = lds.tile_s; int& excl_s = lds.excl_s;
+    int* const wsum = lds.wsum;
     if (threadIdx.x == 0) tile_s = atomicAdd(&state[2], 1);
     __syncthreads();
     const int tile = tile_s;
@@ -371,29 +380,41 @@ struct SortPlan {
     long long n_counts1; int n_stot1, n_zero_a, stot0_copy;       // stot0: two copies of stot0_copy ints (see os_count_block)
 };
 
-// phase PHASE (1 .. 4) of the sort as block `blk` (< sp.nblk) of a 256-thread workgroup, chosen at compile time (kernels with dynamic
-// LDS carry ONE phase each: with the static LDS of two phases beside a
-// dynamic allocation hipcc 7.2 dies in instruction selection -- "Illegal instruction detected: Operand has incorrect register class
-// V_CMP_NE_U32_e32 0, $src_shared_base")
+// phase PHASE (1 .. 5) of the sort as block `blk` (< sp.nblk) of a 256-thread workgroup, chosen at compile time, on `lds_raw`: LDS of at
+// least sort_phase_lds_bytes<PHASE>() bytes that the rider workgroup owns (16-byte aligned).  The bin count follows the plan: 1 024 bins for
+// digits of at most 10 bits (every table below 2^20 rows), 4 096 otherwise (keys below 2^24).
+// (Kernels with dynamic LDS used to carry static LDS for ONE phase each: with the static LDS of two phases beside a dynamic allocation hipcc 7.2
+// dies in instruction selection -- "Illegal instruction detected: Operand has incorrect register class V_CMP_NE_U32_e32 0, $src_shared_base";
+// they alias their dynamic allocation now.)
+template <int PHASE> constexpr size_t sort_phase_lds_bytes() {
+    return PHASE == 5 ? sizeof(SortHeadsLds) : (PHASE == 2 || PHASE == 4) ? sizeof(SortScatterLds<OS_BINS_MAX>) : sizeof(int) * OS_BINS_MAX;
+}
 template <int BINS, int PHASE>
-__device__ __forceinline__ void sort_phase_ct(const SortPlan& sp, int blk) {
+__device__ __forceinline__ void sort_phase_bins(const SortPlan& sp, int blk, void* lds_raw) {
     // the riders' schedule, five phases: count 0, scatter 0, count 1, scatter 1, run heads
     if constexpr (PHASE == 1)
         os_count_block<BINS>(blk, sp.nblk, ArrayKeys{sp.idx}, sp.g0, sp.state, sp.counts0, sp.stot0, sp.stot0_copy, sp.n_zero_a, sp.counts1, sp.n_counts1, sp.stot1,
-                             sp.n_stot1, (int*)sp.hstatus);
+                             sp.n_stot1, (int*)sp.hstatus, (int*)lds_raw);
     else if constexpr (PHASE == 2)
         os_scatter_block<false, BINS>(blk, sp.nblk, sp.idx, sp.rows, sp.keys0, sp.vals0, sp.g0, sp.counts0,
-                                      sp.stot0 + (long long)(sp.state[3] & 1) * sp.stot0_copy, sp.nsup, nullptr, nullptr);
+                                      sp.stot0 + (long long)(sp.state[3] & 1) * sp.stot0_copy, sp.nsup, nullptr, nullptr, *(SortScatterLds<BINS>*)lds_raw);
     else if constexpr (PHASE == 3)
-        os_count1_block<BINS>(blk, sp.keys0, sp.g1, sp.counts1, sp.stot1);
+        os_count1_block<BINS>(blk, sp.keys0, sp.g1, sp.counts1, sp.stot1, (int*)lds_raw);
     else if constexpr (PHASE == 4)
-        os_scatter_block<false, BINS>(blk, sp.nblk, sp.keys0, sp.vals0, sp.keys1, sp.pos_sorted, sp.g1, sp.counts1, sp.stot1, sp.nsup, nullptr, nullptr);
+        os_scatter_block<false, BINS>(blk, sp.nblk, sp.keys0, sp.vals0, sp.keys1, sp.pos_sorted, sp.g1, sp.counts1, sp.stot1, sp.nsup, nullptr, nullptr,
+                                      *(SortScatterLds<BINS>*)lds_raw);
     else
-        os_heads_block(sp.keys1, sp.n, sp.nblk, sp.state, sp.hstatus, sp.n_uniq, sp.uniq_ids, sp.seg_off, sp.seg_of);
+        os_heads_block(sp.keys1, sp.n, sp.nblk, sp.state, sp.hstatus, sp.n_uniq, sp.uniq_ids, sp.seg_off, sp.seg_of, *(SortHeadsLds*)lds_raw);
+}
+template <int PHASE>
+__device__ __forceinline__ void sort_phase_ct(const SortPlan& sp, int blk, void* lds_raw) {
+    if constexpr (PHASE == 5) sort_phase_bins<1024, 5>(sp, blk, lds_raw);
+    else if (sp.g0.bits <= 10) sort_phase_bins<1024, PHASE>(sp, blk, lds_raw);        // (block-uniform; g0 has the wider digit)
+    else sort_phase_bins<OS_BINS_MAX, PHASE>(sp, blk, lds_raw);
 }
 
 // riders: a launch of the train step with `plan.nblk` extra 256-thread workgroups IN FRONT of its own (blockIdx < nblk) that run one
-// of the FIVE phases of the step's index sort (sort_phase_ct; 1024-bin instantiation: keys below 2^20); phase 0 = no rider
+// of the FIVE phases of the step's index sort (sort_phase_ct; keys below 2^24); phase 0 = no rider
 struct SortRider { SortPlan plan; int phase; };
 __device__ __forceinline__ int rider_blocks(const SortRider& r) { return r.phase ? r.plan.nblk : 0; }
 static inline int rider_blocks_host(const SortRider& r) { return r.phase ? r.plan.nblk : 0; }

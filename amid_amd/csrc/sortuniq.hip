@@ -248,7 +248,8 @@ __global__ __launch_bounds__(SORT_THREADS) void os_count_kernel(const int* __res
                                                                 int* __restrict__ counts0, int* __restrict__ stot0, int stot0_copy, int n_stot0,
                                                                 int* __restrict__ counts1, long long n_counts1, int* __restrict__ stot1,
                                                                 int n_stot1, int* __restrict__ hstatus) {
-    os_count_block<BINS>(blockIdx.x, gridDim.x, ArrayKeys{keys}, g, state, counts0, stot0, stot0_copy, n_stot0, counts1, n_counts1, stot1, n_stot1, hstatus);
+    __shared__ int hist[BINS];
+    os_count_block<BINS>(blockIdx.x, gridDim.x, ArrayKeys{keys}, g, state, counts0, stot0, stot0_copy, n_stot0, counts1, n_counts1, stot1, n_stot1, hstatus, hist);
 }
 template <bool COUNT_NEXT, int BINS>
 __global__ __launch_bounds__(SORT_THREADS) void os_scatter_kernel(const int* __restrict__ keys_in, const int* __restrict__ vals_in,
@@ -258,12 +259,14 @@ __global__ __launch_bounds__(SORT_THREADS) void os_scatter_kernel(const int* __r
                                                                   const int* __restrict__ state, int stot_copy) {
     // pass 0 reads the stot_0 copy this call fills (os_count_block)
     const int* st = COUNT_NEXT ? stot + (long long)(state[3] & 1) * stot_copy : stot;
-    os_scatter_block<COUNT_NEXT, BINS>(blockIdx.x, gridDim.x, keys_in, vals_in, keys_out, vals_out, g, counts, st, nsup, counts_next, stot_next);
+    __shared__ SortScatterLds<BINS> lds;
+    os_scatter_block<COUNT_NEXT, BINS>(blockIdx.x, gridDim.x, keys_in, vals_in, keys_out, vals_out, g, counts, st, nsup, counts_next, stot_next, lds);
 }
 __global__ __launch_bounds__(SORT_THREADS) void os_heads_kernel(const int* __restrict__ keys, int n, int ntiles, int* __restrict__ state,
                                                                 unsigned* __restrict__ hstatus, int* __restrict__ n_uniq,
                                                                 int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of) {
-    os_heads_block(keys, n, ntiles, state, hstatus, n_uniq, uniq_ids, seg_off, seg_of);
+    __shared__ SortHeadsLds lds;
+    os_heads_block(keys, n, ntiles, state, hstatus, n_uniq, uniq_ids, seg_off, seg_of, lds);
 }
 
 // Stable merge of `world` sorted lists of `len` keys each (list r = keys[r * len ..]): the merged position of entry (r, i) with
@@ -392,13 +395,12 @@ extern "C" int amid_sort_plan_bytes(void) { return (int)sizeof(SortPlan); }
 
 // The sort of amid_sort_unique_i32 / amid_sort_unique_rows_i32 (rows optional) as a PLAN: nothing is launched; launches of the train
 // step that take a plan + a phase (1 .. 4, in this order, each in a later launch of the same stream than the one before) run the
-// sort as extra workgroups of their own (keys below 2^20; AMID_ERR_UNSUPPORTED otherwise).  host_buf: amid_sort_plan_bytes().
+// sort as extra workgroups of their own (keys below 2^24 and at most OS_SUPER_MAX supertiles; AMID_ERR_UNSUPPORTED otherwise).  host_buf: amid_sort_plan_bytes().
 extern "C" int amid_sort_plan_pack(void* host_buf, const int* idx, const int* rows, int n_idx, long long n_rows, void* workspace,
                                    int* pos_sorted, int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq) {
     AMID_CHECK_ARG(host_buf && idx && workspace && pos_sorted && uniq_ids && seg_off && seg_of && n_uniq && n_idx > 0 && n_rows > 0);
     SortPlan sp;
     if (int e = make_plan(sp, idx, rows, n_idx, n_rows, workspace, pos_sorted, uniq_ids, seg_off, seg_of, n_uniq)) return e;
-    if (sp.g0.bits > 10) return AMID_ERR_UNSUPPORTED;           // riders carry the 1024-bin instantiation only (12 KB of LDS)
     *(SortPlan*)host_buf = sp;
     return AMID_OK;
 }

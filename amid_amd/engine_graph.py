@@ -108,8 +108,12 @@ class GraphMixin:
         self._ensure_opt_state()
         self.sync()
         fp = self.dense
-        return dict(step=self.step, seed=self.seed, data=fp.data.clone(), m=fp.m.clone(), v=fp.v.clone(), table=self.table.clone(),
-                    tm=self.table_m.clone(), tv=self.table_v.clone(), tl=self.table_last.clone())
+        # the copies are enqueued on the ENGINE's stream: on torch's they were unordered against the step the caller enqueues next (the
+        # warm-up of capture_train_step) -- with a table of a few GB the copy was still running when that step's optimizer moved rows, and
+        # restore() put a half-stepped table back (found by test_folded_step_matches_the_fifteen_launch_step at 4.3 M rows, round 6)
+        with torch.cuda.stream(self.stream):
+            return dict(step=self.step, seed=self.seed, data=fp.data.clone(), m=fp.m.clone(), v=fp.v.clone(), table=self.table.clone(),
+                        tm=self.table_m.clone(), tv=self.table_v.clone(), tl=self.table_last.clone())
 
     def restore(self, snap) -> None:
         fp = self.dense

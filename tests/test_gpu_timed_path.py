@@ -333,14 +333,15 @@ def test_timed_path_folded_step_vs_oracle(Bn, T, split):
     _timed_vs_oracle(Bn, T, 128, None, split, compact_min=None, pool=True)
 
 
-@pytest.mark.parametrize("Bn,T,split", [(256, 50, "mixed"), (200, 50, "one0"), (64, 33, "all0")])
+@pytest.mark.parametrize("Bn,T,split,n_items", [(256, 50, "mixed", 3000), (200, 50, "one0", 3000), (64, 33, "all0", 3000),
+                                                (256, 50, "mixed", 1_200_000), (700, 40, "mixed", 4_300_000)])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_folded_step_matches_the_fifteen_launch_step(Bn, T, split, use_graph):
-    """SasrecEngine.FUSED_TAIL on / off over the same pool: the step's inputs come out bit-identical (mirrored batch image, index list, live
+def test_folded_step_matches_the_fifteen_launch_step(Bn, T, split, n_items, use_graph):
+    """SasrecEngine.FUSED_TAIL on / off over the same pool (tables of 2^20 rows and more: the riders' sort in 4 096 bins, round 6): the step's inputs come out bit-identical (mirrored batch image, index list, live
     list), the first step's loss too (same forward), its gradients to rounding (the compact list's chunks cut the runs elsewhere, the
     position rows are summed in another order), and five steps -- rows that lag, rows that come back -- leave the same parameters to
     rounding."""
-    D, hid, n_items, K = 128, 32, 3000, 5
+    D, hid, K = 128, 32, 5
     P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=11 + Bn)
     batches = [split_batch(Bn, T, n_items, seed=900 + t, split=split) for t in range(3)]
     for t in (1, 2):                  # rows 1..40 only appear in the first batch: they lag and are caught up when the pool wraps
@@ -369,6 +370,9 @@ def test_folded_step_matches_the_fifteen_launch_step(Bn, T, split, use_graph):
             assert torch.equal(pl.in_pack, packed[t % 3])
             rec["loss"].append(float(pl.loss.item()))
             if t == 0:
+                U = int(pl.n_uniq.item())                # the step's sort: the distinct rows of the list it reduces over, ascending
+                src = pl.idx_c[:pl.n_compact] if (pl.tail2 or getattr(pl, "compact", False)) else pl.idx_all
+                assert torch.equal(pl.uniq_ids[:U].long(), torch.unique(src.long()))
                 rec["first"] = dict(idx=pl.idx_all.clone(), live=pl.live.clone(), table=dense_table_grad(eng, pl),
                                     **{name: eng.dense.view(name, eng.dense.grad).clone() for name in eng.dense.slots})
         eng.check_index_error(pl)
