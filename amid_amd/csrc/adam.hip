@@ -65,8 +65,13 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_pos_kernel(float* __res
                                                                     const StepState* __restrict__ stp, const SortRider rd) {
     // rider: the first workgroups run a phase of the step's index sort (sort_phases.h) beside the catch-up
     const int nrb = rider_blocks(rd);
-    __shared__ __attribute__((aligned(16))) int sort_hist[OS_BINS_MAX];
-    if ((int)blockIdx.x < nrb) { sort_phase_ct<1>(rd.plan, blockIdx.x, sort_hist); return; }
+    __shared__ __attribute__((aligned(16))) int sort_hist[OS_BINS_MAX];      // (16 KB: the 4 096-bin count, or the chain's 1 024-bin scatter)
+    static_assert(sizeof(SortScatterLds<1024>) <= sizeof(int) * OS_BINS_MAX, "the chained phases fit the count's histogram");
+    if ((int)blockIdx.x < nrb) {
+        if (rd.phase == SORT_CHAIN_PHASE) sort_chain_block(rd.plan, blockIdx.x, sort_hist);      // the whole sort (sort_phases.h)
+        else sort_phase_ct<1>(rd.plan, blockIdx.x, sort_hist);
+        return;
+    }
     const int bid = blockIdx.x - nrb, nbk = gridDim.x - nrb;
     __shared__ IdleCoef tab[COEF_TAB];
     __shared__ int any_lag;
@@ -897,9 +902,11 @@ static int catchup_positions(float* table, float* m, float* v, int* last, const 
     SortRider rd;
     rd.phase = 0;
     if (sort_plan != nullptr) {
-        if (sort_phase != 1) return AMID_ERR_UNSUPPORTED;          // this launch carries phase 1
+        if (sort_phase != 1 && sort_phase != SORT_CHAIN_PHASE) return AMID_ERR_UNSUPPORTED;      // this launch carries phase 1, or the whole sort
         rd.plan = *(const SortPlan*)sort_plan;
         rd.phase = sort_phase;
+        // the chain: 1 024-bin plans of at most SORT_CHAIN_MAX_BLOCKS tiles (every rider resident at once: sort_phases.h)
+        if (sort_phase == SORT_CHAIN_PHASE && (rd.plan.g0.bits > 10 || rd.plan.nblk > SORT_CHAIN_MAX_BLOCKS)) return AMID_ERR_UNSUPPORTED;
     }
     lazy_adam_catchup_pos_kernel<<<(int)blocks + rider_blocks_host(rd), 256, 0, (hipStream_t)stream>>>(table, m, v, last, idx, n_idx, D,
                                                                                      (const StepState*)step_state, rd);
@@ -912,7 +919,9 @@ extern "C" int amid_lazy_adam_catchup_positions_f32(float* table, float* m, floa
     return catchup_positions(table, m, v, last, idx, n_idx, D, step_state, nullptr, 0, stream);
 }
 
-// the same launch carrying phase `sort_phase` of a sort plan (amid_sort_plan_pack) as extra workgroups
+// the same launch carrying phase `sort_phase` of a sort plan (amid_sort_plan_pack) as extra workgroups: 1, or 6 = ALL five phases chained in this
+// one launch (keys below 2^20, at most 64 tiles = 131 072 indices: amid_sort_chain_max_indices; AMID_ERR_UNSUPPORTED otherwise)
+extern "C" int amid_sort_chain_max_indices(void) { return SORT_CHAIN_MAX_BLOCKS * SORT_TILE; }
 extern "C" int amid_lazy_adam_catchup_positions_sort_f32(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D,
                                                          const void* step_state, const void* sort_plan, int sort_phase, void* stream) {
     AMID_CHECK_ARG(sort_plan != nullptr);

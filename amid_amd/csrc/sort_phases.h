@@ -301,7 +301,7 @@ constexpr unsigned OS_ST_AGG = 1u << 30, OS_ST_PRE = 2u << 30, OS_ST_VAL = (1u <
 __device__ __forceinline__ void os_heads_block(const int* __restrict__ keys, int n, int ntiles, int* __restrict__ state,
                                                                 unsigned* __restrict__ hstatus, int* __restrict__ n_uniq,
                                                                 int* __restrict__ uniq_ids, int* __restrict__ seg_off, int* __restrict__ seg_of,
-                                                                SortHeadsLds& lds) {
+                                                                SortHeadsLds& lds, long long chain_base = -1) {
     int& tile_s = lds.tile_s; int& excl_s = lds.excl_s;
     int* const wsum = lds.wsum;
     if (threadIdx.x == 0) tile_s = atomicAdd(&state[2], 1);
@@ -353,7 +353,10 @@ __device__ __forceinline__ void os_heads_block(const int* __restrict__ keys, int
         if (lane == 0) {
             __hip_atomic_store(&hstatus[tile], OS_ST_PRE | (unsigned)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             excl_s = excl;
-            if (tile == ntiles - 1) { *n_uniq = excl + total; seg_off[excl + total] = n; state[3] ^= 1; }      // (the next call's stot_0 copy)
+            if (tile == ntiles - 1) {
+                *n_uniq = excl + total; seg_off[excl + total] = n; state[3] ^= 1;       // (the next call's stot_0 copy)
+                if (chain_base >= 0) state[7] = (int)((unsigned)chain_base + 4u * (unsigned)ntiles);      // (sort_chain_block: the next call's barrier base)
+            }
         }
     }
     __syncthreads();
@@ -411,6 +414,43 @@ __device__ __forceinline__ void sort_phase_ct(const SortPlan& sp, int blk, void*
     if constexpr (PHASE == 5) sort_phase_bins<1024, 5>(sp, blk, lds_raw);
     else if (sp.g0.bits <= 10) sort_phase_bins<1024, PHASE>(sp, blk, lds_raw);        // (block-uniform; g0 has the wider digit)
     else sort_phase_bins<OS_BINS_MAX, PHASE>(sp, blk, lds_raw);
+}
+
+// ALL FIVE phases in ONE launch (round 6): the plan's nblk rider workgroups run the phases back to back and meet at a barrier of their own
+// between them -- for the steps that have no five launches to ride in (the one-launch backward at T <= 32, BERT4Rec, the comp modules), whose
+// sort ran as twelve small launches on a side stream (a fork and a join per step: ~ 6 us of idle main stream each inside a replayed graph).
+// The riders are the launch's FIRST workgroups and there are at most SORT_CHAIN_MAX_BLOCKS of them: they are dispatched before any other
+// workgroup of the launch and need 12 KB of LDS each, so all of them are resident when the first one waits (the same assumption the
+// look-back of os_heads_block makes about earlier tiles).  Barrier: state[6] counts arrivals for ever (wrap-safe unsigned differences);
+// state[7] holds its value when the call began -- written by the call before (the last tile of the heads phase, when every rider is past the
+// last barrier); both start at zero with the workspace.  Memory: every rider's stores are released at agent scope before it arrives and
+// the CU's caches are invalidated after it leaves (a rider reads what riders on other XCDs wrote in the phase before; a build without the
+// two fences did not come back on the hardware).
+constexpr int SORT_CHAIN_MAX_BLOCKS = 64, SORT_CHAIN_PHASE = 6;
+__device__ __forceinline__ void sort_chain_barrier(int* __restrict__ state, unsigned base, unsigned target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add((unsigned*)&state[6], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while ((__hip_atomic_load((unsigned*)&state[6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - base) < target) __builtin_amdgcn_s_sleep(2);
+        __threadfence();
+    }
+    __syncthreads();
+}
+// lds_raw: sizeof(SortScatterLds<1024>) bytes (1 024-bin plans only: sp.g0.bits <= 10)
+__device__ __forceinline__ void sort_chain_block(const SortPlan& sp, int blk, void* lds_raw) {
+    const unsigned base = (unsigned)__hip_atomic_load(&sp.state[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned n = (unsigned)sp.nblk;
+    sort_phase_bins<1024, 1>(sp, blk, lds_raw);
+    sort_chain_barrier(sp.state, base, n);
+    sort_phase_bins<1024, 2>(sp, blk, lds_raw);
+    sort_chain_barrier(sp.state, base, 2 * n);
+    sort_phase_bins<1024, 3>(sp, blk, lds_raw);
+    sort_chain_barrier(sp.state, base, 3 * n);
+    sort_phase_bins<1024, 4>(sp, blk, lds_raw);
+    sort_chain_barrier(sp.state, base, 4 * n);
+    // (the heads phase: the tile that takes the LAST ticket also records the barrier counter's value for the next call)
+    os_heads_block(sp.keys1, sp.n, sp.nblk, sp.state, sp.hstatus, sp.n_uniq, sp.uniq_ids, sp.seg_off, sp.seg_of, *(SortHeadsLds*)lds_raw, (long long)base);
 }
 
 // riders: a launch of the train step with `plan.nblk` extra 256-thread workgroups IN FRONT of its own (blockIdx < nblk) that run one

@@ -247,6 +247,10 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         pl.riding = bool(bump_step and sparse and defer_sort and self.SORT_RIDERS and getattr(pl, "strip", False) and not pl.compact
                          and not self._seq_backward(pl)             # (the fused backward is one launch: three of the riders' hosts are gone)
                          and (shp.n_idx + 2047) // 2048 <= 2 * shp.Tenc and self._sort_plan(pl) is not None)
+        # ... or, for the steps without five launches to ride in (the one-launch backward at T <= 32, BERT4Rec, the comp modules): the WHOLE sort
+        # chained inside the catch-up launch (amid_lazy_adam_catchup_positions_sort_f32 phase 6) -- no side stream, no fork, no join
+        pl.chain = bool(bump_step and sparse and defer_sort and self.SORT_CHAIN and not pl.riding and not pl.compact
+                        and shp.n_idx <= lib().value("amid_sort_chain_max_indices") and self.n_rows <= (1 << 20) and self._sort_plan(pl) is not None)
         ent = self.input_pool(pl)
         # the live-sequence step on an input pool in twelve launches (FUSED_TAIL): packing, catch-up and phase 1 of the sort of the COMPACT
         # index list are one launch; the later phases ride in the backward strips and the weight gradients; no embedding-backward launch
@@ -268,7 +272,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             else:
                 L.call("amid_step_head_f32", *head, s)
             self.step += 1
-            pl.compact, pl.riding = True, True
+            pl.compact, pl.riding, pl.chain = True, True, False
             self._sort_owed = False
             return
         if ent is not None:
@@ -284,7 +288,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                        pl.in_words, shp.B, shp.T, shp.NI - 1, self.n_rows, pl.idx_all.data_ptr(), pl.err.data_ptr(),
                        self.step_state.data_ptr(), s)
             self.step += 1
-            if sparse and pl.riding:
+            if sparse and (pl.riding or pl.chain):
                 self._sort_owed = False
             elif sparse:
                 self.ev_idx.record(self.stream)
@@ -302,7 +306,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                    self.step_state.data_ptr() if bump_step else None, s)
         if bump_step:
             self.step += 1
-        if sparse and pl.riding:
+        if sparse and (pl.riding or pl.chain):
             self._sort_owed = False
         elif sparse:
             self.ev_idx.record(self.stream)       # fork point: the index list is complete
@@ -341,6 +345,10 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self._sort_pending = False
 
     SORT_RIDERS = True
+    # the whole sort chained inside the catch-up launch where the riders have no five launches (round 6).  Off by default: the chain takes ~ 45 us
+    # (five phases, four barriers with agent-scope fences), which the catch-up hides only when it replays long gaps -- cfg 4's real epoch in its
+    # steady state 0.2383 -> 0.2331 ms, but + 17 % on a T 20 step without lagging rows and + 5 % on BERT4Rec (DESIGN_HISTORY.md, "Round 6")
+    SORT_CHAIN = False
     # compute = "bf16": the weight gradients' products on the bf16 matrix cores too (amid_sas_wgrad_rows_f32 mma_bf16); 0: fp32 products
     BF16_WGRAD = True
     # compute = "fp32": the weight gradients' products on the bf16 matrix cores at fp32 accuracy -- every operand element as three bf16
@@ -603,8 +611,14 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         if getattr(pl, "tail2", False):           # the step head replayed them
             pl.fold_catchup = False
             return
-        pl.fold_catchup = self._fold_catchup(pl)
+        chain = getattr(pl, "chain", False)
+        pl.fold_catchup = self._fold_catchup(pl) and not chain       # (the chain rides in the catch-up's own launch)
         if pl.fold_catchup:
+            return
+        if chain:                                 # the step's whole sort rides here (five phases, the riders' own barrier between them)
+            lib().call("amid_lazy_adam_catchup_positions_sort_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
+                       self.table_last.data_ptr(), pl.idx_all.data_ptr(), pl.shape.n_idx, self.D, self.step_state.data_ptr(),
+                       self._sort_plan(pl), 6, self.s)
             return
         if getattr(pl, "riding", False):          # phase 1 of the step's sort rides here
             lib().call("amid_lazy_adam_catchup_positions_sort_f32", self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),

@@ -163,7 +163,11 @@ int amid_lazy_adam_catchup_f32(float* table, float* m, float* v, int* last, cons
 /* catch-up driven by the raw (non-unique) index list: needs no sort, so the sort can overlap the forward pass */
 int amid_lazy_adam_catchup_positions_f32(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D,
                                          const void* step_state, void* stream);
-/* ... carrying phase 1 of a sort plan (amid_sort_plan_pack) as extra workgroups in front of its own */
+/* ... carrying phase 1 of a sort plan (amid_sort_plan_pack) as extra workgroups in front of its own -- or, sort_phase = 6, ALL FIVE phases
+ * chained in this one launch (the riders meet at a barrier of their own between the phases): for steps without five launches to ride in, whose
+ * sort ran as a dozen small launches on a side stream.  The chain takes plans with keys below 2^20 over at most
+ * amid_sort_chain_max_indices() indices; AMID_ERR_UNSUPPORTED otherwise. */
+int amid_sort_chain_max_indices(void);
 int amid_lazy_adam_catchup_positions_sort_f32(float* table, float* m, float* v, int* last, const int* idx, int n_idx, int D,
                                               const void* step_state, const void* sort_plan, int sort_phase, void* stream);
 int amid_lazy_adam_apply_f32(float* table, float* m, float* v, int* last, const int* uniq_ids, const int* n_uniq, int n_uniq_max,

@@ -1013,3 +1013,57 @@ def test_graphs_of_four_steps_equal_single_step_replays():
         out.append({k: v.cpu().clone() for k, v in eng.state_dict().items()})
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
+
+
+@pytest.mark.parametrize("Bn,T,n_items", [(256, 20, 3000), (200, 20, 60_000), (64, 12, 900_000), (256, 32, 3000), (1100, 20, 3000), (2900, 20, 3000)])
+@pytest.mark.parametrize("use_graph", [False, True, 4])
+def test_sort_chained_in_the_catchup_launch_equals_the_side_stream_sort(Bn, T, n_items, use_graph):
+    """SasrecEngine.SORT_CHAIN (round 6): where the riders have no five launches (the one-launch backward at T <= 32) the step's WHOLE index sort
+    runs inside the catch-up launch -- its rider workgroups chain the five phases with a barrier of their own -- instead of a dozen launches on
+    a side stream.  Same outputs (the distinct rows ascending, their runs, the positions in list order inside a run), and therefore the same
+    step bit for bit: eight steps over a three-batch pool, eager and replayed."""
+    D, hid, K = 128, 32, 8
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=5 + Bn)
+    batches = [split_batch(Bn, T, n_items, seed=700 + t, split="mixed") for t in range(3)]
+    out = {}
+    for chain in (False, True):
+        eng = make_engine(P, T, lr=1e-3, seed=31)
+        eng.SORT_CHAIN = chain
+        eng.SEQ_BACKWARD = "1"              # (the one-launch backward whatever the batch: B 1100 = 23 rider workgroups, B 2900 = 60)
+        eng.COMPACT_MIN_IDX = 1 << 30       # (... over the full index list)
+        pl = eng.plan(Bn, T, 2, need_grad=True)
+        packed = []
+        for b in batches:
+            cu = {k: v.cuda() for k, v in b.items()}
+            packed.append(eng.pack_batch(pl, cu["i_node"], cu["neg_samples"], cu["seq_d1"], cu["seq_d2"], cu["label"], cu["domain_id"]))
+        eng.set_input_pool(pl, torch.stack(packed))
+        if use_graph:
+            eng.capture_train_step(pl)
+        if use_graph == 4:
+            eng.capture_train_steps(pl, 4)       # (what the train loop and bench.py replay: graphs of four steps -- checked after each graph)
+        rec = dict(loss=[])
+        for t in range(K if use_graph != 4 else K // 4):
+            if use_graph == 4:
+                eng.replay_train_steps(pl, 4)
+            elif use_graph:
+                eng.replay_train_step(pl)
+            else:
+                eng.enqueue_train_step(pl)
+            eng.sync()
+            assert pl.chain == chain and not pl.tail2 and not pl.riding, "the shape was chosen for the one-launch backward: no riders, no fold"
+            src = pl.idx_all.long()
+            U = int(pl.n_uniq.item())
+            want_u, cnt = torch.unique(src, return_counts=True)
+            assert U == want_u.numel() and torch.equal(pl.uniq_ids[:U].long(), want_u), t
+            so = pl.seg_off[:U + 1].long()
+            assert torch.equal(so[1:] - so[:-1], cnt), t
+            assert torch.equal(pl.pos_sorted[:src.numel()].long(), torch.sort(src, stable=True).indices), t
+            rec["loss"].append(float(pl.loss.item()))
+        eng.check_index_error(pl)
+        eng.flush_table()
+        eng.sync()
+        rec["params"] = {k: v.clone() for k, v in eng.state_dict().items()}
+        out[chain] = rec
+    assert out[False]["loss"] == out[True]["loss"], (out[False]["loss"], out[True]["loss"])
+    for k, want in out[False]["params"].items():
+        assert torch.equal(out[True]["params"][k], want), k
