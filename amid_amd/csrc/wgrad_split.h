@@ -20,7 +20,7 @@ __device__ __forceinline__ float f4comp_w(const float4& v, int i) { return i == 
 // not in quarters: with that swizzle each group's 16 fragments cover the 64 banks once.  (Round 4's first layout -- 80 bytes per
 // column, no swizzle, derived for contiguous quarters -- read every fragment in 8 LDS cycles instead of 4: SQ_LDS_BANK_CONFLICT was
 // half of SQ_LDS_IDX_ACTIVE, and the fragment reads of a chunk held the LDS longer than its matrix instructions hold the pipes.)
-// A wave's 4-byte staging writes (lane = column quad & 3, row pair) are 2-way, which a ds_write_b32 hides.  56 KB of LDS, two
+// A wave's 4-byte staging writes (lane = column quad & 3, row pair): see wr_j below.  56 KB of LDS, two
 // workgroups per CU as sas_wgrad_kernel.
 // Two chunks of loads stay in flight per thread (a chunk's 48 matrix instructions per wave are too short to hide a load).
 // Measured (MI355X, 2 layers, B 256 x T 50 with the live-row hint, 21 splits, replayed): 46 us with six pairs, 56 with nine, against 69
@@ -116,6 +116,19 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
     };
     // this thread's 4-byte slot in column 4 cq (+ j columns): k-group rr >> 2 of the column, swizzled (columns 4 cq .. 4 cq + 3 share pi)
     const int wr_off = 4 * cq * WGS_COL_BYTES + 16 * ((rr >> 2) ^ wgs_pi(cq & 3)) + 4 * (rr & 3);
+    // A column is 64 bytes = 16 banks, so column n lies in bank group n & 3: if every lane wrote its column 4 cq + j in step j, the four column
+    // quads of a wave would meet in ONE group -- 32 lanes of a pass on 16 banks, every staging write 2-way (23 % of the LDS cycles of the
+    // launch were conflicts).  Lane (cq & 3 = c) writes its columns in the order j + c instead: the pass covers 32 distinct banks (round 6).
+    const int wrot = lane & 3;
+    int wr_j[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr_j[j] = wr_off + ((j + wrot) & 3) * WGS_COL_BYTES;
+    auto rot4 = [&](const float4& v) {                  // component j of the result = component (j + wrot) & 3 of v
+        float4 r = v;
+        if (wrot & 1) r = make_float4(r.y, r.z, r.w, r.x);
+        if (wrot & 2) r = make_float4(r.z, r.w, r.x, r.y);
+        return r;
+    };
     const int rd_sw = 16 * (gq ^ wgs_pi(i >> 2));
     const int rd_y = (w * 16 + i) * WGS_COL_BYTES + rd_sw, rd_x = i * WGS_COL_BYTES + rd_sw;
     auto chunk = [&](int c0, float4 (&py)[2], float4 (&px)[2], float2 (&ls)[2]) {       // stage chunk c0 (in py / px), refill them with chunk c0 + 2, multiply
@@ -140,12 +153,13 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
 #endif
         }
         bsum = f4add(bsum, f4add(py[0], py[1]));
+        const float4 ry0 = rot4(py[0]), ry1 = rot4(py[1]), rx0 = rot4(px[0]), rx1 = rot4(px[1]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const WgSplit2 sy = wg_split3(f4comp_w(py[0], j), f4comp_w(py[1], j));
-            const WgSplit2 sx = wg_split3(f4comp_w(px[0], j), f4comp_w(px[1], j));
-            char* const yq = Yt + wr_off + j * WGS_COL_BYTES;
-            char* const xq = Xt + wr_off + j * WGS_COL_BYTES;
+            const WgSplit2 sy = wg_split3(f4comp_w(ry0, j), f4comp_w(ry1, j));
+            const WgSplit2 sx = wg_split3(f4comp_w(rx0, j), f4comp_w(rx1, j));
+            char* const yq = Yt + wr_j[j];
+            char* const xq = Xt + wr_j[j];
             *reinterpret_cast<unsigned*>(yq) = sy.hi; *reinterpret_cast<unsigned*>(yq + PLANE) = sy.mid; *reinterpret_cast<unsigned*>(yq + 2 * PLANE) = sy.lo;
             *reinterpret_cast<unsigned*>(xq) = sx.hi; *reinterpret_cast<unsigned*>(xq + PLANE) = sx.mid; *reinterpret_cast<unsigned*>(xq + 2 * PLANE) = sx.lo;
         }
