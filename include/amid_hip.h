@@ -89,7 +89,8 @@ int amid_sort_unique_i32(const int* idx, int n_idx, long long n_rows, void* work
  * amid_lazy_adam_catchup_positions_sort_f32, 2 (scatter 0) amid_sas_strip_ffn_bwd_sort_f32, 3 (digit-1 counts) / 4 (scatter 1)
  * amid_sas_strip_qkv_bwd_sort_f32 with / without the fused feed-forward backward, 5 (run heads) amid_embed_bwd_sort_f32; any other
  * phase number: AMID_ERR_UNSUPPORTED.  host_buf: amid_sort_plan_bytes() bytes; rows optional (as amid_sort_unique_rows_i32);
- * workspace as above.  AMID_ERR_UNSUPPORTED for keys of 2^20 and more. */
+ * workspace as above.  Keys below 2^24 (digits of up to 12 bits: the rider workgroups run the 4 096-bin build on the head of their host
+ * kernel's dynamic LDS; round 6 -- before: below 2^20); AMID_ERR_UNSUPPORTED beyond, and for lists of more than 256 supertiles. */
 int amid_sort_plan_bytes(void);
 int amid_sort_plan_pack(void* host_buf, const int* idx, const int* rows, int n_idx, long long n_rows, void* workspace, int* pos_sorted,
                         int* uniq_ids, int* seg_off, int* seg_of, int* n_uniq);
