@@ -751,7 +751,7 @@ static int seqn_launch_px(const SeqFwdArgs& a, const SeqGeom& sg, void* stream, 
     constexpr size_t lds = (size_t)(3 * (D * D / 2) + WPS * XpStrip<D>::FLOATS + 2 * WPS * NS * 16) * sizeof(float);
     const int grid = sg.live != nullptr ? sg.B : 2 * sg.B;
     if (head != nullptr) {
-        if constexpr (WPS == 4 && NS == 2) {              // (the one build launch_seqn_fwd asks the head for: T 33 ... 64)
+        if constexpr ((WPS == 4 && NS == 2) || (WPS == 2 && NS == 4)) {      // (the builds launch_seqn_fwd asks the head for: T 33 ... 64; 17 ... 32, round 6)
             // (the head's carve inside the three plane slots, its rows T <= 16 HEAD_CHUNK / 2, a workgroup per LIVE sequence = per sample)
             if (sg.live == nullptr || head_lds_floats(D, head->hid) > (size_t)3 * (D * D / 2) || sg.T > 16 * (HEAD_CHUNK / 2) || head->D != D ||
                 head->B != sg.B || head->T != sg.T)
@@ -811,9 +811,9 @@ static int seqn_launch(const SeqFwdArgs& a, const SeqGeom& sg, void* stream, con
 int launch_seqn_fwd(const SeqFwdArgs& a, const SeqGeom& sg, int D, int variant, void* stream, const HeadArgs* head) {
     const int T = sg.T;
     if (head != nullptr) {
-        if (D != 128 || T <= 32 || T > 64 || (variant != 0 && variant != 42)) return AMID_ERR_UNSUPPORTED;
+        if (D != 128 || T <= 16 || T > 64 || (variant != 0 && variant != (T <= 32 ? 24 : 42))) return AMID_ERR_UNSUPPORTED;
         if (a.train && spec_bits(a.spec) != 1) return AMID_ERR_UNSUPPORTED;
-        return seqn_launch<4, 2>(a, sg, stream, head);
+        return T <= 32 ? seqn_launch<2, 4>(a, sg, stream, head) : seqn_launch<4, 2>(a, sg, stream, head);
     }
     if (a.train && spec_bits(a.spec) != 1) return AMID_ERR_UNSUPPORTED;      // part_dropout: the one-bit keep decisions of p = 0.5 (the reference's rate)
     const int wps = T <= 16 ? 1 : T <= 32 ? 2 : 4;

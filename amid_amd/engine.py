@@ -345,6 +345,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self._sort_pending = False
 
     SORT_RIDERS = True
+    FOLD_SHORT = True            # 16 < T <= 32 on an input pool: the folded strips step instead of the one-launch backward (round 6)
     # the whole sort chained inside the catch-up launch where the riders have no five launches (round 6).  Off by default: the chain takes ~ 45 us
     # (five phases, four barriers with agent-scope fences), which the catch-up hides only when it replays long gaps -- cfg 4's real epoch in its
     # steady state 0.2383 -> 0.2331 ms, but + 17 % on a T 20 step without lagging rows and + 5 % on BERT4Rec (DESIGN_HISTORY.md, "Round 6")
@@ -378,6 +379,10 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             return True
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
         if pl.shape.Tenc <= 32:         # short sequences: the strip launches fill a third of the chip, a workgroup per sequence all of it
+            # ... unless the step folds (round 6; 16 < T: the head rides on the forward's tail): the strips host the riders, the gather and the
+            # embedding backward ride too and no side stream forks -- cfg 4's real epoch 238.4 -> 229 us per step (profiles/tools/trace_cfg4.sh)
+            if self.FOLD_SHORT and pl.shape.Tenc > 16 and self.D == 128 and self._folded_step_shape(pl):
+                return False
             return pl.shape.B <= n_cu
         if self.D != 128:               # D 64 at T 50: the five strip launches win (B 512: 0.352 against 0.393 ms; B 256: a tie)
             return False
@@ -719,7 +724,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                     # the folded step: qn / y are not stored -- row statistics instead (pl.ln_stat); the weight gradients rebuild them
                     # (c: x, 12 parameter families, qn, q, k, v, o, stats, r, y, h)
                     gather = (self.table.data_ptr(), pl.idx_all.data_ptr(), fp.ptr("sac1.pos_emb.weight"), fp.ptr("sac2.pos_emb.weight"))
-                    if (self.HEAD_ON_FWD and getattr(self, "_fuse_head", False) and with_loss and not sum_loss and 32 < T <= 64
+                    if (self.HEAD_ON_FWD and getattr(self, "_fuse_head", False) and with_loss and not sum_loss and 16 < T <= 64
                             and self.hid <= 32 and NI <= 64):
                         # ... and a live sequence is a sample: its workgroup finishes with the sample's head (forward + loss + backward,
                         # what amid_head_fwd_bwd_own_vec_f32 does in enqueue_backward otherwise); the last layer's output is not stored

@@ -328,7 +328,8 @@ def _timed_vs_oracle(Bn, T, D, build, split, compact_min, seq_backward=None, poo
 # splits leave a domain without any live sequence (all0 / all1) or with one (one0); B 1100 = the pad run spans ~800 chunks; B 5 = a single
 # chunk-crossing run at most.
 @pytest.mark.parametrize("Bn,T,split", [(256, 50, "mixed"), (256, 50, "all0"), (256, 50, "all1"), (200, 50, "one0"), (250, 40, "mixed"), (300, 40, "mixed"),
-                                        (512, 50, "mixed"), (64, 33, "mixed"), (1100, 50, "mixed"), (37, 47, "mixed"), (5, 64, "all1"), (130, 64, "one0")])
+                                        (512, 50, "mixed"), (64, 33, "mixed"), (1100, 50, "mixed"), (37, 47, "mixed"), (5, 64, "all1"), (130, 64, "one0"),
+                                        (256, 20, "mixed"), (200, 32, "one0"), (64, 17, "mixed"), (300, 24, "all1")])      # (16 < T <= 32: folded since round 6)
 def test_timed_path_folded_step_vs_oracle(Bn, T, split):
     _timed_vs_oracle(Bn, T, 128, None, split, compact_min=None, pool=True)
 
@@ -403,7 +404,8 @@ def test_folded_step_matches_the_fifteen_launch_step(Bn, T, split, n_items, use_
         assert rel_l2(got, want) < 1e-3, (k, rel_l2(got, want), far)
 
 
-@pytest.mark.parametrize("Bn,T,split", [(256, 50, "mixed"), (200, 64, "one0"), (37, 33, "all0"), (300, 40, "mixed")])
+@pytest.mark.parametrize("Bn,T,split", [(256, 50, "mixed"), (200, 64, "one0"), (37, 33, "all0"), (300, 40, "mixed"), (256, 20, "mixed"), (130, 32, "one0"),
+                                        (64, 17, "all1")])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_head_on_the_forward_workgroups_is_bit_identical_to_its_own_launch(Bn, T, split, use_graph):
     """SasrecEngine.HEAD_ON_FWD on / off over the same pool: amid_sas_seq_fwd_split_lnstat_head_f32 runs the head's code on the rows the
@@ -533,7 +535,8 @@ def test_optimizer_in_the_gradient_tail_is_bit_identical_to_its_own_launch(Bn, T
         assert torch.equal(b["params"][k], want), (k, rel_l2(b["params"][k], want))
 
 
-@pytest.mark.parametrize("Bn,T,split,head_on_fwd", [(256, 50, "mixed", True), (200, 64, "one0", True), (37, 33, "all0", True), (300, 40, "mixed", False)])
+@pytest.mark.parametrize("Bn,T,split,head_on_fwd", [(256, 50, "mixed", True), (200, 64, "one0", True), (37, 33, "all0", True), (300, 40, "mixed", False),
+                                                    (256, 20, "mixed", True), (100, 29, "one0", True)])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_gather_in_the_forward_prologue_is_bit_identical_to_its_own_launch(Bn, T, split, head_on_fwd, use_graph):
     """SasrecEngine.GATHER_ON_FWD on / off over the same pool: the forward's workgroups build their own input rows -- table[id] + pos, the row's
