@@ -807,6 +807,17 @@ int amid_sas_strip_qkv_bwd_emb_f32(const float* dq, const float* dk, const float
                                    const float* const* wqT, const float* const* wkT, const float* const* wvT, float ln_eps, int B, int T, int D,
                                    const int* live, float* dx, float* ln_part, const unsigned char* emb_tmq, const void* step_state, int train,
                                    float emb_p_drop, const void* sort_plan, int sort_phase, int mma_bf16, void* stream);
+/* amid_sas_strip_ffn_bwd_f32 (mma_bf16 = 3) as the N-split build on producer-side pieces (csrc/sasrec_strip_px.hip, round 6): eight waves per
+ * 64-row tile -- four strips x two column parts --, the chain's operands cross the parts through LDS as bf16 pieces, the three-plane images of
+ * the TRANSPOSED weights stream through three plane slots (the forward's machinery, amid_sas_seq_fwd_split_f32).  w1T / w2T / woT: per domain,
+ * the images ([3][D][D] bf16).  ln_stat: the forward's row statistics of the layer ([2 B T][4], LN2's mean and rstd at +2) or NULL.
+ * sort_plan: optional rider (phase 2).  D = 128, p_drop = 0.5 or eval.  Agrees with the strip build to rounding (the LayerNorm backward's row
+ * sums are added part by part). */
+int amid_sas_strip_ffn_bwd_px_f32(const float* dxo, const unsigned char* tmq, const float* h, const float* r, const float* const* ln_w,
+                                  const float* const* w1T, const float* const* w2T, const float* const* woT, float ln_eps, int B, int T, int D,
+                                  const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
+                                  float* dr, float* d_o, float* ln_part, const float* ln_stat, const void* sort_plan, int sort_phase,
+                                  void* stream);
 /* amid_sas_wgrad_rows_f32 (mma_bf16 = 3, D = 128) carrying the LAST phase (5: run heads) of a sort plan as extra workgroups */
 int amid_sas_wgrad_rows_sort_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
                                  float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, const void* sort_plan,

@@ -280,3 +280,75 @@ def test_strip_backward_on_bf16_pieces_has_fp32_accuracy(B, T, live):
         assert torch.isfinite(a).all(), i
         e = float((a - b).abs().max() / (b.abs().max() + 1e-30))
         assert e < 4e-6, (i, e)
+
+
+@pytest.mark.parametrize("B,T", [(64, 50), (37, 20), (256, 50), (300, 33)])
+@pytest.mark.parametrize("live", [None, "mixed"])
+@pytest.mark.parametrize("with_stat", [False, True])
+def test_strip_backward_n_split_build_on_pieces_matches_the_strip_build(B, T, live, with_stat):
+    """csrc/sasrec_strip_px.hip (round 6): the feed-forward / out-projection backward chain with two waves per strip -- each owning half the
+    output columns of every product, operands crossing as bf16 pieces -- against the strip build on the same three-plane weight images:
+    every output within 4e-6 of its tensor's largest entry (the LayerNorm backward's row sums are added part by part), with the row
+    statistics recomputed from r or taken from the forward's ln_stat array; the same bits on every repetition."""
+    D = 128
+    c = Ctx(B, T, D, seed=B * 11 + T, live=live)
+    L, pa, s = c.L, c.pa, c.s
+    P = lambda t: pa([t[0].data_ptr(), t[1].data_ptr()])      # noqa: E731
+    lo = live is not None
+    part_s = lambda: torch.full((2 * c.stpg, 2, D), float("nan"), device="cuda")      # noqa: E731
+    lnw = c.vec(1.0)
+    dxo, h, r = c.act(live_only=lo), c.act().relu(), c.act()
+    mats = [c.mat() for _ in range(3)]                   # w1T, w2T, woT
+    img = torch.empty(6, 3, D * D, dtype=torch.bfloat16, device="cuda")
+    L.call("amid_sas_weights_bf16_planes", pa([m[g].data_ptr() for m in mats for g in (0, 1)]), 6, D, 0, 3, img.data_ptr(), s)
+    I = lambda k: pa([img[2 * k].data_ptr(), img[2 * k + 1].data_ptr()])      # noqa: E731
+    stat = torch.zeros(r.shape[0], 4, device="cuda")
+    mean = r.mean(1)
+    stat[:, 2] = mean
+    stat[:, 3] = 1.0 / torch.sqrt(((r - mean[:, None]) ** 2).mean(1) + 1e-8)
+
+    def run(px):
+        out = [c.out() for _ in range(4)]
+        pg = part_s()
+        if px:
+            L.call("amid_sas_strip_ffn_bwd_px_f32", dxo.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), I(0), I(1), I(2), 1e-8,
+                   B, T, D, c.lp(), 1, c.st.data_ptr(), 1, 0.5, *[t.data_ptr() for t in out], pg.data_ptr(), stat.data_ptr() if with_stat else None,
+                   None, 0, s)
+        else:
+            L.call("amid_sas_strip_ffn_bwd_f32", dxo.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), I(0), I(1), I(2), 1e-8,
+                   B, T, D, c.lp(), 1, c.st.data_ptr(), 1, 0.5, *[t.data_ptr() for t in out], pg.data_ptr(), 3, s)
+        torch.cuda.synchronize()
+        return out + [pg]
+    ref, got = run(False), run(True)
+    rl = c.row_live.cuda()
+    for rep in range(10 if (B, T) == (256, 50) else 2):
+        again = run(True)
+        for i, (a, b) in enumerate(zip(again, got)):
+            a, b = (a[rl], b[rl]) if i < 4 else (a, b)
+            assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)), (rep, i)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        if i < 4:
+            a, b = a[rl].double(), b[rl].double()
+        else:
+            ok = torch.isfinite(b)
+            assert bool((torch.isfinite(a) == ok).all()), i
+            a, b = a[ok].double(), b[ok].double()
+        assert torch.isfinite(a).all(), i
+        e = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        assert e < 4e-6, (i, e)
+    if (B, T, with_stat) == (256, 50, True) and live:
+        def timeit(fn, n=50):
+            for _ in range(5): fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n): fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / n
+        out = [c.out() for _ in range(4)]
+        pg = part_s()
+        t_strip = timeit(lambda: L.call("amid_sas_strip_ffn_bwd_f32", dxo.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), I(0), I(1), I(2), 1e-8,
+                                        B, T, D, c.lp(), 1, c.st.data_ptr(), 1, 0.5, *[t.data_ptr() for t in out], pg.data_ptr(), 3, s))
+        t_px = timeit(lambda: L.call("amid_sas_strip_ffn_bwd_px_f32", dxo.data_ptr(), c.tmq.data_ptr(), h.data_ptr(), r.data_ptr(), P(lnw), I(0), I(1), I(2), 1e-8,
+                                     B, T, D, c.lp(), 1, c.st.data_ptr(), 1, 0.5, *[t.data_ptr() for t in out], pg.data_ptr(), stat.data_ptr(), None, 0, s))
+        print(f"PXTIME strip_ffn_bwd: strip build {t_strip:.1f} us, n-split on pieces {t_px:.1f} us (launch-to-launch, eager)")
