@@ -42,6 +42,7 @@ struct EvalHeadArgs {
 };
 
 constexpr int EVAL_THREADS = 512;
+typedef float ev_v2 __attribute__((ext_vector_type(2)));
 
 // u_s[D] (LDS) = mean over T of LN_last of the own sequence's rows, by threads 0..255 in lnmean_rows' order (8 row groups of 32 lanes, rows
 // rg + 8 i, chunks of 64 rows); red [8][D] LDS
@@ -165,11 +166,23 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_head_fast_kernel(const Eval
     const int w = wave_id(), lane = lane_id();
     const int part = lane & 7, jb = lane >> 3;
     // this lane's 4 x 16 weights of the item half: W1[4 jb + jj][D + 4 part + 32 k + c] (issued first: they fly during the LayerNorm)
-    float4 wt[4][4];
+    // (held as PAIRS of hidden units -- wp[pr][k][c] = (W1[4 jb + 2 pr][..], W1[4 jb + 2 pr + 1][..]) -- so that two of the four chains advance in one
+    // v_pk_fma_f32: the vector pipe's packed rate; every chain keeps its own order of additions)
+    ev_v2 wp[2][4][4];
+    {
+        float4 wt[4][4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wt[jj][k] = ld4(a.w1 + (long long)(4 * jb + jj) * 2 * D + D + 4 * part + 32 * k);
+            for (int k = 0; k < 4; ++k) wt[jj][k] = ld4(a.w1 + (long long)(4 * jb + jj) * 2 * D + D + 4 * part + 32 * k);
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                wp[pr][k][0] = ev_v2{wt[2 * pr][k].x, wt[2 * pr + 1][k].x}; wp[pr][k][1] = ev_v2{wt[2 * pr][k].y, wt[2 * pr + 1][k].y};
+                wp[pr][k][2] = ev_v2{wt[2 * pr][k].z, wt[2 * pr + 1][k].z}; wp[pr][k][3] = ev_v2{wt[2 * pr][k].w, wt[2 * pr + 1][k].w};
+            }
+    }
     // the candidates of this wave: n = w + 8 i (round r takes i = 8 r .. 8 r + 7); lane l of a round loads float4 (l & 31) of candidates 2 q + (l >> 5)
     const int* ids = a.ids + (long long)b * NI;
     const int per_wave = (NI - w + 7) / 8;                      // candidates of this wave
@@ -206,16 +219,16 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_head_fast_kernel(const Eval
 #pragma unroll
         for (int i = 0; i < EV_BATCH; ++i) {                    // (a round's tail past per_wave scores the last row again: never stored)
             const float* ir = sl + i * D;
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            ev_v2 a01 = ev_v2{0.f, 0.f}, a23 = ev_v2{0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float4 it = ld4(ir + 4 * part + 32 * k);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    acc[jj] = fmaf(wt[jj][k].x, it.x, acc[jj]); acc[jj] = fmaf(wt[jj][k].y, it.y, acc[jj]);
-                    acc[jj] = fmaf(wt[jj][k].z, it.z, acc[jj]); acc[jj] = fmaf(wt[jj][k].w, it.w, acc[jj]);
-                }
+                a01 = __builtin_elementwise_fma(wp[0][k][0], ev_v2{it.x, it.x}, a01); a23 = __builtin_elementwise_fma(wp[1][k][0], ev_v2{it.x, it.x}, a23);
+                a01 = __builtin_elementwise_fma(wp[0][k][1], ev_v2{it.y, it.y}, a01); a23 = __builtin_elementwise_fma(wp[1][k][1], ev_v2{it.y, it.y}, a23);
+                a01 = __builtin_elementwise_fma(wp[0][k][2], ev_v2{it.z, it.z}, a01); a23 = __builtin_elementwise_fma(wp[1][k][2], ev_v2{it.z, it.z}, a23);
+                a01 = __builtin_elementwise_fma(wp[0][k][3], ev_v2{it.w, it.w}, a01); a23 = __builtin_elementwise_fma(wp[1][k][3], ev_v2{it.w, it.w}, a23);
             }
+            float acc[4] = {a01.x, a01.y, a23.x, a23.y};
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) acc[jj] = group_sum<8>(acc[jj]);
             // lanes part < 4 of hidden block jb take hidden unit j = 4 jb + part (lanes part >= 4 mirror them); the logit's tree over
