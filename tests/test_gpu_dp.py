@@ -157,8 +157,8 @@ def test_two_rank_dp_over_rccl_two_gpus(owner, dense):
 FOLD = dict(n_items=600, D=128, T=50, hid=32, B=24, K=4, seed=23, lr=1e-3)
 
 
-def _fold_batches():
-    c = FOLD
+def _fold_batches(T=50):
+    c = dict(FOLD, T=T)
     out = []
     for t in range(3):            # a pool of three batches walked K = 4 times round: rows lag and come back
         b = orc.synthetic_batch(c["B"], c["T"], c["n_items"] - 1, pad_id=c["n_items"] - 1, neg=1, seed=800 + t)
@@ -166,14 +166,14 @@ def _fold_batches():
     return out
 
 
-def _fold_worker(rank, world, port, q, fused, mode):
+def _fold_worker(rank, world, port, q, fused, mode, T=50):
     """mode: "pair" = graph A | all-gather | graph B (bench.py's path), "local" = the local-gradients graph + eager exchange, "eager"."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from amid_amd.dist import SparseDenseExchange, shard_batch
         from amid_amd.engine import SasrecEngine
-        c = FOLD
+        c = dict(FOLD, T=T)
         torch.cuda.set_device(0)
         P = orc.random_params(orc.sasrec_param_shapes(c["n_items"], c["D"], c["T"], c["hid"]), seed=9)
         eng = SasrecEngine(c["n_items"], c["D"], c["T"], c["hid"], device="cuda:0", lr=c["lr"], seed=SasrecEngine.rank_seed(c["seed"], rank))
@@ -183,7 +183,7 @@ def _fold_worker(rank, world, port, q, fused, mode):
         pl = eng.plan(Bl, c["T"], 2, need_grad=True)
         ex = SparseDenseExchange(eng.merge_backend(world * pl.shape.n_idx), host_staging=True)
         packed = []
-        for batch in _fold_batches():
+        for batch in _fold_batches(T):
             local = {k: v.cuda() for k, v in shard_batch(batch, rank, world).items()}
             packed.append(eng.pack_batch(pl, local["i_node"], local["neg_samples"], local["seq_d1"], local["seq_d2"], local["label"], local["domain_id"]))
         eng.set_input_pool(pl, torch.stack(packed))
@@ -208,11 +208,11 @@ def _fold_worker(rank, world, port, q, fused, mode):
         dist.destroy_process_group()
 
 
-def _fold_run(fused, mode):
+def _fold_run(fused, mode, T=50):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_fold_worker, args=(r, world, port, q, fused, mode)) for r in range(world)]
+    procs = [ctx.Process(target=_fold_worker, args=(r, world, port, q, fused, mode, T)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([_get(q, procs) for _ in range(world)], key=lambda t: t[0])
@@ -223,17 +223,17 @@ def _fold_run(fused, mode):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["pair", "local", "eager"])
-def test_two_rank_dp_folded_step_matches_fifteen_launch_step_and_oracle(mode):
+@pytest.mark.parametrize("mode,T", [("pair", 50), ("local", 50), ("eager", 50), ("pair", 20), ("eager", 20)])      # (T <= 32: folded since round 6, FOLD_SHORT)
+def test_two_rank_dp_folded_step_matches_fifteen_launch_step_and_oracle(mode, T):
     """SasrecEngine.FUSED_TAIL_DP: every rank's local half of the data-parallel step in the single-GPU step's folded form (step head, head on
     the forward's tail, embedding backward on the last strip, position rows in the tail; phase B of the segment reduce + the chunk's packing
     as one launch, amid_grad_tail_live_dp_f32).  Held: the two replicas bit-identical; the first step's loss on every rank bit-identical
     to the fifteen-launch data-parallel step's and its summed dense gradients to rounding; the parameters after K steps (rows that lag
     and come back: a three-batch pool) to rounding of the fifteen-launch step's and within 1e-4 of ONE process stepping the oracle
     (dense Adam) over the global batches."""
-    c = FOLD
+    c = dict(FOLD, T=T)
     world = 2
-    res = {fused: _fold_run(fused, mode) for fused in (False, True)}
+    res = {fused: _fold_run(fused, mode, T) for fused in (False, True)}
     for fused, outs in res.items():
         for k in outs[0][1]:
             assert (outs[0][1][k] == outs[1][1][k]).all(), f"replicas diverged on {k} (folded={fused})"
@@ -247,7 +247,7 @@ def test_two_rank_dp_folded_step_matches_fifteen_launch_step_and_oracle(mode):
     opt = orc.DenseAdam(P, lr=c["lr"])
     Bl = c["B"] // world
     from amid_amd.engine import SasrecEngine
-    batches = _fold_batches()
+    batches = _fold_batches(T)
     for t in range(1, c["K"] + 1):
         per_rank = [orc.philox_masks_sasrec(Bl, c["T"], c["D"], seed=SasrecEngine.rank_seed(c["seed"], r), step=t) for r in range(world)]
         masks = {k: torch.cat([m[k] for m in per_rank], 0) for k in per_rank[0]}
