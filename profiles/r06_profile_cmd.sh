@@ -48,6 +48,12 @@ python3 profiles/tools/cli_throughput.py --cfg1 2>&1 | grep -E "^cfg 1|^wall" > 
 python3 profiles/tools/cli_throughput.py --dr 2>&1 | grep -E "samples/s|^wall" | tail -6 > $O/cli_runsh.txt
 bash profiles/tools/sq_counters.sh $TAG > /dev/null 2>&1
 python3 bench.py --workload cfg4 --steps 480 --warmup 520 --no-cpu-baseline --no-stress > $O/bench_cfg4_steady.json 2> $O/bench_cfg4_steady.err
+# cfg 4 (T 20): the one-launch backward with its side-stream sort instead of the folded strips; ... with the whole sort chained in the catch-up launch;
+# BERT4Rec with the chained sort; one cfg 4 step kernel by kernel
+python3 bench.py --workload cfg4 --steps 480 --warmup 520 --set FOLD_SHORT=0 --no-cpu-baseline --no-stress > $O/bench_cfg4_steady_unfolded.json 2> $O/bench_cfg4_steady_unfolded.err
+python3 bench.py --workload cfg4 --steps 480 --warmup 520 --set FOLD_SHORT=0 --set SORT_CHAIN=1 --no-cpu-baseline --no-stress > $O/bench_cfg4_steady_chain.json 2> $O/bench_cfg4_steady_chain.err
+python3 bench.py --model bert4rec --set SORT_CHAIN=1 --no-cpu-baseline --no-stress > $O/bench_bert4rec_chain.json 2> $O/bench_bert4rec_chain.err
+bash profiles/tools/trace_cfg4.sh > /dev/null 2>&1; cp $R/gpurun_out/tl4/cfg4_step_timeline.txt $O/cfg4_step_timeline.txt
 ls -la $O
 tail -3 $O/smoke.log
 tail -c 600 $O/bench_driver_args.json
