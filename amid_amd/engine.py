@@ -1358,7 +1358,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         return pl.domain.data_ptr() if getattr(self, "_own_domain_only", False) else None
 
     # ------------------------------------------------------------------ evaluation: test(), train_sr.py:31-128
-    # The evaluation batch in four launches (round 6): index marshal + live list, K1 over the live sequences only (no candidate rows: the
+    # The evaluation batch in three launches (round 6; four while K1 is its own launch, GATHER_ON_FWD = False): index marshal + live list, K1 over the live sequences only (no candidate rows: the
     # head gathers them), the inference forward over the live sequences (nothing saved), amid_eval_head_f32 (LN_last + mean, the scorer over
     # the 1 + neg_nums candidates, masked BCE, the positive's rank).  test() reads only the own domain's logits of a sample (utils.py:21-40)
     # and masks the other domain's loss terms (train_sr.py:63-64), so nothing else is computed; model.forward keeps returning both.

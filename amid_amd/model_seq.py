@@ -300,7 +300,7 @@ class SASRec(nn.Module):
     def eval_ranks(self, ep: Dict[str, torch.Tensor], fix_value: float, use_graph: bool = True) -> Optional[Dict[str, torch.Tensor]]:
         """test()'s arithmetic (train_sr.py:31-128) over a whole evaluation set resident in HBM (ep = DeviceBatches.epoch_tensors()):
         per batch the eval-mode forward of every sample's OWN domain sequence, its 1 + neg_nums scores, the masked BCE mean (:63-64) and
-        the positive's rank with and without fix_value (:114-115; utils.py:21-40, :296-297) -- four launches replayed as one graph
+        the positive's rank with and without fix_value (:114-115; utils.py:21-40, :296-297) -- three launches replayed as one graph
         (SasrecEngine.enqueue_eval).  Returns device tensors rank [n, B], rank_raw [n, B] (int32) and loss [n], or None when this model
         evaluates through forward() (isItC / isInC / isDR, BERT4Rec, shapes the one-launch forward does not cover)."""
         eng = self.engine

@@ -86,7 +86,7 @@ def test(model, args, val_batches):
     model.eval()
     stats = AverageMeter("loss", "loss_cls")
     ranks, ranks_raw, doms, ovs, losses = [], [], [], [], []
-    # the plain SASRec model: the whole evaluation set resident in HBM, per batch four launches replayed as one graph -- the own domain's
+    # the plain SASRec model: the whole evaluation set resident in HBM, per batch three launches replayed as one graph -- the own domain's
     # sequence only (the other domain's logits are never read: utils.py:21-40, train_sr.py:63-64), candidates gathered inside the scorer,
     # BCE and both ranks in the same launch (SASRec.eval_ranks); every other model goes through model.forward below
     fused = None
