@@ -678,14 +678,14 @@ static int strip_qkv_bwd(const float* dq, const float* dk, const float* dv, cons
     const bool ride = rd.phase != 0;
     ScorerSum ss = {};
     if (scorer != nullptr) {
-        if (!(ride && ffn && D == 128 && mma_bf16 == 3)) return AMID_ERR_UNSUPPORTED;       // the riders' host: the middle launch on bf16 pieces
+        if (!(ride && ffn && D == 128 && (mma_bf16 == 3 || mma_bf16 == 1))) return AMID_ERR_UNSUPPORTED;       // the riders' host: the middle launch on bf16 pieces / one piece
         ss = *scorer;
     }
     if (D == 128 && mma_bf16 == 3 && ffn) return ride ? launch_strip_rider_x<strip_qkv_bwd_kernel<128, true, 3, 3>, 128>(sg, rd, ss.nblk, stream, a, f, ss)
                                                       : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0, 3>, 128>(sg, rd, stream, a, f, ss);
     if (D == 128 && mma_bf16 == 3) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4, 3>, 128>(sg, rd, stream, a, f, ss)
                                                : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0, 3>, 128>(sg, rd, stream, a, f, ss);
-    if (D == 128 && mma_bf16 && ffn) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, true, 3, 1>, 128>(sg, rd, stream, a, f, ss)
+    if (D == 128 && mma_bf16 && ffn) return ride ? launch_strip_rider_x<strip_qkv_bwd_kernel<128, true, 3, 1>, 128>(sg, rd, ss.nblk, stream, a, f, ss)
                                                  : launch_strip_rider<strip_qkv_bwd_kernel<128, true, 0, 1>, 128>(sg, rd, stream, a, f, ss);
     if (D == 128 && mma_bf16) return ride ? launch_strip_rider<strip_qkv_bwd_kernel<128, false, 4, 1>, 128>(sg, rd, stream, a, f, ss)
                                           : launch_strip_rider<strip_qkv_bwd_kernel<128, false, 0, 1>, 128>(sg, rd, stream, a, f, ss);

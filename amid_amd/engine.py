@@ -252,6 +252,14 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         pl.chain = bool(bump_step and sparse and defer_sort and self.SORT_CHAIN and not pl.riding and not pl.compact
                         and shp.n_idx <= lib().value("amid_sort_chain_max_indices") and self.n_rows <= (1 << 20) and self._sort_plan(pl) is not None)
         ent = self.input_pool(pl)
+        # compute = "bf16": the step folds like the fp32 one when its shape does (the decisions below then see "f32": _ceff)
+        self._bf16_as_f32 = False
+        if self.compute == "bf16" and self.BF16_FOLD and bump_step and shp.B <= self.BF16_FOLD_MAX_B:
+            self._bf16_as_f32 = True
+            if not (ent is not None and sparse and defer_sort and with_live and self._tail2_ok(pl)):
+                self._bf16_as_f32 = False
+            else:
+                pl.riding = False            # (decided above with the mode's own launches in mind: the folded step rides on the compact list's plan)
         # the live-sequence step on an input pool in twelve launches (FUSED_TAIL): packing, catch-up and phase 1 of the sort of the COMPACT
         # index list are one launch; the later phases ride in the backward strips and the weight gradients; no embedding-backward launch
         pl.tail2 = bool(ent is not None and bump_step and sparse and defer_sort and with_live and self._tail2_ok(pl))
@@ -345,6 +353,16 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self._sort_pending = False
 
     SORT_RIDERS = True
+    # compute = "bf16" on a step that folds (round 6): the fp32 step's nine launches -- its forward on bf16 pieces included, which is MORE than the mode
+    # asks for -- with the backward strips' data-gradient products on ONE bf16 piece (they read the hi plane of the three-plane images).  Decided per
+    # step in enqueue_prepare (_bf16_as_f32); batches beyond BF16_FOLD_MAX_B keep the unfolded bf16 launches (measured faster there: DESIGN.md 5.0).
+    BF16_FOLD = True
+    BF16_FOLD_MAX_B = 384
+    _bf16_as_f32 = False
+
+    def _ceff(self) -> str:
+        """The compute mode the step's path decisions see: "f32" for a compute = "bf16" step that takes the folded launches."""
+        return "f32" if self._bf16_as_f32 else self.compute
     FOLD_SHORT = True            # 16 < T <= 32 on an input pool: the folded strips step instead of the one-launch backward (round 6)
     # the whole sort chained inside the catch-up launch where the riders have no five launches (round 6).  Off by default: the chain takes ~ 45 us
     # (five phases, four barriers with agent-scope fences), which the catch-up hides only when it replays long gaps -- cfg 4's real epoch in its
@@ -456,7 +474,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     def _folded_step_shape(self, pl: SasrecPlan) -> bool:
         """The conditions of the folded twelve-launch step that do not depend on how the backward runs (_tail2_ok adds those)."""
         return bool(self.FUSED_TAIL and self._fold_ctx() and self.SORT_RIDERS and pl.need_grad and self.D == 128
-                    and self.compute == "f32" and not self.dr and not self.itc_bs and not self.inc_bs and not getattr(self, "comp", "")
+                    and self._ceff() == "f32" and not self.dr and not self.itc_bs and not self.inc_bs and not getattr(self, "comp", "")
                     and pl.shape.NI > 1 and self.FUSED_HEAD and self.BWD_SPLIT and pl.strip
                     and self.input_pool(pl) is not None and self.live_forward_ok(pl) and self._wgrad_mode(self.D) == 3
                     and not self._fold_catchup(pl) and self._sort_plan_c(pl) is not None and (pl.n_compact + 2047) // 2048 <= 12 * pl.splits)
@@ -465,7 +483,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         shp = pl.shape
         # (inside enqueue_train_step the segment reduce's runs across chunks are finished by THIS step's optimizer launch; inside
         # enqueue_local_grads -- what a data-parallel exchange ships -- by a launch of their own behind the tail, amid_grad_tail_live_dp_f32)
-        return bool(self.FUSED_TAIL and self._fold_ctx() and self.SORT_RIDERS and pl.need_grad and self.D == 128 and self.compute == "f32" and not self.dr
+        return bool(self.FUSED_TAIL and self._fold_ctx() and self.SORT_RIDERS and pl.need_grad and self.D == 128 and self._ceff() == "f32" and not self.dr
                     and not self.itc_bs and not self.inc_bs and not getattr(self, "comp", "") and pl.shape.NI > 1
                     and self.FUSED_HEAD and self.live_forward_ok(pl) and self._p3_bwd_for(pl) and self._wgrad_mode(self.D) == 3
                     and not self._fold_catchup(pl) and self._sort_plan_c(pl) is not None
@@ -559,7 +577,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
 
     def _p3_bwd_for(self, pl: SasrecPlan) -> bool:
         """Whether this plan's backward strips take their data-gradient products on bf16 pieces (three-plane images of the transposes)."""
-        return bool(self.compute != "bf16" and self.BWD_SPLIT and pl.strip and self.D == 128 and not self._seq_backward(pl))
+        return bool(self._ceff() != "bf16" and self.BWD_SPLIT and pl.strip and self.D == 128 and not self._seq_backward(pl))
 
     def _wT16x3_buf(self):
         if not hasattr(self, "wT16x3"):
@@ -568,7 +586,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
 
     def _fwd_on_pieces(self, pl: SasrecPlan, B: int, T: int) -> bool:
         """Whether this step's encoder forward is the one-launch kernel with its products on bf16 pieces (amid_sas_seq_fwd_split_f32)."""
-        return bool(self.compute != "bf16" and self.FWD_SPLIT and self.D == 128 and pl.strip and self.SEQ_FORWARD and not self.inc_bs
+        return bool(self._ceff() != "bf16" and self.FWD_SPLIT and self.D == 128 and pl.strip and self.SEQ_FORWARD and not self.inc_bs
                     and lib().value("amid_sas_seq_supported", B, T, self.D, self.H))
 
     def _enqueue_k1(self, pl: SasrecPlan, pos0, pos1, tmq, tr: int, p_drop: float, lf) -> None:
@@ -714,7 +732,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                      tl(pl.qn), tl(pl.q), tl(pl.k), tl(pl.v), tl(pl.o), tl(pl.stats), tl(pl.r), tl(pl.y), tl(pl.h))
                 self._ptr_cache[key] = c
             split = self._fwd_on_pieces(pl, B, T)
-            if self.compute == "bf16" or split:       # this step's weights as bf16 fragment images (one plane: operands rounded to bf16;
+            if self._ceff() == "bf16" or split:       # this step's weights as bf16 fragment images (one plane: operands rounded to bf16;
                 planes = 3 if split else 1            # three: hi + mid + lo = the fp32 weight exactly), then the forward on them
                 src, w16 = self._w16_images(planes)
                 if not getattr(pl, "w16_written", False):      # (the train step's gather K1 wrote them with extra workgroups)
@@ -957,10 +975,12 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 dst += [self.wT[l, g, w].data_ptr() for w in range(6)]
         # compute = "bf16" on the strip path: the strip backward's data-gradient products take bf16 fragment images of the transposed weights
         # (the fp32 transposes are still refreshed: the row-tile fallbacks and tests read them)
-        self._bf16_bwd = bool(self.compute == "bf16" and pl.strip)
+        self._bf16_bwd = bool(self._ceff() == "bf16" and pl.strip)
         # (the fused per-sequence backward -- amid_sas_seq_bwd_f32 -- keeps the fp32 matrix instructions)
         self._p3_bwd = self._p3_bwd_for(pl)
         bf = 3 if self._p3_bwd else 1 if self._bf16_bwd else 0
+        if self._bf16_as_f32 and self._p3_bwd:
+            bf = 1                      # one bf16 piece: the strips' rings stream the hi plane of the three-plane images
         if self._bf16_bwd:
             if not hasattr(self, "wT16"):
                 self.wT16 = torch.empty(2, 2, 6, D * D, dtype=torch.bfloat16, device=self.device)
@@ -1301,6 +1321,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self.enqueue_optimizer(pl)
         finally:
             self._in_train_step = False
+            self._bf16_as_f32 = False
 
     # ------------------------------------------------------------------ data parallel (one process per GPU)
     def enqueue_local_grads(self, pl: SasrecPlan) -> None:
@@ -1313,6 +1334,7 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             self._enqueue_fwd_bwd(pl)
         finally:
             self._in_local_grads = False
+            self._bf16_as_f32 = False
 
     def _fork_sort(self, pl: SasrecPlan) -> None:
         """Start the side-stream sort behind the catch-up launch, beside the forward (forks behind the forward or beside the weight

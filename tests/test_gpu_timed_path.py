@@ -1070,3 +1070,60 @@ def test_sort_chained_in_the_catchup_launch_equals_the_side_stream_sort(Bn, T, n
     assert out[False]["loss"] == out[True]["loss"], (out[False]["loss"], out[True]["loss"])
     for k, want in out[False]["params"].items():
         assert torch.equal(out[True]["params"][k], want), k
+
+
+@pytest.mark.parametrize("Bn,T", [(256, 50), (200, 20)])
+def test_bf16_step_on_a_pool_takes_the_folded_launches(Bn, T):
+    """compute = "bf16" on an input pool (round 6, SasrecEngine.BF16_FOLD): the step takes the fp32 step's nine folded launches -- the forward on
+    bf16 pieces (more than the mode asks for), the gather in its prologue and the head on its tail -- with the three strip launches' data-gradient
+    products on ONE bf16 piece (mma mode 1 on the hi plane of the three-plane images).  Held: the launch list; loss and own logits at the
+    fp32 step's bars (the forward is fp32-accurate); every gradient tensor inside the bf16 bars of its kind (BF16_GRAD_BARS) and NOT fp32-exact
+    for the tensors behind a strip product (the mode is on); batches beyond BF16_FOLD_MAX_B keep the unfolded bf16 launches."""
+    from amid_amd._lib import lib
+    D, hid, n_items = 128, 32, 3000
+    P = orc.random_params(orc.sasrec_param_shapes(n_items, D, T, hid), seed=300 + D + Bn)
+    batch = split_batch(Bn, T, n_items, seed=Bn + T, split="mixed")
+    seed, step = 21, 4
+    masks = orc.philox_masks_sasrec(Bn, T, D, seed=seed, step=step)
+    eng = make_engine(P, T, seed=seed, compute="bf16")
+    pl = eng.plan(Bn, T, 2, need_grad=True)
+    L = lib()
+    calls, orig = [], L.call
+    def spy(name, *a):
+        calls.append((name, a))
+        return orig(name, *a)
+    L.call = spy
+    try:
+        timed_pool_step(eng, pl, batch, step, seed)
+    finally:
+        L.call = orig
+    names = [c[0] for c in calls]
+    assert pl.tail2 and "amid_sas_seq_fwd_gather_head_f32" in names and "amid_grad_tail_opt_f32" in names, names
+    strips = [c for c in calls if c[0] in ("amid_sas_strip_ffn_bwd_sort_f32", "amid_sas_strip_qkv_bwd_sort_scorer_f32", "amid_sas_strip_qkv_bwd_emb_f32")]
+    assert len(strips) == 3
+    for name, a in strips:       # the precision argument: one bf16 piece
+        mode = a[-2] if name != "amid_sas_strip_qkv_bwd_sort_scorer_f32" else a[-11]
+        assert mode == 1, (name, mode)
+    keep = gpu_relu_keep(eng, pl, batch)
+    loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, masks, relu_keep=keep)
+    assert abs(float(pl.loss.item()) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    dom = batch["domain_id"]
+    own = torch.where(dom[:, None] == 0, pl.p1.cpu(), pl.p2.cpu())
+    assert relmax(own, torch.where(dom[:, None] == 0, p1, p2)) < 1e-4
+    worst = 0.0
+    for name in eng.dense.slots:
+        got, want = eng.dense.view(name, eng.dense.grad).cpu().clone(), grads[name].clone()
+        if name.endswith("in_proj_bias"):
+            n3 = got.numel() // 3
+            got[n3:2 * n3] = 0; want[n3:2 * n3] = 0
+        e2 = rel_l2(got, want)
+        assert e2 < BF16_GRAD_BARS[bf16_grad_kind(name)], (name, e2)
+        if "attention_layers.0.in_proj_weight" in name:
+            worst = max(worst, e2)
+    assert worst > 1e-5, "layer 0's q / k / v weight gradients sit behind bf16 strip products: fp32-exact means the mode is off"
+    assert rel_l2(dense_table_grad(eng, pl), grads["item_emb_layer.emb_item.weight"]) < BF16_GRAD_BARS["table"]
+    big = make_engine(P, T, seed=seed, compute="bf16")
+    big.BF16_FOLD_MAX_B = Bn - 1
+    plb = big.plan(Bn, T, 2, need_grad=True)
+    timed_pool_step(big, plb, batch, step, seed)
+    assert not plb.tail2
