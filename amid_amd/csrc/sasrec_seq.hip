@@ -440,6 +440,9 @@ extern "C" int amid_sas_seq_supported(int B, int T, int D, int H) {
 // (optional) = the step state whose step_done the launch re-joins
 struct SeqGather { const float* table; const int* idx; const float* pos[2]; float* items; int ni; StepState* done; };
 
+// set around a call by the *_p1_f32 entries: the pieces build multiplies ONE piece per operand (bf16 products on the three-plane images' hi planes)
+static thread_local int tl_one_piece = 0;
+
 static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
                         const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
                         const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
@@ -484,6 +487,7 @@ static int seq_fwd_impl(int n_layers, const float* const* x_in, float* xout, con
         a.g_done = gat->done;
     }
     a.w16 = (const unsigned short*)w16; a.w16_planes = w16_planes;
+    a.one_piece = (tl_one_piece && w16 != nullptr && w16_planes == 3) ? 1 : 0;
     a.att_scale = sqrtf(1.0f / (float)(D / H));
     a.st = (const StepState*)step_state;
     a.train = (train && p_drop > 0.f) ? 1 : 0;
@@ -678,6 +682,45 @@ extern "C" int amid_sas_seq_fwd_gather_f32(int n_layers, const float* const* x_i
     const SeqGather gat{table, idx_all, {pos0, pos1}, items, NI, (StepState*)step_state};
     return seq_fwd_impl(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, nullptr, q, k, v, o, stats, r, nullptr, h,
                         tmq, ln_eps, B, T, D, H, live, step_state, train, p_drop, w16x3, stream, 3, ln_stat, nullptr, false, &gat);
+}
+// amid_sas_seq_fwd_gather_head_f32 / amid_sas_seq_fwd_gather_f32 with the twelve projection products on ONE bf16 piece per operand (compute = "bf16"
+// on the folded step, round 6): the same launches -- three-plane images, pieces in the exchange (the LayerNorm statistics still see the exact
+// rows) -- reading only the hi planes and multiplying only the hi pieces: bf16 products with fp32 accumulation, a sixth of the matrix work.
+extern "C" int amid_sas_seq_fwd_gather_head_p1_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                                   const float* const* w_in, const float* const* b_in, const float* const* w_o,
+                                                   const float* const* b_o, const float* const* ln2_w, const float* const* ln2_b,
+                                                   const float* const* w1, const float* const* b1, const float* const* w2,
+                                                   const float* const* b2, float* const* ln_stat, float* const* q, float* const* k,
+                                                   float* const* v, float* const* o, float* const* stats, float* const* r, float* const* h,
+                                                   unsigned char* tmq, float ln_eps, int B, int T, int D, int H, const int* live,
+                                                   void* step_state, int train, float p_drop, const void* w16x3,
+                                                   const float* const* last_ln_w, const float* const* last_ln_b, float* items,
+                                                   const float* sw1, const float* sb1, const float* sw2, const float* sb2, const float* labels,
+                                                   const long long* domain_id, int NI, int hid, float* u, float* p1, float* p2, float* dp1,
+                                                   float* dp2, float* loss_part, float* dx, float* ditems, float* ln_part, float* hidg,
+                                                   const float* table, const int* idx_all, const float* pos0, const float* pos1, void* stream) {
+    tl_one_piece = 1;
+    const int rc = amid_sas_seq_fwd_gather_head_f32(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, ln_stat, q, k, v, o,
+                                                    stats, r, h, tmq, ln_eps, B, T, D, H, live, step_state, train, p_drop, w16x3, last_ln_w, last_ln_b, items,
+                                                    sw1, sb1, sw2, sb2, labels, domain_id, NI, hid, u, p1, p2, dp1, dp2, loss_part, dx, ditems, ln_part, hidg,
+                                                    table, idx_all, pos0, pos1, stream);
+    tl_one_piece = 0;
+    return rc;
+}
+extern "C" int amid_sas_seq_fwd_gather_p1_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w,
+                                              const float* const* ln1_b, const float* const* w_in, const float* const* b_in,
+                                              const float* const* w_o, const float* const* b_o, const float* const* ln2_w,
+                                              const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                              const float* const* w2, const float* const* b2, float* const* ln_stat, float* const* q,
+                                              float* const* k, float* const* v, float* const* o, float* const* stats, float* const* r,
+                                              float* const* h, unsigned char* tmq, float ln_eps, int B, int T, int D, int H,
+                                              const int* live, void* step_state, int train, float p_drop, const void* w16x3, float* items, int NI,
+                                              const float* table, const int* idx_all, const float* pos0, const float* pos1, void* stream) {
+    tl_one_piece = 1;
+    const int rc = amid_sas_seq_fwd_gather_f32(n_layers, x_in, xout, ln1_w, ln1_b, w_in, b_in, w_o, b_o, ln2_w, ln2_b, w1, b1, w2, b2, ln_stat, q, k, v, o, stats, r,
+                                               h, tmq, ln_eps, B, T, D, H, live, step_state, train, p_drop, w16x3, items, NI, table, idx_all, pos0, pos1, stream);
+    tl_one_piece = 0;
+    return rc;
 }
 extern "C" int amid_sas_seq_fwd_gather_infer_f32(int n_layers, float* xout, const float* const* ln1_w, const float* const* ln1_b,
                                                  const float* const* w_in, const float* const* b_in, const float* const* w_o,

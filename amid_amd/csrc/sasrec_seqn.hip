@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_kernel(const SeqFwdArg
 // LayerNorm statistics come from the row put back together (hi + mid + lo is the value exactly); only the own columns' gains are held.
 // HEAD: the train step's head on the workgroup's tail (seqn_fwd_px_head_kernel below) -- the last layer's output goes to an LDS image instead
 // of a.xout and head_own_rows_body (csrc/head_parts.h) runs on it.
-template <int D, int WPS, int NS, bool HEAD>
+template <int D, int WPS, int NS, bool HEAD, bool ONE = false>
 __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqGeom& sg, float* const smem, const HeadArgs* ha) {
     constexpr int NT = D / 16, NW = WPS * NS, NCT = NT / NS;
     constexpr int H = NT, NH = NCT;
@@ -443,6 +443,7 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
     }
     using Ring = SeqRing3<D, NW>;
     Ring ring(smem);
+    ring.one = ONE;
     auto w16 = [&](int layer, int which) { return a.w16 + ((size_t)((layer * 2 + g) * 6 + which)) * 3 * D * D; };     // q, k, v, o, c1, c2
     ring.first(w16(0, 1));
     float* const xps = smem + 3 * Ring::SLAB + si * XpStrip<D>::FLOATS;         // this strip's exchange slots
@@ -545,7 +546,7 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
         SEQN_STAMP(2);
         {   // k = x Wk^T + bk
             part_cols<NCT>(bias, P.b_in[g] + D, c0);
-            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 2), c0, [&](int ct, int j) { if (!lnst) part_spread<NCT>(gqn, off_own, Qno, ct, j, 1); });
+            seqn_product_xp<D, NCT, ONE>(acc, xps, ring, w16(l, 2), c0, [&](int ct, int j) { if (!lnst) part_spread<NCT>(gqn, off_own, Qno, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ko.v[c] = acc[c] + bias.v[c];
         }
@@ -554,7 +555,7 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
             ring.next();
             SEQN_STAMP(4);
             part_cols<NCT>(bias, P.b_in[g] + 2 * D, c0);
-            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 0), c0, [&](int ct, int j) { part_spread<NCT>(gk, off_own, Ko, ct, j, 1); });
+            seqn_product_xp<D, NCT, ONE>(acc, xps, ring, w16(l, 0), c0, [&](int ct, int j) { part_spread<NCT>(gk, off_own, Ko, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Vo.v[c] = acc[c] + bias.v[c];
         }
@@ -566,7 +567,7 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
             SEQN_STAMP(6);
             ring.hold_next = true;                         // M + L hold the attention images behind this product
             part_cols<NCT>(bias, P.b_in[g], c0);
-            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 3), c0, [&](int ct, int j) { part_spread<NCT>(gv, off_own, Vo, ct, j, 1); });
+            seqn_product_xp<D, NCT, ONE>(acc, xps, ring, w16(l, 3), c0, [&](int ct, int j) { part_spread<NCT>(gv, off_own, Vo, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Qo.v[c] = acc[c] + bias.v[c];
         }
@@ -620,7 +621,7 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
         {
             ring.next();
             SEQN_STAMP(10);
-            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 4), c0, [&](int ct, int j) { part_spread<NCT>(go, off_own, Oo, ct, j, 1); });
+            seqn_product_xp<D, NCT, ONE>(acc, xps, ring, w16(l, 4), c0, [&](int ct, int j) { part_spread<NCT>(go, off_own, Oo, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ro.v[c] = Qno.v[c] + (acc[c] + bias.v[c]);
         }
@@ -668,7 +669,7 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
             ring.next();
             SEQN_STAMP(13);
             part_cols<NCT>(bias, P.b1[g], c0);
-            seqn_product_xp<D, NCT>(acc, xps, ring, w16(l, 5), c0, [&](int ct, int j) { part_spread<NCT>(gr, off_own, Ro, ct, j, 1); });
+            seqn_product_xp<D, NCT, ONE>(acc, xps, ring, w16(l, 5), c0, [&](int ct, int j) { part_spread<NCT>(gr, off_own, Ro, ct, j, 1); });
 #pragma unroll
             for (int c = 0; c < NCT; ++c) Ho.v[c] = acc[c] + bias.v[c];
             if (a.train) part_dropout<NCT>(Ho, rr1, c0, a.spec, a.ffn_scale, (local * D) & 127);
@@ -684,7 +685,7 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
             ring.next();
             SEQN_STAMP(15);
             part_cols<NCT>(bias, P.b2[g], c0);
-            seqn_product_xp<D, NCT>(acc, xps, ring, w16(last ? l : l + 1, 1), c0, [&](int ct, int j) {
+            seqn_product_xp<D, NCT, ONE>(acc, xps, ring, w16(last ? l : l + 1, 1), c0, [&](int ct, int j) {
                 if (!lnst) part_spread<NCT>(gy, off_own, Yo, ct, j, 1);
                 part_spread<NCT>(gh, off_own, Ho, ct, j, 3);
             });
@@ -734,16 +735,16 @@ __device__ __forceinline__ void seqn_fwd_px_body(const SeqFwdArgs& a, const SeqG
     }
 }
 
-template <int D, int WPS, int NS>
+template <int D, int WPS, int NS, bool ONE = false>
 __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_kernel(const SeqFwdArgs a, const SeqGeom sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    seqn_fwd_px_body<D, WPS, NS, false>(a, sg, smem, nullptr);
+    seqn_fwd_px_body<D, WPS, NS, false, ONE>(a, sg, smem, nullptr);
 }
 
-template <int D, int WPS, int NS>
+template <int D, int WPS, int NS, bool ONE = false>
 __global__ __launch_bounds__(64 * WPS * NS) void seqn_fwd_px_head_kernel(const SeqFwdArgs a, const SeqGeom sg, const HeadArgs ha) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    seqn_fwd_px_body<D, WPS, NS, true>(a, sg, smem, &ha);
+    seqn_fwd_px_body<D, WPS, NS, true, ONE>(a, sg, smem, &ha);
 }
 
 template <int D, int WPS, int NS>
@@ -756,12 +757,32 @@ static int seqn_launch_px(const SeqFwdArgs& a, const SeqGeom& sg, void* stream, 
             if (sg.live == nullptr || head_lds_floats(D, head->hid) > (size_t)3 * (D * D / 2) || sg.T > 16 * (HEAD_CHUNK / 2) || head->D != D ||
                 head->B != sg.B || head->T != sg.T)
                 return AMID_ERR_UNSUPPORTED;
+            if (a.one_piece) {
+                auto kern1 = seqn_fwd_px_head_kernel<D, WPS, NS, true>;
+                static unsigned long long attr_done1 = 0;
+                if (int rc = lds_attr_once((const void*)kern1, lds, attr_done1)) return rc;
+                kern1<<<grid, 64 * WPS * NS, lds, (hipStream_t)stream>>>(a, sg, *head);
+                hipError_t e1 = hipGetLastError();
+                return e1 == hipSuccess ? AMID_OK : (int)e1;
+            }
             auto kern = seqn_fwd_px_head_kernel<D, WPS, NS>;
             static unsigned long long attr_done = 0;
             if (int rc = lds_attr_once((const void*)kern, lds, attr_done)) return rc;
             kern<<<grid, 64 * WPS * NS, lds, (hipStream_t)stream>>>(a, sg, *head);
             hipError_t e = hipGetLastError();
             return e == hipSuccess ? AMID_OK : (int)e;
+        } else {
+            return AMID_ERR_UNSUPPORTED;
+        }
+    }
+    if (a.one_piece) {
+        if constexpr ((WPS == 4 && NS == 2) || (WPS == 2 && NS == 4)) {      // (the builds a folded step asks for)
+            auto kern1 = seqn_fwd_px_kernel<D, WPS, NS, true>;
+            static unsigned long long attr_done1 = 0;
+            if (int rc = lds_attr_once((const void*)kern1, lds, attr_done1)) return rc;
+            kern1<<<grid, 64 * WPS * NS, lds, (hipStream_t)stream>>>(a, sg);
+            hipError_t e1 = hipGetLastError();
+            return e1 == hipSuccess ? AMID_OK : (int)e1;
         } else {
             return AMID_ERR_UNSUPPORTED;
         }

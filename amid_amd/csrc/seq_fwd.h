@@ -31,6 +31,7 @@ struct SeqFwdArgs {
     // [D][D] written by amid_sas_weights_bf16 for THIS step's weights; nullptr = exact fp32 products
     const unsigned short* w16;
     int w16_planes;                      // 1: bf16 products (operands rounded); 3: fp32 products on three bf16 pieces per operand
+    int one_piece;                       // (seqn_fwd_px kernels, three-plane images) bf16 products: only the hi planes and the operands' hi pieces
     // optional (seqn_fwd_px kernels, round 6): the gather K1 as the workgroup's PROLOGUE -- embItemLayerEnhance.forward + Log2feats' position
     // add, embedding dropout and == 0 mask (model_seq.py:27-29, :361-366).  g_table != nullptr: layer 0's input rows are not read from x0 but
     // built from table[g_idx[row]] + g_pos[domain][t] (K1's arithmetic, operation for operation: the same bits) and -- in a forward that a

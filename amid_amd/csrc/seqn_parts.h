@@ -414,8 +414,9 @@ template <int D, int NW> struct SeqRing3 {
     float* buf; unsigned off0; int w;
     const unsigned short* cur; const unsigned short* nxt;
     bool hi_ready, rest_ready, rest_late, hold_next;
+    bool one;                            // ONE piece per operand (compute = "bf16" on the folded step): only the hi planes are streamed
     __device__ __forceinline__ explicit SeqRing3(float* lds)
-        : buf(lds), cur(nullptr), nxt(nullptr), hi_ready(false), rest_ready(false), rest_late(false), hold_next(false) {
+        : buf(lds), cur(nullptr), nxt(nullptr), hi_ready(false), rest_ready(false), rest_late(false), hold_next(false), one(false) {
         w = wave_id();
         const int p = w * 64 + lane_id();
         const int n = p / CPR, pos = p % CPR;
@@ -439,7 +440,8 @@ template <int D, int NW> struct SeqRing3 {
     }
     __device__ __forceinline__ void first(const unsigned short* __restrict__ W0) {
         cur = W0; hi_ready = true; rest_ready = true;
-        plane(hslot(), W0); plane(mslot(), W0 + (size_t)D * D); plane(lslot(), W0 + (size_t)2 * D * D);
+        plane(hslot(), W0);
+        if (!one) { plane(mslot(), W0 + (size_t)D * D); plane(lslot(), W0 + (size_t)2 * D * D); }
     }
     // Round 5: a product walks its HI plane first.  Schedule of product i (weight cur):
     //   next()      everything requested so far has landed and every wave is past product i - 1 (and past the attention images, which live in
@@ -456,7 +458,7 @@ template <int D, int NW> struct SeqRing3 {
         __syncthreads();
         if (!hi_ready) plane(hslot(), cur);                  // (never in steady state: kept for a ring that is started without first())
         rest_late = !hi_ready;
-        if (!rest_ready) { plane(mslot(), cur + (size_t)D * D); plane(lslot(), cur + (size_t)2 * D * D); }
+        if (!rest_ready && !one) { plane(mslot(), cur + (size_t)D * D); plane(lslot(), cur + (size_t)2 * D * D); }
         hold_next = false;
     }
     __device__ __forceinline__ void begin(const unsigned short* __restrict__ Wnext) { nxt = Wnext; }
@@ -514,7 +516,8 @@ __device__ __forceinline__ void xp_row(StripRegs<D>& full, const float* __restri
 // of its first use (lgkmcnt(1) / (0) in front of most matrix instructions).  A step = one column tile of one k-step: two weight fragments
 // (pass 1: mid, lo planes) or one (pass 2: hi plane), three matrix instructions.  Weight reads run PD steps ahead; LDS operations return
 // in order, so a step waits until only the reads issued behind its own are outstanding.
-template <int D, int NCT, class Ring>
+// ONE: the hi plane against the operand's hi piece only -- bf16 products (operands rounded to nearest even), a sixth of the matrix instructions
+template <int D, int NCT, class Ring, bool ONE = false>
 __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __restrict__ xps, Ring& ring, int c0) {
     constexpr int KS = D / 32, NSTEP = KS * NCT, CT_BYTES = 16 * (D / 2) * 4, PLANE_BYTES = Ring::SLAB * 4;
     constexpr int PD1 = FRAG_AHEAD_2, PD2 = FRAG_AHEAD_1;
@@ -554,11 +557,12 @@ __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __re
             if constexpr (t + PD2 < NSTEP) issue(std::integral_constant<int, t + PD2>{});
             constexpr int last = t + PD2 < NSTEP ? t + PD2 : NSTEP - 1;
             asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wf[k]), "+v"(ah[s]), "+v"(am[s]), "+v"(al[s]) : "n"(last - t));
-            acc[c] = mma(wf[k], al[s], acc[c]); acc[c] = mma(wf[k], am[s], acc[c]); acc[c] = mma(wf[k], ah[s], acc[c]);
+            if constexpr (!ONE) { acc[c] = mma(wf[k], al[s], acc[c]); acc[c] = mma(wf[k], am[s], acc[c]); }
+            acc[c] = mma(wf[k], ah[s], acc[c]);
         });
     }
     ring.mid_sync();
-    {   // second pass: the lo plane against the operand's hi piece, the mid plane against (mid, hi)
+    if constexpr (!ONE) {   // second pass: the lo plane against the operand's hi piece, the mid plane against (mid, hi)
         f32x4 wm[PD1 + 1], wl[PD1 + 1], ah[KS], am[KS];
         static_for<KS>([&](auto S) {
             constexpr int s = decltype(S)::value;
@@ -582,7 +586,7 @@ __device__ __forceinline__ void part_mma_xp(f32x4 (&acc)[NCT], const float* __re
 }
 
 // one product of seqn_fwd_px_kernel: the next weight is announced, the deferred stores leave behind the matrix instructions
-template <int D, int NCT, class Ring, class Stores>
+template <int D, int NCT, bool ONE = false, class Ring, class Stores>
 __device__ __forceinline__ void seqn_product_xp(f32x4 (&acc)[NCT], const float* __restrict__ xps, Ring& ring, const unsigned short* __restrict__ wn16,
                                                 int c0, const Stores& stores) {
 #pragma unroll
@@ -595,7 +599,7 @@ __device__ __forceinline__ void seqn_product_xp(f32x4 (&acc)[NCT], const float* 
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) { stores(ct, 1); stores(ct, 3); }
 #endif
-    part_mma_xp<D, NCT>(acc, xps, ring, c0);
+    part_mma_xp<D, NCT, Ring, ONE>(acc, xps, ring, c0);
 #ifdef AMID_EXP_STORES_LAST
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) { stores(ct, 1); stores(ct, 3); }

@@ -355,9 +355,10 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
     SORT_RIDERS = True
     # compute = "bf16" on a step that folds (round 6): the fp32 step's nine launches -- its forward on bf16 pieces included, which is MORE than the mode
     # asks for -- with the backward strips' data-gradient products on ONE bf16 piece (they read the hi plane of the three-plane images).  Decided per
-    # step in enqueue_prepare (_bf16_as_f32); batches beyond BF16_FOLD_MAX_B keep the unfolded bf16 launches (measured faster there: DESIGN.md 5.0).
+    # step in enqueue_prepare (_bf16_as_f32); BF16_FOLD_MAX_B: batches beyond it keep the unfolded bf16 launches.
     BF16_FOLD = True
-    BF16_FOLD_MAX_B = 384
+    BF16_FOLD_MAX_B = 1 << 30          # (with the forward on one piece too the fold wins at B 512 as well: cfg 3 bf16 0.4915 -> 0.4751)
+    BF16_FWD_ONE = True          # ... and its forward multiplies ONE piece per operand too (amid_sas_seq_fwd_gather_*_p1_f32): bf16 products
     _bf16_as_f32 = False
 
     def _ceff(self) -> str:
@@ -746,7 +747,9 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                             and self.hid <= 32 and NI <= 64):
                         # ... and a live sequence is a sample: its workgroup finishes with the sample's head (forward + loss + backward,
                         # what amid_head_fwd_bwd_own_vec_f32 does in enqueue_backward otherwise); the last layer's output is not stored
-                        L.call("amid_sas_seq_fwd_gather_head_f32" if gat else "amid_sas_seq_fwd_split_lnstat_head_f32", 2, c[0],
+                        # (compute = "bf16" on the folded step: the same launch multiplying ONE piece per operand, BF16_FWD_ONE)
+                        p1 = "_p1" if (gat and self._bf16_as_f32 and self.BF16_FWD_ONE) else ""
+                        L.call(f"amid_sas_seq_fwd_gather_head{p1}_f32" if gat else "amid_sas_seq_fwd_split_lnstat_head_f32", 2, c[0],
                                pl.x[2].data_ptr() if self.HEAD_ON_FWD_KEEPS_X else None, *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
                                pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(),
                                self._pp("sac{d}.last_layernorm.weight"), self._pp("sac{d}.last_layernorm.bias"),
@@ -757,7 +760,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                                pl.last_part.data_ptr(), self._hidg(pl).data_ptr(), *(gather if gat else ()), s)
                         pl.head_done = True
                     elif gat:
-                        L.call("amid_sas_seq_fwd_gather_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
+                        p1 = "_p1" if (self._bf16_as_f32 and self.BF16_FWD_ONE) else ""
+                        L.call(f"amid_sas_seq_fwd_gather{p1}_f32", 2, c[0], pl.x[2].data_ptr(), *c[1:13], self._ln_stat(pl)[1], *c[14:20], c[21],
                                pl.tmq.data_ptr(), SASREC_LN_EPS, B, T, D, self.H, lf, st, tr, SASREC_P_DROP, w16.data_ptr(),
                                pl.xg.data_ptr() + 4 * 2 * shp.Mi * D, NI, *gather, s)
                     else:

@@ -262,6 +262,8 @@ def algorithmic_work(Bw=B, n_uniq=None, T=T):
         # ... and with the gather K1 as its prologue (round 6): + the rows it gathers and stores for the backward (not counted: the launch is matrix-bound)
         "amid_sas_seq_fwd_gather_head_f32": ("mfma16x6", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
         "amid_sas_seq_fwd_gather_f32": ("mfma16x6", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
+        "amid_sas_seq_fwd_gather_head_p1_f32": ("mfma16", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
+        "amid_sas_seq_fwd_gather_p1_f32": ("mfma16", 12 * gl + 2 * 4.0 * T * T * hd * Bw * H),
         "amid_step_head_w16_f32": ("hbm", (Bw * T + Bw * (1 + NEG)) * 28 + (2 * Bw * T + 2 * Bw * (1 + NEG)) * 20 + U * (D * 4 * 6 + 8) + 48 * D * D * 10),
         "amid_sas_wgrad_rows_sort_ln_f32": (WGRAD_KIND, 6 * gemm),
         "amid_sas_strip_qkv_bwd_sort_scorer_f32": ("mfma", 6 * gl),     # layer 1's q / k / v backward + layer 0's feed-forward backward (+ riders)
@@ -294,6 +296,7 @@ KERNEL_SYMBOL = {          # C-ABI entry -> substring of the device kernel's nam
     "amid_grad_tail_live_f32": "grad_tail_live_kernel", "amid_grad_tail_nospans_f32": "grad_tail_kernel", "amid_optimizer_step_spans_f32": "optimizer_step_spans_kernel",
     "amid_grad_tail_opt_f32": "grad_tail_opt_kernel", "amid_step_head_w16_f32": "step_head_kernel",
     "amid_sas_seq_fwd_gather_head_f32": ("seqn_fwd_px_head_kernel",), "amid_sas_seq_fwd_gather_f32": ("seqn_fwd_px_kernel",),
+    "amid_sas_seq_fwd_gather_head_p1_f32": ("seqn_fwd_px_head_kernel",), "amid_sas_seq_fwd_gather_p1_f32": ("seqn_fwd_px_kernel",),
     "amid_bert_strip_qkv_fwd_pro_p3_f32": "bert_strip_qkv_fwd_kernel", "amid_bert_strip_oproj_ffn_fwd_p3_f32#0": "bert_strip_oproj_ffn_fwd_kernelILb1",
     "amid_bert_strip_oproj_ffn_fwd_p3_f32#1": "bert_strip_oproj_ffn_fwd_kernelILb0", "amid_bert_strip_ffn_bwd_p3_f32": "bert_strip_ffn_bwd_kernel",
     "amid_bert_strip_qkv_bwd_p3_f32#0": "bert_strip_qkv_bwd_kernelILb1", "amid_bert_strip_qkv_bwd_p3_f32#1": "bert_strip_qkv_bwd_kernelILb0",
@@ -858,10 +861,10 @@ def main():
                 roof["frac_of_fp32_mfma_peak"] = round(roof["achieved"] / PEAK_F32_MFMA_TFLOPS, 4)
                 roof["operands"] = kernels[dom]["operands"]
             roof["timing"] = "HIP events around this kernel's launches only, 20 steps enqueued back to back (the queue stays full, as in the timed region)"
-        if dom in ("amid_sas_seq_fwd_split_lnstat_head_f32", "amid_sas_seq_fwd_gather_head_f32") and use_pool and world == 1:
+        if dom in ("amid_sas_seq_fwd_split_lnstat_head_f32", "amid_sas_seq_fwd_gather_head_f32", "amid_sas_seq_fwd_gather_head_p1_f32") and use_pool and world == 1:
             # like for like with the earlier rounds' lines: the encoder forward as its own launch (the head back in a launch of its own),
             # timed the same way -- HIP events around that kernel's launches only, steps enqueued back to back -- behind the timed region
-            alone = "amid_sas_seq_fwd_gather_f32" if dom == "amid_sas_seq_fwd_gather_head_f32" else "amid_sas_seq_fwd_split_lnstat_f32"
+            alone = {"amid_sas_seq_fwd_gather_head_f32": "amid_sas_seq_fwd_gather_f32", "amid_sas_seq_fwd_gather_head_p1_f32": "amid_sas_seq_fwd_gather_p1_f32"}.get(dom, "amid_sas_seq_fwd_split_lnstat_f32")
             eng.HEAD_ON_FWD = False
             try:
                 L.timer = KernelTimer(only={alone})
@@ -878,7 +881,7 @@ def main():
                 roof["encoder_as_its_own_launch"] = {"kernel": alone, "avg_launch_us": round(us, 2), "achieved": ach, "unit": "TFLOP/s",
                                                      "peak": roof["peak"], "frac": round(ach / roof["peak"], 4),
                                                      "what": "the same forward without the head on its tail (SasrecEngine.HEAD_ON_FWD = False), same timing"}
-        if dom in ("amid_sas_seq_fwd_split_lnstat_head_f32", "amid_sas_seq_fwd_gather_head_f32"):
+        if dom in ("amid_sas_seq_fwd_split_lnstat_head_f32", "amid_sas_seq_fwd_gather_head_f32", "amid_sas_seq_fwd_gather_head_p1_f32"):
             roof["note"] = ("this launch also runs the train step's head on the tail of its workgroups (LN_last + mean, scorer, loss and their "
                             "backward: ~6.5 us of its duration); `achieved` divides the ENCODER's algorithmic FLOP by the whole launch -- the forward "
                             "alone is the dominant kernel of the line `bench.py --set HEAD_ON_FWD=0` (profiles/r05_bench_twelve_launches.json)")

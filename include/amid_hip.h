@@ -934,6 +934,28 @@ int amid_sas_seq_fwd_gather_f32(int n_layers, const float* const* x_in, float* x
                                 float ln_eps, int B, int T, int D, int H, const int* live, void* step_state, int train, float p_drop,
                                 const void* w16x3, float* items, int NI, const float* table, const int* idx_all, const float* pos0,
                                 const float* pos1, void* stream);
+/* ... with the twelve projection products on ONE bf16 piece per operand (compute = "bf16" on the folded step, round 6): the same launches on
+ * the same three-plane images, reading only the hi planes and multiplying only the operands' hi pieces -- bf16 products, fp32 accumulation. */
+int amid_sas_seq_fwd_gather_head_p1_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                     const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                     const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                     const float* const* w2, const float* const* b2, float* const* ln_stat, float* const* q, float* const* k,
+                                     float* const* v, float* const* o, float* const* stats, float* const* r, float* const* h, unsigned char* tmq,
+                                     float ln_eps, int B, int T, int D, int H, const int* live, void* step_state, int train, float p_drop,
+                                     const void* w16x3, const float* const* last_ln_w, const float* const* last_ln_b, float* items,
+                                     const float* sw1, const float* sb1, const float* sw2, const float* sb2, const float* labels,
+                                     const long long* domain_id, int NI, int hid, float* u, float* p1, float* p2, float* dp1, float* dp2,
+                                     float* loss_part, float* dx, float* ditems, float* ln_part, float* hidg, const float* table,
+                                     const int* idx_all, const float* pos0, const float* pos1, void* stream);
+int amid_sas_seq_fwd_gather_p1_f32(int n_layers, const float* const* x_in, float* xout, const float* const* ln1_w, const float* const* ln1_b,
+                                const float* const* w_in, const float* const* b_in, const float* const* w_o, const float* const* b_o,
+                                const float* const* ln2_w, const float* const* ln2_b, const float* const* w1, const float* const* b1,
+                                const float* const* w2, const float* const* b2, float* const* ln_stat, float* const* q, float* const* k,
+                                float* const* v, float* const* o, float* const* stats, float* const* r, float* const* h, unsigned char* tmq,
+                                float ln_eps, int B, int T, int D, int H, const int* live, void* step_state, int train, float p_drop,
+                                const void* w16x3, float* items, int NI, const float* table, const int* idx_all, const float* pos0,
+                                const float* pos1, void* stream);
+
 int amid_sas_seq_fwd_gather_infer_f32(int n_layers, float* xout, const float* const* ln1_w, const float* const* ln1_b, const float* const* w_in,
                                       const float* const* b_in, const float* const* w_o, const float* const* b_o, const float* const* ln2_w,
                                       const float* const* ln2_b, const float* const* w1, const float* const* b1, const float* const* w2,

@@ -272,6 +272,15 @@ BF16_GRAD_BARS = {"conv1_b": 5.6e-2, "conv1_w": 7.9e-2, "conv2_b": 4.2e-2, "conv
                   "scorer": 6.3e-2, "table": 7.3e-2}
 
 
+# the folded bf16 step (test_bf16_step_on_a_pool_takes_the_folded_launches): 2 x the relative L2 error of a gradient tensor of the kind against the fp32
+# oracle at ITS shapes -- B 256 x T 50 is the larger: half the samples of BF16_GRAD_BARS' B 512, so sqrt(2) more rounding noise per tensor; the
+# unfolded bf16 step measures the same values there to three digits (conv1_b 6.91e-2 against 6.92e-2, pos_emb 7.83e-2 both, ...: the folded
+# step multiplies the same bf16-rounded operands), gpurun_out/parity.log "folded bf16" / "timed bf16 B=256 T=50"
+BF16_FOLD_GRAD_BARS = {"conv1_b": 1.4e-1, "conv1_w": 1.5e-1, "conv2_b": 1.15e-1, "conv2_w": 1.33e-1, "in_proj_b": 1.27e-1, "in_proj_w": 1.45e-1,
+                       "ln1": 1.34e-1, "ln2": 1.25e-1, "ln_last": 1.0e-1, "out_proj_b": 1.18e-1, "out_proj_w": 1.32e-1, "pos_emb": 1.57e-1,
+                       "scorer": 8.4e-2, "table": 1.0e-1}
+
+
 def timed_pool_step(eng, pl, batch, step, seed):
     """Step `step` as bench.py runs it: the batch resident in an input pool, the WHOLE step (enqueue_train_step: with the pool the
     step's head and tail are folded -- SasrecEngine.FUSED_TAIL -- and the segment reduce is finished inside the optimizer launch).  The
@@ -1075,9 +1084,9 @@ def test_sort_chained_in_the_catchup_launch_equals_the_side_stream_sort(Bn, T, n
 @pytest.mark.parametrize("Bn,T", [(256, 50), (200, 20)])
 def test_bf16_step_on_a_pool_takes_the_folded_launches(Bn, T):
     """compute = "bf16" on an input pool (round 6, SasrecEngine.BF16_FOLD): the step takes the fp32 step's nine folded launches -- the forward on
-    bf16 pieces (more than the mode asks for), the gather in its prologue and the head on its tail -- with the three strip launches' data-gradient
-    products on ONE bf16 piece (mma mode 1 on the hi plane of the three-plane images).  Held: the launch list; loss and own logits at the
-    fp32 step's bars (the forward is fp32-accurate); every gradient tensor inside the bf16 bars of its kind (BF16_GRAD_BARS) and NOT fp32-exact
+    bf16 pieces multiplying ONE piece per operand (amid_sas_seq_fwd_gather_head_p1_f32), the gather in its prologue and the head on its tail -- with
+    the three strip launches' data-gradient products on one bf16 piece too (mma mode 1 on the hi plane of the three-plane images).  Held: the launch
+    list; loss and own logits at the bf16 mode's bars; every gradient tensor inside the bf16 bars of its kind (BF16_GRAD_BARS) and NOT fp32-exact
     for the tensors behind a strip product (the mode is on); batches beyond BF16_FOLD_MAX_B keep the unfolded bf16 launches."""
     from amid_amd._lib import lib
     D, hid, n_items = 128, 32, 3000
@@ -1098,7 +1107,7 @@ def test_bf16_step_on_a_pool_takes_the_folded_launches(Bn, T):
     finally:
         L.call = orig
     names = [c[0] for c in calls]
-    assert pl.tail2 and "amid_sas_seq_fwd_gather_head_f32" in names and "amid_grad_tail_opt_f32" in names, names
+    assert pl.tail2 and "amid_sas_seq_fwd_gather_head_p1_f32" in names and "amid_grad_tail_opt_f32" in names, names
     strips = [c for c in calls if c[0] in ("amid_sas_strip_ffn_bwd_sort_f32", "amid_sas_strip_qkv_bwd_sort_scorer_f32", "amid_sas_strip_qkv_bwd_emb_f32")]
     assert len(strips) == 3
     for name, a in strips:       # the precision argument: one bf16 piece
@@ -1106,22 +1115,28 @@ def test_bf16_step_on_a_pool_takes_the_folded_launches(Bn, T):
         assert mode == 1, (name, mode)
     keep = gpu_relu_keep(eng, pl, batch)
     loss, (p1, p2), grads = orc.loss_and_grads("sasrec", P, batch, masks, relu_keep=keep)
-    assert abs(float(pl.loss.item()) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    assert abs(float(pl.loss.item()) - float(loss)) < 2e-3
     dom = batch["domain_id"]
     own = torch.where(dom[:, None] == 0, pl.p1.cpu(), pl.p2.cpu())
-    assert relmax(own, torch.where(dom[:, None] == 0, p1, p2)) < 1e-4
-    worst = 0.0
+    e = relmax(own, torch.where(dom[:, None] == 0, p1, p2))
+    assert 1e-5 < e < 2e-2, e                      # (the forward multiplies bf16 operands: the mode's own bars, not fp32-exact)
+    worst, measured = 0.0, {}
     for name in eng.dense.slots:
         got, want = eng.dense.view(name, eng.dense.grad).cpu().clone(), grads[name].clone()
         if name.endswith("in_proj_bias"):
             n3 = got.numel() // 3
             got[n3:2 * n3] = 0; want[n3:2 * n3] = 0
         e2 = rel_l2(got, want)
-        assert e2 < BF16_GRAD_BARS[bf16_grad_kind(name)], (name, e2)
+        kind = bf16_grad_kind(name)
+        measured[kind] = max(measured.get(kind, 0.0), e2)
         if "attention_layers.0.in_proj_weight" in name:
             worst = max(worst, e2)
-    assert worst > 1e-5, "layer 0's q / k / v weight gradients sit behind bf16 strip products: fp32-exact means the mode is off"
-    assert rel_l2(dense_table_grad(eng, pl), grads["item_emb_layer.emb_item.weight"]) < BF16_GRAD_BARS["table"]
+    log(f"folded bf16 B={Bn} T={T}: grad rel L2 by kind " + " ".join(f"{k}:{v:.2e}" for k, v in sorted(measured.items())))
+    for kind, e2 in measured.items():
+        assert e2 < BF16_FOLD_GRAD_BARS[kind], (kind, e2, BF16_FOLD_GRAD_BARS[kind])
+    if True:
+        assert worst > 1e-5, "layer 0's q / k / v weight gradients sit behind bf16 strip products: fp32-exact means the mode is off"
+    assert rel_l2(dense_table_grad(eng, pl), grads["item_emb_layer.emb_item.weight"]) < BF16_FOLD_GRAD_BARS["table"]
     big = make_engine(P, T, seed=seed, compute="bf16")
     big.BF16_FOLD_MAX_B = Bn - 1
     plb = big.plan(Bn, T, 2, need_grad=True)
