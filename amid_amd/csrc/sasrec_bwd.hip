@@ -883,8 +883,9 @@ static int sas_wgrad(const float* const* dy, const float* const* x, int n_layers
         SortRider rd;
         rd.plan = *(const SortPlan*)sort_plan;
         rd.phase = 5;
-        if (!(mma_bf16 == 3 && D == 128 && a.row_domain != nullptr && splits * 6 * n_layers >= rd.plan.nblk)) return AMID_ERR_UNSUPPORTED;
-        return launch_sas_wgrad_split(a, &rd, n_layers, 3, live_bytes, stream);
+        // (mma_bf16 = 4: the same launch on ONE piece per operand -- bf16 products, the folded bf16 step)
+        if (!((mma_bf16 == 3 || mma_bf16 == 4) && D == 128 && a.row_domain != nullptr && splits * 6 * n_layers >= rd.plan.nblk)) return AMID_ERR_UNSUPPORTED;
+        return launch_sas_wgrad_split(a, &rd, n_layers, mma_bf16, live_bytes, stream);
     }
     if (mma_bf16 >= 2) {      // fp32 operands as three bf16 pieces each (sasrec_wgrad_split.hip): D = 128 only
         if (D != 128) return AMID_ERR_UNSUPPORTED;

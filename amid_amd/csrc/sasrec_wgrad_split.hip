@@ -50,6 +50,13 @@ int launch_sas_wgrad_split(const WgradArgs& a, const SortRider* rdp, int n_layer
     const dim3 grid(a.splits, 6 * n_layers, 2);
     if (rdp != nullptr) {
         rd = *rdp;
+        if (mode == 4) {          // ONE piece per operand: bf16 products (compute = "bf16" on the folded step)
+            static unsigned long long done_r1 = 0;
+            if (int e = lds_attr_once((const void*)sas_wgrad_split_kernel<128, 1, true, true>, WGS_LDS_FIXED + WG_LIVE_MAX * sizeof(int), done_r1)) return e;
+            sas_wgrad_split_kernel<128, 1, true, true><<<dim3(a.splits, 6 * n_layers, 3), GEMM_THREADS, WGS_LDS_FIXED + live_bytes, (hipStream_t)stream>>>(a, rd);
+            AMID_LAUNCH_CHECK();
+            return AMID_OK;
+        }
         static unsigned long long done_r = 0;
         if (int e = lds_attr_once((const void*)sas_wgrad_split_kernel<128, 6, true, true>, WGS_LDS_FIXED + WG_LIVE_MAX * sizeof(int), done_r)) return e;
         sas_wgrad_split_kernel<128, 6, true, true><<<dim3(a.splits, 6 * n_layers, 3), GEMM_THREADS, WGS_LDS_FIXED + live_bytes, (hipStream_t)stream>>>(a, rd);

@@ -51,7 +51,7 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
                                                  int g, int split, const WgsRows& a, f32x4 (&acc)[8], float* __restrict__ bias_out,
                                                  const WgsLn ln = WgsLn{nullptr, 0, nullptr, nullptr}) {
     constexpr int D = 128;
-    static_assert(NTERM == 6 || NTERM == 9, "piece pairs kept");
+    static_assert(NTERM == 6 || NTERM == 9 || NTERM == 1, "piece pairs kept (1: the hi pieces only -- bf16 products, compute = \"bf16\" on the folded step)");
     constexpr int NTn = D / 16;
     constexpr int PLANE = D * WGS_COL_BYTES;
     char* const Yt = reinterpret_cast<char*>(smem);                // planes hi, mid, lo
@@ -160,11 +160,22 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
             const WgSplit2 sx = wg_split3(f4comp_w(rx0, j), f4comp_w(rx1, j));
             char* const yq = Yt + wr_j[j];
             char* const xq = Xt + wr_j[j];
-            *reinterpret_cast<unsigned*>(yq) = sy.hi; *reinterpret_cast<unsigned*>(yq + PLANE) = sy.mid; *reinterpret_cast<unsigned*>(yq + 2 * PLANE) = sy.lo;
-            *reinterpret_cast<unsigned*>(xq) = sx.hi; *reinterpret_cast<unsigned*>(xq + PLANE) = sx.mid; *reinterpret_cast<unsigned*>(xq + 2 * PLANE) = sx.lo;
+            *reinterpret_cast<unsigned*>(yq) = sy.hi; *reinterpret_cast<unsigned*>(xq) = sx.hi;
+            if constexpr (NTERM != 1) {
+                *reinterpret_cast<unsigned*>(yq + PLANE) = sy.mid; *reinterpret_cast<unsigned*>(yq + 2 * PLANE) = sy.lo;
+                *reinterpret_cast<unsigned*>(xq + PLANE) = sx.mid; *reinterpret_cast<unsigned*>(xq + 2 * PLANE) = sx.lo;
+            }
         }
         __syncthreads();
         fetch(c0 + 2 * WGS_ROWS, py, px, ls);           // unconditionally (a skipped refill would cost a register copy and a wait here)
+        if constexpr (NTERM == 1) {
+            const wg_v4u y0 = *reinterpret_cast<const wg_v4u*>(Yt + rd_y);
+#pragma unroll
+            for (int t = 0; t < NTn; ++t) {
+                const wg_v4u x0 = *reinterpret_cast<const wg_v4u*>(Xt + rd_x + t * 16 * WGS_COL_BYTES);
+                acc[t] = wg_mma16(y0, x0, acc[t]);
+            }
+        } else {
         const wg_v4u y0 = *reinterpret_cast<const wg_v4u*>(Yt + rd_y), y1 = *reinterpret_cast<const wg_v4u*>(Yt + PLANE + rd_y),
                      y2 = *reinterpret_cast<const wg_v4u*>(Yt + 2 * PLANE + rd_y);
 #pragma unroll
@@ -177,6 +188,7 @@ __device__ __forceinline__ void wgrad_split_tile(float* smem, const float* __res
             c = wg_mma16(y2, x[0], c); c = wg_mma16(y0, x[2], c); c = wg_mma16(y1, x[1], c);
             c = wg_mma16(y1, x[0], c); c = wg_mma16(y0, x[1], c); c = wg_mma16(y0, x[0], c);
             acc[t] = c;
+        }
         }
     };
     if (has_ln && threadIdx.x < 64) {                  // (visible behind the first chunk's barrier)

@@ -344,6 +344,8 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
             return 0
         if self.BF16_WGRAD and getattr(self, "_bf16_bwd", False):
             return 1
+        if self._bf16_as_f32 and self.BF16_WGRAD and self.BF16_FWD_ONE and getattr(self, "_wgrad_one", False):
+            return 4                    # (the folded bf16 step's weight-gradient launch: ONE piece per operand -- asked for at the launch site only)
         return {"9": 2, "6": 3}.get(self.WGRAD_SPLIT, 0)
 
     def join_sort(self) -> None:
@@ -1135,9 +1137,14 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
                 for l in (0, 1):                       # gradients are rebuilt from x / r while they are staged
                     xx[6 * l + 0], xx[6 * l + 4] = pl.x[l].data_ptr(), pl.r[l].data_ptr()
                 fam = lambda fmt: ptr_array([fp.ptr(fmt.format(d=d, l=l)) for l in (0, 1) for d in (1, 2)])      # noqa: E731  [layer][domain]
+                self._wgrad_one = True              # (the folded bf16 step: this launch on ONE piece per operand, _wgrad_mode -> 4)
+                try:
+                    wmode = self._wgrad_mode(D)
+                finally:
+                    self._wgrad_one = False
                 L.call("amid_sas_wgrad_rows_sort_ln_f32", ptr_array(dy), ptr_array(xx), 2, M, D, pl.splits,
                        ptr_array([pl.w_part[0].data_ptr(), pl.w_part[1].data_ptr()]), ptr_array([pl.b_part[0].data_ptr(), pl.b_part[1].data_ptr()]),
-                       self._own_rows(pl), B, T, self._wgrad_mode(D), self._sort_plan_c(pl), self._ln_stat(pl)[1],
+                       self._own_rows(pl), B, T, wmode, self._sort_plan_c(pl), self._ln_stat(pl)[1],
                        fam("sac{d}.attention_layernorms.{l}.weight"), fam("sac{d}.attention_layernorms.{l}.bias"),
                        fam("sac{d}.forward_layernorms.{l}.weight"), fam("sac{d}.forward_layernorms.{l}.bias"), s)
             else:

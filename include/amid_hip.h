@@ -818,7 +818,9 @@ int amid_sas_strip_ffn_bwd_px_f32(const float* dxo, const unsigned char* tmq, co
                                   const int* live, int layer, const void* step_state, int train, float p_drop, float* dpre2, float* dpre1,
                                   float* dr, float* d_o, float* ln_part, const float* ln_stat, const void* sort_plan, int sort_phase,
                                   void* stream);
-/* amid_sas_wgrad_rows_f32 (mma_bf16 = 3, D = 128) carrying the LAST phase (5: run heads) of a sort plan as extra workgroups */
+/* amid_sas_wgrad_rows_f32 (mma_bf16 = 3, D = 128) carrying the LAST phase (5: run heads) of a sort plan as extra workgroups.
+ * (amid_sas_wgrad_rows_sort_ln_f32 also takes mma_bf16 = 4: the same launch staging and multiplying ONE bf16 piece per operand -- bf16
+ * products with fp32 accumulation, the folded bf16 step's weight gradients; round 6) */
 int amid_sas_wgrad_rows_sort_f32(const float* const* dy, const float* const* x, int n_layers, int M, int D, int splits, float* const* w_part,
                                  float* const* b_part, const long long* row_domain, int B, int T, int mma_bf16, const void* sort_plan,
                                  void* stream);
