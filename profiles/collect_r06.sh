@@ -8,7 +8,7 @@ P=$R/profiles
 last() { [ -s "$1" ] || { echo "collect_r06: $1 is missing or empty -- nothing copied" >&2; exit 1; }; tail -n 1 "$1" > "$2"; }
 last $O/bench.json $P/r06_bench.json
 last $O/bench_driver_args.json $P/r06_bench_driver_args.json
-for w in cfg1 cfg3 cfg4 cfg3_bf16 cfg2_bf16 bert4rec cfg4_steady cfg4_steady_unfolded cfg4_steady_chain bert4rec_chain ten_launches eleven_launches twelve_launches fifteen_launches; do last $O/bench_$w.json $P/r06_bench_$w.json; done
+for w in cfg1 cfg3 cfg4 cfg3_bf16 cfg2_bf16 cfg3_bf16_unfolded cfg2_bf16_unfolded bert4rec cfg4_steady cfg4_steady_unfolded cfg4_steady_chain bert4rec_chain ten_launches eleven_launches twelve_launches fifteen_launches; do last $O/bench_$w.json $P/r06_bench_$w.json; done
 last $O/bench_cfg5-uniform.json $P/r06_bench_cfg5_uniform.json
 last $O/bench_cfg5-real.json $P/r06_bench_cfg5_real.json
 last $O/eval_under_prof.json $P/r06_eval_under_prof.json

@@ -34,6 +34,9 @@ for w in cfg5-uniform cfg5-real cfg4 cfg3 cfg1; do python3 bench.py --workload $
 python3 bench.py --model bert4rec --no-cpu-baseline > $O/bench_bert4rec.json 2> $O/bench_bert4rec.err
 python3 bench.py --dtype bf16 --no-cpu-baseline > $O/bench_cfg2_bf16.json 2> $O/bench_cfg2_bf16.err
 python3 bench.py --workload cfg3 --dtype bf16 --no-cpu-baseline > $O/bench_cfg3_bf16.json 2> $O/bench_cfg3_bf16.err
+# the bf16 step as it ran before it folded (round 5's launches with bf16 products)
+python3 bench.py --dtype bf16 --set BF16_FOLD=0 --no-cpu-baseline --no-stress > $O/bench_cfg2_bf16_unfolded.json 2> $O/bench_cfg2_bf16_unfolded.err
+python3 bench.py --workload cfg3 --dtype bf16 --set BF16_FOLD=0 --no-cpu-baseline --no-stress > $O/bench_cfg3_bf16_unfolded.json 2> $O/bench_cfg3_bf16_unfolded.err
 # A/B on this box: the embedding gather as its own launch (ten launches); the optimizer as its own launch too (round 5's eleven launches);
 # the head as its own launch as well; round 4's fifteen launches
 python3 bench.py --set GATHER_ON_FWD=0 --no-cpu-baseline --no-stress > $O/bench_ten_launches.json 2> $O/bench_ten_launches.err
