@@ -566,9 +566,13 @@ class SasrecEngine(InputMixin, GraphMixin, DataParallelMixin):
         """(host pointer array of the 24 encoder weights [layer][domain][q, k, v, o, conv1, conv2], the image buffer) for `planes` bf16
         planes per weight (1: operands rounded to bf16; 3: hi + mid + lo = the fp32 weight exactly)."""
         D, fp = self.D, self.dense
-        if getattr(self, "_w16_planes", 0) != planes:
-            self.w16 = torch.empty(2, 2, 6, planes, D * D, dtype=torch.bfloat16, device=self.device)
-            self._w16_planes = planes
+        # one buffer per plane count, never re-allocated: captured graphs hold these addresses, and a compute = "bf16" engine alternates between
+        # three planes (its folded train step, round 6) and one (its evaluation forward)
+        bufs = self.__dict__.setdefault("_w16_bufs", {})
+        if planes not in bufs:
+            bufs[planes] = torch.empty(2, 2, 6, planes, D * D, dtype=torch.bfloat16, device=self.device)
+        self.w16 = bufs[planes]
+        if getattr(self, "_w16_src", None) is None:
             srcs = []
             for l in (0, 1):
                 for g in (1, 2):
